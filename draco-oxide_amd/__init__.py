@@ -1,0 +1,14 @@
+"""draco-oxide_amd — MI355X-native attribute-encoding hot path of draco-oxide.
+
+Python here is plumbing only: a ctypes binding of libdraco_mi.so (C ABI in include/draco_mi.h)
+whose names mirror the reference crate (`encode::encode(mesh, &mut buf, Config::default())`,
+`Mesh`, `Attribute`, `MeshBuilder`).  All arithmetic runs in the HIP kernels under csrc/.
+The package directory name contains a hyphen, so import it through the `draco_oxide_amd` shim at
+the repository root.
+"""
+from .binding import (  # noqa: F401
+    ATT_POSITION, ATT_NORMAL, ATT_COLOR, ATT_TEXCOORD, ATT_CUSTOM, DOMAIN_POSITION, DOMAIN_CORNER,
+    F32, U32, I32, FLAG_TIMINGS, POS_SCHEME_DELTA,
+    Attribute, Mesh, MeshBuilder, Config, DracoMiError, Job, Connectivity,
+    encode, encode_mesh, encode_attributes, encode_connectivity, mesh_prepare, device_count, library_path, load_library,
+)

@@ -1,0 +1,424 @@
+"""ctypes binding of libdraco_mi.so.  No arithmetic lives here; see include/draco_mi.h for the ABI.
+
+Reference interface mirrored (paths relative to draco-oxide/src/):
+  encode(mesh, writer, cfg)      encode/mod.rs:59      (Mesh consumed, bytes appended to the writer)
+  Config.default()               encode/mod.rs:32-42   (only the default configuration is public)
+  Mesh / Attribute / MeshBuilder core/mesh/mod.rs:13-23, core/attribute/mod.rs:26-49, core/mesh/builder.rs:14-90
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ATT_POSITION, ATT_NORMAL, ATT_COLOR, ATT_TEXCOORD, ATT_CUSTOM = 0, 1, 2, 3, 4
+DOMAIN_POSITION, DOMAIN_CORNER = 0, 1
+U32, I32, F32 = 5, 6, 9
+FLAG_TIMINGS = 1
+POS_SCHEME_DELTA = 0xD0
+NONE = 0xFFFFFFFF
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_PKG, "libdraco_mi.so")
+_lib = None
+
+
+class DracoMiError(RuntimeError):
+    def __init__(self, status, what, detail):
+        super().__init__(f"libdraco_mi status {status} ({what}): {detail}")
+        self.status = status
+
+
+class _Attribute(C.Structure):
+    _fields_ = [("values", C.c_void_p), ("num_unique", C.c_uint32), ("component_type", C.c_uint8), ("num_components", C.c_uint8),
+                ("att_type", C.c_uint8), ("domain", C.c_uint8), ("unique_id", C.c_uint32), ("parent_index", C.c_int32),
+                ("point_to_value", C.c_void_p), ("num_points", C.c_uint32)]
+
+
+class _CornerTable(C.Structure):
+    _fields_ = [("num_faces", C.c_uint32), ("num_vertices", C.c_uint32), ("corner_to_point", C.c_void_p), ("corner_to_vertex", C.c_void_p),
+                ("opposite", C.c_void_p), ("left_most_corner", C.c_void_p), ("sequence", C.c_void_p), ("sequence_len", C.c_uint32)]
+
+
+class _Config(C.Structure):
+    _fields_ = [("pos_bits", C.c_uint8), ("uv_bits", C.c_uint8), ("generic_bits", C.c_uint8), ("pos_scheme", C.c_uint8),
+                ("device", C.c_int32), ("stream", C.c_void_p), ("flags", C.c_uint32)]
+
+
+class _Buffer(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("len", C.c_size_t), ("cap", C.c_size_t)]
+
+
+class _Timings(C.Structure):
+    _fields_ = [("quantize_ms", C.c_float), ("predict_ms", C.c_float), ("histogram_ms", C.c_float), ("table_ms", C.c_float),
+                ("rans_ms", C.c_float), ("total_ms", C.c_float), ("predict_bytes", C.c_uint64), ("symbols", C.c_uint64), ("num_streams", C.c_uint32)]
+
+
+class _Mesh(C.Structure):
+    _fields_ = [("faces", C.c_void_p), ("num_faces", C.c_uint32), ("atts", C.POINTER(_Attribute)), ("num_atts", C.c_uint32)]
+
+
+class _Conn(C.Structure):
+    _fields_ = [("num_tables", C.c_uint32), ("tables", C.POINTER(_CornerTable)), ("seeds", C.c_void_p), ("num_seeds", C.c_uint32), ("owner", C.c_void_p)]
+
+
+EXPORTS = ["dmi_encode_attributes", "dmi_job_create", "dmi_job_encode", "dmi_job_timings", "dmi_job_destroy", "dmi_encode_mesh",
+           "dmi_mesh_prepare", "dmi_encode_connectivity", "dmi_conn_free", "dmi_free", "dmi_strerror", "dmi_last_error", "dmi_device_count"]
+
+
+def library_path():
+    return _LIB
+
+
+def build_library():
+    """hipcc cross-compile of csrc/ for gfx950 (no GPU needed)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_PKG, "csrc")])
+
+
+def load_library():
+    """Load libdraco_mi.so; fails loudly if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        raise ImportError(f"{_LIB} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+                          "draco-oxide_amd has no CPU fallback.")
+    L = C.CDLL(_LIB)
+    L.dmi_strerror.restype = C.c_char_p
+    L.dmi_strerror.argtypes = [C.c_int]
+    L.dmi_last_error.restype = C.c_char_p
+    L.dmi_device_count.restype = C.c_int
+    L.dmi_free.argtypes = [C.POINTER(_Buffer)]
+    L.dmi_encode_attributes.argtypes = [C.POINTER(_Attribute), C.POINTER(_CornerTable), C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(_Config), C.POINTER(_Buffer)]
+    L.dmi_job_create.argtypes = [C.POINTER(_Attribute), C.POINTER(_CornerTable), C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(_Config), C.POINTER(C.c_void_p)]
+    L.dmi_job_encode.argtypes = [C.c_void_p, C.POINTER(_Buffer)]
+    L.dmi_job_timings.argtypes = [C.c_void_p, C.POINTER(_Timings)]
+    L.dmi_job_destroy.argtypes = [C.c_void_p]
+    L.dmi_encode_mesh.argtypes = [C.POINTER(_Mesh), C.POINTER(_Config), C.POINTER(_Buffer)]
+    L.dmi_mesh_prepare.argtypes = [C.POINTER(_Mesh), C.POINTER(_Config), C.POINTER(_Buffer), C.POINTER(C.c_void_p)]
+    L.dmi_encode_connectivity.argtypes = [C.POINTER(_Mesh), C.POINTER(_Buffer), C.POINTER(_Conn)]
+    L.dmi_conn_free.argtypes = [C.POINTER(_Conn)]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        L = load_library()
+        raise DracoMiError(rc, L.dmi_strerror(rc).decode(), L.dmi_last_error().decode())
+
+
+def device_count():
+    return int(load_library().dmi_device_count())
+
+
+def _take(buf):
+    L = load_library()
+    try:
+        return C.string_at(buf.data, buf.len) if buf.len else b""
+    finally:
+        L.dmi_free(C.byref(buf))
+
+
+# --------------------------------------------------------------------------------------------------
+# Data model (host side)
+# --------------------------------------------------------------------------------------------------
+class Attribute:
+    """Unique values + optional point→value map, as core/attribute/mod.rs:26-49 stores them."""
+
+    def __init__(self, values, att_type, domain=DOMAIN_POSITION, unique_id=0, parent_index=-1, point_to_value=None, num_points=None):
+        v = np.ascontiguousarray(values)
+        if v.ndim == 1:
+            v = v.reshape(-1, 1)
+        if v.dtype == np.float32:
+            self.component_type = F32
+        elif v.dtype == np.uint32:
+            self.component_type = U32
+        elif v.dtype == np.int32:
+            self.component_type = I32
+        else:
+            raise TypeError("attribute values must be float32 / uint32 / int32")
+        self.values = v
+        self.att_type = att_type
+        self.domain = domain
+        self.unique_id = unique_id
+        self.parent_index = parent_index
+        self.point_to_value = None if point_to_value is None else np.ascontiguousarray(point_to_value, dtype=np.uint32)
+        self.num_points = int(num_points if num_points is not None else (len(self.point_to_value) if self.point_to_value is not None else v.shape[0]))
+
+    def _c(self):
+        a = _Attribute()
+        a.values = self.values.ctypes.data
+        a.num_unique = self.values.shape[0]
+        a.component_type = self.component_type
+        a.num_components = self.values.shape[1]
+        a.att_type = self.att_type
+        a.domain = self.domain
+        a.unique_id = self.unique_id
+        a.parent_index = self.parent_index
+        a.point_to_value = None if self.point_to_value is None else self.point_to_value.ctypes.data
+        a.num_points = self.num_points
+        return a
+
+
+class Mesh:
+    """faces (point indices) + attributes; attribute 0 must be the Position attribute."""
+
+    def __init__(self, faces, attributes):
+        self.faces = np.ascontiguousarray(faces, dtype=np.uint32).reshape(-1, 3)
+        self.attributes = list(attributes)
+
+    def _c(self):
+        arr = (_Attribute * len(self.attributes))(*[a._c() for a in self.attributes])
+        m = _Mesh()
+        m.faces = self.faces.ctypes.data
+        m.num_faces = self.faces.shape[0]
+        m.atts = arr
+        m.num_atts = len(self.attributes)
+        m._keep = arr
+        return m
+
+
+def _dedup_rows(rows):
+    """First-occurrence value dedup with f32 `==` semantics (core/attribute/mod.rs:394-452): -0.0 == 0.0, NaN != NaN."""
+    r = np.ascontiguousarray(rows)
+    if r.shape[0] == 0:
+        return r, None
+    key = r
+    nan_rows = None
+    if r.dtype == np.float32:
+        key = r + np.float32(0.0)          # -0.0 → +0.0
+        key = np.where(key == 0, np.float32(0.0), key)
+        nan_rows = np.isnan(r).any(axis=1)
+    kb = np.ascontiguousarray(key).view(np.dtype((np.void, key.dtype.itemsize * key.shape[1]))).ravel()
+    _, first, inv = np.unique(kb, return_index=True, return_inverse=True)
+    rep = first[inv]                         # first occurrence of each row's class
+    if nan_rows is not None and nan_rows.any():
+        idx = np.arange(r.shape[0])
+        rep = np.where(nan_rows, idx, rep)   # NaN rows are never merged
+    is_first = rep == np.arange(r.shape[0])
+    if is_first.all():
+        return r, None
+    new_id = np.cumsum(is_first) - 1
+    p2v = new_id[rep].astype(np.uint32)
+    return np.ascontiguousarray(r[is_first]), p2v
+
+
+class MeshBuilder:
+    """core/mesh/builder.rs:14-90 for the common case: per-attribute value dedup (Attribute::from),
+    Position swapped to slot 0, points that agree in every attribute merged, degenerate faces dropped.
+    (Unreferenced-point removal, builder.rs:129-189, is not needed by callers that index every point.)"""
+
+    def __init__(self):
+        self._atts = []
+        self._faces = None
+
+    def add_attribute(self, data, att_type, domain=DOMAIN_POSITION, parents=()):
+        d = np.ascontiguousarray(data)
+        if d.ndim == 1:
+            d = d.reshape(-1, 1)
+        self._atts.append(dict(data=d, type=att_type, domain=domain, parents=list(parents), id=len(self._atts)))
+        return len(self._atts) - 1
+
+    def set_connectivity_attribute(self, faces):
+        self._faces = np.ascontiguousarray(faces, dtype=np.uint32).reshape(-1, 3)
+
+    def build(self):
+        atts = []
+        for a in self._atts:
+            vals, p2v = _dedup_rows(a["data"])
+            atts.append(dict(a, values=vals, p2v=p2v, npoints=a["data"].shape[0]))
+        for i, a in enumerate(atts):
+            if a["type"] == ATT_POSITION:
+                atts[0], atts[i] = atts[i], atts[0]
+                break
+        faces = self._faces
+        npts = int(faces.max()) + 1 if faces.size else 0
+        keys = np.stack([(a["p2v"][:npts] if a["p2v"] is not None else np.arange(npts, dtype=np.uint32)) for a in atts], axis=1)
+        kb = np.ascontiguousarray(keys).view(np.dtype((np.void, 4 * keys.shape[1]))).ravel()
+        _, first, inv = np.unique(kb, return_index=True, return_inverse=True)
+        rep = first[inv]
+        is_first = rep == np.arange(npts)
+        if not is_first.all():
+            new_id = (np.cumsum(is_first) - 1).astype(np.uint32)
+            mapping = new_id[rep]
+            faces = mapping[faces]
+            for a in atts:
+                m = a["p2v"] if a["p2v"] is not None else np.arange(npts, dtype=np.uint32)
+                a["p2v"] = np.ascontiguousarray(m[:npts][is_first])
+                a["npoints"] = int(is_first.sum())
+        keep = (faces[:, 0] != faces[:, 1]) & (faces[:, 1] != faces[:, 2]) & (faces[:, 2] != faces[:, 0])
+        faces = faces[keep]
+        id_to_index = {a["id"]: i for i, a in enumerate(atts)}
+        out = []
+        for a in atts:
+            parent = id_to_index[a["parents"][0]] if a["parents"] else -1
+            out.append(Attribute(a["values"], a["type"], a["domain"], unique_id=a["id"], parent_index=parent, point_to_value=a["p2v"], num_points=a["npoints"]))
+        return Mesh(faces, out)
+
+
+class Config:
+    """encode::Config — only `Config.default()` is constructible in the reference (encode/mod.rs:22-42).
+    The extra fields select the internal variants the reference compiles but does not expose."""
+
+    def __init__(self, pos_bits=0, uv_bits=0, generic_bits=0, pos_scheme=0, device=0, stream=None, flags=0):
+        self.pos_bits, self.uv_bits, self.generic_bits, self.pos_scheme = pos_bits, uv_bits, generic_bits, pos_scheme
+        self.device, self.stream, self.flags = device, stream, flags
+
+    @classmethod
+    def default(cls):
+        return cls()
+
+    def _c(self):
+        c = _Config()
+        c.pos_bits, c.uv_bits, c.generic_bits, c.pos_scheme = self.pos_bits, self.uv_bits, self.generic_bits, self.pos_scheme
+        c.device = self.device
+        c.stream = self.stream
+        c.flags = self.flags
+        return c
+
+
+# --------------------------------------------------------------------------------------------------
+# Entry points
+# --------------------------------------------------------------------------------------------------
+def encode_mesh(mesh, cfg=None):
+    """Whole .drc for `mesh` (header + host Edgebreaker connectivity + device attribute section)."""
+    L = load_library()
+    cfg = cfg or Config.default()
+    m, c, out = mesh._c(), cfg._c(), _Buffer()
+    _check(L.dmi_encode_mesh(C.byref(m), C.byref(c), C.byref(out)))
+    return _take(out)
+
+
+def encode(mesh, writer, cfg=None):
+    """encode::encode(mesh, &mut writer, cfg): appends the .drc bytes to `writer` (a bytearray)."""
+    writer.extend(encode_mesh(mesh, cfg))
+
+
+class Connectivity:
+    """Host connectivity stage output: header+connectivity bytes and the flat tables/sequences/seeds."""
+
+    def __init__(self, mesh):
+        L = load_library()
+        self._L = L
+        self._conn = _Conn()
+        m, out = mesh._c(), _Buffer()
+        _check(L.dmi_encode_connectivity(C.byref(m), C.byref(out), C.byref(self._conn)))
+        self.bytes = _take(out)
+        self.num_tables = self._conn.num_tables
+        self.num_seeds = self._conn.num_seeds
+
+    def _arr(self, ptr, n):
+        if not ptr or n == 0:
+            return np.zeros(0, np.uint32)
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32)), shape=(n,)).copy()
+
+    def seeds(self):
+        return self._arr(self._conn.seeds, self._conn.num_seeds)
+
+    def table(self, i):
+        t = self._conn.tables[i]
+        nc = 3 * t.num_faces
+        return dict(num_faces=t.num_faces, num_vertices=t.num_vertices, corner_to_point=self._arr(t.corner_to_point, nc),
+                    corner_to_vertex=self._arr(t.corner_to_vertex, nc), opposite=self._arr(t.opposite, nc),
+                    left_most_corner=self._arr(t.left_most_corner, t.num_vertices), sequence=self._arr(t.sequence, t.sequence_len))
+
+    def close(self):
+        if self._conn.owner:
+            self._L.dmi_conn_free(C.byref(self._conn))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _tables_c(tables):
+    keep = []
+    arr = (_CornerTable * len(tables))()
+    for i, t in enumerate(tables):
+        ct = arr[i]
+        c2p = np.ascontiguousarray(t["corner_to_point"], dtype=np.uint32)
+        c2v = np.ascontiguousarray(t["corner_to_vertex"], dtype=np.uint32)
+        opp = np.ascontiguousarray(t["opposite"], dtype=np.uint32)
+        keep += [c2p, c2v, opp]
+        ct.num_faces = len(c2p) // 3
+        ct.num_vertices = int(t["num_vertices"])
+        ct.corner_to_point, ct.corner_to_vertex, ct.opposite = c2p.ctypes.data, c2v.ctypes.data, opp.ctypes.data
+        if t.get("left_most_corner") is not None:
+            lmc = np.ascontiguousarray(t["left_most_corner"], dtype=np.uint32)
+            keep.append(lmc)
+            ct.left_most_corner = lmc.ctypes.data
+        if t.get("sequence") is not None:
+            seq = np.ascontiguousarray(t["sequence"], dtype=np.uint32)
+            keep.append(seq)
+            ct.sequence = seq.ctypes.data
+            ct.sequence_len = len(seq)
+    return arr, keep
+
+
+def encode_attributes(attributes, tables, seeds=None, cfg=None):
+    """attribute::encode_attributes drop-in: attribute-section bytes for attributes[i] on tables[i]."""
+    L = load_library()
+    cfg = cfg or Config.default()
+    atts = (_Attribute * len(attributes))(*[a._c() for a in attributes])
+    tabs, keep = _tables_c(tables)
+    sd = None if seeds is None else np.ascontiguousarray(seeds, dtype=np.uint32)
+    out, c = _Buffer(), cfg._c()
+    _check(L.dmi_encode_attributes(atts, tabs, len(attributes), None if sd is None else sd.ctypes.data, 0 if sd is None else len(sd), C.byref(c), C.byref(out)))
+    return _take(out)
+
+
+class Job:
+    """Resident attribute-encoding job: inputs live in HBM, `encode()` runs the device pipeline."""
+
+    def __init__(self, handle, head=b""):
+        self._L = load_library()
+        self._h = C.c_void_p(handle)
+        self.header_and_connectivity = head
+
+    @classmethod
+    def from_tables(cls, attributes, tables, seeds=None, cfg=None):
+        L = load_library()
+        cfg = cfg or Config.default()
+        atts = (_Attribute * len(attributes))(*[a._c() for a in attributes])
+        tabs, keep = _tables_c(tables)
+        sd = None if seeds is None else np.ascontiguousarray(seeds, dtype=np.uint32)
+        h, c = C.c_void_p(), cfg._c()
+        _check(L.dmi_job_create(atts, tabs, len(attributes), None if sd is None else sd.ctypes.data, 0 if sd is None else len(sd), C.byref(c), C.byref(h)))
+        return cls(h.value)
+
+    def encode(self):
+        out = _Buffer()
+        _check(self._L.dmi_job_encode(self._h, C.byref(out)))
+        return _take(out)
+
+    def timings(self):
+        t = _Timings()
+        _check(self._L.dmi_job_timings(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in _Timings._fields_}
+
+    def close(self):
+        if self._h:
+            self._L.dmi_job_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def mesh_prepare(mesh, cfg=None):
+    """Host stages (corner tables, Edgebreaker, sequencer) + upload; returns a resident Job."""
+    L = load_library()
+    cfg = cfg or Config.default()
+    m, c, head, h = mesh._c(), cfg._c(), _Buffer(), C.c_void_p()
+    _check(L.dmi_mesh_prepare(C.byref(m), C.byref(c), C.byref(head), C.byref(h)))
+    return Job(h.value, _take(head))
+
+
+def encode_connectivity(mesh):
+    return Connectivity(mesh)

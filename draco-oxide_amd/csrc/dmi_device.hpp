@@ -1,0 +1,57 @@
+// dmi_device.hpp — launch wrappers of the gfx950 kernels in dmi_kernels.hip.
+// All pointers are device pointers unless stated otherwise; every launch goes to `stream`.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace dmi {
+
+// ---- quantization (a4-a6) ----------------------------------------------------------------------
+// meta layout (floats): [0..N) per-component min, [N] range, [N+1..2N] per-component max (debug)
+void launch_minmax_f32(const float* vals, uint32_t n_values, int N, float* partials, uint32_t max_blocks, float* meta, hipStream_t s);
+void launch_quant_coord(const float* vals, uint32_t n_values, int N, const float* meta, int bits, int32_t* q, hipStream_t s);
+void launch_quant_oct(const float* vals, uint32_t n_values, int32_t* q, uint32_t* zero_flag, hipStream_t s);
+
+// ---- sequence-order gather: rank[c2v[seq[i]]] = i, qs[i] = q[p2v[c2p[seq[i]]]], joint min/max --
+// minmax: int32[2] pre-initialised to {INT_MAX, INT_MIN}
+void launch_seq_gather(const uint32_t* seq, uint32_t n, const uint32_t* c2v, const uint32_t* c2p, const uint32_t* p2v,
+                       const int32_t* q, int N, uint32_t* rank, int32_t* qs, int32_t* minmax, hipStream_t s);
+
+// ---- predict + transform (a7-a14) → symbols ------------------------------------------------------
+void launch_pred_parallelogram_wrapped(const uint32_t* seq, uint32_t n, const uint32_t* c2v, const uint32_t* opp, const uint32_t* rank,
+                                       const int32_t* qs, const int32_t* minmax, int N, uint32_t* sym, hipStream_t s);
+void launch_pred_delta_difference(uint32_t n, const int32_t* qs, int N, uint32_t* sym, hipStream_t s);
+// counters[0] += number of flips that are false
+void launch_pred_normal_octorth(const uint32_t* seq, uint32_t n, const uint32_t* c2p, const uint32_t* opp_att, const uint32_t* pos_p2v,
+                                const int32_t* q_pos, const int32_t* qs, uint32_t* sym, uint8_t* flips, uint32_t* counters, hipStream_t s);
+// orient[i]: 0 = no bit pushed, 1 = false, 2 = true
+void launch_pred_texcoord_wrapped(const uint32_t* seq, uint32_t n, const uint32_t* c2v, const uint32_t* c2p, const uint32_t* rank,
+                                  const int32_t* qs, const uint32_t* pos_p2v, const int32_t* q_pos, uint32_t pos_len,
+                                  const int32_t* minmax, uint32_t* sym, uint8_t* orient, hipStream_t s);
+// per-block summaries of the orientation flags, stitched on the host:
+// summary[b] = {valid_count, first_value(0/1, 2 = none), last_value, internal_transitions}
+void launch_orient_summary(const uint8_t* orient, uint32_t n, uint32_t* summary, uint32_t* n_blocks_out_host, hipStream_t s);
+uint32_t orient_summary_blocks(uint32_t n);
+
+// ---- histogram (a16) -------------------------------------------------------------------------------
+void launch_histogram(const uint32_t* sym, uint64_t n_sym, uint32_t* hist, uint32_t bins, uint32_t* overflow_flag, hipStream_t s);
+
+// ---- serial coders: one wavefront per stream (a18, a19, a11, a13) ------------------------------------
+struct RansEntry { uint32_t freq, cum, magic, pad; };   // magic = floor(2^32 / freq) (0xFFFFFFFF for freq 1)
+struct ChainDesc {
+  uint32_t kind;            // 0 = rANS over symbols (reverse order), 1 = rABS over flips (forward), 2 = rABS over orientation flags
+  uint32_t precision;       // rANS precision bits
+  uint64_t n;               // symbols / entries
+  const uint32_t* sym;      // kind 0
+  const RansEntry* table;   // kind 0
+  const uint8_t* bits;      // kind 1/2
+  uint32_t p0;              // kind 1/2: zero probability
+  uint32_t pad;
+  uint8_t* out;             // byte output
+  uint64_t cap;
+  uint32_t* out_len;        // [0] = bytes written, [1] = error flag (1 = state too large, 2 = capacity)
+};
+void launch_chains(const ChainDesc* descs_dev, uint32_t n_streams, hipStream_t s);
+
+}  // namespace dmi

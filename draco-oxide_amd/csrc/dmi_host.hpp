@@ -1,0 +1,108 @@
+// dmi_host.hpp — host-side (CPU) stages of libdraco_mi: the serial graph walks that feed the GPU
+// attribute pass and the byte-level container around it.  Flat uint32 arrays throughout (the
+// reference uses BTreeMap / Vec::remove).
+//
+// Reference behaviour each piece reproduces (paths relative to draco-oxide/src/):
+//   CornerTables::build_universal   core/corner_table/mod.rs:84-118,252-416
+//   CornerTables::build_attribute   core/corner_table/attribute_corner_table.rs:16-137
+//   run_edgebreaker                 encode/connectivity/edgebreaker.rs:128-530,575-656
+//   attribute_sequence              shared/attribute/sequence.rs:48-151
+//   FreqTable                       encode/entropy/rans.rs:146-239, shared/entropy/mod.rs:41-64
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/draco_mi.h"
+
+namespace dmi {
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+struct ByteSink {
+  std::vector<uint8_t> b;
+  void u8(uint8_t v) { b.push_back(v); }
+  void u16(uint32_t v) { u8((uint8_t)v); u8((uint8_t)(v >> 8)); }
+  void u32(uint32_t v) { u16(v & 0xFFFF); u16(v >> 16); }
+  void f32(float f) { uint32_t x; std::memcpy(&x, &f, 4); u32(x); }
+  void leb128(uint64_t v) { do { uint8_t x = v & 0x7F; v >>= 7; u8(v ? (x | 0x80) : x); } while (v); }   // utils/bit_coder.rs:20-33
+  void bytes(const uint8_t* p, size_t n) { b.insert(b.end(), p, p + n); }
+  void bytes(const std::vector<uint8_t>& v) { b.insert(b.end(), v.begin(), v.end()); }
+};
+
+// LSB-first bit packer (core/bit_coder.rs:113-188 with LsbFirst): first value lands in the low bits.
+struct BitPackerLsb {
+  std::vector<uint8_t>& out;
+  uint64_t acc = 0;
+  unsigned nbits = 0;
+  explicit BitPackerLsb(std::vector<uint8_t>& o) : out(o) {}
+  void put(unsigned size, uint32_t value) {
+    acc |= (uint64_t)value << nbits;
+    nbits += size;
+    while (nbits >= 8) { out.push_back((uint8_t)acc); acc >>= 8; nbits -= 8; }
+  }
+  void flush() { if (nbits) { out.push_back((uint8_t)acc); acc = 0; nbits = 0; } }
+};
+
+inline uint32_t corner_next(uint32_t c) { return (c % 3 == 2) ? c - 2 : c + 1; }
+inline uint32_t corner_prev(uint32_t c) { return (c % 3 == 0) ? c + 2 : c - 1; }
+
+struct AttTable {
+  std::vector<uint32_t> c2v, opp, lmc;
+  std::vector<uint8_t> seam_edge;
+  uint32_t num_vertices = 0;
+};
+
+struct CornerTables {
+  uint32_t F = 0, V = 0;
+  std::vector<uint32_t> c2p, c2v, opp, lmc;
+  std::vector<AttTable> att;   // one per non-position attribute, in attribute order
+
+  // pos_p2v: point→position value index (NULL = identity).  Returns a dmi_status.
+  int build_universal(const uint32_t* faces, uint32_t num_faces, const uint32_t* pos_p2v, std::string& err);
+  // att_p2v: point→value index of the attribute (NULL = identity).
+  void build_attribute(const uint32_t* att_p2v);
+};
+
+struct EdgebreakerResult {
+  std::vector<uint32_t> seeds;          // corners_of_edgebreaker
+  std::vector<uint8_t> connectivity;    // bytes written by encode_connectivity (without the 11-byte header)
+};
+int run_edgebreaker(const CornerTables& ct, EdgebreakerResult& out, std::string& err);
+
+// Attribute sequencer over a flat table view.
+struct TableRef {
+  uint32_t F, V;
+  const uint32_t *c2v, *opp, *lmc;
+};
+void attribute_sequence(const TableRef& t, const uint32_t* seeds, uint32_t n_seeds, std::vector<uint32_t>& seq);
+
+// rABS bit coder (encode/entropy/rans.rs:71-128), host version for the small connectivity streams.
+struct RabsHost {
+  uint32_t state = 4096, p0;
+  std::vector<uint8_t> out;
+  explicit RabsHost(uint32_t zero_prob) : p0(zero_prob) {}
+  void put(unsigned bit) {
+    const uint32_t f1 = 256 - p0, f = bit ? f1 : p0;
+    if (state >= ((16u * f) << 8)) { out.push_back((uint8_t)state); state >>= 8; }
+    state = ((state / f) << 8) + state % f + (bit ? 0 : f1);
+  }
+  bool finish();   // appends the tagged state; false on StateTooLarge
+};
+uint8_t zero_probability(uint64_t count_zero, float denominator);   // the f32 "(c0/len)*256+0.5 → clamp(1,255)" idiom
+
+// Normalised frequency table + its serialisation.
+struct FreqTable {
+  uint32_t precision = 12;       // rANS precision bits
+  uint32_t bit_length = 1;       // value written before the table (symbol_coding.rs:118-119)
+  std::vector<uint32_t> freq;    // normalised, sums to 2^precision
+  std::vector<uint32_t> cum;
+  std::vector<uint8_t> header;   // u8(1) method, u8(bit_length), leb128(num_symbols), table bytes
+  // hist[s] = count of symbol s; returns dmi_status
+  int build(const uint32_t* hist, size_t bins, std::string& err);
+};
+
+bool append_tagged_state(uint32_t state_minus_base, std::vector<uint8_t>& out);   // rans.rs:48-68
+
+}  // namespace dmi

@@ -1,0 +1,692 @@
+// dmi_job.cpp — C ABI of libdraco_mi.so (include/draco_mi.h) and the per-mesh job that drives the
+// gfx950 kernels: upload once → quantize → sequence-order gather → predict+transform → histogram →
+// (host) table normalisation → one-wave-per-stream rANS/rABS → byte splice.
+// There is NO CPU fallback: without a HIP device every encode entry point returns DMI_ERR_NO_DEVICE.
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+
+#include "dmi_device.hpp"
+#include "dmi_host.hpp"
+
+namespace dmi {
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) { g_last_error = msg; return code; }
+
+#define HIP_TRY(expr)                                                                                              \
+  do {                                                                                                             \
+    hipError_t e_ = (expr);                                                                                        \
+    if (e_ != hipSuccess) {                                                                                        \
+      const bool nodev = (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice || e_ == hipErrorInsufficientDriver || e_ == hipErrorNotInitialized); \
+      return fail(nodev ? DMI_ERR_NO_DEVICE : (e_ == hipErrorOutOfMemory ? DMI_ERR_OUT_OF_MEMORY : DMI_ERR_HIP),    \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                                              \
+    }                                                                                                              \
+  } while (0)
+
+enum Scheme : uint8_t { kDelta = 0, kParallelogram = 1, kTexCoord = 5, kNormal = 6 };   // prediction_scheme/mod.rs:74-86
+enum Transform : uint8_t { kDifference = 0, kWrapped = 1, kOctOrth = 3 };              // prediction_transform/mod.rs:92-101
+enum Port : uint8_t { kToBits = 1, kCoordwise = 2, kOct = 3 };                          // portabilization/mod.rs:85-92
+
+struct DevMem {
+  void* p = nullptr;
+  size_t bytes = 0;
+  ~DevMem() { if (p) (void)hipFree(p); }
+  int alloc(size_t n) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    bytes = n;
+    if (n == 0) return DMI_OK;
+    HIP_TRY(hipMalloc(&p, n));
+    return DMI_OK;
+  }
+  template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct TableDev {
+  uint32_t F = 0, V = 0, n_seq = 0;
+  DevMem c2v, opp, seq;   // c2p is shared by all tables of a job
+  // sharing: a table whose arrays equal another table's reuses its device copies
+  int alias_of = -1;
+};
+
+struct AttJob {
+  dmi_attribute desc{};
+  Scheme scheme = kDelta;
+  Transform transform = kDifference;
+  Port port = kCoordwise;
+  int bits = 11;
+  int nq = 0;            // components after portabilization
+  int table = 0;         // index into tables
+  int parent = -1;
+  DevMem raw, p2v, q, rank, qs, sym, aux /*flips or orient*/, hist, rtable, out, meta, partials, small /*minmax[2], counters[2], flags[2], out_len[2]*2*/, summary;
+  uint32_t bins = 0;
+  uint64_t n_sym = 0;
+  uint64_t out_cap = 0, aux_cap = 0;
+  DevMem aux_out;
+  FreqTable ft;
+};
+
+}  // namespace
+}  // namespace dmi
+
+using namespace dmi;
+
+struct dmi_job {
+  dmi_config cfg{};
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::vector<AttJob> atts;
+  std::vector<TableDev> tables;
+  DevMem c2p;
+  DevMem descs;
+  void* pinned = nullptr;   // host-pinned readback area
+  size_t pinned_bytes = 0;
+  hipEvent_t ev[8]{};
+  bool have_events = false;
+  dmi_timings last{};
+  uint64_t predict_bytes = 0;
+  ~dmi_job() {
+    if (pinned) (void)hipHostFree(pinned);
+    if (have_events) for (auto& e : ev) (void)hipEventDestroy(e);
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+namespace {
+
+int upload(DevMem& m, const void* src, size_t bytes, hipStream_t s) {
+  int rc = m.alloc(bytes);
+  if (rc) return rc;
+  if (bytes) HIP_TRY(hipMemcpyAsync(m.p, src, bytes, hipMemcpyHostToDevice, s));
+  return DMI_OK;
+}
+
+int validate_and_plan(const dmi_attribute* atts, uint32_t n_atts, const dmi_config& cfg, std::vector<AttJob>& out) {
+  out.resize(n_atts);
+  for (uint32_t i = 0; i < n_atts; ++i) {
+    AttJob& a = out[i];
+    a.desc = atts[i];
+    const dmi_attribute& d = atts[i];
+    if (d.num_components < 1 || d.num_components > 4) return fail(DMI_ERR_UNSUPPORTED_NUM_COMPONENTS, "attribute " + std::to_string(i) + ": components must be 1..4");
+    // GroupConfig::default_for, attribute_encoder.rs:59-108
+    switch (d.att_type) {
+      case DMI_ATT_POSITION: a.scheme = kParallelogram; a.transform = kWrapped; break;
+      case DMI_ATT_NORMAL: a.scheme = kNormal; a.transform = kOctOrth; break;
+      case DMI_ATT_TEXCOORD: a.scheme = kTexCoord; a.transform = kWrapped; break;
+      case DMI_ATT_CUSTOM: a.scheme = kParallelogram; a.transform = kWrapped; break;
+      default: a.scheme = kDelta; a.transform = kDifference; break;
+    }
+    if (d.att_type == DMI_ATT_POSITION && cfg.pos_scheme == 0xD0) { a.scheme = kDelta; a.transform = kDifference; }
+    // portabilization::Config::default_for, portabilization/mod.rs:126-142
+    a.port = d.att_type == DMI_ATT_NORMAL ? kOct : (d.att_type == DMI_ATT_CUSTOM ? kToBits : kCoordwise);
+    a.bits = d.att_type == DMI_ATT_POSITION ? (cfg.pos_bits ? cfg.pos_bits : 11)
+             : d.att_type == DMI_ATT_TEXCOORD ? (cfg.uv_bits ? cfg.uv_bits : 10)
+             : d.att_type == DMI_ATT_NORMAL ? 8 : (cfg.generic_bits ? cfg.generic_bits : 11);
+    if (a.bits < 1 || a.bits > 30) return fail(DMI_ERR_INVALID_ARGUMENT, "quantization bits out of range");
+    if (a.port == kToBits) {
+      if (d.component_type != DMI_U32 && d.component_type != DMI_I32 && d.component_type != DMI_F32)
+        return fail(DMI_ERR_UNSUPPORTED_DATA_TYPE, "ToBits needs a 4-byte component type");
+      a.nq = d.num_components;
+    } else {
+      if (d.component_type != DMI_F32) return fail(DMI_ERR_UNSUPPORTED_DATA_TYPE, "only f32 attributes are quantized on the device");
+      a.nq = (a.port == kOct) ? 2 : d.num_components;
+      if (a.port == kOct && d.num_components != 3) return fail(DMI_ERR_UNSUPPORTED_NUM_COMPONENTS, "normals need 3 components");
+    }
+    a.parent = -1;
+    if (a.scheme == kNormal || a.scheme == kTexCoord) {
+      // parents are looked up among already-encoded attributes (encode/attribute/mod.rs:63-66)
+      if (d.parent_index < 0) return fail(DMI_ERR_BAD_PARENT, "attribute " + std::to_string(i) + " needs a Position parent");
+      if ((uint32_t)d.parent_index >= i) return fail(DMI_ERR_PARENT_NOT_ENCODED, "parent attribute is not encoded before its child");
+      const dmi_attribute& p = atts[d.parent_index];
+      if (a.scheme == kNormal && p.att_type != DMI_ATT_POSITION) return fail(DMI_ERR_BAD_PARENT, "normal prediction needs a Position parent");
+      if (out[d.parent_index].nq != 3) return fail(DMI_ERR_BAD_PARENT, "parent attribute must have 3 components");
+      if (a.nq != 2) return fail(DMI_ERR_UNSUPPORTED_NUM_COMPONENTS, "texture coordinates / normals must portabilize to 2 components");
+      a.parent = d.parent_index;
+    } else if (d.parent_index >= 0 && (uint32_t)d.parent_index >= i) {
+      return fail(DMI_ERR_PARENT_NOT_ENCODED, "parent attribute is not encoded before its child");
+    }
+    a.table = (int)i;
+  }
+  return DMI_OK;
+}
+
+uint32_t symbol_bins(const AttJob& a) {
+  // upper bound of (largest symbol + 1) from the quantizer's range:
+  //   wrapped difference: |corr| ≤ max_diff/2 ≤ 2^(bits-1) → zig-zag ≤ 2^bits            → bins 2^bits + 2
+  //   plain difference:   |corr| ≤ 2^bits - 1             → zig-zag ≤ 2^(bits+1) - 1     → bins 2^(bits+1)
+  //   oct-orthogonal:     corr ∈ [0, 255]                                                 → bins 256 (+slack)
+  if (a.transform == kOctOrth) return 512;
+  if (a.port == kToBits) return 0;   // decided after the min/max readback
+  if (a.transform == kWrapped) return (1u << a.bits) + 2;
+  return 1u << (a.bits + 1);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dmi_strerror(int s) {
+  switch (s) {
+    case DMI_OK: return "ok";
+    case DMI_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case DMI_ERR_UNSUPPORTED_DATA_TYPE: return "unsupported data type";
+    case DMI_ERR_UNSUPPORTED_NUM_COMPONENTS: return "unsupported number of components";
+    case DMI_ERR_PARENT_NOT_ENCODED: return "parent attribute not encoded yet";
+    case DMI_ERR_BAD_PARENT: return "bad parent attribute";
+    case DMI_ERR_ZERO_NORMAL: return "zero-length normal";
+    case DMI_ERR_ENTROPY: return "entropy coder error";
+    case DMI_ERR_ALPHABET_TOO_LARGE: return "symbol alphabet too large";
+    case DMI_ERR_NO_DEVICE: return "no HIP device (libdraco_mi has no CPU fallback)";
+    case DMI_ERR_HIP: return "HIP runtime error";
+    case DMI_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case DMI_ERR_CONNECTIVITY: return "connectivity encoding error";
+    case DMI_ERR_UNUSED_VERTICES: return "mesh contains unused vertices";
+    case DMI_ERR_IO: return "i/o error";
+  }
+  return "unknown";
+}
+const char* dmi_last_error(void) { return g_last_error.c_str(); }
+
+int dmi_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void dmi_free(dmi_buffer* b) {
+  if (!b) return;
+  std::free(b->data);
+  b->data = nullptr;
+  b->len = b->cap = 0;
+}
+
+static int to_buffer(const std::vector<uint8_t>& v, dmi_buffer* out) {
+  out->data = static_cast<uint8_t*>(std::malloc(v.size() ? v.size() : 1));
+  if (!out->data) return fail(DMI_ERR_OUT_OF_MEMORY, "malloc");
+  if (!v.empty()) std::memcpy(out->data, v.data(), v.size());
+  out->len = out->cap = v.size();
+  return DMI_OK;
+}
+
+int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, uint32_t n_atts, const uint32_t* seeds, uint32_t n_seeds,
+                   const dmi_config* cfg_in, dmi_job** job_out) {
+  if (!atts || !tables || !job_out || n_atts == 0 || n_atts > 255) return fail(DMI_ERR_INVALID_ARGUMENT, "null argument or bad attribute count");
+  dmi_config cfg{};
+  if (cfg_in) cfg = *cfg_in;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(DMI_ERR_NO_DEVICE, "no HIP device visible; libdraco_mi has no CPU fallback");
+  HIP_TRY(hipSetDevice(cfg.device));
+  std::unique_ptr<dmi_job> job(new dmi_job());
+  job->cfg = cfg;
+  if (cfg.stream) job->stream = static_cast<hipStream_t>(cfg.stream);
+  else { HIP_TRY(hipStreamCreate(&job->stream)); job->own_stream = true; }
+  hipStream_t s = job->stream;
+  int rc = validate_and_plan(atts, n_atts, cfg, job->atts);
+  if (rc) return rc;
+
+  const uint32_t F = tables[0].num_faces;
+  const size_t C = (size_t)F * 3;
+  for (uint32_t i = 0; i < n_atts; ++i) {
+    if (tables[i].num_faces != F) return fail(DMI_ERR_INVALID_ARGUMENT, "all corner tables must have the same face count");
+    if (!tables[i].corner_to_point || !tables[i].corner_to_vertex || !tables[i].opposite) return fail(DMI_ERR_INVALID_ARGUMENT, "corner table arrays missing");
+  }
+  rc = upload(job->c2p, tables[0].corner_to_point, C * 4, s);
+  if (rc) return rc;
+
+  // tables: reuse device copies when a table is identical to an earlier one (no seams)
+  job->tables.resize(n_atts);
+  std::vector<std::vector<uint32_t>> host_seq(n_atts);
+  for (uint32_t i = 0; i < n_atts; ++i) {
+    TableDev& t = job->tables[i];
+    t.F = F;
+    t.V = tables[i].num_vertices;
+    for (uint32_t j = 0; j < i && t.alias_of < 0; ++j) {
+      if (job->tables[j].alias_of >= 0) continue;
+      if (tables[j].num_vertices != t.V) continue;
+      const bool same_ptr = tables[j].corner_to_vertex == tables[i].corner_to_vertex && tables[j].opposite == tables[i].opposite;
+      if (same_ptr || (std::memcmp(tables[j].corner_to_vertex, tables[i].corner_to_vertex, C * 4) == 0 &&
+                       std::memcmp(tables[j].opposite, tables[i].opposite, C * 4) == 0))
+        t.alias_of = (int)j;
+    }
+    if (t.alias_of >= 0) { job->atts[i].table = t.alias_of; continue; }
+    rc = upload(t.c2v, tables[i].corner_to_vertex, C * 4, s);
+    if (rc) return rc;
+    rc = upload(t.opp, tables[i].opposite, C * 4, s);
+    if (rc) return rc;
+    const uint32_t* seq = tables[i].sequence;
+    uint32_t n_seq = tables[i].sequence_len;
+    if (!seq) {
+      if (!seeds && n_seeds) return fail(DMI_ERR_INVALID_ARGUMENT, "no sequence and no seeds");
+      if (!tables[i].left_most_corner) return fail(DMI_ERR_INVALID_ARGUMENT, "left_most_corner needed to compute the sequence");
+      TableRef tr{F, t.V, tables[i].corner_to_vertex, tables[i].opposite, tables[i].left_most_corner};
+      attribute_sequence(tr, seeds, n_seeds, host_seq[i]);
+      seq = host_seq[i].data();
+      n_seq = (uint32_t)host_seq[i].size();
+    }
+    t.n_seq = n_seq;
+    rc = upload(t.seq, seq, (size_t)n_seq * 4, s);
+    if (rc) return rc;
+  }
+
+  size_t pinned_need = 256;
+  uint64_t pb = 0;
+  for (uint32_t i = 0; i < n_atts; ++i) {
+    AttJob& a = job->atts[i];
+    const dmi_attribute& d = a.desc;
+    const TableDev& t = job->tables[a.table];
+    const size_t vbytes = (size_t)d.num_unique * d.num_components * 4;
+    if (d.num_unique && !d.values) return fail(DMI_ERR_INVALID_ARGUMENT, "attribute values missing");
+    rc = upload(a.raw, d.values, vbytes, s);
+    if (rc) return rc;
+    if (d.point_to_value) { rc = upload(a.p2v, d.point_to_value, (size_t)d.num_points * 4, s); if (rc) return rc; }
+    const uint32_t n = t.n_seq;
+    a.n_sym = (uint64_t)n * a.nq;
+    if (a.port != kToBits) { rc = a.q.alloc((size_t)d.num_unique * a.nq * 4); if (rc) return rc; }
+    if ((rc = a.rank.alloc((size_t)t.V * 4))) return rc;
+    if ((rc = a.qs.alloc((size_t)n * a.nq * 4))) return rc;
+    if ((rc = a.sym.alloc((size_t)a.n_sym * 4))) return rc;
+    if (a.scheme == kNormal || a.scheme == kTexCoord) {
+      if ((rc = a.aux.alloc(n ? n : 1))) return rc;
+      a.aux_cap = (uint64_t)n + 16;   // ≤ 1 byte per coded bit + flush
+      if ((rc = a.aux_out.alloc(a.aux_cap))) return rc;
+    }
+    if (a.scheme == kTexCoord) { if ((rc = a.summary.alloc((size_t)std::max(1u, orient_summary_blocks(n)) * 16))) return rc; }
+    a.bins = symbol_bins(a);
+    if (a.port == kToBits) a.bins = 1u << 20;   // capacity; the real bound is checked after the min/max readback
+    if ((rc = a.hist.alloc((size_t)a.bins * 4))) return rc;
+    if ((rc = a.rtable.alloc((size_t)a.bins * sizeof(RansEntry)))) return rc;
+    a.out_cap = a.n_sym * 3 + 16;   // ≤ 3 renormalisation bytes per symbol (P ≤ 20) + flush
+    if ((rc = a.out.alloc(a.out_cap))) return rc;
+    if ((rc = a.meta.alloc(64))) return rc;
+    if ((rc = a.partials.alloc((size_t)2048 * 8 * 4))) return rc;
+    if ((rc = a.small.alloc(64))) return rc;
+    pinned_need += 256 + (size_t)a.bins * 4 + (size_t)std::max(1u, orient_summary_blocks(n)) * 16;
+    // algorithmic bytes of the quantize+predict pass: 4·Nin + 4·Nsym per value, 8 per sequence entry
+    pb += (uint64_t)d.num_unique * 4 * d.num_components + a.n_sym * 4 + (uint64_t)n * 8;
+  }
+  pb += (uint64_t)F * 24;   // corner_to_point + opposite, once
+  job->predict_bytes = pb;
+  HIP_TRY(hipHostMalloc(&job->pinned, pinned_need, hipHostMallocDefault));
+  job->pinned_bytes = pinned_need;
+  if ((rc = job->descs.alloc(sizeof(ChainDesc) * (size_t)n_atts * 2))) return rc;
+  if (cfg.flags & DMI_FLAG_TIMINGS) {
+    for (auto& e : job->ev) HIP_TRY(hipEventCreate(&e));
+    job->have_events = true;
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  *job_out = job.release();
+  return DMI_OK;
+}
+
+void dmi_job_destroy(dmi_job* job) { delete job; }
+
+int dmi_job_timings(const dmi_job* job, dmi_timings* t) {
+  if (!job || !t) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
+  *t = job->last;
+  return DMI_OK;
+}
+
+int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
+  if (!job || !out) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
+  HIP_TRY(hipSetDevice(job->cfg.device));
+  hipStream_t s = job->stream;
+  const bool timed = job->have_events;
+  const auto wall0 = std::chrono::steady_clock::now();
+  const uint32_t n_atts = (uint32_t)job->atts.size();
+  const uint32_t* c2p = job->c2p.as<uint32_t>();
+  uint8_t* pinned = static_cast<uint8_t*>(job->pinned);
+
+  // ---- stage 1: quantization (portabilization) -------------------------------------------------
+  if (timed) HIP_TRY(hipEventRecord(job->ev[0], s));
+  for (auto& a : job->atts) {
+    const dmi_attribute& d = a.desc;
+    HIP_TRY(hipMemsetAsync(a.small.p, 0, 64, s));
+    if (a.port == kCoordwise) {
+      launch_minmax_f32(a.raw.as<float>(), d.num_unique, d.num_components, a.partials.as<float>(), 2048, a.meta.as<float>(), s);
+      launch_quant_coord(a.raw.as<float>(), d.num_unique, d.num_components, a.meta.as<float>(), a.bits, a.q.as<int32_t>(), s);
+    } else if (a.port == kOct) {
+      launch_quant_oct(a.raw.as<float>(), d.num_unique, a.q.as<int32_t>(), a.small.as<uint32_t>() + 4, s);
+    }
+  }
+  // ---- stage 2: sequence-order gather + predict + transform ---------------------------------------
+  if (timed) HIP_TRY(hipEventRecord(job->ev[1], s));
+  for (auto& a : job->atts) {
+    const TableDev& t = job->tables[a.table];
+    const int32_t* q = a.port == kToBits ? a.raw.as<int32_t>() : a.q.as<int32_t>();
+    int32_t* minmax = a.small.as<int32_t>();          // small: [0..1] minmax, [2..3] counters, [4] zero-normal flag, [5] hist overflow
+    static const int32_t init_mm[2] = {2147483647, -2147483647 - 1};
+    HIP_TRY(hipMemcpyAsync(minmax, init_mm, 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(a.rank.p, 0xFF, a.rank.bytes, s));
+    launch_seq_gather(t.seq.as<uint32_t>(), t.n_seq, t.c2v.as<uint32_t>(), c2p, a.p2v.as<uint32_t>(), q, a.nq, a.rank.as<uint32_t>(), a.qs.as<int32_t>(), minmax, s);
+  }
+  for (auto& a : job->atts) {
+    const TableDev& t = job->tables[a.table];
+    const int32_t* minmax = a.small.as<int32_t>();
+    uint32_t* counters = a.small.as<uint32_t>() + 2;
+    const uint32_t n = t.n_seq;
+    if (n == 0) continue;
+    switch (a.scheme) {
+      case kParallelogram:
+        launch_pred_parallelogram_wrapped(t.seq.as<uint32_t>(), n, t.c2v.as<uint32_t>(), t.opp.as<uint32_t>(), a.rank.as<uint32_t>(), a.qs.as<int32_t>(), minmax, a.nq, a.sym.as<uint32_t>(), s);
+        break;
+      case kDelta:
+        launch_pred_delta_difference(n, a.qs.as<int32_t>(), a.nq, a.sym.as<uint32_t>(), s);
+        break;
+      case kNormal: {
+        const AttJob& p = job->atts[a.parent];
+        launch_pred_normal_octorth(t.seq.as<uint32_t>(), n, c2p, t.opp.as<uint32_t>(), p.p2v.as<uint32_t>(), p.q.as<int32_t>(), a.qs.as<int32_t>(), a.sym.as<uint32_t>(), a.aux.as<uint8_t>(), counters, s);
+        break;
+      }
+      case kTexCoord: {
+        const AttJob& p = job->atts[a.parent];
+        const int32_t* qp = p.port == kToBits ? p.raw.as<int32_t>() : p.q.as<int32_t>();
+        launch_pred_texcoord_wrapped(t.seq.as<uint32_t>(), n, t.c2v.as<uint32_t>(), c2p, a.rank.as<uint32_t>(), a.qs.as<int32_t>(), p.p2v.as<uint32_t>(), qp, p.desc.num_points, minmax, a.sym.as<uint32_t>(), a.aux.as<uint8_t>(), s);
+        launch_orient_summary(a.aux.as<uint8_t>(), n, a.summary.as<uint32_t>(), nullptr, s);
+        break;
+      }
+    }
+  }
+  // ---- stage 3: histograms ---------------------------------------------------------------------------
+  if (timed) HIP_TRY(hipEventRecord(job->ev[2], s));
+  std::vector<size_t> pin_off(n_atts);
+  size_t off = 0;
+  for (uint32_t i = 0; i < n_atts; ++i) {
+    AttJob& a = job->atts[i];
+    if (a.port == kToBits) {
+      // alphabet bound needs the value range: read min/max first
+      int32_t mm[2];
+      HIP_TRY(hipMemcpyAsync(mm, a.small.p, 8, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      const uint64_t span = (mm[1] >= mm[0]) ? (uint64_t)((int64_t)mm[1] - (int64_t)mm[0]) : 0;
+      const uint64_t need = (a.transform == kWrapped ? span + 3 : 2 * span + 2);
+      if (need > (1u << 20)) return fail(DMI_ERR_ALPHABET_TOO_LARGE, "custom attribute value range needs more than 2^20 symbols");
+      a.bins = (uint32_t)need;
+    }
+    HIP_TRY(hipMemsetAsync(a.hist.p, 0, (size_t)a.bins * 4, s));
+    if (a.n_sym) launch_histogram(a.sym.as<uint32_t>(), a.n_sym, a.hist.as<uint32_t>(), a.bins, a.small.as<uint32_t>() + 5, s);
+    pin_off[i] = off;
+    HIP_TRY(hipMemcpyAsync(pinned + off, a.small.p, 64, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(pinned + off + 64, a.meta.p, 64, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(pinned + off + 128, a.hist.p, (size_t)a.bins * 4, hipMemcpyDeviceToHost, s));
+    size_t o2 = off + 128 + (size_t)a.bins * 4;
+    if (a.scheme == kTexCoord) {
+      const uint32_t nb = orient_summary_blocks(job->tables[a.table].n_seq);
+      if (nb) HIP_TRY(hipMemcpyAsync(pinned + o2, a.summary.p, (size_t)nb * 16, hipMemcpyDeviceToHost, s));
+      o2 += (size_t)std::max(1u, nb) * 16;
+    }
+    off = (o2 + 63) & ~(size_t)63;
+  }
+  if (timed) HIP_TRY(hipEventRecord(job->ev[3], s));
+  HIP_TRY(hipStreamSynchronize(s));
+  const auto t_tab0 = std::chrono::steady_clock::now();
+
+  // ---- stage 4 (host): normalise tables, build chain descriptors -----------------------------------------
+  std::vector<ChainDesc> descs;
+  struct AuxInfo { uint8_t zero_prob = 0; uint32_t count = 0; int desc = -1; };
+  std::vector<AuxInfo> aux(n_atts);
+  std::vector<int> rans_desc(n_atts, -1);
+  std::string err;
+  for (uint32_t i = 0; i < n_atts; ++i) {
+    AttJob& a = job->atts[i];
+    const uint8_t* base = pinned + pin_off[i];
+    const uint32_t* small = reinterpret_cast<const uint32_t*>(base);
+    if (small[4]) return fail(DMI_ERR_ZERO_NORMAL, "attribute " + std::to_string(i) + " contains a zero-length normal (reference assert, geom.rs:45)");
+    if (small[5]) return fail(DMI_ERR_ALPHABET_TOO_LARGE, "symbol outside the histogram bound");
+    const uint32_t n = job->tables[a.table].n_seq;
+    if (a.n_sym == 0) return fail(DMI_ERR_ENTROPY, "attribute " + std::to_string(i) + " has no values to code (empty histogram)");
+    const uint32_t* hist = reinterpret_cast<const uint32_t*>(base + 128);
+    int rc = a.ft.build(hist, a.bins, err);
+    if (rc) return fail(rc, err);
+    std::vector<RansEntry> rt(a.ft.freq.size());
+    for (size_t k = 0; k < rt.size(); ++k) {
+      const uint32_t f = a.ft.freq[k];
+      rt[k] = RansEntry{f ? f : 1u, a.ft.cum[k], f <= 1u ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / f), 0u};
+    }
+    HIP_TRY(hipMemcpyAsync(a.rtable.p, rt.data(), rt.size() * sizeof(RansEntry), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));   // rt is a stack-scoped staging vector
+    ChainDesc d{};
+    d.kind = 0; d.precision = a.ft.precision; d.n = a.n_sym; d.sym = a.sym.as<uint32_t>(); d.table = a.rtable.as<RansEntry>();
+    d.out = a.out.as<uint8_t>(); d.cap = a.out_cap; d.out_len = a.small.as<uint32_t>() + 8;
+    rans_desc[i] = (int)descs.size();
+    descs.push_back(d);
+    if (a.scheme == kNormal) {
+      // mesh_normal_prediction.rs:147-150
+      const uint32_t count_false = small[2];
+      aux[i].zero_prob = zero_probability(count_false, (float)n);
+      aux[i].count = n;
+      ChainDesc r{};
+      r.kind = 1; r.n = n; r.bits = a.aux.as<uint8_t>(); r.p0 = aux[i].zero_prob; r.out = a.aux_out.as<uint8_t>(); r.cap = a.aux_cap; r.out_len = a.small.as<uint32_t>() + 10;
+      aux[i].desc = (int)descs.size();
+      descs.push_back(r);
+    } else if (a.scheme == kTexCoord) {
+      // stitch per-block summaries: len = Σ count, freq_count_0 = forward transitions with last := true
+      const uint32_t nb = orient_summary_blocks(n);
+      const uint32_t* sm = reinterpret_cast<const uint32_t*>(base + 128 + (size_t)a.bins * 4);
+      uint64_t len = 0, trans = 0;
+      uint32_t last = 1;
+      for (uint32_t b = 0; b < nb; ++b) {
+        const uint32_t cnt = sm[4 * b], first = sm[4 * b + 1], lastv = sm[4 * b + 2], tr = sm[4 * b + 3];
+        if (!cnt) continue;
+        if (first != last) ++trans;
+        trans += tr;
+        last = lastv;
+        len += cnt;
+      }
+      aux[i].zero_prob = zero_probability(trans, (float)len + 0.001f);
+      aux[i].count = (uint32_t)len;
+      ChainDesc r{};
+      r.kind = 2; r.n = n; r.bits = a.aux.as<uint8_t>(); r.p0 = aux[i].zero_prob; r.out = a.aux_out.as<uint8_t>(); r.cap = a.aux_cap; r.out_len = a.small.as<uint32_t>() + 10;
+      aux[i].desc = (int)descs.size();
+      descs.push_back(r);
+    }
+  }
+  HIP_TRY(hipMemcpyAsync(job->descs.p, descs.data(), descs.size() * sizeof(ChainDesc), hipMemcpyHostToDevice, s));
+  const auto t_tab1 = std::chrono::steady_clock::now();
+
+  // ---- stage 5: serial coders, one wavefront per stream -------------------------------------------------
+  if (timed) HIP_TRY(hipEventRecord(job->ev[4], s));
+  launch_chains(job->descs.as<ChainDesc>(), (uint32_t)descs.size(), s);
+  if (timed) HIP_TRY(hipEventRecord(job->ev[5], s));
+  for (uint32_t i = 0; i < n_atts; ++i) HIP_TRY(hipMemcpyAsync(pinned + pin_off[i], job->atts[i].small.p, 64, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  std::vector<std::vector<uint8_t>> rans_bytes(n_atts), aux_bytes(n_atts);
+  for (uint32_t i = 0; i < n_atts; ++i) {
+    AttJob& a = job->atts[i];
+    const uint32_t* small = reinterpret_cast<const uint32_t*>(pinned + pin_off[i]);
+    if (small[9] || small[11]) return fail(DMI_ERR_ENTROPY, small[9] == 1 || small[11] == 1 ? "rANS state too large" : "coder output capacity exceeded");
+    rans_bytes[i].resize(small[8]);
+    if (small[8]) HIP_TRY(hipMemcpyAsync(rans_bytes[i].data(), a.out.p, small[8], hipMemcpyDeviceToHost, s));
+    if (aux[i].desc >= 0) {
+      aux_bytes[i].resize(small[10]);
+      if (small[10]) HIP_TRY(hipMemcpyAsync(aux_bytes[i].data(), a.aux_out.p, small[10], hipMemcpyDeviceToHost, s));
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+
+  // ---- stage 6 (host): splice the attribute section (encode/attribute/mod.rs:26-57, attribute_encoder.rs:159-160,344-386)
+  ByteSink w;
+  w.u8((uint8_t)n_atts);
+  for (uint32_t i = 0; i < n_atts; ++i) { w.u8((uint8_t)((uint8_t)i - 1)); w.u8(job->atts[i].desc.domain); w.u8(0); }   // Q13
+  for (uint32_t i = 0; i < n_atts; ++i) {
+    const AttJob& a = job->atts[i];
+    w.u8(1); w.u8(a.desc.att_type); w.u8(a.desc.component_type); w.u8(a.desc.num_components); w.u8(0); w.u8((uint8_t)a.desc.unique_id); w.u8((uint8_t)a.port);
+  }
+  for (uint32_t i = 0; i < n_atts; ++i) {
+    const AttJob& a = job->atts[i];
+    const uint8_t* base = pinned + pin_off[i];
+    // note: pinned[off..off+64) was overwritten by the second readback of `small`; min/max live at the same offsets
+    const int32_t* mm = reinterpret_cast<const int32_t*>(base);
+    const float* meta = reinterpret_cast<const float*>(base + 64);
+    w.u8((uint8_t)a.scheme);
+    w.u8((uint8_t)a.transform);
+    w.u8(1);   // rans_encoding
+    w.bytes(a.ft.header);
+    w.leb128(rans_bytes[i].size());
+    w.bytes(rans_bytes[i]);
+    ByteSink tinfo;
+    if (a.transform == kWrapped) { tinfo.u32((uint32_t)mm[0]); tinfo.u32((uint32_t)mm[1]); }
+    else if (a.transform == kOctOrth) { tinfo.u32(255); tinfo.u32(127); }
+    if (a.scheme == kNormal) {
+      w.bytes(tinfo.b);
+      w.u8(aux[i].zero_prob);
+      w.leb128(aux_bytes[i].size());
+      w.bytes(aux_bytes[i]);
+    } else if (a.scheme == kTexCoord) {
+      w.u32(aux[i].count);
+      w.u8(aux[i].zero_prob);
+      w.leb128(aux_bytes[i].size());
+      w.bytes(aux_bytes[i]);
+      w.bytes(tinfo.b);
+    } else {
+      w.bytes(tinfo.b);
+    }
+    if (a.port == kCoordwise) {   // quantization_coordinate_wise.rs:56-59
+      for (int k = 0; k < a.desc.num_components; ++k) w.f32(meta[k]);
+      w.f32(meta[a.desc.num_components]);
+      w.u8((uint8_t)a.bits);
+    } else if (a.port == kOct) {
+      w.u8(8);                     // octahedral_quantization.rs:43
+    }
+  }
+  int rc = to_buffer(w.b, out);
+  if (rc) return rc;
+
+  dmi_timings tm{};
+  if (timed) {
+    HIP_TRY(hipEventSynchronize(job->ev[5]));
+    (void)hipEventElapsedTime(&tm.quantize_ms, job->ev[0], job->ev[1]);
+    (void)hipEventElapsedTime(&tm.predict_ms, job->ev[1], job->ev[2]);
+    (void)hipEventElapsedTime(&tm.histogram_ms, job->ev[2], job->ev[3]);
+    (void)hipEventElapsedTime(&tm.rans_ms, job->ev[4], job->ev[5]);
+  }
+  tm.table_ms = std::chrono::duration<float, std::milli>(t_tab1 - t_tab0).count();
+  tm.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+  tm.predict_bytes = job->predict_bytes;
+  for (auto& a : job->atts) tm.symbols += a.n_sym;
+  tm.num_streams = (uint32_t)descs.size();
+  job->last = tm;
+  return DMI_OK;
+}
+
+int dmi_encode_attributes(const dmi_attribute* atts, const dmi_corner_table* tables, uint32_t n_atts, const uint32_t* seeds, uint32_t n_seeds,
+                          const dmi_config* cfg, dmi_buffer* out) {
+  dmi_job* job = nullptr;
+  int rc = dmi_job_create(atts, tables, n_atts, seeds, n_seeds, cfg, &job);
+  if (rc) return rc;
+  rc = dmi_job_encode(job, out);
+  dmi_job_destroy(job);
+  return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Whole-mesh entry points: host connectivity + device attributes.
+// ------------------------------------------------------------------------------------------------
+struct ConnOwner {
+  CornerTables ct;
+  EdgebreakerResult eb;
+  std::vector<std::vector<uint32_t>> seqs;
+  std::vector<dmi_corner_table> views;
+};
+
+static int build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std::vector<uint8_t>& bytes) {
+  if (!mesh || !mesh->atts || mesh->num_atts == 0 || (!mesh->faces && mesh->num_faces)) return fail(DMI_ERR_INVALID_ARGUMENT, "bad mesh");
+  if (mesh->atts[0].att_type != DMI_ATT_POSITION) return fail(DMI_ERR_INVALID_ARGUMENT, "attribute 0 must be the Position attribute (core/mesh/builder.rs:115-125)");
+  std::string err;
+  int rc = o.ct.build_universal(mesh->faces, mesh->num_faces, mesh->atts[0].point_to_value, err);
+  if (rc) return fail(rc, err);
+  for (uint32_t i = 0; i < mesh->num_atts; ++i) {
+    if (mesh->atts[i].att_type == DMI_ATT_POSITION) continue;   // edgebreaker.rs:183-190
+    o.ct.build_attribute(mesh->atts[i].point_to_value);
+  }
+  rc = run_edgebreaker(o.ct, o.eb, err);
+  if (rc) return fail(rc, err);
+  ByteSink s;
+  for (char ch : {'D', 'R', 'A', 'C', 'O'}) s.u8((uint8_t)ch);   // encode/header/mod.rs:26-54
+  s.u8(2); s.u8(2); s.u8(1); s.u8(1); s.u16(0);
+  s.bytes(o.eb.connectivity);
+  bytes.swap(s.b);
+  // views: attribute i uses the universal table when i == 0 or no attribute table i-1 exists
+  // (all_inclusive_corner_table.rs:31-45)
+  o.views.resize(mesh->num_atts);
+  o.seqs.resize(mesh->num_atts);
+  for (uint32_t i = 0; i < mesh->num_atts; ++i) {
+    dmi_corner_table& v = o.views[i];
+    v.num_faces = o.ct.F;
+    v.corner_to_point = o.ct.c2p.data();
+    const bool use_att = i > 0 && (i - 1) < o.ct.att.size();
+    bool seamless = true;
+    if (use_att) { const AttTable& t = o.ct.att[i - 1]; for (size_t c = 0; c < t.seam_edge.size(); ++c) if (t.seam_edge[c] && o.ct.opp[c] != kNone) { seamless = false; break; } }
+    if (use_att && !seamless) {
+      const AttTable& t = o.ct.att[i - 1];
+      v.num_vertices = t.num_vertices; v.corner_to_vertex = t.c2v.data(); v.opposite = t.opp.data(); v.left_most_corner = t.lmc.data();
+      TableRef tr{o.ct.F, t.num_vertices, t.c2v.data(), t.opp.data(), t.lmc.data()};
+      attribute_sequence(tr, o.eb.seeds.data(), (uint32_t)o.eb.seeds.size(), o.seqs[i]);
+    } else {
+      // a seam-free attribute table is identical to the universal one (same ids, same order)
+      v.num_vertices = o.ct.V; v.corner_to_vertex = o.ct.c2v.data(); v.opposite = o.ct.opp.data(); v.left_most_corner = o.ct.lmc.data();
+      if (i == 0 || o.seqs[0].empty()) {
+        TableRef tr{o.ct.F, o.ct.V, o.ct.c2v.data(), o.ct.opp.data(), o.ct.lmc.data()};
+        attribute_sequence(tr, o.eb.seeds.data(), (uint32_t)o.eb.seeds.size(), o.seqs[i]);
+      } else {
+        o.seqs[i] = o.seqs[0];
+      }
+    }
+    v.sequence = o.seqs[i].data();
+    v.sequence_len = (uint32_t)o.seqs[i].size();
+  }
+  return DMI_OK;
+}
+
+int dmi_encode_connectivity(const dmi_mesh* mesh, dmi_buffer* header_and_connectivity, dmi_conn* conn) {
+  if (!header_and_connectivity || !conn) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
+  auto* o = new ConnOwner();
+  std::vector<uint8_t> bytes;
+  int rc = build_connectivity(mesh, *o, bytes);
+  if (rc) { delete o; return rc; }
+  rc = to_buffer(bytes, header_and_connectivity);
+  if (rc) { delete o; return rc; }
+  conn->num_tables = (uint32_t)o->views.size();
+  conn->tables = o->views.data();
+  conn->seeds = o->eb.seeds.data();
+  conn->num_seeds = (uint32_t)o->eb.seeds.size();
+  conn->owner = o;
+  return DMI_OK;
+}
+void dmi_conn_free(dmi_conn* conn) {
+  if (!conn) return;
+  delete static_cast<ConnOwner*>(conn->owner);
+  conn->owner = nullptr; conn->tables = nullptr; conn->seeds = nullptr; conn->num_tables = conn->num_seeds = 0;
+}
+
+int dmi_mesh_prepare(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buffer* header_and_connectivity, dmi_job** job) {
+  if (!header_and_connectivity || !job) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
+  ConnOwner o;
+  std::vector<uint8_t> bytes;
+  int rc = build_connectivity(mesh, o, bytes);
+  if (rc) return rc;
+  rc = dmi_job_create(mesh->atts, o.views.data(), mesh->num_atts, o.eb.seeds.data(), (uint32_t)o.eb.seeds.size(), cfg, job);
+  if (rc) return rc;
+  return to_buffer(bytes, header_and_connectivity);
+}
+
+int dmi_encode_mesh(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buffer* out) {
+  if (!out) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
+  dmi_buffer head{}, att{};
+  dmi_job* job = nullptr;
+  int rc = dmi_mesh_prepare(mesh, cfg, &head, &job);
+  if (rc) return rc;
+  rc = dmi_job_encode(job, &att);
+  dmi_job_destroy(job);
+  if (rc) { dmi_free(&head); return rc; }
+  std::vector<uint8_t> all(head.data, head.data + head.len);
+  all.insert(all.end(), att.data, att.data + att.len);
+  dmi_free(&head);
+  dmi_free(&att);
+  return to_buffer(all, out);
+}
+
+}  // extern "C"

@@ -1,0 +1,733 @@
+// dmi_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels for the draco attribute-encoding
+// hot path.  Integer / bit-twiddling work bounded by HBM bandwidth: no MFMA.  Build with
+// -ffp-contract=off so every f32 operation rounds separately like the Rust reference.
+//
+// Reference arithmetic each kernel reproduces (paths relative to draco-oxide/src/):
+//   k_minmax_f32 / k_minmax_final      encode/attribute/portabilization/quantization_coordinate_wise.rs:24-68
+//   k_quant_coord                      ...quantization_coordinate_wise.rs:70-91
+//   k_quant_oct                        ...octahedral_quantization.rs:49-64, prediction_transform/geom.rs:40-91,137-157
+//   k_seq_gather                       attribute_encoder.rs:332-338 (sequence order), wrapped_difference.rs:36-52 (min/max)
+//   k_pred_parallelogram_wrapped       shared/attribute/prediction_scheme/mesh_parallelogram_prediction.rs:186-237 + wrapped_difference.rs:54-99
+//   k_pred_delta_difference            .../delta_prediction.rs:56-71 + prediction_transform/difference.rs:26-34
+//   k_pred_normal_octorth              .../mesh_normal_prediction.rs:22-44,75-144 + prediction_transform/oct_orthogonal.rs:23-85
+//   k_pred_texcoord_wrapped            .../mesh_prediction_for_texture_coordinates.rs:32-81,107-219 + wrapped_difference.rs
+//   k_histogram                        encode/entropy/symbol_coding.rs:149-157
+//   k_chains                           encode/entropy/rans.rs:33-68 (rANS), :91-128 (rABS)
+#include "dmi_device.hpp"
+
+namespace dmi {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr uint32_t kNoneD = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint32_t cnext(uint32_t c) { return (c % 3u == 2u) ? c - 2u : c + 1u; }
+__device__ __forceinline__ uint32_t cprev(uint32_t c) { return (c % 3u == 0u) ? c + 2u : c - 1u; }
+
+// Rust `as` casts: saturating, NaN → 0.
+__device__ __forceinline__ int32_t f32_to_i32_sat(float f) {
+  if (f != f) return 0;
+  if (f >= 2147483648.0f) return 2147483647;
+  if (f <= -2147483648.0f) return (-2147483647 - 1);
+  return (int32_t)f;
+}
+__device__ __forceinline__ int64_t f32_to_i64_sat(float f) {
+  if (f != f) return 0;
+  if (f >= 9223372036854775808.0f) return 9223372036854775807ll;
+  if (f <= -9223372036854775808.0f) return (-9223372036854775807ll - 1);
+  return (int64_t)f;
+}
+__device__ __forceinline__ int32_t wadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+__device__ __forceinline__ int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
+__device__ __forceinline__ int32_t wmul(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
+__device__ __forceinline__ int64_t wadd64(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }
+__device__ __forceinline__ int64_t wsub64(int64_t a, int64_t b) { return (int64_t)((uint64_t)a - (uint64_t)b); }
+__device__ __forceinline__ int64_t wmul64(int64_t a, int64_t b) { return (int64_t)((uint64_t)a * (uint64_t)b); }
+__device__ __forceinline__ int64_t wabs64(int64_t a) { return a < 0 ? (int64_t)(0ull - (uint64_t)a) : a; }
+__device__ __forceinline__ int64_t wdiv64(int64_t a, int64_t b) { return (b == -1) ? (int64_t)(0ull - (uint64_t)a) : a / b; }
+__device__ __forceinline__ uint32_t zigzag(int32_t v) {   // utils/mod.rs:152-158
+  return v >= 0 ? ((uint32_t)v << 1) : ((((uint32_t)(-(v + 1))) << 1) + 1u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// min / max of f32 components, both seeded with +0.0 (quirk Q1).  Reductions use the reference's
+// own comparisons (`<`, `>`): a partial can never be -0.0 or NaN, so the tree order is irrelevant.
+// ------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void block_reduce_minmax(float (&mn)[N], float (&mx)[N], float* out) {
+  __shared__ float sh[2 * N * (kBlock / 64)];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      float a = __shfl_down(mn[k], off, 64);
+      float b = __shfl_down(mx[k], off, 64);
+      if (a < mn[k]) mn[k] = a;
+      if (b > mx[k]) mx[k] = b;
+    }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) { sh[wave * 2 * N + k] = mn[k]; sh[wave * 2 * N + N + k] = mx[k]; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kBlock / 64; ++w) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        float a = sh[w * 2 * N + k], b = sh[w * 2 * N + N + k];
+        if (a < mn[k]) mn[k] = a;
+        if (b > mx[k]) mx[k] = b;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) { out[k] = mn[k]; out[N + k] = mx[k]; }
+  }
+}
+
+template <int N>
+__global__ __launch_bounds__(kBlock) void k_minmax_f32(const float* __restrict__ vals, uint32_t n, float* __restrict__ partials) {
+  float mn[N], mx[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) { mn[k] = 0.0f; mx[k] = 0.0f; }
+  for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < n; v += gridDim.x * kBlock) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const float x = vals[(size_t)v * N + k];
+      if (x < mn[k]) mn[k] = x;
+      if (x > mx[k]) mx[k] = x;
+    }
+  }
+  block_reduce_minmax<N>(mn, mx, partials + (size_t)blockIdx.x * 2 * N);
+}
+
+template <int N>
+__global__ __launch_bounds__(kBlock) void k_minmax_final(const float* __restrict__ partials, uint32_t nblocks, float* __restrict__ meta) {
+  float mn[N], mx[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) { mn[k] = 0.0f; mx[k] = 0.0f; }
+  for (uint32_t b = threadIdx.x; b < nblocks; b += kBlock) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const float a = partials[(size_t)b * 2 * N + k], c = partials[(size_t)b * 2 * N + N + k];
+      if (a < mn[k]) mn[k] = a;
+      if (c > mx[k]) mx[k] = c;
+    }
+  }
+  __shared__ float res[2 * N];
+  block_reduce_minmax<N>(mn, mx, res);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float delta_max = 0.0f;   // one shared range (Q2)
+#pragma unroll
+    for (int k = 0; k < N; ++k) { const float d = res[N + k] - res[k]; if (d > delta_max) delta_max = d; }
+#pragma unroll
+    for (int k = 0; k < N; ++k) { meta[k] = res[k]; meta[N + 1 + k] = res[N + k]; }
+    meta[N] = delta_max;
+  }
+}
+
+// q = trunc(((v - min) / range) * (2^bits - 1) + 0.5), range == 0 skips the divide (Q3).  Flat over components.
+template <int N>
+__global__ __launch_bounds__(kBlock) void k_quant_coord(const float* __restrict__ vals, uint64_t n_comp, const float* __restrict__ meta, float maxq, int32_t* __restrict__ q) {
+  float mn[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) mn[k] = meta[k];
+  const float range = meta[N];
+  for (uint64_t e = (uint64_t)blockIdx.x * kBlock + threadIdx.x; e < n_comp; e += (uint64_t)gridDim.x * kBlock) {
+    const int k = (int)(e % N);
+    float m = mn[0];
+#pragma unroll
+    for (int j = 1; j < N; ++j) if (k == j) m = mn[j];
+    const float diff = vals[e] - m;
+    const float normalized = (range == 0.0f) ? diff : diff / range;
+    const float quantized = normalized * maxq;
+    q[e] = (int32_t)f32_to_i64_sat(quantized + 0.5f);
+  }
+}
+
+// geom.rs:40-91 (f32 path; Q5: the fold uses the pre-fold u and v; Q6: no normalisation)
+__device__ __forceinline__ void oct_transform(float x, float y, float z, float& u, float& v) {
+  const float abs_sum = fabsf(x) + fabsf(y) + fabsf(z);
+  u = y / abs_sum;
+  v = z / abs_sum;
+  if (x < 0.0f) {
+    const float uo = (u < 0.0f) ? fabsf(v) - 1.0f : 1.0f - fabsf(v);
+    const float vo = (v < 0.0f) ? fabsf(u) - 1.0f : 1.0f - fabsf(u);
+    u = uo;
+    v = vo;
+  }
+}
+// geom.rs:137-157 (Q7)
+__device__ __forceinline__ void oct_faithful(int32_t u, int32_t v, int32_t& x, int32_t& y) {
+  x = u; y = v;
+  if ((u == 0 && v == 0) || (u == 255 && v == 0) || (u == 0 && v == 255)) { x = 255; y = 255; }
+  else if (u == 0 && v > 127) y = 127 - (v - 127);
+  else if (u == 255 && v < 127) y = 127 + (127 - v);
+  else if (v == 255 && u < 127) x = 127 + (127 - u);
+  else if (v == 0 && u > 127) x = 127 - (u - 127);
+}
+__device__ __forceinline__ void oct_quantize(float x, float y, float z, int32_t& qx, int32_t& qy) {
+  float u, v;
+  oct_transform(x, y, z, u, v);
+  const float a = (u + 1.0f) * 127.0f;   // (1 << 8-1) - 1 = 127 (Q4)
+  const float b = (v + 1.0f) * 127.0f;
+  oct_faithful(f32_to_i32_sat(a), f32_to_i32_sat(b), qx, qy);
+}
+
+__global__ __launch_bounds__(kBlock) void k_quant_oct(const float* __restrict__ vals, uint32_t n, int32_t* __restrict__ q, uint32_t* __restrict__ zero_flag) {
+  for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < n; v += gridDim.x * kBlock) {
+    const float x = vals[(size_t)v * 3], y = vals[(size_t)v * 3 + 1], z = vals[(size_t)v * 3 + 2];
+    if (x == 0.0f && y == 0.0f && z == 0.0f) { atomicOr(zero_flag, 1u); q[(size_t)v * 2] = 0; q[(size_t)v * 2 + 1] = 0; continue; }
+    int32_t a, b;
+    oct_quantize(x, y, z, a, b);
+    q[(size_t)v * 2] = a;
+    q[(size_t)v * 2 + 1] = b;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sequence-order gather.  Each vertex is emitted exactly once by the sequencer, so
+//   rank[v] < i  ⇔  vertices_up_till_now.contains(v)         (the reference's O(V) scan, F10)
+// and, because all corners of one (attribute-)vertex carry the same value,
+//   qs[rank[vertex(c)]] == attribute.get(point_idx(c))        for every already-coded corner c.
+// ------------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(kBlock) void k_seq_gather(const uint32_t* __restrict__ seq, uint32_t n, const uint32_t* __restrict__ c2v,
+                                                       const uint32_t* __restrict__ c2p, const uint32_t* __restrict__ p2v,
+                                                       const int32_t* __restrict__ q, uint32_t* __restrict__ rank, int32_t* __restrict__ qs,
+                                                       int32_t* __restrict__ minmax) {
+  int32_t mn = 2147483647, mx = (-2147483647 - 1);
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const uint32_t c = seq[i];
+    rank[c2v[c]] = i;
+    uint32_t p = c2p[c];
+    if (p2v) p = p2v[p];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const int32_t v = q[(size_t)p * N + k];
+      qs[(size_t)i * N + k] = v;
+      mn = min(mn, v);
+      mx = max(mx, v);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { mn = min(mn, __shfl_down(mn, off, 64)); mx = max(mx, __shfl_down(mx, off, 64)); }
+  if ((threadIdx.x & 63) == 0) { atomicMin(&minmax[0], mn); atomicMax(&minmax[1], mx); }
+}
+
+// WrappedDifference::squeeze parameters from the joint min/max (wrapped_difference.rs:62-69, Q16)
+struct WrapParams { int32_t mn, mx, max_diff, max_corr, min_corr; };
+__device__ __forceinline__ WrapParams wrap_params(const int32_t* minmax) {
+  WrapParams w;
+  w.mn = minmax[0]; w.mx = minmax[1];
+  w.max_diff = wadd(1, wsub(w.mx, w.mn));
+  w.max_corr = w.max_diff / 2;
+  w.min_corr = (int32_t)(0u - (uint32_t)w.max_corr);
+  if ((w.max_diff & 1) == 0) w.max_corr = wsub(w.max_corr, 1);
+  return w;
+}
+__device__ __forceinline__ uint32_t wrap_symbol(int32_t orig, int32_t pred, const WrapParams& w) {
+  pred = pred < w.mn ? w.mn : (pred > w.mx ? w.mx : pred);
+  const int32_t val = wsub(orig, pred);
+  int32_t corr = val;
+  if (val > w.max_corr) corr = wsub(val, w.max_diff);
+  else if (val < w.min_corr) corr = wadd(val, w.max_diff);
+  return zigzag(corr);
+}
+
+template <int N>
+__global__ __launch_bounds__(kBlock) void k_pred_parallelogram_wrapped(const uint32_t* __restrict__ seq, uint32_t n, const uint32_t* __restrict__ c2v,
+                                                                       const uint32_t* __restrict__ opp, const uint32_t* __restrict__ rank,
+                                                                       const int32_t* __restrict__ qs, const int32_t* __restrict__ minmax,
+                                                                       uint32_t* __restrict__ sym) {
+  const WrapParams w = wrap_params(minmax);
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const uint32_t c = seq[i];
+    const uint32_t o = opp[c];
+    int32_t pred[N];
+    bool have = false;
+    if (o != kNoneD) {
+      const uint32_t ro = rank[c2v[o]], rn = rank[c2v[cnext(c)]], rp = rank[c2v[cprev(c)]];
+      if (ro < i && rn < i && rp < i) {
+        have = true;
+#pragma unroll
+        for (int k = 0; k < N; ++k) pred[k] = wsub(wadd(qs[(size_t)rn * N + k], qs[(size_t)rp * N + k]), qs[(size_t)ro * N + k]);
+      }
+    }
+    if (!have) {
+      // value of the previously coded vertex (Q15): qs[i-1]; zero for the very first entry
+#pragma unroll
+      for (int k = 0; k < N; ++k) pred[k] = (i > 0) ? qs[(size_t)(i - 1) * N + k] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) sym[(size_t)i * N + k] = wrap_symbol(qs[(size_t)i * N + k], pred[k], w);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_pred_delta_difference(uint64_t n_comp, int N, const int32_t* __restrict__ qs, uint32_t* __restrict__ sym) {
+  for (uint64_t e = (uint64_t)blockIdx.x * kBlock + threadIdx.x; e < n_comp; e += (uint64_t)gridDim.x * kBlock) {
+    const int32_t pred = (e >= (uint64_t)N) ? qs[e - N] : 0;
+    sym[e] = zigzag(wsub(qs[e], pred));
+  }
+}
+
+// oct_orthogonal.rs:23-74
+__device__ __forceinline__ int32_t isgn(int32_t v) { return v > 0 ? 1 : (v < 0 ? -1 : 0); }
+__device__ __forceinline__ int32_t iabs(int32_t v) { return v < 0 ? (int32_t)(0u - (uint32_t)v) : v; }
+__device__ __forceinline__ void oct_orthogonal(int32_t o0, int32_t o1, int32_t p0, int32_t p1, uint32_t& s0, uint32_t& s1) {
+  const int32_t one = 127;
+  p0 = wsub(p0, one); p1 = wsub(p1, one); o0 = wsub(o0, one); o1 = wsub(o1, one);
+  if (wadd(iabs(p0), iabs(p1)) > one) {
+    const int32_t pa = p0, qs = -isgn(wmul(p0, p1));
+    p0 = wadd(wmul(qs, p1), wmul(isgn(pa), one));
+    p1 = wadd(wmul(qs, pa), wmul(isgn(p1), one));
+    const int32_t oa = o0, qo = -isgn(wmul(o0, o1));
+    o0 = wadd(wmul(qo, o1), wmul(isgn(oa), one));
+    o1 = wadd(wmul(qo, oa), wmul(isgn(o1), one));
+  }
+  if (!(p0 == 0 && p1 == 0)) {
+    // at most three quarter turns bring pred into {p0 < 0, p1 <= 0}
+    for (int t = 0; t < 4 && (p0 >= 0 || p1 > 0); ++t) {
+      int32_t tmp = p0; p0 = (int32_t)(0u - (uint32_t)p1); p1 = tmp;
+      tmp = o0; o0 = (int32_t)(0u - (uint32_t)o1); o1 = tmp;
+    }
+  }
+  int32_t c0 = wsub(o0, p0), c1 = wsub(o1, p1);
+  if (c0 < 0) c0 = wadd(c0, 255);
+  if (c1 < 0) c1 = wadd(c1, 255);
+  s0 = (uint32_t)c0; s1 = (uint32_t)c1;
+}
+
+__global__ __launch_bounds__(kBlock) void k_pred_normal_octorth(const uint32_t* __restrict__ seq, uint32_t n, const uint32_t* __restrict__ c2p,
+                                                                const uint32_t* __restrict__ opp, const uint32_t* __restrict__ pos_p2v,
+                                                                const int32_t* __restrict__ q_pos, const int32_t* __restrict__ qs,
+                                                                uint32_t* __restrict__ sym, uint8_t* __restrict__ flips, uint32_t* __restrict__ counters) {
+  uint32_t n_false = 0;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const uint32_t c = seq[i];
+    auto pos_of = [&](uint32_t corner, int32_t* out) {
+      uint32_t p = c2p[corner];
+      if (pos_p2v) p = pos_p2v[p];
+      out[0] = q_pos[(size_t)p * 3]; out[1] = q_pos[(size_t)p * 3 + 1]; out[2] = q_pos[(size_t)p * 3 + 2];
+    };
+    int32_t pc[3];
+    pos_of(c, pc);
+    // swing left to the start of the fan (or full turn), then right, summing face normals
+    uint32_t cur = c;
+    for (;;) { const uint32_t o = opp[cnext(cur)]; if (o == kNoneD) break; cur = cnext(o); if (cur == c) break; }
+    const uint32_t start = cur;
+    int64_t sum0 = 0, sum1 = 0, sum2 = 0;
+    for (;;) {
+      int32_t pn[3], pp[3];
+      pos_of(cnext(cur), pn);
+      pos_of(cprev(cur), pp);
+      const int32_t dn0 = wsub(pn[0], pc[0]), dn1 = wsub(pn[1], pc[1]), dn2 = wsub(pn[2], pc[2]);
+      const int32_t dp0 = wsub(pp[0], pc[0]), dp1 = wsub(pp[1], pc[1]), dp2 = wsub(pp[2], pc[2]);
+      sum0 = wadd64(sum0, (int64_t)wsub(wmul(dn1, dp2), wmul(dn2, dp1)));   // cross in i32, sum in i64
+      sum1 = wadd64(sum1, (int64_t)wsub(wmul(dn2, dp0), wmul(dn0, dp2)));
+      sum2 = wadd64(sum2, (int64_t)wsub(wmul(dn0, dp1), wmul(dn1, dp0)));
+      const uint32_t o = opp[cprev(cur)];
+      if (o == kNoneD) break;
+      cur = cprev(o);
+      if (cur == start) break;
+    }
+    const int64_t upper = 1ll << 29;
+    const int64_t abs_sum = wadd64(wadd64(wabs64(sum0), wabs64(sum1)), wabs64(sum2));
+    if (abs_sum > upper) {
+      const int64_t quot = abs_sum / upper;
+      sum0 = wdiv64(sum0, quot); sum1 = wdiv64(sum1, quot); sum2 = wdiv64(sum2, quot);
+    }
+    const int32_t n0 = (int32_t)sum0, n1 = (int32_t)sum1, n2 = (int32_t)sum2;
+    int32_t p0 = 0, p1 = 0;
+    if (!(n0 == 0 && n1 == 0 && n2 == 0)) oct_quantize((float)n0, (float)n1, (float)n2, p0, p1);
+    const int32_t a0 = qs[(size_t)i * 2], a1 = qs[(size_t)i * 2 + 1];
+    const int32_t m0 = wmul(p0, -1), m1 = wmul(p1, -1);
+    const int32_t d10 = wsub(p0, a0), d11 = wsub(p1, a1), d20 = wsub(m0, a0), d21 = wsub(m1, a1);
+    const int32_t dot1 = wadd(wmul(d10, d10), wmul(d11, d11)), dot2 = wadd(wmul(d20, d20), wmul(d21, d21));
+    const bool flip = dot1 > dot2;   // Q8: flip negates the octahedral coordinates
+    if (flip) { p0 = m0; p1 = m1; } else ++n_false;
+    flips[i] = flip ? 1 : 0;
+    uint32_t s0, s1;
+    oct_orthogonal(a0, a1, p0, p1, s0, s1);
+    sym[(size_t)i * 2] = s0;
+    sym[(size_t)i * 2 + 1] = s1;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) n_false += __shfl_down(n_false, off, 64);
+  if ((threadIdx.x & 63) == 0 && n_false) atomicAdd(&counters[0], n_false);
+}
+
+// mesh_prediction_for_texture_coordinates.rs:32-48
+__device__ __forceinline__ uint64_t int_sqrt(uint64_t value) {
+  if (value == 0) return 0;
+  uint64_t act = value, sq = 1;
+  while (act >= 2) { sq *= 2; act /= 4; }
+  sq = (sq + value / sq) / 2;
+  while (sq * sq > value) sq = (sq + value / sq) / 2;
+  return sq;
+}
+
+__global__ __launch_bounds__(kBlock) void k_pred_texcoord_wrapped(const uint32_t* __restrict__ seq, uint32_t n, const uint32_t* __restrict__ c2v,
+                                                                  const uint32_t* __restrict__ c2p, const uint32_t* __restrict__ rank,
+                                                                  const int32_t* __restrict__ qs, const uint32_t* __restrict__ pos_p2v,
+                                                                  const int32_t* __restrict__ q_pos, uint32_t pos_len, const int32_t* __restrict__ minmax,
+                                                                  uint32_t* __restrict__ sym, uint8_t* __restrict__ orient) {
+  const WrapParams w = wrap_params(minmax);
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const uint32_t c = seq[i], nc = cnext(c), pc = cprev(c);
+    const uint32_t rn = rank[c2v[nc]], rp = rank[c2v[pc]];
+    const int32_t cu0 = qs[(size_t)i * 2], cu1 = qs[(size_t)i * 2 + 1];
+    int32_t pred0 = 0, pred1 = 0;
+    uint8_t oflag = 0;
+    bool done = false;
+    if (rn < i && rp < i) {
+      const int64_t nu0 = qs[(size_t)rn * 2], nu1 = qs[(size_t)rn * 2 + 1], pu0 = qs[(size_t)rp * 2], pu1 = qs[(size_t)rp * 2 + 1];
+      if (nu0 == pu0 && nu1 == pu1) {
+        pred0 = (int32_t)pu0; pred1 = (int32_t)pu1; done = true;   // degenerate: identical neighbour UVs
+      } else {
+        auto pos_of = [&](uint32_t corner, int64_t* out) {   // get_position_for_vertex :22-30
+          const uint32_t p = c2p[corner];
+          if (p < pos_len) {
+            const uint32_t v = pos_p2v ? pos_p2v[p] : p;
+            out[0] = q_pos[(size_t)v * 3]; out[1] = q_pos[(size_t)v * 3 + 1]; out[2] = q_pos[(size_t)v * 3 + 2];
+          } else { out[0] = out[1] = out[2] = 0; }
+        };
+        int64_t cp[3], np[3], pp[3];
+        pos_of(c, cp); pos_of(nc, np); pos_of(pc, pp);
+        const int64_t pn0 = wsub64(pp[0], np[0]), pn1 = wsub64(pp[1], np[1]), pn2 = wsub64(pp[2], np[2]);
+        const uint64_t pn2sq = (uint64_t)wadd64(wadd64(wmul64(pn0, pn0), wmul64(pn1, pn1)), wmul64(pn2, pn2));
+        if (pn2sq != 0) {
+          const int64_t cn0 = wsub64(cp[0], np[0]), cn1 = wsub64(cp[1], np[1]), cn2 = wsub64(cp[2], np[2]);
+          const int64_t cn_dot_pn = wadd64(wadd64(wmul64(pn0, cn0), wmul64(pn1, cn1)), wmul64(pn2, cn2));
+          const int64_t pnu0 = wsub64(pu0, nu0), pnu1 = wsub64(pu1, nu1);
+          const int64_t I64MAX = 9223372036854775807ll;
+          const int64_t n_uv_absmax = max(wabs64(nu0), wabs64(nu1));
+          const int64_t pn_uv_absmax = max(wabs64(pnu0), wabs64(pnu1));
+          const int64_t pn_absmax = max(max(wabs64(pn0), wabs64(pn1)), wabs64(pn2));
+          const bool overflow = (n_uv_absmax > wdiv64(I64MAX, (int64_t)pn2sq)) || (wabs64(cn_dot_pn) > wdiv64(I64MAX, pn_uv_absmax)) ||
+                                (wabs64(cn_dot_pn) > wdiv64(I64MAX, pn_absmax));
+          if (!overflow) {
+            const int64_t xu0 = wadd64(wmul64(nu0, (int64_t)pn2sq), wmul64(pnu0, cn_dot_pn));
+            const int64_t xu1 = wadd64(wmul64(nu1, (int64_t)pn2sq), wmul64(pnu1, cn_dot_pn));
+            const int64_t xp0 = wadd64(np[0], wdiv64(wmul64(pn0, cn_dot_pn), (int64_t)pn2sq));
+            const int64_t xp1 = wadd64(np[1], wdiv64(wmul64(pn1, cn_dot_pn), (int64_t)pn2sq));
+            const int64_t xp2 = wadd64(np[2], wdiv64(wmul64(pn2, cn_dot_pn), (int64_t)pn2sq));
+            const int64_t cx0 = wsub64(cp[0], xp0), cx1 = wsub64(cp[1], xp1), cx2 = wsub64(cp[2], xp2);
+            const uint64_t cx2sq = (uint64_t)wadd64(wadd64(wmul64(cx0, cx0), wmul64(cx1, cx1)), wmul64(cx2, cx2));
+            const uint64_t nrm = int_sqrt(cx2sq * pn2sq);
+            const int64_t cxu0 = wmul64(pnu1, (int64_t)nrm), cxu1 = wmul64((int64_t)(0ull - (uint64_t)pnu0), (int64_t)nrm);
+            const int64_t a0 = wdiv64(wadd64(xu0, cxu0), (int64_t)pn2sq), a1 = wdiv64(wadd64(xu1, cxu1), (int64_t)pn2sq);
+            const int64_t b0 = wdiv64(wsub64(xu0, cxu0), (int64_t)pn2sq), b1 = wdiv64(wsub64(xu1, cxu1), (int64_t)pn2sq);
+            const int64_t ea0 = wsub64(cu0, a0), ea1 = wsub64(cu1, a1), eb0 = wsub64(cu0, b0), eb1 = wsub64(cu1, b1);
+            const int64_t da = wadd64(wmul64(ea0, ea0), wmul64(ea1, ea1)), db = wadd64(wmul64(eb0, eb0), wmul64(eb1, eb1));
+            if (da < db) { oflag = 2; pred0 = (int32_t)a0; pred1 = (int32_t)a1; }
+            else { oflag = 1; pred0 = (int32_t)b0; pred1 = (int32_t)b1; }
+            done = true;
+          }
+        }
+      }
+    }
+    if (!done) {   // fallback_predict :51-81 (the `prev` branch is intentionally absent)
+      if (rn < i) { pred0 = qs[(size_t)rn * 2]; pred1 = qs[(size_t)rn * 2 + 1]; }
+      else if (i > 0) { pred0 = qs[(size_t)(i - 1) * 2]; pred1 = qs[(size_t)(i - 1) * 2 + 1]; }
+    }
+    orient[i] = oflag;
+    sym[(size_t)i * 2] = wrap_symbol(cu0, pred0, w);
+    sym[(size_t)i * 2 + 1] = wrap_symbol(cu1, pred1, w);
+  }
+}
+
+// Per-block summary of the orientation flags so the host can stitch the count of bits and the number
+// of forward transitions (mesh_prediction_for_texture_coordinates.rs:224-235) without a serial pass.
+constexpr uint32_t kOrientChunk = 4096;
+__global__ __launch_bounds__(64) void k_orient_summary(const uint8_t* __restrict__ orient, uint32_t n, uint32_t* __restrict__ summary) {
+  const uint32_t lo = blockIdx.x * kOrientChunk, hi = min(n, lo + kOrientChunk);
+  const uint32_t lane = threadIdx.x;
+  uint32_t count = 0, trans = 0, first = 2, last = 2;
+  for (uint32_t base = lo; base < hi; base += 64) {
+    const uint32_t i = base + lane;
+    const uint32_t f = (i < hi) ? orient[i] : 0;
+    const unsigned long long valid = __ballot(f != 0);
+    const unsigned long long ones = __ballot(f == 2);
+    if (valid == 0) continue;
+    // value of the previous valid lane (or `last` carried from the previous batch)
+    const unsigned long long below = valid & ((1ull << lane) - 1ull);
+    uint32_t prev;
+    if (below) { const int pl = 63 - __clzll(below); prev = (uint32_t)((ones >> pl) & 1ull); }
+    else prev = last;
+    const uint32_t mine = (f == 2);
+    const bool is_t = (f != 0) && (prev != 2) && (prev != mine);
+    trans += (uint32_t)__popcll(__ballot(is_t));
+    count += (uint32_t)__popcll(valid);
+    if (first == 2) { const int fl = __ffsll((long long)valid) - 1; first = (uint32_t)((ones >> fl) & 1ull); }
+    { const int ll = 63 - __clzll(valid); last = (uint32_t)((ones >> ll) & 1ull); }
+  }
+  if (lane == 0) {
+    summary[blockIdx.x * 4 + 0] = count;
+    summary[blockIdx.x * 4 + 1] = first;
+    summary[blockIdx.x * 4 + 2] = last;
+    summary[blockIdx.x * 4 + 3] = trans;
+  }
+}
+
+// Symbol histogram, LDS-privatised when the alphabet fits (≤ 16K bins = 64 KiB of the CU's 160 KiB).
+constexpr uint32_t kLdsBins = 16384;
+__global__ __launch_bounds__(kBlock) void k_histogram(const uint32_t* __restrict__ sym, uint64_t n, uint32_t* __restrict__ hist, uint32_t bins,
+                                                      uint32_t* __restrict__ overflow) {
+  extern __shared__ uint32_t lds[];
+  const bool use_lds = bins <= kLdsBins;
+  if (use_lds) { for (uint32_t b = threadIdx.x; b < bins; b += kBlock) lds[b] = 0; __syncthreads(); }
+  for (uint64_t e = (uint64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (uint64_t)gridDim.x * kBlock) {
+    const uint32_t s = sym[e];
+    if (s >= bins) { atomicOr(overflow, 1u); continue; }
+    if (use_lds) atomicAdd(&lds[s], 1u); else atomicAdd(&hist[s], 1u);
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < bins; b += kBlock) { const uint32_t v = lds[b]; if (v) atomicAdd(&hist[b], v); }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Serial coders.  The rANS / rABS state recurrence is one dependency chain per stream, so
+// a stream is owned by ONE wavefront: all 64 lanes fetch symbols + table rows for the next 64 steps in
+// parallel, the chain itself runs on wave-uniform values, each step parks (state, #bytes) in its lane,
+// and the bytes of the 64 steps are emitted together at wavefront prefix-sum offsets.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(v, d, 64); if (lane >= (uint32_t)d) v += t; }
+  return v;
+}
+__device__ __forceinline__ uint32_t div_magic(uint32_t f) { return f <= 1u ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / f); }
+// exact x / f with magic = floor(2^32/f): the estimate is q or q-1 for any 32-bit x
+__device__ __forceinline__ void divmod_magic(uint32_t x, uint32_t f, uint32_t magic, uint32_t& q, uint32_t& r) {
+  q = __umulhi(x, magic);
+  r = x - q * f;
+  if (r >= f) { ++q; r -= f; }
+}
+__device__ __forceinline__ uint32_t flush_state(uint32_t s, uint8_t* out, uint64_t pos, uint64_t cap, uint32_t& err) {   // rans.rs:48-68
+  uint32_t nb, v;
+  if (s < (1u << 6)) { nb = 1; v = s; }
+  else if (s < (1u << 14)) { nb = 2; v = (1u << 14) + s; }
+  else if (s < (1u << 22)) { nb = 3; v = (2u << 22) + s; }
+  else if (s < (1u << 30)) { nb = 4; v = (3u << 30) + s; }
+  else { err = 1; return 0; }
+  if (pos + nb > cap) { err = 2; return 0; }
+  for (uint32_t k = 0; k < nb; ++k) out[pos + k] = (uint8_t)(v >> (8 * k));
+  return nb;
+}
+
+__device__ void rans_chain(const ChainDesc& d, uint32_t lane) {
+  const uint32_t P = d.precision;
+  const uint64_t n = d.n;
+  uint32_t x = 4u << P;
+  uint64_t pos = 0;
+  uint32_t err = 0;
+  for (uint64_t base = 0; base < n && !err; base += 64) {
+    const uint64_t idx = base + lane;
+    const bool act = idx < n;
+    RansEntry e{1u, 0u, 0xFFFFFFFFu, 0u};
+    if (act) e = d.table[d.sym[n - 1 - idx]];   // symbols are fed in reverse (symbol_coding.rs:161-163)
+    const uint32_t cnt = (uint32_t)min((uint64_t)64, n - base);
+    uint32_t my_x = 0, my_k = 0;
+    for (uint32_t j = 0; j < cnt; ++j) {
+      const uint32_t f = rl(e.freq, j), c = rl(e.cum, j), m = rl(e.magic, j);
+      const uint32_t thr = f << 10;   // ((L >> P) * f) << 8 with L = 4 << P
+      uint32_t xr = x, k = 0;
+      while (xr >= thr) { xr >>= 8; ++k; }
+      if (lane == j) { my_x = x; my_k = k; }
+      uint32_t q, r;
+      divmod_magic(xr, f, m, q, r);
+      x = (q << P) + r + c;
+    }
+    const uint32_t incl = wave_inclusive_scan(my_k, lane);
+    const uint32_t total = rl(incl, 63);
+    if (pos + total > d.cap) { err = 2; break; }
+    const uint64_t at = pos + (incl - my_k);
+    for (uint32_t t = 0; t < my_k; ++t) d.out[at + t] = (uint8_t)(my_x >> (8 * t));
+    pos += total;
+  }
+  if (lane == 0) {
+    if (!err) pos += flush_state(x - (4u << P), d.out, pos, d.cap, err);
+    d.out_len[0] = (uint32_t)pos;
+    d.out_len[1] = err;
+  }
+}
+
+// rABS with precision 8, L = 4096, single-`if` renormalisation (Q21).
+// kind 1: bits[i] ∈ {0,1}, coded in forward order (normal flips, Q9).
+// kind 2: orientation flags {0 none, 1 false, 2 true}; the coded bit of entry j is (o[j] == o[j+1]) with
+//         o[len] = true, fed in forward order (mesh_prediction_for_texture_coordinates.rs:241-256, Q10).
+__device__ void rabs_chain(const ChainDesc& d, uint32_t lane) {
+  const uint32_t p0 = d.p0, f1 = 256u - p0;
+  const uint32_t m0 = div_magic(p0), m1 = div_magic(f1);
+  uint32_t x = 4096u;
+  uint64_t pos = 0;
+  uint32_t err = 0;
+  uint32_t pending = 2;   // kind 2: orientation of the last valid entry still waiting for its successor
+  const uint64_t n = d.n;
+  for (uint64_t base = 0; base <= n && !err; base += 64) {
+    const uint64_t idx = base + lane;
+    uint32_t fl = 0;
+    if (idx < n) fl = d.bits[idx];
+    unsigned long long todo;      // lanes that contribute one coded bit, in lane order
+    uint32_t bitv;                // the bit each such lane codes
+    if (d.kind == 1) {
+      todo = __ballot(idx < n);
+      bitv = fl;
+      if (base >= n) break;
+    } else {
+      const unsigned long long valid = __ballot(fl != 0);
+      const unsigned long long ones = __ballot(fl == 2);
+      const bool tail = base + 64 > n;   // last batch: flush the pending entry against `true`
+      // lane L (valid) codes the bit of the PREVIOUS valid entry: (prev == mine)
+      const unsigned long long below = valid & ((1ull << lane) - 1ull);
+      uint32_t prev;
+      if (below) { const int pl = 63 - __clzll(below); prev = (uint32_t)((ones >> pl) & 1ull); } else prev = pending;
+      const uint32_t mine = (fl == 2);
+      const bool codes = (fl != 0) && (prev != 2);
+      todo = __ballot(codes);
+      bitv = (prev == mine) ? 1u : 0u;
+      if (valid) { const int ll = 63 - __clzll(valid); pending = (uint32_t)((ones >> ll) & 1ull); }
+      if (tail) {
+        // one extra coded bit for the final pending entry, issued by the first lane past the data
+        const uint32_t extra_lane = (uint32_t)(n - base);   // 0..63
+        if (pending != 2 && extra_lane < 64) {
+          if (lane == extra_lane) bitv = (pending == 1u) ? 1u : 0u;
+          todo |= (1ull << extra_lane);
+        } else if (pending != 2) {
+          // cannot happen: tail ⇒ n - base < 64
+        }
+      }
+    }
+    uint32_t my_x = 0, my_k = 0, step = 0;
+    unsigned long long rem = todo;
+    while (rem) {
+      const uint32_t j = (uint32_t)(__ffsll((long long)rem) - 1);
+      rem &= rem - 1;
+      const uint32_t bit = rl(bitv, j);
+      const uint32_t f = bit ? f1 : p0, m = bit ? m1 : m0;
+      uint32_t xr = x, k = 0;
+      if (xr >= ((16u * f) << 8)) { xr >>= 8; k = 1; }
+      if (lane == step) { my_x = x; my_k = k; }
+      ++step;
+      uint32_t q, r;
+      divmod_magic(xr, f, m, q, r);
+      x = (q << 8) + r + (bit ? 0u : f1);
+    }
+    const uint32_t incl = wave_inclusive_scan(my_k, lane);
+    const uint32_t total = rl(incl, 63);
+    if (pos + total > d.cap) { err = 2; break; }
+    if (my_k) d.out[pos + (incl - my_k)] = (uint8_t)my_x;
+    pos += total;
+    if (d.kind == 2 && base + 64 > n) break;
+  }
+  if (lane == 0) {
+    if (!err) pos += flush_state(x - 4096u, d.out, pos, d.cap, err);
+    d.out_len[0] = (uint32_t)pos;
+    d.out_len[1] = err;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_chains(const ChainDesc* __restrict__ descs) {
+  const ChainDesc d = descs[blockIdx.x];
+  if (d.kind == 0) rans_chain(d, threadIdx.x); else rabs_chain(d, threadIdx.x);
+}
+
+inline uint32_t grid_for(uint64_t work, uint32_t cap = 256 * 8) {
+  uint64_t b = (work + kBlock - 1) / kBlock;
+  if (b < 1) b = 1;
+  return (uint32_t)(b > cap ? cap : b);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------------
+void launch_minmax_f32(const float* vals, uint32_t n, int N, float* partials, uint32_t max_blocks, float* meta, hipStream_t s) {
+  uint32_t g = grid_for(n, max_blocks);
+  switch (N) {
+    case 1: hipLaunchKernelGGL(k_minmax_f32<1>, g, kBlock, 0, s, vals, n, partials); hipLaunchKernelGGL(k_minmax_final<1>, 1, kBlock, 0, s, partials, g, meta); break;
+    case 2: hipLaunchKernelGGL(k_minmax_f32<2>, g, kBlock, 0, s, vals, n, partials); hipLaunchKernelGGL(k_minmax_final<2>, 1, kBlock, 0, s, partials, g, meta); break;
+    case 3: hipLaunchKernelGGL(k_minmax_f32<3>, g, kBlock, 0, s, vals, n, partials); hipLaunchKernelGGL(k_minmax_final<3>, 1, kBlock, 0, s, partials, g, meta); break;
+    default: hipLaunchKernelGGL(k_minmax_f32<4>, g, kBlock, 0, s, vals, n, partials); hipLaunchKernelGGL(k_minmax_final<4>, 1, kBlock, 0, s, partials, g, meta); break;
+  }
+}
+
+void launch_quant_coord(const float* vals, uint32_t n, int N, const float* meta, int bits, int32_t* q, hipStream_t s) {
+  const float maxq = (float)(uint64_t)((1ull << bits) - 1ull);
+  const uint64_t nc = (uint64_t)n * N;
+  const uint32_t g = grid_for(nc);
+  switch (N) {
+    case 1: hipLaunchKernelGGL(k_quant_coord<1>, g, kBlock, 0, s, vals, nc, meta, maxq, q); break;
+    case 2: hipLaunchKernelGGL(k_quant_coord<2>, g, kBlock, 0, s, vals, nc, meta, maxq, q); break;
+    case 3: hipLaunchKernelGGL(k_quant_coord<3>, g, kBlock, 0, s, vals, nc, meta, maxq, q); break;
+    default: hipLaunchKernelGGL(k_quant_coord<4>, g, kBlock, 0, s, vals, nc, meta, maxq, q); break;
+  }
+}
+
+void launch_quant_oct(const float* vals, uint32_t n, int32_t* q, uint32_t* zero_flag, hipStream_t s) {
+  hipLaunchKernelGGL(k_quant_oct, grid_for(n), kBlock, 0, s, vals, n, q, zero_flag);
+}
+
+void launch_seq_gather(const uint32_t* seq, uint32_t n, const uint32_t* c2v, const uint32_t* c2p, const uint32_t* p2v, const int32_t* q, int N,
+                       uint32_t* rank, int32_t* qs, int32_t* minmax, hipStream_t s) {
+  const uint32_t g = grid_for(n);
+  switch (N) {
+    case 1: hipLaunchKernelGGL(k_seq_gather<1>, g, kBlock, 0, s, seq, n, c2v, c2p, p2v, q, rank, qs, minmax); break;
+    case 2: hipLaunchKernelGGL(k_seq_gather<2>, g, kBlock, 0, s, seq, n, c2v, c2p, p2v, q, rank, qs, minmax); break;
+    case 3: hipLaunchKernelGGL(k_seq_gather<3>, g, kBlock, 0, s, seq, n, c2v, c2p, p2v, q, rank, qs, minmax); break;
+    default: hipLaunchKernelGGL(k_seq_gather<4>, g, kBlock, 0, s, seq, n, c2v, c2p, p2v, q, rank, qs, minmax); break;
+  }
+}
+
+void launch_pred_parallelogram_wrapped(const uint32_t* seq, uint32_t n, const uint32_t* c2v, const uint32_t* opp, const uint32_t* rank,
+                                       const int32_t* qs, const int32_t* minmax, int N, uint32_t* sym, hipStream_t s) {
+  const uint32_t g = grid_for(n);
+  switch (N) {
+    case 1: hipLaunchKernelGGL(k_pred_parallelogram_wrapped<1>, g, kBlock, 0, s, seq, n, c2v, opp, rank, qs, minmax, sym); break;
+    case 2: hipLaunchKernelGGL(k_pred_parallelogram_wrapped<2>, g, kBlock, 0, s, seq, n, c2v, opp, rank, qs, minmax, sym); break;
+    case 3: hipLaunchKernelGGL(k_pred_parallelogram_wrapped<3>, g, kBlock, 0, s, seq, n, c2v, opp, rank, qs, minmax, sym); break;
+    default: hipLaunchKernelGGL(k_pred_parallelogram_wrapped<4>, g, kBlock, 0, s, seq, n, c2v, opp, rank, qs, minmax, sym); break;
+  }
+}
+
+void launch_pred_delta_difference(uint32_t n, const int32_t* qs, int N, uint32_t* sym, hipStream_t s) {
+  const uint64_t nc = (uint64_t)n * N;
+  hipLaunchKernelGGL(k_pred_delta_difference, grid_for(nc), kBlock, 0, s, nc, N, qs, sym);
+}
+
+void launch_pred_normal_octorth(const uint32_t* seq, uint32_t n, const uint32_t* c2p, const uint32_t* opp_att, const uint32_t* pos_p2v,
+                                const int32_t* q_pos, const int32_t* qs, uint32_t* sym, uint8_t* flips, uint32_t* counters, hipStream_t s) {
+  hipLaunchKernelGGL(k_pred_normal_octorth, grid_for(n), kBlock, 0, s, seq, n, c2p, opp_att, pos_p2v, q_pos, qs, sym, flips, counters);
+}
+
+void launch_pred_texcoord_wrapped(const uint32_t* seq, uint32_t n, const uint32_t* c2v, const uint32_t* c2p, const uint32_t* rank, const int32_t* qs,
+                                  const uint32_t* pos_p2v, const int32_t* q_pos, uint32_t pos_len, const int32_t* minmax, uint32_t* sym,
+                                  uint8_t* orient, hipStream_t s) {
+  hipLaunchKernelGGL(k_pred_texcoord_wrapped, grid_for(n), kBlock, 0, s, seq, n, c2v, c2p, rank, qs, pos_p2v, q_pos, pos_len, minmax, sym, orient);
+}
+
+uint32_t orient_summary_blocks(uint32_t n) { return (n + kOrientChunk - 1) / kOrientChunk; }
+void launch_orient_summary(const uint8_t* orient, uint32_t n, uint32_t* summary, uint32_t*, hipStream_t s) {
+  const uint32_t g = orient_summary_blocks(n);
+  if (g) hipLaunchKernelGGL(k_orient_summary, g, 64, 0, s, orient, n, summary);
+}
+
+void launch_histogram(const uint32_t* sym, uint64_t n_sym, uint32_t* hist, uint32_t bins, uint32_t* overflow_flag, hipStream_t s) {
+  const size_t lds = bins <= kLdsBins ? (size_t)bins * 4 : 0;
+  // few, fat blocks: each block flushes its private histogram once
+  const uint32_t g = grid_for(n_sym, 512);
+  hipLaunchKernelGGL(k_histogram, g, kBlock, lds, s, sym, n_sym, hist, bins, overflow_flag);
+}
+
+void launch_chains(const ChainDesc* descs_dev, uint32_t n_streams, hipStream_t s) {
+  if (n_streams) hipLaunchKernelGGL(k_chains, n_streams, 64, 0, s, descs_dev);
+}
+
+}  // namespace dmi

@@ -1,0 +1,481 @@
+// host_conn.cpp — corner tables, Edgebreaker traversal + connectivity bytes, attribute sequencer.
+// CPU, single thread per mesh, flat arrays.  Output is bit-identical to the reference's
+// (quirks kept: SURVEY.md §8a-Q Q22 half-edge matching, per-vertex "hole" ids).
+#include <algorithm>
+
+#include "dmi_host.hpp"
+
+namespace dmi {
+
+namespace {
+
+struct UniversalBuilder {
+  CornerTables& t;
+  uint32_t C;
+  explicit UniversalBuilder(CornerTables& tt) : t(tt), C(tt.F * 3) {}
+
+  uint32_t swing_left(uint32_t c) const { uint32_t o = t.opp[corner_next(c)]; return o == kNone ? kNone : corner_next(o); }
+  uint32_t swing_right(uint32_t c) const { uint32_t o = t.opp[corner_prev(c)]; return o == kNone ? kNone : corner_prev(o); }
+
+  // Half-edge matching (core/corner_table/mod.rs:252-340).  Each vertex owns a bucket of pending
+  // half-edges (sink vertex, corner) sized by its corner count; a corner looks for the reverse edge
+  // in its sink's bucket.  Quirk Q22: a candidate with the same tip vertex aborts the search.
+  void match_half_edges() {
+    std::vector<uint32_t> count;
+    count.reserve(t.V ? t.V : 16);
+    for (uint32_t c = 0; c < C; ++c) {
+      uint32_t v = t.c2v[c];
+      if (v >= count.size()) count.resize((size_t)v + 1, 0);
+      ++count[v];
+    }
+    const uint32_t nv = (uint32_t)count.size();
+    std::vector<uint32_t> start(nv + 1, 0);
+    for (uint32_t v = 0; v < nv; ++v) start[v + 1] = start[v] + count[v];
+    std::vector<uint32_t> he_sink(C, kNone), he_corner(C, kNone);
+    t.opp.assign(C, kNone);
+    for (uint32_t c = 0; c < C; ++c) {
+      const uint32_t tip = t.c2v[c], src = t.c2v[corner_next(c)], snk = t.c2v[corner_prev(c)];
+      if (c % 3 == 0 && (tip == src || tip == snk || src == snk)) continue;   // :289-295
+      uint32_t found = kNone;
+      const uint32_t lo = start[snk], hi = start[snk + 1];
+      for (uint32_t s = lo; s < hi; ++s) {
+        if (he_sink[s] == kNone) break;
+        if (he_sink[s] != src) continue;
+        if (t.c2v[he_corner[s]] == tip) break;   // Q22: mirrored face → stop searching
+        found = he_corner[s];
+        uint32_t k = s;                           // delete slot s, keep order
+        while (k + 1 < hi && he_sink[k + 1] != kNone) { he_sink[k] = he_sink[k + 1]; he_corner[k] = he_corner[k + 1]; ++k; }
+        he_sink[k] = kNone;
+        break;
+      }
+      if (found == kNone) {
+        for (uint32_t s = start[src]; s < start[src + 1]; ++s)
+          if (he_sink[s] == kNone) { he_sink[s] = snk; he_corner[s] = c; break; }
+      } else {
+        t.opp[c] = found;
+        t.opp[found] = c;
+      }
+    }
+    t.V = nv;
+  }
+
+  // "some undirected edge has more than two faces" (mod.rs:121-145) without the global sort:
+  // group edges by their smaller endpoint (counting sort), then sort each small group.
+  bool has_non_manifold_edge() const {
+    const uint32_t nv = t.V;
+    std::vector<uint32_t> start(nv + 1, 0);
+    for (uint32_t f = 0; f < t.F; ++f)
+      for (int k = 0; k < 3; ++k) {
+        uint32_t a = t.c2v[3 * f + k], b = t.c2v[3 * f + (k + 1) % 3];
+        ++start[std::min(a, b) + 1];
+      }
+    for (uint32_t v = 0; v < nv; ++v) start[v + 1] += start[v];
+    std::vector<uint32_t> other(C), fill(start.begin(), start.end() - 1);
+    for (uint32_t f = 0; f < t.F; ++f)
+      for (int k = 0; k < 3; ++k) {
+        uint32_t a = t.c2v[3 * f + k], b = t.c2v[3 * f + (k + 1) % 3];
+        other[fill[std::min(a, b)]++] = std::max(a, b);
+      }
+    for (uint32_t v = 0; v < nv; ++v) {
+      uint32_t* lo = other.data() + start[v];
+      uint32_t* hi = other.data() + start[v + 1];
+      if (hi - lo < 3) continue;
+      std::sort(lo, hi);
+      for (uint32_t* p = lo + 2; p < hi; ++p) if (p[0] == p[-1] && p[0] == p[-2]) return true;
+    }
+    return false;
+  }
+
+  // Break connectivity at non-manifold edges (mod.rs:149-234, following Draco).
+  void break_non_manifold_edges() {
+    std::vector<uint8_t> seen(C, 0);
+    std::vector<std::pair<uint32_t, uint32_t>> sinks;
+    bool changed;
+    do {
+      changed = false;
+      for (uint32_t c0 = 0; c0 < C; ++c0) {
+        if (seen[c0]) continue;
+        sinks.clear();
+        uint32_t first = c0, cur = c0;
+        for (uint32_t n; (n = swing_left(cur)) != kNone && n != first && !seen[n];) cur = n;
+        first = cur;
+        for (;;) {
+          seen[cur] = 1;
+          const uint32_t sink_c = corner_next(cur), sink_v = t.c2v[sink_c], edge_c = corner_prev(cur);
+          bool updated = false;
+          for (auto& s : sinks) {
+            if (s.first != sink_v) continue;
+            const uint32_t other_edge = s.second, oe = t.opp[edge_c];
+            if (oe != kNone && oe == other_edge) continue;
+            const uint32_t oo = t.opp[other_edge];
+            if (oe != kNone) t.opp[oe] = kNone;
+            if (oo != kNone) t.opp[oo] = kNone;
+            t.opp[edge_c] = kNone;
+            t.opp[other_edge] = kNone;
+            updated = true;
+            break;
+          }
+          if (updated) { changed = true; break; }
+          sinks.emplace_back(t.c2v[corner_prev(cur)], sink_c);
+          const uint32_t r = swing_right(cur);
+          if (r == kNone) break;
+          cur = r;
+          if (cur == first) break;
+        }
+      }
+    } while (changed);
+  }
+
+  // Left-most corners + non-manifold vertex splitting (mod.rs:342-416).
+  void left_most_corners() {
+    t.lmc.assign(t.V, kNone);
+    std::vector<uint8_t> vdone(t.V, 0), cdone(C, 0);
+    for (uint32_t c = 0; c < C; ++c) {
+      if (cdone[c]) continue;
+      uint32_t v = t.c2v[c];
+      const bool split = vdone[v] != 0;
+      if (split) { v = t.V++; t.lmc.push_back(kNone); vdone.push_back(0); }
+      vdone[v] = 1;
+      cdone[c] = 1;
+      t.lmc[v] = c;
+      if (split) t.c2v[c] = v;
+      uint32_t a = swing_left(c);
+      while (a != kNone && a != c) {
+        cdone[a] = 1;
+        t.lmc[v] = a;
+        if (split) t.c2v[a] = v;
+        a = swing_left(a);
+      }
+      if (a == kNone) {
+        for (a = c; a != kNone; a = swing_right(a)) { cdone[a] = 1; if (split) t.c2v[a] = v; }
+      }
+    }
+  }
+};
+
+}  // namespace
+
+int CornerTables::build_universal(const uint32_t* faces, uint32_t num_faces, const uint32_t* pos_p2v, std::string& err) {
+  F = num_faces;
+  const uint32_t C = 3 * F;
+  c2p.assign(faces, faces + C);
+  c2v.resize(C);
+  uint32_t maxv = 0;
+  for (uint32_t c = 0; c < C; ++c) { c2v[c] = pos_p2v ? pos_p2v[faces[c]] : faces[c]; maxv = std::max(maxv, c2v[c]); }
+  V = C ? maxv + 1 : 0;
+  {   // core/corner_table/mod.rs:105-108: unused vertex ids are a panic in the reference
+    std::vector<uint8_t> used(V, 0);
+    for (uint32_t c = 0; c < C; ++c) used[c2v[c]] = 1;
+    for (uint32_t v = 0; v < V; ++v) if (!used[v]) { err = "mesh contains unused vertices"; return DMI_ERR_UNUSED_VERTICES; }
+  }
+  UniversalBuilder b(*this);
+  b.match_half_edges();
+  if (b.has_non_manifold_edge()) b.break_non_manifold_edges();
+  b.left_most_corners();
+  att.clear();
+  return DMI_OK;
+}
+
+// core/corner_table/attribute_corner_table.rs:16-137
+void CornerTables::build_attribute(const uint32_t* p2v) {
+  const uint32_t C = 3 * F;
+  att.emplace_back();
+  AttTable& a = att.back();
+  a.seam_edge.assign(C, 0);
+  std::vector<uint8_t> vseam(V, 0);
+  auto val = [&](uint32_t corner) { uint32_t p = c2p[corner]; return p2v ? p2v[p] : p; };
+  for (uint32_t c = 0; c < C; ++c) {
+    const uint32_t o = opp[c];
+    if (o == kNone) {
+      a.seam_edge[c] = 1;
+      vseam[c2v[corner_next(c)]] = 1;
+      vseam[c2v[corner_prev(c)]] = 1;
+      continue;
+    }
+    if (o < c) continue;
+    // the two shared endpoints: next(c)↔prev(o) and prev(c)↔next(o)
+    if (val(corner_next(c)) != val(corner_prev(o)) || val(corner_prev(c)) != val(corner_next(o))) {
+      a.seam_edge[c] = a.seam_edge[o] = 1;
+      vseam[c2v[corner_next(c)]] = vseam[c2v[corner_prev(c)]] = 1;
+      vseam[c2v[corner_next(o)]] = vseam[c2v[corner_prev(o)]] = 1;
+    }
+  }
+  a.opp.resize(C);
+  for (uint32_t c = 0; c < C; ++c) a.opp[c] = a.seam_edge[c] ? kNone : opp[c];
+  a.c2v.assign(C, 0);
+  a.lmc.clear();
+  a.lmc.reserve(V);
+  uint32_t nv = 0;
+  auto a_swing_left = [&](uint32_t c) { uint32_t o = a.opp[corner_next(c)]; return o == kNone ? kNone : corner_next(o); };
+  auto u_swing_right = [&](uint32_t c) { uint32_t o = opp[corner_prev(c)]; return o == kNone ? kNone : corner_prev(o); };
+  for (uint32_t v = 0; v < V; ++v) {
+    uint32_t first = lmc[v];
+    if (vseam[v]) for (uint32_t n; (n = a_swing_left(first)) != kNone && n != lmc[v];) first = n;   // seam-aware swing to the fan start
+    uint32_t id = nv++;
+    a.c2v[first] = id;
+    a.lmc.push_back(first);
+    for (uint32_t cur = u_swing_right(first); cur != kNone && cur != first; cur = u_swing_right(cur)) {
+      if (a.seam_edge[corner_next(cur)]) { id = nv++; a.lmc.push_back(cur); }
+      a.c2v[cur] = id;
+    }
+  }
+  a.num_vertices = nv;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Edgebreaker (encode/connectivity/edgebreaker.rs), Standard traversal.
+// ------------------------------------------------------------------------------------------------
+namespace {
+enum : uint8_t { SYM_C, SYM_S, SYM_L, SYM_R, SYM_E };
+
+struct Walker {
+  const CornerTables& t;
+  const uint32_t C;
+  std::vector<uint8_t> vvis, fvis, hole_done;
+  std::vector<uint32_t> hole_of;      // per vertex, kNone = interior
+  std::vector<uint32_t> stack, processed, init_corners;
+  std::vector<uint64_t> split_symbol_of_face;   // ~0 = none
+  std::vector<uint8_t> symbols, start_interior;
+  struct Split { uint64_t merging, split; uint8_t right; };
+  std::vector<Split> splits;
+  uint64_t symbol_idx = ~0ull, num_split_symbols = 0;
+  bool bad = false;
+
+  explicit Walker(const CornerTables& tt) : t(tt), C(tt.F * 3) {
+    vvis.assign(t.V, 0);
+    fvis.assign(t.F, 0);
+    split_symbol_of_face.assign(t.F, ~0ull);
+  }
+  uint32_t right_of(uint32_t c) const { return t.opp[corner_next(c)]; }
+  uint32_t left_of(uint32_t c) const { return t.opp[corner_prev(c)]; }
+  uint32_t swing_right(uint32_t c) const { uint32_t o = t.opp[corner_prev(c)]; return o == kNone ? kNone : corner_prev(o); }
+
+  // edgebreaker.rs:195-224 — the inner walk rotates inside one face (never crosses an edge), so
+  // each boundary vertex ends up with its own id.
+  void label_boundaries() {
+    hole_of.assign(t.V, kNone);
+    for (uint32_t c0 = 0; c0 < C; ++c0) {
+      if (t.opp[c0] != kNone) continue;
+      uint32_t v = t.c2v[corner_next(c0)];
+      if (hole_of[v] != kNone) continue;
+      const uint32_t id = (uint32_t)hole_done.size();
+      hole_done.push_back(0);
+      uint32_t c = c0;
+      while (hole_of[v] == kNone) {
+        hole_of[v] = id;
+        c = corner_next(c);
+        while (t.opp[c] != kNone) c = corner_next(c);
+        v = t.c2v[corner_next(c)];
+      }
+    }
+  }
+  // edgebreaker.rs:226-256
+  void mark_boundary(uint32_t start_corner, bool include_first) {
+    uint32_t c = corner_prev(start_corner);
+    while (t.opp[c] != kNone) c = corner_next(t.opp[c]);
+    const uint32_t sv = t.c2v[start_corner];
+    if (include_first) vvis[sv] = 1;
+    if (hole_of[sv] == kNone) { bad = true; return; }
+    hole_done[hole_of[sv]] = 1;
+    for (uint32_t v = t.c2v[corner_prev(c)]; v != sv; v = t.c2v[corner_prev(c)]) {
+      vvis[v] = 1;
+      c = corner_next(c);
+      while (t.opp[c] != kNone) c = corner_next(t.opp[c]);
+    }
+  }
+  void note_split(uint64_t merging, uint8_t right, uint32_t face) {
+    if (split_symbol_of_face[face] != ~0ull) splits.push_back({merging, split_symbol_of_face[face], right});
+  }
+  // edgebreaker.rs:261-350
+  void run_from(uint32_t c) {
+    stack.clear();
+    stack.push_back(c);
+    while (!stack.empty() && !bad) {
+      c = stack.back();
+      if (c == kNone) { bad = true; return; }
+      if (fvis[c / 3]) { stack.pop_back(); continue; }
+      for (uint32_t steps = 0; steps < t.F; ++steps) {
+        if (c == kNone) { bad = true; return; }
+        ++symbol_idx;
+        const uint32_t f = c / 3, v = t.c2v[c];
+        fvis[f] = 1;
+        processed.push_back(c);
+        if (!vvis[v]) {
+          vvis[v] = 1;
+          if (hole_of[v] == kNone) { symbols.push_back(SYM_C); c = right_of(c); continue; }
+        }
+        const uint32_t rc = right_of(c), lc = left_of(c);
+        const bool rv = rc == kNone || fvis[rc / 3], lv = lc == kNone || fvis[lc / 3];
+        if (rv) {
+          if (rc != kNone) note_split(symbol_idx, 1, rc / 3);
+          if (lv) {
+            if (lc != kNone) note_split(symbol_idx, 0, lc / 3);
+            symbols.push_back(SYM_E);
+            stack.pop_back();
+            break;
+          }
+          symbols.push_back(SYM_R);
+          c = lc;
+        } else if (lv) {
+          if (lc != kNone) note_split(symbol_idx, 0, lc / 3);
+          symbols.push_back(SYM_L);
+          c = rc;
+        } else {
+          symbols.push_back(SYM_S);
+          ++num_split_symbols;
+          if (hole_of[v] != kNone && !hole_done[hole_of[v]]) mark_boundary(c, false);
+          split_symbol_of_face[f] = symbol_idx;
+          stack.back() = lc;
+          stack.push_back(rc);
+          break;
+        }
+      }
+    }
+  }
+  // edgebreaker.rs:411-431
+  bool pick_start(uint32_t face, uint32_t& corner) const {
+    uint32_t c = 3 * face;
+    for (int k = 0; k < 3; ++k) {
+      if (t.opp[c] == kNone) { corner = c; return false; }
+      if (hole_of[t.c2v[c]] != kNone) {
+        uint32_t r = c;
+        while (r != kNone) { c = r; r = swing_right(r); }
+        corner = corner_prev(c);
+        return false;
+      }
+      c = corner_next(c);
+    }
+    corner = c;
+    return true;
+  }
+};
+}  // namespace
+
+bool append_tagged_state(uint32_t s, std::vector<uint8_t>& out) {   // rans.rs:48-68
+  if (s < (1u << 6)) out.push_back((uint8_t)s);
+  else if (s < (1u << 14)) { uint32_t v = (1u << 14) + s; out.push_back((uint8_t)v); out.push_back((uint8_t)(v >> 8)); }
+  else if (s < (1u << 22)) { uint32_t v = (2u << 22) + s; out.push_back((uint8_t)v); out.push_back((uint8_t)(v >> 8)); out.push_back((uint8_t)(v >> 16)); }
+  else if (s < (1u << 30)) { uint32_t v = (3u << 30) + s; for (int k = 0; k < 4; ++k) out.push_back((uint8_t)(v >> (8 * k))); }
+  else return false;
+  return true;
+}
+bool RabsHost::finish() { return append_tagged_state(state - 4096, out); }
+
+uint8_t zero_probability(uint64_t count_zero, float denominator) {
+  float p = ((float)count_zero / denominator) * 256.0f + 0.5f;
+  uint32_t q = (p != p || p <= 0.0f) ? 0u : (p >= 65535.0f ? 65535u : (uint32_t)p);   // Rust `as u16`
+  return (uint8_t)std::min(255u, std::max(1u, q));
+}
+
+int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& err) {
+  Walker w(t);
+  ByteSink s;
+  s.u8(0);   // EdgebreakerKind::Standard
+  w.label_boundaries();
+  s.leb128(t.V);
+  s.leb128(t.F);
+  s.u8((uint8_t)t.att.size());
+  for (uint32_t f = 0; f < t.F && !w.bad; ++f) {   // edgebreaker.rs:478-511 (loop over corners ≡ loop over faces)
+    if (w.fvis[f]) continue;
+    uint32_t start;
+    const bool interior = w.pick_start(f, start);
+    w.start_interior.push_back(interior);
+    if (interior) {
+      w.vvis[t.c2v[start]] = w.vvis[t.c2v[corner_next(start)]] = w.vvis[t.c2v[corner_prev(start)]] = 1;
+      w.fvis[f] = 1;
+      w.init_corners.push_back(corner_next(start));
+      w.run_from(t.opp[corner_next(start)]);
+    } else {
+      w.mark_boundary(corner_next(start), true);
+      w.run_from(start);
+    }
+  }
+  if (w.bad) { err = "edgebreaker: inconsistent connectivity (reference unwrap() panic)"; return DMI_ERR_CONNECTIVITY; }
+  s.leb128(w.symbols.size());
+  s.leb128(w.num_split_symbols);
+  {   // encode_topology_splits :375-403
+    s.leb128(w.splits.size());
+    uint64_t last = 0;
+    for (auto& sp : w.splits) { s.leb128(sp.merging - last); s.leb128(sp.merging - sp.split); last = sp.merging; }
+    BitPackerLsb bp(s.b);
+    for (auto& sp : w.splits) bp.put(1, sp.right);
+    bp.flush();
+  }
+  {   // DefaultTraversal::encode :575-656 — CLERS bits, reversed, LSB-first
+    static const uint8_t len[5] = {1, 3, 3, 3, 3};
+    static const uint8_t code[5] = {0, 0b1, 0b11, 0b101, 0b111};
+    std::vector<uint8_t> bits;
+    bits.reserve(w.symbols.size() / 2 + 8);
+    BitPackerLsb bp(bits);
+    for (size_t i = w.symbols.size(); i-- > 0;) bp.put(len[w.symbols[i]], code[w.symbols[i]]);
+    bp.flush();
+    s.leb128(bits.size());
+    s.bytes(bits);
+  }
+  auto rabs_block = [&](const std::vector<uint8_t>& flags) -> bool {   // zero_prob, then bits reversed
+    uint64_t zeros = 0;
+    for (uint8_t b : flags) zeros += !b;
+    const uint8_t zp = zero_probability(zeros, (float)flags.size());
+    s.u8(zp);
+    RabsHost rc(zp);
+    for (size_t i = flags.size(); i-- > 0;) rc.put(flags[i]);
+    if (!rc.finish()) return false;
+    s.leb128(rc.out.size());
+    s.bytes(rc.out);
+    return true;
+  };
+  if (!rabs_block(w.start_interior)) { err = "rABS state too large"; return DMI_ERR_ENTROPY; }
+  {   // attribute seams :611-653
+    std::vector<uint8_t> fv(t.F, 0);
+    std::vector<std::vector<uint8_t>> seams(t.att.size());
+    for (auto& v : seams) v.reserve(t.F * 3 / 2);
+    for (size_t i = w.processed.size(); i-- > 0;) {
+      const uint32_t c = w.processed[i];
+      const uint32_t cs[3] = {c, corner_next(c), corner_prev(c)};
+      fv[c / 3] = 1;
+      for (uint32_t cc : cs) {
+        const uint32_t o = t.opp[cc];
+        if (o == kNone || fv[o / 3]) continue;
+        for (size_t j = 0; j < t.att.size(); ++j) seams[j].push_back(t.att[j].seam_edge[cc]);
+      }
+    }
+    for (auto& sd : seams) if (!rabs_block(sd)) { err = "rABS state too large"; return DMI_ERR_ENTROPY; }
+  }
+  out.seeds.assign(w.init_corners.rbegin(), w.init_corners.rend());
+  out.seeds.insert(out.seeds.end(), w.processed.begin(), w.processed.end());
+  out.connectivity.swap(s.b);
+  return DMI_OK;
+}
+
+// Attribute sequencer (shared/attribute/sequence.rs:48-151) as a plain O(F) depth-first walk.
+// The reference also deletes every stack entry lying in the face it has just marked visited;
+// such entries are skipped on pop anyway, so the emitted order is unchanged without the deletion.
+void attribute_sequence(const TableRef& t, const uint32_t* seeds, uint32_t n_seeds, std::vector<uint32_t>& seq) {
+  std::vector<uint8_t> vvis(t.V, 0), fvis(t.F, 0);
+  std::vector<uint32_t> stack(seeds, seeds + n_seeds);
+  seq.clear();
+  seq.reserve(t.V);
+  auto emit = [&](uint32_t c) { uint32_t v = t.c2v[c]; if (!vvis[v]) { vvis[v] = 1; seq.push_back(c); } };
+  while (!stack.empty()) {
+    const uint32_t c = stack.back();
+    stack.pop_back();
+    if (fvis[c / 3]) continue;
+    const uint32_t nc = corner_next(c), pc = corner_prev(c);
+    if (!vvis[t.c2v[nc]] || !vvis[t.c2v[pc]]) { emit(nc); emit(pc); stack.push_back(c); continue; }
+    fvis[c / 3] = 1;
+    const uint32_t v = t.c2v[c];
+    const uint32_t right = t.opp[nc], left = t.opp[pc];
+    if (!vvis[v]) {
+      emit(c);
+      const uint32_t l0 = t.lmc[v];
+      const bool boundary = t.opp[corner_next(l0)] == kNone;   // is_on_boundary: swing_left(lmc) is None
+      if (!boundary) { if (right != kNone) stack.push_back(right); continue; }
+    }
+    const bool rdone = right != kNone && fvis[right / 3], ldone = left != kNone && fvis[left / 3];
+    if (rdone) { if (!ldone && left != kNone) stack.push_back(left); }
+    else if (ldone) { if (right != kNone) stack.push_back(right); }
+    else { if (left != kNone) stack.push_back(left); if (right != kNone) stack.push_back(right); }
+  }
+}
+
+}  // namespace dmi

@@ -1,0 +1,62 @@
+"""Deterministic synthetic meshes for tests and bench.py: a closed torus-topology
+grid of n×n quads split into 2 triangles (F = 2n², V = n², valence 6, no boundary, no seams).
+Plain numpy workload plumbing — no encoder arithmetic."""
+import numpy as np
+
+from .binding import ATT_NORMAL, ATT_POSITION, ATT_TEXCOORD, DOMAIN_CORNER, DOMAIN_POSITION, Attribute, Mesh
+
+SEED = 0xD7AC0
+
+
+def grid_size_for_triangles(f):
+    return int(np.sqrt(f / 2.0))
+
+
+def torus_grid(n, seed=SEED, normals=True, uvs=True, open_boundary=False):
+    """Returns (faces [F,3] uint32, pos [V,3] f32, nrm [V,3] f32 or None, uv [V,2] f32 or None)."""
+    rng = np.random.default_rng(seed)
+    iu, iv = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    u = (iu.ravel() / n).astype(np.float64)
+    v = (iv.ravel() / n).astype(np.float64)
+    R, r = 1.0, 0.35
+    cu, su, cv, sv = np.cos(2 * np.pi * u), np.sin(2 * np.pi * u), np.cos(2 * np.pi * v), np.sin(2 * np.pi * v)
+    pos = np.stack([(R + r * cv) * cu, (R + r * cv) * su, r * sv], axis=1)
+    pos += rng.uniform(-1e-3, 1e-3, size=pos.shape)
+    pos = pos.astype(np.float32)
+    nrm = None
+    if normals:
+        # analytic torus normal + a little noise (so that no two vertices share a normal), unit length
+        nr = np.stack([cv * cu, cv * su, sv], axis=1) + rng.uniform(-1e-3, 1e-3, size=(n * n, 3))
+        nrm = (nr / np.linalg.norm(nr, axis=1, keepdims=True)).astype(np.float32)
+    uv = None
+    if uvs:
+        uv = np.stack([u, v], axis=1) + rng.uniform(-1e-4, 1e-4, size=(n * n, 2))
+        uv = np.clip(uv, 0.0, 1.0).astype(np.float32)
+    m = n - 1 if open_boundary else n
+    a, b = np.meshgrid(np.arange(m), np.arange(m), indexing="ij")
+    a, b = a.ravel(), b.ravel()
+    a1, b1 = (a + 1) % n, (b + 1) % n
+    i00, i10, i01, i11 = a * n + b, a1 * n + b, a * n + b1, a1 * n + b1
+    faces = np.empty((2 * m * m, 3), np.uint32)
+    faces[0::2] = np.stack([i00, i10, i11], axis=1)
+    faces[1::2] = np.stack([i00, i11, i01], axis=1)
+    return faces, pos, nrm, uv
+
+
+def torus_mesh(n, seed=SEED, normals=True, uvs=True, open_boundary=False):
+    """A `Mesh` whose attributes are already in MeshBuilder's output form.  Values are checked to be
+    pairwise distinct so that Attribute::from's dedup (core/attribute/mod.rs:394-452) is the identity."""
+    faces, pos, nrm, uv = torus_grid(n, seed, normals, uvs, open_boundary)
+    for name, arr in (("pos", pos), ("nrm", nrm), ("uv", uv)):
+        if arr is None:
+            continue
+        a = arr + np.float32(0.0)
+        rows = np.ascontiguousarray(a).view(np.dtype((np.void, a.dtype.itemsize * a.shape[1]))).ravel()
+        if len(np.unique(rows)) != len(rows):
+            raise ValueError(f"synthetic {name} values are not unique; use MeshBuilder to deduplicate")
+    atts = [Attribute(pos, ATT_POSITION, DOMAIN_POSITION, unique_id=0)]
+    if nrm is not None:
+        atts.append(Attribute(nrm, ATT_NORMAL, DOMAIN_CORNER, unique_id=len(atts), parent_index=0))
+    if uv is not None:
+        atts.append(Attribute(uv, ATT_TEXCOORD, DOMAIN_CORNER, unique_id=len(atts), parent_index=0))
+    return Mesh(faces, atts)

