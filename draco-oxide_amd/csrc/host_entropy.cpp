@@ -52,6 +52,10 @@ int FreqTable::build(const uint32_t* hist, size_t bins, std::string& err) {
       }
     }
   }
+  // The reference's over-correction can drive an occurring symbol to frequency 0; its coder then never
+  // terminates (`while state >= 0`, rans.rs:40) — there is no reference output for such a histogram.
+  for (size_t s = 0; s < num_symbols; ++s)
+    if (hist[s] && !freq[s]) { err = "normalised frequency of an occurring symbol is zero (the reference encoder does not terminate on this input)"; return DMI_ERR_ENTROPY; }
   cum.resize(num_symbols);
   uint32_t c = 0;
   for (size_t s = 0; s < num_symbols; ++s) { cum[s] = c; c += freq[s]; }

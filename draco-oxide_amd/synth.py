@@ -30,7 +30,13 @@ def torus_grid(n, seed=SEED, normals=True, uvs=True, open_boundary=False):
         nrm = (nr / np.linalg.norm(nr, axis=1, keepdims=True)).astype(np.float32)
     uv = None
     if uvs:
-        uv = np.stack([u, v], axis=1) + rng.uniform(-1e-4, 1e-4, size=(n * n, 2))
+        # periodic chart (no jump where the torus closes) + noise.  A plain (u, v) chart puts a 0↔1
+        # discontinuity along the closing edges; at 10M triangles its long tail of rare residual symbols
+        # drives the reference's frequency normalisation (encode/entropy/rans.rs:172-190) to assign a
+        # zero frequency to occurring symbols, after which RansCoder::write never terminates — such a
+        # mesh has no reference output to be bit-exact against.
+        uv = np.stack([0.5 + 0.49 * np.cos(2 * np.pi * u), 0.5 + 0.49 * np.cos(2 * np.pi * v)], axis=1)
+        uv = uv + rng.uniform(-1e-4, 1e-4, size=(n * n, 2))
         uv = np.clip(uv, 0.0, 1.0).astype(np.float32)
     m = n - 1 if open_boundary else n
     a, b = np.meshgrid(np.arange(m), np.arange(m), indexing="ij")

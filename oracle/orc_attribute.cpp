@@ -9,6 +9,8 @@
 // (wrapping), casts follow Rust `as` (float→int saturating, NaN→0) — quirk Q18.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <limits>
 
 #include "oracle.hpp"
@@ -16,6 +18,8 @@
 namespace orc {
 
 namespace {
+
+inline void trace(const char* what, size_t a = 0) { static const bool on = std::getenv("ORC_TRACE") != nullptr; if (on) std::fprintf(stderr, "[orc] %s %zu\n", what, a); }
 
 inline i32 wadd(i32 a, i32 b) { return (i32)((u32)a + (u32)b); }
 inline i32 wsub(i32 a, i32 b) { return (i32)((u32)a - (u32)b); }
@@ -342,7 +346,9 @@ std::string encode_attributes(const std::vector<Attribute>& atts, const ConnOutp
     TableView tv;
     tv.ct = &conn.ct;
     tv.at = (i > 0 && i - 1 < conn.att_tables.size()) ? &conn.att_tables[i - 1] : nullptr;
+    trace("attribute", i);
     std::vector<u32> seq = compute_sequence(tv, conn.corners_of_edgebreaker, opt.faithful);
+    trace("sequence", seq.size());
 
     // Portabilization::new + portabilize, :283-299
     Bytes port_info;
@@ -420,6 +426,7 @@ std::string encode_attributes(const std::vector<Attribute>& atts, const ConnOutp
       for (size_t k = 0; k < seq.size(); ++k) cx.rank[tv.vertex_idx(seq[k])] = (u32)k;
       // `rank[v] < i` ⇔ vertices_up_till_now.contains(v): every vertex is emitted once (sequence.rs:41-46)
     }
+    trace("portabilized", pa.vals.size());
     std::vector<i32> origs(seq.size() * N), preds(seq.size() * N);
     std::vector<u8> flips, orientation;
     for (size_t k = 0; k < seq.size(); ++k) {   // :332-338
@@ -435,6 +442,7 @@ std::string encode_attributes(const std::vector<Attribute>& atts, const ConnOutp
       const i32* o = pa.get(tv.point_idx(c));
       for (int j = 0; j < N; ++j) origs[k * N + j] = o[j];
     }
+    trace("predicted", flips.size() + orientation.size());
     // transform: map_with_tentative_metadata + squeeze
     Bytes transform_info;
     std::vector<u32> symbols(seq.size() * N);
@@ -469,7 +477,9 @@ std::string encode_attributes(const std::vector<Attribute>& atts, const ConnOutp
     // symbols are cast `as u64` from i32 (:347-350): a negative i32 would sign-extend to a huge
     // index; the transforms above only produce non-negatives for sane inputs.
     for (u32 s : symbols) if ((i32)s < 0) return "negative symbol (reference would index out of bounds)";
+    { u32 mxs = 0; for (u32 s2 : symbols) if (s2 > mxs) mxs = s2; trace("max symbol", mxs); }
     std::string e = encode_symbols_direct(symbols, w);
+    trace("symbols coded", w.size());
     if (!e.empty()) return e;
 
     auto write_rabs_block = [&](u8 zero_prob, const std::vector<u8>& bits) -> std::string {
@@ -531,8 +541,10 @@ std::string encode_mesh(const Mesh& mesh, const Options& opt, Bytes& w, Blobs* d
   w.w16(0);     // flags (metadata off)
   const size_t conn_begin = w.size();
   ConnOutput conn;
+  trace("connectivity begin");
   std::string e = encode_connectivity(mesh, w, conn);
   if (!e.empty()) return e;
+  trace("connectivity bytes", w.size());
   const size_t att_begin = w.size();
   e = encode_attributes(mesh.atts, conn, opt, w, dump);
   if (!e.empty()) return e;

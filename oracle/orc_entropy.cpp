@@ -2,6 +2,8 @@
 // Restatement of encode/entropy/{rans,symbol_coding}.rs and shared/entropy/mod.rs, plus the inverse
 // (decode/entropy/rans.rs) used only for round-trip self-checks.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <numeric>
 
 #include "oracle.hpp"
@@ -26,6 +28,7 @@ std::string RansCoder::init(const std::vector<u64>& dist, u32 precision_bits) {
 std::string RansCoder::write(u64 idx) {
   if (idx >= freq.size()) return "InvalidSymbolIndex";
   u64 f = freq[idx];
+  if (f == 0) return "symbol with zero normalised frequency (the reference loops forever / divides by zero here, rans.rs:40-44)";
   // Rust precedence: `*` before `<<`:  ((l_base >> P) * f) << 8
   while (state >= (((l_base >> precision) * f) << 8)) {
     out.w8((u8)(state & 0xFF));
@@ -93,6 +96,7 @@ static std::string normalise_and_write_table(const std::vector<u64>& freq_counts
     distribution[i] = new_freq;
     total_rans_prob += new_freq;
   }
+  if (std::getenv("ORC_TRACE")) std::fprintf(stderr, "[orc] normalise: num_symbols %zu total %llu target %llu total_freq %.1f\n", num_symbols, (unsigned long long)total_rans_prob, (unsigned long long)rans_precision, total_freq);
   if (total_rans_prob != rans_precision) {
     std::vector<size_t> sorted(num_symbols);
     std::iota(sorted.begin(), sorted.end(), 0);
