@@ -238,6 +238,9 @@ using Blobs = std::map<std::string, std::vector<u8>>;   // named debug dumps for
 std::string encode_attributes(const std::vector<Attribute>& atts, const ConnOutput& conn, const Options& opt, Bytes& w, Blobs* dump);  // encode/attribute/mod.rs:13-93
 std::string encode_mesh(const Mesh& mesh, const Options& opt, Bytes& w, Blobs* dump);   // encode/mod.rs:59-97
 
+// wall-clock seconds of the last encode_mesh: [0] connectivity, [1] attribute section, [2] sequencer part of [1]
+extern double g_stage_seconds[3];
+
 // helpers shared by .cpp files
 i32 to_positive_i32(i32 v);   // utils/mod.rs:152-158
 template <class T> inline void blob_put(Blobs* b, const std::string& k, const std::vector<T>& v) {

@@ -8,6 +8,7 @@
 // -ffp-contract=off (see Makefile).  Integer arithmetic follows Rust release-mode semantics
 // (wrapping), casts follow Rust `as` (float→int saturating, NaN→0) — quirk Q18.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -298,6 +299,8 @@ PortType port_type_for(AttType t) { return t == Normal ? PortOct : (t == Custom 
 
 }  // namespace
 
+double g_stage_seconds[3] = {0, 0, 0};   // connectivity, attributes (total), of which sequencer
+
 // encode/attribute/mod.rs:13-93
 std::string encode_attributes(const std::vector<Attribute>& atts, const ConnOutput& conn, const Options& opt, Bytes& w, Blobs* dump) {
   w.w8((u8)atts.size());                                         // :26
@@ -347,7 +350,9 @@ std::string encode_attributes(const std::vector<Attribute>& atts, const ConnOutp
     tv.ct = &conn.ct;
     tv.at = (i > 0 && i - 1 < conn.att_tables.size()) ? &conn.att_tables[i - 1] : nullptr;
     trace("attribute", i);
+    const auto tseq0 = std::chrono::steady_clock::now();
     std::vector<u32> seq = compute_sequence(tv, conn.corners_of_edgebreaker, opt.faithful);
+    g_stage_seconds[2] += std::chrono::duration<double>(std::chrono::steady_clock::now() - tseq0).count();
     trace("sequence", seq.size());
 
     // Portabilization::new + portabilize, :283-299
@@ -542,12 +547,17 @@ std::string encode_mesh(const Mesh& mesh, const Options& opt, Bytes& w, Blobs* d
   const size_t conn_begin = w.size();
   ConnOutput conn;
   trace("connectivity begin");
+  g_stage_seconds[0] = g_stage_seconds[1] = g_stage_seconds[2] = 0.0;
+  const auto t0 = std::chrono::steady_clock::now();
   std::string e = encode_connectivity(mesh, w, conn);
   if (!e.empty()) return e;
+  const auto t1 = std::chrono::steady_clock::now();
+  g_stage_seconds[0] = std::chrono::duration<double>(t1 - t0).count();
   trace("connectivity bytes", w.size());
   const size_t att_begin = w.size();
   e = encode_attributes(mesh.atts, conn, opt, w, dump);
   if (!e.empty()) return e;
+  g_stage_seconds[1] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
   if (dump) {
     (*dump)["conn.bytes"] = std::vector<u8>(w.begin() + conn_begin, w.begin() + att_begin);
     (*dump)["atts.bytes"] = std::vector<u8>(w.begin() + att_begin, w.end());

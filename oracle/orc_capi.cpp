@@ -90,6 +90,7 @@ int orc_encode(void* sp, const int* opts, int want_dump) {
   s->last_encode_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return g_err.empty() ? 0 : 1;
 }
+void orc_last_stage_seconds(double* out) { out[0] = g_stage_seconds[0]; out[1] = g_stage_seconds[1]; out[2] = g_stage_seconds[2]; }
 double orc_last_encode_seconds(void* sp) { return static_cast<Session*>(sp)->last_encode_seconds; }
 const uint8_t* orc_drc(void* sp, uint64_t* len) { auto* s = static_cast<Session*>(sp); *len = s->drc.size(); return s->drc.data(); }
 const uint8_t* orc_blob(void* sp, const char* key, uint64_t* len) {

@@ -58,6 +58,7 @@ def lib():
     L.orc_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.orc_last_encode_seconds.argtypes = [C.c_void_p]
     L.orc_last_encode_seconds.restype = C.c_double
+    L.orc_last_stage_seconds.argtypes = [C.c_void_p]
     L.orc_drc.argtypes = [C.c_void_p, C.c_void_p]
     L.orc_drc.restype = C.c_void_p
     L.orc_blob.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
@@ -173,6 +174,12 @@ class Session:
 
     def encode_seconds(self):
         return float(self.L.orc_last_encode_seconds(self.h))
+
+    def stage_seconds(self):
+        """(connectivity, attribute section, sequencer part of the attribute section) of the last encode."""
+        out = np.zeros(3, np.float64)
+        self.L.orc_last_stage_seconds(_ptr(out))
+        return tuple(float(x) for x in out)
 
     def blob(self, key, dtype=np.uint8):
         n = C.c_uint64(0)
