@@ -38,13 +38,17 @@ uint32_t orient_summary_blocks(uint32_t n);
 void launch_histogram(const uint32_t* sym, uint64_t n_sym, uint32_t* hist, uint32_t bins, uint32_t* overflow_flag, hipStream_t s);
 
 // ---- serial coders: one wavefront per stream (a18, a19, a11, a13) ------------------------------------
-struct RansEntry { uint32_t freq, cum, magic, pad; };   // magic = floor(2^32 / freq) (0xFFFFFFFF for freq 1)
+// Coding record of one symbol (see dmi_chains.hip): x / f = mulhi(x, m) >> (b & 31); bit 8 of b flags f == 1;
+// d = 2^P - f; c = cumulative frequency.
+struct RansEntry { uint32_t m, b, d, c; };
+RansEntry make_rans_entry(uint32_t freq, uint32_t cum, uint32_t precision);   // host helper
+void launch_rans_prep(const uint32_t* sym, uint64_t n, const RansEntry* table, RansEntry* rec, hipStream_t s);
 struct ChainDesc {
-  uint32_t kind;            // 0 = rANS over symbols (reverse order), 1 = rABS over flips (forward), 2 = rABS over orientation flags
+  uint32_t kind;            // 0 = rANS over coding records, 1 = rABS over flips (forward), 2 = rABS over orientation flags
   uint32_t precision;       // rANS precision bits
   uint64_t n;               // symbols / entries
-  const uint32_t* sym;      // kind 0
-  const RansEntry* table;   // kind 0
+  const uint32_t* sym;      // unused by the kernel (kept for debugging)
+  const RansEntry* table;   // kind 0: n coding records in coding order (k_rans_prep output)
   const uint8_t* bits;      // kind 1/2
   uint32_t p0;              // kind 1/2: zero probability
   uint32_t pad;

@@ -62,7 +62,7 @@ struct AttJob {
   int nq = 0;            // components after portabilization
   int table = 0;         // index into tables
   int parent = -1;
-  DevMem raw, p2v, q, rank, qs, sym, aux /*flips or orient*/, hist, rtable, out, meta, partials, small /*minmax[2], counters[2], flags[2], out_len[2]*2*/, summary;
+  DevMem raw, p2v, q, rank, qs, sym, aux /*flips or orient*/, hist, rtable, rec, out, meta, partials, small /*minmax[2], counters[2], flags[2], out_len[2]*2*/, summary;
   uint32_t bins = 0;
   uint64_t n_sym = 0;
   uint64_t out_cap = 0, aux_cap = 0;
@@ -153,6 +153,25 @@ int validate_and_plan(const dmi_attribute* atts, uint32_t n_atts, const dmi_conf
   }
   return DMI_OK;
 }
+
+}  // namespace
+
+namespace dmi {
+// Coding record of a symbol with normalised frequency f (see dmi_chains.hip for the exactness argument).
+RansEntry make_rans_entry(uint32_t f, uint32_t cum, uint32_t precision) {
+  RansEntry e{0u, 0u, 0u, cum};
+  if (f == 0) return e;                       // never coded
+  e.d = (1u << precision) - f;
+  if (f == 1) { e.m = 0xFFFFFFFFu; e.b = 0x100u; return e; }   // flagged: the batch takes the generic loop
+  unsigned lg = 31u - (unsigned)__builtin_clz(f);
+  if ((f & (f - 1)) == 0) { e.m = 0x80000000u; e.b = lg - 1; return e; }
+  e.m = (uint32_t)((((uint64_t)1 << (32 + lg)) + f - 1) / f);
+  e.b = lg;
+  return e;
+}
+}  // namespace dmi
+
+namespace {
 
 uint32_t symbol_bins(const AttJob& a) {
   // upper bound of (largest symbol + 1) from the quantizer's range:
@@ -299,6 +318,7 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
     if (a.port == kToBits) a.bins = 1u << 20;   // capacity; the real bound is checked after the min/max readback
     if ((rc = a.hist.alloc((size_t)a.bins * 4))) return rc;
     if ((rc = a.rtable.alloc((size_t)a.bins * sizeof(RansEntry)))) return rc;
+    if ((rc = a.rec.alloc((size_t)a.n_sym * sizeof(RansEntry)))) return rc;
     a.out_cap = a.n_sym * 3 + 16;   // ≤ 3 renormalisation bytes per symbol (P ≤ 20) + flush
     if ((rc = a.out.alloc(a.out_cap))) return rc;
     if ((rc = a.meta.alloc(64))) return rc;
@@ -442,14 +462,13 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
     int rc = a.ft.build(hist, a.bins, err);
     if (rc) return fail(rc, err);
     std::vector<RansEntry> rt(a.ft.freq.size());
-    for (size_t k = 0; k < rt.size(); ++k) {
-      const uint32_t f = a.ft.freq[k];
-      rt[k] = RansEntry{f ? f : 1u, a.ft.cum[k], f <= 1u ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / f), 0u};
-    }
+    for (size_t k = 0; k < rt.size(); ++k) rt[k] = make_rans_entry(a.ft.freq[k], a.ft.cum[k], a.ft.precision);
     HIP_TRY(hipMemcpyAsync(a.rtable.p, rt.data(), rt.size() * sizeof(RansEntry), hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));   // rt is a stack-scoped staging vector
+    // symbols → coding records in coding order (data-parallel), consumed by the scalar chain
+    launch_rans_prep(a.sym.as<uint32_t>(), a.n_sym, a.rtable.as<RansEntry>(), a.rec.as<RansEntry>(), s);
     ChainDesc d{};
-    d.kind = 0; d.precision = a.ft.precision; d.n = a.n_sym; d.sym = a.sym.as<uint32_t>(); d.table = a.rtable.as<RansEntry>();
+    d.kind = 0; d.precision = a.ft.precision; d.n = a.n_sym; d.sym = a.sym.as<uint32_t>(); d.table = a.rec.as<RansEntry>();
     d.out = a.out.as<uint8_t>(); d.cap = a.out_cap; d.out_len = a.small.as<uint32_t>() + 8;
     rans_desc[i] = (int)descs.size();
     descs.push_back(d);

@@ -12,7 +12,7 @@
 //   k_pred_normal_octorth              .../mesh_normal_prediction.rs:22-44,75-144 + prediction_transform/oct_orthogonal.rs:23-85
 //   k_pred_texcoord_wrapped            .../mesh_prediction_for_texture_coordinates.rs:32-81,107-219 + wrapped_difference.rs
 //   k_histogram                        encode/entropy/symbol_coding.rs:149-157
-//   k_chains                           encode/entropy/rans.rs:33-68 (rANS), :91-128 (rABS)
+//   (the serial rANS/rABS coders live in dmi_chains.hip)
 #include "dmi_device.hpp"
 
 namespace dmi {
@@ -490,154 +490,6 @@ __global__ __launch_bounds__(kBlock) void k_histogram(const uint32_t* __restrict
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Serial coders.  The rANS / rABS state recurrence is one dependency chain per stream, so
-// a stream is owned by ONE wavefront: all 64 lanes fetch symbols + table rows for the next 64 steps in
-// parallel, the chain itself runs on wave-uniform values, each step parks (state, #bytes) in its lane,
-// and the bytes of the 64 steps are emitted together at wavefront prefix-sum offsets.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(v, d, 64); if (lane >= (uint32_t)d) v += t; }
-  return v;
-}
-__device__ __forceinline__ uint32_t div_magic(uint32_t f) { return f <= 1u ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / f); }
-// exact x / f with magic = floor(2^32/f): the estimate is q or q-1 for any 32-bit x
-__device__ __forceinline__ void divmod_magic(uint32_t x, uint32_t f, uint32_t magic, uint32_t& q, uint32_t& r) {
-  q = __umulhi(x, magic);
-  r = x - q * f;
-  if (r >= f) { ++q; r -= f; }
-}
-__device__ __forceinline__ uint32_t flush_state(uint32_t s, uint8_t* out, uint64_t pos, uint64_t cap, uint32_t& err) {   // rans.rs:48-68
-  uint32_t nb, v;
-  if (s < (1u << 6)) { nb = 1; v = s; }
-  else if (s < (1u << 14)) { nb = 2; v = (1u << 14) + s; }
-  else if (s < (1u << 22)) { nb = 3; v = (2u << 22) + s; }
-  else if (s < (1u << 30)) { nb = 4; v = (3u << 30) + s; }
-  else { err = 1; return 0; }
-  if (pos + nb > cap) { err = 2; return 0; }
-  for (uint32_t k = 0; k < nb; ++k) out[pos + k] = (uint8_t)(v >> (8 * k));
-  return nb;
-}
-
-__device__ void rans_chain(const ChainDesc& d, uint32_t lane) {
-  const uint32_t P = d.precision;
-  const uint64_t n = d.n;
-  uint32_t x = 4u << P;
-  uint64_t pos = 0;
-  uint32_t err = 0;
-  for (uint64_t base = 0; base < n && !err; base += 64) {
-    const uint64_t idx = base + lane;
-    const bool act = idx < n;
-    RansEntry e{1u, 0u, 0xFFFFFFFFu, 0u};
-    if (act) e = d.table[d.sym[n - 1 - idx]];   // symbols are fed in reverse (symbol_coding.rs:161-163)
-    const uint32_t cnt = (uint32_t)min((uint64_t)64, n - base);
-    uint32_t my_x = 0, my_k = 0;
-    for (uint32_t j = 0; j < cnt; ++j) {
-      const uint32_t f = rl(e.freq, j), c = rl(e.cum, j), m = rl(e.magic, j);
-      const uint32_t thr = f << 10;   // ((L >> P) * f) << 8 with L = 4 << P
-      uint32_t xr = x, k = 0;
-      while (xr >= thr) { xr >>= 8; ++k; }
-      if (lane == j) { my_x = x; my_k = k; }
-      uint32_t q, r;
-      divmod_magic(xr, f, m, q, r);
-      x = (q << P) + r + c;
-    }
-    const uint32_t incl = wave_inclusive_scan(my_k, lane);
-    const uint32_t total = rl(incl, 63);
-    if (pos + total > d.cap) { err = 2; break; }
-    const uint64_t at = pos + (incl - my_k);
-    for (uint32_t t = 0; t < my_k; ++t) d.out[at + t] = (uint8_t)(my_x >> (8 * t));
-    pos += total;
-  }
-  if (lane == 0) {
-    if (!err) pos += flush_state(x - (4u << P), d.out, pos, d.cap, err);
-    d.out_len[0] = (uint32_t)pos;
-    d.out_len[1] = err;
-  }
-}
-
-// rABS with precision 8, L = 4096, single-`if` renormalisation (Q21).
-// kind 1: bits[i] ∈ {0,1}, coded in forward order (normal flips, Q9).
-// kind 2: orientation flags {0 none, 1 false, 2 true}; the coded bit of entry j is (o[j] == o[j+1]) with
-//         o[len] = true, fed in forward order (mesh_prediction_for_texture_coordinates.rs:241-256, Q10).
-__device__ void rabs_chain(const ChainDesc& d, uint32_t lane) {
-  const uint32_t p0 = d.p0, f1 = 256u - p0;
-  const uint32_t m0 = div_magic(p0), m1 = div_magic(f1);
-  uint32_t x = 4096u;
-  uint64_t pos = 0;
-  uint32_t err = 0;
-  uint32_t pending = 2;   // kind 2: orientation of the last valid entry still waiting for its successor
-  const uint64_t n = d.n;
-  for (uint64_t base = 0; base <= n && !err; base += 64) {
-    const uint64_t idx = base + lane;
-    uint32_t fl = 0;
-    if (idx < n) fl = d.bits[idx];
-    unsigned long long todo;      // lanes that contribute one coded bit, in lane order
-    uint32_t bitv;                // the bit each such lane codes
-    if (d.kind == 1) {
-      todo = __ballot(idx < n);
-      bitv = fl;
-      if (base >= n) break;
-    } else {
-      const unsigned long long valid = __ballot(fl != 0);
-      const unsigned long long ones = __ballot(fl == 2);
-      const bool tail = base + 64 > n;   // last batch: flush the pending entry against `true`
-      // lane L (valid) codes the bit of the PREVIOUS valid entry: (prev == mine)
-      const unsigned long long below = valid & ((1ull << lane) - 1ull);
-      uint32_t prev;
-      if (below) { const int pl = 63 - __clzll(below); prev = (uint32_t)((ones >> pl) & 1ull); } else prev = pending;
-      const uint32_t mine = (fl == 2);
-      const bool codes = (fl != 0) && (prev != 2);
-      todo = __ballot(codes);
-      bitv = (prev == mine) ? 1u : 0u;
-      if (valid) { const int ll = 63 - __clzll(valid); pending = (uint32_t)((ones >> ll) & 1ull); }
-      if (tail) {
-        // one extra coded bit for the final pending entry, issued by the first lane past the data
-        const uint32_t extra_lane = (uint32_t)(n - base);   // 0..63
-        if (pending != 2 && extra_lane < 64) {
-          if (lane == extra_lane) bitv = (pending == 1u) ? 1u : 0u;
-          todo |= (1ull << extra_lane);
-        } else if (pending != 2) {
-          // cannot happen: tail ⇒ n - base < 64
-        }
-      }
-    }
-    uint32_t my_x = 0, my_k = 0, step = 0;
-    unsigned long long rem = todo;
-    while (rem) {
-      const uint32_t j = (uint32_t)(__ffsll((long long)rem) - 1);
-      rem &= rem - 1;
-      const uint32_t bit = rl(bitv, j);
-      const uint32_t f = bit ? f1 : p0, m = bit ? m1 : m0;
-      uint32_t xr = x, k = 0;
-      if (xr >= ((16u * f) << 8)) { xr >>= 8; k = 1; }
-      if (lane == step) { my_x = x; my_k = k; }
-      ++step;
-      uint32_t q, r;
-      divmod_magic(xr, f, m, q, r);
-      x = (q << 8) + r + (bit ? 0u : f1);
-    }
-    const uint32_t incl = wave_inclusive_scan(my_k, lane);
-    const uint32_t total = rl(incl, 63);
-    if (pos + total > d.cap) { err = 2; break; }
-    if (my_k) d.out[pos + (incl - my_k)] = (uint8_t)my_x;
-    pos += total;
-    if (d.kind == 2 && base + 64 > n) break;
-  }
-  if (lane == 0) {
-    if (!err) pos += flush_state(x - 4096u, d.out, pos, d.cap, err);
-    d.out_len[0] = (uint32_t)pos;
-    d.out_len[1] = err;
-  }
-}
-
-__global__ __launch_bounds__(64) void k_chains(const ChainDesc* __restrict__ descs) {
-  const ChainDesc d = descs[blockIdx.x];
-  if (d.kind == 0) rans_chain(d, threadIdx.x); else rabs_chain(d, threadIdx.x);
-}
-
 inline uint32_t grid_for(uint64_t work, uint32_t cap = 256 * 8) {
   uint64_t b = (work + kBlock - 1) / kBlock;
   if (b < 1) b = 1;
@@ -724,10 +576,6 @@ void launch_histogram(const uint32_t* sym, uint64_t n_sym, uint32_t* hist, uint3
   // few, fat blocks: each block flushes its private histogram once
   const uint32_t g = grid_for(n_sym, 512);
   hipLaunchKernelGGL(k_histogram, g, kBlock, lds, s, sym, n_sym, hist, bins, overflow_flag);
-}
-
-void launch_chains(const ChainDesc* descs_dev, uint32_t n_streams, hipStream_t s) {
-  if (n_streams) hipLaunchKernelGGL(k_chains, n_streams, 64, 0, s, descs_dev);
 }
 
 }  // namespace dmi
