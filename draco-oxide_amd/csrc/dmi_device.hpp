@@ -43,18 +43,22 @@ void launch_histogram(const uint32_t* sym, uint64_t n_sym, uint32_t* hist, uint3
 struct RansEntry { uint32_t m, b, d, c; };
 RansEntry make_rans_entry(uint32_t freq, uint32_t cum, uint32_t precision);   // host helper
 void launch_rans_prep(const uint32_t* sym, uint64_t n, const RansEntry* table, RansEntry* rec, hipStream_t s);
+void launch_bits_prep(const uint8_t* bits, uint64_t n, RansEntry e0, RansEntry e1, RansEntry* rec, hipStream_t s);
+// chunk_info[2c] = compact offset of 4096-flag chunk c, [2c+1] = value (0/1) of the first valid flag after it (1 if none)
+void launch_orient_prep(const uint8_t* orient, uint32_t n, const uint32_t* chunk_info, RansEntry e0, RansEntry e1, RansEntry* rec, hipStream_t s);
 struct ChainDesc {
   uint32_t kind;            // 0 = rANS over coding records, 1 = rABS over flips (forward), 2 = rABS over orientation flags
   uint32_t precision;       // rANS precision bits
   uint64_t n;               // symbols / entries
   const uint32_t* sym;      // unused by the kernel (kept for debugging)
   const RansEntry* table;   // kind 0: n coding records in coding order (k_rans_prep output)
-  const uint8_t* bits;      // kind 1/2
-  uint32_t p0;              // kind 1/2: zero probability
-  uint32_t pad;
+  const uint8_t* bits;      // unused by the kernel
+  uint32_t p0;              // kind 1/2: zero probability (informational)
+  uint32_t state0;          // initial state: 4 << precision (rANS) / 4096 (rABS)
   uint8_t* out;             // byte output
   uint64_t cap;
   uint32_t* out_len;        // [0] = bytes written, [1] = error flag (1 = state too large, 2 = capacity)
+  uint32_t* ticks;          // optional: chain duration in 100 MHz ticks
 };
 void launch_chains(const ChainDesc* descs_dev, uint32_t n_streams, hipStream_t s);
 

@@ -66,7 +66,7 @@ struct AttJob {
   uint32_t bins = 0;
   uint64_t n_sym = 0;
   uint64_t out_cap = 0, aux_cap = 0;
-  DevMem aux_out;
+  DevMem aux_out, aux_rec, chunk_info;
   FreqTable ft;
 };
 
@@ -312,13 +312,17 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
       if ((rc = a.aux.alloc(n ? n : 1))) return rc;
       a.aux_cap = (uint64_t)n + 16;   // ≤ 1 byte per coded bit + flush
       if ((rc = a.aux_out.alloc(a.aux_cap))) return rc;
+      if ((rc = a.aux_rec.alloc(((size_t)n + 192) * sizeof(RansEntry)))) return rc;   // +192: prefetch padding of the chain
+      HIP_TRY(hipMemsetAsync(a.aux_rec.p, 0, a.aux_rec.bytes, s));
+      if ((rc = a.chunk_info.alloc((size_t)std::max(1u, orient_summary_blocks(n)) * 8))) return rc;
     }
     if (a.scheme == kTexCoord) { if ((rc = a.summary.alloc((size_t)std::max(1u, orient_summary_blocks(n)) * 16))) return rc; }
     a.bins = symbol_bins(a);
     if (a.port == kToBits) a.bins = 1u << 20;   // capacity; the real bound is checked after the min/max readback
     if ((rc = a.hist.alloc((size_t)a.bins * 4))) return rc;
     if ((rc = a.rtable.alloc((size_t)a.bins * sizeof(RansEntry)))) return rc;
-    if ((rc = a.rec.alloc((size_t)a.n_sym * sizeof(RansEntry)))) return rc;
+    if ((rc = a.rec.alloc(((size_t)a.n_sym + 192) * sizeof(RansEntry)))) return rc;   // +192: prefetch padding of the chain
+    HIP_TRY(hipMemsetAsync(a.rec.p, 0, a.rec.bytes, s));
     a.out_cap = a.n_sym * 3 + 16;   // ≤ 3 renormalisation bytes per symbol (P ≤ 20) + flush
     if ((rc = a.out.alloc(a.out_cap))) return rc;
     if ((rc = a.meta.alloc(64))) return rc;
@@ -468,8 +472,8 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
     // symbols → coding records in coding order (data-parallel), consumed by the scalar chain
     launch_rans_prep(a.sym.as<uint32_t>(), a.n_sym, a.rtable.as<RansEntry>(), a.rec.as<RansEntry>(), s);
     ChainDesc d{};
-    d.kind = 0; d.precision = a.ft.precision; d.n = a.n_sym; d.sym = a.sym.as<uint32_t>(); d.table = a.rec.as<RansEntry>();
-    d.out = a.out.as<uint8_t>(); d.cap = a.out_cap; d.out_len = a.small.as<uint32_t>() + 8;
+    d.kind = 0; d.precision = a.ft.precision; d.n = a.n_sym; d.sym = a.sym.as<uint32_t>(); d.table = a.rec.as<RansEntry>(); d.state0 = 4u << a.ft.precision;
+    d.out = a.out.as<uint8_t>(); d.cap = a.out_cap; d.out_len = a.small.as<uint32_t>() + 8; d.ticks = a.small.as<uint32_t>() + 12;
     rans_desc[i] = (int)descs.size();
     descs.push_back(d);
     if (a.scheme == kNormal) {
@@ -478,7 +482,11 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
       aux[i].zero_prob = zero_probability(count_false, (float)n);
       aux[i].count = n;
       ChainDesc r{};
-      r.kind = 1; r.n = n; r.bits = a.aux.as<uint8_t>(); r.p0 = aux[i].zero_prob; r.out = a.aux_out.as<uint8_t>(); r.cap = a.aux_cap; r.out_len = a.small.as<uint32_t>() + 10;
+      {   // rABS (rans.rs:91-108): bit 1 codes with f1 = 256 - p0 and offset 0, bit 0 with p0 and offset f1
+        const uint32_t p0 = aux[i].zero_prob, f1 = 256u - p0;
+        launch_bits_prep(a.aux.as<uint8_t>(), n, make_rans_entry(p0, f1, 8), make_rans_entry(f1, 0, 8), a.aux_rec.as<RansEntry>(), s);
+      }
+      r.kind = 1; r.n = n; r.precision = 8; r.state0 = 4096; r.table = a.aux_rec.as<RansEntry>(); r.p0 = aux[i].zero_prob; r.out = a.aux_out.as<uint8_t>(); r.cap = a.aux_cap; r.out_len = a.small.as<uint32_t>() + 10; r.ticks = a.small.as<uint32_t>() + 13;
       aux[i].desc = (int)descs.size();
       descs.push_back(r);
     } else if (a.scheme == kTexCoord) {
@@ -498,7 +506,18 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
       aux[i].zero_prob = zero_probability(trans, (float)len + 0.001f);
       aux[i].count = (uint32_t)len;
       ChainDesc r{};
-      r.kind = 2; r.n = n; r.bits = a.aux.as<uint8_t>(); r.p0 = aux[i].zero_prob; r.out = a.aux_out.as<uint8_t>(); r.cap = a.aux_cap; r.out_len = a.small.as<uint32_t>() + 10;
+      {   // compact offsets + successor values per 4096-flag chunk, then flags → coding records on the device
+        std::vector<uint32_t> info(2 * (size_t)std::max(1u, nb));
+        uint32_t off = 0;
+        for (uint32_t b = 0; b < nb; ++b) { info[2 * b] = off; off += sm[4 * b]; }
+        uint32_t nextv = 1;   // `true` after the last valid entry
+        for (uint32_t b = nb; b-- > 0;) { info[2 * b + 1] = nextv; if (sm[4 * b]) nextv = sm[4 * b + 1]; }
+        HIP_TRY(hipMemcpyAsync(a.chunk_info.p, info.data(), info.size() * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        const uint32_t p0 = aux[i].zero_prob, f1 = 256u - p0;
+        launch_orient_prep(a.aux.as<uint8_t>(), n, a.chunk_info.as<uint32_t>(), make_rans_entry(p0, f1, 8), make_rans_entry(f1, 0, 8), a.aux_rec.as<RansEntry>(), s);
+      }
+      r.kind = 2; r.n = len; r.precision = 8; r.state0 = 4096; r.table = a.aux_rec.as<RansEntry>(); r.p0 = aux[i].zero_prob; r.out = a.aux_out.as<uint8_t>(); r.cap = a.aux_cap; r.out_len = a.small.as<uint32_t>() + 10; r.ticks = a.small.as<uint32_t>() + 13;
       aux[i].desc = (int)descs.size();
       descs.push_back(r);
     }
@@ -517,6 +536,7 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
     AttJob& a = job->atts[i];
     const uint32_t* small = reinterpret_cast<const uint32_t*>(pinned + pin_off[i]);
     if (small[9] || small[11]) return fail(DMI_ERR_ENTROPY, small[9] == 1 || small[11] == 1 ? "rANS state too large" : "coder output capacity exceeded");
+    if (std::getenv("DMI_TRACE")) std::fprintf(stderr, "[dmi] attribute %u: rANS chain %.3f ms (%llu symbols), aux chain %.3f ms\n", i, small[12] * 1e-5, (unsigned long long)a.n_sym, small[13] * 1e-5);
     rans_bytes[i].resize(small[8]);
     if (small[8]) HIP_TRY(hipMemcpyAsync(rans_bytes[i].data(), a.out.p, small[8], hipMemcpyDeviceToHost, s));
     if (aux[i].desc >= 0) {
