@@ -155,19 +155,17 @@ __device__ void run_chain(const ChainDesc& d, uint32_t lane) {
       load_rec8(cur, g + 8);
     }
     // bytes of the 64 steps: lane j re-derives its byte count from (parked state, frequency)
-    uint32_t my_k = 0;
-    if (lane < cnt) {
-      const uint32_t f = (1u << P) - me.d;
-      const uint64_t thr = (uint64_t)f << thr_shift;
-      uint64_t xx = parked;
-      while (xx >= thr) { xx >>= 8; ++my_k; }
-    }
-    const unsigned long long k1 = __ballot(my_k & 1u), k2 = __ballot(my_k & 2u);
-    const uint32_t before = lanes_below(k1) + 2u * lanes_below(k2);
-    const uint32_t total = (uint32_t)__popcll(k1) + 2u * (uint32_t)__popcll(k2);
+    // (f ≤ 2^20 ⇒ f << thr_shift < 2^32; parked < 2^30; at most 3 bytes per step)
+    const uint32_t thr = (lane < cnt) ? (((1u << P) - me.d) << thr_shift) : 0xFFFFFFFFu;
+    const bool b0 = parked >= thr, b1 = (parked >> 8) >= thr, b2 = (parked >> 16) >= thr;
+    const unsigned long long m0 = __ballot(b0), m1 = __ballot(b1), m2 = __ballot(b2);
+    const uint32_t before = lanes_below(m0) + lanes_below(m1) + lanes_below(m2);
+    const uint32_t total = (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);
     if (pos + total > d.cap) { err = 2; break; }
-    const uint64_t at = pos + before;
-    for (uint32_t t = 0; t < my_k; ++t) d.out[at + t] = (uint8_t)(parked >> (8 * t));
+    uint8_t* at = d.out + pos + before;
+    if (b0) at[0] = (uint8_t)parked;
+    if (b1) at[1] = (uint8_t)(parked >> 8);
+    if (b2) at[2] = (uint8_t)(parked >> 16);
     pos += total;
   }
   if (lane == 0) {

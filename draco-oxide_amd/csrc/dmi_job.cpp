@@ -48,7 +48,8 @@ struct DevMem {
 
 struct TableDev {
   uint32_t F = 0, V = 0, n_seq = 0;
-  DevMem c2v, opp, seq;   // c2p is shared by all tables of a job
+  DevMem c2v, opp, seq, rank;   // c2p is shared by all tables of a job; rank is shared by the attributes of the table
+  bool c2v_is_c2p = false;       // corner_to_vertex identical to corner_to_point: the kernels read one array
   // sharing: a table whose arrays equal another table's reuses its device copies
   int alias_of = -1;
 };
@@ -62,7 +63,7 @@ struct AttJob {
   int nq = 0;            // components after portabilization
   int table = 0;         // index into tables
   int parent = -1;
-  DevMem raw, p2v, q, rank, qs, sym, aux /*flips or orient*/, hist, rtable, rec, out, meta, partials, small /*minmax[2], counters[2], flags[2], out_len[2]*2*/, summary;
+  DevMem raw, p2v, q, fn, qs, sym, aux /*flips or orient*/, hist, rtable, rec, out, meta, partials, small /*minmax[2], counters[2], flags[2], out_len[2]*2*/, summary;
   uint32_t bins = 0;
   uint64_t n_sym = 0;
   uint64_t out_cap = 0, aux_cap = 0;
@@ -272,8 +273,9 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
         t.alias_of = (int)j;
     }
     if (t.alias_of >= 0) { job->atts[i].table = t.alias_of; continue; }
-    rc = upload(t.c2v, tables[i].corner_to_vertex, C * 4, s);
-    if (rc) return rc;
+    t.c2v_is_c2p = std::memcmp(tables[i].corner_to_vertex, tables[0].corner_to_point, C * 4) == 0;
+    if (!t.c2v_is_c2p) { rc = upload(t.c2v, tables[i].corner_to_vertex, C * 4, s); if (rc) return rc; }
+    if ((rc = t.rank.alloc((size_t)t.V * 4))) return rc;
     rc = upload(t.opp, tables[i].opposite, C * 4, s);
     if (rc) return rc;
     const uint32_t* seq = tables[i].sequence;
@@ -305,7 +307,6 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
     const uint32_t n = t.n_seq;
     a.n_sym = (uint64_t)n * a.nq;
     if (a.port != kToBits) { rc = a.q.alloc((size_t)d.num_unique * a.nq * 4); if (rc) return rc; }
-    if ((rc = a.rank.alloc((size_t)t.V * 4))) return rc;
     if ((rc = a.qs.alloc((size_t)n * a.nq * 4))) return rc;
     if ((rc = a.sym.alloc((size_t)a.n_sym * 4))) return rc;
     if (a.scheme == kNormal || a.scheme == kTexCoord) {
@@ -316,6 +317,7 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
       HIP_TRY(hipMemsetAsync(a.aux_rec.p, 0, a.aux_rec.bytes, s));
       if ((rc = a.chunk_info.alloc((size_t)std::max(1u, orient_summary_blocks(n)) * 8))) return rc;
     }
+    if (a.scheme == kNormal) { if ((rc = a.fn.alloc((size_t)F * 3 * 4))) return rc; }
     if (a.scheme == kTexCoord) { if ((rc = a.summary.alloc((size_t)std::max(1u, orient_summary_blocks(n)) * 16))) return rc; }
     a.bins = symbol_bins(a);
     if (a.port == kToBits) a.bins = 1u << 20;   // capacity; the real bound is checked after the min/max readback
@@ -379,13 +381,29 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
   // ---- stage 2: sequence-order gather + predict + transform ---------------------------------------
   if (timed) HIP_TRY(hipEventRecord(job->ev[1], s));
   for (auto& a : job->atts) {
-    const TableDev& t = job->tables[a.table];
-    const int32_t* q = a.port == kToBits ? a.raw.as<int32_t>() : a.q.as<int32_t>();
-    int32_t* minmax = a.small.as<int32_t>();          // small: [0..1] minmax, [2..3] counters, [4] zero-normal flag, [5] hist overflow
-    static const int32_t init_mm[2] = {2147483647, -2147483647 - 1};
-    HIP_TRY(hipMemcpyAsync(minmax, init_mm, 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemsetAsync(a.rank.p, 0xFF, a.rank.bytes, s));
-    launch_seq_gather(t.seq.as<uint32_t>(), t.n_seq, t.c2v.as<uint32_t>(), c2p, a.p2v.as<uint32_t>(), q, a.nq, a.rank.as<uint32_t>(), a.qs.as<int32_t>(), minmax, s);
+    static const int32_t init_mm[2] = {2147483647, -2147483647 - 1};   // small: [0..1] minmax, [2..3] counters, [4] zero-normal flag, [5] hist overflow
+    HIP_TRY(hipMemcpyAsync(a.small.p, init_mm, 8, hipMemcpyHostToDevice, s));
+  }
+  for (size_t ti = 0; ti < job->tables.size(); ++ti) {
+    TableDev& t = job->tables[ti];
+    if (t.alias_of >= 0) continue;
+    GatherArgs ga{};
+    auto flush = [&]() {
+      if (ga.count) launch_seq_gather(t.seq.as<uint32_t>(), t.n_seq, t.c2v_is_c2p ? c2p : t.c2v.as<uint32_t>(), c2p, t.rank.as<uint32_t>(), ga, s);
+      ga.count = 0;
+    };
+    HIP_TRY(hipMemsetAsync(t.rank.p, 0xFF, t.rank.bytes, s));
+    for (auto& a : job->atts) {
+      if ((size_t)a.table != ti) continue;
+      GatherAtt& g = ga.a[ga.count++];
+      g.q = a.port == kToBits ? a.raw.as<int32_t>() : a.q.as<int32_t>();
+      g.p2v = a.p2v.as<uint32_t>();
+      g.qs = a.qs.as<int32_t>();
+      g.minmax = a.small.as<int32_t>();
+      g.N = a.nq;
+      if (ga.count == kMaxGather) flush();
+    }
+    flush();
   }
   for (auto& a : job->atts) {
     const TableDev& t = job->tables[a.table];
@@ -395,20 +413,21 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
     if (n == 0) continue;
     switch (a.scheme) {
       case kParallelogram:
-        launch_pred_parallelogram_wrapped(t.seq.as<uint32_t>(), n, t.c2v.as<uint32_t>(), t.opp.as<uint32_t>(), a.rank.as<uint32_t>(), a.qs.as<int32_t>(), minmax, a.nq, a.sym.as<uint32_t>(), s);
+        launch_pred_parallelogram_wrapped(t.seq.as<uint32_t>(), n, (t.c2v_is_c2p ? c2p : t.c2v.as<uint32_t>()), t.opp.as<uint32_t>(), t.rank.as<uint32_t>(), a.qs.as<int32_t>(), minmax, a.nq, a.sym.as<uint32_t>(), s);
         break;
       case kDelta:
         launch_pred_delta_difference(n, a.qs.as<int32_t>(), a.nq, a.sym.as<uint32_t>(), s);
         break;
       case kNormal: {
         const AttJob& p = job->atts[a.parent];
-        launch_pred_normal_octorth(t.seq.as<uint32_t>(), n, c2p, t.opp.as<uint32_t>(), p.p2v.as<uint32_t>(), p.q.as<int32_t>(), a.qs.as<int32_t>(), a.sym.as<uint32_t>(), a.aux.as<uint8_t>(), counters, s);
+        launch_face_normals(c2p, t.F, p.p2v.as<uint32_t>(), p.q.as<int32_t>(), a.fn.as<int32_t>(), s);
+        launch_pred_normal_octorth(t.seq.as<uint32_t>(), n, t.opp.as<uint32_t>(), a.fn.as<int32_t>(), a.qs.as<int32_t>(), a.sym.as<uint32_t>(), a.aux.as<uint8_t>(), counters, s);
         break;
       }
       case kTexCoord: {
         const AttJob& p = job->atts[a.parent];
         const int32_t* qp = p.port == kToBits ? p.raw.as<int32_t>() : p.q.as<int32_t>();
-        launch_pred_texcoord_wrapped(t.seq.as<uint32_t>(), n, t.c2v.as<uint32_t>(), c2p, a.rank.as<uint32_t>(), a.qs.as<int32_t>(), p.p2v.as<uint32_t>(), qp, p.desc.num_points, minmax, a.sym.as<uint32_t>(), a.aux.as<uint8_t>(), s);
+        launch_pred_texcoord_wrapped(t.seq.as<uint32_t>(), n, (t.c2v_is_c2p ? c2p : t.c2v.as<uint32_t>()), c2p, t.rank.as<uint32_t>(), a.qs.as<int32_t>(), p.p2v.as<uint32_t>(), qp, p.desc.num_points, minmax, a.sym.as<uint32_t>(), a.aux.as<uint8_t>(), s);
         launch_orient_summary(a.aux.as<uint8_t>(), n, a.summary.as<uint32_t>(), nullptr, s);
         break;
       }

@@ -193,28 +193,67 @@ __global__ __launch_bounds__(kBlock) void k_quant_oct(const float* __restrict__ 
 // and, because all corners of one (attribute-)vertex carry the same value,
 //   qs[rank[vertex(c)]] == attribute.get(point_idx(c))        for every already-coded corner c.
 // ------------------------------------------------------------------------------------------------
+// One launch serves every attribute coded on the same corner table (they share the sequence, hence the
+// rank array and the seq / corner_to_vertex / corner_to_point traffic).
 template <int N>
+__device__ __forceinline__ void gather_one(const GatherAtt& a, uint32_t p, uint32_t i, int32_t& mn, int32_t& mx) {
+  if (a.p2v) p = a.p2v[p];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const int32_t v = a.q[(size_t)p * N + k];
+    a.qs[(size_t)i * N + k] = v;
+    mn = min(mn, v);
+    mx = max(mx, v);
+  }
+}
 __global__ __launch_bounds__(kBlock) void k_seq_gather(const uint32_t* __restrict__ seq, uint32_t n, const uint32_t* __restrict__ c2v,
-                                                       const uint32_t* __restrict__ c2p, const uint32_t* __restrict__ p2v,
-                                                       const int32_t* __restrict__ q, uint32_t* __restrict__ rank, int32_t* __restrict__ qs,
-                                                       int32_t* __restrict__ minmax) {
-  int32_t mn = 2147483647, mx = (-2147483647 - 1);
+                                                       const uint32_t* __restrict__ c2p, uint32_t* __restrict__ rank, GatherArgs args) {
+  int32_t mn[kMaxGather], mx[kMaxGather];
+#pragma unroll
+  for (int a = 0; a < kMaxGather; ++a) { mn[a] = 2147483647; mx[a] = (-2147483647 - 1); }
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const uint32_t c = seq[i];
-    rank[c2v[c]] = i;
-    uint32_t p = c2p[c];
-    if (p2v) p = p2v[p];
+    const uint32_t v = c2v[c];
+    rank[v] = i;
+    const uint32_t p = (c2p == c2v) ? v : c2p[c];   // identical arrays are passed as the same pointer
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-      const int32_t v = q[(size_t)p * N + k];
-      qs[(size_t)i * N + k] = v;
-      mn = min(mn, v);
-      mx = max(mx, v);
+    for (int a = 0; a < kMaxGather; ++a) {
+      if (a >= args.count) break;
+      switch (args.a[a].N) {
+        case 1: gather_one<1>(args.a[a], p, i, mn[a], mx[a]); break;
+        case 2: gather_one<2>(args.a[a], p, i, mn[a], mx[a]); break;
+        case 3: gather_one<3>(args.a[a], p, i, mn[a], mx[a]); break;
+        default: gather_one<4>(args.a[a], p, i, mn[a], mx[a]); break;
+      }
     }
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { mn = min(mn, __shfl_down(mn, off, 64)); mx = max(mx, __shfl_down(mx, off, 64)); }
-  if ((threadIdx.x & 63) == 0) { atomicMin(&minmax[0], mn); atomicMax(&minmax[1], mx); }
+  for (int a = 0; a < kMaxGather; ++a) {
+    if (a >= args.count) break;
+    int32_t lo = mn[a], hi = mx[a];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_down(lo, off, 64)); hi = max(hi, __shfl_down(hi, off, 64)); }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&args.a[a].minmax[0], lo); atomicMax(&args.a[a].minmax[1], hi); }
+  }
+}
+
+// Per-face normal of the quantised positions (i32 cross product, wrapping).  For every corner cc of face f
+//   cross(pos[next(cc)] - pos[cc], pos[prev(cc)] - pos[cc])
+// is the same vector (cyclic invariance holds in the ring Z/2^32), and every corner of a vertex fan sits at
+// the fan vertex's position, so mesh_normal_prediction.rs:22-44 evaluates exactly fn[face(cc)] per fan face.
+__global__ __launch_bounds__(kBlock) void k_face_normals(const uint32_t* __restrict__ c2p, uint32_t nfaces, const uint32_t* __restrict__ pos_p2v,
+                                                         const int32_t* __restrict__ q_pos, int32_t* __restrict__ fn) {
+  for (uint32_t f = blockIdx.x * kBlock + threadIdx.x; f < nfaces; f += gridDim.x * kBlock) {
+    uint32_t p0 = c2p[(size_t)3 * f], p1 = c2p[(size_t)3 * f + 1], p2 = c2p[(size_t)3 * f + 2];
+    if (pos_p2v) { p0 = pos_p2v[p0]; p1 = pos_p2v[p1]; p2 = pos_p2v[p2]; }
+    const int32_t ax = wsub(q_pos[(size_t)p1 * 3], q_pos[(size_t)p0 * 3]), ay = wsub(q_pos[(size_t)p1 * 3 + 1], q_pos[(size_t)p0 * 3 + 1]),
+                  az = wsub(q_pos[(size_t)p1 * 3 + 2], q_pos[(size_t)p0 * 3 + 2]);
+    const int32_t bx = wsub(q_pos[(size_t)p2 * 3], q_pos[(size_t)p0 * 3]), by = wsub(q_pos[(size_t)p2 * 3 + 1], q_pos[(size_t)p0 * 3 + 1]),
+                  bz = wsub(q_pos[(size_t)p2 * 3 + 2], q_pos[(size_t)p0 * 3 + 2]);
+    fn[(size_t)3 * f] = wsub(wmul(ay, bz), wmul(az, by));
+    fn[(size_t)3 * f + 1] = wsub(wmul(az, bx), wmul(ax, bz));
+    fn[(size_t)3 * f + 2] = wsub(wmul(ax, by), wmul(ay, bx));
+  }
 }
 
 // WrappedDifference::squeeze parameters from the joint min/max (wrapped_difference.rs:62-69, Q16)
@@ -300,38 +339,38 @@ __device__ __forceinline__ void oct_orthogonal(int32_t o0, int32_t o1, int32_t p
   s0 = (uint32_t)c0; s1 = (uint32_t)c1;
 }
 
-__global__ __launch_bounds__(kBlock) void k_pred_normal_octorth(const uint32_t* __restrict__ seq, uint32_t n, const uint32_t* __restrict__ c2p,
-                                                                const uint32_t* __restrict__ opp, const uint32_t* __restrict__ pos_p2v,
-                                                                const int32_t* __restrict__ q_pos, const int32_t* __restrict__ qs,
+__global__ __launch_bounds__(kBlock) void k_pred_normal_octorth(const uint32_t* __restrict__ seq, uint32_t n, const uint32_t* __restrict__ opp,
+                                                                const int32_t* __restrict__ fn, const int32_t* __restrict__ qs,
                                                                 uint32_t* __restrict__ sym, uint8_t* __restrict__ flips, uint32_t* __restrict__ counters) {
   uint32_t n_false = 0;
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const uint32_t c = seq[i];
-    auto pos_of = [&](uint32_t corner, int32_t* out) {
-      uint32_t p = c2p[corner];
-      if (pos_p2v) p = pos_p2v[p];
-      out[0] = q_pos[(size_t)p * 3]; out[1] = q_pos[(size_t)p * 3 + 1]; out[2] = q_pos[(size_t)p * 3 + 2];
-    };
-    int32_t pc[3];
-    pos_of(c, pc);
-    // swing left to the start of the fan (or full turn), then right, summing face normals
-    uint32_t cur = c;
-    for (;;) { const uint32_t o = opp[cnext(cur)]; if (o == kNoneD) break; cur = cnext(o); if (cur == c) break; }
-    const uint32_t start = cur;
-    int64_t sum0 = 0, sum1 = 0, sum2 = 0;
-    for (;;) {
-      int32_t pn[3], pp[3];
-      pos_of(cnext(cur), pn);
-      pos_of(cprev(cur), pp);
-      const int32_t dn0 = wsub(pn[0], pc[0]), dn1 = wsub(pn[1], pc[1]), dn2 = wsub(pn[2], pc[2]);
-      const int32_t dp0 = wsub(pp[0], pc[0]), dp1 = wsub(pp[1], pc[1]), dp2 = wsub(pp[2], pc[2]);
-      sum0 = wadd64(sum0, (int64_t)wsub(wmul(dn1, dp2), wmul(dn2, dp1)));   // cross in i32, sum in i64
-      sum1 = wadd64(sum1, (int64_t)wsub(wmul(dn2, dp0), wmul(dn0, dp2)));
-      sum2 = wadd64(sum2, (int64_t)wsub(wmul(dn0, dp1), wmul(dn1, dp0)));
+    // Sum of the face normals over the vertex fan (i32 terms, i64 wrapping sum: order-independent).  The
+    // reference swings left to the fan start and then right; the same set of faces is reached by swinging
+    // right from c and, if the fan is open, left from c.
+    int64_t sum0, sum1, sum2;
+    {
+      const uint32_t f = c / 3u;
+      sum0 = fn[(size_t)3 * f]; sum1 = fn[(size_t)3 * f + 1]; sum2 = fn[(size_t)3 * f + 2];
+    }
+    bool open = false;
+    for (uint32_t cur = c;;) {
       const uint32_t o = opp[cprev(cur)];
-      if (o == kNoneD) break;
+      if (o == kNoneD) { open = true; break; }
       cur = cprev(o);
-      if (cur == start) break;
+      if (cur == c) break;
+      const uint32_t f = cur / 3u;
+      sum0 = wadd64(sum0, (int64_t)fn[(size_t)3 * f]); sum1 = wadd64(sum1, (int64_t)fn[(size_t)3 * f + 1]); sum2 = wadd64(sum2, (int64_t)fn[(size_t)3 * f + 2]);
+    }
+    if (open) {
+      for (uint32_t cur = c;;) {
+        const uint32_t o = opp[cnext(cur)];
+        if (o == kNoneD) break;
+        cur = cnext(o);
+        if (cur == c) break;
+        const uint32_t f = cur / 3u;
+        sum0 = wadd64(sum0, (int64_t)fn[(size_t)3 * f]); sum1 = wadd64(sum1, (int64_t)fn[(size_t)3 * f + 1]); sum2 = wadd64(sum2, (int64_t)fn[(size_t)3 * f + 2]);
+      }
     }
     const int64_t upper = 1ll << 29;
     const int64_t abs_sum = wadd64(wadd64(wabs64(sum0), wabs64(sum1)), wabs64(sum2));
@@ -527,15 +566,12 @@ void launch_quant_oct(const float* vals, uint32_t n, int32_t* q, uint32_t* zero_
   hipLaunchKernelGGL(k_quant_oct, grid_for(n), kBlock, 0, s, vals, n, q, zero_flag);
 }
 
-void launch_seq_gather(const uint32_t* seq, uint32_t n, const uint32_t* c2v, const uint32_t* c2p, const uint32_t* p2v, const int32_t* q, int N,
-                       uint32_t* rank, int32_t* qs, int32_t* minmax, hipStream_t s) {
-  const uint32_t g = grid_for(n);
-  switch (N) {
-    case 1: hipLaunchKernelGGL(k_seq_gather<1>, g, kBlock, 0, s, seq, n, c2v, c2p, p2v, q, rank, qs, minmax); break;
-    case 2: hipLaunchKernelGGL(k_seq_gather<2>, g, kBlock, 0, s, seq, n, c2v, c2p, p2v, q, rank, qs, minmax); break;
-    case 3: hipLaunchKernelGGL(k_seq_gather<3>, g, kBlock, 0, s, seq, n, c2v, c2p, p2v, q, rank, qs, minmax); break;
-    default: hipLaunchKernelGGL(k_seq_gather<4>, g, kBlock, 0, s, seq, n, c2v, c2p, p2v, q, rank, qs, minmax); break;
-  }
+void launch_seq_gather(const uint32_t* seq, uint32_t n, const uint32_t* c2v, const uint32_t* c2p, uint32_t* rank, const GatherArgs& args, hipStream_t s) {
+  hipLaunchKernelGGL(k_seq_gather, grid_for(n), kBlock, 0, s, seq, n, c2v, c2p, rank, args);
+}
+
+void launch_face_normals(const uint32_t* c2p, uint32_t nfaces, const uint32_t* pos_p2v, const int32_t* q_pos, int32_t* fn, hipStream_t s) {
+  if (nfaces) hipLaunchKernelGGL(k_face_normals, grid_for(nfaces), kBlock, 0, s, c2p, nfaces, pos_p2v, q_pos, fn);
 }
 
 void launch_pred_parallelogram_wrapped(const uint32_t* seq, uint32_t n, const uint32_t* c2v, const uint32_t* opp, const uint32_t* rank,
@@ -554,9 +590,9 @@ void launch_pred_delta_difference(uint32_t n, const int32_t* qs, int N, uint32_t
   hipLaunchKernelGGL(k_pred_delta_difference, grid_for(nc), kBlock, 0, s, nc, N, qs, sym);
 }
 
-void launch_pred_normal_octorth(const uint32_t* seq, uint32_t n, const uint32_t* c2p, const uint32_t* opp_att, const uint32_t* pos_p2v,
-                                const int32_t* q_pos, const int32_t* qs, uint32_t* sym, uint8_t* flips, uint32_t* counters, hipStream_t s) {
-  hipLaunchKernelGGL(k_pred_normal_octorth, grid_for(n), kBlock, 0, s, seq, n, c2p, opp_att, pos_p2v, q_pos, qs, sym, flips, counters);
+void launch_pred_normal_octorth(const uint32_t* seq, uint32_t n, const uint32_t* opp_att, const int32_t* fn, const int32_t* qs, uint32_t* sym,
+                                uint8_t* flips, uint32_t* counters, hipStream_t s) {
+  hipLaunchKernelGGL(k_pred_normal_octorth, grid_for(n), kBlock, 0, s, seq, n, opp_att, fn, qs, sym, flips, counters);
 }
 
 void launch_pred_texcoord_wrapped(const uint32_t* seq, uint32_t n, const uint32_t* c2v, const uint32_t* c2p, const uint32_t* rank, const int32_t* qs,
