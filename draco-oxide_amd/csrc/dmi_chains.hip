@@ -45,9 +45,27 @@ __device__ __forceinline__ uint32_t flush_state(uint32_t s, uint8_t* out, uint64
 }
 
 // ---- prep kernels ---------------------------------------------------------------------------------
+// Also writes one flag per batch of 64 records: "contains a frequency-1 symbol" (each wavefront covers one
+// aligned batch: the grid stride is a multiple of 256).
 __global__ __launch_bounds__(256) void k_rans_prep(const uint32_t* __restrict__ sym, uint64_t n, const RansEntry* __restrict__ table,
-                                                   RansEntry* __restrict__ rec) {
-  for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (uint64_t)gridDim.x * 256) rec[t] = table[sym[n - 1 - t]];
+                                                   RansEntry* __restrict__ rec, uint32_t* __restrict__ batch_flags) {
+  const uint64_t n_round = (n + 63) & ~(uint64_t)63;
+  for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < n_round; t += (uint64_t)gridDim.x * 256) {
+    RansEntry e{0u, 0u, 0u, 0u};
+    if (t < n) { e = table[sym[n - 1 - t]]; rec[t] = e; }
+    const unsigned long long any = __ballot((e.b >> 8) != 0);
+    if ((threadIdx.x & 63) == 0) batch_flags[t >> 6] = any != 0ull;
+  }
+}
+
+// Per-batch "contains a frequency-1 record" flags for a finished record stream (rABS streams).
+__global__ __launch_bounds__(256) void k_batch_flags(const RansEntry* __restrict__ rec, uint64_t n, uint32_t* __restrict__ batch_flags) {
+  const uint64_t n_round = (n + 63) & ~(uint64_t)63;
+  for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < n_round; t += (uint64_t)gridDim.x * 256) {
+    const uint32_t b = (t < n) ? rec[t].b : 0u;
+    const unsigned long long any = __ballot((b >> 8) != 0);
+    if ((threadIdx.x & 63) == 0) batch_flags[t >> 6] = any != 0ull;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_bits_prep(const uint8_t* __restrict__ bits, uint64_t n, RansEntry e0, RansEntry e1, RansEntry* __restrict__ rec) {
@@ -96,11 +114,12 @@ __global__ __launch_bounds__(64) void k_orient_prep(const uint8_t* __restrict__ 
 }
 
 // ---- the chain -------------------------------------------------------------------------------------
-struct Rec8 { RansEntry r[8]; };
-typedef const Rec8 __attribute__((address_space(4))) * const_rec8_t;   // constant address space ⇒ scalar loads
-__device__ __forceinline__ void load_rec8(Rec8& dst, const_rec8_t src) {
+// Records travel through SGPRs in groups of 4 (one s_load_dwordx16), fetched two groups (8 steps) ahead.
+struct Rec4 { RansEntry r[4]; };
+typedef const Rec4 __attribute__((address_space(4))) * const_rec4_t;   // constant address space ⇒ scalar loads
+__device__ __forceinline__ void load_rec4(Rec4& dst, const_rec4_t src) {
 #pragma unroll
-  for (int k = 0; k < 8; ++k) { dst.r[k].m = src->r[k].m; dst.r[k].b = src->r[k].b; dst.r[k].d = src->r[k].d; dst.r[k].c = src->r[k].c; }
+  for (int k = 0; k < 4; ++k) { dst.r[k].m = src->r[k].m; dst.r[k].b = src->r[k].b; dst.r[k].d = src->r[k].d; dst.r[k].c = src->r[k].c; }
 }
 
 #define DMI_CHAIN_STEP(R, J)                                                                     \
@@ -123,25 +142,33 @@ __device__ void run_chain(const ChainDesc& d, uint32_t lane) {
   uint32_t x = x0;
   uint64_t pos = 0;
   uint32_t err = 0;
-  RansEntry mine = rec[lane];                     // batch 0 (padding makes this safe for any n)
-  Rec8 cur;
-  load_rec8(cur, (const_rec8_t)(uintptr_t)rec);
+  typedef const uint32_t __attribute__((address_space(4))) * const_u32_t;
+  const_u32_t flags = (const_u32_t)(uintptr_t)d.batch_flags;   // nullable
+  uint32_t flag_next = d.force_generic ? 1u : (flags ? flags[0] : 0u);
+  Rec4 g0, g1;   // the next two groups to execute
+  load_rec4(g0, (const_rec4_t)(uintptr_t)rec);
+  load_rec4(g1, (const_rec4_t)(uintptr_t)rec + 1);
   for (uint64_t base = 0; base < n; base += 64) {
     const uint32_t cnt = (uint32_t)min((uint64_t)64, n - base);
-    const RansEntry me = mine;
-    mine = rec[base + 64 + lane];                 // prefetch the next batch's per-lane records
-    const bool has_f1 = __ballot(lane < cnt && (me.b >> 8) != 0) != 0ull;   // a frequency-1 symbol in this batch
+    // (global address space: a flat access would also count in lgkmcnt and stall the scalar-load waits)
+    typedef const RansEntry __attribute__((address_space(1))) * grec_t;
+    const grec_t grec = (grec_t)(uintptr_t)rec;
+    RansEntry me;                                 // used only by the emission phase at the end of the batch
+    me.m = grec[base + lane].m; me.b = grec[base + lane].b; me.d = grec[base + lane].d; me.c = grec[base + lane].c;
+    const bool has_f1 = flag_next != 0u;          // a frequency-1 symbol in this batch (flag fetched one batch ahead)
+    if (!d.force_generic && flags) flag_next = flags[(base >> 6) + 1];
     uint32_t parked = 0;
     x = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
-    const_rec8_t g = (const_rec8_t)(uintptr_t)(rec + base);
+    const_rec4_t g = (const_rec4_t)(uintptr_t)(rec + base);
     if (cnt == 64 && !has_f1) {
 #pragma unroll
-      for (int gi = 0; gi < 8; ++gi) {
-        Rec8 nxt;
-        load_rec8(nxt, g + gi + 1);               // one group ahead (runs into the next batch at gi = 7)
+      for (int gi = 0; gi < 16; ++gi) {
+        Rec4 g2;
+        load_rec4(g2, g + gi + 2);                // two groups ahead (runs into the next batch at gi ≥ 14)
 #pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8) DMI_CHAIN_STEP(cur.r[s8], gi * 8 + s8)
-        cur = nxt;
+        for (int s4 = 0; s4 < 4; ++s4) DMI_CHAIN_STEP(g0.r[s4], gi * 4 + s4)
+        g0 = g1;
+        g1 = g2;
       }
     } else {
       for (uint32_t j = 0; j < cnt; ++j) {
@@ -152,7 +179,8 @@ __device__ void run_chain(const ChainDesc& d, uint32_t lane) {
         if (lane == j) parked = x;
         x = (x >> sh) + (q0 >> sh) * dj + cj;
       }
-      load_rec8(cur, g + 8);
+      load_rec4(g0, g + 16);
+      load_rec4(g1, g + 17);
     }
     // bytes of the 64 steps: lane j re-derives its byte count from (parked state, frequency)
     // (f ≤ 2^20 ⇒ f << thr_shift < 2^32; parked < 2^30; at most 3 bytes per step)
@@ -162,7 +190,8 @@ __device__ void run_chain(const ChainDesc& d, uint32_t lane) {
     const uint32_t before = lanes_below(m0) + lanes_below(m1) + lanes_below(m2);
     const uint32_t total = (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);
     if (pos + total > d.cap) { err = 2; break; }
-    uint8_t* at = d.out + pos + before;
+    typedef uint8_t __attribute__((address_space(1))) * gbyte_t;
+    gbyte_t at = (gbyte_t)(uintptr_t)d.out + pos + before;
     if (b0) at[0] = (uint8_t)parked;
     if (b1) at[1] = (uint8_t)(parked >> 8);
     if (b2) at[2] = (uint8_t)(parked >> 16);
@@ -186,8 +215,8 @@ inline uint32_t grid256(uint64_t n) { uint64_t g = (n + 255) / 256; return (uint
 
 }  // namespace
 
-void launch_rans_prep(const uint32_t* sym, uint64_t n, const RansEntry* table, RansEntry* rec, hipStream_t s) {
-  if (n) hipLaunchKernelGGL(k_rans_prep, grid256(n), 256, 0, s, sym, n, table, rec);
+void launch_rans_prep(const uint32_t* sym, uint64_t n, const RansEntry* table, RansEntry* rec, uint32_t* batch_flags, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_rans_prep, grid256(n), 256, 0, s, sym, n, table, rec, batch_flags);
 }
 void launch_bits_prep(const uint8_t* bits, uint64_t n, RansEntry e0, RansEntry e1, RansEntry* rec, hipStream_t s) {
   if (n) hipLaunchKernelGGL(k_bits_prep, grid256(n), 256, 0, s, bits, n, e0, e1, rec);
@@ -195,6 +224,9 @@ void launch_bits_prep(const uint8_t* bits, uint64_t n, RansEntry e0, RansEntry e
 void launch_orient_prep(const uint8_t* orient, uint32_t n, const uint32_t* chunk_info, RansEntry e0, RansEntry e1, RansEntry* rec, hipStream_t s) {
   const uint32_t chunks = (n + 4095u) / 4096u;
   if (chunks) hipLaunchKernelGGL(k_orient_prep, chunks, 64, 0, s, orient, n, chunk_info, e0, e1, rec);
+}
+void launch_batch_flags(const RansEntry* rec, uint64_t n, uint32_t* batch_flags, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_batch_flags, grid256(n), 256, 0, s, rec, n, batch_flags);
 }
 void launch_chains(const ChainDesc* descs_dev, uint32_t n_streams, hipStream_t s) {
   if (n_streams) hipLaunchKernelGGL(k_chains, n_streams, 64, 0, s, descs_dev);

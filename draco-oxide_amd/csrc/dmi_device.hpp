@@ -46,7 +46,9 @@ void launch_histogram(const uint32_t* sym, uint64_t n_sym, uint32_t* hist, uint3
 // d = 2^P - f; c = cumulative frequency.
 struct RansEntry { uint32_t m, b, d, c; };
 RansEntry make_rans_entry(uint32_t freq, uint32_t cum, uint32_t precision);   // host helper
-void launch_rans_prep(const uint32_t* sym, uint64_t n, const RansEntry* table, RansEntry* rec, hipStream_t s);
+// batch_flags: (n + 63) / 64 + 1 words; [b] != 0 ⇔ batch b holds a frequency-1 symbol
+void launch_rans_prep(const uint32_t* sym, uint64_t n, const RansEntry* table, RansEntry* rec, uint32_t* batch_flags, hipStream_t s);
+void launch_batch_flags(const RansEntry* rec, uint64_t n, uint32_t* batch_flags, hipStream_t s);
 void launch_bits_prep(const uint8_t* bits, uint64_t n, RansEntry e0, RansEntry e1, RansEntry* rec, hipStream_t s);
 // chunk_info[2c] = compact offset of 4096-flag chunk c, [2c+1] = value (0/1) of the first valid flag after it (1 if none)
 void launch_orient_prep(const uint8_t* orient, uint32_t n, const uint32_t* chunk_info, RansEntry e0, RansEntry e1, RansEntry* rec, hipStream_t s);
@@ -56,8 +58,8 @@ struct ChainDesc {
   uint64_t n;               // symbols / entries
   const uint32_t* sym;      // unused by the kernel (kept for debugging)
   const RansEntry* table;   // kind 0: n coding records in coding order (k_rans_prep output)
-  const uint8_t* bits;      // unused by the kernel
-  uint32_t p0;              // kind 1/2: zero probability (informational)
+  const uint32_t* batch_flags;   // kind 0: per-batch frequency-1 flags (k_rans_prep), NULL otherwise
+  uint32_t force_generic;   // kind 1/2: 1 when a coded frequency is 1 (p0 ∈ {1, 255}): every batch takes the generic loop
   uint32_t state0;          // initial state: 4 << precision (rANS) / 4096 (rABS)
   uint8_t* out;             // byte output
   uint64_t cap;

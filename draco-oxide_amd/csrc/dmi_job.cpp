@@ -67,7 +67,7 @@ struct AttJob {
   uint32_t bins = 0;
   uint64_t n_sym = 0;
   uint64_t out_cap = 0, aux_cap = 0;
-  DevMem aux_out, aux_rec, chunk_info;
+  DevMem aux_out, aux_rec, chunk_info, batch_flags, aux_flags;
   FreqTable ft;
 };
 
@@ -315,6 +315,8 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
       if ((rc = a.aux_out.alloc(a.aux_cap))) return rc;
       if ((rc = a.aux_rec.alloc(((size_t)n + 192) * sizeof(RansEntry)))) return rc;   // +192: prefetch padding of the chain
       HIP_TRY(hipMemsetAsync(a.aux_rec.p, 0, a.aux_rec.bytes, s));
+      if ((rc = a.aux_flags.alloc(((size_t)n / 64 + 4) * 4))) return rc;
+      HIP_TRY(hipMemsetAsync(a.aux_flags.p, 0, a.aux_flags.bytes, s));
       if ((rc = a.chunk_info.alloc((size_t)std::max(1u, orient_summary_blocks(n)) * 8))) return rc;
     }
     if (a.scheme == kNormal) { if ((rc = a.fn.alloc((size_t)F * 3 * 4))) return rc; }
@@ -325,6 +327,8 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
     if ((rc = a.rtable.alloc((size_t)a.bins * sizeof(RansEntry)))) return rc;
     if ((rc = a.rec.alloc(((size_t)a.n_sym + 192) * sizeof(RansEntry)))) return rc;   // +192: prefetch padding of the chain
     HIP_TRY(hipMemsetAsync(a.rec.p, 0, a.rec.bytes, s));
+    if ((rc = a.batch_flags.alloc(((size_t)a.n_sym / 64 + 4) * 4))) return rc;
+    HIP_TRY(hipMemsetAsync(a.batch_flags.p, 0, a.batch_flags.bytes, s));
     a.out_cap = a.n_sym * 3 + 16;   // ≤ 3 renormalisation bytes per symbol (P ≤ 20) + flush
     if ((rc = a.out.alloc(a.out_cap))) return rc;
     if ((rc = a.meta.alloc(64))) return rc;
@@ -489,9 +493,9 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
     HIP_TRY(hipMemcpyAsync(a.rtable.p, rt.data(), rt.size() * sizeof(RansEntry), hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));   // rt is a stack-scoped staging vector
     // symbols → coding records in coding order (data-parallel), consumed by the scalar chain
-    launch_rans_prep(a.sym.as<uint32_t>(), a.n_sym, a.rtable.as<RansEntry>(), a.rec.as<RansEntry>(), s);
+    launch_rans_prep(a.sym.as<uint32_t>(), a.n_sym, a.rtable.as<RansEntry>(), a.rec.as<RansEntry>(), a.batch_flags.as<uint32_t>(), s);
     ChainDesc d{};
-    d.kind = 0; d.precision = a.ft.precision; d.n = a.n_sym; d.sym = a.sym.as<uint32_t>(); d.table = a.rec.as<RansEntry>(); d.state0 = 4u << a.ft.precision;
+    d.kind = 0; d.precision = a.ft.precision; d.n = a.n_sym; d.sym = a.sym.as<uint32_t>(); d.table = a.rec.as<RansEntry>(); d.state0 = 4u << a.ft.precision; d.batch_flags = a.batch_flags.as<uint32_t>();
     d.out = a.out.as<uint8_t>(); d.cap = a.out_cap; d.out_len = a.small.as<uint32_t>() + 8; d.ticks = a.small.as<uint32_t>() + 12;
     rans_desc[i] = (int)descs.size();
     descs.push_back(d);
@@ -504,8 +508,9 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
       {   // rABS (rans.rs:91-108): bit 1 codes with f1 = 256 - p0 and offset 0, bit 0 with p0 and offset f1
         const uint32_t p0 = aux[i].zero_prob, f1 = 256u - p0;
         launch_bits_prep(a.aux.as<uint8_t>(), n, make_rans_entry(p0, f1, 8), make_rans_entry(f1, 0, 8), a.aux_rec.as<RansEntry>(), s);
+        launch_batch_flags(a.aux_rec.as<RansEntry>(), n, a.aux_flags.as<uint32_t>(), s);
       }
-      r.kind = 1; r.n = n; r.precision = 8; r.state0 = 4096; r.table = a.aux_rec.as<RansEntry>(); r.p0 = aux[i].zero_prob; r.out = a.aux_out.as<uint8_t>(); r.cap = a.aux_cap; r.out_len = a.small.as<uint32_t>() + 10; r.ticks = a.small.as<uint32_t>() + 13;
+      r.kind = 1; r.n = n; r.precision = 8; r.state0 = 4096; r.table = a.aux_rec.as<RansEntry>(); r.force_generic = 0; r.batch_flags = a.aux_flags.as<uint32_t>(); r.out = a.aux_out.as<uint8_t>(); r.cap = a.aux_cap; r.out_len = a.small.as<uint32_t>() + 10; r.ticks = a.small.as<uint32_t>() + 13;
       aux[i].desc = (int)descs.size();
       descs.push_back(r);
     } else if (a.scheme == kTexCoord) {
@@ -535,8 +540,9 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
         HIP_TRY(hipStreamSynchronize(s));
         const uint32_t p0 = aux[i].zero_prob, f1 = 256u - p0;
         launch_orient_prep(a.aux.as<uint8_t>(), n, a.chunk_info.as<uint32_t>(), make_rans_entry(p0, f1, 8), make_rans_entry(f1, 0, 8), a.aux_rec.as<RansEntry>(), s);
+        launch_batch_flags(a.aux_rec.as<RansEntry>(), len, a.aux_flags.as<uint32_t>(), s);
       }
-      r.kind = 2; r.n = len; r.precision = 8; r.state0 = 4096; r.table = a.aux_rec.as<RansEntry>(); r.p0 = aux[i].zero_prob; r.out = a.aux_out.as<uint8_t>(); r.cap = a.aux_cap; r.out_len = a.small.as<uint32_t>() + 10; r.ticks = a.small.as<uint32_t>() + 13;
+      r.kind = 2; r.n = len; r.precision = 8; r.state0 = 4096; r.table = a.aux_rec.as<RansEntry>(); r.force_generic = 0; r.batch_flags = a.aux_flags.as<uint32_t>(); r.out = a.aux_out.as<uint8_t>(); r.cap = a.aux_cap; r.out_len = a.small.as<uint32_t>() + 10; r.ticks = a.small.as<uint32_t>() + 13;
       aux[i].desc = (int)descs.size();
       descs.push_back(r);
     }
