@@ -18,19 +18,20 @@ void launch_quant_oct(const float* vals, uint32_t n_values, int32_t* q, uint32_t
 constexpr int kMaxGather = 4;
 struct GatherAtt { const int32_t* q; const uint32_t* p2v; int32_t* qs; int32_t* minmax; int N; int pad; };
 struct GatherArgs { GatherAtt a[kMaxGather]; int count; };
-void launch_seq_gather(const uint32_t* seq, uint32_t n, const uint32_t* c2v, const uint32_t* c2p, uint32_t* rank, const GatherArgs& args, hipStream_t s);
+void launch_seq_gather(const uint32_t* seq, uint32_t n, const uint32_t* c2p, const GatherArgs& args, hipStream_t s);
 // fn[3f..3f+2] = cross(pos[c1]-pos[c0], pos[c2]-pos[c0]) of the quantised positions of face f (i32, wrapping)
 void launch_face_normals(const uint32_t* c2p, uint32_t nfaces, const uint32_t* pos_p2v, const int32_t* q_pos, int32_t* fn, hipStream_t s);
 
 // ---- predict + transform (a7-a14) → symbols ------------------------------------------------------
-void launch_pred_parallelogram_wrapped(const uint32_t* seq, uint32_t n, const uint32_t* c2v, const uint32_t* opp, const uint32_t* rank,
+// c2r[c] = sequence index of corner c's vertex (DMI_NONE if never coded): "already coded" ⇔ c2r[c] < i
+void launch_pred_parallelogram_wrapped(const uint32_t* seq, uint32_t n, const uint32_t* c2r, const uint32_t* opp,
                                        const int32_t* qs, const int32_t* minmax, int N, uint32_t* sym, hipStream_t s);
 void launch_pred_delta_difference(uint32_t n, const int32_t* qs, int N, uint32_t* sym, hipStream_t s);
 // counters[0] += number of flips that are false
 void launch_pred_normal_octorth(const uint32_t* seq, uint32_t n, const uint32_t* opp_att, const int32_t* fn, const int32_t* qs, uint32_t* sym,
                                 uint8_t* flips, uint32_t* counters, hipStream_t s);
 // orient[i]: 0 = no bit pushed, 1 = false, 2 = true
-void launch_pred_texcoord_wrapped(const uint32_t* seq, uint32_t n, const uint32_t* c2v, const uint32_t* c2p, const uint32_t* rank,
+void launch_pred_texcoord_wrapped(const uint32_t* seq, uint32_t n, const uint32_t* c2r, const uint32_t* c2p,
                                   const int32_t* qs, const uint32_t* pos_p2v, const int32_t* q_pos, uint32_t pos_len,
                                   const int32_t* minmax, uint32_t* sym, uint8_t* orient, hipStream_t s);
 // per-block summaries of the orientation flags, stitched on the host:

@@ -48,8 +48,7 @@ struct DevMem {
 
 struct TableDev {
   uint32_t F = 0, V = 0, n_seq = 0;
-  DevMem c2v, opp, seq, rank;   // c2p is shared by all tables of a job; rank is shared by the attributes of the table
-  bool c2v_is_c2p = false;       // corner_to_vertex identical to corner_to_point: the kernels read one array
+  DevMem c2r, opp, seq;   // c2p is shared by all tables of a job; c2r = corner → sequence index of its vertex
   // sharing: a table whose arrays equal another table's reuses its device copies
   int alias_of = -1;
 };
@@ -254,12 +253,19 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
     if (tables[i].num_faces != F) return fail(DMI_ERR_INVALID_ARGUMENT, "all corner tables must have the same face count");
     if (!tables[i].corner_to_point || !tables[i].corner_to_vertex || !tables[i].opposite) return fail(DMI_ERR_INVALID_ARGUMENT, "corner table arrays missing");
   }
-  rc = upload(job->c2p, tables[0].corner_to_point, C * 4, s);
-  if (rc) return rc;
-
-  // tables: reuse device copies when a table is identical to an earlier one (no seams)
+  // ---- resident layout of the connectivity inputs --------------------------------------------------------
+  // The tables arrive in the mesh's own face/vertex numbering.  Every predictor walks them in the coding
+  // (Edgebreaker) order, so they are re-indexed once, here, into that order (a pure relabelling: the
+  // bitstream does not depend on internal corner / vertex ids):
+  //   * vertices → their sequence index: c2r[c] = rank of vertex(c) in the table's sequence (NONE if never
+  //     coded), so "already coded" (the reference's `contains`) is `c2r[c] < i` with no indirection;
+  //   * faces → ordered by the smallest sequence index among their universal vertices (counting sort), so
+  //     consecutive sequence entries touch consecutive corners;
+  //   * corner-indexed arrays (c2p, opp, c2r) and corner ids stored in `seq` / `opp` follow the new face order.
+  // Tables identical to an earlier one (seam-free attribute tables) reuse its device copies.
   job->tables.resize(n_atts);
   std::vector<std::vector<uint32_t>> host_seq(n_atts);
+  std::vector<const uint32_t*> seq_of(n_atts, nullptr);
   for (uint32_t i = 0; i < n_atts; ++i) {
     TableDev& t = job->tables[i];
     t.F = F;
@@ -273,11 +279,6 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
         t.alias_of = (int)j;
     }
     if (t.alias_of >= 0) { job->atts[i].table = t.alias_of; continue; }
-    t.c2v_is_c2p = std::memcmp(tables[i].corner_to_vertex, tables[0].corner_to_point, C * 4) == 0;
-    if (!t.c2v_is_c2p) { rc = upload(t.c2v, tables[i].corner_to_vertex, C * 4, s); if (rc) return rc; }
-    if ((rc = t.rank.alloc((size_t)t.V * 4))) return rc;
-    rc = upload(t.opp, tables[i].opposite, C * 4, s);
-    if (rc) return rc;
     const uint32_t* seq = tables[i].sequence;
     uint32_t n_seq = tables[i].sequence_len;
     if (!seq) {
@@ -288,9 +289,49 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
       seq = host_seq[i].data();
       n_seq = (uint32_t)host_seq[i].size();
     }
+    for (uint32_t k = 0; k < n_seq; ++k) if (seq[k] >= C) return fail(DMI_ERR_INVALID_ARGUMENT, "sequence entry out of range");
     t.n_seq = n_seq;
-    rc = upload(t.seq, seq, (size_t)n_seq * 4, s);
+    seq_of[i] = seq;
+  }
+  {
+    // face order from table 0 (the universal table)
+    std::vector<uint32_t> rank0(tables[0].num_vertices, kNone);
+    for (uint32_t k = 0; k < job->tables[0].n_seq; ++k) rank0[tables[0].corner_to_vertex[seq_of[0][k]]] = k;
+    const uint32_t nkeys = job->tables[0].n_seq + 1;   // key n_seq: faces none of whose vertices was coded
+    std::vector<uint32_t> key(F), start(nkeys + 1, 0);
+    for (uint32_t f = 0; f < F; ++f) {
+      uint32_t m = kNone;
+      for (int k = 0; k < 3; ++k) m = std::min(m, rank0[tables[0].corner_to_vertex[3 * (size_t)f + k]]);
+      key[f] = (m == kNone) ? nkeys - 1 : m;
+      ++start[key[f] + 1];
+    }
+    for (uint32_t k = 0; k < nkeys; ++k) start[k + 1] += start[k];
+    std::vector<uint32_t> new_face(F);
+    for (uint32_t f = 0; f < F; ++f) new_face[f] = start[key[f]]++;
+    auto map_corner = [&](uint32_t c) { return c == kNone ? kNone : 3u * new_face[c / 3u] + c % 3u; };
+    std::vector<uint32_t> tmp(C), tmp2(C);
+    for (size_t c = 0; c < C; ++c) tmp[map_corner((uint32_t)c)] = tables[0].corner_to_point[c];
+    rc = upload(job->c2p, tmp.data(), C * 4, s);
     if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s));
+    std::vector<uint32_t> rank, seq2;
+    for (uint32_t i = 0; i < n_atts; ++i) {
+      TableDev& t = job->tables[i];
+      if (t.alias_of >= 0) continue;
+      rank.assign(t.V, kNone);
+      for (uint32_t k = 0; k < t.n_seq; ++k) rank[tables[i].corner_to_vertex[seq_of[i][k]]] = k;
+      for (size_t c = 0; c < C; ++c) {
+        const uint32_t c2 = map_corner((uint32_t)c);
+        tmp[c2] = rank[tables[i].corner_to_vertex[c]];
+        tmp2[c2] = map_corner(tables[i].opposite[c]);
+      }
+      if ((rc = upload(t.c2r, tmp.data(), C * 4, s))) return rc;
+      if ((rc = upload(t.opp, tmp2.data(), C * 4, s))) return rc;
+      seq2.resize(t.n_seq);
+      for (uint32_t k = 0; k < t.n_seq; ++k) seq2[k] = map_corner(seq_of[i][k]);
+      if ((rc = upload(t.seq, seq2.data(), (size_t)t.n_seq * 4, s))) return rc;
+      HIP_TRY(hipStreamSynchronize(s));   // tmp/tmp2/seq2 are reused
+    }
   }
 
   size_t pinned_need = 256;
@@ -393,10 +434,9 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
     if (t.alias_of >= 0) continue;
     GatherArgs ga{};
     auto flush = [&]() {
-      if (ga.count) launch_seq_gather(t.seq.as<uint32_t>(), t.n_seq, t.c2v_is_c2p ? c2p : t.c2v.as<uint32_t>(), c2p, t.rank.as<uint32_t>(), ga, s);
+      if (ga.count) launch_seq_gather(t.seq.as<uint32_t>(), t.n_seq, c2p, ga, s);
       ga.count = 0;
     };
-    HIP_TRY(hipMemsetAsync(t.rank.p, 0xFF, t.rank.bytes, s));
     for (auto& a : job->atts) {
       if ((size_t)a.table != ti) continue;
       GatherAtt& g = ga.a[ga.count++];
@@ -417,7 +457,7 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
     if (n == 0) continue;
     switch (a.scheme) {
       case kParallelogram:
-        launch_pred_parallelogram_wrapped(t.seq.as<uint32_t>(), n, (t.c2v_is_c2p ? c2p : t.c2v.as<uint32_t>()), t.opp.as<uint32_t>(), t.rank.as<uint32_t>(), a.qs.as<int32_t>(), minmax, a.nq, a.sym.as<uint32_t>(), s);
+        launch_pred_parallelogram_wrapped(t.seq.as<uint32_t>(), n, t.c2r.as<uint32_t>(), t.opp.as<uint32_t>(), a.qs.as<int32_t>(), minmax, a.nq, a.sym.as<uint32_t>(), s);
         break;
       case kDelta:
         launch_pred_delta_difference(n, a.qs.as<int32_t>(), a.nq, a.sym.as<uint32_t>(), s);
@@ -431,7 +471,7 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
       case kTexCoord: {
         const AttJob& p = job->atts[a.parent];
         const int32_t* qp = p.port == kToBits ? p.raw.as<int32_t>() : p.q.as<int32_t>();
-        launch_pred_texcoord_wrapped(t.seq.as<uint32_t>(), n, (t.c2v_is_c2p ? c2p : t.c2v.as<uint32_t>()), c2p, t.rank.as<uint32_t>(), a.qs.as<int32_t>(), p.p2v.as<uint32_t>(), qp, p.desc.num_points, minmax, a.sym.as<uint32_t>(), a.aux.as<uint8_t>(), s);
+        launch_pred_texcoord_wrapped(t.seq.as<uint32_t>(), n, t.c2r.as<uint32_t>(), c2p, a.qs.as<int32_t>(), p.p2v.as<uint32_t>(), qp, p.desc.num_points, minmax, a.sym.as<uint32_t>(), a.aux.as<uint8_t>(), s);
         launch_orient_summary(a.aux.as<uint8_t>(), n, a.summary.as<uint32_t>(), nullptr, s);
         break;
       }
