@@ -7,20 +7,19 @@
 
 namespace dmi {
 
-// ---- quantization (a4-a6) ----------------------------------------------------------------------
+// ---- quantization (a4-a6), fused with the coding-order gather ---------------------------------------
 // meta layout (floats): [0..N) per-component min, [N] range, [N+1..2N] per-component max (debug)
 void launch_minmax_f32(const float* vals, uint32_t n_values, int N, float* partials, uint32_t max_blocks, float* meta, hipStream_t s);
-void launch_quant_coord(const float* vals, uint32_t n_values, int N, const float* meta, int bits, int32_t* q, hipStream_t s);
-void launch_quant_oct(const float* vals, uint32_t n_values, int32_t* q, uint32_t* zero_flag, hipStream_t s);
-
-// ---- sequence-order gather: rank[c2v[seq[i]]] = i and, for every attribute coded on this table,
-//      qs[i] = q[p2v[c2p[seq[i]]]] plus the joint min/max (minmax: int32[2] pre-initialised to {INT_MAX, INT_MIN})
+void launch_check_normals(const float* vals, uint32_t n_values, uint32_t* zero_flag, hipStream_t s);
+// qs[i] = portabilize(raw[p2v[c2p[seq[i]]]]) for every attribute of one corner table + joint i32 min/max
+// (minmax: int32[2] pre-initialised to {INT_MAX, INT_MIN}).  kind: 0 coordinate-wise, 1 octahedral, 2 ToBits.
 constexpr int kMaxGather = 4;
-struct GatherAtt { const int32_t* q; const uint32_t* p2v; int32_t* qs; int32_t* minmax; int N; int pad; };
-struct GatherArgs { GatherAtt a[kMaxGather]; int count; };
-void launch_seq_gather(const uint32_t* seq, uint32_t n, const uint32_t* c2p, const GatherArgs& args, hipStream_t s);
-// fn[3f..3f+2] = cross(pos[c1]-pos[c0], pos[c2]-pos[c0]) of the quantised positions of face f (i32, wrapping)
-void launch_face_normals(const uint32_t* c2p, uint32_t nfaces, const uint32_t* pos_p2v, const int32_t* q_pos, int32_t* fn, hipStream_t s);
+struct QuantAtt { const float* raw; const uint32_t* p2v; int32_t* qs; int32_t* minmax; const float* meta; float maxq; int kind; int N; int pad; };
+struct QuantArgs { QuantAtt a[kMaxGather]; int count; };
+void launch_seq_quantize(const uint32_t* seq, uint32_t n, const uint32_t* c2p, const QuantArgs& args, hipStream_t s);
+// fn[3f..3f+2] = cross(pos[c1]-pos[c0], pos[c2]-pos[c0]) of the quantised positions of face f (i32, wrapping);
+// c2r_pos / qs_pos: the position attribute's corner→sequence-index table and sequence-ordered values
+void launch_face_normals(const uint32_t* c2r_pos, uint32_t nfaces, const int32_t* qs_pos, int32_t* fn, hipStream_t s);
 
 // ---- predict + transform (a7-a14) → symbols ------------------------------------------------------
 // c2r[c] = sequence index of corner c's vertex (DMI_NONE if never coded): "already coded" ⇔ c2r[c] < i
@@ -31,9 +30,8 @@ void launch_pred_delta_difference(uint32_t n, const int32_t* qs, int N, uint32_t
 void launch_pred_normal_octorth(const uint32_t* seq, uint32_t n, const uint32_t* opp_att, const int32_t* fn, const int32_t* qs, uint32_t* sym,
                                 uint8_t* flips, uint32_t* counters, hipStream_t s);
 // orient[i]: 0 = no bit pushed, 1 = false, 2 = true
-void launch_pred_texcoord_wrapped(const uint32_t* seq, uint32_t n, const uint32_t* c2r, const uint32_t* c2p,
-                                  const int32_t* qs, const uint32_t* pos_p2v, const int32_t* q_pos, uint32_t pos_len,
-                                  const int32_t* minmax, uint32_t* sym, uint8_t* orient, hipStream_t s);
+void launch_pred_texcoord_wrapped(const uint32_t* seq, uint32_t n, const uint32_t* c2r, const int32_t* qs, const uint32_t* c2r_pos,
+                                  const int32_t* qs_pos, const int32_t* minmax, uint32_t* sym, uint8_t* orient, hipStream_t s);
 // per-block summaries of the orientation flags, stitched on the host:
 // summary[b] = {valid_count, first_value(0/1, 2 = none), last_value, internal_transitions}
 void launch_orient_summary(const uint8_t* orient, uint32_t n, uint32_t* summary, uint32_t* n_blocks_out_host, hipStream_t s);

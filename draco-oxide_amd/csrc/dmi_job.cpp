@@ -62,7 +62,7 @@ struct AttJob {
   int nq = 0;            // components after portabilization
   int table = 0;         // index into tables
   int parent = -1;
-  DevMem raw, p2v, q, fn, qs, sym, aux /*flips or orient*/, hist, rtable, rec, out, meta, partials, small /*minmax[2], counters[2], flags[2], out_len[2]*2*/, summary;
+  DevMem raw, p2v, fn, qs, sym, aux /*flips or orient*/, hist, rtable, rec, out, meta, partials, small /*minmax[2], counters[2], flags[2], out_len[2]*2*/, summary;
   uint32_t bins = 0;
   uint64_t n_sym = 0;
   uint64_t out_cap = 0, aux_cap = 0;
@@ -334,6 +334,8 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
     }
   }
 
+  uint32_t max_point = 0;
+  for (size_t c = 0; c < C; ++c) max_point = std::max(max_point, tables[0].corner_to_point[c]);
   size_t pinned_need = 256;
   uint64_t pb = 0;
   for (uint32_t i = 0; i < n_atts; ++i) {
@@ -345,9 +347,9 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
     rc = upload(a.raw, d.values, vbytes, s);
     if (rc) return rc;
     if (d.point_to_value) { rc = upload(a.p2v, d.point_to_value, (size_t)d.num_points * 4, s); if (rc) return rc; }
+    if (d.num_points <= max_point && F) return fail(DMI_ERR_INVALID_ARGUMENT, "attribute " + std::to_string(i) + " has fewer points than the faces reference");
     const uint32_t n = t.n_seq;
     a.n_sym = (uint64_t)n * a.nq;
-    if (a.port != kToBits) { rc = a.q.alloc((size_t)d.num_unique * a.nq * 4); if (rc) return rc; }
     if ((rc = a.qs.alloc((size_t)n * a.nq * 4))) return rc;
     if ((rc = a.sym.alloc((size_t)a.n_sym * 4))) return rc;
     if (a.scheme == kNormal || a.scheme == kTexCoord) {
@@ -411,19 +413,15 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
   const uint32_t* c2p = job->c2p.as<uint32_t>();
   uint8_t* pinned = static_cast<uint8_t*>(job->pinned);
 
-  // ---- stage 1: quantization (portabilization) -------------------------------------------------
+  // ---- stage 1: value ranges (streamed over the unique values) ---------------------------------------------
   if (timed) HIP_TRY(hipEventRecord(job->ev[0], s));
   for (auto& a : job->atts) {
     const dmi_attribute& d = a.desc;
     HIP_TRY(hipMemsetAsync(a.small.p, 0, 64, s));
-    if (a.port == kCoordwise) {
-      launch_minmax_f32(a.raw.as<float>(), d.num_unique, d.num_components, a.partials.as<float>(), 2048, a.meta.as<float>(), s);
-      launch_quant_coord(a.raw.as<float>(), d.num_unique, d.num_components, a.meta.as<float>(), a.bits, a.q.as<int32_t>(), s);
-    } else if (a.port == kOct) {
-      launch_quant_oct(a.raw.as<float>(), d.num_unique, a.q.as<int32_t>(), a.small.as<uint32_t>() + 4, s);
-    }
+    if (a.port == kCoordwise) launch_minmax_f32(a.raw.as<float>(), d.num_unique, d.num_components, a.partials.as<float>(), 2048, a.meta.as<float>(), s);
+    else if (a.port == kOct) launch_check_normals(a.raw.as<float>(), d.num_unique, a.small.as<uint32_t>() + 4, s);
   }
-  // ---- stage 2: sequence-order gather + predict + transform ---------------------------------------
+  // ---- stage 2: portabilization in coding order + predict + transform ---------------------------------------
   if (timed) HIP_TRY(hipEventRecord(job->ev[1], s));
   for (auto& a : job->atts) {
     static const int32_t init_mm[2] = {2147483647, -2147483647 - 1};   // small: [0..1] minmax, [2..3] counters, [4] zero-normal flag, [5] hist overflow
@@ -432,20 +430,23 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
   for (size_t ti = 0; ti < job->tables.size(); ++ti) {
     TableDev& t = job->tables[ti];
     if (t.alias_of >= 0) continue;
-    GatherArgs ga{};
+    QuantArgs qa{};
     auto flush = [&]() {
-      if (ga.count) launch_seq_gather(t.seq.as<uint32_t>(), t.n_seq, c2p, ga, s);
-      ga.count = 0;
+      if (qa.count) launch_seq_quantize(t.seq.as<uint32_t>(), t.n_seq, c2p, qa, s);
+      qa.count = 0;
     };
     for (auto& a : job->atts) {
       if ((size_t)a.table != ti) continue;
-      GatherAtt& g = ga.a[ga.count++];
-      g.q = a.port == kToBits ? a.raw.as<int32_t>() : a.q.as<int32_t>();
+      QuantAtt& g = qa.a[qa.count++];
+      g.raw = a.raw.as<float>();
       g.p2v = a.p2v.as<uint32_t>();
       g.qs = a.qs.as<int32_t>();
       g.minmax = a.small.as<int32_t>();
-      g.N = a.nq;
-      if (ga.count == kMaxGather) flush();
+      g.meta = a.meta.as<float>();
+      g.maxq = (float)(uint64_t)((1ull << a.bits) - 1ull);
+      g.kind = a.port == kCoordwise ? 0 : (a.port == kOct ? 1 : 2);
+      g.N = a.desc.num_components;
+      if (qa.count == kMaxGather) flush();
     }
     flush();
   }
@@ -464,14 +465,13 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
         break;
       case kNormal: {
         const AttJob& p = job->atts[a.parent];
-        launch_face_normals(c2p, t.F, p.p2v.as<uint32_t>(), p.q.as<int32_t>(), a.fn.as<int32_t>(), s);
+        launch_face_normals(job->tables[p.table].c2r.as<uint32_t>(), t.F, p.qs.as<int32_t>(), a.fn.as<int32_t>(), s);
         launch_pred_normal_octorth(t.seq.as<uint32_t>(), n, t.opp.as<uint32_t>(), a.fn.as<int32_t>(), a.qs.as<int32_t>(), a.sym.as<uint32_t>(), a.aux.as<uint8_t>(), counters, s);
         break;
       }
       case kTexCoord: {
         const AttJob& p = job->atts[a.parent];
-        const int32_t* qp = p.port == kToBits ? p.raw.as<int32_t>() : p.q.as<int32_t>();
-        launch_pred_texcoord_wrapped(t.seq.as<uint32_t>(), n, t.c2r.as<uint32_t>(), c2p, a.qs.as<int32_t>(), p.p2v.as<uint32_t>(), qp, p.desc.num_points, minmax, a.sym.as<uint32_t>(), a.aux.as<uint8_t>(), s);
+        launch_pred_texcoord_wrapped(t.seq.as<uint32_t>(), n, t.c2r.as<uint32_t>(), a.qs.as<int32_t>(), job->tables[p.table].c2r.as<uint32_t>(), p.qs.as<int32_t>(), minmax, a.sym.as<uint32_t>(), a.aux.as<uint8_t>(), s);
         launch_orient_summary(a.aux.as<uint8_t>(), n, a.summary.as<uint32_t>(), nullptr, s);
         break;
       }

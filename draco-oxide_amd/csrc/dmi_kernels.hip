@@ -138,23 +138,13 @@ __global__ __launch_bounds__(kBlock) void k_minmax_final(const float* __restrict
   }
 }
 
-// q = trunc(((v - min) / range) * (2^bits - 1) + 0.5), range == 0 skips the divide (Q3).  Flat over components.
-template <int N>
-__global__ __launch_bounds__(kBlock) void k_quant_coord(const float* __restrict__ vals, uint64_t n_comp, const float* __restrict__ meta, float maxq, int32_t* __restrict__ q) {
-  float mn[N];
-#pragma unroll
-  for (int k = 0; k < N; ++k) mn[k] = meta[k];
-  const float range = meta[N];
-  for (uint64_t e = (uint64_t)blockIdx.x * kBlock + threadIdx.x; e < n_comp; e += (uint64_t)gridDim.x * kBlock) {
-    const int k = (int)(e % N);
-    float m = mn[0];
-#pragma unroll
-    for (int j = 1; j < N; ++j) if (k == j) m = mn[j];
-    const float diff = vals[e] - m;
-    const float normalized = (range == 0.0f) ? diff : diff / range;
-    const float quantized = normalized * maxq;
-    q[e] = (int32_t)f32_to_i64_sat(quantized + 0.5f);
-  }
+// q = trunc(((v - min) / range) * (2^bits - 1) + 0.5), range == 0 skips the divide (Q3); every f32 operation
+// rounds separately (no FMA contraction), the cast is Rust's `as i64 as i32`.
+__device__ __forceinline__ int32_t quant_coord(float v, float mn, float range, float maxq) {
+  const float diff = v - mn;
+  const float normalized = (range == 0.0f) ? diff : diff / range;
+  const float quantized = normalized * maxq;
+  return (int32_t)f32_to_i64_sat(quantized + 0.5f);
 }
 
 // geom.rs:40-91 (f32 path; Q5: the fold uses the pre-fold u and v; Q6: no normalisation)
@@ -186,37 +176,39 @@ __device__ __forceinline__ void oct_quantize(float x, float y, float z, int32_t&
   oct_faithful(f32_to_i32_sat(a), f32_to_i32_sat(b), qx, qy);
 }
 
-__global__ __launch_bounds__(kBlock) void k_quant_oct(const float* __restrict__ vals, uint32_t n, int32_t* __restrict__ q, uint32_t* __restrict__ zero_flag) {
-  for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < n; v += gridDim.x * kBlock) {
-    const float x = vals[(size_t)v * 3], y = vals[(size_t)v * 3 + 1], z = vals[(size_t)v * 3 + 2];
-    if (x == 0.0f && y == 0.0f && z == 0.0f) { atomicOr(zero_flag, 1u); q[(size_t)v * 2] = 0; q[(size_t)v * 2 + 1] = 0; continue; }
-    int32_t a, b;
-    oct_quantize(x, y, z, a, b);
-    q[(size_t)v * 2] = a;
-    q[(size_t)v * 2 + 1] = b;
-  }
+// Any zero-length normal is an error in the reference (geom.rs:45 assert): streamed check over the unique values.
+__global__ __launch_bounds__(kBlock) void k_check_normals(const float* __restrict__ vals, uint32_t n, uint32_t* __restrict__ zero_flag) {
+  bool bad = false;
+  for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < n; v += gridDim.x * kBlock)
+    bad |= (vals[(size_t)v * 3] == 0.0f && vals[(size_t)v * 3 + 1] == 0.0f && vals[(size_t)v * 3 + 2] == 0.0f);
+  if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(zero_flag, 1u);
 }
 
 // ------------------------------------------------------------------------------------------------
-// Sequence-order gather.  Each vertex is emitted exactly once by the sequencer, so
-//   rank[v] < i  ⇔  vertices_up_till_now.contains(v)         (the reference's O(V) scan, F10)
-// and, because all corners of one (attribute-)vertex carry the same value,
-//   qs[rank[vertex(c)]] == attribute.get(point_idx(c))        for every already-coded corner c.
+// Portabilization in coding order.  Entry i of the sequence is quantized straight into qs[i]:
+//   qs[i] = portabilize(raw[p2v[point(seq[i])]])          (attribute_encoder.rs:332-338 reads exactly these)
+// so no value-ordered quantized array is ever materialised.  Every attribute coded on the same corner table
+// is served by one launch (they share seq / corner_to_point traffic); the joint i32 min/max of each attribute
+// (wrapped_difference.rs:36-52, Q16) is reduced on the fly.  All corners of one (attribute-)vertex carry the
+// same value, so qs[c2r[c]] == attribute.get(point_idx(c)) for every corner c of the table.
 // ------------------------------------------------------------------------------------------------
-// One launch serves every attribute coded on the same corner table (they share the sequence, hence the
-// rank array and the seq / corner_to_vertex / corner_to_point traffic).
 template <int N>
-__device__ __forceinline__ void gather_one(const GatherAtt& a, uint32_t p, uint32_t i, int32_t& mn, int32_t& mx) {
+__device__ __forceinline__ void quantize_one(const QuantAtt& a, uint32_t p, uint32_t i, int32_t& mn, int32_t& mx) {
   if (a.p2v) p = a.p2v[p];
+  int32_t out[N];
+  int nq = N;
+  if (a.kind == 0) {   // coordinate-wise (meta: min[N], range)
 #pragma unroll
-  for (int k = 0; k < N; ++k) {
-    const int32_t v = a.q[(size_t)p * N + k];
-    a.qs[(size_t)i * N + k] = v;
-    mn = min(mn, v);
-    mx = max(mx, v);
+    for (int k = 0; k < N; ++k) out[k] = quant_coord(a.raw[(size_t)p * N + k], a.meta[k], a.meta[N], a.maxq);
+  } else if (a.kind == 1) {   // octahedral (N == 3 → 2 components)
+    if (N == 3) { int32_t u, v; oct_quantize(a.raw[(size_t)p * 3], a.raw[(size_t)p * 3 + 1], a.raw[(size_t)p * 3 + 2], u, v); out[0] = u; out[1] = v; nq = 2; }
+  } else {   // ToBits: the 4-byte values reinterpreted as i32
+#pragma unroll
+    for (int k = 0; k < N; ++k) out[k] = __float_as_int(a.raw[(size_t)p * N + k]);
   }
+  for (int k = 0; k < nq; ++k) { a.qs[(size_t)i * nq + k] = out[k]; mn = min(mn, out[k]); mx = max(mx, out[k]); }
 }
-__global__ __launch_bounds__(kBlock) void k_seq_gather(const uint32_t* __restrict__ seq, uint32_t n, const uint32_t* __restrict__ c2p, GatherArgs args) {
+__global__ __launch_bounds__(kBlock) void k_seq_quantize(const uint32_t* __restrict__ seq, uint32_t n, const uint32_t* __restrict__ c2p, QuantArgs args) {
   int32_t mn[kMaxGather], mx[kMaxGather];
 #pragma unroll
   for (int a = 0; a < kMaxGather; ++a) { mn[a] = 2147483647; mx[a] = (-2147483647 - 1); }
@@ -226,10 +218,10 @@ __global__ __launch_bounds__(kBlock) void k_seq_gather(const uint32_t* __restric
     for (int a = 0; a < kMaxGather; ++a) {
       if (a >= args.count) break;
       switch (args.a[a].N) {
-        case 1: gather_one<1>(args.a[a], p, i, mn[a], mx[a]); break;
-        case 2: gather_one<2>(args.a[a], p, i, mn[a], mx[a]); break;
-        case 3: gather_one<3>(args.a[a], p, i, mn[a], mx[a]); break;
-        default: gather_one<4>(args.a[a], p, i, mn[a], mx[a]); break;
+        case 1: quantize_one<1>(args.a[a], p, i, mn[a], mx[a]); break;
+        case 2: quantize_one<2>(args.a[a], p, i, mn[a], mx[a]); break;
+        case 3: quantize_one<3>(args.a[a], p, i, mn[a], mx[a]); break;
+        default: quantize_one<4>(args.a[a], p, i, mn[a], mx[a]); break;
       }
     }
   }
@@ -247,15 +239,17 @@ __global__ __launch_bounds__(kBlock) void k_seq_gather(const uint32_t* __restric
 //   cross(pos[next(cc)] - pos[cc], pos[prev(cc)] - pos[cc])
 // is the same vector (cyclic invariance holds in the ring Z/2^32), and every corner of a vertex fan sits at
 // the fan vertex's position, so mesh_normal_prediction.rs:22-44 evaluates exactly fn[face(cc)] per fan face.
-__global__ __launch_bounds__(kBlock) void k_face_normals(const uint32_t* __restrict__ c2p, uint32_t nfaces, const uint32_t* __restrict__ pos_p2v,
-                                                         const int32_t* __restrict__ q_pos, int32_t* __restrict__ fn) {
+__global__ __launch_bounds__(kBlock) void k_face_normals(const uint32_t* __restrict__ c2r_pos, uint32_t nfaces, const int32_t* __restrict__ qs_pos,
+                                                         int32_t* __restrict__ fn) {
   for (uint32_t f = blockIdx.x * kBlock + threadIdx.x; f < nfaces; f += gridDim.x * kBlock) {
-    uint32_t p0 = c2p[(size_t)3 * f], p1 = c2p[(size_t)3 * f + 1], p2 = c2p[(size_t)3 * f + 2];
-    if (pos_p2v) { p0 = pos_p2v[p0]; p1 = pos_p2v[p1]; p2 = pos_p2v[p2]; }
-    const int32_t ax = wsub(q_pos[(size_t)p1 * 3], q_pos[(size_t)p0 * 3]), ay = wsub(q_pos[(size_t)p1 * 3 + 1], q_pos[(size_t)p0 * 3 + 1]),
-                  az = wsub(q_pos[(size_t)p1 * 3 + 2], q_pos[(size_t)p0 * 3 + 2]);
-    const int32_t bx = wsub(q_pos[(size_t)p2 * 3], q_pos[(size_t)p0 * 3]), by = wsub(q_pos[(size_t)p2 * 3 + 1], q_pos[(size_t)p0 * 3 + 1]),
-                  bz = wsub(q_pos[(size_t)p2 * 3 + 2], q_pos[(size_t)p0 * 3 + 2]);
+    // position of a corner = qs_pos[sequence index of its vertex in the position attribute's table]
+    const uint32_t r0 = c2r_pos[(size_t)3 * f], r1 = c2r_pos[(size_t)3 * f + 1], r2 = c2r_pos[(size_t)3 * f + 2];
+    int32_t p0[3] = {0, 0, 0}, p1[3] = {0, 0, 0}, p2[3] = {0, 0, 0};
+    if (r0 != kNoneD) { p0[0] = qs_pos[(size_t)r0 * 3]; p0[1] = qs_pos[(size_t)r0 * 3 + 1]; p0[2] = qs_pos[(size_t)r0 * 3 + 2]; }
+    if (r1 != kNoneD) { p1[0] = qs_pos[(size_t)r1 * 3]; p1[1] = qs_pos[(size_t)r1 * 3 + 1]; p1[2] = qs_pos[(size_t)r1 * 3 + 2]; }
+    if (r2 != kNoneD) { p2[0] = qs_pos[(size_t)r2 * 3]; p2[1] = qs_pos[(size_t)r2 * 3 + 1]; p2[2] = qs_pos[(size_t)r2 * 3 + 2]; }
+    const int32_t ax = wsub(p1[0], p0[0]), ay = wsub(p1[1], p0[1]), az = wsub(p1[2], p0[2]);
+    const int32_t bx = wsub(p2[0], p0[0]), by = wsub(p2[1], p0[1]), bz = wsub(p2[2], p0[2]);
     fn[(size_t)3 * f] = wsub(wmul(ay, bz), wmul(az, by));
     fn[(size_t)3 * f + 1] = wsub(wmul(az, bx), wmul(ax, bz));
     fn[(size_t)3 * f + 2] = wsub(wmul(ax, by), wmul(ay, bx));
@@ -415,9 +409,8 @@ __device__ __forceinline__ uint64_t int_sqrt(uint64_t value) {
 }
 
 __global__ __launch_bounds__(kBlock) void k_pred_texcoord_wrapped(const uint32_t* __restrict__ seq, uint32_t n, const uint32_t* __restrict__ c2r,
-                                                                  const uint32_t* __restrict__ c2p,
-                                                                  const int32_t* __restrict__ qs, const uint32_t* __restrict__ pos_p2v,
-                                                                  const int32_t* __restrict__ q_pos, uint32_t pos_len, const int32_t* __restrict__ minmax,
+                                                                  const int32_t* __restrict__ qs, const uint32_t* __restrict__ c2r_pos,
+                                                                  const int32_t* __restrict__ qs_pos, const int32_t* __restrict__ minmax,
                                                                   uint32_t* __restrict__ sym, uint8_t* __restrict__ orient) {
   const WrapParams w = wrap_params(minmax);
   DMI_FOR_SEQUENCE(i, n) {
@@ -432,15 +425,15 @@ __global__ __launch_bounds__(kBlock) void k_pred_texcoord_wrapped(const uint32_t
       if (nu0 == pu0 && nu1 == pu1) {
         pred0 = (int32_t)pu0; pred1 = (int32_t)pu1; done = true;   // degenerate: identical neighbour UVs
       } else {
-        auto pos_of = [&](uint32_t corner, int64_t* out) {   // get_position_for_vertex :22-30
-          const uint32_t p = c2p[corner];
-          if (p < pos_len) {
-            const uint32_t v = pos_p2v ? pos_p2v[p] : p;
-            out[0] = q_pos[(size_t)v * 3]; out[1] = q_pos[(size_t)v * 3 + 1]; out[2] = q_pos[(size_t)v * 3 + 2];
-          } else { out[0] = out[1] = out[2] = 0; }
+        // get_position_for_vertex :22-30 — position of a corner = qs_pos[its vertex's sequence index in the
+        // position attribute's table]; when both attributes share a table these are i, rn, rp themselves.
+        auto pos_at = [&](uint32_t r, int64_t* out) {
+          if (r != kNoneD) { out[0] = qs_pos[(size_t)r * 3]; out[1] = qs_pos[(size_t)r * 3 + 1]; out[2] = qs_pos[(size_t)r * 3 + 2]; }
+          else { out[0] = out[1] = out[2] = 0; }
         };
+        const bool shared = (c2r_pos == c2r);
         int64_t cp[3], np[3], pp[3];
-        pos_of(c, cp); pos_of(nc, np); pos_of(pc, pp);
+        pos_at(shared ? i : c2r_pos[c], cp); pos_at(shared ? rn : c2r_pos[nc], np); pos_at(shared ? rp : c2r_pos[pc], pp);
         const int64_t pn0 = wsub64(pp[0], np[0]), pn1 = wsub64(pp[1], np[1]), pn2 = wsub64(pp[2], np[2]);
         const uint64_t pn2sq = (uint64_t)wadd64(wadd64(wmul64(pn0, pn0), wmul64(pn1, pn1)), wmul64(pn2, pn2));
         if (pn2sq != 0) {
@@ -557,28 +550,16 @@ void launch_minmax_f32(const float* vals, uint32_t n, int N, float* partials, ui
   }
 }
 
-void launch_quant_coord(const float* vals, uint32_t n, int N, const float* meta, int bits, int32_t* q, hipStream_t s) {
-  const float maxq = (float)(uint64_t)((1ull << bits) - 1ull);
-  const uint64_t nc = (uint64_t)n * N;
-  const uint32_t g = grid_for(nc);
-  switch (N) {
-    case 1: hipLaunchKernelGGL(k_quant_coord<1>, g, kBlock, 0, s, vals, nc, meta, maxq, q); break;
-    case 2: hipLaunchKernelGGL(k_quant_coord<2>, g, kBlock, 0, s, vals, nc, meta, maxq, q); break;
-    case 3: hipLaunchKernelGGL(k_quant_coord<3>, g, kBlock, 0, s, vals, nc, meta, maxq, q); break;
-    default: hipLaunchKernelGGL(k_quant_coord<4>, g, kBlock, 0, s, vals, nc, meta, maxq, q); break;
-  }
+void launch_check_normals(const float* vals, uint32_t n, uint32_t* zero_flag, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_check_normals, grid_for(n), kBlock, 0, s, vals, n, zero_flag);
 }
 
-void launch_quant_oct(const float* vals, uint32_t n, int32_t* q, uint32_t* zero_flag, hipStream_t s) {
-  hipLaunchKernelGGL(k_quant_oct, grid_for(n), kBlock, 0, s, vals, n, q, zero_flag);
+void launch_seq_quantize(const uint32_t* seq, uint32_t n, const uint32_t* c2p, const QuantArgs& args, hipStream_t s) {
+  hipLaunchKernelGGL(k_seq_quantize, grid_for(n), kBlock, 0, s, seq, n, c2p, args);
 }
 
-void launch_seq_gather(const uint32_t* seq, uint32_t n, const uint32_t* c2p, const GatherArgs& args, hipStream_t s) {
-  hipLaunchKernelGGL(k_seq_gather, grid_for(n), kBlock, 0, s, seq, n, c2p, args);
-}
-
-void launch_face_normals(const uint32_t* c2p, uint32_t nfaces, const uint32_t* pos_p2v, const int32_t* q_pos, int32_t* fn, hipStream_t s) {
-  if (nfaces) hipLaunchKernelGGL(k_face_normals, grid_for(nfaces), kBlock, 0, s, c2p, nfaces, pos_p2v, q_pos, fn);
+void launch_face_normals(const uint32_t* c2r_pos, uint32_t nfaces, const int32_t* qs_pos, int32_t* fn, hipStream_t s) {
+  if (nfaces) hipLaunchKernelGGL(k_face_normals, grid_for(nfaces), kBlock, 0, s, c2r_pos, nfaces, qs_pos, fn);
 }
 
 void launch_pred_parallelogram_wrapped(const uint32_t* seq, uint32_t n, const uint32_t* c2r, const uint32_t* opp,
@@ -602,10 +583,9 @@ void launch_pred_normal_octorth(const uint32_t* seq, uint32_t n, const uint32_t*
   hipLaunchKernelGGL(k_pred_normal_octorth, grid_for(n), kBlock, 0, s, seq, n, opp_att, fn, qs, sym, flips, counters);
 }
 
-void launch_pred_texcoord_wrapped(const uint32_t* seq, uint32_t n, const uint32_t* c2r, const uint32_t* c2p, const int32_t* qs,
-                                  const uint32_t* pos_p2v, const int32_t* q_pos, uint32_t pos_len, const int32_t* minmax, uint32_t* sym,
-                                  uint8_t* orient, hipStream_t s) {
-  hipLaunchKernelGGL(k_pred_texcoord_wrapped, grid_for(n), kBlock, 0, s, seq, n, c2r, c2p, qs, pos_p2v, q_pos, pos_len, minmax, sym, orient);
+void launch_pred_texcoord_wrapped(const uint32_t* seq, uint32_t n, const uint32_t* c2r, const int32_t* qs, const uint32_t* c2r_pos,
+                                  const int32_t* qs_pos, const int32_t* minmax, uint32_t* sym, uint8_t* orient, hipStream_t s) {
+  hipLaunchKernelGGL(k_pred_texcoord_wrapped, grid_for(n), kBlock, 0, s, seq, n, c2r, qs, c2r_pos, qs_pos, minmax, sym, orient);
 }
 
 uint32_t orient_summary_blocks(uint32_t n) { return (n + kOrientChunk - 1) / kOrientChunk; }
