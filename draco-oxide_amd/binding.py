@@ -62,7 +62,7 @@ class _Conn(C.Structure):
     _fields_ = [("num_tables", C.c_uint32), ("tables", C.POINTER(_CornerTable)), ("seeds", C.c_void_p), ("num_seeds", C.c_uint32), ("owner", C.c_void_p)]
 
 
-EXPORTS = ["dmi_encode_attributes", "dmi_job_create", "dmi_job_encode", "dmi_job_timings", "dmi_job_destroy", "dmi_encode_mesh",
+EXPORTS = ["dmi_encode_attributes", "dmi_encode_attributes_batch", "dmi_jobs_encode", "dmi_job_create", "dmi_job_encode", "dmi_job_timings", "dmi_job_destroy", "dmi_encode_mesh",
            "dmi_mesh_prepare", "dmi_encode_connectivity", "dmi_conn_free", "dmi_free", "dmi_strerror", "dmi_last_error", "dmi_device_count"]
 
 
@@ -92,6 +92,7 @@ def load_library():
     L.dmi_encode_attributes.argtypes = [C.POINTER(_Attribute), C.POINTER(_CornerTable), C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(_Config), C.POINTER(_Buffer)]
     L.dmi_job_create.argtypes = [C.POINTER(_Attribute), C.POINTER(_CornerTable), C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(_Config), C.POINTER(C.c_void_p)]
     L.dmi_job_encode.argtypes = [C.c_void_p, C.POINTER(_Buffer)]
+    L.dmi_jobs_encode.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(_Buffer)]
     L.dmi_job_timings.argtypes = [C.c_void_p, C.POINTER(_Timings)]
     L.dmi_job_destroy.argtypes = [C.c_void_p]
     L.dmi_encode_mesh.argtypes = [C.POINTER(_Mesh), C.POINTER(_Config), C.POINTER(_Buffer)]
@@ -409,6 +410,17 @@ class Job:
             self.close()
         except Exception:
             pass
+
+
+def jobs_encode(jobs):
+    """Batch form: all jobs (created with the same Config.stream) are encoded together — one host wait for all
+    histograms and ONE launch holding every rANS/rABS stream.  Returns the list of attribute sections."""
+    L = load_library()
+    n = len(jobs)
+    handles = (C.c_void_p * n)(*[j._h for j in jobs])
+    outs = (_Buffer * n)()
+    _check(L.dmi_jobs_encode(handles, n, outs))
+    return [_take(outs[i]) for i in range(n)]
 
 
 def mesh_prepare(mesh, cfg=None):

@@ -53,6 +53,8 @@ struct TableDev {
   int alias_of = -1;
 };
 
+struct AuxInfo { uint8_t zero_prob = 0; uint32_t count = 0; int desc = -1; };
+
 struct AttJob {
   dmi_attribute desc{};
   Scheme scheme = kDelta;
@@ -68,6 +70,8 @@ struct AttJob {
   uint64_t out_cap = 0, aux_cap = 0;
   DevMem aux_out, aux_rec, chunk_info, batch_flags, aux_flags;
   FreqTable ft;
+  std::vector<RansEntry> rt_host;     // staging (kept alive until the copies have been issued)
+  std::vector<uint32_t> info_host;
 };
 
 }  // namespace
@@ -89,6 +93,12 @@ struct dmi_job {
   bool have_events = false;
   dmi_timings last{};
   uint64_t predict_bytes = 0;
+  struct Run {   // state carried between the phases of one encode
+    std::vector<size_t> pin_off;
+    std::vector<AuxInfo> aux;
+    std::vector<ChainDesc> descs;
+    std::vector<std::vector<uint8_t>> rans_bytes, aux_bytes;
+  } run;
   ~dmi_job() {
     if (pinned) (void)hipHostFree(pinned);
     if (have_events) for (auto& e : ev) (void)hipEventDestroy(e);
@@ -403,16 +413,15 @@ int dmi_job_timings(const dmi_job* job, dmi_timings* t) {
   return DMI_OK;
 }
 
-int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
-  if (!job || !out) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
+// The encode pipeline of one job, split at its host synchronisation points so that a batch of jobs can share
+// them (one sync for all histograms, ONE k_chains launch holding every stream of every job).
+static int encode_phase_a(dmi_job* job) {   // device: ranges → coding-order portabilization → predict → histograms; async read-back
   HIP_TRY(hipSetDevice(job->cfg.device));
   hipStream_t s = job->stream;
-  const bool timed = job->have_events;
-  const auto wall0 = std::chrono::steady_clock::now();
   const uint32_t n_atts = (uint32_t)job->atts.size();
-  const uint32_t* c2p = job->c2p.as<uint32_t>();
   uint8_t* pinned = static_cast<uint8_t*>(job->pinned);
-
+  const bool timed = job->have_events;
+  const uint32_t* c2p = job->c2p.as<uint32_t>();
   // ---- stage 1: value ranges (streamed over the unique values) ---------------------------------------------
   if (timed) HIP_TRY(hipEventRecord(job->ev[0], s));
   for (auto& a : job->atts) {
@@ -479,7 +488,8 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
   }
   // ---- stage 3: histograms ---------------------------------------------------------------------------
   if (timed) HIP_TRY(hipEventRecord(job->ev[2], s));
-  std::vector<size_t> pin_off(n_atts);
+  std::vector<size_t>& pin_off = job->run.pin_off;
+  pin_off.assign(n_atts, 0);
   size_t off = 0;
   for (uint32_t i = 0; i < n_atts; ++i) {
     AttJob& a = job->atts[i];
@@ -508,14 +518,19 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
     off = (o2 + 63) & ~(size_t)63;
   }
   if (timed) HIP_TRY(hipEventRecord(job->ev[3], s));
-  HIP_TRY(hipStreamSynchronize(s));
-  const auto t_tab0 = std::chrono::steady_clock::now();
+  return DMI_OK;
+}
 
+static int encode_phase_b(dmi_job* job) {   // host: table normalisation; device: coding records; fills job->run.descs
+  hipStream_t s = job->stream;
+  const uint32_t n_atts = (uint32_t)job->atts.size();
+  uint8_t* pinned = static_cast<uint8_t*>(job->pinned);
   // ---- stage 4 (host): normalise tables, build chain descriptors -----------------------------------------
-  std::vector<ChainDesc> descs;
-  struct AuxInfo { uint8_t zero_prob = 0; uint32_t count = 0; int desc = -1; };
-  std::vector<AuxInfo> aux(n_atts);
-  std::vector<int> rans_desc(n_atts, -1);
+  std::vector<ChainDesc>& descs = job->run.descs;
+  descs.clear();
+  std::vector<AuxInfo>& aux = job->run.aux;
+  aux.assign(n_atts, AuxInfo{});
+  const std::vector<size_t>& pin_off = job->run.pin_off;
   std::string err;
   for (uint32_t i = 0; i < n_atts; ++i) {
     AttJob& a = job->atts[i];
@@ -528,16 +543,15 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
     const uint32_t* hist = reinterpret_cast<const uint32_t*>(base + 128);
     int rc = a.ft.build(hist, a.bins, err);
     if (rc) return fail(rc, err);
-    std::vector<RansEntry> rt(a.ft.freq.size());
+    std::vector<RansEntry>& rt = a.rt_host;
+    rt.resize(a.ft.freq.size());
     for (size_t k = 0; k < rt.size(); ++k) rt[k] = make_rans_entry(a.ft.freq[k], a.ft.cum[k], a.ft.precision);
     HIP_TRY(hipMemcpyAsync(a.rtable.p, rt.data(), rt.size() * sizeof(RansEntry), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));   // rt is a stack-scoped staging vector
     // symbols → coding records in coding order (data-parallel), consumed by the scalar chain
     launch_rans_prep(a.sym.as<uint32_t>(), a.n_sym, a.rtable.as<RansEntry>(), a.rec.as<RansEntry>(), a.batch_flags.as<uint32_t>(), s);
     ChainDesc d{};
     d.kind = 0; d.precision = a.ft.precision; d.n = a.n_sym; d.sym = a.sym.as<uint32_t>(); d.table = a.rec.as<RansEntry>(); d.state0 = 4u << a.ft.precision; d.batch_flags = a.batch_flags.as<uint32_t>();
     d.out = a.out.as<uint8_t>(); d.cap = a.out_cap; d.out_len = a.small.as<uint32_t>() + 8; d.ticks = a.small.as<uint32_t>() + 12;
-    rans_desc[i] = (int)descs.size();
     descs.push_back(d);
     if (a.scheme == kNormal) {
       // mesh_normal_prediction.rs:147-150
@@ -571,13 +585,13 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
       aux[i].count = (uint32_t)len;
       ChainDesc r{};
       {   // compact offsets + successor values per 4096-flag chunk, then flags → coding records on the device
-        std::vector<uint32_t> info(2 * (size_t)std::max(1u, nb));
+        std::vector<uint32_t>& info = a.info_host;
+        info.assign(2 * (size_t)std::max(1u, nb), 0u);
         uint32_t off = 0;
         for (uint32_t b = 0; b < nb; ++b) { info[2 * b] = off; off += sm[4 * b]; }
         uint32_t nextv = 1;   // `true` after the last valid entry
         for (uint32_t b = nb; b-- > 0;) { info[2 * b + 1] = nextv; if (sm[4 * b]) nextv = sm[4 * b + 1]; }
         HIP_TRY(hipMemcpyAsync(a.chunk_info.p, info.data(), info.size() * 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipStreamSynchronize(s));
         const uint32_t p0 = aux[i].zero_prob, f1 = 256u - p0;
         launch_orient_prep(a.aux.as<uint8_t>(), n, a.chunk_info.as<uint32_t>(), make_rans_entry(p0, f1, 8), make_rans_entry(f1, 0, 8), a.aux_rec.as<RansEntry>(), s);
         launch_batch_flags(a.aux_rec.as<RansEntry>(), len, a.aux_flags.as<uint32_t>(), s);
@@ -587,16 +601,27 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
       descs.push_back(r);
     }
   }
-  HIP_TRY(hipMemcpyAsync(job->descs.p, descs.data(), descs.size() * sizeof(ChainDesc), hipMemcpyHostToDevice, s));
-  const auto t_tab1 = std::chrono::steady_clock::now();
+  return DMI_OK;
+}
 
-  // ---- stage 5: serial coders, one wavefront per stream -------------------------------------------------
-  if (timed) HIP_TRY(hipEventRecord(job->ev[4], s));
-  launch_chains(job->descs.as<ChainDesc>(), (uint32_t)descs.size(), s);
-  if (timed) HIP_TRY(hipEventRecord(job->ev[5], s));
-  for (uint32_t i = 0; i < n_atts; ++i) HIP_TRY(hipMemcpyAsync(pinned + pin_off[i], job->atts[i].small.p, 64, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  std::vector<std::vector<uint8_t>> rans_bytes(n_atts), aux_bytes(n_atts);
+static int encode_phase_c1(dmi_job* job) {   // after the chains: async read-back of lengths / error flags
+  hipStream_t s = job->stream;
+  const uint32_t n_atts = (uint32_t)job->atts.size();
+  uint8_t* pinned = static_cast<uint8_t*>(job->pinned);
+  for (uint32_t i = 0; i < n_atts; ++i) HIP_TRY(hipMemcpyAsync(pinned + job->run.pin_off[i], job->atts[i].small.p, 64, hipMemcpyDeviceToHost, s));
+  return DMI_OK;
+}
+
+static int encode_phase_c2(dmi_job* job) {   // lengths known: async copy of the coded bytes
+  hipStream_t s = job->stream;
+  const uint32_t n_atts = (uint32_t)job->atts.size();
+  uint8_t* pinned = static_cast<uint8_t*>(job->pinned);
+  auto& rans_bytes = job->run.rans_bytes;
+  auto& aux_bytes = job->run.aux_bytes;
+  rans_bytes.assign(n_atts, {});
+  aux_bytes.assign(n_atts, {});
+  const std::vector<size_t>& pin_off = job->run.pin_off;
+  const std::vector<AuxInfo>& aux = job->run.aux;
   for (uint32_t i = 0; i < n_atts; ++i) {
     AttJob& a = job->atts[i];
     const uint32_t* small = reinterpret_cast<const uint32_t*>(pinned + pin_off[i]);
@@ -609,8 +634,16 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
       if (small[10]) HIP_TRY(hipMemcpyAsync(aux_bytes[i].data(), a.aux_out.p, small[10], hipMemcpyDeviceToHost, s));
     }
   }
-  HIP_TRY(hipStreamSynchronize(s));
+  return DMI_OK;
+}
 
+static int encode_phase_c3(dmi_job* job, dmi_buffer* out) {   // host: splice the attribute section
+  const uint32_t n_atts = (uint32_t)job->atts.size();
+  uint8_t* pinned = static_cast<uint8_t*>(job->pinned);
+  const std::vector<size_t>& pin_off = job->run.pin_off;
+  const std::vector<AuxInfo>& aux = job->run.aux;
+  const auto& rans_bytes = job->run.rans_bytes;
+  const auto& aux_bytes = job->run.aux_bytes;
   // ---- stage 6 (host): splice the attribute section (encode/attribute/mod.rs:26-57, attribute_encoder.rs:159-160,344-386)
   ByteSink w;
   w.u8((uint8_t)n_atts);
@@ -656,8 +689,30 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
       w.u8(8);                     // octahedral_quantization.rs:43
     }
   }
-  int rc = to_buffer(w.b, out);
+  return to_buffer(w.b, out);
+}
+
+int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
+  if (!job || !out) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
+  hipStream_t s = job->stream;
+  const bool timed = job->have_events;
+  const auto wall0 = std::chrono::steady_clock::now();
+  int rc = encode_phase_a(job);
   if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(s));
+  const auto t_tab0 = std::chrono::steady_clock::now();
+  if ((rc = encode_phase_b(job))) return rc;
+  const std::vector<ChainDesc>& descs = job->run.descs;
+  HIP_TRY(hipMemcpyAsync(job->descs.p, descs.data(), descs.size() * sizeof(ChainDesc), hipMemcpyHostToDevice, s));
+  const auto t_tab1 = std::chrono::steady_clock::now();
+  if (timed) HIP_TRY(hipEventRecord(job->ev[4], s));
+  launch_chains(job->descs.as<ChainDesc>(), (uint32_t)descs.size(), s);
+  if (timed) HIP_TRY(hipEventRecord(job->ev[5], s));
+  if ((rc = encode_phase_c1(job))) return rc;
+  HIP_TRY(hipStreamSynchronize(s));
+  if ((rc = encode_phase_c2(job))) return rc;
+  HIP_TRY(hipStreamSynchronize(s));
+  if ((rc = encode_phase_c3(job, out))) return rc;
 
   dmi_timings tm{};
   if (timed) {
@@ -676,6 +731,42 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
   return DMI_OK;
 }
 
+// Batch form: every job's data-parallel stages are queued back to back, the host waits once, and all rANS/rABS
+// streams of all jobs run in ONE k_chains launch (thousands of wavefronts — the regime where the one-wavefront-
+// per-stream coder fills the chip).  All jobs must live on the same device; they are serialised on jobs[0]'s
+// stream order-wise by using each job's own stream only when they are the same stream (see dmi_encode_attributes_batch).
+int dmi_jobs_encode(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
+  if (!jobs || !outs || n == 0) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
+  for (uint32_t j = 0; j < n; ++j) if (!jobs[j] || jobs[j]->cfg.device != jobs[0]->cfg.device) return fail(DMI_ERR_INVALID_ARGUMENT, "batched jobs must live on one device");
+  // jobs created with one shared dmi_config.stream need a single wait per phase; otherwise every distinct stream is waited for
+  auto sync_all = [&]() -> int {
+    hipStream_t last = nullptr;
+    for (uint32_t j = 0; j < n; ++j) { if (j && jobs[j]->stream == last) continue; last = jobs[j]->stream; HIP_TRY(hipStreamSynchronize(last)); }
+    return DMI_OK;
+  };
+  hipStream_t s = jobs[0]->stream;
+  int rc;
+  for (uint32_t j = 0; j < n; ++j) if ((rc = encode_phase_a(jobs[j]))) return rc;
+  if ((rc = sync_all())) return rc;
+  std::vector<ChainDesc> all;
+  for (uint32_t j = 0; j < n; ++j) {
+    if ((rc = encode_phase_b(jobs[j]))) return rc;
+    all.insert(all.end(), jobs[j]->run.descs.begin(), jobs[j]->run.descs.end());
+  }
+  if ((rc = sync_all())) return rc;   // coding records of every job are in place
+  DevMem descs_dev;
+  if ((rc = descs_dev.alloc(all.size() * sizeof(ChainDesc)))) return rc;
+  HIP_TRY(hipMemcpyAsync(descs_dev.p, all.data(), all.size() * sizeof(ChainDesc), hipMemcpyHostToDevice, s));
+  launch_chains(descs_dev.as<ChainDesc>(), (uint32_t)all.size(), s);
+  HIP_TRY(hipStreamSynchronize(s));
+  for (uint32_t j = 0; j < n; ++j) if ((rc = encode_phase_c1(jobs[j]))) return rc;
+  if ((rc = sync_all())) return rc;
+  for (uint32_t j = 0; j < n; ++j) if ((rc = encode_phase_c2(jobs[j]))) return rc;
+  if ((rc = sync_all())) return rc;
+  for (uint32_t j = 0; j < n; ++j) if ((rc = encode_phase_c3(jobs[j], &outs[j]))) return rc;
+  return DMI_OK;
+}
+
 int dmi_encode_attributes(const dmi_attribute* atts, const dmi_corner_table* tables, uint32_t n_atts, const uint32_t* seeds, uint32_t n_seeds,
                           const dmi_config* cfg, dmi_buffer* out) {
   dmi_job* job = nullptr;
@@ -683,6 +774,22 @@ int dmi_encode_attributes(const dmi_attribute* atts, const dmi_corner_table* tab
   if (rc) return rc;
   rc = dmi_job_encode(job, out);
   dmi_job_destroy(job);
+  return rc;
+}
+
+int dmi_encode_attributes_batch(const dmi_batch_item* items, uint32_t n, const dmi_config* cfg_in, dmi_buffer* outs) {
+  if (!items || !outs || n == 0) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
+  dmi_config cfg{};
+  if (cfg_in) cfg = *cfg_in;
+  HIP_TRY(hipSetDevice(cfg.device));
+  hipStream_t own = nullptr;
+  if (!cfg.stream) { HIP_TRY(hipStreamCreate(&own)); cfg.stream = own; }
+  std::vector<dmi_job*> jobs(n, nullptr);
+  int rc = DMI_OK;
+  for (uint32_t j = 0; j < n && !rc; ++j) rc = dmi_job_create(items[j].atts, items[j].tables, items[j].n_atts, items[j].seeds, items[j].n_seeds, &cfg, &jobs[j]);
+  if (!rc) rc = dmi_jobs_encode(jobs.data(), n, outs);
+  for (auto* j : jobs) dmi_job_destroy(j);
+  if (own) (void)hipStreamDestroy(own);
   return rc;
 }
 

@@ -123,6 +123,22 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out);
 int dmi_job_timings(const dmi_job* job, dmi_timings* t);
 void dmi_job_destroy(dmi_job* job);
 
+/* --- Batches of independent meshes (the glTF transcoder calls encode::encode once per primitive:
+ * io/gltf/encode.rs:932-955,1827-1842).  All jobs must have been created with the same dmi_config.stream.
+ * Their data-parallel stages are queued back to back, the host waits once for every histogram, and every
+ * rANS/rABS stream of every job runs in ONE launch (one wavefront per stream).  outs[j] receives job j's
+ * attribute section. */
+int dmi_jobs_encode(dmi_job** jobs, uint32_t n_jobs, dmi_buffer* outs);
+typedef struct dmi_batch_item {
+  const dmi_attribute* atts;
+  const dmi_corner_table* tables;
+  uint32_t n_atts;
+  const uint32_t* seeds;
+  uint32_t n_seeds;
+} dmi_batch_item;
+/* dmi_encode_attributes for n meshes at once (host pointers in, n attribute sections out). */
+int dmi_encode_attributes_batch(const dmi_batch_item* items, uint32_t n, const dmi_config* cfg, dmi_buffer* outs);
+
 /* --- Drop-in for encode::encode(mesh, writer, Config::default()) (encode/mod.rs:59-97) ----------
  * Host: header, Edgebreaker connectivity, corner tables, sequencer.  Device: attribute section.
  * `faces` are point indices (Mesh::faces); atts[0] must be the Position attribute

@@ -199,3 +199,19 @@ def test_ten_million_triangles_full_attribute_set():
     if os.environ.get("DMI_SKIP_FULL_ORACLE") != "1":
         want = oracle_from_product_mesh(mesh).encode(dump=False)
         _assert_same(head + a, want, "10M triangles")
+
+
+def test_batch_of_meshes_one_chain_launch():
+    """dmi_jobs_encode: many independent meshes, one host wait for the histograms, ONE launch with every
+    rANS/rABS stream; each attribute section must equal the single-job (and oracle) result."""
+    specs = [(12, False, True, True), (40, True, True, True), (25, False, False, False), (64, False, True, True),
+             (33, True, False, True), (9, False, True, False), (50, False, True, True), (18, True, True, True)]
+    meshes = [synth.torus_mesh(n, seed=1000 + k, normals=nr, uvs=uv, open_boundary=ob) for k, (n, ob, nr, uv) in enumerate(specs)]
+    jobs = [dmi.mesh_prepare(m) for m in meshes]
+    outs = dmi.jobs_encode(jobs)
+    for m, j, o in zip(meshes, jobs, outs):
+        want = oracle_from_product_mesh(m).encode()
+        _assert_same(j.header_and_connectivity + o, want, "batch item")
+        assert o == j.encode()
+    for j in jobs:
+        j.close()
