@@ -136,8 +136,9 @@ def main():
                        "parallelism": f"{world} independent meshes, one per GPU" + (", RCCL gather of bitstreams to rank 0" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                          "traffic": None,
-                         "kernel": "quantize+predict pass = k_minmax_f32 + k_minmax_final + k_quant_coord + k_quant_oct + k_seq_gather + "
-                                   "k_pred_parallelogram_wrapped + k_pred_normal_octorth + k_pred_texcoord_wrapped + k_orient_summary (one launch of each per attribute per step)",
+                         "kernel": "quantize+predict pass = k_init_small + k_minmax_f32 + k_minmax_final + k_check_normals + k_seq_quantize + "
+                                   "k_pred_parallelogram_wrapped + k_face_normals + k_pred_normal_octorth + k_pred_texcoord_wrapped + k_orient_summary "
+                                   "(every launch between the first and the histogram stage of one step, hipEvent-timed on the job's stream)",
                          "algorithmic_bytes": int(tm["predict_bytes"]), "duration_ms": round(pass_ms, 4)},
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},
             "chains": {"streams": int(tm["num_streams"]), "symbols": int(tm["symbols"]),

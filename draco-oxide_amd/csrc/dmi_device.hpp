@@ -9,6 +9,7 @@ namespace dmi {
 
 // ---- quantization (a4-a6), fused with the coding-order gather ---------------------------------------
 // meta layout (floats): [0..N) per-component min, [N] range, [N+1..2N] per-component max (debug)
+void launch_init_small(uint32_t* small16, hipStream_t s);   // 16 scratch words: minmax seeds + zeros
 void launch_minmax_f32(const float* vals, uint32_t n_values, int N, float* partials, uint32_t max_blocks, float* meta, hipStream_t s);
 void launch_check_normals(const float* vals, uint32_t n_values, uint32_t* zero_flag, hipStream_t s);
 // qs[i] = portabilize(raw[p2v[c2p[seq[i]]]]) for every attribute of one corner table + joint i32 min/max

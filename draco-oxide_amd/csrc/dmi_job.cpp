@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
+#include <thread>
 
 #include "dmi_device.hpp"
 #include "dmi_host.hpp"
@@ -93,14 +94,17 @@ struct dmi_job {
   bool have_events = false;
   dmi_timings last{};
   uint64_t predict_bytes = 0;
+  uint8_t* out_pinned = nullptr;   // grow-only pinned arena for the coded bytes of one encode
+  size_t out_pinned_cap = 0;
   struct Run {   // state carried between the phases of one encode
+    std::vector<size_t> rans_off, aux_off;   // offsets into out_pinned
     std::vector<size_t> pin_off;
     std::vector<AuxInfo> aux;
     std::vector<ChainDesc> descs;
-    std::vector<std::vector<uint8_t>> rans_bytes, aux_bytes;
   } run;
   ~dmi_job() {
     if (pinned) (void)hipHostFree(pinned);
+    if (out_pinned) (void)hipHostFree(out_pinned);
     if (have_events) for (auto& e : ev) (void)hipEventDestroy(e);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
@@ -426,16 +430,13 @@ static int encode_phase_a(dmi_job* job) {   // device: ranges → coding-order p
   if (timed) HIP_TRY(hipEventRecord(job->ev[0], s));
   for (auto& a : job->atts) {
     const dmi_attribute& d = a.desc;
-    HIP_TRY(hipMemsetAsync(a.small.p, 0, 64, s));
+    launch_init_small(a.small.as<uint32_t>(), s);   // zero + minmax := {INT_MAX, INT_MIN}
     if (a.port == kCoordwise) launch_minmax_f32(a.raw.as<float>(), d.num_unique, d.num_components, a.partials.as<float>(), 2048, a.meta.as<float>(), s);
     else if (a.port == kOct) launch_check_normals(a.raw.as<float>(), d.num_unique, a.small.as<uint32_t>() + 4, s);
   }
   // ---- stage 2: portabilization in coding order + predict + transform ---------------------------------------
   if (timed) HIP_TRY(hipEventRecord(job->ev[1], s));
-  for (auto& a : job->atts) {
-    static const int32_t init_mm[2] = {2147483647, -2147483647 - 1};   // small: [0..1] minmax, [2..3] counters, [4] zero-normal flag, [5] hist overflow
-    HIP_TRY(hipMemcpyAsync(a.small.p, init_mm, 8, hipMemcpyHostToDevice, s));
-  }
+  // small: [0..1] minmax, [2..3] counters, [4] zero-normal flag, [5] hist overflow, [8..13] coder lengths / flags / ticks
   for (size_t ti = 0; ti < job->tables.size(); ++ti) {
     TableDev& t = job->tables[ti];
     if (t.alias_of >= 0) continue;
@@ -616,23 +617,31 @@ static int encode_phase_c2(dmi_job* job) {   // lengths known: async copy of the
   hipStream_t s = job->stream;
   const uint32_t n_atts = (uint32_t)job->atts.size();
   uint8_t* pinned = static_cast<uint8_t*>(job->pinned);
-  auto& rans_bytes = job->run.rans_bytes;
-  auto& aux_bytes = job->run.aux_bytes;
-  rans_bytes.assign(n_atts, {});
-  aux_bytes.assign(n_atts, {});
   const std::vector<size_t>& pin_off = job->run.pin_off;
   const std::vector<AuxInfo>& aux = job->run.aux;
+  auto& rans_off = job->run.rans_off;
+  auto& aux_off = job->run.aux_off;
+  rans_off.assign(n_atts, 0);
+  aux_off.assign(n_atts, 0);
+  size_t total = 0;
+  for (uint32_t i = 0; i < n_atts; ++i) {
+    const uint32_t* small = reinterpret_cast<const uint32_t*>(pinned + pin_off[i]);
+    if (small[9] || small[11]) return fail(DMI_ERR_ENTROPY, small[9] == 1 || small[11] == 1 ? "rANS state too large" : "coder output capacity exceeded");
+    if (std::getenv("DMI_TRACE")) std::fprintf(stderr, "[dmi] attribute %u: rANS chain %.3f ms (%llu symbols), aux chain %.3f ms\n", i, small[12] * 1e-5, (unsigned long long)job->atts[i].n_sym, small[13] * 1e-5);
+    rans_off[i] = total; total += (small[8] + 15u) & ~15u;
+    if (aux[i].desc >= 0) { aux_off[i] = total; total += (small[10] + 15u) & ~15u; }
+  }
+  if (total > job->out_pinned_cap) {
+    if (job->out_pinned) (void)hipHostFree(job->out_pinned);
+    job->out_pinned = nullptr;
+    job->out_pinned_cap = total + total / 4 + 4096;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&job->out_pinned), job->out_pinned_cap, hipHostMallocDefault));
+  }
   for (uint32_t i = 0; i < n_atts; ++i) {
     AttJob& a = job->atts[i];
     const uint32_t* small = reinterpret_cast<const uint32_t*>(pinned + pin_off[i]);
-    if (small[9] || small[11]) return fail(DMI_ERR_ENTROPY, small[9] == 1 || small[11] == 1 ? "rANS state too large" : "coder output capacity exceeded");
-    if (std::getenv("DMI_TRACE")) std::fprintf(stderr, "[dmi] attribute %u: rANS chain %.3f ms (%llu symbols), aux chain %.3f ms\n", i, small[12] * 1e-5, (unsigned long long)a.n_sym, small[13] * 1e-5);
-    rans_bytes[i].resize(small[8]);
-    if (small[8]) HIP_TRY(hipMemcpyAsync(rans_bytes[i].data(), a.out.p, small[8], hipMemcpyDeviceToHost, s));
-    if (aux[i].desc >= 0) {
-      aux_bytes[i].resize(small[10]);
-      if (small[10]) HIP_TRY(hipMemcpyAsync(aux_bytes[i].data(), a.aux_out.p, small[10], hipMemcpyDeviceToHost, s));
-    }
+    if (small[8]) HIP_TRY(hipMemcpyAsync(job->out_pinned + rans_off[i], a.out.p, small[8], hipMemcpyDeviceToHost, s));
+    if (aux[i].desc >= 0 && small[10]) HIP_TRY(hipMemcpyAsync(job->out_pinned + aux_off[i], a.aux_out.p, small[10], hipMemcpyDeviceToHost, s));
   }
   return DMI_OK;
 }
@@ -642,8 +651,8 @@ static int encode_phase_c3(dmi_job* job, dmi_buffer* out) {   // host: splice th
   uint8_t* pinned = static_cast<uint8_t*>(job->pinned);
   const std::vector<size_t>& pin_off = job->run.pin_off;
   const std::vector<AuxInfo>& aux = job->run.aux;
-  const auto& rans_bytes = job->run.rans_bytes;
-  const auto& aux_bytes = job->run.aux_bytes;
+  const auto& rans_off = job->run.rans_off;
+  const auto& aux_off = job->run.aux_off;
   // ---- stage 6 (host): splice the attribute section (encode/attribute/mod.rs:26-57, attribute_encoder.rs:159-160,344-386)
   ByteSink w;
   w.u8((uint8_t)n_atts);
@@ -662,21 +671,22 @@ static int encode_phase_c3(dmi_job* job, dmi_buffer* out) {   // host: splice th
     w.u8((uint8_t)a.transform);
     w.u8(1);   // rans_encoding
     w.bytes(a.ft.header);
-    w.leb128(rans_bytes[i].size());
-    w.bytes(rans_bytes[i]);
+    const uint32_t* lens = reinterpret_cast<const uint32_t*>(base);   // small[8] = rANS bytes, small[10] = rABS bytes
+    w.leb128(lens[8]);
+    w.bytes(job->out_pinned + rans_off[i], lens[8]);
     ByteSink tinfo;
     if (a.transform == kWrapped) { tinfo.u32((uint32_t)mm[0]); tinfo.u32((uint32_t)mm[1]); }
     else if (a.transform == kOctOrth) { tinfo.u32(255); tinfo.u32(127); }
     if (a.scheme == kNormal) {
       w.bytes(tinfo.b);
       w.u8(aux[i].zero_prob);
-      w.leb128(aux_bytes[i].size());
-      w.bytes(aux_bytes[i]);
+      w.leb128(lens[10]);
+      w.bytes(job->out_pinned + aux_off[i], lens[10]);
     } else if (a.scheme == kTexCoord) {
       w.u32(aux[i].count);
       w.u8(aux[i].zero_prob);
-      w.leb128(aux_bytes[i].size());
-      w.bytes(aux_bytes[i]);
+      w.leb128(lens[10]);
+      w.bytes(job->out_pinned + aux_off[i], lens[10]);
       w.bytes(tinfo.b);
     } else {
       w.bytes(tinfo.b);
@@ -738,32 +748,61 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
 int dmi_jobs_encode(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
   if (!jobs || !outs || n == 0) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
   for (uint32_t j = 0; j < n; ++j) if (!jobs[j] || jobs[j]->cfg.device != jobs[0]->cfg.device) return fail(DMI_ERR_INVALID_ARGUMENT, "batched jobs must live on one device");
-  // jobs created with one shared dmi_config.stream need a single wait per phase; otherwise every distinct stream is waited for
-  auto sync_all = [&]() -> int {
-    hipStream_t last = nullptr;
-    for (uint32_t j = 0; j < n; ++j) { if (j && jobs[j]->stream == last) continue; last = jobs[j]->stream; HIP_TRY(hipStreamSynchronize(last)); }
+  const int device = jobs[0]->cfg.device;
+  // Small meshes are launch-bound (≈30 API calls per job), so the per-job phases are issued from several host
+  // threads, each walking a contiguous slice of the jobs (jobs that own their stream then also overlap on the GPU).
+  unsigned hw = std::thread::hardware_concurrency();
+  const uint32_t n_threads = std::max(1u, std::min({n, hw ? hw : 4u, 16u}));
+  auto parallel = [&](auto&& fn, bool sync_after = true) -> int {
+    std::vector<int> rcs(n_threads, DMI_OK);
+    std::vector<std::string> errs(n_threads);
+    auto work = [&](uint32_t t) {
+      if (hipSetDevice(device) != hipSuccess) { rcs[t] = DMI_ERR_HIP; errs[t] = "hipSetDevice"; return; }
+      const uint32_t lo = (uint32_t)((uint64_t)n * t / n_threads), hi = (uint32_t)((uint64_t)n * (t + 1) / n_threads);
+      for (uint32_t j = lo; j < hi; ++j) { const int rc = fn(j); if (rc) { rcs[t] = rc; errs[t] = g_last_error; return; } }
+      if (sync_after) {   // each worker waits for its own slice's streams
+        hipStream_t last = nullptr;
+        for (uint32_t j = lo; j < hi; ++j) {
+          if (j > lo && jobs[j]->stream == last) continue;
+          last = jobs[j]->stream;
+          if (hipStreamSynchronize(last) != hipSuccess) { rcs[t] = DMI_ERR_HIP; errs[t] = "hipStreamSynchronize"; return; }
+        }
+      }
+    };
+    if (n_threads == 1) work(0);
+    else {
+      std::vector<std::thread> th;
+      for (uint32_t t = 0; t < n_threads; ++t) th.emplace_back(work, t);
+      for (auto& x : th) x.join();
+    }
+    for (uint32_t t = 0; t < n_threads; ++t) if (rcs[t]) return fail(rcs[t], errs[t]);
     return DMI_OK;
   };
   hipStream_t s = jobs[0]->stream;
   int rc;
-  for (uint32_t j = 0; j < n; ++j) if ((rc = encode_phase_a(jobs[j]))) return rc;
-  if ((rc = sync_all())) return rc;
+  const bool trace = std::getenv("DMI_TRACE") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  const auto t0 = now();
+  if ((rc = parallel([&](uint32_t j) { return encode_phase_a(jobs[j]); }))) return rc;
+  const auto t1 = now();
+  const auto t2 = t1;
+  if ((rc = parallel([&](uint32_t j) { return encode_phase_b(jobs[j]); }))) return rc;
   std::vector<ChainDesc> all;
-  for (uint32_t j = 0; j < n; ++j) {
-    if ((rc = encode_phase_b(jobs[j]))) return rc;
-    all.insert(all.end(), jobs[j]->run.descs.begin(), jobs[j]->run.descs.end());
-  }
-  if ((rc = sync_all())) return rc;   // coding records of every job are in place
+  for (uint32_t j = 0; j < n; ++j) all.insert(all.end(), jobs[j]->run.descs.begin(), jobs[j]->run.descs.end());
+  const auto t3 = now();
+  const auto t4 = t3;   // (workers have waited for their streams: coding records of every job are in place)
   DevMem descs_dev;
   if ((rc = descs_dev.alloc(all.size() * sizeof(ChainDesc)))) return rc;
   HIP_TRY(hipMemcpyAsync(descs_dev.p, all.data(), all.size() * sizeof(ChainDesc), hipMemcpyHostToDevice, s));
   launch_chains(descs_dev.as<ChainDesc>(), (uint32_t)all.size(), s);
   HIP_TRY(hipStreamSynchronize(s));
-  for (uint32_t j = 0; j < n; ++j) if ((rc = encode_phase_c1(jobs[j]))) return rc;
-  if ((rc = sync_all())) return rc;
-  for (uint32_t j = 0; j < n; ++j) if ((rc = encode_phase_c2(jobs[j]))) return rc;
-  if ((rc = sync_all())) return rc;
-  for (uint32_t j = 0; j < n; ++j) if ((rc = encode_phase_c3(jobs[j], &outs[j]))) return rc;
+  const auto t5 = now();
+  if ((rc = parallel([&](uint32_t j) { return encode_phase_c1(jobs[j]); }))) return rc;
+  if ((rc = parallel([&](uint32_t j) { return encode_phase_c2(jobs[j]); }))) return rc;
+  const auto t6 = now();
+  if ((rc = parallel([&](uint32_t j) { return encode_phase_c3(jobs[j], &outs[j]); }, false))) return rc;
+  if (trace) std::fprintf(stderr, "[dmi] batch of %u on %u host threads: phase A issue %.2f ms, wait %.2f, phase B (host tables + prep issue) %.2f, wait %.2f, chains (%zu streams) %.2f, read-back %.2f, splice %.2f\n", n, n_threads, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), all.size(), ms(t4, t5), ms(t5, t6), ms(t6, now()));
   return DMI_OK;
 }
 

@@ -96,6 +96,11 @@ __device__ __forceinline__ void block_reduce_minmax(float (&mn)[N], float (&mx)[
   }
 }
 
+// per-attribute scratch words: [0..1] joint i32 min/max (seeded INT_MAX / INT_MIN), everything else zero
+__global__ __launch_bounds__(64) void k_init_small(uint32_t* __restrict__ small) {
+  if (threadIdx.x < 16) small[threadIdx.x] = threadIdx.x == 0 ? 0x7FFFFFFFu : (threadIdx.x == 1 ? 0x80000000u : 0u);
+}
+
 template <int N>
 __global__ __launch_bounds__(kBlock) void k_minmax_f32(const float* __restrict__ vals, uint32_t n, float* __restrict__ partials) {
   float mn[N], mx[N];
@@ -540,6 +545,8 @@ inline uint32_t grid_for(uint64_t work, uint32_t cap = 256 * 8) {
 // ------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
+void launch_init_small(uint32_t* small, hipStream_t s) { hipLaunchKernelGGL(k_init_small, 1, 64, 0, s, small); }
+
 void launch_minmax_f32(const float* vals, uint32_t n, int N, float* partials, uint32_t max_blocks, float* meta, hipStream_t s) {
   uint32_t g = grid_for(n, max_blocks);
   switch (N) {

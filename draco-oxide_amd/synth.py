@@ -59,7 +59,16 @@ def torus_mesh(n, seed=SEED, normals=True, uvs=True, open_boundary=False):
         a = arr + np.float32(0.0)
         rows = np.ascontiguousarray(a).view(np.dtype((np.void, a.dtype.itemsize * a.shape[1]))).ravel()
         if len(np.unique(rows)) != len(rows):
-            raise ValueError(f"synthetic {name} values are not unique; use MeshBuilder to deduplicate")
+            # a chance duplicate: go through the builder so that value dedup (and the seams it creates) is applied
+            from .binding import MeshBuilder
+            b = MeshBuilder()
+            pid = b.add_attribute(pos, ATT_POSITION, DOMAIN_POSITION)
+            if nrm is not None:
+                b.add_attribute(nrm, ATT_NORMAL, DOMAIN_CORNER, parents=[pid])
+            if uv is not None:
+                b.add_attribute(uv, ATT_TEXCOORD, DOMAIN_CORNER, parents=[pid])
+            b.set_connectivity_attribute(faces)
+            return b.build()
     atts = [Attribute(pos, ATT_POSITION, DOMAIN_POSITION, unique_id=0)]
     if nrm is not None:
         atts.append(Attribute(nrm, ATT_NORMAL, DOMAIN_CORNER, unique_id=len(atts), parent_index=0))
