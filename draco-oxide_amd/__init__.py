@@ -12,3 +12,4 @@ from .binding import (  # noqa: F401
     Attribute, Mesh, MeshBuilder, Config, DracoMiError, Job, Connectivity,
     encode, encode_mesh, encode_attributes, encode_connectivity, mesh_prepare, jobs_encode, device_count, library_path, load_library,
 )
+from . import gltf, synth  # noqa: E402,F401
