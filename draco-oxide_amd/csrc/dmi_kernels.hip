@@ -403,13 +403,44 @@ __global__ __launch_bounds__(kBlock) void k_pred_normal_octorth(const uint32_t* 
   if ((threadIdx.x & 63) == 0 && n_false) atomicAdd(&counters[0], n_false);
 }
 
+// Exact i64 `a / d` (truncating) for the texture-coordinate predictor.  The software 64-bit divide costs ~100
+// instructions; when |a| and d fit 52 bits the f64 quotient is within one of the answer and one remainder
+// check fixes it.  Anything larger takes the generic divide.
+__device__ __forceinline__ int64_t div_exact(int64_t a, int64_t d) {
+  const int64_t lim = 1ll << 52;
+  if (d > 0 && d < lim && a > -lim && a < lim) {
+    int64_t q = (int64_t)((double)a / (double)d);
+    const int64_t r = a - q * d;
+    if (a >= 0) { if (r < 0) --q; else if (r >= d) ++q; }
+    else { if (r > 0) ++q; else if (r <= -d) --q; }
+    return q;
+  }
+  return wdiv64(a, d);
+}
+// `a > i64::MAX / b` without the divide: for a ≥ 0, b > 0 it is a·b > i64::MAX (128-bit product)
+__device__ __forceinline__ bool exceeds_max_over(int64_t a, int64_t b) {
+  if (a < 0 || b <= 0) return a > wdiv64(9223372036854775807ll, b);
+  const uint64_t hi = __umul64hi((uint64_t)a, (uint64_t)b), lo = (uint64_t)a * (uint64_t)b;
+  return hi != 0ull || lo > 9223372036854775807ull;
+}
+
 // mesh_prediction_for_texture_coordinates.rs:32-48
+__device__ __forceinline__ uint64_t udiv_exact(uint64_t a, uint64_t d) {
+  const uint64_t lim = 1ull << 52;
+  if (a < lim && d < lim) {
+    uint64_t q = (uint64_t)((double)a / (double)d);
+    const int64_t r = (int64_t)a - (int64_t)(q * d);
+    if (r < 0) --q; else if (r >= (int64_t)d) ++q;
+    return q;
+  }
+  return a / d;
+}
 __device__ __forceinline__ uint64_t int_sqrt(uint64_t value) {
   if (value == 0) return 0;
   uint64_t act = value, sq = 1;
   while (act >= 2) { sq *= 2; act /= 4; }
-  sq = (sq + value / sq) / 2;
-  while (sq * sq > value) sq = (sq + value / sq) / 2;
+  sq = (sq + udiv_exact(value, sq)) / 2;
+  while (sq * sq > value) sq = (sq + udiv_exact(value, sq)) / 2;
   return sq;
 }
 
@@ -445,24 +476,23 @@ __global__ __launch_bounds__(kBlock) void k_pred_texcoord_wrapped(const uint32_t
           const int64_t cn0 = wsub64(cp[0], np[0]), cn1 = wsub64(cp[1], np[1]), cn2 = wsub64(cp[2], np[2]);
           const int64_t cn_dot_pn = wadd64(wadd64(wmul64(pn0, cn0), wmul64(pn1, cn1)), wmul64(pn2, cn2));
           const int64_t pnu0 = wsub64(pu0, nu0), pnu1 = wsub64(pu1, nu1);
-          const int64_t I64MAX = 9223372036854775807ll;
           const int64_t n_uv_absmax = max(wabs64(nu0), wabs64(nu1));
           const int64_t pn_uv_absmax = max(wabs64(pnu0), wabs64(pnu1));
           const int64_t pn_absmax = max(max(wabs64(pn0), wabs64(pn1)), wabs64(pn2));
-          const bool overflow = (n_uv_absmax > wdiv64(I64MAX, (int64_t)pn2sq)) || (wabs64(cn_dot_pn) > wdiv64(I64MAX, pn_uv_absmax)) ||
-                                (wabs64(cn_dot_pn) > wdiv64(I64MAX, pn_absmax));
+          const bool overflow = exceeds_max_over(n_uv_absmax, (int64_t)pn2sq) || exceeds_max_over(wabs64(cn_dot_pn), pn_uv_absmax) ||
+                                exceeds_max_over(wabs64(cn_dot_pn), pn_absmax);
           if (!overflow) {
             const int64_t xu0 = wadd64(wmul64(nu0, (int64_t)pn2sq), wmul64(pnu0, cn_dot_pn));
             const int64_t xu1 = wadd64(wmul64(nu1, (int64_t)pn2sq), wmul64(pnu1, cn_dot_pn));
-            const int64_t xp0 = wadd64(np[0], wdiv64(wmul64(pn0, cn_dot_pn), (int64_t)pn2sq));
-            const int64_t xp1 = wadd64(np[1], wdiv64(wmul64(pn1, cn_dot_pn), (int64_t)pn2sq));
-            const int64_t xp2 = wadd64(np[2], wdiv64(wmul64(pn2, cn_dot_pn), (int64_t)pn2sq));
+            const int64_t xp0 = wadd64(np[0], div_exact(wmul64(pn0, cn_dot_pn), (int64_t)pn2sq));
+            const int64_t xp1 = wadd64(np[1], div_exact(wmul64(pn1, cn_dot_pn), (int64_t)pn2sq));
+            const int64_t xp2 = wadd64(np[2], div_exact(wmul64(pn2, cn_dot_pn), (int64_t)pn2sq));
             const int64_t cx0 = wsub64(cp[0], xp0), cx1 = wsub64(cp[1], xp1), cx2 = wsub64(cp[2], xp2);
             const uint64_t cx2sq = (uint64_t)wadd64(wadd64(wmul64(cx0, cx0), wmul64(cx1, cx1)), wmul64(cx2, cx2));
             const uint64_t nrm = int_sqrt(cx2sq * pn2sq);
             const int64_t cxu0 = wmul64(pnu1, (int64_t)nrm), cxu1 = wmul64((int64_t)(0ull - (uint64_t)pnu0), (int64_t)nrm);
-            const int64_t a0 = wdiv64(wadd64(xu0, cxu0), (int64_t)pn2sq), a1 = wdiv64(wadd64(xu1, cxu1), (int64_t)pn2sq);
-            const int64_t b0 = wdiv64(wsub64(xu0, cxu0), (int64_t)pn2sq), b1 = wdiv64(wsub64(xu1, cxu1), (int64_t)pn2sq);
+            const int64_t a0 = div_exact(wadd64(xu0, cxu0), (int64_t)pn2sq), a1 = div_exact(wadd64(xu1, cxu1), (int64_t)pn2sq);
+            const int64_t b0 = div_exact(wsub64(xu0, cxu0), (int64_t)pn2sq), b1 = div_exact(wsub64(xu1, cxu1), (int64_t)pn2sq);
             const int64_t ea0 = wsub64(cu0, a0), ea1 = wsub64(cu1, a1), eb0 = wsub64(cu0, b0), eb1 = wsub64(cu1, b1);
             const int64_t da = wadd64(wmul64(ea0, ea0), wmul64(ea1, ea1)), db = wadd64(wmul64(eb0, eb0), wmul64(eb1, eb1));
             if (da < db) { oflag = 2; pred0 = (int32_t)a0; pred1 = (int32_t)a1; }
