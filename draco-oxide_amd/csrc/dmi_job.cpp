@@ -94,10 +94,13 @@ struct dmi_job {
   bool have_events = false;
   dmi_timings last{};
   uint64_t predict_bytes = 0;
+  hipGraphExec_t graph_a = nullptr;   // phase A captured once (launch-bound for small meshes)
+  bool graph_tried = false;
   uint8_t* out_pinned = nullptr;   // grow-only pinned arena for the coded bytes of one encode
   size_t out_pinned_cap = 0;
   struct Run {   // state carried between the phases of one encode
     std::vector<size_t> rans_off, aux_off;   // offsets into out_pinned
+    std::vector<const uint8_t*> rans_ptr, aux_ptr;   // host addresses of the coded bytes (pinned memory)
     std::vector<size_t> pin_off;
     std::vector<AuxInfo> aux;
     std::vector<ChainDesc> descs;
@@ -105,6 +108,7 @@ struct dmi_job {
   ~dmi_job() {
     if (pinned) (void)hipHostFree(pinned);
     if (out_pinned) (void)hipHostFree(out_pinned);
+    if (graph_a) (void)hipGraphExecDestroy(graph_a);
     if (have_events) for (auto& e : ev) (void)hipEventDestroy(e);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
@@ -623,6 +627,8 @@ static int encode_phase_c2(dmi_job* job) {   // lengths known: async copy of the
   auto& aux_off = job->run.aux_off;
   rans_off.assign(n_atts, 0);
   aux_off.assign(n_atts, 0);
+  job->run.rans_ptr.assign(n_atts, nullptr);
+  job->run.aux_ptr.assign(n_atts, nullptr);
   size_t total = 0;
   for (uint32_t i = 0; i < n_atts; ++i) {
     const uint32_t* small = reinterpret_cast<const uint32_t*>(pinned + pin_off[i]);
@@ -642,6 +648,8 @@ static int encode_phase_c2(dmi_job* job) {   // lengths known: async copy of the
     const uint32_t* small = reinterpret_cast<const uint32_t*>(pinned + pin_off[i]);
     if (small[8]) HIP_TRY(hipMemcpyAsync(job->out_pinned + rans_off[i], a.out.p, small[8], hipMemcpyDeviceToHost, s));
     if (aux[i].desc >= 0 && small[10]) HIP_TRY(hipMemcpyAsync(job->out_pinned + aux_off[i], a.aux_out.p, small[10], hipMemcpyDeviceToHost, s));
+    job->run.rans_ptr[i] = job->out_pinned + rans_off[i];
+    job->run.aux_ptr[i] = job->out_pinned + aux_off[i];
   }
   return DMI_OK;
 }
@@ -651,8 +659,8 @@ static int encode_phase_c3(dmi_job* job, dmi_buffer* out) {   // host: splice th
   uint8_t* pinned = static_cast<uint8_t*>(job->pinned);
   const std::vector<size_t>& pin_off = job->run.pin_off;
   const std::vector<AuxInfo>& aux = job->run.aux;
-  const auto& rans_off = job->run.rans_off;
-  const auto& aux_off = job->run.aux_off;
+  const auto& rans_ptr = job->run.rans_ptr;
+  const auto& aux_ptr = job->run.aux_ptr;
   // ---- stage 6 (host): splice the attribute section (encode/attribute/mod.rs:26-57, attribute_encoder.rs:159-160,344-386)
   ByteSink w;
   w.u8((uint8_t)n_atts);
@@ -673,7 +681,7 @@ static int encode_phase_c3(dmi_job* job, dmi_buffer* out) {   // host: splice th
     w.bytes(a.ft.header);
     const uint32_t* lens = reinterpret_cast<const uint32_t*>(base);   // small[8] = rANS bytes, small[10] = rABS bytes
     w.leb128(lens[8]);
-    w.bytes(job->out_pinned + rans_off[i], lens[8]);
+    w.bytes(rans_ptr[i], lens[8]);
     ByteSink tinfo;
     if (a.transform == kWrapped) { tinfo.u32((uint32_t)mm[0]); tinfo.u32((uint32_t)mm[1]); }
     else if (a.transform == kOctOrth) { tinfo.u32(255); tinfo.u32(127); }
@@ -681,12 +689,12 @@ static int encode_phase_c3(dmi_job* job, dmi_buffer* out) {   // host: splice th
       w.bytes(tinfo.b);
       w.u8(aux[i].zero_prob);
       w.leb128(lens[10]);
-      w.bytes(job->out_pinned + aux_off[i], lens[10]);
+      w.bytes(aux_ptr[i], lens[10]);
     } else if (a.scheme == kTexCoord) {
       w.u32(aux[i].count);
       w.u8(aux[i].zero_prob);
       w.leb128(lens[10]);
-      w.bytes(job->out_pinned + aux_off[i], lens[10]);
+      w.bytes(aux_ptr[i], lens[10]);
       w.bytes(tinfo.b);
     } else {
       w.bytes(tinfo.b);
@@ -700,6 +708,31 @@ static int encode_phase_c3(dmi_job* job, dmi_buffer* out) {   // host: splice th
     }
   }
   return to_buffer(w.b, out);
+}
+
+// Phase A as one hipGraph replay: ≈30 launches/memsets/copies per job collapse into a single API call.  Jobs with
+// event timing or a ToBits attribute (whose alphabet bound needs a mid-phase host wait) stay on the eager path.
+static int run_phase_a(dmi_job* job) {
+  hipStream_t s = job->stream;
+  if (job->graph_a) { HIP_TRY(hipSetDevice(job->cfg.device)); HIP_TRY(hipGraphLaunch(job->graph_a, s)); return DMI_OK; }
+  bool eligible = !job->have_events && !job->graph_tried;
+  for (auto& a : job->atts) if (a.port == kToBits) eligible = false;
+  if (!eligible) return encode_phase_a(job);
+  job->graph_tried = true;
+  HIP_TRY(hipSetDevice(job->cfg.device));
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) return encode_phase_a(job);
+  const int rc = encode_phase_a(job);
+  hipGraph_t graph = nullptr;
+  const hipError_t e = hipStreamEndCapture(s, &graph);
+  if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+  if (e != hipSuccess || !graph) return encode_phase_a(job);
+  hipGraphExec_t exec = nullptr;
+  const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (ei != hipSuccess || !exec) return encode_phase_a(job);
+  job->graph_a = exec;
+  HIP_TRY(hipGraphLaunch(exec, s));
+  return DMI_OK;
 }
 
 int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
@@ -784,7 +817,7 @@ int dmi_jobs_encode(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   const auto t0 = now();
-  if ((rc = parallel([&](uint32_t j) { return encode_phase_a(jobs[j]); }))) return rc;
+  if ((rc = parallel([&](uint32_t j) { return run_phase_a(jobs[j]); }))) return rc;
   const auto t1 = now();
   const auto t2 = t1;
   if ((rc = parallel([&](uint32_t j) { return encode_phase_b(jobs[j]); }))) return rc;

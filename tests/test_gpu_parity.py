@@ -215,3 +215,70 @@ def test_batch_of_meshes_one_chain_launch():
         assert o == j.encode()
     for j in jobs:
         j.close()
+
+
+def _soup_mesh(seed, n_pts=60, n_faces=160, uv_per_corner=True):
+    """Random triangle soup over few points: non-manifold edges/vertices, many components, per-corner UVs
+    (seams everywhere) — both builders, then both encoders."""
+    rng = np.random.default_rng(seed)
+    pos = rng.uniform(-1, 1, size=(n_pts, 3)).astype(np.float32)
+    faces = rng.integers(0, n_pts, size=(n_faces, 3)).astype(np.uint32)
+    faces = faces[(faces[:, 0] != faces[:, 1]) & (faces[:, 1] != faces[:, 2]) & (faces[:, 2] != faces[:, 0])]
+    corner_pts = faces.ravel()
+    cpos = pos[corner_pts]
+    nrm = rng.normal(size=(n_pts, 3)).astype(np.float32)
+    cnrm = nrm[corner_pts]
+    cuv = (rng.integers(0, 6, size=(len(corner_pts), 2)) / 5.0).astype(np.float32) if uv_per_corner else rng.uniform(0, 1, size=(n_pts, 2)).astype(np.float32)[corner_pts]
+    f2 = np.arange(len(corner_pts), dtype=np.uint32).reshape(-1, 3)
+    b = dmi.MeshBuilder()
+    pid = b.add_attribute(cpos, dmi.ATT_POSITION)
+    b.add_attribute(cnrm, dmi.ATT_NORMAL, dmi.DOMAIN_CORNER, parents=[pid])
+    b.add_attribute(cuv, dmi.ATT_TEXCOORD, dmi.DOMAIN_CORNER, parents=[pid])
+    b.set_connectivity_attribute(f2)
+    sess = orc.Session.from_arrays(f2, [dict(data=cpos, type=orc.POSITION), dict(data=cnrm, type=orc.NORMAL, domain=orc.DOM_CORNER, parents=[0]),
+                                        dict(data=cuv, type=orc.TEXCOORD, domain=orc.DOM_CORNER, parents=[0])])
+    return b.build(), sess
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_triangle_soup_bit_exact(seed):
+    mesh, sess = _soup_mesh(seed, uv_per_corner=(seed % 2 == 0))
+    try:
+        want = sess.encode()
+    except orc.OracleError as e:
+        # inputs the reference itself cannot encode (its panics / non-termination) must be error codes here too
+        with pytest.raises(dmi.DracoMiError):
+            dmi.encode_mesh(mesh)
+        pytest.skip(f"reference rejects this soup: {e}")
+    _assert_same(dmi.encode_mesh(mesh), want, f"soup {seed}")
+
+
+def test_high_valence_fan_and_disjoint_components():
+    # a 400-triangle cone (one vertex of valence 400) next to a separate small grid
+    k = 400
+    ang = np.linspace(0, 2 * np.pi, k, endpoint=False)
+    ring = np.stack([np.cos(ang), np.sin(ang), 0.1 * np.sin(5 * ang)], axis=1)
+    pos = np.concatenate([[[0, 0, 1.0]], ring]).astype(np.float32)
+    faces = np.array([[0, 1 + i, 1 + (i + 1) % k] for i in range(k)], np.uint32)
+    gf, gp, gn, gu = synth.torus_grid(9, open_boundary=True)
+    pos2 = np.concatenate([pos, gp + np.float32(3.0)]).astype(np.float32)
+    faces2 = np.concatenate([faces, gf + np.uint32(len(pos))]).astype(np.uint32)
+    nrm = pos2 / np.maximum(np.linalg.norm(pos2, axis=1, keepdims=True), 1e-6)
+    uv = (pos2[:, :2] * 0.1 + 0.5).astype(np.float32)
+    mesh = dmi.Mesh(faces2, [dmi.Attribute(pos2, dmi.ATT_POSITION), dmi.Attribute(nrm.astype(np.float32), dmi.ATT_NORMAL, dmi.DOMAIN_CORNER, 1, 0),
+                             dmi.Attribute(uv, dmi.ATT_TEXCOORD, dmi.DOMAIN_CORNER, 2, 0)])
+    want = oracle_from_product_mesh(mesh).encode()
+    _assert_same(dmi.encode_mesh(mesh), want, "cone + grid")
+
+
+@pytest.mark.parametrize("pos_bits,uv_bits", [(1, 1), (5, 3), (16, 16), (20, 14)])
+def test_quantization_bit_widths(pos_bits, uv_bits):
+    mesh = synth.torus_mesh(30)
+    sess = oracle_from_product_mesh(mesh)
+    try:
+        want = sess.encode(pos_bits=pos_bits, uv_bits=uv_bits)
+    except orc.OracleError:
+        with pytest.raises(dmi.DracoMiError):
+            dmi.encode_mesh(mesh, dmi.Config(pos_bits=pos_bits, uv_bits=uv_bits))
+        return
+    _assert_same(dmi.encode_mesh(mesh, dmi.Config(pos_bits=pos_bits, uv_bits=uv_bits)), want, f"{pos_bits}/{uv_bits} bits")
