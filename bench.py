@@ -72,11 +72,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available() or dmi.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: libdraco_mi has no CPU fallback")
+    # DMI_BENCH_BACKEND=gloo lets the N>1 control flow be exercised on a 1-GPU box (all ranks share cuda:0,
+    # the gather runs on CPU tensors); the driver's multi-GPU runs use the default: nccl = RCCL over xGMI.
+    backend = os.environ.get("DMI_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    gather_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     # every rank owns one mesh of the workload shape (weak scaling); different seeds → different meshes
     mesh = synth.torus_mesh(args.grid, seed=synth.SEED + rank)
@@ -91,7 +99,7 @@ def main():
     def step():
         blob = job.encode()
         if world > 1:
-            dmi_dist.gather_bitstreams(blob, device=dev)
+            dmi_dist.gather_bitstreams(blob, device=gather_dev)
         return blob
 
     for _ in range(args.warmup):
@@ -112,7 +120,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t_start
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     tm = job.timings()

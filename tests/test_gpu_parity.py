@@ -282,3 +282,13 @@ def test_quantization_bit_widths(pos_bits, uv_bits):
             dmi.encode_mesh(mesh, dmi.Config(pos_bits=pos_bits, uv_bits=uv_bits))
         return
     _assert_same(dmi.encode_mesh(mesh, dmi.Config(pos_bits=pos_bits, uv_bits=uv_bits)), want, f"{pos_bits}/{uv_bits} bits")
+
+
+def test_empty_mesh_is_an_error_code_not_a_crash():
+    pos = np.zeros((0, 3), np.float32)
+    mesh = dmi.Mesh(np.zeros((0, 3), np.uint32), [dmi.Attribute(pos, dmi.ATT_POSITION)])
+    with pytest.raises(dmi.DracoMiError):
+        dmi.encode_mesh(mesh)
+    sess = orc.Session.from_arrays(np.zeros((0, 3), np.uint32), [dict(data=pos, type=orc.POSITION)])
+    with pytest.raises(orc.OracleError):
+        sess.encode()
