@@ -9,7 +9,7 @@
 //       k_orient_prep    orientation flags → compacted transition bits, forward
 //                        (mesh_prediction_for_texture_coordinates.rs:241-256)
 //   * k_chains: per 64 records the wave walks 64 steps on SGPRs (records arrive through s_load_dwordx16,
-//     one group of 8 ahead) — per step: exact x/f by multiply-high, renormalisation shift from the
+//     one chunk of 8 ahead) — per step: exact x/f by multiply-high, renormalisation shift from the
 //     quotient's bit length, state update — parking each pre-renormalisation state in its lane; then all
 //     64 lanes emit their renormalisation bytes at wavefront prefix-sum offsets.
 //
@@ -114,12 +114,14 @@ __global__ __launch_bounds__(64) void k_orient_prep(const uint8_t* __restrict__ 
 }
 
 // ---- the chain -------------------------------------------------------------------------------------
-// Records travel through SGPRs in groups of 4 (one s_load_dwordx16), fetched two groups (8 steps) ahead.
-struct Rec4 { RansEntry r[4]; };
-typedef const Rec4 __attribute__((address_space(4))) * const_rec4_t;   // constant address space ⇒ scalar loads
-__device__ __forceinline__ void load_rec4(Rec4& dst, const_rec4_t src) {
+// Records travel through SGPRs in chunks of 8 (two s_load_dwordx16), double-buffered: scalar loads return out of
+// order, so every wait is lgkmcnt(0) — the chunk for steps k+8..k+15 is requested right after the wait that
+// releases steps k..k+7 and has 8 steps (≈350 clocks) to arrive.
+struct Rec8 { RansEntry r[8]; };
+typedef const Rec8 __attribute__((address_space(4))) * const_rec8_t;   // constant address space ⇒ scalar loads
+__device__ __forceinline__ void load_rec8(Rec8& dst, const_rec8_t src) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { dst.r[k].m = src->r[k].m; dst.r[k].b = src->r[k].b; dst.r[k].d = src->r[k].d; dst.r[k].c = src->r[k].c; }
+  for (int k = 0; k < 8; ++k) { dst.r[k].m = src->r[k].m; dst.r[k].b = src->r[k].b; dst.r[k].d = src->r[k].d; dst.r[k].c = src->r[k].c; }
 }
 
 #define DMI_CHAIN_STEP(R, J)                                                                     \
@@ -130,85 +132,142 @@ __device__ __forceinline__ void load_rec4(Rec4& dst, const_rec4_t src) {
     x = (x >> sh) + (q0 >> sh) * (R).d + (R).c;                                                  \
   }
 
-// The record buffer is padded with ≥ 136 zero records past n, so group prefetches may run ahead freely.
+// A stream is owned by a workgroup of TWO wavefronts that talk through LDS:
+//   wave 0 (walker)  runs the recurrence on its scalar unit and parks the 64 pre-renormalisation states of a
+//                    batch in a VGPR (lane j = step j), then drops them into a ring slot and bumps `produced`;
+//   wave 1 (emitter) picks the slot up, derives every step's byte count from (state, frequency), takes wavefront
+//                    prefix sums with ballots + mbcnt and stores the bytes; it also touches the records a few
+//                    batches AHEAD of the walker so that the walker's scalar loads hit L2.
+// LDS operations of one wavefront execute in order, so "slot, then counter" needs no fence; the walker only looks at
+// `consumed` when its cached copy says the ring could be full (once per kRing batches).
+// The record buffer is padded with kChainPad records past n, so chunk and batch prefetches may run ahead freely.
+constexpr uint32_t kRing = 8;
+constexpr uint32_t kAhead = 4;   // batches between the emitter's position and the records it pulls into L2
+struct ChainShared {
+  uint32_t ring[kRing][64];
+  uint32_t produced, consumed, final_x, done;
+};
+typedef const RansEntry __attribute__((address_space(1))) * grec_t;   // global (not flat): flat accesses count in lgkmcnt too
+typedef volatile ChainShared __attribute__((address_space(3))) * lds_shared_t;   // LDS address space ⇒ ds_read/ds_write
+
 template <uint32_t BIAS>
-__device__ void run_chain(const ChainDesc& d, uint32_t lane) {
+__device__ void chain_walker(const ChainDesc& d, uint32_t lane, lds_shared_t sh) {
   constexpr uint32_t bias = BIAS;                 // 29 (rANS, threshold f·2^10) or 27 (rABS, f·2^12)
-  constexpr uint32_t thr_shift = 39u - BIAS;      // 10 / 12
   const uint32_t P = d.precision;
   const uint64_t n = d.n;
   const RansEntry* __restrict__ rec = d.table;
-  const uint32_t x0 = d.state0;
-  uint32_t x = x0;
-  uint64_t pos = 0;
-  uint32_t err = 0;
+  uint32_t x = d.state0;
   typedef const uint32_t __attribute__((address_space(4))) * const_u32_t;
   const_u32_t flags = (const_u32_t)(uintptr_t)d.batch_flags;   // nullable
   uint32_t flag_next = d.force_generic ? 1u : (flags ? flags[0] : 0u);
-  Rec4 g0, g1;   // the next two groups to execute
-  load_rec4(g0, (const_rec4_t)(uintptr_t)rec);
-  load_rec4(g1, (const_rec4_t)(uintptr_t)rec + 1);
-  for (uint64_t base = 0; base < n; base += 64) {
+  Rec8 ca, cb;   // ca: the chunk about to execute; cb: the one after it
+  load_rec8(ca, (const_rec8_t)(uintptr_t)rec);
+  const grec_t grec = (grec_t)(uintptr_t)rec;
+  uint32_t k = 0, consumed_seen = 0;
+  for (uint64_t base = 0; base < n; base += 64, ++k) {
     const uint32_t cnt = (uint32_t)min((uint64_t)64, n - base);
-    // (global address space: a flat access would also count in lgkmcnt and stall the scalar-load waits)
-    typedef const RansEntry __attribute__((address_space(1))) * grec_t;
-    const grec_t grec = (grec_t)(uintptr_t)rec;
-    RansEntry me;                                 // used only by the emission phase at the end of the batch
-    me.m = grec[base + lane].m; me.b = grec[base + lane].b; me.d = grec[base + lane].d; me.c = grec[base + lane].c;
     const bool has_f1 = flag_next != 0u;          // a frequency-1 symbol in this batch (flag fetched one batch ahead)
     if (!d.force_generic && flags) flag_next = flags[(base >> 6) + 1];
     uint32_t parked = 0;
     x = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
-    const_rec4_t g = (const_rec4_t)(uintptr_t)(rec + base);
+    const_rec8_t g = (const_rec8_t)(uintptr_t)(rec + base);
     if (cnt == 64 && !has_f1) {
 #pragma unroll
-      for (int gi = 0; gi < 16; ++gi) {
-        Rec4 g2;
-        load_rec4(g2, g + gi + 2);                // two groups ahead (runs into the next batch at gi ≥ 14)
+      for (int ci = 0; ci < 8; ci += 2) {
+        load_rec8(cb, g + ci + 1);
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) DMI_CHAIN_STEP(g0.r[s4], gi * 4 + s4)
-        g0 = g1;
-        g1 = g2;
+        for (int s8 = 0; s8 < 8; ++s8) DMI_CHAIN_STEP(ca.r[s8], ci * 8 + s8)
+        load_rec8(ca, g + ci + 2);                // ci = 6: the next batch's first chunk
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) DMI_CHAIN_STEP(cb.r[s8], ci * 8 + 8 + s8)
       }
     } else {
+      const uint32_t md = grec[base + lane].d, mc = grec[base + lane].c;
       for (uint32_t j = 0; j < cnt; ++j) {
-        const uint32_t dj = rl(me.d, j), cj = rl(me.c, j);
+        const uint32_t dj = rl(md, j), cj = rl(mc, j);
         const uint32_t f = (1u << P) - dj;
         const uint32_t q0 = x / f;
         const uint32_t sh = (bias - (uint32_t)__builtin_clz(q0)) & 0x18u;
         if (lane == j) parked = x;
         x = (x >> sh) + (q0 >> sh) * dj + cj;
       }
-      load_rec4(g0, g + 16);
-      load_rec4(g1, g + 17);
+      load_rec8(ca, g + 8);
     }
+    while (k - consumed_seen >= kRing) {          // ring full (rare: the emitter is ≈6× faster than the walker)
+      consumed_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->consumed);
+      if (k - consumed_seen >= kRing) __builtin_amdgcn_s_sleep(4);
+    }
+    sh->ring[k & (kRing - 1u)][lane] = parked;
+    sh->produced = k + 1u;
+  }
+  sh->final_x = x;
+  sh->done = 1u;
+}
+
+template <uint32_t BIAS>
+__device__ void chain_emitter(const ChainDesc& d, uint32_t lane, lds_shared_t sh) {
+  constexpr uint32_t thr_shift = 39u - BIAS;      // 10 / 12
+  const uint32_t P = d.precision;
+  const uint64_t n = d.n;
+  const grec_t grec = (grec_t)(uintptr_t)d.table;
+  typedef uint8_t __attribute__((address_space(1))) * gbyte_t;
+  uint64_t pos = 0;
+  uint32_t err = 0, touched = 0;
+  uint32_t me_d = grec[lane].d;                    // lane j's record of the batch being emitted (only d is needed)
+  uint32_t far = 0;
+#pragma unroll
+  for (uint32_t a = 1; a < kAhead; ++a) touched ^= grec[(uint64_t)a * 64u + lane].m;
+  uint32_t k = 0;
+  for (uint64_t base = 0; base < n; base += 64, ++k) {
+    const uint32_t cnt = (uint32_t)min((uint64_t)64, n - base);
+    const uint32_t my_d = me_d;                    // requested one batch ago
+    touched ^= far;
+    me_d = grec[base + 64u + lane].d;
+    far = grec[base + (uint64_t)kAhead * 64u + lane].m;   // one dword per record = every line of that batch
+    while ((uint32_t)__builtin_amdgcn_readfirstlane((int)sh->produced) <= k) __builtin_amdgcn_s_sleep(2);
+    const uint32_t parked = sh->ring[k & (kRing - 1u)][lane];
+    sh->consumed = k + 1u;                         // (LDS is in order: the slot read above is performed first)
     // bytes of the 64 steps: lane j re-derives its byte count from (parked state, frequency)
     // (f ≤ 2^20 ⇒ f << thr_shift < 2^32; parked < 2^30; at most 3 bytes per step)
-    const uint32_t thr = (lane < cnt) ? (((1u << P) - me.d) << thr_shift) : 0xFFFFFFFFu;
+    const uint32_t thr = (lane < cnt) ? (((1u << P) - my_d) << thr_shift) : 0xFFFFFFFFu;
     const bool b0 = parked >= thr, b1 = (parked >> 8) >= thr, b2 = (parked >> 16) >= thr;
     const unsigned long long m0 = __ballot(b0), m1 = __ballot(b1), m2 = __ballot(b2);
     const uint32_t before = lanes_below(m0) + lanes_below(m1) + lanes_below(m2);
     const uint32_t total = (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);
-    if (pos + total > d.cap) { err = 2; break; }
-    typedef uint8_t __attribute__((address_space(1))) * gbyte_t;
-    gbyte_t at = (gbyte_t)(uintptr_t)d.out + pos + before;
-    if (b0) at[0] = (uint8_t)parked;
-    if (b1) at[1] = (uint8_t)(parked >> 8);
-    if (b2) at[2] = (uint8_t)(parked >> 16);
-    pos += total;
+    if (pos + total > d.cap) err = 2;
+    if (!err) {
+      gbyte_t at = (gbyte_t)(uintptr_t)d.out + pos + before;
+      if (b0) at[0] = (uint8_t)parked;
+      if (b1) at[1] = (uint8_t)(parked >> 8);
+      if (b2) at[2] = (uint8_t)(parked >> 16);
+      pos += total;
+    }
   }
+  while ((uint32_t)__builtin_amdgcn_readfirstlane((int)sh->done) == 0u) __builtin_amdgcn_s_sleep(2);
+  const uint32_t x = sh->final_x;
   if (lane == 0) {
-    if (!err) pos += flush_state(x - x0, d.out, pos, d.cap, err);
+    if (!err) pos += flush_state(x - d.state0, d.out, pos, d.cap, err);
+    if ((touched ^ far) == 0x9E3779B9u && pos == ~0ull) err = 3;   // keeps the look-ahead loads alive; never true
     d.out_len[0] = (uint32_t)pos;
     d.out_len[1] = err;
   }
 }
 
-__global__ __launch_bounds__(64) void k_chains(const ChainDesc* __restrict__ descs) {
+__global__ __launch_bounds__(128) void k_chains(const ChainDesc* __restrict__ descs) {
+  __shared__ ChainShared shared;
   const ChainDesc d = descs[blockIdx.x];
   const uint64_t t0 = wall_clock64();   // 100 MHz constant-rate counter
-  if (d.kind == 0) run_chain<29u>(d, threadIdx.x); else run_chain<27u>(d, threadIdx.x);
-  if (threadIdx.x == 0 && d.ticks) d.ticks[0] = (uint32_t)(wall_clock64() - t0);
+  if (threadIdx.x == 0) { shared.produced = 0; shared.consumed = 0; shared.final_x = 0; shared.done = 0; }
+  __syncthreads();
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t lane = threadIdx.x & 63u;
+  const lds_shared_t sh = (lds_shared_t)&shared;
+  if (wave == 0) {
+    if (d.kind == 0) chain_walker<29u>(d, lane, sh); else chain_walker<27u>(d, lane, sh);
+  } else {
+    if (d.kind == 0) chain_emitter<29u>(d, lane, sh); else chain_emitter<27u>(d, lane, sh);
+    if (lane == 0 && d.ticks) d.ticks[0] = (uint32_t)(wall_clock64() - t0);
+  }
 }
 
 inline uint32_t grid256(uint64_t n) { uint64_t g = (n + 255) / 256; return (uint32_t)(g > 4096 ? 4096 : (g ? g : 1)); }
@@ -229,7 +288,7 @@ void launch_batch_flags(const RansEntry* rec, uint64_t n, uint32_t* batch_flags,
   if (n) hipLaunchKernelGGL(k_batch_flags, grid256(n), 256, 0, s, rec, n, batch_flags);
 }
 void launch_chains(const ChainDesc* descs_dev, uint32_t n_streams, hipStream_t s) {
-  if (n_streams) hipLaunchKernelGGL(k_chains, n_streams, 64, 0, s, descs_dev);
+  if (n_streams) hipLaunchKernelGGL(k_chains, n_streams, 128, 0, s, descs_dev);
 }
 
 }  // namespace dmi

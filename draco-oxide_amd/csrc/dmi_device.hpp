@@ -41,10 +41,11 @@ uint32_t orient_summary_blocks(uint32_t n);
 // ---- histogram (a16) -------------------------------------------------------------------------------
 void launch_histogram(const uint32_t* sym, uint64_t n_sym, uint32_t* hist, uint32_t bins, uint32_t* overflow_flag, hipStream_t s);
 
-// ---- serial coders: one wavefront per stream (a18, a19, a11, a13) ------------------------------------
+// ---- serial coders: two wavefronts per stream (a18, a19, a11, a13) ------------------------------------
 // Coding record of one symbol (see dmi_chains.hip): x / f = mulhi(x, m) >> (b & 31); bit 8 of b flags f == 1;
 // d = 2^P - f; c = cumulative frequency.
 struct RansEntry { uint32_t m, b, d, c; };
+constexpr size_t kChainPad = 384;   // records a stream's buffer extends past n: the chain's look-ahead loads may run that far
 RansEntry make_rans_entry(uint32_t freq, uint32_t cum, uint32_t precision);   // host helper
 // batch_flags: (n + 63) / 64 + 1 words; [b] != 0 ⇔ batch b holds a frequency-1 symbol
 void launch_rans_prep(const uint32_t* sym, uint64_t n, const RansEntry* table, RansEntry* rec, uint32_t* batch_flags, hipStream_t s);

@@ -374,7 +374,7 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
       if ((rc = a.aux.alloc(n ? n : 1))) return rc;
       a.aux_cap = (uint64_t)n + 16;   // ≤ 1 byte per coded bit + flush
       if ((rc = a.aux_out.alloc(a.aux_cap))) return rc;
-      if ((rc = a.aux_rec.alloc(((size_t)n + 192) * sizeof(RansEntry)))) return rc;   // +192: prefetch padding of the chain
+      if ((rc = a.aux_rec.alloc(((size_t)n + kChainPad) * sizeof(RansEntry)))) return rc;
       HIP_TRY(hipMemsetAsync(a.aux_rec.p, 0, a.aux_rec.bytes, s));
       if ((rc = a.aux_flags.alloc(((size_t)n / 64 + 4) * 4))) return rc;
       HIP_TRY(hipMemsetAsync(a.aux_flags.p, 0, a.aux_flags.bytes, s));
@@ -386,7 +386,7 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
     if (a.port == kToBits) a.bins = 1u << 20;   // capacity; the real bound is checked after the min/max readback
     if ((rc = a.hist.alloc((size_t)a.bins * 4))) return rc;
     if ((rc = a.rtable.alloc((size_t)a.bins * sizeof(RansEntry)))) return rc;
-    if ((rc = a.rec.alloc(((size_t)a.n_sym + 192) * sizeof(RansEntry)))) return rc;   // +192: prefetch padding of the chain
+    if ((rc = a.rec.alloc(((size_t)a.n_sym + kChainPad) * sizeof(RansEntry)))) return rc;
     HIP_TRY(hipMemsetAsync(a.rec.p, 0, a.rec.bytes, s));
     if ((rc = a.batch_flags.alloc(((size_t)a.n_sym / 64 + 4) * 4))) return rc;
     HIP_TRY(hipMemsetAsync(a.batch_flags.p, 0, a.batch_flags.bytes, s));
