@@ -9,13 +9,22 @@ namespace dmi {
 
 // ---- quantization (a4-a6), fused with the coding-order gather ---------------------------------------
 // meta layout (floats): [0..N) per-component min, [N] range, [N+1..2N] per-component max (debug)
-void launch_init_small(uint32_t* small16, hipStream_t s);   // 16 scratch words: minmax seeds + zeros
-void launch_minmax_f32(const float* vals, uint32_t n_values, int N, float* partials, uint32_t max_blocks, float* meta, hipStream_t s);
-void launch_check_normals(const float* vals, uint32_t n_values, uint32_t* zero_flag, hipStream_t s);
-// qs[i] = portabilize(raw[p2v[c2p[seq[i]]]]) for every attribute of one corner table + joint i32 min/max
-// (minmax: int32[2] pre-initialised to {INT_MAX, INT_MIN}).  kind: 0 coordinate-wise, 1 octahedral, 2 ToBits.
+// Stage 1 for up to kMaxRangeAtts attributes in two launches: f32 min/max (kind 0, seeded 0.0: Q1) → meta, zero-length
+// normal check (kind 1) → small[4]; every attribute's 16 scratch words are (re)initialised: [0..1] = {INT_MAX, INT_MIN}.
+constexpr int kMaxRangeAtts = 8;
+constexpr uint32_t kRangeMaxBlocks = 1024;   // partials: kRangeMaxBlocks * 2N floats per attribute
+struct RangeAtt { const float* raw; float* partials; float* meta; uint32_t* small; uint32_t n; int N; int kind; uint32_t first_block, blocks; };
+struct RangeArgs { RangeAtt a[kMaxRangeAtts]; int count; };
+void launch_value_ranges(RangeArgs& args, hipStream_t s);
+// joint i32 min/max of the sequence-ordered quantized values: per-block partials of k_seq_quantize → minmax[2]
+struct MinMaxAtt { const int32_t* ipartials; int32_t* minmax; uint32_t blocks; uint32_t pad; };
+struct MinMaxArgs { MinMaxAtt a[kMaxRangeAtts]; int count; };
+void launch_i32_minmax_final(const MinMaxArgs& args, hipStream_t s);
+uint32_t seq_quantize_blocks(uint32_t n);   // grid of launch_seq_quantize = partials written per attribute
+// qs[i] = portabilize(raw[p2v[c2p[seq[i]]]]) for every attribute of one corner table + per-block joint i32 min/max
+// partials (ipartials: int32[2 * seq_quantize_blocks(n)]).  kind: 0 coordinate-wise, 1 octahedral, 2 ToBits.
 constexpr int kMaxGather = 4;
-struct QuantAtt { const float* raw; const uint32_t* p2v; int32_t* qs; int32_t* minmax; const float* meta; float maxq; int kind; int N; int pad; };
+struct QuantAtt { const float* raw; const uint32_t* p2v; int32_t* qs; int32_t* ipartials; const float* meta; float maxq; int kind; int N; int pad; };
 struct QuantArgs { QuantAtt a[kMaxGather]; int count; };
 void launch_seq_quantize(const uint32_t* seq, uint32_t n, const uint32_t* c2p, const QuantArgs& args, hipStream_t s);
 // fn[3f..3f+2] = cross(pos[c1]-pos[c0], pos[c2]-pos[c0]) of the quantised positions of face f (i32, wrapping);

@@ -65,7 +65,7 @@ struct AttJob {
   int nq = 0;            // components after portabilization
   int table = 0;         // index into tables
   int parent = -1;
-  DevMem raw, p2v, fn, qs, sym, aux /*flips or orient*/, hist, rtable, rec, out, meta, partials, small /*minmax[2], counters[2], flags[2], out_len[2]*2*/, summary;
+  DevMem raw, p2v, fn, qs, sym, aux /*flips or orient*/, hist, rtable, rec, out, meta, partials, ipartials, small /*minmax[2], counters[2], flags[2], out_len[2]*2*/, summary;
   uint32_t bins = 0;
   uint64_t n_sym = 0;
   uint64_t out_cap = 0, aux_cap = 0;
@@ -393,7 +393,8 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
     a.out_cap = a.n_sym * 3 + 16;   // ≤ 3 renormalisation bytes per symbol (P ≤ 20) + flush
     if ((rc = a.out.alloc(a.out_cap))) return rc;
     if ((rc = a.meta.alloc(64))) return rc;
-    if ((rc = a.partials.alloc((size_t)2048 * 8 * 4))) return rc;
+    if ((rc = a.partials.alloc((size_t)kRangeMaxBlocks * 8 * 4))) return rc;
+    if ((rc = a.ipartials.alloc((size_t)2048 * 2 * 4))) return rc;   // ≥ 2 * seq_quantize_blocks(n)
     if ((rc = a.small.alloc(64))) return rc;
     pinned_need += 256 + (size_t)a.bins * 4 + (size_t)std::max(1u, orient_summary_blocks(n)) * 16;
     // algorithmic bytes of the quantize+predict pass: 4·Nin + 4·Nsym per value, 8 per sequence entry
@@ -432,11 +433,20 @@ static int encode_phase_a(dmi_job* job) {   // device: ranges → coding-order p
   const uint32_t* c2p = job->c2p.as<uint32_t>();
   // ---- stage 1: value ranges (streamed over the unique values) ---------------------------------------------
   if (timed) HIP_TRY(hipEventRecord(job->ev[0], s));
-  for (auto& a : job->atts) {
-    const dmi_attribute& d = a.desc;
-    launch_init_small(a.small.as<uint32_t>(), s);   // zero + minmax := {INT_MAX, INT_MIN}
-    if (a.port == kCoordwise) launch_minmax_f32(a.raw.as<float>(), d.num_unique, d.num_components, a.partials.as<float>(), 2048, a.meta.as<float>(), s);
-    else if (a.port == kOct) launch_check_normals(a.raw.as<float>(), d.num_unique, a.small.as<uint32_t>() + 4, s);
+  {
+    RangeArgs ra{};
+    for (auto& a : job->atts) {
+      RangeAtt& r = ra.a[ra.count++];
+      r.raw = a.raw.as<float>();
+      r.partials = a.partials.as<float>();
+      r.meta = a.meta.as<float>();
+      r.small = a.small.as<uint32_t>();   // zeroed here; [0..1] := {INT_MAX, INT_MIN}; [4] := zero-length normal seen
+      r.n = a.desc.num_unique;
+      r.N = a.desc.num_components;
+      r.kind = a.port == kCoordwise ? 0 : (a.port == kOct ? 1 : 2);
+      if (ra.count == kMaxRangeAtts) { launch_value_ranges(ra, s); ra.count = 0; }
+    }
+    launch_value_ranges(ra, s);
   }
   // ---- stage 2: portabilization in coding order + predict + transform ---------------------------------------
   if (timed) HIP_TRY(hipEventRecord(job->ev[1], s));
@@ -455,7 +465,7 @@ static int encode_phase_a(dmi_job* job) {   // device: ranges → coding-order p
       g.raw = a.raw.as<float>();
       g.p2v = a.p2v.as<uint32_t>();
       g.qs = a.qs.as<int32_t>();
-      g.minmax = a.small.as<int32_t>();
+      g.ipartials = a.ipartials.as<int32_t>();
       g.meta = a.meta.as<float>();
       g.maxq = (float)(uint64_t)((1ull << a.bits) - 1ull);
       g.kind = a.port == kCoordwise ? 0 : (a.port == kOct ? 1 : 2);
@@ -463,6 +473,17 @@ static int encode_phase_a(dmi_job* job) {   // device: ranges → coding-order p
       if (qa.count == kMaxGather) flush();
     }
     flush();
+  }
+  {
+    MinMaxArgs ma{};
+    for (auto& a : job->atts) {
+      MinMaxAtt& m = ma.a[ma.count++];
+      m.ipartials = a.ipartials.as<int32_t>();
+      m.minmax = a.small.as<int32_t>();
+      m.blocks = seq_quantize_blocks(job->tables[a.table].n_seq);
+      if (ma.count == kMaxRangeAtts) { launch_i32_minmax_final(ma, s); ma.count = 0; }
+    }
+    launch_i32_minmax_final(ma, s);
   }
   for (auto& a : job->atts) {
     const TableDev& t = job->tables[a.table];

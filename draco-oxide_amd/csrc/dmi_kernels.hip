@@ -96,38 +96,62 @@ __device__ __forceinline__ void block_reduce_minmax(float (&mn)[N], float (&mx)[
   }
 }
 
-// per-attribute scratch words: [0..1] joint i32 min/max (seeded INT_MAX / INT_MIN), everything else zero
-__global__ __launch_bounds__(64) void k_init_small(uint32_t* __restrict__ small) {
-  if (threadIdx.x < 16) small[threadIdx.x] = threadIdx.x == 0 ? 0x7FFFFFFFu : (threadIdx.x == 1 ? 0x80000000u : 0u);
-}
-
+// ------------------------------------------------------------------------------------------------
+// Stage 1, every attribute of a job in two launches (same-address atomics from a full-chip grid serialise at
+// ≈11 ns each — scripts/probes/atomics_probe.hip — so every reduction here goes through per-block partials).
+//   k_value_ranges        block → (attribute, slice): f32 min/max partials (coordinate-wise attributes) or the
+//                         zero-length-normal check (geom.rs:45 assert) as a per-block flag
+//   k_value_ranges_final  one block per attribute: partials → meta (min[N], shared range Q2, max[N]); seeds the
+//                         16 scratch words: [0..1] joint i32 min/max = {INT_MAX, INT_MIN}, [4] zero-normal flag, rest 0
+// ------------------------------------------------------------------------------------------------
 template <int N>
-__global__ __launch_bounds__(kBlock) void k_minmax_f32(const float* __restrict__ vals, uint32_t n, float* __restrict__ partials) {
+__device__ __forceinline__ void range_slice(const RangeAtt& a, uint32_t block, float* out) {
   float mn[N], mx[N];
 #pragma unroll
   for (int k = 0; k < N; ++k) { mn[k] = 0.0f; mx[k] = 0.0f; }
-  for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < n; v += gridDim.x * kBlock) {
+  for (uint32_t v = block * kBlock + threadIdx.x; v < a.n; v += a.blocks * kBlock) {
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-      const float x = vals[(size_t)v * N + k];
+      const float x = a.raw[(size_t)v * N + k];
       if (x < mn[k]) mn[k] = x;
       if (x > mx[k]) mx[k] = x;
     }
   }
-  block_reduce_minmax<N>(mn, mx, partials + (size_t)blockIdx.x * 2 * N);
+  block_reduce_minmax<N>(mn, mx, out);
+}
+__global__ __launch_bounds__(kBlock) void k_value_ranges(RangeArgs args) {
+  int ai = 0;
+  while (ai + 1 < args.count && blockIdx.x >= args.a[ai + 1].first_block) ++ai;
+  const RangeAtt& a = args.a[ai];
+  const uint32_t block = blockIdx.x - a.first_block;
+  if (a.kind == 0) {
+    float* out = a.partials + (size_t)block * 2 * a.N;
+    switch (a.N) {
+      case 1: range_slice<1>(a, block, out); break;
+      case 2: range_slice<2>(a, block, out); break;
+      case 3: range_slice<3>(a, block, out); break;
+      default: range_slice<4>(a, block, out); break;
+    }
+  } else if (a.kind == 1) {
+    bool bad = false;
+    for (uint32_t v = block * kBlock + threadIdx.x; v < a.n; v += a.blocks * kBlock)
+      bad |= (a.raw[(size_t)v * 3] == 0.0f && a.raw[(size_t)v * 3 + 1] == 0.0f && a.raw[(size_t)v * 3 + 2] == 0.0f);
+    const int any = __syncthreads_or(bad ? 1 : 0);
+    if (threadIdx.x == 0) reinterpret_cast<uint32_t*>(a.partials)[block] = any ? 1u : 0u;
+  }
 }
 
 template <int N>
-__global__ __launch_bounds__(kBlock) void k_minmax_final(const float* __restrict__ partials, uint32_t nblocks, float* __restrict__ meta) {
+__device__ __forceinline__ void range_final(const RangeAtt& a) {
   float mn[N], mx[N];
 #pragma unroll
   for (int k = 0; k < N; ++k) { mn[k] = 0.0f; mx[k] = 0.0f; }
-  for (uint32_t b = threadIdx.x; b < nblocks; b += kBlock) {
+  for (uint32_t b = threadIdx.x; b < a.blocks; b += kBlock) {
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-      const float a = partials[(size_t)b * 2 * N + k], c = partials[(size_t)b * 2 * N + N + k];
-      if (a < mn[k]) mn[k] = a;
-      if (c > mx[k]) mx[k] = c;
+      const float lo = a.partials[(size_t)b * 2 * N + k], hi = a.partials[(size_t)b * 2 * N + N + k];
+      if (lo < mn[k]) mn[k] = lo;
+      if (hi > mx[k]) mx[k] = hi;
     }
   }
   __shared__ float res[2 * N];
@@ -138,9 +162,27 @@ __global__ __launch_bounds__(kBlock) void k_minmax_final(const float* __restrict
 #pragma unroll
     for (int k = 0; k < N; ++k) { const float d = res[N + k] - res[k]; if (d > delta_max) delta_max = d; }
 #pragma unroll
-    for (int k = 0; k < N; ++k) { meta[k] = res[k]; meta[N + 1 + k] = res[N + k]; }
-    meta[N] = delta_max;
+    for (int k = 0; k < N; ++k) { a.meta[k] = res[k]; a.meta[N + 1 + k] = res[N + k]; }
+    a.meta[N] = delta_max;
   }
+}
+__global__ __launch_bounds__(kBlock) void k_value_ranges_final(RangeArgs args) {
+  const RangeAtt& a = args.a[blockIdx.x];
+  uint32_t zero_normal = 0;
+  if (a.kind == 0) {
+    switch (a.N) {
+      case 1: range_final<1>(a); break;
+      case 2: range_final<2>(a); break;
+      case 3: range_final<3>(a); break;
+      default: range_final<4>(a); break;
+    }
+  } else if (a.kind == 1) {
+    bool bad = false;
+    for (uint32_t b = threadIdx.x; b < a.blocks; b += kBlock) bad |= reinterpret_cast<const uint32_t*>(a.partials)[b] != 0u;
+    zero_normal = __syncthreads_or(bad ? 1 : 0) ? 1u : 0u;
+  }
+  if (threadIdx.x < 16)
+    a.small[threadIdx.x] = threadIdx.x == 0 ? 0x7FFFFFFFu : (threadIdx.x == 1 ? 0x80000000u : (threadIdx.x == 4 ? zero_normal : 0u));
 }
 
 // q = trunc(((v - min) / range) * (2^bits - 1) + 0.5), range == 0 skips the divide (Q3); every f32 operation
@@ -179,14 +221,6 @@ __device__ __forceinline__ void oct_quantize(float x, float y, float z, int32_t&
   const float a = (u + 1.0f) * 127.0f;   // (1 << 8-1) - 1 = 127 (Q4)
   const float b = (v + 1.0f) * 127.0f;
   oct_faithful(f32_to_i32_sat(a), f32_to_i32_sat(b), qx, qy);
-}
-
-// Any zero-length normal is an error in the reference (geom.rs:45 assert): streamed check over the unique values.
-__global__ __launch_bounds__(kBlock) void k_check_normals(const float* __restrict__ vals, uint32_t n, uint32_t* __restrict__ zero_flag) {
-  bool bad = false;
-  for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < n; v += gridDim.x * kBlock)
-    bad |= (vals[(size_t)v * 3] == 0.0f && vals[(size_t)v * 3 + 1] == 0.0f && vals[(size_t)v * 3 + 2] == 0.0f);
-  if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(zero_flag, 1u);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -230,13 +264,40 @@ __global__ __launch_bounds__(kBlock) void k_seq_quantize(const uint32_t* __restr
       }
     }
   }
+  __shared__ int32_t red[kMaxGather][2][kBlock / 64];
 #pragma unroll
   for (int a = 0; a < kMaxGather; ++a) {
     if (a >= args.count) break;
     int32_t lo = mn[a], hi = mx[a];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_down(lo, off, 64)); hi = max(hi, __shfl_down(hi, off, 64)); }
-    if ((threadIdx.x & 63) == 0) { atomicMin(&args.a[a].minmax[0], lo); atomicMax(&args.a[a].minmax[1], hi); }
+    if ((threadIdx.x & 63) == 0) { red[a][0][threadIdx.x >> 6] = lo; red[a][1][threadIdx.x >> 6] = hi; }
+  }
+  __syncthreads();
+  if (threadIdx.x < (uint32_t)args.count) {   // one partial per block and attribute; k_i32_minmax_final folds them
+    int32_t lo = red[threadIdx.x][0][0], hi = red[threadIdx.x][1][0];
+#pragma unroll
+    for (int w = 1; w < kBlock / 64; ++w) { lo = min(lo, red[threadIdx.x][0][w]); hi = max(hi, red[threadIdx.x][1][w]); }
+    args.a[threadIdx.x].ipartials[2 * blockIdx.x] = lo;
+    args.a[threadIdx.x].ipartials[2 * blockIdx.x + 1] = hi;
+  }
+}
+
+// Joint i32 min/max (wrapped_difference.rs:36-52, Q16) of every attribute: one block per attribute.
+__global__ __launch_bounds__(kBlock) void k_i32_minmax_final(MinMaxArgs args) {
+  const MinMaxAtt& a = args.a[blockIdx.x];
+  int32_t lo = 2147483647, hi = (-2147483647 - 1);
+  for (uint32_t b = threadIdx.x; b < a.blocks; b += kBlock) { lo = min(lo, a.ipartials[2 * b]); hi = max(hi, a.ipartials[2 * b + 1]); }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_down(lo, off, 64)); hi = max(hi, __shfl_down(hi, off, 64)); }
+  __shared__ int32_t red[2][kBlock / 64];
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = lo; red[1][threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 1; w < kBlock / 64; ++w) { lo = min(lo, red[0][w]); hi = max(hi, red[1][w]); }
+    a.minmax[0] = lo;
+    a.minmax[1] = hi;
   }
 }
 
@@ -400,7 +461,15 @@ __global__ __launch_bounds__(kBlock) void k_pred_normal_octorth(const uint32_t* 
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) n_false += __shfl_down(n_false, off, 64);
-  if ((threadIdx.x & 63) == 0 && n_false) atomicAdd(&counters[0], n_false);
+  __shared__ uint32_t wave_false[kBlock / 64];
+  if ((threadIdx.x & 63) == 0) wave_false[threadIdx.x >> 6] = n_false;
+  __syncthreads();
+  if (threadIdx.x == 0) {   // one atomic per block (same-address atomics serialise)
+    uint32_t t = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) t += wave_false[w];
+    if (t) atomicAdd(&counters[0], t);
+  }
 }
 
 // Exact i64 `a / d` (truncating) for the texture-coordinate predictor.  The software 64-bit divide costs ~100
@@ -575,22 +644,24 @@ inline uint32_t grid_for(uint64_t work, uint32_t cap = 256 * 8) {
 // ------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
-void launch_init_small(uint32_t* small, hipStream_t s) { hipLaunchKernelGGL(k_init_small, 1, 64, 0, s, small); }
-
-void launch_minmax_f32(const float* vals, uint32_t n, int N, float* partials, uint32_t max_blocks, float* meta, hipStream_t s) {
-  uint32_t g = grid_for(n, max_blocks);
-  switch (N) {
-    case 1: hipLaunchKernelGGL(k_minmax_f32<1>, g, kBlock, 0, s, vals, n, partials); hipLaunchKernelGGL(k_minmax_final<1>, 1, kBlock, 0, s, partials, g, meta); break;
-    case 2: hipLaunchKernelGGL(k_minmax_f32<2>, g, kBlock, 0, s, vals, n, partials); hipLaunchKernelGGL(k_minmax_final<2>, 1, kBlock, 0, s, partials, g, meta); break;
-    case 3: hipLaunchKernelGGL(k_minmax_f32<3>, g, kBlock, 0, s, vals, n, partials); hipLaunchKernelGGL(k_minmax_final<3>, 1, kBlock, 0, s, partials, g, meta); break;
-    default: hipLaunchKernelGGL(k_minmax_f32<4>, g, kBlock, 0, s, vals, n, partials); hipLaunchKernelGGL(k_minmax_final<4>, 1, kBlock, 0, s, partials, g, meta); break;
+void launch_value_ranges(RangeArgs& args, hipStream_t s) {
+  if (args.count == 0) return;
+  uint32_t total = 0;
+  for (int i = 0; i < args.count; ++i) {
+    RangeAtt& a = args.a[i];
+    a.blocks = a.kind == 2 ? 0u : std::min<uint32_t>(kRangeMaxBlocks, std::max<uint32_t>(1u, (a.n + kBlock - 1) / kBlock));
+    a.first_block = total;
+    total += a.blocks;
   }
+  if (total) hipLaunchKernelGGL(k_value_ranges, total, kBlock, 0, s, args);
+  hipLaunchKernelGGL(k_value_ranges_final, (uint32_t)args.count, kBlock, 0, s, args);
 }
 
-void launch_check_normals(const float* vals, uint32_t n, uint32_t* zero_flag, hipStream_t s) {
-  if (n) hipLaunchKernelGGL(k_check_normals, grid_for(n), kBlock, 0, s, vals, n, zero_flag);
+void launch_i32_minmax_final(const MinMaxArgs& args, hipStream_t s) {
+  if (args.count) hipLaunchKernelGGL(k_i32_minmax_final, (uint32_t)args.count, kBlock, 0, s, args);
 }
 
+uint32_t seq_quantize_blocks(uint32_t n) { return grid_for(n); }
 void launch_seq_quantize(const uint32_t* seq, uint32_t n, const uint32_t* c2p, const QuantArgs& args, hipStream_t s) {
   hipLaunchKernelGGL(k_seq_quantize, grid_for(n), kBlock, 0, s, seq, n, c2p, args);
 }
