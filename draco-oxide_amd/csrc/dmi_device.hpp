@@ -21,12 +21,12 @@ struct MinMaxAtt { const int32_t* ipartials; int32_t* minmax; uint32_t blocks; u
 struct MinMaxArgs { MinMaxAtt a[kMaxRangeAtts]; int count; };
 void launch_i32_minmax_final(const MinMaxArgs& args, hipStream_t s);
 uint32_t seq_quantize_blocks(uint32_t n);   // grid of launch_seq_quantize = partials written per attribute
-// qs[i] = portabilize(raw[p2v[c2p[seq[i]]]]) for every attribute of one corner table + per-block joint i32 min/max
+// qs[i] = portabilize(raw[s2v ? s2v[i] : s2p[i]]) for every attribute of one corner table (s2p[i] = point_idx(seq[i])) + per-block joint i32 min/max
 // partials (ipartials: int32[2 * seq_quantize_blocks(n)]).  kind: 0 coordinate-wise, 1 octahedral, 2 ToBits.
 constexpr int kMaxGather = 4;
-struct QuantAtt { const float* raw; const uint32_t* p2v; int32_t* qs; int32_t* ipartials; const float* meta; float maxq; int kind; int N; int pad; };
+struct QuantAtt { const float* raw; const uint32_t* s2v; int32_t* qs; int32_t* ipartials; const float* meta; float maxq; int kind; int N; int pad; };
 struct QuantArgs { QuantAtt a[kMaxGather]; int count; };
-void launch_seq_quantize(const uint32_t* seq, uint32_t n, const uint32_t* c2p, const QuantArgs& args, hipStream_t s);
+void launch_seq_quantize(const uint32_t* s2p, uint32_t n, const QuantArgs& args, hipStream_t s);
 // fn[3f..3f+2] = cross(pos[c1]-pos[c0], pos[c2]-pos[c0]) of the quantised positions of face f (i32, wrapping);
 // c2r_pos / qs_pos: the position attribute's corner→sequence-index table and sequence-ordered values
 void launch_face_normals(const uint32_t* c2r_pos, uint32_t nfaces, const int32_t* qs_pos, int32_t* fn, hipStream_t s);

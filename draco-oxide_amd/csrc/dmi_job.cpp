@@ -49,7 +49,8 @@ struct DevMem {
 
 struct TableDev {
   uint32_t F = 0, V = 0, n_seq = 0;
-  DevMem c2r, opp, seq;   // c2p is shared by all tables of a job; c2r = corner → sequence index of its vertex
+  DevMem c2r, opp, seq, s2p;   // c2r = corner → sequence index of its vertex; s2p = sequence index → point (= point_idx(seq[i]))
+  std::vector<uint32_t> s2p_host;
   // sharing: a table whose arrays equal another table's reuses its device copies
   int alias_of = -1;
 };
@@ -65,7 +66,7 @@ struct AttJob {
   int nq = 0;            // components after portabilization
   int table = 0;         // index into tables
   int parent = -1;
-  DevMem raw, p2v, fn, qs, sym, aux /*flips or orient*/, hist, rtable, rec, out, meta, partials, ipartials, small /*minmax[2], counters[2], flags[2], out_len[2]*2*/, summary;
+  DevMem raw, s2v /*sequence index → value index, only with a point_to_value map*/, fn, qs, sym, aux /*flips or orient*/, hist, rtable, rec, out, meta, partials, ipartials, small /*minmax[2], counters[2], flags[2], out_len[2]*2*/, summary;
   uint32_t bins = 0;
   uint64_t n_sym = 0;
   uint64_t out_cap = 0, aux_cap = 0;
@@ -86,7 +87,6 @@ struct dmi_job {
   bool own_stream = false;
   std::vector<AttJob> atts;
   std::vector<TableDev> tables;
-  DevMem c2p;
   DevMem descs;
   void* pinned = nullptr;   // host-pinned readback area
   size_t pinned_bytes = 0;
@@ -328,10 +328,6 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
     for (uint32_t f = 0; f < F; ++f) new_face[f] = start[key[f]]++;
     auto map_corner = [&](uint32_t c) { return c == kNone ? kNone : 3u * new_face[c / 3u] + c % 3u; };
     std::vector<uint32_t> tmp(C), tmp2(C);
-    for (size_t c = 0; c < C; ++c) tmp[map_corner((uint32_t)c)] = tables[0].corner_to_point[c];
-    rc = upload(job->c2p, tmp.data(), C * 4, s);
-    if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(s));
     std::vector<uint32_t> rank, seq2;
     for (uint32_t i = 0; i < n_atts; ++i) {
       TableDev& t = job->tables[i];
@@ -348,6 +344,10 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
       seq2.resize(t.n_seq);
       for (uint32_t k = 0; k < t.n_seq; ++k) seq2[k] = map_corner(seq_of[i][k]);
       if ((rc = upload(t.seq, seq2.data(), (size_t)t.n_seq * 4, s))) return rc;
+      // the point every sequence entry stands for (attribute_encoder.rs:332-338 reads attribute.get(point_idx(c)))
+      t.s2p_host.resize(t.n_seq);
+      for (uint32_t k = 0; k < t.n_seq; ++k) t.s2p_host[k] = tables[0].corner_to_point[seq_of[i][k]];
+      if ((rc = upload(t.s2p, t.s2p_host.data(), (size_t)t.n_seq * 4, s))) return rc;
       HIP_TRY(hipStreamSynchronize(s));   // tmp/tmp2/seq2 are reused
     }
   }
@@ -364,8 +364,18 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
     if (d.num_unique && !d.values) return fail(DMI_ERR_INVALID_ARGUMENT, "attribute values missing");
     rc = upload(a.raw, d.values, vbytes, s);
     if (rc) return rc;
-    if (d.point_to_value) { rc = upload(a.p2v, d.point_to_value, (size_t)d.num_points * 4, s); if (rc) return rc; }
     if (d.num_points <= max_point && F) return fail(DMI_ERR_INVALID_ARGUMENT, "attribute " + std::to_string(i) + " has fewer points than the faces reference");
+    if (d.point_to_value) {   // sequence index → value index: the map composed with the table's sequence → point array
+      std::vector<uint32_t> s2v(t.n_seq);
+      for (uint32_t k = 0; k < t.n_seq; ++k) {
+        s2v[k] = d.point_to_value[t.s2p_host[k]];
+        if (s2v[k] >= d.num_unique) return fail(DMI_ERR_INVALID_ARGUMENT, "attribute " + std::to_string(i) + ": point_to_value entry out of range");
+      }
+      if ((rc = upload(a.s2v, s2v.data(), (size_t)t.n_seq * 4, s))) return rc;
+      HIP_TRY(hipStreamSynchronize(s));
+    } else if (d.num_unique <= max_point && F) {
+      return fail(DMI_ERR_INVALID_ARGUMENT, "attribute " + std::to_string(i) + " has fewer values than the faces reference");
+    }
     const uint32_t n = t.n_seq;
     a.n_sym = (uint64_t)n * a.nq;
     if ((rc = a.qs.alloc((size_t)n * a.nq * 4))) return rc;
@@ -430,7 +440,6 @@ static int encode_phase_a(dmi_job* job) {   // device: ranges → coding-order p
   const uint32_t n_atts = (uint32_t)job->atts.size();
   uint8_t* pinned = static_cast<uint8_t*>(job->pinned);
   const bool timed = job->have_events;
-  const uint32_t* c2p = job->c2p.as<uint32_t>();
   // ---- stage 1: value ranges (streamed over the unique values) ---------------------------------------------
   if (timed) HIP_TRY(hipEventRecord(job->ev[0], s));
   {
@@ -456,14 +465,14 @@ static int encode_phase_a(dmi_job* job) {   // device: ranges → coding-order p
     if (t.alias_of >= 0) continue;
     QuantArgs qa{};
     auto flush = [&]() {
-      if (qa.count) launch_seq_quantize(t.seq.as<uint32_t>(), t.n_seq, c2p, qa, s);
+      if (qa.count) launch_seq_quantize(t.s2p.as<uint32_t>(), t.n_seq, qa, s);
       qa.count = 0;
     };
     for (auto& a : job->atts) {
       if ((size_t)a.table != ti) continue;
       QuantAtt& g = qa.a[qa.count++];
       g.raw = a.raw.as<float>();
-      g.p2v = a.p2v.as<uint32_t>();
+      g.s2v = a.s2v.as<uint32_t>();
       g.qs = a.qs.as<int32_t>();
       g.ipartials = a.ipartials.as<int32_t>();
       g.meta = a.meta.as<float>();
@@ -562,6 +571,7 @@ static int encode_phase_b(dmi_job* job) {   // host: table normalisation; device
     AttJob& a = job->atts[i];
     const uint8_t* base = pinned + pin_off[i];
     const uint32_t* small = reinterpret_cast<const uint32_t*>(base);
+    if (std::getenv("DMI_TRACE")) std::fprintf(stderr, "[dmi] attribute %u small: %08x %08x %u %u %u %u %u %u\n", i, small[0], small[1], small[2], small[3], small[4], small[5], small[6], small[7]);
     if (small[4]) return fail(DMI_ERR_ZERO_NORMAL, "attribute " + std::to_string(i) + " contains a zero-length normal (reference assert, geom.rs:45)");
     if (small[5]) return fail(DMI_ERR_ALPHABET_TOO_LARGE, "symbol outside the histogram bound");
     const uint32_t n = job->tables[a.table].n_seq;

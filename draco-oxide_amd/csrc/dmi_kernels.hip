@@ -167,8 +167,9 @@ __device__ __forceinline__ void range_final(const RangeAtt& a) {
   }
 }
 __global__ __launch_bounds__(kBlock) void k_value_ranges_final(RangeArgs args) {
-  const RangeAtt& a = args.a[blockIdx.x];
-  uint32_t zero_normal = 0;
+  const RangeAtt a = args.a[blockIdx.x];
+  if (threadIdx.x < 16) a.small[threadIdx.x] = threadIdx.x == 0 ? 0x7FFFFFFFu : (threadIdx.x == 1 ? 0x80000000u : 0u);
+  __syncthreads();   // the seeding stores are performed before any flag store below
   if (a.kind == 0) {
     switch (a.N) {
       case 1: range_final<1>(a); break;
@@ -179,10 +180,8 @@ __global__ __launch_bounds__(kBlock) void k_value_ranges_final(RangeArgs args) {
   } else if (a.kind == 1) {
     bool bad = false;
     for (uint32_t b = threadIdx.x; b < a.blocks; b += kBlock) bad |= reinterpret_cast<const uint32_t*>(a.partials)[b] != 0u;
-    zero_normal = __syncthreads_or(bad ? 1 : 0) ? 1u : 0u;
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) a.small[4] = 1u;   // same value from every writer
   }
-  if (threadIdx.x < 16)
-    a.small[threadIdx.x] = threadIdx.x == 0 ? 0x7FFFFFFFu : (threadIdx.x == 1 ? 0x80000000u : (threadIdx.x == 4 ? zero_normal : 0u));
 }
 
 // q = trunc(((v - min) / range) * (2^bits - 1) + 0.5), range == 0 skips the divide (Q3); every f32 operation
@@ -225,7 +224,8 @@ __device__ __forceinline__ void oct_quantize(float x, float y, float z, int32_t&
 
 // ------------------------------------------------------------------------------------------------
 // Portabilization in coding order.  Entry i of the sequence is quantized straight into qs[i]:
-//   qs[i] = portabilize(raw[p2v[point(seq[i])]])          (attribute_encoder.rs:332-338 reads exactly these)
+//   qs[i] = portabilize(raw[value(point(seq[i]))])        (attribute_encoder.rs:332-338 reads exactly these)
+// The index chain seq → corner_to_point → point_to_value is composed once at job creation (s2p / s2v).
 // so no value-ordered quantized array is ever materialised.  Every attribute coded on the same corner table
 // is served by one launch (they share seq / corner_to_point traffic); the joint i32 min/max of each attribute
 // (wrapped_difference.rs:36-52, Q16) is reduced on the fly.  All corners of one (attribute-)vertex carry the
@@ -233,7 +233,7 @@ __device__ __forceinline__ void oct_quantize(float x, float y, float z, int32_t&
 // ------------------------------------------------------------------------------------------------
 template <int N>
 __device__ __forceinline__ void quantize_one(const QuantAtt& a, uint32_t p, uint32_t i, int32_t& mn, int32_t& mx) {
-  if (a.p2v) p = a.p2v[p];
+  if (a.s2v) p = a.s2v[i];
   int32_t out[N];
   int nq = N;
   if (a.kind == 0) {   // coordinate-wise (meta: min[N], range)
@@ -247,12 +247,12 @@ __device__ __forceinline__ void quantize_one(const QuantAtt& a, uint32_t p, uint
   }
   for (int k = 0; k < nq; ++k) { a.qs[(size_t)i * nq + k] = out[k]; mn = min(mn, out[k]); mx = max(mx, out[k]); }
 }
-__global__ __launch_bounds__(kBlock) void k_seq_quantize(const uint32_t* __restrict__ seq, uint32_t n, const uint32_t* __restrict__ c2p, QuantArgs args) {
+__global__ __launch_bounds__(kBlock) void k_seq_quantize(const uint32_t* __restrict__ s2p, uint32_t n, QuantArgs args) {
   int32_t mn[kMaxGather], mx[kMaxGather];
 #pragma unroll
   for (int a = 0; a < kMaxGather; ++a) { mn[a] = 2147483647; mx[a] = (-2147483647 - 1); }
   DMI_FOR_SEQUENCE(i, n) {
-    const uint32_t p = c2p[seq[i]];
+    const uint32_t p = s2p[i];
 #pragma unroll
     for (int a = 0; a < kMaxGather; ++a) {
       if (a >= args.count) break;
@@ -662,8 +662,8 @@ void launch_i32_minmax_final(const MinMaxArgs& args, hipStream_t s) {
 }
 
 uint32_t seq_quantize_blocks(uint32_t n) { return grid_for(n); }
-void launch_seq_quantize(const uint32_t* seq, uint32_t n, const uint32_t* c2p, const QuantArgs& args, hipStream_t s) {
-  hipLaunchKernelGGL(k_seq_quantize, grid_for(n), kBlock, 0, s, seq, n, c2p, args);
+void launch_seq_quantize(const uint32_t* s2p, uint32_t n, const QuantArgs& args, hipStream_t s) {
+  hipLaunchKernelGGL(k_seq_quantize, grid_for(n), kBlock, 0, s, s2p, n, args);
 }
 
 void launch_face_normals(const uint32_t* c2r_pos, uint32_t nfaces, const int32_t* qs_pos, int32_t* fn, hipStream_t s) {
