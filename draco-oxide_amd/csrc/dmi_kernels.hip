@@ -34,6 +34,13 @@ __device__ __forceinline__ uint32_t cprev(uint32_t c) { return (c % 3u == 0u) ? 
        ch_ < end_; ch_ += (gridDim.x >> 3))                                                              \
     for (uint32_t I = ch_ * kBlock + threadIdx.x; I < (N); I = (N))
 
+// Same sweep in tiles of K·kBlock entries (each thread handles K entries of a tile, kBlock apart).
+#define DMI_FOR_TILES(BASE, N, K)                                                                                   \
+  for (uint32_t nch_ = ((N) + kBlock * (K) - 1) / (kBlock * (K)), per_ = (nch_ + 7u) / 8u, xcd_ = blockIdx.x & 7u,   \
+                end_ = min(nch_, (xcd_ + 1u) * per_), ch_ = xcd_ * per_ + (blockIdx.x >> 3);                       \
+       ch_ < end_; ch_ += (gridDim.x >> 3))                                                                        \
+    for (uint32_t BASE = ch_ * kBlock * (K), once_ = 1; once_; once_ = 0)
+
 // Rust `as` casts: saturating, NaN → 0.
 __device__ __forceinline__ int32_t f32_to_i32_sat(float f) {
   if (f != f) return 0;
@@ -231,36 +238,59 @@ __device__ __forceinline__ void oct_quantize(float x, float y, float z, int32_t&
 // (wrapped_difference.rs:36-52, Q16) is reduced on the fly.  All corners of one (attribute-)vertex carry the
 // same value, so qs[c2r[c]] == attribute.get(point_idx(c)) for every corner c of the table.
 // ------------------------------------------------------------------------------------------------
+// Each thread owns kTile entries of a tile (entry t of the tile at base + t·kBlock + threadIdx.x) and issues all of
+// their gathers before touching any of them: the pass is latency-bound otherwise (one 12-byte gather in flight per
+// lane is ≈3 TB/s by Little's law at HBM latency).
+constexpr int kTile = 4;
 template <int N>
-__device__ __forceinline__ void quantize_one(const QuantAtt& a, uint32_t p, uint32_t i, int32_t& mn, int32_t& mx) {
-  if (a.s2v) p = a.s2v[i];
-  int32_t out[N];
-  int nq = N;
-  if (a.kind == 0) {   // coordinate-wise (meta: min[N], range)
+__device__ __forceinline__ void quantize_tile(const QuantAtt& a, const uint32_t (&p)[kTile], uint32_t base, uint32_t n, int32_t& mn, int32_t& mx) {
+  uint32_t v[kTile];
+  float raw[kTile][N];
 #pragma unroll
-    for (int k = 0; k < N; ++k) out[k] = quant_coord(a.raw[(size_t)p * N + k], a.meta[k], a.meta[N], a.maxq);
-  } else if (a.kind == 1) {   // octahedral (N == 3 → 2 components)
-    if (N == 3) { int32_t u, v; oct_quantize(a.raw[(size_t)p * 3], a.raw[(size_t)p * 3 + 1], a.raw[(size_t)p * 3 + 2], u, v); out[0] = u; out[1] = v; nq = 2; }
-  } else {   // ToBits: the 4-byte values reinterpreted as i32
-#pragma unroll
-    for (int k = 0; k < N; ++k) out[k] = __float_as_int(a.raw[(size_t)p * N + k]);
+  for (int t = 0; t < kTile; ++t) {
+    const uint32_t i = base + t * kBlock + threadIdx.x;
+    v[t] = (a.s2v && i < n) ? a.s2v[i] : p[t];
   }
-  for (int k = 0; k < nq; ++k) { a.qs[(size_t)i * nq + k] = out[k]; mn = min(mn, out[k]); mx = max(mx, out[k]); }
+#pragma unroll
+  for (int t = 0; t < kTile; ++t) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) raw[t][k] = a.raw[(size_t)v[t] * N + k];   // (entries past n read value 0: harmless)
+  }
+#pragma unroll
+  for (int t = 0; t < kTile; ++t) {
+    const uint32_t i = base + t * kBlock + threadIdx.x;
+    int32_t out[N];
+    int nq = N;
+    if (a.kind == 0) {   // coordinate-wise (meta: min[N], range)
+#pragma unroll
+      for (int k = 0; k < N; ++k) out[k] = quant_coord(raw[t][k], a.meta[k], a.meta[N], a.maxq);
+    } else if (a.kind == 1) {   // octahedral (N == 3 → 2 components)
+      if (N == 3) { int32_t u, w; oct_quantize(raw[t][0], raw[t][1], raw[t][2], u, w); out[0] = u; out[1] = w; nq = 2; }
+    } else {   // ToBits: the 4-byte values reinterpreted as i32
+#pragma unroll
+      for (int k = 0; k < N; ++k) out[k] = __float_as_int(raw[t][k]);
+    }
+    if (i < n) {
+      for (int k = 0; k < nq; ++k) { a.qs[(size_t)i * nq + k] = out[k]; mn = min(mn, out[k]); mx = max(mx, out[k]); }
+    }
+  }
 }
 __global__ __launch_bounds__(kBlock) void k_seq_quantize(const uint32_t* __restrict__ s2p, uint32_t n, QuantArgs args) {
   int32_t mn[kMaxGather], mx[kMaxGather];
 #pragma unroll
   for (int a = 0; a < kMaxGather; ++a) { mn[a] = 2147483647; mx[a] = (-2147483647 - 1); }
-  DMI_FOR_SEQUENCE(i, n) {
-    const uint32_t p = s2p[i];
+  DMI_FOR_TILES(base, n, kTile) {
+    uint32_t p[kTile];
+#pragma unroll
+    for (int t = 0; t < kTile; ++t) { const uint32_t i = base + t * kBlock + threadIdx.x; p[t] = i < n ? s2p[i] : 0u; }
 #pragma unroll
     for (int a = 0; a < kMaxGather; ++a) {
       if (a >= args.count) break;
       switch (args.a[a].N) {
-        case 1: quantize_one<1>(args.a[a], p, i, mn[a], mx[a]); break;
-        case 2: quantize_one<2>(args.a[a], p, i, mn[a], mx[a]); break;
-        case 3: quantize_one<3>(args.a[a], p, i, mn[a], mx[a]); break;
-        default: quantize_one<4>(args.a[a], p, i, mn[a], mx[a]); break;
+        case 1: quantize_tile<1>(args.a[a], p, base, n, mn[a], mx[a]); break;
+        case 2: quantize_tile<2>(args.a[a], p, base, n, mn[a], mx[a]); break;
+        case 3: quantize_tile<3>(args.a[a], p, base, n, mn[a], mx[a]); break;
+        default: quantize_tile<4>(args.a[a], p, base, n, mn[a], mx[a]); break;
       }
     }
   }
@@ -661,9 +691,9 @@ void launch_i32_minmax_final(const MinMaxArgs& args, hipStream_t s) {
   if (args.count) hipLaunchKernelGGL(k_i32_minmax_final, (uint32_t)args.count, kBlock, 0, s, args);
 }
 
-uint32_t seq_quantize_blocks(uint32_t n) { return grid_for(n); }
+uint32_t seq_quantize_blocks(uint32_t n) { return grid_for(((uint64_t)n + kTile - 1) / kTile); }
 void launch_seq_quantize(const uint32_t* s2p, uint32_t n, const QuantArgs& args, hipStream_t s) {
-  hipLaunchKernelGGL(k_seq_quantize, grid_for(n), kBlock, 0, s, s2p, n, args);
+  hipLaunchKernelGGL(k_seq_quantize, seq_quantize_blocks(n), kBlock, 0, s, s2p, n, args);
 }
 
 void launch_face_normals(const uint32_t* c2r_pos, uint32_t nfaces, const int32_t* qs_pos, int32_t* fn, hipStream_t s) {
