@@ -31,6 +31,16 @@ void launch_seq_quantize(const uint32_t* s2p, uint32_t n, const QuantArgs& args,
 // c2r_pos / qs_pos: the position attribute's corner→sequence-index table and sequence-ordered values
 void launch_face_normals(const uint32_t* c2r_pos, uint32_t nfaces, const int32_t* qs_pos, int32_t* fn, hipStream_t s);
 
+// Seam-free fast path: position (parallelogram, 3 components) + normal and/or texture coordinates coded on the SAME
+// corner table in one sweep (see k_predict_fused).  qs_nrm / qs_uv null = attribute absent (at least one is set).
+struct FusedArgs {
+  const uint32_t* seq; const uint32_t* c2r; const uint32_t* opp; uint32_t n; uint32_t pad;
+  const int32_t* qs_pos; const int32_t* mm_pos; uint32_t* sym_pos;
+  const int32_t* qs_nrm; uint32_t* sym_nrm; uint8_t* flips; uint32_t* counters;
+  const int32_t* qs_uv; const int32_t* mm_uv; uint32_t* sym_uv; uint8_t* orient;
+};
+void launch_predict_fused(const FusedArgs& a, hipStream_t s);
+
 // ---- predict + transform (a7-a14) → symbols ------------------------------------------------------
 // c2r[c] = sequence index of corner c's vertex (DMI_NONE if never coded): "already coded" ⇔ c2r[c] < i
 void launch_pred_parallelogram_wrapped(const uint32_t* seq, uint32_t n, const uint32_t* c2r, const uint32_t* opp,

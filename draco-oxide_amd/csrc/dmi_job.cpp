@@ -66,6 +66,8 @@ struct AttJob {
   int nq = 0;            // components after portabilization
   int table = 0;         // index into tables
   int parent = -1;
+  int fused_into = -1;   // ≥ 0: predicted by the fused seam-free sweep launched for that position attribute
+  int fused_nrm = -1, fused_uv = -1;   // (on a position attribute) the attributes its fused sweep also predicts
   DevMem raw, s2v /*sequence index → value index, only with a point_to_value map*/, fn, qs, sym, aux /*flips or orient*/, hist, rtable, rec, out, meta, partials, ipartials, small /*minmax[2], counters[2], flags[2], out_len[2]*2*/, summary;
   uint32_t bins = 0;
   uint64_t n_sym = 0;
@@ -352,6 +354,20 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
     }
   }
 
+  // Seam-free fast path: a normal / texture-coordinate attribute coded on the same corner table as its parent
+  // position attribute (3 components, parallelogram) is predicted together with it in one sweep (k_predict_fused).
+  if (!std::getenv("DMI_NO_FUSED")) {
+    for (uint32_t i = 0; i < n_atts; ++i) {
+      AttJob& a = job->atts[i];
+      if ((a.scheme != kNormal && a.scheme != kTexCoord) || a.parent < 0) continue;
+      AttJob& p = job->atts[a.parent];
+      if (p.scheme != kParallelogram || p.nq != 3 || p.table != a.table) continue;
+      int& slot = a.scheme == kNormal ? p.fused_nrm : p.fused_uv;
+      if (slot >= 0) continue;   // one of each kind per sweep; further ones take their own kernels
+      slot = (int)i;
+      a.fused_into = a.parent;
+    }
+  }
   uint32_t max_point = 0;
   for (size_t c = 0; c < C; ++c) max_point = std::max(max_point, tables[0].corner_to_point[c]);
   size_t pinned_need = 256;
@@ -390,7 +406,7 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
       HIP_TRY(hipMemsetAsync(a.aux_flags.p, 0, a.aux_flags.bytes, s));
       if ((rc = a.chunk_info.alloc((size_t)std::max(1u, orient_summary_blocks(n)) * 8))) return rc;
     }
-    if (a.scheme == kNormal) { if ((rc = a.fn.alloc((size_t)F * 3 * 4))) return rc; }
+    if (a.scheme == kNormal && a.fused_into < 0) { if ((rc = a.fn.alloc((size_t)F * 3 * 4))) return rc; }
     if (a.scheme == kTexCoord) { if ((rc = a.summary.alloc((size_t)std::max(1u, orient_summary_blocks(n)) * 16))) return rc; }
     a.bins = symbol_bins(a);
     if (a.port == kToBits) a.bins = 1u << 20;   // capacity; the real bound is checked after the min/max readback
@@ -500,6 +516,23 @@ static int encode_phase_a(dmi_job* job) {   // device: ranges → coding-order p
     uint32_t* counters = a.small.as<uint32_t>() + 2;
     const uint32_t n = t.n_seq;
     if (n == 0) continue;
+    if (a.fused_into >= 0) continue;   // predicted by its parent's fused sweep
+    if (a.fused_nrm >= 0 || a.fused_uv >= 0) {
+      FusedArgs fa{};
+      fa.seq = t.seq.as<uint32_t>(); fa.c2r = t.c2r.as<uint32_t>(); fa.opp = t.opp.as<uint32_t>(); fa.n = n;
+      fa.qs_pos = a.qs.as<int32_t>(); fa.mm_pos = minmax; fa.sym_pos = a.sym.as<uint32_t>();
+      if (a.fused_nrm >= 0) {
+        AttJob& q = job->atts[a.fused_nrm];
+        fa.qs_nrm = q.qs.as<int32_t>(); fa.sym_nrm = q.sym.as<uint32_t>(); fa.flips = q.aux.as<uint8_t>(); fa.counters = q.small.as<uint32_t>() + 2;
+      }
+      if (a.fused_uv >= 0) {
+        AttJob& q = job->atts[a.fused_uv];
+        fa.qs_uv = q.qs.as<int32_t>(); fa.mm_uv = q.small.as<int32_t>(); fa.sym_uv = q.sym.as<uint32_t>(); fa.orient = q.aux.as<uint8_t>();
+      }
+      launch_predict_fused(fa, s);
+      if (a.fused_uv >= 0) { AttJob& q = job->atts[a.fused_uv]; launch_orient_summary(q.aux.as<uint8_t>(), n, q.summary.as<uint32_t>(), nullptr, s); }
+      continue;
+    }
     switch (a.scheme) {
       case kParallelogram:
         launch_pred_parallelogram_wrapped(t.seq.as<uint32_t>(), n, t.c2r.as<uint32_t>(), t.opp.as<uint32_t>(), a.qs.as<int32_t>(), minmax, a.nq, a.sym.as<uint32_t>(), s);

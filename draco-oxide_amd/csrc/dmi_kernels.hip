@@ -337,18 +337,39 @@ __global__ __launch_bounds__(kBlock) void k_i32_minmax_final(MinMaxArgs args) {
 // the fan vertex's position, so mesh_normal_prediction.rs:22-44 evaluates exactly fn[face(cc)] per fan face.
 __global__ __launch_bounds__(kBlock) void k_face_normals(const uint32_t* __restrict__ c2r_pos, uint32_t nfaces, const int32_t* __restrict__ qs_pos,
                                                          int32_t* __restrict__ fn) {
-  for (uint32_t f = blockIdx.x * kBlock + threadIdx.x; f < nfaces; f += gridDim.x * kBlock) {
+  DMI_FOR_TILES(base, nfaces, kTile) {
     // position of a corner = qs_pos[sequence index of its vertex in the position attribute's table]
-    const uint32_t r0 = c2r_pos[(size_t)3 * f], r1 = c2r_pos[(size_t)3 * f + 1], r2 = c2r_pos[(size_t)3 * f + 2];
-    int32_t p0[3] = {0, 0, 0}, p1[3] = {0, 0, 0}, p2[3] = {0, 0, 0};
-    if (r0 != kNoneD) { p0[0] = qs_pos[(size_t)r0 * 3]; p0[1] = qs_pos[(size_t)r0 * 3 + 1]; p0[2] = qs_pos[(size_t)r0 * 3 + 2]; }
-    if (r1 != kNoneD) { p1[0] = qs_pos[(size_t)r1 * 3]; p1[1] = qs_pos[(size_t)r1 * 3 + 1]; p1[2] = qs_pos[(size_t)r1 * 3 + 2]; }
-    if (r2 != kNoneD) { p2[0] = qs_pos[(size_t)r2 * 3]; p2[1] = qs_pos[(size_t)r2 * 3 + 1]; p2[2] = qs_pos[(size_t)r2 * 3 + 2]; }
-    const int32_t ax = wsub(p1[0], p0[0]), ay = wsub(p1[1], p0[1]), az = wsub(p1[2], p0[2]);
-    const int32_t bx = wsub(p2[0], p0[0]), by = wsub(p2[1], p0[1]), bz = wsub(p2[2], p0[2]);
-    fn[(size_t)3 * f] = wsub(wmul(ay, bz), wmul(az, by));
-    fn[(size_t)3 * f + 1] = wsub(wmul(az, bx), wmul(ax, bz));
-    fn[(size_t)3 * f + 2] = wsub(wmul(ax, by), wmul(ay, bx));
+    uint32_t r[kTile][3];
+    int32_t p[kTile][3][3];
+#pragma unroll
+    for (int t = 0; t < kTile; ++t) {
+      const uint32_t f = min(base + t * kBlock + threadIdx.x, nfaces - 1u);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) r[t][k] = c2r_pos[(size_t)3 * f + k];
+    }
+#pragma unroll
+    for (int t = 0; t < kTile; ++t) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const size_t at = (size_t)(r[t][k] != kNoneD ? r[t][k] : 0u) * 3;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) p[t][k][d] = qs_pos[at + d];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < kTile; ++t) {
+      const uint32_t f = base + t * kBlock + threadIdx.x;
+      if (f >= nfaces) continue;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        if (r[t][k] == kNoneD) { p[t][k][0] = 0; p[t][k][1] = 0; p[t][k][2] = 0; }
+      }
+      const int32_t ax = wsub(p[t][1][0], p[t][0][0]), ay = wsub(p[t][1][1], p[t][0][1]), az = wsub(p[t][1][2], p[t][0][2]);
+      const int32_t bx = wsub(p[t][2][0], p[t][0][0]), by = wsub(p[t][2][1], p[t][0][1]), bz = wsub(p[t][2][2], p[t][0][2]);
+      fn[(size_t)3 * f] = wsub(wmul(ay, bz), wmul(az, by));
+      fn[(size_t)3 * f + 1] = wsub(wmul(az, bx), wmul(ax, bz));
+      fn[(size_t)3 * f + 2] = wsub(wmul(ax, by), wmul(ay, bx));
+    }
   }
 }
 
@@ -543,71 +564,249 @@ __device__ __forceinline__ uint64_t int_sqrt(uint64_t value) {
   return sq;
 }
 
+// One entry of mesh_prediction_for_texture_coordinates.rs:107-219 on already fetched operands: cu = the entry's
+// own UV, nu / pu = UVs of the next / previous corner's vertex (both coded), cp / np / pp = the three quantised
+// positions (get_position_for_vertex :22-30).  Returns false when the fallback must be used.
+__device__ __forceinline__ bool texcoord_predict(const int32_t (&cu)[2], const int32_t (&nuv)[2], const int32_t (&puv)[2], const int32_t (&cpi)[3],
+                                                 const int32_t (&npi)[3], const int32_t (&ppi)[3], int32_t& pred0, int32_t& pred1, uint8_t& oflag) {
+  const int64_t nu0 = nuv[0], nu1 = nuv[1], pu0 = puv[0], pu1 = puv[1];
+  if (nu0 == pu0 && nu1 == pu1) { pred0 = (int32_t)pu0; pred1 = (int32_t)pu1; return true; }   // degenerate: identical neighbour UVs
+  const int64_t cp[3] = {cpi[0], cpi[1], cpi[2]}, np[3] = {npi[0], npi[1], npi[2]}, pp[3] = {ppi[0], ppi[1], ppi[2]};
+  const int64_t pn0 = wsub64(pp[0], np[0]), pn1 = wsub64(pp[1], np[1]), pn2 = wsub64(pp[2], np[2]);
+  const uint64_t pn2sq = (uint64_t)wadd64(wadd64(wmul64(pn0, pn0), wmul64(pn1, pn1)), wmul64(pn2, pn2));
+  if (pn2sq == 0) return false;
+  const int64_t cn0 = wsub64(cp[0], np[0]), cn1 = wsub64(cp[1], np[1]), cn2 = wsub64(cp[2], np[2]);
+  const int64_t cn_dot_pn = wadd64(wadd64(wmul64(pn0, cn0), wmul64(pn1, cn1)), wmul64(pn2, cn2));
+  const int64_t pnu0 = wsub64(pu0, nu0), pnu1 = wsub64(pu1, nu1);
+  const int64_t n_uv_absmax = max(wabs64(nu0), wabs64(nu1));
+  const int64_t pn_uv_absmax = max(wabs64(pnu0), wabs64(pnu1));
+  const int64_t pn_absmax = max(max(wabs64(pn0), wabs64(pn1)), wabs64(pn2));
+  const bool overflow = exceeds_max_over(n_uv_absmax, (int64_t)pn2sq) || exceeds_max_over(wabs64(cn_dot_pn), pn_uv_absmax) ||
+                        exceeds_max_over(wabs64(cn_dot_pn), pn_absmax);
+  if (overflow) return false;
+  const int64_t xu0 = wadd64(wmul64(nu0, (int64_t)pn2sq), wmul64(pnu0, cn_dot_pn));
+  const int64_t xu1 = wadd64(wmul64(nu1, (int64_t)pn2sq), wmul64(pnu1, cn_dot_pn));
+  const int64_t xp0 = wadd64(np[0], div_exact(wmul64(pn0, cn_dot_pn), (int64_t)pn2sq));
+  const int64_t xp1 = wadd64(np[1], div_exact(wmul64(pn1, cn_dot_pn), (int64_t)pn2sq));
+  const int64_t xp2 = wadd64(np[2], div_exact(wmul64(pn2, cn_dot_pn), (int64_t)pn2sq));
+  const int64_t cx0 = wsub64(cp[0], xp0), cx1 = wsub64(cp[1], xp1), cx2 = wsub64(cp[2], xp2);
+  const uint64_t cx2sq = (uint64_t)wadd64(wadd64(wmul64(cx0, cx0), wmul64(cx1, cx1)), wmul64(cx2, cx2));
+  const uint64_t nrm = int_sqrt(cx2sq * pn2sq);
+  const int64_t cxu0 = wmul64(pnu1, (int64_t)nrm), cxu1 = wmul64((int64_t)(0ull - (uint64_t)pnu0), (int64_t)nrm);
+  const int64_t a0 = div_exact(wadd64(xu0, cxu0), (int64_t)pn2sq), a1 = div_exact(wadd64(xu1, cxu1), (int64_t)pn2sq);
+  const int64_t b0 = div_exact(wsub64(xu0, cxu0), (int64_t)pn2sq), b1 = div_exact(wsub64(xu1, cxu1), (int64_t)pn2sq);
+  const int64_t ea0 = wsub64(cu[0], a0), ea1 = wsub64(cu[1], a1), eb0 = wsub64(cu[0], b0), eb1 = wsub64(cu[1], b1);
+  const int64_t da = wadd64(wmul64(ea0, ea0), wmul64(ea1, ea1)), db = wadd64(wmul64(eb0, eb0), wmul64(eb1, eb1));
+  if (da < db) { oflag = 2; pred0 = (int32_t)a0; pred1 = (int32_t)a1; }
+  else { oflag = 1; pred0 = (int32_t)b0; pred1 = (int32_t)b1; }
+  return true;
+}
+
+constexpr int kTexTile = 2;   // the i64 projection is register-hungry: two entries per thread
 __global__ __launch_bounds__(kBlock) void k_pred_texcoord_wrapped(const uint32_t* __restrict__ seq, uint32_t n, const uint32_t* __restrict__ c2r,
                                                                   const int32_t* __restrict__ qs, const uint32_t* __restrict__ c2r_pos,
                                                                   const int32_t* __restrict__ qs_pos, const int32_t* __restrict__ minmax,
                                                                   uint32_t* __restrict__ sym, uint8_t* __restrict__ orient) {
   const WrapParams w = wrap_params(minmax);
+  const bool shared = (c2r_pos == c2r);   // both attributes on one table: the position ranks are i, rn, rp themselves
+  DMI_FOR_TILES(base, n, kTexTile) {
+    uint32_t i[kTexTile], c[kTexTile], rn[kTexTile], rp[kTexTile], qc[kTexTile], qn[kTexTile], qp[kTexTile];
+#pragma unroll
+    for (int t = 0; t < kTexTile; ++t) { i[t] = min(base + t * kBlock + threadIdx.x, n - 1u); c[t] = seq[i[t]]; }
+#pragma unroll
+    for (int t = 0; t < kTexTile; ++t) {
+      const uint32_t nc = cnext(c[t]), pc = cprev(c[t]);
+      rn[t] = c2r[nc]; rp[t] = c2r[pc];
+      if (!shared) { qc[t] = c2r_pos[c[t]]; qn[t] = c2r_pos[nc]; qp[t] = c2r_pos[pc]; }
+    }
+    int32_t cu[kTexTile][2], nu[kTexTile][2], pu[kTexTile][2], lastv[kTexTile][2], cp[kTexTile][3], np[kTexTile][3], pp[kTexTile][3];
+    bool both[kTexTile];
+#pragma unroll
+    for (int t = 0; t < kTexTile; ++t) {
+      if (shared) { qc[t] = i[t]; qn[t] = rn[t]; qp[t] = rp[t]; }
+      both[t] = rn[t] < i[t] && rp[t] < i[t];
+      const uint32_t prev = i[t] > 0 ? i[t] - 1u : 0u;
+      const size_t in_ = (size_t)(rn[t] < i[t] ? rn[t] : prev) * 2, ip_ = (size_t)(rp[t] < i[t] ? rp[t] : prev) * 2;
+      cu[t][0] = qs[(size_t)i[t] * 2]; cu[t][1] = qs[(size_t)i[t] * 2 + 1];
+      nu[t][0] = qs[in_]; nu[t][1] = qs[in_ + 1];
+      pu[t][0] = qs[ip_]; pu[t][1] = qs[ip_ + 1];
+      lastv[t][0] = qs[(size_t)prev * 2]; lastv[t][1] = qs[(size_t)prev * 2 + 1];
+      // positions are only read when both neighbours are coded; a missing rank (never coded) reads as zero
+      const size_t jc = (size_t)((both[t] && qc[t] != kNoneD) ? qc[t] : 0u) * 3, jn = (size_t)((both[t] && qn[t] != kNoneD) ? qn[t] : 0u) * 3,
+                   jp = (size_t)((both[t] && qp[t] != kNoneD) ? qp[t] : 0u) * 3;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { cp[t][d] = qs_pos[jc + d]; np[t][d] = qs_pos[jn + d]; pp[t][d] = qs_pos[jp + d]; }
+    }
+#pragma unroll
+    for (int t = 0; t < kTexTile; ++t) {
+      if (base + t * kBlock + threadIdx.x >= n) continue;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        if (qc[t] == kNoneD) cp[t][d] = 0;
+        if (qn[t] == kNoneD) np[t][d] = 0;
+        if (qp[t] == kNoneD) pp[t][d] = 0;
+      }
+      int32_t pred0 = 0, pred1 = 0;
+      uint8_t oflag = 0;
+      bool done = false;
+      if (both[t]) done = texcoord_predict(cu[t], nu[t], pu[t], cp[t], np[t], pp[t], pred0, pred1, oflag);
+      if (!done) {   // fallback_predict :51-81 (the `prev` branch is intentionally absent)
+        oflag = 0;
+        if (rn[t] < i[t]) { pred0 = nu[t][0]; pred1 = nu[t][1]; }
+        else if (i[t] > 0) { pred0 = lastv[t][0]; pred1 = lastv[t][1]; }
+        else { pred0 = 0; pred1 = 0; }
+      }
+      orient[i[t]] = oflag;
+      sym[(size_t)i[t] * 2] = wrap_symbol(cu[t][0], pred0, w);
+      sym[(size_t)i[t] * 2 + 1] = wrap_symbol(cu[t][1], pred1, w);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// All predictors of a seam-free mesh in ONE sweep.  When the normal / texture-coordinate attributes are coded on
+// the same corner table as their parent position attribute (no seams: the attribute tables alias the universal
+// one), entry i of every attribute is the same vertex and the three predictors walk the same neighbourhood:
+//   * corner table entries (seq, opp, c2r) are fetched once instead of once per attribute;
+//   * the quantised positions of the 1-ring feed the parallelogram, the texture-coordinate projection AND the
+//     normal predictor, whose per-face cross products (mesh_normal_prediction.rs:22-44) are formed on the fly from
+//     the ring positions — swinging to the next fan face brings in exactly one new vertex — so neither the
+//     per-face normal array nor its kernel exist on this path.
+// Results are identical to k_pred_parallelogram_wrapped<3> + k_face_normals + k_pred_normal_octorth +
+// k_pred_texcoord_wrapped (the tests run both paths against the oracle).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load3(const int32_t* __restrict__ q, uint32_t r, int32_t (&out)[3]) {
+  if (r != kNoneD) { out[0] = q[(size_t)r * 3]; out[1] = q[(size_t)r * 3 + 1]; out[2] = q[(size_t)r * 3 + 2]; }
+  else { out[0] = 0; out[1] = 0; out[2] = 0; }
+}
+// sum += cross(a - c, b - c): i32 wrapping terms, widened to i64 (wrapping sum)
+__device__ __forceinline__ void add_face_normal(const int32_t (&a)[3], const int32_t (&b)[3], const int32_t (&c)[3], int64_t (&sum)[3]) {
+  const int32_t ax = wsub(a[0], c[0]), ay = wsub(a[1], c[1]), az = wsub(a[2], c[2]);
+  const int32_t bx = wsub(b[0], c[0]), by = wsub(b[1], c[1]), bz = wsub(b[2], c[2]);
+  sum[0] = wadd64(sum[0], (int64_t)wsub(wmul(ay, bz), wmul(az, by)));
+  sum[1] = wadd64(sum[1], (int64_t)wsub(wmul(az, bx), wmul(ax, bz)));
+  sum[2] = wadd64(sum[2], (int64_t)wsub(wmul(ax, by), wmul(ay, bx)));
+}
+
+template <bool HAS_NRM, bool HAS_UV>
+__global__ __launch_bounds__(kBlock) void k_predict_fused(FusedArgs a) {
+  const uint32_t* __restrict__ seq = a.seq;
+  const uint32_t* __restrict__ c2r = a.c2r;
+  const uint32_t* __restrict__ opp = a.opp;
+  const int32_t* __restrict__ qs_pos = a.qs_pos;
+  const uint32_t n = a.n;
+  const WrapParams wp = wrap_params(a.mm_pos);
+  WrapParams wu = wp;
+  if (HAS_UV) wu = wrap_params(a.mm_uv);
+  uint32_t n_false = 0;
   DMI_FOR_SEQUENCE(i, n) {
     const uint32_t c = seq[i], nc = cnext(c), pc = cprev(c);
-    const uint32_t rn = c2r[nc], rp = c2r[pc];
-    const int32_t cu0 = qs[(size_t)i * 2], cu1 = qs[(size_t)i * 2 + 1];
-    int32_t pred0 = 0, pred1 = 0;
-    uint8_t oflag = 0;
-    bool done = false;
-    if (rn < i && rp < i) {
-      const int64_t nu0 = qs[(size_t)rn * 2], nu1 = qs[(size_t)rn * 2 + 1], pu0 = qs[(size_t)rp * 2], pu1 = qs[(size_t)rp * 2 + 1];
-      if (nu0 == pu0 && nu1 == pu1) {
-        pred0 = (int32_t)pu0; pred1 = (int32_t)pu1; done = true;   // degenerate: identical neighbour UVs
-      } else {
-        // get_position_for_vertex :22-30 — position of a corner = qs_pos[its vertex's sequence index in the
-        // position attribute's table]; when both attributes share a table these are i, rn, rp themselves.
-        auto pos_at = [&](uint32_t r, int64_t* out) {
-          if (r != kNoneD) { out[0] = qs_pos[(size_t)r * 3]; out[1] = qs_pos[(size_t)r * 3 + 1]; out[2] = qs_pos[(size_t)r * 3 + 2]; }
-          else { out[0] = out[1] = out[2] = 0; }
-        };
-        const bool shared = (c2r_pos == c2r);
-        int64_t cp[3], np[3], pp[3];
-        pos_at(shared ? i : c2r_pos[c], cp); pos_at(shared ? rn : c2r_pos[nc], np); pos_at(shared ? rp : c2r_pos[pc], pp);
-        const int64_t pn0 = wsub64(pp[0], np[0]), pn1 = wsub64(pp[1], np[1]), pn2 = wsub64(pp[2], np[2]);
-        const uint64_t pn2sq = (uint64_t)wadd64(wadd64(wmul64(pn0, pn0), wmul64(pn1, pn1)), wmul64(pn2, pn2));
-        if (pn2sq != 0) {
-          const int64_t cn0 = wsub64(cp[0], np[0]), cn1 = wsub64(cp[1], np[1]), cn2 = wsub64(cp[2], np[2]);
-          const int64_t cn_dot_pn = wadd64(wadd64(wmul64(pn0, cn0), wmul64(pn1, cn1)), wmul64(pn2, cn2));
-          const int64_t pnu0 = wsub64(pu0, nu0), pnu1 = wsub64(pu1, nu1);
-          const int64_t n_uv_absmax = max(wabs64(nu0), wabs64(nu1));
-          const int64_t pn_uv_absmax = max(wabs64(pnu0), wabs64(pnu1));
-          const int64_t pn_absmax = max(max(wabs64(pn0), wabs64(pn1)), wabs64(pn2));
-          const bool overflow = exceeds_max_over(n_uv_absmax, (int64_t)pn2sq) || exceeds_max_over(wabs64(cn_dot_pn), pn_uv_absmax) ||
-                                exceeds_max_over(wabs64(cn_dot_pn), pn_absmax);
-          if (!overflow) {
-            const int64_t xu0 = wadd64(wmul64(nu0, (int64_t)pn2sq), wmul64(pnu0, cn_dot_pn));
-            const int64_t xu1 = wadd64(wmul64(nu1, (int64_t)pn2sq), wmul64(pnu1, cn_dot_pn));
-            const int64_t xp0 = wadd64(np[0], div_exact(wmul64(pn0, cn_dot_pn), (int64_t)pn2sq));
-            const int64_t xp1 = wadd64(np[1], div_exact(wmul64(pn1, cn_dot_pn), (int64_t)pn2sq));
-            const int64_t xp2 = wadd64(np[2], div_exact(wmul64(pn2, cn_dot_pn), (int64_t)pn2sq));
-            const int64_t cx0 = wsub64(cp[0], xp0), cx1 = wsub64(cp[1], xp1), cx2 = wsub64(cp[2], xp2);
-            const uint64_t cx2sq = (uint64_t)wadd64(wadd64(wmul64(cx0, cx0), wmul64(cx1, cx1)), wmul64(cx2, cx2));
-            const uint64_t nrm = int_sqrt(cx2sq * pn2sq);
-            const int64_t cxu0 = wmul64(pnu1, (int64_t)nrm), cxu1 = wmul64((int64_t)(0ull - (uint64_t)pnu0), (int64_t)nrm);
-            const int64_t a0 = div_exact(wadd64(xu0, cxu0), (int64_t)pn2sq), a1 = div_exact(wadd64(xu1, cxu1), (int64_t)pn2sq);
-            const int64_t b0 = div_exact(wsub64(xu0, cxu0), (int64_t)pn2sq), b1 = div_exact(wsub64(xu1, cxu1), (int64_t)pn2sq);
-            const int64_t ea0 = wsub64(cu0, a0), ea1 = wsub64(cu1, a1), eb0 = wsub64(cu0, b0), eb1 = wsub64(cu1, b1);
-            const int64_t da = wadd64(wmul64(ea0, ea0), wmul64(ea1, ea1)), db = wadd64(wmul64(eb0, eb0), wmul64(eb1, eb1));
-            if (da < db) { oflag = 2; pred0 = (int32_t)a0; pred1 = (int32_t)a1; }
-            else { oflag = 1; pred0 = (int32_t)b0; pred1 = (int32_t)b1; }
-            done = true;
-          }
+    const uint32_t rn = c2r[nc], rp = c2r[pc], o = opp[c];
+    const uint32_t ro = (o != kNoneD) ? c2r[o] : kNoneD;
+    const bool both = rn < i && rp < i;
+    const bool have = both && ro < i;   // (o == NONE ⇒ ro == NONE ⇒ false)
+    int32_t Pc[3], Pn[3], Pp[3], Po[3], Plast[3] = {0, 0, 0};
+    load3(qs_pos, i, Pc);
+    if (HAS_NRM || both) { load3(qs_pos, rn, Pn); load3(qs_pos, rp, Pp); }
+    if (have) load3(qs_pos, ro, Po);
+    else if (i > 0) load3(qs_pos, i - 1u, Plast);
+    // ---- positions: mesh_parallelogram_prediction.rs:186-237 + wrapped difference ----
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int32_t pred = have ? wsub(wadd(Pn[k], Pp[k]), Po[k]) : Plast[k];   // Q15: previously coded vertex, 0 for the first entry
+      a.sym_pos[(size_t)i * 3 + k] = wrap_symbol(Pc[k], pred, wp);
+    }
+    // ---- texture coordinates: mesh_prediction_for_texture_coordinates.rs:51-81,107-219 ----
+    if (HAS_UV) {
+      const int32_t* __restrict__ qu = a.qs_uv;
+      const int32_t cu[2] = {qu[(size_t)i * 2], qu[(size_t)i * 2 + 1]};
+      int32_t pred0 = 0, pred1 = 0;
+      uint8_t oflag = 0;
+      bool done = false;
+      int32_t nu[2] = {0, 0};
+      if (rn < i) { nu[0] = qu[(size_t)rn * 2]; nu[1] = qu[(size_t)rn * 2 + 1]; }
+      if (both) {
+        const int32_t pu[2] = {qu[(size_t)rp * 2], qu[(size_t)rp * 2 + 1]};
+        done = texcoord_predict(cu, nu, pu, Pc, Pn, Pp, pred0, pred1, oflag);
+      }
+      if (!done) {
+        oflag = 0;
+        if (rn < i) { pred0 = nu[0]; pred1 = nu[1]; }
+        else if (i > 0) { pred0 = qu[(size_t)(i - 1u) * 2]; pred1 = qu[(size_t)(i - 1u) * 2 + 1]; }
+        else { pred0 = 0; pred1 = 0; }
+      }
+      a.orient[i] = oflag;
+      a.sym_uv[(size_t)i * 2] = wrap_symbol(cu[0], pred0, wu);
+      a.sym_uv[(size_t)i * 2 + 1] = wrap_symbol(cu[1], pred1, wu);
+    }
+    // ---- normals: mesh_normal_prediction.rs:22-44,75-144 + oct_orthogonal.rs ----
+    if (HAS_NRM) {
+      // Fan sum of cross(pos[next] - pos_c, pos[prev] - pos_c).  Swinging right from a face (next = A, prev = B) lands in
+      // the face (next = new vertex, prev = A); swinging left lands in (next = B, prev = new vertex).
+      int64_t sum[3] = {0, 0, 0};
+      add_face_normal(Pn, Pp, Pc, sum);
+      bool open = false;
+      {
+        int32_t A[3] = {Pn[0], Pn[1], Pn[2]};
+        for (uint32_t cur = c;;) {
+          const uint32_t o2 = opp[cprev(cur)];
+          if (o2 == kNoneD) { open = true; break; }
+          cur = cprev(o2);
+          if (cur == c) break;
+          int32_t W[3];
+          load3(qs_pos, c2r[o2], W);
+          add_face_normal(W, A, Pc, sum);
+          A[0] = W[0]; A[1] = W[1]; A[2] = W[2];
         }
       }
+      if (open) {
+        int32_t B[3] = {Pp[0], Pp[1], Pp[2]};
+        for (uint32_t cur = c;;) {
+          const uint32_t o2 = opp[cnext(cur)];
+          if (o2 == kNoneD) break;
+          cur = cnext(o2);
+          if (cur == c) break;
+          int32_t W[3];
+          load3(qs_pos, c2r[o2], W);
+          add_face_normal(B, W, Pc, sum);
+          B[0] = W[0]; B[1] = W[1]; B[2] = W[2];
+        }
+      }
+      int64_t sum0 = sum[0], sum1 = sum[1], sum2 = sum[2];
+      const int64_t upper = 1ll << 29;
+      const int64_t abs_sum = wadd64(wadd64(wabs64(sum0), wabs64(sum1)), wabs64(sum2));
+      if (abs_sum > upper) {
+        const int64_t quot = abs_sum / upper;
+        sum0 = wdiv64(sum0, quot); sum1 = wdiv64(sum1, quot); sum2 = wdiv64(sum2, quot);
+      }
+      const int32_t n0 = (int32_t)sum0, n1 = (int32_t)sum1, n2 = (int32_t)sum2;
+      int32_t p0 = 0, p1 = 0;
+      if (!(n0 == 0 && n1 == 0 && n2 == 0)) oct_quantize((float)n0, (float)n1, (float)n2, p0, p1);
+      const int32_t a0 = a.qs_nrm[(size_t)i * 2], a1 = a.qs_nrm[(size_t)i * 2 + 1];
+      const int32_t m0 = wmul(p0, -1), m1 = wmul(p1, -1);
+      const int32_t d10 = wsub(p0, a0), d11 = wsub(p1, a1), d20 = wsub(m0, a0), d21 = wsub(m1, a1);
+      const int32_t dot1 = wadd(wmul(d10, d10), wmul(d11, d11)), dot2 = wadd(wmul(d20, d20), wmul(d21, d21));
+      const bool flip = dot1 > dot2;   // Q8: flip negates the octahedral coordinates
+      if (flip) { p0 = m0; p1 = m1; } else ++n_false;
+      a.flips[i] = flip ? 1 : 0;
+      uint32_t s0, s1;
+      oct_orthogonal(a0, a1, p0, p1, s0, s1);
+      a.sym_nrm[(size_t)i * 2] = s0;
+      a.sym_nrm[(size_t)i * 2 + 1] = s1;
     }
-    if (!done) {   // fallback_predict :51-81 (the `prev` branch is intentionally absent)
-      if (rn < i) { pred0 = qs[(size_t)rn * 2]; pred1 = qs[(size_t)rn * 2 + 1]; }
-      else if (i > 0) { pred0 = qs[(size_t)(i - 1) * 2]; pred1 = qs[(size_t)(i - 1) * 2 + 1]; }
+  }
+  if (HAS_NRM) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) n_false += __shfl_down(n_false, off, 64);
+    __shared__ uint32_t wave_false[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) wave_false[threadIdx.x >> 6] = n_false;
+    __syncthreads();
+    if (threadIdx.x == 0) {   // one atomic per block (same-address atomics serialise)
+      uint32_t t = 0;
+#pragma unroll
+      for (int w = 0; w < kBlock / 64; ++w) t += wave_false[w];
+      if (t) atomicAdd(&a.counters[0], t);
     }
-    orient[i] = oflag;
-    sym[(size_t)i * 2] = wrap_symbol(cu0, pred0, w);
-    sym[(size_t)i * 2 + 1] = wrap_symbol(cu1, pred1, w);
   }
 }
 
@@ -691,13 +890,14 @@ void launch_i32_minmax_final(const MinMaxArgs& args, hipStream_t s) {
   if (args.count) hipLaunchKernelGGL(k_i32_minmax_final, (uint32_t)args.count, kBlock, 0, s, args);
 }
 
-uint32_t seq_quantize_blocks(uint32_t n) { return grid_for(((uint64_t)n + kTile - 1) / kTile); }
+inline uint32_t tiles_grid(uint64_t n) { return grid_for((n + kTile - 1) / kTile); }   // grid of a DMI_FOR_TILES kernel
+uint32_t seq_quantize_blocks(uint32_t n) { return tiles_grid(n); }
 void launch_seq_quantize(const uint32_t* s2p, uint32_t n, const QuantArgs& args, hipStream_t s) {
   hipLaunchKernelGGL(k_seq_quantize, seq_quantize_blocks(n), kBlock, 0, s, s2p, n, args);
 }
 
 void launch_face_normals(const uint32_t* c2r_pos, uint32_t nfaces, const int32_t* qs_pos, int32_t* fn, hipStream_t s) {
-  if (nfaces) hipLaunchKernelGGL(k_face_normals, grid_for(nfaces), kBlock, 0, s, c2r_pos, nfaces, qs_pos, fn);
+  if (nfaces) hipLaunchKernelGGL(k_face_normals, tiles_grid(nfaces), kBlock, 0, s, c2r_pos, nfaces, qs_pos, fn);
 }
 
 void launch_pred_parallelogram_wrapped(const uint32_t* seq, uint32_t n, const uint32_t* c2r, const uint32_t* opp,
@@ -723,7 +923,15 @@ void launch_pred_normal_octorth(const uint32_t* seq, uint32_t n, const uint32_t*
 
 void launch_pred_texcoord_wrapped(const uint32_t* seq, uint32_t n, const uint32_t* c2r, const int32_t* qs, const uint32_t* c2r_pos,
                                   const int32_t* qs_pos, const int32_t* minmax, uint32_t* sym, uint8_t* orient, hipStream_t s) {
-  hipLaunchKernelGGL(k_pred_texcoord_wrapped, grid_for(n), kBlock, 0, s, seq, n, c2r, qs, c2r_pos, qs_pos, minmax, sym, orient);
+  hipLaunchKernelGGL(k_pred_texcoord_wrapped, grid_for(((uint64_t)n + kTexTile - 1) / kTexTile), kBlock, 0, s, seq, n, c2r, qs, c2r_pos, qs_pos, minmax, sym, orient);
+}
+
+void launch_predict_fused(const FusedArgs& a, hipStream_t s) {
+  if (a.n == 0) return;
+  const uint32_t g = grid_for(a.n);
+  if (a.qs_nrm && a.qs_uv) hipLaunchKernelGGL((k_predict_fused<true, true>), g, kBlock, 0, s, a);
+  else if (a.qs_nrm) hipLaunchKernelGGL((k_predict_fused<true, false>), g, kBlock, 0, s, a);
+  else hipLaunchKernelGGL((k_predict_fused<false, true>), g, kBlock, 0, s, a);
 }
 
 uint32_t orient_summary_blocks(uint32_t n) { return (n + kOrientChunk - 1) / kOrientChunk; }
