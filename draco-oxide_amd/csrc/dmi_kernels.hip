@@ -14,6 +14,7 @@
 //   k_histogram                        encode/entropy/symbol_coding.rs:149-157
 //   (the serial rANS/rABS coders live in dmi_chains.hip)
 #include "dmi_device.hpp"
+#include <cstdlib>
 
 namespace dmi {
 namespace {
@@ -564,10 +565,10 @@ __device__ __forceinline__ uint64_t int_sqrt(uint64_t value) {
   return sq;
 }
 
-// One entry of mesh_prediction_for_texture_coordinates.rs:107-219 on already fetched operands: cu = the entry's
+// General form (any i32 operands, wrapping i64 arithmetic exactly as the reference's release build): cu = the entry's
 // own UV, nu / pu = UVs of the next / previous corner's vertex (both coded), cp / np / pp = the three quantised
 // positions (get_position_for_vertex :22-30).  Returns false when the fallback must be used.
-__device__ __forceinline__ bool texcoord_predict(const int32_t (&cu)[2], const int32_t (&nuv)[2], const int32_t (&puv)[2], const int32_t (&cpi)[3],
+__device__ __noinline__ bool texcoord_predict_general(const int32_t (&cu)[2], const int32_t (&nuv)[2], const int32_t (&puv)[2], const int32_t (&cpi)[3],
                                                  const int32_t (&npi)[3], const int32_t (&ppi)[3], int32_t& pred0, int32_t& pred1, uint8_t& oflag) {
   const int64_t nu0 = nuv[0], nu1 = nuv[1], pu0 = puv[0], pu1 = puv[1];
   if (nu0 == pu0 && nu1 == pu1) { pred0 = (int32_t)pu0; pred1 = (int32_t)pu1; return true; }   // degenerate: identical neighbour UVs
@@ -600,6 +601,100 @@ __device__ __forceinline__ bool texcoord_predict(const int32_t (&cu)[2], const i
   if (da < db) { oflag = 2; pred0 = (int32_t)a0; pred1 = (int32_t)a1; }
   else { oflag = 1; pred0 = (int32_t)b0; pred1 = (int32_t)b1; }
   return true;
+}
+
+// a / d (truncating) for a divisor shared by several divisions: inv = 1.0 / (double)d is formed once.  |a|, d < 2^31: one
+// f64 multiply on 32-bit conversions; < 2^52: the same on 64-bit conversions (|fl(a·inv) - a/d| < 1, so the truncated
+// quotient is off by at most one and one remainder test fixes it); anything larger: the generic divide.
+__device__ __forceinline__ int64_t div_shared(int64_t a, int64_t d, double inv) {
+  if (d < (1ll << 31) && a > -(1ll << 31) && a < (1ll << 31)) {
+    const int32_t a32 = (int32_t)a, d32 = (int32_t)d;
+    int32_t q = (int32_t)((double)a32 * inv);
+    const int32_t r = (int32_t)((uint32_t)a32 - (uint32_t)q * (uint32_t)d32);   // the true remainder lies in (-d, d] ∪ …: it fits i32, the product may not
+    if (a32 >= 0) { if (r < 0) --q; else if (r >= d32) ++q; }
+    else { if (r > 0) ++q; else if (r <= -d32) --q; }
+    return (int64_t)q;
+  }
+  const int64_t lim = 1ll << 52;
+  if (d < lim && a > -lim && a < lim) {
+    int64_t q = (int64_t)((double)a * inv);
+    const int64_t r = a - q * d;
+    if (a >= 0) { if (r < 0) --q; else if (r >= d) ++q; }
+    else { if (r > 0) ++q; else if (r <= -d) --q; }
+    return q;
+  }
+  return wdiv64(a, d);
+}
+// floor(sqrt(value)) for value < 2^52 — what the reference's Newton iteration (:32-48) converges to from any start
+// (every integer Newton step from s > 0 lands at or above floor(sqrt), the loop then descends onto it; below 2^52
+// nothing in that sequence can overflow).  Larger values replay the reference's sequence literally.
+__device__ __forceinline__ uint64_t int_sqrt_fast(uint64_t value) {
+  if (value < (1ull << 52)) {
+    uint64_t r = (uint64_t)sqrt((double)value);
+    if (r * r > value) --r;
+    else if ((r + 1) * (r + 1) <= value) ++r;
+    return r;
+  }
+  return int_sqrt(value);
+}
+__device__ __forceinline__ bool fits31(int64_t v) { return v > -(1ll << 31) && v < (1ll << 31); }
+
+// One entry of mesh_prediction_for_texture_coordinates.rs:107-219 on already fetched operands: cu = the entry's
+// own UV, nu / pu = UVs of the next / previous corner's vertex (both coded), cp / np / pp = the three quantised
+// positions (get_position_for_vertex :22-30).  Returns false when the fallback must be used.
+// Quantised values are < 2^30, so first-level differences fit i32 and their products are single 32×32→64 multiplies;
+// when |pn|², cn·pn fit 31 bits (neighbouring vertices: always, in practice) the reference's three overflow guards are
+// provably false.  Every shortcut is exact integer arithmetic on values that cannot wrap, so the results equal the
+// general form's; operands outside these ranges take texcoord_predict_general.
+__device__ __forceinline__ bool texcoord_predict(const int32_t (&cu)[2], const int32_t (&nuv)[2], const int32_t (&puv)[2], const int32_t (&cp)[3],
+                                                 const int32_t (&np)[3], const int32_t (&pp)[3], int32_t& pred0, int32_t& pred1, uint8_t& oflag) {
+  if (nuv[0] == puv[0] && nuv[1] == puv[1]) { pred0 = puv[0]; pred1 = puv[1]; return true; }   // degenerate: identical neighbour UVs
+  const uint32_t lim30 = 1u << 30;
+  bool small = (uint32_t)nuv[0] < lim30 && (uint32_t)nuv[1] < lim30 && (uint32_t)puv[0] < lim30 && (uint32_t)puv[1] < lim30 &&
+               (uint32_t)cu[0] < lim30 && (uint32_t)cu[1] < lim30;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) small = small && (uint32_t)cp[k] < lim30 && (uint32_t)np[k] < lim30 && (uint32_t)pp[k] < lim30;
+  if (small) {
+    const int32_t pn[3] = {pp[0] - np[0], pp[1] - np[1], pp[2] - np[2]};
+    const int32_t cn[3] = {cp[0] - np[0], cp[1] - np[1], cp[2] - np[2]};
+    const int64_t pn2sq = (int64_t)pn[0] * pn[0] + (int64_t)pn[1] * pn[1] + (int64_t)pn[2] * pn[2];   // < 3·2^60
+    if (pn2sq == 0) return false;
+    const int64_t cdp = (int64_t)pn[0] * cn[0] + (int64_t)pn[1] * cn[1] + (int64_t)pn[2] * cn[2];
+    if (pn2sq < (1ll << 31) && fits31(cdp)) {
+      // guards :138-141: n_uv_absmax·pn2sq < 2^61, |cdp|·pn_uv_absmax < 2^62, |cdp|·pn_absmax < 2^62 — never above i64::MAX
+      const int32_t pnu0 = puv[0] - nuv[0], pnu1 = puv[1] - nuv[1];
+      const int32_t d32 = (int32_t)pn2sq, c32 = (int32_t)cdp;
+      const int64_t xu0 = (int64_t)nuv[0] * d32 + (int64_t)pnu0 * c32, xu1 = (int64_t)nuv[1] * d32 + (int64_t)pnu1 * c32;
+      const double inv = 1.0 / (double)d32;
+      const int64_t cx0 = (int64_t)cp[0] - ((int64_t)np[0] + div_shared((int64_t)pn[0] * c32, pn2sq, inv));
+      const int64_t cx1 = (int64_t)cp[1] - ((int64_t)np[1] + div_shared((int64_t)pn[1] * c32, pn2sq, inv));
+      const int64_t cx2 = (int64_t)cp[2] - ((int64_t)np[2] + div_shared((int64_t)pn[2] * c32, pn2sq, inv));
+      if (fits31(cx0) && fits31(cx1) && fits31(cx2)) {
+        const int32_t x0 = (int32_t)cx0, x1 = (int32_t)cx1, x2 = (int32_t)cx2;
+        const uint64_t cx2sq = (uint64_t)((int64_t)x0 * x0 + (int64_t)x1 * x1 + (int64_t)x2 * x2);   // < 3·2^62 < 2^64
+        if (cx2sq < (1ull << 21)) {   // cx2sq·pn2sq < 2^52
+          const int32_t nrm = (int32_t)int_sqrt_fast(cx2sq * (uint64_t)pn2sq);   // < 2^26
+          const int64_t cxu0 = (int64_t)pnu1 * nrm, cxu1 = -((int64_t)pnu0 * nrm);
+          const int64_t a0 = div_shared(xu0 + cxu0, pn2sq, inv), a1 = div_shared(xu1 + cxu1, pn2sq, inv);
+          const int64_t b0 = div_shared(xu0 - cxu0, pn2sq, inv), b1 = div_shared(xu1 - cxu1, pn2sq, inv);
+          const int64_t ea0 = (int64_t)cu[0] - a0, ea1 = (int64_t)cu[1] - a1, eb0 = (int64_t)cu[0] - b0, eb1 = (int64_t)cu[1] - b1;
+          int64_t da, db;
+          if (fits31(ea0) && fits31(ea1) && fits31(eb0) && fits31(eb1)) {
+            const int32_t e0 = (int32_t)ea0, e1 = (int32_t)ea1, f0 = (int32_t)eb0, f1 = (int32_t)eb1;
+            da = (int64_t)e0 * e0 + (int64_t)e1 * e1;
+            db = (int64_t)f0 * f0 + (int64_t)f1 * f1;
+          } else {
+            da = wadd64(wmul64(ea0, ea0), wmul64(ea1, ea1));
+            db = wadd64(wmul64(eb0, eb0), wmul64(eb1, eb1));
+          }
+          if (da < db) { oflag = 2; pred0 = (int32_t)a0; pred1 = (int32_t)a1; }
+          else { oflag = 1; pred0 = (int32_t)b0; pred1 = (int32_t)b1; }
+          return true;
+        }
+      }
+    }
+  }
+  return texcoord_predict_general(cu, nuv, puv, cp, np, pp, pred0, pred1, oflag);
 }
 
 constexpr int kTexTile = 2;   // the i64 projection is register-hungry: two entries per thread
@@ -688,6 +783,62 @@ __device__ __forceinline__ void add_face_normal(const int32_t (&a)[3], const int
   sum[2] = wadd64(sum[2], (int64_t)wsub(wmul(ax, by), wmul(ay, bx)));
 }
 
+// Fan sum of cross(pos[next] - pos_c, pos[prev] - pos_c) over every face around the vertex of corner c
+// (mesh_normal_prediction.rs:22-44: i32 wrapping terms, i64 wrapping sum — order-independent).  The reference swings
+// left to the fan start and then right; the same set of faces is reached by swinging right AND left from c at the
+// same time until the walkers meet (closed fan) or both fall off a boundary / seam (opp = NONE).  Swinging right from a
+// face (next = A, prev = B) lands in the face (next = new vertex, prev = A); swinging left lands in (next = B, prev =
+// new vertex): one new vertex per face.  The three dependent fetches of a face (opp hop → rank of the new vertex → its
+// position) are software-pipelined across rounds, so a fan of valence v costs ≈ v/2 + 3 memory latencies, not 3v.
+__device__ __forceinline__ void fan_normal_sum(uint32_t c, const uint32_t* __restrict__ opp, const uint32_t* __restrict__ c2r_pos,
+                                               const int32_t* __restrict__ qs_pos, const int32_t (&Pc)[3], const int32_t (&Pn)[3], const int32_t (&Pp)[3],
+                                               int64_t (&sum)[3]) {
+  add_face_normal(Pn, Pp, Pc, sum);
+  uint32_t curR = c, curL = c;
+  bool actR = true, actL = true;
+  uint32_t s1R = kNoneD, s1L = kNoneD;          // stage 1: corner of the new vertex, rank not fetched yet
+  uint32_t s2R = 0, s2L = 0; bool v2R = false, v2L = false;   // stage 2: rank fetched, position not yet
+  int32_t WR[3], WL[3]; bool v3R = false, v3L = false;        // stage 3: position fetched, face not added yet
+  int32_t A[3] = {Pn[0], Pn[1], Pn[2]}, B[3] = {Pp[0], Pp[1], Pp[2]};
+  for (uint32_t guard = 0; guard < (1u << 24); ++guard) {   // (a consistent table terminates by itself; the guard bounds a malformed one)
+    if (!(actR || actL || s1R != kNoneD || s1L != kNoneD || v2R || v2L || v3R || v3L)) break;
+    // ---- issue: next hops, ranks of last round's corners, positions of last round's ranks
+    const uint32_t oR = actR ? opp[cprev(curR)] : kNoneD;
+    const uint32_t oL = actL ? opp[cnext(curL)] : kNoneD;
+    const uint32_t rkR = s1R != kNoneD ? c2r_pos[s1R] : kNoneD;
+    const uint32_t rkL = s1L != kNoneD ? c2r_pos[s1L] : kNoneD;
+    int32_t XR[3] = {0, 0, 0}, XL[3] = {0, 0, 0};
+    if (v2R) load3(qs_pos, s2R, XR);
+    if (v2L) load3(qs_pos, s2L, XL);
+    // ---- retire stage 3 (positions fetched in the previous round)
+    if (v3R) { add_face_normal(WR, A, Pc, sum); A[0] = WR[0]; A[1] = WR[1]; A[2] = WR[2]; }
+    if (v3L) { add_face_normal(B, WL, Pc, sum); B[0] = WL[0]; B[1] = WL[1]; B[2] = WL[2]; }
+    // ---- advance the pipeline
+    v3R = v2R; v3L = v2L;
+    WR[0] = XR[0]; WR[1] = XR[1]; WR[2] = XR[2]; WL[0] = XL[0]; WL[1] = XL[1]; WL[2] = XL[2];
+    v2R = s1R != kNoneD; v2L = s1L != kNoneD;
+    s2R = rkR; s2L = rkL;
+    s1R = kNoneD; s1L = kNoneD;
+    // ---- walkers: right first, then left against the updated right walker
+    if (actR) {
+      if (oR == kNoneD) actR = false;
+      else {
+        const uint32_t nR = cprev(oR);
+        if (nR == curL) { actR = false; actL = false; }   // the next right face is the left walker's face: closed
+        else { s1R = oR; curR = nR; }
+      }
+    }
+    if (actL) {
+      if (oL == kNoneD) actL = false;
+      else {
+        const uint32_t nL = cnext(oL);
+        if (nL == curR) { actR = false; actL = false; }
+        else { s1L = oL; curL = nL; }
+      }
+    }
+  }
+}
+
 template <bool HAS_NRM, bool HAS_UV>
 __global__ __launch_bounds__(kBlock) void k_predict_fused(FusedArgs a) {
   const uint32_t* __restrict__ seq = a.seq;
@@ -744,34 +895,7 @@ __global__ __launch_bounds__(kBlock) void k_predict_fused(FusedArgs a) {
       // Fan sum of cross(pos[next] - pos_c, pos[prev] - pos_c).  Swinging right from a face (next = A, prev = B) lands in
       // the face (next = new vertex, prev = A); swinging left lands in (next = B, prev = new vertex).
       int64_t sum[3] = {0, 0, 0};
-      add_face_normal(Pn, Pp, Pc, sum);
-      bool open = false;
-      {
-        int32_t A[3] = {Pn[0], Pn[1], Pn[2]};
-        for (uint32_t cur = c;;) {
-          const uint32_t o2 = opp[cprev(cur)];
-          if (o2 == kNoneD) { open = true; break; }
-          cur = cprev(o2);
-          if (cur == c) break;
-          int32_t W[3];
-          load3(qs_pos, c2r[o2], W);
-          add_face_normal(W, A, Pc, sum);
-          A[0] = W[0]; A[1] = W[1]; A[2] = W[2];
-        }
-      }
-      if (open) {
-        int32_t B[3] = {Pp[0], Pp[1], Pp[2]};
-        for (uint32_t cur = c;;) {
-          const uint32_t o2 = opp[cnext(cur)];
-          if (o2 == kNoneD) break;
-          cur = cnext(o2);
-          if (cur == c) break;
-          int32_t W[3];
-          load3(qs_pos, c2r[o2], W);
-          add_face_normal(B, W, Pc, sum);
-          B[0] = W[0]; B[1] = W[1]; B[2] = W[2];
-        }
-      }
+      fan_normal_sum(c, opp, c2r, qs_pos, Pc, Pn, Pp, sum);
       int64_t sum0 = sum[0], sum1 = sum[1], sum2 = sum[2];
       const int64_t upper = 1ll << 29;
       const int64_t abs_sum = wadd64(wadd64(wabs64(sum0), wabs64(sum1)), wabs64(sum2));
@@ -928,7 +1052,8 @@ void launch_pred_texcoord_wrapped(const uint32_t* seq, uint32_t n, const uint32_
 
 void launch_predict_fused(const FusedArgs& a, hipStream_t s) {
   if (a.n == 0) return;
-  const uint32_t g = grid_for(a.n);
+  static const uint32_t env_cap = std::getenv("DMI_FUSED_GRID") ? (uint32_t)std::atoi(std::getenv("DMI_FUSED_GRID")) : 0u;   // tuning aid
+  const uint32_t g = env_cap ? grid_for(a.n, env_cap) : grid_for(a.n);
   if (a.qs_nrm && a.qs_uv) hipLaunchKernelGGL((k_predict_fused<true, true>), g, kBlock, 0, s, a);
   else if (a.qs_nrm) hipLaunchKernelGGL((k_predict_fused<true, false>), g, kBlock, 0, s, a);
   else hipLaunchKernelGGL((k_predict_fused<false, true>), g, kBlock, 0, s, a);
