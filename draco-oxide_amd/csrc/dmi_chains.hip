@@ -270,6 +270,43 @@ __global__ __launch_bounds__(128) void k_chains(const ChainDesc* __restrict__ de
   }
 }
 
+// ---- batch read-back: every stream's bytes packed into one arena (one D2H for a whole batch of meshes) -----------
+// table[k] = {offset (16-byte aligned), length, error flag} of stream k, table[n] = {total, 0, 0}.
+__global__ __launch_bounds__(1024) void k_pack_offsets(const ChainDesc* __restrict__ descs, uint32_t n, PackEntry* __restrict__ table) {
+  __shared__ uint64_t wave_sum[16];
+  __shared__ uint64_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < n; base += 1024) {
+    const uint32_t k = base + threadIdx.x;
+    uint32_t len = 0, err = 0;
+    if (k < n) { len = descs[k].out_len[0]; err = descs[k].out_len[1]; }
+    const uint64_t padded = ((uint64_t)len + 15ull) & ~15ull;
+    uint64_t incl = padded;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint64_t t = __shfl_up(incl, d, 64); if ((threadIdx.x & 63) >= (uint32_t)d) incl += t; }
+    if ((threadIdx.x & 63) == 63) wave_sum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint64_t before = carry;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += wave_sum[w];
+    if (k < n) { table[k].offset = before + incl - padded; table[k].len = len; table[k].err = err; }
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = before + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { table[n].offset = carry; table[n].len = 0; table[n].err = 0; }
+}
+constexpr uint32_t kPackSplit = 8;   // blocks per stream
+__global__ __launch_bounds__(256) void k_pack_copy(const ChainDesc* __restrict__ descs, const PackEntry* __restrict__ table, uint8_t* __restrict__ arena) {
+  const uint32_t k = blockIdx.x;
+  const uint32_t len = table[k].len;
+  const uint64_t vecs = ((uint64_t)len + 15ull) >> 4;   // whole 16-byte words (the source buffers are padded allocations)
+  const uint64_t lo = vecs * blockIdx.y / kPackSplit, hi = vecs * (blockIdx.y + 1) / kPackSplit;
+  const uint4* __restrict__ src = reinterpret_cast<const uint4*>(descs[k].out);
+  uint4* __restrict__ dst = reinterpret_cast<uint4*>(arena + table[k].offset);
+  for (uint64_t v = lo + threadIdx.x; v < hi; v += 256) dst[v] = src[v];
+}
+
 inline uint32_t grid256(uint64_t n) { uint64_t g = (n + 255) / 256; return (uint32_t)(g > 4096 ? 4096 : (g ? g : 1)); }
 
 }  // namespace
@@ -286,6 +323,11 @@ void launch_orient_prep(const uint8_t* orient, uint32_t n, const uint32_t* chunk
 }
 void launch_batch_flags(const RansEntry* rec, uint64_t n, uint32_t* batch_flags, hipStream_t s) {
   if (n) hipLaunchKernelGGL(k_batch_flags, grid256(n), 256, 0, s, rec, n, batch_flags);
+}
+void launch_pack_streams(const ChainDesc* descs_dev, uint32_t n_streams, PackEntry* table, uint8_t* arena, hipStream_t s) {
+  if (!n_streams) return;
+  hipLaunchKernelGGL(k_pack_offsets, 1, 1024, 0, s, descs_dev, n_streams, table);
+  hipLaunchKernelGGL(k_pack_copy, dim3(n_streams, kPackSplit), 256, 0, s, descs_dev, table, arena);
 }
 void launch_chains(const ChainDesc* descs_dev, uint32_t n_streams, hipStream_t s) {
   if (n_streams) hipLaunchKernelGGL(k_chains, n_streams, 128, 0, s, descs_dev);

@@ -87,5 +87,10 @@ struct ChainDesc {
   uint32_t* ticks;          // optional: chain duration in 100 MHz ticks
 };
 void launch_chains(const ChainDesc* descs_dev, uint32_t n_streams, hipStream_t s);
+// Batch read-back: pack the coded bytes of every stream into `arena` (16-byte aligned slots, in stream order);
+// table[k] = {offset, length, error} and table[n_streams].offset = total bytes.  Stream outputs must be allocated with
+// ≥ 16 bytes of slack (the copy moves whole 16-byte words).
+struct PackEntry { uint64_t offset; uint32_t len; uint32_t err; };
+void launch_pack_streams(const ChainDesc* descs_dev, uint32_t n_streams, PackEntry* table, uint8_t* arena, hipStream_t s);
 
 }  // namespace dmi

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
+#include <mutex>
 #include <thread>
 
 #include "dmi_device.hpp"
@@ -55,7 +56,7 @@ struct TableDev {
   int alias_of = -1;
 };
 
-struct AuxInfo { uint8_t zero_prob = 0; uint32_t count = 0; int desc = -1; };
+struct AuxInfo { uint8_t zero_prob = 0; uint32_t count = 0; int rans_desc = -1; int desc = -1; };
 
 struct AttJob {
   dmi_attribute desc{};
@@ -103,6 +104,7 @@ struct dmi_job {
   struct Run {   // state carried between the phases of one encode
     std::vector<size_t> rans_off, aux_off;   // offsets into out_pinned
     std::vector<const uint8_t*> rans_ptr, aux_ptr;   // host addresses of the coded bytes (pinned memory)
+    std::vector<uint32_t> rans_len, aux_len;
     std::vector<size_t> pin_off;
     std::vector<AuxInfo> aux;
     std::vector<ChainDesc> descs;
@@ -399,7 +401,7 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
     if (a.scheme == kNormal || a.scheme == kTexCoord) {
       if ((rc = a.aux.alloc(n ? n : 1))) return rc;
       a.aux_cap = (uint64_t)n + 16;   // ≤ 1 byte per coded bit + flush
-      if ((rc = a.aux_out.alloc(a.aux_cap))) return rc;
+      if ((rc = a.aux_out.alloc(a.aux_cap + 16))) return rc;   // +16: the batch pack kernel copies whole 16-byte words
       if ((rc = a.aux_rec.alloc(((size_t)n + kChainPad) * sizeof(RansEntry)))) return rc;
       HIP_TRY(hipMemsetAsync(a.aux_rec.p, 0, a.aux_rec.bytes, s));
       if ((rc = a.aux_flags.alloc(((size_t)n / 64 + 4) * 4))) return rc;
@@ -417,7 +419,7 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
     if ((rc = a.batch_flags.alloc(((size_t)a.n_sym / 64 + 4) * 4))) return rc;
     HIP_TRY(hipMemsetAsync(a.batch_flags.p, 0, a.batch_flags.bytes, s));
     a.out_cap = a.n_sym * 3 + 16;   // ≤ 3 renormalisation bytes per symbol (P ≤ 20) + flush
-    if ((rc = a.out.alloc(a.out_cap))) return rc;
+    if ((rc = a.out.alloc(a.out_cap + 16))) return rc;
     if ((rc = a.meta.alloc(64))) return rc;
     if ((rc = a.partials.alloc((size_t)kRangeMaxBlocks * 8 * 4))) return rc;
     if ((rc = a.ipartials.alloc((size_t)2048 * 2 * 4))) return rc;   // ≥ 2 * seq_quantize_blocks(n)
@@ -621,6 +623,7 @@ static int encode_phase_b(dmi_job* job) {   // host: table normalisation; device
     ChainDesc d{};
     d.kind = 0; d.precision = a.ft.precision; d.n = a.n_sym; d.sym = a.sym.as<uint32_t>(); d.table = a.rec.as<RansEntry>(); d.state0 = 4u << a.ft.precision; d.batch_flags = a.batch_flags.as<uint32_t>();
     d.out = a.out.as<uint8_t>(); d.cap = a.out_cap; d.out_len = a.small.as<uint32_t>() + 8; d.ticks = a.small.as<uint32_t>() + 12;
+    aux[i].rans_desc = (int)descs.size();
     descs.push_back(d);
     if (a.scheme == kNormal) {
       // mesh_normal_prediction.rs:147-150
@@ -693,6 +696,8 @@ static int encode_phase_c2(dmi_job* job) {   // lengths known: async copy of the
   aux_off.assign(n_atts, 0);
   job->run.rans_ptr.assign(n_atts, nullptr);
   job->run.aux_ptr.assign(n_atts, nullptr);
+  job->run.rans_len.assign(n_atts, 0);
+  job->run.aux_len.assign(n_atts, 0);
   size_t total = 0;
   for (uint32_t i = 0; i < n_atts; ++i) {
     const uint32_t* small = reinterpret_cast<const uint32_t*>(pinned + pin_off[i]);
@@ -714,6 +719,31 @@ static int encode_phase_c2(dmi_job* job) {   // lengths known: async copy of the
     if (aux[i].desc >= 0 && small[10]) HIP_TRY(hipMemcpyAsync(job->out_pinned + aux_off[i], a.aux_out.p, small[10], hipMemcpyDeviceToHost, s));
     job->run.rans_ptr[i] = job->out_pinned + rans_off[i];
     job->run.aux_ptr[i] = job->out_pinned + aux_off[i];
+    job->run.rans_len[i] = small[8];
+    job->run.aux_len[i] = aux[i].desc >= 0 ? small[10] : 0u;
+  }
+  return DMI_OK;
+}
+
+// Batch form of c1 + c2: lengths, error flags and bytes come from the packed arena (one table + one byte copy per batch).
+static int encode_phase_c_packed(dmi_job* job, const PackEntry* table, uint32_t first_desc, const uint8_t* arena_host) {
+  const uint32_t n_atts = (uint32_t)job->atts.size();
+  const std::vector<AuxInfo>& aux = job->run.aux;
+  job->run.rans_ptr.assign(n_atts, nullptr);
+  job->run.aux_ptr.assign(n_atts, nullptr);
+  job->run.rans_len.assign(n_atts, 0);
+  job->run.aux_len.assign(n_atts, 0);
+  for (uint32_t i = 0; i < n_atts; ++i) {
+    const PackEntry& r = table[first_desc + (uint32_t)aux[i].rans_desc];
+    if (r.err) return fail(DMI_ERR_ENTROPY, r.err == 1 ? "rANS state too large" : "coder output capacity exceeded");
+    job->run.rans_ptr[i] = arena_host + r.offset;
+    job->run.rans_len[i] = r.len;
+    if (aux[i].desc >= 0) {
+      const PackEntry& x = table[first_desc + (uint32_t)aux[i].desc];
+      if (x.err) return fail(DMI_ERR_ENTROPY, x.err == 1 ? "rABS state too large" : "coder output capacity exceeded");
+      job->run.aux_ptr[i] = arena_host + x.offset;
+      job->run.aux_len[i] = x.len;
+    }
   }
   return DMI_OK;
 }
@@ -736,29 +766,29 @@ static int encode_phase_c3(dmi_job* job, dmi_buffer* out) {   // host: splice th
   for (uint32_t i = 0; i < n_atts; ++i) {
     const AttJob& a = job->atts[i];
     const uint8_t* base = pinned + pin_off[i];
-    // note: pinned[off..off+64) was overwritten by the second readback of `small`; min/max live at the same offsets
+    // (pinned[off..off+64) holds `small` as read back after phase A — or again after the chains: min/max sit at the same offsets)
     const int32_t* mm = reinterpret_cast<const int32_t*>(base);
     const float* meta = reinterpret_cast<const float*>(base + 64);
     w.u8((uint8_t)a.scheme);
     w.u8((uint8_t)a.transform);
     w.u8(1);   // rans_encoding
     w.bytes(a.ft.header);
-    const uint32_t* lens = reinterpret_cast<const uint32_t*>(base);   // small[8] = rANS bytes, small[10] = rABS bytes
-    w.leb128(lens[8]);
-    w.bytes(rans_ptr[i], lens[8]);
+    const uint32_t rans_len = job->run.rans_len[i], aux_len = job->run.aux_len[i];
+    w.leb128(rans_len);
+    w.bytes(rans_ptr[i], rans_len);
     ByteSink tinfo;
     if (a.transform == kWrapped) { tinfo.u32((uint32_t)mm[0]); tinfo.u32((uint32_t)mm[1]); }
     else if (a.transform == kOctOrth) { tinfo.u32(255); tinfo.u32(127); }
     if (a.scheme == kNormal) {
       w.bytes(tinfo.b);
       w.u8(aux[i].zero_prob);
-      w.leb128(lens[10]);
-      w.bytes(aux_ptr[i], lens[10]);
+      w.leb128(aux_len);
+      w.bytes(aux_ptr[i], aux_len);
     } else if (a.scheme == kTexCoord) {
       w.u32(aux[i].count);
       w.u8(aux[i].zero_prob);
-      w.leb128(lens[10]);
-      w.bytes(aux_ptr[i], lens[10]);
+      w.leb128(aux_len);
+      w.bytes(aux_ptr[i], aux_len);
       w.bytes(tinfo.b);
     } else {
       w.bytes(tinfo.b);
@@ -842,6 +872,57 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
 // streams of all jobs run in ONE k_chains launch (thousands of wavefronts — the regime where the one-wavefront-
 // per-stream coder fills the chip).  All jobs must live on the same device; they are serialised on jobs[0]'s
 // stream order-wise by using each job's own stream only when they are the same stream (see dmi_encode_attributes_batch).
+// Device + pinned staging of one batch read-back, kept between calls (grow-only; a small pool so that concurrent
+// dmi_jobs_encode calls do not share one).
+struct BatchArena {
+  int device = -1;
+  void* bytes_dev = nullptr; size_t bytes_dev_cap = 0;
+  void* table_dev = nullptr; void* table_host = nullptr; size_t table_cap = 0;
+  void* bytes_host = nullptr; size_t bytes_host_cap = 0;
+  bool in_use = false;
+  int reserve(size_t dev_bytes, size_t table_bytes) {
+    if (dev_bytes > bytes_dev_cap) {
+      if (bytes_dev) (void)hipFree(bytes_dev);
+      bytes_dev = nullptr; bytes_dev_cap = 0;
+      HIP_TRY(hipMalloc(&bytes_dev, dev_bytes + dev_bytes / 4 + 4096));
+      bytes_dev_cap = dev_bytes + dev_bytes / 4 + 4096;
+    }
+    if (table_bytes > table_cap) {
+      if (table_dev) (void)hipFree(table_dev);
+      if (table_host) (void)hipHostFree(table_host);
+      table_dev = table_host = nullptr; table_cap = 0;
+      HIP_TRY(hipMalloc(&table_dev, table_bytes * 2));
+      HIP_TRY(hipHostMalloc(&table_host, table_bytes * 2, hipHostMallocDefault));
+      table_cap = table_bytes * 2;
+    }
+    return DMI_OK;
+  }
+  int reserve_host(size_t bytes) {
+    if (bytes > bytes_host_cap) {
+      if (bytes_host) (void)hipHostFree(bytes_host);
+      bytes_host = nullptr; bytes_host_cap = 0;
+      HIP_TRY(hipHostMalloc(&bytes_host, bytes + bytes / 4 + 4096, hipHostMallocDefault));
+      bytes_host_cap = bytes + bytes / 4 + 4096;
+    }
+    return DMI_OK;
+  }
+};
+static std::mutex g_arena_mutex;
+static std::vector<BatchArena*> g_arenas;   // (never freed: process-lifetime staging)
+static BatchArena* acquire_batch_arena(int device) {
+  std::lock_guard<std::mutex> lock(g_arena_mutex);
+  for (BatchArena* a : g_arenas) if (!a->in_use && a->device == device) { a->in_use = true; return a; }
+  BatchArena* a = new BatchArena();
+  a->device = device;
+  a->in_use = true;
+  g_arenas.push_back(a);
+  return a;
+}
+static void release_batch_arena(BatchArena* a) {
+  std::lock_guard<std::mutex> lock(g_arena_mutex);
+  a->in_use = false;
+}
+
 int dmi_jobs_encode(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
   if (!jobs || !outs || n == 0) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
   for (uint32_t j = 0; j < n; ++j) if (!jobs[j] || jobs[j]->cfg.device != jobs[0]->cfg.device) return fail(DMI_ERR_INVALID_ARGUMENT, "batched jobs must live on one device");
@@ -895,8 +976,27 @@ int dmi_jobs_encode(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
   launch_chains(descs_dev.as<ChainDesc>(), (uint32_t)all.size(), s);
   HIP_TRY(hipStreamSynchronize(s));
   const auto t5 = now();
-  if ((rc = parallel([&](uint32_t j) { return encode_phase_c1(jobs[j]); }))) return rc;
-  if ((rc = parallel([&](uint32_t j) { return encode_phase_c2(jobs[j]); }))) return rc;
+  // read-back: every stream of every job packed into one arena on the device → one table copy + one byte copy
+  const uint32_t n_streams = (uint32_t)all.size();
+  std::vector<uint32_t> first_desc(n, 0);
+  size_t cap_sum = 0;
+  {
+    uint32_t at = 0;
+    for (uint32_t j = 0; j < n; ++j) { first_desc[j] = at; at += (uint32_t)jobs[j]->run.descs.size(); }
+    for (const ChainDesc& d : all) cap_sum += ((size_t)d.cap + 31) & ~(size_t)15;
+  }
+  BatchArena* arena = acquire_batch_arena(device);
+  struct Release { BatchArena* a; ~Release() { release_batch_arena(a); } } release{arena};
+  if ((rc = arena->reserve(cap_sum, (size_t)(n_streams + 1) * sizeof(PackEntry)))) return rc;
+  launch_pack_streams(descs_dev.as<ChainDesc>(), n_streams, static_cast<PackEntry*>(arena->table_dev), static_cast<uint8_t*>(arena->bytes_dev), s);
+  HIP_TRY(hipMemcpyAsync(arena->table_host, arena->table_dev, (size_t)(n_streams + 1) * sizeof(PackEntry), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  const PackEntry* table = static_cast<const PackEntry*>(arena->table_host);
+  const size_t total = (size_t)table[n_streams].offset;
+  if ((rc = arena->reserve_host(total))) return rc;
+  if (total) HIP_TRY(hipMemcpyAsync(arena->bytes_host, arena->bytes_dev, total, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  for (uint32_t j = 0; j < n; ++j) if ((rc = encode_phase_c_packed(jobs[j], table, first_desc[j], static_cast<const uint8_t*>(arena->bytes_host)))) return rc;
   const auto t6 = now();
   if ((rc = parallel([&](uint32_t j) { return encode_phase_c3(jobs[j], &outs[j]); }, false))) return rc;
   if (trace) std::fprintf(stderr, "[dmi] batch of %u on %u host threads: phase A issue %.2f ms, wait %.2f, phase B (host tables + prep issue) %.2f, wait %.2f, chains (%zu streams) %.2f, read-back %.2f, splice %.2f\n", n, n_threads, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), all.size(), ms(t4, t5), ms(t5, t6), ms(t6, now()));

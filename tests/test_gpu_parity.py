@@ -57,6 +57,17 @@ def test_synthetic_drc_bit_exact(n, open_boundary, normals, uvs):
     _assert_same(dmi.encode_mesh(mesh), want, f"grid {n}")
 
 
+@pytest.mark.parametrize("n,open_boundary,normals,uvs", [(40, False, True, True), (33, True, True, True), (150, True, False, True), (90, False, True, False)])
+def test_per_attribute_kernels_match_the_fused_sweep(n, open_boundary, normals, uvs, monkeypatch):
+    """Seam-free meshes take the fused predictor sweep; DMI_NO_FUSED (read at job creation) forces the general
+    per-attribute kernels (parallelogram / per-face normals + fan / texcoord).  Both must give the oracle's bytes."""
+    mesh = synth.torus_mesh(n, normals=normals, uvs=uvs, open_boundary=open_boundary)
+    want = oracle_from_product_mesh(mesh).encode()
+    _assert_same(dmi.encode_mesh(mesh), want, f"fused grid {n}")
+    monkeypatch.setenv("DMI_NO_FUSED", "1")
+    _assert_same(dmi.encode_mesh(mesh), want, f"per-attribute grid {n}")
+
+
 def test_append_semantics_of_encode():
     mesh = synth.torus_mesh(16)
     buf = bytearray(b"xyz")
