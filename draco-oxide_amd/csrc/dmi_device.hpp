@@ -58,7 +58,10 @@ void launch_orient_summary(const uint8_t* orient, uint32_t n, uint32_t* summary,
 uint32_t orient_summary_blocks(uint32_t n);
 
 // ---- histogram (a16) -------------------------------------------------------------------------------
-void launch_histogram(const uint32_t* sym, uint64_t n_sym, uint32_t* hist, uint32_t bins, uint32_t* overflow_flag, hipStream_t s);
+// histograms (pre-zeroed) of up to kMaxRangeAtts symbol streams in one launch; *overflow |= 1 when a symbol ≥ bins is met
+struct HistAtt { const uint32_t* sym; uint64_t n; uint32_t* hist; uint32_t* overflow; uint32_t bins; uint32_t first_block, blocks, pad; };
+struct HistArgs { HistAtt a[kMaxRangeAtts]; int count; };
+void launch_histograms(HistArgs& args, hipStream_t s);
 
 // ---- serial coders: two wavefronts per stream (a18, a19, a11, a13) ------------------------------------
 // Coding record of one symbol (see dmi_chains.hip): x / f = mulhi(x, m) >> (b & 31); bit 8 of b flags f == 1;

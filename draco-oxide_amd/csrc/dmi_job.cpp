@@ -48,6 +48,13 @@ struct DevMem {
   template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
+// A view into the job's slab (same accessors as DevMem, no ownership)
+struct SlabView {
+  void* p = nullptr;
+  size_t bytes = 0;
+  template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
 struct TableDev {
   uint32_t F = 0, V = 0, n_seq = 0;
   DevMem c2r, opp, seq, s2p;   // c2r = corner → sequence index of its vertex; s2p = sequence index → point (= point_idx(seq[i]))
@@ -69,7 +76,12 @@ struct AttJob {
   int parent = -1;
   int fused_into = -1;   // ≥ 0: predicted by the fused seam-free sweep launched for that position attribute
   int fused_nrm = -1, fused_uv = -1;   // (on a position attribute) the attributes its fused sweep also predicts
-  DevMem raw, s2v /*sequence index → value index, only with a point_to_value map*/, fn, qs, sym, aux /*flips or orient*/, hist, rtable, rec, out, meta, partials, ipartials, small /*minmax[2], counters[2], flags[2], out_len[2]*2*/, summary;
+  DevMem raw, s2v /*sequence index → value index, only with a point_to_value map*/, fn, qs, sym, aux /*flips or orient*/, rtable, rec, out, partials, ipartials;
+  // views into dmi_job::slab — one memset, one read-back per encode: small = 16 scratch words (minmax[2], counters[2], flags[2], …,
+  // out_len[2]*2, ticks[2]), meta = quantization ranges, hist = symbol histogram (bins_cap words), summary = orientation chunk summaries
+  SlabView small, meta, hist, summary;
+  size_t slab_off = 0;
+  uint32_t bins_cap = 0;
   uint32_t bins = 0;
   uint64_t n_sym = 0;
   uint64_t out_cap = 0, aux_cap = 0;
@@ -91,6 +103,7 @@ struct dmi_job {
   std::vector<AttJob> atts;
   std::vector<TableDev> tables;
   DevMem descs;
+  DevMem slab;   // small / meta / hist / summary of every attribute, laid out exactly like the pinned read-back buffer
   void* pinned = nullptr;   // host-pinned readback area
   size_t pinned_bytes = 0;
   hipEvent_t ev[8]{};
@@ -372,7 +385,7 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
   }
   uint32_t max_point = 0;
   for (size_t c = 0; c < C; ++c) max_point = std::max(max_point, tables[0].corner_to_point[c]);
-  size_t pinned_need = 256;
+  size_t pinned_need = 0;
   uint64_t pb = 0;
   for (uint32_t i = 0; i < n_atts; ++i) {
     AttJob& a = job->atts[i];
@@ -409,10 +422,9 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
       if ((rc = a.chunk_info.alloc((size_t)std::max(1u, orient_summary_blocks(n)) * 8))) return rc;
     }
     if (a.scheme == kNormal && a.fused_into < 0) { if ((rc = a.fn.alloc((size_t)F * 3 * 4))) return rc; }
-    if (a.scheme == kTexCoord) { if ((rc = a.summary.alloc((size_t)std::max(1u, orient_summary_blocks(n)) * 16))) return rc; }
     a.bins = symbol_bins(a);
     if (a.port == kToBits) a.bins = 1u << 20;   // capacity; the real bound is checked after the min/max readback
-    if ((rc = a.hist.alloc((size_t)a.bins * 4))) return rc;
+    a.bins_cap = a.bins;
     if ((rc = a.rtable.alloc((size_t)a.bins * sizeof(RansEntry)))) return rc;
     if ((rc = a.rec.alloc(((size_t)a.n_sym + kChainPad) * sizeof(RansEntry)))) return rc;
     HIP_TRY(hipMemsetAsync(a.rec.p, 0, a.rec.bytes, s));
@@ -420,16 +432,27 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
     HIP_TRY(hipMemsetAsync(a.batch_flags.p, 0, a.batch_flags.bytes, s));
     a.out_cap = a.n_sym * 3 + 16;   // ≤ 3 renormalisation bytes per symbol (P ≤ 20) + flush
     if ((rc = a.out.alloc(a.out_cap + 16))) return rc;
-    if ((rc = a.meta.alloc(64))) return rc;
     if ((rc = a.partials.alloc((size_t)kRangeMaxBlocks * 8 * 4))) return rc;
     if ((rc = a.ipartials.alloc((size_t)2048 * 2 * 4))) return rc;   // ≥ 2 * seq_quantize_blocks(n)
-    if ((rc = a.small.alloc(64))) return rc;
-    pinned_need += 256 + (size_t)a.bins * 4 + (size_t)std::max(1u, orient_summary_blocks(n)) * 16;
+    // slab slot of this attribute: [small 64 B][meta 64 B][hist bins_cap·4][summary], 256-byte aligned
+    a.slab_off = pinned_need;
+    pinned_need += 128 + (size_t)a.bins_cap * 4 + (a.scheme == kTexCoord ? (size_t)std::max(1u, orient_summary_blocks(n)) * 16 : 0);
+    pinned_need = (pinned_need + 255) & ~(size_t)255;
     // algorithmic bytes of the quantize+predict pass: 4·Nin + 4·Nsym per value, 8 per sequence entry
     pb += (uint64_t)d.num_unique * 4 * d.num_components + a.n_sym * 4 + (uint64_t)n * 8;
   }
   pb += (uint64_t)F * 24;   // corner_to_point + opposite, once
   job->predict_bytes = pb;
+  pinned_need += 256;
+  if ((rc = job->slab.alloc(pinned_need))) return rc;
+  HIP_TRY(hipMemsetAsync(job->slab.p, 0, pinned_need, s));
+  for (auto& a : job->atts) {
+    uint8_t* base = job->slab.as<uint8_t>() + a.slab_off;
+    a.small = SlabView{base, 64};
+    a.meta = SlabView{base + 64, 64};
+    a.hist = SlabView{base + 128, (size_t)a.bins_cap * 4};
+    a.summary = SlabView{base + 128 + (size_t)a.bins_cap * 4, a.scheme == kTexCoord ? (size_t)std::max(1u, orient_summary_blocks(job->tables[a.table].n_seq)) * 16 : 0};
+  }
   HIP_TRY(hipHostMalloc(&job->pinned, pinned_need, hipHostMallocDefault));
   job->pinned_bytes = pinned_need;
   if ((rc = job->descs.alloc(sizeof(ChainDesc) * (size_t)n_atts * 2))) return rc;
@@ -460,6 +483,7 @@ static int encode_phase_a(dmi_job* job) {   // device: ranges → coding-order p
   const bool timed = job->have_events;
   // ---- stage 1: value ranges (streamed over the unique values) ---------------------------------------------
   if (timed) HIP_TRY(hipEventRecord(job->ev[0], s));
+  HIP_TRY(hipMemsetAsync(job->slab.p, 0, job->slab.bytes, s));   // histograms, scratch words, summaries: one memset
   {
     RangeArgs ra{};
     for (auto& a : job->atts) {
@@ -560,7 +584,7 @@ static int encode_phase_a(dmi_job* job) {   // device: ranges → coding-order p
   if (timed) HIP_TRY(hipEventRecord(job->ev[2], s));
   std::vector<size_t>& pin_off = job->run.pin_off;
   pin_off.assign(n_atts, 0);
-  size_t off = 0;
+  HistArgs ha{};
   for (uint32_t i = 0; i < n_atts; ++i) {
     AttJob& a = job->atts[i];
     if (a.port == kToBits) {
@@ -570,23 +594,17 @@ static int encode_phase_a(dmi_job* job) {   // device: ranges → coding-order p
       HIP_TRY(hipStreamSynchronize(s));
       const uint64_t span = (mm[1] >= mm[0]) ? (uint64_t)((int64_t)mm[1] - (int64_t)mm[0]) : 0;
       const uint64_t need = (a.transform == kWrapped ? span + 3 : 2 * span + 2);
-      if (need > (1u << 20)) return fail(DMI_ERR_ALPHABET_TOO_LARGE, "custom attribute value range needs more than 2^20 symbols");
+      if (need > a.bins_cap) return fail(DMI_ERR_ALPHABET_TOO_LARGE, "custom attribute value range needs more than 2^20 symbols");
       a.bins = (uint32_t)need;
     }
-    HIP_TRY(hipMemsetAsync(a.hist.p, 0, (size_t)a.bins * 4, s));
-    if (a.n_sym) launch_histogram(a.sym.as<uint32_t>(), a.n_sym, a.hist.as<uint32_t>(), a.bins, a.small.as<uint32_t>() + 5, s);
-    pin_off[i] = off;
-    HIP_TRY(hipMemcpyAsync(pinned + off, a.small.p, 64, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(pinned + off + 64, a.meta.p, 64, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(pinned + off + 128, a.hist.p, (size_t)a.bins * 4, hipMemcpyDeviceToHost, s));
-    size_t o2 = off + 128 + (size_t)a.bins * 4;
-    if (a.scheme == kTexCoord) {
-      const uint32_t nb = orient_summary_blocks(job->tables[a.table].n_seq);
-      if (nb) HIP_TRY(hipMemcpyAsync(pinned + o2, a.summary.p, (size_t)nb * 16, hipMemcpyDeviceToHost, s));
-      o2 += (size_t)std::max(1u, nb) * 16;
-    }
-    off = (o2 + 63) & ~(size_t)63;
+    HistAtt& h = ha.a[ha.count++];
+    h.sym = a.sym.as<uint32_t>(); h.n = a.n_sym; h.hist = a.hist.as<uint32_t>(); h.bins = a.bins; h.overflow = a.small.as<uint32_t>() + 5;
+    if (ha.count == kMaxRangeAtts) { launch_histograms(ha, s); ha.count = 0; }
+    pin_off[i] = a.slab_off;
   }
+  launch_histograms(ha, s);
+  // scratch words, ranges, histograms and orientation summaries of every attribute: one copy (the pinned buffer mirrors the slab)
+  HIP_TRY(hipMemcpyAsync(pinned, job->slab.p, job->slab.bytes, hipMemcpyDeviceToHost, s));
   if (timed) HIP_TRY(hipEventRecord(job->ev[3], s));
   return DMI_OK;
 }
@@ -642,7 +660,7 @@ static int encode_phase_b(dmi_job* job) {   // host: table normalisation; device
     } else if (a.scheme == kTexCoord) {
       // stitch per-block summaries: len = Σ count, freq_count_0 = forward transitions with last := true
       const uint32_t nb = orient_summary_blocks(n);
-      const uint32_t* sm = reinterpret_cast<const uint32_t*>(base + 128 + (size_t)a.bins * 4);
+      const uint32_t* sm = reinterpret_cast<const uint32_t*>(base + 128 + (size_t)a.bins_cap * 4);
       uint64_t len = 0, trans = 0;
       uint32_t last = 1;
       for (uint32_t b = 0; b < nb; ++b) {

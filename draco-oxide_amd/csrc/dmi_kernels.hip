@@ -967,21 +967,25 @@ __global__ __launch_bounds__(64) void k_orient_summary(const uint8_t* __restrict
   }
 }
 
-// Symbol histogram, LDS-privatised when the alphabet fits (≤ 16K bins = 64 KiB of the CU's 160 KiB).
+// Symbol histograms of every attribute of a job in one launch (block → (attribute, slice)), LDS-privatised when the
+// alphabet fits (≤ 16K bins = 64 KiB of the CU's 160 KiB).  Few, fat blocks: each flushes its private copy once.
 constexpr uint32_t kLdsBins = 16384;
-__global__ __launch_bounds__(kBlock) void k_histogram(const uint32_t* __restrict__ sym, uint64_t n, uint32_t* __restrict__ hist, uint32_t bins,
-                                                      uint32_t* __restrict__ overflow) {
+__global__ __launch_bounds__(kBlock) void k_histogram(HistArgs args) {
   extern __shared__ uint32_t lds[];
-  const bool use_lds = bins <= kLdsBins;
-  if (use_lds) { for (uint32_t b = threadIdx.x; b < bins; b += kBlock) lds[b] = 0; __syncthreads(); }
-  for (uint64_t e = (uint64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (uint64_t)gridDim.x * kBlock) {
-    const uint32_t s = sym[e];
-    if (s >= bins) { atomicOr(overflow, 1u); continue; }
-    if (use_lds) atomicAdd(&lds[s], 1u); else atomicAdd(&hist[s], 1u);
+  int ai = 0;
+  while (ai + 1 < args.count && blockIdx.x >= args.a[ai + 1].first_block) ++ai;
+  const HistAtt a = args.a[ai];
+  const uint32_t block = blockIdx.x - a.first_block;
+  const bool use_lds = a.bins <= kLdsBins;
+  if (use_lds) { for (uint32_t b = threadIdx.x; b < a.bins; b += kBlock) lds[b] = 0; __syncthreads(); }
+  for (uint64_t e = (uint64_t)block * kBlock + threadIdx.x; e < a.n; e += (uint64_t)a.blocks * kBlock) {
+    const uint32_t s = a.sym[e];
+    if (s >= a.bins) { atomicOr(a.overflow, 1u); continue; }
+    if (use_lds) atomicAdd(&lds[s], 1u); else atomicAdd(&a.hist[s], 1u);
   }
   if (use_lds) {
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < bins; b += kBlock) { const uint32_t v = lds[b]; if (v) atomicAdd(&hist[b], v); }
+    for (uint32_t b = threadIdx.x; b < a.bins; b += kBlock) { const uint32_t v = lds[b]; if (v) atomicAdd(&a.hist[b], v); }
   }
 }
 
@@ -1065,11 +1069,17 @@ void launch_orient_summary(const uint8_t* orient, uint32_t n, uint32_t* summary,
   if (g) hipLaunchKernelGGL(k_orient_summary, g, 64, 0, s, orient, n, summary);
 }
 
-void launch_histogram(const uint32_t* sym, uint64_t n_sym, uint32_t* hist, uint32_t bins, uint32_t* overflow_flag, hipStream_t s) {
-  const size_t lds = bins <= kLdsBins ? (size_t)bins * 4 : 0;
-  // few, fat blocks: each block flushes its private histogram once
-  const uint32_t g = grid_for(n_sym, 512);
-  hipLaunchKernelGGL(k_histogram, g, kBlock, lds, s, sym, n_sym, hist, bins, overflow_flag);
+void launch_histograms(HistArgs& args, hipStream_t s) {
+  uint32_t total = 0;
+  size_t lds = 0;
+  for (int i = 0; i < args.count; ++i) {
+    HistAtt& a = args.a[i];
+    a.blocks = a.n ? grid_for(a.n, 512) : 0u;
+    a.first_block = total;
+    total += a.blocks;
+    if (a.blocks && a.bins <= kLdsBins) lds = std::max(lds, (size_t)a.bins * 4);
+  }
+  if (total) hipLaunchKernelGGL(k_histogram, total, kBlock, lds, s, args);
 }
 
 }  // namespace dmi
