@@ -56,6 +56,18 @@ def cpu_baseline(mesh, seconds_budget=30.0):
     }
 
 
+def pmc_traffic_bytes():
+    """HBM bytes of one quantize+predict pass from the committed rocprofv3 PMC passes (FETCH_SIZE with the gfx950 x2
+    correction + WRITE_SIZE, profiles/round1_pmc_traffic.csv, produced by scripts/summarize_profiles.py); None if absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic.csv")
+    try:
+        last = [l for l in open(path) if l.startswith("# quantize+predict pass per step")][-1]
+        nums = [float(x) for x in __import__("re").findall(r"([0-9.]+) MB", last)]   # fetch raw, fetch doubled, write
+        return int((nums[1] + nums[2]) * 1e6)
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,10 +155,10 @@ def main():
                        "triangles_per_gpu": n_tris, "attributes": "pos3+nrm3+uv2", "bitstream_bytes": out_len,
                        "parallelism": f"{world} independent meshes, one per GPU" + (", RCCL gather of bitstreams to rank 0" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                         "traffic": None,
-                         "kernel": "quantize+predict pass = k_init_small + k_minmax_f32 + k_minmax_final + k_check_normals + k_seq_quantize + "
-                                   "k_pred_parallelogram_wrapped + k_face_normals + k_pred_normal_octorth + k_pred_texcoord_wrapped + k_orient_summary "
-                                   "(every launch between the first and the histogram stage of one step, hipEvent-timed on the job's stream)",
+                         "traffic": pmc_traffic_bytes(),
+                         "kernel": "quantize+predict pass = slab memset + k_value_ranges + k_value_ranges_final + k_seq_quantize + k_i32_minmax_final + "
+                                   "k_predict_fused + k_orient_summary (every launch between the first and the histogram stage of one step, "
+                                   "hipEvent-timed on the job's stream)",
                          "algorithmic_bytes": int(tm["predict_bytes"]), "duration_ms": round(pass_ms, 4)},
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},
             "chains": {"streams": int(tm["num_streams"]), "symbols": int(tm["symbols"]),

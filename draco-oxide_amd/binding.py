@@ -63,7 +63,7 @@ class _Conn(C.Structure):
 
 
 EXPORTS = ["dmi_encode_attributes", "dmi_encode_attributes_batch", "dmi_jobs_encode", "dmi_job_create", "dmi_job_encode", "dmi_job_timings", "dmi_job_destroy", "dmi_encode_mesh",
-           "dmi_mesh_prepare", "dmi_encode_connectivity", "dmi_conn_free", "dmi_free", "dmi_strerror", "dmi_last_error", "dmi_device_count"]
+           "dmi_mesh_prepare", "dmi_meshes_prepare", "dmi_encode_connectivity", "dmi_conn_free", "dmi_free", "dmi_strerror", "dmi_last_error", "dmi_device_count"]
 
 
 def library_path():
@@ -97,6 +97,7 @@ def load_library():
     L.dmi_job_destroy.argtypes = [C.c_void_p]
     L.dmi_encode_mesh.argtypes = [C.POINTER(_Mesh), C.POINTER(_Config), C.POINTER(_Buffer)]
     L.dmi_mesh_prepare.argtypes = [C.POINTER(_Mesh), C.POINTER(_Config), C.POINTER(_Buffer), C.POINTER(C.c_void_p)]
+    L.dmi_meshes_prepare.argtypes = [C.POINTER(_Mesh), C.c_uint32, C.POINTER(_Config), C.POINTER(_Buffer), C.POINTER(C.c_void_p)]
     L.dmi_encode_connectivity.argtypes = [C.POINTER(_Mesh), C.POINTER(_Buffer), C.POINTER(_Conn)]
     L.dmi_conn_free.argtypes = [C.POINTER(_Conn)]
     _lib = L
@@ -430,6 +431,26 @@ def mesh_prepare(mesh, cfg=None):
     m, c, head, h = mesh._c(), cfg._c(), _Buffer(), C.c_void_p()
     _check(L.dmi_mesh_prepare(C.byref(m), C.byref(c), C.byref(head), C.byref(h)))
     return Job(h.value, _take(head))
+
+
+def meshes_prepare(meshes, cfg=None):
+    """mesh_prepare for a list of meshes, host stages on a thread pool inside the library (dmi_meshes_prepare)."""
+    L = load_library()
+    cfg = cfg or Config.default()
+    n = len(meshes)
+    if n == 0:
+        return []
+    arr = (_Mesh * n)()
+    keep = []
+    for i, m in enumerate(meshes):
+        cm = m._c()
+        keep.append(cm)
+        arr[i] = cm
+    c = cfg._c()
+    heads = (_Buffer * n)()
+    handles = (C.c_void_p * n)()
+    _check(L.dmi_meshes_prepare(arr, n, C.byref(c), heads, handles))
+    return [Job(handles[i], _take(heads[i])) for i in range(n)]
 
 
 def encode_connectivity(mesh):

@@ -117,12 +117,23 @@ __device__ __forceinline__ void range_slice(const RangeAtt& a, uint32_t block, f
   float mn[N], mx[N];
 #pragma unroll
   for (int k = 0; k < N; ++k) { mn[k] = 0.0f; mx[k] = 0.0f; }
-  for (uint32_t v = block * kBlock + threadIdx.x; v < a.n; v += a.blocks * kBlock) {
+  // four values per thread and round, all loads issued before the compares (more bytes in flight per lane)
+  const uint32_t stride = a.blocks * kBlock;
+  for (uint32_t v0 = block * kBlock + threadIdx.x; v0 < a.n; v0 += 4 * stride) {
+    float x[4][N];
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-      const float x = a.raw[(size_t)v * N + k];
-      if (x < mn[k]) mn[k] = x;
-      if (x > mx[k]) mx[k] = x;
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t v = v0 + u * stride;
+#pragma unroll
+      for (int k = 0; k < N; ++k) x[u][k] = (v < a.n) ? a.raw[(size_t)v * N + k] : 0.0f;   // 0.0 is the seed: neutral
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        if (x[u][k] < mn[k]) mn[k] = x[u][k];
+        if (x[u][k] > mx[k]) mx[k] = x[u][k];
+      }
     }
   }
   block_reduce_minmax<N>(mn, mx, out);

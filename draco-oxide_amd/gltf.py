@@ -17,7 +17,7 @@ import struct
 
 import numpy as np
 
-from .binding import (ATT_NORMAL, ATT_POSITION, ATT_TEXCOORD, DOMAIN_CORNER, DOMAIN_POSITION, Config, MeshBuilder, jobs_encode, mesh_prepare)
+from .binding import (ATT_NORMAL, ATT_POSITION, ATT_TEXCOORD, DOMAIN_CORNER, DOMAIN_POSITION, Config, MeshBuilder, jobs_encode, meshes_prepare)
 
 _COMPONENTS = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4}
 _INDEX_DTYPE = {5121: np.uint8, 5123: np.uint16, 5125: np.uint32}
@@ -107,7 +107,7 @@ def transcode_glb(data, cfg=None):
                 continue                                                           # encode.rs:934-936
             prims.append((prim, names, m))
             meshes.append(m)
-    jobs = [mesh_prepare(m, cfg) for m in meshes]
+    jobs = meshes_prepare(meshes, cfg)   # host connectivity of all primitives on a thread pool
     sections = jobs_encode(jobs) if jobs else []
     blobs = [j.header_and_connectivity + s for j, s in zip(jobs, sections)]
     for j in jobs:

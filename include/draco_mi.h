@@ -156,6 +156,11 @@ int dmi_encode_mesh(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buffer* out
  * included) and a resident job for the attribute section. */
 int dmi_mesh_prepare(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buffer* header_and_connectivity, dmi_job** job);
 
+/* dmi_mesh_prepare for n independent meshes (the glTF transcoder's primitives, io/gltf/encode.rs:932-955): the host
+ * graph walks and uploads of different meshes run concurrently on a pool of host threads.  All-or-nothing: on error no
+ * job or buffer is left allocated. */
+int dmi_meshes_prepare(const dmi_mesh* meshes, uint32_t n, const dmi_config* cfg, dmi_buffer* header_and_connectivity, dmi_job** jobs);
+
 /* Host connectivity only (no GPU needed): header + connectivity bytes, plus the flat tables that
  * dmi_encode_attributes consumes.  Tables are library-owned and freed by dmi_conn_free. */
 typedef struct dmi_conn {

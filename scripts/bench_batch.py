@@ -15,12 +15,10 @@ grids = [max(8, synth.grid_size_for_triangles(t)) for t in tris]
 dev = torch.device("cuda", 0)
 stream = torch.cuda.Stream(dev)
 cfg = dmi.Config()   # every job owns its stream: host threads issue in parallel, small kernels overlap on the GPU
+meshes = [synth.torus_mesh(n, seed=synth.SEED + 7 * k) for k, n in enumerate(grids)]
+total = sum(len(m.faces) for m in meshes)
 t0 = time.time()
-jobs, total = [], 0
-for k, n in enumerate(grids):
-    m = synth.torus_mesh(n, seed=synth.SEED + 7 * k)
-    total += len(m.faces)
-    jobs.append(dmi.mesh_prepare(m, cfg))
+jobs = dmi.meshes_prepare(meshes, cfg)   # corner tables, Edgebreaker, sequencers, uploads: thread pool inside the library
 prep = time.time() - t0
 outs = dmi.jobs_encode(jobs)   # warm-up
 torch.cuda.synchronize()

@@ -218,7 +218,7 @@ def test_batch_of_meshes_one_chain_launch():
     specs = [(12, False, True, True), (40, True, True, True), (25, False, False, False), (64, False, True, True),
              (33, True, False, True), (9, False, True, False), (50, False, True, True), (18, True, True, True)]
     meshes = [synth.torus_mesh(n, seed=1000 + k, normals=nr, uvs=uv, open_boundary=ob) for k, (n, ob, nr, uv) in enumerate(specs)]
-    jobs = [dmi.mesh_prepare(m) for m in meshes]
+    jobs = dmi.meshes_prepare(meshes)   # host connectivity of all meshes on the library's thread pool
     outs = dmi.jobs_encode(jobs)
     for m, j, o in zip(meshes, jobs, outs):
         want = oracle_from_product_mesh(m).encode()
