@@ -10,10 +10,11 @@ namespace dmi {
 // ---- quantization (a4-a6), fused with the coding-order gather ---------------------------------------
 // meta layout (floats): [0..N) per-component min, [N] range, [N+1..2N] per-component max (debug)
 // Stage 1 for up to kMaxRangeAtts attributes in two launches: f32 min/max (kind 0, seeded 0.0: Q1) → meta, zero-length
-// normal check (kind 1) → small[4]; every attribute's 16 scratch words are (re)initialised: [0..1] = {INT_MAX, INT_MIN}.
+// normal check (kind 1) → small[4]; every attribute's 16 scratch words are (re)initialised: [0..1] = {INT_MAX, INT_MIN},
+// and `zero[0..zero_words)` (the rest of its slab slot: ranges, histogram, summaries) is cleared.
 constexpr int kMaxRangeAtts = 8;
 constexpr uint32_t kRangeMaxBlocks = 1024;   // partials: kRangeMaxBlocks * 2N floats per attribute
-struct RangeAtt { const float* raw; float* partials; float* meta; uint32_t* small; uint32_t n; int N; int kind; uint32_t first_block, blocks; };
+struct RangeAtt { const float* raw; float* partials; float* meta; uint32_t* small; uint32_t* zero; size_t zero_words; uint32_t n; int N; int kind; uint32_t first_block, blocks; };
 struct RangeArgs { RangeAtt a[kMaxRangeAtts]; int count; };
 void launch_value_ranges(RangeArgs& args, hipStream_t s);
 // joint i32 min/max of the sequence-ordered quantized values: per-block partials of k_seq_quantize → minmax[2]

@@ -484,7 +484,6 @@ static int encode_phase_a(dmi_job* job) {   // device: ranges → coding-order p
   const bool timed = job->have_events;
   // ---- stage 1: value ranges (streamed over the unique values) ---------------------------------------------
   if (timed) HIP_TRY(hipEventRecord(job->ev[0], s));
-  HIP_TRY(hipMemsetAsync(job->slab.p, 0, job->slab.bytes, s));   // histograms, scratch words, summaries: one memset
   {
     RangeArgs ra{};
     for (auto& a : job->atts) {
@@ -493,6 +492,8 @@ static int encode_phase_a(dmi_job* job) {   // device: ranges → coding-order p
       r.partials = a.partials.as<float>();
       r.meta = a.meta.as<float>();
       r.small = a.small.as<uint32_t>();   // zeroed here; [0..1] := {INT_MAX, INT_MIN}; [4] := zero-length normal seen
+      r.zero = a.meta.as<uint32_t>();   // meta, histogram, summaries: contiguous in the slab slot
+      r.zero_words = (a.meta.bytes + a.hist.bytes + a.summary.bytes) / 4;
       r.n = a.desc.num_unique;
       r.N = a.desc.num_components;
       r.kind = a.port == kCoordwise ? 0 : (a.port == kOct ? 1 : 2);
@@ -1102,14 +1103,23 @@ static int build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std::vector<ui
   if (!mesh || !mesh->atts || mesh->num_atts == 0 || (!mesh->faces && mesh->num_faces)) return fail(DMI_ERR_INVALID_ARGUMENT, "bad mesh");
   if (mesh->atts[0].att_type != DMI_ATT_POSITION) return fail(DMI_ERR_INVALID_ARGUMENT, "attribute 0 must be the Position attribute (core/mesh/builder.rs:115-125)");
   std::string err;
+  const bool trace = std::getenv("DMI_TRACE") != nullptr;
+  auto tick = [] { return std::chrono::steady_clock::now(); };
+  auto since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
+  auto c0 = tick();
   int rc = o.ct.build_universal(mesh->faces, mesh->num_faces, mesh->atts[0].point_to_value, err);
   if (rc) return fail(rc, err);
+  const double t_univ = since(c0);
   for (uint32_t i = 0; i < mesh->num_atts; ++i) {
     if (mesh->atts[i].att_type == DMI_ATT_POSITION) continue;   // edgebreaker.rs:183-190
     o.ct.build_attribute(mesh->atts[i].point_to_value);
   }
+  const double t_att = since(c0) - t_univ;
+  auto c1 = tick();
   rc = run_edgebreaker(o.ct, o.eb, err);
   if (rc) return fail(rc, err);
+  const double t_eb = since(c1);
+  auto c2 = tick();
   ByteSink s;
   for (char ch : {'D', 'R', 'A', 'C', 'O'}) s.u8((uint8_t)ch);   // encode/header/mod.rs:26-54
   s.u8(2); s.u8(2); s.u8(1); s.u8(1); s.u16(0);
@@ -1144,6 +1154,8 @@ static int build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std::vector<ui
     v.sequence = o.seqs[i].data();
     v.sequence_len = (uint32_t)o.seqs[i].size();
   }
+  if (trace) std::fprintf(stderr, "[dmi] host connectivity of %u faces: universal corner table %.1f ms, attribute tables %.1f, Edgebreaker %.1f, sequencers %.1f\n",
+                          mesh->num_faces, t_univ, t_att, t_eb, since(c2));
   return DMI_OK;
 }
 

@@ -188,7 +188,9 @@ __device__ __forceinline__ void range_final(const RangeAtt& a) {
 __global__ __launch_bounds__(kBlock) void k_value_ranges_final(RangeArgs args) {
   const RangeAtt a = args.a[blockIdx.x];
   if (threadIdx.x < 16) a.small[threadIdx.x] = threadIdx.x == 0 ? 0x7FFFFFFFu : (threadIdx.x == 1 ? 0x80000000u : 0u);
-  __syncthreads();   // the seeding stores are performed before any flag store below
+  // the rest of the attribute's slab slot (ranges, histogram, orientation summaries) starts every encode at zero
+  for (size_t w = threadIdx.x; w < a.zero_words; w += kBlock) a.zero[w] = 0u;
+  __syncthreads();   // the seeding stores are performed before any flag / range store below
   if (a.kind == 0) {
     switch (a.N) {
       case 1: range_final<1>(a); break;
@@ -951,10 +953,19 @@ constexpr uint32_t kOrientChunk = 4096;
 __global__ __launch_bounds__(64) void k_orient_summary(const uint8_t* __restrict__ orient, uint32_t n, uint32_t* __restrict__ summary) {
   const uint32_t lo = blockIdx.x * kOrientChunk, hi = min(n, lo + kOrientChunk);
   const uint32_t lane = threadIdx.x;
+  // stage the chunk through LDS with 16-byte loads: the scan below is a 64-step dependent loop, and a global byte
+  // load per step would expose one memory latency per step
+  __shared__ __attribute__((aligned(16))) uint8_t staged[kOrientChunk];
+  for (uint32_t w = lane; w < kOrientChunk / 16; w += 64) {
+    const uint32_t at = lo + w * 16;
+    if (at + 16 <= n) *reinterpret_cast<uint4*>(staged + w * 16) = *reinterpret_cast<const uint4*>(orient + at);
+    else for (uint32_t b = 0; b < 16; ++b) staged[w * 16 + b] = (at + b < n) ? orient[at + b] : (uint8_t)0;
+  }
+  __syncthreads();
   uint32_t count = 0, trans = 0, first = 2, last = 2;
   for (uint32_t base = lo; base < hi; base += 64) {
     const uint32_t i = base + lane;
-    const uint32_t f = (i < hi) ? orient[i] : 0;
+    const uint32_t f = (i < hi) ? staged[i - lo] : 0;
     const unsigned long long valid = __ballot(f != 0);
     const unsigned long long ones = __ballot(f == 2);
     if (valid == 0) continue;
