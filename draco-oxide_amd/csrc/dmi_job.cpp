@@ -434,7 +434,7 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
     a.out_cap = a.n_sym * 3 + 16;   // ≤ 3 renormalisation bytes per symbol (P ≤ 20) + flush
     if ((rc = a.out.alloc(a.out_cap + 16))) return rc;
     if ((rc = a.partials.alloc((size_t)kRangeMaxBlocks * 8 * 4))) return rc;
-    if ((rc = a.ipartials.alloc((size_t)2048 * 2 * 4))) return rc;   // ≥ 2 * seq_quantize_blocks(n)
+    if ((rc = a.ipartials.alloc((size_t)kSeqQuantizeMaxBlocks * 2 * 4))) return rc;   // ≥ 2 * seq_quantize_blocks(n)
     // slab slot of this attribute: [small 64 B][meta 64 B][hist bins_cap·4][summary], 256-byte aligned
     a.slab_off = pinned_need;
     pinned_need += 128 + (size_t)a.bins_cap * 4 + (a.scheme == kTexCoord ? (size_t)std::max(1u, orient_summary_blocks(n)) * 16 : 0);

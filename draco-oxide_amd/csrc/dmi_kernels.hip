@@ -1040,7 +1040,7 @@ void launch_i32_minmax_final(const MinMaxArgs& args, hipStream_t s) {
   if (args.count) hipLaunchKernelGGL(k_i32_minmax_final, (uint32_t)args.count, kBlock, 0, s, args);
 }
 
-inline uint32_t tiles_grid(uint64_t n) { return grid_for((n + kTile - 1) / kTile); }   // grid of a DMI_FOR_TILES kernel
+inline uint32_t tiles_grid(uint64_t n) { return grid_for((n + kTile - 1) / kTile, kSeqQuantizeMaxBlocks); }   // grid of a DMI_FOR_TILES kernel
 uint32_t seq_quantize_blocks(uint32_t n) { return tiles_grid(n); }
 void launch_seq_quantize(const uint32_t* s2p, uint32_t n, const QuantArgs& args, hipStream_t s) {
   hipLaunchKernelGGL(k_seq_quantize, seq_quantize_blocks(n), kBlock, 0, s, s2p, n, args);
@@ -1079,7 +1079,7 @@ void launch_pred_texcoord_wrapped(const uint32_t* seq, uint32_t n, const uint32_
 void launch_predict_fused(const FusedArgs& a, hipStream_t s) {
   if (a.n == 0) return;
   static const uint32_t env_cap = std::getenv("DMI_FUSED_GRID") ? (uint32_t)std::atoi(std::getenv("DMI_FUSED_GRID")) : 0u;   // tuning aid
-  const uint32_t g = env_cap ? grid_for(a.n, env_cap) : grid_for(a.n);
+  const uint32_t g = grid_for(a.n, env_cap ? env_cap : 8192u);   // 2-3 chunks per block: measured best on the 10M workload (2048: +5 %)
   if (a.qs_nrm && a.qs_uv) hipLaunchKernelGGL((k_predict_fused<true, true>), g, kBlock, 0, s, a);
   else if (a.qs_nrm) hipLaunchKernelGGL((k_predict_fused<true, false>), g, kBlock, 0, s, a);
   else hipLaunchKernelGGL((k_predict_fused<false, true>), g, kBlock, 0, s, a);
