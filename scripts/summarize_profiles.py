@@ -9,21 +9,22 @@ def short(n):
     m = re.search(r"(k_[a-z_0-9]+(<\d>)?)", n)
     return m.group(1) if m else n[:40]
 
-rows = list(csv.DictReader(open(glob.glob(f"{stats_dir}/*/*_kernel_stats.csv")[0])))
-out = [f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline   ({tag}, MI355X)", "kernel, calls, total_ms, avg_us, pct"]
+rows = list(csv.DictReader(open((glob.glob(f"{stats_dir}/*/*_kernel_stats.csv") + glob.glob(f"{stats_dir}/*_kernel_stats.csv"))[0])))
+out = [f"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline   ({tag}, MI355X)", "kernel, calls, total_ms, avg_us, pct"]
 for r in rows:
     out.append(f"{short(r['Name'])}, {r['Calls']}, {float(r['TotalDurationNs'])/1e6:.3f}, {float(r['AverageNs'])/1e3:.2f}, {r['Percentage']}")
 open(f"profiles/{tag}_kernel_stats.csv", "w").write("\n".join(out) + "\n")
 
 def agg(d, cname):
     acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(glob.glob(f"{d}/*/*_counter_collection.csv")[0])):
+    for r in csv.DictReader(open((glob.glob(f"{d}/*/*_counter_collection.csv") + glob.glob(f"{d}/*_counter_collection.csv"))[0])):
         if r["Counter_Name"] == cname:
             acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     return acc
 F, W = agg(fetch_dir, "FETCH_SIZE"), agg(write_dir, "WRITE_SIZE")
-PASS = {"k_init_small", "k_minmax_f32<3>", "k_minmax_f32<2>", "k_minmax_final<3>", "k_minmax_final<2>", "k_check_normals", "k_seq_quantize",
-        "k_pred_parallelogram_wrapped<3>", "k_face_normals", "k_pred_normal_octorth", "k_pred_texcoord_wrapped", "k_orient_summary"}
+PASS = {"k_value_ranges", "k_value_ranges_final", "k_seq_quantize", "k_i32_minmax_final", "k_predict_fused", "k_orient_summary",
+        # the per-attribute kernels of meshes with seams (not launched by the seam-free bench workload)
+        "k_pred_parallelogram_wrapped<3>", "k_face_normals", "k_pred_normal_octorth", "k_pred_texcoord_wrapped"}
 lines = [f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps {pmc_steps - 1} --warmup 1 --no-cpu-baseline ({tag})",
          "# per-launch averages, MB; counter unit KiB.  fetch_x2 = FETCH_SIZE doubled (gfx950 reports half of a wide coalesced read; exact for the",
          "# streaming kernels, an upper bound for the gather kernels whose access width is uncalibrated — MI355X_MICROARCH.md §HBM)",
