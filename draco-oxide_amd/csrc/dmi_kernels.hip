@@ -864,7 +864,7 @@ __global__ __launch_bounds__(kBlock) void k_predict_fused(FusedArgs a) {
   if (HAS_UV) wu = wrap_params(a.mm_uv);
   uint32_t n_false = 0;
   DMI_FOR_SEQUENCE(i, n) {
-    const uint32_t c = seq[i], nc = cnext(c), pc = cprev(c);
+    const uint32_t c = __builtin_nontemporal_load(&seq[i]), nc = cnext(c), pc = cprev(c);
     const uint32_t rn = c2r[nc], rp = c2r[pc], o = opp[c];
     const uint32_t ro = (o != kNoneD) ? c2r[o] : kNoneD;
     const bool both = rn < i && rp < i;
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(kBlock) void k_predict_fused(FusedArgs a) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int32_t pred = have ? wsub(wadd(Pn[k], Pp[k]), Po[k]) : Plast[k];   // Q15: previously coded vertex, 0 for the first entry
-      a.sym_pos[(size_t)i * 3 + k] = wrap_symbol(Pc[k], pred, wp);
+      __builtin_nontemporal_store(wrap_symbol(Pc[k], pred, wp), &a.sym_pos[(size_t)i * 3 + k]);
     }
     // ---- texture coordinates: mesh_prediction_for_texture_coordinates.rs:51-81,107-219 ----
     if (HAS_UV) {
@@ -899,9 +899,9 @@ __global__ __launch_bounds__(kBlock) void k_predict_fused(FusedArgs a) {
         else if (i > 0) { pred0 = qu[(size_t)(i - 1u) * 2]; pred1 = qu[(size_t)(i - 1u) * 2 + 1]; }
         else { pred0 = 0; pred1 = 0; }
       }
-      a.orient[i] = oflag;
-      a.sym_uv[(size_t)i * 2] = wrap_symbol(cu[0], pred0, wu);
-      a.sym_uv[(size_t)i * 2 + 1] = wrap_symbol(cu[1], pred1, wu);
+      __builtin_nontemporal_store(oflag, &a.orient[i]);
+      __builtin_nontemporal_store(wrap_symbol(cu[0], pred0, wu), &a.sym_uv[(size_t)i * 2]);
+      __builtin_nontemporal_store(wrap_symbol(cu[1], pred1, wu), &a.sym_uv[(size_t)i * 2 + 1]);
     }
     // ---- normals: mesh_normal_prediction.rs:22-44,75-144 + oct_orthogonal.rs ----
     if (HAS_NRM) {
@@ -925,11 +925,11 @@ __global__ __launch_bounds__(kBlock) void k_predict_fused(FusedArgs a) {
       const int32_t dot1 = wadd(wmul(d10, d10), wmul(d11, d11)), dot2 = wadd(wmul(d20, d20), wmul(d21, d21));
       const bool flip = dot1 > dot2;   // Q8: flip negates the octahedral coordinates
       if (flip) { p0 = m0; p1 = m1; } else ++n_false;
-      a.flips[i] = flip ? 1 : 0;
+      __builtin_nontemporal_store((uint8_t)(flip ? 1 : 0), &a.flips[i]);
       uint32_t s0, s1;
       oct_orthogonal(a0, a1, p0, p1, s0, s1);
-      a.sym_nrm[(size_t)i * 2] = s0;
-      a.sym_nrm[(size_t)i * 2 + 1] = s1;
+      __builtin_nontemporal_store(s0, &a.sym_nrm[(size_t)i * 2]);
+      __builtin_nontemporal_store(s1, &a.sym_nrm[(size_t)i * 2 + 1]);
     }
   }
   if (HAS_NRM) {
