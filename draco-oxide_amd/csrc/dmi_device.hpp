@@ -40,8 +40,11 @@ struct FusedArgs {
   const int32_t* qs_pos; const int32_t* mm_pos; uint32_t* sym_pos;
   const int32_t* qs_nrm; uint32_t* sym_nrm; uint8_t* flips; uint32_t* counters;
   const int32_t* qs_uv; const int32_t* mm_uv; uint32_t* sym_uv; uint8_t* orient;
+  const uint32_t* fan_hdr; const uint32_t* fan_apex; const uint32_t* fan;   // fan rows of the table (launch_build_fans)
 };
 void launch_predict_fused(const FusedArgs& a, hipStream_t s);
+// Per coded vertex, in coding order: hdr[n], apex[n], fan[8n] (32-byte aligned) — see k_build_fans.  Once per job.
+void launch_build_fans(const uint32_t* seq, uint32_t n, const uint32_t* c2r, const uint32_t* opp, uint32_t* hdr, uint32_t* apex, uint32_t* fan, hipStream_t s);
 
 // ---- predict + transform (a7-a14) → symbols ------------------------------------------------------
 // c2r[c] = sequence index of corner c's vertex (DMI_NONE if never coded): "already coded" ⇔ c2r[c] < i

@@ -58,6 +58,7 @@ struct SlabView {
 
 struct TableDev {
   uint32_t F = 0, V = 0, n_seq = 0;
+  DevMem fan_hdr, fan_apex, fan;   // fan rows (only for tables with a fused sweep)
   DevMem c2r, opp, seq, s2p;   // c2r = corner → sequence index of its vertex; s2p = sequence index → point (= point_idx(seq[i]))
   std::vector<uint32_t> s2p_host;
   // sharing: a table whose arrays equal another table's reuses its device copies
@@ -384,6 +385,15 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
       a.fused_into = a.parent;
     }
   }
+  for (auto& a : job->atts) {   // fan rows of the tables a fused sweep runs on: the corner table re-laid out per coded vertex
+    if (a.fused_nrm < 0 && a.fused_uv < 0) continue;
+    TableDev& t = job->tables[a.table];
+    if (t.fan.p || t.n_seq == 0) continue;
+    if ((rc = t.fan_hdr.alloc((size_t)t.n_seq * 4))) return rc;
+    if ((rc = t.fan_apex.alloc((size_t)t.n_seq * 4))) return rc;
+    if ((rc = t.fan.alloc((size_t)t.n_seq * 32))) return rc;
+    launch_build_fans(t.seq.as<uint32_t>(), t.n_seq, t.c2r.as<uint32_t>(), t.opp.as<uint32_t>(), t.fan_hdr.as<uint32_t>(), t.fan_apex.as<uint32_t>(), t.fan.as<uint32_t>(), s);
+  }
   uint32_t max_point = 0;
   for (size_t c = 0; c < C; ++c) max_point = std::max(max_point, tables[0].corner_to_point[c]);
   size_t pinned_need = 0;
@@ -549,6 +559,7 @@ static int encode_phase_a(dmi_job* job) {   // device: ranges → coding-order p
       FusedArgs fa{};
       fa.seq = t.seq.as<uint32_t>(); fa.c2r = t.c2r.as<uint32_t>(); fa.opp = t.opp.as<uint32_t>(); fa.n = n;
       fa.qs_pos = a.qs.as<int32_t>(); fa.mm_pos = minmax; fa.sym_pos = a.sym.as<uint32_t>();
+      fa.fan_hdr = t.fan_hdr.as<uint32_t>(); fa.fan_apex = t.fan_apex.as<uint32_t>(); fa.fan = t.fan.as<uint32_t>();
       if (a.fused_nrm >= 0) {
         AttJob& q = job->atts[a.fused_nrm];
         fa.qs_nrm = q.qs.as<int32_t>(); fa.sym_nrm = q.sym.as<uint32_t>(); fa.flips = q.aux.as<uint8_t>(); fa.counters = q.small.as<uint32_t>() + 2;

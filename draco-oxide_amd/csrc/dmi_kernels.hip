@@ -852,6 +852,78 @@ __device__ __forceinline__ void fan_normal_sum(uint32_t c, const uint32_t* __res
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fan rows: the corner table of a seam-free mesh re-laid out per CODED VERTEX, in coding order (built once per job by
+// k_build_fans, like c2r).  Row i = the ranks of the 1-ring of sequence entry i in fan order:
+//   fan[8i+0] = a = rank of next(c), fan[8i+1] = b = rank of prev(c)                (c = seq[i])
+//   then the new vertices met swinging right from c (one per face), then those met swinging left (open fans only);
+//   a closed fan's last right vertex is b itself and is not stored again.
+//   hdr[i] = faces_right | faces_left << 8 | closed << 16 | overflow << 17,   apex[i] = rank across the edge opposite c.
+// The sweep then reads 40 contiguous bytes per entry instead of chasing `opp`/`c2r` (two dependent, two-thirds-empty
+// gathers per fan face), and all its position gathers are independent.  Rows that do not fit (valence > 8) set
+// `overflow` and take the corner-table walk.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kFanSlots = 8;
+__global__ __launch_bounds__(kBlock) void k_build_fans(const uint32_t* __restrict__ seq, uint32_t n, const uint32_t* __restrict__ c2r,
+                                                       const uint32_t* __restrict__ opp, uint32_t* __restrict__ hdr, uint32_t* __restrict__ apex,
+                                                       uint32_t* __restrict__ fan) {
+  DMI_FOR_SEQUENCE(i, n) {
+    const uint32_t c = seq[i];
+    uint32_t row[kFanSlots];
+#pragma unroll
+    for (uint32_t k = 0; k < kFanSlots; ++k) row[k] = kNoneD;
+    row[0] = c2r[cnext(c)];
+    row[1] = c2r[cprev(c)];
+    const uint32_t o = opp[c];
+    apex[i] = (o != kNoneD) ? c2r[o] : kNoneD;
+    uint32_t stored = 2, faces_r = 0, faces_l = 0;
+    bool closed = false, overflow = false;
+    uint32_t pending = kNoneD;   // the right vertex met last; written once it is known not to be the closing one (= b)
+    for (uint32_t cur = c, guard = 0; guard < (1u << 24); ++guard) {
+      const uint32_t o2 = opp[cprev(cur)];
+      if (o2 == kNoneD) break;
+      cur = cprev(o2);
+      if (cur == c) { closed = true; break; }
+      if (pending != kNoneD) {
+        if (stored < kFanSlots) {
+#pragma unroll
+          for (uint32_t k = 2; k < kFanSlots; ++k) if (k == stored) row[k] = pending;
+        } else overflow = true;
+        ++stored;
+      }
+      pending = c2r[o2];
+      ++faces_r;
+    }
+    if (!closed && pending != kNoneD) {   // open fan: the last right vertex is a real ring vertex
+      if (stored < kFanSlots) {
+#pragma unroll
+        for (uint32_t k = 2; k < kFanSlots; ++k) if (k == stored) row[k] = pending;
+      } else overflow = true;
+      ++stored;
+    }
+    if (!closed) {
+      for (uint32_t cur = c, guard = 0; guard < (1u << 24); ++guard) {
+        const uint32_t o2 = opp[cnext(cur)];
+        if (o2 == kNoneD) break;
+        cur = cnext(o2);
+        if (cur == c) break;
+        const uint32_t w = c2r[o2];
+        if (stored < kFanSlots) {
+#pragma unroll
+          for (uint32_t k = 2; k < kFanSlots; ++k) if (k == stored) row[k] = w;
+        } else overflow = true;
+        ++stored;
+        ++faces_l;
+      }
+    }
+    if (faces_r > 255u || faces_l > 255u) overflow = true;
+    hdr[i] = (faces_r & 255u) | ((faces_l & 255u) << 8) | (closed ? 1u << 16 : 0u) | (overflow ? 1u << 17 : 0u);
+    uint4* dst = reinterpret_cast<uint4*>(fan + (size_t)i * kFanSlots);
+    dst[0] = make_uint4(row[0], row[1], row[2], row[3]);
+    dst[1] = make_uint4(row[4], row[5], row[6], row[7]);
+  }
+}
+
 template <bool HAS_NRM, bool HAS_UV>
 __global__ __launch_bounds__(kBlock) void k_predict_fused(FusedArgs a) {
   const uint32_t* __restrict__ seq = a.seq;
@@ -864,14 +936,56 @@ __global__ __launch_bounds__(kBlock) void k_predict_fused(FusedArgs a) {
   if (HAS_UV) wu = wrap_params(a.mm_uv);
   uint32_t n_false = 0;
   DMI_FOR_SEQUENCE(i, n) {
-    const uint32_t c = __builtin_nontemporal_load(&seq[i]), nc = cnext(c), pc = cprev(c);
-    const uint32_t rn = c2r[nc], rp = c2r[pc], o = opp[c];
-    const uint32_t ro = (o != kNoneD) ? c2r[o] : kNoneD;
-    const bool both = rn < i && rp < i;
-    const bool have = both && ro < i;   // (o == NONE ⇒ ro == NONE ⇒ false)
-    int32_t Pc[3], Pn[3], Pp[3], Po[3], Plast[3] = {0, 0, 0};
+    uint32_t rn, rp, ro;
+    int32_t Pc[3], Pn[3] = {0, 0, 0}, Pp[3] = {0, 0, 0}, Po[3], Plast[3] = {0, 0, 0};
+    int64_t sum[3] = {0, 0, 0};
     load3(qs_pos, i, Pc);
-    if (HAS_NRM || both) { load3(qs_pos, rn, Pn); load3(qs_pos, rp, Pp); }
+    const uint32_t h = __builtin_nontemporal_load(&a.fan_hdr[i]);
+    if (!(h & (1u << 17))) {
+      // ---- fan row: every rank of the 1-ring in one 32-byte read, every position gather independent ----
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4* row4 = reinterpret_cast<const u32x4*>(a.fan + (size_t)i * kFanSlots);
+      const u32x4 r0 = __builtin_nontemporal_load(&row4[0]), r1 = __builtin_nontemporal_load(&row4[1]);
+      const uint32_t row[kFanSlots] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+      rn = row[0]; rp = row[1];
+      ro = __builtin_nontemporal_load(&a.fan_apex[i]);
+      const uint32_t faces_r = h & 255u, faces_l = (h >> 8) & 255u;
+      const bool closed = (h >> 16) & 1u;
+      const uint32_t stored_r = (closed && faces_r) ? faces_r - 1u : faces_r;
+      const uint32_t cnt = HAS_NRM ? 2u + stored_r + faces_l : 2u;
+      int32_t P[kFanSlots][3];
+      const bool need_np = HAS_NRM || (rn < i && rp < i);
+#pragma unroll
+      for (uint32_t k = 0; k < kFanSlots; ++k) {
+        if (k < cnt && (k >= 2 || need_np)) load3(qs_pos, row[k], P[k]);
+        else { P[k][0] = 0; P[k][1] = 0; P[k][2] = 0; }
+      }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { Pn[d] = P[0][d]; Pp[d] = P[1][d]; }
+      if (HAS_NRM) {
+        // faces: (next, prev) = (a, b); right of it (w1, a), (w2, w1), …, closing (b, w_last); left of it (b, u1), (u1, u2), …
+        add_face_normal(Pn, Pp, Pc, sum);
+        int32_t R[3] = {Pn[0], Pn[1], Pn[2]}, L[3] = {Pp[0], Pp[1], Pp[2]};
+#pragma unroll
+        for (uint32_t k = 2; k < kFanSlots; ++k) {
+          if (k < cnt) {
+            if (k < 2u + stored_r) { add_face_normal(P[k], R, Pc, sum); R[0] = P[k][0]; R[1] = P[k][1]; R[2] = P[k][2]; }
+            else { add_face_normal(L, P[k], Pc, sum); L[0] = P[k][0]; L[1] = P[k][1]; L[2] = P[k][2]; }
+          }
+        }
+        if (closed && faces_r) add_face_normal(Pp, R, Pc, sum);
+      }
+    } else {
+      // ---- row overflow (valence > 8): walk the corner table ----
+      const uint32_t c = seq[i], nc = cnext(c), pc = cprev(c);
+      rn = c2r[nc]; rp = c2r[pc];
+      const uint32_t o = opp[c];
+      ro = (o != kNoneD) ? c2r[o] : kNoneD;
+      if (HAS_NRM || (rn < i && rp < i)) { load3(qs_pos, rn, Pn); load3(qs_pos, rp, Pp); }
+      if (HAS_NRM) fan_normal_sum(c, opp, c2r, qs_pos, Pc, Pn, Pp, sum);
+    }
+    const bool both = rn < i && rp < i;
+    const bool have = both && ro < i;   // (no opposite corner ⇒ ro == NONE ⇒ false)
     if (have) load3(qs_pos, ro, Po);
     else if (i > 0) load3(qs_pos, i - 1u, Plast);
     // ---- positions: mesh_parallelogram_prediction.rs:186-237 + wrapped difference ----
@@ -907,8 +1021,6 @@ __global__ __launch_bounds__(kBlock) void k_predict_fused(FusedArgs a) {
     if (HAS_NRM) {
       // Fan sum of cross(pos[next] - pos_c, pos[prev] - pos_c).  Swinging right from a face (next = A, prev = B) lands in
       // the face (next = new vertex, prev = A); swinging left lands in (next = B, prev = new vertex).
-      int64_t sum[3] = {0, 0, 0};
-      fan_normal_sum(c, opp, c2r, qs_pos, Pc, Pn, Pp, sum);
       int64_t sum0 = sum[0], sum1 = sum[1], sum2 = sum[2];
       const int64_t upper = 1ll << 29;
       const int64_t abs_sum = wadd64(wadd64(wabs64(sum0), wabs64(sum1)), wabs64(sum2));
@@ -1074,6 +1186,10 @@ void launch_pred_normal_octorth(const uint32_t* seq, uint32_t n, const uint32_t*
 void launch_pred_texcoord_wrapped(const uint32_t* seq, uint32_t n, const uint32_t* c2r, const int32_t* qs, const uint32_t* c2r_pos,
                                   const int32_t* qs_pos, const int32_t* minmax, uint32_t* sym, uint8_t* orient, hipStream_t s) {
   hipLaunchKernelGGL(k_pred_texcoord_wrapped, grid_for(((uint64_t)n + kTexTile - 1) / kTexTile), kBlock, 0, s, seq, n, c2r, qs, c2r_pos, qs_pos, minmax, sym, orient);
+}
+
+void launch_build_fans(const uint32_t* seq, uint32_t n, const uint32_t* c2r, const uint32_t* opp, uint32_t* hdr, uint32_t* apex, uint32_t* fan, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_build_fans, grid_for(n, 8192), kBlock, 0, s, seq, n, c2r, opp, hdr, apex, fan);
 }
 
 void launch_predict_fused(const FusedArgs& a, hipStream_t s) {
