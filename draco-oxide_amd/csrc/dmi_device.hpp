@@ -29,12 +29,10 @@ constexpr int kMaxGather = 4;
 struct QuantAtt { const float* raw; const uint32_t* s2v; int32_t* qs; int32_t* ipartials; const float* meta; float maxq; int kind; int N; int pad; };
 struct QuantArgs { QuantAtt a[kMaxGather]; int count; };
 void launch_seq_quantize(const uint32_t* s2p, uint32_t n, const QuantArgs& args, hipStream_t s);
-// fn[3f..3f+2] = cross(pos[c1]-pos[c0], pos[c2]-pos[c0]) of the quantised positions of face f (i32, wrapping);
-// c2r_pos / qs_pos: the position attribute's corner→sequence-index table and sequence-ordered values
-void launch_face_normals(const uint32_t* c2r_pos, uint32_t nfaces, const int32_t* qs_pos, int32_t* fn, hipStream_t s);
 
-// Seam-free fast path: position (parallelogram, 3 components) + normal and/or texture coordinates coded on the SAME
-// corner table in one sweep (see k_predict_fused).  qs_nrm / qs_uv null = attribute absent (at least one is set).
+// Fan-row sweep (see k_predict_fused).  Seam-free fast path: position (parallelogram, 3 components) + normal and/or texture
+// coordinates coded on the SAME corner table in one sweep; qs_nrm / qs_uv null = attribute absent.  sym_pos null = a normal
+// attribute alone on its own table (c2r = the position table's array, fan rows built with centre_in_apex).
 struct FusedArgs {
   const uint32_t* seq; const uint32_t* c2r; const uint32_t* opp; uint32_t n; uint32_t pad;
   const int32_t* qs_pos; const int32_t* mm_pos; uint32_t* sym_pos;
@@ -44,16 +42,16 @@ struct FusedArgs {
 };
 void launch_predict_fused(const FusedArgs& a, hipStream_t s);
 // Per coded vertex, in coding order: hdr[n], apex[n], fan[8n] (32-byte aligned) — see k_build_fans.  Once per job.
-void launch_build_fans(const uint32_t* seq, uint32_t n, const uint32_t* c2r, const uint32_t* opp, uint32_t* hdr, uint32_t* apex, uint32_t* fan, hipStream_t s);
+// centre_in_apex: apex[i] = c2r[seq[i]] (the fan centre's rank) instead of the rank across the opposite edge — for a normal
+// attribute swept on its own table (c2r = the position table's, opp/seq = the normal table's).
+void launch_build_fans(const uint32_t* seq, uint32_t n, const uint32_t* c2r, const uint32_t* opp, uint32_t* hdr, uint32_t* apex, uint32_t* fan, bool centre_in_apex,
+                       hipStream_t s);
 
 // ---- predict + transform (a7-a14) → symbols ------------------------------------------------------
 // c2r[c] = sequence index of corner c's vertex (DMI_NONE if never coded): "already coded" ⇔ c2r[c] < i
 void launch_pred_parallelogram_wrapped(const uint32_t* seq, uint32_t n, const uint32_t* c2r, const uint32_t* opp,
                                        const int32_t* qs, const int32_t* minmax, int N, uint32_t* sym, hipStream_t s);
 void launch_pred_delta_difference(uint32_t n, const int32_t* qs, int N, uint32_t* sym, hipStream_t s);
-// counters[0] += number of flips that are false
-void launch_pred_normal_octorth(const uint32_t* seq, uint32_t n, const uint32_t* opp_att, const int32_t* fn, const int32_t* qs, uint32_t* sym,
-                                uint8_t* flips, uint32_t* counters, hipStream_t s);
 // orient[i]: 0 = no bit pushed, 1 = false, 2 = true
 void launch_pred_texcoord_wrapped(const uint32_t* seq, uint32_t n, const uint32_t* c2r, const int32_t* qs, const uint32_t* c2r_pos,
                                   const int32_t* qs_pos, const int32_t* minmax, uint32_t* sym, uint8_t* orient, hipStream_t s);

@@ -78,7 +78,7 @@ struct AttJob {
   int parent = -1;
   int fused_into = -1;   // ≥ 0: predicted by the fused seam-free sweep launched for that position attribute
   int fused_nrm = -1, fused_uv = -1;   // (on a position attribute) the attributes its fused sweep also predicts
-  DevMem raw, s2v /*sequence index → value index, only with a point_to_value map*/, fn, qs, sym, aux /*flips or orient*/, rtable, rec, out, partials, ipartials;
+  DevMem raw, s2v /*sequence index → value index, only with a point_to_value map*/, qs, sym, aux /*flips or orient*/, rtable, rec, out, partials, ipartials;
   // views into dmi_job::slab — one memset, one read-back per encode: small = 16 scratch words (minmax[2], counters[2], flags[2], …,
   // out_len[2]*2, ticks[2]), meta = quantization ranges, hist = symbol histogram (bins_cap words), summary = orientation chunk summaries
   SlabView small, meta, hist, summary;
@@ -88,6 +88,7 @@ struct AttJob {
   uint64_t n_sym = 0;
   uint64_t out_cap = 0, aux_cap = 0;
   DevMem aux_out, aux_rec, chunk_info, batch_flags, aux_flags;
+  DevMem fan_hdr, fan_apex, fan;   // fan rows of a normal attribute swept on its own table (position ranks, centre in apex)
   FreqTable ft;
   std::vector<RansEntry> rt_host;     // staging (kept alive until the copies have been issued)
   std::vector<uint32_t> info_host;
@@ -392,7 +393,7 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
     if ((rc = t.fan_hdr.alloc((size_t)t.n_seq * 4))) return rc;
     if ((rc = t.fan_apex.alloc((size_t)t.n_seq * 4))) return rc;
     if ((rc = t.fan.alloc((size_t)t.n_seq * 32))) return rc;
-    launch_build_fans(t.seq.as<uint32_t>(), t.n_seq, t.c2r.as<uint32_t>(), t.opp.as<uint32_t>(), t.fan_hdr.as<uint32_t>(), t.fan_apex.as<uint32_t>(), t.fan.as<uint32_t>(), s);
+    launch_build_fans(t.seq.as<uint32_t>(), t.n_seq, t.c2r.as<uint32_t>(), t.opp.as<uint32_t>(), t.fan_hdr.as<uint32_t>(), t.fan_apex.as<uint32_t>(), t.fan.as<uint32_t>(), false, s);
   }
   uint32_t max_point = 0;
   for (size_t c = 0; c < C; ++c) max_point = std::max(max_point, tables[0].corner_to_point[c]);
@@ -432,7 +433,13 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
       HIP_TRY(hipMemsetAsync(a.aux_flags.p, 0, a.aux_flags.bytes, s));
       if ((rc = a.chunk_info.alloc((size_t)std::max(1u, orient_summary_blocks(n)) * 8))) return rc;
     }
-    if (a.scheme == kNormal && a.fused_into < 0) { if ((rc = a.fn.alloc((size_t)F * 3 * 4))) return rc; }
+    if (a.scheme == kNormal && a.fused_into < 0 && n) {   // fan rows: this table's fans, ranks in the parent position table
+      const TableDev& pt = job->tables[job->atts[a.parent].table];
+      if ((rc = a.fan_hdr.alloc((size_t)n * 4))) return rc;
+      if ((rc = a.fan_apex.alloc((size_t)n * 4))) return rc;
+      if ((rc = a.fan.alloc((size_t)n * 32))) return rc;
+      launch_build_fans(t.seq.as<uint32_t>(), n, pt.c2r.as<uint32_t>(), t.opp.as<uint32_t>(), a.fan_hdr.as<uint32_t>(), a.fan_apex.as<uint32_t>(), a.fan.as<uint32_t>(), true, s);
+    }
     a.bins = symbol_bins(a);
     if (a.port == kToBits) a.bins = 1u << 20;   // capacity; the real bound is checked after the min/max readback
     a.bins_cap = a.bins;
@@ -580,9 +587,14 @@ static int encode_phase_a(dmi_job* job) {   // device: ranges → coding-order p
         launch_pred_delta_difference(n, a.qs.as<int32_t>(), a.nq, a.sym.as<uint32_t>(), s);
         break;
       case kNormal: {
+        // the fan-row sweep with only the normal attribute: fans of this (attribute) table, positions through the parent's table
         const AttJob& p = job->atts[a.parent];
-        launch_face_normals(job->tables[p.table].c2r.as<uint32_t>(), t.F, p.qs.as<int32_t>(), a.fn.as<int32_t>(), s);
-        launch_pred_normal_octorth(t.seq.as<uint32_t>(), n, t.opp.as<uint32_t>(), a.fn.as<int32_t>(), a.qs.as<int32_t>(), a.sym.as<uint32_t>(), a.aux.as<uint8_t>(), counters, s);
+        FusedArgs fa{};
+        fa.seq = t.seq.as<uint32_t>(); fa.c2r = job->tables[p.table].c2r.as<uint32_t>(); fa.opp = t.opp.as<uint32_t>(); fa.n = n;
+        fa.qs_pos = p.qs.as<int32_t>();
+        fa.qs_nrm = a.qs.as<int32_t>(); fa.sym_nrm = a.sym.as<uint32_t>(); fa.flips = a.aux.as<uint8_t>(); fa.counters = counters;
+        fa.fan_hdr = a.fan_hdr.as<uint32_t>(); fa.fan_apex = a.fan_apex.as<uint32_t>(); fa.fan = a.fan.as<uint32_t>();
+        launch_predict_fused(fa, s);
         break;
       }
       case kTexCoord: {

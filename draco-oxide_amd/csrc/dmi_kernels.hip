@@ -3,14 +3,17 @@
 // -ffp-contract=off so every f32 operation rounds separately like the Rust reference.
 //
 // Reference arithmetic each kernel reproduces (paths relative to draco-oxide/src/):
-//   k_minmax_f32 / k_minmax_final      encode/attribute/portabilization/quantization_coordinate_wise.rs:24-68
-//   k_quant_coord                      ...quantization_coordinate_wise.rs:70-91
-//   k_quant_oct                        ...octahedral_quantization.rs:49-64, prediction_transform/geom.rs:40-91,137-157
-//   k_seq_gather                       attribute_encoder.rs:332-338 (sequence order), wrapped_difference.rs:36-52 (min/max)
-//   k_pred_parallelogram_wrapped       shared/attribute/prediction_scheme/mesh_parallelogram_prediction.rs:186-237 + wrapped_difference.rs:54-99
+//   k_value_ranges / _final            encode/attribute/portabilization/quantization_coordinate_wise.rs:24-68; prediction_transform/geom.rs:45
+//   k_seq_quantize                     ...quantization_coordinate_wise.rs:70-91; octahedral_quantization.rs:49-64 + geom.rs:40-91,137-157;
+//                                      to_bits.rs:41-49; attribute_encoder.rs:332-338 (sequence order); wrapped_difference.rs:36-52 (min/max)
+//   k_build_fans                       (layout) core/corner_table/mod.rs swing_left/right around every coded vertex, once per job
+//   k_predict_fused<pos,nrm,uv>        shared/attribute/prediction_scheme/mesh_parallelogram_prediction.rs:186-237 + wrapped_difference.rs:54-99,
+//                                      .../mesh_normal_prediction.rs:22-44,75-144 + prediction_transform/oct_orthogonal.rs:23-85,
+//                                      .../mesh_prediction_for_texture_coordinates.rs:32-81,107-219
+//   k_pred_parallelogram_wrapped       the parallelogram predictor alone (custom attributes, attributes on seam tables)
+//   k_pred_texcoord_wrapped            the texture-coordinate predictor alone (UV seams)
 //   k_pred_delta_difference            .../delta_prediction.rs:56-71 + prediction_transform/difference.rs:26-34
-//   k_pred_normal_octorth              .../mesh_normal_prediction.rs:22-44,75-144 + prediction_transform/oct_orthogonal.rs:23-85
-//   k_pred_texcoord_wrapped            .../mesh_prediction_for_texture_coordinates.rs:32-81,107-219 + wrapped_difference.rs
+//   k_orient_summary                   mesh_prediction_for_texture_coordinates.rs:224-235 (bit / transition counts)
 //   k_histogram                        encode/entropy/symbol_coding.rs:149-157
 //   (the serial rANS/rABS coders live in dmi_chains.hip)
 #include "dmi_device.hpp"
@@ -345,48 +348,6 @@ __global__ __launch_bounds__(kBlock) void k_i32_minmax_final(MinMaxArgs args) {
   }
 }
 
-// Per-face normal of the quantised positions (i32 cross product, wrapping).  For every corner cc of face f
-//   cross(pos[next(cc)] - pos[cc], pos[prev(cc)] - pos[cc])
-// is the same vector (cyclic invariance holds in the ring Z/2^32), and every corner of a vertex fan sits at
-// the fan vertex's position, so mesh_normal_prediction.rs:22-44 evaluates exactly fn[face(cc)] per fan face.
-__global__ __launch_bounds__(kBlock) void k_face_normals(const uint32_t* __restrict__ c2r_pos, uint32_t nfaces, const int32_t* __restrict__ qs_pos,
-                                                         int32_t* __restrict__ fn) {
-  DMI_FOR_TILES(base, nfaces, kTile) {
-    // position of a corner = qs_pos[sequence index of its vertex in the position attribute's table]
-    uint32_t r[kTile][3];
-    int32_t p[kTile][3][3];
-#pragma unroll
-    for (int t = 0; t < kTile; ++t) {
-      const uint32_t f = min(base + t * kBlock + threadIdx.x, nfaces - 1u);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) r[t][k] = c2r_pos[(size_t)3 * f + k];
-    }
-#pragma unroll
-    for (int t = 0; t < kTile; ++t) {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const size_t at = (size_t)(r[t][k] != kNoneD ? r[t][k] : 0u) * 3;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) p[t][k][d] = qs_pos[at + d];
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < kTile; ++t) {
-      const uint32_t f = base + t * kBlock + threadIdx.x;
-      if (f >= nfaces) continue;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        if (r[t][k] == kNoneD) { p[t][k][0] = 0; p[t][k][1] = 0; p[t][k][2] = 0; }
-      }
-      const int32_t ax = wsub(p[t][1][0], p[t][0][0]), ay = wsub(p[t][1][1], p[t][0][1]), az = wsub(p[t][1][2], p[t][0][2]);
-      const int32_t bx = wsub(p[t][2][0], p[t][0][0]), by = wsub(p[t][2][1], p[t][0][1]), bz = wsub(p[t][2][2], p[t][0][2]);
-      fn[(size_t)3 * f] = wsub(wmul(ay, bz), wmul(az, by));
-      fn[(size_t)3 * f + 1] = wsub(wmul(az, bx), wmul(ax, bz));
-      fn[(size_t)3 * f + 2] = wsub(wmul(ax, by), wmul(ay, bx));
-    }
-  }
-}
-
 // WrappedDifference::squeeze parameters from the joint min/max (wrapped_difference.rs:62-69, Q16)
 struct WrapParams { int32_t mn, mx, max_diff, max_corr, min_corr; };
 __device__ __forceinline__ WrapParams wrap_params(const int32_t* minmax) {
@@ -468,73 +429,6 @@ __device__ __forceinline__ void oct_orthogonal(int32_t o0, int32_t o1, int32_t p
   if (c0 < 0) c0 = wadd(c0, 255);
   if (c1 < 0) c1 = wadd(c1, 255);
   s0 = (uint32_t)c0; s1 = (uint32_t)c1;
-}
-
-__global__ __launch_bounds__(kBlock) void k_pred_normal_octorth(const uint32_t* __restrict__ seq, uint32_t n, const uint32_t* __restrict__ opp,
-                                                                const int32_t* __restrict__ fn, const int32_t* __restrict__ qs,
-                                                                uint32_t* __restrict__ sym, uint8_t* __restrict__ flips, uint32_t* __restrict__ counters) {
-  uint32_t n_false = 0;
-  DMI_FOR_SEQUENCE(i, n) {
-    const uint32_t c = seq[i];
-    // Sum of the face normals over the vertex fan (i32 terms, i64 wrapping sum: order-independent).  The
-    // reference swings left to the fan start and then right; the same set of faces is reached by swinging
-    // right from c and, if the fan is open, left from c.
-    int64_t sum0, sum1, sum2;
-    {
-      const uint32_t f = c / 3u;
-      sum0 = fn[(size_t)3 * f]; sum1 = fn[(size_t)3 * f + 1]; sum2 = fn[(size_t)3 * f + 2];
-    }
-    bool open = false;
-    for (uint32_t cur = c;;) {
-      const uint32_t o = opp[cprev(cur)];
-      if (o == kNoneD) { open = true; break; }
-      cur = cprev(o);
-      if (cur == c) break;
-      const uint32_t f = cur / 3u;
-      sum0 = wadd64(sum0, (int64_t)fn[(size_t)3 * f]); sum1 = wadd64(sum1, (int64_t)fn[(size_t)3 * f + 1]); sum2 = wadd64(sum2, (int64_t)fn[(size_t)3 * f + 2]);
-    }
-    if (open) {
-      for (uint32_t cur = c;;) {
-        const uint32_t o = opp[cnext(cur)];
-        if (o == kNoneD) break;
-        cur = cnext(o);
-        if (cur == c) break;
-        const uint32_t f = cur / 3u;
-        sum0 = wadd64(sum0, (int64_t)fn[(size_t)3 * f]); sum1 = wadd64(sum1, (int64_t)fn[(size_t)3 * f + 1]); sum2 = wadd64(sum2, (int64_t)fn[(size_t)3 * f + 2]);
-      }
-    }
-    const int64_t upper = 1ll << 29;
-    const int64_t abs_sum = wadd64(wadd64(wabs64(sum0), wabs64(sum1)), wabs64(sum2));
-    if (abs_sum > upper) {
-      const int64_t quot = abs_sum / upper;
-      sum0 = wdiv64(sum0, quot); sum1 = wdiv64(sum1, quot); sum2 = wdiv64(sum2, quot);
-    }
-    const int32_t n0 = (int32_t)sum0, n1 = (int32_t)sum1, n2 = (int32_t)sum2;
-    int32_t p0 = 0, p1 = 0;
-    if (!(n0 == 0 && n1 == 0 && n2 == 0)) oct_quantize((float)n0, (float)n1, (float)n2, p0, p1);
-    const int32_t a0 = qs[(size_t)i * 2], a1 = qs[(size_t)i * 2 + 1];
-    const int32_t m0 = wmul(p0, -1), m1 = wmul(p1, -1);
-    const int32_t d10 = wsub(p0, a0), d11 = wsub(p1, a1), d20 = wsub(m0, a0), d21 = wsub(m1, a1);
-    const int32_t dot1 = wadd(wmul(d10, d10), wmul(d11, d11)), dot2 = wadd(wmul(d20, d20), wmul(d21, d21));
-    const bool flip = dot1 > dot2;   // Q8: flip negates the octahedral coordinates
-    if (flip) { p0 = m0; p1 = m1; } else ++n_false;
-    flips[i] = flip ? 1 : 0;
-    uint32_t s0, s1;
-    oct_orthogonal(a0, a1, p0, p1, s0, s1);
-    sym[(size_t)i * 2] = s0;
-    sym[(size_t)i * 2 + 1] = s1;
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) n_false += __shfl_down(n_false, off, 64);
-  __shared__ uint32_t wave_false[kBlock / 64];
-  if ((threadIdx.x & 63) == 0) wave_false[threadIdx.x >> 6] = n_false;
-  __syncthreads();
-  if (threadIdx.x == 0) {   // one atomic per block (same-address atomics serialise)
-    uint32_t t = 0;
-#pragma unroll
-    for (int w = 0; w < kBlock / 64; ++w) t += wave_false[w];
-    if (t) atomicAdd(&counters[0], t);
-  }
 }
 
 // Exact i64 `a / d` (truncating) for the texture-coordinate predictor.  The software 64-bit divide costs ~100
@@ -866,7 +760,7 @@ __device__ __forceinline__ void fan_normal_sum(uint32_t c, const uint32_t* __res
 constexpr uint32_t kFanSlots = 8;
 __global__ __launch_bounds__(kBlock) void k_build_fans(const uint32_t* __restrict__ seq, uint32_t n, const uint32_t* __restrict__ c2r,
                                                        const uint32_t* __restrict__ opp, uint32_t* __restrict__ hdr, uint32_t* __restrict__ apex,
-                                                       uint32_t* __restrict__ fan) {
+                                                       uint32_t* __restrict__ fan, int centre_in_apex) {
   DMI_FOR_SEQUENCE(i, n) {
     const uint32_t c = seq[i];
     uint32_t row[kFanSlots];
@@ -875,7 +769,7 @@ __global__ __launch_bounds__(kBlock) void k_build_fans(const uint32_t* __restric
     row[0] = c2r[cnext(c)];
     row[1] = c2r[cprev(c)];
     const uint32_t o = opp[c];
-    apex[i] = (o != kNoneD) ? c2r[o] : kNoneD;
+    apex[i] = centre_in_apex ? c2r[c] : ((o != kNoneD) ? c2r[o] : kNoneD);
     uint32_t stored = 2, faces_r = 0, faces_l = 0;
     bool closed = false, overflow = false;
     uint32_t pending = kNoneD;   // the right vertex met last; written once it is known not to be the closing one (= b)
@@ -924,23 +818,26 @@ __global__ __launch_bounds__(kBlock) void k_build_fans(const uint32_t* __restric
   }
 }
 
-template <bool HAS_NRM, bool HAS_UV>
+// HAS_POS = false: the normal attribute alone, on its own (seam) table — `c2r` is then the POSITION table's corner →
+// rank array (fan rows hold position ranks), `opp` the normal table's, and apex[i] is the rank of the fan's centre.
+template <bool HAS_POS, bool HAS_NRM, bool HAS_UV>
 __global__ __launch_bounds__(kBlock) void k_predict_fused(FusedArgs a) {
   const uint32_t* __restrict__ seq = a.seq;
   const uint32_t* __restrict__ c2r = a.c2r;
   const uint32_t* __restrict__ opp = a.opp;
   const int32_t* __restrict__ qs_pos = a.qs_pos;
   const uint32_t n = a.n;
-  const WrapParams wp = wrap_params(a.mm_pos);
-  WrapParams wu = wp;
+  WrapParams wp{}, wu{};
+  if (HAS_POS) wp = wrap_params(a.mm_pos);
   if (HAS_UV) wu = wrap_params(a.mm_uv);
   uint32_t n_false = 0;
   DMI_FOR_SEQUENCE(i, n) {
     uint32_t rn, rp, ro;
-    int32_t Pc[3], Pn[3] = {0, 0, 0}, Pp[3] = {0, 0, 0}, Po[3], Plast[3] = {0, 0, 0};
+    int32_t Pc[3], Pn[3] = {0, 0, 0}, Pp[3] = {0, 0, 0}, Po[3] = {0, 0, 0}, Plast[3] = {0, 0, 0};
     int64_t sum[3] = {0, 0, 0};
-    load3(qs_pos, i, Pc);
     const uint32_t h = __builtin_nontemporal_load(&a.fan_hdr[i]);
+    ro = __builtin_nontemporal_load(&a.fan_apex[i]);   // HAS_POS: rank across the edge opposite c; else: rank of the centre
+    load3(qs_pos, HAS_POS ? i : ro, Pc);
     if (!(h & (1u << 17))) {
       // ---- fan row: every rank of the 1-ring in one 32-byte read, every position gather independent ----
       typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -948,13 +845,12 @@ __global__ __launch_bounds__(kBlock) void k_predict_fused(FusedArgs a) {
       const u32x4 r0 = __builtin_nontemporal_load(&row4[0]), r1 = __builtin_nontemporal_load(&row4[1]);
       const uint32_t row[kFanSlots] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
       rn = row[0]; rp = row[1];
-      ro = __builtin_nontemporal_load(&a.fan_apex[i]);
       const uint32_t faces_r = h & 255u, faces_l = (h >> 8) & 255u;
       const bool closed = (h >> 16) & 1u;
       const uint32_t stored_r = (closed && faces_r) ? faces_r - 1u : faces_r;
       const uint32_t cnt = HAS_NRM ? 2u + stored_r + faces_l : 2u;
       int32_t P[kFanSlots][3];
-      const bool need_np = HAS_NRM || (rn < i && rp < i);
+      const bool need_np = HAS_NRM || (HAS_POS && rn < i && rp < i);
 #pragma unroll
       for (uint32_t k = 0; k < kFanSlots; ++k) {
         if (k < cnt && (k >= 2 || need_np)) load3(qs_pos, row[k], P[k]);
@@ -979,20 +875,20 @@ __global__ __launch_bounds__(kBlock) void k_predict_fused(FusedArgs a) {
       // ---- row overflow (valence > 8): walk the corner table ----
       const uint32_t c = seq[i], nc = cnext(c), pc = cprev(c);
       rn = c2r[nc]; rp = c2r[pc];
-      const uint32_t o = opp[c];
-      ro = (o != kNoneD) ? c2r[o] : kNoneD;
-      if (HAS_NRM || (rn < i && rp < i)) { load3(qs_pos, rn, Pn); load3(qs_pos, rp, Pp); }
+      if (HAS_NRM || (HAS_POS && rn < i && rp < i)) { load3(qs_pos, rn, Pn); load3(qs_pos, rp, Pp); }
       if (HAS_NRM) fan_normal_sum(c, opp, c2r, qs_pos, Pc, Pn, Pp, sum);
     }
-    const bool both = rn < i && rp < i;
-    const bool have = both && ro < i;   // (no opposite corner ⇒ ro == NONE ⇒ false)
-    if (have) load3(qs_pos, ro, Po);
-    else if (i > 0) load3(qs_pos, i - 1u, Plast);
-    // ---- positions: mesh_parallelogram_prediction.rs:186-237 + wrapped difference ----
+    const bool both = HAS_POS && rn < i && rp < i;
+    if (HAS_POS) {
+      // ---- positions: mesh_parallelogram_prediction.rs:186-237 + wrapped difference ----
+      const bool have = both && ro < i;   // (no opposite corner ⇒ ro == NONE ⇒ false)
+      if (have) load3(qs_pos, ro, Po);
+      else if (i > 0) load3(qs_pos, i - 1u, Plast);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int32_t pred = have ? wsub(wadd(Pn[k], Pp[k]), Po[k]) : Plast[k];   // Q15: previously coded vertex, 0 for the first entry
-      __builtin_nontemporal_store(wrap_symbol(Pc[k], pred, wp), &a.sym_pos[(size_t)i * 3 + k]);
+      for (int k = 0; k < 3; ++k) {
+        const int32_t pred = have ? wsub(wadd(Pn[k], Pp[k]), Po[k]) : Plast[k];   // Q15: previously coded vertex, 0 for the first entry
+        __builtin_nontemporal_store(wrap_symbol(Pc[k], pred, wp), &a.sym_pos[(size_t)i * 3 + k]);
+      }
     }
     // ---- texture coordinates: mesh_prediction_for_texture_coordinates.rs:51-81,107-219 ----
     if (HAS_UV) {
@@ -1158,10 +1054,6 @@ void launch_seq_quantize(const uint32_t* s2p, uint32_t n, const QuantArgs& args,
   hipLaunchKernelGGL(k_seq_quantize, seq_quantize_blocks(n), kBlock, 0, s, s2p, n, args);
 }
 
-void launch_face_normals(const uint32_t* c2r_pos, uint32_t nfaces, const int32_t* qs_pos, int32_t* fn, hipStream_t s) {
-  if (nfaces) hipLaunchKernelGGL(k_face_normals, tiles_grid(nfaces), kBlock, 0, s, c2r_pos, nfaces, qs_pos, fn);
-}
-
 void launch_pred_parallelogram_wrapped(const uint32_t* seq, uint32_t n, const uint32_t* c2r, const uint32_t* opp,
                                        const int32_t* qs, const int32_t* minmax, int N, uint32_t* sym, hipStream_t s) {
   const uint32_t g = grid_for(n);
@@ -1178,27 +1070,24 @@ void launch_pred_delta_difference(uint32_t n, const int32_t* qs, int N, uint32_t
   hipLaunchKernelGGL(k_pred_delta_difference, grid_for(nc), kBlock, 0, s, nc, N, qs, sym);
 }
 
-void launch_pred_normal_octorth(const uint32_t* seq, uint32_t n, const uint32_t* opp_att, const int32_t* fn, const int32_t* qs, uint32_t* sym,
-                                uint8_t* flips, uint32_t* counters, hipStream_t s) {
-  hipLaunchKernelGGL(k_pred_normal_octorth, grid_for(n), kBlock, 0, s, seq, n, opp_att, fn, qs, sym, flips, counters);
-}
-
 void launch_pred_texcoord_wrapped(const uint32_t* seq, uint32_t n, const uint32_t* c2r, const int32_t* qs, const uint32_t* c2r_pos,
                                   const int32_t* qs_pos, const int32_t* minmax, uint32_t* sym, uint8_t* orient, hipStream_t s) {
   hipLaunchKernelGGL(k_pred_texcoord_wrapped, grid_for(((uint64_t)n + kTexTile - 1) / kTexTile), kBlock, 0, s, seq, n, c2r, qs, c2r_pos, qs_pos, minmax, sym, orient);
 }
 
-void launch_build_fans(const uint32_t* seq, uint32_t n, const uint32_t* c2r, const uint32_t* opp, uint32_t* hdr, uint32_t* apex, uint32_t* fan, hipStream_t s) {
-  if (n) hipLaunchKernelGGL(k_build_fans, grid_for(n, 8192), kBlock, 0, s, seq, n, c2r, opp, hdr, apex, fan);
+void launch_build_fans(const uint32_t* seq, uint32_t n, const uint32_t* c2r, const uint32_t* opp, uint32_t* hdr, uint32_t* apex, uint32_t* fan, bool centre_in_apex,
+                       hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_build_fans, grid_for(n, 8192), kBlock, 0, s, seq, n, c2r, opp, hdr, apex, fan, centre_in_apex ? 1 : 0);
 }
 
 void launch_predict_fused(const FusedArgs& a, hipStream_t s) {
   if (a.n == 0) return;
   static const uint32_t env_cap = std::getenv("DMI_FUSED_GRID") ? (uint32_t)std::atoi(std::getenv("DMI_FUSED_GRID")) : 0u;   // tuning aid
   const uint32_t g = grid_for(a.n, env_cap ? env_cap : 8192u);   // 2-3 chunks per block: measured best on the 10M workload (2048: +5 %)
-  if (a.qs_nrm && a.qs_uv) hipLaunchKernelGGL((k_predict_fused<true, true>), g, kBlock, 0, s, a);
-  else if (a.qs_nrm) hipLaunchKernelGGL((k_predict_fused<true, false>), g, kBlock, 0, s, a);
-  else hipLaunchKernelGGL((k_predict_fused<false, true>), g, kBlock, 0, s, a);
+  if (!a.sym_pos) hipLaunchKernelGGL((k_predict_fused<false, true, false>), g, kBlock, 0, s, a);   // a normal attribute on its own table
+  else if (a.qs_nrm && a.qs_uv) hipLaunchKernelGGL((k_predict_fused<true, true, true>), g, kBlock, 0, s, a);
+  else if (a.qs_nrm) hipLaunchKernelGGL((k_predict_fused<true, true, false>), g, kBlock, 0, s, a);
+  else hipLaunchKernelGGL((k_predict_fused<true, false, true>), g, kBlock, 0, s, a);
 }
 
 uint32_t orient_summary_blocks(uint32_t n) { return (n + kOrientChunk - 1) / kOrientChunk; }
