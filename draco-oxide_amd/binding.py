@@ -19,7 +19,7 @@ POS_SCHEME_DELTA = 0xD0
 NONE = 0xFFFFFFFF
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_PKG, "libdraco_mi.so")
+_LIB = os.environ.get("DMI_LIBRARY") or os.path.join(_PKG, "libdraco_mi.so")   # DMI_LIBRARY: A/B runs against another in-tree build
 _lib = None
 
 

@@ -282,6 +282,41 @@ def test_high_valence_fan_and_disjoint_components():
     _assert_same(dmi.encode_mesh(mesh), want, "cone + grid")
 
 
+def _cones(valence, closed_surface, missing_wedge, seed):
+    """Two apexes over a ring of `valence` vertices (closed surface: ring vertices have valence 4, apexes `valence`), or a
+    single cone (apex fan closed, ring vertices on the boundary), optionally with one wedge removed (open apex fan)."""
+    rng = np.random.default_rng(seed)
+    k = valence
+    ang = np.linspace(0, 2 * np.pi, k, endpoint=False)
+    ring = np.stack([np.cos(ang), np.sin(ang), 0.05 * rng.normal(size=k)], axis=1)
+    pos = [[0, 0, 1.0]] + ring.tolist()
+    faces = [[0, 1 + i, 1 + (i + 1) % k] for i in range(k)]
+    if missing_wedge:
+        faces = faces[:-1]
+    if closed_surface:
+        pos.append([0, 0, -1.0])
+        b = len(pos) - 1
+        faces += [[b, 1 + (i + 1) % k, 1 + i] for i in range(k)]
+    pos = np.asarray(pos, np.float32) + rng.uniform(-1e-3, 1e-3, size=(len(pos), 3)).astype(np.float32)
+    nrm = (pos / np.linalg.norm(pos, axis=1, keepdims=True)).astype(np.float32)
+    uv = (pos[:, :2] * 0.4 + 0.5 + rng.uniform(-1e-3, 1e-3, size=(len(pos), 2))).astype(np.float32)
+    return dmi.Mesh(np.asarray(faces, np.uint32), [dmi.Attribute(pos, dmi.ATT_POSITION), dmi.Attribute(nrm, dmi.ATT_NORMAL, dmi.DOMAIN_CORNER, 1, 0),
+                                                     dmi.Attribute(uv, dmi.ATT_TEXCOORD, dmi.DOMAIN_CORNER, 2, 0)])
+
+
+@pytest.mark.parametrize("valence", [3, 4, 6, 7, 8, 9, 10, 13])
+def test_fan_rows_around_their_capacity(valence, monkeypatch):
+    """Fan rows hold 8 ranks: closed fans up to valence 8 and open fans up to 6 extra faces fit, larger ones take the
+    corner-table walk.  Closed and open fans on both sides of the limit, fused and per-attribute kernels."""
+    for closed_surface, wedge in ((True, False), (False, False), (False, True), (True, True)):
+        mesh = _cones(valence, closed_surface, wedge, seed=valence * 7 + closed_surface * 2 + wedge)
+        want = oracle_from_product_mesh(mesh).encode()
+        _assert_same(dmi.encode_mesh(mesh), want, f"cones v={valence} closed={closed_surface} wedge={wedge}")
+        monkeypatch.setenv("DMI_NO_FUSED", "1")
+        _assert_same(dmi.encode_mesh(mesh), want, f"cones v={valence} closed={closed_surface} wedge={wedge} (per-attribute)")
+        monkeypatch.delenv("DMI_NO_FUSED")
+
+
 @pytest.mark.parametrize("pos_bits,uv_bits", [(1, 1), (5, 3), (16, 16), (20, 14)])
 def test_quantization_bit_widths(pos_bits, uv_bits):
     mesh = synth.torus_mesh(30)
