@@ -58,12 +58,21 @@ class _Mesh(C.Structure):
     _fields_ = [("faces", C.c_void_p), ("num_faces", C.c_uint32), ("atts", C.POINTER(_Attribute)), ("num_atts", C.c_uint32)]
 
 
+class _RawAttribute(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("num_points", C.c_uint32), ("component_type", C.c_uint8), ("num_components", C.c_uint8),
+                ("att_type", C.c_uint8), ("domain", C.c_uint8), ("num_parents", C.c_uint32), ("parents", C.c_void_p)]
+
+
+class _BuiltMesh(C.Structure):
+    _fields_ = [("mesh", _Mesh), ("owner", C.c_void_p)]
+
+
 class _Conn(C.Structure):
     _fields_ = [("num_tables", C.c_uint32), ("tables", C.POINTER(_CornerTable)), ("seeds", C.c_void_p), ("num_seeds", C.c_uint32), ("owner", C.c_void_p)]
 
 
 EXPORTS = ["dmi_encode_attributes", "dmi_encode_attributes_batch", "dmi_jobs_encode", "dmi_job_create", "dmi_job_encode", "dmi_job_timings", "dmi_job_destroy", "dmi_encode_mesh",
-           "dmi_mesh_prepare", "dmi_meshes_prepare", "dmi_encode_connectivity", "dmi_conn_free", "dmi_free", "dmi_strerror", "dmi_last_error", "dmi_device_count"]
+           "dmi_mesh_prepare", "dmi_meshes_prepare", "dmi_mesh_build", "dmi_built_mesh_free", "dmi_encode_connectivity", "dmi_conn_free", "dmi_free", "dmi_strerror", "dmi_last_error", "dmi_device_count"]
 
 
 def library_path():
@@ -97,6 +106,9 @@ def load_library():
     L.dmi_job_destroy.argtypes = [C.c_void_p]
     L.dmi_encode_mesh.argtypes = [C.POINTER(_Mesh), C.POINTER(_Config), C.POINTER(_Buffer)]
     L.dmi_mesh_prepare.argtypes = [C.POINTER(_Mesh), C.POINTER(_Config), C.POINTER(_Buffer), C.POINTER(C.c_void_p)]
+    L.dmi_mesh_build.argtypes = [C.POINTER(_RawAttribute), C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(_BuiltMesh)]
+    L.dmi_built_mesh_free.argtypes = [C.POINTER(_BuiltMesh)]
+    L.dmi_built_mesh_free.restype = None
     L.dmi_meshes_prepare.argtypes = [C.POINTER(_Mesh), C.c_uint32, C.POINTER(_Config), C.POINTER(_Buffer), C.POINTER(C.c_void_p)]
     L.dmi_encode_connectivity.argtypes = [C.POINTER(_Mesh), C.POINTER(_Buffer), C.POINTER(_Conn)]
     L.dmi_conn_free.argtypes = [C.POINTER(_Conn)]
@@ -207,9 +219,8 @@ def _dedup_rows(rows):
 
 
 class MeshBuilder:
-    """core/mesh/builder.rs:14-90 for the common case: per-attribute value dedup (Attribute::from),
-    Position swapped to slot 0, points that agree in every attribute merged, degenerate faces dropped.
-    (Unreferenced-point removal, builder.rs:129-189, is not needed by callers that index every point.)"""
+    """core/mesh/builder.rs:14-90: per-attribute value dedup (Attribute::from), Position swapped to slot 0, points that
+    agree in every attribute merged, degenerate faces dropped, unreferenced points removed."""
 
     def __init__(self):
         self._atts = []
@@ -226,6 +237,45 @@ class MeshBuilder:
         self._faces = np.ascontiguousarray(faces, dtype=np.uint32).reshape(-1, 3)
 
     def build(self):
+        """MeshBuilder::build through the library (dmi_mesh_build, C++, host only)."""
+        L = load_library()
+        n = len(self._atts)
+        raw = (_RawAttribute * max(n, 1))()
+        keep = []
+        np_of = {F32: np.float32, U32: np.uint32, I32: np.int32}
+        for i, a in enumerate(self._atts):
+            d = a["data"]
+            ct = {np.dtype(np.float32): F32, np.dtype(np.uint32): U32, np.dtype(np.int32): I32}.get(d.dtype)
+            if ct is None:
+                raise TypeError("attribute rows must be float32 / uint32 / int32")
+            par = np.ascontiguousarray(a["parents"], dtype=np.uint32)
+            keep.append((d, par))
+            raw[i].data = d.ctypes.data
+            raw[i].num_points = d.shape[0]
+            raw[i].component_type, raw[i].num_components, raw[i].att_type, raw[i].domain = ct, d.shape[1], a["type"], a["domain"]
+            raw[i].num_parents = len(par)
+            raw[i].parents = par.ctypes.data if len(par) else None
+        faces = self._faces if self._faces is not None else np.zeros((0, 3), np.uint32)
+        built = _BuiltMesh()
+        _check(L.dmi_mesh_build(raw, n, faces.ctypes.data if faces.size else None, faces.shape[0], C.byref(built)))
+        try:
+            m = built.mesh
+            out_faces = np.ctypeslib.as_array(C.cast(m.faces, C.POINTER(C.c_uint32)), shape=(m.num_faces, 3)).copy() if m.num_faces else np.zeros((0, 3), np.uint32)
+            out = []
+            for i in range(m.num_atts):
+                a = m.atts[i]
+                dt = np_of[a.component_type]
+                vals = (np.frombuffer(C.string_at(a.values, a.num_unique * a.num_components * 4), dtype=dt).reshape(a.num_unique, a.num_components).copy()
+                        if a.num_unique else np.zeros((0, a.num_components), dt))
+                p2v = np.frombuffer(C.string_at(a.point_to_value, a.num_points * 4), dtype=np.uint32).copy() if a.point_to_value else None
+                out.append(Attribute(vals, a.att_type, a.domain, unique_id=a.unique_id, parent_index=a.parent_index, point_to_value=p2v, num_points=a.num_points))
+        finally:
+            L.dmi_built_mesh_free(C.byref(built))
+        return Mesh(out_faces, out)
+
+    def build_numpy(self):
+        """The same result with numpy (kept as an independent cross-check of the C++ builder; it does not remove
+        unreferenced points, builder.rs:129-189, which callers that index every point never have)."""
         atts = []
         for a in self._atts:
             vals, p2v = _dedup_rows(a["data"])

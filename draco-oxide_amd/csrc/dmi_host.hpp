@@ -19,6 +19,7 @@
 namespace dmi {
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
+int host_fail(int code, const std::string& msg);   // sets dmi_last_error() for the calling thread, returns code
 
 struct ByteSink {
   std::vector<uint8_t> b;

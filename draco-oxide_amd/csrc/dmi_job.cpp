@@ -15,11 +15,11 @@
 #include "dmi_host.hpp"
 
 namespace dmi {
+thread_local std::string g_last_error;
+int host_fail(int code, const std::string& msg) { g_last_error = msg; return code; }   // shared with the host-only translation units
 namespace {
 
-thread_local std::string g_last_error;
-
-int fail(int code, const std::string& msg) { g_last_error = msg; return code; }
+int fail(int code, const std::string& msg) { return host_fail(code, msg); }
 
 #define HIP_TRY(expr)                                                                                              \
   do {                                                                                                             \

@@ -173,6 +173,21 @@ typedef struct dmi_conn {
 int dmi_encode_connectivity(const dmi_mesh* mesh, dmi_buffer* header_and_connectivity, dmi_conn* conn);
 void dmi_conn_free(dmi_conn* conn);
 
+/* --- MeshBuilder::build (core/mesh/builder.rs:62-90) + Attribute::from's value dedup (core/attribute/mod.rs:394-452) ----
+ * Host only.  Attributes in add order (AttributeId = index, builder.rs:31-39), one row per point; the result is the `Mesh` the
+ * reference hands to encode::encode: unique values in first-occurrence order with point_to_value maps, Position swapped to
+ * slot 0, identical points merged, degenerate faces and unreferenced points removed.  Arrays are owned by the library. */
+typedef struct dmi_raw_attribute {
+  const void* data;          /* num_points rows of num_components components */
+  uint32_t num_points;
+  uint8_t component_type, num_components, att_type, domain;
+  uint32_t num_parents;
+  const uint32_t* parents;   /* ids (add-order indices) of the parent attributes */
+} dmi_raw_attribute;
+typedef struct dmi_built_mesh { dmi_mesh mesh; void* owner; } dmi_built_mesh;
+int dmi_mesh_build(const dmi_raw_attribute* atts, uint32_t n_atts, const uint32_t* faces, uint32_t num_faces, dmi_built_mesh* out);
+void dmi_built_mesh_free(dmi_built_mesh* m);
+
 void dmi_free(dmi_buffer* buf);
 const char* dmi_strerror(int status);
 /* Last error detail for the calling thread (HIP error string, offending attribute, ...). */

@@ -106,3 +106,63 @@ def test_mesh_builder_matches_oracle_on_fixture_rows():
     assert (mesh.faces == s0.faces()).all()
     for a, o in zip(mesh.attributes, atts):
         assert (a.values == o["data"]).all()
+
+
+def _assert_built_like_oracle(mesh, sess):
+    assert (mesh.faces == sess.faces()).all()
+    atts = sess.attributes()
+    assert len(mesh.attributes) == len(atts)
+    for a, o in zip(mesh.attributes, atts):
+        assert a.values.shape == o["data"].shape and a.values.tobytes() == o["data"].tobytes()
+        assert (a.point_to_value is None) == (o["p2v"] is None)
+        if o["p2v"] is not None:
+            assert (a.point_to_value == o["p2v"]).all()
+        assert a.num_points == o["len"] and a.unique_id == o["id"]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_cpp_mesh_builder_matches_the_restated_builder(seed):
+    """dmi_mesh_build (C++, hash based) against the oracle's MeshBuilder restatement on rows with repeated values, -0.0 / 0.0,
+    NaNs, degenerate faces and points no face references (unreferenced-point removal, builder.rs:129-189)."""
+    rng = np.random.default_rng(seed)
+    n_pts, n_faces = 40, 30
+    pool = rng.integers(-2, 3, size=(12, 3)).astype(np.float32)
+    pos = pool[rng.integers(0, len(pool), size=n_pts)].copy()
+    pos[3] = [-0.0, 1.0, 0.0]
+    pos[9] = [0.0, 1.0, -0.0]
+    if seed % 2 == 0:
+        pos[5, 1] = np.nan
+        pos[17, 1] = np.nan
+    uv = (rng.integers(0, 3, size=(n_pts, 2)) / 2.0).astype(np.float32)
+    nrm = pool[rng.integers(0, len(pool), size=n_pts)] + np.float32(0.25)
+    ids = rng.integers(0, 4, size=(n_pts, 1)).astype(np.uint32)
+    faces = rng.integers(0, n_pts - 5, size=(n_faces, 3)).astype(np.uint32)     # the last points stay unreferenced
+    faces[4] = [7, 7, 2]                                                          # degenerate
+    b = dmi.MeshBuilder()
+    b.add_attribute(uv, dmi.ATT_TEXCOORD, dmi.DOMAIN_CORNER, parents=[1])       # Position is NOT added first: it must be swapped to slot 0
+    pid = b.add_attribute(pos, dmi.ATT_POSITION)
+    b.add_attribute(nrm, dmi.ATT_NORMAL, dmi.DOMAIN_CORNER, parents=[pid])
+    b.add_attribute(ids, dmi.ATT_CUSTOM, dmi.DOMAIN_CORNER)
+    b.set_connectivity_attribute(faces)
+    mesh = b.build()
+    sess = orc.Session.from_arrays(faces, [dict(data=uv, type=orc.TEXCOORD, domain=orc.DOM_CORNER, parents=[1]), dict(data=pos, type=orc.POSITION),
+                                           dict(data=nrm, type=orc.NORMAL, domain=orc.DOM_CORNER, parents=[1]), dict(data=ids, type=orc.CUSTOM, domain=orc.DOM_CORNER)])
+    _assert_built_like_oracle(mesh, sess)
+    assert mesh.attributes[0].att_type == dmi.ATT_POSITION and mesh.attributes[1].parent_index == 0
+
+
+def test_cpp_and_numpy_builders_agree_when_every_point_is_referenced():
+    faces, pos, nrm, uv = synth.torus_grid(12)
+    corner = faces.ravel()
+    b = dmi.MeshBuilder()
+    pid = b.add_attribute(pos[corner], dmi.ATT_POSITION)
+    b.add_attribute(nrm[corner], dmi.ATT_NORMAL, dmi.DOMAIN_CORNER, parents=[pid])
+    b.add_attribute(uv[corner], dmi.ATT_TEXCOORD, dmi.DOMAIN_CORNER, parents=[pid])
+    b.set_connectivity_attribute(np.arange(len(corner), dtype=np.uint32).reshape(-1, 3))
+    m1, m2 = b.build(), b.build_numpy()
+    assert (m1.faces == m2.faces).all()
+    for a, c in zip(m1.attributes, m2.attributes):
+        assert a.values.tobytes() == c.values.tobytes() and a.num_points == c.num_points
+        assert (a.point_to_value is None) == (c.point_to_value is None)
+        if a.point_to_value is not None:
+            assert (a.point_to_value == c.point_to_value).all()
