@@ -2,10 +2,25 @@
 // All pointers are device pointers unless stated otherwise; every launch goes to `stream`.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <vector>
 
 #include <cstdint>
 
 namespace dmi {
+
+// ---- kernel steps ---------------------------------------------------------------------------------
+// Every data-parallel launch of the encode pipeline is described by a KernelStep (kernel id, argument block, grid).  The
+// launch_* functions below either launch their step at once or — while a sink is set for the calling thread — append it to
+// the sink, so that a batch driver can run the SAME phase of many jobs in one multi-item launch (launch_steps_multi).
+// `level` orders the steps of one job: steps of equal level are independent of each other.
+enum KernelId : int { K_RANGES, K_RANGES_FINAL, K_SEQ_QUANT, K_I32_FINAL, K_FUSED_PNU, K_FUSED_PN, K_FUSED_PU, K_FUSED_N,
+                      K_PAR1, K_PAR2, K_PAR3, K_PAR4, K_DELTA, K_TEX, K_ORIENT, K_HIST, K_COUNT };
+constexpr int kStepLevels = 7;
+struct KernelStep { int id; int level; uint32_t blocks; uint32_t lds; uint32_t args_size; uint32_t pad; alignas(8) uint8_t args[640]; };
+void set_step_sink(std::vector<KernelStep>* sink);   // thread-local; nullptr = launch immediately
+void launch_step(const KernelStep& st, hipStream_t s);
+// items: device array of the kernel's argument blocks; block_info[b] = {item, block within the item}; item_blocks[i] = its grid
+void launch_steps_multi(int id, const void* items, const uint2* block_info, const uint32_t* item_blocks, uint32_t total_blocks, uint32_t lds, hipStream_t s);
 
 // ---- quantization (a4-a6), fused with the coding-order gather ---------------------------------------
 // meta layout (floats): [0..N) per-component min, [N] range, [N+1..2N] per-component max (debug)
@@ -28,6 +43,7 @@ uint32_t seq_quantize_blocks(uint32_t n);   // grid of launch_seq_quantize = par
 constexpr int kMaxGather = 4;
 struct QuantAtt { const float* raw; const uint32_t* s2v; int32_t* qs; int32_t* ipartials; const float* meta; float maxq; int kind; int N; int pad; };
 struct QuantArgs { QuantAtt a[kMaxGather]; int count; };
+struct SeqQuantArgs { const uint32_t* s2p; uint32_t n; uint32_t pad; QuantArgs q; };
 void launch_seq_quantize(const uint32_t* s2p, uint32_t n, const QuantArgs& args, hipStream_t s);
 
 // Fan-row sweep (see k_predict_fused).  Seam-free fast path: position (parallelogram, 3 components) + normal and/or texture
@@ -41,6 +57,11 @@ struct FusedArgs {
   const uint32_t* fan_hdr; const uint32_t* fan_apex; const uint32_t* fan;   // fan rows of the table (launch_build_fans)
 };
 void launch_predict_fused(const FusedArgs& a, hipStream_t s);
+struct ParArgs { const uint32_t* seq; const uint32_t* c2r; const uint32_t* opp; const int32_t* qs; const int32_t* minmax; uint32_t* sym; uint32_t n; uint32_t pad; };
+struct DeltaArgs { uint64_t n_comp; const int32_t* qs; uint32_t* sym; int N; int pad; };
+struct TexArgs { const uint32_t* seq; const uint32_t* c2r; const int32_t* qs; const uint32_t* c2r_pos; const int32_t* qs_pos; const int32_t* minmax; uint32_t* sym;
+                 uint8_t* orient; uint32_t n; uint32_t pad; };
+struct OrientArgs { const uint8_t* orient; uint32_t* summary; uint32_t n; uint32_t pad; };
 // Per coded vertex, in coding order: hdr[n], apex[n], fan[8n] (32-byte aligned) — see k_build_fans.  Once per job.
 // centre_in_apex: apex[i] = c2r[seq[i]] (the fan centre's rank) instead of the rank across the opposite edge — for a normal
 // attribute swept on its own table (c2r = the position table's, opp/seq = the normal table's).

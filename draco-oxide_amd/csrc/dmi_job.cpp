@@ -973,7 +973,8 @@ int dmi_jobs_encode(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
   // Small meshes are launch-bound (≈30 API calls per job), so the per-job phases are issued from several host
   // threads, each walking a contiguous slice of the jobs (jobs that own their stream then also overlap on the GPU).
   unsigned hw = std::thread::hardware_concurrency();
-  const uint32_t n_threads = std::max(1u, std::min({n, hw ? hw : 4u, 16u}));
+  static const uint32_t thread_cap = std::getenv("DMI_BATCH_THREADS") ? (uint32_t)std::atoi(std::getenv("DMI_BATCH_THREADS")) : 16u;
+  const uint32_t n_threads = std::max(1u, std::min({n, hw ? hw : 4u, std::max(1u, thread_cap)}));
   auto parallel = [&](auto&& fn, bool sync_after = true) -> int {
     std::vector<int> rcs(n_threads, DMI_OK);
     std::vector<std::string> errs(n_threads);

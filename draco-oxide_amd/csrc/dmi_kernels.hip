@@ -18,6 +18,8 @@
 //   (the serial rANS/rABS coders live in dmi_chains.hip)
 #include "dmi_device.hpp"
 #include <cstdlib>
+#include <cstring>
+#include <vector>
 
 namespace dmi {
 namespace {
@@ -28,21 +30,24 @@ constexpr uint32_t kNoneD = 0xFFFFFFFFu;
 __device__ __forceinline__ uint32_t cnext(uint32_t c) { return (c % 3u == 2u) ? c - 2u : c + 1u; }
 __device__ __forceinline__ uint32_t cprev(uint32_t c) { return (c % 3u == 0u) ? c + 2u : c - 1u; }
 
+// Every kernel body is a __device__ function of (its argument block, blk_, nblk_) = (block index, block count) WITHIN ITS
+// WORK ITEM: DMI_KERNEL generates the plain kernel (one item: blockIdx.x / gridDim.x) and the multi-item kernel that serves
+// the same phase of many jobs in one launch (block_info[blockIdx.x] = {item, block within the item}).
 // XCD-aware sweep of a sequence-ordered range.  Blocks are dealt round-robin over the 8 XCDs (block b and
 // b+8 share an L2), and Edgebreaker-order neighbours of entry i sit one "ring" (a few thousand entries)
 // before/after i.  Each XCD therefore owns one contiguous eighth of the chunk list and its blocks sweep it in
 // step, so ring neighbours are fetched once per L2 instead of once per XCD.  (Placement affects speed only.)
 #define DMI_FOR_SEQUENCE(I, N)                                                                           \
-  for (uint32_t nch_ = ((N) + kBlock - 1) / kBlock, per_ = (nch_ + 7u) / 8u, xcd_ = blockIdx.x & 7u,      \
-                end_ = min(nch_, (xcd_ + 1u) * per_), ch_ = xcd_ * per_ + (blockIdx.x >> 3);             \
-       ch_ < end_; ch_ += (gridDim.x >> 3))                                                              \
+  for (uint32_t nch_ = ((N) + kBlock - 1) / kBlock, per_ = (nch_ + 7u) / 8u, xcd_ = blk_ & 7u,      \
+                end_ = min(nch_, (xcd_ + 1u) * per_), ch_ = xcd_ * per_ + (blk_ >> 3);             \
+       ch_ < end_; ch_ += (nblk_ >> 3))                                                              \
     for (uint32_t I = ch_ * kBlock + threadIdx.x; I < (N); I = (N))
 
 // Same sweep in tiles of K·kBlock entries (each thread handles K entries of a tile, kBlock apart).
 #define DMI_FOR_TILES(BASE, N, K)                                                                                   \
-  for (uint32_t nch_ = ((N) + kBlock * (K) - 1) / (kBlock * (K)), per_ = (nch_ + 7u) / 8u, xcd_ = blockIdx.x & 7u,   \
-                end_ = min(nch_, (xcd_ + 1u) * per_), ch_ = xcd_ * per_ + (blockIdx.x >> 3);                       \
-       ch_ < end_; ch_ += (gridDim.x >> 3))                                                                        \
+  for (uint32_t nch_ = ((N) + kBlock * (K) - 1) / (kBlock * (K)), per_ = (nch_ + 7u) / 8u, xcd_ = blk_ & 7u,   \
+                end_ = min(nch_, (xcd_ + 1u) * per_), ch_ = xcd_ * per_ + (blk_ >> 3);                       \
+       ch_ < end_; ch_ += (nblk_ >> 3))                                                                        \
     for (uint32_t BASE = ch_ * kBlock * (K), once_ = 1; once_; once_ = 0)
 
 // Rust `as` casts: saturating, NaN → 0.
@@ -141,11 +146,11 @@ __device__ __forceinline__ void range_slice(const RangeAtt& a, uint32_t block, f
   }
   block_reduce_minmax<N>(mn, mx, out);
 }
-__global__ __launch_bounds__(kBlock) void k_value_ranges(RangeArgs args) {
+__device__ __forceinline__ void k_value_ranges_body(const RangeArgs& args, const uint32_t blk_, const uint32_t nblk_) {
   int ai = 0;
-  while (ai + 1 < args.count && blockIdx.x >= args.a[ai + 1].first_block) ++ai;
+  while (ai + 1 < args.count && blk_ >= args.a[ai + 1].first_block) ++ai;
   const RangeAtt& a = args.a[ai];
-  const uint32_t block = blockIdx.x - a.first_block;
+  const uint32_t block = blk_ - a.first_block;
   if (a.kind == 0) {
     float* out = a.partials + (size_t)block * 2 * a.N;
     switch (a.N) {
@@ -188,8 +193,8 @@ __device__ __forceinline__ void range_final(const RangeAtt& a) {
     a.meta[N] = delta_max;
   }
 }
-__global__ __launch_bounds__(kBlock) void k_value_ranges_final(RangeArgs args) {
-  const RangeAtt a = args.a[blockIdx.x];
+__device__ __forceinline__ void k_value_ranges_final_body(const RangeArgs& args, const uint32_t blk_, const uint32_t nblk_) {
+  const RangeAtt a = args.a[blk_];
   if (threadIdx.x < 16) a.small[threadIdx.x] = threadIdx.x == 0 ? 0x7FFFFFFFu : (threadIdx.x == 1 ? 0x80000000u : 0u);
   // the rest of the attribute's slab slot (ranges, histogram, orientation summaries) starts every encode at zero
   for (size_t w = threadIdx.x; w < a.zero_words; w += kBlock) a.zero[w] = 0u;
@@ -292,7 +297,10 @@ __device__ __forceinline__ void quantize_tile(const QuantAtt& a, const uint32_t 
     }
   }
 }
-__global__ __launch_bounds__(kBlock) void k_seq_quantize(const uint32_t* __restrict__ s2p, uint32_t n, QuantArgs args) {
+__device__ __forceinline__ void k_seq_quantize_body(const SeqQuantArgs& sq, const uint32_t blk_, const uint32_t nblk_) {
+  const uint32_t* __restrict__ s2p = sq.s2p;
+  const uint32_t n = sq.n;
+  const QuantArgs& args = sq.q;
   int32_t mn[kMaxGather], mx[kMaxGather];
 #pragma unroll
   for (int a = 0; a < kMaxGather; ++a) { mn[a] = 2147483647; mx[a] = (-2147483647 - 1); }
@@ -325,14 +333,14 @@ __global__ __launch_bounds__(kBlock) void k_seq_quantize(const uint32_t* __restr
     int32_t lo = red[threadIdx.x][0][0], hi = red[threadIdx.x][1][0];
 #pragma unroll
     for (int w = 1; w < kBlock / 64; ++w) { lo = min(lo, red[threadIdx.x][0][w]); hi = max(hi, red[threadIdx.x][1][w]); }
-    args.a[threadIdx.x].ipartials[2 * blockIdx.x] = lo;
-    args.a[threadIdx.x].ipartials[2 * blockIdx.x + 1] = hi;
+    args.a[threadIdx.x].ipartials[2 * blk_] = lo;
+    args.a[threadIdx.x].ipartials[2 * blk_ + 1] = hi;
   }
 }
 
 // Joint i32 min/max (wrapped_difference.rs:36-52, Q16) of every attribute: one block per attribute.
-__global__ __launch_bounds__(kBlock) void k_i32_minmax_final(MinMaxArgs args) {
-  const MinMaxAtt& a = args.a[blockIdx.x];
+__device__ __forceinline__ void k_i32_minmax_final_body(const MinMaxArgs& args, const uint32_t blk_, const uint32_t nblk_) {
+  const MinMaxAtt& a = args.a[blk_];
   int32_t lo = 2147483647, hi = (-2147483647 - 1);
   for (uint32_t b = threadIdx.x; b < a.blocks; b += kBlock) { lo = min(lo, a.ipartials[2 * b]); hi = max(hi, a.ipartials[2 * b + 1]); }
 #pragma unroll
@@ -369,10 +377,14 @@ __device__ __forceinline__ uint32_t wrap_symbol(int32_t orig, int32_t pred, cons
 }
 
 template <int N>
-__global__ __launch_bounds__(kBlock) void k_pred_parallelogram_wrapped(const uint32_t* __restrict__ seq, uint32_t n, const uint32_t* __restrict__ c2r,
-                                                                       const uint32_t* __restrict__ opp,
-                                                                       const int32_t* __restrict__ qs, const int32_t* __restrict__ minmax,
-                                                                       uint32_t* __restrict__ sym) {
+__device__ __forceinline__ void k_pred_parallelogram_wrapped_body(const ParArgs& pa, const uint32_t blk_, const uint32_t nblk_) {
+  const uint32_t* __restrict__ seq = pa.seq;
+  const uint32_t n = pa.n;
+  const uint32_t* __restrict__ c2r = pa.c2r;
+  const uint32_t* __restrict__ opp = pa.opp;
+  const int32_t* __restrict__ qs = pa.qs;
+  const int32_t* __restrict__ minmax = pa.minmax;
+  uint32_t* __restrict__ sym = pa.sym;
   const WrapParams w = wrap_params(minmax);
   DMI_FOR_SEQUENCE(i, n) {
     const uint32_t c = seq[i];
@@ -397,8 +409,12 @@ __global__ __launch_bounds__(kBlock) void k_pred_parallelogram_wrapped(const uin
   }
 }
 
-__global__ __launch_bounds__(kBlock) void k_pred_delta_difference(uint64_t n_comp, int N, const int32_t* __restrict__ qs, uint32_t* __restrict__ sym) {
-  for (uint64_t e = (uint64_t)blockIdx.x * kBlock + threadIdx.x; e < n_comp; e += (uint64_t)gridDim.x * kBlock) {
+__device__ __forceinline__ void k_pred_delta_difference_body(const DeltaArgs& da, const uint32_t blk_, const uint32_t nblk_) {
+  const uint64_t n_comp = da.n_comp;
+  const int N = da.N;
+  const int32_t* __restrict__ qs = da.qs;
+  uint32_t* __restrict__ sym = da.sym;
+  for (uint64_t e = (uint64_t)blk_ * kBlock + threadIdx.x; e < n_comp; e += (uint64_t)nblk_ * kBlock) {
     const int32_t pred = (e >= (uint64_t)N) ? qs[e - N] : 0;
     sym[e] = zigzag(wsub(qs[e], pred));
   }
@@ -605,10 +621,16 @@ __device__ __forceinline__ bool texcoord_predict(const int32_t (&cu)[2], const i
 }
 
 constexpr int kTexTile = 2;   // the i64 projection is register-hungry: two entries per thread
-__global__ __launch_bounds__(kBlock) void k_pred_texcoord_wrapped(const uint32_t* __restrict__ seq, uint32_t n, const uint32_t* __restrict__ c2r,
-                                                                  const int32_t* __restrict__ qs, const uint32_t* __restrict__ c2r_pos,
-                                                                  const int32_t* __restrict__ qs_pos, const int32_t* __restrict__ minmax,
-                                                                  uint32_t* __restrict__ sym, uint8_t* __restrict__ orient) {
+__device__ __forceinline__ void k_pred_texcoord_wrapped_body(const TexArgs& ta, const uint32_t blk_, const uint32_t nblk_) {
+  const uint32_t* __restrict__ seq = ta.seq;
+  const uint32_t n = ta.n;
+  const uint32_t* __restrict__ c2r = ta.c2r;
+  const int32_t* __restrict__ qs = ta.qs;
+  const uint32_t* __restrict__ c2r_pos = ta.c2r_pos;
+  const int32_t* __restrict__ qs_pos = ta.qs_pos;
+  const int32_t* __restrict__ minmax = ta.minmax;
+  uint32_t* __restrict__ sym = ta.sym;
+  uint8_t* __restrict__ orient = ta.orient;
   const WrapParams w = wrap_params(minmax);
   const bool shared = (c2r_pos == c2r);   // both attributes on one table: the position ranks are i, rn, rp themselves
   DMI_FOR_TILES(base, n, kTexTile) {
@@ -761,6 +783,7 @@ constexpr uint32_t kFanSlots = 8;
 __global__ __launch_bounds__(kBlock) void k_build_fans(const uint32_t* __restrict__ seq, uint32_t n, const uint32_t* __restrict__ c2r,
                                                        const uint32_t* __restrict__ opp, uint32_t* __restrict__ hdr, uint32_t* __restrict__ apex,
                                                        uint32_t* __restrict__ fan, int centre_in_apex) {
+  const uint32_t blk_ = blockIdx.x, nblk_ = gridDim.x;
   DMI_FOR_SEQUENCE(i, n) {
     const uint32_t c = seq[i];
     uint32_t row[kFanSlots];
@@ -821,7 +844,7 @@ __global__ __launch_bounds__(kBlock) void k_build_fans(const uint32_t* __restric
 // HAS_POS = false: the normal attribute alone, on its own (seam) table — `c2r` is then the POSITION table's corner →
 // rank array (fan rows hold position ranks), `opp` the normal table's, and apex[i] is the rank of the fan's centre.
 template <bool HAS_POS, bool HAS_NRM, bool HAS_UV>
-__global__ __launch_bounds__(kBlock) void k_predict_fused(FusedArgs a) {
+__device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const uint32_t blk_, const uint32_t nblk_) {
   const uint32_t* __restrict__ seq = a.seq;
   const uint32_t* __restrict__ c2r = a.c2r;
   const uint32_t* __restrict__ opp = a.opp;
@@ -958,8 +981,11 @@ __global__ __launch_bounds__(kBlock) void k_predict_fused(FusedArgs a) {
 // Per-block summary of the orientation flags so the host can stitch the count of bits and the number
 // of forward transitions (mesh_prediction_for_texture_coordinates.rs:224-235) without a serial pass.
 constexpr uint32_t kOrientChunk = 4096;
-__global__ __launch_bounds__(64) void k_orient_summary(const uint8_t* __restrict__ orient, uint32_t n, uint32_t* __restrict__ summary) {
-  const uint32_t lo = blockIdx.x * kOrientChunk, hi = min(n, lo + kOrientChunk);
+__device__ __forceinline__ void k_orient_summary_body(const OrientArgs& oa, const uint32_t blk_, const uint32_t nblk_) {
+  const uint8_t* __restrict__ orient = oa.orient;
+  const uint32_t n = oa.n;
+  uint32_t* __restrict__ summary = oa.summary;
+  const uint32_t lo = blk_ * kOrientChunk, hi = min(n, lo + kOrientChunk);
   const uint32_t lane = threadIdx.x;
   // stage the chunk through LDS with 16-byte loads: the scan below is a 64-step dependent loop, and a global byte
   // load per step would expose one memory latency per step
@@ -990,22 +1016,22 @@ __global__ __launch_bounds__(64) void k_orient_summary(const uint8_t* __restrict
     { const int ll = 63 - __clzll(valid); last = (uint32_t)((ones >> ll) & 1ull); }
   }
   if (lane == 0) {
-    summary[blockIdx.x * 4 + 0] = count;
-    summary[blockIdx.x * 4 + 1] = first;
-    summary[blockIdx.x * 4 + 2] = last;
-    summary[blockIdx.x * 4 + 3] = trans;
+    summary[blk_ * 4 + 0] = count;
+    summary[blk_ * 4 + 1] = first;
+    summary[blk_ * 4 + 2] = last;
+    summary[blk_ * 4 + 3] = trans;
   }
 }
 
 // Symbol histograms of every attribute of a job in one launch (block → (attribute, slice)), LDS-privatised when the
 // alphabet fits (≤ 16K bins = 64 KiB of the CU's 160 KiB).  Few, fat blocks: each flushes its private copy once.
 constexpr uint32_t kLdsBins = 16384;
-__global__ __launch_bounds__(kBlock) void k_histogram(HistArgs args) {
+__device__ __forceinline__ void k_histogram_body(const HistArgs& args, const uint32_t blk_, const uint32_t nblk_) {
   extern __shared__ uint32_t lds[];
   int ai = 0;
-  while (ai + 1 < args.count && blockIdx.x >= args.a[ai + 1].first_block) ++ai;
+  while (ai + 1 < args.count && blk_ >= args.a[ai + 1].first_block) ++ai;
   const HistAtt a = args.a[ai];
-  const uint32_t block = blockIdx.x - a.first_block;
+  const uint32_t block = blk_ - a.first_block;
   const bool use_lds = a.bins <= kLdsBins;
   if (use_lds) { for (uint32_t b = threadIdx.x; b < a.bins; b += kBlock) lds[b] = 0; __syncthreads(); }
   for (uint64_t e = (uint64_t)block * kBlock + threadIdx.x; e < a.n; e += (uint64_t)a.blocks * kBlock) {
@@ -1026,10 +1052,86 @@ inline uint32_t grid_for(uint64_t work, uint32_t cap = 256 * 8) {
   return (uint32_t)(b > cap ? cap : b);
 }
 
+// ---- kernel wrappers: one work item per launch, or many (the same phase of a whole batch of jobs) ----
+#define DMI_KERNEL(NAME, BODY, ARGS, THREADS)                                                                                         \
+  __global__ __launch_bounds__(THREADS) void NAME(ARGS a) { BODY(a, blockIdx.x, gridDim.x); }                                         \
+  __global__ __launch_bounds__(THREADS) void NAME##_multi(const ARGS* __restrict__ items, const uint2* __restrict__ block_info,       \
+                                                          const uint32_t* __restrict__ item_blocks) {                                 \
+    const uint2 bi = block_info[blockIdx.x];                                                                                          \
+    BODY(items[bi.x], bi.y, item_blocks[bi.x]);                                                                                        \
+  }
+DMI_KERNEL(k_value_ranges, k_value_ranges_body, RangeArgs, kBlock)
+DMI_KERNEL(k_value_ranges_final, k_value_ranges_final_body, RangeArgs, kBlock)
+DMI_KERNEL(k_seq_quantize, k_seq_quantize_body, SeqQuantArgs, kBlock)
+DMI_KERNEL(k_i32_minmax_final, k_i32_minmax_final_body, MinMaxArgs, kBlock)
+DMI_KERNEL(k_predict_fused_pnu, (k_predict_fused_body<true, true, true>), FusedArgs, kBlock)
+DMI_KERNEL(k_predict_fused_pn, (k_predict_fused_body<true, true, false>), FusedArgs, kBlock)
+DMI_KERNEL(k_predict_fused_pu, (k_predict_fused_body<true, false, true>), FusedArgs, kBlock)
+DMI_KERNEL(k_predict_fused_n, (k_predict_fused_body<false, true, false>), FusedArgs, kBlock)
+DMI_KERNEL(k_pred_parallelogram_wrapped1, k_pred_parallelogram_wrapped_body<1>, ParArgs, kBlock)
+DMI_KERNEL(k_pred_parallelogram_wrapped2, k_pred_parallelogram_wrapped_body<2>, ParArgs, kBlock)
+DMI_KERNEL(k_pred_parallelogram_wrapped3, k_pred_parallelogram_wrapped_body<3>, ParArgs, kBlock)
+DMI_KERNEL(k_pred_parallelogram_wrapped4, k_pred_parallelogram_wrapped_body<4>, ParArgs, kBlock)
+DMI_KERNEL(k_pred_delta_difference, k_pred_delta_difference_body, DeltaArgs, kBlock)
+DMI_KERNEL(k_pred_texcoord_wrapped, k_pred_texcoord_wrapped_body, TexArgs, kBlock)
+DMI_KERNEL(k_orient_summary, k_orient_summary_body, OrientArgs, 64)
+DMI_KERNEL(k_histogram, k_histogram_body, HistArgs, kBlock)
+
+thread_local std::vector<KernelStep>* g_step_sink = nullptr;
+
+template <class Args>
+void emit(int id, int level, const Args& a, uint32_t blocks, uint32_t lds, hipStream_t s) {
+  static_assert(sizeof(Args) <= sizeof(KernelStep::args), "KernelStep::args too small");
+  if (blocks == 0) return;
+  KernelStep st{};
+  st.id = id; st.level = level; st.blocks = blocks; st.lds = lds; st.args_size = (uint32_t)sizeof(Args);
+  std::memcpy(st.args, &a, sizeof(Args));
+  if (g_step_sink) g_step_sink->push_back(st);
+  else launch_step(st, s);
+}
+
 }  // namespace
 
+void set_step_sink(std::vector<KernelStep>* sink) { g_step_sink = sink; }
+
+#define DMI_CASE(ID, NAME, ARGS, THREADS) \
+  case ID: hipLaunchKernelGGL(NAME, st.blocks, THREADS, st.lds, s, *reinterpret_cast<const ARGS*>(st.args)); break;
+#define DMI_CASE_MULTI(ID, NAME, ARGS, THREADS) \
+  case ID: hipLaunchKernelGGL(NAME##_multi, total_blocks, THREADS, lds, s, static_cast<const ARGS*>(items), block_info, item_blocks); break;
+#define DMI_ALL_KERNELS(X)                                                   \
+  X(K_RANGES, k_value_ranges, RangeArgs, kBlock)                             \
+  X(K_RANGES_FINAL, k_value_ranges_final, RangeArgs, kBlock)                 \
+  X(K_SEQ_QUANT, k_seq_quantize, SeqQuantArgs, kBlock)                       \
+  X(K_I32_FINAL, k_i32_minmax_final, MinMaxArgs, kBlock)                     \
+  X(K_FUSED_PNU, k_predict_fused_pnu, FusedArgs, kBlock)                     \
+  X(K_FUSED_PN, k_predict_fused_pn, FusedArgs, kBlock)                       \
+  X(K_FUSED_PU, k_predict_fused_pu, FusedArgs, kBlock)                       \
+  X(K_FUSED_N, k_predict_fused_n, FusedArgs, kBlock)                         \
+  X(K_PAR1, k_pred_parallelogram_wrapped1, ParArgs, kBlock)                  \
+  X(K_PAR2, k_pred_parallelogram_wrapped2, ParArgs, kBlock)                  \
+  X(K_PAR3, k_pred_parallelogram_wrapped3, ParArgs, kBlock)                  \
+  X(K_PAR4, k_pred_parallelogram_wrapped4, ParArgs, kBlock)                  \
+  X(K_DELTA, k_pred_delta_difference, DeltaArgs, kBlock)                     \
+  X(K_TEX, k_pred_texcoord_wrapped, TexArgs, kBlock)                         \
+  X(K_ORIENT, k_orient_summary, OrientArgs, 64)                              \
+  X(K_HIST, k_histogram, HistArgs, kBlock)
+
+void launch_step(const KernelStep& st, hipStream_t s) {
+  switch (st.id) {
+    DMI_ALL_KERNELS(DMI_CASE)
+    default: break;
+  }
+}
+void launch_steps_multi(int id, const void* items, const uint2* block_info, const uint32_t* item_blocks, uint32_t total_blocks, uint32_t lds, hipStream_t s) {
+  if (!total_blocks) return;
+  switch (id) {
+    DMI_ALL_KERNELS(DMI_CASE_MULTI)
+    default: break;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
-// launch wrappers
+// launch wrappers (each emits one KernelStep: launched at once, or collected when a sink is set)
 // ------------------------------------------------------------------------------------------------
 void launch_value_ranges(RangeArgs& args, hipStream_t s) {
   if (args.count == 0) return;
@@ -1040,39 +1142,35 @@ void launch_value_ranges(RangeArgs& args, hipStream_t s) {
     a.first_block = total;
     total += a.blocks;
   }
-  if (total) hipLaunchKernelGGL(k_value_ranges, total, kBlock, 0, s, args);
-  hipLaunchKernelGGL(k_value_ranges_final, (uint32_t)args.count, kBlock, 0, s, args);
+  emit(K_RANGES, 0, args, total, 0, s);
+  emit(K_RANGES_FINAL, 1, args, (uint32_t)args.count, 0, s);
 }
 
-void launch_i32_minmax_final(const MinMaxArgs& args, hipStream_t s) {
-  if (args.count) hipLaunchKernelGGL(k_i32_minmax_final, (uint32_t)args.count, kBlock, 0, s, args);
-}
+void launch_i32_minmax_final(const MinMaxArgs& args, hipStream_t s) { emit(K_I32_FINAL, 3, args, (uint32_t)args.count, 0, s); }
 
 inline uint32_t tiles_grid(uint64_t n) { return grid_for((n + kTile - 1) / kTile, kSeqQuantizeMaxBlocks); }   // grid of a DMI_FOR_TILES kernel
 uint32_t seq_quantize_blocks(uint32_t n) { return tiles_grid(n); }
 void launch_seq_quantize(const uint32_t* s2p, uint32_t n, const QuantArgs& args, hipStream_t s) {
-  hipLaunchKernelGGL(k_seq_quantize, seq_quantize_blocks(n), kBlock, 0, s, s2p, n, args);
+  SeqQuantArgs sq{};
+  sq.s2p = s2p; sq.n = n; sq.q = args;
+  emit(K_SEQ_QUANT, 2, sq, seq_quantize_blocks(n), 0, s);
 }
 
 void launch_pred_parallelogram_wrapped(const uint32_t* seq, uint32_t n, const uint32_t* c2r, const uint32_t* opp,
                                        const int32_t* qs, const int32_t* minmax, int N, uint32_t* sym, hipStream_t s) {
-  const uint32_t g = grid_for(n);
-  switch (N) {
-    case 1: hipLaunchKernelGGL(k_pred_parallelogram_wrapped<1>, g, kBlock, 0, s, seq, n, c2r, opp, qs, minmax, sym); break;
-    case 2: hipLaunchKernelGGL(k_pred_parallelogram_wrapped<2>, g, kBlock, 0, s, seq, n, c2r, opp, qs, minmax, sym); break;
-    case 3: hipLaunchKernelGGL(k_pred_parallelogram_wrapped<3>, g, kBlock, 0, s, seq, n, c2r, opp, qs, minmax, sym); break;
-    default: hipLaunchKernelGGL(k_pred_parallelogram_wrapped<4>, g, kBlock, 0, s, seq, n, c2r, opp, qs, minmax, sym); break;
-  }
+  ParArgs pa{seq, c2r, opp, qs, minmax, sym, n, 0u};
+  emit(N == 1 ? K_PAR1 : (N == 2 ? K_PAR2 : (N == 3 ? K_PAR3 : K_PAR4)), 4, pa, grid_for(n), 0, s);
 }
 
 void launch_pred_delta_difference(uint32_t n, const int32_t* qs, int N, uint32_t* sym, hipStream_t s) {
-  const uint64_t nc = (uint64_t)n * N;
-  hipLaunchKernelGGL(k_pred_delta_difference, grid_for(nc), kBlock, 0, s, nc, N, qs, sym);
+  DeltaArgs da{(uint64_t)n * N, qs, sym, N, 0};
+  emit(K_DELTA, 4, da, da.n_comp ? grid_for(da.n_comp) : 0u, 0, s);
 }
 
 void launch_pred_texcoord_wrapped(const uint32_t* seq, uint32_t n, const uint32_t* c2r, const int32_t* qs, const uint32_t* c2r_pos,
                                   const int32_t* qs_pos, const int32_t* minmax, uint32_t* sym, uint8_t* orient, hipStream_t s) {
-  hipLaunchKernelGGL(k_pred_texcoord_wrapped, grid_for(((uint64_t)n + kTexTile - 1) / kTexTile), kBlock, 0, s, seq, n, c2r, qs, c2r_pos, qs_pos, minmax, sym, orient);
+  TexArgs ta{seq, c2r, qs, c2r_pos, qs_pos, minmax, sym, orient, n, 0u};
+  emit(K_TEX, 4, ta, grid_for(((uint64_t)n + kTexTile - 1) / kTexTile), 0, s);
 }
 
 void launch_build_fans(const uint32_t* seq, uint32_t n, const uint32_t* c2r, const uint32_t* opp, uint32_t* hdr, uint32_t* apex, uint32_t* fan, bool centre_in_apex,
@@ -1084,16 +1182,14 @@ void launch_predict_fused(const FusedArgs& a, hipStream_t s) {
   if (a.n == 0) return;
   static const uint32_t env_cap = std::getenv("DMI_FUSED_GRID") ? (uint32_t)std::atoi(std::getenv("DMI_FUSED_GRID")) : 0u;   // tuning aid
   const uint32_t g = grid_for(a.n, env_cap ? env_cap : 8192u);   // 2-3 chunks per block: measured best on the 10M workload (2048: +5 %)
-  if (!a.sym_pos) hipLaunchKernelGGL((k_predict_fused<false, true, false>), g, kBlock, 0, s, a);   // a normal attribute on its own table
-  else if (a.qs_nrm && a.qs_uv) hipLaunchKernelGGL((k_predict_fused<true, true, true>), g, kBlock, 0, s, a);
-  else if (a.qs_nrm) hipLaunchKernelGGL((k_predict_fused<true, true, false>), g, kBlock, 0, s, a);
-  else hipLaunchKernelGGL((k_predict_fused<true, false, true>), g, kBlock, 0, s, a);
+  const int id = !a.sym_pos ? K_FUSED_N /* a normal attribute on its own table */ : ((a.qs_nrm && a.qs_uv) ? K_FUSED_PNU : (a.qs_nrm ? K_FUSED_PN : K_FUSED_PU));
+  emit(id, 4, a, g, 0, s);
 }
 
 uint32_t orient_summary_blocks(uint32_t n) { return (n + kOrientChunk - 1) / kOrientChunk; }
 void launch_orient_summary(const uint8_t* orient, uint32_t n, uint32_t* summary, uint32_t*, hipStream_t s) {
-  const uint32_t g = orient_summary_blocks(n);
-  if (g) hipLaunchKernelGGL(k_orient_summary, g, 64, 0, s, orient, n, summary);
+  OrientArgs oa{orient, summary, n, 0u};
+  emit(K_ORIENT, 5, oa, orient_summary_blocks(n), 0, s);
 }
 
 void launch_histograms(HistArgs& args, hipStream_t s) {
@@ -1106,7 +1202,7 @@ void launch_histograms(HistArgs& args, hipStream_t s) {
     total += a.blocks;
     if (a.blocks && a.bins <= kLdsBins) lds = std::max(lds, (size_t)a.bins * 4);
   }
-  if (total) hipLaunchKernelGGL(k_histogram, total, kBlock, lds, s, args);
+  emit(K_HIST, 6, args, total, (uint32_t)lds, s);
 }
 
 }  // namespace dmi
