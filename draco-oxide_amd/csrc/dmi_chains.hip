@@ -307,6 +307,16 @@ __global__ __launch_bounds__(256) void k_pack_copy(const ChainDesc* __restrict__
   for (uint64_t v = lo + threadIdx.x; v < hi; v += 256) dst[v] = src[v];
 }
 
+// Generic gather of device ranges into one arena (batch read-back of the jobs' slabs): 16-byte words, 256-aligned pieces.
+__global__ __launch_bounds__(256) void k_copy_items(const CopyItem* __restrict__ items, uint8_t* __restrict__ arena) {
+  const CopyItem it = items[blockIdx.x];
+  const uint64_t vecs = it.bytes >> 4;
+  const uint64_t lo = vecs * blockIdx.y / kPackSplit, hi = vecs * (blockIdx.y + 1) / kPackSplit;
+  const uint4* __restrict__ src = reinterpret_cast<const uint4*>(it.src);
+  uint4* __restrict__ dst = reinterpret_cast<uint4*>(arena + it.dst_offset);
+  for (uint64_t v = lo + threadIdx.x; v < hi; v += 256) dst[v] = src[v];
+}
+
 inline uint32_t grid256(uint64_t n) { uint64_t g = (n + 255) / 256; return (uint32_t)(g > 4096 ? 4096 : (g ? g : 1)); }
 
 }  // namespace
@@ -328,6 +338,9 @@ void launch_pack_streams(const ChainDesc* descs_dev, uint32_t n_streams, PackEnt
   if (!n_streams) return;
   hipLaunchKernelGGL(k_pack_offsets, 1, 1024, 0, s, descs_dev, n_streams, table);
   hipLaunchKernelGGL(k_pack_copy, dim3(n_streams, kPackSplit), 256, 0, s, descs_dev, table, arena);
+}
+void launch_copy_items(const CopyItem* items_dev, uint32_t n_items, uint8_t* arena, hipStream_t s) {
+  if (n_items) hipLaunchKernelGGL(k_copy_items, dim3(n_items, kPackSplit), 256, 0, s, items_dev, arena);
 }
 void launch_chains(const ChainDesc* descs_dev, uint32_t n_streams, hipStream_t s) {
   if (n_streams) hipLaunchKernelGGL(k_chains, n_streams, 128, 0, s, descs_dev);

@@ -118,6 +118,9 @@ void launch_chains(const ChainDesc* descs_dev, uint32_t n_streams, hipStream_t s
 // table[k] = {offset, length, error} and table[n_streams].offset = total bytes.  Stream outputs must be allocated with
 // ≥ 16 bytes of slack (the copy moves whole 16-byte words).
 struct PackEntry { uint64_t offset; uint32_t len; uint32_t err; };
+// items[k] = {device source (16-byte aligned), destination offset in `arena`, bytes (multiple of 16)}
+struct CopyItem { const void* src; uint64_t dst_offset; uint64_t bytes; };
+void launch_copy_items(const CopyItem* items_dev, uint32_t n_items, uint8_t* arena, hipStream_t s);
 void launch_pack_streams(const ChainDesc* descs_dev, uint32_t n_streams, PackEntry* table, uint8_t* arena, hipStream_t s);
 
 }  // namespace dmi

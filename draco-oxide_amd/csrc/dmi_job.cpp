@@ -115,6 +115,7 @@ struct dmi_job {
   uint64_t predict_bytes = 0;
   hipGraphExec_t graph_a = nullptr;   // phase A captured once (launch-bound for small meshes)
   bool graph_tried = false;
+  uint8_t* readback = nullptr;     // where the slab of the current encode was read back to (pinned, or a batch arena slot)
   uint8_t* out_pinned = nullptr;   // grow-only pinned arena for the coded bytes of one encode
   size_t out_pinned_cap = 0;
   struct Run {   // state carried between the phases of one encode
@@ -493,8 +494,9 @@ int dmi_job_timings(const dmi_job* job, dmi_timings* t) {
 
 // The encode pipeline of one job, split at its host synchronisation points so that a batch of jobs can share
 // them (one sync for all histograms, ONE k_chains launch holding every stream of every job).
-static int encode_phase_a(dmi_job* job) {   // device: ranges → coding-order portabilization → predict → histograms; async read-back
-  HIP_TRY(hipSetDevice(job->cfg.device));
+static int encode_phase_a(dmi_job* job, bool plan_only = false) {   // device: ranges → coding-order portabilization → predict → histograms; async read-back
+  // plan_only: the caller has set a step sink — every launch below is collected, not issued, and the read-back is the caller's
+  if (!plan_only) HIP_TRY(hipSetDevice(job->cfg.device));
   hipStream_t s = job->stream;
   const uint32_t n_atts = (uint32_t)job->atts.size();
   uint8_t* pinned = static_cast<uint8_t*>(job->pinned);
@@ -629,7 +631,7 @@ static int encode_phase_a(dmi_job* job) {   // device: ranges → coding-order p
   }
   launch_histograms(ha, s);
   // scratch words, ranges, histograms and orientation summaries of every attribute: one copy (the pinned buffer mirrors the slab)
-  HIP_TRY(hipMemcpyAsync(pinned, job->slab.p, job->slab.bytes, hipMemcpyDeviceToHost, s));
+  if (!plan_only) HIP_TRY(hipMemcpyAsync(pinned, job->slab.p, job->slab.bytes, hipMemcpyDeviceToHost, s));
   if (timed) HIP_TRY(hipEventRecord(job->ev[3], s));
   return DMI_OK;
 }
@@ -637,7 +639,7 @@ static int encode_phase_a(dmi_job* job) {   // device: ranges → coding-order p
 static int encode_phase_b(dmi_job* job) {   // host: table normalisation; device: coding records; fills job->run.descs
   hipStream_t s = job->stream;
   const uint32_t n_atts = (uint32_t)job->atts.size();
-  uint8_t* pinned = static_cast<uint8_t*>(job->pinned);
+  uint8_t* pinned = job->readback ? job->readback : static_cast<uint8_t*>(job->pinned);
   // ---- stage 4 (host): normalise tables, build chain descriptors -----------------------------------------
   std::vector<ChainDesc>& descs = job->run.descs;
   descs.clear();
@@ -722,7 +724,7 @@ static int encode_phase_b(dmi_job* job) {   // host: table normalisation; device
 static int encode_phase_c1(dmi_job* job) {   // after the chains: async read-back of lengths / error flags
   hipStream_t s = job->stream;
   const uint32_t n_atts = (uint32_t)job->atts.size();
-  uint8_t* pinned = static_cast<uint8_t*>(job->pinned);
+  uint8_t* pinned = job->readback ? job->readback : static_cast<uint8_t*>(job->pinned);
   for (uint32_t i = 0; i < n_atts; ++i) HIP_TRY(hipMemcpyAsync(pinned + job->run.pin_off[i], job->atts[i].small.p, 64, hipMemcpyDeviceToHost, s));
   return DMI_OK;
 }
@@ -730,7 +732,7 @@ static int encode_phase_c1(dmi_job* job) {   // after the chains: async read-bac
 static int encode_phase_c2(dmi_job* job) {   // lengths known: async copy of the coded bytes
   hipStream_t s = job->stream;
   const uint32_t n_atts = (uint32_t)job->atts.size();
-  uint8_t* pinned = static_cast<uint8_t*>(job->pinned);
+  uint8_t* pinned = job->readback ? job->readback : static_cast<uint8_t*>(job->pinned);
   const std::vector<size_t>& pin_off = job->run.pin_off;
   const std::vector<AuxInfo>& aux = job->run.aux;
   auto& rans_off = job->run.rans_off;
@@ -793,7 +795,7 @@ static int encode_phase_c_packed(dmi_job* job, const PackEntry* table, uint32_t 
 
 static int encode_phase_c3(dmi_job* job, dmi_buffer* out) {   // host: splice the attribute section
   const uint32_t n_atts = (uint32_t)job->atts.size();
-  uint8_t* pinned = static_cast<uint8_t*>(job->pinned);
+  uint8_t* pinned = job->readback ? job->readback : static_cast<uint8_t*>(job->pinned);
   const std::vector<size_t>& pin_off = job->run.pin_off;
   const std::vector<AuxInfo>& aux = job->run.aux;
   const auto& rans_ptr = job->run.rans_ptr;
@@ -877,6 +879,7 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
   hipStream_t s = job->stream;
   const bool timed = job->have_events;
   const auto wall0 = std::chrono::steady_clock::now();
+  job->readback = nullptr;
   int rc = encode_phase_a(job);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(s));
@@ -922,6 +925,8 @@ struct BatchArena {
   void* bytes_dev = nullptr; size_t bytes_dev_cap = 0;
   void* table_dev = nullptr; void* table_host = nullptr; size_t table_cap = 0;
   void* bytes_host = nullptr; size_t bytes_host_cap = 0;
+  void* plan_host = nullptr; void* plan_dev = nullptr; size_t plan_cap = 0;       // launch plan of a batch (argument blocks, block maps)
+  void* slabs_host = nullptr; void* slabs_dev = nullptr; size_t slabs_cap = 0;   // every job's slab, packed
   bool in_use = false;
   int reserve(size_t dev_bytes, size_t table_bytes) {
     if (dev_bytes > bytes_dev_cap) {
@@ -938,6 +943,17 @@ struct BatchArena {
       HIP_TRY(hipHostMalloc(&table_host, table_bytes * 2, hipHostMallocDefault));
       table_cap = table_bytes * 2;
     }
+    return DMI_OK;
+  }
+  static int reserve_pair(void*& host, void*& dev, size_t& cap, size_t bytes) {
+    if (bytes <= cap) return DMI_OK;
+    if (host) (void)hipHostFree(host);
+    if (dev) (void)hipFree(dev);
+    host = dev = nullptr; cap = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    HIP_TRY(hipHostMalloc(&host, want, hipHostMallocDefault));
+    HIP_TRY(hipMalloc(&dev, want));
+    cap = want;
     return DMI_OK;
   }
   int reserve_host(size_t bytes) {
@@ -964,6 +980,77 @@ static BatchArena* acquire_batch_arena(int device) {
 static void release_batch_arena(BatchArena* a) {
   std::lock_guard<std::mutex> lock(g_arena_mutex);
   a->in_use = false;
+}
+
+// Phase A of a whole batch in ONE launch per (level, kernel): every job's launches are collected as KernelSteps (the same
+// code path as a single encode, with a sink set), grouped, their argument blocks and block maps uploaded in one copy, and each
+// group served by a multi-item kernel; the slabs come back packed in one copy.  Small meshes are otherwise bound by the ≈2.4 µs
+// the GPU spends per tiny kernel (9 per job).
+static int run_phase_a_batched(dmi_job** jobs, const std::vector<uint32_t>& which, BatchArena* arena, hipStream_t s) {
+  const uint32_t n = (uint32_t)which.size();
+  if (!n) return DMI_OK;
+  std::vector<std::vector<KernelStep>> steps(n);
+  for (uint32_t k = 0; k < n; ++k) {
+    dmi_job* job = jobs[which[k]];
+    set_step_sink(&steps[k]);
+    const int rc = encode_phase_a(job, true);
+    set_step_sink(nullptr);
+    if (rc) return rc;
+  }
+  struct Group { int level, id; uint32_t lds = 0, total_blocks = 0; std::vector<const KernelStep*> items; size_t off_args = 0, off_info = 0, off_blocks = 0; };
+  std::vector<Group> groups;
+  for (int level = 0; level < kStepLevels; ++level) {
+    for (int id = 0; id < K_COUNT; ++id) {
+      Group g;
+      g.level = level; g.id = id;
+      for (uint32_t k = 0; k < n; ++k)
+        for (const KernelStep& st : steps[k])
+          if (st.level == level && st.id == id) { g.items.push_back(&st); g.total_blocks += st.blocks; g.lds = std::max(g.lds, st.lds); }
+      if (!g.items.empty()) groups.push_back(std::move(g));
+    }
+  }
+  auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  size_t plan_bytes = 0;
+  for (Group& g : groups) {
+    g.off_args = plan_bytes; plan_bytes = align(plan_bytes + (size_t)g.items.size() * g.items[0]->args_size);
+    g.off_info = plan_bytes; plan_bytes = align(plan_bytes + (size_t)g.total_blocks * sizeof(uint2));
+    g.off_blocks = plan_bytes; plan_bytes = align(plan_bytes + g.items.size() * sizeof(uint32_t));
+  }
+  // slab read-back layout
+  std::vector<CopyItem> copies(n);
+  size_t slab_bytes = 0;
+  for (uint32_t k = 0; k < n; ++k) {
+    dmi_job* job = jobs[which[k]];
+    copies[k] = CopyItem{job->slab.p, (uint64_t)slab_bytes, (uint64_t)(job->slab.bytes & ~(size_t)15)};
+    slab_bytes = align(slab_bytes + job->slab.bytes);
+  }
+  const size_t off_copies = plan_bytes;
+  plan_bytes = align(plan_bytes + copies.size() * sizeof(CopyItem));
+  int rc;
+  if ((rc = BatchArena::reserve_pair(arena->plan_host, arena->plan_dev, arena->plan_cap, plan_bytes))) return rc;
+  if ((rc = BatchArena::reserve_pair(arena->slabs_host, arena->slabs_dev, arena->slabs_cap, slab_bytes))) return rc;
+  uint8_t* ph = static_cast<uint8_t*>(arena->plan_host);
+  for (const Group& g : groups) {
+    const size_t asz = g.items[0]->args_size;
+    uint2* info = reinterpret_cast<uint2*>(ph + g.off_info);
+    uint32_t* blocks = reinterpret_cast<uint32_t*>(ph + g.off_blocks);
+    uint32_t at = 0;
+    for (size_t i = 0; i < g.items.size(); ++i) {
+      std::memcpy(ph + g.off_args + i * asz, g.items[i]->args, asz);
+      blocks[i] = g.items[i]->blocks;
+      for (uint32_t b = 0; b < g.items[i]->blocks; ++b) info[at++] = make_uint2((uint32_t)i, b);
+    }
+  }
+  std::memcpy(ph + off_copies, copies.data(), copies.size() * sizeof(CopyItem));
+  HIP_TRY(hipMemcpyAsync(arena->plan_dev, arena->plan_host, plan_bytes, hipMemcpyHostToDevice, s));
+  const uint8_t* pd = static_cast<const uint8_t*>(arena->plan_dev);
+  for (const Group& g : groups)
+    launch_steps_multi(g.id, pd + g.off_args, reinterpret_cast<const uint2*>(pd + g.off_info), reinterpret_cast<const uint32_t*>(pd + g.off_blocks), g.total_blocks, g.lds, s);
+  launch_copy_items(reinterpret_cast<const CopyItem*>(pd + off_copies), n, static_cast<uint8_t*>(arena->slabs_dev), s);
+  HIP_TRY(hipMemcpyAsync(arena->slabs_host, arena->slabs_dev, slab_bytes, hipMemcpyDeviceToHost, s));
+  for (uint32_t k = 0; k < n; ++k) jobs[which[k]]->readback = static_cast<uint8_t*>(arena->slabs_host) + copies[k].dst_offset;
+  HIP_TRY(hipStreamSynchronize(s));
+  return DMI_OK;
 }
 
 int dmi_jobs_encode(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
@@ -1010,6 +1097,20 @@ int dmi_jobs_encode(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
   // that job's histograms, normalises its tables and queues the record prep — host work of early jobs overlaps the
   // data-parallel kernels of later ones.  The chains of ALL jobs then run in one launch: a long-running kernel per job
   // would pin one of the few hardware queues each and serialise the batch (measured: 114 ms instead of 8).
+  BatchArena* arena = acquire_batch_arena(device);
+  struct Release { BatchArena* a; ~Release() { release_batch_arena(a); } } release{arena};
+  // jobs whose phase A can be planned ahead (no mid-phase host wait, no per-job event timing) share one launch per kernel
+  std::vector<uint32_t> batched;
+  std::vector<uint8_t> is_batched(n, 0);
+  for (uint32_t j = 0; j < n; ++j) {
+    jobs[j]->readback = nullptr;
+    bool ok = !jobs[j]->have_events && !std::getenv("DMI_NO_BATCHED_PHASES");
+    for (auto& a : jobs[j]->atts) if (a.port == kToBits) ok = false;
+    if (ok) { batched.push_back(j); is_batched[j] = 1; }
+  }
+  HIP_TRY(hipSetDevice(device));
+  if ((rc = run_phase_a_batched(jobs, batched, arena, s))) return rc;
+  const auto t1 = now();
   std::vector<uint32_t> order(n);
   for (uint32_t j = 0; j < n; ++j) order[j] = j;
   auto job_size = [&](uint32_t j) { uint64_t t = 0; for (auto& a : jobs[j]->atts) t += a.n_sym; return t; };
@@ -1024,13 +1125,13 @@ int dmi_jobs_encode(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
       std::vector<uint32_t> mine;
       for (uint32_t k = t; k < n; k += n_threads) mine.push_back(order[k]);
       const auto w0 = std::chrono::steady_clock::now();
-      for (uint32_t j : mine) { const int r = run_phase_a(jobs[j]); if (r) return bail(r, g_last_error); }
+      for (uint32_t j : mine) { if (is_batched[j]) continue; const int r = run_phase_a(jobs[j]); if (r) return bail(r, g_last_error); }
       const auto w1 = std::chrono::steady_clock::now();
       double wait_ms = 0, b_ms = 0;
       for (uint32_t j : mine) {
         dmi_job* job = jobs[j];
         const auto x0 = std::chrono::steady_clock::now();
-        if (hipStreamSynchronize(job->stream) != hipSuccess) return bail(DMI_ERR_HIP, "hipStreamSynchronize");
+        if (!is_batched[j] && hipStreamSynchronize(job->stream) != hipSuccess) return bail(DMI_ERR_HIP, "hipStreamSynchronize");
         const auto x1 = std::chrono::steady_clock::now();
         int r = encode_phase_b(job);
         if (r) return bail(r, g_last_error);
@@ -1069,8 +1170,6 @@ int dmi_jobs_encode(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
     for (uint32_t j = 0; j < n; ++j) { first_desc[j] = at; at += (uint32_t)jobs[j]->run.descs.size(); }
     for (const ChainDesc& d : all) cap_sum += ((size_t)d.cap + 31) & ~(size_t)15;
   }
-  BatchArena* arena = acquire_batch_arena(device);
-  struct Release { BatchArena* a; ~Release() { release_batch_arena(a); } } release{arena};
   if ((rc = arena->reserve(cap_sum, (size_t)(n_streams + 1) * sizeof(PackEntry)))) return rc;
   launch_pack_streams(descs_dev.as<ChainDesc>(), n_streams, static_cast<PackEntry*>(arena->table_dev), static_cast<uint8_t*>(arena->bytes_dev), s);
   HIP_TRY(hipMemcpyAsync(arena->table_host, arena->table_dev, (size_t)(n_streams + 1) * sizeof(PackEntry), hipMemcpyDeviceToHost, s));
@@ -1083,7 +1182,7 @@ int dmi_jobs_encode(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
   for (uint32_t j = 0; j < n; ++j) if ((rc = encode_phase_c_packed(jobs[j], table, first_desc[j], static_cast<const uint8_t*>(arena->bytes_host)))) return rc;
   const auto t6 = now();
   if ((rc = parallel([&](uint32_t j) { return encode_phase_c3(jobs[j], &outs[j]); }, false))) return rc;
-  if (trace) std::fprintf(stderr, "[dmi] batch of %u on %u host threads: data-parallel phases + tables (pipelined per job) %.2f ms, chains (%zu streams, one launch) %.2f, packed read-back %.2f, splice %.2f\n", n, n_threads, ms(t0, t4), all.size(), ms(t4, t5), ms(t5, t6), ms(t6, now()));
+  if (trace) std::fprintf(stderr, "[dmi] batch of %u (%zu with batched phases) on %u host threads: data-parallel phases %.2f ms, tables + record prep %.2f, chains (%zu streams, one launch) %.2f, packed read-back %.2f, splice %.2f\n", n, batched.size(), n_threads, ms(t0, t1), ms(t1, t4), all.size(), ms(t4, t5), ms(t5, t6), ms(t6, now()));
   return DMI_OK;
 }
 
