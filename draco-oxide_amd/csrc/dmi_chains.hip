@@ -24,6 +24,7 @@
 // Renormalisation: `while x ≥ f·2^T { x >>= 8 }`  ⇔  bytes = (bitlen(x/f) - (T-7)) >> 3      (T = 10 / 12)
 //     (x ≥ f·2^m ⇔ floor(x/f) ≥ 2^m, and floor(floor(x/2^8)/f) = floor(x/f) >> 8).
 #include "dmi_device.hpp"
+#include <cstring>
 
 namespace dmi {
 namespace {
@@ -47,10 +48,14 @@ __device__ __forceinline__ uint32_t flush_state(uint32_t s, uint8_t* out, uint64
 // ---- prep kernels ---------------------------------------------------------------------------------
 // Also writes one flag per batch of 64 records: "contains a frequency-1 symbol" (each wavefront covers one
 // aligned batch: the grid stride is a multiple of 256).
-__global__ __launch_bounds__(256) void k_rans_prep(const uint32_t* __restrict__ sym, uint64_t n, const RansEntry* __restrict__ table,
-                                                   RansEntry* __restrict__ rec, uint32_t* __restrict__ batch_flags) {
+__device__ __forceinline__ void k_rans_prep_body(const RansPrepArgs& a, const uint32_t blk_, const uint32_t nblk_) {
+  const uint32_t* __restrict__ sym = a.sym;
+  const uint64_t n = a.n;
+  const RansEntry* __restrict__ table = a.table;
+  RansEntry* __restrict__ rec = a.rec;
+  uint32_t* __restrict__ batch_flags = a.batch_flags;
   const uint64_t n_round = (n + 63) & ~(uint64_t)63;
-  for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < n_round; t += (uint64_t)gridDim.x * 256) {
+  for (uint64_t t = (uint64_t)blk_ * 256 + threadIdx.x; t < n_round; t += (uint64_t)nblk_ * 256) {
     RansEntry e{0u, 0u, 0u, 0u};
     if (t < n) { e = table[sym[n - 1 - t]]; rec[t] = e; }
     const unsigned long long any = __ballot((e.b >> 8) != 0);
@@ -59,26 +64,37 @@ __global__ __launch_bounds__(256) void k_rans_prep(const uint32_t* __restrict__ 
 }
 
 // Per-batch "contains a frequency-1 record" flags for a finished record stream (rABS streams).
-__global__ __launch_bounds__(256) void k_batch_flags(const RansEntry* __restrict__ rec, uint64_t n, uint32_t* __restrict__ batch_flags) {
+__device__ __forceinline__ void k_batch_flags_body(const BatchFlagsArgs& a, const uint32_t blk_, const uint32_t nblk_) {
+  const RansEntry* __restrict__ rec = a.rec;
+  const uint64_t n = a.n;
+  uint32_t* __restrict__ batch_flags = a.batch_flags;
   const uint64_t n_round = (n + 63) & ~(uint64_t)63;
-  for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < n_round; t += (uint64_t)gridDim.x * 256) {
+  for (uint64_t t = (uint64_t)blk_ * 256 + threadIdx.x; t < n_round; t += (uint64_t)nblk_ * 256) {
     const uint32_t b = (t < n) ? rec[t].b : 0u;
     const unsigned long long any = __ballot((b >> 8) != 0);
     if ((threadIdx.x & 63) == 0) batch_flags[t >> 6] = any != 0ull;
   }
 }
 
-__global__ __launch_bounds__(256) void k_bits_prep(const uint8_t* __restrict__ bits, uint64_t n, RansEntry e0, RansEntry e1, RansEntry* __restrict__ rec) {
-  for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (uint64_t)gridDim.x * 256) rec[t] = bits[t] ? e1 : e0;
+__device__ __forceinline__ void k_bits_prep_body(const BitsPrepArgs& a, const uint32_t blk_, const uint32_t nblk_) {
+  const uint8_t* __restrict__ bits = a.bits;
+  const uint64_t n = a.n;
+  const RansEntry e0 = a.e0, e1 = a.e1;
+  RansEntry* __restrict__ rec = a.rec;
+  for (uint64_t t = (uint64_t)blk_ * 256 + threadIdx.x; t < n; t += (uint64_t)nblk_ * 256) rec[t] = bits[t] ? e1 : e0;
 }
 
 // One wavefront per chunk of 4096 orientation flags {0 none, 1 false, 2 true}.  The coded bit of valid
 // entry j is (o[j] == o[j+1]) where o[j+1] is the next valid entry, or `true` after the last one.
 // chunk_info[c] = {compact offset of the chunk, value of the first valid entry after the chunk (1 if none)}.
-__global__ __launch_bounds__(64) void k_orient_prep(const uint8_t* __restrict__ orient, uint32_t n, const uint32_t* __restrict__ chunk_info,
-                                                    RansEntry e0, RansEntry e1, RansEntry* __restrict__ rec) {
+__device__ __forceinline__ void k_orient_prep_body(const OrientPrepArgs& a, const uint32_t blk_, const uint32_t nblk_) {
+  const uint8_t* __restrict__ orient = a.orient;
+  const uint32_t n = a.n;
+  const uint32_t* __restrict__ chunk_info = a.chunk_info;
+  const RansEntry e0 = a.e0, e1 = a.e1;
+  RansEntry* __restrict__ rec = a.rec;
   const uint32_t lane = threadIdx.x;
-  const uint32_t lo = blockIdx.x * 4096u;
+  const uint32_t lo = blk_ * 4096u;
   const uint32_t nb = (min(n, lo + 4096u) - lo + 63u) / 64u;   // batches in this chunk (≤ 64)
   // pass 1: valid count per batch → exclusive offsets (lane b owns batch b)
   uint32_t cnt = 0;
@@ -92,8 +108,8 @@ __global__ __launch_bounds__(64) void k_orient_prep(const uint8_t* __restrict__ 
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(excl, d, 64); if (lane >= (uint32_t)d) excl += t; }
   excl -= cnt;
-  const uint32_t chunk_off = chunk_info[2 * blockIdx.x];
-  uint32_t carry = chunk_info[2 * blockIdx.x + 1];   // value of the next valid entry after the batch being processed
+  const uint32_t chunk_off = chunk_info[2 * blk_];
+  uint32_t carry = chunk_info[2 * blk_ + 1];   // value of the next valid entry after the batch being processed
   // pass 2: batches from last to first so that the successor's value is known
   for (uint32_t bb = nb; bb-- > 0;) {
     const uint32_t i = lo + bb * 64u + lane;
@@ -317,22 +333,77 @@ __global__ __launch_bounds__(256) void k_copy_items(const CopyItem* __restrict__
   for (uint64_t v = lo + threadIdx.x; v < hi; v += 256) dst[v] = src[v];
 }
 
+// The inverse: pieces of one staging arena scattered to their device destinations (batch upload of the jobs' coding tables).
+__global__ __launch_bounds__(256) void k_scatter_items(const CopyItem* __restrict__ items, const uint8_t* __restrict__ arena) {
+  const CopyItem it = items[blockIdx.x];   // src = device destination, dst_offset = offset of the piece in the arena
+  const uint64_t vecs = it.bytes >> 4;
+  const uint4* __restrict__ src = reinterpret_cast<const uint4*>(arena + it.dst_offset);
+  uint4* __restrict__ dst = reinterpret_cast<uint4*>(const_cast<void*>(it.src));
+  for (uint64_t v = threadIdx.x; v < vecs; v += 256) dst[v] = src[v];
+}
+
 inline uint32_t grid256(uint64_t n) { uint64_t g = (n + 255) / 256; return (uint32_t)(g > 4096 ? 4096 : (g ? g : 1)); }
+
+#define DMI_PREP_KERNEL(NAME, BODY, ARGS, THREADS)                                                                                    \
+  __global__ __launch_bounds__(THREADS) void NAME(ARGS a) { BODY(a, blockIdx.x, gridDim.x); }                                         \
+  __global__ __launch_bounds__(THREADS) void NAME##_multi(const ARGS* __restrict__ items, const uint2* __restrict__ block_info,       \
+                                                          const uint32_t* __restrict__ item_blocks) {                                 \
+    const uint2 bi = block_info[blockIdx.x];                                                                                          \
+    BODY(items[bi.x], bi.y, item_blocks[bi.x]);                                                                                        \
+  }
+DMI_PREP_KERNEL(k_rans_prep, k_rans_prep_body, RansPrepArgs, 256)
+DMI_PREP_KERNEL(k_batch_flags, k_batch_flags_body, BatchFlagsArgs, 256)
+DMI_PREP_KERNEL(k_bits_prep, k_bits_prep_body, BitsPrepArgs, 256)
+DMI_PREP_KERNEL(k_orient_prep, k_orient_prep_body, OrientPrepArgs, 64)
+
+template <class Args>
+void emit_prep(int id, int level, const Args& a, uint32_t blocks, hipStream_t s) {
+  static_assert(sizeof(Args) <= sizeof(KernelStep::args), "KernelStep::args too small");
+  if (blocks == 0) return;
+  KernelStep st{};
+  st.id = id; st.level = level; st.blocks = blocks; st.lds = 0; st.args_size = (uint32_t)sizeof(Args);
+  std::memcpy(st.args, &a, sizeof(Args));
+  if (!step_sink_push(st)) launch_step(st, s);
+}
 
 }  // namespace
 
+void launch_prep_step(const KernelStep& st, hipStream_t s) {
+  switch (st.id) {
+    case K_RANS_PREP: hipLaunchKernelGGL(k_rans_prep, st.blocks, 256, 0, s, *reinterpret_cast<const RansPrepArgs*>(st.args)); break;
+    case K_BATCH_FLAGS: hipLaunchKernelGGL(k_batch_flags, st.blocks, 256, 0, s, *reinterpret_cast<const BatchFlagsArgs*>(st.args)); break;
+    case K_BITS_PREP: hipLaunchKernelGGL(k_bits_prep, st.blocks, 256, 0, s, *reinterpret_cast<const BitsPrepArgs*>(st.args)); break;
+    case K_ORIENT_PREP: hipLaunchKernelGGL(k_orient_prep, st.blocks, 64, 0, s, *reinterpret_cast<const OrientPrepArgs*>(st.args)); break;
+    default: break;
+  }
+}
+void launch_prep_steps_multi(int id, const void* items, const uint2* block_info, const uint32_t* item_blocks, uint32_t total_blocks, hipStream_t s) {
+  switch (id) {
+    case K_RANS_PREP: hipLaunchKernelGGL(k_rans_prep_multi, total_blocks, 256, 0, s, static_cast<const RansPrepArgs*>(items), block_info, item_blocks); break;
+    case K_BATCH_FLAGS: hipLaunchKernelGGL(k_batch_flags_multi, total_blocks, 256, 0, s, static_cast<const BatchFlagsArgs*>(items), block_info, item_blocks); break;
+    case K_BITS_PREP: hipLaunchKernelGGL(k_bits_prep_multi, total_blocks, 256, 0, s, static_cast<const BitsPrepArgs*>(items), block_info, item_blocks); break;
+    case K_ORIENT_PREP: hipLaunchKernelGGL(k_orient_prep_multi, total_blocks, 64, 0, s, static_cast<const OrientPrepArgs*>(items), block_info, item_blocks); break;
+    default: break;
+  }
+}
+
+// record prep: symbols / bits / orientation flags → coding records (level 0), then the per-batch frequency-1 flags of the rABS
+// record streams (level 1)
 void launch_rans_prep(const uint32_t* sym, uint64_t n, const RansEntry* table, RansEntry* rec, uint32_t* batch_flags, hipStream_t s) {
-  if (n) hipLaunchKernelGGL(k_rans_prep, grid256(n), 256, 0, s, sym, n, table, rec, batch_flags);
+  RansPrepArgs a{sym, table, rec, batch_flags, n};
+  emit_prep(K_RANS_PREP, 0, a, n ? grid256(n) : 0u, s);
 }
 void launch_bits_prep(const uint8_t* bits, uint64_t n, RansEntry e0, RansEntry e1, RansEntry* rec, hipStream_t s) {
-  if (n) hipLaunchKernelGGL(k_bits_prep, grid256(n), 256, 0, s, bits, n, e0, e1, rec);
+  BitsPrepArgs a{bits, rec, n, e0, e1};
+  emit_prep(K_BITS_PREP, 0, a, n ? grid256(n) : 0u, s);
 }
 void launch_orient_prep(const uint8_t* orient, uint32_t n, const uint32_t* chunk_info, RansEntry e0, RansEntry e1, RansEntry* rec, hipStream_t s) {
-  const uint32_t chunks = (n + 4095u) / 4096u;
-  if (chunks) hipLaunchKernelGGL(k_orient_prep, chunks, 64, 0, s, orient, n, chunk_info, e0, e1, rec);
+  OrientPrepArgs a{orient, chunk_info, rec, e0, e1, n, 0u};
+  emit_prep(K_ORIENT_PREP, 0, a, (n + 4095u) / 4096u, s);
 }
 void launch_batch_flags(const RansEntry* rec, uint64_t n, uint32_t* batch_flags, hipStream_t s) {
-  if (n) hipLaunchKernelGGL(k_batch_flags, grid256(n), 256, 0, s, rec, n, batch_flags);
+  BatchFlagsArgs a{rec, batch_flags, n};
+  emit_prep(K_BATCH_FLAGS, 1, a, n ? grid256(n) : 0u, s);
 }
 void launch_pack_streams(const ChainDesc* descs_dev, uint32_t n_streams, PackEntry* table, uint8_t* arena, hipStream_t s) {
   if (!n_streams) return;
@@ -341,6 +412,9 @@ void launch_pack_streams(const ChainDesc* descs_dev, uint32_t n_streams, PackEnt
 }
 void launch_copy_items(const CopyItem* items_dev, uint32_t n_items, uint8_t* arena, hipStream_t s) {
   if (n_items) hipLaunchKernelGGL(k_copy_items, dim3(n_items, kPackSplit), 256, 0, s, items_dev, arena);
+}
+void launch_scatter_items(const CopyItem* items_dev, uint32_t n_items, const uint8_t* arena, hipStream_t s) {
+  if (n_items) hipLaunchKernelGGL(k_scatter_items, n_items, 256, 0, s, items_dev, arena);
 }
 void launch_chains(const ChainDesc* descs_dev, uint32_t n_streams, hipStream_t s) {
   if (n_streams) hipLaunchKernelGGL(k_chains, n_streams, 128, 0, s, descs_dev);

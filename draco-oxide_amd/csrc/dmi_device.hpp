@@ -14,10 +14,12 @@ namespace dmi {
 // the sink, so that a batch driver can run the SAME phase of many jobs in one multi-item launch (launch_steps_multi).
 // `level` orders the steps of one job: steps of equal level are independent of each other.
 enum KernelId : int { K_RANGES, K_RANGES_FINAL, K_SEQ_QUANT, K_I32_FINAL, K_FUSED_PNU, K_FUSED_PN, K_FUSED_PU, K_FUSED_N,
-                      K_PAR1, K_PAR2, K_PAR3, K_PAR4, K_DELTA, K_TEX, K_ORIENT, K_HIST, K_COUNT };
+                      K_PAR1, K_PAR2, K_PAR3, K_PAR4, K_DELTA, K_TEX, K_ORIENT, K_HIST,
+                      K_RANS_PREP, K_BITS_PREP, K_ORIENT_PREP, K_BATCH_FLAGS /* record prep: dmi_chains.hip */, K_COUNT };
 constexpr int kStepLevels = 7;
 struct KernelStep { int id; int level; uint32_t blocks; uint32_t lds; uint32_t args_size; uint32_t pad; alignas(8) uint8_t args[640]; };
 void set_step_sink(std::vector<KernelStep>* sink);   // thread-local; nullptr = launch immediately
+bool step_sink_push(const KernelStep& st);           // true = a sink is set and took the step
 void launch_step(const KernelStep& st, hipStream_t s);
 // items: device array of the kernel's argument blocks; block_info[b] = {item, block within the item}; item_blocks[i] = its grid
 void launch_steps_multi(int id, const void* items, const uint2* block_info, const uint32_t* item_blocks, uint32_t total_blocks, uint32_t lds, hipStream_t s);
@@ -114,6 +116,13 @@ struct ChainDesc {
   uint32_t* ticks;          // optional: chain duration in 100 MHz ticks
 };
 void launch_chains(const ChainDesc* descs_dev, uint32_t n_streams, hipStream_t s);
+// argument blocks of the record-prep kernels (K_RANS_PREP … K_BATCH_FLAGS); launch_step / launch_steps_multi dispatch to these
+struct RansPrepArgs { const uint32_t* sym; const RansEntry* table; RansEntry* rec; uint32_t* batch_flags; uint64_t n; };
+struct BitsPrepArgs { const uint8_t* bits; RansEntry* rec; uint64_t n; RansEntry e0, e1; };
+struct OrientPrepArgs { const uint8_t* orient; const uint32_t* chunk_info; RansEntry* rec; RansEntry e0, e1; uint32_t n; uint32_t pad; };
+struct BatchFlagsArgs { const RansEntry* rec; uint32_t* batch_flags; uint64_t n; };
+void launch_prep_step(const KernelStep& st, hipStream_t s);
+void launch_prep_steps_multi(int id, const void* items, const uint2* block_info, const uint32_t* item_blocks, uint32_t total_blocks, hipStream_t s);
 // Batch read-back: pack the coded bytes of every stream into `arena` (16-byte aligned slots, in stream order);
 // table[k] = {offset, length, error} and table[n_streams].offset = total bytes.  Stream outputs must be allocated with
 // ≥ 16 bytes of slack (the copy moves whole 16-byte words).
@@ -121,6 +130,8 @@ struct PackEntry { uint64_t offset; uint32_t len; uint32_t err; };
 // items[k] = {device source (16-byte aligned), destination offset in `arena`, bytes (multiple of 16)}
 struct CopyItem { const void* src; uint64_t dst_offset; uint64_t bytes; };
 void launch_copy_items(const CopyItem* items_dev, uint32_t n_items, uint8_t* arena, hipStream_t s);
+// the inverse: arena[dst_offset .. +bytes) → items[k].src (a device destination)
+void launch_scatter_items(const CopyItem* items_dev, uint32_t n_items, const uint8_t* arena, hipStream_t s);
 void launch_pack_streams(const ChainDesc* descs_dev, uint32_t n_streams, PackEntry* table, uint8_t* arena, hipStream_t s);
 
 }  // namespace dmi

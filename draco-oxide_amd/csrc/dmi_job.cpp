@@ -122,6 +122,8 @@ struct dmi_job {
     std::vector<size_t> rans_off, aux_off;   // offsets into out_pinned
     std::vector<const uint8_t*> rans_ptr, aux_ptr;   // host addresses of the coded bytes (pinned memory)
     std::vector<uint32_t> rans_len, aux_len;
+    struct Pending { void* dst; const void* src; size_t bytes; };
+    std::vector<Pending> pending;   // host → device copies deferred to the batch driver (plan mode of phase B)
     std::vector<size_t> pin_off;
     std::vector<AuxInfo> aux;
     std::vector<ChainDesc> descs;
@@ -432,7 +434,7 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
       HIP_TRY(hipMemsetAsync(a.aux_rec.p, 0, a.aux_rec.bytes, s));
       if ((rc = a.aux_flags.alloc(((size_t)n / 64 + 4) * 4))) return rc;
       HIP_TRY(hipMemsetAsync(a.aux_flags.p, 0, a.aux_flags.bytes, s));
-      if ((rc = a.chunk_info.alloc((size_t)std::max(1u, orient_summary_blocks(n)) * 8))) return rc;
+      if ((rc = a.chunk_info.alloc((size_t)std::max(1u, orient_summary_blocks(n)) * 8 + 16))) return rc;
     }
     if (a.scheme == kNormal && a.fused_into < 0 && n) {   // fan rows: this table's fans, ranks in the parent position table
       const TableDev& pt = job->tables[job->atts[a.parent].table];
@@ -636,8 +638,15 @@ static int encode_phase_a(dmi_job* job, bool plan_only = false) {   // device: r
   return DMI_OK;
 }
 
-static int encode_phase_b(dmi_job* job) {   // host: table normalisation; device: coding records; fills job->run.descs
+static int encode_phase_b(dmi_job* job, bool plan_only = false) {   // host: table normalisation; device: coding records; fills job->run.descs
+  // plan_only: a step sink is set — launches are collected, uploads are deferred to job->run.pending: no HIP call is made
   hipStream_t s = job->stream;
+  job->run.pending.clear();
+  auto upload_table = [&](void* dst, const void* src, size_t bytes) -> int {
+    if (plan_only) { job->run.pending.push_back({dst, src, (bytes + 15) & ~(size_t)15}); return DMI_OK; }
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+    return DMI_OK;
+  };
   const uint32_t n_atts = (uint32_t)job->atts.size();
   uint8_t* pinned = job->readback ? job->readback : static_cast<uint8_t*>(job->pinned);
   // ---- stage 4 (host): normalise tables, build chain descriptors -----------------------------------------
@@ -662,7 +671,7 @@ static int encode_phase_b(dmi_job* job) {   // host: table normalisation; device
     std::vector<RansEntry>& rt = a.rt_host;
     rt.resize(a.ft.freq.size());
     for (size_t k = 0; k < rt.size(); ++k) rt[k] = make_rans_entry(a.ft.freq[k], a.ft.cum[k], a.ft.precision);
-    HIP_TRY(hipMemcpyAsync(a.rtable.p, rt.data(), rt.size() * sizeof(RansEntry), hipMemcpyHostToDevice, s));
+    { const int urc = upload_table(a.rtable.p, rt.data(), rt.size() * sizeof(RansEntry)); if (urc) return urc; }
     // symbols → coding records in coding order (data-parallel), consumed by the scalar chain
     launch_rans_prep(a.sym.as<uint32_t>(), a.n_sym, a.rtable.as<RansEntry>(), a.rec.as<RansEntry>(), a.batch_flags.as<uint32_t>(), s);
     ChainDesc d{};
@@ -708,7 +717,8 @@ static int encode_phase_b(dmi_job* job) {   // host: table normalisation; device
         for (uint32_t b = 0; b < nb; ++b) { info[2 * b] = off; off += sm[4 * b]; }
         uint32_t nextv = 1;   // `true` after the last valid entry
         for (uint32_t b = nb; b-- > 0;) { info[2 * b + 1] = nextv; if (sm[4 * b]) nextv = sm[4 * b + 1]; }
-        HIP_TRY(hipMemcpyAsync(a.chunk_info.p, info.data(), info.size() * 4, hipMemcpyHostToDevice, s));
+        info.resize((info.size() + 3) & ~(size_t)3, 0u);   // whole 16-byte words (the batch driver copies in uint4)
+        { const int urc = upload_table(a.chunk_info.p, info.data(), info.size() * 4); if (urc) return urc; }
         const uint32_t p0 = aux[i].zero_prob, f1 = 256u - p0;
         launch_orient_prep(a.aux.as<uint8_t>(), n, a.chunk_info.as<uint32_t>(), make_rans_entry(p0, f1, 8), make_rans_entry(f1, 0, 8), a.aux_rec.as<RansEntry>(), s);
         launch_batch_flags(a.aux_rec.as<RansEntry>(), len, a.aux_flags.as<uint32_t>(), s);
@@ -982,10 +992,53 @@ static void release_batch_arena(BatchArena* a) {
   a->in_use = false;
 }
 
+// A batch's launch plan: the KernelSteps of many jobs grouped by (level, kernel); argument blocks, block maps and any extra
+// tables go to the device in ONE copy, then every group is one multi-item launch.
+struct BatchPlan {
+  struct Group { int level, id; uint32_t lds = 0, total_blocks = 0; std::vector<const KernelStep*> items; size_t off_args = 0, off_info = 0, off_blocks = 0; };
+  std::vector<Group> groups;
+  size_t bytes = 0;
+  static size_t align(size_t v) { return (v + 255) & ~(size_t)255; }
+  void add(const std::vector<std::vector<KernelStep>>& steps, int n_levels) {
+    for (int level = 0; level < n_levels; ++level) {
+      for (int id = 0; id < K_COUNT; ++id) {
+        Group g;
+        g.level = level; g.id = id;
+        for (const auto& job_steps : steps)
+          for (const KernelStep& st : job_steps)
+            if (st.level == level && st.id == id) { g.items.push_back(&st); g.total_blocks += st.blocks; g.lds = std::max(g.lds, st.lds); }
+        if (!g.items.empty()) groups.push_back(std::move(g));
+      }
+    }
+    for (Group& g : groups) {
+      g.off_args = bytes; bytes = align(bytes + (size_t)g.items.size() * g.items[0]->args_size);
+      g.off_info = bytes; bytes = align(bytes + (size_t)g.total_blocks * sizeof(uint2));
+      g.off_blocks = bytes; bytes = align(bytes + g.items.size() * sizeof(uint32_t));
+    }
+  }
+  size_t reserve(size_t n) { const size_t off = bytes; bytes = align(bytes + n); return off; }
+  void fill(uint8_t* ph) const {
+    for (const Group& g : groups) {
+      const size_t asz = g.items[0]->args_size;
+      uint2* info = reinterpret_cast<uint2*>(ph + g.off_info);
+      uint32_t* blocks = reinterpret_cast<uint32_t*>(ph + g.off_blocks);
+      uint32_t at = 0;
+      for (size_t i = 0; i < g.items.size(); ++i) {
+        std::memcpy(ph + g.off_args + i * asz, g.items[i]->args, asz);
+        blocks[i] = g.items[i]->blocks;
+        for (uint32_t b = 0; b < g.items[i]->blocks; ++b) info[at++] = make_uint2((uint32_t)i, b);
+      }
+    }
+  }
+  void launch(const uint8_t* pd, hipStream_t s) const {
+    for (const Group& g : groups)
+      launch_steps_multi(g.id, pd + g.off_args, reinterpret_cast<const uint2*>(pd + g.off_info), reinterpret_cast<const uint32_t*>(pd + g.off_blocks), g.total_blocks, g.lds, s);
+  }
+};
+
 // Phase A of a whole batch in ONE launch per (level, kernel): every job's launches are collected as KernelSteps (the same
-// code path as a single encode, with a sink set), grouped, their argument blocks and block maps uploaded in one copy, and each
-// group served by a multi-item kernel; the slabs come back packed in one copy.  Small meshes are otherwise bound by the ≈2.4 µs
-// the GPU spends per tiny kernel (9 per job).
+// code path as a single encode, with a sink set), grouped, uploaded in one copy and served by multi-item kernels; the slabs
+// come back packed in one copy.  Small meshes are otherwise bound by the ≈2.4 µs the GPU spends per tiny kernel (9 per job).
 static int run_phase_a_batched(dmi_job** jobs, const std::vector<uint32_t>& which, BatchArena* arena, hipStream_t s) {
   const uint32_t n = (uint32_t)which.size();
   if (!n) return DMI_OK;
@@ -997,59 +1050,62 @@ static int run_phase_a_batched(dmi_job** jobs, const std::vector<uint32_t>& whic
     set_step_sink(nullptr);
     if (rc) return rc;
   }
-  struct Group { int level, id; uint32_t lds = 0, total_blocks = 0; std::vector<const KernelStep*> items; size_t off_args = 0, off_info = 0, off_blocks = 0; };
-  std::vector<Group> groups;
-  for (int level = 0; level < kStepLevels; ++level) {
-    for (int id = 0; id < K_COUNT; ++id) {
-      Group g;
-      g.level = level; g.id = id;
-      for (uint32_t k = 0; k < n; ++k)
-        for (const KernelStep& st : steps[k])
-          if (st.level == level && st.id == id) { g.items.push_back(&st); g.total_blocks += st.blocks; g.lds = std::max(g.lds, st.lds); }
-      if (!g.items.empty()) groups.push_back(std::move(g));
-    }
-  }
-  auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  size_t plan_bytes = 0;
-  for (Group& g : groups) {
-    g.off_args = plan_bytes; plan_bytes = align(plan_bytes + (size_t)g.items.size() * g.items[0]->args_size);
-    g.off_info = plan_bytes; plan_bytes = align(plan_bytes + (size_t)g.total_blocks * sizeof(uint2));
-    g.off_blocks = plan_bytes; plan_bytes = align(plan_bytes + g.items.size() * sizeof(uint32_t));
-  }
-  // slab read-back layout
+  BatchPlan plan;
+  plan.add(steps, kStepLevels);
   std::vector<CopyItem> copies(n);
   size_t slab_bytes = 0;
   for (uint32_t k = 0; k < n; ++k) {
     dmi_job* job = jobs[which[k]];
     copies[k] = CopyItem{job->slab.p, (uint64_t)slab_bytes, (uint64_t)(job->slab.bytes & ~(size_t)15)};
-    slab_bytes = align(slab_bytes + job->slab.bytes);
+    slab_bytes = BatchPlan::align(slab_bytes + job->slab.bytes);
   }
-  const size_t off_copies = plan_bytes;
-  plan_bytes = align(plan_bytes + copies.size() * sizeof(CopyItem));
+  const size_t off_copies = plan.reserve(copies.size() * sizeof(CopyItem));
   int rc;
-  if ((rc = BatchArena::reserve_pair(arena->plan_host, arena->plan_dev, arena->plan_cap, plan_bytes))) return rc;
+  if ((rc = BatchArena::reserve_pair(arena->plan_host, arena->plan_dev, arena->plan_cap, plan.bytes))) return rc;
   if ((rc = BatchArena::reserve_pair(arena->slabs_host, arena->slabs_dev, arena->slabs_cap, slab_bytes))) return rc;
   uint8_t* ph = static_cast<uint8_t*>(arena->plan_host);
-  for (const Group& g : groups) {
-    const size_t asz = g.items[0]->args_size;
-    uint2* info = reinterpret_cast<uint2*>(ph + g.off_info);
-    uint32_t* blocks = reinterpret_cast<uint32_t*>(ph + g.off_blocks);
-    uint32_t at = 0;
-    for (size_t i = 0; i < g.items.size(); ++i) {
-      std::memcpy(ph + g.off_args + i * asz, g.items[i]->args, asz);
-      blocks[i] = g.items[i]->blocks;
-      for (uint32_t b = 0; b < g.items[i]->blocks; ++b) info[at++] = make_uint2((uint32_t)i, b);
-    }
-  }
+  plan.fill(ph);
   std::memcpy(ph + off_copies, copies.data(), copies.size() * sizeof(CopyItem));
-  HIP_TRY(hipMemcpyAsync(arena->plan_dev, arena->plan_host, plan_bytes, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(arena->plan_dev, arena->plan_host, plan.bytes, hipMemcpyHostToDevice, s));
   const uint8_t* pd = static_cast<const uint8_t*>(arena->plan_dev);
-  for (const Group& g : groups)
-    launch_steps_multi(g.id, pd + g.off_args, reinterpret_cast<const uint2*>(pd + g.off_info), reinterpret_cast<const uint32_t*>(pd + g.off_blocks), g.total_blocks, g.lds, s);
+  plan.launch(pd, s);
   launch_copy_items(reinterpret_cast<const CopyItem*>(pd + off_copies), n, static_cast<uint8_t*>(arena->slabs_dev), s);
   HIP_TRY(hipMemcpyAsync(arena->slabs_host, arena->slabs_dev, slab_bytes, hipMemcpyDeviceToHost, s));
   for (uint32_t k = 0; k < n; ++k) jobs[which[k]]->readback = static_cast<uint8_t*>(arena->slabs_host) + copies[k].dst_offset;
   HIP_TRY(hipStreamSynchronize(s));
+  return DMI_OK;
+}
+
+// Record prep of a whole batch (after every job's tables were normalised on the host, in plan mode): the coding tables of all
+// jobs travel in one copy and are scattered to their buffers by one kernel; then one launch per prep kernel.
+static int run_phase_b_batched(dmi_job** jobs, const std::vector<uint32_t>& which, const std::vector<std::vector<KernelStep>>& steps, BatchArena* arena, hipStream_t s) {
+  if (which.empty()) return DMI_OK;
+  BatchPlan plan;
+  plan.add(steps, 2);
+  std::vector<CopyItem> items;
+  size_t table_bytes = 0;
+  for (uint32_t j : which)
+    for (const auto& p : jobs[j]->run.pending) { items.push_back(CopyItem{p.dst, 0, (uint64_t)p.bytes}); table_bytes += (p.bytes + 255) & ~(size_t)255; }
+  const size_t off_items = plan.reserve(items.size() * sizeof(CopyItem));
+  const size_t off_tables = plan.reserve(table_bytes);
+  int rc;
+  if ((rc = BatchArena::reserve_pair(arena->plan_host, arena->plan_dev, arena->plan_cap, plan.bytes))) return rc;
+  uint8_t* ph = static_cast<uint8_t*>(arena->plan_host);
+  plan.fill(ph);
+  {
+    size_t at = off_tables, k = 0;
+    for (uint32_t j : which)
+      for (const auto& p : jobs[j]->run.pending) {
+        std::memcpy(ph + at, p.src, p.bytes);   // (sources are padded to whole 16-byte words by their owners)
+        items[k++].dst_offset = at;
+        at += (p.bytes + 255) & ~(size_t)255;
+      }
+  }
+  std::memcpy(ph + off_items, items.data(), items.size() * sizeof(CopyItem));
+  HIP_TRY(hipMemcpyAsync(arena->plan_dev, arena->plan_host, plan.bytes, hipMemcpyHostToDevice, s));
+  const uint8_t* pd = static_cast<const uint8_t*>(arena->plan_dev);
+  launch_scatter_items(reinterpret_cast<const CopyItem*>(pd + off_items), (uint32_t)items.size(), pd, s);
+  plan.launch(pd, s);
   return DMI_OK;
 }
 
@@ -1111,6 +1167,7 @@ int dmi_jobs_encode(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
   HIP_TRY(hipSetDevice(device));
   if ((rc = run_phase_a_batched(jobs, batched, arena, s))) return rc;
   const auto t1 = now();
+  std::vector<std::vector<KernelStep>> b_steps(n);   // record-prep steps of the batched jobs (filled by the workers)
   std::vector<uint32_t> order(n);
   for (uint32_t j = 0; j < n; ++j) order[j] = j;
   auto job_size = [&](uint32_t j) { uint64_t t = 0; for (auto& a : jobs[j]->atts) t += a.n_sym; return t; };
@@ -1133,7 +1190,9 @@ int dmi_jobs_encode(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
         const auto x0 = std::chrono::steady_clock::now();
         if (!is_batched[j] && hipStreamSynchronize(job->stream) != hipSuccess) return bail(DMI_ERR_HIP, "hipStreamSynchronize");
         const auto x1 = std::chrono::steady_clock::now();
-        int r = encode_phase_b(job);
+        int r;
+        if (is_batched[j]) { set_step_sink(&b_steps[j]); r = encode_phase_b(job, true); set_step_sink(nullptr); }
+        else r = encode_phase_b(job);
         if (r) return bail(r, g_last_error);
         const auto x2 = std::chrono::steady_clock::now();
         wait_ms += std::chrono::duration<double, std::milli>(x1 - x0).count();
@@ -1151,6 +1210,12 @@ int dmi_jobs_encode(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
       for (auto& x : th) x.join();
     }
     for (uint32_t t = 0; t < n_threads; ++t) if (rcs[t]) return fail(rcs[t], errs[t]);
+  }
+  {
+    std::vector<std::vector<KernelStep>> only;
+    only.reserve(batched.size());
+    for (uint32_t j : batched) only.push_back(std::move(b_steps[j]));
+    if ((rc = run_phase_b_batched(jobs, batched, only, arena, s))) return rc;
   }
   const auto t4 = now();
   std::vector<ChainDesc> all;

@@ -1093,6 +1093,7 @@ void emit(int id, int level, const Args& a, uint32_t blocks, uint32_t lds, hipSt
 }  // namespace
 
 void set_step_sink(std::vector<KernelStep>* sink) { g_step_sink = sink; }
+bool step_sink_push(const KernelStep& st) { if (!g_step_sink) return false; g_step_sink->push_back(st); return true; }
 
 #define DMI_CASE(ID, NAME, ARGS, THREADS) \
   case ID: hipLaunchKernelGGL(NAME, st.blocks, THREADS, st.lds, s, *reinterpret_cast<const ARGS*>(st.args)); break;
@@ -1119,14 +1120,14 @@ void set_step_sink(std::vector<KernelStep>* sink) { g_step_sink = sink; }
 void launch_step(const KernelStep& st, hipStream_t s) {
   switch (st.id) {
     DMI_ALL_KERNELS(DMI_CASE)
-    default: break;
+    default: launch_prep_step(st, s); break;
   }
 }
 void launch_steps_multi(int id, const void* items, const uint2* block_info, const uint32_t* item_blocks, uint32_t total_blocks, uint32_t lds, hipStream_t s) {
   if (!total_blocks) return;
   switch (id) {
     DMI_ALL_KERNELS(DMI_CASE_MULTI)
-    default: break;
+    default: launch_prep_steps_multi(id, items, block_info, item_blocks, total_blocks, s); break;
   }
 }
 
