@@ -264,6 +264,48 @@ def test_random_triangle_soup_bit_exact(seed):
     _assert_same(dmi.encode_mesh(mesh), want, f"soup {seed}")
 
 
+def test_mixed_batch_seams_custom_attributes_and_high_valence():
+    """dmi_jobs_encode over meshes that take every kernel family: seam-free (fused sweep), UV / normal seams (per-attribute
+    kernels, lone-normal sweep), a ToBits custom attribute (mid-phase host wait ⇒ that job keeps its own launches), fan rows
+    beyond their capacity.  Each output must equal the single-job result and the oracle's."""
+    meshes, wants = [], []
+    for seed in (2, 4, 6):
+        m, sess = _soup_mesh(seed, uv_per_corner=True)
+        try:
+            wants.append(sess.encode())
+            meshes.append(m)
+        except orc.OracleError:
+            pass
+    for v, cs, w in ((9, True, False), (13, False, True), (5, True, True)):
+        m = _cones(v, cs, w, seed=v)
+        meshes.append(m)
+        wants.append(oracle_from_product_mesh(m).encode())
+    for n, ob in ((21, False), (34, True)):
+        m = synth.torus_mesh(n, seed=77 + n, open_boundary=ob)
+        meshes.append(m)
+        wants.append(oracle_from_product_mesh(m).encode())
+    # per-corner custom ids + a colour attribute
+    faces, pos, nrm, uv = synth.torus_grid(14)
+    corner = faces.ravel()
+    b = dmi.MeshBuilder()
+    pid = b.add_attribute(pos[corner], dmi.ATT_POSITION)
+    b.add_attribute(uv[corner], dmi.ATT_TEXCOORD, dmi.DOMAIN_CORNER, parents=[pid])
+    feat = (np.arange(len(corner)) // 12).astype(np.uint32).reshape(-1, 1)
+    b.add_attribute(feat, dmi.ATT_CUSTOM, dmi.DOMAIN_CORNER)
+    f2 = np.arange(len(corner), dtype=np.uint32).reshape(-1, 3)
+    b.set_connectivity_attribute(f2)
+    meshes.append(b.build())
+    wants.append(orc.Session.from_arrays(f2, [dict(data=pos[corner], type=orc.POSITION), dict(data=uv[corner], type=orc.TEXCOORD, domain=orc.DOM_CORNER, parents=[0]),
+                                              dict(data=feat, type=orc.CUSTOM, domain=orc.DOM_CORNER)]).encode())
+    jobs = dmi.meshes_prepare(meshes)
+    outs = dmi.jobs_encode(jobs)
+    for k, (j, o, want) in enumerate(zip(jobs, outs, wants)):
+        _assert_same(j.header_and_connectivity + o, want, f"mixed batch item {k}")
+        assert o == j.encode()
+    for j in jobs:
+        j.close()
+
+
 def test_high_valence_fan_and_disjoint_components():
     # a 400-triangle cone (one vertex of valence 400) next to a separate small grid
     k = 400
