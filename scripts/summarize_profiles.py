@@ -34,7 +34,7 @@ for n in sorted(set(F) | set(W)):
     f, w = F.get(n, [0]), W.get(n, [0])
     fa, wa = sum(f) / len(f) * 1024 / 1e6, sum(w) / len(w) * 1024 / 1e6
     lines.append(f"{n}, {len(f)}, {fa:.2f}, {2*fa:.2f}, {wa:.2f}")
-    if n in PASS:
+    if n in PASS or n.startswith("k_predict_fused") or n.startswith("k_pred_parallelogram"):
         tf += fa * len(f) / pmc_steps
         tw += wa * len(w) / pmc_steps
 lines.append(f"# quantize+predict pass per step: fetch {tf:.1f} MB raw / {2*tf:.1f} MB doubled, write {tw:.1f} MB")
