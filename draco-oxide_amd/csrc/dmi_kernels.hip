@@ -491,7 +491,19 @@ __device__ __forceinline__ uint64_t int_sqrt(uint64_t value) {
 // General form (any i32 operands, wrapping i64 arithmetic exactly as the reference's release build): cu = the entry's
 // own UV, nu / pu = UVs of the next / previous corner's vertex (both coded), cp / np / pp = the three quantised
 // positions (get_position_for_vertex :22-30).  Returns false when the fallback must be used.
-__device__ __noinline__ bool texcoord_predict_general(const int32_t (&cu)[2], const int32_t (&nuv)[2], const int32_t (&puv)[2], const int32_t (&cpi)[3],
+// (all operands and results travel by value: references to the callers' arrays would force them into scratch memory on every
+// entry — 64 bytes of private-segment stores per vertex, ≈ 0.3 GB of HBM writes on the 10M workload — even though this
+// out-of-line form almost never runs)
+struct TexPred { int32_t pred0, pred1; uint32_t oflag; uint32_t ok; };
+__device__ __noinline__ TexPred texcoord_predict_general_v(int32_t cu0, int32_t cu1, int32_t nuv0, int32_t nuv1, int32_t puv0, int32_t puv1, int32_t cp0, int32_t cp1,
+                                                          int32_t cp2, int32_t np0, int32_t np1, int32_t np2, int32_t pp0, int32_t pp1, int32_t pp2);
+__device__ __forceinline__ bool texcoord_predict_general(const int32_t (&cu)[2], const int32_t (&nuv)[2], const int32_t (&puv)[2], const int32_t (&cpi)[3],
+                                                        const int32_t (&npi)[3], const int32_t (&ppi)[3], int32_t& pred0, int32_t& pred1, uint8_t& oflag) {
+  const TexPred r = texcoord_predict_general_v(cu[0], cu[1], nuv[0], nuv[1], puv[0], puv[1], cpi[0], cpi[1], cpi[2], npi[0], npi[1], npi[2], ppi[0], ppi[1], ppi[2]);
+  if (r.ok) { pred0 = r.pred0; pred1 = r.pred1; if (r.oflag) oflag = (uint8_t)r.oflag; }
+  return r.ok != 0;
+}
+__device__ __forceinline__ bool texcoord_predict_general_impl(const int32_t (&cu)[2], const int32_t (&nuv)[2], const int32_t (&puv)[2], const int32_t (&cpi)[3],
                                                  const int32_t (&npi)[3], const int32_t (&ppi)[3], int32_t& pred0, int32_t& pred1, uint8_t& oflag) {
   const int64_t nu0 = nuv[0], nu1 = nuv[1], pu0 = puv[0], pu1 = puv[1];
   if (nu0 == pu0 && nu1 == pu1) { pred0 = (int32_t)pu0; pred1 = (int32_t)pu1; return true; }   // degenerate: identical neighbour UVs
@@ -524,6 +536,16 @@ __device__ __noinline__ bool texcoord_predict_general(const int32_t (&cu)[2], co
   if (da < db) { oflag = 2; pred0 = (int32_t)a0; pred1 = (int32_t)a1; }
   else { oflag = 1; pred0 = (int32_t)b0; pred1 = (int32_t)b1; }
   return true;
+}
+
+__device__ __noinline__ TexPred texcoord_predict_general_v(int32_t cu0, int32_t cu1, int32_t nuv0, int32_t nuv1, int32_t puv0, int32_t puv1, int32_t cp0, int32_t cp1,
+                                                          int32_t cp2, int32_t np0, int32_t np1, int32_t np2, int32_t pp0, int32_t pp1, int32_t pp2) {
+  const int32_t cu[2] = {cu0, cu1}, nuv[2] = {nuv0, nuv1}, puv[2] = {puv0, puv1}, cp[3] = {cp0, cp1, cp2}, np[3] = {np0, np1, np2}, pp[3] = {pp0, pp1, pp2};
+  TexPred r{0, 0, 0u, 0u};
+  uint8_t oflag = 0;
+  r.ok = texcoord_predict_general_impl(cu, nuv, puv, cp, np, pp, r.pred0, r.pred1, oflag) ? 1u : 0u;
+  r.oflag = oflag;
+  return r;
 }
 
 // a / d (truncating) for a divisor shared by several divisions: inv = 1.0 / (double)d is formed once.  |a|, d < 2^31: one
