@@ -45,6 +45,11 @@ __device__ __forceinline__ uint32_t flush_state(uint32_t s, uint8_t* out, uint64
   return nb;
 }
 
+// select between two coding records field by field (a struct-valued ?: goes through private memory)
+__device__ __forceinline__ RansEntry pick(bool one, const RansEntry& e0, const RansEntry& e1) {
+  return RansEntry{one ? e1.m : e0.m, one ? e1.b : e0.b, one ? e1.d : e0.d, one ? e1.c : e0.c};
+}
+
 // ---- prep kernels ---------------------------------------------------------------------------------
 // Also writes one flag per batch of 64 records: "contains a frequency-1 symbol" (each wavefront covers one
 // aligned batch: the grid stride is a multiple of 256).
@@ -81,7 +86,7 @@ __device__ __forceinline__ void k_bits_prep_body(const BitsPrepArgs& a, const ui
   const uint64_t n = a.n;
   const RansEntry e0 = a.e0, e1 = a.e1;
   RansEntry* __restrict__ rec = a.rec;
-  for (uint64_t t = (uint64_t)blk_ * 256 + threadIdx.x; t < n; t += (uint64_t)nblk_ * 256) rec[t] = bits[t] ? e1 : e0;
+  for (uint64_t t = (uint64_t)blk_ * 256 + threadIdx.x; t < n; t += (uint64_t)nblk_ * 256) rec[t] = pick(bits[t] != 0, e0, e1);
 }
 
 // One wavefront per chunk of 4096 orientation flags {0 none, 1 false, 2 true}.  The coded bit of valid
@@ -123,7 +128,7 @@ __device__ __forceinline__ void k_orient_prep_body(const OrientPrepArgs& a, cons
     if (f != 0) {
       const uint32_t mine = (f == 2);
       const uint32_t at = chunk_off + rl(excl, bb) + lanes_below(valid);
-      rec[at] = (mine == nxt) ? e1 : e0;
+      rec[at] = pick(mine == nxt, e0, e1);
     }
     carry = (uint32_t)((ones >> (__ffsll((long long)valid) - 1)) & 1ull);
   }
