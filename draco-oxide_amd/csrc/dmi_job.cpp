@@ -139,6 +139,17 @@ struct dmi_job {
 
 namespace {
 
+// [0, n) in contiguous slices on up to 16 host threads (large, embarrassingly parallel index loops of job creation)
+template <class Fn>
+void parallel_for(size_t n, Fn&& fn) {
+  unsigned hw = std::thread::hardware_concurrency();
+  const size_t n_threads = n < (1u << 20) ? 1 : std::max<size_t>(1, std::min<size_t>({hw ? hw : 4u, 16u, n >> 18}));
+  if (n_threads == 1) { fn((size_t)0, n); return; }
+  std::vector<std::thread> th;
+  for (size_t t = 0; t < n_threads; ++t) th.emplace_back([&, t] { fn(n * t / n_threads, n * (t + 1) / n_threads); });
+  for (auto& x : th) x.join();
+}
+
 int upload(DevMem& m, const void* src, size_t bytes, hipStream_t s) {
   int rc = m.alloc(bytes);
   if (rc) return rc;
@@ -288,6 +299,9 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
   int rc = validate_and_plan(atts, n_atts, cfg, job->atts);
   if (rc) return rc;
 
+  const bool trace_create = std::getenv("DMI_TRACE") != nullptr;
+  const auto tc0 = std::chrono::steady_clock::now();
+  auto since_ms = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
   const uint32_t F = tables[0].num_faces;
   const size_t C = (size_t)F * 3;
   for (uint32_t i = 0; i < n_atts; ++i) {
@@ -334,47 +348,66 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
     t.n_seq = n_seq;
     seq_of[i] = seq;
   }
+  const double t_seq = since_ms(tc0);
   {
     // face order from table 0 (the universal table)
-    std::vector<uint32_t> rank0(tables[0].num_vertices, kNone);
-    for (uint32_t k = 0; k < job->tables[0].n_seq; ++k) rank0[tables[0].corner_to_vertex[seq_of[0][k]]] = k;
+    // (scratch arrays are allocated uninitialised and first touched by the threads that fill them)
+    auto raw_u32 = [](size_t n) { return std::unique_ptr<uint32_t[]>(new uint32_t[n ? n : 1]); };
+    auto fill_none = [](uint32_t* p, size_t n) { parallel_for(n, [&](size_t lo, size_t hi) { std::fill(p + lo, p + hi, kNone); }); };
+    auto rank0_buf = raw_u32(tables[0].num_vertices);
+    uint32_t* rank0 = rank0_buf.get();
+    fill_none(rank0, tables[0].num_vertices);
+    parallel_for(job->tables[0].n_seq, [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) rank0[tables[0].corner_to_vertex[seq_of[0][k]]] = (uint32_t)k; });
     const uint32_t nkeys = job->tables[0].n_seq + 1;   // key n_seq: faces none of whose vertices was coded
-    std::vector<uint32_t> key(F), start(nkeys + 1, 0);
-    for (uint32_t f = 0; f < F; ++f) {
-      uint32_t m = kNone;
-      for (int k = 0; k < 3; ++k) m = std::min(m, rank0[tables[0].corner_to_vertex[3 * (size_t)f + k]]);
-      key[f] = (m == kNone) ? nkeys - 1 : m;
-      ++start[key[f] + 1];
-    }
+    auto key_buf = raw_u32(F);
+    uint32_t* key = key_buf.get();
+    std::vector<uint32_t> start(nkeys + 1, 0);
+    parallel_for(F, [&](size_t lo, size_t hi) {
+      for (size_t f = lo; f < hi; ++f) {
+        uint32_t m = kNone;
+        for (int k = 0; k < 3; ++k) m = std::min(m, rank0[tables[0].corner_to_vertex[3 * f + k]]);
+        key[f] = (m == kNone) ? nkeys - 1 : m;
+      }
+    });
+    for (uint32_t f = 0; f < F; ++f) ++start[key[f] + 1];
     for (uint32_t k = 0; k < nkeys; ++k) start[k + 1] += start[k];
-    std::vector<uint32_t> new_face(F);
+    auto new_face_buf = raw_u32(F);
+    uint32_t* new_face = new_face_buf.get();
     for (uint32_t f = 0; f < F; ++f) new_face[f] = start[key[f]]++;
     auto map_corner = [&](uint32_t c) { return c == kNone ? kNone : 3u * new_face[c / 3u] + c % 3u; };
-    std::vector<uint32_t> tmp(C), tmp2(C);
-    std::vector<uint32_t> rank, seq2;
+    auto tmp_buf = raw_u32(C), tmp2_buf = raw_u32(C);
+    uint32_t* tmp = tmp_buf.get();
+    uint32_t* tmp2 = tmp2_buf.get();
+    std::unique_ptr<uint32_t[]> rank_buf;
+    std::vector<uint32_t> seq2;
     for (uint32_t i = 0; i < n_atts; ++i) {
       TableDev& t = job->tables[i];
       if (t.alias_of >= 0) continue;
-      rank.assign(t.V, kNone);
-      for (uint32_t k = 0; k < t.n_seq; ++k) rank[tables[i].corner_to_vertex[seq_of[i][k]]] = k;
-      for (size_t c = 0; c < C; ++c) {
-        const uint32_t c2 = map_corner((uint32_t)c);
-        tmp[c2] = rank[tables[i].corner_to_vertex[c]];
-        tmp2[c2] = map_corner(tables[i].opposite[c]);
-      }
-      if ((rc = upload(t.c2r, tmp.data(), C * 4, s))) return rc;
-      if ((rc = upload(t.opp, tmp2.data(), C * 4, s))) return rc;
+      rank_buf = raw_u32(t.V);
+      uint32_t* rank = rank_buf.get();
+      fill_none(rank, t.V);
+      parallel_for(t.n_seq, [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) rank[tables[i].corner_to_vertex[seq_of[i][k]]] = (uint32_t)k; });
+      parallel_for(C, [&](size_t lo, size_t hi) {
+        for (size_t c = lo; c < hi; ++c) {
+          const uint32_t c2 = map_corner((uint32_t)c);
+          tmp[c2] = rank[tables[i].corner_to_vertex[c]];
+          tmp2[c2] = map_corner(tables[i].opposite[c]);
+        }
+      });
+      if ((rc = upload(t.c2r, tmp, C * 4, s))) return rc;
+      if ((rc = upload(t.opp, tmp2, C * 4, s))) return rc;
       seq2.resize(t.n_seq);
-      for (uint32_t k = 0; k < t.n_seq; ++k) seq2[k] = map_corner(seq_of[i][k]);
+      parallel_for(t.n_seq, [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) seq2[k] = map_corner(seq_of[i][k]); });
       if ((rc = upload(t.seq, seq2.data(), (size_t)t.n_seq * 4, s))) return rc;
       // the point every sequence entry stands for (attribute_encoder.rs:332-338 reads attribute.get(point_idx(c)))
       t.s2p_host.resize(t.n_seq);
-      for (uint32_t k = 0; k < t.n_seq; ++k) t.s2p_host[k] = tables[0].corner_to_point[seq_of[i][k]];
+      parallel_for(t.n_seq, [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) t.s2p_host[k] = tables[0].corner_to_point[seq_of[i][k]]; });
       if ((rc = upload(t.s2p, t.s2p_host.data(), (size_t)t.n_seq * 4, s))) return rc;
       HIP_TRY(hipStreamSynchronize(s));   // tmp/tmp2/seq2 are reused
     }
   }
 
+  const double t_relabel = since_ms(tc0) - t_seq;
   // Seam-free fast path: a normal / texture-coordinate attribute coded on the same corner table as its parent
   // position attribute (3 components, parallelogram) is predicted together with it in one sweep (k_predict_fused).
   if (!std::getenv("DMI_NO_FUSED")) {
@@ -482,6 +515,7 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
     job->have_events = true;
   }
   HIP_TRY(hipStreamSynchronize(s));
+  if (trace_create) std::fprintf(stderr, "[dmi] job create (%u faces): sequences %.1f ms, relabel + table uploads %.1f, attribute uploads + buffers + fan rows %.1f\n", F, t_seq, t_relabel, since_ms(tc0) - t_seq - t_relabel);
   *job_out = job.release();
   return DMI_OK;
 }
