@@ -1245,6 +1245,7 @@ int dmi_jobs_encode(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
     }
     for (uint32_t t = 0; t < n_threads; ++t) if (rcs[t]) return fail(rcs[t], errs[t]);
   }
+  const auto t3 = now();
   {
     std::vector<std::vector<KernelStep>> only;
     only.reserve(batched.size());
@@ -1281,7 +1282,7 @@ int dmi_jobs_encode(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
   for (uint32_t j = 0; j < n; ++j) if ((rc = encode_phase_c_packed(jobs[j], table, first_desc[j], static_cast<const uint8_t*>(arena->bytes_host)))) return rc;
   const auto t6 = now();
   if ((rc = parallel([&](uint32_t j) { return encode_phase_c3(jobs[j], &outs[j]); }, false))) return rc;
-  if (trace) std::fprintf(stderr, "[dmi] batch of %u (%zu with batched phases) on %u host threads: data-parallel phases %.2f ms, tables + record prep %.2f, chains (%zu streams, one launch) %.2f, packed read-back %.2f, splice %.2f\n", n, batched.size(), n_threads, ms(t0, t1), ms(t1, t4), all.size(), ms(t4, t5), ms(t5, t6), ms(t6, now()));
+  if (trace) std::fprintf(stderr, "[dmi] batch of %u (%zu with batched phases) on %u host threads: data-parallel phases %.2f ms, tables (host threads) %.2f + record prep plan/upload/launch %.2f, chains (%zu streams, one launch) %.2f, packed read-back %.2f, splice %.2f\n", n, batched.size(), n_threads, ms(t0, t1), ms(t1, t3), ms(t3, t4), all.size(), ms(t4, t5), ms(t5, t6), ms(t6, now()));
   return DMI_OK;
 }
 
