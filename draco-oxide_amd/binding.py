@@ -58,6 +58,10 @@ class _Mesh(C.Structure):
     _fields_ = [("faces", C.c_void_p), ("num_faces", C.c_uint32), ("atts", C.POINTER(_Attribute)), ("num_atts", C.c_uint32)]
 
 
+class _BatchItem(C.Structure):
+    _fields_ = [("atts", C.POINTER(_Attribute)), ("tables", C.POINTER(_CornerTable)), ("n_atts", C.c_uint32), ("seeds", C.c_void_p), ("n_seeds", C.c_uint32)]
+
+
 class _RawAttribute(C.Structure):
     _fields_ = [("data", C.c_void_p), ("num_points", C.c_uint32), ("component_type", C.c_uint8), ("num_components", C.c_uint8),
                 ("att_type", C.c_uint8), ("domain", C.c_uint8), ("num_parents", C.c_uint32), ("parents", C.c_void_p)]
@@ -420,6 +424,27 @@ def encode_attributes(attributes, tables, seeds=None, cfg=None):
     out, c = _Buffer(), cfg._c()
     _check(L.dmi_encode_attributes(atts, tabs, len(attributes), None if sd is None else sd.ctypes.data, 0 if sd is None else len(sd), C.byref(c), C.byref(out)))
     return _take(out)
+
+
+def encode_attributes_batch(items, cfg=None):
+    """dmi_encode_attributes_batch: items = [(attributes, tables, seeds or None), ...] → one attribute section per item."""
+    L = load_library()
+    cfg = cfg or Config.default()
+    n = len(items)
+    arr = (_BatchItem * n)()
+    keep = []
+    for i, (attributes, tables, seeds) in enumerate(items):
+        atts = (_Attribute * len(attributes))(*[a._c() for a in attributes])
+        tabs, k = _tables_c(tables)
+        sd = None if seeds is None else np.ascontiguousarray(seeds, dtype=np.uint32)
+        keep.append((atts, tabs, k, sd, attributes))
+        arr[i].atts, arr[i].tables, arr[i].n_atts = atts, tabs, len(attributes)
+        arr[i].seeds = None if sd is None else sd.ctypes.data
+        arr[i].n_seeds = 0 if sd is None else len(sd)
+    outs = (_Buffer * n)()
+    c = cfg._c()
+    _check(L.dmi_encode_attributes_batch(arr, n, C.byref(c), outs))
+    return [_take(outs[i]) for i in range(n)]
 
 
 class Job:

@@ -264,6 +264,30 @@ def test_random_triangle_soup_bit_exact(seed):
     _assert_same(dmi.encode_mesh(mesh), want, f"soup {seed}")
 
 
+def test_encode_attributes_batch_at_the_boundary():
+    """dmi_encode_attributes_batch: host pointers in for n meshes (tables / sequences / seeds as the reference's connectivity
+    stage hands them over — here the oracle's), one attribute section out per mesh, all jobs on one stream."""
+    items, wants = [], []
+    for name in ("tetrahedron", "sphere", "torus"):
+        sess = obj_session(name)
+        sess.encode()
+        mesh = product_mesh_from_oracle(sess)
+        items.append((mesh.attributes, tables_from_oracle(sess, len(mesh.attributes)), None))
+        wants.append(bytes(sess.blob("atts.bytes")))
+    for n in (11, 30):
+        mesh = synth.torus_mesh(n, seed=5 + n)
+        sess = oracle_from_product_mesh(mesh)
+        sess.encode()
+        tabs = tables_from_oracle(sess, len(mesh.attributes))
+        for t in tabs:
+            t["sequence"] = None                         # library sequencer from the Edgebreaker seeds
+        items.append((mesh.attributes, tabs, sess.blob("conn.corners", np.uint32)))
+        wants.append(bytes(sess.blob("atts.bytes")))
+    outs = dmi.encode_attributes_batch(items)
+    for k, (o, w) in enumerate(zip(outs, wants)):
+        _assert_same(o, w, f"boundary batch item {k}")
+
+
 def test_mixed_batch_seams_custom_attributes_and_high_valence():
     """dmi_jobs_encode over meshes that take every kernel family: seam-free (fused sweep), UV / normal seams (per-attribute
     kernels, lone-normal sweep), a ToBits custom attribute (mid-phase host wait ⇒ that job keeps its own launches), fan rows
