@@ -264,6 +264,24 @@ def test_random_triangle_soup_bit_exact(seed):
     _assert_same(dmi.encode_mesh(mesh), want, f"soup {seed}")
 
 
+def test_two_uv_sets_two_normal_sets_and_a_colour():
+    """Only one normal and one texcoord attribute join the position's fused sweep; further ones of the same kind run their own
+    kernels on the (aliased) table, generic attributes take delta + difference."""
+    rng = np.random.default_rng(9)
+    faces, pos, nrm, uv = synth.torus_grid(26)
+    nrm2 = nrm + rng.normal(scale=0.05, size=nrm.shape).astype(np.float32)
+    nrm2 = (nrm2 / np.linalg.norm(nrm2, axis=1, keepdims=True)).astype(np.float32)
+    uv2 = np.clip(uv * np.float32(0.5) + rng.uniform(0, 0.4, size=uv.shape).astype(np.float32), 0, 1).astype(np.float32)
+    col = rng.uniform(0, 1, size=(len(pos), 3)).astype(np.float32)
+    atts = [dmi.Attribute(pos, dmi.ATT_POSITION, dmi.DOMAIN_POSITION, 0),
+            dmi.Attribute(nrm, dmi.ATT_NORMAL, dmi.DOMAIN_CORNER, 1, 0), dmi.Attribute(uv, dmi.ATT_TEXCOORD, dmi.DOMAIN_CORNER, 2, 0),
+            dmi.Attribute(uv2, dmi.ATT_TEXCOORD, dmi.DOMAIN_CORNER, 3, 0), dmi.Attribute(nrm2, dmi.ATT_NORMAL, dmi.DOMAIN_CORNER, 4, 0),
+            dmi.Attribute(col, dmi.ATT_COLOR, dmi.DOMAIN_CORNER, 5)]
+    mesh = dmi.Mesh(faces, atts)
+    want = oracle_from_product_mesh(mesh).encode()
+    _assert_same(dmi.encode_mesh(mesh), want, "2 uv + 2 normal + colour")
+
+
 def test_encode_attributes_batch_at_the_boundary():
     """dmi_encode_attributes_batch: host pointers in for n meshes (tables / sequences / seeds as the reference's connectivity
     stage hands them over — here the oracle's), one attribute section out per mesh, all jobs on one stream."""
