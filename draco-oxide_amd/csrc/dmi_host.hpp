@@ -64,6 +64,7 @@ struct CornerTables {
   int build_universal(const uint32_t* faces, uint32_t num_faces, const uint32_t* pos_p2v, std::string& err);
   // att_p2v: point→value index of the attribute (NULL = identity).
   void build_attribute(const uint32_t* att_p2v);
+  void build_attribute_into(AttTable& a, const uint32_t* att_p2v) const;   // thread-safe w.r.t. other attribute tables
 };
 
 struct EdgebreakerResult {

@@ -1333,9 +1333,17 @@ static int build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std::vector<ui
   int rc = o.ct.build_universal(mesh->faces, mesh->num_faces, mesh->atts[0].point_to_value, err);
   if (rc) return fail(rc, err);
   const double t_univ = since(c0);
-  for (uint32_t i = 0; i < mesh->num_atts; ++i) {
-    if (mesh->atts[i].att_type == DMI_ATT_POSITION) continue;   // edgebreaker.rs:183-190
-    o.ct.build_attribute(mesh->atts[i].point_to_value);
+  {   // attribute corner tables (edgebreaker.rs:183-190): independent of each other — one host thread each for large meshes
+    std::vector<const uint32_t*> maps;
+    for (uint32_t i = 0; i < mesh->num_atts; ++i) if (mesh->atts[i].att_type != DMI_ATT_POSITION) maps.push_back(mesh->atts[i].point_to_value);
+    o.ct.att.resize(maps.size());
+    if (maps.size() > 1 && mesh->num_faces > 100000) {
+      std::vector<std::thread> th;
+      for (size_t k = 0; k < maps.size(); ++k) th.emplace_back([&, k] { o.ct.build_attribute_into(o.ct.att[k], maps[k]); });
+      for (auto& x : th) x.join();
+    } else {
+      for (size_t k = 0; k < maps.size(); ++k) o.ct.build_attribute_into(o.ct.att[k], maps[k]);
+    }
   }
   const double t_att = since(c0) - t_univ;
   auto c1 = tick();

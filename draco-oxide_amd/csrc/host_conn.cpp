@@ -178,9 +178,13 @@ int CornerTables::build_universal(const uint32_t* faces, uint32_t num_faces, con
 
 // core/corner_table/attribute_corner_table.rs:16-137
 void CornerTables::build_attribute(const uint32_t* p2v) {
-  const uint32_t C = 3 * F;
   att.emplace_back();
-  AttTable& a = att.back();
+  build_attribute_into(att.back(), p2v);
+}
+
+// (reads the universal table only: attribute tables of one mesh can be built concurrently)
+void CornerTables::build_attribute_into(AttTable& a, const uint32_t* p2v) const {
+  const uint32_t C = 3 * F;
   a.seam_edge.assign(C, 0);
   std::vector<uint8_t> vseam(V, 0);
   auto val = [&](uint32_t corner) { uint32_t p = c2p[corner]; return p2v ? p2v[p] : p; };
