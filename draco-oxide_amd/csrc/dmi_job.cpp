@@ -893,7 +893,8 @@ static int encode_phase_c3(dmi_job* job, dmi_buffer* out) {   // host: splice th
   return to_buffer(w.b, out);
 }
 
-// Phase A as one hipGraph replay: ≈30 launches/memsets/copies per job collapse into a single API call.  Jobs with
+// Phase A as one hipGraph replay (single-job re-encodes and the jobs of a batch that keep their own launches): the ≈9 launches and
+// the read-back of a job collapse into a single API call.  Jobs with
 // event timing or a ToBits attribute (whose alphabet bound needs a mid-phase host wait) stay on the eager path.
 static int run_phase_a(dmi_job* job) {
   hipStream_t s = job->stream;
@@ -1147,7 +1148,7 @@ int dmi_jobs_encode(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
   if (!jobs || !outs || n == 0) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
   for (uint32_t j = 0; j < n; ++j) if (!jobs[j] || jobs[j]->cfg.device != jobs[0]->cfg.device) return fail(DMI_ERR_INVALID_ARGUMENT, "batched jobs must live on one device");
   const int device = jobs[0]->cfg.device;
-  // Small meshes are launch-bound (≈30 API calls per job), so the per-job phases are issued from several host
+  // Small meshes are launch-bound, so whatever stays per job (table normalisation; the phases of jobs that cannot be planned ahead) runs on several host
   // threads, each walking a contiguous slice of the jobs (jobs that own their stream then also overlap on the GPU).
   unsigned hw = std::thread::hardware_concurrency();
   static const uint32_t thread_cap = std::getenv("DMI_BATCH_THREADS") ? (uint32_t)std::atoi(std::getenv("DMI_BATCH_THREADS")) : 16u;

@@ -713,13 +713,13 @@ __device__ __forceinline__ void k_pred_texcoord_wrapped_body(const TexArgs& ta, 
 // All predictors of a seam-free mesh in ONE sweep.  When the normal / texture-coordinate attributes are coded on
 // the same corner table as their parent position attribute (no seams: the attribute tables alias the universal
 // one), entry i of every attribute is the same vertex and the three predictors walk the same neighbourhood:
-//   * corner table entries (seq, opp, c2r) are fetched once instead of once per attribute;
+//   * the connectivity of the pass is the entry's fan row (see k_build_fans): fetched once instead of `opp`/`c2r` chases
+//     per attribute;
 //   * the quantised positions of the 1-ring feed the parallelogram, the texture-coordinate projection AND the
 //     normal predictor, whose per-face cross products (mesh_normal_prediction.rs:22-44) are formed on the fly from
-//     the ring positions — swinging to the next fan face brings in exactly one new vertex — so neither the
-//     per-face normal array nor its kernel exist on this path.
-// Results are identical to k_pred_parallelogram_wrapped<3> + k_face_normals + k_pred_normal_octorth +
-// k_pred_texcoord_wrapped (the tests run both paths against the oracle).
+//     the ring positions — each fan face brings in exactly one new vertex — so no per-face normal array exists.
+// Results are identical to the per-attribute kernels (k_pred_parallelogram_wrapped<3>, k_predict_fused<0,1,0>,
+// k_pred_texcoord_wrapped): the tests run both paths against the oracle.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void load3(const int32_t* __restrict__ q, uint32_t r, int32_t (&out)[3]) {
   if (r != kNoneD) { out[0] = q[(size_t)r * 3]; out[1] = q[(size_t)r * 3 + 1]; out[2] = q[(size_t)r * 3 + 2]; }
