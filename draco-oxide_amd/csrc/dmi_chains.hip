@@ -63,8 +63,8 @@ __device__ __forceinline__ void k_rans_prep_body(const RansPrepArgs& a, const ui
   for (uint64_t t = (uint64_t)blk_ * 256 + threadIdx.x; t < n_round; t += (uint64_t)nblk_ * 256) {
     RansEntry e{0u, 0u, 0u, 0u};
     if (t < n) { e = table[sym[n - 1 - t]]; rec[t] = e; }
-    const unsigned long long any = __ballot((e.b >> 8) != 0);
-    if ((threadIdx.x & 63) == 0) batch_flags[t >> 6] = any != 0ull;
+    const unsigned long long f1 = __ballot((e.b & 0x100u) != 0), multi = __ballot((e.b & 0x200u) != 0);
+    if ((threadIdx.x & 63) == 0) batch_flags[t >> 6] = (f1 != 0ull ? 1u : 0u) | (multi != 0ull ? 2u : 0u);
   }
 }
 
@@ -76,8 +76,8 @@ __device__ __forceinline__ void k_batch_flags_body(const BatchFlagsArgs& a, cons
   const uint64_t n_round = (n + 63) & ~(uint64_t)63;
   for (uint64_t t = (uint64_t)blk_ * 256 + threadIdx.x; t < n_round; t += (uint64_t)nblk_ * 256) {
     const uint32_t b = (t < n) ? rec[t].b : 0u;
-    const unsigned long long any = __ballot((b >> 8) != 0);
-    if ((threadIdx.x & 63) == 0) batch_flags[t >> 6] = any != 0ull;
+    const unsigned long long f1 = __ballot((b & 0x100u) != 0), multi = __ballot((b & 0x200u) != 0);
+    if ((threadIdx.x & 63) == 0) batch_flags[t >> 6] = (f1 != 0ull ? 1u : 0u) | (multi != 0ull ? 2u : 0u);
   }
 }
 
@@ -161,6 +161,16 @@ __device__ __forceinline__ void load_rec8(Rec8& dst, const_rec8_t src) {
 //                    batches AHEAD of the walker so that the walker's scalar loads hit L2.
 // LDS operations of one wavefront execute in order, so "slot, then counter" needs no fence; the walker only looks at
 // `consumed` when its cached copy says the ring could be full (once per kRing batches).
+// The same step for a batch in which no symbol can renormalise by more than one byte (every f ≥ 2^(P-8): x/f < 2^18): the byte
+// count is one compare-and-select instead of count-leading-zeros, subtract, mask — 9 scalar instructions + the writelane.
+#define DMI_CHAIN_STEP_1B(R, J)                                                                  \
+  {                                                                                              \
+    const uint32_t q0 = __umulhi(x, (R).m) >> ((R).b & 31u);                                     \
+    const uint32_t sh = (q0 >> thr_shift) ? 8u : 0u;                                             \
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(parked) : "s"(x), "i"(J));                  \
+    x = (x >> sh) + (q0 >> sh) * (R).d + (R).c;                                                  \
+  }
+
 // The record buffer is padded with kChainPad records past n, so chunk and batch prefetches may run ahead freely.
 constexpr uint32_t kRing = 8;
 constexpr uint32_t kAhead = 4;   // batches between the emitter's position and the records it pulls into L2
@@ -171,9 +181,10 @@ struct ChainShared {
 typedef const RansEntry __attribute__((address_space(1))) * grec_t;   // global (not flat): flat accesses count in lgkmcnt too
 typedef volatile ChainShared __attribute__((address_space(3))) * lds_shared_t;   // LDS address space ⇒ ds_read/ds_write
 
-template <uint32_t BIAS>
+template <uint32_t BIAS, bool ONE_BYTE>
 __device__ void chain_walker(const ChainDesc& d, uint32_t lane, lds_shared_t sh) {
   constexpr uint32_t bias = BIAS;                 // 29 (rANS, threshold f·2^10) or 27 (rABS, f·2^12)
+  constexpr uint32_t thr_shift = 39u - BIAS;      // 10 / 12
   const uint32_t P = d.precision;
   const uint64_t n = d.n;
   const RansEntry* __restrict__ rec = d.table;
@@ -187,20 +198,24 @@ __device__ void chain_walker(const ChainDesc& d, uint32_t lane, lds_shared_t sh)
   uint32_t k = 0, consumed_seen = 0;
   for (uint64_t base = 0; base < n; base += 64, ++k) {
     const uint32_t cnt = (uint32_t)min((uint64_t)64, n - base);
-    const bool has_f1 = flag_next != 0u;          // a frequency-1 symbol in this batch (flag fetched one batch ahead)
+    const bool has_f1 = (flag_next & 1u) != 0u;   // a frequency-1 symbol in this batch (flags fetched one batch ahead)
+    const bool multi = (flag_next & 2u) != 0u;    // a symbol rare enough (f < 2^(P-8)) to renormalise by more than one byte
     if (!d.force_generic && flags) flag_next = flags[(base >> 6) + 1];
     uint32_t parked = 0;
     x = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
     const_rec8_t g = (const_rec8_t)(uintptr_t)(rec + base);
-    if (cnt == 64 && !has_f1) {
+    // ONE_BYTE streams (almost every batch free of rare symbols): the 9-instruction step, and the generic loop for the few
+    // batches that hold a frequency-1 or a rare symbol; other streams: the count-leading-zeros step for every batch without a
+    // frequency-1 symbol.  (One unrolled body per instantiation: with both in one loop the scheduler sinks the record loads.)
+    if (cnt == 64 && !has_f1 && (!ONE_BYTE || !multi)) {
 #pragma unroll
       for (int ci = 0; ci < 8; ci += 2) {
         load_rec8(cb, g + ci + 1);
 #pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8) DMI_CHAIN_STEP(ca.r[s8], ci * 8 + s8)
+        for (int s8 = 0; s8 < 8; ++s8) { if (ONE_BYTE) DMI_CHAIN_STEP_1B(ca.r[s8], ci * 8 + s8) else DMI_CHAIN_STEP(ca.r[s8], ci * 8 + s8) }
         load_rec8(ca, g + ci + 2);                // ci = 6: the next batch's first chunk
 #pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8) DMI_CHAIN_STEP(cb.r[s8], ci * 8 + 8 + s8)
+        for (int s8 = 0; s8 < 8; ++s8) { if (ONE_BYTE) DMI_CHAIN_STEP_1B(cb.r[s8], ci * 8 + 8 + s8) else DMI_CHAIN_STEP(cb.r[s8], ci * 8 + 8 + s8) }
       }
     } else {
       const uint32_t md = grec[base + lane].d, mc = grec[base + lane].c;
@@ -284,7 +299,8 @@ __global__ __launch_bounds__(128) void k_chains(const ChainDesc* __restrict__ de
   const uint32_t lane = threadIdx.x & 63u;
   const lds_shared_t sh = (lds_shared_t)&shared;
   if (wave == 0) {
-    if (d.kind == 0) chain_walker<29u>(d, lane, sh); else chain_walker<27u>(d, lane, sh);
+    if (d.kind == 0) { if (d.one_byte) chain_walker<29u, true>(d, lane, sh); else chain_walker<29u, false>(d, lane, sh); }
+    else chain_walker<27u, true>(d, lane, sh);   // rABS renormalises with a single `if` (rans.rs:97): never more than one byte
   } else {
     if (d.kind == 0) chain_emitter<29u>(d, lane, sh); else chain_emitter<27u>(d, lane, sh);
     if (lane == 0 && d.ticks) d.ticks[0] = (uint32_t)(wall_clock64() - t0);

@@ -106,6 +106,8 @@ struct ChainDesc {
   uint32_t precision;       // rANS precision bits
   uint64_t n;               // symbols / entries
   const uint32_t* sym;      // unused by the kernel (kept for debugging)
+  uint32_t one_byte;        // kind 0: 1 = almost every batch is free of rare symbols (f < 2^(P-8)): take the one-byte-renormalisation step
+  uint32_t pad0;
   const RansEntry* table;   // kind 0: n coding records in coding order (k_rans_prep output)
   const uint32_t* batch_flags;   // kind 0: per-batch frequency-1 flags (k_rans_prep), NULL otherwise
   uint32_t force_generic;   // kind 1/2: 1 when a coded frequency is 1 (p0 ∈ {1, 255}): every batch takes the generic loop

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
@@ -214,11 +215,13 @@ RansEntry make_rans_entry(uint32_t f, uint32_t cum, uint32_t precision) {
   RansEntry e{0u, 0u, 0u, cum};
   if (f == 0) return e;                       // never coded
   e.d = (1u << precision) - f;
-  if (f == 1) { e.m = 0xFFFFFFFFu; e.b = 0x100u; return e; }   // flagged: the batch takes the generic loop
+  // bit 9 of b: f < 2^(P-8) — the state can exceed f·2^18, i.e. this symbol may renormalise by more than one byte
+  const uint32_t multi = (precision >= 8 && ((uint64_t)f << 8) < ((uint64_t)1 << precision)) ? 0x200u : 0u;
+  if (f == 1) { e.m = 0xFFFFFFFFu; e.b = 0x100u | multi; return e; }   // flagged: the batch takes the generic loop
   unsigned lg = 31u - (unsigned)__builtin_clz(f);
-  if ((f & (f - 1)) == 0) { e.m = 0x80000000u; e.b = lg - 1; return e; }
+  if ((f & (f - 1)) == 0) { e.m = 0x80000000u; e.b = (lg - 1) | multi; return e; }
   e.m = (uint32_t)((((uint64_t)1 << (32 + lg)) + f - 1) / f);
-  e.b = lg;
+  e.b = lg | multi;
   return e;
 }
 }  // namespace dmi
@@ -710,6 +713,13 @@ static int encode_phase_b(dmi_job* job, bool plan_only = false) {   // host: tab
     launch_rans_prep(a.sym.as<uint32_t>(), a.n_sym, a.rtable.as<RansEntry>(), a.rec.as<RansEntry>(), a.batch_flags.as<uint32_t>(), s);
     ChainDesc d{};
     d.kind = 0; d.precision = a.ft.precision; d.n = a.n_sym; d.sym = a.sym.as<uint32_t>(); d.table = a.rec.as<RansEntry>(); d.state0 = 4u << a.ft.precision; d.batch_flags = a.batch_flags.as<uint32_t>();
+    {   // which step the stream's walker uses: the one-byte step pays off when few batches of 64 hold a rare symbol (f < 2^(P-8))
+      uint64_t rare = 0;
+      for (size_t k = 0; k < a.ft.freq.size(); ++k)
+        if (a.ft.freq[k] && ((uint64_t)a.ft.freq[k] << 8) < ((uint64_t)1 << a.ft.precision)) rare += hist[k];
+      const double clean = std::pow(1.0 - (double)rare / (double)std::max<uint64_t>(a.n_sym, 1), 64.0);
+      d.one_byte = clean > 0.8 ? 1u : 0u;
+    }
     d.out = a.out.as<uint8_t>(); d.cap = a.out_cap; d.out_len = a.small.as<uint32_t>() + 8; d.ticks = a.small.as<uint32_t>() + 12;
     aux[i].rans_desc = (int)descs.size();
     descs.push_back(d);
