@@ -56,17 +56,30 @@ __global__ void p_calib(uint64_t* out, uint32_t a, uint32_t b, uint32_t c, uint3
   if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = w1 - w0; out[2] = x + v; }
 }
 
+// chain steps with the record traffic of the real loop: one s_load_dwordx16 per 4 steps (into scratch SGPRs, from `out`)
+__global__ void p_step_sload(uint64_t* out, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  uint32_t x = a, y = b, z = c, w = d, v = 0;
+  uint64_t t0 = clock64();
+  asm volatile(".rept 128\n"
+               ".rept 4\n s_mul_hi_u32 s40, %0, %1\n s_lshr_b32 s40, s40, 3\n s_flbit_i32_b32 s41, s40\n s_sub_i32 s41, 29, s41\n s_and_b32 s41, s41, 24\n"
+               "v_writelane_b32 %4, %0, 7\n s_lshr_b32 %0, %0, s41\n s_lshr_b32 s40, s40, s41\n s_mul_i32 s40, s40, %2\n s_add_i32 %0, %0, %3\n s_add_i32 %0, %0, s40\n.endr\n"
+               "s_load_dwordx16 s[44:59], %5, 0x0\n.endr\n s_waitcnt lgkmcnt(0)"
+               : "+s"(x), "+s"(y), "+s"(z), "+s"(w), "+v"(v) : "s"(out) : "s40", "s41", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "scc");
+  uint64_t t1 = clock64();
+  if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = x + y + z + w + v; }
+}
+
 typedef void (*kern_t)(uint64_t*, uint32_t, uint32_t, uint32_t, uint32_t);
 struct Entry { const char* name; kern_t k; int instrs; };
 
 int main() {
-  uint64_t* d; hipMalloc(&d, 32);
+  uint64_t* d; hipMalloc(&d, 4096);
   Entry es[] = {{"empty", p_empty, 0}, {"s_add dep", p_add_dep, 1}, {"s_add x3 indep", p_add_indep, 3}, {"s_mul_i32 dep", p_mul_dep, 1},
                 {"s_mul_hi_u32 dep", p_mulhi_dep, 1}, {"s_lshr dep", p_lshr_dep, 1}, {"s_flbit dep", p_flbit_dep, 1}, {"s_and dep", p_and_dep, 1},
                 {"s_add + writelane(dep)", p_add_wl, 2}, {"s_add + writelane(indep)", p_add_wl_other, 2}, {"writelane only", p_wl_only, 1},
                 {"v_add dep", p_vadd_dep, 1}, {"v_mul_hi dep", p_vmulhi_dep, 1}, {"s_nop", p_nop, 1},
                 {"chain step", p_step, 11}, {"chain step no writelane", p_step_nowl, 10}, {"chain step writelane first", p_step_wlfirst, 11},
-                {"chain step add order", p_step_alt, 11}};
+                {"chain step add order", p_step_alt, 11}, {"4 steps + s_load_dwordx16 (x128)", p_step_sload, 45}};
   for (auto& e : es) {
     uint64_t best = ~0ull;
     for (int r = 0; r < 5; ++r) {
