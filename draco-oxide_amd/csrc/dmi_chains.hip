@@ -181,53 +181,56 @@ struct ChainShared {
 typedef const RansEntry __attribute__((address_space(1))) * grec_t;   // global (not flat): flat accesses count in lgkmcnt too
 typedef volatile ChainShared __attribute__((address_space(3))) * lds_shared_t;   // LDS address space ⇒ ds_read/ds_write
 
+#include "dmi_walker_asm.inc"
+
+// The walker.  Runs of consecutive full batches without a flagged symbol execute in one hand-scheduled assembly loop
+// (scripts/gen_walker_asm.py → dmi_walker_asm.inc: records double-buffered in two fixed 32-SGPR sets, the next chunk
+// requested right after each wait, ≈ 20 instructions of hand-off per 64 steps); a flagged batch (frequency-1 symbol; for
+// ONE_BYTE streams also a rare symbol) and the tail batch take the generic divide loop here.
 template <uint32_t BIAS, bool ONE_BYTE>
 __device__ void chain_walker(const ChainDesc& d, uint32_t lane, lds_shared_t sh) {
   constexpr uint32_t bias = BIAS;                 // 29 (rANS, threshold f·2^10) or 27 (rABS, f·2^12)
-  constexpr uint32_t thr_shift = 39u - BIAS;      // 10 / 12
   const uint32_t P = d.precision;
   const uint64_t n = d.n;
   const RansEntry* __restrict__ rec = d.table;
   uint32_t x = d.state0;
   typedef const uint32_t __attribute__((address_space(4))) * const_u32_t;
   const_u32_t flags = (const_u32_t)(uintptr_t)d.batch_flags;   // nullable
-  uint32_t flag_next = d.force_generic ? 1u : (flags ? flags[0] : 0u);
-  Rec8 ca, cb;   // ca: the chunk about to execute; cb: the one after it
-  load_rec8(ca, (const_rec8_t)(uintptr_t)rec);
   const grec_t grec = (grec_t)(uintptr_t)rec;
+  const uint32_t nb = (uint32_t)((n + 63) >> 6), full = (uint32_t)(n >> 6);
+  constexpr uint32_t flag_mask = ONE_BYTE ? 3u : 1u;   // bit 0: frequency-1 symbol, bit 1: rare symbol (may renormalise > 1 byte)
+  const uint32_t ring_lane = (uint32_t)(uintptr_t)&sh->ring[0][lane];
+  const uint32_t produced_at = (uint32_t)(uintptr_t)&sh->produced, consumed_at = (uint32_t)(uintptr_t)&sh->consumed;
   uint32_t k = 0, consumed_seen = 0;
-  for (uint64_t base = 0; base < n; base += 64, ++k) {
+  while (k < nb) {
+    const uint32_t flag = d.force_generic ? 1u : (flags ? flags[k] : 1u);
+    if (k < full && !(flag & flag_mask)) {
+      uint32_t left = full - k, vtmp, parked;
+      const uint64_t rec_at = (uint64_t)(uintptr_t)(rec + (uint64_t)k * 64u), flag_at = (uint64_t)(uintptr_t)(d.batch_flags + k);
+      if (BIAS == 27u)
+        asm volatile(DMI_WALKER_ASM_ONE_BYTE_RABS : "+s"(x), "+s"(k), "+s"(left), "+s"(consumed_seen), "=&v"(vtmp), "=&v"(parked)
+                     : "s"(rec_at), "s"(flag_at), "v"(ring_lane), "v"(produced_at), "v"(consumed_at) : DMI_WALKER_ASM_CLOBBERS);
+      else if (ONE_BYTE)
+        asm volatile(DMI_WALKER_ASM_ONE_BYTE_RANS : "+s"(x), "+s"(k), "+s"(left), "+s"(consumed_seen), "=&v"(vtmp), "=&v"(parked)
+                     : "s"(rec_at), "s"(flag_at), "v"(ring_lane), "v"(produced_at), "v"(consumed_at) : DMI_WALKER_ASM_CLOBBERS);
+      else
+        asm volatile(DMI_WALKER_ASM_GENERAL_RANS : "+s"(x), "+s"(k), "+s"(left), "+s"(consumed_seen), "=&v"(vtmp), "=&v"(parked)
+                     : "s"(rec_at), "s"(flag_at), "v"(ring_lane), "v"(produced_at), "v"(consumed_at) : DMI_WALKER_ASM_CLOBBERS);
+      continue;
+    }
+    // generic batch: hardware divide per step, records through the vector path
+    const uint64_t base = (uint64_t)k << 6;
     const uint32_t cnt = (uint32_t)min((uint64_t)64, n - base);
-    const bool has_f1 = (flag_next & 1u) != 0u;   // a frequency-1 symbol in this batch (flags fetched one batch ahead)
-    const bool multi = (flag_next & 2u) != 0u;    // a symbol rare enough (f < 2^(P-8)) to renormalise by more than one byte
-    if (!d.force_generic && flags) flag_next = flags[(base >> 6) + 1];
     uint32_t parked = 0;
     x = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
-    const_rec8_t g = (const_rec8_t)(uintptr_t)(rec + base);
-    // ONE_BYTE streams (almost every batch free of rare symbols): the 9-instruction step, and the generic loop for the few
-    // batches that hold a frequency-1 or a rare symbol; other streams: the count-leading-zeros step for every batch without a
-    // frequency-1 symbol.  (One unrolled body per instantiation: with both in one loop the scheduler sinks the record loads.)
-    if (cnt == 64 && !has_f1 && (!ONE_BYTE || !multi)) {
-#pragma unroll
-      for (int ci = 0; ci < 8; ci += 2) {
-        load_rec8(cb, g + ci + 1);
-#pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8) { if (ONE_BYTE) DMI_CHAIN_STEP_1B(ca.r[s8], ci * 8 + s8) else DMI_CHAIN_STEP(ca.r[s8], ci * 8 + s8) }
-        load_rec8(ca, g + ci + 2);                // ci = 6: the next batch's first chunk
-#pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8) { if (ONE_BYTE) DMI_CHAIN_STEP_1B(cb.r[s8], ci * 8 + 8 + s8) else DMI_CHAIN_STEP(cb.r[s8], ci * 8 + 8 + s8) }
-      }
-    } else {
-      const uint32_t md = grec[base + lane].d, mc = grec[base + lane].c;
-      for (uint32_t j = 0; j < cnt; ++j) {
-        const uint32_t dj = rl(md, j), cj = rl(mc, j);
-        const uint32_t f = (1u << P) - dj;
-        const uint32_t q0 = x / f;
-        const uint32_t sh = (bias - (uint32_t)__builtin_clz(q0)) & 0x18u;
-        if (lane == j) parked = x;
-        x = (x >> sh) + (q0 >> sh) * dj + cj;
-      }
-      load_rec8(ca, g + 8);
+    const uint32_t md = grec[base + lane].d, mc = grec[base + lane].c;
+    for (uint32_t j = 0; j < cnt; ++j) {
+      const uint32_t dj = rl(md, j), cj = rl(mc, j);
+      const uint32_t f = (1u << P) - dj;
+      const uint32_t q0 = x / f;
+      const uint32_t shf = (bias - (uint32_t)__builtin_clz(q0)) & 0x18u;
+      if (lane == j) parked = x;
+      x = (x >> shf) + (q0 >> shf) * dj + cj;
     }
     while (k - consumed_seen >= kRing) {          // ring full (rare: the emitter is ≈6× faster than the walker)
       consumed_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->consumed);
@@ -235,6 +238,7 @@ __device__ void chain_walker(const ChainDesc& d, uint32_t lane, lds_shared_t sh)
     }
     sh->ring[k & (kRing - 1u)][lane] = parked;
     sh->produced = k + 1u;
+    ++k;
   }
   sh->final_x = x;
   sh->done = 1u;
