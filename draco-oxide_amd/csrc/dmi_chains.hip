@@ -47,7 +47,7 @@ __device__ __forceinline__ uint32_t flush_state(uint32_t s, uint8_t* out, uint64
 
 // select between two coding records field by field (a struct-valued ?: goes through private memory)
 __device__ __forceinline__ RansEntry pick(bool one, const RansEntry& e0, const RansEntry& e1) {
-  return RansEntry{one ? e1.m : e0.m, one ? e1.b : e0.b, one ? e1.d : e0.d, one ? e1.c : e0.c};
+  return RansEntry{one ? e1.m : e0.m, one ? e1.b : e0.b, one ? e1.d : e0.d, one ? e1.c : e0.c, one ? e1.t : e0.t};
 }
 
 // ---- prep kernels ---------------------------------------------------------------------------------
@@ -61,7 +61,7 @@ __device__ __forceinline__ void k_rans_prep_body(const RansPrepArgs& a, const ui
   uint32_t* __restrict__ batch_flags = a.batch_flags;
   const uint64_t n_round = (n + 63) & ~(uint64_t)63;
   for (uint64_t t = (uint64_t)blk_ * 256 + threadIdx.x; t < n_round; t += (uint64_t)nblk_ * 256) {
-    RansEntry e{0u, 0u, 0u, 0u};
+    RansEntry e{0u, 0u, 0u, 0u, 0u};
     if (t < n) { e = table[sym[n - 1 - t]]; rec[t] = e; }
     const unsigned long long f1 = __ballot((e.b & 0x100u) != 0), multi = __ballot((e.b & 0x200u) != 0);
     if ((threadIdx.x & 63) == 0) batch_flags[t >> 6] = (f1 != 0ull ? 1u : 0u) | (multi != 0ull ? 2u : 0u);
@@ -135,24 +135,12 @@ __device__ __forceinline__ void k_orient_prep_body(const OrientPrepArgs& a, cons
 }
 
 // ---- the chain -------------------------------------------------------------------------------------
-// Records travel through SGPRs in chunks of 8 (two s_load_dwordx16), double-buffered: scalar loads return out of
-// order, so every wait is lgkmcnt(0) — the chunk for steps k+8..k+15 is requested right after the wait that
-// releases steps k..k+7 and has 8 steps (≈350 clocks) to arrive.
-struct Rec8 { RansEntry r[8]; };
-typedef const Rec8 __attribute__((address_space(4))) * const_rec8_t;   // constant address space ⇒ scalar loads
-__device__ __forceinline__ void load_rec8(Rec8& dst, const_rec8_t src) {
-#pragma unroll
-  for (int k = 0; k < 8; ++k) { dst.r[k].m = src->r[k].m; dst.r[k].b = src->r[k].b; dst.r[k].d = src->r[k].d; dst.r[k].c = src->r[k].c; }
-}
-
-#define DMI_CHAIN_STEP(R, J)                                                                     \
-  {                                                                                              \
-    const uint32_t q0 = __umulhi(x, (R).m) >> ((R).b & 31u);                                     \
-    const uint32_t sh = (bias - (uint32_t)__builtin_clz(q0)) & 0x18u;                            \
-    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(parked) : "s"(x), "i"(J));                  \
-    x = (x >> sh) + (q0 >> sh) * (R).d + (R).c;                                                  \
-  }
-
+// One step of the recurrence on the scalar unit (x, the record's m b d c t in SGPRs; s100 s101 temporaries):
+//   general step, any renormalisation (10 scalar + 1 writelane):
+//     q0 = mulhi(x, m) >> b ; sh = (BIAS - clz(q0)) & 24 ; park x in lane j ; x = (x >> sh) + (q0 >> sh)·d + c
+//   one-byte step, for batches in which no symbol can renormalise by more than one byte (9 scalar + 1 writelane):
+//     sh = (x ≥ t) ? 8 : 0 ; park x ; x >>= sh ; x = x + (mulhi(x, m) >> b)·d + c        (divide AFTER renormalising)
+// The steady state is generated assembly (scripts/gen_walker_asm.py → dmi_walker_asm.inc); see chain_walker below.
 // A stream is owned by a workgroup of TWO wavefronts that talk through LDS:
 //   wave 0 (walker)  runs the recurrence on its scalar unit and parks the 64 pre-renormalisation states of a
 //                    batch in a VGPR (lane j = step j), then drops them into a ring slot and bumps `produced`;
@@ -184,7 +172,7 @@ typedef volatile ChainShared __attribute__((address_space(3))) * lds_shared_t;  
 #include "dmi_walker_asm.inc"
 
 // The walker.  Runs of consecutive full batches without a flagged symbol execute in one hand-scheduled assembly loop
-// (scripts/gen_walker_asm.py → dmi_walker_asm.inc: records double-buffered in two fixed 32-SGPR sets, the next chunk
+// (scripts/gen_walker_asm.py → dmi_walker_asm.inc: records double-buffered in two fixed 40-SGPR sets, the next chunk
 // requested right after each wait, ≈ 20 instructions of hand-off per 64 steps); a flagged batch (frequency-1 symbol; for
 // ONE_BYTE streams also a rare symbol) and the tail batch take the generic divide loop here.
 template <uint32_t BIAS, bool ONE_BYTE>
@@ -207,11 +195,8 @@ __device__ void chain_walker(const ChainDesc& d, uint32_t lane, lds_shared_t sh)
     if (k < full && !(flag & flag_mask)) {
       uint32_t left = full - k, vtmp, parked;
       const uint64_t rec_at = (uint64_t)(uintptr_t)(rec + (uint64_t)k * 64u), flag_at = (uint64_t)(uintptr_t)(d.batch_flags + k);
-      if (BIAS == 27u)
-        asm volatile(DMI_WALKER_ASM_ONE_BYTE_RABS : "+s"(x), "+s"(k), "+s"(left), "+s"(consumed_seen), "=&v"(vtmp), "=&v"(parked)
-                     : "s"(rec_at), "s"(flag_at), "v"(ring_lane), "v"(produced_at), "v"(consumed_at) : DMI_WALKER_ASM_CLOBBERS);
-      else if (ONE_BYTE)
-        asm volatile(DMI_WALKER_ASM_ONE_BYTE_RANS : "+s"(x), "+s"(k), "+s"(left), "+s"(consumed_seen), "=&v"(vtmp), "=&v"(parked)
+      if (ONE_BYTE)
+        asm volatile(DMI_WALKER_ASM_ONE_BYTE : "+s"(x), "+s"(k), "+s"(left), "+s"(consumed_seen), "=&v"(vtmp), "=&v"(parked)
                      : "s"(rec_at), "s"(flag_at), "v"(ring_lane), "v"(produced_at), "v"(consumed_at) : DMI_WALKER_ASM_CLOBBERS);
       else
         asm volatile(DMI_WALKER_ASM_GENERAL_RANS : "+s"(x), "+s"(k), "+s"(left), "+s"(consumed_seen), "=&v"(vtmp), "=&v"(parked)

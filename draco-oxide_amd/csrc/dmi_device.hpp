@@ -90,11 +90,11 @@ struct HistArgs { HistAtt a[kMaxRangeAtts]; int count; };
 void launch_histograms(HistArgs& args, hipStream_t s);
 
 // ---- serial coders: two wavefronts per stream (a18, a19, a11, a13) ------------------------------------
-// Coding record of one symbol (see dmi_chains.hip): x / f = mulhi(x, m) >> (b & 31); bit 8 of b flags f == 1;
-// d = 2^P - f; c = cumulative frequency.
-struct RansEntry { uint32_t m, b, d, c; };
+// Coding record of one symbol (see dmi_chains.hip), 20 bytes: x / f = mulhi(x, m) >> (b & 31); bit 8 of b flags f == 1, bit 9
+// f < 2^(P-8); d = 2^P - f; c = cumulative frequency; t = renormalisation threshold (x ≥ t ⇒ at least one byte leaves).
+struct RansEntry { uint32_t m, b, d, c, t; };   // t = f << 10 (rANS) / f << 12 (rABS): the renormalisation threshold
 constexpr size_t kChainPad = 384;   // records a stream's buffer extends past n: the chain's look-ahead loads may run that far
-RansEntry make_rans_entry(uint32_t freq, uint32_t cum, uint32_t precision);   // host helper
+RansEntry make_rans_entry(uint32_t freq, uint32_t cum, uint32_t precision);   // host helper (precision 8 = rABS: threshold f << 12)
 // batch_flags: (n + 63) / 64 + 1 words; [b] != 0 ⇔ batch b holds a frequency-1 symbol
 void launch_rans_prep(const uint32_t* sym, uint64_t n, const RansEntry* table, RansEntry* rec, uint32_t* batch_flags, hipStream_t s);
 void launch_batch_flags(const RansEntry* rec, uint64_t n, uint32_t* batch_flags, hipStream_t s);

@@ -212,8 +212,9 @@ int validate_and_plan(const dmi_attribute* atts, uint32_t n_atts, const dmi_conf
 namespace dmi {
 // Coding record of a symbol with normalised frequency f (see dmi_chains.hip for the exactness argument).
 RansEntry make_rans_entry(uint32_t f, uint32_t cum, uint32_t precision) {
-  RansEntry e{0u, 0u, 0u, cum};
+  RansEntry e{0u, 0u, 0u, cum, 0u};
   if (f == 0) return e;                       // never coded
+  e.t = f << (precision == 8 ? 12 : 10);      // rans.rs:40 `state >= (L >> P) * f << 8` with L = 4·2^P; rABS :97 with L = 4096
   e.d = (1u << precision) - f;
   // bit 9 of b: f < 2^(P-8) — the state can exceed f·2^18, i.e. this symbol may renormalise by more than one byte
   const uint32_t multi = (precision >= 8 && ((uint64_t)f << 8) < ((uint64_t)1 << precision)) ? 0x200u : 0u;
@@ -482,7 +483,7 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
     a.bins = symbol_bins(a);
     if (a.port == kToBits) a.bins = 1u << 20;   // capacity; the real bound is checked after the min/max readback
     a.bins_cap = a.bins;
-    if ((rc = a.rtable.alloc((size_t)a.bins * sizeof(RansEntry)))) return rc;
+    if ((rc = a.rtable.alloc(((size_t)a.bins + 4) * sizeof(RansEntry)))) return rc;   // +4: uploads are padded to 4 entries (whole 16-byte words)
     if ((rc = a.rec.alloc(((size_t)a.n_sym + kChainPad) * sizeof(RansEntry)))) return rc;
     HIP_TRY(hipMemsetAsync(a.rec.p, 0, a.rec.bytes, s));
     if ((rc = a.batch_flags.alloc(((size_t)a.n_sym / 64 + 4) * 4))) return rc;
@@ -706,8 +707,8 @@ static int encode_phase_b(dmi_job* job, bool plan_only = false) {   // host: tab
     int rc = a.ft.build(hist, a.bins, err);
     if (rc) return fail(rc, err);
     std::vector<RansEntry>& rt = a.rt_host;
-    rt.resize(a.ft.freq.size());
-    for (size_t k = 0; k < rt.size(); ++k) rt[k] = make_rans_entry(a.ft.freq[k], a.ft.cum[k], a.ft.precision);
+    rt.assign((a.ft.freq.size() + 3) & ~(size_t)3, RansEntry{0u, 0u, 0u, 0u, 0u});   // 4 entries = 80 bytes = whole 16-byte words
+    for (size_t k = 0; k < a.ft.freq.size(); ++k) rt[k] = make_rans_entry(a.ft.freq[k], a.ft.cum[k], a.ft.precision);
     { const int urc = upload_table(a.rtable.p, rt.data(), rt.size() * sizeof(RansEntry)); if (urc) return urc; }
     // symbols → coding records in coding order (data-parallel), consumed by the scalar chain
     launch_rans_prep(a.sym.as<uint32_t>(), a.n_sym, a.rtable.as<RansEntry>(), a.rec.as<RansEntry>(), a.batch_flags.as<uint32_t>(), s);
