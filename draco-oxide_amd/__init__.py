@@ -10,6 +10,6 @@ from .binding import (  # noqa: F401
     ATT_POSITION, ATT_NORMAL, ATT_COLOR, ATT_TEXCOORD, ATT_CUSTOM, DOMAIN_POSITION, DOMAIN_CORNER,
     F32, U32, I32, FLAG_TIMINGS, POS_SCHEME_DELTA,
     Attribute, Mesh, MeshBuilder, Config, DracoMiError, Job, Connectivity,
-    encode, encode_mesh, encode_attributes, encode_attributes_batch, encode_connectivity, mesh_prepare, meshes_prepare, jobs_encode, device_count, library_path, load_library,
+    encode, encode_mesh, encode_attributes, encode_attributes_batch, encode_connectivity, mesh_prepare, meshes_prepare, jobs_encode, jobs_encode_raw, EncodedBatch, device_count, library_path, load_library,
 )
 from . import gltf, synth  # noqa: E402,F401

@@ -499,6 +499,40 @@ def jobs_encode(jobs):
     return [_take(outs[i]) for i in range(n)]
 
 
+class EncodedBatch:
+    """The library-owned outputs of one dmi_jobs_encode call (no copy into Python objects): `len(batch)`, `batch.nbytes`,
+    `batch[i]` → bytes (copies that item), `batch.free()` / context manager → dmi_free of every buffer."""
+    def __init__(self, outs, n):
+        self._outs, self._n = outs, n
+    def __len__(self):
+        return self._n
+    @property
+    def nbytes(self):
+        return sum(self._outs[i].len for i in range(self._n))
+    def __getitem__(self, i):
+        b = self._outs[i]
+        return C.string_at(b.data, b.len) if b.len else b""
+    def free(self):
+        L = load_library()
+        for i in range(self._n):
+            L.dmi_free(C.byref(self._outs[i]))
+        self._n = 0
+    def __enter__(self):
+        return self
+    def __exit__(self, *a):
+        self.free()
+
+
+def jobs_encode_raw(jobs):
+    """jobs_encode at the cost of the C-ABI call alone: returns an EncodedBatch (caller frees)."""
+    L = load_library()
+    n = len(jobs)
+    handles = (C.c_void_p * n)(*[j._h for j in jobs])
+    outs = (_Buffer * n)()
+    _check(L.dmi_jobs_encode(handles, n, outs))
+    return EncodedBatch(outs, n)
+
+
 def mesh_prepare(mesh, cfg=None):
     """Host stages (corner tables, Edgebreaker, sequencer) + upload; returns a resident Job."""
     L = load_library()

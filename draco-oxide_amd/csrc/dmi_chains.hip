@@ -162,10 +162,14 @@ __device__ __forceinline__ void k_orient_prep_body(const OrientPrepArgs& a, cons
 // The record buffer is padded with kChainPad records past n, so chunk and batch prefetches may run ahead freely.
 constexpr uint32_t kRing = 8;
 constexpr uint32_t kAhead = 4;   // batches between the emitter's position and the records it pulls into L2
+// One walker/emitter pair's LDS.  `produced` / `consumed` count ring slots over the pair's whole life (all the streams it
+// serves): a stream of nb batches takes nb + 1 slots, the last one carrying {lane 0: final state, lane 1: the next stream
+// of the pair} — hand-over between streams needs no other synchronisation.
 struct ChainShared {
   uint32_t ring[kRing][64];
-  uint32_t produced, consumed, final_x, done;
+  uint32_t produced, consumed, pad[2];
 };
+constexpr uint32_t kNoStream = 0xFFFFFFFFu;
 typedef const RansEntry __attribute__((address_space(1))) * grec_t;   // global (not flat): flat accesses count in lgkmcnt too
 typedef volatile ChainShared __attribute__((address_space(3))) * lds_shared_t;   // LDS address space ⇒ ds_read/ds_write
 
@@ -175,8 +179,9 @@ typedef volatile ChainShared __attribute__((address_space(3))) * lds_shared_t;  
 // (scripts/gen_walker_asm.py → dmi_walker_asm.inc: records double-buffered in two fixed 40-SGPR sets, the next chunk
 // requested right after each wait, ≈ 20 instructions of hand-off per 64 steps); a flagged batch (frequency-1 symbol; for
 // ONE_BYTE streams also a rare symbol) and the tail batch take the generic divide loop here.
+// K = the pair's slot counter (see ChainShared); returns the final state.
 template <uint32_t BIAS, bool ONE_BYTE>
-__device__ void chain_walker(const ChainDesc& d, uint32_t lane, lds_shared_t sh) {
+__device__ uint32_t chain_walker(const ChainDesc& d, uint32_t lane, lds_shared_t sh, uint32_t& K, uint32_t& consumed_seen) {
   constexpr uint32_t bias = BIAS;                 // 29 (rANS, threshold f·2^10) or 27 (rABS, f·2^12)
   const uint32_t P = d.precision;
   const uint64_t n = d.n;
@@ -189,18 +194,19 @@ __device__ void chain_walker(const ChainDesc& d, uint32_t lane, lds_shared_t sh)
   constexpr uint32_t flag_mask = ONE_BYTE ? 3u : 1u;   // bit 0: frequency-1 symbol, bit 1: rare symbol (may renormalise > 1 byte)
   const uint32_t ring_lane = (uint32_t)(uintptr_t)&sh->ring[0][lane];
   const uint32_t produced_at = (uint32_t)(uintptr_t)&sh->produced, consumed_at = (uint32_t)(uintptr_t)&sh->consumed;
-  uint32_t k = 0, consumed_seen = 0;
+  uint32_t k = 0;                                 // batch of this stream
   while (k < nb) {
     const uint32_t flag = d.force_generic ? 1u : (flags ? flags[k] : 1u);
     if (k < full && !(flag & flag_mask)) {
       uint32_t left = full - k, vtmp, parked;
       const uint64_t rec_at = (uint64_t)(uintptr_t)(rec + (uint64_t)k * 64u), flag_at = (uint64_t)(uintptr_t)(d.batch_flags + k);
       if (ONE_BYTE)
-        asm volatile(DMI_WALKER_ASM_ONE_BYTE : "+s"(x), "+s"(k), "+s"(left), "+s"(consumed_seen), "=&v"(vtmp), "=&v"(parked)
+        asm volatile(DMI_WALKER_ASM_ONE_BYTE : "+s"(x), "+s"(K), "+s"(left), "+s"(consumed_seen), "=&v"(vtmp), "=&v"(parked)
                      : "s"(rec_at), "s"(flag_at), "v"(ring_lane), "v"(produced_at), "v"(consumed_at) : DMI_WALKER_ASM_CLOBBERS);
       else
-        asm volatile(DMI_WALKER_ASM_GENERAL_RANS : "+s"(x), "+s"(k), "+s"(left), "+s"(consumed_seen), "=&v"(vtmp), "=&v"(parked)
+        asm volatile(DMI_WALKER_ASM_GENERAL_RANS : "+s"(x), "+s"(K), "+s"(left), "+s"(consumed_seen), "=&v"(vtmp), "=&v"(parked)
                      : "s"(rec_at), "s"(flag_at), "v"(ring_lane), "v"(produced_at), "v"(consumed_at) : DMI_WALKER_ASM_CLOBBERS);
+      k = full - left;
       continue;
     }
     // generic batch: hardware divide per step, records through the vector path
@@ -217,20 +223,21 @@ __device__ void chain_walker(const ChainDesc& d, uint32_t lane, lds_shared_t sh)
       if (lane == j) parked = x;
       x = (x >> shf) + (q0 >> shf) * dj + cj;
     }
-    while (k - consumed_seen >= kRing) {          // ring full (rare: the emitter is ≈6× faster than the walker)
+    while (K - consumed_seen >= kRing) {          // ring full (rare: the emitter is ≈6× faster than the walker)
       consumed_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->consumed);
-      if (k - consumed_seen >= kRing) __builtin_amdgcn_s_sleep(4);
+      if (K - consumed_seen >= kRing) __builtin_amdgcn_s_sleep(4);
     }
-    sh->ring[k & (kRing - 1u)][lane] = parked;
-    sh->produced = k + 1u;
+    sh->ring[K & (kRing - 1u)][lane] = parked;
+    sh->produced = K + 1u;
+    ++K;
     ++k;
   }
-  sh->final_x = x;
-  sh->done = 1u;
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
 }
 
+// The emitter of a pair; returns the pair's next stream (from the stream's closing slot).
 template <uint32_t BIAS>
-__device__ void chain_emitter(const ChainDesc& d, uint32_t lane, lds_shared_t sh) {
+__device__ uint32_t chain_emitter(const ChainDesc& d, uint32_t lane, lds_shared_t sh, uint32_t& K) {
   constexpr uint32_t thr_shift = 39u - BIAS;      // 10 / 12
   const uint32_t P = d.precision;
   const uint64_t n = d.n;
@@ -242,16 +249,15 @@ __device__ void chain_emitter(const ChainDesc& d, uint32_t lane, lds_shared_t sh
   uint32_t far = 0;
 #pragma unroll
   for (uint32_t a = 1; a < kAhead; ++a) touched ^= grec[(uint64_t)a * 64u + lane].m;
-  uint32_t k = 0;
-  for (uint64_t base = 0; base < n; base += 64, ++k) {
+  for (uint64_t base = 0; base < n; base += 64, ++K) {
     const uint32_t cnt = (uint32_t)min((uint64_t)64, n - base);
     const uint32_t my_d = me_d;                    // requested one batch ago
     touched ^= far;
     me_d = grec[base + 64u + lane].d;
     far = grec[base + (uint64_t)kAhead * 64u + lane].m;   // one dword per record = every line of that batch
-    while ((uint32_t)__builtin_amdgcn_readfirstlane((int)sh->produced) <= k) __builtin_amdgcn_s_sleep(2);
-    const uint32_t parked = sh->ring[k & (kRing - 1u)][lane];
-    sh->consumed = k + 1u;                         // (LDS is in order: the slot read above is performed first)
+    while ((int32_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)sh->produced) - K) <= 0) __builtin_amdgcn_s_sleep(2);
+    const uint32_t parked = sh->ring[K & (kRing - 1u)][lane];
+    sh->consumed = K + 1u;                         // (LDS is in order: the slot read above is performed first)
     // bytes of the 64 steps: lane j re-derives its byte count from (parked state, frequency)
     // (f ≤ 2^20 ⇒ f << thr_shift < 2^32; parked < 2^30; at most 3 bytes per step)
     const uint32_t thr = (lane < cnt) ? (((1u << P) - my_d) << thr_shift) : 0xFFFFFFFFu;
@@ -268,31 +274,74 @@ __device__ void chain_emitter(const ChainDesc& d, uint32_t lane, lds_shared_t sh
       pos += total;
     }
   }
-  while ((uint32_t)__builtin_amdgcn_readfirstlane((int)sh->done) == 0u) __builtin_amdgcn_s_sleep(2);
-  const uint32_t x = sh->final_x;
+  // the stream's closing slot
+  while ((int32_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)sh->produced) - K) <= 0) __builtin_amdgcn_s_sleep(2);
+  const uint32_t closing = sh->ring[K & (kRing - 1u)][lane];
+  sh->consumed = K + 1u;
+  ++K;
+  const uint32_t x = rl(closing, 0), next = rl(closing, 1);
   if (lane == 0) {
     if (!err) pos += flush_state(x - d.state0, d.out, pos, d.cap, err);
     if ((touched ^ far) == 0x9E3779B9u && pos == ~0ull) err = 3;   // keeps the look-ahead loads alive; never true
     d.out_len[0] = (uint32_t)pos;
     d.out_len[1] = err;
   }
+  return next;
 }
 
-__global__ __launch_bounds__(128) void k_chains(const ChainDesc* __restrict__ descs) {
-  __shared__ ChainShared shared;
-  const ChainDesc d = descs[blockIdx.x];
-  const uint64_t t0 = wall_clock64();   // 100 MHz constant-rate counter
-  if (threadIdx.x == 0) { shared.produced = 0; shared.consumed = 0; shared.final_x = 0; shared.done = 0; }
+// Every rANS / rABS stream of a launch.  A workgroup is FOUR walker/emitter pairs: a wavefront issues one instruction per
+// ≈ 4 clocks and the scalar unit of a SIMD serves one wavefront per clock turn, so two walkers on one SIMD run at half
+// speed each — the walkers are wavefronts 0..3 of the workgroup, which the dispatcher places on the four SIMDs of one CU
+// (wavefront w + 4 shares the SIMD of wavefront w: scripts/probes/simd_probe.hip), and pair p's emitter is wavefront
+// 4 + (p + 1) % 4, i.e. on another SIMD than its walker.  With ≤ 256 workgroups (one per CU) every walker of the chip
+// has a SIMD's scalar unit to itself.  Streams are served longest first (`order`): the first 4·gridDim.x are dealt
+// statically (stream s → workgroup s mod G, pair s / G: the longest G streams sit alone on their CUs' first SIMD), the rest
+// is pulled through the counter `next_stream` (zeroed by the launcher) when a pair finishes a stream — the launch lasts max(longest stream, total steps / walkers)
+// instead of being at the mercy of the dispatcher's placement (1024-mesh batch: 13.5 → … ms).
+constexpr uint32_t kChainPairs = 4;
+__global__ __launch_bounds__(512) void k_chains(const ChainDesc* __restrict__ descs, const uint32_t* __restrict__ order, uint32_t n_streams,
+                                                uint32_t* __restrict__ next_stream) {
+  __shared__ ChainShared shared[kChainPairs];
+  if (threadIdx.x < kChainPairs) { shared[threadIdx.x].produced = 0; shared[threadIdx.x].consumed = 0; }
   __syncthreads();
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t lane = threadIdx.x & 63u;
-  const lds_shared_t sh = (lds_shared_t)&shared;
-  if (wave == 0) {
-    if (d.kind == 0) { if (d.one_byte) chain_walker<29u, true>(d, lane, sh); else chain_walker<29u, false>(d, lane, sh); }
-    else chain_walker<27u, true>(d, lane, sh);   // rABS renormalises with a single `if` (rans.rs:97): never more than one byte
+  const bool walker = wave < kChainPairs;
+  const uint32_t pair = walker ? wave : ((wave - kChainPairs) + kChainPairs - 1u) % kChainPairs;   // emitter of pair p = wavefront 4 + (p + 1) % 4
+  const lds_shared_t sh = (lds_shared_t)&shared[pair];
+  const uint32_t first = pair * gridDim.x + blockIdx.x;
+  if (first >= n_streams) return;
+  // (two loops with their own variables: the walker's live in SGPRs for the assembly, the emitter's do not)
+  if (walker) {
+    uint32_t K = 0, consumed_seen = 0, sid = first;
+    while (sid != kNoStream) {
+      const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)(order ? order[sid] : sid));
+      const ChainDesc d = descs[at];
+      uint32_t x;
+      if (d.kind == 0) x = d.one_byte ? chain_walker<29u, true>(d, lane, sh, K, consumed_seen) : chain_walker<29u, false>(d, lane, sh, K, consumed_seen);
+      else x = chain_walker<27u, true>(d, lane, sh, K, consumed_seen);   // rABS renormalises with a single `if` (rans.rs:97): never more than one byte
+      uint32_t next = 0;
+      if (lane == 0) next = atomicAdd(next_stream, 1u);
+      next = (uint32_t)__builtin_amdgcn_readfirstlane((int)next) + kChainPairs * gridDim.x;
+      if (next >= n_streams) next = kNoStream;
+      while (K - consumed_seen >= kRing) {
+        consumed_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->consumed);
+        if (K - consumed_seen >= kRing) __builtin_amdgcn_s_sleep(4);
+      }
+      sh->ring[K & (kRing - 1u)][lane] = lane == 0 ? x : next;
+      sh->produced = K + 1u;
+      ++K;
+      sid = next;
+    }
   } else {
-    if (d.kind == 0) chain_emitter<29u>(d, lane, sh); else chain_emitter<27u>(d, lane, sh);
-    if (lane == 0 && d.ticks) d.ticks[0] = (uint32_t)(wall_clock64() - t0);
+    uint32_t K = 0, sid = first;
+    while (sid != kNoStream) {
+      const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)(order ? order[sid] : sid));
+      const ChainDesc d = descs[at];
+      const uint64_t t0 = wall_clock64();   // 100 MHz constant-rate counter
+      sid = d.kind == 0 ? chain_emitter<29u>(d, lane, sh, K) : chain_emitter<27u>(d, lane, sh, K);
+      if (lane == 0 && d.ticks) d.ticks[0] = (uint32_t)(wall_clock64() - t0);
+    }
   }
 }
 
@@ -426,8 +475,14 @@ void launch_copy_items(const CopyItem* items_dev, uint32_t n_items, uint8_t* are
 void launch_scatter_items(const CopyItem* items_dev, uint32_t n_items, const uint8_t* arena, hipStream_t s) {
   if (n_items) hipLaunchKernelGGL(k_scatter_items, n_items, 256, 0, s, items_dev, arena);
 }
-void launch_chains(const ChainDesc* descs_dev, uint32_t n_streams, hipStream_t s) {
-  if (n_streams) hipLaunchKernelGGL(k_chains, n_streams, 128, 0, s, descs_dev);
+uint32_t chain_grid(uint32_t n_streams) {
+  static const uint32_t cap = [] { const char* e = std::getenv("DMI_CHAIN_GRID"); const int v = e ? std::atoi(e) : 0; return v > 0 ? (uint32_t)v : 256u; }();
+  return n_streams < cap ? n_streams : cap;
+}
+void launch_chains(const ChainDesc* descs_dev, const uint32_t* order_dev, uint32_t n_streams, uint32_t* next_stream_dev, hipStream_t s) {
+  if (!n_streams) return;
+  (void)hipMemsetAsync(next_stream_dev, 0, sizeof(uint32_t), s);
+  hipLaunchKernelGGL(k_chains, chain_grid(n_streams), 512, 0, s, descs_dev, order_dev, n_streams, next_stream_dev);
 }
 
 }  // namespace dmi

@@ -117,7 +117,10 @@ struct ChainDesc {
   uint32_t* out_len;        // [0] = bytes written, [1] = error flag (1 = state too large, 2 = capacity)
   uint32_t* ticks;          // optional: chain duration in 100 MHz ticks
 };
-void launch_chains(const ChainDesc* descs_dev, uint32_t n_streams, hipStream_t s);
+// Persistent chain kernel: `order_dev` (nullable) = stream indices longest first; `next_stream_dev` = one device word for the
+// pull counter (zeroed by the launcher on the stream).
+uint32_t chain_grid(uint32_t n_streams);
+void launch_chains(const ChainDesc* descs_dev, const uint32_t* order_dev, uint32_t n_streams, uint32_t* next_stream_dev, hipStream_t s);
 // argument blocks of the record-prep kernels (K_RANS_PREP … K_BATCH_FLAGS); launch_step / launch_steps_multi dispatch to these
 struct RansPrepArgs { const uint32_t* sym; const RansEntry* table; RansEntry* rec; uint32_t* batch_flags; uint64_t n; };
 struct BitsPrepArgs { const uint8_t* bits; RansEntry* rec; uint64_t n; RansEntry e0, e1; };

@@ -513,7 +513,7 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
   }
   HIP_TRY(hipHostMalloc(&job->pinned, pinned_need, hipHostMallocDefault));
   job->pinned_bytes = pinned_need;
-  if ((rc = job->descs.alloc(sizeof(ChainDesc) * (size_t)n_atts * 2))) return rc;
+  if ((rc = job->descs.alloc(sizeof(ChainDesc) * (size_t)n_atts * 2 + 16)   /* + the chain kernel's pull counter */)) return rc;
   if (cfg.flags & DMI_FLAG_TIMINGS) {
     for (auto& e : job->ev) HIP_TRY(hipEventCreate(&e));
     job->have_events = true;
@@ -945,7 +945,7 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
   HIP_TRY(hipMemcpyAsync(job->descs.p, descs.data(), descs.size() * sizeof(ChainDesc), hipMemcpyHostToDevice, s));
   const auto t_tab1 = std::chrono::steady_clock::now();
   if (timed) HIP_TRY(hipEventRecord(job->ev[4], s));
-  launch_chains(job->descs.as<ChainDesc>(), (uint32_t)descs.size(), s);
+  launch_chains(job->descs.as<ChainDesc>(), nullptr, (uint32_t)descs.size(), reinterpret_cast<uint32_t*>(job->descs.as<ChainDesc>() + job->atts.size() * 2), s);
   if (timed) HIP_TRY(hipEventRecord(job->ev[5], s));
   if ((rc = encode_phase_c1(job))) return rc;
   HIP_TRY(hipStreamSynchronize(s));
@@ -1267,10 +1267,17 @@ int dmi_jobs_encode(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
   const auto t4 = now();
   std::vector<ChainDesc> all;
   for (uint32_t j = 0; j < n; ++j) all.insert(all.end(), jobs[j]->run.descs.begin(), jobs[j]->run.descs.end());
-  DevMem descs_dev;
-  if ((rc = descs_dev.alloc(all.size() * sizeof(ChainDesc)))) return rc;
-  HIP_TRY(hipMemcpyAsync(descs_dev.p, all.data(), all.size() * sizeof(ChainDesc), hipMemcpyHostToDevice, s));
-  launch_chains(descs_dev.as<ChainDesc>(), (uint32_t)all.size(), s);
+  // the chain kernel serves the streams longest first (its pairs pull work; see k_chains)
+  std::vector<uint32_t> by_length(all.size());
+  for (uint32_t k = 0; k < (uint32_t)all.size(); ++k) by_length[k] = k;
+  std::stable_sort(by_length.begin(), by_length.end(), [&](uint32_t x, uint32_t y) { return all[x].n > all[y].n; });
+  DevMem descs_dev;   // descriptors | order | pull counter
+  const size_t order_at = all.size() * sizeof(ChainDesc), counter_at = order_at + ((all.size() * sizeof(uint32_t) + 15) & ~(size_t)15);
+  if ((rc = descs_dev.alloc(counter_at + 16))) return rc;
+  HIP_TRY(hipMemcpyAsync(descs_dev.p, all.data(), order_at, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(descs_dev.p) + order_at, by_length.data(), all.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+  launch_chains(descs_dev.as<ChainDesc>(), reinterpret_cast<const uint32_t*>(static_cast<uint8_t*>(descs_dev.p) + order_at), (uint32_t)all.size(),
+                reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(descs_dev.p) + counter_at), s);
   HIP_TRY(hipStreamSynchronize(s));
   const auto t5 = now();
   // read-back: every stream of every job packed into one arena on the device → one table copy + one byte copy
