@@ -62,7 +62,7 @@ __device__ __forceinline__ void k_rans_prep_body(const RansPrepArgs& a, const ui
   const uint64_t n_round = (n + 63) & ~(uint64_t)63;
   for (uint64_t t = (uint64_t)blk_ * 256 + threadIdx.x; t < n_round; t += (uint64_t)nblk_ * 256) {
     RansEntry e{0u, 0u, 0u, 0u, 0u};
-    if (t < n) { e = table[sym[n - 1 - t]]; rec[t] = e; }
+    if (t < n) { const uint32_t v = sym[n - 1 - t]; if (v < a.bins) e = table[v]; rec[t] = e; }
     const unsigned long long f1 = __ballot((e.b & 0x100u) != 0), multi = __ballot((e.b & 0x200u) != 0);
     if ((threadIdx.x & 63) == 0) batch_flags[t >> 6] = (f1 != 0ull ? 1u : 0u) | (multi != 0ull ? 2u : 0u);
   }
@@ -71,7 +71,7 @@ __device__ __forceinline__ void k_rans_prep_body(const RansPrepArgs& a, const ui
 // Per-batch "contains a frequency-1 record" flags for a finished record stream (rABS streams).
 __device__ __forceinline__ void k_batch_flags_body(const BatchFlagsArgs& a, const uint32_t blk_, const uint32_t nblk_) {
   const RansEntry* __restrict__ rec = a.rec;
-  const uint64_t n = a.n;
+  const uint64_t n = a.n_dev ? min((uint64_t)*a.n_dev, a.n) : a.n;   // (the grid is sized for a.n)
   uint32_t* __restrict__ batch_flags = a.batch_flags;
   const uint64_t n_round = (n + 63) & ~(uint64_t)63;
   for (uint64_t t = (uint64_t)blk_ * 256 + threadIdx.x; t < n_round; t += (uint64_t)nblk_ * 256) {
@@ -84,7 +84,7 @@ __device__ __forceinline__ void k_batch_flags_body(const BatchFlagsArgs& a, cons
 __device__ __forceinline__ void k_bits_prep_body(const BitsPrepArgs& a, const uint32_t blk_, const uint32_t nblk_) {
   const uint8_t* __restrict__ bits = a.bits;
   const uint64_t n = a.n;
-  const RansEntry e0 = a.e0, e1 = a.e1;
+  const RansEntry e0 = a.entries ? a.entries[0] : a.e0, e1 = a.entries ? a.entries[1] : a.e1;
   RansEntry* __restrict__ rec = a.rec;
   for (uint64_t t = (uint64_t)blk_ * 256 + threadIdx.x; t < n; t += (uint64_t)nblk_ * 256) rec[t] = pick(bits[t] != 0, e0, e1);
 }
@@ -96,7 +96,7 @@ __device__ __forceinline__ void k_orient_prep_body(const OrientPrepArgs& a, cons
   const uint8_t* __restrict__ orient = a.orient;
   const uint32_t n = a.n;
   const uint32_t* __restrict__ chunk_info = a.chunk_info;
-  const RansEntry e0 = a.e0, e1 = a.e1;
+  const RansEntry e0 = a.entries ? a.entries[0] : a.e0, e1 = a.entries ? a.entries[1] : a.e1;
   RansEntry* __restrict__ rec = a.rec;
   const uint32_t lane = threadIdx.x;
   const uint32_t lo = blk_ * 4096u;
@@ -131,6 +131,252 @@ __device__ __forceinline__ void k_orient_prep_body(const OrientPrepArgs& a, cons
       rec[at] = pick(mine == nxt, e0, e1);
     }
     carry = (uint32_t)((ones >> (__ffsll((long long)valid) - 1)) & 1ull);
+  }
+}
+
+// ---- the table stage on the device (see TableAtt) -------------------------------------------------------------
+struct TablesLds {
+  uint64_t red[kTablesThreads / 64];
+  uint32_t stage[4 * 1024];   // orientation summaries, 1024 blocks at a time
+  uint32_t nextv;
+};
+__device__ __forceinline__ uint64_t block_sum(uint64_t v, uint64_t* red) {   // every thread receives the total
+#pragma unroll
+  for (int o = 32; o; o >>= 1) v += (uint64_t)__shfl_xor((unsigned long long)v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63u) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  uint64_t t = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < kTablesThreads / 64; ++w) t += red[w];
+  return t;
+}
+__device__ __forceinline__ uint64_t block_max(uint64_t v, uint64_t* red) {
+#pragma unroll
+  for (int o = 32; o; o >>= 1) { const uint64_t t = (uint64_t)__shfl_xor((unsigned long long)v, o, 64); v = t > v ? t : v; }
+  __syncthreads();
+  if ((threadIdx.x & 63u) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  uint64_t t = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < kTablesThreads / 64; ++w) t = red[w] > t ? red[w] : t;
+  return t;
+}
+// the f32 "(c0 / len) * 256 + 0.5 → u16 → clamp(1, 255)" idiom of the metadata coders (mesh_normal_prediction.rs:147-150)
+__device__ __forceinline__ uint32_t zero_probability_dev(uint64_t count_zero, float denominator) {
+  const float p = ((float)count_zero / denominator) * 256.0f + 0.5f;
+  const uint32_t q = (p != p || p <= 0.0f) ? 0u : (p >= 65535.0f ? 65535u : (uint32_t)p);   // Rust `as u16`
+  return min(255u, max(1u, q));
+}
+// bytes symbol s contributes to the serialised table (rans.rs:199-228) and their values
+__device__ __forceinline__ uint32_t table_token(const uint32_t* freq, uint32_t s, uint32_t& bytes) {
+  const uint32_t f = freq[s];
+  if (f) {
+    const uint32_t extra = f >= (1u << 14) ? 2u : (f >= (1u << 6) ? 1u : 0u);
+    bytes = ((f << 2) | extra) & 0xFFu;
+    for (uint32_t b = 0; b < extra; ++b) bytes |= ((f >> (8u * (b + 1u) - 2u)) & 0xFFu) << (8u * (b + 1u));
+    return 1u + extra;
+  }
+  // a zero: r = zeros that follow directly (capped at 64; the last symbol of the table is non-zero).  The serial loop emits
+  // `(r << 2) | 3` and skips the r zeros when r ≤ 63, and `(64 << 2) | 3` truncated to a byte (= 3) WITHOUT skipping when
+  // more follow (Q20) — so a zero emits a token iff it starts its run or at least 63 zeros follow it.
+  uint32_t r = 0;
+  while (r < 64u && freq[s + r + 1u] == 0u) ++r;
+  const bool starts = s == 0u || freq[s - 1u] != 0u;
+  if (!starts && r < 63u) return 0u;
+  bytes = r >= 64u ? 3u : ((r << 2) | 3u);
+  return 1u;
+}
+__device__ __forceinline__ void write_desc(ChainDesc* at, uint32_t kind, uint32_t precision, uint64_t n, const uint32_t* sym, uint32_t one_byte, const RansEntry* table,
+                                           const uint32_t* batch_flags, uint32_t state0, uint8_t* out, uint64_t cap, uint32_t* out_len, uint32_t* ticks) {
+  ChainDesc d;
+  d.kind = kind; d.precision = precision; d.n = n; d.sym = sym; d.one_byte = one_byte; d.pad0 = 0; d.table = table; d.batch_flags = batch_flags;
+  d.force_generic = 0; d.state0 = state0; d.out = out; d.cap = cap; d.out_len = out_len; d.ticks = ticks;
+  *at = d;
+}
+
+__device__ void k_tables_body(const TableAtt& a, const uint32_t, const uint32_t) {
+  __shared__ TablesLds lds;
+  const uint32_t tid = threadIdx.x, T = kTablesThreads;
+  const uint32_t* __restrict__ hist = a.hist;
+  uint32_t* freq = a.freq;
+  const uint32_t bins = a.bins;
+  uint32_t err = 0;
+  // ---- alphabet, bit_length, precision (symbol_coding.rs:46,118-141; Q11) ----
+  uint64_t tot = 0, last = 0;
+  for (uint32_t s = tid; s < bins; s += T) { const uint32_t h = hist[s]; tot += h; if (h) last = s + 1u; }
+  const uint64_t total = block_sum(tot, lds.red);
+  const uint32_t num_symbols = (uint32_t)block_max(last, lds.red);
+  uint32_t precision = 12, bit_length = 1;
+  if (num_symbols == 0) err = 1;
+  if (!err) {
+    const uint64_t nonzero = total - hist[0];
+    const uint32_t bl = (nonzero ? 64u - (uint32_t)__builtin_clzll(nonzero) : 0u) + 1u;
+    bit_length = min(18u, max(1u, bl));
+    precision = bit_length <= 8 ? 12u : bit_length == 9 ? 13u : bit_length == 10 ? 15u : bit_length == 11 ? 16u : bit_length == 12 ? 18u : bit_length == 13 ? 19u : 20u;
+  }
+  const uint64_t target = 1ull << precision;
+  // ---- normalisation (rans.rs:146-190) ----
+  if (!err) {
+    uint64_t part = 0;
+    const double totd = (double)total;
+    for (uint32_t s = tid; s < num_symbols; s += T) {
+      const uint32_t h = hist[s];
+      uint64_t nf = (uint64_t)(((double)h / totd) * (double)target + 0.5);
+      if (nf == 0 && h) nf = 1;
+      freq[s] = (uint32_t)nf;
+      part += nf;
+    }
+    const uint64_t sum = block_sum(part, lds.red);   // (the barriers inside also publish freq[] to the block)
+    if (sum < target) {
+      // the deficit goes to the largest frequency, the LAST of equals (stable sort by key, Q12)
+      uint64_t best = 0;
+      for (uint32_t s = tid; s < num_symbols; s += T) { const uint64_t key = ((uint64_t)freq[s] << 32) | s; best = key > best ? key : best; }
+      best = block_max(best, lds.red);
+      if (tid == 0) freq[(uint32_t)best] += (uint32_t)(target - sum);
+    } else if (sum > target) {
+      // one off each of the `excess` largest, largest first, higher index first among equals: with T = the excess-th largest
+      // value, everything above T loses one, and of the entries equal to T the ones with the highest indices
+      const uint64_t excess = sum - target;
+      if (excess > num_symbols) err = 2;
+      if (!err) {
+        uint32_t lo = 0, hi = (uint32_t)target;
+        while (lo < hi) {   // largest T with #(freq ≥ T) ≥ excess
+          const uint32_t mid = lo + (hi - lo + 1u) / 2u;
+          uint64_t c = 0;
+          for (uint32_t s = tid; s < num_symbols; s += T) c += freq[s] >= mid;
+          c = block_sum(c, lds.red);
+          if (c >= excess) lo = mid; else hi = mid - 1u;
+        }
+        const uint32_t thr = lo;
+        if (thr == 0) err = 3;   // a zero would be decremented
+        if (!err) {
+          uint64_t above = 0;
+          for (uint32_t s = tid; s < num_symbols; s += T) above += freq[s] > thr;
+          above = block_sum(above, lds.red);
+          const uint64_t need = excess - above;   // ≥ 1 entries equal to thr, from the highest index down
+          uint32_t ilo = 0, ihi = num_symbols - 1u;
+          while (ilo < ihi) {   // largest I with #(freq == thr, index ≥ I) ≥ need
+            const uint32_t mid = ilo + (ihi - ilo + 1u) / 2u;
+            uint64_t c = 0;
+            for (uint32_t s = tid; s < num_symbols; s += T) c += (freq[s] == thr && s >= mid);
+            c = block_sum(c, lds.red);
+            if (c >= need) ilo = mid; else ihi = mid - 1u;
+          }
+          __syncthreads();
+          for (uint32_t s = tid; s < num_symbols; s += T) { const uint32_t f = freq[s]; if (f > thr || (f == thr && s >= ilo)) freq[s] = f - 1u; }
+        }
+      }
+    }
+    __syncthreads();
+    // the over-correction can drive an occurring symbol to 0: the reference coder does not terminate on such a table
+    uint64_t bad = 0;
+    for (uint32_t s = tid; s < num_symbols; s += T) bad += (hist[s] != 0u && freq[s] == 0u);
+    if (block_sum(bad, lds.red) && !err) err = 4;
+  }
+  // ---- cumulative frequencies → coding records; the serialised table (rans.rs:192-228) ----
+  uint32_t prefix = 0, hdr_len = 0;
+  uint64_t rare = 0;
+  uint8_t* hdr = a.hdr;
+  if (!err) {
+    uint8_t pre[8];
+    pre[0] = 1; pre[1] = (uint8_t)bit_length;   // SymbolEncodingMethod::DirectCoded, bit_length
+    prefix = 2;
+    for (uint32_t v = num_symbols;;) { const uint8_t b = v & 0x7Fu; v >>= 7; if (v) pre[prefix++] = b | 0x80u; else { pre[prefix++] = b; break; } }
+    if ((uint64_t)prefix + 3ull * num_symbols > a.hdr_cap) err = 5;
+    if (!err && tid == 0) for (uint32_t k = 0; k < prefix; ++k) hdr[k] = pre[k];
+  }
+  if (!err) {
+    uint64_t carry = 0;   // (header bytes << 32) | cumulative frequency
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t base = 0; base < num_symbols; base += T) {
+      const uint32_t s = base + tid;
+      uint32_t f = 0, nbytes = 0, bytes = 0;
+      if (s < num_symbols) { f = freq[s]; nbytes = table_token(freq, s, bytes); }
+      const uint64_t v = ((uint64_t)nbytes << 32) | f;
+      uint64_t incl = v;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const uint64_t t = (uint64_t)__shfl_up((unsigned long long)incl, d, 64); if (lane >= (uint32_t)d) incl += t; }
+      __syncthreads();
+      if (lane == 63u) lds.red[wave] = incl;
+      __syncthreads();
+      uint64_t before = carry, chunk = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < kTablesThreads / 64; ++w) { if (w < wave) before += lds.red[w]; chunk += lds.red[w]; }
+      const uint64_t excl = before + incl - v;
+      if (s < num_symbols) {
+        a.rtable[s] = make_rans_entry(f, (uint32_t)excl, precision);
+        uint8_t* at = hdr + prefix + (uint32_t)(excl >> 32);
+        for (uint32_t k = 0; k < nbytes; ++k) at[k] = (uint8_t)(bytes >> (8u * k));
+        if (f && ((uint64_t)f << 8) < target) rare += hist[s];
+      }
+      carry += chunk;
+    }
+    hdr_len = prefix + (uint32_t)(carry >> 32);
+    rare = block_sum(rare, lds.red);
+  }
+  // ---- the metadata stream of the prediction scheme ----
+  uint32_t zero_prob = 0, aux_count = 0;
+  if (a.aux_kind == 1) {           // normal flips: mesh_normal_prediction.rs:147-150 (count of `false` in small[2])
+    aux_count = a.n_entries;
+    zero_prob = zero_probability_dev(a.small[2], (float)a.n_entries);
+  } else if (a.aux_kind == 2) {    // orientations: stitch the per-block summaries {count, first, last, transitions} (…texture_coordinates.rs:224-253, Q10)
+    const uint32_t nb = a.summary_blocks;
+    uint64_t len = 0, trans = 0;
+    uint32_t lastv = 1, off = 0;
+    for (uint32_t base = 0; base < nb; base += 1024u) {
+      const uint32_t cnt = min(1024u, nb - base);
+      __syncthreads();
+      for (uint32_t k = tid; k < 4u * cnt; k += T) lds.stage[k] = a.summary[4u * base + k];
+      __syncthreads();
+      if (tid == 0)
+        for (uint32_t b = 0; b < cnt; ++b) {
+          const uint32_t c = lds.stage[4 * b];
+          a.chunk_info[2 * (base + b)] = off;
+          off += c;
+          if (!c) continue;
+          if (lds.stage[4 * b + 1] != lastv) ++trans;
+          trans += lds.stage[4 * b + 3];
+          lastv = lds.stage[4 * b + 2];
+          len += c;
+        }
+    }
+    if (tid == 0) lds.nextv = 1u;   // `true` after the last valid entry
+    for (uint32_t hi = nb; hi > 0;) {
+      const uint32_t base = (hi - 1u) & ~1023u, cnt = hi - base;
+      __syncthreads();
+      for (uint32_t k = tid; k < 4u * cnt; k += T) lds.stage[k] = a.summary[4u * base + k];
+      __syncthreads();
+      if (tid == 0) {
+        uint32_t nextv = lds.nextv;
+        for (uint32_t b = cnt; b-- > 0;) { a.chunk_info[2 * (base + b) + 1] = nextv; if (lds.stage[4 * b]) nextv = lds.stage[4 * b + 1]; }
+        lds.nextv = nextv;
+      }
+      hi = base;
+    }
+    if (tid == 0) { lds.red[0] = len; lds.red[1] = trans; }
+    __syncthreads();
+    len = lds.red[0]; trans = lds.red[1];
+    __syncthreads();
+    aux_count = (uint32_t)len;
+    zero_prob = zero_probability_dev(trans, (float)len + 0.001f);
+  }
+  if (tid == 0) {
+    a.small[6] = hdr_len;
+    a.small[7] = err;
+    a.small[14] = zero_prob;
+    a.small[15] = aux_count;
+    // which step the stream's walker uses: the one-byte step pays off when few batches of 64 hold a rare symbol (f < 2^(P-8))
+    const double clean = pow(1.0 - (double)rare / (double)max((uint64_t)1, a.n_sym), 64.0);
+    write_desc(a.desc, 0u, precision, err ? 0ull : a.n_sym, a.sym, clean > 0.8 ? 1u : 0u, a.rec, a.batch_flags, 4u << precision, a.out, a.out_cap, a.small + 8, a.small + 12);
+    if (a.aux_kind) {
+      // rABS (rans.rs:91-108): bit 1 codes with f1 = 256 - p0 and offset 0, bit 0 with p0 and offset f1
+      const uint32_t p0 = zero_prob, f1 = 256u - p0;
+      a.aux_entries[0] = make_rans_entry(p0, f1, 8);
+      a.aux_entries[1] = make_rans_entry(f1, 0, 8);
+      write_desc(a.aux_desc, a.aux_kind, 8u, aux_count, nullptr, 0u, a.aux_rec, a.aux_flags, 4096u, a.aux_out, a.aux_cap, a.small + 10, a.small + 13);
+    }
+    if (a.hdr_desc) write_desc(a.hdr_desc, 3u, 0u, 0ull, nullptr, 0u, nullptr, nullptr, 0u, a.hdr, a.hdr_cap, a.small + 6, nullptr);
   }
 }
 
@@ -414,6 +660,7 @@ DMI_PREP_KERNEL(k_rans_prep, k_rans_prep_body, RansPrepArgs, 256)
 DMI_PREP_KERNEL(k_batch_flags, k_batch_flags_body, BatchFlagsArgs, 256)
 DMI_PREP_KERNEL(k_bits_prep, k_bits_prep_body, BitsPrepArgs, 256)
 DMI_PREP_KERNEL(k_orient_prep, k_orient_prep_body, OrientPrepArgs, 64)
+DMI_PREP_KERNEL(k_tables, k_tables_body, TableAtt, kTablesThreads)
 
 template <class Args>
 void emit_prep(int id, int level, const Args& a, uint32_t blocks, hipStream_t s) {
@@ -433,6 +680,7 @@ void launch_prep_step(const KernelStep& st, hipStream_t s) {
     case K_BATCH_FLAGS: hipLaunchKernelGGL(k_batch_flags, st.blocks, 256, 0, s, *reinterpret_cast<const BatchFlagsArgs*>(st.args)); break;
     case K_BITS_PREP: hipLaunchKernelGGL(k_bits_prep, st.blocks, 256, 0, s, *reinterpret_cast<const BitsPrepArgs*>(st.args)); break;
     case K_ORIENT_PREP: hipLaunchKernelGGL(k_orient_prep, st.blocks, 64, 0, s, *reinterpret_cast<const OrientPrepArgs*>(st.args)); break;
+    case K_TABLES: hipLaunchKernelGGL(k_tables, st.blocks, kTablesThreads, 0, s, *reinterpret_cast<const TableAtt*>(st.args)); break;
     default: break;
   }
 }
@@ -442,27 +690,37 @@ void launch_prep_steps_multi(int id, const void* items, const uint2* block_info,
     case K_BATCH_FLAGS: hipLaunchKernelGGL(k_batch_flags_multi, total_blocks, 256, 0, s, static_cast<const BatchFlagsArgs*>(items), block_info, item_blocks); break;
     case K_BITS_PREP: hipLaunchKernelGGL(k_bits_prep_multi, total_blocks, 256, 0, s, static_cast<const BitsPrepArgs*>(items), block_info, item_blocks); break;
     case K_ORIENT_PREP: hipLaunchKernelGGL(k_orient_prep_multi, total_blocks, 64, 0, s, static_cast<const OrientPrepArgs*>(items), block_info, item_blocks); break;
+    case K_TABLES: hipLaunchKernelGGL(k_tables_multi, total_blocks, kTablesThreads, 0, s, static_cast<const TableAtt*>(items), block_info, item_blocks); break;
     default: break;
   }
 }
 
-// record prep: symbols / bits / orientation flags → coding records (level 0), then the per-batch frequency-1 flags of the rABS
-// record streams (level 1)
-void launch_rans_prep(const uint32_t* sym, uint64_t n, const RansEntry* table, RansEntry* rec, uint32_t* batch_flags, hipStream_t s) {
-  RansPrepArgs a{sym, table, rec, batch_flags, n};
-  emit_prep(K_RANS_PREP, 0, a, n ? grid256(n) : 0u, s);
+// record prep: symbols / bits / orientation flags → coding records, then the per-batch frequency-1 flags of the rABS record streams
+// levels: the table kernel (device form) 0, record prep 1, batch flags of the rABS record streams 2
+void launch_tables(const TableAtt& a, hipStream_t s) { emit_prep(K_TABLES, 0, a, 1u, s); }
+void launch_rans_prep(const uint32_t* sym, uint64_t n, const RansEntry* table, uint32_t bins, RansEntry* rec, uint32_t* batch_flags, hipStream_t s) {
+  RansPrepArgs a{sym, table, rec, batch_flags, n, bins, 0u};
+  emit_prep(K_RANS_PREP, 1, a, n ? grid256(n) : 0u, s);
 }
 void launch_bits_prep(const uint8_t* bits, uint64_t n, RansEntry e0, RansEntry e1, RansEntry* rec, hipStream_t s) {
-  BitsPrepArgs a{bits, rec, n, e0, e1};
-  emit_prep(K_BITS_PREP, 0, a, n ? grid256(n) : 0u, s);
+  BitsPrepArgs a{bits, rec, n, e0, e1, nullptr};
+  emit_prep(K_BITS_PREP, 1, a, n ? grid256(n) : 0u, s);
+}
+void launch_bits_prep_dev(const uint8_t* bits, uint64_t n, const RansEntry* entries, RansEntry* rec, hipStream_t s) {
+  BitsPrepArgs a{bits, rec, n, RansEntry{}, RansEntry{}, entries};
+  emit_prep(K_BITS_PREP, 1, a, n ? grid256(n) : 0u, s);
 }
 void launch_orient_prep(const uint8_t* orient, uint32_t n, const uint32_t* chunk_info, RansEntry e0, RansEntry e1, RansEntry* rec, hipStream_t s) {
-  OrientPrepArgs a{orient, chunk_info, rec, e0, e1, n, 0u};
-  emit_prep(K_ORIENT_PREP, 0, a, (n + 4095u) / 4096u, s);
+  OrientPrepArgs a{orient, chunk_info, rec, e0, e1, n, 0u, nullptr};
+  emit_prep(K_ORIENT_PREP, 1, a, (n + 4095u) / 4096u, s);
 }
-void launch_batch_flags(const RansEntry* rec, uint64_t n, uint32_t* batch_flags, hipStream_t s) {
-  BatchFlagsArgs a{rec, batch_flags, n};
-  emit_prep(K_BATCH_FLAGS, 1, a, n ? grid256(n) : 0u, s);
+void launch_orient_prep_dev(const uint8_t* orient, uint32_t n, const uint32_t* chunk_info, const RansEntry* entries, RansEntry* rec, hipStream_t s) {
+  OrientPrepArgs a{orient, chunk_info, rec, RansEntry{}, RansEntry{}, n, 0u, entries};
+  emit_prep(K_ORIENT_PREP, 1, a, (n + 4095u) / 4096u, s);
+}
+void launch_batch_flags(const RansEntry* rec, uint64_t n, const uint32_t* n_dev, uint32_t* batch_flags, hipStream_t s) {
+  BatchFlagsArgs a{rec, batch_flags, n, n_dev};
+  emit_prep(K_BATCH_FLAGS, 2, a, n ? grid256(n) : 0u, s);
 }
 void launch_pack_streams(const ChainDesc* descs_dev, uint32_t n_streams, PackEntry* table, uint8_t* arena, hipStream_t s) {
   if (!n_streams) return;

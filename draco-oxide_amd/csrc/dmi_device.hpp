@@ -15,8 +15,9 @@ namespace dmi {
 // `level` orders the steps of one job: steps of equal level are independent of each other.
 enum KernelId : int { K_RANGES, K_RANGES_FINAL, K_SEQ_QUANT, K_I32_FINAL, K_FUSED_PNU, K_FUSED_PN, K_FUSED_PU, K_FUSED_N,
                       K_PAR1, K_PAR2, K_PAR3, K_PAR4, K_DELTA, K_TEX, K_ORIENT, K_HIST,
-                      K_RANS_PREP, K_BITS_PREP, K_ORIENT_PREP, K_BATCH_FLAGS /* record prep: dmi_chains.hip */, K_COUNT };
-constexpr int kStepLevels = 7;
+                      K_RANS_PREP, K_BITS_PREP, K_ORIENT_PREP, K_BATCH_FLAGS, K_TABLES /* tables + record prep: dmi_chains.hip */, K_COUNT };
+constexpr int kStepLevels = 7;        // data-parallel phases: levels 0..6
+constexpr int kPrepLevels = 3;        // tables (device form), record prep, batch flags: levels kStepLevels + 0..2 when planned together with the phases
 struct KernelStep { int id; int level; uint32_t blocks; uint32_t lds; uint32_t args_size; uint32_t pad; alignas(8) uint8_t args[640]; };
 void set_step_sink(std::vector<KernelStep>* sink);   // thread-local; nullptr = launch immediately
 bool step_sink_push(const KernelStep& st);           // true = a sink is set and took the step
@@ -94,13 +95,29 @@ void launch_histograms(HistArgs& args, hipStream_t s);
 // f < 2^(P-8); d = 2^P - f; c = cumulative frequency; t = renormalisation threshold (x ≥ t ⇒ at least one byte leaves).
 struct RansEntry { uint32_t m, b, d, c, t; };   // t = f << 10 (rANS) / f << 12 (rABS): the renormalisation threshold
 constexpr size_t kChainPad = 384;   // records a stream's buffer extends past n: the chain's look-ahead loads may run that far
-RansEntry make_rans_entry(uint32_t freq, uint32_t cum, uint32_t precision);   // host helper (precision 8 = rABS: threshold f << 12)
+// Coding record of a symbol with normalised frequency f (see dmi_chains.hip for the exactness argument); precision 8 = rABS.
+__host__ __device__ inline RansEntry make_rans_entry(uint32_t f, uint32_t cum, uint32_t precision) {
+  RansEntry e{0u, 0u, 0u, cum, 0u};
+  if (f == 0) return e;                       // never coded
+  e.t = f << (precision == 8 ? 12 : 10);      // rans.rs:40 `state >= (L >> P) * f << 8` with L = 4·2^P; rABS :97 with L = 4096
+  e.d = (1u << precision) - f;
+  // bit 9 of b: f < 2^(P-8) — the state can exceed f·2^18, i.e. this symbol may renormalise by more than one byte
+  const uint32_t multi = (precision >= 8 && ((uint64_t)f << 8) < ((uint64_t)1 << precision)) ? 0x200u : 0u;
+  if (f == 1) { e.m = 0xFFFFFFFFu; e.b = 0x100u | multi; return e; }   // flagged: the batch takes the generic loop
+  const unsigned lg = 31u - (unsigned)__builtin_clz(f);
+  if ((f & (f - 1)) == 0) { e.m = 0x80000000u; e.b = (lg - 1) | multi; return e; }
+  e.m = (uint32_t)((((uint64_t)1 << (32 + lg)) + f - 1) / f);
+  e.b = lg | multi;
+  return e;
+}
 // batch_flags: (n + 63) / 64 + 1 words; [b] != 0 ⇔ batch b holds a frequency-1 symbol
-void launch_rans_prep(const uint32_t* sym, uint64_t n, const RansEntry* table, RansEntry* rec, uint32_t* batch_flags, hipStream_t s);
-void launch_batch_flags(const RansEntry* rec, uint64_t n, uint32_t* batch_flags, hipStream_t s);
+void launch_rans_prep(const uint32_t* sym, uint64_t n, const RansEntry* table, uint32_t bins, RansEntry* rec, uint32_t* batch_flags, hipStream_t s);
+void launch_batch_flags(const RansEntry* rec, uint64_t n, const uint32_t* n_dev, uint32_t* batch_flags, hipStream_t s);
 void launch_bits_prep(const uint8_t* bits, uint64_t n, RansEntry e0, RansEntry e1, RansEntry* rec, hipStream_t s);
+void launch_bits_prep_dev(const uint8_t* bits, uint64_t n, const RansEntry* entries, RansEntry* rec, hipStream_t s);   // record pair in device memory
 // chunk_info[2c] = compact offset of 4096-flag chunk c, [2c+1] = value (0/1) of the first valid flag after it (1 if none)
 void launch_orient_prep(const uint8_t* orient, uint32_t n, const uint32_t* chunk_info, RansEntry e0, RansEntry e1, RansEntry* rec, hipStream_t s);
+void launch_orient_prep_dev(const uint8_t* orient, uint32_t n, const uint32_t* chunk_info, const RansEntry* entries, RansEntry* rec, hipStream_t s);
 struct ChainDesc {
   uint32_t kind;            // 0 = rANS over coding records, 1 = rABS over flips (forward), 2 = rABS over orientation flags
   uint32_t precision;       // rANS precision bits
@@ -122,10 +139,30 @@ struct ChainDesc {
 uint32_t chain_grid(uint32_t n_streams);
 void launch_chains(const ChainDesc* descs_dev, const uint32_t* order_dev, uint32_t n_streams, uint32_t* next_stream_dev, hipStream_t s);
 // argument blocks of the record-prep kernels (K_RANS_PREP … K_BATCH_FLAGS); launch_step / launch_steps_multi dispatch to these
-struct RansPrepArgs { const uint32_t* sym; const RansEntry* table; RansEntry* rec; uint32_t* batch_flags; uint64_t n; };
-struct BitsPrepArgs { const uint8_t* bits; RansEntry* rec; uint64_t n; RansEntry e0, e1; };
-struct OrientPrepArgs { const uint8_t* orient; const uint32_t* chunk_info; RansEntry* rec; RansEntry e0, e1; uint32_t n; uint32_t pad; };
-struct BatchFlagsArgs { const RansEntry* rec; uint32_t* batch_flags; uint64_t n; };
+// `bins`: symbols ≥ bins (only possible after a histogram overflow, which is reported as an error) take an all-zero record.
+// `entries` (nullable): {record of bit 0, record of bit 1} in device memory (written by k_tables) instead of e0 / e1;
+// `n_dev` (nullable): the record count in device memory (texture-coordinate orientation streams, whose length the device finds).
+struct RansPrepArgs { const uint32_t* sym; const RansEntry* table; RansEntry* rec; uint32_t* batch_flags; uint64_t n; uint32_t bins; uint32_t pad; };
+struct BitsPrepArgs { const uint8_t* bits; RansEntry* rec; uint64_t n; RansEntry e0, e1; const RansEntry* entries; };
+struct OrientPrepArgs { const uint8_t* orient; const uint32_t* chunk_info; RansEntry* rec; RansEntry e0, e1; uint32_t n; uint32_t pad; const RansEntry* entries; };
+struct BatchFlagsArgs { const RansEntry* rec; uint32_t* batch_flags; uint64_t n; const uint32_t* n_dev; };
+// Device form of the table stage (a17 + the descriptors of the streams): one workgroup per attribute normalises the histogram
+// (RansSymbolEncoder::new, rans.rs:146-239), serialises the table, builds the coding-record table, closes the metadata
+// streams' parameters (zero_prob, record pair, orientation chunk offsets) and writes the attribute's chain descriptors —
+// nothing of an encode comes back to the host before the chains have run.
+// small[] words written here: [6] header bytes, [7] table error (1 empty histogram, 2 normalisation overflow, 3 underflow,
+// 4 occurring symbol normalised to 0, 5 header capacity), [14] metadata zero_prob, [15] metadata entry count.
+struct TableAtt {
+  const uint32_t* hist; uint32_t* freq /* scratch: bins words */; RansEntry* rtable; uint8_t* hdr; uint32_t* small;
+  uint64_t n_sym; uint32_t bins; uint32_t hdr_cap;
+  ChainDesc* desc; const uint32_t* sym; const RansEntry* rec; const uint32_t* batch_flags; uint8_t* out; uint64_t out_cap;   // the rANS stream
+  uint32_t aux_kind /* 0 none, 1 normal flips, 2 texture-coordinate orientations */; uint32_t n_entries /* sequence entries */;
+  const uint32_t* summary; uint32_t* chunk_info; RansEntry* aux_entries; uint32_t summary_blocks; uint32_t pad;
+  ChainDesc* aux_desc; const RansEntry* aux_rec; const uint32_t* aux_flags; uint8_t* aux_out; uint64_t aux_cap;
+  ChainDesc* hdr_desc;   // nullable: pseudo-descriptor {out = hdr, out_len = small + 6} so that the header rides the packed read-back
+};
+constexpr uint32_t kTablesThreads = 1024;
+void launch_tables(const TableAtt& a, hipStream_t s);
 void launch_prep_step(const KernelStep& st, hipStream_t s);
 void launch_prep_steps_multi(int id, const void* items, const uint2* block_info, const uint32_t* item_blocks, uint32_t total_blocks, hipStream_t s);
 // Batch read-back: pack the coded bytes of every stream into `arena` (16-byte aligned slots, in stream order);

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <memory>
 #include <mutex>
+#include <functional>
 #include <thread>
 
 #include "dmi_device.hpp"
@@ -89,6 +90,8 @@ struct AttJob {
   uint64_t n_sym = 0;
   uint64_t out_cap = 0, aux_cap = 0;
   DevMem aux_out, aux_rec, chunk_info, batch_flags, aux_flags;
+  DevMem freq, hdr, aux_entries;   // device form of the table stage: normalised-frequency scratch, serialised table, rABS record pair
+  uint32_t hdr_cap = 0;
   DevMem fan_hdr, fan_apex, fan;   // fan rows of a normal attribute swept on its own table (position ranks, centre in apex)
   FreqTable ft;
   std::vector<RansEntry> rt_host;     // staging (kept alive until the copies have been issued)
@@ -117,12 +120,17 @@ struct dmi_job {
   hipGraphExec_t graph_a = nullptr;   // phase A captured once (launch-bound for small meshes)
   bool graph_tried = false;
   uint8_t* readback = nullptr;     // where the slab of the current encode was read back to (pinned, or a batch arena slot)
+  bool dev_tables = false;         // tables, metadata parameters and chain descriptors are produced on the device (k_tables): no host round trip
+                                   // between the histograms and the chains (DMI_HOST_TABLES=1 or a ToBits attribute keep the host form)
   uint8_t* out_pinned = nullptr;   // grow-only pinned arena for the coded bytes of one encode
   size_t out_pinned_cap = 0;
   struct Run {   // state carried between the phases of one encode
     std::vector<size_t> rans_off, aux_off;   // offsets into out_pinned
     std::vector<const uint8_t*> rans_ptr, aux_ptr;   // host addresses of the coded bytes (pinned memory)
     std::vector<uint32_t> rans_len, aux_len;
+    std::vector<const uint8_t*> hdr_ptr;     // serialised frequency tables (host form: FreqTable::header; device form: read back)
+    std::vector<uint32_t> hdr_len;
+    std::vector<size_t> hdr_off;
     struct Pending { void* dst; const void* src; size_t bytes; };
     std::vector<Pending> pending;   // host → device copies deferred to the batch driver (plan mode of phase B)
     std::vector<size_t> pin_off;
@@ -209,23 +217,6 @@ int validate_and_plan(const dmi_attribute* atts, uint32_t n_atts, const dmi_conf
 
 }  // namespace
 
-namespace dmi {
-// Coding record of a symbol with normalised frequency f (see dmi_chains.hip for the exactness argument).
-RansEntry make_rans_entry(uint32_t f, uint32_t cum, uint32_t precision) {
-  RansEntry e{0u, 0u, 0u, cum, 0u};
-  if (f == 0) return e;                       // never coded
-  e.t = f << (precision == 8 ? 12 : 10);      // rans.rs:40 `state >= (L >> P) * f << 8` with L = 4·2^P; rABS :97 with L = 4096
-  e.d = (1u << precision) - f;
-  // bit 9 of b: f < 2^(P-8) — the state can exceed f·2^18, i.e. this symbol may renormalise by more than one byte
-  const uint32_t multi = (precision >= 8 && ((uint64_t)f << 8) < ((uint64_t)1 << precision)) ? 0x200u : 0u;
-  if (f == 1) { e.m = 0xFFFFFFFFu; e.b = 0x100u | multi; return e; }   // flagged: the batch takes the generic loop
-  unsigned lg = 31u - (unsigned)__builtin_clz(f);
-  if ((f & (f - 1)) == 0) { e.m = 0x80000000u; e.b = (lg - 1) | multi; return e; }
-  e.m = (uint32_t)((((uint64_t)1 << (32 + lg)) + f - 1) / f);
-  e.b = lg | multi;
-  return e;
-}
-}  // namespace dmi
 
 namespace {
 
@@ -484,6 +475,12 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
     if (a.port == kToBits) a.bins = 1u << 20;   // capacity; the real bound is checked after the min/max readback
     a.bins_cap = a.bins;
     if ((rc = a.rtable.alloc(((size_t)a.bins + 4) * sizeof(RansEntry)))) return rc;   // +4: uploads are padded to 4 entries (whole 16-byte words)
+    if (a.port != kToBits) {
+      a.hdr_cap = 8u + 3u * a.bins;   // method, bit_length, leb128(num_symbols), ≤ 3 bytes per symbol
+      if ((rc = a.freq.alloc(((size_t)a.bins + 68) * 4))) return rc;
+      if ((rc = a.hdr.alloc((size_t)a.hdr_cap + 32))) return rc;   // (+ slack: the batch pack kernel copies whole 16-byte words)
+      if ((rc = a.aux_entries.alloc(64))) return rc;
+    }
     if ((rc = a.rec.alloc(((size_t)a.n_sym + kChainPad) * sizeof(RansEntry)))) return rc;
     HIP_TRY(hipMemsetAsync(a.rec.p, 0, a.rec.bytes, s));
     if ((rc = a.batch_flags.alloc(((size_t)a.n_sym / 64 + 4) * 4))) return rc;
@@ -513,6 +510,8 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
   }
   HIP_TRY(hipHostMalloc(&job->pinned, pinned_need, hipHostMallocDefault));
   job->pinned_bytes = pinned_need;
+  job->dev_tables = !std::getenv("DMI_HOST_TABLES");
+  for (auto& a : job->atts) if (a.port == kToBits) job->dev_tables = false;
   if ((rc = job->descs.alloc(sizeof(ChainDesc) * (size_t)n_atts * 2 + 16)   /* + the chain kernel's pull counter */)) return rc;
   if (cfg.flags & DMI_FLAG_TIMINGS) {
     for (auto& e : job->ev) HIP_TRY(hipEventCreate(&e));
@@ -671,7 +670,7 @@ static int encode_phase_a(dmi_job* job, bool plan_only = false) {   // device: r
   }
   launch_histograms(ha, s);
   // scratch words, ranges, histograms and orientation summaries of every attribute: one copy (the pinned buffer mirrors the slab)
-  if (!plan_only) HIP_TRY(hipMemcpyAsync(pinned, job->slab.p, job->slab.bytes, hipMemcpyDeviceToHost, s));
+  if (!plan_only && !job->dev_tables) HIP_TRY(hipMemcpyAsync(pinned, job->slab.p, job->slab.bytes, hipMemcpyDeviceToHost, s));
   if (timed) HIP_TRY(hipEventRecord(job->ev[3], s));
   return DMI_OK;
 }
@@ -692,6 +691,8 @@ static int encode_phase_b(dmi_job* job, bool plan_only = false) {   // host: tab
   descs.clear();
   std::vector<AuxInfo>& aux = job->run.aux;
   aux.assign(n_atts, AuxInfo{});
+  job->run.hdr_ptr.assign(n_atts, nullptr);
+  job->run.hdr_len.assign(n_atts, 0);
   const std::vector<size_t>& pin_off = job->run.pin_off;
   std::string err;
   for (uint32_t i = 0; i < n_atts; ++i) {
@@ -706,12 +707,14 @@ static int encode_phase_b(dmi_job* job, bool plan_only = false) {   // host: tab
     const uint32_t* hist = reinterpret_cast<const uint32_t*>(base + 128);
     int rc = a.ft.build(hist, a.bins, err);
     if (rc) return fail(rc, err);
+    job->run.hdr_ptr[i] = a.ft.header.data();
+    job->run.hdr_len[i] = (uint32_t)a.ft.header.size();
     std::vector<RansEntry>& rt = a.rt_host;
     rt.assign((a.ft.freq.size() + 3) & ~(size_t)3, RansEntry{0u, 0u, 0u, 0u, 0u});   // 4 entries = 80 bytes = whole 16-byte words
     for (size_t k = 0; k < a.ft.freq.size(); ++k) rt[k] = make_rans_entry(a.ft.freq[k], a.ft.cum[k], a.ft.precision);
     { const int urc = upload_table(a.rtable.p, rt.data(), rt.size() * sizeof(RansEntry)); if (urc) return urc; }
     // symbols → coding records in coding order (data-parallel), consumed by the scalar chain
-    launch_rans_prep(a.sym.as<uint32_t>(), a.n_sym, a.rtable.as<RansEntry>(), a.rec.as<RansEntry>(), a.batch_flags.as<uint32_t>(), s);
+    launch_rans_prep(a.sym.as<uint32_t>(), a.n_sym, a.rtable.as<RansEntry>(), a.bins, a.rec.as<RansEntry>(), a.batch_flags.as<uint32_t>(), s);
     ChainDesc d{};
     d.kind = 0; d.precision = a.ft.precision; d.n = a.n_sym; d.sym = a.sym.as<uint32_t>(); d.table = a.rec.as<RansEntry>(); d.state0 = 4u << a.ft.precision; d.batch_flags = a.batch_flags.as<uint32_t>();
     {   // which step the stream's walker uses: the one-byte step pays off when few batches of 64 hold a rare symbol (f < 2^(P-8))
@@ -733,7 +736,7 @@ static int encode_phase_b(dmi_job* job, bool plan_only = false) {   // host: tab
       {   // rABS (rans.rs:91-108): bit 1 codes with f1 = 256 - p0 and offset 0, bit 0 with p0 and offset f1
         const uint32_t p0 = aux[i].zero_prob, f1 = 256u - p0;
         launch_bits_prep(a.aux.as<uint8_t>(), n, make_rans_entry(p0, f1, 8), make_rans_entry(f1, 0, 8), a.aux_rec.as<RansEntry>(), s);
-        launch_batch_flags(a.aux_rec.as<RansEntry>(), n, a.aux_flags.as<uint32_t>(), s);
+        launch_batch_flags(a.aux_rec.as<RansEntry>(), n, nullptr, a.aux_flags.as<uint32_t>(), s);
       }
       r.kind = 1; r.n = n; r.precision = 8; r.state0 = 4096; r.table = a.aux_rec.as<RansEntry>(); r.force_generic = 0; r.batch_flags = a.aux_flags.as<uint32_t>(); r.out = a.aux_out.as<uint8_t>(); r.cap = a.aux_cap; r.out_len = a.small.as<uint32_t>() + 10; r.ticks = a.small.as<uint32_t>() + 13;
       aux[i].desc = (int)descs.size();
@@ -766,7 +769,7 @@ static int encode_phase_b(dmi_job* job, bool plan_only = false) {   // host: tab
         { const int urc = upload_table(a.chunk_info.p, info.data(), info.size() * 4); if (urc) return urc; }
         const uint32_t p0 = aux[i].zero_prob, f1 = 256u - p0;
         launch_orient_prep(a.aux.as<uint8_t>(), n, a.chunk_info.as<uint32_t>(), make_rans_entry(p0, f1, 8), make_rans_entry(f1, 0, 8), a.aux_rec.as<RansEntry>(), s);
-        launch_batch_flags(a.aux_rec.as<RansEntry>(), len, a.aux_flags.as<uint32_t>(), s);
+        launch_batch_flags(a.aux_rec.as<RansEntry>(), len, nullptr, a.aux_flags.as<uint32_t>(), s);
       }
       r.kind = 2; r.n = len; r.precision = 8; r.state0 = 4096; r.table = a.aux_rec.as<RansEntry>(); r.force_generic = 0; r.batch_flags = a.aux_flags.as<uint32_t>(); r.out = a.aux_out.as<uint8_t>(); r.cap = a.aux_cap; r.out_len = a.small.as<uint32_t>() + 10; r.ticks = a.small.as<uint32_t>() + 13;
       aux[i].desc = (int)descs.size();
@@ -776,10 +779,87 @@ static int encode_phase_b(dmi_job* job, bool plan_only = false) {   // host: tab
   return DMI_OK;
 }
 
+// Device form of phase B: one k_tables workgroup per attribute (normalisation, serialised table, coding records, metadata
+// parameters, chain descriptors written to desc_base[…]), then the record prep — launches only, nothing waits for the host.
+// run.descs keeps a host mirror of the static descriptor fields (stream lengths as the host knows them, capacities).
+static uint32_t count_streams(const dmi_job* job) {
+  uint32_t k = 0;
+  for (const auto& a : job->atts) k += (a.scheme == kNormal || a.scheme == kTexCoord) ? 2u : 1u;
+  return k;
+}
+static int encode_phase_b_dev(dmi_job* job, ChainDesc* desc_base, ChainDesc* hdr_desc_base) {
+  hipStream_t s = job->stream;
+  const uint32_t n_atts = (uint32_t)job->atts.size();
+  std::vector<ChainDesc>& descs = job->run.descs;
+  descs.clear();
+  std::vector<AuxInfo>& aux = job->run.aux;
+  aux.assign(n_atts, AuxInfo{});
+  job->run.pending.clear();
+  for (uint32_t i = 0; i < n_atts; ++i) {
+    AttJob& a = job->atts[i];
+    const uint32_t n = job->tables[a.table].n_seq;
+    if (a.n_sym == 0) return fail(DMI_ERR_ENTROPY, "attribute " + std::to_string(i) + " has no values to code (empty histogram)");
+    TableAtt ta{};
+    ta.hist = a.hist.as<uint32_t>(); ta.freq = a.freq.as<uint32_t>(); ta.rtable = a.rtable.as<RansEntry>(); ta.hdr = a.hdr.as<uint8_t>(); ta.small = a.small.as<uint32_t>();
+    ta.n_sym = a.n_sym; ta.bins = a.bins; ta.hdr_cap = a.hdr_cap;
+    aux[i].rans_desc = (int)descs.size();
+    ta.desc = desc_base + descs.size();
+    ta.sym = a.sym.as<uint32_t>(); ta.rec = a.rec.as<RansEntry>(); ta.batch_flags = a.batch_flags.as<uint32_t>(); ta.out = a.out.as<uint8_t>(); ta.out_cap = a.out_cap;
+    ChainDesc d{};
+    d.kind = 0; d.n = a.n_sym; d.out = a.out.as<uint8_t>(); d.cap = a.out_cap; d.out_len = a.small.as<uint32_t>() + 8;
+    descs.push_back(d);
+    if (a.scheme == kNormal || a.scheme == kTexCoord) {
+      ta.aux_kind = a.scheme == kNormal ? 1u : 2u;
+      ta.n_entries = n;
+      ta.summary = a.summary.as<uint32_t>(); ta.chunk_info = a.chunk_info.as<uint32_t>(); ta.aux_entries = a.aux_entries.as<RansEntry>();
+      ta.summary_blocks = a.scheme == kTexCoord ? orient_summary_blocks(n) : 0u;
+      aux[i].desc = (int)descs.size();
+      ta.aux_desc = desc_base + descs.size();
+      ta.aux_rec = a.aux_rec.as<RansEntry>(); ta.aux_flags = a.aux_flags.as<uint32_t>(); ta.aux_out = a.aux_out.as<uint8_t>(); ta.aux_cap = a.aux_cap;
+      ChainDesc r{};
+      r.kind = ta.aux_kind; r.n = n; r.out = a.aux_out.as<uint8_t>(); r.cap = a.aux_cap; r.out_len = a.small.as<uint32_t>() + 10;
+      descs.push_back(r);
+    }
+    ta.hdr_desc = hdr_desc_base ? hdr_desc_base + i : nullptr;
+    launch_tables(ta, s);
+    launch_rans_prep(a.sym.as<uint32_t>(), a.n_sym, a.rtable.as<RansEntry>(), a.bins, a.rec.as<RansEntry>(), a.batch_flags.as<uint32_t>(), s);
+    if (a.scheme == kNormal) {
+      launch_bits_prep_dev(a.aux.as<uint8_t>(), n, a.aux_entries.as<RansEntry>(), a.aux_rec.as<RansEntry>(), s);
+      launch_batch_flags(a.aux_rec.as<RansEntry>(), n, nullptr, a.aux_flags.as<uint32_t>(), s);
+    } else if (a.scheme == kTexCoord) {
+      launch_orient_prep_dev(a.aux.as<uint8_t>(), n, a.chunk_info.as<uint32_t>(), a.aux_entries.as<RansEntry>(), a.aux_rec.as<RansEntry>(), s);
+      launch_batch_flags(a.aux_rec.as<RansEntry>(), n, a.small.as<uint32_t>() + 15, a.aux_flags.as<uint32_t>(), s);
+    }
+  }
+  return DMI_OK;
+}
+
+// errors the device reports through an attribute's scratch words (device form; the host form meets them in phase B)
+static int check_device_flags(const uint32_t* small, uint32_t i) {
+  if (small[4]) return fail(DMI_ERR_ZERO_NORMAL, "attribute " + std::to_string(i) + " contains a zero-length normal (reference assert, geom.rs:45)");
+  if (small[5]) return fail(DMI_ERR_ALPHABET_TOO_LARGE, "symbol outside the histogram bound");
+  switch (small[7]) {
+    case 0: return DMI_OK;
+    case 1: return fail(DMI_ERR_ENTROPY, "empty symbol histogram");
+    case 2: return fail(DMI_ERR_ENTROPY, "frequency normalisation overflow");
+    case 3: return fail(DMI_ERR_ENTROPY, "frequency normalisation underflow");
+    case 4: return fail(DMI_ERR_ENTROPY, "normalised frequency of an occurring symbol is zero (the reference encoder does not terminate on this input)");
+    default: return fail(DMI_ERR_ENTROPY, "serialised frequency table exceeds its buffer");
+  }
+}
+
 static int encode_phase_c1(dmi_job* job) {   // after the chains: async read-back of lengths / error flags
   hipStream_t s = job->stream;
   const uint32_t n_atts = (uint32_t)job->atts.size();
   uint8_t* pinned = job->readback ? job->readback : static_cast<uint8_t*>(job->pinned);
+  if (job->dev_tables) {   // nothing has come back yet: scratch words + quantization ranges of every attribute, 128 bytes each
+    job->run.pin_off.assign(n_atts, 0);
+    for (uint32_t i = 0; i < n_atts; ++i) {
+      job->run.pin_off[i] = job->atts[i].slab_off;
+      HIP_TRY(hipMemcpyAsync(pinned + job->run.pin_off[i], job->atts[i].small.p, 128, hipMemcpyDeviceToHost, s));
+    }
+    return DMI_OK;
+  }
   for (uint32_t i = 0; i < n_atts; ++i) HIP_TRY(hipMemcpyAsync(pinned + job->run.pin_off[i], job->atts[i].small.p, 64, hipMemcpyDeviceToHost, s));
   return DMI_OK;
 }
@@ -799,6 +879,20 @@ static int encode_phase_c2(dmi_job* job) {   // lengths known: async copy of the
   job->run.rans_len.assign(n_atts, 0);
   job->run.aux_len.assign(n_atts, 0);
   size_t total = 0;
+  std::vector<AuxInfo>& aux_w = job->run.aux;
+  if (job->dev_tables) {
+    job->run.hdr_ptr.assign(n_atts, nullptr);
+    job->run.hdr_len.assign(n_atts, 0);
+    job->run.hdr_off.assign(n_atts, 0);
+    for (uint32_t i = 0; i < n_atts; ++i) {
+      const uint32_t* small = reinterpret_cast<const uint32_t*>(pinned + pin_off[i]);
+      const int frc = check_device_flags(small, i);
+      if (frc) return frc;
+      aux_w[i].zero_prob = (uint8_t)small[14];
+      aux_w[i].count = small[15];
+      job->run.hdr_off[i] = total; total += (small[6] + 15u) & ~15u;
+    }
+  }
   for (uint32_t i = 0; i < n_atts; ++i) {
     const uint32_t* small = reinterpret_cast<const uint32_t*>(pinned + pin_off[i]);
     if (small[9] || small[11]) return fail(DMI_ERR_ENTROPY, small[9] == 1 || small[11] == 1 ? "rANS state too large" : "coder output capacity exceeded");
@@ -821,6 +915,11 @@ static int encode_phase_c2(dmi_job* job) {   // lengths known: async copy of the
     job->run.aux_ptr[i] = job->out_pinned + aux_off[i];
     job->run.rans_len[i] = small[8];
     job->run.aux_len[i] = aux[i].desc >= 0 ? small[10] : 0u;
+    if (job->dev_tables) {
+      if (small[6]) HIP_TRY(hipMemcpyAsync(job->out_pinned + job->run.hdr_off[i], a.hdr.p, small[6], hipMemcpyDeviceToHost, s));
+      job->run.hdr_ptr[i] = job->out_pinned + job->run.hdr_off[i];
+      job->run.hdr_len[i] = small[6];
+    }
   }
   return DMI_OK;
 }
@@ -872,7 +971,7 @@ static int encode_phase_c3(dmi_job* job, dmi_buffer* out) {   // host: splice th
     w.u8((uint8_t)a.scheme);
     w.u8((uint8_t)a.transform);
     w.u8(1);   // rans_encoding
-    w.bytes(a.ft.header);
+    w.bytes(job->run.hdr_ptr[i], job->run.hdr_len[i]);
     const uint32_t rans_len = job->run.rans_len[i], aux_len = job->run.aux_len[i];
     w.leb128(rans_len);
     w.bytes(rans_ptr[i], rans_len);
@@ -938,12 +1037,18 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
   job->readback = nullptr;
   int rc = encode_phase_a(job);
   if (rc) return rc;
-  HIP_TRY(hipStreamSynchronize(s));
-  const auto t_tab0 = std::chrono::steady_clock::now();
-  if ((rc = encode_phase_b(job))) return rc;
+  auto t_tab0 = std::chrono::steady_clock::now(), t_tab1 = t_tab0;
+  if (job->dev_tables) {
+    // tables, metadata parameters and descriptors on the device: the stream runs from the first kernel to the chains without a host wait
+    if ((rc = encode_phase_b_dev(job, job->descs.as<ChainDesc>(), nullptr))) return rc;
+  } else {
+    HIP_TRY(hipStreamSynchronize(s));
+    t_tab0 = std::chrono::steady_clock::now();
+    if ((rc = encode_phase_b(job))) return rc;
+    HIP_TRY(hipMemcpyAsync(job->descs.p, job->run.descs.data(), job->run.descs.size() * sizeof(ChainDesc), hipMemcpyHostToDevice, s));
+    t_tab1 = std::chrono::steady_clock::now();
+  }
   const std::vector<ChainDesc>& descs = job->run.descs;
-  HIP_TRY(hipMemcpyAsync(job->descs.p, descs.data(), descs.size() * sizeof(ChainDesc), hipMemcpyHostToDevice, s));
-  const auto t_tab1 = std::chrono::steady_clock::now();
   if (timed) HIP_TRY(hipEventRecord(job->ev[4], s));
   launch_chains(job->descs.as<ChainDesc>(), nullptr, (uint32_t)descs.size(), reinterpret_cast<uint32_t*>(job->descs.as<ChainDesc>() + job->atts.size() * 2), s);
   if (timed) HIP_TRY(hipEventRecord(job->ev[5], s));
@@ -962,6 +1067,7 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
     (void)hipEventElapsedTime(&tm.rans_ms, job->ev[4], job->ev[5]);
   }
   tm.table_ms = std::chrono::duration<float, std::milli>(t_tab1 - t_tab0).count();
+  if (timed && job->dev_tables) (void)hipEventElapsedTime(&tm.table_ms, job->ev[3], job->ev[4]);   // k_tables + record prep on the device
   tm.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
   tm.predict_bytes = job->predict_bytes;
   for (auto& a : job->atts) tm.symbols += a.n_sym;
@@ -983,6 +1089,15 @@ struct BatchArena {
   void* bytes_host = nullptr; size_t bytes_host_cap = 0;
   void* plan_host = nullptr; void* plan_dev = nullptr; size_t plan_cap = 0;       // launch plan of a batch (argument blocks, block maps)
   void* slabs_host = nullptr; void* slabs_dev = nullptr; size_t slabs_cap = 0;   // every job's slab, packed
+  void* descs_dev = nullptr; size_t descs_cap = 0;   // device form: chain descriptors | header pseudo-descriptors | stream order | pull counter
+  int reserve_descs(size_t bytes) {
+    if (bytes <= descs_cap) return DMI_OK;
+    if (descs_dev) (void)hipFree(descs_dev);
+    descs_dev = nullptr; descs_cap = 0;
+    HIP_TRY(hipMalloc(&descs_dev, bytes + bytes / 4 + 4096));
+    descs_cap = bytes + bytes / 4 + 4096;
+    return DMI_OK;
+  }
   bool in_use = false;
   int reserve(size_t dev_bytes, size_t table_bytes) {
     if (dev_bytes > bytes_dev_cap) {
@@ -1127,7 +1242,7 @@ static int run_phase_a_batched(dmi_job** jobs, const std::vector<uint32_t>& whic
 static int run_phase_b_batched(dmi_job** jobs, const std::vector<uint32_t>& which, const std::vector<std::vector<KernelStep>>& steps, BatchArena* arena, hipStream_t s) {
   if (which.empty()) return DMI_OK;
   BatchPlan plan;
-  plan.add(steps, 2);
+  plan.add(steps, kPrepLevels);
   std::vector<CopyItem> items;
   size_t table_bytes = 0;
   for (uint32_t j : which)
@@ -1152,6 +1267,105 @@ static int run_phase_b_batched(dmi_job** jobs, const std::vector<uint32_t>& whic
   const uint8_t* pd = static_cast<const uint8_t*>(arena->plan_dev);
   launch_scatter_items(reinterpret_cast<const CopyItem*>(pd + off_items), (uint32_t)items.size(), pd, s);
   plan.launch(pd, s);
+  return DMI_OK;
+}
+
+// Device form of a batch: the phases, the table stage and the record prep of ALL jobs are planned together (one upload, one
+// launch per (level, kernel)), the chain descriptors are written by k_tables, and the chains follow on the same stream — the
+// host waits for the first time when everything has been coded.  Read-back: one packed arena (coded bytes + serialised tables),
+// one table of {offset, length, error}, 128 scratch bytes per attribute.
+typedef std::function<int(const std::function<int(uint32_t)>&, bool)> ParallelJobs;   // fn(job index) over all jobs on the batch's host threads
+static int jobs_encode_device(dmi_job** jobs, uint32_t n, dmi_buffer* outs, BatchArena* arena, const ParallelJobs& parallel, bool trace) {
+  hipStream_t s = jobs[0]->stream;
+  int rc;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  const auto t0 = now();
+  std::vector<uint32_t> first_desc(n + 1, 0), first_att(n + 1, 0);
+  for (uint32_t j = 0; j < n; ++j) { first_desc[j + 1] = first_desc[j] + count_streams(jobs[j]); first_att[j + 1] = first_att[j] + (uint32_t)jobs[j]->atts.size(); }
+  const uint32_t n_streams = first_desc[n], n_atts = first_att[n], n_descs = n_streams + n_atts;
+  const size_t order_at = (size_t)n_descs * sizeof(ChainDesc), counter_at = order_at + (((size_t)n_streams * 4 + 15) & ~(size_t)15);
+  if ((rc = arena->reserve_descs(counter_at + 16))) return rc;
+  ChainDesc* descs_dev = static_cast<ChainDesc*>(arena->descs_dev);
+  // ---- plan (host threads; no HIP call) ----
+  std::vector<std::vector<KernelStep>> steps(n);
+  if ((rc = parallel([&](uint32_t j) {
+        dmi_job* job = jobs[j];
+        job->readback = nullptr;
+        set_step_sink(&steps[j]);
+        int r = encode_phase_a(job, true);
+        const size_t n_a = steps[j].size();
+        if (!r) r = encode_phase_b_dev(job, descs_dev + first_desc[j], descs_dev + n_streams + first_att[j]);
+        set_step_sink(nullptr);
+        for (size_t k = n_a; k < steps[j].size(); ++k) steps[j][k].level += kStepLevels;
+        return r;
+      }, false))) return rc;
+  BatchPlan plan;
+  plan.add(steps, kStepLevels + kPrepLevels);
+  // stream order for the chain kernel (longest first), scratch-word copies, capacities
+  std::vector<uint64_t> length(n_streams);
+  size_t cap_sum = 0;
+  for (uint32_t j = 0; j < n; ++j)
+    for (size_t k = 0; k < jobs[j]->run.descs.size(); ++k) { const ChainDesc& d = jobs[j]->run.descs[k]; length[first_desc[j] + k] = d.n; cap_sum += ((size_t)d.cap + 31) & ~(size_t)15; }
+  for (uint32_t j = 0; j < n; ++j) for (auto& a : jobs[j]->atts) cap_sum += ((size_t)a.hdr_cap + 31) & ~(size_t)15;
+  std::vector<uint32_t> by_length(n_streams);
+  for (uint32_t k = 0; k < n_streams; ++k) by_length[k] = k;
+  std::stable_sort(by_length.begin(), by_length.end(), [&](uint32_t x, uint32_t y) { return length[x] > length[y]; });
+  std::vector<CopyItem> copies;
+  copies.reserve(n_atts);
+  for (uint32_t j = 0; j < n; ++j) for (auto& a : jobs[j]->atts) copies.push_back(CopyItem{a.small.p, (uint64_t)copies.size() * 128u, 128u});
+  const size_t off_copies = plan.reserve(copies.size() * sizeof(CopyItem));
+  const size_t off_order = plan.reserve((size_t)n_streams * 4);
+  if ((rc = BatchArena::reserve_pair(arena->plan_host, arena->plan_dev, arena->plan_cap, plan.bytes))) return rc;
+  if ((rc = BatchArena::reserve_pair(arena->slabs_host, arena->slabs_dev, arena->slabs_cap, (size_t)n_atts * 128))) return rc;
+  if ((rc = arena->reserve(cap_sum, (size_t)(n_descs + 1) * sizeof(PackEntry)))) return rc;
+  uint8_t* ph = static_cast<uint8_t*>(arena->plan_host);
+  plan.fill(ph);
+  std::memcpy(ph + off_copies, copies.data(), copies.size() * sizeof(CopyItem));
+  std::memcpy(ph + off_order, by_length.data(), (size_t)n_streams * 4);
+  const auto t1 = now();
+  // ---- the whole encode: one upload, then launches only ----
+  HIP_TRY(hipMemcpyAsync(arena->plan_dev, arena->plan_host, plan.bytes, hipMemcpyHostToDevice, s));
+  const uint8_t* pd = static_cast<const uint8_t*>(arena->plan_dev);
+  plan.launch(pd, s);
+  launch_chains(descs_dev, reinterpret_cast<const uint32_t*>(pd + off_order), n_streams, reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(arena->descs_dev) + counter_at), s);
+  launch_pack_streams(descs_dev, n_descs, static_cast<PackEntry*>(arena->table_dev), static_cast<uint8_t*>(arena->bytes_dev), s);
+  launch_copy_items(reinterpret_cast<const CopyItem*>(pd + off_copies), n_atts, static_cast<uint8_t*>(arena->slabs_dev), s);
+  HIP_TRY(hipMemcpyAsync(arena->table_host, arena->table_dev, (size_t)(n_descs + 1) * sizeof(PackEntry), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(arena->slabs_host, arena->slabs_dev, (size_t)n_atts * 128, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  const auto t2 = now();
+  const PackEntry* table = static_cast<const PackEntry*>(arena->table_host);
+  const size_t total = (size_t)table[n_descs].offset;
+  if ((rc = arena->reserve_host(total))) return rc;
+  if (total) HIP_TRY(hipMemcpyAsync(arena->bytes_host, arena->bytes_dev, total, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  const auto t3 = now();
+  const uint8_t* bytes_host = static_cast<const uint8_t*>(arena->bytes_host);
+  if ((rc = parallel([&](uint32_t j) {
+        dmi_job* job = jobs[j];
+        const uint32_t na = (uint32_t)job->atts.size();
+        job->readback = static_cast<uint8_t*>(arena->slabs_host) + (size_t)first_att[j] * 128;
+        job->run.pin_off.assign(na, 0);
+        job->run.hdr_ptr.assign(na, nullptr);
+        job->run.hdr_len.assign(na, 0);
+        for (uint32_t i = 0; i < na; ++i) {
+          job->run.pin_off[i] = (size_t)i * 128;
+          const uint32_t* small = reinterpret_cast<const uint32_t*>(job->readback + job->run.pin_off[i]);
+          const int frc = check_device_flags(small, i);
+          if (frc) return frc;
+          job->run.aux[i].zero_prob = (uint8_t)small[14];
+          job->run.aux[i].count = small[15];
+          const PackEntry& h = table[n_streams + first_att[j] + i];
+          job->run.hdr_ptr[i] = bytes_host + h.offset;
+          job->run.hdr_len[i] = h.len;
+        }
+        int r = encode_phase_c_packed(job, table, first_desc[j], bytes_host);
+        if (!r) r = encode_phase_c3(job, &outs[j]);
+        return r;
+      }, false))) return rc;
+  if (trace) std::fprintf(stderr, "[dmi] batch of %u, device form: plan %.2f ms (%zu launches), upload + every kernel + chains (%u streams) + packing %.2f, byte read-back %.2f, splice %.2f\n", n, ms(t0, t1),
+                          plan.groups.size(), n_streams, ms(t1, t2), ms(t2, t3), ms(t3, now()));
   return DMI_OK;
 }
 
@@ -1211,6 +1425,11 @@ int dmi_jobs_encode(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
     if (ok) { batched.push_back(j); is_batched[j] = 1; }
   }
   HIP_TRY(hipSetDevice(device));
+  {
+    bool all_device = batched.size() == n;
+    for (uint32_t j = 0; j < n && all_device; ++j) all_device = jobs[j]->dev_tables;
+    if (all_device) return jobs_encode_device(jobs, n, outs, arena, parallel, trace);
+  }
   if ((rc = run_phase_a_batched(jobs, batched, arena, s))) return rc;
   const auto t1 = now();
   std::vector<std::vector<KernelStep>> b_steps(n);   // record-prep steps of the batched jobs (filled by the workers)
