@@ -76,7 +76,7 @@ class _Conn(C.Structure):
 
 
 EXPORTS = ["dmi_encode_attributes", "dmi_encode_attributes_batch", "dmi_jobs_encode", "dmi_job_create", "dmi_job_encode", "dmi_job_timings", "dmi_job_destroy", "dmi_encode_mesh",
-           "dmi_mesh_prepare", "dmi_meshes_prepare", "dmi_mesh_build", "dmi_built_mesh_free", "dmi_encode_connectivity", "dmi_conn_free", "dmi_free", "dmi_strerror", "dmi_last_error", "dmi_device_count"]
+           "dmi_mesh_prepare", "dmi_meshes_prepare", "dmi_mesh_build", "dmi_built_mesh_free", "dmi_encode_connectivity", "dmi_conn_free", "dmi_free", "dmi_free_many", "dmi_strerror", "dmi_last_error", "dmi_device_count"]
 
 
 def library_path():
@@ -102,6 +102,8 @@ def load_library():
     L.dmi_last_error.restype = C.c_char_p
     L.dmi_device_count.restype = C.c_int
     L.dmi_free.argtypes = [C.POINTER(_Buffer)]
+    L.dmi_free_many.argtypes = [C.POINTER(_Buffer), C.c_uint32]
+    L.dmi_free_many.restype = None
     L.dmi_encode_attributes.argtypes = [C.POINTER(_Attribute), C.POINTER(_CornerTable), C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(_Config), C.POINTER(_Buffer)]
     L.dmi_job_create.argtypes = [C.POINTER(_Attribute), C.POINTER(_CornerTable), C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(_Config), C.POINTER(C.c_void_p)]
     L.dmi_job_encode.argtypes = [C.c_void_p, C.POINTER(_Buffer)]
@@ -513,9 +515,8 @@ class EncodedBatch:
         b = self._outs[i]
         return C.string_at(b.data, b.len) if b.len else b""
     def free(self):
-        L = load_library()
-        for i in range(self._n):
-            L.dmi_free(C.byref(self._outs[i]))
+        if self._n:
+            load_library().dmi_free_many(self._outs, self._n)
         self._n = 0
     def __enter__(self):
         return self

@@ -269,6 +269,10 @@ void dmi_free(dmi_buffer* b) {
   b->data = nullptr;
   b->len = b->cap = 0;
 }
+void dmi_free_many(dmi_buffer* bufs, uint32_t n) {
+  if (!bufs) return;
+  for (uint32_t k = 0; k < n; ++k) dmi_free(&bufs[k]);
+}
 
 static int to_buffer(const std::vector<uint8_t>& v, dmi_buffer* out) {
   out->data = static_cast<uint8_t*>(std::malloc(v.size() ? v.size() : 1));
@@ -955,7 +959,19 @@ static int encode_phase_c3(dmi_job* job, dmi_buffer* out) {   // host: splice th
   const auto& rans_ptr = job->run.rans_ptr;
   const auto& aux_ptr = job->run.aux_ptr;
   // ---- stage 6 (host): splice the attribute section (encode/attribute/mod.rs:26-57, attribute_encoder.rs:159-160,344-386)
-  ByteSink w;
+  // written straight into the caller's buffer: its size is bounded by the parts (< 96 bytes of framing per attribute)
+  size_t bound = 16;
+  for (uint32_t i = 0; i < n_atts; ++i) bound += 96 + (size_t)job->run.hdr_len[i] + job->run.rans_len[i] + job->run.aux_len[i];
+  struct RawSink {
+    uint8_t* p; size_t n = 0;
+    void u8(uint8_t v) { p[n++] = v; }
+    void u32(uint32_t v) { std::memcpy(p + n, &v, 4); n += 4; }   // little-endian host
+    void f32(float f) { std::memcpy(p + n, &f, 4); n += 4; }
+    void leb128(uint64_t v) { do { uint8_t x = v & 0x7F; v >>= 7; u8(v ? (x | 0x80) : x); } while (v); }
+    void bytes(const uint8_t* q, size_t k) { if (k) std::memcpy(p + n, q, k); n += k; }
+    void bytes(const std::vector<uint8_t>& v) { bytes(v.data(), v.size()); }
+  } w{static_cast<uint8_t*>(std::malloc(bound))};
+  if (!w.p) return fail(DMI_ERR_OUT_OF_MEMORY, "malloc");
   w.u8((uint8_t)n_atts);
   for (uint32_t i = 0; i < n_atts; ++i) { w.u8((uint8_t)((uint8_t)i - 1)); w.u8(job->atts[i].desc.domain); w.u8(0); }   // Q13
   for (uint32_t i = 0; i < n_atts; ++i) {
@@ -1000,7 +1016,10 @@ static int encode_phase_c3(dmi_job* job, dmi_buffer* out) {   // host: splice th
       w.u8(8);                     // octahedral_quantization.rs:43
     }
   }
-  return to_buffer(w.b, out);
+  out->data = w.p;
+  out->len = w.n;
+  out->cap = bound;
+  return DMI_OK;
 }
 
 // Phase A as one hipGraph replay (single-job re-encodes and the jobs of a batch that keep their own launches): the ≈9 launches and
@@ -1156,21 +1175,26 @@ static void release_batch_arena(BatchArena* a) {
 // A batch's launch plan: the KernelSteps of many jobs grouped by (level, kernel); argument blocks, block maps and any extra
 // tables go to the device in ONE copy, then every group is one multi-item launch.
 struct BatchPlan {
-  struct Group { int level, id; uint32_t lds = 0, total_blocks = 0; std::vector<const KernelStep*> items; size_t off_args = 0, off_info = 0, off_blocks = 0; };
+  struct Group { int level = 0, id = 0; uint32_t lds = 0, total_blocks = 0; std::vector<const KernelStep*> items; size_t off_args = 0, off_info = 0, off_blocks = 0; };
   std::vector<Group> groups;
   size_t bytes = 0;
   static size_t align(size_t v) { return (v + 255) & ~(size_t)255; }
   void add(const std::vector<std::vector<KernelStep>>& steps, int n_levels) {
-    for (int level = 0; level < n_levels; ++level) {
-      for (int id = 0; id < K_COUNT; ++id) {
-        Group g;
-        g.level = level; g.id = id;
-        for (const auto& job_steps : steps)
-          for (const KernelStep& st : job_steps)
-            if (st.level == level && st.id == id) { g.items.push_back(&st); g.total_blocks += st.blocks; g.lds = std::max(g.lds, st.lds); }
-        if (!g.items.empty()) groups.push_back(std::move(g));
+    // one pass: bucket (level, kernel) → group, in job order; then the groups in (level, kernel) order
+    std::vector<Group> bucket((size_t)n_levels * K_COUNT);
+    for (const auto& job_steps : steps)
+      for (const KernelStep& st : job_steps) {
+        if (st.level < 0 || st.level >= n_levels || st.id < 0 || st.id >= K_COUNT) continue;
+        Group& g = bucket[(size_t)st.level * K_COUNT + st.id];
+        g.items.push_back(&st); g.total_blocks += st.blocks; g.lds = std::max(g.lds, st.lds);
       }
-    }
+    for (int level = 0; level < n_levels; ++level)
+      for (int id = 0; id < K_COUNT; ++id) {
+        Group& g = bucket[(size_t)level * K_COUNT + id];
+        if (g.items.empty()) continue;
+        g.level = level; g.id = id;
+        groups.push_back(std::move(g));
+      }
     for (Group& g : groups) {
       g.off_args = bytes; bytes = align(bytes + (size_t)g.items.size() * g.items[0]->args_size);
       g.off_info = bytes; bytes = align(bytes + (size_t)g.total_blocks * sizeof(uint2));
@@ -1178,18 +1202,25 @@ struct BatchPlan {
     }
   }
   size_t reserve(size_t n) { const size_t off = bytes; bytes = align(bytes + n); return off; }
-  void fill(uint8_t* ph) const {
-    for (const Group& g : groups) {
-      const size_t asz = g.items[0]->args_size;
-      uint2* info = reinterpret_cast<uint2*>(ph + g.off_info);
-      uint32_t* blocks = reinterpret_cast<uint32_t*>(ph + g.off_blocks);
-      uint32_t at = 0;
-      for (size_t i = 0; i < g.items.size(); ++i) {
-        std::memcpy(ph + g.off_args + i * asz, g.items[i]->args, asz);
-        blocks[i] = g.items[i]->blocks;
-        for (uint32_t b = 0; b < g.items[i]->blocks; ++b) info[at++] = make_uint2((uint32_t)i, b);
-      }
+  void fill_group(uint8_t* ph, const Group& g) const {
+    const size_t asz = g.items[0]->args_size;
+    uint2* info = reinterpret_cast<uint2*>(ph + g.off_info);
+    uint32_t* blocks = reinterpret_cast<uint32_t*>(ph + g.off_blocks);
+    uint32_t at = 0;
+    for (size_t i = 0; i < g.items.size(); ++i) {
+      std::memcpy(ph + g.off_args + i * asz, g.items[i]->args, asz);
+      blocks[i] = g.items[i]->blocks;
+      for (uint32_t b = 0; b < g.items[i]->blocks; ++b) info[at++] = make_uint2((uint32_t)i, b);
     }
+  }
+  void fill(uint8_t* ph) const {
+    if (groups.size() < 4) { for (const Group& g : groups) fill_group(ph, g); return; }
+    std::atomic<size_t> next{0};   // groups differ a lot in size: a few host threads pull them
+    auto work = [&] { for (size_t k; (k = next.fetch_add(1)) < groups.size();) fill_group(ph, groups[k]); };
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < std::min<size_t>(groups.size(), 8); ++t) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
   }
   void launch(const uint8_t* pd, hipStream_t s) const {
     for (const Group& g : groups)
@@ -1300,8 +1331,10 @@ static int jobs_encode_device(dmi_job** jobs, uint32_t n, dmi_buffer* outs, Batc
         for (size_t k = n_a; k < steps[j].size(); ++k) steps[j][k].level += kStepLevels;
         return r;
       }, false))) return rc;
+  const auto ta = now();
   BatchPlan plan;
   plan.add(steps, kStepLevels + kPrepLevels);
+  const auto tb = now();
   // stream order for the chain kernel (longest first), scratch-word copies, capacities
   std::vector<uint64_t> length(n_streams);
   size_t cap_sum = 0;
@@ -1364,7 +1397,20 @@ static int jobs_encode_device(dmi_job** jobs, uint32_t n, dmi_buffer* outs, Batc
         if (!r) r = encode_phase_c3(job, &outs[j]);
         return r;
       }, false))) return rc;
-  if (trace) std::fprintf(stderr, "[dmi] batch of %u, device form: plan %.2f ms (%zu launches), upload + every kernel + chains (%u streams) + packing %.2f, byte read-back %.2f, splice %.2f\n", n, ms(t0, t1),
+  if (trace) {   // per-stream chain clocks (100 MHz ticks written by the emitters)
+    double sum_ms = 0, max_ms = 0, steps = 0, big_steps = 0, big_ms = 0;
+    for (uint32_t j = 0; j < n; ++j)
+      for (uint32_t i = 0; i < (uint32_t)jobs[j]->atts.size(); ++i) {
+        const uint32_t* small = reinterpret_cast<const uint32_t*>(jobs[j]->readback + jobs[j]->run.pin_off[i]);
+        const double r = small[12] * 1e-5, x = jobs[j]->run.aux[i].desc >= 0 ? small[13] * 1e-5 : 0.0;
+        const double ns = (double)jobs[j]->atts[i].n_sym, nx = jobs[j]->run.aux[i].desc >= 0 ? (double)jobs[j]->run.aux[i].count : 0.0;
+        sum_ms += r + x; max_ms = std::max({max_ms, r, x}); steps += ns + nx;
+        if (ns > 50000) { big_steps += ns; big_ms += r; }
+      }
+    std::fprintf(stderr, "[dmi] chains: %.0f steps, stream times sum %.1f ms (/1024 walkers = %.2f ms), longest %.2f ms, %.1f ns/step overall, %.1f ns/step on rANS streams > 50k symbols\n", steps, sum_ms,
+                 sum_ms / 1024.0, max_ms, sum_ms * 1e6 / std::max(1.0, steps), big_ms * 1e6 / std::max(1.0, big_steps));
+  }
+  if (trace) std::fprintf(stderr, "[dmi] batch of %u, device form: plan %.2f ms (steps %.2f, grouping %.2f, fill %.2f; %zu launches), upload + every kernel + chains (%u streams) + packing %.2f, byte read-back %.2f, splice %.2f\n", n, ms(t0, t1), ms(t0, ta), ms(ta, tb), ms(tb, t1),
                           plan.groups.size(), n_streams, ms(t1, t2), ms(t2, t3), ms(t3, now()));
   return DMI_OK;
 }

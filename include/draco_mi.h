@@ -189,6 +189,8 @@ int dmi_mesh_build(const dmi_raw_attribute* atts, uint32_t n_atts, const uint32_
 void dmi_built_mesh_free(dmi_built_mesh* m);
 
 void dmi_free(dmi_buffer* buf);
+/* dmi_free of bufs[0..n): the outputs of a batch call released in one call */
+void dmi_free_many(dmi_buffer* bufs, uint32_t n);
 const char* dmi_strerror(int status);
 /* Last error detail for the calling thread (HIP error string, offending attribute, ...). */
 const char* dmi_last_error(void);
