@@ -422,3 +422,52 @@ def test_empty_mesh_is_an_error_code_not_a_crash():
     sess = orc.Session.from_arrays(np.zeros((0, 3), np.uint32), [dict(data=pos, type=orc.POSITION)])
     with pytest.raises(orc.OracleError):
         sess.encode()
+
+
+def _heavy_tailed_mesh(n, seed):
+    """Torus grid whose positions and UVs carry a few far outliers and a noisy band: sparse symbol histograms with runs of
+    more than 64 empty bins (the zero-run tokens of the serialised table, Q20) and many equal normalised frequencies (Q12)."""
+    faces, pos, nrm, uv = synth.torus_grid(n, seed)
+    rng = np.random.default_rng(seed)
+    pos = pos.copy()
+    uv = uv.copy()
+    idx = rng.choice(len(pos), size=max(3, len(pos) // 50), replace=False)
+    pos[idx] += rng.normal(0, 0.4, size=(len(idx), 3)).astype(np.float32)
+    pos[idx[:3]] *= np.float32(7.0)
+    uv[idx] = np.clip(uv[idx] + rng.normal(0, 0.2, size=(len(idx), 2)), 0, 1).astype(np.float32)
+    b = dmi.MeshBuilder()
+    pid = b.add_attribute(pos, dmi.ATT_POSITION, dmi.DOMAIN_POSITION)
+    b.add_attribute(nrm, dmi.ATT_NORMAL, dmi.DOMAIN_CORNER, parents=[pid])
+    b.add_attribute(uv, dmi.ATT_TEXCOORD, dmi.DOMAIN_CORNER, parents=[pid])
+    b.set_connectivity_attribute(faces)
+    return b.build()
+
+
+@pytest.mark.parametrize("n,pos_bits,uv_bits", [(12, 11, 10), (48, 11, 10), (48, 16, 14), (90, 14, 12), (25, 20, 16)])
+def test_device_tables_match_host_tables_and_the_oracle(n, pos_bits, uv_bits, monkeypatch):
+    """The table stage runs on the device (k_tables: normalisation, serialised table, coding records, metadata parameters,
+    chain descriptors); DMI_HOST_TABLES=1 (read at job creation) keeps the host form.  Same bytes, and the oracle's."""
+    mesh = _heavy_tailed_mesh(n, seed=n * 31 + pos_bits)
+    cfg = dmi.Config(pos_bits=pos_bits, uv_bits=uv_bits)
+    want = oracle_from_product_mesh(mesh).encode(pos_bits=pos_bits, uv_bits=uv_bits)
+    _assert_same(dmi.encode_mesh(mesh, cfg), want, f"device tables n={n} {pos_bits}/{uv_bits}")
+    monkeypatch.setenv("DMI_HOST_TABLES", "1")
+    _assert_same(dmi.encode_mesh(mesh, cfg), want, f"host tables n={n} {pos_bits}/{uv_bits}")
+
+
+def test_batch_device_form_equals_host_form(monkeypatch):
+    """dmi_jobs_encode plans phases + table stage + record prep of all jobs as one upload and runs the chains without a host
+    wait (device form); with DMI_HOST_TABLES=1 the same batch takes the host-table pipeline.  Both equal per-mesh encodes."""
+    meshes = [_heavy_tailed_mesh(8 + 3 * k, seed=100 + k) for k in range(10)] + [synth.torus_mesh(20 + k, seed=k, open_boundary=bool(k & 1)) for k in range(6)]
+    want = [oracle_from_product_mesh(m).encode() for m in meshes]
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("DMI_HOST_TABLES", env)
+        jobs = dmi.meshes_prepare(meshes)
+        heads = [j.header_and_connectivity for j in jobs]
+        outs = dmi.jobs_encode(jobs)
+        with dmi.jobs_encode_raw(jobs) as raw:
+            assert [raw[i] for i in range(len(raw))] == outs
+        for k, (job, out) in enumerate(zip(jobs, outs)):
+            assert out == job.encode(), f"mesh {k}: batch != single (host tables: {env})"
+            _assert_same(heads[k] + out, want[k], f"mesh {k} (host tables: {env})")
