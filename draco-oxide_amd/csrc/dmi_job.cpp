@@ -37,14 +37,47 @@ enum Scheme : uint8_t { kDelta = 0, kParallelogram = 1, kTexCoord = 5, kNormal =
 enum Transform : uint8_t { kDifference = 0, kWrapped = 1, kOctOrth = 3 };              // prediction_transform/mod.rs:92-101
 enum Port : uint8_t { kToBits = 1, kCoordwise = 2, kOct = 3 };                          // portabilization/mod.rs:85-92
 
+// Device memory of one job comes from a few large chunks (DevPool) instead of one hipMalloc per buffer: job creation for a batch
+// of meshes runs on many host threads, and ≈ 70 allocations + ≈ 20 memsets per job serialise on the runtime (17 ms of
+// thread time per job before, most of it here).  A chunk is zeroed once when it is created, so pooled buffers start zeroed.
+struct DevPool {
+  struct Chunk { void* p; size_t cap, used; };
+  std::vector<Chunk> chunks;
+  size_t chunk_bytes = 0;
+  hipStream_t stream = nullptr;
+  ~DevPool() { for (auto& c : chunks) if (c.p) (void)hipFree(c.p); }
+  void* take(size_t n) {
+    n = (n + 255) & ~(size_t)255;
+    if (chunks.empty() || chunks.back().used + n > chunks.back().cap) {
+      Chunk c{nullptr, std::max(n, chunk_bytes), 0};
+      if (hipMalloc(&c.p, c.cap) != hipSuccess) return nullptr;
+      if (hipMemsetAsync(c.p, 0, c.cap, stream) != hipSuccess) { (void)hipFree(c.p); return nullptr; }
+      chunks.push_back(c);
+    }
+    Chunk& c = chunks.back();
+    void* p = static_cast<uint8_t*>(c.p) + c.used;
+    c.used += n;
+    return p;
+  }
+};
+static thread_local DevPool* g_active_pool = nullptr;   // set while dmi_job_create runs on this thread
+
 struct DevMem {
   void* p = nullptr;
   size_t bytes = 0;
-  ~DevMem() { if (p) (void)hipFree(p); }
+  bool pooled = false;
+  ~DevMem() { if (p && !pooled) (void)hipFree(p); }
   int alloc(size_t n) {
-    if (p) { (void)hipFree(p); p = nullptr; }
+    if (p && !pooled) (void)hipFree(p);
+    p = nullptr; pooled = false;
     bytes = n;
     if (n == 0) return DMI_OK;
+    if (g_active_pool) {
+      p = g_active_pool->take(n);
+      if (!p) return host_fail(DMI_ERR_HIP, "hipMalloc (job pool)");
+      pooled = true;
+      return DMI_OK;
+    }
     HIP_TRY(hipMalloc(&p, n));
     return DMI_OK;
   }
@@ -103,10 +136,19 @@ struct AttJob {
 
 using namespace dmi;
 
+// hipStreamCreate costs ≈ 1 ms and serialises across host threads (31 ms per job with 32 creator threads): jobs created by
+// dmi_meshes_prepare share one library-owned stream per worker thread, kept for the life of the process.
+struct StreamHolder {
+  hipStream_t s = nullptr;
+  ~StreamHolder() { if (s) (void)hipStreamDestroy(s); }
+};
+static thread_local std::shared_ptr<StreamHolder> g_adopt_stream;   // set by a dmi_meshes_prepare worker around dmi_job_create
+
 struct dmi_job {
   dmi_config cfg{};
   hipStream_t stream = nullptr;
-  bool own_stream = false;
+  std::shared_ptr<StreamHolder> stream_owner;   // set when the library created the stream
+  DevPool pool;   // (declared before every DevMem of the job: destroyed after them)
   std::vector<AttJob> atts;
   std::vector<TableDev> tables;
   DevMem descs;
@@ -142,7 +184,6 @@ struct dmi_job {
     if (out_pinned) (void)hipHostFree(out_pinned);
     if (graph_a) (void)hipGraphExecDestroy(graph_a);
     if (have_events) for (auto& e : ev) (void)hipEventDestroy(e);
-    if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
 };
 
@@ -290,13 +331,31 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(DMI_ERR_NO_DEVICE, "no HIP device visible; libdraco_mi has no CPU fallback");
   HIP_TRY(hipSetDevice(cfg.device));
+  const auto t_enter = std::chrono::steady_clock::now();
   std::unique_ptr<dmi_job> job(new dmi_job());
   job->cfg = cfg;
   if (cfg.stream) job->stream = static_cast<hipStream_t>(cfg.stream);
-  else { HIP_TRY(hipStreamCreate(&job->stream)); job->own_stream = true; }
+  else if (g_adopt_stream) { job->stream_owner = g_adopt_stream; job->stream = g_adopt_stream->s; }
+  else {
+    job->stream_owner = std::make_shared<StreamHolder>();
+    HIP_TRY(hipStreamCreate(&job->stream_owner->s));
+    job->stream = job->stream_owner->s;
+  }
   hipStream_t s = job->stream;
   int rc = validate_and_plan(atts, n_atts, cfg, job->atts);
   if (rc) return rc;
+  {   // device memory of the job: a pool sized from the mesh (tables 24 B/face + 88 B/vertex each, ≈ 31 B per coded component, raw values)
+    const size_t F0 = tables[0].num_faces;
+    size_t est = 0;
+    for (uint32_t i = 0; i < n_atts; ++i) {
+      const size_t V0 = tables[i].num_vertices;
+      est += F0 * 24 + V0 * 88 + (size_t)atts[i].num_unique * atts[i].num_components * 4 + V0 * ((size_t)job->atts[i].nq * 31 + 48) + ((size_t)1 << 20);
+    }
+    job->pool.stream = s;
+    job->pool.chunk_bytes = est + est / 8;
+  }
+  g_active_pool = std::getenv("DMI_NO_POOL") ? nullptr : &job->pool;
+  struct PoolGuard { ~PoolGuard() { g_active_pool = nullptr; } } pool_guard;
 
   const bool trace_create = std::getenv("DMI_TRACE") != nullptr;
   const auto tc0 = std::chrono::steady_clock::now();
@@ -463,9 +522,9 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
       a.aux_cap = (uint64_t)n + 16;   // ≤ 1 byte per coded bit + flush
       if ((rc = a.aux_out.alloc(a.aux_cap + 16))) return rc;   // +16: the batch pack kernel copies whole 16-byte words
       if ((rc = a.aux_rec.alloc(((size_t)n + kChainPad) * sizeof(RansEntry)))) return rc;
-      HIP_TRY(hipMemsetAsync(a.aux_rec.p, 0, a.aux_rec.bytes, s));
+      if (!a.aux_rec.pooled) HIP_TRY(hipMemsetAsync(a.aux_rec.p, 0, a.aux_rec.bytes, s));
       if ((rc = a.aux_flags.alloc(((size_t)n / 64 + 4) * 4))) return rc;
-      HIP_TRY(hipMemsetAsync(a.aux_flags.p, 0, a.aux_flags.bytes, s));
+      if (!a.aux_flags.pooled) HIP_TRY(hipMemsetAsync(a.aux_flags.p, 0, a.aux_flags.bytes, s));
       if ((rc = a.chunk_info.alloc((size_t)std::max(1u, orient_summary_blocks(n)) * 8 + 16))) return rc;
     }
     if (a.scheme == kNormal && a.fused_into < 0 && n) {   // fan rows: this table's fans, ranks in the parent position table
@@ -486,9 +545,9 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
       if ((rc = a.aux_entries.alloc(64))) return rc;
     }
     if ((rc = a.rec.alloc(((size_t)a.n_sym + kChainPad) * sizeof(RansEntry)))) return rc;
-    HIP_TRY(hipMemsetAsync(a.rec.p, 0, a.rec.bytes, s));
+    if (!a.rec.pooled) HIP_TRY(hipMemsetAsync(a.rec.p, 0, a.rec.bytes, s));
     if ((rc = a.batch_flags.alloc(((size_t)a.n_sym / 64 + 4) * 4))) return rc;
-    HIP_TRY(hipMemsetAsync(a.batch_flags.p, 0, a.batch_flags.bytes, s));
+    if (!a.batch_flags.pooled) HIP_TRY(hipMemsetAsync(a.batch_flags.p, 0, a.batch_flags.bytes, s));
     a.out_cap = a.n_sym * 3 + 16;   // ≤ 3 renormalisation bytes per symbol (P ≤ 20) + flush
     if ((rc = a.out.alloc(a.out_cap + 16))) return rc;
     if ((rc = a.partials.alloc((size_t)kRangeMaxBlocks * 8 * 4))) return rc;
@@ -504,7 +563,7 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
   job->predict_bytes = pb;
   pinned_need += 256;
   if ((rc = job->slab.alloc(pinned_need))) return rc;
-  HIP_TRY(hipMemsetAsync(job->slab.p, 0, pinned_need, s));
+  if (!job->slab.pooled) HIP_TRY(hipMemsetAsync(job->slab.p, 0, pinned_need, s));
   for (auto& a : job->atts) {
     uint8_t* base = job->slab.as<uint8_t>() + a.slab_off;
     a.small = SlabView{base, 64};
@@ -512,8 +571,7 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
     a.hist = SlabView{base + 128, (size_t)a.bins_cap * 4};
     a.summary = SlabView{base + 128 + (size_t)a.bins_cap * 4, a.scheme == kTexCoord ? (size_t)std::max(1u, orient_summary_blocks(job->tables[a.table].n_seq)) * 16 : 0};
   }
-  HIP_TRY(hipHostMalloc(&job->pinned, pinned_need, hipHostMallocDefault));
-  job->pinned_bytes = pinned_need;
+  job->pinned_bytes = pinned_need;   // (the pinned mirror is allocated by the first single-job encode: a batch reads back through its arena)
   job->dev_tables = !std::getenv("DMI_HOST_TABLES");
   for (auto& a : job->atts) if (a.port == kToBits) job->dev_tables = false;
   if ((rc = job->descs.alloc(sizeof(ChainDesc) * (size_t)n_atts * 2 + 16)   /* + the chain kernel's pull counter */)) return rc;
@@ -522,7 +580,8 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
     job->have_events = true;
   }
   HIP_TRY(hipStreamSynchronize(s));
-  if (trace_create) std::fprintf(stderr, "[dmi] job create (%u faces): sequences %.1f ms, relabel + table uploads %.1f, attribute uploads + buffers + fan rows %.1f\n", F, t_seq, t_relabel, since_ms(tc0) - t_seq - t_relabel);
+  if (trace_create) std::fprintf(stderr, "[dmi] job create (%u faces): sequences %.1f ms, relabel + table uploads %.1f, attribute uploads + buffers + fan rows %.1f, stream + plan %.1f\n", F, t_seq, t_relabel, since_ms(tc0) - t_seq - t_relabel,
+                                 std::chrono::duration<double, std::milli>(tc0 - t_enter).count());
   *job_out = job.release();
   return DMI_OK;
 }
@@ -542,6 +601,7 @@ static int encode_phase_a(dmi_job* job, bool plan_only = false) {   // device: r
   if (!plan_only) HIP_TRY(hipSetDevice(job->cfg.device));
   hipStream_t s = job->stream;
   const uint32_t n_atts = (uint32_t)job->atts.size();
+  if (!plan_only && !job->pinned) HIP_TRY(hipHostMalloc(&job->pinned, job->pinned_bytes, hipHostMallocDefault));
   uint8_t* pinned = static_cast<uint8_t*>(job->pinned);
   const bool timed = job->have_events;
   // ---- stage 1: value ranges (streamed over the unique values) ---------------------------------------------
@@ -1027,6 +1087,7 @@ static int encode_phase_c3(dmi_job* job, dmi_buffer* out) {   // host: splice th
 // event timing or a ToBits attribute (whose alphabet bound needs a mid-phase host wait) stay on the eager path.
 static int run_phase_a(dmi_job* job) {
   hipStream_t s = job->stream;
+  if (!job->pinned) { HIP_TRY(hipSetDevice(job->cfg.device)); HIP_TRY(hipHostMalloc(&job->pinned, job->pinned_bytes, hipHostMallocDefault)); }   // (not inside a stream capture)
   if (job->graph_a) { HIP_TRY(hipSetDevice(job->cfg.device)); HIP_TRY(hipGraphLaunch(job->graph_a, s)); return DMI_OK; }
   bool eligible = !job->have_events && !job->graph_tried;
   for (auto& a : job->atts) if (a.port == kToBits) eligible = false;
@@ -1721,19 +1782,34 @@ int dmi_meshes_prepare(const dmi_mesh* meshes, uint32_t n, const dmi_config* cfg
   std::vector<uint32_t> order(n);
   for (uint32_t j = 0; j < n; ++j) order[j] = j;
   std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return meshes[x].num_faces > meshes[y].num_faces; });
-  auto work = [&]() {
+  const int device = cfg ? cfg->device : 0;
+  const bool library_streams = !(cfg && cfg->stream);
+  auto work = [&](uint32_t t) {
+    if (library_streams) {   // this worker's stream (process-lifetime pool, created on first use)
+      static std::mutex m;
+      static std::vector<std::pair<int, std::shared_ptr<StreamHolder>>> pool[32];
+      std::lock_guard<std::mutex> lock(m);
+      std::shared_ptr<StreamHolder> found;
+      for (auto& e : pool[t]) if (e.first == device) found = e.second;
+      if (!found && hipSetDevice(device) == hipSuccess) {
+        found = std::make_shared<StreamHolder>();
+        if (hipStreamCreate(&found->s) != hipSuccess) found.reset(); else pool[t].push_back({device, found});
+      }
+      g_adopt_stream = found;   // (null: dmi_job_create makes its own)
+    }
     for (;;) {
       const uint32_t k = next.fetch_add(1);
-      if (k >= n) return;
+      if (k >= n) break;
       const uint32_t j = order[k];
       rcs[j] = dmi_mesh_prepare(&meshes[j], cfg, &header_and_connectivity[j], &jobs[j]);
       if (rcs[j]) errs[j] = g_last_error;
     }
+    g_adopt_stream.reset();
   };
-  if (n_threads == 1) work();
+  if (n_threads == 1) work(0);
   else {
     std::vector<std::thread> th;
-    for (uint32_t t = 0; t < n_threads; ++t) th.emplace_back(work);
+    for (uint32_t t = 0; t < n_threads; ++t) th.emplace_back(work, t);
     for (auto& x : th) x.join();
   }
   for (uint32_t j = 0; j < n; ++j) {
