@@ -56,6 +56,32 @@ def cpu_baseline(mesh, seconds_budget=30.0):
     }
 
 
+def batch_regime(n_meshes=256, steps=3):
+    """The batch form of the same path (BASELINE configs[3] shape): n independent meshes, F log-uniform in [2k, 200k], pos+nrm+uv,
+    resident jobs, ONE dmi_jobs_encode per step, timed at the C ABI (the call + dmi_free_many of its outputs)."""
+    meshes = synth.batch_meshes(n_meshes)
+    total = sum(len(m.faces) for m in meshes)
+    t0 = time.time()
+    jobs = dmi.meshes_prepare(meshes, dmi.Config())
+    prepare_s = time.time() - t0
+    with dmi.jobs_encode_raw(jobs):   # warm-up
+        pass
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        with dmi.jobs_encode_raw(jobs) as batch:
+            pass
+    dt = (time.perf_counter() - t0) / steps
+    with dmi.jobs_encode_raw(jobs) as batch:
+        nbytes = batch.nbytes
+        assert batch[0] == jobs[0].encode() and batch[n_meshes - 1] == jobs[n_meshes - 1].encode()
+    for j in jobs:
+        j.close()
+    return {"workload": f"{n_meshes} independent meshes, F log-uniform [2k,200k], pos+nrm+uv, one dmi_jobs_encode per step", "triangles": int(total),
+            "ms_per_batch": round(dt * 1e3, 3), "value": round(total / dt / 1e6, 2), "unit": "Mtriangles/s", "bitstream_bytes": int(nbytes),
+            "host_prepare_s": round(prepare_s, 2)}
+
+
 def pmc_traffic_bytes():
     """HBM bytes of one quantize+predict pass from the committed rocprofv3 PMC passes (FETCH_SIZE with the gfx950 x2
     correction + WRITE_SIZE, profiles/round1_pmc_traffic.csv, produced by scripts/summarize_profiles.py); None if absent."""
@@ -75,6 +101,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--grid", type=int, default=2236, help="grid side n (F = 2 n^2); default = the 10M-triangle workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batch", action="store_true", help="skip the extra batch-regime measurement (N=1 only, outside the timed steps)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -165,6 +192,11 @@ def main():
                        "msym_per_s_longest_chain": round((n_tris // 2 * 3) / max(stages["rans_ms"], 1e-9) / 1e3, 2)},
             "host_prepare_s": round(prepare_s, 2),
         }
+        if not args.no_batch and world == 1:   # reported beside the headline, never part of `value`
+            try:
+                line["batch_regime"] = batch_regime()
+            except Exception as e:   # the headline line must not depend on it
+                line["batch_regime"] = {"error": str(e)[:200]}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(mesh)
         print(json.dumps(line), flush=True)

@@ -75,3 +75,10 @@ def torus_mesh(n, seed=SEED, normals=True, uvs=True, open_boundary=False):
     if uv is not None:
         atts.append(Attribute(uv, ATT_TEXCOORD, DOMAIN_CORNER, unique_id=len(atts), parent_index=0))
     return Mesh(faces, atts)
+
+
+def batch_meshes(n_meshes, lo=2e3, hi=2e5, seed=SEED):
+    """The batch workload (BASELINE configs[3] shape): n independent torus grids, triangle counts log-uniform in [lo, hi]."""
+    rng = np.random.default_rng(seed)
+    tris = np.exp(rng.uniform(np.log(lo), np.log(hi), size=n_meshes))
+    return [torus_mesh(max(8, grid_size_for_triangles(t)), seed=seed + 7 * k) for k, t in enumerate(tris)]

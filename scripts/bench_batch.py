@@ -9,13 +9,9 @@ from draco_oxide_amd import synth
 
 n_meshes = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-rng = np.random.default_rng(synth.SEED)
-tris = np.exp(rng.uniform(np.log(2e3), np.log(2e5), size=n_meshes))
-grids = [max(8, synth.grid_size_for_triangles(t)) for t in tris]
 dev = torch.device("cuda", 0)
-stream = torch.cuda.Stream(dev)
-cfg = dmi.Config()   # every job owns its stream: host threads issue in parallel, small kernels overlap on the GPU
-meshes = [synth.torus_mesh(n, seed=synth.SEED + 7 * k) for k, n in enumerate(grids)]
+cfg = dmi.Config()
+meshes = synth.batch_meshes(n_meshes)
 total = sum(len(m.faces) for m in meshes)
 t0 = time.time()
 jobs = dmi.meshes_prepare(meshes, cfg)   # corner tables, Edgebreaker, sequencers, uploads: thread pool inside the library
