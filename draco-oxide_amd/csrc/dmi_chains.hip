@@ -501,12 +501,7 @@ __device__ uint32_t chain_emitter(const ChainDesc& d, uint32_t lane, lds_shared_
     touched ^= far;
     me_d = grec[base + 64u + lane].d;
     far = grec[base + (uint64_t)kAhead * 64u + lane].m;   // one dword per record = every line of that batch
-    // (the walker needs ≈ 2700 clocks per batch and this wavefront shares a SIMD with another pair's walker, whose scalar issue
-    // slots a tight poll would eat: one long nap when the slot is not there yet, then short ones)
-    if ((int32_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)sh->produced) - K) <= 0) {
-      __builtin_amdgcn_s_sleep(24);
-      while ((int32_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)sh->produced) - K) <= 0) __builtin_amdgcn_s_sleep(6);
-    }
+    while ((int32_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)sh->produced) - K) <= 0) __builtin_amdgcn_s_sleep(2);
     const uint32_t parked = sh->ring[K & (kRing - 1u)][lane];
     sh->consumed = K + 1u;                         // (LDS is in order: the slot read above is performed first)
     // bytes of the 64 steps: lane j re-derives its byte count from (parked state, frequency)
