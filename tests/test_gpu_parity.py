@@ -471,3 +471,34 @@ def test_batch_device_form_equals_host_form(monkeypatch):
         for k, (job, out) in enumerate(zip(jobs, outs)):
             assert out == job.encode(), f"mesh {k}: batch != single (host tables: {env})"
             _assert_same(heads[k] + out, want[k], f"mesh {k} (host tables: {env})")
+
+
+def test_concurrent_calls_from_host_threads():
+    """encode::encode is re-entrant (no globals, encode/mod.rs:59); so is the library: whole-mesh encodes and batch calls issued from
+    several host threads at once (ctypes drops the GIL) give the bytes of the serial runs."""
+    import threading
+    meshes = [synth.torus_mesh(24 + 5 * k, seed=40 + k, open_boundary=bool(k & 1)) for k in range(6)]
+    want = [oracle_from_product_mesh(m).encode() for m in meshes]
+    got = [None] * len(meshes)
+    batch_out = [None, None]
+
+    def whole(k):
+        for _ in range(3):
+            got[k] = dmi.encode_mesh(meshes[k])
+
+    def batch(slot):
+        jobs = dmi.meshes_prepare(meshes[slot::2])
+        for _ in range(3):
+            outs = dmi.jobs_encode(jobs)
+        batch_out[slot] = [j.header_and_connectivity + o for j, o in zip(jobs, outs)]
+
+    threads = [threading.Thread(target=whole, args=(k,)) for k in range(len(meshes))] + [threading.Thread(target=batch, args=(s,)) for s in (0, 1)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for k in range(len(meshes)):
+        _assert_same(got[k], want[k], f"threaded whole-mesh encode {k}")
+    for slot in (0, 1):
+        for k, blob in zip(range(slot, len(meshes), 2), batch_out[slot]):
+            _assert_same(blob, want[k], f"threaded batch {slot}, mesh {k}")
