@@ -51,3 +51,51 @@ def concatenate_with_index(blobs):
         offsets.append((pos, len(b)))
         pos += len(b)
     return b"".join(blobs), np.asarray(offsets, dtype=np.int64)
+
+
+def gather_blob_lists(local_blobs, local_indices, num_items, device=None, group=None, dst=0):
+    """Batch form of the gather: every rank holds the finished bitstreams of the items it owns (`local_indices`, as dealt by
+    shard_indices); `dst` receives all `num_items` of them in item order (None elsewhere).  One size exchange + one padded
+    gather for the whole batch: each rank's payload is an index/length table followed by its bytes."""
+    assert len(local_blobs) == len(local_indices)
+    table = np.empty(1 + 2 * len(local_blobs), dtype=np.int64)
+    table[0] = len(local_blobs)
+    table[1::2] = np.asarray(local_indices, dtype=np.int64)
+    table[2::2] = np.asarray([len(b) for b in local_blobs], dtype=np.int64)
+    got = gather_bitstreams(table.tobytes() + b"".join(local_blobs), device=device, group=group, dst=dst)
+    if got is None:
+        return None
+    out = [None] * num_items
+    for payload in got:
+        n = int(np.frombuffer(payload, dtype=np.int64, count=1)[0])
+        t = np.frombuffer(payload, dtype=np.int64, count=1 + 2 * n)
+        pos = (1 + 2 * n) * 8
+        for k in range(n):
+            idx, ln = int(t[1 + 2 * k]), int(t[2 + 2 * k])
+            out[idx] = payload[pos:pos + ln]
+            pos += ln
+    missing = [i for i, b in enumerate(out) if b is None]
+    if missing:
+        raise RuntimeError(f"gather_blob_lists: items {missing[:8]} were owned by no rank")
+    return out
+
+
+def encode_meshes_sharded(meshes, cfg=None, device=None, group=None, dst=0):
+    """BASELINE configs[3] on N GPUs: the batch is dealt to the ranks by triangle count (shard_indices, LPT), every rank prepares
+    and codes its share with ONE dmi_jobs_encode on its own GPU (no data-path collective), and the finished `.drc` blobs are
+    gathered onto `dst` in mesh order (RCCL when the group is nccl).  Every rank passes the same `meshes` list (or at least the
+    same triangle counts: a rank only touches the meshes it owns).  Returns the list of blobs on `dst`, None elsewhere."""
+    from . import binding
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    mine = shard_indices(len(meshes), rank, world, weights=[len(m.faces) for m in meshes])
+    blobs = []
+    if mine:
+        jobs = binding.meshes_prepare([meshes[i] for i in mine], cfg)
+        sections = binding.jobs_encode(jobs)
+        blobs = [j.header_and_connectivity + s for j, s in zip(jobs, sections)]
+        for j in jobs:
+            j.close()
+    if world == 1:
+        return blobs
+    return gather_blob_lists(blobs, mine, len(meshes), device=device, group=group, dst=dst)

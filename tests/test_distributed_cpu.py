@@ -28,10 +28,14 @@ def _worker(rank, world, port, q):
         blob = rng.integers(0, 256, size=1000 + 777 * rank, dtype=np.uint8).tobytes()
         got = dd.gather_bitstreams(blob)
         empty = dd.gather_bitstreams(b"" if rank == 1 else b"x")
+        # batch form: 7 items dealt by weight, each rank contributes the blobs of the items it owns
+        weights = [50, 900, 20, 400, 400, 10, 70]
+        mine = dd.shard_indices(len(weights), rank, world, weights=weights)
+        lists = dd.gather_blob_lists([bytes([i]) * weights[i] for i in mine], mine, len(weights))
         if rank == 0:
-            q.put((got, empty))
+            q.put((got, empty, lists))
         else:
-            assert got is None and empty is None
+            assert got is None and empty is None and lists is None
     finally:
         dist.destroy_process_group()
 
@@ -43,7 +47,7 @@ def test_gather_bitstreams_gloo_world2():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got, empty = q.get(timeout=120)
+    got, empty, lists = q.get(timeout=120)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -51,6 +55,7 @@ def test_gather_bitstreams_gloo_world2():
         want = np.random.default_rng(100 + r).integers(0, 256, size=1000 + 777 * r, dtype=np.uint8).tobytes()
         assert got[r] == want
     assert empty == [b"x", b""]
+    assert lists == [bytes([i]) * w for i, w in enumerate([50, 900, 20, 400, 400, 10, 70])]
     buf, index = dd.concatenate_with_index(got)
     assert len(buf) == sum(len(b) for b in got) and index.tolist() == [[0, 1000], [1000, 1777]]
 
