@@ -98,7 +98,8 @@ typedef struct dmi_timings {
   float quantize_ms;     /* min/max + quantize kernels, all attributes */
   float predict_ms;      /* rank/gather + predict+transform kernels (the HBM-roofline pass) */
   float histogram_ms;
-  float table_ms;        /* D2H histogram, host normalisation, H2D table (wall, host-inclusive) */
+  float table_ms;        /* table stage + record prep: k_tables and the prep kernels on the device (host-table form: D2H histogram,
+                            host normalisation, H2D tables — host-inclusive wall time) */
   float rans_ms;         /* rANS + rABS chain kernel */
   float total_ms;        /* first launch → last byte on host */
   uint64_t predict_bytes;    /* algorithmic bytes of the quantize+predict pass (SURVEY §8d formula) */
@@ -124,10 +125,9 @@ int dmi_job_timings(const dmi_job* job, dmi_timings* t);
 void dmi_job_destroy(dmi_job* job);
 
 /* --- Batches of independent meshes (the glTF transcoder calls encode::encode once per primitive:
- * io/gltf/encode.rs:932-955,1827-1842).  All jobs must have been created with the same dmi_config.stream.
- * Their data-parallel stages are queued back to back, the host waits once for every histogram, and every
- * rANS/rABS stream of every job runs in ONE launch (one wavefront per stream).  outs[j] receives job j's
- * attribute section. */
+ * io/gltf/encode.rs:932-955,1827-1842).  All jobs must live on one device.  The phases, the table stage and the record prep
+ * of ALL jobs are planned together (one upload, one launch per kernel), every rANS/rABS stream of every job runs in ONE
+ * persistent launch, and the host waits once — for the packed read-back.  outs[j] receives job j's attribute section. */
 int dmi_jobs_encode(dmi_job** jobs, uint32_t n_jobs, dmi_buffer* outs);
 typedef struct dmi_batch_item {
   const dmi_attribute* atts;
