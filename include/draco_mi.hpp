@@ -199,5 +199,50 @@ Result<Unit, Err> encode(core::Mesh mesh, ByteWriter& writer, const Config& cfg)
   return Result<Unit, Err>::ok(Unit{});
 }
 
+// The two halves of encode(), split at the seam a native replacement slots into (encode/mod.rs:86,90):
+//   connectivity::encode_connectivity(faces, &mut atts, &mut writer, cfg)  -> ConnectivityEncoderOutput   (host: header is written by encode())
+//   attribute::encode_attributes(atts, &mut writer, conn_out, &cfg)                                         (the MI355X hot path)
+namespace connectivity {
+// encode/connectivity/mod.rs:17-36.  Owns the flat corner tables, seeds (`corners_of_edgebreaker`) and sequences the attribute encoder consumes.
+class ConnectivityEncoderOutput {
+  dmi_conn c_{};
+ public:
+  ConnectivityEncoderOutput() = default;
+  ConnectivityEncoderOutput(const ConnectivityEncoderOutput&) = delete;
+  ConnectivityEncoderOutput& operator=(const ConnectivityEncoderOutput&) = delete;
+  ConnectivityEncoderOutput(ConnectivityEncoderOutput&& o) noexcept : c_(o.c_) { o.c_ = dmi_conn{}; }
+  ~ConnectivityEncoderOutput() { dmi_conn_free(&c_); }
+  dmi_conn& raw() { return c_; }
+  const dmi_conn& raw() const { return c_; }
+};
+// Appends the header (encode/header/mod.rs:26-54) and the Edgebreaker connectivity section to `writer`.
+template <class ByteWriter = std::vector<uint8_t>>
+Result<ConnectivityEncoderOutput, Err> encode_connectivity(const core::Mesh& mesh, ByteWriter& writer) {
+  ConnectivityEncoderOutput out;
+  dmi_buffer head{};
+  const int rc = dmi_encode_connectivity(&mesh.raw(), &head, &out.raw());
+  if (rc != DMI_OK) return Result<ConnectivityEncoderOutput, Err>::err(Err::last(rc));
+  writer.insert(writer.end(), head.data, head.data + head.len);
+  dmi_free(&head);
+  return Result<ConnectivityEncoderOutput, Err>::ok(std::move(out));
+}
+}  // namespace connectivity
+
+namespace attribute {
+// encode/attribute/mod.rs:13-93: attribute i is coded against the universal corner table (i = 0) or attribute table i-1
+// (all_inclusive_corner_table.rs:31-45); appends the attribute section to `writer`.
+template <class ByteWriter = std::vector<uint8_t>>
+Result<Unit, Err> encode_attributes(const core::Mesh& mesh, ByteWriter& writer, const connectivity::ConnectivityEncoderOutput& conn_out, const Config& cfg) {
+  const dmi_config c = cfg.raw();
+  const dmi_conn& k = conn_out.raw();
+  dmi_buffer out{};
+  const int rc = dmi_encode_attributes(mesh.raw().atts, k.tables, mesh.raw().num_atts, k.seeds, k.num_seeds, &c, &out);
+  if (rc != DMI_OK) return Result<Unit, Err>::err(Err::last(rc));
+  writer.insert(writer.end(), out.data, out.data + out.len);
+  dmi_free(&out);
+  return Result<Unit, Err>::ok(Unit{});
+}
+}  // namespace attribute
+
 }  // namespace encode
 }  // namespace draco_oxide

@@ -177,6 +177,17 @@ static void test_encode_appends_to_the_writer() {   // encode/mod.rs:59: `writer
   const std::vector<uint8_t> want = oracle_encode(raw);
   CHECK(writer.size() == want.size() + 2 && writer[0] == 0xDE && writer[1] == 0xAD && std::equal(want.begin(), want.end(), writer.begin() + 2), "previous bytes kept, stream appended");
 }
+static void test_the_two_halves_of_encode() {   // encode/mod.rs:83-93: header + connectivity, then the attribute section
+  std::printf("test_the_two_halves_of_encode\n");
+  const RawMesh raw = torus(17);
+  auto mesh = build(raw);
+  std::vector<uint8_t> writer;
+  auto conn_out = encode::connectivity::encode_connectivity(mesh, writer).unwrap();
+  const size_t head = writer.size();
+  encode::attribute::encode_attributes(mesh, writer, conn_out, encode::Config::default_()).unwrap();
+  CHECK(head > 11 && writer.size() > head, "both sections were appended");
+  CHECK(writer == oracle_encode(raw), "connectivity + attributes == encode()");
+}
 static void test_zero_length_normal_is_an_err_not_an_abort() {   // prediction_transform/geom.rs:45 asserts in the reference
   std::printf("test_zero_length_normal_is_an_err_not_an_abort\n");
   RawMesh raw = torus(6);
@@ -200,6 +211,7 @@ int main(int argc, char** argv) {
     en("cube_quads.obj", load_obj_rows(data + "/cube_quads.obj"));
     en("sphere.obj", load_obj_rows(data + "/sphere.obj"));
     test_encode_appends_to_the_writer();
+    test_the_two_halves_of_encode();
     test_zero_length_normal_is_an_err_not_an_abort();
   }
   std::printf(g_failed ? "%d check(s) FAILED\n" : "all checks passed\n", g_failed);
