@@ -183,9 +183,8 @@ def main():
                        "parallelism": f"{world} independent meshes, one per GPU" + (", RCCL gather of bitstreams to rank 0" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                          "traffic": pmc_traffic_bytes(),
-                         "kernel": "quantize+predict pass = slab memset + k_value_ranges + k_value_ranges_final + k_seq_quantize + k_i32_minmax_final + "
-                                   "k_predict_fused + k_orient_summary (every launch between the first and the histogram stage of one step, "
-                                   "hipEvent-timed on the job's stream)",
+                         "kernel": "quantize+predict pass = k_value_ranges + k_value_ranges_final (incl. slab clear) + k_seq_quantize + k_i32_minmax_final + "
+                                   "k_predict_fused (every launch between the first and the histogram stage of one step, hipEvent-timed on the job's stream)",
                          "algorithmic_bytes": int(tm["predict_bytes"]), "duration_ms": round(pass_ms, 4)},
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},
             "chains": {"streams": int(tm["num_streams"]), "symbols": int(tm["symbols"]),

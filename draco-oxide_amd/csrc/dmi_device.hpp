@@ -87,7 +87,9 @@ uint32_t orient_summary_blocks(uint32_t n);
 // ---- histogram (a16) -------------------------------------------------------------------------------
 // histograms (pre-zeroed) of up to kMaxRangeAtts symbol streams in one launch; *overflow |= 1 when a symbol ≥ bins is met
 struct HistAtt { const uint32_t* sym; uint64_t n; uint32_t* hist; uint32_t* overflow; uint32_t bins; uint32_t first_block, blocks, pad; };
-struct HistArgs { HistAtt a[kMaxRangeAtts]; int count; };
+// `orient` (optional, orient.orient != null): the orientation-flag summaries of one texture-coordinate attribute, computed by extra
+// blocks of the same launch (launch_orient_summary is the standalone form)
+struct HistArgs { HistAtt a[kMaxRangeAtts]; int count; uint32_t hist_blocks; OrientArgs orient; };
 void launch_histograms(HistArgs& args, hipStream_t s);
 
 // ---- serial coders: two wavefronts per stream (a18, a19, a11, a13) ------------------------------------

@@ -660,6 +660,7 @@ static int encode_phase_a(dmi_job* job, bool plan_only = false) {   // device: r
     }
     launch_i32_minmax_final(ma, s);
   }
+  OrientArgs fused_orient{};
   for (auto& a : job->atts) {
     const TableDev& t = job->tables[a.table];
     const int32_t* minmax = a.small.as<int32_t>();
@@ -681,7 +682,7 @@ static int encode_phase_a(dmi_job* job, bool plan_only = false) {   // device: r
         fa.qs_uv = q.qs.as<int32_t>(); fa.mm_uv = q.small.as<int32_t>(); fa.sym_uv = q.sym.as<uint32_t>(); fa.orient = q.aux.as<uint8_t>();
       }
       launch_predict_fused(fa, s);
-      if (a.fused_uv >= 0) { AttJob& q = job->atts[a.fused_uv]; launch_orient_summary(q.aux.as<uint8_t>(), n, q.summary.as<uint32_t>(), nullptr, s); }
+      if (a.fused_uv >= 0) { AttJob& q = job->atts[a.fused_uv]; fused_orient = OrientArgs{q.aux.as<uint8_t>(), q.summary.as<uint32_t>(), n, 0u}; }   // summarised by the histogram launch
       continue;
     }
     switch (a.scheme) {
@@ -732,6 +733,7 @@ static int encode_phase_a(dmi_job* job, bool plan_only = false) {   // device: r
     if (ha.count == kMaxRangeAtts) { launch_histograms(ha, s); ha.count = 0; }
     pin_off[i] = a.slab_off;
   }
+  ha.orient = fused_orient;
   launch_histograms(ha, s);
   // scratch words, ranges, histograms and orientation summaries of every attribute: one copy (the pinned buffer mirrors the slab)
   if (!plan_only && !job->dev_tables) HIP_TRY(hipMemcpyAsync(pinned, job->slab.p, job->slab.bytes, hipMemcpyDeviceToHost, s));

@@ -1003,7 +1003,8 @@ __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const u
 // Per-block summary of the orientation flags so the host can stitch the count of bits and the number
 // of forward transitions (mesh_prediction_for_texture_coordinates.rs:224-235) without a serial pass.
 constexpr uint32_t kOrientChunk = 4096;
-__device__ __forceinline__ void k_orient_summary_body(const OrientArgs& oa, const uint32_t blk_, const uint32_t nblk_) {
+template <uint32_t THREADS>
+__device__ __forceinline__ void orient_summary_impl(const OrientArgs& oa, const uint32_t blk_) {
   const uint8_t* __restrict__ orient = oa.orient;
   const uint32_t n = oa.n;
   uint32_t* __restrict__ summary = oa.summary;
@@ -1012,12 +1013,13 @@ __device__ __forceinline__ void k_orient_summary_body(const OrientArgs& oa, cons
   // stage the chunk through LDS with 16-byte loads: the scan below is a 64-step dependent loop, and a global byte
   // load per step would expose one memory latency per step
   __shared__ __attribute__((aligned(16))) uint8_t staged[kOrientChunk];
-  for (uint32_t w = lane; w < kOrientChunk / 16; w += 64) {
+  for (uint32_t w = lane; w < kOrientChunk / 16; w += THREADS) {
     const uint32_t at = lo + w * 16;
     if (at + 16 <= n) *reinterpret_cast<uint4*>(staged + w * 16) = *reinterpret_cast<const uint4*>(orient + at);
     else for (uint32_t b = 0; b < 16; ++b) staged[w * 16 + b] = (at + b < n) ? orient[at + b] : (uint8_t)0;
   }
   __syncthreads();
+  if (THREADS > 64 && lane >= 64) return;   // the scan is one wavefront's (no barrier follows)
   uint32_t count = 0, trans = 0, first = 2, last = 2;
   for (uint32_t base = lo; base < hi; base += 64) {
     const uint32_t i = base + lane;
@@ -1045,11 +1047,16 @@ __device__ __forceinline__ void k_orient_summary_body(const OrientArgs& oa, cons
   }
 }
 
+__device__ __forceinline__ void k_orient_summary_body(const OrientArgs& oa, const uint32_t blk_, const uint32_t) { orient_summary_impl<64>(oa, blk_); }
+
 // Symbol histograms of every attribute of a job in one launch (block → (attribute, slice)), LDS-privatised when the
 // alphabet fits (≤ 16K bins = 64 KiB of the CU's 160 KiB).  Few, fat blocks: each flushes its private copy once.
 constexpr uint32_t kLdsBins = 16384;
 __device__ __forceinline__ void k_histogram_body(const HistArgs& args, const uint32_t blk_, const uint32_t nblk_) {
   extern __shared__ uint32_t lds[];
+  // trailing blocks: the orientation-flag summaries of the job's fused sweep ride this launch (they depend on the same sweep as the
+  // histograms and would otherwise be a 16 µs serial step of the pass)
+  if (blk_ >= args.hist_blocks) { orient_summary_impl<kBlock>(args.orient, blk_ - args.hist_blocks); return; }
   int ai = 0;
   while (ai + 1 < args.count && blk_ >= args.a[ai + 1].first_block) ++ai;
   const HistAtt a = args.a[ai];
@@ -1225,7 +1232,9 @@ void launch_histograms(HistArgs& args, hipStream_t s) {
     total += a.blocks;
     if (a.blocks && a.bins <= kLdsBins) lds = std::max(lds, (size_t)a.bins * 4);
   }
-  emit(K_HIST, 6, args, total, (uint32_t)lds, s);
+  args.hist_blocks = total;
+  const uint32_t orient_blocks = args.orient.orient ? orient_summary_blocks(args.orient.n) : 0u;
+  emit(K_HIST, 6, args, total + orient_blocks, (uint32_t)lds, s);
 }
 
 }  // namespace dmi
