@@ -502,3 +502,34 @@ def test_concurrent_calls_from_host_threads():
     for slot in (0, 1):
         for k, blob in zip(range(slot, len(meshes), 2), batch_out[slot]):
             _assert_same(blob, want[k], f"threaded batch {slot}, mesh {k}")
+
+
+def test_many_tiny_meshes_stress_the_table_stage():
+    """Tiny meshes give tiny symbol histograms full of equal normalised frequencies: the tie-breaking of the table normalisation
+    (deficit to the LAST of the largest; excess from the largest, highest index first — Q12) decides most of their tables.
+    150 random soups / grids, random bit widths, one batch call; device-form tables against the oracle."""
+    rng = np.random.default_rng(2024)
+    meshes, cfgs = [], []
+    for k in range(150):
+        if k % 3 == 0:
+            n = int(rng.integers(3, 9))
+            m = synth.torus_mesh(n, seed=int(rng.integers(1, 1 << 30)), open_boundary=bool(k & 1))
+        else:
+            m = _heavy_tailed_mesh(int(rng.integers(3, 12)), seed=int(rng.integers(1, 1 << 30)))
+        meshes.append(m)
+    by_cfg = {}
+    for k, m in enumerate(meshes):
+        by_cfg.setdefault((int(rng.integers(2, 17)), int(rng.integers(2, 15))), []).append(k)
+    checked = 0
+    for (pb, ub), idx in by_cfg.items():
+        cfg = dmi.Config(pos_bits=pb, uv_bits=ub)
+        jobs = dmi.meshes_prepare([meshes[k] for k in idx], cfg)
+        outs = dmi.jobs_encode(jobs)
+        for k, job, out in zip(idx, jobs, outs):
+            try:
+                want = oracle_from_product_mesh(meshes[k]).encode(pos_bits=pb, uv_bits=ub)
+            except orc.OracleError:
+                continue   # (a table the reference cannot code: the batch call would have raised for the whole batch)
+            _assert_same(job.header_and_connectivity + out, want, f"tiny mesh {k} at {pb}/{ub} bits")
+            checked += 1
+    assert checked >= 140
