@@ -1478,8 +1478,19 @@ static int jobs_encode_device(dmi_job** jobs, uint32_t n, dmi_buffer* outs, Batc
   return DMI_OK;
 }
 
+static int jobs_encode_impl(dmi_job** jobs, uint32_t n, dmi_buffer* outs);
 int dmi_jobs_encode(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
   if (!jobs || !outs || n == 0) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
+  for (uint32_t j = 0; j < n; ++j) outs[j] = dmi_buffer{};
+  const int rc = jobs_encode_impl(jobs, n, outs);
+  if (rc) {   // all or nothing: no output of a failed batch is left allocated (the error text survives the frees)
+    const std::string why = g_last_error;
+    dmi_free_many(outs, n);
+    g_last_error = why;
+  }
+  return rc;
+}
+static int jobs_encode_impl(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
   for (uint32_t j = 0; j < n; ++j) if (!jobs[j] || jobs[j]->cfg.device != jobs[0]->cfg.device) return fail(DMI_ERR_INVALID_ARGUMENT, "batched jobs must live on one device");
   const int device = jobs[0]->cfg.device;
   // Small meshes are launch-bound, so whatever stays per job (table normalisation; the phases of jobs that cannot be planned ahead) runs on several host

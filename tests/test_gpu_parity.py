@@ -533,3 +533,25 @@ def test_many_tiny_meshes_stress_the_table_stage():
             _assert_same(job.header_and_connectivity + out, want, f"tiny mesh {k} at {pb}/{ub} bits")
             checked += 1
     assert checked >= 140
+
+
+def test_a_failing_mesh_fails_the_batch_cleanly():
+    """A zero-length normal is an assert in the reference (geom.rs:45) and an error code here; in a batch it fails the whole call,
+    leaves no output allocated, and the next call on the healthy jobs works."""
+    good = [synth.torus_mesh(12 + k, seed=70 + k) for k in range(4)]
+    faces, pos, nrm, uv = synth.torus_grid(10, 5)
+    nrm = nrm.copy()
+    nrm[7] = 0.0
+    b = dmi.MeshBuilder()
+    pid = b.add_attribute(pos, dmi.ATT_POSITION, dmi.DOMAIN_POSITION)
+    b.add_attribute(nrm, dmi.ATT_NORMAL, dmi.DOMAIN_CORNER, parents=[pid])
+    b.set_connectivity_attribute(faces)
+    bad = b.build()
+    jobs = dmi.meshes_prepare(good[:2] + [bad] + good[2:])
+    with pytest.raises(dmi.DracoMiError) as e:
+        dmi.jobs_encode(jobs)
+    assert e.value.status == 6   # DMI_ERR_ZERO_NORMAL
+    healthy = jobs[:2] + jobs[3:]
+    outs = dmi.jobs_encode(healthy)
+    for m, job, out in zip(good, healthy, outs):
+        _assert_same(job.header_and_connectivity + out, oracle_from_product_mesh(m).encode(), "healthy job after a failed batch")
