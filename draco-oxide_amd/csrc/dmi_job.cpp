@@ -1368,113 +1368,214 @@ static int run_phase_b_batched(dmi_job** jobs, const std::vector<uint32_t>& whic
 // launch per (level, kernel)), the chain descriptors are written by k_tables, and the chains follow on the same stream — the
 // host waits for the first time when everything has been coded.  Read-back: one packed arena (coded bytes + serialised tables),
 // one table of {offset, length, error}, 128 scratch bytes per attribute.
-typedef std::function<int(const std::function<int(uint32_t)>&, bool)> ParallelJobs;   // fn(job index) over all jobs on the batch's host threads
-static int jobs_encode_device(dmi_job** jobs, uint32_t n, dmi_buffer* outs, BatchArena* arena, const ParallelJobs& parallel, bool trace) {
-  hipStream_t s = jobs[0]->stream;
-  int rc;
-  auto now = [] { return std::chrono::steady_clock::now(); };
-  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-  const auto t0 = now();
-  std::vector<uint32_t> first_desc(n + 1, 0), first_att(n + 1, 0);
-  for (uint32_t j = 0; j < n; ++j) { first_desc[j + 1] = first_desc[j] + count_streams(jobs[j]); first_att[j + 1] = first_att[j] + (uint32_t)jobs[j]->atts.size(); }
-  const uint32_t n_streams = first_desc[n], n_atts = first_att[n], n_descs = n_streams + n_atts;
-  const size_t order_at = (size_t)n_descs * sizeof(ChainDesc), counter_at = order_at + (((size_t)n_streams * 4 + 15) & ~(size_t)15);
-  if ((rc = arena->reserve_descs(counter_at + 16))) return rc;
-  ChainDesc* descs_dev = static_cast<ChainDesc*>(arena->descs_dev);
-  // ---- plan (host threads; no HIP call) ----
-  std::vector<std::vector<KernelStep>> steps(n);
-  if ((rc = parallel([&](uint32_t j) {
-        dmi_job* job = jobs[j];
-        job->readback = nullptr;
-        set_step_sink(&steps[j]);
-        int r = encode_phase_a(job, true);
-        const size_t n_a = steps[j].size();
-        if (!r) r = encode_phase_b_dev(job, descs_dev + first_desc[j], descs_dev + n_streams + first_att[j]);
-        set_step_sink(nullptr);
-        for (size_t k = n_a; k < steps[j].size(); ++k) steps[j][k].level += kStepLevels;
-        return r;
-      }, false))) return rc;
-  const auto ta = now();
-  BatchPlan plan;
-  plan.add(steps, kStepLevels + kPrepLevels);
-  const auto tb = now();
-  // stream order for the chain kernel (longest first), scratch-word copies, capacities
-  std::vector<uint64_t> length(n_streams);
-  size_t cap_sum = 0;
-  for (uint32_t j = 0; j < n; ++j)
-    for (size_t k = 0; k < jobs[j]->run.descs.size(); ++k) { const ChainDesc& d = jobs[j]->run.descs[k]; length[first_desc[j] + k] = d.n; cap_sum += ((size_t)d.cap + 31) & ~(size_t)15; }
-  for (uint32_t j = 0; j < n; ++j) for (auto& a : jobs[j]->atts) cap_sum += ((size_t)a.hdr_cap + 31) & ~(size_t)15;
-  std::vector<uint32_t> by_length(n_streams);
-  for (uint32_t k = 0; k < n_streams; ++k) by_length[k] = k;
-  std::stable_sort(by_length.begin(), by_length.end(), [&](uint32_t x, uint32_t y) { return length[x] > length[y]; });
-  std::vector<CopyItem> copies;
-  copies.reserve(n_atts);
-  for (uint32_t j = 0; j < n; ++j) for (auto& a : jobs[j]->atts) copies.push_back(CopyItem{a.small.p, (uint64_t)copies.size() * 128u, 128u});
-  const size_t off_copies = plan.reserve(copies.size() * sizeof(CopyItem));
-  const size_t off_order = plan.reserve((size_t)n_streams * 4);
-  if ((rc = BatchArena::reserve_pair(arena->plan_host, arena->plan_dev, arena->plan_cap, plan.bytes))) return rc;
-  if ((rc = BatchArena::reserve_pair(arena->slabs_host, arena->slabs_dev, arena->slabs_cap, (size_t)n_atts * 128))) return rc;
-  if ((rc = arena->reserve(cap_sum, (size_t)(n_descs + 1) * sizeof(PackEntry)))) return rc;
-  uint8_t* ph = static_cast<uint8_t*>(arena->plan_host);
-  plan.fill(ph);
-  std::memcpy(ph + off_copies, copies.data(), copies.size() * sizeof(CopyItem));
-  std::memcpy(ph + off_order, by_length.data(), (size_t)n_streams * 4);
-  const auto t1 = now();
-  // ---- the whole encode: one upload, then launches only ----
-  HIP_TRY(hipMemcpyAsync(arena->plan_dev, arena->plan_host, plan.bytes, hipMemcpyHostToDevice, s));
-  const uint8_t* pd = static_cast<const uint8_t*>(arena->plan_dev);
-  plan.launch(pd, s);
-  launch_chains(descs_dev, reinterpret_cast<const uint32_t*>(pd + off_order), n_streams, reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(arena->descs_dev) + counter_at), s);
-  launch_pack_streams(descs_dev, n_descs, static_cast<PackEntry*>(arena->table_dev), static_cast<uint8_t*>(arena->bytes_dev), s);
-  launch_copy_items(reinterpret_cast<const CopyItem*>(pd + off_copies), n_atts, static_cast<uint8_t*>(arena->slabs_dev), s);
-  HIP_TRY(hipMemcpyAsync(arena->table_host, arena->table_dev, (size_t)(n_descs + 1) * sizeof(PackEntry), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(arena->slabs_host, arena->slabs_dev, (size_t)n_atts * 128, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  const auto t2 = now();
-  const PackEntry* table = static_cast<const PackEntry*>(arena->table_host);
-  const size_t total = (size_t)table[n_descs].offset;
-  if ((rc = arena->reserve_host(total))) return rc;
-  if (total) HIP_TRY(hipMemcpyAsync(arena->bytes_host, arena->bytes_dev, total, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  const auto t3 = now();
-  const uint8_t* bytes_host = static_cast<const uint8_t*>(arena->bytes_host);
-  if ((rc = parallel([&](uint32_t j) {
-        dmi_job* job = jobs[j];
-        const uint32_t na = (uint32_t)job->atts.size();
-        job->readback = static_cast<uint8_t*>(arena->slabs_host) + (size_t)first_att[j] * 128;
-        job->run.pin_off.assign(na, 0);
-        job->run.hdr_ptr.assign(na, nullptr);
-        job->run.hdr_len.assign(na, 0);
-        for (uint32_t i = 0; i < na; ++i) {
-          job->run.pin_off[i] = (size_t)i * 128;
-          const uint32_t* small = reinterpret_cast<const uint32_t*>(job->readback + job->run.pin_off[i]);
-          const int frc = check_device_flags(small, i);
-          if (frc) return frc;
-          job->run.aux[i].zero_prob = (uint8_t)small[14];
-          job->run.aux[i].count = small[15];
-          const PackEntry& h = table[n_streams + first_att[j] + i];
-          job->run.hdr_ptr[i] = bytes_host + h.offset;
-          job->run.hdr_len[i] = h.len;
-        }
-        int r = encode_phase_c_packed(job, table, first_desc[j], bytes_host);
-        if (!r) r = encode_phase_c3(job, &outs[j]);
-        return r;
-      }, false))) return rc;
-  if (trace) {   // per-stream chain clocks (100 MHz ticks written by the emitters)
-    double sum_ms = 0, max_ms = 0, steps = 0, big_steps = 0, big_ms = 0;
+// A batch is begun (plan, upload, launches: returns without waiting) and finished (wait, read back, splice) separately, so that
+// two halves of a large batch can be in flight on two streams: the data-parallel kernels of the second half run under the
+// chain launch of the first, which is latency-bound by its longest stream and leaves the vector units idle.
+static int parallel_items(uint32_t n, uint32_t n_threads, int device, const std::function<int(uint32_t)>& fn) {
+  n_threads = std::max(1u, std::min(n, n_threads));
+  std::vector<int> rcs(n_threads, DMI_OK);
+  std::vector<std::string> errs(n_threads);
+  auto work = [&](uint32_t t) {
+    if (hipSetDevice(device) != hipSuccess) { rcs[t] = DMI_ERR_HIP; errs[t] = "hipSetDevice"; return; }
+    const uint32_t lo = (uint32_t)((uint64_t)n * t / n_threads), hi = (uint32_t)((uint64_t)n * (t + 1) / n_threads);
+    for (uint32_t k = lo; k < hi; ++k) { const int rc = fn(k); if (rc) { rcs[t] = rc; errs[t] = g_last_error; return; } }
+  };
+  if (n_threads == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < n_threads; ++t) th.emplace_back(work, t);
+    for (auto& x : th) x.join();
+  }
+  for (uint32_t t = 0; t < n_threads; ++t) if (rcs[t]) return fail(rcs[t], errs[t]);
+  return DMI_OK;
+}
+
+struct DeviceBatch {
+  std::vector<dmi_job*> jobs;
+  std::vector<dmi_buffer*> outs;
+  BatchArena* arena = nullptr;
+  hipStream_t s = nullptr;
+  uint32_t n_threads = 1;
+  int device = 0;
+  std::vector<uint32_t> first_desc, first_att;
+  uint32_t n_streams = 0, n_atts = 0, n_descs = 0;
+  size_t launches = 0;
+  double t_plan = 0, t_wait = 0, t_bytes = 0, t_splice = 0;
+  ~DeviceBatch() { if (arena) release_batch_arena(arena); }
+
+  int begin() {
+    const uint32_t n = (uint32_t)jobs.size();
+    int rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    first_desc.assign(n + 1, 0);
+    first_att.assign(n + 1, 0);
+    for (uint32_t j = 0; j < n; ++j) { first_desc[j + 1] = first_desc[j] + count_streams(jobs[j]); first_att[j + 1] = first_att[j] + (uint32_t)jobs[j]->atts.size(); }
+    n_streams = first_desc[n]; n_atts = first_att[n]; n_descs = n_streams + n_atts;
+    const size_t order_at = (size_t)n_descs * sizeof(ChainDesc), counter_at = order_at + (((size_t)n_streams * 4 + 15) & ~(size_t)15);
+    if ((rc = arena->reserve_descs(counter_at + 16))) return rc;
+    ChainDesc* descs_dev = static_cast<ChainDesc*>(arena->descs_dev);
+    // ---- plan (host threads; no HIP call) ----
+    std::vector<std::vector<KernelStep>> steps(n);
+    if ((rc = parallel_items(n, n_threads, device, [&](uint32_t j) {
+          dmi_job* job = jobs[j];
+          job->readback = nullptr;
+          set_step_sink(&steps[j]);
+          int r = encode_phase_a(job, true);
+          const size_t n_a = steps[j].size();
+          if (!r) r = encode_phase_b_dev(job, descs_dev + first_desc[j], descs_dev + n_streams + first_att[j]);
+          set_step_sink(nullptr);
+          for (size_t k = n_a; k < steps[j].size(); ++k) steps[j][k].level += kStepLevels;
+          return r;
+        }))) return rc;
+    BatchPlan plan;
+    plan.add(steps, kStepLevels + kPrepLevels);
+    launches = plan.groups.size();
+    // stream order for the chain kernel (longest first), scratch-word copies, capacities
+    std::vector<uint64_t> length(n_streams);
+    size_t cap_sum = 0;
     for (uint32_t j = 0; j < n; ++j)
-      for (uint32_t i = 0; i < (uint32_t)jobs[j]->atts.size(); ++i) {
-        const uint32_t* small = reinterpret_cast<const uint32_t*>(jobs[j]->readback + jobs[j]->run.pin_off[i]);
-        const double r = small[12] * 1e-5, x = jobs[j]->run.aux[i].desc >= 0 ? small[13] * 1e-5 : 0.0;
-        const double ns = (double)jobs[j]->atts[i].n_sym, nx = jobs[j]->run.aux[i].desc >= 0 ? (double)jobs[j]->run.aux[i].count : 0.0;
+      for (size_t k = 0; k < jobs[j]->run.descs.size(); ++k) { const ChainDesc& d = jobs[j]->run.descs[k]; length[first_desc[j] + k] = d.n; cap_sum += ((size_t)d.cap + 31) & ~(size_t)15; }
+    for (uint32_t j = 0; j < n; ++j) for (auto& a : jobs[j]->atts) cap_sum += ((size_t)a.hdr_cap + 31) & ~(size_t)15;
+    std::vector<uint32_t> by_length(n_streams);
+    for (uint32_t k = 0; k < n_streams; ++k) by_length[k] = k;
+    std::stable_sort(by_length.begin(), by_length.end(), [&](uint32_t x, uint32_t y) { return length[x] > length[y]; });
+    std::vector<CopyItem> copies;
+    copies.reserve(n_atts);
+    for (uint32_t j = 0; j < n; ++j) for (auto& a : jobs[j]->atts) copies.push_back(CopyItem{a.small.p, (uint64_t)copies.size() * 128u, 128u});
+    const size_t off_copies = plan.reserve(copies.size() * sizeof(CopyItem));
+    const size_t off_order = plan.reserve((size_t)n_streams * 4);
+    if ((rc = BatchArena::reserve_pair(arena->plan_host, arena->plan_dev, arena->plan_cap, plan.bytes))) return rc;
+    if ((rc = BatchArena::reserve_pair(arena->slabs_host, arena->slabs_dev, arena->slabs_cap, (size_t)n_atts * 128))) return rc;
+    if ((rc = arena->reserve(cap_sum, (size_t)(n_descs + 1) * sizeof(PackEntry)))) return rc;
+    uint8_t* ph = static_cast<uint8_t*>(arena->plan_host);
+    plan.fill(ph);
+    std::memcpy(ph + off_copies, copies.data(), copies.size() * sizeof(CopyItem));
+    std::memcpy(ph + off_order, by_length.data(), (size_t)n_streams * 4);
+    // ---- the whole encode: one upload, then launches only ----
+    HIP_TRY(hipMemcpyAsync(arena->plan_dev, arena->plan_host, plan.bytes, hipMemcpyHostToDevice, s));
+    const uint8_t* pd = static_cast<const uint8_t*>(arena->plan_dev);
+    plan.launch(pd, s);
+    launch_chains(descs_dev, reinterpret_cast<const uint32_t*>(pd + off_order), n_streams, reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(arena->descs_dev) + counter_at), s);
+    launch_pack_streams(descs_dev, n_descs, static_cast<PackEntry*>(arena->table_dev), static_cast<uint8_t*>(arena->bytes_dev), s);
+    launch_copy_items(reinterpret_cast<const CopyItem*>(pd + off_copies), n_atts, static_cast<uint8_t*>(arena->slabs_dev), s);
+    HIP_TRY(hipMemcpyAsync(arena->table_host, arena->table_dev, (size_t)(n_descs + 1) * sizeof(PackEntry), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(arena->slabs_host, arena->slabs_dev, (size_t)n_atts * 128, hipMemcpyDeviceToHost, s));
+    t_plan = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return DMI_OK;
+  }
+
+  int finish() {
+    const uint32_t n = (uint32_t)jobs.size();
+    int rc;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t1 = now();
+    HIP_TRY(hipStreamSynchronize(s));
+    const auto t2 = now();
+    const PackEntry* table = static_cast<const PackEntry*>(arena->table_host);
+    const size_t total = (size_t)table[n_descs].offset;
+    if ((rc = arena->reserve_host(total))) return rc;
+    if (total) HIP_TRY(hipMemcpyAsync(arena->bytes_host, arena->bytes_dev, total, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const auto t3 = now();
+    const uint8_t* bytes_host = static_cast<const uint8_t*>(arena->bytes_host);
+    if ((rc = parallel_items(n, n_threads, device, [&](uint32_t j) {
+          dmi_job* job = jobs[j];
+          const uint32_t na = (uint32_t)job->atts.size();
+          job->readback = static_cast<uint8_t*>(arena->slabs_host) + (size_t)first_att[j] * 128;
+          job->run.pin_off.assign(na, 0);
+          job->run.hdr_ptr.assign(na, nullptr);
+          job->run.hdr_len.assign(na, 0);
+          for (uint32_t i = 0; i < na; ++i) {
+            job->run.pin_off[i] = (size_t)i * 128;
+            const uint32_t* small = reinterpret_cast<const uint32_t*>(job->readback + job->run.pin_off[i]);
+            const int frc = check_device_flags(small, i);
+            if (frc) return frc;
+            job->run.aux[i].zero_prob = (uint8_t)small[14];
+            job->run.aux[i].count = small[15];
+            const PackEntry& h = table[n_streams + first_att[j] + i];
+            job->run.hdr_ptr[i] = bytes_host + h.offset;
+            job->run.hdr_len[i] = h.len;
+          }
+          int r = encode_phase_c_packed(job, table, first_desc[j], bytes_host);
+          if (!r) r = encode_phase_c3(job, outs[j]);
+          return r;
+        }))) return rc;
+    t_wait = ms(t1, t2); t_bytes = ms(t2, t3); t_splice = ms(t3, now());
+    return DMI_OK;
+  }
+
+  void trace(const char* name) const {   // per-stream chain clocks (100 MHz ticks written by the emitters) + host stages
+    double sum_ms = 0, max_ms = 0, steps = 0, big_steps = 0, big_ms = 0;
+    for (dmi_job* job : jobs)
+      for (uint32_t i = 0; i < (uint32_t)job->atts.size(); ++i) {
+        const uint32_t* small = reinterpret_cast<const uint32_t*>(job->readback + job->run.pin_off[i]);
+        const double r = small[12] * 1e-5, x = job->run.aux[i].desc >= 0 ? small[13] * 1e-5 : 0.0;
+        const double ns = (double)job->atts[i].n_sym, nx = job->run.aux[i].desc >= 0 ? (double)job->run.aux[i].count : 0.0;
         sum_ms += r + x; max_ms = std::max({max_ms, r, x}); steps += ns + nx;
         if (ns > 50000) { big_steps += ns; big_ms += r; }
       }
-    std::fprintf(stderr, "[dmi] chains: %.0f steps, stream times sum %.1f ms (/1024 walkers = %.2f ms), longest %.2f ms, %.1f ns/step overall, %.1f ns/step on rANS streams > 50k symbols\n", steps, sum_ms,
+    std::fprintf(stderr, "[dmi] %s: %zu jobs, %u streams, %zu launches; plan + issue %.2f ms, wait for the stream %.2f, byte read-back %.2f, splice %.2f; chains: %.0f steps, stream times sum %.1f ms "
+                 "(/1024 walkers = %.2f), longest %.2f ms, %.1f ns/step (%.1f on rANS streams > 50k symbols)\n", name, jobs.size(), n_streams, launches, t_plan, t_wait, t_bytes, t_splice, steps, sum_ms,
                  sum_ms / 1024.0, max_ms, sum_ms * 1e6 / std::max(1.0, steps), big_ms * 1e6 / std::max(1.0, big_steps));
   }
-  if (trace) std::fprintf(stderr, "[dmi] batch of %u, device form: plan %.2f ms (steps %.2f, grouping %.2f, fill %.2f; %zu launches), upload + every kernel + chains (%u streams) + packing %.2f, byte read-back %.2f, splice %.2f\n", n, ms(t0, t1), ms(t0, ta), ms(ta, tb), ms(tb, t1),
-                          plan.groups.size(), n_streams, ms(t1, t2), ms(t2, t3), ms(t3, now()));
+};
+
+// The two streams of a split batch (process lifetime, one pair per device; created back to back so that they land on different
+// hardware queues — two streams that share a queue run their kernels strictly one after the other).
+static bool batch_stream_pair(int device, hipStream_t& a, hipStream_t& b) {
+  struct Pair { int device; hipStream_t a, b; };
+  static std::mutex m;
+  static std::vector<Pair> pairs;
+  std::lock_guard<std::mutex> lock(m);
+  for (auto& e : pairs) if (e.device == device) { a = e.a; b = e.b; return true; }
+  Pair p{device, nullptr, nullptr};
+  if (hipStreamCreateWithFlags(&p.a, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&p.b, hipStreamNonBlocking) != hipSuccess) return false;
+  pairs.push_back(p);
+  a = p.a; b = p.b;
+  return true;
+}
+
+static int jobs_encode_device(dmi_job** jobs, uint32_t n, dmi_buffer* outs, uint32_t n_threads, bool trace) {
+  const int device = jobs[0]->cfg.device;
+  // Large batches run as two halves in flight: the jobs with the longest streams first (≈ 45 % of the symbols), the rest behind
+  // them on a second stream — its data-parallel kernels (and the host's planning of it) run under the first half's chain launch.
+  std::vector<uint32_t> order(n);
+  for (uint32_t j = 0; j < n; ++j) order[j] = j;
+  auto symbols = [&](uint32_t j) { uint64_t t = 0; for (auto& a : jobs[j]->atts) t += a.n_sym; return t; };
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return symbols(x) > symbols(y); });
+  uint64_t total = 0;
+  for (uint32_t j = 0; j < n; ++j) total += symbols(j);
+  uint32_t n_first = n;
+  hipStream_t main_stream = jobs[0]->stream, side = nullptr;
+  bool library_streams = true;   // a caller's stream (dmi_config.stream) is honoured: everything stays on it
+  for (uint32_t j = 0; j < n; ++j) if (jobs[j]->cfg.stream) library_streams = false;
+  if (n >= 32 && library_streams && std::getenv("DMI_SPLIT") && batch_stream_pair(device, main_stream, side)) {
+    uint64_t acc = 0;
+    n_first = 0;
+    while (n_first < n && acc * 100 < total * 45) acc += symbols(order[n_first++]);
+    if (n_first < 8 || n - n_first < 8) n_first = n;
+  }
+  DeviceBatch first, second;
+  auto fill = [&](DeviceBatch& b, uint32_t lo, uint32_t hi, hipStream_t s) {
+    for (uint32_t k = lo; k < hi; ++k) { b.jobs.push_back(jobs[order[k]]); b.outs.push_back(&outs[order[k]]); }
+    b.arena = acquire_batch_arena(device);
+    b.s = s; b.n_threads = n_threads; b.device = device;
+  };
+  fill(first, 0, n_first, main_stream);
+  int rc;
+  if ((rc = first.begin())) return rc;
+  if (n_first < n) {
+    fill(second, n_first, n, side);
+    if ((rc = second.begin())) { (void)hipStreamSynchronize(first.s); (void)hipStreamSynchronize(second.s); return rc; }
+  }
+  rc = first.finish();
+  if (n_first < n) {
+    if (rc) (void)hipStreamSynchronize(second.s);   // a failed first half: let the second drain, report the first error
+    else rc = second.finish();
+  }
+  if (rc) return rc;
+  if (trace) { first.trace(n_first < n ? "batch, device form, first half" : "batch, device form"); if (n_first < n) second.trace("batch, device form, second half"); }
   return DMI_OK;
 }
 
@@ -1534,7 +1635,7 @@ static int jobs_encode_impl(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
   // data-parallel kernels of later ones.  The chains of ALL jobs then run in one launch: a long-running kernel per job
   // would pin one of the few hardware queues each and serialise the batch (measured: 114 ms instead of 8).
   BatchArena* arena = acquire_batch_arena(device);
-  struct Release { BatchArena* a; ~Release() { release_batch_arena(a); } } release{arena};
+  struct Release { BatchArena* a; ~Release() { if (a) release_batch_arena(a); } } release{arena};
   // jobs whose phase A can be planned ahead (no mid-phase host wait, no per-job event timing) share one launch per kernel
   std::vector<uint32_t> batched;
   std::vector<uint8_t> is_batched(n, 0);
@@ -1548,7 +1649,7 @@ static int jobs_encode_impl(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
   {
     bool all_device = batched.size() == n;
     for (uint32_t j = 0; j < n && all_device; ++j) all_device = jobs[j]->dev_tables;
-    if (all_device) return jobs_encode_device(jobs, n, outs, arena, parallel, trace);
+    if (all_device) { release.a = nullptr; release_batch_arena(arena); return jobs_encode_device(jobs, n, outs, n_threads, trace); }
   }
   if ((rc = run_phase_a_batched(jobs, batched, arena, s))) return rc;
   const auto t1 = now();

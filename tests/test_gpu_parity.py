@@ -555,3 +555,16 @@ def test_a_failing_mesh_fails_the_batch_cleanly():
     outs = dmi.jobs_encode(healthy)
     for m, job, out in zip(good, healthy, outs):
         _assert_same(job.header_and_connectivity + out, oracle_from_product_mesh(m).encode(), "healthy job after a failed batch")
+
+
+def test_split_batch_two_halves_in_flight(monkeypatch):
+    """DMI_SPLIT=1 (experimental, off by default): a batch of ≥ 32 library-stream jobs runs as two halves in flight on two streams
+    (begin A, begin B, finish A, finish B).  Same bytes as the one-piece batch and as the oracle."""
+    meshes = [synth.torus_mesh(6 + k, seed=300 + k, open_boundary=bool(k % 4 == 0)) for k in range(40)]
+    jobs = dmi.meshes_prepare(meshes)
+    whole = dmi.jobs_encode(jobs)
+    monkeypatch.setenv("DMI_SPLIT", "1")
+    halves = dmi.jobs_encode(jobs)
+    assert halves == whole
+    for k in (0, 7, 39):
+        _assert_same(jobs[k].header_and_connectivity + halves[k], oracle_from_product_mesh(meshes[k]).encode(), f"split batch, mesh {k}")
