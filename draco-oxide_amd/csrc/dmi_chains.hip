@@ -2,7 +2,7 @@
 //
 // The rANS/rABS state recurrence is ONE dependency chain per stream (a single non-interleaved
 // stream per attribute), so a stream is owned by one wavefront and the chain runs on the SCALAR unit:
-//   * prep kernels (data-parallel, all CUs) turn the stream into 16-byte coding records {m, b, d, c}
+//   * prep kernels (data-parallel, all CUs) turn the stream into 20-byte coding records {m, b, d, c, t}
 //     in coding order, so the chain never touches a symbol table:
 //       k_rans_prep      symbols, reversed (symbol_coding.rs:161-163)
 //       k_bits_prep      rABS bits, forward (normal flips, mesh_normal_prediction.rs:154-157)
@@ -395,16 +395,6 @@ __device__ void k_tables_body(const TableAtt& a, const uint32_t, const uint32_t)
 //                    batches AHEAD of the walker so that the walker's scalar loads hit L2.
 // LDS operations of one wavefront execute in order, so "slot, then counter" needs no fence; the walker only looks at
 // `consumed` when its cached copy says the ring could be full (once per kRing batches).
-// The same step for a batch in which no symbol can renormalise by more than one byte (every f ≥ 2^(P-8): x/f < 2^18): the byte
-// count is one compare-and-select instead of count-leading-zeros, subtract, mask — 9 scalar instructions + the writelane.
-#define DMI_CHAIN_STEP_1B(R, J)                                                                  \
-  {                                                                                              \
-    const uint32_t q0 = __umulhi(x, (R).m) >> ((R).b & 31u);                                     \
-    const uint32_t sh = (q0 >> thr_shift) ? 8u : 0u;                                             \
-    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(parked) : "s"(x), "i"(J));                  \
-    x = (x >> sh) + (q0 >> sh) * (R).d + (R).c;                                                  \
-  }
-
 // The record buffer is padded with kChainPad records past n, so chunk and batch prefetches may run ahead freely.
 constexpr uint32_t kRing = 8;
 constexpr uint32_t kAhead = 4;   // batches between the emitter's position and the records it pulls into L2
@@ -420,13 +410,20 @@ typedef const RansEntry __attribute__((address_space(1))) * grec_t;   // global 
 typedef volatile ChainShared __attribute__((address_space(3))) * lds_shared_t;   // LDS address space ⇒ ds_read/ds_write
 
 #include "dmi_walker_asm.inc"
+// Two parking modes.  Dense: the state before every step is parked (lane j = step j) and the emitter only sheds bytes.  Sparse: the
+// state before every kPark-th step only (one v_writelane per kPark steps: the walker is bound by its instruction count — 266 → 251 ms
+// on the 15M-symbol chain); lane l of a ring slot holds the state before step l·kPark and the emitter re-runs the steps in between
+// with the same exact arithmetic.  The heavier emitter costs more than it saves once pairs share SIMDs (every walker then has another
+// pair's emitter on its SIMD: 1024-mesh batch 16.1 → 19.3 ms), so a launch is sparse only when its streams fit one per CU.
+constexpr uint32_t kPark = DMI_WALKER_PARK;
+constexpr uint32_t kParkLanes = 64u / kPark;
 
 // The walker.  Runs of consecutive full batches without a flagged symbol execute in one hand-scheduled assembly loop
 // (scripts/gen_walker_asm.py → dmi_walker_asm.inc: records double-buffered in two fixed 40-SGPR sets, the next chunk
 // requested right after each wait, ≈ 20 instructions of hand-off per 64 steps); a flagged batch (frequency-1 symbol; for
 // ONE_BYTE streams also a rare symbol) and the tail batch take the generic divide loop here.
 // K = the pair's slot counter (see ChainShared); returns the final state.
-template <uint32_t BIAS, bool ONE_BYTE>
+template <uint32_t BIAS, bool ONE_BYTE, uint32_t PARK>
 __device__ uint32_t chain_walker(const ChainDesc& d, uint32_t lane, lds_shared_t sh, uint32_t& K, uint32_t& consumed_seen) {
   constexpr uint32_t bias = BIAS;                 // 29 (rANS, threshold f·2^10) or 27 (rABS, f·2^12)
   const uint32_t P = d.precision;
@@ -446,12 +443,12 @@ __device__ uint32_t chain_walker(const ChainDesc& d, uint32_t lane, lds_shared_t
     if (k < full && !(flag & flag_mask)) {
       uint32_t left = full - k, vtmp, parked;
       const uint64_t rec_at = (uint64_t)(uintptr_t)(rec + (uint64_t)k * 64u), flag_at = (uint64_t)(uintptr_t)(d.batch_flags + k);
-      if (ONE_BYTE)
-        asm volatile(DMI_WALKER_ASM_ONE_BYTE : "+s"(x), "+s"(K), "+s"(left), "+s"(consumed_seen), "=&v"(vtmp), "=&v"(parked)
-                     : "s"(rec_at), "s"(flag_at), "v"(ring_lane), "v"(produced_at), "v"(consumed_at) : DMI_WALKER_ASM_CLOBBERS);
-      else
-        asm volatile(DMI_WALKER_ASM_GENERAL_RANS : "+s"(x), "+s"(K), "+s"(left), "+s"(consumed_seen), "=&v"(vtmp), "=&v"(parked)
-                     : "s"(rec_at), "s"(flag_at), "v"(ring_lane), "v"(produced_at), "v"(consumed_at) : DMI_WALKER_ASM_CLOBBERS);
+#define DMI_WALKER_RUN(BODY)                                                                                                \
+  asm volatile(BODY : "+s"(x), "+s"(K), "+s"(left), "+s"(consumed_seen), "=&v"(vtmp), "=&v"(parked)                          \
+               : "s"(rec_at), "s"(flag_at), "v"(ring_lane), "v"(produced_at), "v"(consumed_at) : DMI_WALKER_ASM_CLOBBERS)
+      if (ONE_BYTE) { if (PARK == 1) DMI_WALKER_RUN(DMI_WALKER_ASM_ONE_BYTE_P1); else DMI_WALKER_RUN(DMI_WALKER_ASM_ONE_BYTE_P4); }
+      else { if (PARK == 1) DMI_WALKER_RUN(DMI_WALKER_ASM_GENERAL_RANS_P1); else DMI_WALKER_RUN(DMI_WALKER_ASM_GENERAL_RANS_P4); }
+#undef DMI_WALKER_RUN
       k = full - left;
       continue;
     }
@@ -466,7 +463,7 @@ __device__ uint32_t chain_walker(const ChainDesc& d, uint32_t lane, lds_shared_t
       const uint32_t f = (1u << P) - dj;
       const uint32_t q0 = x / f;
       const uint32_t shf = (bias - (uint32_t)__builtin_clz(q0)) & 0x18u;
-      if (lane == j) parked = x;
+      if ((j % PARK) == 0u && lane == j / PARK) parked = x;   // parking mode of the launch, like the assembly loop
       x = (x >> shf) + (q0 >> shf) * dj + cj;
     }
     while (K - consumed_seen >= kRing) {          // ring full (rare: the emitter is ≈6× faster than the walker)
@@ -481,9 +478,9 @@ __device__ uint32_t chain_walker(const ChainDesc& d, uint32_t lane, lds_shared_t
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
 }
 
-// The emitter of a pair; returns the pair's next stream (from the stream's closing slot).
+// The emitter of a pair, dense parking (one parked state per step); returns the pair's next stream (from the stream's closing slot).
 template <uint32_t BIAS>
-__device__ uint32_t chain_emitter(const ChainDesc& d, uint32_t lane, lds_shared_t sh, uint32_t& K) {
+__device__ uint32_t chain_emitter_dense(const ChainDesc& d, uint32_t lane, lds_shared_t sh, uint32_t& K) {
   constexpr uint32_t thr_shift = 39u - BIAS;      // 10 / 12
   const uint32_t P = d.precision;
   const uint64_t n = d.n;
@@ -535,6 +532,93 @@ __device__ uint32_t chain_emitter(const ChainDesc& d, uint32_t lane, lds_shared_
   return next;
 }
 
+// The emitter of a pair, sparse parking; returns the pair's next stream (from the stream's closing slot).
+// Lane l < kParkLanes owns steps l·kPark … l·kPark + kPark - 1 of a batch: from the parked state it replays them (renormalisation
+// byte count from the thresholds f·2^T, f·2^(T+8), f·2^(T+16); exact quotient by multiply-high, or the state itself for a
+// frequency-1 record; x' = xs + q·d + c — the walker's arithmetic), keeping every step's bytes; a prefix sum over the lanes
+// gives each lane its output offset.  The records of the NEXT batch are requested before this one is processed.
+struct EmitRec { uint32_t m, b, d, c; };
+template <uint32_t BIAS>
+__device__ uint32_t chain_emitter_sparse(const ChainDesc& d, uint32_t lane, lds_shared_t sh, uint32_t& K) {
+  constexpr uint32_t thr_shift = 39u - BIAS;      // 10 / 12
+  const uint32_t P = d.precision;
+  const uint64_t n = d.n;
+  const grec_t grec = (grec_t)(uintptr_t)d.table;
+  typedef uint8_t __attribute__((address_space(1))) * gbyte_t;
+  uint64_t pos = 0;
+  uint32_t err = 0, touched = 0;
+  const bool owner = lane < kParkLanes;
+  EmitRec cur[kPark], nxt[kPark];
+#pragma unroll
+  for (uint32_t k = 0; k < kPark; ++k) {
+    const grec_t r = grec + ((owner ? lane : 0u) * kPark + k);   // (the record buffer is padded: reads past n are harmless)
+    nxt[k] = EmitRec{r->m, r->b, r->d, r->c};
+  }
+  uint32_t far = 0;
+#pragma unroll
+  for (uint32_t a = 1; a < kAhead; ++a) touched ^= grec[(uint64_t)a * 64u + lane].m;
+  for (uint64_t base = 0; base < n; base += 64, ++K) {
+    const uint32_t cnt = (uint32_t)min((uint64_t)64, n - base);
+    touched ^= far;
+#pragma unroll
+    for (uint32_t k = 0; k < kPark; ++k) cur[k] = nxt[k];   // requested one batch ago
+#pragma unroll
+    for (uint32_t k = 0; k < kPark; ++k) {
+      const grec_t r = grec + (base + 64u + (owner ? lane : 0u) * kPark + k);
+      nxt[k] = EmitRec{r->m, r->b, r->d, r->c};
+    }
+    far = grec[base + (uint64_t)kAhead * 64u + lane].m;   // one dword per record = every line of that batch
+    while ((int32_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)sh->produced) - K) <= 0) __builtin_amdgcn_s_sleep(2);
+    uint32_t x = sh->ring[K & (kRing - 1u)][lane];
+    sh->consumed = K + 1u;                         // (LDS is in order: the slot read above is performed first)
+    // replay: bytes[k] = the (≤ 3) low bytes step k sheds, counts = their numbers, 2 bits each
+    uint32_t bytes[kPark], counts = 0, mine = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kPark; ++k) {
+      const bool live = owner && lane * kPark + k < cnt;
+      const uint32_t f = (1u << P) - cur[k].d;
+      const uint32_t thr = f << thr_shift;   // (f ≤ 2^20 ⇒ < 2^32; x < 2^30; at most 3 bytes per step)
+      const uint32_t nb = live ? (uint32_t)(x >= thr) + (uint32_t)((x >> 8) >= thr) + (uint32_t)((x >> 16) >= thr) : 0u;
+      bytes[k] = x;
+      counts |= nb << (2u * k);
+      mine += nb;
+      const uint32_t xs = x >> (8u * nb);
+      const uint32_t q = (cur[k].b & 0x100u) ? xs : (__umulhi(xs, cur[k].m) >> (cur[k].b & 31u));
+      x = xs + q * cur[k].d + cur[k].c;
+    }
+    uint32_t incl = mine;   // prefix over the owning lanes
+#pragma unroll
+    for (uint32_t dlt = 1; dlt < kParkLanes; dlt <<= 1) { const uint32_t t = __shfl_up(incl, dlt, 64); if (lane >= dlt) incl += t; }
+    const uint32_t total = rl(incl, kParkLanes - 1u);
+    if (pos + total > d.cap) err = 2;
+    if (!err) {
+      gbyte_t at = (gbyte_t)(uintptr_t)d.out + pos + (incl - mine);
+#pragma unroll
+      for (uint32_t k = 0; k < kPark; ++k) {
+        const uint32_t nb = (counts >> (2u * k)) & 3u;
+        if (nb > 0) at[0] = (uint8_t)bytes[k];
+        if (nb > 1) at[1] = (uint8_t)(bytes[k] >> 8);
+        if (nb > 2) at[2] = (uint8_t)(bytes[k] >> 16);
+        at += nb;
+      }
+      pos += total;
+    }
+  }
+  // the stream's closing slot
+  while ((int32_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)sh->produced) - K) <= 0) __builtin_amdgcn_s_sleep(2);
+  const uint32_t closing = sh->ring[K & (kRing - 1u)][lane];
+  sh->consumed = K + 1u;
+  ++K;
+  const uint32_t x = rl(closing, 0), next = rl(closing, 1);
+  if (lane == 0) {
+    if (!err) pos += flush_state(x - d.state0, d.out, pos, d.cap, err);
+    if ((touched ^ far ^ nxt[0].m) == 0x9E3779B9u && pos == ~0ull) err = 3;   // keeps the look-ahead loads alive; never true
+    d.out_len[0] = (uint32_t)pos;
+    d.out_len[1] = err;
+  }
+  return next;
+}
+
 // Every rANS / rABS stream of a launch.  A workgroup is FOUR walker/emitter pairs: a wavefront issues one instruction per
 // ≈ 4 clocks and the scalar unit of a SIMD serves one wavefront per clock turn, so two walkers on one SIMD run at half
 // speed each — the walkers are wavefronts 0..3 of the workgroup, which the dispatcher places on the four SIMDs of one CU
@@ -545,6 +629,7 @@ __device__ uint32_t chain_emitter(const ChainDesc& d, uint32_t lane, lds_shared_
 // is pulled through the counter `next_stream` (zeroed by the launcher) when a pair finishes a stream — the launch lasts max(longest stream, total steps / walkers)
 // instead of being at the mercy of the dispatcher's placement (1024-mesh batch: 13.5 → … ms).
 constexpr uint32_t kChainPairs = 4;
+template <uint32_t PARK>
 __global__ __launch_bounds__(512) void k_chains(const ChainDesc* __restrict__ descs, const uint32_t* __restrict__ order, uint32_t n_streams,
                                                 uint32_t* __restrict__ next_stream) {
   __shared__ ChainShared shared[kChainPairs];
@@ -564,8 +649,8 @@ __global__ __launch_bounds__(512) void k_chains(const ChainDesc* __restrict__ de
       const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)(order ? order[sid] : sid));
       const ChainDesc d = descs[at];
       uint32_t x;
-      if (d.kind == 0) x = d.one_byte ? chain_walker<29u, true>(d, lane, sh, K, consumed_seen) : chain_walker<29u, false>(d, lane, sh, K, consumed_seen);
-      else x = chain_walker<27u, true>(d, lane, sh, K, consumed_seen);   // rABS renormalises with a single `if` (rans.rs:97): never more than one byte
+      if (d.kind == 0) x = d.one_byte ? chain_walker<29u, true, PARK>(d, lane, sh, K, consumed_seen) : chain_walker<29u, false, PARK>(d, lane, sh, K, consumed_seen);
+      else x = chain_walker<27u, true, PARK>(d, lane, sh, K, consumed_seen);   // rABS renormalises with a single `if` (rans.rs:97): never more than one byte
       uint32_t next = 0;
       if (lane == 0) next = atomicAdd(next_stream, 1u);
       next = (uint32_t)__builtin_amdgcn_readfirstlane((int)next) + kChainPairs * gridDim.x;
@@ -585,7 +670,8 @@ __global__ __launch_bounds__(512) void k_chains(const ChainDesc* __restrict__ de
       const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)(order ? order[sid] : sid));
       const ChainDesc d = descs[at];
       const uint64_t t0 = wall_clock64();   // 100 MHz constant-rate counter
-      sid = d.kind == 0 ? chain_emitter<29u>(d, lane, sh, K) : chain_emitter<27u>(d, lane, sh, K);
+      if (PARK == 1) sid = d.kind == 0 ? chain_emitter_dense<29u>(d, lane, sh, K) : chain_emitter_dense<27u>(d, lane, sh, K);
+      else sid = d.kind == 0 ? chain_emitter_sparse<29u>(d, lane, sh, K) : chain_emitter_sparse<27u>(d, lane, sh, K);
       if (lane == 0 && d.ticks) d.ticks[0] = (uint32_t)(wall_clock64() - t0);
     }
   }
@@ -740,7 +826,9 @@ uint32_t chain_grid(uint32_t n_streams) {
 void launch_chains(const ChainDesc* descs_dev, const uint32_t* order_dev, uint32_t n_streams, uint32_t* next_stream_dev, hipStream_t s) {
   if (!n_streams) return;
   (void)hipMemsetAsync(next_stream_dev, 0, sizeof(uint32_t), s);
-  hipLaunchKernelGGL(k_chains, chain_grid(n_streams), 512, 0, s, descs_dev, order_dev, n_streams, next_stream_dev);
+  // sparse parking when every stream has a CU (and so every walker and every emitter a SIMD) to itself
+  if (n_streams <= chain_grid(n_streams)) hipLaunchKernelGGL(k_chains<DMI_WALKER_PARK>, chain_grid(n_streams), 512, 0, s, descs_dev, order_dev, n_streams, next_stream_dev);
+  else hipLaunchKernelGGL(k_chains<1u>, chain_grid(n_streams), 512, 0, s, descs_dev, order_dev, n_streams, next_stream_dev);
 }
 
 }  // namespace dmi
