@@ -473,6 +473,13 @@ class Job:
         _check(self._L.dmi_job_encode(self._h, C.byref(out)))
         return _take(out)
 
+    def encode_raw(self):
+        """encode() at the cost of the C-ABI call alone: the attribute section stays in the library-owned buffer (an EncodedBatch of
+        one item: `len(batch[0])`-free access through `.nbytes`, `batch[0]` copies, `.free()` / context manager releases)."""
+        outs = (_Buffer * 1)()
+        _check(self._L.dmi_job_encode(self._h, outs))
+        return EncodedBatch(outs, 1)
+
     def timings(self):
         t = _Timings()
         _check(self._L.dmi_job_timings(self._h, C.byref(t)))
