@@ -8,10 +8,9 @@
 //       k_bits_prep      rABS bits, forward (normal flips, mesh_normal_prediction.rs:154-157)
 //       k_orient_prep    orientation flags → compacted transition bits, forward
 //                        (mesh_prediction_for_texture_coordinates.rs:241-256)
-//   * k_chains: per 64 records the wave walks 64 steps on SGPRs (records arrive through s_load_dwordx16,
-//     one chunk of 8 ahead) — per step: exact x/f by multiply-high, renormalisation shift from the
-//     quotient's bit length, state update — parking each pre-renormalisation state in its lane; then all
-//     64 lanes emit their renormalisation bytes at wavefront prefix-sum offsets.
+//   * k_chains: per 64 records a walker wavefront walks 64 steps on SGPRs (records arrive through s_load_dwordx16,
+//     one chunk of 8 ahead) — per step: exact x/f by multiply-high, renormalisation shift, state update — parking
+//     pre-renormalisation states in lanes; its emitter wavefront turns them into bytes at prefix-sum offsets.
 //
 // rABS is the same recurrence with precision 8 and L = 4096 instead of 4·2^P (rans.rs:78-108): the
 // renormalisation threshold is f·2^12 instead of f·2^10, nothing else changes, so both run the same loop.
@@ -387,10 +386,10 @@ __device__ void k_tables_body(const TableAtt& a, const uint32_t, const uint32_t)
 //   one-byte step, for batches in which no symbol can renormalise by more than one byte (9 scalar + 1 writelane):
 //     sh = (x ≥ t) ? 8 : 0 ; park x ; x >>= sh ; x = x + (mulhi(x, m) >> b)·d + c        (divide AFTER renormalising)
 // The steady state is generated assembly (scripts/gen_walker_asm.py → dmi_walker_asm.inc); see chain_walker below.
-// A stream is owned by a workgroup of TWO wavefronts that talk through LDS:
-//   wave 0 (walker)  runs the recurrence on its scalar unit and parks the 64 pre-renormalisation states of a
-//                    batch in a VGPR (lane j = step j), then drops them into a ring slot and bumps `produced`;
-//   wave 1 (emitter) picks the slot up, derives every step's byte count from (state, frequency), takes wavefront
+// A stream is owned by a PAIR of wavefronts that talk through LDS (four pairs per workgroup, see k_chains):
+//   the walker   runs the recurrence on its scalar unit and parks pre-renormalisation states of a batch in a VGPR (every
+//                state, lane j = step j; or every 4th in a sparse launch), then drops them into a ring slot and bumps `produced`;
+//   the emitter  picks the slot up, derives every step's byte count from (state, frequency), takes wavefront
 //                    prefix sums with ballots + mbcnt and stores the bytes; it also touches the records a few
 //                    batches AHEAD of the walker so that the walker's scalar loads hit L2.
 // LDS operations of one wavefront execute in order, so "slot, then counter" needs no fence; the walker only looks at
