@@ -451,6 +451,19 @@ __device__ uint32_t chain_walker(const ChainDesc& d, uint32_t lane, lds_shared_t
       k = full - left;
       continue;
     }
+    if (ONE_BYTE && BIAS == 29u && k < full && (flag & 3u) == 2u) {
+      // a batch of a one-byte stream that holds a rare symbol (but no frequency-1 one): ONE batch through the general assembly step
+      // (≈ 2.9k clocks) instead of the divide loop below (≈ 7k)
+      uint32_t left = 1u, vtmp, parked;
+      const uint64_t rec_at = (uint64_t)(uintptr_t)(rec + (uint64_t)k * 64u), flag_at = (uint64_t)(uintptr_t)(d.batch_flags + k);
+#define DMI_WALKER_RUN(BODY)                                                                                                \
+  asm volatile(BODY : "+s"(x), "+s"(K), "+s"(left), "+s"(consumed_seen), "=&v"(vtmp), "=&v"(parked)                          \
+               : "s"(rec_at), "s"(flag_at), "v"(ring_lane), "v"(produced_at), "v"(consumed_at) : DMI_WALKER_ASM_CLOBBERS)
+      if (PARK == 1) DMI_WALKER_RUN(DMI_WALKER_ASM_GENERAL_RANS_P1); else DMI_WALKER_RUN(DMI_WALKER_ASM_GENERAL_RANS_P4);
+#undef DMI_WALKER_RUN
+      k += 1u - left;
+      continue;
+    }
     // generic batch: hardware divide per step, records through the vector path
     const uint64_t base = (uint64_t)k << 6;
     const uint32_t cnt = (uint32_t)min((uint64_t)64, n - base);
