@@ -425,7 +425,6 @@ constexpr uint32_t kParkLanes = 64u / kPark;
 template <uint32_t BIAS, bool ONE_BYTE, uint32_t PARK>
 __device__ uint32_t chain_walker(const ChainDesc& d, uint32_t lane, lds_shared_t sh, uint32_t& K, uint32_t& consumed_seen) {
   constexpr uint32_t bias = BIAS;                 // 29 (rANS, threshold f·2^10) or 27 (rABS, f·2^12)
-  const uint32_t P = d.precision;
   const uint64_t n = d.n;
   const RansEntry* __restrict__ rec = d.table;
   uint32_t x = d.state0;
@@ -464,16 +463,16 @@ __device__ uint32_t chain_walker(const ChainDesc& d, uint32_t lane, lds_shared_t
       k += 1u - left;
       continue;
     }
-    // generic batch: hardware divide per step, records through the vector path
+    // generic batch (a frequency-1 symbol, or the partial last batch): one record per lane through the vector path, broadcast step
+    // by step; the quotient by multiply-high like the assembly step, or the state itself for a frequency-1 record
     const uint64_t base = (uint64_t)k << 6;
     const uint32_t cnt = (uint32_t)min((uint64_t)64, n - base);
     uint32_t parked = 0;
     x = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
-    const uint32_t md = grec[base + lane].d, mc = grec[base + lane].c;
+    const uint32_t mm = grec[base + lane].m, mb = grec[base + lane].b, md = grec[base + lane].d, mc = grec[base + lane].c;
     for (uint32_t j = 0; j < cnt; ++j) {
-      const uint32_t dj = rl(md, j), cj = rl(mc, j);
-      const uint32_t f = (1u << P) - dj;
-      const uint32_t q0 = x / f;
+      const uint32_t mj = rl(mm, j), bj = rl(mb, j), dj = rl(md, j), cj = rl(mc, j);
+      const uint32_t q0 = (bj & 0x100u) ? x : (__umulhi(x, mj) >> (bj & 31u));
       const uint32_t shf = (bias - (uint32_t)__builtin_clz(q0)) & 0x18u;
       if ((j % PARK) == 0u && lane == j / PARK) parked = x;   // parking mode of the launch, like the assembly loop
       x = (x >> shf) + (q0 >> shf) * dj + cj;
