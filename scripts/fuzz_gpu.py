@@ -1,0 +1,51 @@
+"""One-off GPU fuzz (needs an MI355X): random triangle soups with normals and UVs, heavy-tailed grids and tiny meshes at random
+quantization widths, each encoded through the whole-mesh call, the device-table batch call and the host-table form, compared with the
+oracle (test infrastructure).  usage: fuzz_gpu.py [cases] [first_seed]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import draco_oxide_amd as dmi
+import orc
+from helpers import oracle_from_product_mesh
+import test_gpu_parity as T
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+rng = np.random.default_rng(seed0)
+bad = rejected = 0
+for c in range(n_cases):
+    seed = seed0 + c
+    kind = c % 3
+    if kind == 0:
+        mesh, sess = T._soup_mesh(seed, uv_per_corner=bool(c & 1))
+    elif kind == 1:
+        mesh = T._heavy_tailed_mesh(int(rng.integers(3, 60)), seed)
+        sess = oracle_from_product_mesh(mesh)
+    else:
+        mesh = dmi.synth.torus_mesh(int(rng.integers(3, 40)), seed=seed, open_boundary=bool(c & 2), normals=bool(c & 4), uvs=bool(c & 8) or not (c & 4))
+        sess = oracle_from_product_mesh(mesh)
+    pb, ub = int(rng.integers(1, 21)), int(rng.integers(1, 17))
+    cfg = dmi.Config(pos_bits=pb, uv_bits=ub)
+    try:
+        want = sess.encode(pos_bits=pb, uv_bits=ub)
+    except orc.OracleError:
+        rejected += 1
+        try:
+            dmi.encode_mesh(mesh, cfg)
+            print(f"case {c} (seed {seed}, {pb}/{ub} bits): the oracle rejects, the library does not"); bad += 1
+        except dmi.DracoMiError:
+            pass
+        continue
+    got = {"whole": dmi.encode_mesh(mesh, cfg)}
+    jobs = dmi.meshes_prepare([mesh, mesh], cfg)
+    outs = dmi.jobs_encode(jobs)
+    got["batch"] = jobs[1].header_and_connectivity + outs[1]
+    os.environ["DMI_HOST_TABLES"] = "1"
+    got["host tables"] = dmi.encode_mesh(mesh, cfg)
+    del os.environ["DMI_HOST_TABLES"]
+    for name, g in got.items():
+        if g != want:
+            print(f"case {c} (seed {seed}, kind {kind}, {pb}/{ub} bits, {len(mesh.faces)} faces): {name} differs ({len(g)} vs {len(want)} bytes)"); bad += 1
+print(f"{n_cases} cases, {rejected} rejected by the reference algorithm, {bad} mismatches")
+sys.exit(1 if bad else 0)
