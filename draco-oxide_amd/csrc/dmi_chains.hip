@@ -640,7 +640,9 @@ __device__ uint32_t chain_emitter_sparse(const ChainDesc& d, uint32_t lane, lds_
 // is pulled through the counter `next_stream` (zeroed by the launcher) when a pair finishes a stream — the launch lasts max(longest stream, total steps / walkers)
 // instead of being at the mercy of the dispatcher's placement (1024-mesh batch: 13.5 → … ms).
 constexpr uint32_t kChainPairs = 4;
-template <uint32_t PARK>
+// PAIRS = pairs of a workgroup that take streams: 4 (every SIMD hosts a walker and another pair's emitter), or 2 — pairs 0 and 2, whose
+// walkers sit on the first and third SIMD and whose emitters on the second and fourth, so that no wavefront shares a SIMD (sparse launches).
+template <uint32_t PARK, uint32_t PAIRS>
 __global__ __launch_bounds__(512) void k_chains(const ChainDesc* __restrict__ descs, const uint32_t* __restrict__ order, uint32_t n_streams,
                                                 uint32_t* __restrict__ next_stream) {
   __shared__ ChainShared shared[kChainPairs];
@@ -651,7 +653,8 @@ __global__ __launch_bounds__(512) void k_chains(const ChainDesc* __restrict__ de
   const bool walker = wave < kChainPairs;
   const uint32_t pair = walker ? wave : ((wave - kChainPairs) + kChainPairs - 1u) % kChainPairs;   // emitter of pair p = wavefront 4 + (p + 1) % 4
   const lds_shared_t sh = (lds_shared_t)&shared[pair];
-  const uint32_t first = pair * gridDim.x + blockIdx.x;
+  if (PAIRS == 2u && (pair & 1u)) return;
+  const uint32_t first = (PAIRS == 2u ? pair / 2u : pair) * gridDim.x + blockIdx.x;
   if (first >= n_streams) return;
   // (two loops with their own variables: the walker's live in SGPRs for the assembly, the emitter's do not)
   if (walker) {
@@ -664,7 +667,7 @@ __global__ __launch_bounds__(512) void k_chains(const ChainDesc* __restrict__ de
       else x = chain_walker<27u, true, PARK>(d, lane, sh, K, consumed_seen);   // rABS renormalises with a single `if` (rans.rs:97): never more than one byte
       uint32_t next = 0;
       if (lane == 0) next = atomicAdd(next_stream, 1u);
-      next = (uint32_t)__builtin_amdgcn_readfirstlane((int)next) + kChainPairs * gridDim.x;
+      next = (uint32_t)__builtin_amdgcn_readfirstlane((int)next) + PAIRS * gridDim.x;
       if (next >= n_streams) next = kNoStream;
       while (K - consumed_seen >= kRing) {
         consumed_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->consumed);
@@ -834,12 +837,21 @@ uint32_t chain_grid(uint32_t n_streams) {
   static const uint32_t cap = [] { const char* e = std::getenv("DMI_CHAIN_GRID"); const int v = e ? std::atoi(e) : 0; return v > 0 ? (uint32_t)v : 256u; }();
   return n_streams < cap ? n_streams : cap;
 }
-void launch_chains(const ChainDesc* descs_dev, const uint32_t* order_dev, uint32_t n_streams, uint32_t* next_stream_dev, hipStream_t s) {
+// Which form a launch takes.  Dense: 4 pairs per CU, ≈ 20 ns per step (a walker shares its SIMD with an emitter).  Sparse: 2 pairs per CU,
+// ≈ 16.2 ns per step.  A launch lasts about max(longest stream, all steps / walkers) steps — the sparse form wins while the longest
+// stream dominates (single meshes, batches of a few hundred), the dense one when the sum does.
+bool chain_launch_sparse(uint64_t longest_steps, uint64_t total_steps, uint32_t n_streams) {
+  if (std::getenv("DMI_CHAIN_DENSE")) return false;
+  const uint32_t g = chain_grid(n_streams);
+  const double dense = 20.0 * (double)std::max<uint64_t>(longest_steps, total_steps / (4ull * g));
+  const double sparse = 16.2 * (double)std::max<uint64_t>(longest_steps, total_steps / (2ull * g));
+  return sparse <= dense;
+}
+void launch_chains(const ChainDesc* descs_dev, const uint32_t* order_dev, uint32_t n_streams, uint32_t* next_stream_dev, bool sparse, hipStream_t s) {
   if (!n_streams) return;
   (void)hipMemsetAsync(next_stream_dev, 0, sizeof(uint32_t), s);
-  // sparse parking when every stream has a CU (and so every walker and every emitter a SIMD) to itself
-  if (n_streams <= chain_grid(n_streams)) hipLaunchKernelGGL(k_chains<DMI_WALKER_PARK>, chain_grid(n_streams), 512, 0, s, descs_dev, order_dev, n_streams, next_stream_dev);
-  else hipLaunchKernelGGL(k_chains<1u>, chain_grid(n_streams), 512, 0, s, descs_dev, order_dev, n_streams, next_stream_dev);
+  if (sparse) hipLaunchKernelGGL((k_chains<DMI_WALKER_PARK, 2u>), chain_grid(n_streams), 512, 0, s, descs_dev, order_dev, n_streams, next_stream_dev);
+  else hipLaunchKernelGGL((k_chains<1u, 4u>), chain_grid(n_streams), 512, 0, s, descs_dev, order_dev, n_streams, next_stream_dev);
 }
 
 }  // namespace dmi

@@ -139,7 +139,9 @@ struct ChainDesc {
 // Persistent chain kernel: `order_dev` (nullable) = stream indices longest first; `next_stream_dev` = one device word for the
 // pull counter (zeroed by the launcher on the stream).
 uint32_t chain_grid(uint32_t n_streams);
-void launch_chains(const ChainDesc* descs_dev, const uint32_t* order_dev, uint32_t n_streams, uint32_t* next_stream_dev, hipStream_t s);
+// sparse = sparse parking on two pairs per CU (see k_chains); chain_launch_sparse picks the form from the streams' step counts
+bool chain_launch_sparse(uint64_t longest_steps, uint64_t total_steps, uint32_t n_streams);
+void launch_chains(const ChainDesc* descs_dev, const uint32_t* order_dev, uint32_t n_streams, uint32_t* next_stream_dev, bool sparse, hipStream_t s);
 // argument blocks of the record-prep kernels (K_RANS_PREP … K_BATCH_FLAGS); launch_step / launch_steps_multi dispatch to these
 // `bins`: symbols ≥ bins (only possible after a histogram overflow, which is reported as an error) take an all-zero record.
 // `entries` (nullable): {record of bit 0, record of bit 1} in device memory (written by k_tables) instead of e0 / e1;

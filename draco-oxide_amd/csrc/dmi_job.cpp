@@ -1132,7 +1132,12 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
   }
   const std::vector<ChainDesc>& descs = job->run.descs;
   if (timed) HIP_TRY(hipEventRecord(job->ev[4], s));
-  launch_chains(job->descs.as<ChainDesc>(), nullptr, (uint32_t)descs.size(), reinterpret_cast<uint32_t*>(job->descs.as<ChainDesc>() + job->atts.size() * 2), s);
+  {
+    uint64_t longest = 0, total = 0;
+    for (const ChainDesc& cd : descs) { longest = std::max<uint64_t>(longest, cd.n); total += cd.n; }
+    launch_chains(job->descs.as<ChainDesc>(), nullptr, (uint32_t)descs.size(), reinterpret_cast<uint32_t*>(job->descs.as<ChainDesc>() + job->atts.size() * 2),
+                  chain_launch_sparse(longest, total, (uint32_t)descs.size()), s);
+  }
   if (timed) HIP_TRY(hipEventRecord(job->ev[5], s));
   if ((rc = encode_phase_c1(job))) return rc;
   HIP_TRY(hipStreamSynchronize(s));
@@ -1400,6 +1405,7 @@ struct DeviceBatch {
   std::vector<uint32_t> first_desc, first_att;
   uint32_t n_streams = 0, n_atts = 0, n_descs = 0;
   size_t launches = 0;
+  bool sparse_chains = false;
   double t_plan = 0, t_wait = 0, t_bytes = 0, t_splice = 0;
   ~DeviceBatch() { if (arena) release_batch_arena(arena); }
 
@@ -1455,7 +1461,12 @@ struct DeviceBatch {
     HIP_TRY(hipMemcpyAsync(arena->plan_dev, arena->plan_host, plan.bytes, hipMemcpyHostToDevice, s));
     const uint8_t* pd = static_cast<const uint8_t*>(arena->plan_dev);
     plan.launch(pd, s);
-    launch_chains(descs_dev, reinterpret_cast<const uint32_t*>(pd + off_order), n_streams, reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(arena->descs_dev) + counter_at), s);
+    {
+      uint64_t longest = 0, total = 0;
+      for (uint64_t v : length) { longest = std::max(longest, v); total += v; }
+      sparse_chains = chain_launch_sparse(longest, total, n_streams);
+      launch_chains(descs_dev, reinterpret_cast<const uint32_t*>(pd + off_order), n_streams, reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(arena->descs_dev) + counter_at), sparse_chains, s);
+    }
     launch_pack_streams(descs_dev, n_descs, static_cast<PackEntry*>(arena->table_dev), static_cast<uint8_t*>(arena->bytes_dev), s);
     launch_copy_items(reinterpret_cast<const CopyItem*>(pd + off_copies), n_atts, static_cast<uint8_t*>(arena->slabs_dev), s);
     HIP_TRY(hipMemcpyAsync(arena->table_host, arena->table_dev, (size_t)(n_descs + 1) * sizeof(PackEntry), hipMemcpyDeviceToHost, s));
@@ -1515,8 +1526,8 @@ struct DeviceBatch {
         sum_ms += r + x; max_ms = std::max({max_ms, r, x}); steps += ns + nx;
         if (ns > 50000) { big_steps += ns; big_ms += r; }
       }
-    std::fprintf(stderr, "[dmi] %s: %zu jobs, %u streams, %zu launches; plan + issue %.2f ms, wait for the stream %.2f, byte read-back %.2f, splice %.2f; chains: %.0f steps, stream times sum %.1f ms "
-                 "(/1024 walkers = %.2f), longest %.2f ms, %.1f ns/step (%.1f on rANS streams > 50k symbols)\n", name, jobs.size(), n_streams, launches, t_plan, t_wait, t_bytes, t_splice, steps, sum_ms,
+    std::fprintf(stderr, "[dmi] %s: %zu jobs, %u streams (%s chain launch), %zu launches; plan + issue %.2f ms, wait for the stream %.2f, byte read-back %.2f, splice %.2f; chains: %.0f steps, stream times sum %.1f ms "
+                 "(/1024 walkers = %.2f), longest %.2f ms, %.1f ns/step (%.1f on rANS streams > 50k symbols)\n", name, jobs.size(), n_streams, sparse_chains ? "sparse" : "dense", launches, t_plan, t_wait, t_bytes, t_splice, steps, sum_ms,
                  sum_ms / 1024.0, max_ms, sum_ms * 1e6 / std::max(1.0, steps), big_ms * 1e6 / std::max(1.0, big_steps));
   }
 };
@@ -1716,8 +1727,12 @@ static int jobs_encode_impl(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
   if ((rc = descs_dev.alloc(counter_at + 16))) return rc;
   HIP_TRY(hipMemcpyAsync(descs_dev.p, all.data(), order_at, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(descs_dev.p) + order_at, by_length.data(), all.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-  launch_chains(descs_dev.as<ChainDesc>(), reinterpret_cast<const uint32_t*>(static_cast<uint8_t*>(descs_dev.p) + order_at), (uint32_t)all.size(),
-                reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(descs_dev.p) + counter_at), s);
+  {
+    uint64_t longest = 0, total = 0;
+    for (const ChainDesc& cd : all) { longest = std::max<uint64_t>(longest, cd.n); total += cd.n; }
+    launch_chains(descs_dev.as<ChainDesc>(), reinterpret_cast<const uint32_t*>(static_cast<uint8_t*>(descs_dev.p) + order_at), (uint32_t)all.size(),
+                  reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(descs_dev.p) + counter_at), chain_launch_sparse(longest, total, (uint32_t)all.size()), s);
+  }
   HIP_TRY(hipStreamSynchronize(s));
   const auto t5 = now();
   // read-back: every stream of every job packed into one arena on the device → one table copy + one byte copy
