@@ -136,11 +136,11 @@ def main():
     prepare_s = time.time() - t0
 
     def step():
-        # the product boundary is the C ABI: the section lands in a library-owned host buffer; a Python `bytes` copy is made only
-        # where one is needed (the gather at N > 1)
+        # the product boundary is the C ABI: the section lands in a library-owned host buffer, which the gather at N > 1 reads in place
+        # (rank 0 receives every rank's section in one pinned host buffer)
         with job.encode_raw() as out:
             if world > 1:
-                dmi_dist.gather_bitstreams(out[0], device=gather_dev)
+                dmi_dist.gather_bitstreams(out.view(0), device=gather_dev, as_bytes=False)
             return out.nbytes
 
     for _ in range(args.warmup):

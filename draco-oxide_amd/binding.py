@@ -521,6 +521,12 @@ class EncodedBatch:
     def __getitem__(self, i):
         b = self._outs[i]
         return C.string_at(b.data, b.len) if b.len else b""
+    def view(self, i):
+        """Item i as a zero-copy uint8 numpy view of the library-owned buffer (valid until free())."""
+        b = self._outs[i]
+        if not b.len:
+            return np.zeros(0, np.uint8)
+        return np.ctypeslib.as_array((C.c_uint8 * b.len).from_address(b.data))
     def free(self):
         if self._n:
             load_library().dmi_free_many(self._outs, self._n)

@@ -22,26 +22,46 @@ def shard_indices(num_items, rank, world_size, weights=None):
     return [i for i in range(num_items) if owner[i] == rank]
 
 
-def gather_bitstreams(blob, device=None, group=None, dst=0):
-    """Gather one byte string per rank onto `dst`.  Returns the list of per-rank byte strings on `dst`
-    (None elsewhere).  Sizes are exchanged with an all_gather, payloads with one padded gather."""
+_recv_cache = {}   # (world, cap, device) → (device receive buffer, pinned host mirror): reused across calls
+
+
+def gather_bitstreams(blob, device=None, group=None, dst=0, as_bytes=True):
+    """Gather one byte string per rank onto `dst`.  `blob`: bytes, or a uint8 numpy array / memoryview (no copy is made on the way
+    to the device).  Returns the list of per-rank byte strings on `dst` (None elsewhere); with as_bytes=False the items are uint8
+    numpy views of one host buffer that is reused by the next call (no per-rank copies: a pipeline that streams the blobs onwards).
+    Sizes are exchanged with an all_gather, payloads with one padded gather into one contiguous buffer and one copy to the host."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = device if device is not None else torch.device("cpu")
-    n = torch.tensor([len(blob)], dtype=torch.int64, device=dev)
+    src = np.frombuffer(blob, dtype=np.uint8) if isinstance(blob, (bytes, bytearray, memoryview)) else np.ascontiguousarray(blob, dtype=np.uint8)
+    n = torch.tensor([len(src)], dtype=torch.int64, device=dev)
     sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(sizes, n, group=group)
     sizes = [int(s.item()) for s in sizes]
-    cap = max(max(sizes), 1)
+    cap = (max(max(sizes), 1) + 255) & ~255
     payload = torch.zeros(cap, dtype=torch.uint8, device=dev)
-    if len(blob):
-        payload[: len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
-    if rank == dst:
-        recv = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
-        dist.gather(payload, recv, dst=dst, group=group)
-        return [bytes(recv[r][: sizes[r]].cpu().numpy().tobytes()) for r in range(world)]
-    dist.gather(payload, None, dst=dst, group=group)
-    return None
+    if len(src):
+        with __import__("warnings").catch_warnings():
+            __import__("warnings").simplefilter("ignore")   # (read-only buffer: it is only read)
+            payload[: len(src)].copy_(torch.from_numpy(src), non_blocking=False)
+    if rank != dst:
+        dist.gather(payload, None, dst=dst, group=group)
+        return None
+    key = (world, cap, str(dev))
+    if key not in _recv_cache:
+        _recv_cache.clear()
+        recv = torch.empty((world, cap), dtype=torch.uint8, device=dev)
+        host = torch.empty((world, cap), dtype=torch.uint8, pin_memory=(dev.type == "cuda")) if dev.type == "cuda" else None
+        _recv_cache[key] = (recv, host)
+    recv, host = _recv_cache[key]
+    dist.gather(payload, [recv[r] for r in range(world)], dst=dst, group=group)
+    if host is not None:
+        host.copy_(recv, non_blocking=False)
+        arr = host.numpy()
+    else:
+        arr = recv.numpy()
+    views = [arr[r, : sizes[r]] for r in range(world)]
+    return [v.tobytes() for v in views] if as_bytes else views
 
 
 def concatenate_with_index(blobs):

@@ -61,3 +61,34 @@ def test_batch_sharded_over_two_ranks_matches_the_oracle():
     # world size 1 (no process group), in this process — after the children, so that nothing is spawned from a process that holds the GPU
     assert dmi.device_count() >= 1
     assert dd.encode_meshes_sharded(meshes) == want
+
+
+def _nccl_single(port, q):
+    import numpy as np
+    import torch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        from draco_oxide_amd import distributed as dd
+        blob = np.random.default_rng(5).integers(0, 256, size=100_003, dtype=np.uint8)
+        a = dd.gather_bitstreams(blob.tobytes(), device=dev)
+        b = dd.gather_bitstreams(blob, device=dev, as_bytes=False)
+        b_ok = bool((b[0] == blob).all())   # (views of the receive buffer: valid until the next gather)
+        c = dd.gather_blob_lists([blob.tobytes(), b"xyz"], [1, 0], 2, device=dev)
+        q.put((a[0] == blob.tobytes(), b_ok, c == [b"xyz", blob.tobytes()]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_on_the_rccl_path_single_rank():
+    """The device branch of the gather (RCCL group, device tensors, pinned host mirror) with a one-rank group — what a 1-GPU box can run."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_single, args=(_free_port(), q))
+    p.start()
+    got = q.get(timeout=300)
+    p.join(timeout=300)
+    assert p.exitcode == 0 and got == (True, True, True)
