@@ -1,6 +1,7 @@
 // dmi_job.cpp — C ABI of libdraco_mi.so (include/draco_mi.h) and the per-mesh job that drives the
-// gfx950 kernels: upload once → quantize → sequence-order gather → predict+transform → histogram →
-// (host) table normalisation → one-wave-per-stream rANS/rABS → byte splice.
+// gfx950 kernels: upload once → value ranges → sequence-order gather + quantize → predict+transform → histograms →
+// table stage (k_tables; host form behind DMI_HOST_TABLES) → record prep → walker/emitter rANS/rABS chains → byte splice;
+// the batch drivers (one upload, one launch per kernel for all jobs, one chain launch, one packed read-back).
 // There is NO CPU fallback: without a HIP device every encode entry point returns DMI_ERR_NO_DEVICE.
 #include <algorithm>
 #include <atomic>

@@ -1,4 +1,5 @@
-// host_entropy.cpp — frequency-table normalisation + serialisation on the host.
+// host_entropy.cpp — frequency-table normalisation + serialisation on the host (the host form of the table stage: DMI_HOST_TABLES=1
+// and ToBits attributes; the device form is k_tables in dmi_chains.hip — tests compare the two).
 // Reproduces RansSymbolEncoder::new (encode/entropy/rans.rs:146-239) and the DirectCoded prologue
 // of encode_symbols (encode/entropy/symbol_coding.rs:17-55,109-141) from a symbol histogram.
 #include <algorithm>
