@@ -1031,7 +1031,17 @@ static int encode_phase_c3(dmi_job* job, dmi_buffer* out) {   // host: splice th
     void u32(uint32_t v) { std::memcpy(p + n, &v, 4); n += 4; }   // little-endian host
     void f32(float f) { std::memcpy(p + n, &f, 4); n += 4; }
     void leb128(uint64_t v) { do { uint8_t x = v & 0x7F; v >>= 7; u8(v ? (x | 0x80) : x); } while (v); }
-    void bytes(const uint8_t* q, size_t k) { if (k) std::memcpy(p + n, q, k); n += k; }
+    void bytes(const uint8_t* q, size_t k) {
+      if (k >= ((size_t)32 << 20)) {   // a large stream (≈ 100M-triangle meshes): the copy — and the first touch of the output pages — on a few threads
+        const size_t parts = std::min<size_t>(8, k >> 22);
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < parts; ++t) th.emplace_back([=] { const size_t lo = k * t / parts, hi = k * (t + 1) / parts; std::memcpy(p + n + lo, q + lo, hi - lo); });
+        for (auto& x : th) x.join();
+      } else if (k) {
+        std::memcpy(p + n, q, k);
+      }
+      n += k;
+    }
     void bytes(const std::vector<uint8_t>& v) { bytes(v.data(), v.size()); }
   } w{static_cast<uint8_t*>(std::malloc(bound))};
   if (!w.p) return fail(DMI_ERR_OUT_OF_MEMORY, "malloc");

@@ -1049,9 +1049,9 @@ __device__ __forceinline__ void orient_summary_impl(const OrientArgs& oa, const 
 
 __device__ __forceinline__ void k_orient_summary_body(const OrientArgs& oa, const uint32_t blk_, const uint32_t) { orient_summary_impl<64>(oa, blk_); }
 
-// Symbol histograms of every attribute of a job in one launch (block → (attribute, slice)), LDS-privatised when the
-// alphabet fits (≤ 16K bins = 64 KiB of the CU's 160 KiB).  Few, fat blocks: each flushes its private copy once.
-constexpr uint32_t kLdsBins = 16384;
+// Symbol histograms of every attribute of a job in one launch (block → (attribute, slice)), the first 16K bins privatised in LDS
+// (64 KiB of the CU's 160 KiB).  Few, fat blocks: each flushes its private copy once.
+constexpr uint32_t kLdsBins = 12288;   // 48 KiB: with the static LDS of the launch (orientation staging) below the 64 KiB a workgroup may always take
 __device__ __forceinline__ void k_histogram_body(const HistArgs& args, const uint32_t blk_, const uint32_t nblk_) {
   extern __shared__ uint32_t lds[];
   // trailing blocks: the orientation-flag summaries of the job's fused sweep ride this launch (they depend on the same sweep as the
@@ -1061,17 +1061,19 @@ __device__ __forceinline__ void k_histogram_body(const HistArgs& args, const uin
   while (ai + 1 < args.count && blk_ >= args.a[ai + 1].first_block) ++ai;
   const HistAtt a = args.a[ai];
   const uint32_t block = blk_ - a.first_block;
-  const bool use_lds = a.bins <= kLdsBins;
-  if (use_lds) { for (uint32_t b = threadIdx.x; b < a.bins; b += kBlock) lds[b] = 0; __syncthreads(); }
+  // the first kLdsBins bins are privatised in LDS; larger alphabets (≥ 14-bit wrapped differences) send their high — rare: the
+  // residuals concentrate near zero — symbols straight to the global histogram.  (All-global atomics on a peaked distribution
+  // serialise on a few addresses: 320 ms instead of 0.7 for the 150M position symbols of a 100M-triangle mesh.)
+  const uint32_t lds_bins = min(a.bins, kLdsBins);
+  for (uint32_t b = threadIdx.x; b < lds_bins; b += kBlock) lds[b] = 0;
+  __syncthreads();
   for (uint64_t e = (uint64_t)block * kBlock + threadIdx.x; e < a.n; e += (uint64_t)a.blocks * kBlock) {
     const uint32_t s = a.sym[e];
     if (s >= a.bins) { atomicOr(a.overflow, 1u); continue; }
-    if (use_lds) atomicAdd(&lds[s], 1u); else atomicAdd(&a.hist[s], 1u);
+    if (s < lds_bins) atomicAdd(&lds[s], 1u); else atomicAdd(&a.hist[s], 1u);
   }
-  if (use_lds) {
-    __syncthreads();
-    for (uint32_t b = threadIdx.x; b < a.bins; b += kBlock) { const uint32_t v = lds[b]; if (v) atomicAdd(&a.hist[b], v); }
-  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < lds_bins; b += kBlock) { const uint32_t v = lds[b]; if (v) atomicAdd(&a.hist[b], v); }
 }
 
 inline uint32_t grid_for(uint64_t work, uint32_t cap = 256 * 8) {
@@ -1230,7 +1232,7 @@ void launch_histograms(HistArgs& args, hipStream_t s) {
     a.blocks = a.n ? grid_for(a.n, 512) : 0u;
     a.first_block = total;
     total += a.blocks;
-    if (a.blocks && a.bins <= kLdsBins) lds = std::max(lds, (size_t)a.bins * 4);
+    if (a.blocks) lds = std::max(lds, (size_t)std::min(a.bins, kLdsBins) * 4);
   }
   args.hist_blocks = total;
   const uint32_t orient_blocks = args.orient.orient ? orient_summary_blocks(args.orient.n) : 0u;
