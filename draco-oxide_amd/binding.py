@@ -51,7 +51,8 @@ class _Buffer(C.Structure):
 
 class _Timings(C.Structure):
     _fields_ = [("quantize_ms", C.c_float), ("predict_ms", C.c_float), ("histogram_ms", C.c_float), ("table_ms", C.c_float),
-                ("rans_ms", C.c_float), ("total_ms", C.c_float), ("predict_bytes", C.c_uint64), ("symbols", C.c_uint64), ("num_streams", C.c_uint32)]
+                ("rans_ms", C.c_float), ("total_ms", C.c_float), ("predict_bytes", C.c_uint64), ("symbols", C.c_uint64), ("num_streams", C.c_uint32),
+                ("host_chains", C.c_uint32), ("longest_stream_ms", C.c_float), ("readback_wait_ms", C.c_float)]
 
 
 class _Mesh(C.Structure):
@@ -76,7 +77,7 @@ class _Conn(C.Structure):
 
 
 EXPORTS = ["dmi_encode_attributes", "dmi_encode_attributes_batch", "dmi_jobs_encode", "dmi_job_create", "dmi_job_encode", "dmi_job_timings", "dmi_job_destroy", "dmi_encode_mesh",
-           "dmi_mesh_prepare", "dmi_meshes_prepare", "dmi_mesh_build", "dmi_built_mesh_free", "dmi_encode_connectivity", "dmi_conn_free", "dmi_free", "dmi_free_many", "dmi_strerror", "dmi_last_error", "dmi_device_count"]
+           "dmi_mesh_prepare", "dmi_meshes_prepare", "dmi_mesh_build", "dmi_built_mesh_free", "dmi_encode_connectivity", "dmi_conn_free", "dmi_host_rans_stream", "dmi_host_rabs_stream", "dmi_free", "dmi_free_many", "dmi_strerror", "dmi_last_error", "dmi_device_count"]
 
 
 def library_path():
@@ -118,6 +119,8 @@ def load_library():
     L.dmi_meshes_prepare.argtypes = [C.POINTER(_Mesh), C.c_uint32, C.POINTER(_Config), C.POINTER(_Buffer), C.POINTER(C.c_void_p)]
     L.dmi_encode_connectivity.argtypes = [C.POINTER(_Mesh), C.POINTER(_Buffer), C.POINTER(_Conn)]
     L.dmi_conn_free.argtypes = [C.POINTER(_Conn)]
+    L.dmi_host_rans_stream.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(_Buffer)]
+    L.dmi_host_rabs_stream.argtypes = [C.c_uint8, C.c_void_p, C.c_uint64, C.POINTER(_Buffer)]
     _lib = L
     return L
 
@@ -578,3 +581,23 @@ def meshes_prepare(meshes, cfg=None):
 
 def encode_connectivity(mesh):
     return Connectivity(mesh)
+
+
+def host_rans_stream(freq, precision, symbols):
+    """The hybrid form's host-core rANS coder on its own (no device): `symbols` coded last to first with the normalised
+    frequencies `freq` (sum 2^precision); returns the stream bytes incl. the tagged final state."""
+    L = load_library()
+    f = np.ascontiguousarray(freq, dtype=np.uint32)
+    s = np.ascontiguousarray(symbols, dtype=np.uint32)
+    out = _Buffer()
+    _check(L.dmi_host_rans_stream(f.ctypes.data, len(f), precision, s.ctypes.data, len(s), C.byref(out)))
+    return _take(out)
+
+
+def host_rabs_stream(zero_prob, bits):
+    """The hybrid form's host-core rABS coder on its own: `bits` coded first to last with P(0) = zero_prob / 256."""
+    L = load_library()
+    b = np.ascontiguousarray(bits, dtype=np.uint8)
+    out = _Buffer()
+    _check(L.dmi_host_rabs_stream(zero_prob, b.ctypes.data, len(b), C.byref(out)))
+    return _take(out)

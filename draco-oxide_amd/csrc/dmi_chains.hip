@@ -127,7 +127,7 @@ __device__ __forceinline__ void k_orient_prep_body(const OrientPrepArgs& a, cons
     if (f != 0) {
       const uint32_t mine = (f == 2);
       const uint32_t at = chunk_off + rl(excl, bb) + lanes_below(valid);
-      rec[at] = pick(mine == nxt, e0, e1);
+      if (a.bits_out) a.bits_out[at] = (uint8_t)(mine == nxt); else rec[at] = pick(mine == nxt, e0, e1);
     }
     carry = (uint32_t)((ones >> (__ffsll((long long)valid) - 1)) & 1ull);
   }
@@ -363,6 +363,7 @@ __device__ void k_tables_body(const TableAtt& a, const uint32_t, const uint32_t)
   if (tid == 0) {
     a.small[6] = hdr_len;
     a.small[7] = err;
+    a.small[12] = precision;   // (read by the host-core chains; a device chain overwrites it with its clock)
     a.small[14] = zero_prob;
     a.small[15] = aux_count;
     // which step the stream's walker uses: the one-byte step pays off when few batches of 64 hold a rare symbol (f < 2^(P-8))
@@ -811,11 +812,15 @@ void launch_bits_prep_dev(const uint8_t* bits, uint64_t n, const RansEntry* entr
   emit_prep(K_BITS_PREP, 1, a, n ? grid256(n) : 0u, s);
 }
 void launch_orient_prep(const uint8_t* orient, uint32_t n, const uint32_t* chunk_info, RansEntry e0, RansEntry e1, RansEntry* rec, hipStream_t s) {
-  OrientPrepArgs a{orient, chunk_info, rec, e0, e1, n, 0u, nullptr};
+  OrientPrepArgs a{orient, chunk_info, rec, e0, e1, n, 0u, nullptr, nullptr};
   emit_prep(K_ORIENT_PREP, 1, a, (n + 4095u) / 4096u, s);
 }
 void launch_orient_prep_dev(const uint8_t* orient, uint32_t n, const uint32_t* chunk_info, const RansEntry* entries, RansEntry* rec, hipStream_t s) {
-  OrientPrepArgs a{orient, chunk_info, rec, RansEntry{}, RansEntry{}, n, 0u, entries};
+  OrientPrepArgs a{orient, chunk_info, rec, RansEntry{}, RansEntry{}, n, 0u, entries, nullptr};
+  emit_prep(K_ORIENT_PREP, 1, a, (n + 4095u) / 4096u, s);
+}
+void launch_orient_bits(const uint8_t* orient, uint32_t n, const uint32_t* chunk_info, uint8_t* bits_out, hipStream_t s) {
+  OrientPrepArgs a{orient, chunk_info, nullptr, RansEntry{}, RansEntry{}, n, 0u, nullptr, bits_out};
   emit_prep(K_ORIENT_PREP, 1, a, (n + 4095u) / 4096u, s);
 }
 void launch_batch_flags(const RansEntry* rec, uint64_t n, const uint32_t* n_dev, uint32_t* batch_flags, hipStream_t s) {

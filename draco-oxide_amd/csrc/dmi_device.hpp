@@ -120,6 +120,8 @@ void launch_bits_prep_dev(const uint8_t* bits, uint64_t n, const RansEntry* entr
 // chunk_info[2c] = compact offset of 4096-flag chunk c, [2c+1] = value (0/1) of the first valid flag after it (1 if none)
 void launch_orient_prep(const uint8_t* orient, uint32_t n, const uint32_t* chunk_info, RansEntry e0, RansEntry e1, RansEntry* rec, hipStream_t s);
 void launch_orient_prep_dev(const uint8_t* orient, uint32_t n, const uint32_t* chunk_info, const RansEntry* entries, RansEntry* rec, hipStream_t s);
+// the compacted transition bits (bits_out[k] = bit k of the stream, 1 byte each) instead of coding records: the stream is coded on a host core
+void launch_orient_bits(const uint8_t* orient, uint32_t n, const uint32_t* chunk_info, uint8_t* bits_out, hipStream_t s);
 struct ChainDesc {
   uint32_t kind;            // 0 = rANS over coding records, 1 = rABS over flips (forward), 2 = rABS over orientation flags
   uint32_t precision;       // rANS precision bits
@@ -148,14 +150,16 @@ void launch_chains(const ChainDesc* descs_dev, const uint32_t* order_dev, uint32
 // `n_dev` (nullable): the record count in device memory (texture-coordinate orientation streams, whose length the device finds).
 struct RansPrepArgs { const uint32_t* sym; const RansEntry* table; RansEntry* rec; uint32_t* batch_flags; uint64_t n; uint32_t bins; uint32_t pad; };
 struct BitsPrepArgs { const uint8_t* bits; RansEntry* rec; uint64_t n; RansEntry e0, e1; const RansEntry* entries; };
-struct OrientPrepArgs { const uint8_t* orient; const uint32_t* chunk_info; RansEntry* rec; RansEntry e0, e1; uint32_t n; uint32_t pad; const RansEntry* entries; };
+struct OrientPrepArgs { const uint8_t* orient; const uint32_t* chunk_info; RansEntry* rec; RansEntry e0, e1; uint32_t n; uint32_t pad; const RansEntry* entries;
+                        uint8_t* bits_out; /* nullable: the compacted transition bits themselves (1 byte each) instead of coding records — host-core chains */ };
 struct BatchFlagsArgs { const RansEntry* rec; uint32_t* batch_flags; uint64_t n; const uint32_t* n_dev; };
 // Device form of the table stage (a17 + the descriptors of the streams): one workgroup per attribute normalises the histogram
 // (RansSymbolEncoder::new, rans.rs:146-239), serialises the table, builds the coding-record table, closes the metadata
 // streams' parameters (zero_prob, record pair, orientation chunk offsets) and writes the attribute's chain descriptors —
 // nothing of an encode comes back to the host before the chains have run.
 // small[] words written here: [6] header bytes, [7] table error (1 empty histogram, 2 normalisation overflow, 3 underflow,
-// 4 occurring symbol normalised to 0, 5 header capacity), [14] metadata zero_prob, [15] metadata entry count.
+// 4 occurring symbol normalised to 0, 5 header capacity), [12] rANS precision (until a device chain stores its clock there),
+// [14] metadata zero_prob, [15] metadata entry count.
 struct TableAtt {
   const uint32_t* hist; uint32_t* freq /* scratch: bins words */; RansEntry* rtable; uint8_t* hdr; uint32_t* small;
   uint64_t n_sym; uint32_t bins; uint32_t hdr_cap;

@@ -16,6 +16,7 @@
 
 #include "dmi_device.hpp"
 #include "dmi_host.hpp"
+#include "host_chains.hpp"
 
 namespace dmi {
 thread_local std::string g_last_error;
@@ -37,6 +38,7 @@ int fail(int code, const std::string& msg) { return host_fail(code, msg); }
 enum Scheme : uint8_t { kDelta = 0, kParallelogram = 1, kTexCoord = 5, kNormal = 6 };   // prediction_scheme/mod.rs:74-86
 enum Transform : uint8_t { kDifference = 0, kWrapped = 1, kOctOrth = 3 };              // prediction_transform/mod.rs:92-101
 enum Port : uint8_t { kToBits = 1, kCoordwise = 2, kOct = 3 };                          // portabilization/mod.rs:85-92
+constexpr uint64_t kHostChainMinSymbols = 32768;   // a job whose longest stream is at least this long codes its streams on host cores (hybrid form)
 
 // Device memory of one job comes from a few large chunks (DevPool) instead of one hipMalloc per buffer: job creation for a batch
 // of meshes runs on many host threads, and ≈ 70 allocations + ≈ 20 memsets per job serialise on the runtime (17 ms of
@@ -124,6 +126,7 @@ struct AttJob {
   uint64_t n_sym = 0;
   uint64_t out_cap = 0, aux_cap = 0;
   DevMem aux_out, aux_rec, chunk_info, batch_flags, aux_flags;
+  DevMem aux_bits;   // host-core chains: the compacted orientation transition bits (1 byte each)
   DevMem freq, hdr, aux_entries;   // device form of the table stage: normalised-frequency scratch, serialised table, rABS record pair
   uint32_t hdr_cap = 0;
   DevMem fan_hdr, fan_apex, fan;   // fan rows of a normal attribute swept on its own table (position ranks, centre in apex)
@@ -167,6 +170,11 @@ struct dmi_job {
                                    // between the histograms and the chains (DMI_HOST_TABLES=1 or a ToBits attribute keep the host form)
   uint8_t* out_pinned = nullptr;   // grow-only pinned arena for the coded bytes of one encode
   size_t out_pinned_cap = 0;
+  // Hybrid form (host_chains.cpp): the streams of a single large mesh are coded on host cores from the device-built symbols and tables.
+  bool host_chains = false;
+  struct HostStage* stage = nullptr;                 // pinned staging of symbols / tables / metadata bits (process-wide pool)
+  std::vector<std::unique_ptr<HostChainOut>> host_out;   // [2·i] rANS stream of attribute i, [2·i + 1] its metadata rABS stream
+  std::vector<hipEvent_t> copy_ev;                   // "attribute i has arrived"
   struct Run {   // state carried between the phases of one encode
     std::vector<size_t> rans_off, aux_off;   // offsets into out_pinned
     std::vector<const uint8_t*> rans_ptr, aux_ptr;   // host addresses of the coded bytes (pinned memory)
@@ -180,13 +188,56 @@ struct dmi_job {
     std::vector<AuxInfo> aux;
     std::vector<ChainDesc> descs;
   } run;
-  ~dmi_job() {
+  ~dmi_job();
+  void release() {
     if (pinned) (void)hipHostFree(pinned);
     if (out_pinned) (void)hipHostFree(out_pinned);
     if (graph_a) (void)hipGraphExecDestroy(graph_a);
     if (have_events) for (auto& e : ev) (void)hipEventDestroy(e);
+    for (auto& e : copy_ev) (void)hipEventDestroy(e);
   }
 };
+
+// Pinned host staging for the hybrid form, pooled for the life of the process: pinning ≈ 150 MB costs tens of milliseconds, which a
+// create → encode → destroy call (dmi_encode_attributes) would otherwise pay every time.
+struct HostStage {
+  int device = -1;
+  uint8_t* p = nullptr;
+  size_t cap = 0;
+  bool in_use = false;
+};
+static std::mutex g_stage_mutex;
+static std::vector<HostStage*> g_stages;   // (never freed: process-lifetime staging)
+static HostStage* acquire_stage(int device, size_t bytes) {
+  HostStage* best = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_stage_mutex);
+    for (HostStage* st : g_stages) {   // the smallest free stage that fits, else the largest free one (it is grown below)
+      if (st->in_use || st->device != device) continue;
+      const bool fits = st->cap >= bytes, best_fits = best && best->cap >= bytes;
+      if (!best || (fits && (!best_fits || st->cap < best->cap)) || (!fits && !best_fits && st->cap > best->cap)) best = st;
+    }
+    if (!best) { best = new HostStage(); best->device = device; g_stages.push_back(best); }
+    best->in_use = true;
+  }
+  if (best->cap < bytes) {
+    if (best->p) (void)hipHostFree(best->p);
+    best->p = nullptr; best->cap = 0;
+    const size_t want = bytes + bytes / 8 + 4096;
+    if (hipHostMalloc(reinterpret_cast<void**>(&best->p), want, hipHostMallocDefault) != hipSuccess) { best->p = nullptr; std::lock_guard<std::mutex> lock(g_stage_mutex); best->in_use = false; return nullptr; }
+    best->cap = want;
+  }
+  return best;
+}
+static void release_stage(HostStage* st) {
+  if (!st) return;
+  std::lock_guard<std::mutex> lock(g_stage_mutex);
+  st->in_use = false;
+}
+dmi_job::~dmi_job() {
+  release();
+  release_stage(stage);
+}
 
 namespace {
 
@@ -350,7 +401,7 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
     size_t est = 0;
     for (uint32_t i = 0; i < n_atts; ++i) {
       const size_t V0 = tables[i].num_vertices;
-      est += F0 * 24 + V0 * 88 + (size_t)atts[i].num_unique * atts[i].num_components * 4 + V0 * ((size_t)job->atts[i].nq * 31 + 48) + ((size_t)1 << 20);
+      est += F0 * 24 + V0 * 88 + (size_t)atts[i].num_unique * atts[i].num_components * 4 + V0 * ((size_t)job->atts[i].nq * 31 + 49) + ((size_t)1 << 20);
     }
     job->pool.stream = s;
     job->pool.chunk_bytes = est + est / 8;
@@ -367,6 +418,29 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
     if (tables[i].num_faces != F) return fail(DMI_ERR_INVALID_ARGUMENT, "all corner tables must have the same face count");
     if (!tables[i].corner_to_point || !tables[i].corner_to_vertex || !tables[i].opposite) return fail(DMI_ERR_INVALID_ARGUMENT, "corner table arrays missing");
   }
+  // caller-supplied tables index host and device arrays below: every entry is range-checked once, here (error codes, not crashes)
+  for (uint32_t i = 0; i < n_atts; ++i) {
+    bool same = false;   // (a table that shares its arrays with an earlier one was checked there)
+    for (uint32_t j = 0; j < i && !same; ++j)
+      same = tables[j].corner_to_vertex == tables[i].corner_to_vertex && tables[j].opposite == tables[i].opposite && tables[j].left_most_corner == tables[i].left_most_corner &&
+             tables[j].num_vertices == tables[i].num_vertices;
+    if (same) continue;
+    const uint32_t V = tables[i].num_vertices;
+    const uint32_t* c2v = tables[i].corner_to_vertex;
+    const uint32_t* opp = tables[i].opposite;
+    const uint32_t* lmc = tables[i].left_most_corner;
+    std::atomic<int> bad{0};
+    parallel_for(C, [&](size_t lo, size_t hi) {
+      int b = 0;
+      for (size_t c = lo; c < hi; ++c) { if (c2v[c] >= V) b |= 1; if (opp[c] != kNone && opp[c] >= C) b |= 2; }
+      if (b) bad.fetch_or(b);
+    });
+    if (lmc) parallel_for(V, [&](size_t lo, size_t hi) { for (size_t v = lo; v < hi; ++v) if (lmc[v] != kNone && lmc[v] >= C) { bad.fetch_or(4); break; } });
+    if (bad & 1) return fail(DMI_ERR_INVALID_ARGUMENT, "corner table " + std::to_string(i) + ": corner_to_vertex entry ≥ num_vertices");
+    if (bad & 2) return fail(DMI_ERR_INVALID_ARGUMENT, "corner table " + std::to_string(i) + ": opposite entry outside [0, 3F)");
+    if (bad & 4) return fail(DMI_ERR_INVALID_ARGUMENT, "corner table " + std::to_string(i) + ": left_most_corner entry outside [0, 3F)");
+  }
+  if (seeds) for (uint32_t k = 0; k < n_seeds; ++k) if (seeds[k] >= C) return fail(DMI_ERR_INVALID_ARGUMENT, "seed corner outside [0, 3F)");
   // ---- resident layout of the connectivity inputs --------------------------------------------------------
   // The tables arrive in the mesh's own face/vertex numbering.  Every predictor walks them in the coding
   // (Edgebreaker) order, so they are re-indexed once, here, into that order (a pure relabelling: the
@@ -527,6 +601,7 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
       if ((rc = a.aux_flags.alloc(((size_t)n / 64 + 4) * 4))) return rc;
       if (!a.aux_flags.pooled) HIP_TRY(hipMemsetAsync(a.aux_flags.p, 0, a.aux_flags.bytes, s));
       if ((rc = a.chunk_info.alloc((size_t)std::max(1u, orient_summary_blocks(n)) * 8 + 16))) return rc;
+      if (a.scheme == kTexCoord && (rc = a.aux_bits.alloc((size_t)n + 16))) return rc;
     }
     if (a.scheme == kNormal && a.fused_into < 0 && n) {   // fan rows: this table's fans, ranks in the parent position table
       const TableDev& pt = job->tables[job->atts[a.parent].table];
@@ -575,6 +650,15 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
   job->pinned_bytes = pinned_need;   // (the pinned mirror is allocated by the first single-job encode: a batch reads back through its arena)
   job->dev_tables = !std::getenv("DMI_HOST_TABLES");
   for (auto& a : job->atts) if (a.port == kToBits) job->dev_tables = false;
+  {   // where the serial coders of a single-job encode run: DMI_CHAINS=device|host forces, default = by the longest stream
+    // (a host core steps ≈ 6× faster than a scalar-unit walker, but costs a read-back of the symbols and a few thread starts)
+    const char* m = std::getenv("DMI_CHAINS");
+    uint64_t longest = 0;
+    for (auto& a : job->atts) longest = std::max<uint64_t>(longest, a.n_sym);
+    if (m && std::strcmp(m, "host") == 0) job->host_chains = true;
+    else if (m && std::strcmp(m, "device") == 0) job->host_chains = false;
+    else job->host_chains = longest >= kHostChainMinSymbols;
+  }
   if ((rc = job->descs.alloc(sizeof(ChainDesc) * (size_t)n_atts * 2 + 16)   /* + the chain kernel's pull counter */)) return rc;
   if (cfg.flags & DMI_FLAG_TIMINGS) {
     for (auto& e : job->ev) HIP_TRY(hipEventCreate(&e));
@@ -742,7 +826,8 @@ static int encode_phase_a(dmi_job* job, bool plan_only = false) {   // device: r
   return DMI_OK;
 }
 
-static int encode_phase_b(dmi_job* job, bool plan_only = false) {   // host: table normalisation; device: coding records; fills job->run.descs
+static int encode_phase_b(dmi_job* job, bool plan_only = false, bool host_chains = false) {   // host: table normalisation; device: coding records; fills job->run.descs
+  // host_chains: the streams are coded on host cores (encode_tail_host): no coding records are built, orientation flags are compacted to bits
   // plan_only: a step sink is set — launches are collected, uploads are deferred to job->run.pending: no HIP call is made
   hipStream_t s = job->stream;
   job->run.pending.clear();
@@ -779,9 +864,11 @@ static int encode_phase_b(dmi_job* job, bool plan_only = false) {   // host: tab
     std::vector<RansEntry>& rt = a.rt_host;
     rt.assign((a.ft.freq.size() + 3) & ~(size_t)3, RansEntry{0u, 0u, 0u, 0u, 0u});   // 4 entries = 80 bytes = whole 16-byte words
     for (size_t k = 0; k < a.ft.freq.size(); ++k) rt[k] = make_rans_entry(a.ft.freq[k], a.ft.cum[k], a.ft.precision);
-    { const int urc = upload_table(a.rtable.p, rt.data(), rt.size() * sizeof(RansEntry)); if (urc) return urc; }
-    // symbols → coding records in coding order (data-parallel), consumed by the scalar chain
-    launch_rans_prep(a.sym.as<uint32_t>(), a.n_sym, a.rtable.as<RansEntry>(), a.bins, a.rec.as<RansEntry>(), a.batch_flags.as<uint32_t>(), s);
+    if (!host_chains) {
+      { const int urc = upload_table(a.rtable.p, rt.data(), rt.size() * sizeof(RansEntry)); if (urc) return urc; }
+      // symbols → coding records in coding order (data-parallel), consumed by the scalar chain
+      launch_rans_prep(a.sym.as<uint32_t>(), a.n_sym, a.rtable.as<RansEntry>(), a.bins, a.rec.as<RansEntry>(), a.batch_flags.as<uint32_t>(), s);
+    }
     ChainDesc d{};
     d.kind = 0; d.precision = a.ft.precision; d.n = a.n_sym; d.sym = a.sym.as<uint32_t>(); d.table = a.rec.as<RansEntry>(); d.state0 = 4u << a.ft.precision; d.batch_flags = a.batch_flags.as<uint32_t>();
     {   // which step the stream's walker uses: the one-byte step pays off when few batches of 64 hold a rare symbol (f < 2^(P-8))
@@ -800,7 +887,7 @@ static int encode_phase_b(dmi_job* job, bool plan_only = false) {   // host: tab
       aux[i].zero_prob = zero_probability(count_false, (float)n);
       aux[i].count = n;
       ChainDesc r{};
-      {   // rABS (rans.rs:91-108): bit 1 codes with f1 = 256 - p0 and offset 0, bit 0 with p0 and offset f1
+      if (!host_chains) {   // rABS (rans.rs:91-108): bit 1 codes with f1 = 256 - p0 and offset 0, bit 0 with p0 and offset f1
         const uint32_t p0 = aux[i].zero_prob, f1 = 256u - p0;
         launch_bits_prep(a.aux.as<uint8_t>(), n, make_rans_entry(p0, f1, 8), make_rans_entry(f1, 0, 8), a.aux_rec.as<RansEntry>(), s);
         launch_batch_flags(a.aux_rec.as<RansEntry>(), n, nullptr, a.aux_flags.as<uint32_t>(), s);
@@ -835,8 +922,11 @@ static int encode_phase_b(dmi_job* job, bool plan_only = false) {   // host: tab
         info.resize((info.size() + 3) & ~(size_t)3, 0u);   // whole 16-byte words (the batch driver copies in uint4)
         { const int urc = upload_table(a.chunk_info.p, info.data(), info.size() * 4); if (urc) return urc; }
         const uint32_t p0 = aux[i].zero_prob, f1 = 256u - p0;
-        launch_orient_prep(a.aux.as<uint8_t>(), n, a.chunk_info.as<uint32_t>(), make_rans_entry(p0, f1, 8), make_rans_entry(f1, 0, 8), a.aux_rec.as<RansEntry>(), s);
-        launch_batch_flags(a.aux_rec.as<RansEntry>(), len, nullptr, a.aux_flags.as<uint32_t>(), s);
+        if (host_chains) launch_orient_bits(a.aux.as<uint8_t>(), n, a.chunk_info.as<uint32_t>(), a.aux_bits.as<uint8_t>(), s);
+        else {
+          launch_orient_prep(a.aux.as<uint8_t>(), n, a.chunk_info.as<uint32_t>(), make_rans_entry(p0, f1, 8), make_rans_entry(f1, 0, 8), a.aux_rec.as<RansEntry>(), s);
+          launch_batch_flags(a.aux_rec.as<RansEntry>(), len, nullptr, a.aux_flags.as<uint32_t>(), s);
+        }
       }
       r.kind = 2; r.n = len; r.precision = 8; r.state0 = 4096; r.table = a.aux_rec.as<RansEntry>(); r.force_generic = 0; r.batch_flags = a.aux_flags.as<uint32_t>(); r.out = a.aux_out.as<uint8_t>(); r.cap = a.aux_cap; r.out_len = a.small.as<uint32_t>() + 10; r.ticks = a.small.as<uint32_t>() + 13;
       aux[i].desc = (int)descs.size();
@@ -854,7 +944,7 @@ static uint32_t count_streams(const dmi_job* job) {
   for (const auto& a : job->atts) k += (a.scheme == kNormal || a.scheme == kTexCoord) ? 2u : 1u;
   return k;
 }
-static int encode_phase_b_dev(dmi_job* job, ChainDesc* desc_base, ChainDesc* hdr_desc_base) {
+static int encode_phase_b_dev(dmi_job* job, ChainDesc* desc_base, ChainDesc* hdr_desc_base, bool host_chains = false) {
   hipStream_t s = job->stream;
   const uint32_t n_atts = (uint32_t)job->atts.size();
   std::vector<ChainDesc>& descs = job->run.descs;
@@ -889,6 +979,10 @@ static int encode_phase_b_dev(dmi_job* job, ChainDesc* desc_base, ChainDesc* hdr
     }
     ta.hdr_desc = hdr_desc_base ? hdr_desc_base + i : nullptr;
     launch_tables(ta, s);
+    if (host_chains) {   // no coding records: the streams are coded on host cores from the symbols, the table and the metadata bits
+      if (a.scheme == kTexCoord) launch_orient_bits(a.aux.as<uint8_t>(), n, a.chunk_info.as<uint32_t>(), a.aux_bits.as<uint8_t>(), s);
+      continue;
+    }
     launch_rans_prep(a.sym.as<uint32_t>(), a.n_sym, a.rtable.as<RansEntry>(), a.bins, a.rec.as<RansEntry>(), a.batch_flags.as<uint32_t>(), s);
     if (a.scheme == kNormal) {
       launch_bits_prep_dev(a.aux.as<uint8_t>(), n, a.aux_entries.as<RansEntry>(), a.aux_rec.as<RansEntry>(), s);
@@ -1095,6 +1189,143 @@ static int encode_phase_c3(dmi_job* job, dmi_buffer* out) {   // host: splice th
   return DMI_OK;
 }
 
+// Hybrid tail of a single-job encode (job->host_chains): after the table stage the symbols, the device-built coding tables, the
+// serialised tables and the metadata bits come back into pinned staging (largest attribute first, one event per attribute) and every
+// stream is coded by host_rans_chain / host_rabs_chain on its own host core as soon as its attribute has arrived; then the splice.
+// The strict dependency chain of one stream is the only stage that leaves the device: a 15M-symbol stream takes ≈ 240 ms on a
+// scalar-unit walker and ≈ 40 ms on one 5 GHz core.  Batches (dmi_jobs_encode) keep the device chains.
+static int encode_tail_host(dmi_job* job, dmi_buffer* out, float* chain_ms, float* longest_ms, float* wait_ms) {
+  hipStream_t s = job->stream;
+  const uint32_t n_atts = (uint32_t)job->atts.size();
+  const bool dev = job->dev_tables;
+  struct Slot { size_t small = 0, sym = 0, table = 0, hdr = 0, bits = 0; };
+  std::vector<Slot> slot(n_atts);
+  size_t need = 0;
+  auto take = [&](size_t bytes) { const size_t at = need; need = (need + bytes + 255) & ~(size_t)255; return at; };
+  for (uint32_t i = 0; i < n_atts; ++i) {
+    const AttJob& a = job->atts[i];
+    const bool has_aux = a.scheme == kNormal || a.scheme == kTexCoord;
+    slot[i].small = take(128);
+    slot[i].sym = take((size_t)a.n_sym * 4);
+    if (dev) { slot[i].table = take((size_t)a.bins * sizeof(RansEntry)); slot[i].hdr = take(a.hdr_cap); }
+    if (has_aux) slot[i].bits = take((size_t)job->tables[a.table].n_seq + 16);
+  }
+  if (!job->stage || job->stage->cap < need) {
+    release_stage(job->stage);
+    job->stage = acquire_stage(job->cfg.device, need);
+    if (!job->stage) return fail(DMI_ERR_OUT_OF_MEMORY, "hipHostMalloc (host-chain staging)");
+  }
+  uint8_t* base = job->stage->p;
+  while (job->copy_ev.size() < n_atts) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); job->copy_ev.push_back(e); }
+  while (job->host_out.size() < 2 * (size_t)n_atts) job->host_out.emplace_back(new HostChainOut());
+  std::vector<uint32_t> order(n_atts);
+  for (uint32_t i = 0; i < n_atts; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return job->atts[x].n_sym > job->atts[y].n_sym; });
+  for (uint32_t i : order) {
+    AttJob& a = job->atts[i];
+    const uint32_t n = job->tables[a.table].n_seq;
+    if (dev) {
+      HIP_TRY(hipMemcpyAsync(base + slot[i].small, a.small.p, 128, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipMemcpyAsync(base + slot[i].table, a.rtable.p, (size_t)a.bins * sizeof(RansEntry), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipMemcpyAsync(base + slot[i].hdr, a.hdr.p, a.hdr_cap, hipMemcpyDeviceToHost, s));
+    }
+    if (a.n_sym) HIP_TRY(hipMemcpyAsync(base + slot[i].sym, a.sym.p, (size_t)a.n_sym * 4, hipMemcpyDeviceToHost, s));
+    if (a.scheme == kNormal && n) HIP_TRY(hipMemcpyAsync(base + slot[i].bits, a.aux.p, n, hipMemcpyDeviceToHost, s));
+    if (a.scheme == kTexCoord && n) HIP_TRY(hipMemcpyAsync(base + slot[i].bits, a.aux_bits.p, n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(job->copy_ev[i], s));
+  }
+  // streams, longest first; a few host threads pull them
+  struct Stream { uint32_t att; bool aux; uint64_t n; };
+  std::vector<Stream> streams;
+  for (uint32_t i : order) {
+    const AttJob& a = job->atts[i];
+    streams.push_back({i, false, a.n_sym});
+    if (a.scheme == kNormal || a.scheme == kTexCoord) streams.push_back({i, true, job->tables[a.table].n_seq});
+  }
+  std::stable_sort(streams.begin(), streams.end(), [](const Stream& x, const Stream& y) { return x.n > y.n; });
+  std::vector<int> rcs(streams.size(), DMI_OK);
+  std::vector<std::string> errs(streams.size());
+  std::vector<AuxInfo>& aux = job->run.aux;
+  const int device = job->cfg.device;
+  std::atomic<size_t> next{0};
+  const auto t_chain0 = std::chrono::steady_clock::now();
+  auto work = [&] {
+    (void)hipSetDevice(device);
+    for (size_t k; (k = next.fetch_add(1)) < streams.size();) {
+      const Stream& st = streams[k];
+      const uint32_t i = st.att;
+      AttJob& a = job->atts[i];
+      const auto w0 = std::chrono::steady_clock::now();
+      if (hipEventSynchronize(job->copy_ev[i]) != hipSuccess) { rcs[k] = DMI_ERR_HIP; errs[k] = "hipEventSynchronize (host-chain staging)"; continue; }
+      const auto w1 = std::chrono::steady_clock::now();
+      const uint32_t* small = reinterpret_cast<const uint32_t*>(base + slot[i].small);
+      if (dev) {
+        const int frc = check_device_flags(small, i);
+        if (frc) { rcs[k] = frc; errs[k] = g_last_error; continue; }
+      }
+      HostChainOut& o = *job->host_out[2 * (size_t)i + (st.aux ? 1 : 0)];
+      if (!st.aux) {
+        const RansEntry* table = dev ? reinterpret_cast<const RansEntry*>(base + slot[i].table) : a.rt_host.data();
+        const uint32_t bins = dev ? a.bins : (uint32_t)a.ft.freq.size();
+        const uint32_t precision = dev ? small[12] : a.ft.precision;
+        host_rans_chain(reinterpret_cast<const uint32_t*>(base + slot[i].sym), a.n_sym, table, bins, precision, o);
+      } else {
+        const uint32_t p0 = dev ? small[14] : aux[i].zero_prob, f1 = 256u - p0;
+        const uint64_t count = dev ? small[15] : aux[i].count;
+        const RansEntry e[2] = {make_rans_entry(p0, f1, 8), make_rans_entry(f1, 0, 8)};   // rABS (rans.rs:91-108): bit 0 codes with p0 and offset f1, bit 1 with f1 and offset 0
+        host_rabs_chain(base + slot[i].bits, count, e, o);
+      }
+      if (k == 0) {   // the longest stream
+        if (wait_ms) *wait_ms = std::chrono::duration<float, std::milli>(w1 - w0).count();
+        if (longest_ms) *longest_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - w1).count();
+      }
+      if (o.err) {
+        rcs[k] = o.err == 2 ? DMI_ERR_OUT_OF_MEMORY : DMI_ERR_ENTROPY;
+        errs[k] = o.err == 1 ? (st.aux ? "rABS state too large" : "rANS state too large") : (o.err == 2 ? "malloc (host-chain output)" : "symbol outside the coding table");
+      }
+    }
+  };
+  {
+    unsigned hw = std::thread::hardware_concurrency();
+    const size_t n_threads = std::max<size_t>(1, std::min<size_t>({streams.size(), hw ? hw : 4u, 16u}));
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < n_threads; ++t) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  if (chain_ms) *chain_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_chain0).count();
+  for (size_t k = 0; k < streams.size(); ++k) if (rcs[k]) return fail(rcs[k], errs[k]);
+  // hand the parts to the splice
+  job->run.rans_ptr.assign(n_atts, nullptr); job->run.aux_ptr.assign(n_atts, nullptr);
+  job->run.rans_len.assign(n_atts, 0); job->run.aux_len.assign(n_atts, 0);
+  if (dev) {
+    job->readback = base;
+    job->run.pin_off.assign(n_atts, 0);
+    job->run.hdr_ptr.assign(n_atts, nullptr);
+    job->run.hdr_len.assign(n_atts, 0);
+  }
+  for (uint32_t i = 0; i < n_atts; ++i) {
+    const AttJob& a = job->atts[i];
+    const HostChainOut& r = *job->host_out[2 * (size_t)i];
+    if (r.len > 0xFFFFFFFFull) return fail(DMI_ERR_ENTROPY, "coded stream exceeds 4 GiB");
+    job->run.rans_ptr[i] = r.data; job->run.rans_len[i] = (uint32_t)r.len;
+    if (a.scheme == kNormal || a.scheme == kTexCoord) {
+      const HostChainOut& x = *job->host_out[2 * (size_t)i + 1];
+      job->run.aux_ptr[i] = x.data; job->run.aux_len[i] = (uint32_t)x.len;
+    }
+    if (dev) {
+      const uint32_t* small = reinterpret_cast<const uint32_t*>(base + slot[i].small);
+      job->run.pin_off[i] = slot[i].small;
+      job->run.hdr_ptr[i] = base + slot[i].hdr;
+      job->run.hdr_len[i] = small[6];
+      aux[i].zero_prob = (uint8_t)small[14];
+      aux[i].count = small[15];
+    }
+  }
+  return encode_phase_c3(job, out);
+}
+
 // Phase A as one hipGraph replay (single-job re-encodes and the jobs of a batch that keep their own launches): the ≈9 launches and
 // the read-back of a job collapse into a single API call.  Jobs with
 // event timing or a ToBits attribute (whose alphabet bound needs a mid-phase host wait) stay on the eager path.
@@ -1128,33 +1359,42 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
   const bool timed = job->have_events;
   const auto wall0 = std::chrono::steady_clock::now();
   job->readback = nullptr;
+  // (a failure after the first launch waits for the stream before it returns: the caller may destroy the job at once)
+  struct Drain { hipStream_t s; bool armed = true; ~Drain() { if (armed) (void)hipStreamSynchronize(s); } } drain{s};
   int rc = encode_phase_a(job);
   if (rc) return rc;
   auto t_tab0 = std::chrono::steady_clock::now(), t_tab1 = t_tab0;
+  const bool host_chains = job->host_chains;
   if (job->dev_tables) {
     // tables, metadata parameters and descriptors on the device: the stream runs from the first kernel to the chains without a host wait
-    if ((rc = encode_phase_b_dev(job, job->descs.as<ChainDesc>(), nullptr))) return rc;
+    if ((rc = encode_phase_b_dev(job, job->descs.as<ChainDesc>(), nullptr, host_chains))) return rc;
   } else {
     HIP_TRY(hipStreamSynchronize(s));
     t_tab0 = std::chrono::steady_clock::now();
-    if ((rc = encode_phase_b(job))) return rc;
-    HIP_TRY(hipMemcpyAsync(job->descs.p, job->run.descs.data(), job->run.descs.size() * sizeof(ChainDesc), hipMemcpyHostToDevice, s));
+    if ((rc = encode_phase_b(job, false, host_chains))) return rc;
+    if (!host_chains) HIP_TRY(hipMemcpyAsync(job->descs.p, job->run.descs.data(), job->run.descs.size() * sizeof(ChainDesc), hipMemcpyHostToDevice, s));
     t_tab1 = std::chrono::steady_clock::now();
   }
   const std::vector<ChainDesc>& descs = job->run.descs;
   if (timed) HIP_TRY(hipEventRecord(job->ev[4], s));
-  {
+  float host_chain_ms = 0.0f, longest_ms = 0.0f, wait_ms = 0.0f;
+  if (host_chains) {
+    // hybrid form: symbols + tables back over PCIe, every stream on a host core, splice
+    if ((rc = encode_tail_host(job, out, &host_chain_ms, &longest_ms, &wait_ms))) { (void)hipStreamSynchronize(s); return rc; }
+  } else {
     uint64_t longest = 0, total = 0;
     for (const ChainDesc& cd : descs) { longest = std::max<uint64_t>(longest, cd.n); total += cd.n; }
     launch_chains(job->descs.as<ChainDesc>(), nullptr, (uint32_t)descs.size(), reinterpret_cast<uint32_t*>(job->descs.as<ChainDesc>() + job->atts.size() * 2),
                   chain_launch_sparse(longest, total, (uint32_t)descs.size()), s);
   }
   if (timed) HIP_TRY(hipEventRecord(job->ev[5], s));
-  if ((rc = encode_phase_c1(job))) return rc;
-  HIP_TRY(hipStreamSynchronize(s));
-  if ((rc = encode_phase_c2(job))) return rc;
-  HIP_TRY(hipStreamSynchronize(s));
-  if ((rc = encode_phase_c3(job, out))) return rc;
+  if (!host_chains) {
+    if ((rc = encode_phase_c1(job))) { (void)hipStreamSynchronize(s); return rc; }
+    HIP_TRY(hipStreamSynchronize(s));
+    if ((rc = encode_phase_c2(job))) { (void)hipStreamSynchronize(s); return rc; }
+    HIP_TRY(hipStreamSynchronize(s));
+    if ((rc = encode_phase_c3(job, out))) return rc;
+  }
 
   dmi_timings tm{};
   if (timed) {
@@ -1164,13 +1404,18 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
     (void)hipEventElapsedTime(&tm.histogram_ms, job->ev[2], job->ev[3]);
     (void)hipEventElapsedTime(&tm.rans_ms, job->ev[4], job->ev[5]);
   }
+  if (host_chains) tm.rans_ms = host_chain_ms;   // read-back of symbols / tables + the host-core chains (wall clock)
   tm.table_ms = std::chrono::duration<float, std::milli>(t_tab1 - t_tab0).count();
   if (timed && job->dev_tables) (void)hipEventElapsedTime(&tm.table_ms, job->ev[3], job->ev[4]);   // k_tables + record prep on the device
   tm.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
   tm.predict_bytes = job->predict_bytes;
   for (auto& a : job->atts) tm.symbols += a.n_sym;
-  tm.num_streams = (uint32_t)descs.size();
+  tm.num_streams = host_chains ? count_streams(job) : (uint32_t)descs.size();
+  tm.host_chains = host_chains ? 1u : 0u;
+  tm.longest_stream_ms = longest_ms;
+  tm.readback_wait_ms = wait_ms;
   job->last = tm;
+  drain.armed = false;   // every path above ended with a stream synchronisation
   return DMI_OK;
 }
 
@@ -1418,7 +1663,11 @@ struct DeviceBatch {
   size_t launches = 0;
   bool sparse_chains = false;
   double t_plan = 0, t_wait = 0, t_bytes = 0, t_splice = 0;
-  ~DeviceBatch() { if (arena) release_batch_arena(arena); }
+  ~DeviceBatch() {
+    if (!arena) return;
+    if (s) (void)hipStreamSynchronize(s);   // (also on error paths: nothing of this batch may still be writing into the arena when the next one takes it)
+    release_batch_arena(arena);
+  }
 
   int begin() {
     const uint32_t n = (uint32_t)jobs.size();
@@ -1810,6 +2059,21 @@ struct ConnOwner {
 static int build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std::vector<uint8_t>& bytes) {
   if (!mesh || !mesh->atts || mesh->num_atts == 0 || (!mesh->faces && mesh->num_faces)) return fail(DMI_ERR_INVALID_ARGUMENT, "bad mesh");
   if (mesh->atts[0].att_type != DMI_ATT_POSITION) return fail(DMI_ERR_INVALID_ARGUMENT, "attribute 0 must be the Position attribute (core/mesh/builder.rs:115-125)");
+  for (uint32_t i = 0; i < mesh->num_atts; ++i)
+    if (mesh->atts[i].point_to_value == nullptr && mesh->atts[i].num_unique < mesh->atts[i].num_points) return fail(DMI_ERR_INVALID_ARGUMENT, "attribute " + std::to_string(i) + ": fewer values than points and no point_to_value map");
+  {   // faces index the attributes' points (and, through point_to_value, their values) from here on
+    const size_t C = (size_t)mesh->num_faces * 3;
+    const uint32_t P = mesh->atts[0].num_points;
+    std::atomic<int> bad{0};
+    parallel_for(C, [&](size_t lo, size_t hi) { for (size_t c = lo; c < hi; ++c) if (mesh->faces[c] >= P) { bad.store(1); break; } });
+    if (bad) return fail(DMI_ERR_INVALID_ARGUMENT, "face index ≥ number of points");
+    for (uint32_t i = 0; i < mesh->num_atts; ++i) {
+      const dmi_attribute& a = mesh->atts[i];
+      if (a.num_points < P) return fail(DMI_ERR_INVALID_ARGUMENT, "attribute " + std::to_string(i) + " has fewer points than the Position attribute");
+      if (a.point_to_value) parallel_for(a.num_points, [&](size_t lo, size_t hi) { for (size_t p = lo; p < hi; ++p) if (a.point_to_value[p] >= a.num_unique) { bad.store(1); break; } });
+      if (bad) return fail(DMI_ERR_INVALID_ARGUMENT, "attribute " + std::to_string(i) + ": point_to_value entry out of range");
+    }
+  }
   std::string err;
   const bool trace = std::getenv("DMI_TRACE") != nullptr;
   auto tick = [] { return std::chrono::steady_clock::now(); };
@@ -1904,7 +2168,9 @@ int dmi_mesh_prepare(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buffer* he
   if (rc) return rc;
   rc = dmi_job_create(mesh->atts, o.views.data(), mesh->num_atts, o.eb.seeds.data(), (uint32_t)o.eb.seeds.size(), cfg, job);
   if (rc) return rc;
-  return to_buffer(bytes, header_and_connectivity);
+  rc = to_buffer(bytes, header_and_connectivity);
+  if (rc) { dmi_job_destroy(*job); *job = nullptr; }
+  return rc;
 }
 
 // dmi_mesh_prepare for n independent meshes: the serial graph walks (corner tables, Edgebreaker, sequencers) and the
@@ -1959,6 +2225,38 @@ int dmi_meshes_prepare(const dmi_mesh* meshes, uint32_t n, const dmi_config* cfg
     for (uint32_t k = 0; k < n; ++k) { if (jobs[k]) { dmi_job_destroy(jobs[k]); jobs[k] = nullptr; } dmi_free(&header_and_connectivity[k]); }
     return fail(rc, e);
   }
+  return DMI_OK;
+}
+
+// The host-core stream coders of the hybrid form on their own (no device involved): tests pin them against the oracle's coders,
+// bench.py times them on one core of the GPU box beside the device walker.
+int dmi_host_rans_stream(const uint32_t* freq, uint32_t num_symbols, uint32_t precision, const uint32_t* symbols, uint64_t n, dmi_buffer* out) {
+  if (!freq || !out || (!symbols && n) || precision < 8 || precision > 20) return fail(DMI_ERR_INVALID_ARGUMENT, "bad argument");
+  std::vector<RansEntry> table(num_symbols);
+  uint64_t cum = 0;
+  for (uint32_t k = 0; k < num_symbols; ++k) {
+    if (freq[k] > (1u << precision)) return fail(DMI_ERR_INVALID_ARGUMENT, "frequency above 2^precision");
+    table[k] = make_rans_entry(freq[k], (uint32_t)cum, precision);
+    cum += freq[k];
+  }
+  if (cum != (1ull << precision)) return fail(DMI_ERR_INVALID_ARGUMENT, "frequencies must sum to 2^precision");
+  for (uint64_t k = 0; k < n; ++k) if (symbols[k] >= num_symbols || !freq[symbols[k]]) return fail(DMI_ERR_ENTROPY, "symbol without a frequency");
+  HostChainOut o;
+  host_rans_chain(symbols, n, table.data(), num_symbols, precision, o);
+  if (o.err) return fail(o.err == 2 ? DMI_ERR_OUT_OF_MEMORY : DMI_ERR_ENTROPY, o.err == 1 ? "rANS state too large" : "host chain error");
+  out->data = o.data; out->len = o.len; out->cap = o.cap;
+  o.data = nullptr; o.cap = 0;   // ownership moves to the caller (dmi_free → free)
+  return DMI_OK;
+}
+int dmi_host_rabs_stream(uint8_t zero_prob, const uint8_t* bits, uint64_t n, dmi_buffer* out) {
+  if (!out || (!bits && n) || zero_prob == 0) return fail(DMI_ERR_INVALID_ARGUMENT, "bad argument");
+  const uint32_t p0 = zero_prob, f1 = 256u - p0;
+  const RansEntry e[2] = {make_rans_entry(p0, f1, 8), make_rans_entry(f1, 0, 8)};
+  HostChainOut o;
+  host_rabs_chain(bits, n, e, o);
+  if (o.err) return fail(o.err == 2 ? DMI_ERR_OUT_OF_MEMORY : DMI_ERR_ENTROPY, o.err == 1 ? "rABS state too large" : "host chain error");
+  out->data = o.data; out->len = o.len; out->cap = o.cap;
+  o.data = nullptr; o.cap = 0;
   return DMI_OK;
 }
 

@@ -1,0 +1,144 @@
+// host_chains.cpp — the serial rANS / rABS recurrence of ONE long stream on ONE host core (the hybrid form of a single large
+// mesh: every data-parallel stage and the table stage stay on the GPU; the symbols and the device-built coding table come
+// back over PCIe and the strict dependency chain x' = (x / f)·2^P + x % f + c runs where a dependent integer chain is
+// fastest — a 5 GHz out-of-order core retires one step per ≈ 10 clocks, the gfx950 scalar unit one per ≈ 39 at 2.4 GHz).
+// Batches of many meshes keep the device chains (dmi_chains.hip): thousands of streams in flight fill the chip.
+// This is not a fallback: nothing here runs without the device stages before it, and a job without a HIP device fails.
+//
+// Reference arithmetic (draco-oxide/src/): encode/entropy/rans.rs:33-46 (RansCoder::write), :48-68 (flush), :91-108
+// (RabsCoder::write), encode/entropy/symbol_coding.rs:161-163 (symbols are fed in reverse).
+// The coding records are the ones k_tables / make_rans_entry build for the device walker (exact x / f by multiply-high,
+// d = 2^P - f so that (x / f)·2^P + x % f = x + (x / f)·d, renormalisation threshold t = f·2^10 or f·2^12): the proof of
+// exactness is in dmi_chains.hip.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "dmi_device.hpp"
+#include "dmi_host.hpp"
+#include "host_chains.hpp"
+
+namespace dmi {
+
+namespace {
+
+inline uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+
+// bytes of the tagged final state (rans.rs:48-68); 0 = StateTooLarge
+inline uint32_t flush_bytes(uint32_t s, uint8_t* at) {
+  uint32_t nb, v;
+  if (s < (1u << 6)) { nb = 1; v = s; }
+  else if (s < (1u << 14)) { nb = 2; v = (1u << 14) + s; }
+  else if (s < (1u << 22)) { nb = 3; v = (2u << 22) + s; }
+  else if (s < (1u << 30)) { nb = 4; v = (3u << 30) + s; }
+  else return 0;
+  for (uint32_t k = 0; k < nb; ++k) at[k] = (uint8_t)(v >> (8 * k));
+  return nb;
+}
+
+// one step, any renormalisation (≤ 3 bytes: x < 2^30, t ≥ 2^10): the bytes leave low byte first, exactly the reference's loop
+inline uint32_t step_general(uint32_t x, const RansEntry& e, uint8_t*& p) {
+  const uint64_t t = e.t;
+  const uint32_t nb = (uint32_t)(x >= t) + (uint32_t)(x >= (t << 8)) + (uint32_t)(x >= (t << 16));
+  std::memcpy(p, &x, 4);   // little-endian host: bytes 0..2 of x in emission order; only nb of them are kept
+  p += nb;
+  x >>= 8u * nb;
+  const uint32_t q = (e.b & 0x100u) ? x : (mulhi32(x, e.m) >> (e.b & 31u));   // f == 1: x / f = x
+  return x + q * e.d + e.c;
+}
+
+}  // namespace
+
+bool HostChainOut::reserve(size_t need) {
+  if (need <= cap) return true;
+  size_t want = std::max(need, cap + cap / 2 + 4096);
+  uint8_t* q = static_cast<uint8_t*>(std::realloc(data, want));
+  if (!q) return false;
+  data = q; cap = want;
+  return true;
+}
+HostChainOut::~HostChainOut() { std::free(data); }
+
+// n symbols, fed last to first; table[s] = the coding record of symbol s (bins entries); state0 = 4·2^P.
+// err: 0 ok, 1 StateTooLarge (rans.rs:63-65), 2 out of memory, 3 symbol outside the table.
+template <class Sym>
+static void rans_chain_impl(const Sym* sym, uint64_t n, const RansEntry* table, uint32_t bins, uint32_t precision, HostChainOut& out) {
+  out.len = 0; out.err = 0;
+  uint32_t x = 4u << precision;
+  const uint32_t state0 = x;
+  // the output grows in steps: a block of kBlock symbols sheds at most 3·kBlock bytes (+ 4 of store slack + 4 of flush)
+  constexpr uint64_t kBlock = 4096;
+  if (!out.reserve(n / 2 + 3 * kBlock + 64)) { out.err = 2; return; }
+  uint8_t* p = out.data;
+  uint64_t i = n;
+  while (i > 0) {
+    const uint64_t cnt = std::min<uint64_t>(kBlock, i);
+    {
+      const size_t used = (size_t)(p - out.data);
+      if (used + 3 * cnt + 16 > out.cap) { if (!out.reserve(used + used / 2 + 3 * cnt + 64)) { out.err = 2; return; } p = out.data + used; }
+    }
+    const uint64_t stop = i - cnt;
+    for (; i > stop; --i) {
+      const uint32_t s = (uint32_t)sym[i - 1];
+      if (__builtin_expect(s >= bins, 0)) { out.err = 3; return; }
+      const RansEntry e = table[s];
+      if (__builtin_expect((e.b & 0x300u) == 0u, 1)) {
+        // f ≥ 2^(P-8): the state can shed at most one byte (x < 2^(P+10) = t_min·2^8); branch-free — the byte leaves 57 % of the time
+        *p = (uint8_t)x;
+        const bool r = x >= e.t;
+        p += r;
+        const uint32_t xs = __builtin_unpredictable(r) ? (x >> 8) : x;
+        x = xs + (mulhi32(xs, e.m) >> (e.b & 31u)) * e.d + e.c;
+      } else {
+        if (__builtin_expect(e.t == 0u, 0)) { out.err = 3; return; }   // a symbol the table does not code (never after a clean histogram)
+        x = step_general(x, e, p);
+      }
+    }
+  }
+  const uint32_t nb = flush_bytes(x - state0, p);
+  if (!nb) { out.err = 1; return; }
+  p += nb;
+  out.len = (size_t)(p - out.data);
+}
+
+void host_rans_chain(const uint32_t* sym, uint64_t n, const RansEntry* table, uint32_t bins, uint32_t precision, HostChainOut& out) {
+  rans_chain_impl(sym, n, table, bins, precision, out);
+}
+void host_rans_chain16(const uint16_t* sym, uint64_t n, const RansEntry* table, uint32_t bins, uint32_t precision, HostChainOut& out) {
+  rans_chain_impl(sym, n, table, bins, precision, out);
+}
+
+// n bits, fed first to last (mesh_normal_prediction.rs:154-157, mesh_prediction_for_texture_coordinates.rs:241-256);
+// e[0] / e[1] = coding records of bit 0 / bit 1 (make_rans_entry(p0, 256 - p0, 8) / make_rans_entry(256 - p0, 0, 8)).
+void host_rabs_chain(const uint8_t* bits, uint64_t n, const RansEntry* e, HostChainOut& out) {
+  out.len = 0; out.err = 0;
+  uint32_t x = 4096u;
+  if (!out.reserve(n + 64)) { out.err = 2; return; }   // ≤ 1 byte per bit (single `if`, rans.rs:97)
+  uint8_t* p = out.data;
+  const bool flagged = ((e[0].b | e[1].b) & 0x100u) != 0u;   // p0 ∈ {1, 255}: one of the frequencies is 1
+  if (!flagged) {
+    // both records side by side so that the select is an index, not a branch
+    const uint32_t m[2] = {e[0].m, e[1].m}, b[2] = {e[0].b & 31u, e[1].b & 31u}, d[2] = {e[0].d, e[1].d}, c[2] = {e[0].c, e[1].c}, t[2] = {e[0].t, e[1].t};
+    for (uint64_t i = 0; i < n; ++i) {
+      const uint32_t k = bits[i] != 0;
+      *p = (uint8_t)x;
+      const bool r = x >= t[k];
+      p += r;
+      const uint32_t xs = __builtin_unpredictable(r) ? (x >> 8) : x;
+      x = xs + (mulhi32(xs, m[k]) >> b[k]) * d[k] + c[k];
+    }
+  } else {
+    for (uint64_t i = 0; i < n; ++i) {
+      const RansEntry& r = e[bits[i] != 0];
+      if (x >= r.t) { *p++ = (uint8_t)x; x >>= 8; }
+      const uint32_t q = (r.b & 0x100u) ? x : (mulhi32(x, r.m) >> (r.b & 31u));
+      x = x + q * r.d + r.c;
+    }
+  }
+  const uint32_t nb = flush_bytes(x - 4096u, p);
+  if (!nb) { out.err = 1; return; }
+  p += nb;
+  out.len = (size_t)(p - out.data);
+}
+
+}  // namespace dmi

@@ -100,6 +100,28 @@ def gather_blob_lists(local_blobs, local_indices, num_items, device=None, group=
     return out
 
 
+def _rank_config(cfg, device):
+    """The Config a rank encodes with: its HIP ordinal is the CUDA `device` it was given, else LOCAL_RANK (one process per GPU;
+    with HIP_VISIBLE_DEVICES isolating one GPU per process the ordinal folds to 0).  A cfg that names another GPU than `device`
+    is a caller bug: every rank would otherwise prepare and encode on device 0."""
+    import copy
+    import os
+    from . import binding
+    n_dev = max(binding.device_count(), 1)
+    if device is not None and getattr(device, "type", "cpu") == "cuda" and device.index is not None:
+        ordinal = int(device.index)
+    else:
+        ordinal = int(os.environ.get("LOCAL_RANK", "0")) % n_dev
+    if cfg is None:
+        return binding.Config(device=ordinal)
+    if device is not None and getattr(device, "type", "cpu") == "cuda" and device.index is not None and cfg.device != ordinal:
+        raise ValueError(f"encode_meshes_sharded: cfg.device={cfg.device} but the rank's device is cuda:{ordinal}")
+    if device is None or getattr(device, "type", "cpu") != "cuda":
+        cfg = copy.copy(cfg)
+        cfg.device = cfg.device if cfg.device else ordinal   # an explicit non-zero ordinal is honoured
+    return cfg
+
+
 def encode_meshes_sharded(meshes, cfg=None, device=None, group=None, dst=0):
     """BASELINE configs[3] on N GPUs: the batch is dealt to the ranks by triangle count (shard_indices, LPT), every rank prepares
     and codes its share with ONE dmi_jobs_encode on its own GPU (no data-path collective), and the finished `.drc` blobs are
@@ -108,6 +130,7 @@ def encode_meshes_sharded(meshes, cfg=None, device=None, group=None, dst=0):
     from . import binding
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    cfg = _rank_config(cfg, device)
     mine = shard_indices(len(meshes), rank, world, weights=[len(m.faces) for m in meshes])
     blobs = []
     if mine:

@@ -100,11 +100,14 @@ typedef struct dmi_timings {
   float histogram_ms;
   float table_ms;        /* table stage + record prep: k_tables and the prep kernels on the device (host-table form: D2H histogram,
                             host normalisation, H2D tables — host-inclusive wall time) */
-  float rans_ms;         /* rANS + rABS chain kernel */
+  float rans_ms;         /* rANS + rABS coders: the chain kernel (device form), or read-back + host-core chains (hybrid form, wall clock) */
   float total_ms;        /* first launch → last byte on host */
   uint64_t predict_bytes;    /* algorithmic bytes of the quantize+predict pass (SURVEY §8d formula) */
   uint64_t symbols;          /* rANS symbols coded */
   uint32_t num_streams;      /* rANS + rABS chains */
+  uint32_t host_chains;      /* 1 = the streams of this encode were coded on host cores (hybrid form, long single meshes), 0 = on the device */
+  float longest_stream_ms;   /* hybrid form: the coder of the longest stream alone (its symbols already on the host); device form: 0 */
+  float readback_wait_ms;    /* hybrid form: time the longest stream's host thread waited for its symbols / tables to arrive */
 } dmi_timings;
 
 /* --- Drop-in for attribute::encode_attributes (encode/attribute/mod.rs:13-93) ------------------
@@ -187,6 +190,15 @@ typedef struct dmi_raw_attribute {
 typedef struct dmi_built_mesh { dmi_mesh mesh; void* owner; } dmi_built_mesh;
 int dmi_mesh_build(const dmi_raw_attribute* atts, uint32_t n_atts, const uint32_t* faces, uint32_t num_faces, dmi_built_mesh* out);
 void dmi_built_mesh_free(dmi_built_mesh* m);
+
+/* --- The hybrid form's host-core stream coders on their own (host only, no device) ----------------
+ * A single large mesh codes its streams on host cores from the device-built symbols and tables (dmi_job_encode, see
+ * DESIGN.md §5); these two entry points expose exactly those coders so that tests can pin them against the reference's
+ * RansCoder / RabsCoder (encode/entropy/rans.rs:33-68, :91-128) and the bench can time one host core beside the device
+ * walker.  freq[] = normalised frequencies summing to 2^precision; symbols are coded LAST TO FIRST
+ * (encode/entropy/symbol_coding.rs:161-163), bits first to last; the tagged final state is appended (rans.rs:48-68). */
+int dmi_host_rans_stream(const uint32_t* freq, uint32_t num_symbols, uint32_t precision, const uint32_t* symbols, uint64_t n, dmi_buffer* out);
+int dmi_host_rabs_stream(uint8_t zero_prob, const uint8_t* bits, uint64_t n, dmi_buffer* out);
 
 void dmi_free(dmi_buffer* buf);
 /* dmi_free of bufs[0..n): the outputs of a batch call released in one call */

@@ -161,6 +161,15 @@ def test_one_million_triangles_positions_only_bit_exact():
     _assert_same(dmi.encode_mesh(mesh), want, "1M positions")
 
 
+def test_one_million_triangles_positions_only_delta_config1():
+    """BASELINE configs[1] as stated: 1M-triangle synthetic mesh, positions only, delta prediction + difference transform, 11-bit
+    quantization, one MI355X.  The reference compiles this scheme but `encode::Config` cannot select it ("sequential encoder" is
+    `unimplemented!`, attribute_encoder.rs:254-256): the oracle restates the delta/difference arithmetic on the Edgebreaker order."""
+    mesh = synth.torus_mesh(707, normals=False, uvs=False)
+    want = oracle_from_product_mesh(mesh).encode(positions_delta=True)
+    _assert_same(dmi.encode_mesh(mesh, dmi.Config(pos_scheme=dmi.POS_SCHEME_DELTA, pos_bits=11)), want, "1M positions, delta")
+
+
 def _leb(a, p):
     v, sh = 0, 0
     while True:
@@ -176,7 +185,7 @@ def test_ten_million_triangles_full_attribute_set():
     """BASELINE config 3 size (n=2236 → 9 999 392 triangles, pos+nrm+uv).  Size-independent properties
     first (run-to-run determinism; every attribute's rANS stream decodes with the oracle's inverse coder
     to exactly V·N symbols and the section is consumed to the last byte), then full byte parity with the
-    oracle (≈35 s of single-core CPU)."""
+    oracle (≈6 s of single-core CPU)."""
     n = int(os.environ.get("DMI_FULL_N", "2236"))
     mesh = synth.torus_mesh(n)
     job = dmi.mesh_prepare(mesh)
