@@ -184,4 +184,17 @@ void launch_copy_items(const CopyItem* items_dev, uint32_t n_items, uint8_t* are
 void launch_scatter_items(const CopyItem* items_dev, uint32_t n_items, const uint8_t* arena, hipStream_t s);
 void launch_pack_streams(const ChainDesc* descs_dev, uint32_t n_streams, PackEntry* table, uint8_t* arena, hipStream_t s);
 
+// ---- coding-order relabelling of the connectivity inputs on the device (dmi_relabel.hip; job creation of large meshes) ----
+void launch_fill_u32(uint32_t* p, uint64_t n, uint32_t v, hipStream_t s);
+void launch_rank_scatter(const uint32_t* seq, uint32_t n_seq, const uint32_t* c2v, uint32_t* rank /* pre-filled with DMI_NONE */, hipStream_t s);
+void launch_face_keys(const uint32_t* c2v, const uint32_t* rank, uint32_t F, uint32_t none_key, uint32_t* key, uint32_t* face, hipStream_t s);
+size_t sort_faces_temp_bytes(uint32_t F, int key_bits);
+hipError_t launch_sort_faces(void* temp, size_t temp_bytes, const uint32_t* key_in, uint32_t* key_out, const uint32_t* face_in, uint32_t* order_out, uint32_t F, int key_bits, hipStream_t s);
+void launch_new_face(const uint32_t* order, uint32_t F, uint32_t* new_face, hipStream_t s);
+void launch_remap_table(const uint32_t* c2v, const uint32_t* opp, const uint32_t* rank, const uint32_t* order, const uint32_t* new_face, uint64_t C, uint32_t* c2r_out, uint32_t* opp_out,
+                        hipStream_t s);
+void launch_remap_seq(const uint32_t* seq, uint32_t n_seq, const uint32_t* new_face, const uint32_t* c2p, uint32_t* seq_out, uint32_t* s2p_out, hipStream_t s);
+void launch_compose_s2v(const uint32_t* s2p, uint32_t n_seq, const uint32_t* p2v, uint32_t num_points, uint32_t num_unique, uint32_t* s2v, uint32_t* bad, hipStream_t s);
+void launch_max_u32(const uint32_t* a, uint64_t n, uint32_t* out /* pre-zeroed */, hipStream_t s);
+
 }  // namespace dmi

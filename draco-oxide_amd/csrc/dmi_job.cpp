@@ -38,6 +38,7 @@ int fail(int code, const std::string& msg) { return host_fail(code, msg); }
 enum Scheme : uint8_t { kDelta = 0, kParallelogram = 1, kTexCoord = 5, kNormal = 6 };   // prediction_scheme/mod.rs:74-86
 enum Transform : uint8_t { kDifference = 0, kWrapped = 1, kOctOrth = 3 };              // prediction_transform/mod.rs:92-101
 enum Port : uint8_t { kToBits = 1, kCoordwise = 2, kOct = 3 };                          // portabilization/mod.rs:85-92
+constexpr uint32_t kDeviceRelabelMinFaces = 1u << 17;   // job creation relabels the connectivity inputs with kernels from this size up (dmi_relabel.hip)
 constexpr uint64_t kHostChainMinSymbols = 32768;   // a job whose longest stream is at least this long codes its streams on host cores (hybrid form)
 
 // Device memory of one job comes from a few large chunks (DevPool) instead of one hipMalloc per buffer: job creation for a batch
@@ -241,11 +242,26 @@ dmi_job::~dmi_job() {
 
 namespace {
 
+struct TempDev {   // device temporaries of job creation (outside the job's pool: they are released when creation ends)
+  std::vector<void*> ptrs;
+  ~TempDev() { for (void* q : ptrs) (void)hipFree(q); }
+  template <class T> T* take(size_t n) { void* q = nullptr; if (hipMalloc(&q, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr; ptrs.push_back(q); return static_cast<T*>(q); }
+};
+
+// Host threads the library may use at once in one call: the machine's hardware threads, capped by DMI_HOST_THREADS (read per call:
+// one process per GPU on a shared host sets it to its share, cores / world size).
+unsigned host_threads() {
+  unsigned hw = std::thread::hardware_concurrency();
+  if (!hw) hw = 4;
+  if (const char* e = std::getenv("DMI_HOST_THREADS")) { const int v = std::atoi(e); if (v > 0) hw = std::min<unsigned>(hw, (unsigned)v); }
+  return hw;
+}
+
 // [0, n) in contiguous slices on up to 16 host threads (large, embarrassingly parallel index loops of job creation)
 template <class Fn>
 void parallel_for(size_t n, Fn&& fn) {
-  unsigned hw = std::thread::hardware_concurrency();
-  const size_t n_threads = n < (1u << 20) ? 1 : std::max<size_t>(1, std::min<size_t>({hw ? hw : 4u, 16u, n >> 18}));
+  const unsigned hw = host_threads();
+  const size_t n_threads = n < (1u << 20) ? 1 : std::max<size_t>(1, std::min<size_t>({hw, 16u, n >> 18}));
   if (n_threads == 1) { fn((size_t)0, n); return; }
   std::vector<std::thread> th;
   for (size_t t = 0; t < n_threads; ++t) th.emplace_back([&, t] { fn(n * t / n_threads, n * (t + 1) / n_threads); });
@@ -477,12 +493,69 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
       seq = host_seq[i].data();
       n_seq = (uint32_t)host_seq[i].size();
     }
-    for (uint32_t k = 0; k < n_seq; ++k) if (seq[k] >= C) return fail(DMI_ERR_INVALID_ARGUMENT, "sequence entry out of range");
+    {
+      std::atomic<int> bad_seq{0};
+      parallel_for(n_seq, [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) if (seq[k] >= C) { bad_seq.store(1); break; } });
+      if (bad_seq) return fail(DMI_ERR_INVALID_ARGUMENT, "sequence entry out of range");
+    }
     t.n_seq = n_seq;
     seq_of[i] = seq;
   }
   const double t_seq = since_ms(tc0);
-  {
+  // Large meshes are relabelled by kernels (dmi_relabel.hip): the caller's arrays go up as they are and the rank scatter, the face
+  // keys, the stable sort and the corner remaps run on the device — what remains on the host is validation and the PCIe upload.
+  // Small meshes (launch-bound: a batch creates thousands of jobs on host threads) keep the host form below.  Same arrays either way.
+  bool device_relabel = F >= kDeviceRelabelMinFaces;
+  if (const char* e = std::getenv("DMI_RELABEL")) device_relabel = std::strcmp(e, "device") == 0 ? true : (std::strcmp(e, "host") == 0 ? false : device_relabel);
+  TempDev tmpdev;
+  uint32_t* d_bad = nullptr;        // device flag: a point_to_value entry out of range (device form)
+  uint32_t* d_max_point = nullptr;  // device word: largest point index the faces reference (device form)
+  if (device_relabel) {
+    uint32_t max_seq = 0, max_v = 0;
+    for (uint32_t i = 0; i < n_atts; ++i) if (job->tables[i].alias_of < 0) { max_seq = std::max(max_seq, job->tables[i].n_seq); max_v = std::max(max_v, job->tables[i].V); }
+    uint32_t* d_c2p = tmpdev.take<uint32_t>(C);
+    uint32_t* d_c2v = tmpdev.take<uint32_t>(C);
+    uint32_t* d_opp = tmpdev.take<uint32_t>(C);
+    uint32_t* d_seq = tmpdev.take<uint32_t>(max_seq);
+    uint32_t* d_rank = tmpdev.take<uint32_t>(max_v);
+    uint32_t* d_key = tmpdev.take<uint32_t>(F);
+    uint32_t* d_key2 = tmpdev.take<uint32_t>(F);
+    uint32_t* d_face = tmpdev.take<uint32_t>(F);
+    uint32_t* d_order = tmpdev.take<uint32_t>(F);
+    uint32_t* d_new_face = tmpdev.take<uint32_t>(F);
+    uint32_t* d_words = tmpdev.take<uint32_t>(4);
+    const uint32_t none_key = job->tables[0].n_seq;   // faces none of whose vertices was coded sort last
+    int key_bits = 1;
+    while (key_bits < 32 && (1ull << key_bits) <= none_key) ++key_bits;
+    const size_t sort_bytes = sort_faces_temp_bytes(F, key_bits);
+    void* d_sort = tmpdev.take<uint8_t>(sort_bytes);
+    if (!d_c2p || !d_c2v || !d_opp || !d_seq || !d_rank || !d_key || !d_key2 || !d_face || !d_order || !d_new_face || !d_words || !d_sort)
+      return fail(DMI_ERR_OUT_OF_MEMORY, "hipMalloc (relabelling temporaries)");
+    d_bad = d_words; d_max_point = d_words + 1;
+    HIP_TRY(hipMemsetAsync(d_words, 0, 16, s));
+    HIP_TRY(hipMemcpyAsync(d_c2p, tables[0].corner_to_point, C * 4, hipMemcpyHostToDevice, s));
+    launch_max_u32(d_c2p, C, d_max_point, s);
+    for (uint32_t i = 0; i < n_atts; ++i) {
+      TableDev& t = job->tables[i];
+      if (t.alias_of >= 0) continue;
+      HIP_TRY(hipMemcpyAsync(d_c2v, tables[i].corner_to_vertex, C * 4, hipMemcpyHostToDevice, s));
+      HIP_TRY(hipMemcpyAsync(d_opp, tables[i].opposite, C * 4, hipMemcpyHostToDevice, s));
+      if (t.n_seq) HIP_TRY(hipMemcpyAsync(d_seq, seq_of[i], (size_t)t.n_seq * 4, hipMemcpyHostToDevice, s));
+      launch_fill_u32(d_rank, t.V, kNone, s);
+      launch_rank_scatter(d_seq, t.n_seq, d_c2v, d_rank, s);
+      if (i == 0) {   // the face order comes from the universal table
+        launch_face_keys(d_c2v, d_rank, F, none_key, d_key, d_face, s);
+        HIP_TRY(launch_sort_faces(d_sort, sort_bytes, d_key, d_key2, d_face, d_order, F, key_bits, s));
+        launch_new_face(d_order, F, d_new_face, s);
+      }
+      if ((rc = t.c2r.alloc(C * 4))) return rc;
+      if ((rc = t.opp.alloc(C * 4))) return rc;
+      if ((rc = t.seq.alloc((size_t)t.n_seq * 4))) return rc;
+      if ((rc = t.s2p.alloc((size_t)t.n_seq * 4))) return rc;
+      launch_remap_table(d_c2v, d_opp, d_rank, d_order, d_new_face, C, t.c2r.as<uint32_t>(), t.opp.as<uint32_t>(), s);
+      launch_remap_seq(d_seq, t.n_seq, d_new_face, d_c2p, t.seq.as<uint32_t>(), t.s2p.as<uint32_t>(), s);
+    }
+  } else {
     // face order from table 0 (the universal table)
     // (scratch arrays are allocated uninitialised and first touched by the threads that fill them)
     auto raw_u32 = [](size_t n) { return std::unique_ptr<uint32_t[]>(new uint32_t[n ? n : 1]); };
@@ -565,7 +638,19 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
     launch_build_fans(t.seq.as<uint32_t>(), t.n_seq, t.c2r.as<uint32_t>(), t.opp.as<uint32_t>(), t.fan_hdr.as<uint32_t>(), t.fan_apex.as<uint32_t>(), t.fan.as<uint32_t>(), false, s);
   }
   uint32_t max_point = 0;
-  for (size_t c = 0; c < C; ++c) max_point = std::max(max_point, tables[0].corner_to_point[c]);
+  if (device_relabel) {
+    HIP_TRY(hipMemcpyAsync(&max_point, d_max_point, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  } else {
+    std::atomic<uint32_t> mp{0};
+    parallel_for(C, [&](size_t lo, size_t hi) {
+      uint32_t m = 0;
+      for (size_t c = lo; c < hi; ++c) m = std::max(m, tables[0].corner_to_point[c]);
+      uint32_t cur = mp.load();
+      while (m > cur && !mp.compare_exchange_weak(cur, m)) {}
+    });
+    max_point = mp.load();
+  }
   size_t pinned_need = 0;
   uint64_t pb = 0;
   for (uint32_t i = 0; i < n_atts; ++i) {
@@ -577,7 +662,13 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
     rc = upload(a.raw, d.values, vbytes, s);
     if (rc) return rc;
     if (d.num_points <= max_point && F) return fail(DMI_ERR_INVALID_ARGUMENT, "attribute " + std::to_string(i) + " has fewer points than the faces reference");
-    if (d.point_to_value) {   // sequence index → value index: the map composed with the table's sequence → point array
+    if (d.point_to_value && device_relabel) {   // sequence index → value index, composed on the device; out-of-range entries raise d_bad
+      uint32_t* d_p2v = tmpdev.take<uint32_t>(d.num_points);
+      if (!d_p2v) return fail(DMI_ERR_OUT_OF_MEMORY, "hipMalloc (point_to_value upload)");
+      HIP_TRY(hipMemcpyAsync(d_p2v, d.point_to_value, (size_t)d.num_points * 4, hipMemcpyHostToDevice, s));
+      if ((rc = a.s2v.alloc((size_t)t.n_seq * 4))) return rc;
+      launch_compose_s2v(t.s2p.as<uint32_t>(), t.n_seq, d_p2v, d.num_points, d.num_unique, a.s2v.as<uint32_t>(), d_bad, s);
+    } else if (d.point_to_value) {   // sequence index → value index: the map composed with the table's sequence → point array
       std::vector<uint32_t> s2v(t.n_seq);
       for (uint32_t k = 0; k < t.n_seq; ++k) {
         s2v[k] = d.point_to_value[t.s2p_host[k]];
@@ -664,8 +755,11 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
     for (auto& e : job->ev) HIP_TRY(hipEventCreate(&e));
     job->have_events = true;
   }
+  uint32_t bad_p2v = 0;
+  if (d_bad) HIP_TRY(hipMemcpyAsync(&bad_p2v, d_bad, 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  if (trace_create) std::fprintf(stderr, "[dmi] job create (%u faces): sequences %.1f ms, relabel + table uploads %.1f, attribute uploads + buffers + fan rows %.1f, stream + plan %.1f\n", F, t_seq, t_relabel, since_ms(tc0) - t_seq - t_relabel,
+  if (bad_p2v) return fail(DMI_ERR_INVALID_ARGUMENT, "point_to_value entry out of range");
+  if (trace_create) std::fprintf(stderr, "[dmi] job create (%u faces, %s relabelling): sequences %.1f ms, relabel + table uploads %.1f, attribute uploads + buffers + fan rows %.1f, stream + plan %.1f\n", F, device_relabel ? "device" : "host", t_seq, t_relabel, since_ms(tc0) - t_seq - t_relabel,
                                  std::chrono::duration<double, std::milli>(tc0 - t_enter).count());
   *job_out = job.release();
   return DMI_OK;
@@ -1286,8 +1380,7 @@ static int encode_tail_host(dmi_job* job, dmi_buffer* out, float* chain_ms, floa
     }
   };
   {
-    unsigned hw = std::thread::hardware_concurrency();
-    const size_t n_threads = std::max<size_t>(1, std::min<size_t>({streams.size(), hw ? hw : 4u, 16u}));
+    const size_t n_threads = std::max<size_t>(1, std::min<size_t>({streams.size(), (size_t)host_threads(), (size_t)16}));
     std::vector<std::thread> th;
     for (size_t t = 1; t < n_threads; ++t) th.emplace_back(work);
     work();
@@ -1867,9 +1960,8 @@ static int jobs_encode_impl(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
   const int device = jobs[0]->cfg.device;
   // Small meshes are launch-bound, so whatever stays per job (table normalisation; the phases of jobs that cannot be planned ahead) runs on several host
   // threads, each walking a contiguous slice of the jobs (jobs that own their stream then also overlap on the GPU).
-  unsigned hw = std::thread::hardware_concurrency();
   static const uint32_t thread_cap = std::getenv("DMI_BATCH_THREADS") ? (uint32_t)std::atoi(std::getenv("DMI_BATCH_THREADS")) : 16u;
-  const uint32_t n_threads = std::max(1u, std::min({n, hw ? hw : 4u, std::max(1u, thread_cap)}));
+  const uint32_t n_threads = std::max(1u, std::min({n, (uint32_t)host_threads(), std::max(1u, thread_cap)}));
   auto parallel = [&](auto&& fn, bool sync_after = true) -> int {
     std::vector<int> rcs(n_threads, DMI_OK);
     std::vector<std::string> errs(n_threads);
@@ -2179,8 +2271,7 @@ int dmi_mesh_prepare(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buffer* he
 int dmi_meshes_prepare(const dmi_mesh* meshes, uint32_t n, const dmi_config* cfg, dmi_buffer* header_and_connectivity, dmi_job** jobs) {
   if (!meshes || !header_and_connectivity || !jobs || n == 0) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
   for (uint32_t j = 0; j < n; ++j) { jobs[j] = nullptr; header_and_connectivity[j] = dmi_buffer{}; }
-  unsigned hw = std::thread::hardware_concurrency();
-  const uint32_t n_threads = std::max(1u, std::min({n, hw ? hw : 4u, 32u}));
+  const uint32_t n_threads = std::max(1u, std::min({n, (uint32_t)host_threads(), 32u}));
   std::vector<int> rcs(n, DMI_OK);
   std::vector<std::string> errs(n);
   std::atomic<uint32_t> next{0};

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "dmi_device.hpp"
 #include "dmi_host.hpp"
@@ -36,14 +37,24 @@ inline uint32_t flush_bytes(uint32_t s, uint8_t* at) {
   return nb;
 }
 
+// The host form of a coding record: the device record's multiplier m and shift b folded into one 64-bit multiplier, so that the
+// exact quotient is the HIGH HALF of one 64×64 multiply — x / f = (x·m) >> (32 + b) = hi64(x · (m << (32 - b))) — three clocks on
+// the dependency chain instead of multiply, shift, shift.  flags: bit 8 f == 1 (x / f = x), bit 9 f < 2^(P-8) (may shed > 1 byte).
+struct HostRec { uint64_t m64; uint32_t d, c, t, flags; };
+inline HostRec host_rec(const RansEntry& e) {
+  const uint32_t b = e.b & 31u;
+  return HostRec{(uint64_t)e.m << (32u - b), e.d, e.c, e.t, e.b & 0x300u};   // (b ≤ 19: nothing is shifted out; f == 1 never multiplies)
+}
+inline uint32_t quot(uint32_t x, uint64_t m64) { return (uint32_t)(((unsigned __int128)x * m64) >> 64); }
+
 // one step, any renormalisation (≤ 3 bytes: x < 2^30, t ≥ 2^10): the bytes leave low byte first, exactly the reference's loop
-inline uint32_t step_general(uint32_t x, const RansEntry& e, uint8_t*& p) {
+inline uint32_t step_general(uint32_t x, const HostRec& e, uint8_t*& p) {
   const uint64_t t = e.t;
   const uint32_t nb = (uint32_t)(x >= t) + (uint32_t)(x >= (t << 8)) + (uint32_t)(x >= (t << 16));
   std::memcpy(p, &x, 4);   // little-endian host: bytes 0..2 of x in emission order; only nb of them are kept
   p += nb;
   x >>= 8u * nb;
-  const uint32_t q = (e.b & 0x100u) ? x : (mulhi32(x, e.m) >> (e.b & 31u));   // f == 1: x / f = x
+  const uint32_t q = (e.flags & 0x100u) ? x : quot(x, e.m64);   // f == 1: x / f = x
   return x + q * e.d + e.c;
 }
 
@@ -66,6 +77,9 @@ static void rans_chain_impl(const Sym* sym, uint64_t n, const RansEntry* table, 
   out.len = 0; out.err = 0;
   uint32_t x = 4u << precision;
   const uint32_t state0 = x;
+  std::vector<HostRec> recs(bins);
+  for (uint32_t k = 0; k < bins; ++k) recs[k] = host_rec(table[k]);
+  const HostRec* __restrict__ rec = recs.data();
   // the output grows in steps: a block of kBlock symbols sheds at most 3·kBlock bytes (+ 4 of store slack + 4 of flush)
   constexpr uint64_t kBlock = 4096;
   if (!out.reserve(n / 2 + 3 * kBlock + 64)) { out.err = 2; return; }
@@ -81,14 +95,14 @@ static void rans_chain_impl(const Sym* sym, uint64_t n, const RansEntry* table, 
     for (; i > stop; --i) {
       const uint32_t s = (uint32_t)sym[i - 1];
       if (__builtin_expect(s >= bins, 0)) { out.err = 3; return; }
-      const RansEntry e = table[s];
-      if (__builtin_expect((e.b & 0x300u) == 0u, 1)) {
-        // f ≥ 2^(P-8): the state can shed at most one byte (x < 2^(P+10) = t_min·2^8); branch-free — the byte leaves 57 % of the time
+      const HostRec e = rec[s];
+      if (__builtin_expect(e.flags == 0u, 1)) {
+        // f ≥ 2^(P-8): the state can shed at most one byte (x < 2^(P+10) ≤ t·2^8); branch-free — the byte leaves about every other step
         *p = (uint8_t)x;
         const bool r = x >= e.t;
         p += r;
         const uint32_t xs = __builtin_unpredictable(r) ? (x >> 8) : x;
-        x = xs + (mulhi32(xs, e.m) >> (e.b & 31u)) * e.d + e.c;
+        x = (xs + e.c) + quot(xs, e.m64) * e.d;
       } else {
         if (__builtin_expect(e.t == 0u, 0)) { out.err = 3; return; }   // a symbol the table does not code (never after a clean histogram)
         x = step_general(x, e, p);
@@ -115,23 +129,25 @@ void host_rabs_chain(const uint8_t* bits, uint64_t n, const RansEntry* e, HostCh
   uint32_t x = 4096u;
   if (!out.reserve(n + 64)) { out.err = 2; return; }   // ≤ 1 byte per bit (single `if`, rans.rs:97)
   uint8_t* p = out.data;
-  const bool flagged = ((e[0].b | e[1].b) & 0x100u) != 0u;   // p0 ∈ {1, 255}: one of the frequencies is 1
+  const HostRec h[2] = {host_rec(e[0]), host_rec(e[1])};
+  const bool flagged = ((h[0].flags | h[1].flags) & 0x100u) != 0u;   // p0 ∈ {1, 255}: one of the frequencies is 1
   if (!flagged) {
     // both records side by side so that the select is an index, not a branch
-    const uint32_t m[2] = {e[0].m, e[1].m}, b[2] = {e[0].b & 31u, e[1].b & 31u}, d[2] = {e[0].d, e[1].d}, c[2] = {e[0].c, e[1].c}, t[2] = {e[0].t, e[1].t};
+    const uint64_t m[2] = {h[0].m64, h[1].m64};
+    const uint32_t d[2] = {h[0].d, h[1].d}, c[2] = {h[0].c, h[1].c}, t[2] = {h[0].t, h[1].t};
     for (uint64_t i = 0; i < n; ++i) {
       const uint32_t k = bits[i] != 0;
       *p = (uint8_t)x;
       const bool r = x >= t[k];
       p += r;
       const uint32_t xs = __builtin_unpredictable(r) ? (x >> 8) : x;
-      x = xs + (mulhi32(xs, m[k]) >> b[k]) * d[k] + c[k];
+      x = (xs + c[k]) + quot(xs, m[k]) * d[k];
     }
   } else {
     for (uint64_t i = 0; i < n; ++i) {
-      const RansEntry& r = e[bits[i] != 0];
+      const HostRec& r = h[bits[i] != 0];
       if (x >= r.t) { *p++ = (uint8_t)x; x >>= 8; }
-      const uint32_t q = (r.b & 0x100u) ? x : (mulhi32(x, r.m) >> (r.b & 31u));
+      const uint32_t q = (r.flags & 0x100u) ? x : quot(x, r.m64);
       x = x + q * r.d + r.c;
     }
   }

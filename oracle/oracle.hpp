@@ -14,6 +14,7 @@
 // LEB128, rANS/rABS round trips.
 #pragma once
 #include <array>
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -238,8 +239,18 @@ using Blobs = std::map<std::string, std::vector<u8>>;   // named debug dumps for
 std::string encode_attributes(const std::vector<Attribute>& atts, const ConnOutput& conn, const Options& opt, Bytes& w, Blobs* dump);  // encode/attribute/mod.rs:13-93
 std::string encode_mesh(const Mesh& mesh, const Options& opt, Bytes& w, Blobs* dump);   // encode/mod.rs:59-97
 
-// wall-clock seconds of the last encode_mesh: [0] connectivity, [1] attribute section, [2] sequencer part of [1]
-extern double g_stage_seconds[3];
+// wall-clock seconds of the last encode_mesh (BASELINE.md §3 stage split): [0] connectivity, [1] attribute section, [2] sequencer part
+// of [1], [3] corner tables (part of [0]; Edgebreaker + connectivity bytes = [0] - [3]), [4] quantize (portabilization), [5] predict,
+// [6] prediction transform, [7] histogram + table normalisation/serialisation, [8] rANS + rABS coders, [9] symbols through the rANS coder
+constexpr int kStageSlots = 10;
+extern double g_stage_seconds[kStageSlots];
+struct StageTimer {   // adds the scope's wall time to g_stage_seconds[slot]
+  int slot;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  explicit StageTimer(int s) : slot(s) {}
+  ~StageTimer() { g_stage_seconds[slot] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+extern double g_rans_symbols;   // (slot 9's unit)
 
 // helpers shared by .cpp files
 i32 to_positive_i32(i32 v);   // utils/mod.rs:152-158

@@ -9,6 +9,7 @@
 // (wrapping), casts follow Rust `as` (float→int saturating, NaN→0) — quirk Q18.
 #include <algorithm>
 #include <chrono>
+#include <memory>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -299,7 +300,8 @@ PortType port_type_for(AttType t) { return t == Normal ? PortOct : (t == Custom 
 
 }  // namespace
 
-double g_stage_seconds[3] = {0, 0, 0};   // connectivity, attributes (total), of which sequencer
+double g_stage_seconds[kStageSlots] = {0};   // see oracle.hpp
+double g_rans_symbols = 0;
 
 // encode/attribute/mod.rs:13-93
 std::string encode_attributes(const std::vector<Attribute>& atts, const ConnOutput& conn, const Options& opt, Bytes& w, Blobs* dump) {
@@ -358,6 +360,7 @@ std::string encode_attributes(const std::vector<Attribute>& atts, const ConnOutp
     // Portabilization::new + portabilize, :283-299
     Bytes port_info;
     PortAtt pa;
+    std::unique_ptr<StageTimer> t_quant(new StageTimer(4));
     pa.id = att.id; pa.type = att.type; pa.has_map = att.has_map; pa.p2v = &att.p2v; pa.num_unique = att.num_unique();
     const PortType pt = port_type_for(att.type);
     if (pt == PortToBits) {
@@ -407,6 +410,7 @@ std::string encode_attributes(const std::vector<Attribute>& atts, const ConnOutp
         }
       }
     }
+    t_quant.reset();
     if (pa.ncomp < 1 || pa.ncomp > 4) return "UnsupportedNumComponents";
     const int N = pa.ncomp;
 
@@ -424,6 +428,7 @@ std::string encode_attributes(const std::vector<Attribute>& atts, const ConnOutp
       parent = parents[0];
     }
     if (transform == TrOctOrth && N != 2) return "oct transform needs N == 2 (oct_orthogonal.rs:29)";
+    std::unique_ptr<StageTimer> t_pred(new StageTimer(5));
     Ctx cx{tv, seq, pa, parent, opt.faithful, {}, {}};
     cx.record.reserve(seq.size());
     if (!opt.faithful) {
@@ -448,6 +453,8 @@ std::string encode_attributes(const std::vector<Attribute>& atts, const ConnOutp
       for (int j = 0; j < N; ++j) origs[k * N + j] = o[j];
     }
     trace("predicted", flips.size() + orientation.size());
+    t_pred.reset();
+    std::unique_ptr<StageTimer> t_tr(new StageTimer(6));
     // transform: map_with_tentative_metadata + squeeze
     Bytes transform_info;
     std::vector<u32> symbols(seq.size() * N);
@@ -478,6 +485,7 @@ std::string encode_attributes(const std::vector<Attribute>& atts, const ConnOutp
       transform_info.w32(255);
       transform_info.w32(255 / 2);
     }
+    t_tr.reset();
     w.w8(1);   // rans_encoding flag :344
     // symbols are cast `as u64` from i32 (:347-350): a negative i32 would sign-extend to a huge
     // index; the transforms above only produce non-negatives for sane inputs.
@@ -488,6 +496,7 @@ std::string encode_attributes(const std::vector<Attribute>& atts, const ConnOutp
     if (!e.empty()) return e;
 
     auto write_rabs_block = [&](u8 zero_prob, const std::vector<u8>& bits) -> std::string {
+      StageTimer t_rabs(8);
       RabsCoder rc(zero_prob);
       for (u8 b : bits) rc.write(b);
       Bytes b;
@@ -547,7 +556,8 @@ std::string encode_mesh(const Mesh& mesh, const Options& opt, Bytes& w, Blobs* d
   const size_t conn_begin = w.size();
   ConnOutput conn;
   trace("connectivity begin");
-  g_stage_seconds[0] = g_stage_seconds[1] = g_stage_seconds[2] = 0.0;
+  for (double& v : g_stage_seconds) v = 0.0;
+  g_rans_symbols = 0;
   const auto t0 = std::chrono::steady_clock::now();
   std::string e = encode_connectivity(mesh, w, conn);
   if (!e.empty()) return e;

@@ -91,6 +91,8 @@ int orc_encode(void* sp, const int* opts, int want_dump) {
   return g_err.empty() ? 0 : 1;
 }
 void orc_last_stage_seconds(double* out) { out[0] = g_stage_seconds[0]; out[1] = g_stage_seconds[1]; out[2] = g_stage_seconds[2]; }
+// all kStageSlots slots of oracle.hpp + the number of symbols slot 9 coded (out: kStageSlots + 1 doubles)
+void orc_last_stage_split(double* out) { for (int k = 0; k < kStageSlots; ++k) out[k] = g_stage_seconds[k]; out[kStageSlots] = g_rans_symbols; }
 double orc_last_encode_seconds(void* sp) { return static_cast<Session*>(sp)->last_encode_seconds; }
 const uint8_t* orc_drc(void* sp, uint64_t* len) { auto* s = static_cast<Session*>(sp); *len = s->drc.size(); return s->drc.data(); }
 const uint8_t* orc_blob(void* sp, const char* key, uint64_t* len) {

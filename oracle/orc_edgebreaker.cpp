@@ -177,14 +177,18 @@ std::string encode_connectivity(const Mesh& mesh, Bytes& w, ConnOutput& out) {
   const Attribute* pos = nullptr;
   for (auto& a : mesh.atts) if (a.type == Position) { pos = &a; break; }
   if (!pos) return "no position attribute";
-  std::string err = out.ct.build(mesh.faces, *pos);
-  if (!err.empty()) return err;
-  // init_attribute_data :172-193 — one table per non-Position attribute, in attribute order
-  out.att_tables.clear();
-  for (auto& a : mesh.atts) {
-    if (a.type == Position) continue;
-    out.att_tables.emplace_back();
-    out.att_tables.back().build(out.ct, a);
+  std::string err;
+  {
+    StageTimer t_ct(3);
+    err = out.ct.build(mesh.faces, *pos);
+    if (!err.empty()) return err;
+    // init_attribute_data :172-193 — one table per non-Position attribute, in attribute order
+    out.att_tables.clear();
+    for (auto& a : mesh.atts) {
+      if (a.type == Position) continue;
+      out.att_tables.emplace_back();
+      out.att_tables.back().build(out.ct, a);
+    }
   }
   const CornerTable& ct = out.ct;
   EB eb(ct);

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include <numeric>
 
 #include "oracle.hpp"
@@ -148,6 +149,7 @@ static u32 precision_for_bit_length(u32 bit_length) {   // symbol_coding.rs:120-
 // encode_symbols(.., DirectCoded) symbol_coding.rs:17-55,109-166
 std::string encode_symbols_direct(const std::vector<u32>& symbols, Bytes& w) {
   w.w8(1);   // SymbolEncodingMethod::DirectCoded.write_to, shared/entropy/mod.rs:33-36
+  std::unique_ptr<StageTimer> t_tab(new StageTimer(7));
   u64 num_nonzero = 0;
   for (u32 s : symbols) if (s > 0) ++num_nonzero;   // :46 (quirk Q11)
   u32 bl = (u32)(64 - (num_nonzero ? __builtin_clzll(num_nonzero) : 64)) + 1;
@@ -168,6 +170,9 @@ std::string encode_symbols_direct(const std::vector<u32>& symbols, Bytes& w) {
   RansCoder rc;
   e = rc.init(dist, P);
   if (!e.empty()) return e;
+  t_tab.reset();
+  StageTimer t_rans(8), t_rans_only(9);
+  g_rans_symbols += (double)symbols.size();
   for (size_t i = symbols.size(); i-- > 0;) {   // :161-163 reversed
     e = rc.write(symbols[i]);
     if (!e.empty()) return e;
@@ -214,7 +219,8 @@ std::string rans_decode_stream(const u8* data, size_t len, const std::vector<u64
     state = q * dist[s] + r - cum[s];
     out[i] = s;
   }
-  if (pos != 0) return "trailing bytes";
+  // (bytes may remain: when the FIRST symbol the encoder coded is rare, its renormalisation sheds bytes of the initial state, which no
+  //  decoder reads back — the reference's reverse reader simply stops, decode/entropy/rans.rs:58-69)
   return "";
 }
 
@@ -230,8 +236,7 @@ std::string rabs_decode_stream(const u8* data, size_t len, u64 p0, size_t n, std
     u64 x = state, q = x >> 8, r = x & 255, xn = q * f1;
     if (r < f1) { state = xn + r; out[i] = 1; } else { state = x - xn - f1; out[i] = 0; }
   }
-  if (pos != 0) return "trailing bytes";
-  return "";
+  return "";   // (see rans_decode_stream: unread bytes of the initial state are legal)
 }
 
 // decode/entropy/symbol_coding.rs (direct-coded branch) + RansSymbolDecoder::new rans.rs:139-200.

@@ -181,6 +181,15 @@ class Session:
         self.L.orc_last_stage_seconds(_ptr(out))
         return tuple(float(x) for x in out)
 
+    def stage_split(self):
+        """BASELINE.md §3 per-stage split of the last encode (seconds on one host core)."""
+        out = np.zeros(11, np.float64)
+        self.L.orc_last_stage_split(_ptr(out))
+        conn, atts, seq, tables, quant, pred, trans, hist_tab, coders, rans_only, n_rans = (float(x) for x in out)
+        return {"corner_tables_s": tables, "edgebreaker_s": conn - tables, "sequencer_s": seq, "quantize_s": quant, "predict_s": pred, "transform_s": trans,
+                "histogram_and_tables_s": hist_tab, "rans_rabs_coders_s": coders, "attribute_section_s": atts, "connectivity_s": conn,
+                "rans_only_msym_per_s": (n_rans / rans_only / 1e6) if rans_only > 0 else 0.0, "rans_symbols": n_rans}
+
     def blob(self, key, dtype=np.uint8):
         n = C.c_uint64(0)
         p = self.L.orc_blob(self.h, key.encode(), C.byref(n))

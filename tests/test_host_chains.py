@@ -35,8 +35,6 @@ def test_host_rans_stream_equals_the_oracle_coder(precision, n_sym, n, seed):
     live = np.nonzero(f)[0]
     rare = live[np.argsort(f[live])[: max(1, len(live) // 10)]]
     syms[rng.integers(0, n, size=max(1, n // 50))] = rng.choice(rare, size=max(1, n // 50))
-    syms[-1] = int(np.argmax(f))   # (the first symbol coded: a rare one sheds bytes of the INITIAL state, which no decoder reads back — the oracle's
-                                   #  strict inverse reports them as trailing bytes)
     got = dmi.host_rans_stream(f, precision, syms)
     want = orc.rans_encode_raw(f.astype(np.uint64), precision, np.ascontiguousarray(syms[::-1]))   # the reference feeds the symbols in reverse (symbol_coding.rs:161-163)
     assert got == want
