@@ -77,7 +77,7 @@ class _Conn(C.Structure):
 
 
 EXPORTS = ["dmi_encode_attributes", "dmi_encode_attributes_batch", "dmi_jobs_encode", "dmi_job_create", "dmi_job_encode", "dmi_job_timings", "dmi_job_destroy", "dmi_encode_mesh",
-           "dmi_mesh_prepare", "dmi_meshes_prepare", "dmi_mesh_build", "dmi_built_mesh_free", "dmi_encode_connectivity", "dmi_conn_free", "dmi_host_rans_stream", "dmi_host_rabs_stream", "dmi_free", "dmi_free_many", "dmi_strerror", "dmi_last_error", "dmi_device_count"]
+           "dmi_mesh_prepare", "dmi_meshes_prepare", "dmi_shard_meshes", "dmi_meshes_prepare_devices", "dmi_jobs_encode_devices", "dmi_mesh_build", "dmi_built_mesh_free", "dmi_encode_connectivity", "dmi_conn_free", "dmi_host_rans_stream", "dmi_host_rabs_stream", "dmi_free", "dmi_free_many", "dmi_strerror", "dmi_last_error", "dmi_device_count"]
 
 
 def library_path():
@@ -118,6 +118,9 @@ def load_library():
     L.dmi_built_mesh_free.restype = None
     L.dmi_meshes_prepare.argtypes = [C.POINTER(_Mesh), C.c_uint32, C.POINTER(_Config), C.POINTER(_Buffer), C.POINTER(C.c_void_p)]
     L.dmi_encode_connectivity.argtypes = [C.POINTER(_Mesh), C.POINTER(_Buffer), C.POINTER(_Conn)]
+    L.dmi_shard_meshes.argtypes = [C.POINTER(_Mesh), C.c_uint32, C.c_uint32, C.c_void_p]
+    L.dmi_meshes_prepare_devices.argtypes = [C.POINTER(_Mesh), C.c_uint32, C.POINTER(_Config), C.c_void_p, C.POINTER(_Buffer), C.POINTER(C.c_void_p)]
+    L.dmi_jobs_encode_devices.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(_Buffer)]
     L.dmi_conn_free.argtypes = [C.POINTER(_Conn)]
     L.dmi_host_rans_stream.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(_Buffer)]
     L.dmi_host_rabs_stream.argtypes = [C.c_uint8, C.c_void_p, C.c_uint64, C.POINTER(_Buffer)]
@@ -581,6 +584,53 @@ def meshes_prepare(meshes, cfg=None):
 
 def encode_connectivity(mesh):
     return Connectivity(mesh)
+
+
+def shard_meshes(meshes, n_devices):
+    """dmi_shard_meshes: device index per mesh, dealt by triangle count (LPT)."""
+    L = load_library()
+    n = len(meshes)
+    arr = (_Mesh * max(n, 1))()
+    keep = []
+    for i, m in enumerate(meshes):
+        cm = m._c()
+        keep.append(cm)
+        arr[i] = cm
+    out = np.zeros(max(n, 1), np.int32)
+    _check(L.dmi_shard_meshes(arr, n, n_devices, out.ctypes.data))
+    return [int(x) for x in out[:n]]
+
+
+def meshes_prepare_devices(meshes, device_of_mesh, cfg=None):
+    """dmi_meshes_prepare_devices: mesh j prepared on HIP device device_of_mesh[j] (one process, several GPUs)."""
+    L = load_library()
+    cfg = cfg or Config.default()
+    n = len(meshes)
+    if n == 0:
+        return []
+    arr = (_Mesh * n)()
+    keep = []
+    for i, m in enumerate(meshes):
+        cm = m._c()
+        keep.append(cm)
+        arr[i] = cm
+    dev = np.ascontiguousarray(device_of_mesh, dtype=np.int32)
+    assert len(dev) == n
+    c = cfg._c()
+    heads = (_Buffer * n)()
+    handles = (C.c_void_p * n)()
+    _check(L.dmi_meshes_prepare_devices(arr, n, C.byref(c), dev.ctypes.data, heads, handles))
+    return [Job(handles[i], _take(heads[i])) for i in range(n)]
+
+
+def jobs_encode_devices(jobs):
+    """dmi_jobs_encode_devices: one dmi_jobs_encode per device, all devices concurrently; sections in job order."""
+    L = load_library()
+    n = len(jobs)
+    handles = (C.c_void_p * n)(*[j._h for j in jobs])
+    outs = (_Buffer * n)()
+    _check(L.dmi_jobs_encode_devices(handles, n, outs))
+    return [_take(outs[i]) for i in range(n)]
 
 
 def host_rans_stream(freq, precision, symbols):

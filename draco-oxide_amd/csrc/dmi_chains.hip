@@ -53,7 +53,8 @@ __device__ __forceinline__ RansEntry pick(bool one, const RansEntry& e0, const R
 // Also writes one flag per batch of 64 records: "contains a frequency-1 symbol" (each wavefront covers one
 // aligned batch: the grid stride is a multiple of 256).
 __device__ __forceinline__ void k_rans_prep_body(const RansPrepArgs& a, const uint32_t blk_, const uint32_t nblk_) {
-  const uint32_t* __restrict__ sym = a.sym;
+  const void* __restrict__ sym = a.sym;
+  const bool s16 = a.sym16 != 0u;
   const uint64_t n = a.n;
   const RansEntry* __restrict__ table = a.table;
   RansEntry* __restrict__ rec = a.rec;
@@ -61,7 +62,7 @@ __device__ __forceinline__ void k_rans_prep_body(const RansPrepArgs& a, const ui
   const uint64_t n_round = (n + 63) & ~(uint64_t)63;
   for (uint64_t t = (uint64_t)blk_ * 256 + threadIdx.x; t < n_round; t += (uint64_t)nblk_ * 256) {
     RansEntry e{0u, 0u, 0u, 0u, 0u};
-    if (t < n) { const uint32_t v = sym[n - 1 - t]; if (v < a.bins) e = table[v]; rec[t] = e; }
+    if (t < n) { const uint32_t v = s16 ? (uint32_t)static_cast<const uint16_t*>(sym)[n - 1 - t] : static_cast<const uint32_t*>(sym)[n - 1 - t]; if (v < a.bins) e = table[v]; rec[t] = e; }
     const unsigned long long f1 = __ballot((e.b & 0x100u) != 0), multi = __ballot((e.b & 0x200u) != 0);
     if ((threadIdx.x & 63) == 0) batch_flags[t >> 6] = (f1 != 0ull ? 1u : 0u) | (multi != 0ull ? 2u : 0u);
   }
@@ -186,7 +187,7 @@ __device__ __forceinline__ uint32_t table_token(const uint32_t* freq, uint32_t s
   bytes = r >= 64u ? 3u : ((r << 2) | 3u);
   return 1u;
 }
-__device__ __forceinline__ void write_desc(ChainDesc* at, uint32_t kind, uint32_t precision, uint64_t n, const uint32_t* sym, uint32_t one_byte, const RansEntry* table,
+__device__ __forceinline__ void write_desc(ChainDesc* at, uint32_t kind, uint32_t precision, uint64_t n, const void* sym, uint32_t one_byte, const RansEntry* table,
                                            const uint32_t* batch_flags, uint32_t state0, uint8_t* out, uint64_t cap, uint32_t* out_len, uint32_t* ticks) {
   ChainDesc d;
   d.kind = kind; d.precision = precision; d.n = n; d.sym = sym; d.one_byte = one_byte; d.pad0 = 0; d.table = table; d.batch_flags = batch_flags;
@@ -799,8 +800,8 @@ void launch_prep_steps_multi(int id, const void* items, const uint2* block_info,
 // record prep: symbols / bits / orientation flags → coding records, then the per-batch frequency-1 flags of the rABS record streams
 // levels: the table kernel (device form) 0, record prep 1, batch flags of the rABS record streams 2
 void launch_tables(const TableAtt& a, hipStream_t s) { emit_prep(K_TABLES, 0, a, 1u, s); }
-void launch_rans_prep(const uint32_t* sym, uint64_t n, const RansEntry* table, uint32_t bins, RansEntry* rec, uint32_t* batch_flags, hipStream_t s) {
-  RansPrepArgs a{sym, table, rec, batch_flags, n, bins, 0u};
+void launch_rans_prep(const void* sym, bool sym16, uint64_t n, const RansEntry* table, uint32_t bins, RansEntry* rec, uint32_t* batch_flags, hipStream_t s) {
+  RansPrepArgs a{sym, table, rec, batch_flags, n, bins, sym16 ? 1u : 0u};
   emit_prep(K_RANS_PREP, 1, a, n ? grid256(n) : 0u, s);
 }
 void launch_bits_prep(const uint8_t* bits, uint64_t n, RansEntry e0, RansEntry e1, RansEntry* rec, hipStream_t s) {

@@ -14,6 +14,7 @@ namespace dmi {
 // the sink, so that a batch driver can run the SAME phase of many jobs in one multi-item launch (launch_steps_multi).
 // `level` orders the steps of one job: steps of equal level are independent of each other.
 enum KernelId : int { K_RANGES, K_RANGES_FINAL, K_SEQ_QUANT, K_I32_FINAL, K_FUSED_PNU, K_FUSED_PN, K_FUSED_PU, K_FUSED_N,
+                      K_PACKED_PNU, K_PACKED_PN, K_PACKED_PU, K_PACKED_N /* the same sweeps on packed values (QFmt) */,
                       K_PAR1, K_PAR2, K_PAR3, K_PAR4, K_DELTA, K_TEX, K_ORIENT, K_HIST,
                       K_RANS_PREP, K_BITS_PREP, K_ORIENT_PREP, K_BATCH_FLAGS, K_TABLES /* tables + record prep: dmi_chains.hip */, K_COUNT };
 constexpr int kStepLevels = 7;        // data-parallel phases: levels 0..6
@@ -44,7 +45,15 @@ uint32_t seq_quantize_blocks(uint32_t n);   // grid of launch_seq_quantize = par
 // qs[i] = portabilize(raw[s2v ? s2v[i] : s2p[i]]) for every attribute of one corner table (s2p[i] = point_idx(seq[i])) + per-block joint i32 min/max
 // partials (ipartials: int32[2 * seq_quantize_blocks(n)]).  kind: 0 coordinate-wise, 1 octahedral, 2 ToBits.
 constexpr int kMaxGather = 4;
-struct QuantAtt { const float* raw; const uint32_t* s2v; int32_t* qs; int32_t* ipartials; const float* meta; float maxq; int kind; int N; int pad; };
+// Layout of an attribute's quantized values `qs` (one entry per sequence index):
+//   QF_I32  nq int32 per entry (any shape; every kernel reads it)
+//   QF_P64  positions of a fused sweep, ≤ 21 bits: x | y << 21 | z << 42 in one uint64 — a neighbour is ONE aligned 8-byte gather (12-byte rows
+//           straddle 128-byte lines) and the sweep's LDS windows hold 1.5× as many vertices
+//   QF_B16  octahedral normals inside a fused sweep: u | v << 8 in a uint16        QF_H32  texture coordinates inside a fused sweep, ≤ 16 bits: u | v << 16
+// Coordinate-wise and octahedral quantization only produce values in [0, 2^bits) (NaN → 0, ±inf → 0 or the range ends: see quant_coord), so the
+// packed forms lose nothing.  Symbols are stored as uint16 when the attribute's alphabet bound (symbol_bins) fits 16 bits (`sym16`).
+enum QFmt : int { QF_I32 = 0, QF_P64 = 1, QF_B16 = 2, QF_H32 = 3 };
+struct QuantAtt { const float* raw; const uint32_t* s2v; void* qs; int32_t* ipartials; const float* meta; float maxq; int kind; int N; int fmt; };
 struct QuantArgs { QuantAtt a[kMaxGather]; int count; };
 struct SeqQuantArgs { const uint32_t* s2p; uint32_t n; uint32_t pad; QuantArgs q; };
 void launch_seq_quantize(const uint32_t* s2p, uint32_t n, const QuantArgs& args, hipStream_t s);
@@ -53,17 +62,20 @@ void launch_seq_quantize(const uint32_t* s2p, uint32_t n, const QuantArgs& args,
 // coordinates coded on the SAME corner table in one sweep; qs_nrm / qs_uv null = attribute absent.  sym_pos null = a normal
 // attribute alone on its own table (c2r = the position table's array, fan rows built with centre_in_apex).
 struct FusedArgs {
-  const uint32_t* seq; const uint32_t* c2r; const uint32_t* opp; uint32_t n; uint32_t pad;
-  const int32_t* qs_pos; const int32_t* mm_pos; uint32_t* sym_pos;
-  const int32_t* qs_nrm; uint32_t* sym_nrm; uint8_t* flips; uint32_t* counters;
-  const int32_t* qs_uv; const int32_t* mm_uv; uint32_t* sym_uv; uint8_t* orient;
+  const uint32_t* seq; const uint32_t* c2r; const uint32_t* opp; uint32_t n;
+  uint32_t packed;   // 1: qs_pos is QF_P64, qs_nrm QF_B16, qs_uv QF_H32; 0: all QF_I32
+  const void* qs_pos; const int32_t* mm_pos; void* sym_pos;
+  const void* qs_nrm; void* sym_nrm; uint8_t* flips; uint32_t* counters;
+  const void* qs_uv; const int32_t* mm_uv; void* sym_uv; uint8_t* orient;
   const uint32_t* fan_hdr; const uint32_t* fan_apex; const uint32_t* fan;   // fan rows of the table (launch_build_fans)
+  uint32_t sym16;    // bit 0 / 1 / 2: sym_pos / sym_nrm / sym_uv are uint16 arrays
+  uint32_t pad;
 };
 void launch_predict_fused(const FusedArgs& a, hipStream_t s);
-struct ParArgs { const uint32_t* seq; const uint32_t* c2r; const uint32_t* opp; const int32_t* qs; const int32_t* minmax; uint32_t* sym; uint32_t n; uint32_t pad; };
-struct DeltaArgs { uint64_t n_comp; const int32_t* qs; uint32_t* sym; int N; int pad; };
-struct TexArgs { const uint32_t* seq; const uint32_t* c2r; const int32_t* qs; const uint32_t* c2r_pos; const int32_t* qs_pos; const int32_t* minmax; uint32_t* sym;
-                 uint8_t* orient; uint32_t n; uint32_t pad; };
+struct ParArgs { const uint32_t* seq; const uint32_t* c2r; const uint32_t* opp; const int32_t* qs; const int32_t* minmax; void* sym; uint32_t n; uint32_t sym16; };
+struct DeltaArgs { uint64_t n_comp; const int32_t* qs; void* sym; int N; int sym16; };
+struct TexArgs { const uint32_t* seq; const uint32_t* c2r; const int32_t* qs; const uint32_t* c2r_pos; const void* qs_pos /* QF_I32 or QF_P64: pos_fmt */; const int32_t* minmax; void* sym;
+                 uint8_t* orient; uint32_t n; uint32_t sym16; int pos_fmt; int pad; };
 struct OrientArgs { const uint8_t* orient; uint32_t* summary; uint32_t n; uint32_t pad; };
 // Per coded vertex, in coding order: hdr[n], apex[n], fan[8n] (32-byte aligned) — see k_build_fans.  Once per job.
 // centre_in_apex: apex[i] = c2r[seq[i]] (the fan centre's rank) instead of the rank across the opposite edge — for a normal
@@ -74,11 +86,11 @@ void launch_build_fans(const uint32_t* seq, uint32_t n, const uint32_t* c2r, con
 // ---- predict + transform (a7-a14) → symbols ------------------------------------------------------
 // c2r[c] = sequence index of corner c's vertex (DMI_NONE if never coded): "already coded" ⇔ c2r[c] < i
 void launch_pred_parallelogram_wrapped(const uint32_t* seq, uint32_t n, const uint32_t* c2r, const uint32_t* opp,
-                                       const int32_t* qs, const int32_t* minmax, int N, uint32_t* sym, hipStream_t s);
-void launch_pred_delta_difference(uint32_t n, const int32_t* qs, int N, uint32_t* sym, hipStream_t s);
+                                       const int32_t* qs, const int32_t* minmax, int N, void* sym, bool sym16, hipStream_t s);
+void launch_pred_delta_difference(uint32_t n, const int32_t* qs, int N, void* sym, bool sym16, hipStream_t s);
 // orient[i]: 0 = no bit pushed, 1 = false, 2 = true
 void launch_pred_texcoord_wrapped(const uint32_t* seq, uint32_t n, const uint32_t* c2r, const int32_t* qs, const uint32_t* c2r_pos,
-                                  const int32_t* qs_pos, const int32_t* minmax, uint32_t* sym, uint8_t* orient, hipStream_t s);
+                                  const void* qs_pos, int pos_fmt, const int32_t* minmax, void* sym, bool sym16, uint8_t* orient, hipStream_t s);
 // per-block summaries of the orientation flags, stitched on the host:
 // summary[b] = {valid_count, first_value(0/1, 2 = none), last_value, internal_transitions}
 void launch_orient_summary(const uint8_t* orient, uint32_t n, uint32_t* summary, uint32_t* n_blocks_out_host, hipStream_t s);
@@ -86,7 +98,7 @@ uint32_t orient_summary_blocks(uint32_t n);
 
 // ---- histogram (a16) -------------------------------------------------------------------------------
 // histograms (pre-zeroed) of up to kMaxRangeAtts symbol streams in one launch; *overflow |= 1 when a symbol ≥ bins is met
-struct HistAtt { const uint32_t* sym; uint64_t n; uint32_t* hist; uint32_t* overflow; uint32_t bins; uint32_t first_block, blocks, pad; };
+struct HistAtt { const void* sym; uint64_t n; uint32_t* hist; uint32_t* overflow; uint32_t bins; uint32_t first_block, blocks, sym16; };
 // `orient` (optional, orient.orient != null): the orientation-flag summaries of one texture-coordinate attribute, computed by extra
 // blocks of the same launch (launch_orient_summary is the standalone form)
 struct HistArgs { HistAtt a[kMaxRangeAtts]; int count; uint32_t hist_blocks; OrientArgs orient; };
@@ -113,7 +125,7 @@ __host__ __device__ inline RansEntry make_rans_entry(uint32_t f, uint32_t cum, u
   return e;
 }
 // batch_flags: (n + 63) / 64 + 1 words; [b] != 0 ⇔ batch b holds a frequency-1 symbol
-void launch_rans_prep(const uint32_t* sym, uint64_t n, const RansEntry* table, uint32_t bins, RansEntry* rec, uint32_t* batch_flags, hipStream_t s);
+void launch_rans_prep(const void* sym, bool sym16, uint64_t n, const RansEntry* table, uint32_t bins, RansEntry* rec, uint32_t* batch_flags, hipStream_t s);
 void launch_batch_flags(const RansEntry* rec, uint64_t n, const uint32_t* n_dev, uint32_t* batch_flags, hipStream_t s);
 void launch_bits_prep(const uint8_t* bits, uint64_t n, RansEntry e0, RansEntry e1, RansEntry* rec, hipStream_t s);
 void launch_bits_prep_dev(const uint8_t* bits, uint64_t n, const RansEntry* entries, RansEntry* rec, hipStream_t s);   // record pair in device memory
@@ -126,7 +138,7 @@ struct ChainDesc {
   uint32_t kind;            // 0 = rANS over coding records, 1 = rABS over flips (forward), 2 = rABS over orientation flags
   uint32_t precision;       // rANS precision bits
   uint64_t n;               // symbols / entries
-  const uint32_t* sym;      // unused by the kernel (kept for debugging)
+  const void* sym;          // unused by the kernel (kept for debugging)
   uint32_t one_byte;        // kind 0: 1 = almost every batch is free of rare symbols (f < 2^(P-8)): take the one-byte-renormalisation step
   uint32_t pad0;
   const RansEntry* table;   // kind 0: n coding records in coding order (k_rans_prep output)
@@ -148,7 +160,7 @@ void launch_chains(const ChainDesc* descs_dev, const uint32_t* order_dev, uint32
 // `bins`: symbols ≥ bins (only possible after a histogram overflow, which is reported as an error) take an all-zero record.
 // `entries` (nullable): {record of bit 0, record of bit 1} in device memory (written by k_tables) instead of e0 / e1;
 // `n_dev` (nullable): the record count in device memory (texture-coordinate orientation streams, whose length the device finds).
-struct RansPrepArgs { const uint32_t* sym; const RansEntry* table; RansEntry* rec; uint32_t* batch_flags; uint64_t n; uint32_t bins; uint32_t pad; };
+struct RansPrepArgs { const void* sym; const RansEntry* table; RansEntry* rec; uint32_t* batch_flags; uint64_t n; uint32_t bins; uint32_t sym16; };
 struct BitsPrepArgs { const uint8_t* bits; RansEntry* rec; uint64_t n; RansEntry e0, e1; const RansEntry* entries; };
 struct OrientPrepArgs { const uint8_t* orient; const uint32_t* chunk_info; RansEntry* rec; RansEntry e0, e1; uint32_t n; uint32_t pad; const RansEntry* entries;
                         uint8_t* bits_out; /* nullable: the compacted transition bits themselves (1 byte each) instead of coding records — host-core chains */ };
@@ -163,7 +175,7 @@ struct BatchFlagsArgs { const RansEntry* rec; uint32_t* batch_flags; uint64_t n;
 struct TableAtt {
   const uint32_t* hist; uint32_t* freq /* scratch: bins words */; RansEntry* rtable; uint8_t* hdr; uint32_t* small;
   uint64_t n_sym; uint32_t bins; uint32_t hdr_cap;
-  ChainDesc* desc; const uint32_t* sym; const RansEntry* rec; const uint32_t* batch_flags; uint8_t* out; uint64_t out_cap;   // the rANS stream
+  ChainDesc* desc; const void* sym; const RansEntry* rec; const uint32_t* batch_flags; uint8_t* out; uint64_t out_cap;   // the rANS stream
   uint32_t aux_kind /* 0 none, 1 normal flips, 2 texture-coordinate orientations */; uint32_t n_entries /* sequence entries */;
   const uint32_t* summary; uint32_t* chunk_info; RansEntry* aux_entries; uint32_t summary_blocks; uint32_t pad;
   ChainDesc* aux_desc; const RansEntry* aux_rec; const uint32_t* aux_flags; uint8_t* aux_out; uint64_t aux_cap;

@@ -75,6 +75,25 @@ __device__ __forceinline__ uint32_t zigzag(int32_t v) {   // utils/mod.rs:152-15
   return v >= 0 ? ((uint32_t)v << 1) : ((((uint32_t)(-(v + 1))) << 1) + 1u);
 }
 
+// ---- layouts of quantized values and symbols (QFmt, sym16: dmi_device.hpp) ----
+__device__ __forceinline__ uint64_t pack_p64(int32_t x, int32_t y, int32_t z) { return (uint64_t)(uint32_t)x | ((uint64_t)(uint32_t)y << 21) | ((uint64_t)(uint32_t)z << 42); }
+__device__ __forceinline__ void unpack_p64(uint64_t v, int32_t (&out)[3]) {
+  out[0] = (int32_t)((uint32_t)v & 0x1FFFFFu); out[1] = (int32_t)((uint32_t)(v >> 21) & 0x1FFFFFu); out[2] = (int32_t)((uint32_t)(v >> 42) & 0x1FFFFFu);
+}
+// quantized position of sequence entry r (zeros for a missing rank) from a QF_I32 or QF_P64 array
+__device__ __forceinline__ void load_pos_fmt(const void* __restrict__ q, int fmt, uint32_t r, int32_t (&out)[3]) {
+  if (r == 0xFFFFFFFFu) { out[0] = 0; out[1] = 0; out[2] = 0; }
+  else if (fmt == QF_P64) unpack_p64(static_cast<const uint64_t*>(q)[r], out);
+  else { const int32_t* p = static_cast<const int32_t*>(q) + (size_t)r * 3; out[0] = p[0]; out[1] = p[1]; out[2] = p[2]; }
+}
+__device__ __forceinline__ void store_sym(void* __restrict__ sym, bool s16, size_t idx, uint32_t v) {
+  if (s16) __builtin_nontemporal_store((uint16_t)v, static_cast<uint16_t*>(sym) + idx);
+  else __builtin_nontemporal_store(v, static_cast<uint32_t*>(sym) + idx);
+}
+__device__ __forceinline__ uint32_t load_sym(const void* __restrict__ sym, bool s16, uint64_t idx) {
+  return s16 ? (uint32_t)static_cast<const uint16_t*>(sym)[idx] : static_cast<const uint32_t*>(sym)[idx];
+}
+
 // ------------------------------------------------------------------------------------------------
 // min / max of f32 components, both seeded with +0.0 (quirk Q1).  Reductions use the reference's
 // own comparisons (`<`, `>`): a partial can never be -0.0 or NaN, so the tree order is irrelevant.
@@ -293,7 +312,11 @@ __device__ __forceinline__ void quantize_tile(const QuantAtt& a, const uint32_t 
       for (int k = 0; k < N; ++k) out[k] = __float_as_int(raw[t][k]);
     }
     if (i < n) {
-      for (int k = 0; k < nq; ++k) { a.qs[(size_t)i * nq + k] = out[k]; mn = min(mn, out[k]); mx = max(mx, out[k]); }
+      for (int k = 0; k < nq; ++k) { mn = min(mn, out[k]); mx = max(mx, out[k]); }
+      if (a.fmt == QF_P64) { if (N == 3) static_cast<uint64_t*>(a.qs)[i] = pack_p64(out[0], out[1], out[2]); }
+      else if (a.fmt == QF_B16) static_cast<uint16_t*>(a.qs)[i] = (uint16_t)((uint32_t)out[0] | ((uint32_t)out[1] << 8));
+      else if (a.fmt == QF_H32) static_cast<uint32_t*>(a.qs)[i] = (uint32_t)out[0] | ((uint32_t)out[1] << 16);
+      else { int32_t* q = static_cast<int32_t*>(a.qs); for (int k = 0; k < nq; ++k) q[(size_t)i * nq + k] = out[k]; }
     }
   }
 }
@@ -384,7 +407,8 @@ __device__ __forceinline__ void k_pred_parallelogram_wrapped_body(const ParArgs&
   const uint32_t* __restrict__ opp = pa.opp;
   const int32_t* __restrict__ qs = pa.qs;
   const int32_t* __restrict__ minmax = pa.minmax;
-  uint32_t* __restrict__ sym = pa.sym;
+  void* __restrict__ sym = pa.sym;
+  const bool s16 = pa.sym16 != 0u;
   const WrapParams w = wrap_params(minmax);
   DMI_FOR_SEQUENCE(i, n) {
     const uint32_t c = seq[i];
@@ -405,7 +429,7 @@ __device__ __forceinline__ void k_pred_parallelogram_wrapped_body(const ParArgs&
       for (int k = 0; k < N; ++k) pred[k] = (i > 0) ? qs[(size_t)(i - 1) * N + k] : 0;
     }
 #pragma unroll
-    for (int k = 0; k < N; ++k) sym[(size_t)i * N + k] = wrap_symbol(qs[(size_t)i * N + k], pred[k], w);
+    for (int k = 0; k < N; ++k) store_sym(sym, s16, (size_t)i * N + k, wrap_symbol(qs[(size_t)i * N + k], pred[k], w));
   }
 }
 
@@ -413,10 +437,11 @@ __device__ __forceinline__ void k_pred_delta_difference_body(const DeltaArgs& da
   const uint64_t n_comp = da.n_comp;
   const int N = da.N;
   const int32_t* __restrict__ qs = da.qs;
-  uint32_t* __restrict__ sym = da.sym;
+  void* __restrict__ sym = da.sym;
+  const bool s16 = da.sym16 != 0;
   for (uint64_t e = (uint64_t)blk_ * kBlock + threadIdx.x; e < n_comp; e += (uint64_t)nblk_ * kBlock) {
     const int32_t pred = (e >= (uint64_t)N) ? qs[e - N] : 0;
-    sym[e] = zigzag(wsub(qs[e], pred));
+    store_sym(sym, s16, e, zigzag(wsub(qs[e], pred)));
   }
 }
 
@@ -649,9 +674,11 @@ __device__ __forceinline__ void k_pred_texcoord_wrapped_body(const TexArgs& ta, 
   const uint32_t* __restrict__ c2r = ta.c2r;
   const int32_t* __restrict__ qs = ta.qs;
   const uint32_t* __restrict__ c2r_pos = ta.c2r_pos;
-  const int32_t* __restrict__ qs_pos = ta.qs_pos;
+  const void* __restrict__ qs_pos = ta.qs_pos;
+  const int pos_fmt = ta.pos_fmt;
   const int32_t* __restrict__ minmax = ta.minmax;
-  uint32_t* __restrict__ sym = ta.sym;
+  void* __restrict__ sym = ta.sym;
+  const bool s16 = ta.sym16 != 0u;
   uint8_t* __restrict__ orient = ta.orient;
   const WrapParams w = wrap_params(minmax);
   const bool shared = (c2r_pos == c2r);   // both attributes on one table: the position ranks are i, rn, rp themselves
@@ -678,10 +705,9 @@ __device__ __forceinline__ void k_pred_texcoord_wrapped_body(const TexArgs& ta, 
       pu[t][0] = qs[ip_]; pu[t][1] = qs[ip_ + 1];
       lastv[t][0] = qs[(size_t)prev * 2]; lastv[t][1] = qs[(size_t)prev * 2 + 1];
       // positions are only read when both neighbours are coded; a missing rank (never coded) reads as zero
-      const size_t jc = (size_t)((both[t] && qc[t] != kNoneD) ? qc[t] : 0u) * 3, jn = (size_t)((both[t] && qn[t] != kNoneD) ? qn[t] : 0u) * 3,
-                   jp = (size_t)((both[t] && qp[t] != kNoneD) ? qp[t] : 0u) * 3;
-#pragma unroll
-      for (int d = 0; d < 3; ++d) { cp[t][d] = qs_pos[jc + d]; np[t][d] = qs_pos[jn + d]; pp[t][d] = qs_pos[jp + d]; }
+      load_pos_fmt(qs_pos, pos_fmt, (both[t] && qc[t] != kNoneD) ? qc[t] : 0u, cp[t]);
+      load_pos_fmt(qs_pos, pos_fmt, (both[t] && qn[t] != kNoneD) ? qn[t] : 0u, np[t]);
+      load_pos_fmt(qs_pos, pos_fmt, (both[t] && qp[t] != kNoneD) ? qp[t] : 0u, pp[t]);
     }
 #pragma unroll
     for (int t = 0; t < kTexTile; ++t) {
@@ -703,8 +729,8 @@ __device__ __forceinline__ void k_pred_texcoord_wrapped_body(const TexArgs& ta, 
         else { pred0 = 0; pred1 = 0; }
       }
       orient[i[t]] = oflag;
-      sym[(size_t)i[t] * 2] = wrap_symbol(cu[t][0], pred0, w);
-      sym[(size_t)i[t] * 2 + 1] = wrap_symbol(cu[t][1], pred1, w);
+      store_sym(sym, s16, (size_t)i[t] * 2, wrap_symbol(cu[t][0], pred0, w));
+      store_sym(sym, s16, (size_t)i[t] * 2 + 1, wrap_symbol(cu[t][1], pred1, w));
     }
   }
 }
@@ -721,17 +747,19 @@ __device__ __forceinline__ void k_pred_texcoord_wrapped_body(const TexArgs& ta, 
 // Results are identical to the per-attribute kernels (k_pred_parallelogram_wrapped<3>, k_predict_fused<0,1,0>,
 // k_pred_texcoord_wrapped): the tests run both paths against the oracle.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void load3(const int32_t* __restrict__ q, uint32_t r, int32_t (&out)[3]) {
-  if (r != kNoneD) { out[0] = q[(size_t)r * 3]; out[1] = q[(size_t)r * 3 + 1]; out[2] = q[(size_t)r * 3 + 2]; }
-  else { out[0] = 0; out[1] = 0; out[2] = 0; }
-}
-// sum += cross(a - c, b - c): i32 wrapping terms, widened to i64 (wrapping sum)
+// sum += cross(a - c, b - c): i32 wrapping terms, widened to i64 (wrapping sum).
+// M24: the operands are differences of values below 2^21 (QF_P64 positions), so they fit 24 signed bits and the low 32 bits of their
+// product — all the wrapping multiply keeps — come from the full-rate 24-bit multiplier (v_mul_i32_i24) instead of the quarter-rate
+// 32-bit one: six multiplies per fan face are a fifth of the sweep's vector work.
+template <bool M24>
+__device__ __forceinline__ int32_t mul_w(int32_t a, int32_t b) { return M24 ? __mul24(a, b) : wmul(a, b); }
+template <bool M24>
 __device__ __forceinline__ void add_face_normal(const int32_t (&a)[3], const int32_t (&b)[3], const int32_t (&c)[3], int64_t (&sum)[3]) {
   const int32_t ax = wsub(a[0], c[0]), ay = wsub(a[1], c[1]), az = wsub(a[2], c[2]);
   const int32_t bx = wsub(b[0], c[0]), by = wsub(b[1], c[1]), bz = wsub(b[2], c[2]);
-  sum[0] = wadd64(sum[0], (int64_t)wsub(wmul(ay, bz), wmul(az, by)));
-  sum[1] = wadd64(sum[1], (int64_t)wsub(wmul(az, bx), wmul(ax, bz)));
-  sum[2] = wadd64(sum[2], (int64_t)wsub(wmul(ax, by), wmul(ay, bx)));
+  sum[0] = wadd64(sum[0], (int64_t)wsub(mul_w<M24>(ay, bz), mul_w<M24>(az, by)));
+  sum[1] = wadd64(sum[1], (int64_t)wsub(mul_w<M24>(az, bx), mul_w<M24>(ax, bz)));
+  sum[2] = wadd64(sum[2], (int64_t)wsub(mul_w<M24>(ax, by), mul_w<M24>(ay, bx)));
 }
 
 // Fan sum of cross(pos[next] - pos_c, pos[prev] - pos_c) over every face around the vertex of corner c
@@ -741,10 +769,12 @@ __device__ __forceinline__ void add_face_normal(const int32_t (&a)[3], const int
 // face (next = A, prev = B) lands in the face (next = new vertex, prev = A); swinging left lands in (next = B, prev =
 // new vertex): one new vertex per face.  The three dependent fetches of a face (opp hop → rank of the new vertex → its
 // position) are software-pipelined across rounds, so a fan of valence v costs ≈ v/2 + 3 memory latencies, not 3v.
+template <bool PACKED>
 __device__ __forceinline__ void fan_normal_sum(uint32_t c, const uint32_t* __restrict__ opp, const uint32_t* __restrict__ c2r_pos,
-                                               const int32_t* __restrict__ qs_pos, const int32_t (&Pc)[3], const int32_t (&Pn)[3], const int32_t (&Pp)[3],
+                                               const void* __restrict__ qs_pos, const int32_t (&Pc)[3], const int32_t (&Pn)[3], const int32_t (&Pp)[3],
                                                int64_t (&sum)[3]) {
-  add_face_normal(Pn, Pp, Pc, sum);
+  constexpr int fmt = PACKED ? QF_P64 : QF_I32;
+  add_face_normal<PACKED>(Pn, Pp, Pc, sum);
   uint32_t curR = c, curL = c;
   bool actR = true, actL = true;
   uint32_t s1R = kNoneD, s1L = kNoneD;          // stage 1: corner of the new vertex, rank not fetched yet
@@ -759,11 +789,11 @@ __device__ __forceinline__ void fan_normal_sum(uint32_t c, const uint32_t* __res
     const uint32_t rkR = s1R != kNoneD ? c2r_pos[s1R] : kNoneD;
     const uint32_t rkL = s1L != kNoneD ? c2r_pos[s1L] : kNoneD;
     int32_t XR[3] = {0, 0, 0}, XL[3] = {0, 0, 0};
-    if (v2R) load3(qs_pos, s2R, XR);
-    if (v2L) load3(qs_pos, s2L, XL);
+    if (v2R) load_pos_fmt(qs_pos, fmt, s2R, XR);
+    if (v2L) load_pos_fmt(qs_pos, fmt, s2L, XL);
     // ---- retire stage 3 (positions fetched in the previous round)
-    if (v3R) { add_face_normal(WR, A, Pc, sum); A[0] = WR[0]; A[1] = WR[1]; A[2] = WR[2]; }
-    if (v3L) { add_face_normal(B, WL, Pc, sum); B[0] = WL[0]; B[1] = WL[1]; B[2] = WL[2]; }
+    if (v3R) { add_face_normal<PACKED>(WR, A, Pc, sum); A[0] = WR[0]; A[1] = WR[1]; A[2] = WR[2]; }
+    if (v3L) { add_face_normal<PACKED>(B, WL, Pc, sum); B[0] = WL[0]; B[1] = WL[1]; B[2] = WL[2]; }
     // ---- advance the pipeline
     v3R = v2R; v3L = v2L;
     WR[0] = XR[0]; WR[1] = XR[1]; WR[2] = XR[2]; WL[0] = XL[0]; WL[1] = XL[1]; WL[2] = XL[2];
@@ -865,24 +895,33 @@ __global__ __launch_bounds__(kBlock) void k_build_fans(const uint32_t* __restric
 
 // HAS_POS = false: the normal attribute alone, on its own (seam) table — `c2r` is then the POSITION table's corner →
 // rank array (fan rows hold position ranks), `opp` the normal table's, and apex[i] is the rank of the fan's centre.
-template <bool HAS_POS, bool HAS_NRM, bool HAS_UV>
+// PACKED: the positions are QF_P64 (and, with HAS_POS, the normals QF_B16 and the texture coordinates QF_H32 — the three
+// attributes of a fused sweep are packed together or not at all); a lone normal attribute's own values stay QF_I32.
+template <bool HAS_POS, bool HAS_NRM, bool HAS_UV, bool PACKED>
 __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const uint32_t blk_, const uint32_t nblk_) {
   const uint32_t* __restrict__ seq = a.seq;
   const uint32_t* __restrict__ c2r = a.c2r;
   const uint32_t* __restrict__ opp = a.opp;
-  const int32_t* __restrict__ qs_pos = a.qs_pos;
+  const void* __restrict__ qs_pos = a.qs_pos;
+  constexpr int pos_fmt = PACKED ? QF_P64 : QF_I32;
+  constexpr bool own_packed = PACKED && HAS_POS;
   const uint32_t n = a.n;
+  const bool s16_pos = (a.sym16 & 1u) != 0u, s16_nrm = (a.sym16 & 2u) != 0u, s16_uv = (a.sym16 & 4u) != 0u;
   WrapParams wp{}, wu{};
   if (HAS_POS) wp = wrap_params(a.mm_pos);
   if (HAS_UV) wu = wrap_params(a.mm_uv);
   uint32_t n_false = 0;
+  auto load_uv = [&](uint32_t r, int32_t (&out)[2]) {
+    if (own_packed) { const uint32_t v = static_cast<const uint32_t*>(a.qs_uv)[r]; out[0] = (int32_t)(v & 0xFFFFu); out[1] = (int32_t)(v >> 16); }
+    else { const int32_t* q = static_cast<const int32_t*>(a.qs_uv) + (size_t)r * 2; out[0] = q[0]; out[1] = q[1]; }
+  };
   DMI_FOR_SEQUENCE(i, n) {
     uint32_t rn, rp, ro;
     int32_t Pc[3], Pn[3] = {0, 0, 0}, Pp[3] = {0, 0, 0}, Po[3] = {0, 0, 0}, Plast[3] = {0, 0, 0};
     int64_t sum[3] = {0, 0, 0};
     const uint32_t h = __builtin_nontemporal_load(&a.fan_hdr[i]);
     ro = __builtin_nontemporal_load(&a.fan_apex[i]);   // HAS_POS: rank across the edge opposite c; else: rank of the centre
-    load3(qs_pos, HAS_POS ? i : ro, Pc);
+    load_pos_fmt(qs_pos, pos_fmt, HAS_POS ? i : ro, Pc);
     if (!(h & (1u << 17))) {
       // ---- fan row: every rank of the 1-ring in one 32-byte read, every position gather independent ----
       typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -898,65 +937,67 @@ __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const u
       const bool need_np = HAS_NRM || (HAS_POS && rn < i && rp < i);
 #pragma unroll
       for (uint32_t k = 0; k < kFanSlots; ++k) {
-        if (k < cnt && (k >= 2 || need_np)) load3(qs_pos, row[k], P[k]);
+        if (k < cnt && (k >= 2 || need_np)) load_pos_fmt(qs_pos, pos_fmt, row[k], P[k]);
         else { P[k][0] = 0; P[k][1] = 0; P[k][2] = 0; }
       }
 #pragma unroll
       for (int d = 0; d < 3; ++d) { Pn[d] = P[0][d]; Pp[d] = P[1][d]; }
       if (HAS_NRM) {
         // faces: (next, prev) = (a, b); right of it (w1, a), (w2, w1), …, closing (b, w_last); left of it (b, u1), (u1, u2), …
-        add_face_normal(Pn, Pp, Pc, sum);
+        add_face_normal<PACKED>(Pn, Pp, Pc, sum);
         int32_t R[3] = {Pn[0], Pn[1], Pn[2]}, L[3] = {Pp[0], Pp[1], Pp[2]};
 #pragma unroll
         for (uint32_t k = 2; k < kFanSlots; ++k) {
           if (k < cnt) {
-            if (k < 2u + stored_r) { add_face_normal(P[k], R, Pc, sum); R[0] = P[k][0]; R[1] = P[k][1]; R[2] = P[k][2]; }
-            else { add_face_normal(L, P[k], Pc, sum); L[0] = P[k][0]; L[1] = P[k][1]; L[2] = P[k][2]; }
+            if (k < 2u + stored_r) { add_face_normal<PACKED>(P[k], R, Pc, sum); R[0] = P[k][0]; R[1] = P[k][1]; R[2] = P[k][2]; }
+            else { add_face_normal<PACKED>(L, P[k], Pc, sum); L[0] = P[k][0]; L[1] = P[k][1]; L[2] = P[k][2]; }
           }
         }
-        if (closed && faces_r) add_face_normal(Pp, R, Pc, sum);
+        if (closed && faces_r) add_face_normal<PACKED>(Pp, R, Pc, sum);
       }
     } else {
       // ---- row overflow (valence > 8): walk the corner table ----
       const uint32_t c = seq[i], nc = cnext(c), pc = cprev(c);
       rn = c2r[nc]; rp = c2r[pc];
-      if (HAS_NRM || (HAS_POS && rn < i && rp < i)) { load3(qs_pos, rn, Pn); load3(qs_pos, rp, Pp); }
-      if (HAS_NRM) fan_normal_sum(c, opp, c2r, qs_pos, Pc, Pn, Pp, sum);
+      if (HAS_NRM || (HAS_POS && rn < i && rp < i)) { load_pos_fmt(qs_pos, pos_fmt, rn, Pn); load_pos_fmt(qs_pos, pos_fmt, rp, Pp); }
+      if (HAS_NRM) fan_normal_sum<PACKED>(c, opp, c2r, qs_pos, Pc, Pn, Pp, sum);
     }
     const bool both = HAS_POS && rn < i && rp < i;
     if (HAS_POS) {
       // ---- positions: mesh_parallelogram_prediction.rs:186-237 + wrapped difference ----
       const bool have = both && ro < i;   // (no opposite corner ⇒ ro == NONE ⇒ false)
-      if (have) load3(qs_pos, ro, Po);
-      else if (i > 0) load3(qs_pos, i - 1u, Plast);
+      if (have) load_pos_fmt(qs_pos, pos_fmt, ro, Po);
+      else if (i > 0) load_pos_fmt(qs_pos, pos_fmt, i - 1u, Plast);
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int32_t pred = have ? wsub(wadd(Pn[k], Pp[k]), Po[k]) : Plast[k];   // Q15: previously coded vertex, 0 for the first entry
-        __builtin_nontemporal_store(wrap_symbol(Pc[k], pred, wp), &a.sym_pos[(size_t)i * 3 + k]);
+        store_sym(a.sym_pos, s16_pos, (size_t)i * 3 + k, wrap_symbol(Pc[k], pred, wp));
       }
     }
     // ---- texture coordinates: mesh_prediction_for_texture_coordinates.rs:51-81,107-219 ----
     if (HAS_UV) {
-      const int32_t* __restrict__ qu = a.qs_uv;
-      const int32_t cu[2] = {qu[(size_t)i * 2], qu[(size_t)i * 2 + 1]};
+      int32_t cu[2];
+      load_uv(i, cu);
       int32_t pred0 = 0, pred1 = 0;
       uint8_t oflag = 0;
       bool done = false;
       int32_t nu[2] = {0, 0};
-      if (rn < i) { nu[0] = qu[(size_t)rn * 2]; nu[1] = qu[(size_t)rn * 2 + 1]; }
+      if (rn < i) load_uv(rn, nu);
       if (both) {
-        const int32_t pu[2] = {qu[(size_t)rp * 2], qu[(size_t)rp * 2 + 1]};
+        int32_t pu[2];
+        load_uv(rp, pu);
         done = texcoord_predict(cu, nu, pu, Pc, Pn, Pp, pred0, pred1, oflag);
       }
       if (!done) {
         oflag = 0;
         if (rn < i) { pred0 = nu[0]; pred1 = nu[1]; }
-        else if (i > 0) { pred0 = qu[(size_t)(i - 1u) * 2]; pred1 = qu[(size_t)(i - 1u) * 2 + 1]; }
+        else if (i > 0) { int32_t lu[2]; load_uv(i - 1u, lu); pred0 = lu[0]; pred1 = lu[1]; }
         else { pred0 = 0; pred1 = 0; }
       }
       __builtin_nontemporal_store(oflag, &a.orient[i]);
-      __builtin_nontemporal_store(wrap_symbol(cu[0], pred0, wu), &a.sym_uv[(size_t)i * 2]);
-      __builtin_nontemporal_store(wrap_symbol(cu[1], pred1, wu), &a.sym_uv[(size_t)i * 2 + 1]);
+      const uint32_t s0 = wrap_symbol(cu[0], pred0, wu), s1 = wrap_symbol(cu[1], pred1, wu);
+      if (s16_uv) __builtin_nontemporal_store(s0 | (s1 << 16), static_cast<uint32_t*>(a.sym_uv) + i);   // (symbols < 2^16: one 4-byte store)
+      else { store_sym(a.sym_uv, false, (size_t)i * 2, s0); store_sym(a.sym_uv, false, (size_t)i * 2 + 1, s1); }
     }
     // ---- normals: mesh_normal_prediction.rs:22-44,75-144 + oct_orthogonal.rs ----
     if (HAS_NRM) {
@@ -972,7 +1013,9 @@ __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const u
       const int32_t n0 = (int32_t)sum0, n1 = (int32_t)sum1, n2 = (int32_t)sum2;
       int32_t p0 = 0, p1 = 0;
       if (!(n0 == 0 && n1 == 0 && n2 == 0)) oct_quantize((float)n0, (float)n1, (float)n2, p0, p1);
-      const int32_t a0 = a.qs_nrm[(size_t)i * 2], a1 = a.qs_nrm[(size_t)i * 2 + 1];
+      int32_t a0, a1;
+      if (own_packed) { const uint32_t v = static_cast<const uint16_t*>(a.qs_nrm)[i]; a0 = (int32_t)(v & 0xFFu); a1 = (int32_t)(v >> 8); }
+      else { const int32_t* q = static_cast<const int32_t*>(a.qs_nrm) + (size_t)i * 2; a0 = q[0]; a1 = q[1]; }
       const int32_t m0 = wmul(p0, -1), m1 = wmul(p1, -1);
       const int32_t d10 = wsub(p0, a0), d11 = wsub(p1, a1), d20 = wsub(m0, a0), d21 = wsub(m1, a1);
       const int32_t dot1 = wadd(wmul(d10, d10), wmul(d11, d11)), dot2 = wadd(wmul(d20, d20), wmul(d21, d21));
@@ -981,8 +1024,8 @@ __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const u
       __builtin_nontemporal_store((uint8_t)(flip ? 1 : 0), &a.flips[i]);
       uint32_t s0, s1;
       oct_orthogonal(a0, a1, p0, p1, s0, s1);
-      __builtin_nontemporal_store(s0, &a.sym_nrm[(size_t)i * 2]);
-      __builtin_nontemporal_store(s1, &a.sym_nrm[(size_t)i * 2 + 1]);
+      if (s16_nrm) __builtin_nontemporal_store(s0 | (s1 << 16), static_cast<uint32_t*>(a.sym_nrm) + i);
+      else { store_sym(a.sym_nrm, false, (size_t)i * 2, s0); store_sym(a.sym_nrm, false, (size_t)i * 2 + 1, s1); }
     }
   }
   if (HAS_NRM) {
@@ -1068,7 +1111,7 @@ __device__ __forceinline__ void k_histogram_body(const HistArgs& args, const uin
   for (uint32_t b = threadIdx.x; b < lds_bins; b += kBlock) lds[b] = 0;
   __syncthreads();
   for (uint64_t e = (uint64_t)block * kBlock + threadIdx.x; e < a.n; e += (uint64_t)a.blocks * kBlock) {
-    const uint32_t s = a.sym[e];
+    const uint32_t s = load_sym(a.sym, a.sym16 != 0u, e);
     if (s >= a.bins) { atomicOr(a.overflow, 1u); continue; }
     if (s < lds_bins) atomicAdd(&lds[s], 1u); else atomicAdd(&a.hist[s], 1u);
   }
@@ -1095,10 +1138,14 @@ DMI_KERNEL(k_value_ranges, k_value_ranges_body, RangeArgs, kBlock)
 DMI_KERNEL(k_value_ranges_final, k_value_ranges_final_body, RangeArgs, kBlock)
 DMI_KERNEL(k_seq_quantize, k_seq_quantize_body, SeqQuantArgs, kBlock)
 DMI_KERNEL(k_i32_minmax_final, k_i32_minmax_final_body, MinMaxArgs, kBlock)
-DMI_KERNEL(k_predict_fused_pnu, (k_predict_fused_body<true, true, true>), FusedArgs, kBlock)
-DMI_KERNEL(k_predict_fused_pn, (k_predict_fused_body<true, true, false>), FusedArgs, kBlock)
-DMI_KERNEL(k_predict_fused_pu, (k_predict_fused_body<true, false, true>), FusedArgs, kBlock)
-DMI_KERNEL(k_predict_fused_n, (k_predict_fused_body<false, true, false>), FusedArgs, kBlock)
+DMI_KERNEL(k_predict_fused_pnu, (k_predict_fused_body<true, true, true, false>), FusedArgs, kBlock)
+DMI_KERNEL(k_predict_fused_pn, (k_predict_fused_body<true, true, false, false>), FusedArgs, kBlock)
+DMI_KERNEL(k_predict_fused_pu, (k_predict_fused_body<true, false, true, false>), FusedArgs, kBlock)
+DMI_KERNEL(k_predict_fused_n, (k_predict_fused_body<false, true, false, false>), FusedArgs, kBlock)
+DMI_KERNEL(k_predict_packed_pnu, (k_predict_fused_body<true, true, true, true>), FusedArgs, kBlock)
+DMI_KERNEL(k_predict_packed_pn, (k_predict_fused_body<true, true, false, true>), FusedArgs, kBlock)
+DMI_KERNEL(k_predict_packed_pu, (k_predict_fused_body<true, false, true, true>), FusedArgs, kBlock)
+DMI_KERNEL(k_predict_packed_n, (k_predict_fused_body<false, true, false, true>), FusedArgs, kBlock)
 DMI_KERNEL(k_pred_parallelogram_wrapped1, k_pred_parallelogram_wrapped_body<1>, ParArgs, kBlock)
 DMI_KERNEL(k_pred_parallelogram_wrapped2, k_pred_parallelogram_wrapped_body<2>, ParArgs, kBlock)
 DMI_KERNEL(k_pred_parallelogram_wrapped3, k_pred_parallelogram_wrapped_body<3>, ParArgs, kBlock)
@@ -1139,6 +1186,10 @@ bool step_sink_push(const KernelStep& st) { if (!g_step_sink) return false; g_st
   X(K_FUSED_PN, k_predict_fused_pn, FusedArgs, kBlock)                       \
   X(K_FUSED_PU, k_predict_fused_pu, FusedArgs, kBlock)                       \
   X(K_FUSED_N, k_predict_fused_n, FusedArgs, kBlock)                         \
+  X(K_PACKED_PNU, k_predict_packed_pnu, FusedArgs, kBlock)                   \
+  X(K_PACKED_PN, k_predict_packed_pn, FusedArgs, kBlock)                     \
+  X(K_PACKED_PU, k_predict_packed_pu, FusedArgs, kBlock)                     \
+  X(K_PACKED_N, k_predict_packed_n, FusedArgs, kBlock)                       \
   X(K_PAR1, k_pred_parallelogram_wrapped1, ParArgs, kBlock)                  \
   X(K_PAR2, k_pred_parallelogram_wrapped2, ParArgs, kBlock)                  \
   X(K_PAR3, k_pred_parallelogram_wrapped3, ParArgs, kBlock)                  \
@@ -1189,19 +1240,19 @@ void launch_seq_quantize(const uint32_t* s2p, uint32_t n, const QuantArgs& args,
 }
 
 void launch_pred_parallelogram_wrapped(const uint32_t* seq, uint32_t n, const uint32_t* c2r, const uint32_t* opp,
-                                       const int32_t* qs, const int32_t* minmax, int N, uint32_t* sym, hipStream_t s) {
-  ParArgs pa{seq, c2r, opp, qs, minmax, sym, n, 0u};
+                                       const int32_t* qs, const int32_t* minmax, int N, void* sym, bool sym16, hipStream_t s) {
+  ParArgs pa{seq, c2r, opp, qs, minmax, sym, n, sym16 ? 1u : 0u};
   emit(N == 1 ? K_PAR1 : (N == 2 ? K_PAR2 : (N == 3 ? K_PAR3 : K_PAR4)), 4, pa, grid_for(n), 0, s);
 }
 
-void launch_pred_delta_difference(uint32_t n, const int32_t* qs, int N, uint32_t* sym, hipStream_t s) {
-  DeltaArgs da{(uint64_t)n * N, qs, sym, N, 0};
+void launch_pred_delta_difference(uint32_t n, const int32_t* qs, int N, void* sym, bool sym16, hipStream_t s) {
+  DeltaArgs da{(uint64_t)n * N, qs, sym, N, sym16 ? 1 : 0};
   emit(K_DELTA, 4, da, da.n_comp ? grid_for(da.n_comp) : 0u, 0, s);
 }
 
 void launch_pred_texcoord_wrapped(const uint32_t* seq, uint32_t n, const uint32_t* c2r, const int32_t* qs, const uint32_t* c2r_pos,
-                                  const int32_t* qs_pos, const int32_t* minmax, uint32_t* sym, uint8_t* orient, hipStream_t s) {
-  TexArgs ta{seq, c2r, qs, c2r_pos, qs_pos, minmax, sym, orient, n, 0u};
+                                  const void* qs_pos, int pos_fmt, const int32_t* minmax, void* sym, bool sym16, uint8_t* orient, hipStream_t s) {
+  TexArgs ta{seq, c2r, qs, c2r_pos, qs_pos, minmax, sym, orient, n, sym16 ? 1u : 0u, pos_fmt, 0};
   emit(K_TEX, 4, ta, grid_for(((uint64_t)n + kTexTile - 1) / kTexTile), 0, s);
 }
 
@@ -1214,7 +1265,8 @@ void launch_predict_fused(const FusedArgs& a, hipStream_t s) {
   if (a.n == 0) return;
   static const uint32_t env_cap = std::getenv("DMI_FUSED_GRID") ? (uint32_t)std::atoi(std::getenv("DMI_FUSED_GRID")) : 0u;   // tuning aid
   const uint32_t g = grid_for(a.n, env_cap ? env_cap : 8192u);   // 2-3 chunks per block: measured best on the 10M workload (2048: +5 %)
-  const int id = !a.sym_pos ? K_FUSED_N /* a normal attribute on its own table */ : ((a.qs_nrm && a.qs_uv) ? K_FUSED_PNU : (a.qs_nrm ? K_FUSED_PN : K_FUSED_PU));
+  int id = !a.sym_pos ? K_FUSED_N /* a normal attribute on its own table */ : ((a.qs_nrm && a.qs_uv) ? K_FUSED_PNU : (a.qs_nrm ? K_FUSED_PN : K_FUSED_PU));
+  if (a.packed) id += K_PACKED_PNU - K_FUSED_PNU;
   emit(id, 4, a, g, 0, s);
 }
 

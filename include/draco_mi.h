@@ -164,6 +164,15 @@ int dmi_mesh_prepare(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buffer* he
  * job or buffer is left allocated. */
 int dmi_meshes_prepare(const dmi_mesh* meshes, uint32_t n, const dmi_config* cfg, dmi_buffer* header_and_connectivity, dmi_job** jobs);
 
+/* --- One process, several GPUs (a single-process caller — the Rust crate — has no torch.distributed): the same batch calls with a
+ * device per mesh / job.  dmi_shard_meshes deals n meshes over n_devices by triangle count (greedy longest-processing-time, the
+ * partition of the one-process-per-GPU form); dmi_meshes_prepare_devices prepares mesh j on HIP device device_of_mesh[j]
+ * (dmi_config.device is ignored, dmi_config.stream must be null); dmi_jobs_encode_devices groups the jobs by their device and runs
+ * one dmi_jobs_encode per device concurrently.  outs[j] / jobs[j] / header_and_connectivity[j] stay in mesh order.  All or nothing. */
+int dmi_shard_meshes(const dmi_mesh* meshes, uint32_t n, uint32_t n_devices, int32_t* device_of_mesh);
+int dmi_meshes_prepare_devices(const dmi_mesh* meshes, uint32_t n, const dmi_config* cfg, const int32_t* device_of_mesh, dmi_buffer* header_and_connectivity, dmi_job** jobs);
+int dmi_jobs_encode_devices(dmi_job** jobs, uint32_t n_jobs, dmi_buffer* outs);
+
 /* Host connectivity only (no GPU needed): header + connectivity bytes, plus the flat tables that
  * dmi_encode_attributes consumes.  Tables are library-owned and freed by dmi_conn_free. */
 typedef struct dmi_conn {

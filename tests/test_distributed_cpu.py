@@ -69,3 +69,31 @@ def test_shard_indices_cover_and_balance():
         loads = [sum(weights[i] for i in o) for o in owned]
         assert max(loads) <= sum(weights) / world + max(weights)
     assert dd.shard_indices(5, 1, 2) == [1, 3]
+
+
+def test_shard_meshes_matches_the_python_deal_and_rank_config(monkeypatch):
+    """dmi_shard_meshes (C, for single-process callers) deals exactly like distributed.shard_indices (LPT by triangle count); and
+    encode_meshes_sharded picks each rank's HIP ordinal from LOCAL_RANK / its torch device (every rank used device 0)."""
+    import numpy as np
+    import pytest
+    import torch
+    import draco_oxide_amd as dmi
+    from draco_oxide_amd import binding, distributed as dd
+    rng = np.random.default_rng(4)
+    meshes = []
+    for k in range(23):
+        f = int(rng.integers(1, 400))
+        meshes.append(dmi.Mesh(np.zeros((f, 3), np.uint32), [dmi.Attribute(np.zeros((1, 3), np.float32), dmi.ATT_POSITION)]))
+    for world in (1, 2, 3, 8):
+        deal = dmi.shard_meshes(meshes, world)
+        for r in range(world):
+            assert [i for i, d in enumerate(deal) if d == r] == dd.shard_indices(len(meshes), r, world, weights=[len(m.faces) for m in meshes])
+    monkeypatch.setattr(binding, "device_count", lambda: 8)
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    assert dd._rank_config(None, None).device == 5
+    assert dd._rank_config(None, torch.device("cuda", 3)).device == 3
+    assert dd._rank_config(dmi.Config(device=3, pos_bits=14), torch.device("cuda", 3)).pos_bits == 14
+    with pytest.raises(ValueError):
+        dd._rank_config(dmi.Config(device=1), torch.device("cuda", 3))
+    monkeypatch.setenv("LOCAL_RANK", "9")
+    assert dd._rank_config(None, torch.device("cpu")).device == 1   # 9 % 8 visible devices

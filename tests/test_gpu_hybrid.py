@@ -101,3 +101,24 @@ def test_one_million_triangles_on_device_chains(monkeypatch):
     monkeypatch.setenv("DMI_CHAINS", "device")
     mesh = synth.torus_mesh(707, normals=False, uvs=False)
     _assert_same(dmi.encode_mesh(mesh), oracle_from_product_mesh(mesh).encode(), "1M positions, device chains")
+
+
+@pytest.mark.parametrize("toggle", ["DMI_NO_PACKED", "DMI_NO_SYM16"])
+def test_packed_values_and_16_bit_symbols_are_layouts_not_arithmetic(toggle, monkeypatch):
+    """The attributes of a fused sweep keep their quantized values packed (positions ≤ 21 bits in a uint64, normals in a uint16,
+    texture coordinates ≤ 16 bits in a uint32) and symbols are uint16 where the alphabet allows; DMI_NO_PACKED / DMI_NO_SYM16 (read
+    at job creation) switch the layouts off.  Same bytes — and the widths at which packing does not apply take the plain layout."""
+    cases = [(synth.torus_mesh(40), None), (synth.torus_mesh(33, open_boundary=True), None), (synth.torus_mesh(64, uvs=False), None),
+             (synth.torus_mesh(50, normals=False), None), (synth.torus_mesh(30), dmi.Config(pos_bits=15, uv_bits=15)),
+             (synth.torus_mesh(30), dmi.Config(pos_bits=16, uv_bits=16)), (synth.torus_mesh(30), dmi.Config(pos_bits=21, uv_bits=12)),
+             (synth.torus_mesh(30), dmi.Config(pos_bits=22, uv_bits=17)), (_cones(13, True, False, seed=3), None)]
+    for mesh, cfg in cases:
+        kw = {} if cfg is None else dict(pos_bits=cfg.pos_bits, uv_bits=cfg.uv_bits)
+        try:
+            want = oracle_from_product_mesh(mesh).encode(**kw)
+        except orc.OracleError:
+            continue
+        _assert_same(dmi.encode_mesh(mesh, cfg), want, f"packed layouts {kw}")
+        monkeypatch.setenv(toggle, "1")
+        _assert_same(dmi.encode_mesh(mesh, cfg), want, f"{toggle} {kw}")
+        monkeypatch.delenv(toggle)

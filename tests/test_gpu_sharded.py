@@ -92,3 +92,26 @@ def test_gather_on_the_rccl_path_single_rank():
     got = q.get(timeout=300)
     p.join(timeout=300)
     assert p.exitcode == 0 and got == (True, True, True)
+
+
+def test_single_process_multi_device_entries():
+    """dmi_shard_meshes / dmi_meshes_prepare_devices / dmi_jobs_encode_devices: what a single-process caller (the Rust crate) uses to
+    spread a batch over several GPUs.  On a 1-GPU box every mesh lands on device 0 (one group, plain dmi_jobs_encode underneath); with
+    more devices the groups run concurrently.  Sections come back in mesh order and equal the oracle's."""
+    import draco_oxide_amd as dmi
+    from helpers import oracle_from_product_mesh
+    meshes = _meshes()
+    ndev = dmi.device_count()
+    deal = dmi.shard_meshes(meshes, ndev)
+    assert len(deal) == len(meshes) and set(deal) <= set(range(ndev))
+    # LPT: loads differ by at most the heaviest mesh
+    loads = [sum(len(m.faces) for m, d in zip(meshes, deal) if d == k) for k in range(ndev)]
+    assert max(loads) - min(loads) <= max(len(m.faces) for m in meshes)
+    jobs = dmi.meshes_prepare_devices(meshes, deal)
+    outs = dmi.jobs_encode_devices(jobs)
+    for m, j, o in zip(meshes, jobs, outs):
+        assert j.header_and_connectivity + o == oracle_from_product_mesh(m).encode()
+    for j in jobs:
+        j.close()
+    with pytest.raises(dmi.DracoMiError):
+        dmi.meshes_prepare_devices(meshes, [ndev + 3] * len(meshes))   # a device that does not exist: an error code
