@@ -9,9 +9,13 @@
 //   attribute_sequence              shared/attribute/sequence.rs:48-151
 //   FreqTable                       encode/entropy/rans.rs:146-239, shared/entropy/mod.rs:41-64
 #pragma once
+#include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/draco_mi.h"
@@ -20,6 +24,25 @@ namespace dmi {
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 int host_fail(int code, const std::string& msg);   // sets dmi_last_error() for the calling thread, returns code
+
+// Host threads the library may use at once in one call: the machine's hardware threads, capped by DMI_HOST_THREADS (read per call:
+// one process per GPU on a shared host sets it to its share, cores / world size).
+inline unsigned host_threads() {
+  unsigned hw = std::thread::hardware_concurrency();
+  if (!hw) hw = 4;
+  if (const char* e = std::getenv("DMI_HOST_THREADS")) { const int v = std::atoi(e); if (v > 0) hw = std::min<unsigned>(hw, (unsigned)v); }
+  return hw;
+}
+// [0, n) in contiguous slices on up to 32 host threads (large, embarrassingly parallel index loops); fn(lo, hi)
+template <class Fn>
+inline void parallel_for(size_t n, Fn&& fn) {
+  const unsigned hw = host_threads();
+  const size_t n_threads = n < (1u << 20) ? 1 : std::max<size_t>(1, std::min<size_t>({(size_t)hw, (size_t)32, n >> 18}));
+  if (n_threads == 1) { fn((size_t)0, n); return; }
+  std::vector<std::thread> th;
+  for (size_t t = 0; t < n_threads; ++t) th.emplace_back([&, t] { fn(n * t / n_threads, n * (t + 1) / n_threads); });
+  for (auto& x : th) x.join();
+}
 
 struct ByteSink {
   std::vector<uint8_t> b;
@@ -71,7 +94,11 @@ struct EdgebreakerResult {
   std::vector<uint32_t> seeds;          // corners_of_edgebreaker
   std::vector<uint8_t> connectivity;    // bytes written by encode_connectivity (without the 11-byte header)
 };
-int run_edgebreaker(const CornerTables& ct, EdgebreakerResult& out, std::string& err);
+// Optional call-outs of run_edgebreaker, so that a large mesh's other serial walks overlap it: `seeds_ready` fires when the traversal
+// is over and out.seeds is final (the attribute sequencers only need those), `before_seams` right before the attribute seam flags are
+// read (ct.att[] — built by another thread meanwhile — must be complete when it returns).
+struct EdgebreakerHooks { std::function<void()> seeds_ready, before_seams; };
+int run_edgebreaker(const CornerTables& ct, EdgebreakerResult& out, std::string& err, const EdgebreakerHooks* hooks = nullptr);
 
 // Attribute sequencer over a flat table view.
 struct TableRef {

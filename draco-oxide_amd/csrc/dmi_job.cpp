@@ -38,6 +38,7 @@ int fail(int code, const std::string& msg) { return host_fail(code, msg); }
 enum Scheme : uint8_t { kDelta = 0, kParallelogram = 1, kTexCoord = 5, kNormal = 6 };   // prediction_scheme/mod.rs:74-86
 enum Transform : uint8_t { kDifference = 0, kWrapped = 1, kOctOrth = 3 };              // prediction_transform/mod.rs:92-101
 enum Port : uint8_t { kToBits = 1, kCoordwise = 2, kOct = 3 };                          // portabilization/mod.rs:85-92
+constexpr uint32_t kMaxPrepareWorkers = 128;   // host threads of one dmi_meshes_prepare call
 constexpr uint32_t kDeviceRelabelMinFaces = 1u << 17;   // job creation relabels the connectivity inputs with kernels from this size up (dmi_relabel.hip)
 constexpr uint64_t kHostChainMinSymbols = 32768;   // a job whose longest stream is at least this long codes its streams on host cores (hybrid form)
 
@@ -249,26 +250,6 @@ struct TempDev {   // device temporaries of job creation (outside the job's pool
   ~TempDev() { for (void* q : ptrs) (void)hipFree(q); }
   template <class T> T* take(size_t n) { void* q = nullptr; if (hipMalloc(&q, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr; ptrs.push_back(q); return static_cast<T*>(q); }
 };
-
-// Host threads the library may use at once in one call: the machine's hardware threads, capped by DMI_HOST_THREADS (read per call:
-// one process per GPU on a shared host sets it to its share, cores / world size).
-unsigned host_threads() {
-  unsigned hw = std::thread::hardware_concurrency();
-  if (!hw) hw = 4;
-  if (const char* e = std::getenv("DMI_HOST_THREADS")) { const int v = std::atoi(e); if (v > 0) hw = std::min<unsigned>(hw, (unsigned)v); }
-  return hw;
-}
-
-// [0, n) in contiguous slices on up to 16 host threads (large, embarrassingly parallel index loops of job creation)
-template <class Fn>
-void parallel_for(size_t n, Fn&& fn) {
-  const unsigned hw = host_threads();
-  const size_t n_threads = n < (1u << 20) ? 1 : std::max<size_t>(1, std::min<size_t>({hw, 16u, n >> 18}));
-  if (n_threads == 1) { fn((size_t)0, n); return; }
-  std::vector<std::thread> th;
-  for (size_t t = 0; t < n_threads; ++t) th.emplace_back([&, t] { fn(n * t / n_threads, n * (t + 1) / n_threads); });
-  for (auto& x : th) x.join();
-}
 
 int upload(DevMem& m, const void* src, size_t bytes, hipStream_t s) {
   int rc = m.alloc(bytes);
@@ -2232,24 +2213,50 @@ static int build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std::vector<ui
   int rc = o.ct.build_universal(mesh->faces, mesh->num_faces, mesh->atts[0].point_to_value, err);
   if (rc) return fail(rc, err);
   const double t_univ = since(c0);
-  {   // attribute corner tables (edgebreaker.rs:183-190): independent of each other — one host thread each for large meshes
-    std::vector<const uint32_t*> maps;
-    for (uint32_t i = 0; i < mesh->num_atts; ++i) if (mesh->atts[i].att_type != DMI_ATT_POSITION) maps.push_back(mesh->atts[i].point_to_value);
-    o.ct.att.resize(maps.size());
-    if (maps.size() > 1 && mesh->num_faces > 100000) {
+  // The serial graph walks of one large mesh overlap on a few host threads: the attribute corner tables (their loops are parallel
+  // themselves) are built while the Edgebreaker traversal runs (it reads the universal table only; the seam flags are needed at its
+  // end), and the attribute sequencers start as soon as the traversal has produced its seeds, beside the assembly of the
+  // connectivity bytes.  Small meshes (a batch already runs one mesh per host thread) do the same steps one after the other.
+  std::vector<const uint32_t*> maps;
+  for (uint32_t i = 0; i < mesh->num_atts; ++i) if (mesh->atts[i].att_type != DMI_ATT_POSITION) maps.push_back(mesh->atts[i].point_to_value);
+  o.ct.att.resize(maps.size());
+  const bool overlap = mesh->num_faces > 100000;
+  double t_att = 0, t_eb = 0, t_seq = 0;
+  o.views.resize(mesh->num_atts);
+  o.seqs.resize(mesh->num_atts);
+  auto universal_view = [&](dmi_corner_table& v) { v.num_vertices = o.ct.V; v.corner_to_vertex = o.ct.c2v.data(); v.opposite = o.ct.opp.data(); v.left_most_corner = o.ct.lmc.data(); };
+  auto sequence_universal = [&] {
+    TableRef tr{o.ct.F, o.ct.V, o.ct.c2v.data(), o.ct.opp.data(), o.ct.lmc.data()};
+    attribute_sequence(tr, o.eb.seeds.data(), (uint32_t)o.eb.seeds.size(), o.seqs[0]);
+  };
+  auto build_att_tables = [&] {
+    const auto a0 = tick();
+    if (maps.size() > 1 && overlap) {
       std::vector<std::thread> th;
       for (size_t k = 0; k < maps.size(); ++k) th.emplace_back([&, k] { o.ct.build_attribute_into(o.ct.att[k], maps[k]); });
       for (auto& x : th) x.join();
     } else {
       for (size_t k = 0; k < maps.size(); ++k) o.ct.build_attribute_into(o.ct.att[k], maps[k]);
     }
+    t_att = since(a0);
+  };
+  std::thread att_thread, seq_thread;
+  EdgebreakerHooks hooks;
+  if (overlap) {
+    att_thread = std::thread(build_att_tables);
+    hooks.seeds_ready = [&] { seq_thread = std::thread([&] { const auto q0 = tick(); sequence_universal(); t_seq = since(q0); }); };
+    hooks.before_seams = [&] { if (att_thread.joinable()) att_thread.join(); };
+  } else {
+    build_att_tables();
   }
-  const double t_att = since(c0) - t_univ;
   auto c1 = tick();
-  rc = run_edgebreaker(o.ct, o.eb, err);
+  rc = run_edgebreaker(o.ct, o.eb, err, overlap ? &hooks : nullptr);
+  if (att_thread.joinable()) att_thread.join();
+  if (seq_thread.joinable()) seq_thread.join();
   if (rc) return fail(rc, err);
-  const double t_eb = since(c1);
+  t_eb = since(c1);
   auto c2 = tick();
+  if (!overlap) sequence_universal();
   ByteSink s;
   for (char ch : {'D', 'R', 'A', 'C', 'O'}) s.u8((uint8_t)ch);   // encode/header/mod.rs:26-54
   s.u8(2); s.u8(2); s.u8(1); s.u8(1); s.u16(0);
@@ -2257,35 +2264,36 @@ static int build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std::vector<ui
   bytes.swap(s.b);
   // views: attribute i uses the universal table when i == 0 or no attribute table i-1 exists
   // (all_inclusive_corner_table.rs:31-45)
-  o.views.resize(mesh->num_atts);
-  o.seqs.resize(mesh->num_atts);
-  for (uint32_t i = 0; i < mesh->num_atts; ++i) {
-    dmi_corner_table& v = o.views[i];
-    v.num_faces = o.ct.F;
-    v.corner_to_point = o.ct.c2p.data();
-    const bool use_att = i > 0 && (i - 1) < o.ct.att.size();
-    bool seamless = true;
-    if (use_att) { const AttTable& t = o.ct.att[i - 1]; for (size_t c = 0; c < t.seam_edge.size(); ++c) if (t.seam_edge[c] && o.ct.opp[c] != kNone) { seamless = false; break; } }
-    if (use_att && !seamless) {
-      const AttTable& t = o.ct.att[i - 1];
-      v.num_vertices = t.num_vertices; v.corner_to_vertex = t.c2v.data(); v.opposite = t.opp.data(); v.left_most_corner = t.lmc.data();
-      TableRef tr{o.ct.F, t.num_vertices, t.c2v.data(), t.opp.data(), t.lmc.data()};
-      attribute_sequence(tr, o.eb.seeds.data(), (uint32_t)o.eb.seeds.size(), o.seqs[i]);
-    } else {
-      // a seam-free attribute table is identical to the universal one (same ids, same order)
-      v.num_vertices = o.ct.V; v.corner_to_vertex = o.ct.c2v.data(); v.opposite = o.ct.opp.data(); v.left_most_corner = o.ct.lmc.data();
-      if (i == 0 || o.seqs[0].empty()) {
-        TableRef tr{o.ct.F, o.ct.V, o.ct.c2v.data(), o.ct.opp.data(), o.ct.lmc.data()};
-        attribute_sequence(tr, o.eb.seeds.data(), (uint32_t)o.eb.seeds.size(), o.seqs[i]);
+  {
+    std::vector<std::thread> th;   // sequences of attribute tables with seams: independent walks
+    for (uint32_t i = 0; i < mesh->num_atts; ++i) {
+      dmi_corner_table& v = o.views[i];
+      v.num_faces = o.ct.F;
+      v.corner_to_point = o.ct.c2p.data();
+      const bool use_att = i > 0 && (i - 1) < o.ct.att.size();
+      bool seamless = true;
+      if (use_att) { const AttTable& t = o.ct.att[i - 1]; for (size_t c = 0; c < t.seam_edge.size(); ++c) if (t.seam_edge[c] && o.ct.opp[c] != kNone) { seamless = false; break; } }
+      if (use_att && !seamless) {
+        const AttTable& t = o.ct.att[i - 1];
+        v.num_vertices = t.num_vertices; v.corner_to_vertex = t.c2v.data(); v.opposite = t.opp.data(); v.left_most_corner = t.lmc.data();
+        auto walk = [&o, i, &t] { TableRef tr{o.ct.F, t.num_vertices, t.c2v.data(), t.opp.data(), t.lmc.data()}; attribute_sequence(tr, o.eb.seeds.data(), (uint32_t)o.eb.seeds.size(), o.seqs[i]); };
+        if (overlap) th.emplace_back(walk); else walk();
       } else {
-        o.seqs[i] = o.seqs[0];
+        // a seam-free attribute table is identical to the universal one (same ids, same order)
+        universal_view(v);
       }
     }
-    v.sequence = o.seqs[i].data();
-    v.sequence_len = (uint32_t)o.seqs[i].size();
+    for (auto& x : th) x.join();
+    for (uint32_t i = 0; i < mesh->num_atts; ++i) {
+      dmi_corner_table& v = o.views[i];
+      if (v.corner_to_vertex == o.ct.c2v.data() && i > 0) o.seqs[i] = o.seqs[0];
+      v.sequence = o.seqs[i].data();
+      v.sequence_len = (uint32_t)o.seqs[i].size();
+    }
   }
-  if (trace) std::fprintf(stderr, "[dmi] host connectivity of %u faces: universal corner table %.1f ms, attribute tables %.1f, Edgebreaker %.1f, sequencers %.1f\n",
-                          mesh->num_faces, t_univ, t_att, t_eb, since(c2));
+  if (!overlap) t_seq = since(c2);
+  if (trace) std::fprintf(stderr, "[dmi] host connectivity of %u faces (%s): universal corner table %.1f ms, attribute tables %.1f, Edgebreaker %.1f, universal sequencer %.1f, seam-table sequencers + views %.1f; total %.1f\n",
+                          mesh->num_faces, overlap ? "overlapped: attribute tables and sequencer beside the Edgebreaker walk" : "in sequence", t_univ, t_att, t_eb, t_seq, since(c2), since(c0));
   return DMI_OK;
 }
 
@@ -2357,7 +2365,9 @@ int dmi_shard_meshes(const dmi_mesh* meshes, uint32_t n, uint32_t n_devices, int
 static int meshes_prepare_impl(const dmi_mesh* meshes, uint32_t n, const dmi_config* cfg, const int32_t* device_of_mesh, dmi_buffer* header_and_connectivity, dmi_job** jobs) {
   if (!meshes || !header_and_connectivity || !jobs || n == 0) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
   for (uint32_t j = 0; j < n; ++j) { jobs[j] = nullptr; header_and_connectivity[j] = dmi_buffer{}; }
-  const uint32_t n_threads = std::max(1u, std::min({n, (uint32_t)host_threads(), 32u}));
+  // (the walks are serial per mesh and independent across meshes: as many workers as the host gives — 128 at most — minus what a
+  //  concurrent dmi_jobs_encode of the previous batch needs; DMI_HOST_THREADS caps a process's share)
+  const uint32_t n_threads = std::max(1u, std::min({n, (uint32_t)host_threads(), kMaxPrepareWorkers}));
   std::vector<int> rcs(n, DMI_OK);
   std::vector<std::string> errs(n);
   std::atomic<uint32_t> next{0};
@@ -2368,7 +2378,7 @@ static int meshes_prepare_impl(const dmi_mesh* meshes, uint32_t n, const dmi_con
   const bool library_streams = !(cfg && cfg->stream);
   auto worker_stream = [&](uint32_t t, int device) {   // worker t's stream on `device` (process-lifetime pool, created on first use)
     static std::mutex m;
-    static std::vector<std::pair<int, std::shared_ptr<StreamHolder>>> pool[32];
+    static std::vector<std::pair<int, std::shared_ptr<StreamHolder>>> pool[kMaxPrepareWorkers];
     std::lock_guard<std::mutex> lock(m);
     std::shared_ptr<StreamHolder> found;
     for (auto& e : pool[t]) if (e.first == device) found = e.second;

@@ -2,6 +2,8 @@
 // CPU, single thread per mesh, flat arrays.  Output is bit-identical to the reference's
 // (quirks kept: SURVEY.md §8a-Q Q22 half-edge matching, per-vertex "hole" ids).
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
 
 #include "dmi_host.hpp"
 
@@ -57,6 +59,83 @@ struct UniversalBuilder {
       }
     }
     t.V = nv;
+  }
+
+  // ---- the same tables on host threads, for the inputs whose result does not depend on the corner order ----
+  // With no vertex-degenerate face and no undirected edge shared by more than two faces, the bucket matching above links corner c to
+  // the one corner c' that carries the reverse half-edge (sink → source) unless both have the same tip (Q22) — whichever of the two
+  // comes first — so the table can be built from complete buckets in any order.  The edge count is has_non_manifold_edge()'s
+  // predicate (≥ 3 faces on an edge): such meshes, and meshes with degenerate faces, return false and take the serial path.
+  bool match_half_edges_parallel() {
+    const uint32_t nv = t.V;
+    std::vector<uint32_t> count(nv + 1, 0);
+    std::atomic<int> degenerate{0};
+    parallel_for(t.F, [&](size_t lo, size_t hi) {
+      for (size_t f = lo; f < hi; ++f) {
+        const uint32_t a = t.c2v[3 * f], b = t.c2v[3 * f + 1], c = t.c2v[3 * f + 2];
+        if (a == b || b == c || a == c) { degenerate.store(1, std::memory_order_relaxed); return; }
+        __atomic_fetch_add(&count[a], 1u, __ATOMIC_RELAXED);   // half-edges leaving a vertex = its corner count
+        __atomic_fetch_add(&count[b], 1u, __ATOMIC_RELAXED);
+        __atomic_fetch_add(&count[c], 1u, __ATOMIC_RELAXED);
+      }
+    });
+    if (degenerate.load()) return false;
+    std::vector<uint32_t> start(nv + 1, 0);
+    for (uint32_t v = 0; v < nv; ++v) start[v + 1] = start[v] + count[v];
+    std::vector<uint32_t> cursor(start.begin(), start.end() - 1);
+    std::vector<uint32_t> he_sink(C), he_corner(C);
+    parallel_for(C, [&](size_t lo, size_t hi) {
+      for (size_t c = lo; c < hi; ++c) {
+        const uint32_t src = t.c2v[corner_next((uint32_t)c)], snk = t.c2v[corner_prev((uint32_t)c)];
+        const uint32_t slot = __atomic_fetch_add(&cursor[src], 1u, __ATOMIC_RELAXED);
+        he_sink[slot] = snk;
+        he_corner[slot] = (uint32_t)c;
+      }
+    });
+    t.opp.resize(C);
+    std::atomic<int> crowded{0};
+    parallel_for(C, [&](size_t lo, size_t hi) {
+      for (size_t c = lo; c < hi; ++c) {
+        const uint32_t tip = t.c2v[c], src = t.c2v[corner_next((uint32_t)c)], snk = t.c2v[corner_prev((uint32_t)c)];
+        uint32_t same = 0, rev = 0, found = kNone;
+        for (uint32_t s2 = start[src]; s2 < start[src + 1]; ++s2) same += he_sink[s2] == snk;
+        for (uint32_t s2 = start[snk]; s2 < start[snk + 1]; ++s2) if (he_sink[s2] == src) { ++rev; found = he_corner[s2]; }
+        if (same + rev > 2) { crowded.store(1, std::memory_order_relaxed); return; }
+        t.opp[c] = (rev == 1 && same == 1 && t.c2v[found] != tip) ? found : kNone;
+      }
+    });
+    return !crowded.load();
+  }
+
+  // Left-most corners when every vertex has ONE fan (no vertex is split, mod.rs:368-385): for an open fan the left-most corner is
+  // where swinging left ends whatever the start; for a closed fan the serial walk starts at the vertex's first corner c in corner
+  // order and stops on the corner before c — swing_right(c).  A vertex whose fan does not hold all of its corners has several
+  // fans: false, and the serial walk (which splits such vertices) runs instead.
+  bool left_most_corners_parallel() {
+    const uint32_t nv = t.V;
+    std::vector<uint32_t> first(nv, kNone), count(nv, 0);
+    parallel_for(C, [&](size_t lo, size_t hi) {
+      for (size_t c = lo; c < hi; ++c) {
+        const uint32_t v = t.c2v[c];
+        __atomic_fetch_add(&count[v], 1u, __ATOMIC_RELAXED);
+        uint32_t cur = __atomic_load_n(&first[v], __ATOMIC_RELAXED);
+        while ((uint32_t)c < cur && !__atomic_compare_exchange_n(&first[v], &cur, (uint32_t)c, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+      }
+    });
+    t.lmc.assign(nv, kNone);
+    std::atomic<int> several{0};
+    parallel_for(nv, [&](size_t lo, size_t hi) {
+      for (size_t v = lo; v < hi; ++v) {
+        const uint32_t c = first[v];
+        if (c == kNone) continue;
+        uint32_t fan = 1, left = c, a = swing_left(c);
+        while (a != kNone && a != c && fan <= count[v]) { left = a; ++fan; a = swing_left(a); }
+        if (a == kNone) for (uint32_t r = swing_right(c); r != kNone && fan <= count[v]; r = swing_right(r)) ++fan;   // open fan: the corners to the right of c
+        if (fan != count[v]) { several.store(1, std::memory_order_relaxed); return; }
+        t.lmc[v] = left;
+      }
+    });
+    return !several.load();
   }
 
   // "some undirected edge has more than two faces" (mod.rs:121-145) without the global sort:
@@ -160,18 +239,29 @@ int CornerTables::build_universal(const uint32_t* faces, uint32_t num_faces, con
   const uint32_t C = 3 * F;
   c2p.assign(faces, faces + C);
   c2v.resize(C);
-  uint32_t maxv = 0;
-  for (uint32_t c = 0; c < C; ++c) { c2v[c] = pos_p2v ? pos_p2v[faces[c]] : faces[c]; maxv = std::max(maxv, c2v[c]); }
-  V = C ? maxv + 1 : 0;
+  std::atomic<uint32_t> maxv_a{0};
+  parallel_for(C, [&](size_t lo, size_t hi) {
+    uint32_t m = 0;
+    for (size_t c = lo; c < hi; ++c) { c2v[c] = pos_p2v ? pos_p2v[faces[c]] : faces[c]; m = std::max(m, c2v[c]); }
+    uint32_t cur = maxv_a.load();
+    while (m > cur && !maxv_a.compare_exchange_weak(cur, m)) {}
+  });
+  V = C ? maxv_a.load() + 1 : 0;
   {   // core/corner_table/mod.rs:105-108: unused vertex ids are a panic in the reference
     std::vector<uint8_t> used(V, 0);
-    for (uint32_t c = 0; c < C; ++c) used[c2v[c]] = 1;
-    for (uint32_t v = 0; v < V; ++v) if (!used[v]) { err = "mesh contains unused vertices"; return DMI_ERR_UNUSED_VERTICES; }
+    parallel_for(C, [&](size_t lo, size_t hi) { for (size_t c = lo; c < hi; ++c) used[c2v[c]] = 1; });   // (racing stores of the same value)
+    std::atomic<int> unused{0};
+    parallel_for(V, [&](size_t lo, size_t hi) { for (size_t v = lo; v < hi; ++v) if (!used[v]) { unused.store(1); break; } });
+    if (unused.load()) { err = "mesh contains unused vertices"; return DMI_ERR_UNUSED_VERTICES; }
   }
   UniversalBuilder b(*this);
-  b.match_half_edges();
-  if (b.has_non_manifold_edge()) b.break_non_manifold_edges();
-  b.left_most_corners();
+  const bool serial_only = std::getenv("DMI_SERIAL_TABLES") != nullptr;   // (tests: the literal serial walks on every input)
+  const bool big = C >= (1u << 18) && !serial_only;   // small meshes: a batch already runs one mesh per host thread
+  if (!(big && b.match_half_edges_parallel())) {
+    b.match_half_edges();
+    if (b.has_non_manifold_edge()) b.break_non_manifold_edges();
+  }
+  if (!(big && b.left_most_corners_parallel())) b.left_most_corners();
   att.clear();
   return DMI_OK;
 }
@@ -182,47 +272,67 @@ void CornerTables::build_attribute(const uint32_t* p2v) {
   build_attribute_into(att.back(), p2v);
 }
 
-// (reads the universal table only: attribute tables of one mesh can be built concurrently)
+// (reads the universal table only: attribute tables of one mesh can be built concurrently; the loops of a large mesh run on host
+// threads themselves — seam flags are idempotent byte stores, the attribute-vertex ids of a universal vertex are a prefix sum over
+// the per-vertex counts: exactly the ids the serial `nv++` walk hands out)
 void CornerTables::build_attribute_into(AttTable& a, const uint32_t* p2v) const {
   const uint32_t C = 3 * F;
   a.seam_edge.assign(C, 0);
   std::vector<uint8_t> vseam(V, 0);
   auto val = [&](uint32_t corner) { uint32_t p = c2p[corner]; return p2v ? p2v[p] : p; };
-  for (uint32_t c = 0; c < C; ++c) {
-    const uint32_t o = opp[c];
-    if (o == kNone) {
-      a.seam_edge[c] = 1;
-      vseam[c2v[corner_next(c)]] = 1;
-      vseam[c2v[corner_prev(c)]] = 1;
-      continue;
+  parallel_for(C, [&](size_t lo, size_t hi) {
+    for (size_t cc = lo; cc < hi; ++cc) {
+      const uint32_t c = (uint32_t)cc;
+      const uint32_t o = opp[c];
+      if (o == kNone) {
+        a.seam_edge[c] = 1;
+        vseam[c2v[corner_next(c)]] = 1;
+        vseam[c2v[corner_prev(c)]] = 1;
+        continue;
+      }
+      if (o < c) continue;
+      // the two shared endpoints: next(c)↔prev(o) and prev(c)↔next(o)
+      if (val(corner_next(c)) != val(corner_prev(o)) || val(corner_prev(c)) != val(corner_next(o))) {
+        a.seam_edge[c] = a.seam_edge[o] = 1;
+        vseam[c2v[corner_next(c)]] = vseam[c2v[corner_prev(c)]] = 1;
+        vseam[c2v[corner_next(o)]] = vseam[c2v[corner_prev(o)]] = 1;
+      }
     }
-    if (o < c) continue;
-    // the two shared endpoints: next(c)↔prev(o) and prev(c)↔next(o)
-    if (val(corner_next(c)) != val(corner_prev(o)) || val(corner_prev(c)) != val(corner_next(o))) {
-      a.seam_edge[c] = a.seam_edge[o] = 1;
-      vseam[c2v[corner_next(c)]] = vseam[c2v[corner_prev(c)]] = 1;
-      vseam[c2v[corner_next(o)]] = vseam[c2v[corner_prev(o)]] = 1;
-    }
-  }
+  });
   a.opp.resize(C);
-  for (uint32_t c = 0; c < C; ++c) a.opp[c] = a.seam_edge[c] ? kNone : opp[c];
+  parallel_for(C, [&](size_t lo, size_t hi) { for (size_t c = lo; c < hi; ++c) a.opp[c] = a.seam_edge[c] ? kNone : opp[c]; });
   a.c2v.assign(C, 0);
-  a.lmc.clear();
-  a.lmc.reserve(V);
-  uint32_t nv = 0;
   auto a_swing_left = [&](uint32_t c) { uint32_t o = a.opp[corner_next(c)]; return o == kNone ? kNone : corner_next(o); };
   auto u_swing_right = [&](uint32_t c) { uint32_t o = opp[corner_prev(c)]; return o == kNone ? kNone : corner_prev(o); };
-  for (uint32_t v = 0; v < V; ++v) {
+  auto fan_start = [&](uint32_t v) {   // seam-aware swing to the fan start (attribute_corner_table.rs:101-113)
     uint32_t first = lmc[v];
-    if (vseam[v]) for (uint32_t n; (n = a_swing_left(first)) != kNone && n != lmc[v];) first = n;   // seam-aware swing to the fan start
-    uint32_t id = nv++;
-    a.c2v[first] = id;
-    a.lmc.push_back(first);
-    for (uint32_t cur = u_swing_right(first); cur != kNone && cur != first; cur = u_swing_right(cur)) {
-      if (a.seam_edge[corner_next(cur)]) { id = nv++; a.lmc.push_back(cur); }
-      a.c2v[cur] = id;
+    if (vseam[v]) for (uint32_t n; (n = a_swing_left(first)) != kNone && n != lmc[v];) first = n;
+    return first;
+  };
+  // attribute vertices per universal vertex: 1 + the seam edges its right swing crosses (:116-133)
+  std::vector<uint32_t> base((size_t)V + 1, 0);
+  parallel_for(V, [&](size_t lo, size_t hi) {
+    for (size_t v = lo; v < hi; ++v) {
+      uint32_t k = 1;
+      if (vseam[v]) { const uint32_t first = fan_start((uint32_t)v); for (uint32_t cur = u_swing_right(first); cur != kNone && cur != first; cur = u_swing_right(cur)) k += a.seam_edge[corner_next(cur)]; }
+      base[v + 1] = k;
     }
-  }
+  });
+  for (uint32_t v = 0; v < V; ++v) base[v + 1] += base[v];
+  const uint32_t nv = base[V];
+  a.lmc.assign(nv, kNone);
+  parallel_for(V, [&](size_t lo, size_t hi) {
+    for (size_t v = lo; v < hi; ++v) {
+      const uint32_t first = fan_start((uint32_t)v);
+      uint32_t id = base[v];
+      a.c2v[first] = id;
+      a.lmc[id] = first;
+      for (uint32_t cur = u_swing_right(first); cur != kNone && cur != first; cur = u_swing_right(cur)) {
+        if (a.seam_edge[corner_next(cur)]) { ++id; a.lmc[id] = cur; }
+        a.c2v[cur] = id;
+      }
+    }
+  });
   a.num_vertices = nv;
 }
 
@@ -371,7 +481,7 @@ uint8_t zero_probability(uint64_t count_zero, float denominator) {
   return (uint8_t)std::min(255u, std::max(1u, q));
 }
 
-int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& err) {
+int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& err, const EdgebreakerHooks* hooks) {
   Walker w(t);
   ByteSink s;
   s.u8(0);   // EdgebreakerKind::Standard
@@ -394,7 +504,10 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
       w.run_from(start);
     }
   }
-  if (w.bad) { err = "edgebreaker: inconsistent connectivity (reference unwrap() panic)"; return DMI_ERR_CONNECTIVITY; }
+  if (w.bad) { err = "edgebreaker: inconsistent connectivity (reference unwrap() panic)"; if (hooks && hooks->before_seams) hooks->before_seams(); return DMI_ERR_CONNECTIVITY; }
+  out.seeds.assign(w.init_corners.rbegin(), w.init_corners.rend());   // edgebreaker.rs:523-529
+  out.seeds.insert(out.seeds.end(), w.processed.begin(), w.processed.end());
+  if (hooks && hooks->seeds_ready) hooks->seeds_ready();
   s.leb128(w.symbols.size());
   s.leb128(w.num_split_symbols);
   {   // encode_topology_splits :375-403
@@ -428,6 +541,7 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
     s.bytes(rc.out);
     return true;
   };
+  if (hooks && hooks->before_seams) hooks->before_seams();
   if (!rabs_block(w.start_interior)) { err = "rABS state too large"; return DMI_ERR_ENTROPY; }
   {   // attribute seams :611-653
     std::vector<uint8_t> fv(t.F, 0);
@@ -445,8 +559,6 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
     }
     for (auto& sd : seams) if (!rabs_block(sd)) { err = "rABS state too large"; return DMI_ERR_ENTROPY; }
   }
-  out.seeds.assign(w.init_corners.rbegin(), w.init_corners.rend());
-  out.seeds.insert(out.seeds.end(), w.processed.begin(), w.processed.end());
   out.connectivity.swap(s.b);
   return DMI_OK;
 }

@@ -166,3 +166,84 @@ def test_cpp_and_numpy_builders_agree_when_every_point_is_referenced():
         assert (a.point_to_value is None) == (c.point_to_value is None)
         if a.point_to_value is not None:
             assert (a.point_to_value == c.point_to_value).all()
+
+
+def _conn_snapshot(mesh):
+    conn = dmi.encode_connectivity(mesh)
+    snap = [conn.bytes, conn.seeds()]
+    for i in range(conn.num_tables):
+        t = conn.table(i)
+        snap += [t["corner_to_vertex"], t["opposite"], t["left_most_corner"], t["sequence"], np.uint32(t["num_vertices"])]
+    conn.close()
+    return snap
+
+
+def _same(a, b):
+    return len(a) == len(b) and all((x == y) if isinstance(x, (bytes, np.integer)) else (x.shape == y.shape and (x == y).all()) for x, y in zip(a, b))
+
+
+def _large_cases():
+    """Meshes above the size at which the host stages go parallel (≥ 2^18 corners): closed / open grids, UV seams, a non-manifold
+    soup (edge test → serial matching + edge breaking), two sheets glued at single vertices (manifold edges, several fans per vertex →
+    serial left-most-corner walk with vertex splits), a position-degenerate face (→ serial matching)."""
+    out = {}
+    out["closed grid"] = synth.torus_mesh(420)             # (≥ 2^20 corners: the loops really run on several threads)
+    out["open grid, no normals"] = synth.torus_mesh(310, normals=False, open_boundary=True)
+    faces, pos, nrm, uv = synth.torus_grid(420, open_boundary=True)
+    corner = faces.ravel()
+    cuv = uv[corner].copy()
+    cuv[np.repeat((np.arange(len(faces)) % 11) == 0, 3)] += np.float32(0.25)     # UV seams along scattered faces
+    b = dmi.MeshBuilder()
+    pid = b.add_attribute(pos[corner], dmi.ATT_POSITION)
+    b.add_attribute(nrm[corner], dmi.ATT_NORMAL, dmi.DOMAIN_CORNER, parents=[pid])
+    b.add_attribute(cuv, dmi.ATT_TEXCOORD, dmi.DOMAIN_CORNER, parents=[pid])
+    b.set_connectivity_attribute(np.arange(len(corner), dtype=np.uint32).reshape(-1, 3))
+    out["UV seams"] = b.build()
+    rng = np.random.default_rng(7)
+    n_pts = 40000
+    sf = rng.integers(0, n_pts, size=(100000, 3)).astype(np.uint32)
+    sf = sf[(sf[:, 0] != sf[:, 1]) & (sf[:, 1] != sf[:, 2]) & (sf[:, 2] != sf[:, 0])]
+    used = np.unique(sf)
+    remap = np.zeros(n_pts, np.uint32)
+    remap[used] = np.arange(len(used), dtype=np.uint32)
+    out["non-manifold soup"] = dmi.Mesh(remap[sf], [dmi.Attribute(rng.uniform(-1, 1, size=(len(used), 3)).astype(np.float32), dmi.ATT_POSITION)])
+    f1, p1, _, _ = synth.torus_grid(220, open_boundary=True)
+    f2 = f1.copy() + np.uint32(len(p1))
+    p2 = p1 + np.float32(5.0)
+    glue = f2.copy()
+    for a_, b_ in ((0, 0), (777, 4242)):          # vertex b_ of sheet 2 becomes vertex a_ of sheet 1
+        glue[glue == np.uint32(len(p1) + b_)] = np.uint32(a_)
+    allp = np.concatenate([p1, p2])
+    ff = np.concatenate([f1, glue])
+    used = np.unique(ff)
+    remap = np.zeros(len(allp), np.uint32)
+    remap[used] = np.arange(len(used), dtype=np.uint32)
+    out["sheets glued at vertices"] = dmi.Mesh(remap[ff], [dmi.Attribute(allp[used], dmi.ATT_POSITION)])
+    f3, p3, _, _ = synth.torus_grid(300)
+    p3 = p3.copy()
+    p3[5] = p3[6]                                  # duplicate position value: the builder keeps both points (their faces become position-degenerate)
+    b = dmi.MeshBuilder()
+    pid = b.add_attribute(p3, dmi.ATT_POSITION)
+    b.add_attribute(np.arange(len(p3), dtype=np.uint32).reshape(-1, 1), dmi.ATT_CUSTOM)   # keeps the two points distinct
+    b.set_connectivity_attribute(f3)
+    out["position-degenerate faces"] = b.build()
+    return out
+
+
+@pytest.mark.parametrize("name", ["closed grid", "open grid, no normals", "UV seams", "non-manifold soup", "sheets glued at vertices", "position-degenerate faces"])
+def test_parallel_host_stages_equal_the_serial_walks_and_the_oracle(name, monkeypatch):
+    """Large meshes build their corner tables on host threads when the result cannot depend on the corner order, and overlap the
+    attribute tables / sequencers with the Edgebreaker walk; DMI_SERIAL_TABLES=1 forces the literal serial walks.  Same tables, same
+    connectivity bytes, same seeds and sequences — and the oracle's."""
+    mesh = _large_cases()[name]
+    assert 3 * len(mesh.faces) >= 1 << 18
+    fast = _conn_snapshot(mesh)
+    monkeypatch.setenv("DMI_SERIAL_TABLES", "1")
+    slow = _conn_snapshot(mesh)
+    assert _same(fast, slow)
+    sess = oracle_from_product_mesh(mesh)
+    try:
+        sess.encode()
+    except orc.OracleError:
+        return   # (an input the reference cannot encode: the two forms agreeing is all there is to check)
+    assert fast[0][11:] == bytes(sess.blob("conn.bytes"))
