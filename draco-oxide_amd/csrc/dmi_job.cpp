@@ -39,6 +39,7 @@ enum Scheme : uint8_t { kDelta = 0, kParallelogram = 1, kTexCoord = 5, kNormal =
 enum Transform : uint8_t { kDifference = 0, kWrapped = 1, kOctOrth = 3 };              // prediction_transform/mod.rs:92-101
 enum Port : uint8_t { kToBits = 1, kCoordwise = 2, kOct = 3 };                          // portabilization/mod.rs:85-92
 constexpr uint32_t kMaxPrepareWorkers = 128;   // host threads of one dmi_meshes_prepare call
+constexpr uint32_t kPrepareStreams = 16;       // library streams their jobs are created on (per device)
 constexpr uint32_t kDeviceRelabelMinFaces = 1u << 17;   // job creation relabels the connectivity inputs with kernels from this size up (dmi_relabel.hip)
 constexpr uint64_t kHostChainMinSymbols = 32768;   // a job whose longest stream is at least this long codes its streams on host cores (hybrid form)
 
@@ -2397,7 +2398,8 @@ static int meshes_prepare_impl(const dmi_mesh* meshes, uint32_t n, const dmi_con
       dmi_config c{};
       if (cfg) c = *cfg;
       if (device_of_mesh) c.device = device_of_mesh[j];
-      if (library_streams && adopted_for != c.device) { g_adopt_stream = worker_stream(t, c.device); adopted_for = c.device; }   // (null: dmi_job_create makes its own)
+      // (creating a stream costs ≈ 1 ms and serialises across threads: the workers share kPrepareStreams of them)
+      if (library_streams && adopted_for != c.device) { g_adopt_stream = worker_stream(t % kPrepareStreams, c.device); adopted_for = c.device; }   // (null: dmi_job_create makes its own)
       rcs[j] = dmi_mesh_prepare(&meshes[j], &c, &header_and_connectivity[j], &jobs[j]);
       if (rcs[j]) errs[j] = g_last_error;
     }

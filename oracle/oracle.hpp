@@ -239,6 +239,24 @@ using Blobs = std::map<std::string, std::vector<u8>>;   // named debug dumps for
 std::string encode_attributes(const std::vector<Attribute>& atts, const ConnOutput& conn, const Options& opt, Bytes& w, Blobs* dump);  // encode/attribute/mod.rs:13-93
 std::string encode_mesh(const Mesh& mesh, const Options& opt, Bytes& w, Blobs* dump);   // encode/mod.rs:59-97
 
+// ---------------------------------------------------------------------------------------------
+// The attribute section read backwards (orc_decode.cpp): what a decoder recovers once the connectivity stage is known.
+// ---------------------------------------------------------------------------------------------
+struct DecodedAttribute {
+  u32 id = 0;
+  AttType type = Position;
+  CompType ctype = F32;
+  int ncomp = 0, ncomp_port = 0;        // components of the attribute / of its portable (quantized) form
+  u8 domain = 0, port = 0, scheme = 0, transform = 0;
+  std::vector<u32> seq;                 // the attribute's coding sequence (corners)
+  std::vector<i32> portable;            // quantized values, sequence order, ncomp_port per entry
+  std::vector<float> values;            // dequantized values, sequence order, ncomp per entry (ToBits: the raw 4-byte values)
+  std::vector<i32> by_vertex;           // (Position) quantized values by universal vertex
+};
+std::string decode_attributes(const u8* data, size_t len, const ConnOutput& conn, std::vector<DecodedAttribute>& out, size_t* consumed);
+void oct_orthogonal_inverse(const i32* pred, const i32* corr, i32* orig);   // oct_orthogonal.rs:23-74 inverted
+void oct_orthogonal_map(const i32* orig, const i32* pred, i32* corr);       // oct_orthogonal.rs:23-74
+
 // wall-clock seconds of the last encode_mesh (BASELINE.md §3 stage split): [0] connectivity, [1] attribute section, [2] sequencer part
 // of [1], [3] corner tables (part of [0]; Edgebreaker + connectivity bytes = [0] - [3]), [4] quantize (portabilization), [5] predict,
 // [6] prediction transform, [7] histogram + table normalisation/serialisation, [8] rANS + rABS coders, [9] symbols through the rANS coder

@@ -263,6 +263,8 @@ void predict_texcoord(const Ctx& cx, u32 c, size_t i, std::vector<u8>& orientati
   texcoord_fallback(cx, c, i, out);
 }
 
+}  // namespace
+
 // oct_orthogonal.rs:23-74 (a10)
 void oct_orthogonal_map(const i32* orig_in, const i32* pred_in, i32* corr) {
   const i32 one = 255 / 2;
@@ -291,6 +293,8 @@ void oct_orthogonal_map(const i32* orig_in, const i32* pred_in, i32* corr) {
   if (c1 < 0) c1 = wadd(c1, 255);
   corr[0] = c0; corr[1] = c1;
 }
+
+namespace {
 
 enum Scheme : u8 { SchDelta = 0, SchParallelogram = 1, SchTexCoord = 5, SchNormal = 6 };   // prediction_scheme/mod.rs:74-86
 enum Transform : u8 { TrDifference = 0, TrWrapped = 1, TrOctOrth = 3 };                  // prediction_transform/mod.rs:92-101

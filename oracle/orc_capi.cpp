@@ -15,6 +15,8 @@ struct Session {
   Blobs blobs;
   std::string err;
   double last_encode_seconds = 0.0;
+  std::vector<DecodedAttribute> decoded;
+  std::vector<std::vector<u32>> decoded_points;
 };
 thread_local std::string g_err;
 }  // namespace
@@ -102,6 +104,43 @@ const uint8_t* orc_blob(void* sp, const char* key, uint64_t* len) {
   *len = it->second.size();
   return it->second.data();
 }
+
+// ---- the attribute section read backwards (orc_decode.cpp) ----
+// Decodes `data` (an attribute section: the oracle's own, or the product's) against the connectivity stage of the session's mesh.
+// Results stay in the session: orc_decoded_count / orc_decoded_info / orc_decoded_array.
+int orc_decode_attributes(void* sp, const uint8_t* data, uint64_t len, uint64_t* consumed) {
+  auto* s = static_cast<Session*>(sp);
+  Bytes scratch;
+  ConnOutput conn;
+  g_err = encode_connectivity(s->mesh, scratch, conn);   // what a decoder knows after ITS connectivity stage: the same tables and seeds
+  if (!g_err.empty()) return 1;
+  size_t used = 0;
+  s->decoded.clear();
+  g_err = decode_attributes(data, (size_t)len, conn, s->decoded, &used);
+  if (consumed) *consumed = used;
+  if (g_err.empty()) {   // the points behind the sequence entries, for the caller's comparisons
+    s->decoded_points.assign(s->decoded.size(), {});
+    for (size_t i = 0; i < s->decoded.size(); ++i) for (u32 c : s->decoded[i].seq) s->decoded_points[i].push_back(conn.ct.point_idx(c));
+  }
+  return g_err.empty() ? 0 : 1;
+}
+uint32_t orc_decoded_count(void* sp) { return (u32) static_cast<Session*>(sp)->decoded.size(); }
+// info[8] = {id, type, ncomp, ncomp_port, port, scheme, transform, entries}
+void orc_decoded_info(void* sp, uint32_t i, uint32_t* info) {
+  auto& a = static_cast<Session*>(sp)->decoded[i];
+  info[0] = a.id; info[1] = a.type; info[2] = (u32)a.ncomp; info[3] = (u32)a.ncomp_port; info[4] = a.port; info[5] = a.scheme; info[6] = a.transform; info[7] = (u32)a.seq.size();
+}
+// which: 0 portable (i32), 1 values (f32 / raw 4-byte), 2 point index of every sequence entry (u32)
+const void* orc_decoded_array(void* sp, uint32_t i, int which, uint64_t* count) {
+  auto* s = static_cast<Session*>(sp);
+  auto& a = s->decoded[i];
+  if (which == 0) { *count = a.portable.size(); return a.portable.data(); }
+  if (which == 1) { *count = a.values.size(); return a.values.data(); }
+  *count = s->decoded_points[i].size();
+  return s->decoded_points[i].data();
+}
+// oct_orthogonal.rs:23-74 and its inverse on one pair (KAT: the map must be invertible on the whole octahedral grid)
+void orc_oct_orthogonal(const int32_t* orig, const int32_t* pred, int32_t* corr, int32_t* back) { oct_orthogonal_map(orig, pred, corr); oct_orthogonal_inverse(pred, corr, back); }
 
 // ---- small KAT hooks ----
 uint64_t orc_leb128(uint64_t v, uint8_t* out) { Bytes b; leb128_write(v, b); std::memcpy(out, b.data(), b.size()); return b.size(); }

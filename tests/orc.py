@@ -76,6 +76,13 @@ def lib():
     L.orc_encode_symbols.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
     L.orc_encode_symbols.restype = C.c_int64
     L.orc_decode_symbols.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+    L.orc_decode_attributes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    L.orc_decoded_count.argtypes = [C.c_void_p]
+    L.orc_decoded_count.restype = C.c_uint32
+    L.orc_decoded_info.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    L.orc_decoded_array.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
+    L.orc_decoded_array.restype = C.c_void_p
+    L.orc_oct_orthogonal.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -190,6 +197,31 @@ class Session:
                 "histogram_and_tables_s": hist_tab, "rans_rabs_coders_s": coders, "attribute_section_s": atts, "connectivity_s": conn,
                 "rans_only_msym_per_s": (n_rans / rans_only / 1e6) if rans_only > 0 else 0.0, "rans_symbols": n_rans}
 
+    def decode_attributes(self, section):
+        """The attribute section `section` (bytes) read backwards against this mesh's connectivity stage (oracle/orc_decode.cpp).
+        Returns [dict(id, type, ncomp, ncomp_port, port, scheme, transform, portable [n, ncomp_port] i32, values [n, ncomp] f32 (u32 for
+        ToBits), points [n] u32 = the point behind every sequence entry)], and the number of bytes consumed."""
+        b = np.frombuffer(section, dtype=np.uint8)
+        used = C.c_uint64(0)
+        self._check(self.L.orc_decode_attributes(self.h, _ptr(b), len(b), C.byref(used)))
+        out = []
+        for i in range(self.L.orc_decoded_count(self.h)):
+            info = np.zeros(8, np.uint32)
+            self.L.orc_decoded_info(self.h, i, _ptr(info))
+            aid, ty, nc, ncp, port, scheme, transform, n = [int(x) for x in info]
+
+            def arr(which, dtype, cols):
+                cnt = C.c_uint64(0)
+                p = self.L.orc_decoded_array(self.h, i, which, C.byref(cnt))
+                if not p or cnt.value == 0:
+                    return np.zeros((0, cols) if cols else 0, dtype)
+                a = np.frombuffer(C.string_at(p, cnt.value * 4), dtype=dtype).copy()
+                return a.reshape(-1, cols) if cols else a
+            vals = arr(1, np.uint32 if port == 1 else np.float32, nc)
+            out.append(dict(id=aid, type=ty, ncomp=nc, ncomp_port=ncp, port=port, scheme=scheme, transform=transform,
+                            portable=arr(0, np.int32, ncp), values=vals, points=arr(2, np.uint32, 0)))
+        return out, used.value
+
     def blob(self, key, dtype=np.uint8):
         n = C.c_uint64(0)
         p = self.L.orc_blob(self.h, key.encode(), C.byref(n))
@@ -264,3 +296,11 @@ def decode_symbols(data, n):
     if lib().orc_decode_symbols(_ptr(b), len(b), n, _ptr(out), C.byref(used)) != 0:
         raise OracleError(lib().orc_last_error().decode())
     return out, used.value
+
+
+def oct_orthogonal_round_trip(orig, pred):
+    """(corr, back): the oct-orthogonal prediction transform of `orig` against `pred` and its inverse applied to the result."""
+    o = np.asarray(orig, np.int32); p = np.asarray(pred, np.int32)
+    corr = np.zeros(2, np.int32); back = np.zeros(2, np.int32)
+    lib().orc_oct_orthogonal(_ptr(o), _ptr(p), _ptr(corr), _ptr(back))
+    return corr, back

@@ -71,3 +71,158 @@ def test_duck_transcode_blob_bit_exact():
     p2 = doc2["meshes"][0]["primitives"][0]
     assert all("bufferView" not in doc2["accessors"][p2["attributes"][k]] for k in ids)
     assert len(out) < len(data)
+
+
+# ---- BASELINE configs[3]: lists of assets, one batch ---------------------------------------------------------------------------
+def _pad4(b):
+    return b + b"\0" * ((4 - len(b) % 4) % 4)
+
+
+def _make_asset(prims, interleave=False):
+    """A glTF document + one buffer holding `prims` = [dict(pos, nrm|None, uv|None, idx, feat|None, index_type)] as triangle
+    primitives of one mesh (+ an untouched extra bufferView that must be carried over)."""
+    buf = bytearray()
+    views, accessors, gprims = [], [], []
+
+    def add_view(data, stride=None, target=None):
+        off = len(buf)
+        buf.extend(_pad4(bytes(data)))
+        v = {"buffer": 0, "byteOffset": off, "byteLength": len(data)}
+        if stride:
+            v["byteStride"] = stride
+        views.append(v)
+        return len(views) - 1
+
+    for p in prims:
+        attrs = {}
+        cols = [("POSITION", p["pos"], "VEC3")] + ([("NORMAL", p["nrm"], "VEC3")] if p.get("nrm") is not None else []) + \
+               ([("TEXCOORD_0", p["uv"], "VEC2")] if p.get("uv") is not None else [])
+        if interleave:
+            rows = np.concatenate([c[1] for c in cols], axis=1).astype("<f4")
+            stride = rows.shape[1] * 4
+            vi = add_view(rows.tobytes(), stride=stride)
+            off = 0
+            for name, arr, ty in cols:
+                accessors.append({"bufferView": vi, "byteOffset": off, "componentType": 5126, "count": len(arr), "type": ty})
+                attrs[name] = len(accessors) - 1
+                off += arr.shape[1] * 4
+        else:
+            for name, arr, ty in cols:
+                vi = add_view(arr.astype("<f4").tobytes())
+                accessors.append({"bufferView": vi, "componentType": 5126, "count": len(arr), "type": ty})
+                attrs[name] = len(accessors) - 1
+        if p.get("feat") is not None:
+            ct, dt = p.get("feat_type", (5123, "<u2"))
+            vi = add_view(p["feat"].astype(dt).tobytes())
+            accessors.append({"bufferView": vi, "componentType": ct, "count": len(p["feat"]), "type": "SCALAR"})
+            attrs["_FEATURE_ID_0"] = len(accessors) - 1
+        ct, dt = {"u16": (5123, "<u2"), "u32": (5125, "<u4"), "u8": (5121, "u1")}[p.get("index_type", "u32")]
+        vi = add_view(p["idx"].astype(dt).tobytes())
+        accessors.append({"bufferView": vi, "componentType": ct, "count": p["idx"].size, "type": "SCALAR"})
+        gprims.append({"attributes": attrs, "indices": len(accessors) - 1, "mode": 4})
+    extra = add_view(b"carried over, byte for byte!")
+    doc = {"asset": {"version": "2.0"}, "buffers": [{"byteLength": len(buf)}], "bufferViews": views, "accessors": accessors,
+           "meshes": [{"primitives": gprims}], "nodes": [{"mesh": 0}], "scenes": [{"nodes": [0]}], "scene": 0,
+           "images": [{"bufferView": extra, "mimeType": "image/png"}]}
+    return doc, bytes(buf)
+
+
+def _prim(n, seed, normals=True, uvs=True, feat=False, open_boundary=False, index_type="u32"):
+    from draco_oxide_amd import synth
+    faces, pos, nrm, uv = synth.torus_grid(n, seed=seed, normals=normals, uvs=uvs, open_boundary=open_boundary)
+    d = dict(pos=pos, nrm=nrm, uv=uv, idx=faces.ravel(), index_type=index_type)
+    if feat:
+        d["feat"] = (np.arange(len(pos)) // 7 % 50).astype(np.uint32)
+    return d
+
+
+def _oracle_blob(p):
+    """The `.drc` the reference would embed for primitive dict `p`: attributes in sorted-name order, ids in add order."""
+    cols = [("NORMAL", p.get("nrm")), ("POSITION", p["pos"]), ("TEXCOORD_0", p.get("uv"))]
+    cols = [(n, a) for n, a in cols if a is not None]
+    pos_id = [n for n, _ in cols].index("POSITION")
+    specs = []
+    for n, a in cols:
+        ty = {"POSITION": orc.POSITION, "NORMAL": orc.NORMAL, "TEXCOORD_0": orc.TEXCOORD}[n]
+        specs.append(dict(data=a.astype(np.float32), type=ty, domain=orc.DOM_POSITION if n == "POSITION" else orc.DOM_CORNER, parents=[] if n == "POSITION" else [pos_id]))
+    if p.get("feat") is not None:
+        specs.append(dict(data=p["feat"].astype(np.uint32).reshape(-1, 1), type=orc.CUSTOM, domain=orc.DOM_CORNER))
+    return orc.Session.from_arrays(p["idx"].reshape(-1, 3), specs).encode()
+
+
+@pytest.mark.gpu
+def test_transcode_a_list_of_assets_as_one_batch(tmp_path):
+    """configs[3] through the driver: GLB bytes, a `.glb` path, a `.gltf` with an external `.bin`, a `.gltf` with a data URI — separate
+    and interleaved vertex buffers, u16 / u32 indices, primitives without normals / UVs, a `_FEATURE_ID_0` set — all primitives of all
+    files in ONE batch; every embedded blob equals the oracle's for that primitive, other bufferViews are carried over."""
+    import base64
+    files = [
+        [_prim(9, 1), _prim(14, 2, normals=False, index_type="u16"), _prim(11, 3, uvs=False, open_boundary=True)],
+        [_prim(20, 4, feat=True), _prim(8, 5, index_type="u16")],
+        [_prim(16, 6, open_boundary=True)],
+        [_prim(12, 7, feat=True, normals=False, uvs=False), _prim(10, 8)],
+    ]
+    sources = []
+    doc, buf = _make_asset(files[0])
+    sources.append(gltf.write_glb(doc, buf))                                       # GLB bytes
+    doc, buf = _make_asset(files[1], interleave=True)
+    (tmp_path / "b.glb").write_bytes(gltf.write_glb(doc, buf))
+    sources.append(str(tmp_path / "b.glb"))                                        # .glb path
+    doc, buf = _make_asset(files[2])
+    doc["buffers"][0]["uri"] = "c.bin"
+    (tmp_path / "c.bin").write_bytes(buf)
+    (tmp_path / "c.gltf").write_text(json.dumps(doc))
+    sources.append(str(tmp_path / "c.gltf"))                                       # .gltf + external .bin
+    doc, buf = _make_asset(files[3], interleave=True)
+    doc["buffers"][0]["uri"] = "data:application/octet-stream;base64," + base64.b64encode(buf).decode()
+    (tmp_path / "d.gltf").write_text(json.dumps(doc))
+    sources.append(str(tmp_path / "d.gltf"))                                       # .gltf + data URI
+    sources.append(open(DUCK, "rb").read())
+    results = gltf.transcode_files(sources)
+    assert len(results) == 5
+    for prims, (glb, blobs) in zip(files, results[:4]):
+        assert len(blobs) == len(prims)
+        embedded = gltf.draco_blobs_of(glb)
+        for p, blob, (payload, ids) in zip(prims, blobs, embedded):
+            want = _oracle_blob(p)
+            assert blob == want
+            assert payload[: len(want)] == want and len(payload) - len(want) < 4
+            expect_names = sorted(n for n in ("NORMAL", "POSITION", "TEXCOORD_0") if p.get({"NORMAL": "nrm", "POSITION": "pos", "TEXCOORD_0": "uv"}[n]) is not None)
+            expect_names += ["_FEATURE_ID_0"] if p.get("feat") is not None else []
+            assert ids == {n: k for k, n in enumerate(expect_names)}
+        doc2, bin2 = gltf.read_glb(glb)
+        img = doc2["bufferViews"][doc2["images"][0]["bufferView"]]
+        assert bin2[img["byteOffset"]: img["byteOffset"] + img["byteLength"]] == b"carried over, byte for byte!"
+        assert "KHR_draco_mesh_compression" in doc2["extensionsRequired"] and len(glb) % 4 == 0
+    data, doc, binary, prim = _duck()
+    assert results[4][1][0] == _oracle_session(doc, binary, prim).encode()
+    # the single-process multi-device path (every mesh on device 0 here) gives the same blobs
+    again = gltf.transcode_files(sources, devices="all")
+    assert [b for _, bl in again for b in bl] == [b for _, bl in results for b in bl]
+
+
+@pytest.mark.gpu
+def test_transcode_1024_primitives_in_one_batch():
+    """64 assets × 16 primitives = 1024 meshes through transcode_files in one dmi_jobs_encode; a sample of blobs against the oracle."""
+    rng = np.random.default_rng(5)
+    files = [[_prim(int(rng.integers(6, 40)), seed=1000 + 16 * f + k, open_boundary=bool((f + k) % 3 == 0), index_type="u16" if k % 2 else "u32") for k in range(16)] for f in range(64)]
+    sources = [gltf.write_glb(*_make_asset(prims, interleave=bool(i % 2))) for i, prims in enumerate(files)]
+    results = gltf.transcode_files(sources)
+    assert sum(len(blobs) for _, blobs in results) == 1024
+    for f, k in [(0, 0), (5, 3), (17, 15), (33, 8), (63, 15), (40, 1), (21, 7), (9, 12)]:
+        assert results[f][1][k] == _oracle_blob(files[f][k])
+
+
+def test_primitive_the_reference_cannot_encode_is_refused():
+    doc, buf = _make_asset([_prim(6, 1)])
+    prim = doc["meshes"][0]["primitives"][0]
+    prim["attributes"]["COLOR_0"] = prim["attributes"]["NORMAL"]      # sorts before POSITION: the reference's parent ids go wrong
+    with pytest.raises(ValueError):
+        gltf.primitive_to_mesh(doc, buf, prim)
+
+
+def test_feature_id_accessor_conversions():
+    vals = np.array([0, 1, 255, 7, 300.9, -4.0, np.nan], np.float32)
+    doc = {"accessors": [{"bufferView": 0, "componentType": 5126, "count": len(vals), "type": "SCALAR"}], "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 4 * len(vals)}]}
+    got = gltf._accessor_u32_scalars(doc, vals.astype("<f4").tobytes(), 0)
+    assert got.tolist() == [0, 1, 255, 7, 300, 0, 0]                    # Rust `as u32`: truncates, saturates at 0, NaN → 0
