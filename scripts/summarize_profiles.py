@@ -1,44 +1,98 @@
-"""Turn the rocprofv3 outputs merged into gpurun_out/ into the committed summaries under profiles/.
-usage: summarize_profiles.py <tag> <stats_dir> <fetch_dir> <write_dir> <bench_log> <steps_in_pmc_run>"""
-import collections, csv, glob, json, re, sys
+"""Turn the rocprofv3 outputs of scripts/profile_round.sh (gpurun_out/<tag>/{stats,fetch,write,sq,tcp}) into the committed summaries
+under profiles/.   usage: summarize_profiles.py <tag> <dir> <steps_in_pmc_runs> [--traffic-only]
+  profiles/<tag>_kernel_stats.csv   per-kernel calls / total / average (rocprofv3 --kernel-trace --stats)
+  profiles/<tag>_pmc_traffic.csv    per-kernel FETCH_SIZE / WRITE_SIZE per launch + the quantize+predict pass per step
+  profiles/<tag>_pmc_sq.csv         per-kernel wave issue / wait split (SQ counters) and L1 request counters
+  profiles/<tag>_bench.json         the bench line of the same session (roofline.traffic = this session's counters)
+--traffic-only prints the pass's HBM bytes per step (FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE)."""
+import collections, csv, glob, json, os, re, sys
 
-tag, stats_dir, fetch_dir, write_dir, bench_log, pmc_steps = sys.argv[1:7]
-pmc_steps = int(pmc_steps)
+tag, base, pmc_steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
+traffic_only = "--traffic-only" in sys.argv
+
 
 def short(n):
-    m = re.search(r"(k_[a-z_0-9]+(<\d>)?)", n)
-    return m.group(1) if m else n[:40]
+    m = re.search(r"(k_[a-z_0-9]+)", n)
+    return m.group(1) if m else re.sub(r"\(.*", "", n)[:48]
 
-rows = list(csv.DictReader(open((glob.glob(f"{stats_dir}/*/*_kernel_stats.csv") + glob.glob(f"{stats_dir}/*_kernel_stats.csv"))[0])))
-out = [f"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline   ({tag}, MI355X)", "kernel, calls, total_ms, avg_us, pct"]
-for r in rows:
-    out.append(f"{short(r['Name'])}, {r['Calls']}, {float(r['TotalDurationNs'])/1e6:.3f}, {float(r['AverageNs'])/1e3:.2f}, {r['Percentage']}")
+
+def find(sub, suffix):
+    hits = glob.glob(f"{base}/{sub}/**/*{suffix}", recursive=True)
+    return hits[0] if hits else None
+
+
+def agg(sub, names):
+    acc = {n: collections.defaultdict(list) for n in names}
+    path = find(sub, "_counter_collection.csv")
+    if not path:
+        return acc
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] in acc:
+            acc[r["Counter_Name"]][short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return acc
+
+
+PASS_PREFIXES = ("k_value_ranges", "k_seq_quantize", "k_i32_minmax_final", "k_predict_fused", "k_predict_packed", "k_orient_summary", "k_pred_parallelogram",
+                 "k_pred_texcoord", "k_pred_delta")
+F = agg("fetch", ["FETCH_SIZE"])["FETCH_SIZE"]
+W = agg("write", ["WRITE_SIZE"])["WRITE_SIZE"]
+tf = tw = 0.0
+rows = []
+for n in sorted(set(F) | set(W)):
+    f, w = F.get(n, [0.0]), W.get(n, [0.0])
+    fa, wa = sum(f) / len(f) * 1024 / 1e6, sum(w) / len(w) * 1024 / 1e6      # counter unit: KiB
+    rows.append(f"{n}, {max(len(f), len(w))}, {fa:.2f}, {2 * fa:.2f}, {wa:.2f}")
+    if n.startswith(PASS_PREFIXES):
+        tf += sum(f) * 1024 / pmc_steps
+        tw += sum(w) * 1024 / pmc_steps
+traffic = int(2 * tf + tw)
+if traffic_only:
+    print(traffic)
+    sys.exit(0)
+
+os.makedirs("profiles", exist_ok=True)
+stats = find("stats", "_kernel_stats.csv")
+out = [f"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-batch --no-scopes   ({tag}, MI355X)",
+       "kernel, calls, total_ms, avg_us, pct"]
+if stats:
+    for r in csv.DictReader(open(stats)):
+        out.append(f"{short(r['Name'])}, {r['Calls']}, {float(r['TotalDurationNs']) / 1e6:.3f}, {float(r['AverageNs']) / 1e3:.2f}, {r['Percentage']}")
 open(f"profiles/{tag}_kernel_stats.csv", "w").write("\n".join(out) + "\n")
 
-def agg(d, cname):
-    acc = collections.defaultdict(list)
-    for r in csv.DictReader(open((glob.glob(f"{d}/*/*_counter_collection.csv") + glob.glob(f"{d}/*_counter_collection.csv"))[0])):
-        if r["Counter_Name"] == cname:
-            acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
-    return acc
-F, W = agg(fetch_dir, "FETCH_SIZE"), agg(write_dir, "WRITE_SIZE")
-PASS = {"k_value_ranges", "k_value_ranges_final", "k_seq_quantize", "k_i32_minmax_final", "k_predict_fused", "k_orient_summary",
-        # the per-attribute kernels of meshes with seams (not launched by the seam-free bench workload)
-        "k_pred_parallelogram_wrapped<3>", "k_face_normals", "k_pred_normal_octorth", "k_pred_texcoord_wrapped"}
-lines = [f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps {pmc_steps - 1} --warmup 1 --no-cpu-baseline ({tag})",
+lines = [f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps {pmc_steps - 1} --warmup 1 --no-cpu-baseline --no-batch --no-scopes ({tag})",
          "# per-launch averages, MB; counter unit KiB.  fetch_x2 = FETCH_SIZE doubled (gfx950 reports half of a wide coalesced read; exact for the",
          "# streaming kernels, an upper bound for the gather kernels whose access width is uncalibrated — MI355X_MICROARCH.md §HBM)",
-         "kernel, launches, fetch_MB, fetch_x2_MB, write_MB"]
-tf = tw = 0.0
-for n in sorted(set(F) | set(W)):
-    f, w = F.get(n, [0]), W.get(n, [0])
-    fa, wa = sum(f) / len(f) * 1024 / 1e6, sum(w) / len(w) * 1024 / 1e6
-    lines.append(f"{n}, {len(f)}, {fa:.2f}, {2*fa:.2f}, {wa:.2f}")
-    if n in PASS or n.startswith("k_predict_fused") or n.startswith("k_pred_parallelogram"):
-        tf += fa * len(f) / pmc_steps
-        tw += wa * len(w) / pmc_steps
-lines.append(f"# quantize+predict pass per step: fetch {tf:.1f} MB raw / {2*tf:.1f} MB doubled, write {tw:.1f} MB")
+         "kernel, launches, fetch_MB, fetch_x2_MB, write_MB"] + rows
+lines.append(f"# quantize+predict pass per step: fetch {tf / 1e6:.1f} MB raw / {2 * tf / 1e6:.1f} MB doubled, write {tw / 1e6:.1f} MB, total {traffic / 1e6:.1f} MB")
 open(f"profiles/{tag}_pmc_traffic.csv", "w").write("\n".join(lines) + "\n")
-bench = [l for l in open(bench_log) if l.startswith("{")][-1]
-open(f"profiles/{tag}_bench.json", "w").write(bench)
-print("\n".join(out[:16])); print(lines[-1]); print(json.loads(bench)["roofline"], json.loads(bench)["value"])
+
+sq_names = ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAVES"]
+tcp_names = ["TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_PENDING_STALL_CYCLES_sum", "GRBM_GUI_ACTIVE"]
+SQ, TCP = agg("sq", sq_names), agg("tcp", tcp_names)
+kernels = sorted(set().union(*[set(v) for v in SQ.values()], *[set(v) for v in TCP.values()]))
+sq_lines = [f"# rocprofv3 --pmc {' '.join(sq_names)} and --pmc {' '.join(tcp_names)} (two passes), per-launch averages ({tag})",
+            "# SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves: valu_share = ACTIVE_INST_VALU / WAVE_CYCLES = share of the waves'",
+            "# lifetime spent issuing vector ALU work, wait_share = WAIT_ANY / WAVE_CYCLES = parked on s_waitcnt / barriers (memory), issue_stall_share = WAIT_INST_ANY / WAVE_CYCLES",
+            "kernel, launches, waves, valu_insts_per_wave, valu_share, wait_share, issue_stall_share, l1_to_l2_read_req, l1_accesses, l1_pending_stall_cycles"]
+for k in kernels:
+    def avg(d, name):
+        v = d[name].get(k, [])
+        return sum(v) / len(v) if v else 0.0
+    wc, waves = avg(SQ, "SQ_WAVE_CYCLES"), avg(SQ, "SQ_WAVES")
+    if wc <= 0 and avg(TCP, "TCP_TOTAL_CACHE_ACCESSES_sum") <= 0:
+        continue
+    sq_lines.append(f"{k}, {len(SQ['SQ_WAVE_CYCLES'].get(k, []))}, {waves:.0f}, {avg(SQ, 'SQ_INSTS_VALU') / max(waves, 1):.0f}, {avg(SQ, 'SQ_ACTIVE_INST_VALU') / max(wc, 1):.3f}, "
+                    f"{avg(SQ, 'SQ_WAIT_ANY') / max(wc, 1):.3f}, {avg(SQ, 'SQ_WAIT_INST_ANY') / max(wc, 1):.3f}, {avg(TCP, 'TCP_TCC_READ_REQ_sum'):.0f}, "
+                    f"{avg(TCP, 'TCP_TOTAL_CACHE_ACCESSES_sum'):.0f}, {avg(TCP, 'TCP_PENDING_STALL_CYCLES_sum'):.0f}")
+open(f"profiles/{tag}_pmc_sq.csv", "w").write("\n".join(sq_lines) + "\n")
+
+bench_log = f"{base}/bench.log"
+if os.path.exists(bench_log):
+    js = [l for l in open(bench_log) if l.startswith("{")]
+    if js:
+        open(f"profiles/{tag}_bench.json", "w").write(js[-1])
+        b = json.loads(js[-1])
+        print(b["value"], b["roofline"])
+print("\n".join(out[:14]))
+print(lines[-1])
+print("\n".join(sq_lines[3:]))
