@@ -15,6 +15,7 @@ namespace dmi {
 // `level` orders the steps of one job: steps of equal level are independent of each other.
 enum KernelId : int { K_RANGES, K_RANGES_FINAL, K_SEQ_QUANT, K_I32_FINAL, K_FUSED_PNU, K_FUSED_PN, K_FUSED_PU, K_FUSED_N,
                       K_PACKED_PNU, K_PACKED_PN, K_PACKED_PU, K_PACKED_N /* the same sweeps on packed values (QFmt) */,
+                      K_WINDOW_PNU, K_WINDOW_PN, K_WINDOW_PU /* … with LDS-staged neighbourhoods */,
                       K_PAR1, K_PAR2, K_PAR3, K_PAR4, K_DELTA, K_TEX, K_ORIENT, K_HIST,
                       K_RANS_PREP, K_BITS_PREP, K_ORIENT_PREP, K_BATCH_FLAGS, K_TABLES /* tables + record prep: dmi_chains.hip */, K_COUNT };
 constexpr int kStepLevels = 7;        // data-parallel phases: levels 0..6

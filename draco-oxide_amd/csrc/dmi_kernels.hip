@@ -1043,6 +1043,218 @@ __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const u
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same sweep with its prediction neighbourhoods staged through LDS (packed values only: positions QF_P64, normals QF_B16,
+// texture coordinates QF_H32).  The 1-ring of the 256 consecutive sequence entries of a chunk lives in three short runs of the
+// coding order: right around the chunk (the strip the traversal is laying down), one ring behind it and one ring ahead of it
+// (Edgebreaker order: a ring is a few thousand entries).  The block reads its fan rows, finds where the two far runs start (a block
+// minimum over the ranks that fall outside the near window), copies the three windows of packed positions — and the near / behind
+// windows of packed texture coordinates — into LDS with coalesced loads, and every gather of the sweep then reads LDS; a rank outside
+// the windows (irregular meshes, the seams of the spiral) falls back to its global gather.  Results are the fused sweep's.
+// MEASURED (10M-triangle workload, MI355X): 217 µs against 155 µs for the plain packed sweep — the staging costs two barriers and a
+// block reduction per 256 entries and, above all, registers (124 VGPRs against 69: 4 waves per SIMD instead of 7; capped to 80 it
+// spills 3 KB per thread and takes 13 ms), while the plain sweep's gathers already land on lines its own L2 holds.  Kept behind
+// DMI_FUSED_WINDOWS=1 as the recorded experiment; not the default.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kWinBack = 64, kWinFwd = 64, kWinNear = kBlock + kWinBack + kWinFwd, kWinFar = 512;
+template <bool HAS_NRM, bool HAS_UV>
+__device__ __forceinline__ void k_predict_window_body(const FusedArgs& a, const uint32_t blk_, const uint32_t nblk_) {
+  __shared__ uint64_t wpos[kWinNear + 2 * kWinFar];
+  __shared__ uint32_t wuv[HAS_UV ? kWinNear + kWinFar : 1];
+  __shared__ uint32_t wmin[2][kBlock / 64];
+  __shared__ uint32_t wave_false[kBlock / 64];
+  const uint32_t* __restrict__ seq = a.seq;
+  const uint32_t* __restrict__ c2r = a.c2r;
+  const uint32_t* __restrict__ opp = a.opp;
+  const uint64_t* __restrict__ qpos = static_cast<const uint64_t*>(a.qs_pos);
+  const uint32_t* __restrict__ quv = static_cast<const uint32_t*>(a.qs_uv);
+  const uint32_t n = a.n;
+  const bool s16_pos = (a.sym16 & 1u) != 0u, s16_nrm = (a.sym16 & 2u) != 0u, s16_uv = (a.sym16 & 4u) != 0u;
+  const WrapParams wp = wrap_params(a.mm_pos);
+  WrapParams wu{};
+  if (HAS_UV) wu = wrap_params(a.mm_uv);
+  uint32_t n_false = 0;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t nch = (n + kBlock - 1) / kBlock, per = (nch + 7u) / 8u, xcd = blk_ & 7u, end = min(nch, (xcd + 1u) * per);
+  for (uint32_t ch = xcd * per + (blk_ >> 3); ch < end; ch += (nblk_ >> 3)) {
+    const uint32_t base = ch * kBlock, i = base + tid;
+    const bool live = i < n;
+    // ---- the chunk's fan rows ----
+    uint32_t h = 0, ro = kNoneD, row[kFanSlots];
+#pragma unroll
+    for (uint32_t k = 0; k < kFanSlots; ++k) row[k] = kNoneD;
+    if (live) {
+      ro = a.fan_apex[i];
+      const uint4* row4 = reinterpret_cast<const uint4*>(a.fan + (size_t)i * kFanSlots);
+      const uint4 r0 = row4[0], r1 = row4[1];
+      row[0] = r0.x; row[1] = r0.y; row[2] = r0.z; row[3] = r0.w; row[4] = r1.x; row[5] = r1.y; row[6] = r1.z; row[7] = r1.w;
+    }
+    // ---- where the far windows start: block minimum of the ranks behind / ahead of the near window ----
+    const uint32_t near_lo = base >= kWinBack ? base - kWinBack : 0u, near_n = min(n, base + kBlock + kWinFwd) - near_lo;
+    uint32_t mb = kNoneD, mf = kNoneD;
+    {
+      const uint32_t near_hi = near_lo + near_n;
+#pragma unroll
+      for (uint32_t k = 0; k < kFanSlots; ++k) { const uint32_t r = row[k]; if (r < near_lo) mb = min(mb, r); else if (r >= near_hi && r != kNoneD) mf = min(mf, r); }
+      if (ro < near_lo) mb = min(mb, ro); else if (ro >= near_hi && ro != kNoneD) mf = min(mf, ro);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) { mb = min(mb, (uint32_t)__shfl_xor((int)mb, off, 64)); mf = min(mf, (uint32_t)__shfl_xor((int)mf, off, 64)); }
+      if ((tid & 63u) == 0u) { wmin[0][tid >> 6] = mb; wmin[1][tid >> 6] = mf; }
+      __syncthreads();
+#pragma unroll
+      for (int w = 0; w < kBlock / 64; ++w) { mb = min(mb, wmin[0][w]); mf = min(mf, wmin[1][w]); }
+    }
+    const uint32_t back_lo = mb, back_n = mb == kNoneD ? 0u : min(kWinFar, near_lo - mb);   // [mb, mb + back_n) stays below the near window
+    const uint32_t fwd_lo = mf, fwd_n = mf == kNoneD ? 0u : min(kWinFar, n - mf);
+    // ---- stage the windows (coalesced) ----
+    for (uint32_t k = tid; k < near_n; k += kBlock) wpos[k] = qpos[near_lo + k];
+    for (uint32_t k = tid; k < back_n; k += kBlock) wpos[kWinNear + k] = qpos[back_lo + k];
+    for (uint32_t k = tid; k < fwd_n; k += kBlock) wpos[kWinNear + kWinFar + k] = qpos[fwd_lo + k];
+    if (HAS_UV) {
+      for (uint32_t k = tid; k < near_n; k += kBlock) wuv[k] = quv[near_lo + k];
+      for (uint32_t k = tid; k < back_n; k += kBlock) wuv[kWinNear + k] = quv[back_lo + k];
+    }
+    __syncthreads();
+    if (live) {   // (the rows are read again rather than kept in registers across the staging: the sweep is register-bound)
+      h = a.fan_hdr[i];
+      ro = a.fan_apex[i];
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4* row4 = reinterpret_cast<const u32x4*>(a.fan + (size_t)i * kFanSlots);
+      const u32x4 r0 = __builtin_nontemporal_load(&row4[0]), r1 = __builtin_nontemporal_load(&row4[1]);
+      row[0] = r0.x; row[1] = r0.y; row[2] = r0.z; row[3] = r0.w; row[4] = r1.x; row[5] = r1.y; row[6] = r1.z; row[7] = r1.w;
+    }
+    auto fetch_pos = [&](uint32_t r, int32_t (&out)[3]) {
+      if (r == kNoneD) { out[0] = 0; out[1] = 0; out[2] = 0; return; }
+      uint32_t d;
+      uint64_t v;
+      if ((d = r - near_lo) < near_n) v = wpos[d];
+      else if ((d = r - back_lo) < back_n) v = wpos[kWinNear + d];
+      else if ((d = r - fwd_lo) < fwd_n) v = wpos[kWinNear + kWinFar + d];
+      else v = qpos[r];
+      unpack_p64(v, out);
+    };
+    auto fetch_uv = [&](uint32_t r, int32_t (&out)[2]) {
+      uint32_t d, v;
+      if ((d = r - near_lo) < near_n) v = wuv[d];
+      else if ((d = r - back_lo) < back_n) v = wuv[kWinNear + d];
+      else v = quv[r];
+      out[0] = (int32_t)(v & 0xFFFFu); out[1] = (int32_t)(v >> 16);
+    };
+    if (live) {
+      uint32_t rn, rp;
+      int32_t Pc[3], Pn[3] = {0, 0, 0}, Pp[3] = {0, 0, 0}, Po[3] = {0, 0, 0}, Plast[3] = {0, 0, 0};
+      int64_t sum[3] = {0, 0, 0};
+      fetch_pos(i, Pc);
+      if (!(h & (1u << 17))) {
+        rn = row[0]; rp = row[1];
+        const uint32_t faces_r = h & 255u, faces_l = (h >> 8) & 255u;
+        const bool closed = (h >> 16) & 1u;
+        const uint32_t stored_r = (closed && faces_r) ? faces_r - 1u : faces_r;
+        const uint32_t cnt = HAS_NRM ? 2u + stored_r + faces_l : 2u;
+        int32_t P[kFanSlots][3];
+        const bool need_np = HAS_NRM || (rn < i && rp < i);
+#pragma unroll
+        for (uint32_t k = 0; k < kFanSlots; ++k) {
+          if (k < cnt && (k >= 2 || need_np)) fetch_pos(row[k], P[k]);
+          else { P[k][0] = 0; P[k][1] = 0; P[k][2] = 0; }
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { Pn[d] = P[0][d]; Pp[d] = P[1][d]; }
+        if (HAS_NRM) {
+          add_face_normal<true>(Pn, Pp, Pc, sum);
+          int32_t R[3] = {Pn[0], Pn[1], Pn[2]}, L[3] = {Pp[0], Pp[1], Pp[2]};
+#pragma unroll
+          for (uint32_t k = 2; k < kFanSlots; ++k) {
+            if (k < cnt) {
+              if (k < 2u + stored_r) { add_face_normal<true>(P[k], R, Pc, sum); R[0] = P[k][0]; R[1] = P[k][1]; R[2] = P[k][2]; }
+              else { add_face_normal<true>(L, P[k], Pc, sum); L[0] = P[k][0]; L[1] = P[k][1]; L[2] = P[k][2]; }
+            }
+          }
+          if (closed && faces_r) add_face_normal<true>(Pp, R, Pc, sum);
+        }
+      } else {
+        // ---- row overflow (valence > 8): walk the corner table (global gathers) ----
+        const uint32_t c = seq[i], nc = cnext(c), pc = cprev(c);
+        rn = c2r[nc]; rp = c2r[pc];
+        if (HAS_NRM || (rn < i && rp < i)) { fetch_pos(rn, Pn); fetch_pos(rp, Pp); }
+        if (HAS_NRM) fan_normal_sum<true>(c, opp, c2r, a.qs_pos, Pc, Pn, Pp, sum);
+      }
+      const bool both = rn < i && rp < i;
+      {
+        const bool have = both && ro < i;
+        if (have) fetch_pos(ro, Po);
+        else if (i > 0) fetch_pos(i - 1u, Plast);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int32_t pred = have ? wsub(wadd(Pn[k], Pp[k]), Po[k]) : Plast[k];
+          store_sym(a.sym_pos, s16_pos, (size_t)i * 3 + k, wrap_symbol(Pc[k], pred, wp));
+        }
+      }
+      if (HAS_UV) {
+        int32_t cu[2];
+        fetch_uv(i, cu);
+        int32_t pred0 = 0, pred1 = 0;
+        uint8_t oflag = 0;
+        bool done = false;
+        int32_t nu[2] = {0, 0};
+        if (rn < i) fetch_uv(rn, nu);
+        if (both) {
+          int32_t pu[2];
+          fetch_uv(rp, pu);
+          done = texcoord_predict(cu, nu, pu, Pc, Pn, Pp, pred0, pred1, oflag);
+        }
+        if (!done) {
+          oflag = 0;
+          if (rn < i) { pred0 = nu[0]; pred1 = nu[1]; }
+          else if (i > 0) { int32_t lu[2]; fetch_uv(i - 1u, lu); pred0 = lu[0]; pred1 = lu[1]; }
+          else { pred0 = 0; pred1 = 0; }
+        }
+        __builtin_nontemporal_store(oflag, &a.orient[i]);
+        const uint32_t s0 = wrap_symbol(cu[0], pred0, wu), s1 = wrap_symbol(cu[1], pred1, wu);
+        if (s16_uv) __builtin_nontemporal_store(s0 | (s1 << 16), static_cast<uint32_t*>(a.sym_uv) + i);
+        else { store_sym(a.sym_uv, false, (size_t)i * 2, s0); store_sym(a.sym_uv, false, (size_t)i * 2 + 1, s1); }
+      }
+      if (HAS_NRM) {
+        int64_t sum0 = sum[0], sum1 = sum[1], sum2 = sum[2];
+        const int64_t upper = 1ll << 29;
+        const int64_t abs_sum = wadd64(wadd64(wabs64(sum0), wabs64(sum1)), wabs64(sum2));
+        if (abs_sum > upper) {
+          const int64_t quot = abs_sum / upper;
+          sum0 = wdiv64(sum0, quot); sum1 = wdiv64(sum1, quot); sum2 = wdiv64(sum2, quot);
+        }
+        const int32_t n0 = (int32_t)sum0, n1 = (int32_t)sum1, n2 = (int32_t)sum2;
+        int32_t p0 = 0, p1 = 0;
+        if (!(n0 == 0 && n1 == 0 && n2 == 0)) oct_quantize((float)n0, (float)n1, (float)n2, p0, p1);
+        const uint32_t v = static_cast<const uint16_t*>(a.qs_nrm)[i];
+        const int32_t a0 = (int32_t)(v & 0xFFu), a1 = (int32_t)(v >> 8);
+        const int32_t m0 = wmul(p0, -1), m1 = wmul(p1, -1);
+        const int32_t d10 = wsub(p0, a0), d11 = wsub(p1, a1), d20 = wsub(m0, a0), d21 = wsub(m1, a1);
+        const int32_t dot1 = wadd(wmul(d10, d10), wmul(d11, d11)), dot2 = wadd(wmul(d20, d20), wmul(d21, d21));
+        const bool flip = dot1 > dot2;
+        if (flip) { p0 = m0; p1 = m1; } else ++n_false;
+        __builtin_nontemporal_store((uint8_t)(flip ? 1 : 0), &a.flips[i]);
+        uint32_t s0, s1;
+        oct_orthogonal(a0, a1, p0, p1, s0, s1);
+        if (s16_nrm) __builtin_nontemporal_store(s0 | (s1 << 16), static_cast<uint32_t*>(a.sym_nrm) + i);
+        else { store_sym(a.sym_nrm, false, (size_t)i * 2, s0); store_sym(a.sym_nrm, false, (size_t)i * 2 + 1, s1); }
+      }
+    }
+    __syncthreads();   // the next chunk restages the windows
+  }
+  if (HAS_NRM) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) n_false += __shfl_down(n_false, off, 64);
+    if ((tid & 63) == 0) wave_false[tid >> 6] = n_false;
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t t = 0;
+#pragma unroll
+      for (int w = 0; w < kBlock / 64; ++w) t += wave_false[w];
+      if (t) atomicAdd(&a.counters[0], t);
+    }
+  }
+}
+
 // Per-block summary of the orientation flags so the host can stitch the count of bits and the number
 // of forward transitions (mesh_prediction_for_texture_coordinates.rs:224-235) without a serial pass.
 constexpr uint32_t kOrientChunk = 4096;
@@ -1146,6 +1358,9 @@ DMI_KERNEL(k_predict_packed_pnu, (k_predict_fused_body<true, true, true, true>),
 DMI_KERNEL(k_predict_packed_pn, (k_predict_fused_body<true, true, false, true>), FusedArgs, kBlock)
 DMI_KERNEL(k_predict_packed_pu, (k_predict_fused_body<true, false, true, true>), FusedArgs, kBlock)
 DMI_KERNEL(k_predict_packed_n, (k_predict_fused_body<false, true, false, true>), FusedArgs, kBlock)
+DMI_KERNEL(k_predict_window_pnu, (k_predict_window_body<true, true>), FusedArgs, kBlock)
+DMI_KERNEL(k_predict_window_pn, (k_predict_window_body<true, false>), FusedArgs, kBlock)
+DMI_KERNEL(k_predict_window_pu, (k_predict_window_body<false, true>), FusedArgs, kBlock)
 DMI_KERNEL(k_pred_parallelogram_wrapped1, k_pred_parallelogram_wrapped_body<1>, ParArgs, kBlock)
 DMI_KERNEL(k_pred_parallelogram_wrapped2, k_pred_parallelogram_wrapped_body<2>, ParArgs, kBlock)
 DMI_KERNEL(k_pred_parallelogram_wrapped3, k_pred_parallelogram_wrapped_body<3>, ParArgs, kBlock)
@@ -1190,6 +1405,9 @@ bool step_sink_push(const KernelStep& st) { if (!g_step_sink) return false; g_st
   X(K_PACKED_PN, k_predict_packed_pn, FusedArgs, kBlock)                     \
   X(K_PACKED_PU, k_predict_packed_pu, FusedArgs, kBlock)                     \
   X(K_PACKED_N, k_predict_packed_n, FusedArgs, kBlock)                       \
+  X(K_WINDOW_PNU, k_predict_window_pnu, FusedArgs, kBlock)                   \
+  X(K_WINDOW_PN, k_predict_window_pn, FusedArgs, kBlock)                     \
+  X(K_WINDOW_PU, k_predict_window_pu, FusedArgs, kBlock)                     \
   X(K_PAR1, k_pred_parallelogram_wrapped1, ParArgs, kBlock)                  \
   X(K_PAR2, k_pred_parallelogram_wrapped2, ParArgs, kBlock)                  \
   X(K_PAR3, k_pred_parallelogram_wrapped3, ParArgs, kBlock)                  \
@@ -1267,7 +1485,10 @@ void launch_predict_fused(const FusedArgs& a, hipStream_t s) {
   const uint32_t g = grid_for(a.n, env_cap ? env_cap : 8192u);   // 2-3 chunks per block: measured best on the 10M workload (2048: +5 %)
   int id = !a.sym_pos ? K_FUSED_N /* a normal attribute on its own table */ : ((a.qs_nrm && a.qs_uv) ? K_FUSED_PNU : (a.qs_nrm ? K_FUSED_PN : K_FUSED_PU));
   if (a.packed) id += K_PACKED_PNU - K_FUSED_PNU;
-  emit(id, 4, a, g, 0, s);
+  static const bool windows = std::getenv("DMI_FUSED_WINDOWS") != nullptr;   // LDS-staged neighbourhoods (see k_predict_window_body)
+  if (windows && a.packed && a.sym_pos) id = id == K_PACKED_PNU ? K_WINDOW_PNU : (id == K_PACKED_PN ? K_WINDOW_PN : K_WINDOW_PU);
+  static const uint32_t env_lds = std::getenv("DMI_FUSED_LDS") ? (uint32_t)std::atoi(std::getenv("DMI_FUSED_LDS")) : 0u;   // tuning aid: unused dynamic LDS per block = fewer blocks per CU
+  emit(id, 4, a, g, env_lds, s);
 }
 
 uint32_t orient_summary_blocks(uint32_t n) { return (n + kOrientChunk - 1) / kOrientChunk; }

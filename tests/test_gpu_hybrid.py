@@ -122,3 +122,19 @@ def test_packed_values_and_16_bit_symbols_are_layouts_not_arithmetic(toggle, mon
         monkeypatch.setenv(toggle, "1")
         _assert_same(dmi.encode_mesh(mesh, cfg), want, f"{toggle} {kw}")
         monkeypatch.delenv(toggle)
+
+
+def test_lds_window_sweep_gives_the_same_bytes(monkeypatch):
+    """DMI_FUSED_WINDOWS=1: the packed fused sweep with its prediction neighbourhoods staged through LDS (k_predict_window_*; slower
+    than the plain sweep on MI355X, kept as the recorded experiment).  Closed / open grids, a mesh without UVs, one without normals,
+    high-valence fans (row overflow → corner-table walk), ranks outside every window (two far-apart components)."""
+    monkeypatch.setenv("DMI_FUSED_WINDOWS", "1")
+    cases = [synth.torus_mesh(40), synth.torus_mesh(150, open_boundary=True), synth.torus_mesh(64, uvs=False), synth.torus_mesh(50, normals=False), _cones(13, True, False, seed=3)]
+    f1, p1, n1, u1 = synth.torus_grid(30, seed=1)
+    f2, p2, n2, u2 = synth.torus_grid(41, seed=2, open_boundary=True)
+    two = dmi.Mesh(np.concatenate([f1, f2 + np.uint32(len(p1))]), [dmi.Attribute(np.concatenate([p1, p2 + np.float32(4.0)]), dmi.ATT_POSITION),
+                                                                   dmi.Attribute(np.concatenate([n1, n2]), dmi.ATT_NORMAL, dmi.DOMAIN_CORNER, 1, 0),
+                                                                   dmi.Attribute(np.concatenate([u1, u2]), dmi.ATT_TEXCOORD, dmi.DOMAIN_CORNER, 2, 0)])
+    cases.append(two)
+    for mesh in cases:
+        _assert_same(dmi.encode_mesh(mesh), oracle_from_product_mesh(mesh).encode(), "LDS-window sweep")
