@@ -39,6 +39,19 @@ from draco_oxide_amd import synth  # noqa: E402
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ≈6.3 TB/s achievable)
 
 
+def usable_cpus():
+    """CPUs this process may actually use: its affinity mask, capped by the cgroup's CPU quota (a container on a 256-thread host may be
+    allowed 16 CPUs' worth of time)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(mesh):
     """Reference algorithm on one host core: the oracle (CPU restatement, kind "port"), timed on the SAME mesh, with the per-stage
     split of BASELINE.md §3; scope of `value` matched to the GPU timed region (attribute section minus the sequencer).  The
@@ -53,7 +66,7 @@ def cpu_baseline(mesh):
     scope_s = max(split["attribute_section_s"] - split["sequencer_s"], 1e-9)
     f = len(mesh.faces)
     out = {
-        "value": round(f / scope_s / 1e6, 4), "unit": "Mtriangles/s", "cores": 1, "kind": "port",
+        "value": round(f / scope_s / 1e6, 4), "unit": "Mtriangles/s", "cores": 1, "kind": "port", "host_cpus_usable": usable_cpus(),
         "sample": f"whole workload mesh ({f} triangles), oracle `ranked` mode (same bytes, O(1) already-coded test), attribute section minus sequencer = {scope_s:.2f} s; "
                   f"whole .drc {wall:.2f} s = {f / wall / 1e6:.3f} Mtri/s end to end",
         "end_to_end_mtri_per_s": round(f / wall / 1e6, 4),
@@ -181,7 +194,7 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # the ranks share the host: each one's library threads (connectivity walks, splice, host-core chains) get an equal share
-        os.environ.setdefault("DMI_HOST_THREADS", str(max(4, (os.cpu_count() or 8) // world)))
+        os.environ.setdefault("DMI_HOST_THREADS", str(max(2, usable_cpus() // world)))
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:

@@ -11,6 +11,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -25,11 +26,33 @@ namespace dmi {
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 int host_fail(int code, const std::string& msg);   // sets dmi_last_error() for the calling thread, returns code
 
-// Host threads the library may use at once in one call: the machine's hardware threads, capped by DMI_HOST_THREADS (read per call:
-// one process per GPU on a shared host sets it to its share, cores / world size).
+// Host threads the library may use at once in one call: the machine's hardware threads, no more than the CPU quota of the process's
+// cgroup (a container on a 256-thread host may be allowed 16 CPUs' worth of time: threads beyond the quota only add throttling —
+// measured on the GPU box: 1024-mesh prepare 0.36 s on 16 threads, 0.47–0.68 s on 128), capped by DMI_HOST_THREADS (read per call: one
+// process per GPU on a shared host sets it to its share, cores / world size).
+inline unsigned cgroup_cpu_quota() {   // 0 = unlimited / unknown
+  static const unsigned quota = [] {
+    unsigned q = 0;
+    if (std::FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {           // cgroup v2: "<quota|max> <period>"
+      char a[32] = {0};
+      unsigned long period = 0;
+      if (std::fscanf(f, "%31s %lu", a, &period) == 2 && period && std::strcmp(a, "max") != 0) q = (unsigned)((std::strtoul(a, nullptr, 10) + period - 1) / period);
+      std::fclose(f);
+    } else if (std::FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // cgroup v1
+      long quota_us = -1, period_us = 0;
+      if (std::fscanf(g, "%ld", &quota_us) != 1) quota_us = -1;
+      std::fclose(g);
+      if (std::FILE* h = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(h, "%ld", &period_us) != 1) period_us = 0; std::fclose(h); }
+      if (quota_us > 0 && period_us > 0) q = (unsigned)((quota_us + period_us - 1) / period_us);
+    }
+    return q;
+  }();
+  return quota;
+}
 inline unsigned host_threads() {
   unsigned hw = std::thread::hardware_concurrency();
   if (!hw) hw = 4;
+  if (const unsigned q = cgroup_cpu_quota()) hw = std::min(hw, std::max(1u, q));
   if (const char* e = std::getenv("DMI_HOST_THREADS")) { const int v = std::atoi(e); if (v > 0) hw = std::min<unsigned>(hw, (unsigned)v); }
   return hw;
 }

@@ -40,23 +40,57 @@ enum Transform : uint8_t { kDifference = 0, kWrapped = 1, kOctOrth = 3 };       
 enum Port : uint8_t { kToBits = 1, kCoordwise = 2, kOct = 3 };                          // portabilization/mod.rs:85-92
 constexpr uint32_t kMaxPrepareWorkers = 128;   // host threads of one dmi_meshes_prepare call
 constexpr uint32_t kPrepareStreams = 16;       // library streams their jobs are created on (per device)
-constexpr uint32_t kDeviceRelabelMinFaces = 1u << 17;   // job creation relabels the connectivity inputs with kernels from this size up (dmi_relabel.hip)
+constexpr uint32_t kDeviceRelabelMinFaces = 1u << 20;   // job creation relabels the connectivity inputs with kernels from this size up (dmi_relabel.hip): its temporaries
+                                                      // are device allocations, whose release synchronises the device — a batch of mid-sized meshes on many threads must not take it
 constexpr uint64_t kHostChainMinSymbols = 32768;   // a job whose longest stream is at least this long codes its streams on host cores (hybrid form)
 
 // Device memory of one job comes from a few large chunks (DevPool) instead of one hipMalloc per buffer: job creation for a batch
 // of meshes runs on many host threads, and ≈ 70 allocations + ≈ 20 memsets per job serialise on the runtime (17 ms of
 // thread time per job before, most of it here).  A chunk is zeroed once when it is created, so pooled buffers start zeroed.
+// Released job chunks are kept (per device, in power-of-two size classes, up to kChunkCacheBytes in total) and handed to the next job of
+// that class: a transcode pipeline creates and destroys a thousand jobs per batch, and hipMalloc / hipFree serialise across the host
+// threads that do it (hipFree also synchronises the device).  A reused chunk is zeroed again on the new job's stream.
+struct ChunkCache {
+  struct Item { int device; void* p; size_t cap; };
+  std::mutex m;
+  std::vector<Item> items;
+  size_t bytes = 0;
+  static constexpr size_t kChunkCacheBytes = (size_t)64 << 30;
+  static size_t size_class(size_t n) {   // powers of two up to 1 GiB, multiples of 256 MiB above (a 100M-triangle job is 33 GB)
+    if (n > ((size_t)1 << 30)) return (n + (((size_t)1 << 28) - 1)) & ~(((size_t)1 << 28) - 1);
+    size_t c = (size_t)1 << 20;
+    while (c < n) c <<= 1;
+    return c;
+  }
+  void* acquire(int device, size_t cap) {
+    std::lock_guard<std::mutex> lock(m);
+    for (size_t k = items.size(); k-- > 0;)
+      if (items[k].device == device && items[k].cap == cap) { void* p = items[k].p; bytes -= cap; items.erase(items.begin() + (long)k); return p; }
+    return nullptr;
+  }
+  bool release(int device, void* p, size_t cap) {   // false: not kept (the caller frees it)
+    std::lock_guard<std::mutex> lock(m);
+    if (bytes + cap > kChunkCacheBytes) return false;
+    items.push_back({device, p, cap});
+    bytes += cap;
+    return true;
+  }
+};
+static ChunkCache g_chunk_cache;   // (process lifetime)
+
 struct DevPool {
   struct Chunk { void* p; size_t cap, used; };
   std::vector<Chunk> chunks;
   size_t chunk_bytes = 0;
   hipStream_t stream = nullptr;
-  ~DevPool() { for (auto& c : chunks) if (c.p) (void)hipFree(c.p); }
+  int device = 0;
+  ~DevPool() { for (auto& c : chunks) if (c.p && !g_chunk_cache.release(device, c.p, c.cap)) (void)hipFree(c.p); }
   void* take(size_t n) {
     n = (n + 255) & ~(size_t)255;
     if (chunks.empty() || chunks.back().used + n > chunks.back().cap) {
-      Chunk c{nullptr, std::max(n, chunk_bytes), 0};
-      if (hipMalloc(&c.p, c.cap) != hipSuccess) return nullptr;
+      Chunk c{nullptr, ChunkCache::size_class(std::max(n, chunk_bytes)), 0};
+      c.p = g_chunk_cache.acquire(device, c.cap);
+      if (!c.p && hipMalloc(&c.p, c.cap) != hipSuccess) return nullptr;
       if (hipMemsetAsync(c.p, 0, c.cap, stream) != hipSuccess) { (void)hipFree(c.p); return nullptr; }
       chunks.push_back(c);
     }
@@ -101,7 +135,7 @@ struct TableDev {
   uint32_t F = 0, V = 0, n_seq = 0;
   DevMem fan_hdr, fan_apex, fan;   // fan rows (only for tables with a fused sweep)
   DevMem c2r, opp, seq, s2p;   // c2r = corner → sequence index of its vertex; s2p = sequence index → point (= point_idx(seq[i]))
-  std::vector<uint32_t> s2p_host;
+  const uint32_t* s2p_host = nullptr;   // (during job creation, host-relabel form) the same array in the upload staging
   // sharing: a table whose arrays equal another table's reuses its device copies
   int alias_of = -1;
 };
@@ -160,6 +194,7 @@ struct dmi_job {
   DevPool pool;   // (declared before every DevMem of the job: destroyed after them)
   std::vector<AttJob> atts;
   std::vector<TableDev> tables;
+  DevMem upload_region;   // every array job creation uploads, in one piece (host-relabel form): filled through one pinned staging copy
   DevMem descs;
   DevMem slab;   // small / meta / hist / summary of every attribute, laid out exactly like the pinned read-back buffer
   void* pinned = nullptr;   // host-pinned readback area
@@ -195,6 +230,7 @@ struct dmi_job {
   } run;
   ~dmi_job();
   void release() {
+    if (stream) (void)hipStreamSynchronize(stream);   // (the job's device memory goes back to a cache, not through a synchronising hipFree)
     if (pinned) (void)hipHostFree(pinned);
     if (out_pinned) (void)hipHostFree(out_pinned);
     if (graph_a) (void)hipGraphExecDestroy(graph_a);
@@ -228,7 +264,7 @@ static HostStage* acquire_stage(int device, size_t bytes) {
   if (best->cap < bytes) {
     if (best->p) (void)hipHostFree(best->p);
     best->p = nullptr; best->cap = 0;
-    const size_t want = bytes + bytes / 8 + 4096;
+    const size_t want = ChunkCache::size_class(bytes);   // (size classes: a worker's next mesh rarely makes its stage grow again)
     if (hipHostMalloc(reinterpret_cast<void**>(&best->p), want, hipHostMallocDefault) != hipSuccess) { best->p = nullptr; std::lock_guard<std::mutex> lock(g_stage_mutex); best->in_use = false; return nullptr; }
     best->cap = want;
   }
@@ -404,6 +440,7 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
       est += F0 * 24 + V0 * 88 + (size_t)atts[i].num_unique * atts[i].num_components * 4 + V0 * ((size_t)job->atts[i].nq * 31 + 49) + ((size_t)1 << 20);
     }
     job->pool.stream = s;
+    job->pool.device = cfg.device;
     job->pool.chunk_bytes = est + est / 8;
   }
   g_active_pool = std::getenv("DMI_NO_POOL") ? nullptr : &job->pool;
@@ -495,6 +532,21 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
   // Large meshes are relabelled by kernels (dmi_relabel.hip): the caller's arrays go up as they are and the rank scatter, the face
   // keys, the stable sort and the corner remaps run on the device — what remains on the host is validation and the PCIe upload.
   // Small meshes (launch-bound: a batch creates thousands of jobs on host threads) keep the host form below.  Same arrays either way.
+  // Host-relabel form: everything job creation uploads (relabelled tables, sequences, raw attribute values, composed maps) is written
+  // by the host threads straight into ONE pinned staging buffer laid out like one region of the job's device memory, and goes up in a
+  // single copy — a batch creates a thousand jobs on a hundred threads, and per-array copies from pageable memory serialise in the
+  // runtime (57 ms of thread time per mesh before; 128 workers gained nothing over 16).
+  struct StageGuard { HostStage* st = nullptr; ~StageGuard() { release_stage(st); } } stage_guard;
+  uint8_t* stage_host = nullptr;
+  uint8_t* stage_dev = nullptr;
+  size_t stage_at = 0, stage_cap = 0;
+  auto staged = [&](DevMem& m, size_t bytes) -> void* {   // a sub-array of the upload region; returns where the host writes it
+    const size_t at = stage_at;
+    stage_at += (bytes + 255) & ~(size_t)255;
+    if (stage_at > stage_cap) return nullptr;
+    m.p = stage_dev + at; m.bytes = bytes; m.pooled = true;   // (a view: the region owns the memory)
+    return stage_host + at;
+  };
   bool device_relabel = F >= kDeviceRelabelMinFaces;
   if (const char* e = std::getenv("DMI_RELABEL")) device_relabel = std::strcmp(e, "device") == 0 ? true : (std::strcmp(e, "host") == 0 ? false : device_relabel);
   TempDev tmpdev;
@@ -571,11 +623,17 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
     uint32_t* new_face = new_face_buf.get();
     for (uint32_t f = 0; f < F; ++f) new_face[f] = start[key[f]]++;
     auto map_corner = [&](uint32_t c) { return c == kNone ? kNone : 3u * new_face[c / 3u] + c % 3u; };
-    auto tmp_buf = raw_u32(C), tmp2_buf = raw_u32(C);
-    uint32_t* tmp = tmp_buf.get();
-    uint32_t* tmp2 = tmp2_buf.get();
+    {   // the upload region and its pinned staging
+      size_t need = 0;
+      auto add = [&](size_t bytes) { need += (bytes + 255) & ~(size_t)255; };
+      for (uint32_t i = 0; i < n_atts; ++i) { if (job->tables[i].alias_of < 0) { add(C * 4); add(C * 4); add((size_t)job->tables[i].n_seq * 4); add((size_t)job->tables[i].n_seq * 4); } }
+      for (uint32_t i = 0; i < n_atts; ++i) { add((size_t)atts[i].num_unique * atts[i].num_components * 4); if (atts[i].point_to_value) add((size_t)job->tables[job->atts[i].table].n_seq * 4); }
+      if ((rc = job->upload_region.alloc(need))) return rc;
+      stage_guard.st = acquire_stage(cfg.device, need);
+      if (!stage_guard.st) return fail(DMI_ERR_OUT_OF_MEMORY, "hipHostMalloc (upload staging)");
+      stage_host = stage_guard.st->p; stage_dev = job->upload_region.as<uint8_t>(); stage_cap = need;
+    }
     std::unique_ptr<uint32_t[]> rank_buf;
-    std::vector<uint32_t> seq2;
     for (uint32_t i = 0; i < n_atts; ++i) {
       TableDev& t = job->tables[i];
       if (t.alias_of >= 0) continue;
@@ -583,6 +641,11 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
       uint32_t* rank = rank_buf.get();
       fill_none(rank, t.V);
       parallel_for(t.n_seq, [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) rank[tables[i].corner_to_vertex[seq_of[i][k]]] = (uint32_t)k; });
+      uint32_t* tmp = static_cast<uint32_t*>(staged(t.c2r, C * 4));
+      uint32_t* tmp2 = static_cast<uint32_t*>(staged(t.opp, C * 4));
+      uint32_t* seq2 = static_cast<uint32_t*>(staged(t.seq, (size_t)t.n_seq * 4));
+      uint32_t* s2p = static_cast<uint32_t*>(staged(t.s2p, (size_t)t.n_seq * 4));
+      if (!tmp || !tmp2 || !seq2 || !s2p) return fail(DMI_ERR_HIP, "upload staging overflow");
       parallel_for(C, [&](size_t lo, size_t hi) {
         for (size_t c = lo; c < hi; ++c) {
           const uint32_t c2 = map_corner((uint32_t)c);
@@ -590,19 +653,18 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
           tmp2[c2] = map_corner(tables[i].opposite[c]);
         }
       });
-      if ((rc = upload(t.c2r, tmp, C * 4, s))) return rc;
-      if ((rc = upload(t.opp, tmp2, C * 4, s))) return rc;
-      seq2.resize(t.n_seq);
-      parallel_for(t.n_seq, [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) seq2[k] = map_corner(seq_of[i][k]); });
-      if ((rc = upload(t.seq, seq2.data(), (size_t)t.n_seq * 4, s))) return rc;
-      // the point every sequence entry stands for (attribute_encoder.rs:332-338 reads attribute.get(point_idx(c)))
-      t.s2p_host.resize(t.n_seq);
-      parallel_for(t.n_seq, [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) t.s2p_host[k] = tables[0].corner_to_point[seq_of[i][k]]; });
-      if ((rc = upload(t.s2p, t.s2p_host.data(), (size_t)t.n_seq * 4, s))) return rc;
-      HIP_TRY(hipStreamSynchronize(s));   // tmp/tmp2/seq2 are reused
+      // the corners of the sequence in the new face order, and the point every sequence entry stands for
+      // (attribute_encoder.rs:332-338 reads attribute.get(point_idx(c)))
+      parallel_for(t.n_seq, [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) { seq2[k] = map_corner(seq_of[i][k]); s2p[k] = tables[0].corner_to_point[seq_of[i][k]]; } });
+      t.s2p_host = s2p;
     }
   }
 
+  size_t stage_copied = 0;
+  if (stage_host && stage_at) {   // the tables go up now (the fan-row kernels below read them), the attribute arrays after their loop
+    HIP_TRY(hipMemcpyAsync(stage_dev, stage_host, stage_at, hipMemcpyHostToDevice, s));
+    stage_copied = stage_at;
+  }
   const double t_relabel = since_ms(tc0) - t_seq;
   // Seam-free fast path: a normal / texture-coordinate attribute coded on the same corner table as its parent
   // position attribute (3 components, parallelogram) is predicted together with it in one sweep (k_predict_fused).
@@ -662,8 +724,15 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
     const TableDev& t = job->tables[a.table];
     const size_t vbytes = (size_t)d.num_unique * d.num_components * 4;
     if (d.num_unique && !d.values) return fail(DMI_ERR_INVALID_ARGUMENT, "attribute values missing");
-    rc = upload(a.raw, d.values, vbytes, s);
-    if (rc) return rc;
+    if (stage_host) {
+      void* dst = staged(a.raw, vbytes);
+      if (!dst) return fail(DMI_ERR_HIP, "upload staging overflow");
+      if (vbytes >= ((size_t)8 << 20)) parallel_for(vbytes, [&](size_t lo, size_t hi) { std::memcpy(static_cast<uint8_t*>(dst) + lo, static_cast<const uint8_t*>(d.values) + lo, hi - lo); });
+      else if (vbytes) std::memcpy(dst, d.values, vbytes);
+    } else {
+      rc = upload(a.raw, d.values, vbytes, s);
+      if (rc) return rc;
+    }
     if (d.num_points <= max_point && F) return fail(DMI_ERR_INVALID_ARGUMENT, "attribute " + std::to_string(i) + " has fewer points than the faces reference");
     if (d.point_to_value && device_relabel) {   // sequence index → value index, composed on the device; out-of-range entries raise d_bad
       uint32_t* d_p2v = tmpdev.take<uint32_t>(d.num_points);
@@ -672,13 +741,12 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
       if ((rc = a.s2v.alloc((size_t)t.n_seq * 4))) return rc;
       launch_compose_s2v(t.s2p.as<uint32_t>(), t.n_seq, d_p2v, d.num_points, d.num_unique, a.s2v.as<uint32_t>(), d_bad, s);
     } else if (d.point_to_value) {   // sequence index → value index: the map composed with the table's sequence → point array
-      std::vector<uint32_t> s2v(t.n_seq);
+      uint32_t* s2v = static_cast<uint32_t*>(staged(a.s2v, (size_t)t.n_seq * 4));
+      if (!s2v) return fail(DMI_ERR_HIP, "upload staging overflow");
       for (uint32_t k = 0; k < t.n_seq; ++k) {
         s2v[k] = d.point_to_value[t.s2p_host[k]];
         if (s2v[k] >= d.num_unique) return fail(DMI_ERR_INVALID_ARGUMENT, "attribute " + std::to_string(i) + ": point_to_value entry out of range");
       }
-      if ((rc = upload(a.s2v, s2v.data(), (size_t)t.n_seq * 4, s))) return rc;
-      HIP_TRY(hipStreamSynchronize(s));
     } else if (d.num_unique <= max_point && F) {
       return fail(DMI_ERR_INVALID_ARGUMENT, "attribute " + std::to_string(i) + " has fewer values than the faces reference");
     }
@@ -729,6 +797,7 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
     // algorithmic bytes of the quantize+predict pass: 4·Nin + 4·Nsym per value, 8 per sequence entry
     pb += (uint64_t)d.num_unique * 4 * d.num_components + a.n_sym * 4 + (uint64_t)n * 8;
   }
+  if (stage_host && stage_at > stage_copied) HIP_TRY(hipMemcpyAsync(stage_dev + stage_copied, stage_host + stage_copied, stage_at - stage_copied, hipMemcpyHostToDevice, s));
   pb += (uint64_t)F * 24;   // corner_to_point + opposite, once
   job->predict_bytes = pb;
   pinned_need += 256;

@@ -256,7 +256,9 @@ int CornerTables::build_universal(const uint32_t* faces, uint32_t num_faces, con
   }
   UniversalBuilder b(*this);
   const bool serial_only = std::getenv("DMI_SERIAL_TABLES") != nullptr;   // (tests: the literal serial walks on every input)
-  const bool big = C >= (1u << 18) && !serial_only;   // small meshes: a batch already runs one mesh per host thread
+  // (the order-independent builders do more work per corner — atomics, two bucket scans — and only win once their loops really run on
+  //  several threads, which parallel_for does from 2^20 items; below that, and in a batch of meshes on a thread each, the serial walks)
+  const bool big = (C >= (1u << 21) || std::getenv("DMI_PARALLEL_TABLES")) && !serial_only;
   if (!(big && b.match_half_edges_parallel())) {
     b.match_half_edges();
     if (b.has_non_manifold_edge()) b.break_non_manifold_edges();

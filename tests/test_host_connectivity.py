@@ -237,7 +237,9 @@ def test_parallel_host_stages_equal_the_serial_walks_and_the_oracle(name, monkey
     connectivity bytes, same seeds and sequences — and the oracle's."""
     mesh = _large_cases()[name]
     assert 3 * len(mesh.faces) >= 1 << 18
+    monkeypatch.setenv("DMI_PARALLEL_TABLES", "1")   # (the library takes these builders from 2^21 corners by itself)
     fast = _conn_snapshot(mesh)
+    monkeypatch.delenv("DMI_PARALLEL_TABLES")
     monkeypatch.setenv("DMI_SERIAL_TABLES", "1")
     slow = _conn_snapshot(mesh)
     assert _same(fast, slow)
