@@ -72,12 +72,22 @@ class _BuiltMesh(C.Structure):
     _fields_ = [("mesh", _Mesh), ("owner", C.c_void_p)]
 
 
+class _DecodedAttribute(C.Structure):
+    _fields_ = [("att_type", C.c_uint8), ("component_type", C.c_uint8), ("num_components", C.c_uint8), ("domain", C.c_uint8),
+                ("scheme", C.c_uint8), ("transform", C.c_uint8), ("portabilization", C.c_uint8), ("bits", C.c_uint8),
+                ("unique_id", C.c_uint32), ("num_points", C.c_uint32), ("values", C.c_void_p)]
+
+
+class _Decoded(C.Structure):
+    _fields_ = [("num_attributes", C.c_uint32), ("attributes", C.POINTER(_DecodedAttribute)), ("owner", C.c_void_p)]
+
+
 class _Conn(C.Structure):
     _fields_ = [("num_tables", C.c_uint32), ("tables", C.POINTER(_CornerTable)), ("seeds", C.c_void_p), ("num_seeds", C.c_uint32), ("owner", C.c_void_p)]
 
 
 EXPORTS = ["dmi_encode_attributes", "dmi_encode_attributes_batch", "dmi_jobs_encode", "dmi_job_create", "dmi_job_encode", "dmi_job_timings", "dmi_job_destroy", "dmi_encode_mesh",
-           "dmi_mesh_prepare", "dmi_meshes_prepare", "dmi_shard_meshes", "dmi_meshes_prepare_devices", "dmi_jobs_encode_devices", "dmi_mesh_build", "dmi_built_mesh_free", "dmi_encode_connectivity", "dmi_conn_free", "dmi_host_rans_stream", "dmi_host_rabs_stream", "dmi_free", "dmi_free_many", "dmi_strerror", "dmi_last_error", "dmi_device_count"]
+           "dmi_mesh_prepare", "dmi_meshes_prepare", "dmi_shard_meshes", "dmi_meshes_prepare_devices", "dmi_jobs_encode_devices", "dmi_mesh_build", "dmi_built_mesh_free", "dmi_encode_connectivity", "dmi_conn_free", "dmi_host_rans_stream", "dmi_host_rabs_stream", "dmi_decode_attributes", "dmi_decoded_free", "dmi_free", "dmi_free_many", "dmi_strerror", "dmi_last_error", "dmi_device_count"]
 
 
 def library_path():
@@ -122,6 +132,9 @@ def load_library():
     L.dmi_meshes_prepare_devices.argtypes = [C.POINTER(_Mesh), C.c_uint32, C.POINTER(_Config), C.c_void_p, C.POINTER(_Buffer), C.POINTER(C.c_void_p)]
     L.dmi_jobs_encode_devices.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(_Buffer)]
     L.dmi_conn_free.argtypes = [C.POINTER(_Conn)]
+    L.dmi_decode_attributes.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(_CornerTable), C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(_Config), C.POINTER(_Decoded)]
+    L.dmi_decoded_free.argtypes = [C.POINTER(_Decoded)]
+    L.dmi_decoded_free.restype = None
     L.dmi_host_rans_stream.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(_Buffer)]
     L.dmi_host_rabs_stream.argtypes = [C.c_uint8, C.c_void_p, C.c_uint64, C.POINTER(_Buffer)]
     _lib = L
@@ -651,3 +664,27 @@ def host_rabs_stream(zero_prob, bits):
     out = _Buffer()
     _check(L.dmi_host_rabs_stream(zero_prob, b.ctypes.data, len(b), C.byref(out)))
     return _take(out)
+
+
+def decode_attributes(section, tables, num_points, seeds=None, cfg=None):
+    """dmi_decode_attributes: the attribute section `section` read back against the corner tables of the connectivity stage (the
+    arrays encode_attributes takes).  Returns [dict(att_type, num_components, unique_id, scheme, transform, portabilization, bits,
+    values [num_points, num_components] float32 — uint32 for a ToBits attribute)]."""
+    L = load_library()
+    cfg = cfg or Config.default()
+    b = np.frombuffer(section, dtype=np.uint8)
+    tabs, keep = _tables_c(tables)
+    sd = None if seeds is None else np.ascontiguousarray(seeds, dtype=np.uint32)
+    out, c = _Decoded(), cfg._c()
+    _check(L.dmi_decode_attributes(b.ctypes.data, len(b), tabs, len(tables), None if sd is None else sd.ctypes.data, 0 if sd is None else len(sd), num_points, C.byref(c), C.byref(out)))
+    try:
+        res = []
+        for i in range(out.num_attributes):
+            a = out.attributes[i]
+            raw = C.string_at(a.values, a.num_points * a.num_components * 4) if a.num_points else b""
+            vals = np.frombuffer(raw, dtype=np.uint32 if a.portabilization == 1 else np.float32).reshape(a.num_points, a.num_components).copy()
+            res.append(dict(att_type=a.att_type, num_components=a.num_components, unique_id=a.unique_id, domain=a.domain, scheme=a.scheme, transform=a.transform,
+                            portabilization=a.portabilization, bits=a.bits, values=vals))
+        return res
+    finally:
+        L.dmi_decoded_free(C.byref(out))

@@ -1,0 +1,353 @@
+// dmi_decode.cpp — dmi_decode_attributes: the attribute section read back ("decoder-side inverse kernels").
+//
+// What a decoder does once its connectivity stage has rebuilt the corner tables (here: handed over by the caller, exactly the arrays
+// dmi_encode_attributes takes), split by where each stage can run:
+//   host cores (serial, like their encoders)   frequency table + rANS symbol decoding (decode/entropy/symbol_coding.rs:125-210,
+//                                              rans.rs:58-69), rABS metadata bits (rans.rs:106-127), and the predictions whose
+//                                              inputs are values of the SAME attribute decoded earlier: parallelogram + wrapped
+//                                              difference, delta + difference, texture coordinates (each entry needs its
+//                                              predecessors: a dependency chain through the whole sequence)
+//   device (data-parallel)                     normals — their prediction only reads the already decoded POSITIONS — with the
+//                                              oct-orthogonal transform inverted (k_decode_normals), and the dequantization of every
+//                                              attribute scattered to its points (k_dequantize)
+// The layout parsed here is the one encode_attributes writes (encode/attribute/mod.rs:26-57, attribute_encoder.rs:159-160,344-386);
+// the reference's own decode/attribute/* is an unbuilt prototype of an older layout, so everything above the entropy layer is the
+// encoder spec inverted (the same derivation as oracle/orc_decode.cpp, which the tests compare this against).
+// No CPU fallback: without a HIP device the call returns DMI_ERR_NO_DEVICE.
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <memory>
+
+#include "dmi_device.hpp"
+#include "dmi_host.hpp"
+#include "host_chains.hpp"
+
+namespace dmi {
+namespace {
+
+#define HIP_TRY_D(expr)                                                                                            \
+  do {                                                                                                             \
+    hipError_t e_ = (expr);                                                                                        \
+    if (e_ != hipSuccess) {                                                                                        \
+      const bool nodev = (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice || e_ == hipErrorInsufficientDriver || e_ == hipErrorNotInitialized); \
+      return host_fail(nodev ? DMI_ERR_NO_DEVICE : (e_ == hipErrorOutOfMemory ? DMI_ERR_OUT_OF_MEMORY : DMI_ERR_HIP), std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    }                                                                                                              \
+  } while (0)
+
+inline int32_t wadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+inline int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
+inline int64_t wadd64(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }
+inline int64_t wsub64(int64_t a, int64_t b) { return (int64_t)((uint64_t)a - (uint64_t)b); }
+inline int64_t wmul64(int64_t a, int64_t b) { return (int64_t)((uint64_t)a * (uint64_t)b); }
+inline int64_t wabs64(int64_t a) { return a < 0 ? (int64_t)(0 - (uint64_t)a) : a; }
+inline int64_t wdiv64(int64_t a, int64_t b) { if (a == std::numeric_limits<int64_t>::min() && b == -1) return a; return a / b; }
+inline int32_t from_positive(uint32_t s) { return (s & 1u) ? (int32_t)(0u - ((s >> 1) + 1u)) : (int32_t)(s >> 1); }   // utils/mod.rs:152-158 inverted
+
+uint64_t int_sqrt(uint64_t value) {   // mesh_prediction_for_texture_coordinates.rs:32-48
+  if (value == 0) return 0;
+  uint64_t act = value, sq = 1;
+  while (act >= 2) { sq *= 2; act /= 4; }
+  sq = (sq + value / sq) / 2;
+  while (sq * sq > value) sq = (sq + value / sq) / 2;
+  return sq;
+}
+
+struct Reader {
+  const uint8_t* p; size_t n, at = 0;
+  bool ok = true;
+  uint8_t r8() { if (at >= n) { ok = false; return 0; } return p[at++]; }
+  uint32_t r32() { uint32_t v = 0; for (int k = 0; k < 4; ++k) v |= (uint32_t)r8() << (8 * k); return v; }
+  float rf32() { const uint32_t b = r32(); float f; std::memcpy(&f, &b, 4); return f; }
+  uint64_t leb() { uint64_t v = 0; uint32_t sh = 0; uint8_t b; do { b = r8(); v |= (uint64_t)(b & 0x7F) << sh; sh += 7; } while ((b & 0x80) && ok && sh < 70); return v; }
+};
+
+// DirectCoded symbols (decode/entropy/symbol_coding.rs:125-210 + RansSymbolDecoder::new rans.rs:139-200): method, bit_length,
+// frequency table with zero-run tokens, leb128 length, stream
+int decode_symbols(Reader& r, uint64_t n, std::vector<uint32_t>& out) {
+  if (r.r8() != 1) return host_fail(DMI_ERR_ENTROPY, "symbols are not direct coded");
+  const uint8_t bl = r.r8();
+  if (bl < 1 || bl > 18) return host_fail(DMI_ERR_ENTROPY, "bad symbol bit length");
+  static const uint8_t prec_of[19] = {0, 12, 12, 12, 12, 12, 12, 12, 12, 13, 15, 16, 18, 19, 20, 20, 20, 20, 20};
+  const uint32_t P = prec_of[bl];
+  const uint64_t num_symbols = r.leb();
+  if (!r.ok || num_symbols > ((uint64_t)1 << 21)) return host_fail(DMI_ERR_ENTROPY, "bad frequency table size");
+  std::vector<uint32_t> freq((size_t)num_symbols, 0);
+  for (uint64_t i = 0; i < num_symbols; ++i) {
+    const uint8_t b = r.r8();
+    const uint32_t token = b & 3u;
+    if (token == 3) {
+      const uint32_t offset = b >> 2;
+      if (i + offset >= num_symbols) return host_fail(DMI_ERR_ENTROPY, "zero run past the frequency table");
+      i += offset;
+    } else {
+      uint32_t count = b >> 2;
+      for (uint32_t j = 0; j < token; ++j) count |= (uint32_t)r.r8() << (8 * (j + 1) - 2);
+      freq[(size_t)i] = count;
+    }
+  }
+  const uint64_t nbytes = r.leb();
+  if (!r.ok || r.at + nbytes > r.n) return host_fail(DMI_ERR_ENTROPY, "symbol stream past the section");
+  out.resize((size_t)n);
+  if (!host_rans_decode(r.p + r.at, (size_t)nbytes, freq.data(), (uint32_t)num_symbols, P, n, out.data())) return host_fail(DMI_ERR_ENTROPY, "truncated or inconsistent rANS stream");
+  r.at += (size_t)nbytes;
+  return DMI_OK;
+}
+
+struct DevBuf {   // (a decode call owns a handful of device arrays)
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int upload(const void* src, size_t bytes, hipStream_t s) {
+    HIP_TRY_D(hipMalloc(&p, bytes ? bytes : 4));
+    if (bytes) HIP_TRY_D(hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, s));
+    return DMI_OK;
+  }
+  int alloc(size_t bytes) { HIP_TRY_D(hipMalloc(&p, bytes ? bytes : 4)); return DMI_OK; }
+  template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct Owner {
+  std::vector<dmi_decoded_attribute> atts;   // (values pointers are filled in as the attributes finish)
+  std::vector<std::vector<float>> values;
+};
+
+}  // namespace
+}  // namespace dmi
+
+using namespace dmi;
+
+extern "C" {
+
+void dmi_decoded_free(dmi_decoded* d) {
+  if (!d) return;
+  delete static_cast<Owner*>(d->owner);
+  d->owner = nullptr; d->attributes = nullptr; d->num_attributes = 0;
+}
+
+int dmi_decode_attributes(const uint8_t* section, size_t len, const dmi_corner_table* tables, uint32_t n_tables, const uint32_t* seeds, uint32_t n_seeds,
+                          uint32_t num_points, const dmi_config* cfg_in, dmi_decoded* out) {
+  if (!section || !tables || !out || n_tables == 0) return host_fail(DMI_ERR_INVALID_ARGUMENT, "null argument");
+  dmi_config cfg{};
+  if (cfg_in) cfg = *cfg_in;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return host_fail(DMI_ERR_NO_DEVICE, "no HIP device visible; libdraco_mi has no CPU fallback");
+  HIP_TRY_D(hipSetDevice(cfg.device));
+  hipStream_t s = static_cast<hipStream_t>(cfg.stream);
+  struct OwnStream { hipStream_t s = nullptr; ~OwnStream() { if (s) (void)hipStreamDestroy(s); } } own;
+  if (!s) { HIP_TRY_D(hipStreamCreate(&own.s)); s = own.s; }
+
+  Reader r{section, len};
+  const uint32_t n_atts = r.r8();                                                  // encode/attribute/mod.rs:26
+  if (n_atts == 0 || n_atts > n_tables) return host_fail(DMI_ERR_INVALID_ARGUMENT, "the section codes " + std::to_string(n_atts) + " attributes, " + std::to_string(n_tables) + " corner tables given");
+  std::vector<uint8_t> domain(n_atts);
+  for (uint32_t i = 0; i < n_atts; ++i) { r.r8(); domain[i] = r.r8(); r.r8(); }   // :30-39 (data id, domain, traversal)
+  std::unique_ptr<Owner> owner(new Owner());
+  owner->atts.resize(n_atts);
+  owner->values.resize(n_atts);
+  std::vector<uint8_t> port(n_atts);
+  for (uint32_t i = 0; i < n_atts; ++i) {                                         // :43-57
+    dmi_decoded_attribute& a = owner->atts[i];
+    if (r.r8() != 1) return host_fail(DMI_ERR_UNSUPPORTED_DATA_TYPE, "attribute decoder with more than one attribute");
+    a.att_type = r.r8(); a.component_type = r.r8(); a.num_components = r.r8();
+    r.r8();                                                                        // normalized
+    a.unique_id = r.r8();
+    a.portabilization = port[i] = r.r8();
+    a.domain = domain[i];
+    a.num_points = num_points;
+    if (a.num_components < 1 || a.num_components > 4) return host_fail(DMI_ERR_UNSUPPORTED_NUM_COMPONENTS, "components must be 1..4");
+  }
+  if (!r.ok) return host_fail(DMI_ERR_ENTROPY, "truncated attribute headers");
+  const uint32_t F = tables[0].num_faces;
+  const size_t C = (size_t)F * 3;
+  for (uint32_t i = 0; i < n_atts; ++i) {
+    if (tables[i].num_faces != F || !tables[i].corner_to_point || !tables[i].corner_to_vertex || !tables[i].opposite) return host_fail(DMI_ERR_INVALID_ARGUMENT, "corner table arrays missing");
+    for (size_t c = 0; c < C; ++c) {
+      if (tables[i].corner_to_vertex[c] >= tables[i].num_vertices || tables[i].corner_to_point[c] >= num_points || (tables[i].opposite[c] != kNone && tables[i].opposite[c] >= C))
+        return host_fail(DMI_ERR_INVALID_ARGUMENT, "corner table " + std::to_string(i) + ": entry out of range");
+    }
+  }
+  // the corner tables on the device (shared by the kernels of every attribute)
+  DevBuf d_c2p;
+  int rc = d_c2p.upload(tables[0].corner_to_point, C * 4, s);
+  if (rc) return rc;
+  std::vector<int32_t> pos_by_vertex;   // decoded positions by UNIVERSAL vertex (the parent of normals and texture coordinates)
+  int pos_att = -1;
+  DevBuf d_pos, d_c2v_pos;
+
+  for (uint32_t i = 0; i < n_atts; ++i) {
+    dmi_decoded_attribute& a = owner->atts[i];
+    const dmi_corner_table& t = tables[i];
+    a.scheme = r.r8(); a.transform = r.r8();                                       // attribute_encoder.rs:159-160
+    if (r.r8() != 1) return host_fail(DMI_ERR_ENTROPY, "rans_encoding flag not set");
+    std::vector<uint32_t> seq_own;
+    const uint32_t* seq = t.sequence;
+    uint32_t n = t.sequence_len;
+    if (!seq) {
+      if (!t.left_most_corner) return host_fail(DMI_ERR_INVALID_ARGUMENT, "left_most_corner needed to compute the sequence");
+      TableRef tr{F, t.num_vertices, t.corner_to_vertex, t.opposite, t.left_most_corner};
+      attribute_sequence(tr, seeds, n_seeds, seq_own);
+      seq = seq_own.data(); n = (uint32_t)seq_own.size();
+    }
+    for (uint32_t k = 0; k < n; ++k) if (seq[k] >= C) return host_fail(DMI_ERR_INVALID_ARGUMENT, "sequence entry out of range");
+    const int N = port[i] == 3 ? 2 : a.num_components;
+    std::vector<uint32_t> sym;
+    if ((rc = decode_symbols(r, (uint64_t)n * N, sym))) return rc;
+    int32_t t_min = 0, t_max = 0;
+    bool meta_ok = true;
+    auto read_transform_info = [&] {
+      if (a.transform == 1) { t_min = (int32_t)r.r32(); t_max = (int32_t)r.r32(); }
+      else if (a.transform == 3) { if (r.r32() != 255 || r.r32() != 127) meta_ok = false; }
+    };
+    std::vector<uint8_t> bits;
+    auto read_rabs = [&](uint64_t count) -> int {
+      const uint8_t zp = r.r8();
+      const uint64_t nbytes = r.leb();
+      if (!r.ok || zp == 0 || r.at + nbytes > len) return host_fail(DMI_ERR_ENTROPY, "truncated rABS block");
+      bits.resize((size_t)count);
+      if (!host_rabs_decode(section + r.at, (size_t)nbytes, zp, count, bits.data())) return host_fail(DMI_ERR_ENTROPY, "truncated rABS stream");
+      r.at += (size_t)nbytes;
+      std::reverse(bits.begin(), bits.end());   // the encoder pushed them first to last; an ANS decoder pops the last one first
+      return DMI_OK;
+    };
+    if (a.scheme == 6) { read_transform_info(); if ((rc = read_rabs(n))) return rc; }
+    else if (a.scheme == 5) {
+      const uint32_t count = r.r32();
+      if (count > n) return host_fail(DMI_ERR_ENTROPY, "more orientation bits than entries");
+      if ((rc = read_rabs(count))) return rc;
+      bool last = true;   // transitions → orientations (mesh_prediction_for_texture_coordinates.rs:241-256 inverted)
+      for (size_t k = count; k-- > 0;) { if (!bits[k]) last = !last; bits[k] = last ? 1 : 0; }
+      read_transform_info();
+    } else read_transform_info();
+    float q_min[4] = {0, 0, 0, 0}, q_range = 0;
+    int q_bits = 0;
+    if (port[i] == 2) { for (int k = 0; k < a.num_components; ++k) q_min[k] = r.rf32(); q_range = r.rf32(); q_bits = r.r8(); }
+    else if (port[i] == 3) { if (r.r8() != 8) meta_ok = false; }
+    else if (port[i] != 1) return host_fail(DMI_ERR_UNSUPPORTED_DATA_TYPE, "unknown portabilization");
+    if (!r.ok || !meta_ok) return host_fail(DMI_ERR_ENTROPY, "truncated or unexpected attribute metadata");
+    a.bits = (uint8_t)(port[i] == 3 ? 8 : q_bits);
+    if ((a.scheme == 5 || a.scheme == 6) && pos_att < 0) return host_fail(DMI_ERR_BAD_PARENT, "attribute " + std::to_string(i) + " needs a decoded Position attribute");
+
+    std::vector<int32_t> val((size_t)t.num_vertices * N, 0);   // quantized values by this table's vertex
+    DevBuf d_val, d_c2v, d_opp, d_seq, d_sym, d_flips;
+    if ((rc = d_c2v.upload(t.corner_to_vertex, C * 4, s))) return rc;
+    if (a.scheme == 6) {
+      // ---- normals on the device: every entry independently from the decoded positions ----
+      if (a.transform != 3) return host_fail(DMI_ERR_UNSUPPORTED_DATA_TYPE, "normal prediction without the oct-orthogonal transform");
+      if (N != 2) return host_fail(DMI_ERR_UNSUPPORTED_NUM_COMPONENTS, "normals must portabilize to 2 components");
+      if ((rc = d_opp.upload(t.opposite, C * 4, s)) || (rc = d_seq.upload(seq, (size_t)n * 4, s)) || (rc = d_sym.upload(sym.data(), sym.size() * 4, s)) ||
+          (rc = d_flips.upload(bits.data(), bits.size(), s)) || (rc = d_val.alloc(val.size() * 4)))
+        return rc;
+      HIP_TRY_D(hipMemsetAsync(d_val.p, 0, val.size() * 4, s));
+      DecodeNormalArgs da{d_seq.as<uint32_t>(), n, 0u, d_c2v_pos.as<uint32_t>(), d_opp.as<uint32_t>(), d_c2v.as<uint32_t>(), d_pos.as<int32_t>(), d_sym.as<uint32_t>(), d_flips.as<uint8_t>(),
+                          d_val.as<int32_t>()};
+      launch_decode_normals(da, s);
+    } else {
+      // ---- sequential predictions on a host core ----
+      std::vector<uint32_t> when(t.num_vertices, 0);   // sequence index + 1 of a decoded vertex
+      auto have = [&](uint32_t v, size_t k) { return when[v] != 0 && when[v] - 1 < k; };
+      const int32_t max_diff = a.transform == 1 ? wadd(1, wsub(t_max, t_min)) : 0;
+      size_t next_bit = 0;
+      for (size_t k = 0; k < n; ++k) {
+        const uint32_t c = seq[k];
+        int32_t pred[4] = {0, 0, 0, 0};
+        auto previous_value = [&] { if (k > 0) { const int32_t* v = val.data() + (size_t)t.corner_to_vertex[seq[k - 1]] * N; for (int j = 0; j < N; ++j) pred[j] = v[j]; } };
+        if (a.scheme == 1) {                                                      // mesh_parallelogram_prediction.rs:186-237
+          const uint32_t opp = t.opposite[c];
+          bool done = false;
+          if (opp != kNone) {
+            const uint32_t ov = t.corner_to_vertex[opp], nv = t.corner_to_vertex[corner_next(c)], pv = t.corner_to_vertex[corner_prev(c)];
+            if (have(ov, k) && have(nv, k) && have(pv, k)) {
+              for (int j = 0; j < N; ++j) pred[j] = wsub(wadd(val[(size_t)nv * N + j], val[(size_t)pv * N + j]), val[(size_t)ov * N + j]);
+              done = true;
+            }
+          }
+          if (!done) previous_value();
+        } else if (a.scheme == 0) {                                               // delta_prediction.rs:56-71
+          previous_value();
+        } else if (a.scheme == 5) {                                               // mesh_prediction_for_texture_coordinates.rs:51-81,107-219
+          if (N != 2) return host_fail(DMI_ERR_UNSUPPORTED_NUM_COMPONENTS, "texture coordinates must have 2 components");
+          const uint32_t nc = corner_next(c), pc = corner_prev(c);
+          const uint32_t nv = t.corner_to_vertex[nc], pv = t.corner_to_vertex[pc];
+          auto pos_of = [&](uint32_t corner, int64_t* o) { const int32_t* q = pos_by_vertex.data() + (size_t)tables[pos_att].corner_to_vertex[corner] * 3; o[0] = q[0]; o[1] = q[1]; o[2] = q[2]; };
+          bool done = false;
+          if (have(nv, k) && have(pv, k)) {
+            const int64_t nu[2] = {val[(size_t)nv * 2], val[(size_t)nv * 2 + 1]}, pu[2] = {val[(size_t)pv * 2], val[(size_t)pv * 2 + 1]};
+            if (nu[0] == pu[0] && nu[1] == pu[1]) { pred[0] = (int32_t)pu[0]; pred[1] = (int32_t)pu[1]; done = true; }
+            else {
+              int64_t cp[3], np[3], pp[3], pn[3], cn[3];
+              pos_of(c, cp); pos_of(nc, np); pos_of(pc, pp);
+              for (int j = 0; j < 3; ++j) { pn[j] = wsub64(pp[j], np[j]); cn[j] = wsub64(cp[j], np[j]); }
+              const uint64_t pn2 = (uint64_t)wadd64(wadd64(wmul64(pn[0], pn[0]), wmul64(pn[1], pn[1])), wmul64(pn[2], pn[2]));
+              if (pn2 != 0) {
+                const int64_t cdp = wadd64(wadd64(wmul64(pn[0], cn[0]), wmul64(pn[1], cn[1])), wmul64(pn[2], cn[2]));
+                const int64_t pnu[2] = {wsub64(pu[0], nu[0]), wsub64(pu[1], nu[1])};
+                const int64_t I64MAX = std::numeric_limits<int64_t>::max();
+                const int64_t n_uv_absmax = std::max(wabs64(nu[0]), wabs64(nu[1])), pn_uv_absmax = std::max(wabs64(pnu[0]), wabs64(pnu[1]));
+                const int64_t pn_absmax = std::max(std::max(wabs64(pn[0]), wabs64(pn[1])), wabs64(pn[2]));
+                if (!(n_uv_absmax > wdiv64(I64MAX, (int64_t)pn2)) && !(wabs64(cdp) > wdiv64(I64MAX, pn_uv_absmax)) && !(wabs64(cdp) > wdiv64(I64MAX, pn_absmax))) {
+                  int64_t x_uv[2], cxv[3];
+                  for (int j = 0; j < 2; ++j) x_uv[j] = wadd64(wmul64(nu[j], (int64_t)pn2), wmul64(pnu[j], cdp));
+                  for (int j = 0; j < 3; ++j) cxv[j] = wsub64(cp[j], wadd64(np[j], wdiv64(wmul64(pn[j], cdp), (int64_t)pn2)));
+                  const uint64_t cx2 = (uint64_t)wadd64(wadd64(wmul64(cxv[0], cxv[0]), wmul64(cxv[1], cxv[1])), wmul64(cxv[2], cxv[2]));
+                  const uint64_t norm = int_sqrt(cx2 * pn2);
+                  const int64_t cx_uv[2] = {wmul64(pnu[1], (int64_t)norm), wmul64((int64_t)(0 - (uint64_t)pnu[0]), (int64_t)norm)};
+                  if (next_bit >= bits.size()) return host_fail(DMI_ERR_ENTROPY, "orientation stream exhausted");
+                  const bool first = bits[next_bit++] != 0;                       // the encoder's choice, read back
+                  for (int j = 0; j < 2; ++j) pred[j] = (int32_t)wdiv64(first ? wadd64(x_uv[j], cx_uv[j]) : wsub64(x_uv[j], cx_uv[j]), (int64_t)pn2);
+                  done = true;
+                }
+              }
+            }
+          }
+          if (!done) { if (have(nv, k)) { pred[0] = val[(size_t)nv * 2]; pred[1] = val[(size_t)nv * 2 + 1]; } else previous_value(); }
+        } else {
+          return host_fail(DMI_ERR_UNSUPPORTED_DATA_TYPE, "unknown prediction scheme " + std::to_string(a.scheme));
+        }
+        const uint32_t v = t.corner_to_vertex[c];
+        for (int j = 0; j < N; ++j) {
+          int32_t o;
+          if (a.transform == 1) {                                                 // wrapped_difference.rs:54-99 inverted
+            int32_t p = pred[j];
+            if (t_min <= t_max) p = p < t_min ? t_min : (p > t_max ? t_max : p);
+            o = wadd(p, from_positive(sym[k * N + j]));
+            if (o > t_max) o = wsub(o, max_diff); else if (o < t_min) o = wadd(o, max_diff);
+          } else if (a.transform == 0) {                                          // difference.rs:26-34 inverted
+            o = wadd(pred[j], from_positive(sym[k * N + j]));
+          } else {
+            return host_fail(DMI_ERR_UNSUPPORTED_DATA_TYPE, "transform " + std::to_string(a.transform) + " on a sequential scheme");
+          }
+          val[(size_t)v * N + j] = o;
+        }
+        when[v] = (uint32_t)k + 1;
+      }
+      if (a.scheme == 5 && next_bit != bits.size()) return host_fail(DMI_ERR_ENTROPY, "orientation bits left over");
+      if ((rc = d_val.upload(val.data(), val.size() * 4, s))) return rc;
+      if (a.att_type == DMI_ATT_POSITION && N == 3 && pos_att < 0) {   // the parent of the normals / texture coordinates that follow
+        pos_att = (int)i;
+        pos_by_vertex = val;
+        if ((rc = d_pos.upload(pos_by_vertex.data(), pos_by_vertex.size() * 4, s)) || (rc = d_c2v_pos.upload(t.corner_to_vertex, C * 4, s))) return rc;
+      }
+    }
+    // ---- dequantization, scattered to the points (device) ----
+    DevBuf d_out;
+    owner->values[i].assign((size_t)num_points * a.num_components, 0.0f);
+    if ((rc = d_out.alloc(owner->values[i].size() * 4))) return rc;
+    HIP_TRY_D(hipMemsetAsync(d_out.p, 0, owner->values[i].size() * 4, s));
+    DequantizeArgs qa{};
+    qa.c2p = d_c2p.as<uint32_t>(); qa.c2v = d_c2v.as<uint32_t>(); qa.corners = C; qa.q = d_val.as<int32_t>(); qa.out = d_out.as<float>();
+    for (int k = 0; k < 4; ++k) qa.mn[k] = q_min[k];
+    qa.delta = port[i] == 2 ? q_range / (float)(uint64_t)((1ull << q_bits) - 1ull) : 0.0f;
+    qa.kind = port[i]; qa.N = a.num_components;
+    launch_dequantize(qa, s);
+    HIP_TRY_D(hipMemcpyAsync(owner->values[i].data(), d_out.p, owner->values[i].size() * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY_D(hipStreamSynchronize(s));   // (the attribute's device arrays go out of scope)
+    a.values = owner->values[i].data();
+  }
+  if (r.at != len) return host_fail(DMI_ERR_ENTROPY, std::to_string(len - r.at) + " bytes left after the last attribute");
+  out->num_attributes = n_atts;
+  out->attributes = owner->atts.data();
+  out->owner = owner.release();
+  return DMI_OK;
+}
+
+}  // extern "C"

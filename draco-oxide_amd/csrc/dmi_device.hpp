@@ -197,6 +197,16 @@ void launch_copy_items(const CopyItem* items_dev, uint32_t n_items, uint8_t* are
 void launch_scatter_items(const CopyItem* items_dev, uint32_t n_items, const uint8_t* arena, hipStream_t s);
 void launch_pack_streams(const ChainDesc* descs_dev, uint32_t n_streams, PackEntry* table, uint8_t* arena, hipStream_t s);
 
+// ---- decoder side: the data-parallel stages of reading an attribute section back (dmi_decode.cpp drives them) ----
+// normals: entry i (corner seq[i] of the normal attribute's table) is predicted from the decoded positions of its fan and corrected by its
+// two symbols; the octahedral coordinates land at the attribute vertex of the corner
+struct DecodeNormalArgs { const uint32_t* seq; uint32_t n; uint32_t pad; const uint32_t* c2v_pos /* universal vertex per corner */; const uint32_t* opp /* this table's */;
+                          const uint32_t* c2v_att; const int32_t* pos_by_vertex /* 3 per universal vertex */; const uint32_t* sym; const uint8_t* flips; int32_t* oct_by_vertex; };
+void launch_decode_normals(const DecodeNormalArgs& a, hipStream_t s);
+// values[point_idx(c)] = dequantize(q[vertex(c)]) for every corner; kind: 1 ToBits, 2 coordinate-wise (mn, delta), 3 octahedral
+struct DequantizeArgs { const uint32_t* c2p; const uint32_t* c2v; uint64_t corners; const int32_t* q; float* out; float mn[4]; float delta; int kind; int N; int pad; };
+void launch_dequantize(const DequantizeArgs& a, hipStream_t s);
+
 // ---- coding-order relabelling of the connectivity inputs on the device (dmi_relabel.hip; job creation of large meshes) ----
 void launch_fill_u32(uint32_t* p, uint64_t n, uint32_t v, hipStream_t s);
 void launch_rank_scatter(const uint32_t* seq, uint32_t n_seq, const uint32_t* c2v, uint32_t* rank /* pre-filled with DMI_NONE */, hipStream_t s);

@@ -1338,6 +1338,96 @@ __device__ __forceinline__ void k_histogram_body(const HistArgs& args, const uin
   for (uint32_t b = threadIdx.x; b < lds_bins; b += kBlock) { const uint32_t v = lds[b]; if (v) atomicAdd(&a.hist[b], v); }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Decoder side: the stages of reading an attribute section back that are data-parallel.  Entropy decoding and the
+// position / texture-coordinate predictions are sequential like their encoders (each value needs the ones decoded before it) and
+// run on host cores (dmi_decode.cpp); the NORMAL predictor only needs the — already decoded — positions, so every entry of a
+// normal attribute is reconstructed independently here, and dequantization is a scatter over corners.
+//   k_decode_normals   mesh_normal_prediction.rs:22-44,75-144 re-run + oct_orthogonal.rs:23-74 inverted (the reference's own inverse
+//                      is unimplemented!(): decode/attribute/inverse_prediction_transform/oct_orthogonal.rs:40)
+//   k_dequantize       the inverse of quantization_coordinate_wise.rs:70-91 / octahedral_quantization.rs:49-64 (Draco's dequantizers:
+//                      v = min + q · range / (2^bits - 1); octahedral (u, v) → unit vector), written to every point of the vertex
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void invert_diamond_encoder(int32_t& a, int32_t& b) {   // oct_orthogonal.rs:35-45 (sign(0) = 0 and all)
+  const int32_t a0 = a, q = -isgn(wmul(a, b));
+  a = wadd(wmul(q, b), wmul(isgn(a0), 127));
+  b = wadd(wmul(q, a0), wmul(isgn(b), 127));
+}
+__device__ __forceinline__ void invert_diamond_involution(int32_t& s, int32_t& t) {   // the format's involution (inverts the map above off the axes)
+  int32_t sign_s, sign_t;
+  if (s >= 0 && t >= 0) { sign_s = 1; sign_t = 1; }
+  else if (s <= 0 && t <= 0) { sign_s = -1; sign_t = -1; }
+  else { sign_s = s > 0 ? 1 : -1; sign_t = t > 0 ? 1 : -1; }
+  const int32_t cs = sign_s * 127, ct = sign_t * 127;
+  int32_t us = t + t - ct, ut = s + s - cs;
+  if (sign_s * sign_t >= 0) { us = -us; ut = -ut; }
+  s = (us + cs) / 2;
+  t = (ut + ct) / 2;
+}
+__device__ __forceinline__ void oct_orthogonal_inverse(int32_t p0, int32_t p1, int32_t c0, int32_t c1, int32_t& o0, int32_t& o1) {
+  p0 = wsub(p0, 127); p1 = wsub(p1, 127);
+  const bool inverted = wadd(iabs(p0), iabs(p1)) > 127;
+  if (inverted) invert_diamond_encoder(p0, p1);
+  int turns = 0;
+  if (!(p0 == 0 && p1 == 0)) for (; turns < 4 && (p0 >= 0 || p1 > 0); ++turns) { const int32_t t = p0; p0 = (int32_t)(0u - (uint32_t)p1); p1 = t; }
+  o0 = wadd(c0, p0); o1 = wadd(c1, p1);
+  if (o0 > 127) o0 = wsub(o0, 255);
+  if (o1 > 127) o1 = wsub(o1, 255);
+  for (int k = 0; k < (4 - turns % 4) % 4; ++k) { const int32_t t = o0; o0 = (int32_t)(0u - (uint32_t)o1); o1 = t; }
+  if (inverted) invert_diamond_involution(o0, o1);
+  o0 = wadd(o0, 127); o1 = wadd(o1, 127);
+}
+__global__ __launch_bounds__(kBlock) void k_decode_normals(DecodeNormalArgs a) {
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < a.n; i += gridDim.x * kBlock) {
+    const uint32_t c = a.seq[i];
+    auto pos_of = [&](uint32_t corner, int32_t (&o)[3]) { const int32_t* q = a.pos_by_vertex + (size_t)a.c2v_pos[corner] * 3; o[0] = q[0]; o[1] = q[1]; o[2] = q[2]; };
+    int32_t Pc[3];
+    pos_of(c, Pc);
+    // the fan of the vertex on THIS attribute's table: swing left to its start, then right over every face (the reference's walk)
+    uint32_t cur = c;
+    for (uint32_t guard = 0; guard < (1u << 24); ++guard) { const uint32_t o = a.opp[cnext(cur)]; if (o == kNoneD) break; cur = cnext(o); if (cur == c) break; }
+    const uint32_t start = cur;
+    int64_t sum[3] = {0, 0, 0};
+    for (uint32_t guard = 0; guard < (1u << 24); ++guard) {
+      int32_t Pn[3], Pp[3];
+      pos_of(cnext(cur), Pn); pos_of(cprev(cur), Pp);
+      add_face_normal<false>(Pn, Pp, Pc, sum);
+      const uint32_t o = a.opp[cprev(cur)];
+      if (o == kNoneD) break;
+      cur = cprev(o);
+      if (cur == start) break;
+    }
+    const int64_t upper = 1ll << 29;
+    const int64_t abs_sum = wadd64(wadd64(wabs64(sum[0]), wabs64(sum[1])), wabs64(sum[2]));
+    if (abs_sum > upper) { const int64_t quot = abs_sum / upper; sum[0] = wdiv64(sum[0], quot); sum[1] = wdiv64(sum[1], quot); sum[2] = wdiv64(sum[2], quot); }
+    const int32_t n0 = (int32_t)sum[0], n1 = (int32_t)sum[1], n2 = (int32_t)sum[2];
+    int32_t p0 = 0, p1 = 0;
+    if (!(n0 == 0 && n1 == 0 && n2 == 0)) oct_quantize((float)n0, (float)n1, (float)n2, p0, p1);
+    if (a.flips[i]) { p0 = wmul(p0, -1); p1 = wmul(p1, -1); }   // the encoder's choice (Q8), read back from its rABS stream
+    int32_t o0, o1;
+    oct_orthogonal_inverse(p0, p1, (int32_t)a.sym[(size_t)i * 2], (int32_t)a.sym[(size_t)i * 2 + 1], o0, o1);
+    int32_t* dst = a.oct_by_vertex + (size_t)a.c2v_att[c] * 2;
+    dst[0] = o0; dst[1] = o1;
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_dequantize(DequantizeArgs a) {
+  for (uint64_t c = (uint64_t)blockIdx.x * kBlock + threadIdx.x; c < a.corners; c += (uint64_t)gridDim.x * kBlock) {
+    const uint32_t p = a.c2p[c], v = a.c2v[c];
+    if (a.kind == 2) {          // coordinate-wise
+      for (int k = 0; k < a.N; ++k) a.out[(size_t)p * a.N + k] = a.mn[k] + (float)a.q[(size_t)v * a.N + k] * a.delta;
+    } else if (a.kind == 3) {   // octahedral, 8 bits
+      const float u = (float)a.q[(size_t)v * 2] / 127.0f - 1.0f, w = (float)a.q[(size_t)v * 2 + 1] / 127.0f - 1.0f;
+      float x = 1.0f - fabsf(u) - fabsf(w), y = u, z = w;
+      if (x < 0.0f) { const float ya = y, za = z; y = (ya < 0.0f ? -1.0f : 1.0f) * (1.0f - fabsf(za)); z = (za < 0.0f ? -1.0f : 1.0f) * (1.0f - fabsf(ya)); }
+      const float nrm = sqrtf(x * x + y * y + z * z);
+      if (nrm > 0.0f) { x /= nrm; y /= nrm; z /= nrm; }
+      a.out[(size_t)p * 3] = x; a.out[(size_t)p * 3 + 1] = y; a.out[(size_t)p * 3 + 2] = z;
+    } else {                    // ToBits: the portable values are the values
+      for (int k = 0; k < a.N; ++k) a.out[(size_t)p * a.N + k] = __int_as_float(a.q[(size_t)v * a.N + k]);
+    }
+  }
+}
+
 inline uint32_t grid_for(uint64_t work, uint32_t cap = 256 * 8) {
   uint64_t b = (work + kBlock - 1) / kBlock;
   if (b < 1) b = 1;
@@ -1497,6 +1587,9 @@ void launch_predict_fused(const FusedArgs& a, hipStream_t s) {
   static const uint32_t env_lds = std::getenv("DMI_FUSED_LDS") ? (uint32_t)std::atoi(std::getenv("DMI_FUSED_LDS")) : 0u;   // tuning aid: unused dynamic LDS per block = fewer blocks per CU
   emit(id, 4, a, g, env_lds, s);
 }
+
+void launch_decode_normals(const DecodeNormalArgs& a, hipStream_t s) { if (a.n) hipLaunchKernelGGL(k_decode_normals, grid_for(a.n, 8192), kBlock, 0, s, a); }
+void launch_dequantize(const DequantizeArgs& a, hipStream_t s) { if (a.corners) hipLaunchKernelGGL(k_dequantize, grid_for(a.corners, 8192), kBlock, 0, s, a); }
 
 uint32_t orient_summary_blocks(uint32_t n) { return (n + kOrientChunk - 1) / kOrientChunk; }
 void launch_orient_summary(const uint8_t* orient, uint32_t n, uint32_t* summary, uint32_t*, hipStream_t s) {

@@ -157,4 +157,60 @@ void host_rabs_chain(const uint8_t* bits, uint64_t n, const RansEntry* e, HostCh
   out.len = (size_t)(p - out.data);
 }
 
+// ---- the inverse coders (decode/entropy/rans.rs:36-69, :106-127): the decoder side's serial stage, on a host core ----
+namespace {
+inline bool read_tagged_state(const uint8_t* data, size_t& pos, uint64_t& state) {   // rans.rs:36-46: the last byte's top two bits give the state's width
+  if (pos == 0) return false;
+  const uint8_t meta = data[--pos];
+  const uint32_t flag = meta >> 6;
+  if (pos < flag) return false;
+  uint64_t s = 0;
+  for (uint32_t k = 0; k < flag; ++k) s |= (uint64_t)data[pos - flag + k] << (8 * k);
+  pos -= flag;
+  state = s | ((uint64_t)(meta & 0x3F) << (flag << 3));
+  return true;
+}
+}  // namespace
+
+// n symbols in FORWARD order (the encoder fed them last to first); freq[] = normalised frequencies summing to 2^precision.
+// Returns false on a truncated stream / a frequency table that does not sum to 2^precision.
+bool host_rans_decode(const uint8_t* data, size_t len, const uint32_t* freq, uint32_t num_symbols, uint32_t precision, uint64_t n, uint32_t* out) {
+  size_t pos = len;
+  uint64_t x;
+  if (!read_tagged_state(data, pos, x)) return false;
+  const uint64_t L = (uint64_t)4 << precision, mask = ((uint64_t)1 << precision) - 1;
+  x += L;
+  std::vector<uint32_t> slot((size_t)1 << precision), cum(num_symbols);
+  uint64_t c = 0;
+  for (uint32_t s = 0; s < num_symbols; ++s) {
+    cum[s] = (uint32_t)c;
+    if (c + freq[s] > ((uint64_t)1 << precision)) return false;
+    for (uint32_t k = 0; k < freq[s]; ++k) slot[c + k] = s;
+    c += freq[s];
+  }
+  if (c != ((uint64_t)1 << precision)) return false;
+  for (uint64_t i = 0; i < n; ++i) {
+    while (x < L) { if (pos == 0) return false; x = x * 256 + data[--pos]; }
+    const uint64_t q = x >> precision, r = x & mask;
+    const uint32_t s = slot[r];
+    x = q * freq[s] + r - cum[s];
+    out[i] = s;
+  }
+  return true;
+}
+// n bits in the order the decoder pops them (= the REVERSE of the order the encoder pushed them)
+bool host_rabs_decode(const uint8_t* data, size_t len, uint32_t zero_prob, uint64_t n, uint8_t* out) {
+  size_t pos = len;
+  uint64_t x;
+  if (!read_tagged_state(data, pos, x)) return false;
+  x += 4096;
+  const uint64_t f1 = 256 - zero_prob;
+  for (uint64_t i = 0; i < n; ++i) {
+    if (x < 4096) { if (pos == 0) return false; x = (x << 8) + data[--pos]; }
+    const uint64_t q = x >> 8, r = x & 255, xn = q * f1;
+    if (r < f1) { x = xn + r; out[i] = 1; } else { x = x - xn - f1; out[i] = 0; }
+  }
+  return true;
+}
+
 }  // namespace dmi

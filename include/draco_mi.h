@@ -200,6 +200,26 @@ typedef struct dmi_built_mesh { dmi_mesh mesh; void* owner; } dmi_built_mesh;
 int dmi_mesh_build(const dmi_raw_attribute* atts, uint32_t n_atts, const uint32_t* faces, uint32_t num_faces, dmi_built_mesh* out);
 void dmi_built_mesh_free(dmi_built_mesh* m);
 
+/* --- Decoder side: the attribute section read back --------------------------------------------------------------
+ * What a decoder does after its connectivity stage: `tables[i]` / `seeds` are the arrays dmi_encode_attributes takes (a decoder
+ * rebuilds exactly these from the connectivity bytes), `section` is the output of dmi_encode_attributes / dmi_job_encode.
+ * Entropy decoding (decode/entropy/{rans,symbol_coding}.rs) and the predictions that need earlier values of the same attribute run
+ * on host cores — they are dependency chains like their encoders — normals (predicted from the decoded positions) and all
+ * dequantization run on the device.  The reference's own decode/attribute/ is an unbuilt prototype of an older layout
+ * (decode/mod.rs:5-6); everything above the entropy layer is the encoder spec inverted.
+ * values: num_points rows of num_components f32 (the raw 4-byte values of a ToBits attribute), library-owned until dmi_decoded_free. */
+typedef struct dmi_decoded_attribute {
+  uint8_t att_type, component_type, num_components, domain;
+  uint8_t scheme, transform, portabilization, bits;   /* wire ids of the prediction scheme / transform / portabilization, quantization bits */
+  uint32_t unique_id;
+  uint32_t num_points;
+  const float* values;
+} dmi_decoded_attribute;
+typedef struct dmi_decoded { uint32_t num_attributes; const dmi_decoded_attribute* attributes; void* owner; } dmi_decoded;
+int dmi_decode_attributes(const uint8_t* section, size_t len, const dmi_corner_table* tables, uint32_t n_tables, const uint32_t* seeds, uint32_t n_seeds,
+                          uint32_t num_points, const dmi_config* cfg, dmi_decoded* out);
+void dmi_decoded_free(dmi_decoded* d);
+
 /* --- The hybrid form's host-core stream coders on their own (host only, no device) ----------------
  * A single large mesh codes its streams on host cores from the device-built symbols and tables (dmi_job_encode, see
  * DESIGN.md §5); these two entry points expose exactly those coders so that tests can pin them against the reference's
