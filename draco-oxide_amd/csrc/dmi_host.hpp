@@ -128,7 +128,10 @@ struct TableRef {
   uint32_t F, V;
   const uint32_t *c2v, *opp, *lmc;
 };
-void attribute_sequence(const TableRef& t, const uint32_t* seeds, uint32_t n_seeds, std::vector<uint32_t>& seq);
+// on_boundary (optional): one byte per vertex, != 0 ⇔ the vertex lies on a boundary of `t` (vertex_boundary_flags) — spares the walk two
+// dependent loads per vertex
+void attribute_sequence(const TableRef& t, const uint32_t* seeds, uint32_t n_seeds, std::vector<uint32_t>& seq, const uint8_t* on_boundary = nullptr);
+void vertex_boundary_flags(const TableRef& t, std::vector<uint8_t>& on_boundary);   // parallel slices for a large table
 
 // rABS bit coder (encode/entropy/rans.rs:71-128), host version for the small connectivity streams.
 struct RabsHost {
@@ -142,7 +145,9 @@ struct RabsHost {
   }
   bool finish();   // appends the tagged state; false on StateTooLarge
 };
-uint8_t zero_probability(uint64_t count_zero, float denominator);   // the f32 "(c0/len)*256+0.5 → clamp(1,255)" idiom
+uint8_t zero_probability(uint64_t count_zero, float denominator);
+// the rABS stream of n flags fed first to last, on the multiply-high host coder (host_chains.cpp); false on StateTooLarge
+bool host_rabs_bytes(uint8_t zero_prob, const uint8_t* fed, uint64_t n, std::vector<uint8_t>& bytes);   // the f32 "(c0/len)*256+0.5 → clamp(1,255)" idiom
 
 // Normalised frequency table + its serialisation.
 struct FreqTable {

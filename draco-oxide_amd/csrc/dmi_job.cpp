@@ -2295,9 +2295,10 @@ static int build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std::vector<ui
   o.views.resize(mesh->num_atts);
   o.seqs.resize(mesh->num_atts);
   auto universal_view = [&](dmi_corner_table& v) { v.num_vertices = o.ct.V; v.corner_to_vertex = o.ct.c2v.data(); v.opposite = o.ct.opp.data(); v.left_most_corner = o.ct.lmc.data(); };
+  std::vector<uint8_t> on_boundary;
   auto sequence_universal = [&] {
     TableRef tr{o.ct.F, o.ct.V, o.ct.c2v.data(), o.ct.opp.data(), o.ct.lmc.data()};
-    attribute_sequence(tr, o.eb.seeds.data(), (uint32_t)o.eb.seeds.size(), o.seqs[0]);
+    attribute_sequence(tr, o.eb.seeds.data(), (uint32_t)o.eb.seeds.size(), o.seqs[0], on_boundary.empty() ? nullptr : on_boundary.data());
   };
   auto build_att_tables = [&] {
     const auto a0 = tick();
@@ -2310,17 +2311,20 @@ static int build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std::vector<ui
     }
     t_att = since(a0);
   };
-  std::thread att_thread, seq_thread;
+  std::thread att_thread, seq_thread, flag_thread;
   EdgebreakerHooks hooks;
   if (overlap) {
+    // the sequencer's per-vertex boundary test, ahead of time (beside the start of the traversal)
+    flag_thread = std::thread([&] { TableRef tr{o.ct.F, o.ct.V, o.ct.c2v.data(), o.ct.opp.data(), o.ct.lmc.data()}; vertex_boundary_flags(tr, on_boundary); });
     att_thread = std::thread(build_att_tables);
-    hooks.seeds_ready = [&] { seq_thread = std::thread([&] { const auto q0 = tick(); sequence_universal(); t_seq = since(q0); }); };
+    hooks.seeds_ready = [&] { if (flag_thread.joinable()) flag_thread.join(); seq_thread = std::thread([&] { const auto q0 = tick(); sequence_universal(); t_seq = since(q0); }); };
     hooks.before_seams = [&] { if (att_thread.joinable()) att_thread.join(); };
   } else {
     build_att_tables();
   }
   auto c1 = tick();
   rc = run_edgebreaker(o.ct, o.eb, err, overlap ? &hooks : nullptr);
+  if (flag_thread.joinable()) flag_thread.join();
   if (att_thread.joinable()) att_thread.join();
   if (seq_thread.joinable()) seq_thread.join();
   if (rc) return fail(rc, err);

@@ -52,10 +52,9 @@ __device__ __forceinline__ uint32_t cprev(uint32_t c) { return (c % 3u == 0u) ? 
 
 // Rust `as` casts: saturating, NaN → 0.
 __device__ __forceinline__ int32_t f32_to_i32_sat(float f) {
-  if (f != f) return 0;
-  if (f >= 2147483648.0f) return 2147483647;
-  if (f <= -2147483648.0f) return (-2147483647 - 1);
-  return (int32_t)f;
+  int32_t r;   // v_cvt_i32_f32 truncates, saturates and turns NaN into 0: the cast's semantics in one instruction
+  asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(f));
+  return r;
 }
 __device__ __forceinline__ int64_t f32_to_i64_sat(float f) {
   if (f != f) return 0;
@@ -238,7 +237,9 @@ __device__ __forceinline__ int32_t quant_coord(float v, float mn, float range, f
   const float diff = v - mn;
   const float normalized = (range == 0.0f) ? diff : diff / range;
   const float quantized = normalized * maxq;
-  return (int32_t)f32_to_i64_sat(quantized + 0.5f);
+  const float h = quantized + 0.5f;
+  if (fabsf(h) < 2147483648.0f) return (int32_t)h;   // (the i64 conversion is ≈ 20 instructions; its low word is this whenever it fits)
+  return (int32_t)f32_to_i64_sat(h);
 }
 
 // geom.rs:40-91 (f32 path; Q5: the fold uses the pre-fold u and v; Q6: no normalisation)
@@ -283,33 +284,47 @@ __device__ __forceinline__ void oct_quantize(float x, float y, float z, int32_t&
 // their gathers before touching any of them: the pass is latency-bound otherwise (one 12-byte gather in flight per
 // lane is ≈3 TB/s by Little's law at HBM latency).
 constexpr int kTile = 4;
+template <int N> struct RawTile { float v[kTile][N]; };
+// issue: the kTile gathers of one attribute (value indices first when the attribute has its own point → value map)
 template <int N>
-__device__ __forceinline__ void quantize_tile(const QuantAtt& a, const uint32_t (&p)[kTile], uint32_t base, uint32_t n, int32_t& mn, int32_t& mx) {
+__device__ __forceinline__ void gather_tile(const QuantAtt& a, const uint32_t (&p)[kTile], uint32_t base, uint32_t n, RawTile<N>& r) {
   uint32_t v[kTile];
-  float raw[kTile][N];
 #pragma unroll
   for (int t = 0; t < kTile; ++t) {
     const uint32_t i = base + t * kBlock + threadIdx.x;
     v[t] = (a.s2v && i < n) ? a.s2v[i] : p[t];
+#if defined(DMI_ABLATE) && DMI_ABLATE == 6
+    v[t] = i < n ? i : 0u;
+#endif
   }
 #pragma unroll
   for (int t = 0; t < kTile; ++t) {
 #pragma unroll
-    for (int k = 0; k < N; ++k) raw[t][k] = a.raw[(size_t)v[t] * N + k];   // (entries past n read value 0: harmless)
+    for (int k = 0; k < N; ++k) r.v[t][k] = a.raw[(size_t)v[t] * N + k];   // (entries past n read value 0: harmless)
   }
+}
+// retire: quantize and store the tile
+template <int N>
+__device__ __forceinline__ void finish_tile(const QuantAtt& a, const RawTile<N>& r, uint32_t base, uint32_t n, int32_t& mn, int32_t& mx) {
 #pragma unroll
   for (int t = 0; t < kTile; ++t) {
     const uint32_t i = base + t * kBlock + threadIdx.x;
     int32_t out[N];
     int nq = N;
+#if defined(DMI_ABLATE) && DMI_ABLATE == 7
+    if (true) {
+      for (int k = 0; k < N; ++k) out[k] = __float_as_int(r.v[t][k]) & 255;
+      if (a.kind == 1) nq = 2;
+    } else
+#endif
     if (a.kind == 0) {   // coordinate-wise (meta: min[N], range)
 #pragma unroll
-      for (int k = 0; k < N; ++k) out[k] = quant_coord(raw[t][k], a.meta[k], a.meta[N], a.maxq);
+      for (int k = 0; k < N; ++k) out[k] = quant_coord(r.v[t][k], a.meta[k], a.meta[N], a.maxq);
     } else if (a.kind == 1) {   // octahedral (N == 3 → 2 components)
-      if (N == 3) { int32_t u, w; oct_quantize(raw[t][0], raw[t][1], raw[t][2], u, w); out[0] = u; out[1] = w; nq = 2; }
+      if (N == 3) { int32_t u, w; oct_quantize(r.v[t][0], r.v[t][1], r.v[t][2], u, w); out[0] = u; out[1] = w; nq = 2; }
     } else {   // ToBits: the 4-byte values reinterpreted as i32
 #pragma unroll
-      for (int k = 0; k < N; ++k) out[k] = __float_as_int(raw[t][k]);
+      for (int k = 0; k < N; ++k) out[k] = __float_as_int(r.v[t][k]);
     }
     if (i < n) {
       for (int k = 0; k < nq; ++k) { mn = min(mn, out[k]); mx = max(mx, out[k]); }
@@ -320,6 +335,27 @@ __device__ __forceinline__ void quantize_tile(const QuantAtt& a, const uint32_t 
     }
   }
 }
+template <int N>
+__device__ __forceinline__ void quantize_tile(const QuantAtt& a, const uint32_t (&p)[kTile], uint32_t base, uint32_t n, int32_t& mn, int32_t& mx) {
+  RawTile<N> r;
+  gather_tile<N>(a, p, base, n, r);
+  finish_tile<N>(a, r, base, n, mn, mx);
+}
+// The common attribute sets of one table issue EVERY attribute's gathers before the first value is touched: a store between two
+// attributes' gathers orders them (the pointers may alias as far as the compiler knows), and the tile would pay one memory latency
+// per attribute instead of one.
+template <int N0, int N1>
+__device__ __forceinline__ void quantize_tiles2(const QuantArgs& q, const uint32_t (&p)[kTile], uint32_t base, uint32_t n, int32_t (&mn)[kMaxGather], int32_t (&mx)[kMaxGather]) {
+  RawTile<N0> r0; RawTile<N1> r1;
+  gather_tile<N0>(q.a[0], p, base, n, r0); gather_tile<N1>(q.a[1], p, base, n, r1);
+  finish_tile<N0>(q.a[0], r0, base, n, mn[0], mx[0]); finish_tile<N1>(q.a[1], r1, base, n, mn[1], mx[1]);
+}
+template <int N0, int N1, int N2>
+__device__ __forceinline__ void quantize_tiles3(const QuantArgs& q, const uint32_t (&p)[kTile], uint32_t base, uint32_t n, int32_t (&mn)[kMaxGather], int32_t (&mx)[kMaxGather]) {
+  RawTile<N0> r0; RawTile<N1> r1; RawTile<N2> r2;
+  gather_tile<N0>(q.a[0], p, base, n, r0); gather_tile<N1>(q.a[1], p, base, n, r1); gather_tile<N2>(q.a[2], p, base, n, r2);
+  finish_tile<N0>(q.a[0], r0, base, n, mn[0], mx[0]); finish_tile<N1>(q.a[1], r1, base, n, mn[1], mx[1]); finish_tile<N2>(q.a[2], r2, base, n, mn[2], mx[2]);
+}
 __device__ __forceinline__ void k_seq_quantize_body(const SeqQuantArgs& sq, const uint32_t blk_, const uint32_t nblk_) {
   const uint32_t* __restrict__ s2p = sq.s2p;
   const uint32_t n = sq.n;
@@ -327,10 +363,15 @@ __device__ __forceinline__ void k_seq_quantize_body(const SeqQuantArgs& sq, cons
   int32_t mn[kMaxGather], mx[kMaxGather];
 #pragma unroll
   for (int a = 0; a < kMaxGather; ++a) { mn[a] = 2147483647; mx[a] = (-2147483647 - 1); }
+  const int sig = args.count * 1000 + (args.count > 0 ? args.a[0].N * 100 : 0) + (args.count > 1 ? args.a[1].N * 10 : 0) + (args.count > 2 ? args.a[2].N : 0);
   DMI_FOR_TILES(base, n, kTile) {
     uint32_t p[kTile];
 #pragma unroll
     for (int t = 0; t < kTile; ++t) { const uint32_t i = base + t * kBlock + threadIdx.x; p[t] = i < n ? s2p[i] : 0u; }
+    if (sig == 3332) { quantize_tiles3<3, 3, 2>(args, p, base, n, mn, mx); continue; }   // position, normal, texture coordinate
+    if (sig == 3323) { quantize_tiles3<3, 2, 3>(args, p, base, n, mn, mx); continue; }
+    if (sig == 2330) { quantize_tiles2<3, 3>(args, p, base, n, mn, mx); continue; }
+    if (sig == 2320) { quantize_tiles2<3, 2>(args, p, base, n, mn, mx); continue; }
 #pragma unroll
     for (int a = 0; a < kMaxGather; ++a) {
       if (a >= args.count) break;
@@ -953,7 +994,11 @@ __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const u
         int32_t R[3] = {Pn[0], Pn[1], Pn[2]}, L[3] = {Pp[0], Pp[1], Pp[2]};
 #pragma unroll
         for (uint32_t k = 2; k < kFanSlots; ++k) {
+#if defined(DMI_ABLATE) && DMI_ABLATE == 2
+          if (false) {
+#else
           if (k < cnt) {
+#endif
             int32_t W[3];
             ring(k, W);
             if (k < 2u + stored_r) { add_face_normal<PACKED>(W, R, Pc, sum); R[0] = W[0]; R[1] = W[1]; R[2] = W[2]; }
@@ -993,7 +1038,11 @@ __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const u
       if (both) {
         int32_t pu[2];
         load_uv(rp, pu);
+#if defined(DMI_ABLATE) && DMI_ABLATE == 3
+        pred0 = pu[0] + Pn[0] - Pp[1]; pred1 = pu[1] + Pc[2]; done = true;
+#else
         done = texcoord_predict(cu, nu, pu, Pc, Pn, Pp, pred0, pred1, oflag);
+#endif
       }
       if (!done) {
         oflag = 0;
@@ -1019,7 +1068,11 @@ __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const u
       }
       const int32_t n0 = (int32_t)sum0, n1 = (int32_t)sum1, n2 = (int32_t)sum2;
       int32_t p0 = 0, p1 = 0;
+#if defined(DMI_ABLATE) && (DMI_ABLATE == 4 || DMI_ABLATE == 1)
+      p0 = (n0 ^ n2) & 255; p1 = (n1 + n2) & 255;
+#else
       if (!(n0 == 0 && n1 == 0 && n2 == 0)) oct_quantize((float)n0, (float)n1, (float)n2, p0, p1);
+#endif
       int32_t a0, a1;
       if (own_packed) { const uint32_t v = static_cast<const uint16_t*>(a.qs_nrm)[i]; a0 = (int32_t)(v & 0xFFu); a1 = (int32_t)(v >> 8); }
       else { const int32_t* q = static_cast<const int32_t*>(a.qs_nrm) + (size_t)i * 2; a0 = q[0]; a1 = q[1]; }
@@ -1030,7 +1083,11 @@ __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const u
       if (flip) { p0 = m0; p1 = m1; } else ++n_false;
       __builtin_nontemporal_store((uint8_t)(flip ? 1 : 0), &a.flips[i]);
       uint32_t s0, s1;
+#if defined(DMI_ABLATE) && (DMI_ABLATE == 5 || DMI_ABLATE == 1)
+      s0 = (uint32_t)(a0 + p0) & 255u; s1 = (uint32_t)(a1 ^ p1) & 255u;
+#else
       oct_orthogonal(a0, a1, p0, p1, s0, s1);
+#endif
       if (s16_nrm) __builtin_nontemporal_store(s0 | (s1 << 16), static_cast<uint32_t*>(a.sym_nrm) + i);
       else { store_sym(a.sym_nrm, false, (size_t)i * 2, s0); store_sym(a.sym_nrm, false, (size_t)i * 2 + 1, s1); }
     }

@@ -157,6 +157,16 @@ void host_rabs_chain(const uint8_t* bits, uint64_t n, const RansEntry* e, HostCh
   out.len = (size_t)(p - out.data);
 }
 
+bool host_rabs_bytes(uint8_t zero_prob, const uint8_t* fed, uint64_t n, std::vector<uint8_t>& bytes) {
+  const uint32_t p0 = zero_prob, f1 = 256u - p0;
+  const RansEntry e[2] = {make_rans_entry(p0, f1, 8), make_rans_entry(f1, 0, 8)};
+  HostChainOut o;
+  host_rabs_chain(fed, n, e, o);
+  if (o.err) return false;
+  bytes.assign(o.data, o.data + o.len);
+  return true;
+}
+
 // ---- the inverse coders (decode/entropy/rans.rs:36-69, :106-127): the decoder side's serial stage, on a host core ----
 namespace {
 inline bool read_tagged_state(const uint8_t* data, size_t& pos, uint64_t& state) {   // rans.rs:36-46: the last byte's top two bits give the state's width

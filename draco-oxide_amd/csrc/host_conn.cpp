@@ -3,7 +3,10 @@
 // (quirks kept: SURVEY.md §8a-Q Q22 half-edge matching, per-vertex "hole" ids).
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
+#include <thread>
 
 #include "dmi_host.hpp"
 
@@ -484,6 +487,10 @@ uint8_t zero_probability(uint64_t count_zero, float denominator) {
 }
 
 int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& err, const EdgebreakerHooks* hooks) {
+  const bool trace = t.F > 100000 && std::getenv("DMI_TRACE") != nullptr;
+  auto tick = [] { return std::chrono::steady_clock::now(); };
+  auto since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
+  const auto t0 = tick();
   Walker w(t);
   ByteSink s;
   s.u8(0);   // EdgebreakerKind::Standard
@@ -506,6 +513,7 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
       w.run_from(start);
     }
   }
+  const double t_walk = since(t0);
   if (w.bad) { err = "edgebreaker: inconsistent connectivity (reference unwrap() panic)"; if (hooks && hooks->before_seams) hooks->before_seams(); return DMI_ERR_CONNECTIVITY; }
   out.seeds.assign(w.init_corners.rbegin(), w.init_corners.rend());   // edgebreaker.rs:523-529
   out.seeds.insert(out.seeds.end(), w.processed.begin(), w.processed.end());
@@ -531,36 +539,122 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
     s.leb128(bits.size());
     s.bytes(bits);
   }
-  auto rabs_block = [&](const std::vector<uint8_t>& flags) -> bool {   // zero_prob, then bits reversed
-    uint64_t zeros = 0;
-    for (uint8_t b : flags) zeros += !b;
-    const uint8_t zp = zero_probability(zeros, (float)flags.size());
+  // zero_prob, then the flags fed last to first (`fed` = the flags already in feeding order)
+  auto rabs_block_fed = [&](const uint8_t* fed, size_t n, uint64_t zeros) -> bool {
+    const uint8_t zp = zero_probability(zeros, (float)n);
     s.u8(zp);
-    RabsHost rc(zp);
-    for (size_t i = flags.size(); i-- > 0;) rc.put(flags[i]);
-    if (!rc.finish()) return false;
-    s.leb128(rc.out.size());
-    s.bytes(rc.out);
+    std::vector<uint8_t> bytes;
+    if (!host_rabs_bytes(zp, fed, n, bytes)) return false;
+    s.leb128(bytes.size());
+    s.bytes(bytes);
     return true;
   };
+  const double t_bits = since(t0);
   if (hooks && hooks->before_seams) hooks->before_seams();
-  if (!rabs_block(w.start_interior)) { err = "rABS state too large"; return DMI_ERR_ENTROPY; }
-  {   // attribute seams :611-653
-    std::vector<uint8_t> fv(t.F, 0);
-    std::vector<std::vector<uint8_t>> seams(t.att.size());
-    for (auto& v : seams) v.reserve(t.F * 3 / 2);
-    for (size_t i = w.processed.size(); i-- > 0;) {
-      const uint32_t c = w.processed[i];
-      const uint32_t cs[3] = {c, corner_next(c), corner_prev(c)};
-      fv[c / 3] = 1;
-      for (uint32_t cc : cs) {
-        const uint32_t o = t.opp[cc];
-        if (o == kNone || fv[o / 3]) continue;
-        for (size_t j = 0; j < t.att.size(); ++j) seams[j].push_back(t.att[j].seam_edge[cc]);
-      }
-    }
-    for (auto& sd : seams) if (!rabs_block(sd)) { err = "rABS state too large"; return DMI_ERR_ENTROPY; }
+  const double t_wait = since(t0);
+  {
+    std::vector<uint8_t> fed(w.start_interior.rbegin(), w.start_interior.rend());
+    uint64_t zeros = 0;
+    for (uint8_t b : fed) zeros += !b;
+    if (!rabs_block_fed(fed.data(), fed.size(), zeros)) { err = "rABS state too large"; return DMI_ERR_ENTROPY; }
   }
+  {   // attribute seams :611-653.  The reference walks the processed faces last to first, marks each visited and emits, for its three
+      // corners in turn, the seam flag of every edge whose other face has not been visited yet.  "Not visited yet" only depends on the two
+      // faces' positions in `processed`, so the flags are produced in parallel slices — straight into the order the rABS coder is fed in
+      // (the reverse of the order of emission: faces first to last, corners prev, next, c) — and the streams of the attributes are
+      // coded side by side on the multiply-high coder of host_chains.cpp (a divide per flag was 2/3 of this stage).
+    const size_t n = w.processed.size(), A = t.att.size();
+    std::vector<uint32_t> where(t.F, kNone);           // position of a face in `processed`
+    std::atomic<int> twice{0};
+    parallel_for(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) where[w.processed[i] / 3] = (uint32_t)i; });
+    parallel_for(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) if (where[w.processed[i] / 3] != (uint32_t)i) { twice.store(1); break; } });
+    std::vector<std::vector<uint8_t>> fed(A);
+    std::vector<uint64_t> zeros(A, 0);
+    if (!twice.load() && A) {
+      // corners of face i whose flag is emitted, as a mask over (c, next, prev)
+      auto mask_of = [&](size_t i) -> uint32_t {
+        const uint32_t c = w.processed[i];
+        const uint32_t cs[3] = {c, corner_next(c), corner_prev(c)};
+        uint32_t m = 0;
+        for (int k = 0; k < 3; ++k) {
+          const uint32_t o = t.opp[cs[k]];
+          if (o == kNone) continue;
+          const uint32_t wo = where[o / 3];
+          if (wo == kNone || wo < (uint32_t)i) m |= 1u << k;      // its face comes later in the walk from the back (or never: a start face)
+        }
+        return m;
+      };
+      constexpr size_t kChunk = 1u << 16;
+      const size_t n_chunks = (n + kChunk - 1) / kChunk;
+      std::vector<uint8_t> mask(n);
+      std::vector<uint64_t> chunk_sum(n_chunks + 1, 0);
+      {
+        std::vector<std::atomic<uint64_t>> acc(n_chunks);
+        for (auto& a : acc) a.store(0);
+        parallel_for(n, [&](size_t lo, size_t hi) {
+          for (size_t i = lo; i < hi;) {
+            const size_t end = std::min(hi, (i / kChunk + 1) * kChunk);
+            uint64_t k = 0;
+            for (size_t j = i; j < end; ++j) { mask[j] = (uint8_t)mask_of(j); k += (uint64_t)__builtin_popcount(mask[j]); }
+            acc[i / kChunk].fetch_add(k);
+            i = end;
+          }
+        });
+        for (size_t c = 0; c < n_chunks; ++c) chunk_sum[c + 1] = chunk_sum[c] + acc[c].load();
+      }
+      const uint64_t total = chunk_sum[n_chunks];
+      for (auto& v : fed) v.resize(total);
+      std::vector<std::atomic<uint64_t>> zacc(A);
+      for (auto& a : zacc) a.store(0);
+      parallel_for(n, [&](size_t lo, size_t hi) {
+        uint64_t pos = chunk_sum[lo / kChunk];
+        for (size_t j = (lo / kChunk) * kChunk; j < lo; ++j) pos += (uint64_t)__builtin_popcount(mask[j]);
+        std::vector<uint64_t> z(A, 0);
+        for (size_t i = lo; i < hi; ++i) {
+          const uint32_t c = w.processed[i];
+          const uint32_t cs[3] = {c, corner_next(c), corner_prev(c)};
+          for (int k = 2; k >= 0; --k) {
+            if (!(mask[i] >> k & 1u)) continue;
+            for (size_t j = 0; j < A; ++j) { const uint8_t f = t.att[j].seam_edge[cs[k]]; fed[j][pos] = f; z[j] += !f; }
+            ++pos;
+          }
+        }
+        for (size_t j = 0; j < A; ++j) zacc[j].fetch_add(z[j]);
+      });
+      for (size_t j = 0; j < A; ++j) zeros[j] = zacc[j].load();
+    } else if (A) {   // a face processed twice (malformed tables): the reference's loop as it stands
+      std::vector<uint8_t> fv(t.F, 0);
+      std::vector<std::vector<uint8_t>> seams(A);
+      for (size_t i = n; i-- > 0;) {
+        const uint32_t c = w.processed[i];
+        const uint32_t cs[3] = {c, corner_next(c), corner_prev(c)};
+        fv[c / 3] = 1;
+        for (uint32_t cc : cs) {
+          const uint32_t o = t.opp[cc];
+          if (o == kNone || fv[o / 3]) continue;
+          for (size_t j = 0; j < A; ++j) seams[j].push_back(t.att[j].seam_edge[cc]);
+        }
+      }
+      for (size_t j = 0; j < A; ++j) { fed[j].assign(seams[j].rbegin(), seams[j].rend()); for (uint8_t b : fed[j]) zeros[j] += !b; }
+    }
+    // one coder per attribute, side by side for large meshes
+    std::vector<std::vector<uint8_t>> coded(A);
+    std::vector<uint8_t> ok(A, 1), zp(A, 0);
+    auto code_one = [&](size_t j) { zp[j] = zero_probability(zeros[j], (float)fed[j].size()); ok[j] = host_rabs_bytes(zp[j], fed[j].data(), fed[j].size(), coded[j]) ? 1 : 0; };
+    if (A > 1 && n >= (1u << 20) && host_threads() > 1) {
+      std::vector<std::thread> th;
+      for (size_t j = 0; j < A; ++j) th.emplace_back(code_one, j);
+      for (auto& x : th) x.join();
+    } else for (size_t j = 0; j < A; ++j) code_one(j);
+    for (size_t j = 0; j < A; ++j) {
+      if (!ok[j]) { err = "rABS state too large"; return DMI_ERR_ENTROPY; }
+      s.u8(zp[j]);
+      s.leb128(coded[j].size());
+      s.bytes(coded[j]);
+    }
+  }
+  if (trace) std::fprintf(stderr, "[dmi]   Edgebreaker of %u faces: boundaries + traversal %.1f ms, seeds + CLERS bits %.1f, wait for the seam flags %.1f, seam streams %.1f\n", t.F, t_walk,
+                          t_bits - t_walk, t_wait - t_bits, since(t0) - t_wait);
   out.connectivity.swap(s.b);
   return DMI_OK;
 }
@@ -568,7 +662,14 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
 // Attribute sequencer (shared/attribute/sequence.rs:48-151) as a plain O(F) depth-first walk.
 // The reference also deletes every stack entry lying in the face it has just marked visited;
 // such entries are skipped on pop anyway, so the emitted order is unchanged without the deletion.
-void attribute_sequence(const TableRef& t, const uint32_t* seeds, uint32_t n_seeds, std::vector<uint32_t>& seq) {
+void vertex_boundary_flags(const TableRef& t, std::vector<uint8_t>& on_boundary) {
+  on_boundary.assign(t.V, 0);
+  parallel_for(t.V, [&](size_t lo, size_t hi) {
+    for (size_t v = lo; v < hi; ++v) { const uint32_t l0 = t.lmc[v]; on_boundary[v] = (l0 != kNone && t.opp[corner_next(l0)] == kNone) ? 1 : 0; }
+  });
+}
+
+void attribute_sequence(const TableRef& t, const uint32_t* seeds, uint32_t n_seeds, std::vector<uint32_t>& seq, const uint8_t* on_boundary) {
   std::vector<uint8_t> vvis(t.V, 0), fvis(t.F, 0);
   std::vector<uint32_t> stack(seeds, seeds + n_seeds);
   seq.clear();
@@ -585,8 +686,9 @@ void attribute_sequence(const TableRef& t, const uint32_t* seeds, uint32_t n_see
     const uint32_t right = t.opp[nc], left = t.opp[pc];
     if (!vvis[v]) {
       emit(c);
-      const uint32_t l0 = t.lmc[v];
-      const bool boundary = t.opp[corner_next(l0)] == kNone;   // is_on_boundary: swing_left(lmc) is None
+      bool boundary;
+      if (on_boundary) boundary = on_boundary[v] != 0;
+      else { const uint32_t l0 = t.lmc[v]; boundary = t.opp[corner_next(l0)] == kNone; }   // is_on_boundary: swing_left(lmc) is None
       if (!boundary) { if (right != kNone) stack.push_back(right); continue; }
     }
     const bool rdone = right != kNone && fvis[right / 3], ldone = left != kNone && fvis[left / 3];

@@ -128,6 +128,33 @@ def test_degenerate_inputs():
         _assert_same(dmi.encode_mesh(mesh), sess.encode(), "degenerate")
 
 
+def test_non_finite_and_huge_values_follow_the_casts():
+    """NaN / ±inf / huge magnitudes in the raw values: the quantizers' `as` casts (saturating, NaN → 0) decide the bytes —
+    the device's one-instruction conversions against the oracle's restated casts."""
+    faces, pos, nrm, uv = synth.torus_grid(24)
+    rng = np.random.default_rng(9)
+    pos = pos.copy(); nrm = nrm.copy(); uv = uv.copy()
+    for trial, (bad_pos, bad_uv, bad_nrm) in enumerate([((np.nan,), (), ()), ((np.inf, -np.inf), (), ()), ((), (np.nan, np.inf), ()),
+                                                       ((3e38, -3e38), (1e30,), (1e30, 1e-30)), ((np.nan, np.inf), (np.nan, -np.inf), (3e38,))]):
+        p2, n2, u2 = pos.copy(), nrm.copy(), uv.copy()
+        for v in bad_pos:
+            p2[rng.integers(0, len(p2), 5), rng.integers(0, 3, 5)] = np.float32(v)
+        for v in bad_uv:
+            u2[rng.integers(0, len(u2), 5), rng.integers(0, 2, 5)] = np.float32(v)
+        for v in bad_nrm:
+            n2[rng.integers(0, len(n2), 5), rng.integers(0, 3, 5)] *= np.float32(v)
+        mesh = dmi.Mesh(faces, [dmi.Attribute(p2, dmi.ATT_POSITION), dmi.Attribute(n2, dmi.ATT_NORMAL, unique_id=1, parent_index=0),
+                                dmi.Attribute(u2, dmi.ATT_TEXCOORD, unique_id=2, parent_index=0)])
+        sess = oracle_from_product_mesh(mesh)
+        try:
+            want = sess.encode()
+        except orc.OracleError:
+            with pytest.raises(dmi.DracoMiError):
+                dmi.encode_mesh(mesh)
+            continue
+        _assert_same(dmi.encode_mesh(mesh), want, f"non-finite trial {trial}")
+
+
 def test_zero_normal_is_an_error_code():
     faces, pos, nrm, _ = synth.torus_grid(10)
     nrm = nrm.copy()
