@@ -10,7 +10,7 @@ from .binding import (  # noqa: F401
     ATT_POSITION, ATT_NORMAL, ATT_COLOR, ATT_TEXCOORD, ATT_CUSTOM, DOMAIN_POSITION, DOMAIN_CORNER,
     F32, U32, I32, FLAG_TIMINGS, POS_SCHEME_DELTA,
     Attribute, Mesh, MeshBuilder, Config, DracoMiError, Job, Connectivity,
-    encode, encode_mesh, encode_attributes, encode_attributes_batch, encode_connectivity, mesh_prepare, meshes_prepare, jobs_encode, jobs_encode_raw, EncodedBatch, device_count, library_path, load_library,
+    encode, encode_mesh, encode_attributes, encode_attributes_batch, encode_connectivity, mesh_prepare, meshes_prepare, jobs_encode, jobs_encode_raw, EncodedBatch, device_count, release_cached_memory, library_path, load_library,
     host_rans_stream, host_rabs_stream, decode_attributes, shard_meshes, meshes_prepare_devices, jobs_encode_devices,
 )
 from . import gltf, synth  # noqa: E402,F401

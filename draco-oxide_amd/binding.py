@@ -87,7 +87,7 @@ class _Conn(C.Structure):
 
 
 EXPORTS = ["dmi_encode_attributes", "dmi_encode_attributes_batch", "dmi_jobs_encode", "dmi_job_create", "dmi_job_encode", "dmi_job_timings", "dmi_job_destroy", "dmi_encode_mesh",
-           "dmi_mesh_prepare", "dmi_meshes_prepare", "dmi_shard_meshes", "dmi_meshes_prepare_devices", "dmi_jobs_encode_devices", "dmi_mesh_build", "dmi_built_mesh_free", "dmi_encode_connectivity", "dmi_conn_free", "dmi_host_rans_stream", "dmi_host_rabs_stream", "dmi_decode_attributes", "dmi_decoded_free", "dmi_free", "dmi_free_many", "dmi_strerror", "dmi_last_error", "dmi_device_count"]
+           "dmi_mesh_prepare", "dmi_meshes_prepare", "dmi_shard_meshes", "dmi_meshes_prepare_devices", "dmi_jobs_encode_devices", "dmi_mesh_build", "dmi_built_mesh_free", "dmi_encode_connectivity", "dmi_conn_free", "dmi_host_rans_stream", "dmi_host_rabs_stream", "dmi_decode_attributes", "dmi_decoded_free", "dmi_free", "dmi_free_many", "dmi_strerror", "dmi_last_error", "dmi_device_count", "dmi_release_cached_memory"]
 
 
 def library_path():
@@ -112,6 +112,7 @@ def load_library():
     L.dmi_strerror.argtypes = [C.c_int]
     L.dmi_last_error.restype = C.c_char_p
     L.dmi_device_count.restype = C.c_int
+    L.dmi_release_cached_memory.restype = None
     L.dmi_free.argtypes = [C.POINTER(_Buffer)]
     L.dmi_free_many.argtypes = [C.POINTER(_Buffer), C.c_uint32]
     L.dmi_free_many.restype = None
@@ -149,6 +150,11 @@ def _check(rc):
 
 def device_count():
     return int(load_library().dmi_device_count())
+
+
+def release_cached_memory():
+    """Hand back what the library keeps between calls (device chunks, pinned staging, recycled host arrays)."""
+    load_library().dmi_release_cached_memory()
 
 
 def _take(buf):

@@ -184,6 +184,9 @@ int dmi_decode_attributes(const uint8_t* section, size_t len, const dmi_corner_t
     uint32_t n = t.sequence_len;
     if (!seq) {
       if (!t.left_most_corner) return host_fail(DMI_ERR_INVALID_ARGUMENT, "left_most_corner needed to compute the sequence");
+      if (n_seeds && !seeds) return host_fail(DMI_ERR_INVALID_ARGUMENT, "null seeds");
+      for (uint32_t k = 0; k < n_seeds; ++k) if (seeds[k] >= C) return host_fail(DMI_ERR_INVALID_ARGUMENT, "seed corner out of range");
+      for (uint32_t v = 0; v < t.num_vertices; ++v) if (t.left_most_corner[v] >= C) return host_fail(DMI_ERR_INVALID_ARGUMENT, "left_most_corner entry out of range");
       TableRef tr{F, t.num_vertices, t.corner_to_vertex, t.opposite, t.left_most_corner};
       attribute_sequence(tr, seeds, n_seeds, seq_own);
       seq = seq_own.data(); n = (uint32_t)seq_own.size();
@@ -220,7 +223,7 @@ int dmi_decode_attributes(const uint8_t* section, size_t len, const dmi_corner_t
     } else read_transform_info();
     float q_min[4] = {0, 0, 0, 0}, q_range = 0;
     int q_bits = 0;
-    if (port[i] == 2) { for (int k = 0; k < a.num_components; ++k) q_min[k] = r.rf32(); q_range = r.rf32(); q_bits = r.r8(); }
+    if (port[i] == 2) { for (int k = 0; k < a.num_components; ++k) q_min[k] = r.rf32(); q_range = r.rf32(); q_bits = r.r8(); if (q_bits < 1 || q_bits > 31) meta_ok = false; }
     else if (port[i] == 3) { if (r.r8() != 8) meta_ok = false; }
     else if (port[i] != 1) return host_fail(DMI_ERR_UNSUPPORTED_DATA_TYPE, "unknown portabilization");
     if (!r.ok || !meta_ok) return host_fail(DMI_ERR_ENTROPY, "truncated or unexpected attribute metadata");

@@ -68,6 +68,14 @@ struct ChunkCache {
       if (items[k].device == device && items[k].cap == cap) { void* p = items[k].p; bytes -= cap; items.erase(items.begin() + (long)k); return p; }
     return nullptr;
   }
+  void drop_all() {
+    std::vector<Item> gone;
+    { std::lock_guard<std::mutex> lock(m); gone.swap(items); bytes = 0; }
+    int prev = 0;
+    const bool have_prev = hipGetDevice(&prev) == hipSuccess;
+    for (auto& it : gone) if (hipSetDevice(it.device) == hipSuccess) (void)hipFree(it.p);
+    if (have_prev) (void)hipSetDevice(prev);
+  }
   bool release(int device, void* p, size_t cap) {   // false: not kept (the caller frees it)
     std::lock_guard<std::mutex> lock(m);
     if (bytes + cap > kChunkCacheBytes) return false;
@@ -390,6 +398,19 @@ int dmi_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
+}
+
+// What the library keeps between calls so that the next one does not pay for it again: released device chunks (hipMalloc / hipFree
+// serialise), idle pinned staging buffers, and the large host arrays of the connectivity stage (dmi_host.hpp).  Live jobs are untouched.
+void dmi_release_cached_memory(void) {
+  host_pool_drop_all();
+  g_chunk_cache.drop_all();
+  std::lock_guard<std::mutex> lock(g_stage_mutex);
+  for (HostStage* st : g_stages) {
+    if (st->in_use || !st->p) continue;
+    (void)hipHostFree(st->p);
+    st->p = nullptr; st->cap = 0;
+  }
 }
 
 void dmi_free(dmi_buffer* b) {
@@ -2254,6 +2275,15 @@ struct ConnOwner {
   CornerTables ct;
   EdgebreakerResult eb;
   std::vector<std::vector<uint32_t>> seqs;
+  ConnOwner() = default;
+  ConnOwner(const ConnOwner&) = delete;
+  ConnOwner& operator=(const ConnOwner&) = delete;
+  ~ConnOwner() {   // the large arrays go back to the host pool (dmi_host.hpp)
+    pool_give(ct.c2p); pool_give(ct.c2v); pool_give(ct.opp); pool_give(ct.lmc);
+    for (auto& a : ct.att) { pool_give(a.c2v); pool_give(a.opp); pool_give(a.lmc); pool_give(a.seam_edge); }
+    pool_give(eb.seeds);
+    for (auto& q : seqs) pool_give(q);
+  }
   std::vector<dmi_corner_table> views;
 };
 
@@ -2295,7 +2325,8 @@ static int build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std::vector<ui
   o.views.resize(mesh->num_atts);
   o.seqs.resize(mesh->num_atts);
   auto universal_view = [&](dmi_corner_table& v) { v.num_vertices = o.ct.V; v.corner_to_vertex = o.ct.c2v.data(); v.opposite = o.ct.opp.data(); v.left_most_corner = o.ct.lmc.data(); };
-  std::vector<uint8_t> on_boundary;
+  Pooled<uint8_t> on_boundary_p;
+  std::vector<uint8_t>& on_boundary = on_boundary_p.v;
   auto sequence_universal = [&] {
     TableRef tr{o.ct.F, o.ct.V, o.ct.c2v.data(), o.ct.opp.data(), o.ct.lmc.data()};
     attribute_sequence(tr, o.eb.seeds.data(), (uint32_t)o.eb.seeds.size(), o.seqs[0], on_boundary.empty() ? nullptr : on_boundary.data());
@@ -2360,7 +2391,7 @@ static int build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std::vector<ui
     for (auto& x : th) x.join();
     for (uint32_t i = 0; i < mesh->num_atts; ++i) {
       dmi_corner_table& v = o.views[i];
-      if (v.corner_to_vertex == o.ct.c2v.data() && i > 0) o.seqs[i] = o.seqs[0];
+      if (v.corner_to_vertex == o.ct.c2v.data() && i > 0) { pool_fit(o.seqs[i], o.seqs[0].size()); o.seqs[i].assign(o.seqs[0].begin(), o.seqs[0].end()); }
       v.sequence = o.seqs[i].data();
       v.sequence_len = (uint32_t)o.seqs[i].size();
     }
@@ -2394,14 +2425,26 @@ void dmi_conn_free(dmi_conn* conn) {
 
 int dmi_mesh_prepare(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buffer* header_and_connectivity, dmi_job** job) {
   if (!header_and_connectivity || !job) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
-  ConnOwner o;
-  std::vector<uint8_t> bytes;
-  int rc = build_connectivity(mesh, o, bytes);
-  if (rc) return rc;
-  rc = dmi_job_create(mesh->atts, o.views.data(), mesh->num_atts, o.eb.seeds.data(), (uint32_t)o.eb.seeds.size(), cfg, job);
-  if (rc) return rc;
-  rc = to_buffer(bytes, header_and_connectivity);
-  if (rc) { dmi_job_destroy(*job); *job = nullptr; }
+  const bool trace = std::getenv("DMI_TRACE") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+  double t_conn = 0, t_create = 0, t_buf = 0;
+  int rc;
+  {
+    std::unique_ptr<ConnOwner> op(new ConnOwner());
+    ConnOwner& o = *op;
+    std::vector<uint8_t> bytes;
+    rc = build_connectivity(mesh, o, bytes);
+    if (rc) return rc;
+    t_conn = ms();
+    rc = dmi_job_create(mesh->atts, o.views.data(), mesh->num_atts, o.eb.seeds.data(), (uint32_t)o.eb.seeds.size(), cfg, job);
+    if (rc) return rc;
+    t_create = ms();
+    rc = to_buffer(bytes, header_and_connectivity);
+    if (rc) { dmi_job_destroy(*job); *job = nullptr; }
+    t_buf = ms();
+  }
+  if (trace && mesh->num_faces > 100000) std::fprintf(stderr, "[dmi] mesh_prepare: connectivity %.1f ms, job create %.1f, output buffer %.1f, release of the host tables %.1f\n", t_conn, t_create - t_conn, t_buf - t_create, ms() - t_buf);
   return rc;
 }
 
@@ -2530,16 +2573,27 @@ int dmi_encode_mesh(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buffer* out
   if (!out) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
   dmi_buffer head{}, att{};
   dmi_job* job = nullptr;
+  const bool trace = std::getenv("DMI_TRACE") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
   int rc = dmi_mesh_prepare(mesh, cfg, &head, &job);
   if (rc) return rc;
+  const double t_prep = ms();
   rc = dmi_job_encode(job, &att);
+  const double t_enc = ms();
   dmi_job_destroy(job);
+  const double t_destroy = ms();
   if (rc) { dmi_free(&head); return rc; }
-  std::vector<uint8_t> all(head.data, head.data + head.len);
-  all.insert(all.end(), att.data, att.data + att.len);
+  // header + connectivity + attribute section in one library-owned buffer
+  out->data = static_cast<uint8_t*>(std::malloc(head.len + att.len ? head.len + att.len : 1));
+  if (!out->data) { dmi_free(&head); dmi_free(&att); return fail(DMI_ERR_OUT_OF_MEMORY, "out of host memory"); }
+  std::memcpy(out->data, head.data, head.len);
+  std::memcpy(out->data + head.len, att.data, att.len);
+  out->len = out->cap = head.len + att.len;
   dmi_free(&head);
   dmi_free(&att);
-  return to_buffer(all, out);
+  if (trace) std::fprintf(stderr, "[dmi] encode_mesh: prepare %.1f ms, encode %.1f, job destroy %.1f, splice %.1f\n", t_prep, t_enc - t_prep, t_destroy - t_enc, ms() - t_destroy);
+  return DMI_OK;
 }
 
 }  // extern "C"

@@ -283,7 +283,10 @@ __device__ __forceinline__ void oct_quantize(float x, float y, float z, int32_t&
 // Each thread owns kTile entries of a tile (entry t of the tile at base + t·kBlock + threadIdx.x) and issues all of
 // their gathers before touching any of them: the pass is latency-bound otherwise (one 12-byte gather in flight per
 // lane is ≈3 TB/s by Little's law at HBM latency).
-constexpr int kTile = 4;
+#ifndef DMI_KTILE
+#define DMI_KTILE 2
+#endif
+constexpr int kTile = DMI_KTILE;
 template <int N> struct RawTile { float v[kTile][N]; };
 // issue: the kTile gathers of one attribute (value indices first when the attribute has its own point → value map)
 template <int N>

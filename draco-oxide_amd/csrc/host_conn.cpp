@@ -71,7 +71,8 @@ struct UniversalBuilder {
   // predicate (≥ 3 faces on an edge): such meshes, and meshes with degenerate faces, return false and take the serial path.
   bool match_half_edges_parallel() {
     const uint32_t nv = t.V;
-    std::vector<uint32_t> count(nv + 1, 0);
+    Pooled<uint32_t> count_p((size_t)nv + 1, 0u);
+    std::vector<uint32_t>& count = count_p.v;
     std::atomic<int> degenerate{0};
     parallel_for(t.F, [&](size_t lo, size_t hi) {
       for (size_t f = lo; f < hi; ++f) {
@@ -83,10 +84,11 @@ struct UniversalBuilder {
       }
     });
     if (degenerate.load()) return false;
-    std::vector<uint32_t> start(nv + 1, 0);
+    Pooled<uint32_t> start_p((size_t)nv + 1, 0u), cursor_p((size_t)nv), he_sink_p(C), he_corner_p(C);
+    std::vector<uint32_t>&start = start_p.v, &cursor = cursor_p.v, &he_sink = he_sink_p.v, &he_corner = he_corner_p.v;
     for (uint32_t v = 0; v < nv; ++v) start[v + 1] = start[v] + count[v];
-    std::vector<uint32_t> cursor(start.begin(), start.end() - 1);
-    std::vector<uint32_t> he_sink(C), he_corner(C);
+    cursor.assign(start.begin(), start.end() - 1);
+    he_sink.resize(C); he_corner.resize(C);
     parallel_for(C, [&](size_t lo, size_t hi) {
       for (size_t c = lo; c < hi; ++c) {
         const uint32_t src = t.c2v[corner_next((uint32_t)c)], snk = t.c2v[corner_prev((uint32_t)c)];
@@ -95,6 +97,7 @@ struct UniversalBuilder {
         he_corner[slot] = (uint32_t)c;
       }
     });
+    pool_fit(t.opp, C);
     t.opp.resize(C);
     std::atomic<int> crowded{0};
     parallel_for(C, [&](size_t lo, size_t hi) {
@@ -116,7 +119,8 @@ struct UniversalBuilder {
   // fans: false, and the serial walk (which splits such vertices) runs instead.
   bool left_most_corners_parallel() {
     const uint32_t nv = t.V;
-    std::vector<uint32_t> first(nv, kNone), count(nv, 0);
+    Pooled<uint32_t> first_p(nv, kNone), count_p(nv, 0u);
+    std::vector<uint32_t>&first = first_p.v, &count = count_p.v;
     parallel_for(C, [&](size_t lo, size_t hi) {
       for (size_t c = lo; c < hi; ++c) {
         const uint32_t v = t.c2v[c];
@@ -125,6 +129,7 @@ struct UniversalBuilder {
         while ((uint32_t)c < cur && !__atomic_compare_exchange_n(&first[v], &cur, (uint32_t)c, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
       }
     });
+    pool_fit(t.lmc, nv);
     t.lmc.assign(nv, kNone);
     std::atomic<int> several{0};
     parallel_for(nv, [&](size_t lo, size_t hi) {
@@ -240,7 +245,9 @@ struct UniversalBuilder {
 int CornerTables::build_universal(const uint32_t* faces, uint32_t num_faces, const uint32_t* pos_p2v, std::string& err) {
   F = num_faces;
   const uint32_t C = 3 * F;
+  pool_fit(c2p, C);
   c2p.assign(faces, faces + C);
+  pool_fit(c2v, C);
   c2v.resize(C);
   std::atomic<uint32_t> maxv_a{0};
   parallel_for(C, [&](size_t lo, size_t hi) {
@@ -251,7 +258,8 @@ int CornerTables::build_universal(const uint32_t* faces, uint32_t num_faces, con
   });
   V = C ? maxv_a.load() + 1 : 0;
   {   // core/corner_table/mod.rs:105-108: unused vertex ids are a panic in the reference
-    std::vector<uint8_t> used(V, 0);
+    Pooled<uint8_t> used_p(V, (uint8_t)0);
+    std::vector<uint8_t>& used = used_p.v;
     parallel_for(C, [&](size_t lo, size_t hi) { for (size_t c = lo; c < hi; ++c) used[c2v[c]] = 1; });   // (racing stores of the same value)
     std::atomic<int> unused{0};
     parallel_for(V, [&](size_t lo, size_t hi) { for (size_t v = lo; v < hi; ++v) if (!used[v]) { unused.store(1); break; } });
@@ -282,8 +290,10 @@ void CornerTables::build_attribute(const uint32_t* p2v) {
 // the per-vertex counts: exactly the ids the serial `nv++` walk hands out)
 void CornerTables::build_attribute_into(AttTable& a, const uint32_t* p2v) const {
   const uint32_t C = 3 * F;
+  pool_fit(a.seam_edge, C);
   a.seam_edge.assign(C, 0);
-  std::vector<uint8_t> vseam(V, 0);
+  Pooled<uint8_t> vseam_p(V, (uint8_t)0);
+  std::vector<uint8_t>& vseam = vseam_p.v;
   auto val = [&](uint32_t corner) { uint32_t p = c2p[corner]; return p2v ? p2v[p] : p; };
   parallel_for(C, [&](size_t lo, size_t hi) {
     for (size_t cc = lo; cc < hi; ++cc) {
@@ -304,8 +314,10 @@ void CornerTables::build_attribute_into(AttTable& a, const uint32_t* p2v) const 
       }
     }
   });
+  pool_fit(a.opp, C);
   a.opp.resize(C);
   parallel_for(C, [&](size_t lo, size_t hi) { for (size_t c = lo; c < hi; ++c) a.opp[c] = a.seam_edge[c] ? kNone : opp[c]; });
+  pool_fit(a.c2v, C);
   a.c2v.assign(C, 0);
   auto a_swing_left = [&](uint32_t c) { uint32_t o = a.opp[corner_next(c)]; return o == kNone ? kNone : corner_next(o); };
   auto u_swing_right = [&](uint32_t c) { uint32_t o = opp[corner_prev(c)]; return o == kNone ? kNone : corner_prev(o); };
@@ -315,7 +327,8 @@ void CornerTables::build_attribute_into(AttTable& a, const uint32_t* p2v) const 
     return first;
   };
   // attribute vertices per universal vertex: 1 + the seam edges its right swing crosses (:116-133)
-  std::vector<uint32_t> base((size_t)V + 1, 0);
+  Pooled<uint32_t> base_p((size_t)V + 1, 0u);
+  std::vector<uint32_t>& base = base_p.v;
   parallel_for(V, [&](size_t lo, size_t hi) {
     for (size_t v = lo; v < hi; ++v) {
       uint32_t k = 1;
@@ -325,6 +338,7 @@ void CornerTables::build_attribute_into(AttTable& a, const uint32_t* p2v) const 
   });
   for (uint32_t v = 0; v < V; ++v) base[v + 1] += base[v];
   const uint32_t nv = base[V];
+  pool_fit(a.lmc, nv);
   a.lmc.assign(nv, kNone);
   parallel_for(V, [&](size_t lo, size_t hi) {
     for (size_t v = lo; v < hi; ++v) {
@@ -361,10 +375,15 @@ struct Walker {
   bool bad = false;
 
   explicit Walker(const CornerTables& tt) : t(tt), C(tt.F * 3) {
-    vvis.assign(t.V, 0);
-    fvis.assign(t.F, 0);
-    split_symbol_of_face.assign(t.F, ~0ull);
+    pool_fit(vvis, t.V); vvis.assign(t.V, 0);
+    pool_fit(fvis, t.F); fvis.assign(t.F, 0);
+    pool_fit(split_symbol_of_face, t.F); split_symbol_of_face.assign(t.F, ~0ull);
+    pool_fit(processed, t.F);
+    pool_fit(symbols, t.F);
   }
+  ~Walker() { pool_give(vvis); pool_give(fvis); pool_give(hole_of); pool_give(processed); pool_give(split_symbol_of_face); pool_give(symbols); }
+  Walker(const Walker&) = delete;
+  Walker& operator=(const Walker&) = delete;
   uint32_t right_of(uint32_t c) const { return t.opp[corner_next(c)]; }
   uint32_t left_of(uint32_t c) const { return t.opp[corner_prev(c)]; }
   uint32_t swing_right(uint32_t c) const { uint32_t o = t.opp[corner_prev(c)]; return o == kNone ? kNone : corner_prev(o); }
@@ -372,6 +391,7 @@ struct Walker {
   // edgebreaker.rs:195-224 — the inner walk rotates inside one face (never crosses an edge), so
   // each boundary vertex ends up with its own id.
   void label_boundaries() {
+    pool_fit(hole_of, t.V);
     hole_of.assign(t.V, kNone);
     for (uint32_t c0 = 0; c0 < C; ++c0) {
       if (t.opp[c0] != kNone) continue;
@@ -470,6 +490,16 @@ struct Walker {
 };
 }  // namespace
 
+size_t host_pool_limit() {
+  static const size_t limit = [] {
+    const char* e = std::getenv("DMI_HOST_CACHE_MB");
+    return (size_t)(e ? std::max(0l, std::atol(e)) : 4096l) << 20;
+  }();
+  return limit;
+}
+std::atomic<size_t>& host_pool_bytes() { static std::atomic<size_t> b{0}; return b; }
+void host_pool_drop_all() { VecPool<uint8_t>::get().drop_all(); VecPool<uint32_t>::get().drop_all(); VecPool<uint64_t>::get().drop_all(); }
+
 bool append_tagged_state(uint32_t s, std::vector<uint8_t>& out) {   // rans.rs:48-68
   if (s < (1u << 6)) out.push_back((uint8_t)s);
   else if (s < (1u << 14)) { uint32_t v = (1u << 14) + s; out.push_back((uint8_t)v); out.push_back((uint8_t)(v >> 8)); }
@@ -515,6 +545,7 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
   }
   const double t_walk = since(t0);
   if (w.bad) { err = "edgebreaker: inconsistent connectivity (reference unwrap() panic)"; if (hooks && hooks->before_seams) hooks->before_seams(); return DMI_ERR_CONNECTIVITY; }
+  pool_fit(out.seeds, w.init_corners.size() + w.processed.size());
   out.seeds.assign(w.init_corners.rbegin(), w.init_corners.rend());   // edgebreaker.rs:523-529
   out.seeds.insert(out.seeds.end(), w.processed.begin(), w.processed.end());
   if (hooks && hooks->seeds_ready) hooks->seeds_ready();
@@ -531,7 +562,8 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
   {   // DefaultTraversal::encode :575-656 — CLERS bits, reversed, LSB-first
     static const uint8_t len[5] = {1, 3, 3, 3, 3};
     static const uint8_t code[5] = {0, 0b1, 0b11, 0b101, 0b111};
-    std::vector<uint8_t> bits;
+    Pooled<uint8_t> bits_p(w.symbols.size() / 2 + 8);
+    std::vector<uint8_t>& bits = bits_p.v;
     bits.reserve(w.symbols.size() / 2 + 8);
     BitPackerLsb bp(bits);
     for (size_t i = w.symbols.size(); i-- > 0;) bp.put(len[w.symbols[i]], code[w.symbols[i]]);
@@ -564,11 +596,13 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
       // (the reverse of the order of emission: faces first to last, corners prev, next, c) — and the streams of the attributes are
       // coded side by side on the multiply-high coder of host_chains.cpp (a divide per flag was 2/3 of this stage).
     const size_t n = w.processed.size(), A = t.att.size();
-    std::vector<uint32_t> where(t.F, kNone);           // position of a face in `processed`
+    Pooled<uint32_t> where_p(t.F, kNone);              // position of a face in `processed`
+    std::vector<uint32_t>& where = where_p.v;
     std::atomic<int> twice{0};
     parallel_for(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) where[w.processed[i] / 3] = (uint32_t)i; });
     parallel_for(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) if (where[w.processed[i] / 3] != (uint32_t)i) { twice.store(1); break; } });
     std::vector<std::vector<uint8_t>> fed(A);
+    struct GiveBack { std::vector<std::vector<uint8_t>>& v; ~GiveBack() { for (auto& x : v) pool_give(x); } } fed_back{fed};
     std::vector<uint64_t> zeros(A, 0);
     if (!twice.load() && A) {
       // corners of face i whose flag is emitted, as a mask over (c, next, prev)
@@ -586,7 +620,8 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
       };
       constexpr size_t kChunk = 1u << 16;
       const size_t n_chunks = (n + kChunk - 1) / kChunk;
-      std::vector<uint8_t> mask(n);
+      Pooled<uint8_t> mask_p(n, (uint8_t)0);
+      std::vector<uint8_t>& mask = mask_p.v;
       std::vector<uint64_t> chunk_sum(n_chunks + 1, 0);
       {
         std::vector<std::atomic<uint64_t>> acc(n_chunks);
@@ -603,7 +638,7 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
         for (size_t c = 0; c < n_chunks; ++c) chunk_sum[c + 1] = chunk_sum[c] + acc[c].load();
       }
       const uint64_t total = chunk_sum[n_chunks];
-      for (auto& v : fed) v.resize(total);
+      for (auto& v : fed) { pool_fit(v, total); v.resize(total); }
       std::vector<std::atomic<uint64_t>> zacc(A);
       for (auto& a : zacc) a.store(0);
       parallel_for(n, [&](size_t lo, size_t hi) {
@@ -663,6 +698,7 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
 // The reference also deletes every stack entry lying in the face it has just marked visited;
 // such entries are skipped on pop anyway, so the emitted order is unchanged without the deletion.
 void vertex_boundary_flags(const TableRef& t, std::vector<uint8_t>& on_boundary) {
+  pool_fit(on_boundary, t.V);
   on_boundary.assign(t.V, 0);
   parallel_for(t.V, [&](size_t lo, size_t hi) {
     for (size_t v = lo; v < hi; ++v) { const uint32_t l0 = t.lmc[v]; on_boundary[v] = (l0 != kNone && t.opp[corner_next(l0)] == kNone) ? 1 : 0; }
@@ -670,10 +706,12 @@ void vertex_boundary_flags(const TableRef& t, std::vector<uint8_t>& on_boundary)
 }
 
 void attribute_sequence(const TableRef& t, const uint32_t* seeds, uint32_t n_seeds, std::vector<uint32_t>& seq, const uint8_t* on_boundary) {
-  std::vector<uint8_t> vvis(t.V, 0), fvis(t.F, 0);
-  std::vector<uint32_t> stack(seeds, seeds + n_seeds);
-  seq.clear();
-  seq.reserve(t.V);
+  Pooled<uint8_t> vvis_p(t.V, (uint8_t)0), fvis_p(t.F, (uint8_t)0);
+  std::vector<uint8_t>&vvis = vvis_p.v, &fvis = fvis_p.v;
+  Pooled<uint32_t> stack_p(n_seeds);
+  std::vector<uint32_t>& stack = stack_p.v;
+  stack.assign(seeds, seeds + n_seeds);
+  pool_fit(seq, t.V);
   auto emit = [&](uint32_t c) { uint32_t v = t.c2v[c]; if (!vvis[v]) { vvis[v] = 1; seq.push_back(c); } };
   while (!stack.empty()) {
     const uint32_t c = stack.back();

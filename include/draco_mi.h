@@ -237,6 +237,9 @@ const char* dmi_strerror(int status);
 const char* dmi_last_error(void);
 /* Number of HIP devices visible (0 when there is no GPU); never initialises a context. */
 int dmi_device_count(void);
+/* The library keeps released device chunks, idle pinned staging buffers and the large host arrays of the connectivity stage for its next
+ * call (the host arrays up to DMI_HOST_CACHE_MB, default 4096; 0 = keep none).  This hands all of it back; live jobs are untouched. */
+void dmi_release_cached_memory(void);
 
 #ifdef __cplusplus
 }

@@ -249,3 +249,33 @@ def test_parallel_host_stages_equal_the_serial_walks_and_the_oracle(name, monkey
     except orc.OracleError:
         return   # (an input the reference cannot encode: the two forms agreeing is all there is to check)
     assert fast[0][11:] == bytes(sess.blob("conn.bytes"))
+
+
+def test_recycled_host_arrays_do_not_change_the_bytes():
+    """A large mesh takes its index arrays from the host pool (dmi_host.hpp): repeated calls, a release of everything the library
+    keeps in between, and a different mesh in between give the same connectivity bytes, tables and sequences."""
+    big = synth.torus_mesh(600)                       # 720k faces: above the pool's 4 MiB threshold
+    other = synth.torus_mesh(450, open_boundary=True)
+
+    def snapshot(mesh):
+        conn = dmi.encode_connectivity(mesh)
+        out = (bytes(conn.bytes), conn.seeds().copy(), [{k: (np.array(v).copy() if v is not None and not np.isscalar(v) else v) for k, v in conn.table(i).items()} for i in range(conn.num_tables)])
+        conn.close()
+        return out
+
+    def same(a, b):
+        assert a[0] == b[0] and (a[1] == b[1]).all() and len(a[2]) == len(b[2])
+        for ta, tb in zip(a[2], b[2]):
+            for k in ta:
+                if isinstance(ta[k], np.ndarray):
+                    assert (ta[k] == tb[k]).all(), k
+                else:
+                    assert ta[k] == tb[k], k
+
+    first = snapshot(big)
+    same(first, snapshot(big))                        # recycled arrays
+    second = snapshot(other)
+    same(first, snapshot(big))                        # arrays last used by a different mesh
+    dmi.release_cached_memory()
+    same(first, snapshot(big))
+    same(second, snapshot(other))
