@@ -165,9 +165,10 @@ inline uint32_t corner_next(uint32_t c) { return (c % 3 == 2) ? c - 2 : c + 1; }
 inline uint32_t corner_prev(uint32_t c) { return (c % 3 == 0) ? c + 2 : c - 1; }
 
 struct AttTable {
-  std::vector<uint32_t> c2v, opp, lmc;
+  std::vector<uint32_t> c2v, opp, lmc;   // empty when the attribute has no interior seam: its table IS the universal one (same ids, same order)
   std::vector<uint8_t> seam_edge;
   uint32_t num_vertices = 0;
+  bool interior_seams = false;           // some edge with two faces is a seam of this attribute
 };
 
 struct CornerTables {
@@ -179,7 +180,9 @@ struct CornerTables {
   int build_universal(const uint32_t* faces, uint32_t num_faces, const uint32_t* pos_p2v, std::string& err);
   // att_p2v: point→value index of the attribute (NULL = identity).
   void build_attribute(const uint32_t* att_p2v);
-  void build_attribute_into(AttTable& a, const uint32_t* att_p2v) const;   // thread-safe w.r.t. other attribute tables
+  // thread-safe w.r.t. other attribute tables.  same_as_position: att_p2v is the Position attribute's own map — no edge can be a seam
+  void build_attribute_into(AttTable& a, const uint32_t* att_p2v, bool same_as_position = false) const;
+  void copy_attribute_into(AttTable& a, const AttTable& from) const;   // an attribute with the map of an earlier one
 };
 
 struct EdgebreakerResult {

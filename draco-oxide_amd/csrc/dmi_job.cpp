@@ -2333,13 +2333,20 @@ static int build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std::vector<ui
   };
   auto build_att_tables = [&] {
     const auto a0 = tick();
+    // an attribute indexed like the Position attribute has no seams but the boundary; one indexed like an earlier attribute has that one's table
+    auto build_one = [&](size_t k) {
+      for (size_t j = 0; j < k; ++j) if (maps[j] == maps[k]) return;   // (copied below, once its original is complete)
+      o.ct.build_attribute_into(o.ct.att[k], maps[k], maps[k] == mesh->atts[0].point_to_value);
+    };
     if (maps.size() > 1 && overlap) {
       std::vector<std::thread> th;
-      for (size_t k = 0; k < maps.size(); ++k) th.emplace_back([&, k] { o.ct.build_attribute_into(o.ct.att[k], maps[k]); });
+      for (size_t k = 0; k < maps.size(); ++k) th.emplace_back(build_one, k);
       for (auto& x : th) x.join();
     } else {
-      for (size_t k = 0; k < maps.size(); ++k) o.ct.build_attribute_into(o.ct.att[k], maps[k]);
+      for (size_t k = 0; k < maps.size(); ++k) build_one(k);
     }
+    for (size_t k = 0; k < maps.size(); ++k)
+      for (size_t j = 0; j < k; ++j) if (maps[j] == maps[k]) { o.ct.copy_attribute_into(o.ct.att[k], o.ct.att[j]); break; }
     t_att = since(a0);
   };
   std::thread att_thread, seq_thread, flag_thread;
@@ -2376,8 +2383,7 @@ static int build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std::vector<ui
       v.num_faces = o.ct.F;
       v.corner_to_point = o.ct.c2p.data();
       const bool use_att = i > 0 && (i - 1) < o.ct.att.size();
-      bool seamless = true;
-      if (use_att) { const AttTable& t = o.ct.att[i - 1]; for (size_t c = 0; c < t.seam_edge.size(); ++c) if (t.seam_edge[c] && o.ct.opp[c] != kNone) { seamless = false; break; } }
+      const bool seamless = !use_att || !o.ct.att[i - 1].interior_seams;
       if (use_att && !seamless) {
         const AttTable& t = o.ct.att[i - 1];
         v.num_vertices = t.num_vertices; v.corner_to_vertex = t.c2v.data(); v.opposite = t.opp.data(); v.left_most_corner = t.lmc.data();

@@ -288,14 +288,31 @@ void CornerTables::build_attribute(const uint32_t* p2v) {
 // (reads the universal table only: attribute tables of one mesh can be built concurrently; the loops of a large mesh run on host
 // threads themselves — seam flags are idempotent byte stores, the attribute-vertex ids of a universal vertex are a prefix sum over
 // the per-vertex counts: exactly the ids the serial `nv++` walk hands out)
-void CornerTables::build_attribute_into(AttTable& a, const uint32_t* p2v) const {
+void CornerTables::copy_attribute_into(AttTable& a, const AttTable& from) const {
+  auto copy = [](auto& dst, const auto& src) { pool_fit(dst, src.size()); dst.assign(src.begin(), src.end()); };
+  copy(a.seam_edge, from.seam_edge); copy(a.c2v, from.c2v); copy(a.opp, from.opp); copy(a.lmc, from.lmc);
+  a.num_vertices = from.num_vertices;
+  a.interior_seams = from.interior_seams;
+}
+
+void CornerTables::build_attribute_into(AttTable& a, const uint32_t* p2v, bool same_as_position) const {
   const uint32_t C = 3 * F;
   pool_fit(a.seam_edge, C);
   a.seam_edge.assign(C, 0);
+  a.interior_seams = false;
+  pool_give(a.c2v); pool_give(a.opp); pool_give(a.lmc);
+  a.num_vertices = V;
+  if (same_as_position) {   // the universal vertices ARE this attribute's values: only the boundary edges are seams
+    parallel_for(C, [&](size_t lo, size_t hi) { for (size_t c = lo; c < hi; ++c) a.seam_edge[c] = opp[c] == kNone ? 1 : 0; });
+    return;
+  }
   Pooled<uint8_t> vseam_p(V, (uint8_t)0);
   std::vector<uint8_t>& vseam = vseam_p.v;
   auto val = [&](uint32_t corner) { uint32_t p = c2p[corner]; return p2v ? p2v[p] : p; };
+  std::atomic<int> interior{0};
   parallel_for(C, [&](size_t lo, size_t hi) {
+    bool any = false;
+    struct Note { std::atomic<int>& f; bool& any; ~Note() { if (any) f.store(1, std::memory_order_relaxed); } } note{interior, any};
     for (size_t cc = lo; cc < hi; ++cc) {
       const uint32_t c = (uint32_t)cc;
       const uint32_t o = opp[c];
@@ -311,9 +328,12 @@ void CornerTables::build_attribute_into(AttTable& a, const uint32_t* p2v) const 
         a.seam_edge[c] = a.seam_edge[o] = 1;
         vseam[c2v[corner_next(c)]] = vseam[c2v[corner_prev(c)]] = 1;
         vseam[c2v[corner_next(o)]] = vseam[c2v[corner_prev(o)]] = 1;
+        any = true;
       }
     }
   });
+  a.interior_seams = interior.load() != 0;
+  if (!a.interior_seams) return;   // (no table of its own: every consumer takes the universal one)
   pool_fit(a.opp, C);
   a.opp.resize(C);
   parallel_for(C, [&](size_t lo, size_t hi) { for (size_t c = lo; c < hi; ++c) a.opp[c] = a.seam_edge[c] ? kNone : opp[c]; });
@@ -596,15 +616,20 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
       // (the reverse of the order of emission: faces first to last, corners prev, next, c) — and the streams of the attributes are
       // coded side by side on the multiply-high coder of host_chains.cpp (a divide per flag was 2/3 of this stage).
     const size_t n = w.processed.size(), A = t.att.size();
-    Pooled<uint32_t> where_p(t.F, kNone);              // position of a face in `processed`
+    const bool sliced = n >= (1u << 20) && A;          // (a small mesh — one of a batch, on its own thread — walks the loop as it stands)
+    Pooled<uint32_t> where_p;                          // position of a face in `processed`
     std::vector<uint32_t>& where = where_p.v;
     std::atomic<int> twice{0};
-    parallel_for(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) where[w.processed[i] / 3] = (uint32_t)i; });
-    parallel_for(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) if (where[w.processed[i] / 3] != (uint32_t)i) { twice.store(1); break; } });
+    if (sliced) {
+      pool_fit(where, t.F);
+      where.assign(t.F, kNone);
+      parallel_for(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) where[w.processed[i] / 3] = (uint32_t)i; });
+      parallel_for(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) if (where[w.processed[i] / 3] != (uint32_t)i) { twice.store(1); break; } });
+    }
     std::vector<std::vector<uint8_t>> fed(A);
     struct GiveBack { std::vector<std::vector<uint8_t>>& v; ~GiveBack() { for (auto& x : v) pool_give(x); } } fed_back{fed};
     std::vector<uint64_t> zeros(A, 0);
-    if (!twice.load() && A) {
+    if (sliced && !twice.load()) {
       // corners of face i whose flag is emitted, as a mask over (c, next, prev)
       auto mask_of = [&](size_t i) -> uint32_t {
         const uint32_t c = w.processed[i];
@@ -657,7 +682,7 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
         for (size_t j = 0; j < A; ++j) zacc[j].fetch_add(z[j]);
       });
       for (size_t j = 0; j < A; ++j) zeros[j] = zacc[j].load();
-    } else if (A) {   // a face processed twice (malformed tables): the reference's loop as it stands
+    } else if (A) {   // small meshes, and a face processed twice (malformed tables): the reference's loop as it stands
       std::vector<uint8_t> fv(t.F, 0);
       std::vector<std::vector<uint8_t>> seams(A);
       for (size_t i = n; i-- > 0;) {
