@@ -169,6 +169,7 @@ struct AttTable {
   std::vector<uint8_t> seam_edge;
   uint32_t num_vertices = 0;
   bool interior_seams = false;           // some edge with two faces is a seam of this attribute
+  int alias_of = -1;                     // index (in CornerTables::att) of the earlier attribute this one was copied from
 };
 
 struct CornerTables {

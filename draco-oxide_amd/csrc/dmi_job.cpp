@@ -2346,7 +2346,7 @@ static int build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std::vector<ui
       for (size_t k = 0; k < maps.size(); ++k) build_one(k);
     }
     for (size_t k = 0; k < maps.size(); ++k)
-      for (size_t j = 0; j < k; ++j) if (maps[j] == maps[k]) { o.ct.copy_attribute_into(o.ct.att[k], o.ct.att[j]); break; }
+      for (size_t j = 0; j < k; ++j) if (maps[j] == maps[k]) { o.ct.copy_attribute_into(o.ct.att[k], o.ct.att[j]); o.ct.att[k].alias_of = (int)j; break; }
     t_att = since(a0);
   };
   std::thread att_thread, seq_thread, flag_thread;

@@ -69,43 +69,56 @@ struct UniversalBuilder {
   // the one corner c' that carries the reverse half-edge (sink → source) unless both have the same tip (Q22) — whichever of the two
   // comes first — so the table can be built from complete buckets in any order.  The edge count is has_non_manifold_edge()'s
   // predicate (≥ 3 faces on an edge): such meshes, and meshes with degenerate faces, return false and take the serial path.
+  // kThreads = false: the same passes on the calling thread with plain adds (a small mesh of a batch: no sort, no deletions, and the
+  // non-manifold-edge test for free — faster than the literal walk + has_non_manifold_edge()).
+  template <bool kThreads>
   bool match_half_edges_parallel() {
     const uint32_t nv = t.V;
+    auto bump = [](uint32_t* p) -> uint32_t { if (kThreads) return __atomic_fetch_add(p, 1u, __ATOMIC_RELAXED); return (*p)++; };
+    auto slices = [&](size_t n, auto&& fn) { if (kThreads) parallel_for(n, fn); else fn((size_t)0, n); };
+    // Half-edges are bucketed by the SMALLER endpoint of their undirected edge, tagged with their direction: one scan of one bucket then
+    // shows a corner both the half-edges that run its way and the ones that run against it.
+    if (nv >= (1u << 31)) return false;   // (the tag lives in bit 31)
     Pooled<uint32_t> count_p((size_t)nv + 1, 0u);
     std::vector<uint32_t>& count = count_p.v;
     std::atomic<int> degenerate{0};
-    parallel_for(t.F, [&](size_t lo, size_t hi) {
+    slices(t.F, [&](size_t lo, size_t hi) {
       for (size_t f = lo; f < hi; ++f) {
         const uint32_t a = t.c2v[3 * f], b = t.c2v[3 * f + 1], c = t.c2v[3 * f + 2];
         if (a == b || b == c || a == c) { degenerate.store(1, std::memory_order_relaxed); return; }
-        __atomic_fetch_add(&count[a], 1u, __ATOMIC_RELAXED);   // half-edges leaving a vertex = its corner count
-        __atomic_fetch_add(&count[b], 1u, __ATOMIC_RELAXED);
-        __atomic_fetch_add(&count[c], 1u, __ATOMIC_RELAXED);
+        bump(&count[std::min(a, b)]);
+        bump(&count[std::min(b, c)]);
+        bump(&count[std::min(c, a)]);
       }
     });
     if (degenerate.load()) return false;
-    Pooled<uint32_t> start_p((size_t)nv + 1, 0u), cursor_p((size_t)nv), he_sink_p(C), he_corner_p(C);
-    std::vector<uint32_t>&start = start_p.v, &cursor = cursor_p.v, &he_sink = he_sink_p.v, &he_corner = he_corner_p.v;
+    Pooled<uint32_t> start_p((size_t)nv + 1, 0u), cursor_p((size_t)nv), he_key_p(C), he_corner_p(C);
+    std::vector<uint32_t>&start = start_p.v, &cursor = cursor_p.v, &he_key = he_key_p.v, &he_corner = he_corner_p.v;
     for (uint32_t v = 0; v < nv; ++v) start[v + 1] = start[v] + count[v];
     cursor.assign(start.begin(), start.end() - 1);
-    he_sink.resize(C); he_corner.resize(C);
-    parallel_for(C, [&](size_t lo, size_t hi) {
+    he_key.resize(C); he_corner.resize(C);
+    slices(C, [&](size_t lo, size_t hi) {
       for (size_t c = lo; c < hi; ++c) {
         const uint32_t src = t.c2v[corner_next((uint32_t)c)], snk = t.c2v[corner_prev((uint32_t)c)];
-        const uint32_t slot = __atomic_fetch_add(&cursor[src], 1u, __ATOMIC_RELAXED);
-        he_sink[slot] = snk;
+        const uint32_t slot = bump(&cursor[std::min(src, snk)]);
+        he_key[slot] = src < snk ? snk : (src | 0x80000000u);   // the larger endpoint; bit 31: the half-edge runs from it down
         he_corner[slot] = (uint32_t)c;
       }
     });
     pool_fit(t.opp, C);
     t.opp.resize(C);
     std::atomic<int> crowded{0};
-    parallel_for(C, [&](size_t lo, size_t hi) {
+    slices(C, [&](size_t lo, size_t hi) {
       for (size_t c = lo; c < hi; ++c) {
         const uint32_t tip = t.c2v[c], src = t.c2v[corner_next((uint32_t)c)], snk = t.c2v[corner_prev((uint32_t)c)];
+        const uint32_t low = std::min(src, snk);
+        const uint32_t mine = src < snk ? snk : (src | 0x80000000u), against = mine ^ 0x80000000u;
         uint32_t same = 0, rev = 0, found = kNone;
-        for (uint32_t s2 = start[src]; s2 < start[src + 1]; ++s2) same += he_sink[s2] == snk;
-        for (uint32_t s2 = start[snk]; s2 < start[snk + 1]; ++s2) if (he_sink[s2] == src) { ++rev; found = he_corner[s2]; }
+        for (uint32_t s2 = start[low]; s2 < start[low + 1]; ++s2) {
+          const uint32_t k = he_key[s2];
+          same += k == mine;
+          if (k == against) { ++rev; found = he_corner[s2]; }
+        }
         if (same + rev > 2) { crowded.store(1, std::memory_order_relaxed); return; }
         t.opp[c] = (rev == 1 && same == 1 && t.c2v[found] != tip) ? found : kNone;
       }
@@ -245,6 +258,9 @@ struct UniversalBuilder {
 int CornerTables::build_universal(const uint32_t* faces, uint32_t num_faces, const uint32_t* pos_p2v, std::string& err) {
   F = num_faces;
   const uint32_t C = 3 * F;
+  static const bool trace = std::getenv("DMI_TRACE_TABLES") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
   pool_fit(c2p, C);
   c2p.assign(faces, faces + C);
   pool_fit(c2v, C);
@@ -265,16 +281,21 @@ int CornerTables::build_universal(const uint32_t* faces, uint32_t num_faces, con
     parallel_for(V, [&](size_t lo, size_t hi) { for (size_t v = lo; v < hi; ++v) if (!used[v]) { unused.store(1); break; } });
     if (unused.load()) { err = "mesh contains unused vertices"; return DMI_ERR_UNUSED_VERTICES; }
   }
+  const double t_ids = ms();
   UniversalBuilder b(*this);
   const bool serial_only = std::getenv("DMI_SERIAL_TABLES") != nullptr;   // (tests: the literal serial walks on every input)
   // (the order-independent builders do more work per corner — atomics, two bucket scans — and only win once their loops really run on
   //  several threads, which parallel_for does from 2^20 items; below that, and in a batch of meshes on a thread each, the serial walks)
   const bool big = (C >= (1u << 21) || std::getenv("DMI_PARALLEL_TABLES")) && !serial_only;
-  if (!(big && b.match_half_edges_parallel())) {
+  const bool matched = serial_only ? false : (big ? b.match_half_edges_parallel<true>() : b.match_half_edges_parallel<false>());
+  if (!matched) {
     b.match_half_edges();
     if (b.has_non_manifold_edge()) b.break_non_manifold_edges();
   }
+  const double t_match = ms();
   if (!(big && b.left_most_corners_parallel())) b.left_most_corners();
+  if (trace) std::fprintf(stderr, "[dmi]   universal table of %u faces: copy + vertex ids %.3f ms, half-edge matching %.3f (%s), left-most corners %.3f\n", F, t_ids, t_match - t_ids,
+                          matched ? "order-free" : "reference walk", ms() - t_match);
   att.clear();
   return DMI_OK;
 }
@@ -300,6 +321,7 @@ void CornerTables::build_attribute_into(AttTable& a, const uint32_t* p2v, bool s
   pool_fit(a.seam_edge, C);
   a.seam_edge.assign(C, 0);
   a.interior_seams = false;
+  a.alias_of = -1;
   pool_give(a.c2v); pool_give(a.opp); pool_give(a.lmc);
   a.num_vertices = V;
   if (same_as_position) {   // the universal vertices ARE this attribute's values: only the boundary edges are seams
@@ -616,6 +638,17 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
       // (the reverse of the order of emission: faces first to last, corners prev, next, c) — and the streams of the attributes are
       // coded side by side on the multiply-high coder of host_chains.cpp (a divide per flag was 2/3 of this stage).
     const size_t n = w.processed.size(), A = t.att.size();
+    // Which streams are distinct: an attribute without interior seams flags no emitted edge (they all have two faces) — ONE all-zero
+    // stream serves every such attribute; an attribute copied from an earlier one repeats that one's stream.
+    std::vector<int> stream_of(A, -1);   // attribute whose stream this one repeats (itself: its own flags), -1 = the all-zero stream
+    std::vector<size_t> own;
+    for (size_t j = 0; j < A; ++j) {
+      if (!t.att[j].interior_seams) continue;
+      const int a0 = t.att[j].alias_of;
+      if (a0 >= 0 && (size_t)a0 < j && stream_of[(size_t)a0] == a0) stream_of[j] = a0;
+      else { stream_of[j] = (int)j; own.push_back(j); }
+    }
+    uint64_t total = 0;                  // edges emitted (the length of every stream)
     const bool sliced = n >= (1u << 20) && A;          // (a small mesh — one of a batch, on its own thread — walks the loop as it stands)
     Pooled<uint32_t> where_p;                          // position of a face in `processed`
     std::vector<uint32_t>& where = where_p.v;
@@ -662,11 +695,11 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
         });
         for (size_t c = 0; c < n_chunks; ++c) chunk_sum[c + 1] = chunk_sum[c] + acc[c].load();
       }
-      const uint64_t total = chunk_sum[n_chunks];
-      for (auto& v : fed) { pool_fit(v, total); v.resize(total); }
+      total = chunk_sum[n_chunks];
+      for (size_t j : own) { pool_fit(fed[j], total); fed[j].resize(total); }
       std::vector<std::atomic<uint64_t>> zacc(A);
       for (auto& a : zacc) a.store(0);
-      parallel_for(n, [&](size_t lo, size_t hi) {
+      if (!own.empty()) parallel_for(n, [&](size_t lo, size_t hi) {
         uint64_t pos = chunk_sum[lo / kChunk];
         for (size_t j = (lo / kChunk) * kChunk; j < lo; ++j) pos += (uint64_t)__builtin_popcount(mask[j]);
         std::vector<uint64_t> z(A, 0);
@@ -675,7 +708,7 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
           const uint32_t cs[3] = {c, corner_next(c), corner_prev(c)};
           for (int k = 2; k >= 0; --k) {
             if (!(mask[i] >> k & 1u)) continue;
-            for (size_t j = 0; j < A; ++j) { const uint8_t f = t.att[j].seam_edge[cs[k]]; fed[j][pos] = f; z[j] += !f; }
+            for (size_t j : own) { const uint8_t f = t.att[j].seam_edge[cs[k]]; fed[j][pos] = f; z[j] += !f; }
             ++pos;
           }
         }
@@ -692,25 +725,36 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
         for (uint32_t cc : cs) {
           const uint32_t o = t.opp[cc];
           if (o == kNone || fv[o / 3]) continue;
-          for (size_t j = 0; j < A; ++j) seams[j].push_back(t.att[j].seam_edge[cc]);
+          ++total;
+          for (size_t j : own) seams[j].push_back(t.att[j].seam_edge[cc]);
         }
       }
-      for (size_t j = 0; j < A; ++j) { fed[j].assign(seams[j].rbegin(), seams[j].rend()); for (uint8_t b : fed[j]) zeros[j] += !b; }
+      for (size_t j : own) { fed[j].assign(seams[j].rbegin(), seams[j].rend()); for (uint8_t b : fed[j]) zeros[j] += !b; }
     }
+    Pooled<uint8_t> all_zero_p;
+    const bool need_zero = own.size() < A && std::find(stream_of.begin(), stream_of.end(), -1) != stream_of.end();
+    if (need_zero) { pool_fit(all_zero_p.v, total); all_zero_p.v.assign(total, 0); }
     // one coder per attribute, side by side for large meshes
-    std::vector<std::vector<uint8_t>> coded(A);
-    std::vector<uint8_t> ok(A, 1), zp(A, 0);
-    auto code_one = [&](size_t j) { zp[j] = zero_probability(zeros[j], (float)fed[j].size()); ok[j] = host_rabs_bytes(zp[j], fed[j].data(), fed[j].size(), coded[j]) ? 1 : 0; };
-    if (A > 1 && n >= (1u << 20) && host_threads() > 1) {
+    std::vector<std::vector<uint8_t>> coded(A + 1);   // [A] = the all-zero stream
+    std::vector<uint8_t> ok(A + 1, 1), zp(A + 1, 0);
+    auto code_one = [&](size_t j) {
+      const uint8_t* bits = j == A ? all_zero_p.v.data() : fed[j].data();
+      zp[j] = zero_probability(j == A ? total : zeros[j], (float)total);
+      ok[j] = host_rabs_bytes(zp[j], bits, total, coded[j]) ? 1 : 0;
+    };
+    std::vector<size_t> todo(own);
+    if (need_zero) todo.push_back(A);
+    if (todo.size() > 1 && n >= (1u << 20) && host_threads() > 1) {
       std::vector<std::thread> th;
-      for (size_t j = 0; j < A; ++j) th.emplace_back(code_one, j);
+      for (size_t j : todo) th.emplace_back(code_one, j);
       for (auto& x : th) x.join();
-    } else for (size_t j = 0; j < A; ++j) code_one(j);
+    } else for (size_t j : todo) code_one(j);
     for (size_t j = 0; j < A; ++j) {
-      if (!ok[j]) { err = "rABS state too large"; return DMI_ERR_ENTROPY; }
-      s.u8(zp[j]);
-      s.leb128(coded[j].size());
-      s.bytes(coded[j]);
+      const size_t from = stream_of[j] < 0 ? A : (size_t)stream_of[j];
+      if (!ok[from]) { err = "rABS state too large"; return DMI_ERR_ENTROPY; }
+      s.u8(zp[from]);
+      s.leb128(coded[from].size());
+      s.bytes(coded[from]);
     }
   }
   if (trace) std::fprintf(stderr, "[dmi]   Edgebreaker of %u faces: boundaries + traversal %.1f ms, seeds + CLERS bits %.1f, wait for the seam flags %.1f, seam streams %.1f\n", t.F, t_walk,
