@@ -67,6 +67,7 @@ struct FusedArgs {
   uint32_t packed;   // 1: qs_pos is QF_P64, qs_nrm QF_B16, qs_uv QF_H32; 0: all QF_I32
   const void* qs_pos; const int32_t* mm_pos; void* sym_pos;
   const void* qs_nrm; void* sym_nrm; uint8_t* flips; uint32_t* counters;
+  uint32_t* flip_partials;   // one word per block of the launch: its count of unflipped normals (summed into counters[0] by the histogram launch — a same-address atomic per block costs ≈ 11 ns each, serialised: 90 µs for 8192 blocks)
   const void* qs_uv; const int32_t* mm_uv; void* sym_uv; uint8_t* orient;
   const uint32_t* fan_hdr; const uint32_t* fan_apex; const uint32_t* fan;   // fan rows of the table (launch_build_fans)
   uint32_t sym16;    // bit 0 / 1 / 2: sym_pos / sym_nrm / sym_uv are uint16 arrays
@@ -99,11 +100,14 @@ uint32_t orient_summary_blocks(uint32_t n);
 
 // ---- histogram (a16) -------------------------------------------------------------------------------
 // histograms (pre-zeroed) of up to kMaxRangeAtts symbol streams in one launch; *overflow |= 1 when a symbol ≥ bins is met
-struct HistAtt { const void* sym; uint64_t n; uint32_t* hist; uint32_t* overflow; uint32_t bins; uint32_t first_block, blocks, sym16; };
+struct HistAtt { const void* sym; uint64_t n; uint32_t* hist; uint32_t* overflow; uint32_t bins; uint32_t first_block, blocks, sym16;
+                 const uint32_t* flip_partials; uint32_t* flip_count; uint32_t n_flip_partials, pad; };   // a normal attribute: its sweep's per-block counts → flip_count[0]
 // `orient` (optional, orient.orient != null): the orientation-flag summaries of one texture-coordinate attribute, computed by extra
 // blocks of the same launch (launch_orient_summary is the standalone form)
 struct HistArgs { HistAtt a[kMaxRangeAtts]; int count; uint32_t hist_blocks; OrientArgs orient; };
 void launch_histograms(HistArgs& args, hipStream_t s);
+constexpr uint32_t kSweepMaxBlocks = 16384;   // grid cap of the fused predictor sweep = entries of a flip_partials array
+uint32_t predict_fused_blocks(uint32_t n);    // grid of launch_predict_fused
 
 // ---- serial coders: two wavefronts per stream (a18, a19, a11, a13) ------------------------------------
 // Coding record of one symbol (see dmi_chains.hip), 20 bytes: x / f = mulhi(x, m) >> (b & 31); bit 8 of b flags f == 1, bit 9

@@ -173,6 +173,8 @@ struct AttJob {
   uint64_t n_sym = 0;
   uint64_t out_cap = 0, aux_cap = 0;
   DevMem aux_out, aux_rec, chunk_info, batch_flags, aux_flags;
+  DevMem flip_partials;   // normals: per-block counts of the sweep (kSweepMaxBlocks words)
+  uint32_t flip_blocks = 0;   // blocks of the sweep launched this encode
   DevMem aux_bits;   // host-core chains: the compacted orientation transition bits (1 byte each)
   DevMem freq, hdr, aux_entries;   // device form of the table stage: normalised-frequency scratch, serialised table, rABS record pair
   uint32_t hdr_cap = 0;
@@ -785,6 +787,7 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
       if (!a.aux_flags.pooled) HIP_TRY(hipMemsetAsync(a.aux_flags.p, 0, a.aux_flags.bytes, s));
       if ((rc = a.chunk_info.alloc((size_t)std::max(1u, orient_summary_blocks(n)) * 8 + 16))) return rc;
       if (a.scheme == kTexCoord && (rc = a.aux_bits.alloc((size_t)n + 16))) return rc;
+      if (a.scheme == kNormal && (rc = a.flip_partials.alloc((size_t)kSweepMaxBlocks * 4))) return rc;
     }
     if (a.scheme == kNormal && a.fused_into < 0 && n) {   // fan rows: this table's fans, ranks in the parent position table
       const TableDev& pt = job->tables[job->atts[a.parent].table];
@@ -951,6 +954,7 @@ static int encode_phase_a(dmi_job* job, bool plan_only = false) {   // device: r
       if (a.fused_nrm >= 0) {
         AttJob& q = job->atts[a.fused_nrm];
         fa.qs_nrm = q.qs.p; fa.sym_nrm = q.sym.p; fa.flips = q.aux.as<uint8_t>(); fa.counters = q.small.as<uint32_t>() + 2;
+        fa.flip_partials = q.flip_partials.as<uint32_t>(); q.flip_blocks = predict_fused_blocks(n);
         if (q.sym16) fa.sym16 |= 2u;
       }
       if (a.fused_uv >= 0) {
@@ -976,6 +980,7 @@ static int encode_phase_a(dmi_job* job, bool plan_only = false) {   // device: r
         fa.seq = t.seq.as<uint32_t>(); fa.c2r = job->tables[p.table].c2r.as<uint32_t>(); fa.opp = t.opp.as<uint32_t>(); fa.n = n;
         fa.qs_pos = p.qs.p; fa.packed = p.qfmt == QF_P64 ? 1u : 0u;   // (the parent's positions may be packed by its own fused sweep; this attribute's values are not)
         fa.qs_nrm = a.qs.p; fa.sym_nrm = a.sym.p; fa.flips = a.aux.as<uint8_t>(); fa.counters = counters;
+        fa.flip_partials = a.flip_partials.as<uint32_t>(); a.flip_blocks = predict_fused_blocks(n);
         fa.sym16 = a.sym16 ? 2u : 0u;
         fa.fan_hdr = a.fan_hdr.as<uint32_t>(); fa.fan_apex = a.fan_apex.as<uint32_t>(); fa.fan = a.fan.as<uint32_t>();
         launch_predict_fused(fa, s);
@@ -1008,6 +1013,7 @@ static int encode_phase_a(dmi_job* job, bool plan_only = false) {   // device: r
     }
     HistAtt& h = ha.a[ha.count++];
     h.sym = a.sym.p; h.sym16 = a.sym16 ? 1u : 0u; h.n = a.n_sym; h.hist = a.hist.as<uint32_t>(); h.bins = a.bins; h.overflow = a.small.as<uint32_t>() + 5;
+    if (a.scheme == kNormal && a.flip_partials.p && a.n_sym) { h.flip_partials = a.flip_partials.as<uint32_t>(); h.flip_count = a.small.as<uint32_t>() + 2; h.n_flip_partials = a.flip_blocks; }
     if (ha.count == kMaxRangeAtts) { launch_histograms(ha, s); ha.count = 0; }
     pin_off[i] = a.slab_off;
   }

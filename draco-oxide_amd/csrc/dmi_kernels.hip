@@ -959,18 +959,45 @@ __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const u
     if (own_packed) { const uint32_t v = static_cast<const uint32_t*>(a.qs_uv)[r]; out[0] = (int32_t)(v & 0xFFFFu); out[1] = (int32_t)(v >> 16); }
     else { const int32_t* q = static_cast<const int32_t*>(a.qs_uv) + (size_t)r * 2; out[0] = q[0]; out[1] = q[1]; }
   };
-  DMI_FOR_SEQUENCE(i, n) {
+  // The sweep of one entry is two dependent memory round trips (its fan row, then the positions the row names) and then arithmetic.  With
+  // DMI_SWEEP_PREFETCH the first round trip of a block's NEXT chunk is issued before the current chunk's arithmetic (12 registers).
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#ifdef DMI_SWEEP_PREFETCH
+  constexpr bool kPrefetch = PACKED && HAS_POS;
+#else
+  constexpr bool kPrefetch = false;
+#endif
+  struct Level1 { uint32_t h, ro; u32x4 r0, r1; uint64_t pc; };
+  auto fetch_level1 = [&](uint32_t i, Level1& o) {
+    o.h = __builtin_nontemporal_load(&a.fan_hdr[i]);
+    o.ro = __builtin_nontemporal_load(&a.fan_apex[i]);
+    const u32x4* row4 = reinterpret_cast<const u32x4*>(a.fan + (size_t)i * kFanSlots);
+    o.r0 = __builtin_nontemporal_load(&row4[0]); o.r1 = __builtin_nontemporal_load(&row4[1]);
+    o.pc = static_cast<const uint64_t*>(qs_pos)[i];
+  };
+  const uint32_t nch_ = (n + kBlock - 1) / kBlock, per_ = (nch_ + 7u) / 8u, xcd_ = blk_ & 7u, end_ = min(nch_, (xcd_ + 1u) * per_), stride_ = nblk_ >> 3;
+  uint32_t ch_ = xcd_ * per_ + (blk_ >> 3);   // (DMI_FOR_SEQUENCE's chunk walk, spelled out)
+  Level1 cur{}, nxt{};
+  if (kPrefetch && ch_ < end_ && ch_ * kBlock + threadIdx.x < n) fetch_level1(ch_ * kBlock + threadIdx.x, cur);
+  for (; ch_ < end_; ch_ += stride_) {
+    const uint32_t i = ch_ * kBlock + threadIdx.x;
+    if (kPrefetch) { const uint32_t i2 = (ch_ + stride_) * kBlock + threadIdx.x; if (ch_ + stride_ < end_ && i2 < n) fetch_level1(i2, nxt); }
+    if (i < n) {
     uint32_t rn, rp, ro;
     int32_t Pc[3], Pn[3] = {0, 0, 0}, Pp[3] = {0, 0, 0}, Po[3] = {0, 0, 0}, Plast[3] = {0, 0, 0};
     int64_t sum[3] = {0, 0, 0};
-    const uint32_t h = __builtin_nontemporal_load(&a.fan_hdr[i]);
-    ro = __builtin_nontemporal_load(&a.fan_apex[i]);   // HAS_POS: rank across the edge opposite c; else: rank of the centre
-    load_pos_fmt(qs_pos, pos_fmt, HAS_POS ? i : ro, Pc);
+    uint32_t h;
+    if (kPrefetch) { h = cur.h; ro = cur.ro; unpack_p64(cur.pc, Pc); }
+    else {
+      h = __builtin_nontemporal_load(&a.fan_hdr[i]);
+      ro = __builtin_nontemporal_load(&a.fan_apex[i]);   // HAS_POS: rank across the edge opposite c; else: rank of the centre
+      load_pos_fmt(qs_pos, pos_fmt, HAS_POS ? i : ro, Pc);
+    }
     if (!(h & (1u << 17))) {
       // ---- fan row: every rank of the 1-ring in one 32-byte read, every position gather independent ----
-      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-      const u32x4* row4 = reinterpret_cast<const u32x4*>(a.fan + (size_t)i * kFanSlots);
-      const u32x4 r0 = __builtin_nontemporal_load(&row4[0]), r1 = __builtin_nontemporal_load(&row4[1]);
+      u32x4 r0, r1;
+      if (kPrefetch) { r0 = cur.r0; r1 = cur.r1; }
+      else { const u32x4* row4 = reinterpret_cast<const u32x4*>(a.fan + (size_t)i * kFanSlots); r0 = __builtin_nontemporal_load(&row4[0]); r1 = __builtin_nontemporal_load(&row4[1]); }
       const uint32_t row[kFanSlots] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
       rn = row[0]; rp = row[1];
       const uint32_t faces_r = h & 255u, faces_l = (h >> 8) & 255u;
@@ -1094,6 +1121,8 @@ __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const u
       if (s16_nrm) __builtin_nontemporal_store(s0 | (s1 << 16), static_cast<uint32_t*>(a.sym_nrm) + i);
       else { store_sym(a.sym_nrm, false, (size_t)i * 2, s0); store_sym(a.sym_nrm, false, (size_t)i * 2 + 1, s1); }
     }
+    }
+    if (kPrefetch) cur = nxt;
   }
   if (HAS_NRM) {
 #pragma unroll
@@ -1101,11 +1130,12 @@ __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const u
     __shared__ uint32_t wave_false[kBlock / 64];
     if ((threadIdx.x & 63) == 0) wave_false[threadIdx.x >> 6] = n_false;
     __syncthreads();
-    if (threadIdx.x == 0) {   // one atomic per block (same-address atomics serialise)
+    if (threadIdx.x == 0) {
       uint32_t t = 0;
 #pragma unroll
       for (int w = 0; w < kBlock / 64; ++w) t += wave_false[w];
-      if (t) atomicAdd(&a.counters[0], t);
+            if (a.flip_partials) a.flip_partials[blk_] = t;   // (summed by the histogram launch: no same-address atomic per block)
+      else if (t) atomicAdd(&a.counters[0], t);
     }
   }
 }
@@ -1317,7 +1347,8 @@ __device__ __forceinline__ void k_predict_window_body(const FusedArgs& a, const 
       uint32_t t = 0;
 #pragma unroll
       for (int w = 0; w < kBlock / 64; ++w) t += wave_false[w];
-      if (t) atomicAdd(&a.counters[0], t);
+      if (a.flip_partials) a.flip_partials[blk_] = t;
+      else if (t) atomicAdd(&a.counters[0], t);
     }
   }
 }
@@ -1383,6 +1414,16 @@ __device__ __forceinline__ void k_histogram_body(const HistArgs& args, const uin
   while (ai + 1 < args.count && blk_ >= args.a[ai + 1].first_block) ++ai;
   const HistAtt a = args.a[ai];
   const uint32_t block = blk_ - a.first_block;
+  if (block == 0 && a.flip_partials) {   // the unflipped-normal count of the attribute's sweep: its per-block counts, summed once
+    uint32_t t = 0;
+    for (uint32_t b = threadIdx.x; b < a.n_flip_partials; b += kBlock) t += a.flip_partials[b];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    __shared__ uint32_t wave_sum[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t sum = 0; for (int w = 0; w < kBlock / 64; ++w) sum += wave_sum[w]; a.flip_count[0] = sum; }
+  }
   // the first kLdsBins bins are privatised in LDS; larger alphabets (≥ 14-bit wrapped differences) send their high — rare: the
   // residuals concentrate near zero — symbols straight to the global histogram.  (All-global atomics on a peaked distribution
   // serialise on a few addresses: 320 ms instead of 0.7 for the 150M position symbols of a 100M-triangle mesh.)
@@ -1636,10 +1677,13 @@ void launch_build_fans(const uint32_t* seq, uint32_t n, const uint32_t* c2r, con
   if (n) hipLaunchKernelGGL(k_build_fans, grid_for(n, 8192), kBlock, 0, s, seq, n, c2r, opp, hdr, apex, fan, centre_in_apex ? 1 : 0);
 }
 
+uint32_t predict_fused_blocks(uint32_t n) {
+  static const uint32_t env_cap = std::getenv("DMI_FUSED_GRID") ? (uint32_t)std::atoi(std::getenv("DMI_FUSED_GRID")) : 0u;   // tuning aid
+  return grid_for(n, env_cap ? std::min(env_cap, kSweepMaxBlocks) : 8192u);   // 2-3 chunks per block: measured best on the 10M workload
+}
 void launch_predict_fused(const FusedArgs& a, hipStream_t s) {
   if (a.n == 0) return;
-  static const uint32_t env_cap = std::getenv("DMI_FUSED_GRID") ? (uint32_t)std::atoi(std::getenv("DMI_FUSED_GRID")) : 0u;   // tuning aid
-  const uint32_t g = grid_for(a.n, env_cap ? env_cap : 8192u);   // 2-3 chunks per block: measured best on the 10M workload (2048: +5 %)
+  const uint32_t g = predict_fused_blocks(a.n);
   int id = !a.sym_pos ? K_FUSED_N /* a normal attribute on its own table */ : ((a.qs_nrm && a.qs_uv) ? K_FUSED_PNU : (a.qs_nrm ? K_FUSED_PN : K_FUSED_PU));
   if (a.packed) id += K_PACKED_PNU - K_FUSED_PNU;
   static const bool windows = std::getenv("DMI_FUSED_WINDOWS") != nullptr;   // LDS-staged neighbourhoods (see k_predict_window_body)
