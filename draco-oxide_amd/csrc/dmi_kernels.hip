@@ -493,22 +493,27 @@ __device__ __forceinline__ void k_pred_delta_difference_body(const DeltaArgs& da
 __device__ __forceinline__ int32_t isgn(int32_t v) { return v > 0 ? 1 : (v < 0 ? -1 : 0); }
 __device__ __forceinline__ int32_t iabs(int32_t v) { return v < 0 ? (int32_t)(0u - (uint32_t)v) : v; }
 __device__ __forceinline__ void oct_orthogonal(int32_t o0, int32_t o1, int32_t p0, int32_t p1, uint32_t& s0, uint32_t& s1) {
+  // (every value here is an octahedral coordinate or a difference of two: |v| ≤ 2^9, so the wrapping i32 products of the reference are
+  //  exact on the full-rate 24-bit multiplier, and a product with a sign is a select)
   const int32_t one = 127;
   p0 = wsub(p0, one); p1 = wsub(p1, one); o0 = wsub(o0, one); o1 = wsub(o1, one);
   if (wadd(iabs(p0), iabs(p1)) > one) {
-    const int32_t pa = p0, qs = -isgn(wmul(p0, p1));
-    p0 = wadd(wmul(qs, p1), wmul(isgn(pa), one));
-    p1 = wadd(wmul(qs, pa), wmul(isgn(p1), one));
-    const int32_t oa = o0, qo = -isgn(wmul(o0, o1));
-    o0 = wadd(wmul(qo, o1), wmul(isgn(oa), one));
-    o1 = wadd(wmul(qo, oa), wmul(isgn(o1), one));
+    const int32_t pa = p0, qs = -isgn(__mul24(p0, p1));
+    p0 = wadd(__mul24(qs, p1), __mul24(isgn(pa), one));
+    p1 = wadd(__mul24(qs, pa), __mul24(isgn(p1), one));
+    const int32_t oa = o0, qo = -isgn(__mul24(o0, o1));
+    o0 = wadd(__mul24(qo, o1), __mul24(isgn(oa), one));
+    o1 = wadd(__mul24(qo, oa), __mul24(isgn(o1), one));
   }
-  if (!(p0 == 0 && p1 == 0)) {
-    // at most three quarter turns bring pred into {p0 < 0, p1 <= 0}
-    for (int t = 0; t < 4 && (p0 >= 0 || p1 > 0); ++t) {
-      int32_t tmp = p0; p0 = (int32_t)(0u - (uint32_t)p1); p1 = tmp;
-      tmp = o0; o0 = (int32_t)(0u - (uint32_t)o1); o1 = tmp;
-    }
+  // The reference turns both points by quarter turns (x, y) → (−y, x) until the prediction lies in {p0 < 0, p1 <= 0}: the number of
+  // turns only depends on the prediction's quadrant — none there, one for {p0 <= 0, p1 > 0}, two for {p0 > 0, p1 >= 0}, three for
+  // {p0 >= 0, p1 < 0} (the four sets tile the plane without the origin, which is not turned at all).
+  const int turns = (p0 == 0 && p1 == 0) ? 0 : ((p0 < 0 && p1 <= 0) ? 0 : ((p0 <= 0 && p1 > 0) ? 1 : ((p0 > 0 && p1 >= 0) ? 2 : 3)));
+  const bool swap = (turns & 1) != 0, neg0 = turns == 1 || turns == 2, neg1 = turns == 2 || turns == 3;
+  {
+    const int32_t a0 = swap ? p1 : p0, a1 = swap ? p0 : p1, b0 = swap ? o1 : o0, b1 = swap ? o0 : o1;
+    p0 = neg0 ? (int32_t)(0u - (uint32_t)a0) : a0; p1 = neg1 ? (int32_t)(0u - (uint32_t)a1) : a1;
+    o0 = neg0 ? (int32_t)(0u - (uint32_t)b0) : b0; o1 = neg1 ? (int32_t)(0u - (uint32_t)b1) : b1;
   }
   int32_t c0 = wsub(o0, p0), c1 = wsub(o1, p1);
   if (c0 < 0) c0 = wadd(c0, 255);
@@ -1106,9 +1111,9 @@ __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const u
       int32_t a0, a1;
       if (own_packed) { const uint32_t v = static_cast<const uint16_t*>(a.qs_nrm)[i]; a0 = (int32_t)(v & 0xFFu); a1 = (int32_t)(v >> 8); }
       else { const int32_t* q = static_cast<const int32_t*>(a.qs_nrm) + (size_t)i * 2; a0 = q[0]; a1 = q[1]; }
-      const int32_t m0 = wmul(p0, -1), m1 = wmul(p1, -1);
+      const int32_t m0 = (int32_t)(0u - (uint32_t)p0), m1 = (int32_t)(0u - (uint32_t)p1);
       const int32_t d10 = wsub(p0, a0), d11 = wsub(p1, a1), d20 = wsub(m0, a0), d21 = wsub(m1, a1);
-      const int32_t dot1 = wadd(wmul(d10, d10), wmul(d11, d11)), dot2 = wadd(wmul(d20, d20), wmul(d21, d21));
+      const int32_t dot1 = wadd(__mul24(d10, d10), __mul24(d11, d11)), dot2 = wadd(__mul24(d20, d20), __mul24(d21, d21));   // (|d| ≤ 510: exact)
       const bool flip = dot1 > dot2;   // Q8: flip negates the octahedral coordinates
       if (flip) { p0 = m0; p1 = m1; } else ++n_false;
       __builtin_nontemporal_store((uint8_t)(flip ? 1 : 0), &a.flips[i]);
@@ -1324,9 +1329,9 @@ __device__ __forceinline__ void k_predict_window_body(const FusedArgs& a, const 
         if (!(n0 == 0 && n1 == 0 && n2 == 0)) oct_quantize((float)n0, (float)n1, (float)n2, p0, p1);
         const uint32_t v = static_cast<const uint16_t*>(a.qs_nrm)[i];
         const int32_t a0 = (int32_t)(v & 0xFFu), a1 = (int32_t)(v >> 8);
-        const int32_t m0 = wmul(p0, -1), m1 = wmul(p1, -1);
+        const int32_t m0 = (int32_t)(0u - (uint32_t)p0), m1 = (int32_t)(0u - (uint32_t)p1);
         const int32_t d10 = wsub(p0, a0), d11 = wsub(p1, a1), d20 = wsub(m0, a0), d21 = wsub(m1, a1);
-        const int32_t dot1 = wadd(wmul(d10, d10), wmul(d11, d11)), dot2 = wadd(wmul(d20, d20), wmul(d21, d21));
+        const int32_t dot1 = wadd(__mul24(d10, d10), __mul24(d11, d11)), dot2 = wadd(__mul24(d20, d20), __mul24(d21, d21));   // (|d| ≤ 510: exact)
         const bool flip = dot1 > dot2;
         if (flip) { p0 = m0; p1 = m1; } else ++n_false;
         __builtin_nontemporal_store((uint8_t)(flip ? 1 : 0), &a.flips[i]);
