@@ -167,9 +167,12 @@ int dmi_decode_attributes(const uint8_t* section, size_t len, const dmi_corner_t
     }
   }
   // the corner tables on the device (shared by the kernels of every attribute)
-  DevBuf d_c2p;
+  DevBuf d_c2p, d_last;
   int rc = d_c2p.upload(tables[0].corner_to_point, C * 4, s);
   if (rc) return rc;
+  if ((rc = d_last.alloc((size_t)num_points * 4))) return rc;
+  HIP_TRY_D(hipMemsetAsync(d_last.p, 0, (size_t)num_points * 4, s));
+  launch_last_corners(d_c2p.as<uint32_t>(), C, d_last.as<uint32_t>(), s);
   std::vector<int32_t> pos_by_vertex;   // decoded positions by UNIVERSAL vertex (the parent of normals and texture coordinates)
   int pos_att = -1;
   DevBuf d_pos, d_c2v_pos;
@@ -337,7 +340,7 @@ int dmi_decode_attributes(const uint8_t* section, size_t len, const dmi_corner_t
     if ((rc = d_out.alloc(owner->values[i].size() * 4))) return rc;
     HIP_TRY_D(hipMemsetAsync(d_out.p, 0, owner->values[i].size() * 4, s));
     DequantizeArgs qa{};
-    qa.c2p = d_c2p.as<uint32_t>(); qa.c2v = d_c2v.as<uint32_t>(); qa.corners = C; qa.q = d_val.as<int32_t>(); qa.out = d_out.as<float>();
+    qa.c2p = d_c2p.as<uint32_t>(); qa.c2v = d_c2v.as<uint32_t>(); qa.corners = C; qa.q = d_val.as<int32_t>(); qa.out = d_out.as<float>(); qa.last_corner = d_last.as<uint32_t>();
     for (int k = 0; k < 4; ++k) qa.mn[k] = q_min[k];
     qa.delta = port[i] == 2 ? q_range / (float)(uint64_t)((1ull << q_bits) - 1ull) : 0.0f;
     qa.kind = port[i]; qa.N = a.num_components;

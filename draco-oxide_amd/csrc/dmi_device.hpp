@@ -208,8 +208,11 @@ struct DecodeNormalArgs { const uint32_t* seq; uint32_t n; uint32_t pad; const u
                           const uint32_t* c2v_att; const int32_t* pos_by_vertex /* 3 per universal vertex */; const uint32_t* sym; const uint8_t* flips; int32_t* oct_by_vertex; };
 void launch_decode_normals(const DecodeNormalArgs& a, hipStream_t s);
 // values[point_idx(c)] = dequantize(q[vertex(c)]) for every corner; kind: 1 ToBits, 2 coordinate-wise (mn, delta), 3 octahedral
-struct DequantizeArgs { const uint32_t* c2p; const uint32_t* c2v; uint64_t corners; const int32_t* q; float* out; float mn[4]; float delta; int kind; int N; int pad; };
+// last_corner[p] = 1 + the largest corner that references point p (launch_last_corners): a point met by several vertices of the attribute's
+// table (a non-manifold vertex split in two) takes the value of its last corner — the result of a serial loop over the corners
+struct DequantizeArgs { const uint32_t* c2p; const uint32_t* c2v; uint64_t corners; const int32_t* q; float* out; const uint32_t* last_corner; float mn[4]; float delta; int kind; int N; int pad; };
 void launch_dequantize(const DequantizeArgs& a, hipStream_t s);
+void launch_last_corners(const uint32_t* c2p, uint64_t corners, uint32_t* last_corner /* zeroed, one word per point */, hipStream_t s);
 
 // ---- coding-order relabelling of the connectivity inputs on the device (dmi_relabel.hip; job creation of large meshes) ----
 void launch_fill_u32(uint32_t* p, uint64_t n, uint32_t v, hipStream_t s);

@@ -1516,9 +1516,13 @@ __global__ __launch_bounds__(kBlock) void k_decode_normals(DecodeNormalArgs a) {
     dst[0] = o0; dst[1] = o1;
   }
 }
+__global__ __launch_bounds__(kBlock) void k_last_corners(const uint32_t* __restrict__ c2p, uint64_t corners, uint32_t* __restrict__ last) {
+  for (uint64_t c = (uint64_t)blockIdx.x * kBlock + threadIdx.x; c < corners; c += (uint64_t)gridDim.x * kBlock) atomicMax(&last[c2p[c]], (uint32_t)c + 1u);
+}
 __global__ __launch_bounds__(kBlock) void k_dequantize(DequantizeArgs a) {
   for (uint64_t c = (uint64_t)blockIdx.x * kBlock + threadIdx.x; c < a.corners; c += (uint64_t)gridDim.x * kBlock) {
     const uint32_t p = a.c2p[c], v = a.c2v[c];
+    if (a.last_corner && a.last_corner[p] != (uint32_t)c + 1u) continue;   // (one writer per point: its last corner)
     if (a.kind == 2) {          // coordinate-wise
       for (int k = 0; k < a.N; ++k) a.out[(size_t)p * a.N + k] = a.mn[k] + (float)a.q[(size_t)v * a.N + k] * a.delta;
     } else if (a.kind == 3) {   // octahedral, 8 bits
@@ -1698,6 +1702,7 @@ void launch_predict_fused(const FusedArgs& a, hipStream_t s) {
 }
 
 void launch_decode_normals(const DecodeNormalArgs& a, hipStream_t s) { if (a.n) hipLaunchKernelGGL(k_decode_normals, grid_for(a.n, 8192), kBlock, 0, s, a); }
+void launch_last_corners(const uint32_t* c2p, uint64_t corners, uint32_t* last_corner, hipStream_t s) { if (corners) hipLaunchKernelGGL(k_last_corners, grid_for(corners, 8192), kBlock, 0, s, c2p, corners, last_corner); }
 void launch_dequantize(const DequantizeArgs& a, hipStream_t s) { if (a.corners) hipLaunchKernelGGL(k_dequantize, grid_for(a.corners, 8192), kBlock, 0, s, a); }
 
 uint32_t orient_summary_blocks(uint32_t n) { return (n + kOrientChunk - 1) / kOrientChunk; }

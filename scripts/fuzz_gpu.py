@@ -7,13 +7,13 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import draco_oxide_amd as dmi
 import orc
-from helpers import oracle_from_product_mesh
+from helpers import oracle_from_product_mesh, oracle_values_by_point
 import test_gpu_parity as T
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 rng = np.random.default_rng(seed0)
-bad = rejected = 0
+bad = rejected = decoded = 0
 for c in range(n_cases):
     seed = seed0 + c
     kind = c % 3
@@ -47,5 +47,25 @@ for c in range(n_cases):
     for name, g in got.items():
         if g != want:
             print(f"case {c} (seed {seed}, kind {kind}, {pb}/{ub} bits, {len(mesh.faces)} faces): {name} differs ({len(g)} vs {len(want)} bytes)"); bad += 1
-print(f"{n_cases} cases, {rejected} rejected by the reference algorithm, {bad} mismatches")
+    # the product's decoder against the oracle's, value for value (by point)
+    try:
+        section = outs[1]
+        conn = dmi.encode_connectivity(mesh)
+        tables = [conn.table(i) for i in range(conn.num_tables)]
+        dec = dmi.decode_attributes(section, tables, mesh.attributes[0].num_points, seeds=conn.seeds())
+        conn.close()
+        ref, used = sess.decode_attributes(section)
+        assert used == len(section) and len(ref) == len(dec)
+        for i, (g, d) in enumerate(zip(dec, ref)):
+            per_point, seen = oracle_values_by_point(tables[i], tables[0], d, len(g["values"]))
+            if g["portabilization"] == 3:
+                ok = np.abs(g["values"][seen] - per_point[seen]).max(initial=0) < 2e-6
+            else:
+                ok = (g["values"][seen].view(np.uint32) == per_point[seen].view(np.uint32)).all()
+            if not ok:
+                print(f"case {c} (seed {seed}): decoded attribute {i} differs from the oracle decoder"); bad += 1
+        decoded += 1
+    except (dmi.DracoMiError, orc.OracleError, AssertionError) as e:
+        print(f"case {c} (seed {seed}, kind {kind}, {pb}/{ub} bits): decoder: {type(e).__name__} {str(e)[:120]}"); bad += 1
+print(f"{n_cases} cases, {rejected} rejected by the reference algorithm, {decoded} decoded back by both decoders, {bad} mismatches")
 sys.exit(1 if bad else 0)

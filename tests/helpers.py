@@ -50,3 +50,22 @@ def tables_from_oracle(sess, n_atts):
         t["sequence"] = sess.blob(f"att{i}.seq", np.uint32)
         tabs.append(t)
     return tabs
+
+
+def oracle_values_by_point(table, universal_table, decoded, num_points):
+    """The oracle decoder's values (one per sequence entry = per vertex of the attribute's table) laid out per POINT the way the product
+    lays them out: a point takes the value of the vertex of its LAST corner (a point can be met by two vertices of a table — a
+    non-manifold vertex split in two — whose decoded values differ when the reference's lossy normal case hits one of them).
+    Returns (values [num_points, n], referenced [num_points] bool)."""
+    c2p = np.asarray(universal_table["corner_to_point"])
+    c2v = np.asarray(table["corner_to_vertex"])
+    seq = np.asarray(table["sequence"])
+    vals = np.asarray(decoded["values"])
+    by_vertex = np.zeros((int(table["num_vertices"]), vals.shape[1]), vals.dtype)
+    by_vertex[c2v[seq]] = vals
+    last = np.full(num_points, -1, np.int64)
+    last[c2p] = np.arange(len(c2p))                     # (numpy keeps the last assignment of a repeated index: the largest corner)
+    out = np.zeros((num_points, vals.shape[1]), vals.dtype)
+    ref = last >= 0
+    out[ref] = by_vertex[c2v[last[ref]]]
+    return out, ref

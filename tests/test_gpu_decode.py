@@ -8,7 +8,7 @@ import pytest
 import draco_oxide_amd as dmi
 import orc
 from draco_oxide_amd import synth
-from helpers import oracle_from_product_mesh
+from helpers import oracle_values_by_point, oracle_from_product_mesh
 
 pytestmark = pytest.mark.gpu
 
@@ -60,12 +60,13 @@ def test_product_batch_sections_decode():
 
 
 # ---- dmi_decode_attributes: the product's own decoder-side path (host cores for the serial stages, device for normals + dequantization) ----
-def _decode_with_product(mesh, section):
+def _decode_with_product(mesh, section, want_tables=False):
     conn = dmi.encode_connectivity(mesh)
     tables = [conn.table(i) for i in range(conn.num_tables)]
     seeds = conn.seeds()
     conn.close()
-    return dmi.decode_attributes(section, tables, mesh.attributes[0].num_points, seeds=seeds)
+    got = dmi.decode_attributes(section, tables, mesh.attributes[0].num_points, seeds=seeds)
+    return (got, tables) if want_tables else got
 
 
 def _expand(att):
@@ -77,16 +78,13 @@ def _check_against_oracle_decoder(mesh, section, kw=None):
     """The product's decoder and the oracle's decoder agree value for value (per point), and both sit within the quantization error
     of the inputs."""
     kw = kw or {}
-    got = _decode_with_product(mesh, section)
+    got, tables = _decode_with_product(mesh, section, want_tables=True)
     sess = oracle_from_product_mesh(mesh)
     ref, used = sess.decode_attributes(section)
     assert used == len(section) and len(got) == len(ref) == len(mesh.attributes)
     for i, (g, d, att) in enumerate(zip(got, ref, mesh.attributes)):
         assert g["att_type"] == att.att_type and g["num_components"] == att.values.shape[1] and g["unique_id"] == att.unique_id
-        per_point = np.zeros_like(g["values"])
-        per_point[d["points"]] = d["values"]                      # the oracle's values, sequence order → points
-        seen = np.zeros(len(per_point), bool)
-        seen[d["points"]] = True
+        per_point, seen = oracle_values_by_point(tables[i], tables[0], d, len(g["values"]))   # every point a corner references
         if g["portabilization"] == 3:
             assert np.abs(g["values"][seen] - per_point[seen]).max() < 2e-6, f"attribute {i}: normals differ between the two decoders"
             n = _expand(att)
