@@ -280,6 +280,22 @@ def main():
                        "streams": int(tm["num_streams"]), "symbols": int(tm["symbols"]), "longest_stream_symbols": longest_symbols},
             "host_connectivity_s": round(connectivity_s, 3), "job_create_s": round(job_create_s, 3),
         }
+        try:   # the fraction against a device copy measured on this box as well as against the nominal peak
+            n_copy = 1 << 28   # 1 GiB of f32 read + 1 GiB written per copy
+            src = torch.empty(n_copy, dtype=torch.float32, device=dev).fill_(1.0)
+            dst = torch.empty_like(src)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            dst.copy_(src); torch.cuda.synchronize(dev)
+            e0.record()
+            for _ in range(10):
+                dst.copy_(src)
+            e1.record(); torch.cuda.synchronize(dev)
+            copy_gbps = 10 * 2 * n_copy * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            line["roofline"]["measured_copy_gbps"] = round(copy_gbps, 1)
+            line["roofline"]["frac_of_measured_copy"] = round(achieved / copy_gbps, 5)
+            del src, dst
+        except Exception as e:
+            line["roofline"]["measured_copy_error"] = str(e)[:120]
         if hybrid and stages["longest_stream_ms"] > 0:
             line["chains"]["host_core_msym_per_s"] = round(longest_symbols / stages["longest_stream_ms"] / 1e3, 2)
         else:
