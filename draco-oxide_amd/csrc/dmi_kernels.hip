@@ -356,7 +356,19 @@ __device__ __forceinline__ void quantize_tiles2(const QuantArgs& q, const uint32
 template <int N0, int N1, int N2>
 __device__ __forceinline__ void quantize_tiles3(const QuantArgs& q, const uint32_t (&p)[kTile], uint32_t base, uint32_t n, int32_t (&mn)[kMaxGather], int32_t (&mx)[kMaxGather]) {
   RawTile<N0> r0; RawTile<N1> r1; RawTile<N2> r2;
+#if defined(DMI_ABLATE) && DMI_ABLATE == 9
+  if constexpr (N0 == 3 && N1 == 3 && N2 == 2) {   // what ONE 32-byte gather per entry would cost: eight floats from one row of attribute 0's array (wrapped to stay inside it)
+    const uint32_t rows = n * 3u / 8u;
+#pragma unroll
+    for (int t = 0; t < kTile; ++t) {
+      const float4* row = reinterpret_cast<const float4*>(q.a[0].raw) + (size_t)(p[t] % rows) * 2;
+      const float4 lo = row[0], hi = row[1];
+      r0.v[t][0] = lo.x; r0.v[t][1] = lo.y; r0.v[t][2] = lo.z; r1.v[t][0] = lo.w + 2.0f; r1.v[t][1] = hi.x; r1.v[t][2] = hi.y; r2.v[t][0] = hi.z; r2.v[t][1] = hi.w;
+    }
+  } else { gather_tile<N0>(q.a[0], p, base, n, r0); gather_tile<N1>(q.a[1], p, base, n, r1); gather_tile<N2>(q.a[2], p, base, n, r2); }
+#else
   gather_tile<N0>(q.a[0], p, base, n, r0); gather_tile<N1>(q.a[1], p, base, n, r1); gather_tile<N2>(q.a[2], p, base, n, r2);
+#endif
   finish_tile<N0>(q.a[0], r0, base, n, mn[0], mx[0]); finish_tile<N1>(q.a[1], r1, base, n, mn[1], mx[1]); finish_tile<N2>(q.a[2], r2, base, n, mn[2], mx[2]);
 }
 __device__ __forceinline__ void k_seq_quantize_body(const SeqQuantArgs& sq, const uint32_t blk_, const uint32_t nblk_) {
