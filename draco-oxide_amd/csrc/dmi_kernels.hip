@@ -814,6 +814,13 @@ __device__ __forceinline__ void k_pred_texcoord_wrapped_body(const TexArgs& ta, 
 // 32-bit one: six multiplies per fan face are a fifth of the sweep's vector work.
 template <bool M24>
 __device__ __forceinline__ int32_t mul_w(int32_t a, int32_t b) { return M24 ? __mul24(a, b) : wmul(a, b); }
+// sum += cross(ea, eb) of two edge vectors (already relative to the fan's centre): the body of add_face_normal
+template <bool M24>
+__device__ __forceinline__ void add_edge_cross(const int32_t (&ea)[3], const int32_t (&eb)[3], int64_t (&sum)[3]) {
+  sum[0] = wadd64(sum[0], (int64_t)wsub(mul_w<M24>(ea[1], eb[2]), mul_w<M24>(ea[2], eb[1])));
+  sum[1] = wadd64(sum[1], (int64_t)wsub(mul_w<M24>(ea[2], eb[0]), mul_w<M24>(ea[0], eb[2])));
+  sum[2] = wadd64(sum[2], (int64_t)wsub(mul_w<M24>(ea[0], eb[1]), mul_w<M24>(ea[1], eb[0])));
+}
 template <bool M24>
 __device__ __forceinline__ void add_face_normal(const int32_t (&a)[3], const int32_t (&b)[3], const int32_t (&c)[3], int64_t (&sum)[3]) {
   const int32_t ax = wsub(a[0], c[0]), ay = wsub(a[1], c[1]), az = wsub(a[2], c[2]);
@@ -1037,8 +1044,10 @@ __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const u
       ring(0, Pn); ring(1, Pp);
       if (HAS_NRM) {
         // faces: (next, prev) = (a, b); right of it (w1, a), (w2, w1), …, closing (b, w_last); left of it (b, u1), (u1, u2), …
-        add_face_normal<PACKED>(Pn, Pp, Pc, sum);
-        int32_t R[3] = {Pn[0], Pn[1], Pn[2]}, L[3] = {Pp[0], Pp[1], Pp[2]};
+        // (edge vectors ring − centre are formed once per ring vertex and serve the two faces it borders; R / L = the edge the right /
+        //  left walk stands on — the closing face of a closed fan runs from b, which no left face has replaced, to the last right vertex)
+        int32_t R[3] = {wsub(Pn[0], Pc[0]), wsub(Pn[1], Pc[1]), wsub(Pn[2], Pc[2])}, L[3] = {wsub(Pp[0], Pc[0]), wsub(Pp[1], Pc[1]), wsub(Pp[2], Pc[2])};
+        add_edge_cross<PACKED>(R, L, sum);
 #pragma unroll
         for (uint32_t k = 2; k < kFanSlots; ++k) {
 #if defined(DMI_ABLATE) && DMI_ABLATE == 2
@@ -1048,11 +1057,12 @@ __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const u
 #endif
             int32_t W[3];
             ring(k, W);
-            if (k < 2u + stored_r) { add_face_normal<PACKED>(W, R, Pc, sum); R[0] = W[0]; R[1] = W[1]; R[2] = W[2]; }
-            else { add_face_normal<PACKED>(L, W, Pc, sum); L[0] = W[0]; L[1] = W[1]; L[2] = W[2]; }
+            W[0] = wsub(W[0], Pc[0]); W[1] = wsub(W[1], Pc[1]); W[2] = wsub(W[2], Pc[2]);
+            if (k < 2u + stored_r) { add_edge_cross<PACKED>(W, R, sum); R[0] = W[0]; R[1] = W[1]; R[2] = W[2]; }
+            else { add_edge_cross<PACKED>(L, W, sum); L[0] = W[0]; L[1] = W[1]; L[2] = W[2]; }
           }
         }
-        if (closed && faces_r) add_face_normal<PACKED>(Pp, R, Pc, sum);
+        if (closed && faces_r) add_edge_cross<PACKED>(L, R, sum);
       }
     } else {
       // ---- row overflow (valence > 8): walk the corner table ----
