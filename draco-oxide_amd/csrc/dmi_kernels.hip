@@ -1077,11 +1077,26 @@ __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const u
       const bool have = both && ro < i;   // (no opposite corner ⇒ ro == NONE ⇒ false)
       if (have) load_pos_fmt(qs_pos, pos_fmt, ro, Po);
       else if (i > 0) load_pos_fmt(qs_pos, pos_fmt, i - 1u, Plast);
+#if defined(DMI_ABLATE) && (DMI_ABLATE == 10 || DMI_ABLATE == 11)
+      {   // what the three 2-byte stores at a 6-byte stride cost: 10 = one dword + one short per entry, 11 = no position symbol stores at all
+        uint32_t sy[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const int32_t pred = have ? wsub(wadd(Pn[k], Pp[k]), Po[k]) : Plast[k]; sy[k] = wrap_symbol(Pc[k], pred, wp); }
+#if DMI_ABLATE == 10
+        uint8_t* at = static_cast<uint8_t*>(a.sym_pos) + (size_t)i * 6;
+        __builtin_nontemporal_store(sy[0] | (sy[1] << 16), reinterpret_cast<uint32_t*>(at));
+        __builtin_nontemporal_store((uint16_t)sy[2], reinterpret_cast<uint16_t*>(at + 4));
+#else
+        if ((sy[0] ^ sy[1] ^ sy[2]) == 0x7FFFFFFFu) store_sym(a.sym_pos, s16_pos, (size_t)i * 3, sy[0]);
+#endif
+      }
+#else
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int32_t pred = have ? wsub(wadd(Pn[k], Pp[k]), Po[k]) : Plast[k];   // Q15: previously coded vertex, 0 for the first entry
         store_sym(a.sym_pos, s16_pos, (size_t)i * 3 + k, wrap_symbol(Pc[k], pred, wp));
       }
+#endif
     }
     // ---- texture coordinates: mesh_prediction_for_texture_coordinates.rs:51-81,107-219 ----
     if (HAS_UV) {
