@@ -324,7 +324,7 @@ __device__ __forceinline__ void finish_tile(const QuantAtt& a, const RawTile<N>&
 #pragma unroll
       for (int k = 0; k < N; ++k) out[k] = quant_coord(r.v[t][k], a.meta[k], a.meta[N], a.maxq);
     } else if (a.kind == 1) {   // octahedral (N == 3 → 2 components)
-      if (N == 3) { int32_t u, w; oct_quantize(r.v[t][0], r.v[t][1], r.v[t][2], u, w); out[0] = u; out[1] = w; nq = 2; }
+      if constexpr (N == 3) { int32_t u, w; oct_quantize(r.v[t][0], r.v[t][1], r.v[t][2], u, w); out[0] = u; out[1] = w; nq = 2; }
     } else {   // ToBits: the 4-byte values reinterpreted as i32
 #pragma unroll
       for (int k = 0; k < N; ++k) out[k] = __float_as_int(r.v[t][k]);
@@ -634,40 +634,6 @@ __device__ __noinline__ TexPred texcoord_predict_general_v(int32_t cu0, int32_t 
   return r;
 }
 
-// a / d (truncating) for a divisor shared by several divisions: inv = 1.0 / (double)d is formed once.  |a|, d < 2^31: one
-// f64 multiply on 32-bit conversions; < 2^52: the same on 64-bit conversions (|fl(a·inv) - a/d| < 1, so the truncated
-// quotient is off by at most one and one remainder test fixes it); anything larger: the generic divide.
-__device__ __forceinline__ int64_t div_shared(int64_t a, int64_t d, double inv) {
-  if (d < (1ll << 31) && a > -(1ll << 31) && a < (1ll << 31)) {
-    const int32_t a32 = (int32_t)a, d32 = (int32_t)d;
-    int32_t q = (int32_t)((double)a32 * inv);
-    const int32_t r = (int32_t)((uint32_t)a32 - (uint32_t)q * (uint32_t)d32);   // the true remainder lies in (-d, d] ∪ …: it fits i32, the product may not
-    if (a32 >= 0) { if (r < 0) --q; else if (r >= d32) ++q; }
-    else { if (r > 0) ++q; else if (r <= -d32) --q; }
-    return (int64_t)q;
-  }
-  const int64_t lim = 1ll << 52;
-  if (d < lim && a > -lim && a < lim) {
-    int64_t q = (int64_t)((double)a * inv);
-    const int64_t r = a - q * d;
-    if (a >= 0) { if (r < 0) --q; else if (r >= d) ++q; }
-    else { if (r > 0) ++q; else if (r <= -d) --q; }
-    return q;
-  }
-  return wdiv64(a, d);
-}
-// floor(sqrt(value)) for value < 2^52 — what the reference's Newton iteration (:32-48) converges to from any start
-// (every integer Newton step from s > 0 lands at or above floor(sqrt), the loop then descends onto it; below 2^52
-// nothing in that sequence can overflow).  Larger values replay the reference's sequence literally.
-__device__ __forceinline__ uint64_t int_sqrt_fast(uint64_t value) {
-  if (value < (1ull << 52)) {
-    uint64_t r = (uint64_t)sqrt((double)value);
-    if (r * r > value) --r;
-    else if ((r + 1) * (r + 1) <= value) ++r;
-    return r;
-  }
-  return int_sqrt(value);
-}
 __device__ __forceinline__ bool fits31(int64_t v) { return v > -(1ll << 31) && v < (1ll << 31); }
 
 // One entry of mesh_prediction_for_texture_coordinates.rs:107-219 on already fetched operands: cu = the entry's
@@ -677,54 +643,82 @@ __device__ __forceinline__ bool fits31(int64_t v) { return v > -(1ll << 31) && v
 // when |pn|², cn·pn fit 31 bits (neighbouring vertices: always, in practice) the reference's three overflow guards are
 // provably false.  Every shortcut is exact integer arithmetic on values that cannot wrap, so the results equal the
 // general form's; operands outside these ranges take texcoord_predict_general.
+// (floor(sqrt(value)) is what the reference's Newton iteration (:32-48) converges to from any start: every integer Newton step from
+//  s > 0 lands at or above it and the loop then descends onto it; the f64 tier below forms it directly.)
+// trunc(a / d) for integers held in doubles, |a| < 2^53, 0 < d < 2^31, inv ≈ 1 / d: the product a·inv is within one of the quotient,
+// the remainder a − q·d is exact in one fma (it is an integer below 2^33), and one step fixes the quotient — ten full-rate
+// instructions where the i64 form pays two emulated i64 ↔ f64 conversions and a 64-bit multiply.
+__device__ __forceinline__ double div_trunc_f64(double a, double d, double inv) {
+  double q = trunc(a * inv);
+  const double r = fma(-q, d, a);
+  if (a >= 0.0) { if (r < 0.0) q -= 1.0; else if (r >= d) q += 1.0; }
+  else { if (r > 0.0) q += 1.0; else if (r <= -d) q -= 1.0; }
+  return q;
+}
+// The projection in exact f64 arithmetic, for the operand sizes of ordinary meshes: texture coordinates below 2^20, |pn|² and cn·pn
+// below 2^31 (as the integer tier below), the foot of the perpendicular within 2^11 of the corner, residuals below 2^26.  Every product
+// and sum formed here is an integer of magnitude < 2^53 — exactly representable — so the results are the i64 form's.  Returns 0: not
+// applicable (take the integer tiers), 1: predicted, 2: the reference's own fallback (|pn|² = 0 is handled by the caller's integer tier).
+__device__ __forceinline__ int texcoord_predict_f64(const int32_t (&cu)[2], const int32_t (&nuv)[2], const int32_t (&puv)[2], const int32_t (&cp)[3],
+                                                    const int32_t (&np)[3], const int32_t (&pn)[3], int32_t d32, int32_t c32, int32_t& pred0, int32_t& pred1, uint8_t& oflag) {
+  const uint32_t lim20 = 1u << 20;
+  if (!((uint32_t)nuv[0] < lim20 && (uint32_t)nuv[1] < lim20 && (uint32_t)puv[0] < lim20 && (uint32_t)puv[1] < lim20 && (uint32_t)cu[0] < lim20 && (uint32_t)cu[1] < lim20)) return 0;
+  const double d = (double)d32, c = (double)c32;
+  const double inv = 1.0 / d;
+  double cx[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double foot = div_trunc_f64((double)pn[k] * c, d, inv);   // |pn_k|·|c| < 2^16·2^31
+    cx[k] = (double)cp[k] - ((double)np[k] + foot);
+    if (!(fabs(cx[k]) < 2048.0)) return 0;
+  }
+  const double cx2sq = fma(cx[0], cx[0], fma(cx[1], cx[1], cx[2] * cx[2]));   // < 3·2^22
+  if (!(cx2sq < 2097152.0)) return 0;                                            // (the integer tier's bound: cx2sq·|pn|² < 2^52)
+  const double v = cx2sq * d;
+  double nrm = trunc(sqrt(v));                                                   // floor(sqrt(v)) up to one unit; the squares below are exact (nrm < 2^26)
+  if (nrm * nrm > v) nrm -= 1.0;
+  else if ((nrm + 1.0) * (nrm + 1.0) <= v) nrm += 1.0;
+  const double pnu0 = (double)(puv[0] - nuv[0]), pnu1 = (double)(puv[1] - nuv[1]);
+  const double xu0 = fma((double)nuv[0], d, pnu0 * c), xu1 = fma((double)nuv[1], d, pnu1 * c);   // |·| < 2^51 + 2^51
+  const double cxu0 = pnu1 * nrm, cxu1 = -(pnu0 * nrm);                          // < 2^46
+  // the two candidates one after the other (fewer doubles alive at once); residuals below 2^26 keep the squared distances exact
+  const double lim26 = 67108864.0;
+  const double a0 = div_trunc_f64(xu0 + cxu0, d, inv), a1 = div_trunc_f64(xu1 + cxu1, d, inv);
+  const double ea0 = (double)cu[0] - a0, ea1 = (double)cu[1] - a1;
+  if (!(fabs(ea0) < lim26 && fabs(ea1) < lim26)) return 0;
+  const double da = fma(ea0, ea0, ea1 * ea1);                                    // < 2^53
+  const int32_t ia0 = (int32_t)a0, ia1 = (int32_t)a1;                           // (|a| < 2^27: the casts are exact)
+  const double b0 = div_trunc_f64(xu0 - cxu0, d, inv), b1 = div_trunc_f64(xu1 - cxu1, d, inv);
+  const double eb0 = (double)cu[0] - b0, eb1 = (double)cu[1] - b1;
+  if (!(fabs(eb0) < lim26 && fabs(eb1) < lim26)) return 0;
+  const double db = fma(eb0, eb0, eb1 * eb1);
+  if (da < db) { oflag = 2; pred0 = ia0; pred1 = ia1; }
+  else { oflag = 1; pred0 = (int32_t)b0; pred1 = (int32_t)b1; }
+  return 1;
+}
+
+// One entry: the exact f64 tier in line (ordinary operand sizes), everything else through the out-of-line general form.
 __device__ __forceinline__ bool texcoord_predict(const int32_t (&cu)[2], const int32_t (&nuv)[2], const int32_t (&puv)[2], const int32_t (&cp)[3],
                                                  const int32_t (&np)[3], const int32_t (&pp)[3], int32_t& pred0, int32_t& pred1, uint8_t& oflag) {
   if (nuv[0] == puv[0] && nuv[1] == puv[1]) { pred0 = puv[0]; pred1 = puv[1]; return true; }   // degenerate: identical neighbour UVs
-  const uint32_t lim30 = 1u << 30;
-  bool small = (uint32_t)nuv[0] < lim30 && (uint32_t)nuv[1] < lim30 && (uint32_t)puv[0] < lim30 && (uint32_t)puv[1] < lim30 &&
-               (uint32_t)cu[0] < lim30 && (uint32_t)cu[1] < lim30;
+#ifndef DMI_NO_F64_TEXCOORD
+  const uint32_t lim15 = 1u << 15;   // positions below 2^30 and |pn| components below 2^15: |pn|² < 3·2^30 checked exactly below
+  bool small = true;
 #pragma unroll
-  for (int k = 0; k < 3; ++k) small = small && (uint32_t)cp[k] < lim30 && (uint32_t)np[k] < lim30 && (uint32_t)pp[k] < lim30;
+  for (int k = 0; k < 3; ++k) small = small && (uint32_t)cp[k] < (1u << 30) && (uint32_t)np[k] < (1u << 30) && (uint32_t)pp[k] < (1u << 30);
   if (small) {
     const int32_t pn[3] = {pp[0] - np[0], pp[1] - np[1], pp[2] - np[2]};
     const int32_t cn[3] = {cp[0] - np[0], cp[1] - np[1], cp[2] - np[2]};
-    const int64_t pn2sq = (int64_t)pn[0] * pn[0] + (int64_t)pn[1] * pn[1] + (int64_t)pn[2] * pn[2];   // < 3·2^60
-    if (pn2sq == 0) return false;
-    const int64_t cdp = (int64_t)pn[0] * cn[0] + (int64_t)pn[1] * cn[1] + (int64_t)pn[2] * cn[2];
-    if (pn2sq < (1ll << 31) && fits31(cdp)) {
-      // guards :138-141: n_uv_absmax·pn2sq < 2^61, |cdp|·pn_uv_absmax < 2^62, |cdp|·pn_absmax < 2^62 — never above i64::MAX
-      const int32_t pnu0 = puv[0] - nuv[0], pnu1 = puv[1] - nuv[1];
-      const int32_t d32 = (int32_t)pn2sq, c32 = (int32_t)cdp;
-      const int64_t xu0 = (int64_t)nuv[0] * d32 + (int64_t)pnu0 * c32, xu1 = (int64_t)nuv[1] * d32 + (int64_t)pnu1 * c32;
-      const double inv = 1.0 / (double)d32;
-      const int64_t cx0 = (int64_t)cp[0] - ((int64_t)np[0] + div_shared((int64_t)pn[0] * c32, pn2sq, inv));
-      const int64_t cx1 = (int64_t)cp[1] - ((int64_t)np[1] + div_shared((int64_t)pn[1] * c32, pn2sq, inv));
-      const int64_t cx2 = (int64_t)cp[2] - ((int64_t)np[2] + div_shared((int64_t)pn[2] * c32, pn2sq, inv));
-      if (fits31(cx0) && fits31(cx1) && fits31(cx2)) {
-        const int32_t x0 = (int32_t)cx0, x1 = (int32_t)cx1, x2 = (int32_t)cx2;
-        const uint64_t cx2sq = (uint64_t)((int64_t)x0 * x0 + (int64_t)x1 * x1 + (int64_t)x2 * x2);   // < 3·2^62 < 2^64
-        if (cx2sq < (1ull << 21)) {   // cx2sq·pn2sq < 2^52
-          const int32_t nrm = (int32_t)int_sqrt_fast(cx2sq * (uint64_t)pn2sq);   // < 2^26
-          const int64_t cxu0 = (int64_t)pnu1 * nrm, cxu1 = -((int64_t)pnu0 * nrm);
-          const int64_t a0 = div_shared(xu0 + cxu0, pn2sq, inv), a1 = div_shared(xu1 + cxu1, pn2sq, inv);
-          const int64_t b0 = div_shared(xu0 - cxu0, pn2sq, inv), b1 = div_shared(xu1 - cxu1, pn2sq, inv);
-          const int64_t ea0 = (int64_t)cu[0] - a0, ea1 = (int64_t)cu[1] - a1, eb0 = (int64_t)cu[0] - b0, eb1 = (int64_t)cu[1] - b1;
-          int64_t da, db;
-          if (fits31(ea0) && fits31(ea1) && fits31(eb0) && fits31(eb1)) {
-            const int32_t e0 = (int32_t)ea0, e1 = (int32_t)ea1, f0 = (int32_t)eb0, f1 = (int32_t)eb1;
-            da = (int64_t)e0 * e0 + (int64_t)e1 * e1;
-            db = (int64_t)f0 * f0 + (int64_t)f1 * f1;
-          } else {
-            da = wadd64(wmul64(ea0, ea0), wmul64(ea1, ea1));
-            db = wadd64(wmul64(eb0, eb0), wmul64(eb1, eb1));
-          }
-          if (da < db) { oflag = 2; pred0 = (int32_t)a0; pred1 = (int32_t)a1; }
-          else { oflag = 1; pred0 = (int32_t)b0; pred1 = (int32_t)b1; }
-          return true;
-        }
+    if ((uint32_t)iabs(pn[0]) < lim15 && (uint32_t)iabs(pn[1]) < lim15 && (uint32_t)iabs(pn[2]) < lim15) {
+      const int32_t d32 = pn[0] * pn[0] + pn[1] * pn[1] + pn[2] * pn[2];   // < 3·2^30: no wrap, but it may reach 2^31 …
+      const int64_t cdp = (int64_t)pn[0] * cn[0] + (int64_t)pn[1] * cn[1] + (int64_t)pn[2] * cn[2];
+      if (d32 > 0 && fits31(cdp)) {                                          // … in which case it is negative here (and |pn|² = 0 is the reference's fallback, below)
+        const int t = texcoord_predict_f64(cu, nuv, puv, cp, np, pn, d32, (int32_t)cdp, pred0, pred1, oflag);
+        if (t == 1) return true;
       }
     }
   }
+#endif
   return texcoord_predict_general(cu, nuv, puv, cp, np, pp, pred0, pred1, oflag);
 }
 
@@ -1098,36 +1092,7 @@ __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const u
       }
 #endif
     }
-    // ---- texture coordinates: mesh_prediction_for_texture_coordinates.rs:51-81,107-219 ----
-    if (HAS_UV) {
-      int32_t cu[2];
-      load_uv(i, cu);
-      int32_t pred0 = 0, pred1 = 0;
-      uint8_t oflag = 0;
-      bool done = false;
-      int32_t nu[2] = {0, 0};
-      if (rn < i) load_uv(rn, nu);
-      if (both) {
-        int32_t pu[2];
-        load_uv(rp, pu);
-#if defined(DMI_ABLATE) && DMI_ABLATE == 3
-        pred0 = pu[0] + Pn[0] - Pp[1]; pred1 = pu[1] + Pc[2]; done = true;
-#else
-        done = texcoord_predict(cu, nu, pu, Pc, Pn, Pp, pred0, pred1, oflag);
-#endif
-      }
-      if (!done) {
-        oflag = 0;
-        if (rn < i) { pred0 = nu[0]; pred1 = nu[1]; }
-        else if (i > 0) { int32_t lu[2]; load_uv(i - 1u, lu); pred0 = lu[0]; pred1 = lu[1]; }
-        else { pred0 = 0; pred1 = 0; }
-      }
-      __builtin_nontemporal_store(oflag, &a.orient[i]);
-      const uint32_t s0 = wrap_symbol(cu[0], pred0, wu), s1 = wrap_symbol(cu[1], pred1, wu);
-      if (s16_uv) __builtin_nontemporal_store(s0 | (s1 << 16), static_cast<uint32_t*>(a.sym_uv) + i);   // (symbols < 2^16: one 4-byte store)
-      else { store_sym(a.sym_uv, false, (size_t)i * 2, s0); store_sym(a.sym_uv, false, (size_t)i * 2 + 1, s1); }
-    }
-    // ---- normals: mesh_normal_prediction.rs:22-44,75-144 + oct_orthogonal.rs ----
+    // ---- normals: mesh_normal_prediction.rs:22-44,75-144 + oct_orthogonal.rs (before the texture coordinates: the fan sums die here) ----
     if (HAS_NRM) {
       // Fan sum of cross(pos[next] - pos_c, pos[prev] - pos_c).  Swinging right from a face (next = A, prev = B) lands in
       // the face (next = new vertex, prev = A); swinging left lands in (next = B, prev = new vertex).
@@ -1162,6 +1127,35 @@ __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const u
 #endif
       if (s16_nrm) __builtin_nontemporal_store(s0 | (s1 << 16), static_cast<uint32_t*>(a.sym_nrm) + i);
       else { store_sym(a.sym_nrm, false, (size_t)i * 2, s0); store_sym(a.sym_nrm, false, (size_t)i * 2 + 1, s1); }
+    }
+    // ---- texture coordinates: mesh_prediction_for_texture_coordinates.rs:51-81,107-219 ----
+    if (HAS_UV) {
+      int32_t cu[2];
+      load_uv(i, cu);
+      int32_t pred0 = 0, pred1 = 0;
+      uint8_t oflag = 0;
+      bool done = false;
+      int32_t nu[2] = {0, 0};
+      if (rn < i) load_uv(rn, nu);
+      if (both) {
+        int32_t pu[2];
+        load_uv(rp, pu);
+#if defined(DMI_ABLATE) && DMI_ABLATE == 3
+        pred0 = pu[0] + Pn[0] - Pp[1]; pred1 = pu[1] + Pc[2]; done = true;
+#else
+        done = texcoord_predict(cu, nu, pu, Pc, Pn, Pp, pred0, pred1, oflag);
+#endif
+      }
+      if (!done) {
+        oflag = 0;
+        if (rn < i) { pred0 = nu[0]; pred1 = nu[1]; }
+        else if (i > 0) { int32_t lu[2]; load_uv(i - 1u, lu); pred0 = lu[0]; pred1 = lu[1]; }
+        else { pred0 = 0; pred1 = 0; }
+      }
+      __builtin_nontemporal_store(oflag, &a.orient[i]);
+      const uint32_t s0 = wrap_symbol(cu[0], pred0, wu), s1 = wrap_symbol(cu[1], pred1, wu);
+      if (s16_uv) __builtin_nontemporal_store(s0 | (s1 << 16), static_cast<uint32_t*>(a.sym_uv) + i);   // (symbols < 2^16: one 4-byte store)
+      else { store_sym(a.sym_uv, false, (size_t)i * 2, s0); store_sym(a.sym_uv, false, (size_t)i * 2 + 1, s1); }
     }
     }
     if (kPrefetch) cur = nxt;
