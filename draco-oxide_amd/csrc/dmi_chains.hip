@@ -763,6 +763,8 @@ DMI_PREP_KERNEL(k_batch_flags, k_batch_flags_body, BatchFlagsArgs, 256)
 DMI_PREP_KERNEL(k_bits_prep, k_bits_prep_body, BitsPrepArgs, 256)
 DMI_PREP_KERNEL(k_orient_prep, k_orient_prep_body, OrientPrepArgs, 64)
 DMI_PREP_KERNEL(k_tables, k_tables_body, TableAtt, kTablesThreads)
+// the table stage of every attribute of ONE job in one launch (block b = attribute b): three dependent 100 µs launches otherwise
+__global__ __launch_bounds__(kTablesThreads) void k_tables_group(TableGroup g) { k_tables_body(g.a[blockIdx.x], 0u, 1u); }
 
 template <class Args>
 void emit_prep(int id, int level, const Args& a, uint32_t blocks, hipStream_t s) {
@@ -800,6 +802,7 @@ void launch_prep_steps_multi(int id, const void* items, const uint2* block_info,
 // record prep: symbols / bits / orientation flags → coding records, then the per-batch frequency-1 flags of the rABS record streams
 // levels: the table kernel (device form) 0, record prep 1, batch flags of the rABS record streams 2
 void launch_tables(const TableAtt& a, hipStream_t s) { emit_prep(K_TABLES, 0, a, 1u, s); }
+void launch_tables_group(const TableGroup& g, hipStream_t s) { if (g.count > 0) hipLaunchKernelGGL(k_tables_group, (uint32_t)g.count, kTablesThreads, 0, s, g); }
 void launch_rans_prep(const void* sym, bool sym16, uint64_t n, const RansEntry* table, uint32_t bins, RansEntry* rec, uint32_t* batch_flags, hipStream_t s) {
   RansPrepArgs a{sym, table, rec, batch_flags, n, bins, sym16 ? 1u : 0u};
   emit_prep(K_RANS_PREP, 1, a, n ? grid256(n) : 0u, s);

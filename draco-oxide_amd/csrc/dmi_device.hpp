@@ -23,6 +23,7 @@ constexpr int kPrepLevels = 3;        // tables (device form), record prep, batc
 struct KernelStep { int id; int level; uint32_t blocks; uint32_t lds; uint32_t args_size; uint32_t pad; alignas(8) uint8_t args[640]; };
 void set_step_sink(std::vector<KernelStep>* sink);   // thread-local; nullptr = launch immediately
 bool step_sink_push(const KernelStep& st);           // true = a sink is set and took the step
+bool step_sink_active();
 void launch_step(const KernelStep& st, hipStream_t s);
 // items: device array of the kernel's argument blocks; block_info[b] = {item, block within the item}; item_blocks[i] = its grid
 void launch_steps_multi(int id, const void* items, const uint2* block_info, const uint32_t* item_blocks, uint32_t total_blocks, uint32_t lds, hipStream_t s);
@@ -188,6 +189,9 @@ struct TableAtt {
 };
 constexpr uint32_t kTablesThreads = 1024;
 void launch_tables(const TableAtt& a, hipStream_t s);
+constexpr int kTableGroup = 8;
+struct TableGroup { TableAtt a[kTableGroup]; int count; int pad; };
+void launch_tables_group(const TableGroup& g, hipStream_t s);   // immediate launch (no step sink): one job's attributes, one block each
 void launch_prep_step(const KernelStep& st, hipStream_t s);
 void launch_prep_steps_multi(int id, const void* items, const uint2* block_info, const uint32_t* item_blocks, uint32_t total_blocks, hipStream_t s);
 // Batch read-back: pack the coded bytes of every stream into `arena` (16-byte aligned slots, in stream order);

@@ -1151,10 +1151,34 @@ static int encode_phase_b_dev(dmi_job* job, ChainDesc* desc_base, ChainDesc* hdr
   std::vector<AuxInfo>& aux = job->run.aux;
   aux.assign(n_atts, AuxInfo{});
   job->run.pending.clear();
+  // a single job's table stage is ONE launch (a block per attribute); a batch collects per-attribute steps into its multi-item launch
+  const bool grouped = !step_sink_active();
+  std::unique_ptr<TableGroup> group(grouped ? new TableGroup() : nullptr);
+  if (group) group->count = 0;
+  for (uint32_t i = 0; i < n_atts; ++i) {
+    AttJob& a = job->atts[i];
+    if (a.n_sym == 0) return fail(DMI_ERR_ENTROPY, "attribute " + std::to_string(i) + " has no values to code (empty histogram)");
+  }
+  for (int pass = 0; pass < 2; ++pass)
   for (uint32_t i = 0; i < n_atts; ++i) {
     AttJob& a = job->atts[i];
     const uint32_t n = job->tables[a.table].n_seq;
-    if (a.n_sym == 0) return fail(DMI_ERR_ENTROPY, "attribute " + std::to_string(i) + " has no values to code (empty histogram)");
+    if (pass == 1) {   // what depends on the table kernel's outputs
+      if (i == 0 && group) { launch_tables_group(*group, s); group->count = 0; }
+      if (host_chains) {   // no coding records: the streams are coded on host cores from the symbols, the table and the metadata bits
+        if (a.scheme == kTexCoord) launch_orient_bits(a.aux.as<uint8_t>(), n, a.chunk_info.as<uint32_t>(), a.aux_bits.as<uint8_t>(), s);
+        continue;
+      }
+      launch_rans_prep(a.sym.p, a.sym16, a.n_sym, a.rtable.as<RansEntry>(), a.bins, a.rec.as<RansEntry>(), a.batch_flags.as<uint32_t>(), s);
+      if (a.scheme == kNormal) {
+        launch_bits_prep_dev(a.aux.as<uint8_t>(), n, a.aux_entries.as<RansEntry>(), a.aux_rec.as<RansEntry>(), s);
+        launch_batch_flags(a.aux_rec.as<RansEntry>(), n, nullptr, a.aux_flags.as<uint32_t>(), s);
+      } else if (a.scheme == kTexCoord) {
+        launch_orient_prep_dev(a.aux.as<uint8_t>(), n, a.chunk_info.as<uint32_t>(), a.aux_entries.as<RansEntry>(), a.aux_rec.as<RansEntry>(), s);
+        launch_batch_flags(a.aux_rec.as<RansEntry>(), n, a.small.as<uint32_t>() + 15, a.aux_flags.as<uint32_t>(), s);
+      }
+      continue;
+    }
     TableAtt ta{};
     ta.hist = a.hist.as<uint32_t>(); ta.freq = a.freq.as<uint32_t>(); ta.rtable = a.rtable.as<RansEntry>(); ta.hdr = a.hdr.as<uint8_t>(); ta.small = a.small.as<uint32_t>();
     ta.n_sym = a.n_sym; ta.bins = a.bins; ta.hdr_cap = a.hdr_cap;
@@ -1177,18 +1201,11 @@ static int encode_phase_b_dev(dmi_job* job, ChainDesc* desc_base, ChainDesc* hdr
       descs.push_back(r);
     }
     ta.hdr_desc = hdr_desc_base ? hdr_desc_base + i : nullptr;
-    launch_tables(ta, s);
-    if (host_chains) {   // no coding records: the streams are coded on host cores from the symbols, the table and the metadata bits
-      if (a.scheme == kTexCoord) launch_orient_bits(a.aux.as<uint8_t>(), n, a.chunk_info.as<uint32_t>(), a.aux_bits.as<uint8_t>(), s);
-      continue;
-    }
-    launch_rans_prep(a.sym.p, a.sym16, a.n_sym, a.rtable.as<RansEntry>(), a.bins, a.rec.as<RansEntry>(), a.batch_flags.as<uint32_t>(), s);
-    if (a.scheme == kNormal) {
-      launch_bits_prep_dev(a.aux.as<uint8_t>(), n, a.aux_entries.as<RansEntry>(), a.aux_rec.as<RansEntry>(), s);
-      launch_batch_flags(a.aux_rec.as<RansEntry>(), n, nullptr, a.aux_flags.as<uint32_t>(), s);
-    } else if (a.scheme == kTexCoord) {
-      launch_orient_prep_dev(a.aux.as<uint8_t>(), n, a.chunk_info.as<uint32_t>(), a.aux_entries.as<RansEntry>(), a.aux_rec.as<RansEntry>(), s);
-      launch_batch_flags(a.aux_rec.as<RansEntry>(), n, a.small.as<uint32_t>() + 15, a.aux_flags.as<uint32_t>(), s);
+    if (group) {
+      group->a[group->count++] = ta;
+      if (group->count == kTableGroup) { launch_tables_group(*group, s); group->count = 0; }
+    } else {
+      launch_tables(ta, s);
     }
   }
   return DMI_OK;

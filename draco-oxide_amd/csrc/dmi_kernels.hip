@@ -1625,6 +1625,7 @@ void emit(int id, int level, const Args& a, uint32_t blocks, uint32_t lds, hipSt
 
 void set_step_sink(std::vector<KernelStep>* sink) { g_step_sink = sink; }
 bool step_sink_push(const KernelStep& st) { if (!g_step_sink) return false; g_step_sink->push_back(st); return true; }
+bool step_sink_active() { return g_step_sink != nullptr; }
 
 #define DMI_CASE(ID, NAME, ARGS, THREADS) \
   case ID: hipLaunchKernelGGL(NAME, st.blocks, THREADS, st.lds, s, *reinterpret_cast<const ARGS*>(st.args)); break;
