@@ -17,7 +17,7 @@ enum KernelId : int { K_RANGES, K_RANGES_FINAL, K_SEQ_QUANT, K_I32_FINAL, K_FUSE
                       K_PACKED_PNU, K_PACKED_PN, K_PACKED_PU, K_PACKED_N /* the same sweeps on packed values (QFmt) */,
                       K_WINDOW_PNU, K_WINDOW_PN, K_WINDOW_PU /* … with LDS-staged neighbourhoods */,
                       K_PAR1, K_PAR2, K_PAR3, K_PAR4, K_DELTA, K_TEX, K_ORIENT, K_HIST,
-                      K_RANS_PREP, K_BITS_PREP, K_ORIENT_PREP, K_BATCH_FLAGS, K_TABLES /* tables + record prep: dmi_chains.hip */, K_COUNT };
+                      K_TEX_FIXUP, K_RANS_PREP, K_BITS_PREP, K_ORIENT_PREP, K_BATCH_FLAGS, K_TABLES /* tables + record prep: dmi_chains.hip */, K_COUNT };
 constexpr int kStepLevels = 7;        // data-parallel phases: levels 0..6
 constexpr int kPrepLevels = 3;        // tables (device form), record prep, batch flags: levels kStepLevels + 0..2 when planned together with the phases
 struct KernelStep { int id; int level; uint32_t blocks; uint32_t lds; uint32_t args_size; uint32_t pad; alignas(8) uint8_t args[640]; };
@@ -73,6 +73,10 @@ struct FusedArgs {
   const uint32_t* fan_hdr; const uint32_t* fan_apex; const uint32_t* fan;   // fan rows of the table (launch_build_fans)
   uint32_t sym16;    // bit 0 / 1 / 2: sym_pos / sym_nrm / sym_uv are uint16 arrays
   uint32_t pad;
+  // Texture-coordinate entries outside the sweep's exact f64 tier (large operands) are not predicted in the sweep: their sequence indices
+  // go to fix_list (fix_count[0] of them, appended one atomic per wavefront) and k_texcoord_fixup — launched right after the sweep —
+  // predicts them with the general i64 form.  The sweep itself then holds no out-of-line call: 58 VGPRs instead of 80, 8 waves per SIMD.
+  uint32_t* fix_list; uint32_t* fix_count;
 };
 void launch_predict_fused(const FusedArgs& a, hipStream_t s);
 struct ParArgs { const uint32_t* seq; const uint32_t* c2r; const uint32_t* opp; const int32_t* qs; const int32_t* minmax; void* sym; uint32_t n; uint32_t sym16; };

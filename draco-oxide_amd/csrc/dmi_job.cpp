@@ -174,6 +174,7 @@ struct AttJob {
   uint64_t out_cap = 0, aux_cap = 0;
   DevMem aux_out, aux_rec, chunk_info, batch_flags, aux_flags;
   DevMem flip_partials;   // normals: per-block counts of the sweep (kSweepMaxBlocks words)
+  DevMem fix_list;        // texture coordinates of a fused sweep: the entries it defers to k_texcoord_fixup (≤ one per sequence entry)
   uint32_t flip_blocks = 0;   // blocks of the sweep launched this encode
   DevMem aux_bits;   // host-core chains: the compacted orientation transition bits (1 byte each)
   DevMem freq, hdr, aux_entries;   // device form of the table stage: normalised-frequency scratch, serialised table, rABS record pair
@@ -788,6 +789,7 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
       if ((rc = a.chunk_info.alloc((size_t)std::max(1u, orient_summary_blocks(n)) * 8 + 16))) return rc;
       if (a.scheme == kTexCoord && (rc = a.aux_bits.alloc((size_t)n + 16))) return rc;
       if (a.scheme == kNormal && (rc = a.flip_partials.alloc((size_t)kSweepMaxBlocks * 4))) return rc;
+      if (a.scheme == kTexCoord && a.fused_into >= 0 && (rc = a.fix_list.alloc((size_t)n * 4 + 4))) return rc;
     }
     if (a.scheme == kNormal && a.fused_into < 0 && n) {   // fan rows: this table's fans, ranks in the parent position table
       const TableDev& pt = job->tables[job->atts[a.parent].table];
@@ -960,6 +962,7 @@ static int encode_phase_a(dmi_job* job, bool plan_only = false) {   // device: r
       if (a.fused_uv >= 0) {
         AttJob& q = job->atts[a.fused_uv];
         fa.qs_uv = q.qs.p; fa.mm_uv = q.small.as<int32_t>(); fa.sym_uv = q.sym.p; fa.orient = q.aux.as<uint8_t>();
+        fa.fix_list = q.fix_list.as<uint32_t>(); fa.fix_count = q.small.as<uint32_t>() + 3;
         if (q.sym16) fa.sym16 |= 4u;
       }
       launch_predict_fused(fa, s);

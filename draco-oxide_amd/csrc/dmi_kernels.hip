@@ -697,28 +697,34 @@ __device__ __forceinline__ int texcoord_predict_f64(const int32_t (&cu)[2], cons
   return 1;
 }
 
-// One entry: the exact f64 tier in line (ordinary operand sizes), everything else through the out-of-line general form.
-__device__ __forceinline__ bool texcoord_predict(const int32_t (&cu)[2], const int32_t (&nuv)[2], const int32_t (&puv)[2], const int32_t (&cp)[3],
-                                                 const int32_t (&np)[3], const int32_t (&pp)[3], int32_t& pred0, int32_t& pred1, uint8_t& oflag) {
-  if (nuv[0] == puv[0] && nuv[1] == puv[1]) { pred0 = puv[0]; pred1 = puv[1]; return true; }   // degenerate: identical neighbour UVs
+// One entry in the exact f64 tier (ordinary operand sizes).  1: predicted, 0: the reference's own fallback (|pn|² = 0), 2: operands outside
+// the tier — the caller takes the general i64 form (texcoord_predict) or defers the entry to k_texcoord_fixup (the fused sweeps).
+__device__ __forceinline__ int texcoord_try(const int32_t (&cu)[2], const int32_t (&nuv)[2], const int32_t (&puv)[2], const int32_t (&cp)[3],
+                                            const int32_t (&np)[3], const int32_t (&pp)[3], int32_t& pred0, int32_t& pred1, uint8_t& oflag) {
+  if (nuv[0] == puv[0] && nuv[1] == puv[1]) { pred0 = puv[0]; pred1 = puv[1]; return 1; }   // degenerate: identical neighbour UVs
 #ifndef DMI_NO_F64_TEXCOORD
-  const uint32_t lim15 = 1u << 15;   // positions below 2^30 and |pn| components below 2^15: |pn|² < 3·2^30 checked exactly below
   bool small = true;
 #pragma unroll
   for (int k = 0; k < 3; ++k) small = small && (uint32_t)cp[k] < (1u << 30) && (uint32_t)np[k] < (1u << 30) && (uint32_t)pp[k] < (1u << 30);
   if (small) {
+    const uint32_t lim15 = 1u << 15;   // |pn| components below 2^15: |pn|² < 3·2^30 cannot wrap an i32, but may reach 2^31 (then it is negative below)
     const int32_t pn[3] = {pp[0] - np[0], pp[1] - np[1], pp[2] - np[2]};
     const int32_t cn[3] = {cp[0] - np[0], cp[1] - np[1], cp[2] - np[2]};
     if ((uint32_t)iabs(pn[0]) < lim15 && (uint32_t)iabs(pn[1]) < lim15 && (uint32_t)iabs(pn[2]) < lim15) {
-      const int32_t d32 = pn[0] * pn[0] + pn[1] * pn[1] + pn[2] * pn[2];   // < 3·2^30: no wrap, but it may reach 2^31 …
+      const int32_t d32 = pn[0] * pn[0] + pn[1] * pn[1] + pn[2] * pn[2];
+      if (d32 == 0) return 0;                                                  // mesh_prediction_for_texture_coordinates.rs: |pn|² = 0 → fallback
       const int64_t cdp = (int64_t)pn[0] * cn[0] + (int64_t)pn[1] * cn[1] + (int64_t)pn[2] * cn[2];
-      if (d32 > 0 && fits31(cdp)) {                                          // … in which case it is negative here (and |pn|² = 0 is the reference's fallback, below)
-        const int t = texcoord_predict_f64(cu, nuv, puv, cp, np, pn, d32, (int32_t)cdp, pred0, pred1, oflag);
-        if (t == 1) return true;
-      }
+      if (d32 > 0 && fits31(cdp) && texcoord_predict_f64(cu, nuv, puv, cp, np, pn, d32, (int32_t)cdp, pred0, pred1, oflag) == 1) return 1;
     }
   }
 #endif
+  return 2;
+}
+// One entry: the exact f64 tier in line (ordinary operand sizes), everything else through the out-of-line general form.
+__device__ __forceinline__ bool texcoord_predict(const int32_t (&cu)[2], const int32_t (&nuv)[2], const int32_t (&puv)[2], const int32_t (&cp)[3],
+                                                 const int32_t (&np)[3], const int32_t (&pp)[3], int32_t& pred0, int32_t& pred1, uint8_t& oflag) {
+  const int st = texcoord_try(cu, nuv, puv, cp, np, pp, pred0, pred1, oflag);
+  if (st != 2) return st == 1;
   return texcoord_predict_general(cu, nuv, puv, cp, np, pp, pred0, pred1, oflag);
 }
 
@@ -955,6 +961,40 @@ __global__ __launch_bounds__(kBlock) void k_build_fans(const uint32_t* __restric
   }
 }
 
+// the stores of one texture-coordinate entry (orientation flag + wrapped-difference symbols)
+__device__ __forceinline__ void uv_emit(const FusedArgs& a, uint32_t i, const int32_t (&cu)[2], int32_t pred0, int32_t pred1, uint8_t oflag, const WrapParams& wu, bool s16_uv) {
+  __builtin_nontemporal_store(oflag, &a.orient[i]);
+  const uint32_t s0 = wrap_symbol(cu[0], pred0, wu), s1 = wrap_symbol(cu[1], pred1, wu);
+  if (s16_uv) __builtin_nontemporal_store(s0 | (s1 << 16), static_cast<uint32_t*>(a.sym_uv) + i);   // (symbols < 2^16: one 4-byte store)
+  else { store_sym(a.sym_uv, false, (size_t)i * 2, s0); store_sym(a.sym_uv, false, (size_t)i * 2 + 1, s1); }
+}
+// The texture-coordinate entries a fused sweep deferred (operands outside its f64 tier): the general i64 form, entry by entry.  Every
+// listed entry has both neighbours coded (the sweep only defers inside `both`); positions and UVs are the sweep's (packed or plain).
+__device__ __forceinline__ void k_texcoord_fixup_body(const FusedArgs& a, const uint32_t blk_, const uint32_t nblk_) {
+  const uint32_t count = min(a.fix_count[0], a.n);
+  if (count == 0) return;
+  const bool packed = a.packed != 0u, s16_uv = (a.sym16 & 4u) != 0u;
+  const WrapParams wu = wrap_params(a.mm_uv);
+  auto load_uv = [&](uint32_t r, int32_t (&out)[2]) {
+    if (packed) { const uint32_t v = static_cast<const uint32_t*>(a.qs_uv)[r]; out[0] = (int32_t)(v & 0xFFFFu); out[1] = (int32_t)(v >> 16); }
+    else { const int32_t* q = static_cast<const int32_t*>(a.qs_uv) + (size_t)r * 2; out[0] = q[0]; out[1] = q[1]; }
+  };
+  for (uint32_t k = blk_ * kBlock + threadIdx.x; k < count; k += nblk_ * kBlock) {
+    const uint32_t i = a.fix_list[k];
+    uint32_t rn, rp;
+    if (a.fan_hdr[i] & (1u << 17)) { const uint32_t c = a.seq[i]; rn = a.c2r[cnext(c)]; rp = a.c2r[cprev(c)]; }
+    else { rn = a.fan[(size_t)i * kFanSlots]; rp = a.fan[(size_t)i * kFanSlots + 1]; }
+    int32_t Pc[3], Pn[3], Pp[3], cu[2], nu[2], pu[2];
+    const int fmt = packed ? QF_P64 : QF_I32;
+    load_pos_fmt(a.qs_pos, fmt, i, Pc); load_pos_fmt(a.qs_pos, fmt, rn, Pn); load_pos_fmt(a.qs_pos, fmt, rp, Pp);
+    load_uv(i, cu); load_uv(rn, nu); load_uv(rp, pu);
+    int32_t pred0 = 0, pred1 = 0;
+    uint8_t oflag = 0;
+    if (!texcoord_predict_general_impl(cu, nu, pu, Pc, Pn, Pp, pred0, pred1, oflag)) { oflag = 0; pred0 = nu[0]; pred1 = nu[1]; }   // (rn < i: the sweep's fallback)
+    uv_emit(a, i, cu, pred0, pred1, oflag, wu, s16_uv);
+  }
+}
+
 // HAS_POS = false: the normal attribute alone, on its own (seam) table — `c2r` is then the POSITION table's corner →
 // rank array (fan rows hold position ranks), `opp` the normal table's, and apex[i] is the rank of the fan's centre.
 // PACKED: the positions are QF_P64 (and, with HAS_POS, the normals QF_B16 and the texture coordinates QF_H32 — the three
@@ -1000,6 +1040,7 @@ __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const u
   for (; ch_ < end_; ch_ += stride_) {
     const uint32_t i = ch_ * kBlock + threadIdx.x;
     if (kPrefetch) { const uint32_t i2 = (ch_ + stride_) * kBlock + threadIdx.x; if (ch_ + stride_ < end_ && i2 < n) fetch_level1(i2, nxt); }
+    [[maybe_unused]] bool deferred = false;
     if (i < n) {
     uint32_t rn, rp, ro;
     int32_t Pc[3], Pn[3] = {0, 0, 0}, Pp[3] = {0, 0, 0}, Po[3] = {0, 0, 0}, Plast[3] = {0, 0, 0};
@@ -1143,7 +1184,9 @@ __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const u
 #if defined(DMI_ABLATE) && DMI_ABLATE == 3
         pred0 = pu[0] + Pn[0] - Pp[1]; pred1 = pu[1] + Pc[2]; done = true;
 #else
-        done = texcoord_predict(cu, nu, pu, Pc, Pn, Pp, pred0, pred1, oflag);
+        const int st = texcoord_try(cu, nu, pu, Pc, Pn, Pp, pred0, pred1, oflag);
+        done = st == 1;
+        deferred = st == 2;   // operands outside the f64 tier: k_texcoord_fixup predicts this entry with the general form
 #endif
       }
       if (!done) {
@@ -1152,11 +1195,18 @@ __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const u
         else if (i > 0) { int32_t lu[2]; load_uv(i - 1u, lu); pred0 = lu[0]; pred1 = lu[1]; }
         else { pred0 = 0; pred1 = 0; }
       }
-      __builtin_nontemporal_store(oflag, &a.orient[i]);
-      const uint32_t s0 = wrap_symbol(cu[0], pred0, wu), s1 = wrap_symbol(cu[1], pred1, wu);
-      if (s16_uv) __builtin_nontemporal_store(s0 | (s1 << 16), static_cast<uint32_t*>(a.sym_uv) + i);   // (symbols < 2^16: one 4-byte store)
-      else { store_sym(a.sym_uv, false, (size_t)i * 2, s0); store_sym(a.sym_uv, false, (size_t)i * 2 + 1, s1); }
+      if (!deferred) uv_emit(a, i, cu, pred0, pred1, oflag, wu, s16_uv);
     }
+    }
+    if (HAS_UV) {   // deferred entries of this wavefront: one atomic for all of them
+      const uint64_t m = __ballot(deferred);
+      if (m) {
+        const uint32_t lane = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));   // deferred lanes below this one
+        uint32_t base = 0;
+        if (lane == 0 && deferred) base = atomicAdd(a.fix_count, (uint32_t)__popcll(m));
+        base = __shfl(base, (int)__builtin_ctzll(m), 64);
+        if (deferred) a.fix_list[base + lane] = i;
+      }
     }
     if (kPrefetch) cur = nxt;
   }
@@ -1607,6 +1657,7 @@ DMI_KERNEL(k_pred_delta_difference, k_pred_delta_difference_body, DeltaArgs, kBl
 DMI_KERNEL(k_pred_texcoord_wrapped, k_pred_texcoord_wrapped_body, TexArgs, kBlock)
 DMI_KERNEL(k_orient_summary, k_orient_summary_body, OrientArgs, 64)
 DMI_KERNEL(k_histogram, k_histogram_body, HistArgs, kBlock)
+DMI_KERNEL(k_texcoord_fixup, k_texcoord_fixup_body, FusedArgs, kBlock)
 
 thread_local std::vector<KernelStep>* g_step_sink = nullptr;
 
@@ -1654,7 +1705,8 @@ bool step_sink_active() { return g_step_sink != nullptr; }
   X(K_DELTA, k_pred_delta_difference, DeltaArgs, kBlock)                     \
   X(K_TEX, k_pred_texcoord_wrapped, TexArgs, kBlock)                         \
   X(K_ORIENT, k_orient_summary, OrientArgs, 64)                              \
-  X(K_HIST, k_histogram, HistArgs, kBlock)
+  X(K_HIST, k_histogram, HistArgs, kBlock)                                   \
+  X(K_TEX_FIXUP, k_texcoord_fixup, FusedArgs, kBlock)
 
 void launch_step(const KernelStep& st, hipStream_t s) {
   switch (st.id) {
@@ -1731,6 +1783,7 @@ void launch_predict_fused(const FusedArgs& a, hipStream_t s) {
   if (windows && a.packed && a.sym_pos) id = id == K_PACKED_PNU ? K_WINDOW_PNU : (id == K_PACKED_PN ? K_WINDOW_PN : K_WINDOW_PU);
   static const uint32_t env_lds = std::getenv("DMI_FUSED_LDS") ? (uint32_t)std::atoi(std::getenv("DMI_FUSED_LDS")) : 0u;   // tuning aid: unused dynamic LDS per block = fewer blocks per CU
   emit(id, 4, a, g, env_lds, s);
+  if (a.qs_uv && a.sym_pos && id != K_WINDOW_PNU && id != K_WINDOW_PU) emit(K_TEX_FIXUP, 5, a, 64u, 0, s);   // the entries the sweep deferred (usually none: the launch finds count = 0)
 }
 
 void launch_decode_normals(const DecodeNormalArgs& a, hipStream_t s) { if (a.n) hipLaunchKernelGGL(k_decode_normals, grid_for(a.n, 8192), kBlock, 0, s, a); }
