@@ -77,6 +77,9 @@ inline void parallel_for(size_t n, Fn&& fn) {
 constexpr size_t kPoolMinBytes = (size_t)4 << 20;
 size_t host_pool_limit();                       // bytes
 std::atomic<size_t>& host_pool_bytes();         // bytes held by the pools of every element type
+// Large index arrays are walked with strides of a mesh row (tens of KB): with 4 KiB pages nearly every step of the serial walks is a
+// TLB miss.  Freshly reserved pool storage asks for transparent huge pages before its first touch (no-op where THP is off).
+void advise_huge_pages(void* p, size_t bytes);
 template <class T>
 struct VecPool {
   std::mutex m;
@@ -97,7 +100,7 @@ struct VecPool {
       }
     }
     std::vector<T> v;
-    if (n * sizeof(T) >= kPoolMinBytes) v.reserve(n);
+    if (n * sizeof(T) >= kPoolMinBytes) { v.reserve(n); advise_huge_pages(v.data(), v.capacity() * sizeof(T)); }
     return v;
   }
   void give(std::vector<T>& v) {
