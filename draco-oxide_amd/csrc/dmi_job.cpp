@@ -3,264 +3,22 @@
 // table stage (k_tables; host form behind DMI_HOST_TABLES) → record prep → walker/emitter rANS/rABS chains → byte splice;
 // the batch drivers (one upload, one launch per kernel for all jobs, one chain launch, one packed read-back).
 // There is NO CPU fallback: without a HIP device every encode entry point returns DMI_ERR_NO_DEVICE.
-#include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <memory>
-#include <mutex>
-#include <functional>
-#include <thread>
-
-#include "dmi_device.hpp"
-#include "dmi_host.hpp"
-#include "host_chains.hpp"
+#include "dmi_job.hpp"
 
 namespace dmi {
 thread_local std::string g_last_error;
 int host_fail(int code, const std::string& msg) { g_last_error = msg; return code; }   // shared with the host-only translation units
-namespace {
-
-int fail(int code, const std::string& msg) { return host_fail(code, msg); }
-
-#define HIP_TRY(expr)                                                                                              \
-  do {                                                                                                             \
-    hipError_t e_ = (expr);                                                                                        \
-    if (e_ != hipSuccess) {                                                                                        \
-      const bool nodev = (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice || e_ == hipErrorInsufficientDriver || e_ == hipErrorNotInitialized); \
-      return fail(nodev ? DMI_ERR_NO_DEVICE : (e_ == hipErrorOutOfMemory ? DMI_ERR_OUT_OF_MEMORY : DMI_ERR_HIP),    \
-                  std::string(#expr) + ": " + hipGetErrorString(e_));                                              \
-    }                                                                                                              \
-  } while (0)
-
-enum Scheme : uint8_t { kDelta = 0, kParallelogram = 1, kTexCoord = 5, kNormal = 6 };   // prediction_scheme/mod.rs:74-86
-enum Transform : uint8_t { kDifference = 0, kWrapped = 1, kOctOrth = 3 };              // prediction_transform/mod.rs:92-101
-enum Port : uint8_t { kToBits = 1, kCoordwise = 2, kOct = 3 };                          // portabilization/mod.rs:85-92
-constexpr uint32_t kMaxPrepareWorkers = 128;   // host threads of one dmi_meshes_prepare call
-constexpr uint32_t kPrepareStreams = 16;       // library streams their jobs are created on (per device)
-constexpr uint32_t kDeviceRelabelMinFaces = 1u << 20;   // job creation relabels the connectivity inputs with kernels from this size up (dmi_relabel.hip): its temporaries
-                                                      // are device allocations, whose release synchronises the device — a batch of mid-sized meshes on many threads must not take it
-constexpr uint64_t kHostChainMinSymbols = 32768;   // a job whose longest stream is at least this long codes its streams on host cores (hybrid form)
-
-// Device memory of one job comes from a few large chunks (DevPool) instead of one hipMalloc per buffer: job creation for a batch
-// of meshes runs on many host threads, and ≈ 70 allocations + ≈ 20 memsets per job serialise on the runtime (17 ms of
-// thread time per job before, most of it here).  A chunk is zeroed once when it is created, so pooled buffers start zeroed.
-// Released job chunks are kept (per device, in power-of-two size classes, up to kChunkCacheBytes in total) and handed to the next job of
-// that class: a transcode pipeline creates and destroys a thousand jobs per batch, and hipMalloc / hipFree serialise across the host
-// threads that do it (hipFree also synchronises the device).  A reused chunk is zeroed again on the new job's stream.
-struct ChunkCache {
-  struct Item { int device; void* p; size_t cap; };
-  std::mutex m;
-  std::vector<Item> items;
-  size_t bytes = 0;
-  static constexpr size_t kChunkCacheBytes = (size_t)64 << 30;
-  static size_t size_class(size_t n) {   // powers of two up to 1 GiB, multiples of 256 MiB above (a 100M-triangle job is 33 GB)
-    if (n > ((size_t)1 << 30)) return (n + (((size_t)1 << 28) - 1)) & ~(((size_t)1 << 28) - 1);
-    size_t c = (size_t)1 << 20;
-    while (c < n) c <<= 1;
-    return c;
-  }
-  void* acquire(int device, size_t cap) {
-    std::lock_guard<std::mutex> lock(m);
-    for (size_t k = items.size(); k-- > 0;)
-      if (items[k].device == device && items[k].cap == cap) { void* p = items[k].p; bytes -= cap; items.erase(items.begin() + (long)k); return p; }
-    return nullptr;
-  }
-  void drop_all() {
-    std::vector<Item> gone;
-    { std::lock_guard<std::mutex> lock(m); gone.swap(items); bytes = 0; }
-    int prev = 0;
-    const bool have_prev = hipGetDevice(&prev) == hipSuccess;
-    for (auto& it : gone) if (hipSetDevice(it.device) == hipSuccess) (void)hipFree(it.p);
-    if (have_prev) (void)hipSetDevice(prev);
-  }
-  bool release(int device, void* p, size_t cap) {   // false: not kept (the caller frees it)
-    std::lock_guard<std::mutex> lock(m);
-    if (bytes + cap > kChunkCacheBytes) return false;
-    items.push_back({device, p, cap});
-    bytes += cap;
-    return true;
-  }
-};
-static ChunkCache g_chunk_cache;   // (process lifetime)
-
-struct DevPool {
-  struct Chunk { void* p; size_t cap, used; };
-  std::vector<Chunk> chunks;
-  size_t chunk_bytes = 0;
-  hipStream_t stream = nullptr;
-  int device = 0;
-  ~DevPool() { for (auto& c : chunks) if (c.p && !g_chunk_cache.release(device, c.p, c.cap)) (void)hipFree(c.p); }
-  void* take(size_t n) {
-    n = (n + 255) & ~(size_t)255;
-    if (chunks.empty() || chunks.back().used + n > chunks.back().cap) {
-      Chunk c{nullptr, ChunkCache::size_class(std::max(n, chunk_bytes)), 0};
-      c.p = g_chunk_cache.acquire(device, c.cap);
-      if (!c.p && hipMalloc(&c.p, c.cap) != hipSuccess) return nullptr;
-      if (hipMemsetAsync(c.p, 0, c.cap, stream) != hipSuccess) { (void)hipFree(c.p); return nullptr; }
-      chunks.push_back(c);
-    }
-    Chunk& c = chunks.back();
-    void* p = static_cast<uint8_t*>(c.p) + c.used;
-    c.used += n;
-    return p;
-  }
-};
-static thread_local DevPool* g_active_pool = nullptr;   // set while dmi_job_create runs on this thread
-
-struct DevMem {
-  void* p = nullptr;
-  size_t bytes = 0;
-  bool pooled = false;
-  ~DevMem() { if (p && !pooled) (void)hipFree(p); }
-  int alloc(size_t n) {
-    if (p && !pooled) (void)hipFree(p);
-    p = nullptr; pooled = false;
-    bytes = n;
-    if (n == 0) return DMI_OK;
-    if (g_active_pool) {
-      p = g_active_pool->take(n);
-      if (!p) return host_fail(DMI_ERR_HIP, "hipMalloc (job pool)");
-      pooled = true;
-      return DMI_OK;
-    }
-    HIP_TRY(hipMalloc(&p, n));
-    return DMI_OK;
-  }
-  template <class T> T* as() const { return static_cast<T*>(p); }
-};
-
-// A view into the job's slab (same accessors as DevMem, no ownership)
-struct SlabView {
-  void* p = nullptr;
-  size_t bytes = 0;
-  template <class T> T* as() const { return static_cast<T*>(p); }
-};
-
-struct TableDev {
-  uint32_t F = 0, V = 0, n_seq = 0;
-  DevMem fan_hdr, fan_apex, fan;   // fan rows (only for tables with a fused sweep)
-  DevMem c2r, opp, seq, s2p;   // c2r = corner → sequence index of its vertex; s2p = sequence index → point (= point_idx(seq[i]))
-  const uint32_t* s2p_host = nullptr;   // (during job creation, host-relabel form) the same array in the upload staging
-  // sharing: a table whose arrays equal another table's reuses its device copies
-  int alias_of = -1;
-};
-
-struct AuxInfo { uint8_t zero_prob = 0; uint32_t count = 0; int rans_desc = -1; int desc = -1; };
-
-struct AttJob {
-  dmi_attribute desc{};
-  Scheme scheme = kDelta;
-  Transform transform = kDifference;
-  Port port = kCoordwise;
-  int bits = 11;
-  int nq = 0;            // components after portabilization
-  int table = 0;         // index into tables
-  int parent = -1;
-  int fused_into = -1;   // ≥ 0: predicted by the fused seam-free sweep launched for that position attribute
-  int fused_nrm = -1, fused_uv = -1;   // (on a position attribute) the attributes its fused sweep also predicts
-  int qfmt = QF_I32;     // layout of qs (QFmt): packed for the attributes of a fused sweep whose widths allow it
-  bool sym16 = false;    // symbols stored as uint16 (alphabet bound ≤ 65536)
-  DevMem raw, s2v /*sequence index → value index, only with a point_to_value map*/, qs, sym, aux /*flips or orient*/, rtable, rec, out, partials, ipartials;
-  // views into dmi_job::slab — one memset, one read-back per encode: small = 16 scratch words (minmax[2], counters[2], flags[2], …,
-  // out_len[2]*2, ticks[2]), meta = quantization ranges, hist = symbol histogram (bins_cap words), summary = orientation chunk summaries
-  SlabView small, meta, hist, summary;
-  size_t slab_off = 0;
-  uint32_t bins_cap = 0;
-  uint32_t bins = 0;
-  uint64_t n_sym = 0;
-  uint64_t out_cap = 0, aux_cap = 0;
-  DevMem aux_out, aux_rec, chunk_info, batch_flags, aux_flags;
-  DevMem flip_partials;   // normals: per-block counts of the sweep (kSweepMaxBlocks words)
-  DevMem fix_list;        // texture coordinates of a fused sweep: the entries it defers to k_texcoord_fixup (≤ one per sequence entry)
-  uint32_t flip_blocks = 0;   // blocks of the sweep launched this encode
-  DevMem aux_bits;   // host-core chains: the compacted orientation transition bits (1 byte each)
-  DevMem freq, hdr, aux_entries;   // device form of the table stage: normalised-frequency scratch, serialised table, rABS record pair
-  uint32_t hdr_cap = 0;
-  DevMem fan_hdr, fan_apex, fan;   // fan rows of a normal attribute swept on its own table (position ranks, centre in apex)
-  FreqTable ft;
-  std::vector<RansEntry> rt_host;     // staging (kept alive until the copies have been issued)
-  std::vector<uint32_t> info_host;
-};
-
-}  // namespace
+ChunkCache g_chunk_cache;
+thread_local DevPool* g_active_pool = nullptr;
 }  // namespace dmi
 
 using namespace dmi;
 
-// hipStreamCreate costs ≈ 1 ms and serialises across host threads (31 ms per job with 32 creator threads): jobs created by
-// dmi_meshes_prepare share one library-owned stream per worker thread, kept for the life of the process.
-struct StreamHolder {
-  hipStream_t s = nullptr;
-  ~StreamHolder() { if (s) (void)hipStreamDestroy(s); }
-};
-static thread_local std::shared_ptr<StreamHolder> g_adopt_stream;   // set by a dmi_meshes_prepare worker around dmi_job_create
+thread_local std::shared_ptr<StreamHolder> g_adopt_stream;
 
-struct dmi_job {
-  dmi_config cfg{};
-  hipStream_t stream = nullptr;
-  std::shared_ptr<StreamHolder> stream_owner;   // set when the library created the stream
-  DevPool pool;   // (declared before every DevMem of the job: destroyed after them)
-  std::vector<AttJob> atts;
-  std::vector<TableDev> tables;
-  DevMem upload_region;   // every array job creation uploads, in one piece (host-relabel form): filled through one pinned staging copy
-  DevMem descs;
-  DevMem slab;   // small / meta / hist / summary of every attribute, laid out exactly like the pinned read-back buffer
-  void* pinned = nullptr;   // host-pinned readback area
-  size_t pinned_bytes = 0;
-  hipEvent_t ev[8]{};
-  bool have_events = false;
-  dmi_timings last{};
-  uint64_t predict_bytes = 0;
-  hipGraphExec_t graph_a = nullptr;   // phase A captured once (launch-bound for small meshes)
-  bool graph_tried = false;
-  uint8_t* readback = nullptr;     // where the slab of the current encode was read back to (pinned, or a batch arena slot)
-  bool dev_tables = false;         // tables, metadata parameters and chain descriptors are produced on the device (k_tables): no host round trip
-                                   // between the histograms and the chains (DMI_HOST_TABLES=1 or a ToBits attribute keep the host form)
-  uint8_t* out_pinned = nullptr;   // grow-only pinned arena for the coded bytes of one encode
-  size_t out_pinned_cap = 0;
-  // Hybrid form (host_chains.cpp): the streams of a single large mesh are coded on host cores from the device-built symbols and tables.
-  bool host_chains = false;
-  struct HostStage* stage = nullptr;                 // pinned staging of symbols / tables / metadata bits (process-wide pool)
-  std::vector<std::unique_ptr<HostChainOut>> host_out;   // [2·i] rANS stream of attribute i, [2·i + 1] its metadata rABS stream
-  std::vector<hipEvent_t> copy_ev;                   // "attribute i has arrived"
-  struct Run {   // state carried between the phases of one encode
-    std::vector<size_t> rans_off, aux_off;   // offsets into out_pinned
-    std::vector<const uint8_t*> rans_ptr, aux_ptr;   // host addresses of the coded bytes (pinned memory)
-    std::vector<uint32_t> rans_len, aux_len;
-    std::vector<const uint8_t*> hdr_ptr;     // serialised frequency tables (host form: FreqTable::header; device form: read back)
-    std::vector<uint32_t> hdr_len;
-    std::vector<size_t> hdr_off;
-    struct Pending { void* dst; const void* src; size_t bytes; };
-    std::vector<Pending> pending;   // host → device copies deferred to the batch driver (plan mode of phase B)
-    std::vector<size_t> pin_off;
-    std::vector<AuxInfo> aux;
-    std::vector<ChainDesc> descs;
-  } run;
-  ~dmi_job();
-  void release() {
-    if (stream) (void)hipStreamSynchronize(stream);   // (the job's device memory goes back to a cache, not through a synchronising hipFree)
-    if (pinned) (void)hipHostFree(pinned);
-    if (out_pinned) (void)hipHostFree(out_pinned);
-    if (graph_a) (void)hipGraphExecDestroy(graph_a);
-    if (have_events) for (auto& e : ev) (void)hipEventDestroy(e);
-    for (auto& e : copy_ev) (void)hipEventDestroy(e);
-  }
-};
-
-// Pinned host staging for the hybrid form, pooled for the life of the process: pinning ≈ 150 MB costs tens of milliseconds, which a
-// create → encode → destroy call (dmi_encode_attributes) would otherwise pay every time.
-struct HostStage {
-  int device = -1;
-  uint8_t* p = nullptr;
-  size_t cap = 0;
-  bool in_use = false;
-};
 static std::mutex g_stage_mutex;
 static std::vector<HostStage*> g_stages;   // (never freed: process-lifetime staging)
-static HostStage* acquire_stage(int device, size_t bytes) {
+HostStage* acquire_stage(int device, size_t bytes) {
   HostStage* best = nullptr;
   {
     std::lock_guard<std::mutex> lock(g_stage_mutex);
@@ -281,7 +39,7 @@ static HostStage* acquire_stage(int device, size_t bytes) {
   }
   return best;
 }
-static void release_stage(HostStage* st) {
+void release_stage(HostStage* st) {
   if (!st) return;
   std::lock_guard<std::mutex> lock(g_stage_mutex);
   st->in_use = false;
@@ -290,14 +48,7 @@ dmi_job::~dmi_job() {
   release();
   release_stage(stage);
 }
-
 namespace {
-
-struct TempDev {   // device temporaries of job creation (outside the job's pool: they are released when creation ends)
-  std::vector<void*> ptrs;
-  ~TempDev() { for (void* q : ptrs) (void)hipFree(q); }
-  template <class T> T* take(size_t n) { void* q = nullptr; if (hipMalloc(&q, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr; ptrs.push_back(q); return static_cast<T*>(q); }
-};
 
 int upload(DevMem& m, const void* src, size_t bytes, hipStream_t s) {
   int rc = m.alloc(bytes);
@@ -427,13 +178,17 @@ void dmi_free_many(dmi_buffer* bufs, uint32_t n) {
   for (uint32_t k = 0; k < n; ++k) dmi_free(&bufs[k]);
 }
 
-static int to_buffer(const std::vector<uint8_t>& v, dmi_buffer* out) {
+}  // extern "C"
+namespace dmi {
+int to_buffer(const std::vector<uint8_t>& v, dmi_buffer* out) {
   out->data = static_cast<uint8_t*>(std::malloc(v.size() ? v.size() : 1));
   if (!out->data) return fail(DMI_ERR_OUT_OF_MEMORY, "malloc");
   if (!v.empty()) std::memcpy(out->data, v.data(), v.size());
   out->len = out->cap = v.size();
   return DMI_OK;
 }
+}  // namespace dmi
+extern "C" {
 
 int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, uint32_t n_atts, const uint32_t* seeds, uint32_t n_seeds,
                    const dmi_config* cfg_in, dmi_job** job_out) {
@@ -2292,340 +2047,6 @@ int dmi_encode_attributes_batch(const dmi_batch_item* items, uint32_t n, const d
   for (auto* j : jobs) dmi_job_destroy(j);
   if (own) (void)hipStreamDestroy(own);
   return rc;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Whole-mesh entry points: host connectivity + device attributes.
-// ------------------------------------------------------------------------------------------------
-struct ConnOwner {
-  CornerTables ct;
-  EdgebreakerResult eb;
-  std::vector<std::vector<uint32_t>> seqs;
-  ConnOwner() = default;
-  ConnOwner(const ConnOwner&) = delete;
-  ConnOwner& operator=(const ConnOwner&) = delete;
-  ~ConnOwner() {   // the large arrays go back to the host pool (dmi_host.hpp)
-    pool_give(ct.c2p); pool_give(ct.c2v); pool_give(ct.opp); pool_give(ct.lmc);
-    for (auto& a : ct.att) { pool_give(a.c2v); pool_give(a.opp); pool_give(a.lmc); pool_give(a.seam_edge); }
-    pool_give(eb.seeds);
-    for (auto& q : seqs) pool_give(q);
-  }
-  std::vector<dmi_corner_table> views;
-};
-
-static int build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std::vector<uint8_t>& bytes) {
-  if (!mesh || !mesh->atts || mesh->num_atts == 0 || (!mesh->faces && mesh->num_faces)) return fail(DMI_ERR_INVALID_ARGUMENT, "bad mesh");
-  if (mesh->atts[0].att_type != DMI_ATT_POSITION) return fail(DMI_ERR_INVALID_ARGUMENT, "attribute 0 must be the Position attribute (core/mesh/builder.rs:115-125)");
-  for (uint32_t i = 0; i < mesh->num_atts; ++i)
-    if (mesh->atts[i].point_to_value == nullptr && mesh->atts[i].num_unique < mesh->atts[i].num_points) return fail(DMI_ERR_INVALID_ARGUMENT, "attribute " + std::to_string(i) + ": fewer values than points and no point_to_value map");
-  {   // faces index the attributes' points (and, through point_to_value, their values) from here on
-    const size_t C = (size_t)mesh->num_faces * 3;
-    const uint32_t P = mesh->atts[0].num_points;
-    std::atomic<int> bad{0};
-    parallel_for(C, [&](size_t lo, size_t hi) { for (size_t c = lo; c < hi; ++c) if (mesh->faces[c] >= P) { bad.store(1); break; } });
-    if (bad) return fail(DMI_ERR_INVALID_ARGUMENT, "face index ≥ number of points");
-    for (uint32_t i = 0; i < mesh->num_atts; ++i) {
-      const dmi_attribute& a = mesh->atts[i];
-      if (a.num_points < P) return fail(DMI_ERR_INVALID_ARGUMENT, "attribute " + std::to_string(i) + " has fewer points than the Position attribute");
-      if (a.point_to_value) parallel_for(a.num_points, [&](size_t lo, size_t hi) { for (size_t p = lo; p < hi; ++p) if (a.point_to_value[p] >= a.num_unique) { bad.store(1); break; } });
-      if (bad) return fail(DMI_ERR_INVALID_ARGUMENT, "attribute " + std::to_string(i) + ": point_to_value entry out of range");
-    }
-  }
-  std::string err;
-  const bool trace = std::getenv("DMI_TRACE") != nullptr;
-  auto tick = [] { return std::chrono::steady_clock::now(); };
-  auto since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
-  auto c0 = tick();
-  int rc = o.ct.build_universal(mesh->faces, mesh->num_faces, mesh->atts[0].point_to_value, err);
-  if (rc) return fail(rc, err);
-  const double t_univ = since(c0);
-  // The serial graph walks of one large mesh overlap on a few host threads: the attribute corner tables (their loops are parallel
-  // themselves) are built while the Edgebreaker traversal runs (it reads the universal table only; the seam flags are needed at its
-  // end), and the attribute sequencers start as soon as the traversal has produced its seeds, beside the assembly of the
-  // connectivity bytes.  Small meshes (a batch already runs one mesh per host thread) do the same steps one after the other.
-  std::vector<const uint32_t*> maps;
-  for (uint32_t i = 0; i < mesh->num_atts; ++i) if (mesh->atts[i].att_type != DMI_ATT_POSITION) maps.push_back(mesh->atts[i].point_to_value);
-  o.ct.att.resize(maps.size());
-  const bool overlap = mesh->num_faces > 100000;
-  double t_att = 0, t_eb = 0, t_seq = 0;
-  o.views.resize(mesh->num_atts);
-  o.seqs.resize(mesh->num_atts);
-  auto universal_view = [&](dmi_corner_table& v) { v.num_vertices = o.ct.V; v.corner_to_vertex = o.ct.c2v.data(); v.opposite = o.ct.opp.data(); v.left_most_corner = o.ct.lmc.data(); };
-  Pooled<uint8_t> on_boundary_p;
-  std::vector<uint8_t>& on_boundary = on_boundary_p.v;
-  auto sequence_universal = [&] {
-    TableRef tr{o.ct.F, o.ct.V, o.ct.c2v.data(), o.ct.opp.data(), o.ct.lmc.data()};
-    attribute_sequence(tr, o.eb.seeds.data(), (uint32_t)o.eb.seeds.size(), o.seqs[0], on_boundary.empty() ? nullptr : on_boundary.data());
-  };
-  auto build_att_tables = [&] {
-    const auto a0 = tick();
-    // an attribute indexed like the Position attribute has no seams but the boundary; one indexed like an earlier attribute has that one's table
-    auto build_one = [&](size_t k) {
-      for (size_t j = 0; j < k; ++j) if (maps[j] == maps[k]) return;   // (copied below, once its original is complete)
-      o.ct.build_attribute_into(o.ct.att[k], maps[k], maps[k] == mesh->atts[0].point_to_value);
-    };
-    if (maps.size() > 1 && overlap) {
-      std::vector<std::thread> th;
-      for (size_t k = 0; k < maps.size(); ++k) th.emplace_back(build_one, k);
-      for (auto& x : th) x.join();
-    } else {
-      for (size_t k = 0; k < maps.size(); ++k) build_one(k);
-    }
-    for (size_t k = 0; k < maps.size(); ++k)
-      for (size_t j = 0; j < k; ++j) if (maps[j] == maps[k]) { o.ct.copy_attribute_into(o.ct.att[k], o.ct.att[j]); o.ct.att[k].alias_of = (int)j; break; }
-    t_att = since(a0);
-  };
-  std::thread att_thread, seq_thread, flag_thread;
-  EdgebreakerHooks hooks;
-  if (overlap) {
-    // the sequencer's per-vertex boundary test, ahead of time (beside the start of the traversal)
-    flag_thread = std::thread([&] { TableRef tr{o.ct.F, o.ct.V, o.ct.c2v.data(), o.ct.opp.data(), o.ct.lmc.data()}; vertex_boundary_flags(tr, on_boundary); });
-    att_thread = std::thread(build_att_tables);
-    hooks.seeds_ready = [&] { if (flag_thread.joinable()) flag_thread.join(); seq_thread = std::thread([&] { const auto q0 = tick(); sequence_universal(); t_seq = since(q0); }); };
-    hooks.before_seams = [&] { if (att_thread.joinable()) att_thread.join(); };
-  } else {
-    build_att_tables();
-  }
-  auto c1 = tick();
-  rc = run_edgebreaker(o.ct, o.eb, err, overlap ? &hooks : nullptr);
-  if (flag_thread.joinable()) flag_thread.join();
-  if (att_thread.joinable()) att_thread.join();
-  if (seq_thread.joinable()) seq_thread.join();
-  if (rc) return fail(rc, err);
-  t_eb = since(c1);
-  auto c2 = tick();
-  if (!overlap) sequence_universal();
-  ByteSink s;
-  for (char ch : {'D', 'R', 'A', 'C', 'O'}) s.u8((uint8_t)ch);   // encode/header/mod.rs:26-54
-  s.u8(2); s.u8(2); s.u8(1); s.u8(1); s.u16(0);
-  s.bytes(o.eb.connectivity);
-  bytes.swap(s.b);
-  // views: attribute i uses the universal table when i == 0 or no attribute table i-1 exists
-  // (all_inclusive_corner_table.rs:31-45)
-  {
-    std::vector<std::thread> th;   // sequences of attribute tables with seams: independent walks
-    for (uint32_t i = 0; i < mesh->num_atts; ++i) {
-      dmi_corner_table& v = o.views[i];
-      v.num_faces = o.ct.F;
-      v.corner_to_point = o.ct.c2p.data();
-      const bool use_att = i > 0 && (i - 1) < o.ct.att.size();
-      const bool seamless = !use_att || !o.ct.att[i - 1].interior_seams;
-      if (use_att && !seamless) {
-        const AttTable& t = o.ct.att[i - 1];
-        v.num_vertices = t.num_vertices; v.corner_to_vertex = t.c2v.data(); v.opposite = t.opp.data(); v.left_most_corner = t.lmc.data();
-        auto walk = [&o, i, &t] { TableRef tr{o.ct.F, t.num_vertices, t.c2v.data(), t.opp.data(), t.lmc.data()}; attribute_sequence(tr, o.eb.seeds.data(), (uint32_t)o.eb.seeds.size(), o.seqs[i]); };
-        if (overlap) th.emplace_back(walk); else walk();
-      } else {
-        // a seam-free attribute table is identical to the universal one (same ids, same order)
-        universal_view(v);
-      }
-    }
-    for (auto& x : th) x.join();
-    for (uint32_t i = 0; i < mesh->num_atts; ++i) {
-      dmi_corner_table& v = o.views[i];
-      if (v.corner_to_vertex == o.ct.c2v.data() && i > 0) { pool_fit(o.seqs[i], o.seqs[0].size()); o.seqs[i].assign(o.seqs[0].begin(), o.seqs[0].end()); }
-      v.sequence = o.seqs[i].data();
-      v.sequence_len = (uint32_t)o.seqs[i].size();
-    }
-  }
-  if (!overlap) t_seq = since(c2);
-  if (trace) std::fprintf(stderr, "[dmi] host connectivity of %u faces (%s): universal corner table %.1f ms, attribute tables %.1f, Edgebreaker %.1f, universal sequencer %.1f, seam-table sequencers + views %.1f; total %.1f\n",
-                          mesh->num_faces, overlap ? "overlapped: attribute tables and sequencer beside the Edgebreaker walk" : "in sequence", t_univ, t_att, t_eb, t_seq, since(c2), since(c0));
-  return DMI_OK;
-}
-
-int dmi_encode_connectivity(const dmi_mesh* mesh, dmi_buffer* header_and_connectivity, dmi_conn* conn) {
-  if (!header_and_connectivity || !conn) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
-  auto* o = new ConnOwner();
-  std::vector<uint8_t> bytes;
-  int rc = build_connectivity(mesh, *o, bytes);
-  if (rc) { delete o; return rc; }
-  rc = to_buffer(bytes, header_and_connectivity);
-  if (rc) { delete o; return rc; }
-  conn->num_tables = (uint32_t)o->views.size();
-  conn->tables = o->views.data();
-  conn->seeds = o->eb.seeds.data();
-  conn->num_seeds = (uint32_t)o->eb.seeds.size();
-  conn->owner = o;
-  return DMI_OK;
-}
-void dmi_conn_free(dmi_conn* conn) {
-  if (!conn) return;
-  delete static_cast<ConnOwner*>(conn->owner);
-  conn->owner = nullptr; conn->tables = nullptr; conn->seeds = nullptr; conn->num_tables = conn->num_seeds = 0;
-}
-
-int dmi_mesh_prepare(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buffer* header_and_connectivity, dmi_job** job) {
-  if (!header_and_connectivity || !job) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
-  const bool trace = std::getenv("DMI_TRACE") != nullptr;
-  const auto t0 = std::chrono::steady_clock::now();
-  auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
-  double t_conn = 0, t_create = 0, t_buf = 0;
-  int rc;
-  {
-    std::unique_ptr<ConnOwner> op(new ConnOwner());
-    ConnOwner& o = *op;
-    std::vector<uint8_t> bytes;
-    rc = build_connectivity(mesh, o, bytes);
-    if (rc) return rc;
-    t_conn = ms();
-    rc = dmi_job_create(mesh->atts, o.views.data(), mesh->num_atts, o.eb.seeds.data(), (uint32_t)o.eb.seeds.size(), cfg, job);
-    if (rc) return rc;
-    t_create = ms();
-    rc = to_buffer(bytes, header_and_connectivity);
-    if (rc) { dmi_job_destroy(*job); *job = nullptr; }
-    t_buf = ms();
-  }
-  if (trace && mesh->num_faces > 100000) std::fprintf(stderr, "[dmi] mesh_prepare: connectivity %.1f ms, job create %.1f, output buffer %.1f, release of the host tables %.1f\n", t_conn, t_create - t_conn, t_buf - t_create, ms() - t_buf);
-  return rc;
-}
-
-// dmi_mesh_prepare for n independent meshes: the serial graph walks (corner tables, Edgebreaker, sequencers) and the
-// uploads of different meshes run on a pool of host threads — the connectivity stage is the end-to-end bottleneck of a
-// batch transcode once the attribute section is coded on the GPU.
-static int meshes_prepare_impl(const dmi_mesh* meshes, uint32_t n, const dmi_config* cfg, const int32_t* device_of_mesh, dmi_buffer* header_and_connectivity, dmi_job** jobs);
-int dmi_meshes_prepare(const dmi_mesh* meshes, uint32_t n, const dmi_config* cfg, dmi_buffer* header_and_connectivity, dmi_job** jobs) {
-  return meshes_prepare_impl(meshes, n, cfg, nullptr, header_and_connectivity, jobs);
-}
-// One process, several GPUs: mesh j is prepared on HIP device device_of_mesh[j] (dmi_shard_meshes deals them by triangle count).
-int dmi_meshes_prepare_devices(const dmi_mesh* meshes, uint32_t n, const dmi_config* cfg, const int32_t* device_of_mesh, dmi_buffer* header_and_connectivity, dmi_job** jobs) {
-  if (!device_of_mesh) return fail(DMI_ERR_INVALID_ARGUMENT, "device_of_mesh is null");
-  if (cfg && cfg->stream) return fail(DMI_ERR_INVALID_ARGUMENT, "a caller stream belongs to one device: leave dmi_config.stream null for a multi-device batch");
-  const int ndev = dmi_device_count();
-  for (uint32_t j = 0; j < n; ++j) if (device_of_mesh[j] < 0 || device_of_mesh[j] >= ndev) return fail(ndev ? DMI_ERR_INVALID_ARGUMENT : DMI_ERR_NO_DEVICE, "device ordinal out of range");
-  return meshes_prepare_impl(meshes, n, cfg, device_of_mesh, header_and_connectivity, jobs);
-}
-// Greedy longest-processing-time deal of n meshes over n_devices by triangle count (the partition the multi-process form uses:
-// draco-oxide_amd/distributed.py shard_indices): heaviest mesh first, each to the least loaded device, ties to the lower index.
-int dmi_shard_meshes(const dmi_mesh* meshes, uint32_t n, uint32_t n_devices, int32_t* device_of_mesh) {
-  if (!meshes || !device_of_mesh || n_devices == 0) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
-  std::vector<uint32_t> order(n);
-  for (uint32_t j = 0; j < n; ++j) order[j] = j;
-  std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return meshes[x].num_faces > meshes[y].num_faces; });
-  std::vector<uint64_t> load(n_devices, 0);
-  for (uint32_t j : order) {
-    uint32_t best = 0;
-    for (uint32_t d = 1; d < n_devices; ++d) if (load[d] < load[best]) best = d;
-    device_of_mesh[j] = (int32_t)best;
-    load[best] += meshes[j].num_faces;
-  }
-  return DMI_OK;
-}
-static int meshes_prepare_impl(const dmi_mesh* meshes, uint32_t n, const dmi_config* cfg, const int32_t* device_of_mesh, dmi_buffer* header_and_connectivity, dmi_job** jobs) {
-  if (!meshes || !header_and_connectivity || !jobs || n == 0) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
-  for (uint32_t j = 0; j < n; ++j) { jobs[j] = nullptr; header_and_connectivity[j] = dmi_buffer{}; }
-  // (the walks are serial per mesh and independent across meshes: as many workers as the host gives — 128 at most — minus what a
-  //  concurrent dmi_jobs_encode of the previous batch needs; DMI_HOST_THREADS caps a process's share)
-  const uint32_t n_threads = std::max(1u, std::min({n, (uint32_t)host_threads(), kMaxPrepareWorkers}));
-  std::vector<int> rcs(n, DMI_OK);
-  std::vector<std::string> errs(n);
-  std::atomic<uint32_t> next{0};
-  // largest meshes first: the walks are serial per mesh, so the longest one should not start last
-  std::vector<uint32_t> order(n);
-  for (uint32_t j = 0; j < n; ++j) order[j] = j;
-  std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return meshes[x].num_faces > meshes[y].num_faces; });
-  const bool library_streams = !(cfg && cfg->stream);
-  auto worker_stream = [&](uint32_t t, int device) {   // worker t's stream on `device` (process-lifetime pool, created on first use)
-    static std::mutex m;
-    static std::vector<std::pair<int, std::shared_ptr<StreamHolder>>> pool[kMaxPrepareWorkers];
-    std::lock_guard<std::mutex> lock(m);
-    std::shared_ptr<StreamHolder> found;
-    for (auto& e : pool[t]) if (e.first == device) found = e.second;
-    if (!found && hipSetDevice(device) == hipSuccess) {
-      found = std::make_shared<StreamHolder>();
-      if (hipStreamCreate(&found->s) != hipSuccess) found.reset(); else pool[t].push_back({device, found});
-    }
-    return found;
-  };
-  auto work = [&](uint32_t t) {
-    int adopted_for = -1;
-    for (;;) {
-      const uint32_t k = next.fetch_add(1);
-      if (k >= n) break;
-      const uint32_t j = order[k];
-      dmi_config c{};
-      if (cfg) c = *cfg;
-      if (device_of_mesh) c.device = device_of_mesh[j];
-      // (creating a stream costs ≈ 1 ms and serialises across threads: the workers share kPrepareStreams of them)
-      if (library_streams && adopted_for != c.device) { g_adopt_stream = worker_stream(t % kPrepareStreams, c.device); adopted_for = c.device; }   // (null: dmi_job_create makes its own)
-      rcs[j] = dmi_mesh_prepare(&meshes[j], &c, &header_and_connectivity[j], &jobs[j]);
-      if (rcs[j]) errs[j] = g_last_error;
-    }
-    g_adopt_stream.reset();
-  };
-  if (n_threads == 1) work(0);
-  else {
-    std::vector<std::thread> th;
-    for (uint32_t t = 0; t < n_threads; ++t) th.emplace_back(work, t);
-    for (auto& x : th) x.join();
-  }
-  for (uint32_t j = 0; j < n; ++j) {
-    if (!rcs[j]) continue;
-    const int rc = rcs[j];
-    const std::string e = "mesh " + std::to_string(j) + ": " + errs[j];
-    for (uint32_t k = 0; k < n; ++k) { if (jobs[k]) { dmi_job_destroy(jobs[k]); jobs[k] = nullptr; } dmi_free(&header_and_connectivity[k]); }
-    return fail(rc, e);
-  }
-  return DMI_OK;
-}
-
-// The host-core stream coders of the hybrid form on their own (no device involved): tests pin them against the oracle's coders,
-// bench.py times them on one core of the GPU box beside the device walker.
-int dmi_host_rans_stream(const uint32_t* freq, uint32_t num_symbols, uint32_t precision, const uint32_t* symbols, uint64_t n, dmi_buffer* out) {
-  if (!freq || !out || (!symbols && n) || precision < 8 || precision > 20) return fail(DMI_ERR_INVALID_ARGUMENT, "bad argument");
-  std::vector<RansEntry> table(num_symbols);
-  uint64_t cum = 0;
-  for (uint32_t k = 0; k < num_symbols; ++k) {
-    if (freq[k] > (1u << precision)) return fail(DMI_ERR_INVALID_ARGUMENT, "frequency above 2^precision");
-    table[k] = make_rans_entry(freq[k], (uint32_t)cum, precision);
-    cum += freq[k];
-  }
-  if (cum != (1ull << precision)) return fail(DMI_ERR_INVALID_ARGUMENT, "frequencies must sum to 2^precision");
-  for (uint64_t k = 0; k < n; ++k) if (symbols[k] >= num_symbols || !freq[symbols[k]]) return fail(DMI_ERR_ENTROPY, "symbol without a frequency");
-  HostChainOut o;
-  host_rans_chain(symbols, n, table.data(), num_symbols, precision, o);
-  if (o.err) return fail(o.err == 2 ? DMI_ERR_OUT_OF_MEMORY : DMI_ERR_ENTROPY, o.err == 1 ? "rANS state too large" : "host chain error");
-  out->data = o.data; out->len = o.len; out->cap = o.cap;
-  o.data = nullptr; o.cap = 0;   // ownership moves to the caller (dmi_free → free)
-  return DMI_OK;
-}
-int dmi_host_rabs_stream(uint8_t zero_prob, const uint8_t* bits, uint64_t n, dmi_buffer* out) {
-  if (!out || (!bits && n) || zero_prob == 0) return fail(DMI_ERR_INVALID_ARGUMENT, "bad argument");
-  const uint32_t p0 = zero_prob, f1 = 256u - p0;
-  const RansEntry e[2] = {make_rans_entry(p0, f1, 8), make_rans_entry(f1, 0, 8)};
-  HostChainOut o;
-  host_rabs_chain(bits, n, e, o);
-  if (o.err) return fail(o.err == 2 ? DMI_ERR_OUT_OF_MEMORY : DMI_ERR_ENTROPY, o.err == 1 ? "rABS state too large" : "host chain error");
-  out->data = o.data; out->len = o.len; out->cap = o.cap;
-  o.data = nullptr; o.cap = 0;
-  return DMI_OK;
-}
-
-int dmi_encode_mesh(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buffer* out) {
-  if (!out) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
-  dmi_buffer head{}, att{};
-  dmi_job* job = nullptr;
-  const bool trace = std::getenv("DMI_TRACE") != nullptr;
-  const auto t0 = std::chrono::steady_clock::now();
-  auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
-  int rc = dmi_mesh_prepare(mesh, cfg, &head, &job);
-  if (rc) return rc;
-  const double t_prep = ms();
-  rc = dmi_job_encode(job, &att);
-  const double t_enc = ms();
-  dmi_job_destroy(job);
-  const double t_destroy = ms();
-  if (rc) { dmi_free(&head); return rc; }
-  // header + connectivity + attribute section in one library-owned buffer
-  out->data = static_cast<uint8_t*>(std::malloc(head.len + att.len ? head.len + att.len : 1));
-  if (!out->data) { dmi_free(&head); dmi_free(&att); return fail(DMI_ERR_OUT_OF_MEMORY, "out of host memory"); }
-  std::memcpy(out->data, head.data, head.len);
-  std::memcpy(out->data + head.len, att.data, att.len);
-  out->len = out->cap = head.len + att.len;
-  dmi_free(&head);
-  dmi_free(&att);
-  if (trace) std::fprintf(stderr, "[dmi] encode_mesh: prepare %.1f ms, encode %.1f, job destroy %.1f, splice %.1f\n", t_prep, t_enc - t_prep, t_destroy - t_enc, ms() - t_destroy);
-  return DMI_OK;
 }
 
 }  // extern "C"

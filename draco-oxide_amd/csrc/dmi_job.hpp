@@ -1,0 +1,263 @@
+// dmi_job.hpp — internal types shared by the translation units behind the C ABI (include/draco_mi.h):
+//   dmi_job.cpp      job creation from caller-supplied tables, the encode phases of one job, the batch drivers
+//   dmi_prepare.cpp  whole-mesh entry points: host + device connectivity stage, dmi_mesh_prepare / dmi_meshes_prepare / dmi_encode_mesh
+// Device memory of a job (pooled chunks), pinned staging pools, the per-attribute and per-table device state.
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <mutex>
+#include <functional>
+#include <thread>
+
+#include "dmi_device.hpp"
+#include "dmi_host.hpp"
+#include "host_chains.hpp"
+
+namespace dmi {
+extern thread_local std::string g_last_error;
+inline int fail(int code, const std::string& msg) { return host_fail(code, msg); }
+
+#define HIP_TRY(expr)                                                                                              \
+  do {                                                                                                             \
+    hipError_t e_ = (expr);                                                                                        \
+    if (e_ != hipSuccess) {                                                                                        \
+      const bool nodev = (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice || e_ == hipErrorInsufficientDriver || e_ == hipErrorNotInitialized); \
+      return fail(nodev ? DMI_ERR_NO_DEVICE : (e_ == hipErrorOutOfMemory ? DMI_ERR_OUT_OF_MEMORY : DMI_ERR_HIP),    \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                                              \
+    }                                                                                                              \
+  } while (0)
+
+enum Scheme : uint8_t { kDelta = 0, kParallelogram = 1, kTexCoord = 5, kNormal = 6 };   // prediction_scheme/mod.rs:74-86
+enum Transform : uint8_t { kDifference = 0, kWrapped = 1, kOctOrth = 3 };              // prediction_transform/mod.rs:92-101
+enum Port : uint8_t { kToBits = 1, kCoordwise = 2, kOct = 3 };                          // portabilization/mod.rs:85-92
+constexpr uint32_t kMaxPrepareWorkers = 128;   // host threads of one dmi_meshes_prepare call
+constexpr uint32_t kPrepareStreams = 16;       // library streams their jobs are created on (per device)
+constexpr uint32_t kDeviceRelabelMinFaces = 1u << 20;   // job creation relabels the connectivity inputs with kernels from this size up (dmi_relabel.hip): its temporaries
+                                                      // are device allocations, whose release synchronises the device — a batch of mid-sized meshes on many threads must not take it
+constexpr uint64_t kHostChainMinSymbols = 32768;   // a job whose longest stream is at least this long codes its streams on host cores (hybrid form)
+// Device memory of one job comes from a few large chunks (DevPool) instead of one hipMalloc per buffer: job creation for a batch
+// of meshes runs on many host threads, and ≈ 70 allocations + ≈ 20 memsets per job serialise on the runtime (17 ms of
+// thread time per job before, most of it here).  A chunk is zeroed once when it is created, so pooled buffers start zeroed.
+// Released job chunks are kept (per device, in power-of-two size classes, up to kChunkCacheBytes in total) and handed to the next job of
+// that class: a transcode pipeline creates and destroys a thousand jobs per batch, and hipMalloc / hipFree serialise across the host
+// threads that do it (hipFree also synchronises the device).  A reused chunk is zeroed again on the new job's stream.
+struct ChunkCache {
+  struct Item { int device; void* p; size_t cap; };
+  std::mutex m;
+  std::vector<Item> items;
+  size_t bytes = 0;
+  static constexpr size_t kChunkCacheBytes = (size_t)64 << 30;
+  static size_t size_class(size_t n) {   // powers of two up to 1 GiB, multiples of 256 MiB above (a 100M-triangle job is 33 GB)
+    if (n > ((size_t)1 << 30)) return (n + (((size_t)1 << 28) - 1)) & ~(((size_t)1 << 28) - 1);
+    size_t c = (size_t)1 << 20;
+    while (c < n) c <<= 1;
+    return c;
+  }
+  void* acquire(int device, size_t cap) {
+    std::lock_guard<std::mutex> lock(m);
+    for (size_t k = items.size(); k-- > 0;)
+      if (items[k].device == device && items[k].cap == cap) { void* p = items[k].p; bytes -= cap; items.erase(items.begin() + (long)k); return p; }
+    return nullptr;
+  }
+  void drop_all() {
+    std::vector<Item> gone;
+    { std::lock_guard<std::mutex> lock(m); gone.swap(items); bytes = 0; }
+    int prev = 0;
+    const bool have_prev = hipGetDevice(&prev) == hipSuccess;
+    for (auto& it : gone) if (hipSetDevice(it.device) == hipSuccess) (void)hipFree(it.p);
+    if (have_prev) (void)hipSetDevice(prev);
+  }
+  bool release(int device, void* p, size_t cap) {   // false: not kept (the caller frees it)
+    std::lock_guard<std::mutex> lock(m);
+    if (bytes + cap > kChunkCacheBytes) return false;
+    items.push_back({device, p, cap});
+    bytes += cap;
+    return true;
+  }
+};
+extern ChunkCache g_chunk_cache;   // (process lifetime)
+
+struct DevPool {
+  struct Chunk { void* p; size_t cap, used; };
+  std::vector<Chunk> chunks;
+  size_t chunk_bytes = 0;
+  hipStream_t stream = nullptr;
+  int device = 0;
+  ~DevPool() { for (auto& c : chunks) if (c.p && !g_chunk_cache.release(device, c.p, c.cap)) (void)hipFree(c.p); }
+  void* take(size_t n) {
+    n = (n + 255) & ~(size_t)255;
+    if (chunks.empty() || chunks.back().used + n > chunks.back().cap) {
+      Chunk c{nullptr, ChunkCache::size_class(std::max(n, chunk_bytes)), 0};
+      c.p = g_chunk_cache.acquire(device, c.cap);
+      if (!c.p && hipMalloc(&c.p, c.cap) != hipSuccess) return nullptr;
+      if (hipMemsetAsync(c.p, 0, c.cap, stream) != hipSuccess) { (void)hipFree(c.p); return nullptr; }
+      chunks.push_back(c);
+    }
+    Chunk& c = chunks.back();
+    void* p = static_cast<uint8_t*>(c.p) + c.used;
+    c.used += n;
+    return p;
+  }
+};
+extern thread_local DevPool* g_active_pool;   // set while dmi_job_create runs on this thread
+
+struct DevMem {
+  void* p = nullptr;
+  size_t bytes = 0;
+  bool pooled = false;
+  ~DevMem() { if (p && !pooled) (void)hipFree(p); }
+  int alloc(size_t n) {
+    if (p && !pooled) (void)hipFree(p);
+    p = nullptr; pooled = false;
+    bytes = n;
+    if (n == 0) return DMI_OK;
+    if (g_active_pool) {
+      p = g_active_pool->take(n);
+      if (!p) return host_fail(DMI_ERR_HIP, "hipMalloc (job pool)");
+      pooled = true;
+      return DMI_OK;
+    }
+    HIP_TRY(hipMalloc(&p, n));
+    return DMI_OK;
+  }
+  template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+// A view into the job's slab (same accessors as DevMem, no ownership)
+struct SlabView {
+  void* p = nullptr;
+  size_t bytes = 0;
+  template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct TableDev {
+  uint32_t F = 0, V = 0, n_seq = 0;
+  DevMem fan_hdr, fan_apex, fan;   // fan rows (only for tables with a fused sweep)
+  DevMem c2r, opp, seq, s2p;   // c2r = corner → sequence index of its vertex; s2p = sequence index → point (= point_idx(seq[i]))
+  const uint32_t* s2p_host = nullptr;   // (during job creation, host-relabel form) the same array in the upload staging
+  // sharing: a table whose arrays equal another table's reuses its device copies
+  int alias_of = -1;
+};
+
+struct AuxInfo { uint8_t zero_prob = 0; uint32_t count = 0; int rans_desc = -1; int desc = -1; };
+
+struct AttJob {
+  dmi_attribute desc{};
+  Scheme scheme = kDelta;
+  Transform transform = kDifference;
+  Port port = kCoordwise;
+  int bits = 11;
+  int nq = 0;            // components after portabilization
+  int table = 0;         // index into tables
+  int parent = -1;
+  int fused_into = -1;   // ≥ 0: predicted by the fused seam-free sweep launched for that position attribute
+  int fused_nrm = -1, fused_uv = -1;   // (on a position attribute) the attributes its fused sweep also predicts
+  int qfmt = QF_I32;     // layout of qs (QFmt): packed for the attributes of a fused sweep whose widths allow it
+  bool sym16 = false;    // symbols stored as uint16 (alphabet bound ≤ 65536)
+  DevMem raw, s2v /*sequence index → value index, only with a point_to_value map*/, qs, sym, aux /*flips or orient*/, rtable, rec, out, partials, ipartials;
+  // views into dmi_job::slab — one memset, one read-back per encode: small = 16 scratch words (minmax[2], counters[2], flags[2], …,
+  // out_len[2]*2, ticks[2]), meta = quantization ranges, hist = symbol histogram (bins_cap words), summary = orientation chunk summaries
+  SlabView small, meta, hist, summary;
+  size_t slab_off = 0;
+  uint32_t bins_cap = 0;
+  uint32_t bins = 0;
+  uint64_t n_sym = 0;
+  uint64_t out_cap = 0, aux_cap = 0;
+  DevMem aux_out, aux_rec, chunk_info, batch_flags, aux_flags;
+  DevMem flip_partials;   // normals: per-block counts of the sweep (kSweepMaxBlocks words)
+  DevMem fix_list;        // texture coordinates of a fused sweep: the entries it defers to k_texcoord_fixup (≤ one per sequence entry)
+  uint32_t flip_blocks = 0;   // blocks of the sweep launched this encode
+  DevMem aux_bits;   // host-core chains: the compacted orientation transition bits (1 byte each)
+  DevMem freq, hdr, aux_entries;   // device form of the table stage: normalised-frequency scratch, serialised table, rABS record pair
+  uint32_t hdr_cap = 0;
+  DevMem fan_hdr, fan_apex, fan;   // fan rows of a normal attribute swept on its own table (position ranks, centre in apex)
+  FreqTable ft;
+  std::vector<RansEntry> rt_host;     // staging (kept alive until the copies have been issued)
+  std::vector<uint32_t> info_host;
+};
+}  // namespace dmi
+using namespace dmi;   // (internal header: every includer is a library translation unit)
+
+// hipStreamCreate costs ≈ 1 ms and serialises across host threads (31 ms per job with 32 creator threads): jobs created by
+// dmi_meshes_prepare share one library-owned stream per worker thread, kept for the life of the process.
+struct StreamHolder {
+  hipStream_t s = nullptr;
+  ~StreamHolder() { if (s) (void)hipStreamDestroy(s); }
+};
+extern thread_local std::shared_ptr<StreamHolder> g_adopt_stream;   // set by a dmi_meshes_prepare worker around dmi_job_create
+
+struct dmi_job {
+  dmi_config cfg{};
+  hipStream_t stream = nullptr;
+  std::shared_ptr<StreamHolder> stream_owner;   // set when the library created the stream
+  DevPool pool;   // (declared before every DevMem of the job: destroyed after them)
+  std::vector<AttJob> atts;
+  std::vector<TableDev> tables;
+  DevMem upload_region;   // every array job creation uploads, in one piece (host-relabel form): filled through one pinned staging copy
+  DevMem descs;
+  DevMem slab;   // small / meta / hist / summary of every attribute, laid out exactly like the pinned read-back buffer
+  void* pinned = nullptr;   // host-pinned readback area
+  size_t pinned_bytes = 0;
+  hipEvent_t ev[8]{};
+  bool have_events = false;
+  dmi_timings last{};
+  uint64_t predict_bytes = 0;
+  hipGraphExec_t graph_a = nullptr;   // phase A captured once (launch-bound for small meshes)
+  bool graph_tried = false;
+  uint8_t* readback = nullptr;     // where the slab of the current encode was read back to (pinned, or a batch arena slot)
+  bool dev_tables = false;         // tables, metadata parameters and chain descriptors are produced on the device (k_tables): no host round trip
+                                   // between the histograms and the chains (DMI_HOST_TABLES=1 or a ToBits attribute keep the host form)
+  uint8_t* out_pinned = nullptr;   // grow-only pinned arena for the coded bytes of one encode
+  size_t out_pinned_cap = 0;
+  // Hybrid form (host_chains.cpp): the streams of a single large mesh are coded on host cores from the device-built symbols and tables.
+  bool host_chains = false;
+  struct HostStage* stage = nullptr;                 // pinned staging of symbols / tables / metadata bits (process-wide pool)
+  std::vector<std::unique_ptr<HostChainOut>> host_out;   // [2·i] rANS stream of attribute i, [2·i + 1] its metadata rABS stream
+  std::vector<hipEvent_t> copy_ev;                   // "attribute i has arrived"
+  struct Run {   // state carried between the phases of one encode
+    std::vector<size_t> rans_off, aux_off;   // offsets into out_pinned
+    std::vector<const uint8_t*> rans_ptr, aux_ptr;   // host addresses of the coded bytes (pinned memory)
+    std::vector<uint32_t> rans_len, aux_len;
+    std::vector<const uint8_t*> hdr_ptr;     // serialised frequency tables (host form: FreqTable::header; device form: read back)
+    std::vector<uint32_t> hdr_len;
+    std::vector<size_t> hdr_off;
+    struct Pending { void* dst; const void* src; size_t bytes; };
+    std::vector<Pending> pending;   // host → device copies deferred to the batch driver (plan mode of phase B)
+    std::vector<size_t> pin_off;
+    std::vector<AuxInfo> aux;
+    std::vector<ChainDesc> descs;
+  } run;
+  ~dmi_job();
+  void release() {
+    if (stream) (void)hipStreamSynchronize(stream);   // (the job's device memory goes back to a cache, not through a synchronising hipFree)
+    if (pinned) (void)hipHostFree(pinned);
+    if (out_pinned) (void)hipHostFree(out_pinned);
+    if (graph_a) (void)hipGraphExecDestroy(graph_a);
+    if (have_events) for (auto& e : ev) (void)hipEventDestroy(e);
+    for (auto& e : copy_ev) (void)hipEventDestroy(e);
+  }
+};
+
+// Pinned host staging for the hybrid form, pooled for the life of the process: pinning ≈ 150 MB costs tens of milliseconds, which a
+// create → encode → destroy call (dmi_encode_attributes) would otherwise pay every time.
+struct HostStage {
+  int device = -1;
+  uint8_t* p = nullptr;
+  size_t cap = 0;
+  bool in_use = false;
+};
+HostStage* acquire_stage(int device, size_t bytes);
+void release_stage(HostStage* st);
+namespace dmi {
+int to_buffer(const std::vector<uint8_t>& v, dmi_buffer* out);
+struct TempDev {   // device temporaries of job creation (outside the job's pool: they are released when creation ends)
+  std::vector<void*> ptrs;
+  ~TempDev() { for (void* q : ptrs) (void)hipFree(q); }
+  template <class T> T* take(size_t n) { void* q = nullptr; if (hipMalloc(&q, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr; ptrs.push_back(q); return static_cast<T*>(q); }
+};
+}  // namespace dmi
