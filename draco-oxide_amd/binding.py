@@ -123,6 +123,7 @@ def load_library():
     L.dmi_job_timings.argtypes = [C.c_void_p, C.POINTER(_Timings)]
     L.dmi_job_destroy.argtypes = [C.c_void_p]
     L.dmi_encode_mesh.argtypes = [C.POINTER(_Mesh), C.POINTER(_Config), C.POINTER(_Buffer)]
+    L.dmi_device_corner_table.argtypes = [C.POINTER(_Mesh), C.POINTER(_Config), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.dmi_mesh_prepare.argtypes = [C.POINTER(_Mesh), C.POINTER(_Config), C.POINTER(_Buffer), C.POINTER(C.c_void_p)]
     L.dmi_mesh_build.argtypes = [C.POINTER(_RawAttribute), C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(_BuiltMesh)]
     L.dmi_built_mesh_free.argtypes = [C.POINTER(_BuiltMesh)]
@@ -603,6 +604,25 @@ def meshes_prepare(meshes, cfg=None):
 
 def encode_connectivity(mesh):
     return Connectivity(mesh)
+
+
+CONN_BAD_INDEX, CONN_DEGENERATE, CONN_NONMANIFOLD_EDGE, CONN_MULTI_FAN, CONN_UNUSED_VERTEX, CONN_HAS_BOUNDARY = 1, 2, 4, 8, 16, 32
+
+
+def device_corner_table(mesh, cfg=None):
+    """dmi_device_corner_table: the universal corner table of one mesh built by the device kernels (dmi_conn.hip), read back.
+    → dict(num_vertices, opposite, left_most_corner, on_boundary, flags); num_vertices == 0 with flags != 0: the host builder's case."""
+    L = load_library()
+    cfg = cfg or Config.default()
+    m, c = mesh._c(), cfg._c()
+    nf = len(mesh.faces)
+    cap = int(mesh.attributes[0].values.shape[0])
+    opp = np.zeros(3 * nf, np.uint32)
+    lmc = np.zeros(max(cap, 1), np.uint32)
+    onb = np.zeros(max(cap, 1), np.uint8)
+    nv, flags = C.c_uint32(0), C.c_uint32(0)
+    _check(L.dmi_device_corner_table(C.byref(m), C.byref(c), opp.ctypes.data, lmc.ctypes.data, onb.ctypes.data, C.byref(nv), C.byref(flags)))
+    return dict(num_vertices=nv.value, opposite=opp, left_most_corner=lmc[:nv.value], on_boundary=onb[:nv.value], flags=flags.value)
 
 
 def shard_meshes(meshes, n_devices):

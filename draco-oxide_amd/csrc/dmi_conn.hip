@@ -1,0 +1,282 @@
+// dmi_conn.hip — the order-free half of the connectivity stage on the device (gfx950, wave64), ONE launch per kernel for all meshes
+// of a batch (concatenated arrays with per-mesh offsets; ids stay mesh-local so that every mesh's slice is the table the host walks
+// and the relabelling kernels consume as they are).
+//
+// Reference stages (paths relative to draco-oxide/src/):
+//   k_conn_faces      core/corner_table/mod.rs:84-118     conn_faces = pos.p2v[face], the unused-vertex panic (:105-108) as a flag
+//   k_conn_fill/match core/corner_table/mod.rs:252-340    compute_table: opposite corners.  The reference matches half-edges in corner
+//                     order with per-vertex buckets; for a mesh without vertex-degenerate faces and with at most two faces on every
+//                     undirected edge the result does not depend on that order (corner c is linked to the one corner carrying the
+//                     reverse half-edge unless both have the same tip, Q22) — the argument of host_conn.cpp's order-free builder,
+//                     which this restates with device atomics.  Meshes outside that class are FLAGGED, and the host runs the
+//                     reference's serial walks on them (host_conn.cpp): nothing is approximated here.
+//   k_conn_vertices   core/corner_table/mod.rs:342-416    left-most corners when every vertex has one fan (else flagged: the serial
+//                     walk splits such vertices), and GenericCornerTable::is_on_boundary (:36-38) per vertex for the sequencer
+//   k_conn_seams      core/corner_table/attribute_corner_table.rs:25-64   seam edges of an attribute: only "does any edge with two faces
+//                     separate different attribute values" is decided here (a seam-free attribute takes the universal table, the
+//                     common case); an attribute with interior seams gets its table from the host builder.
+// Then the coding-order relabelling of small meshes, batched (the large-mesh form lives in dmi_relabel.hip):
+//   k_batch_rank / k_batch_face_key / k_batch_place / k_batch_bucket_sort / k_batch_remap / k_batch_remap_seq
+#include "dmi_device.hpp"
+#include <algorithm>
+
+namespace dmi {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr uint32_t kNoneD = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint32_t cnext(uint32_t c) { return (c % 3u == 2u) ? c - 2u : c + 1u; }
+__device__ __forceinline__ uint32_t cprev(uint32_t c) { return (c % 3u == 0u) ? c + 2u : c - 1u; }
+inline uint32_t grid_of(uint64_t n, uint32_t per_thread = 1) {
+  const uint64_t g = (n + (uint64_t)kBlock * per_thread - 1) / ((uint64_t)kBlock * per_thread);
+  return (uint32_t)(g > 65535ull * 32 ? 65535ull * 32 : (g ? g : 1));
+}
+
+// mesh of a global face / vertex index: the last mesh whose offset is ≤ x (offsets ascending; empty meshes share an offset with their successor)
+template <class Get>
+__device__ __forceinline__ uint32_t find_mesh(uint32_t M, uint32_t x, Get off) {
+  uint32_t lo = 0, hi = M;   // invariant: off(lo) ≤ x < off(hi) with off(M) = ∞
+  while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (off(mid) <= x) lo = mid; else hi = mid; }
+  return lo;
+}
+
+// ---- exclusive prefix sum over uint32 (in place): block sums → one block scans them → blocks rescan their tile ----
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kBlock * kScanItems;
+__device__ __forceinline__ uint32_t wave_inclusive(uint32_t v) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const uint32_t u = __shfl_up(v, off, 64); if ((int)(threadIdx.x & 63) >= off) v += u; }
+  return v;
+}
+// exclusive scan of one value per thread across the block; returns the thread's offset, *total = block sum
+__device__ __forceinline__ uint32_t block_exclusive(uint32_t v, uint32_t* total) {
+  __shared__ uint32_t wsum[kBlock / 64 + 1];
+  const uint32_t inc = wave_inclusive(v);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();   // (wsum may still be read by a previous call)
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w) { if (w < wave) base += wsum[w]; all += wsum[w]; }
+  if (total) *total = all;
+  return base + inc - v;
+}
+__global__ __launch_bounds__(kBlock) void k_scan_reduce(const uint32_t* __restrict__ data, uint32_t n, uint32_t* __restrict__ partials) {
+  const uint32_t base = blockIdx.x * kScanTile;
+  uint32_t sum = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) { const uint32_t i = base + k * kBlock + threadIdx.x; if (i < n) sum += data[i]; }
+  uint32_t total;
+  (void)block_exclusive(sum, &total);
+  if (threadIdx.x == 0) partials[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(kBlock) void k_scan_partials(uint32_t* __restrict__ partials, uint32_t n_partials) {
+  // one block: every thread owns a contiguous slice of the partials
+  const uint32_t per = (n_partials + kBlock - 1) / kBlock;
+  const uint32_t lo = min(n_partials, threadIdx.x * per), hi = min(n_partials, lo + per);
+  uint32_t sum = 0;
+  for (uint32_t i = lo; i < hi; ++i) sum += partials[i];
+  uint32_t run = block_exclusive(sum, nullptr);
+  for (uint32_t i = lo; i < hi; ++i) { const uint32_t v = partials[i]; partials[i] = run; run += v; }
+}
+__global__ __launch_bounds__(kBlock) void k_scan_apply(uint32_t* __restrict__ data, uint32_t n, const uint32_t* __restrict__ partials) {
+  // thread t owns items [t·kScanItems, (t+1)·kScanItems) of the tile (a serial scan in registers, then a block scan of the thread sums)
+  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+  uint32_t v[kScanItems], sum = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) { v[k] = (base + k < n) ? data[base + k] : 0u; sum += v[k]; }
+  uint32_t run = block_exclusive(sum, nullptr) + partials[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) { if (base + k < n) data[base + k] = run; run += v[k]; }
+}
+
+// A flag is raised by at most a few atomics however many threads find its cause (same-address atomics serialise at ≈ 11 ns each).
+__device__ __forceinline__ void raise(uint32_t* flags, uint32_t m, uint32_t bit) {
+  if (!(__atomic_load_n(&flags[m], __ATOMIC_RELAXED) & bit)) atomicOr(&flags[m], bit);
+}
+// per-mesh maximum: one atomic per wavefront when all its lanes are in the same mesh
+__device__ __forceinline__ void mesh_max(uint32_t* dst, uint32_t m, uint32_t v, bool have) {
+  const uint64_t mask = __ballot(have);
+  if (mask == 0ull) return;   // (wave-uniform)
+  const uint32_t m0 = __shfl(m, __ffsll((long long)mask) - 1, 64);
+  if (__ballot(have && m != m0) == 0ull) {
+    uint32_t x = have ? v : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x = max(x, (uint32_t)__shfl_down(x, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(&dst[m0], x);
+  } else if (have) {
+    atomicMax(&dst[m], v);
+  }
+}
+
+// ---- universal corner tables of a batch ----
+// per face: vertex ids (through the position map), range / degenerate checks, half-edge counts per bucket (= smaller endpoint of the
+// edge), first corner per vertex, largest vertex id per mesh
+__global__ __launch_bounds__(kBlock) void k_conn_faces(const ConnArgs a) {
+  uint32_t cur_m = kNoneD, cur_max = 0;   // largest vertex id seen for mesh cur_m (a single large mesh: the grid is capped and every thread loops)
+  for (uint32_t f = blockIdx.x * kBlock + threadIdx.x; f < a.total_faces; f += gridDim.x * kBlock) {
+    const uint32_t m = a.M == 1 ? 0u : find_mesh(a.M, f, [&](uint32_t k) { return a.meshes[k].face_off; });
+    if (m != cur_m) { if (cur_m != kNoneD) atomicMax(&a.vmax[cur_m], cur_max); cur_m = m; cur_max = 0; }
+    const ConnMeshDesc d = a.meshes[m];
+    const uint32_t lf = f - d.face_off;
+    uint32_t v[3];
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const uint32_t p = a.faces[3ull * f + k];
+      if (p >= d.num_points) { bad = true; v[k] = 0; continue; }
+      v[k] = d.p2v_off != kNoneD ? a.p2v[d.p2v_off + p] : p;
+      if (v[k] >= d.Vcap) { bad = true; v[k] = 0; }
+    }
+    if (a.c2v != a.faces) { a.c2v[3ull * f] = v[0]; a.c2v[3ull * f + 1] = v[1]; a.c2v[3ull * f + 2] = v[2]; }
+    if (bad) { raise(a.flags, m, CONN_BAD_INDEX); continue; }
+    if (v[0] == v[1] || v[1] == v[2] || v[0] == v[2]) { raise(a.flags, m, CONN_DEGENERATE); continue; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      atomicAdd(&a.ecount[d.vert_off + min(v[k], v[(k + 1) % 3])], 1u);
+      atomicMin(&a.first[d.vert_off + v[k]], 3u * lf + k);
+    }
+    cur_max = max(cur_max, max(v[0], max(v[1], v[2])));
+  }
+  mesh_max(a.vmax, cur_m, cur_max, cur_m != kNoneD);
+}
+// per corner: its half-edge (source = vertex(next), sink = vertex(prev)) into the bucket of the smaller endpoint, keyed by the larger one
+// and the direction (bit 31: the half-edge runs from the larger endpoint down)
+__global__ __launch_bounds__(kBlock) void k_conn_fill(const ConnArgs a) {
+  const uint64_t C = 3ull * a.total_faces;
+  for (uint64_t c = (uint64_t)blockIdx.x * kBlock + threadIdx.x; c < C; c += (uint64_t)gridDim.x * kBlock) {
+    const uint32_t f = (uint32_t)(c / 3u);
+    const uint32_t m = find_mesh(a.M, f, [&](uint32_t k) { return a.meshes[k].face_off; });
+    if (a.flags[m] & (CONN_BAD_INDEX | CONN_DEGENERATE)) continue;   // (the host builds this mesh's tables)
+    const ConnMeshDesc d = a.meshes[m];
+    const uint32_t lc = (uint32_t)(c - 3ull * d.face_off);
+    const uint64_t cb = 3ull * d.face_off;
+    const uint32_t src = a.c2v[cb + cnext(lc)], snk = a.c2v[cb + cprev(lc)];
+    const uint32_t low = min(src, snk);
+    const uint32_t slot = a.ecount[d.vert_off + low] + atomicAdd(&a.efill[d.vert_off + low], 1u);   // ecount holds the bucket starts by now
+    a.he_key[slot] = src < snk ? snk : (src | 0x80000000u);
+    a.he_corner[slot] = lc;
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_conn_match(const ConnArgs a) {
+  const uint64_t C = 3ull * a.total_faces;
+  for (uint64_t c = (uint64_t)blockIdx.x * kBlock + threadIdx.x; c < C; c += (uint64_t)gridDim.x * kBlock) {
+    const uint32_t f = (uint32_t)(c / 3u);
+    const uint32_t m = find_mesh(a.M, f, [&](uint32_t k) { return a.meshes[k].face_off; });
+    if (a.flags[m] & (CONN_BAD_INDEX | CONN_DEGENERATE)) { a.opp[c] = kNoneD; continue; }
+    const ConnMeshDesc d = a.meshes[m];
+    const uint32_t lc = (uint32_t)(c - 3ull * d.face_off);
+    const uint64_t cb = 3ull * d.face_off;
+    const uint32_t tip = a.c2v[c], src = a.c2v[cb + cnext(lc)], snk = a.c2v[cb + cprev(lc)];
+    const uint32_t low = min(src, snk);
+    const uint32_t mine = src < snk ? snk : (src | 0x80000000u), against = mine ^ 0x80000000u;
+    uint32_t same = 0, rev = 0, found = kNoneD;
+    for (uint32_t s = a.ecount[d.vert_off + low], e = a.ecount[d.vert_off + low + 1]; s < e; ++s) {
+      const uint32_t k = a.he_key[s];
+      same += k == mine;
+      if (k == against) { ++rev; found = a.he_corner[s]; }
+    }
+    if (same + rev > 2) raise(a.flags, m, CONN_NONMANIFOLD_EDGE);
+    const uint32_t o = (rev == 1 && same == 1 && a.c2v[cb + found] != tip) ? found : kNoneD;
+    a.opp[c] = o;
+    if (o == kNoneD) raise(a.flags, m, CONN_HAS_BOUNDARY);
+  }
+}
+// per vertex: left-most corner of its (single) fan, the boundary flag; every corner of the fan is ticked off in cdone
+__global__ __launch_bounds__(kBlock) void k_conn_vertices(const ConnArgs a) {
+  for (uint32_t gv = blockIdx.x * kBlock + threadIdx.x; gv < a.total_verts; gv += gridDim.x * kBlock) {
+    const uint32_t m = find_mesh(a.M, gv, [&](uint32_t k) { return a.meshes[k].vert_off; });
+    const ConnMeshDesc d = a.meshes[m];
+    const uint32_t v = gv - d.vert_off;
+    a.lmc[gv] = kNoneD;
+    a.on_boundary[gv] = 0;
+    if (a.flags[m] & (CONN_BAD_INDEX | CONN_DEGENERATE | CONN_NONMANIFOLD_EDGE)) continue;
+    if (d.F == 0 || v > a.vmax[m]) continue;   // ids past the largest referenced one are not vertices of the table (V = max + 1)
+    const uint32_t c = a.first[gv];
+    if (c == kNoneD) { raise(a.flags, m, CONN_UNUSED_VERTEX); continue; }
+    const uint64_t cb = 3ull * d.face_off;
+    const uint32_t* __restrict__ opp = a.opp + cb;
+    uint8_t* __restrict__ done = a.cdone + cb;
+    auto swing_left = [&](uint32_t x) { const uint32_t o = opp[cnext(x)]; return o == kNoneD ? kNoneD : cnext(o); };
+    auto swing_right = [&](uint32_t x) { const uint32_t o = opp[cprev(x)]; return o == kNoneD ? kNoneD : cprev(o); };
+    uint32_t left = c, x = swing_left(c), steps = 0;
+    done[c] = 1;
+    while (x != kNoneD && x != c && steps < (1u << 20)) { done[x] = 1; left = x; x = swing_left(x); ++steps; }
+    if (steps >= (1u << 20)) { raise(a.flags, m, CONN_MULTI_FAN); continue; }
+    if (x == kNoneD) {   // open fan: the corners to the right of c
+      steps = 0;
+      for (uint32_t r = swing_right(c); r != kNoneD && steps < (1u << 20); r = swing_right(r), ++steps) done[r] = 1;
+    }
+    a.lmc[gv] = left;
+    a.on_boundary[gv] = opp[cnext(left)] == kNoneD ? 1 : 0;
+  }
+}
+// a corner no fan ticked off: its vertex has several fans (the serial walk splits it into several vertices: mod.rs:368-385)
+__global__ __launch_bounds__(kBlock) void k_conn_check(const ConnArgs a) {
+  const uint64_t C = 3ull * a.total_faces;
+  for (uint64_t c = (uint64_t)blockIdx.x * kBlock + threadIdx.x; c < C; c += (uint64_t)gridDim.x * kBlock) {
+    if (a.cdone[c]) continue;
+    const uint32_t m = find_mesh(a.M, (uint32_t)(c / 3u), [&](uint32_t k) { return a.meshes[k].face_off; });
+    if (a.flags[m] & (CONN_BAD_INDEX | CONN_DEGENERATE | CONN_NONMANIFOLD_EDGE)) continue;
+    raise(a.flags, m, CONN_MULTI_FAN);
+  }
+}
+
+// attribute_corner_table.rs:44-63 for one attribute of every mesh: does any edge with two faces separate different values?
+__global__ __launch_bounds__(kBlock) void k_conn_seams(const ConnSeamArgs a) {
+  const uint64_t C = 3ull * a.total_faces;
+  for (uint64_t c = (uint64_t)blockIdx.x * kBlock + threadIdx.x; c < C; c += (uint64_t)gridDim.x * kBlock) {
+    const uint32_t m = find_mesh(a.M, (uint32_t)(c / 3u), [&](uint32_t k) { return a.meshes[k].face_off; });
+    const uint32_t map_off = a.map_off[m];
+    if (map_off == kConnMapSkip) continue;   // no such attribute / indexed like the Position attribute: boundary edges are its only seams
+    const ConnMeshDesc d = a.meshes[m];
+    const uint64_t cb = 3ull * d.face_off;
+    const uint32_t lc = (uint32_t)(c - cb);
+    const uint32_t o = a.opp[c];
+    if (o == kNoneD || o < lc) continue;
+    auto val = [&](uint32_t corner) { const uint32_t p = a.faces[cb + corner]; return map_off == kConnMapIdentity ? p : a.maps[map_off + p]; };
+    if (val(cnext(lc)) != val(cprev(o)) || val(cprev(lc)) != val(cnext(o))) a.interior[m] = 1u;   // (same value from every writer)
+  }
+}
+
+}  // namespace
+
+void launch_exclusive_scan_u32(uint32_t* data, uint32_t n, uint32_t* partials, hipStream_t s) {
+  if (!n) return;
+  const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
+  hipLaunchKernelGGL(k_scan_reduce, tiles, kBlock, 0, s, data, n, partials);
+  hipLaunchKernelGGL(k_scan_partials, 1, kBlock, 0, s, partials, tiles);
+  hipLaunchKernelGGL(k_scan_apply, tiles, kBlock, 0, s, data, n, partials);
+}
+size_t scan_partials_words(uint32_t n) { return (size_t)(n + kScanTile - 1) / kScanTile + 1; }
+
+// flags / vmax / efill / cdone zeroed, first filled with DMI_NONE, ecount zeroed by the caller's memsets (conn_tables_clear)
+hipError_t conn_tables_clear(const ConnArgs& a, hipStream_t s) {
+  hipError_t e;
+  const size_t nv = (size_t)a.total_verts + 1, C = 3ull * a.total_faces;
+  if ((e = hipMemsetAsync(a.flags, 0, (size_t)a.M * 4, s)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(a.vmax, 0, (size_t)a.M * 4, s)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(a.ecount, 0, nv * 4, s)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(a.efill, 0, nv * 4, s)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(a.first, 0xFF, nv * 4, s)) != hipSuccess) return e;
+  if (C && (e = hipMemsetAsync(a.cdone, 0, C, s)) != hipSuccess) return e;
+  return hipSuccess;
+}
+void launch_conn_tables(const ConnArgs& a, hipStream_t s) {
+  if (!a.total_faces || !a.M) return;
+  const uint64_t C = 3ull * a.total_faces;
+  hipLaunchKernelGGL(k_conn_faces, a.M == 1 ? std::min(grid_of(a.total_faces), 2048u) : grid_of(a.total_faces), kBlock, 0, s, a);
+  launch_exclusive_scan_u32(a.ecount, a.total_verts + 1, a.scan_partials, s);
+  hipLaunchKernelGGL(k_conn_fill, grid_of(C), kBlock, 0, s, a);
+  hipLaunchKernelGGL(k_conn_match, grid_of(C), kBlock, 0, s, a);
+  hipLaunchKernelGGL(k_conn_vertices, grid_of(a.total_verts), kBlock, 0, s, a);
+  hipLaunchKernelGGL(k_conn_check, grid_of(C), kBlock, 0, s, a);
+}
+void launch_conn_seams(const ConnSeamArgs& a, hipStream_t s) {
+  if (!a.total_faces || !a.M) return;
+  hipLaunchKernelGGL(k_conn_seams, grid_of(3ull * a.total_faces), kBlock, 0, s, a);
+}
+
+}  // namespace dmi

@@ -59,7 +59,17 @@ struct Reader {
   uint8_t r8() { if (at >= n) { ok = false; return 0; } return p[at++]; }
   uint32_t r32() { uint32_t v = 0; for (int k = 0; k < 4; ++k) v |= (uint32_t)r8() << (8 * k); return v; }
   float rf32() { const uint32_t b = r32(); float f; std::memcpy(&f, &b, 4); return f; }
-  uint64_t leb() { uint64_t v = 0; uint32_t sh = 0; uint8_t b; do { b = r8(); v |= (uint64_t)(b & 0x7F) << sh; sh += 7; } while ((b & 0x80) && ok && sh < 70); return v; }
+  // at most ten bytes; a tenth byte may only carry bit 63 (anything longer or larger is a malformed section, not a wrapped shift)
+  uint64_t leb() {
+    uint64_t v = 0; uint32_t sh = 0; uint8_t b;
+    do {
+      b = r8();
+      if (sh == 63 && (b & 0x7E)) { ok = false; return 0; }
+      v |= (uint64_t)(b & 0x7F) << sh; sh += 7;
+    } while ((b & 0x80) && ok && sh < 70);
+    if (b & 0x80) ok = false;
+    return v;
+  }
 };
 
 // DirectCoded symbols (decode/entropy/symbol_coding.rs:125-210 + RansSymbolDecoder::new rans.rs:139-200): method, bit_length,
@@ -87,7 +97,7 @@ int decode_symbols(Reader& r, uint64_t n, std::vector<uint32_t>& out) {
     }
   }
   const uint64_t nbytes = r.leb();
-  if (!r.ok || r.at + nbytes > r.n) return host_fail(DMI_ERR_ENTROPY, "symbol stream past the section");
+  if (!r.ok || nbytes > r.n - r.at) return host_fail(DMI_ERR_ENTROPY, "symbol stream past the section");   // (no addition: nbytes is attacker-controlled)
   out.resize((size_t)n);
   if (!host_rans_decode(r.p + r.at, (size_t)nbytes, freq.data(), (uint32_t)num_symbols, P, n, out.data())) return host_fail(DMI_ERR_ENTROPY, "truncated or inconsistent rANS stream");
   r.at += (size_t)nbytes;
@@ -208,7 +218,7 @@ int dmi_decode_attributes(const uint8_t* section, size_t len, const dmi_corner_t
     auto read_rabs = [&](uint64_t count) -> int {
       const uint8_t zp = r.r8();
       const uint64_t nbytes = r.leb();
-      if (!r.ok || zp == 0 || r.at + nbytes > len) return host_fail(DMI_ERR_ENTROPY, "truncated rABS block");
+      if (!r.ok || zp == 0 || nbytes > len - r.at) return host_fail(DMI_ERR_ENTROPY, "truncated rABS block");
       bits.resize((size_t)count);
       if (!host_rabs_decode(section + r.at, (size_t)nbytes, zp, count, bits.data())) return host_fail(DMI_ERR_ENTROPY, "truncated rABS stream");
       r.at += (size_t)nbytes;

@@ -235,4 +235,42 @@ void launch_remap_seq(const uint32_t* seq, uint32_t n_seq, const uint32_t* new_f
 void launch_compose_s2v(const uint32_t* s2p, uint32_t n_seq, const uint32_t* p2v, uint32_t num_points, uint32_t num_unique, uint32_t* s2v, uint32_t* bad, hipStream_t s);
 void launch_max_u32(const uint32_t* a, uint64_t n, uint32_t* out /* pre-zeroed */, hipStream_t s);
 
+
+// ---- connectivity tables on the device (dmi_conn.hip): the order-free half of the connectivity stage, batched ----
+// M meshes concatenated: corner arrays are indexed by global corner (3·face_off[m] + local corner), vertex arrays by global vertex
+// (vert_off[m] + local vertex, Vcap[m] slots per mesh = the Position attribute's value count); the ids STORED are mesh-local.
+struct ConnMeshDesc { uint32_t face_off, vert_off, F, Vcap; uint32_t p2v_off /* into ConnArgs::p2v, DMI_NONE = identity */, num_points, pad0, pad1; };
+enum ConnFlag : uint32_t {
+  CONN_BAD_INDEX = 1,          // a face index ≥ num_points or a position value index ≥ Vcap → DMI_ERR_INVALID_ARGUMENT
+  CONN_DEGENERATE = 2,         // a vertex-degenerate face        ┐
+  CONN_NONMANIFOLD_EDGE = 4,   // an edge with more than two faces ├ the result depends on the corner order: the host runs the reference's serial walks
+  CONN_MULTI_FAN = 8,          // a vertex with several fans       ┘
+  CONN_UNUSED_VERTEX = 16,     // an id below the largest referenced one that no face uses (mod.rs:105-108 panic) → DMI_ERR_UNUSED_VERTICES
+  CONN_HAS_BOUNDARY = 32       // some corner has no opposite (information: the Edgebreaker's boundary labelling can be skipped without it)
+};
+struct ConnArgs {
+  const ConnMeshDesc* meshes; uint32_t M, total_faces, total_verts, pad;
+  const uint32_t* faces;   // 3·total_faces point ids
+  const uint32_t* p2v;     // concatenated position maps (nullable)
+  uint32_t* c2v;           // out: vertex per corner; == faces when no mesh has a position map (then not written)
+  uint32_t* opp;           // out
+  uint32_t* lmc;           // out: per vertex
+  uint8_t* on_boundary;    // out: per vertex
+  uint32_t* flags;         // out: M words of ConnFlag
+  uint32_t* vmax;          // out: M words, the largest vertex id a face references (V = vmax + 1)
+  uint32_t *ecount, *efill, *first;   // scratch: total_verts + 1 words each
+  uint32_t *he_key, *he_corner;       // scratch: 3·total_faces words each
+  uint8_t* cdone;                     // scratch: 3·total_faces bytes
+  uint32_t* scan_partials;            // scratch: scan_partials_words(total_verts + 1)
+};
+hipError_t conn_tables_clear(const ConnArgs& a, hipStream_t s);   // the memsets launch_conn_tables expects
+void launch_conn_tables(const ConnArgs& a, hipStream_t s);
+// one attribute of every mesh: interior[m] = 1 when an edge with two faces separates different values of the attribute
+// map_off[m]: offset of the attribute's point → value map in `maps`, kConnMapIdentity = identity, kConnMapSkip = nothing to decide for this mesh
+constexpr uint32_t kConnMapIdentity = 0xFFFFFFFFu, kConnMapSkip = 0xFFFFFFFEu;
+struct ConnSeamArgs { const ConnMeshDesc* meshes; uint32_t M, total_faces; const uint32_t* faces; const uint32_t* opp; const uint32_t* maps; const uint32_t* map_off; uint32_t* interior /* zeroed */; };
+void launch_conn_seams(const ConnSeamArgs& a, hipStream_t s);
+void launch_exclusive_scan_u32(uint32_t* data, uint32_t n, uint32_t* partials, hipStream_t s);   // in place
+size_t scan_partials_words(uint32_t n);
+
 }  // namespace dmi

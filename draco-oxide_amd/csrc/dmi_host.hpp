@@ -177,11 +177,15 @@ struct AttTable {
 
 struct CornerTables {
   uint32_t F = 0, V = 0;
-  std::vector<uint32_t> c2p, c2v, opp, lmc;
+  // What every reader uses.  The arrays live in the *_own vectors when the host builds the tables (build_universal), in the caller's
+  // face array (c2p, and c2v of a mesh without a position map) or in the pinned read-back of the device-built tables (dmi_prepare.cpp).
+  const uint32_t *c2p = nullptr, *c2v = nullptr, *opp = nullptr, *lmc = nullptr;
+  std::vector<uint32_t> c2p_own, c2v_own, opp_own, lmc_own;
+  bool no_boundary = false;   // known: every corner has an opposite (the device pass reports it) — the Edgebreaker skips its boundary labelling scan
   std::vector<AttTable> att;   // one per non-position attribute, in attribute order
 
-  // pos_p2v: point→position value index (NULL = identity).  Returns a dmi_status.
-  int build_universal(const uint32_t* faces, uint32_t num_faces, const uint32_t* pos_p2v, std::string& err);
+  // pos_p2v: point→position value index (NULL = identity).  Returns a dmi_status.  copy_faces = false: c2p views `faces` itself.
+  int build_universal(const uint32_t* faces, uint32_t num_faces, const uint32_t* pos_p2v, std::string& err, bool copy_faces = true);
   // att_p2v: point→value index of the attribute (NULL = identity).
   void build_attribute(const uint32_t* att_p2v);
   // thread-safe w.r.t. other attribute tables.  same_as_position: att_p2v is the Position attribute's own map — no edge can be a seam

@@ -18,6 +18,27 @@ thread_local std::shared_ptr<StreamHolder> g_adopt_stream;
 
 static std::mutex g_stage_mutex;
 static std::vector<HostStage*> g_stages;   // (never freed: process-lifetime staging)
+// Staging memory is ordinary host memory on transparent huge pages, registered with the runtime (page-locked, DMA at pinned-memory speed):
+// the host's serial walks read the device-built tables straight out of it, and with 4 KiB pages — what hipHostMalloc hands out — nearly
+// every step of such a walk misses the TLB (Edgebreaker traversal of the 10M-triangle grid: 78 ms on huge pages, 110–130 ms without).
+// hipHostMalloc remains the fallback where registration fails.
+static void stage_free(HostStage* st) {
+  if (st->p) { if (st->registered) { (void)hipHostUnregister(st->p); std::free(st->p); } else (void)hipHostFree(st->p); }
+  st->p = nullptr; st->cap = 0; st->registered = false;
+}
+static bool stage_alloc(HostStage* st, size_t want) {
+  static const bool plain = std::getenv("DMI_NO_THP") != nullptr;
+  void* q = nullptr;
+  if (!plain && want >= ((size_t)4 << 20) && posix_memalign(&q, (size_t)2 << 20, want) == 0 && q) {
+    advise_huge_pages(q, want);
+    if (hipHostRegister(q, want, hipHostRegisterDefault) == hipSuccess) { st->p = static_cast<uint8_t*>(q); st->cap = want; st->registered = true; return true; }
+    (void)hipGetLastError();
+    std::free(q);
+  }
+  if (hipHostMalloc(reinterpret_cast<void**>(&st->p), want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); st->p = nullptr; return false; }
+  st->cap = want; st->registered = false;
+  return true;
+}
 HostStage* acquire_stage(int device, size_t bytes) {
   HostStage* best = nullptr;
   {
@@ -31,11 +52,15 @@ HostStage* acquire_stage(int device, size_t bytes) {
     best->in_use = true;
   }
   if (best->cap < bytes) {
-    if (best->p) (void)hipHostFree(best->p);
-    best->p = nullptr; best->cap = 0;
+    stage_free(best);
     const size_t want = ChunkCache::size_class(bytes);   // (size classes: a worker's next mesh rarely makes its stage grow again)
-    if (hipHostMalloc(reinterpret_cast<void**>(&best->p), want, hipHostMallocDefault) != hipSuccess) { best->p = nullptr; std::lock_guard<std::mutex> lock(g_stage_mutex); best->in_use = false; return nullptr; }
-    best->cap = want;
+    if (!stage_alloc(best, want)) {
+      {   // pinned memory exhausted with idle stages parked: release them and try once more
+        std::lock_guard<std::mutex> lock(g_stage_mutex);
+        for (HostStage* st : g_stages) if (!st->in_use && st->p) stage_free(st);
+      }
+      if (!stage_alloc(best, want)) { std::lock_guard<std::mutex> lock(g_stage_mutex); best->in_use = false; return nullptr; }
+    }
   }
   return best;
 }
@@ -160,11 +185,7 @@ void dmi_release_cached_memory(void) {
   host_pool_drop_all();
   g_chunk_cache.drop_all();
   std::lock_guard<std::mutex> lock(g_stage_mutex);
-  for (HostStage* st : g_stages) {
-    if (st->in_use || !st->p) continue;
-    (void)hipHostFree(st->p);
-    st->p = nullptr; st->cap = 0;
-  }
+  for (HostStage* st : g_stages) if (!st->in_use && st->p) stage_free(st);
 }
 
 void dmi_free(dmi_buffer* b) {
@@ -192,6 +213,14 @@ extern "C" {
 
 int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, uint32_t n_atts, const uint32_t* seeds, uint32_t n_seeds,
                    const dmi_config* cfg_in, dmi_job** job_out) {
+  return dmi::job_create_impl(atts, tables, n_atts, seeds, n_seeds, cfg_in, nullptr, job_out);
+}
+}  // extern "C"
+
+// dev (nullable): the universal table's arrays as the device connectivity stage left them in HBM (dmi_prepare.cpp) — every table whose
+// host arrays are tables[0]'s takes them from there instead of the host (no upload, no range check: the library built them).
+int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tables, uint32_t n_atts, const uint32_t* seeds, uint32_t n_seeds,
+                         const dmi_config* cfg_in, const DeviceTableView* dev, dmi_job** job_out) {
   if (!atts || !tables || !job_out || n_atts == 0 || n_atts > 255) return fail(DMI_ERR_INVALID_ARGUMENT, "null argument or bad attribute count");
   dmi_config cfg{};
   if (cfg_in) cfg = *cfg_in;
@@ -273,7 +302,8 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
       if (same) t.alias_of = (int)j;
     }
     if (t.alias_of >= 0) { job->atts[i].table = t.alias_of; continue; }
-    {   // caller-supplied tables index host and device arrays below: every entry of a distinct table is range-checked once, here (error codes, not crashes)
+    const bool from_device = dev && tables[i].corner_to_vertex == tables[0].corner_to_vertex && tables[i].opposite == tables[0].opposite;
+    if (!from_device) {   // caller-supplied tables index host and device arrays below: every entry of a distinct table is range-checked once, here (error codes, not crashes)
       const uint32_t V = tables[i].num_vertices;
       const uint32_t* c2v = tables[i].corner_to_vertex;
       const uint32_t* opp = tables[i].opposite;
@@ -299,7 +329,7 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
       seq = host_seq[i].data();
       n_seq = (uint32_t)host_seq[i].size();
     }
-    {
+    if (!(from_device && dev->trusted_sequences)) {
       std::atomic<int> bad_seq{0};
       parallel_for(n_seq, [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) if (seq[k] >= C) { bad_seq.store(1); break; } });
       if (bad_seq) return fail(DMI_ERR_INVALID_ARGUMENT, "sequence entry out of range");
@@ -326,17 +356,28 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
     m.p = stage_dev + at; m.bytes = bytes; m.pooled = true;   // (a view: the region owns the memory)
     return stage_host + at;
   };
-  bool device_relabel = F >= kDeviceRelabelMinFaces;
-  if (const char* e = std::getenv("DMI_RELABEL")) device_relabel = std::strcmp(e, "device") == 0 ? true : (std::strcmp(e, "host") == 0 ? false : device_relabel);
+  bool device_relabel = F >= kDeviceRelabelMinFaces || dev != nullptr;
+  if (const char* e = std::getenv("DMI_RELABEL")) device_relabel = std::strcmp(e, "device") == 0 ? true : (std::strcmp(e, "host") == 0 ? (dev != nullptr) : device_relabel);
   TempDev tmpdev;
+  {
+    size_t hint = (size_t)64 << 10;
+    for (uint32_t i = 0; i < n_atts; ++i) if (atts[i].point_to_value) hint += (size_t)atts[i].num_points * 4 + 256;
+    uint32_t max_seq = 0, max_v = 0;
+    for (uint32_t i = 0; i < n_atts; ++i) if (job->tables[i].alias_of < 0) { max_seq = std::max(max_seq, job->tables[i].n_seq); max_v = std::max(max_v, job->tables[i].V); }
+    hint += C * 4 * 3 + ((size_t)max_seq + max_v) * 4 + (size_t)F * 4 * 9 + ((size_t)1 << 20);   // (sort scratch ≈ two key/value pairs)
+    tmpdev.init(cfg.device, s, hint);
+  }
   uint32_t* d_bad = nullptr;        // device flag: a point_to_value entry out of range (device form)
   uint32_t* d_max_point = nullptr;  // device word: largest point index the faces reference (device form)
   if (device_relabel) {
     uint32_t max_seq = 0, max_v = 0;
     for (uint32_t i = 0; i < n_atts; ++i) if (job->tables[i].alias_of < 0) { max_seq = std::max(max_seq, job->tables[i].n_seq); max_v = std::max(max_v, job->tables[i].V); }
-    uint32_t* d_c2p = tmpdev.take<uint32_t>(C);
-    uint32_t* d_c2v = tmpdev.take<uint32_t>(C);
-    uint32_t* d_opp = tmpdev.take<uint32_t>(C);
+    bool host_tables = !dev;   // some table still comes from host arrays
+    for (uint32_t i = 0; i < n_atts && dev; ++i)
+      if (job->tables[i].alias_of < 0 && !(tables[i].corner_to_vertex == tables[0].corner_to_vertex && tables[i].opposite == tables[0].opposite)) host_tables = true;
+    const uint32_t* d_c2p = dev ? dev->c2p : tmpdev.take<uint32_t>(C);
+    uint32_t* d_c2v_up = host_tables ? tmpdev.take<uint32_t>(C) : nullptr;
+    uint32_t* d_opp_up = host_tables ? tmpdev.take<uint32_t>(C) : nullptr;
     uint32_t* d_seq = tmpdev.take<uint32_t>(max_seq);
     uint32_t* d_rank = tmpdev.take<uint32_t>(max_v);
     uint32_t* d_key = tmpdev.take<uint32_t>(F);
@@ -350,17 +391,22 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
     while (key_bits < 32 && (1ull << key_bits) <= none_key) ++key_bits;
     const size_t sort_bytes = sort_faces_temp_bytes(F, key_bits);
     void* d_sort = tmpdev.take<uint8_t>(sort_bytes);
-    if (!d_c2p || !d_c2v || !d_opp || !d_seq || !d_rank || !d_key || !d_key2 || !d_face || !d_order || !d_new_face || !d_words || !d_sort)
+    if (!d_c2p || (host_tables && (!d_c2v_up || !d_opp_up)) || !d_seq || !d_rank || !d_key || !d_key2 || !d_face || !d_order || !d_new_face || !d_words || !d_sort)
       return fail(DMI_ERR_OUT_OF_MEMORY, "hipMalloc (relabelling temporaries)");
     d_bad = d_words; d_max_point = d_words + 1;
     HIP_TRY(hipMemsetAsync(d_words, 0, 16, s));
-    HIP_TRY(hipMemcpyAsync(d_c2p, tables[0].corner_to_point, C * 4, hipMemcpyHostToDevice, s));
+    if (!dev) HIP_TRY(hipMemcpyAsync(const_cast<uint32_t*>(d_c2p), tables[0].corner_to_point, C * 4, hipMemcpyHostToDevice, s));
     launch_max_u32(d_c2p, C, d_max_point, s);
     for (uint32_t i = 0; i < n_atts; ++i) {
       TableDev& t = job->tables[i];
       if (t.alias_of >= 0) continue;
-      HIP_TRY(hipMemcpyAsync(d_c2v, tables[i].corner_to_vertex, C * 4, hipMemcpyHostToDevice, s));
-      HIP_TRY(hipMemcpyAsync(d_opp, tables[i].opposite, C * 4, hipMemcpyHostToDevice, s));
+      const bool resident = dev && tables[i].corner_to_vertex == tables[0].corner_to_vertex && tables[i].opposite == tables[0].opposite;
+      const uint32_t* d_c2v = resident ? dev->c2v : d_c2v_up;
+      const uint32_t* d_opp = resident ? dev->opp : d_opp_up;
+      if (!resident) {
+        HIP_TRY(hipMemcpyAsync(d_c2v_up, tables[i].corner_to_vertex, C * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_opp_up, tables[i].opposite, C * 4, hipMemcpyHostToDevice, s));
+      }
       if (t.n_seq) HIP_TRY(hipMemcpyAsync(d_seq, seq_of[i], (size_t)t.n_seq * 4, hipMemcpyHostToDevice, s));
       launch_fill_u32(d_rank, t.V, kNone, s);
       launch_rank_scatter(d_seq, t.n_seq, d_c2v, d_rank, s);
@@ -618,6 +664,7 @@ int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, ui
   return DMI_OK;
 }
 
+extern "C" {
 void dmi_job_destroy(dmi_job* job) { delete job; }
 
 int dmi_job_timings(const dmi_job* job, dmi_timings* t) {

@@ -51,18 +51,34 @@ struct ChunkCache {
   std::mutex m;
   std::vector<Item> items;
   size_t bytes = 0;
-  static constexpr size_t kChunkCacheBytes = (size_t)64 << 30;
+  // what the cache may hold: DMI_DEVICE_CACHE_MB, default = half of the device's memory, at most 64 GiB (read once)
+  static size_t limit_bytes() {
+    static const size_t limit = [] {
+      if (const char* e = std::getenv("DMI_DEVICE_CACHE_MB")) return (size_t)std::max(0l, std::atol(e)) << 20;
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || !total_b) return (size_t)16 << 30;
+      return std::min<size_t>((size_t)64 << 30, total_b / 2);
+    }();
+    return limit;
+  }
   static size_t size_class(size_t n) {   // powers of two up to 1 GiB, multiples of 256 MiB above (a 100M-triangle job is 33 GB)
     if (n > ((size_t)1 << 30)) return (n + (((size_t)1 << 28) - 1)) & ~(((size_t)1 << 28) - 1);
     size_t c = (size_t)1 << 20;
     while (c < n) c <<= 1;
     return c;
   }
-  void* acquire(int device, size_t cap) {
+  // the smallest cached chunk of `device` that holds `cap` bytes without being more than twice as large; its size comes back in `cap`
+  void* acquire(int device, size_t& cap) {
     std::lock_guard<std::mutex> lock(m);
-    for (size_t k = items.size(); k-- > 0;)
-      if (items[k].device == device && items[k].cap == cap) { void* p = items[k].p; bytes -= cap; items.erase(items.begin() + (long)k); return p; }
-    return nullptr;
+    size_t best = items.size();
+    for (size_t k = 0; k < items.size(); ++k)
+      if (items[k].device == device && items[k].cap >= cap && items[k].cap <= 2 * cap && (best == items.size() || items[k].cap < items[best].cap)) best = k;
+    if (best == items.size()) return nullptr;
+    void* p = items[best].p;
+    cap = items[best].cap;
+    bytes -= cap;
+    items.erase(items.begin() + (long)best);
+    return p;
   }
   void drop_all() {
     std::vector<Item> gone;
@@ -74,7 +90,7 @@ struct ChunkCache {
   }
   bool release(int device, void* p, size_t cap) {   // false: not kept (the caller frees it)
     std::lock_guard<std::mutex> lock(m);
-    if (bytes + cap > kChunkCacheBytes) return false;
+    if (bytes + cap > limit_bytes()) return false;
     items.push_back({device, p, cap});
     bytes += cap;
     return true;
@@ -88,14 +104,19 @@ struct DevPool {
   size_t chunk_bytes = 0;
   hipStream_t stream = nullptr;
   int device = 0;
+  bool zero = true;   // chunks are cleared when they are taken (job memory); temporaries skip it
   ~DevPool() { for (auto& c : chunks) if (c.p && !g_chunk_cache.release(device, c.p, c.cap)) (void)hipFree(c.p); }
   void* take(size_t n) {
     n = (n + 255) & ~(size_t)255;
     if (chunks.empty() || chunks.back().used + n > chunks.back().cap) {
       Chunk c{nullptr, ChunkCache::size_class(std::max(n, chunk_bytes)), 0};
       c.p = g_chunk_cache.acquire(device, c.cap);
-      if (!c.p && hipMalloc(&c.p, c.cap) != hipSuccess) return nullptr;
-      if (hipMemsetAsync(c.p, 0, c.cap, stream) != hipSuccess) { (void)hipFree(c.p); return nullptr; }
+      if (!c.p && hipMalloc(&c.p, c.cap) != hipSuccess) {   // out of memory with chunks parked in the cache: hand them back and try once more
+        (void)hipGetLastError();
+        g_chunk_cache.drop_all();
+        if (hipMalloc(&c.p, c.cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+      }
+      if (zero && hipMemsetAsync(c.p, 0, c.cap, stream) != hipSuccess) { (void)hipFree(c.p); return nullptr; }
       chunks.push_back(c);
     }
     Chunk& c = chunks.back();
@@ -118,7 +139,7 @@ struct DevMem {
     if (n == 0) return DMI_OK;
     if (g_active_pool) {
       p = g_active_pool->take(n);
-      if (!p) return host_fail(DMI_ERR_HIP, "hipMalloc (job pool)");
+      if (!p) return host_fail(DMI_ERR_OUT_OF_MEMORY, "hipMalloc (job pool)");
       pooled = true;
       return DMI_OK;
     }
@@ -250,14 +271,22 @@ struct HostStage {
   uint8_t* p = nullptr;
   size_t cap = 0;
   bool in_use = false;
+  bool registered = false;   // malloc + hipHostRegister (huge pages) rather than hipHostMalloc
 };
 HostStage* acquire_stage(int device, size_t bytes);
 void release_stage(HostStage* st);
 namespace dmi {
 int to_buffer(const std::vector<uint8_t>& v, dmi_buffer* out);
-struct TempDev {   // device temporaries of job creation (outside the job's pool: they are released when creation ends)
-  std::vector<void*> ptrs;
-  ~TempDev() { for (void* q : ptrs) (void)hipFree(q); }
-  template <class T> T* take(size_t n) { void* q = nullptr; if (hipMalloc(&q, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr; ptrs.push_back(q); return static_cast<T*>(q); }
+// the universal corner table of a mesh as the device connectivity stage left it in HBM (mesh-local ids, the mesh's own numbering)
+struct DeviceTableView { const uint32_t* c2p; const uint32_t* c2v; const uint32_t* opp; bool trusted_sequences; };
+int job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tables, uint32_t n_atts, const uint32_t* seeds, uint32_t n_seeds,
+                    const dmi_config* cfg, const DeviceTableView* dev, dmi_job** job);
+// Device temporaries of job creation / the connectivity stage: bump-allocated from cached chunks like a job's own memory (hipMalloc and
+// hipFree serialise across host threads, and hipFree waits for the device), not cleared; handed back when the work on `stream` is over.
+struct TempDev {
+  DevPool pool;
+  void init(int device, hipStream_t s, size_t bytes_hint) { pool.device = device; pool.stream = s; pool.chunk_bytes = bytes_hint; pool.zero = false; }
+  ~TempDev() { if (!pool.chunks.empty()) (void)hipStreamSynchronize(pool.stream); }   // (nothing may still be using a chunk when the cache hands it to the next taker)
+  template <class T> T* take(size_t n) { return static_cast<T*>(pool.take((n ? n : 1) * sizeof(T))); }
 };
 }  // namespace dmi

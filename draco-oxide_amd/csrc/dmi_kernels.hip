@@ -707,14 +707,15 @@ __device__ __forceinline__ int texcoord_try(const int32_t (&cu)[2], const int32_
 #pragma unroll
   for (int k = 0; k < 3; ++k) small = small && (uint32_t)cp[k] < (1u << 30) && (uint32_t)np[k] < (1u << 30) && (uint32_t)pp[k] < (1u << 30);
   if (small) {
-    const uint32_t lim15 = 1u << 15;   // |pn| components below 2^15: |pn|² < 3·2^30 cannot wrap an i32, but may reach 2^31 (then it is negative below)
+    const uint32_t lim15 = 1u << 15;   // |pn| components below 2^15: |pn|² < 3·2^30 — formed in uint32 (no signed wrap), admitted below 2^31 only
     const int32_t pn[3] = {pp[0] - np[0], pp[1] - np[1], pp[2] - np[2]};
     const int32_t cn[3] = {cp[0] - np[0], cp[1] - np[1], cp[2] - np[2]};
     if ((uint32_t)iabs(pn[0]) < lim15 && (uint32_t)iabs(pn[1]) < lim15 && (uint32_t)iabs(pn[2]) < lim15) {
-      const int32_t d32 = pn[0] * pn[0] + pn[1] * pn[1] + pn[2] * pn[2];
-      if (d32 == 0) return 0;                                                  // mesh_prediction_for_texture_coordinates.rs: |pn|² = 0 → fallback
+      const uint32_t du = (uint32_t)(pn[0] * pn[0]) + (uint32_t)(pn[1] * pn[1]) + (uint32_t)(pn[2] * pn[2]);   // each square < 2^30
+      if (du == 0) return 0;                                                   // mesh_prediction_for_texture_coordinates.rs: |pn|² = 0 → fallback
+      const int32_t d32 = (int32_t)du;
       const int64_t cdp = (int64_t)pn[0] * cn[0] + (int64_t)pn[1] * cn[1] + (int64_t)pn[2] * cn[2];
-      if (d32 > 0 && fits31(cdp) && texcoord_predict_f64(cu, nuv, puv, cp, np, pn, d32, (int32_t)cdp, pred0, pred1, oflag) == 1) return 1;
+      if (du < (1u << 31) && fits31(cdp) && texcoord_predict_f64(cu, nuv, puv, cp, np, pn, d32, (int32_t)cdp, pred0, pred1, oflag) == 1) return 1;
     }
   }
 #endif

@@ -21,8 +21,8 @@ struct UniversalBuilder {
   uint32_t C;
   explicit UniversalBuilder(CornerTables& tt) : t(tt), C(tt.F * 3) {}
 
-  uint32_t swing_left(uint32_t c) const { uint32_t o = t.opp[corner_next(c)]; return o == kNone ? kNone : corner_next(o); }
-  uint32_t swing_right(uint32_t c) const { uint32_t o = t.opp[corner_prev(c)]; return o == kNone ? kNone : corner_prev(o); }
+  uint32_t swing_left(uint32_t c) const { uint32_t o = t.opp_own[corner_next(c)]; return o == kNone ? kNone : corner_next(o); }
+  uint32_t swing_right(uint32_t c) const { uint32_t o = t.opp_own[corner_prev(c)]; return o == kNone ? kNone : corner_prev(o); }
 
   // Half-edge matching (core/corner_table/mod.rs:252-340).  Each vertex owns a bucket of pending
   // half-edges (sink vertex, corner) sized by its corner count; a corner looks for the reverse edge
@@ -31,7 +31,7 @@ struct UniversalBuilder {
     std::vector<uint32_t> count;
     count.reserve(t.V ? t.V : 16);
     for (uint32_t c = 0; c < C; ++c) {
-      uint32_t v = t.c2v[c];
+      uint32_t v = t.c2v_own[c];
       if (v >= count.size()) count.resize((size_t)v + 1, 0);
       ++count[v];
     }
@@ -39,16 +39,16 @@ struct UniversalBuilder {
     std::vector<uint32_t> start(nv + 1, 0);
     for (uint32_t v = 0; v < nv; ++v) start[v + 1] = start[v] + count[v];
     std::vector<uint32_t> he_sink(C, kNone), he_corner(C, kNone);
-    t.opp.assign(C, kNone);
+    t.opp_own.assign(C, kNone);
     for (uint32_t c = 0; c < C; ++c) {
-      const uint32_t tip = t.c2v[c], src = t.c2v[corner_next(c)], snk = t.c2v[corner_prev(c)];
+      const uint32_t tip = t.c2v_own[c], src = t.c2v_own[corner_next(c)], snk = t.c2v_own[corner_prev(c)];
       if (c % 3 == 0 && (tip == src || tip == snk || src == snk)) continue;   // :289-295
       uint32_t found = kNone;
       const uint32_t lo = start[snk], hi = start[snk + 1];
       for (uint32_t s = lo; s < hi; ++s) {
         if (he_sink[s] == kNone) break;
         if (he_sink[s] != src) continue;
-        if (t.c2v[he_corner[s]] == tip) break;   // Q22: mirrored face → stop searching
+        if (t.c2v_own[he_corner[s]] == tip) break;   // Q22: mirrored face → stop searching
         found = he_corner[s];
         uint32_t k = s;                           // delete slot s, keep order
         while (k + 1 < hi && he_sink[k + 1] != kNone) { he_sink[k] = he_sink[k + 1]; he_corner[k] = he_corner[k + 1]; ++k; }
@@ -59,8 +59,8 @@ struct UniversalBuilder {
         for (uint32_t s = start[src]; s < start[src + 1]; ++s)
           if (he_sink[s] == kNone) { he_sink[s] = snk; he_corner[s] = c; break; }
       } else {
-        t.opp[c] = found;
-        t.opp[found] = c;
+        t.opp_own[c] = found;
+        t.opp_own[found] = c;
       }
     }
     t.V = nv;
@@ -86,7 +86,7 @@ struct UniversalBuilder {
     std::atomic<int> degenerate{0};
     slices(t.F, [&](size_t lo, size_t hi) {
       for (size_t f = lo; f < hi; ++f) {
-        const uint32_t a = t.c2v[3 * f], b = t.c2v[3 * f + 1], c = t.c2v[3 * f + 2];
+        const uint32_t a = t.c2v_own[3 * f], b = t.c2v_own[3 * f + 1], c = t.c2v_own[3 * f + 2];
         if (a == b || b == c || a == c) { degenerate.store(1, std::memory_order_relaxed); return; }
         bump(&count[std::min(a, b)]);
         bump(&count[std::min(b, c)]);
@@ -101,18 +101,18 @@ struct UniversalBuilder {
     he_key.resize(C); he_corner.resize(C);
     slices(C, [&](size_t lo, size_t hi) {
       for (size_t c = lo; c < hi; ++c) {
-        const uint32_t src = t.c2v[corner_next((uint32_t)c)], snk = t.c2v[corner_prev((uint32_t)c)];
+        const uint32_t src = t.c2v_own[corner_next((uint32_t)c)], snk = t.c2v_own[corner_prev((uint32_t)c)];
         const uint32_t slot = bump(&cursor[std::min(src, snk)]);
         he_key[slot] = src < snk ? snk : (src | 0x80000000u);   // the larger endpoint; bit 31: the half-edge runs from it down
         he_corner[slot] = (uint32_t)c;
       }
     });
-    pool_fit(t.opp, C);
-    t.opp.resize(C);
+    pool_fit(t.opp_own, C);
+    t.opp_own.resize(C);
     std::atomic<int> crowded{0};
     slices(C, [&](size_t lo, size_t hi) {
       for (size_t c = lo; c < hi; ++c) {
-        const uint32_t tip = t.c2v[c], src = t.c2v[corner_next((uint32_t)c)], snk = t.c2v[corner_prev((uint32_t)c)];
+        const uint32_t tip = t.c2v_own[c], src = t.c2v_own[corner_next((uint32_t)c)], snk = t.c2v_own[corner_prev((uint32_t)c)];
         const uint32_t low = std::min(src, snk);
         const uint32_t mine = src < snk ? snk : (src | 0x80000000u), against = mine ^ 0x80000000u;
         uint32_t same = 0, rev = 0, found = kNone;
@@ -122,7 +122,7 @@ struct UniversalBuilder {
           if (k == against) { ++rev; found = he_corner[s2]; }
         }
         if (same + rev > 2) { crowded.store(1, std::memory_order_relaxed); return; }
-        t.opp[c] = (rev == 1 && same == 1 && t.c2v[found] != tip) ? found : kNone;
+        t.opp_own[c] = (rev == 1 && same == 1 && t.c2v_own[found] != tip) ? found : kNone;
       }
     });
     return !crowded.load();
@@ -138,14 +138,14 @@ struct UniversalBuilder {
     std::vector<uint32_t>&first = first_p.v, &count = count_p.v;
     parallel_for(C, [&](size_t lo, size_t hi) {
       for (size_t c = lo; c < hi; ++c) {
-        const uint32_t v = t.c2v[c];
+        const uint32_t v = t.c2v_own[c];
         __atomic_fetch_add(&count[v], 1u, __ATOMIC_RELAXED);
         uint32_t cur = __atomic_load_n(&first[v], __ATOMIC_RELAXED);
         while ((uint32_t)c < cur && !__atomic_compare_exchange_n(&first[v], &cur, (uint32_t)c, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
       }
     });
-    pool_fit(t.lmc, nv);
-    t.lmc.assign(nv, kNone);
+    pool_fit(t.lmc_own, nv);
+    t.lmc_own.assign(nv, kNone);
     std::atomic<int> several{0};
     parallel_for(nv, [&](size_t lo, size_t hi) {
       for (size_t v = lo; v < hi; ++v) {
@@ -155,7 +155,7 @@ struct UniversalBuilder {
         while (a != kNone && a != c && fan <= count[v]) { left = a; ++fan; a = swing_left(a); }
         if (a == kNone) for (uint32_t r = swing_right(c); r != kNone && fan <= count[v]; r = swing_right(r)) ++fan;   // open fan: the corners to the right of c
         if (fan != count[v]) { several.store(1, std::memory_order_relaxed); return; }
-        t.lmc[v] = left;
+        t.lmc_own[v] = left;
       }
     });
     return !several.load();
@@ -168,14 +168,14 @@ struct UniversalBuilder {
     std::vector<uint32_t> start(nv + 1, 0);
     for (uint32_t f = 0; f < t.F; ++f)
       for (int k = 0; k < 3; ++k) {
-        uint32_t a = t.c2v[3 * f + k], b = t.c2v[3 * f + (k + 1) % 3];
+        uint32_t a = t.c2v_own[3 * f + k], b = t.c2v_own[3 * f + (k + 1) % 3];
         ++start[std::min(a, b) + 1];
       }
     for (uint32_t v = 0; v < nv; ++v) start[v + 1] += start[v];
     std::vector<uint32_t> other(C), fill(start.begin(), start.end() - 1);
     for (uint32_t f = 0; f < t.F; ++f)
       for (int k = 0; k < 3; ++k) {
-        uint32_t a = t.c2v[3 * f + k], b = t.c2v[3 * f + (k + 1) % 3];
+        uint32_t a = t.c2v_own[3 * f + k], b = t.c2v_own[3 * f + (k + 1) % 3];
         other[fill[std::min(a, b)]++] = std::max(a, b);
       }
     for (uint32_t v = 0; v < nv; ++v) {
@@ -203,22 +203,22 @@ struct UniversalBuilder {
         first = cur;
         for (;;) {
           seen[cur] = 1;
-          const uint32_t sink_c = corner_next(cur), sink_v = t.c2v[sink_c], edge_c = corner_prev(cur);
+          const uint32_t sink_c = corner_next(cur), sink_v = t.c2v_own[sink_c], edge_c = corner_prev(cur);
           bool updated = false;
           for (auto& s : sinks) {
             if (s.first != sink_v) continue;
-            const uint32_t other_edge = s.second, oe = t.opp[edge_c];
+            const uint32_t other_edge = s.second, oe = t.opp_own[edge_c];
             if (oe != kNone && oe == other_edge) continue;
-            const uint32_t oo = t.opp[other_edge];
-            if (oe != kNone) t.opp[oe] = kNone;
-            if (oo != kNone) t.opp[oo] = kNone;
-            t.opp[edge_c] = kNone;
-            t.opp[other_edge] = kNone;
+            const uint32_t oo = t.opp_own[other_edge];
+            if (oe != kNone) t.opp_own[oe] = kNone;
+            if (oo != kNone) t.opp_own[oo] = kNone;
+            t.opp_own[edge_c] = kNone;
+            t.opp_own[other_edge] = kNone;
             updated = true;
             break;
           }
           if (updated) { changed = true; break; }
-          sinks.emplace_back(t.c2v[corner_prev(cur)], sink_c);
+          sinks.emplace_back(t.c2v_own[corner_prev(cur)], sink_c);
           const uint32_t r = swing_right(cur);
           if (r == kNone) break;
           cur = r;
@@ -230,26 +230,26 @@ struct UniversalBuilder {
 
   // Left-most corners + non-manifold vertex splitting (mod.rs:342-416).
   void left_most_corners() {
-    t.lmc.assign(t.V, kNone);
+    t.lmc_own.assign(t.V, kNone);
     std::vector<uint8_t> vdone(t.V, 0), cdone(C, 0);
     for (uint32_t c = 0; c < C; ++c) {
       if (cdone[c]) continue;
-      uint32_t v = t.c2v[c];
+      uint32_t v = t.c2v_own[c];
       const bool split = vdone[v] != 0;
-      if (split) { v = t.V++; t.lmc.push_back(kNone); vdone.push_back(0); }
+      if (split) { v = t.V++; t.lmc_own.push_back(kNone); vdone.push_back(0); }
       vdone[v] = 1;
       cdone[c] = 1;
-      t.lmc[v] = c;
-      if (split) t.c2v[c] = v;
+      t.lmc_own[v] = c;
+      if (split) t.c2v_own[c] = v;
       uint32_t a = swing_left(c);
       while (a != kNone && a != c) {
         cdone[a] = 1;
-        t.lmc[v] = a;
-        if (split) t.c2v[a] = v;
+        t.lmc_own[v] = a;
+        if (split) t.c2v_own[a] = v;
         a = swing_left(a);
       }
       if (a == kNone) {
-        for (a = c; a != kNone; a = swing_right(a)) { cdone[a] = 1; if (split) t.c2v[a] = v; }
+        for (a = c; a != kNone; a = swing_right(a)) { cdone[a] = 1; if (split) t.c2v_own[a] = v; }
       }
     }
   }
@@ -257,16 +257,17 @@ struct UniversalBuilder {
 
 }  // namespace
 
-int CornerTables::build_universal(const uint32_t* faces, uint32_t num_faces, const uint32_t* pos_p2v, std::string& err) {
+int CornerTables::build_universal(const uint32_t* faces, uint32_t num_faces, const uint32_t* pos_p2v, std::string& err, bool copy_faces) {
   F = num_faces;
   const uint32_t C = 3 * F;
   static const bool trace = std::getenv("DMI_TRACE_TABLES") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
   auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
-  pool_fit(c2p, C);
-  c2p.assign(faces, faces + C);
-  pool_fit(c2v, C);
-  c2v.resize(C);
+  if (copy_faces) { pool_fit(c2p_own, C); c2p_own.resize(C); parallel_for(C, [&](size_t lo, size_t hi) { std::copy(faces + lo, faces + hi, c2p_own.data() + lo); }); c2p = c2p_own.data(); }
+  else c2p = faces;   // (the caller's array outlives these tables: dmi_mesh_prepare / dmi_encode_mesh)
+  pool_fit(c2v_own, C);
+  c2v_own.resize(C);
+  std::vector<uint32_t>& c2v = c2v_own;
   std::atomic<uint32_t> maxv_a{0};
   parallel_for(C, [&](size_t lo, size_t hi) {
     uint32_t m = 0;
@@ -298,6 +299,8 @@ int CornerTables::build_universal(const uint32_t* faces, uint32_t num_faces, con
   if (!(big && b.left_most_corners_parallel())) b.left_most_corners();
   if (trace) std::fprintf(stderr, "[dmi]   universal table of %u faces: copy + vertex ids %.3f ms, half-edge matching %.3f (%s), left-most corners %.3f\n", F, t_ids, t_match - t_ids,
                           matched ? "order-free" : "reference walk", ms() - t_match);
+  this->c2v = c2v_own.data(); opp = opp_own.data(); lmc = lmc_own.data();
+  no_boundary = false;
   att.clear();
   return DMI_OK;
 }
@@ -443,6 +446,7 @@ struct Walker {
   // edgebreaker.rs:195-224 — the inner walk rotates inside one face (never crosses an edge), so
   // each boundary vertex ends up with its own id.
   void label_boundaries() {
+    if (t.no_boundary) return;   // (no vertex flag is ever set: hole_of is never read)
     pool_fit(hole_of, t.V);
     hole_of.assign(t.V, kNone);
     for (uint32_t c0 = 0; c0 < C; ++c0) {
@@ -467,7 +471,7 @@ struct Walker {
     while (t.opp[c] != kNone) c = corner_next(t.opp[c]);
     const uint32_t sv = t.c2v[start_corner];
     if (include_first) vvis[sv] |= 1;
-    if (hole_of[sv] == kNone) { bad = true; return; }
+    if (hole_of.empty() || hole_of[sv] == kNone) { bad = true; return; }
     hole_done[hole_of[sv]] = 1;
     for (uint32_t v = t.c2v[corner_prev(c)]; v != sv; v = t.c2v[corner_prev(c)]) {
       vvis[v] |= 1;
@@ -489,7 +493,7 @@ struct Walker {
       for (uint32_t steps = 0; steps < t.F; ++steps) {
         if (c == kNone) { bad = true; return; }
         ++symbol_idx;
-        prefetch_neighbours(t.opp.data() + c); prefetch_neighbours(t.c2v.data() + c);
+        prefetch_neighbours(t.opp + c); prefetch_neighbours(t.c2v + c);
         const uint32_t f = c / 3, v = t.c2v[c];
         prefetch_neighbours(fvis.data() + f); prefetch_neighbours(vvis.data() + v);
         fvis[f] |= 1;
@@ -518,7 +522,7 @@ struct Walker {
         } else {
           symbols.push_back(SYM_S);
           ++num_split_symbols;
-          if (hole_of[v] != kNone && !hole_done[hole_of[v]]) mark_boundary(c, false);
+          if ((vflags & 2) && !hole_done[hole_of[v]]) mark_boundary(c, false);
           split_symbol_of_face[f] = symbol_idx;
           fvis[f] |= 2;
           stack.back() = lc;
@@ -533,7 +537,7 @@ struct Walker {
     uint32_t c = 3 * face;
     for (int k = 0; k < 3; ++k) {
       if (t.opp[c] == kNone) { corner = c; return false; }
-      if (hole_of[t.c2v[c]] != kNone) {
+      if (vvis[t.c2v[c]] & 2) {
         uint32_t r = c;
         while (r != kNone) { c = r; r = swing_right(r); }
         corner = corner_prev(c);

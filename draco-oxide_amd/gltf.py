@@ -18,6 +18,7 @@ JSON byte-equality with the reference is not part of the bit-exact contract; the
 import base64
 import json
 import os
+import urllib.parse
 import struct
 
 import numpy as np
@@ -166,7 +167,13 @@ def load_document(source):
         if uri.startswith("data:"):
             buffers.append(base64.b64decode(uri.split(",", 1)[1]))
         else:
-            buffers.append(open(os.path.join(base, uri), "rb").read())
+            # an external buffer of an untrusted .gltf: percent-decoded, relative, and inside the asset's own directory
+            rel = urllib.parse.unquote(uri)
+            path = os.path.realpath(os.path.join(base, rel))
+            root = os.path.realpath(base)
+            if os.path.isabs(rel) or not (path == root or path.startswith(root + os.sep)):
+                raise ValueError(f".gltf buffer uri leaves the asset directory: {uri!r}")
+            buffers.append(open(path, "rb").read())
     return doc, buffers
 
 
@@ -259,17 +266,19 @@ def encode_batch(meshes, cfg=None, devices=None, group=None, device=None):
         return distributed.encode_meshes_sharded(meshes, cfg, device=device, group=group)
     n_dev = device_count() if devices == "all" else int(devices or 1)
     n_dev = max(1, min(n_dev, device_count()))
-    if n_dev > 1:
-        deal = shard_meshes(meshes, n_dev)
-        jobs = meshes_prepare_devices(meshes, deal, cfg)
-        sections = jobs_encode_devices(jobs)
-    else:
-        jobs = meshes_prepare(meshes, cfg or Config.default())   # host connectivity of all primitives on a thread pool
-        sections = jobs_encode(jobs)
-    blobs = [j.header_and_connectivity + s for j, s in zip(jobs, sections)]
-    for j in jobs:
-        j.close()
-    return blobs
+    jobs = []
+    try:   # (the jobs hold device memory: closed whatever the encode does)
+        if n_dev > 1:
+            deal = shard_meshes(meshes, n_dev)
+            jobs = meshes_prepare_devices(meshes, deal, cfg)
+            sections = jobs_encode_devices(jobs)
+        else:
+            jobs = meshes_prepare(meshes, cfg or Config.default())   # connectivity stage of all primitives: host walks on a thread pool, tables on the device
+            sections = jobs_encode(jobs)
+        return [j.header_and_connectivity + s for j, s in zip(jobs, sections)]
+    finally:
+        for j in jobs:
+            j.close()
 
 
 def transcode_files(sources, cfg=None, devices=None, group=None, device=None):

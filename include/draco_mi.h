@@ -185,6 +185,15 @@ typedef struct dmi_conn {
 int dmi_encode_connectivity(const dmi_mesh* mesh, dmi_buffer* header_and_connectivity, dmi_conn* conn);
 void dmi_conn_free(dmi_conn* conn);
 
+/* The order-free half of the connectivity stage on the device (core/corner_table/mod.rs:252-340 compute_table, :342-416
+ * compute_left_most_corners, :36-38 is_on_boundary) for ONE mesh, read back: opposite[3F], left_most_corner[V] (nullable),
+ * on_boundary[V] (nullable; sized for the Position attribute's value count).  dmi_mesh_prepare / dmi_meshes_prepare run the same
+ * kernels internally (batched: one launch per kernel for all meshes).  *flags != 0 with *num_vertices == 0: the mesh has vertex-degenerate
+ * faces, an edge with more than two faces or a vertex with several fans — the result then depends on the corner order and the
+ * library takes the reference's serial walks on the host instead (dmi_encode_connectivity's tables); nothing was written. */
+int dmi_device_corner_table(const dmi_mesh* mesh, const dmi_config* cfg, uint32_t* opposite, uint32_t* left_most_corner, uint8_t* on_boundary,
+                            uint32_t* num_vertices, uint32_t* flags);
+
 /* --- MeshBuilder::build (core/mesh/builder.rs:62-90) + Attribute::from's value dedup (core/attribute/mod.rs:394-452) ----
  * Host only.  Attributes in add order (AttributeId = index, builder.rs:31-39), one row per point; the result is the `Mesh` the
  * reference hands to encode::encode: unique values in first-occurrence order with point_to_value maps, Position swapped to
