@@ -12,11 +12,9 @@
 //                     reference's serial walks on them (host_conn.cpp): nothing is approximated here.
 //   k_conn_vertices   core/corner_table/mod.rs:342-416    left-most corners when every vertex has one fan (else flagged: the serial
 //                     walk splits such vertices), and GenericCornerTable::is_on_boundary (:36-38) per vertex for the sequencer
-//   k_conn_seams      core/corner_table/attribute_corner_table.rs:25-64   seam edges of an attribute: only "does any edge with two faces
-//                     separate different attribute values" is decided here (a seam-free attribute takes the universal table, the
-//                     common case); an attribute with interior seams gets its table from the host builder.
-// Then the coding-order relabelling of small meshes, batched (the large-mesh form lives in dmi_relabel.hip):
-//   k_batch_rank / k_batch_face_key / k_batch_place / k_batch_bucket_sort / k_batch_remap / k_batch_remap_seq
+// Attribute corner tables (attribute_corner_table.rs:16-137) stay with the host builder: one comparison per edge, no bucket matching.
+// Then the coding-order relabelling of the meshes of a batch (the single-large-mesh form lives in dmi_relabel.hip):
+//   k_rl_rank / k_rl_keys / k_rl_place / k_rl_sort_buckets / k_rl_remap / k_rl_seq — a counting sort by key, no library sort
 #include "dmi_device.hpp"
 #include <algorithm>
 
@@ -224,20 +222,83 @@ __global__ __launch_bounds__(kBlock) void k_conn_check(const ConnArgs a) {
   }
 }
 
-// attribute_corner_table.rs:44-63 for one attribute of every mesh: does any edge with two faces separate different values?
-__global__ __launch_bounds__(kBlock) void k_conn_seams(const ConnSeamArgs a) {
-  const uint64_t C = 3ull * a.total_faces;
-  for (uint64_t c = (uint64_t)blockIdx.x * kBlock + threadIdx.x; c < C; c += (uint64_t)gridDim.x * kBlock) {
-    const uint32_t m = find_mesh(a.M, (uint32_t)(c / 3u), [&](uint32_t k) { return a.meshes[k].face_off; });
-    const uint32_t map_off = a.map_off[m];
-    if (map_off == kConnMapSkip) continue;   // no such attribute / indexed like the Position attribute: boundary edges are its only seams
-    const ConnMeshDesc d = a.meshes[m];
-    const uint64_t cb = 3ull * d.face_off;
-    const uint32_t lc = (uint32_t)(c - cb);
-    const uint32_t o = a.opp[c];
-    if (o == kNoneD || o < lc) continue;
-    auto val = [&](uint32_t corner) { const uint32_t p = a.faces[cb + corner]; return map_off == kConnMapIdentity ? p : a.maps[map_off + p]; };
-    if (val(cnext(lc)) != val(cprev(o)) || val(cprev(lc)) != val(cnext(o))) a.interior[m] = 1u;   // (same value from every writer)
+// ---- coding-order relabelling of a batch of (small) meshes: dmi_relabel.hip's steps with per-mesh descriptors, one launch per step ----
+// (reference seam and the argument why this is a pure relabelling: dmi_relabel.hip / DESIGN.md §3)
+template <class F> __device__ __forceinline__ uint32_t find_item(const RelabelItem* __restrict__ items, uint32_t n, uint32_t x, F off) {
+  return find_mesh(n, x, [&](uint32_t k) { return off(items[k]); });
+}
+// rank[vertex(seq[k])] = k
+__global__ __launch_bounds__(kBlock) void k_rl_rank(const RelabelBatch b) {
+  for (uint32_t g = blockIdx.x * kBlock + threadIdx.x; g < b.total_seq; g += gridDim.x * kBlock) {
+    const RelabelItem& it = b.items[find_item(b.items, b.n_items, g, [](const RelabelItem& x) { return x.seq_off; })];
+    const uint32_t k = g - it.seq_off;
+    b.rank[it.vert_off + it.c2v[it.seq[k]]] = k;
+  }
+}
+// key[f] = smallest sequence index among the face's vertices (n_seq when none was coded); bucket sizes per key
+__global__ __launch_bounds__(kBlock) void k_rl_keys(const RelabelBatch b) {
+  for (uint32_t g = blockIdx.x * kBlock + threadIdx.x; g < b.total_faces; g += gridDim.x * kBlock) {
+    const RelabelItem& it = b.items[find_item(b.items, b.n_items, g, [](const RelabelItem& x) { return x.face_off; })];
+    const uint32_t f = g - it.face_off;
+    const uint32_t* r = b.rank + it.vert_off;
+    const uint32_t m = min(r[it.c2v[3ull * f]], min(r[it.c2v[3ull * f + 1]], r[it.c2v[3ull * f + 2]]));
+    const uint32_t key = m == kNoneD ? it.n_seq : m;
+    b.key[g] = key;
+    atomicAdd(&b.count[it.key_off + key], 1u);
+  }
+}
+// faces into their buckets (the scan of the bucket sizes is a global face position: the keys of mesh m occupy [key_off[m], key_off[m+1]))
+__global__ __launch_bounds__(kBlock) void k_rl_place(const RelabelBatch b) {
+  for (uint32_t g = blockIdx.x * kBlock + threadIdx.x; g < b.total_faces; g += gridDim.x * kBlock) {
+    const RelabelItem& it = b.items[find_item(b.items, b.n_items, g, [](const RelabelItem& x) { return x.face_off; })];
+    const uint32_t bucket = it.key_off + b.key[g];
+    const uint32_t pos = b.count[bucket] + atomicAdd(&b.fill[bucket], 1u);
+    b.order[pos] = g - it.face_off;
+  }
+}
+// faces of equal key in face order (the host form's stable counting sort): a bucket holds the faces around one vertex — a handful
+__global__ __launch_bounds__(kBlock) void k_rl_sort_buckets(const RelabelBatch b) {
+  for (uint32_t g = blockIdx.x * kBlock + threadIdx.x; g < b.total_keys; g += gridDim.x * kBlock) {
+    const uint32_t lo = b.count[g], hi = b.count[g + 1];
+    if (hi <= lo) continue;
+    uint32_t* o = b.order;
+    for (uint32_t i = lo + 1; i < hi; ++i) {   // insertion sort
+      const uint32_t v = o[i];
+      uint32_t j = i;
+      while (j > lo && o[j - 1] > v) { o[j] = o[j - 1]; --j; }
+      o[j] = v;
+    }
+    const RelabelItem& it = b.items[find_item(b.items, b.n_items, g, [](const RelabelItem& x) { return x.key_off; })];
+    for (uint32_t i = lo; i < hi; ++i) b.new_face[it.face_off + o[i]] = i - it.face_off;
+  }
+}
+__device__ __forceinline__ uint32_t map_corner(uint32_t c, const uint32_t* __restrict__ new_face) { return c == kNoneD ? kNoneD : 3u * new_face[c / 3u] + c % 3u; }
+// one thread per NEW corner: c2r_out[c2] = rank[c2v[c]], opp_out[c2] = map(opp[c]) with c = 3·order[c2 / 3] + c2 % 3
+__global__ __launch_bounds__(kBlock) void k_rl_remap(const RelabelBatch b) {
+  const uint64_t C = 3ull * b.total_faces;
+  for (uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x; g < C; g += (uint64_t)gridDim.x * kBlock) {
+    const uint32_t gf = (uint32_t)(g / 3u), k = (uint32_t)(g - 3ull * gf);
+    const RelabelItem& it = b.items[find_item(b.items, b.n_items, gf, [](const RelabelItem& x) { return x.face_off; })];
+    const uint32_t c2 = 3u * (gf - it.face_off) + k;
+    const uint32_t c = 3u * b.order[gf] + k;
+    it.c2r[c2] = b.rank[it.vert_off + it.c2v[c]];
+    it.opp_out[c2] = map_corner(it.opp[c], b.new_face + it.face_off);
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_rl_seq(const RelabelBatch b) {
+  for (uint32_t g = blockIdx.x * kBlock + threadIdx.x; g < b.total_seq; g += gridDim.x * kBlock) {
+    const RelabelItem& it = b.items[find_item(b.items, b.n_items, g, [](const RelabelItem& x) { return x.seq_off; })];
+    const uint32_t k = g - it.seq_off, c = it.seq[k];
+    it.seq_out[k] = map_corner(c, b.new_face + it.face_off);
+    it.s2p[k] = it.c2p[c];
+  }
+}
+// s2v[k] = point_to_value[s2p[k]] for every attribute of the batch that carries a map
+__global__ __launch_bounds__(kBlock) void k_compose_batch(const ComposeItem* __restrict__ items, uint32_t n_items, uint32_t total) {
+  for (uint32_t g = blockIdx.x * kBlock + threadIdx.x; g < total; g += gridDim.x * kBlock) {
+    const ComposeItem& it = items[find_mesh(n_items, g, [&](uint32_t k) { return items[k].off; })];
+    const uint32_t k = g - it.off;
+    it.s2v[k] = it.p2v[it.s2p[k]];   // (maps and faces were range-checked by the connectivity stage)
   }
 }
 
@@ -274,9 +335,18 @@ void launch_conn_tables(const ConnArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_conn_vertices, grid_of(a.total_verts), kBlock, 0, s, a);
   hipLaunchKernelGGL(k_conn_check, grid_of(C), kBlock, 0, s, a);
 }
-void launch_conn_seams(const ConnSeamArgs& a, hipStream_t s) {
-  if (!a.total_faces || !a.M) return;
-  hipLaunchKernelGGL(k_conn_seams, grid_of(3ull * a.total_faces), kBlock, 0, s, a);
+void launch_relabel_batch(const RelabelBatch& b, hipStream_t s) {
+  if (!b.n_items || !b.total_faces) return;
+  hipLaunchKernelGGL(k_rl_rank, grid_of(b.total_seq), kBlock, 0, s, b);
+  hipLaunchKernelGGL(k_rl_keys, grid_of(b.total_faces), kBlock, 0, s, b);
+  launch_exclusive_scan_u32(b.count, b.total_keys + 1, b.scan_partials, s);
+  hipLaunchKernelGGL(k_rl_place, grid_of(b.total_faces), kBlock, 0, s, b);
+  hipLaunchKernelGGL(k_rl_sort_buckets, grid_of(b.total_keys), kBlock, 0, s, b);
+  hipLaunchKernelGGL(k_rl_remap, grid_of(3ull * b.total_faces), kBlock, 0, s, b);
+  hipLaunchKernelGGL(k_rl_seq, grid_of(b.total_seq), kBlock, 0, s, b);
+}
+void launch_compose_batch(const ComposeItem* items_dev, uint32_t n_items, uint32_t total, hipStream_t s) {
+  if (n_items && total) hipLaunchKernelGGL(k_compose_batch, grid_of(total), kBlock, 0, s, items_dev, n_items, total);
 }
 
 }  // namespace dmi

@@ -265,11 +265,28 @@ struct ConnArgs {
 };
 hipError_t conn_tables_clear(const ConnArgs& a, hipStream_t s);   // the memsets launch_conn_tables expects
 void launch_conn_tables(const ConnArgs& a, hipStream_t s);
-// one attribute of every mesh: interior[m] = 1 when an edge with two faces separates different values of the attribute
-// map_off[m]: offset of the attribute's point → value map in `maps`, kConnMapIdentity = identity, kConnMapSkip = nothing to decide for this mesh
-constexpr uint32_t kConnMapIdentity = 0xFFFFFFFFu, kConnMapSkip = 0xFFFFFFFEu;
-struct ConnSeamArgs { const ConnMeshDesc* meshes; uint32_t M, total_faces; const uint32_t* faces; const uint32_t* opp; const uint32_t* maps; const uint32_t* map_off; uint32_t* interior /* zeroed */; };
-void launch_conn_seams(const ConnSeamArgs& a, hipStream_t s);
+// Coding-order relabelling of a batch of meshes in one launch per step (the arrays of dmi_relabel.hip, per mesh): inputs in the mesh's own
+// numbering (device arrays of the connectivity stage + the uploaded sequence), outputs in the job's memory.
+struct RelabelItem {
+  const uint32_t *c2p, *c2v, *opp, *seq;
+  uint32_t F, V, n_seq, pad;
+  uint32_t face_off, vert_off, key_off /* Σ (n_seq + 1) */, seq_off;   // this mesh's slices of the batch scratch arrays
+  uint32_t *c2r, *opp_out, *seq_out, *s2p;
+};
+struct RelabelBatch {
+  const RelabelItem* items; uint32_t n_items, total_faces, total_verts, total_keys, total_seq, pad;
+  uint32_t* rank;          // total_verts, filled with DMI_NONE
+  uint32_t* key;           // total_faces
+  uint32_t *count, *fill;  // total_keys + 1, zeroed
+  uint32_t *order, *new_face;   // total_faces
+  uint32_t* scan_partials;      // scan_partials_words(total_keys + 1)
+};
+void launch_relabel_batch(const RelabelBatch& b, hipStream_t s);
+struct ComposeItem { const uint32_t* s2p; const uint32_t* p2v; uint32_t* s2v; uint32_t off /* Σ n_seq of the items before */, n; };
+void launch_compose_batch(const ComposeItem* items_dev, uint32_t n_items, uint32_t total, hipStream_t s);
+// fan rows of many tables in one launch (k_build_fans per item)
+struct FanItem { const uint32_t *seq, *c2r, *opp; uint32_t *hdr, *apex, *fan; uint32_t off /* Σ n of the items before */, n, centre_in_apex, pad; };
+void launch_build_fans_batch(const FanItem* items_dev, uint32_t n_items, uint32_t total, hipStream_t s);
 void launch_exclusive_scan_u32(uint32_t* data, uint32_t n, uint32_t* partials, hipStream_t s);   // in place
 size_t scan_partials_words(uint32_t n);
 

@@ -213,14 +213,15 @@ extern "C" {
 
 int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, uint32_t n_atts, const uint32_t* seeds, uint32_t n_seeds,
                    const dmi_config* cfg_in, dmi_job** job_out) {
-  return dmi::job_create_impl(atts, tables, n_atts, seeds, n_seeds, cfg_in, nullptr, job_out);
+  return dmi::job_create_impl(atts, tables, n_atts, seeds, n_seeds, cfg_in, nullptr, job_out, nullptr);
 }
 }  // extern "C"
 
 // dev (nullable): the universal table's arrays as the device connectivity stage left them in HBM (dmi_prepare.cpp) — every table whose
 // host arrays are tables[0]'s takes them from there instead of the host (no upload, no range check: the library built them).
 int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tables, uint32_t n_atts, const uint32_t* seeds, uint32_t n_seeds,
-                         const dmi_config* cfg_in, const DeviceTableView* dev, dmi_job** job_out) {
+                         const dmi_config* cfg_in, const DeviceTableView* dev, dmi_job** job_out, JobDefer* defer) {
+  if (defer && !dev) return fail(DMI_ERR_INVALID_ARGUMENT, "deferred job creation needs device-resident tables");
   if (!atts || !tables || !job_out || n_atts == 0 || n_atts > 255) return fail(DMI_ERR_INVALID_ARGUMENT, "null argument or bad attribute count");
   dmi_config cfg{};
   if (cfg_in) cfg = *cfg_in;
@@ -247,7 +248,7 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
       const size_t V0 = tables[i].num_vertices;
       est += F0 * 24 + V0 * 88 + (size_t)atts[i].num_unique * atts[i].num_components * 4 + V0 * ((size_t)job->atts[i].nq * 31 + 49) + ((size_t)1 << 20);
     }
-    job->pool.stream = s;
+    job->pool.stream = defer ? defer->stream : s;   // (a batch clears the chunk on the coordinator's stream: its kernels follow on the same stream)
     job->pool.device = cfg.device;
     job->pool.chunk_bytes = est + est / 8;
   }
@@ -369,7 +370,19 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
   }
   uint32_t* d_bad = nullptr;        // device flag: a point_to_value entry out of range (device form)
   uint32_t* d_max_point = nullptr;  // device word: largest point index the faces reference (device form)
-  if (device_relabel) {
+  if (defer) {
+    for (uint32_t i = 1; i < n_atts; ++i) if (job->tables[i].alias_of != 0) return fail(DMI_ERR_INVALID_ARGUMENT, "deferred job creation: every table must be the universal one");
+    TableDev& t = job->tables[0];
+    if ((rc = t.c2r.alloc(C * 4))) return rc;
+    if ((rc = t.opp.alloc(C * 4))) return rc;
+    if ((rc = t.seq.alloc((size_t)t.n_seq * 4))) return rc;
+    if ((rc = t.s2p.alloc((size_t)t.n_seq * 4))) return rc;
+    defer->has_relabel = true;
+    RelabelItem& r = defer->relabel;
+    r.c2p = dev->c2p; r.c2v = dev->c2v; r.opp = dev->opp; r.seq = seq_of[0];
+    r.F = F; r.V = t.V; r.n_seq = t.n_seq;
+    r.c2r = t.c2r.as<uint32_t>(); r.opp_out = t.opp.as<uint32_t>(); r.seq_out = t.seq.as<uint32_t>(); r.s2p = t.s2p.as<uint32_t>();
+  } else if (device_relabel) {
     uint32_t max_seq = 0, max_v = 0;
     for (uint32_t i = 0; i < n_atts; ++i) if (job->tables[i].alias_of < 0) { max_seq = std::max(max_seq, job->tables[i].n_seq); max_v = std::max(max_v, job->tables[i].V); }
     bool host_tables = !dev;   // some table still comes from host arrays
@@ -525,10 +538,13 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
     if ((rc = t.fan_hdr.alloc((size_t)t.n_seq * 4))) return rc;
     if ((rc = t.fan_apex.alloc((size_t)t.n_seq * 4))) return rc;
     if ((rc = t.fan.alloc((size_t)t.n_seq * 32))) return rc;
-    launch_build_fans(t.seq.as<uint32_t>(), t.n_seq, t.c2r.as<uint32_t>(), t.opp.as<uint32_t>(), t.fan_hdr.as<uint32_t>(), t.fan_apex.as<uint32_t>(), t.fan.as<uint32_t>(), false, s);
+    if (defer) defer->fans.push_back(FanItem{t.seq.as<uint32_t>(), t.c2r.as<uint32_t>(), t.opp.as<uint32_t>(), t.fan_hdr.as<uint32_t>(), t.fan_apex.as<uint32_t>(), t.fan.as<uint32_t>(), 0u, t.n_seq, 0u, 0u});
+    else launch_build_fans(t.seq.as<uint32_t>(), t.n_seq, t.c2r.as<uint32_t>(), t.opp.as<uint32_t>(), t.fan_hdr.as<uint32_t>(), t.fan_apex.as<uint32_t>(), t.fan.as<uint32_t>(), false, s);
   }
   uint32_t max_point = 0;
-  if (device_relabel) {
+  if (defer) {
+    // (the connectivity stage checked the faces against the points, its caller the attributes' point and value counts)
+  } else if (device_relabel) {
     HIP_TRY(hipMemcpyAsync(&max_point, d_max_point, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
   } else {
@@ -549,7 +565,11 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
     const TableDev& t = job->tables[a.table];
     const size_t vbytes = (size_t)d.num_unique * d.num_components * 4;
     if (d.num_unique && !d.values) return fail(DMI_ERR_INVALID_ARGUMENT, "attribute values missing");
-    if (stage_host) {
+    if (defer) {
+      if ((rc = a.raw.alloc(vbytes))) return rc;
+      if (vbytes && i < defer->values_dev.size() && defer->values_dev[i]) defer->copies.push_back({a.raw.p, defer->values_dev[i], vbytes});
+      else if (vbytes) HIP_TRY(hipMemcpyAsync(a.raw.p, d.values, vbytes, hipMemcpyHostToDevice, defer->stream));
+    } else if (stage_host) {
       void* dst = staged(a.raw, vbytes);
       if (!dst) return fail(DMI_ERR_HIP, "upload staging overflow");
       if (vbytes >= ((size_t)8 << 20)) parallel_for(vbytes, [&](size_t lo, size_t hi) { std::memcpy(static_cast<uint8_t*>(dst) + lo, static_cast<const uint8_t*>(d.values) + lo, hi - lo); });
@@ -559,7 +579,11 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
       if (rc) return rc;
     }
     if (d.num_points <= max_point && F) return fail(DMI_ERR_INVALID_ARGUMENT, "attribute " + std::to_string(i) + " has fewer points than the faces reference");
-    if (d.point_to_value && device_relabel) {   // sequence index → value index, composed on the device; out-of-range entries raise d_bad
+    if (d.point_to_value && defer) {
+      if (!(i < defer->maps_dev.size() && defer->maps_dev[i])) return fail(DMI_ERR_INVALID_ARGUMENT, "deferred job creation: point_to_value map not resident");
+      if ((rc = a.s2v.alloc((size_t)t.n_seq * 4))) return rc;
+      defer->compose.push_back(ComposeItem{t.s2p.as<uint32_t>(), defer->maps_dev[i], a.s2v.as<uint32_t>(), 0u, t.n_seq});
+    } else if (d.point_to_value && device_relabel) {   // sequence index → value index, composed on the device; out-of-range entries raise d_bad
       uint32_t* d_p2v = tmpdev.take<uint32_t>(d.num_points);
       if (!d_p2v) return fail(DMI_ERR_OUT_OF_MEMORY, "hipMalloc (point_to_value upload)");
       HIP_TRY(hipMemcpyAsync(d_p2v, d.point_to_value, (size_t)d.num_points * 4, hipMemcpyHostToDevice, s));
@@ -597,7 +621,8 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
       if ((rc = a.fan_hdr.alloc((size_t)n * 4))) return rc;
       if ((rc = a.fan_apex.alloc((size_t)n * 4))) return rc;
       if ((rc = a.fan.alloc((size_t)n * 32))) return rc;
-      launch_build_fans(t.seq.as<uint32_t>(), n, pt.c2r.as<uint32_t>(), t.opp.as<uint32_t>(), a.fan_hdr.as<uint32_t>(), a.fan_apex.as<uint32_t>(), a.fan.as<uint32_t>(), true, s);
+      if (defer) defer->fans.push_back(FanItem{t.seq.as<uint32_t>(), pt.c2r.as<uint32_t>(), t.opp.as<uint32_t>(), a.fan_hdr.as<uint32_t>(), a.fan_apex.as<uint32_t>(), a.fan.as<uint32_t>(), 0u, n, 1u, 0u});
+      else launch_build_fans(t.seq.as<uint32_t>(), n, pt.c2r.as<uint32_t>(), t.opp.as<uint32_t>(), a.fan_hdr.as<uint32_t>(), a.fan_apex.as<uint32_t>(), a.fan.as<uint32_t>(), true, s);
     }
     a.bins = symbol_bins(a);
     if (a.port == kToBits) a.bins = 1u << 20;   // capacity; the real bound is checked after the min/max readback
@@ -656,7 +681,7 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
   }
   uint32_t bad_p2v = 0;
   if (d_bad) HIP_TRY(hipMemcpyAsync(&bad_p2v, d_bad, 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  if (!defer) HIP_TRY(hipStreamSynchronize(s));   // (a batch waits once, for all its jobs)
   if (bad_p2v) return fail(DMI_ERR_INVALID_ARGUMENT, "point_to_value entry out of range");
   if (trace_create) std::fprintf(stderr, "[dmi] job create (%u faces, %s relabelling): sequences %.1f ms, relabel + table uploads %.1f, attribute uploads + buffers + fan rows %.1f, stream + plan %.1f\n", F, device_relabel ? "device" : "host", t_seq, t_relabel, since_ms(tc0) - t_seq - t_relabel,
                                  std::chrono::duration<double, std::milli>(tc0 - t_enter).count());

@@ -279,8 +279,24 @@ namespace dmi {
 int to_buffer(const std::vector<uint8_t>& v, dmi_buffer* out);
 // the universal corner table of a mesh as the device connectivity stage left it in HBM (mesh-local ids, the mesh's own numbering)
 struct DeviceTableView { const uint32_t* c2p; const uint32_t* c2v; const uint32_t* opp; bool trusted_sequences; };
+// Job creation as part of a batch (dmi_meshes_prepare): the job is planned and its memory laid out on a worker thread, but every piece of
+// device work is only RECORDED here — the coordinator runs the uploads, the relabelling, the fan rows and the map compositions of all
+// jobs in one launch per kernel (dmi_prepare.cpp).  Requires device-resident tables and a mesh whose tables are all the universal one.
+struct JobDefer {
+  // in
+  hipStream_t stream = nullptr;                 // the coordinator's stream (the job's chunk is cleared on it)
+  std::vector<const void*> values_dev;          // per attribute: its raw values, already in device memory (nullptr: take them from the host pointer now)
+  std::vector<const uint32_t*> maps_dev;        // per attribute: its point → value map in device memory (nullptr = none)
+  // out
+  struct Copy { void* dst; const void* src_dev; size_t bytes; };
+  std::vector<Copy> copies;                     // device → device: values into the job's buffers
+  bool has_relabel = false;
+  RelabelItem relabel{};                        // seq = HOST pointer of the sequence (the coordinator uploads it); offsets filled by the coordinator
+  std::vector<FanItem> fans;                    // off filled by the coordinator
+  std::vector<ComposeItem> compose;
+};
 int job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tables, uint32_t n_atts, const uint32_t* seeds, uint32_t n_seeds,
-                    const dmi_config* cfg, const DeviceTableView* dev, dmi_job** job);
+                    const dmi_config* cfg, const DeviceTableView* dev, dmi_job** job, JobDefer* defer = nullptr);
 // Device temporaries of job creation / the connectivity stage: bump-allocated from cached chunks like a job's own memory (hipMalloc and
 // hipFree serialise across host threads, and hipFree waits for the device), not cleared; handed back when the work on `stream` is over.
 struct TempDev {

@@ -901,11 +901,9 @@ __device__ __forceinline__ void fan_normal_sum(uint32_t c, const uint32_t* __res
 // `overflow` and take the corner-table walk.
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t kFanSlots = 8;
-__global__ __launch_bounds__(kBlock) void k_build_fans(const uint32_t* __restrict__ seq, uint32_t n, const uint32_t* __restrict__ c2r,
-                                                       const uint32_t* __restrict__ opp, uint32_t* __restrict__ hdr, uint32_t* __restrict__ apex,
-                                                       uint32_t* __restrict__ fan, int centre_in_apex) {
-  const uint32_t blk_ = blockIdx.x, nblk_ = gridDim.x;
-  DMI_FOR_SEQUENCE(i, n) {
+__device__ __forceinline__ void build_fan_row(uint32_t i, const uint32_t* __restrict__ seq, const uint32_t* __restrict__ c2r, const uint32_t* __restrict__ opp,
+                                              uint32_t* __restrict__ hdr, uint32_t* __restrict__ apex, uint32_t* __restrict__ fan, int centre_in_apex) {
+  {
     const uint32_t c = seq[i];
     uint32_t row[kFanSlots];
 #pragma unroll
@@ -959,6 +957,21 @@ __global__ __launch_bounds__(kBlock) void k_build_fans(const uint32_t* __restric
     uint4* dst = reinterpret_cast<uint4*>(fan + (size_t)i * kFanSlots);
     dst[0] = make_uint4(row[0], row[1], row[2], row[3]);
     dst[1] = make_uint4(row[4], row[5], row[6], row[7]);
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_build_fans(const uint32_t* __restrict__ seq, uint32_t n, const uint32_t* __restrict__ c2r,
+                                                       const uint32_t* __restrict__ opp, uint32_t* __restrict__ hdr, uint32_t* __restrict__ apex,
+                                                       uint32_t* __restrict__ fan, int centre_in_apex) {
+  const uint32_t blk_ = blockIdx.x, nblk_ = gridDim.x;
+  DMI_FOR_SEQUENCE(i, n) build_fan_row(i, seq, c2r, opp, hdr, apex, fan, centre_in_apex);
+}
+// the fan rows of many (small) tables in one launch: entry g of the concatenation belongs to the last item whose offset is ≤ g
+__global__ __launch_bounds__(kBlock) void k_build_fans_batch(const FanItem* __restrict__ items, uint32_t n_items, uint32_t total) {
+  for (uint32_t g = blockIdx.x * kBlock + threadIdx.x; g < total; g += gridDim.x * kBlock) {
+    uint32_t lo = 0, hi = n_items;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (items[mid].off <= g) lo = mid; else hi = mid; }
+    const FanItem it = items[lo];
+    build_fan_row(g - it.off, it.seq, it.c2r, it.opp, it.hdr, it.apex, it.fan, (int)it.centre_in_apex);
   }
 }
 
@@ -1769,6 +1782,10 @@ void launch_pred_texcoord_wrapped(const uint32_t* seq, uint32_t n, const uint32_
 void launch_build_fans(const uint32_t* seq, uint32_t n, const uint32_t* c2r, const uint32_t* opp, uint32_t* hdr, uint32_t* apex, uint32_t* fan, bool centre_in_apex,
                        hipStream_t s) {
   if (n) hipLaunchKernelGGL(k_build_fans, grid_for(n, 8192), kBlock, 0, s, seq, n, c2r, opp, hdr, apex, fan, centre_in_apex ? 1 : 0);
+}
+
+void launch_build_fans_batch(const FanItem* items_dev, uint32_t n_items, uint32_t total, hipStream_t s) {
+  if (n_items && total) hipLaunchKernelGGL(k_build_fans_batch, grid_for(total, 65535u * 16u), kBlock, 0, s, items_dev, n_items, total);
 }
 
 uint32_t predict_fused_blocks(uint32_t n) {

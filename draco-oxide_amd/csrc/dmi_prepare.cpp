@@ -17,6 +17,14 @@ std::shared_ptr<StreamHolder> thread_stream(int device) {
   return h;
 }
 
+// The universal corner table of a mesh as the device connectivity stage built it, read back for the host's serial walks (pinned staging).
+struct PrebuiltTable {
+  const uint32_t *c2v = nullptr, *opp = nullptr, *lmc = nullptr;
+  const uint8_t* on_boundary = nullptr;
+  uint32_t V = 0;
+  bool no_boundary = false;
+};
+
 constexpr uint32_t kDeviceTablesMinFaces = 1u << 16;   // a single mesh from this size up gets its universal corner table from the device (dmi_conn.hip)
 
 // The universal corner table of ONE mesh built on the device (dmi_conn.hip) and read back for the host's serial walks: faces up,
@@ -29,16 +37,14 @@ struct DeviceTables {
   HostStage* host = nullptr;
   uint32_t *d_faces = nullptr, *d_c2v = nullptr, *d_opp = nullptr, *d_lmc = nullptr;
   uint8_t* d_onb = nullptr;
-  const uint32_t *h_opp = nullptr, *h_c2v = nullptr;
-  uint32_t* h_lmc = nullptr;
-  const uint8_t* h_onb = nullptr;
+  PrebuiltTable pre;
   uint32_t V = 0, Vcap = 0, flags = 0;
-  bool valid = false, have_lmc = false;
+  bool valid = false;
   double t_up = 0, t_kernels = 0, t_down = 0;
   ~DeviceTables() { if (stream && valid) (void)hipStreamSynchronize(stream); release_stage(host); }
 
   // DMI_OK with valid = true: ct views the tables; DMI_OK with valid = false: not covered (the caller runs the host builder); else an error
-  int build(const dmi_mesh* mesh, CornerTables& ct) {
+  int build(const dmi_mesh* mesh, std::vector<uint32_t>& c2v_store) {
     const uint32_t F = mesh->num_faces;
     const size_t C = (size_t)F * 3;
     const dmi_attribute& pos = mesh->atts[0];
@@ -72,8 +78,8 @@ struct DeviceTables {
     uint8_t* hp = host->p;
     uint32_t* hp_opp = reinterpret_cast<uint32_t*>(hp);
     uint32_t* hp_c2v = mapped ? hp_opp + C : nullptr;
-    h_lmc = reinterpret_cast<uint32_t*>(hp + C * 4 * (mapped ? 2 : 1));
-    uint8_t* hp_onb = reinterpret_cast<uint8_t*>(h_lmc + nv);
+    uint32_t* hp_lmc = reinterpret_cast<uint32_t*>(hp + C * 4 * (mapped ? 2 : 1));
+    uint8_t* hp_onb = reinterpret_cast<uint8_t*>(hp_lmc + nv);
     uint32_t* hp_words = reinterpret_cast<uint32_t*>(hp + ((C * 4 * (mapped ? 2 : 1) + nv * 5 + 255) & ~(size_t)255));
     const ConnMeshDesc desc{0u, 0u, F, Vcap, mapped ? 0u : kNone, P, 0u, 0u};
     HIP_TRY(hipMemcpyAsync(d_desc, &desc, sizeof desc, hipMemcpyHostToDevice, stream));
@@ -88,14 +94,15 @@ struct DeviceTables {
     HIP_TRY(hipMemcpyAsync(hp_opp, d_opp, C * 4, hipMemcpyDeviceToHost, stream));
     if (mapped) HIP_TRY(hipMemcpyAsync(hp_c2v, d_c2v, C * 4, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(hp_onb, d_onb, Vcap, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(hp_lmc, d_lmc, (size_t)Vcap * 4, hipMemcpyDeviceToHost, stream));
     t_kernels = ms();
     // while the device works: the vertex ids of a mesh without a position map are its faces — the walks read them at random, so they get a
     // copy on huge pages (the caller's array is on whatever pages its allocator chose); storage from the host pool, written in parallel slices
     const uint32_t* c2v_host = nullptr;
     if (!mapped) {
-      pool_fit(ct.c2v_own, C);
-      if (ct.c2v_own.capacity() < C) ct.c2v_own.reserve(C);   // (below the pool's size threshold pool_fit hands out an empty vector)
-      uint32_t* dst = ct.c2v_own.data();   // (capacity ≥ C; the vector's size stays 0: it only carries the storage back to the pool)
+      pool_fit(c2v_store, C);
+      if (c2v_store.capacity() < C) c2v_store.reserve(C);   // (below the pool's size threshold pool_fit hands out an empty vector)
+      uint32_t* dst = c2v_store.data();   // (capacity ≥ C; the vector's size stays 0: it only carries the storage back to the pool)
       const uint32_t* src = mesh->faces;
       parallel_for(C, [&](size_t lo, size_t hi) { std::memcpy(dst + lo, src + lo, (hi - lo) * 4); });
       c2v_host = dst;
@@ -107,26 +114,18 @@ struct DeviceTables {
     if (flags & (CONN_DEGENERATE | CONN_NONMANIFOLD_EDGE | CONN_MULTI_FAN)) return DMI_OK;   // the reference's serial walks decide (host_conn.cpp)
     if (flags & CONN_UNUSED_VERTEX) return fail(DMI_ERR_UNUSED_VERTICES, "mesh contains unused vertices");
     V = hp_words[1] + 1;
-    h_opp = hp_opp; h_c2v = hp_c2v; h_onb = hp_onb;
-    ct.F = F; ct.V = V;
-    ct.c2p = mesh->faces;
-    ct.c2v = mapped ? h_c2v : c2v_host;
-    ct.opp = h_opp;
-    ct.lmc = nullptr;   // fetch_lmc() when a reader needs it
-    ct.no_boundary = !(flags & CONN_HAS_BOUNDARY);
-    ct.att.clear();
+    pre.c2v = mapped ? hp_c2v : c2v_host; pre.opp = hp_opp; pre.lmc = hp_lmc; pre.on_boundary = hp_onb; pre.V = V;
+    pre.no_boundary = !(flags & CONN_HAS_BOUNDARY);
     valid = true;
     return DMI_OK;
   }
-  int fetch_lmc(CornerTables& ct) {
-    if (!valid || have_lmc) return DMI_OK;
-    HIP_TRY(hipMemcpyAsync(h_lmc, d_lmc, (size_t)V * 4, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    ct.lmc = h_lmc;
-    have_lmc = true;
-    return DMI_OK;
-  }
 };
+void view_prebuilt(CornerTables& ct, const dmi_mesh* mesh, const PrebuiltTable& pre) {
+  ct.F = mesh->num_faces; ct.V = pre.V;
+  ct.c2p = mesh->faces; ct.c2v = pre.c2v; ct.opp = pre.opp; ct.lmc = pre.lmc;
+  ct.no_boundary = pre.no_boundary;
+  ct.att.clear();
+}
 
 }  // namespace
 
@@ -151,7 +150,8 @@ struct ConnOwner {
   std::vector<dmi_corner_table> views;
 };
 
-static int build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std::vector<uint8_t>& bytes, DeviceTables* dt = nullptr) {
+// pre (nullable): the universal table already built by the device stage; view_faces: c2p may view the caller's face array (it outlives `o`)
+static int build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std::vector<uint8_t>& bytes, const PrebuiltTable* pre = nullptr, bool view_faces = false) {
   if (!mesh || !mesh->atts || mesh->num_atts == 0 || (!mesh->faces && mesh->num_faces)) return fail(DMI_ERR_INVALID_ARGUMENT, "bad mesh");
   if (mesh->atts[0].att_type != DMI_ATT_POSITION) return fail(DMI_ERR_INVALID_ARGUMENT, "attribute 0 must be the Position attribute (core/mesh/builder.rs:115-125)");
   for (uint32_t i = 0; i < mesh->num_atts; ++i)
@@ -162,8 +162,8 @@ static int build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std::vector<ui
   auto since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
   auto c0 = tick();
   int rc = DMI_OK;
-  if (dt && (rc = dt->build(mesh, o.ct))) return rc;   // (the device pass range-checks the faces and the position map itself)
-  const bool on_device = dt && dt->valid;
+  const bool on_device = pre != nullptr;   // (the device pass range-checked the faces and the position map itself)
+  if (pre) view_prebuilt(o.ct, mesh, *pre);
   {   // faces index the attributes' points (and, through point_to_value, their values) from here on
     const size_t C = (size_t)mesh->num_faces * 3;
     const uint32_t P = mesh->atts[0].num_points;
@@ -178,7 +178,7 @@ static int build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std::vector<ui
     }
   }
   if (!on_device) {
-    rc = o.ct.build_universal(mesh->faces, mesh->num_faces, mesh->atts[0].point_to_value, err, /*copy_faces=*/!dt);
+    rc = o.ct.build_universal(mesh->faces, mesh->num_faces, mesh->atts[0].point_to_value, err, /*copy_faces=*/!view_faces);
     if (rc) return fail(rc, err);
   }
   const double t_univ = since(c0);
@@ -196,16 +196,12 @@ static int build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std::vector<ui
   auto universal_view = [&](dmi_corner_table& v) { v.num_vertices = o.ct.V; v.corner_to_vertex = o.ct.c2v; v.opposite = o.ct.opp; v.left_most_corner = o.ct.lmc; };
   Pooled<uint8_t> on_boundary_p;
   std::vector<uint8_t>& on_boundary = on_boundary_p.v;
-  const uint8_t* boundary_flags = on_device ? dt->h_onb : nullptr;   // per vertex: on a boundary of the universal table (the device pass computes them with the left-most corners)
+  const uint8_t* boundary_flags = on_device ? pre->on_boundary : nullptr;   // per vertex: on a boundary of the universal table (the device pass computes them with the left-most corners)
   auto sequence_universal = [&] {
     TableRef tr{o.ct.F, o.ct.V, o.ct.c2v, o.ct.opp, o.ct.lmc};
     attribute_sequence(tr, o.eb.seeds.data(), (uint32_t)o.eb.seeds.size(), o.seqs[0], boundary_flags ? boundary_flags : (on_boundary.empty() ? nullptr : on_boundary.data()));
   };
-  if (on_device) {   // the host attribute-table builder walks fans from the left-most corners: fetched only for meshes with an attribute indexed unlike the Position attribute
-    bool need_lmc = false;
-    for (const uint32_t* m : maps) need_lmc = need_lmc || m != mesh->atts[0].point_to_value;
-    if (need_lmc && (rc = dt->fetch_lmc(o.ct))) return rc;
-  }
+
   auto build_att_tables = [&] {
     const auto a0 = tick();
     // an attribute indexed like the Position attribute has no seams but the boundary; one indexed like an earlier attribute has that one's table
@@ -278,7 +274,6 @@ static int build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std::vector<ui
     }
   }
   if (!overlap) t_seq = since(c2);
-  if (trace && on_device) std::fprintf(stderr, "[dmi]   universal table of %u faces on the device: uploads issued %.2f ms, kernels + read-back issued %.2f, arrived %.2f (flags %#x)\n", mesh->num_faces, dt->t_up, dt->t_kernels, dt->t_down, dt->flags);
   if (trace) std::fprintf(stderr, "[dmi] host connectivity of %u faces (%s): universal corner table %.1f ms, attribute tables %.1f, Edgebreaker %.1f, universal sequencer %.1f, seam-table sequencers + views %.1f; total %.1f\n",
                           mesh->num_faces, overlap ? "overlapped: attribute tables and sequencer beside the Edgebreaker walk" : "in sequence", t_univ, t_att, t_eb, t_seq, since(c2), since(c0));
   return DMI_OK;
@@ -294,18 +289,16 @@ int dmi_device_corner_table(const dmi_mesh* mesh, const dmi_config* cfg, uint32_
   auto holder = thread_stream(dt.device);
   if (!holder) return fail(DMI_ERR_HIP, "hipStreamCreate");
   dt.stream = cfg && cfg->stream ? static_cast<hipStream_t>(cfg->stream) : holder->s;
-  CornerTables ct;
+  std::vector<uint32_t> c2v_store;
   *flags = 0; *num_vertices = 0;
-  const int rc = dt.build(mesh, ct);
+  const int rc = dt.build(mesh, c2v_store);
   *flags = dt.flags;
   if (rc) return rc;
   if (!dt.valid) return DMI_OK;   // flags say why: the host builder's case
-  int rc2 = dt.fetch_lmc(ct);
-  if (rc2) return rc2;
   *num_vertices = dt.V;
-  std::memcpy(opposite, dt.h_opp, (size_t)mesh->num_faces * 12);
-  if (left_most_corner) std::memcpy(left_most_corner, dt.h_lmc, (size_t)dt.V * 4);
-  if (on_boundary) std::memcpy(on_boundary, dt.h_onb, dt.V);
+  std::memcpy(opposite, dt.pre.opp, (size_t)mesh->num_faces * 12);
+  if (left_most_corner) std::memcpy(left_most_corner, dt.pre.lmc, (size_t)dt.V * 4);
+  if (on_boundary) std::memcpy(on_boundary, dt.pre.on_boundary, dt.V);
   return DMI_OK;
 }
 
@@ -358,7 +351,11 @@ int dmi_mesh_prepare(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buffer* he
         if (g_adopt_stream) dt.stream = g_adopt_stream->s;
       }
     }
-    rc = build_connectivity(mesh, o, bytes, want_device && dt.stream ? &dt : nullptr);
+    if (want_device && dt.stream) {
+      if ((rc = dt.build(mesh, o.ct.c2v_own))) return rc;
+      if (trace) std::fprintf(stderr, "[dmi]   universal table of %u faces on the device: uploads issued %.2f ms, kernels + read-back issued %.2f, arrived %.2f (flags %#x)\n", mesh->num_faces, dt.t_up, dt.t_kernels, dt.t_down, dt.flags);
+    }
+    rc = build_connectivity(mesh, o, bytes, dt.valid ? &dt.pre : nullptr, /*view_faces=*/true);
     if (rc) return rc;
     t_conn = ms();
     const DeviceTableView view{dt.d_faces, dt.d_c2v, dt.d_opp, true};
@@ -404,6 +401,357 @@ int dmi_shard_meshes(const dmi_mesh* meshes, uint32_t n, uint32_t n_devices, int
   }
   return DMI_OK;
 }
+
+// ---- dmi_meshes_prepare, device form -------------------------------------------------------------------------------------------
+// The meshes of a batch that live on one device go through the connectivity stage TOGETHER: their faces (and position maps) are packed
+// into one staging copy, the universal corner tables of all of them come out of one launch per kernel (dmi_conn.hip) and back in one
+// read-back; host threads then run what is serial per mesh (attribute tables, Edgebreaker, sequencers) and lay every job out in its
+// own device memory without issuing device work; the coordinator finally uploads all sequences in one copy and runs the coding-order
+// relabelling, the fan rows and the map compositions of all jobs in one launch per kernel.  Raw attribute values travel up beside the
+// host walks.  A mesh the order-free table construction does not cover (device flags), or one with an attribute table of its own
+// (interior seams), takes the per-mesh path (dmi_mesh_prepare) — same bytes either way (tests/test_gpu_batch_prepare.py).
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// Two more library streams per (host thread, device): consecutive groups of a slice alternate between them, so the read-back of one
+// group's tables overlaps the upload of the next group's faces (the two directions of the link run side by side).
+static hipStream_t group_stream(int device, int which) {
+  static thread_local std::vector<std::pair<int, std::shared_ptr<StreamHolder>>> mine[2];
+  for (auto& e : mine[which]) if (e.first == device) return e.second->s;
+  auto h = std::make_shared<StreamHolder>();
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  mine[which].push_back({device, h});
+  return h->s;
+}
+
+namespace {
+// One group of a slice: its meshes' faces / maps / values concatenated in one upload region, its tables in one read-back.
+struct PrepGroup {
+  struct MeshLay { size_t faces = 0, pos_map = (size_t)-1; std::vector<size_t> values, maps; uint32_t face_off = 0, vert_off = 0, Vcap = 0; bool mapped = false; };
+  std::vector<uint32_t> which;   // mesh indices (into the caller's array)
+  std::vector<MeshLay> lay;
+  uint64_t total_faces = 0, total_verts = 0;
+  size_t up_a = 0, up_b = 0, C = 0;
+  bool any_mapped = false;
+  hipStream_t S = nullptr;
+  TempDev mem;
+  HostStage* stage = nullptr;
+  uint8_t* hp = nullptr;
+  uint8_t* d_up = nullptr;
+  const uint32_t* d_faces = nullptr;
+  uint32_t *d_c2v = nullptr, *d_opp = nullptr;
+  size_t rb_opp = 0, rb_c2v = 0, rb_lmc = 0, rb_onb = 0, rb_words = 0;
+  hipEvent_t ev_tables = nullptr, ev_values = nullptr;
+  bool tables_in = false;
+  std::mutex wait_mutex;
+  ~PrepGroup() {
+    if (S) (void)hipStreamSynchronize(S);
+    if (ev_tables) (void)hipEventDestroy(ev_tables);
+    if (ev_values) (void)hipEventDestroy(ev_values);
+    release_stage(stage);
+  }
+  int wait_tables() {   // (any worker: the first one blocks on the event, the others on the mutex)
+    std::lock_guard<std::mutex> lock(wait_mutex);
+    if (tables_in) return DMI_OK;
+    HIP_TRY(hipEventSynchronize(ev_tables));
+    tables_in = true;
+    return DMI_OK;
+  }
+};
+}  // namespace
+
+static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32_t>& which_all, const dmi_config& cfg0, int device, uint32_t n_threads,
+                                dmi_buffer* heads, dmi_job** jobs, std::vector<uint8_t>& done, const std::function<std::shared_ptr<StreamHolder>(uint32_t, int)>& worker_stream) {
+  const uint32_t M = (uint32_t)which_all.size();
+  if (!M) return DMI_OK;
+  const bool trace = std::getenv("DMI_TRACE") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+  HIP_TRY(hipSetDevice(device));
+  auto holder = thread_stream(device);
+  if (!holder) return fail(DMI_ERR_HIP, "hipStreamCreate");
+  hipStream_t S = holder->s;   // the coordinator's stream: job chunks are cleared on it, the deferred kernels of all jobs run on it
+  struct SyncOnExit { hipStream_t s; ~SyncOnExit() { (void)hipStreamSynchronize(s); } } sync_on_exit{S};   // (also on error paths: a job the caller then destroys must not have its chunk cleared late)
+  // ---- groups of ≈ 8M faces: the tables of the first arrive while the last is still being sent ----
+  static const uint64_t group_faces = std::getenv("DMI_PREP_GROUP_FACES") ? (uint64_t)std::atoll(std::getenv("DMI_PREP_GROUP_FACES")) : (uint64_t)(6u << 20);
+  std::vector<std::unique_ptr<PrepGroup>> groups;
+  std::vector<std::pair<uint32_t, uint32_t>> where(M);   // position in which_all → (group, index within the group)
+  for (uint32_t k = 0; k < M; ++k) {
+    const dmi_mesh& m = meshes[which_all[k]];
+    if (groups.empty() || groups.back()->total_faces + m.num_faces > group_faces) {
+      if (groups.empty() || groups.back()->total_faces) groups.emplace_back(new PrepGroup());
+    }
+    PrepGroup& g = *groups.back();
+    PrepGroup::MeshLay l;
+    l.face_off = (uint32_t)g.total_faces; l.vert_off = (uint32_t)g.total_verts; l.Vcap = m.atts[0].num_unique;
+    l.mapped = m.atts[0].point_to_value != nullptr;
+    g.any_mapped = g.any_mapped || l.mapped;
+    g.total_faces += m.num_faces; g.total_verts += l.Vcap;
+    where[k] = {(uint32_t)groups.size() - 1, (uint32_t)g.which.size()};
+    g.which.push_back(which_all[k]);
+    g.lay.push_back(std::move(l));
+  }
+  auto parallel_over = [&](uint32_t count, const std::function<int(uint32_t, uint32_t)>& fn, const std::function<uint64_t(uint32_t)>& weight) -> int {   // fn(worker, i), heaviest first unless weight is null
+    std::vector<uint32_t> order(count);
+    for (uint32_t k = 0; k < count; ++k) order[k] = k;
+    if (weight) std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return weight(x) > weight(y); });
+    std::atomic<uint32_t> next{0};
+    const uint32_t nt = std::max(1u, std::min(n_threads, count));
+    std::vector<int> rcs(nt, DMI_OK);
+    std::vector<std::string> errs(nt);
+    auto work = [&](uint32_t t) {
+      (void)hipSetDevice(device);
+      for (uint32_t i; (i = next.fetch_add(1)) < count;) { const int rc = fn(t, order[i]); if (rc) { rcs[t] = rc; errs[t] = g_last_error; next.store(count); return; } }
+    };
+    if (nt == 1) work(0);
+    else { std::vector<std::thread> th; for (uint32_t t = 0; t < nt; ++t) th.emplace_back(work, t); for (auto& x : th) x.join(); }
+    for (uint32_t t = 0; t < nt; ++t) if (rcs[t]) return fail(rcs[t], errs[t]);
+    return DMI_OK;
+  };
+  int rc;
+  // ---- phase 1, group by group: layout, pack, send, build the tables, fetch them (nothing here waits for the device) ----
+  for (size_t gi = 0; gi < groups.size(); ++gi) {
+    PrepGroup& g = *groups[gi];
+    const uint32_t Mg = (uint32_t)g.which.size();
+    g.S = group_stream(device, (int)(gi & 1));
+    if (!g.S) return fail(DMI_ERR_HIP, "hipStreamCreate");
+    g.C = (size_t)g.total_faces * 3;
+    {   // faces are ONE array (global corner index = 3·face_off + local corner): no per-mesh padding
+      size_t at = 0;
+      for (uint32_t k = 0; k < Mg; ++k) { g.lay[k].faces = at; at += (size_t)meshes[g.which[k]].num_faces * 12; }
+      g.up_a = align256(at);
+      for (uint32_t k = 0; k < Mg; ++k) if (g.lay[k].mapped) { g.lay[k].pos_map = g.up_a; g.up_a = align256(g.up_a + (size_t)meshes[g.which[k]].atts[0].num_points * 4); }
+    }
+    bool want_lmc = false;   // left-most corners are only read by the host builder of attribute tables (an attribute indexed unlike the Position attribute)
+    for (uint32_t k = 0; k < Mg; ++k) {
+      const dmi_mesh& m = meshes[g.which[k]];
+      PrepGroup::MeshLay& l = g.lay[k];
+      l.values.assign(m.num_atts, (size_t)-1); l.maps.assign(m.num_atts, (size_t)-1);
+      for (uint32_t i = 0; i < m.num_atts; ++i) {
+        const dmi_attribute& a = m.atts[i];
+        const size_t vb = (size_t)a.num_unique * a.num_components * 4;
+        if (vb) { l.values[i] = g.up_a + g.up_b; g.up_b = align256(g.up_b + ((vb + 15) & ~(size_t)15)); }
+        if (a.att_type != DMI_ATT_POSITION && a.point_to_value != m.atts[0].point_to_value) want_lmc = true;
+        if (a.point_to_value) {
+          if (i == 0) l.maps[i] = l.pos_map;
+          else {
+            bool shared = false;
+            for (uint32_t j = 0; j < i && !shared; ++j) if (m.atts[j].point_to_value == a.point_to_value) { l.maps[i] = l.maps[j]; shared = true; }
+            if (!shared) { l.maps[i] = g.up_a + g.up_b; g.up_b = align256(g.up_b + (size_t)a.num_points * 4); }
+          }
+        }
+      }
+    }
+    const size_t up_bytes = g.up_a + g.up_b, C = g.C;
+    const size_t nv = (size_t)g.total_verts + 1, parts = scan_partials_words((uint32_t)nv);
+    g.mem.init(device, g.S, up_bytes + C * 4 * (g.any_mapped ? 4 : 3) + C + nv * 4 * 4 + nv + parts * 4 + (size_t)Mg * (sizeof(ConnMeshDesc) + 8) + ((size_t)1 << 20));
+    g.d_up = g.mem.take<uint8_t>(up_bytes);
+    g.d_faces = reinterpret_cast<const uint32_t*>(g.d_up);
+    g.d_c2v = g.any_mapped ? g.mem.take<uint32_t>(C) : const_cast<uint32_t*>(g.d_faces);
+    g.d_opp = g.mem.take<uint32_t>(C);
+    uint32_t* d_lmc = g.mem.take<uint32_t>(nv);
+    uint8_t* d_onb = g.mem.take<uint8_t>(nv);
+    uint32_t* d_words = g.mem.take<uint32_t>((size_t)2 * Mg);
+    ConnMeshDesc* d_desc = g.mem.take<ConnMeshDesc>(Mg);
+    ConnArgs a{};
+    a.ecount = g.mem.take<uint32_t>(nv); a.efill = g.mem.take<uint32_t>(nv); a.first = g.mem.take<uint32_t>(nv);
+    a.he_key = g.mem.take<uint32_t>(C); a.he_corner = g.mem.take<uint32_t>(C);
+    a.cdone = g.mem.take<uint8_t>(C);
+    a.scan_partials = g.mem.take<uint32_t>(parts);
+    if (!g.d_up || !g.d_c2v || !g.d_opp || !d_lmc || !d_onb || !d_words || !d_desc || !a.ecount || !a.efill || !a.first || !a.he_key || !a.he_corner || !a.cdone || !a.scan_partials)
+      return fail(DMI_ERR_OUT_OF_MEMORY, "hipMalloc (batch connectivity stage)");
+    // host: staging of the upload | read-back: opp, [c2v], lmc, on_boundary, flags/vmax | descriptors
+    g.rb_opp = align256(up_bytes); g.rb_c2v = g.rb_opp + align256(C * 4); g.rb_lmc = g.rb_c2v + (g.any_mapped ? align256(C * 4) : 0); g.rb_onb = g.rb_lmc + align256(nv * 4);
+    g.rb_words = g.rb_onb + align256(nv);
+    const size_t rb_desc = g.rb_words + align256((size_t)Mg * 8), host_need = rb_desc + align256((size_t)Mg * sizeof(ConnMeshDesc));
+    g.stage = acquire_stage(device, host_need);
+    if (!g.stage) return fail(DMI_ERR_OUT_OF_MEMORY, "hipHostMalloc (batch connectivity staging)");
+    uint8_t* hp = g.hp = g.stage->p;
+    ConnMeshDesc* h_desc = reinterpret_cast<ConnMeshDesc*>(hp + rb_desc);
+    for (uint32_t k = 0; k < Mg; ++k) {
+      const dmi_mesh& m = meshes[g.which[k]];
+      h_desc[k] = ConnMeshDesc{g.lay[k].face_off, g.lay[k].vert_off, m.num_faces, g.lay[k].Vcap, g.lay[k].mapped ? (uint32_t)(g.lay[k].pos_map / 4) : kNone, m.atts[0].num_points, 0u, 0u};
+    }
+    auto faces_of = [&](uint32_t k) { return (uint64_t)meshes[g.which[k]].num_faces; };
+    if ((rc = parallel_over(Mg, [&](uint32_t, uint32_t k) -> int {
+          const dmi_mesh& m = meshes[g.which[k]];
+          std::memcpy(hp + g.lay[k].faces, m.faces, (size_t)m.num_faces * 12);
+          if (g.lay[k].mapped) std::memcpy(hp + g.lay[k].pos_map, m.atts[0].point_to_value, (size_t)m.atts[0].num_points * 4);
+          return DMI_OK;
+        }, faces_of))) return rc;
+    HIP_TRY(hipMemcpyAsync(g.d_up, hp, g.up_a, hipMemcpyHostToDevice, g.S));
+    HIP_TRY(hipMemcpyAsync(d_desc, h_desc, (size_t)Mg * sizeof(ConnMeshDesc), hipMemcpyHostToDevice, g.S));
+    a.meshes = d_desc; a.M = Mg; a.total_faces = (uint32_t)g.total_faces; a.total_verts = (uint32_t)g.total_verts;
+    a.faces = g.d_faces; a.p2v = reinterpret_cast<const uint32_t*>(g.d_up); a.c2v = g.d_c2v; a.opp = g.d_opp; a.lmc = d_lmc; a.on_boundary = d_onb; a.flags = d_words; a.vmax = d_words + Mg;
+    HIP_TRY(conn_tables_clear(a, g.S));
+    launch_conn_tables(a, g.S);
+    HIP_TRY(hipMemcpyAsync(hp + g.rb_words, d_words, (size_t)Mg * 8, hipMemcpyDeviceToHost, g.S));
+    HIP_TRY(hipMemcpyAsync(hp + g.rb_opp, g.d_opp, C * 4, hipMemcpyDeviceToHost, g.S));
+    if (g.any_mapped) HIP_TRY(hipMemcpyAsync(hp + g.rb_c2v, g.d_c2v, C * 4, hipMemcpyDeviceToHost, g.S));
+    if (want_lmc) HIP_TRY(hipMemcpyAsync(hp + g.rb_lmc, d_lmc, (size_t)g.total_verts * 4, hipMemcpyDeviceToHost, g.S));
+    HIP_TRY(hipMemcpyAsync(hp + g.rb_onb, d_onb, (size_t)g.total_verts, hipMemcpyDeviceToHost, g.S));
+    HIP_TRY(hipEventCreateWithFlags(&g.ev_tables, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(g.ev_tables, g.S));
+    // part B: values and attribute maps, packed while the device builds the tables and sent behind their read-back
+    if ((rc = parallel_over(Mg, [&](uint32_t, uint32_t k) -> int {
+          const dmi_mesh& m = meshes[g.which[k]];
+          for (uint32_t i = 0; i < m.num_atts; ++i) {
+            const dmi_attribute& at = m.atts[i];
+            const size_t vb = (size_t)at.num_unique * at.num_components * 4;
+            if (vb) std::memcpy(hp + g.lay[k].values[i], at.values, vb);
+            if (at.point_to_value && i > 0 && g.lay[k].maps[i] >= g.up_a) {
+              bool first = true;
+              for (uint32_t j = 0; j < i; ++j) if (m.atts[j].point_to_value == at.point_to_value) first = false;
+              if (first) std::memcpy(hp + g.lay[k].maps[i], at.point_to_value, (size_t)at.num_points * 4);
+            }
+          }
+          return DMI_OK;
+        }, faces_of))) return rc;
+    if (g.up_b) HIP_TRY(hipMemcpyAsync(g.d_up + g.up_a, hp + g.up_a, g.up_b, hipMemcpyHostToDevice, g.S));
+    HIP_TRY(hipEventCreateWithFlags(&g.ev_values, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(g.ev_values, g.S));
+  }
+  const double t_issue = ms();
+  // ---- phase 2: host walks + job layout per mesh, group by group as their tables arrive ----
+  std::vector<std::unique_ptr<ConnOwner>> owners(M);
+  std::vector<JobDefer> defers(M);
+  std::vector<uint8_t> deferred(M, 0);
+  std::vector<uint32_t> walk_order(M);   // group order; inside a group the largest mesh first
+  for (uint32_t k = 0; k < M; ++k) walk_order[k] = k;
+  std::stable_sort(walk_order.begin(), walk_order.end(), [&](uint32_t x, uint32_t y) {
+    if (where[x].first != where[y].first) return where[x].first < where[y].first;
+    return meshes[which_all[x]].num_faces > meshes[which_all[y]].num_faces;
+  });
+  rc = parallel_over(M, [&](uint32_t t, uint32_t i) -> int {
+    const uint32_t kk = walk_order[i];
+    PrepGroup& g = *groups[where[kk].first];
+    const uint32_t k = where[kk].second, j = g.which[k], Mg = (uint32_t)g.which.size();
+    const dmi_mesh& m = meshes[j];
+    int r = g.wait_tables();
+    if (r) return r;
+    auto bail = [&](int code, const std::string& what) { return fail(code, "mesh " + std::to_string(j) + ": " + what); };
+    const uint8_t* hp = g.hp;
+    const uint32_t* h_words = reinterpret_cast<const uint32_t*>(hp + g.rb_words);
+    const uint32_t flags = h_words[k];
+    if (flags & CONN_BAD_INDEX) return bail(DMI_ERR_INVALID_ARGUMENT, "face index ≥ number of points, or a position value index out of range");
+    if (flags & (CONN_DEGENERATE | CONN_NONMANIFOLD_EDGE | CONN_MULTI_FAN)) return DMI_OK;   // the per-mesh path (the reference's serial walks)
+    if (flags & CONN_UNUSED_VERTEX) return bail(DMI_ERR_UNUSED_VERTICES, "mesh contains unused vertices");
+    PrebuiltTable pre;
+    const size_t cb = (size_t)g.lay[k].face_off * 3;
+    pre.c2v = g.lay[k].mapped ? reinterpret_cast<const uint32_t*>(hp + g.rb_c2v) + cb : m.faces;
+    pre.opp = reinterpret_cast<const uint32_t*>(hp + g.rb_opp) + cb;
+    pre.lmc = reinterpret_cast<const uint32_t*>(hp + g.rb_lmc) + g.lay[k].vert_off;
+    pre.on_boundary = hp + g.rb_onb + g.lay[k].vert_off;
+    pre.V = h_words[Mg + k] + 1;
+    pre.no_boundary = !(flags & CONN_HAS_BOUNDARY);
+    owners[kk].reset(new ConnOwner());
+    ConnOwner& o = *owners[kk];
+    std::vector<uint8_t> bytes;
+    if ((r = build_connectivity(&m, o, bytes, &pre, /*view_faces=*/true))) return bail(r, g_last_error);
+    dmi_config c = cfg0;
+    c.device = device;
+    g_adopt_stream = worker_stream(t % kPrepareStreams, device);   // the job's own stream for its encodes
+    struct Drop { ~Drop() { g_adopt_stream.reset(); } } drop;
+    bool all_universal = true;
+    for (uint32_t a = 1; a < m.num_atts; ++a) all_universal = all_universal && o.views[a].corner_to_vertex == o.views[0].corner_to_vertex && o.views[a].opposite == o.views[0].opposite;
+    if (all_universal) {
+      JobDefer& d = defers[kk];
+      d.stream = S;
+      d.values_dev.assign(m.num_atts, nullptr); d.maps_dev.assign(m.num_atts, nullptr);
+      for (uint32_t a = 0; a < m.num_atts; ++a) {
+        if (g.lay[k].values[a] != (size_t)-1) d.values_dev[a] = g.d_up + g.lay[k].values[a];
+        if (g.lay[k].maps[a] != (size_t)-1) d.maps_dev[a] = reinterpret_cast<const uint32_t*>(g.d_up + g.lay[k].maps[a]);
+      }
+      const DeviceTableView view{g.d_faces + cb, g.d_c2v + cb, g.d_opp + cb, true};
+      r = job_create_impl(m.atts, o.views.data(), m.num_atts, nullptr, 0, &c, &view, &jobs[j], &d);
+      deferred[kk] = r == DMI_OK;
+    } else {   // an attribute table of its own: the host relabelling form reads the tables where the walks read them
+      r = job_create_impl(m.atts, o.views.data(), m.num_atts, o.eb.seeds.data(), (uint32_t)o.eb.seeds.size(), &c, nullptr, &jobs[j], nullptr);
+      owners[kk].reset();
+    }
+    if (r) return bail(r, g_last_error);
+    if ((r = to_buffer(bytes, &heads[j]))) return r;
+    done[j] = 1;
+    return DMI_OK;
+  }, nullptr);
+  if (rc) return rc;   // (the groups' destructors wait for their streams)
+  const double t_walks = ms();
+  // ---- phase 3: all deferred device work: sequences up in one copy, then one launch per kernel on the coordinator's stream ----
+  std::vector<RelabelItem> items;
+  std::vector<FanItem> fans;
+  std::vector<ComposeItem> comps;
+  struct Move { void* dst; const void* src; size_t bytes; };
+  std::vector<Move> moves;
+  std::vector<const uint32_t*> seq_src;
+  uint64_t rf = 0, rv = 0, rk = 0, rs = 0, fan_total = 0, comp_total = 0;
+  for (uint32_t kk = 0; kk < M; ++kk) {
+    if (!deferred[kk]) continue;
+    JobDefer& d = defers[kk];
+    if (d.has_relabel) {
+      RelabelItem it = d.relabel;
+      it.face_off = (uint32_t)rf; it.vert_off = (uint32_t)rv; it.key_off = (uint32_t)rk; it.seq_off = (uint32_t)rs;
+      seq_src.push_back(it.seq);
+      rf += it.F; rv += it.V; rk += (uint64_t)it.n_seq + 1; rs += it.n_seq;
+      items.push_back(it);
+    }
+    for (FanItem f : d.fans) { f.off = (uint32_t)fan_total; fan_total += f.n; fans.push_back(f); }
+    for (ComposeItem ci : d.compose) { ci.off = (uint32_t)comp_total; comp_total += ci.n; comps.push_back(ci); }
+    for (const auto& cp : d.copies) moves.push_back({cp.dst, cp.src_dev, (cp.bytes + 15) & ~(size_t)15});
+  }
+  if (rf >= (1ull << 32) / 3 || rv >= (1ull << 32) || rk >= (1ull << 32) || fan_total >= (1ull << 32) || comp_total >= (1ull << 32)) return fail(DMI_ERR_INVALID_ARGUMENT, "batch slice too large");
+  for (auto& g : groups) HIP_TRY(hipStreamWaitEvent(S, g->ev_values, 0));   // the values the jobs copy from must have arrived
+  TempDev mem3;
+  struct StageGuard { HostStage* st = nullptr; ~StageGuard() { release_stage(st); } } stage3;
+  if (!items.empty() || !moves.empty()) {
+    // CopyItem{destination, offset of the source relative to `base`, bytes}: one base for all groups' regions
+    const uint8_t* base = nullptr;
+    for (auto& mv : moves) if (!base || static_cast<const uint8_t*>(mv.src) < base) base = static_cast<const uint8_t*>(mv.src);
+    std::vector<CopyItem> copies;
+    copies.reserve(moves.size());
+    for (auto& mv : moves) copies.push_back(CopyItem{mv.dst, (uint64_t)(static_cast<const uint8_t*>(mv.src) - base), (uint64_t)mv.bytes});
+    const size_t off_items = align256((size_t)rs * 4), off_fans = off_items + align256(items.size() * sizeof(RelabelItem)), off_comps = off_fans + align256(fans.size() * sizeof(FanItem)),
+                 off_copies = off_comps + align256(comps.size() * sizeof(ComposeItem)), need2 = off_copies + align256(copies.size() * sizeof(CopyItem));
+    stage3.st = acquire_stage(device, need2);
+    if (!stage3.st) return fail(DMI_ERR_OUT_OF_MEMORY, "hipHostMalloc (batch sequences staging)");
+    uint8_t* h2 = stage3.st->p;
+    const size_t nk = (size_t)rk + 1, parts2 = scan_partials_words((uint32_t)nk);
+    mem3.init(device, S, need2 + (rv + 4 * rf + 2 * nk + parts2 + 64) * 4 + ((size_t)1 << 16));
+    uint8_t* d2 = mem3.take<uint8_t>(need2);
+    RelabelBatch b{};
+    b.rank = mem3.take<uint32_t>(rv ? rv : 1); b.key = mem3.take<uint32_t>(rf ? rf : 1); b.count = mem3.take<uint32_t>(nk); b.fill = mem3.take<uint32_t>(nk);
+    b.order = mem3.take<uint32_t>(rf ? rf : 1); b.new_face = mem3.take<uint32_t>(rf ? rf : 1); b.scan_partials = mem3.take<uint32_t>(parts2);
+    if (!d2 || !b.rank || !b.key || !b.count || !b.fill || !b.order || !b.new_face || !b.scan_partials) return fail(DMI_ERR_OUT_OF_MEMORY, "hipMalloc (batch relabelling)");
+    if ((rc = parallel_over((uint32_t)items.size(), [&](uint32_t, uint32_t i) -> int { std::memcpy(h2 + (size_t)items[i].seq_off * 4, seq_src[i], (size_t)items[i].n_seq * 4); return DMI_OK; },
+                            [&](uint32_t i) { return (uint64_t)items[i].n_seq; }))) return rc;
+    for (auto& it : items) it.seq = reinterpret_cast<const uint32_t*>(d2) + it.seq_off;
+    if (!items.empty()) std::memcpy(h2 + off_items, items.data(), items.size() * sizeof(RelabelItem));
+    if (!fans.empty()) std::memcpy(h2 + off_fans, fans.data(), fans.size() * sizeof(FanItem));
+    if (!comps.empty()) std::memcpy(h2 + off_comps, comps.data(), comps.size() * sizeof(ComposeItem));
+    if (!copies.empty()) std::memcpy(h2 + off_copies, copies.data(), copies.size() * sizeof(CopyItem));
+    HIP_TRY(hipMemcpyAsync(d2, h2, need2, hipMemcpyHostToDevice, S));
+    HIP_TRY(hipMemsetAsync(b.rank, 0xFF, (size_t)(rv ? rv : 1) * 4, S));
+    HIP_TRY(hipMemsetAsync(b.count, 0, nk * 4, S));
+    HIP_TRY(hipMemsetAsync(b.fill, 0, nk * 4, S));
+    b.items = reinterpret_cast<const RelabelItem*>(d2 + off_items); b.n_items = (uint32_t)items.size();
+    b.total_faces = (uint32_t)rf; b.total_verts = (uint32_t)rv; b.total_keys = (uint32_t)rk; b.total_seq = (uint32_t)rs;
+    launch_scatter_items(reinterpret_cast<const CopyItem*>(d2 + off_copies), (uint32_t)copies.size(), base, S);
+    launch_relabel_batch(b, S);
+    launch_compose_batch(reinterpret_cast<const ComposeItem*>(d2 + off_comps), (uint32_t)comps.size(), (uint32_t)comp_total, S);
+    launch_build_fans_batch(reinterpret_cast<const FanItem*>(d2 + off_fans), (uint32_t)fans.size(), (uint32_t)fan_total, S);
+  }
+  // (while the device works: the meshes' host tables go back to the pool — a thousand small frees — on the worker threads)
+  (void)parallel_over(M, [&](uint32_t, uint32_t kk) -> int { owners[kk].reset(); return DMI_OK; }, nullptr);
+  HIP_TRY(hipStreamSynchronize(S));
+  const double t_dev = ms();
+  groups.clear();
+  if (trace) {
+    uint64_t tf = 0;
+    for (uint32_t k = 0; k < M; ++k) tf += meshes[which_all[k]].num_faces;
+    std::fprintf(stderr, "[dmi] batch prepare, device form: %u meshes, %llu faces: layout + pack + issue of the connectivity kernels %.2f ms, host walks + job layouts %.2f (%u threads), "
+                         "sequences up + relabelling + fan rows %.2f, release %.2f; %zu jobs deferred, total %.2f\n", M, (unsigned long long)tf, t_issue, t_walks - t_issue, n_threads, t_dev - t_walks, ms() - t_dev, items.size(), ms());
+  }
+  return DMI_OK;
+}
+
 static int meshes_prepare_impl(const dmi_mesh* meshes, uint32_t n, const dmi_config* cfg, const int32_t* device_of_mesh, dmi_buffer* header_and_connectivity, dmi_job** jobs) {
   if (!meshes || !header_and_connectivity || !jobs || n == 0) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
   for (uint32_t j = 0; j < n; ++j) { jobs[j] = nullptr; header_and_connectivity[j] = dmi_buffer{}; }
@@ -418,7 +766,7 @@ static int meshes_prepare_impl(const dmi_mesh* meshes, uint32_t n, const dmi_con
   for (uint32_t j = 0; j < n; ++j) order[j] = j;
   std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return meshes[x].num_faces > meshes[y].num_faces; });
   const bool library_streams = !(cfg && cfg->stream);
-  auto worker_stream = [&](uint32_t t, int device) {   // worker t's stream on `device` (process-lifetime pool, created on first use)
+  const std::function<std::shared_ptr<StreamHolder>(uint32_t, int)> worker_stream = [&](uint32_t t, int device) {   // worker t's stream on `device` (process-lifetime pool, created on first use)
     static std::mutex m;
     static std::vector<std::pair<int, std::shared_ptr<StreamHolder>>> pool[kMaxPrepareWorkers];
     std::lock_guard<std::mutex> lock(m);
@@ -430,23 +778,74 @@ static int meshes_prepare_impl(const dmi_mesh* meshes, uint32_t n, const dmi_con
     }
     return found;
   };
+  // device form first (prepare_slice_device): the eligible meshes of every device in slices of ≤ 64M faces; whatever it leaves goes mesh by mesh below
+  std::vector<uint8_t> done(n, 0);
+  int ndev = 0;
+  if (!std::getenv("DMI_HOST_CONNECTIVITY") && hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) {
+    std::vector<int> devices;
+    for (uint32_t j = 0; j < n; ++j) { const int d = device_of_mesh ? device_of_mesh[j] : (cfg ? cfg->device : 0); if (std::find(devices.begin(), devices.end(), d) == devices.end()) devices.push_back(d); }
+    const uint32_t min_faces = std::getenv("DMI_BATCH_MIN_FACES") ? (uint32_t)std::atoi(std::getenv("DMI_BATCH_MIN_FACES")) : 1u;
+    auto eligible = [&](const dmi_mesh& m) {
+      if (!m.atts || m.num_atts == 0 || m.num_atts > 255 || !m.faces || m.num_faces < min_faces || m.num_faces >= kDeviceRelabelMinFaces) return false;
+      if (m.atts[0].att_type != DMI_ATT_POSITION || m.atts[0].num_unique == 0 || m.atts[0].num_points == 0) return false;
+      for (uint32_t i = 0; i < m.num_atts; ++i) if (m.atts[i].num_unique && !m.atts[i].values) return false;
+      return true;
+    };
+    std::vector<int> dev_rc(devices.size(), DMI_OK);
+    std::vector<std::string> dev_err(devices.size());
+    auto run_device = [&](size_t g) {
+      const int d = devices[g];
+      dmi_config c{};
+      if (cfg) c = *cfg;
+      c.device = d;
+      const uint32_t share = std::max(1u, n_threads / (uint32_t)devices.size());
+      std::vector<uint32_t> slice;
+      uint64_t faces = 0, verts = 0;
+      auto flush = [&]() -> int {
+        if (slice.empty()) return DMI_OK;
+        const int rc = prepare_slice_device(meshes, slice, c, d, share, header_and_connectivity, jobs, done, worker_stream);
+        slice.clear(); faces = verts = 0;
+        return rc;
+      };
+      for (uint32_t j = 0; j < n && !dev_rc[g]; ++j) {
+        if ((device_of_mesh ? device_of_mesh[j] : c.device) != d || !eligible(meshes[j])) continue;
+        if (faces + meshes[j].num_faces > (64u << 20) || verts + meshes[j].atts[0].num_unique >= (1u << 30)) { if ((dev_rc[g] = flush())) break; }
+        slice.push_back(j); faces += meshes[j].num_faces; verts += meshes[j].atts[0].num_unique;
+      }
+      if (!dev_rc[g]) dev_rc[g] = flush();
+      if (dev_rc[g]) dev_err[g] = g_last_error;
+    };
+    if (devices.size() == 1) run_device(0);
+    else { std::vector<std::thread> th; for (size_t g = 0; g < devices.size(); ++g) th.emplace_back(run_device, g); for (auto& x : th) x.join(); }
+    for (size_t g = 0; g < devices.size(); ++g)
+      if (dev_rc[g]) {
+        for (uint32_t k = 0; k < n; ++k) { if (jobs[k]) { dmi_job_destroy(jobs[k]); jobs[k] = nullptr; } dmi_free(&header_and_connectivity[k]); }
+        return fail(dev_rc[g], dev_err[g]);
+      }
+  }
   auto work = [&](uint32_t t) {
     int adopted_for = -1;
     for (;;) {
       const uint32_t k = next.fetch_add(1);
       if (k >= n) break;
       const uint32_t j = order[k];
+      if (done[j]) continue;
       dmi_config c{};
       if (cfg) c = *cfg;
       if (device_of_mesh) c.device = device_of_mesh[j];
       // (creating a stream costs ≈ 1 ms and serialises across threads: the workers share kPrepareStreams of them)
       if (library_streams && adopted_for != c.device) { g_adopt_stream = worker_stream(t % kPrepareStreams, c.device); adopted_for = c.device; }   // (null: dmi_job_create makes its own)
+      if (jobs[j]) { dmi_job_destroy(jobs[j]); jobs[j] = nullptr; }
+      dmi_free(&header_and_connectivity[j]);
       rcs[j] = dmi_mesh_prepare(&meshes[j], &c, &header_and_connectivity[j], &jobs[j]);
       if (rcs[j]) errs[j] = g_last_error;
     }
     g_adopt_stream.reset();
   };
-  if (n_threads == 1) work(0);
+  bool any_left = false;
+  for (uint32_t j = 0; j < n; ++j) any_left = any_left || !done[j];
+  if (!any_left) {}
+  else if (n_threads == 1) work(0);
   else {
     std::vector<std::thread> th;
     for (uint32_t t = 0; t < n_threads; ++t) th.emplace_back(work, t);
