@@ -52,7 +52,8 @@ class _Buffer(C.Structure):
 class _Timings(C.Structure):
     _fields_ = [("quantize_ms", C.c_float), ("predict_ms", C.c_float), ("histogram_ms", C.c_float), ("table_ms", C.c_float),
                 ("rans_ms", C.c_float), ("total_ms", C.c_float), ("predict_bytes", C.c_uint64), ("symbols", C.c_uint64), ("num_streams", C.c_uint32),
-                ("host_chains", C.c_uint32), ("longest_stream_ms", C.c_float), ("readback_wait_ms", C.c_float)]
+                ("host_chains", C.c_uint32), ("longest_stream_ms", C.c_float), ("readback_wait_ms", C.c_float),
+                ("mesh_readback_ms", C.c_float), ("tables_ms", C.c_float), ("connectivity_ms", C.c_float), ("job_create_ms", C.c_float), ("call_ms", C.c_float)]
 
 
 class _Mesh(C.Structure):
@@ -121,9 +122,11 @@ def load_library():
     L.dmi_job_encode.argtypes = [C.c_void_p, C.POINTER(_Buffer)]
     L.dmi_jobs_encode.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(_Buffer)]
     L.dmi_job_timings.argtypes = [C.c_void_p, C.POINTER(_Timings)]
+    L.dmi_last_call_timings.argtypes = [C.POINTER(_Timings)]
     L.dmi_job_destroy.argtypes = [C.c_void_p]
     L.dmi_encode_mesh.argtypes = [C.POINTER(_Mesh), C.POINTER(_Config), C.POINTER(_Buffer)]
     L.dmi_device_corner_table.argtypes = [C.POINTER(_Mesh), C.POINTER(_Config), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.dmi_encode_mesh_device.argtypes = [C.POINTER(_Mesh), C.POINTER(_Config), C.POINTER(_Buffer)]
     L.dmi_mesh_prepare.argtypes = [C.POINTER(_Mesh), C.POINTER(_Config), C.POINTER(_Buffer), C.POINTER(C.c_void_p)]
     L.dmi_mesh_build.argtypes = [C.POINTER(_RawAttribute), C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(_BuiltMesh)]
     L.dmi_built_mesh_free.argtypes = [C.POINTER(_BuiltMesh)]
@@ -600,6 +603,63 @@ def meshes_prepare(meshes, cfg=None):
     handles = (C.c_void_p * n)()
     _check(L.dmi_meshes_prepare(arr, n, C.byref(c), heads, handles))
     return [Job(handles[i], _take(heads[i])) for i in range(n)]
+
+
+def last_call_timings():
+    """dmi_last_call_timings: stage times of this thread's last whole-mesh / boundary call."""
+    t = _Timings()
+    _check(load_library().dmi_last_call_timings(C.byref(t)))
+    return {k: getattr(t, k) for k, _ in _Timings._fields_}
+
+
+class DeviceMesh:
+    """A mesh whose faces, attribute values and point → value maps live in device memory (torch tensors on one HIP device):
+    the input of dmi_encode_mesh_device.  Built from a host `Mesh` by `DeviceMesh.upload(mesh, device)`."""
+
+    def __init__(self, mesh, tensors, device):
+        self.mesh, self._t, self.device = mesh, tensors, device
+
+    @classmethod
+    def upload(cls, mesh, device=0):
+        import torch
+        dev = torch.device("cuda", device)
+        t = {"faces": torch.from_numpy(mesh.faces.view(np.int32)).to(dev), "values": [], "maps": {}}
+        for a in mesh.attributes:
+            t["values"].append(torch.from_numpy(np.ascontiguousarray(a.values).view(np.int32)).to(dev))
+            if a.point_to_value is not None and id(a.point_to_value) not in t["maps"]:
+                t["maps"][id(a.point_to_value)] = torch.from_numpy(np.ascontiguousarray(a.point_to_value, dtype=np.uint32).view(np.int32)).to(dev)
+        torch.cuda.synchronize(dev)
+        return cls(mesh, t, device)
+
+    def _c(self):
+        m = self.mesh._c()
+        m.faces = self._t["faces"].data_ptr()
+        arr = m._keep
+        for i, a in enumerate(self.mesh.attributes):
+            arr[i].values = self._t["values"][i].data_ptr()
+            if a.point_to_value is not None:
+                arr[i].point_to_value = self._t["maps"][id(a.point_to_value)].data_ptr()
+        return m
+
+
+def encode_mesh_device(dmesh, cfg=None):
+    """dmi_encode_mesh_device: whole .drc of a mesh resident in HBM."""
+    L = load_library()
+    cfg = cfg or Config(device=dmesh.device)
+    m, c, out = dmesh._c(), cfg._c(), _Buffer()
+    _check(L.dmi_encode_mesh_device(C.byref(m), C.byref(c), C.byref(out)))
+    return _take(out)
+
+
+def encode_mesh_device_raw(dmesh, cfg=None, cmesh=None):
+    """encode_mesh_device at the cost of the C-ABI call alone: the `.drc` stays in the library-owned buffer (an EncodedBatch of one item).
+    `cmesh`: a `dmesh._c()` made ahead of time (the ctypes structs of the call)."""
+    L = load_library()
+    cfg = cfg or Config(device=dmesh.device)
+    m, c = cmesh if cmesh is not None else dmesh._c(), cfg._c()
+    outs = (_Buffer * 1)()
+    _check(L.dmi_encode_mesh_device(C.byref(m), C.byref(c), outs))
+    return EncodedBatch(outs, 1)
 
 
 def encode_connectivity(mesh):

@@ -7,6 +7,7 @@
 
 namespace dmi {
 thread_local std::string g_last_error;
+thread_local dmi_timings g_last_call{};
 int host_fail(int code, const std::string& msg) { g_last_error = msg; return code; }   // shared with the host-only translation units
 ChunkCache g_chunk_cache;
 thread_local DevPool* g_active_pool = nullptr;
@@ -75,10 +76,10 @@ dmi_job::~dmi_job() {
 }
 namespace {
 
-int upload(DevMem& m, const void* src, size_t bytes, hipStream_t s) {
+int upload(DevMem& m, const void* src, size_t bytes, hipStream_t s, hipMemcpyKind kind = hipMemcpyHostToDevice) {
   int rc = m.alloc(bytes);
   if (rc) return rc;
-  if (bytes) HIP_TRY(hipMemcpyAsync(m.p, src, bytes, hipMemcpyHostToDevice, s));
+  if (bytes) HIP_TRY(hipMemcpyAsync(m.p, src, bytes, kind, s));
   return DMI_OK;
 }
 
@@ -172,6 +173,11 @@ const char* dmi_strerror(int s) {
   return "unknown";
 }
 const char* dmi_last_error(void) { return g_last_error.c_str(); }
+int dmi_last_call_timings(dmi_timings* t) {
+  if (!t) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
+  *t = g_last_call;
+  return DMI_OK;
+}
 
 int dmi_device_count(void) {
   int n = 0;
@@ -575,7 +581,7 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
       if (vbytes >= ((size_t)8 << 20)) parallel_for(vbytes, [&](size_t lo, size_t hi) { std::memcpy(static_cast<uint8_t*>(dst) + lo, static_cast<const uint8_t*>(d.values) + lo, hi - lo); });
       else if (vbytes) std::memcpy(dst, d.values, vbytes);
     } else {
-      rc = upload(a.raw, d.values, vbytes, s);
+      rc = upload(a.raw, d.values, vbytes, s, dev && dev->values_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
       if (rc) return rc;
     }
     if (d.num_points <= max_point && F) return fail(DMI_ERR_INVALID_ARGUMENT, "attribute " + std::to_string(i) + " has fewer points than the faces reference");
@@ -2098,10 +2104,16 @@ static int jobs_encode_impl(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
 int dmi_encode_attributes(const dmi_attribute* atts, const dmi_corner_table* tables, uint32_t n_atts, const uint32_t* seeds, uint32_t n_seeds,
                           const dmi_config* cfg, dmi_buffer* out) {
   dmi_job* job = nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto ms = [&] { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
   int rc = dmi_job_create(atts, tables, n_atts, seeds, n_seeds, cfg, &job);
   if (rc) return rc;
+  const float t_create = ms();
   rc = dmi_job_encode(job, out);
+  g_last_call = job->last;
+  g_last_call.job_create_ms = t_create;
   dmi_job_destroy(job);
+  g_last_call.call_ms = ms();
   return rc;
 }
 

@@ -20,6 +20,7 @@
 
 namespace dmi {
 extern thread_local std::string g_last_error;
+extern thread_local dmi_timings g_last_call;   // dmi_last_call_timings
 inline int fail(int code, const std::string& msg) { return host_fail(code, msg); }
 
 #define HIP_TRY(expr)                                                                                              \
@@ -278,7 +279,9 @@ void release_stage(HostStage* st);
 namespace dmi {
 int to_buffer(const std::vector<uint8_t>& v, dmi_buffer* out);
 // the universal corner table of a mesh as the device connectivity stage left it in HBM (mesh-local ids, the mesh's own numbering)
-struct DeviceTableView { const uint32_t* c2p; const uint32_t* c2v; const uint32_t* opp; bool trusted_sequences; };
+struct DeviceTableView { const uint32_t* c2p; const uint32_t* c2v; const uint32_t* opp; bool trusted_sequences;
+                         bool values_on_device = false;   // dmi_attribute::values are device pointers (dmi_encode_mesh_device): copied device to device
+};
 // Job creation as part of a batch (dmi_meshes_prepare): the job is planned and its memory laid out on a worker thread, but every piece of
 // device work is only RECORDED here — the coordinator runs the uploads, the relabelling, the fan rows and the map compositions of all
 // jobs in one launch per kernel (dmi_prepare.cpp).  Requires device-resident tables and a mesh whose tables are all the universal one.

@@ -44,7 +44,9 @@ struct DeviceTables {
   ~DeviceTables() { if (stream && valid) (void)hipStreamSynchronize(stream); release_stage(host); }
 
   // DMI_OK with valid = true: ct views the tables; DMI_OK with valid = false: not covered (the caller runs the host builder); else an error
-  int build(const dmi_mesh* mesh, std::vector<uint32_t>& c2v_store) {
+  // src_faces / src_pos_map (nullable): the mesh's faces / position map already in device memory (dmi_encode_mesh_device) — used where they
+  // are; `mesh` then holds their host copies on huge pages (the staging they were read back into)
+  int build(const dmi_mesh* mesh, std::vector<uint32_t>& c2v_store, const uint32_t* src_faces = nullptr, const uint32_t* src_pos_map = nullptr) {
     const uint32_t F = mesh->num_faces;
     const size_t C = (size_t)F * 3;
     const dmi_attribute& pos = mesh->atts[0];
@@ -57,8 +59,8 @@ struct DeviceTables {
     const bool mapped = pos.point_to_value != nullptr;
     const size_t nv = (size_t)Vcap + 1, parts = scan_partials_words((uint32_t)nv);
     mem.init(device, stream, C * 4 * (mapped ? 5 : 4) + (mapped ? (size_t)P * 4 : 0) + nv * 4 * 4 + nv + C + parts * 4 + ((size_t)1 << 16));
-    d_faces = mem.take<uint32_t>(C);
-    uint32_t* d_p2v = mapped ? mem.take<uint32_t>(P) : nullptr;
+    d_faces = src_faces ? const_cast<uint32_t*>(src_faces) : mem.take<uint32_t>(C);
+    uint32_t* d_p2v = mapped ? (src_pos_map ? const_cast<uint32_t*>(src_pos_map) : mem.take<uint32_t>(P)) : nullptr;
     d_c2v = mapped ? mem.take<uint32_t>(C) : d_faces;
     d_opp = mem.take<uint32_t>(C);
     d_lmc = mem.take<uint32_t>(nv);
@@ -83,8 +85,8 @@ struct DeviceTables {
     uint32_t* hp_words = reinterpret_cast<uint32_t*>(hp + ((C * 4 * (mapped ? 2 : 1) + nv * 5 + 255) & ~(size_t)255));
     const ConnMeshDesc desc{0u, 0u, F, Vcap, mapped ? 0u : kNone, P, 0u, 0u};
     HIP_TRY(hipMemcpyAsync(d_desc, &desc, sizeof desc, hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(d_faces, mesh->faces, C * 4, hipMemcpyHostToDevice, stream));
-    if (mapped) HIP_TRY(hipMemcpyAsync(d_p2v, pos.point_to_value, (size_t)P * 4, hipMemcpyHostToDevice, stream));
+    if (!src_faces) HIP_TRY(hipMemcpyAsync(d_faces, mesh->faces, C * 4, hipMemcpyHostToDevice, stream));
+    if (mapped && !src_pos_map) HIP_TRY(hipMemcpyAsync(d_p2v, pos.point_to_value, (size_t)P * 4, hipMemcpyHostToDevice, stream));
     t_up = ms();
     a.meshes = d_desc; a.M = 1; a.total_faces = F; a.total_verts = Vcap;
     a.faces = d_faces; a.p2v = d_p2v; a.c2v = d_c2v; a.opp = d_opp; a.lmc = d_lmc; a.on_boundary = d_onb; a.flags = d_words; a.vmax = d_words + 1;
@@ -99,7 +101,8 @@ struct DeviceTables {
     // while the device works: the vertex ids of a mesh without a position map are its faces — the walks read them at random, so they get a
     // copy on huge pages (the caller's array is on whatever pages its allocator chose); storage from the host pool, written in parallel slices
     const uint32_t* c2v_host = nullptr;
-    if (!mapped) {
+    if (!mapped && src_faces) c2v_host = mesh->faces;
+    else if (!mapped) {
       pool_fit(c2v_store, C);
       if (c2v_store.capacity() < C) c2v_store.reserve(C);   // (below the pool's size threshold pool_fit hands out an empty vector)
       uint32_t* dst = c2v_store.data();   // (capacity ≥ C; the vector's size stays 0: it only carries the storage back to the pool)
@@ -323,8 +326,18 @@ void dmi_conn_free(dmi_conn* conn) {
   conn->owner = nullptr; conn->tables = nullptr; conn->seeds = nullptr; conn->num_tables = conn->num_seeds = 0;
 }
 
+// src (nullable): dmi_encode_mesh_device — the device copies of the faces / position map; mesh->atts[i].values are device pointers.
+// Returns kNeedHostValues when such a mesh has to take the host builders (its values must come down first).
+struct DeviceMeshSrc { const uint32_t* faces; const uint32_t* pos_map; };
+static thread_local double g_tables_ms = 0;   // universal-table time of the running mesh_prepare_impl (device form)
+constexpr int kNeedHostValues = -77;
+static int mesh_prepare_impl(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buffer* header_and_connectivity, dmi_job** job, const DeviceMeshSrc* src);
 int dmi_mesh_prepare(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buffer* header_and_connectivity, dmi_job** job) {
+  return mesh_prepare_impl(mesh, cfg, header_and_connectivity, job, nullptr);
+}
+static int mesh_prepare_impl(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buffer* header_and_connectivity, dmi_job** job, const DeviceMeshSrc* src) {
   if (!header_and_connectivity || !job) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
+  g_tables_ms = 0;
   const bool trace = std::getenv("DMI_TRACE") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
   auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
@@ -341,7 +354,8 @@ int dmi_mesh_prepare(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buffer* he
     struct Adopt { bool set = false; ~Adopt() { if (set) g_adopt_stream.reset(); } } adopt;
     const bool in_batch = (bool)g_adopt_stream;
     int ndev = 0;
-    const bool want_device = mesh && !std::getenv("DMI_HOST_CONNECTIVITY") && mesh->num_faces >= (in_batch ? kDeviceRelabelMinFaces : kDeviceTablesMinFaces) &&
+    const bool want_device = mesh && mesh->atts && mesh->num_atts && mesh->faces && mesh->atts[0].att_type == DMI_ATT_POSITION &&
+                             (src || (!std::getenv("DMI_HOST_CONNECTIVITY") && mesh->num_faces >= (in_batch ? kDeviceRelabelMinFaces : kDeviceTablesMinFaces))) &&
                              hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0;
     if (want_device) {
       dt.device = cfg ? cfg->device : 0;
@@ -352,13 +366,15 @@ int dmi_mesh_prepare(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buffer* he
       }
     }
     if (want_device && dt.stream) {
-      if ((rc = dt.build(mesh, o.ct.c2v_own))) return rc;
+      if ((rc = dt.build(mesh, o.ct.c2v_own, src ? src->faces : nullptr, src ? src->pos_map : nullptr))) return rc;
+      g_tables_ms = dt.t_down;
       if (trace) std::fprintf(stderr, "[dmi]   universal table of %u faces on the device: uploads issued %.2f ms, kernels + read-back issued %.2f, arrived %.2f (flags %#x)\n", mesh->num_faces, dt.t_up, dt.t_kernels, dt.t_down, dt.flags);
     }
+    if (src && !dt.valid) return kNeedHostValues;
     rc = build_connectivity(mesh, o, bytes, dt.valid ? &dt.pre : nullptr, /*view_faces=*/true);
     if (rc) return rc;
     t_conn = ms();
-    const DeviceTableView view{dt.d_faces, dt.d_c2v, dt.d_opp, true};
+    const DeviceTableView view{dt.d_faces, dt.d_c2v, dt.d_opp, true, src != nullptr};
     rc = job_create_impl(mesh->atts, o.views.data(), mesh->num_atts, o.eb.seeds.data(), (uint32_t)o.eb.seeds.size(), cfg, dt.valid ? &view : nullptr, job);
     if (rc) return rc;
     t_create = ms();
@@ -366,6 +382,8 @@ int dmi_mesh_prepare(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buffer* he
     if (rc) { dmi_job_destroy(*job); *job = nullptr; }
     t_buf = ms();
   }
+  g_last_call = dmi_timings{};
+  g_last_call.tables_ms = (float)g_tables_ms; g_last_call.connectivity_ms = (float)t_conn; g_last_call.job_create_ms = (float)(t_create - t_conn);
   if (trace && mesh->num_faces > 100000) std::fprintf(stderr, "[dmi] mesh_prepare: connectivity %.1f ms, job create %.1f, output buffer %.1f, release of the host tables %.1f\n", t_conn, t_create - t_conn, t_buf - t_create, ms() - t_buf);
   return rc;
 }
@@ -905,6 +923,7 @@ int dmi_encode_mesh(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buffer* out
   const double t_prep = ms();
   rc = dmi_job_encode(job, &att);
   const double t_enc = ms();
+  { const dmi_timings pre = g_last_call; g_last_call = job->last; g_last_call.tables_ms = pre.tables_ms; g_last_call.connectivity_ms = pre.connectivity_ms; g_last_call.job_create_ms = pre.job_create_ms; }
   dmi_job_destroy(job);
   const double t_destroy = ms();
   if (rc) { dmi_free(&head); return rc; }
@@ -916,7 +935,81 @@ int dmi_encode_mesh(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buffer* out
   out->len = out->cap = head.len + att.len;
   dmi_free(&head);
   dmi_free(&att);
+  g_last_call.call_ms = (float)ms();
   if (trace) std::fprintf(stderr, "[dmi] encode_mesh: prepare %.1f ms, encode %.1f, job destroy %.1f, splice %.1f\n", t_prep, t_enc - t_prep, t_destroy - t_enc, ms() - t_destroy);
+  return DMI_OK;
+}
+
+// encode::encode for a mesh whose buffers already live in HBM: `mesh` is a host struct whose faces, attribute values and point → value maps
+// are DEVICE pointers on cfg->device.  Faces and maps are read back once (the Edgebreaker traversal and the sequencer are serial host walks),
+// the values never leave the device; the tables are built from the device faces where they are.
+int dmi_encode_mesh_device(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buffer* out) {
+  if (!out || !mesh || !mesh->atts || mesh->num_atts == 0 || mesh->num_atts > 255 || (!mesh->faces && mesh->num_faces)) return fail(DMI_ERR_INVALID_ARGUMENT, "bad mesh");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(DMI_ERR_NO_DEVICE, "no HIP device visible; libdraco_mi has no CPU fallback");
+  const int device = cfg ? cfg->device : 0;
+  HIP_TRY(hipSetDevice(device));
+  auto holder = thread_stream(device);
+  if (!holder) return fail(DMI_ERR_HIP, "hipStreamCreate");
+  hipStream_t s = cfg && cfg->stream ? static_cast<hipStream_t>(cfg->stream) : holder->s;
+  const bool trace = std::getenv("DMI_TRACE") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+  // host shadow: faces and the distinct maps in one pinned read-back (huge pages: the walks read the faces from there)
+  const size_t C = (size_t)mesh->num_faces * 3;
+  std::vector<dmi_attribute> atts(mesh->atts, mesh->atts + mesh->num_atts);
+  std::vector<size_t> map_at(mesh->num_atts, (size_t)-1);
+  size_t need = ((C * 4 + 255) & ~(size_t)255);
+  for (uint32_t i = 0; i < mesh->num_atts; ++i) {
+    if (!atts[i].point_to_value) continue;
+    for (uint32_t j = 0; j < i; ++j) if (mesh->atts[j].point_to_value == atts[i].point_to_value) map_at[i] = map_at[j];
+    if (map_at[i] == (size_t)-1) { map_at[i] = need; need += ((size_t)atts[i].num_points * 4 + 255) & ~(size_t)255; }
+  }
+  struct StageGuard { HostStage* st = nullptr; ~StageGuard() { release_stage(st); } } stage;
+  stage.st = acquire_stage(device, need + 256);
+  if (!stage.st) return fail(DMI_ERR_OUT_OF_MEMORY, "hipHostMalloc (mesh read-back)");
+  uint8_t* hp = stage.st->p;
+  if (C) HIP_TRY(hipMemcpyAsync(hp, mesh->faces, C * 4, hipMemcpyDeviceToHost, s));
+  for (uint32_t i = 0; i < mesh->num_atts; ++i) {
+    if (!atts[i].point_to_value) continue;
+    bool first = true;
+    for (uint32_t j = 0; j < i; ++j) if (mesh->atts[j].point_to_value == mesh->atts[i].point_to_value) first = false;
+    if (first) HIP_TRY(hipMemcpyAsync(hp + map_at[i], mesh->atts[i].point_to_value, (size_t)atts[i].num_points * 4, hipMemcpyDeviceToHost, s));
+    atts[i].point_to_value = reinterpret_cast<const uint32_t*>(hp + map_at[i]);
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  const double t_down = ms();
+  dmi_mesh shadow{reinterpret_cast<const uint32_t*>(hp), mesh->num_faces, atts.data(), mesh->num_atts};
+  const DeviceMeshSrc src{mesh->faces, mesh->atts[0].point_to_value};
+  dmi_buffer head{}, att{};
+  dmi_job* job = nullptr;
+  int rc = mesh_prepare_impl(&shadow, cfg, &head, &job, &src);
+  std::vector<std::vector<uint8_t>> host_values;
+  if (rc == kNeedHostValues) {   // outside the order-free class: the reference's serial walks and the host relabelling read everything on the host
+    host_values.resize(mesh->num_atts);
+    for (uint32_t i = 0; i < mesh->num_atts; ++i) {
+      const size_t vb = (size_t)atts[i].num_unique * atts[i].num_components * 4;
+      host_values[i].resize(vb ? vb : 1);
+      if (vb) HIP_TRY(hipMemcpy(host_values[i].data(), atts[i].values, vb, hipMemcpyDeviceToHost));
+      atts[i].values = host_values[i].data();
+    }
+    rc = mesh_prepare_impl(&shadow, cfg, &head, &job, nullptr);
+  }
+  if (rc) return rc;
+  const double t_prep = ms();
+  rc = dmi_job_encode(job, &att);
+  { const dmi_timings pre = g_last_call; g_last_call = job->last; g_last_call.tables_ms = pre.tables_ms; g_last_call.connectivity_ms = pre.connectivity_ms; g_last_call.job_create_ms = pre.job_create_ms; g_last_call.mesh_readback_ms = (float)t_down; }
+  dmi_job_destroy(job);
+  if (rc) { dmi_free(&head); return rc; }
+  out->data = static_cast<uint8_t*>(std::malloc(head.len + att.len ? head.len + att.len : 1));
+  if (!out->data) { dmi_free(&head); dmi_free(&att); return fail(DMI_ERR_OUT_OF_MEMORY, "out of host memory"); }
+  std::memcpy(out->data, head.data, head.len);
+  std::memcpy(out->data + head.len, att.data, att.len);
+  out->len = out->cap = head.len + att.len;
+  dmi_free(&head);
+  dmi_free(&att);
+  g_last_call.call_ms = (float)ms();
+  if (trace) std::fprintf(stderr, "[dmi] encode_mesh_device: faces + maps read back %.1f ms, prepare %.1f, encode + splice %.1f\n", t_down, t_prep - t_down, ms() - t_prep);
   return DMI_OK;
 }
 

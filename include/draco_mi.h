@@ -108,7 +108,16 @@ typedef struct dmi_timings {
   uint32_t host_chains;      /* 1 = the streams of this encode were coded on host cores (hybrid form, long single meshes), 0 = on the device */
   float longest_stream_ms;   /* hybrid form: the coder of the longest stream alone (its symbols already on the host); device form: 0 */
   float readback_wait_ms;    /* hybrid form: time the longest stream's host thread waited for its symbols / tables to arrive */
+  /* whole-mesh calls only (dmi_last_call_timings): host wall clock of the stages around the encode */
+  float mesh_readback_ms;    /* dmi_encode_mesh_device: faces + maps read back for the host walks */
+  float tables_ms;           /* universal corner table: device kernels + read-back (or the host builder) */
+  float connectivity_ms;     /* the whole connectivity stage, tables_ms included: Edgebreaker traversal, connectivity bytes, sequencers */
+  float job_create_ms;       /* coding-order relabelling, uploads, fan rows, buffers */
+  float call_ms;             /* the whole call */
 } dmi_timings;
+/* Timings of the last dmi_encode_mesh / dmi_encode_mesh_device / dmi_encode_attributes call of the calling thread (per-stage device
+ * times when that call's dmi_config carried DMI_FLAG_TIMINGS). */
+int dmi_last_call_timings(dmi_timings* t);
 
 /* --- Drop-in for attribute::encode_attributes (encode/attribute/mod.rs:13-93) ------------------
  * atts[i] is encoded against tables[i]; `seeds` = Output::corners_of_edgebreaker
@@ -153,6 +162,11 @@ typedef struct dmi_mesh {
   uint32_t num_atts;
 } dmi_mesh;
 int dmi_encode_mesh(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buffer* out);
+
+/* The same call for a mesh that already lives in HBM: `mesh` is a host struct whose `faces`, `atts[i].values` and
+ * `atts[i].point_to_value` are DEVICE pointers on cfg->device.  Faces and maps are read back once (the Edgebreaker traversal and the
+ * attribute sequencer are serial host walks); the attribute values never leave the device.  bench.py's `value` times this call. */
+int dmi_encode_mesh_device(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buffer* out);
 
 /* Host stages of dmi_encode_mesh split out, so a caller (bench.py, a batch driver) can keep the
  * serial graph walks outside a timed/pipelined region: returns the connectivity bytes (header
