@@ -7,6 +7,7 @@ Reference interface mirrored (paths relative to draco-oxide/src/):
 """
 import ctypes as C
 import os
+import sys
 import subprocess
 
 import numpy as np
@@ -105,6 +106,13 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm wheels bundle their own HIP / HSA runtime; a process that loads the system runtime first (through libdraco_mi.so) and
+    # torch's second ends up with two of them, and the second finds no GPU.  With torch imported first there is one runtime for both.
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(_LIB):
         raise ImportError(f"{_LIB} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
                           "draco-oxide_amd has no CPU fallback.")

@@ -225,10 +225,8 @@ void launch_last_corners(const uint32_t* c2p, uint64_t corners, uint32_t* last_c
 // ---- coding-order relabelling of the connectivity inputs on the device (dmi_relabel.hip; job creation of large meshes) ----
 void launch_fill_u32(uint32_t* p, uint64_t n, uint32_t v, hipStream_t s);
 void launch_rank_scatter(const uint32_t* seq, uint32_t n_seq, const uint32_t* c2v, uint32_t* rank /* pre-filled with DMI_NONE */, hipStream_t s);
-void launch_face_keys(const uint32_t* c2v, const uint32_t* rank, uint32_t F, uint32_t none_key, uint32_t* key, uint32_t* face, hipStream_t s);
-size_t sort_faces_temp_bytes(uint32_t F, int key_bits);
-hipError_t launch_sort_faces(void* temp, size_t temp_bytes, const uint32_t* key_in, uint32_t* key_out, const uint32_t* face_in, uint32_t* order_out, uint32_t F, int key_bits, hipStream_t s);
-void launch_new_face(const uint32_t* order, uint32_t F, uint32_t* new_face, hipStream_t s);
+hipError_t launch_face_order(const uint32_t* c2v, const uint32_t* rank, uint32_t F, uint32_t n_keys, uint32_t* key, uint32_t* count, uint32_t* fill, uint32_t* scan_partials,
+                             uint32_t* order, uint32_t* new_face, hipStream_t s);
 void launch_remap_table(const uint32_t* c2v, const uint32_t* opp, const uint32_t* rank, const uint32_t* order, const uint32_t* new_face, uint64_t C, uint32_t* c2r_out, uint32_t* opp_out,
                         hipStream_t s);
 void launch_remap_seq(const uint32_t* seq, uint32_t n_seq, const uint32_t* new_face, const uint32_t* c2p, uint32_t* seq_out, uint32_t* s2p_out, hipStream_t s);

@@ -400,17 +400,14 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
     uint32_t* d_seq = tmpdev.take<uint32_t>(max_seq);
     uint32_t* d_rank = tmpdev.take<uint32_t>(max_v);
     uint32_t* d_key = tmpdev.take<uint32_t>(F);
-    uint32_t* d_key2 = tmpdev.take<uint32_t>(F);
-    uint32_t* d_face = tmpdev.take<uint32_t>(F);
     uint32_t* d_order = tmpdev.take<uint32_t>(F);
     uint32_t* d_new_face = tmpdev.take<uint32_t>(F);
     uint32_t* d_words = tmpdev.take<uint32_t>(4);
-    const uint32_t none_key = job->tables[0].n_seq;   // faces none of whose vertices was coded sort last
-    int key_bits = 1;
-    while (key_bits < 32 && (1ull << key_bits) <= none_key) ++key_bits;
-    const size_t sort_bytes = sort_faces_temp_bytes(F, key_bits);
-    void* d_sort = tmpdev.take<uint8_t>(sort_bytes);
-    if (!d_c2p || (host_tables && (!d_c2v_up || !d_opp_up)) || !d_seq || !d_rank || !d_key || !d_key2 || !d_face || !d_order || !d_new_face || !d_words || !d_sort)
+    const uint32_t n_keys = job->tables[0].n_seq + 1;   // key n_seq: faces none of whose vertices was coded sort last
+    uint32_t* d_count = tmpdev.take<uint32_t>((size_t)n_keys + 1);
+    uint32_t* d_fill = tmpdev.take<uint32_t>((size_t)n_keys + 1);
+    uint32_t* d_parts = tmpdev.take<uint32_t>(scan_partials_words(n_keys + 1));
+    if (!d_c2p || (host_tables && (!d_c2v_up || !d_opp_up)) || !d_seq || !d_rank || !d_key || !d_order || !d_new_face || !d_words || !d_count || !d_fill || !d_parts)
       return fail(DMI_ERR_OUT_OF_MEMORY, "hipMalloc (relabelling temporaries)");
     d_bad = d_words; d_max_point = d_words + 1;
     HIP_TRY(hipMemsetAsync(d_words, 0, 16, s));
@@ -430,9 +427,7 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
       launch_fill_u32(d_rank, t.V, kNone, s);
       launch_rank_scatter(d_seq, t.n_seq, d_c2v, d_rank, s);
       if (i == 0) {   // the face order comes from the universal table
-        launch_face_keys(d_c2v, d_rank, F, none_key, d_key, d_face, s);
-        HIP_TRY(launch_sort_faces(d_sort, sort_bytes, d_key, d_key2, d_face, d_order, F, key_bits, s));
-        launch_new_face(d_order, F, d_new_face, s);
+        HIP_TRY(launch_face_order(d_c2v, d_rank, F, n_keys, d_key, d_count, d_fill, d_parts, d_order, d_new_face, s));
       }
       if ((rc = t.c2r.alloc(C * 4))) return rc;
       if ((rc = t.opp.alloc(C * 4))) return rc;

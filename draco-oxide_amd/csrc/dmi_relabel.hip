@@ -3,8 +3,8 @@
 // The corner tables arrive in the mesh's own face / vertex numbering; every predictor walks them in the coding (Edgebreaker) order.
 // dmi_job_create therefore re-indexes them once (a pure relabelling: the bitstream does not depend on internal corner / vertex ids):
 //   vertices → their sequence index          rank[vertex(seq[k])] = k                          k_rank_scatter
-//   faces    → ordered by the smallest sequence index among their (universal) vertices,        k_face_keys + a stable radix sort of
-//              faces of equal key in face order (= the host form's counting sort)              (key, face) pairs + k_new_face
+//   faces    → ordered by the smallest sequence index among their (universal) vertices,        k_face_keys + a counting sort by key: bucket sizes,
+//              faces of equal key in face order (= the host form's counting sort)              prefix sum, k_place_faces, k_sort_buckets (→ new_face)
 //   corner-indexed arrays and the corner ids stored in `seq` / `opp` follow the new face order k_remap_table, k_remap_seq
 //   seq → corner_to_point → point_to_value is composed once                                    k_remap_seq (s2p), k_compose_s2v
 // ≈ 1 GB of streaming / scattered traffic for a 10M-triangle mesh: well under a millisecond of kernels, against 130 ms on 16 host
@@ -12,8 +12,6 @@
 // small meshes, whose creation is bound by per-launch costs; both produce identical arrays (tests compare the encodes).
 // Reference seam: the arrays are the flat view of ConnectivityEncoderOutput::Edgebreaker{corner_table, corners_of_edgebreaker} handed to
 // attribute::encode_attributes (encode/attribute/mod.rs:13-93); sequence = Traverser::compute_seqeunce (shared/attribute/sequence.rs:48).
-#include <hipcub/hipcub.hpp>
-
 #include "dmi_device.hpp"
 
 namespace dmi {
@@ -33,20 +31,37 @@ __global__ __launch_bounds__(kBlock) void k_rank_scatter(const uint32_t* __restr
   for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n_seq; k += gridDim.x * kBlock) rank[c2v[seq[k]]] = k;
 }
 
-// key[f] = smallest sequence index among the face's vertices (none_key when no vertex of the face was coded); face[f] = f
+// key[f] = smallest sequence index among the face's vertices (none_key when no vertex of the face was coded); count[key]++
+// (a bucket holds the faces around one coded vertex — a handful — so the atomics spread over as many addresses as there are vertices)
 __global__ __launch_bounds__(kBlock) void k_face_keys(const uint32_t* __restrict__ c2v, const uint32_t* __restrict__ rank, uint32_t F, uint32_t none_key,
-                                                      uint32_t* __restrict__ key, uint32_t* __restrict__ face) {
+                                                      uint32_t* __restrict__ key, uint32_t* __restrict__ count) {
   for (uint32_t f = blockIdx.x * kBlock + threadIdx.x; f < F; f += gridDim.x * kBlock) {
     const uint32_t a = rank[c2v[3 * (size_t)f]], b = rank[c2v[3 * (size_t)f + 1]], c = rank[c2v[3 * (size_t)f + 2]];
     const uint32_t m = min(a, min(b, c));
-    key[f] = (m == kNoneD) ? none_key : m;
-    face[f] = f;
+    const uint32_t k = (m == kNoneD) ? none_key : m;
+    key[f] = k;
+    atomicAdd(&count[k], 1u);
   }
 }
-
-// order[j] = the face at position j of the new order  →  new_face[order[j]] = j
-__global__ __launch_bounds__(kBlock) void k_new_face(const uint32_t* __restrict__ order, uint32_t F, uint32_t* __restrict__ new_face) {
-  for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < F; j += gridDim.x * kBlock) new_face[order[j]] = j;
+// faces into their buckets (start = exclusive prefix sum of the bucket sizes), in whatever order the atomics hand out
+__global__ __launch_bounds__(kBlock) void k_place_faces(const uint32_t* __restrict__ key, uint32_t F, const uint32_t* __restrict__ start, uint32_t* __restrict__ fill, uint32_t* __restrict__ order) {
+  for (uint32_t f = blockIdx.x * kBlock + threadIdx.x; f < F; f += gridDim.x * kBlock) {
+    const uint32_t k = key[f];
+    order[start[k] + atomicAdd(&fill[k], 1u)] = f;
+  }
+}
+// faces of equal key in face order (the host form's stable counting sort), then new_face[order[j]] = j
+__global__ __launch_bounds__(kBlock) void k_sort_buckets(const uint32_t* __restrict__ start, uint32_t n_keys, uint32_t* __restrict__ order, uint32_t* __restrict__ new_face) {
+  for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n_keys; k += gridDim.x * kBlock) {
+    const uint32_t lo = start[k], hi = start[k + 1];
+    for (uint32_t i = lo + 1; i < hi; ++i) {   // insertion sort
+      const uint32_t v = order[i];
+      uint32_t j = i;
+      while (j > lo && order[j - 1] > v) { order[j] = order[j - 1]; --j; }
+      order[j] = v;
+    }
+    for (uint32_t i = lo; i < hi; ++i) new_face[order[i]] = i;
+  }
 }
 
 __device__ __forceinline__ uint32_t map_corner(uint32_t c, const uint32_t* __restrict__ new_face) { return c == kNoneD ? kNoneD : 3u * new_face[c / 3u] + c % 3u; }
@@ -106,20 +121,22 @@ void launch_fill_u32(uint32_t* p, uint64_t n, uint32_t v, hipStream_t s) { if (n
 void launch_rank_scatter(const uint32_t* seq, uint32_t n_seq, const uint32_t* c2v, uint32_t* rank, hipStream_t s) {
   if (n_seq) hipLaunchKernelGGL(k_rank_scatter, grid_of(n_seq), kBlock, 0, s, seq, n_seq, c2v, rank);
 }
-void launch_face_keys(const uint32_t* c2v, const uint32_t* rank, uint32_t F, uint32_t none_key, uint32_t* key, uint32_t* face, hipStream_t s) {
-  if (F) hipLaunchKernelGGL(k_face_keys, grid_of(F), kBlock, 0, s, c2v, rank, F, none_key, key, face);
-}
-size_t sort_faces_temp_bytes(uint32_t F, int key_bits) {
-  size_t bytes = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)F, 0, key_bits, (hipStream_t) nullptr);
-  return bytes;
-}
-// stable: faces of equal key keep their face order (the host form's counting sort)
-hipError_t launch_sort_faces(void* temp, size_t temp_bytes, const uint32_t* key_in, uint32_t* key_out, const uint32_t* face_in, uint32_t* order_out, uint32_t F, int key_bits, hipStream_t s) {
+// The face order of one mesh: order[j] = the face at position j, new_face[f] = its position.  Faces sorted by key (= the smallest sequence
+// index among their vertices, none_key = n_keys - 1 for faces no coded vertex touches), equal keys in face order: a counting sort —
+// bucket sizes by atomics, a prefix sum (dmi_conn.hip), placement, a tiny sort inside every bucket.  No library sort.
+// count / fill: n_keys + 1 words each, zeroed by this call; scan_partials: scan_partials_words(n_keys + 1).
+hipError_t launch_face_order(const uint32_t* c2v, const uint32_t* rank, uint32_t F, uint32_t n_keys, uint32_t* key, uint32_t* count, uint32_t* fill, uint32_t* scan_partials,
+                             uint32_t* order, uint32_t* new_face, hipStream_t s) {
   if (!F) return hipSuccess;
-  return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, key_in, key_out, face_in, order_out, (int)F, 0, key_bits, s);
+  hipError_t e;
+  if ((e = hipMemsetAsync(count, 0, ((size_t)n_keys + 1) * 4, s)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(fill, 0, ((size_t)n_keys + 1) * 4, s)) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_face_keys, grid_of(F), kBlock, 0, s, c2v, rank, F, n_keys - 1, key, count);
+  launch_exclusive_scan_u32(count, n_keys + 1, scan_partials, s);
+  hipLaunchKernelGGL(k_place_faces, grid_of(F), kBlock, 0, s, key, F, count, fill, order);
+  hipLaunchKernelGGL(k_sort_buckets, grid_of(n_keys), kBlock, 0, s, count, n_keys, order, new_face);
+  return hipSuccess;
 }
-void launch_new_face(const uint32_t* order, uint32_t F, uint32_t* new_face, hipStream_t s) { if (F) hipLaunchKernelGGL(k_new_face, grid_of(F), kBlock, 0, s, order, F, new_face); }
 void launch_remap_table(const uint32_t* c2v, const uint32_t* opp, const uint32_t* rank, const uint32_t* order, const uint32_t* new_face, uint64_t C, uint32_t* c2r_out, uint32_t* opp_out,
                         hipStream_t s) {
   if (C) hipLaunchKernelGGL(k_remap_table, grid_of(C), kBlock, 0, s, c2v, opp, rank, order, new_face, C, c2r_out, opp_out);
