@@ -194,8 +194,17 @@ struct CornerTables {
 };
 
 struct EdgebreakerResult {
-  std::vector<uint32_t> seeds;          // corners_of_edgebreaker
+  // corners_of_edgebreaker (edgebreaker.rs:523-529) = reverse(init_face_connectivity_corners) ++ processed_connectivity_corners, kept as its two
+  // parts: the attribute sequencers read them where the traversal left them (no 4-bytes-per-face copy on the critical path)
+  std::vector<uint32_t> init_rev, processed;
+  std::vector<uint32_t> seeds;          // the concatenation, only when a caller asks for it (materialize_seeds: dmi_encode_connectivity's public view)
   std::vector<uint8_t> connectivity;    // bytes written by encode_connectivity (without the 11-byte header)
+  void materialize_seeds() {
+    if (!seeds.empty() || (init_rev.empty() && processed.empty())) return;
+    pool_fit(seeds, init_rev.size() + processed.size());
+    seeds.assign(init_rev.begin(), init_rev.end());
+    seeds.insert(seeds.end(), processed.begin(), processed.end());
+  }
 };
 // Optional call-outs of run_edgebreaker, so that a large mesh's other serial walks overlap it: `seeds_ready` fires when the traversal
 // is over and out.seeds is final (the attribute sequencers only need those), `before_seams` right before the attribute seam flags are
@@ -211,6 +220,11 @@ struct TableRef {
 // on_boundary (optional): one byte per vertex, != 0 ⇔ the vertex lies on a boundary of `t` (vertex_boundary_flags) — spares the walk two
 // dependent loads per vertex
 void attribute_sequence(const TableRef& t, const uint32_t* seeds, uint32_t n_seeds, std::vector<uint32_t>& seq, const uint8_t* on_boundary = nullptr);
+// the seeds in two parts (first ++ second), e.g. EdgebreakerResult::init_rev ++ processed
+void attribute_sequence(const TableRef& t, const uint32_t* first, uint32_t n_first, const uint32_t* second, uint32_t n_second, std::vector<uint32_t>& seq, const uint8_t* on_boundary = nullptr);
+inline void attribute_sequence(const TableRef& t, const EdgebreakerResult& eb, std::vector<uint32_t>& seq, const uint8_t* on_boundary = nullptr) {
+  attribute_sequence(t, eb.init_rev.data(), (uint32_t)eb.init_rev.size(), eb.processed.data(), (uint32_t)eb.processed.size(), seq, on_boundary);
+}
 void vertex_boundary_flags(const TableRef& t, std::vector<uint8_t>& on_boundary);   // parallel slices for a large table
 
 // rABS bit coder (encode/entropy/rans.rs:71-128), host version for the small connectivity streams.

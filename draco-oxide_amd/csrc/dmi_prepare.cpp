@@ -207,7 +207,7 @@ struct ConnOwner {
   ~ConnOwner() {   // the large arrays go back to the host pool (dmi_host.hpp)
     pool_give(ct.c2p_own); pool_give(ct.c2v_own); pool_give(ct.opp_own); pool_give(ct.lmc_own);
     for (auto& a : ct.att) { pool_give(a.c2v); pool_give(a.opp); pool_give(a.lmc); pool_give(a.seam_edge); }
-    pool_give(eb.seeds);
+    pool_give(eb.seeds); pool_give(eb.processed);
     for (auto& q : seqs) pool_give(q);
   }
   std::vector<dmi_corner_table> views;
@@ -262,7 +262,7 @@ static int build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std::vector<ui
   const uint8_t* boundary_flags = on_device ? pre->on_boundary : nullptr;   // per vertex: on a boundary of the universal table (the device pass computes them with the left-most corners)
   auto sequence_universal = [&] {
     TableRef tr{o.ct.F, o.ct.V, o.ct.c2v, o.ct.opp, o.ct.lmc};
-    attribute_sequence(tr, o.eb.seeds.data(), (uint32_t)o.eb.seeds.size(), o.seqs[0], boundary_flags ? boundary_flags : (on_boundary.empty() ? nullptr : on_boundary.data()));
+    attribute_sequence(tr, o.eb, o.seqs[0], boundary_flags ? boundary_flags : (on_boundary.empty() ? nullptr : on_boundary.data()));
   };
 
   auto build_att_tables = [&] {
@@ -321,7 +321,7 @@ static int build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std::vector<ui
       if (use_att && !seamless) {
         const AttTable& t = o.ct.att[i - 1];
         v.num_vertices = t.num_vertices; v.corner_to_vertex = t.c2v.data(); v.opposite = t.opp.data(); v.left_most_corner = t.lmc.data();
-        auto walk = [&o, i, &t] { TableRef tr{o.ct.F, t.num_vertices, t.c2v.data(), t.opp.data(), t.lmc.data()}; attribute_sequence(tr, o.eb.seeds.data(), (uint32_t)o.eb.seeds.size(), o.seqs[i]); };
+        auto walk = [&o, i, &t] { TableRef tr{o.ct.F, t.num_vertices, t.c2v.data(), t.opp.data(), t.lmc.data()}; attribute_sequence(tr, o.eb, o.seqs[i]); };
         if (overlap) th.emplace_back(walk); else walk();
       } else {
         // a seam-free attribute table is identical to the universal one (same ids, same order)
@@ -375,6 +375,7 @@ int dmi_encode_connectivity(const dmi_mesh* mesh, dmi_buffer* header_and_connect
   if (rc) { delete o; return rc; }
   conn->num_tables = (uint32_t)o->views.size();
   conn->tables = o->views.data();
+  o->eb.materialize_seeds();
   conn->seeds = o->eb.seeds.data();
   conn->num_seeds = (uint32_t)o->eb.seeds.size();
   conn->owner = o;
@@ -436,7 +437,7 @@ static int mesh_prepare_impl(const dmi_mesh* mesh, const dmi_config* cfg, dmi_bu
     if (rc) return rc;
     t_conn = ms();
     const DeviceTableView view{dt.d_faces, dt.d_c2v, dt.d_opp, true, src != nullptr};
-    rc = job_create_impl(mesh->atts, o.views.data(), mesh->num_atts, o.eb.seeds.data(), (uint32_t)o.eb.seeds.size(), cfg, dt.valid ? &view : nullptr, job);
+    rc = job_create_impl(mesh->atts, o.views.data(), mesh->num_atts, nullptr, 0, cfg, dt.valid ? &view : nullptr, job);   // (every view carries its sequence: no seeds needed)
     if (rc) return rc;
     t_create = ms();
     rc = to_buffer(bytes, header_and_connectivity);
@@ -745,7 +746,7 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
       r = job_create_impl(m.atts, o.views.data(), m.num_atts, nullptr, 0, &c, &view, &jobs[j], &d);
       deferred[kk] = r == DMI_OK;
     } else {   // an attribute table of its own: the host relabelling form reads the tables where the walks read them
-      r = job_create_impl(m.atts, o.views.data(), m.num_atts, o.eb.seeds.data(), (uint32_t)o.eb.seeds.size(), &c, nullptr, &jobs[j], nullptr);
+      r = job_create_impl(m.atts, o.views.data(), m.num_atts, nullptr, 0, &c, nullptr, &jobs[j], nullptr);
       owners[kk].reset();
     }
     if (r) return bail(r, g_last_error);

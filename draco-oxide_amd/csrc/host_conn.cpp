@@ -614,9 +614,11 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
   }
   const double t_walk = since(t0);
   if (w.bad) { err = "edgebreaker: inconsistent connectivity (reference unwrap() panic)"; if (hooks && hooks->before_seams) hooks->before_seams(); return DMI_ERR_CONNECTIVITY; }
-  pool_fit(out.seeds, w.init_corners.size() + w.processed.size());
-  out.seeds.assign(w.init_corners.rbegin(), w.init_corners.rend());   // edgebreaker.rs:523-529
-  out.seeds.insert(out.seeds.end(), w.processed.begin(), w.processed.end());
+  out.init_rev.assign(w.init_corners.rbegin(), w.init_corners.rend());   // edgebreaker.rs:523-529
+  pool_give(out.processed);
+  out.processed.swap(w.processed);   // (the walker's own array: its remaining readers below go through `processed`)
+  out.seeds.clear();
+  const std::vector<uint32_t>& processed = out.processed;
   if (hooks && hooks->seeds_ready) hooks->seeds_ready();
   s.leb128(w.symbols.size());
   s.leb128(w.num_split_symbols);
@@ -664,7 +666,7 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
       // faces' positions in `processed`, so the flags are produced in parallel slices — straight into the order the rABS coder is fed in
       // (the reverse of the order of emission: faces first to last, corners prev, next, c) — and the streams of the attributes are
       // coded side by side on the multiply-high coder of host_chains.cpp (a divide per flag was 2/3 of this stage).
-    const size_t n = w.processed.size(), A = t.att.size();
+    const size_t n = processed.size(), A = t.att.size();
     // Which streams are distinct: an attribute without interior seams flags no emitted edge (they all have two faces) — ONE all-zero
     // stream serves every such attribute; an attribute copied from an earlier one repeats that one's stream.
     std::vector<int> stream_of(A, -1);   // attribute whose stream this one repeats (itself: its own flags), -1 = the all-zero stream
@@ -683,8 +685,8 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
     if (sliced) {
       pool_fit(where, t.F);
       where.assign(t.F, kNone);
-      parallel_for(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) where[w.processed[i] / 3] = (uint32_t)i; });
-      parallel_for(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) if (where[w.processed[i] / 3] != (uint32_t)i) { twice.store(1); break; } });
+      parallel_for(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) where[processed[i] / 3] = (uint32_t)i; });
+      parallel_for(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) if (where[processed[i] / 3] != (uint32_t)i) { twice.store(1); break; } });
     }
     std::vector<std::vector<uint8_t>> fed(A);
     struct GiveBack { std::vector<std::vector<uint8_t>>& v; ~GiveBack() { for (auto& x : v) pool_give(x); } } fed_back{fed};
@@ -692,7 +694,7 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
     if (sliced && !twice.load()) {
       // corners of face i whose flag is emitted, as a mask over (c, next, prev)
       auto mask_of = [&](size_t i) -> uint32_t {
-        const uint32_t c = w.processed[i];
+        const uint32_t c = processed[i];
         const uint32_t cs[3] = {c, corner_next(c), corner_prev(c)};
         uint32_t m = 0;
         for (int k = 0; k < 3; ++k) {
@@ -731,7 +733,7 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
         for (size_t j = (lo / kChunk) * kChunk; j < lo; ++j) pos += (uint64_t)__builtin_popcount(mask[j]);
         std::vector<uint64_t> z(A, 0);
         for (size_t i = lo; i < hi; ++i) {
-          const uint32_t c = w.processed[i];
+          const uint32_t c = processed[i];
           const uint32_t cs[3] = {c, corner_next(c), corner_prev(c)};
           for (int k = 2; k >= 0; --k) {
             if (!(mask[i] >> k & 1u)) continue;
@@ -746,7 +748,7 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
       std::vector<uint8_t> fv(t.F, 0);
       std::vector<std::vector<uint8_t>> seams(A);
       for (size_t i = n; i-- > 0;) {
-        const uint32_t c = w.processed[i];
+        const uint32_t c = processed[i];
         const uint32_t cs[3] = {c, corner_next(c), corner_prev(c)};
         fv[c / 3] = 1;
         for (uint32_t cc : cs) {
@@ -802,28 +804,37 @@ void vertex_boundary_flags(const TableRef& t, std::vector<uint8_t>& on_boundary)
 }
 
 void attribute_sequence(const TableRef& t, const uint32_t* seeds, uint32_t n_seeds, std::vector<uint32_t>& seq, const uint8_t* on_boundary) {
+  attribute_sequence(t, nullptr, 0, seeds, n_seeds, seq, on_boundary);
+}
+// The reference's stack starts as the seeds and only ever grows above them: what the walk pushes is popped before the next seed.  The seeds
+// are therefore read in place, last to first (second part, then first part), and only the pushes live on a stack of their own.
+void attribute_sequence(const TableRef& t, const uint32_t* first, uint32_t n_first, const uint32_t* second, uint32_t n_second, std::vector<uint32_t>& seq, const uint8_t* on_boundary) {
   Pooled<uint8_t> vvis_p(t.V, (uint8_t)0), fvis_p(t.F, (uint8_t)0);
-  std::vector<uint8_t>&vvis = vvis_p.v, &fvis = fvis_p.v;
-  Pooled<uint32_t> stack_p(n_seeds);
-  std::vector<uint32_t>& stack = stack_p.v;
-  stack.assign(seeds, seeds + n_seeds);
+  std::vector<uint8_t>&vvis = vvis_p.v, &fvis = fvis_p.v;   // vvis: bit 0 visited, bit 1 the vertex lies on a boundary (from on_boundary: one load less per new vertex)
+  if (on_boundary) parallel_for(t.V, [&](size_t lo, size_t hi) { for (size_t v = lo; v < hi; ++v) vvis[v] = on_boundary[v] ? 2 : 0; });
+  std::vector<uint32_t> stack;
+  stack.reserve(1024);
+  uint64_t left = (uint64_t)n_first + n_second;
   pool_fit(seq, t.V);
-  auto emit = [&](uint32_t c) { uint32_t v = t.c2v[c]; if (!vvis[v]) { vvis[v] = 1; seq.push_back(c); } };
-  while (!stack.empty()) {
-    const uint32_t c = stack.back();
-    stack.pop_back();
+  auto emit = [&](uint32_t c) { uint32_t v = t.c2v[c]; if (!(vvis[v] & 1)) { vvis[v] |= 1; seq.push_back(c); } };
+  for (;;) {
+    uint32_t c;
+    if (!stack.empty()) { c = stack.back(); stack.pop_back(); }
+    else if (left) { --left; c = left >= n_first ? second[left - n_first] : first[left]; }
+    else break;
     if (fvis[c / 3]) continue;
     prefetch_neighbours(t.opp + c); prefetch_neighbours(t.c2v + c); prefetch_neighbours(fvis.data() + c / 3);
     const uint32_t nc = corner_next(c), pc = corner_prev(c);
-    if (!vvis[t.c2v[nc]] || !vvis[t.c2v[pc]]) { emit(nc); emit(pc); stack.push_back(c); continue; }
+    if (!(vvis[t.c2v[nc]] & 1) || !(vvis[t.c2v[pc]] & 1)) { emit(nc); emit(pc); stack.push_back(c); continue; }
     fvis[c / 3] = 1;
     const uint32_t v = t.c2v[c];
     prefetch_neighbours(vvis.data() + v);
     const uint32_t right = t.opp[nc], left = t.opp[pc];
-    if (!vvis[v]) {
+    const uint8_t vflags = vvis[v];
+    if (!(vflags & 1)) {
       emit(c);
       bool boundary;
-      if (on_boundary) boundary = on_boundary[v] != 0;
+      if (on_boundary) boundary = (vflags & 2) != 0;
       else { const uint32_t l0 = t.lmc[v]; boundary = t.opp[corner_next(l0)] == kNone; }   // is_on_boundary: swing_left(lmc) is None
       if (!boundary) { if (right != kNone) stack.push_back(right); continue; }
     }
