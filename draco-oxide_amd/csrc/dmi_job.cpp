@@ -884,6 +884,7 @@ static int encode_phase_b(dmi_job* job, bool plan_only = false, bool host_chains
     if (std::getenv("DMI_TRACE")) std::fprintf(stderr, "[dmi] attribute %u small: %08x %08x %u %u %u %u %u %u\n", i, small[0], small[1], small[2], small[3], small[4], small[5], small[6], small[7]);
     if (small[4]) return fail(DMI_ERR_ZERO_NORMAL, "attribute " + std::to_string(i) + " contains a zero-length normal (reference assert, geom.rs:45)");
     if (small[5]) return fail(DMI_ERR_ALPHABET_TOO_LARGE, "symbol outside the histogram bound");
+    { const int brc = check_value_bounds(a, small, i); if (brc) return brc; }
     const uint32_t n = job->tables[a.table].n_seq;
     if (a.n_sym == 0) return fail(DMI_ERR_ENTROPY, "attribute " + std::to_string(i) + " has no values to code (empty histogram)");
     const uint32_t* hist = reinterpret_cast<const uint32_t*>(base + 128);
@@ -1043,6 +1044,17 @@ static int encode_phase_b_dev(dmi_job* job, ChainDesc* desc_base, ChainDesc* hdr
 }
 
 // errors the device reports through an attribute's scratch words (device form; the host form meets them in phase B)
+// The packed value layouts (QF_P64 / QF_H32) and the 16-bit symbols narrow what they store; what keeps that exact is the quantizer's bound
+// 0 ≤ q < 2^bits (NaN → 0, ±inf → a range end).  The joint min/max every encode computes anyway (small[0..1]) is held to that bound here:
+// a violated bound is an error, never a silently truncated field.
+static int check_value_bounds(const AttJob& a, const uint32_t* small, uint32_t i) {
+  if (a.port != kCoordwise || (a.qfmt == QF_I32 && !a.sym16)) return DMI_OK;
+  const int32_t mn = (int32_t)small[0], mx = (int32_t)small[1];
+  if (mn > mx) return DMI_OK;   // (no entries: the seeds)
+  if (mn < 0 || (int64_t)mx > ((int64_t)1 << a.bits) - 1)
+    return fail(DMI_ERR_ALPHABET_TOO_LARGE, "attribute " + std::to_string(i) + ": a quantized value lies outside [0, 2^bits) — packed layouts cannot hold it");
+  return DMI_OK;
+}
 static int check_device_flags(const uint32_t* small, uint32_t i) {
   if (small[4]) return fail(DMI_ERR_ZERO_NORMAL, "attribute " + std::to_string(i) + " contains a zero-length normal (reference assert, geom.rs:45)");
   if (small[5]) return fail(DMI_ERR_ALPHABET_TOO_LARGE, "symbol outside the histogram bound");
@@ -1094,7 +1106,8 @@ static int encode_phase_c2(dmi_job* job) {   // lengths known: async copy of the
     job->run.hdr_off.assign(n_atts, 0);
     for (uint32_t i = 0; i < n_atts; ++i) {
       const uint32_t* small = reinterpret_cast<const uint32_t*>(pinned + pin_off[i]);
-      const int frc = check_device_flags(small, i);
+      int frc = check_device_flags(small, i);
+      if (!frc) frc = check_value_bounds(job->atts[i], small, i);
       if (frc) return frc;
       aux_w[i].zero_prob = (uint8_t)small[14];
       aux_w[i].count = small[15];
@@ -1186,6 +1199,9 @@ static int encode_phase_c3(dmi_job* job, dmi_buffer* out) {   // host: splice th
     void bytes(const std::vector<uint8_t>& v) { bytes(v.data(), v.size()); }
   } w{static_cast<uint8_t*>(std::malloc(bound))};
   if (!w.p) return fail(DMI_ERR_OUT_OF_MEMORY, "malloc");
+  job->last_fixups = 0;
+  for (uint32_t i = 0; i < n_atts; ++i)
+    if (job->atts[i].scheme == kTexCoord && job->atts[i].fused_into >= 0) job->last_fixups += reinterpret_cast<const uint32_t*>(pinned + pin_off[i])[3];
   w.u8((uint8_t)n_atts);
   for (uint32_t i = 0; i < n_atts; ++i) { w.u8((uint8_t)((uint8_t)i - 1)); w.u8(job->atts[i].desc.domain); w.u8(0); }   // Q13
   for (uint32_t i = 0; i < n_atts; ++i) {
@@ -1307,7 +1323,8 @@ static int encode_tail_host(dmi_job* job, dmi_buffer* out, float* chain_ms, floa
       const auto w1 = std::chrono::steady_clock::now();
       const uint32_t* small = reinterpret_cast<const uint32_t*>(base + slot[i].small);
       if (dev) {
-        const int frc = check_device_flags(small, i);
+        int frc = check_device_flags(small, i);
+        if (!frc) frc = check_value_bounds(a, small, i);
         if (frc) { rcs[k] = frc; errs[k] = g_last_error; continue; }
       }
       HostChainOut& o = *job->host_out[2 * (size_t)i + (st.aux ? 1 : 0)];
@@ -1461,6 +1478,7 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
   tm.host_chains = host_chains ? 1u : 0u;
   tm.longest_stream_ms = longest_ms;
   tm.readback_wait_ms = wait_ms;
+  tm.texcoord_fixups = job->last_fixups;
   job->last = tm;
   drain.armed = false;   // every path above ended with a stream synchronisation
   return DMI_OK;
@@ -1807,7 +1825,8 @@ struct DeviceBatch {
           for (uint32_t i = 0; i < na; ++i) {
             job->run.pin_off[i] = (size_t)i * 128;
             const uint32_t* small = reinterpret_cast<const uint32_t*>(job->readback + job->run.pin_off[i]);
-            const int frc = check_device_flags(small, i);
+            int frc = check_device_flags(small, i);
+            if (!frc) frc = check_value_bounds(job->atts[i], small, i);
             if (frc) return frc;
             job->run.aux[i].zero_prob = (uint8_t)small[14];
             job->run.aux[i].count = small[15];

@@ -228,6 +228,7 @@ struct dmi_job {
   hipEvent_t ev[8]{};
   bool have_events = false;
   dmi_timings last{};
+  uint32_t last_fixups = 0;   // texture-coordinate entries the last encode's fused sweep deferred to k_texcoord_fixup
   uint64_t predict_bytes = 0;
   hipGraphExec_t graph_a = nullptr;   // phase A captured once (launch-bound for small meshes)
   bool graph_tried = false;

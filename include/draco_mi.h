@@ -114,6 +114,7 @@ typedef struct dmi_timings {
   float connectivity_ms;     /* the whole connectivity stage, tables_ms included: Edgebreaker traversal, connectivity bytes, sequencers */
   float job_create_ms;       /* coding-order relabelling, uploads, fan rows, buffers */
   float call_ms;             /* the whole call */
+  uint32_t texcoord_fixups;  /* texture-coordinate entries of the fused sweep whose operands were outside its exact f64 tier: predicted by the general i64 form (k_texcoord_fixup) */
 } dmi_timings;
 /* Timings of the last dmi_encode_mesh / dmi_encode_mesh_device / dmi_encode_attributes call of the calling thread (per-stage device
  * times when that call's dmi_config carried DMI_FLAG_TIMINGS). */

@@ -108,3 +108,40 @@ def test_config4_hundred_million_triangles_14_bit_single_mesh():
             del os.environ["DMI_CHAINS"]
         assert j2.encode() == a
         j2.close()
+
+
+@pytest.mark.parametrize("pos_bits,uv_bits", [(14, 12), (12, 10)])
+def test_one_million_triangles_at_14_and_12_bits_byte_parity(pos_bits, uv_bits):
+    """configs[4]'s quantization (14-bit positions) at a size the oracle still answers in seconds: 999 698 triangles, pos+nrm+uv, whole
+    `.drc` byte for byte (the 100M-triangle mesh itself is property-checked only).  The operand bounds of the sweep's exact tiers (f64
+    texture-coordinate projection, 24-bit multiplier for the fan sums) depend on the bit widths; at these the sweep defers nothing."""
+    mesh = synth.torus_mesh(707)
+    cfg = dmi.Config(pos_bits=pos_bits, uv_bits=uv_bits, flags=dmi.FLAG_TIMINGS)
+    want = oracle_from_product_mesh(mesh).encode(pos_bits=pos_bits, uv_bits=uv_bits)
+    job = dmi.mesh_prepare(mesh, cfg)
+    try:
+        got = job.header_and_connectivity + job.encode()
+        fixups = job.timings()["texcoord_fixups"]
+    finally:
+        job.close()
+    _assert_same(got, want, f"1M triangles at {pos_bits}/{uv_bits} bits")
+    assert fixups == 0
+    _assert_same(dmi.encode_mesh(mesh, dmi.Config(pos_bits=pos_bits, uv_bits=uv_bits)), want, f"1M triangles at {pos_bits}/{uv_bits} bits, dmi_encode_mesh")
+
+
+@pytest.mark.parametrize("n,pos_bits,uv_bits", [(40, 20, 16), (96, 21, 16), (300, 20, 16)])
+def test_wide_quantization_provably_enters_the_texcoord_fixup_kernel(n, pos_bits, uv_bits):
+    """With 20/21-bit positions on a coarse grid the edge vectors leave the fused sweep's exact f64 tier (|pn| components ≥ 2^15): those
+    entries go to k_texcoord_fixup's general i64 form.  The job reports how many (dmi_timings.texcoord_fixups) — the test fails if the
+    path it claims to cover was not taken — and the bytes must still be the oracle's."""
+    mesh = synth.torus_mesh(n)
+    cfg = dmi.Config(pos_bits=pos_bits, uv_bits=uv_bits, flags=dmi.FLAG_TIMINGS)
+    want = oracle_from_product_mesh(mesh).encode(pos_bits=pos_bits, uv_bits=uv_bits)
+    job = dmi.mesh_prepare(mesh, cfg)
+    try:
+        got = job.header_and_connectivity + job.encode()
+        fixups = job.timings()["texcoord_fixups"]
+    finally:
+        job.close()
+    _assert_same(got, want, f"grid {n} at {pos_bits}/{uv_bits} bits")
+    assert fixups > 0, "no entry was deferred: this case no longer reaches k_texcoord_fixup"
