@@ -701,6 +701,7 @@ int dmi_job_timings(const dmi_job* job, dmi_timings* t) {
 
 // The encode pipeline of one job, split at its host synchronisation points so that a batch of jobs can share
 // them (one sync for all histograms, ONE k_chains launch holding every stream of every job).
+static int check_value_bounds(const AttJob& a, const uint32_t* small, uint32_t i);
 static int encode_phase_a(dmi_job* job, bool plan_only = false) {   // device: ranges → coding-order portabilization → predict → histograms; async read-back
   // plan_only: the caller has set a step sink — every launch below is collected, not issued, and the read-back is the caller's
   if (!plan_only) HIP_TRY(hipSetDevice(job->cfg.device));
