@@ -135,10 +135,12 @@ __device__ __forceinline__ void k_orient_prep_body(const OrientPrepArgs& a, cons
 }
 
 // ---- the table stage on the device (see TableAtt) -------------------------------------------------------------
+constexpr uint32_t kTablesLdsBins = 8192;   // alphabets up to this size have their normalised frequencies staged in LDS for the serialisation
 struct TablesLds {
   uint64_t red[kTablesThreads / 64];
   uint32_t stage[4 * 1024];   // orientation summaries, 1024 blocks at a time
   uint32_t nextv;
+  uint32_t fq[kTablesLdsBins + 2];   // normalised frequencies: a zero's token scans up to 64 entries ahead — from LDS, not 64 dependent global loads
 };
 __device__ __forceinline__ uint64_t block_sum(uint64_t v, uint64_t* red) {   // every thread receives the total
 #pragma unroll
@@ -240,28 +242,37 @@ __device__ void k_tables_body(const TableAtt& a, const uint32_t, const uint32_t)
       const uint64_t excess = sum - target;
       if (excess > num_symbols) err = 2;
       if (!err) {
+        // the two searches below sweep the frequencies ≈ 30 times: a thread keeps its (strided) entries in registers when the alphabet allows
+        // (≤ 8 per thread = 8192 symbols: every default-width attribute), so a sweep costs a block reduction and no memory round trip
+        constexpr uint32_t kKeep = 8;
+        const bool kept = num_symbols <= kKeep * T;
+        uint32_t fr[kKeep];
+#pragma unroll
+        for (uint32_t j = 0; j < kKeep; ++j) { const uint32_t s = tid + j * T; fr[j] = (kept && s < num_symbols) ? freq[s] : 0u; }
+        auto count_if = [&](auto&& pred) -> uint64_t {   // #(s < num_symbols : pred(freq[s], s)) over the block
+          uint64_t c = 0;
+          if (kept) {
+#pragma unroll
+            for (uint32_t j = 0; j < kKeep; ++j) { const uint32_t s = tid + j * T; c += (s < num_symbols && pred(fr[j], s)) ? 1u : 0u; }
+          } else {
+            for (uint32_t s = tid; s < num_symbols; s += T) c += pred(freq[s], s) ? 1u : 0u;
+          }
+          return block_sum(c, lds.red);
+        };
         uint32_t lo = 0, hi = (uint32_t)target;
         while (lo < hi) {   // largest T with #(freq ≥ T) ≥ excess
           const uint32_t mid = lo + (hi - lo + 1u) / 2u;
-          uint64_t c = 0;
-          for (uint32_t s = tid; s < num_symbols; s += T) c += freq[s] >= mid;
-          c = block_sum(c, lds.red);
-          if (c >= excess) lo = mid; else hi = mid - 1u;
+          if (count_if([&](uint32_t f, uint32_t) { return f >= mid; }) >= excess) lo = mid; else hi = mid - 1u;
         }
         const uint32_t thr = lo;
         if (thr == 0) err = 3;   // a zero would be decremented
         if (!err) {
-          uint64_t above = 0;
-          for (uint32_t s = tid; s < num_symbols; s += T) above += freq[s] > thr;
-          above = block_sum(above, lds.red);
+          const uint64_t above = count_if([&](uint32_t f, uint32_t) { return f > thr; });
           const uint64_t need = excess - above;   // ≥ 1 entries equal to thr, from the highest index down
           uint32_t ilo = 0, ihi = num_symbols - 1u;
           while (ilo < ihi) {   // largest I with #(freq == thr, index ≥ I) ≥ need
             const uint32_t mid = ilo + (ihi - ilo + 1u) / 2u;
-            uint64_t c = 0;
-            for (uint32_t s = tid; s < num_symbols; s += T) c += (freq[s] == thr && s >= mid);
-            c = block_sum(c, lds.red);
-            if (c >= need) ilo = mid; else ihi = mid - 1u;
+            if (count_if([&](uint32_t f, uint32_t s) { return f == thr && s >= mid; }) >= need) ilo = mid; else ihi = mid - 1u;
           }
           __syncthreads();
           for (uint32_t s = tid; s < num_symbols; s += T) { const uint32_t f = freq[s]; if (f > thr || (f == thr && s >= ilo)) freq[s] = f - 1u; }
@@ -289,10 +300,17 @@ __device__ void k_tables_body(const TableAtt& a, const uint32_t, const uint32_t)
   if (!err) {
     uint64_t carry = 0;   // (header bytes << 32) | cumulative frequency
     const uint32_t lane = tid & 63u, wave = tid >> 6;
+    const bool staged = num_symbols <= kTablesLdsBins;
+    if (staged) {
+      for (uint32_t s = tid; s < num_symbols; s += T) lds.fq[s] = freq[s];
+      if (tid == 0) { lds.fq[num_symbols] = 1u; lds.fq[num_symbols + 1u] = 1u; }   // (never read past: the last symbol of a table is non-zero; a stop all the same)
+      __syncthreads();
+    }
+    const uint32_t* fsrc = staged ? lds.fq : freq;
     for (uint32_t base = 0; base < num_symbols; base += T) {
       const uint32_t s = base + tid;
       uint32_t f = 0, nbytes = 0, bytes = 0;
-      if (s < num_symbols) { f = freq[s]; nbytes = table_token(freq, s, bytes); }
+      if (s < num_symbols) { f = fsrc[s]; nbytes = table_token(fsrc, s, bytes); }
       const uint64_t v = ((uint64_t)nbytes << 32) | f;
       uint64_t incl = v;
 #pragma unroll
@@ -321,43 +339,59 @@ __device__ void k_tables_body(const TableAtt& a, const uint32_t, const uint32_t)
     aux_count = a.n_entries;
     zero_prob = zero_probability_dev(a.small[2], (float)a.n_entries);
   } else if (a.aux_kind == 2) {    // orientations: stitch the per-block summaries {count, first, last, transitions} (…texture_coordinates.rs:224-253, Q10)
+    // Every thread owns a run of consecutive chunks; what crosses the runs — the compact offset, the value of the last valid flag before
+    // the run, the value of the first valid flag after it — comes from block-wide scans (the serial loops this replaces walked all chunks
+    // on one lane: ≈ 0.2 ms for the 1221 chunks of the 10M-triangle workload, most of the table stage).
     const uint32_t nb = a.summary_blocks;
-    uint64_t len = 0, trans = 0;
-    uint32_t lastv = 1, off = 0;
-    for (uint32_t base = 0; base < nb; base += 1024u) {
-      const uint32_t cnt = min(1024u, nb - base);
-      __syncthreads();
-      for (uint32_t k = tid; k < 4u * cnt; k += T) lds.stage[k] = a.summary[4u * base + k];
-      __syncthreads();
-      if (tid == 0)
-        for (uint32_t b = 0; b < cnt; ++b) {
-          const uint32_t c = lds.stage[4 * b];
-          a.chunk_info[2 * (base + b)] = off;
-          off += c;
-          if (!c) continue;
-          if (lds.stage[4 * b + 1] != lastv) ++trans;
-          trans += lds.stage[4 * b + 3];
-          lastv = lds.stage[4 * b + 2];
-          len += c;
-        }
+    const uint32_t per = (nb + T - 1u) / T;
+    const uint32_t b0 = min(nb, tid * per), b1 = min(nb, b0 + per);
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    uint64_t cnt = 0, tr = 0;
+    uint32_t has = 0, firstv = 1, lastv = 1;
+    for (uint32_t b = b0; b < b1; ++b) {
+      const uint32_t c = a.summary[4u * b];
+      if (!c) continue;
+      const uint32_t f = a.summary[4u * b + 1u], l = a.summary[4u * b + 2u];
+      if (has) tr += f != lastv; else firstv = f;
+      tr += a.summary[4u * b + 3u];
+      lastv = l; has = 1; cnt += c;
     }
-    if (tid == 0) lds.nextv = 1u;   // `true` after the last valid entry
-    for (uint32_t hi = nb; hi > 0;) {
-      const uint32_t base = (hi - 1u) & ~1023u, cnt = hi - base;
-      __syncthreads();
-      for (uint32_t k = tid; k < 4u * cnt; k += T) lds.stage[k] = a.summary[4u * base + k];
-      __syncthreads();
-      if (tid == 0) {
-        uint32_t nextv = lds.nextv;
-        for (uint32_t b = cnt; b-- > 0;) { a.chunk_info[2 * (base + b) + 1] = nextv; if (lds.stage[4 * b]) nextv = lds.stage[4 * b + 1]; }
-        lds.nextv = nextv;
-      }
-      hi = base;
+    // exclusive scans over the threads: counts (sum), "last valid value so far" (forward), "first valid value from here on" (backward)
+    uint64_t inc_cnt = cnt;
+    uint32_t fwd = has ? (2u | lastv) : 0u;     // bit 1: some chunk up to and including this thread holds a flag; bit 0: the last such value
+    uint32_t bwd = has ? (2u | firstv) : 0u;    // the same from the other end
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint64_t c2 = (uint64_t)__shfl_up((unsigned long long)inc_cnt, d, 64);
+      const uint32_t f2 = (uint32_t)__shfl_up((int)fwd, d, 64), g2 = (uint32_t)__shfl_down((int)bwd, d, 64);
+      if (lane >= (uint32_t)d) { inc_cnt += c2; if (!(fwd & 2u)) fwd = f2; }
+      if (lane + (uint32_t)d < 64u) { if (!(bwd & 2u)) bwd = g2; }
     }
-    if (tid == 0) { lds.red[0] = len; lds.red[1] = trans; }
     __syncthreads();
-    len = lds.red[0]; trans = lds.red[1];
+    if (lane == 63u) { lds.red[wave] = inc_cnt; lds.stage[wave] = fwd; }
+    if (lane == 0u) lds.stage[64u + wave] = bwd;
     __syncthreads();
+    uint64_t before = 0, total_cnt = 0;
+    uint32_t prev = 0, next = 0;   // (2 | value) of the last valid flag before this thread's wave / the first one after it
+#pragma unroll
+    for (uint32_t w = 0; w < kTablesThreads / 64; ++w) {
+      total_cnt += lds.red[w];
+      if (w < wave) { before += lds.red[w]; if (lds.stage[w] & 2u) prev = lds.stage[w]; }
+    }
+    for (uint32_t w = kTablesThreads / 64; w-- > wave + 1u;) if (lds.stage[64u + w] & 2u) next = lds.stage[64u + w];
+    // within the wave: the neighbours' inclusive results are the exclusive ones
+    const uint32_t f_ex = (uint32_t)__shfl_up((int)fwd, 1, 64), g_ex = (uint32_t)__shfl_down((int)bwd, 1, 64);
+    const uint32_t prev_t = (lane > 0u && (f_ex & 2u)) ? f_ex : prev;
+    const uint32_t next_t = (lane < 63u && (g_ex & 2u)) ? g_ex : next;
+    const uint32_t last_before = (prev_t & 2u) ? (prev_t & 1u) : 1u;   // `last` starts as true (…texture_coordinates.rs:224-235)
+    const uint32_t first_after = (next_t & 2u) ? (next_t & 1u) : 1u;   // `true` after the last valid entry
+    if (has && firstv != last_before) ++tr;
+    uint32_t off = (uint32_t)(before + inc_cnt - cnt);
+    for (uint32_t b = b0; b < b1; ++b) { a.chunk_info[2u * b] = off; off += a.summary[4u * b]; }
+    uint32_t nextv = first_after;
+    for (uint32_t b = b1; b-- > b0;) { a.chunk_info[2u * b + 1u] = nextv; if (a.summary[4u * b]) nextv = a.summary[4u * b + 1u]; }
+    const uint64_t trans = block_sum(tr, lds.red);
+    const uint64_t len = total_cnt;
     aux_count = (uint32_t)len;
     zero_prob = zero_probability_dev(trans, (float)len + 0.001f);
   }

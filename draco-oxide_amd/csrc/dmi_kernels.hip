@@ -1504,9 +1504,11 @@ __device__ __forceinline__ void k_orient_summary_body(const OrientArgs& oa, cons
 
 // Symbol histograms of every attribute of a job in one launch (block → (attribute, slice)), the first 16K bins privatised in LDS
 // (64 KiB of the CU's 160 KiB).  Few, fat blocks: each flushes its private copy once.
+constexpr uint32_t kHistHotWords = 1024;   // 64 hot bins × 16 copies (see k_histogram_body)
 constexpr uint32_t kLdsBins = 12288;   // 48 KiB: with the static LDS of the launch (orientation staging) below the 64 KiB a workgroup may always take
 __device__ __forceinline__ void k_histogram_body(const HistArgs& args, const uint32_t blk_, const uint32_t nblk_) {
-  extern __shared__ uint32_t lds[];
+  extern __shared__ uint32_t lds_all[];
+  uint32_t* lds = lds_all;
   // trailing blocks: the orientation-flag summaries of the job's fused sweep ride this launch (they depend on the same sweep as the
   // histograms and would otherwise be a 16 µs serial step of the pass)
   if (blk_ >= args.hist_blocks) { orient_summary_impl<kBlock>(args.orient, blk_ - args.hist_blocks); return; }
@@ -1528,15 +1530,44 @@ __device__ __forceinline__ void k_histogram_body(const HistArgs& args, const uin
   // residuals concentrate near zero — symbols straight to the global histogram.  (All-global atomics on a peaked distribution
   // serialise on a few addresses: 320 ms instead of 0.7 for the 150M position symbols of a 100M-triangle mesh.)
   const uint32_t lds_bins = min(a.bins, kLdsBins);
+  // The residuals pile up on the smallest symbols, and LDS atomics of one wavefront to one address execute one after the other: the first
+  // kHotBins bins are kept in kHotCopies copies (a lane adds to copy lane % kHotCopies), folded together at the end.
+  constexpr uint32_t kHotBins = 64, kHotCopies = 16;
+  uint32_t* hot = lds;   // kHistHotWords words in front of the private bins (launch_histograms sizes the dynamic LDS)
+  lds += kHistHotWords;
+  static_assert(kHotBins * kHotCopies == kHistHotWords, "hot copies");
   for (uint32_t b = threadIdx.x; b < lds_bins; b += kBlock) lds[b] = 0;
+  for (uint32_t b = threadIdx.x; b < kHotBins * kHotCopies; b += kBlock) hot[b] = 0;
   __syncthreads();
-  for (uint64_t e = (uint64_t)block * kBlock + threadIdx.x; e < a.n; e += (uint64_t)a.blocks * kBlock) {
-    const uint32_t s = load_sym(a.sym, a.sym16 != 0u, e);
-    if (s >= a.bins) { atomicOr(a.overflow, 1u); continue; }
-    if (s < lds_bins) atomicAdd(&lds[s], 1u); else atomicAdd(&a.hist[s], 1u);
+  const uint32_t copy = (threadIdx.x & (kHotCopies - 1u)) * kHotBins;
+  auto add = [&](uint32_t s) {
+    if (s < kHotBins) atomicAdd(&hot[copy + s], 1u);
+    else if (s < lds_bins) atomicAdd(&lds[s], 1u);
+    else if (s < a.bins) atomicAdd(&a.hist[s], 1u);
+    else atomicOr(a.overflow, 1u);
+  };
+  if (a.sym16) {   // eight 16-bit symbols per load (the symbol arrays are 16-byte aligned and padded)
+    const uint64_t n8 = a.n / 8;
+    const uint4* __restrict__ src = static_cast<const uint4*>(a.sym);
+    for (uint64_t e = (uint64_t)block * kBlock + threadIdx.x; e < n8; e += (uint64_t)a.blocks * kBlock) {
+      const uint4 v = src[e];
+      add(v.x & 0xFFFFu); add(v.x >> 16); add(v.y & 0xFFFFu); add(v.y >> 16); add(v.z & 0xFFFFu); add(v.z >> 16); add(v.w & 0xFFFFu); add(v.w >> 16);
+    }
+    if (block == 0) for (uint64_t e = n8 * 8 + threadIdx.x; e < a.n; e += kBlock) add((uint32_t)static_cast<const uint16_t*>(a.sym)[e]);
+  } else {
+    const uint64_t n4 = a.n / 4;
+    const uint4* __restrict__ src = static_cast<const uint4*>(a.sym);
+    for (uint64_t e = (uint64_t)block * kBlock + threadIdx.x; e < n4; e += (uint64_t)a.blocks * kBlock) { const uint4 v = src[e]; add(v.x); add(v.y); add(v.z); add(v.w); }
+    if (block == 0) for (uint64_t e = n4 * 4 + threadIdx.x; e < a.n; e += kBlock) add(static_cast<const uint32_t*>(a.sym)[e]);
   }
   __syncthreads();
-  for (uint32_t b = threadIdx.x; b < lds_bins; b += kBlock) { const uint32_t v = lds[b]; if (v) atomicAdd(&a.hist[b], v); }
+  for (uint32_t b = threadIdx.x; b < lds_bins; b += kBlock) {
+    uint32_t v = lds[b];
+    if (b < kHotBins) for (uint32_t c = 0; c < kHotCopies; ++c) v += hot[c * kHotBins + b];
+    if (v) atomicAdd(&a.hist[b], v);
+  }
+  if (lds_bins < kHotBins)   // (an alphabet smaller than the hot range: its copies still hold counts for bins < a.bins)
+    for (uint32_t b = lds_bins + threadIdx.x; b < min(a.bins, kHotBins); b += kBlock) { uint32_t v = 0; for (uint32_t c = 0; c < kHotCopies; ++c) v += hot[c * kHotBins + b]; if (v) atomicAdd(&a.hist[b], v); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1822,7 +1853,7 @@ void launch_histograms(HistArgs& args, hipStream_t s) {
     a.blocks = a.n ? grid_for(a.n, 512) : 0u;
     a.first_block = total;
     total += a.blocks;
-    if (a.blocks) lds = std::max(lds, (size_t)std::min(a.bins, kLdsBins) * 4);
+    if (a.blocks) lds = std::max(lds, ((size_t)std::min(a.bins, kLdsBins) + kHistHotWords) * 4);
   }
   args.hist_blocks = total;
   const uint32_t orient_blocks = args.orient.orient ? orient_summary_blocks(args.orient.n) : 0u;
