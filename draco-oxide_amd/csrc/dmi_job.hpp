@@ -275,6 +275,17 @@ struct HostStage {
   bool in_use = false;
   bool registered = false;   // malloc + hipHostRegister (huge pages) rather than hipHostMalloc
 };
+
+// ---- the encode phases of one job (dmi_encode.cpp), shared with the batch drivers (dmi_batch.cpp) ----
+int check_value_bounds(const dmi::AttJob& a, const uint32_t* small, uint32_t i);
+int encode_phase_a(dmi_job* job, bool plan_only = false);
+int encode_phase_b(dmi_job* job, bool plan_only = false, bool host_chains = false);
+uint32_t count_streams(const dmi_job* job);
+int encode_phase_b_dev(dmi_job* job, dmi::ChainDesc* desc_base, dmi::ChainDesc* hdr_desc_base, bool host_chains = false);
+int check_device_flags(const uint32_t* small, uint32_t i);
+int encode_phase_c_packed(dmi_job* job, const dmi::PackEntry* table, uint32_t first_desc, const uint8_t* arena_host);
+int encode_phase_c3(dmi_job* job, dmi_buffer* out);
+int run_phase_a(dmi_job* job);
 HostStage* acquire_stage(int device, size_t bytes);
 void release_stage(HostStage* st);
 namespace dmi {

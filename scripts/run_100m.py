@@ -17,6 +17,7 @@ atts = [dmi.Attribute(pos, dmi.ATT_POSITION, dmi.DOMAIN_POSITION, unique_id=0), 
         dmi.Attribute(uv, dmi.ATT_TEXCOORD, dmi.DOMAIN_CORNER, unique_id=2, parent_index=0)]
 mesh = dmi.Mesh(faces, atts)
 t_gen = time.time() - t0
+import torch  # noqa: E402  (one HIP runtime for torch and the library: torch first)
 t0 = time.time()
 job = dmi.mesh_prepare(mesh, dmi.Config(pos_bits=pos_bits, flags=dmi.FLAG_TIMINGS))
 t_prep = time.time() - t0
@@ -24,7 +25,14 @@ t0 = time.time(); a = job.encode(); t_enc = time.time() - t0
 tm = job.timings()
 t0 = time.time(); b = job.encode(); t_enc2 = time.time() - t0
 assert a == b, "two encodes differ"
+head = job.header_and_connectivity
 job.close()
+# whole .drc in one call (device corner tables, host walks, relabelling, encode): twice — the second call has the library's pools warm
+e2e = []
+for _ in range(2):
+    t0 = time.time(); drc = dmi.encode_mesh(mesh, dmi.Config(pos_bits=pos_bits, flags=dmi.FLAG_TIMINGS)); e2e.append(time.time() - t0)
+    assert drc == head + a, "dmi_encode_mesh differs from prepare + encode"
+call = dmi.last_call_timings()
 
 
 def leb(buf, p):
@@ -58,4 +66,7 @@ F = len(faces)
 print(json.dumps({"triangles": F, "pos_bits": pos_bits, "attribute_section_bytes": len(a), "bytes_per_triangle": round((len(a) + len(job.header_and_connectivity)) / F, 3),
                   "generate_s": round(t_gen, 1), "host_prepare_s": round(t_prep, 1), "encode_s": round(min(t_enc, t_enc2), 3), "mtri_per_s": round(F / min(t_enc, t_enc2) / 1e6, 2),
                   "stages_ms": {k: round(float(tm[k]), 2) for k in ("quantize_ms", "predict_ms", "histogram_ms", "table_ms", "rans_ms", "total_ms")},
-                  "checks": "deterministic; 3 rANS streams decode to V*N symbols; section consumed to the last byte"}))
+                  "end_to_end_s": [round(x, 3) for x in e2e], "end_to_end_mtri_per_s": round(F / min(e2e) / 1e6, 2),
+                  "end_to_end_split_ms": {k: round(float(call[k]), 1) for k in ("tables_ms", "connectivity_ms", "job_create_ms", "total_ms", "call_ms")},
+                  "roofline_frac_of_8TBps": round(tm["predict_bytes"] / ((tm["quantize_ms"] + tm["predict_ms"]) * 1e-3) / 8e12, 4),
+                  "checks": "deterministic; 3 rANS streams decode to V*N symbols; section consumed to the last byte; dmi_encode_mesh == prepare + encode"}))
