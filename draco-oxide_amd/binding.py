@@ -613,6 +613,13 @@ def meshes_prepare(meshes, cfg=None):
     return [Job(handles[i], _take(heads[i])) for i in range(n)]
 
 
+def init(device=0, staging_bytes=0, device_bytes=0):
+    """dmi_init: pay the process's one-time costs for `device` now (context, code objects, stream, optional staging / device pool)."""
+    L = load_library()
+    L.dmi_init.argtypes = [C.c_int, C.c_size_t, C.c_size_t]
+    _check(L.dmi_init(device, staging_bytes, device_bytes))
+
+
 def last_call_timings():
     """dmi_last_call_timings: stage times of this thread's last whole-mesh / boundary call."""
     t = _Timings()

@@ -57,8 +57,10 @@ constexpr int kMaxGather = 4;
 enum QFmt : int { QF_I32 = 0, QF_P64 = 1, QF_B16 = 2, QF_H32 = 3 };
 struct QuantAtt { const float* raw; const uint32_t* s2v; void* qs; int32_t* ipartials; const float* meta; float maxq; int kind; int N; int fmt; };
 struct QuantArgs { QuantAtt a[kMaxGather]; int count; };
-struct SeqQuantArgs { const uint32_t* s2p; uint32_t n; uint32_t pad; QuantArgs q; };
-void launch_seq_quantize(const uint32_t* s2p, uint32_t n, const QuantArgs& args, hipStream_t s);
+// dest (nullable): the pass runs in TILE-SORTED order — slot j holds point s2p[j] and is written to sequence index dest[j]; inside a tile of
+// consecutive sequence entries the slots are ordered by point, so a wavefront's gathers fall on a few lines instead of one line per lane
+struct SeqQuantArgs { const uint32_t* s2p; uint32_t n; uint32_t pad; const uint32_t* dest; QuantArgs q; };
+void launch_seq_quantize(const uint32_t* s2p, const uint32_t* dest, uint32_t n, const QuantArgs& args, hipStream_t s);
 
 // Fan-row sweep (see k_predict_fused).  Seam-free fast path: position (parallelogram, 3 components) + normal and/or texture
 // coordinates coded on the SAME corner table in one sweep; qs_nrm / qs_uv null = attribute absent.  sym_pos null = a normal

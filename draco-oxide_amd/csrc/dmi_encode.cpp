@@ -41,7 +41,7 @@ int encode_phase_a(dmi_job* job, bool plan_only) {   // device: ranges → codin
     if (t.alias_of >= 0) continue;
     QuantArgs qa{};
     auto flush = [&]() {
-      if (qa.count) launch_seq_quantize(t.s2p.as<uint32_t>(), t.n_seq, qa, s);
+      if (qa.count) launch_seq_quantize(t.s2p_sorted.p ? t.s2p_sorted.as<uint32_t>() : t.s2p.as<uint32_t>(), t.s2p_sorted.p ? t.sorted_dest.as<uint32_t>() : nullptr, t.n_seq, qa, s);
       qa.count = 0;
     };
     for (auto& a : job->atts) {

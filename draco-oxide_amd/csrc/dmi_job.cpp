@@ -679,6 +679,28 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
     for (auto& e : job->ev) HIP_TRY(hipEventCreate(&e));
     job->have_events = true;
   }
+  // EXPERIMENT (DMI_TILE_SORT=<entries per tile>): the quantize gather in tile-sorted order — inside a tile of consecutive sequence entries the
+  // slots are ordered by point index (host sort here; a device sort would follow if the kernel gains).
+  if (const char* ts = std::getenv("DMI_TILE_SORT")) {
+    const uint32_t tile = (uint32_t)std::max(1024, std::atoi(ts));
+    if (!defer) for (auto& t : job->tables) {
+      if (t.alias_of >= 0 || t.n_seq == 0) continue;
+      std::vector<uint32_t> s2p_h(t.n_seq), dest(t.n_seq), sorted(t.n_seq);
+      HIP_TRY(hipMemcpyAsync(s2p_h.data(), t.s2p.p, (size_t)t.n_seq * 4, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      for (uint32_t k = 0; k < t.n_seq; ++k) dest[k] = k;
+      parallel_for((t.n_seq + tile - 1) / tile, [&](size_t lo, size_t hi) {
+        for (size_t b = lo; b < hi; ++b) {
+          const size_t a0 = b * tile, a1 = std::min<size_t>(t.n_seq, a0 + tile);
+          std::sort(dest.begin() + (long)a0, dest.begin() + (long)a1, [&](uint32_t x, uint32_t y) { return s2p_h[x] < s2p_h[y]; });
+        }
+      });
+      for (uint32_t k = 0; k < t.n_seq; ++k) sorted[k] = s2p_h[dest[k]];
+      if ((rc = upload(t.s2p_sorted, sorted.data(), (size_t)t.n_seq * 4, s))) return rc;
+      if ((rc = upload(t.sorted_dest, dest.data(), (size_t)t.n_seq * 4, s))) return rc;
+      HIP_TRY(hipStreamSynchronize(s));
+    }
+  }
   uint32_t bad_p2v = 0;
   if (d_bad) HIP_TRY(hipMemcpyAsync(&bad_p2v, d_bad, 4, hipMemcpyDeviceToHost, s));
   if (!defer) HIP_TRY(hipStreamSynchronize(s));   // (a batch waits once, for all its jobs)

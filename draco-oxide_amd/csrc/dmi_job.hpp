@@ -160,6 +160,7 @@ struct SlabView {
 struct TableDev {
   uint32_t F = 0, V = 0, n_seq = 0;
   DevMem fan_hdr, fan_apex, fan;   // fan rows (only for tables with a fused sweep)
+  DevMem s2p_sorted, sorted_dest;   // tile-sorted form of the quantize gather: slot j → point / sequence index (optional)
   DevMem c2r, opp, seq, s2p;   // c2r = corner → sequence index of its vertex; s2p = sequence index → point (= point_idx(seq[i]))
   const uint32_t* s2p_host = nullptr;   // (during job creation, host-relabel form) the same array in the upload staging
   // sharing: a table whose arrays equal another table's reuses its device copies

@@ -290,12 +290,12 @@ constexpr int kTile = DMI_KTILE;
 template <int N> struct RawTile { float v[kTile][N]; };
 // issue: the kTile gathers of one attribute (value indices first when the attribute has its own point → value map)
 template <int N>
-__device__ __forceinline__ void gather_tile(const QuantAtt& a, const uint32_t (&p)[kTile], uint32_t base, uint32_t n, RawTile<N>& r) {
+__device__ __forceinline__ void gather_tile(const QuantAtt& a, const uint32_t (&p)[kTile], const uint32_t (&d)[kTile], uint32_t base, uint32_t n, RawTile<N>& r) {
   uint32_t v[kTile];
 #pragma unroll
   for (int t = 0; t < kTile; ++t) {
     const uint32_t i = base + t * kBlock + threadIdx.x;
-    v[t] = (a.s2v && i < n) ? a.s2v[i] : p[t];
+    v[t] = (a.s2v && i < n) ? a.s2v[d[t]] : p[t];
 #if defined(DMI_ABLATE) && DMI_ABLATE == 6
     v[t] = i < n ? i : 0u;
 #endif
@@ -308,10 +308,11 @@ __device__ __forceinline__ void gather_tile(const QuantAtt& a, const uint32_t (&
 }
 // retire: quantize and store the tile
 template <int N>
-__device__ __forceinline__ void finish_tile(const QuantAtt& a, const RawTile<N>& r, uint32_t base, uint32_t n, int32_t& mn, int32_t& mx) {
+__device__ __forceinline__ void finish_tile(const QuantAtt& a, const RawTile<N>& r, const uint32_t (&d)[kTile], uint32_t base, uint32_t n, int32_t& mn, int32_t& mx) {
 #pragma unroll
   for (int t = 0; t < kTile; ++t) {
-    const uint32_t i = base + t * kBlock + threadIdx.x;
+    const uint32_t slot = base + t * kBlock + threadIdx.x;
+    const uint32_t i = d[t];   // sequence index this slot is written to (= slot unless the pass runs tile-sorted)
     int32_t out[N];
     int nq = N;
 #if defined(DMI_ABLATE) && DMI_ABLATE == 7
@@ -329,7 +330,7 @@ __device__ __forceinline__ void finish_tile(const QuantAtt& a, const RawTile<N>&
 #pragma unroll
       for (int k = 0; k < N; ++k) out[k] = __float_as_int(r.v[t][k]);
     }
-    if (i < n) {
+    if (slot < n) {
       for (int k = 0; k < nq; ++k) { mn = min(mn, out[k]); mx = max(mx, out[k]); }
       if (a.fmt == QF_P64) { if (N == 3) static_cast<uint64_t*>(a.qs)[i] = pack_p64(out[0], out[1], out[2]); }
       else if (a.fmt == QF_B16) static_cast<uint16_t*>(a.qs)[i] = (uint16_t)((uint32_t)out[0] | ((uint32_t)out[1] << 8));
@@ -339,22 +340,22 @@ __device__ __forceinline__ void finish_tile(const QuantAtt& a, const RawTile<N>&
   }
 }
 template <int N>
-__device__ __forceinline__ void quantize_tile(const QuantAtt& a, const uint32_t (&p)[kTile], uint32_t base, uint32_t n, int32_t& mn, int32_t& mx) {
+__device__ __forceinline__ void quantize_tile(const QuantAtt& a, const uint32_t (&p)[kTile], const uint32_t (&d)[kTile], uint32_t base, uint32_t n, int32_t& mn, int32_t& mx) {
   RawTile<N> r;
-  gather_tile<N>(a, p, base, n, r);
-  finish_tile<N>(a, r, base, n, mn, mx);
+  gather_tile<N>(a, p, d, base, n, r);
+  finish_tile<N>(a, r, d, base, n, mn, mx);
 }
 // The common attribute sets of one table issue EVERY attribute's gathers before the first value is touched: a store between two
 // attributes' gathers orders them (the pointers may alias as far as the compiler knows), and the tile would pay one memory latency
 // per attribute instead of one.
 template <int N0, int N1>
-__device__ __forceinline__ void quantize_tiles2(const QuantArgs& q, const uint32_t (&p)[kTile], uint32_t base, uint32_t n, int32_t (&mn)[kMaxGather], int32_t (&mx)[kMaxGather]) {
+__device__ __forceinline__ void quantize_tiles2(const QuantArgs& q, const uint32_t (&p)[kTile], const uint32_t (&d)[kTile], uint32_t base, uint32_t n, int32_t (&mn)[kMaxGather], int32_t (&mx)[kMaxGather]) {
   RawTile<N0> r0; RawTile<N1> r1;
-  gather_tile<N0>(q.a[0], p, base, n, r0); gather_tile<N1>(q.a[1], p, base, n, r1);
-  finish_tile<N0>(q.a[0], r0, base, n, mn[0], mx[0]); finish_tile<N1>(q.a[1], r1, base, n, mn[1], mx[1]);
+  gather_tile<N0>(q.a[0], p, d, base, n, r0); gather_tile<N1>(q.a[1], p, d, base, n, r1);
+  finish_tile<N0>(q.a[0], r0, d, base, n, mn[0], mx[0]); finish_tile<N1>(q.a[1], r1, d, base, n, mn[1], mx[1]);
 }
 template <int N0, int N1, int N2>
-__device__ __forceinline__ void quantize_tiles3(const QuantArgs& q, const uint32_t (&p)[kTile], uint32_t base, uint32_t n, int32_t (&mn)[kMaxGather], int32_t (&mx)[kMaxGather]) {
+__device__ __forceinline__ void quantize_tiles3(const QuantArgs& q, const uint32_t (&p)[kTile], const uint32_t (&d)[kTile], uint32_t base, uint32_t n, int32_t (&mn)[kMaxGather], int32_t (&mx)[kMaxGather]) {
   RawTile<N0> r0; RawTile<N1> r1; RawTile<N2> r2;
 #if defined(DMI_ABLATE) && DMI_ABLATE == 9
   if constexpr (N0 == 3 && N1 == 3 && N2 == 2) {   // what ONE 32-byte gather per entry would cost: eight floats from one row of attribute 0's array (wrapped to stay inside it)
@@ -365,11 +366,11 @@ __device__ __forceinline__ void quantize_tiles3(const QuantArgs& q, const uint32
       const float4 lo = row[0], hi = row[1];
       r0.v[t][0] = lo.x; r0.v[t][1] = lo.y; r0.v[t][2] = lo.z; r1.v[t][0] = lo.w + 2.0f; r1.v[t][1] = hi.x; r1.v[t][2] = hi.y; r2.v[t][0] = hi.z; r2.v[t][1] = hi.w;
     }
-  } else { gather_tile<N0>(q.a[0], p, base, n, r0); gather_tile<N1>(q.a[1], p, base, n, r1); gather_tile<N2>(q.a[2], p, base, n, r2); }
+  } else { gather_tile<N0>(q.a[0], p, d, base, n, r0); gather_tile<N1>(q.a[1], p, d, base, n, r1); gather_tile<N2>(q.a[2], p, d, base, n, r2); }
 #else
-  gather_tile<N0>(q.a[0], p, base, n, r0); gather_tile<N1>(q.a[1], p, base, n, r1); gather_tile<N2>(q.a[2], p, base, n, r2);
+  gather_tile<N0>(q.a[0], p, d, base, n, r0); gather_tile<N1>(q.a[1], p, d, base, n, r1); gather_tile<N2>(q.a[2], p, d, base, n, r2);
 #endif
-  finish_tile<N0>(q.a[0], r0, base, n, mn[0], mx[0]); finish_tile<N1>(q.a[1], r1, base, n, mn[1], mx[1]); finish_tile<N2>(q.a[2], r2, base, n, mn[2], mx[2]);
+  finish_tile<N0>(q.a[0], r0, d, base, n, mn[0], mx[0]); finish_tile<N1>(q.a[1], r1, d, base, n, mn[1], mx[1]); finish_tile<N2>(q.a[2], r2, d, base, n, mn[2], mx[2]);
 }
 __device__ __forceinline__ void k_seq_quantize_body(const SeqQuantArgs& sq, const uint32_t blk_, const uint32_t nblk_) {
   const uint32_t* __restrict__ s2p = sq.s2p;
@@ -380,21 +381,21 @@ __device__ __forceinline__ void k_seq_quantize_body(const SeqQuantArgs& sq, cons
   for (int a = 0; a < kMaxGather; ++a) { mn[a] = 2147483647; mx[a] = (-2147483647 - 1); }
   const int sig = args.count * 1000 + (args.count > 0 ? args.a[0].N * 100 : 0) + (args.count > 1 ? args.a[1].N * 10 : 0) + (args.count > 2 ? args.a[2].N : 0);
   DMI_FOR_TILES(base, n, kTile) {
-    uint32_t p[kTile];
+    uint32_t p[kTile], d[kTile];
 #pragma unroll
-    for (int t = 0; t < kTile; ++t) { const uint32_t i = base + t * kBlock + threadIdx.x; p[t] = i < n ? s2p[i] : 0u; }
-    if (sig == 3332) { quantize_tiles3<3, 3, 2>(args, p, base, n, mn, mx); continue; }   // position, normal, texture coordinate
-    if (sig == 3323) { quantize_tiles3<3, 2, 3>(args, p, base, n, mn, mx); continue; }
-    if (sig == 2330) { quantize_tiles2<3, 3>(args, p, base, n, mn, mx); continue; }
-    if (sig == 2320) { quantize_tiles2<3, 2>(args, p, base, n, mn, mx); continue; }
+    for (int t = 0; t < kTile; ++t) { const uint32_t i = base + t * kBlock + threadIdx.x; p[t] = i < n ? s2p[i] : 0u; d[t] = (sq.dest && i < n) ? sq.dest[i] : i; }
+    if (sig == 3332) { quantize_tiles3<3, 3, 2>(args, p, d, base, n, mn, mx); continue; }   // position, normal, texture coordinate
+    if (sig == 3323) { quantize_tiles3<3, 2, 3>(args, p, d, base, n, mn, mx); continue; }
+    if (sig == 2330) { quantize_tiles2<3, 3>(args, p, d, base, n, mn, mx); continue; }
+    if (sig == 2320) { quantize_tiles2<3, 2>(args, p, d, base, n, mn, mx); continue; }
 #pragma unroll
     for (int a = 0; a < kMaxGather; ++a) {
       if (a >= args.count) break;
       switch (args.a[a].N) {
-        case 1: quantize_tile<1>(args.a[a], p, base, n, mn[a], mx[a]); break;
-        case 2: quantize_tile<2>(args.a[a], p, base, n, mn[a], mx[a]); break;
-        case 3: quantize_tile<3>(args.a[a], p, base, n, mn[a], mx[a]); break;
-        default: quantize_tile<4>(args.a[a], p, base, n, mn[a], mx[a]); break;
+        case 1: quantize_tile<1>(args.a[a], p, d, base, n, mn[a], mx[a]); break;
+        case 2: quantize_tile<2>(args.a[a], p, d, base, n, mn[a], mx[a]); break;
+        case 3: quantize_tile<3>(args.a[a], p, d, base, n, mn[a], mx[a]); break;
+        default: quantize_tile<4>(args.a[a], p, d, base, n, mn[a], mx[a]); break;
       }
     }
   }
@@ -1787,9 +1788,9 @@ void launch_i32_minmax_final(const MinMaxArgs& args, hipStream_t s) { emit(K_I32
 
 inline uint32_t tiles_grid(uint64_t n) { return grid_for((n + kTile - 1) / kTile, kSeqQuantizeMaxBlocks); }   // grid of a DMI_FOR_TILES kernel
 uint32_t seq_quantize_blocks(uint32_t n) { return tiles_grid(n); }
-void launch_seq_quantize(const uint32_t* s2p, uint32_t n, const QuantArgs& args, hipStream_t s) {
+void launch_seq_quantize(const uint32_t* s2p, const uint32_t* dest, uint32_t n, const QuantArgs& args, hipStream_t s) {
   SeqQuantArgs sq{};
-  sq.s2p = s2p; sq.n = n; sq.q = args;
+  sq.s2p = s2p; sq.dest = dest; sq.n = n; sq.q = args;
   emit(K_SEQ_QUANT, 2, sq, seq_quantize_blocks(n), 0, s);
 }
 

@@ -342,6 +342,34 @@ static int build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std::vector<ui
   return DMI_OK;
 }
 
+int dmi_init(int device, size_t staging_bytes, size_t device_bytes) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(DMI_ERR_NO_DEVICE, "no HIP device visible; libdraco_mi has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(DMI_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+  HIP_TRY(hipSetDevice(device));
+  NumaPin pin(device);   // (the staging is first touched — placed — on the GPU's memory node)
+  auto holder = thread_stream(device);
+  if (!holder) return fail(DMI_ERR_HIP, "hipStreamCreate");
+  hipStream_t s = holder->s;
+  {   // one launch per kernel file loads its code object: a 1-element prefix sum (dmi_conn.hip), a 4-word fill (dmi_relabel.hip), and the two below
+    TempDev tmp;
+    tmp.init(device, s, (size_t)1 << 20);
+    uint32_t* w = tmp.take<uint32_t>(64);
+    if (!w) return fail(DMI_ERR_OUT_OF_MEMORY, "hipMalloc");
+    HIP_TRY(hipMemsetAsync(w, 0, 256, s));
+    launch_exclusive_scan_u32(w, 1, w + 8, s);
+    launch_fill_u32(w + 16, 4, 0u, s);
+    launch_last_corners(w, 1, w + 24, s);                                    // dmi_kernels.hip (corner 0 → point w[0] = 0)
+    const CopyItem none{w + 32, 0, 0};
+    HIP_TRY(hipMemcpyAsync(w + 40, &none, sizeof none, hipMemcpyHostToDevice, s));
+    launch_scatter_items(reinterpret_cast<const CopyItem*>(w + 40), 1, reinterpret_cast<const uint8_t*>(w), s);   // dmi_chains.hip (an empty piece)
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  if (staging_bytes) { HostStage* st = acquire_stage(device, staging_bytes); if (!st) return fail(DMI_ERR_OUT_OF_MEMORY, "hipHostMalloc (staging)"); std::memset(st->p, 0, st->cap); release_stage(st); }
+  if (device_bytes) { TempDev tmp; tmp.init(device, s, device_bytes); if (!tmp.take<uint8_t>(device_bytes)) return fail(DMI_ERR_OUT_OF_MEMORY, "hipMalloc"); }
+  return DMI_OK;
+}
+
 // The device half of the connectivity stage on its own (tests hold it against the host builders; dmi_mesh_prepare uses it internally).
 int dmi_device_corner_table(const dmi_mesh* mesh, const dmi_config* cfg, uint32_t* opposite, uint32_t* left_most_corner, uint8_t* on_boundary, uint32_t* num_vertices, uint32_t* flags) {
   if (!mesh || !mesh->atts || mesh->num_atts == 0 || (!mesh->faces && mesh->num_faces) || !opposite || !num_vertices || !flags) return fail(DMI_ERR_INVALID_ARGUMENT, "null");

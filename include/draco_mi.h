@@ -261,6 +261,11 @@ const char* dmi_strerror(int status);
 const char* dmi_last_error(void);
 /* Number of HIP devices visible (0 when there is no GPU); never initialises a context. */
 int dmi_device_count(void);
+/* Optional: pay a process's one-time costs for `device` now instead of inside its first encode — HIP context, the library's code objects
+ * (one launch per kernel file), the calling thread's library stream, `staging_bytes` of pinned huge-page staging and `device_bytes` of
+ * pooled device memory (both 0 = none; a 10M-triangle whole-mesh call uses ≈ 250 MB and ≈ 4 GB).  The first whole-mesh call of a process
+ * is otherwise 0.15–0.2 s slower than the following ones. */
+int dmi_init(int device, size_t staging_bytes, size_t device_bytes);
 /* The library keeps released device chunks, idle pinned staging buffers and the large host arrays of the connectivity stage for its next
  * call (the host arrays up to DMI_HOST_CACHE_MB, default 4096; 0 = keep none).  This hands all of it back; live jobs are untouched. */
 void dmi_release_cached_memory(void);

@@ -5,6 +5,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
+import torch  # noqa: F401  (one HIP runtime for torch and the library)
 import draco_oxide_amd as dmi
 import orc
 from helpers import oracle_from_product_mesh, oracle_values_by_point
@@ -44,6 +45,17 @@ for c in range(n_cases):
     os.environ["DMI_HOST_TABLES"] = "1"
     got["host tables"] = dmi.encode_mesh(mesh, cfg)
     del os.environ["DMI_HOST_TABLES"]
+    # round 3: the mesh resident in HBM (device corner tables whatever the size; flagged meshes fall back to the reference's walks) and the
+    # per-mesh host form of the batch prepare
+    got["mesh in HBM"] = dmi.encode_mesh_device(dmi.DeviceMesh.upload(mesh), cfg)
+    os.environ["DMI_HOST_CONNECTIVITY"] = "1"
+    jobs2 = dmi.meshes_prepare([mesh], cfg)
+    got["batch, host connectivity"] = jobs2[0].header_and_connectivity + dmi.jobs_encode(jobs2)[0]
+    del os.environ["DMI_HOST_CONNECTIVITY"]
+    for j in jobs2:
+        j.close()
+    for j in jobs:
+        j.close()
     for name, g in got.items():
         if g != want:
             print(f"case {c} (seed {seed}, kind {kind}, {pb}/{ub} bits, {len(mesh.faces)} faces): {name} differs ({len(g)} vs {len(want)} bytes)"); bad += 1
