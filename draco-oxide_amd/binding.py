@@ -84,12 +84,17 @@ class _Decoded(C.Structure):
     _fields_ = [("num_attributes", C.c_uint32), ("attributes", C.POINTER(_DecodedAttribute)), ("owner", C.c_void_p)]
 
 
+class _DecodedMesh(C.Structure):
+    _fields_ = [("num_faces", C.c_uint32), ("num_points", C.c_uint32), ("faces", C.POINTER(C.c_uint32)), ("num_attributes", C.c_uint32),
+                ("attributes", C.POINTER(_DecodedAttribute)), ("owner", C.c_void_p)]
+
+
 class _Conn(C.Structure):
     _fields_ = [("num_tables", C.c_uint32), ("tables", C.POINTER(_CornerTable)), ("seeds", C.c_void_p), ("num_seeds", C.c_uint32), ("owner", C.c_void_p)]
 
 
 EXPORTS = ["dmi_encode_attributes", "dmi_encode_attributes_batch", "dmi_jobs_encode", "dmi_job_create", "dmi_job_encode", "dmi_job_timings", "dmi_job_destroy", "dmi_encode_mesh",
-           "dmi_mesh_prepare", "dmi_meshes_prepare", "dmi_shard_meshes", "dmi_meshes_prepare_devices", "dmi_jobs_encode_devices", "dmi_mesh_build", "dmi_built_mesh_free", "dmi_encode_connectivity", "dmi_conn_free", "dmi_host_rans_stream", "dmi_host_rabs_stream", "dmi_decode_attributes", "dmi_decoded_free", "dmi_free", "dmi_free_many", "dmi_strerror", "dmi_last_error", "dmi_device_count", "dmi_release_cached_memory"]
+           "dmi_mesh_prepare", "dmi_meshes_prepare", "dmi_shard_meshes", "dmi_meshes_prepare_devices", "dmi_jobs_encode_devices", "dmi_mesh_build", "dmi_built_mesh_free", "dmi_encode_connectivity", "dmi_conn_free", "dmi_host_rans_stream", "dmi_host_rabs_stream", "dmi_decode_attributes", "dmi_decoded_free", "dmi_decode_mesh", "dmi_decoded_mesh_free", "dmi_decode_connectivity", "dmi_decoded_conn_free", "dmi_free", "dmi_free_many", "dmi_strerror", "dmi_last_error", "dmi_device_count", "dmi_release_cached_memory"]
 
 
 def library_path():
@@ -133,6 +138,12 @@ def load_library():
     L.dmi_last_call_timings.argtypes = [C.POINTER(_Timings)]
     L.dmi_job_destroy.argtypes = [C.c_void_p]
     L.dmi_encode_mesh.argtypes = [C.POINTER(_Mesh), C.POINTER(_Config), C.POINTER(_Buffer)]
+    L.dmi_decode_mesh.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(_Config), C.POINTER(_DecodedMesh)]
+    L.dmi_decoded_mesh_free.argtypes = [C.POINTER(_DecodedMesh)]
+    L.dmi_decoded_mesh_free.restype = None
+    L.dmi_decode_connectivity.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(_Conn), C.POINTER(C.c_size_t)]
+    L.dmi_decoded_conn_free.argtypes = [C.POINTER(_Conn)]
+    L.dmi_decoded_conn_free.restype = None
     L.dmi_device_corner_table.argtypes = [C.POINTER(_Mesh), C.POINTER(_Config), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.dmi_encode_mesh_device.argtypes = [C.POINTER(_Mesh), C.POINTER(_Config), C.POINTER(_Buffer)]
     L.dmi_mesh_prepare.argtypes = [C.POINTER(_Mesh), C.POINTER(_Config), C.POINTER(_Buffer), C.POINTER(C.c_void_p)]
@@ -700,6 +711,52 @@ def device_corner_table(mesh, cfg=None):
     return dict(num_vertices=nv.value, opposite=opp, left_most_corner=lmc[:nv.value], on_boundary=onb[:nv.value], flags=flags.value)
 
 
+def _decoded_attributes(atts, n):
+    res = []
+    for i in range(n):
+        a = atts[i]
+        raw = C.string_at(a.values, a.num_points * a.num_components * 4) if a.num_points else b""
+        vals = np.frombuffer(raw, dtype=np.uint32 if a.portabilization == 1 else np.float32).reshape(a.num_points, a.num_components).copy()
+        res.append(dict(att_type=a.att_type, num_components=a.num_components, unique_id=a.unique_id, domain=a.domain, scheme=a.scheme, transform=a.transform,
+                        portabilization=a.portabilization, bits=a.bits, values=vals))
+    return res
+
+
+def decode_mesh(drc, cfg=None):
+    """dmi_decode_mesh: a whole `.drc` from its bytes alone → dict(faces [F, 3] point indices in decode order, num_points,
+    attributes [dict(att_type, …, values [num_points, num_components])])."""
+    L = load_library()
+    cfg = cfg or Config.default()
+    b = np.frombuffer(bytes(drc), dtype=np.uint8)
+    out, c = _DecodedMesh(), cfg._c()
+    _check(L.dmi_decode_mesh(b.ctypes.data, len(b), C.byref(c), C.byref(out)))
+    try:
+        faces = np.ctypeslib.as_array(out.faces, shape=(3 * out.num_faces,)).copy().reshape(-1, 3) if out.num_faces else np.zeros((0, 3), np.uint32)
+        return dict(faces=faces, num_points=out.num_points, attributes=_decoded_attributes(out.attributes, out.num_attributes))
+    finally:
+        L.dmi_decoded_mesh_free(C.byref(out))
+
+
+def decode_connectivity(header_and_connectivity):
+    """dmi_decode_connectivity (host only): → dict(tables [dict like Connectivity.table, sequence empty], seeds, consumed)."""
+    L = load_library()
+    b = np.frombuffer(bytes(header_and_connectivity), dtype=np.uint8)
+    conn, used = _Conn(), C.c_size_t(0)
+    _check(L.dmi_decode_connectivity(b.ctypes.data, len(b), C.byref(conn), C.byref(used)))
+    try:
+        def arr(ptr, n):
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32)), shape=(n,)).copy() if ptr and n else np.zeros(0, np.uint32)
+        tables = []
+        for i in range(conn.num_tables):
+            t = conn.tables[i]
+            nc = 3 * t.num_faces
+            tables.append(dict(num_faces=t.num_faces, num_vertices=t.num_vertices, corner_to_point=arr(t.corner_to_point, nc), corner_to_vertex=arr(t.corner_to_vertex, nc),
+                               opposite=arr(t.opposite, nc), left_most_corner=arr(t.left_most_corner, t.num_vertices), sequence=np.zeros(0, np.uint32)))
+        return dict(tables=tables, seeds=arr(conn.seeds, conn.num_seeds), consumed=used.value)
+    finally:
+        L.dmi_decoded_conn_free(C.byref(conn))
+
+
 def shard_meshes(meshes, n_devices):
     """dmi_shard_meshes: device index per mesh, dealt by triangle count (LPT)."""
     L = load_library()
@@ -779,13 +836,6 @@ def decode_attributes(section, tables, num_points, seeds=None, cfg=None):
     out, c = _Decoded(), cfg._c()
     _check(L.dmi_decode_attributes(b.ctypes.data, len(b), tabs, len(tables), None if sd is None else sd.ctypes.data, 0 if sd is None else len(sd), num_points, C.byref(c), C.byref(out)))
     try:
-        res = []
-        for i in range(out.num_attributes):
-            a = out.attributes[i]
-            raw = C.string_at(a.values, a.num_points * a.num_components * 4) if a.num_points else b""
-            vals = np.frombuffer(raw, dtype=np.uint32 if a.portabilization == 1 else np.float32).reshape(a.num_points, a.num_components).copy()
-            res.append(dict(att_type=a.att_type, num_components=a.num_components, unique_id=a.unique_id, domain=a.domain, scheme=a.scheme, transform=a.transform,
-                            portabilization=a.portabilization, bits=a.bits, values=vals))
-        return res
+        return _decoded_attributes(out.attributes, out.num_attributes)
     finally:
         L.dmi_decoded_free(C.byref(out))

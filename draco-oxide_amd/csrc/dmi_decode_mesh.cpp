@@ -1,0 +1,367 @@
+// dmi_decode_mesh.cpp — a whole `.drc` read back from its bytes alone: header, Edgebreaker connectivity (standard traversal), attribute
+// section.  The reference has no working decoder (decode/ is not compiled: lib.rs:14; its connectivity decoder spirale_reversi.rs is
+// `unimplemented!` at :1088), so this follows the format the reference's ENCODER writes (encode/connectivity/edgebreaker.rs:458-656 — Draco's
+// standard Edgebreaker bitstream) with the reverse decoding every Draco-family decoder uses: the symbols are stored last to first, so
+// reading them in stored order grows the mesh from the traversal's END — every symbol glues one face to the open boundary of what has been
+// rebuilt so far (C closes a fan, R / L add a vertex, S joins two boundaries, E starts a component), topology-split events re-activate
+// edges, and interior start faces close the last hole of their component.  Attribute seams then give the per-attribute corner tables
+// (attribute_corner_table.rs:79-137 run from the decoded flags), and the attribute section goes through dmi_decode_attributes
+// (dmi_decode.cpp) with the rebuilt tables — serial stages on host cores, normals and dequantization on the device.
+// Host code except for that call.  What it proves in tests: a `.drc` the library wrote means, by itself, the mesh that went in
+// (tests/test_gpu_decode_mesh.py) — same-author evidence, not a reference pin.
+#include <algorithm>
+#include <map>
+#include <memory>
+#include <unordered_map>
+
+#include "dmi_host.hpp"
+#include "host_chains.hpp"
+
+namespace dmi {
+namespace {
+
+struct Bytes {
+  const uint8_t* p; size_t n, at = 0;
+  bool ok = true;
+  uint8_t u8() { if (at >= n) { ok = false; return 0; } return p[at++]; }
+  uint64_t leb() {   // utils/bit_coder.rs:20-33; at most ten bytes
+    uint64_t v = 0; uint32_t sh = 0; uint8_t b;
+    do {
+      b = u8();
+      if (sh == 63 && (b & 0x7E)) { ok = false; return 0; }
+      v |= (uint64_t)(b & 0x7F) << sh; sh += 7;
+    } while ((b & 0x80) && ok && sh < 70);
+    if (b & 0x80) ok = false;
+    return v;
+  }
+  bool take(size_t k, const uint8_t*& q) { if (k > n - at) { ok = false; return false; } q = p + at; at += k; return true; }
+};
+
+// {u8 zero_prob, leb nbytes, rABS bytes} → `count` flags in the order the encoder EMITTED them (it fed the coder the reversed list; an ANS
+// decoder pops the last one fed first)
+bool read_flag_block(Bytes& b, uint64_t count, std::vector<uint8_t>& flags) {
+  const uint8_t zp = b.u8();
+  const uint64_t nbytes = b.leb();
+  const uint8_t* data = nullptr;
+  if (!b.ok || !b.take((size_t)nbytes, data)) return false;
+  flags.assign((size_t)count, 0);
+  if (count == 0) return true;
+  if (zp == 0) return false;
+  return host_rabs_decode(data, (size_t)nbytes, zp, count, flags.data());
+}
+
+enum : uint8_t { SYM_C, SYM_S, SYM_L, SYM_R, SYM_E };
+
+struct DecodedConnectivity {
+  uint32_t F = 0, V = 0;
+  std::vector<uint32_t> c2v, opp, lmc;         // universal table, vertices compacted
+  std::vector<uint32_t> seeds;                 // reverse(interior start corners) ++ tip corners of the symbol faces, last decoded first (= the encoder's corners_of_edgebreaker)
+  std::vector<std::vector<uint8_t>> seam;      // per attribute table: seam flag per corner (both sides of a seam edge, every boundary corner)
+};
+
+int decode_connectivity(Bytes& b, DecodedConnectivity& out) {
+  auto bad = [](const char* what) { return host_fail(DMI_ERR_CONNECTIVITY, std::string("connectivity section: ") + what); };
+  if (b.u8() != 0) return bad("not the standard Edgebreaker traversal");
+  const uint64_t V_enc = b.leb(), F64 = b.leb();
+  const uint32_t n_tables = b.u8();
+  const uint64_t n_symbols = b.leb(), n_split_symbols = b.leb();
+  (void)n_split_symbols;
+  // every symbol takes at least one bit of what is left, and every face is a symbol's or the interior start face of a component (which has at
+  // least one symbol): a damaged count cannot make the decoder allocate more than a small multiple of the file
+  if (!b.ok || F64 >= (1ull << 30) || V_enc > 3 * F64 + 3 || n_symbols > F64 || n_symbols > 8 * (uint64_t)(b.n - b.at) || F64 > 2 * n_symbols) return bad("implausible counts");
+  const uint32_t F = (uint32_t)F64;
+  struct Split { uint64_t source, split; uint8_t right; };
+  const uint64_t n_splits = b.leb();
+  if (!b.ok || n_splits > n_symbols) return bad("implausible topology-split count");
+  std::vector<Split> splits((size_t)n_splits);
+  {
+    uint64_t last = 0;
+    for (auto& s : splits) { const uint64_t d = b.leb(), back = b.leb(); s.source = last + d; if (back > s.source) return bad("topology split before the first symbol"); s.split = s.source - back; last = s.source; }
+    const uint8_t* bits = nullptr;
+    if (!b.ok || !b.take((size_t)((n_splits + 7) / 8), bits)) return bad("truncated topology splits");
+    for (size_t k = 0; k < splits.size(); ++k) splits[k].right = (bits[k / 8] >> (k % 8)) & 1u;
+  }
+  std::vector<uint8_t> symbols((size_t)n_symbols);
+  {
+    const uint64_t nbytes = b.leb();
+    const uint8_t* data = nullptr;
+    if (!b.ok || !b.take((size_t)nbytes, data)) return bad("truncated symbols");
+    uint64_t pos = 0;
+    auto bit = [&]() -> uint32_t { if (pos >= nbytes * 8) { b.ok = false; return 0; } const uint32_t v = (data[pos / 8] >> (pos % 8)) & 1u; ++pos; return v; };
+    for (auto& s : symbols) {   // LSB-first: C = 0, S = 001, L = 011, R = 101, E = 111 (edgebreaker.rs:575-598)
+      if (bit() == 0) { s = SYM_C; continue; }
+      const uint32_t x = bit() | (bit() << 1);
+      s = x == 0 ? SYM_S : (x == 1 ? SYM_L : (x == 2 ? SYM_R : SYM_E));
+    }
+    if (!b.ok) return bad("symbol bits exhausted");
+  }
+  const size_t C = (size_t)F * 3;
+  std::vector<uint32_t> c2v(C, kNone), opp(C, kNone);
+  std::vector<uint32_t> vcorner;   // left-most corner per vertex, maintained as the faces are glued on
+  auto vertex = [&](uint32_t c) { return c2v[c]; };
+  auto set_opp = [&](uint32_t x, uint32_t y) { opp[x] = y; opp[y] = x; };
+  auto new_vertex = [&]() { vcorner.push_back(kNone); return (uint32_t)vcorner.size() - 1; };
+  auto swing_left = [&](uint32_t c) { const uint32_t o = opp[corner_next(c)]; return o == kNone ? kNone : corner_next(o); };
+  std::vector<uint32_t> active;
+  std::unordered_map<uint64_t, uint32_t> split_corner;   // decoder symbol id of an S → the corner a topology split re-activated for it
+  uint32_t n_faces = 0;
+  size_t splits_left = splits.size();
+  for (uint64_t sid = 0; sid < n_symbols; ++sid) {
+    if (n_faces >= F) return bad("more symbols than faces");
+    const uint32_t corner = 3 * n_faces++;
+    bool check_split = false;
+    switch (symbols[(size_t)sid]) {
+      case SYM_C: {
+        if (active.empty()) return bad("C without an active edge");
+        const uint32_t ca = active.back();
+        const uint32_t vx = vertex(corner_next(ca));
+        if (vx == kNone || vcorner[vx] == kNone) return bad("C at an unknown vertex");
+        const uint32_t cb = corner_next(vcorner[vx]);
+        if (ca == cb || opp[ca] != kNone || opp[cb] != kNone) return bad("C between edges that are not open");
+        set_opp(ca, corner + 1);
+        set_opp(cb, corner + 2);
+        const uint32_t va_prev = vertex(corner_prev(ca)), vb_next = vertex(corner_next(cb));
+        if (vx == va_prev || vx == vb_next) return bad("degenerate C");
+        c2v[corner] = vx; c2v[corner + 1] = vb_next; c2v[corner + 2] = va_prev;
+        vcorner[va_prev] = corner + 2;
+        active.back() = corner;
+        break;
+      }
+      case SYM_R: case SYM_L: {
+        if (active.empty()) return bad("R/L without an active edge");
+        const uint32_t ca = active.back();
+        if (opp[ca] != kNone) return bad("R/L on a closed edge");
+        const bool right = symbols[(size_t)sid] == SYM_R;
+        const uint32_t opp_corner = right ? corner + 2 : corner + 1, corner_l = right ? corner + 1 : corner, corner_r = right ? corner : corner + 2;
+        set_opp(opp_corner, ca);
+        const uint32_t nv = new_vertex();
+        c2v[opp_corner] = nv; vcorner[nv] = opp_corner;
+        const uint32_t vr = vertex(corner_prev(ca));
+        c2v[corner_r] = vr; vcorner[vr] = corner_r;
+        c2v[corner_l] = vertex(corner_next(ca));
+        active.back() = corner;
+        check_split = true;
+        break;
+      }
+      case SYM_S: {
+        if (active.empty()) return bad("S without an active edge");
+        const uint32_t cb = active.back();
+        active.pop_back();
+        const auto it = split_corner.find(sid);
+        if (it != split_corner.end()) active.push_back(it->second);
+        if (active.empty()) return bad("S with one active edge");
+        const uint32_t ca = active.back();
+        if (ca == cb || opp[ca] != kNone || opp[cb] != kNone) return bad("S between edges that are not open");
+        set_opp(ca, corner + 2);
+        set_opp(cb, corner + 1);
+        const uint32_t vp = vertex(corner_prev(ca));
+        c2v[corner] = vp; c2v[corner + 1] = vertex(corner_next(ca));
+        const uint32_t vb_prev = vertex(corner_prev(cb));
+        c2v[corner + 2] = vb_prev; vcorner[vb_prev] = corner + 2;
+        uint32_t cn = corner_next(cb);
+        const uint32_t vn = vertex(cn);
+        if (vn == kNone || vp == kNone) return bad("S at unknown vertices");
+        vcorner[vp] = vcorner[vn];   // the merged vertex keeps n's left-most corner
+        const uint32_t first = cn;
+        for (uint64_t guard = 0; cn != kNone; ++guard) {   // n's corners (counter-clockwise from the new face) now belong to p
+          c2v[cn] = vp;
+          cn = swing_left(cn);
+          if (cn == first || guard > C) return bad("S closes a loop");
+        }
+        if (vn != vp) vcorner[vn] = kNone;   // isolated
+        active.back() = corner;
+        break;
+      }
+      default: {   // SYM_E
+        const uint32_t v0 = new_vertex(), v1 = new_vertex(), v2 = new_vertex();
+        c2v[corner] = v0; c2v[corner + 1] = v1; c2v[corner + 2] = v2;
+        vcorner[v0] = corner; vcorner[v1] = corner + 1; vcorner[v2] = corner + 2;
+        active.push_back(corner);
+        check_split = true;
+      }
+    }
+    if (check_split) {   // (only R, L and E can be the source of a topology split)
+      const uint64_t enc_id = n_symbols - sid - 1;
+      while (splits_left && splits[splits_left - 1].source == enc_id) {
+        const Split& sp = splits[--splits_left];
+        if (sp.split > n_symbols - 1) return bad("topology split symbol out of range");
+        const uint32_t top = active.back();
+        split_corner[n_symbols - sp.split - 1] = sp.right ? corner_next(top) : corner_prev(top);
+      }
+      if (splits_left && splits[splits_left - 1].source > enc_id) return bad("topology split out of order");
+    }
+  }
+  // start faces: one flag per component, first-encoded component first = the order the stack pops them
+  std::vector<uint8_t> interior;
+  if (!read_flag_block(b, active.size(), interior)) return bad("truncated start-face flags");
+  std::vector<uint32_t> init_corners;
+  for (size_t k = 0; !active.empty(); ++k) {
+    const uint32_t ca = active.back();
+    active.pop_back();
+    if (!interior[k]) continue;   // the traversal started at a boundary edge: nothing to add
+    if (n_faces >= F) return bad("more start faces than faces");
+    const uint32_t vn = vertex(corner_next(ca));
+    if (vn == kNone || vcorner[vn] == kNone) return bad("start face at an unknown vertex");
+    const uint32_t cb = corner_next(vcorner[vn]);
+    const uint32_t vx = vertex(corner_next(cb));
+    if (vx == kNone || vcorner[vx] == kNone) return bad("start face at an unknown vertex");
+    const uint32_t cc = corner_next(vcorner[vx]);
+    if (ca == cb || ca == cc || cb == cc || opp[ca] != kNone || opp[cb] != kNone || opp[cc] != kNone) return bad("start face between edges that are not open");
+    const uint32_t vp = vertex(corner_next(cc));
+    const uint32_t nc = 3 * n_faces++;
+    set_opp(nc, ca); set_opp(nc + 1, cb); set_opp(nc + 2, cc);
+    c2v[nc] = vx; c2v[nc + 1] = vp; c2v[nc + 2] = vn;
+    init_corners.push_back(nc);
+  }
+  if (n_faces != F) return bad("face count does not match the symbols");
+  // compact the vertex ids (S symbols left merged-away ids behind) and rebuild the left-most corners from the finished table
+  std::vector<uint32_t> remap(vcorner.size(), kNone);
+  uint32_t V = 0;
+  for (size_t c = 0; c < C; ++c) { if (c2v[c] == kNone) return bad("corner without a vertex"); if (remap[c2v[c]] == kNone) remap[c2v[c]] = V++; c2v[c] = remap[c2v[c]]; }
+  if (V != V_enc) return bad("vertex count does not match the header");
+  std::vector<uint32_t> lmc(V, kNone);
+  for (uint32_t c = 0; c < C; ++c) {
+    const uint32_t v = c2v[c];
+    if (lmc[v] != kNone) continue;
+    uint32_t left = c, a = swing_left(c);
+    for (uint64_t guard = 0; a != kNone && a != c && guard <= C; ++guard) { left = a; a = swing_left(a); }
+    lmc[v] = a == kNone ? left : c;   // open fan: where swinging left ends; closed fan: any corner serves (its swing_left exists)
+  }
+  // attribute seams (edgebreaker.rs:611-653): faces in decode order, corners c, next, prev; an edge is decided by its EARLIER face
+  out.seam.assign(n_tables, std::vector<uint8_t>());
+  uint64_t n_flags = 0;
+  for (uint32_t f = 0; f < F; ++f) for (uint32_t k = 0; k < 3; ++k) { const uint32_t o = opp[3 * f + k]; if (o != kNone && o / 3 > f) ++n_flags; }
+  for (uint32_t t = 0; t < n_tables; ++t) {
+    std::vector<uint8_t> flags;
+    if (!read_flag_block(b, n_flags, flags)) return bad("truncated seam flags");
+    std::vector<uint8_t>& seam = out.seam[t];
+    seam.assign(C, 0);
+    size_t at = 0;
+    for (uint32_t f = 0; f < F; ++f) {
+      const uint32_t cs[3] = {3 * f, 3 * f + 1, 3 * f + 2};
+      for (uint32_t c : cs) {
+        const uint32_t o = opp[c];
+        if (o == kNone) { seam[c] = 1; continue; }
+        if (o / 3 < f) continue;
+        if (flags[at++]) seam[c] = seam[o] = 1;
+      }
+    }
+  }
+  out.F = F; out.V = V;
+  out.c2v.swap(c2v); out.opp.swap(opp); out.lmc.swap(lmc);
+  out.seeds.assign(init_corners.rbegin(), init_corners.rend());
+  for (uint64_t k = 0; k < n_symbols; ++k) out.seeds.push_back(3u * (uint32_t)(n_symbols - 1 - k));
+  return DMI_OK;
+}
+
+// everything the attribute decoder needs, rebuilt from the connectivity bytes
+struct DecodedTables {
+  DecodedConnectivity dc;
+  CornerTables ct;
+  std::vector<uint32_t> faces;   // corner → point
+  uint32_t num_points = 0;
+  std::vector<dmi_corner_table> views;
+  size_t consumed = 0;
+};
+
+int decode_tables(const uint8_t* drc, size_t len, DecodedTables& d) {
+  static const uint8_t kHeader[11] = {'D', 'R', 'A', 'C', 'O', 2, 2, 1, 1, 0, 0};   // encode/header/mod.rs:26-54: version 2.2, triangular mesh, Edgebreaker, no flags
+  if (len < sizeof kHeader || std::memcmp(drc, kHeader, sizeof kHeader) != 0) return host_fail(DMI_ERR_INVALID_ARGUMENT, "not a DRACO 2.2 Edgebreaker mesh without metadata");
+  Bytes b{drc, len, sizeof kHeader};
+  DecodedConnectivity& dc = d.dc;
+  const int rc = decode_connectivity(b, dc);
+  if (rc) return rc;
+  d.consumed = b.at;
+  // per-attribute corner tables from the seam flags: attribute i > 0 takes table i - 1 when it has interior seams, else the universal one
+  CornerTables& ct = d.ct;
+  ct.F = dc.F; ct.V = dc.V;
+  ct.c2p = nullptr; ct.c2v = dc.c2v.data(); ct.opp = dc.opp.data(); ct.lmc = dc.lmc.data();
+  ct.att.resize(dc.seam.size());
+  for (size_t t = 0; t < dc.seam.size(); ++t) { ct.att[t].seam_edge.swap(dc.seam[t]); ct.attribute_from_seams(ct.att[t]); }
+  // points: corners that share the universal vertex and every attribute's vertex are one point (the finest partition all tables agree on)
+  const size_t C = (size_t)dc.F * 3;
+  d.faces.resize(C);
+  {
+    std::map<std::vector<uint32_t>, uint32_t> ids;
+    std::vector<uint32_t> key;
+    for (size_t c = 0; c < C; ++c) {
+      key.assign(1, dc.c2v[c]);
+      for (auto& a : ct.att) if (a.interior_seams) key.push_back(a.c2v[c]);
+      auto it = ids.find(key);
+      if (it == ids.end()) it = ids.emplace(key, d.num_points++).first;
+      d.faces[c] = it->second;
+    }
+  }
+  d.views.resize(1 + ct.att.size());
+  for (size_t i = 0; i < d.views.size(); ++i) {
+    dmi_corner_table& t = d.views[i];
+    t = dmi_corner_table{};
+    t.num_faces = dc.F;
+    t.corner_to_point = d.faces.data();
+    const AttTable* a = i > 0 && ct.att[i - 1].interior_seams ? &ct.att[i - 1] : nullptr;
+    t.num_vertices = a ? a->num_vertices : dc.V;
+    t.corner_to_vertex = a ? a->c2v.data() : dc.c2v.data();
+    t.opposite = a ? a->opp.data() : dc.opp.data();
+    t.left_most_corner = a ? a->lmc.data() : dc.lmc.data();
+  }
+  return DMI_OK;
+}
+
+struct MeshOwner {
+  DecodedTables d;
+  dmi_decoded atts{};
+  ~MeshOwner() { dmi_decoded_free(&atts); }
+};
+
+}  // namespace
+}  // namespace dmi
+
+using namespace dmi;
+
+extern "C" {
+
+int dmi_decode_connectivity(const uint8_t* header_and_connectivity, size_t len, dmi_conn* conn, size_t* consumed) {
+  if (!header_and_connectivity || !conn) return host_fail(DMI_ERR_INVALID_ARGUMENT, "null argument");
+  *conn = dmi_conn{};
+  std::unique_ptr<DecodedTables> d(new DecodedTables());
+  const int rc = decode_tables(header_and_connectivity, len, *d);
+  if (rc) return rc;
+  if (consumed) *consumed = d->consumed;
+  conn->num_tables = (uint32_t)d->views.size();
+  conn->tables = d->views.data();
+  conn->seeds = d->dc.seeds.data();
+  conn->num_seeds = (uint32_t)d->dc.seeds.size();
+  conn->owner = d.release();
+  return DMI_OK;
+}
+void dmi_decoded_conn_free(dmi_conn* conn) {
+  if (!conn) return;
+  delete static_cast<DecodedTables*>(conn->owner);
+  *conn = dmi_conn{};
+}
+
+void dmi_decoded_mesh_free(dmi_decoded_mesh* m) {
+  if (!m) return;
+  delete static_cast<MeshOwner*>(m->owner);
+  *m = dmi_decoded_mesh{};
+}
+
+int dmi_decode_mesh(const uint8_t* drc, size_t len, const dmi_config* cfg, dmi_decoded_mesh* out) {
+  if (!drc || !out) return host_fail(DMI_ERR_INVALID_ARGUMENT, "null argument");
+  *out = dmi_decoded_mesh{};
+  std::unique_ptr<MeshOwner> owner(new MeshOwner());
+  DecodedTables& d = owner->d;
+  int rc = decode_tables(drc, len, d);
+  if (rc) return rc;
+  rc = dmi_decode_attributes(drc + d.consumed, len - d.consumed, d.views.data(), (uint32_t)d.views.size(), d.dc.seeds.data(), (uint32_t)d.dc.seeds.size(), d.num_points, cfg, &owner->atts);
+  if (rc) return rc;
+  out->num_faces = d.dc.F;
+  out->num_points = d.num_points;
+  out->faces = d.faces.data();
+  out->num_attributes = owner->atts.num_attributes;
+  out->attributes = owner->atts.attributes;
+  out->owner = owner.release();
+  return DMI_OK;
+}
+
+}  // extern "C"

@@ -191,6 +191,8 @@ struct CornerTables {
   // thread-safe w.r.t. other attribute tables.  same_as_position: att_p2v is the Position attribute's own map — no edge can be a seam
   void build_attribute_into(AttTable& a, const uint32_t* att_p2v, bool same_as_position = false) const;
   void copy_attribute_into(AttTable& a, const AttTable& from) const;   // an attribute with the map of an earlier one
+  void attribute_from_seams(AttTable& a) const;   // decoder side: a.seam_edge given (both corners of every seam edge, every boundary corner)
+  void finish_attribute(AttTable& a, const std::vector<uint8_t>& vseam) const;   // a.opp / c2v / lmc from a.seam_edge (vseam: vertices on a seam)
 };
 
 struct EdgebreakerResult {

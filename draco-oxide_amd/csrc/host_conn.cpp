@@ -361,6 +361,28 @@ void CornerTables::build_attribute_into(AttTable& a, const uint32_t* p2v, bool s
   });
   a.interior_seams = interior.load() != 0;
   if (!a.interior_seams) return;   // (no table of its own: every consumer takes the universal one)
+  finish_attribute(a, vseam);
+}
+
+// The attribute table of a decoder: the seam flags come from the bitstream (DefaultTraversal's seam stream, edgebreaker.rs:611-653) instead of
+// from value comparisons; a.seam_edge must hold them for BOTH corners of every seam edge and for every boundary corner.
+void CornerTables::attribute_from_seams(AttTable& a) const {
+  const uint32_t C = 3 * F;
+  a.alias_of = -1;
+  a.num_vertices = V;
+  a.interior_seams = false;
+  std::vector<uint8_t> vseam(V, 0);
+  for (uint32_t c = 0; c < C; ++c) {
+    if (!a.seam_edge[c]) continue;
+    vseam[c2v[corner_next(c)]] = vseam[c2v[corner_prev(c)]] = 1;
+    if (opp[c] != kNone) a.interior_seams = true;
+  }
+  if (a.interior_seams) finish_attribute(a, vseam);
+}
+
+// attribute_corner_table.rs:79-137 (recompute_vertices) from the seam flags
+void CornerTables::finish_attribute(AttTable& a, const std::vector<uint8_t>& vseam) const {
+  const uint32_t C = 3 * F;
   pool_fit(a.opp, C);
   a.opp.resize(C);
   parallel_for(C, [&](size_t lo, size_t hi) { for (size_t c = lo; c < hi; ++c) a.opp[c] = a.seam_edge[c] ? kNone : opp[c]; });

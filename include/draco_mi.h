@@ -244,6 +244,27 @@ int dmi_decode_attributes(const uint8_t* section, size_t len, const dmi_corner_t
                           uint32_t num_points, const dmi_config* cfg, dmi_decoded* out);
 void dmi_decoded_free(dmi_decoded* d);
 
+/* A whole `.drc` read back from its bytes alone (round 3): header (encode/header/mod.rs:26-54), Edgebreaker connectivity in the standard
+ * traversal (the format encode/connectivity/edgebreaker.rs:458-656 writes, decoded the way every Draco-family decoder does: symbols in stored
+ * order, one face per symbol glued to the open boundary, topology splits, interior start faces, attribute seams → per-attribute corner
+ * tables), then dmi_decode_attributes on the rebuilt tables.  The reference's own decoder is not part of its crate (lib.rs:14) and its
+ * connectivity decoder is unimplemented (decode/connectivity/spirale_reversi.rs:1088); this is the inverse of the ENCODER's format.
+ * faces: 3·num_faces point indices in decode order (the reverse of the coding order); points: corners that agree in the universal vertex
+ * and in every attribute's vertex; attributes[i].values: num_points rows.  Everything is library-owned until dmi_decoded_mesh_free. */
+typedef struct dmi_decoded_mesh {
+  uint32_t num_faces, num_points;
+  const uint32_t* faces;
+  uint32_t num_attributes;
+  const dmi_decoded_attribute* attributes;
+  void* owner;
+} dmi_decoded_mesh;
+int dmi_decode_mesh(const uint8_t* drc, size_t len, const dmi_config* cfg, dmi_decoded_mesh* out);
+/* The connectivity half alone (host only, no GPU): header + connectivity bytes → the corner tables and seeds dmi_decode_attributes takes
+ * (tables[j].sequence stays null: the decoder derives it).  *consumed (nullable) = where the attribute section starts. */
+int dmi_decode_connectivity(const uint8_t* header_and_connectivity, size_t len, dmi_conn* conn, size_t* consumed);
+void dmi_decoded_conn_free(dmi_conn* conn);
+void dmi_decoded_mesh_free(dmi_decoded_mesh* m);
+
 /* --- The hybrid form's host-core stream coders on their own (host only, no device) ----------------
  * A single large mesh codes its streams on host cores from the device-built symbols and tables (dmi_job_encode, see
  * DESIGN.md §5); these two entry points expose exactly those coders so that tests can pin them against the reference's
