@@ -84,6 +84,10 @@ class _Decoded(C.Structure):
     _fields_ = [("num_attributes", C.c_uint32), ("attributes", C.POINTER(_DecodedAttribute)), ("owner", C.c_void_p)]
 
 
+class _DecodeTimings(C.Structure):
+    _fields_ = [(k, C.c_float) for k in ("connectivity_ms", "tables_ms", "sequence_ms", "entropy_ms", "inverse_ms", "device_ms", "attributes_ms", "call_ms")]
+
+
 class _DecodedMesh(C.Structure):
     _fields_ = [("num_faces", C.c_uint32), ("num_points", C.c_uint32), ("faces", C.POINTER(C.c_uint32)), ("num_attributes", C.c_uint32),
                 ("attributes", C.POINTER(_DecodedAttribute)), ("owner", C.c_void_p)]
@@ -94,7 +98,7 @@ class _Conn(C.Structure):
 
 
 EXPORTS = ["dmi_encode_attributes", "dmi_encode_attributes_batch", "dmi_jobs_encode", "dmi_job_create", "dmi_job_encode", "dmi_job_timings", "dmi_job_destroy", "dmi_encode_mesh",
-           "dmi_mesh_prepare", "dmi_meshes_prepare", "dmi_shard_meshes", "dmi_meshes_prepare_devices", "dmi_jobs_encode_devices", "dmi_mesh_build", "dmi_built_mesh_free", "dmi_encode_connectivity", "dmi_conn_free", "dmi_host_rans_stream", "dmi_host_rabs_stream", "dmi_decode_attributes", "dmi_decoded_free", "dmi_decode_mesh", "dmi_decoded_mesh_free", "dmi_decode_connectivity", "dmi_decoded_conn_free", "dmi_free", "dmi_free_many", "dmi_strerror", "dmi_last_error", "dmi_device_count", "dmi_release_cached_memory"]
+           "dmi_mesh_prepare", "dmi_meshes_prepare", "dmi_shard_meshes", "dmi_meshes_prepare_devices", "dmi_jobs_encode_devices", "dmi_mesh_build", "dmi_built_mesh_free", "dmi_encode_connectivity", "dmi_conn_free", "dmi_host_rans_stream", "dmi_host_rabs_stream", "dmi_decode_attributes", "dmi_decoded_free", "dmi_decode_mesh", "dmi_decoded_mesh_free", "dmi_decode_connectivity", "dmi_decoded_conn_free", "dmi_last_decode_timings", "dmi_free", "dmi_free_many", "dmi_strerror", "dmi_last_error", "dmi_device_count", "dmi_release_cached_memory"]
 
 
 def library_path():
@@ -139,6 +143,7 @@ def load_library():
     L.dmi_job_destroy.argtypes = [C.c_void_p]
     L.dmi_encode_mesh.argtypes = [C.POINTER(_Mesh), C.POINTER(_Config), C.POINTER(_Buffer)]
     L.dmi_decode_mesh.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(_Config), C.POINTER(_DecodedMesh)]
+    L.dmi_last_decode_timings.argtypes = [C.POINTER(_DecodeTimings)]
     L.dmi_decoded_mesh_free.argtypes = [C.POINTER(_DecodedMesh)]
     L.dmi_decoded_mesh_free.restype = None
     L.dmi_decode_connectivity.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(_Conn), C.POINTER(C.c_size_t)]
@@ -735,6 +740,14 @@ def decode_mesh(drc, cfg=None):
         return dict(faces=faces, num_points=out.num_points, attributes=_decoded_attributes(out.attributes, out.num_attributes))
     finally:
         L.dmi_decoded_mesh_free(C.byref(out))
+
+
+def last_decode_timings():
+    """dmi_last_decode_timings: host wall clock of this thread's last decode call by stage (ms)."""
+    L = load_library()
+    t = _DecodeTimings()
+    _check(L.dmi_last_decode_timings(C.byref(t)))
+    return {k: getattr(t, k) for k, _ in _DecodeTimings._fields_}
 
 
 def decode_connectivity(header_and_connectivity):

@@ -17,13 +17,17 @@
 #include <algorithm>
 #include <cmath>
 #include <limits>
+#include <chrono>
 #include <memory>
+#include <thread>
 
 #include "dmi_device.hpp"
 #include "dmi_host.hpp"
 #include "host_chains.hpp"
 
 namespace dmi {
+thread_local dmi_decode_timings g_last_decode{};   // dmi_last_decode_timings
+thread_local bool g_inside_decode_mesh = false;     // dmi_decode_mesh is the caller: its connectivity / table times stay
 namespace {
 
 #define HIP_TRY_D(expr)                                                                                            \
@@ -72,17 +76,29 @@ struct Reader {
   }
 };
 
+// What the parse pass records per attribute, and what its entropy thread leaves behind
+struct AttPlan {
+  int N = 0;
+  std::vector<uint32_t> seq_own; const uint32_t* seq = nullptr; uint32_t n = 0;
+  std::vector<uint32_t> freq; uint32_t P = 0; const uint8_t* rans = nullptr; size_t rans_bytes = 0;
+  bool has_rabs = false; uint8_t zp = 0; const uint8_t* rabs = nullptr; size_t rabs_bytes = 0; uint64_t rabs_count = 0;
+  int32_t t_min = 0, t_max = 0;
+  float q_min[4] = {0, 0, 0, 0}, q_range = 0; int q_bits = 0;
+  std::vector<uint32_t> sym; std::vector<uint8_t> bits;
+  int rc = 0; std::string err;
+};
+
 // DirectCoded symbols (decode/entropy/symbol_coding.rs:125-210 + RansSymbolDecoder::new rans.rs:139-200): method, bit_length,
-// frequency table with zero-run tokens, leb128 length, stream
-int decode_symbols(Reader& r, uint64_t n, std::vector<uint32_t>& out) {
+// frequency table with zero-run tokens, leb128 length, stream — located, not decoded (the attribute's host thread does that)
+int locate_symbols(Reader& r, AttPlan& pl) {
   if (r.r8() != 1) return host_fail(DMI_ERR_ENTROPY, "symbols are not direct coded");
   const uint8_t bl = r.r8();
   if (bl < 1 || bl > 18) return host_fail(DMI_ERR_ENTROPY, "bad symbol bit length");
   static const uint8_t prec_of[19] = {0, 12, 12, 12, 12, 12, 12, 12, 12, 13, 15, 16, 18, 19, 20, 20, 20, 20, 20};
-  const uint32_t P = prec_of[bl];
+  pl.P = prec_of[bl];
   const uint64_t num_symbols = r.leb();
   if (!r.ok || num_symbols > ((uint64_t)1 << 21)) return host_fail(DMI_ERR_ENTROPY, "bad frequency table size");
-  std::vector<uint32_t> freq((size_t)num_symbols, 0);
+  pl.freq.assign((size_t)num_symbols, 0);
   for (uint64_t i = 0; i < num_symbols; ++i) {
     const uint8_t b = r.r8();
     const uint32_t token = b & 3u;
@@ -93,13 +109,12 @@ int decode_symbols(Reader& r, uint64_t n, std::vector<uint32_t>& out) {
     } else {
       uint32_t count = b >> 2;
       for (uint32_t j = 0; j < token; ++j) count |= (uint32_t)r.r8() << (8 * (j + 1) - 2);
-      freq[(size_t)i] = count;
+      pl.freq[(size_t)i] = count;
     }
   }
   const uint64_t nbytes = r.leb();
   if (!r.ok || nbytes > r.n - r.at) return host_fail(DMI_ERR_ENTROPY, "symbol stream past the section");   // (no addition: nbytes is attacker-controlled)
-  out.resize((size_t)n);
-  if (!host_rans_decode(r.p + r.at, (size_t)nbytes, freq.data(), (uint32_t)num_symbols, P, n, out.data())) return host_fail(DMI_ERR_ENTROPY, "truncated or inconsistent rANS stream");
+  pl.rans = r.p + r.at; pl.rans_bytes = (size_t)nbytes;
   r.at += (size_t)nbytes;
   return DMI_OK;
 }
@@ -128,6 +143,12 @@ using namespace dmi;
 
 extern "C" {
 
+int dmi_last_decode_timings(dmi_decode_timings* t) {
+  if (!t) return host_fail(DMI_ERR_INVALID_ARGUMENT, "null argument");
+  *t = g_last_decode;
+  return DMI_OK;
+}
+
 void dmi_decoded_free(dmi_decoded* d) {
   if (!d) return;
   delete static_cast<Owner*>(d->owner);
@@ -137,6 +158,8 @@ void dmi_decoded_free(dmi_decoded* d) {
 int dmi_decode_attributes(const uint8_t* section, size_t len, const dmi_corner_table* tables, uint32_t n_tables, const uint32_t* seeds, uint32_t n_seeds,
                           uint32_t num_points, const dmi_config* cfg_in, dmi_decoded* out) {
   if (!section || !tables || !out || n_tables == 0) return host_fail(DMI_ERR_INVALID_ARGUMENT, "null argument");
+  const auto t_call0 = std::chrono::steady_clock::now();
+  { const float c = g_last_decode.connectivity_ms, tb = g_last_decode.tables_ms; g_last_decode = dmi_decode_timings{}; if (g_inside_decode_mesh) { g_last_decode.connectivity_ms = c; g_last_decode.tables_ms = tb; } }
   dmi_config cfg{};
   if (cfg_in) cfg = *cfg_in;
   int ndev = 0;
@@ -187,61 +210,118 @@ int dmi_decode_attributes(const uint8_t* section, size_t len, const dmi_corner_t
   int pos_att = -1;
   DevBuf d_pos, d_c2v_pos;
 
+  // ---- 1. parse: every length in the section is explicit, so the blocks of all attributes are located without decoding anything ----
+  std::vector<AttPlan> plans(n_atts);
   for (uint32_t i = 0; i < n_atts; ++i) {
     dmi_decoded_attribute& a = owner->atts[i];
-    const dmi_corner_table& t = tables[i];
+    AttPlan& pl = plans[i];
     a.scheme = r.r8(); a.transform = r.r8();                                       // attribute_encoder.rs:159-160
     if (r.r8() != 1) return host_fail(DMI_ERR_ENTROPY, "rans_encoding flag not set");
-    std::vector<uint32_t> seq_own;
-    const uint32_t* seq = t.sequence;
-    uint32_t n = t.sequence_len;
-    if (!seq) {
-      if (!t.left_most_corner) return host_fail(DMI_ERR_INVALID_ARGUMENT, "left_most_corner needed to compute the sequence");
-      if (n_seeds && !seeds) return host_fail(DMI_ERR_INVALID_ARGUMENT, "null seeds");
-      for (uint32_t k = 0; k < n_seeds; ++k) if (seeds[k] >= C) return host_fail(DMI_ERR_INVALID_ARGUMENT, "seed corner out of range");
-      for (uint32_t v = 0; v < t.num_vertices; ++v) if (t.left_most_corner[v] >= C) return host_fail(DMI_ERR_INVALID_ARGUMENT, "left_most_corner entry out of range");
-      TableRef tr{F, t.num_vertices, t.corner_to_vertex, t.opposite, t.left_most_corner};
-      attribute_sequence(tr, seeds, n_seeds, seq_own);
-      seq = seq_own.data(); n = (uint32_t)seq_own.size();
-    }
-    for (uint32_t k = 0; k < n; ++k) if (seq[k] >= C) return host_fail(DMI_ERR_INVALID_ARGUMENT, "sequence entry out of range");
-    const int N = port[i] == 3 ? 2 : a.num_components;
-    std::vector<uint32_t> sym;
-    if ((rc = decode_symbols(r, (uint64_t)n * N, sym))) return rc;
-    int32_t t_min = 0, t_max = 0;
+    pl.N = port[i] == 3 ? 2 : a.num_components;
+    if ((rc = locate_symbols(r, pl))) return rc;
     bool meta_ok = true;
     auto read_transform_info = [&] {
-      if (a.transform == 1) { t_min = (int32_t)r.r32(); t_max = (int32_t)r.r32(); }
+      if (a.transform == 1) { pl.t_min = (int32_t)r.r32(); pl.t_max = (int32_t)r.r32(); }
       else if (a.transform == 3) { if (r.r32() != 255 || r.r32() != 127) meta_ok = false; }
     };
-    std::vector<uint8_t> bits;
-    auto read_rabs = [&](uint64_t count) -> int {
-      const uint8_t zp = r.r8();
+    auto locate_rabs = [&]() -> int {
+      pl.zp = r.r8();
       const uint64_t nbytes = r.leb();
-      if (!r.ok || zp == 0 || nbytes > len - r.at) return host_fail(DMI_ERR_ENTROPY, "truncated rABS block");
-      bits.resize((size_t)count);
-      if (!host_rabs_decode(section + r.at, (size_t)nbytes, zp, count, bits.data())) return host_fail(DMI_ERR_ENTROPY, "truncated rABS stream");
+      if (!r.ok || pl.zp == 0 || nbytes > len - r.at) return host_fail(DMI_ERR_ENTROPY, "truncated rABS block");
+      pl.rabs = section + r.at; pl.rabs_bytes = (size_t)nbytes; pl.has_rabs = true;
       r.at += (size_t)nbytes;
-      std::reverse(bits.begin(), bits.end());   // the encoder pushed them first to last; an ANS decoder pops the last one first
       return DMI_OK;
     };
-    if (a.scheme == 6) { read_transform_info(); if ((rc = read_rabs(n))) return rc; }
-    else if (a.scheme == 5) {
-      const uint32_t count = r.r32();
-      if (count > n) return host_fail(DMI_ERR_ENTROPY, "more orientation bits than entries");
-      if ((rc = read_rabs(count))) return rc;
-      bool last = true;   // transitions → orientations (mesh_prediction_for_texture_coordinates.rs:241-256 inverted)
-      for (size_t k = count; k-- > 0;) { if (!bits[k]) last = !last; bits[k] = last ? 1 : 0; }
-      read_transform_info();
-    } else read_transform_info();
-    float q_min[4] = {0, 0, 0, 0}, q_range = 0;
-    int q_bits = 0;
-    if (port[i] == 2) { for (int k = 0; k < a.num_components; ++k) q_min[k] = r.rf32(); q_range = r.rf32(); q_bits = r.r8(); if (q_bits < 1 || q_bits > 31) meta_ok = false; }
+    if (a.scheme == 6) { read_transform_info(); if ((rc = locate_rabs())) return rc; }
+    else if (a.scheme == 5) { pl.rabs_count = r.r32(); if ((rc = locate_rabs())) return rc; read_transform_info(); }
+    else read_transform_info();
+    if (port[i] == 2) { for (int k = 0; k < a.num_components; ++k) pl.q_min[k] = r.rf32(); pl.q_range = r.rf32(); pl.q_bits = r.r8(); if (pl.q_bits < 1 || pl.q_bits > 31) meta_ok = false; }
     else if (port[i] == 3) { if (r.r8() != 8) meta_ok = false; }
     else if (port[i] != 1) return host_fail(DMI_ERR_UNSUPPORTED_DATA_TYPE, "unknown portabilization");
     if (!r.ok || !meta_ok) return host_fail(DMI_ERR_ENTROPY, "truncated or unexpected attribute metadata");
-    a.bits = (uint8_t)(port[i] == 3 ? 8 : q_bits);
+    a.bits = (uint8_t)(port[i] == 3 ? 8 : pl.q_bits);
+  }
+  if (r.at != len) return host_fail(DMI_ERR_ENTROPY, std::to_string(len - r.at) + " bytes left after the last attribute");
+
+  // ---- 2. host threads: one traversal per DISTINCT corner table (attributes without seams share the universal one), then one entropy
+  //         decoder per attribute (its rANS symbols + its rABS bits), all attributes at once ----
+  const auto t_seq0 = std::chrono::steady_clock::now();
+  std::vector<int> seq_owner(n_atts, -1);   // the attribute whose plan holds this attribute's sequence
+  for (uint32_t i = 0; i < n_atts; ++i) {
+    const dmi_corner_table& t = tables[i];
+    if (t.sequence) { plans[i].seq = t.sequence; plans[i].n = t.sequence_len; seq_owner[i] = (int)i; continue; }
+    if (!t.left_most_corner) return host_fail(DMI_ERR_INVALID_ARGUMENT, "left_most_corner needed to compute the sequence");
+    for (uint32_t j = 0; j < i && seq_owner[i] < 0; ++j)
+      if (!tables[j].sequence && tables[j].corner_to_vertex == t.corner_to_vertex && tables[j].opposite == t.opposite && tables[j].left_most_corner == t.left_most_corner && tables[j].num_vertices == t.num_vertices) seq_owner[i] = seq_owner[j];
+    if (seq_owner[i] < 0) seq_owner[i] = (int)i;
+  }
+  if (n_seeds && !seeds) return host_fail(DMI_ERR_INVALID_ARGUMENT, "null seeds");
+  for (uint32_t k = 0; k < n_seeds; ++k) if (seeds[k] >= C) return host_fail(DMI_ERR_INVALID_ARGUMENT, "seed corner out of range");
+  {
+    std::vector<std::thread> walkers;
+    for (uint32_t i = 0; i < n_atts; ++i) {
+      if (seq_owner[i] != (int)i || tables[i].sequence) continue;
+      const dmi_corner_table& t = tables[i];
+      for (uint32_t v = 0; v < t.num_vertices; ++v) if (t.left_most_corner[v] >= C) { for (auto& w : walkers) w.join(); return host_fail(DMI_ERR_INVALID_ARGUMENT, "left_most_corner entry out of range"); }
+      AttPlan* pl = &plans[i];
+      walkers.emplace_back([pl, &t, F, seeds, n_seeds] {
+        TableRef tr{F, t.num_vertices, t.corner_to_vertex, t.opposite, t.left_most_corner};
+        attribute_sequence(tr, seeds, n_seeds, pl->seq_own);
+        pl->seq = pl->seq_own.data(); pl->n = (uint32_t)pl->seq_own.size();
+      });
+    }
+    for (auto& w : walkers) w.join();
+  }
+  for (uint32_t i = 0; i < n_atts; ++i) {
+    if (seq_owner[i] != (int)i) { plans[i].seq = plans[seq_owner[i]].seq; plans[i].n = plans[seq_owner[i]].n; }
+    for (uint32_t k = 0; k < plans[i].n && seq_owner[i] == (int)i; ++k) if (plans[i].seq[k] >= C) return host_fail(DMI_ERR_INVALID_ARGUMENT, "sequence entry out of range");
+  }
+  const auto t_ent0 = std::chrono::steady_clock::now();
+  g_last_decode.sequence_ms = std::chrono::duration<float, std::milli>(t_ent0 - t_seq0).count();
+  {
+    std::vector<std::thread> coders;
+    for (uint32_t i = 0; i < n_atts; ++i) {
+      AttPlan* pl = &plans[i];
+      const uint8_t scheme = owner->atts[i].scheme;
+      auto body = [pl, scheme] {
+        pl->sym.resize((size_t)pl->n * pl->N);
+        if (!host_rans_decode(pl->rans, pl->rans_bytes, pl->freq.data(), (uint32_t)pl->freq.size(), pl->P, (uint64_t)pl->n * pl->N, pl->sym.data())) { pl->rc = DMI_ERR_ENTROPY; pl->err = "truncated or inconsistent rANS stream"; return; }
+        if (!pl->has_rabs) return;
+        const uint64_t count = scheme == 6 ? pl->n : pl->rabs_count;
+        if (count > pl->n) { pl->rc = DMI_ERR_ENTROPY; pl->err = "more orientation bits than entries"; return; }
+        pl->bits.resize((size_t)count);
+        if (!host_rabs_decode(pl->rabs, pl->rabs_bytes, pl->zp, count, pl->bits.data())) { pl->rc = DMI_ERR_ENTROPY; pl->err = "truncated rABS stream"; return; }
+        std::reverse(pl->bits.begin(), pl->bits.end());   // the encoder pushed them first to last; an ANS decoder pops the last one first
+        if (scheme == 5) {   // transitions → orientations (mesh_prediction_for_texture_coordinates.rs:241-256 inverted)
+          bool last = true;
+          for (size_t k = (size_t)count; k-- > 0;) { if (!pl->bits[k]) last = !last; pl->bits[k] = last ? 1 : 0; }
+        }
+      };
+      if (i + 1 < n_atts) coders.emplace_back(body); else body();   // (the calling thread takes the last one)
+    }
+    for (auto& w : coders) w.join();
+  }
+  for (uint32_t i = 0; i < n_atts; ++i) if (plans[i].rc) return host_fail(plans[i].rc, "attribute " + std::to_string(i) + ": " + plans[i].err);
+  const auto t_inv0 = std::chrono::steady_clock::now();
+  g_last_decode.entropy_ms = std::chrono::duration<float, std::milli>(t_inv0 - t_ent0).count();
+  double inverse_ms = 0;
+
+  // ---- 3. predictions inverted in attribute order (a normal / texture coordinate needs the decoded positions) ----
+  for (uint32_t i = 0; i < n_atts; ++i) {
+    dmi_decoded_attribute& a = owner->atts[i];
+    const dmi_corner_table& t = tables[i];
+    AttPlan& pl = plans[i];
+    const uint32_t* seq = pl.seq;
+    const uint32_t n = pl.n;
+    const int N = pl.N;
+    const std::vector<uint32_t>& sym = pl.sym;
+    const std::vector<uint8_t>& bits = pl.bits;
+    const int32_t t_min = pl.t_min, t_max = pl.t_max;
+    const float* q_min = pl.q_min;
+    const float q_range = pl.q_range;
+    const int q_bits = pl.q_bits;
     if ((a.scheme == 5 || a.scheme == 6) && pos_att < 0) return host_fail(DMI_ERR_BAD_PARENT, "attribute " + std::to_string(i) + " needs a decoded Position attribute");
+    const auto t_att0 = std::chrono::steady_clock::now();
 
     std::vector<int32_t> val((size_t)t.num_vertices * N, 0);   // quantized values by this table's vertex
     DevBuf d_val, d_c2v, d_opp, d_seq, d_sym, d_flips;
@@ -337,6 +417,7 @@ int dmi_decode_attributes(const uint8_t* section, size_t len, const dmi_corner_t
         when[v] = (uint32_t)k + 1;
       }
       if (a.scheme == 5 && next_bit != bits.size()) return host_fail(DMI_ERR_ENTROPY, "orientation bits left over");
+      inverse_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_att0).count();
       if ((rc = d_val.upload(val.data(), val.size() * 4, s))) return rc;
       if (a.att_type == DMI_ATT_POSITION && N == 3 && pos_att < 0) {   // the parent of the normals / texture coordinates that follow
         pos_att = (int)i;
@@ -359,7 +440,12 @@ int dmi_decode_attributes(const uint8_t* section, size_t len, const dmi_corner_t
     HIP_TRY_D(hipStreamSynchronize(s));   // (the attribute's device arrays go out of scope)
     a.values = owner->values[i].data();
   }
-  if (r.at != len) return host_fail(DMI_ERR_ENTROPY, std::to_string(len - r.at) + " bytes left after the last attribute");
+  {
+    const auto t_end = std::chrono::steady_clock::now();
+    g_last_decode.inverse_ms = (float)inverse_ms;
+    g_last_decode.device_ms = std::chrono::duration<float, std::milli>(t_end - t_inv0).count() - (float)inverse_ms;
+    g_last_decode.attributes_ms = std::chrono::duration<float, std::milli>(t_end - t_call0).count();
+  }
   out->num_attributes = n_atts;
   out->attributes = owner->atts.data();
   out->owner = owner.release();

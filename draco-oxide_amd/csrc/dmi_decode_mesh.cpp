@@ -10,6 +10,7 @@
 // Host code except for that call.  What it proves in tests: a `.drc` the library wrote means, by itself, the mesh that went in
 // (tests/test_gpu_decode_mesh.py) — same-author evidence, not a reference pin.
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <memory>
 #include <unordered_map>
@@ -18,6 +19,8 @@
 #include "host_chains.hpp"
 
 namespace dmi {
+extern thread_local dmi_decode_timings g_last_decode;   // dmi_decode.cpp
+extern thread_local bool g_inside_decode_mesh;
 namespace {
 
 struct Bytes {
@@ -269,9 +272,11 @@ int decode_tables(const uint8_t* drc, size_t len, DecodedTables& d) {
   if (len < sizeof kHeader || std::memcmp(drc, kHeader, sizeof kHeader) != 0) return host_fail(DMI_ERR_INVALID_ARGUMENT, "not a DRACO 2.2 Edgebreaker mesh without metadata");
   Bytes b{drc, len, sizeof kHeader};
   DecodedConnectivity& dc = d.dc;
+  const auto t0 = std::chrono::steady_clock::now();
   const int rc = decode_connectivity(b, dc);
   if (rc) return rc;
   d.consumed = b.at;
+  const auto t1 = std::chrono::steady_clock::now();
   // per-attribute corner tables from the seam flags: attribute i > 0 takes table i - 1 when it has interior seams, else the universal one
   CornerTables& ct = d.ct;
   ct.F = dc.F; ct.V = dc.V;
@@ -282,14 +287,21 @@ int decode_tables(const uint8_t* drc, size_t len, DecodedTables& d) {
   const size_t C = (size_t)dc.F * 3;
   d.faces.resize(C);
   {
-    std::map<std::vector<uint32_t>, uint32_t> ids;
-    std::vector<uint32_t> key;
+    // per universal vertex a short chain of the points issued so far, each with a representative corner; ids in corner order
+    std::vector<const uint32_t*> keys;
+    for (auto& a : ct.att) if (a.interior_seams) keys.push_back(a.c2v.data());
+    std::vector<uint32_t> head(dc.V, kNone), next_of, rep;
+    next_of.reserve(dc.V); rep.reserve(dc.V);
     for (size_t c = 0; c < C; ++c) {
-      key.assign(1, dc.c2v[c]);
-      for (auto& a : ct.att) if (a.interior_seams) key.push_back(a.c2v[c]);
-      auto it = ids.find(key);
-      if (it == ids.end()) it = ids.emplace(key, d.num_points++).first;
-      d.faces[c] = it->second;
+      const uint32_t v = dc.c2v[c];
+      uint32_t pid = head[v];
+      for (; pid != kNone; pid = next_of[pid]) {
+        bool same = true;
+        for (const uint32_t* k : keys) same = same && k[c] == k[rep[pid]];
+        if (same) break;
+      }
+      if (pid == kNone) { pid = d.num_points++; next_of.push_back(head[v]); rep.push_back((uint32_t)c); head[v] = pid; }
+      d.faces[c] = pid;
     }
   }
   d.views.resize(1 + ct.att.size());
@@ -304,6 +316,9 @@ int decode_tables(const uint8_t* drc, size_t len, DecodedTables& d) {
     t.opposite = a ? a->opp.data() : dc.opp.data();
     t.left_most_corner = a ? a->lmc.data() : dc.lmc.data();
   }
+  g_last_decode = dmi_decode_timings{};
+  g_last_decode.connectivity_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
+  g_last_decode.tables_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t1).count();
   return DMI_OK;
 }
 
@@ -349,11 +364,14 @@ void dmi_decoded_mesh_free(dmi_decoded_mesh* m) {
 int dmi_decode_mesh(const uint8_t* drc, size_t len, const dmi_config* cfg, dmi_decoded_mesh* out) {
   if (!drc || !out) return host_fail(DMI_ERR_INVALID_ARGUMENT, "null argument");
   *out = dmi_decoded_mesh{};
+  const auto t0 = std::chrono::steady_clock::now();
   std::unique_ptr<MeshOwner> owner(new MeshOwner());
   DecodedTables& d = owner->d;
   int rc = decode_tables(drc, len, d);
   if (rc) return rc;
+  g_inside_decode_mesh = true;
   rc = dmi_decode_attributes(drc + d.consumed, len - d.consumed, d.views.data(), (uint32_t)d.views.size(), d.dc.seeds.data(), (uint32_t)d.dc.seeds.size(), d.num_points, cfg, &owner->atts);
+  g_inside_decode_mesh = false;
   if (rc) return rc;
   out->num_faces = d.dc.F;
   out->num_points = d.num_points;
@@ -361,6 +379,7 @@ int dmi_decode_mesh(const uint8_t* drc, size_t len, const dmi_config* cfg, dmi_d
   out->num_attributes = owner->atts.num_attributes;
   out->attributes = owner->atts.attributes;
   out->owner = owner.release();
+  g_last_decode.call_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return DMI_OK;
 }
 

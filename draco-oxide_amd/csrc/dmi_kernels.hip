@@ -85,9 +85,15 @@ __device__ __forceinline__ void load_pos_fmt(const void* __restrict__ q, int fmt
   else if (fmt == QF_P64) unpack_p64(static_cast<const uint64_t*>(q)[r], out);
   else { const int32_t* p = static_cast<const int32_t*>(q) + (size_t)r * 3; out[0] = p[0]; out[1] = p[1]; out[2] = p[2]; }
 }
+// symbol stores of the predictors: nontemporal by default (A/B: -DDMI_SYM_TEMPORAL keeps them in L2 / MALL for the histogram that follows)
+#ifdef DMI_SYM_TEMPORAL
+#define DMI_SYM_STORE(v, p) (*(p) = (v))
+#else
+#define DMI_SYM_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#endif
 __device__ __forceinline__ void store_sym(void* __restrict__ sym, bool s16, size_t idx, uint32_t v) {
-  if (s16) __builtin_nontemporal_store((uint16_t)v, static_cast<uint16_t*>(sym) + idx);
-  else __builtin_nontemporal_store(v, static_cast<uint32_t*>(sym) + idx);
+  if (s16) DMI_SYM_STORE((uint16_t)v, static_cast<uint16_t*>(sym) + idx);
+  else DMI_SYM_STORE(v, static_cast<uint32_t*>(sym) + idx);
 }
 __device__ __forceinline__ uint32_t load_sym(const void* __restrict__ sym, bool s16, uint64_t idx) {
   return s16 ? (uint32_t)static_cast<const uint16_t*>(sym)[idx] : static_cast<const uint32_t*>(sym)[idx];
@@ -980,7 +986,7 @@ __global__ __launch_bounds__(kBlock) void k_build_fans_batch(const FanItem* __re
 __device__ __forceinline__ void uv_emit(const FusedArgs& a, uint32_t i, const int32_t (&cu)[2], int32_t pred0, int32_t pred1, uint8_t oflag, const WrapParams& wu, bool s16_uv) {
   __builtin_nontemporal_store(oflag, &a.orient[i]);
   const uint32_t s0 = wrap_symbol(cu[0], pred0, wu), s1 = wrap_symbol(cu[1], pred1, wu);
-  if (s16_uv) __builtin_nontemporal_store(s0 | (s1 << 16), static_cast<uint32_t*>(a.sym_uv) + i);   // (symbols < 2^16: one 4-byte store)
+  if (s16_uv) DMI_SYM_STORE(s0 | (s1 << 16), static_cast<uint32_t*>(a.sym_uv) + i);   // (symbols < 2^16: one 4-byte store)
   else { store_sym(a.sym_uv, false, (size_t)i * 2, s0); store_sym(a.sym_uv, false, (size_t)i * 2 + 1, s1); }
 }
 // The texture-coordinate entries a fused sweep deferred (operands outside its f64 tier): the general i64 form, entry by entry.  Every
@@ -1014,7 +1020,7 @@ __device__ __forceinline__ void k_texcoord_fixup_body(const FusedArgs& a, const 
 // rank array (fan rows hold position ranks), `opp` the normal table's, and apex[i] is the rank of the fan's centre.
 // PACKED: the positions are QF_P64 (and, with HAS_POS, the normals QF_B16 and the texture coordinates QF_H32 — the three
 // attributes of a fused sweep are packed together or not at all); a lone normal attribute's own values stay QF_I32.
-template <bool HAS_POS, bool HAS_NRM, bool HAS_UV, bool PACKED>
+template <bool HAS_POS, bool HAS_NRM, bool HAS_UV, bool PACKED, bool STAGED = false>
 __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const uint32_t blk_, const uint32_t nblk_) {
   const uint32_t* __restrict__ seq = a.seq;
   const uint32_t* __restrict__ c2r = a.c2r;
@@ -1040,7 +1046,46 @@ __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const u
 #else
   constexpr bool kPrefetch = false;
 #endif
+  // STAGED (round 3, the single-mesh launches): the same prefetch without registers — the next chunk's level-1 data (fan row, header, apex
+  // rank, own packed position: 48 B per entry) goes global → LDS by `global_load_lds` (no VGPR destination) while the current chunk computes;
+  // every lane stages and later reads its OWN entry, so the only ordering needed is the issuing wave's vmcnt (no barrier).  3 KB per
+  // wavefront.  With the kernel held at 8 waves per SIMD (amdgpu_waves_per_eu: 64 VGPRs, 28 SGPRs parked in VGPR lanes) the 10M-triangle
+  // sweep takes 119.3 µs instead of 130.2 (pn 85.1 → 80.1, pu 85.7 → 81.9); at the 7 waves the compiler picks by itself only −3 %.  The
+  // batch launches (`_multi`: one or two chunks per block, nothing to run ahead of) lose 23 % with it and keep the direct loads.
+  constexpr bool kGlds = STAGED && PACKED && HAS_POS;
+  constexpr bool kStaged = kPrefetch || kGlds;
+  constexpr uint32_t kImg = 3072;
+  __shared__ __attribute__((aligned(16))) uint8_t glds_img[kGlds ? (kBlock / 64) * kImg : 16];
+  uint8_t* const wimg = glds_img + (kGlds ? (threadIdx.x >> 6) * kImg : 0u);
+  const uint32_t lane_ = threadIdx.x & 63u;
   struct Level1 { uint32_t h, ro; u32x4 r0, r1; uint64_t pc; };
+  auto stage_level1 = [&](uint32_t i) {
+    using G = const __attribute__((address_space(1))) void*;
+    using S = __attribute__((address_space(3))) void*;
+    const uint32_t ii = i < n ? i : n - 1u;
+    const uint8_t* row = reinterpret_cast<const uint8_t*>(a.fan + (size_t)ii * kFanSlots);
+    const uint32_t* pc32 = reinterpret_cast<const uint32_t*>(static_cast<const uint64_t*>(qs_pos) + ii);
+    // (aux 2 = nt, as the direct form's nontemporal loads: the once-read rows must not push the raw values of the next step out of the MALL —
+    //  with the default policy the NEXT launch of k_value_ranges took 32.1 µs instead of 29.3)
+    __builtin_amdgcn_global_load_lds((G)row, (S)wimg, 16, 0, 2);
+    __builtin_amdgcn_global_load_lds((G)(row + 16), (S)(wimg + 1024), 16, 0, 2);
+    __builtin_amdgcn_global_load_lds((G)&a.fan_hdr[ii], (S)(wimg + 2048), 4, 0, 2);
+    __builtin_amdgcn_global_load_lds((G)&a.fan_apex[ii], (S)(wimg + 2304), 4, 0, 2);
+    __builtin_amdgcn_global_load_lds((G)pc32, (S)(wimg + 2560), 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((G)(pc32 + 1), (S)(wimg + 2816), 4, 0, 0);
+  };
+  auto take_level1 = [&](Level1& o) {
+    // the wave's own DMAs have landed (nothing else orders a ds_read behind them; a counted vmcnt(5) that leaves the previous chunk's
+    // stores in flight measured the same)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    o.r0 = *reinterpret_cast<const u32x4*>(wimg + lane_ * 16u);
+    o.r1 = *reinterpret_cast<const u32x4*>(wimg + 1024u + lane_ * 16u);
+    o.h = *reinterpret_cast<const uint32_t*>(wimg + 2048u + lane_ * 4u);
+    o.ro = *reinterpret_cast<const uint32_t*>(wimg + 2304u + lane_ * 4u);
+    const uint32_t lo = *reinterpret_cast<const uint32_t*>(wimg + 2560u + lane_ * 4u), hi = *reinterpret_cast<const uint32_t*>(wimg + 2816u + lane_ * 4u);
+    o.pc = (uint64_t)lo | ((uint64_t)hi << 32);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // … and have been read before the next DMA overwrites the image
+  };
   auto fetch_level1 = [&](uint32_t i, Level1& o) {
     o.h = __builtin_nontemporal_load(&a.fan_hdr[i]);
     o.ro = __builtin_nontemporal_load(&a.fan_apex[i]);
@@ -1052,8 +1097,10 @@ __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const u
   uint32_t ch_ = xcd_ * per_ + (blk_ >> 3);   // (DMI_FOR_SEQUENCE's chunk walk, spelled out)
   Level1 cur{}, nxt{};
   if (kPrefetch && ch_ < end_ && ch_ * kBlock + threadIdx.x < n) fetch_level1(ch_ * kBlock + threadIdx.x, cur);
+  if (kGlds && ch_ < end_) stage_level1(ch_ * kBlock + threadIdx.x);
   for (; ch_ < end_; ch_ += stride_) {
     const uint32_t i = ch_ * kBlock + threadIdx.x;
+    if (kGlds) { take_level1(cur); if (ch_ + stride_ < end_) stage_level1((ch_ + stride_) * kBlock + threadIdx.x); }
     if (kPrefetch) { const uint32_t i2 = (ch_ + stride_) * kBlock + threadIdx.x; if (ch_ + stride_ < end_ && i2 < n) fetch_level1(i2, nxt); }
     [[maybe_unused]] bool deferred = false;
     if (i < n) {
@@ -1061,7 +1108,7 @@ __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const u
     int32_t Pc[3], Pn[3] = {0, 0, 0}, Pp[3] = {0, 0, 0}, Po[3] = {0, 0, 0}, Plast[3] = {0, 0, 0};
     int64_t sum[3] = {0, 0, 0};
     uint32_t h;
-    if (kPrefetch) { h = cur.h; ro = cur.ro; unpack_p64(cur.pc, Pc); }
+    if (kStaged) { h = cur.h; ro = cur.ro; unpack_p64(cur.pc, Pc); }
     else {
       h = __builtin_nontemporal_load(&a.fan_hdr[i]);
       ro = __builtin_nontemporal_load(&a.fan_apex[i]);   // HAS_POS: rank across the edge opposite c; else: rank of the centre
@@ -1070,7 +1117,7 @@ __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const u
     if (!(h & (1u << 17))) {
       // ---- fan row: every rank of the 1-ring in one 32-byte read, every position gather independent ----
       u32x4 r0, r1;
-      if (kPrefetch) { r0 = cur.r0; r1 = cur.r1; }
+      if (kStaged) { r0 = cur.r0; r1 = cur.r1; }
       else { const u32x4* row4 = reinterpret_cast<const u32x4*>(a.fan + (size_t)i * kFanSlots); r0 = __builtin_nontemporal_load(&row4[0]); r1 = __builtin_nontemporal_load(&row4[1]); }
       const uint32_t row[kFanSlots] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
       rn = row[0]; rp = row[1];
@@ -1181,7 +1228,7 @@ __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const u
 #else
       oct_orthogonal(a0, a1, p0, p1, s0, s1);
 #endif
-      if (s16_nrm) __builtin_nontemporal_store(s0 | (s1 << 16), static_cast<uint32_t*>(a.sym_nrm) + i);
+      if (s16_nrm) DMI_SYM_STORE(s0 | (s1 << 16), static_cast<uint32_t*>(a.sym_nrm) + i);
       else { store_sym(a.sym_nrm, false, (size_t)i * 2, s0); store_sym(a.sym_nrm, false, (size_t)i * 2 + 1, s1); }
     }
     // ---- texture coordinates: mesh_prediction_for_texture_coordinates.rs:51-81,107-219 ----
@@ -1673,6 +1720,26 @@ inline uint32_t grid_for(uint64_t work, uint32_t cap = 256 * 8) {
 }
 
 // ---- kernel wrappers: one work item per launch, or many (the same phase of a whole batch of jobs) ----
+// DMI_KERNEL2: the single-item launch and the batch launch run different instantiations; OCC: an occupancy attribute for the single one
+#define DMI_KERNEL2(NAME, BODY, BODY_MULTI, ARGS, THREADS, OCC)                                                                       \
+  __global__ __launch_bounds__(THREADS) OCC void NAME(ARGS a) { BODY(a, blockIdx.x, gridDim.x); }                                     \
+  __global__ __launch_bounds__(THREADS) DMI_MULTI_OCC void NAME##_multi(const ARGS* __restrict__ items, const uint2* __restrict__ block_info,       \
+                                                          const uint32_t* __restrict__ item_blocks) {                                 \
+    const uint2 bi = block_info[blockIdx.x];                                                                                          \
+    BODY_MULTI(items[bi.x], bi.y, item_blocks[bi.x]);                                                                                  \
+  }
+#ifndef DMI_MULTI_OCC
+#define DMI_MULTI_OCC
+#endif
+#ifdef DMI_SWEEP_NO_GLDS   // (A/B builds: scripts/glds_probe.sh)
+#define DMI_SWEEP_STAGED false
+#ifndef DMI_SWEEP_OCC
+#define DMI_SWEEP_OCC
+#endif
+#else
+#define DMI_SWEEP_STAGED true
+#define DMI_SWEEP_OCC __attribute__((amdgpu_waves_per_eu(8, 8)))
+#endif
 #define DMI_KERNEL(NAME, BODY, ARGS, THREADS)                                                                                         \
   __global__ __launch_bounds__(THREADS) void NAME(ARGS a) { BODY(a, blockIdx.x, gridDim.x); }                                         \
   __global__ __launch_bounds__(THREADS) void NAME##_multi(const ARGS* __restrict__ items, const uint2* __restrict__ block_info,       \
@@ -1682,15 +1749,20 @@ inline uint32_t grid_for(uint64_t work, uint32_t cap = 256 * 8) {
   }
 DMI_KERNEL(k_value_ranges, k_value_ranges_body, RangeArgs, kBlock)
 DMI_KERNEL(k_value_ranges_final, k_value_ranges_final_body, RangeArgs, kBlock)
-DMI_KERNEL(k_seq_quantize, k_seq_quantize_body, SeqQuantArgs, kBlock)
+// k_seq_quantize at the compiler's own choice: 104 SGPRs = 7 waves per SIMD (gfx9 SGPR file: 800 per SIMD); capped to 8 waves' worth (73 SGPRs
+// parked in VGPR lanes, still 55 VGPRs) the 10M-triangle gather takes 91.5 µs instead of 97.3
+#ifndef DMI_SEQ_OCC
+#define DMI_SEQ_OCC __attribute__((amdgpu_waves_per_eu(8, 8)))
+#endif
+DMI_KERNEL2(k_seq_quantize, k_seq_quantize_body, k_seq_quantize_body, SeqQuantArgs, kBlock, DMI_SEQ_OCC)
 DMI_KERNEL(k_i32_minmax_final, k_i32_minmax_final_body, MinMaxArgs, kBlock)
 DMI_KERNEL(k_predict_fused_pnu, (k_predict_fused_body<true, true, true, false>), FusedArgs, kBlock)
 DMI_KERNEL(k_predict_fused_pn, (k_predict_fused_body<true, true, false, false>), FusedArgs, kBlock)
 DMI_KERNEL(k_predict_fused_pu, (k_predict_fused_body<true, false, true, false>), FusedArgs, kBlock)
 DMI_KERNEL(k_predict_fused_n, (k_predict_fused_body<false, true, false, false>), FusedArgs, kBlock)
-DMI_KERNEL(k_predict_packed_pnu, (k_predict_fused_body<true, true, true, true>), FusedArgs, kBlock)
-DMI_KERNEL(k_predict_packed_pn, (k_predict_fused_body<true, true, false, true>), FusedArgs, kBlock)
-DMI_KERNEL(k_predict_packed_pu, (k_predict_fused_body<true, false, true, true>), FusedArgs, kBlock)
+DMI_KERNEL2(k_predict_packed_pnu, (k_predict_fused_body<true, true, true, true, DMI_SWEEP_STAGED>), (k_predict_fused_body<true, true, true, true>), FusedArgs, kBlock, DMI_SWEEP_OCC)
+DMI_KERNEL2(k_predict_packed_pn, (k_predict_fused_body<true, true, false, true, DMI_SWEEP_STAGED>), (k_predict_fused_body<true, true, false, true>), FusedArgs, kBlock, DMI_SWEEP_OCC)
+DMI_KERNEL2(k_predict_packed_pu, (k_predict_fused_body<true, false, true, true, DMI_SWEEP_STAGED>), (k_predict_fused_body<true, false, true, true>), FusedArgs, kBlock, DMI_SWEEP_OCC)
 DMI_KERNEL(k_predict_packed_n, (k_predict_fused_body<false, true, false, true>), FusedArgs, kBlock)
 DMI_KERNEL(k_predict_window_pnu, (k_predict_window_body<true, true>), FusedArgs, kBlock)
 DMI_KERNEL(k_predict_window_pn, (k_predict_window_body<true, false>), FusedArgs, kBlock)

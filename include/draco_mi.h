@@ -251,6 +251,19 @@ void dmi_decoded_free(dmi_decoded* d);
  * connectivity decoder is unimplemented (decode/connectivity/spirale_reversi.rs:1088); this is the inverse of the ENCODER's format.
  * faces: 3·num_faces point indices in decode order (the reverse of the coding order); points: corners that agree in the universal vertex
  * and in every attribute's vertex; attributes[i].values: num_points rows.  Everything is library-owned until dmi_decoded_mesh_free. */
+/* Host wall clock of the calling thread's last dmi_decode_attributes / dmi_decode_mesh, by stage. */
+typedef struct dmi_decode_timings {
+  float connectivity_ms;   /* dmi_decode_mesh only: symbols → universal corner table + seam flags */
+  float tables_ms;         /* dmi_decode_mesh only: per-attribute corner tables from the seams + point ids */
+  float sequence_ms;       /* attribute traversals (one host thread per distinct corner table) */
+  float entropy_ms;        /* rANS symbols + rABS bits, one host thread per attribute (decode/entropy/rans.rs:36-69) */
+  float inverse_ms;        /* sequential predictions inverted on a host core (positions, texture coordinates, generic) */
+  float device_ms;         /* uploads, k_decode_normals, k_dequantize, read-back */
+  float attributes_ms;     /* the whole dmi_decode_attributes */
+  float call_ms;           /* dmi_decode_mesh: the whole call */
+} dmi_decode_timings;
+int dmi_last_decode_timings(dmi_decode_timings* t);
+
 typedef struct dmi_decoded_mesh {
   uint32_t num_faces, num_points;
   const uint32_t* faces;
