@@ -289,17 +289,21 @@ __device__ __forceinline__ void oct_quantize(float x, float y, float z, int32_t&
 // Each thread owns kTile entries of a tile (entry t of the tile at base + t·kBlock + threadIdx.x) and issues all of
 // their gathers before touching any of them: the pass is latency-bound otherwise (one 12-byte gather in flight per
 // lane is ≈3 TB/s by Little's law at HBM latency).
-#ifndef DMI_KTILE
-#define DMI_KTILE 2
+// KT (entries per thread): 1 in the single-mesh launch, 2 in the batch launch — measured at 8 waves per SIMD: 10M-triangle mesh 85.0 µs at 1
+// against 89.9 at 2 (98.1 at 3: spills); 1024-mesh batch 457 µs at 2 against 494 at 1.
+#ifndef DMI_KTILE_SINGLE
+#define DMI_KTILE_SINGLE 1
 #endif
-constexpr int kTile = DMI_KTILE;
-template <int N> struct RawTile { float v[kTile][N]; };
-// issue: the kTile gathers of one attribute (value indices first when the attribute has its own point → value map)
-template <int N>
-__device__ __forceinline__ void gather_tile(const QuantAtt& a, const uint32_t (&p)[kTile], const uint32_t (&d)[kTile], uint32_t base, uint32_t n, RawTile<N>& r) {
-  uint32_t v[kTile];
+#ifndef DMI_KTILE_MULTI
+#define DMI_KTILE_MULTI 2
+#endif
+template <int N, int KT> struct RawTile { float v[KT][N]; };
+// issue: the KT gathers of one attribute (value indices first when the attribute has its own point → value map)
+template <int N, int KT>
+__device__ __forceinline__ void gather_tile(const QuantAtt& a, const uint32_t (&p)[KT], const uint32_t (&d)[KT], uint32_t base, uint32_t n, RawTile<N, KT>& r) {
+  uint32_t v[KT];
 #pragma unroll
-  for (int t = 0; t < kTile; ++t) {
+  for (int t = 0; t < KT; ++t) {
     const uint32_t i = base + t * kBlock + threadIdx.x;
     v[t] = (a.s2v && i < n) ? a.s2v[d[t]] : p[t];
 #if defined(DMI_ABLATE) && DMI_ABLATE == 6
@@ -307,16 +311,16 @@ __device__ __forceinline__ void gather_tile(const QuantAtt& a, const uint32_t (&
 #endif
   }
 #pragma unroll
-  for (int t = 0; t < kTile; ++t) {
+  for (int t = 0; t < KT; ++t) {
 #pragma unroll
     for (int k = 0; k < N; ++k) r.v[t][k] = a.raw[(size_t)v[t] * N + k];   // (entries past n read value 0: harmless)
   }
 }
 // retire: quantize and store the tile
-template <int N>
-__device__ __forceinline__ void finish_tile(const QuantAtt& a, const RawTile<N>& r, const uint32_t (&d)[kTile], uint32_t base, uint32_t n, int32_t& mn, int32_t& mx) {
+template <int N, int KT>
+__device__ __forceinline__ void finish_tile(const QuantAtt& a, const RawTile<N, KT>& r, const uint32_t (&d)[KT], uint32_t base, uint32_t n, int32_t& mn, int32_t& mx) {
 #pragma unroll
-  for (int t = 0; t < kTile; ++t) {
+  for (int t = 0; t < KT; ++t) {
     const uint32_t slot = base + t * kBlock + threadIdx.x;
     const uint32_t i = d[t];   // sequence index this slot is written to (= slot unless the pass runs tile-sorted)
     int32_t out[N];
@@ -345,39 +349,40 @@ __device__ __forceinline__ void finish_tile(const QuantAtt& a, const RawTile<N>&
     }
   }
 }
-template <int N>
-__device__ __forceinline__ void quantize_tile(const QuantAtt& a, const uint32_t (&p)[kTile], const uint32_t (&d)[kTile], uint32_t base, uint32_t n, int32_t& mn, int32_t& mx) {
-  RawTile<N> r;
-  gather_tile<N>(a, p, d, base, n, r);
-  finish_tile<N>(a, r, d, base, n, mn, mx);
+template <int N, int KT>
+__device__ __forceinline__ void quantize_tile(const QuantAtt& a, const uint32_t (&p)[KT], const uint32_t (&d)[KT], uint32_t base, uint32_t n, int32_t& mn, int32_t& mx) {
+  RawTile<N, KT> r;
+  gather_tile<N, KT>(a, p, d, base, n, r);
+  finish_tile<N, KT>(a, r, d, base, n, mn, mx);
 }
 // The common attribute sets of one table issue EVERY attribute's gathers before the first value is touched: a store between two
 // attributes' gathers orders them (the pointers may alias as far as the compiler knows), and the tile would pay one memory latency
 // per attribute instead of one.
-template <int N0, int N1>
-__device__ __forceinline__ void quantize_tiles2(const QuantArgs& q, const uint32_t (&p)[kTile], const uint32_t (&d)[kTile], uint32_t base, uint32_t n, int32_t (&mn)[kMaxGather], int32_t (&mx)[kMaxGather]) {
-  RawTile<N0> r0; RawTile<N1> r1;
-  gather_tile<N0>(q.a[0], p, d, base, n, r0); gather_tile<N1>(q.a[1], p, d, base, n, r1);
-  finish_tile<N0>(q.a[0], r0, d, base, n, mn[0], mx[0]); finish_tile<N1>(q.a[1], r1, d, base, n, mn[1], mx[1]);
+template <int N0, int N1, int KT>
+__device__ __forceinline__ void quantize_tiles2(const QuantArgs& q, const uint32_t (&p)[KT], const uint32_t (&d)[KT], uint32_t base, uint32_t n, int32_t (&mn)[kMaxGather], int32_t (&mx)[kMaxGather]) {
+  RawTile<N0, KT> r0; RawTile<N1, KT> r1;
+  gather_tile<N0, KT>(q.a[0], p, d, base, n, r0); gather_tile<N1, KT>(q.a[1], p, d, base, n, r1);
+  finish_tile<N0, KT>(q.a[0], r0, d, base, n, mn[0], mx[0]); finish_tile<N1, KT>(q.a[1], r1, d, base, n, mn[1], mx[1]);
 }
-template <int N0, int N1, int N2>
-__device__ __forceinline__ void quantize_tiles3(const QuantArgs& q, const uint32_t (&p)[kTile], const uint32_t (&d)[kTile], uint32_t base, uint32_t n, int32_t (&mn)[kMaxGather], int32_t (&mx)[kMaxGather]) {
-  RawTile<N0> r0; RawTile<N1> r1; RawTile<N2> r2;
+template <int N0, int N1, int N2, int KT>
+__device__ __forceinline__ void quantize_tiles3(const QuantArgs& q, const uint32_t (&p)[KT], const uint32_t (&d)[KT], uint32_t base, uint32_t n, int32_t (&mn)[kMaxGather], int32_t (&mx)[kMaxGather]) {
+  RawTile<N0, KT> r0; RawTile<N1, KT> r1; RawTile<N2, KT> r2;
 #if defined(DMI_ABLATE) && DMI_ABLATE == 9
   if constexpr (N0 == 3 && N1 == 3 && N2 == 2) {   // what ONE 32-byte gather per entry would cost: eight floats from one row of attribute 0's array (wrapped to stay inside it)
     const uint32_t rows = n * 3u / 8u;
 #pragma unroll
-    for (int t = 0; t < kTile; ++t) {
+    for (int t = 0; t < KT; ++t) {
       const float4* row = reinterpret_cast<const float4*>(q.a[0].raw) + (size_t)(p[t] % rows) * 2;
       const float4 lo = row[0], hi = row[1];
       r0.v[t][0] = lo.x; r0.v[t][1] = lo.y; r0.v[t][2] = lo.z; r1.v[t][0] = lo.w + 2.0f; r1.v[t][1] = hi.x; r1.v[t][2] = hi.y; r2.v[t][0] = hi.z; r2.v[t][1] = hi.w;
     }
-  } else { gather_tile<N0>(q.a[0], p, d, base, n, r0); gather_tile<N1>(q.a[1], p, d, base, n, r1); gather_tile<N2>(q.a[2], p, d, base, n, r2); }
+  } else { gather_tile<N0, KT>(q.a[0], p, d, base, n, r0); gather_tile<N1, KT>(q.a[1], p, d, base, n, r1); gather_tile<N2, KT>(q.a[2], p, d, base, n, r2); }
 #else
-  gather_tile<N0>(q.a[0], p, d, base, n, r0); gather_tile<N1>(q.a[1], p, d, base, n, r1); gather_tile<N2>(q.a[2], p, d, base, n, r2);
+  gather_tile<N0, KT>(q.a[0], p, d, base, n, r0); gather_tile<N1, KT>(q.a[1], p, d, base, n, r1); gather_tile<N2, KT>(q.a[2], p, d, base, n, r2);
 #endif
-  finish_tile<N0>(q.a[0], r0, d, base, n, mn[0], mx[0]); finish_tile<N1>(q.a[1], r1, d, base, n, mn[1], mx[1]); finish_tile<N2>(q.a[2], r2, d, base, n, mn[2], mx[2]);
+  finish_tile<N0, KT>(q.a[0], r0, d, base, n, mn[0], mx[0]); finish_tile<N1, KT>(q.a[1], r1, d, base, n, mn[1], mx[1]); finish_tile<N2, KT>(q.a[2], r2, d, base, n, mn[2], mx[2]);
 }
+template <int KT>
 __device__ __forceinline__ void k_seq_quantize_body(const SeqQuantArgs& sq, const uint32_t blk_, const uint32_t nblk_) {
   const uint32_t* __restrict__ s2p = sq.s2p;
   const uint32_t n = sq.n;
@@ -386,22 +391,22 @@ __device__ __forceinline__ void k_seq_quantize_body(const SeqQuantArgs& sq, cons
 #pragma unroll
   for (int a = 0; a < kMaxGather; ++a) { mn[a] = 2147483647; mx[a] = (-2147483647 - 1); }
   const int sig = args.count * 1000 + (args.count > 0 ? args.a[0].N * 100 : 0) + (args.count > 1 ? args.a[1].N * 10 : 0) + (args.count > 2 ? args.a[2].N : 0);
-  DMI_FOR_TILES(base, n, kTile) {
-    uint32_t p[kTile], d[kTile];
+  DMI_FOR_TILES(base, n, KT) {
+    uint32_t p[KT], d[KT];
 #pragma unroll
-    for (int t = 0; t < kTile; ++t) { const uint32_t i = base + t * kBlock + threadIdx.x; p[t] = i < n ? s2p[i] : 0u; d[t] = (sq.dest && i < n) ? sq.dest[i] : i; }
-    if (sig == 3332) { quantize_tiles3<3, 3, 2>(args, p, d, base, n, mn, mx); continue; }   // position, normal, texture coordinate
-    if (sig == 3323) { quantize_tiles3<3, 2, 3>(args, p, d, base, n, mn, mx); continue; }
-    if (sig == 2330) { quantize_tiles2<3, 3>(args, p, d, base, n, mn, mx); continue; }
-    if (sig == 2320) { quantize_tiles2<3, 2>(args, p, d, base, n, mn, mx); continue; }
+    for (int t = 0; t < KT; ++t) { const uint32_t i = base + t * kBlock + threadIdx.x; p[t] = i < n ? s2p[i] : 0u; d[t] = (sq.dest && i < n) ? sq.dest[i] : i; }
+    if (sig == 3332) { quantize_tiles3<3, 3, 2, KT>(args, p, d, base, n, mn, mx); continue; }   // position, normal, texture coordinate
+    if (sig == 3323) { quantize_tiles3<3, 2, 3, KT>(args, p, d, base, n, mn, mx); continue; }
+    if (sig == 2330) { quantize_tiles2<3, 3, KT>(args, p, d, base, n, mn, mx); continue; }
+    if (sig == 2320) { quantize_tiles2<3, 2, KT>(args, p, d, base, n, mn, mx); continue; }
 #pragma unroll
     for (int a = 0; a < kMaxGather; ++a) {
       if (a >= args.count) break;
       switch (args.a[a].N) {
-        case 1: quantize_tile<1>(args.a[a], p, d, base, n, mn[a], mx[a]); break;
-        case 2: quantize_tile<2>(args.a[a], p, d, base, n, mn[a], mx[a]); break;
-        case 3: quantize_tile<3>(args.a[a], p, d, base, n, mn[a], mx[a]); break;
-        default: quantize_tile<4>(args.a[a], p, d, base, n, mn[a], mx[a]); break;
+        case 1: quantize_tile<1, KT>(args.a[a], p, d, base, n, mn[a], mx[a]); break;
+        case 2: quantize_tile<2, KT>(args.a[a], p, d, base, n, mn[a], mx[a]); break;
+        case 3: quantize_tile<3, KT>(args.a[a], p, d, base, n, mn[a], mx[a]); break;
+        default: quantize_tile<4, KT>(args.a[a], p, d, base, n, mn[a], mx[a]); break;
       }
     }
   }
@@ -1754,7 +1759,7 @@ DMI_KERNEL(k_value_ranges_final, k_value_ranges_final_body, RangeArgs, kBlock)
 #ifndef DMI_SEQ_OCC
 #define DMI_SEQ_OCC __attribute__((amdgpu_waves_per_eu(8, 8)))
 #endif
-DMI_KERNEL2(k_seq_quantize, k_seq_quantize_body, k_seq_quantize_body, SeqQuantArgs, kBlock, DMI_SEQ_OCC)
+DMI_KERNEL2(k_seq_quantize, k_seq_quantize_body<DMI_KTILE_SINGLE>, k_seq_quantize_body<DMI_KTILE_MULTI>, SeqQuantArgs, kBlock, DMI_SEQ_OCC)
 DMI_KERNEL(k_i32_minmax_final, k_i32_minmax_final_body, MinMaxArgs, kBlock)
 DMI_KERNEL(k_predict_fused_pnu, (k_predict_fused_body<true, true, true, false>), FusedArgs, kBlock)
 DMI_KERNEL(k_predict_fused_pn, (k_predict_fused_body<true, true, false, false>), FusedArgs, kBlock)
@@ -1858,8 +1863,12 @@ void launch_value_ranges(RangeArgs& args, hipStream_t s) {
 
 void launch_i32_minmax_final(const MinMaxArgs& args, hipStream_t s) { emit(K_I32_FINAL, 3, args, (uint32_t)args.count, 0, s); }
 
-inline uint32_t tiles_grid(uint64_t n) { return grid_for((n + kTile - 1) / kTile, kSeqQuantizeMaxBlocks); }   // grid of a DMI_FOR_TILES kernel
-uint32_t seq_quantize_blocks(uint32_t n) { return tiles_grid(n); }
+// grid of k_seq_quantize (a DMI_FOR_TILES kernel: any grid is correct, this one gives every block work): the steps of a batch are recorded
+// (step sink) and run as the `_multi` launch, two entries per thread
+uint32_t seq_quantize_blocks(uint32_t n) {
+  const uint64_t kt = step_sink_active() ? DMI_KTILE_MULTI : DMI_KTILE_SINGLE;
+  return grid_for(((uint64_t)n + kt - 1) / kt, kSeqQuantizeMaxBlocks);
+}
 void launch_seq_quantize(const uint32_t* s2p, const uint32_t* dest, uint32_t n, const QuantArgs& args, hipStream_t s) {
   SeqQuantArgs sq{};
   sq.s2p = s2p; sq.dest = dest; sq.n = n; sq.q = args;
