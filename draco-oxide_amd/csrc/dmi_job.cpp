@@ -679,12 +679,22 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
     for (auto& e : job->ev) HIP_TRY(hipEventCreate(&e));
     job->have_events = true;
   }
-  // EXPERIMENT (DMI_TILE_SORT=<entries per tile>): the quantize gather in tile-sorted order — inside a tile of consecutive sequence entries the
-  // slots are ordered by point index (host sort here; a device sort would follow if the kernel gains).
-  if (const char* ts = std::getenv("DMI_TILE_SORT")) {
-    const uint32_t tile = (uint32_t)std::max(1024, std::atoi(ts));
-    if (!defer) for (auto& t : job->tables) {
-      if (t.alias_of >= 0 || t.n_seq == 0) continue;
+  // The quantize gather in tile-sorted order: inside tiles of consecutive sequence entries the slots are ordered by point index —
+  // the gather's wavefronts then read neighbouring points (−9 µs of the pass at 10M triangles).  Large single jobs only (a batch's meshes are
+  // smaller than a tile); sorted on the device (k_tile_sort).  DMI_TILE_SORT=0 switches it off, =<entries> picks the tile (a power of two up
+  // to 16384 on the device; larger tiles — the 100M-triangle experiment — by a host sort).
+  {
+    static const int env_tile = std::getenv("DMI_TILE_SORT") ? std::atoi(std::getenv("DMI_TILE_SORT")) : -1;
+    uint32_t tile = env_tile < 0 ? (1u << kTileSortMaxLog2) : (uint32_t)env_tile;
+    if (tile && !defer) for (auto& t : job->tables) {
+      if (t.alias_of >= 0 || t.n_seq < kTileSortMinEntries) continue;
+      if (tile <= (1u << kTileSortMaxLog2)) {
+        uint32_t lg = 6;
+        while ((1u << lg) < tile) ++lg;
+        if ((rc = t.s2p_sorted.alloc((size_t)t.n_seq * 4)) || (rc = t.sorted_dest.alloc((size_t)t.n_seq * 4))) return rc;
+        HIP_TRY(launch_tile_sort(t.s2p.as<uint32_t>(), t.n_seq, lg, t.s2p_sorted.as<uint32_t>(), t.sorted_dest.as<uint32_t>(), s));
+        continue;
+      }
       std::vector<uint32_t> s2p_h(t.n_seq), dest(t.n_seq), sorted(t.n_seq);
       HIP_TRY(hipMemcpyAsync(s2p_h.data(), t.s2p.p, (size_t)t.n_seq * 4, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));

@@ -433,7 +433,18 @@ __device__ __forceinline__ void k_seq_quantize_body(const SeqQuantArgs& sq, cons
 __device__ __forceinline__ void k_i32_minmax_final_body(const MinMaxArgs& args, const uint32_t blk_, const uint32_t nblk_) {
   const MinMaxAtt& a = args.a[blk_];
   int32_t lo = 2147483647, hi = (-2147483647 - 1);
-  for (uint32_t b = threadIdx.x; b < a.blocks; b += kBlock) { lo = min(lo, a.ipartials[2 * b]); hi = max(hi, a.ipartials[2 * b + 1]); }
+  // two partial pairs per 16-byte load, eight loads in flight per thread: the 8192 partials of a large mesh are two rounds, not 32 dependent ones
+  typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+  const i32x4* __restrict__ p4 = reinterpret_cast<const i32x4*>(a.ipartials);
+  const uint32_t n4 = a.blocks >> 1;
+  for (uint32_t b = threadIdx.x; b < n4; b += kBlock * 8u) {
+    i32x4 v[8];
+#pragma unroll
+    for (uint32_t u = 0; u < 8; ++u) { const uint32_t at = b + u * kBlock; v[u] = at < n4 ? p4[at] : i32x4{2147483647, (-2147483647 - 1), 2147483647, (-2147483647 - 1)}; }
+#pragma unroll
+    for (uint32_t u = 0; u < 8; ++u) { lo = min(lo, min(v[u].x, v[u].z)); hi = max(hi, max(v[u].y, v[u].w)); }
+  }
+  if ((a.blocks & 1u) && threadIdx.x == 0) { lo = min(lo, a.ipartials[2 * (a.blocks - 1)]); hi = max(hi, a.ipartials[2 * (a.blocks - 1) + 1]); }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_down(lo, off, 64)); hi = max(hi, __shfl_down(hi, off, 64)); }
   __shared__ int32_t red[2][kBlock / 64];

@@ -115,6 +115,34 @@ __global__ __launch_bounds__(kBlock) void k_max_u32(const uint32_t* __restrict__
   if (threadIdx.x == 0) { for (int w = 1; w < kBlock / 64; ++w) m = max(m, red[w]); atomicMax(out, m); }
 }
 
+// ---- the tile-sorted form of the quantize gather: inside tiles of 2^tile_log2 consecutive sequence entries the slots are ordered by
+// point index, so that the lanes of a wavefront of k_seq_quantize read neighbouring points; slot j reads point out_p[j] and writes sequence
+// entry out_dest[j].  One workgroup per tile, a bitonic network over (point << 32 | position in the tile) in LDS (8 bytes per entry: 128 KB at
+// the largest tile, 16 K entries); the slots past n sort to the end and are not written.  Job creation only.
+constexpr uint32_t kSortThreads = 1024;
+__global__ __launch_bounds__(kSortThreads) void k_tile_sort(const uint32_t* __restrict__ s2p, uint32_t n, uint32_t tile_log2, uint32_t* __restrict__ out_p,
+                                                           uint32_t* __restrict__ out_dest) {
+  extern __shared__ uint64_t tile_keys[];
+  const uint32_t T = 1u << tile_log2, a0 = blockIdx.x << tile_log2;
+  for (uint32_t k = threadIdx.x; k < T; k += kSortThreads) { const uint32_t i = a0 + k; tile_keys[k] = i < n ? (((uint64_t)s2p[i] << 32) | k) : ~0ull; }
+  __syncthreads();
+  for (uint32_t size = 2; size <= T; size <<= 1) {
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      for (uint32_t k = threadIdx.x; k < (T >> 1); k += kSortThreads) {
+        const uint32_t lo = 2u * k - (k & (stride - 1u)), hi = lo + stride;   // pair (lo, lo + stride) of the network
+        const bool ascending = (lo & size) == 0u;
+        const uint64_t x = tile_keys[lo], y = tile_keys[hi];
+        if ((x > y) == ascending) { tile_keys[lo] = y; tile_keys[hi] = x; }
+      }
+      __syncthreads();
+    }
+  }
+  for (uint32_t k = threadIdx.x; k < T; k += kSortThreads) {
+    const uint32_t i = a0 + k;
+    if (i < n) { const uint64_t v = tile_keys[k]; out_p[i] = (uint32_t)(v >> 32); out_dest[i] = a0 + (uint32_t)v; }
+  }
+}
+
 }  // namespace
 
 void launch_fill_u32(uint32_t* p, uint64_t n, uint32_t v, hipStream_t s) { if (n) hipLaunchKernelGGL(k_fill_u32, grid_of(n), kBlock, 0, s, p, n, v); }
@@ -148,5 +176,16 @@ void launch_compose_s2v(const uint32_t* s2p, uint32_t n_seq, const uint32_t* p2v
   if (n_seq) hipLaunchKernelGGL(k_compose_s2v, grid_of(n_seq), kBlock, 0, s, s2p, n_seq, p2v, num_points, num_unique, s2v, bad);
 }
 void launch_max_u32(const uint32_t* a, uint64_t n, uint32_t* out, hipStream_t s) { if (n) hipLaunchKernelGGL(k_max_u32, std::min<uint32_t>(grid_of(n), 2048u), kBlock, 0, s, a, n, out); }
+
+hipError_t launch_tile_sort(const uint32_t* s2p, uint32_t n, uint32_t tile_log2, uint32_t* s2p_sorted, uint32_t* dest, hipStream_t s) {
+  if (!n) return hipSuccess;
+  if (tile_log2 < 6 || tile_log2 > kTileSortMaxLog2) return hipErrorInvalidValue;
+  const uint32_t lds = 8u << tile_log2;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_sort), hipFuncAttributeMaxDynamicSharedMemorySize, 8 << kTileSortMaxLog2);   // 128 KB of the CU's 160
+  if (attr != hipSuccess) return attr;
+  const uint32_t T = 1u << tile_log2;
+  hipLaunchKernelGGL(k_tile_sort, (n + T - 1) / T, kSortThreads, lds, s, s2p, n, tile_log2, s2p_sorted, dest);
+  return hipGetLastError();
+}
 
 }  // namespace dmi
