@@ -257,53 +257,57 @@ int dmi_decode_attributes(const uint8_t* section, size_t len, const dmi_corner_t
   }
   if (n_seeds && !seeds) return host_fail(DMI_ERR_INVALID_ARGUMENT, "null seeds");
   for (uint32_t k = 0; k < n_seeds; ++k) if (seeds[k] >= C) return host_fail(DMI_ERR_INVALID_ARGUMENT, "seed corner out of range");
+  // the entropy decoders need the entry count of their attribute before its traversal has run: a traversal visits every vertex its table's
+  // corners name, so the count is the table's vertex count unless the caller's table carries unused vertices — the decoders start with that
+  // guess beside the traversals, and an attribute whose traversal comes back with another count is decoded again
+  auto decode_entropy = [&](uint32_t i, uint32_t n_entries) {
+    AttPlan* pl = &plans[i];
+    const uint8_t scheme = owner->atts[i].scheme;
+    pl->rc = 0; pl->err.clear();
+    pl->sym.resize((size_t)n_entries * pl->N);
+    if (!host_rans_decode(pl->rans, pl->rans_bytes, pl->freq.data(), (uint32_t)pl->freq.size(), pl->P, (uint64_t)n_entries * pl->N, pl->sym.data())) { pl->rc = DMI_ERR_ENTROPY; pl->err = "truncated or inconsistent rANS stream"; return; }
+    if (!pl->has_rabs) return;
+    const uint64_t count = scheme == 6 ? n_entries : pl->rabs_count;
+    if (count > n_entries) { pl->rc = DMI_ERR_ENTROPY; pl->err = "more orientation bits than entries"; return; }
+    pl->bits.resize((size_t)count);
+    if (!host_rabs_decode(pl->rabs, pl->rabs_bytes, pl->zp, count, pl->bits.data())) { pl->rc = DMI_ERR_ENTROPY; pl->err = "truncated rABS stream"; return; }
+    std::reverse(pl->bits.begin(), pl->bits.end());   // the encoder pushed them first to last; an ANS decoder pops the last one first
+    if (scheme == 5) {   // transitions → orientations (mesh_prediction_for_texture_coordinates.rs:241-256 inverted)
+      bool last = true;
+      for (size_t k = (size_t)count; k-- > 0;) { if (!pl->bits[k]) last = !last; pl->bits[k] = last ? 1 : 0; }
+    }
+  };
+  std::vector<uint32_t> n_guess(n_atts);
   {
-    std::vector<std::thread> walkers;
+    std::vector<std::thread> walkers, coders;
+    auto join_all = [&] { for (auto& w : walkers) w.join(); for (auto& w : coders) w.join(); };
     for (uint32_t i = 0; i < n_atts; ++i) {
       if (seq_owner[i] != (int)i || tables[i].sequence) continue;
       const dmi_corner_table& t = tables[i];
-      for (uint32_t v = 0; v < t.num_vertices; ++v) if (t.left_most_corner[v] >= C) { for (auto& w : walkers) w.join(); return host_fail(DMI_ERR_INVALID_ARGUMENT, "left_most_corner entry out of range"); }
+      for (uint32_t v = 0; v < t.num_vertices; ++v) if (t.left_most_corner[v] >= C) { join_all(); return host_fail(DMI_ERR_INVALID_ARGUMENT, "left_most_corner entry out of range"); }
       AttPlan* pl = &plans[i];
       walkers.emplace_back([pl, &t, F, seeds, n_seeds] {
         TableRef tr{F, t.num_vertices, t.corner_to_vertex, t.opposite, t.left_most_corner};
         attribute_sequence(tr, seeds, n_seeds, pl->seq_own);
-        pl->seq = pl->seq_own.data(); pl->n = (uint32_t)pl->seq_own.size();
       });
     }
+    for (uint32_t i = 0; i < n_atts; ++i) {
+      n_guess[i] = tables[i].sequence ? tables[i].sequence_len : tables[i].num_vertices;
+      coders.emplace_back(decode_entropy, i, n_guess[i]);
+    }
     for (auto& w : walkers) w.join();
+    g_last_decode.sequence_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_seq0).count();
+    for (auto& w : coders) w.join();
   }
+  for (uint32_t i = 0; i < n_atts; ++i) if (seq_owner[i] == (int)i && !tables[i].sequence) { plans[i].seq = plans[i].seq_own.data(); plans[i].n = (uint32_t)plans[i].seq_own.size(); }
   for (uint32_t i = 0; i < n_atts; ++i) {
     if (seq_owner[i] != (int)i) { plans[i].seq = plans[seq_owner[i]].seq; plans[i].n = plans[seq_owner[i]].n; }
     for (uint32_t k = 0; k < plans[i].n && seq_owner[i] == (int)i; ++k) if (plans[i].seq[k] >= C) return host_fail(DMI_ERR_INVALID_ARGUMENT, "sequence entry out of range");
-  }
-  const auto t_ent0 = std::chrono::steady_clock::now();
-  g_last_decode.sequence_ms = std::chrono::duration<float, std::milli>(t_ent0 - t_seq0).count();
-  {
-    std::vector<std::thread> coders;
-    for (uint32_t i = 0; i < n_atts; ++i) {
-      AttPlan* pl = &plans[i];
-      const uint8_t scheme = owner->atts[i].scheme;
-      auto body = [pl, scheme] {
-        pl->sym.resize((size_t)pl->n * pl->N);
-        if (!host_rans_decode(pl->rans, pl->rans_bytes, pl->freq.data(), (uint32_t)pl->freq.size(), pl->P, (uint64_t)pl->n * pl->N, pl->sym.data())) { pl->rc = DMI_ERR_ENTROPY; pl->err = "truncated or inconsistent rANS stream"; return; }
-        if (!pl->has_rabs) return;
-        const uint64_t count = scheme == 6 ? pl->n : pl->rabs_count;
-        if (count > pl->n) { pl->rc = DMI_ERR_ENTROPY; pl->err = "more orientation bits than entries"; return; }
-        pl->bits.resize((size_t)count);
-        if (!host_rabs_decode(pl->rabs, pl->rabs_bytes, pl->zp, count, pl->bits.data())) { pl->rc = DMI_ERR_ENTROPY; pl->err = "truncated rABS stream"; return; }
-        std::reverse(pl->bits.begin(), pl->bits.end());   // the encoder pushed them first to last; an ANS decoder pops the last one first
-        if (scheme == 5) {   // transitions → orientations (mesh_prediction_for_texture_coordinates.rs:241-256 inverted)
-          bool last = true;
-          for (size_t k = (size_t)count; k-- > 0;) { if (!pl->bits[k]) last = !last; pl->bits[k] = last ? 1 : 0; }
-        }
-      };
-      if (i + 1 < n_atts) coders.emplace_back(body); else body();   // (the calling thread takes the last one)
-    }
-    for (auto& w : coders) w.join();
+    if (plans[i].n != n_guess[i]) decode_entropy(i, plans[i].n);   // (a table with vertices no corner names)
   }
   for (uint32_t i = 0; i < n_atts; ++i) if (plans[i].rc) return host_fail(plans[i].rc, "attribute " + std::to_string(i) + ": " + plans[i].err);
   const auto t_inv0 = std::chrono::steady_clock::now();
-  g_last_decode.entropy_ms = std::chrono::duration<float, std::milli>(t_inv0 - t_ent0).count();
+  g_last_decode.entropy_ms = std::chrono::duration<float, std::milli>(t_inv0 - t_seq0).count();   // (beside the traversals: the longer of the two)
   double inverse_ms = 0;
 
   // ---- 3. predictions inverted in attribute order (a normal / texture coordinate needs the decoded positions) ----
@@ -343,8 +347,25 @@ int dmi_decode_attributes(const uint8_t* section, size_t len, const dmi_corner_t
       auto have = [&](uint32_t v, size_t k) { return when[v] != 0 && when[v] - 1 < k; };
       const int32_t max_diff = a.transform == 1 ? wadd(1, wsub(t_max, t_min)) : 0;
       size_t next_bit = 0;
+      // the walk's loads run ahead of it in three steps (each needs what the step before it fetched): corner rows of entry k + 32, the
+      // opposite corner's vertex of entry k + 20, the values / decode marks of the three or four vertices of entry k + 10
+      const uint32_t* pos_c2v = pos_att >= 0 ? tables[pos_att].corner_to_vertex : nullptr;
+      auto run_ahead = [&](size_t k) {
+        if (k + 32 < n) { const uint32_t c1 = seq[k + 32]; __builtin_prefetch(&t.opposite[c1]); __builtin_prefetch(&t.corner_to_vertex[3 * (c1 / 3)]); if (pos_c2v && a.scheme == 5) __builtin_prefetch(&pos_c2v[3 * (c1 / 3)]); }
+        if (k + 20 < n && a.scheme == 1) { const uint32_t o = t.opposite[seq[k + 20]]; if (o != kNone) __builtin_prefetch(&t.corner_to_vertex[o]); }
+        if (k + 10 < n) {
+          const uint32_t c3 = seq[k + 10], f3 = 3 * (c3 / 3);
+          for (uint32_t j = 0; j < 3; ++j) {
+            const uint32_t v = t.corner_to_vertex[f3 + j];
+            __builtin_prefetch(&when[v]); __builtin_prefetch(&val[(size_t)v * N]);
+            if (pos_c2v && a.scheme == 5) __builtin_prefetch(&pos_by_vertex[(size_t)pos_c2v[f3 + j] * 3]);
+          }
+          if (a.scheme == 1) { const uint32_t o = t.opposite[c3]; if (o != kNone) { const uint32_t v = t.corner_to_vertex[o]; __builtin_prefetch(&when[v]); __builtin_prefetch(&val[(size_t)v * N]); } }
+        }
+      };
       for (size_t k = 0; k < n; ++k) {
         const uint32_t c = seq[k];
+        run_ahead(k);
         int32_t pred[4] = {0, 0, 0, 0};
         auto previous_value = [&] { if (k > 0) { const int32_t* v = val.data() + (size_t)t.corner_to_vertex[seq[k - 1]] * N; for (int j = 0; j < N; ++j) pred[j] = v[j]; } };
         if (a.scheme == 1) {                                                      // mesh_parallelogram_prediction.rs:186-237

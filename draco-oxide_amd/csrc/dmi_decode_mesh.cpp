@@ -11,8 +11,11 @@
 // (tests/test_gpu_decode_mesh.py) — same-author evidence, not a reference pin.
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <memory>
+#include <thread>
 #include <unordered_map>
 
 #include "dmi_host.hpp"
@@ -64,6 +67,14 @@ struct DecodedConnectivity {
 
 int decode_connectivity(Bytes& b, DecodedConnectivity& out) {
   auto bad = [](const char* what) { return host_fail(DMI_ERR_CONNECTIVITY, std::string("connectivity section: ") + what); };
+  const bool trace = std::getenv("DMI_TRACE") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[dmi]   decode_connectivity: %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
   if (b.u8() != 0) return bad("not the standard Edgebreaker traversal");
   const uint64_t V_enc = b.leb(), F64 = b.leb();
   const uint32_t n_tables = b.u8();
@@ -98,6 +109,7 @@ int decode_connectivity(Bytes& b, DecodedConnectivity& out) {
     }
     if (!b.ok) return bad("symbol bits exhausted");
   }
+  lap("header, split events, symbol bits");
   const size_t C = (size_t)F * 3;
   std::vector<uint32_t> c2v(C, kNone), opp(C, kNone);
   std::vector<uint32_t> vcorner;   // left-most corner per vertex, maintained as the faces are glued on
@@ -194,6 +206,7 @@ int decode_connectivity(Bytes& b, DecodedConnectivity& out) {
       if (splits_left && splits[splits_left - 1].source > enc_id) return bad("topology split out of order");
     }
   }
+  lap("symbols -> faces");
   // start faces: one flag per component, first-encoded component first = the order the stack pops them
   std::vector<uint8_t> interior;
   if (!read_flag_block(b, active.size(), interior)) return bad("truncated start-face flags");
@@ -222,34 +235,50 @@ int decode_connectivity(Bytes& b, DecodedConnectivity& out) {
   uint32_t V = 0;
   for (size_t c = 0; c < C; ++c) { if (c2v[c] == kNone) return bad("corner without a vertex"); if (remap[c2v[c]] == kNone) remap[c2v[c]] = V++; c2v[c] = remap[c2v[c]]; }
   if (V != V_enc) return bad("vertex count does not match the header");
+  // left-most corners in two streaming passes (no fan walks): an open fan's is its one corner with nothing to the left, a closed fan's its
+  // first corner
   std::vector<uint32_t> lmc(V, kNone);
-  for (uint32_t c = 0; c < C; ++c) {
-    const uint32_t v = c2v[c];
-    if (lmc[v] != kNone) continue;
-    uint32_t left = c, a = swing_left(c);
-    for (uint64_t guard = 0; a != kNone && a != c && guard <= C; ++guard) { left = a; a = swing_left(a); }
-    lmc[v] = a == kNone ? left : c;   // open fan: where swinging left ends; closed fan: any corner serves (its swing_left exists)
-  }
-  // attribute seams (edgebreaker.rs:611-653): faces in decode order, corners c, next, prev; an edge is decided by its EARLIER face
+  for (uint32_t c = 0; c < C; ++c) if (opp[corner_next(c)] == kNone) lmc[c2v[c]] = c;
+  for (uint32_t c = 0; c < C; ++c) if (lmc[c2v[c]] == kNone) lmc[c2v[c]] = c;
+  lap("start faces, vertex compaction, left-most corners");
+  // attribute seams (edgebreaker.rs:611-653): faces in decode order, corners c, next, prev; an edge is decided by its EARLIER face.  The blocks
+  // are located first (their lengths are explicit), then every table's flags are decoded and applied on a host thread of their own.
   out.seam.assign(n_tables, std::vector<uint8_t>());
   uint64_t n_flags = 0;
   for (uint32_t f = 0; f < F; ++f) for (uint32_t k = 0; k < 3; ++k) { const uint32_t o = opp[3 * f + k]; if (o != kNone && o / 3 > f) ++n_flags; }
-  for (uint32_t t = 0; t < n_tables; ++t) {
-    std::vector<uint8_t> flags;
-    if (!read_flag_block(b, n_flags, flags)) return bad("truncated seam flags");
-    std::vector<uint8_t>& seam = out.seam[t];
-    seam.assign(C, 0);
-    size_t at = 0;
-    for (uint32_t f = 0; f < F; ++f) {
-      const uint32_t cs[3] = {3 * f, 3 * f + 1, 3 * f + 2};
-      for (uint32_t c : cs) {
-        const uint32_t o = opp[c];
-        if (o == kNone) { seam[c] = 1; continue; }
-        if (o / 3 < f) continue;
-        if (flags[at++]) seam[c] = seam[o] = 1;
-      }
-    }
+  struct FlagBlock { uint8_t zp; const uint8_t* data; size_t nbytes; bool ok; };
+  std::vector<FlagBlock> blocks(n_tables);
+  for (auto& fb : blocks) {
+    fb.zp = b.u8();
+    const uint64_t nbytes = b.leb();
+    fb.data = nullptr; fb.nbytes = (size_t)nbytes; fb.ok = true;
+    if (!b.ok || !b.take((size_t)nbytes, fb.data) || (n_flags && fb.zp == 0)) return bad("truncated seam flags");
   }
+  {
+    auto body = [&](uint32_t t) {
+      FlagBlock& fb = blocks[t];
+      std::vector<uint8_t> flags((size_t)n_flags, 0);
+      if (n_flags && !host_rabs_decode(fb.data, fb.nbytes, fb.zp, n_flags, flags.data())) { fb.ok = false; return; }
+      std::vector<uint8_t>& seam = out.seam[t];
+      seam.assign(C, 0);
+      size_t at = 0;
+      for (uint32_t f = 0; f < F; ++f) {
+        const uint32_t cs[3] = {3 * f, 3 * f + 1, 3 * f + 2};
+        for (uint32_t c : cs) {
+          const uint32_t o = opp[c];
+          if (o == kNone) { seam[c] = 1; continue; }
+          if (o / 3 < f) continue;
+          if (flags[at++]) seam[c] = seam[o] = 1;
+        }
+      }
+    };
+    std::vector<std::thread> workers;
+    for (uint32_t t = 0; t + 1 < n_tables; ++t) workers.emplace_back(body, t);
+    if (n_tables) body(n_tables - 1);
+    for (auto& w : workers) w.join();
+    for (auto& fb : blocks) if (!fb.ok) return bad("truncated seam flags");
+  }
+  lap("seam flags");
   out.F = F; out.V = V;
   out.c2v.swap(c2v); out.opp.swap(opp); out.lmc.swap(lmc);
   out.seeds.assign(init_corners.rbegin(), init_corners.rend());

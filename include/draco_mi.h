@@ -255,8 +255,9 @@ void dmi_decoded_free(dmi_decoded* d);
 typedef struct dmi_decode_timings {
   float connectivity_ms;   /* dmi_decode_mesh only: symbols → universal corner table + seam flags */
   float tables_ms;         /* dmi_decode_mesh only: per-attribute corner tables from the seams + point ids */
-  float sequence_ms;       /* attribute traversals (one host thread per distinct corner table) */
-  float entropy_ms;        /* rANS symbols + rABS bits, one host thread per attribute (decode/entropy/rans.rs:36-69) */
+  float sequence_ms;       /* attribute traversals (one host thread per distinct corner table), run BESIDE the entropy decoders */
+  float entropy_ms;        /* traversals + rANS symbols + rABS bits, one host thread per attribute (decode/entropy/rans.rs:36-69): the wall
+                              clock of both together (sequence_ms is contained in it) */
   float inverse_ms;        /* sequential predictions inverted on a host core (positions, texture coordinates, generic) */
   float device_ms;         /* uploads, k_decode_normals, k_dequantize, read-back */
   float attributes_ms;     /* the whole dmi_decode_attributes */

@@ -10,11 +10,13 @@ import draco_oxide_amd as dmi
 import orc
 from helpers import oracle_from_product_mesh, oracle_values_by_point
 import test_gpu_parity as T
+from test_gpu_decode import numpy_quantize
+from test_gpu_decode_mesh import _canonical_faces, _requantize
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 rng = np.random.default_rng(seed0)
-bad = rejected = decoded = 0
+bad = rejected = decoded = whole = 0
 for c in range(n_cases):
     seed = seed0 + c
     kind = c % 3
@@ -79,5 +81,18 @@ for c in range(n_cases):
         decoded += 1
     except (dmi.DracoMiError, orc.OracleError, AssertionError) as e:
         print(f"case {c} (seed {seed}, kind {kind}, {pb}/{ub} bits): decoder: {type(e).__name__} {str(e)[:120]}"); bad += 1
+    # the whole file from its bytes alone: the decoded triangles are the input's (quantized position rows, labelling-free)
+    try:
+        dm = dmi.decode_mesh(want)
+        pos = mesh.attributes[0]
+        q, mn, rg = numpy_quantize(pos.values, pb)
+        q = q if pos.point_to_value is None else q[pos.point_to_value]
+        in_faces = np.asarray(mesh.faces, np.int64).reshape(-1, 3)
+        got_rows = _requantize(dm["attributes"][0]["values"], mn, rg, pb)[dm["faces"].astype(np.int64)]
+        assert dm["faces"].shape == in_faces.shape and (_canonical_faces(q[in_faces]) == _canonical_faces(got_rows)).all()
+        whole += 1
+    except (dmi.DracoMiError, AssertionError) as e:
+        print(f"case {c} (seed {seed}, kind {kind}, {pb}/{ub} bits): decode_mesh: {type(e).__name__} {str(e)[:120]}"); bad += 1
+print(f"{whole} whole files read back by dmi_decode_mesh")
 print(f"{n_cases} cases, {rejected} rejected by the reference algorithm, {decoded} decoded back by both decoders, {bad} mismatches")
 sys.exit(1 if bad else 0)
