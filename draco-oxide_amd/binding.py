@@ -98,7 +98,7 @@ class _Conn(C.Structure):
 
 
 EXPORTS = ["dmi_encode_attributes", "dmi_encode_attributes_batch", "dmi_jobs_encode", "dmi_job_create", "dmi_job_encode", "dmi_job_timings", "dmi_job_destroy", "dmi_encode_mesh",
-           "dmi_mesh_prepare", "dmi_meshes_prepare", "dmi_shard_meshes", "dmi_meshes_prepare_devices", "dmi_jobs_encode_devices", "dmi_mesh_build", "dmi_built_mesh_free", "dmi_encode_connectivity", "dmi_conn_free", "dmi_host_rans_stream", "dmi_host_rabs_stream", "dmi_decode_attributes", "dmi_decoded_free", "dmi_decode_mesh", "dmi_decoded_mesh_free", "dmi_decode_connectivity", "dmi_decoded_conn_free", "dmi_last_decode_timings", "dmi_free", "dmi_free_many", "dmi_strerror", "dmi_last_error", "dmi_device_count", "dmi_release_cached_memory"]
+           "dmi_mesh_prepare", "dmi_meshes_prepare", "dmi_shard_meshes", "dmi_meshes_prepare_devices", "dmi_jobs_encode_devices", "dmi_mesh_build", "dmi_built_mesh_free", "dmi_encode_connectivity", "dmi_conn_free", "dmi_host_rans_stream", "dmi_host_rabs_stream", "dmi_host_rabs_constant_stream", "dmi_decode_attributes", "dmi_decoded_free", "dmi_decode_mesh", "dmi_decoded_mesh_free", "dmi_decode_connectivity", "dmi_decoded_conn_free", "dmi_last_decode_timings", "dmi_free", "dmi_free_many", "dmi_strerror", "dmi_last_error", "dmi_device_count", "dmi_release_cached_memory"]
 
 
 def library_path():
@@ -166,6 +166,7 @@ def load_library():
     L.dmi_decoded_free.restype = None
     L.dmi_host_rans_stream.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(_Buffer)]
     L.dmi_host_rabs_stream.argtypes = [C.c_uint8, C.c_void_p, C.c_uint64, C.POINTER(_Buffer)]
+    L.dmi_host_rabs_constant_stream.argtypes = [C.c_uint8, C.c_uint32, C.c_uint64, C.POINTER(_Buffer)]
     _lib = L
     return L
 
@@ -834,6 +835,14 @@ def host_rabs_stream(zero_prob, bits):
     b = np.ascontiguousarray(bits, dtype=np.uint8)
     out = _Buffer()
     _check(L.dmi_host_rabs_stream(zero_prob, b.ctypes.data, len(b), C.byref(out)))
+    return _take(out)
+
+
+def host_rabs_constant_stream(zero_prob, bit, n):
+    """n copies of `bit` through the rABS coder by its period (dmi_host_rabs_constant_stream): the bytes host_rabs_stream gives for them."""
+    L = load_library()
+    out = _Buffer()
+    _check(L.dmi_host_rabs_constant_stream(C.c_uint8(zero_prob), C.c_uint32(bit), C.c_uint64(n), C.byref(out)))
     return _take(out)
 
 

@@ -243,6 +243,7 @@ struct RabsHost {
 };
 uint8_t zero_probability(uint64_t count_zero, float denominator);
 // the rABS stream of n flags fed first to last, on the multiply-high host coder (host_chains.cpp); false on StateTooLarge
+bool host_rabs_constant(uint8_t zero_prob, uint32_t bit, uint64_t n, std::vector<uint8_t>& bytes);   // n copies of one bit, without the n steps (host_chains.cpp)
 bool host_rabs_bytes(uint8_t zero_prob, const uint8_t* fed, uint64_t n, std::vector<uint8_t>& bytes);   // the f32 "(c0/len)*256+0.5 → clamp(1,255)" idiom
 
 // Normalised frequency table + its serialisation.

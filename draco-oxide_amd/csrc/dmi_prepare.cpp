@@ -1002,6 +1002,13 @@ int dmi_host_rabs_stream(uint8_t zero_prob, const uint8_t* bits, uint64_t n, dmi
   return DMI_OK;
 }
 
+int dmi_host_rabs_constant_stream(uint8_t zero_prob, uint32_t bit, uint64_t n, dmi_buffer* out) {
+  if (!out || zero_prob == 0 || bit > 1) return fail(DMI_ERR_INVALID_ARGUMENT, "bad argument");
+  std::vector<uint8_t> bytes;
+  if (!host_rabs_constant(zero_prob, bit, n, bytes)) return fail(DMI_ERR_ENTROPY, "rABS state too large");
+  return to_buffer(bytes, out);
+}
+
 int dmi_encode_mesh(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buffer* out) {
   if (!out) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
   NumaPin pin(cfg ? cfg->device : 0);   // (also around the encode: the host-core chains read the symbols the staging DMA brought in)

@@ -167,6 +167,51 @@ bool host_rabs_bytes(uint8_t zero_prob, const uint8_t* fed, uint64_t n, std::vec
   return true;
 }
 
+// n copies of ONE bit (the seam-flag stream of an attribute without seams: 1.5 flags per face, all zero).  With the bit fixed a step is a
+// function of the state alone, so the states — and with them the bytes that leave — repeat: for zero_prob 255 after 1410 steps with a
+// period of 1409 steps and one byte.  The first window of steps runs as the coder runs them, the period is read off the recorded states, the
+// rest of the stream is the period's bytes over and over; a window without a repeat falls back to the plain loop.  Same bytes as
+// host_rabs_bytes on n equal bits (tests/test_host_chains.py).
+bool host_rabs_constant(uint8_t zero_prob, uint32_t bit, uint64_t n, std::vector<uint8_t>& bytes) {
+  const uint32_t p0 = zero_prob, f1 = 256u - p0;
+  const HostRec h = host_rec(bit ? make_rans_entry(f1, 0, 8) : make_rans_entry(p0, f1, 8));
+  auto step = [&](uint32_t x, std::vector<uint8_t>& out) {   // host_rabs_chain's generic loop body
+    if (x >= h.t) { out.push_back((uint8_t)x); x >>= 8; }
+    const uint32_t q = (h.flags & 0x100u) ? x : quot(x, h.m64);
+    return x + q * h.d + h.c;
+  };
+  constexpr uint64_t kWindow = 1u << 14;
+  const uint64_t W = std::min<uint64_t>(n, kWindow);
+  std::vector<uint32_t> xs((size_t)W + 1), ob((size_t)W + 1);
+  bytes.clear();
+  uint32_t x = 4096u;
+  for (uint64_t i = 0; i < W; ++i) { xs[(size_t)i] = x; ob[(size_t)i] = (uint32_t)bytes.size(); x = step(x, bytes); }
+  xs[(size_t)W] = x; ob[(size_t)W] = (uint32_t)bytes.size();
+  uint64_t left = n - W;
+  if (left) {
+    uint64_t period = 0;
+    for (uint64_t l = 1; l <= W; ++l) if (xs[(size_t)(W - l)] == x) { period = l; break; }
+    if (period) {
+      const size_t from = ob[(size_t)(W - period)], per_bytes = ob[(size_t)W] - from;
+      const uint64_t reps = left / period, rem = left % period;
+      const std::vector<uint8_t> cycle(bytes.begin() + (long)from, bytes.begin() + (long)(from + per_bytes));
+      bytes.reserve(bytes.size() + (size_t)reps * per_bytes + per_bytes + 8);
+      if (per_bytes == 1) bytes.insert(bytes.end(), (size_t)reps, cycle[0]);
+      else for (uint64_t r = 0; r < reps; ++r) bytes.insert(bytes.end(), cycle.begin(), cycle.end());
+      const size_t tail = ob[(size_t)(W - period + rem)] - from;
+      bytes.insert(bytes.end(), cycle.begin(), cycle.begin() + (long)tail);
+      x = xs[(size_t)(W - period + rem)];
+    } else {
+      for (uint64_t i = 0; i < left; ++i) x = step(x, bytes);
+    }
+  }
+  uint8_t fl[4];
+  const uint32_t nb = flush_bytes(x - 4096u, fl);
+  if (!nb) return false;
+  bytes.insert(bytes.end(), fl, fl + nb);
+  return true;
+}
+
 // ---- the inverse coders (decode/entropy/rans.rs:36-69, :106-127): the decoder side's serial stage, on a host core ----
 namespace {
 inline bool read_tagged_state(const uint8_t* data, size_t& pos, uint64_t& state) {   // rans.rs:36-46: the last byte's top two bits give the state's width

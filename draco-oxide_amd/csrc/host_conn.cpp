@@ -713,7 +713,16 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
     std::vector<std::vector<uint8_t>> fed(A);
     struct GiveBack { std::vector<std::vector<uint8_t>>& v; ~GiveBack() { for (auto& x : v) pool_give(x); } } fed_back{fed};
     std::vector<uint64_t> zeros(A, 0);
-    if (sliced && !twice.load()) {
+    if (sliced && !twice.load() && own.empty()) {
+      // no attribute has seams of its own: only the stream length is needed — every interior edge is emitted once (by the earlier of its two
+      // faces in the walk from the back, or by the processed one when the other is a start face)
+      if (t.no_boundary) total = (uint64_t)t.F * 3 / 2;
+      else {
+        std::atomic<uint64_t> inner{0};
+        parallel_for((size_t)t.F * 3, [&](size_t lo, size_t hi) { uint64_t k = 0; for (size_t c = lo; c < hi; ++c) k += t.opp[c] != kNone; inner.fetch_add(k); });
+        total = inner.load() / 2;
+      }
+    } else if (sliced && !twice.load()) {
       // corners of face i whose flag is emitted, as a mask over (c, next, prev)
       auto mask_of = [&](size_t i) -> uint32_t {
         const uint32_t c = processed[i];
@@ -782,16 +791,14 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
       }
       for (size_t j : own) { fed[j].assign(seams[j].rbegin(), seams[j].rend()); for (uint8_t b : fed[j]) zeros[j] += !b; }
     }
-    Pooled<uint8_t> all_zero_p;
+    // (the stream of an attribute without seams is `total` zero flags: coded by its period, host_rabs_constant — no flag array, no 1.5 steps per face)
     const bool need_zero = own.size() < A && std::find(stream_of.begin(), stream_of.end(), -1) != stream_of.end();
-    if (need_zero) { pool_fit(all_zero_p.v, total); all_zero_p.v.assign(total, 0); }
     // one coder per attribute, side by side for large meshes
     std::vector<std::vector<uint8_t>> coded(A + 1);   // [A] = the all-zero stream
     std::vector<uint8_t> ok(A + 1, 1), zp(A + 1, 0);
     auto code_one = [&](size_t j) {
-      const uint8_t* bits = j == A ? all_zero_p.v.data() : fed[j].data();
       zp[j] = zero_probability(j == A ? total : zeros[j], (float)total);
-      ok[j] = host_rabs_bytes(zp[j], bits, total, coded[j]) ? 1 : 0;
+      ok[j] = (j == A ? host_rabs_constant(zp[j], 0u, total, coded[j]) : host_rabs_bytes(zp[j], fed[j].data(), total, coded[j])) ? 1 : 0;
     };
     std::vector<size_t> todo(own);
     if (need_zero) todo.push_back(A);

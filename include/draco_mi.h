@@ -287,6 +287,10 @@ void dmi_decoded_mesh_free(dmi_decoded_mesh* m);
  * (encode/entropy/symbol_coding.rs:161-163), bits first to last; the tagged final state is appended (rans.rs:48-68). */
 int dmi_host_rans_stream(const uint32_t* freq, uint32_t num_symbols, uint32_t precision, const uint32_t* symbols, uint64_t n, dmi_buffer* out);
 int dmi_host_rabs_stream(uint8_t zero_prob, const uint8_t* bits, uint64_t n, dmi_buffer* out);
+/* The same stream for n copies of ONE bit without stepping through them: with the bit fixed the coder's states repeat (zero_prob 255: after
+ * 1410 steps, period 1409 steps / 1 byte), so the bytes are a prefix, the period's bytes repeated, a tail.  The connectivity stage codes
+ * the seam flags of every attribute without seams this way (encode/connectivity/edgebreaker.rs:611-653: 1.5 zero flags per face). */
+int dmi_host_rabs_constant_stream(uint8_t zero_prob, uint32_t bit, uint64_t n, dmi_buffer* out);
 
 void dmi_free(dmi_buffer* buf);
 /* dmi_free of bufs[0..n): the outputs of a batch call released in one call */

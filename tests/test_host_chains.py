@@ -59,3 +59,21 @@ def test_host_rans_stream_rejects_what_the_reference_cannot_code():
         dmi.host_rans_stream(f, 12, np.array([0, 1, 2], np.uint32))       # symbol 1 has no frequency
     with pytest.raises(dmi.DracoMiError):
         dmi.host_rans_stream(np.array([10, 20], np.uint32), 12, np.array([0], np.uint32))   # does not sum to 2^12
+
+
+@pytest.mark.parametrize("zero_prob", [255, 254, 250, 200, 129, 128, 64, 3, 2, 1])
+@pytest.mark.parametrize("bit", [0, 1])
+def test_constant_bit_stream_by_its_period_equals_the_stepping_coder(zero_prob, bit):
+    """dmi_host_rabs_constant_stream (the all-zero seam-flag stream of the connectivity stage): n copies of one bit coded as prefix + repeated
+    period + tail — byte for byte what the stepping coder (pinned against the oracle's above) writes, across the window edge, whole periods,
+    period ± 1, and streams too short to repeat."""
+    lengths = [0, 1, 2, 100, 1409, 1410, 1411, 2819, 16383, 16384, 16385, 16384 + 1409, 16384 + 1410, 16384 + 3 * 1409 + 7, 100000, 1500007]
+    for n in lengths:
+        bits = np.full(n, bit, np.uint8)
+        try:
+            want = dmi.host_rabs_stream(zero_prob, bits)
+        except dmi.DracoMiError:
+            with pytest.raises(dmi.DracoMiError):
+                dmi.host_rabs_constant_stream(zero_prob, bit, n)
+            continue
+        assert dmi.host_rabs_constant_stream(zero_prob, bit, n) == want, f"zero_prob {zero_prob}, bit {bit}, n {n}"

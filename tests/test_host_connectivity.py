@@ -60,7 +60,7 @@ def test_connectivity_matches_oracle_on_fixtures(name):
     _compare_conn(sess, product_mesh_from_oracle(sess))
 
 
-@pytest.mark.parametrize("n,open_boundary", [(12, False), (17, True), (40, False)])
+@pytest.mark.parametrize("n,open_boundary", [(12, False), (17, True), (40, False), (120, False), (151, True)])   # (the last two: > 16384 seam flags, the all-zero stream coded by its period)
 def test_connectivity_matches_oracle_on_synthetic(n, open_boundary):
     mesh = synth.torus_mesh(n, open_boundary=open_boundary)
     _compare_conn(oracle_from_product_mesh(mesh), mesh)
