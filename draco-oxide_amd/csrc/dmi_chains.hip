@@ -101,11 +101,20 @@ __device__ __forceinline__ void k_orient_prep_body(const OrientPrepArgs& a, cons
   const uint32_t lane = threadIdx.x;
   const uint32_t lo = blk_ * 4096u;
   const uint32_t nb = (min(n, lo + 4096u) - lo + 63u) / 64u;   // batches in this chunk (≤ 64)
+  // the chunk goes through LDS with 16-byte loads (as in the summary kernel): a wavefront owns a whole chunk, a launch has about one
+  // wavefront per SIMD, and 2 × 64 global byte loads waited for one after the other were 39 µs of latency per launch
+  __shared__ __attribute__((aligned(16))) uint8_t staged[4096];
+#pragma unroll
+  for (uint32_t w = 0; w < 4; ++w) {
+    const uint32_t off = (w * 64u + lane) * 16u, at = lo + off;
+    if (at + 16u <= n) *reinterpret_cast<uint4*>(staged + off) = *reinterpret_cast<const uint4*>(orient + at);
+    else for (uint32_t k = 0; k < 16u; ++k) staged[off + k] = (at + k < n) ? orient[at + k] : (uint8_t)0;
+  }
+  __syncthreads();
   // pass 1: valid count per batch → exclusive offsets (lane b owns batch b)
   uint32_t cnt = 0;
   for (uint32_t b = 0; b < nb; ++b) {
-    const uint32_t i = lo + b * 64u + lane;
-    const uint32_t f = (i < n) ? orient[i] : 0u;
+    const uint32_t f = staged[b * 64u + lane];
     const uint32_t c = (uint32_t)__popcll(__ballot(f != 0));
     if (lane == b) cnt = c;
   }
@@ -117,8 +126,7 @@ __device__ __forceinline__ void k_orient_prep_body(const OrientPrepArgs& a, cons
   uint32_t carry = chunk_info[2 * blk_ + 1];   // value of the next valid entry after the batch being processed
   // pass 2: batches from last to first so that the successor's value is known
   for (uint32_t bb = nb; bb-- > 0;) {
-    const uint32_t i = lo + bb * 64u + lane;
-    const uint32_t f = (i < n) ? orient[i] : 0u;
+    const uint32_t f = staged[bb * 64u + lane];
     const unsigned long long valid = __ballot(f != 0);
     const unsigned long long ones = __ballot(f == 2);
     if (valid == 0ull) continue;
