@@ -6,7 +6,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d "$out/batch_stats" -o st --output-format csv -- python3 "$root/scripts/bench_batch.py" 256 5 > "$out/batch_stats.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d "$out/batch_stats" -o st --output-format csv -- python3 "$root/scripts/bench_batch.py" 256 5 > "$out/batch_stats.log" 2>&1
 tail -2 "$out/batch_stats.log"
 cd "$root"
 python3 - "$out" "$tag" <<'PY'
