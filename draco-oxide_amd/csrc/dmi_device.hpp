@@ -13,7 +13,7 @@ namespace dmi {
 // launch_* functions below either launch their step at once or — while a sink is set for the calling thread — append it to
 // the sink, so that a batch driver can run the SAME phase of many jobs in one multi-item launch (launch_steps_multi).
 // `level` orders the steps of one job: steps of equal level are independent of each other.
-enum KernelId : int { K_RANGES, K_RANGES_FINAL, K_SEQ_QUANT, K_I32_FINAL, K_FUSED_PNU, K_FUSED_PN, K_FUSED_PU, K_FUSED_N,
+enum KernelId : int { K_RANGES, K_RANGES_FINAL, K_SEQ_QUANT, K_SEQ_QUANT_BIG, K_I32_FINAL, K_FUSED_PNU, K_FUSED_PN, K_FUSED_PU, K_FUSED_N,
                       K_PACKED_PNU, K_PACKED_PN, K_PACKED_PU, K_PACKED_N /* the same sweeps on packed values (QFmt) */,
                       K_WINDOW_PNU, K_WINDOW_PN, K_WINDOW_PU /* … with LDS-staged neighbourhoods */,
                       K_PAR1, K_PAR2, K_PAR3, K_PAR4, K_DELTA, K_TEX, K_ORIENT, K_HIST,
@@ -43,6 +43,7 @@ struct MinMaxAtt { const int32_t* ipartials; int32_t* minmax; uint32_t blocks; u
 struct MinMaxArgs { MinMaxAtt a[kMaxRangeAtts]; int count; };
 void launch_i32_minmax_final(const MinMaxArgs& args, hipStream_t s);
 constexpr uint32_t kSeqQuantizeMaxBlocks = 8192;
+constexpr uint32_t kSeqQuantizeBigEntries = 1u << 23;   // longer sequences: k_seq_quantize_big (dmi_kernels.hip)
 uint32_t seq_quantize_blocks(uint32_t n);   // grid of launch_seq_quantize = partials written per attribute (≤ kSeqQuantizeMaxBlocks)
 // qs[i] = portabilize(raw[s2v ? s2v[i] : s2p[i]]) for every attribute of one corner table (s2p[i] = point_idx(seq[i])) + per-block joint i32 min/max
 // partials (ipartials: int32[2 * seq_quantize_blocks(n)]).  kind: 0 coordinate-wise, 1 octahedral, 2 ToBits.

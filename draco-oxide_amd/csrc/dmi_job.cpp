@@ -687,7 +687,7 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
     static const int env_tile = std::getenv("DMI_TILE_SORT") ? std::atoi(std::getenv("DMI_TILE_SORT")) : -1;
     uint32_t tile = env_tile < 0 ? (1u << kTileSortMaxLog2) : (uint32_t)env_tile;
     if (tile && !defer) for (auto& t : job->tables) {
-      if (t.alias_of >= 0 || t.n_seq < kTileSortMinEntries) continue;
+      if (t.alias_of >= 0 || t.n_seq < kTileSortMinEntries || (env_tile < 0 && t.n_seq > kTileSortMaxEntries)) continue;
       if (tile <= (1u << kTileSortMaxLog2)) {
         uint32_t lg = 6;
         while ((1u << lg) < tile) ++lg;

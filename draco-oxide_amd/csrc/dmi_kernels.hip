@@ -1771,6 +1771,9 @@ DMI_KERNEL(k_value_ranges_final, k_value_ranges_final_body, RangeArgs, kBlock)
 #define DMI_SEQ_OCC __attribute__((amdgpu_waves_per_eu(8, 8)))
 #endif
 DMI_KERNEL2(k_seq_quantize, k_seq_quantize_body<DMI_KTILE_SINGLE>, k_seq_quantize_body<DMI_KTILE_MULTI>, SeqQuantArgs, kBlock, DMI_SEQ_OCC)
+// … and sequences above kSeqQuantizeBigEntries (a 100M-triangle mesh: the gather is bound by what survives in L2 between rings, and fewer
+// lines in flight keep more of it) take two entries per thread at the compiler's own 7 waves: 100M triangles 1.75–1.93 ms against 2.27
+DMI_KERNEL(k_seq_quantize_big, k_seq_quantize_body<2>, SeqQuantArgs, kBlock)
 DMI_KERNEL(k_i32_minmax_final, k_i32_minmax_final_body, MinMaxArgs, kBlock)
 DMI_KERNEL(k_predict_fused_pnu, (k_predict_fused_body<true, true, true, false>), FusedArgs, kBlock)
 DMI_KERNEL(k_predict_fused_pn, (k_predict_fused_body<true, true, false, false>), FusedArgs, kBlock)
@@ -1820,6 +1823,7 @@ bool step_sink_active() { return g_step_sink != nullptr; }
   X(K_RANGES, k_value_ranges, RangeArgs, kBlock)                             \
   X(K_RANGES_FINAL, k_value_ranges_final, RangeArgs, kBlock)                 \
   X(K_SEQ_QUANT, k_seq_quantize, SeqQuantArgs, kBlock)                       \
+  X(K_SEQ_QUANT_BIG, k_seq_quantize_big, SeqQuantArgs, kBlock)               \
   X(K_I32_FINAL, k_i32_minmax_final, MinMaxArgs, kBlock)                     \
   X(K_FUSED_PNU, k_predict_fused_pnu, FusedArgs, kBlock)                     \
   X(K_FUSED_PN, k_predict_fused_pn, FusedArgs, kBlock)                       \
@@ -1877,13 +1881,13 @@ void launch_i32_minmax_final(const MinMaxArgs& args, hipStream_t s) { emit(K_I32
 // grid of k_seq_quantize (a DMI_FOR_TILES kernel: any grid is correct, this one gives every block work): the steps of a batch are recorded
 // (step sink) and run as the `_multi` launch, two entries per thread
 uint32_t seq_quantize_blocks(uint32_t n) {
-  const uint64_t kt = step_sink_active() ? DMI_KTILE_MULTI : DMI_KTILE_SINGLE;
+  const uint64_t kt = (step_sink_active() || n > kSeqQuantizeBigEntries) ? DMI_KTILE_MULTI : DMI_KTILE_SINGLE;
   return grid_for(((uint64_t)n + kt - 1) / kt, kSeqQuantizeMaxBlocks);
 }
 void launch_seq_quantize(const uint32_t* s2p, const uint32_t* dest, uint32_t n, const QuantArgs& args, hipStream_t s) {
   SeqQuantArgs sq{};
   sq.s2p = s2p; sq.dest = dest; sq.n = n; sq.q = args;
-  emit(K_SEQ_QUANT, 2, sq, seq_quantize_blocks(n), 0, s);
+  emit(n > kSeqQuantizeBigEntries ? K_SEQ_QUANT_BIG : K_SEQ_QUANT, 2, sq, seq_quantize_blocks(n), 0, s);
 }
 
 void launch_pred_parallelogram_wrapped(const uint32_t* seq, uint32_t n, const uint32_t* c2r, const uint32_t* opp,
