@@ -9,9 +9,9 @@ mkdir -p gpurun_out/r3
 export DMI_BENCH_BACKEND=gloo
 for n in 1 2 4 8; do
   if [ $n = 1 ]; then
-    python bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-scopes --no-batch >> $out 2>> gpurun_out/r3/scaling_one_host.err
+    timeout 600 python bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-scopes --no-batch >> $out 2>> gpurun_out/r3/scaling_one_host.err
   else
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29500 + n)) bench.py --gpus $n --steps 5 --warmup 2 --no-cpu-baseline --batch-meshes 1024 >> $out 2>> gpurun_out/r3/scaling_one_host.err
+    timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29500 + n)) bench.py --gpus $n --steps 5 --warmup 2 --no-cpu-baseline --batch-meshes 1024 >> $out 2>> gpurun_out/r3/scaling_one_host.err
   fi
 done
 python - <<'PY'
