@@ -684,10 +684,12 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
   // smaller than a tile); sorted on the device (k_tile_sort).  DMI_TILE_SORT=0 switches it off, =<entries> picks the tile (a power of two up
   // to 16384 on the device; larger tiles — the 100M-triangle experiment — by a host sort).
   {
-    static const int env_tile = std::getenv("DMI_TILE_SORT") ? std::atoi(std::getenv("DMI_TILE_SORT")) : -1;
+    // (read per job creation, not once: the tests run small meshes through every form — DMI_TILE_SORT_MIN lowers the length it starts at)
+    const int env_tile = std::getenv("DMI_TILE_SORT") ? std::atoi(std::getenv("DMI_TILE_SORT")) : -1;
+    const uint32_t min_entries = std::getenv("DMI_TILE_SORT_MIN") ? (uint32_t)std::atoi(std::getenv("DMI_TILE_SORT_MIN")) : kTileSortMinEntries;
     uint32_t tile = env_tile < 0 ? (1u << kTileSortMaxLog2) : (uint32_t)env_tile;
     if (tile && !defer) for (auto& t : job->tables) {
-      if (t.alias_of >= 0 || t.n_seq < kTileSortMinEntries || (env_tile < 0 && t.n_seq > kTileSortMaxEntries)) continue;
+      if (t.alias_of >= 0 || t.n_seq == 0 || t.n_seq < min_entries || (env_tile < 0 && t.n_seq > kTileSortMaxEntries)) continue;
       if (tile <= (1u << kTileSortMaxLog2)) {
         uint32_t lg = 6;
         while ((1u << lg) < tile) ++lg;

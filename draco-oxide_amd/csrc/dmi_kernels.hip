@@ -1880,14 +1880,16 @@ void launch_i32_minmax_final(const MinMaxArgs& args, hipStream_t s) { emit(K_I32
 
 // grid of k_seq_quantize (a DMI_FOR_TILES kernel: any grid is correct, this one gives every block work): the steps of a batch are recorded
 // (step sink) and run as the `_multi` launch, two entries per thread
+// (DMI_SEQ_BIG_ENTRIES: the length above which the big form runs — read per call so that the tests can put small meshes through it)
+static uint32_t seq_big_entries() { const char* e = std::getenv("DMI_SEQ_BIG_ENTRIES"); return e ? (uint32_t)std::atoll(e) : kSeqQuantizeBigEntries; }
 uint32_t seq_quantize_blocks(uint32_t n) {
-  const uint64_t kt = (step_sink_active() || n > kSeqQuantizeBigEntries) ? DMI_KTILE_MULTI : DMI_KTILE_SINGLE;
+  const uint64_t kt = (step_sink_active() || n > seq_big_entries()) ? DMI_KTILE_MULTI : DMI_KTILE_SINGLE;
   return grid_for(((uint64_t)n + kt - 1) / kt, kSeqQuantizeMaxBlocks);
 }
 void launch_seq_quantize(const uint32_t* s2p, const uint32_t* dest, uint32_t n, const QuantArgs& args, hipStream_t s) {
   SeqQuantArgs sq{};
   sq.s2p = s2p; sq.dest = dest; sq.n = n; sq.q = args;
-  emit(n > kSeqQuantizeBigEntries ? K_SEQ_QUANT_BIG : K_SEQ_QUANT, 2, sq, seq_quantize_blocks(n), 0, s);
+  emit(n > seq_big_entries() ? K_SEQ_QUANT_BIG : K_SEQ_QUANT, 2, sq, seq_quantize_blocks(n), 0, s);
 }
 
 void launch_pred_parallelogram_wrapped(const uint32_t* seq, uint32_t n, const uint32_t* c2r, const uint32_t* opp,

@@ -604,3 +604,42 @@ def test_split_batch_two_halves_in_flight(monkeypatch):
     assert halves == whole
     for k in (0, 7, 39):
         _assert_same(jobs[k].header_and_connectivity + halves[k], oracle_from_product_mesh(meshes[k]).encode(), f"split batch, mesh {k}")
+
+
+@pytest.mark.parametrize("tile", [64, 256, 4096, 16384])
+@pytest.mark.parametrize("n,open_boundary,normals,uvs", [(41, False, True, True), (33, True, True, True), (150, True, False, True), (64, False, True, False)])
+def test_tile_sorted_quantize_gather_gives_the_same_bytes(tile, n, open_boundary, normals, uvs, monkeypatch):
+    """The quantize gather of large jobs runs tile-sorted (k_tile_sort: slots of every tile of the sequence ordered by point index).  Forced onto
+    small meshes here — tiles that divide the sequence and tiles that do not (a partly filled last tile), tiles larger than the mesh —
+    through the whole-mesh call, the mesh-in-HBM call and the DMI_NO_FUSED kernels: the oracle's bytes every time."""
+    mesh = synth.torus_mesh(n, normals=normals, uvs=uvs, open_boundary=open_boundary)
+    want = oracle_from_product_mesh(mesh).encode()
+    monkeypatch.setenv("DMI_TILE_SORT", str(tile))
+    monkeypatch.setenv("DMI_TILE_SORT_MIN", "0")
+    _assert_same(dmi.encode_mesh(mesh), want, f"tile {tile}, grid {n}")
+    _assert_same(dmi.encode_mesh_device(dmi.DeviceMesh.upload(mesh)), want, f"tile {tile}, grid {n}, mesh in HBM")
+    monkeypatch.setenv("DMI_NO_FUSED", "1")
+    _assert_same(dmi.encode_mesh(mesh), want, f"tile {tile}, grid {n}, per-attribute kernels")
+
+
+def test_tile_sorted_gather_with_seams_and_value_maps(monkeypatch):
+    """Attributes with their own point → value maps (s2v) and seam tables under the tile-sorted gather."""
+    mesh, sess = _soup_mesh(77, n_pts=400, n_faces=1500, uv_per_corner=True)
+    want = sess.encode()
+    monkeypatch.setenv("DMI_TILE_SORT", "128")
+    monkeypatch.setenv("DMI_TILE_SORT_MIN", "0")
+    _assert_same(dmi.encode_mesh(mesh), want, "soup, tile 128")
+
+
+@pytest.mark.parametrize("n,open_boundary,normals,uvs,kw", [(40, False, True, True, {}), (150, True, False, True, {}), (90, False, True, False, dict(pos_bits=14, uv_bits=12))])
+def test_long_sequence_form_of_the_quantize_gather(n, open_boundary, normals, uvs, kw, monkeypatch):
+    """Sequences above 2^23 entries (a 100M-triangle mesh) take k_seq_quantize_big; DMI_SEQ_BIG_ENTRIES=0 sends small meshes through it."""
+    mesh = synth.torus_mesh(n, normals=normals, uvs=uvs, open_boundary=open_boundary)
+    want = oracle_from_product_mesh(mesh).encode(**kw)
+    monkeypatch.setenv("DMI_SEQ_BIG_ENTRIES", "0")
+    _assert_same(dmi.encode_mesh(mesh, dmi.Config(**kw)), want, f"long-sequence form, grid {n}")
+    jobs = dmi.meshes_prepare([mesh, mesh], dmi.Config(**kw))
+    outs = dmi.jobs_encode(jobs)
+    _assert_same(jobs[1].header_and_connectivity + outs[1], want, f"long-sequence form in a batch, grid {n}")
+    for j in jobs:
+        j.close()
