@@ -98,7 +98,7 @@ class _Conn(C.Structure):
 
 
 EXPORTS = ["dmi_encode_attributes", "dmi_encode_attributes_batch", "dmi_jobs_encode", "dmi_job_create", "dmi_job_encode", "dmi_job_timings", "dmi_job_destroy", "dmi_encode_mesh",
-           "dmi_mesh_prepare", "dmi_meshes_prepare", "dmi_shard_meshes", "dmi_meshes_prepare_devices", "dmi_jobs_encode_devices", "dmi_mesh_build", "dmi_built_mesh_free", "dmi_encode_connectivity", "dmi_conn_free", "dmi_host_rans_stream", "dmi_host_rabs_stream", "dmi_host_rabs_constant_stream", "dmi_decode_attributes", "dmi_decoded_free", "dmi_decode_mesh", "dmi_decoded_mesh_free", "dmi_decode_connectivity", "dmi_decoded_conn_free", "dmi_last_decode_timings", "dmi_free", "dmi_free_many", "dmi_strerror", "dmi_last_error", "dmi_device_count", "dmi_release_cached_memory"]
+           "dmi_mesh_prepare", "dmi_meshes_prepare", "dmi_shard_meshes", "dmi_meshes_prepare_devices", "dmi_jobs_encode_devices", "dmi_mesh_build", "dmi_built_mesh_free", "dmi_encode_connectivity", "dmi_conn_free", "dmi_host_rans_stream", "dmi_host_rabs_stream", "dmi_host_rabs_constant_stream", "dmi_tile_sort_slots", "dmi_decode_attributes", "dmi_decoded_free", "dmi_decode_mesh", "dmi_decoded_mesh_free", "dmi_decode_connectivity", "dmi_decoded_conn_free", "dmi_last_decode_timings", "dmi_free", "dmi_free_many", "dmi_strerror", "dmi_last_error", "dmi_device_count", "dmi_release_cached_memory"]
 
 
 def library_path():
@@ -167,6 +167,7 @@ def load_library():
     L.dmi_host_rans_stream.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(_Buffer)]
     L.dmi_host_rabs_stream.argtypes = [C.c_uint8, C.c_void_p, C.c_uint64, C.POINTER(_Buffer)]
     L.dmi_host_rabs_constant_stream.argtypes = [C.c_uint8, C.c_uint32, C.c_uint64, C.POINTER(_Buffer)]
+    L.dmi_tile_sort_slots.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_Config), C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -836,6 +837,17 @@ def host_rabs_stream(zero_prob, bits):
     out = _Buffer()
     _check(L.dmi_host_rabs_stream(zero_prob, b.ctypes.data, len(b), C.byref(out)))
     return _take(out)
+
+
+def tile_sort_slots(sequence_to_point, tile_entries, block_entries=16384, cfg=None):
+    """dmi_tile_sort_slots: → (slot_point, slot_entry) of the tile-sorted quantize gather."""
+    L = load_library()
+    cfg = cfg or Config.default()
+    s2p = np.ascontiguousarray(sequence_to_point, dtype=np.uint32)
+    sp, se = np.zeros(len(s2p), np.uint32), np.zeros(len(s2p), np.uint32)
+    c = cfg._c()
+    _check(L.dmi_tile_sort_slots(s2p.ctypes.data, len(s2p), tile_entries, block_entries, C.byref(c), sp.ctypes.data, se.ctypes.data))
+    return sp, se
 
 
 def host_rabs_constant_stream(zero_prob, bit, n):

@@ -229,9 +229,11 @@ void launch_last_corners(const uint32_t* c2p, uint64_t corners, uint32_t* last_c
 void launch_fill_u32(uint32_t* p, uint64_t n, uint32_t v, hipStream_t s);
 void launch_rank_scatter(const uint32_t* seq, uint32_t n_seq, const uint32_t* c2v, uint32_t* rank /* pre-filled with DMI_NONE */, hipStream_t s);
 // Tile-sorted quantize gather (job creation): slots of every 2^tile_log2-entry tile of the sequence ordered by point index; s2p_sorted[j] = the point
-// slot j reads, dest[j] = the sequence entry it writes.  tile_log2 ≤ kTileSortMaxLog2 (one workgroup sorts a tile in LDS).
+// slot j reads, dest[j] = the sequence entry it writes.  Tiles up to 2^local_log2 ≤ 2^kTileSortMaxLog2 entries are sorted by one workgroup in LDS; larger
+// ones need `scratch` (tile_sort_scratch_bytes: one 8-byte key per entry of the padded sequence) for the long strides of the network.
 constexpr uint32_t kTileSortMaxLog2 = 14;
-hipError_t launch_tile_sort(const uint32_t* s2p, uint32_t n, uint32_t tile_log2, uint32_t* s2p_sorted, uint32_t* dest, hipStream_t s);
+size_t tile_sort_scratch_bytes(uint32_t n, uint32_t tile_log2, uint32_t local_log2);
+hipError_t launch_tile_sort(const uint32_t* s2p, uint32_t n, uint32_t tile_log2, uint32_t local_log2, uint64_t* scratch, uint32_t* s2p_sorted, uint32_t* dest, hipStream_t s);
 hipError_t launch_face_order(const uint32_t* c2v, const uint32_t* rank, uint32_t F, uint32_t n_keys, uint32_t* key, uint32_t* count, uint32_t* fill, uint32_t* scan_partials,
                              uint32_t* order, uint32_t* new_face, hipStream_t s);
 void launch_remap_table(const uint32_t* c2v, const uint32_t* opp, const uint32_t* rank, const uint32_t* order, const uint32_t* new_face, uint64_t C, uint32_t* c2r_out, uint32_t* opp_out,

@@ -680,37 +680,29 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
     job->have_events = true;
   }
   // The quantize gather in tile-sorted order: inside tiles of consecutive sequence entries the slots are ordered by point index —
-  // the gather's wavefronts then read neighbouring points (−9 µs of the pass at 10M triangles).  Large single jobs only (a batch's meshes are
-  // smaller than a tile); sorted on the device (k_tile_sort).  DMI_TILE_SORT=0 switches it off, =<entries> picks the tile (a power of two up
-  // to 16384 on the device; larger tiles — the 100M-triangle experiment — by a host sort).
+  // the gather's wavefronts then read neighbouring points.  Large single jobs only (a batch's meshes are smaller than a tile); sorted on the
+  // device (launch_tile_sort: tiles of up to 16 K entries in one workgroup's LDS, larger ones with the long strides in global memory).  A tile has
+  // to span more than one ring of the coding order to pay: 16 K entries up to 2^23-entry sequences (10M triangles: ring ≈ 9 K), kTileSortBigLog2
+  // above (100M triangles: ring ≈ 28 K).  DMI_TILE_SORT=0 switches it off, =<entries> picks the tile (rounded up to a power of two).
   {
-    // (read per job creation, not once: the tests run small meshes through every form — DMI_TILE_SORT_MIN lowers the length it starts at)
+    // (read per job creation, not once: the tests run small meshes through every form — DMI_TILE_SORT_MIN lowers the length it starts at,
+    //  DMI_TILE_SORT_LOCAL the block size, so that small meshes reach the global-memory strides)
     const int env_tile = std::getenv("DMI_TILE_SORT") ? std::atoi(std::getenv("DMI_TILE_SORT")) : -1;
     const uint32_t min_entries = std::getenv("DMI_TILE_SORT_MIN") ? (uint32_t)std::atoi(std::getenv("DMI_TILE_SORT_MIN")) : kTileSortMinEntries;
-    uint32_t tile = env_tile < 0 ? (1u << kTileSortMaxLog2) : (uint32_t)env_tile;
-    if (tile && !defer) for (auto& t : job->tables) {
-      if (t.alias_of >= 0 || t.n_seq == 0 || t.n_seq < min_entries || (env_tile < 0 && t.n_seq > kTileSortMaxEntries)) continue;
-      if (tile <= (1u << kTileSortMaxLog2)) {
-        uint32_t lg = 6;
-        while ((1u << lg) < tile) ++lg;
-        if ((rc = t.s2p_sorted.alloc((size_t)t.n_seq * 4)) || (rc = t.sorted_dest.alloc((size_t)t.n_seq * 4))) return rc;
-        HIP_TRY(launch_tile_sort(t.s2p.as<uint32_t>(), t.n_seq, lg, t.s2p_sorted.as<uint32_t>(), t.sorted_dest.as<uint32_t>(), s));
-        continue;
+    uint32_t local_lg = kTileSortMaxLog2;
+    if (const char* e = std::getenv("DMI_TILE_SORT_LOCAL")) { local_lg = 6; while ((1u << local_lg) < (uint32_t)std::atoi(e) && local_lg < kTileSortMaxLog2) ++local_lg; }
+    if (env_tile != 0 && !defer) for (auto& t : job->tables) {
+      if (t.alias_of >= 0 || t.n_seq == 0 || t.n_seq < min_entries) continue;
+      uint32_t lg = t.n_seq > kTileSortMaxEntries ? kTileSortBigLog2 : kTileSortMaxLog2;
+      if (env_tile > 0) { lg = 6; while ((1u << lg) < (uint32_t)env_tile && lg < 24) ++lg; }
+      if ((rc = t.s2p_sorted.alloc((size_t)t.n_seq * 4)) || (rc = t.sorted_dest.alloc((size_t)t.n_seq * 4))) return rc;
+      const size_t scratch_bytes = tile_sort_scratch_bytes(t.n_seq, lg, local_lg);
+      uint64_t* scratch = nullptr;
+      if (scratch_bytes) {
+        scratch = tmpdev.take<uint64_t>(scratch_bytes / 8);
+        if (!scratch) return fail(DMI_ERR_OUT_OF_MEMORY, "hipMalloc (tile sort keys)");
       }
-      std::vector<uint32_t> s2p_h(t.n_seq), dest(t.n_seq), sorted(t.n_seq);
-      HIP_TRY(hipMemcpyAsync(s2p_h.data(), t.s2p.p, (size_t)t.n_seq * 4, hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipStreamSynchronize(s));
-      for (uint32_t k = 0; k < t.n_seq; ++k) dest[k] = k;
-      parallel_for((t.n_seq + tile - 1) / tile, [&](size_t lo, size_t hi) {
-        for (size_t b = lo; b < hi; ++b) {
-          const size_t a0 = b * tile, a1 = std::min<size_t>(t.n_seq, a0 + tile);
-          std::sort(dest.begin() + (long)a0, dest.begin() + (long)a1, [&](uint32_t x, uint32_t y) { return s2p_h[x] < s2p_h[y]; });
-        }
-      });
-      for (uint32_t k = 0; k < t.n_seq; ++k) sorted[k] = s2p_h[dest[k]];
-      if ((rc = upload(t.s2p_sorted, sorted.data(), (size_t)t.n_seq * 4, s))) return rc;
-      if ((rc = upload(t.sorted_dest, dest.data(), (size_t)t.n_seq * 4, s))) return rc;
-      HIP_TRY(hipStreamSynchronize(s));
+      HIP_TRY(launch_tile_sort(t.s2p.as<uint32_t>(), t.n_seq, lg, local_lg, scratch, t.s2p_sorted.as<uint32_t>(), t.sorted_dest.as<uint32_t>(), s));
     }
   }
   uint32_t bad_p2v = 0;
@@ -724,6 +716,28 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
 }
 
 extern "C" {
+int dmi_tile_sort_slots(const uint32_t* sequence_to_point, uint32_t n, uint32_t tile_entries, uint32_t block_entries, const dmi_config* cfg_in, uint32_t* slot_point, uint32_t* slot_entry) {
+  if ((!sequence_to_point || !slot_point || !slot_entry) && n) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
+  dmi_config cfg{};
+  if (cfg_in) cfg = *cfg_in;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(DMI_ERR_NO_DEVICE, "no HIP device visible; libdraco_mi has no CPU fallback");
+  HIP_TRY(hipSetDevice(cfg.device));
+  if (!n) return DMI_OK;
+  uint32_t lg = 6, local_lg = 6;
+  while ((1u << lg) < tile_entries && lg < 24) ++lg;
+  while ((1u << local_lg) < block_entries && local_lg < kTileSortMaxLog2) ++local_lg;
+  struct Dev { void* p = nullptr; ~Dev() { if (p) (void)hipFree(p); } } in, outp, outd, scratch;
+  HIP_TRY(hipMalloc(&in.p, (size_t)n * 4)); HIP_TRY(hipMalloc(&outp.p, (size_t)n * 4)); HIP_TRY(hipMalloc(&outd.p, (size_t)n * 4));
+  const size_t sb = tile_sort_scratch_bytes(n, lg, local_lg);
+  if (sb) HIP_TRY(hipMalloc(&scratch.p, sb));
+  HIP_TRY(hipMemcpy(in.p, sequence_to_point, (size_t)n * 4, hipMemcpyHostToDevice));
+  HIP_TRY(launch_tile_sort(static_cast<const uint32_t*>(in.p), n, lg, local_lg, static_cast<uint64_t*>(scratch.p), static_cast<uint32_t*>(outp.p), static_cast<uint32_t*>(outd.p), nullptr));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(slot_point, outp.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(slot_entry, outd.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  return DMI_OK;
+}
 void dmi_job_destroy(dmi_job* job) { delete job; }
 
 int dmi_job_timings(const dmi_job* job, dmi_timings* t) {

@@ -117,20 +117,29 @@ __global__ __launch_bounds__(kBlock) void k_max_u32(const uint32_t* __restrict__
 
 // ---- the tile-sorted form of the quantize gather: inside tiles of 2^tile_log2 consecutive sequence entries the slots are ordered by
 // point index, so that the lanes of a wavefront of k_seq_quantize read neighbouring points; slot j reads point out_p[j] and writes sequence
-// entry out_dest[j].  One workgroup per tile, a bitonic network over (point << 32 | position in the tile) in LDS (8 bytes per entry: 128 KB at
-// the largest tile, 16 K entries); the slots past n sort to the end and are not written.  Job creation only.
+// entry out_dest[j].  A bitonic network over (point << 32 | position in the tile).  Tiles of up to 2^local_log2 entries (16 K: 128 KB of LDS)
+// are one workgroup's: every stage in LDS.  Larger tiles (a 100M-triangle mesh wants 64–128 K entries: more than one ring of its coding
+// order) run the strides below 2^local_log2 in LDS, block by block, and the longer ones as passes over a key array in global memory:
+//   k_tile_sort_local(first)  →  for size = 2^(local+1) … 2^tile: { k_tile_merge_global per stride ≥ 2^local;  k_tile_sort_local(size) }
+// The slots past n carry the largest key, sort to the end of their tile and are not written.  Job creation only.
 constexpr uint32_t kSortThreads = 1024;
-__global__ __launch_bounds__(kSortThreads) void k_tile_sort(const uint32_t* __restrict__ s2p, uint32_t n, uint32_t tile_log2, uint32_t* __restrict__ out_p,
-                                                           uint32_t* __restrict__ out_dest) {
+// One block of 2^local_log2 entries.  first: keys are formed from s2p and the stages size = 2 … 2^local_log2 run; otherwise the keys come from
+// `keys` and only the strides below the block size of stage `size` run.  last: the results are written (out_p / out_dest), else the keys.
+__global__ __launch_bounds__(kSortThreads) void k_tile_sort_local(const uint32_t* __restrict__ s2p, uint32_t n, uint32_t local_log2, uint32_t tile_log2, uint32_t size,
+                                                                 int first, int last, uint64_t* __restrict__ keys, uint32_t* __restrict__ out_p, uint32_t* __restrict__ out_dest) {
   extern __shared__ uint64_t tile_keys[];
-  const uint32_t T = 1u << tile_log2, a0 = blockIdx.x << tile_log2;
-  for (uint32_t k = threadIdx.x; k < T; k += kSortThreads) { const uint32_t i = a0 + k; tile_keys[k] = i < n ? (((uint64_t)s2p[i] << 32) | k) : ~0ull; }
+  const uint32_t T = 1u << local_log2, a0 = blockIdx.x << local_log2, tile_mask = (1u << tile_log2) - 1u;
+  for (uint32_t k = threadIdx.x; k < T; k += kSortThreads) {
+    const uint32_t i = a0 + k;
+    tile_keys[k] = first ? (i < n ? (((uint64_t)s2p[i] << 32) | (i & tile_mask)) : ~0ull) : keys[i];
+  }
   __syncthreads();
-  for (uint32_t size = 2; size <= T; size <<= 1) {
-    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+  const uint32_t size_lo = first ? 2u : size, size_hi = first ? T : size;
+  for (uint32_t sz = size_lo; sz <= size_hi; sz <<= 1) {
+    for (uint32_t stride = min(sz >> 1, T >> 1); stride > 0; stride >>= 1) {
       for (uint32_t k = threadIdx.x; k < (T >> 1); k += kSortThreads) {
         const uint32_t lo = 2u * k - (k & (stride - 1u)), hi = lo + stride;   // pair (lo, lo + stride) of the network
-        const bool ascending = (lo & size) == 0u;
+        const bool ascending = (((a0 + lo) & tile_mask) & sz) == 0u;          // (position inside the tile: the last stage, sz = the tile, is ascending everywhere)
         const uint64_t x = tile_keys[lo], y = tile_keys[hi];
         if ((x > y) == ascending) { tile_keys[lo] = y; tile_keys[hi] = x; }
       }
@@ -139,7 +148,18 @@ __global__ __launch_bounds__(kSortThreads) void k_tile_sort(const uint32_t* __re
   }
   for (uint32_t k = threadIdx.x; k < T; k += kSortThreads) {
     const uint32_t i = a0 + k;
-    if (i < n) { const uint64_t v = tile_keys[k]; out_p[i] = (uint32_t)(v >> 32); out_dest[i] = a0 + (uint32_t)v; }
+    const uint64_t v = tile_keys[k];
+    if (!last) keys[i] = v;
+    else if (i < n) { out_p[i] = (uint32_t)(v >> 32); out_dest[i] = (i & ~tile_mask) + (uint32_t)v; }
+  }
+}
+// one pair per thread of stage `size`, stride ≥ a block: n_pad entries (a multiple of the tile)
+__global__ __launch_bounds__(kBlock) void k_tile_merge_global(uint64_t* __restrict__ keys, uint64_t n_pairs, uint32_t stride, uint32_t size, uint32_t tile_mask) {
+  for (uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x; k < n_pairs; k += (uint64_t)gridDim.x * kBlock) {
+    const uint64_t lo = 2ull * k - (k & (uint64_t)(stride - 1u)), hi = lo + stride;
+    const bool ascending = (((uint32_t)lo & tile_mask) & size) == 0u;
+    const uint64_t x = keys[lo], y = keys[hi];
+    if ((x > y) == ascending) { keys[lo] = y; keys[hi] = x; }
   }
 }
 
@@ -177,14 +197,31 @@ void launch_compose_s2v(const uint32_t* s2p, uint32_t n_seq, const uint32_t* p2v
 }
 void launch_max_u32(const uint32_t* a, uint64_t n, uint32_t* out, hipStream_t s) { if (n) hipLaunchKernelGGL(k_max_u32, std::min<uint32_t>(grid_of(n), 2048u), kBlock, 0, s, a, n, out); }
 
-hipError_t launch_tile_sort(const uint32_t* s2p, uint32_t n, uint32_t tile_log2, uint32_t* s2p_sorted, uint32_t* dest, hipStream_t s) {
+size_t tile_sort_scratch_bytes(uint32_t n, uint32_t tile_log2, uint32_t local_log2) {
+  if (tile_log2 <= local_log2) return 0;
+  const uint64_t T = 1ull << tile_log2;
+  return (size_t)(((uint64_t)n + T - 1) / T * T * 8);
+}
+hipError_t launch_tile_sort(const uint32_t* s2p, uint32_t n, uint32_t tile_log2, uint32_t local_log2, uint64_t* scratch, uint32_t* s2p_sorted, uint32_t* dest, hipStream_t s) {
   if (!n) return hipSuccess;
-  if (tile_log2 < 6 || tile_log2 > kTileSortMaxLog2) return hipErrorInvalidValue;
-  const uint32_t lds = 8u << tile_log2;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_sort), hipFuncAttributeMaxDynamicSharedMemorySize, 8 << kTileSortMaxLog2);   // 128 KB of the CU's 160
+  if (local_log2 > kTileSortMaxLog2) local_log2 = kTileSortMaxLog2;
+  if (tile_log2 < 6 || tile_log2 > 24 || local_log2 < 6) return hipErrorInvalidValue;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_sort_local), hipFuncAttributeMaxDynamicSharedMemorySize, 8 << kTileSortMaxLog2);   // 128 KB of the CU's 160
   if (attr != hipSuccess) return attr;
-  const uint32_t T = 1u << tile_log2;
-  hipLaunchKernelGGL(k_tile_sort, (n + T - 1) / T, kSortThreads, lds, s, s2p, n, tile_log2, s2p_sorted, dest);
+  if (tile_log2 <= local_log2) {   // a tile is a block
+    const uint32_t T = 1u << tile_log2;
+    hipLaunchKernelGGL(k_tile_sort_local, (n + T - 1) / T, kSortThreads, 8u << tile_log2, s, s2p, n, tile_log2, tile_log2, 0u, 1, 1, (uint64_t*)nullptr, s2p_sorted, dest);
+    return hipGetLastError();
+  }
+  if (!scratch) return hipErrorInvalidValue;
+  const uint64_t T = 1ull << tile_log2, n_pad = ((uint64_t)n + T - 1) / T * T;
+  const uint32_t B = 1u << local_log2, blocks = (uint32_t)(n_pad >> local_log2), lds = 8u << local_log2, tile_mask = (uint32_t)(T - 1);
+  hipLaunchKernelGGL(k_tile_sort_local, blocks, kSortThreads, lds, s, s2p, n, local_log2, tile_log2, 0u, 1, 0, scratch, s2p_sorted, dest);
+  for (uint32_t size = B << 1; size <= (uint32_t)T; size <<= 1) {
+    for (uint32_t stride = size >> 1; stride >= B; stride >>= 1)
+      hipLaunchKernelGGL(k_tile_merge_global, (uint32_t)std::min<uint64_t>((n_pad / 2 + kBlock - 1) / kBlock, 65535ull * 16), kBlock, 0, s, scratch, n_pad / 2, stride, size, tile_mask);
+    hipLaunchKernelGGL(k_tile_sort_local, blocks, kSortThreads, lds, s, s2p, n, local_log2, tile_log2, size, 0, size == (uint32_t)T ? 1 : 0, scratch, s2p_sorted, dest);
+  }
   return hipGetLastError();
 }
 

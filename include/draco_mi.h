@@ -244,6 +244,13 @@ int dmi_decode_attributes(const uint8_t* section, size_t len, const dmi_corner_t
                           uint32_t num_points, const dmi_config* cfg, dmi_decoded* out);
 void dmi_decoded_free(dmi_decoded* d);
 
+/* The slot order of the tile-sorted quantize gather (job creation of large meshes) on its own, for tests and tuning: inside every
+ * tile of tile_entries consecutive sequence entries (rounded up to a power of two) the slots are ordered by point index — slot j reads point
+ * slot_point[j] and writes sequence entry slot_entry[j]; block_entries = what one workgroup sorts in LDS (≤ 16384; larger tiles run their long
+ * strides in global memory).  No reference counterpart: a layout choice of this library; the bitstream does not depend on it. */
+int dmi_tile_sort_slots(const uint32_t* sequence_to_point, uint32_t n, uint32_t tile_entries, uint32_t block_entries, const dmi_config* cfg,
+                        uint32_t* slot_point, uint32_t* slot_entry);
+
 /* A whole `.drc` read back from its bytes alone (round 3): header (encode/header/mod.rs:26-54), Edgebreaker connectivity in the standard
  * traversal (the format encode/connectivity/edgebreaker.rs:458-656 writes, decoded the way every Draco-family decoder does: symbols in stored
  * order, one face per symbol glued to the open boundary, topology splits, interior start faces, attribute seams → per-attribute corner

@@ -622,6 +622,20 @@ def test_tile_sorted_quantize_gather_gives_the_same_bytes(tile, n, open_boundary
     _assert_same(dmi.encode_mesh(mesh), want, f"tile {tile}, grid {n}, per-attribute kernels")
 
 
+@pytest.mark.parametrize("tile,local", [(512, 64), (4096, 256), (2048, 1024), (65536, 128)])
+@pytest.mark.parametrize("n,open_boundary,normals,uvs", [(41, False, True, True), (150, True, False, True)])
+def test_tile_sorted_gather_with_tiles_larger_than_a_workgroup(tile, local, n, open_boundary, normals, uvs, monkeypatch):
+    """Tiles above 16 K entries (what a 100M-triangle mesh gets) run the network's long strides in global memory (k_tile_merge_global) and the
+    short ones block by block in LDS; DMI_TILE_SORT_LOCAL shrinks the block so that small meshes take that path: 1-3 global stages, a padded
+    last tile, a tile larger than the whole sequence."""
+    mesh = synth.torus_mesh(n, normals=normals, uvs=uvs, open_boundary=open_boundary)
+    want = oracle_from_product_mesh(mesh).encode()
+    monkeypatch.setenv("DMI_TILE_SORT", str(tile))
+    monkeypatch.setenv("DMI_TILE_SORT_LOCAL", str(local))
+    monkeypatch.setenv("DMI_TILE_SORT_MIN", "0")
+    _assert_same(dmi.encode_mesh(mesh), want, f"tile {tile} / block {local}, grid {n}")
+
+
 def test_tile_sorted_gather_with_seams_and_value_maps(monkeypatch):
     """Attributes with their own point → value maps (s2v) and seam tables under the tile-sorted gather."""
     mesh, sess = _soup_mesh(77, n_pts=400, n_faces=1500, uv_per_corner=True)

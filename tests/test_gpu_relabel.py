@@ -118,3 +118,20 @@ def test_out_of_range_inputs_are_error_codes_in_both_forms(monkeypatch):
         with pytest.raises(dmi.DracoMiError):
             dmi.encode_attributes(atts, [dict(t) for t in base], seeds=seeds)
     conn.close()
+
+
+@pytest.mark.parametrize("n,tile,block", [(1, 64, 64), (63, 64, 64), (64, 64, 64), (1000, 64, 64), (5000, 256, 64), (70001, 16384, 16384), (100000, 4096, 128),
+                                          (100000, 65536, 1024), (300007, 131072, 16384), (40000, 1 << 20, 256)])
+def test_tile_sort_orders_every_tile_by_point(n, tile, block):
+    """dmi_tile_sort_slots (k_tile_sort_local / k_tile_merge_global): inside every tile the slots hold the tile's points in ascending order and
+    slot_entry is the permutation that goes with it — blocks that are whole tiles, tiles of several blocks (long strides in global memory), a
+    partly filled last tile, a tile larger than the sequence."""
+    rng = np.random.default_rng(n)
+    s2p = rng.permutation(max(n, 1) * 3)[:n].astype(np.uint32)   # distinct points, as a sequence has them
+    sp, se = dmi.tile_sort_slots(s2p, tile, block)
+    t = 1 << int(np.ceil(np.log2(tile)))
+    for a0 in range(0, n, t):
+        a1 = min(n, a0 + t)
+        assert (sp[a0:a1] == np.sort(s2p[a0:a1])).all(), f"tile at {a0}"
+        assert ((se[a0:a1] >= a0) & (se[a0:a1] < a1)).all()
+    assert (s2p[se] == sp).all() and len(np.unique(se)) == n
