@@ -43,7 +43,7 @@ struct MinMaxAtt { const int32_t* ipartials; int32_t* minmax; uint32_t blocks; u
 struct MinMaxArgs { MinMaxAtt a[kMaxRangeAtts]; int count; };
 void launch_i32_minmax_final(const MinMaxArgs& args, hipStream_t s);
 constexpr uint32_t kSeqQuantizeMaxBlocks = 8192;
-constexpr uint32_t kSeqQuantizeBigEntries = 1u << 23;   // longer sequences: k_seq_quantize_big (dmi_kernels.hip)
+constexpr uint32_t kSeqQuantizeBigEntries = 1u << 24;   // longer sequences: k_seq_quantize_big (dmi_kernels.hip)
 uint32_t seq_quantize_blocks(uint32_t n);   // grid of launch_seq_quantize = partials written per attribute (≤ kSeqQuantizeMaxBlocks)
 // qs[i] = portabilize(raw[s2v ? s2v[i] : s2p[i]]) for every attribute of one corner table (s2p[i] = point_idx(seq[i])) + per-block joint i32 min/max
 // partials (ipartials: int32[2 * seq_quantize_blocks(n)]).  kind: 0 coordinate-wise, 1 octahedral, 2 ToBits.

@@ -682,8 +682,8 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
   // The quantize gather in tile-sorted order: inside tiles of consecutive sequence entries the slots are ordered by point index —
   // the gather's wavefronts then read neighbouring points.  Large single jobs only (a batch's meshes are smaller than a tile); sorted on the
   // device (launch_tile_sort: tiles of up to 16 K entries in one workgroup's LDS, larger ones with the long strides in global memory).  A tile has
-  // to span more than one ring of the coding order to pay: 16 K entries up to 2^23-entry sequences (10M triangles: ring ≈ 9 K), kTileSortBigLog2
-  // above (100M triangles: ring ≈ 28 K).  DMI_TILE_SORT=0 switches it off, =<entries> picks the tile (rounded up to a power of two).
+  // to span about two rings of the coding order to pay (below).  DMI_TILE_SORT=0 switches it off, =<entries> picks the tile (rounded up to a
+  // power of two).
   {
     // (read per job creation, not once: the tests run small meshes through every form — DMI_TILE_SORT_MIN lowers the length it starts at,
     //  DMI_TILE_SORT_LOCAL the block size, so that small meshes reach the global-memory strides)
@@ -693,7 +693,9 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
     if (const char* e = std::getenv("DMI_TILE_SORT_LOCAL")) { local_lg = 6; while ((1u << local_lg) < (uint32_t)std::atoi(e) && local_lg < kTileSortMaxLog2) ++local_lg; }
     if (env_tile != 0 && !defer) for (auto& t : job->tables) {
       if (t.alias_of >= 0 || t.n_seq == 0 || t.n_seq < min_entries) continue;
-      uint32_t lg = t.n_seq > kTileSortMaxEntries ? kTileSortBigLog2 : kTileSortMaxLog2;
+      // ≈ 2.2 rings of the coding order (a ring of a grid-like mesh is ≈ 4·√V entries), as a power of two between 16 K and 128 K — measured:
+      // 10M triangles 16 K (32 K +2 %, 64 K +7 %), 20M 32 K (128 K +6 %), 40M 32–64 K (128 K +8 %), 100M 64–128 K (256 K +9 %)
+      uint32_t lg = (uint32_t)std::min<long>(kTileSortBigLog2, std::max<long>(kTileSortMaxLog2, std::lround(std::log2(8.8 * std::sqrt((double)t.n_seq)))));
       if (env_tile > 0) { lg = 6; while ((1u << lg) < (uint32_t)env_tile && lg < 24) ++lg; }
       if ((rc = t.s2p_sorted.alloc((size_t)t.n_seq * 4)) || (rc = t.sorted_dest.alloc((size_t)t.n_seq * 4))) return rc;
       const size_t scratch_bytes = tile_sort_scratch_bytes(t.n_seq, lg, local_lg);

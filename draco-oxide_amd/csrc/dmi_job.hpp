@@ -41,8 +41,7 @@ constexpr uint32_t kPrepareStreams = 16;       // library streams their jobs are
 constexpr uint32_t kDeviceRelabelMinFaces = 1u << 20;   // job creation relabels the connectivity inputs with kernels from this size up (dmi_relabel.hip): its temporaries
                                                       // are device allocations, whose release synchronises the device — a batch of mid-sized meshes on many threads must not take it
 constexpr uint32_t kTileSortMinEntries = 1u << 18;   // sequences at least this long run their quantize gather tile-sorted (dmi_job.cpp) …
-constexpr uint32_t kTileSortMaxEntries = 1u << 23;   // … in 16 K-entry tiles up to this length (10M triangles: ring ≈ 9 K entries), in tiles of …
-constexpr uint32_t kTileSortBigLog2 = 17;             // … 2^17 entries above it (100M triangles: ring ≈ 28 K; a tile has to span more than one ring to pay)
+constexpr uint32_t kTileSortBigLog2 = 17;             // … in tiles of 2^14 … 2^17 entries, by the sequence length (dmi_job.cpp)
 constexpr uint64_t kHostChainMinSymbols = 32768;   // a job whose longest stream is at least this long codes its streams on host cores (hybrid form)
 // Device memory of one job comes from a few large chunks (DevPool) instead of one hipMalloc per buffer: job creation for a batch
 // of meshes runs on many host threads, and ≈ 70 allocations + ≈ 20 memsets per job serialise on the runtime (17 ms of

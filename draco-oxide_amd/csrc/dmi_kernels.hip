@@ -1771,7 +1771,7 @@ DMI_KERNEL(k_value_ranges_final, k_value_ranges_final_body, RangeArgs, kBlock)
 #define DMI_SEQ_OCC __attribute__((amdgpu_waves_per_eu(8, 8)))
 #endif
 DMI_KERNEL2(k_seq_quantize, k_seq_quantize_body<DMI_KTILE_SINGLE>, k_seq_quantize_body<DMI_KTILE_MULTI>, SeqQuantArgs, kBlock, DMI_SEQ_OCC)
-// … and sequences above kSeqQuantizeBigEntries (a 100M-triangle mesh: the gather is bound by what survives in L2 between rings, and fewer
+// … and sequences above kSeqQuantizeBigEntries = 2^24 (a 100M-triangle mesh: the gather is bound by what survives in L2 between rings, and fewer
 // lines in flight keep more of it) take two entries per thread at the compiler's own 7 waves: 100M triangles 1.75–1.93 ms against 2.27
 DMI_KERNEL(k_seq_quantize_big, k_seq_quantize_body<2>, SeqQuantArgs, kBlock)
 DMI_KERNEL(k_i32_minmax_final, k_i32_minmax_final_body, MinMaxArgs, kBlock)
