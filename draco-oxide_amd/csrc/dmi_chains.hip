@@ -257,31 +257,69 @@ __device__ void k_tables_body(const TableAtt& a, const uint32_t, const uint32_t)
         uint32_t fr[kKeep];
 #pragma unroll
         for (uint32_t j = 0; j < kKeep; ++j) { const uint32_t s = tid + j * T; fr[j] = (kept && s < num_symbols) ? freq[s] : 0u; }
-        auto count_if = [&](auto&& pred) -> uint64_t {   // #(s < num_symbols : pred(freq[s], s)) over the block
-          uint64_t c = 0;
-          if (kept) {
+        // Both quantities are order statistics: thr = the excess-th largest frequency, ilo = the need-th largest INDEX among the entries equal to
+        // thr.  Each is selected by its digits, 8 bits at a time from the top (three sweeps for keys below 2^24): a sweep counts the candidates'
+        // current digit into 256 LDS bins, one thread walks the bins from the top to the one that holds the k-th, the candidates narrow to it.
+        // (Rounds 2–3a bisected both: ≈ 30 block reductions, half of this kernel's 62 µs.)
+        uint32_t* sel_hist = lds.stage;          // 256 bins (the orientation summaries use the array later)
+        uint32_t* sel_out = lds.stage + 256;     // [0] the digit chosen, [1] how many of the k are still to be found inside it
+        auto select_kth_largest = [&](auto&& key_of, uint32_t k, uint32_t& remaining_out) -> uint32_t {   // key_of(f, s, ok): the entry's key, ok = it takes part
+          uint32_t prefix_bits = 0, remaining = k;
+          for (int shift = 16; shift >= 0; shift -= 8) {
+            for (uint32_t b = tid; b < 256u; b += T) sel_hist[b] = 0u;
+            __syncthreads();
+            const uint32_t hi_mask = shift == 16 ? 0u : (0xFFFFFFFFu << (shift + 8));   // the digits already fixed
+            // (frequencies pile up on a few digits: the lanes of a wavefront that share a digit send ONE LDS atomic — a 1024-thread block adding
+            //  to one bin entry by entry is ≈ 14 µs a sweep)
+            auto visit = [&](uint32_t f, uint32_t s2, bool in_range) {
+              bool ok = in_range;
+              const uint32_t key = key_of(f, s2, ok);
+              bool todo = in_range && ok && (key & hi_mask) == (prefix_bits & hi_mask);
+              const uint32_t digit = (key >> shift) & 255u;
+              for (unsigned long long m = __ballot(todo); m; m = __ballot(todo)) {
+                const uint32_t d0 = (uint32_t)__shfl((int)digit, __ffsll((long long)m) - 1, 64);
+                const unsigned long long same = __ballot(todo && digit == d0);
+                if ((tid & 63u) == (uint32_t)(__ffsll((long long)same) - 1)) atomicAdd(&sel_hist[d0], (uint32_t)__popcll(same));
+                if (digit == d0) todo = false;
+              }
+            };
+            if (kept) {
 #pragma unroll
-            for (uint32_t j = 0; j < kKeep; ++j) { const uint32_t s = tid + j * T; c += (s < num_symbols && pred(fr[j], s)) ? 1u : 0u; }
-          } else {
-            for (uint32_t s = tid; s < num_symbols; s += T) c += pred(freq[s], s) ? 1u : 0u;
+              for (uint32_t j = 0; j < kKeep; ++j) { const uint32_t s2 = tid + j * T; visit(fr[j], s2, s2 < num_symbols); }
+            } else {
+              for (uint32_t base = 0; base < num_symbols; base += T) { const uint32_t s2 = base + tid; visit(s2 < num_symbols ? freq[s2] : 0u, s2, s2 < num_symbols); }
+            }
+            __syncthreads();
+            if (tid < 64u) {   // the bin that holds the k-th from the top: lane l owns bins 4l … 4l + 3, a suffix sum over the lanes finds the group
+              const uint32_t c0 = sel_hist[4u * tid], c1 = sel_hist[4u * tid + 1u], c2 = sel_hist[4u * tid + 2u], c3 = sel_hist[4u * tid + 3u];
+              const uint32_t g = c0 + c1 + c2 + c3;
+              uint32_t suf = g;
+#pragma unroll
+              for (int d = 1; d < 64; d <<= 1) { const uint32_t t = (uint32_t)__shfl_down((int)suf, d, 64); if (tid + (uint32_t)d < 64u) suf += t; }
+              const uint32_t above = suf - g, left = remaining;
+              if (tid == 0 && suf < left) { sel_out[0] = 0u; sel_out[1] = left - above; }   // (fewer candidates than k: cannot happen for the two uses below)
+              if (above < left && left <= suf) {
+                uint32_t rem = left - above, d = 4u * tid + 3u;
+                if (c3 < rem) { rem -= c3; --d; if (c2 < rem) { rem -= c2; --d; if (c1 < rem) { rem -= c1; --d; } } }
+                sel_out[0] = d; sel_out[1] = rem;
+              }
+            }
+            __syncthreads();
+            prefix_bits |= sel_out[0] << shift;
+            remaining = sel_out[1];
+            __syncthreads();
           }
-          return block_sum(c, lds.red);
+          remaining_out = remaining;
+          return prefix_bits;
         };
-        uint32_t lo = 0, hi = (uint32_t)target;
-        while (lo < hi) {   // largest T with #(freq ≥ T) ≥ excess
-          const uint32_t mid = lo + (hi - lo + 1u) / 2u;
-          if (count_if([&](uint32_t f, uint32_t) { return f >= mid; }) >= excess) lo = mid; else hi = mid - 1u;
-        }
-        const uint32_t thr = lo;
+        // (frequencies are at most 2^precision ≤ 2^20 and indices below 2^21: 24-bit keys)
+        uint32_t need32 = 0;
+        const uint32_t thr = select_kth_largest([&](uint32_t f, uint32_t, bool&) { return f; }, (uint32_t)excess, need32);
         if (thr == 0) err = 3;   // a zero would be decremented
         if (!err) {
-          const uint64_t above = count_if([&](uint32_t f, uint32_t) { return f > thr; });
-          const uint64_t need = excess - above;   // ≥ 1 entries equal to thr, from the highest index down
-          uint32_t ilo = 0, ihi = num_symbols - 1u;
-          while (ilo < ihi) {   // largest I with #(freq == thr, index ≥ I) ≥ need
-            const uint32_t mid = ilo + (ihi - ilo + 1u) / 2u;
-            if (count_if([&](uint32_t f, uint32_t s) { return f == thr && s >= mid; }) >= need) ilo = mid; else ihi = mid - 1u;
-          }
+          // need32 = excess − #(freq > thr): that many entries equal to thr lose one, from the highest index down
+          uint32_t unused = 0;
+          const uint32_t ilo = select_kth_largest([&](uint32_t f, uint32_t s2, bool& ok) { ok = f == thr; return s2; }, need32, unused);
           __syncthreads();
           for (uint32_t s = tid; s < num_symbols; s += T) { const uint32_t f = freq[s]; if (f > thr || (f == thr && s >= ilo)) freq[s] = f - 1u; }
         }
