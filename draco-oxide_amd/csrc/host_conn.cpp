@@ -775,7 +775,14 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
         for (size_t j = 0; j < A; ++j) zacc[j].fetch_add(z[j]);
       });
       for (size_t j = 0; j < A; ++j) zeros[j] = zacc[j].load();
-    } else if (A) {   // small meshes, and a face processed twice (malformed tables): the reference's loop as it stands
+    } else if (A && own.empty() && [&] {   // a small mesh without seams: only the stream length — every face processed once ⇒ the interior-edge count
+                 std::vector<uint8_t> seen(t.F, 0);
+                 for (size_t i = 0; i < n; ++i) { uint8_t& f = seen[processed[i] / 3]; if (f) return false; f = 1; }
+                 return true;
+               }()) {
+      if (t.no_boundary) total = (uint64_t)t.F * 3 / 2;
+      else { uint64_t k = 0; for (size_t c = 0; c < (size_t)t.F * 3; ++c) k += t.opp[c] != kNone; total = k / 2; }
+    } else if (A) {   // small meshes with seams, and a face processed twice (malformed tables): the reference's loop as it stands
       std::vector<uint8_t> fv(t.F, 0);
       std::vector<std::vector<uint8_t>> seams(A);
       for (size_t i = n; i-- > 0;) {
