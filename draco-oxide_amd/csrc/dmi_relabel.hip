@@ -206,7 +206,8 @@ hipError_t launch_tile_sort(const uint32_t* s2p, uint32_t n, uint32_t tile_log2,
   if (!n) return hipSuccess;
   if (local_log2 > kTileSortMaxLog2) local_log2 = kTileSortMaxLog2;
   if (tile_log2 < 6 || tile_log2 > 24 || local_log2 < 6) return hipErrorInvalidValue;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_sort_local), hipFuncAttributeMaxDynamicSharedMemorySize, 8 << kTileSortMaxLog2);   // 128 KB of the CU's 160
+  // 128 KB of the CU's 160 (set on every call: the attribute belongs to the current device, and a process may drive several)
+  const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_sort_local), hipFuncAttributeMaxDynamicSharedMemorySize, 8 << kTileSortMaxLog2);
   if (attr != hipSuccess) return attr;
   if (tile_log2 <= local_log2) {   // a tile is a block
     const uint32_t T = 1u << tile_log2;
