@@ -205,3 +205,26 @@ def test_product_decoder_survives_mutated_sections():
         except dmi.DracoMiError:
             outcomes[1] += 1
     assert outcomes[1] > 50, outcomes
+
+
+def test_product_decoder_with_vertices_no_corner_names():
+    """The entropy decoders start beside the traversals with the table's vertex count as their entry count; a table that carries a vertex no
+    corner names (the caller's tables may) has fewer entries, and those attributes are decoded again with the traversal's count: same values."""
+    mesh = synth.torus_mesh(24)
+    job = dmi.mesh_prepare(mesh)
+    section = job.encode()
+    job.close()
+    want, tables = _decode_with_product(mesh, section, want_tables=True)
+    conn = dmi.encode_connectivity(mesh)
+    seeds = conn.seeds()
+    conn.close()
+    padded = []
+    for t in tables:
+        t = dict(t)
+        t["sequence"] = None   # (let the decoder traverse)
+        t["num_vertices"] = t["num_vertices"] + 3
+        t["left_most_corner"] = np.concatenate([t["left_most_corner"], np.zeros(3, np.uint32)])
+        padded.append(t)
+    got = dmi.decode_attributes(section, padded, mesh.attributes[0].num_points, seeds=seeds)
+    for g, w in zip(got, want):
+        assert (g["values"].view(np.uint32) == w["values"].view(np.uint32)).all()
