@@ -74,6 +74,20 @@ class _BuiltMesh(C.Structure):
     _fields_ = [("mesh", _Mesh), ("owner", C.c_void_p)]
 
 
+class _RawAccessor(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("count", C.c_uint32), ("byte_stride", C.c_uint32), ("component_type", C.c_uint8), ("num_components", C.c_uint8),
+                ("att_type", C.c_uint8), ("domain", C.c_uint8), ("num_parents", C.c_uint32), ("parents", C.c_void_p)]
+
+
+class _RawMesh(C.Structure):
+    _fields_ = [("atts", C.POINTER(_RawAccessor)), ("n_atts", C.c_uint32), ("indices", C.c_void_p), ("index_type", C.c_uint8), ("num_faces", C.c_uint32)]
+
+
+class _BuildTimings(C.Structure):
+    _fields_ = [("pack_ms", C.c_float), ("kernels_ms", C.c_float), ("call_ms", C.c_float), ("device_meshes", C.c_uint32), ("host_meshes", C.c_uint32),
+                ("bytes_up", C.c_uint64), ("bytes_down", C.c_uint64)]
+
+
 class _DecodedAttribute(C.Structure):
     _fields_ = [("att_type", C.c_uint8), ("component_type", C.c_uint8), ("num_components", C.c_uint8), ("domain", C.c_uint8),
                 ("scheme", C.c_uint8), ("transform", C.c_uint8), ("portabilization", C.c_uint8), ("bits", C.c_uint8),
@@ -98,7 +112,8 @@ class _Conn(C.Structure):
 
 
 EXPORTS = ["dmi_encode_attributes", "dmi_encode_attributes_batch", "dmi_jobs_encode", "dmi_job_create", "dmi_job_encode", "dmi_job_timings", "dmi_job_destroy", "dmi_encode_mesh",
-           "dmi_mesh_prepare", "dmi_meshes_prepare", "dmi_shard_meshes", "dmi_meshes_prepare_devices", "dmi_jobs_encode_devices", "dmi_mesh_build", "dmi_built_mesh_free", "dmi_encode_connectivity", "dmi_conn_free", "dmi_host_rans_stream", "dmi_host_rabs_stream", "dmi_host_rabs_constant_stream", "dmi_tile_sort_slots", "dmi_decode_attributes", "dmi_decoded_free", "dmi_decode_mesh", "dmi_decoded_mesh_free", "dmi_decode_connectivity", "dmi_decoded_conn_free", "dmi_last_decode_timings", "dmi_free", "dmi_free_many", "dmi_strerror", "dmi_last_error", "dmi_device_count", "dmi_release_cached_memory"]
+           "dmi_mesh_prepare", "dmi_meshes_prepare", "dmi_shard_meshes", "dmi_meshes_prepare_devices", "dmi_jobs_encode_devices", "dmi_mesh_build", "dmi_built_mesh_free", "dmi_encode_connectivity", "dmi_conn_free", "dmi_host_rans_stream", "dmi_host_rabs_stream", "dmi_host_rabs_constant_stream", "dmi_tile_sort_slots", "dmi_decode_attributes", "dmi_decoded_free", "dmi_decode_mesh", "dmi_decoded_mesh_free", "dmi_decode_connectivity", "dmi_decoded_conn_free", "dmi_last_decode_timings", "dmi_free", "dmi_free_many", "dmi_strerror", "dmi_last_error", "dmi_device_count", "dmi_release_cached_memory",
+           "dmi_init", "dmi_last_call_timings", "dmi_device_corner_table", "dmi_encode_mesh_device", "dmi_meshes_build", "dmi_built_meshes_prepare", "dmi_last_build_timings"]
 
 
 def library_path():
@@ -117,7 +132,7 @@ def load_library():
         return _lib
     # PyTorch-ROCm wheels bundle their own HIP / HSA runtime; a process that loads the system runtime first (through libdraco_mi.so) and
     # torch's second ends up with two of them, and the second finds no GPU.  With torch imported first there is one runtime for both.
-    if "torch" not in sys.modules:
+    if "torch" not in sys.modules and not os.environ.get("DMI_NO_TORCH_PREIMPORT") and "asan" not in os.path.basename(_LIB):
         try:
             import torch  # noqa: F401
         except ImportError:
@@ -168,6 +183,10 @@ def load_library():
     L.dmi_host_rabs_stream.argtypes = [C.c_uint8, C.c_void_p, C.c_uint64, C.POINTER(_Buffer)]
     L.dmi_host_rabs_constant_stream.argtypes = [C.c_uint8, C.c_uint32, C.c_uint64, C.POINTER(_Buffer)]
     L.dmi_tile_sort_slots.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_Config), C.c_void_p, C.c_void_p]
+    L.dmi_init.argtypes = [C.c_int, C.c_size_t, C.c_size_t]
+    L.dmi_meshes_build.argtypes = [C.POINTER(_RawMesh), C.c_uint32, C.POINTER(_Config), C.c_uint32, C.POINTER(_BuiltMesh)]
+    L.dmi_built_meshes_prepare.argtypes = [C.POINTER(_BuiltMesh), C.c_uint32, C.POINTER(_Config), C.POINTER(_Buffer), C.POINTER(C.c_void_p)]
+    L.dmi_last_build_timings.argtypes = [C.POINTER(_BuildTimings)]
     _lib = L
     return L
 
@@ -368,6 +387,142 @@ class MeshBuilder:
             parent = id_to_index[a["parents"][0]] if a["parents"] else -1
             out.append(Attribute(a["values"], a["type"], a["domain"], unique_id=a["id"], parent_index=parent, point_to_value=a["p2v"], num_points=a["npoints"]))
         return Mesh(faces, out)
+
+
+BUILD_HOST_VALUES = 1
+_NP_CT = {np.dtype(np.float32): F32, np.dtype(np.uint32): U32, np.dtype(np.int32): I32}
+_CT_NP = {F32: np.float32, U32: np.uint32, I32: np.int32}
+_INDEX_CT = {np.dtype(np.uint8): 1, np.dtype(np.uint16): 3, np.dtype(np.uint32): 5}
+
+
+class RawMesh:
+    """What MeshBuilder collects for one primitive, WITHOUT copying: views of the accessors' bytes (io/gltf/decode.rs:2328-2525 hands
+    these to MeshBuilder::add_attribute).  `rows`: 2-D array of float32 / uint32 / int32 whose rows may be strided (a glTF bufferView
+    with a byteStride); `indices`: contiguous uint8 / uint16 / uint32, 3 per face."""
+
+    def __init__(self):
+        self.atts = []
+        self.indices = None
+
+    def add_attribute(self, rows, att_type, domain=DOMAIN_POSITION, parents=()):
+        r = rows if rows.ndim == 2 else rows.reshape(-1, 1)
+        if r.dtype not in _NP_CT or (r.shape[1] > 1 and r.strides[1] != 4):
+            raise TypeError("attribute rows must be float32 / uint32 / int32 with contiguous components")
+        self.atts.append((r, att_type, domain, np.ascontiguousarray(parents, dtype=np.uint32)))
+        return len(self.atts) - 1
+
+    def set_indices(self, idx):
+        i = np.ascontiguousarray(idx).reshape(-1)
+        if i.dtype not in _INDEX_CT:
+            i = i.astype(np.uint32)
+        self.indices = i[: len(i) // 3 * 3]
+
+
+class BuiltBatch:
+    """The meshes of one dmi_meshes_build call (library-owned; `free()` / context manager releases them).  `mesh(j)` copies mesh j into
+    a host `Mesh` (needs host_values=True at build time); `summary(j)` = (num_faces, num_points, [unique ids in slot order])."""
+
+    def __init__(self, arr, n, keep):
+        self._arr, self._n, self._keep = arr, n, keep
+
+    def __len__(self):
+        return self._n
+
+    def num_faces(self, j):
+        return int(self._arr[j].mesh.num_faces)
+
+    def summary(self, j):
+        m = self._arr[j].mesh
+        return int(m.num_faces), int(m.atts[0].num_points) if m.num_atts else 0, [int(m.atts[i].unique_id) for i in range(m.num_atts)]
+
+    def mesh(self, j):
+        m = self._arr[j].mesh
+        faces = np.ctypeslib.as_array(C.cast(m.faces, C.POINTER(C.c_uint32)), shape=(m.num_faces, 3)).copy() if m.num_faces else np.zeros((0, 3), np.uint32)
+        out = []
+        for i in range(m.num_atts):
+            a = m.atts[i]
+            if a.num_unique and not a.values:
+                raise ValueError("the values of this batch stayed on the device (build with host_values=True to copy meshes out)")
+            dt = _CT_NP[a.component_type]
+            vals = (np.frombuffer(C.string_at(a.values, a.num_unique * a.num_components * 4), dtype=dt).reshape(a.num_unique, a.num_components).copy()
+                    if a.num_unique else np.zeros((0, a.num_components), dt))
+            p2v = np.frombuffer(C.string_at(a.point_to_value, a.num_points * 4), dtype=np.uint32).copy() if a.point_to_value else None
+            out.append(Attribute(vals, a.att_type, a.domain, unique_id=a.unique_id, parent_index=a.parent_index, point_to_value=p2v, num_points=a.num_points))
+        return Mesh(faces, out)
+
+    def free(self):
+        if self._n:
+            L = load_library()
+            for j in range(self._n):
+                L.dmi_built_mesh_free(C.byref(self._arr[j]))
+        self._n = 0
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.free()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def meshes_build(raw_meshes, cfg=None, host_values=False):
+    """dmi_meshes_build: MeshBuilder::build for a list of RawMesh on the device → BuiltBatch."""
+    L = load_library()
+    cfg = cfg or Config.default()
+    n = len(raw_meshes)
+    if n == 0:
+        return BuiltBatch(None, 0, None)
+    arr = (_RawMesh * n)()
+    keep = []
+    for j, rm in enumerate(raw_meshes):
+        acc = (_RawAccessor * max(len(rm.atts), 1))()
+        for i, (r, att_type, domain, par) in enumerate(rm.atts):
+            acc[i].data = r.ctypes.data
+            acc[i].count = r.shape[0]
+            acc[i].byte_stride = r.strides[0] if r.shape[0] > 1 else 0
+            acc[i].component_type, acc[i].num_components, acc[i].att_type, acc[i].domain = _NP_CT[r.dtype], r.shape[1], att_type, domain
+            acc[i].num_parents = len(par)
+            acc[i].parents = par.ctypes.data if len(par) else None
+        idx = rm.indices if rm.indices is not None else np.zeros(0, np.uint32)
+        arr[j].atts, arr[j].n_atts = acc, len(rm.atts)
+        arr[j].indices = idx.ctypes.data if len(idx) else None
+        arr[j].index_type = _INDEX_CT[idx.dtype]
+        arr[j].num_faces = len(idx) // 3
+        keep.append((acc, idx, rm))
+    built = (_BuiltMesh * n)()
+    c = cfg._c()
+    _check(L.dmi_meshes_build(arr, n, C.byref(c), BUILD_HOST_VALUES if host_values else 0, built))
+    return BuiltBatch(built, n, keep)
+
+
+def last_build_timings():
+    t = _BuildTimings()
+    _check(load_library().dmi_last_build_timings(C.byref(t)))
+    return {k: getattr(t, k) for k, _ in _BuildTimings._fields_}
+
+
+def built_meshes_prepare(batch, which=None, cfg=None):
+    """dmi_built_meshes_prepare: the connectivity stage + job creation for meshes a BuiltBatch holds on the device (all of them, or the
+    indices `which`) — nothing is uploaded again.  Returns the Jobs in that order."""
+    L = load_library()
+    cfg = cfg or Config.default()
+    which = list(range(len(batch))) if which is None else list(which)
+    n = len(which)
+    if n == 0:
+        return []
+    arr = (_BuiltMesh * n)()
+    for k, j in enumerate(which):
+        arr[k] = batch._arr[j]
+    c = cfg._c()
+    heads = (_Buffer * n)()
+    handles = (C.c_void_p * n)()
+    _check(L.dmi_built_meshes_prepare(arr, n, C.byref(c), heads, handles))
+    return [Job(handles[i], _take(heads[i])) for i in range(n)]
 
 
 class Config:
@@ -634,7 +789,6 @@ def meshes_prepare(meshes, cfg=None):
 def init(device=0, staging_bytes=0, device_bytes=0):
     """dmi_init: pay the process's one-time costs for `device` now (context, code objects, stream, optional staging / device pool)."""
     L = load_library()
-    L.dmi_init.argtypes = [C.c_int, C.c_size_t, C.c_size_t]
     _check(L.dmi_init(device, staging_bytes, device_bytes))
 
 

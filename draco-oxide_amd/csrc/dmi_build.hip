@@ -1,0 +1,328 @@
+// dmi_build.hip — MeshBuilder::build on the device (gfx950, wave64), ONE launch per kernel for all meshes of a batch.
+//
+// Reference stages (paths relative to draco-oxide/src/):
+//   value dedup     core/attribute/mod.rs:394-452   Attribute::from — pairwise `==`, duplicates map to their FIRST occurrence, ids compacted
+//                                                   in first-occurrence order; f32 `==` classes (-0.0 == 0.0, a row holding a NaN equals
+//                                                   nothing: macros/.../lib.rs:167-175)
+//   point merge     core/mesh/builder.rs:194-279    points that agree in EVERY attribute's value id are one point (first occurrence kept)
+//   degenerate      core/mesh/builder.rs:77-79      faces with a repeated point id are dropped
+//   unused points   core/mesh/builder.rs:129-189    points no face references are removed, faces renumbered; a value that loses its last
+//                                                   point leaves the buffer (Attribute::remove, mod.rs:454-483), order preserved
+// The reference's builders are O(V²) scans; what they compute is order statistics of equivalence classes: "first occurrence" = the
+// smallest index of a class, "rank" = a prefix sum over first-occurrence flags.  Here every class is found with an open-addressing hash
+// table whose slots hold a ROW INDEX: inserting row p either claims an empty slot, or meets a slot whose row compares equal — then the slot
+// keeps the smaller of the two indices (atomicMin) — or probes on.  Whatever the interleaving, a slot ends up holding the smallest index of
+// its class, so the result does not depend on scheduling.  Ranks are exclusive scans; compactions are scatters at scanned offsets.
+// Covered class: every attribute of a mesh has the same point count, rows of 1–4 four-byte components, faces index existing points, at least
+// one face survives.  Anything else is FLAGGED and the host builder (host_mesh.cpp) takes that mesh — nothing is approximated here.
+#include "dmi_device.hpp"
+#include <algorithm>
+
+namespace dmi {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr uint32_t kNoneD = 0xFFFFFFFFu;
+
+inline uint32_t grid_of(uint64_t n) {
+  const uint64_t g = (n + kBlock - 1) / kBlock;
+  return (uint32_t)(g > 65535ull * 32 ? 65535ull * 32 : (g ? g : 1));
+}
+// the last entry whose offset is ≤ x (offsets ascending)
+template <class Get>
+__device__ __forceinline__ uint32_t find_last(uint32_t n, uint32_t x, Get off) {
+  uint32_t lo = 0, hi = n;
+  while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (off(mid) <= x) lo = mid; else hi = mid; }
+  return lo;
+}
+__device__ __forceinline__ uint32_t mesh_of_face(const MbArgs& a, uint32_t f) { return a.M == 1 ? 0u : find_last(a.M, f, [&](uint32_t k) { return a.meshes[k].face_off; }); }
+__device__ __forceinline__ uint32_t mesh_of_point(const MbArgs& a, uint32_t p) { return a.M == 1 ? 0u : find_last(a.M, p, [&](uint32_t k) { return a.meshes[k].point_off; }); }
+__device__ __forceinline__ uint32_t item_of(const MbArgs& a, uint32_t ap) { return a.n_items == 1 ? 0u : find_last(a.n_items, ap, [&](uint32_t k) { return a.items[k].ap_off; }); }
+
+__device__ __forceinline__ uint32_t wave_inclusive(uint32_t v) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const uint32_t u = __shfl_up(v, off, 64); if ((int)(threadIdx.x & 63) >= off) v += u; }
+  return v;
+}
+__device__ __forceinline__ uint32_t block_exclusive(uint32_t v, uint32_t* total) {
+  __shared__ uint32_t wsum[kBlock / 64 + 1];
+  const uint32_t inc = wave_inclusive(v);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w) { if (w < wave) base += wsum[w]; all += wsum[w]; }
+  if (total) *total = all;
+  return base + inc - v;
+}
+__device__ __forceinline__ void raise(MbMeshOut* out, uint32_t m, uint32_t bit) {
+  if (!(__atomic_load_n(&out[m].flags, __ATOMIC_RELAXED) & bit)) atomicOr(&out[m].flags, bit);
+}
+__device__ __forceinline__ uint32_t mix(uint32_t h, uint32_t w) {
+  h ^= w;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  return h ^ (h >> 16);
+}
+// `==` on f32 bit patterns once NaN rows are out of the way: equal bits, or both zeros (-0.0 == 0.0) — a zero of either sign becomes +0
+__device__ __forceinline__ uint32_t canon(uint32_t w, bool is_float) { return (is_float && (w << 1) == 0u) ? 0u : w; }
+__device__ __forceinline__ bool is_nan_bits(uint32_t w) { return (w & 0x7FFFFFFFu) > 0x7F800000u; }
+
+// ---- faces: index range, largest referenced point per mesh (num_vertices = max + 1, builder.rs:196-199) ----
+__global__ __launch_bounds__(kBlock) void k_mb_face_range(const MbArgs a) {
+  const uint64_t C = 3ull * a.total_faces;
+  for (uint64_t c = (uint64_t)blockIdx.x * kBlock + threadIdx.x; c < C; c += (uint64_t)gridDim.x * kBlock) {
+    const uint32_t m = mesh_of_face(a, (uint32_t)(c / 3u));
+    const uint32_t p = a.raw_faces[c];
+    if (p >= a.meshes[m].P) { raise(a.mesh_out, m, MB_BAD_INDEX); continue; }
+    if (__atomic_load_n(&a.mesh_out[m].nv, __ATOMIC_RELAXED) < p + 1) atomicMax(&a.mesh_out[m].nv, p + 1);
+  }
+}
+
+// ---- value classes per attribute ----
+__global__ __launch_bounds__(kBlock) void k_mb_value_insert(const MbArgs a) {
+  for (uint32_t ap = blockIdx.x * kBlock + threadIdx.x; ap < a.total_ap; ap += gridDim.x * kBlock) {
+    const MbItem it = a.items[item_of(a, ap)];
+    const uint32_t p = ap - it.ap_off;
+    const uint32_t* __restrict__ rows = a.raw_values + it.row_off;
+    const bool fl = it.is_float != 0;
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    bool nan = false;
+    uint32_t h = 0x9E3779B9u;
+    for (uint32_t k = 0; k < it.words; ++k) {
+      const uint32_t x = rows[(size_t)p * it.words + k];
+      nan = nan || (fl && is_nan_bits(x));
+      w[k] = canon(x, fl);
+      h = mix(h, w[k]);
+    }
+    if (nan) { a.vslot[ap] = kNoneD; continue; }   // equals nothing, not even itself: a class of its own
+    uint32_t* __restrict__ tab = a.vtab + it.tab_off;
+    h &= it.tab_mask;
+    for (;;) {
+      uint32_t s = __atomic_load_n(&tab[h], __ATOMIC_RELAXED);
+      if (s == kNoneD) {
+        s = atomicCAS(&tab[h], kNoneD, p);
+        if (s == kNoneD) break;
+      }
+      bool same = true;   // (s may be lowered meanwhile by another member of ITS class: every index a slot ever holds is of one class)
+      for (uint32_t k = 0; k < it.words; ++k) same = same && canon(rows[(size_t)s * it.words + k], fl) == w[k];
+      if (same) { if (p < s) atomicMin(&tab[h], p); break; }
+      h = (h + 1) & it.tab_mask;
+    }
+    a.vslot[ap] = h;
+  }
+}
+// representative (first occurrence) of every row; first-occurrence flags for the rank scan
+__global__ __launch_bounds__(kBlock) void k_mb_value_first(const MbArgs a) {
+  for (uint32_t ap = blockIdx.x * kBlock + threadIdx.x; ap < a.total_ap; ap += gridDim.x * kBlock) {
+    const MbItem& it = a.items[item_of(a, ap)];
+    const uint32_t p = ap - it.ap_off, s = a.vslot[ap];
+    const uint32_t rep = s == kNoneD ? p : a.vtab[it.tab_off + s];
+    a.vid[ap] = rep;
+    a.vflag[ap] = rep == p ? 1u : 0u;
+  }
+}
+// value id = rank of the representative among the first occurrences (mod.rs:426-443); vfirst[id] = the point that carries the value
+__global__ __launch_bounds__(kBlock) void k_mb_value_ids(const MbArgs a) {
+  for (uint32_t ap = blockIdx.x * kBlock + threadIdx.x; ap < a.total_ap; ap += gridDim.x * kBlock) {
+    const MbItem& it = a.items[item_of(a, ap)];
+    const uint32_t p = ap - it.ap_off, rep = a.vid[ap];
+    const uint32_t id = a.vflag[it.ap_off + rep] - a.vflag[it.ap_off];
+    a.vid[ap] = id;
+    if (rep == p) a.vfirst[it.ap_off + id] = p;
+  }
+}
+
+// ---- point classes: the tuple of value ids (builder.rs:254-279 hashes the unique values' bytes at the point — the same classes) ----
+constexpr int kMaxKey = 8;   // attributes per mesh the device form takes (MB_MAX_ATTS)
+__global__ __launch_bounds__(kBlock) void k_mb_point_insert(const MbArgs a) {
+  for (uint32_t gp = blockIdx.x * kBlock + threadIdx.x; gp < a.total_points; gp += gridDim.x * kBlock) {
+    const MbMesh me = a.meshes[mesh_of_point(a, gp)];
+    const uint32_t p = gp - me.point_off;
+    a.pslot[gp] = kNoneD;
+    if (p >= a.mesh_out[me.index].nv) continue;   // points past the largest referenced one take no part (builder.rs:200, :258)
+    uint32_t key[kMaxKey];
+    uint32_t h = 0x9E3779B9u;
+    for (uint32_t k = 0; k < me.n_items; ++k) { key[k] = a.vid[a.items[me.item0 + k].ap_off + p]; h = mix(h, key[k]); }
+    uint32_t* __restrict__ tab = a.ptab + me.ptab_off;
+    h &= me.ptab_mask;
+    for (;;) {
+      uint32_t s = __atomic_load_n(&tab[h], __ATOMIC_RELAXED);
+      if (s == kNoneD) {
+        s = atomicCAS(&tab[h], kNoneD, p);
+        if (s == kNoneD) break;
+      }
+      bool same = true;
+      for (uint32_t k = 0; k < me.n_items; ++k) same = same && a.vid[a.items[me.item0 + k].ap_off + s] == key[k];
+      if (same) { if (p < s) atomicMin(&tab[h], p); break; }
+      h = (h + 1) & me.ptab_mask;
+    }
+    a.pslot[gp] = h;
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_mb_point_first(const MbArgs a) {
+  for (uint32_t gp = blockIdx.x * kBlock + threadIdx.x; gp < a.total_points; gp += gridDim.x * kBlock) {
+    const MbMesh& me = a.meshes[mesh_of_point(a, gp)];
+    const uint32_t p = gp - me.point_off, s = a.pslot[gp];
+    const uint32_t rep = s == kNoneD ? kNoneD : a.ptab[me.ptab_off + s];
+    a.prep[gp] = rep;
+    a.pflag[gp] = rep == p ? 1u : 0u;
+  }
+}
+// faces through the point map; degenerate ones dropped; the merged points a surviving face references are marked
+__global__ __launch_bounds__(kBlock) void k_mb_faces_map(const MbArgs a) {
+  for (uint32_t f = blockIdx.x * kBlock + threadIdx.x; f < a.total_faces; f += gridDim.x * kBlock) {
+    const MbMesh& me = a.meshes[mesh_of_face(a, f)];
+    uint32_t v[3];
+    bool ok = !(a.mesh_out[me.index].flags & MB_BAD_INDEX);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const uint32_t p = a.raw_faces[3ull * f + k];
+      v[k] = 0;
+      if (!ok || p >= me.P) { ok = false; continue; }
+      v[k] = a.pflag[me.point_off + a.prep[me.point_off + p]] - a.pflag[me.point_off];   // rank of the class = the merged point's id
+    }
+    ok = ok && v[0] != v[1] && v[1] != v[2] && v[0] != v[2];
+    a.keep[f] = ok ? 1u : 0u;
+    if (!ok) continue;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { a.tmp_faces[3ull * f + k] = v[k]; a.used[me.point_off + v[k]] = 1u; }
+  }
+}
+// (after the scans of pflag / used) does point p of its mesh survive, and as which point
+__device__ __forceinline__ bool survives(const MbArgs& a, const MbMesh& me, uint32_t p, uint32_t* new_point) {
+  if (p >= a.mesh_out[me.index].nv || a.prep[me.point_off + p] != p) return false;
+  const uint32_t merged = a.pflag[me.point_off + p] - a.pflag[me.point_off];
+  const uint32_t lo = a.used[me.point_off + merged], hi = a.used[me.point_off + merged + 1];
+  *new_point = lo - a.used[me.point_off];
+  return hi != lo;
+}
+// values that keep at least one point
+__global__ __launch_bounds__(kBlock) void k_mb_values_used(const MbArgs a) {
+  for (uint32_t ap = blockIdx.x * kBlock + threadIdx.x; ap < a.total_ap; ap += gridDim.x * kBlock) {
+    const MbItem& it = a.items[item_of(a, ap)];
+    const MbMesh& me = a.meshes[it.mesh];
+    uint32_t q;
+    if (survives(a, me, ap - it.ap_off, &q)) a.vused[it.ap_off + a.vid[ap]] = 1u;
+  }
+}
+// counts and output offsets of every mesh / attribute: arena A = faces of all meshes (one array, mesh after mesh) then the point → value
+// maps, arena B = the unique values.  One block.
+__global__ __launch_bounds__(kBlock) void k_mb_layout(const MbArgs a) {
+  for (uint32_t m = threadIdx.x; m < a.M; m += kBlock) {
+    const MbMesh& me = a.meshes[m];
+    MbMeshOut& o = a.mesh_out[m];
+    o.face_out_off = a.keep[me.face_off];
+    o.F_out = a.keep[me.face_off + me.F] - a.keep[me.face_off];
+    o.P_out = a.used[me.point_off + me.P] - a.used[me.point_off];
+    o.classes = a.pflag[me.point_off + me.P] - a.pflag[me.point_off];
+    if (o.F_out == 0) o.flags |= MB_EMPTY;
+  }
+  __syncthreads();
+  const uint32_t faces_words = 3u * a.keep[a.total_faces];
+  const uint32_t per = (a.n_items + kBlock - 1) / kBlock;
+  const uint32_t lo = min(a.n_items, threadIdx.x * per), hi = min(a.n_items, lo + per);
+  uint32_t map_sum = 0, val_sum = 0;
+  for (uint32_t i = lo; i < hi; ++i) {
+    const MbItem& it = a.items[i];
+    MbItemOut& o = a.item_out[i];
+    o.n_first = a.vflag[it.ap_off + it.P] - a.vflag[it.ap_off];
+    o.n_out = a.vused[it.ap_off + it.P] - a.vused[it.ap_off];
+    o.has_map = o.n_first != it.P ? 1u : 0u;   // a map exists iff a duplicate was found (mod.rs:444-446); removals keep it
+    if (o.has_map) map_sum += (a.mesh_out[it.mesh].P_out + 63u) & ~63u;
+    val_sum += (o.n_out * it.words + 63u) & ~63u;
+  }
+  uint32_t map_total, val_total;
+  uint32_t map_run = block_exclusive(map_sum, &map_total) + ((faces_words + 63u) & ~63u);
+  uint32_t val_run = block_exclusive(val_sum, &val_total);
+  for (uint32_t i = lo; i < hi; ++i) {
+    const MbItem& it = a.items[i];
+    MbItemOut& o = a.item_out[i];
+    o.map_off = map_run;
+    o.val_off = val_run;
+    if (o.has_map) map_run += (a.mesh_out[it.mesh].P_out + 63u) & ~63u;
+    val_run += (o.n_out * it.words + 63u) & ~63u;
+  }
+  if (threadIdx.x == 0) { a.totals[0] = ((faces_words + 63u) & ~63u) + map_total; a.totals[1] = val_total; a.totals[2] = faces_words; }
+}
+// surviving faces, renumbered by the surviving points, into arena A
+__global__ __launch_bounds__(kBlock) void k_mb_faces_out(const MbArgs a) {
+  for (uint32_t f = blockIdx.x * kBlock + threadIdx.x; f < a.total_faces; f += gridDim.x * kBlock) {
+    const uint32_t at = a.keep[f];
+    if (a.keep[f + 1] == at) continue;
+    const MbMesh& me = a.meshes[mesh_of_face(a, f)];
+    const uint32_t base = a.used[me.point_off];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) a.arena_a[3ull * at + k] = a.used[me.point_off + a.tmp_faces[3ull * f + k]] - base;
+  }
+}
+// maps of the surviving points and the values that are left, in first-occurrence order
+__global__ __launch_bounds__(kBlock) void k_mb_attributes_out(const MbArgs a) {
+  for (uint32_t ap = blockIdx.x * kBlock + threadIdx.x; ap < a.total_ap; ap += gridDim.x * kBlock) {
+    const uint32_t i = item_of(a, ap);
+    const MbItem& it = a.items[i];
+    const MbItemOut& o = a.item_out[i];
+    const MbMesh& me = a.meshes[it.mesh];
+    const uint32_t p = ap - it.ap_off;
+    uint32_t q;
+    if (o.has_map && survives(a, me, p, &q)) a.arena_a[o.map_off + q] = a.vused[it.ap_off + a.vid[ap]] - a.vused[it.ap_off];
+    // the same index as a VALUE id of this attribute
+    if (p < o.n_first && a.vused[ap + 1] != a.vused[ap]) {
+      const uint32_t r = a.vused[ap] - a.vused[it.ap_off];
+      const uint32_t* __restrict__ src = a.raw_values + it.row_off + (size_t)a.vfirst[ap] * it.words;
+      uint32_t* __restrict__ dst = a.arena_b + o.val_off + (size_t)r * it.words;
+      for (uint32_t k = 0; k < it.words; ++k) dst[k] = src[k];
+    }
+  }
+}
+// the index arrays of a group in which some are narrower than 32 bits (glTF UNSIGNED_BYTE / UNSIGNED_SHORT): all of them into ONE u32 face array
+__global__ __launch_bounds__(kBlock) void k_mb_widen(const MbWiden* __restrict__ items, uint32_t n_items, uint32_t total, const uint8_t* __restrict__ src, uint32_t* __restrict__ dst) {
+  for (uint32_t g = blockIdx.x * kBlock + threadIdx.x; g < total; g += gridDim.x * kBlock) {
+    const MbWiden& it = items[find_last(n_items, g, [&](uint32_t k) { return items[k].off; })];
+    const uint32_t k = g - it.off;
+    const uint8_t* s = src + it.src_byte_off;
+    dst[it.dst_off + k] = it.bytes == 1 ? (uint32_t)s[k] : it.bytes == 2 ? (uint32_t)reinterpret_cast<const uint16_t*>(s)[k] : reinterpret_cast<const uint32_t*>(s)[k];
+  }
+}
+
+}  // namespace
+
+hipError_t mesh_build_clear(const MbArgs& a, size_t vtab_words, size_t ptab_words, hipStream_t s) {
+  hipError_t e;
+  if ((e = hipMemsetAsync(a.vtab, 0xFF, vtab_words * 4, s)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(a.ptab, 0xFF, ptab_words * 4, s)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(a.mesh_out, 0, (size_t)a.M * sizeof(MbMeshOut), s)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(a.vflag + a.total_ap, 0, 4, s)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(a.vused, 0, ((size_t)a.total_ap + 1) * 4, s)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(a.pflag + a.total_points, 0, 4, s)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(a.used, 0, ((size_t)a.total_points + 1) * 4, s)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(a.keep + a.total_faces, 0, 4, s)) != hipSuccess) return e;
+  return hipSuccess;
+}
+void launch_mesh_build(const MbArgs& a, hipStream_t s) {
+  if (!a.M || !a.total_faces || !a.total_ap) return;
+  hipLaunchKernelGGL(k_mb_face_range, grid_of(3ull * a.total_faces), kBlock, 0, s, a);
+  hipLaunchKernelGGL(k_mb_value_insert, grid_of(a.total_ap), kBlock, 0, s, a);
+  hipLaunchKernelGGL(k_mb_value_first, grid_of(a.total_ap), kBlock, 0, s, a);
+  launch_exclusive_scan_u32(a.vflag, a.total_ap + 1, a.scan_partials, s);
+  hipLaunchKernelGGL(k_mb_value_ids, grid_of(a.total_ap), kBlock, 0, s, a);
+  hipLaunchKernelGGL(k_mb_point_insert, grid_of(a.total_points), kBlock, 0, s, a);
+  hipLaunchKernelGGL(k_mb_point_first, grid_of(a.total_points), kBlock, 0, s, a);
+  launch_exclusive_scan_u32(a.pflag, a.total_points + 1, a.scan_partials, s);
+  hipLaunchKernelGGL(k_mb_faces_map, grid_of(a.total_faces), kBlock, 0, s, a);
+  launch_exclusive_scan_u32(a.keep, a.total_faces + 1, a.scan_partials, s);
+  launch_exclusive_scan_u32(a.used, a.total_points + 1, a.scan_partials, s);
+  hipLaunchKernelGGL(k_mb_values_used, grid_of(a.total_ap), kBlock, 0, s, a);
+  launch_exclusive_scan_u32(a.vused, a.total_ap + 1, a.scan_partials, s);
+  hipLaunchKernelGGL(k_mb_layout, 1, kBlock, 0, s, a);
+  hipLaunchKernelGGL(k_mb_faces_out, grid_of(a.total_faces), kBlock, 0, s, a);
+  hipLaunchKernelGGL(k_mb_attributes_out, grid_of(a.total_ap), kBlock, 0, s, a);
+}
+void launch_widen_indices(const MbWiden* items_dev, uint32_t n_items, uint32_t total, const uint8_t* src, uint32_t* dst, hipStream_t s) {
+  if (n_items && total) hipLaunchKernelGGL(k_mb_widen, grid_of(total), kBlock, 0, s, items_dev, n_items, total, src, dst);
+}
+
+}  // namespace dmi

@@ -297,4 +297,29 @@ void launch_build_fans_batch(const FanItem* items_dev, uint32_t n_items, uint32_
 void launch_exclusive_scan_u32(uint32_t* data, uint32_t n, uint32_t* partials, hipStream_t s);   // in place
 size_t scan_partials_words(uint32_t n);
 
+// ---- MeshBuilder::build on the device (dmi_build.hip): value dedup, point merge, degenerate faces, unused points — batched ----
+// M meshes concatenated.  "Item" = one (mesh, attribute); att-point arrays are indexed by ap = item.ap_off + point, point arrays by
+// mesh.point_off + point, face arrays by mesh.face_off + face.  Rows are 1–4 four-byte words.
+constexpr uint32_t kMbMaxAtts = 8;
+enum MbFlag : uint32_t { MB_BAD_INDEX = 1 /* a face index ≥ the point count */, MB_EMPTY = 2 /* no face survives: builder.rs:129 skips the point removal */ };
+struct MbMesh { uint32_t index, n_items, item0, P, F, face_off, point_off, ptab_off, ptab_mask, pad0, pad1, pad2; };
+struct MbItem { uint32_t mesh, P, words, is_float, row_off /* words into raw_values */, ap_off, tab_off, tab_mask; };
+struct MbMeshOut { uint32_t flags, nv /* largest referenced point + 1 */, F_out, P_out, face_out_off /* faces before this mesh's in arena A */, classes, pad0, pad1; };
+struct MbItemOut { uint32_t n_first /* values after Attribute::from */, n_out /* values left at the end */, has_map, map_off /* words into arena A */, val_off /* words into arena B */, pad0, pad1, pad2; };
+struct MbWiden { uint32_t off /* Σ elements of the items before */, bytes /* 1 or 2 */, dst_off /* words */, pad; uint64_t src_byte_off; };
+struct MbArgs {
+  const MbMesh* meshes; const MbItem* items; uint32_t M, n_items, total_faces, total_points, total_ap, pad;
+  const uint32_t* raw_values;   // rows of every item
+  const uint32_t* raw_faces;    // 3·total_faces point ids
+  uint32_t *vtab, *ptab;        // hash tables (filled with DMI_NONE)
+  uint32_t *vslot, *vflag /* total_ap + 1 */, *vid, *vfirst, *vused /* total_ap + 1 */;
+  uint32_t *pslot, *prep, *pflag /* total_points + 1 */, *used /* total_points + 1 */;
+  uint32_t *keep /* total_faces + 1 */, *tmp_faces /* 3·total_faces */, *scan_partials;
+  MbMeshOut* mesh_out; MbItemOut* item_out; uint32_t* totals /* [0] arena A words, [1] arena B words, [2] face words */;
+  uint32_t *arena_a, *arena_b;
+};
+hipError_t mesh_build_clear(const MbArgs& a, size_t vtab_words, size_t ptab_words, hipStream_t s);
+void launch_mesh_build(const MbArgs& a, hipStream_t s);
+void launch_widen_indices(const MbWiden* items_dev, uint32_t n_items, uint32_t total, const uint8_t* src, uint32_t* dst, hipStream_t s);
+
 }  // namespace dmi

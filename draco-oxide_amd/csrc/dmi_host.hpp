@@ -259,4 +259,9 @@ struct FreqTable {
 
 bool append_tagged_state(uint32_t state_minus_base, std::vector<uint8_t>& out);   // rans.rs:48-68
 
+// What dmi_built_mesh::owner points to: the host builder's arrays (host_mesh.cpp) or a member of a device-built group (dmi_build.cpp).
+struct BuiltBase {
+  virtual ~BuiltBase() = default;
+};
+
 }  // namespace dmi

@@ -564,7 +564,7 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
     const dmi_attribute& d = a.desc;
     const TableDev& t = job->tables[a.table];
     const size_t vbytes = (size_t)d.num_unique * d.num_components * 4;
-    if (d.num_unique && !d.values) return fail(DMI_ERR_INVALID_ARGUMENT, "attribute values missing");
+    if (d.num_unique && !d.values && !(defer && i < defer->values_dev.size() && defer->values_dev[i])) return fail(DMI_ERR_INVALID_ARGUMENT, "attribute values missing");
     if (defer) {
       if ((rc = a.raw.alloc(vbytes))) return rc;
       if (vbytes && i < defer->values_dev.size() && defer->values_dev[i]) defer->copies.push_back({a.raw.p, defer->values_dev[i], vbytes});

@@ -323,4 +323,36 @@ struct TempDev {
   ~TempDev() { if (!pool.chunks.empty()) (void)hipStreamSynchronize(pool.stream); }   // (nothing may still be using a chunk when the cache hands it to the next taker)
   template <class T> T* take(size_t n) { return static_cast<T*>(pool.take((n ? n : 1) * sizeof(T))); }
 };
+
+// ---- device-built meshes (dmi_build.cpp → dmi_prepare.cpp) ----
+// The meshes one group of dmi_meshes_build produced, resident on `device`: arena A = the faces of all members as ONE array (member after
+// member: the layout the batched connectivity kernels index) followed by the point → value maps, arena B = the unique values.  A host copy
+// of arena A (the serial walks read faces and maps) — and of arena B on request — lives in pinned staging.  Shared by its members' owners.
+struct BuiltGroup {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  TempDev keep;
+  uint8_t* d_base = nullptr;          // arena A at offset 0, arena B at b_off
+  size_t a_bytes = 0, b_off = 0, b_bytes = 0;
+  HostStage* stage = nullptr;
+  uint8_t *h_a = nullptr, *h_b = nullptr;
+  struct Att { size_t val_off = 0, map_off = (size_t)-1; uint32_t n_unique = 0; };   // byte offsets from d_base (maps also from h_a)
+  struct Member { uint32_t F = 0, P = 0, raw_faces = 0; size_t faces_off = 0 /* bytes into arena A */; std::vector<Att> atts /* in the built mesh's order */; };
+  std::vector<Member> members;        // in arena order
+  uint64_t total_faces = 0;           // Σ members' F
+  BuiltGroup() = default;
+  BuiltGroup(const BuiltGroup&) = delete;
+  BuiltGroup& operator=(const BuiltGroup&) = delete;
+  ~BuiltGroup() { if (stream) (void)hipStreamSynchronize(stream); release_stage(stage); }
+};
+struct BuiltDevice : BuiltBase {
+  std::shared_ptr<BuiltGroup> group;
+  uint32_t member = 0;
+  std::vector<dmi_attribute> views;        // host view (values null unless they were read back)
+  std::vector<std::vector<uint32_t>> parents;
+};
+// library streams / NUMA placement shared by the whole-mesh translation units (defined in dmi_prepare.cpp)
+std::shared_ptr<StreamHolder> library_thread_stream(int device);
+hipStream_t library_group_stream(int device, int which);
+struct NumaScope { void* impl = nullptr; explicit NumaScope(int device); ~NumaScope(); NumaScope(const NumaScope&) = delete; NumaScope& operator=(const NumaScope&) = delete; };
 }  // namespace dmi

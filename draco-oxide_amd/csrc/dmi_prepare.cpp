@@ -531,13 +531,24 @@ static hipStream_t group_stream(int device, int which) {
   return h->s;
 }
 
+extern "C++" {
+namespace dmi {
+std::shared_ptr<StreamHolder> library_thread_stream(int device) { return thread_stream(device); }
+hipStream_t library_group_stream(int device, int which) { return group_stream(device, which); }
+NumaScope::NumaScope(int device) : impl(new NumaPin(device)) {}
+NumaScope::~NumaScope() { delete static_cast<NumaPin*>(impl); }
+}  // namespace dmi
+}  // extern "C++"
+
 namespace {
 // One group of a slice: its meshes' faces / maps / values concatenated in one upload region, its tables in one read-back.
 struct PrepGroup {
-  struct MeshLay { size_t faces = 0, pos_map = (size_t)-1; std::vector<size_t> values, maps; uint32_t face_off = 0, vert_off = 0, Vcap = 0; bool mapped = false; };
+  struct MeshLay { size_t faces = 0, pos_map = (size_t)-1; std::vector<size_t> values, maps; uint32_t face_off = 0, vert_off = 0, Vcap = 0, desc_index = 0; bool mapped = false; };
   std::vector<uint32_t> which;   // mesh indices (into the caller's array)
   std::vector<MeshLay> lay;
   uint64_t total_faces = 0, total_verts = 0;
+  uint32_t n_desc = 0;                 // connectivity descriptors of the group (= its meshes, or every member of an adopted built group)
+  BuiltGroup* adopted = nullptr;       // the group is a device-built one (dmi_meshes_build): nothing to pack or upload
   size_t up_a = 0, up_b = 0, C = 0;
   bool any_mapped = false;
   hipStream_t S = nullptr;
@@ -567,8 +578,13 @@ struct PrepGroup {
 };
 }  // namespace
 
+// adopt (nullable): the groups are device-built ones (dmi_meshes_build) — which_all then lists their PRESENT members in group order
+// (present[member] = index into the caller's arrays, -1 = not part of this call; the connectivity kernels run over every member: the
+// arena's faces are one array)
+struct AdoptedGroup { BuiltGroup* bg; std::vector<int32_t> present; };
 static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32_t>& which_all, const dmi_config& cfg0, int device, uint32_t n_threads,
-                                dmi_buffer* heads, dmi_job** jobs, std::vector<uint8_t>& done, const std::function<std::shared_ptr<StreamHolder>(uint32_t, int)>& worker_stream) {
+                                dmi_buffer* heads, dmi_job** jobs, std::vector<uint8_t>& done, const std::function<std::shared_ptr<StreamHolder>(uint32_t, int)>& worker_stream,
+                                const std::vector<AdoptedGroup>* adopt = nullptr) {
   const uint32_t M = (uint32_t)which_all.size();
   if (!M) return DMI_OK;
   const bool trace = std::getenv("DMI_TRACE") != nullptr;
@@ -584,7 +600,35 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
   static const uint64_t group_faces = std::getenv("DMI_PREP_GROUP_FACES") ? (uint64_t)std::atoll(std::getenv("DMI_PREP_GROUP_FACES")) : (uint64_t)(6u << 20);
   std::vector<std::unique_ptr<PrepGroup>> groups;
   std::vector<std::pair<uint32_t, uint32_t>> where(M);   // position in which_all → (group, index within the group)
-  for (uint32_t k = 0; k < M; ++k) {
+  if (adopt) {
+    uint32_t k = 0;
+    for (const AdoptedGroup& ag : *adopt) {
+      groups.emplace_back(new PrepGroup());
+      PrepGroup& g = *groups.back();
+      g.adopted = ag.bg;
+      uint64_t vert = 0;
+      for (uint32_t mi = 0; mi < ag.bg->members.size(); ++mi) {
+        const BuiltGroup::Member& mem = ag.bg->members[mi];
+        const uint32_t vcap = mem.atts.empty() ? 0u : mem.atts[0].n_unique;
+        const bool mapped = !mem.atts.empty() && mem.atts[0].map_off != (size_t)-1;
+        g.any_mapped = g.any_mapped || mapped;
+        if (ag.present[mi] >= 0) {
+          if (k >= M || which_all[k] != (uint32_t)ag.present[mi]) return fail(DMI_ERR_INVALID_ARGUMENT, "adopted groups: member order");
+          PrepGroup::MeshLay l;
+          l.face_off = (uint32_t)(mem.faces_off / 12); l.vert_off = (uint32_t)vert; l.Vcap = vcap; l.desc_index = mi; l.mapped = mapped;
+          where[k] = {(uint32_t)groups.size() - 1, (uint32_t)g.which.size()};
+          g.which.push_back(which_all[k]);
+          g.lay.push_back(std::move(l));
+          ++k;
+        }
+        vert += vcap;
+      }
+      if (vert >= (1ull << 31) || ag.bg->total_faces >= (1ull << 30)) return fail(DMI_ERR_INVALID_ARGUMENT, "built group too large");
+      g.total_faces = ag.bg->total_faces; g.total_verts = vert; g.n_desc = (uint32_t)ag.bg->members.size();
+    }
+    if (k != M) return fail(DMI_ERR_INVALID_ARGUMENT, "adopted groups: member count");
+  }
+  for (uint32_t k = 0; k < M && !adopt; ++k) {
     const dmi_mesh& m = meshes[which_all[k]];
     if (groups.empty() || groups.back()->total_faces + m.num_faces > group_faces) {
       if (groups.empty() || groups.back()->total_faces) groups.emplace_back(new PrepGroup());
@@ -592,6 +636,7 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     PrepGroup& g = *groups.back();
     PrepGroup::MeshLay l;
     l.face_off = (uint32_t)g.total_faces; l.vert_off = (uint32_t)g.total_verts; l.Vcap = m.atts[0].num_unique;
+    l.desc_index = (uint32_t)g.which.size();
     l.mapped = m.atts[0].point_to_value != nullptr;
     g.any_mapped = g.any_mapped || l.mapped;
     g.total_faces += m.num_faces; g.total_verts += l.Vcap;
@@ -624,6 +669,74 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     g.S = group_stream(device, (int)(gi & 1));
     if (!g.S) return fail(DMI_ERR_HIP, "hipStreamCreate");
     g.C = (size_t)g.total_faces * 3;
+    if (g.adopted) {
+      // a device-built group: faces (one array), maps and values are where dmi_meshes_build left them; offsets are bytes from its base
+      BuiltGroup& bg = *g.adopted;
+      bool want_lmc = false;
+      for (uint32_t k = 0; k < Mg; ++k) {
+        const dmi_mesh& m = meshes[g.which[k]];
+        const BuiltGroup::Member& mem = bg.members[g.lay[k].desc_index];
+        PrepGroup::MeshLay& l = g.lay[k];
+        if (mem.atts.size() != m.num_atts) return fail(DMI_ERR_INVALID_ARGUMENT, "built mesh: attribute count");
+        l.values.assign(m.num_atts, (size_t)-1); l.maps.assign(m.num_atts, (size_t)-1);
+        for (uint32_t i = 0; i < m.num_atts; ++i) {
+          if (mem.atts[i].n_unique) l.values[i] = mem.atts[i].val_off;
+          l.maps[i] = mem.atts[i].map_off;
+          if (m.atts[i].att_type != DMI_ATT_POSITION && m.atts[i].point_to_value != m.atts[0].point_to_value) want_lmc = true;
+        }
+        l.pos_map = l.maps[0];
+        l.faces = mem.faces_off;
+      }
+      const size_t C = g.C, nv = (size_t)g.total_verts + 1, parts = scan_partials_words((uint32_t)nv);
+      const uint32_t ND = g.n_desc;
+      g.mem.init(device, g.S, C * 4 * (g.any_mapped ? 4 : 3) + C + nv * 4 * 4 + nv + parts * 4 + (size_t)ND * (sizeof(ConnMeshDesc) + 8) + ((size_t)1 << 20));
+      g.d_up = bg.d_base;
+      g.d_faces = reinterpret_cast<const uint32_t*>(bg.d_base);
+      g.d_c2v = g.any_mapped ? g.mem.take<uint32_t>(C) : const_cast<uint32_t*>(g.d_faces);
+      g.d_opp = g.mem.take<uint32_t>(C);
+      uint32_t* d_lmc = g.mem.take<uint32_t>(nv);
+      uint8_t* d_onb = g.mem.take<uint8_t>(nv);
+      uint32_t* d_words = g.mem.take<uint32_t>((size_t)2 * ND);
+      ConnMeshDesc* d_desc = g.mem.take<ConnMeshDesc>(ND);
+      ConnArgs a{};
+      a.ecount = g.mem.take<uint32_t>(nv); a.efill = g.mem.take<uint32_t>(nv); a.first = g.mem.take<uint32_t>(nv);
+      a.he_key = g.mem.take<uint32_t>(C); a.he_corner = g.mem.take<uint32_t>(C);
+      a.cdone = g.mem.take<uint8_t>(C);
+      a.scan_partials = g.mem.take<uint32_t>(parts);
+      if (!g.d_c2v || !g.d_opp || !d_lmc || !d_onb || !d_words || !d_desc || !a.ecount || !a.efill || !a.first || !a.he_key || !a.he_corner || !a.cdone || !a.scan_partials)
+        return fail(DMI_ERR_OUT_OF_MEMORY, "hipMalloc (batch connectivity stage)");
+      g.rb_opp = 0; g.rb_c2v = g.rb_opp + align256(C * 4); g.rb_lmc = g.rb_c2v + (g.any_mapped ? align256(C * 4) : 0); g.rb_onb = g.rb_lmc + align256(nv * 4);
+      g.rb_words = g.rb_onb + align256(nv);
+      const size_t rb_desc = g.rb_words + align256((size_t)ND * 8), host_need = rb_desc + align256((size_t)ND * sizeof(ConnMeshDesc));
+      g.stage = acquire_stage(device, host_need);
+      if (!g.stage) return fail(DMI_ERR_OUT_OF_MEMORY, "hipHostMalloc (batch connectivity staging)");
+      uint8_t* hp = g.hp = g.stage->p;
+      ConnMeshDesc* h_desc = reinterpret_cast<ConnMeshDesc*>(hp + rb_desc);
+      uint64_t vert = 0;
+      for (uint32_t mi = 0; mi < ND; ++mi) {
+        const BuiltGroup::Member& mem = bg.members[mi];
+        const uint32_t vcap = mem.atts.empty() ? 0u : mem.atts[0].n_unique;
+        const bool mapped = !mem.atts.empty() && mem.atts[0].map_off != (size_t)-1;
+        h_desc[mi] = ConnMeshDesc{(uint32_t)(mem.faces_off / 12), (uint32_t)vert, mem.F, vcap, mapped ? (uint32_t)(mem.atts[0].map_off / 4) : kNone, mem.P, 0u, 0u};
+        vert += vcap;
+      }
+      HIP_TRY(hipMemcpyAsync(d_desc, h_desc, (size_t)ND * sizeof(ConnMeshDesc), hipMemcpyHostToDevice, g.S));
+      a.meshes = d_desc; a.M = ND; a.total_faces = (uint32_t)g.total_faces; a.total_verts = (uint32_t)g.total_verts;
+      a.faces = g.d_faces; a.p2v = reinterpret_cast<const uint32_t*>(g.d_up); a.c2v = g.d_c2v; a.opp = g.d_opp; a.lmc = d_lmc; a.on_boundary = d_onb; a.flags = d_words; a.vmax = d_words + ND;
+      HIP_TRY(conn_tables_clear(a, g.S));
+      launch_conn_tables(a, g.S);
+      HIP_TRY(hipMemcpyAsync(hp + g.rb_words, d_words, (size_t)ND * 8, hipMemcpyDeviceToHost, g.S));
+      if (C) HIP_TRY(hipMemcpyAsync(hp + g.rb_opp, g.d_opp, C * 4, hipMemcpyDeviceToHost, g.S));
+      if (g.any_mapped && C) HIP_TRY(hipMemcpyAsync(hp + g.rb_c2v, g.d_c2v, C * 4, hipMemcpyDeviceToHost, g.S));
+      if (want_lmc && g.total_verts) HIP_TRY(hipMemcpyAsync(hp + g.rb_lmc, d_lmc, (size_t)g.total_verts * 4, hipMemcpyDeviceToHost, g.S));
+      if (g.total_verts) HIP_TRY(hipMemcpyAsync(hp + g.rb_onb, d_onb, (size_t)g.total_verts, hipMemcpyDeviceToHost, g.S));
+      HIP_TRY(hipEventCreateWithFlags(&g.ev_tables, hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(g.ev_tables, g.S));
+      HIP_TRY(hipEventCreateWithFlags(&g.ev_values, hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(g.ev_values, g.S));
+      continue;
+    }
+    g.n_desc = Mg;
     {   // faces are ONE array (global corner index = 3·face_off + local corner): no per-mesh padding
       size_t at = 0;
       for (uint32_t k = 0; k < Mg; ++k) { g.lay[k].faces = at; at += (size_t)meshes[g.which[k]].num_faces * 12; }
@@ -733,14 +846,14 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
   rc = parallel_over(M, [&](uint32_t t, uint32_t i) -> int {
     const uint32_t kk = walk_order[i];
     PrepGroup& g = *groups[where[kk].first];
-    const uint32_t k = where[kk].second, j = g.which[k], Mg = (uint32_t)g.which.size();
+    const uint32_t k = where[kk].second, j = g.which[k];
     const dmi_mesh& m = meshes[j];
     int r = g.wait_tables();
     if (r) return r;
     auto bail = [&](int code, const std::string& what) { return fail(code, "mesh " + std::to_string(j) + ": " + what); };
     const uint8_t* hp = g.hp;
     const uint32_t* h_words = reinterpret_cast<const uint32_t*>(hp + g.rb_words);
-    const uint32_t flags = h_words[k];
+    const uint32_t flags = h_words[g.lay[k].desc_index];
     if (flags & CONN_BAD_INDEX) return bail(DMI_ERR_INVALID_ARGUMENT, "face index ≥ number of points, or a position value index out of range");
     if (flags & (CONN_DEGENERATE | CONN_NONMANIFOLD_EDGE | CONN_MULTI_FAN)) return DMI_OK;   // the per-mesh path (the reference's serial walks)
     if (flags & CONN_UNUSED_VERTEX) return bail(DMI_ERR_UNUSED_VERTICES, "mesh contains unused vertices");
@@ -750,7 +863,7 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     pre.opp = reinterpret_cast<const uint32_t*>(hp + g.rb_opp) + cb;
     pre.lmc = reinterpret_cast<const uint32_t*>(hp + g.rb_lmc) + g.lay[k].vert_off;
     pre.on_boundary = hp + g.rb_onb + g.lay[k].vert_off;
-    pre.V = h_words[Mg + k] + 1;
+    pre.V = h_words[g.n_desc + g.lay[k].desc_index] + 1;
     pre.no_boundary = !(flags & CONN_HAS_BOUNDARY);
     owners[kk].reset(new ConnOwner());
     ConnOwner& o = *owners[kk];
@@ -773,6 +886,12 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
       const DeviceTableView view{g.d_faces + cb, g.d_c2v + cb, g.d_opp + cb, true};
       r = job_create_impl(m.atts, o.views.data(), m.num_atts, nullptr, 0, &c, &view, &jobs[j], &d);
       deferred[kk] = r == DMI_OK;
+    } else if (g.adopted) {   // an attribute table of its own, values resident in the built group: the universal table from the device, the seam tables from the host
+      std::vector<dmi_attribute> atts_dev(m.atts, m.atts + m.num_atts);
+      for (uint32_t a = 0; a < m.num_atts; ++a) atts_dev[a].values = g.lay[k].values[a] != (size_t)-1 ? static_cast<const void*>(g.d_up + g.lay[k].values[a]) : nullptr;
+      const DeviceTableView view{g.d_faces + cb, g.d_c2v + cb, g.d_opp + cb, true, true};
+      r = job_create_impl(atts_dev.data(), o.views.data(), m.num_atts, nullptr, 0, &c, &view, &jobs[j], nullptr);
+      owners[kk].reset();
     } else {   // an attribute table of its own: the host relabelling form reads the tables where the walks read them
       r = job_create_impl(m.atts, o.views.data(), m.num_atts, nullptr, 0, &c, nullptr, &jobs[j], nullptr);
       owners[kk].reset();
@@ -861,6 +980,20 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
   return DMI_OK;
 }
 
+// worker t's stream on `device` (process-lifetime pool, created on first use)
+static std::shared_ptr<StreamHolder> prepare_worker_stream(uint32_t t, int device) {
+  static std::mutex m;
+  static std::vector<std::pair<int, std::shared_ptr<StreamHolder>>> pool[kMaxPrepareWorkers];
+  std::lock_guard<std::mutex> lock(m);
+  std::shared_ptr<StreamHolder> found;
+  for (auto& e : pool[t]) if (e.first == device) found = e.second;
+  if (!found && hipSetDevice(device) == hipSuccess) {
+    found = std::make_shared<StreamHolder>();
+    if (hipStreamCreate(&found->s) != hipSuccess) found.reset(); else pool[t].push_back({device, found});
+  }
+  return found;
+}
+
 static int meshes_prepare_impl(const dmi_mesh* meshes, uint32_t n, const dmi_config* cfg, const int32_t* device_of_mesh, dmi_buffer* header_and_connectivity, dmi_job** jobs) {
   if (!meshes || !header_and_connectivity || !jobs || n == 0) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
   for (uint32_t j = 0; j < n; ++j) { jobs[j] = nullptr; header_and_connectivity[j] = dmi_buffer{}; }
@@ -875,18 +1008,7 @@ static int meshes_prepare_impl(const dmi_mesh* meshes, uint32_t n, const dmi_con
   for (uint32_t j = 0; j < n; ++j) order[j] = j;
   std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return meshes[x].num_faces > meshes[y].num_faces; });
   const bool library_streams = !(cfg && cfg->stream);
-  const std::function<std::shared_ptr<StreamHolder>(uint32_t, int)> worker_stream = [&](uint32_t t, int device) {   // worker t's stream on `device` (process-lifetime pool, created on first use)
-    static std::mutex m;
-    static std::vector<std::pair<int, std::shared_ptr<StreamHolder>>> pool[kMaxPrepareWorkers];
-    std::lock_guard<std::mutex> lock(m);
-    std::shared_ptr<StreamHolder> found;
-    for (auto& e : pool[t]) if (e.first == device) found = e.second;
-    if (!found && hipSetDevice(device) == hipSuccess) {
-      found = std::make_shared<StreamHolder>();
-      if (hipStreamCreate(&found->s) != hipSuccess) found.reset(); else pool[t].push_back({device, found});
-    }
-    return found;
-  };
+  const std::function<std::shared_ptr<StreamHolder>(uint32_t, int)> worker_stream = prepare_worker_stream;
   // device form first (prepare_slice_device): the eligible meshes of every device in slices of ≤ 64M faces; whatever it leaves goes mesh by mesh below
   std::vector<uint8_t> done(n, 0);
   int ndev = 0;
@@ -1110,6 +1232,125 @@ int dmi_encode_mesh_device(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buff
   dmi_free(&att);
   g_last_call.call_ms = (float)ms();
   if (trace) std::fprintf(stderr, "[dmi] encode_mesh_device: faces + maps read back %.1f ms, prepare %.1f, encode + splice %.1f\n", t_down, t_prep - t_down, ms() - t_prep);
+  return DMI_OK;
+}
+
+// ---- dmi_meshes_prepare for device-built meshes (dmi_meshes_build): nothing is packed or uploaded again ----
+// One member of a built group through the single-mesh path: its tables from the device copies of its faces / position map, its values copied
+// device to device; a mesh the order-free table construction does not cover takes the host walks with its values brought down first.
+static int prepare_built_single(const dmi_mesh& view, const BuiltDevice& bd, const dmi_config& cfg, dmi_buffer* head, dmi_job** job) {
+  const BuiltGroup& bg = *bd.group;
+  const BuiltGroup::Member& mem = bg.members[bd.member];
+  std::vector<dmi_attribute> atts(view.atts, view.atts + view.num_atts);
+  for (uint32_t i = 0; i < view.num_atts; ++i) atts[i].values = mem.atts[i].n_unique ? static_cast<const void*>(bg.d_base + mem.atts[i].val_off) : nullptr;
+  const dmi_mesh shadow{view.faces, view.num_faces, atts.data(), view.num_atts};
+  const DeviceMeshSrc src{reinterpret_cast<const uint32_t*>(bg.d_base + mem.faces_off),
+                          mem.atts[0].map_off != (size_t)-1 ? reinterpret_cast<const uint32_t*>(bg.d_base + mem.atts[0].map_off) : nullptr};
+  dmi_config c = cfg;
+  c.device = bg.device;
+  int rc = mesh_prepare_impl(&shadow, &c, head, job, &src);
+  if (rc != kNeedHostValues) return rc;
+  std::vector<std::vector<uint8_t>> host_values(view.num_atts);
+  HIP_TRY(hipSetDevice(bg.device));
+  for (uint32_t i = 0; i < view.num_atts; ++i) {
+    if (view.atts[i].values) { atts[i].values = view.atts[i].values; continue; }   // (read back by the build: DMI_BUILD_HOST_VALUES)
+    const size_t vb = (size_t)atts[i].num_unique * atts[i].num_components * 4;
+    host_values[i].resize(vb ? vb : 1);
+    if (vb) HIP_TRY(hipMemcpy(host_values[i].data(), bg.d_base + mem.atts[i].val_off, vb, hipMemcpyDeviceToHost));
+    atts[i].values = host_values[i].data();
+  }
+  return mesh_prepare_impl(&shadow, &c, head, job, nullptr);
+}
+
+int dmi_built_meshes_prepare(const dmi_built_mesh* built, uint32_t n, const dmi_config* cfg, dmi_buffer* header_and_connectivity, dmi_job** jobs) {
+  if (!built || !header_and_connectivity || !jobs || n == 0) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
+  for (uint32_t j = 0; j < n; ++j) { jobs[j] = nullptr; header_and_connectivity[j] = dmi_buffer{}; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(DMI_ERR_NO_DEVICE, "no HIP device visible; libdraco_mi has no CPU fallback");
+  dmi_config c0{};
+  if (cfg) c0 = *cfg;
+  if (c0.stream) return fail(DMI_ERR_INVALID_ARGUMENT, "dmi_built_meshes_prepare runs on library streams: leave dmi_config.stream null");
+  const uint32_t n_threads = std::max(1u, std::min({n, (uint32_t)host_threads(), kMaxPrepareWorkers}));
+  std::vector<dmi_mesh> views(n);
+  std::vector<const BuiltDevice*> dev(n, nullptr);
+  std::vector<uint32_t> host_list;
+  for (uint32_t j = 0; j < n; ++j) {
+    views[j] = built[j].mesh;
+    if (!built[j].owner) return fail(DMI_ERR_INVALID_ARGUMENT, "built mesh " + std::to_string(j) + " is empty");
+    dev[j] = dynamic_cast<const BuiltDevice*>(static_cast<const BuiltBase*>(built[j].owner));
+    if (!dev[j]) host_list.push_back(j);
+  }
+  auto bail = [&](int rc) {
+    const std::string e = g_last_error;
+    for (uint32_t k = 0; k < n; ++k) { if (jobs[k]) { dmi_job_destroy(jobs[k]); jobs[k] = nullptr; } dmi_free(&header_and_connectivity[k]); }
+    return fail(rc, e);
+  };
+  int rc;
+  // meshes the host builder made (outside the device form's class): the ordinary batch prepare
+  if (!host_list.empty()) {
+    std::vector<dmi_mesh> hm;
+    for (uint32_t j : host_list) hm.push_back(views[j]);
+    std::vector<dmi_buffer> hh(hm.size());
+    std::vector<dmi_job*> hj(hm.size(), nullptr);
+    if ((rc = meshes_prepare_impl(hm.data(), (uint32_t)hm.size(), &c0, nullptr, hh.data(), hj.data()))) return bail(rc);
+    for (size_t k = 0; k < host_list.size(); ++k) { header_and_connectivity[host_list[k]] = hh[k]; jobs[host_list[k]] = hj[k]; }
+  }
+  // the device-built ones, group by group in the order of their first member
+  std::vector<uint8_t> done(n, 0);
+  std::vector<BuiltGroup*> order;
+  for (uint32_t j = 0; j < n; ++j) if (dev[j] && std::find(order.begin(), order.end(), dev[j]->group.get()) == order.end()) order.push_back(dev[j]->group.get());
+  std::vector<uint32_t> singles;
+  std::vector<AdoptedGroup> slice;
+  std::vector<uint32_t> slice_which;
+  uint64_t slice_faces = 0, slice_verts = 0;
+  int slice_device = -1;
+  auto flush = [&]() -> int {
+    if (slice.empty()) return DMI_OK;
+    dmi_config c = c0;
+    c.device = slice_device;
+    const int r = prepare_slice_device(views.data(), slice_which, c, slice_device, n_threads, header_and_connectivity, jobs, done, prepare_worker_stream, &slice);
+    slice.clear(); slice_which.clear(); slice_faces = slice_verts = 0;
+    return r;
+  };
+  for (BuiltGroup* bg : order) {
+    AdoptedGroup ag{bg, std::vector<int32_t>(bg->members.size(), -1)};
+    for (uint32_t j = 0; j < n; ++j) if (dev[j] && dev[j]->group.get() == bg) {
+      if (dev[j]->member >= ag.present.size() || ag.present[dev[j]->member] >= 0) return bail(fail(DMI_ERR_INVALID_ARGUMENT, "built mesh " + std::to_string(j) + " appears twice"));
+      ag.present[dev[j]->member] = (int32_t)j;
+    }
+    bool large = false;
+    uint64_t verts = 0;
+    for (const auto& mem : bg->members) { large = large || mem.F >= kDeviceRelabelMinFaces; verts += mem.atts.empty() ? 0u : mem.atts[0].n_unique; }
+    if (large || std::getenv("DMI_HOST_CONNECTIVITY")) { for (int32_t j : ag.present) if (j >= 0) singles.push_back((uint32_t)j); continue; }
+    if (!slice.empty() && (slice_device != bg->device || slice_faces + bg->total_faces > (64u << 20) || slice_verts + verts >= (1u << 30)) && (rc = flush())) return bail(rc);
+    slice_device = bg->device;
+    for (int32_t j : ag.present) if (j >= 0) slice_which.push_back((uint32_t)j);
+    slice_faces += bg->total_faces; slice_verts += verts;
+    slice.push_back(std::move(ag));
+  }
+  if ((rc = flush())) return bail(rc);
+  // what the batched form left: meshes its table kernels flagged (the reference's serial walks decide) and the large ones
+  for (uint32_t j = 0; j < n; ++j) if (dev[j] && !done[j] && std::find(singles.begin(), singles.end(), j) == singles.end()) singles.push_back(j);
+  if (!singles.empty()) {
+    std::atomic<uint32_t> next{0};
+    const uint32_t nt = std::max(1u, std::min(n_threads, (uint32_t)singles.size()));
+    std::vector<int> rcs(singles.size(), DMI_OK);
+    std::vector<std::string> errs(singles.size());
+    auto work = [&](uint32_t t) {
+      for (uint32_t k; (k = next.fetch_add(1)) < singles.size();) {
+        const uint32_t j = singles[k];
+        if (jobs[j]) { dmi_job_destroy(jobs[j]); jobs[j] = nullptr; }
+        dmi_free(&header_and_connectivity[j]);
+        g_adopt_stream = prepare_worker_stream(t % kPrepareStreams, dev[j]->group->device);
+        rcs[k] = prepare_built_single(views[j], *dev[j], c0, &header_and_connectivity[j], &jobs[j]);
+        g_adopt_stream.reset();
+        if (rcs[k]) errs[k] = "mesh " + std::to_string(j) + ": " + g_last_error;
+      }
+    };
+    if (nt == 1) work(0);
+    else { std::vector<std::thread> th; for (uint32_t t = 0; t < nt; ++t) th.emplace_back(work, t); for (auto& x : th) x.join(); }
+    for (size_t k = 0; k < singles.size(); ++k) if (rcs[k]) { g_last_error = errs[k]; return bail(rcs[k]); }
+  }
   return DMI_OK;
 }
 

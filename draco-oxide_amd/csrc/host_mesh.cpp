@@ -123,7 +123,7 @@ void remove_points(BuiltAtt& a, const std::vector<uint8_t>& drop) {
   }
 }
 
-struct BuiltOwner {
+struct BuiltOwner : BuiltBase {
   std::vector<BuiltAtt> atts;
   std::vector<uint32_t> faces;
   std::vector<dmi_attribute> views;
@@ -247,13 +247,13 @@ int dmi_mesh_build(const dmi_raw_attribute* in, uint32_t n_atts, const uint32_t*
   out->mesh.num_faces = (uint32_t)(faces.size() / 3);
   out->mesh.atts = o->views.data();
   out->mesh.num_atts = (uint32_t)o->views.size();
-  out->owner = o.release();
+  out->owner = static_cast<BuiltBase*>(o.release());
   return DMI_OK;
 }
 
 void dmi_built_mesh_free(dmi_built_mesh* m) {
   if (!m || !m->owner) return;
-  delete static_cast<BuiltOwner*>(m->owner);
+  delete static_cast<BuiltBase*>(m->owner);
   m->owner = nullptr;
   m->mesh = dmi_mesh{};
 }

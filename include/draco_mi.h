@@ -224,6 +224,48 @@ typedef struct dmi_built_mesh { dmi_mesh mesh; void* owner; } dmi_built_mesh;
 int dmi_mesh_build(const dmi_raw_attribute* atts, uint32_t n_atts, const uint32_t* faces, uint32_t num_faces, dmi_built_mesh* out);
 void dmi_built_mesh_free(dmi_built_mesh* m);
 
+/* --- MeshBuilder::build for a BATCH of primitives, on the device ---------------------------------------------------------
+ * What the glTF importer does once per triangle primitive (io/gltf/decode.rs:2328-2525: accessors → MeshBuilder::add_attribute →
+ * build()) for n primitives in one call: the accessors' rows and the index arrays go up once (pinned staging), every step of
+ * MeshBuilder::build — Attribute::from's value dedup with `==` classes (core/attribute/mod.rs:394-452), the merge of points that agree in
+ * every attribute (core/mesh/builder.rs:194-279), degenerate faces (:77-79), unreferenced points (:129-189) — runs as ONE launch per
+ * kernel for all primitives (dmi_build.hip: hash-based class search whose result does not depend on scheduling, prefix-sum ranks), and
+ * the faces and point → value maps come back in one read-back (the host's serial walks need them).  The unique values stay in device
+ * memory unless DMI_BUILD_HOST_VALUES is set.  out[j].mesh equals what dmi_mesh_build returns for primitive j (same value order, maps,
+ * surviving points and faces, Position in slot 0) with atts[i].values == NULL when the values stayed on the device.  Primitives outside
+ * the device form's class (attributes of different point counts, components that are not 4 bytes wide, more than 8 attributes, a face
+ * index out of range, no surviving face) take the host builder inside the same call.  Free every out[j] with dmi_built_mesh_free. */
+typedef struct dmi_raw_accessor {
+  const void* data;          /* first element, host memory */
+  uint32_t count;            /* elements = points */
+  uint32_t byte_stride;      /* distance between elements, 0 = tightly packed (glTF bufferView.byteStride) */
+  uint8_t component_type, num_components, att_type, domain;
+  uint32_t num_parents;
+  const uint32_t* parents;   /* ids (add-order indices) of the parent attributes */
+} dmi_raw_accessor;
+typedef struct dmi_raw_mesh {
+  const dmi_raw_accessor* atts;   /* in add order: AttributeId = index (builder.rs:31-39) */
+  uint32_t n_atts;
+  const void* indices;            /* 3·num_faces point indices */
+  uint8_t index_type;             /* DMI_U8 / DMI_U16 / DMI_U32 (glTF 5121 / 5123 / 5125) */
+  uint32_t num_faces;
+} dmi_raw_mesh;
+#define DMI_BUILD_HOST_VALUES 1u   /* also read the unique values back: out[j].mesh is a complete host Mesh */
+int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg, uint32_t flags, dmi_built_mesh* out);
+/* dmi_meshes_prepare for meshes that dmi_meshes_build left resident on cfg->device: nothing is packed or uploaded again — the connectivity
+ * kernels read the built faces and maps where they are, the jobs copy their values device to device.  Same bytes as dmi_meshes_prepare on
+ * the equivalent host meshes.  The built meshes may be freed as soon as this returns. */
+int dmi_built_meshes_prepare(const dmi_built_mesh* built, uint32_t n, const dmi_config* cfg, dmi_buffer* header_and_connectivity, dmi_job** jobs);
+/* Stage times of the calling thread's last dmi_meshes_build (milliseconds; kernels_ms is hipEvent time summed over the groups). */
+typedef struct dmi_build_timings {
+  float pack_ms;       /* host threads: rows and indices into pinned staging */
+  float kernels_ms;    /* device: the build kernels of all groups */
+  float call_ms;       /* the whole call */
+  uint32_t device_meshes, host_meshes;   /* primitives built by the kernels / by the host builder */
+  uint64_t bytes_up, bytes_down;
+} dmi_build_timings;
+int dmi_last_build_timings(dmi_build_timings* t);
+
 /* --- Decoder side: the attribute section read back --------------------------------------------------------------
  * What a decoder does after its connectivity stage: `tables[i]` / `seeds` are the arrays dmi_encode_attributes takes (a decoder
  * rebuilds exactly these from the connectivity bytes), `section` is the output of dmi_encode_attributes / dmi_job_encode.
