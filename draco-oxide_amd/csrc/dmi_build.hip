@@ -72,13 +72,42 @@ __device__ __forceinline__ uint32_t canon(uint32_t w, bool is_float) { return (i
 __device__ __forceinline__ bool is_nan_bits(uint32_t w) { return (w & 0x7FFFFFFFu) > 0x7F800000u; }
 
 // ---- faces: index range, largest referenced point per mesh (num_vertices = max + 1, builder.rs:196-199) ----
+// A block owns kRangePer·kBlock consecutive corners; a thread keeps the maximum of the mesh it is in and hands it over when the mesh
+// changes (rare) or at the end, where a wavefront whose lanes all sit in one mesh sends ONE atomic (same-address atomics execute one after
+// the other, ≈ 11 ns each: one per corner made this kernel 20–44 ms).
+constexpr int kRangePer = 32;
+__device__ __forceinline__ void nv_max(MbMeshOut* out, uint32_t m, uint32_t v) {
+  if (v && __atomic_load_n(&out[m].nv, __ATOMIC_RELAXED) < v) atomicMax(&out[m].nv, v);
+}
 __global__ __launch_bounds__(kBlock) void k_mb_face_range(const MbArgs a) {
-  const uint64_t C = 3ull * a.total_faces;
-  for (uint64_t c = (uint64_t)blockIdx.x * kBlock + threadIdx.x; c < C; c += (uint64_t)gridDim.x * kBlock) {
-    const uint32_t m = mesh_of_face(a, (uint32_t)(c / 3u));
+  const uint64_t C = 3ull * a.total_faces, base = (uint64_t)blockIdx.x * (kRangePer * kBlock);
+  uint32_t cur_m = kNoneD, cur_max = 0, cur_end = 0, cur_P = 0;   // cur_end: first face past mesh cur_m
+  for (int k = 0; k < kRangePer; ++k) {
+    const uint64_t c = base + (uint64_t)k * kBlock + threadIdx.x;
+    if (c >= C) break;
+    const uint32_t f = (uint32_t)(c / 3u);
+    if (cur_m == kNoneD || f >= cur_end) {
+      if (cur_m != kNoneD) nv_max(a.mesh_out, cur_m, cur_max);
+      cur_m = mesh_of_face(a, f);
+      cur_end = a.meshes[cur_m].face_off + a.meshes[cur_m].F;
+      cur_P = a.meshes[cur_m].P;
+      cur_max = 0;
+    }
     const uint32_t p = a.raw_faces[c];
-    if (p >= a.meshes[m].P) { raise(a.mesh_out, m, MB_BAD_INDEX); continue; }
-    if (__atomic_load_n(&a.mesh_out[m].nv, __ATOMIC_RELAXED) < p + 1) atomicMax(&a.mesh_out[m].nv, p + 1);
+    if (p >= cur_P) raise(a.mesh_out, cur_m, MB_BAD_INDEX);
+    else cur_max = max(cur_max, p + 1);
+  }
+  const bool have = cur_m != kNoneD;
+  const uint64_t mask = __ballot(have);
+  if (mask == 0ull) return;
+  const uint32_t m0 = __shfl(cur_m, __ffsll((long long)mask) - 1, 64);
+  if (__ballot(have && cur_m != m0) == 0ull) {
+    uint32_t x = have ? cur_max : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x = max(x, (uint32_t)__shfl_down(x, off, 64));
+    if ((threadIdx.x & 63) == 0) nv_max(a.mesh_out, m0, x);
+  } else if (have) {
+    nv_max(a.mesh_out, cur_m, cur_max);
   }
 }
 
@@ -304,7 +333,7 @@ hipError_t mesh_build_clear(const MbArgs& a, size_t vtab_words, size_t ptab_word
 }
 void launch_mesh_build(const MbArgs& a, hipStream_t s) {
   if (!a.M || !a.total_faces || !a.total_ap) return;
-  hipLaunchKernelGGL(k_mb_face_range, grid_of(3ull * a.total_faces), kBlock, 0, s, a);
+  hipLaunchKernelGGL(k_mb_face_range, (uint32_t)((3ull * a.total_faces + kRangePer * kBlock - 1) / (kRangePer * kBlock)), kBlock, 0, s, a);
   hipLaunchKernelGGL(k_mb_value_insert, grid_of(a.total_ap), kBlock, 0, s, a);
   hipLaunchKernelGGL(k_mb_value_first, grid_of(a.total_ap), kBlock, 0, s, a);
   launch_exclusive_scan_u32(a.vflag, a.total_ap + 1, a.scan_partials, s);

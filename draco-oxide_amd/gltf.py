@@ -9,9 +9,12 @@ Mirrors what the reference's transcoder does around the hot path (paths relative
     to the BIN chunk and zero-padded to 4 bytes (the bufferView byteLength includes the pad), placeholder
     accessors without bufferView, extension attributes POSITION→1, NORMAL→0, TEXCOORD_0→2
   * io/gltf/encode.rs:362-400    GLB container: "glTF", 2, length | JSON chunk (space padded) | BIN chunk
-All primitives of a file — of a whole LIST of files (`transcode_files`, BASELINE configs[3]) — are encoded as ONE batch: one
-dmi_jobs_encode on one GPU, one per device from a single process (dmi_jobs_encode_devices), or dealt over the ranks of a
-torch.distributed job and gathered on rank 0 (distributed.encode_meshes_sharded).  Inputs: `.glb`, or `.gltf` with external /
+All primitives of a file — of a whole LIST of files (`transcode_files`, BASELINE configs[3]) — go through the device as batches: the
+accessors' bytes are handed to dmi_meshes_build as they lie in the BIN chunk (MeshBuilder::build on the GPU for all primitives at once —
+nothing is copied or deduplicated in Python), dmi_built_meshes_prepare runs the connectivity stage on the resident result and
+dmi_jobs_encode codes every stream; consecutive batches overlap (build + prepare of batch k+1 beside the encode of batch k).  On one
+GPU, on several GPUs of this process (a share per device, a thread each), or dealt over the ranks of a torch.distributed job BEFORE
+anything is built (a rank parses the JSON of every file but touches only the bytes of its own primitives) and gathered on rank 0.  Inputs: `.glb`, or `.gltf` with external /
 data-URI buffers; `_FEATURE_ID_n` attributes (EXT_mesh_features) become Custom u32 corner attributes (decode.rs:2490-2516).
 JSON byte-equality with the reference is not part of the bit-exact contract; the embedded .drc blobs are.
 """
@@ -23,8 +26,10 @@ import struct
 
 import numpy as np
 
-from .binding import (ATT_CUSTOM, ATT_NORMAL, ATT_POSITION, ATT_TEXCOORD, DOMAIN_CORNER, DOMAIN_POSITION, Config, MeshBuilder, device_count, jobs_encode,
-                      jobs_encode_devices, meshes_prepare, meshes_prepare_devices, shard_meshes)
+import threading
+
+from .binding import (ATT_CUSTOM, ATT_NORMAL, ATT_POSITION, ATT_TEXCOORD, DOMAIN_CORNER, DOMAIN_POSITION, Config, MeshBuilder, RawMesh, built_meshes_prepare, device_count,
+                      jobs_encode, jobs_encode_devices, last_build_timings, meshes_build, meshes_prepare, meshes_prepare_devices, shard_meshes)
 
 _COMPONENTS = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4}
 _INDEX_DTYPE = {5121: np.uint8, 5123: np.uint16, 5125: np.uint32}
@@ -113,6 +118,71 @@ def _accessor_u32_scalars(doc, binary, index):
 _STANDARD_PREFIXES = ("POSITION", "NORMAL", "TANGENT", "TEXCOORD_", "COLOR_", "JOINTS_", "WEIGHTS_")
 
 
+def _accessor_f32_view(doc, binary, index):
+    """_accessor_f32 without the copy: a (count, n) float32 VIEW of the buffer's bytes (rows `byteStride` apart)."""
+    acc = doc["accessors"][index]
+    view = doc["bufferViews"][acc["bufferView"]]
+    n = _COMPONENTS[acc["type"]]
+    start = view.get("byteOffset", 0) + acc.get("byteOffset", 0)
+    stride = view.get("byteStride", 0) or 4 * n
+    count = acc["count"]
+    if count == 0:
+        return np.zeros((0, n), np.float32)
+    raw = np.frombuffer(_buffer_of(binary, view), dtype=np.uint8, count=stride * (count - 1) + 4 * n, offset=start)
+    rows = np.lib.stride_tricks.as_strided(raw, shape=(count, 4 * n), strides=(stride, 1), writeable=False)
+    return rows.view("<f4")
+
+
+def _accessor_indices_view(doc, binary, index):
+    acc = doc["accessors"][index]
+    view = doc["bufferViews"][acc["bufferView"]]
+    start = view.get("byteOffset", 0) + acc.get("byteOffset", 0)
+    return np.frombuffer(_buffer_of(binary, view), dtype=_INDEX_DTYPE[acc["componentType"]], count=acc["count"], offset=start)
+
+
+def _primitive_names(prim):
+    """The attribute names of a triangle primitive in AttributeId order, and the position's id — or a ValueError where the reference's
+    importer hands out a wrong parent id (see primitive_to_mesh)."""
+    standard = sorted(k for k in prim["attributes"] if k.startswith(_STANDARD_PREFIXES))
+    names = [k for k in standard if k in _SEMANTIC_TYPE]
+    if "POSITION" not in names:
+        raise ValueError("primitive without POSITION")
+    pos_id = standard.index("POSITION")
+    if pos_id != names.index("POSITION") and len(names) > 1:
+        raise ValueError("the reference hands NORMAL / TEXCOORD_0 a parent id that is not the position attribute for this set of semantics "
+                         f"({standard}); its encoder panics on such a primitive")
+    return names, pos_id
+
+
+def primitive_weight(doc, prim):
+    """Triangles of a primitive from the JSON alone (what a sharded job deals by, before any rank touches the BIN chunk)."""
+    if "indices" in prim:
+        return int(doc["accessors"][prim["indices"]]["count"]) // 3
+    return int(doc["accessors"][prim["attributes"]["POSITION"]]["count"]) // 3
+
+
+def primitive_to_raw(doc, binary, prim):
+    """One triangle primitive → (RawMesh, names): what primitive_to_mesh feeds MeshBuilder (decode.rs:2328-2525), as VIEWS of the
+    accessors' bytes — dmi_meshes_build runs MeshBuilder::build on the device."""
+    if prim.get("mode", 4) != 4:
+        raise ValueError("only triangle primitives are transcoded")
+    names, pos_id = _primitive_names(prim)
+    rm = RawMesh()
+    count = 0
+    for name in names:
+        rows = _accessor_f32_view(doc, binary, prim["attributes"][name])
+        count = len(rows)
+        if name == "POSITION":
+            rm.add_attribute(rows, ATT_POSITION, DOMAIN_POSITION)
+        else:
+            rm.add_attribute(rows, _SEMANTIC_TYPE[name], DOMAIN_CORNER, parents=[pos_id])
+    for name in sorted(k for k in prim["attributes"] if k.startswith("_FEATURE_ID_")):
+        rm.add_attribute(_accessor_u32_scalars(doc, binary, prim["attributes"][name]).reshape(-1, 1), ATT_CUSTOM, DOMAIN_CORNER)
+        names.append(name)
+    rm.set_indices(_accessor_indices_view(doc, binary, prim["indices"]) if "indices" in prim else np.arange(count, dtype=np.uint32))
+    return rm, names
+
+
 def primitive_to_mesh(doc, binary, prim):
     """One triangle primitive → `Mesh` exactly as the reference builds it (decode.rs:2328-2525).  Returns (mesh, names): `names` =
     the glTF attribute names in AttributeId order (POSITION / NORMAL / TEXCOORD_0 sorted by name, then the `_FEATURE_ID_n`)."""
@@ -177,8 +247,8 @@ def load_document(source):
     return doc, buffers
 
 
-def _collect(doc, buffers):
-    """The primitives of a document that get compressed: [(prim, names, mesh)] (triangle primitives with POSITION and faces)."""
+def _plan(doc):
+    """The primitives of a document that get compressed — [(prim, names, triangles)] — from the JSON alone."""
     prims = []
     for mesh in doc.get("meshes", []):
         for prim in mesh.get("primitives", []):
@@ -186,18 +256,31 @@ def _collect(doc, buffers):
                 continue
             if "KHR_draco_mesh_compression" in prim.get("extensions", {}):
                 raise ValueError("KHR_draco_mesh_compression input is not supported (decode.rs:2478-2483)")
-            m, names = primitive_to_mesh(doc, buffers, prim)
-            if len(m.faces) == 0:
-                continue                                                           # encode.rs:934-936
-            prims.append((prim, names, m))
+            names, _ = _primitive_names(prim)
+            names = names + sorted(k for k in prim["attributes"] if k.startswith("_FEATURE_ID_"))
+            prims.append((prim, names, primitive_weight(doc, prim)))
     return prims
 
 
-def _assemble(doc, buffers, prims, blobs):
-    """The output GLB of one document: compressed primitives get placeholder accessors + the extension, every other bufferView
-    (of any input buffer) is carried over into the single BIN chunk."""
+def _collect(doc, buffers):
+    """Host-builder form (tests, encode_batch callers): [(prim, names, mesh)] of the primitives that get compressed."""
+    out = []
+    for prim, _, _ in _plan(doc):
+        m, names = primitive_to_mesh(doc, buffers, prim)
+        if len(m.faces) == 0:
+            continue                                                           # encode.rs:934-936
+        out.append((prim, names, m))
+    return out
+
+
+def _assemble(doc, buffers, prims, results):
+    """The output GLB of one document.  prims = [(prim, names, …)], results = [(blob, num_faces, num_points) or None] per primitive
+    (None: the built mesh has no face — encode.rs:934-936 leaves such a primitive alone).  Compressed primitives get placeholder
+    accessors + the extension, every other bufferView (of any input buffer) is carried over into the single BIN chunk."""
     replaced = set()
-    for prim, names, _ in prims:
+    for (prim, names, *_), res in zip(prims, results):
+        if res is None:
+            continue
         replaced.update(prim["attributes"][n] for n in names)
         if "indices" in prim:
             replaced.add(prim["indices"])
@@ -226,22 +309,26 @@ def _assemble(doc, buffers, prims, blobs):
     for img in doc.get("images", []):
         if "bufferView" in img:
             img["bufferView"] = carry(img["bufferView"])
-    for (prim, names, m), blob in zip(prims, blobs):
+    any_compressed = False
+    for (prim, names, *_), res in zip(prims, results):
+        if res is None:
+            continue
+        blob, num_faces, num_points = res
+        any_compressed = True
         start = len(new_bin)
         new_bin.extend(blob)
         new_bin.extend(b"\0" * ((4 - len(new_bin) % 4) % 4))
         new_views.append({"buffer": 0, "byteOffset": start, "byteLength": len(new_bin) - start})    # length includes the pad
-        by_id = sorted(m.attributes, key=lambda a: a.unique_id)                   # AttributeId = add order = `names` order
-        ext = {"bufferView": len(new_views) - 1, "attributes": {n: int(a.unique_id) for n, a in zip(names, by_id)}}
+        # AttributeId = add order = `names` order (the built mesh has Position in slot 0, ids unchanged: builder.rs:115-125)
+        ext = {"bufferView": len(new_views) - 1, "attributes": {n: k for k, n in enumerate(names)}}
         prim.setdefault("extensions", {})["KHR_draco_mesh_compression"] = ext
         if "indices" in prim:
-            ia = doc["accessors"][prim["indices"]]
-            ia["count"] = int(len(m.faces) * 3)
+            doc["accessors"][prim["indices"]]["count"] = int(num_faces) * 3
         for n in names:
-            doc["accessors"][prim["attributes"][n]]["count"] = int(m.attributes[0].num_points)
+            doc["accessors"][prim["attributes"][n]]["count"] = int(num_points)
     doc["bufferViews"] = new_views
     doc["buffers"] = [{"byteLength": len(new_bin)}]
-    if prims:
+    if any_compressed:
         for key in ("extensionsUsed", "extensionsRequired"):
             lst = doc.setdefault(key, [])
             if "KHR_draco_mesh_compression" not in lst:
@@ -249,11 +336,114 @@ def _assemble(doc, buffers, prims, blobs):
     return write_glb(doc, bytes(new_bin))
 
 
-def encode_batch(meshes, cfg=None, devices=None, group=None, device=None):
-    """Every mesh of a transcode job as ONE batch → list of `.drc` blobs in mesh order (None on the ranks that are not the
-    destination of a sharded job).  torch.distributed initialised with more than one rank: the batch is dealt over the ranks by
-    triangle count and gathered on rank 0 (RCCL for an nccl group).  Otherwise `devices` (a count, or "all") spreads it over the
-    GPUs of this process (dmi_shard_meshes + dmi_meshes_prepare_devices + dmi_jobs_encode_devices); default: one GPU."""
+def _chunks_by_weight(weights, limit):
+    """Consecutive index ranges of ≈ `limit` triangles each."""
+    out, cur, acc = [], [], 0
+    for i, w in enumerate(weights):
+        if cur and acc + w > limit:
+            out.append(cur)
+            cur, acc = [], 0
+        cur.append(i)
+        acc += w
+    if cur:
+        out.append(cur)
+    return out
+
+
+def _pipelined(chunks, stage1, stage2):
+    """stage2(stage1(chunk)) for every chunk, stage1 of chunk k+1 running beside stage2 of chunk k (the library calls release the GIL)."""
+    results = [None] * len(chunks)
+    if len(chunks) <= 1:
+        for k, ch in enumerate(chunks):
+            results[k] = stage2(stage1(ch))
+        return results
+    err = []
+    pending = None                                                       # (thread, k)
+
+    def run2(k, mid):
+        try:
+            results[k] = stage2(mid)
+        except BaseException as e:                                        # noqa: BLE001 — re-raised on the caller's thread
+            err.append(e)
+
+    for k, ch in enumerate(chunks):
+        mid = stage1(ch)
+        if pending is not None:
+            pending.join()
+        if err:
+            _drop(mid)
+            raise err[0]
+        pending = threading.Thread(target=run2, args=(k, mid))
+        pending.start()
+    pending.join()
+    if err:
+        raise err[0]
+    return results
+
+
+def _drop(mid):
+    for j in (mid[0] if mid else []):
+        j.close()
+
+
+PIPELINE_TRIANGLES = 6 << 20     # triangles per pipeline stage of a large batch (one connectivity group of the library)
+
+
+def encode_raw_batch(raws, cfg=None, pipeline=True, timings=None):
+    """RawMesh list → [(blob, num_faces, num_points) or None (no face left)] on ONE device: dmi_meshes_build → dmi_built_meshes_prepare →
+    dmi_jobs_encode, in stages of ≈ PIPELINE_TRIANGLES triangles whose build + prepare overlap the previous stage's encode."""
+    cfg = cfg or Config.default()
+    out = [None] * len(raws)
+    if not raws:
+        return out
+    import time
+    weights = [len(r.indices) // 3 if r.indices is not None else 0 for r in raws]
+    chunks = _chunks_by_weight(weights, PIPELINE_TRIANGLES) if pipeline else [list(range(len(raws)))]
+    tm = timings if timings is not None else {}
+    for key in ("build_s", "prepare_s", "encode_s", "build_kernels_ms", "build_pack_ms"):
+        tm.setdefault(key, 0.0)
+
+    def stage1(ch):
+        t0 = time.perf_counter()
+        batch = meshes_build([raws[i] for i in ch], cfg)
+        t1 = time.perf_counter()
+        try:
+            bt = last_build_timings()
+            keep = [k for k in range(len(ch)) if batch.num_faces(k) > 0]
+            info = [batch.summary(k) for k in keep]
+            jobs = built_meshes_prepare(batch, keep, cfg)
+        finally:
+            batch.free()
+        t2 = time.perf_counter()
+        tm["build_s"] += t1 - t0
+        tm["prepare_s"] += t2 - t1
+        tm["build_kernels_ms"] += bt["kernels_ms"]
+        tm["build_pack_ms"] += bt["pack_ms"]
+        return jobs, [ch[k] for k in keep], info
+
+    def stage2(mid):
+        jobs, where, info = mid
+        t0 = time.perf_counter()
+        try:
+            sections = jobs_encode(jobs) if jobs else []
+            for j, s, i, (nf, npts, _) in zip(jobs, sections, where, info):
+                out[i] = (j.header_and_connectivity + s, nf, npts)
+        finally:
+            for j in jobs:
+                j.close()
+        tm["encode_s"] += time.perf_counter() - t0
+        return None
+
+    _pipelined(chunks, stage1, stage2)
+    return out
+
+
+def encode_batch(meshes, cfg=None, devices=None, group=None, device=None, pipeline=False):
+    """Every (already built, host-memory) mesh of a transcode job as ONE batch → list of `.drc` blobs in mesh order (None on the ranks
+    that are not the destination of a sharded job).  torch.distributed initialised with more than one rank: the batch is dealt over
+    the ranks by triangle count and gathered on rank 0 (RCCL for an nccl group).  Otherwise `devices` (a count, or "all") spreads it
+    over the GPUs of this process (dmi_shard_meshes + dmi_meshes_prepare_devices + dmi_jobs_encode_devices); default: one GPU.
+    pipeline=True (one GPU): stages of ≈ PIPELINE_TRIANGLES triangles, dmi_meshes_prepare of stage k+1 beside dmi_jobs_encode of stage k."""
     if not meshes:
         return []
     try:
@@ -266,6 +456,25 @@ def encode_batch(meshes, cfg=None, devices=None, group=None, device=None):
         return distributed.encode_meshes_sharded(meshes, cfg, device=device, group=group)
     n_dev = device_count() if devices == "all" else int(devices or 1)
     n_dev = max(1, min(n_dev, device_count()))
+    if n_dev == 1 and pipeline:
+        cfg = cfg or Config.default()
+        out = [None] * len(meshes)
+        chunks = _chunks_by_weight([len(m.faces) for m in meshes], PIPELINE_TRIANGLES)
+
+        def stage1(ch):
+            return meshes_prepare([meshes[i] for i in ch], cfg), ch
+
+        def stage2(mid):
+            jobs, ch = mid
+            try:
+                for j, s, i in zip(jobs, jobs_encode(jobs), ch):
+                    out[i] = j.header_and_connectivity + s
+            finally:
+                for j in jobs:
+                    j.close()
+
+        _pipelined(chunks, stage1, stage2)
+        return out
     jobs = []
     try:   # (the jobs hold device memory: closed whatever the encode does)
         if n_dev > 1:
@@ -281,23 +490,82 @@ def encode_batch(meshes, cfg=None, devices=None, group=None, device=None):
             j.close()
 
 
-def transcode_files(sources, cfg=None, devices=None, group=None, device=None):
-    """BASELINE configs[3]: a LIST of glTF assets (GLB bytes, `.glb` / `.gltf` paths) → their Draco-compressed GLBs.  The triangle
-    primitives of ALL files form one batch (encode_batch: one GPU, several GPUs of this process, or the ranks of a torch.distributed
-    job); every file is then reassembled around its blobs (io/gltf/transcoder.rs:134-151 runs the files one by one, and
-    io/gltf/encode.rs:1827-1842 their primitives one by one).  Returns [(glb_bytes, [blob, ...]), ...] in input order — on the
-    destination rank; None on the other ranks of a sharded job."""
+def transcode_files(sources, cfg=None, devices=None, group=None, device=None, pipeline=True, timings=None):
+    """BASELINE configs[3]: a LIST of glTF assets (GLB bytes, `.glb` / `.gltf` paths) → their Draco-compressed GLBs
+    (io/gltf/transcoder.rs:134-151 runs the files one by one, io/gltf/encode.rs:1827-1842 their primitives one by one; here the triangle
+    primitives of ALL files go through the device together: encode_raw_batch).  One GPU, `devices` GPUs of this process (each takes a
+    share by triangle count, a thread per device), or the ranks of a torch.distributed job: the primitives are dealt by the triangle
+    counts the JSON states, each rank builds and encodes ONLY its share, rank 0 gathers the blobs and reassembles the files.
+    Returns [(glb_bytes, [blob, ...]), ...] in input order — on the destination rank; None on the other ranks of a sharded job.
+    timings (optional dict): parse_s, build_s, prepare_s, encode_s, assemble_s, primitives_built (this rank)."""
+    import time
+    tm = timings if timings is not None else {}
+    t0 = time.perf_counter()
     docs = [load_document(src) for src in sources]
-    per_file = [_collect(doc, buffers) for doc, buffers in docs]
-    meshes = [m for prims in per_file for (_, _, m) in prims]
-    blobs = encode_batch(meshes, cfg, devices=devices, group=group, device=device)
-    if blobs is None:
-        return None
+    per_file = [_plan(doc) for doc, _ in docs]
+    flat = [(fi, pi) for fi, prims in enumerate(per_file) for pi in range(len(prims))]
+    weights = [per_file[fi][pi][2] for fi, pi in flat]
+    try:
+        import torch.distributed as dist
+        world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        rank = dist.get_rank(group) if world > 1 else 0
+    except ImportError:
+        world, rank = 1, 0
+    if world > 1:
+        from . import distributed
+        mine = distributed.shard_indices(len(flat), rank, world, weights=weights)
+        cfg = distributed._rank_config(cfg, device)
+    else:
+        mine = list(range(len(flat)))
+    raws = [primitive_to_raw(docs[flat[i][0]][0], docs[flat[i][0]][1], per_file[flat[i][0]][flat[i][1]][0])[0] for i in mine]
+    tm["parse_s"] = time.perf_counter() - t0
+    tm["primitives_built"] = len(raws)
+    n_dev = device_count() if devices == "all" else int(devices or 1)
+    n_dev = max(1, min(n_dev, device_count()))
+    if world == 1 and n_dev > 1 and raws:
+        from .distributed import shard_indices
+        w_mine = [weights[i] for i in mine]
+        local = [None] * len(raws)
+        errs = []
+
+        def run(d):
+            try:
+                idx = shard_indices(len(raws), d, n_dev, weights=w_mine)
+                c = Config(**{**(cfg.__dict__ if cfg else {}), "device": d})
+                for i, r in zip(idx, encode_raw_batch([raws[i] for i in idx], c, pipeline=pipeline)):
+                    local[i] = r
+            except BaseException as e:                                    # noqa: BLE001
+                errs.append(e)
+
+        threads = [threading.Thread(target=run, args=(d,)) for d in range(n_dev)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errs:
+            raise errs[0]
+    else:
+        local = encode_raw_batch(raws, cfg, pipeline=pipeline, timings=tm)
+    if world > 1:
+        # the blobs travel with their face / point counts (rank 0 writes them into the placeholder accessors); 8 zero bytes = no face left
+        payloads = [(np.array([r[1], r[2]], np.uint32).tobytes() + r[0]) if r is not None else b"\0" * 8 for r in local]
+        got = distributed.gather_blob_lists(payloads, mine, len(flat), device=device, group=group)
+        if got is None:
+            return None
+        results = []
+        for b in got:
+            b = bytes(b)
+            nf, npts = np.frombuffer(b[:8], np.uint32)
+            results.append((b[8:], int(nf), int(npts)) if len(b) > 8 else None)
+    else:
+        results = local
+    t1 = time.perf_counter()
     out, at = [], 0
     for (doc, buffers), prims in zip(docs, per_file):
-        mine = blobs[at: at + len(prims)]
+        mine_r = results[at: at + len(prims)]
         at += len(prims)
-        out.append((_assemble(doc, buffers, prims, mine), [bytes(b) for b in mine]))
+        out.append((_assemble(doc, buffers, prims, mine_r), [bytes(r[0]) for r in mine_r if r is not None]))
+    tm["assemble_s"] = time.perf_counter() - t1
     return out
 
 

@@ -97,3 +97,75 @@ def test_shard_meshes_matches_the_python_deal_and_rank_config(monkeypatch):
         dd._rank_config(dmi.Config(device=1), torch.device("cuda", 3))
     monkeypatch.setenv("LOCAL_RANK", "9")
     assert dd._rank_config(None, torch.device("cpu")).device == 1   # 9 % 8 visible devices
+
+
+# ---- the transcode driver shards BEFORE it builds (io/gltf/transcoder.rs:134-151 around encode.rs:932-955) ----
+def _fake_assets():
+    """Three small GLBs (5 primitives) made with the test module's asset writer."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_gltf as tg
+    from draco_oxide_amd import gltf
+    files = [[tg._prim(9, 1), tg._prim(14, 2, normals=False, index_type="u16")], [tg._prim(20, 4, feat=True)], [tg._prim(12, 7), tg._prim(6, 8, uvs=False)]]
+    return [gltf.write_glb(*tg._make_asset(prims, interleave=bool(i % 2))) for i, prims in enumerate(files)]
+
+
+def _fake_encode_raw_batch(raws, cfg=None, pipeline=True, timings=None):
+    """Stands in for the device: a "blob" that names the primitive by a digest of the bytes its views reference."""
+    import hashlib
+    out = []
+    for r in raws:
+        h = hashlib.sha256()
+        for rows, t, d, par in r.atts:
+            h.update(np.ascontiguousarray(rows).tobytes())
+        h.update(np.ascontiguousarray(r.indices).tobytes())
+        out.append((h.digest(), len(r.indices) // 3, r.atts[0][0].shape[0]))
+    return out
+
+
+def _transcode_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from draco_oxide_amd import gltf
+        built = []
+        real = gltf.primitive_to_raw
+        gltf.primitive_to_raw = lambda doc, binary, prim: (built.append(gltf.primitive_weight(doc, prim)), real(doc, binary, prim))[1]
+        gltf.encode_raw_batch = _fake_encode_raw_batch
+        tm = {}
+        res = gltf.transcode_files(_fake_assets(), timings=tm)
+        q.put((rank, built, tm["primitives_built"], res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_transcode_files_shards_before_building_gloo_world2():
+    from draco_oxide_amd import gltf
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_transcode_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, built0, n0, res0), (_, built1, n1, res1) = got
+    # every rank touched only the primitives shard_indices gave it: the two shares partition the five primitives by the JSON's counts
+    weights = [2 * 9 * 9, 2 * 14 * 14, 2 * 20 * 20, 2 * 12 * 12, 2 * 6 * 6]
+    want0 = [weights[i] for i in dd.shard_indices(5, 0, 2, weights=weights)]
+    want1 = [weights[i] for i in dd.shard_indices(5, 1, 2, weights=weights)]
+    assert built0 == want0 and built1 == want1 and n0 == len(want0) and n1 == len(want1) and n0 + n1 == 5
+    assert res1 is None and len(res0) == 3
+    # rank 0 assembled every file around the gathered blobs: the same GLBs as a single process makes with the same stand-in encoder
+    gltf_encode = gltf.encode_raw_batch
+    gltf.encode_raw_batch = _fake_encode_raw_batch
+    try:
+        single = gltf.transcode_files(_fake_assets())
+    finally:
+        gltf.encode_raw_batch = gltf_encode
+    assert [g for g, _ in res0] == [g for g, _ in single] and [b for _, b in res0] == [b for _, b in single]
+    doc, _ = gltf.read_glb(res0[0][0])
+    assert doc["accessors"][doc["meshes"][0]["primitives"][1]["indices"]]["count"] == 2 * 14 * 14 * 3

@@ -226,3 +226,36 @@ def test_feature_id_accessor_conversions():
     doc = {"accessors": [{"bufferView": 0, "componentType": 5126, "count": len(vals), "type": "SCALAR"}], "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 4 * len(vals)}]}
     got = gltf._accessor_u32_scalars(doc, vals.astype("<f4").tobytes(), 0)
     assert got.tolist() == [0, 1, 255, 7, 300, 0, 0]                    # Rust `as u32`: truncates, saturates at 0, NaN → 0
+
+
+@pytest.mark.gpu
+def test_pipelined_stages_give_the_same_files(monkeypatch):
+    """Small stages (build + prepare of stage k+1 beside the encode of stage k) against one stage; encode_batch's pipelined form too."""
+    rng = np.random.default_rng(9)
+    files = [[_prim(int(rng.integers(6, 30)), seed=2000 + 8 * f + k, open_boundary=bool((f + k) % 4 == 0), index_type="u16" if k % 2 else "u32") for k in range(8)] for f in range(6)]
+    sources = [gltf.write_glb(*_make_asset(prims, interleave=bool(i % 2))) for i, prims in enumerate(files)]
+    one = gltf.transcode_files(sources, pipeline=False)
+    monkeypatch.setattr(gltf, "PIPELINE_TRIANGLES", 3000)
+    tm = {}
+    many = gltf.transcode_files(sources, pipeline=True, timings=tm)
+    assert [g for g, _ in many] == [g for g, _ in one]
+    assert tm["primitives_built"] == 48 and tm["build_s"] > 0 and tm["encode_s"] > 0
+    meshes = [gltf.primitive_to_mesh(*gltf.read_glb(src), prim)[0] for src in sources[:3] for prim in gltf.read_glb(src)[0]["meshes"][0]["primitives"]]
+    assert gltf.encode_batch(meshes, pipeline=True) == gltf.encode_batch(meshes)
+
+
+@pytest.mark.gpu
+def test_primitive_without_a_surviving_face_is_left_alone():
+    """encode.rs:934-936: a primitive whose built mesh has no face (all its faces are degenerate once equal points are merged) is not
+    compressed; its accessors keep their bufferViews."""
+    flat = _prim(6, 3)
+    flat["pos"] = np.zeros_like(flat["pos"])
+    flat["nrm"] = np.tile(np.array([[0, 0, 1]], np.float32), (len(flat["pos"]), 1))
+    flat["uv"] = np.zeros_like(flat["uv"])
+    good = _prim(7, 4)
+    (glb, blobs), = gltf.transcode_files([gltf.write_glb(*_make_asset([flat, good]))])
+    assert blobs == [_oracle_blob(good)]
+    doc, _ = gltf.read_glb(glb)
+    p0, p1 = doc["meshes"][0]["primitives"]
+    assert "extensions" not in p0 and "bufferView" in doc["accessors"][p0["attributes"]["POSITION"]]
+    assert "KHR_draco_mesh_compression" in p1["extensions"] and "bufferView" not in doc["accessors"][p1["attributes"]["POSITION"]]

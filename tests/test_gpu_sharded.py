@@ -115,3 +115,37 @@ def test_single_process_multi_device_entries():
         j.close()
     with pytest.raises(dmi.DracoMiError):
         dmi.meshes_prepare_devices(meshes, [ndev + 3] * len(meshes))   # a device that does not exist: an error code
+
+
+def _transcode_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import test_distributed_cpu as tdc
+        from draco_oxide_amd import gltf
+        tm = {}
+        res = gltf.transcode_files(tdc._fake_assets(), timings=tm)
+        q.put((rank, tm["primitives_built"], None if res is None else [blobs for _, blobs in res]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_transcode_files_over_two_ranks_builds_only_its_share():
+    """transcode_files in a two-rank job: each rank builds (dmi_meshes_build) and encodes only the primitives dealt to it, rank 0 holds
+    every blob — the same blobs a single process produces."""
+    import test_distributed_cpu as tdc
+    from draco_oxide_amd import gltf
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_transcode_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert got[0][1] + got[1][1] == 5 and 0 < got[0][1] < 5 and got[1][2] is None
+    single = gltf.transcode_files(tdc._fake_assets())
+    assert got[0][2] == [blobs for _, blobs in single]
