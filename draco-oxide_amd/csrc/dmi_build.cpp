@@ -164,6 +164,7 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
   const bool trace = std::getenv("DMI_TRACE") != nullptr;
   const bool host_values = (flags & DMI_BUILD_HOST_VALUES) != 0;
   const uint32_t n_threads = std::max(1u, std::min((uint32_t)host_threads(), kMaxPrepareWorkers));
+  const uint32_t pack_threads = std::max(2u, n_threads / 4);   // (copies into staging: a few cores saturate the memory bus; a transcode pipeline runs the previous stage's host walks beside this)
   int rc;
   for (uint32_t j = 0; j < n; ++j) if ((rc = check_raw(raw[j], j))) return rc;
   struct Cleanup { dmi_built_mesh* out; uint32_t n; bool armed = true; ~Cleanup() { if (armed) for (uint32_t j = 0; j < n; ++j) dmi_built_mesh_free(&out[j]); } } cleanup{out, n};
@@ -300,7 +301,7 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
       }
     }
     const double p0 = ms();
-    if ((rc = run_parallel((uint32_t)tasks.size(), n_threads, [&](uint32_t t) -> int {
+    if ((rc = run_parallel((uint32_t)tasks.size(), pack_threads, [&](uint32_t t) -> int {
           const Task& tk = tasks[t];
           const dmi_raw_mesh& m = raw[g.which[tk.k]];
           if (tk.i < m.n_atts) pack_rows(hp + g.row_at[g.meshes[tk.k].item0 + tk.i], m.atts[tk.i], (size_t)m.atts[tk.i].num_components * 4, tk.lo, tk.hi);

@@ -843,13 +843,18 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     if (where[x].first != where[y].first) return where[x].first < where[y].first;
     return meshes[which_all[x]].num_faces > meshes[which_all[y]].num_faces;
   });
+  std::atomic<uint64_t> ns_wait{0}, ns_conn{0}, ns_job{0}, ns_buf{0};   // thread time by step (trace)
+  auto now_ns = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   rc = parallel_over(M, [&](uint32_t t, uint32_t i) -> int {
     const uint32_t kk = walk_order[i];
     PrepGroup& g = *groups[where[kk].first];
     const uint32_t k = where[kk].second, j = g.which[k];
     const dmi_mesh& m = meshes[j];
+    const uint64_t w0 = now_ns();
     int r = g.wait_tables();
     if (r) return r;
+    const uint64_t w1 = now_ns();
+    ns_wait += w1 - w0;
     auto bail = [&](int code, const std::string& what) { return fail(code, "mesh " + std::to_string(j) + ": " + what); };
     const uint8_t* hp = g.hp;
     const uint32_t* h_words = reinterpret_cast<const uint32_t*>(hp + g.rb_words);
@@ -869,6 +874,8 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     ConnOwner& o = *owners[kk];
     std::vector<uint8_t> bytes;
     if ((r = build_connectivity(&m, o, bytes, &pre, /*view_faces=*/true))) return bail(r, g_last_error);
+    const uint64_t w2 = now_ns();
+    ns_conn += w2 - w1;
     dmi_config c = cfg0;
     c.device = device;
     g_adopt_stream = worker_stream(t % kPrepareStreams, device);   // the job's own stream for its encodes
@@ -897,7 +904,10 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
       owners[kk].reset();
     }
     if (r) return bail(r, g_last_error);
+    const uint64_t w3 = now_ns();
+    ns_job += w3 - w2;
     if ((r = to_buffer(bytes, &heads[j]))) return r;
+    ns_buf += now_ns() - w3;
     done[j] = 1;
     return DMI_OK;
   }, nullptr);
@@ -975,7 +985,8 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     uint64_t tf = 0;
     for (uint32_t k = 0; k < M; ++k) tf += meshes[which_all[k]].num_faces;
     std::fprintf(stderr, "[dmi] batch prepare, device form: %u meshes, %llu faces: layout + pack + issue of the connectivity kernels %.2f ms, host walks + job layouts %.2f (%u threads), "
-                         "sequences up + relabelling + fan rows %.2f, release %.2f; %zu jobs deferred, total %.2f\n", M, (unsigned long long)tf, t_issue, t_walks - t_issue, n_threads, t_dev - t_walks, ms() - t_dev, items.size(), ms());
+                         "sequences up + relabelling + fan rows %.2f, release %.2f; %zu jobs deferred, total %.2f; thread time: waiting for tables %.1f ms, connectivity (Edgebreaker, sequencer, bytes) %.1f, job layout %.1f, output buffer %.1f\n", M, (unsigned long long)tf, t_issue, t_walks - t_issue, n_threads, t_dev - t_walks, ms() - t_dev, items.size(), ms(),
+                         ns_wait.load() / 1e6, ns_conn.load() / 1e6, ns_job.load() / 1e6, ns_buf.load() / 1e6);
   }
   return DMI_OK;
 }

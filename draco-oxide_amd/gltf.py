@@ -12,7 +12,7 @@ Mirrors what the reference's transcoder does around the hot path (paths relative
 All primitives of a file — of a whole LIST of files (`transcode_files`, BASELINE configs[3]) — go through the device as batches: the
 accessors' bytes are handed to dmi_meshes_build as they lie in the BIN chunk (MeshBuilder::build on the GPU for all primitives at once —
 nothing is copied or deduplicated in Python), dmi_built_meshes_prepare runs the connectivity stage on the resident result and
-dmi_jobs_encode codes every stream; consecutive batches overlap (build + prepare of batch k+1 beside the encode of batch k).  On one
+dmi_jobs_encode codes every stream; consecutive stages overlap (build of stage k+2, prepare of stage k+1, encode of stage k).  On one
 GPU, on several GPUs of this process (a share per device, a thread each), or dealt over the ranks of a torch.distributed job BEFORE
 anything is built (a rank parses the JSON of every file but touches only the bytes of its own primitives) and gathered on rank 0.  Inputs: `.glb`, or `.gltf` with external /
 data-URI buffers; `_FEATURE_ID_n` attributes (EXT_mesh_features) become Custom u32 corner attributes (decode.rs:2490-2516).
@@ -36,31 +36,35 @@ _INDEX_DTYPE = {5121: np.uint8, 5123: np.uint16, 5125: np.uint32}
 _SEMANTIC_TYPE = {"POSITION": ATT_POSITION, "NORMAL": ATT_NORMAL, "TEXCOORD_0": ATT_TEXCOORD}
 
 
-def read_glb(data):
+def read_glb(data, copy=True):
+    """GLB container → (JSON document, BIN chunk).  copy=False: the BIN chunk is a memoryview of `data` (a transcode reads the accessors
+    where the caller's bytes lie; a GB of BIN chunks is not copied to be parsed)."""
     magic, version, length = struct.unpack_from("<4sII", data, 0)
     if magic != b"glTF" or version != 2:
         raise ValueError("not a GLB v2 file")
     off, doc, binary = 12, None, b""
+    view = memoryview(data)
     while off < length:
         clen, ctype = struct.unpack_from("<II", data, off)
-        chunk = data[off + 8: off + 8 + clen]
+        chunk = view[off + 8: off + 8 + clen]
         if ctype == 0x4E4F534A:
-            doc = json.loads(chunk.decode("utf-8"))
+            doc = json.loads(bytes(chunk).decode("utf-8"))
         elif ctype == 0x004E4942:
-            binary = bytes(chunk)
+            binary = bytes(chunk) if copy else chunk
         off += 8 + clen
     return doc, binary
 
 
 def write_glb(doc, binary):
     js = json.dumps(doc, separators=(",", ":")).encode("utf-8")
-    js += b" " * ((4 - len(js) % 4) % 4)                      # JSON chunk is space padded (encode.rs:392-396)
-    binary = bytes(binary) + b"\0" * ((4 - len(binary) % 4) % 4)
-    total = 12 + 8 + len(js) + (8 + len(binary) if binary else 0)
-    out = struct.pack("<4sII", b"glTF", 2, total) + struct.pack("<II", len(js), 0x4E4F534A) + js
-    if binary:
-        out += struct.pack("<II", len(binary), 0x004E4942) + binary
-    return out
+    js_pad = b" " * ((4 - len(js) % 4) % 4)                   # JSON chunk is space padded (encode.rs:392-396)
+    bin_pad = b"\0" * ((4 - len(binary) % 4) % 4)
+    n_js, n_bin = len(js) + len(js_pad), len(binary) + len(bin_pad)
+    total = 12 + 8 + n_js + (8 + n_bin if n_bin else 0)
+    parts = [struct.pack("<4sII", b"glTF", 2, total), struct.pack("<II", n_js, 0x4E4F534A), js, js_pad]
+    if n_bin:
+        parts += [struct.pack("<II", n_bin, 0x004E4942), binary, bin_pad]
+    return b"".join(parts)                                    # (one copy of the BIN chunk)
 
 
 def _buffer_of(binary, view):
@@ -128,6 +132,8 @@ def _accessor_f32_view(doc, binary, index):
     count = acc["count"]
     if count == 0:
         return np.zeros((0, n), np.float32)
+    if stride == 4 * n:
+        return np.frombuffer(_buffer_of(binary, view), dtype="<f4", count=count * n, offset=start).reshape(count, n)
     raw = np.frombuffer(_buffer_of(binary, view), dtype=np.uint8, count=stride * (count - 1) + 4 * n, offset=start)
     rows = np.lib.stride_tricks.as_strided(raw, shape=(count, 4 * n), strides=(stride, 1), writeable=False)
     return rows.view("<f4")
@@ -221,11 +227,11 @@ def primitive_to_mesh(doc, binary, prim):
 def load_document(source):
     """`.glb` bytes / path, or a `.gltf` path (external and data-URI buffers resolved) → (doc, buffers): buffers = list of bytes."""
     if isinstance(source, (bytes, bytearray, memoryview)):
-        doc, binary = read_glb(bytes(source))
+        doc, binary = read_glb(source, copy=False)
         return doc, [binary]
     data = open(source, "rb").read()
     if data[:4] == b"glTF":
-        doc, binary = read_glb(data)
+        doc, binary = read_glb(data, copy=False)
         return doc, [binary]
     doc = json.loads(data.decode("utf-8"))
     base = os.path.dirname(os.path.abspath(source))
@@ -333,7 +339,7 @@ def _assemble(doc, buffers, prims, results):
             lst = doc.setdefault(key, [])
             if "KHR_draco_mesh_compression" not in lst:
                 lst.append("KHR_draco_mesh_compression")
-    return write_glb(doc, bytes(new_bin))
+    return write_glb(doc, new_bin)
 
 
 def _chunks_by_weight(weights, limit):
@@ -350,79 +356,118 @@ def _chunks_by_weight(weights, limit):
     return out
 
 
-def _pipelined(chunks, stage1, stage2):
-    """stage2(stage1(chunk)) for every chunk, stage1 of chunk k+1 running beside stage2 of chunk k (the library calls release the GIL)."""
-    results = [None] * len(chunks)
-    if len(chunks) <= 1:
-        for k, ch in enumerate(chunks):
-            results[k] = stage2(stage1(ch))
-        return results
+def _pipelined(chunks, *stages):
+    """stages[-1](…stages[0](chunk)) for every chunk, every stage on a thread of its own, one chunk in flight between neighbours: stage s of
+    chunk k+1 runs beside stage s+1 of chunk k (the library calls release the GIL).  The first element of what a stage returns is a list of
+    jobs (closed if a later stage fails)."""
+    if len(chunks) <= 1 or len(stages) == 1:
+        for ch in chunks:
+            x = ch
+            for st in stages:
+                x = st(x)
+        return
+    import queue
+    qs = [queue.Queue(maxsize=1) for _ in range(len(stages) - 1)]
     err = []
-    pending = None                                                       # (thread, k)
+    stop = object()
 
-    def run2(k, mid):
-        try:
-            results[k] = stage2(mid)
-        except BaseException as e:                                        # noqa: BLE001 — re-raised on the caller's thread
-            err.append(e)
+    def run(si):
+        src = qs[si - 1]
+        while True:
+            x = src.get()
+            if x is stop:
+                break
+            try:
+                if err:
+                    _drop(x)
+                    continue
+                y = stages[si](x)
+                if si + 1 < len(stages):
+                    qs[si].put(y)
+            except BaseException as e:                                    # noqa: BLE001 — re-raised on the caller's thread
+                err.append(e)
+                _drop(x)
+        if si + 1 < len(stages):
+            qs[si].put(stop)
 
-    for k, ch in enumerate(chunks):
-        mid = stage1(ch)
-        if pending is not None:
-            pending.join()
-        if err:
-            _drop(mid)
-            raise err[0]
-        pending = threading.Thread(target=run2, args=(k, mid))
-        pending.start()
-    pending.join()
+    threads = [threading.Thread(target=run, args=(si,)) for si in range(1, len(stages))]
+    for t in threads:
+        t.start()
+    try:
+        for ch in chunks:
+            if err:
+                break
+            qs[0].put(stages[0](ch))
+    except BaseException as e:                                            # noqa: BLE001
+        err.append(e)
+    qs[0].put(stop)
+    for t in threads:
+        t.join()
     if err:
         raise err[0]
-    return results
 
 
 def _drop(mid):
-    for j in (mid[0] if mid else []):
-        j.close()
+    """Release what a stage handed on when a later stage cannot take it: jobs are closed, a built batch is freed."""
+    first = mid[0] if isinstance(mid, tuple) and mid else None
+    if hasattr(first, "free"):
+        first.free()
+    elif isinstance(first, list):
+        for j in first:
+            if hasattr(j, "close"):
+                j.close()
 
 
 PIPELINE_TRIANGLES = 6 << 20     # triangles per pipeline stage of a large batch (one connectivity group of the library)
 
 
-def encode_raw_batch(raws, cfg=None, pipeline=True, timings=None):
+def encode_raw_batch(raws, cfg=None, pipeline=True, timings=None, weights=None, on_done=None):
     """RawMesh list → [(blob, num_faces, num_points) or None (no face left)] on ONE device: dmi_meshes_build → dmi_built_meshes_prepare →
-    dmi_jobs_encode, in stages of ≈ PIPELINE_TRIANGLES triangles whose build + prepare overlap the previous stage's encode."""
+    dmi_jobs_encode, in stages of ≈ PIPELINE_TRIANGLES triangles: the build of stage k+2, the prepare of stage k+1 and the encode of stage k
+    run side by side (three threads; the host walks of the prepare are the longest step and keep the host's cores, the build's packing and
+    the encode's read-back fit beside them).  `raws` may be a callable i → RawMesh (made when its stage is built: the accessor views of
+    stage k+2 are set up beside the device work of the earlier stages) together with `weights` (triangles per primitive).
+    on_done(indices, out) (optional): a fourth stage, called with the primitives of every finished stage (the caller reassembles files)."""
     cfg = cfg or Config.default()
-    out = [None] * len(raws)
-    if not raws:
+    make = raws if callable(raws) else None
+    n = len(weights) if make else len(raws)
+    out = [None] * n
+    if not n:
         return out
     import time
-    weights = [len(r.indices) // 3 if r.indices is not None else 0 for r in raws]
-    chunks = _chunks_by_weight(weights, PIPELINE_TRIANGLES) if pipeline else [list(range(len(raws)))]
+    if weights is None:
+        weights = [len(r.indices) // 3 if r.indices is not None else 0 for r in raws]
+    chunks = _chunks_by_weight(weights, PIPELINE_TRIANGLES) if pipeline else [list(range(n))]
     tm = timings if timings is not None else {}
-    for key in ("build_s", "prepare_s", "encode_s", "build_kernels_ms", "build_pack_ms"):
+    for key in ("views_s", "build_s", "prepare_s", "encode_s", "build_kernels_ms", "build_pack_ms"):
         tm.setdefault(key, 0.0)
 
-    def stage1(ch):
+    def build(ch):
         t0 = time.perf_counter()
-        batch = meshes_build([raws[i] for i in ch], cfg)
+        mine = [make(i) for i in ch] if make else [raws[i] for i in ch]
         t1 = time.perf_counter()
+        batch = meshes_build(mine, cfg)
+        bt = last_build_timings()
+        tm["views_s"] += t1 - t0
+        tm["build_s"] += time.perf_counter() - t1
+        tm["build_kernels_ms"] += bt["kernels_ms"]
+        tm["build_pack_ms"] += bt["pack_ms"]
+        return batch, ch
+
+    def prepare(mid):
+        batch, ch = mid
+        t0 = time.perf_counter()
         try:
-            bt = last_build_timings()
             keep = [k for k in range(len(ch)) if batch.num_faces(k) > 0]
             info = [batch.summary(k) for k in keep]
             jobs = built_meshes_prepare(batch, keep, cfg)
         finally:
             batch.free()
-        t2 = time.perf_counter()
-        tm["build_s"] += t1 - t0
-        tm["prepare_s"] += t2 - t1
-        tm["build_kernels_ms"] += bt["kernels_ms"]
-        tm["build_pack_ms"] += bt["pack_ms"]
+        tm["prepare_s"] += time.perf_counter() - t0
         return jobs, [ch[k] for k in keep], info
 
-    def stage2(mid):
-        jobs, where, info = mid
+    def encode(mid):
+        jobs, where, info = mid[:3]
         t0 = time.perf_counter()
         try:
             sections = jobs_encode(jobs) if jobs else []
@@ -432,9 +477,19 @@ def encode_raw_batch(raws, cfg=None, pipeline=True, timings=None):
             for j in jobs:
                 j.close()
         tm["encode_s"] += time.perf_counter() - t0
+        return None, mid[3]
+
+    def prepare_ch(mid):
+        return prepare(mid) + (mid[1],)
+
+    def finish(mid):
+        on_done(mid[1], out)
         return None
 
-    _pipelined(chunks, stage1, stage2)
+    if on_done:
+        _pipelined(chunks, build, prepare_ch, encode, finish)
+    else:
+        _pipelined(chunks, build, prepare_ch, encode)
     return out
 
 
@@ -497,7 +552,7 @@ def transcode_files(sources, cfg=None, devices=None, group=None, device=None, pi
     share by triangle count, a thread per device), or the ranks of a torch.distributed job: the primitives are dealt by the triangle
     counts the JSON states, each rank builds and encodes ONLY its share, rank 0 gathers the blobs and reassembles the files.
     Returns [(glb_bytes, [blob, ...]), ...] in input order — on the destination rank; None on the other ranks of a sharded job.
-    timings (optional dict): parse_s, build_s, prepare_s, encode_s, assemble_s, primitives_built (this rank)."""
+    timings (optional dict): parse_s (JSON), views_s (accessor views), build_s, prepare_s, encode_s, assemble_s, primitives_built (this rank)."""
     import time
     tm = timings if timings is not None else {}
     t0 = time.perf_counter()
@@ -517,22 +572,27 @@ def transcode_files(sources, cfg=None, devices=None, group=None, device=None, pi
         cfg = distributed._rank_config(cfg, device)
     else:
         mine = list(range(len(flat)))
-    raws = [primitive_to_raw(docs[flat[i][0]][0], docs[flat[i][0]][1], per_file[flat[i][0]][flat[i][1]][0])[0] for i in mine]
+    built = [0]
+
+    def raw_of(k):   # the k-th primitive of this rank's share (made when its stage is built)
+        fi, pi = flat[mine[k]]
+        built[0] += 1
+        return primitive_to_raw(docs[fi][0], docs[fi][1], per_file[fi][pi][0])[0]
+
+    w_mine = [weights[i] for i in mine]
     tm["parse_s"] = time.perf_counter() - t0
-    tm["primitives_built"] = len(raws)
     n_dev = device_count() if devices == "all" else int(devices or 1)
     n_dev = max(1, min(n_dev, device_count()))
-    if world == 1 and n_dev > 1 and raws:
+    if world == 1 and n_dev > 1 and mine:
         from .distributed import shard_indices
-        w_mine = [weights[i] for i in mine]
-        local = [None] * len(raws)
+        local = [None] * len(mine)
         errs = []
 
         def run(d):
             try:
-                idx = shard_indices(len(raws), d, n_dev, weights=w_mine)
+                idx = shard_indices(len(mine), d, n_dev, weights=w_mine)
                 c = Config(**{**(cfg.__dict__ if cfg else {}), "device": d})
-                for i, r in zip(idx, encode_raw_batch([raws[i] for i in idx], c, pipeline=pipeline)):
+                for i, r in zip(idx, encode_raw_batch(lambda k: raw_of(idx[k]), c, pipeline=pipeline, weights=[w_mine[i] for i in idx])):
                     local[i] = r
             except BaseException as e:                                    # noqa: BLE001
                 errs.append(e)
@@ -545,7 +605,32 @@ def transcode_files(sources, cfg=None, devices=None, group=None, device=None, pi
         if errs:
             raise errs[0]
     else:
-        local = encode_raw_batch(raws, cfg, pipeline=pipeline, timings=tm)
+        # one device: a file is reassembled as soon as its last primitive is coded (a fourth stage beside the device work of the next ones)
+        assembled = [None] * len(docs)
+        left = [len(prims) for prims in per_file]
+        first = [0] * len(docs)
+        for fi in range(1, len(docs)):
+            first[fi] = first[fi - 1] + len(per_file[fi - 1])
+        tm["assemble_s"] = 0.0
+
+        def on_done(indices, out):
+            ta = time.perf_counter()
+            for k in indices:
+                fi = flat[mine[k]][0]
+                left[fi] -= 1
+                if left[fi] == 0 and world == 1:
+                    res = out[first[fi]: first[fi] + len(per_file[fi])]
+                    assembled[fi] = (_assemble(docs[fi][0], docs[fi][1], per_file[fi], res), [r[0] for r in res if r is not None])
+            tm["assemble_s"] += time.perf_counter() - ta
+
+        local = encode_raw_batch(raw_of, cfg, pipeline=pipeline, timings=tm, weights=w_mine, on_done=on_done if world == 1 else None)
+        if world == 1:
+            tm["primitives_built"] = built[0]
+            for fi in range(len(docs)):
+                if assembled[fi] is None:   # (a file without a compressible primitive)
+                    assembled[fi] = (_assemble(docs[fi][0], docs[fi][1], per_file[fi], []), [])
+            return assembled
+    tm["primitives_built"] = built[0]
     if world > 1:
         # the blobs travel with their face / point counts (rank 0 writes them into the placeholder accessors); 8 zero bytes = no face left
         payloads = [(np.array([r[1], r[2]], np.uint32).tobytes() + r[0]) if r is not None else b"\0" * 8 for r in local]

@@ -82,3 +82,42 @@ def batch_meshes(n_meshes, lo=2e3, hi=2e5, seed=SEED):
     rng = np.random.default_rng(seed)
     tris = np.exp(rng.uniform(np.log(lo), np.log(hi), size=n_meshes))
     return [torus_mesh(max(8, grid_size_for_triangles(t)), seed=seed + 7 * k) for k, t in enumerate(tris)]
+
+
+def torus_glb(n, seed=SEED, open_boundary=False):
+    """One torus grid as a minimal GLB (one mesh, one triangle primitive; POSITION / NORMAL / TEXCOORD_0 as separate float accessors,
+    UNSIGNED_SHORT indices when the vertex count allows, else UNSIGNED_INT) → (glb bytes, triangles)."""
+    import json
+    import struct
+    faces, pos, nrm, uv = torus_grid(n, seed, open_boundary=open_boundary)
+    idx = faces.ravel().astype("<u2" if len(pos) <= 65535 else "<u4")
+    parts = [pos.astype("<f4").tobytes(), nrm.astype("<f4").tobytes(), uv.astype("<f4").tobytes(), idx.tobytes()]
+    views, off = [], 0
+    for b in parts:
+        views.append({"buffer": 0, "byteOffset": off, "byteLength": len(b)})
+        off += (len(b) + 3) & ~3
+    binary = b"".join(b + b"\0" * ((4 - len(b) % 4) % 4) for b in parts)
+    acc = [{"bufferView": 0, "componentType": 5126, "count": len(pos), "type": "VEC3", "min": pos.min(axis=0).tolist(), "max": pos.max(axis=0).tolist()},
+           {"bufferView": 1, "componentType": 5126, "count": len(pos), "type": "VEC3"},
+           {"bufferView": 2, "componentType": 5126, "count": len(pos), "type": "VEC2"},
+           {"bufferView": 3, "componentType": 5123 if idx.dtype.itemsize == 2 else 5125, "count": int(idx.size), "type": "SCALAR"}]
+    doc = {"asset": {"version": "2.0"}, "buffers": [{"byteLength": len(binary)}], "bufferViews": views, "accessors": acc,
+           "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "NORMAL": 1, "TEXCOORD_0": 2}, "indices": 3, "mode": 4}]}],
+           "nodes": [{"mesh": 0}], "scenes": [{"nodes": [0]}], "scene": 0}
+    js = json.dumps(doc, separators=(",", ":")).encode("utf-8")
+    js += b" " * ((4 - len(js) % 4) % 4)
+    total = 12 + 8 + len(js) + 8 + len(binary)
+    return struct.pack("<4sII", b"glTF", 2, total) + struct.pack("<II", len(js), 0x4E4F534A) + js + struct.pack("<II", len(binary), 0x004E4942) + binary, len(faces)
+
+
+def batch_glbs(n_files, lo=2e3, hi=2e5, seed=SEED):
+    """The batch workload of batch_meshes as GLB files in memory (BASELINE configs[3]: "1024 glTF/glb meshes through … transcode") →
+    ([glb bytes], total triangles).  Same grids, same seeds."""
+    rng = np.random.default_rng(seed)
+    tris = np.exp(rng.uniform(np.log(lo), np.log(hi), size=n_files))
+    out, total = [], 0
+    for k, t in enumerate(tris):
+        g, f = torus_glb(max(8, grid_size_for_triangles(t)), seed=seed + 7 * k)
+        out.append(g)
+        total += f
+    return out, total

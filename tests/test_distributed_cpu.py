@@ -110,16 +110,18 @@ def _fake_assets():
     return [gltf.write_glb(*tg._make_asset(prims, interleave=bool(i % 2))) for i, prims in enumerate(files)]
 
 
-def _fake_encode_raw_batch(raws, cfg=None, pipeline=True, timings=None):
+def _fake_encode_raw_batch(raws, cfg=None, pipeline=True, timings=None, weights=None, on_done=None):
     """Stands in for the device: a "blob" that names the primitive by a digest of the bytes its views reference."""
     import hashlib
     out = []
-    for r in raws:
+    for r in ([raws(i) for i in range(len(weights))] if callable(raws) else raws):
         h = hashlib.sha256()
         for rows, t, d, par in r.atts:
             h.update(np.ascontiguousarray(rows).tobytes())
         h.update(np.ascontiguousarray(r.indices).tobytes())
         out.append((h.digest(), len(r.indices) // 3, r.atts[0][0].shape[0]))
+    if on_done:
+        on_done(list(range(len(out))), out)
     return out
 
 
