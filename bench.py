@@ -170,15 +170,14 @@ def transcode_regime(n_files=1024, steps=2, device=0):
         dt = time.perf_counter() - t0
         if best is None or dt < best:
             best, best_tm = dt, tm
-    t0 = time.perf_counter()
-    res1 = gltf.transcode_files(glbs, cfg, pipeline=False)
-    unpiped = time.perf_counter() - t0
+    res1 = gltf.transcode_files(glbs[: n_files // 8 + 1], cfg, pipeline=False)   # one stage: the same files
     # a sample of the embedded blobs against whole-mesh encodes of the host-built meshes (dmi_mesh_build), which the tests hold against the oracle
     ok = True
     for i in sorted({0, n_files // 3, n_files // 2, n_files - 1}):
         doc, binary = gltf.read_glb(glbs[i])
         mesh, _ = gltf.primitive_to_mesh(doc, binary, doc["meshes"][0]["primitives"][0])
-        ok = ok and res[i][1][0] == dmi.encode_mesh(mesh, cfg) and res1[i][1][0] == res[i][1][0]
+        ok = ok and res[i][1][0] == dmi.encode_mesh(mesh, cfg)
+    ok = ok and all(a[0] == b[0] for a, b in zip(res1, res))
     out_bytes = sum(len(g) for g, _ in res)
     tm = best_tm
     return {"workload": f"BASELINE configs[3]: {n_files} GLB files in memory (one primitive each, F log-uniform [2k,200k], pos+nrm+uv, u16/u32 indices) → gltf.transcode_files → {n_files} "
@@ -188,8 +187,8 @@ def transcode_regime(n_files=1024, steps=2, device=0):
                          "prepare (device tables, host walks, relabelling)": round(tm["prepare_s"] * 1e3, 2), "encode (beside the next stage's build + prepare)": round(tm["encode_s"] * 1e3, 2),
                          "assemble": round(tm["assemble_s"] * 1e3, 2)},
             "build_kernels_ms": round(tm["build_kernels_ms"], 3), "build_pack_ms": round(tm["build_pack_ms"], 3),
-            "unpipelined_ms": round(unpiped * 1e3, 2), "input_bytes": int(in_bytes), "output_bytes": int(out_bytes),
-            "sample_blobs_equal_whole_mesh_encodes": bool(ok)}
+            "input_bytes": int(in_bytes), "output_bytes": int(out_bytes),
+            "sample_blobs_equal_whole_mesh_encodes_and_one_stage_files": bool(ok)}
 
 
 def batch_sharded(n_meshes, rank, world, local_rank, gather_dev, steps=2):
