@@ -430,6 +430,11 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
       ++n_device;
     }
     bg.total_faces = faces_seen;
+    // the universal corner tables of the group's meshes, right behind the build: on the host by the time dmi_built_meshes_prepare walks them
+    // (a mesh of 2^20 faces or more goes through the single-mesh prepare, which builds its own)
+    bool any_large = false;
+    for (const auto& mem : bg.members) any_large = any_large || mem.F >= kDeviceRelabelMinFaces;
+    if (!any_large && faces_seen && !std::getenv("DMI_HOST_CONNECTIVITY") && (rc = built_group_issue_tables(bg, g.S))) return rc;
     bg.stream = nullptr; bg.keep.pool.stream = nullptr;   // (everything of the build has arrived; the library stream belongs to this thread, the group may outlive it)
     release_stage(g.up_stage); g.up_stage = nullptr;
   }

@@ -340,11 +340,31 @@ struct BuiltGroup {
   struct Member { uint32_t F = 0, P = 0, raw_faces = 0; size_t faces_off = 0 /* bytes into arena A */; std::vector<Att> atts /* in the built mesh's order */; };
   std::vector<Member> members;        // in arena order
   uint64_t total_faces = 0;           // Σ members' F
+  // The universal corner tables of all members (dmi_conn.hip), issued by dmi_meshes_build right behind the build so that they are on the
+  // host by the time dmi_built_meshes_prepare's walks want them (a transcode pipeline prepares stage k while stage k+1 is built).
+  struct Conn {
+    bool issued = false, any_mapped = false;
+    TempDev mem;
+    HostStage* stage = nullptr;
+    uint8_t* hp = nullptr;
+    uint32_t *d_c2v = nullptr, *d_opp = nullptr;
+    size_t rb_opp = 0, rb_c2v = 0, rb_lmc = 0, rb_onb = 0, rb_words = 0;
+    uint32_t n_desc = 0;
+    uint64_t total_verts = 0;
+    hipEvent_t ev = nullptr;
+  } conn;
   BuiltGroup() = default;
   BuiltGroup(const BuiltGroup&) = delete;
   BuiltGroup& operator=(const BuiltGroup&) = delete;
-  ~BuiltGroup() { if (stream) (void)hipStreamSynchronize(stream); release_stage(stage); }
+  ~BuiltGroup() {
+    if (conn.ev) { (void)hipEventSynchronize(conn.ev); (void)hipEventDestroy(conn.ev); }
+    if (stream) (void)hipStreamSynchronize(stream);
+    release_stage(conn.stage);
+    release_stage(stage);
+  }
 };
+// the connectivity kernels + read-back of a built group on `s` (dmi_prepare.cpp); bg.conn.ev fires when the tables are on the host
+int built_group_issue_tables(BuiltGroup& bg, hipStream_t s);
 struct BuiltDevice : BuiltBase {
   std::shared_ptr<BuiltGroup> group;
   uint32_t member = 0;

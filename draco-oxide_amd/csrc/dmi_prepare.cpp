@@ -560,6 +560,7 @@ struct PrepGroup {
   uint32_t *d_c2v = nullptr, *d_opp = nullptr;
   size_t rb_opp = 0, rb_c2v = 0, rb_lmc = 0, rb_onb = 0, rb_words = 0;
   hipEvent_t ev_tables = nullptr, ev_values = nullptr;
+  hipEvent_t ev_tables_borrowed = nullptr;   // an adopted group's tables were issued by its build: the event belongs to the BuiltGroup
   bool tables_in = false;
   std::mutex wait_mutex;
   ~PrepGroup() {
@@ -571,12 +572,72 @@ struct PrepGroup {
   int wait_tables() {   // (any worker: the first one blocks on the event, the others on the mutex)
     std::lock_guard<std::mutex> lock(wait_mutex);
     if (tables_in) return DMI_OK;
-    HIP_TRY(hipEventSynchronize(ev_tables));
+    HIP_TRY(hipEventSynchronize(ev_tables_borrowed ? ev_tables_borrowed : ev_tables));
     tables_in = true;
     return DMI_OK;
   }
 };
 }  // namespace
+
+// The universal corner tables of every member of a device-built group: descriptors up, the dmi_conn.hip kernels, the tables back into the
+// group's own staging.  Nothing here waits; bg.conn.ev fires when the read-back has arrived.
+extern "C++" int dmi::built_group_issue_tables(BuiltGroup& bg, hipStream_t s) {
+  BuiltGroup::Conn& cn = bg.conn;
+  if (cn.issued) return DMI_OK;
+  HIP_TRY(hipSetDevice(bg.device));
+  const uint32_t ND = (uint32_t)bg.members.size();
+  uint64_t verts = 0;
+  cn.any_mapped = false;
+  for (const auto& mem : bg.members) { verts += mem.atts.empty() ? 0u : mem.atts[0].n_unique; cn.any_mapped = cn.any_mapped || (!mem.atts.empty() && mem.atts[0].map_off != (size_t)-1); }
+  if (verts >= (1ull << 31) || bg.total_faces >= (1ull << 30)) return fail(DMI_ERR_INVALID_ARGUMENT, "built group too large");
+  cn.total_verts = verts; cn.n_desc = ND;
+  const size_t C = (size_t)bg.total_faces * 3, nv = (size_t)verts + 1, parts = scan_partials_words((uint32_t)nv);
+  cn.mem.init(bg.device, s, C * 4 * (cn.any_mapped ? 4 : 3) + C + nv * 4 * 4 + nv + parts * 4 + (size_t)ND * (sizeof(ConnMeshDesc) + 8) + ((size_t)1 << 20));
+  const uint32_t* d_faces = reinterpret_cast<const uint32_t*>(bg.d_base);
+  cn.d_c2v = cn.any_mapped ? cn.mem.take<uint32_t>(C) : const_cast<uint32_t*>(d_faces);
+  cn.d_opp = cn.mem.take<uint32_t>(C);
+  uint32_t* d_lmc = cn.mem.take<uint32_t>(nv);
+  uint8_t* d_onb = cn.mem.take<uint8_t>(nv);
+  uint32_t* d_words = cn.mem.take<uint32_t>((size_t)2 * ND);
+  ConnMeshDesc* d_desc = cn.mem.take<ConnMeshDesc>(ND);
+  ConnArgs a{};
+  a.ecount = cn.mem.take<uint32_t>(nv); a.efill = cn.mem.take<uint32_t>(nv); a.first = cn.mem.take<uint32_t>(nv);
+  a.he_key = cn.mem.take<uint32_t>(C); a.he_corner = cn.mem.take<uint32_t>(C);
+  a.cdone = cn.mem.take<uint8_t>(C);
+  a.scan_partials = cn.mem.take<uint32_t>(parts);
+  if (!cn.d_c2v || !cn.d_opp || !d_lmc || !d_onb || !d_words || !d_desc || !a.ecount || !a.efill || !a.first || !a.he_key || !a.he_corner || !a.cdone || !a.scan_partials)
+    return fail(DMI_ERR_OUT_OF_MEMORY, "hipMalloc (batch connectivity stage)");
+  cn.rb_opp = 0; cn.rb_c2v = cn.rb_opp + align256(C * 4); cn.rb_lmc = cn.rb_c2v + (cn.any_mapped ? align256(C * 4) : 0); cn.rb_onb = cn.rb_lmc + align256(nv * 4);
+  cn.rb_words = cn.rb_onb + align256(nv);
+  const size_t rb_desc = cn.rb_words + align256((size_t)ND * 8), host_need = rb_desc + align256((size_t)ND * sizeof(ConnMeshDesc));
+  cn.stage = acquire_stage(bg.device, host_need);
+  if (!cn.stage) return fail(DMI_ERR_OUT_OF_MEMORY, "hipHostMalloc (batch connectivity staging)");
+  uint8_t* hp = cn.hp = cn.stage->p;
+  ConnMeshDesc* h_desc = reinterpret_cast<ConnMeshDesc*>(hp + rb_desc);
+  uint64_t vert = 0;
+  for (uint32_t mi = 0; mi < ND; ++mi) {
+    const BuiltGroup::Member& mem = bg.members[mi];
+    const uint32_t vcap = mem.atts.empty() ? 0u : mem.atts[0].n_unique;
+    const bool mapped = !mem.atts.empty() && mem.atts[0].map_off != (size_t)-1;
+    h_desc[mi] = ConnMeshDesc{(uint32_t)(mem.faces_off / 12), (uint32_t)vert, mem.F, vcap, mapped ? (uint32_t)(mem.atts[0].map_off / 4) : kNone, mem.P, 0u, 0u};
+    vert += vcap;
+  }
+  HIP_TRY(hipMemcpyAsync(d_desc, h_desc, (size_t)ND * sizeof(ConnMeshDesc), hipMemcpyHostToDevice, s));
+  a.meshes = d_desc; a.M = ND; a.total_faces = (uint32_t)bg.total_faces; a.total_verts = (uint32_t)verts;
+  a.faces = d_faces; a.p2v = reinterpret_cast<const uint32_t*>(bg.d_base); a.c2v = cn.d_c2v; a.opp = cn.d_opp; a.lmc = d_lmc; a.on_boundary = d_onb; a.flags = d_words; a.vmax = d_words + ND;
+  HIP_TRY(conn_tables_clear(a, s));
+  launch_conn_tables(a, s);
+  HIP_TRY(hipMemcpyAsync(hp + cn.rb_words, d_words, (size_t)ND * 8, hipMemcpyDeviceToHost, s));
+  if (C) HIP_TRY(hipMemcpyAsync(hp + cn.rb_opp, cn.d_opp, C * 4, hipMemcpyDeviceToHost, s));
+  if (cn.any_mapped && C) HIP_TRY(hipMemcpyAsync(hp + cn.rb_c2v, cn.d_c2v, C * 4, hipMemcpyDeviceToHost, s));
+  if (verts) HIP_TRY(hipMemcpyAsync(hp + cn.rb_lmc, d_lmc, (size_t)verts * 4, hipMemcpyDeviceToHost, s));
+  if (verts) HIP_TRY(hipMemcpyAsync(hp + cn.rb_onb, d_onb, (size_t)verts, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipEventCreateWithFlags(&cn.ev, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(cn.ev, s));
+  cn.mem.pool.stream = nullptr;   // (the stream is a thread's library stream and the group may outlive the thread: its destructor waits for cn.ev instead)
+  cn.issued = true;
+  return DMI_OK;
+}
 
 // adopt (nullable): the groups are device-built ones (dmi_meshes_build) — which_all then lists their PRESENT members in group order
 // (present[member] = index into the caller's arrays, -1 = not part of this call; the connectivity kernels run over every member: the
@@ -687,53 +748,14 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
         l.pos_map = l.maps[0];
         l.faces = mem.faces_off;
       }
-      const size_t C = g.C, nv = (size_t)g.total_verts + 1, parts = scan_partials_words((uint32_t)nv);
-      const uint32_t ND = g.n_desc;
-      g.mem.init(device, g.S, C * 4 * (g.any_mapped ? 4 : 3) + C + nv * 4 * 4 + nv + parts * 4 + (size_t)ND * (sizeof(ConnMeshDesc) + 8) + ((size_t)1 << 20));
+      (void)want_lmc;   // (left-most corners always come back for a built group: 4 bytes per vertex)
+      if (!bg.conn.issued && (rc = built_group_issue_tables(bg, g.S))) return rc;
       g.d_up = bg.d_base;
       g.d_faces = reinterpret_cast<const uint32_t*>(bg.d_base);
-      g.d_c2v = g.any_mapped ? g.mem.take<uint32_t>(C) : const_cast<uint32_t*>(g.d_faces);
-      g.d_opp = g.mem.take<uint32_t>(C);
-      uint32_t* d_lmc = g.mem.take<uint32_t>(nv);
-      uint8_t* d_onb = g.mem.take<uint8_t>(nv);
-      uint32_t* d_words = g.mem.take<uint32_t>((size_t)2 * ND);
-      ConnMeshDesc* d_desc = g.mem.take<ConnMeshDesc>(ND);
-      ConnArgs a{};
-      a.ecount = g.mem.take<uint32_t>(nv); a.efill = g.mem.take<uint32_t>(nv); a.first = g.mem.take<uint32_t>(nv);
-      a.he_key = g.mem.take<uint32_t>(C); a.he_corner = g.mem.take<uint32_t>(C);
-      a.cdone = g.mem.take<uint8_t>(C);
-      a.scan_partials = g.mem.take<uint32_t>(parts);
-      if (!g.d_c2v || !g.d_opp || !d_lmc || !d_onb || !d_words || !d_desc || !a.ecount || !a.efill || !a.first || !a.he_key || !a.he_corner || !a.cdone || !a.scan_partials)
-        return fail(DMI_ERR_OUT_OF_MEMORY, "hipMalloc (batch connectivity stage)");
-      g.rb_opp = 0; g.rb_c2v = g.rb_opp + align256(C * 4); g.rb_lmc = g.rb_c2v + (g.any_mapped ? align256(C * 4) : 0); g.rb_onb = g.rb_lmc + align256(nv * 4);
-      g.rb_words = g.rb_onb + align256(nv);
-      const size_t rb_desc = g.rb_words + align256((size_t)ND * 8), host_need = rb_desc + align256((size_t)ND * sizeof(ConnMeshDesc));
-      g.stage = acquire_stage(device, host_need);
-      if (!g.stage) return fail(DMI_ERR_OUT_OF_MEMORY, "hipHostMalloc (batch connectivity staging)");
-      uint8_t* hp = g.hp = g.stage->p;
-      ConnMeshDesc* h_desc = reinterpret_cast<ConnMeshDesc*>(hp + rb_desc);
-      uint64_t vert = 0;
-      for (uint32_t mi = 0; mi < ND; ++mi) {
-        const BuiltGroup::Member& mem = bg.members[mi];
-        const uint32_t vcap = mem.atts.empty() ? 0u : mem.atts[0].n_unique;
-        const bool mapped = !mem.atts.empty() && mem.atts[0].map_off != (size_t)-1;
-        h_desc[mi] = ConnMeshDesc{(uint32_t)(mem.faces_off / 12), (uint32_t)vert, mem.F, vcap, mapped ? (uint32_t)(mem.atts[0].map_off / 4) : kNone, mem.P, 0u, 0u};
-        vert += vcap;
-      }
-      HIP_TRY(hipMemcpyAsync(d_desc, h_desc, (size_t)ND * sizeof(ConnMeshDesc), hipMemcpyHostToDevice, g.S));
-      a.meshes = d_desc; a.M = ND; a.total_faces = (uint32_t)g.total_faces; a.total_verts = (uint32_t)g.total_verts;
-      a.faces = g.d_faces; a.p2v = reinterpret_cast<const uint32_t*>(g.d_up); a.c2v = g.d_c2v; a.opp = g.d_opp; a.lmc = d_lmc; a.on_boundary = d_onb; a.flags = d_words; a.vmax = d_words + ND;
-      HIP_TRY(conn_tables_clear(a, g.S));
-      launch_conn_tables(a, g.S);
-      HIP_TRY(hipMemcpyAsync(hp + g.rb_words, d_words, (size_t)ND * 8, hipMemcpyDeviceToHost, g.S));
-      if (C) HIP_TRY(hipMemcpyAsync(hp + g.rb_opp, g.d_opp, C * 4, hipMemcpyDeviceToHost, g.S));
-      if (g.any_mapped && C) HIP_TRY(hipMemcpyAsync(hp + g.rb_c2v, g.d_c2v, C * 4, hipMemcpyDeviceToHost, g.S));
-      if (want_lmc && g.total_verts) HIP_TRY(hipMemcpyAsync(hp + g.rb_lmc, d_lmc, (size_t)g.total_verts * 4, hipMemcpyDeviceToHost, g.S));
-      if (g.total_verts) HIP_TRY(hipMemcpyAsync(hp + g.rb_onb, d_onb, (size_t)g.total_verts, hipMemcpyDeviceToHost, g.S));
-      HIP_TRY(hipEventCreateWithFlags(&g.ev_tables, hipEventDisableTiming));
-      HIP_TRY(hipEventRecord(g.ev_tables, g.S));
-      HIP_TRY(hipEventCreateWithFlags(&g.ev_values, hipEventDisableTiming));
-      HIP_TRY(hipEventRecord(g.ev_values, g.S));
+      g.d_c2v = bg.conn.d_c2v; g.d_opp = bg.conn.d_opp;
+      g.hp = bg.conn.hp;
+      g.rb_opp = bg.conn.rb_opp; g.rb_c2v = bg.conn.rb_c2v; g.rb_lmc = bg.conn.rb_lmc; g.rb_onb = bg.conn.rb_onb; g.rb_words = bg.conn.rb_words;
+      g.ev_tables_borrowed = bg.conn.ev;
       continue;
     }
     g.n_desc = Mg;
@@ -936,7 +958,8 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     for (const auto& cp : d.copies) moves.push_back({cp.dst, cp.src_dev, (cp.bytes + 15) & ~(size_t)15});
   }
   if (rf >= (1ull << 32) / 3 || rv >= (1ull << 32) || rk >= (1ull << 32) || fan_total >= (1ull << 32) || comp_total >= (1ull << 32)) return fail(DMI_ERR_INVALID_ARGUMENT, "batch slice too large");
-  for (auto& g : groups) HIP_TRY(hipStreamWaitEvent(S, g->ev_values, 0));   // the values the jobs copy from must have arrived
+  for (auto& g : groups) if (g->ev_values) HIP_TRY(hipStreamWaitEvent(S, g->ev_values, 0));   // the values the jobs copy from must have arrived (a built group's are: its build waited)
+  for (auto& g : groups) if (g->ev_tables_borrowed) HIP_TRY(hipStreamWaitEvent(S, g->ev_tables_borrowed, 0));   // (its device tables, which the relabelling reads)
   TempDev mem3;
   struct StageGuard { HostStage* st = nullptr; ~StageGuard() { release_stage(st); } } stage3;
   if (!items.empty() || !moves.empty()) {
