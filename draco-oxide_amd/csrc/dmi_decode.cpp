@@ -155,8 +155,18 @@ void dmi_decoded_free(dmi_decoded* d) {
   d->owner = nullptr; d->attributes = nullptr; d->num_attributes = 0;
 }
 
+static int decode_attributes_impl(const uint8_t* section, size_t len, const dmi_corner_table* tables, uint32_t n_tables, const uint32_t* seeds, uint32_t n_seeds,
+                                  uint32_t num_points, const dmi_config* cfg_in, dmi_decoded* out);
+// (no exception crosses the C boundary: a damaged file that asks for more memory than there is comes back as an error code)
 int dmi_decode_attributes(const uint8_t* section, size_t len, const dmi_corner_table* tables, uint32_t n_tables, const uint32_t* seeds, uint32_t n_seeds,
                           uint32_t num_points, const dmi_config* cfg_in, dmi_decoded* out) {
+  try {
+    return decode_attributes_impl(section, len, tables, n_tables, seeds, n_seeds, num_points, cfg_in, out);
+  } catch (const std::bad_alloc&) { return host_fail(DMI_ERR_OUT_OF_MEMORY, "out of memory decoding the attribute section"); }
+  catch (const std::exception& e) { return host_fail(DMI_ERR_ENTROPY, std::string("attribute decoding failed: ") + e.what()); }
+}
+static int decode_attributes_impl(const uint8_t* section, size_t len, const dmi_corner_table* tables, uint32_t n_tables, const uint32_t* seeds, uint32_t n_seeds,
+                                  uint32_t num_points, const dmi_config* cfg_in, dmi_decoded* out) {
   if (!section || !tables || !out || n_tables == 0) return host_fail(DMI_ERR_INVALID_ARGUMENT, "null argument");
   const auto t_call0 = std::chrono::steady_clock::now();
   { const float c = g_last_decode.connectivity_ms, tb = g_last_decode.tables_ms; g_last_decode = dmi_decode_timings{}; if (g_inside_decode_mesh) { g_last_decode.connectivity_ms = c; g_last_decode.tables_ms = tb; } }
@@ -279,25 +289,40 @@ int dmi_decode_attributes(const uint8_t* section, size_t len, const dmi_corner_t
   };
   std::vector<uint32_t> n_guess(n_atts);
   {
-    std::vector<std::thread> walkers, coders;
-    auto join_all = [&] { for (auto& w : walkers) w.join(); for (auto& w : coders) w.join(); };
+    // traversals and entropy decoders as items of ONE guarded pool (at most host_threads() threads; an exception in a worker — a size the file
+    // asked for that cannot be allocated, no thread left — comes back as a status instead of std::terminate)
+    struct Item { int kind; uint32_t i; };
+    std::vector<Item> items;
     for (uint32_t i = 0; i < n_atts; ++i) {
       if (seq_owner[i] != (int)i || tables[i].sequence) continue;
       const dmi_corner_table& t = tables[i];
-      for (uint32_t v = 0; v < t.num_vertices; ++v) if (t.left_most_corner[v] >= C) { join_all(); return host_fail(DMI_ERR_INVALID_ARGUMENT, "left_most_corner entry out of range"); }
-      AttPlan* pl = &plans[i];
-      walkers.emplace_back([pl, &t, F, seeds, n_seeds] {
-        TableRef tr{F, t.num_vertices, t.corner_to_vertex, t.opposite, t.left_most_corner};
-        attribute_sequence(tr, seeds, n_seeds, pl->seq_own);
-      });
+      for (uint32_t v = 0; v < t.num_vertices; ++v) if (t.left_most_corner[v] >= C) return host_fail(DMI_ERR_INVALID_ARGUMENT, "left_most_corner entry out of range");
+      items.push_back({0, i});
     }
+    const size_t n_walks = items.size();
+    uint64_t asked = 0;
     for (uint32_t i = 0; i < n_atts; ++i) {
       n_guess[i] = tables[i].sequence ? tables[i].sequence_len : tables[i].num_vertices;
-      coders.emplace_back(decode_entropy, i, n_guess[i]);
+      if (n_guess[i] > C) return host_fail(DMI_ERR_INVALID_ARGUMENT, "corner table " + std::to_string(i) + ": more vertices than corners");
+      asked += (uint64_t)n_guess[i] * plans[i].N * 4 + n_guess[i];
+      items.push_back({1, i});
     }
-    for (auto& w : walkers) w.join();
-    g_last_decode.sequence_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_seq0).count();
-    for (auto& w : coders) w.join();
+    if (asked > decode_budget_bytes()) return host_fail(DMI_ERR_OUT_OF_MEMORY, "the section's symbol arrays exceed the decode budget (DMI_DECODE_BUDGET_MB)");
+    std::atomic<size_t> walks_left{n_walks};
+    std::atomic<int64_t> seq_done_ns{0};
+    const int st = guarded_pool(items.size(), std::max(host_threads(), (unsigned)std::min<size_t>(items.size(), 8)), [&](size_t k) {
+      const Item it = items[k];
+      if (it.kind == 0) {
+        const dmi_corner_table& t = tables[it.i];
+        TableRef tr{F, t.num_vertices, t.corner_to_vertex, t.opposite, t.left_most_corner};
+        attribute_sequence(tr, seeds, n_seeds, plans[it.i].seq_own);
+        if (walks_left.fetch_sub(1) == 1) seq_done_ns.store(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_seq0).count());
+      } else {
+        decode_entropy(it.i, n_guess[it.i]);
+      }
+    });
+    g_last_decode.sequence_ms = (float)(seq_done_ns.load() / 1e6);
+    if (st) return host_fail(st == 1 ? DMI_ERR_OUT_OF_MEMORY : DMI_ERR_ENTROPY, st == 1 ? "out of memory decoding the attribute streams" : "attribute stream decoding failed");
   }
   for (uint32_t i = 0; i < n_atts; ++i) if (seq_owner[i] == (int)i && !tables[i].sequence) { plans[i].seq = plans[i].seq_own.data(); plans[i].n = (uint32_t)plans[i].seq_own.size(); }
   for (uint32_t i = 0; i < n_atts; ++i) {

@@ -246,6 +246,10 @@ int decode_connectivity(Bytes& b, DecodedConnectivity& out) {
   out.seam.assign(n_tables, std::vector<uint8_t>());
   uint64_t n_flags = 0;
   for (uint32_t f = 0; f < F; ++f) for (uint32_t k = 0; k < 3; ++k) { const uint32_t o = opp[3 * f + k]; if (o != kNone && o / 3 > f) ++n_flags; }
+  // every table costs C + n_flags bytes here and three corner arrays afterwards, and an all-zero flag stream costs the file a few bytes
+  // (a constant rABS stream): a small file may name 255 tables of millions of faces — bounded before anything is allocated
+  if ((uint64_t)n_tables * ((uint64_t)C * 14 + n_flags) > decode_budget_bytes())
+    return host_fail(DMI_ERR_OUT_OF_MEMORY, "the file's " + std::to_string(n_tables) + " attribute tables of " + std::to_string(F) + " faces exceed the decode budget (DMI_DECODE_BUDGET_MB)");
   struct FlagBlock { uint8_t zp; const uint8_t* data; size_t nbytes; bool ok; };
   std::vector<FlagBlock> blocks(n_tables);
   for (auto& fb : blocks) {
@@ -272,10 +276,8 @@ int decode_connectivity(Bytes& b, DecodedConnectivity& out) {
         }
       }
     };
-    std::vector<std::thread> workers;
-    for (uint32_t t = 0; t + 1 < n_tables; ++t) workers.emplace_back(body, t);
-    if (n_tables) body(n_tables - 1);
-    for (auto& w : workers) w.join();
+    const int st = guarded_pool(n_tables, host_threads(), [&](size_t t) { body((uint32_t)t); });
+    if (st) return host_fail(st == 1 ? DMI_ERR_OUT_OF_MEMORY : DMI_ERR_CONNECTIVITY, st == 1 ? "out of memory decoding the seam flags" : "seam flag decoding failed");
     for (auto& fb : blocks) if (!fb.ok) return bad("truncated seam flags");
   }
   lap("seam flags");
@@ -367,8 +369,13 @@ extern "C" {
 int dmi_decode_connectivity(const uint8_t* header_and_connectivity, size_t len, dmi_conn* conn, size_t* consumed) {
   if (!header_and_connectivity || !conn) return host_fail(DMI_ERR_INVALID_ARGUMENT, "null argument");
   *conn = dmi_conn{};
-  std::unique_ptr<DecodedTables> d(new DecodedTables());
-  const int rc = decode_tables(header_and_connectivity, len, *d);
+  std::unique_ptr<DecodedTables> d;
+  int rc;
+  try {
+    d.reset(new DecodedTables());
+    rc = decode_tables(header_and_connectivity, len, *d);
+  } catch (const std::bad_alloc&) { return host_fail(DMI_ERR_OUT_OF_MEMORY, "out of memory decoding the connectivity"); }
+  catch (const std::exception& e) { return host_fail(DMI_ERR_CONNECTIVITY, std::string("connectivity decoding failed: ") + e.what()); }
   if (rc) return rc;
   if (consumed) *consumed = d->consumed;
   conn->num_tables = (uint32_t)d->views.size();
@@ -394,10 +401,15 @@ int dmi_decode_mesh(const uint8_t* drc, size_t len, const dmi_config* cfg, dmi_d
   if (!drc || !out) return host_fail(DMI_ERR_INVALID_ARGUMENT, "null argument");
   *out = dmi_decoded_mesh{};
   const auto t0 = std::chrono::steady_clock::now();
-  std::unique_ptr<MeshOwner> owner(new MeshOwner());
-  DecodedTables& d = owner->d;
-  int rc = decode_tables(drc, len, d);
+  std::unique_ptr<MeshOwner> owner;
+  int rc;
+  try {
+    owner.reset(new MeshOwner());
+    rc = decode_tables(drc, len, owner->d);
+  } catch (const std::bad_alloc&) { return host_fail(DMI_ERR_OUT_OF_MEMORY, "out of memory decoding the connectivity"); }
+  catch (const std::exception& e) { return host_fail(DMI_ERR_CONNECTIVITY, std::string("connectivity decoding failed: ") + e.what()); }
   if (rc) return rc;
+  DecodedTables& d = owner->d;
   g_inside_decode_mesh = true;
   rc = dmi_decode_attributes(drc + d.consumed, len - d.consumed, d.views.data(), (uint32_t)d.views.size(), d.dc.seeds.data(), (uint32_t)d.dc.seeds.size(), d.num_points, cfg, &owner->atts);
   g_inside_decode_mesh = false;

@@ -18,6 +18,7 @@
 #include <string>
 #include <atomic>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -258,6 +259,34 @@ struct FreqTable {
 };
 
 bool append_tagged_state(uint32_t state_minus_base, std::vector<uint8_t>& out);   // rans.rs:48-68
+
+// fn(i) for i in [0, n) on at most `max_threads` host threads (a fixed pool, not a thread per item: n may come out of an untrusted file).
+// An exception in a worker — std::bad_alloc on a size a damaged file asked for, std::system_error when the process is out of threads — is
+// caught there (a throw out of a std::thread body is std::terminate) and reported: returns 0, 1 = out of memory, 2 = another exception.
+template <class Fn>
+inline int guarded_pool(size_t n, unsigned max_threads, Fn&& fn) {
+  std::atomic<size_t> next{0};
+  std::atomic<int> status{0};
+  auto work = [&] {
+    try {
+      for (size_t i; (i = next.fetch_add(1)) < n;) fn(i);
+    } catch (const std::bad_alloc&) { status.store(1); next.store(n); }
+    catch (...) { int z = 0; status.compare_exchange_strong(z, 2); next.store(n); }
+  };
+  const size_t nt = std::max<size_t>(1, std::min<size_t>(n, max_threads ? max_threads : 1));
+  std::vector<std::thread> th;
+  try {
+    for (size_t t = 1; t < nt; ++t) th.emplace_back(work);
+  } catch (...) { /* fewer threads than planned: the ones that started (and this one) take the items */ }
+  work();
+  for (auto& x : th) x.join();
+  return status.load();
+}
+// bytes a decode call may allocate for what a file ASKS for before anything is known to be real (DMI_DECODE_BUDGET_MB, default 16384)
+inline size_t decode_budget_bytes() {
+  static const size_t b = [] { const char* e = std::getenv("DMI_DECODE_BUDGET_MB"); return (size_t)(e && std::atol(e) > 0 ? std::atol(e) : 16384) << 20; }();
+  return b;
+}
 
 // What dmi_built_mesh::owner points to: the host builder's arrays (host_mesh.cpp) or a member of a device-built group (dmi_build.cpp).
 struct BuiltBase {

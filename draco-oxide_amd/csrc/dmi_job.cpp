@@ -704,7 +704,12 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
         scratch = tmpdev.take<uint64_t>(scratch_bytes / 8);
         if (!scratch) return fail(DMI_ERR_OUT_OF_MEMORY, "hipMalloc (tile sort keys)");
       }
-      HIP_TRY(launch_tile_sort(t.s2p.as<uint32_t>(), t.n_seq, lg, local_lg, scratch, t.s2p_sorted.as<uint32_t>(), t.sorted_dest.as<uint32_t>(), s));
+      // (a layout optimisation the bitstream does not depend on: if its launch cannot be set up — 128 KB of LDS on a part that has less — the
+      //  plain gather runs instead)
+      if (launch_tile_sort(t.s2p.as<uint32_t>(), t.n_seq, lg, local_lg, scratch, t.s2p_sorted.as<uint32_t>(), t.sorted_dest.as<uint32_t>(), s) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)t.s2p_sorted.alloc(0); (void)t.sorted_dest.alloc(0);
+      }
     }
   }
   uint32_t bad_p2v = 0;

@@ -150,3 +150,25 @@ def test_malformed_connectivity_is_an_error_code():
         except dmi.DracoMiError:
             rejected += 1
     assert rejected > 0
+
+
+def test_decode_budget_bounds_what_a_file_may_ask_for():
+    """ADVICE r3: the whole-file decoder sizes per-table arrays from counts the FILE states (255 tables × millions of faces from a ~1 MB file);
+    they are bounded by DMI_DECODE_BUDGET_MB before anything is allocated, and the call returns DMI_ERR_OUT_OF_MEMORY (11) — no abort."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import draco_oxide_amd as dmi; from draco_oxide_amd import synth\n"
+        "m = synth.torus_mesh(90)\n"                      # 16 200 faces, two attribute tables
+        "conn = dmi.encode_connectivity(m); b = conn.bytes; conn.close()\n"
+        "try:\n    dmi.decode_connectivity(b); print('decoded')\n"
+        "except dmi.DracoMiError as e:\n    print('status', e.status)\n") % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, DMI_DECODE_BUDGET_MB="1", DMI_NO_TORCH_PREIMPORT="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300).stdout
+    assert "status 11" in out, out
+    env["DMI_DECODE_BUDGET_MB"] = "64"
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300).stdout
+    assert "decoded" in out, out
