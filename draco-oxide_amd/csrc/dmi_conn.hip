@@ -244,16 +244,14 @@ __global__ __launch_bounds__(kBlock) void k_rl_keys(const RelabelBatch b) {
     const uint32_t m = min(r[it.c2v[3ull * f]], min(r[it.c2v[3ull * f + 1]], r[it.c2v[3ull * f + 2]]));
     const uint32_t key = m == kNoneD ? it.n_seq : m;
     b.key[g] = key;
-    atomicAdd(&b.count[it.key_off + key], 1u);
+    b.new_face[g] = atomicAdd(&b.count[it.key_off + key], 1u);   // arrival number in the bucket (parked in new_face until k_rl_sort_buckets writes it)
   }
 }
 // faces into their buckets (the scan of the bucket sizes is a global face position: the keys of mesh m occupy [key_off[m], key_off[m+1]))
 __global__ __launch_bounds__(kBlock) void k_rl_place(const RelabelBatch b) {
   for (uint32_t g = blockIdx.x * kBlock + threadIdx.x; g < b.total_faces; g += gridDim.x * kBlock) {
     const RelabelItem& it = b.items[find_item(b.items, b.n_items, g, [](const RelabelItem& x) { return x.face_off; })];
-    const uint32_t bucket = it.key_off + b.key[g];
-    const uint32_t pos = b.count[bucket] + atomicAdd(&b.fill[bucket], 1u);
-    b.order[pos] = g - it.face_off;
+    b.order[b.count[it.key_off + b.key[g]] + b.new_face[g]] = g - it.face_off;
   }
 }
 // faces of equal key in face order (the host form's stable counting sort): a bucket holds the faces around one vertex — a handful

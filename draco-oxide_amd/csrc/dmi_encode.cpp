@@ -799,12 +799,15 @@ int dmi_encode_attributes(const dmi_attribute* atts, const dmi_corner_table* tab
   dmi_job* job = nullptr;
   const auto t0 = std::chrono::steady_clock::now();
   auto ms = [&] { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+  g_one_shot_call = true;   // (create → encode → destroy: no layout work that only pays over many encodes)
   int rc = dmi_job_create(atts, tables, n_atts, seeds, n_seeds, cfg, &job);
+  g_one_shot_call = false;
   if (rc) return rc;
   const float t_create = ms();
   rc = dmi_job_encode(job, out);
   g_last_call = job->last;
   g_last_call.job_create_ms = t_create;
+  g_last_call.job_create_device_ms = job->create_device_ms;
   dmi_job_destroy(job);
   g_last_call.call_ms = ms();
   return rc;

@@ -7,6 +7,7 @@
 namespace dmi {
 thread_local std::string g_last_error;
 thread_local dmi_timings g_last_call{};
+thread_local bool g_one_shot_call = false;
 int host_fail(int code, const std::string& msg) { g_last_error = msg; return code; }   // shared with the host-only translation units
 ChunkCache g_chunk_cache;
 thread_local DevPool* g_active_pool = nullptr;
@@ -373,6 +374,10 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
     hint += C * 4 * 3 + ((size_t)max_seq + max_v) * 4 + (size_t)F * 4 * 9 + ((size_t)1 << 20);   // (sort scratch ≈ two key/value pairs)
     tmpdev.init(cfg.device, s, hint);
   }
+  const bool faces_checked = dev && dev->trusted_sequences;   // tables built by dmi_conn.hip from faces it range-checked against the point count
+  hipEvent_t ev_c0 = nullptr, ev_c1 = nullptr;   // device span of job creation (DMI_FLAG_TIMINGS, not for deferred batch jobs)
+  struct EvGuard { hipEvent_t &a, &b; ~EvGuard() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } ev_guard{ev_c0, ev_c1};
+  if ((cfg.flags & DMI_FLAG_TIMINGS) && !defer) { HIP_TRY(hipEventCreate(&ev_c0)); HIP_TRY(hipEventCreate(&ev_c1)); HIP_TRY(hipEventRecord(ev_c0, s)); }
   uint32_t* d_bad = nullptr;        // device flag: a point_to_value entry out of range (device form)
   uint32_t* d_max_point = nullptr;  // device word: largest point index the faces reference (device form)
   if (defer) {
@@ -411,7 +416,7 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
     d_bad = d_words; d_max_point = d_words + 1;
     HIP_TRY(hipMemsetAsync(d_words, 0, 16, s));
     if (!dev) HIP_TRY(hipMemcpyAsync(const_cast<uint32_t*>(d_c2p), tables[0].corner_to_point, C * 4, hipMemcpyHostToDevice, s));
-    launch_max_u32(d_c2p, C, d_max_point, s);
+    if (!faces_checked) launch_max_u32(d_c2p, C, d_max_point, s);   // (the library's own connectivity stage range-checked the faces it built the tables from)
     for (uint32_t i = 0; i < n_atts; ++i) {
       TableDev& t = job->tables[i];
       if (t.alias_of >= 0) continue;
@@ -544,6 +549,8 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
   uint32_t max_point = 0;
   if (defer) {
     // (the connectivity stage checked the faces against the points, its caller the attributes' point and value counts)
+  } else if (device_relabel && faces_checked) {
+    // (no read-back, no wait in the middle of job creation: everything up to the final synchronisation is queued behind the relabelling)
   } else if (device_relabel) {
     HIP_TRY(hipMemcpyAsync(&max_point, d_max_point, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -691,7 +698,9 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
     const uint32_t min_entries = std::getenv("DMI_TILE_SORT_MIN") ? (uint32_t)std::atoi(std::getenv("DMI_TILE_SORT_MIN")) : kTileSortMinEntries;
     uint32_t local_lg = kTileSortMaxLog2;
     if (const char* e = std::getenv("DMI_TILE_SORT_LOCAL")) { local_lg = 6; while ((1u << local_lg) < (uint32_t)std::atoi(e) && local_lg < kTileSortMaxLog2) ++local_lg; }
-    if (env_tile != 0 && !defer) for (auto& t : job->tables) {
+    // a create → encode → destroy call sorts (≈ 0.31 ms per 10M triangles) for ONE gather that the sort makes 14–18 µs faster: only resident
+    // jobs (dmi_job_create / dmi_mesh_prepare: encoded many times) or an explicit DMI_TILE_SORT take it
+    if (env_tile != 0 && !defer && !(g_one_shot_call && env_tile < 0)) for (auto& t : job->tables) {
       if (t.alias_of >= 0 || t.n_seq == 0 || t.n_seq < min_entries) continue;
       // ≈ 2.2 rings of the coding order (a ring of a grid-like mesh is ≈ 4·√V entries), as a power of two between 16 K and 128 K — measured:
       // 10M triangles 16 K (32 K +2 %, 64 K +7 %), 20M 32 K (128 K +6 %), 40M 32–64 K (128 K +8 %), 100M 64–128 K (256 K +9 %)
@@ -714,7 +723,9 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
   }
   uint32_t bad_p2v = 0;
   if (d_bad) HIP_TRY(hipMemcpyAsync(&bad_p2v, d_bad, 4, hipMemcpyDeviceToHost, s));
+  if (ev_c1) HIP_TRY(hipEventRecord(ev_c1, s));
   if (!defer) HIP_TRY(hipStreamSynchronize(s));   // (a batch waits once, for all its jobs)
+  if (ev_c1) { float span = 0; if (hipEventElapsedTime(&span, ev_c0, ev_c1) == hipSuccess) job->create_device_ms = span; else (void)hipGetLastError(); }
   if (bad_p2v) return fail(DMI_ERR_INVALID_ARGUMENT, "point_to_value entry out of range");
   if (trace_create) std::fprintf(stderr, "[dmi] job create (%u faces, %s relabelling): sequences %.1f ms, relabel + table uploads %.1f, attribute uploads + buffers + fan rows %.1f, stream + plan %.1f\n", F, device_relabel ? "device" : "host", t_seq, t_relabel, since_ms(tc0) - t_seq - t_relabel,
                                  std::chrono::duration<double, std::milli>(tc0 - t_enter).count());

@@ -21,6 +21,7 @@
 namespace dmi {
 extern thread_local std::string g_last_error;
 extern thread_local dmi_timings g_last_call;   // dmi_last_call_timings
+extern thread_local bool g_one_shot_call;      // set by the create → encode → destroy entry points (dmi_encode_mesh[_device], dmi_encode_attributes): layout work that only pays over many encodes is skipped
 inline int fail(int code, const std::string& msg) { return host_fail(code, msg); }
 
 #define HIP_TRY(expr)                                                                                              \
@@ -231,6 +232,7 @@ struct dmi_job {
   hipEvent_t ev[8]{};
   bool have_events = false;
   dmi_timings last{};
+  float create_device_ms = 0;   // device span of job creation (hipEvents on the job's stream; DMI_FLAG_TIMINGS)
   uint32_t last_fixups = 0;   // texture-coordinate entries the last encode's fused sweep deferred to k_texcoord_fixup
   uint64_t predict_bytes = 0;
   hipGraphExec_t graph_a = nullptr;   // phase A captured once (launch-bound for small meshes)

@@ -34,21 +34,18 @@ __global__ __launch_bounds__(kBlock) void k_rank_scatter(const uint32_t* __restr
 // key[f] = smallest sequence index among the face's vertices (none_key when no vertex of the face was coded); count[key]++
 // (a bucket holds the faces around one coded vertex — a handful — so the atomics spread over as many addresses as there are vertices)
 __global__ __launch_bounds__(kBlock) void k_face_keys(const uint32_t* __restrict__ c2v, const uint32_t* __restrict__ rank, uint32_t F, uint32_t none_key,
-                                                      uint32_t* __restrict__ key, uint32_t* __restrict__ count) {
+                                                      uint32_t* __restrict__ key, uint32_t* __restrict__ count, uint32_t* __restrict__ slot) {
   for (uint32_t f = blockIdx.x * kBlock + threadIdx.x; f < F; f += gridDim.x * kBlock) {
     const uint32_t a = rank[c2v[3 * (size_t)f]], b = rank[c2v[3 * (size_t)f + 1]], c = rank[c2v[3 * (size_t)f + 2]];
     const uint32_t m = min(a, min(b, c));
     const uint32_t k = (m == kNoneD) ? none_key : m;
     key[f] = k;
-    atomicAdd(&count[k], 1u);
+    slot[f] = atomicAdd(&count[k], 1u);   // the face's arrival number in its bucket: the placement below needs no second round of atomics
   }
 }
-// faces into their buckets (start = exclusive prefix sum of the bucket sizes), in whatever order the atomics hand out
-__global__ __launch_bounds__(kBlock) void k_place_faces(const uint32_t* __restrict__ key, uint32_t F, const uint32_t* __restrict__ start, uint32_t* __restrict__ fill, uint32_t* __restrict__ order) {
-  for (uint32_t f = blockIdx.x * kBlock + threadIdx.x; f < F; f += gridDim.x * kBlock) {
-    const uint32_t k = key[f];
-    order[start[k] + atomicAdd(&fill[k], 1u)] = f;
-  }
+// faces into their buckets (start = exclusive prefix sum of the bucket sizes), in the order the counting atomics handed out
+__global__ __launch_bounds__(kBlock) void k_place_faces(const uint32_t* __restrict__ key, uint32_t F, const uint32_t* __restrict__ start, const uint32_t* __restrict__ slot, uint32_t* __restrict__ order) {
+  for (uint32_t f = blockIdx.x * kBlock + threadIdx.x; f < F; f += gridDim.x * kBlock) order[start[key[f]] + slot[f]] = f;
 }
 // faces of equal key in face order (the host form's stable counting sort), then new_face[order[j]] = j
 __global__ __launch_bounds__(kBlock) void k_sort_buckets(const uint32_t* __restrict__ start, uint32_t n_keys, uint32_t* __restrict__ order, uint32_t* __restrict__ new_face) {
@@ -178,10 +175,10 @@ hipError_t launch_face_order(const uint32_t* c2v, const uint32_t* rank, uint32_t
   if (!F) return hipSuccess;
   hipError_t e;
   if ((e = hipMemsetAsync(count, 0, ((size_t)n_keys + 1) * 4, s)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(fill, 0, ((size_t)n_keys + 1) * 4, s)) != hipSuccess) return e;
-  hipLaunchKernelGGL(k_face_keys, grid_of(F), kBlock, 0, s, c2v, rank, F, n_keys - 1, key, count);
+  (void)fill;   // (round 3's second round of atomics: the arrival numbers of the counting pass — parked in new_face until k_sort_buckets writes it — replace it)
+  hipLaunchKernelGGL(k_face_keys, grid_of(F), kBlock, 0, s, c2v, rank, F, n_keys - 1, key, count, new_face);
   launch_exclusive_scan_u32(count, n_keys + 1, scan_partials, s);
-  hipLaunchKernelGGL(k_place_faces, grid_of(F), kBlock, 0, s, key, F, count, fill, order);
+  hipLaunchKernelGGL(k_place_faces, grid_of(F), kBlock, 0, s, key, F, count, new_face, order);
   hipLaunchKernelGGL(k_sort_buckets, grid_of(n_keys), kBlock, 0, s, count, n_keys, order, new_face);
   return hipSuccess;
 }
