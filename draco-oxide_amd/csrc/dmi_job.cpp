@@ -257,8 +257,15 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
     job->pool.stream = defer ? defer->stream : s;   // (a batch clears the chunk on the coordinator's stream: its kernels follow on the same stream)
     job->pool.device = cfg.device;
     job->pool.chunk_bytes = est + est / 8;
+    // A batch job's chunk is small and one memset clears it (a thousand jobs must not issue five memsets each).  A single job's chunk is
+    // gigabytes (4.5 GB per 10M triangles: 0.9 ms of fill per call), of which only a few KB have to start as zeros: those are cleared
+    // one by one below (`needs_clear`).  DMI_POISON=1 fills such a chunk with 0xA5 instead — the tests run once that way, so that no buffer
+    // silently depends on what the chunk held.
+    job->pool.zero = defer != nullptr || std::getenv("DMI_ZERO_CHUNKS") != nullptr;
+    job->pool.poison = !job->pool.zero && std::getenv("DMI_POISON") != nullptr;
   }
   g_active_pool = std::getenv("DMI_NO_POOL") ? nullptr : &job->pool;
+  const bool needs_clear = g_active_pool && !job->pool.zero;   // pooled buffers do not start as zeros: the ones that must are cleared where they are allocated
   struct PoolGuard { ~PoolGuard() { g_active_pool = nullptr; } } pool_guard;
 
   const bool trace_create = std::getenv("DMI_TRACE") != nullptr;
@@ -616,8 +623,9 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
       if ((rc = a.aux_out.alloc(a.aux_cap + 16))) return rc;   // +16: the batch pack kernel copies whole 16-byte words
       if ((rc = a.aux_rec.alloc(((size_t)n + kChainPad) * sizeof(RansEntry)))) return rc;
       if (!a.aux_rec.pooled) HIP_TRY(hipMemsetAsync(a.aux_rec.p, 0, a.aux_rec.bytes, s));
+      else if (needs_clear) HIP_TRY(hipMemsetAsync(a.aux_rec.as<RansEntry>() + n, 0, kChainPad * sizeof(RansEntry), s));   // (the records past n: the chains read ahead into them)
       if ((rc = a.aux_flags.alloc(((size_t)n / 64 + 4) * 4))) return rc;
-      if (!a.aux_flags.pooled) HIP_TRY(hipMemsetAsync(a.aux_flags.p, 0, a.aux_flags.bytes, s));
+      if (!a.aux_flags.pooled || needs_clear) HIP_TRY(hipMemsetAsync(a.aux_flags.p, 0, a.aux_flags.bytes, s));
       if ((rc = a.chunk_info.alloc((size_t)std::max(1u, orient_summary_blocks(n)) * 8 + 16))) return rc;
       if (a.scheme == kTexCoord && (rc = a.aux_bits.alloc((size_t)n + 16))) return rc;
       if (a.scheme == kNormal && (rc = a.flip_partials.alloc((size_t)kSweepMaxBlocks * 4))) return rc;
@@ -643,8 +651,9 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
     }
     if ((rc = a.rec.alloc(((size_t)a.n_sym + kChainPad) * sizeof(RansEntry)))) return rc;
     if (!a.rec.pooled) HIP_TRY(hipMemsetAsync(a.rec.p, 0, a.rec.bytes, s));
+    else if (needs_clear) HIP_TRY(hipMemsetAsync(a.rec.as<RansEntry>() + a.n_sym, 0, kChainPad * sizeof(RansEntry), s));
     if ((rc = a.batch_flags.alloc(((size_t)a.n_sym / 64 + 4) * 4))) return rc;
-    if (!a.batch_flags.pooled) HIP_TRY(hipMemsetAsync(a.batch_flags.p, 0, a.batch_flags.bytes, s));
+    if (!a.batch_flags.pooled || needs_clear) HIP_TRY(hipMemsetAsync(a.batch_flags.p, 0, a.batch_flags.bytes, s));
     a.out_cap = a.n_sym * 3 + 16;   // ≤ 3 renormalisation bytes per symbol (P ≤ 20) + flush
     if ((rc = a.out.alloc(a.out_cap + 16))) return rc;
     if ((rc = a.partials.alloc((size_t)kRangeMaxBlocks * 8 * 4))) return rc;
@@ -661,7 +670,7 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
   job->predict_bytes = pb;
   pinned_need += 256;
   if ((rc = job->slab.alloc(pinned_need))) return rc;
-  if (!job->slab.pooled) HIP_TRY(hipMemsetAsync(job->slab.p, 0, pinned_need, s));
+  if (!job->slab.pooled || needs_clear) HIP_TRY(hipMemsetAsync(job->slab.p, 0, pinned_need, s));
   for (auto& a : job->atts) {
     uint8_t* base = job->slab.as<uint8_t>() + a.slab_off;
     a.small = SlabView{base, 64};

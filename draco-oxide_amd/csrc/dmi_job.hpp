@@ -109,6 +109,7 @@ struct DevPool {
   hipStream_t stream = nullptr;
   int device = 0;
   bool zero = true;   // chunks are cleared when they are taken (job memory); temporaries skip it
+  bool poison = false;   // test mode (DMI_POISON): an uncleared chunk is filled with 0xA5 — nothing may depend on what it held
   ~DevPool() { for (auto& c : chunks) if (c.p && !g_chunk_cache.release(device, c.p, c.cap)) (void)hipFree(c.p); }
   void* take(size_t n) {
     n = (n + 255) & ~(size_t)255;
@@ -120,7 +121,7 @@ struct DevPool {
         g_chunk_cache.drop_all();
         if (hipMalloc(&c.p, c.cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
       }
-      if (zero && hipMemsetAsync(c.p, 0, c.cap, stream) != hipSuccess) { (void)hipFree(c.p); return nullptr; }
+      if ((zero || poison) && hipMemsetAsync(c.p, zero ? 0 : 0xA5, c.cap, stream) != hipSuccess) { (void)hipFree(c.p); return nullptr; }
       chunks.push_back(c);
     }
     Chunk& c = chunks.back();
