@@ -271,23 +271,25 @@ __global__ __launch_bounds__(kBlock) void k_rl_sort_buckets(const RelabelBatch b
   }
 }
 __device__ __forceinline__ uint32_t map_corner(uint32_t c, const uint32_t* __restrict__ new_face) { return c == kNoneD ? kNoneD : 3u * new_face[c / 3u] + c % 3u; }
-// one thread per NEW corner: c2r_out[c2] = rank[c2v[c]], opp_out[c2] = map(opp[c]) with c = 3·order[c2 / 3] + c2 % 3
+// one thread per NEW corner of every table: c2r_out[c2] = rank[c2v[c]], opp_out[c2] = map(opp[c]) with c = 3·order[c2 / 3] + c2 % 3 — order and
+// new_face are the universal table's of the same mesh (order_item), the ranks the table's own
 __global__ __launch_bounds__(kBlock) void k_rl_remap(const RelabelBatch b) {
-  const uint64_t C = 3ull * b.total_faces;
+  const uint64_t C = 3ull * b.total_remap_faces;
   for (uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x; g < C; g += (uint64_t)gridDim.x * kBlock) {
     const uint32_t gf = (uint32_t)(g / 3u), k = (uint32_t)(g - 3ull * gf);
-    const RelabelItem& it = b.items[find_item(b.items, b.n_items, gf, [](const RelabelItem& x) { return x.face_off; })];
-    const uint32_t c2 = 3u * (gf - it.face_off) + k;
-    const uint32_t c = 3u * b.order[gf] + k;
+    const RelabelItem& it = b.items[find_item(b.items, b.n_items, gf, [](const RelabelItem& x) { return x.remap_off; })];
+    const uint32_t uf = b.items[it.order_item].face_off;
+    const uint32_t f2 = gf - it.remap_off, c2 = 3u * f2 + k;
+    const uint32_t c = 3u * b.order[uf + f2] + k;
     it.c2r[c2] = b.rank[it.vert_off + it.c2v[c]];
-    it.opp_out[c2] = map_corner(it.opp[c], b.new_face + it.face_off);
+    it.opp_out[c2] = map_corner(it.opp[c], b.new_face + uf);
   }
 }
 __global__ __launch_bounds__(kBlock) void k_rl_seq(const RelabelBatch b) {
   for (uint32_t g = blockIdx.x * kBlock + threadIdx.x; g < b.total_seq; g += gridDim.x * kBlock) {
     const RelabelItem& it = b.items[find_item(b.items, b.n_items, g, [](const RelabelItem& x) { return x.seq_off; })];
     const uint32_t k = g - it.seq_off, c = it.seq[k];
-    it.seq_out[k] = map_corner(c, b.new_face + it.face_off);
+    it.seq_out[k] = map_corner(c, b.new_face + b.items[it.order_item].face_off);
     it.s2p[k] = it.c2p[c];
   }
 }
@@ -340,7 +342,7 @@ void launch_relabel_batch(const RelabelBatch& b, hipStream_t s) {
   launch_exclusive_scan_u32(b.count, b.total_keys + 1, b.scan_partials, s);
   hipLaunchKernelGGL(k_rl_place, grid_of(b.total_faces), kBlock, 0, s, b);
   hipLaunchKernelGGL(k_rl_sort_buckets, grid_of(b.total_keys), kBlock, 0, s, b);
-  hipLaunchKernelGGL(k_rl_remap, grid_of(3ull * b.total_faces), kBlock, 0, s, b);
+  hipLaunchKernelGGL(k_rl_remap, grid_of(3ull * b.total_remap_faces), kBlock, 0, s, b);
   hipLaunchKernelGGL(k_rl_seq, grid_of(b.total_seq), kBlock, 0, s, b);
 }
 void launch_compose_batch(const ComposeItem* items_dev, uint32_t n_items, uint32_t total, hipStream_t s) {

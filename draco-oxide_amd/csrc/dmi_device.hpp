@@ -274,14 +274,18 @@ hipError_t conn_tables_clear(const ConnArgs& a, hipStream_t s);   // the memsets
 void launch_conn_tables(const ConnArgs& a, hipStream_t s);
 // Coding-order relabelling of a batch of meshes in one launch per step (the arrays of dmi_relabel.hip, per mesh): inputs in the mesh's own
 // numbering (device arrays of the connectivity stage + the uploaded sequence), outputs in the job's memory.
+// An item is one corner table of a job.  The face order is the universal table's (sequence.rs walks that one first): an attribute table of
+// its own (interior seams: attribute_corner_table.rs:16-137) is relabelled with the universal item's face order (`order_item`) and its own
+// vertex ranks; it takes no part in the counting sort (its slices of key / count are empty).
 struct RelabelItem {
   const uint32_t *c2p, *c2v, *opp, *seq;
-  uint32_t F, V, n_seq, pad;
-  uint32_t face_off, vert_off, key_off /* Σ (n_seq + 1) */, seq_off;   // this mesh's slices of the batch scratch arrays
+  uint32_t F, V, n_seq, order_item /* index of the item whose face order this table follows (itself for a universal table) */;
+  uint32_t face_off, vert_off, key_off /* Σ (n_seq + 1) */, seq_off;   // this table's slices of the batch scratch arrays (face_off / key_off: universal tables only)
+  uint32_t remap_off /* Σ F of the items before: the corner space of k_rl_remap */, pad0, pad1, pad2;
   uint32_t *c2r, *opp_out, *seq_out, *s2p;
 };
 struct RelabelBatch {
-  const RelabelItem* items; uint32_t n_items, total_faces, total_verts, total_keys, total_seq, pad;
+  const RelabelItem* items; uint32_t n_items, total_faces /* universal tables */, total_verts, total_keys, total_seq, total_remap_faces /* all tables */;
   uint32_t* rank;          // total_verts, filled with DMI_NONE
   uint32_t* key;           // total_faces
   uint32_t *count, *fill;  // total_keys + 1, zeroed

@@ -388,17 +388,25 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
   uint32_t* d_bad = nullptr;        // device flag: a point_to_value entry out of range (device form)
   uint32_t* d_max_point = nullptr;  // device word: largest point index the faces reference (device form)
   if (defer) {
-    for (uint32_t i = 1; i < n_atts; ++i) if (job->tables[i].alias_of != 0) return fail(DMI_ERR_INVALID_ARGUMENT, "deferred job creation: every table must be the universal one");
-    TableDev& t = job->tables[0];
-    if ((rc = t.c2r.alloc(C * 4))) return rc;
-    if ((rc = t.opp.alloc(C * 4))) return rc;
-    if ((rc = t.seq.alloc((size_t)t.n_seq * 4))) return rc;
-    if ((rc = t.s2p.alloc((size_t)t.n_seq * 4))) return rc;
-    defer->has_relabel = true;
-    RelabelItem& r = defer->relabel;
-    r.c2p = dev->c2p; r.c2v = dev->c2v; r.opp = dev->opp; r.seq = seq_of[0];
-    r.F = F; r.V = t.V; r.n_seq = t.n_seq;
-    r.c2r = t.c2r.as<uint32_t>(); r.opp_out = t.opp.as<uint32_t>(); r.seq_out = t.seq.as<uint32_t>(); r.s2p = t.s2p.as<uint32_t>();
+    // every distinct table becomes an item of the coordinator's batched relabelling: the universal one from the device arrays of the
+    // connectivity stage, an attribute table of its own (interior seams) from the host arrays the walks used — the coordinator uploads those
+    if (job->tables[0].alias_of >= 0) return fail(DMI_ERR_INVALID_ARGUMENT, "deferred job creation: table 0 must be the universal one");
+    for (uint32_t i = 0; i < n_atts; ++i) {
+      TableDev& t = job->tables[i];
+      if (t.alias_of >= 0) continue;
+      if ((rc = t.c2r.alloc(C * 4))) return rc;
+      if ((rc = t.opp.alloc(C * 4))) return rc;
+      if ((rc = t.seq.alloc((size_t)t.n_seq * 4))) return rc;
+      if ((rc = t.s2p.alloc((size_t)t.n_seq * 4))) return rc;
+      RelabelItem r{};
+      const bool resident = tables[i].corner_to_vertex == tables[0].corner_to_vertex && tables[i].opposite == tables[0].opposite;
+      r.c2p = dev->c2p; r.c2v = resident ? dev->c2v : nullptr; r.opp = resident ? dev->opp : nullptr; r.seq = seq_of[i];
+      r.F = F; r.V = t.V; r.n_seq = t.n_seq; r.order_item = 0;
+      r.c2r = t.c2r.as<uint32_t>(); r.opp_out = t.opp.as<uint32_t>(); r.seq_out = t.seq.as<uint32_t>(); r.s2p = t.s2p.as<uint32_t>();
+      defer->relabels.push_back(r);
+      defer->host_c2v.push_back(resident ? nullptr : tables[i].corner_to_vertex);
+      defer->host_opp.push_back(resident ? nullptr : tables[i].opposite);
+    }
   } else if (device_relabel) {
     uint32_t max_seq = 0, max_v = 0;
     for (uint32_t i = 0; i < n_atts; ++i) if (job->tables[i].alias_of < 0) { max_seq = std::max(max_seq, job->tables[i].n_seq); max_v = std::max(max_v, job->tables[i].V); }

@@ -311,8 +311,12 @@ struct JobDefer {
   // out
   struct Copy { void* dst; const void* src_dev; size_t bytes; };
   std::vector<Copy> copies;                     // device → device: values into the job's buffers
-  bool has_relabel = false;
-  RelabelItem relabel{};                        // seq = HOST pointer of the sequence (the coordinator uploads it); offsets filled by the coordinator
+  // One RelabelItem per distinct corner table of the job, the universal one first.  seq = HOST pointer of the table's sequence (the
+  // coordinator uploads it); an attribute table of its own (interior seams) also carries HOST pointers of its vertex ids / opposite
+  // corners in host_c2v / host_opp (uploaded by the coordinator: c2v / opp of the item are then null until it has placed them);
+  // order_item = index WITHIN relabels of the table whose face order the item follows (0); offsets filled by the coordinator.
+  std::vector<RelabelItem> relabels;
+  std::vector<const uint32_t*> host_c2v, host_opp;   // parallel to relabels (null: the table is resident)
   std::vector<FanItem> fans;                    // off filled by the coordinator
   std::vector<ComposeItem> compose;
 };

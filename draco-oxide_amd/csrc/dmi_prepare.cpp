@@ -213,6 +213,9 @@ struct ConnOwner {
   std::vector<dmi_corner_table> views;
 };
 
+// thread time of the connectivity stage by step, summed over the meshes of a batch (trace): attribute tables, Edgebreaker (traversal +
+// connectivity bytes incl. the seam streams), universal sequencer, seam-table sequencers
+static std::atomic<uint64_t> g_conn_us[4];
 // pre (nullable): the universal table already built by the device stage; view_faces: c2p may view the caller's face array (it outlives `o`)
 static int build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std::vector<uint8_t>& bytes, const PrebuiltTable* pre = nullptr, bool view_faces = false) {
   if (!mesh || !mesh->atts || mesh->num_atts == 0 || (!mesh->faces && mesh->num_faces)) return fail(DMI_ERR_INVALID_ARGUMENT, "bad mesh");
@@ -268,9 +271,19 @@ static int build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std::vector<ui
   auto build_att_tables = [&] {
     const auto a0 = tick();
     // an attribute indexed like the Position attribute has no seams but the boundary; one indexed like an earlier attribute has that one's table
+    // an attribute indexed like the Position attribute — the same map array, or a map with the same entries (a builder gives every attribute its
+    // own array: normals that repeat exactly where positions repeat) — has no seam but the boundary: one memcmp instead of a test per edge
+    const uint32_t* pos_map = mesh->atts[0].point_to_value;
+    const uint32_t P0 = mesh->atts[0].num_points;
+    auto like_position = [&](const uint32_t* m, uint32_t n_points) {
+      if (m == pos_map) return true;
+      return m && pos_map && n_points == P0 && std::memcmp(m, pos_map, (size_t)P0 * 4) == 0;
+    };
+    std::vector<uint32_t> map_points;
+    for (uint32_t i = 0; i < mesh->num_atts; ++i) if (mesh->atts[i].att_type != DMI_ATT_POSITION) map_points.push_back(mesh->atts[i].num_points);
     auto build_one = [&](size_t k) {
       for (size_t j = 0; j < k; ++j) if (maps[j] == maps[k]) return;   // (copied below, once its original is complete)
-      o.ct.build_attribute_into(o.ct.att[k], maps[k], maps[k] == mesh->atts[0].point_to_value);
+      o.ct.build_attribute_into(o.ct.att[k], maps[k], like_position(maps[k], map_points[k]));
     };
     if (maps.size() > 1 && overlap) {
       std::vector<std::thread> th;
@@ -337,7 +350,8 @@ static int build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std::vector<ui
     }
   }
   if (!overlap) t_seq = since(c2);
-  if (trace) std::fprintf(stderr, "[dmi] host connectivity of %u faces (%s): universal corner table %.1f ms, attribute tables %.1f, Edgebreaker %.1f, universal sequencer %.1f, seam-table sequencers + views %.1f; total %.1f\n",
+  if (trace) { g_conn_us[0] += (uint64_t)(t_att * 1e3); g_conn_us[1] += (uint64_t)(t_eb * 1e3); g_conn_us[2] += (uint64_t)(t_seq * 1e3); g_conn_us[3] += (uint64_t)((since(c2) - (overlap ? 0 : t_seq)) * 1e3); }
+  if (trace && mesh->num_faces > 100000) std::fprintf(stderr, "[dmi] host connectivity of %u faces (%s): universal corner table %.1f ms, attribute tables %.1f, Edgebreaker %.1f, universal sequencer %.1f, seam-table sequencers + views %.1f; total %.1f\n",
                           mesh->num_faces, overlap ? "overlapped: attribute tables and sequencer beside the Edgebreaker walk" : "in sequence", t_univ, t_att, t_eb, t_seq, since(c2), since(c0));
   return DMI_OK;
 }
@@ -903,9 +917,11 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     c.device = device;
     g_adopt_stream = worker_stream(t % kPrepareStreams, device);   // the job's own stream for its encodes
     struct Drop { ~Drop() { g_adopt_stream.reset(); } } drop;
+    // (a mesh with attribute tables of its own — interior seams — is deferred like the others: its seam tables go up with the sequences)
+    static const bool defer_seams = !std::getenv("DMI_NO_DEFER_SEAMS");
     bool all_universal = true;
     for (uint32_t a = 1; a < m.num_atts; ++a) all_universal = all_universal && o.views[a].corner_to_vertex == o.views[0].corner_to_vertex && o.views[a].opposite == o.views[0].opposite;
-    if (all_universal) {
+    if (all_universal || defer_seams) {
       JobDefer& d = defers[kk];
       d.stream = S;
       d.values_dev.assign(m.num_atts, nullptr); d.maps_dev.assign(m.num_atts, nullptr);
@@ -942,23 +958,29 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
   std::vector<ComposeItem> comps;
   struct Move { void* dst; const void* src; size_t bytes; };
   std::vector<Move> moves;
-  std::vector<const uint32_t*> seq_src;
-  uint64_t rf = 0, rv = 0, rk = 0, rs = 0, fan_total = 0, comp_total = 0;
+  std::vector<const uint32_t*> seq_src, c2v_src, opp_src;   // host sources per item (c2v / opp: attribute tables of their own)
+  uint64_t rf = 0, rv = 0, rk = 0, rs = 0, rr = 0, fan_total = 0, comp_total = 0, host_table_words = 0;
   for (uint32_t kk = 0; kk < M; ++kk) {
     if (!deferred[kk]) continue;
     JobDefer& d = defers[kk];
-    if (d.has_relabel) {
-      RelabelItem it = d.relabel;
-      it.face_off = (uint32_t)rf; it.vert_off = (uint32_t)rv; it.key_off = (uint32_t)rk; it.seq_off = (uint32_t)rs;
-      seq_src.push_back(it.seq);
-      rf += it.F; rv += it.V; rk += (uint64_t)it.n_seq + 1; rs += it.n_seq;
+    const uint32_t first_item = (uint32_t)items.size();
+    for (size_t q = 0; q < d.relabels.size(); ++q) {
+      RelabelItem it = d.relabels[q];
+      const bool universal = q == 0;
+      it.order_item = first_item;
+      it.face_off = (uint32_t)rf; it.vert_off = (uint32_t)rv; it.key_off = (uint32_t)rk; it.seq_off = (uint32_t)rs; it.remap_off = (uint32_t)rr;
+      seq_src.push_back(it.seq); c2v_src.push_back(d.host_c2v[q]); opp_src.push_back(d.host_opp[q]);
+      if (universal) { rf += it.F; rk += (uint64_t)it.n_seq + 1; }
+      else host_table_words += 6ull * it.F;
+      rv += it.V; rs += it.n_seq; rr += it.F;
       items.push_back(it);
     }
     for (FanItem f : d.fans) { f.off = (uint32_t)fan_total; fan_total += f.n; fans.push_back(f); }
     for (ComposeItem ci : d.compose) { ci.off = (uint32_t)comp_total; comp_total += ci.n; comps.push_back(ci); }
     for (const auto& cp : d.copies) moves.push_back({cp.dst, cp.src_dev, (cp.bytes + 15) & ~(size_t)15});
   }
-  if (rf >= (1ull << 32) / 3 || rv >= (1ull << 32) || rk >= (1ull << 32) || fan_total >= (1ull << 32) || comp_total >= (1ull << 32)) return fail(DMI_ERR_INVALID_ARGUMENT, "batch slice too large");
+  if (rf >= (1ull << 32) / 3 || rr >= (1ull << 32) / 3 || rv >= (1ull << 32) || rk >= (1ull << 32) || fan_total >= (1ull << 32) || comp_total >= (1ull << 32) || (rs + host_table_words) * 4 >= (1ull << 36))
+    return fail(DMI_ERR_INVALID_ARGUMENT, "batch slice too large");
   for (auto& g : groups) if (g->ev_values) HIP_TRY(hipStreamWaitEvent(S, g->ev_values, 0));   // the values the jobs copy from must have arrived (a built group's are: its build waited)
   for (auto& g : groups) if (g->ev_tables_borrowed) HIP_TRY(hipStreamWaitEvent(S, g->ev_tables_borrowed, 0));   // (its device tables, which the relabelling reads)
   TempDev mem3;
@@ -970,7 +992,9 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     std::vector<CopyItem> copies;
     copies.reserve(moves.size());
     for (auto& mv : moves) copies.push_back(CopyItem{mv.dst, (uint64_t)(static_cast<const uint8_t*>(mv.src) - base), (uint64_t)mv.bytes});
-    const size_t off_items = align256((size_t)rs * 4), off_fans = off_items + align256(items.size() * sizeof(RelabelItem)), off_comps = off_fans + align256(fans.size() * sizeof(FanItem)),
+    // staging: [sequences of every item | vertex ids + opposite corners of the attribute tables of their own | descriptors]
+    const size_t off_tables = align256((size_t)rs * 4);
+    const size_t off_items = off_tables + align256((size_t)host_table_words * 4), off_fans = off_items + align256(items.size() * sizeof(RelabelItem)), off_comps = off_fans + align256(fans.size() * sizeof(FanItem)),
                  off_copies = off_comps + align256(comps.size() * sizeof(ComposeItem)), need2 = off_copies + align256(copies.size() * sizeof(CopyItem));
     stage3.st = acquire_stage(device, need2);
     if (!stage3.st) return fail(DMI_ERR_OUT_OF_MEMORY, "hipHostMalloc (batch sequences staging)");
@@ -982,9 +1006,18 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     b.rank = mem3.take<uint32_t>(rv ? rv : 1); b.key = mem3.take<uint32_t>(rf ? rf : 1); b.count = mem3.take<uint32_t>(nk); b.fill = mem3.take<uint32_t>(nk);
     b.order = mem3.take<uint32_t>(rf ? rf : 1); b.new_face = mem3.take<uint32_t>(rf ? rf : 1); b.scan_partials = mem3.take<uint32_t>(parts2);
     if (!d2 || !b.rank || !b.key || !b.count || !b.fill || !b.order || !b.new_face || !b.scan_partials) return fail(DMI_ERR_OUT_OF_MEMORY, "hipMalloc (batch relabelling)");
-    if ((rc = parallel_over((uint32_t)items.size(), [&](uint32_t, uint32_t i) -> int { std::memcpy(h2 + (size_t)items[i].seq_off * 4, seq_src[i], (size_t)items[i].n_seq * 4); return DMI_OK; },
-                            [&](uint32_t i) { return (uint64_t)items[i].n_seq; }))) return rc;
-    for (auto& it : items) it.seq = reinterpret_cast<const uint32_t*>(d2) + it.seq_off;
+    std::vector<size_t> table_at(items.size(), 0);
+    { size_t at = off_tables; for (size_t i = 0; i < items.size(); ++i) if (c2v_src[i]) { table_at[i] = at; at += (size_t)items[i].F * 24; } }
+    if ((rc = parallel_over((uint32_t)items.size(), [&](uint32_t, uint32_t i) -> int {
+          std::memcpy(h2 + (size_t)items[i].seq_off * 4, seq_src[i], (size_t)items[i].n_seq * 4);
+          if (c2v_src[i]) { std::memcpy(h2 + table_at[i], c2v_src[i], (size_t)items[i].F * 12); std::memcpy(h2 + table_at[i] + (size_t)items[i].F * 12, opp_src[i], (size_t)items[i].F * 12); }
+          return DMI_OK;
+        }, [&](uint32_t i) { return (uint64_t)items[i].n_seq + (c2v_src[i] ? 6ull * items[i].F : 0ull); }))) return rc;
+    for (size_t i = 0; i < items.size(); ++i) {
+      RelabelItem& it = items[i];
+      it.seq = reinterpret_cast<const uint32_t*>(d2) + it.seq_off;
+      if (c2v_src[i]) { it.c2v = reinterpret_cast<const uint32_t*>(d2 + table_at[i]); it.opp = it.c2v + (size_t)it.F * 3; }
+    }
     if (!items.empty()) std::memcpy(h2 + off_items, items.data(), items.size() * sizeof(RelabelItem));
     if (!fans.empty()) std::memcpy(h2 + off_fans, fans.data(), fans.size() * sizeof(FanItem));
     if (!comps.empty()) std::memcpy(h2 + off_comps, comps.data(), comps.size() * sizeof(ComposeItem));
@@ -993,7 +1026,7 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     HIP_TRY(hipMemsetAsync(b.rank, 0xFF, (size_t)(rv ? rv : 1) * 4, S));
     HIP_TRY(hipMemsetAsync(b.count, 0, nk * 4, S));
     b.items = reinterpret_cast<const RelabelItem*>(d2 + off_items); b.n_items = (uint32_t)items.size();
-    b.total_faces = (uint32_t)rf; b.total_verts = (uint32_t)rv; b.total_keys = (uint32_t)rk; b.total_seq = (uint32_t)rs;
+    b.total_faces = (uint32_t)rf; b.total_verts = (uint32_t)rv; b.total_keys = (uint32_t)rk; b.total_seq = (uint32_t)rs; b.total_remap_faces = (uint32_t)rr;
     launch_scatter_items(reinterpret_cast<const CopyItem*>(d2 + off_copies), (uint32_t)copies.size(), base, S);
     launch_relabel_batch(b, S);
     launch_compose_batch(reinterpret_cast<const ComposeItem*>(d2 + off_comps), (uint32_t)comps.size(), (uint32_t)comp_total, S);
@@ -1010,6 +1043,8 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     std::fprintf(stderr, "[dmi] batch prepare, device form: %u meshes, %llu faces: layout + pack + issue of the connectivity kernels %.2f ms, host walks + job layouts %.2f (%u threads), "
                          "sequences up + relabelling + fan rows %.2f, release %.2f; %zu jobs deferred, total %.2f; thread time: waiting for tables %.1f ms, connectivity (Edgebreaker, sequencer, bytes) %.1f, job layout %.1f, output buffer %.1f\n", M, (unsigned long long)tf, t_issue, t_walks - t_issue, n_threads, t_dev - t_walks, ms() - t_dev, items.size(), ms(),
                          ns_wait.load() / 1e6, ns_conn.load() / 1e6, ns_job.load() / 1e6, ns_buf.load() / 1e6);
+    std::fprintf(stderr, "[dmi]   connectivity thread time: attribute tables %.1f ms, Edgebreaker + connectivity bytes %.1f, universal sequencer (+ views) %.1f, rest %.1f\n",
+                 g_conn_us[0].exchange(0) / 1e3, g_conn_us[1].exchange(0) / 1e3, g_conn_us[2].exchange(0) / 1e3, g_conn_us[3].exchange(0) / 1e3);
   }
   return DMI_OK;
 }

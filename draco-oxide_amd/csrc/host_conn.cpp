@@ -335,7 +335,6 @@ void CornerTables::build_attribute_into(AttTable& a, const uint32_t* p2v, bool s
   }
   Pooled<uint8_t> vseam_p(V, (uint8_t)0);
   std::vector<uint8_t>& vseam = vseam_p.v;
-  auto val = [&](uint32_t corner) { uint32_t p = c2p[corner]; return p2v ? p2v[p] : p; };
   std::atomic<int> interior{0};
   parallel_for(C, [&](size_t lo, size_t hi) {
     bool any = false;
@@ -350,8 +349,11 @@ void CornerTables::build_attribute_into(AttTable& a, const uint32_t* p2v, bool s
         continue;
       }
       if (o < c) continue;
-      // the two shared endpoints: next(c)↔prev(o) and prev(c)↔next(o)
-      if (val(corner_next(c)) != val(corner_prev(o)) || val(corner_prev(c)) != val(corner_next(o))) {
+      // the two shared endpoints: next(c)↔prev(o) and prev(c)↔next(o) — the same POINT on both sides (the rule inside an indexed mesh) needs no
+      // look-up of its value
+      const uint32_t pa = c2p[corner_next(c)], pb = c2p[corner_prev(o)], pc = c2p[corner_prev(c)], pd = c2p[corner_next(o)];
+      auto value_of = [&](uint32_t p) { return p2v ? p2v[p] : p; };
+      if ((pa != pb && value_of(pa) != value_of(pb)) || (pc != pd && value_of(pc) != value_of(pd))) {
         a.seam_edge[c] = a.seam_edge[o] = 1;
         vseam[c2v[corner_next(c)]] = vseam[c2v[corner_prev(c)]] = 1;
         vseam[c2v[corner_next(o)]] = vseam[c2v[corner_prev(o)]] = 1;
@@ -409,8 +411,12 @@ void CornerTables::finish_attribute(AttTable& a, const std::vector<uint8_t>& vse
   const uint32_t nv = base[V];
   pool_fit(a.lmc, nv);
   a.lmc.assign(nv, kNone);
+  // a vertex no seam touches keeps ONE attribute vertex, its fan start is the universal left-most corner: its corners take their id in a
+  // streaming pass over the corners — only the vertices ON a seam (a vanishing share of a mesh) walk their fans
+  parallel_for(C, [&](size_t lo, size_t hi) { for (size_t c = lo; c < hi; ++c) { const uint32_t v = c2v[c]; if (!vseam[v]) a.c2v[c] = base[v]; } });
   parallel_for(V, [&](size_t lo, size_t hi) {
     for (size_t v = lo; v < hi; ++v) {
+      if (!vseam[v]) { a.lmc[base[v]] = lmc[v]; continue; }
       const uint32_t first = fan_start((uint32_t)v);
       uint32_t id = base[v];
       a.c2v[first] = id;
@@ -783,8 +789,12 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
       if (t.no_boundary) total = (uint64_t)t.F * 3 / 2;
       else { uint64_t k = 0; for (size_t c = 0; c < (size_t)t.F * 3; ++c) k += t.opp[c] != kNone; total = k / 2; }
     } else if (A) {   // small meshes with seams, and a face processed twice (malformed tables): the reference's loop as it stands
+      // (the flags are written from the back of arrays sized for every corner — the coder is fed in the reverse of the order of emission — and
+      //  moved to the front at the end: no growing vectors, no reversing copy)
       std::vector<uint8_t> fv(t.F, 0);
-      std::vector<std::vector<uint8_t>> seams(A);
+      const size_t cap = 3 * n;
+      for (size_t j : own) { pool_fit(fed[j], cap); fed[j].resize(cap); }
+      size_t at = cap;
       for (size_t i = n; i-- > 0;) {
         const uint32_t c = processed[i];
         const uint32_t cs[3] = {c, corner_next(c), corner_prev(c)};
@@ -793,10 +803,11 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
           const uint32_t o = t.opp[cc];
           if (o == kNone || fv[o / 3]) continue;
           ++total;
-          for (size_t j : own) seams[j].push_back(t.att[j].seam_edge[cc]);
+          --at;
+          for (size_t j : own) { const uint8_t f = t.att[j].seam_edge[cc]; fed[j][at] = f; zeros[j] += !f; }
         }
       }
-      for (size_t j : own) { fed[j].assign(seams[j].rbegin(), seams[j].rend()); for (uint8_t b : fed[j]) zeros[j] += !b; }
+      for (size_t j : own) { std::memmove(fed[j].data(), fed[j].data() + at, (size_t)total); fed[j].resize((size_t)total); }
     }
     // (the stream of an attribute without seams is `total` zero flags: coded by its period, host_rabs_constant — no flag array, no 1.5 steps per face)
     const bool need_zero = own.size() < A && std::find(stream_of.begin(), stream_of.end(), -1) != stream_of.end();

@@ -121,3 +121,25 @@ def batch_glbs(n_files, lo=2e3, hi=2e5, seed=SEED):
         out.append(g)
         total += f
     return out, total
+
+
+def seam_torus_rows(n, seed=SEED):
+    """The torus grid as an exporter writes it: an (n+1)×(n+1) sheet of points whose last row / column REPEAT the positions and normals of the
+    first (the surface closes) but carry their own texture coordinates (u or v = 1 instead of 0) — per-point rows + faces.  MeshBuilder merges
+    the repeated positions / normals (point → value maps), the UV attribute keeps a seam along both closing curves (an attribute corner
+    table of its own: attribute_corner_table.rs:16-137).  → (faces [2n², 3] uint32, pos, nrm, uv per point)."""
+    _, pos0, nrm0, _ = torus_grid(n, seed)
+    rng = np.random.default_rng(seed + 1)
+    m = n + 1
+    iu, iv = np.meshgrid(np.arange(m), np.arange(m), indexing="ij")
+    src = ((iu % n) * n + (iv % n)).ravel()
+    pos, nrm = pos0[src], nrm0[src]
+    uv = np.stack([iu.ravel() / n, iv.ravel() / n], axis=1) + rng.uniform(-1e-4, 1e-4, size=(m * m, 2)) * 0.0
+    uv = uv.astype(np.float32)
+    a, b = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    a, b = a.ravel(), b.ravel()
+    i00, i10, i01, i11 = a * m + b, (a + 1) * m + b, a * m + b + 1, (a + 1) * m + b + 1
+    faces = np.empty((2 * n * n, 3), np.uint32)
+    faces[0::2] = np.stack([i00, i10, i11], axis=1)
+    faces[1::2] = np.stack([i00, i11, i01], axis=1)
+    return faces, pos, nrm, uv

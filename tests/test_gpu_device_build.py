@@ -232,3 +232,40 @@ def test_large_mesh_build_and_prepare():
         finally:
             job.close()
     assert got == dmi.encode_mesh(mesh)
+
+
+def test_exporter_style_seams_through_the_deferred_batch_path():
+    """Meshes the way exporters write them (synth.seam_torus_rows: positions / normals repeated along the closing curves, texture coordinates
+    with a seam there): MeshBuilder merges the positions, the UV attribute keeps a corner table of its own — built, prepared (deferred job
+    creation with the seam table uploaded beside the sequences) and coded as a batch; bytes against the oracle's whole pipeline."""
+    raws, want = [], []
+    for k, n in enumerate((9, 14, 23, 31)):
+        faces, pos, nrm, uv = synth.seam_torus_rows(n, seed=500 + k)
+        rm = dmi.RawMesh()
+        rm.add_attribute(pos, dmi.ATT_POSITION, dmi.DOMAIN_POSITION)
+        rm.add_attribute(nrm, dmi.ATT_NORMAL, dmi.DOMAIN_CORNER, [0])
+        rm.add_attribute(uv, dmi.ATT_TEXCOORD, dmi.DOMAIN_CORNER, [0])
+        rm.set_indices(faces.ravel())
+        raws.append(rm)
+        sess = orc.Session.from_arrays(faces, [dict(data=pos, type=orc.POSITION), dict(data=nrm, type=orc.NORMAL, domain=orc.DOM_CORNER, parents=[0]),
+                                               dict(data=uv, type=orc.TEXCOORD, domain=orc.DOM_CORNER, parents=[0])])
+        want.append(sess.encode())
+    with dmi.meshes_build(raws, host_values=True) as batch:
+        for j in range(len(raws)):
+            m = batch.mesh(j)
+            assert m.attributes[0].point_to_value is not None and m.attributes[2].point_to_value is None   # positions merged, UVs all distinct
+        jobs = dmi.built_meshes_prepare(batch)
+        try:
+            got = [j.header_and_connectivity + s for j, s in zip(jobs, dmi.jobs_encode(jobs))]
+        finally:
+            for j in jobs:
+                j.close()
+        host_meshes = [batch.mesh(j) for j in range(len(raws))]
+    assert got == want
+    # the same meshes from host memory through dmi_meshes_prepare (host-packed groups defer their seam tables too)
+    jobs = dmi.meshes_prepare(host_meshes)
+    try:
+        assert [j.header_and_connectivity + s for j, s in zip(jobs, dmi.jobs_encode(jobs))] == want
+    finally:
+        for j in jobs:
+            j.close()
