@@ -180,7 +180,25 @@ def transcode_regime(n_files=1024, steps=2, device=0):
     ok = ok and all(a[0] == b[0] for a, b in zip(res1, res))
     out_bytes = sum(len(g) for g, _ in res)
     tm = best_tm
-    return {"workload": f"BASELINE configs[3]: {n_files} GLB files in memory (one primitive each, F log-uniform [2k,200k], pos+nrm+uv, u16/u32 indices) → gltf.transcode_files → {n_files} "
+    seam = None
+    try:   # the same shape of files the way exporters write them: repeated positions / normals along the closing curves, a UV seam there
+        n_s = max(8, n_files // 4)
+        sglbs, stotal = synth.batch_glbs(n_s, seams=True)
+        gltf.transcode_files(sglbs, cfg)
+        ts = []
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            sres = gltf.transcode_files(sglbs, cfg)
+            ts.append(time.perf_counter() - t0)
+        doc, binary = gltf.read_glb(sglbs[n_s // 2])
+        mesh, _ = gltf.primitive_to_mesh(doc, binary, doc["meshes"][0]["primitives"][0])
+        seam = {"files": n_s, "triangles": int(stotal), "value": round(stotal / min(ts) / 1e6, 2), "unit": "Mtriangles/s", "ms_per_batch": round(min(ts) * 1e3, 2),
+                "what": "positions / normals repeated along the closing curves (merged by the device MeshBuilder), texture coordinates with a seam there: the UV attribute has a corner table of its own",
+                "sample_blob_equals_whole_mesh_encode": bool(sres[n_s // 2][1][0] == dmi.encode_mesh(mesh, cfg))}
+    except Exception as e:
+        seam = {"error": str(e)[:200]}
+    return {"with_uv_seams": seam,
+            "workload": f"BASELINE configs[3]: {n_files} GLB files in memory (one primitive each, F log-uniform [2k,200k], pos+nrm+uv, u16/u32 indices) → gltf.transcode_files → {n_files} "
                         "Draco-compressed GLBs: JSON parse, device MeshBuilder::build (dmi_meshes_build), dmi_built_meshes_prepare, dmi_jobs_encode, reassembly — all inside the timed call",
             "triangles": int(total), "value": round(total / best / 1e6, 2), "unit": "Mtriangles/s", "ms_per_batch": round(best * 1e3, 2),
             "split_ms": {"parse (JSON)": round(tm["parse_s"] * 1e3, 2), "accessor views (per stage, beside the device work)": round(tm["views_s"] * 1e3, 2), "build (pack, upload, kernels, faces + maps back)": round(tm["build_s"] * 1e3, 2),
@@ -246,6 +264,39 @@ def batch_sharded(n_meshes, rank, world, local_rank, gather_dev, steps=2):
                "host_threads_per_rank": int(os.environ.get("DMI_HOST_THREADS", usable_cpus())),
                "blobs_on_rank0": len(got), "sample_checked_against_single_encodes": len(check), "sample_ok": bool(ok)}
     return res
+
+
+def transcode_sharded(n_files, rank, world, local_rank, gather_dev, steps=2):
+    """BASELINE configs[3] over the N ranks of this run, as it is worded: n GLB files through gltf.transcode_files in the torch.distributed job —
+    every rank parses the JSON of all files, the primitives are dealt by the triangle counts the JSON states (LPT), each rank builds
+    (dmi_meshes_build), prepares and encodes ONLY its share, rank 0 gathers the blobs (RCCL) and reassembles every file.  Strong scaling."""
+    from draco_oxide_amd import gltf
+    glbs, total = synth.batch_glbs(n_files)
+    cfg = dmi.Config(device=local_rank)
+    gltf.transcode_files(glbs, cfg, device=gather_dev)
+    dist.barrier()
+    torch.cuda.synchronize()
+    built = 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tm = {}
+        res = gltf.transcode_files(glbs, cfg, device=gather_dev, timings=tm)
+        built = tm["primitives_built"]
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt, float(built), -float(built)], dtype=torch.float64, device=gather_dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt, built_max, built_min = float(t[0]), int(t[1]), int(-t[2])
+    if rank != 0:
+        return None
+    doc, binary = gltf.read_glb(glbs[n_files // 2])
+    mesh, _ = gltf.primitive_to_mesh(doc, binary, doc["meshes"][0]["primitives"][0])
+    return {"workload": f"BASELINE configs[3]: {n_files} GLB files in memory through gltf.transcode_files over {world} rank(s): primitives dealt from the JSON's counts before anything is built, "
+                        "each rank builds / prepares / encodes its share, blobs gathered on rank 0, files reassembled there", "scaling": "strong", "n_gpus": world,
+            "triangles": int(total), "ms_per_step": round(dt / steps * 1e3, 2), "value": round(total * steps / dt / 1e6, 2), "unit": "Mtriangles/s",
+            "primitives_built_per_rank_min_max": [built_min, built_max], "files_on_rank0": len(res),
+            "sample_blob_equals_whole_mesh_encode": bool(res[n_files // 2][1][0] == dmi.encode_mesh(mesh, cfg))}
 
 
 def main():
@@ -473,6 +524,14 @@ def main():
             except Exception as e:
                 if rank == 0:
                     line["batch_sharded"] = {"error": str(e)[:200]}
+            if args.transcode_files > 0:
+                try:
+                    res = transcode_sharded(args.transcode_files, rank, world, local_rank, gather_dev)
+                    if rank == 0:
+                        line["transcode_sharded"] = res
+                except Exception as e:
+                    if rank == 0:
+                        line["transcode_sharded"] = {"error": str(e)[:200]}
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(mesh)

@@ -84,12 +84,13 @@ def batch_meshes(n_meshes, lo=2e3, hi=2e5, seed=SEED):
     return [torus_mesh(max(8, grid_size_for_triangles(t)), seed=seed + 7 * k) for k, t in enumerate(tris)]
 
 
-def torus_glb(n, seed=SEED, open_boundary=False):
+def torus_glb(n, seed=SEED, open_boundary=False, seams=False):
     """One torus grid as a minimal GLB (one mesh, one triangle primitive; POSITION / NORMAL / TEXCOORD_0 as separate float accessors,
-    UNSIGNED_SHORT indices when the vertex count allows, else UNSIGNED_INT) → (glb bytes, triangles)."""
+    UNSIGNED_SHORT indices when the vertex count allows, else UNSIGNED_INT) → (glb bytes, triangles).  seams: the exporter-style sheet of
+    seam_torus_rows (positions / normals repeated along the closing curves, a UV seam there)."""
     import json
     import struct
-    faces, pos, nrm, uv = torus_grid(n, seed, open_boundary=open_boundary)
+    faces, pos, nrm, uv = seam_torus_rows(n, seed) if seams else torus_grid(n, seed, open_boundary=open_boundary)
     idx = faces.ravel().astype("<u2" if len(pos) <= 65535 else "<u4")
     parts = [pos.astype("<f4").tobytes(), nrm.astype("<f4").tobytes(), uv.astype("<f4").tobytes(), idx.tobytes()]
     views, off = [], 0
@@ -110,14 +111,14 @@ def torus_glb(n, seed=SEED, open_boundary=False):
     return struct.pack("<4sII", b"glTF", 2, total) + struct.pack("<II", len(js), 0x4E4F534A) + js + struct.pack("<II", len(binary), 0x004E4942) + binary, len(faces)
 
 
-def batch_glbs(n_files, lo=2e3, hi=2e5, seed=SEED):
+def batch_glbs(n_files, lo=2e3, hi=2e5, seed=SEED, seams=False):
     """The batch workload of batch_meshes as GLB files in memory (BASELINE configs[3]: "1024 glTF/glb meshes through … transcode") →
     ([glb bytes], total triangles).  Same grids, same seeds."""
     rng = np.random.default_rng(seed)
     tris = np.exp(rng.uniform(np.log(lo), np.log(hi), size=n_files))
     out, total = [], 0
     for k, t in enumerate(tris):
-        g, f = torus_glb(max(8, grid_size_for_triangles(t)), seed=seed + 7 * k)
+        g, f = torus_glb(max(8, grid_size_for_triangles(t)), seed=seed + 7 * k, seams=seams)
         out.append(g)
         total += f
     return out, total
