@@ -113,7 +113,7 @@ class _Conn(C.Structure):
 
 EXPORTS = ["dmi_encode_attributes", "dmi_encode_attributes_batch", "dmi_jobs_encode", "dmi_job_create", "dmi_job_encode", "dmi_job_timings", "dmi_job_destroy", "dmi_encode_mesh",
            "dmi_mesh_prepare", "dmi_meshes_prepare", "dmi_shard_meshes", "dmi_meshes_prepare_devices", "dmi_jobs_encode_devices", "dmi_mesh_build", "dmi_built_mesh_free", "dmi_encode_connectivity", "dmi_conn_free", "dmi_host_rans_stream", "dmi_host_rabs_stream", "dmi_host_rabs_constant_stream", "dmi_tile_sort_slots", "dmi_decode_attributes", "dmi_decoded_free", "dmi_decode_mesh", "dmi_decoded_mesh_free", "dmi_decode_connectivity", "dmi_decoded_conn_free", "dmi_last_decode_timings", "dmi_free", "dmi_free_many", "dmi_strerror", "dmi_last_error", "dmi_device_count", "dmi_release_cached_memory",
-           "dmi_init", "dmi_last_call_timings", "dmi_device_corner_table", "dmi_encode_mesh_device", "dmi_meshes_build", "dmi_built_meshes_prepare", "dmi_last_build_timings"]
+           "dmi_init", "dmi_last_call_timings", "dmi_device_corner_table", "dmi_encode_mesh_device", "dmi_meshes_build", "dmi_built_meshes_prepare", "dmi_last_build_timings", "dmi_device_attribute_table"]
 
 
 def library_path():
@@ -187,6 +187,7 @@ def load_library():
     L.dmi_meshes_build.argtypes = [C.POINTER(_RawMesh), C.c_uint32, C.POINTER(_Config), C.c_uint32, C.POINTER(_BuiltMesh)]
     L.dmi_built_meshes_prepare.argtypes = [C.POINTER(_BuiltMesh), C.c_uint32, C.POINTER(_Config), C.POINTER(_Buffer), C.POINTER(C.c_void_p)]
     L.dmi_last_build_timings.argtypes = [C.POINTER(_BuildTimings)]
+    L.dmi_device_attribute_table.argtypes = [C.POINTER(_Mesh), C.POINTER(_Config), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     _lib = L
     return L
 
@@ -870,6 +871,19 @@ def device_corner_table(mesh, cfg=None):
     nv, flags = C.c_uint32(0), C.c_uint32(0)
     _check(L.dmi_device_corner_table(C.byref(m), C.byref(c), opp.ctypes.data, lmc.ctypes.data, onb.ctypes.data, C.byref(nv), C.byref(flags)))
     return dict(num_vertices=nv.value, opposite=opp, left_most_corner=lmc[:nv.value], on_boundary=onb[:nv.value], flags=flags.value)
+
+
+def device_attribute_table(mesh, att_index, cfg=None):
+    """dmi_device_attribute_table: the corner table of attribute `att_index` of one mesh built by the device kernels (k_att_*), read back.
+    → dict(num_vertices, interior_seams, seam_edge, corner_to_vertex, opposite, left_most_corner, flags); num_vertices == 0: flagged mesh."""
+    L = load_library()
+    cfg = cfg or Config.default()
+    m, c = mesh._c(), cfg._c()
+    nc = 3 * len(mesh.faces)
+    seam, c2v, opp, lmc = np.zeros(nc, np.uint8), np.zeros(nc, np.uint32), np.zeros(nc, np.uint32), np.zeros(max(nc, 1), np.uint32)
+    nv, interior, flags = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+    _check(L.dmi_device_attribute_table(C.byref(m), C.byref(c), att_index, seam.ctypes.data, c2v.ctypes.data, opp.ctypes.data, lmc.ctypes.data, C.byref(nv), C.byref(interior), C.byref(flags)))
+    return dict(num_vertices=nv.value, interior_seams=bool(interior.value), seam_edge=seam, corner_to_vertex=c2v, opposite=opp, left_most_corner=lmc[:nv.value], flags=flags.value)
 
 
 def _decoded_attributes(atts, n):

@@ -401,6 +401,7 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
         mem.atts[s].val_off = bg.b_off + (size_t)io.val_off * 4;
         mem.atts[s].map_off = io.has_map ? (size_t)io.map_off * 4 : (size_t)-1;
         mem.atts[s].n_unique = io.n_out;
+        mem.atts[s].att_type = m.atts[order[s]].att_type;
       }
       bg.members.push_back(std::move(mem));
       if (mo.flags) { redo.push_back(j); continue; }   // (its slot in the arena stays: the connectivity kernels skip nothing, the caller's list decides)

@@ -222,6 +222,99 @@ __global__ __launch_bounds__(kBlock) void k_conn_check(const ConnArgs a) {
   }
 }
 
+// ---- attribute corner tables of a batch (attribute_corner_table.rs:16-137) ----
+// The host builder (host_conn.cpp build_attribute_into / finish_attribute) restated per corner / per vertex: every step is order-free.
+constexpr uint32_t kConnSkip = CONN_BAD_INDEX | CONN_DEGENERATE | CONN_NONMANIFOLD_EDGE | CONN_MULTI_FAN | CONN_UNUSED_VERTEX;
+__device__ __forceinline__ uint32_t att_item_of_corner(const AttArgs& t, uint32_t g) { return find_mesh(t.n_items, g, [&](uint32_t k) { return t.items[k].corner_off; }); }
+__device__ __forceinline__ uint32_t att_item_of_vertex(const AttArgs& t, uint32_t g) { return find_mesh(t.n_items, g, [&](uint32_t k) { return t.items[k].vert_off; }); }
+// seam test per edge (:44-63): a boundary, or the attribute's values differ at either shared endpoint
+__global__ __launch_bounds__(kBlock) void k_att_seams(const ConnArgs a, const AttArgs t) {
+  for (uint32_t g = blockIdx.x * kBlock + threadIdx.x; g < t.total_corners; g += gridDim.x * kBlock) {
+    const uint32_t i = att_item_of_corner(t, g);
+    const AttItemDesc it = t.items[i];
+    const ConnMeshDesc d = a.meshes[it.mesh];
+    if (a.flags[it.mesh] & kConnSkip) continue;
+    const uint32_t c = g - it.corner_off;
+    if (c >= 3u * d.F) continue;
+    const uint64_t cb = 3ull * d.face_off;
+    const uint32_t o = a.opp[cb + c];
+    const uint32_t* __restrict__ c2v = a.c2v + cb;
+    uint8_t* __restrict__ vs = t.vseam + it.vert_off;
+    if (o == kNoneD) { t.seam[g] = 1; vs[c2v[cnext(c)]] = 1; vs[c2v[cprev(c)]] = 1; continue; }
+    if (o < c) continue;
+    const uint32_t* __restrict__ f = a.faces + cb;
+    const uint32_t pa = f[cnext(c)], pb = f[cprev(o)], pc = f[cprev(c)], pd = f[cnext(o)];
+    auto val = [&](uint32_t p) { return it.map_off != kNoneD ? a.p2v[it.map_off + p] : p; };
+    if ((pa != pb && val(pa) != val(pb)) || (pc != pd && val(pc) != val(pd))) {
+      t.seam[g] = 1; t.seam[it.corner_off + o] = 1;
+      vs[c2v[cnext(c)]] = 1; vs[c2v[cprev(c)]] = 1; vs[c2v[cnext(o)]] = 1; vs[c2v[cprev(o)]] = 1;
+      if (!__atomic_load_n(&t.info[i].interior, __ATOMIC_RELAXED)) atomicOr(&t.info[i].interior, 1u);
+    }
+  }
+}
+// seam-aware fan start of vertex v (:101-113) and the walk to the right over the UNIVERSAL table (:116-133)
+struct AttFan {
+  const uint32_t* __restrict__ opp; const uint8_t* __restrict__ seam; uint32_t lmc_v;
+  __device__ __forceinline__ uint32_t a_swing_left(uint32_t c) const { const uint32_t n = cnext(c); if (seam[n]) return kNoneD; const uint32_t o = opp[n]; return o == kNoneD ? kNoneD : cnext(o); }
+  __device__ __forceinline__ uint32_t u_swing_right(uint32_t c) const { const uint32_t o = opp[cprev(c)]; return o == kNoneD ? kNoneD : cprev(o); }
+  __device__ __forceinline__ uint32_t start() const { uint32_t first = lmc_v, steps = 0; for (uint32_t n; (n = a_swing_left(first)) != kNoneD && n != lmc_v && steps < (1u << 20); ++steps) first = n; return first; }
+};
+__global__ __launch_bounds__(kBlock) void k_att_count(const ConnArgs a, const AttArgs t) {
+  for (uint32_t g = blockIdx.x * kBlock + threadIdx.x; g < t.total_verts; g += gridDim.x * kBlock) {
+    const AttItemDesc it = t.items[att_item_of_vertex(t, g)];
+    const ConnMeshDesc d = a.meshes[it.mesh];
+    const uint32_t v = g - it.vert_off;
+    if ((a.flags[it.mesh] & kConnSkip) || d.F == 0 || v > a.vmax[it.mesh]) continue;   // (count stays 0)
+    uint32_t k = 1;
+    if (t.vseam[g]) {
+      const AttFan fan{a.opp + 3ull * d.face_off, t.seam + it.corner_off, a.lmc[d.vert_off + v]};
+      const uint32_t first = fan.start();
+      uint32_t steps = 0;
+      for (uint32_t cur = fan.u_swing_right(first); cur != kNoneD && cur != first && steps < (1u << 20); cur = fan.u_swing_right(cur), ++steps) k += fan.seam[cnext(cur)];
+    }
+    t.count[g] = k;
+  }
+}
+// corners of vertices no seam touches: one attribute vertex, the universal left-most corner; every corner's opposite
+__global__ __launch_bounds__(kBlock) void k_att_corners(const ConnArgs a, const AttArgs t) {
+  for (uint32_t g = blockIdx.x * kBlock + threadIdx.x; g < t.total_corners; g += gridDim.x * kBlock) {
+    const AttItemDesc it = t.items[att_item_of_corner(t, g)];
+    const ConnMeshDesc d = a.meshes[it.mesh];
+    if (a.flags[it.mesh] & kConnSkip) continue;
+    const uint32_t c = g - it.corner_off;
+    if (c >= 3u * d.F) continue;
+    const uint64_t cb = 3ull * d.face_off;
+    t.opp[g] = t.seam[g] ? kNoneD : a.opp[cb + c];
+    const uint32_t v = a.c2v[cb + c];
+    if (!t.vseam[it.vert_off + v]) t.c2v[g] = t.count[it.vert_off + v] - t.count[it.vert_off];
+  }
+}
+// per vertex: left-most corners; the vertices ON a seam walk their fan and hand out their attribute vertices
+__global__ __launch_bounds__(kBlock) void k_att_vertices(const ConnArgs a, const AttArgs t) {
+  for (uint32_t g = blockIdx.x * kBlock + threadIdx.x; g < t.total_verts; g += gridDim.x * kBlock) {
+    const uint32_t i = att_item_of_vertex(t, g);
+    const AttItemDesc it = t.items[i];
+    const ConnMeshDesc d = a.meshes[it.mesh];
+    const uint32_t v = g - it.vert_off;
+    if ((a.flags[it.mesh] & kConnSkip) || d.F == 0 || v > a.vmax[it.mesh]) continue;
+    const uint32_t base0 = t.count[it.vert_off];
+    uint32_t id = t.count[g] - base0;
+    uint32_t* __restrict__ lmc = t.lmc + base0;   // (the scan is global: the items' attribute vertices lie one after the other)
+    if (v == 0) { t.info[i].num_vertices = t.count[it.vert_off + a.vmax[it.mesh] + 1] - base0; t.info[i].pad = base0; t.info[i].done = 1; }   // pad = where the item's left-most corners start
+    if (!t.vseam[g]) { lmc[id] = a.lmc[d.vert_off + v]; continue; }
+    const AttFan fan{a.opp + 3ull * d.face_off, t.seam + it.corner_off, a.lmc[d.vert_off + v]};
+    const uint32_t first = fan.start();
+    uint32_t* __restrict__ c2v = t.c2v + it.corner_off;
+    c2v[first] = id;
+    lmc[id] = first;
+    uint32_t steps = 0;
+    for (uint32_t cur = fan.u_swing_right(first); cur != kNoneD && cur != first && steps < (1u << 20); cur = fan.u_swing_right(cur), ++steps) {
+      if (fan.seam[cnext(cur)]) { ++id; lmc[id] = cur; }
+      c2v[cur] = id;
+    }
+  }
+}
+
 // ---- coding-order relabelling of a batch of (small) meshes: dmi_relabel.hip's steps with per-mesh descriptors, one launch per step ----
 // (reference seam and the argument why this is a pure relabelling: dmi_relabel.hip / DESIGN.md §3)
 template <class F> __device__ __forceinline__ uint32_t find_item(const RelabelItem* __restrict__ items, uint32_t n, uint32_t x, F off) {
@@ -334,6 +427,23 @@ void launch_conn_tables(const ConnArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_conn_match, grid_of(C), kBlock, 0, s, a);
   hipLaunchKernelGGL(k_conn_vertices, grid_of(a.total_verts), kBlock, 0, s, a);
   hipLaunchKernelGGL(k_conn_check, grid_of(C), kBlock, 0, s, a);
+}
+hipError_t att_tables_clear(const AttArgs& t, hipStream_t s) {
+  hipError_t e;
+  if (!t.n_items) return hipSuccess;
+  if ((e = hipMemsetAsync(t.seam, 0, t.total_corners, s)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(t.vseam, 0, t.total_verts, s)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(t.count, 0, ((size_t)t.total_verts + 1) * 4, s)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(t.info, 0, (size_t)t.n_items * sizeof(AttInfo), s)) != hipSuccess) return e;
+  return hipSuccess;
+}
+void launch_att_tables(const ConnArgs& a, const AttArgs& t, hipStream_t s) {
+  if (!t.n_items || !t.total_corners) return;
+  hipLaunchKernelGGL(k_att_seams, grid_of(t.total_corners), kBlock, 0, s, a, t);
+  hipLaunchKernelGGL(k_att_count, grid_of(t.total_verts), kBlock, 0, s, a, t);
+  launch_exclusive_scan_u32(t.count, t.total_verts + 1, t.scan_partials, s);
+  hipLaunchKernelGGL(k_att_corners, grid_of(t.total_corners), kBlock, 0, s, a, t);
+  hipLaunchKernelGGL(k_att_vertices, grid_of(t.total_verts), kBlock, 0, s, a, t);
 }
 void launch_relabel_batch(const RelabelBatch& b, hipStream_t s) {
   if (!b.n_items || !b.total_faces) return;

@@ -272,6 +272,26 @@ struct ConnArgs {
 };
 hipError_t conn_tables_clear(const ConnArgs& a, hipStream_t s);   // the memsets launch_conn_tables expects
 void launch_conn_tables(const ConnArgs& a, hipStream_t s);
+// Attribute corner tables of a batch on the device (core/corner_table/attribute_corner_table.rs:16-137), after launch_conn_tables on the same
+// stream.  An "att item" = one (mesh, non-position attribute) whose point → value map may differ from the position's: seam test per edge
+// (:44-63), attribute vertices per universal vertex = 1 + the seam edges its right swing crosses (:116-133), ids by a prefix sum, seam-aware fan
+// starts (:101-113).  Per-corner arrays of the items are concatenated (corner_off), per-vertex scratch too (vert_off, Vcap slots per item);
+// att vertex ids are item-local.  Items of meshes the universal kernels flagged are skipped (info stays 0: the host builds those meshes).
+struct AttItemDesc { uint32_t mesh /* index of its ConnMeshDesc */, map_off /* words into ConnArgs::p2v, DMI_NONE = identity */, corner_off, vert_off; };
+struct AttInfo { uint32_t interior /* some edge with two faces is a seam */, num_vertices, done /* 1: tables written */, pad /* offset of the item's left-most corners in AttArgs::lmc */; };
+struct AttArgs {
+  const AttItemDesc* items; uint32_t n_items, total_corners, total_verts, pad;
+  uint8_t* seam;        // total_corners: 1 = the edge opposite the corner is a seam of the attribute (boundary edges included); zeroed by att_tables_clear
+  uint8_t* vseam;       // total_verts: the universal vertex lies on a seam; zeroed
+  uint32_t* count;      // total_verts + 1: attribute vertices per universal vertex → exclusive scan (zeroed)
+  uint32_t* c2v;        // total_corners: attribute vertex per corner (item-local ids)
+  uint32_t* opp;        // total_corners: opposite corner, DMI_NONE across seams
+  uint32_t* lmc;        // total_corners (worst case): left-most corner per attribute vertex, at [Σ attribute vertices of the items before + id]
+  AttInfo* info;        // n_items, zeroed
+  uint32_t* scan_partials;   // scan_partials_words(total_verts + 1)
+};
+hipError_t att_tables_clear(const AttArgs& t, hipStream_t s);
+void launch_att_tables(const ConnArgs& a, const AttArgs& t, hipStream_t s);
 // Coding-order relabelling of a batch of meshes in one launch per step (the arrays of dmi_relabel.hip, per mesh): inputs in the mesh's own
 // numbering (device arrays of the connectivity stage + the uploaded sequence), outputs in the job's memory.
 // An item is one corner table of a job.  The face order is the universal table's (sequence.rs walks that one first): an attribute table of

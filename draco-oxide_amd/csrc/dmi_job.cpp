@@ -399,8 +399,10 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
       if ((rc = t.seq.alloc((size_t)t.n_seq * 4))) return rc;
       if ((rc = t.s2p.alloc((size_t)t.n_seq * 4))) return rc;
       RelabelItem r{};
-      const bool resident = tables[i].corner_to_vertex == tables[0].corner_to_vertex && tables[i].opposite == tables[0].opposite;
+      bool resident = tables[i].corner_to_vertex == tables[0].corner_to_vertex && tables[i].opposite == tables[0].opposite;
       r.c2p = dev->c2p; r.c2v = resident ? dev->c2v : nullptr; r.opp = resident ? dev->opp : nullptr; r.seq = seq_of[i];
+      for (uint32_t k = 0; k < dev->n_att && !resident; ++k)   // an attribute table the device built: its device copies
+        if (dev->att_key[k] == tables[i].corner_to_vertex) { r.c2v = dev->att_c2v[k]; r.opp = dev->att_opp[k]; resident = true; }
       r.F = F; r.V = t.V; r.n_seq = t.n_seq; r.order_item = 0;
       r.c2r = t.c2r.as<uint32_t>(); r.opp_out = t.opp.as<uint32_t>(); r.seq_out = t.seq.as<uint32_t>(); r.s2p = t.s2p.as<uint32_t>();
       defer->relabels.push_back(r);

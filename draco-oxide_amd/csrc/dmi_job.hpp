@@ -299,6 +299,9 @@ int to_buffer(const std::vector<uint8_t>& v, dmi_buffer* out);
 // the universal corner table of a mesh as the device connectivity stage left it in HBM (mesh-local ids, the mesh's own numbering)
 struct DeviceTableView { const uint32_t* c2p; const uint32_t* c2v; const uint32_t* opp; bool trusted_sequences;
                          bool values_on_device = false;   // dmi_attribute::values are device pointers (dmi_encode_mesh_device): copied device to device
+                         // attribute corner tables the device built (k_att_*): a table whose host corner_to_vertex array is att_key[k] has its device
+                         // copies at att_c2v[k] / att_opp[k] (the deferred relabelling reads them there: nothing is uploaded)
+                         uint32_t n_att = 0; const uint32_t* const* att_key = nullptr; const uint32_t* const* att_c2v = nullptr; const uint32_t* const* att_opp = nullptr;
 };
 // Job creation as part of a batch (dmi_meshes_prepare): the job is planned and its memory laid out on a worker thread, but every piece of
 // device work is only RECORDED here — the coordinator runs the uploads, the relabelling, the fan rows and the map compositions of all
@@ -331,6 +334,24 @@ struct TempDev {
   template <class T> T* take(size_t n) { return static_cast<T*>(pool.take((n ? n : 1) * sizeof(T))); }
 };
 
+// Attribute corner tables of one connectivity group on the device (dmi_conn.hip k_att_*): one item per (mesh of the group, non-position
+// attribute) whose point → value map is not the position map entry for entry (such an attribute has no seam but the boundary).  The tables
+// stay on the device for the batched relabelling and come back for the host's walks (seam flags → the Edgebreaker's seam streams, the
+// table → the attribute's sequencer).  Methods: dmi_prepare.cpp.
+struct AttStage {
+  struct Item { uint32_t member /* the mesh's ConnMeshDesc */, k /* index among its non-position attributes */, corner_off, vert_off, F; };
+  std::vector<Item> items;            // sorted by member
+  std::vector<AttItemDesc> descs;
+  size_t corners = 0, verts = 0;
+  uint32_t *d_c2v = nullptr, *d_opp = nullptr;
+  size_t rb_items = 0, rb_info = 0, rb_seam = 0, rb_c2v = 0, rb_opp = 0, rb_lmc = 0;   // offsets in the group's host staging
+  const uint8_t* hp = nullptr;        // that staging (set by issue)
+  void add(uint32_t member, uint32_t k, uint32_t F, uint32_t vcap, uint32_t map_off_words);
+  size_t layout(size_t at);           // places the read-back regions from offset `at` on; returns their end
+  size_t device_bytes() const;
+  int issue(const ConnArgs& a, TempDev& mem, uint8_t* host, hipStream_t s);   // after launch_conn_tables on s
+};
+
 // ---- device-built meshes (dmi_build.cpp → dmi_prepare.cpp) ----
 // The meshes one group of dmi_meshes_build produced, resident on `device`: arena A = the faces of all members as ONE array (member after
 // member: the layout the batched connectivity kernels index) followed by the point → value maps, arena B = the unique values.  A host copy
@@ -343,7 +364,7 @@ struct BuiltGroup {
   size_t a_bytes = 0, b_off = 0, b_bytes = 0;
   HostStage* stage = nullptr;
   uint8_t *h_a = nullptr, *h_b = nullptr;
-  struct Att { size_t val_off = 0, map_off = (size_t)-1; uint32_t n_unique = 0; };   // byte offsets from d_base (maps also from h_a)
+  struct Att { size_t val_off = 0, map_off = (size_t)-1; uint32_t n_unique = 0; uint8_t att_type = 0; };   // byte offsets from d_base (maps also from h_a)
   struct Member { uint32_t F = 0, P = 0, raw_faces = 0; size_t faces_off = 0 /* bytes into arena A */; std::vector<Att> atts /* in the built mesh's order */; };
   std::vector<Member> members;        // in arena order
   uint64_t total_faces = 0;           // Σ members' F
@@ -359,6 +380,7 @@ struct BuiltGroup {
     uint32_t n_desc = 0;
     uint64_t total_verts = 0;
     hipEvent_t ev = nullptr;
+    AttStage att;   // attribute corner tables of the members' attributes (k_att_*)
   } conn;
   BuiltGroup() = default;
   BuiltGroup(const BuiltGroup&) = delete;

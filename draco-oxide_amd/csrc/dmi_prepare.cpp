@@ -6,6 +6,8 @@ using namespace dmi;
 
 #include <sched.h>
 
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
 namespace {
 
 // The serial walks of the connectivity stage are bound by memory latency; on a two-socket host a thread that wanders to the other socket
@@ -83,6 +85,10 @@ struct PrebuiltTable {
   const uint8_t* on_boundary = nullptr;
   uint32_t V = 0;
   bool no_boundary = false;
+  // attribute corner tables the device built (k_att_*), by index among the mesh's non-position attributes; ready = false: the host builds it
+  struct Att { bool ready = false, interior = false; uint32_t nv = 0; const uint8_t* seam = nullptr; const uint32_t *c2v = nullptr, *opp = nullptr, *lmc = nullptr;
+               const uint32_t *d_c2v = nullptr, *d_opp = nullptr; };
+  std::vector<Att> att;
 };
 
 constexpr uint32_t kDeviceTablesMinFaces = 1u << 16;   // a single mesh from this size up gets its universal corner table from the device (dmi_conn.hip)
@@ -283,6 +289,18 @@ static int build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std::vector<ui
     for (uint32_t i = 0; i < mesh->num_atts; ++i) if (mesh->atts[i].att_type != DMI_ATT_POSITION) map_points.push_back(mesh->atts[i].num_points);
     auto build_one = [&](size_t k) {
       for (size_t j = 0; j < k; ++j) if (maps[j] == maps[k]) return;   // (copied below, once its original is complete)
+      if (pre && k < pre->att.size() && pre->att[k].ready) {   // built by the device (k_att_*) and read back: copied into the walks' arrays
+        const PrebuiltTable::Att& pa = pre->att[k];
+        AttTable& a = o.ct.att[k];
+        if (!pa.interior) { o.ct.build_attribute_into(a, nullptr, /*same_as_position=*/true); return; }   // (no seam but the boundary: flags from the universal table)
+        const size_t C = (size_t)o.ct.F * 3;
+        a.alias_of = -1; a.interior_seams = true; a.num_vertices = pa.nv;
+        pool_fit(a.seam_edge, C); a.seam_edge.assign(pa.seam, pa.seam + C);
+        pool_fit(a.c2v, C); a.c2v.assign(pa.c2v, pa.c2v + C);
+        pool_fit(a.opp, C); a.opp.assign(pa.opp, pa.opp + C);
+        pool_fit(a.lmc, pa.nv); a.lmc.assign(pa.lmc, pa.lmc + pa.nv);
+        return;
+      }
       o.ct.build_attribute_into(o.ct.att[k], maps[k], like_position(maps[k], map_points[k]));
     };
     if (maps.size() > 1 && overlap) {
@@ -404,6 +422,70 @@ int dmi_device_corner_table(const dmi_mesh* mesh, const dmi_config* cfg, uint32_
   std::memcpy(opposite, dt.pre.opp, (size_t)mesh->num_faces * 12);
   if (left_most_corner) std::memcpy(left_most_corner, dt.pre.lmc, (size_t)dt.V * 4);
   if (on_boundary) std::memcpy(on_boundary, dt.pre.on_boundary, dt.V);
+  return DMI_OK;
+}
+
+// One attribute corner table of ONE mesh built by the device kernels (k_att_* behind the universal table's kernels), read back — what the batch
+// prepare runs for every (mesh, attribute) whose map differs from the position map, exposed so that tests hold it against the host builder.
+int dmi_device_attribute_table(const dmi_mesh* mesh, const dmi_config* cfg, uint32_t att_index, uint8_t* seam_edge, uint32_t* corner_to_vertex, uint32_t* opposite,
+                               uint32_t* left_most_corner, uint32_t* num_vertices, uint32_t* interior_seams, uint32_t* flags) {
+  if (!mesh || !mesh->atts || att_index == 0 || att_index >= mesh->num_atts || !mesh->faces || !mesh->num_faces || !seam_edge || !corner_to_vertex || !opposite || !left_most_corner || !num_vertices || !interior_seams || !flags)
+    return fail(DMI_ERR_INVALID_ARGUMENT, "bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(DMI_ERR_NO_DEVICE, "no HIP device visible; libdraco_mi has no CPU fallback");
+  const int device = cfg ? cfg->device : 0;
+  HIP_TRY(hipSetDevice(device));
+  auto holder = thread_stream(device);
+  if (!holder) return fail(DMI_ERR_HIP, "hipStreamCreate");
+  hipStream_t s = holder->s;
+  const dmi_attribute& pos = mesh->atts[0];
+  const dmi_attribute& at = mesh->atts[att_index];
+  const uint32_t F = mesh->num_faces, Vcap = pos.num_unique, P = pos.num_points;
+  const size_t C = (size_t)F * 3, nv = (size_t)Vcap + 1, parts = scan_partials_words((uint32_t)nv);
+  if (at.num_points < P) return fail(DMI_ERR_INVALID_ARGUMENT, "attribute has fewer points than the Position attribute");
+  AttStage st;
+  const size_t map_pos_at = align256(C * 4), map_att_at = map_pos_at + (pos.point_to_value ? align256((size_t)P * 4) : 0), up = map_att_at + (at.point_to_value ? align256((size_t)at.num_points * 4) : 0);
+  st.add(0, 0, F, Vcap, at.point_to_value ? (uint32_t)(map_att_at / 4) : kNone);
+  const size_t rb_words = align256(up), host_need = st.layout(rb_words + 256 + align256(sizeof(ConnMeshDesc)));
+  TempDev mem;
+  mem.init(device, s, up + C * 4 * 4 + C + nv * 4 * 4 + nv + parts * 4 + st.device_bytes() + ((size_t)1 << 20));
+  struct StageGuard { HostStage* st = nullptr; ~StageGuard() { release_stage(st); } } stage;
+  stage.st = acquire_stage(device, host_need);
+  if (!stage.st) return fail(DMI_ERR_OUT_OF_MEMORY, "hipHostMalloc");
+  uint8_t* hp = stage.st->p;
+  uint8_t* d_up = mem.take<uint8_t>(up);
+  ConnArgs a{};
+  uint32_t* d_c2v = pos.point_to_value ? mem.take<uint32_t>(C) : reinterpret_cast<uint32_t*>(d_up);
+  a.opp = mem.take<uint32_t>(C); a.lmc = mem.take<uint32_t>(nv); a.on_boundary = mem.take<uint8_t>(nv);
+  uint32_t* d_words = mem.take<uint32_t>(2);
+  ConnMeshDesc* d_desc = mem.take<ConnMeshDesc>(1);
+  a.ecount = mem.take<uint32_t>(nv); a.efill = mem.take<uint32_t>(nv); a.first = mem.take<uint32_t>(nv);
+  a.he_key = mem.take<uint32_t>(C); a.he_corner = mem.take<uint32_t>(C); a.cdone = mem.take<uint8_t>(C); a.scan_partials = mem.take<uint32_t>(parts);
+  if (!d_up || !d_c2v || !a.opp || !a.lmc || !a.on_boundary || !d_words || !d_desc || !a.ecount || !a.efill || !a.first || !a.he_key || !a.he_corner || !a.cdone || !a.scan_partials) return fail(DMI_ERR_OUT_OF_MEMORY, "hipMalloc");
+  std::memcpy(hp, mesh->faces, C * 4);
+  if (pos.point_to_value) std::memcpy(hp + map_pos_at, pos.point_to_value, (size_t)P * 4);
+  if (at.point_to_value) std::memcpy(hp + map_att_at, at.point_to_value, (size_t)at.num_points * 4);
+  ConnMeshDesc* h_desc = reinterpret_cast<ConnMeshDesc*>(hp + rb_words + 256);
+  *h_desc = ConnMeshDesc{0u, 0u, F, Vcap, pos.point_to_value ? (uint32_t)(map_pos_at / 4) : kNone, P, 0u, 0u};
+  HIP_TRY(hipMemcpyAsync(d_up, hp, up, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d_desc, h_desc, sizeof(ConnMeshDesc), hipMemcpyHostToDevice, s));
+  a.meshes = d_desc; a.M = 1; a.total_faces = F; a.total_verts = Vcap;
+  a.faces = reinterpret_cast<const uint32_t*>(d_up); a.p2v = reinterpret_cast<const uint32_t*>(d_up); a.c2v = d_c2v; a.flags = d_words; a.vmax = d_words + 1;
+  HIP_TRY(conn_tables_clear(a, s));
+  launch_conn_tables(a, s);
+  HIP_TRY(hipMemcpyAsync(hp + rb_words, d_words, 8, hipMemcpyDeviceToHost, s));
+  int rc = st.issue(a, mem, hp, s);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(s));
+  *flags = reinterpret_cast<const uint32_t*>(hp + rb_words)[0];
+  const AttInfo info = *reinterpret_cast<const AttInfo*>(hp + st.rb_info);
+  *num_vertices = 0; *interior_seams = 0;
+  if (!info.done) return DMI_OK;   // flags say why: the host builder's case
+  *num_vertices = info.num_vertices; *interior_seams = info.interior;
+  std::memcpy(seam_edge, hp + st.rb_seam, C);
+  std::memcpy(corner_to_vertex, hp + st.rb_c2v, C * 4);
+  std::memcpy(opposite, hp + st.rb_opp, C * 4);
+  std::memcpy(left_most_corner, reinterpret_cast<const uint32_t*>(hp + st.rb_lmc) + info.pad, (size_t)info.num_vertices * 4);
   return DMI_OK;
 }
 
@@ -533,7 +615,6 @@ int dmi_shard_meshes(const dmi_mesh* meshes, uint32_t n, uint32_t n_devices, int
 // relabelling, the fan rows and the map compositions of all jobs in one launch per kernel.  Raw attribute values travel up beside the
 // host walks.  A mesh the order-free table construction does not cover (device flags), or one with an attribute table of its own
 // (interior seams), takes the per-mesh path (dmi_mesh_prepare) — same bytes either way (tests/test_gpu_batch_prepare.py).
-static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // Two more library streams per (host thread, device): consecutive groups of a slice alternate between them, so the read-back of one
 // group's tables overlaps the upload of the next group's faces (the two directions of the link run side by side).
@@ -564,6 +645,7 @@ struct PrepGroup {
   uint64_t total_faces = 0, total_verts = 0;
   uint32_t n_desc = 0;                 // connectivity descriptors of the group (= its meshes, or every member of an adopted built group)
   BuiltGroup* adopted = nullptr;       // the group is a device-built one (dmi_meshes_build): nothing to pack or upload
+  AttStage att;                        // attribute corner tables the device builds for the group's meshes (host-packed groups; an adopted group's are its build's)
   size_t up_a = 0, up_b = 0, C = 0;
   bool any_mapped = false;
   hipStream_t S = nullptr;
@@ -594,6 +676,62 @@ struct PrepGroup {
 };
 }  // namespace
 
+extern "C++" {
+void dmi::AttStage::add(uint32_t member, uint32_t k, uint32_t F, uint32_t vcap, uint32_t map_off_words) {
+  items.push_back({member, k, (uint32_t)corners, (uint32_t)verts, F});
+  descs.push_back(AttItemDesc{member, map_off_words, (uint32_t)corners, (uint32_t)verts});
+  corners += (size_t)F * 3; verts += vcap;
+}
+size_t dmi::AttStage::layout(size_t at) {
+  if (corners >= (1ull << 32) || verts >= (1ull << 32)) { items.clear(); descs.clear(); corners = verts = 0; }   // (too large for one launch: the host builds them)
+  rb_items = at; rb_info = rb_items + align256(items.size() * sizeof(AttItemDesc)); rb_seam = rb_info + align256(items.size() * sizeof(AttInfo));
+  rb_c2v = rb_seam + align256(corners); rb_opp = rb_c2v + align256(corners * 4); rb_lmc = rb_opp + align256(corners * 4);
+  return rb_lmc + align256(corners * 4);
+}
+size_t dmi::AttStage::device_bytes() const { return corners * 13 + (verts + 1) * 5 + items.size() * (sizeof(AttItemDesc) + sizeof(AttInfo)) + scan_partials_words((uint32_t)verts + 1) * 4 + 4096; }
+int dmi::AttStage::issue(const ConnArgs& a, TempDev& mem, uint8_t* host, hipStream_t s) {
+  hp = host;
+  if (items.empty()) return DMI_OK;
+  AttArgs t{};
+  t.n_items = (uint32_t)items.size(); t.total_corners = (uint32_t)corners; t.total_verts = (uint32_t)verts;
+  AttItemDesc* d_items = mem.take<AttItemDesc>(items.size());
+  t.seam = mem.take<uint8_t>(corners); t.vseam = mem.take<uint8_t>(verts); t.count = mem.take<uint32_t>(verts + 1);
+  t.c2v = mem.take<uint32_t>(corners); t.opp = mem.take<uint32_t>(corners); t.lmc = mem.take<uint32_t>(corners);
+  t.info = mem.take<AttInfo>(items.size()); t.scan_partials = mem.take<uint32_t>(scan_partials_words((uint32_t)verts + 1));
+  if (!d_items || !t.seam || !t.vseam || !t.count || !t.c2v || !t.opp || !t.lmc || !t.info || !t.scan_partials) return fail(DMI_ERR_OUT_OF_MEMORY, "hipMalloc (attribute corner tables)");
+  std::memcpy(host + rb_items, descs.data(), descs.size() * sizeof(AttItemDesc));
+  HIP_TRY(hipMemcpyAsync(d_items, host + rb_items, items.size() * sizeof(AttItemDesc), hipMemcpyHostToDevice, s));
+  t.items = d_items;
+  HIP_TRY(att_tables_clear(t, s));
+  launch_att_tables(a, t, s);
+  d_c2v = t.c2v; d_opp = t.opp;
+  HIP_TRY(hipMemcpyAsync(host + rb_info, t.info, items.size() * sizeof(AttInfo), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(host + rb_seam, t.seam, corners, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(host + rb_c2v, t.c2v, corners * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(host + rb_opp, t.opp, corners * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(host + rb_lmc, t.lmc, corners * 4, hipMemcpyDeviceToHost, s));
+  return DMI_OK;
+}
+}  // extern "C++"
+// the attribute tables the device built for one mesh of a group → pre.att (by index among the mesh's non-position attributes)
+static void att_stage_fill(const AttStage& st, uint32_t member, uint32_t n_nonpos, std::vector<PrebuiltTable::Att>& out) {
+  out.assign(n_nonpos, PrebuiltTable::Att{});
+  if (st.items.empty() || !st.hp) return;
+  const AttInfo* info = reinterpret_cast<const AttInfo*>(st.hp + st.rb_info);
+  auto lo = std::lower_bound(st.items.begin(), st.items.end(), member, [](const AttStage::Item& x, uint32_t mi) { return x.member < mi; });
+  for (auto it = lo; it != st.items.end() && it->member == member; ++it) {
+    const size_t q = (size_t)(it - st.items.begin());
+    if (!info[q].done || it->k >= n_nonpos) continue;
+    PrebuiltTable::Att& pa = out[it->k];
+    pa.ready = true; pa.interior = info[q].interior != 0; pa.nv = info[q].num_vertices;
+    pa.seam = st.hp + st.rb_seam + it->corner_off;
+    pa.c2v = reinterpret_cast<const uint32_t*>(st.hp + st.rb_c2v) + it->corner_off;
+    pa.opp = reinterpret_cast<const uint32_t*>(st.hp + st.rb_opp) + it->corner_off;
+    pa.lmc = reinterpret_cast<const uint32_t*>(st.hp + st.rb_lmc) + info[q].pad;
+    pa.d_c2v = st.d_c2v + it->corner_off; pa.d_opp = st.d_opp + it->corner_off;
+  }
+}
+
 // The universal corner tables of every member of a device-built group: descriptors up, the dmi_conn.hip kernels, the tables back into the
 // group's own staging.  Nothing here waits; bg.conn.ev fires when the read-back has arrived.
 extern "C++" int dmi::built_group_issue_tables(BuiltGroup& bg, hipStream_t s) {
@@ -607,7 +745,9 @@ extern "C++" int dmi::built_group_issue_tables(BuiltGroup& bg, hipStream_t s) {
   if (verts >= (1ull << 31) || bg.total_faces >= (1ull << 30)) return fail(DMI_ERR_INVALID_ARGUMENT, "built group too large");
   cn.total_verts = verts; cn.n_desc = ND;
   const size_t C = (size_t)bg.total_faces * 3, nv = (size_t)verts + 1, parts = scan_partials_words((uint32_t)nv);
-  cn.mem.init(bg.device, s, C * 4 * (cn.any_mapped ? 4 : 3) + C + nv * 4 * 4 + nv + parts * 4 + (size_t)ND * (sizeof(ConnMeshDesc) + 8) + ((size_t)1 << 20));
+  size_t att_bytes = 0;   // (upper bound of the attribute-table arrays: every non-position attribute a candidate)
+  for (const auto& mem : bg.members) if (mem.atts.size() > 1) att_bytes += (mem.atts.size() - 1) * ((size_t)mem.F * 3 * 13 + (size_t)(mem.atts[0].n_unique + 1) * 5 + 512);
+  cn.mem.init(bg.device, s, C * 4 * (cn.any_mapped ? 4 : 3) + C + nv * 4 * 4 + nv + parts * 4 + (size_t)ND * (sizeof(ConnMeshDesc) + 8) + att_bytes + ((size_t)2 << 20));
   const uint32_t* d_faces = reinterpret_cast<const uint32_t*>(bg.d_base);
   cn.d_c2v = cn.any_mapped ? cn.mem.take<uint32_t>(C) : const_cast<uint32_t*>(d_faces);
   cn.d_opp = cn.mem.take<uint32_t>(C);
@@ -624,7 +764,24 @@ extern "C++" int dmi::built_group_issue_tables(BuiltGroup& bg, hipStream_t s) {
     return fail(DMI_ERR_OUT_OF_MEMORY, "hipMalloc (batch connectivity stage)");
   cn.rb_opp = 0; cn.rb_c2v = cn.rb_opp + align256(C * 4); cn.rb_lmc = cn.rb_c2v + (cn.any_mapped ? align256(C * 4) : 0); cn.rb_onb = cn.rb_lmc + align256(nv * 4);
   cn.rb_words = cn.rb_onb + align256(nv);
-  const size_t rb_desc = cn.rb_words + align256((size_t)ND * 8), host_need = rb_desc + align256((size_t)ND * sizeof(ConnMeshDesc));
+  // candidates for an attribute table of their own: non-position attributes whose map is not the position map entry for entry
+  AttStage& st = cn.att;
+  st = AttStage{};
+  static const bool host_att = std::getenv("DMI_HOST_ATT_TABLES") != nullptr;
+  for (uint32_t mi = 0; mi < ND && !host_att; ++mi) {
+    const BuiltGroup::Member& mem = bg.members[mi];
+    if (mem.atts.empty() || !mem.F) continue;
+    uint32_t k = 0;
+    for (size_t a = 0; a < mem.atts.size(); ++a) {
+      if (mem.atts[a].att_type == DMI_ATT_POSITION) continue;
+      const size_t ma = mem.atts[a].map_off, mp = mem.atts[0].map_off;
+      const bool same = (ma == (size_t)-1 && mp == (size_t)-1) || (ma != (size_t)-1 && mp != (size_t)-1 && std::memcmp(bg.h_a + ma, bg.h_a + mp, (size_t)mem.P * 4) == 0);
+      if (!same) st.add(mi, k, mem.F, mem.atts[0].n_unique, ma == (size_t)-1 ? kNone : (uint32_t)(ma / 4));
+      ++k;
+    }
+  }
+  const size_t rb_desc = cn.rb_words + align256((size_t)ND * 8);
+  const size_t host_need = st.layout(rb_desc + align256((size_t)ND * sizeof(ConnMeshDesc)));
   cn.stage = acquire_stage(bg.device, host_need);
   if (!cn.stage) return fail(DMI_ERR_OUT_OF_MEMORY, "hipHostMalloc (batch connectivity staging)");
   uint8_t* hp = cn.hp = cn.stage->p;
@@ -640,6 +797,7 @@ extern "C++" int dmi::built_group_issue_tables(BuiltGroup& bg, hipStream_t s) {
   HIP_TRY(hipMemcpyAsync(d_desc, h_desc, (size_t)ND * sizeof(ConnMeshDesc), hipMemcpyHostToDevice, s));
   a.meshes = d_desc; a.M = ND; a.total_faces = (uint32_t)bg.total_faces; a.total_verts = (uint32_t)verts;
   a.faces = d_faces; a.p2v = reinterpret_cast<const uint32_t*>(bg.d_base); a.c2v = cn.d_c2v; a.opp = cn.d_opp; a.lmc = d_lmc; a.on_boundary = d_onb; a.flags = d_words; a.vmax = d_words + ND;
+  int rc_att = DMI_OK;
   HIP_TRY(conn_tables_clear(a, s));
   launch_conn_tables(a, s);
   HIP_TRY(hipMemcpyAsync(hp + cn.rb_words, d_words, (size_t)ND * 8, hipMemcpyDeviceToHost, s));
@@ -647,6 +805,7 @@ extern "C++" int dmi::built_group_issue_tables(BuiltGroup& bg, hipStream_t s) {
   if (cn.any_mapped && C) HIP_TRY(hipMemcpyAsync(hp + cn.rb_c2v, cn.d_c2v, C * 4, hipMemcpyDeviceToHost, s));
   if (verts) HIP_TRY(hipMemcpyAsync(hp + cn.rb_lmc, d_lmc, (size_t)verts * 4, hipMemcpyDeviceToHost, s));
   if (verts) HIP_TRY(hipMemcpyAsync(hp + cn.rb_onb, d_onb, (size_t)verts, hipMemcpyDeviceToHost, s));
+  if ((rc_att = st.issue(a, cn.mem, hp, s))) return rc_att;
   HIP_TRY(hipEventCreateWithFlags(&cn.ev, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(cn.ev, s));
   cn.mem.pool.stream = nullptr;   // (the stream is a thread's library stream and the group may outlive the thread: its destructor waits for cn.ev instead)
@@ -779,12 +938,25 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
       for (uint32_t k = 0; k < Mg; ++k) { g.lay[k].faces = at; at += (size_t)meshes[g.which[k]].num_faces * 12; }
       g.up_a = align256(at);
       for (uint32_t k = 0; k < Mg; ++k) if (g.lay[k].mapped) { g.lay[k].pos_map = g.up_a; g.up_a = align256(g.up_a + (size_t)meshes[g.which[k]].atts[0].num_points * 4); }
+      // the other attributes' maps ride in part A too (the attribute-table kernels read them right behind the universal tables)
+      for (uint32_t k = 0; k < Mg; ++k) {
+        const dmi_mesh& m = meshes[g.which[k]];
+        g.lay[k].maps.assign(m.num_atts, (size_t)-1);
+        for (uint32_t i = 1; i < m.num_atts; ++i) {
+          const dmi_attribute& a = m.atts[i];
+          if (!a.point_to_value) continue;
+          bool shared = a.point_to_value == m.atts[0].point_to_value;
+          if (shared) g.lay[k].maps[i] = g.lay[k].pos_map;
+          for (uint32_t j = 1; j < i && !shared; ++j) if (m.atts[j].point_to_value == a.point_to_value) { g.lay[k].maps[i] = g.lay[k].maps[j]; shared = true; }
+          if (!shared) { g.lay[k].maps[i] = g.up_a; g.up_a = align256(g.up_a + (size_t)a.num_points * 4); }
+        }
+      }
     }
     bool want_lmc = false;   // left-most corners are only read by the host builder of attribute tables (an attribute indexed unlike the Position attribute)
     for (uint32_t k = 0; k < Mg; ++k) {
       const dmi_mesh& m = meshes[g.which[k]];
       PrepGroup::MeshLay& l = g.lay[k];
-      l.values.assign(m.num_atts, (size_t)-1); l.maps.assign(m.num_atts, (size_t)-1);
+      l.values.assign(m.num_atts, (size_t)-1);
       for (uint32_t i = 0; i < m.num_atts; ++i) {
         const dmi_attribute& a = m.atts[i];
         const size_t vb = (size_t)a.num_unique * a.num_components * 4;
@@ -792,17 +964,34 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
         if (a.att_type != DMI_ATT_POSITION && a.point_to_value != m.atts[0].point_to_value) want_lmc = true;
         if (a.point_to_value) {
           if (i == 0) l.maps[i] = l.pos_map;
-          else {
-            bool shared = false;
-            for (uint32_t j = 0; j < i && !shared; ++j) if (m.atts[j].point_to_value == a.point_to_value) { l.maps[i] = l.maps[j]; shared = true; }
-            if (!shared) { l.maps[i] = g.up_a + g.up_b; g.up_b = align256(g.up_b + (size_t)a.num_points * 4); }
-          }
+          else for (uint32_t j = 0; j < i; ++j) if (m.atts[j].point_to_value == a.point_to_value) { l.maps[i] = l.maps[j]; break; }   // (placed in part A above)
+        }
+      }
+    }
+    // attribute corner tables on the device for the attributes whose maps are not the position map entry for entry
+    {
+      static const bool host_att = std::getenv("DMI_HOST_ATT_TABLES") != nullptr;
+      for (uint32_t k = 0; k < Mg && !host_att; ++k) {
+        const dmi_mesh& m = meshes[g.which[k]];
+        if (!m.num_faces) continue;
+        uint32_t idx = 0;
+        for (uint32_t i = 0; i < m.num_atts; ++i) {
+          const dmi_attribute& a = m.atts[i];
+          if (a.att_type == DMI_ATT_POSITION) continue;
+          const uint32_t* pm = m.atts[0].point_to_value;
+          const bool same = a.point_to_value == pm || (a.point_to_value && pm && a.num_points == m.atts[0].num_points && std::memcmp(a.point_to_value, pm, (size_t)a.num_points * 4) == 0);
+          bool earlier = false;   // (an attribute with the map array of an earlier one copies that one's table on the host)
+          for (uint32_t j = 1; j < i && !earlier; ++j) earlier = m.atts[j].att_type != DMI_ATT_POSITION && m.atts[j].point_to_value == a.point_to_value && a.point_to_value;
+          if (!same && !earlier) g.att.add(k, idx, m.num_faces, g.lay[k].Vcap, a.point_to_value ? (uint32_t)(g.lay[k].maps[i] / 4) : kNone);
+          ++idx;
         }
       }
     }
     const size_t up_bytes = g.up_a + g.up_b, C = g.C;
     const size_t nv = (size_t)g.total_verts + 1, parts = scan_partials_words((uint32_t)nv);
-    g.mem.init(device, g.S, up_bytes + C * 4 * (g.any_mapped ? 4 : 3) + C + nv * 4 * 4 + nv + parts * 4 + (size_t)Mg * (sizeof(ConnMeshDesc) + 8) + ((size_t)1 << 20));
+    const size_t rb_desc0 = align256(up_bytes) + align256(C * 4) + (g.any_mapped ? align256(C * 4) : 0) + align256(nv * 4) + align256(nv) + align256((size_t)Mg * 8);
+    const size_t host_need = g.att.layout(rb_desc0 + align256((size_t)Mg * sizeof(ConnMeshDesc)));   // (may drop the items: before the device memory is sized)
+    g.mem.init(device, g.S, up_bytes + C * 4 * (g.any_mapped ? 4 : 3) + C + nv * 4 * 4 + nv + parts * 4 + (size_t)Mg * (sizeof(ConnMeshDesc) + 8) + g.att.device_bytes() + ((size_t)1 << 20));
     g.d_up = g.mem.take<uint8_t>(up_bytes);
     g.d_faces = reinterpret_cast<const uint32_t*>(g.d_up);
     g.d_c2v = g.any_mapped ? g.mem.take<uint32_t>(C) : const_cast<uint32_t*>(g.d_faces);
@@ -821,7 +1010,8 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     // host: staging of the upload | read-back: opp, [c2v], lmc, on_boundary, flags/vmax | descriptors
     g.rb_opp = align256(up_bytes); g.rb_c2v = g.rb_opp + align256(C * 4); g.rb_lmc = g.rb_c2v + (g.any_mapped ? align256(C * 4) : 0); g.rb_onb = g.rb_lmc + align256(nv * 4);
     g.rb_words = g.rb_onb + align256(nv);
-    const size_t rb_desc = g.rb_words + align256((size_t)Mg * 8), host_need = rb_desc + align256((size_t)Mg * sizeof(ConnMeshDesc));
+    const size_t rb_desc = g.rb_words + align256((size_t)Mg * 8);
+    if (rb_desc != rb_desc0) return fail(DMI_ERR_HIP, "batch connectivity staging layout");
     g.stage = acquire_stage(device, host_need);
     if (!g.stage) return fail(DMI_ERR_OUT_OF_MEMORY, "hipHostMalloc (batch connectivity staging)");
     uint8_t* hp = g.hp = g.stage->p;
@@ -835,6 +1025,13 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
           const dmi_mesh& m = meshes[g.which[k]];
           std::memcpy(hp + g.lay[k].faces, m.faces, (size_t)m.num_faces * 12);
           if (g.lay[k].mapped) std::memcpy(hp + g.lay[k].pos_map, m.atts[0].point_to_value, (size_t)m.atts[0].num_points * 4);
+          for (uint32_t i = 1; i < m.num_atts; ++i) {
+            const dmi_attribute& at = m.atts[i];
+            if (!at.point_to_value || at.point_to_value == m.atts[0].point_to_value) continue;
+            bool first = true;
+            for (uint32_t j = 1; j < i; ++j) if (m.atts[j].point_to_value == at.point_to_value) first = false;
+            if (first) std::memcpy(hp + g.lay[k].maps[i], at.point_to_value, (size_t)at.num_points * 4);
+          }
           return DMI_OK;
         }, faces_of))) return rc;
     HIP_TRY(hipMemcpyAsync(g.d_up, hp, g.up_a, hipMemcpyHostToDevice, g.S));
@@ -848,20 +1045,17 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     if (g.any_mapped) HIP_TRY(hipMemcpyAsync(hp + g.rb_c2v, g.d_c2v, C * 4, hipMemcpyDeviceToHost, g.S));
     if (want_lmc) HIP_TRY(hipMemcpyAsync(hp + g.rb_lmc, d_lmc, (size_t)g.total_verts * 4, hipMemcpyDeviceToHost, g.S));
     HIP_TRY(hipMemcpyAsync(hp + g.rb_onb, d_onb, (size_t)g.total_verts, hipMemcpyDeviceToHost, g.S));
+    if (!g.att.items.empty()) { want_lmc = true; HIP_TRY(hipMemcpyAsync(hp + g.rb_lmc, d_lmc, (size_t)g.total_verts * 4, hipMemcpyDeviceToHost, g.S)); }
+    if ((rc = g.att.issue(a, g.mem, hp, g.S))) return rc;
     HIP_TRY(hipEventCreateWithFlags(&g.ev_tables, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(g.ev_tables, g.S));
-    // part B: values and attribute maps, packed while the device builds the tables and sent behind their read-back
+    // part B: the values, packed while the device builds the tables and sent behind their read-back
     if ((rc = parallel_over(Mg, [&](uint32_t, uint32_t k) -> int {
           const dmi_mesh& m = meshes[g.which[k]];
           for (uint32_t i = 0; i < m.num_atts; ++i) {
             const dmi_attribute& at = m.atts[i];
             const size_t vb = (size_t)at.num_unique * at.num_components * 4;
             if (vb) std::memcpy(hp + g.lay[k].values[i], at.values, vb);
-            if (at.point_to_value && i > 0 && g.lay[k].maps[i] >= g.up_a) {
-              bool first = true;
-              for (uint32_t j = 0; j < i; ++j) if (m.atts[j].point_to_value == at.point_to_value) first = false;
-              if (first) std::memcpy(hp + g.lay[k].maps[i], at.point_to_value, (size_t)at.num_points * 4);
-            }
           }
           return DMI_OK;
         }, faces_of))) return rc;
@@ -907,6 +1101,11 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     pre.on_boundary = hp + g.rb_onb + g.lay[k].vert_off;
     pre.V = h_words[g.n_desc + g.lay[k].desc_index] + 1;
     pre.no_boundary = !(flags & CONN_HAS_BOUNDARY);
+    {   // attribute tables the device built for this mesh (k_att_*)
+      uint32_t n_nonpos = 0;
+      for (uint32_t a = 0; a < m.num_atts; ++a) n_nonpos += m.atts[a].att_type != DMI_ATT_POSITION;
+      att_stage_fill(g.adopted ? g.adopted->conn.att : g.att, g.lay[k].desc_index, n_nonpos, pre.att);
+    }
     owners[kk].reset(new ConnOwner());
     ConnOwner& o = *owners[kk];
     std::vector<uint8_t> bytes;
@@ -929,7 +1128,12 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
         if (g.lay[k].values[a] != (size_t)-1) d.values_dev[a] = g.d_up + g.lay[k].values[a];
         if (g.lay[k].maps[a] != (size_t)-1) d.maps_dev[a] = reinterpret_cast<const uint32_t*>(g.d_up + g.lay[k].maps[a]);
       }
-      const DeviceTableView view{g.d_faces + cb, g.d_c2v + cb, g.d_opp + cb, true};
+      DeviceTableView view{g.d_faces + cb, g.d_c2v + cb, g.d_opp + cb, true};
+      // attribute tables the device built stay where they are: the batched relabelling reads them (key = the host copy the walks used)
+      std::vector<const uint32_t*> att_key, att_c2v, att_opp;
+      for (size_t q = 0; q < pre.att.size() && q < o.ct.att.size(); ++q)
+        if (pre.att[q].ready && pre.att[q].interior && !o.ct.att[q].c2v.empty()) { att_key.push_back(o.ct.att[q].c2v.data()); att_c2v.push_back(pre.att[q].d_c2v); att_opp.push_back(pre.att[q].d_opp); }
+      view.n_att = (uint32_t)att_key.size(); view.att_key = att_key.data(); view.att_c2v = att_c2v.data(); view.att_opp = att_opp.data();
       r = job_create_impl(m.atts, o.views.data(), m.num_atts, nullptr, 0, &c, &view, &jobs[j], &d);
       deferred[kk] = r == DMI_OK;
     } else if (g.adopted) {   // an attribute table of its own, values resident in the built group: the universal table from the device, the seam tables from the host

@@ -526,29 +526,34 @@ struct Walker {
         prefetch_neighbours(fvis.data() + f); prefetch_neighbours(vvis.data() + v);
         fvis[f] |= 1;
         processed.push_back(c);
+        const uint32_t gate = t.opp[c] != kNone ? 0x10u : 0u;   // (the face this one was entered from — or a start face — is always visited)
         const uint8_t vflags = vvis[v];
         if (!(vflags & 1)) {
           vvis[v] = vflags | 1;
-          if (!(vflags & 2)) { symbols.push_back(SYM_C); c = right_of(c); continue; }
+          // (a C face: its tip was unvisited, so neither the right nor the left face — both hold the tip — has been processed)
+          if (!(vflags & 2)) { symbols.push_back((uint8_t)(SYM_C | gate)); c = right_of(c); continue; }
         }
         const uint32_t rc = right_of(c), lc = left_of(c);
         const bool rv = rc == kNone || (fvis[rc / 3] & 1), lv = lc == kNone || (fvis[lc / 3] & 1);
+        // bits 4–6 of a symbol: which of the edges opposite (c, next, prev) lead to a face processed EARLIER (or to a start face) — what the seam
+        // streams emit for this face (edgebreaker.rs:611-636 walks the faces last to first and emits the edges whose other face is not visited yet)
+        const uint8_t nb = (uint8_t)(gate | ((rc != kNone && rv) ? 0x20u : 0u) | ((lc != kNone && lv) ? 0x40u : 0u));
         if (rv) {
           if (rc != kNone) note_split(symbol_idx, 1, rc / 3);
           if (lv) {
             if (lc != kNone) note_split(symbol_idx, 0, lc / 3);
-            symbols.push_back(SYM_E);
+            symbols.push_back((uint8_t)(SYM_E | nb));
             stack.pop_back();
             break;
           }
-          symbols.push_back(SYM_R);
+          symbols.push_back((uint8_t)(SYM_R | nb));
           c = lc;
         } else if (lv) {
           if (lc != kNone) note_split(symbol_idx, 0, lc / 3);
-          symbols.push_back(SYM_L);
+          symbols.push_back((uint8_t)(SYM_L | nb));
           c = rc;
         } else {
-          symbols.push_back(SYM_S);
+          symbols.push_back((uint8_t)(SYM_S | nb));
           ++num_split_symbols;
           if ((vflags & 2) && !hole_done[hole_of[v]]) mark_boundary(c, false);
           split_symbol_of_face[f] = symbol_idx;
@@ -665,7 +670,7 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
     std::vector<uint8_t>& bits = bits_p.v;
     bits.reserve(w.symbols.size() / 2 + 8);
     BitPackerLsb bp(bits);
-    for (size_t i = w.symbols.size(); i-- > 0;) bp.put(len[w.symbols[i]], code[w.symbols[i]]);
+    for (size_t i = w.symbols.size(); i-- > 0;) bp.put(len[w.symbols[i] & 7], code[w.symbols[i] & 7]);
     bp.flush();
     s.leb128(bits.size());
     s.bytes(bits);
@@ -707,10 +712,15 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
     }
     uint64_t total = 0;                  // edges emitted (the length of every stream)
     const bool sliced = n >= (1u << 20) && A;          // (a small mesh — one of a batch, on its own thread — walks the loop as it stands)
+    // every face is an interior start face or processed at least once: with exactly F of them no face was processed twice, and the masks the
+    // traversal left in its symbols (bits 4–6: the edges towards faces processed earlier) are the edges the reference's walk from the back emits
+    uint64_t interior_starts = 0;
+    for (uint8_t b : w.start_interior) interior_starts += b;
+    const bool masks_ok = n + interior_starts == t.F && w.symbols.size() == n && !std::getenv("DMI_NO_SEAM_MASKS");
     Pooled<uint32_t> where_p;                          // position of a face in `processed`
     std::vector<uint32_t>& where = where_p.v;
     std::atomic<int> twice{0};
-    if (sliced) {
+    if (sliced && !masks_ok) {
       pool_fit(where, t.F);
       where.assign(t.F, kNone);
       parallel_for(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) where[processed[i] / 3] = (uint32_t)i; });
@@ -731,6 +741,7 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
     } else if (sliced && !twice.load()) {
       // corners of face i whose flag is emitted, as a mask over (c, next, prev)
       auto mask_of = [&](size_t i) -> uint32_t {
+        if (masks_ok) return (uint32_t)(w.symbols[i] >> 4);
         const uint32_t c = processed[i];
         const uint32_t cs[3] = {c, corner_next(c), corner_prev(c)};
         uint32_t m = 0;
@@ -791,20 +802,35 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
     } else if (A) {   // small meshes with seams, and a face processed twice (malformed tables): the reference's loop as it stands
       // (the flags are written from the back of arrays sized for every corner — the coder is fed in the reverse of the order of emission — and
       //  moved to the front at the end: no growing vectors, no reversing copy)
-      std::vector<uint8_t> fv(t.F, 0);
       const size_t cap = 3 * n;
       for (size_t j : own) { pool_fit(fed[j], cap); fed[j].resize(cap); }
       size_t at = cap;
-      for (size_t i = n; i-- > 0;) {
-        const uint32_t c = processed[i];
-        const uint32_t cs[3] = {c, corner_next(c), corner_prev(c)};
-        fv[c / 3] = 1;
-        for (uint32_t cc : cs) {
-          const uint32_t o = t.opp[cc];
-          if (o == kNone || fv[o / 3]) continue;
-          ++total;
-          --at;
-          for (size_t j : own) { const uint8_t f = t.att[j].seam_edge[cc]; fed[j][at] = f; zeros[j] += !f; }
+      if (masks_ok) {   // no table look-ups: the traversal recorded which edges every face emits
+        for (size_t i = n; i-- > 0;) {
+          const uint32_t m = w.symbols[i] >> 4;
+          if (!m) continue;
+          const uint32_t c = processed[i];
+          const uint32_t cs[3] = {c, corner_next(c), corner_prev(c)};
+          for (int k = 0; k < 3; ++k) {
+            if (!(m >> k & 1u)) continue;
+            ++total;
+            --at;
+            for (size_t j : own) { const uint8_t f = t.att[j].seam_edge[cs[k]]; fed[j][at] = f; zeros[j] += !f; }
+          }
+        }
+      } else {
+        std::vector<uint8_t> fv(t.F, 0);
+        for (size_t i = n; i-- > 0;) {
+          const uint32_t c = processed[i];
+          const uint32_t cs[3] = {c, corner_next(c), corner_prev(c)};
+          fv[c / 3] = 1;
+          for (uint32_t cc : cs) {
+            const uint32_t o = t.opp[cc];
+            if (o == kNone || fv[o / 3]) continue;
+            ++total;
+            --at;
+            for (size_t j : own) { const uint8_t f = t.att[j].seam_edge[cc]; fed[j][at] = f; zeros[j] += !f; }
+          }
         }
       }
       for (size_t j : own) { std::memmove(fed[j].data(), fed[j].data() + at, (size_t)total); fed[j].resize((size_t)total); }

@@ -211,6 +211,15 @@ void dmi_conn_free(dmi_conn* conn);
 int dmi_device_corner_table(const dmi_mesh* mesh, const dmi_config* cfg, uint32_t* opposite, uint32_t* left_most_corner, uint8_t* on_boundary,
                             uint32_t* num_vertices, uint32_t* flags);
 
+/* One attribute corner table (core/corner_table/attribute_corner_table.rs:16-137) of ONE mesh built by the device kernels, read back: seam
+ * flags per corner (1 = the edge opposite the corner is a seam of attribute att_index or a boundary), attribute vertex per corner, opposite corner
+ * (DMI_NONE across seams), left-most corner per attribute vertex (room for 3·num_faces entries).  dmi_meshes_prepare / dmi_built_meshes_prepare
+ * run the same kernels for every (mesh, attribute) whose point → value map is not the position map entry for entry — batched, and the tables
+ * stay on the device for the coding-order relabelling.  *num_vertices == 0 with *flags != 0: the universal table's kernels flagged the mesh
+ * (dmi_device_corner_table) and the host builds its tables. */
+int dmi_device_attribute_table(const dmi_mesh* mesh, const dmi_config* cfg, uint32_t att_index, uint8_t* seam_edge, uint32_t* corner_to_vertex, uint32_t* opposite,
+                               uint32_t* left_most_corner, uint32_t* num_vertices, uint32_t* interior_seams, uint32_t* flags);
+
 /* --- MeshBuilder::build (core/mesh/builder.rs:62-90) + Attribute::from's value dedup (core/attribute/mod.rs:394-452) ----
  * Host only.  Attributes in add order (AttributeId = index, builder.rs:31-39), one row per point; the result is the `Mesh` the
  * reference hands to encode::encode: unique values in first-occurrence order with point_to_value maps, Position swapped to

@@ -106,3 +106,89 @@ def test_large_soup_falls_back_to_the_reference_walks():
     except orc.OracleError:
         pytest.skip("reference rejects this soup")
     _assert_same(dmi.encode_mesh(mesh), want, "random soup (non-manifold): host walks behind the device flags")
+
+
+# ---- attribute corner tables on the device (k_att_*: attribute_corner_table.rs:16-137) ----
+def _compare_attribute_table(mesh, att_index, what):
+    """Device-built attribute table against the host builder's (itself pinned to the oracle and the reference's KATs)."""
+    conn = dmi.encode_connectivity(mesh)
+    uni, want = conn.table(0), conn.table(att_index)
+    conn.close()
+    got = dmi.device_attribute_table(mesh, att_index)
+    assert got["num_vertices"] > 0, (what, got["flags"])
+    own_table = not (np.array_equal(want["corner_to_vertex"], uni["corner_to_vertex"]) and np.array_equal(want["opposite"], uni["opposite"]))
+    assert got["interior_seams"] == own_table, what
+    if not own_table:   # no seam but the boundary: flags = the universal table's boundary corners, one attribute vertex per vertex
+        assert np.array_equal(got["seam_edge"].astype(bool), uni["opposite"] == 0xFFFFFFFF), what
+        assert got["num_vertices"] == uni["num_vertices"] and np.array_equal(got["corner_to_vertex"], uni["corner_to_vertex"]), what
+        return got
+    assert got["num_vertices"] == want["num_vertices"], what
+    assert np.array_equal(got["corner_to_vertex"], want["corner_to_vertex"]), what
+    assert np.array_equal(got["opposite"], want["opposite"]), what
+    assert np.array_equal(got["left_most_corner"], want["left_most_corner"]), what
+    assert np.array_equal(got["seam_edge"].astype(bool), want["opposite"] == 0xFFFFFFFF), what
+    return got
+
+
+def test_device_attribute_table_tetrahedron_kat():
+    # core/corner_table/attribute_corner_table.rs:244-291 test_att_seam: the UV table of tetrahedron.obj
+    mesh = product_mesh_from_oracle(obj_session("tetrahedron"))
+    uv = [i for i, a in enumerate(mesh.attributes) if a.att_type == dmi.ATT_TEXCOORD][0]
+    got = _compare_attribute_table(mesh, uv, "tetrahedron uv")
+    assert all(got["seam_edge"][c] for c in [3, 5, 6, 7, 9, 11])
+    assert got["left_most_corner"].tolist() == [6, 5, 11, 10, 8, 4] and got["corner_to_vertex"][0] == 0
+
+
+@pytest.mark.parametrize("name", ["sphere", "torus", "punctured_sphere", "cube_quads"])
+def test_device_attribute_tables_on_fixtures(name):
+    mesh = product_mesh_from_oracle(obj_session(name))
+    for i in range(1, len(mesh.attributes)):
+        _compare_attribute_table(mesh, i, f"{name} attribute {i}")
+
+
+@pytest.mark.parametrize("n", [7, 40, 129])
+def test_device_attribute_tables_on_exporter_style_seams(n):
+    faces, pos, nrm, uv = synth.seam_torus_rows(n, seed=77 + n)
+    b = dmi.MeshBuilder()
+    b.add_attribute(pos, dmi.ATT_POSITION)
+    b.add_attribute(nrm, dmi.ATT_NORMAL, dmi.DOMAIN_CORNER, parents=[0])
+    b.add_attribute(uv, dmi.ATT_TEXCOORD, dmi.DOMAIN_CORNER, parents=[0])
+    b.set_connectivity_attribute(faces)
+    mesh = b.build()
+    assert not _compare_attribute_table(mesh, 1, "normals repeat with the positions")["interior_seams"]
+    assert _compare_attribute_table(mesh, 2, "uv seam along both closing curves")["interior_seams"]
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_device_attribute_tables_on_seam_soups(seed):
+    """Random soups with per-corner UVs (seams nearly everywhere); meshes the universal kernels flag report no table (the host builds it)."""
+    mesh, _ = _soup_mesh(seed, uv_per_corner=True)
+    uni = dmi.device_corner_table(mesh)
+    for i in range(1, len(mesh.attributes)):
+        if uni["num_vertices"] == 0:
+            got = dmi.device_attribute_table(mesh, i)
+            assert got["num_vertices"] == 0 and got["flags"] != 0
+        else:
+            _compare_attribute_table(mesh, i, f"soup {seed} attribute {i}")
+
+
+def test_seam_meshes_same_bytes_with_device_and_host_attribute_tables(monkeypatch):
+    faces, pos, nrm, uv = synth.seam_torus_rows(60, seed=5)
+    b = dmi.MeshBuilder()
+    b.add_attribute(pos, dmi.ATT_POSITION)
+    b.add_attribute(nrm, dmi.ATT_NORMAL, dmi.DOMAIN_CORNER, parents=[0])
+    b.add_attribute(uv, dmi.ATT_TEXCOORD, dmi.DOMAIN_CORNER, parents=[0])
+    b.set_connectivity_attribute(faces)
+    mesh = b.build()
+    want = oracle_from_product_mesh(mesh).encode()
+
+    def batch():
+        jobs = dmi.meshes_prepare([mesh, mesh])
+        try:
+            return [j.header_and_connectivity + s for j, s in zip(jobs, dmi.jobs_encode(jobs))]
+        finally:
+            for j in jobs:
+                j.close()
+    assert batch() == [want, want]
+    monkeypatch.setenv("DMI_NO_SEAM_MASKS", "1")          # the seam streams by the reference's walk from the back instead of the traversal's masks
+    assert batch() == [want, want]
