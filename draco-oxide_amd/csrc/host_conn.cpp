@@ -323,16 +323,19 @@ void CornerTables::copy_attribute_into(AttTable& a, const AttTable& from) const 
 
 void CornerTables::build_attribute_into(AttTable& a, const uint32_t* p2v, bool same_as_position) const {
   const uint32_t C = 3 * F;
-  pool_fit(a.seam_edge, C);
-  a.seam_edge.assign(C, 0);
   a.interior_seams = false;
   a.alias_of = -1;
   pool_give(a.c2v); pool_give(a.opp); pool_give(a.lmc);
   a.num_vertices = V;
-  if (same_as_position) {   // the universal vertices ARE this attribute's values: only the boundary edges are seams
-    parallel_for(C, [&](size_t lo, size_t hi) { for (size_t c = lo; c < hi; ++c) a.seam_edge[c] = opp[c] == kNone ? 1 : 0; });
+  if (same_as_position) {
+    // the universal vertices ARE this attribute's values: only the boundary edges are seams.  Nobody reads the flags of such an attribute (its
+    // seam stream is all zeros — coded by its period — and its table is the universal one): they are not materialised (6 bytes of writes per
+    // face and attribute pair in a batch of seam-free meshes)
+    pool_give(a.seam_edge);
     return;
   }
+  pool_fit(a.seam_edge, C);
+  a.seam_edge.assign(C, 0);
   Pooled<uint8_t> vseam_p(V, (uint8_t)0);
   std::vector<uint8_t>& vseam = vseam_p.v;
   std::atomic<int> interior{0};
@@ -792,6 +795,8 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
         for (size_t j = 0; j < A; ++j) zacc[j].fetch_add(z[j]);
       });
       for (size_t j = 0; j < A; ++j) zeros[j] = zacc[j].load();
+    } else if (A && own.empty() && masks_ok) {   // no attribute has seams of its own: only the stream length — the edges the traversal recorded
+      for (size_t i = 0; i < n; ++i) total += (uint64_t)__builtin_popcount((unsigned)(w.symbols[i] >> 4));
     } else if (A && own.empty() && [&] {   // a small mesh without seams: only the stream length — every face processed once ⇒ the interior-edge count
                  std::vector<uint8_t> seen(t.F, 0);
                  for (size_t i = 0; i < n; ++i) { uint8_t& f = seen[processed[i] / 3]; if (f) return false; f = 1; }
