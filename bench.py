@@ -156,7 +156,7 @@ def transcode_regime(n_files=1024, steps=2, device=0):
     (in memory, the reference's transcode_buffer form; F log-uniform in [2k, 200k], pos+nrm+uv, u16 / u32 indices) →
     gltf.transcode_files → n Draco-compressed GLBs.  Inside the timed call: JSON parse, accessor views, MeshBuilder::build on the device
     for every primitive (dmi_meshes_build), connectivity stage + job creation (dmi_built_meshes_prepare), dmi_jobs_encode, GLB reassembly;
-    stages of ≈ 6M triangles overlap (build + prepare of stage k+1 beside the encode of stage k)."""
+    about four stages overlap (build of stage k+2, prepare of stage k+1, encode of stage k, reassembly)."""
     from draco_oxide_amd import gltf
     glbs, total = synth.batch_glbs(n_files)
     in_bytes = sum(len(g) for g in glbs)

@@ -113,7 +113,7 @@ class _Conn(C.Structure):
 
 EXPORTS = ["dmi_encode_attributes", "dmi_encode_attributes_batch", "dmi_jobs_encode", "dmi_job_create", "dmi_job_encode", "dmi_job_timings", "dmi_job_destroy", "dmi_encode_mesh",
            "dmi_mesh_prepare", "dmi_meshes_prepare", "dmi_shard_meshes", "dmi_meshes_prepare_devices", "dmi_jobs_encode_devices", "dmi_mesh_build", "dmi_built_mesh_free", "dmi_encode_connectivity", "dmi_conn_free", "dmi_host_rans_stream", "dmi_host_rabs_stream", "dmi_host_rabs_constant_stream", "dmi_tile_sort_slots", "dmi_decode_attributes", "dmi_decoded_free", "dmi_decode_mesh", "dmi_decoded_mesh_free", "dmi_decode_connectivity", "dmi_decoded_conn_free", "dmi_last_decode_timings", "dmi_free", "dmi_free_many", "dmi_strerror", "dmi_last_error", "dmi_device_count", "dmi_release_cached_memory",
-           "dmi_init", "dmi_last_call_timings", "dmi_device_corner_table", "dmi_encode_mesh_device", "dmi_meshes_build", "dmi_built_meshes_prepare", "dmi_last_build_timings", "dmi_device_attribute_table"]
+           "dmi_init", "dmi_last_call_timings", "dmi_device_corner_table", "dmi_encode_mesh_device", "dmi_meshes_build", "dmi_built_meshes_prepare", "dmi_last_build_timings", "dmi_device_attribute_table", "dmi_built_meshes_info", "dmi_built_meshes_free"]
 
 
 def library_path():
@@ -187,6 +187,9 @@ def load_library():
     L.dmi_meshes_build.argtypes = [C.POINTER(_RawMesh), C.c_uint32, C.POINTER(_Config), C.c_uint32, C.POINTER(_BuiltMesh)]
     L.dmi_built_meshes_prepare.argtypes = [C.POINTER(_BuiltMesh), C.c_uint32, C.POINTER(_Config), C.POINTER(_Buffer), C.POINTER(C.c_void_p)]
     L.dmi_last_build_timings.argtypes = [C.POINTER(_BuildTimings)]
+    L.dmi_built_meshes_info.argtypes = [C.POINTER(_BuiltMesh), C.c_uint32, C.c_void_p, C.c_void_p]
+    L.dmi_built_meshes_free.argtypes = [C.POINTER(_BuiltMesh), C.c_uint32]
+    L.dmi_built_meshes_free.restype = None
     L.dmi_device_attribute_table.argtypes = [C.POINTER(_Mesh), C.POINTER(_Config), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     _lib = L
     return L
@@ -451,11 +454,16 @@ class BuiltBatch:
             out.append(Attribute(vals, a.att_type, a.domain, unique_id=a.unique_id, parent_index=a.parent_index, point_to_value=p2v, num_points=a.num_points))
         return Mesh(faces, out)
 
+    def counts(self):
+        """(num_faces, num_points) of every mesh as uint32 arrays — one library call."""
+        nf, npts = np.zeros(max(self._n, 1), np.uint32), np.zeros(max(self._n, 1), np.uint32)
+        if self._n:
+            _check(load_library().dmi_built_meshes_info(self._arr, self._n, nf.ctypes.data, npts.ctypes.data))
+        return nf[: self._n], npts[: self._n]
+
     def free(self):
         if self._n:
-            L = load_library()
-            for j in range(self._n):
-                L.dmi_built_mesh_free(C.byref(self._arr[j]))
+            load_library().dmi_built_meshes_free(self._arr, self._n)
         self._n = 0
 
     def __enter__(self):
@@ -516,9 +524,12 @@ def built_meshes_prepare(batch, which=None, cfg=None):
     n = len(which)
     if n == 0:
         return []
-    arr = (_BuiltMesh * n)()
-    for k, j in enumerate(which):
-        arr[k] = batch._arr[j]
+    if n == len(batch) and which == list(range(n)):
+        arr = batch._arr
+    else:
+        arr = (_BuiltMesh * n)()
+        for k, j in enumerate(which):
+            arr[k] = batch._arr[j]
     c = cfg._c()
     heads = (_Buffer * n)()
     handles = (C.c_void_p * n)()

@@ -150,6 +150,20 @@ int dmi_last_build_timings(dmi_build_timings* t) {
   return DMI_OK;
 }
 
+// face / point counts of n built meshes in one call, and their release in one call (a transcode driver in an interpreted language pays per call)
+int dmi_built_meshes_info(const dmi_built_mesh* built, uint32_t n, uint32_t* num_faces, uint32_t* num_points) {
+  if ((!built && n) || !num_faces || !num_points) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
+  for (uint32_t j = 0; j < n; ++j) {
+    num_faces[j] = built[j].mesh.num_faces;
+    num_points[j] = built[j].mesh.num_atts && built[j].mesh.atts ? built[j].mesh.atts[0].num_points : 0u;
+  }
+  return DMI_OK;
+}
+void dmi_built_meshes_free(dmi_built_mesh* built, uint32_t n) {
+  if (!built) return;
+  for (uint32_t j = 0; j < n; ++j) dmi_built_mesh_free(&built[j]);
+}
+
 int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg, uint32_t flags, dmi_built_mesh* out) {
   if (!raw || !out || n == 0) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
   for (uint32_t j = 0; j < n; ++j) out[j] = dmi_built_mesh{};

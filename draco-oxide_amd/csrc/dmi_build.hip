@@ -23,6 +23,9 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr uint32_t kNoneD = 0xFFFFFFFFu;
+// A table is at most half full, so a probe sequence of honest data is a handful of slots; rows chosen to collide under `mix` would make an
+// insert walk them all (quadratic: a kernel that does not come back).  Past this many probes the mesh is flagged and the host builder takes it.
+constexpr uint32_t kMaxProbes = 2048;
 
 inline uint32_t grid_of(uint64_t n) {
   const uint64_t g = (n + kBlock - 1) / kBlock;
@@ -130,7 +133,9 @@ __global__ __launch_bounds__(kBlock) void k_mb_value_insert(const MbArgs a) {
     if (nan) { a.vslot[ap] = kNoneD; continue; }   // equals nothing, not even itself: a class of its own
     uint32_t* __restrict__ tab = a.vtab + it.tab_off;
     h &= it.tab_mask;
-    for (;;) {
+    uint32_t probes = 0;
+    for (;; ++probes) {
+      if (probes > kMaxProbes) { raise(a.mesh_out, it.mesh, MB_CROWDED); break; }   // rows crafted to collide: the host builder takes the mesh
       uint32_t s = __atomic_load_n(&tab[h], __ATOMIC_RELAXED);
       if (s == kNoneD) {
         s = atomicCAS(&tab[h], kNoneD, p);
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(kBlock) void k_mb_value_insert(const MbArgs a) {
       if (same) { if (p < s) atomicMin(&tab[h], p); break; }
       h = (h + 1) & it.tab_mask;
     }
-    a.vslot[ap] = h;
+    a.vslot[ap] = probes > kMaxProbes ? kNoneD : h;
   }
 }
 // representative (first occurrence) of every row; first-occurrence flags for the rank scan
@@ -178,7 +183,9 @@ __global__ __launch_bounds__(kBlock) void k_mb_point_insert(const MbArgs a) {
     for (uint32_t k = 0; k < me.n_items; ++k) { key[k] = a.vid[a.items[me.item0 + k].ap_off + p]; h = mix(h, key[k]); }
     uint32_t* __restrict__ tab = a.ptab + me.ptab_off;
     h &= me.ptab_mask;
-    for (;;) {
+    uint32_t probes = 0;
+    for (;; ++probes) {
+      if (probes > kMaxProbes) { raise(a.mesh_out, me.index, MB_CROWDED); break; }
       uint32_t s = __atomic_load_n(&tab[h], __ATOMIC_RELAXED);
       if (s == kNoneD) {
         s = atomicCAS(&tab[h], kNoneD, p);
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(kBlock) void k_mb_point_insert(const MbArgs a) {
       if (same) { if (p < s) atomicMin(&tab[h], p); break; }
       h = (h + 1) & me.ptab_mask;
     }
-    a.pslot[gp] = h;
+    a.pslot[gp] = probes > kMaxProbes ? kNoneD : h;
   }
 }
 __global__ __launch_bounds__(kBlock) void k_mb_point_first(const MbArgs a) {
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(kBlock) void k_mb_faces_map(const MbArgs a) {
   for (uint32_t f = blockIdx.x * kBlock + threadIdx.x; f < a.total_faces; f += gridDim.x * kBlock) {
     const MbMesh& me = a.meshes[mesh_of_face(a, f)];
     uint32_t v[3];
-    bool ok = !(a.mesh_out[me.index].flags & MB_BAD_INDEX);
+    bool ok = !(a.mesh_out[me.index].flags & (MB_BAD_INDEX | MB_CROWDED));   // (a flagged mesh keeps no face: the host builder takes it)
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const uint32_t p = a.raw_faces[3ull * f + k];

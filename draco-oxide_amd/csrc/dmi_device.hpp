@@ -325,7 +325,8 @@ size_t scan_partials_words(uint32_t n);
 // M meshes concatenated.  "Item" = one (mesh, attribute); att-point arrays are indexed by ap = item.ap_off + point, point arrays by
 // mesh.point_off + point, face arrays by mesh.face_off + face.  Rows are 1–4 four-byte words.
 constexpr uint32_t kMbMaxAtts = 8;
-enum MbFlag : uint32_t { MB_BAD_INDEX = 1 /* a face index ≥ the point count */, MB_EMPTY = 2 /* no face survives: builder.rs:129 skips the point removal */ };
+enum MbFlag : uint32_t { MB_BAD_INDEX = 1 /* a face index ≥ the point count */, MB_EMPTY = 2 /* no face survives: builder.rs:129 skips the point removal */,
+                         MB_CROWDED = 4 /* a hash probe sequence ran past kMaxProbes (rows crafted to collide): the host builder takes the mesh */ };
 struct MbMesh { uint32_t index, n_items, item0, P, F, face_off, point_off, ptab_off, ptab_mask, pad0, pad1, pad2; };
 struct MbItem { uint32_t mesh, P, words, is_float, row_off /* words into raw_values */, ap_off, tab_off, tab_mask; };
 struct MbMeshOut { uint32_t flags, nv /* largest referenced point + 1 */, F_out, P_out, face_out_off /* faces before this mesh's in arena A */, classes, pad0, pad1; };

@@ -56,15 +56,18 @@ def read_glb(data, copy=True):
 
 
 def write_glb(doc, binary):
+    """GLB container around `doc` and the BIN chunk — bytes, or a list of byte pieces (joined here, ONE copy of the chunk)."""
     js = json.dumps(doc, separators=(",", ":")).encode("utf-8")
     js_pad = b" " * ((4 - len(js) % 4) % 4)                   # JSON chunk is space padded (encode.rs:392-396)
-    bin_pad = b"\0" * ((4 - len(binary) % 4) % 4)
-    n_js, n_bin = len(js) + len(js_pad), len(binary) + len(bin_pad)
+    pieces = list(binary) if isinstance(binary, (list, tuple)) else [binary]
+    bin_len = sum(len(p) for p in pieces)
+    bin_pad = b"\0" * ((4 - bin_len % 4) % 4)
+    n_js, n_bin = len(js) + len(js_pad), bin_len + len(bin_pad)
     total = 12 + 8 + n_js + (8 + n_bin if n_bin else 0)
     parts = [struct.pack("<4sII", b"glTF", 2, total), struct.pack("<II", n_js, 0x4E4F534A), js, js_pad]
     if n_bin:
-        parts += [struct.pack("<II", n_bin, 0x004E4942), binary, bin_pad]
-    return b"".join(parts)                                    # (one copy of the BIN chunk)
+        parts += [struct.pack("<II", n_bin, 0x004E4942)] + pieces + [bin_pad]
+    return b"".join(parts)
 
 
 def _buffer_of(binary, view):
@@ -290,18 +293,26 @@ def _assemble(doc, buffers, prims, results):
         replaced.update(prim["attributes"][n] for n in names)
         if "indices" in prim:
             replaced.add(prim["indices"])
-    new_bin = bytearray()
+    pieces, size = [], [0]                                                      # the new BIN chunk as a list of byte pieces (joined once, by write_glb)
     new_views, view_map = [], {}
+    pad = (b"", b"\0", b"\0\0", b"\0\0\0")
+
+    def put(chunk):
+        pieces.append(chunk)
+        size[0] += len(chunk)
+        if size[0] % 4:
+            p = pad[4 - size[0] % 4]
+            pieces.append(p)
+            size[0] += len(p)
 
     def carry(view_index):
         if view_index not in view_map:
             v = dict(doc["bufferViews"][view_index])
             start = v.get("byteOffset", 0)
             chunk = _buffer_of(buffers, v)[start: start + v["byteLength"]]
-            v["byteOffset"] = len(new_bin)
+            v["byteOffset"] = size[0]
             v["buffer"] = 0
-            new_bin.extend(chunk)
-            new_bin.extend(b"\0" * ((4 - len(new_bin) % 4) % 4))
+            put(chunk)
             view_map[view_index] = len(new_views)
             new_views.append(v)
         return view_map[view_index]
@@ -321,10 +332,9 @@ def _assemble(doc, buffers, prims, results):
             continue
         blob, num_faces, num_points = res
         any_compressed = True
-        start = len(new_bin)
-        new_bin.extend(blob)
-        new_bin.extend(b"\0" * ((4 - len(new_bin) % 4) % 4))
-        new_views.append({"buffer": 0, "byteOffset": start, "byteLength": len(new_bin) - start})    # length includes the pad
+        start = size[0]
+        put(blob)
+        new_views.append({"buffer": 0, "byteOffset": start, "byteLength": size[0] - start})    # length includes the pad
         # AttributeId = add order = `names` order (the built mesh has Position in slot 0, ids unchanged: builder.rs:115-125)
         ext = {"bufferView": len(new_views) - 1, "attributes": {n: k for k, n in enumerate(names)}}
         prim.setdefault("extensions", {})["KHR_draco_mesh_compression"] = ext
@@ -333,20 +343,22 @@ def _assemble(doc, buffers, prims, results):
         for n in names:
             doc["accessors"][prim["attributes"][n]]["count"] = int(num_points)
     doc["bufferViews"] = new_views
-    doc["buffers"] = [{"byteLength": len(new_bin)}]
+    doc["buffers"] = [{"byteLength": size[0]}]
     if any_compressed:
         for key in ("extensionsUsed", "extensionsRequired"):
             lst = doc.setdefault(key, [])
             if "KHR_draco_mesh_compression" not in lst:
                 lst.append("KHR_draco_mesh_compression")
-    return write_glb(doc, new_bin)
+    return write_glb(doc, pieces)
 
 
-def _chunks_by_weight(weights, limit):
-    """Consecutive index ranges of ≈ `limit` triangles each."""
+def _chunks_by_weight(weights, limit, ramp=False):
+    """Consecutive index ranges of ≈ `limit` triangles each.  ramp: the first range is a third of that (a pipeline's first stage runs alone:
+    the sooner it is through, the sooner the stages overlap)."""
     out, cur, acc = [], [], 0
+    ramp = ramp and os.environ.get("DMI_PIPELINE_RAMP", "1") != "0"
     for i, w in enumerate(weights):
-        if cur and acc + w > limit:
+        if cur and acc + w > (limit // 3 if ramp and not out else limit):
             out.append(cur)
             cur, acc = [], 0
         cur.append(i)
@@ -418,12 +430,19 @@ def _drop(mid):
                 j.close()
 
 
-PIPELINE_TRIANGLES = 6 << 20     # triangles per pipeline stage of a large batch (one connectivity group of the library)
+PIPELINE_TRIANGLES = int(os.environ.get("DMI_PIPELINE_TRIANGLES", 0))     # triangles per pipeline stage; 0 = by the size of the batch (stage_triangles)
+
+
+def stage_triangles(total):
+    """Stage size of a pipelined batch: about four stages (enough to overlap build / prepare / encode / reassembly), between 3M and 12M triangles
+    (every stage pays fixed costs — the chain launch is bounded by its longest stream, ≈ 5 ms — and a stage above ≈ 16M stops overlapping;
+    measured on 1024 GLBs / 45M triangles: 2M 153, 4M 208, 6M 233, 9M 244, 12M 247, 16M 249, 24M 210 Mtri/s)."""
+    return PIPELINE_TRIANGLES or min(12 << 20, max(3 << 20, total // 4))
 
 
 def encode_raw_batch(raws, cfg=None, pipeline=True, timings=None, weights=None, on_done=None):
     """RawMesh list → [(blob, num_faces, num_points) or None (no face left)] on ONE device: dmi_meshes_build → dmi_built_meshes_prepare →
-    dmi_jobs_encode, in stages of ≈ PIPELINE_TRIANGLES triangles: the build of stage k+2, the prepare of stage k+1 and the encode of stage k
+    dmi_jobs_encode, in stages of stage_triangles() triangles: the build of stage k+2, the prepare of stage k+1 and the encode of stage k
     run side by side (three threads; the host walks of the prepare are the longest step and keep the host's cores, the build's packing and
     the encode's read-back fit beside them).  `raws` may be a callable i → RawMesh (made when its stage is built: the accessor views of
     stage k+2 are set up beside the device work of the earlier stages) together with `weights` (triangles per primitive).
@@ -437,7 +456,7 @@ def encode_raw_batch(raws, cfg=None, pipeline=True, timings=None, weights=None, 
     import time
     if weights is None:
         weights = [len(r.indices) // 3 if r.indices is not None else 0 for r in raws]
-    chunks = _chunks_by_weight(weights, PIPELINE_TRIANGLES) if pipeline else [list(range(n))]
+    chunks = _chunks_by_weight(weights, stage_triangles(sum(weights)), ramp=True) if pipeline else [list(range(n))]
     tm = timings if timings is not None else {}
     for key in ("views_s", "build_s", "prepare_s", "encode_s", "build_kernels_ms", "build_pack_ms"):
         tm.setdefault(key, 0.0)
@@ -458,8 +477,9 @@ def encode_raw_batch(raws, cfg=None, pipeline=True, timings=None, weights=None, 
         batch, ch = mid
         t0 = time.perf_counter()
         try:
-            keep = [k for k in range(len(ch)) if batch.num_faces(k) > 0]
-            info = [batch.summary(k) for k in keep]
+            nf, npts = batch.counts()
+            keep = [k for k in range(len(ch)) if nf[k] > 0]
+            info = [(int(nf[k]), int(npts[k]), None) for k in keep]
             jobs = built_meshes_prepare(batch, keep, cfg)
         finally:
             batch.free()
@@ -498,7 +518,7 @@ def encode_batch(meshes, cfg=None, devices=None, group=None, device=None, pipeli
     that are not the destination of a sharded job).  torch.distributed initialised with more than one rank: the batch is dealt over
     the ranks by triangle count and gathered on rank 0 (RCCL for an nccl group).  Otherwise `devices` (a count, or "all") spreads it
     over the GPUs of this process (dmi_shard_meshes + dmi_meshes_prepare_devices + dmi_jobs_encode_devices); default: one GPU.
-    pipeline=True (one GPU): stages of ≈ PIPELINE_TRIANGLES triangles, dmi_meshes_prepare of stage k+1 beside dmi_jobs_encode of stage k."""
+    pipeline=True (one GPU): stages of stage_triangles() triangles, dmi_meshes_prepare of stage k+1 beside dmi_jobs_encode of stage k."""
     if not meshes:
         return []
     try:
@@ -514,7 +534,7 @@ def encode_batch(meshes, cfg=None, devices=None, group=None, device=None, pipeli
     if n_dev == 1 and pipeline:
         cfg = cfg or Config.default()
         out = [None] * len(meshes)
-        chunks = _chunks_by_weight([len(m.faces) for m in meshes], PIPELINE_TRIANGLES)
+        chunks = _chunks_by_weight([len(m.faces) for m in meshes], stage_triangles(sum(len(m.faces) for m in meshes)))
 
         def stage1(ch):
             return meshes_prepare([meshes[i] for i in ch], cfg), ch

@@ -263,6 +263,10 @@ typedef struct dmi_raw_mesh {
 } dmi_raw_mesh;
 #define DMI_BUILD_HOST_VALUES 1u   /* also read the unique values back: out[j].mesh is a complete host Mesh */
 int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg, uint32_t flags, dmi_built_mesh* out);
+/* Face and point counts of n built meshes (num_faces[j] == 0: the reference skips such a primitive, io/gltf/encode.rs:934-936), and the release of
+ * all of them, each in ONE call. */
+int dmi_built_meshes_info(const dmi_built_mesh* built, uint32_t n, uint32_t* num_faces, uint32_t* num_points);
+void dmi_built_meshes_free(dmi_built_mesh* built, uint32_t n);
 /* dmi_meshes_prepare for meshes that dmi_meshes_build left resident on cfg->device: nothing is packed or uploaded again — the connectivity
  * kernels read the built faces and maps where they are, the jobs copy their values device to device.  Same bytes as dmi_meshes_prepare on
  * the equivalent host meshes.  The built meshes may be freed as soon as this returns. */

@@ -269,3 +269,32 @@ def test_exporter_style_seams_through_the_deferred_batch_path():
     finally:
         for j in jobs:
             j.close()
+
+
+def test_rows_crafted_to_collide_go_to_the_host_builder():
+    """Rows chosen so that thousands of them start at ONE slot of the value hash table: the kernels' probe cap flags the mesh (MB_CROWDED) and the
+    host builder takes it — same mesh, no runaway kernel."""
+    def mix(h, w):
+        h = (h ^ w) & 0xFFFFFFFF
+        h = (h * 0x85EBCA6B) & 0xFFFFFFFF
+        h ^= h >> 13
+        h = (h * 0xC2B2AE35) & 0xFFFFFFFF
+        return h ^ (h >> 16)
+    n_pts = 6000
+    mask = 16384 - 1                                     # the table of 6000 points: the next power of two ≥ 12000
+    cand = np.arange(1, 1 << 27, dtype=np.uint64)
+    h = (np.uint64(0x9E3779B9) ^ cand) & np.uint64(0xFFFFFFFF)
+    h = (h * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(13)
+    h = (h * np.uint64(0xC2B2AE35)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(16)
+    hit = cand[(h & np.uint64(mask)) == 77][:n_pts].astype(np.uint32)
+    assert len(hit) == n_pts and mix(0x9E3779B9, int(hit[5])) & mask == 77
+    ids = hit.reshape(-1, 1)                              # 6000 distinct one-word rows, all starting at slot 77
+    faces, pos, _, _ = synth.torus_grid(78)               # 6084 points
+    pos, faces = pos[:n_pts], faces[(faces < n_pts).all(axis=1)]
+    specs = [(pos, dmi.ATT_POSITION, dmi.DOMAIN_POSITION, []), (ids, dmi.ATT_CUSTOM, dmi.DOMAIN_CORNER, [])]
+    got, want = _both(specs, faces)
+    _same_mesh(got, want)
+    tm = dmi.last_build_timings()
+    assert tm["device_meshes"] == 0 and tm["host_meshes"] == 1
