@@ -450,7 +450,7 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
     bool any_large = false;
     for (const auto& mem : bg.members) any_large = any_large || mem.F >= kDeviceRelabelMinFaces;
     if (!any_large && faces_seen && !std::getenv("DMI_HOST_CONNECTIVITY") && (rc = built_group_issue_tables(bg, g.S))) return rc;
-    bg.stream = nullptr; bg.keep.pool.stream = nullptr;   // (everything of the build has arrived; the library stream belongs to this thread, the group may outlive it)
+    bg.stream = nullptr; bg.keep.pool.stream = nullptr; bg.keep.owner_waits = true;   // (a null-stream synchronisation would wait for every other stage of a pipeline)   // (everything of the build has arrived; the library stream belongs to this thread, the group may outlive it)
     release_stage(g.up_stage); g.up_stage = nullptr;
   }
   groups.clear();   // (scratch back to the chunk cache; the arenas live on with their members)

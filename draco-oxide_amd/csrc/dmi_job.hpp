@@ -330,7 +330,8 @@ int job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tables, u
 struct TempDev {
   DevPool pool;
   void init(int device, hipStream_t s, size_t bytes_hint) { pool.device = device; pool.stream = s; pool.chunk_bytes = bytes_hint; pool.zero = false; }
-  ~TempDev() { if (!pool.chunks.empty()) (void)hipStreamSynchronize(pool.stream); }   // (nothing may still be using a chunk when the cache hands it to the next taker)
+  bool owner_waits = false;   // the owner itself makes sure the work on the chunks is over before this is destroyed (an event it waits for): no synchronisation here
+  ~TempDev() { if (!owner_waits && !pool.chunks.empty()) (void)hipStreamSynchronize(pool.stream); }   // (nothing may still be using a chunk when the cache hands it to the next taker)
   template <class T> T* take(size_t n) { return static_cast<T*>(pool.take((n ? n : 1) * sizeof(T))); }
 };
 

@@ -808,7 +808,7 @@ extern "C++" int dmi::built_group_issue_tables(BuiltGroup& bg, hipStream_t s) {
   if ((rc_att = st.issue(a, cn.mem, hp, s))) return rc_att;
   HIP_TRY(hipEventCreateWithFlags(&cn.ev, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(cn.ev, s));
-  cn.mem.pool.stream = nullptr;   // (the stream is a thread's library stream and the group may outlive the thread: its destructor waits for cn.ev instead)
+  cn.mem.pool.stream = nullptr; cn.mem.owner_waits = true;   // (the stream is a thread's library stream and the group may outlive the thread: its destructor waits for cn.ev instead)
   cn.issued = true;
   return DMI_OK;
 }
