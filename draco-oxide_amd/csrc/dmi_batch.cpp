@@ -432,7 +432,6 @@ static int jobs_encode_device(dmi_job** jobs, uint32_t n, dmi_buffer* outs, uint
       if (tail.size() >= 2) { order.swap(keep); n_first = (uint32_t)order.size(); } else tail.clear();
     }
   }
-  const uint32_t n_batch = tail.empty() ? n : n_first;
   DeviceBatch first, second;
   auto fill = [&](DeviceBatch& b, uint32_t lo, uint32_t hi, hipStream_t s) {
     for (uint32_t k = lo; k < hi; ++k) { b.jobs.push_back(jobs[order[k]]); b.outs.push_back(&outs[order[k]]); }
@@ -452,7 +451,6 @@ static int jobs_encode_device(dmi_job** jobs, uint32_t n, dmi_buffer* outs, uint
     if (trace) { first.trace("batch, device form"); std::fprintf(stderr, "[dmi]   + %zu jobs with the longest streams coded in the hybrid form beside it: %.2f ms\n", tail.size(), t_tail); }
     return DMI_OK;
   }
-  (void)n_batch;
   if (n_first < n) {
     fill(second, n_first, n, side);
     if ((rc = second.begin())) { (void)hipStreamSynchronize(first.s); (void)hipStreamSynchronize(second.s); return rc; }

@@ -131,9 +131,11 @@ __global__ __launch_bounds__(kBlock) void k_conn_faces(const ConnArgs a) {
     if (a.c2v != a.faces) { a.c2v[3ull * f] = v[0]; a.c2v[3ull * f + 1] = v[1]; a.c2v[3ull * f + 2] = v[2]; }
     if (bad) { raise(a.flags, m, CONN_BAD_INDEX); continue; }
     if (v[0] == v[1] || v[1] == v[2] || v[0] == v[2]) { raise(a.flags, m, CONN_DEGENERATE); continue; }
+    // the half-edge of corner j runs from v[j+1] to v[j+2]: its bucket is the smaller endpoint; the arrival number the counting atomic returns is
+    // the half-edge's place in its bucket (parked in `opp`, which k_conn_match writes later) — k_conn_fill then needs no second round of atomics
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      atomicAdd(&a.ecount[d.vert_off + min(v[k], v[(k + 1) % 3])], 1u);
+      a.opp[3ull * f + (k + 2) % 3] = atomicAdd(&a.ecount[d.vert_off + min(v[k], v[(k + 1) % 3])], 1u);
       atomicMin(&a.first[d.vert_off + v[k]], 3u * lf + k);
     }
     cur_max = max(cur_max, max(v[0], max(v[1], v[2])));
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(kBlock) void k_conn_fill(const ConnArgs a) {
     const uint64_t cb = 3ull * d.face_off;
     const uint32_t src = a.c2v[cb + cnext(lc)], snk = a.c2v[cb + cprev(lc)];
     const uint32_t low = min(src, snk);
-    const uint32_t slot = a.ecount[d.vert_off + low] + atomicAdd(&a.efill[d.vert_off + low], 1u);   // ecount holds the bucket starts by now
+    const uint32_t slot = a.ecount[d.vert_off + low] + a.opp[c];   // ecount holds the bucket starts by now, opp the arrival number from k_conn_faces
     a.he_key[slot] = src < snk ? snk : (src | 0x80000000u);
     a.he_corner[slot] = lc;
   }
@@ -406,14 +408,14 @@ void launch_exclusive_scan_u32(uint32_t* data, uint32_t n, uint32_t* partials, h
 }
 size_t scan_partials_words(uint32_t n) { return (size_t)(n + kScanTile - 1) / kScanTile + 1; }
 
-// flags / vmax / efill / cdone zeroed, first filled with DMI_NONE, ecount zeroed by the caller's memsets (conn_tables_clear)
+// flags / vmax / cdone zeroed, first filled with DMI_NONE, ecount zeroed by the caller's memsets (conn_tables_clear); efill is unused since round 4
+// (the arrival numbers of the counting atomics replace the second round of atomics)
 hipError_t conn_tables_clear(const ConnArgs& a, hipStream_t s) {
   hipError_t e;
   const size_t nv = (size_t)a.total_verts + 1, C = 3ull * a.total_faces;
   if ((e = hipMemsetAsync(a.flags, 0, (size_t)a.M * 4, s)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(a.vmax, 0, (size_t)a.M * 4, s)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(a.ecount, 0, nv * 4, s)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(a.efill, 0, nv * 4, s)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(a.first, 0xFF, nv * 4, s)) != hipSuccess) return e;
   if (C && (e = hipMemsetAsync(a.cdone, 0, C, s)) != hipSuccess) return e;
   return hipSuccess;

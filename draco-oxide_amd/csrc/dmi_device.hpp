@@ -308,7 +308,7 @@ struct RelabelBatch {
   const RelabelItem* items; uint32_t n_items, total_faces /* universal tables */, total_verts, total_keys, total_seq, total_remap_faces /* all tables */;
   uint32_t* rank;          // total_verts, filled with DMI_NONE
   uint32_t* key;           // total_faces
-  uint32_t *count, *fill;  // total_keys + 1, zeroed
+  uint32_t* count;         // total_keys + 1, zeroed: bucket sizes → starts (the arrival number the counting atomic returns is parked in new_face)
   uint32_t *order, *new_face;   // total_faces
   uint32_t* scan_partials;      // scan_partials_words(total_keys + 1)
 };

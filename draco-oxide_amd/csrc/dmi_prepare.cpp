@@ -1207,9 +1207,9 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     mem3.init(device, S, need2 + (rv + 4 * rf + 2 * nk + parts2 + 64) * 4 + ((size_t)1 << 16));
     uint8_t* d2 = mem3.take<uint8_t>(need2);
     RelabelBatch b{};
-    b.rank = mem3.take<uint32_t>(rv ? rv : 1); b.key = mem3.take<uint32_t>(rf ? rf : 1); b.count = mem3.take<uint32_t>(nk); b.fill = mem3.take<uint32_t>(nk);
+    b.rank = mem3.take<uint32_t>(rv ? rv : 1); b.key = mem3.take<uint32_t>(rf ? rf : 1); b.count = mem3.take<uint32_t>(nk);
     b.order = mem3.take<uint32_t>(rf ? rf : 1); b.new_face = mem3.take<uint32_t>(rf ? rf : 1); b.scan_partials = mem3.take<uint32_t>(parts2);
-    if (!d2 || !b.rank || !b.key || !b.count || !b.fill || !b.order || !b.new_face || !b.scan_partials) return fail(DMI_ERR_OUT_OF_MEMORY, "hipMalloc (batch relabelling)");
+    if (!d2 || !b.rank || !b.key || !b.count || !b.order || !b.new_face || !b.scan_partials) return fail(DMI_ERR_OUT_OF_MEMORY, "hipMalloc (batch relabelling)");
     std::vector<size_t> table_at(items.size(), 0);
     { size_t at = off_tables; for (size_t i = 0; i < items.size(); ++i) if (c2v_src[i]) { table_at[i] = at; at += (size_t)items[i].F * 24; } }
     if ((rc = parallel_over((uint32_t)items.size(), [&](uint32_t, uint32_t i) -> int {
