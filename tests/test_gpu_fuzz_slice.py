@@ -23,3 +23,14 @@ def test_fuzz_slice(seed0):
     bad, rejected, decoded, whole = _fuzz().run(250, seed0, log=lines.append)
     assert bad == 0, "\n".join(lines[:20])
     assert decoded + rejected == 250 and whole == decoded
+
+
+def test_fuzz_slice_of_the_device_mesh_build():
+    """scripts/fuzz_build.py: 40 seeded batches of random primitives through dmi_meshes_build against the host builder."""
+    spec = importlib.util.spec_from_file_location("fuzz_build", os.path.join(ROOT, "scripts", "fuzz_build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lines = []
+    bad, prims, n_dev, n_host = mod.run(40, 88000, log=lines.append)
+    assert bad == 0, "\n".join(lines[:20])
+    assert prims > 200 and n_dev > prims // 2

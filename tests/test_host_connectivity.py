@@ -279,3 +279,37 @@ def test_recycled_host_arrays_do_not_change_the_bytes():
     dmi.release_cached_memory()
     same(first, snapshot(big))
     same(second, snapshot(other))
+
+
+def test_host_builder_against_the_restated_builder_on_random_primitives():
+    """The generator of scripts/fuzz_build.py (duplicates, ±0.0, NaN rows, constant attributes, strided rows, degenerate faces, unreferenced points,
+    Position not first) through dmi_mesh_build and the oracle's O(V²) restatement of MeshBuilder::build: 60 primitives of ≤ 250 points.  The device
+    build is held to dmi_mesh_build on thousands of such primitives (tests/test_gpu_fuzz_slice.py, scripts/fuzz_build.py)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fuzz_build", os.path.join(root, "scripts", "fuzz_build.py"))
+    fb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fb)
+    otype = {dmi.ATT_POSITION: orc.POSITION, dmi.ATT_NORMAL: orc.NORMAL, dmi.ATT_TEXCOORD: orc.TEXCOORD, dmi.ATT_CUSTOM: orc.CUSTOM}
+    done = 0
+    for seed in range(4000, 4400):
+        rng = np.random.default_rng(seed)
+        specs, faces, _ = fb.random_primitive(rng)
+        if len(specs[0][0]) > 250 or any(t not in otype for _, t, _, _ in specs):
+            continue
+        b = dmi.MeshBuilder()
+        for rows, t, d, par in specs:
+            b.add_attribute(rows, t, d, parents=par)
+        b.set_connectivity_attribute(faces)
+        sess = orc.Session.from_arrays(faces, [dict(data=np.ascontiguousarray(rows), type=otype[t], domain=orc.DOM_POSITION if d == dmi.DOMAIN_POSITION else orc.DOM_CORNER, parents=par)
+                                               for rows, t, d, par in specs])
+        try:
+            mesh = b.build()
+        except dmi.DracoMiError:
+            continue
+        _assert_built_like_oracle(mesh, sess)
+        done += 1
+        if done == 60:
+            break
+    assert done == 60
