@@ -113,7 +113,7 @@ class _Conn(C.Structure):
 
 EXPORTS = ["dmi_encode_attributes", "dmi_encode_attributes_batch", "dmi_jobs_encode", "dmi_job_create", "dmi_job_encode", "dmi_job_timings", "dmi_job_destroy", "dmi_encode_mesh",
            "dmi_mesh_prepare", "dmi_meshes_prepare", "dmi_shard_meshes", "dmi_meshes_prepare_devices", "dmi_jobs_encode_devices", "dmi_mesh_build", "dmi_built_mesh_free", "dmi_encode_connectivity", "dmi_conn_free", "dmi_host_rans_stream", "dmi_host_rabs_stream", "dmi_host_rabs_constant_stream", "dmi_tile_sort_slots", "dmi_decode_attributes", "dmi_decoded_free", "dmi_decode_mesh", "dmi_decoded_mesh_free", "dmi_decode_connectivity", "dmi_decoded_conn_free", "dmi_last_decode_timings", "dmi_free", "dmi_free_many", "dmi_strerror", "dmi_last_error", "dmi_device_count", "dmi_release_cached_memory",
-           "dmi_init", "dmi_last_call_timings", "dmi_device_corner_table", "dmi_encode_mesh_device", "dmi_meshes_build", "dmi_built_meshes_prepare", "dmi_last_build_timings", "dmi_device_attribute_table", "dmi_built_meshes_info", "dmi_built_meshes_free"]
+           "dmi_init", "dmi_last_call_timings", "dmi_device_corner_table", "dmi_encode_mesh_device", "dmi_meshes_build", "dmi_built_meshes_prepare", "dmi_last_build_timings", "dmi_device_attribute_table", "dmi_built_meshes_info", "dmi_built_meshes_free", "dmi_thread_host_threads", "dmi_usable_host_threads"]
 
 
 def library_path():
@@ -190,6 +190,9 @@ def load_library():
     L.dmi_built_meshes_info.argtypes = [C.POINTER(_BuiltMesh), C.c_uint32, C.c_void_p, C.c_void_p]
     L.dmi_built_meshes_free.argtypes = [C.POINTER(_BuiltMesh), C.c_uint32]
     L.dmi_built_meshes_free.restype = None
+    L.dmi_thread_host_threads.argtypes = [C.c_uint32]
+    L.dmi_thread_host_threads.restype = None
+    L.dmi_usable_host_threads.restype = C.c_int
     L.dmi_device_attribute_table.argtypes = [C.POINTER(_Mesh), C.POINTER(_Config), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     _lib = L
     return L
@@ -203,6 +206,15 @@ def _check(rc):
 
 def device_count():
     return int(load_library().dmi_device_count())
+
+
+def thread_host_threads(n):
+    """dmi_thread_host_threads: cap on the host threads of the library calls THIS thread makes (0 = none)."""
+    load_library().dmi_thread_host_threads(int(n))
+
+
+def usable_host_threads():
+    return int(load_library().dmi_usable_host_threads())
 
 
 def release_cached_memory():

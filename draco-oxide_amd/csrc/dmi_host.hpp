@@ -52,11 +52,15 @@ inline unsigned cgroup_cpu_quota() {   // 0 = unlimited / unknown
   }();
   return quota;
 }
+// a cap for the calls the CALLING thread makes (dmi_thread_host_threads): a pipeline that runs several library calls side by side gives each
+// stage its share, so that together they stay inside the CPU quota (threads beyond it get the whole cgroup throttled)
+inline thread_local unsigned g_thread_host_cap = 0;
 inline unsigned host_threads() {
   unsigned hw = std::thread::hardware_concurrency();
   if (!hw) hw = 4;
   if (const unsigned q = cgroup_cpu_quota()) hw = std::min(hw, std::max(1u, q));
   if (const char* e = std::getenv("DMI_HOST_THREADS")) { const int v = std::atoi(e); if (v > 0) hw = std::min<unsigned>(hw, (unsigned)v); }
+  if (g_thread_host_cap) hw = std::min(hw, g_thread_host_cap);
   return hw;
 }
 // [0, n) in contiguous slices on up to 32 host threads (large, embarrassingly parallel index loops); fn(lo, hi)

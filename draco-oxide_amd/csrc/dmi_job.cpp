@@ -179,6 +179,9 @@ int dmi_last_call_timings(dmi_timings* t) {
   return DMI_OK;
 }
 
+void dmi_thread_host_threads(uint32_t n) { g_thread_host_cap = n; }
+int dmi_usable_host_threads(void) { return (int)host_threads(); }
+
 int dmi_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -29,7 +29,7 @@ import numpy as np
 import threading
 
 from .binding import (ATT_CUSTOM, ATT_NORMAL, ATT_POSITION, ATT_TEXCOORD, DOMAIN_CORNER, DOMAIN_POSITION, Config, MeshBuilder, RawMesh, built_meshes_prepare, device_count,
-                      jobs_encode, jobs_encode_devices, last_build_timings, meshes_build, meshes_prepare, meshes_prepare_devices, shard_meshes)
+                      jobs_encode, jobs_encode_devices, last_build_timings, meshes_build, meshes_prepare, meshes_prepare_devices, shard_meshes, thread_host_threads)
 
 _COMPONENTS = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4}
 _INDEX_DTYPE = {5121: np.uint8, 5123: np.uint16, 5125: np.uint32}
@@ -370,46 +370,55 @@ def _chunks_by_weight(weights, limit, ramp=False):
 
 def _pipelined(chunks, *stages):
     """stages[-1](…stages[0](chunk)) for every chunk, every stage on a thread of its own, one chunk in flight between neighbours: stage s of
-    chunk k+1 runs beside stage s+1 of chunk k (the library calls release the GIL).  The first element of what a stage returns is a list of
-    jobs (closed if a later stage fails)."""
+    chunk k+1 runs beside stage s+1 of chunk k (the library calls release the GIL).  A stage given as (fn, workers) runs on that many threads
+    (its chunks may then finish out of order: the stages after it must not care).  The first element of what a stage returns is a list of
+    jobs or a built batch (released if a later stage fails)."""
+    stages = [st if isinstance(st, tuple) else (st, 1) for st in stages]
     if len(chunks) <= 1 or len(stages) == 1:
         for ch in chunks:
             x = ch
-            for st in stages:
-                x = st(x)
+            for fn, _ in stages:
+                x = fn(x)
         return
     import queue
     qs = [queue.Queue(maxsize=1) for _ in range(len(stages) - 1)]
     err = []
     stop = object()
+    lock = threading.Lock()
+    alive = [w for _, w in stages]
 
     def run(si):
         src = qs[si - 1]
+        fn = stages[si][0]
         while True:
             x = src.get()
             if x is stop:
+                src.put(stop)                                              # (for the stage's other workers; nothing follows a stop)
                 break
             try:
                 if err:
                     _drop(x)
                     continue
-                y = stages[si](x)
+                y = fn(x)
                 if si + 1 < len(stages):
                     qs[si].put(y)
             except BaseException as e:                                    # noqa: BLE001 — re-raised on the caller's thread
                 err.append(e)
                 _drop(x)
-        if si + 1 < len(stages):
+        with lock:
+            alive[si] -= 1
+            last = alive[si] == 0
+        if last and si + 1 < len(stages):
             qs[si].put(stop)
 
-    threads = [threading.Thread(target=run, args=(si,)) for si in range(1, len(stages))]
+    threads = [threading.Thread(target=run, args=(si,)) for si in range(1, len(stages)) for _ in range(stages[si][1])]
     for t in threads:
         t.start()
     try:
         for ch in chunks:
             if err:
                 break
-            qs[0].put(stages[0](ch))
+            qs[0].put(stages[0][0](ch))
     except BaseException as e:                                            # noqa: BLE001
         err.append(e)
     qs[0].put(stop)
@@ -461,7 +470,16 @@ def encode_raw_batch(raws, cfg=None, pipeline=True, timings=None, weights=None, 
     for key in ("views_s", "build_s", "prepare_s", "encode_s", "build_kernels_ms", "build_pack_ms"):
         tm.setdefault(key, 0.0)
 
+    # DMI_STAGE_THREADS="build,prepare,encode": a share of the host threads per stage (dmi_thread_host_threads).  Measured with collection paused
+    # (1024 GLBs, medians of 10): no caps 185 ms, 2/12/2 192, 2/14/2 192, 4/16/4 191 — the stages' pools oversubscribing the 16-CPU quota costs less
+    # than a stage kept short of threads; off unless asked for.
+    share = None
+    if len(chunks) > 1 and os.environ.get("DMI_STAGE_THREADS"):
+        share = [int(x) for x in os.environ["DMI_STAGE_THREADS"].split(",")]
+
     def build(ch):
+        if share:
+            thread_host_threads(share[0])
         t0 = time.perf_counter()
         mine = [make(i) for i in ch] if make else [raws[i] for i in ch]
         t1 = time.perf_counter()
@@ -474,6 +492,8 @@ def encode_raw_batch(raws, cfg=None, pipeline=True, timings=None, weights=None, 
         return batch, ch
 
     def prepare(mid):
+        if share:
+            thread_host_threads(share[1])
         batch, ch = mid
         t0 = time.perf_counter()
         try:
@@ -487,6 +507,8 @@ def encode_raw_batch(raws, cfg=None, pipeline=True, timings=None, weights=None, 
         return jobs, [ch[k] for k in keep], info
 
     def encode(mid):
+        if share:
+            thread_host_threads(share[2])
         jobs, where, info = mid[:3]
         t0 = time.perf_counter()
         try:
@@ -506,10 +528,15 @@ def encode_raw_batch(raws, cfg=None, pipeline=True, timings=None, weights=None, 
         on_done(mid[1], out)
         return None
 
-    if on_done:
-        _pipelined(chunks, build, prepare_ch, encode, finish)
-    else:
-        _pipelined(chunks, build, prepare_ch, encode)
+    prep_workers = int(os.environ.get("DMI_PREPARE_WORKERS", 1))   # (measured: 2 or 3 workers give nothing — the host cores are busy)
+    try:
+        if on_done:
+            _pipelined(chunks, build, (prepare_ch, prep_workers), encode, finish)
+        else:
+            _pipelined(chunks, build, (prepare_ch, prep_workers), encode)
+    finally:
+        if share:
+            thread_host_threads(0)                                         # (the caller's thread ran the build stage under its cap)
     return out
 
 
@@ -573,6 +600,21 @@ def transcode_files(sources, cfg=None, devices=None, group=None, device=None, pi
     counts the JSON states, each rank builds and encodes ONLY its share, rank 0 gathers the blobs and reassembles the files.
     Returns [(glb_bytes, [blob, ...]), ...] in input order — on the destination rank; None on the other ranks of a sharded job.
     timings (optional dict): parse_s (JSON), views_s (accessor views), build_s, prepare_s, encode_s, assemble_s, primitives_built (this rank)."""
+    import gc
+    import time
+    # The call allocates a few hundred thousand small objects (JSON trees, views, jobs) while four stage threads share the interpreter: a full
+    # collection triggered in the middle stops all of them.  Collection is paused for the duration of the call (restored on the way out).
+    gc_was = gc.isenabled() and os.environ.get("DMI_TRANSCODE_GC", "0") == "0"
+    if gc_was:
+        gc.disable()
+    try:
+        return _transcode_files(sources, cfg, devices, group, device, pipeline, timings)
+    finally:
+        if gc_was:
+            gc.enable()
+
+
+def _transcode_files(sources, cfg, devices, group, device, pipeline, timings):
     import time
     tm = timings if timings is not None else {}
     t0 = time.perf_counter()

@@ -362,6 +362,11 @@ void dmi_free_many(dmi_buffer* bufs, uint32_t n);
 const char* dmi_strerror(int status);
 /* Last error detail for the calling thread (HIP error string, offending attribute, ...). */
 const char* dmi_last_error(void);
+/* Host threads the library may use in one call: the machine's hardware threads, no more than the cgroup's CPU quota, DMI_HOST_THREADS, and — for
+ * calls made by the CALLING thread — the cap set here (0 = none).  A pipeline that runs several library calls side by side (a transcode: build ∥
+ * prepare ∥ encode) gives each stage's thread its share, so that together they stay inside the quota. */
+void dmi_thread_host_threads(uint32_t n);
+int dmi_usable_host_threads(void);
 /* Number of HIP devices visible (0 when there is no GPU); never initialises a context. */
 int dmi_device_count(void);
 /* Optional: pay a process's one-time costs for `device` now instead of inside its first encode — HIP context, the library's code objects
