@@ -448,6 +448,22 @@ static const bool kPfFlags = !std::getenv("DMI_PF_NOFLAGS");
 inline void prefetch_neighbours(const uint32_t* p) { if (kPfDist) { __builtin_prefetch(p + kPfDist, 0, 2); __builtin_prefetch(p - kPfDist, 0, 2); } }
 inline void prefetch_neighbours(const uint8_t* p) { if (kPfDist && kPfFlags) { __builtin_prefetch(p + 4 * kPfDist, 1, 2); __builtin_prefetch(p - 4 * kPfDist, 1, 2); } }
 
+// The size of a vector of trivial elements whose first n slots (n ≤ capacity) were written through data(): the walks fill their output arrays
+// (one entry per face / vertex, capacity known up front) through raw pointers — a push_back per step is a call the compilers do not inline
+// (g++: emplace_back<unsigned char>; clang: the split bookkeeping) and cost the 10M-face traversal a third of its time — and resize() would
+// zero-fill 50 MB first.  libstdc++ keeps {begin, end, end of storage}; a layout that does not answer the probe takes the plain resize + copy.
+template <class T>
+inline void set_size_written(std::vector<T>& v, size_t n) {
+  static_assert(std::is_trivially_copyable<T>::value, "trivial elements only");
+  struct Impl { T* b; T* e; T* c; };
+  if (sizeof(std::vector<T>) == sizeof(Impl) && n <= v.capacity()) {
+    Impl& im = reinterpret_cast<Impl&>(v);
+    if (im.b == v.data() && im.e == v.data() + v.size() && im.c == v.data() + v.capacity()) { im.e = im.b + n; return; }
+  }
+  std::vector<T> copy(v.data(), v.data() + n);   // (never taken with libstdc++)
+  v.swap(copy);
+}
+
 struct Walker {
   const CornerTables& t;
   const uint32_t C;
@@ -458,20 +474,20 @@ struct Walker {
   std::vector<uint8_t> symbols, start_interior;
   struct Split { uint64_t merging, split; uint8_t right; };
   std::vector<Split> splits;
-  uint64_t symbol_idx = ~0ull, num_split_symbols = 0;
+  uint64_t num_split_symbols = 0;
+  size_t n_out = 0;                   // faces processed so far = symbols written (processed / symbols are filled through data(): finish() sets their size)
   bool bad = false;
 
   explicit Walker(const CornerTables& tt) : t(tt), C(tt.F * 3) {
     pool_fit(vvis, t.V); vvis.assign(t.V, 0);
     pool_fit(fvis, t.F); fvis.assign(t.F, 0);
-    pool_fit(processed, t.F);
-    pool_fit(symbols, t.F);
+    pool_fit(processed, (size_t)t.F + 1); if (processed.capacity() < (size_t)t.F + 1) processed.reserve((size_t)t.F + 1);
+    pool_fit(symbols, (size_t)t.F + 1); if (symbols.capacity() < (size_t)t.F + 1) symbols.reserve((size_t)t.F + 1);
   }
   ~Walker() { pool_give(vvis); pool_give(fvis); pool_give(hole_of); pool_give(processed); pool_give(symbols); }
   Walker(const Walker&) = delete;
   Walker& operator=(const Walker&) = delete;
-  uint32_t right_of(uint32_t c) const { return t.opp[corner_next(c)]; }
-  uint32_t left_of(uint32_t c) const { return t.opp[corner_prev(c)]; }
+  void finish() { set_size_written(processed, n_out); set_size_written(symbols, n_out); }
   uint32_t swing_right(uint32_t c) const { uint32_t o = t.opp[corner_prev(c)]; return o == kNone ? kNone : corner_prev(o); }
 
   // edgebreaker.rs:195-224 — the inner walk rotates inside one face (never crosses an edge), so
@@ -510,63 +526,79 @@ struct Walker {
       while (t.opp[c] != kNone) c = corner_next(t.opp[c]);
     }
   }
-  void note_split(uint64_t merging, uint8_t right, uint32_t face) {   // (the 8-byte-per-face array is only read for faces flagged as S faces)
-    if (fvis[face] & 2) splits.push_back({merging, split_symbol_of_face[face], right});
+  // (rare: the face across the edge is an S face — the 8-byte-per-face array of the reference is a map over the S faces only)
+  __attribute__((noinline)) void note_split(uint64_t merging, uint8_t right, uint32_t face) { splits.push_back({merging, split_symbol_of_face[face], right}); }
+  // an S face: the left branch waits on the stack, the right one is walked first (rare: kept out of the loop's registers)
+  __attribute__((noinline)) void split_here(uint32_t c, uint32_t f, uint32_t v, uint8_t vflags, uint32_t rc, uint32_t lc, uint64_t symbol_idx) {
+    ++num_split_symbols;
+    if ((vflags & 2) && !hole_done[hole_of[v]]) mark_boundary(c, false);
+    split_symbol_of_face[f] = symbol_idx;
+    fvis[f] |= 2;
+    stack.back() = lc;
+    stack.push_back(rc);
   }
-  // edgebreaker.rs:261-350
+  // edgebreaker.rs:261-350.  The loop keeps its tables and outputs in locals (every flag store is a byte store, which may alias anything the
+  // object holds: members would be reloaded after each of them) and writes one (corner, symbol) pair per step through raw pointers.
   void run_from(uint32_t c) {
+    const uint32_t* const opp = t.opp;
+    const uint32_t* const c2v = t.c2v;
+    uint8_t* const fv = fvis.data();
+    uint8_t* const vv = vvis.data();
+    uint32_t* const proc = processed.data();
+    uint8_t* const sym = symbols.data();
+    const size_t cap = t.F;            // a consistent table never processes a face twice: more symbols than faces ⇒ malformed (the reference would not terminate)
+    size_t n = n_out;
     stack.clear();
     stack.push_back(c);
     while (!stack.empty() && !bad) {
       c = stack.back();
-      if (c == kNone) { bad = true; return; }
-      if (fvis[c / 3] & 1) { stack.pop_back(); continue; }
-      for (uint32_t steps = 0; steps < t.F; ++steps) {
-        if (c == kNone) { bad = true; return; }
-        ++symbol_idx;
-        prefetch_neighbours(t.opp + c); prefetch_neighbours(t.c2v + c);
-        const uint32_t f = c / 3, v = t.c2v[c];
-        prefetch_neighbours(fvis.data() + f); prefetch_neighbours(vvis.data() + v);
-        fvis[f] |= 1;
-        processed.push_back(c);
-        const uint32_t gate = t.opp[c] != kNone ? 0x10u : 0u;   // (the face this one was entered from — or a start face — is always visited)
-        const uint8_t vflags = vvis[v];
+      if (c == kNone) { bad = true; break; }
+      if (fv[c / 3] & 1) { stack.pop_back(); continue; }
+      for (;;) {
+        if (c == kNone || n >= cap) { bad = true; break; }
+        prefetch_neighbours(opp + c); prefetch_neighbours(c2v + c);
+        const uint32_t f = c / 3, k = c - 3 * f, v = c2v[c];
+        const uint32_t cn = k == 2 ? c - 2 : c + 1;
+        prefetch_neighbours(fv + f); prefetch_neighbours(vv + v);
+        fv[f] |= 1;
+        proc[n] = c;
+        const uint32_t gate = opp[c] != kNone ? 0x10u : 0u;   // (the face this one was entered from — or a start face — is always visited)
+        const uint8_t vflags = vv[v];
         if (!(vflags & 1)) {
-          vvis[v] = vflags | 1;
+          vv[v] = vflags | 1;
           // (a C face: its tip was unvisited, so neither the right nor the left face — both hold the tip — has been processed)
-          if (!(vflags & 2)) { symbols.push_back((uint8_t)(SYM_C | gate)); c = right_of(c); continue; }
+          if (!(vflags & 2)) { sym[n++] = (uint8_t)(SYM_C | gate); c = opp[cn]; continue; }
         }
-        const uint32_t rc = right_of(c), lc = left_of(c);
-        const bool rv = rc == kNone || (fvis[rc / 3] & 1), lv = lc == kNone || (fvis[lc / 3] & 1);
+        const uint32_t cp = k == 0 ? c + 2 : c - 1;
+        const uint32_t rc = opp[cn], lc = opp[cp];
+        const uint8_t rf = rc == kNone ? 1 : fv[rc / 3], lf = lc == kNone ? 1 : fv[lc / 3];
+        const bool rv = rf & 1, lv = lf & 1;
         // bits 4–6 of a symbol: which of the edges opposite (c, next, prev) lead to a face processed EARLIER (or to a start face) — what the seam
         // streams emit for this face (edgebreaker.rs:611-636 walks the faces last to first and emits the edges whose other face is not visited yet)
         const uint8_t nb = (uint8_t)(gate | ((rc != kNone && rv) ? 0x20u : 0u) | ((lc != kNone && lv) ? 0x40u : 0u));
+        const uint64_t symbol_idx = n;   // (symbols so far = the index of this one)
         if (rv) {
-          if (rc != kNone) note_split(symbol_idx, 1, rc / 3);
+          if (rc != kNone && (rf & 2)) note_split(symbol_idx, 1, rc / 3);
           if (lv) {
-            if (lc != kNone) note_split(symbol_idx, 0, lc / 3);
-            symbols.push_back((uint8_t)(SYM_E | nb));
+            if (lc != kNone && (lf & 2)) note_split(symbol_idx, 0, lc / 3);
+            sym[n++] = (uint8_t)(SYM_E | nb);
             stack.pop_back();
             break;
           }
-          symbols.push_back((uint8_t)(SYM_R | nb));
+          sym[n++] = (uint8_t)(SYM_R | nb);
           c = lc;
         } else if (lv) {
-          if (lc != kNone) note_split(symbol_idx, 0, lc / 3);
-          symbols.push_back((uint8_t)(SYM_L | nb));
+          if (lc != kNone && (lf & 2)) note_split(symbol_idx, 0, lc / 3);
+          sym[n++] = (uint8_t)(SYM_L | nb);
           c = rc;
         } else {
-          symbols.push_back((uint8_t)(SYM_S | nb));
-          ++num_split_symbols;
-          if ((vflags & 2) && !hole_done[hole_of[v]]) mark_boundary(c, false);
-          split_symbol_of_face[f] = symbol_idx;
-          fvis[f] |= 2;
-          stack.back() = lc;
-          stack.push_back(rc);
+          sym[n++] = (uint8_t)(SYM_S | nb);
+          split_here(c, f, v, vflags, rc, lc, symbol_idx);
           break;
         }
       }
     }
+    n_out = n;
   }
   // edgebreaker.rs:411-431
   bool pick_start(uint32_t face, uint32_t& corner) const {
@@ -587,6 +619,28 @@ struct Walker {
 };
 }  // namespace
 
+}  // namespace dmi
+
+// Large heap arrays of THIS library (every std::vector of index / flag arrays: hidden visibility — no other module's allocations come here) start
+// on a 2 MiB boundary and end on one, and ask for transparent huge pages as a whole.  malloc hands a 5 MB flag array out 16 bytes into its
+// mapping: the 2 MiB-aligned interior that advise_huge_pages can flag leaves its first and last megabytes on 4 KiB pages, and the serial walks
+// (one flag byte per step, a mesh row apart: a new page every step) then miss the TLB on 20–40 % of their flag accesses — the 10M-face
+// traversal on the GPU box's EPYC: 64 ms against 48 ms with every array on huge pages.  Memory comes from posix_memalign: released by the
+// default operator delete (free).  DMI_NO_THP=1: plain malloc.
+void* operator new(std::size_t n) {   // (local to the library: libdraco_mi.map)
+  constexpr std::size_t kHuge = (std::size_t)2 << 20;
+  static const bool off = std::getenv("DMI_NO_THP") != nullptr;
+  if (n >= kHuge && !off) {
+    const std::size_t want = (n + kHuge - 1) & ~(kHuge - 1);
+    void* p = nullptr;
+    if (want >= n && posix_memalign(&p, kHuge, want) == 0 && p) { (void)madvise(p, want, MADV_HUGEPAGE); return p; }
+  }
+  if (void* p = std::malloc(n ? n : 1)) return p;
+  throw std::bad_alloc();
+}
+void* operator new[](std::size_t n) { return ::operator new(n); }
+
+namespace dmi {
 void advise_huge_pages(void* p, size_t bytes) {
   static const bool off = std::getenv("DMI_NO_THP") != nullptr;
   if (off || !p) return;
@@ -627,6 +681,7 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
   auto since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
   const auto t0 = tick();
   Walker w(t);
+  const double t_ctor = since(t0);
   ByteSink s;
   s.u8(0);   // EdgebreakerKind::Standard
   w.label_boundaries();
@@ -648,7 +703,9 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
       w.run_from(start);
     }
   }
+  w.finish();
   const double t_walk = since(t0);
+  if (trace) std::fprintf(stderr, "[dmi]   (walker set-up %.2f ms)\n", t_ctor);
   if (w.bad) { err = "edgebreaker: inconsistent connectivity (reference unwrap() panic)"; if (hooks && hooks->before_seams) hooks->before_seams(); return DMI_ERR_CONNECTIVITY; }
   out.init_rev.assign(w.init_corners.rbegin(), w.init_corners.rend());   // edgebreaker.rs:523-529
   pool_give(out.processed);
@@ -888,39 +945,55 @@ void attribute_sequence(const TableRef& t, const uint32_t* seeds, uint32_t n_see
 // are therefore read in place, last to first (second part, then first part), and only the pushes live on a stack of their own.
 void attribute_sequence(const TableRef& t, const uint32_t* first, uint32_t n_first, const uint32_t* second, uint32_t n_second, std::vector<uint32_t>& seq, const uint8_t* on_boundary) {
   Pooled<uint8_t> vvis_p(t.V, (uint8_t)0), fvis_p(t.F, (uint8_t)0);
-  std::vector<uint8_t>&vvis = vvis_p.v, &fvis = fvis_p.v;   // vvis: bit 0 visited, bit 1 the vertex lies on a boundary (from on_boundary: one load less per new vertex)
-  if (on_boundary) parallel_for(t.V, [&](size_t lo, size_t hi) { for (size_t v = lo; v < hi; ++v) vvis[v] = on_boundary[v] ? 2 : 0; });
-  std::vector<uint32_t> stack;
-  stack.reserve(1024);
-  uint64_t left = (uint64_t)n_first + n_second;
+  // vvis: bit 0 visited, bit 1 the vertex lies on a boundary (from on_boundary: one load less per new vertex)
+  if (on_boundary) parallel_for(t.V, [&](size_t lo, size_t hi) { for (size_t v = lo; v < hi; ++v) vvis_p.v[v] = on_boundary[v] ? 2 : 0; });
+  // (tables, flags, the output and the stack in locals, written through raw pointers: see Walker::run_from)
+  const uint32_t* const opp = t.opp;
+  const uint32_t* const c2v = t.c2v;
+  uint8_t* const vv = vvis_p.v.data();
+  uint8_t* const fv = fvis_p.v.data();
   pool_fit(seq, t.V);
-  auto emit = [&](uint32_t c) { uint32_t v = t.c2v[c]; if (!(vvis[v] & 1)) { vvis[v] |= 1; seq.push_back(c); } };
+  if (seq.capacity() < (size_t)t.V) seq.reserve(t.V);
+  uint32_t* const sq = seq.data();
+  size_t nq = 0;
+  const size_t qcap = t.V;             // (every vertex is emitted once: sequence.rs:41-46)
+  std::vector<uint32_t> stack_store(4096);
+  uint32_t* st = stack_store.data();
+  size_t sn = 0, scap = stack_store.size();
+  auto push = [&](uint32_t x) {
+    if (__builtin_expect(sn == scap, 0)) { stack_store.resize(scap * 2); st = stack_store.data(); scap *= 2; }
+    st[sn++] = x;
+  };
+  uint64_t left = (uint64_t)n_first + n_second;
+  auto emit = [&](uint32_t c) { const uint32_t v = c2v[c]; const uint8_t f = vv[v]; if (!(f & 1) && nq < qcap) { vv[v] = f | 1; sq[nq++] = c; } };
   for (;;) {
     uint32_t c;
-    if (!stack.empty()) { c = stack.back(); stack.pop_back(); }
+    if (sn) c = st[--sn];
     else if (left) { --left; c = left >= n_first ? second[left - n_first] : first[left]; }
     else break;
-    if (fvis[c / 3]) continue;
-    prefetch_neighbours(t.opp + c); prefetch_neighbours(t.c2v + c); prefetch_neighbours(fvis.data() + c / 3);
-    const uint32_t nc = corner_next(c), pc = corner_prev(c);
-    if (!(vvis[t.c2v[nc]] & 1) || !(vvis[t.c2v[pc]] & 1)) { emit(nc); emit(pc); stack.push_back(c); continue; }
-    fvis[c / 3] = 1;
-    const uint32_t v = t.c2v[c];
-    prefetch_neighbours(vvis.data() + v);
-    const uint32_t right = t.opp[nc], left = t.opp[pc];
-    const uint8_t vflags = vvis[v];
+    const uint32_t f = c / 3;
+    if (fv[f]) continue;
+    prefetch_neighbours(opp + c); prefetch_neighbours(c2v + c); prefetch_neighbours(fv + f);
+    const uint32_t k = c - 3 * f, nc = k == 2 ? c - 2 : c + 1, pc = k == 0 ? c + 2 : c - 1;
+    if (!(vv[c2v[nc]] & 1) || !(vv[c2v[pc]] & 1)) { emit(nc); emit(pc); push(c); continue; }
+    fv[f] = 1;
+    const uint32_t v = c2v[c];
+    prefetch_neighbours(vv + v);
+    const uint32_t right = opp[nc], lft = opp[pc];
+    const uint8_t vflags = vv[v];
     if (!(vflags & 1)) {
       emit(c);
       bool boundary;
       if (on_boundary) boundary = (vflags & 2) != 0;
-      else { const uint32_t l0 = t.lmc[v]; boundary = t.opp[corner_next(l0)] == kNone; }   // is_on_boundary: swing_left(lmc) is None
-      if (!boundary) { if (right != kNone) stack.push_back(right); continue; }
+      else { const uint32_t l0 = t.lmc[v]; boundary = opp[corner_next(l0)] == kNone; }   // is_on_boundary: swing_left(lmc) is None
+      if (!boundary) { if (right != kNone) push(right); continue; }
     }
-    const bool rdone = right != kNone && fvis[right / 3], ldone = left != kNone && fvis[left / 3];
-    if (rdone) { if (!ldone && left != kNone) stack.push_back(left); }
-    else if (ldone) { if (right != kNone) stack.push_back(right); }
-    else { if (left != kNone) stack.push_back(left); if (right != kNone) stack.push_back(right); }
+    const bool rdone = right != kNone && fv[right / 3], ldone = lft != kNone && fv[lft / 3];
+    if (rdone) { if (!ldone && lft != kNone) push(lft); }
+    else if (ldone) { if (right != kNone) push(right); }
+    else { if (lft != kNone) push(lft); if (right != kNone) push(right); }
   }
+  set_size_written(seq, nq);
 }
 
 }  // namespace dmi
