@@ -444,7 +444,7 @@ enum : uint8_t { SYM_C, SYM_S, SYM_L, SYM_R, SYM_E };
 // L2 instead of DRAM (10M-triangle grid on the GPU box's EPYC: traversal 144 → 93 ms, sequencer 121 → 64 ms together with huge pages).
 // DMI_PF=<entries> sets the distance for uint32 arrays (0 = off); byte arrays use four times as many entries (the same 64 bytes).
 static const int kPfDist = std::getenv("DMI_PF") ? std::atoi(std::getenv("DMI_PF")) : 16;
-static const bool kPfFlags = !std::getenv("DMI_PF_NOFLAGS");
+static const bool kPfFlags = std::getenv("DMI_PF_FLAGS") != nullptr;   // (the flag arrays stay cache-resident by themselves: prefetching their neighbour lines cost the lean loops 5 % — off unless asked for)
 inline void prefetch_neighbours(const uint32_t* p) { if (kPfDist) { __builtin_prefetch(p + kPfDist, 0, 2); __builtin_prefetch(p - kPfDist, 0, 2); } }
 inline void prefetch_neighbours(const uint8_t* p) { if (kPfDist && kPfFlags) { __builtin_prefetch(p + 4 * kPfDist, 1, 2); __builtin_prefetch(p - 4 * kPfDist, 1, 2); } }
 
