@@ -477,6 +477,8 @@ def encode_raw_batch(raws, cfg=None, pipeline=True, timings=None, weights=None, 
     if len(chunks) > 1 and os.environ.get("DMI_STAGE_THREADS"):
         share = [int(x) for x in os.environ["DMI_STAGE_THREADS"].split(",")]
 
+    trace = tm.get("trace")                                               # (a list: (step, first primitive, start, end) per stage and step, seconds)
+
     def build(ch):
         if share:
             thread_host_threads(share[0])
@@ -489,6 +491,8 @@ def encode_raw_batch(raws, cfg=None, pipeline=True, timings=None, weights=None, 
         tm["build_s"] += time.perf_counter() - t1
         tm["build_kernels_ms"] += bt["kernels_ms"]
         tm["build_pack_ms"] += bt["pack_ms"]
+        if trace is not None:
+            trace.append(("build", ch[0], t0, time.perf_counter()))
         return batch, ch
 
     def prepare(mid):
@@ -504,6 +508,8 @@ def encode_raw_batch(raws, cfg=None, pipeline=True, timings=None, weights=None, 
         finally:
             batch.free()
         tm["prepare_s"] += time.perf_counter() - t0
+        if trace is not None:
+            trace.append(("prepare", ch[0], t0, time.perf_counter()))
         return jobs, [ch[k] for k in keep], info
 
     def encode(mid):
@@ -519,21 +525,28 @@ def encode_raw_batch(raws, cfg=None, pipeline=True, timings=None, weights=None, 
             for j in jobs:
                 j.close()
         tm["encode_s"] += time.perf_counter() - t0
+        if trace is not None:
+            trace.append(("encode", mid[3][0] if len(mid) > 3 and mid[3] else -1, t0, time.perf_counter()))
         return None, mid[3]
 
     def prepare_ch(mid):
         return prepare(mid) + (mid[1],)
 
     def finish(mid):
+        t0 = time.perf_counter()
         on_done(mid[1], out)
+        if trace is not None:
+            trace.append(("assemble", mid[1][0] if mid[1] else -1, t0, time.perf_counter()))
         return None
 
     prep_workers = int(os.environ.get("DMI_PREPARE_WORKERS", 1))   # (measured: 2 or 3 workers give nothing — the host cores are busy)
+    build_workers = int(os.environ.get("DMI_BUILD_WORKERS", 1))
     try:
-        if on_done:
-            _pipelined(chunks, build, (prepare_ch, prep_workers), encode, finish)
+        steps = [(prepare_ch, prep_workers), encode] + ([finish] if on_done else [])
+        if build_workers > 1:   # the builds of two stages side by side (the caller's thread only deals the stages out)
+            _pipelined(chunks, lambda ch: ch, (build, build_workers), *steps)
         else:
-            _pipelined(chunks, build, (prepare_ch, prep_workers), encode)
+            _pipelined(chunks, build, *steps)
     finally:
         if share:
             thread_host_threads(0)                                         # (the caller's thread ran the build stage under its cap)

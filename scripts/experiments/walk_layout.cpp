@@ -412,10 +412,10 @@ struct Shadow {
         const bool rv = rc == kNone || rs, lv = lc == kNone || ls;
         const uint8_t nb = (uint8_t)(gate | ((rc != kNone && rv) ? 0x20u : 0u) | ((lc != kNone && lv) ? 0x40u : 0u));
         if (rv) {
-          if (rs) q = (rs & 0x7FFFFFFFu);          // (the right face: processed at position rs - 1; the shadow moves on from the one after it)
+          if (rs) q = (rs & 0x3FFFFFFFu);          // (the right face: processed at position rs - 1; the shadow moves on from the one after it)
           if (lv) { symbols[n_processed++] = (uint8_t)(SYM_E | nb); stack.pop_back(); break; }
           symbols[n_processed++] = (uint8_t)(SYM_R | nb); c = lc;
-        } else if (lv) { if (ls) q = (ls & 0x7FFFFFFFu); symbols[n_processed++] = (uint8_t)(SYM_L | nb); c = rc; }
+        } else if (lv) { if (ls) q = (ls & 0x3FFFFFFFu); symbols[n_processed++] = (uint8_t)(SYM_L | nb); c = rc; }
         else { symbols[n_processed++] = (uint8_t)(SYM_S | nb); stamp[f] |= 0x80000000u; stack.back() = lc; stack.push_back(rc); break; }
       }
     }
@@ -460,13 +460,54 @@ struct Shadow {
     }
     return n_seq;
   }
+
+  // the sequencer led by the Edgebreaker's own order: its walk runs (mostly) BACKWARDS along the traversal — half of its steps go from the face
+  // processed p-th to the one processed (p-1)-th, most others hop to the neighbouring loop and go on from there — so the face the traversal
+  // processed D steps before the current one is (about) what this walk reaches in D steps.  Visited flags ride in bit 30 of the stamps.
+  size_t sequence_oracle(uint32_t* seq) {
+    size_t n_seq = 0;
+    const int D = kShadowD;
+    uint64_t left = n_processed;
+    stack.clear();
+    constexpr uint32_t kSeq = 0x40000000u, kPos = 0x3FFFFFFFu;
+    auto emit = [&](uint32_t c) { const uint32_t v = c2v[c]; if (!(vvis[v] & 4)) { vvis[v] |= 4; seq[n_seq++] = c; } };
+    for (;;) {
+      uint32_t c;
+      if (!stack.empty()) { c = stack.back(); stack.pop_back(); }
+      else if (left) { --left; c = processed[left]; }
+      else break;
+      const uint32_t st = stamp[c / 3];
+      if (st & kSeq) continue;
+      pf(opp + c); pf(c2v + c);
+      const uint32_t nc = cnext(c), pc = cprev(c);
+      if (!(vvis[c2v[nc]] & 4) || !(vvis[c2v[pc]] & 4)) { emit(nc); emit(pc); stack.push_back(c); continue; }
+      {
+        const uint32_t p = (st & kPos);          // position in processed + 1 (interior start faces: the largest value — no oracle)
+        if (p > (uint32_t)D && p <= n_processed) { const uint32_t g = processed[p - 1 - D]; __builtin_prefetch(opp + g, 0, 3); __builtin_prefetch(c2v + g, 0, 3); __builtin_prefetch(stamp + g / 3, 1, 3); }
+      }
+      stamp[c / 3] = st | kSeq;
+      const uint32_t v = c2v[c];
+      pfb(vvis + v);
+      const uint32_t right = opp[nc], lft = opp[pc];
+      const uint8_t vflags = vvis[v];
+      if (!(vflags & 4)) {
+        emit(c);
+        if (!(vflags & 2)) { if (right != kNone) stack.push_back(right); continue; }
+      }
+      const bool rdone = right != kNone && (stamp[right / 3] & kSeq), ldone = lft != kNone && (stamp[lft / 3] & kSeq);
+      if (rdone) { if (!ldone && lft != kNone) stack.push_back(lft); }
+      else if (ldone) { if (right != kNone) stack.push_back(right); }
+      else { if (lft != kNone) stack.push_back(lft); if (right != kNone) stack.push_back(right); }
+    }
+    return n_seq;
+  }
   void edgebreaker() {
     n_processed = 0;
     for (uint32_t f = 0; f < F; ++f) {
       if (stamp[f]) continue;
       const uint32_t start = 3 * f;
       vvis[c2v[start]] |= 1; vvis[c2v[start + 1]] |= 1; vvis[c2v[start + 2]] |= 1;
-      stamp[f] = 0x7FFFFFFFu;
+      stamp[f] = 0x3FFFFFFFu;
       run_from(opp[cnext(start)]);
     }
   }
@@ -646,8 +687,9 @@ int main(int argc, char** argv) {
         Shadow h{F, V, opp, c2v, stamp, vvis, processedB, symB};
         double t0 = now_ms(); h.edgebreaker(); double t1 = now_ms();
         nS = h.n_processed; b0 = std::min(b0, t1 - t0);
-        std::memset(stamp2, 0, 4 * (size_t)F);
-        t0 = now_ms(); sS = h.sequence(seqB, stamp2, order); t1 = now_ms(); bs = std::min(bs, t1 - t0);
+        if (std::getenv("SEQ_OWN")) { std::memset(stamp2, 0, 4 * (size_t)F); t0 = now_ms(); sS = h.sequence(seqB, stamp2, order); t1 = now_ms(); }
+        else { t0 = now_ms(); sS = h.sequence_oracle(seqB); t1 = now_ms(); }
+        bs = std::min(bs, t1 - t0);
       }
       bool ok = nS == nA;
       for (size_t i = 0; ok && i < nA; ++i) ok = processedA[i] == processedB[i] && symA[i] == symB[i];
