@@ -218,6 +218,7 @@ struct EdgebreakerResult {
 // read (ct.att[] — built by another thread meanwhile — must be complete when it returns).
 struct EdgebreakerHooks { std::function<void()> seeds_ready, before_seams; };
 int run_edgebreaker(const CornerTables& ct, EdgebreakerResult& out, std::string& err, const EdgebreakerHooks* hooks = nullptr);
+extern std::atomic<uint64_t> g_eb_ns[6];   // (trace)
 
 // Attribute sequencer over a flat table view.
 struct TableRef {

@@ -222,6 +222,9 @@ struct ConnOwner {
 // thread time of the connectivity stage by step, summed over the meshes of a batch (trace): attribute tables, Edgebreaker (traversal +
 // connectivity bytes incl. the seam streams), universal sequencer, seam-table sequencers
 static std::atomic<uint64_t> g_conn_us[4];
+// set by a batch worker whose batch keeps every host thread busy with a mesh of its own: a large mesh then walks its steps one after the other on
+// its worker (the overlapped form starts three more threads per mesh — with 16 workers on 16 CPUs they only wait for each other)
+static thread_local bool g_batch_worker_busy = false;
 // pre (nullable): the universal table already built by the device stage; view_faces: c2p may view the caller's face array (it outlives `o`)
 static int build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std::vector<uint8_t>& bytes, const PrebuiltTable* pre = nullptr, bool view_faces = false) {
   if (!mesh || !mesh->atts || mesh->num_atts == 0 || (!mesh->faces && mesh->num_faces)) return fail(DMI_ERR_INVALID_ARGUMENT, "bad mesh");
@@ -261,7 +264,7 @@ static int build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std::vector<ui
   std::vector<const uint32_t*> maps;
   for (uint32_t i = 0; i < mesh->num_atts; ++i) if (mesh->atts[i].att_type != DMI_ATT_POSITION) maps.push_back(mesh->atts[i].point_to_value);
   o.ct.att.resize(maps.size());
-  const bool overlap = mesh->num_faces > 100000;
+  const bool overlap = mesh->num_faces > 100000 && !g_batch_worker_busy;
   double t_att = 0, t_eb = 0, t_seq = 0;
   o.views.resize(mesh->num_atts);
   o.seqs.resize(mesh->num_atts);
@@ -660,6 +663,7 @@ struct PrepGroup {
   hipEvent_t ev_tables_borrowed = nullptr;   // an adopted group's tables were issued by its build: the event belongs to the BuiltGroup
   bool tables_in = false;
   std::mutex wait_mutex;
+  std::atomic<int> issued{0};   // 1: phase 1 of this group is through (its fields are final, its tables on their way); -1: phase 1 failed — the walkers give up
   ~PrepGroup() {
     if (S) (void)hipStreamSynchronize(S);
     if (ev_tables) (void)hipEventDestroy(ev_tables);
@@ -832,7 +836,7 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
   hipStream_t S = holder->s;   // the coordinator's stream: job chunks are cleared on it, the deferred kernels of all jobs run on it
   struct SyncOnExit { hipStream_t s; ~SyncOnExit() { (void)hipStreamSynchronize(s); } } sync_on_exit{S};   // (also on error paths: a job the caller then destroys must not have its chunk cleared late)
   // ---- groups of ≈ 8M faces: the tables of the first arrive while the last is still being sent ----
-  static const uint64_t group_faces = std::getenv("DMI_PREP_GROUP_FACES") ? (uint64_t)std::atoll(std::getenv("DMI_PREP_GROUP_FACES")) : (uint64_t)(6u << 20);
+  static const uint64_t group_faces = std::getenv("DMI_PREP_GROUP_FACES") ? (uint64_t)std::atoll(std::getenv("DMI_PREP_GROUP_FACES")) : (uint64_t)(3u << 20);   // (measured, 256 meshes / 11M faces: 6M 21.5–22 ms, 3M 19.4–20.4, 1.5M 22.6–23.1)
   std::vector<std::unique_ptr<PrepGroup>> groups;
   std::vector<std::pair<uint32_t, uint32_t>> where(M);   // position in which_all → (group, index within the group)
   if (adopt) {
@@ -865,7 +869,8 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
   }
   for (uint32_t k = 0; k < M && !adopt; ++k) {
     const dmi_mesh& m = meshes[which_all[k]];
-    if (groups.empty() || groups.back()->total_faces + m.num_faces > group_faces) {
+    // (the first group is a third of the others: its tables — what the walkers wait for at the start of the call — arrive that much sooner)
+    if (groups.empty() || groups.back()->total_faces + m.num_faces > (groups.size() == 1 ? group_faces / 3 : group_faces)) {
       if (groups.empty() || groups.back()->total_faces) groups.emplace_back(new PrepGroup());
     }
     PrepGroup& g = *groups.back();
@@ -879,12 +884,12 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     g.which.push_back(which_all[k]);
     g.lay.push_back(std::move(l));
   }
-  auto parallel_over = [&](uint32_t count, const std::function<int(uint32_t, uint32_t)>& fn, const std::function<uint64_t(uint32_t)>& weight) -> int {   // fn(worker, i), heaviest first unless weight is null
+  auto parallel_over = [&](uint32_t count, const std::function<int(uint32_t, uint32_t)>& fn, const std::function<uint64_t(uint32_t)>& weight, uint32_t max_threads = 0) -> int {   // fn(worker, i), heaviest first unless weight is null
     std::vector<uint32_t> order(count);
     for (uint32_t k = 0; k < count; ++k) order[k] = k;
     if (weight) std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return weight(x) > weight(y); });
     std::atomic<uint32_t> next{0};
-    const uint32_t nt = std::max(1u, std::min(n_threads, count));
+    const uint32_t nt = std::max(1u, std::min(max_threads ? std::min(max_threads, n_threads) : n_threads, count));
     std::vector<int> rcs(nt, DMI_OK);
     std::vector<std::string> errs(nt);
     auto work = [&](uint32_t t) {
@@ -897,6 +902,120 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     return DMI_OK;
   };
   int rc;
+  // ---- phase 2 (set up here, started behind the first group's phase 1): host walks + job layout per mesh, group by group as their tables arrive ----
+  std::vector<std::unique_ptr<ConnOwner>> owners(M);
+  std::vector<JobDefer> defers(M);
+  std::vector<uint8_t> deferred(M, 0);
+  std::vector<uint32_t> walk_order(M);   // group order; inside a group the largest mesh first
+  for (uint32_t k = 0; k < M; ++k) walk_order[k] = k;
+  std::stable_sort(walk_order.begin(), walk_order.end(), [&](uint32_t x, uint32_t y) {
+    if (where[x].first != where[y].first) return where[x].first < where[y].first;
+    return meshes[which_all[x]].num_faces > meshes[which_all[y]].num_faces;
+  });
+  std::atomic<uint64_t> ns_wait{0}, ns_conn{0}, ns_job{0}, ns_buf{0};   // thread time by step (trace)
+  auto now_ns = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const std::function<int(uint32_t, uint32_t)> walk_one = [&](uint32_t t, uint32_t i) -> int {
+    const uint32_t kk = walk_order[i];
+    struct Busy { bool was = g_batch_worker_busy; ~Busy() { g_batch_worker_busy = was; } } busy;
+    g_batch_worker_busy = M >= 2 * n_threads && n_threads > 1;
+    PrepGroup& g = *groups[where[kk].first];
+    const uint32_t k = where[kk].second, j = g.which[k];
+    const dmi_mesh& m = meshes[j];
+    const uint64_t w0 = now_ns();
+    for (int st; (st = g.issued.load(std::memory_order_acquire)) != 1;) {   // (the coordinator is still packing / sending this group)
+      if (st < 0) return DMI_ERR_HIP;
+      std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    if (!g.adopted) {   // this mesh's values → staging → device, behind the group's table kernels on its stream
+      size_t lo = (size_t)-1, hi = 0;
+      for (uint32_t a = 0; a < m.num_atts; ++a) {
+        const dmi_attribute& at = m.atts[a];
+        const size_t vb = (size_t)at.num_unique * at.num_components * 4;
+        if (!vb) continue;
+        std::memcpy(g.hp + g.lay[k].values[a], at.values, vb);
+        lo = std::min(lo, g.lay[k].values[a]); hi = std::max(hi, g.lay[k].values[a] + vb);
+      }
+      if (hi > lo) HIP_TRY(hipMemcpyAsync(g.d_up + lo, g.hp + lo, hi - lo, hipMemcpyHostToDevice, g.S));
+    }
+    int r = g.wait_tables();
+    if (r) return r;
+    const uint64_t w1 = now_ns();
+    ns_wait += w1 - w0;
+    auto bail = [&](int code, const std::string& what) { return fail(code, "mesh " + std::to_string(j) + ": " + what); };
+    const uint8_t* hp = g.hp;
+    const uint32_t* h_words = reinterpret_cast<const uint32_t*>(hp + g.rb_words);
+    const uint32_t flags = h_words[g.lay[k].desc_index];
+    if (flags & CONN_BAD_INDEX) return bail(DMI_ERR_INVALID_ARGUMENT, "face index ≥ number of points, or a position value index out of range");
+    if (flags & (CONN_DEGENERATE | CONN_NONMANIFOLD_EDGE | CONN_MULTI_FAN)) return DMI_OK;   // the per-mesh path (the reference's serial walks)
+    if (flags & CONN_UNUSED_VERTEX) return bail(DMI_ERR_UNUSED_VERTICES, "mesh contains unused vertices");
+    PrebuiltTable pre;
+    const size_t cb = (size_t)g.lay[k].face_off * 3;
+    pre.c2v = g.lay[k].mapped ? reinterpret_cast<const uint32_t*>(hp + g.rb_c2v) + cb : m.faces;
+    pre.opp = reinterpret_cast<const uint32_t*>(hp + g.rb_opp) + cb;
+    pre.lmc = reinterpret_cast<const uint32_t*>(hp + g.rb_lmc) + g.lay[k].vert_off;
+    pre.on_boundary = hp + g.rb_onb + g.lay[k].vert_off;
+    pre.V = h_words[g.n_desc + g.lay[k].desc_index] + 1;
+    pre.no_boundary = !(flags & CONN_HAS_BOUNDARY);
+    {   // attribute tables the device built for this mesh (k_att_*)
+      uint32_t n_nonpos = 0;
+      for (uint32_t a = 0; a < m.num_atts; ++a) n_nonpos += m.atts[a].att_type != DMI_ATT_POSITION;
+      att_stage_fill(g.adopted ? g.adopted->conn.att : g.att, g.lay[k].desc_index, n_nonpos, pre.att);
+    }
+    owners[kk].reset(new ConnOwner());
+    ConnOwner& o = *owners[kk];
+    std::vector<uint8_t> bytes;
+    if ((r = build_connectivity(&m, o, bytes, &pre, /*view_faces=*/true))) return bail(r, g_last_error);
+    const uint64_t w2 = now_ns();
+    ns_conn += w2 - w1;
+    dmi_config c = cfg0;
+    c.device = device;
+    g_adopt_stream = worker_stream(t % kPrepareStreams, device);   // the job's own stream for its encodes
+    struct Drop { ~Drop() { g_adopt_stream.reset(); } } drop;
+    // (a mesh with attribute tables of its own — interior seams — is deferred like the others: its seam tables go up with the sequences)
+    static const bool defer_seams = !std::getenv("DMI_NO_DEFER_SEAMS");
+    bool all_universal = true;
+    for (uint32_t a = 1; a < m.num_atts; ++a) all_universal = all_universal && o.views[a].corner_to_vertex == o.views[0].corner_to_vertex && o.views[a].opposite == o.views[0].opposite;
+    if (all_universal || defer_seams) {
+      JobDefer& d = defers[kk];
+      d.stream = S;
+      d.values_dev.assign(m.num_atts, nullptr); d.maps_dev.assign(m.num_atts, nullptr);
+      for (uint32_t a = 0; a < m.num_atts; ++a) {
+        if (g.lay[k].values[a] != (size_t)-1) d.values_dev[a] = g.d_up + g.lay[k].values[a];
+        if (g.lay[k].maps[a] != (size_t)-1) d.maps_dev[a] = reinterpret_cast<const uint32_t*>(g.d_up + g.lay[k].maps[a]);
+      }
+      DeviceTableView view{g.d_faces + cb, g.d_c2v + cb, g.d_opp + cb, true};
+      // attribute tables the device built stay where they are: the batched relabelling reads them (key = the host copy the walks used)
+      std::vector<const uint32_t*> att_key, att_c2v, att_opp;
+      for (size_t q = 0; q < pre.att.size() && q < o.ct.att.size(); ++q)
+        if (pre.att[q].ready && pre.att[q].interior && !o.ct.att[q].c2v.empty()) { att_key.push_back(o.ct.att[q].c2v.data()); att_c2v.push_back(pre.att[q].d_c2v); att_opp.push_back(pre.att[q].d_opp); }
+      view.n_att = (uint32_t)att_key.size(); view.att_key = att_key.data(); view.att_c2v = att_c2v.data(); view.att_opp = att_opp.data();
+      r = job_create_impl(m.atts, o.views.data(), m.num_atts, nullptr, 0, &c, &view, &jobs[j], &d);
+      deferred[kk] = r == DMI_OK;
+    } else if (g.adopted) {   // an attribute table of its own, values resident in the built group: the universal table from the device, the seam tables from the host
+      std::vector<dmi_attribute> atts_dev(m.atts, m.atts + m.num_atts);
+      for (uint32_t a = 0; a < m.num_atts; ++a) atts_dev[a].values = g.lay[k].values[a] != (size_t)-1 ? static_cast<const void*>(g.d_up + g.lay[k].values[a]) : nullptr;
+      const DeviceTableView view{g.d_faces + cb, g.d_c2v + cb, g.d_opp + cb, true, true};
+      r = job_create_impl(atts_dev.data(), o.views.data(), m.num_atts, nullptr, 0, &c, &view, &jobs[j], nullptr);
+      owners[kk].reset();
+    } else {   // an attribute table of its own: the host relabelling form reads the tables where the walks read them
+      r = job_create_impl(m.atts, o.views.data(), m.num_atts, nullptr, 0, &c, nullptr, &jobs[j], nullptr);
+      owners[kk].reset();
+    }
+    if (r) return bail(r, g_last_error);
+    const uint64_t w3 = now_ns();
+    ns_job += w3 - w2;
+    if ((r = to_buffer(bytes, &heads[j]))) return r;
+    ns_buf += now_ns() - w3;
+    done[j] = 1;
+    return DMI_OK;
+  };
+  // The walkers start as soon as the FIRST group is on its way: the packing and sending of the later groups (a few threads of their own) runs
+  // beside the walks of the earlier ones (phase 1 used to finish for all groups first: 4–5 ms of a 20 ms prepare with every walker idle).
+  std::thread walkers;
+  int rc_walk = DMI_OK;
+  std::string err_walk;
+  struct JoinWalkers { std::thread& t; std::vector<std::unique_ptr<PrepGroup>>& gs; ~JoinWalkers() { if (t.joinable()) { for (auto& g : gs) { int z = 0; g->issued.compare_exchange_strong(z, -1); } t.join(); } } } join_walkers{walkers, groups};
+  auto pack_threads = [&]() -> uint32_t { return walkers.joinable() ? std::max(2u, n_threads / 4) : 0u; };   // (0 = all: nothing else runs yet)
   // ---- phase 1, group by group: layout, pack, send, build the tables, fetch them (nothing here waits for the device) ----
   for (size_t gi = 0; gi < groups.size(); ++gi) {
     PrepGroup& g = *groups[gi];
@@ -930,6 +1049,8 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
       g.hp = bg.conn.hp;
       g.rb_opp = bg.conn.rb_opp; g.rb_c2v = bg.conn.rb_c2v; g.rb_lmc = bg.conn.rb_lmc; g.rb_onb = bg.conn.rb_onb; g.rb_words = bg.conn.rb_words;
       g.ev_tables_borrowed = bg.conn.ev;
+      g.issued.store(1, std::memory_order_release);
+      if (!walkers.joinable() && M > 1) walkers = std::thread([&] { rc_walk = parallel_over(M, walk_one, nullptr); if (rc_walk) err_walk = g_last_error; });
       continue;
     }
     g.n_desc = Mg;
@@ -1033,7 +1154,7 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
             if (first) std::memcpy(hp + g.lay[k].maps[i], at.point_to_value, (size_t)at.num_points * 4);
           }
           return DMI_OK;
-        }, faces_of))) return rc;
+        }, faces_of, pack_threads()))) return rc;
     HIP_TRY(hipMemcpyAsync(g.d_up, hp, g.up_a, hipMemcpyHostToDevice, g.S));
     HIP_TRY(hipMemcpyAsync(d_desc, h_desc, (size_t)Mg * sizeof(ConnMeshDesc), hipMemcpyHostToDevice, g.S));
     a.meshes = d_desc; a.M = Mg; a.total_faces = (uint32_t)g.total_faces; a.total_verts = (uint32_t)g.total_verts;
@@ -1049,111 +1170,16 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     if ((rc = g.att.issue(a, g.mem, hp, g.S))) return rc;
     HIP_TRY(hipEventCreateWithFlags(&g.ev_tables, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(g.ev_tables, g.S));
-    // part B: the values, packed while the device builds the tables and sent behind their read-back
-    if ((rc = parallel_over(Mg, [&](uint32_t, uint32_t k) -> int {
-          const dmi_mesh& m = meshes[g.which[k]];
-          for (uint32_t i = 0; i < m.num_atts; ++i) {
-            const dmi_attribute& at = m.atts[i];
-            const size_t vb = (size_t)at.num_unique * at.num_components * 4;
-            if (vb) std::memcpy(hp + g.lay[k].values[i], at.values, vb);
-          }
-          return DMI_OK;
-        }, faces_of))) return rc;
-    if (g.up_b) HIP_TRY(hipMemcpyAsync(g.d_up + g.up_a, hp + g.up_a, g.up_b, hipMemcpyHostToDevice, g.S));
+    // part B (the values — more than half of the bytes) is packed and sent mesh by mesh by the walkers, first thing, while they would otherwise
+    // wait for this group's tables (walk_one): phase 1 — what every walker waits for — packs faces and maps only
     HIP_TRY(hipEventCreateWithFlags(&g.ev_values, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(g.ev_values, g.S));
+    g.issued.store(1, std::memory_order_release);
+    if (!walkers.joinable() && M > 1) walkers = std::thread([&] { rc_walk = parallel_over(M, walk_one, nullptr); if (rc_walk) err_walk = g_last_error; });
   }
   const double t_issue = ms();
-  // ---- phase 2: host walks + job layout per mesh, group by group as their tables arrive ----
-  std::vector<std::unique_ptr<ConnOwner>> owners(M);
-  std::vector<JobDefer> defers(M);
-  std::vector<uint8_t> deferred(M, 0);
-  std::vector<uint32_t> walk_order(M);   // group order; inside a group the largest mesh first
-  for (uint32_t k = 0; k < M; ++k) walk_order[k] = k;
-  std::stable_sort(walk_order.begin(), walk_order.end(), [&](uint32_t x, uint32_t y) {
-    if (where[x].first != where[y].first) return where[x].first < where[y].first;
-    return meshes[which_all[x]].num_faces > meshes[which_all[y]].num_faces;
-  });
-  std::atomic<uint64_t> ns_wait{0}, ns_conn{0}, ns_job{0}, ns_buf{0};   // thread time by step (trace)
-  auto now_ns = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  rc = parallel_over(M, [&](uint32_t t, uint32_t i) -> int {
-    const uint32_t kk = walk_order[i];
-    PrepGroup& g = *groups[where[kk].first];
-    const uint32_t k = where[kk].second, j = g.which[k];
-    const dmi_mesh& m = meshes[j];
-    const uint64_t w0 = now_ns();
-    int r = g.wait_tables();
-    if (r) return r;
-    const uint64_t w1 = now_ns();
-    ns_wait += w1 - w0;
-    auto bail = [&](int code, const std::string& what) { return fail(code, "mesh " + std::to_string(j) + ": " + what); };
-    const uint8_t* hp = g.hp;
-    const uint32_t* h_words = reinterpret_cast<const uint32_t*>(hp + g.rb_words);
-    const uint32_t flags = h_words[g.lay[k].desc_index];
-    if (flags & CONN_BAD_INDEX) return bail(DMI_ERR_INVALID_ARGUMENT, "face index ≥ number of points, or a position value index out of range");
-    if (flags & (CONN_DEGENERATE | CONN_NONMANIFOLD_EDGE | CONN_MULTI_FAN)) return DMI_OK;   // the per-mesh path (the reference's serial walks)
-    if (flags & CONN_UNUSED_VERTEX) return bail(DMI_ERR_UNUSED_VERTICES, "mesh contains unused vertices");
-    PrebuiltTable pre;
-    const size_t cb = (size_t)g.lay[k].face_off * 3;
-    pre.c2v = g.lay[k].mapped ? reinterpret_cast<const uint32_t*>(hp + g.rb_c2v) + cb : m.faces;
-    pre.opp = reinterpret_cast<const uint32_t*>(hp + g.rb_opp) + cb;
-    pre.lmc = reinterpret_cast<const uint32_t*>(hp + g.rb_lmc) + g.lay[k].vert_off;
-    pre.on_boundary = hp + g.rb_onb + g.lay[k].vert_off;
-    pre.V = h_words[g.n_desc + g.lay[k].desc_index] + 1;
-    pre.no_boundary = !(flags & CONN_HAS_BOUNDARY);
-    {   // attribute tables the device built for this mesh (k_att_*)
-      uint32_t n_nonpos = 0;
-      for (uint32_t a = 0; a < m.num_atts; ++a) n_nonpos += m.atts[a].att_type != DMI_ATT_POSITION;
-      att_stage_fill(g.adopted ? g.adopted->conn.att : g.att, g.lay[k].desc_index, n_nonpos, pre.att);
-    }
-    owners[kk].reset(new ConnOwner());
-    ConnOwner& o = *owners[kk];
-    std::vector<uint8_t> bytes;
-    if ((r = build_connectivity(&m, o, bytes, &pre, /*view_faces=*/true))) return bail(r, g_last_error);
-    const uint64_t w2 = now_ns();
-    ns_conn += w2 - w1;
-    dmi_config c = cfg0;
-    c.device = device;
-    g_adopt_stream = worker_stream(t % kPrepareStreams, device);   // the job's own stream for its encodes
-    struct Drop { ~Drop() { g_adopt_stream.reset(); } } drop;
-    // (a mesh with attribute tables of its own — interior seams — is deferred like the others: its seam tables go up with the sequences)
-    static const bool defer_seams = !std::getenv("DMI_NO_DEFER_SEAMS");
-    bool all_universal = true;
-    for (uint32_t a = 1; a < m.num_atts; ++a) all_universal = all_universal && o.views[a].corner_to_vertex == o.views[0].corner_to_vertex && o.views[a].opposite == o.views[0].opposite;
-    if (all_universal || defer_seams) {
-      JobDefer& d = defers[kk];
-      d.stream = S;
-      d.values_dev.assign(m.num_atts, nullptr); d.maps_dev.assign(m.num_atts, nullptr);
-      for (uint32_t a = 0; a < m.num_atts; ++a) {
-        if (g.lay[k].values[a] != (size_t)-1) d.values_dev[a] = g.d_up + g.lay[k].values[a];
-        if (g.lay[k].maps[a] != (size_t)-1) d.maps_dev[a] = reinterpret_cast<const uint32_t*>(g.d_up + g.lay[k].maps[a]);
-      }
-      DeviceTableView view{g.d_faces + cb, g.d_c2v + cb, g.d_opp + cb, true};
-      // attribute tables the device built stay where they are: the batched relabelling reads them (key = the host copy the walks used)
-      std::vector<const uint32_t*> att_key, att_c2v, att_opp;
-      for (size_t q = 0; q < pre.att.size() && q < o.ct.att.size(); ++q)
-        if (pre.att[q].ready && pre.att[q].interior && !o.ct.att[q].c2v.empty()) { att_key.push_back(o.ct.att[q].c2v.data()); att_c2v.push_back(pre.att[q].d_c2v); att_opp.push_back(pre.att[q].d_opp); }
-      view.n_att = (uint32_t)att_key.size(); view.att_key = att_key.data(); view.att_c2v = att_c2v.data(); view.att_opp = att_opp.data();
-      r = job_create_impl(m.atts, o.views.data(), m.num_atts, nullptr, 0, &c, &view, &jobs[j], &d);
-      deferred[kk] = r == DMI_OK;
-    } else if (g.adopted) {   // an attribute table of its own, values resident in the built group: the universal table from the device, the seam tables from the host
-      std::vector<dmi_attribute> atts_dev(m.atts, m.atts + m.num_atts);
-      for (uint32_t a = 0; a < m.num_atts; ++a) atts_dev[a].values = g.lay[k].values[a] != (size_t)-1 ? static_cast<const void*>(g.d_up + g.lay[k].values[a]) : nullptr;
-      const DeviceTableView view{g.d_faces + cb, g.d_c2v + cb, g.d_opp + cb, true, true};
-      r = job_create_impl(atts_dev.data(), o.views.data(), m.num_atts, nullptr, 0, &c, &view, &jobs[j], nullptr);
-      owners[kk].reset();
-    } else {   // an attribute table of its own: the host relabelling form reads the tables where the walks read them
-      r = job_create_impl(m.atts, o.views.data(), m.num_atts, nullptr, 0, &c, nullptr, &jobs[j], nullptr);
-      owners[kk].reset();
-    }
-    if (r) return bail(r, g_last_error);
-    const uint64_t w3 = now_ns();
-    ns_job += w3 - w2;
-    if ((r = to_buffer(bytes, &heads[j]))) return r;
-    ns_buf += now_ns() - w3;
-    done[j] = 1;
-    return DMI_OK;
-  }, nullptr);
+  if (walkers.joinable()) { walkers.join(); rc = rc_walk; if (rc) fail(rc, err_walk); }
+  else rc = parallel_over(M, walk_one, nullptr);   // (one mesh)
+  for (auto& g : groups) if (!rc && g->ev_values) HIP_TRY(hipEventRecord(g->ev_values, g->S));   // (behind the last of the walkers' value copies)
   if (rc) return rc;   // (the groups' destructors wait for their streams)
   const double t_walks = ms();
   // ---- phase 3: all deferred device work: sequences up in one copy, then one launch per kernel on the coordinator's stream ----
@@ -1249,6 +1275,8 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
                          ns_wait.load() / 1e6, ns_conn.load() / 1e6, ns_job.load() / 1e6, ns_buf.load() / 1e6);
     std::fprintf(stderr, "[dmi]   connectivity thread time: attribute tables %.1f ms, Edgebreaker + connectivity bytes %.1f, universal sequencer (+ views) %.1f, rest %.1f\n",
                  g_conn_us[0].exchange(0) / 1e3, g_conn_us[1].exchange(0) / 1e3, g_conn_us[2].exchange(0) / 1e3, g_conn_us[3].exchange(0) / 1e3);
+    std::fprintf(stderr, "[dmi]   Edgebreaker thread time by step (%llu meshes): set-up %.2f ms, traversal %.2f, symbols → bits %.2f, seam streams %.2f; whole call incl. its destructors %.2f\n", (unsigned long long)g_eb_ns[4].exchange(0),
+                 g_eb_ns[0].exchange(0) / 1e6, g_eb_ns[1].exchange(0) / 1e6, g_eb_ns[2].exchange(0) / 1e6, g_eb_ns[3].exchange(0) / 1e6, g_eb_ns[5].exchange(0) / 1e6);
   }
   return DMI_OK;
 }

@@ -17,6 +17,8 @@
 
 #include "dmi_device.hpp"
 #include "dmi_host.hpp"
+#include <memory>
+#include <mutex>
 #include "host_chains.hpp"
 
 namespace dmi {
@@ -172,37 +174,65 @@ bool host_rabs_bytes(uint8_t zero_prob, const uint8_t* fed, uint64_t n, std::vec
 // period of 1409 steps and one byte.  The first window of steps runs as the coder runs them, the period is read off the recorded states, the
 // rest of the stream is the period's bytes over and over; a window without a repeat falls back to the plain loop.  Same bytes as
 // host_rabs_bytes on n equal bits (tests/test_host_chains.py).
-bool host_rabs_constant(uint8_t zero_prob, uint32_t bit, uint64_t n, std::vector<uint8_t>& bytes) {
+// The window (states, byte offsets, bytes, period) depends on (zero_prob, bit) alone — and the stream every seam-free attribute of every mesh gets is
+// the same one (all zeros at zero_prob 255) — so it is computed once per process and shared: a call then copies its bytes (a batch of 256 meshes
+// spent 21 ms of thread time re-running the 16 K-step window per mesh).
+namespace {
+struct ConstantWindow {
+  std::vector<uint32_t> xs, ob;   // state before step i, bytes written before step i (i = 0 … W)
+  std::vector<uint8_t> bytes;     // the bytes of the first W steps
+  uint64_t period = 0;            // 0: no repeat inside the window
+  HostRec h;
+};
+inline uint32_t constant_step(const HostRec& h, uint32_t x, std::vector<uint8_t>& out) {   // host_rabs_chain's generic loop body
+  if (x >= h.t) { out.push_back((uint8_t)x); x >>= 8; }
+  const uint32_t q = (h.flags & 0x100u) ? x : quot(x, h.m64);
+  return x + q * h.d + h.c;
+}
+constexpr uint64_t kConstantWindow = 1u << 14;
+std::shared_ptr<const ConstantWindow> constant_window(uint8_t zero_prob, uint32_t bit) {
+  static std::mutex m;
+  static std::shared_ptr<const ConstantWindow> cache[512];
+  const size_t key = (size_t)zero_prob | (bit ? 256u : 0u);
+  {
+    std::lock_guard<std::mutex> lock(m);
+    if (cache[key]) return cache[key];
+  }
+  auto w = std::make_shared<ConstantWindow>();
   const uint32_t p0 = zero_prob, f1 = 256u - p0;
-  const HostRec h = host_rec(bit ? make_rans_entry(f1, 0, 8) : make_rans_entry(p0, f1, 8));
-  auto step = [&](uint32_t x, std::vector<uint8_t>& out) {   // host_rabs_chain's generic loop body
-    if (x >= h.t) { out.push_back((uint8_t)x); x >>= 8; }
-    const uint32_t q = (h.flags & 0x100u) ? x : quot(x, h.m64);
-    return x + q * h.d + h.c;
-  };
-  constexpr uint64_t kWindow = 1u << 14;
-  const uint64_t W = std::min<uint64_t>(n, kWindow);
-  std::vector<uint32_t> xs((size_t)W + 1), ob((size_t)W + 1);
-  bytes.clear();
+  w->h = host_rec(bit ? make_rans_entry(f1, 0, 8) : make_rans_entry(p0, f1, 8));
+  const uint64_t W = kConstantWindow;
+  w->xs.resize((size_t)W + 1); w->ob.resize((size_t)W + 1);
   uint32_t x = 4096u;
-  for (uint64_t i = 0; i < W; ++i) { xs[(size_t)i] = x; ob[(size_t)i] = (uint32_t)bytes.size(); x = step(x, bytes); }
-  xs[(size_t)W] = x; ob[(size_t)W] = (uint32_t)bytes.size();
+  for (uint64_t i = 0; i < W; ++i) { w->xs[(size_t)i] = x; w->ob[(size_t)i] = (uint32_t)w->bytes.size(); x = constant_step(w->h, x, w->bytes); }
+  w->xs[(size_t)W] = x; w->ob[(size_t)W] = (uint32_t)w->bytes.size();
+  for (uint64_t l = 1; l <= W; ++l) if (w->xs[(size_t)(W - l)] == x) { w->period = l; break; }
+  std::lock_guard<std::mutex> lock(m);
+  if (!cache[key]) cache[key] = w;
+  return cache[key];
+}
+}  // namespace
+bool host_rabs_constant(uint8_t zero_prob, uint32_t bit, uint64_t n, std::vector<uint8_t>& bytes) {
+  const std::shared_ptr<const ConstantWindow> cw = constant_window(zero_prob, bit);
+  const ConstantWindow& w = *cw;
+  const uint64_t W = std::min<uint64_t>(n, kConstantWindow);
+  bytes.assign(w.bytes.begin(), w.bytes.begin() + (long)w.ob[(size_t)W]);
+  uint32_t x = w.xs[(size_t)W];
   uint64_t left = n - W;
-  if (left) {
-    uint64_t period = 0;
-    for (uint64_t l = 1; l <= W; ++l) if (xs[(size_t)(W - l)] == x) { period = l; break; }
+  if (left) {   // (W = the whole window here)
+    const uint64_t period = w.period;
     if (period) {
-      const size_t from = ob[(size_t)(W - period)], per_bytes = ob[(size_t)W] - from;
+      const size_t from = w.ob[(size_t)(W - period)], per_bytes = w.ob[(size_t)W] - from;
       const uint64_t reps = left / period, rem = left % period;
-      const std::vector<uint8_t> cycle(bytes.begin() + (long)from, bytes.begin() + (long)(from + per_bytes));
+      const uint8_t* cycle = w.bytes.data() + from;
       bytes.reserve(bytes.size() + (size_t)reps * per_bytes + per_bytes + 8);
       if (per_bytes == 1) bytes.insert(bytes.end(), (size_t)reps, cycle[0]);
-      else for (uint64_t r = 0; r < reps; ++r) bytes.insert(bytes.end(), cycle.begin(), cycle.end());
-      const size_t tail = ob[(size_t)(W - period + rem)] - from;
-      bytes.insert(bytes.end(), cycle.begin(), cycle.begin() + (long)tail);
-      x = xs[(size_t)(W - period + rem)];
+      else for (uint64_t r = 0; r < reps; ++r) bytes.insert(bytes.end(), cycle, cycle + per_bytes);
+      const size_t tail = w.ob[(size_t)(W - period + rem)] - from;
+      bytes.insert(bytes.end(), cycle, cycle + tail);
+      x = w.xs[(size_t)(W - period + rem)];
     } else {
-      for (uint64_t i = 0; i < left; ++i) x = step(x, bytes);
+      for (uint64_t i = 0; i < left; ++i) x = constant_step(w.h, x, bytes);
     }
   }
   uint8_t fl[4];

@@ -438,6 +438,8 @@ void CornerTables::finish_attribute(AttTable& a, const std::vector<uint8_t>& vse
 // ------------------------------------------------------------------------------------------------
 namespace {
 enum : uint8_t { SYM_C, SYM_S, SYM_L, SYM_R, SYM_E };
+// set bits of a three-bit edge mask (the generic x86-64 target has no popcnt: __builtin_popcount is a dozen instructions — 2 ns per face of a batch's seam stage)
+static const uint8_t kBits3[8] = {0, 1, 1, 2, 1, 2, 2, 3};
 // Adjacent-line prefetch for the serial walks.  An Edgebreaker spiral (and the sequencer's depth-first walk) sweeps a front across the
 // mesh: the entries a loop of the front touches lie next to — in memory: in the same or the neighbouring cache line of — the entries the
 // previous loop touched.  Touching line L therefore asks for L−1 and L+1 as well: when the front reaches them, a loop later, they wait in
@@ -675,7 +677,10 @@ uint8_t zero_probability(uint64_t count_zero, float denominator) {
   return (uint8_t)std::min(255u, std::max(1u, q));
 }
 
+std::atomic<uint64_t> g_eb_ns[6];   // trace: thread time of run_edgebreaker by step over all meshes (set-up, traversal, bits, seam streams, count)
 int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& err, const EdgebreakerHooks* hooks) {
+  const bool trace_all = std::getenv("DMI_TRACE") != nullptr;
+  struct Whole { bool on; std::chrono::steady_clock::time_point a = std::chrono::steady_clock::now(); ~Whole() { if (on) g_eb_ns[5] += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - a).count(); } } whole{trace_all};   // (declared first: its destructor runs after every other local's)
   const bool trace = t.F > 100000 && std::getenv("DMI_TRACE") != nullptr;
   auto tick = [] { return std::chrono::steady_clock::now(); };
   auto since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
@@ -726,12 +731,24 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
   {   // DefaultTraversal::encode :575-656 — CLERS bits, reversed, LSB-first
     static const uint8_t len[5] = {1, 3, 3, 3, 3};
     static const uint8_t code[5] = {0, 0b1, 0b11, 0b101, 0b111};
-    Pooled<uint8_t> bits_p(w.symbols.size() / 2 + 8);
+    // (a 64-bit window written four bytes at a time into an array sized for three bits per symbol: a push_back per byte was 1 ns per face)
+    const size_t n_sym = w.symbols.size();
+    Pooled<uint8_t> bits_p((3 * n_sym + 7) / 8 + 16);
     std::vector<uint8_t>& bits = bits_p.v;
-    bits.reserve(w.symbols.size() / 2 + 8);
-    BitPackerLsb bp(bits);
-    for (size_t i = w.symbols.size(); i-- > 0;) bp.put(len[w.symbols[i] & 7], code[w.symbols[i] & 7]);
-    bp.flush();
+    if (bits.capacity() < (3 * n_sym + 7) / 8 + 16) bits.reserve((3 * n_sym + 7) / 8 + 16);
+    uint8_t* const bp = bits.data();
+    const uint8_t* const sym = w.symbols.data();
+    uint64_t acc = 0;
+    unsigned nb = 0;
+    size_t at = 0;
+    for (size_t i = n_sym; i-- > 0;) {
+      const unsigned k = sym[i] & 7u;
+      acc |= (uint64_t)code[k] << nb;
+      nb += len[k];
+      if (nb >= 32) { const uint32_t lo = (uint32_t)acc; std::memcpy(bp + at, &lo, 4); at += 4; acc >>= 32; nb -= 32; }
+    }
+    for (; nb > 0; nb = nb > 8 ? nb - 8 : 0) { bp[at++] = (uint8_t)acc; acc >>= 8; }
+    set_size_written(bits, at);
     s.leb128(bits.size());
     s.bytes(bits);
   }
@@ -825,7 +842,7 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
           for (size_t i = lo; i < hi;) {
             const size_t end = std::min(hi, (i / kChunk + 1) * kChunk);
             uint64_t k = 0;
-            for (size_t j = i; j < end; ++j) { mask[j] = (uint8_t)mask_of(j); k += (uint64_t)__builtin_popcount(mask[j]); }
+            for (size_t j = i; j < end; ++j) { mask[j] = (uint8_t)mask_of(j); k += (uint64_t)kBits3[mask[j] & 7u]; }
             acc[i / kChunk].fetch_add(k);
             i = end;
           }
@@ -838,7 +855,7 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
       for (auto& a : zacc) a.store(0);
       if (!own.empty()) parallel_for(n, [&](size_t lo, size_t hi) {
         uint64_t pos = chunk_sum[lo / kChunk];
-        for (size_t j = (lo / kChunk) * kChunk; j < lo; ++j) pos += (uint64_t)__builtin_popcount(mask[j]);
+        for (size_t j = (lo / kChunk) * kChunk; j < lo; ++j) pos += (uint64_t)kBits3[mask[j] & 7u];
         std::vector<uint64_t> z(A, 0);
         for (size_t i = lo; i < hi; ++i) {
           const uint32_t c = processed[i];
@@ -853,7 +870,7 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
       });
       for (size_t j = 0; j < A; ++j) zeros[j] = zacc[j].load();
     } else if (A && own.empty() && masks_ok) {   // no attribute has seams of its own: only the stream length — the edges the traversal recorded
-      for (size_t i = 0; i < n; ++i) total += (uint64_t)__builtin_popcount((unsigned)(w.symbols[i] >> 4));
+      for (size_t i = 0; i < n; ++i) total += (uint64_t)kBits3[(w.symbols[i] >> 4) & 7u];
     } else if (A && own.empty() && [&] {   // a small mesh without seams: only the stream length — every face processed once ⇒ the interior-edge count
                  std::vector<uint8_t> seen(t.F, 0);
                  for (size_t i = 0; i < n; ++i) { uint8_t& f = seen[processed[i] / 3]; if (f) return false; f = 1; }
@@ -921,6 +938,7 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
       s.bytes(coded[from]);
     }
   }
+  if (trace_all) { g_eb_ns[0] += (uint64_t)(t_ctor * 1e6); g_eb_ns[1] += (uint64_t)((t_walk - t_ctor) * 1e6); g_eb_ns[2] += (uint64_t)((t_bits - t_walk) * 1e6); g_eb_ns[3] += (uint64_t)((since(t0) - t_wait) * 1e6); g_eb_ns[4] += 1; }
   if (trace) std::fprintf(stderr, "[dmi]   Edgebreaker of %u faces: boundaries + traversal %.1f ms, seeds + CLERS bits %.1f, wait for the seam flags %.1f, seam streams %.1f\n", t.F, t_walk,
                           t_bits - t_walk, t_wait - t_bits, since(t0) - t_wait);
   out.connectivity.swap(s.b);

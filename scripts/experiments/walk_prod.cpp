@@ -42,7 +42,7 @@ int main(int argc, char** argv) {
   for (size_t c = C; c-- > 0;) lmc[c2v[c]] = (uint32_t)c;
   for (int r = 0; r < repeats; ++r) {
     CornerTables t;
-    t.F = F; t.V = V; t.c2p = c2v; t.c2v = c2v; t.opp = opp; t.lmc = lmc; t.no_boundary = true;
+    t.F = F; t.V = V; t.c2p = c2v; t.c2v = c2v; t.opp = opp; t.lmc = lmc; t.no_boundary = true; t.att.resize(2);
     EdgebreakerResult eb;
     std::string err;
     double t0 = now_ms();
@@ -55,6 +55,7 @@ int main(int argc, char** argv) {
     double t2 = now_ms();
     std::printf("library walks on this program's tables: run_edgebreaker %.1f ms (rc %d, %zu bytes), attribute_sequence %.1f ms (%zu entries)\n", t1 - t0, rc, eb.connectivity.size(), t2 - t1, seq.size());
   }
+  if (std::getenv("DMI_TRACE")) std::printf("thread time by step over %llu calls: set-up %.3f ms, traversal %.3f, bits %.3f, seam streams %.3f, whole %.3f\n", (unsigned long long)g_eb_ns[4].load(), g_eb_ns[0] / 1e6, g_eb_ns[1] / 1e6, g_eb_ns[2] / 1e6, g_eb_ns[3] / 1e6, g_eb_ns[5] / 1e6);
   if (std::FILE* f = std::fopen("/proc/self/smaps_rollup", "r")) {
     char line[256];
     while (std::fgets(line, sizeof line, f)) if (!std::strncmp(line, "Rss", 3) || !std::strncmp(line, "AnonHuge", 8)) std::fputs(line, stdout);
