@@ -68,16 +68,46 @@ struct NumaPin {
   NumaPin& operator=(const NumaPin&) = delete;
 };
 
-// A library stream per (host thread, device) for the connectivity stage of a whole-mesh call — and, adopted, for the job it creates
-// (hipStreamCreate costs ≈ 1 ms and serialises across threads).
-std::shared_ptr<StreamHolder> thread_stream(int device) {
-  static thread_local std::vector<std::pair<int, std::shared_ptr<StreamHolder>>> mine;
-  for (auto& e : mine) if (e.first == device) return e.second;
-  auto h = std::make_shared<StreamHolder>();
-  if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->s) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-  mine.push_back({device, h});
-  return h;
-}
+// Library streams of a host thread outlive it: a thread takes them from a process-wide pool on first use and its exit hands them back (they are not
+// destroyed).  Work recorded on them can be waited for by ANOTHER thread later — a transcode pipeline's build thread records a group's table
+// event and may be gone when the prepare thread waits for it: with the stream destroyed the runtime's hipEventSynchronize answered "event
+// last recorded in a capturing stream" once in twenty calls — and hipStreamCreate (≈ 1 ms, serialised across threads) is paid once per stream,
+// not once per pipeline thread.  kind 0: the thread's stream (connectivity stage of a whole-mesh call, adopted by the job it creates);
+// kinds 1 / 2: the two group streams (non-blocking).
+namespace {
+struct StreamPool {
+  std::mutex m;
+  std::vector<std::pair<int, std::shared_ptr<StreamHolder>>> idle[3];
+  static StreamPool& get() { static StreamPool* p = new StreamPool(); return *p; }   // (never destroyed: threads may exit after static destruction began)
+};
+struct ThreadStreams {
+  std::vector<std::pair<int, std::shared_ptr<StreamHolder>>> mine[3];
+  ~ThreadStreams() {
+    StreamPool& pool = StreamPool::get();
+    std::lock_guard<std::mutex> lock(pool.m);
+    for (int k = 0; k < 3; ++k) for (auto& e : mine[k]) pool.idle[k].push_back(std::move(e));
+  }
+  std::shared_ptr<StreamHolder> get(int kind, int device) {
+    for (auto& e : mine[kind]) if (e.first == device) return e.second;
+    std::shared_ptr<StreamHolder> h;
+    {
+      StreamPool& pool = StreamPool::get();
+      std::lock_guard<std::mutex> lock(pool.m);
+      auto& idle = pool.idle[kind];
+      for (size_t i = 0; i < idle.size(); ++i) if (idle[i].first == device) { h = std::move(idle[i].second); idle.erase(idle.begin() + (long)i); break; }
+    }
+    if (!h) {
+      h = std::make_shared<StreamHolder>();
+      const hipError_t e = hipSetDevice(device) != hipSuccess ? hipErrorInvalidDevice : (kind == 0 ? hipStreamCreate(&h->s) : hipStreamCreateWithFlags(&h->s, hipStreamNonBlocking));
+      if (e != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    }
+    mine[kind].push_back({device, h});
+    return h;
+  }
+};
+ThreadStreams& thread_streams() { static thread_local ThreadStreams t; return t; }
+}  // namespace
+std::shared_ptr<StreamHolder> thread_stream(int device) { return thread_streams().get(0, device); }
 
 // The universal corner table of a mesh as the device connectivity stage built it, read back for the host's serial walks (pinned staging).
 struct PrebuiltTable {
@@ -622,12 +652,8 @@ int dmi_shard_meshes(const dmi_mesh* meshes, uint32_t n, uint32_t n_devices, int
 // Two more library streams per (host thread, device): consecutive groups of a slice alternate between them, so the read-back of one
 // group's tables overlaps the upload of the next group's faces (the two directions of the link run side by side).
 static hipStream_t group_stream(int device, int which) {
-  static thread_local std::vector<std::pair<int, std::shared_ptr<StreamHolder>>> mine[2];
-  for (auto& e : mine[which]) if (e.first == device) return e.second->s;
-  auto h = std::make_shared<StreamHolder>();
-  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-  mine[which].push_back({device, h});
-  return h->s;
+  const std::shared_ptr<StreamHolder> h = thread_streams().get(1 + (which & 1), device);
+  return h ? h->s : nullptr;
 }
 
 extern "C++" {
@@ -867,7 +893,12 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     }
     if (k != M) return fail(DMI_ERR_INVALID_ARGUMENT, "adopted groups: member count");
   }
-  for (uint32_t k = 0; k < M && !adopt; ++k) {
+  // (host meshes are dealt into groups largest first: the longest walks start first — the walkers take group after group — and none is left for the end)
+  std::vector<uint32_t> by_size(adopt ? 0 : M);
+  for (uint32_t k = 0; k < (uint32_t)by_size.size(); ++k) by_size[k] = k;
+  std::stable_sort(by_size.begin(), by_size.end(), [&](uint32_t x, uint32_t y) { return meshes[which_all[x]].num_faces > meshes[which_all[y]].num_faces; });
+  for (uint32_t kq = 0; kq < M && !adopt; ++kq) {
+    const uint32_t k = by_size[kq];
     const dmi_mesh& m = meshes[which_all[k]];
     // (the first group is a third of the others: its tables — what the walkers wait for at the start of the call — arrive that much sooner)
     if (groups.empty() || groups.back()->total_faces + m.num_faces > (groups.size() == 1 ? group_faces / 3 : group_faces)) {
