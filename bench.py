@@ -56,6 +56,21 @@ def usable_cpus():
     return n
 
 
+def profiled_traffic():
+    """The pass's HBM traffic as the last committed profiling session measured it (profiles/round*_bench.json: FETCH_SIZE / WRITE_SIZE in separate
+    rocprofv3 --pmc passes, scripts/profile_round.sh) — NOT measured in this run (`traffic` is, when the run is part of such a session)."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round*_bench.json"))):
+        try:
+            t = json.load(open(path)).get("roofline", {}).get("traffic")
+        except (OSError, ValueError):
+            continue
+        if t:
+            best = {"bytes": int(t), "source": "profiles/" + os.path.basename(path), "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of that session (profiles/round*_pmc_traffic.csv)"}
+    return best
+
+
 def cpu_baseline(mesh):
     """Reference algorithm on one host core: the oracle (CPU restatement, kind "port"), timed on the SAME mesh and the SAME scope as
     `value` (whole `.drc`), with the per-stage split of BASELINE.md §3.  The reference's own complexity (`faithful`: linear `contains`
@@ -407,6 +422,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                          "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBPS, 5), "achievable_gbps": HBM_ACHIEVABLE_GBPS,
                          "traffic": int(traffic) if traffic else None,
+                         "traffic_profiled": profiled_traffic(),
                          "kernel": "quantize+predict pass = every launch between the first kernel and the histogram stage of one step "
                                    "(value ranges, coding-order gather + quantize, min/max finals, fused predictor sweep), hipEvent-timed on the stream the job launches on, inside the timed steps",
                          "algorithmic_bytes": int(tm["predict_bytes"]), "duration_ms": round(pass_ms, 4),

@@ -28,7 +28,7 @@ import numpy as np
 
 import threading
 
-from .binding import (ATT_CUSTOM, ATT_NORMAL, ATT_POSITION, ATT_TEXCOORD, DOMAIN_CORNER, DOMAIN_POSITION, Config, MeshBuilder, RawMesh, built_meshes_prepare, device_count,
+from .binding import (jobs_encode_raw, ATT_CUSTOM, ATT_NORMAL, ATT_POSITION, ATT_TEXCOORD, DOMAIN_CORNER, DOMAIN_POSITION, Config, MeshBuilder, RawMesh, built_meshes_prepare, device_count,
                       jobs_encode, jobs_encode_devices, last_build_timings, meshes_build, meshes_prepare, meshes_prepare_devices, shard_meshes, thread_host_threads)
 
 _COMPONENTS = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4}
@@ -55,8 +55,9 @@ def read_glb(data, copy=True):
     return doc, binary
 
 
-def write_glb(doc, binary):
-    """GLB container around `doc` and the BIN chunk — bytes, or a list of byte pieces (joined here, ONE copy of the chunk)."""
+def write_glb(doc, binary, with_bin_offset=False):
+    """GLB container around `doc` and the BIN chunk — bytes, or a list of byte pieces (any buffers; joined here, ONE copy of the chunk).
+    with_bin_offset: returns (glb, offset of the chunk's payload in it)."""
     js = json.dumps(doc, separators=(",", ":")).encode("utf-8")
     js_pad = b" " * ((4 - len(js) % 4) % 4)                   # JSON chunk is space padded (encode.rs:392-396)
     pieces = list(binary) if isinstance(binary, (list, tuple)) else [binary]
@@ -67,7 +68,8 @@ def write_glb(doc, binary):
     parts = [struct.pack("<4sII", b"glTF", 2, total), struct.pack("<II", n_js, 0x4E4F534A), js, js_pad]
     if n_bin:
         parts += [struct.pack("<II", n_bin, 0x004E4942)] + pieces + [bin_pad]
-    return b"".join(parts)
+    glb = b"".join(parts)
+    return (glb, 12 + 8 + n_js + 8) if with_bin_offset else glb
 
 
 def _buffer_of(binary, view):
@@ -285,7 +287,9 @@ def _collect(doc, buffers):
 def _assemble(doc, buffers, prims, results):
     """The output GLB of one document.  prims = [(prim, names, …)], results = [(blob, num_faces, num_points) or None] per primitive
     (None: the built mesh has no face — encode.rs:934-936 leaves such a primitive alone).  Compressed primitives get placeholder
-    accessors + the extension, every other bufferView (of any input buffer) is carried over into the single BIN chunk."""
+    accessors + the extension, every other bufferView (of any input buffer) is carried over into the single BIN chunk.  A blob may be a tuple of
+    pieces (header + connectivity bytes, a view of the library-owned attribute section): they meet for the first time in the output file.
+    Returns (glb bytes, [blob, ...]) — the blobs as views into the GLB (no second copy of them)."""
     replaced = set()
     for (prim, names, *_), res in zip(prims, results):
         if res is None:
@@ -298,8 +302,13 @@ def _assemble(doc, buffers, prims, results):
     pad = (b"", b"\0", b"\0\0", b"\0\0\0")
 
     def put(chunk):
-        pieces.append(chunk)
-        size[0] += len(chunk)
+        if isinstance(chunk, tuple):
+            for c in chunk:
+                pieces.append(c)
+                size[0] += len(c)
+        else:
+            pieces.append(chunk)
+            size[0] += len(chunk)
         if size[0] % 4:
             p = pad[4 - size[0] % 4]
             pieces.append(p)
@@ -327,6 +336,7 @@ def _assemble(doc, buffers, prims, results):
         if "bufferView" in img:
             img["bufferView"] = carry(img["bufferView"])
     any_compressed = False
+    spans = []                                                                   # (start, end) of every blob in the BIN chunk
     for (prim, names, *_), res in zip(prims, results):
         if res is None:
             continue
@@ -334,6 +344,7 @@ def _assemble(doc, buffers, prims, results):
         any_compressed = True
         start = size[0]
         put(blob)
+        spans.append((start, start + (sum(len(c) for c in blob) if isinstance(blob, tuple) else len(blob))))
         new_views.append({"buffer": 0, "byteOffset": start, "byteLength": size[0] - start})    # length includes the pad
         # AttributeId = add order = `names` order (the built mesh has Position in slot 0, ids unchanged: builder.rs:115-125)
         ext = {"bufferView": len(new_views) - 1, "attributes": {n: k for k, n in enumerate(names)}}
@@ -349,7 +360,9 @@ def _assemble(doc, buffers, prims, results):
             lst = doc.setdefault(key, [])
             if "KHR_draco_mesh_compression" not in lst:
                 lst.append("KHR_draco_mesh_compression")
-    return write_glb(doc, pieces)
+    glb, at = write_glb(doc, pieces, with_bin_offset=True)
+    mv = memoryview(glb)
+    return glb, [mv[at + a: at + b] for a, b in spans]
 
 
 def _chunks_by_weight(weights, limit, ramp=False):
@@ -449,13 +462,15 @@ def stage_triangles(total):
     return PIPELINE_TRIANGLES or min(12 << 20, max(3 << 20, total // 4))
 
 
-def encode_raw_batch(raws, cfg=None, pipeline=True, timings=None, weights=None, on_done=None):
+def encode_raw_batch(raws, cfg=None, pipeline=True, timings=None, weights=None, on_done=None, keep=None):
     """RawMesh list → [(blob, num_faces, num_points) or None (no face left)] on ONE device: dmi_meshes_build → dmi_built_meshes_prepare →
     dmi_jobs_encode, in stages of stage_triangles() triangles: the build of stage k+2, the prepare of stage k+1 and the encode of stage k
     run side by side (three threads; the host walks of the prepare are the longest step and keep the host's cores, the build's packing and
     the encode's read-back fit beside them).  `raws` may be a callable i → RawMesh (made when its stage is built: the accessor views of
     stage k+2 are set up beside the device work of the earlier stages) together with `weights` (triangles per primitive).
-    on_done(indices, out) (optional): a fourth stage, called with the primitives of every finished stage (the caller reassembles files)."""
+    on_done(indices, out) (optional): a fourth stage, called with the primitives of every finished stage (the caller reassembles files).
+    keep (optional list): zero-copy form — a blob is then the tuple (header + connectivity bytes, uint8 view of the library-owned attribute section) and
+    the stage's EncodedBatch is appended to `keep`: the caller frees them once the views have been used (two 80 MB copies under the interpreter lock less)."""
     cfg = cfg or Config.default()
     make = raws if callable(raws) else None
     n = len(weights) if make else len(raws)
@@ -518,9 +533,15 @@ def encode_raw_batch(raws, cfg=None, pipeline=True, timings=None, weights=None, 
         jobs, where, info = mid[:3]
         t0 = time.perf_counter()
         try:
-            sections = jobs_encode(jobs) if jobs else []
-            for j, s, i, (nf, npts, _) in zip(jobs, sections, where, info):
-                out[i] = (j.header_and_connectivity + s, nf, npts)
+            if keep is not None and jobs:
+                raw = jobs_encode_raw(jobs)
+                keep.append(raw)
+                for k, (j, i, (nf, npts, _)) in enumerate(zip(jobs, where, info)):
+                    out[i] = ((j.header_and_connectivity, raw.view(k)), nf, npts)
+            else:
+                sections = jobs_encode(jobs) if jobs else []
+                for j, s, i, (nf, npts, _) in zip(jobs, sections, where, info):
+                    out[i] = (j.header_and_connectivity + s, nf, npts)
         finally:
             for j in jobs:
                 j.close()
@@ -611,7 +632,8 @@ def transcode_files(sources, cfg=None, devices=None, group=None, device=None, pi
     primitives of ALL files go through the device together: encode_raw_batch).  One GPU, `devices` GPUs of this process (each takes a
     share by triangle count, a thread per device), or the ranks of a torch.distributed job: the primitives are dealt by the triangle
     counts the JSON states, each rank builds and encodes ONLY its share, rank 0 gathers the blobs and reassembles the files.
-    Returns [(glb_bytes, [blob, ...]), ...] in input order — on the destination rank; None on the other ranks of a sharded job.
+    Returns [(glb_bytes, [blob, ...]), ...] in input order — on the destination rank; None on the other ranks of a sharded job.  On one device of one
+    process the blobs are memoryviews INTO their file's bytes (they compare equal to bytes; `bytes(blob)` copies one out).
     timings (optional dict): parse_s (JSON), views_s (accessor views), build_s, prepare_s, encode_s, assemble_s, primitives_built (this rank)."""
     import gc
     import time
@@ -695,15 +717,20 @@ def _transcode_files(sources, cfg, devices, group, device, pipeline, timings):
                 left[fi] -= 1
                 if left[fi] == 0 and world == 1:
                     res = out[first[fi]: first[fi] + len(per_file[fi])]
-                    assembled[fi] = (_assemble(docs[fi][0], docs[fi][1], per_file[fi], res), [r[0] for r in res if r is not None])
+                    assembled[fi] = _assemble(docs[fi][0], docs[fi][1], per_file[fi], res)
             tm["assemble_s"] += time.perf_counter() - ta
 
-        local = encode_raw_batch(raw_of, cfg, pipeline=pipeline, timings=tm, weights=w_mine, on_done=on_done if world == 1 else None)
+        keep = [] if world == 1 else None                                  # the stages' library-owned outputs: views of them go straight into the files
+        try:
+            local = encode_raw_batch(raw_of, cfg, pipeline=pipeline, timings=tm, weights=w_mine, on_done=on_done if world == 1 else None, keep=keep)
+        finally:
+            for raw in keep or []:
+                raw.free()
         if world == 1:
             tm["primitives_built"] = built[0]
             for fi in range(len(docs)):
                 if assembled[fi] is None:   # (a file without a compressible primitive)
-                    assembled[fi] = (_assemble(docs[fi][0], docs[fi][1], per_file[fi], []), [])
+                    assembled[fi] = _assemble(docs[fi][0], docs[fi][1], per_file[fi], [])
             return assembled
     tm["primitives_built"] = built[0]
     if world > 1:
@@ -724,7 +751,8 @@ def _transcode_files(sources, cfg, devices, group, device, pipeline, timings):
     for (doc, buffers), prims in zip(docs, per_file):
         mine_r = results[at: at + len(prims)]
         at += len(prims)
-        out.append((_assemble(doc, buffers, prims, mine_r), [bytes(r[0]) for r in mine_r if r is not None]))
+        glb, views = _assemble(doc, buffers, prims, mine_r)
+        out.append((glb, [bytes(v) for v in views]))                            # (bytes: these results travel between processes / threads)
     tm["assemble_s"] = time.perf_counter() - t1
     return out
 

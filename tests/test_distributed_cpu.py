@@ -110,7 +110,7 @@ def _fake_assets():
     return [gltf.write_glb(*tg._make_asset(prims, interleave=bool(i % 2))) for i, prims in enumerate(files)]
 
 
-def _fake_encode_raw_batch(raws, cfg=None, pipeline=True, timings=None, weights=None, on_done=None):
+def _fake_encode_raw_batch(raws, cfg=None, pipeline=True, timings=None, weights=None, on_done=None, keep=None):
     """Stands in for the device: a "blob" that names the primitive by a digest of the bytes its views reference."""
     import hashlib
     out = []
