@@ -63,6 +63,8 @@ def test_duck_transcode_blob_bit_exact():
     out, blobs = gltf.transcode_glb(data)
     want = _oracle_session(doc, binary, prim).encode()
     assert blobs[0] == want
+    # (one device, one process: the blob is a view INTO the output file — the attribute section went from the library's buffer straight into it)
+    assert isinstance(blobs[0], memoryview) and blobs[0].obj is out and bytes(blobs[0]) == want
     doc2, bin2 = gltf.read_glb(out)
     assert "KHR_draco_mesh_compression" in doc2["extensionsRequired"]
     (payload, ids), = gltf.draco_blobs_of(out)
