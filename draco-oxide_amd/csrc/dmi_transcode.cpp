@@ -1,0 +1,266 @@
+// dmi_transcode.cpp — the transcoder's per-primitive loop behind ONE object: primitives are pushed as the caller's importer produces them, and
+// stages of them run build → prepare → encode on three library threads (dmi_meshes_build of stage k+2 beside dmi_built_meshes_prepare of stage
+// k+1 beside dmi_jobs_encode of stage k); a callback names the primitives whose blobs are final, so that the caller reassembles files while the
+// device works on the next ones.
+// Reference seam: io/gltf/transcoder.rs:134-151 (files one by one), io/gltf/encode.rs:932-955,1827-1842 (their primitives one by one:
+// MeshBuilder::build → encode::encode → bufferView).  Same bytes per primitive as dmi_mesh_build + dmi_encode_mesh (tests/test_gltf.py).
+// Why inside the library: the three calls of a stage were glued together by the caller's interpreter (job wrappers, byte copies, queue hand-overs
+// under one interpreter lock: ≈ 120 of a 165 ms transcode of 1024 files); here a stage changes hands without it.
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/draco_mi.h"
+#include "dmi_host.hpp"
+
+using namespace dmi;
+
+namespace {
+
+struct Stage {
+  uint32_t first = 0, count = 0;            // primitives [first, first + count) in push order
+  std::vector<dmi_built_mesh> built;        // count entries (freed by the prepare step)
+  std::vector<uint32_t> kept;               // indices (relative to first) of the primitives with a face left
+  std::vector<dmi_job*> jobs;               // one per kept primitive (destroyed by the encode step)
+};
+
+// a bounded hand-over between two steps (one stage in flight between neighbours, like the Python driver's queues)
+struct Slot {
+  std::mutex m;
+  std::condition_variable cv;
+  std::deque<std::unique_ptr<Stage>> q;
+  bool closed = false;
+  size_t cap = 1;
+  bool put(std::unique_ptr<Stage> s) {
+    std::unique_lock<std::mutex> lock(m);
+    cv.wait(lock, [&] { return q.size() < cap || closed; });
+    if (closed) return false;
+    q.push_back(std::move(s));
+    cv.notify_all();
+    return true;
+  }
+  std::unique_ptr<Stage> take() {   // null: closed and drained
+    std::unique_lock<std::mutex> lock(m);
+    cv.wait(lock, [&] { return !q.empty() || closed; });
+    if (q.empty()) return nullptr;
+    std::unique_ptr<Stage> s = std::move(q.front());
+    q.pop_front();
+    cv.notify_all();
+    return s;
+  }
+  void close() { std::lock_guard<std::mutex> lock(m); closed = true; cv.notify_all(); }
+};
+
+}  // namespace
+
+struct dmi_transcoder {
+  dmi_config cfg{};
+  uint64_t stage_triangles = 0;
+  dmi_transcode_done_fn done = nullptr;
+  void* user = nullptr;
+  // what was pushed (descriptors are copied; the arrays they point to stay the caller's until the primitive is done)
+  std::mutex push_mutex;
+  std::deque<std::vector<dmi_raw_accessor>> accessors;   // (stable addresses)
+  std::vector<dmi_raw_mesh> prims;
+  uint32_t dispatched = 0;             // primitives already handed to the build step
+  uint64_t pending_triangles = 0;
+  bool first_stage = true;
+  // results, by primitive
+  std::vector<dmi_buffer> heads, sections;
+  std::vector<uint32_t> num_faces, num_points;
+  std::mutex result_mutex;
+  // steps
+  Slot to_build, to_prepare, to_encode;
+  std::thread t_build, t_prepare, t_encode;
+  std::mutex err_mutex;
+  int rc = DMI_OK;
+  std::string err;
+  double ms_build = 0, ms_prepare = 0, ms_encode = 0;
+  bool started = false, finished = false;
+
+  void fail_with(int code) {
+    std::lock_guard<std::mutex> lock(err_mutex);
+    if (rc == DMI_OK) { rc = code; err = dmi_last_error(); }
+  }
+  bool failed() { std::lock_guard<std::mutex> lock(err_mutex); return rc != DMI_OK; }
+
+  static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+  void build_loop() {
+    while (std::unique_ptr<Stage> s = to_build.take()) {
+      if (failed()) continue;
+      const double t0 = now_ms();
+      s->built.assign(s->count, dmi_built_mesh{});
+      const dmi_raw_mesh* p;
+      { std::lock_guard<std::mutex> lock(push_mutex); p = prims.data() + s->first; }   // (prims only grows by reserve-free push_back under the lock: see push)
+      const int r = dmi_meshes_build(p, s->count, &cfg, 0u, s->built.data());
+      ms_build += now_ms() - t0;
+      if (r) { fail_with(r); continue; }
+      if (!to_prepare.put(std::move(s))) break;
+    }
+    to_prepare.close();
+  }
+  void prepare_loop() {
+    while (std::unique_ptr<Stage> s = to_prepare.take()) {
+      const double t0 = now_ms();
+      int r = DMI_OK;
+      if (!failed()) {
+        std::vector<uint32_t> nf(s->count), np(s->count);
+        r = dmi_built_meshes_info(s->built.data(), s->count, nf.data(), np.data());
+        std::vector<dmi_built_mesh> sel;
+        if (!r) {
+          for (uint32_t k = 0; k < s->count; ++k) if (nf[k]) { s->kept.push_back(k); sel.push_back(s->built[k]); }
+          std::lock_guard<std::mutex> lock(result_mutex);
+          for (uint32_t k = 0; k < s->count; ++k) { num_faces[s->first + k] = nf[k]; num_points[s->first + k] = nf[k] ? np[k] : 0; }
+        }
+        if (!r && !sel.empty()) {
+          std::vector<dmi_buffer> h(sel.size());
+          s->jobs.assign(sel.size(), nullptr);
+          r = dmi_built_meshes_prepare(sel.data(), (uint32_t)sel.size(), &cfg, h.data(), s->jobs.data());
+          if (!r) { std::lock_guard<std::mutex> lock(result_mutex); for (size_t q = 0; q < sel.size(); ++q) heads[s->first + s->kept[q]] = h[q]; }
+          else s->jobs.clear();
+        }
+      }
+      dmi_built_meshes_free(s->built.data(), s->count);   // (the jobs copied what they need)
+      s->built.clear();
+      ms_prepare += now_ms() - t0;
+      if (r) { fail_with(r); continue; }
+      if (failed()) { for (dmi_job* j : s->jobs) dmi_job_destroy(j); continue; }
+      if (!to_encode.put(std::move(s))) break;
+    }
+    to_encode.close();
+  }
+  void encode_loop() {
+    while (std::unique_ptr<Stage> s = to_encode.take()) {
+      const double t0 = now_ms();
+      int r = DMI_OK;
+      if (!failed() && !s->jobs.empty()) {
+        std::vector<dmi_buffer> outs(s->jobs.size());
+        r = dmi_jobs_encode(s->jobs.data(), (uint32_t)s->jobs.size(), outs.data());
+        if (!r) { std::lock_guard<std::mutex> lock(result_mutex); for (size_t q = 0; q < outs.size(); ++q) sections[s->first + s->kept[q]] = outs[q]; }
+      }
+      for (dmi_job* j : s->jobs) dmi_job_destroy(j);
+      s->jobs.clear();
+      ms_encode += now_ms() - t0;
+      if (r) { fail_with(r); continue; }
+      if (!failed() && done) done(user, s->first, s->count);
+    }
+  }
+  void start() {
+    if (started) return;
+    started = true;
+    t_build = std::thread([this] { build_loop(); });
+    t_prepare = std::thread([this] { prepare_loop(); });
+    t_encode = std::thread([this] { encode_loop(); });
+  }
+  // hands the primitives pushed so far to the build step once they make a stage (or all of them: flush)
+  void dispatch(bool flush) {
+    const uint64_t want = first_stage ? std::max<uint64_t>(1, stage_triangles / 3) : stage_triangles;   // (the first stage runs alone: the sooner it is through, the sooner the steps overlap)
+    if (dispatched == prims.size() || (!flush && pending_triangles < want)) return;
+    std::unique_ptr<Stage> s(new Stage());
+    s->first = dispatched; s->count = (uint32_t)prims.size() - dispatched;
+    dispatched = (uint32_t)prims.size();
+    pending_triangles = 0;
+    first_stage = false;
+    start();
+    (void)to_build.put(std::move(s));
+  }
+};
+
+extern "C" {
+
+dmi_transcoder* dmi_transcoder_create(const dmi_config* cfg, uint64_t expected_triangles, uint64_t stage_triangles, dmi_transcode_done_fn done, void* user) {
+  std::unique_ptr<dmi_transcoder> t(new dmi_transcoder());
+  if (cfg) t->cfg = *cfg;
+  // about four stages (enough to overlap the steps), between 3M and 12M triangles: a stage pays fixed costs (the chain launch of its encode is bounded
+  // by its longest stream, ≈ 5 ms) and one above ≈ 16M stops overlapping (measured with the Python driver: DESIGN §6b)
+  t->stage_triangles = stage_triangles ? stage_triangles : std::min<uint64_t>((uint64_t)12 << 20, std::max<uint64_t>((uint64_t)3 << 20, expected_triangles / 4));
+  t->done = done; t->user = user;
+  t->to_build.cap = 2;   // (the caller may run a stage ahead of the build)
+  return t.release();
+}
+
+int dmi_transcoder_push(dmi_transcoder* t, const dmi_raw_mesh* prims, uint32_t n) {
+  if (!t || (!prims && n)) return host_fail(DMI_ERR_INVALID_ARGUMENT, "null");
+  if (t->finished) return host_fail(DMI_ERR_INVALID_ARGUMENT, "transcoder already finished");
+  if (t->failed()) { std::lock_guard<std::mutex> lock(t->err_mutex); return host_fail(t->rc, t->err); }
+  {
+    std::lock_guard<std::mutex> lock(t->push_mutex);
+    // (prims may reallocate: the build step reads its slice's address under this lock and the slice itself is never written again — but a
+    //  reallocation would move it: reserve in large steps and copy the descriptors of already dispatched primitives never; see build_loop)
+    if (t->prims.capacity() < t->prims.size() + n) {
+      if (t->dispatched) return host_fail(DMI_ERR_INVALID_ARGUMENT, "dmi_transcoder_push: more primitives than dmi_transcoder_reserve announced");
+      t->prims.reserve(std::max<size_t>(t->prims.size() + n, 2 * t->prims.capacity()));
+    }
+    for (uint32_t k = 0; k < n; ++k) {
+      t->accessors.emplace_back(prims[k].atts, prims[k].atts + prims[k].n_atts);
+      dmi_raw_mesh m = prims[k];
+      m.atts = t->accessors.back().data();
+      t->prims.push_back(m);
+      t->pending_triangles += prims[k].num_faces;
+    }
+    std::lock_guard<std::mutex> rlock(t->result_mutex);
+    t->heads.resize(t->prims.size(), dmi_buffer{}); t->sections.resize(t->prims.size(), dmi_buffer{});
+    t->num_faces.resize(t->prims.size(), 0); t->num_points.resize(t->prims.size(), 0);
+  }
+  t->dispatch(false);
+  return DMI_OK;
+}
+
+int dmi_transcoder_reserve(dmi_transcoder* t, uint32_t n_primitives) {
+  if (!t) return host_fail(DMI_ERR_INVALID_ARGUMENT, "null");
+  std::lock_guard<std::mutex> lock(t->push_mutex);
+  if (t->dispatched && t->prims.capacity() < n_primitives) return host_fail(DMI_ERR_INVALID_ARGUMENT, "dmi_transcoder_reserve after the first stage started");
+  t->prims.reserve(n_primitives);
+  std::lock_guard<std::mutex> rlock(t->result_mutex);
+  t->heads.reserve(n_primitives); t->sections.reserve(n_primitives); t->num_faces.reserve(n_primitives); t->num_points.reserve(n_primitives);
+  return DMI_OK;
+}
+
+int dmi_transcoder_finish(dmi_transcoder* t) {
+  if (!t) return host_fail(DMI_ERR_INVALID_ARGUMENT, "null");
+  if (!t->finished) {
+    t->dispatch(true);
+    t->to_build.close();
+    if (t->t_build.joinable()) t->t_build.join();
+    if (t->t_prepare.joinable()) t->t_prepare.join();
+    if (t->t_encode.joinable()) t->t_encode.join();
+    t->finished = true;
+  }
+  std::lock_guard<std::mutex> lock(t->err_mutex);
+  return t->rc ? host_fail(t->rc, t->err) : DMI_OK;
+}
+
+int dmi_transcoder_result(dmi_transcoder* t, uint32_t i, dmi_buffer* header_and_connectivity, dmi_buffer* section, uint32_t* num_faces, uint32_t* num_points) {
+  if (!t) return host_fail(DMI_ERR_INVALID_ARGUMENT, "null");
+  std::lock_guard<std::mutex> lock(t->result_mutex);
+  if (i >= t->heads.size()) return host_fail(DMI_ERR_INVALID_ARGUMENT, "primitive index out of range");
+  if (header_and_connectivity) *header_and_connectivity = t->heads[i];
+  if (section) *section = t->sections[i];
+  if (num_faces) *num_faces = t->num_faces[i];
+  if (num_points) *num_points = t->num_points[i];
+  return DMI_OK;
+}
+
+int dmi_transcoder_timings(dmi_transcoder* t, double* build_ms, double* prepare_ms, double* encode_ms) {
+  if (!t) return host_fail(DMI_ERR_INVALID_ARGUMENT, "null");
+  if (build_ms) *build_ms = t->ms_build;
+  if (prepare_ms) *prepare_ms = t->ms_prepare;
+  if (encode_ms) *encode_ms = t->ms_encode;
+  return DMI_OK;
+}
+
+void dmi_transcoder_destroy(dmi_transcoder* t) {
+  if (!t) return;
+  if (!t->finished) (void)dmi_transcoder_finish(t);
+  for (auto& b : t->heads) if (b.data) dmi_free(&b);       // (the buffers stay the transcoder's: views of them are valid until here)
+  for (auto& b : t->sections) if (b.data) dmi_free(&b);
+  delete t;
+}
+
+}  // extern "C"

@@ -271,6 +271,26 @@ void dmi_built_meshes_free(dmi_built_mesh* built, uint32_t n);
  * kernels read the built faces and maps where they are, the jobs copy their values device to device.  Same bytes as dmi_meshes_prepare on
  * the equivalent host meshes.  The built meshes may be freed as soon as this returns. */
 int dmi_built_meshes_prepare(const dmi_built_mesh* built, uint32_t n, const dmi_config* cfg, dmi_buffer* header_and_connectivity, dmi_job** jobs);
+/* --- The transcoder's per-primitive loop as ONE object (io/gltf/transcoder.rs:134-151, io/gltf/encode.rs:932-955,1827-1842) -------------------------
+ * The importer pushes triangle primitives as it produces them (descriptors are copied; the accessor / index arrays they point to must stay
+ * valid until the primitive is reported done); stages of ≈ stage_triangles triangles (0: a quarter of expected_triangles, within 3M … 12M;
+ * the first stage a third of that) run dmi_meshes_build → dmi_built_meshes_prepare → dmi_jobs_encode on three library threads, stage k+2 / k+1 / k
+ * side by side.  `done(user, first, count)` is called from a library thread when the primitives [first, first + count) (push order) are final:
+ * dmi_transcoder_result then gives primitive i's header + connectivity bytes and attribute section — blob = the two back to back, what
+ * dmi_encode_mesh writes for the built mesh — and its face / point counts for the placeholder accessors (num_faces == 0: no face left, the
+ * reference leaves such a primitive alone, io/gltf/encode.rs:934-936; both buffers empty).  The buffers are the transcoder's until
+ * dmi_transcoder_destroy.  dmi_transcoder_reserve(total primitives) before the first push; dmi_transcoder_finish flushes the last stage,
+ * waits for everything and returns the first error of any stage (dmi_last_error() of the calling thread names it).  One device (cfg->device). */
+typedef struct dmi_transcoder dmi_transcoder;
+typedef void (*dmi_transcode_done_fn)(void* user, uint32_t first, uint32_t count);
+dmi_transcoder* dmi_transcoder_create(const dmi_config* cfg, uint64_t expected_triangles, uint64_t stage_triangles, dmi_transcode_done_fn done, void* user);
+int dmi_transcoder_reserve(dmi_transcoder* t, uint32_t n_primitives);
+int dmi_transcoder_push(dmi_transcoder* t, const dmi_raw_mesh* prims, uint32_t n);
+int dmi_transcoder_finish(dmi_transcoder* t);
+int dmi_transcoder_result(dmi_transcoder* t, uint32_t i, dmi_buffer* header_and_connectivity, dmi_buffer* section, uint32_t* num_faces, uint32_t* num_points);
+int dmi_transcoder_timings(dmi_transcoder* t, double* build_ms, double* prepare_ms, double* encode_ms);   /* time inside the three calls, summed over the stages */
+void dmi_transcoder_destroy(dmi_transcoder* t);
+
 /* Stage times of the calling thread's last dmi_meshes_build (milliseconds; kernels_ms is hipEvent time summed over the groups). */
 typedef struct dmi_build_timings {
   float pack_ms;       /* host threads: rows and indices into pinned staging */

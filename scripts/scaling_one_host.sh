@@ -3,6 +3,7 @@
 # the gather runs on CPU tensors).  The step is ≈ 95 % host time (two serial graph walks + the host-core stream coders), so what this
 # measures — N ranks contending for the same cores and memory — is what bounds the real N-GPU curve; the GPU stages (≈ 3 % of a step)
 # serialise on the one device here, which an N-GPU node does not do.
+mkdir -p gpurun_out/r4
 out=gpurun_out/r4/scaling_one_host.jsonl
 mkdir -p gpurun_out/r4
 : > $out
