@@ -171,7 +171,8 @@ def transcode_regime(n_files=1024, steps=2, device=0):
     (in memory, the reference's transcode_buffer form; F log-uniform in [2k, 200k], pos+nrm+uv, u16 / u32 indices) →
     gltf.transcode_files → n Draco-compressed GLBs.  Inside the timed call: JSON parse, accessor views, MeshBuilder::build on the device
     for every primitive (dmi_meshes_build), connectivity stage + job creation (dmi_built_meshes_prepare), dmi_jobs_encode, GLB reassembly;
-    about four stages overlap (build of stage k+2, prepare of stage k+1, encode of stage k, reassembly)."""
+    about four stages overlap (builds of stages k+2 / k+3, prepare of stage k+1, encode of stage k, reassembly): the stage loop runs inside the library
+    (dmi_transcoder_*, the C-ABI form of the reference's per-primitive loop)."""
     from draco_oxide_amd import gltf
     glbs, total = synth.batch_glbs(n_files)
     in_bytes = sum(len(g) for g in glbs)
@@ -214,12 +215,13 @@ def transcode_regime(n_files=1024, steps=2, device=0):
         seam = {"error": str(e)[:200]}
     return {"with_uv_seams": seam,
             "workload": f"BASELINE configs[3]: {n_files} GLB files in memory (one primitive each, F log-uniform [2k,200k], pos+nrm+uv, u16/u32 indices) → gltf.transcode_files → {n_files} "
-                        "Draco-compressed GLBs: JSON parse, device MeshBuilder::build (dmi_meshes_build), dmi_built_meshes_prepare, dmi_jobs_encode, reassembly — all inside the timed call",
+                        "Draco-compressed GLBs: JSON parse, accessor views pushed into dmi_transcoder (device MeshBuilder::build, dmi_built_meshes_prepare, dmi_jobs_encode on library threads), reassembly — all inside the timed call",
             "triangles": int(total), "value": round(total / best / 1e6, 2), "unit": "Mtriangles/s", "ms_per_batch": round(best * 1e3, 2),
             "split_ms": {"parse (JSON)": round(tm["parse_s"] * 1e3, 2), "accessor views (per stage, beside the device work)": round(tm["views_s"] * 1e3, 2), "build (pack, upload, kernels, faces + maps back)": round(tm["build_s"] * 1e3, 2),
                          "prepare (device tables, host walks, relabelling)": round(tm["prepare_s"] * 1e3, 2), "encode (beside the next stage's build + prepare)": round(tm["encode_s"] * 1e3, 2),
                          "assemble": round(tm["assemble_s"] * 1e3, 2)},
-            "build_kernels_ms": round(tm["build_kernels_ms"], 3), "build_pack_ms": round(tm["build_pack_ms"], 3),
+            "stage_loop": "inside the library (dmi_transcoder: two build threads, a prepare and an encode thread; the caller's thread makes the accessor views and pushes them, a second "
+                          "interpreter thread reassembles finished files)" if "build_kernels_ms" not in tm else "gltf.py's stage threads (DMI_TRANSCODE_PYTHON=1)",
             "input_bytes": int(in_bytes), "output_bytes": int(out_bytes),
             "sample_blobs_equal_whole_mesh_encodes_and_one_stage_files": bool(ok)}
 

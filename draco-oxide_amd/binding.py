@@ -111,9 +111,11 @@ class _Conn(C.Structure):
     _fields_ = [("num_tables", C.c_uint32), ("tables", C.POINTER(_CornerTable)), ("seeds", C.c_void_p), ("num_seeds", C.c_uint32), ("owner", C.c_void_p)]
 
 
+_TRANSCODE_DONE = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32)   # dmi_transcode_done_fn
 EXPORTS = ["dmi_encode_attributes", "dmi_encode_attributes_batch", "dmi_jobs_encode", "dmi_job_create", "dmi_job_encode", "dmi_job_timings", "dmi_job_destroy", "dmi_encode_mesh",
            "dmi_mesh_prepare", "dmi_meshes_prepare", "dmi_shard_meshes", "dmi_meshes_prepare_devices", "dmi_jobs_encode_devices", "dmi_mesh_build", "dmi_built_mesh_free", "dmi_encode_connectivity", "dmi_conn_free", "dmi_host_rans_stream", "dmi_host_rabs_stream", "dmi_host_rabs_constant_stream", "dmi_tile_sort_slots", "dmi_decode_attributes", "dmi_decoded_free", "dmi_decode_mesh", "dmi_decoded_mesh_free", "dmi_decode_connectivity", "dmi_decoded_conn_free", "dmi_last_decode_timings", "dmi_free", "dmi_free_many", "dmi_strerror", "dmi_last_error", "dmi_device_count", "dmi_release_cached_memory",
-           "dmi_init", "dmi_last_call_timings", "dmi_device_corner_table", "dmi_encode_mesh_device", "dmi_meshes_build", "dmi_built_meshes_prepare", "dmi_last_build_timings", "dmi_device_attribute_table", "dmi_built_meshes_info", "dmi_built_meshes_free", "dmi_thread_host_threads", "dmi_usable_host_threads"]
+           "dmi_init", "dmi_last_call_timings", "dmi_device_corner_table", "dmi_encode_mesh_device", "dmi_meshes_build", "dmi_built_meshes_prepare", "dmi_last_build_timings", "dmi_device_attribute_table", "dmi_built_meshes_info", "dmi_built_meshes_free", "dmi_thread_host_threads", "dmi_usable_host_threads",
+           "dmi_transcoder_create", "dmi_transcoder_reserve", "dmi_transcoder_push", "dmi_transcoder_finish", "dmi_transcoder_result", "dmi_transcoder_timings", "dmi_transcoder_destroy"]
 
 
 def library_path():
@@ -186,6 +188,15 @@ def load_library():
     L.dmi_init.argtypes = [C.c_int, C.c_size_t, C.c_size_t]
     L.dmi_meshes_build.argtypes = [C.POINTER(_RawMesh), C.c_uint32, C.POINTER(_Config), C.c_uint32, C.POINTER(_BuiltMesh)]
     L.dmi_built_meshes_prepare.argtypes = [C.POINTER(_BuiltMesh), C.c_uint32, C.POINTER(_Config), C.POINTER(_Buffer), C.POINTER(C.c_void_p)]
+    L.dmi_transcoder_create.argtypes = [C.POINTER(_Config), C.c_uint64, C.c_uint64, _TRANSCODE_DONE, C.c_void_p]
+    L.dmi_transcoder_create.restype = C.c_void_p
+    L.dmi_transcoder_reserve.argtypes = [C.c_void_p, C.c_uint32]
+    L.dmi_transcoder_push.argtypes = [C.c_void_p, C.POINTER(_RawMesh), C.c_uint32]
+    L.dmi_transcoder_finish.argtypes = [C.c_void_p]
+    L.dmi_transcoder_result.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(_Buffer), C.POINTER(_Buffer), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.dmi_transcoder_timings.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.dmi_transcoder_destroy.argtypes = [C.c_void_p]
+    L.dmi_transcoder_destroy.restype = None
     L.dmi_last_build_timings.argtypes = [C.POINTER(_BuildTimings)]
     L.dmi_built_meshes_info.argtypes = [C.POINTER(_BuiltMesh), C.c_uint32, C.c_void_p, C.c_void_p]
     L.dmi_built_meshes_free.argtypes = [C.POINTER(_BuiltMesh), C.c_uint32]
@@ -491,13 +502,9 @@ class BuiltBatch:
             pass
 
 
-def meshes_build(raw_meshes, cfg=None, host_values=False):
-    """dmi_meshes_build: MeshBuilder::build for a list of RawMesh on the device → BuiltBatch."""
-    L = load_library()
-    cfg = cfg or Config.default()
+def _raw_mesh_array(raw_meshes):
+    """RawMesh list → (dmi_raw_mesh array, what must stay alive while the library reads it)."""
     n = len(raw_meshes)
-    if n == 0:
-        return BuiltBatch(None, 0, None)
     arr = (_RawMesh * n)()
     keep = []
     for j, rm in enumerate(raw_meshes):
@@ -515,6 +522,17 @@ def meshes_build(raw_meshes, cfg=None, host_values=False):
         arr[j].index_type = _INDEX_CT[idx.dtype]
         arr[j].num_faces = len(idx) // 3
         keep.append((acc, idx, rm))
+    return arr, keep
+
+
+def meshes_build(raw_meshes, cfg=None, host_values=False):
+    """dmi_meshes_build: MeshBuilder::build for a list of RawMesh on the device → BuiltBatch."""
+    L = load_library()
+    cfg = cfg or Config.default()
+    n = len(raw_meshes)
+    if n == 0:
+        return BuiltBatch(None, 0, None)
+    arr, keep = _raw_mesh_array(raw_meshes)
     built = (_BuiltMesh * n)()
     c = cfg._c()
     _check(L.dmi_meshes_build(arr, n, C.byref(c), BUILD_HOST_VALUES if host_values else 0, built))
@@ -547,6 +565,72 @@ def built_meshes_prepare(batch, which=None, cfg=None):
     handles = (C.c_void_p * n)()
     _check(L.dmi_built_meshes_prepare(arr, n, C.byref(c), heads, handles))
     return [Job(handles[i], _take(heads[i])) for i in range(n)]
+
+
+class Transcoder:
+    """dmi_transcoder: the transcoder's per-primitive loop inside the library.  push(RawMesh list) as the importer produces them; stages run build →
+    prepare → encode on library threads; on_done(first, count) is called (from a library thread) when the primitives [first, first + count) are
+    final; result(i) → ((header + connectivity, attribute section) as zero-copy uint8 views, num_faces, num_points) or None (no face left).  The
+    views are valid until close()."""
+
+    def __init__(self, cfg=None, expected_triangles=0, n_primitives=0, on_done=None, stage_triangles=0):
+        L = load_library()
+        self._L = L
+        self.errors = []
+
+        def _cb(user, first, count):
+            try:
+                on_done(first, count)
+            except BaseException as e:  # noqa: BLE001 — nothing may propagate into the library's thread; finish() raises it
+                self.errors.append(e)
+
+        self._cb = _TRANSCODE_DONE(_cb) if on_done else C.cast(None, _TRANSCODE_DONE)
+        c = (cfg or Config.default())._c()
+        L.dmi_transcoder_create.restype = C.c_void_p
+        self._h = C.c_void_p(L.dmi_transcoder_create(C.byref(c), C.c_uint64(int(expected_triangles)), C.c_uint64(int(stage_triangles)), self._cb, None))
+        if not self._h:
+            raise MemoryError("dmi_transcoder_create")
+        self._keep = []
+        if n_primitives:
+            _check(L.dmi_transcoder_reserve(self._h, int(n_primitives)))
+
+    def push(self, raw_meshes):
+        if not raw_meshes:
+            return
+        arr, keep = _raw_mesh_array(raw_meshes)
+        self._keep.append(keep)                                            # (the arrays the descriptors point to: alive until close())
+        _check(self._L.dmi_transcoder_push(self._h, arr, len(raw_meshes)))
+
+    def finish(self):
+        _check(self._L.dmi_transcoder_finish(self._h))
+        if self.errors:
+            raise self.errors[0]
+
+    def result(self, i):
+        head, sec = _Buffer(), _Buffer()
+        nf, npts = C.c_uint32(0), C.c_uint32(0)
+        _check(self._L.dmi_transcoder_result(self._h, int(i), C.byref(head), C.byref(sec), C.byref(nf), C.byref(npts)))
+        if not nf.value:
+            return None
+        view = lambda b: np.ctypeslib.as_array((C.c_uint8 * b.len).from_address(b.data)) if b.len else np.zeros(0, np.uint8)  # noqa: E731
+        return (view(head), view(sec)), int(nf.value), int(npts.value)
+
+    def timings(self):
+        b, p, e = C.c_double(0), C.c_double(0), C.c_double(0)
+        _check(self._L.dmi_transcoder_timings(self._h, C.byref(b), C.byref(p), C.byref(e)))
+        return {"build_s": b.value * 1e-3, "prepare_s": p.value * 1e-3, "encode_s": e.value * 1e-3}
+
+    def close(self):
+        if self._h:
+            self._L.dmi_transcoder_destroy(self._h)
+            self._h = None
+        self._keep = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 class Config:

@@ -6,7 +6,9 @@
 // MeshBuilder::build → encode::encode → bufferView).  Same bytes per primitive as dmi_mesh_build + dmi_encode_mesh (tests/test_gltf.py).
 // Why inside the library: the three calls of a stage were glued together by the caller's interpreter (job wrappers, byte copies, queue hand-overs
 // under one interpreter lock: ≈ 120 of a 165 ms transcode of 1024 files); here a stage changes hands without it.
+#include <atomic>
 #include <chrono>
+#include <cstdlib>
 #include <condition_variable>
 #include <deque>
 #include <memory>
@@ -76,7 +78,8 @@ struct dmi_transcoder {
   std::mutex result_mutex;
   // steps
   Slot to_build, to_prepare, to_encode;
-  std::thread t_build, t_prepare, t_encode;
+  std::thread t_build, t_build2, t_prepare, t_encode;
+  std::atomic<int> builders_left{0};
   std::mutex err_mutex;
   int rc = DMI_OK;
   std::string err;
@@ -99,11 +102,11 @@ struct dmi_transcoder {
       const dmi_raw_mesh* p;
       { std::lock_guard<std::mutex> lock(push_mutex); p = prims.data() + s->first; }   // (prims only grows by reserve-free push_back under the lock: see push)
       const int r = dmi_meshes_build(p, s->count, &cfg, 0u, s->built.data());
-      ms_build += now_ms() - t0;
+      { std::lock_guard<std::mutex> lock(err_mutex); ms_build += now_ms() - t0; }
       if (r) { fail_with(r); continue; }
       if (!to_prepare.put(std::move(s))) break;
     }
-    to_prepare.close();
+    if (builders_left.fetch_sub(1) == 1) to_prepare.close();   // (the last build thread out)
   }
   void prepare_loop() {
     while (std::unique_ptr<Stage> s = to_prepare.take()) {
@@ -154,7 +157,13 @@ struct dmi_transcoder {
   void start() {
     if (started) return;
     started = true;
+    // two builds side by side: the packing of stage k+1 beside the upload / kernels / read-back of stage k (the build is the longest chain of a
+    // transcode: DESIGN §6b); DMI_BUILD_WORKERS=1: one
+    const char* e = std::getenv("DMI_BUILD_WORKERS");
+    const int nb = e && std::atoi(e) == 1 ? 1 : 2;
+    builders_left = nb;
     t_build = std::thread([this] { build_loop(); });
+    if (nb > 1) t_build2 = std::thread([this] { build_loop(); });
     t_prepare = std::thread([this] { prepare_loop(); });
     t_encode = std::thread([this] { encode_loop(); });
   }
@@ -228,6 +237,7 @@ int dmi_transcoder_finish(dmi_transcoder* t) {
     t->dispatch(true);
     t->to_build.close();
     if (t->t_build.joinable()) t->t_build.join();
+    if (t->t_build2.joinable()) t->t_build2.join();
     if (t->t_prepare.joinable()) t->t_prepare.join();
     if (t->t_encode.joinable()) t->t_encode.join();
     t->finished = true;

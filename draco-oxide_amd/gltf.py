@@ -701,6 +701,10 @@ def _transcode_files(sources, cfg, devices, group, device, pipeline, timings):
             t.join()
         if errs:
             raise errs[0]
+    elif world == 1 and pipeline and mine and os.environ.get("DMI_TRANSCODE_PYTHON", "0") == "0":
+        # one device, one process: the stage loop runs INSIDE the library (dmi_transcoder: build / prepare / encode threads of its own); this thread
+        # only makes the accessor views and pushes them, the library's callback reassembles a file as soon as its last primitive is coded
+        return _transcode_native(docs, per_file, flat, mine, w_mine, raw_of, built, cfg, tm)
     else:
         # one device: a file is reassembled as soon as its last primitive is coded (a fourth stage beside the device work of the next ones)
         assembled = [None] * len(docs)
@@ -755,6 +759,78 @@ def _transcode_files(sources, cfg, devices, group, device, pipeline, timings):
         out.append((glb, [bytes(v) for v in views]))                            # (bytes: these results travel between processes / threads)
     tm["assemble_s"] = time.perf_counter() - t1
     return out
+
+
+def _transcode_native(docs, per_file, flat, mine, w_mine, raw_of, built, cfg, tm):
+    """transcode_files on one device of one process through dmi_transcoder (binding.Transcoder): the primitives are pushed in slices (their accessor
+    views are made right before), stages of them are built / prepared / encoded on library threads, and `done` — called from the library's encode
+    thread — reassembles every file whose last primitive is final.  mine[k] = index into `flat` of this call's k-th primitive (all of them here)."""
+    import time
+    from .binding import Transcoder
+    assembled = [None] * len(docs)
+    left = [len(prims) for prims in per_file]
+    first = [0] * len(docs)
+    for fi in range(1, len(docs)):
+        first[fi] = first[fi - 1] + len(per_file[fi - 1])
+    for key in ("views_s", "assemble_s"):
+        tm[key] = 0.0
+    holder = []
+
+    import queue
+    finished = queue.Queue()                                                  # (first, count) of the stages the library reports; None ends the reassembly thread
+    errs = []
+
+    def reassemble():
+        try:
+            while True:
+                item = finished.get()
+                if item is None:
+                    return
+                ta = time.perf_counter()
+                t = holder[0]
+                for k in range(item[0], item[0] + item[1]):
+                    fi = flat[mine[k]][0]
+                    left[fi] -= 1
+                    if left[fi] == 0:
+                        res = [t.result(q) for q in range(first[fi], first[fi] + len(per_file[fi]))]
+                        assembled[fi] = _assemble(docs[fi][0], docs[fi][1], per_file[fi], res)
+                tm["assemble_s"] += time.perf_counter() - ta
+        except BaseException as e:                                        # noqa: BLE001 — re-raised on the caller's thread
+            errs.append(e)
+
+    def done(first_k, count):                                                 # (the library's encode thread: hands the stage on and goes back to encoding)
+        finished.put((first_k, count))
+
+    n = len(mine)
+    with Transcoder(cfg, sum(w_mine), n, on_done=done, stage_triangles=PIPELINE_TRIANGLES) as t:
+        holder.append(t)
+        worker = threading.Thread(target=reassemble)
+        worker.start()
+        slice_tris = max(1, sum(w_mine) // 64)                                # (a push per ≈ 1/64 of the triangles: the library starts its first stage early)
+        lo = 0
+        while lo < n:
+            t0 = time.perf_counter()
+            hi, acc = lo, 0
+            while hi < n and (hi == lo or acc + w_mine[hi] <= slice_tris):
+                acc += w_mine[hi]
+                hi += 1
+            raws = [raw_of(k) for k in range(lo, hi)]
+            tm["views_s"] += time.perf_counter() - t0
+            t.push(raws)
+            lo = hi
+        try:
+            t.finish()
+        finally:
+            finished.put(None)
+            worker.join()
+        if errs:
+            raise errs[0]
+        tm.update(t.timings())
+        for fi in range(len(docs)):
+            if assembled[fi] is None:   # (a file without a compressible primitive)
+                assembled[fi] = _assemble(docs[fi][0], docs[fi][1], per_file[fi], [])
+    tm["primitives_built"] = built[0]
+    return assembled
 
 
 def transcode_glb(data, cfg=None):

@@ -164,10 +164,16 @@ def test_transcode_files_shards_before_building_gloo_world2():
     # rank 0 assembled every file around the gathered blobs: the same GLBs as a single process makes with the same stand-in encoder
     gltf_encode = gltf.encode_raw_batch
     gltf.encode_raw_batch = _fake_encode_raw_batch
+    was = os.environ.get("DMI_TRANSCODE_PYTHON")
+    os.environ["DMI_TRANSCODE_PYTHON"] = "1"      # (the stand-in replaces the Python stage loop; a single process otherwise runs the library's own: dmi_transcoder)
     try:
         single = gltf.transcode_files(_fake_assets())
     finally:
         gltf.encode_raw_batch = gltf_encode
+        if was is None:
+            del os.environ["DMI_TRANSCODE_PYTHON"]
+        else:
+            os.environ["DMI_TRANSCODE_PYTHON"] = was
     assert [g for g, _ in res0] == [g for g, _ in single] and [b for _, b in res0] == [b for _, b in single]
     doc, _ = gltf.read_glb(res0[0][0])
     assert doc["accessors"][doc["meshes"][0]["primitives"][1]["indices"]]["count"] == 2 * 14 * 14 * 3
