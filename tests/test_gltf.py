@@ -242,8 +242,46 @@ def test_pipelined_stages_give_the_same_files(monkeypatch):
     many = gltf.transcode_files(sources, pipeline=True, timings=tm)
     assert [g for g, _ in many] == [g for g, _ in one]
     assert tm["primitives_built"] == 48 and tm["build_s"] > 0 and tm["encode_s"] > 0
+    # (that was the library's own stage loop, dmi_transcoder; the interpreter's stage threads give the same files)
+    monkeypatch.setenv("DMI_TRANSCODE_PYTHON", "1")
+    tm2 = {}
+    python_loop = gltf.transcode_files(sources, pipeline=True, timings=tm2)
+    assert [g for g, _ in python_loop] == [g for g, _ in one] and "build_kernels_ms" in tm2
+    monkeypatch.delenv("DMI_TRANSCODE_PYTHON")
     meshes = [gltf.primitive_to_mesh(*gltf.read_glb(src), prim)[0] for src in sources[:3] for prim in gltf.read_glb(src)[0]["meshes"][0]["primitives"]]
     assert gltf.encode_batch(meshes, pipeline=True) == gltf.encode_batch(meshes)
+
+
+@pytest.mark.gpu
+def test_transcoder_object_results_order_and_errors():
+    """dmi_transcoder through its binding: primitives pushed in two slices, stages reported through the callback, results by push index — the
+    blob of primitive i = header + connectivity ++ section = the whole-mesh encode of its built mesh; a primitive with a zero normal
+    fails the run at finish() with the library's error, and nothing is left half-made."""
+    prims = [_prim(int(n), seed=300 + i, index_type="u16" if i % 2 else "u32") for i, n in enumerate([9, 14, 6, 21, 11, 8, 17])]
+    raws, meshes = [], []
+    for p in prims:
+        doc, buf = _make_asset([p])
+        g = gltf.write_glb(doc, buf)
+        d, b = gltf.read_glb(g)
+        raws.append(gltf.primitive_to_raw(d, b, d["meshes"][0]["primitives"][0])[0])
+        meshes.append(gltf.primitive_to_mesh(d, b, d["meshes"][0]["primitives"][0])[0])
+    seen = []
+    with dmi.Transcoder(None, sum(len(r.indices) // 3 for r in raws), len(raws), on_done=lambda first, count: seen.append((first, count)), stage_triangles=400) as t:
+        t.push(raws[:3])
+        t.push(raws[3:])
+        t.finish()
+        assert sorted(k for f, c in seen for k in range(f, f + c)) == list(range(len(raws))) and len(seen) > 1
+        for i, m in enumerate(meshes):
+            (head, section), nf, npts = t.result(i)
+            assert bytes(head) + bytes(section) == dmi.encode_mesh(m) and nf == len(m.faces)
+    bad = dmi.RawMesh()                                                   # a zero normal: the reference panics in the octahedral transform (geom.rs:45) — an error code here
+    pid = bad.add_attribute(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0]], np.float32), dmi.ATT_POSITION)
+    bad.add_attribute(np.array([[0, 0, 1], [0, 0, 0], [0, 1, 0], [1, 0, 0]], np.float32), dmi.ATT_NORMAL, dmi.DOMAIN_CORNER, parents=[pid])
+    bad.set_indices(np.array([0, 1, 2, 1, 3, 2], np.uint32))
+    with dmi.Transcoder(None, 2, 2) as t:
+        t.push([raws[0], bad])
+        with pytest.raises(dmi.DracoMiError):
+            t.finish()
 
 
 @pytest.mark.gpu
