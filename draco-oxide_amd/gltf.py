@@ -574,6 +574,9 @@ def encode_raw_batch(raws, cfg=None, pipeline=True, timings=None, weights=None, 
     return out
 
 
+_ENCODE_RAW_BATCH = encode_raw_batch   # (a test's stand-in for encode_raw_batch must keep being used by the sharded driver)
+
+
 def encode_batch(meshes, cfg=None, devices=None, group=None, device=None, pipeline=False):
     """Every (already built, host-memory) mesh of a transcode job as ONE batch → list of `.drc` blobs in mesh order (None on the ranks
     that are not the destination of a sharded job).  torch.distributed initialised with more than one rank: the batch is dealt over
@@ -725,11 +728,14 @@ def _transcode_files(sources, cfg, devices, group, device, pipeline, timings):
             tm["assemble_s"] += time.perf_counter() - ta
 
         keep = [] if world == 1 else None                                  # the stages' library-owned outputs: views of them go straight into the files
-        try:
-            local = encode_raw_batch(raw_of, cfg, pipeline=pipeline, timings=tm, weights=w_mine, on_done=on_done if world == 1 else None, keep=keep)
-        finally:
-            for raw in keep or []:
-                raw.free()
+        if world > 1 and pipeline and mine and encode_raw_batch is _ENCODE_RAW_BATCH and os.environ.get("DMI_TRANSCODE_PYTHON", "0") == "0":
+            local = _share_native(raw_of, w_mine, cfg, tm)                 # (a rank's share through the library's stage loop; blobs as bytes: they travel)
+        else:
+            try:
+                local = encode_raw_batch(raw_of, cfg, pipeline=pipeline, timings=tm, weights=w_mine, on_done=on_done if world == 1 else None, keep=keep)
+            finally:
+                for raw in keep or []:
+                    raw.free()
         if world == 1:
             tm["primitives_built"] = built[0]
             for fi in range(len(docs)):
@@ -759,6 +765,34 @@ def _transcode_files(sources, cfg, devices, group, device, pipeline, timings):
         out.append((glb, [bytes(v) for v in views]))                            # (bytes: these results travel between processes / threads)
     tm["assemble_s"] = time.perf_counter() - t1
     return out
+
+
+def _share_native(raw_of, w_mine, cfg, tm):
+    """A rank's share of a sharded transcode through dmi_transcoder → [(blob bytes, num_faces, num_points) or None] in the share's order."""
+    import time
+    from .binding import Transcoder
+    n = len(w_mine)
+    tm["views_s"] = 0.0
+    with Transcoder(cfg, sum(w_mine), n, stage_triangles=PIPELINE_TRIANGLES) as t:
+        slice_tris = max(1, sum(w_mine) // 64)
+        lo = 0
+        while lo < n:
+            t0 = time.perf_counter()
+            hi, acc = lo, 0
+            while hi < n and (hi == lo or acc + w_mine[hi] <= slice_tris):
+                acc += w_mine[hi]
+                hi += 1
+            raws = [raw_of(k) for k in range(lo, hi)]
+            tm["views_s"] += time.perf_counter() - t0
+            t.push(raws)
+            lo = hi
+        t.finish()
+        tm.update(t.timings())
+        out = []
+        for k in range(n):
+            r = t.result(k)
+            out.append(None if r is None else (r[0][0].tobytes() + r[0][1].tobytes(), r[1], r[2]))
+        return out
 
 
 def _transcode_native(docs, per_file, flat, mine, w_mine, raw_of, built, cfg, tm):
