@@ -629,6 +629,15 @@ struct Walker {
 // (one flag byte per step, a mesh row apart: a new page every step) then miss the TLB on 20–40 % of their flag accesses — the 10M-face
 // traversal on the GPU box's EPYC: 64 ms against 48 ms with every array on huge pages.  Memory comes from posix_memalign: released by the
 // default operator delete (free).  DMI_NO_THP=1: plain malloc.
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define DMI_NO_OPERATOR_NEW 1      // (the sanitizer build keeps the runtime's allocator: it pairs operator new with operator delete)
+#endif
+#endif
+#if defined(__SANITIZE_ADDRESS__)
+#define DMI_NO_OPERATOR_NEW 1
+#endif
+#ifndef DMI_NO_OPERATOR_NEW
 void* operator new(std::size_t n) {   // (local to the library: libdraco_mi.map)
   constexpr std::size_t kHuge = (std::size_t)2 << 20;
   static const bool off = std::getenv("DMI_NO_THP") != nullptr;
@@ -641,6 +650,7 @@ void* operator new(std::size_t n) {   // (local to the library: libdraco_mi.map)
   throw std::bad_alloc();
 }
 void* operator new[](std::size_t n) { return ::operator new(n); }
+#endif
 
 namespace dmi {
 void advise_huge_pages(void* p, size_t bytes) {
