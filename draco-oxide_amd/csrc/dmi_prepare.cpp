@@ -255,6 +255,8 @@ static std::atomic<uint64_t> g_conn_us[4];
 // set by a batch worker whose batch keeps every host thread busy with a mesh of its own: a large mesh then walks its steps one after the other on
 // its worker (the overlapped form starts three more threads per mesh — with 16 workers on 16 CPUs they only wait for each other)
 static thread_local bool g_batch_worker_busy = false;
+// dmi_encode_mesh_device's read-back of the faces / maps (on a stream of its own, beside the table kernels): waited for right before the host reads them
+static thread_local hipEvent_t g_faces_event = nullptr;
 // pre (nullable): the universal table already built by the device stage; view_faces: c2p may view the caller's face array (it outlives `o`)
 static int build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std::vector<uint8_t>& bytes, const PrebuiltTable* pre = nullptr, bool view_faces = false) {
   if (!mesh || !mesh->atts || mesh->num_atts == 0 || (!mesh->faces && mesh->num_faces)) return fail(DMI_ERR_INVALID_ARGUMENT, "bad mesh");
@@ -589,6 +591,7 @@ static int mesh_prepare_impl(const dmi_mesh* mesh, const dmi_config* cfg, dmi_bu
       g_tables_ms = dt.t_down;
       if (trace) std::fprintf(stderr, "[dmi]   universal table of %u faces on the device: uploads issued %.2f ms, kernels + read-back issued %.2f, arrived %.2f (flags %#x)\n", mesh->num_faces, dt.t_up, dt.t_kernels, dt.t_down, dt.flags);
     }
+    if (g_faces_event) { HIP_TRY(hipEventSynchronize(g_faces_event)); g_faces_event = nullptr; }   // (the host shadow of the faces / maps: in flight since before the table kernels)
     if (src && !dt.valid) return kNeedHostValues;
     rc = build_connectivity(mesh, o, bytes, dt.valid ? &dt.pre : nullptr, /*view_faces=*/true);
     if (rc) return rc;
@@ -1524,16 +1527,22 @@ int dmi_encode_mesh_device(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buff
   stage.st = acquire_stage(device, need + 256);
   if (!stage.st) return fail(DMI_ERR_OUT_OF_MEMORY, "hipHostMalloc (mesh read-back)");
   uint8_t* hp = stage.st->p;
-  if (C) HIP_TRY(hipMemcpyAsync(hp, mesh->faces, C * 4, hipMemcpyDeviceToHost, s));
+  // (on a stream of its own: the table kernels of mesh_prepare_impl run on the thread's stream meanwhile; the host waits for both before its walks)
+  hipStream_t s_down = cfg && cfg->stream ? s : group_stream(device, 0);
+  if (!s_down) s_down = s;
+  if (C) HIP_TRY(hipMemcpyAsync(hp, mesh->faces, C * 4, hipMemcpyDeviceToHost, s_down));
   for (uint32_t i = 0; i < mesh->num_atts; ++i) {
     if (!atts[i].point_to_value) continue;
     bool first = true;
     for (uint32_t j = 0; j < i; ++j) if (mesh->atts[j].point_to_value == mesh->atts[i].point_to_value) first = false;
-    if (first) HIP_TRY(hipMemcpyAsync(hp + map_at[i], mesh->atts[i].point_to_value, (size_t)atts[i].num_points * 4, hipMemcpyDeviceToHost, s));
+    if (first) HIP_TRY(hipMemcpyAsync(hp + map_at[i], mesh->atts[i].point_to_value, (size_t)atts[i].num_points * 4, hipMemcpyDeviceToHost, s_down));
     atts[i].point_to_value = reinterpret_cast<const uint32_t*>(hp + map_at[i]);
   }
-  HIP_TRY(hipStreamSynchronize(s));
-  const double t_down = ms();
+  struct DownEvent { hipEvent_t e = nullptr; ~DownEvent() { g_faces_event = nullptr; if (e) { (void)hipEventSynchronize(e); (void)hipEventDestroy(e); } } } down;
+  HIP_TRY(hipEventCreateWithFlags(&down.e, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(down.e, s_down));
+  g_faces_event = down.e;
+  const double t_down = ms();   // (issue time: the copy itself runs beside the table kernels and is waited for inside mesh_prepare_impl)
   dmi_mesh shadow{reinterpret_cast<const uint32_t*>(hp), mesh->num_faces, atts.data(), mesh->num_atts};
   const DeviceMeshSrc src{mesh->faces, mesh->atts[0].point_to_value};
   dmi_buffer head{}, att{};
