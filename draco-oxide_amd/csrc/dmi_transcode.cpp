@@ -8,6 +8,7 @@
 // under one interpreter lock: ≈ 120 of a 165 ms transcode of 1024 files); here a stage changes hands without it.
 #include <atomic>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <condition_variable>
 #include <deque>
@@ -78,12 +79,15 @@ struct dmi_transcoder {
   std::mutex result_mutex;
   // steps
   Slot to_build, to_prepare, to_encode;
-  std::thread t_build, t_build2, t_prepare, t_encode;
-  std::atomic<int> builders_left{0};
+  std::thread t_build, t_build2, t_prepare, t_prepare2, t_encode;
+  std::atomic<int> builders_left{0}, preparers_left{0};
   std::mutex err_mutex;
   int rc = DMI_OK;
   std::string err;
   double ms_build = 0, ms_prepare = 0, ms_encode = 0;
+  const bool trace = std::getenv("DMI_TRACE") != nullptr;
+  const double t_create = now_ms();
+  void note(const char* step, const Stage& s, double t0) const { if (trace) std::fprintf(stderr, "[dmi] transcoder %-8s stage@%-5u (%4u primitives) %7.1f -> %7.1f ms\n", step, s.first, s.count, t0 - t_create, now_ms() - t_create); }
   bool started = false, finished = false;
 
   void fail_with(int code) {
@@ -103,6 +107,7 @@ struct dmi_transcoder {
       { std::lock_guard<std::mutex> lock(push_mutex); p = prims.data() + s->first; }   // (prims only grows by reserve-free push_back under the lock: see push)
       const int r = dmi_meshes_build(p, s->count, &cfg, 0u, s->built.data());
       { std::lock_guard<std::mutex> lock(err_mutex); ms_build += now_ms() - t0; }
+      note("build", *s, t0);
       if (r) { fail_with(r); continue; }
       if (!to_prepare.put(std::move(s))) break;
     }
@@ -131,12 +136,13 @@ struct dmi_transcoder {
       }
       dmi_built_meshes_free(s->built.data(), s->count);   // (the jobs copied what they need)
       s->built.clear();
-      ms_prepare += now_ms() - t0;
+      { std::lock_guard<std::mutex> lock(err_mutex); ms_prepare += now_ms() - t0; }
+      note("prepare", *s, t0);
       if (r) { fail_with(r); continue; }
       if (failed()) { for (dmi_job* j : s->jobs) dmi_job_destroy(j); continue; }
       if (!to_encode.put(std::move(s))) break;
     }
-    to_encode.close();
+    if (preparers_left.fetch_sub(1) == 1) to_encode.close();   // (the last prepare thread out)
   }
   void encode_loop() {
     while (std::unique_ptr<Stage> s = to_encode.take()) {
@@ -150,6 +156,7 @@ struct dmi_transcoder {
       for (dmi_job* j : s->jobs) dmi_job_destroy(j);
       s->jobs.clear();
       ms_encode += now_ms() - t0;
+      note("encode", *s, t0);
       if (r) { fail_with(r); continue; }
       if (!failed() && done) done(user, s->first, s->count);
     }
@@ -164,7 +171,11 @@ struct dmi_transcoder {
     builders_left = nb;
     t_build = std::thread([this] { build_loop(); });
     if (nb > 1) t_build2 = std::thread([this] { build_loop(); });
+    const char* ep = std::getenv("DMI_PREPARE_WORKERS");
+    const int np = ep && std::atoi(ep) == 2 ? 2 : 1;
+    preparers_left = np;
     t_prepare = std::thread([this] { prepare_loop(); });
+    if (np > 1) t_prepare2 = std::thread([this] { prepare_loop(); });
     t_encode = std::thread([this] { encode_loop(); });
   }
   // hands the primitives pushed so far to the build step once they make a stage (or all of them: flush)
@@ -239,6 +250,7 @@ int dmi_transcoder_finish(dmi_transcoder* t) {
     if (t->t_build.joinable()) t->t_build.join();
     if (t->t_build2.joinable()) t->t_build2.join();
     if (t->t_prepare.joinable()) t->t_prepare.join();
+    if (t->t_prepare2.joinable()) t->t_prepare2.join();
     if (t->t_encode.joinable()) t->t_encode.join();
     t->finished = true;
   }
