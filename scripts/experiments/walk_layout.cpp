@@ -308,7 +308,9 @@ struct LibWalker {
       if (c == kNone) { bad = true; break; }
       if (fv[c / 3] & 1) { stack.pop_back(); continue; }
       for (;;) {
+#ifndef LIB_NO_GUARD
         if (c == kNone || n >= cap) { bad = true; break; }
+#endif
         pf(opp + c); pf(c2v + c);
         const uint32_t f = c / 3, k = c - 3 * f, v = c2v[c];
         const uint32_t cn = k == 2 ? c - 2 : c + 1;
@@ -328,9 +330,13 @@ struct LibWalker {
         const uint8_t nb = (uint8_t)(gate | ((rc != kNone && rv) ? 0x20u : 0u) | ((lc != kNone && lv) ? 0x40u : 0u));
         const uint64_t symbol_idx = n;
         if (rv) {
+#ifndef LIB_NO_SPLITS
           if (rc != kNone && (rf & 2)) note_split(symbol_idx, 1, rc / 3);
+#endif
           if (lv) {
+#ifndef LIB_NO_SPLITS
             if (lc != kNone && (lf & 2)) note_split(symbol_idx, 0, lc / 3);
+#endif
             sym[n++] = (uint8_t)(SYM_E | nb);
             stack.pop_back();
             break;
@@ -338,7 +344,9 @@ struct LibWalker {
           sym[n++] = (uint8_t)(SYM_R | nb);
           c = lc;
         } else if (lv) {
+#ifndef LIB_NO_SPLITS
           if (lc != kNone && (lf & 2)) note_split(symbol_idx, 0, lc / 3);
+#endif
           sym[n++] = (uint8_t)(SYM_L | nb);
           c = rc;
         } else {
@@ -508,6 +516,55 @@ struct Shadow {
       const uint32_t start = 3 * f;
       vvis[c2v[start]] |= 1; vvis[c2v[start + 1]] |= 1; vvis[c2v[start + 2]] |= 1;
       stamp[f] = 0x3FFFFFFFu;
+      run_from(opp[cnext(start)]);
+    }
+  }
+};
+
+
+// ---------------- per-CORNER visited flags: a neighbour's state is cvis[its corner] — no division by three for the two faces across the edges ----------------
+struct CornerFlags {
+  uint32_t F, V;
+  const uint32_t *opp, *c2v;
+  uint8_t *cvis, *vvis;      // cvis: 3F bytes
+  uint32_t* processed; uint8_t* symbols; size_t n_processed = 0;
+  std::vector<uint32_t> stack;
+  void run_from(uint32_t c) {
+    stack.clear(); stack.push_back(c);
+    while (!stack.empty()) {
+      c = stack.back();
+      if (cvis[c] & 1) { stack.pop_back(); continue; }
+      for (;;) {
+        pf(opp + c); pf(c2v + c);
+        const uint32_t f = c / 3, k = c - 3 * f, v = c2v[c], b = c - k;
+        const uint32_t cn = k == 2 ? c - 2 : c + 1;
+        cvis[b] |= 1; cvis[b + 1] |= 1; cvis[b + 2] |= 1;
+        processed[n_processed] = c;
+        const uint32_t gate = opp[c] != kNone ? 0x10u : 0u;
+        const uint8_t vflags = vvis[v];
+        if (!(vflags & 1)) {
+          vvis[v] = vflags | 1;
+          if (!(vflags & 2)) { symbols[n_processed++] = (uint8_t)(SYM_C | gate); c = opp[cn]; continue; }
+        }
+        const uint32_t cp = k == 0 ? c + 2 : c - 1;
+        const uint32_t rc = opp[cn], lc = opp[cp];
+        const bool rv = rc == kNone || (cvis[rc] & 1), lv = lc == kNone || (cvis[lc] & 1);
+        const uint8_t nb = (uint8_t)(gate | ((rc != kNone && rv) ? 0x20u : 0u) | ((lc != kNone && lv) ? 0x40u : 0u));
+        if (rv) {
+          if (lv) { symbols[n_processed++] = (uint8_t)(SYM_E | nb); stack.pop_back(); break; }
+          symbols[n_processed++] = (uint8_t)(SYM_R | nb); c = lc;
+        } else if (lv) { symbols[n_processed++] = (uint8_t)(SYM_L | nb); c = rc; }
+        else { symbols[n_processed++] = (uint8_t)(SYM_S | nb); cvis[b] |= 2; cvis[b + 1] |= 2; cvis[b + 2] |= 2; stack.back() = lc; stack.push_back(rc); break; }
+      }
+    }
+  }
+  void edgebreaker() {
+    n_processed = 0;
+    for (uint32_t f = 0; f < F; ++f) {
+      if (cvis[3 * (size_t)f] & 1) continue;
+      const uint32_t start = 3 * f;
+      vvis[c2v[start]] |= 1; vvis[c2v[start + 1]] |= 1; vvis[c2v[start + 2]] |= 1;
+      cvis[start] |= 1; cvis[start + 1] |= 1; cvis[start + 2] |= 1;
       run_from(opp[cnext(start)]);
     }
   }
@@ -697,6 +754,19 @@ int main(int argc, char** argv) {
       for (size_t i = 0; ok && i < sA; ++i) ok = seqA[i] == seqB[i];
       std::printf("  shadow L1 prefetch, mode %d D = %2d: Edgebreaker %.1f ms (%.2f ns/face), sequencer %.1f ms (%.2f ns/face)  same order: %s\n", mode, D, b0, b0 * 1e6 / F, bs, bs * 1e6 / F, ok ? "yes" : "NO");
     }
+  }
+  {
+    uint8_t* cvis = huge_alloc<uint8_t>(C + 1024) + 512;
+    double b0 = 1e30; size_t nC = 0;
+    for (int r = 0; r < repeats; ++r) {
+      std::memset(cvis, 0, C); std::memset(vvis, 0, V);
+      CornerFlags h{F, V, opp, c2v, cvis, vvis, processedB, symB};
+      double t0 = now_ms(); h.edgebreaker(); double t1 = now_ms();
+      nC = h.n_processed; b0 = std::min(b0, t1 - t0);
+    }
+    bool ok = nC == nA;
+    for (size_t i = 0; ok && i < nA; ++i) ok = processedA[i] == processedB[i] && symA[i] == symB[i];
+    std::printf("  per-corner visited flags: Edgebreaker %.1f ms (%.2f ns/face)  same order: %s\n", b0, b0 * 1e6 / F, ok ? "yes" : "NO");
   }
   { double best = 1e30; size_t nn = 0; for (int r = 0; r < repeats; ++r) { LibWalker w{F, V, opp, c2v}; best = std::min(best, w.edgebreaker()); nn = w.n_out; }
     std::printf("  the library's lean loop, verbatim: %.1f ms (%.2f ns/face), %zu symbols\n", best, best * 1e6 / F, nn); }
