@@ -480,13 +480,27 @@ struct Walker {
   size_t n_out = 0;                   // faces processed so far = symbols written (processed / symbols are filled through data(): finish() sets their size)
   bool bad = false;
 
+  // Large meshes keep their face flags as 32-bit STAMPS (0 = unvisited, else position in `processed` + 1; bit 31: an S face): a step that sees a visited
+  // neighbour then knows where in `processed` the spiral's previous loop passed this spot, a shadow index follows the walk one loop behind, and the
+  // table lines of the face that loop processed a dozen steps later — the neighbours of what this walk reaches a dozen steps from now — are
+  // requested into L1: the hop of a step (corner → opposite[next(corner)] → next corner) then hits L1 instead of L2 (traversal of the 10M-triangle
+  // grid −7…13 % in the stand-alone loop, scripts/experiments/walk_layout.cpp).  Small meshes — a batch's — keep byte flags (their tables sit in L2 / L3).
+  std::vector<uint32_t> stamp;
+  bool use_stamp = false;
+  static constexpr uint32_t kStampS = 0x80000000u, kStampStart = 0x7FFFFFFFu;
+  bool face_visited(uint32_t f) const { return use_stamp ? stamp[f] != 0u : (fvis[f] & 1) != 0; }
+  void mark_start_face(uint32_t f) { if (use_stamp) stamp[f] = kStampStart; else fvis[f] |= 1; }
+
   explicit Walker(const CornerTables& tt) : t(tt), C(tt.F * 3) {
     pool_fit(vvis, t.V); vvis.assign(t.V, 0);
-    pool_fit(fvis, t.F); fvis.assign(t.F, 0);
+    static const bool no_shadow = std::getenv("DMI_NO_SHADOW") != nullptr;
+    use_stamp = t.F >= (1u << 20) && t.F < 0x7FFFFFF0u && !no_shadow;
+    if (use_stamp) { pool_fit(stamp, t.F); stamp.assign(t.F, 0u); }
+    else { pool_fit(fvis, t.F); fvis.assign(t.F, 0); }
     pool_fit(processed, (size_t)t.F + 1); if (processed.capacity() < (size_t)t.F + 1) processed.reserve((size_t)t.F + 1);
     pool_fit(symbols, (size_t)t.F + 1); if (symbols.capacity() < (size_t)t.F + 1) symbols.reserve((size_t)t.F + 1);
   }
-  ~Walker() { pool_give(vvis); pool_give(fvis); pool_give(hole_of); pool_give(processed); pool_give(symbols); }
+  ~Walker() { pool_give(vvis); pool_give(fvis); pool_give(stamp); pool_give(hole_of); pool_give(processed); pool_give(symbols); }
   Walker(const Walker&) = delete;
   Walker& operator=(const Walker&) = delete;
   void finish() { set_size_written(processed, n_out); set_size_written(symbols, n_out); }
@@ -535,34 +549,47 @@ struct Walker {
     ++num_split_symbols;
     if ((vflags & 2) && !hole_done[hole_of[v]]) mark_boundary(c, false);
     split_symbol_of_face[f] = symbol_idx;
-    fvis[f] |= 2;
+    if (use_stamp) stamp[f] |= kStampS; else fvis[f] |= 2;
     stack.back() = lc;
     stack.push_back(rc);
   }
   // edgebreaker.rs:261-350.  The loop keeps its tables and outputs in locals (every flag store is a byte store, which may alias anything the
   // object holds: members would be reloaded after each of them) and writes one (corner, symbol) pair per step through raw pointers.
-  void run_from(uint32_t c) {
+  void run_from(uint32_t c) { if (use_stamp) run_from_t<true>(c); else run_from_t<false>(c); }
+  template <bool kStamp>
+  void run_from_t(uint32_t c) {
     const uint32_t* const opp = t.opp;
     const uint32_t* const c2v = t.c2v;
     uint8_t* const fv = fvis.data();
+    uint32_t* const st = stamp.data();
     uint8_t* const vv = vvis.data();
     uint32_t* const proc = processed.data();
     uint8_t* const sym = symbols.data();
     const size_t cap = t.F;            // a consistent table never processes a face twice: more symbols than faces ⇒ malformed (the reference would not terminate)
     size_t n = n_out;
+    size_t q = ~(size_t)0 >> 1;        // the shadow: position in `processed` of the previous loop's face beside this one (far away until a step sees a visited neighbour)
+    constexpr size_t kAhead = 12;
     stack.clear();
     stack.push_back(c);
     while (!stack.empty() && !bad) {
       c = stack.back();
       if (c == kNone) { bad = true; break; }
-      if (fv[c / 3] & 1) { stack.pop_back(); continue; }
+      if (kStamp ? st[c / 3] != 0u : (fv[c / 3] & 1) != 0) { stack.pop_back(); continue; }
       for (;;) {
         if (c == kNone || n >= cap) { bad = true; break; }
         prefetch_neighbours(opp + c); prefetch_neighbours(c2v + c);
         const uint32_t f = c / 3, k = c - 3 * f, v = c2v[c];
         const uint32_t cn = k == 2 ? c - 2 : c + 1;
-        prefetch_neighbours(fv + f); prefetch_neighbours(vv + v);
-        fv[f] |= 1;
+        if (kStamp) {
+          const size_t qa = q + kAhead;
+          if (qa < n) { const uint32_t g = proc[qa]; __builtin_prefetch(opp + g, 0, 3); __builtin_prefetch(opp + g + 16, 0, 3); __builtin_prefetch(opp + g - 16, 0, 3); __builtin_prefetch(c2v + g, 0, 3); }
+          ++q;
+          st[f] = (uint32_t)n + 1u;
+        } else {
+          prefetch_neighbours(fv + f);
+          fv[f] |= 1;
+        }
+        prefetch_neighbours(vv + v);
         proc[n] = c;
         const uint32_t gate = opp[c] != kNone ? 0x10u : 0u;   // (the face this one was entered from — or a start face — is always visited)
         const uint8_t vflags = vv[v];
@@ -573,16 +600,27 @@ struct Walker {
         }
         const uint32_t cp = k == 0 ? c + 2 : c - 1;
         const uint32_t rc = opp[cn], lc = opp[cp];
-        const uint8_t rf = rc == kNone ? 1 : fv[rc / 3], lf = lc == kNone ? 1 : fv[lc / 3];
-        const bool rv = rf & 1, lv = lf & 1;
+        // (neighbour states: byte flags — bit 0 visited, bit 1 S face — or stamps)
+        uint32_t rs = 0, ls = 0;
+        bool rv, lv, r_split, l_split;
+        if (kStamp) {
+          rs = rc == kNone ? 0u : st[rc / 3]; ls = lc == kNone ? 0u : st[lc / 3];
+          rv = rc == kNone || rs != 0u; lv = lc == kNone || ls != 0u;
+          r_split = (rs & kStampS) != 0u; l_split = (ls & kStampS) != 0u;
+        } else {
+          const uint8_t rf = rc == kNone ? 1 : fv[rc / 3], lf = lc == kNone ? 1 : fv[lc / 3];
+          rv = rf & 1; lv = lf & 1;
+          r_split = rc != kNone && (rf & 2); l_split = lc != kNone && (lf & 2);
+        }
         // bits 4–6 of a symbol: which of the edges opposite (c, next, prev) lead to a face processed EARLIER (or to a start face) — what the seam
         // streams emit for this face (edgebreaker.rs:611-636 walks the faces last to first and emits the edges whose other face is not visited yet)
         const uint8_t nb = (uint8_t)(gate | ((rc != kNone && rv) ? 0x20u : 0u) | ((lc != kNone && lv) ? 0x40u : 0u));
         const uint64_t symbol_idx = n;   // (symbols so far = the index of this one)
         if (rv) {
-          if (rc != kNone && (rf & 2)) note_split(symbol_idx, 1, rc / 3);
+          if (kStamp && rs) q = (size_t)(rs & 0x7FFFFFFFu);   // (the right face was processed at position rs - 1: the shadow moves on from the one after it)
+          if (r_split) note_split(symbol_idx, 1, rc / 3);
           if (lv) {
-            if (lc != kNone && (lf & 2)) note_split(symbol_idx, 0, lc / 3);
+            if (l_split) note_split(symbol_idx, 0, lc / 3);
             sym[n++] = (uint8_t)(SYM_E | nb);
             stack.pop_back();
             break;
@@ -590,7 +628,8 @@ struct Walker {
           sym[n++] = (uint8_t)(SYM_R | nb);
           c = lc;
         } else if (lv) {
-          if (lc != kNone && (lf & 2)) note_split(symbol_idx, 0, lc / 3);
+          if (kStamp && ls) q = (size_t)(ls & 0x7FFFFFFFu);
+          if (l_split) note_split(symbol_idx, 0, lc / 3);
           sym[n++] = (uint8_t)(SYM_L | nb);
           c = rc;
         } else {
@@ -704,14 +743,19 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
   s.leb128(t.F);
   s.u8((uint8_t)t.att.size());
   for (uint32_t f = 0; f < t.F && !w.bad; ++f) {   // edgebreaker.rs:478-511 (loop over corners ≡ loop over faces)
-    if (w.fvis[f] & 1) {
+    if (w.face_visited(f)) {
       // (eight visited faces at a time: after the first component's walk this loop only confirms that nothing is left — 10M byte tests otherwise)
-      const uint8_t* fv = w.fvis.data();
-      while (f + 8 < t.F && (f & 7u) == 7u) {
-        uint64_t eight;
-        std::memcpy(&eight, fv + f + 1, 8);
-        if ((eight & 0x0101010101010101ull) != 0x0101010101010101ull) break;
-        f += 8;
+      if (w.use_stamp) {
+        const uint32_t* st = w.stamp.data();
+        while (f + 8 < t.F && st[f + 1] && st[f + 2] && st[f + 3] && st[f + 4] && st[f + 5] && st[f + 6] && st[f + 7] && st[f + 8]) f += 8;
+      } else {
+        const uint8_t* fv = w.fvis.data();
+        while (f + 8 < t.F && (f & 7u) == 7u) {
+          uint64_t eight;
+          std::memcpy(&eight, fv + f + 1, 8);
+          if ((eight & 0x0101010101010101ull) != 0x0101010101010101ull) break;
+          f += 8;
+        }
       }
       continue;
     }
@@ -720,7 +764,7 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
     w.start_interior.push_back(interior);
     if (interior) {
       w.vvis[t.c2v[start]] |= 1; w.vvis[t.c2v[corner_next(start)]] |= 1; w.vvis[t.c2v[corner_prev(start)]] |= 1;
-      w.fvis[f] |= 1;
+      w.mark_start_face(f);
       w.init_corners.push_back(corner_next(start));
       w.run_from(t.opp[corner_next(start)]);
     } else {

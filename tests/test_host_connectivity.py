@@ -66,6 +66,15 @@ def test_connectivity_matches_oracle_on_synthetic(n, open_boundary):
     _compare_conn(oracle_from_product_mesh(mesh), mesh)
 
 
+@pytest.mark.parametrize("n, open_boundary", [(725, False), (727, True)])
+def test_connectivity_of_a_million_faces_matches_the_oracle(n, open_boundary):
+    """From 2^20 faces the traversal keeps 32-bit stamps instead of byte flags and follows its previous loop with an L1 prefetch (host_conn.cpp Walker):
+    same bytes, seeds and sequences as the oracle on a closed and an open 1.05M-face grid (positions only: the oracle's tables in a few seconds)."""
+    mesh = synth.torus_mesh(n, normals=False, uvs=False, open_boundary=open_boundary)
+    assert len(mesh.faces) >= 1 << 20
+    _compare_conn(oracle_from_product_mesh(mesh), mesh)
+
+
 def test_connectivity_non_manifold_and_seams():
     rng = np.random.default_rng(5)
     # two fans sharing one vertex (non-manifold vertex), an edge with three faces, and UV seams
