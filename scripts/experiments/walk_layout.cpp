@@ -509,6 +509,50 @@ struct Shadow {
     }
     return n_seq;
   }
+
+  // the sequencer with byte flags of its own, led by the traversal's stamps: the face the traversal processed D steps BEFORE the current one is (about)
+  // what this walk reaches in D steps (it runs backwards along the traversal, or hops to the neighbouring loop and goes on from there)
+  size_t sequence_oracle2(uint32_t* seq, uint8_t* fv2) {
+    size_t n_seq = 0;
+    const int D = kShadowD;
+    uint64_t left = n_processed;
+    uint32_t faces_left = F;
+    stack.clear();
+    auto emit = [&](uint32_t c) { const uint32_t v = c2v[c]; if (!(vvis[v] & 4)) { vvis[v] |= 4; seq[n_seq++] = c; } };
+    for (;;) {
+      uint32_t c;
+      if (!faces_left) break;
+      if (!stack.empty()) { c = stack.back(); stack.pop_back(); }
+      else if (left) { --left; c = processed[left]; }
+      else break;
+      if (fv2[c / 3]) continue;
+      pf(opp + c); pf(c2v + c);
+      const uint32_t nc = cnext(c), pc = cprev(c);
+      if (!(vvis[c2v[nc]] & 4) || !(vvis[c2v[pc]] & 4)) { emit(nc); emit(pc); stack.push_back(c); continue; }
+      {
+        const uint32_t p = stamp[c / 3] & 0x3FFFFFFFu;
+        if (p > (uint32_t)D + 1 && p <= n_processed) {
+          const uint32_t g = processed[p - 1 - D];
+          __builtin_prefetch(opp + g, 0, 3); __builtin_prefetch(opp + g + 16, 0, 3); __builtin_prefetch(opp + g - 16, 0, 3); __builtin_prefetch(c2v + g, 0, 3);
+          if (kShadowMode >= 1) __builtin_prefetch(stamp + g / 3, 0, 3);
+          if (kShadowMode >= 2) __builtin_prefetch(fv2 + g / 3, 1, 3);
+        }
+      }
+      fv2[c / 3] = 1; --faces_left;
+      const uint32_t v = c2v[c];
+      const uint32_t right = opp[nc], lft = opp[pc];
+      const uint8_t vflags = vvis[v];
+      if (!(vflags & 4)) {
+        emit(c);
+        if (!(vflags & 2)) { if (right != kNone) stack.push_back(right); continue; }
+      }
+      const bool rdone = right != kNone && fv2[right / 3], ldone = lft != kNone && fv2[lft / 3];
+      if (rdone) { if (!ldone && lft != kNone) stack.push_back(lft); }
+      else if (ldone) { if (right != kNone) stack.push_back(right); }
+      else { if (lft != kNone) stack.push_back(lft); if (right != kNone) stack.push_back(right); }
+    }
+    return n_seq;
+  }
   void edgebreaker() {
     n_processed = 0;
     for (uint32_t f = 0; f < F; ++f) {
@@ -736,7 +780,7 @@ int main(int argc, char** argv) {
     uint32_t* stamp = huge_alloc<uint32_t>(F + 64) + 32;
     uint32_t* stamp2 = huge_alloc<uint32_t>(F + 64) + 32;
     uint32_t* order = huge_alloc<uint32_t>(F + 64) + 32;
-    for (int mode = 0; mode < 1; ++mode) for (int D : {0, 8, 16, 32}) {
+    for (int mode = 0; mode < (std::getenv("SEQ_O2") ? 3 : 1); ++mode) for (int D : {0, 8, 16, 32}) {
       kShadowD = D; kShadowMode = mode;
       double b0 = 1e30, bs = 1e30; size_t nS = 0, sS = 0;
       for (int r = 0; r < repeats; ++r) {
@@ -744,7 +788,8 @@ int main(int argc, char** argv) {
         Shadow h{F, V, opp, c2v, stamp, vvis, processedB, symB};
         double t0 = now_ms(); h.edgebreaker(); double t1 = now_ms();
         nS = h.n_processed; b0 = std::min(b0, t1 - t0);
-        if (std::getenv("SEQ_OWN")) { std::memset(stamp2, 0, 4 * (size_t)F); t0 = now_ms(); sS = h.sequence(seqB, stamp2, order); t1 = now_ms(); }
+        if (std::getenv("SEQ_O2")) { std::memset(fvis, 0, F); t0 = now_ms(); sS = h.sequence_oracle2(seqB, fvis); t1 = now_ms(); }
+        else if (std::getenv("SEQ_OWN")) { std::memset(stamp2, 0, 4 * (size_t)F); t0 = now_ms(); sS = h.sequence(seqB, stamp2, order); t1 = now_ms(); }
         else { t0 = now_ms(); sS = h.sequence_oracle(seqB); t1 = now_ms(); }
         bs = std::min(bs, t1 - t0);
       }
