@@ -480,11 +480,11 @@ struct Walker {
   size_t n_out = 0;                   // faces processed so far = symbols written (processed / symbols are filled through data(): finish() sets their size)
   bool bad = false;
 
-  // Large meshes keep their face flags as 32-bit STAMPS (0 = unvisited, else position in `processed` + 1; bit 31: an S face): a step that sees a visited
+  // Meshes of ≥ 2^16 faces keep their face flags as 32-bit STAMPS (0 = unvisited, else position in `processed` + 1; bit 31: an S face): a step that sees a visited
   // neighbour then knows where in `processed` the spiral's previous loop passed this spot, a shadow index follows the walk one loop behind, and the
   // table lines of the face that loop processed a dozen steps later — the neighbours of what this walk reaches a dozen steps from now — are
   // requested into L1: the hop of a step (corner → opposite[next(corner)] → next corner) then hits L1 instead of L2 (traversal of the 10M-triangle
-  // grid −7…13 % in the stand-alone loop, scripts/experiments/walk_layout.cpp).  Small meshes — a batch's — keep byte flags (their tables sit in L2 / L3).
+  // grid −7…13 % in the stand-alone loop, scripts/experiments/walk_layout.cpp).  Smaller meshes keep byte flags (their tables sit in L2).
   std::vector<uint32_t> stamp;
   bool use_stamp = false;
   static constexpr uint32_t kStampS = 0x80000000u, kStampStart = 0x7FFFFFFFu;
@@ -494,7 +494,8 @@ struct Walker {
   explicit Walker(const CornerTables& tt) : t(tt), C(tt.F * 3) {
     pool_fit(vvis, t.V); vvis.assign(t.V, 0);
     static const bool no_shadow = std::getenv("DMI_NO_SHADOW") != nullptr;
-    use_stamp = t.F >= (1u << 20) && t.F < 0x7FFFFFF0u && !no_shadow;
+    static const uint32_t min_faces = std::getenv("DMI_SHADOW_MIN_FACES") ? (uint32_t)std::atol(std::getenv("DMI_SHADOW_MIN_FACES")) : (1u << 16);   // (256-mesh batch: traversal thread time 71 → 68 ms with the meshes of ≥ 2^16 faces on stamps; below, tables and flags sit in L2)
+    use_stamp = t.F >= min_faces && t.F < 0x7FFFFFF0u && !no_shadow;
     if (use_stamp) { pool_fit(stamp, t.F); stamp.assign(t.F, 0u); }
     else { pool_fit(fvis, t.F); fvis.assign(t.F, 0); }
     pool_fit(processed, (size_t)t.F + 1); if (processed.capacity() < (size_t)t.F + 1) processed.reserve((size_t)t.F + 1);

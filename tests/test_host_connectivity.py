@@ -60,7 +60,7 @@ def test_connectivity_matches_oracle_on_fixtures(name):
     _compare_conn(sess, product_mesh_from_oracle(sess))
 
 
-@pytest.mark.parametrize("n,open_boundary", [(12, False), (17, True), (40, False), (120, False), (151, True)])   # (the last two: > 16384 seam flags, the all-zero stream coded by its period)
+@pytest.mark.parametrize("n,open_boundary", [(12, False), (17, True), (40, False), (120, False), (151, True), (190, False), (191, True)])   # (120 / 151: > 16384 seam flags, the all-zero stream coded by its period; 190 / 191: ≥ 2^16 faces, the traversal on stamps)
 def test_connectivity_matches_oracle_on_synthetic(n, open_boundary):
     mesh = synth.torus_mesh(n, open_boundary=open_boundary)
     _compare_conn(oracle_from_product_mesh(mesh), mesh)
@@ -68,8 +68,9 @@ def test_connectivity_matches_oracle_on_synthetic(n, open_boundary):
 
 @pytest.mark.parametrize("n, open_boundary", [(725, False), (727, True)])
 def test_connectivity_of_a_million_faces_matches_the_oracle(n, open_boundary):
-    """From 2^20 faces the traversal keeps 32-bit stamps instead of byte flags and follows its previous loop with an L1 prefetch (host_conn.cpp Walker):
-    same bytes, seeds and sequences as the oracle on a closed and an open 1.05M-face grid (positions only: the oracle's tables in a few seconds)."""
+    """From 2^16 faces the traversal keeps 32-bit stamps instead of byte flags and follows its previous loop with an L1 prefetch (host_conn.cpp Walker):
+    same bytes, seeds and sequences as the oracle on a closed and an open 1.05M-face grid (positions only: the oracle's tables in a few seconds; the
+    120- / 151-grids of the synthetic cases above and the fixtures cover both sides of the threshold)."""
     mesh = synth.torus_mesh(n, normals=False, uvs=False, open_boundary=open_boundary)
     assert len(mesh.faces) >= 1 << 20
     _compare_conn(oracle_from_product_mesh(mesh), mesh)
