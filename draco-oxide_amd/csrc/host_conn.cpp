@@ -1026,14 +1026,25 @@ void attribute_sequence(const TableRef& t, const uint32_t* seeds, uint32_t n_see
 }
 // The reference's stack starts as the seeds and only ever grows above them: what the walk pushes is popped before the next seed.  The seeds
 // are therefore read in place, last to first (second part, then first part), and only the pushes live on a stack of their own.
-void attribute_sequence(const TableRef& t, const uint32_t* first, uint32_t n_first, const uint32_t* second, uint32_t n_second, std::vector<uint32_t>& seq, const uint8_t* on_boundary) {
-  Pooled<uint8_t> vvis_p(t.V, (uint8_t)0), fvis_p(t.F, (uint8_t)0);
-  // vvis: bit 0 visited, bit 1 the vertex lies on a boundary (from on_boundary: one load less per new vertex)
-  if (on_boundary) parallel_for(t.V, [&](size_t lo, size_t hi) { for (size_t v = lo; v < hi; ++v) vvis_p.v[v] = on_boundary[v] ? 2 : 0; });
+// kStamp (tables of ≥ 2^16 faces): the per-vertex state is a 32-bit stamp — position in `seq` + 1, bit 31 = the vertex lies on a boundary — instead of a
+// flag byte: a step whose tip was emitted by the spiral's previous loop then knows where in `seq` that loop passed, a shadow index follows the walk one
+// loop behind, and the table lines of the corner that loop emitted a few entries later are requested into L1 (the traversal's trick, Walker::run_from_t:
+// 10M faces 44.5 → ≈ 40.5 ms).
+template <bool kStamp>
+static void sequence_impl(const TableRef& t, const uint32_t* first, uint32_t n_first, const uint32_t* second, uint32_t n_second, std::vector<uint32_t>& seq, const uint8_t* on_boundary) {
+  Pooled<uint8_t> vvis_p(kStamp ? 0 : t.V, (uint8_t)0), fvis_p(t.F, (uint8_t)0);
+  Pooled<uint32_t> vst_p(kStamp ? t.V : 0, 0u);
+  constexpr uint32_t kOnBoundary = 0x80000000u, kPos = 0x7FFFFFFFu;
+  // bytes: bit 0 visited, bit 1 the vertex lies on a boundary (from on_boundary: one load less per new vertex)
+  if (on_boundary) {
+    if (kStamp) parallel_for(t.V, [&](size_t lo, size_t hi) { for (size_t v = lo; v < hi; ++v) vst_p.v[v] = on_boundary[v] ? kOnBoundary : 0u; });
+    else parallel_for(t.V, [&](size_t lo, size_t hi) { for (size_t v = lo; v < hi; ++v) vvis_p.v[v] = on_boundary[v] ? 2 : 0; });
+  }
   // (tables, flags, the output and the stack in locals, written through raw pointers: see Walker::run_from)
   const uint32_t* const opp = t.opp;
   const uint32_t* const c2v = t.c2v;
   uint8_t* const vv = vvis_p.v.data();
+  uint32_t* const vs = vst_p.v.data();
   uint8_t* const fv = fvis_p.v.data();
   pool_fit(seq, t.V);
   if (seq.capacity() < (size_t)t.V) seq.reserve(t.V);
@@ -1052,7 +1063,14 @@ void attribute_sequence(const TableRef& t, const uint32_t* first, uint32_t n_fir
   // walk from the traversal's last corner marks a whole component before the next seed is read, so a one-component mesh would otherwise
   // spend F more iterations (10 ms per 10M faces) reading seeds it skips.
   uint32_t faces_left = t.F;
-  auto emit = [&](uint32_t c) { const uint32_t v = c2v[c]; const uint8_t f = vv[v]; if (!(f & 1) && nq < qcap) { vv[v] = f | 1; sq[nq++] = c; } };
+  size_t q = ~(size_t)0 >> 1;          // the shadow: position in `seq` of what the previous loop emitted beside this spot
+  constexpr size_t kAhead = 8;
+  auto visited = [&](uint32_t v) -> bool { return kStamp ? (vs[v] & kPos) != 0u : (vv[v] & 1) != 0; };
+  auto emit = [&](uint32_t c) {
+    const uint32_t v = c2v[c];
+    if (kStamp) { const uint32_t f = vs[v]; if (!(f & kPos) && nq < qcap) { sq[nq] = c; vs[v] = f | (uint32_t)++nq; } }
+    else { const uint8_t f = vv[v]; if (!(f & 1) && nq < qcap) { vv[v] = f | 1; sq[nq++] = c; } }
+  };
   for (;;) {
     uint32_t c;
     if (!faces_left) break;
@@ -1063,19 +1081,26 @@ void attribute_sequence(const TableRef& t, const uint32_t* first, uint32_t n_fir
     if (fv[f]) continue;
     prefetch_neighbours(opp + c); prefetch_neighbours(c2v + c); prefetch_neighbours(fv + f);
     const uint32_t k = c - 3 * f, nc = k == 2 ? c - 2 : c + 1, pc = k == 0 ? c + 2 : c - 1;
-    if (!(vv[c2v[nc]] & 1) || !(vv[c2v[pc]] & 1)) { emit(nc); emit(pc); push(c); continue; }
+    if (!visited(c2v[nc]) || !visited(c2v[pc])) { emit(nc); emit(pc); push(c); continue; }
+    if (kStamp) {
+      const size_t qa = q + kAhead;
+      if (qa < nq) { const uint32_t g = sq[qa]; __builtin_prefetch(opp + g, 0, 3); __builtin_prefetch(opp + g + 16, 0, 3); __builtin_prefetch(opp + g - 16, 0, 3); __builtin_prefetch(c2v + g, 0, 3); }
+    }
     fv[f] = 1;
     --faces_left;
     const uint32_t v = c2v[c];
-    prefetch_neighbours(vv + v);
+    if (!kStamp) prefetch_neighbours(vv + v);
     const uint32_t right = opp[nc], lft = opp[pc];
-    const uint8_t vflags = vv[v];
-    if (!(vflags & 1)) {
+    const uint32_t vflags = kStamp ? vs[v] : (uint32_t)vv[v];
+    if (kStamp ? !(vflags & kPos) : !(vflags & 1)) {
       emit(c);
+      ++q;
       bool boundary;
-      if (on_boundary) boundary = (vflags & 2) != 0;
+      if (on_boundary) boundary = kStamp ? (vflags & kOnBoundary) != 0u : (vflags & 2) != 0;
       else { const uint32_t l0 = t.lmc[v]; boundary = opp[corner_next(l0)] == kNone; }   // is_on_boundary: swing_left(lmc) is None
       if (!boundary) { if (right != kNone) push(right); continue; }
+    } else if (kStamp) {
+      q = (size_t)(vflags & kPos);   // (the tip was emitted at position (vflags & kPos) - 1: the shadow moves on from the entry after it)
     }
     const bool rdone = right != kNone && fv[right / 3], ldone = lft != kNone && fv[lft / 3];
     if (rdone) { if (!ldone && lft != kNone) push(lft); }
@@ -1083,6 +1108,11 @@ void attribute_sequence(const TableRef& t, const uint32_t* first, uint32_t n_fir
     else { if (lft != kNone) push(lft); if (right != kNone) push(right); }
   }
   set_size_written(seq, nq);
+}
+void attribute_sequence(const TableRef& t, const uint32_t* first, uint32_t n_first, const uint32_t* second, uint32_t n_second, std::vector<uint32_t>& seq, const uint8_t* on_boundary) {
+  static const bool no_shadow = std::getenv("DMI_NO_SHADOW") != nullptr || std::getenv("DMI_NO_SEQ_SHADOW") != nullptr;
+  if (t.F >= (1u << 16) && t.V < 0x7FFFFFF0u && !no_shadow) sequence_impl<true>(t, first, n_first, second, n_second, seq, on_boundary);
+  else sequence_impl<false>(t, first, n_first, second, n_second, seq, on_boundary);
 }
 
 }  // namespace dmi

@@ -553,6 +553,49 @@ struct Shadow {
     }
     return n_seq;
   }
+
+  // the sequencer with 32-bit VERTEX stamps (0 = not emitted, else position in `seq` + 1): a step whose tip was emitted by the previous loop knows where in
+  // `seq` that loop passed, and the table lines of the corner it emitted D entries later are requested into L1
+  size_t sequence_vstamp(uint32_t* seq, uint8_t* fv2, uint32_t* vst) {
+    size_t n_seq = 0;
+    const int D = kShadowD;
+    uint64_t left = n_processed;
+    uint32_t faces_left = F;
+    size_t q = ~(size_t)0 >> 1;
+    stack.clear();
+    auto emit = [&](uint32_t c) { const uint32_t v = c2v[c]; if (!vst[v]) { seq[n_seq] = c; vst[v] = (uint32_t)++n_seq; } };
+    for (;;) {
+      uint32_t c;
+      if (!faces_left) break;
+      if (!stack.empty()) { c = stack.back(); stack.pop_back(); }
+      else if (left) { --left; c = processed[left]; }
+      else break;
+      if (fv2[c / 3]) continue;
+      pf(opp + c); pf(c2v + c);
+      const uint32_t nc = cnext(c), pc = cprev(c);
+      if (!vst[c2v[nc]] || !vst[c2v[pc]]) { emit(nc); emit(pc); stack.push_back(c); continue; }
+      {
+        const size_t qa = q + (size_t)D;
+        if (qa < n_seq) { const uint32_t g = seq[qa]; __builtin_prefetch(opp + g, 0, 3); __builtin_prefetch(opp + g + 16, 0, 3); __builtin_prefetch(opp + g - 16, 0, 3); __builtin_prefetch(c2v + g, 0, 3); }
+      }
+      fv2[c / 3] = 1; --faces_left;
+      const uint32_t v = c2v[c];
+      const uint32_t right = opp[nc], lft = opp[pc];
+      const uint32_t vs = vst[v];
+      if (!vs) {
+        emit(c);
+        ++q;
+        if (right != kNone) stack.push_back(right);
+        continue;
+      }
+      q = vs;   // (the tip was emitted at position vs - 1: the shadow moves on from the entry after it)
+      const bool rdone = right != kNone && fv2[right / 3], ldone = lft != kNone && fv2[lft / 3];
+      if (rdone) { if (!ldone && lft != kNone) stack.push_back(lft); }
+      else if (ldone) { if (right != kNone) stack.push_back(right); }
+      else { if (lft != kNone) stack.push_back(lft); if (right != kNone) stack.push_back(right); }
+    }
+    return n_seq;
+  }
   void edgebreaker() {
     n_processed = 0;
     for (uint32_t f = 0; f < F; ++f) {
@@ -788,7 +831,8 @@ int main(int argc, char** argv) {
         Shadow h{F, V, opp, c2v, stamp, vvis, processedB, symB};
         double t0 = now_ms(); h.edgebreaker(); double t1 = now_ms();
         nS = h.n_processed; b0 = std::min(b0, t1 - t0);
-        if (std::getenv("SEQ_O2")) { std::memset(fvis, 0, F); t0 = now_ms(); sS = h.sequence_oracle2(seqB, fvis); t1 = now_ms(); }
+        if (std::getenv("SEQ_VS")) { std::memset(fvis, 0, F); std::memset(stamp2, 0, 4 * (size_t)V); t0 = now_ms(); sS = h.sequence_vstamp(seqB, fvis, stamp2); t1 = now_ms(); }
+        else if (std::getenv("SEQ_O2")) { std::memset(fvis, 0, F); t0 = now_ms(); sS = h.sequence_oracle2(seqB, fvis); t1 = now_ms(); }
         else if (std::getenv("SEQ_OWN")) { std::memset(stamp2, 0, 4 * (size_t)F); t0 = now_ms(); sS = h.sequence(seqB, stamp2, order); t1 = now_ms(); }
         else { t0 = now_ms(); sS = h.sequence_oracle(seqB); t1 = now_ms(); }
         bs = std::min(bs, t1 - t0);
