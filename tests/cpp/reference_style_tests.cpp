@@ -199,6 +199,48 @@ static void test_zero_length_normal_is_an_err_not_an_abort() {   // prediction_t
   if (r.is_err()) CHECK(r.unwrap_err().status == DMI_ERR_ZERO_NORMAL, "DMI_ERR_ZERO_NORMAL");
 }
 
+// io/gltf/encode.rs:1827-1842 — the transcoder's loop over a document's triangle primitives (MeshBuilder::build → encode::encode → bufferView), through
+// the C ABI's dmi_transcoder: primitives pushed as raw accessors, stages built / prepared / encoded on library threads, results by push index.
+struct DoneLog { std::vector<std::pair<uint32_t, uint32_t>> stages; };
+static void on_stage_done(void* user, uint32_t first, uint32_t count) { static_cast<DoneLog*>(user)->stages.push_back({first, count}); }
+static void test_transcoder_loop_over_primitives() {
+  const std::vector<RawMesh> prims = {torus(9), tetrahedron(), torus(14), torus(6), torus(21)};
+  std::vector<std::vector<uint32_t>> idx(prims.size());
+  std::vector<std::vector<dmi_raw_accessor>> acc(prims.size());
+  std::vector<dmi_raw_mesh> raw(prims.size());
+  static const uint32_t parent0 = 0;
+  uint64_t triangles = 0;
+  for (size_t k = 0; k < prims.size(); ++k) {
+    const RawMesh& m = prims[k];
+    for (auto& f : m.faces) for (size_t v : f) idx[k].push_back((uint32_t)v);
+    acc[k].push_back(dmi_raw_accessor{m.pos.data(), (uint32_t)m.pos.size(), 0, DMI_F32, 3, DMI_ATT_POSITION, DMI_DOMAIN_POSITION, 0, nullptr});
+    if (!m.nrm.empty()) acc[k].push_back(dmi_raw_accessor{m.nrm.data(), (uint32_t)m.nrm.size(), 0, DMI_F32, 3, DMI_ATT_NORMAL, DMI_DOMAIN_CORNER, 1, &parent0});
+    if (!m.uv.empty()) acc[k].push_back(dmi_raw_accessor{m.uv.data(), (uint32_t)m.uv.size(), 0, DMI_F32, 2, DMI_ATT_TEXCOORD, DMI_DOMAIN_CORNER, 1, &parent0});
+    raw[k] = dmi_raw_mesh{acc[k].data(), (uint32_t)acc[k].size(), idx[k].data(), DMI_U32, (uint32_t)m.faces.size()};
+    triangles += m.faces.size();
+  }
+  DoneLog log;
+  dmi_transcoder* t = dmi_transcoder_create(nullptr, triangles, /*stage_triangles=*/300, on_stage_done, &log);
+  CHECK(t != nullptr, "dmi_transcoder_create");
+  CHECK(dmi_transcoder_reserve(t, (uint32_t)raw.size()) == DMI_OK, "reserve");
+  CHECK(dmi_transcoder_push(t, raw.data(), 2) == DMI_OK && dmi_transcoder_push(t, raw.data() + 2, (uint32_t)raw.size() - 2) == DMI_OK, "push in two slices");
+  CHECK(dmi_transcoder_finish(t) == DMI_OK, dmi_last_error());
+  uint32_t seen = 0;
+  for (auto& st : log.stages) seen += st.second;
+  CHECK(seen == raw.size() && log.stages.size() > 1, "every primitive reported done, in more than one stage");
+  for (size_t k = 0; k < prims.size(); ++k) {
+    dmi_buffer head{}, section{};
+    uint32_t nf = 0, np = 0;
+    CHECK(dmi_transcoder_result(t, (uint32_t)k, &head, &section, &nf, &np) == DMI_OK, "result");
+    std::vector<uint8_t> blob(head.data, head.data + head.len);
+    blob.insert(blob.end(), section.data, section.data + section.len);
+    const core::Mesh built = build(prims[k]);
+    CHECK(nf == built.get_faces().size() && np == built.get_attributes()[0].len(), "face / point counts of the built mesh (the placeholder accessors)");
+    CHECK(blob == oracle_encode(prims[k]), "blob == the reference algorithm's .drc of the same primitive");
+  }
+  dmi_transcoder_destroy(t);
+}
+
 int main(int argc, char** argv) {
   const bool host_only = argc > 1 && std::string(argv[1]) == "--host";
   const std::string data = argc > 2 ? argv[2] : "tests/golden/data";
@@ -213,6 +255,7 @@ int main(int argc, char** argv) {
     test_encode_appends_to_the_writer();
     test_the_two_halves_of_encode();
     test_zero_length_normal_is_an_err_not_an_abort();
+    test_transcoder_loop_over_primitives();
   }
   std::printf(g_failed ? "%d check(s) FAILED\n" : "all checks passed\n", g_failed);
   return g_failed ? 1 : 0;
