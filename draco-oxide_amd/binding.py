@@ -594,6 +594,10 @@ class Transcoder:
         if n_primitives:
             _check(L.dmi_transcoder_reserve(self._h, int(n_primitives)))
 
+    def reserve(self, n_primitives):
+        """A hint: about this many primitives in all."""
+        _check(self._L.dmi_transcoder_reserve(self._h, int(n_primitives)))
+
     def push(self, raw_meshes):
         if not raw_meshes:
             return

@@ -27,6 +27,7 @@ namespace {
 
 struct Stage {
   uint32_t first = 0, count = 0;            // primitives [first, first + count) in push order
+  std::vector<dmi_raw_mesh> raw;            // their descriptors (a copy: the transcoder's own list may grow — and move — while the stage is built)
   std::vector<dmi_built_mesh> built;        // count entries (freed by the prepare step)
   std::vector<uint32_t> kept;               // indices (relative to first) of the primitives with a face left
   std::vector<dmi_job*> jobs;               // one per kept primitive (destroyed by the encode step)
@@ -103,9 +104,7 @@ struct dmi_transcoder {
       if (failed()) continue;
       const double t0 = now_ms();
       s->built.assign(s->count, dmi_built_mesh{});
-      const dmi_raw_mesh* p;
-      { std::lock_guard<std::mutex> lock(push_mutex); p = prims.data() + s->first; }   // (prims only grows by reserve-free push_back under the lock: see push)
-      const int r = dmi_meshes_build(p, s->count, &cfg, 0u, s->built.data());
+      const int r = dmi_meshes_build(s->raw.data(), s->count, &cfg, 0u, s->built.data());
       { std::lock_guard<std::mutex> lock(err_mutex); ms_build += now_ms() - t0; }
       note("build", *s, t0);
       if (r) { fail_with(r); continue; }
@@ -184,6 +183,7 @@ struct dmi_transcoder {
     if (dispatched == prims.size() || (!flush && pending_triangles < want)) return;
     std::unique_ptr<Stage> s(new Stage());
     s->first = dispatched; s->count = (uint32_t)prims.size() - dispatched;
+    s->raw.assign(prims.begin() + dispatched, prims.end());
     dispatched = (uint32_t)prims.size();
     pending_triangles = 0;
     first_stage = false;
@@ -211,12 +211,6 @@ int dmi_transcoder_push(dmi_transcoder* t, const dmi_raw_mesh* prims, uint32_t n
   if (t->failed()) { std::lock_guard<std::mutex> lock(t->err_mutex); return host_fail(t->rc, t->err); }
   {
     std::lock_guard<std::mutex> lock(t->push_mutex);
-    // (prims may reallocate: the build step reads its slice's address under this lock and the slice itself is never written again — but a
-    //  reallocation would move it: reserve in large steps and copy the descriptors of already dispatched primitives never; see build_loop)
-    if (t->prims.capacity() < t->prims.size() + n) {
-      if (t->dispatched) return host_fail(DMI_ERR_INVALID_ARGUMENT, "dmi_transcoder_push: more primitives than dmi_transcoder_reserve announced");
-      t->prims.reserve(std::max<size_t>(t->prims.size() + n, 2 * t->prims.capacity()));
-    }
     for (uint32_t k = 0; k < n; ++k) {
       t->accessors.emplace_back(prims[k].atts, prims[k].atts + prims[k].n_atts);
       dmi_raw_mesh m = prims[k];
@@ -235,8 +229,7 @@ int dmi_transcoder_push(dmi_transcoder* t, const dmi_raw_mesh* prims, uint32_t n
 int dmi_transcoder_reserve(dmi_transcoder* t, uint32_t n_primitives) {
   if (!t) return host_fail(DMI_ERR_INVALID_ARGUMENT, "null");
   std::lock_guard<std::mutex> lock(t->push_mutex);
-  if (t->dispatched && t->prims.capacity() < n_primitives) return host_fail(DMI_ERR_INVALID_ARGUMENT, "dmi_transcoder_reserve after the first stage started");
-  t->prims.reserve(n_primitives);
+  t->prims.reserve(n_primitives);   // (a hint: a stage carries a copy of its descriptors, the list may grow at any time)
   std::lock_guard<std::mutex> rlock(t->result_mutex);
   t->heads.reserve(n_primitives); t->sections.reserve(n_primitives); t->num_faces.reserve(n_primitives); t->num_points.reserve(n_primitives);
   return DMI_OK;

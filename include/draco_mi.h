@@ -279,7 +279,7 @@ int dmi_built_meshes_prepare(const dmi_built_mesh* built, uint32_t n, const dmi_
  * dmi_transcoder_result then gives primitive i's header + connectivity bytes and attribute section — blob = the two back to back, what
  * dmi_encode_mesh writes for the built mesh — and its face / point counts for the placeholder accessors (num_faces == 0: no face left, the
  * reference leaves such a primitive alone, io/gltf/encode.rs:934-936; both buffers empty).  The buffers are the transcoder's until
- * dmi_transcoder_destroy.  dmi_transcoder_reserve(total primitives) before the first push; dmi_transcoder_finish flushes the last stage,
+ * dmi_transcoder_destroy.  dmi_transcoder_reserve(total primitives) is a hint; dmi_transcoder_finish flushes the last stage,
  * waits for everything and returns the first error of any stage (dmi_last_error() of the calling thread names it).  One device (cfg->device). */
 typedef struct dmi_transcoder dmi_transcoder;
 typedef void (*dmi_transcode_done_fn)(void* user, uint32_t first, uint32_t count);
