@@ -300,11 +300,13 @@ class Mesh:
         return m
 
 
-def _dedup_rows(rows):
-    """First-occurrence value dedup with f32 `==` semantics (core/attribute/mod.rs:394-452): -0.0 == 0.0, NaN != NaN."""
+def _dedup_rows(rows, want_classes=False):
+    """First-occurrence value dedup with f32 `==` semantics (core/attribute/mod.rs:394-452): -0.0 == 0.0, NaN != NaN.
+    want_classes: also the BYTE CLASS of every row — what the point merge compares (core/mesh/builder.rs:254-279 hashes the bytes of
+    the row's unique value): the first occurrence of the row's `==` class, for a NaN row the first row with the same bytes."""
     r = np.ascontiguousarray(rows)
     if r.shape[0] == 0:
-        return r, None
+        return (r, None, np.zeros(0, np.int64)) if want_classes else (r, None)
     key = r
     nan_rows = None
     if r.dtype == np.float32:
@@ -314,15 +316,20 @@ def _dedup_rows(rows):
     kb = np.ascontiguousarray(key).view(np.dtype((np.void, key.dtype.itemsize * key.shape[1]))).ravel()
     _, first, inv = np.unique(kb, return_index=True, return_inverse=True)
     rep = first[inv]                         # first occurrence of each row's class
+    classes = rep
     if nan_rows is not None and nan_rows.any():
         idx = np.arange(r.shape[0])
-        rep = np.where(nan_rows, idx, rep)   # NaN rows are never merged
+        raw = r.view(np.dtype((np.void, r.dtype.itemsize * r.shape[1]))).ravel()
+        _, rfirst, rinv = np.unique(raw, return_index=True, return_inverse=True)
+        classes = np.where(nan_rows, rfirst[rinv], rep)   # byte-identical NaN rows: one class (a NaN row's bytes never equal a NaN-free row's)
+        rep = np.where(nan_rows, idx, rep)   # NaN rows are never merged as VALUES
     is_first = rep == np.arange(r.shape[0])
     if is_first.all():
-        return r, None
+        return (r, None, classes) if want_classes else (r, None)
     new_id = np.cumsum(is_first) - 1
     p2v = new_id[rep].astype(np.uint32)
-    return np.ascontiguousarray(r[is_first]), p2v
+    vals = np.ascontiguousarray(r[is_first])
+    return (vals, p2v, classes) if want_classes else (vals, p2v)
 
 
 class MeshBuilder:
@@ -385,15 +392,15 @@ class MeshBuilder:
         unreferenced points, builder.rs:129-189, which callers that index every point never have)."""
         atts = []
         for a in self._atts:
-            vals, p2v = _dedup_rows(a["data"])
-            atts.append(dict(a, values=vals, p2v=p2v, npoints=a["data"].shape[0]))
+            vals, p2v, classes = _dedup_rows(a["data"], want_classes=True)
+            atts.append(dict(a, values=vals, p2v=p2v, classes=classes, npoints=a["data"].shape[0]))
         for i, a in enumerate(atts):
             if a["type"] == ATT_POSITION:
                 atts[0], atts[i] = atts[i], atts[0]
                 break
         faces = self._faces
         npts = int(faces.max()) + 1 if faces.size else 0
-        keys = np.stack([(a["p2v"][:npts] if a["p2v"] is not None else np.arange(npts, dtype=np.uint32)) for a in atts], axis=1)
+        keys = np.stack([a["classes"][:npts].astype(np.uint32) for a in atts], axis=1)   # byte classes, not value ids: NaN rows (see _dedup_rows)
         kb = np.ascontiguousarray(keys).view(np.dtype((np.void, 4 * keys.shape[1]))).ravel()
         _, first, inv = np.unique(kb, return_index=True, return_inverse=True)
         rep = first[inv]
@@ -404,7 +411,13 @@ class MeshBuilder:
             faces = mapping[faces]
             for a in atts:
                 m = a["p2v"] if a["p2v"] is not None else np.arange(npts, dtype=np.uint32)
-                a["p2v"] = np.ascontiguousarray(m[:npts][is_first])
+                kept = m[:npts][is_first]
+                used = np.zeros(len(a["values"]), bool)
+                used[kept] = True
+                if not used.all():       # a NaN row's value whose only point was merged away leaves the buffer (Attribute::remove, mod.rs:454-483)
+                    kept = (np.cumsum(used) - 1).astype(np.uint32)[kept]
+                    a["values"] = np.ascontiguousarray(a["values"][used])
+                a["p2v"] = np.ascontiguousarray(kept) if a["p2v"] is not None else None
                 a["npoints"] = int(is_first.sum())
         keep = (faces[:, 0] != faces[:, 1]) & (faces[:, 1] != faces[:, 2]) & (faces[:, 2] != faces[:, 0])
         faces = faces[keep]

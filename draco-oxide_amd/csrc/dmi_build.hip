@@ -4,7 +4,9 @@
 //   value dedup     core/attribute/mod.rs:394-452   Attribute::from — pairwise `==`, duplicates map to their FIRST occurrence, ids compacted
 //                                                   in first-occurrence order; f32 `==` classes (-0.0 == 0.0, a row holding a NaN equals
 //                                                   nothing: macros/.../lib.rs:167-175)
-//   point merge     core/mesh/builder.rs:194-279    points that agree in EVERY attribute's value id are one point (first occurrence kept)
+//   point merge     core/mesh/builder.rs:194-279    points whose unique values are BYTE-identical in every attribute are one point (first
+//                                                   occurrence kept): the value id for a row that equals itself, the row's own bytes for a row
+//                                                   holding a NaN (hash_vertex :254-279 hashes bytes — two byte-identical NaN rows merge)
 //   degenerate      core/mesh/builder.rs:77-79      faces with a repeated point id are dropped
 //   unused points   core/mesh/builder.rs:129-189    points no face references are removed, faces renumbered; a value that loses its last
 //                                                   point leaves the buffer (Attribute::remove, mod.rs:454-483), order preserved
@@ -115,22 +117,25 @@ __global__ __launch_bounds__(kBlock) void k_mb_face_range(const MbArgs a) {
 }
 
 // ---- value classes per attribute ----
+// The table finds BYTE classes (what the point merge compares, builder.rs:254-279): rows without a NaN by `==` on canonical words — the value
+// classes of Attribute::from —, rows holding a NaN by their raw bits (a NaN row is a value of its own whatever the table says, but its point
+// merges with the point of a byte-identical NaN row).  A NaN row never compares equal to a NaN-free one under either rule, so one table holds both.
 __global__ __launch_bounds__(kBlock) void k_mb_value_insert(const MbArgs a) {
   for (uint32_t ap = blockIdx.x * kBlock + threadIdx.x; ap < a.total_ap; ap += gridDim.x * kBlock) {
     const MbItem it = a.items[item_of(a, ap)];
     const uint32_t p = ap - it.ap_off;
     const uint32_t* __restrict__ rows = a.raw_values + it.row_off;
     const bool fl = it.is_float != 0;
-    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    uint32_t raw[4] = {0u, 0u, 0u, 0u}, w[4] = {0u, 0u, 0u, 0u};
     bool nan = false;
-    uint32_t h = 0x9E3779B9u;
     for (uint32_t k = 0; k < it.words; ++k) {
-      const uint32_t x = rows[(size_t)p * it.words + k];
-      nan = nan || (fl && is_nan_bits(x));
-      w[k] = canon(x, fl);
-      h = mix(h, w[k]);
+      raw[k] = rows[(size_t)p * it.words + k];
+      nan = nan || (fl && is_nan_bits(raw[k]));
     }
-    if (nan) { a.vslot[ap] = kNoneD; continue; }   // equals nothing, not even itself: a class of its own
+    const bool cn = fl && !nan;   // compare canonical words (-0.0 == 0.0); a NaN row: its bits as they are
+    uint32_t h = nan ? 0x7F4A7C15u : 0x9E3779B9u;
+    for (uint32_t k = 0; k < it.words; ++k) { w[k] = canon(raw[k], cn); h = mix(h, w[k]); }
+    a.vflag[ap] = nan ? 1u : 0u;   // (parked for k_mb_value_first, which writes the first-occurrence flag here)
     uint32_t* __restrict__ tab = a.vtab + it.tab_off;
     h &= it.tab_mask;
     uint32_t probes = 0;
@@ -142,19 +147,23 @@ __global__ __launch_bounds__(kBlock) void k_mb_value_insert(const MbArgs a) {
         if (s == kNoneD) break;
       }
       bool same = true;   // (s may be lowered meanwhile by another member of ITS class: every index a slot ever holds is of one class)
-      for (uint32_t k = 0; k < it.words; ++k) same = same && canon(rows[(size_t)s * it.words + k], fl) == w[k];
+      for (uint32_t k = 0; k < it.words; ++k) same = same && canon(rows[(size_t)s * it.words + k], cn) == w[k];
       if (same) { if (p < s) atomicMin(&tab[h], p); break; }
       h = (h + 1) & it.tab_mask;
     }
     a.vslot[ap] = probes > kMaxProbes ? kNoneD : h;
   }
 }
-// representative (first occurrence) of every row; first-occurrence flags for the rank scan
+// representative (first occurrence) of every row as a VALUE — a NaN row is its own — and as a BYTE CLASS (parked in vslot, whose slot number
+// nobody needs any more: the point merge's key); first-occurrence flags for the rank scan
 __global__ __launch_bounds__(kBlock) void k_mb_value_first(const MbArgs a) {
   for (uint32_t ap = blockIdx.x * kBlock + threadIdx.x; ap < a.total_ap; ap += gridDim.x * kBlock) {
     const MbItem& it = a.items[item_of(a, ap)];
     const uint32_t p = ap - it.ap_off, s = a.vslot[ap];
-    const uint32_t rep = s == kNoneD ? p : a.vtab[it.tab_off + s];
+    const bool nan = a.vflag[ap] != 0u;
+    const uint32_t cls = s == kNoneD ? p : a.vtab[it.tab_off + s];
+    const uint32_t rep = nan ? p : cls;
+    a.vslot[ap] = cls;
     a.vid[ap] = rep;
     a.vflag[ap] = rep == p ? 1u : 0u;
   }
@@ -170,7 +179,8 @@ __global__ __launch_bounds__(kBlock) void k_mb_value_ids(const MbArgs a) {
   }
 }
 
-// ---- point classes: the tuple of value ids (builder.rs:254-279 hashes the unique values' bytes at the point — the same classes) ----
+// ---- point classes: the tuple of byte classes (builder.rs:254-279 hashes the unique values' bytes at the point; vslot holds, per attribute and
+// point, the smallest row index of the row's byte class — k_mb_value_first) ----
 constexpr int kMaxKey = 8;   // attributes per mesh the device form takes (MB_MAX_ATTS)
 __global__ __launch_bounds__(kBlock) void k_mb_point_insert(const MbArgs a) {
   for (uint32_t gp = blockIdx.x * kBlock + threadIdx.x; gp < a.total_points; gp += gridDim.x * kBlock) {
@@ -180,7 +190,7 @@ __global__ __launch_bounds__(kBlock) void k_mb_point_insert(const MbArgs a) {
     if (p >= a.mesh_out[me.index].nv) continue;   // points past the largest referenced one take no part (builder.rs:200, :258)
     uint32_t key[kMaxKey];
     uint32_t h = 0x9E3779B9u;
-    for (uint32_t k = 0; k < me.n_items; ++k) { key[k] = a.vid[a.items[me.item0 + k].ap_off + p]; h = mix(h, key[k]); }
+    for (uint32_t k = 0; k < me.n_items; ++k) { key[k] = a.vslot[a.items[me.item0 + k].ap_off + p]; h = mix(h, key[k]); }
     uint32_t* __restrict__ tab = a.ptab + me.ptab_off;
     h &= me.ptab_mask;
     uint32_t probes = 0;
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(kBlock) void k_mb_point_insert(const MbArgs a) {
         if (s == kNoneD) break;
       }
       bool same = true;
-      for (uint32_t k = 0; k < me.n_items; ++k) same = same && a.vid[a.items[me.item0 + k].ap_off + s] == key[k];
+      for (uint32_t k = 0; k < me.n_items; ++k) same = same && a.vslot[a.items[me.item0 + k].ap_off + s] == key[k];
       if (same) { if (p < s) atomicMin(&tab[h], p); break; }
       h = (h + 1) & me.ptab_mask;
     }

@@ -337,7 +337,7 @@ struct MbArgs {
   const uint32_t* raw_values;   // rows of every item
   const uint32_t* raw_faces;    // 3·total_faces point ids
   uint32_t *vtab, *ptab;        // hash tables (filled with DMI_NONE)
-  uint32_t *vslot, *vflag /* total_ap + 1 */, *vid, *vfirst, *vused /* total_ap + 1 */;
+  uint32_t *vslot /* table slot of the row, then its byte class (k_mb_value_first) */, *vflag /* total_ap + 1 */, *vid, *vfirst, *vused /* total_ap + 1 */;
   uint32_t *pslot, *prep, *pflag /* total_points + 1 */, *used /* total_points + 1 */;
   uint32_t *keep /* total_faces + 1 */, *tmp_faces /* 3·total_faces */, *scan_partials;
   MbMeshOut* mesh_out; MbItemOut* item_out; uint32_t* totals /* [0] arena A words, [1] arena B words, [2] face words */;

@@ -217,9 +217,12 @@ std::string mesh_build(std::vector<Attribute> atts, std::vector<std::array<u32, 
     u32 maxp = 0;
     for (auto& f : faces) for (u32 p : f) maxp = std::max(maxp, p);
     const size_t num_vertices = (size_t)maxp + 1;
-    // hash_vertex :254-279 hashes (type, component type, N, raw value bytes) of every attribute
-    // for which point < len(); identical bytes ⇔ identical unique-value index after value dedup
-    // (NaN payloads excepted), so the key is the tuple of value indices.
+    // hash_vertex :254-279, as it stands: for every attribute with point < len() the key takes (attribute type, component type, N)
+    // and the RAW BYTES of the point's unique value (`get_data_as_bytes()[value_idx * size ..]`), not the value index.  After value
+    // dedup the two agree for every row that compares equal to itself (`==` rows share the first occurrence's bytes; rows that are
+    // `!=` differ in some byte) — but a row holding a NaN equals nothing in remove_duplicate_values (mod.rs:394-452) and so keeps a
+    // unique value of its own, while two byte-identical NaN rows still hash equal here: such points MERGE.  (The reference keeps a
+    // 64-bit SipHash of the key; a collision of that hash is the one thing not restated.)
     std::unordered_map<std::string, u32> uniq;
     std::vector<u32> mapping(num_vertices);
     u32 unique_count = 0;
@@ -227,13 +230,11 @@ std::string mesh_build(std::vector<Attribute> atts, std::vector<std::array<u32, 
     for (size_t p = 0; p < num_vertices; ++p) {
       key.clear();
       for (auto& a : atts) {
-        u32 v = NONE;
-        if (p < a.len()) {
-          v = a.val_idx((u32)p);
-          // bytes compare, not ==: two values that are == but not byte-identical cannot share an
-          // index's bytes, because dedup keeps only the first occurrence's bytes.
-        }
-        key.append(reinterpret_cast<const char*>(&v), 4);
+        if (p >= a.len()) { key.push_back('\0'); continue; }   // :258 — the attribute takes no part
+        key.push_back('\1');
+        key.push_back((char)a.type); key.push_back((char)a.ctype); key.push_back((char)a.ncomp);
+        const size_t vs = a.value_size();
+        key.append(reinterpret_cast<const char*>(a.data.data() + (size_t)a.val_idx((u32)p) * vs), vs);
       }
       auto it = uniq.find(key);
       if (it != uniq.end()) mapping[p] = it->second;

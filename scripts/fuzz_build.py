@@ -1,5 +1,5 @@
 """Fuzz of dmi_meshes_build (device MeshBuilder::build) against dmi_mesh_build (host builder, itself held to the oracle's restated builder by the
-tests): batches of random primitives — rows drawn from small pools (duplicates), ±0.0, NaN rows, constant attributes, strided rows, u8/u16/u32
+tests): batches of random primitives — rows drawn from small pools (duplicates), ±0.0, NaN rows, points copied whole (byte-identical NaN rows), NaN payloads, constant attributes, strided rows, u8/u16/u32
 indices, degenerate faces, unreferenced points, 1–5 attributes, Position not first.  usage: fuzz_build.py [batches] [first_seed]; tests/test_gpu_fuzz_slice.py
 runs a seeded slice under -m gpu."""
 import os
@@ -42,6 +42,21 @@ def random_primitive(rng):
         dom = dmi.DOMAIN_POSITION if t == dmi.ATT_POSITION else dmi.DOMAIN_CORNER
         par = [pos_at] if t in (dmi.ATT_NORMAL, dmi.ATT_TEXCOORD) else []
         specs.append((rows, t, dom, par))
+    if rng.random() < 0.5:   # points that are copies of other points in EVERY attribute — NaN rows included: byte-identical NaN rows merge (builder.rs:254-279)
+        k = max(1, n_pts // 8)
+        src, dst = rng.integers(0, n_pts, size=k), rng.integers(0, n_pts, size=k)
+        for rows, *_ in specs:
+            for s_, d_ in zip(src, dst):
+                rows[d_] = rows[s_]
+        if rng.random() < 0.5:   # … some of them with another NaN payload or the other zero: different bytes, no merge for a NaN row
+            for rows, *_ in specs:
+                if rows.dtype == np.float32 and rng.random() < 0.5:
+                    for d_ in dst[: max(1, k // 2)]:
+                        row = rows[d_]
+                        bits = np.ascontiguousarray(row).view(np.uint32).copy()
+                        bits[np.isnan(row)] ^= np.uint32(1)
+                        bits[row == 0] ^= np.uint32(0x80000000)
+                        rows[d_] = bits.view(np.float32)
     hi = n_pts if rng.random() < 0.7 else max(3, n_pts - int(rng.integers(1, 10)))   # sometimes the last points stay unreferenced
     faces = rng.integers(0, hi, size=(n_faces, 3)).astype(np.uint32)
     if rng.random() < 0.5:

@@ -69,3 +69,67 @@ def oracle_values_by_point(table, universal_table, decoded, num_points):
     ref = last >= 0
     out[ref] = by_vertex[c2v[last[ref]]]
     return out, ref
+
+
+def nan_twin_primitives():
+    """Primitives that hit the one place where the reference's point merge is not "same value ids": core/mesh/builder.rs:254-279 hashes
+    the BYTES of each attribute's unique value at the point.  A row holding a NaN equals nothing in the value dedup
+    (core/attribute/mod.rs:394-452) and keeps a value of its own, but two byte-identical NaN rows hash equal — their points merge when
+    every other attribute agrees.  → [(name, specs [(rows, type, domain, parents)], faces, points expected after the build)]."""
+    nan = np.float32(np.nan)
+
+    def base():
+        pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0], [2, 0, 0], [2, 1, 0], [0, 2, 0], [1, 2, 0]], np.float32)
+        nrm = np.tile(np.array([[0, 0, 1]], np.float32), (8, 1))
+        uv = (pos[:, :2] / np.float32(2.0)).astype(np.float32)
+        faces = np.array([[0, 1, 2], [1, 3, 2], [1, 4, 3], [4, 5, 3], [2, 3, 6], [3, 7, 6]], np.uint32)
+        return pos, nrm, uv, faces
+
+    def specs(pos, nrm, uv):
+        return [(pos, dmi.ATT_POSITION, dmi.DOMAIN_POSITION, []), (nrm, dmi.ATT_NORMAL, dmi.DOMAIN_CORNER, [0]), (uv, dmi.ATT_TEXCOORD, dmi.DOMAIN_CORNER, [0])]
+
+    out = []
+    # 1. NaN in positions, the two points byte-identical in every attribute: they merge (7 points), the second NaN value leaves the buffer
+    pos, nrm, uv, faces = base()
+    pos[5] = [nan, 1, 0]; pos[7] = pos[5]; nrm[7] = nrm[5]; uv[7] = uv[5]
+    out.append(("nan_positions_twins", specs(pos, nrm, uv), faces, 7))
+    # 2. NaN in normals only, twins
+    pos, nrm, uv, faces = base()
+    pos[7] = pos[5]; uv[7] = uv[5]; nrm[5] = [0, nan, 1]; nrm[7] = nrm[5]
+    out.append(("nan_normals_twins", specs(pos, nrm, uv), faces, 7))
+    # 3. NaN rows whose payloads differ: different bytes, no merge
+    pos, nrm, uv, faces = base()
+    pos[7] = pos[5]; uv[7] = uv[5]; nrm[5] = [0, nan, 1]; nrm[7] = nrm[5]
+    nrm.view(np.uint32)[7, 1] ^= 1
+    out.append(("nan_payloads_differ", specs(pos, nrm, uv), faces, 8))
+    # 4. NaN rows that differ in the sign of a zero elsewhere in the row: bytes differ, no merge (a NaN-free row WOULD merge: case 6)
+    pos, nrm, uv, faces = base()
+    pos[7] = pos[5]; uv[7] = uv[5]; nrm[5] = [0.0, nan, 1]; nrm[7] = [-0.0, nan, 1]
+    out.append(("nan_rows_signed_zero", specs(pos, nrm, uv), faces, 8))
+    # 5. byte-identical NaN rows in one attribute, another attribute differs: no merge, both NaN values stay
+    pos, nrm, uv, faces = base()
+    nrm[5] = [0, nan, 1]; nrm[7] = nrm[5]
+    out.append(("nan_twins_other_attribute_differs", specs(pos, nrm, uv), faces, 8))
+    # 6. -0.0 first, 0.0 later (and the other way round in another attribute): `==` rows, ONE value carrying the first occurrence's bytes: merge
+    pos, nrm, uv, faces = base()
+    pos[5] = [2, 1, -0.0]; pos[7] = [2, 1, 0.0]; nrm[5] = [0.0, 0, 1]; nrm[7] = [-0.0, 0, 1]; uv[7] = uv[5]
+    out.append(("signed_zero_first_occurrences", specs(pos, nrm, uv), faces, 7))
+    # 7. three byte-identical NaN points + a NaN row referenced by no face + NaN twins in TWO attributes
+    pos, nrm, uv, faces = base()
+    pos = np.vstack([pos, [[nan, nan, nan]], [[9, 9, 9]]]).astype(np.float32)
+    nrm = np.vstack([nrm, [[0, 0, 1]], [[0, 0, 1]]]).astype(np.float32)
+    uv = np.vstack([uv, [[0, 0]], [[nan, 0]]]).astype(np.float32)
+    for k in (5, 7, 8):
+        pos[k] = [nan, nan, nan]; nrm[k] = [nan, 0, 1]; uv[k] = [0.5, nan]
+    faces = np.vstack([faces, [[0, 8, 2]]]).astype(np.uint32)
+    out.append(("nan_triplet_two_attributes", specs(pos, nrm, uv), faces, 7))   # 10 points: 5, 7, 8 become one, point 9 is referenced by no face
+    # 8. NaN twins where the attribute has NO other duplicate (no point → value map before the merge)
+    pos, nrm, uv, faces = base()
+    nrm = (pos + np.float32(0.5)).astype(np.float32)
+    pos[5] = [nan, 1, 0]; pos[7] = pos[5]; nrm[7] = nrm[5]; uv[7] = uv[5]
+    out.append(("nan_twins_without_a_map", specs(pos, nrm, uv), faces, 7))
+    return out
+
+
+def oracle_session_of_specs(specs, faces):
+    return orc.Session.from_arrays(faces, [dict(data=np.ascontiguousarray(r), type=t, domain=d, parents=list(p)) for r, t, d, p in specs])

@@ -73,6 +73,35 @@ def test_device_build_matches_host_and_oracle_on_messy_rows(seed):
         assert a.num_points == o["len"] and a.unique_id == o["id"]
 
 
+def test_byte_identical_nan_rows_merge_on_the_device_too():
+    """core/mesh/builder.rs:254-279 keys a point on the BYTES of its unique values (tests/helpers.py nan_twin_primitives): the device's byte
+    classes against the host builder and the oracle's literal restatement, one primitive at a time and all of them in one batch."""
+    from helpers import nan_twin_primitives, oracle_session_of_specs
+    cases = nan_twin_primitives()
+    raws = []
+    for name, specs, faces, n_points in cases:
+        got, want = _both(specs, faces)
+        _same_mesh(got, want)
+        assert dmi.last_build_timings()["device_meshes"] == 1, name
+        assert got.attributes[0].num_points == n_points, name
+        sess = oracle_session_of_specs(specs, faces)
+        assert (got.faces == sess.faces()).all(), name
+        for a, o in zip(got.attributes, sess.attributes()):
+            assert a.values.tobytes() == o["data"].tobytes(), name
+            assert (a.point_to_value is None) == (o["p2v"] is None), name
+            assert o["p2v"] is None or (a.point_to_value == o["p2v"]).all(), name
+            assert a.num_points == o["len"], name
+        rm = dmi.RawMesh()
+        for rows, t, d, par in specs:
+            rm.add_attribute(rows, t, d, par)
+        rm.set_indices(faces.ravel())
+        raws.append(rm)
+    with dmi.meshes_build(raws, host_values=True) as batch:
+        assert dmi.last_build_timings()["device_meshes"] == len(cases)
+        for j, (name, specs, faces, n_points) in enumerate(cases):
+            assert batch.mesh(j).attributes[0].num_points == n_points, name
+
+
 @pytest.mark.parametrize("index_dtype", [np.uint8, np.uint16, np.uint32])
 def test_index_widths_and_strided_rows(index_dtype):
     n = 12 if index_dtype == np.uint8 else 40

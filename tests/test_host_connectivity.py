@@ -161,6 +161,27 @@ def test_cpp_mesh_builder_matches_the_restated_builder(seed):
     assert mesh.attributes[0].att_type == dmi.ATT_POSITION and mesh.attributes[1].parent_index == 0
 
 
+def test_byte_identical_nan_rows_merge_like_the_reference_hash():
+    """core/mesh/builder.rs:254-279 keys a point on the BYTES of its unique values: byte-identical NaN rows merge although the value dedup keeps
+    them apart.  Host builder and numpy builder against the oracle's literal restatement; expected point counts written out by hand."""
+    from helpers import nan_twin_primitives, oracle_session_of_specs
+    for name, specs, faces, n_points in nan_twin_primitives():
+        b = dmi.MeshBuilder()
+        for rows, t, d, par in specs:
+            b.add_attribute(rows, t, d, parents=par)
+        b.set_connectivity_attribute(faces)
+        mesh = b.build()
+        sess = oracle_session_of_specs(specs, faces)
+        _assert_built_like_oracle(mesh, sess)
+        assert mesh.attributes[0].num_points == n_points, name
+        m2 = b.build_numpy()
+        assert (m2.faces == mesh.faces).all(), name
+        for a, c in zip(mesh.attributes, m2.attributes):
+            assert a.values.tobytes() == c.values.tobytes() and a.num_points == c.num_points, name
+            assert (a.point_to_value is None) == (c.point_to_value is None), name
+            assert a.point_to_value is None or (a.point_to_value == c.point_to_value).all(), name
+
+
 def test_cpp_and_numpy_builders_agree_when_every_point_is_referenced():
     faces, pos, nrm, uv = synth.torus_grid(12)
     corner = faces.ravel()
