@@ -85,7 +85,22 @@ class _RawMesh(C.Structure):
 
 class _BuildTimings(C.Structure):
     _fields_ = [("pack_ms", C.c_float), ("kernels_ms", C.c_float), ("call_ms", C.c_float), ("device_meshes", C.c_uint32), ("host_meshes", C.c_uint32),
-                ("bytes_up", C.c_uint64), ("bytes_down", C.c_uint64)]
+                ("bytes_up", C.c_uint64), ("bytes_down", C.c_uint64), ("in_place_meshes", C.c_uint32), ("pad", C.c_uint32)]
+
+
+class _Span(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("bytes", C.c_size_t)]
+
+
+class _GltfAsset(C.Structure):
+    _fields_ = [("glb", C.c_void_p), ("glb_bytes", C.c_size_t), ("json", C.c_void_p), ("json_bytes", C.c_size_t), ("buffers", C.POINTER(_Span)), ("n_buffers", C.c_uint32)]
+
+
+class _TranscodeStats(C.Structure):
+    _fields_ = [("files", C.c_uint32), ("primitives", C.c_uint32), ("devices", C.c_uint32), ("pad", C.c_uint32),
+                ("triangles_in", C.c_uint64), ("bytes_in", C.c_uint64), ("bytes_out", C.c_uint64),
+                ("parse_ms", C.c_double), ("register_ms", C.c_double), ("pushed_ms", C.c_double), ("finished_ms", C.c_double),
+                ("build_ms", C.c_double), ("prepare_ms", C.c_double), ("encode_ms", C.c_double), ("assemble_ms", C.c_double), ("call_ms", C.c_double)]
 
 
 class _DecodedAttribute(C.Structure):
@@ -115,7 +130,9 @@ _TRANSCODE_DONE = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32)   # dmi_
 EXPORTS = ["dmi_encode_attributes", "dmi_encode_attributes_batch", "dmi_jobs_encode", "dmi_job_create", "dmi_job_encode", "dmi_job_timings", "dmi_job_destroy", "dmi_encode_mesh",
            "dmi_mesh_prepare", "dmi_meshes_prepare", "dmi_shard_meshes", "dmi_meshes_prepare_devices", "dmi_jobs_encode_devices", "dmi_mesh_build", "dmi_built_mesh_free", "dmi_encode_connectivity", "dmi_conn_free", "dmi_host_rans_stream", "dmi_host_rabs_stream", "dmi_host_rabs_constant_stream", "dmi_tile_sort_slots", "dmi_decode_attributes", "dmi_decoded_free", "dmi_decode_mesh", "dmi_decoded_mesh_free", "dmi_decode_connectivity", "dmi_decoded_conn_free", "dmi_last_decode_timings", "dmi_free", "dmi_free_many", "dmi_strerror", "dmi_last_error", "dmi_device_count", "dmi_release_cached_memory",
            "dmi_init", "dmi_last_call_timings", "dmi_device_corner_table", "dmi_encode_mesh_device", "dmi_meshes_build", "dmi_built_meshes_prepare", "dmi_last_build_timings", "dmi_device_attribute_table", "dmi_built_meshes_info", "dmi_built_meshes_free", "dmi_thread_host_threads", "dmi_usable_host_threads",
-           "dmi_transcoder_create", "dmi_transcoder_reserve", "dmi_transcoder_push", "dmi_transcoder_finish", "dmi_transcoder_result", "dmi_transcoder_timings", "dmi_transcoder_destroy"]
+           "dmi_transcoder_create", "dmi_transcoder_reserve", "dmi_transcoder_push", "dmi_transcoder_finish", "dmi_transcoder_result", "dmi_transcoder_timings", "dmi_transcoder_destroy",
+           "dmi_host_register", "dmi_host_unregister", "dmi_host_alloc", "dmi_host_free", "dmi_host_is_registered",
+           "dmi_transcode_assets", "dmi_transcoded_file", "dmi_transcoded_blobs", "dmi_transcoded_stats", "dmi_transcoded_free", "dmi_json_roundtrip"]
 
 
 def library_path():
@@ -205,6 +222,20 @@ def load_library():
     L.dmi_thread_host_threads.restype = None
     L.dmi_usable_host_threads.restype = C.c_int
     L.dmi_device_attribute_table.argtypes = [C.POINTER(_Mesh), C.POINTER(_Config), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.dmi_host_register.argtypes = [C.c_void_p, C.c_size_t]
+    L.dmi_host_unregister.argtypes = [C.c_void_p]
+    L.dmi_host_alloc.argtypes = [C.c_size_t]
+    L.dmi_host_alloc.restype = C.c_void_p
+    L.dmi_host_free.argtypes = [C.c_void_p]
+    L.dmi_host_free.restype = None
+    L.dmi_host_is_registered.argtypes = [C.c_void_p, C.c_size_t]
+    L.dmi_transcode_assets.argtypes = [C.POINTER(_GltfAsset), C.c_uint32, C.POINTER(_Config), C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.dmi_transcoded_file.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]
+    L.dmi_transcoded_blobs.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.dmi_transcoded_stats.argtypes = [C.c_void_p, C.POINTER(_TranscodeStats)]
+    L.dmi_transcoded_free.argtypes = [C.c_void_p]
+    L.dmi_transcoded_free.restype = None
+    L.dmi_json_roundtrip.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(_Buffer)]
     _lib = L
     return L
 
@@ -550,6 +581,125 @@ def meshes_build(raw_meshes, cfg=None, host_values=False):
     c = cfg._c()
     _check(L.dmi_meshes_build(arr, n, C.byref(c), BUILD_HOST_VALUES if host_values else 0, built))
     return BuiltBatch(built, n, keep)
+
+
+def _address_of(buf):
+    """(address, length) of a bytes-like object's memory (bytes / bytearray / memoryview / numpy array), without copying."""
+    a = np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else buf
+    return a.ctypes.data, a.nbytes
+
+
+def host_register(buf):
+    """dmi_host_register on the memory of a bytes-like object: accessors inside it are then read by the device where they lie (no pack, no
+    upload copy).  The object must stay alive and unchanged until host_unregister(buf).  Returns False where the runtime refuses the range."""
+    addr, n = _address_of(buf)
+    return n > 0 and load_library().dmi_host_register(addr, n) == 0
+
+
+def host_unregister(buf):
+    addr, _ = _address_of(buf)
+    load_library().dmi_host_unregister(addr)
+
+
+class HostBuffer:
+    """dmi_host_alloc memory as a writable uint8 numpy array (`.array`): what an importer reads a file INTO so that nothing is page-locked later."""
+
+    def __init__(self, nbytes):
+        self._p = load_library().dmi_host_alloc(nbytes)
+        if not self._p:
+            raise MemoryError("dmi_host_alloc")
+        self.array = np.ctypeslib.as_array(C.cast(self._p, C.POINTER(C.c_uint8)), shape=(nbytes,))
+
+    def free(self):
+        if self._p:
+            self.array = None
+            load_library().dmi_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+TRANSCODE_NO_REGISTER = 1
+
+
+def json_roundtrip(text):
+    """dmi_json_roundtrip: the library's JSON layer (parse + compact write) on `text` (bytes) → bytes."""
+    L = load_library()
+    out = _Buffer()
+    _check(L.dmi_json_roundtrip(text, len(text), C.byref(out)))
+    try:
+        return C.string_at(out.data, out.len)
+    finally:
+        L.dmi_free(C.byref(out))
+
+
+class _TranscodedHandle:
+    """Owner of a dmi_transcoded: every view handed out keeps it alive; the library's memory goes back when the last one is gone."""
+
+    def __init__(self, h):
+        self.h = h
+
+    def __del__(self):
+        try:
+            if self.h:
+                load_library().dmi_transcoded_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def transcode_assets(assets, cfg=None, devices=None, register=True):
+    """dmi_transcode_assets: `assets` = GLB containers (bytes-like) or (json_bytes, [buffer bytes-like, ...]) pairs → ([(glb, [blob, ...]), ...], stats).
+    glb and the blobs are memoryviews of memory the library owns (the blobs lie inside their file; everything is released when the last view is
+    gone); stats = dmi_transcode_stats as a dict.  devices: HIP ordinals (one dmi_transcoder each; None: cfg.device)."""
+    L = load_library()
+    cfg = cfg or Config.default()
+    n = len(assets)
+    arr = (_GltfAsset * max(n, 1))()
+    keep = []
+    for i, a in enumerate(assets):
+        if isinstance(a, tuple):
+            js, buffers = a
+            js = bytes(js)
+            spans = (_Span * max(len(buffers), 1))()
+            for k, b in enumerate(buffers):
+                addr, nb = _address_of(b) if len(b) else (0, 0)
+                spans[k].data, spans[k].bytes = addr, nb
+            keep.append((js, buffers, spans))
+            arr[i].glb, arr[i].glb_bytes = None, 0
+            arr[i].json, arr[i].json_bytes = C.cast(C.c_char_p(js), C.c_void_p), len(js)
+            arr[i].buffers, arr[i].n_buffers = spans, len(buffers)
+        else:
+            addr, nb = _address_of(a)
+            keep.append(a)
+            arr[i].glb, arr[i].glb_bytes = addr, nb
+    dev = None
+    if devices:
+        dev = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+    c = cfg._c()
+    h = C.c_void_p()
+    _check(L.dmi_transcode_assets(arr, n, C.byref(c), dev, len(devices) if devices else 0, 0 if register else TRANSCODE_NO_REGISTER, C.byref(h)))
+    owner = _TranscodedHandle(h.value)
+    st = _TranscodeStats()
+    _check(L.dmi_transcoded_stats(h, C.byref(st)))
+    out = []
+    p, nb, k = C.c_void_p(), C.c_size_t(), C.c_uint32()
+    for i in range(n):
+        _check(L.dmi_transcoded_file(h, i, C.byref(p), C.byref(nb), C.byref(k)))
+        raw = (C.c_uint8 * nb.value).from_address(p.value)
+        raw._owner = owner
+        glb = memoryview(raw).cast("B")
+        blobs = []
+        if k.value:
+            offs, sizes = np.zeros(k.value, np.uint64), np.zeros(k.value, np.uint64)
+            _check(L.dmi_transcoded_blobs(h, i, offs.ctypes.data, sizes.ctypes.data))
+            blobs = [glb[int(o): int(o) + int(z)] for o, z in zip(offs, sizes)]
+        out.append((glb, blobs))
+    return out, {name: getattr(st, name) for name, _ in _TranscodeStats._fields_ if name != "pad"}
 
 
 def last_build_timings():

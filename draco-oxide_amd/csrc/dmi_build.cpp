@@ -6,12 +6,16 @@
 // threads (strided accessors are de-strided on the way), ONE copy up, the build kernels (one launch per kernel for all primitives of the
 // group), a small read-back of counts and offsets, then ONE read-back of arena A (faces + point → value maps: what the host's serial walks
 // read) — the unique values stay in arena B on the device unless the caller asks for them.  Two streams alternate between consecutive
-// groups, so a group's kernels and read-back overlap the next group's packing and upload.  A primitive the device form does not cover
+// groups, so a group's kernels and read-back overlap the next group's packing and upload.  INGEST (round 5): a group whose accessors and index
+// arrays all lie in page-locked host memory the library knows of (dmi_host_register / dmi_host_alloc: dmi_hostmem.cpp) is not packed at all — one
+// kernel gathers the rows (de-strided) and the indices (widened) straight out of the caller's buffers over PCIe.  A primitive the device form does not cover
 // (see dmi_build.hip) is built by the host builder (dmi_mesh_build) inside the same call: same result either way
 // (tests/test_gpu_device_build.py holds every mesh equal to dmi_mesh_build's and to the oracle's restated builder).
 #include "dmi_job.hpp"
 
 using namespace dmi;
+
+namespace dmi { const void* host_device_view(const void* p, size_t bytes); }   // dmi_hostmem.cpp
 
 namespace {
 
@@ -133,6 +137,8 @@ struct BuildGroup {
   MbArgs args{};
   hipEvent_t ev_counts = nullptr, ev_done = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
   bool host_values = false, large = false;
+  bool ingest = false;                  // every array of every member is read where it lies (page-locked host memory)
+  std::vector<uint64_t> src_view;       // ingest: device-visible address per array, member after member: its accessors, then its indices
   ~BuildGroup() {
     if (S) (void)hipStreamSynchronize(S);
     for (hipEvent_t e : {ev_counts, ev_done, ev_k0, ev_k1}) if (e) (void)hipEventDestroy(e);
@@ -189,12 +195,30 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
   std::vector<std::unique_ptr<BuildGroup>> groups;
   std::vector<uint32_t> host_list;
   const bool no_device = std::getenv("DMI_HOST_BUILD") != nullptr;
+  const bool no_ingest = std::getenv("DMI_NO_INGEST") != nullptr;   // (A/B: pack + copy even where the arrays could be read in place)
   for (uint32_t j = 0; j < n; ++j) {
     const dmi_raw_mesh& m = raw[j];
     if (no_device || !device_form(m)) { host_list.push_back(j); continue; }
     const bool large = m.num_faces >= kDeviceRelabelMinFaces;
     const uint64_t ap = (uint64_t)m.atts[0].count * m.n_atts;
-    bool fresh = groups.empty() || large || groups.back()->large;
+    // can the device read this primitive's arrays where they lie?
+    uint64_t views[kMbMaxAtts + 1];
+    bool in_place = !no_ingest;
+    for (uint32_t i = 0; in_place && i <= m.n_atts; ++i) {
+      const void* p; size_t span; bool aligned;
+      if (i < m.n_atts) {
+        const dmi_raw_accessor& a = m.atts[i];
+        const size_t row = 4u * a.num_components, stride = a.byte_stride ? a.byte_stride : row;
+        p = a.data; span = (size_t)(a.count - 1) * stride + row; aligned = !((uintptr_t)p & 3) && !(stride & 3);
+      } else {
+        const size_t eb = component_bytes(m.index_type);
+        p = m.indices; span = (size_t)m.num_faces * 3 * eb; aligned = !((uintptr_t)p & (eb - 1));
+      }
+      const void* v = aligned ? host_device_view(p, span) : nullptr;
+      in_place = v != nullptr;
+      views[i] = (uint64_t)(uintptr_t)v;
+    }
+    bool fresh = groups.empty() || large || groups.back()->large || groups.back()->ingest != in_place;
     if (!fresh) {
       const BuildGroup& g = *groups.back();
       fresh = g.raw_faces + m.num_faces > group_faces || g.ap + ap >= (1ull << 30) || g.which.size() >= 65536;
@@ -202,6 +226,8 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
     if (fresh) groups.emplace_back(new BuildGroup());
     BuildGroup& g = *groups.back();
     g.large = large;
+    g.ingest = in_place;
+    if (in_place) g.src_view.insert(g.src_view.end(), views, views + m.n_atts + 1);
     MbMesh me{};
     me.index = (uint32_t)g.meshes.size(); me.n_items = m.n_atts; me.item0 = (uint32_t)g.items.size(); me.P = m.atts[0].count; me.F = m.num_faces;
     me.face_off = (uint32_t)g.raw_faces; me.point_off = (uint32_t)g.points;
@@ -240,7 +266,7 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
     g.values_bytes = at;
     if (at >= ((size_t)1 << 34) || vtab_words >= (1ull << 32)) return fail(DMI_ERR_INVALID_ARGUMENT, "build group too large");
     bool any_narrow = false;
-    for (uint32_t k = 0; k < M; ++k) if (component_bytes(raw[g.which[k]].index_type) != 4) any_narrow = true;
+    if (!g.ingest) for (uint32_t k = 0; k < M; ++k) if (component_bytes(raw[g.which[k]].index_type) != 4) any_narrow = true;
     for (uint32_t k = 0; k < M; ++k) {
       const dmi_raw_mesh& m = raw[g.which[k]];
       MbMesh& me = g.meshes[k];
@@ -248,9 +274,10 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
       me.ptab_off = (uint32_t)ptab_words; me.ptab_mask = ts - 1;
       ptab_words += ts;
       // indices: a group of 32-bit index arrays uploads them as ONE array (the kernels' face array); with a narrower array in the group
-      // every array goes up as it is and one launch widens / copies them into the face array
+      // every array goes up as it is and one launch widens / copies them into the face array.  Ingest: the gather kernel widens what it reads,
+      // the face array is written directly.
       g.idx_at[k] = at;
-      at += (size_t)m.num_faces * 3 * component_bytes(m.index_type);
+      at += (size_t)m.num_faces * 3 * (g.ingest ? 4 : component_bytes(m.index_type));
       if (any_narrow) at = align256(at);
     }
     at = align256(at);
@@ -270,7 +297,7 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
     bg.d_base = bg.keep.take<uint8_t>(bg.b_off + bg.b_bytes + 256);
     const size_t parts = scan_partials_words((uint32_t)(std::max({AP, PT, RF}) + 1));
     const size_t scratch_words = (any_narrow ? 3 * RF : 0) + vtab_words + ptab_words + 5 * AP + 2 + 4 * PT + 2 + RF + 1 + 3 * RF + parts + 64 * 16;
-    g.scratch.init(device, g.S, g.up_bytes + scratch_words * 4 + (size_t)M * (sizeof(MbMesh) + sizeof(MbMeshOut) + sizeof(MbWiden)) + (size_t)NI * (sizeof(MbItem) + sizeof(MbItemOut)) + ((size_t)1 << 20));
+    g.scratch.init(device, g.S, g.up_bytes + scratch_words * 4 + (size_t)M * (sizeof(MbMesh) + sizeof(MbMeshOut) + sizeof(MbWiden)) + (size_t)NI * (sizeof(MbItem) + sizeof(MbItemOut)) + (size_t)(NI + M) * sizeof(MbIngest) + ((size_t)1 << 20));
     uint8_t* d_up = g.scratch.take<uint8_t>(g.up_bytes);
     MbArgs& a = g.args;
     a.M = M; a.n_items = NI; a.total_faces = (uint32_t)RF; a.total_points = (uint32_t)PT; a.total_ap = (uint32_t)AP;
@@ -290,8 +317,9 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
     a.raw_values = reinterpret_cast<const uint32_t*>(d_up);
     a.arena_a = reinterpret_cast<uint32_t*>(bg.d_base); a.arena_b = reinterpret_cast<uint32_t*>(bg.d_base + bg.b_off);
     // pinned staging: the upload (released when the group is done) and what stays (arena A's host copy, arena B's on request, the counts)
-    const size_t desc_bytes = align256((size_t)M * sizeof(MbMesh)) + align256((size_t)NI * sizeof(MbItem)) + align256((size_t)M * sizeof(MbWiden));
-    g.up_stage = acquire_stage(device, g.up_bytes + desc_bytes);
+    const size_t desc_bytes = align256((size_t)M * sizeof(MbMesh)) + align256((size_t)NI * sizeof(MbItem)) + align256((size_t)M * sizeof(MbWiden)) + align256((size_t)(NI + M) * sizeof(MbIngest));
+    const size_t stage_data = g.ingest ? 0 : g.up_bytes;   // (ingest: only the descriptors go through staging)
+    g.up_stage = acquire_stage(device, stage_data + desc_bytes);
     const size_t keep_counts = align256((size_t)M * sizeof(MbMeshOut)) + align256((size_t)NI * sizeof(MbItemOut)) + 256;
     const size_t keep_a = align256(bg.a_bytes), keep_b = host_values ? align256(bg.b_bytes) : 0;
     bg.stage = acquire_stage(device, keep_a + keep_b + keep_counts);
@@ -315,6 +343,7 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
       }
     }
     const double p0 = ms();
+    if (g.ingest) tasks.clear();
     if ((rc = run_parallel((uint32_t)tasks.size(), pack_threads, [&](uint32_t t) -> int {
           const Task& tk = tasks[t];
           const dmi_raw_mesh& m = raw[g.which[tk.k]];
@@ -324,7 +353,7 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
         }, [&](uint32_t t) { return (uint64_t)(tasks[t].hi - tasks[t].lo); }))) return rc;
     t_pack += ms() - p0;
     // descriptors ride behind the data in the same staging
-    uint8_t* h_desc = hp + g.up_bytes;
+    uint8_t* h_desc = hp + stage_data;
     std::memcpy(h_desc, g.meshes.data(), (size_t)M * sizeof(MbMesh));
     std::memcpy(h_desc + align256((size_t)M * sizeof(MbMesh)), g.items.data(), (size_t)NI * sizeof(MbItem));
     uint32_t n_widen = 0, widen_total = 0;
@@ -335,13 +364,39 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
         widen_total += 3u * g.meshes[k].F;
       }
     }
-    HIP_TRY(hipMemcpyAsync(d_up, hp, g.up_bytes, hipMemcpyHostToDevice, g.S));
+    uint64_t ingest_words = 0;
+    uint32_t n_ingest = 0;
+    MbIngest* d_ingest = nullptr;
+    if (g.ingest) {
+      MbIngest* w = reinterpret_cast<MbIngest*>(h_desc + align256((size_t)M * sizeof(MbMesh)) + align256((size_t)NI * sizeof(MbItem)) + align256((size_t)M * sizeof(MbWiden)));
+      size_t v = 0;
+      for (uint32_t k = 0; k < M; ++k) {
+        const dmi_raw_mesh& m = raw[g.which[k]];
+        for (uint32_t i = 0; i < m.n_atts; ++i, ++v) {
+          const dmi_raw_accessor& ac = m.atts[i];
+          const uint32_t row = 4u * ac.num_components;
+          MbIngest it{g.src_view[v], ingest_words, ac.count * ac.num_components, (uint32_t)(g.row_at[g.meshes[k].item0 + i] / 4), ac.num_components,
+                      ac.byte_stride && ac.byte_stride != row ? ac.byte_stride : 0u, 4u, 0u};
+          ingest_words += mb_ingest_units(it);
+          w[n_ingest++] = it;
+        }
+        MbIngest it{g.src_view[v++], ingest_words, 3u * m.num_faces, (uint32_t)(g.idx_at[k] / 4), 0u, 0u, (uint32_t)component_bytes(m.index_type), 0u};
+        ingest_words += mb_ingest_units(it);
+        w[n_ingest++] = it;
+      }
+      d_ingest = g.scratch.take<MbIngest>(n_ingest);
+      if (!d_ingest) return fail(DMI_ERR_OUT_OF_MEMORY, "hipMalloc (device mesh build)");
+      HIP_TRY(hipMemcpyAsync(d_ingest, w, (size_t)n_ingest * sizeof(MbIngest), hipMemcpyHostToDevice, g.S));
+    } else {
+      HIP_TRY(hipMemcpyAsync(d_up, hp, g.up_bytes, hipMemcpyHostToDevice, g.S));
+    }
     HIP_TRY(hipMemcpyAsync(d_meshes, h_desc, (size_t)M * sizeof(MbMesh), hipMemcpyHostToDevice, g.S));
     HIP_TRY(hipMemcpyAsync(d_items, h_desc + align256((size_t)M * sizeof(MbMesh)), (size_t)NI * sizeof(MbItem), hipMemcpyHostToDevice, g.S));
     if (n_widen) HIP_TRY(hipMemcpyAsync(d_widen, h_desc + align256((size_t)M * sizeof(MbMesh)) + align256((size_t)NI * sizeof(MbItem)), (size_t)n_widen * sizeof(MbWiden), hipMemcpyHostToDevice, g.S));
     bytes_up += g.up_bytes;
     HIP_TRY(hipEventCreate(&g.ev_k0)); HIP_TRY(hipEventCreate(&g.ev_k1));
     HIP_TRY(hipEventRecord(g.ev_k0, g.S));
+    if (g.ingest) launch_mesh_ingest(d_ingest, n_ingest, ingest_words, reinterpret_cast<uint32_t*>(d_up), g.S);
     if (any_narrow) {
       launch_widen_indices(d_widen, n_widen, widen_total, d_up, d_wide, g.S);
       a.raw_faces = d_wide;
@@ -382,7 +437,7 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
   // ---- while the device works: the primitives the host builder takes ----
   if ((rc = run_parallel((uint32_t)host_list.size(), n_threads, [&](uint32_t k) -> int { return build_on_host(raw[host_list[k]], &out[host_list[k]]); },
                          [&](uint32_t k) { return (uint64_t)raw[host_list[k]].num_faces; }))) return rc;
-  uint32_t n_host = (uint32_t)host_list.size(), n_device = 0;
+  uint32_t n_host = (uint32_t)host_list.size(), n_device = 0, n_in_place = 0;
   double kernels_ms = 0;
 
   // ---- views ----
@@ -443,6 +498,7 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
       out[j].mesh.num_atts = m.n_atts;
       out[j].owner = static_cast<BuiltBase*>(o.release());
       ++n_device;
+      if (g.ingest) ++n_in_place;
     }
     bg.total_faces = faces_seen;
     // the universal corner tables of the group's meshes, right behind the build: on the host by the time dmi_built_meshes_prepare walks them
@@ -457,9 +513,9 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
   if ((rc = run_parallel((uint32_t)redo.size(), n_threads, [&](uint32_t k) -> int { return build_on_host(raw[redo[k]], &out[redo[k]]); }, nullptr))) return rc;
   n_host += (uint32_t)redo.size();
   cleanup.armed = false;
-  g_last_build = dmi_build_timings{(float)t_pack, (float)kernels_ms, (float)ms(), n_device, n_host, bytes_up, bytes_down};
-  if (trace) std::fprintf(stderr, "[dmi] meshes_build: %u primitives (%u on the device, %u on the host): pack %.2f ms, issued by %.2f, kernels %.2f, total %.2f; %.1f MB up, %.1f MB down\n",
-                          n, n_device, n_host, t_pack, t_issued, kernels_ms, ms(), bytes_up / 1e6, bytes_down / 1e6);
+  g_last_build = dmi_build_timings{(float)t_pack, (float)kernels_ms, (float)ms(), n_device, n_host, bytes_up, bytes_down, n_in_place, 0u};
+  if (trace) std::fprintf(stderr, "[dmi] meshes_build: %u primitives (%u on the device — %u read in place —, %u on the host): pack %.2f ms, issued by %.2f, kernels %.2f, total %.2f; %.1f MB up, %.1f MB down\n",
+                          n, n_device, n_in_place, n_host, t_pack, t_issued, kernels_ms, ms(), bytes_up / 1e6, bytes_down / 1e6);
   return DMI_OK;
 }
 

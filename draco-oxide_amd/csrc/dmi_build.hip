@@ -334,8 +334,60 @@ __global__ __launch_bounds__(kBlock) void k_mb_widen(const MbWiden* __restrict__
   }
 }
 
+// Rows and indices out of page-locked host memory (dmi_hostmem.cpp).  A read over PCIe wants wide requests: measured (scripts/experiments/pcie_probe.hip)
+// 16 bytes per lane = 1 KB per wavefront load reaches the link's 55 GB/s, 4 bytes per lane a quarter of it.  So a tightly packed array — accessor rows
+// without a stride, every index array — is cut at the 16-byte boundaries of its SOURCE address: unit 0 is the head before the first boundary (element by
+// element), every other unit one aligned 16-byte load (4 words, or 8 / 16 narrow indices widened on the way; the last one element by element when it
+// is short).  Rows with a byteStride go word by word (unit = one output word).
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ingest_elements(const MbIngest& it, uint32_t* __restrict__ dst, uint64_t b0, uint64_t b1) {   // source bytes [b0, b1)
+  if (it.elem_bytes == 4) for (uint64_t b = b0; b < b1; b += 4) dst[it.dst_word + (b >> 2)] = *reinterpret_cast<const uint32_t*>(it.src + b);
+  else if (it.elem_bytes == 2) for (uint64_t b = b0; b < b1; b += 2) dst[it.dst_word + (b >> 1)] = *reinterpret_cast<const uint16_t*>(it.src + b);
+  else for (uint64_t b = b0; b < b1; ++b) dst[it.dst_word + b] = *reinterpret_cast<const uint8_t*>(it.src + b);
+}
+__global__ __launch_bounds__(kBlock) void k_mb_ingest(const MbIngest* __restrict__ items, uint32_t n_items, uint64_t total, uint32_t* __restrict__ dst) {
+  const uint64_t T = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x; g < total; g += T) {
+    uint32_t lo = 0, hi = n_items;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (items[mid].off <= g) lo = mid; else hi = mid; }
+    const MbIngest it = items[lo];
+    const uint64_t u = g - it.off;
+    if (it.stride_bytes) {   // strided rows: one output word
+      const uint32_t k = (uint32_t)u, r = k / it.row_words, c = k - r * it.row_words;
+      dst[it.dst_word + k] = *(reinterpret_cast<const uint32_t*>(it.src + (uint64_t)r * it.stride_bytes) + c);
+      continue;
+    }
+    const uint64_t bytes = (uint64_t)it.n_words * it.elem_bytes;
+    const uint64_t head = min(bytes, (uint64_t)((16u - (uint32_t)(it.src & 15u)) & 15u));
+    if (u == 0) { ingest_elements(it, dst, 0, head); continue; }
+    const uint64_t b = head + 16ull * (u - 1);
+    if (b + 16 > bytes) { ingest_elements(it, dst, b, bytes); continue; }
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(it.src + b));
+    if (it.elem_bytes == 4) {
+      *reinterpret_cast<u32x4_a4*>(dst + it.dst_word + (b >> 2)) = u32x4_a4{v.x, v.y, v.z, v.w};
+    } else if (it.elem_bytes == 2) {
+      uint32_t* o = dst + it.dst_word + (b >> 1);
+      *reinterpret_cast<u32x4_a4*>(o) = u32x4_a4{v.x & 0xFFFFu, v.x >> 16, v.y & 0xFFFFu, v.y >> 16};
+      *reinterpret_cast<u32x4_a4*>(o + 4) = u32x4_a4{v.z & 0xFFFFu, v.z >> 16, v.w & 0xFFFFu, v.w >> 16};
+    } else {
+      uint32_t* o = dst + it.dst_word + b;
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x4_a4*>(o + 4 * q) = u32x4_a4{w[q] & 0xFFu, (w[q] >> 8) & 0xFFu, (w[q] >> 16) & 0xFFu, w[q] >> 24};
+    }
+  }
+}
+
 }  // namespace
 
+void launch_mesh_ingest(const MbIngest* items_dev, uint32_t n_items, uint64_t total_units, uint32_t* dst, hipStream_t s) {
+  if (!n_items || !total_units) return;
+  const uint64_t want = (total_units + kBlock - 1) / kBlock;
+  // (one block per CU: a link-bound kernel needs few waves — any grid from 256 blocks up reads at the link's rate —, and a grid that fills every wave slot
+  // of the chip keeps the kernels of the other stages' streams waiting: the relabelling of a prepare took 10 ms instead of 3.5 beside such a launch)
+  hipLaunchKernelGGL(k_mb_ingest, (uint32_t)std::min<uint64_t>(want, 256), kBlock, 0, s, items_dev, n_items, total_units, dst);
+}
 hipError_t mesh_build_clear(const MbArgs& a, size_t vtab_words, size_t ptab_words, hipStream_t s) {
   hipError_t e;
   if ((e = hipMemsetAsync(a.vtab, 0xFF, vtab_words * 4, s)) != hipSuccess) return e;

@@ -829,6 +829,13 @@ __global__ __launch_bounds__(256) void k_scatter_items(const CopyItem* __restric
   for (uint64_t v = threadIdx.x; v < vecs; v += 256) dst[v] = src[v];
 }
 
+__global__ __launch_bounds__(256) void k_clear_items(const CopyItem* __restrict__ items) {
+  const CopyItem it = items[blockIdx.x];
+  uint32_t* __restrict__ d = reinterpret_cast<uint32_t*>(const_cast<void*>(it.src));
+  const uint64_t n = it.bytes >> 2;
+  for (uint64_t v = threadIdx.x; v < n; v += 256) d[v] = 0u;
+}
+
 inline uint32_t grid256(uint64_t n) { uint64_t g = (n + 255) / 256; return (uint32_t)(g > 4096 ? 4096 : (g ? g : 1)); }
 
 #define DMI_PREP_KERNEL(NAME, BODY, ARGS, THREADS)                                                                                    \
@@ -918,6 +925,9 @@ void launch_pack_streams(const ChainDesc* descs_dev, uint32_t n_streams, PackEnt
 }
 void launch_copy_items(const CopyItem* items_dev, uint32_t n_items, uint8_t* arena, hipStream_t s) {
   if (n_items) hipLaunchKernelGGL(k_copy_items, dim3(n_items, kPackSplit), 256, 0, s, items_dev, arena);
+}
+void launch_clear_items(const CopyItem* items_dev, uint32_t n_items, hipStream_t s) {
+  if (n_items) hipLaunchKernelGGL(k_clear_items, n_items, 256, 0, s, items_dev);
 }
 void launch_scatter_items(const CopyItem* items_dev, uint32_t n_items, const uint8_t* arena, hipStream_t s) {
   if (n_items) hipLaunchKernelGGL(k_scatter_items, n_items, 256, 0, s, items_dev, arena);

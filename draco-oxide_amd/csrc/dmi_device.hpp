@@ -210,6 +210,8 @@ struct CopyItem { const void* src; uint64_t dst_offset; uint64_t bytes; };
 void launch_copy_items(const CopyItem* items_dev, uint32_t n_items, uint8_t* arena, hipStream_t s);
 // the inverse: arena[dst_offset .. +bytes) → items[k].src (a device destination)
 void launch_scatter_items(const CopyItem* items_dev, uint32_t n_items, const uint8_t* arena, hipStream_t s);
+// items[k].src .. +bytes (a device range, a multiple of 4 bytes) := 0, every range of a batch in one launch
+void launch_clear_items(const CopyItem* items_dev, uint32_t n_items, hipStream_t s);
 void launch_pack_streams(const ChainDesc* descs_dev, uint32_t n_streams, PackEntry* table, uint8_t* arena, hipStream_t s);
 
 // ---- decoder side: the data-parallel stages of reading an attribute section back (dmi_decode.cpp drives them) ----
@@ -343,6 +345,17 @@ struct MbArgs {
   MbMeshOut* mesh_out; MbItemOut* item_out; uint32_t* totals /* [0] arena A words, [1] arena B words, [2] face words */;
   uint32_t *arena_a, *arena_b;
 };
+// Ingest (round 5): accessors / index arrays gathered out of page-locked HOST memory by a kernel (one launch per group) instead of packed into
+// staging by host threads and copied up.  An item is one array of n_words output words written at dst_word of the upload region: accessor rows
+// (elem_bytes 4; stride_bytes 0 = tightly packed, else rows of row_words words that far apart) or indices (elem_bytes 1 / 2 / 4, widened to u32).
+// off = Σ units of the items before (dmi_build.hip k_mb_ingest: a tight array's units are 16-byte pieces of its source, a strided one's its words).
+struct MbIngest { uint64_t src /* device-visible address of the first element */, off; uint32_t n_words, dst_word, row_words, stride_bytes, elem_bytes, pad; };
+inline uint64_t mb_ingest_units(const MbIngest& it) {
+  if (it.stride_bytes) return it.n_words;
+  const uint64_t bytes = (uint64_t)it.n_words * it.elem_bytes, head = std::min<uint64_t>(bytes, (16u - (uint32_t)(it.src & 15u)) & 15u);
+  return 1 + (bytes - head + 15) / 16;
+}
+void launch_mesh_ingest(const MbIngest* items_dev, uint32_t n_items, uint64_t total_units, uint32_t* dst, hipStream_t s);
 hipError_t mesh_build_clear(const MbArgs& a, size_t vtab_words, size_t ptab_words, hipStream_t s);
 void launch_mesh_build(const MbArgs& a, hipStream_t s);
 void launch_widen_indices(const MbWiden* items_dev, uint32_t n_items, uint32_t total, const uint8_t* src, uint32_t* dst, hipStream_t s);

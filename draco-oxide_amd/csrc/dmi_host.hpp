@@ -17,6 +17,7 @@
 #include <functional>
 #include <string>
 #include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -55,14 +56,28 @@ inline unsigned cgroup_cpu_quota() {   // 0 = unlimited / unknown
 // a cap for the calls the CALLING thread makes (dmi_thread_host_threads): a pipeline that runs several library calls side by side gives each
 // stage its share, so that together they stay inside the CPU quota (threads beyond it get the whole cgroup throttled)
 inline thread_local unsigned g_thread_host_cap = 0;
-inline unsigned host_threads() {
+inline unsigned process_host_threads() {   // what the whole process may keep busy
   unsigned hw = std::thread::hardware_concurrency();
   if (!hw) hw = 4;
   if (const unsigned q = cgroup_cpu_quota()) hw = std::min(hw, std::max(1u, q));
   if (const char* e = std::getenv("DMI_HOST_THREADS")) { const int v = std::atoi(e); if (v > 0) hw = std::min<unsigned>(hw, (unsigned)v); }
+  return hw;
+}
+inline unsigned host_threads() {
+  unsigned hw = process_host_threads();
   if (g_thread_host_cap) hw = std::min(hw, g_thread_host_cap);
   return hw;
 }
+// Serial per-mesh walks running at once in the whole PROCESS: two batch prepares side by side (a transcoder's stage k+1 starts its walks while stage
+// k's coordinator waits for the device: relabelling, fan rows) share one budget of process_host_threads() instead of oversubscribing the CPU quota.
+struct WalkSlots {
+  std::mutex m;
+  std::condition_variable cv;
+  unsigned in_use = 0;
+  void acquire() { std::unique_lock<std::mutex> lock(m); const unsigned cap = process_host_threads(); cv.wait(lock, [&] { return in_use < cap; }); ++in_use; }
+  void release() { { std::lock_guard<std::mutex> lock(m); --in_use; } cv.notify_one(); }
+};
+WalkSlots& walk_slots();
 // [0, n) in contiguous slices on up to 32 host threads (large, embarrassingly parallel index loops); fn(lo, hi)
 template <class Fn>
 inline void parallel_for(size_t n, Fn&& fn) {

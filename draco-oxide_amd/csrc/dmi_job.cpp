@@ -264,11 +264,18 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
     // gigabytes (4.5 GB per 10M triangles: 0.9 ms of fill per call), of which only a few KB have to start as zeros: those are cleared
     // one by one below (`needs_clear`).  DMI_POISON=1 fills such a chunk with 0xA5 instead — the tests run once that way, so that no buffer
     // silently depends on what the chunk held.
-    job->pool.zero = defer != nullptr || std::getenv("DMI_ZERO_CHUNKS") != nullptr;
+    // Round 5: a batch job's chunk is not cleared either — a thousand jobs issued a thousand fills of their whole chunks on the coordinator's stream
+    // (17 ms of device time per 1024-file transcode, in front of the relabelling); the few ranges that must start as zeros are RECORDED
+    // (JobDefer::clears) and the coordinator clears them all in one launch.
+    job->pool.zero = std::getenv("DMI_ZERO_CHUNKS") != nullptr;
     job->pool.poison = !job->pool.zero && std::getenv("DMI_POISON") != nullptr;
   }
   g_active_pool = std::getenv("DMI_NO_POOL") ? nullptr : &job->pool;
   const bool needs_clear = g_active_pool && !job->pool.zero;   // pooled buffers do not start as zeros: the ones that must are cleared where they are allocated
+  auto clear_range = [&](void* p, size_t bytes, hipStream_t st) -> hipError_t {   // now, or by the batch's coordinator
+    if (defer && needs_clear) { defer->clears.push_back(JobDefer::Clear{p, bytes}); return hipSuccess; }
+    return hipMemsetAsync(p, 0, bytes, st);
+  };
   struct PoolGuard { ~PoolGuard() { g_active_pool = nullptr; } } pool_guard;
 
   const bool trace_create = std::getenv("DMI_TRACE") != nullptr;
@@ -636,9 +643,9 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
       if ((rc = a.aux_out.alloc(a.aux_cap + 16))) return rc;   // +16: the batch pack kernel copies whole 16-byte words
       if ((rc = a.aux_rec.alloc(((size_t)n + kChainPad) * sizeof(RansEntry)))) return rc;
       if (!a.aux_rec.pooled) HIP_TRY(hipMemsetAsync(a.aux_rec.p, 0, a.aux_rec.bytes, s));
-      else if (needs_clear) HIP_TRY(hipMemsetAsync(a.aux_rec.as<RansEntry>() + n, 0, kChainPad * sizeof(RansEntry), s));   // (the records past n: the chains read ahead into them)
+      else if (needs_clear) HIP_TRY(clear_range(a.aux_rec.as<RansEntry>() + n, kChainPad * sizeof(RansEntry), s));   // (the records past n: the chains read ahead into them)
       if ((rc = a.aux_flags.alloc(((size_t)n / 64 + 4) * 4))) return rc;
-      if (!a.aux_flags.pooled || needs_clear) HIP_TRY(hipMemsetAsync(a.aux_flags.p, 0, a.aux_flags.bytes, s));
+      if (!a.aux_flags.pooled || needs_clear) HIP_TRY(clear_range(a.aux_flags.p, a.aux_flags.bytes, s));
       if ((rc = a.chunk_info.alloc((size_t)std::max(1u, orient_summary_blocks(n)) * 8 + 16))) return rc;
       if (a.scheme == kTexCoord && (rc = a.aux_bits.alloc((size_t)n + 16))) return rc;
       if (a.scheme == kNormal && (rc = a.flip_partials.alloc((size_t)kSweepMaxBlocks * 4))) return rc;
@@ -664,9 +671,9 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
     }
     if ((rc = a.rec.alloc(((size_t)a.n_sym + kChainPad) * sizeof(RansEntry)))) return rc;
     if (!a.rec.pooled) HIP_TRY(hipMemsetAsync(a.rec.p, 0, a.rec.bytes, s));
-    else if (needs_clear) HIP_TRY(hipMemsetAsync(a.rec.as<RansEntry>() + a.n_sym, 0, kChainPad * sizeof(RansEntry), s));
+    else if (needs_clear) HIP_TRY(clear_range(a.rec.as<RansEntry>() + a.n_sym, kChainPad * sizeof(RansEntry), s));
     if ((rc = a.batch_flags.alloc(((size_t)a.n_sym / 64 + 4) * 4))) return rc;
-    if (!a.batch_flags.pooled || needs_clear) HIP_TRY(hipMemsetAsync(a.batch_flags.p, 0, a.batch_flags.bytes, s));
+    if (!a.batch_flags.pooled || needs_clear) HIP_TRY(clear_range(a.batch_flags.p, a.batch_flags.bytes, s));
     a.out_cap = a.n_sym * 3 + 16;   // ≤ 3 renormalisation bytes per symbol (P ≤ 20) + flush
     if ((rc = a.out.alloc(a.out_cap + 16))) return rc;
     if ((rc = a.partials.alloc((size_t)kRangeMaxBlocks * 8 * 4))) return rc;
@@ -683,7 +690,7 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
   job->predict_bytes = pb;
   pinned_need += 256;
   if ((rc = job->slab.alloc(pinned_need))) return rc;
-  if (!job->slab.pooled || needs_clear) HIP_TRY(hipMemsetAsync(job->slab.p, 0, pinned_need, s));
+  if (!job->slab.pooled || needs_clear) HIP_TRY(clear_range(job->slab.p, pinned_need, s));
   for (auto& a : job->atts) {
     uint8_t* base = job->slab.as<uint8_t>() + a.slab_off;
     a.small = SlabView{base, 64};

@@ -314,6 +314,8 @@ struct JobDefer {
   // out
   struct Copy { void* dst; const void* src_dev; size_t bytes; };
   std::vector<Copy> copies;                     // device → device: values into the job's buffers
+  struct Clear { void* p; size_t bytes; };      // (multiples of 4 bytes)
+  std::vector<Clear> clears;                    // ranges of the job's (uncleared) chunk that must start as zeros: one launch for all jobs
   // One RelabelItem per distinct corner table of the job, the universal one first.  seq = HOST pointer of the table's sequence (the
   // coordinator uploads it); an attribute table of its own (interior seams) also carries HOST pointers of its vertex ids / opposite
   // corners in host_c2v / host_opp (uploaded by the coordinator: c2v / opp of the item are then null until it has placed them);

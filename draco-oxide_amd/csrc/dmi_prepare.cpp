@@ -973,6 +973,7 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     }
     int r = g.wait_tables();
     if (r) return r;
+    struct Slot { Slot() { walk_slots().acquire(); } ~Slot() { walk_slots().release(); } } slot;   // (the process-wide budget of running walks: dmi_host.hpp)
     const uint64_t w1 = now_ns();
     ns_wait += w1 - w0;
     auto bail = [&](int code, const std::string& what) { return fail(code, "mesh " + std::to_string(j) + ": " + what); };
@@ -1222,6 +1223,7 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
   std::vector<ComposeItem> comps;
   struct Move { void* dst; const void* src; size_t bytes; };
   std::vector<Move> moves;
+  std::vector<CopyItem> clears;   // ranges of the jobs' uncleared chunks that must start as zeros (JobDefer::clears)
   std::vector<const uint32_t*> seq_src, c2v_src, opp_src;   // host sources per item (c2v / opp: attribute tables of their own)
   uint64_t rf = 0, rv = 0, rk = 0, rs = 0, rr = 0, fan_total = 0, comp_total = 0, host_table_words = 0;
   for (uint32_t kk = 0; kk < M; ++kk) {
@@ -1242,6 +1244,7 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     for (FanItem f : d.fans) { f.off = (uint32_t)fan_total; fan_total += f.n; fans.push_back(f); }
     for (ComposeItem ci : d.compose) { ci.off = (uint32_t)comp_total; comp_total += ci.n; comps.push_back(ci); }
     for (const auto& cp : d.copies) moves.push_back({cp.dst, cp.src_dev, (cp.bytes + 15) & ~(size_t)15});
+    for (const auto& cl : d.clears) clears.push_back(CopyItem{cl.p, 0u, (uint64_t)cl.bytes});
   }
   if (rf >= (1ull << 32) / 3 || rr >= (1ull << 32) / 3 || rv >= (1ull << 32) || rk >= (1ull << 32) || fan_total >= (1ull << 32) || comp_total >= (1ull << 32) || (rs + host_table_words) * 4 >= (1ull << 36))
     return fail(DMI_ERR_INVALID_ARGUMENT, "batch slice too large");
@@ -1249,7 +1252,7 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
   for (auto& g : groups) if (g->ev_tables_borrowed) HIP_TRY(hipStreamWaitEvent(S, g->ev_tables_borrowed, 0));   // (its device tables, which the relabelling reads)
   TempDev mem3;
   struct StageGuard { HostStage* st = nullptr; ~StageGuard() { release_stage(st); } } stage3;
-  if (!items.empty() || !moves.empty()) {
+  if (!items.empty() || !moves.empty() || !clears.empty()) {
     // CopyItem{destination, offset of the source relative to `base`, bytes}: one base for all groups' regions
     const uint8_t* base = nullptr;
     for (auto& mv : moves) if (!base || static_cast<const uint8_t*>(mv.src) < base) base = static_cast<const uint8_t*>(mv.src);
@@ -1259,7 +1262,8 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     // staging: [sequences of every item | vertex ids + opposite corners of the attribute tables of their own | descriptors]
     const size_t off_tables = align256((size_t)rs * 4);
     const size_t off_items = off_tables + align256((size_t)host_table_words * 4), off_fans = off_items + align256(items.size() * sizeof(RelabelItem)), off_comps = off_fans + align256(fans.size() * sizeof(FanItem)),
-                 off_copies = off_comps + align256(comps.size() * sizeof(ComposeItem)), need2 = off_copies + align256(copies.size() * sizeof(CopyItem));
+                 off_copies = off_comps + align256(comps.size() * sizeof(ComposeItem)), off_clears = off_copies + align256(copies.size() * sizeof(CopyItem)),
+                 need2 = off_clears + align256(clears.size() * sizeof(CopyItem));
     stage3.st = acquire_stage(device, need2);
     if (!stage3.st) return fail(DMI_ERR_OUT_OF_MEMORY, "hipHostMalloc (batch sequences staging)");
     uint8_t* h2 = stage3.st->p;
@@ -1286,11 +1290,13 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     if (!fans.empty()) std::memcpy(h2 + off_fans, fans.data(), fans.size() * sizeof(FanItem));
     if (!comps.empty()) std::memcpy(h2 + off_comps, comps.data(), comps.size() * sizeof(ComposeItem));
     if (!copies.empty()) std::memcpy(h2 + off_copies, copies.data(), copies.size() * sizeof(CopyItem));
+    if (!clears.empty()) std::memcpy(h2 + off_clears, clears.data(), clears.size() * sizeof(CopyItem));
     HIP_TRY(hipMemcpyAsync(d2, h2, need2, hipMemcpyHostToDevice, S));
     HIP_TRY(hipMemsetAsync(b.rank, 0xFF, (size_t)(rv ? rv : 1) * 4, S));
     HIP_TRY(hipMemsetAsync(b.count, 0, nk * 4, S));
     b.items = reinterpret_cast<const RelabelItem*>(d2 + off_items); b.n_items = (uint32_t)items.size();
     b.total_faces = (uint32_t)rf; b.total_verts = (uint32_t)rv; b.total_keys = (uint32_t)rk; b.total_seq = (uint32_t)rs; b.total_remap_faces = (uint32_t)rr;
+    launch_clear_items(reinterpret_cast<const CopyItem*>(d2 + off_clears), (uint32_t)clears.size(), S);
     launch_scatter_items(reinterpret_cast<const CopyItem*>(d2 + off_copies), (uint32_t)copies.size(), base, S);
     launch_relabel_batch(b, S);
     launch_compose_batch(reinterpret_cast<const ComposeItem*>(d2 + off_comps), (uint32_t)comps.size(), (uint32_t)comp_total, S);

@@ -1,5 +1,5 @@
 // dmi_transcode.cpp — the transcoder's per-primitive loop behind ONE object: primitives are pushed as the caller's importer produces them, and
-// stages of them run build → prepare → encode on three library threads (dmi_meshes_build of stage k+2 beside dmi_built_meshes_prepare of stage
+// stages of them run build → prepare → encode on library threads — two per step since round 5 — (dmi_meshes_build of stage k+2 beside dmi_built_meshes_prepare of stage
 // k+1 beside dmi_jobs_encode of stage k); a callback names the primitives whose blobs are final, so that the caller reassembles files while the
 // device works on the next ones.
 // Reference seam: io/gltf/transcoder.rs:134-151 (files one by one), io/gltf/encode.rs:932-955,1827-1842 (their primitives one by one:
@@ -80,7 +80,7 @@ struct dmi_transcoder {
   std::mutex result_mutex;
   // steps
   Slot to_build, to_prepare, to_encode;
-  std::thread t_build, t_build2, t_prepare, t_prepare2, t_encode;
+  std::thread t_build, t_build2, t_prepare, t_prepare2, t_encode, t_encode2;
   std::atomic<int> builders_left{0}, preparers_left{0};
   std::mutex err_mutex;
   int rc = DMI_OK;
@@ -154,7 +154,7 @@ struct dmi_transcoder {
       }
       for (dmi_job* j : s->jobs) dmi_job_destroy(j);
       s->jobs.clear();
-      ms_encode += now_ms() - t0;
+      { std::lock_guard<std::mutex> lock(err_mutex); ms_encode += now_ms() - t0; }
       note("encode", *s, t0);
       if (r) { fail_with(r); continue; }
       if (!failed() && done) done(user, s->first, s->count);
@@ -170,12 +170,18 @@ struct dmi_transcoder {
     builders_left = nb;
     t_build = std::thread([this] { build_loop(); });
     if (nb > 1) t_build2 = std::thread([this] { build_loop(); });
+    // two prepares side by side: stage k+1's walks start while stage k's coordinator waits for the device (sequences up, relabelling, fan rows: 3–10 ms
+    // per stage with every host core idle); the walks of both share one process-wide budget (WalkSlots).  DMI_PREPARE_WORKERS=1: one
     const char* ep = std::getenv("DMI_PREPARE_WORKERS");
-    const int np = ep && std::atoi(ep) == 2 ? 2 : 1;
+    const int np = ep && std::atoi(ep) == 1 ? 1 : 2;
     preparers_left = np;
     t_prepare = std::thread([this] { prepare_loop(); });
     if (np > 1) t_prepare2 = std::thread([this] { prepare_loop(); });
+    // two encodes side by side: a stage's chain launch is bounded by its longest stream (≈ 5 ms on one wavefront per SIMD, the rest of the chip idle) —
+    // the launches of consecutive stages overlap instead of queueing at the end of the call.  DMI_ENCODE_WORKERS=1: one
+    const char* ee = std::getenv("DMI_ENCODE_WORKERS");
     t_encode = std::thread([this] { encode_loop(); });
+    if (!(ee && std::atoi(ee) == 1)) t_encode2 = std::thread([this] { encode_loop(); });
   }
   // hands the primitives pushed so far to the build step once they make a stage (or all of them: flush)
   void dispatch(bool flush) {
@@ -245,6 +251,7 @@ int dmi_transcoder_finish(dmi_transcoder* t) {
     if (t->t_prepare.joinable()) t->t_prepare.join();
     if (t->t_prepare2.joinable()) t->t_prepare2.join();
     if (t->t_encode.joinable()) t->t_encode.join();
+    if (t->t_encode2.joinable()) t->t_encode2.join();
     t->finished = true;
   }
   std::lock_guard<std::mutex> lock(t->err_mutex);

@@ -13,6 +13,8 @@
 #include "dmi_host.hpp"
 
 namespace dmi {
+WalkSlots& walk_slots() { static WalkSlots w; return w; }
+
 
 namespace {
 

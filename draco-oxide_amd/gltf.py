@@ -28,7 +28,7 @@ import numpy as np
 
 import threading
 
-from .binding import (jobs_encode_raw, ATT_CUSTOM, ATT_NORMAL, ATT_POSITION, ATT_TEXCOORD, DOMAIN_CORNER, DOMAIN_POSITION, Config, MeshBuilder, RawMesh, built_meshes_prepare, device_count,
+from .binding import (DracoMiError, host_register, host_unregister, jobs_encode_raw, transcode_assets, ATT_CUSTOM, ATT_NORMAL, ATT_POSITION, ATT_TEXCOORD, DOMAIN_CORNER, DOMAIN_POSITION, Config, MeshBuilder, RawMesh, built_meshes_prepare, device_count,
                       jobs_encode, jobs_encode_devices, last_build_timings, meshes_build, meshes_prepare, meshes_prepare_devices, shard_meshes, thread_host_threads)
 
 _COMPONENTS = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4}
@@ -652,10 +652,47 @@ def transcode_files(sources, cfg=None, devices=None, group=None, device=None, pi
             gc.enable()
 
 
+def _native_assets(sources):
+    """The sources of a transcode as dmi_transcode_assets takes them: GLB bytes as they are, a `.gltf` as (JSON text, buffers) with its buffers resolved here."""
+    assets = []
+    for src in sources:
+        if isinstance(src, (bytes, bytearray, memoryview)):
+            assets.append(src)
+            continue
+        data = open(src, "rb").read()
+        if data[:4] == b"glTF":
+            assets.append(data)
+        else:
+            _, buffers = load_document(src)
+            assets.append((data, buffers))
+    return assets
+
+
 def _transcode_files(sources, cfg, devices, group, device, pipeline, timings):
     import time
     tm = timings if timings is not None else {}
     t0 = time.perf_counter()
+    try:
+        import torch.distributed as dist
+        world0 = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    except ImportError:
+        world0 = 1
+    if world0 == 1 and pipeline and os.environ.get("DMI_TRANSCODE_PYTHON", "0") == "0" and sources:
+        # One process: the whole loop — container + JSON parse, primitive plans, accessor descriptors, stages on one dmi_transcoder per device,
+        # file assembly — runs inside the library (dmi_transcode_assets, csrc/dmi_gltf.cpp); the files come back as views of its memory.
+        # The steps below are the same loop in Python: the tests hold the two against each other, ranks of a torch.distributed job use it.
+        n_dev = device_count() if devices == "all" else int(devices or 1)
+        n_dev = max(1, min(n_dev, device_count()))
+        base = cfg.device if cfg is not None else 0
+        try:
+            out, st = transcode_assets(_native_assets(sources), cfg, devices=list(range(n_dev)) if n_dev > 1 else [base], register=os.environ.get("DMI_NO_REGISTER", "0") == "0")
+        except DracoMiError as e:
+            if "gltf:" in str(e):
+                raise ValueError(str(e)) from None
+            raise
+        tm.update({"parse_s": st["parse_ms"] * 1e-3, "register_s": st["register_ms"] * 1e-3, "views_s": 0.0, "build_s": st["build_ms"] * 1e-3, "prepare_s": st["prepare_ms"] * 1e-3,
+                   "encode_s": st["encode_ms"] * 1e-3, "assemble_s": st["assemble_ms"] * 1e-3, "primitives_built": st["primitives"], "native": st})
+        return out
     docs = [load_document(src) for src in sources]
     per_file = [_plan(doc) for doc, _ in docs]
     flat = [(fi, pi) for fi, prims in enumerate(per_file) for pi in range(len(prims))]
@@ -836,33 +873,48 @@ def _transcode_native(docs, per_file, flat, mine, w_mine, raw_of, built, cfg, tm
         finished.put((first_k, count))
 
     n = len(mine)
-    with Transcoder(cfg, sum(w_mine), n, on_done=done, stage_triangles=PIPELINE_TRIANGLES) as t:
-        holder.append(t)
-        worker = threading.Thread(target=reassemble)
-        worker.start()
-        slice_tris = max(1, sum(w_mine) // 64)                                # (a push per ≈ 1/64 of the triangles: the library starts its first stage early)
-        lo = 0
-        while lo < n:
-            t0 = time.perf_counter()
-            hi, acc = lo, 0
-            while hi < n and (hi == lo or acc + w_mine[hi] <= slice_tris):
-                acc += w_mine[hi]
-                hi += 1
-            raws = [raw_of(k) for k in range(lo, hi)]
-            tm["views_s"] += time.perf_counter() - t0
-            t.push(raws)
-            lo = hi
-        try:
-            t.finish()
-        finally:
-            finished.put(None)
-            worker.join()
-        if errs:
-            raise errs[0]
-        tm.update(t.timings())
-        for fi in range(len(docs)):
-            if assembled[fi] is None:   # (a file without a compressible primitive)
-                assembled[fi] = _assemble(docs[fi][0], docs[fi][1], per_file[fi], [])
+    # the files' bytes are page-locked for the duration of the call: the device gathers accessor rows and indices out of them where they lie
+    # (dmi_host_register; DMI_NO_INGEST=1 or a refused range: the library packs and copies as before)
+    locked = []
+    if os.environ.get("DMI_NO_REGISTER", "0") == "0":
+        t0 = time.perf_counter()
+        for _, buffers in docs:
+            for b in buffers:
+                if len(b) >= 4096 and host_register(b):
+                    locked.append(b)
+        tm["register_s"] = time.perf_counter() - t0
+    worker = None
+    try:
+        with Transcoder(cfg, sum(w_mine), n, on_done=done, stage_triangles=PIPELINE_TRIANGLES) as t:
+            holder.append(t)
+            worker = threading.Thread(target=reassemble, daemon=True)
+            worker.start()
+            try:   # (whatever the pushes do — a truncated accessor, an earlier stage's error —, the reassembly thread is told to stop and joined BEFORE the transcoder frees what it reads)
+                slice_tris = max(1, sum(w_mine) // 64)                            # (a push per ≈ 1/64 of the triangles: the library starts its first stage early)
+                lo = 0
+                while lo < n:
+                    t0 = time.perf_counter()
+                    hi, acc = lo, 0
+                    while hi < n and (hi == lo or acc + w_mine[hi] <= slice_tris):
+                        acc += w_mine[hi]
+                        hi += 1
+                    raws = [raw_of(k) for k in range(lo, hi)]
+                    tm["views_s"] += time.perf_counter() - t0
+                    t.push(raws)
+                    lo = hi
+                t.finish()
+            finally:
+                finished.put(None)
+                worker.join()
+            if errs:
+                raise errs[0]
+            tm.update(t.timings())
+            for fi in range(len(docs)):
+                if assembled[fi] is None:   # (a file without a compressible primitive)
+                    assembled[fi] = _assemble(docs[fi][0], docs[fi][1], per_file[fi], [])
+    finally:
+        for b in locked:
+            host_unregister(b)
     tm["primitives_built"] = built[0]
     return assembled
 

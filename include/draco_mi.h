@@ -235,6 +235,20 @@ typedef struct dmi_built_mesh { dmi_mesh mesh; void* owner; } dmi_built_mesh;
 int dmi_mesh_build(const dmi_raw_attribute* atts, uint32_t n_atts, const uint32_t* faces, uint32_t num_faces, dmi_built_mesh* out);
 void dmi_built_mesh_free(dmi_built_mesh* m);
 
+/* --- Host memory the device may read in place (round 5) ----------------------------------------------------------------------------------
+ * The reference reads an asset into a Vec<u8> (io/gltf/transcoder.rs:134-151 → read_scene_from_file / _from_buffer) and copies every accessor
+ * out of it (io/gltf/decode.rs:2277-2309) before MeshBuilder sees a value.  Here the importer page-locks the bytes it read — dmi_host_register on
+ * a buffer it owns (refcounted per exact range; a range that partly overlaps a registered one is refused), or dmi_host_alloc for the buffer it
+ * reads the file INTO — and dmi_meshes_build / dmi_transcoder then gather accessor rows (whatever their byteStride) and index arrays (u8 / u16
+ * widened) straight out of it with one kernel per group: no host pack, no staging copy, no separate upload.  Arrays outside such memory take
+ * the packed path as before — same result either way.  The buffer must stay registered (and unchanged) until the primitives that point
+ * into it are built.  Page-locking fresh pageable memory costs ≈ 40 ms per GiB once; a kernel reads it at ≈ 55 GB/s. */
+int dmi_host_register(const void* p, size_t bytes);
+int dmi_host_unregister(const void* p);
+void* dmi_host_alloc(size_t bytes);       /* page-locked (huge pages from 2 MiB), registered; NULL on failure */
+void dmi_host_free(void* p);
+int dmi_host_is_registered(const void* p, size_t bytes);   /* 1: [p, p + bytes) lies inside memory the device reads in place */
+
 /* --- MeshBuilder::build for a BATCH of primitives, on the device ---------------------------------------------------------
  * What the glTF importer does once per triangle primitive (io/gltf/decode.rs:2328-2525: accessors → MeshBuilder::add_attribute →
  * build()) for n primitives in one call: the accessors' rows and the index arrays go up once (pinned staging), every step of
@@ -275,7 +289,7 @@ int dmi_built_meshes_prepare(const dmi_built_mesh* built, uint32_t n, const dmi_
  * The importer pushes triangle primitives as it produces them (descriptors are copied; the accessor / index arrays they point to must stay
  * valid until the primitive is reported done); stages of ≈ stage_triangles triangles (0: a quarter of expected_triangles, within 3M … 12M;
  * the first stage a third of that) run dmi_meshes_build → dmi_built_meshes_prepare → dmi_jobs_encode on three library threads, stage k+2 / k+1 / k
- * side by side.  `done(user, first, count)` is called from a library thread when the primitives [first, first + count) (push order) are final:
+ * side by side (two threads per step since round 5: stages may finish out of push order).  `done(user, first, count)` is called from a library thread — calls for different stages may come from two threads at once — when the primitives [first, first + count) (push order) are final:
  * dmi_transcoder_result then gives primitive i's header + connectivity bytes and attribute section — blob = the two back to back, what
  * dmi_encode_mesh writes for the built mesh — and its face / point counts for the placeholder accessors (num_faces == 0: no face left, the
  * reference leaves such a primitive alone, io/gltf/encode.rs:934-936; both buffers empty).  The buffers are the transcoder's until
@@ -291,6 +305,49 @@ int dmi_transcoder_result(dmi_transcoder* t, uint32_t i, dmi_buffer* header_and_
 int dmi_transcoder_timings(dmi_transcoder* t, double* build_ms, double* prepare_ms, double* encode_ms);   /* time inside the three calls, summed over the stages */
 void dmi_transcoder_destroy(dmi_transcoder* t);
 
+/* --- A list of glTF assets in, their Draco-compressed GLBs out (round 5; io/gltf/transcoder.rs:134-151 per file: read_scene → compress_scene →
+ * write_scene) --------------------------------------------------------------------------------------------------------------------------------
+ * An asset is a GLB container (`glb`), or a glTF JSON document with its buffers already resolved by the caller (files, data URIs).  Every triangle
+ * primitive with a POSITION becomes one Mesh exactly as the reference's importer builds it (io/gltf/decode.rs:2328-2525: attributes in sorted
+ * semantic order, raw little-endian f32 rows with the view's stride, NORMAL / TEXCOORD_0 as Corner attributes whose parent is the position,
+ * `_FEATURE_ID_n` as Custom u32 attributes; a primitive for which the reference hands out a wrong parent id, or one that is Draco-compressed
+ * already, fails the call), is coded as dmi_encode_mesh codes it, and its file is rewritten as io/gltf/encode.rs:932-1097,362-400 does: blob
+ * appended to the BIN chunk, zero-padded to 4 bytes (the bufferView's byteLength includes the pad), placeholder accessors, the extension's
+ * attribute ids in add order, every other bufferView carried over, JSON chunk space-padded.  The primitives of ALL assets go through the device
+ * together: one dmi_transcoder per entry of `devices` (NULL / 0: cfg->device), the least loaded one takes the next primitive; files are written
+ * by library threads as their last primitive becomes final, into memory the result owns.  The inputs' buffers are page-locked for the call so
+ * that the device reads the accessors in place (DMI_TRANSCODE_NO_REGISTER: not; buffers the caller registered itself cost nothing here).
+ * JSON byte equality with the reference is not part of the bit-exact contract; the embedded blobs are. */
+typedef struct dmi_span { const uint8_t* data; size_t bytes; } dmi_span;
+typedef struct dmi_gltf_asset {
+  const uint8_t* glb; size_t glb_bytes;          /* a GLB container, or (glb == NULL) */
+  const char* json; size_t json_bytes;           /* a glTF document and */
+  const dmi_span* buffers; uint32_t n_buffers;   /* the bytes of its buffers, in `buffers` order */
+} dmi_gltf_asset;
+typedef struct dmi_transcode_stats {
+  uint32_t files, primitives, devices, pad;
+  uint64_t triangles_in, bytes_in, bytes_out;
+  double parse_ms;      /* caller's thread: containers, JSON, primitive plans, accessor descriptors */
+  double register_ms;   /* caller's thread: page-locking the inputs' buffers */
+  double pushed_ms;     /* since the start of the call: the last primitive handed to a transcoder */
+  double finished_ms;   /* since the start of the call: the last stage of the last device coded */
+  double build_ms, prepare_ms, encode_ms;   /* time inside the three stage calls, summed over stages and devices (they overlap) */
+  double assemble_ms;   /* assembly threads, summed */
+  double call_ms;
+} dmi_transcode_stats;
+typedef struct dmi_transcoded dmi_transcoded;
+#define DMI_TRANSCODE_NO_REGISTER 1u
+int dmi_transcode_assets(const dmi_gltf_asset* assets, uint32_t n, const dmi_config* cfg, const int32_t* devices, uint32_t n_devices, uint32_t flags, dmi_transcoded** out);
+/* file i of the result: its GLB bytes (the result's memory, valid until dmi_transcoded_free) and how many primitives were compressed;
+ * dmi_transcoded_blobs: where their blobs lie in the file (offset, size without the pad), in primitive order */
+int dmi_transcoded_file(const dmi_transcoded* r, uint32_t i, const uint8_t** glb, size_t* bytes, uint32_t* n_blobs);
+int dmi_transcoded_blobs(const dmi_transcoded* r, uint32_t i, uint64_t* offsets, uint64_t* sizes);
+int dmi_transcoded_stats(const dmi_transcoded* r, dmi_transcode_stats* s);
+void dmi_transcoded_free(dmi_transcoded* r);
+/* The JSON layer of the above on its own (host only, for tests): parse `text`, write it back compactly — members in document order, number tokens
+ * as written.  out: dmi_free. */
+int dmi_json_roundtrip(const char* text, size_t n, dmi_buffer* out);
+
 /* Stage times of the calling thread's last dmi_meshes_build (milliseconds; kernels_ms is hipEvent time summed over the groups). */
 typedef struct dmi_build_timings {
   float pack_ms;       /* host threads: rows and indices into pinned staging */
@@ -298,6 +355,8 @@ typedef struct dmi_build_timings {
   float call_ms;       /* the whole call */
   uint32_t device_meshes, host_meshes;   /* primitives built by the kernels / by the host builder */
   uint64_t bytes_up, bytes_down;
+  uint32_t in_place_meshes;              /* of device_meshes: accessors and indices read where they lie (dmi_host_register), nothing packed */
+  uint32_t pad;
 } dmi_build_timings;
 int dmi_last_build_timings(dmi_build_timings* t);
 

@@ -64,7 +64,9 @@ def test_duck_transcode_blob_bit_exact():
     want = _oracle_session(doc, binary, prim).encode()
     assert blobs[0] == want
     # (one device, one process: the blob is a view INTO the output file — the attribute section went from the library's buffer straight into it)
-    assert isinstance(blobs[0], memoryview) and blobs[0].obj is out and bytes(blobs[0]) == want
+    assert isinstance(blobs[0], memoryview) and isinstance(out, memoryview) and bytes(blobs[0]) == want
+    lo, hi = np.frombuffer(out, np.uint8).ctypes.data, np.frombuffer(out, np.uint8).ctypes.data + len(out)
+    assert lo <= np.frombuffer(blobs[0], np.uint8).ctypes.data < hi                  # (a view INTO the output file, which is the library's memory)
     doc2, bin2 = gltf.read_glb(out)
     assert "KHR_draco_mesh_compression" in doc2["extensionsRequired"]
     (payload, ids), = gltf.draco_blobs_of(out)
@@ -213,6 +215,31 @@ def test_transcode_1024_primitives_in_one_batch():
     assert sum(len(blobs) for _, blobs in results) == 1024
     for f, k in [(0, 0), (5, 3), (17, 15), (33, 8), (63, 15), (40, 1), (21, 7), (9, 12)]:
         assert results[f][1][k] == _oracle_blob(files[f][k])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seams", [False, True])
+def test_full_size_files_through_the_transcoder_against_the_oracle(seams):
+    """BASELINE configs[3] at its stated sizes: 72 GLB files of 2k–200k triangles each (synth.batch_glbs; seams=True: the exporter-style sheets with
+    repeated positions / normals and a UV seam → device MeshBuilder merges, an attribute corner table of the UVs' own) through gltf.transcode_files —
+    dmi_transcoder: device build, batched prepare, device chains, several stages — and a seeded sample of the embedded blobs, the LARGEST and
+    the smallest file among them, byte for byte against the oracle's encode of the same accessors."""
+    from draco_oxide_amd import synth
+    glbs, total = synth.batch_glbs(72, seed=synth.SEED + (11 if seams else 5), seams=seams)
+    assert total > 2_000_000
+    tm = {}
+    results = gltf.transcode_files(glbs, timings=tm)
+    assert tm["primitives_built"] == 72 and len(results) == 72
+    sizes = [gltf.primitive_weight(*(lambda d: (d, d["meshes"][0]["primitives"][0]))(gltf.read_glb(g)[0])) for g in glbs]
+    assert max(sizes) > 120_000 and min(sizes) < 4_000
+    rng = np.random.default_rng(2024)
+    sample = {int(np.argmax(sizes)), int(np.argmin(sizes))} | {int(i) for i in rng.choice(72, size=6, replace=False)}
+    for i in sorted(sample):
+        doc, binary = gltf.read_glb(glbs[i])
+        want = _oracle_session(doc, binary, doc["meshes"][0]["primitives"][0]).encode()
+        assert bytes(results[i][1][0]) == want, (i, sizes[i])
+        (payload, ids), = gltf.draco_blobs_of(results[i][0])
+        assert payload[: len(want)] == want and len(payload) - len(want) < 4
 
 
 def test_primitive_the_reference_cannot_encode_is_refused():
