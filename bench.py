@@ -177,8 +177,9 @@ def transcode_regime(n_files=1024, steps=5, device=0):
     gltf.transcode_files → n Draco-compressed GLBs.  Inside the timed call: container + JSON parse, primitive plans, accessor descriptors,
     MeshBuilder::build on the device for every primitive, connectivity stage + job creation, dmi_jobs_encode, the files written — all inside
     the library (dmi_transcode_assets, csrc/dmi_gltf.cpp; the interpreter only hands the list over).  `value` is the MEDIAN of `steps` calls
-    (the minimum beside it) with the inputs in ordinary pageable memory, page-locked by the call itself; `inputs_page_locked_by_the_caller` is the
-    same list after dmi_host_register (an importer that reads its files into dmi_host_alloc memory: nothing is locked or packed inside the call)."""
+    (the minimum beside it) with the inputs in ordinary pageable memory (packed into staging by host threads, one copy up per group);
+    `inputs_read_into_dmi_host_alloc_memory` is the same list held in the library's page-locked blocks (an importer that reads its files into
+    dmi_host_alloc memory: accessors go up by DMA where they lie)."""
     from draco_oxide_amd import binding, gltf
     glbs, total = synth.batch_glbs(n_files)
     in_bytes = sum(len(g) for g in glbs)
@@ -205,42 +206,29 @@ def transcode_regime(n_files=1024, steps=5, device=0):
     out_bytes = sum(len(g) for g, _ in res)
     st = tm.get("native", {})
     del res, res1
-    # the same list with its bytes page-locked by the caller beforehand
+    # the same files read into dmi_host_alloc memory beforehand (an importer that reads its files into the library's page-locked blocks): accessors go
+    # up where they lie — no host pack, no staging copy
     locked = None
     try:
-        mine = [g for g in glbs if binding.host_register(g)]
-        gltf.transcode_files(glbs, cfg)
+        held = [binding.HostBuffer.holding(g) for g in glbs]
+        views = [h.view() for h in held]
+        gltf.transcode_files(views, cfg)
         tl, tml = [], []
         for _ in range(steps):
             tm2 = {}
             t0 = time.perf_counter()
-            gltf.transcode_files(glbs, cfg, timings=tm2)
+            gltf.transcode_files(views, cfg, timings=tm2)
             tl.append(time.perf_counter() - t0)
             tml.append(tm2.get("native", {}))
-        for g in mine:
-            binding.host_unregister(g)
+        del views
+        for h in held:
+            h.free()
         m2, b2 = _med_min(tl)
         s2 = tml[tl.index(sorted(tl)[len(tl) // 2])]
         locked = {"value": round(total / m2 / 1e6, 2), "unit": "Mtriangles/s", "ms_per_batch_median": round(m2 * 1e3, 2), "ms_per_batch_min": round(b2 * 1e3, 2),
-                  "files_locked": len(mine), "pushed_ms": round(s2.get("pushed_ms", 0), 2), "finished_ms": round(s2.get("finished_ms", 0), 2)}
+                  "buffers_in_place": int(s2.get("buffers_in_place", 0)), "pushed_ms": round(s2.get("pushed_ms", 0), 2), "finished_ms": round(s2.get("finished_ms", 0), 2)}
     except Exception as e:
         locked = {"error": str(e)[:200]}
-    # pack + copy instead of reading in place (A/B of the ingest)
-    packed = None
-    try:
-        os.environ["DMI_NO_REGISTER"] = "1"
-        tp = []
-        for _ in range(steps):
-            t0 = time.perf_counter()
-            gltf.transcode_files(glbs, cfg)
-            tp.append(time.perf_counter() - t0)
-        m3, b3 = _med_min(tp)
-        packed = {"value": round(total / m3 / 1e6, 2), "ms_per_batch_median": round(m3 * 1e3, 2), "ms_per_batch_min": round(b3 * 1e3, 2),
-                  "what": "DMI_NO_REGISTER=1: accessors packed into staging by host threads and copied up (round 4's ingestion)"}
-    except Exception as e:
-        packed = {"error": str(e)[:200]}
-    finally:
-        os.environ.pop("DMI_NO_REGISTER", None)
     seam = None
     try:   # the same shape of files the way exporters write them: repeated positions / normals along the closing curves, a UV seam there
         n_s = max(8, n_files // 4)
@@ -259,13 +247,12 @@ def transcode_regime(n_files=1024, steps=5, device=0):
                 "sample_blob_equals_whole_mesh_encode": bool(sres[n_s // 2][1][0] == dmi.encode_mesh(mesh, cfg))}
     except Exception as e:
         seam = {"error": str(e)[:200]}
-    return {"with_uv_seams": seam, "inputs_page_locked_by_the_caller": locked, "inputs_packed_and_copied": packed,
+    return {"with_uv_seams": seam, "inputs_read_into_dmi_host_alloc_memory": locked,
             "workload": f"BASELINE configs[3]: {n_files} GLB files in memory (one primitive each, F log-uniform [2k,200k], pos+nrm+uv, u16/u32 indices) → gltf.transcode_files → {n_files} "
                         "Draco-compressed GLBs: container + JSON parse, accessor descriptors, device MeshBuilder::build, dmi_built_meshes_prepare, dmi_jobs_encode, file assembly — "
-                        "all inside dmi_transcode_assets, inside the timed call; inputs in pageable memory, page-locked by the call",
+                        "all inside dmi_transcode_assets, inside the timed call; inputs in pageable memory",
             "triangles": int(total), "value": round(total / med / 1e6, 2), "unit": "Mtriangles/s", "statistic": f"median of {steps} calls", "ms_per_batch": round(med * 1e3, 2), "ms_per_batch_min": round(best * 1e3, 2),
             "split_ms": {"parse (containers, JSON, plans, accessor descriptors; caller's thread)": round(st.get("parse_ms", 0), 2),
-                         "page-locking the inputs (caller's thread, between the pushes)": round(st.get("register_ms", 0), 2),
                          "last primitive pushed at": round(st.get("pushed_ms", 0), 2), "last stage coded at": round(st.get("finished_ms", 0), 2),
                          "build (ingest / pack, kernels, faces + maps back; summed over stages, two threads)": round(st.get("build_ms", 0), 2),
                          "prepare (device tables, host walks, relabelling; summed, two threads)": round(st.get("prepare_ms", 0), 2),

@@ -97,9 +97,9 @@ class _GltfAsset(C.Structure):
 
 
 class _TranscodeStats(C.Structure):
-    _fields_ = [("files", C.c_uint32), ("primitives", C.c_uint32), ("devices", C.c_uint32), ("pad", C.c_uint32),
+    _fields_ = [("files", C.c_uint32), ("primitives", C.c_uint32), ("devices", C.c_uint32), ("buffers_in_place", C.c_uint32),
                 ("triangles_in", C.c_uint64), ("bytes_in", C.c_uint64), ("bytes_out", C.c_uint64),
-                ("parse_ms", C.c_double), ("register_ms", C.c_double), ("pushed_ms", C.c_double), ("finished_ms", C.c_double),
+                ("parse_ms", C.c_double), ("pushed_ms", C.c_double), ("finished_ms", C.c_double),
                 ("build_ms", C.c_double), ("prepare_ms", C.c_double), ("encode_ms", C.c_double), ("assemble_ms", C.c_double), ("call_ms", C.c_double)]
 
 
@@ -131,8 +131,8 @@ EXPORTS = ["dmi_encode_attributes", "dmi_encode_attributes_batch", "dmi_jobs_enc
            "dmi_mesh_prepare", "dmi_meshes_prepare", "dmi_shard_meshes", "dmi_meshes_prepare_devices", "dmi_jobs_encode_devices", "dmi_mesh_build", "dmi_built_mesh_free", "dmi_encode_connectivity", "dmi_conn_free", "dmi_host_rans_stream", "dmi_host_rabs_stream", "dmi_host_rabs_constant_stream", "dmi_tile_sort_slots", "dmi_decode_attributes", "dmi_decoded_free", "dmi_decode_mesh", "dmi_decoded_mesh_free", "dmi_decode_connectivity", "dmi_decoded_conn_free", "dmi_last_decode_timings", "dmi_free", "dmi_free_many", "dmi_strerror", "dmi_last_error", "dmi_device_count", "dmi_release_cached_memory",
            "dmi_init", "dmi_last_call_timings", "dmi_device_corner_table", "dmi_encode_mesh_device", "dmi_meshes_build", "dmi_built_meshes_prepare", "dmi_last_build_timings", "dmi_device_attribute_table", "dmi_built_meshes_info", "dmi_built_meshes_free", "dmi_thread_host_threads", "dmi_usable_host_threads",
            "dmi_transcoder_create", "dmi_transcoder_reserve", "dmi_transcoder_push", "dmi_transcoder_finish", "dmi_transcoder_result", "dmi_transcoder_timings", "dmi_transcoder_destroy",
-           "dmi_host_register", "dmi_host_unregister", "dmi_host_alloc", "dmi_host_free", "dmi_host_is_registered",
-           "dmi_transcode_assets", "dmi_transcoded_file", "dmi_transcoded_blobs", "dmi_transcoded_stats", "dmi_transcoded_free", "dmi_json_roundtrip"]
+           "dmi_host_alloc", "dmi_host_free", "dmi_host_is_registered",
+           "dmi_transcode_assets", "dmi_transcoded_file", "dmi_transcoded_blobs", "dmi_transcoded_stats", "dmi_transcoded_free", "dmi_json_roundtrip", "dmi_transcoded_table"]
 
 
 def library_path():
@@ -222,8 +222,6 @@ def load_library():
     L.dmi_thread_host_threads.restype = None
     L.dmi_usable_host_threads.restype = C.c_int
     L.dmi_device_attribute_table.argtypes = [C.POINTER(_Mesh), C.POINTER(_Config), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
-    L.dmi_host_register.argtypes = [C.c_void_p, C.c_size_t]
-    L.dmi_host_unregister.argtypes = [C.c_void_p]
     L.dmi_host_alloc.argtypes = [C.c_size_t]
     L.dmi_host_alloc.restype = C.c_void_p
     L.dmi_host_free.argtypes = [C.c_void_p]
@@ -233,6 +231,7 @@ def load_library():
     L.dmi_transcoded_file.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]
     L.dmi_transcoded_blobs.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     L.dmi_transcoded_stats.argtypes = [C.c_void_p, C.POINTER(_TranscodeStats)]
+    L.dmi_transcoded_table.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
     L.dmi_transcoded_free.argtypes = [C.c_void_p]
     L.dmi_transcoded_free.restype = None
     L.dmi_json_roundtrip.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(_Buffer)]
@@ -589,20 +588,21 @@ def _address_of(buf):
     return a.ctypes.data, a.nbytes
 
 
-def host_register(buf):
-    """dmi_host_register on the memory of a bytes-like object: accessors inside it are then read by the device where they lie (no pack, no
-    upload copy).  The object must stay alive and unchanged until host_unregister(buf).  Returns False where the runtime refuses the range."""
-    addr, n = _address_of(buf)
-    return n > 0 and load_library().dmi_host_register(addr, n) == 0
-
-
-def host_unregister(buf):
-    addr, _ = _address_of(buf)
-    load_library().dmi_host_unregister(addr)
-
-
 class HostBuffer:
-    """dmi_host_alloc memory as a writable uint8 numpy array (`.array`): what an importer reads a file INTO so that nothing is page-locked later."""
+    """dmi_host_alloc memory as a writable uint8 numpy array (`.array`): what an importer reads a file INTO — accessors inside it go up to the device
+    where they lie (no host pack, no staging copy).  `HostBuffer.holding(data)`: a buffer with a copy of `data` in it."""
+
+    @classmethod
+    def holding(cls, data):
+        a = np.frombuffer(data, dtype=np.uint8)
+        hb = cls(max(1, a.nbytes))
+        hb.array[: a.nbytes] = a
+        hb.nbytes = a.nbytes
+        return hb
+
+    def view(self):
+        """The bytes put in by holding() as a memoryview of the page-locked memory."""
+        return memoryview(self.array[: getattr(self, "nbytes", len(self.array))])
 
     def __init__(self, nbytes):
         self._p = load_library().dmi_host_alloc(nbytes)
@@ -621,9 +621,6 @@ class HostBuffer:
             self.free()
         except Exception:
             pass
-
-
-TRANSCODE_NO_REGISTER = 1
 
 
 def json_roundtrip(text):
@@ -652,7 +649,7 @@ class _TranscodedHandle:
             pass
 
 
-def transcode_assets(assets, cfg=None, devices=None, register=True):
+def transcode_assets(assets, cfg=None, devices=None):
     """dmi_transcode_assets: `assets` = GLB containers (bytes-like) or (json_bytes, [buffer bytes-like, ...]) pairs → ([(glb, [blob, ...]), ...], stats).
     glb and the blobs are memoryviews of memory the library owns (the blobs lie inside their file; everything is released when the last view is
     gone); stats = dmi_transcode_stats as a dict.  devices: HIP ordinals (one dmi_transcoder each; None: cfg.device)."""
@@ -682,23 +679,25 @@ def transcode_assets(assets, cfg=None, devices=None, register=True):
         dev = (C.c_int32 * len(devices))(*[int(d) for d in devices])
     c = cfg._c()
     h = C.c_void_p()
-    _check(L.dmi_transcode_assets(arr, n, C.byref(c), dev, len(devices) if devices else 0, 0 if register else TRANSCODE_NO_REGISTER, C.byref(h)))
+    _check(L.dmi_transcode_assets(arr, n, C.byref(c), dev, len(devices) if devices else 0, 0, C.byref(h)))
     owner = _TranscodedHandle(h.value)
     st = _TranscodeStats()
     _check(L.dmi_transcoded_stats(h, C.byref(st)))
+    addr, size, nblob = np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.zeros(n, np.uint32)
+    cap = max(1, st.primitives)
+    offs, sizes = np.zeros(cap, np.uint64), np.zeros(cap, np.uint64)
+    _check(L.dmi_transcoded_table(h, addr.ctypes.data, size.ctypes.data, nblob.ctypes.data, offs.ctypes.data, sizes.ctypes.data, cap))
     out = []
-    p, nb, k = C.c_void_p(), C.c_size_t(), C.c_uint32()
+    at = 0
+    u8 = C.c_uint8
+    addr, size, nblob, offs, ends = addr.tolist(), size.tolist(), nblob.tolist(), offs.tolist(), (offs + sizes).tolist()
     for i in range(n):
-        _check(L.dmi_transcoded_file(h, i, C.byref(p), C.byref(nb), C.byref(k)))
-        raw = (C.c_uint8 * nb.value).from_address(p.value)
+        raw = (u8 * size[i]).from_address(addr[i])
         raw._owner = owner
         glb = memoryview(raw).cast("B")
-        blobs = []
-        if k.value:
-            offs, sizes = np.zeros(k.value, np.uint64), np.zeros(k.value, np.uint64)
-            _check(L.dmi_transcoded_blobs(h, i, offs.ctypes.data, sizes.ctypes.data))
-            blobs = [glb[int(o): int(o) + int(z)] for o, z in zip(offs, sizes)]
-        out.append((glb, blobs))
+        k = nblob[i]
+        out.append((glb, [glb[offs[q]: ends[q]] for q in range(at, at + k)]))
+        at += k
     return out, {name: getattr(st, name) for name, _ in _TranscodeStats._fields_ if name != "pad"}
 
 

@@ -6,16 +6,19 @@
 // threads (strided accessors are de-strided on the way), ONE copy up, the build kernels (one launch per kernel for all primitives of the
 // group), a small read-back of counts and offsets, then ONE read-back of arena A (faces + point → value maps: what the host's serial walks
 // read) — the unique values stay in arena B on the device unless the caller asks for them.  Two streams alternate between consecutive
-// groups, so a group's kernels and read-back overlap the next group's packing and upload.  INGEST (round 5): a group whose accessors and index
-// arrays all lie in page-locked host memory the library knows of (dmi_host_register / dmi_host_alloc: dmi_hostmem.cpp) is not packed at all — one
-// kernel gathers the rows (de-strided) and the indices (widened) straight out of the caller's buffers over PCIe.  A primitive the device form does not cover
+// groups, so a group's kernels and read-back overlap the next group's packing and upload.  IN PLACE (round 5): a group whose accessors and index
+// arrays all lie in memory the importer got from dmi_host_alloc (page-locked blocks of the library's: dmi_hostmem.cpp) is not packed at all — the
+// DMA engine copies the caller's bytes as they lie (the arrays' ranges merged into spans: about one copy per file), the kernels read the rows with
+// their accessor's stride, one launch gathers the index arrays (u8 / u16 widened) into the face array.  (A kernel reading host memory directly was
+// tried first: it moves the bytes at the link's rate too, but it does so on compute units — 29 ms of device time per 1024-file transcode beside
+// the kernels of three other stages — where the copy engines are idle.)  A primitive the device form does not cover
 // (see dmi_build.hip) is built by the host builder (dmi_mesh_build) inside the same call: same result either way
 // (tests/test_gpu_device_build.py holds every mesh equal to dmi_mesh_build's and to the oracle's restated builder).
 #include "dmi_job.hpp"
 
 using namespace dmi;
 
-namespace dmi { const void* host_device_view(const void* p, size_t bytes); }   // dmi_hostmem.cpp
+namespace dmi { bool host_in_place(const void* p, size_t bytes); }   // dmi_hostmem.cpp: inside a dmi_host_alloc block?
 
 namespace {
 
@@ -137,8 +140,9 @@ struct BuildGroup {
   MbArgs args{};
   hipEvent_t ev_counts = nullptr, ev_done = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
   bool host_values = false, large = false;
-  bool ingest = false;                  // every array of every member is read where it lies (page-locked host memory)
-  std::vector<uint64_t> src_view;       // ingest: device-visible address per array, member after member: its accessors, then its indices
+  bool in_place = false;                // every array of every member lies in page-locked host memory: DMA straight out of the caller's buffers, no pack
+  struct Span { uintptr_t lo, hi; size_t dev_off; };
+  std::vector<Span> spans;              // in place: merged host ranges, one DMA each
   ~BuildGroup() {
     if (S) (void)hipStreamSynchronize(S);
     for (hipEvent_t e : {ev_counts, ev_done, ev_k0, ev_k1}) if (e) (void)hipEventDestroy(e);
@@ -201,8 +205,7 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
     if (no_device || !device_form(m)) { host_list.push_back(j); continue; }
     const bool large = m.num_faces >= kDeviceRelabelMinFaces;
     const uint64_t ap = (uint64_t)m.atts[0].count * m.n_atts;
-    // can the device read this primitive's arrays where they lie?
-    uint64_t views[kMbMaxAtts + 1];
+    // can the DMA engine take this primitive's arrays where they lie?
     bool in_place = !no_ingest;
     for (uint32_t i = 0; in_place && i <= m.n_atts; ++i) {
       const void* p; size_t span; bool aligned;
@@ -214,11 +217,9 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
         const size_t eb = component_bytes(m.index_type);
         p = m.indices; span = (size_t)m.num_faces * 3 * eb; aligned = !((uintptr_t)p & (eb - 1));
       }
-      const void* v = aligned ? host_device_view(p, span) : nullptr;
-      in_place = v != nullptr;
-      views[i] = (uint64_t)(uintptr_t)v;
+      in_place = aligned && host_in_place(p, span);
     }
-    bool fresh = groups.empty() || large || groups.back()->large || groups.back()->ingest != in_place;
+    bool fresh = groups.empty() || large || groups.back()->large || groups.back()->in_place != in_place;
     if (!fresh) {
       const BuildGroup& g = *groups.back();
       fresh = g.raw_faces + m.num_faces > group_faces || g.ap + ap >= (1ull << 30) || g.which.size() >= 65536;
@@ -226,14 +227,14 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
     if (fresh) groups.emplace_back(new BuildGroup());
     BuildGroup& g = *groups.back();
     g.large = large;
-    g.ingest = in_place;
-    if (in_place) g.src_view.insert(g.src_view.end(), views, views + m.n_atts + 1);
+    g.in_place = in_place;
     MbMesh me{};
     me.index = (uint32_t)g.meshes.size(); me.n_items = m.n_atts; me.item0 = (uint32_t)g.items.size(); me.P = m.atts[0].count; me.F = m.num_faces;
     me.face_off = (uint32_t)g.raw_faces; me.point_off = (uint32_t)g.points;
     for (uint32_t i = 0; i < m.n_atts; ++i) {
       MbItem it{};
       it.mesh = me.index; it.P = me.P; it.words = m.atts[i].num_components; it.is_float = m.atts[i].component_type == DMI_F32;
+      it.stride = it.words;
       it.ap_off = (uint32_t)(g.ap + (uint64_t)i * me.P);
       g.items.push_back(it);
     }
@@ -251,33 +252,69 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
     g.host_values = host_values;
     g.S = library_group_stream(device, (int)(gi & 1));
     if (!g.S) return fail(DMI_ERR_HIP, "hipStreamCreate");
-    // upload region: packed rows of every item (256-byte aligned), then the indices (u32 as they are; narrower ones are widened on the device)
+    // upload region: packed rows of every item (256-byte aligned), then the indices (u32 as they are; narrower ones are widened on the device).
+    // In place: the caller's bytes as they lie — the arrays' host ranges merged into spans (arrays of one file sit next to each other: ONE DMA per
+    // file instead of one per accessor — 4096 accessor-sized copies take 3 × the time of the bytes they move), a span's device copy at the same
+    // address modulo 256; the kernels read rows with their accessor's stride, one launch gathers the index arrays into the face array.
     size_t at = 0, vtab_words = 0, ptab_words = 0;
     g.row_at.resize(NI); g.idx_at.resize(M);
+    if (g.in_place) {
+      struct Arr { uintptr_t lo, hi; uint32_t k, i; };
+      std::vector<Arr> arrs;
+      for (uint32_t k = 0; k < M; ++k) {
+        const dmi_raw_mesh& m = raw[g.which[k]];
+        for (uint32_t i = 0; i < m.n_atts; ++i) {
+          const dmi_raw_accessor& ac = m.atts[i];
+          const size_t row = 4u * ac.num_components, stride = ac.byte_stride ? ac.byte_stride : row;
+          arrs.push_back({(uintptr_t)ac.data, (uintptr_t)ac.data + (size_t)(ac.count - 1) * stride + row, k, i});
+        }
+        arrs.push_back({(uintptr_t)m.indices, (uintptr_t)m.indices + (size_t)m.num_faces * 3 * component_bytes(m.index_type), k, m.n_atts});
+      }
+      std::vector<uint32_t> order(arrs.size());
+      for (uint32_t q = 0; q < order.size(); ++q) order[q] = q;
+      std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return arrs[x].lo < arrs[y].lo; });
+      constexpr uintptr_t kGap = 16384;   // bytes of no use that ride along rather than start a new copy
+      for (uint32_t q : order) {
+        const Arr& ar = arrs[q];
+        if (g.spans.empty() || ar.lo > g.spans.back().hi + kGap || !host_in_place(reinterpret_cast<const void*>(g.spans.back().lo), std::max(ar.hi, g.spans.back().hi) - g.spans.back().lo)) {
+          at = align256(at) + (ar.lo & 255);
+          g.spans.push_back({ar.lo, ar.hi, at});
+        } else {
+          g.spans.back().hi = std::max(g.spans.back().hi, ar.hi);
+        }
+        at = g.spans.back().dev_off + (g.spans.back().hi - g.spans.back().lo);
+        const size_t dev = g.spans.back().dev_off + (ar.lo - g.spans.back().lo);
+        if (ar.i < raw[g.which[ar.k]].n_atts) g.row_at[g.meshes[ar.k].item0 + ar.i] = dev; else g.idx_at[ar.k] = dev;
+      }
+      at = align256(at);
+    }
     for (uint32_t i = 0; i < NI; ++i) {
       MbItem& it = g.items[i];
-      g.row_at[i] = at;
-      it.row_off = (uint32_t)(at / 4);
-      at = align256(at + (size_t)it.P * it.words * 4);
+      if (!g.in_place) { g.row_at[i] = at; at = align256(at + (size_t)it.P * it.words * 4); }
+      it.row_off = (uint32_t)(g.row_at[i] / 4);
       const uint32_t ts = pow2_at_least(2ull * it.P);
       it.tab_off = (uint32_t)vtab_words; it.tab_mask = ts - 1;
       vtab_words += ts;
     }
+    if (g.in_place) for (uint32_t k = 0; k < M; ++k) {
+      const dmi_raw_mesh& m = raw[g.which[k]];
+      for (uint32_t i = 0; i < m.n_atts; ++i) if (m.atts[i].byte_stride) g.items[g.meshes[k].item0 + i].stride = m.atts[i].byte_stride / 4;
+    }
     g.values_bytes = at;
     if (at >= ((size_t)1 << 34) || vtab_words >= (1ull << 32)) return fail(DMI_ERR_INVALID_ARGUMENT, "build group too large");
-    bool any_narrow = false;
-    if (!g.ingest) for (uint32_t k = 0; k < M; ++k) if (component_bytes(raw[g.which[k]].index_type) != 4) any_narrow = true;
+    bool any_narrow = g.in_place;   // (in place: the face array is always gathered out of the spans)
+    if (!g.in_place) for (uint32_t k = 0; k < M; ++k) if (component_bytes(raw[g.which[k]].index_type) != 4) any_narrow = true;
     for (uint32_t k = 0; k < M; ++k) {
       const dmi_raw_mesh& m = raw[g.which[k]];
       MbMesh& me = g.meshes[k];
       const uint32_t ts = pow2_at_least(2ull * me.P);
       me.ptab_off = (uint32_t)ptab_words; me.ptab_mask = ts - 1;
       ptab_words += ts;
+      if (g.in_place) continue;
       // indices: a group of 32-bit index arrays uploads them as ONE array (the kernels' face array); with a narrower array in the group
-      // every array goes up as it is and one launch widens / copies them into the face array.  Ingest: the gather kernel widens what it reads,
-      // the face array is written directly.
+      // every array goes up as it is and one launch widens / copies them into the face array
       g.idx_at[k] = at;
-      at += (size_t)m.num_faces * 3 * (g.ingest ? 4 : component_bytes(m.index_type));
+      at += (size_t)m.num_faces * 3 * component_bytes(m.index_type);
       if (any_narrow) at = align256(at);
     }
     at = align256(at);
@@ -297,7 +334,7 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
     bg.d_base = bg.keep.take<uint8_t>(bg.b_off + bg.b_bytes + 256);
     const size_t parts = scan_partials_words((uint32_t)(std::max({AP, PT, RF}) + 1));
     const size_t scratch_words = (any_narrow ? 3 * RF : 0) + vtab_words + ptab_words + 5 * AP + 2 + 4 * PT + 2 + RF + 1 + 3 * RF + parts + 64 * 16;
-    g.scratch.init(device, g.S, g.up_bytes + scratch_words * 4 + (size_t)M * (sizeof(MbMesh) + sizeof(MbMeshOut) + sizeof(MbWiden)) + (size_t)NI * (sizeof(MbItem) + sizeof(MbItemOut)) + (size_t)(NI + M) * sizeof(MbIngest) + ((size_t)1 << 20));
+    g.scratch.init(device, g.S, g.up_bytes + scratch_words * 4 + (size_t)M * (sizeof(MbMesh) + sizeof(MbMeshOut) + sizeof(MbWiden)) + (size_t)NI * (sizeof(MbItem) + sizeof(MbItemOut)) + ((size_t)1 << 20));
     uint8_t* d_up = g.scratch.take<uint8_t>(g.up_bytes);
     MbArgs& a = g.args;
     a.M = M; a.n_items = NI; a.total_faces = (uint32_t)RF; a.total_points = (uint32_t)PT; a.total_ap = (uint32_t)AP;
@@ -317,8 +354,8 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
     a.raw_values = reinterpret_cast<const uint32_t*>(d_up);
     a.arena_a = reinterpret_cast<uint32_t*>(bg.d_base); a.arena_b = reinterpret_cast<uint32_t*>(bg.d_base + bg.b_off);
     // pinned staging: the upload (released when the group is done) and what stays (arena A's host copy, arena B's on request, the counts)
-    const size_t desc_bytes = align256((size_t)M * sizeof(MbMesh)) + align256((size_t)NI * sizeof(MbItem)) + align256((size_t)M * sizeof(MbWiden)) + align256((size_t)(NI + M) * sizeof(MbIngest));
-    const size_t stage_data = g.ingest ? 0 : g.up_bytes;   // (ingest: only the descriptors go through staging)
+    const size_t desc_bytes = align256((size_t)M * sizeof(MbMesh)) + align256((size_t)NI * sizeof(MbItem)) + align256((size_t)M * sizeof(MbWiden));
+    const size_t stage_data = g.in_place ? 0 : g.up_bytes;   // (in place: only the descriptors go through staging)
     g.up_stage = acquire_stage(device, stage_data + desc_bytes);
     const size_t keep_counts = align256((size_t)M * sizeof(MbMeshOut)) + align256((size_t)NI * sizeof(MbItemOut)) + 256;
     const size_t keep_a = align256(bg.a_bytes), keep_b = host_values ? align256(bg.b_bytes) : 0;
@@ -343,7 +380,7 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
       }
     }
     const double p0 = ms();
-    if (g.ingest) tasks.clear();
+    if (g.in_place) tasks.clear();
     if ((rc = run_parallel((uint32_t)tasks.size(), pack_threads, [&](uint32_t t) -> int {
           const Task& tk = tasks[t];
           const dmi_raw_mesh& m = raw[g.which[tk.k]];
@@ -364,39 +401,17 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
         widen_total += 3u * g.meshes[k].F;
       }
     }
-    uint64_t ingest_words = 0;
-    uint32_t n_ingest = 0;
-    MbIngest* d_ingest = nullptr;
-    if (g.ingest) {
-      MbIngest* w = reinterpret_cast<MbIngest*>(h_desc + align256((size_t)M * sizeof(MbMesh)) + align256((size_t)NI * sizeof(MbItem)) + align256((size_t)M * sizeof(MbWiden)));
-      size_t v = 0;
-      for (uint32_t k = 0; k < M; ++k) {
-        const dmi_raw_mesh& m = raw[g.which[k]];
-        for (uint32_t i = 0; i < m.n_atts; ++i, ++v) {
-          const dmi_raw_accessor& ac = m.atts[i];
-          const uint32_t row = 4u * ac.num_components;
-          MbIngest it{g.src_view[v], ingest_words, ac.count * ac.num_components, (uint32_t)(g.row_at[g.meshes[k].item0 + i] / 4), ac.num_components,
-                      ac.byte_stride && ac.byte_stride != row ? ac.byte_stride : 0u, 4u, 0u};
-          ingest_words += mb_ingest_units(it);
-          w[n_ingest++] = it;
-        }
-        MbIngest it{g.src_view[v++], ingest_words, 3u * m.num_faces, (uint32_t)(g.idx_at[k] / 4), 0u, 0u, (uint32_t)component_bytes(m.index_type), 0u};
-        ingest_words += mb_ingest_units(it);
-        w[n_ingest++] = it;
-      }
-      d_ingest = g.scratch.take<MbIngest>(n_ingest);
-      if (!d_ingest) return fail(DMI_ERR_OUT_OF_MEMORY, "hipMalloc (device mesh build)");
-      HIP_TRY(hipMemcpyAsync(d_ingest, w, (size_t)n_ingest * sizeof(MbIngest), hipMemcpyHostToDevice, g.S));
+    if (g.in_place) {
+      for (const BuildGroup::Span& sp : g.spans) { HIP_TRY(hipMemcpyAsync(d_up + sp.dev_off, reinterpret_cast<const void*>(sp.lo), sp.hi - sp.lo, hipMemcpyHostToDevice, g.S)); bytes_up += sp.hi - sp.lo; }
     } else {
       HIP_TRY(hipMemcpyAsync(d_up, hp, g.up_bytes, hipMemcpyHostToDevice, g.S));
+      bytes_up += g.up_bytes;
     }
     HIP_TRY(hipMemcpyAsync(d_meshes, h_desc, (size_t)M * sizeof(MbMesh), hipMemcpyHostToDevice, g.S));
     HIP_TRY(hipMemcpyAsync(d_items, h_desc + align256((size_t)M * sizeof(MbMesh)), (size_t)NI * sizeof(MbItem), hipMemcpyHostToDevice, g.S));
     if (n_widen) HIP_TRY(hipMemcpyAsync(d_widen, h_desc + align256((size_t)M * sizeof(MbMesh)) + align256((size_t)NI * sizeof(MbItem)), (size_t)n_widen * sizeof(MbWiden), hipMemcpyHostToDevice, g.S));
-    bytes_up += g.up_bytes;
     HIP_TRY(hipEventCreate(&g.ev_k0)); HIP_TRY(hipEventCreate(&g.ev_k1));
     HIP_TRY(hipEventRecord(g.ev_k0, g.S));
-    if (g.ingest) launch_mesh_ingest(d_ingest, n_ingest, ingest_words, reinterpret_cast<uint32_t*>(d_up), g.S);
     if (any_narrow) {
       launch_widen_indices(d_widen, n_widen, widen_total, d_up, d_wide, g.S);
       a.raw_faces = d_wide;
@@ -498,7 +513,7 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
       out[j].mesh.num_atts = m.n_atts;
       out[j].owner = static_cast<BuiltBase*>(o.release());
       ++n_device;
-      if (g.ingest) ++n_in_place;
+      if (g.in_place) ++n_in_place;
     }
     bg.total_faces = faces_seen;
     // the universal corner tables of the group's meshes, right behind the build: on the host by the time dmi_built_meshes_prepare walks them

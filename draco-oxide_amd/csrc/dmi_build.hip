@@ -15,6 +15,8 @@
 // table whose slots hold a ROW INDEX: inserting row p either claims an empty slot, or meets a slot whose row compares equal — then the slot
 // keeps the smaller of the two indices (atomicMin) — or probes on.  Whatever the interleaving, a slot ends up holding the smallest index of
 // its class, so the result does not depend on scheduling.  Ranks are exclusive scans; compactions are scatters at scanned offsets.
+// Rows are read where the upload left them: tightly packed (the host packed them) or with their accessor's stride (the caller's buffer came up as
+// it is: dmi_build.cpp "in place").
 // Covered class: every attribute of a mesh has the same point count, rows of 1–4 four-byte components, faces index existing points, at least
 // one face survives.  Anything else is FLAGGED and the host builder (host_mesh.cpp) takes that mesh — nothing is approximated here.
 #include "dmi_device.hpp"
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(kBlock) void k_mb_value_insert(const MbArgs a) {
     uint32_t raw[4] = {0u, 0u, 0u, 0u}, w[4] = {0u, 0u, 0u, 0u};
     bool nan = false;
     for (uint32_t k = 0; k < it.words; ++k) {
-      raw[k] = rows[(size_t)p * it.words + k];
+      raw[k] = rows[(size_t)p * it.stride + k];
       nan = nan || (fl && is_nan_bits(raw[k]));
     }
     const bool cn = fl && !nan;   // compare canonical words (-0.0 == 0.0); a NaN row: its bits as they are
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(kBlock) void k_mb_value_insert(const MbArgs a) {
         if (s == kNoneD) break;
       }
       bool same = true;   // (s may be lowered meanwhile by another member of ITS class: every index a slot ever holds is of one class)
-      for (uint32_t k = 0; k < it.words; ++k) same = same && canon(rows[(size_t)s * it.words + k], cn) == w[k];
+      for (uint32_t k = 0; k < it.words; ++k) same = same && canon(rows[(size_t)s * it.stride + k], cn) == w[k];
       if (same) { if (p < s) atomicMin(&tab[h], p); break; }
       h = (h + 1) & it.tab_mask;
     }
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(kBlock) void k_mb_attributes_out(const MbArgs a) {
     // the same index as a VALUE id of this attribute
     if (p < o.n_first && a.vused[ap + 1] != a.vused[ap]) {
       const uint32_t r = a.vused[ap] - a.vused[it.ap_off];
-      const uint32_t* __restrict__ src = a.raw_values + it.row_off + (size_t)a.vfirst[ap] * it.words;
+      const uint32_t* __restrict__ src = a.raw_values + it.row_off + (size_t)a.vfirst[ap] * it.stride;
       uint32_t* __restrict__ dst = a.arena_b + o.val_off + (size_t)r * it.words;
       for (uint32_t k = 0; k < it.words; ++k) dst[k] = src[k];
     }
@@ -334,60 +336,8 @@ __global__ __launch_bounds__(kBlock) void k_mb_widen(const MbWiden* __restrict__
   }
 }
 
-// Rows and indices out of page-locked host memory (dmi_hostmem.cpp).  A read over PCIe wants wide requests: measured (scripts/experiments/pcie_probe.hip)
-// 16 bytes per lane = 1 KB per wavefront load reaches the link's 55 GB/s, 4 bytes per lane a quarter of it.  So a tightly packed array — accessor rows
-// without a stride, every index array — is cut at the 16-byte boundaries of its SOURCE address: unit 0 is the head before the first boundary (element by
-// element), every other unit one aligned 16-byte load (4 words, or 8 / 16 narrow indices widened on the way; the last one element by element when it
-// is short).  Rows with a byteStride go word by word (unit = one output word).
-typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void ingest_elements(const MbIngest& it, uint32_t* __restrict__ dst, uint64_t b0, uint64_t b1) {   // source bytes [b0, b1)
-  if (it.elem_bytes == 4) for (uint64_t b = b0; b < b1; b += 4) dst[it.dst_word + (b >> 2)] = *reinterpret_cast<const uint32_t*>(it.src + b);
-  else if (it.elem_bytes == 2) for (uint64_t b = b0; b < b1; b += 2) dst[it.dst_word + (b >> 1)] = *reinterpret_cast<const uint16_t*>(it.src + b);
-  else for (uint64_t b = b0; b < b1; ++b) dst[it.dst_word + b] = *reinterpret_cast<const uint8_t*>(it.src + b);
-}
-__global__ __launch_bounds__(kBlock) void k_mb_ingest(const MbIngest* __restrict__ items, uint32_t n_items, uint64_t total, uint32_t* __restrict__ dst) {
-  const uint64_t T = (uint64_t)gridDim.x * kBlock;
-  for (uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x; g < total; g += T) {
-    uint32_t lo = 0, hi = n_items;
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (items[mid].off <= g) lo = mid; else hi = mid; }
-    const MbIngest it = items[lo];
-    const uint64_t u = g - it.off;
-    if (it.stride_bytes) {   // strided rows: one output word
-      const uint32_t k = (uint32_t)u, r = k / it.row_words, c = k - r * it.row_words;
-      dst[it.dst_word + k] = *(reinterpret_cast<const uint32_t*>(it.src + (uint64_t)r * it.stride_bytes) + c);
-      continue;
-    }
-    const uint64_t bytes = (uint64_t)it.n_words * it.elem_bytes;
-    const uint64_t head = min(bytes, (uint64_t)((16u - (uint32_t)(it.src & 15u)) & 15u));
-    if (u == 0) { ingest_elements(it, dst, 0, head); continue; }
-    const uint64_t b = head + 16ull * (u - 1);
-    if (b + 16 > bytes) { ingest_elements(it, dst, b, bytes); continue; }
-    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(it.src + b));
-    if (it.elem_bytes == 4) {
-      *reinterpret_cast<u32x4_a4*>(dst + it.dst_word + (b >> 2)) = u32x4_a4{v.x, v.y, v.z, v.w};
-    } else if (it.elem_bytes == 2) {
-      uint32_t* o = dst + it.dst_word + (b >> 1);
-      *reinterpret_cast<u32x4_a4*>(o) = u32x4_a4{v.x & 0xFFFFu, v.x >> 16, v.y & 0xFFFFu, v.y >> 16};
-      *reinterpret_cast<u32x4_a4*>(o + 4) = u32x4_a4{v.z & 0xFFFFu, v.z >> 16, v.w & 0xFFFFu, v.w >> 16};
-    } else {
-      uint32_t* o = dst + it.dst_word + b;
-      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x4_a4*>(o + 4 * q) = u32x4_a4{w[q] & 0xFFu, (w[q] >> 8) & 0xFFu, (w[q] >> 16) & 0xFFu, w[q] >> 24};
-    }
-  }
-}
-
 }  // namespace
 
-void launch_mesh_ingest(const MbIngest* items_dev, uint32_t n_items, uint64_t total_units, uint32_t* dst, hipStream_t s) {
-  if (!n_items || !total_units) return;
-  const uint64_t want = (total_units + kBlock - 1) / kBlock;
-  // (one block per CU: a link-bound kernel needs few waves — any grid from 256 blocks up reads at the link's rate —, and a grid that fills every wave slot
-  // of the chip keeps the kernels of the other stages' streams waiting: the relabelling of a prepare took 10 ms instead of 3.5 beside such a launch)
-  hipLaunchKernelGGL(k_mb_ingest, (uint32_t)std::min<uint64_t>(want, 256), kBlock, 0, s, items_dev, n_items, total_units, dst);
-}
 hipError_t mesh_build_clear(const MbArgs& a, size_t vtab_words, size_t ptab_words, hipStream_t s) {
   hipError_t e;
   if ((e = hipMemsetAsync(a.vtab, 0xFF, vtab_words * 4, s)) != hipSuccess) return e;

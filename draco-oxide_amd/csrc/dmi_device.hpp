@@ -330,7 +330,7 @@ constexpr uint32_t kMbMaxAtts = 8;
 enum MbFlag : uint32_t { MB_BAD_INDEX = 1 /* a face index ≥ the point count */, MB_EMPTY = 2 /* no face survives: builder.rs:129 skips the point removal */,
                          MB_CROWDED = 4 /* a hash probe sequence ran past kMaxProbes (rows crafted to collide): the host builder takes the mesh */ };
 struct MbMesh { uint32_t index, n_items, item0, P, F, face_off, point_off, ptab_off, ptab_mask, pad0, pad1, pad2; };
-struct MbItem { uint32_t mesh, P, words, is_float, row_off /* words into raw_values */, ap_off, tab_off, tab_mask; };
+struct MbItem { uint32_t mesh, P, words, is_float, row_off /* words into raw_values */, ap_off, tab_off, tab_mask, stride /* words between rows (= words when packed) */, pad; };
 struct MbMeshOut { uint32_t flags, nv /* largest referenced point + 1 */, F_out, P_out, face_out_off /* faces before this mesh's in arena A */, classes, pad0, pad1; };
 struct MbItemOut { uint32_t n_first /* values after Attribute::from */, n_out /* values left at the end */, has_map, map_off /* words into arena A */, val_off /* words into arena B */, pad0, pad1, pad2; };
 struct MbWiden { uint32_t off /* Σ elements of the items before */, bytes /* 1 or 2 */, dst_off /* words */, pad; uint64_t src_byte_off; };
@@ -345,17 +345,6 @@ struct MbArgs {
   MbMeshOut* mesh_out; MbItemOut* item_out; uint32_t* totals /* [0] arena A words, [1] arena B words, [2] face words */;
   uint32_t *arena_a, *arena_b;
 };
-// Ingest (round 5): accessors / index arrays gathered out of page-locked HOST memory by a kernel (one launch per group) instead of packed into
-// staging by host threads and copied up.  An item is one array of n_words output words written at dst_word of the upload region: accessor rows
-// (elem_bytes 4; stride_bytes 0 = tightly packed, else rows of row_words words that far apart) or indices (elem_bytes 1 / 2 / 4, widened to u32).
-// off = Σ units of the items before (dmi_build.hip k_mb_ingest: a tight array's units are 16-byte pieces of its source, a strided one's its words).
-struct MbIngest { uint64_t src /* device-visible address of the first element */, off; uint32_t n_words, dst_word, row_words, stride_bytes, elem_bytes, pad; };
-inline uint64_t mb_ingest_units(const MbIngest& it) {
-  if (it.stride_bytes) return it.n_words;
-  const uint64_t bytes = (uint64_t)it.n_words * it.elem_bytes, head = std::min<uint64_t>(bytes, (16u - (uint32_t)(it.src & 15u)) & 15u);
-  return 1 + (bytes - head + 15) / 16;
-}
-void launch_mesh_ingest(const MbIngest* items_dev, uint32_t n_items, uint64_t total_units, uint32_t* dst, hipStream_t s);
 hipError_t mesh_build_clear(const MbArgs& a, size_t vtab_words, size_t ptab_words, hipStream_t s);
 void launch_mesh_build(const MbArgs& a, hipStream_t s);
 void launch_widen_indices(const MbWiden* items_dev, uint32_t n_items, uint32_t total, const uint8_t* src, uint32_t* dst, hipStream_t s);

@@ -4,9 +4,9 @@
 // attributes whose parent is the position), compress_scene (io/gltf/encode.rs:932-955: encode::encode per primitive) and write_scene
 // (io/gltf/encode.rs:958-1097,362-400: blob appended to the BIN chunk and zero-padded to 4 bytes with the pad inside the bufferView, placeholder
 // accessors, the extension's attribute ids, GLB container with a space-padded JSON chunk) — for ALL files of the list at once:
-//   caller's thread   container + JSON parse, primitives planned, accessor descriptors made (bounds-checked views of the caller's bytes, which are
-//                     page-locked for the call so that the device reads them in place: dmi_hostmem.cpp), pushed into a dmi_transcoder per device
-//                     (the least loaded one takes the next primitive)
+//   caller's thread   container + JSON parse, primitives planned, accessor descriptors made (bounds-checked views of the caller's bytes — copied up
+//                     where they lie when the caller read its files into dmi_host_alloc memory, packed by host threads otherwise: dmi_hostmem.cpp),
+//                     pushed into a dmi_transcoder per device (the least loaded one takes the next primitive)
 //   library threads   per device: build ∥ prepare ∥ encode of consecutive stages (dmi_transcode.cpp)
 //   assembly threads  a file is written — JSON patched and serialised, BIN chunk laid out, blobs copied in — as soon as its last primitive is final,
 //                     into a recycled output arena
@@ -189,7 +189,6 @@ struct dmi_transcoded {
   std::vector<std::unique_ptr<PerDevice>> devs;
   Arena arena;
   dmi_transcode_stats stats{};
-  std::vector<const void*> locked;     // input buffers this call page-locked
   // assembly
   std::mutex q_mutex;
   std::condition_variable q_cv;
@@ -203,7 +202,6 @@ struct dmi_transcoded {
   void enqueue(uint32_t asset) { { std::lock_guard<std::mutex> lock(q_mutex); ready.push_back(asset); } q_cv.notify_one(); }
   ~dmi_transcoded() {
     for (auto& d : devs) if (d->t) dmi_transcoder_destroy(d->t);
-    for (const void* p : locked) (void)dmi_host_unregister(p);
   }
 };
 
@@ -432,6 +430,10 @@ int assemble(dmi_transcoded& R, Asset& a) {
     for (auto& s : spans) a.blobs.emplace_back((size_t)(bin0 - o) + s.first, s.second);
   }
   a.out = o; a.out_bytes = total;
+  // the document, the descriptors and the converted arrays have done their work: released here, on this (assembly) thread, not when the caller drops the result
+  a.doc = Value();
+  a.prims.clear(); a.prims.shrink_to_fit();
+  a.accessors.clear(); a.owned.clear();
   return DMI_OK;
 }
 
@@ -467,6 +469,7 @@ void on_done(void* user, uint32_t first, uint32_t count) {
 extern "C" {
 
 int dmi_transcode_assets(const dmi_gltf_asset* assets, uint32_t n, const dmi_config* cfg, const int32_t* devices, uint32_t n_devices, uint32_t flags, dmi_transcoded** out) {
+  (void)flags;
   if (!out || (!assets && n)) return host_fail(DMI_ERR_INVALID_ARGUMENT, "null");
   *out = nullptr;
   const double t_start = now_ms();
@@ -497,7 +500,7 @@ int dmi_transcode_assets(const dmi_gltf_asset* assets, uint32_t n, const dmi_con
 
   R->assets.reserve(n);
   int rc = DMI_OK;
-  double ms_parse = 0, ms_register = 0;
+  double ms_parse = 0;
   std::vector<dmi_raw_mesh> raws;
   for (uint32_t i = 0; i < n && !rc; ++i) {
     const double t0 = now_ms();
@@ -520,9 +523,7 @@ int dmi_transcode_assets(const dmi_gltf_asset* assets, uint32_t n, const dmi_con
     if (rc) break;
     const double t1 = now_ms();
     ms_parse += t1 - t0;
-    if (!(flags & DMI_TRANSCODE_NO_REGISTER) && !a.prims.empty())
-      for (const Span& b : a.buffers) if (b.n >= 4096 && !dmi_host_is_registered(b.p, b.n) && dmi_host_register(b.p, b.n) == DMI_OK) R->locked.push_back(b.p);
-    ms_register += now_ms() - t1;
+    for (const Span& b : a.buffers) if (b.n && dmi_host_is_registered(b.p, b.n)) ++R->stats.buffers_in_place;
     a.left.store((uint32_t)a.prims.size());
     if (a.prims.empty()) { R->enqueue(i); continue; }   // (a file without a compressible primitive)
     for (size_t k = 0; k < a.prims.size() && !rc; ++k) {
@@ -553,14 +554,12 @@ int dmi_transcode_assets(const dmi_gltf_asset* assets, uint32_t n, const dmi_con
   assemblers.clear();
   if (!rc) { std::lock_guard<std::mutex> lock(R->err_mutex); if (R->rc) { rc = R->rc; first_err = R->err; } }
   if (rc) return host_fail(rc, first_err);
-  // the blobs are in the files now: the transcoders' buffers and the page locks can go
+  // the blobs are in the files now: the transcoders' buffers can go
   for (auto& d : R->devs) { dmi_transcoder_destroy(d->t); d->t = nullptr; }
-  for (const void* p : R->locked) (void)dmi_host_unregister(p);
-  R->locked.clear();
   for (const auto& a : R->assets) R->stats.bytes_out += a->out_bytes;
   R->stats.bytes_in = in_bytes;
   R->stats.files = n;
-  R->stats.parse_ms = ms_parse; R->stats.register_ms = ms_register;
+  R->stats.parse_ms = ms_parse;
   R->stats.pushed_ms = t_pushed - t_start; R->stats.finished_ms = t_finished - t_start;
   R->stats.assemble_ms = (double)R->assemble_ns.load() * 1e-6;
   R->stats.call_ms = now_ms() - t_start;
@@ -583,6 +582,23 @@ int dmi_transcoded_blobs(const dmi_transcoded* r, uint32_t i, uint64_t* offsets,
   const Asset& a = *r->assets[i];
   for (size_t k = 0; k < a.blobs.size(); ++k) { if (offsets) offsets[k] = a.blobs[k].first; if (sizes) sizes[k] = a.blobs[k].second; }
   return DMI_OK;
+}
+
+// every file and every blob of the result in two arrays (a caller in an interpreted language pays per call)
+int dmi_transcoded_table(const dmi_transcoded* r, uint64_t* file_address, uint64_t* file_bytes, uint32_t* file_blobs, uint64_t* blob_offsets, uint64_t* blob_sizes, uint64_t blob_capacity) {
+  if (!r) return host_fail(DMI_ERR_INVALID_ARGUMENT, "null");
+  uint64_t at = 0;
+  for (size_t i = 0; i < r->assets.size(); ++i) {
+    const Asset& a = *r->assets[i];
+    if (file_address) file_address[i] = (uint64_t)(uintptr_t)a.out;
+    if (file_bytes) file_bytes[i] = a.out_bytes;
+    if (file_blobs) file_blobs[i] = (uint32_t)a.blobs.size();
+    for (const auto& b : a.blobs) {
+      if (at < blob_capacity) { if (blob_offsets) blob_offsets[at] = b.first; if (blob_sizes) blob_sizes[at] = b.second; }
+      ++at;
+    }
+  }
+  return at > blob_capacity && (blob_offsets || blob_sizes) ? host_fail(DMI_ERR_INVALID_ARGUMENT, "blob table too small") : DMI_OK;
 }
 
 int dmi_transcoded_stats(const dmi_transcoded* r, dmi_transcode_stats* s) {

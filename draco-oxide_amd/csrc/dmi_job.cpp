@@ -190,8 +190,11 @@ int dmi_device_count(void) {
 
 // What the library keeps between calls so that the next one does not pay for it again: released device chunks (hipMalloc / hipFree
 // serialise), idle pinned staging buffers, and the large host arrays of the connectivity stage (dmi_host.hpp).  Live jobs are untouched.
+extern "C++" { namespace dmi { void gltf_pool_drop_all(); void host_blocks_drop_parked(); } }   // dmi_gltf.cpp (output arena blocks), dmi_hostmem.cpp (parked dmi_host_alloc blocks)
 void dmi_release_cached_memory(void) {
   host_pool_drop_all();
+  gltf_pool_drop_all();
+  host_blocks_drop_parked();
   g_chunk_cache.drop_all();
   std::lock_guard<std::mutex> lock(g_stage_mutex);
   for (HostStage* st : g_stages) if (!st->in_use && st->p) stage_free(st);

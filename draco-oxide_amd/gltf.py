@@ -28,7 +28,7 @@ import numpy as np
 
 import threading
 
-from .binding import (DracoMiError, host_register, host_unregister, jobs_encode_raw, transcode_assets, ATT_CUSTOM, ATT_NORMAL, ATT_POSITION, ATT_TEXCOORD, DOMAIN_CORNER, DOMAIN_POSITION, Config, MeshBuilder, RawMesh, built_meshes_prepare, device_count,
+from .binding import (DracoMiError, jobs_encode_raw, transcode_assets, ATT_CUSTOM, ATT_NORMAL, ATT_POSITION, ATT_TEXCOORD, DOMAIN_CORNER, DOMAIN_POSITION, Config, MeshBuilder, RawMesh, built_meshes_prepare, device_count,
                       jobs_encode, jobs_encode_devices, last_build_timings, meshes_build, meshes_prepare, meshes_prepare_devices, shard_meshes, thread_host_threads)
 
 _COMPONENTS = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4}
@@ -685,12 +685,12 @@ def _transcode_files(sources, cfg, devices, group, device, pipeline, timings):
         n_dev = max(1, min(n_dev, device_count()))
         base = cfg.device if cfg is not None else 0
         try:
-            out, st = transcode_assets(_native_assets(sources), cfg, devices=list(range(n_dev)) if n_dev > 1 else [base], register=os.environ.get("DMI_NO_REGISTER", "0") == "0")
+            out, st = transcode_assets(_native_assets(sources), cfg, devices=list(range(n_dev)) if n_dev > 1 else [base])
         except DracoMiError as e:
             if "gltf:" in str(e):
                 raise ValueError(str(e)) from None
             raise
-        tm.update({"parse_s": st["parse_ms"] * 1e-3, "register_s": st["register_ms"] * 1e-3, "views_s": 0.0, "build_s": st["build_ms"] * 1e-3, "prepare_s": st["prepare_ms"] * 1e-3,
+        tm.update({"parse_s": st["parse_ms"] * 1e-3, "views_s": 0.0, "build_s": st["build_ms"] * 1e-3, "prepare_s": st["prepare_ms"] * 1e-3,
                    "encode_s": st["encode_ms"] * 1e-3, "assemble_s": st["assemble_ms"] * 1e-3, "primitives_built": st["primitives"], "native": st})
         return out
     docs = [load_document(src) for src in sources]
@@ -741,10 +741,6 @@ def _transcode_files(sources, cfg, devices, group, device, pipeline, timings):
             t.join()
         if errs:
             raise errs[0]
-    elif world == 1 and pipeline and mine and os.environ.get("DMI_TRANSCODE_PYTHON", "0") == "0":
-        # one device, one process: the stage loop runs INSIDE the library (dmi_transcoder: build / prepare / encode threads of its own); this thread
-        # only makes the accessor views and pushes them, the library's callback reassembles a file as soon as its last primitive is coded
-        return _transcode_native(docs, per_file, flat, mine, w_mine, raw_of, built, cfg, tm)
     else:
         # one device: a file is reassembled as soon as its last primitive is coded (a fourth stage beside the device work of the next ones)
         assembled = [None] * len(docs)
@@ -830,93 +826,6 @@ def _share_native(raw_of, w_mine, cfg, tm):
             r = t.result(k)
             out.append(None if r is None else (r[0][0].tobytes() + r[0][1].tobytes(), r[1], r[2]))
         return out
-
-
-def _transcode_native(docs, per_file, flat, mine, w_mine, raw_of, built, cfg, tm):
-    """transcode_files on one device of one process through dmi_transcoder (binding.Transcoder): the primitives are pushed in slices (their accessor
-    views are made right before), stages of them are built / prepared / encoded on library threads, and `done` — called from the library's encode
-    thread — reassembles every file whose last primitive is final.  mine[k] = index into `flat` of this call's k-th primitive (all of them here)."""
-    import time
-    from .binding import Transcoder
-    assembled = [None] * len(docs)
-    left = [len(prims) for prims in per_file]
-    first = [0] * len(docs)
-    for fi in range(1, len(docs)):
-        first[fi] = first[fi - 1] + len(per_file[fi - 1])
-    for key in ("views_s", "assemble_s"):
-        tm[key] = 0.0
-    holder = []
-
-    import queue
-    finished = queue.Queue()                                                  # (first, count) of the stages the library reports; None ends the reassembly thread
-    errs = []
-
-    def reassemble():
-        try:
-            while True:
-                item = finished.get()
-                if item is None:
-                    return
-                ta = time.perf_counter()
-                t = holder[0]
-                for k in range(item[0], item[0] + item[1]):
-                    fi = flat[mine[k]][0]
-                    left[fi] -= 1
-                    if left[fi] == 0:
-                        res = [t.result(q) for q in range(first[fi], first[fi] + len(per_file[fi]))]
-                        assembled[fi] = _assemble(docs[fi][0], docs[fi][1], per_file[fi], res)
-                tm["assemble_s"] += time.perf_counter() - ta
-        except BaseException as e:                                        # noqa: BLE001 — re-raised on the caller's thread
-            errs.append(e)
-
-    def done(first_k, count):                                                 # (the library's encode thread: hands the stage on and goes back to encoding)
-        finished.put((first_k, count))
-
-    n = len(mine)
-    # the files' bytes are page-locked for the duration of the call: the device gathers accessor rows and indices out of them where they lie
-    # (dmi_host_register; DMI_NO_INGEST=1 or a refused range: the library packs and copies as before)
-    locked = []
-    if os.environ.get("DMI_NO_REGISTER", "0") == "0":
-        t0 = time.perf_counter()
-        for _, buffers in docs:
-            for b in buffers:
-                if len(b) >= 4096 and host_register(b):
-                    locked.append(b)
-        tm["register_s"] = time.perf_counter() - t0
-    worker = None
-    try:
-        with Transcoder(cfg, sum(w_mine), n, on_done=done, stage_triangles=PIPELINE_TRIANGLES) as t:
-            holder.append(t)
-            worker = threading.Thread(target=reassemble, daemon=True)
-            worker.start()
-            try:   # (whatever the pushes do — a truncated accessor, an earlier stage's error —, the reassembly thread is told to stop and joined BEFORE the transcoder frees what it reads)
-                slice_tris = max(1, sum(w_mine) // 64)                            # (a push per ≈ 1/64 of the triangles: the library starts its first stage early)
-                lo = 0
-                while lo < n:
-                    t0 = time.perf_counter()
-                    hi, acc = lo, 0
-                    while hi < n and (hi == lo or acc + w_mine[hi] <= slice_tris):
-                        acc += w_mine[hi]
-                        hi += 1
-                    raws = [raw_of(k) for k in range(lo, hi)]
-                    tm["views_s"] += time.perf_counter() - t0
-                    t.push(raws)
-                    lo = hi
-                t.finish()
-            finally:
-                finished.put(None)
-                worker.join()
-            if errs:
-                raise errs[0]
-            tm.update(t.timings())
-            for fi in range(len(docs)):
-                if assembled[fi] is None:   # (a file without a compressible primitive)
-                    assembled[fi] = _assemble(docs[fi][0], docs[fi][1], per_file[fi], [])
-    finally:
-        for b in locked:
-            host_unregister(b)
-    tm["primitives_built"] = built[0]
-    return assembled
 
 
 def transcode_glb(data, cfg=None):

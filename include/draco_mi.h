@@ -237,17 +237,15 @@ void dmi_built_mesh_free(dmi_built_mesh* m);
 
 /* --- Host memory the device may read in place (round 5) ----------------------------------------------------------------------------------
  * The reference reads an asset into a Vec<u8> (io/gltf/transcoder.rs:134-151 → read_scene_from_file / _from_buffer) and copies every accessor
- * out of it (io/gltf/decode.rs:2277-2309) before MeshBuilder sees a value.  Here the importer page-locks the bytes it read — dmi_host_register on
- * a buffer it owns (refcounted per exact range; a range that partly overlaps a registered one is refused), or dmi_host_alloc for the buffer it
- * reads the file INTO — and dmi_meshes_build / dmi_transcoder then gather accessor rows (whatever their byteStride) and index arrays (u8 / u16
- * widened) straight out of it with one kernel per group: no host pack, no staging copy, no separate upload.  Arrays outside such memory take
- * the packed path as before — same result either way.  The buffer must stay registered (and unchanged) until the primitives that point
- * into it are built.  Page-locking fresh pageable memory costs ≈ 40 ms per GiB once; a kernel reads it at ≈ 55 GB/s. */
-int dmi_host_register(const void* p, size_t bytes);
-int dmi_host_unregister(const void* p);
-void* dmi_host_alloc(size_t bytes);       /* page-locked (huge pages from 2 MiB), registered; NULL on failure */
+ * out of it (io/gltf/decode.rs:2277-2309) before MeshBuilder sees a value.  Here the importer reads the file INTO memory from dmi_host_alloc —
+ * page-locked blocks on huge pages, registered with the runtime once and recycled (dmi_host_free parks a block; dmi_release_cached_memory hands
+ * the parked ones back) — and dmi_meshes_build / dmi_transcoder / dmi_transcode_assets copy the accessors' bytes up where they lie: the arrays'
+ * ranges merged into spans (about one DMA per file), rows read with their byteStride, index arrays (u8 / u16 widened) gathered on the device.
+ * No host pack, no staging copy.  Arrays in any other memory are packed into staging by host threads as before — same result either way.
+ * (Page-locking the CALLER's own buffers per call was tried and withdrawn: see csrc/dmi_hostmem.cpp.) */
+void* dmi_host_alloc(size_t bytes);       /* NULL on failure; contents unspecified */
 void dmi_host_free(void* p);
-int dmi_host_is_registered(const void* p, size_t bytes);   /* 1: [p, p + bytes) lies inside memory the device reads in place */
+int dmi_host_is_registered(const void* p, size_t bytes);   /* 1: [p, p + bytes) lies inside a block dmi_host_alloc handed out */
 
 /* --- MeshBuilder::build for a BATCH of primitives, on the device ---------------------------------------------------------
  * What the glTF importer does once per triangle primitive (io/gltf/decode.rs:2328-2525: accessors → MeshBuilder::add_attribute →
@@ -315,8 +313,8 @@ void dmi_transcoder_destroy(dmi_transcoder* t);
  * appended to the BIN chunk, zero-padded to 4 bytes (the bufferView's byteLength includes the pad), placeholder accessors, the extension's
  * attribute ids in add order, every other bufferView carried over, JSON chunk space-padded.  The primitives of ALL assets go through the device
  * together: one dmi_transcoder per entry of `devices` (NULL / 0: cfg->device), the least loaded one takes the next primitive; files are written
- * by library threads as their last primitive becomes final, into memory the result owns.  The inputs' buffers are page-locked for the call so
- * that the device reads the accessors in place (DMI_TRANSCODE_NO_REGISTER: not; buffers the caller registered itself cost nothing here).
+ * by library threads as their last primitive becomes final, into memory the result owns.  Inputs that lie in dmi_host_alloc memory go up without
+ * a host pack (above).  `flags`: 0.
  * JSON byte equality with the reference is not part of the bit-exact contract; the embedded blobs are. */
 typedef struct dmi_span { const uint8_t* data; size_t bytes; } dmi_span;
 typedef struct dmi_gltf_asset {
@@ -325,10 +323,10 @@ typedef struct dmi_gltf_asset {
   const dmi_span* buffers; uint32_t n_buffers;   /* the bytes of its buffers, in `buffers` order */
 } dmi_gltf_asset;
 typedef struct dmi_transcode_stats {
-  uint32_t files, primitives, devices, pad;
+  uint32_t files, primitives, devices;
+  uint32_t buffers_in_place;   /* input buffers that lie in dmi_host_alloc memory (their accessors go up without a host pack) */
   uint64_t triangles_in, bytes_in, bytes_out;
   double parse_ms;      /* caller's thread: containers, JSON, primitive plans, accessor descriptors */
-  double register_ms;   /* caller's thread: page-locking the inputs' buffers */
   double pushed_ms;     /* since the start of the call: the last primitive handed to a transcoder */
   double finished_ms;   /* since the start of the call: the last stage of the last device coded */
   double build_ms, prepare_ms, encode_ms;   /* time inside the three stage calls, summed over stages and devices (they overlap) */
@@ -336,12 +334,14 @@ typedef struct dmi_transcode_stats {
   double call_ms;
 } dmi_transcode_stats;
 typedef struct dmi_transcoded dmi_transcoded;
-#define DMI_TRANSCODE_NO_REGISTER 1u
 int dmi_transcode_assets(const dmi_gltf_asset* assets, uint32_t n, const dmi_config* cfg, const int32_t* devices, uint32_t n_devices, uint32_t flags, dmi_transcoded** out);
 /* file i of the result: its GLB bytes (the result's memory, valid until dmi_transcoded_free) and how many primitives were compressed;
  * dmi_transcoded_blobs: where their blobs lie in the file (offset, size without the pad), in primitive order */
 int dmi_transcoded_file(const dmi_transcoded* r, uint32_t i, const uint8_t** glb, size_t* bytes, uint32_t* n_blobs);
 int dmi_transcoded_blobs(const dmi_transcoded* r, uint32_t i, uint64_t* offsets, uint64_t* sizes);
+/* the same for ALL files in one call: per file its address, size and blob count (arrays of stats.files entries); the blobs' (offset, size) pairs
+ * back to back in file order (stats.primitives entries at most: blob_capacity = room in the two arrays) */
+int dmi_transcoded_table(const dmi_transcoded* r, uint64_t* file_address, uint64_t* file_bytes, uint32_t* file_blobs, uint64_t* blob_offsets, uint64_t* blob_sizes, uint64_t blob_capacity);
 int dmi_transcoded_stats(const dmi_transcoded* r, dmi_transcode_stats* s);
 void dmi_transcoded_free(dmi_transcoded* r);
 /* The JSON layer of the above on its own (host only, for tests): parse `text`, write it back compactly — members in document order, number tokens

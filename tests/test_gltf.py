@@ -242,6 +242,33 @@ def test_full_size_files_through_the_transcoder_against_the_oracle(seams):
         assert payload[: len(want)] == want and len(payload) - len(want) < 4
 
 
+@pytest.mark.gpu
+def test_one_process_several_devices_gives_the_one_device_files():
+    """dmi_transcode_assets with a device LIST: one dmi_transcoder per entry, the least loaded one takes the next primitive, the files are written by
+    the same library threads — no second interpreter, no gather.  devices=[0, 0] (two transcoders on the one GPU of the test box) must give the files
+    of devices=[0], and a damaged asset must fail the call with the library's message, nothing left running."""
+    from draco_oxide_amd import binding, synth
+    glbs, total = synth.batch_glbs(40, lo=800, hi=60000, seed=31)
+    rng = np.random.default_rng(4)
+    files = [[_prim(int(rng.integers(6, 30)), seed=3000 + 8 * f + k, open_boundary=bool((f + k) % 4 == 0), index_type="u16" if k % 2 else "u32") for k in range(5)] for f in range(6)]
+    sources = glbs + [gltf.write_glb(*_make_asset(prims, interleave=bool(i % 2))) for i, prims in enumerate(files)]
+    one, st1 = binding.transcode_assets(sources, devices=[0])
+    two, st2 = binding.transcode_assets(sources, devices=[0, 0])
+    assert st1["devices"] == 1 and st2["devices"] == 2 and st1["primitives"] == st2["primitives"] == 40 + 30
+    assert [bytes(g) for g, _ in one] == [bytes(g) for g, _ in two]
+    assert [[bytes(b) for b in bl] for _, bl in one] == [[bytes(b) for b in bl] for _, bl in two]
+    assert bytes(two[41][1][2]) == _oracle_blob(files[1][2])
+    broken = bytearray(sources[3])
+    broken[40:60] = b"x" * 20                                        # inside the JSON chunk
+    with pytest.raises(dmi.DracoMiError, match="gltf"):
+        binding.transcode_assets(sources[:3] + [bytes(broken)] + sources[4:], devices=[0, 0])
+    truncated = sources[5][: len(sources[5]) - 4096]               # the BIN chunk cut short: an accessor reaches past its buffer
+    with pytest.raises(dmi.DracoMiError):
+        binding.transcode_assets([sources[0], truncated], devices=[0])
+    again, _ = binding.transcode_assets(sources[:4], devices=[0])   # the library is in working order after the failures
+    assert bytes(again[2][0]) == bytes(one[2][0])
+
+
 def test_primitive_the_reference_cannot_encode_is_refused():
     doc, buf = _make_asset([_prim(6, 1)])
     prim = doc["meshes"][0]["primitives"][0]

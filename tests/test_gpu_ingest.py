@@ -1,6 +1,6 @@
-"""Accessors read where they lie (round 5; dmi_host_register / dmi_host_alloc + dmi_build.hip k_mb_ingest): a primitive whose arrays sit in page-locked
-host memory is gathered by the device (rows de-strided, u8 / u16 indices widened) instead of packed into staging and copied — the built mesh is the
-host builder's either way."""
+"""Accessors copied up where they lie (round 5; dmi_host_alloc + dmi_build.cpp "in place"): a primitive whose arrays sit in page-locked memory of the
+library's goes up by DMA as it is (rows keep their stride, u8 / u16 indices are widened on the device) instead of being packed into staging by host
+threads — the built mesh is the host builder's either way."""
 import numpy as np
 import pytest
 
@@ -76,22 +76,25 @@ def test_rows_and_indices_gathered_out_of_page_locked_memory():
         hb.free()
 
 
-def test_register_caller_bytes_and_unregister(monkeypatch):
-    glb, _ = synth.torus_glb(60, seed=3)
-    assert binding.host_register(glb) and binding.load_library().dmi_host_is_registered(binding._address_of(glb)[0] + 100, 1000) == 1
-    assert binding.host_register(glb)                                   # the same range again: counted
-    binding.host_unregister(glb)
-    assert binding.load_library().dmi_host_is_registered(binding._address_of(glb)[0] + 100, 1000) == 1
-    binding.host_unregister(glb)
-    assert binding.load_library().dmi_host_is_registered(binding._address_of(glb)[0] + 100, 1000) == 0
-    # a transcode registers the files' bytes itself; with registration off (or the ingest kernel off) the files are the same
+def test_files_read_into_library_memory_transcode_to_the_same_files(monkeypatch):
+    """An importer that reads its files into dmi_host_alloc memory (binding.HostBuffer): the transcode copies their accessors up in place
+    (stats: every buffer in place), and the output files are those of the same bytes in ordinary memory, packed and copied."""
     glbs, _ = synth.batch_glbs(24, lo=500, hi=30000, seed=77)
-    tm = {}
-    a = gltf.transcode_files(glbs, timings=tm)
-    monkeypatch.setenv("DMI_NO_REGISTER", "1")
-    b = gltf.transcode_files(glbs)
-    monkeypatch.delenv("DMI_NO_REGISTER")
-    monkeypatch.setenv("DMI_NO_INGEST", "1")
-    c = gltf.transcode_files(glbs)
-    assert [bytes(g) for g, _ in a] == [bytes(g) for g, _ in b] == [bytes(g) for g, _ in c]
-    assert binding.load_library().dmi_host_is_registered(binding._address_of(glbs[0])[0] + 64, 16) == 0
+    plain, st0 = binding.transcode_assets(glbs)
+    assert st0["buffers_in_place"] == 0
+    held = [binding.HostBuffer.holding(g) for g in glbs]
+    try:
+        assert binding.load_library().dmi_host_is_registered(held[0].array.ctypes.data + 64, 16) == 1
+        placed, st1 = binding.transcode_assets([h.view() for h in held])
+        assert st1["buffers_in_place"] == 24 and st1["primitives"] == 24
+        assert [bytes(g) for g, _ in placed] == [bytes(g) for g, _ in plain]
+        monkeypatch.setenv("DMI_NO_INGEST", "1")                      # (A/B switch: pack even what could go up in place)
+        packed, _ = binding.transcode_assets([h.view() for h in held])
+        assert [bytes(g) for g, _ in packed] == [bytes(g) for g, _ in plain]
+    finally:
+        addr = held[0].array.ctypes.data
+        for h in held:
+            h.free()
+    assert binding.load_library().dmi_host_is_registered(addr + 64, 16) == 0      # parked blocks are not "in place"
+    again = binding.HostBuffer(len(glbs[0]))                       # … and are handed out again
+    again.free()
