@@ -98,6 +98,7 @@ class _GltfAsset(C.Structure):
 
 class _TranscodeStats(C.Structure):
     _fields_ = [("files", C.c_uint32), ("primitives", C.c_uint32), ("devices", C.c_uint32), ("buffers_in_place", C.c_uint32),
+                ("primitives_device_built", C.c_uint32), ("primitives_host_built", C.c_uint32), ("primitives_in_place", C.c_uint32), ("pad", C.c_uint32),
                 ("triangles_in", C.c_uint64), ("bytes_in", C.c_uint64), ("bytes_out", C.c_uint64),
                 ("parse_ms", C.c_double), ("pushed_ms", C.c_double), ("finished_ms", C.c_double),
                 ("build_ms", C.c_double), ("prepare_ms", C.c_double), ("encode_ms", C.c_double), ("assemble_ms", C.c_double), ("call_ms", C.c_double)]
@@ -130,7 +131,7 @@ _TRANSCODE_DONE = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32)   # dmi_
 EXPORTS = ["dmi_encode_attributes", "dmi_encode_attributes_batch", "dmi_jobs_encode", "dmi_job_create", "dmi_job_encode", "dmi_job_timings", "dmi_job_destroy", "dmi_encode_mesh",
            "dmi_mesh_prepare", "dmi_meshes_prepare", "dmi_shard_meshes", "dmi_meshes_prepare_devices", "dmi_jobs_encode_devices", "dmi_mesh_build", "dmi_built_mesh_free", "dmi_encode_connectivity", "dmi_conn_free", "dmi_host_rans_stream", "dmi_host_rabs_stream", "dmi_host_rabs_constant_stream", "dmi_tile_sort_slots", "dmi_decode_attributes", "dmi_decoded_free", "dmi_decode_mesh", "dmi_decoded_mesh_free", "dmi_decode_connectivity", "dmi_decoded_conn_free", "dmi_last_decode_timings", "dmi_free", "dmi_free_many", "dmi_strerror", "dmi_last_error", "dmi_device_count", "dmi_release_cached_memory",
            "dmi_init", "dmi_last_call_timings", "dmi_device_corner_table", "dmi_encode_mesh_device", "dmi_meshes_build", "dmi_built_meshes_prepare", "dmi_last_build_timings", "dmi_device_attribute_table", "dmi_built_meshes_info", "dmi_built_meshes_free", "dmi_thread_host_threads", "dmi_usable_host_threads",
-           "dmi_transcoder_create", "dmi_transcoder_reserve", "dmi_transcoder_push", "dmi_transcoder_finish", "dmi_transcoder_result", "dmi_transcoder_timings", "dmi_transcoder_destroy",
+           "dmi_transcoder_create", "dmi_transcoder_reserve", "dmi_transcoder_push", "dmi_transcoder_finish", "dmi_transcoder_result", "dmi_transcoder_timings", "dmi_transcoder_counts", "dmi_transcoder_destroy",
            "dmi_host_alloc", "dmi_host_free", "dmi_host_is_registered",
            "dmi_transcode_assets", "dmi_transcoded_file", "dmi_transcoded_blobs", "dmi_transcoded_stats", "dmi_transcoded_free", "dmi_json_roundtrip", "dmi_transcoded_table"]
 
@@ -478,6 +479,10 @@ class RawMesh:
         r = rows if rows.ndim == 2 else rows.reshape(-1, 1)
         if r.dtype not in _NP_CT or (r.shape[1] > 1 and r.strides[1] != 4):
             raise TypeError("attribute rows must be float32 / uint32 / int32 with contiguous components")
+        # the library reads rows `byte_stride` apart as an unsigned distance: a reversed view (negative stride), a broadcast one (0) or rows that
+        # overlap (stride below the row size) are copied into rows of their own first
+        if r.shape[0] > 1 and not (4 * r.shape[1] <= r.strides[0] < (1 << 31)):
+            r = np.ascontiguousarray(r)
         self.atts.append((r, att_type, domain, np.ascontiguousarray(parents, dtype=np.uint32)))
         return len(self.atts) - 1
 

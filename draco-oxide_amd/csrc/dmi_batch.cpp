@@ -409,29 +409,9 @@ static int jobs_encode_device(dmi_job** jobs, uint32_t n, dmi_buffer* outs, uint
     while (n_first < n && acc * 100 < total * 45) acc += symbols(order[n_first++]);
     if (n_first < 8 || n - n_first < 8) n_first = n;
   }
-  // The chain launch is bounded by its LONGEST stream (one walker steps at ≈ 17 ns: a 300 K-symbol position stream is 4.8 ms while the sum of all
-  // streams over 1024 walkers is 0.5 ms).  Experiment, OFF by default: with DMI_BATCH_TAIL=<percent> the few jobs whose longest
-  // stream is above that share of the batch's longest are taken out of the batch and coded in the hybrid form — their own small launches, symbols
-  // and tables read back, one host core per stream — on host threads WHILE the device walkers code the rest.  Same bytes, but measured on the
-  // 256-mesh batch at 60 %: 28 jobs leave, the chain launch drops from 4.8 to ≈ 3 ms and the call goes from 7.8 to 9.1 ms — 28 single-job encodes
-  // (launches, waits, staging, a thread per stream) cost more than the tail they remove; a batched hybrid form would be needed, and in the
-  // transcode pipeline the host cores are the scarce resource anyway.
-  std::vector<uint32_t> tail;
-  {
-    static const int pct = std::getenv("DMI_BATCH_TAIL") ? std::atoi(std::getenv("DMI_BATCH_TAIL")) : 0;
-    auto longest_of = [&](uint32_t j) { uint64_t m = 0; for (auto& a : jobs[j]->atts) m = std::max<uint64_t>(m, a.n_sym); return m; };
-    uint64_t longest = 0;
-    for (uint32_t j = 0; j < n; ++j) longest = std::max(longest, longest_of(j));
-    const uint64_t cap = std::max<uint64_t>(kHostChainMinSymbols, longest * (uint64_t)std::max(0, pct) / 100);
-    if (pct > 0 && n >= 16 && n_first == n && library_streams) {
-      std::vector<uint32_t> keep;
-      for (uint32_t k = 0; k < n; ++k) {
-        const uint32_t j = order[k];
-        if (jobs[j]->host_chains && longest_of(j) >= cap && tail.size() < 2 * (size_t)n_threads && tail.size() * 4 < n) tail.push_back(j); else keep.push_back(j);
-      }
-      if (tail.size() >= 2) { order.swap(keep); n_first = (uint32_t)order.size(); } else tail.clear();
-    }
-  }
+  // (The chain launch is bounded by its LONGEST stream — one walker steps at ≈ 17 ns: a 300 K-symbol position stream is 4.8 ms while the sum of all
+  // streams over 1024 walkers is 0.5 ms.  Taking the few longest jobs out of the batch and coding them in the hybrid form on host threads was tried
+  // in round 4 — same bytes, 7.8 → 9.1 ms per 256-mesh encode — and removed: scripts/experiments/README.md.)
   DeviceBatch first, second;
   auto fill = [&](DeviceBatch& b, uint32_t lo, uint32_t hi, hipStream_t s) {
     for (uint32_t k = lo; k < hi; ++k) { b.jobs.push_back(jobs[order[k]]); b.outs.push_back(&outs[order[k]]); }
@@ -441,16 +421,6 @@ static int jobs_encode_device(dmi_job** jobs, uint32_t n, dmi_buffer* outs, uint
   fill(first, 0, n_first, main_stream);
   int rc;
   if ((rc = first.begin())) return rc;
-  if (!tail.empty()) {   // the tail on host threads, beside the batch's launches
-    const auto tt0 = std::chrono::steady_clock::now();
-    const int trc = parallel_items((uint32_t)tail.size(), std::min<uint32_t>(n_threads, (uint32_t)tail.size()), device, [&](uint32_t k) { return dmi_job_encode(jobs[tail[k]], &outs[tail[k]]); });
-    const double t_tail = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tt0).count();
-    rc = first.finish();
-    if (trc) return trc;
-    if (rc) return rc;
-    if (trace) { first.trace("batch, device form"); std::fprintf(stderr, "[dmi]   + %zu jobs with the longest streams coded in the hybrid form beside it: %.2f ms\n", tail.size(), t_tail); }
-    return DMI_OK;
-  }
   if (n_first < n) {
     fill(second, n_first, n, side);
     if ((rc = second.begin())) { (void)hipStreamSynchronize(first.s); (void)hipStreamSynchronize(second.s); return rc; }

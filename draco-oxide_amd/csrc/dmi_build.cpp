@@ -68,6 +68,11 @@ bool device_form(const dmi_raw_mesh& m) {
   if (m.index_type != DMI_U8 && m.index_type != DMI_U16 && m.index_type != DMI_U32) return false;
   const uint32_t P = m.atts[0].count;
   if (!P || P >= (1u << 30) || m.num_faces >= (1u << 30)) return false;
+  // (the kernels index a group's hash tables, rows and arenas with 32-bit word offsets: a primitive whose own tables pass 2^31 words — about 300M
+  // points with four attributes — is the host builder's, whatever else is in the call)
+  uint64_t tab_words = 0, row_words = 0;
+  for (uint32_t i = 0; i < m.n_atts; ++i) { tab_words += pow2_at_least(2ull * P); row_words += (uint64_t)P * m.atts[i].num_components + 64; }
+  if (tab_words >= (1ull << 31) || row_words + 3ull * m.num_faces >= (1ull << 31) || (uint64_t)P * m.n_atts >= (1ull << 30)) return false;
   for (uint32_t i = 0; i < m.n_atts; ++i) {
     const dmi_raw_accessor& a = m.atts[i];
     if (a.count != P || component_bytes(a.component_type) != 4 || a.num_components < 1 || a.num_components > 4 || !a.data) return false;
@@ -124,7 +129,7 @@ int build_on_host(const dmi_raw_mesh& m, dmi_built_mesh* out) {
 // One group of primitives on its way through the device
 struct BuildGroup {
   std::vector<uint32_t> which;          // indices into the caller's array
-  uint64_t raw_faces = 0, points = 0, ap = 0;
+  uint64_t raw_faces = 0, points = 0, ap = 0, tab_words = 0, row_words = 0;   // (the last two: what the 32-bit word offsets of the kernels must hold)
   hipStream_t S = nullptr;
   TempDev scratch;
   HostStage* up_stage = nullptr;
@@ -199,7 +204,7 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
   std::vector<std::unique_ptr<BuildGroup>> groups;
   std::vector<uint32_t> host_list;
   const bool no_device = std::getenv("DMI_HOST_BUILD") != nullptr;
-  const bool no_ingest = std::getenv("DMI_NO_INGEST") != nullptr;   // (A/B: pack + copy even where the arrays could be read in place)
+  const bool no_ingest = std::getenv("DMI_NO_IN_PLACE") != nullptr;   // (A/B: pack + copy even what could go up where it lies)
   for (uint32_t j = 0; j < n; ++j) {
     const dmi_raw_mesh& m = raw[j];
     if (no_device || !device_form(m)) { host_list.push_back(j); continue; }
@@ -222,7 +227,10 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
     bool fresh = groups.empty() || large || groups.back()->large || groups.back()->in_place != in_place;
     if (!fresh) {
       const BuildGroup& g = *groups.back();
-      fresh = g.raw_faces + m.num_faces > group_faces || g.ap + ap >= (1ull << 30) || g.which.size() >= 65536;
+      uint64_t tab = 0, rows = 0;
+      for (uint32_t i = 0; i < m.n_atts; ++i) { tab += pow2_at_least(2ull * m.atts[0].count); rows += (uint64_t)m.atts[0].count * m.atts[i].num_components + 64; }
+      fresh = g.raw_faces + m.num_faces > group_faces || g.ap + ap >= (1ull << 30) || g.which.size() >= 65536 ||
+              g.tab_words + tab >= (1ull << 32) || g.row_words + rows + 3ull * (g.raw_faces + m.num_faces) >= (1ull << 32);
     }
     if (fresh) groups.emplace_back(new BuildGroup());
     BuildGroup& g = *groups.back();
@@ -241,6 +249,7 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
     g.which.push_back(j);
     g.meshes.push_back(me);
     g.raw_faces += m.num_faces; g.points += me.P; g.ap += ap;
+    for (uint32_t i = 0; i < m.n_atts; ++i) { g.tab_words += pow2_at_least(2ull * me.P); g.row_words += (uint64_t)me.P * m.atts[i].num_components + 64; }
   }
   double t_pack = 0;
   uint64_t bytes_up = 0, bytes_down = 0;

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(kBlock) void k_mb_value_ids(const MbArgs a) {
 
 // ---- point classes: the tuple of byte classes (builder.rs:254-279 hashes the unique values' bytes at the point; vslot holds, per attribute and
 // point, the smallest row index of the row's byte class — k_mb_value_first) ----
-constexpr int kMaxKey = 8;   // attributes per mesh the device form takes (MB_MAX_ATTS)
+constexpr int kMaxKey = (int)kMbMaxAtts;   // attributes per mesh the device form takes
 __global__ __launch_bounds__(kBlock) void k_mb_point_insert(const MbArgs a) {
   for (uint32_t gp = blockIdx.x * kBlock + threadIdx.x; gp < a.total_points; gp += gridDim.x * kBlock) {
     const MbMesh me = a.meshes[mesh_of_point(a, gp)];

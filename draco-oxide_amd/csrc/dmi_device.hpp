@@ -326,7 +326,7 @@ size_t scan_partials_words(uint32_t n);
 // ---- MeshBuilder::build on the device (dmi_build.hip): value dedup, point merge, degenerate faces, unused points — batched ----
 // M meshes concatenated.  "Item" = one (mesh, attribute); att-point arrays are indexed by ap = item.ap_off + point, point arrays by
 // mesh.point_off + point, face arrays by mesh.face_off + face.  Rows are 1–4 four-byte words.
-constexpr uint32_t kMbMaxAtts = 8;
+constexpr uint32_t kMbMaxAtts = 16;   // (round 5: 8 → 16; a glTF primitive brings POSITION / NORMAL / TEXCOORD_0 and its _FEATURE_ID_n sets)
 enum MbFlag : uint32_t { MB_BAD_INDEX = 1 /* a face index ≥ the point count */, MB_EMPTY = 2 /* no face survives: builder.rs:129 skips the point removal */,
                          MB_CROWDED = 4 /* a hash probe sequence ran past kMaxProbes (rows crafted to collide): the host builder takes the mesh */ };
 struct MbMesh { uint32_t index, n_items, item0, P, F, face_off, point_off, ptab_off, ptab_mask, pad0, pad1, pad2; };

@@ -546,6 +546,9 @@ int dmi_transcode_assets(const dmi_gltf_asset* assets, uint32_t n, const dmi_con
     double b = 0, p = 0, e = 0;
     (void)dmi_transcoder_timings(d->t, &b, &p, &e);
     R->stats.build_ms += b; R->stats.prepare_ms += p; R->stats.encode_ms += e;
+    uint64_t nd = 0, nh = 0, np = 0;
+    (void)dmi_transcoder_counts(d->t, &nd, &nh, &np);
+    R->stats.primitives_device_built += (uint32_t)nd; R->stats.primitives_host_built += (uint32_t)nh; R->stats.primitives_in_place += (uint32_t)np;
   }
   const double t_finished = now_ms();
   { std::lock_guard<std::mutex> lock(R->q_mutex); R->q_closed = true; }

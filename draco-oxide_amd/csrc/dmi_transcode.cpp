@@ -86,7 +86,8 @@ struct dmi_transcoder {
   int rc = DMI_OK;
   std::string err;
   double ms_build = 0, ms_prepare = 0, ms_encode = 0;
-  const bool trace = std::getenv("DMI_TRACE") != nullptr;
+  uint64_t n_device = 0, n_host = 0, n_in_place = 0;   // primitives built by the kernels / by the host builder / of the former: copied up where they lay
+  const bool trace = std::getenv("DMI_TRACE") != nullptr || std::getenv("DMI_TRACE_STAGES") != nullptr;   // (DMI_TRACE_STAGES: only the stage lines below — the full trace prints a line per mesh)
   const double t_create = now_ms();
   void note(const char* step, const Stage& s, double t0) const { if (trace) std::fprintf(stderr, "[dmi] transcoder %-8s stage@%-5u (%4u primitives) %7.1f -> %7.1f ms\n", step, s.first, s.count, t0 - t_create, now_ms() - t_create); }
   bool started = false, finished = false;
@@ -105,7 +106,9 @@ struct dmi_transcoder {
       const double t0 = now_ms();
       s->built.assign(s->count, dmi_built_mesh{});
       const int r = dmi_meshes_build(s->raw.data(), s->count, &cfg, 0u, s->built.data());
-      { std::lock_guard<std::mutex> lock(err_mutex); ms_build += now_ms() - t0; }
+      dmi_build_timings bt{};
+      (void)dmi_last_build_timings(&bt);
+      { std::lock_guard<std::mutex> lock(err_mutex); ms_build += now_ms() - t0; if (!r) { n_device += bt.device_meshes; n_host += bt.host_meshes; n_in_place += bt.in_place_meshes; } }
       note("build", *s, t0);
       if (r) { fail_with(r); continue; }
       if (!to_prepare.put(std::move(s))) break;
@@ -151,6 +154,7 @@ struct dmi_transcoder {
         std::vector<dmi_buffer> outs(s->jobs.size());
         r = dmi_jobs_encode(s->jobs.data(), (uint32_t)s->jobs.size(), outs.data());
         if (!r) { std::lock_guard<std::mutex> lock(result_mutex); for (size_t q = 0; q < outs.size(); ++q) sections[s->first + s->kept[q]] = outs[q]; }
+        else dmi_free_many(outs.data(), (uint32_t)outs.size());   // (what a failed batch had already produced)
       }
       for (dmi_job* j : s->jobs) dmi_job_destroy(j);
       s->jobs.clear();
@@ -163,29 +167,25 @@ struct dmi_transcoder {
   void start() {
     if (started) return;
     started = true;
-    // two builds side by side: the packing of stage k+1 beside the upload / kernels / read-back of stage k (the build is the longest chain of a
-    // transcode: DESIGN §6b); DMI_BUILD_WORKERS=1: one
-    const char* e = std::getenv("DMI_BUILD_WORKERS");
-    const int nb = e && std::atoi(e) == 1 ? 1 : 2;
-    builders_left = nb;
+    // Two threads per step.  Builds: the packing of stage k+1 beside the upload / kernels / read-back of stage k.  Prepares: stage k+1's walks start
+    // while stage k's coordinator waits for the device (sequences up, relabelling, fan rows: 3–10 ms per stage with every host core idle); the
+    // walks of both share one process-wide budget (WalkSlots).  Encodes: a stage's chain launch is bounded by its longest stream (≈ 5 ms on one
+    // wavefront per SIMD, the rest of the chip idle) — the launches of consecutive stages overlap instead of queueing at the end of the call.
+    // (1024 files, one thread for one of the steps: 100–125 ms against 86–97.)
+    builders_left = 2;
     t_build = std::thread([this] { build_loop(); });
-    if (nb > 1) t_build2 = std::thread([this] { build_loop(); });
-    // two prepares side by side: stage k+1's walks start while stage k's coordinator waits for the device (sequences up, relabelling, fan rows: 3–10 ms
-    // per stage with every host core idle); the walks of both share one process-wide budget (WalkSlots).  DMI_PREPARE_WORKERS=1: one
-    const char* ep = std::getenv("DMI_PREPARE_WORKERS");
-    const int np = ep && std::atoi(ep) == 1 ? 1 : 2;
-    preparers_left = np;
+    t_build2 = std::thread([this] { build_loop(); });
+    preparers_left = 2;
     t_prepare = std::thread([this] { prepare_loop(); });
-    if (np > 1) t_prepare2 = std::thread([this] { prepare_loop(); });
-    // two encodes side by side: a stage's chain launch is bounded by its longest stream (≈ 5 ms on one wavefront per SIMD, the rest of the chip idle) —
-    // the launches of consecutive stages overlap instead of queueing at the end of the call.  DMI_ENCODE_WORKERS=1: one
-    const char* ee = std::getenv("DMI_ENCODE_WORKERS");
+    t_prepare2 = std::thread([this] { prepare_loop(); });
     t_encode = std::thread([this] { encode_loop(); });
-    if (!(ee && std::atoi(ee) == 1)) t_encode2 = std::thread([this] { encode_loop(); });
+    t_encode2 = std::thread([this] { encode_loop(); });
   }
   // hands the primitives pushed so far to the build step once they make a stage (or all of them: flush)
   void dispatch(bool flush) {
-    const uint64_t want = first_stage ? std::max<uint64_t>(1, stage_triangles / 3) : stage_triangles;   // (the first stage runs alone: the sooner it is through, the sooner the steps overlap)
+    // (the first stage runs alone: the sooner it is through, the sooner the steps overlap.  Small LAST stages — half of what is expected to be left,
+    // down to a third of a stage — were tried against the tail of the call: no gain beyond the noise, 105–110 against 95–105 ms per 1024 files)
+    const uint64_t want = first_stage ? std::max<uint64_t>(1, stage_triangles / 3) : stage_triangles;
     if (dispatched == prims.size() || (!flush && pending_triangles < want)) return;
     std::unique_ptr<Stage> s(new Stage());
     s->first = dispatched; s->count = (uint32_t)prims.size() - dispatched;
@@ -224,11 +224,13 @@ int dmi_transcoder_push(dmi_transcoder* t, const dmi_raw_mesh* prims, uint32_t n
       t->prims.push_back(m);
       t->pending_triangles += prims[k].num_faces;
     }
-    std::lock_guard<std::mutex> rlock(t->result_mutex);
-    t->heads.resize(t->prims.size(), dmi_buffer{}); t->sections.resize(t->prims.size(), dmi_buffer{});
-    t->num_faces.resize(t->prims.size(), 0); t->num_points.resize(t->prims.size(), 0);
+    {
+      std::lock_guard<std::mutex> rlock(t->result_mutex);
+      t->heads.resize(t->prims.size(), dmi_buffer{}); t->sections.resize(t->prims.size(), dmi_buffer{});
+      t->num_faces.resize(t->prims.size(), 0); t->num_points.resize(t->prims.size(), 0);
+    }
+    t->dispatch(false);   // (under the push mutex: the primitive list, the dispatch cursor and the thread start belong to one pusher at a time)
   }
-  t->dispatch(false);
   return DMI_OK;
 }
 
@@ -244,7 +246,7 @@ int dmi_transcoder_reserve(dmi_transcoder* t, uint32_t n_primitives) {
 int dmi_transcoder_finish(dmi_transcoder* t) {
   if (!t) return host_fail(DMI_ERR_INVALID_ARGUMENT, "null");
   if (!t->finished) {
-    t->dispatch(true);
+    { std::lock_guard<std::mutex> lock(t->push_mutex); t->dispatch(true); }
     t->to_build.close();
     if (t->t_build.joinable()) t->t_build.join();
     if (t->t_build2.joinable()) t->t_build2.join();
@@ -274,6 +276,15 @@ int dmi_transcoder_timings(dmi_transcoder* t, double* build_ms, double* prepare_
   if (build_ms) *build_ms = t->ms_build;
   if (prepare_ms) *prepare_ms = t->ms_prepare;
   if (encode_ms) *encode_ms = t->ms_encode;
+  return DMI_OK;
+}
+
+int dmi_transcoder_counts(dmi_transcoder* t, uint64_t* device_built, uint64_t* host_built, uint64_t* in_place) {
+  if (!t) return host_fail(DMI_ERR_INVALID_ARGUMENT, "null");
+  std::lock_guard<std::mutex> lock(t->err_mutex);
+  if (device_built) *device_built = t->n_device;
+  if (host_built) *host_built = t->n_host;
+  if (in_place) *in_place = t->n_in_place;
   return DMI_OK;
 }
 

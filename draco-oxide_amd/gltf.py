@@ -485,18 +485,9 @@ def encode_raw_batch(raws, cfg=None, pipeline=True, timings=None, weights=None, 
     for key in ("views_s", "build_s", "prepare_s", "encode_s", "build_kernels_ms", "build_pack_ms"):
         tm.setdefault(key, 0.0)
 
-    # DMI_STAGE_THREADS="build,prepare,encode": a share of the host threads per stage (dmi_thread_host_threads).  Measured with collection paused
-    # (1024 GLBs, medians of 10): no caps 185 ms, 2/12/2 192, 2/14/2 192, 4/16/4 191 — the stages' pools oversubscribing the 16-CPU quota costs less
-    # than a stage kept short of threads; off unless asked for.
-    share = None
-    if len(chunks) > 1 and os.environ.get("DMI_STAGE_THREADS"):
-        share = [int(x) for x in os.environ["DMI_STAGE_THREADS"].split(",")]
-
     trace = tm.get("trace")                                               # (a list: (step, first primitive, start, end) per stage and step, seconds)
 
     def build(ch):
-        if share:
-            thread_host_threads(share[0])
         t0 = time.perf_counter()
         mine = [make(i) for i in ch] if make else [raws[i] for i in ch]
         t1 = time.perf_counter()
@@ -511,8 +502,6 @@ def encode_raw_batch(raws, cfg=None, pipeline=True, timings=None, weights=None, 
         return batch, ch
 
     def prepare(mid):
-        if share:
-            thread_host_threads(share[1])
         batch, ch = mid
         t0 = time.perf_counter()
         try:
@@ -528,8 +517,6 @@ def encode_raw_batch(raws, cfg=None, pipeline=True, timings=None, weights=None, 
         return jobs, [ch[k] for k in keep], info
 
     def encode(mid):
-        if share:
-            thread_host_threads(share[2])
         jobs, where, info = mid[:3]
         t0 = time.perf_counter()
         try:
@@ -560,29 +547,19 @@ def encode_raw_batch(raws, cfg=None, pipeline=True, timings=None, weights=None, 
             trace.append(("assemble", mid[1][0] if mid[1] else -1, t0, time.perf_counter()))
         return None
 
-    prep_workers = int(os.environ.get("DMI_PREPARE_WORKERS", 1))   # (measured: 2 or 3 workers give nothing — the host cores are busy)
-    build_workers = int(os.environ.get("DMI_BUILD_WORKERS", 1))
-    try:
-        steps = [(prepare_ch, prep_workers), encode] + ([finish] if on_done else [])
-        if build_workers > 1:   # the builds of two stages side by side (the caller's thread only deals the stages out)
-            _pipelined(chunks, lambda ch: ch, (build, build_workers), *steps)
-        else:
-            _pipelined(chunks, build, *steps)
-    finally:
-        if share:
-            thread_host_threads(0)                                         # (the caller's thread ran the build stage under its cap)
+    _pipelined(chunks, build, prepare_ch, encode, *([finish] if on_done else []))
     return out
 
 
 _ENCODE_RAW_BATCH = encode_raw_batch   # (a test's stand-in for encode_raw_batch must keep being used by the sharded driver)
 
 
-def encode_batch(meshes, cfg=None, devices=None, group=None, device=None, pipeline=False):
+def encode_batch(meshes, cfg=None, devices=None, group=None, device=None):
     """Every (already built, host-memory) mesh of a transcode job as ONE batch → list of `.drc` blobs in mesh order (None on the ranks
     that are not the destination of a sharded job).  torch.distributed initialised with more than one rank: the batch is dealt over
     the ranks by triangle count and gathered on rank 0 (RCCL for an nccl group).  Otherwise `devices` (a count, or "all") spreads it
     over the GPUs of this process (dmi_shard_meshes + dmi_meshes_prepare_devices + dmi_jobs_encode_devices); default: one GPU.
-    pipeline=True (one GPU): stages of stage_triangles() triangles, dmi_meshes_prepare of stage k+1 beside dmi_jobs_encode of stage k."""
+    (A pipelined form — dmi_meshes_prepare of stage k+1 beside dmi_jobs_encode of stage k — was 1.6 × slower on 256 meshes and is gone.)"""
     if not meshes:
         return []
     try:
@@ -595,25 +572,6 @@ def encode_batch(meshes, cfg=None, devices=None, group=None, device=None, pipeli
         return distributed.encode_meshes_sharded(meshes, cfg, device=device, group=group)
     n_dev = device_count() if devices == "all" else int(devices or 1)
     n_dev = max(1, min(n_dev, device_count()))
-    if n_dev == 1 and pipeline:
-        cfg = cfg or Config.default()
-        out = [None] * len(meshes)
-        chunks = _chunks_by_weight([len(m.faces) for m in meshes], stage_triangles(sum(len(m.faces) for m in meshes)))
-
-        def stage1(ch):
-            return meshes_prepare([meshes[i] for i in ch], cfg), ch
-
-        def stage2(mid):
-            jobs, ch = mid
-            try:
-                for j, s, i in zip(jobs, jobs_encode(jobs), ch):
-                    out[i] = j.header_and_connectivity + s
-            finally:
-                for j in jobs:
-                    j.close()
-
-        _pipelined(chunks, stage1, stage2)
-        return out
     jobs = []
     try:   # (the jobs hold device memory: closed whatever the encode does)
         if n_dev > 1:

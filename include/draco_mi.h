@@ -256,7 +256,7 @@ int dmi_host_is_registered(const void* p, size_t bytes);   /* 1: [p, p + bytes) 
  * the faces and point → value maps come back in one read-back (the host's serial walks need them).  The unique values stay in device
  * memory unless DMI_BUILD_HOST_VALUES is set.  out[j].mesh equals what dmi_mesh_build returns for primitive j (same value order, maps,
  * surviving points and faces, Position in slot 0) with atts[i].values == NULL when the values stayed on the device.  Primitives outside
- * the device form's class (attributes of different point counts, components that are not 4 bytes wide, more than 8 attributes, a face
+ * the device form's class (attributes of different point counts, components that are not 4 bytes wide, more than 16 attributes, a face
  * index out of range, no surviving face) take the host builder inside the same call.  Free every out[j] with dmi_built_mesh_free. */
 typedef struct dmi_raw_accessor {
   const void* data;          /* first element, host memory */
@@ -301,6 +301,9 @@ int dmi_transcoder_push(dmi_transcoder* t, const dmi_raw_mesh* prims, uint32_t n
 int dmi_transcoder_finish(dmi_transcoder* t);
 int dmi_transcoder_result(dmi_transcoder* t, uint32_t i, dmi_buffer* header_and_connectivity, dmi_buffer* section, uint32_t* num_faces, uint32_t* num_points);
 int dmi_transcoder_timings(dmi_transcoder* t, double* build_ms, double* prepare_ms, double* encode_ms);   /* time inside the three calls, summed over the stages */
+/* how the primitives built so far were built: by the device kernels, by the host builder inside the same call (outside the device form's class, or
+ * flagged by the kernels), and — of the former — copied up where they lay (dmi_host_alloc memory) */
+int dmi_transcoder_counts(dmi_transcoder* t, uint64_t* device_built, uint64_t* host_built, uint64_t* in_place);
 void dmi_transcoder_destroy(dmi_transcoder* t);
 
 /* --- A list of glTF assets in, their Draco-compressed GLBs out (round 5; io/gltf/transcoder.rs:134-151 per file: read_scene → compress_scene →
@@ -325,6 +328,7 @@ typedef struct dmi_gltf_asset {
 typedef struct dmi_transcode_stats {
   uint32_t files, primitives, devices;
   uint32_t buffers_in_place;   /* input buffers that lie in dmi_host_alloc memory (their accessors go up without a host pack) */
+  uint32_t primitives_device_built, primitives_host_built, primitives_in_place, pad;   /* dmi_transcoder_counts, summed over the devices */
   uint64_t triangles_in, bytes_in, bytes_out;
   double parse_ms;      /* caller's thread: containers, JSON, primitive plans, accessor descriptors */
   double pushed_ms;     /* since the start of the call: the last primitive handed to a transcoder */

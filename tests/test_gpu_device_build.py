@@ -182,6 +182,22 @@ def test_batch_of_mixed_primitives_one_call():
             _same_mesh(batch.mesh(j), b.build())
 
 
+def test_twelve_attributes_stay_on_the_device_and_seventeen_go_to_the_host():
+    """The device form takes up to 16 attributes per primitive (8 until round 4); more take the host builder inside the same call — same mesh."""
+    rng = np.random.default_rng(12)
+    faces, pos, nrm, uv = synth.torus_grid(20)
+    corner = faces.ravel()[: 3 * 300]
+    pos, nrm, uv = pos[corner], nrm[corner], uv[corner]
+    tri = np.arange(len(corner), dtype=np.uint32).reshape(-1, 3)
+    for extra, on_device in ((9, 1), (14, 0)):
+        specs = [(pos, dmi.ATT_POSITION, dmi.DOMAIN_POSITION, []), (nrm, dmi.ATT_NORMAL, dmi.DOMAIN_CORNER, [0]), (uv, dmi.ATT_TEXCOORD, dmi.DOMAIN_CORNER, [0])]
+        specs += [(rng.integers(0, 3, size=(len(pos), 1)).astype(np.uint32), dmi.ATT_CUSTOM, dmi.DOMAIN_CORNER, []) for _ in range(extra)]
+        got, want = _both(specs, tri)
+        _same_mesh(got, want)
+        tm = dmi.last_build_timings()
+        assert tm["device_meshes"] == on_device and tm["host_meshes"] == 1 - on_device
+
+
 def test_bad_index_goes_to_the_host_builder_and_errors_surface():
     faces, pos, nrm, uv = synth.torus_grid(8)
     bad = faces.copy()

@@ -138,27 +138,3 @@ def test_lds_window_sweep_gives_the_same_bytes(monkeypatch):
     cases.append(two)
     for mesh in cases:
         _assert_same(dmi.encode_mesh(mesh), oracle_from_product_mesh(mesh).encode(), "LDS-window sweep")
-
-
-def test_batch_with_the_hybrid_tail_gives_the_same_bytes():
-    """DMI_BATCH_TAIL (experiment, off by default: DESIGN §5): the jobs with the longest streams leave the batch and are coded in the hybrid form beside it."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import sys, hashlib; sys.path.insert(0, %r)\n"
-        "import draco_oxide_amd as dmi; from draco_oxide_amd import synth\n"
-        "meshes = synth.batch_meshes(24, lo=3e4, hi=2e5)\n"
-        "jobs = dmi.meshes_prepare(meshes)\n"
-        "out = dmi.jobs_encode(jobs)\n"
-        "print('digest', hashlib.sha256(b''.join(j.header_and_connectivity + s for j, s in zip(jobs, out))).hexdigest())\n") % root
-    digests = []
-    for tail in ("0", "50"):
-        env = dict(os.environ, DMI_BATCH_TAIL=tail, DMI_TRACE="1")
-        r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        digests.append([l for l in r.stdout.splitlines() if l.startswith("digest")][0])
-        if tail != "0":
-            assert "coded in the hybrid form beside it" in r.stderr
-    assert digests[0] == digests[1]

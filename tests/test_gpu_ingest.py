@@ -81,14 +81,14 @@ def test_files_read_into_library_memory_transcode_to_the_same_files(monkeypatch)
     (stats: every buffer in place), and the output files are those of the same bytes in ordinary memory, packed and copied."""
     glbs, _ = synth.batch_glbs(24, lo=500, hi=30000, seed=77)
     plain, st0 = binding.transcode_assets(glbs)
-    assert st0["buffers_in_place"] == 0
+    assert st0["buffers_in_place"] == 0 and st0["primitives_in_place"] == 0 and st0["primitives_device_built"] == 24
     held = [binding.HostBuffer.holding(g) for g in glbs]
     try:
         assert binding.load_library().dmi_host_is_registered(held[0].array.ctypes.data + 64, 16) == 1
         placed, st1 = binding.transcode_assets([h.view() for h in held])
-        assert st1["buffers_in_place"] == 24 and st1["primitives"] == 24
+        assert st1["buffers_in_place"] == 24 and st1["primitives"] == 24 and st1["primitives_in_place"] == 24 and st1["primitives_host_built"] == 0
         assert [bytes(g) for g, _ in placed] == [bytes(g) for g, _ in plain]
-        monkeypatch.setenv("DMI_NO_INGEST", "1")                      # (A/B switch: pack even what could go up in place)
+        monkeypatch.setenv("DMI_NO_IN_PLACE", "1")                      # (A/B switch: pack even what could go up in place)
         packed, _ = binding.transcode_assets([h.view() for h in held])
         assert [bytes(g) for g, _ in packed] == [bytes(g) for g, _ in plain]
     finally:
