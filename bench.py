@@ -347,6 +347,24 @@ def transcode_sharded(n_files, rank, world, local_rank, gather_dev, steps=2):
             "sample_blob_equals_whole_mesh_encode": bool(res[n_files // 2][1][0] == dmi.encode_mesh(mesh, cfg))}
 
 
+def transcode_one_process(n_files, devices, steps=3):
+    """BASELINE configs[3] through ONE process and a list of devices: dmi_transcode_assets deals the primitives over one dmi_transcoder per device
+    (the least loaded one takes the next primitive), the library's threads write the files.  No JSON parsed N times, no padded gather."""
+    from draco_oxide_amd import binding
+    glbs, total = synth.batch_glbs(n_files)
+    binding.transcode_assets(glbs, devices=devices)
+    ts, st = [], None
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        res, st = binding.transcode_assets(glbs, devices=devices)
+        ts.append(time.perf_counter() - t0)
+        del res
+    med, best = _med_min(ts)
+    return {"devices": list(devices), "triangles": int(total), "value": round(total / med / 1e6, 2), "unit": "Mtriangles/s", "statistic": f"median of {steps} calls",
+            "ms_per_batch": round(med * 1e3, 2), "ms_per_batch_min": round(best * 1e3, 2), "scaling": "strong",
+            "primitives_built_by_the_host_builder": int(st["primitives_host_built"]), "last_stage_coded_at_ms": round(st["finished_ms"], 2)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -394,11 +412,15 @@ def main():
     tstream = torch.cuda.Stream(dev)
     cfg = dmi.Config(device=local_rank, stream=tstream.cuda_stream, flags=dmi.FLAG_TIMINGS)
 
+    gather_s = [0.0]
+
     def step():
         # the product boundary is the C ABI: the `.drc` lands in a library-owned host buffer, which the gather at N > 1 reads in place
         with dmi.encode_mesh_device_raw(dmesh, cfg, cmesh) as out:
             if world > 1:
+                tg = time.perf_counter()
                 dmi_dist.gather_bitstreams(out.view(0), device=gather_dev, as_bytes=False)
+                gather_s[0] += time.perf_counter() - tg
             return out.nbytes
 
     for _ in range(args.warmup):
@@ -406,6 +428,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
+    gather_s[0] = 0.0
     keys = ("quantize_ms", "predict_ms", "histogram_ms", "table_ms", "rans_ms", "total_ms", "longest_stream_ms", "readback_wait_ms",
             "mesh_readback_ms", "tables_ms", "connectivity_ms", "job_create_ms", "call_ms", "job_create_device_ms")
     stages = {k: 0.0 for k in keys}
@@ -428,6 +451,15 @@ def main():
     for k in stages:
         stages[k] /= max(args.steps, 1)
     step_s = elapsed / max(args.steps, 1)
+    dist_info = None
+    if world > 1:
+        # what the collective layer really was in this run: backend, world size, per-rank gather time and usable host CPUs
+        mine = torch.tensor([gather_s[0] / max(args.steps, 1) * 1e3, float(usable_cpus()), float(host_threads), float(local_rank)], dtype=torch.float64, device=gather_dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                     "gather_ms_per_step_by_rank": [round(float(t[0]), 3) for t in allr], "host_cpus_usable_by_rank": [int(t[1]) for t in allr],
+                     "library_host_threads_by_rank": [int(t[2]) for t in allr], "hip_device_by_rank": [int(t[3]) for t in allr]}
 
     line = None
     if rank == 0:
@@ -581,7 +613,17 @@ def main():
                 except Exception as e:
                     if rank == 0:
                         line["transcode_sharded"] = {"error": str(e)[:200]}
+                # the same list through ONE process driving all N devices (dmi_transcode_assets with a device list: one dmi_transcoder per GPU, no second
+                # interpreter, no gather): rank 0 runs it while the other ranks wait at the barrier below
+                if rank == 0:   # (on a 1-GPU box — scripts/scaling_one_host.sh — the N transcoders share cuda:0)
+                    try:
+                        line["transcode_one_process_n_devices"] = transcode_one_process(args.transcode_files, [k % max(torch.cuda.device_count(), 1) for k in range(world)])
+                    except Exception as e:
+                        line["transcode_one_process_n_devices"] = {"error": str(e)[:200]}
+                dist.barrier()
     if rank == 0:
+        if dist_info is not None:
+            line["distributed"] = dist_info
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(mesh)
         print(json.dumps(line), flush=True)
