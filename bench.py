@@ -352,13 +352,21 @@ def transcode_one_process(n_files, devices, steps=3):
     (the least loaded one takes the next primitive), the library's threads write the files.  No JSON parsed N times, no padded gather."""
     from draco_oxide_amd import binding
     glbs, total = synth.batch_glbs(n_files)
-    binding.transcode_assets(glbs, devices=devices)
-    ts, st = [], None
-    for _ in range(steps):
-        t0 = time.perf_counter()
-        res, st = binding.transcode_assets(glbs, devices=devices)
-        ts.append(time.perf_counter() - t0)
-        del res
+    share = os.environ.get("DMI_HOST_THREADS")          # (the ranks of this run split the host's CPUs among them; this ONE process drives all devices: it gets them all —
+    os.environ["DMI_HOST_THREADS"] = str(usable_cpus())  #  the other ranks wait at a barrier meanwhile)
+    try:
+        binding.transcode_assets(glbs, devices=devices)
+        ts, st = [], None
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            res, st = binding.transcode_assets(glbs, devices=devices)
+            ts.append(time.perf_counter() - t0)
+            del res
+    finally:
+        if share is None:
+            os.environ.pop("DMI_HOST_THREADS", None)
+        else:
+            os.environ["DMI_HOST_THREADS"] = share
     med, best = _med_min(ts)
     return {"devices": list(devices), "triangles": int(total), "value": round(total / med / 1e6, 2), "unit": "Mtriangles/s", "statistic": f"median of {steps} calls",
             "ms_per_batch": round(med * 1e3, 2), "ms_per_batch_min": round(best * 1e3, 2), "scaling": "strong",

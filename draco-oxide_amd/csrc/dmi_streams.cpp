@@ -1,0 +1,119 @@
+// dmi_streams.cpp — library streams that outlive their threads, and the NUMA placement of a whole-mesh call (split out of dmi_prepare.cpp in round 5).
+#include "dmi_prepare.hpp"
+
+using namespace dmi;
+
+#include <sched.h>
+
+namespace {
+
+// The serial walks of the connectivity stage are bound by memory latency; on a two-socket host a thread that wanders to the other socket
+// pays ≈ 100 ns more per miss (10M-triangle traversal: 72 ms with its tables on the local node, 120–130 ms across the sockets).  For the
+// duration of a whole-mesh call the calling thread — and the library threads it starts, which inherit its mask — therefore stay on the
+// CPUs of ONE memory node: the one the call's GPU hangs off (its staging DMA is local there too; the ranks of a multi-GPU job spread over
+// the sockets the way their GPUs do).  The previous mask is restored when the call returns.  DMI_NO_NUMA_PIN=1 turns it off.
+int device_numa_node(int device) {
+  static std::mutex m;
+  static std::vector<std::pair<int, int>> known;
+  std::lock_guard<std::mutex> lock(m);
+  for (auto& e : known) if (e.first == device) return e.second;
+  int node = -1;
+  char bus[64] = {0};
+  if (hipDeviceGetPCIBusId(bus, sizeof bus, device) == hipSuccess) {
+    for (char* c = bus; *c; ++c) *c = (char)std::tolower((unsigned char)*c);
+    const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/numa_node";
+    if (std::FILE* f = std::fopen(path.c_str(), "r")) { if (std::fscanf(f, "%d", &node) != 1) node = -1; std::fclose(f); }
+  } else (void)hipGetLastError();
+  known.push_back({device, node});
+  return node;
+}
+struct NumaPin {
+  cpu_set_t old;
+  bool active = false;
+  explicit NumaPin(int device) {
+    static const bool off = std::getenv("DMI_NO_NUMA_PIN") != nullptr;
+    if (off) return;
+    const int node = device_numa_node(device);
+    if (node < 0) return;
+    cpu_set_t want;
+    CPU_ZERO(&want);
+    const std::string path = "/sys/devices/system/node/node" + std::to_string(node) + "/cpulist";
+    std::FILE* f = std::fopen(path.c_str(), "r");
+    if (!f) return;
+    char buf[1024] = {0};
+    const bool got = std::fgets(buf, sizeof buf, f) != nullptr;
+    std::fclose(f);
+    if (!got) return;
+    for (char* p = buf; *p && *p != '\n';) {   // "0-63,128-191"
+      char* end = nullptr;
+      const long lo = std::strtol(p, &end, 10);
+      if (end == p) break;
+      long hi = lo;
+      p = end;
+      if (*p == '-') { hi = std::strtol(p + 1, &end, 10); p = end; }
+      for (long c = lo; c <= hi && c < CPU_SETSIZE; ++c) CPU_SET((int)c, &want);
+      if (*p == ',') ++p;
+    }
+    if (sched_getaffinity(0, sizeof old, &old) != 0) return;
+    cpu_set_t both;
+    CPU_AND(&both, &old, &want);
+    if (CPU_COUNT(&both) == 0 || CPU_EQUAL(&both, &old)) return;
+    if (sched_setaffinity(0, sizeof both, &both) == 0) active = true;
+  }
+  ~NumaPin() { if (active) (void)sched_setaffinity(0, sizeof old, &old); }
+  NumaPin(const NumaPin&) = delete;
+  NumaPin& operator=(const NumaPin&) = delete;
+};
+
+// Library streams of a host thread outlive it: a thread takes them from a process-wide pool on first use and its exit hands them back (they are not
+// destroyed).  Work recorded on them can be waited for by ANOTHER thread later — a transcode pipeline's build thread records a group's table
+// event and may be gone when the prepare thread waits for it: with the stream destroyed the runtime's hipEventSynchronize answered "event
+// last recorded in a capturing stream" once in twenty calls — and hipStreamCreate (≈ 1 ms, serialised across threads) is paid once per stream,
+// not once per pipeline thread.  kind 0: the thread's stream (connectivity stage of a whole-mesh call, adopted by the job it creates);
+// kinds 1 / 2: the two group streams (non-blocking).
+namespace {
+struct StreamPool {
+  std::mutex m;
+  std::vector<std::pair<int, std::shared_ptr<StreamHolder>>> idle[3];
+  static StreamPool& get() { static StreamPool* p = new StreamPool(); return *p; }   // (never destroyed: threads may exit after static destruction began)
+};
+struct ThreadStreams {
+  std::vector<std::pair<int, std::shared_ptr<StreamHolder>>> mine[3];
+  ~ThreadStreams() {
+    StreamPool& pool = StreamPool::get();
+    std::lock_guard<std::mutex> lock(pool.m);
+    for (int k = 0; k < 3; ++k) for (auto& e : mine[k]) pool.idle[k].push_back(std::move(e));
+  }
+  std::shared_ptr<StreamHolder> get(int kind, int device) {
+    for (auto& e : mine[kind]) if (e.first == device) return e.second;
+    std::shared_ptr<StreamHolder> h;
+    {
+      StreamPool& pool = StreamPool::get();
+      std::lock_guard<std::mutex> lock(pool.m);
+      auto& idle = pool.idle[kind];
+      for (size_t i = 0; i < idle.size(); ++i) if (idle[i].first == device) { h = std::move(idle[i].second); idle.erase(idle.begin() + (long)i); break; }
+    }
+    if (!h) {
+      h = std::make_shared<StreamHolder>();
+      const hipError_t e = hipSetDevice(device) != hipSuccess ? hipErrorInvalidDevice : (kind == 0 ? hipStreamCreate(&h->s) : hipStreamCreateWithFlags(&h->s, hipStreamNonBlocking));
+      if (e != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    }
+    mine[kind].push_back({device, h});
+    return h;
+  }
+};
+ThreadStreams& thread_streams() { static thread_local ThreadStreams t; return t; }
+}  // namespace
+}  // namespace
+
+// Two more library streams per (host thread, device): consecutive groups of a slice alternate between them, so the read-back of one
+// group's tables overlaps the upload of the next group's faces (the two directions of the link run side by side).
+namespace dmi {
+std::shared_ptr<StreamHolder> library_thread_stream(int device) { return thread_streams().get(0, device); }
+hipStream_t library_group_stream(int device, int which) {
+  const std::shared_ptr<StreamHolder> h = thread_streams().get(1 + (which & 1), device);
+  return h ? h->s : nullptr;
+}
+NumaScope::NumaScope(int device) : impl(new NumaPin(device)) {}
+NumaScope::~NumaScope() { delete static_cast<NumaPin*>(impl); }
+}  // namespace dmi
