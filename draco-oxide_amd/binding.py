@@ -54,7 +54,7 @@ class _Timings(C.Structure):
     _fields_ = [("quantize_ms", C.c_float), ("predict_ms", C.c_float), ("histogram_ms", C.c_float), ("table_ms", C.c_float),
                 ("rans_ms", C.c_float), ("total_ms", C.c_float), ("predict_bytes", C.c_uint64), ("symbols", C.c_uint64), ("num_streams", C.c_uint32),
                 ("host_chains", C.c_uint32), ("longest_stream_ms", C.c_float), ("readback_wait_ms", C.c_float),
-                ("mesh_readback_ms", C.c_float), ("tables_ms", C.c_float), ("connectivity_ms", C.c_float), ("job_create_ms", C.c_float), ("call_ms", C.c_float), ("texcoord_fixups", C.c_uint32), ("job_create_device_ms", C.c_float)]
+                ("mesh_readback_ms", C.c_float), ("tables_ms", C.c_float), ("connectivity_ms", C.c_float), ("job_create_ms", C.c_float), ("call_ms", C.c_float), ("texcoord_fixups", C.c_uint32), ("job_create_device_ms", C.c_float), ("early_ms", C.c_float)]
 
 
 class _Mesh(C.Structure):

@@ -60,7 +60,13 @@ struct QuantAtt { const float* raw; const uint32_t* s2v; void* qs; int32_t* ipar
 struct QuantArgs { QuantAtt a[kMaxGather]; int count; };
 // dest (nullable): the pass runs in TILE-SORTED order — slot j holds point s2p[j] and is written to sequence index dest[j]; inside a tile of
 // consecutive sequence entries the slots are ordered by point, so a wavefront's gathers fall on a few lines instead of one line per lane
-struct SeqQuantArgs { const uint32_t* s2p; uint32_t n; uint32_t pad; const uint32_t* dest; QuantArgs q; };
+struct SeqQuantArgs { const uint32_t* s2p /* null: value order (entry i reads value i) */; uint32_t n; uint32_t pad; const uint32_t* dest; QuantArgs q; };
+// The early stage of a whole-mesh call (dmi_kernels.hip): rec[v] = the quantized position / normal / texture coordinate of value v in one 16-byte record
+// (value order; nrm / uv null: the mesh has none), then qs_*[i] = the fields of rec[s2p[i]] + per-block joint i32 min/max partials per attribute
+struct ValueRecArgs { const float *pos, *nrm, *uv; const float *pos_meta, *uv_meta; float pos_maxq, uv_maxq; uint32_t n; uint32_t pad; void* rec; };
+struct GatherRecArgs { const uint32_t* s2p; uint32_t n; uint32_t pad; const void* rec; uint64_t* qs_pos; uint16_t* qs_nrm; uint32_t* qs_uv; int32_t* ipartials[3] /* position, normal, texture coordinate */; };
+void launch_value_quantize_rec(const ValueRecArgs& a, hipStream_t s);
+void launch_seq_gather_rec(const GatherRecArgs& g, hipStream_t s);
 void launch_seq_quantize(const uint32_t* s2p, const uint32_t* dest, uint32_t n, const QuantArgs& args, hipStream_t s);
 
 // Fan-row sweep (see k_predict_fused).  Seam-free fast path: position (parallelogram, 3 components) + normal and/or texture

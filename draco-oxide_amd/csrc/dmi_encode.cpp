@@ -15,8 +15,14 @@ int encode_phase_a(dmi_job* job, bool plan_only) {   // device: ranges → codin
   uint8_t* pinned = static_cast<uint8_t*>(job->pinned);
   const bool timed = job->have_events;
   // ---- stage 1: value ranges (streamed over the unique values) ---------------------------------------------
+  const bool early = job->early != nullptr && !plan_only;   // ranges + quantization ran before the host walks (EarlyQuant): the pass gathers packed values
+  if (early) {
+    HIP_TRY(hipStreamWaitEvent(s, job->early->t1, 0));
+    for (size_t i = 0; i < job->atts.size(); ++i)   // the ranges, the seeded scratch words and the zero-normal flag into the job's slab slot ([small 64 B][meta 64 B])
+      HIP_TRY(hipMemcpyAsync(job->atts[i].small.p, job->early->atts[i].slot, 128, hipMemcpyDeviceToDevice, s));
+  }
   if (timed) HIP_TRY(hipEventRecord(job->ev[0], s));
-  {
+  if (!early) {
     RangeArgs ra{};
     for (auto& a : job->atts) {
       RangeAtt& r = ra.a[ra.count++];
@@ -39,6 +45,19 @@ int encode_phase_a(dmi_job* job, bool plan_only) {   // device: ranges → codin
   for (size_t ti = 0; ti < job->tables.size(); ++ti) {
     TableDev& t = job->tables[ti];
     if (t.alias_of >= 0) continue;
+    if (early) {   // (every attribute of an adopted early stage is per-point and sits on the position's table)
+      if ((size_t)job->atts[0].table != ti) continue;
+      GatherRecArgs ga{};
+      ga.s2p = t.s2p.as<uint32_t>(); ga.n = t.n_seq; ga.rec = job->early->rec;
+      for (size_t i = 0; i < job->atts.size(); ++i) {
+        AttJob& a = job->atts[i];
+        if (a.qfmt == QF_P64) { ga.qs_pos = a.qs.as<uint64_t>(); ga.ipartials[0] = a.ipartials.as<int32_t>(); }
+        else if (a.qfmt == QF_B16) { ga.qs_nrm = a.qs.as<uint16_t>(); ga.ipartials[1] = a.ipartials.as<int32_t>(); }
+        else { ga.qs_uv = a.qs.as<uint32_t>(); ga.ipartials[2] = a.ipartials.as<int32_t>(); }
+      }
+      launch_seq_gather_rec(ga, s);
+      continue;
+    }
     QuantArgs qa{};
     auto flush = [&]() {
       if (qa.count) launch_seq_quantize(t.s2p_sorted.p ? t.s2p_sorted.as<uint32_t>() : t.s2p.as<uint32_t>(), t.s2p_sorted.p ? t.sorted_dest.as<uint32_t>() : nullptr, t.n_seq, qa, s);
@@ -702,7 +721,7 @@ int run_phase_a(dmi_job* job) {
   hipStream_t s = job->stream;
   if (!job->pinned) { HIP_TRY(hipSetDevice(job->cfg.device)); HIP_TRY(hipHostMalloc(&job->pinned, job->pinned_bytes, hipHostMallocDefault)); }   // (not inside a stream capture)
   if (job->graph_a) { HIP_TRY(hipSetDevice(job->cfg.device)); HIP_TRY(hipGraphLaunch(job->graph_a, s)); return DMI_OK; }
-  bool eligible = !job->have_events && !job->graph_tried;
+  bool eligible = !job->have_events && !job->graph_tried && !job->early;   // (the early stage waits for an event of another stream: not captured)
   for (auto& a : job->atts) if (a.port == kToBits) eligible = false;
   if (!eligible) return encode_phase_a(job);
   job->graph_tried = true;
@@ -775,6 +794,7 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
   }
   if (host_chains) tm.rans_ms = host_chain_ms;   // read-back of symbols / tables + the host-core chains (wall clock)
   tm.table_ms = std::chrono::duration<float, std::milli>(t_tab1 - t_tab0).count();
+  if (job->early && job->early->t0 && job->early->t1) { float em = 0; if (hipEventElapsedTime(&em, job->early->t0, job->early->t1) == hipSuccess) tm.early_ms = em; else (void)hipGetLastError(); }
   if (timed && job->dev_tables) (void)hipEventElapsedTime(&tm.table_ms, job->ev[3], job->ev[4]);   // k_tables + record prep on the device
   tm.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
   tm.predict_bytes = job->predict_bytes;

@@ -16,6 +16,7 @@ thread_local DevPool* g_active_pool = nullptr;
 using namespace dmi;
 
 thread_local std::shared_ptr<StreamHolder> g_adopt_stream;
+namespace dmi { thread_local std::unique_ptr<EarlyQuant> g_early_quant; }
 
 static std::mutex g_stage_mutex;
 static std::vector<HostStage*> g_stages;   // (never freed: process-lifetime staging)
@@ -221,6 +222,70 @@ int to_buffer(const std::vector<uint8_t>& v, dmi_buffer* out) {
   return DMI_OK;
 }
 }  // namespace dmi
+// The early stage of a whole-mesh call (EarlyQuant, dmi_job.hpp).  Only for the attribute set of a fused sweep in its packed layouts — a Position
+// (coordinate-wise, 3 components, ≤ 21 bits) with at most one Normal (octahedral) and one TextureCoordinate (2 components, ≤ 16 bits), values in
+// device memory — out stays null for anything else.  Whether the job will really run that sweep is only known once its corner tables are (an
+// attribute with seams of its own leaves the sweep): job_create_impl compares its plan with this one.
+int dmi::early_quantize_issue(const dmi_attribute* atts, uint32_t n_atts, const dmi_config& cfg, hipStream_t side, std::unique_ptr<EarlyQuant>& out) {
+  out.reset();
+  if (!atts || n_atts == 0 || n_atts > 3 || !side || std::getenv("DMI_NO_EARLY") || std::getenv("DMI_NO_PACKED") || std::getenv("DMI_NO_FUSED")) return DMI_OK;
+  std::vector<AttJob> plan;
+  if (validate_and_plan(atts, n_atts, cfg, plan) != DMI_OK) return DMI_OK;   // (the call itself reports the error)
+  int i_pos = -1, i_nrm = -1, i_uv = -1;
+  std::unique_ptr<EarlyQuant> e(new EarlyQuant());
+  e->device = cfg.device; e->stream = side;
+  for (uint32_t i = 0; i < n_atts; ++i) {
+    const AttJob& a = plan[i];
+    const dmi_attribute& d = atts[i];
+    EarlyQuant::Att ea{d.values, d.num_unique, (int)d.num_components, a.port == kCoordwise ? 0 : 1, QF_I32, a.bits, nullptr};
+    // per-point attributes only (one record per value holds all of them), values in device memory
+    if (!d.values || !d.num_unique || d.component_type != DMI_F32 || d.point_to_value || d.num_unique != atts[0].num_unique) return DMI_OK;
+    if (d.att_type == DMI_ATT_POSITION && a.port == kCoordwise && d.num_components == 3 && a.bits <= 21 && a.scheme == kParallelogram && i_pos < 0) { ea.fmt = QF_P64; i_pos = (int)i; }
+    else if (d.att_type == DMI_ATT_NORMAL && a.port == kOct && d.num_components == 3 && i_nrm < 0) { ea.fmt = QF_B16; i_nrm = (int)i; }
+    else if (d.att_type == DMI_ATT_TEXCOORD && a.port == kCoordwise && d.num_components == 2 && a.bits <= 16 && i_uv < 0) { ea.fmt = QF_H32; i_uv = (int)i; }
+    else return DMI_OK;
+    e->atts.push_back(ea);
+  }
+  if (i_pos != 0 || (i_nrm < 0 && i_uv < 0)) return DMI_OK;   // (positions alone are no fused sweep)
+  const uint32_t n = atts[0].num_unique;
+  e->mem.init(cfg.device, side, (size_t)n * 16 + e->atts.size() * ((size_t)kRangeMaxBlocks * 8 * 4 + 4096) + ((size_t)1 << 16));
+  e->rec = e->mem.take<uint8_t>((size_t)n * 16);
+  if (!e->rec) return DMI_OK;   // (no memory to spare: the job quantizes as always)
+  RangeArgs ra{};
+  for (size_t i = 0; i < e->atts.size(); ++i) {
+    EarlyQuant::Att& ea = e->atts[i];
+    ea.slot = e->mem.take<uint8_t>(256);
+    float* partials = e->mem.take<float>((size_t)kRangeMaxBlocks * 8);
+    if (!ea.slot || !partials) return DMI_OK;
+    RangeAtt& r = ra.a[ra.count++];
+    r.raw = static_cast<const float*>(ea.values);
+    r.partials = partials;
+    r.small = reinterpret_cast<uint32_t*>(ea.slot);         // the slot of a job's slab: [small 64 B][meta 64 B]
+    r.meta = reinterpret_cast<float*>(ea.slot + 64);
+    r.zero = reinterpret_cast<uint32_t*>(ea.slot + 64);
+    r.zero_words = 16;
+    r.n = ea.n; r.N = ea.N; r.kind = ea.kind;
+  }
+  HIP_TRY(hipEventCreate(&e->t0)); HIP_TRY(hipEventCreate(&e->t1));
+  HIP_TRY(hipEventRecord(e->t0, side));
+  launch_value_ranges(ra, side);
+  ValueRecArgs va{};
+  va.pos = static_cast<const float*>(e->atts[(size_t)i_pos].values);
+  va.pos_meta = reinterpret_cast<const float*>(e->atts[(size_t)i_pos].slot + 64);
+  va.pos_maxq = (float)(uint64_t)((1ull << e->atts[(size_t)i_pos].bits) - 1ull);
+  if (i_nrm >= 0) va.nrm = static_cast<const float*>(e->atts[(size_t)i_nrm].values);
+  if (i_uv >= 0) {
+    va.uv = static_cast<const float*>(e->atts[(size_t)i_uv].values);
+    va.uv_meta = reinterpret_cast<const float*>(e->atts[(size_t)i_uv].slot + 64);
+    va.uv_maxq = (float)(uint64_t)((1ull << e->atts[(size_t)i_uv].bits) - 1ull);
+  }
+  va.n = n; va.rec = e->rec;
+  launch_value_quantize_rec(va, side);
+  HIP_TRY(hipEventRecord(e->t1, side));
+  out = std::move(e);
+  return DMI_OK;
+}
+
 extern "C" {
 
 int dmi_job_create(const dmi_attribute* atts, const dmi_corner_table* tables, uint32_t n_atts, const uint32_t* seeds, uint32_t n_seeds,
@@ -566,6 +631,17 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
     }
   }
   if (!std::getenv("DMI_NO_SYM16")) for (auto& a : job->atts) a.sym16 = a.port != kToBits && symbol_bins(a) <= 65536u;
+  // the early stage of a whole-mesh call (EarlyQuant): adopted when this plan is the one it guessed — same values, same packed layouts, same bits
+  if (g_early_quant && !defer && dev && dev->values_on_device && g_early_quant->device == cfg.device && g_early_quant->atts.size() == n_atts) {
+    bool same = true;
+    for (uint32_t i = 0; i < n_atts && same; ++i) {
+      const EarlyQuant::Att& ea = g_early_quant->atts[i];
+      const AttJob& a = job->atts[i];
+      same = ea.values == a.desc.values && ea.n == a.desc.num_unique && !a.desc.point_to_value && a.table == job->atts[0].table && ea.fmt == a.qfmt && ea.fmt != QF_I32 && ea.bits == a.bits && ea.kind == (a.port == kCoordwise ? 0 : 1);
+    }
+    if (same) job->early = std::shared_ptr<EarlyQuant>(g_early_quant.release());
+  }
+  g_early_quant.reset();   // (not this job's plan: the early kernels finish on their stream and their memory goes back to the pool)
   for (auto& a : job->atts) {   // fan rows of the tables a fused sweep runs on: the corner table re-laid out per coded vertex
     if (a.fused_nrm < 0 && a.fused_uv < 0) continue;
     TableDev& t = job->tables[a.table];
@@ -611,6 +687,8 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
       if (!dst) return fail(DMI_ERR_HIP, "upload staging overflow");
       if (vbytes >= ((size_t)8 << 20)) parallel_for(vbytes, [&](size_t lo, size_t hi) { std::memcpy(static_cast<uint8_t*>(dst) + lo, static_cast<const uint8_t*>(d.values) + lo, hi - lo); });
       else if (vbytes) std::memcpy(dst, d.values, vbytes);
+    } else if (job->early) {
+      // (no copy of the raw values: ranges and quantization ran on the caller's arrays, the pass gathers the packed values)
     } else {
       rc = upload(a.raw, d.values, vbytes, s, dev && dev->values_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
       if (rc) return rc;

@@ -218,8 +218,10 @@ struct StreamHolder {
 };
 extern thread_local std::shared_ptr<StreamHolder> g_adopt_stream;   // set by a dmi_meshes_prepare worker around dmi_job_create
 
+namespace dmi { struct EarlyQuant; }   // (below, behind TempDev)
 struct dmi_job {
   dmi_config cfg{};
+  std::shared_ptr<EarlyQuant> early;   // (whole-mesh one-shot calls: see EarlyQuant)
   hipStream_t stream = nullptr;
   std::shared_ptr<StreamHolder> stream_owner;   // set when the library created the stream
   DevPool pool;   // (declared before every DevMem of the job: destroyed after them)
@@ -336,6 +338,29 @@ struct TempDev {
   ~TempDev() { if (!owner_waits && !pool.chunks.empty()) (void)hipStreamSynchronize(pool.stream); }   // (nothing may still be using a chunk when the cache hands it to the next taker)
   template <class T> T* take(size_t n) { return static_cast<T*>(pool.take((n ? n : 1) * sizeof(T))); }
 };
+
+// Early stage of a whole-mesh call whose values are already in HBM (dmi_encode_mesh_device): value ranges and the quantization in VALUE order, into the
+// packed layouts of a fused sweep, issued on a side stream BEFORE the host's serial walks — the device has ≈ 90 ms of nothing to do there — so that
+// the pass, once a sequence exists, only gathers one 16-byte record per entry into coding order (dmi_kernels.hip k_seq_gather_rec).  Meshes whose
+// attributes are all per-point (no point → value map).  Adopted by the job the call
+// creates when the job's plan (formats, bits) is the one guessed here; dropped otherwise (the job then quantizes as always).
+struct EarlyQuant {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  TempDev mem;
+  hipEvent_t t0 = nullptr, t1 = nullptr;   // around the early kernels (t1 = "the packed values are there")
+  struct Att { const void* values; uint32_t n; int N, kind, fmt, bits; uint8_t* slot /* [small 64 B][meta 64 B] like a job's slab slot */; };
+  void* rec = nullptr;   // n records of 16 bytes: the quantized position | texture coordinate | normal of value v (dmi_kernels.hip QuantRec)
+  std::vector<Att> atts;
+  ~EarlyQuant() {
+    if (stream) (void)hipStreamSynchronize(stream);
+    if (t0) (void)hipEventDestroy(t0);
+    if (t1) (void)hipEventDestroy(t1);
+  }
+};
+extern thread_local std::unique_ptr<EarlyQuant> g_early_quant;   // set by dmi_encode_mesh_device around mesh_prepare_impl; taken by job_create_impl
+int early_quantize_issue(const dmi_attribute* atts_dev, uint32_t n_atts, const dmi_config& cfg, hipStream_t side, std::unique_ptr<EarlyQuant>& out);
+
 
 // Attribute corner tables of one connectivity group on the device (dmi_conn.hip k_att_*): one item per (mesh of the group, non-position
 // attribute) whose point → value map is not the position map entry for entry (such an attribute has no seam but the boundary).  The tables

@@ -595,7 +595,16 @@ int dmi_encode_mesh_device(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buff
   const DeviceMeshSrc src{mesh->faces, mesh->atts[0].point_to_value};
   dmi_buffer head{}, att{};
   dmi_job* job = nullptr;
-  struct OneShot { OneShot() { g_one_shot_call = true; } ~OneShot() { g_one_shot_call = false; } } one_shot;
+  struct OneShot { OneShot() { g_one_shot_call = true; } ~OneShot() { g_one_shot_call = false; g_early_quant.reset(); } } one_shot;
+  // The values are in HBM and the device is about to idle through ≈ 90 ms of host walks (10M triangles): value ranges and the quantization in value
+  // order run NOW, on the second group stream; the pass after the walks gathers packed values (EarlyQuant).  Large meshes only: a small mesh's encode
+  // is bound by launches and runs its phase A from a captured graph.
+  if (mesh->num_faces >= kDeviceTablesMinFaces) {
+    dmi_config ec = cfg ? *cfg : dmi_config{};
+    ec.device = device;
+    hipStream_t s_early = library_group_stream(device, 1);
+    if (s_early) (void)early_quantize_issue(mesh->atts, mesh->num_atts, ec, s_early, g_early_quant);
+  }
   int rc = mesh_prepare_impl(&shadow, cfg, &head, &job, &src);
   std::vector<std::vector<uint8_t>> host_values;
   if (rc == kNeedHostValues) {   // outside the order-free class: the reference's serial walks and the host relabelling read everything on the host

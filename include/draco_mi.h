@@ -117,6 +117,9 @@ typedef struct dmi_timings {
   uint32_t texcoord_fixups;  /* texture-coordinate entries of the fused sweep whose operands were outside its exact f64 tier: predicted by the general i64 form (k_texcoord_fixup) */
   float job_create_device_ms;   /* whole-mesh calls: device span of job creation (first launch → last, hipEvents on the job's stream): coding-order
                                    relabelling, map compositions, fan rows, buffer clears — what the quantize+predict pass presupposes per call */
+  float early_ms;               /* dmi_encode_mesh_device: value ranges + value-order quantization issued on a side stream BEFORE the host's serial
+                                   walks (hipEvents on that stream); 0 when the call had no early stage.  quantize_ms then covers the coding-order
+                                   gather of the packed values only */
 } dmi_timings;
 /* Timings of the last dmi_encode_mesh / dmi_encode_mesh_device / dmi_encode_attributes call of the calling thread (per-stage device
  * times when that call's dmi_config carried DMI_FLAG_TIMINGS). */

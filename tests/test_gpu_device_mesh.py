@@ -38,3 +38,40 @@ def test_soup_from_hbm_takes_the_host_walks():
         except orc.OracleError:
             continue
         _assert_same(dmi.encode_mesh_device(dmi.DeviceMesh.upload(mesh)), want, f"soup {seed} (device-resident mesh)")
+
+
+@pytest.mark.parametrize("n,normals,uvs,bits", [(200, True, True, None), (230, True, False, None), (210, False, True, None), (190, False, False, None), (220, True, True, (14, 12)),
+                                                 (200, True, True, (22, 10)), (200, True, True, (11, 17))])
+def test_early_quantization_before_the_walks_gives_the_same_bytes(n, normals, uvs, bits, monkeypatch):
+    """A mesh in HBM of ≥ 2^16 faces has its value ranges and its quantization (value order, packed layouts) issued on a side stream BEFORE the host's
+    serial walks; the pass then only gathers the packed values into coding order (k_seq_gather_packed).  Same bytes as the oracle's and as the call
+    with the early stage off; the stage is entered exactly when the fused sweep's packed layouts apply (positions ≤ 21 bits, UVs ≤ 16 bits)."""
+    mesh = synth.torus_mesh(n, normals=normals, uvs=uvs, seed=900 + n)
+    assert len(mesh.faces) >= 1 << 16
+    cfg = dmi.Config(flags=dmi.FLAG_TIMINGS) if bits is None else dmi.Config(pos_bits=bits[0], uv_bits=bits[1], flags=dmi.FLAG_TIMINGS)
+    kw = {} if bits is None else dict(pos_bits=bits[0], uv_bits=bits[1])
+    want = oracle_from_product_mesh(mesh).encode(**kw)
+    dm = dmi.DeviceMesh.upload(mesh)
+    got = dmi.encode_mesh_device(dm, cfg)
+    entered = dmi.last_call_timings()["early_ms"] > 0
+    _assert_same(got, want, f"early stage, grid {n} {kw}")
+    packed_layouts = (normals or uvs) and (bits is None or (bits[0] <= 21 and (not uvs or bits[1] <= 16)))   # (positions alone are no fused sweep)
+    assert entered == packed_layouts
+    monkeypatch.setenv("DMI_NO_EARLY", "1")
+    assert dmi.encode_mesh_device(dm, cfg) == got and dmi.last_call_timings()["early_ms"] == 0
+
+
+def test_early_stage_is_dropped_when_an_attribute_has_seams_of_its_own():
+    """The early stage guesses the fused sweep's layouts before any corner table exists; a UV attribute with interior seams leaves the sweep — the job's
+    plan then differs from the guess, the early result is dropped and the job quantizes as always.  Same bytes as the oracle's."""
+    faces, pos, nrm, uv = synth.seam_torus_rows(190, seed=5)
+    b = dmi.MeshBuilder()
+    pid = b.add_attribute(pos, dmi.ATT_POSITION)
+    b.add_attribute(nrm, dmi.ATT_NORMAL, dmi.DOMAIN_CORNER, parents=[pid])
+    b.add_attribute(uv, dmi.ATT_TEXCOORD, dmi.DOMAIN_CORNER, parents=[pid])
+    b.set_connectivity_attribute(faces)
+    mesh = b.build()
+    assert len(mesh.faces) >= 1 << 16
+    want = oracle_from_product_mesh(mesh).encode()
+    got = dmi.encode_mesh_device(dmi.DeviceMesh.upload(mesh), dmi.Config(flags=dmi.FLAG_TIMINGS))
+    _assert_same(got, want, "seam torus from HBM")
