@@ -450,6 +450,21 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
   };
   bool device_relabel = F >= kDeviceRelabelMinFaces || dev != nullptr;
   if (const char* e = std::getenv("DMI_RELABEL")) device_relabel = std::strcmp(e, "device") == 0 ? true : (std::strcmp(e, "host") == 0 ? (dev != nullptr) : device_relabel);
+  // A one-shot call (create → encode → destroy) whose attributes ALL ride one fused sweep does not re-order its faces: the sweep reads fan rows, the
+  // rows are built once from (seq, c2r, opp) in any numbering the three agree on, and the coding-order relabelling — a locality measure for the
+  // per-attribute kernels that chase opp / c2r in every encode — would be paid (face keys, counting sort, table remap: 0.65 ms of kernels per 10M
+  // faces) to be used exactly once, by the fan build.  The bitstream does not depend on internal face ids (tests: both forms against the oracle).
+  bool plain_order = false;
+  if (!defer && dev && dev->trusted_sequences && g_one_shot_call && n_atts >= 2 && !std::getenv("DMI_NO_FUSED") && !std::getenv("DMI_NO_PLAIN_ORDER")) {
+    const AttJob& p = job->atts[0];
+    int n_nrm = 0, n_uv = 0;
+    bool all = p.scheme == kParallelogram && p.nq == 3 && job->tables[0].alias_of < 0 && p.table == 0;
+    for (uint32_t i = 1; i < n_atts && all; ++i) {
+      const AttJob& a = job->atts[i];
+      all = (a.scheme == kNormal || a.scheme == kTexCoord) && a.parent == 0 && a.table == 0 && (a.scheme == kNormal ? ++n_nrm : ++n_uv) == 1;
+    }
+    plain_order = all;
+  }
   TempDev tmpdev;
   {
     size_t hint = (size_t)64 << 10;
@@ -487,6 +502,22 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
       defer->host_c2v.push_back(resident ? nullptr : tables[i].corner_to_vertex);
       defer->host_opp.push_back(resident ? nullptr : tables[i].opposite);
     }
+  } else if (device_relabel && plain_order) {
+    // The mesh's own face order (see plain_order above): ranks, c2r = rank ∘ c2v, the device stage's opposite corners as they are, the sequence as the
+    // host walk wrote it.  No face keys, no counting sort, no table remap: 0.4 ms of kernels instead of 1.05 for 10M faces.
+    TableDev& t = job->tables[0];
+    uint32_t* d_rank = tmpdev.take<uint32_t>(t.V ? t.V : 1);
+    if (!d_rank) return fail(DMI_ERR_OUT_OF_MEMORY, "hipMalloc (relabelling temporaries)");
+    if ((rc = t.c2r.alloc(C * 4))) return rc;
+    if ((rc = t.opp.alloc(C * 4))) return rc;
+    if ((rc = t.seq.alloc((size_t)t.n_seq * 4))) return rc;
+    if ((rc = t.s2p.alloc((size_t)t.n_seq * 4))) return rc;
+    if (t.n_seq) HIP_TRY(hipMemcpyAsync(t.seq.p, seq_of[0], (size_t)t.n_seq * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(t.opp.p, dev->opp, C * 4, hipMemcpyDeviceToDevice, s));
+    launch_fill_u32(d_rank, t.V, kNone, s);
+    launch_rank_scatter(t.seq.as<uint32_t>(), t.n_seq, dev->c2v, d_rank, s);
+    launch_corner_ranks(dev->c2v, d_rank, C, t.c2r.as<uint32_t>(), s);
+    launch_seq_points(t.seq.as<uint32_t>(), t.n_seq, dev->c2p, t.s2p.as<uint32_t>(), s);
   } else if (device_relabel) {
     uint32_t max_seq = 0, max_v = 0;
     for (uint32_t i = 0; i < n_atts; ++i) if (job->tables[i].alias_of < 0) { max_seq = std::max(max_seq, job->tables[i].n_seq); max_v = std::max(max_v, job->tables[i].V); }

@@ -86,6 +86,16 @@ __global__ __launch_bounds__(kBlock) void k_remap_seq(const uint32_t* __restrict
   }
 }
 
+// The tables of a one-shot job whose attributes all ride the fused sweep stay in the mesh's OWN face order (round 5): the sweep reads fan rows, and
+// the rows are built from (seq, c2r, opp) in whatever numbering these three agree on — only the ranks are needed:
+//   c2r[c] = rank[c2v[c]] for every corner (streaming over c2v, gathers into the rank array);  s2p[k] = corner_to_point[seq[k]]
+__global__ __launch_bounds__(kBlock) void k_corner_ranks(const uint32_t* __restrict__ c2v, const uint32_t* __restrict__ rank, uint64_t C, uint32_t* __restrict__ c2r) {
+  for (uint64_t c = (uint64_t)blockIdx.x * kBlock + threadIdx.x; c < C; c += (uint64_t)gridDim.x * kBlock) c2r[c] = rank[c2v[c]];
+}
+__global__ __launch_bounds__(kBlock) void k_seq_points(const uint32_t* __restrict__ seq, uint32_t n_seq, const uint32_t* __restrict__ c2p, uint32_t* __restrict__ s2p) {
+  for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n_seq; k += gridDim.x * kBlock) s2p[k] = c2p[seq[k]];
+}
+
 // s2v[k] = point_to_value[s2p[k]];  *bad |= 1 when a value index is out of range (reported by the host as an error code)
 __global__ __launch_bounds__(kBlock) void k_compose_s2v(const uint32_t* __restrict__ s2p, uint32_t n_seq, const uint32_t* __restrict__ p2v, uint32_t num_points, uint32_t num_unique,
                                                         uint32_t* __restrict__ s2v, uint32_t* __restrict__ bad) {
@@ -189,6 +199,8 @@ void launch_remap_table(const uint32_t* c2v, const uint32_t* opp, const uint32_t
 void launch_remap_seq(const uint32_t* seq, uint32_t n_seq, const uint32_t* new_face, const uint32_t* c2p, uint32_t* seq_out, uint32_t* s2p_out, hipStream_t s) {
   if (n_seq) hipLaunchKernelGGL(k_remap_seq, grid_of(n_seq), kBlock, 0, s, seq, n_seq, new_face, c2p, seq_out, s2p_out);
 }
+void launch_corner_ranks(const uint32_t* c2v, const uint32_t* rank, uint64_t C, uint32_t* c2r, hipStream_t s) { if (C) hipLaunchKernelGGL(k_corner_ranks, grid_of(C), kBlock, 0, s, c2v, rank, C, c2r); }
+void launch_seq_points(const uint32_t* seq, uint32_t n_seq, const uint32_t* c2p, uint32_t* s2p, hipStream_t s) { if (n_seq) hipLaunchKernelGGL(k_seq_points, grid_of(n_seq), kBlock, 0, s, seq, n_seq, c2p, s2p); }
 void launch_compose_s2v(const uint32_t* s2p, uint32_t n_seq, const uint32_t* p2v, uint32_t num_points, uint32_t num_unique, uint32_t* s2v, uint32_t* bad, hipStream_t s) {
   if (n_seq) hipLaunchKernelGGL(k_compose_s2v, grid_of(n_seq), kBlock, 0, s, s2p, n_seq, p2v, num_points, num_unique, s2v, bad);
 }
