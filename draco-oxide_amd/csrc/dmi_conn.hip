@@ -111,7 +111,7 @@ __device__ __forceinline__ void mesh_max(uint32_t* dst, uint32_t m, uint32_t v, 
 
 // ---- universal corner tables of a batch ----
 // per face: vertex ids (through the position map), range / degenerate checks, half-edge counts per bucket (= smaller endpoint of the
-// edge), first corner per vertex, largest vertex id per mesh
+// edge), a corner per vertex, largest vertex id per mesh
 __global__ __launch_bounds__(kBlock) void k_conn_faces(const ConnArgs a) {
   uint32_t cur_m = kNoneD, cur_max = 0;   // largest vertex id seen for mesh cur_m (a single large mesh: the grid is capped and every thread loops)
   for (uint32_t f = blockIdx.x * kBlock + threadIdx.x; f < a.total_faces; f += gridDim.x * kBlock) {
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kBlock) void k_conn_faces(const ConnArgs a) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       a.opp[3ull * f + (k + 2) % 3] = atomicAdd(&a.ecount[d.vert_off + min(v[k], v[(k + 1) % 3])], 1u);
-      atomicMin(&a.first[d.vert_off + v[k]], 3u * lf + k);
+      a.first[d.vert_off + v[k]] = 3u * lf + k;   // SOME corner of the vertex (a plain store: whichever face writes last wins); k_conn_vertices finds the smallest one of the fan itself
     }
     cur_max = max(cur_max, max(v[0], max(v[1], v[2])));
   }
@@ -201,13 +201,19 @@ __global__ __launch_bounds__(kBlock) void k_conn_vertices(const ConnArgs a) {
     uint8_t* __restrict__ done = a.cdone + cb;
     auto swing_left = [&](uint32_t x) { const uint32_t o = opp[cnext(x)]; return o == kNoneD ? kNoneD : cnext(o); };
     auto swing_right = [&](uint32_t x) { const uint32_t o = opp[cprev(x)]; return o == kNoneD ? kNoneD : cprev(o); };
-    uint32_t left = c, x = swing_left(c), steps = 0;
+    // The reference walks the corners in order and swings left from the FIRST (smallest) corner of the vertex (mod.rs:342-416): an open fan ends at
+    // its left-most corner wherever the walk started; a closed fan's "left-most" corner is the last one met before the walk is back at that smallest
+    // corner, i.e. swing_right(smallest).  c is just some corner of the vertex (round 5: k_conn_faces no longer pays three atomicMin per face to
+    // know the smallest — the walk visits every corner of a closed fan anyway and keeps the minimum).
+    uint32_t left = c, x = swing_left(c), steps = 0, smallest = c;
     done[c] = 1;
-    while (x != kNoneD && x != c && steps < (1u << 20)) { done[x] = 1; left = x; x = swing_left(x); ++steps; }
+    while (x != kNoneD && x != c && steps < (1u << 20)) { done[x] = 1; left = x; smallest = min(smallest, x); x = swing_left(x); ++steps; }
     if (steps >= (1u << 20)) { raise(a.flags, m, CONN_MULTI_FAN); continue; }
     if (x == kNoneD) {   // open fan: the corners to the right of c
       steps = 0;
       for (uint32_t r = swing_right(c); r != kNoneD && steps < (1u << 20); r = swing_right(r), ++steps) done[r] = 1;
+    } else {
+      left = swing_right(smallest);   // (closed: never none)
     }
     a.lmc[gv] = left;
     a.on_boundary[gv] = opp[cnext(left)] == kNoneD ? 1 : 0;
