@@ -341,6 +341,7 @@ __global__ __launch_bounds__(kBlock) void k_rl_keys(const RelabelBatch b) {
   for (uint32_t g = blockIdx.x * kBlock + threadIdx.x; g < b.total_faces; g += gridDim.x * kBlock) {
     const RelabelItem& it = b.items[find_item(b.items, b.n_items, g, [](const RelabelItem& x) { return x.face_off; })];
     const uint32_t f = g - it.face_off;
+    if (it.plain) { if (f == 0) b.count[it.key_off] = it.F; continue; }   // (no order of its own, but its faces keep their places in the batch's position space: the scan below runs over all items)
     const uint32_t* r = b.rank + it.vert_off;
     const uint32_t m = min(r[it.c2v[3ull * f]], min(r[it.c2v[3ull * f + 1]], r[it.c2v[3ull * f + 2]]));
     const uint32_t key = m == kNoneD ? it.n_seq : m;
@@ -352,6 +353,7 @@ __global__ __launch_bounds__(kBlock) void k_rl_keys(const RelabelBatch b) {
 __global__ __launch_bounds__(kBlock) void k_rl_place(const RelabelBatch b) {
   for (uint32_t g = blockIdx.x * kBlock + threadIdx.x; g < b.total_faces; g += gridDim.x * kBlock) {
     const RelabelItem& it = b.items[find_item(b.items, b.n_items, g, [](const RelabelItem& x) { return x.face_off; })];
+    if (it.plain) continue;
     b.order[b.count[it.key_off + b.key[g]] + b.new_face[g]] = g - it.face_off;
   }
 }
@@ -360,6 +362,7 @@ __global__ __launch_bounds__(kBlock) void k_rl_sort_buckets(const RelabelBatch b
   for (uint32_t g = blockIdx.x * kBlock + threadIdx.x; g < b.total_keys; g += gridDim.x * kBlock) {
     const uint32_t lo = b.count[g], hi = b.count[g + 1];
     if (hi <= lo) continue;
+    if (b.items[find_item(b.items, b.n_items, g, [](const RelabelItem& x) { return x.key_off; })].plain) continue;
     uint32_t* o = b.order;
     for (uint32_t i = lo + 1; i < hi; ++i) {   // insertion sort
       const uint32_t v = o[i];
@@ -381,6 +384,7 @@ __global__ __launch_bounds__(kBlock) void k_rl_remap(const RelabelBatch b) {
     const RelabelItem& it = b.items[find_item(b.items, b.n_items, gf, [](const RelabelItem& x) { return x.remap_off; })];
     const uint32_t uf = b.items[it.order_item].face_off;
     const uint32_t f2 = gf - it.remap_off, c2 = 3u * f2 + k;
+    if (it.plain) { it.c2r[c2] = b.rank[it.vert_off + it.c2v[c2]]; it.opp_out[c2] = it.opp[c2]; continue; }   // the mesh's own face order
     const uint32_t c = 3u * b.order[uf + f2] + k;
     it.c2r[c2] = b.rank[it.vert_off + it.c2v[c]];
     it.opp_out[c2] = map_corner(it.opp[c], b.new_face + uf);
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(kBlock) void k_rl_seq(const RelabelBatch b) {
   for (uint32_t g = blockIdx.x * kBlock + threadIdx.x; g < b.total_seq; g += gridDim.x * kBlock) {
     const RelabelItem& it = b.items[find_item(b.items, b.n_items, g, [](const RelabelItem& x) { return x.seq_off; })];
     const uint32_t k = g - it.seq_off, c = it.seq[k];
-    it.seq_out[k] = map_corner(c, b.new_face + b.items[it.order_item].face_off);
+    it.seq_out[k] = it.plain ? c : map_corner(c, b.new_face + b.items[it.order_item].face_off);
     it.s2p[k] = it.c2p[c];
   }
 }
@@ -456,10 +460,12 @@ void launch_att_tables(const ConnArgs& a, const AttArgs& t, hipStream_t s) {
 void launch_relabel_batch(const RelabelBatch& b, hipStream_t s) {
   if (!b.n_items || !b.total_faces) return;
   hipLaunchKernelGGL(k_rl_rank, grid_of(b.total_seq), kBlock, 0, s, b);
-  hipLaunchKernelGGL(k_rl_keys, grid_of(b.total_faces), kBlock, 0, s, b);
-  launch_exclusive_scan_u32(b.count, b.total_keys + 1, b.scan_partials, s);
-  hipLaunchKernelGGL(k_rl_place, grid_of(b.total_faces), kBlock, 0, s, b);
-  hipLaunchKernelGGL(k_rl_sort_buckets, grid_of(b.total_keys), kBlock, 0, s, b);
+  if (b.any_sorted) {
+    hipLaunchKernelGGL(k_rl_keys, grid_of(b.total_faces), kBlock, 0, s, b);
+    launch_exclusive_scan_u32(b.count, b.total_keys + 1, b.scan_partials, s);
+    hipLaunchKernelGGL(k_rl_place, grid_of(b.total_faces), kBlock, 0, s, b);
+    hipLaunchKernelGGL(k_rl_sort_buckets, grid_of(b.total_keys), kBlock, 0, s, b);
+  }
   hipLaunchKernelGGL(k_rl_remap, grid_of(3ull * b.total_remap_faces), kBlock, 0, s, b);
   hipLaunchKernelGGL(k_rl_seq, grid_of(b.total_seq), kBlock, 0, s, b);
 }

@@ -309,10 +309,11 @@ struct RelabelItem {
   const uint32_t *c2p, *c2v, *opp, *seq;
   uint32_t F, V, n_seq, order_item /* index of the item whose face order this table follows (itself for a universal table) */;
   uint32_t face_off, vert_off, key_off /* Σ (n_seq + 1) */, seq_off;   // this table's slices of the batch scratch arrays (face_off / key_off: universal tables only)
-  uint32_t remap_off /* Σ F of the items before: the corner space of k_rl_remap */, pad0, pad1, pad2;
+  uint32_t remap_off /* Σ F of the items before: the corner space of k_rl_remap */, plain /* 1: the job keeps the mesh's own face order (a one-shot job whose attributes all ride the fused sweep: DESIGN §3) — ranks, c2r and s2p only */, pad1, pad2;
   uint32_t *c2r, *opp_out, *seq_out, *s2p;
 };
 struct RelabelBatch {
+  uint32_t any_sorted = 1;   // 0: every item is plain — the counting-sort launches are skipped
   const RelabelItem* items; uint32_t n_items, total_faces /* universal tables */, total_verts, total_keys, total_seq, total_remap_faces /* all tables */;
   uint32_t* rank;          // total_verts, filled with DMI_NONE
   uint32_t* key;           // total_faces

@@ -455,7 +455,7 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
   // per-attribute kernels that chase opp / c2r in every encode — would be paid (face keys, counting sort, table remap: 0.65 ms of kernels per 10M
   // faces) to be used exactly once, by the fan build.  The bitstream does not depend on internal face ids (tests: both forms against the oracle).
   bool plain_order = false;
-  if (!defer && dev && dev->trusted_sequences && g_one_shot_call && n_atts >= 2 && !std::getenv("DMI_NO_FUSED") && !std::getenv("DMI_NO_PLAIN_ORDER")) {
+  if (dev && dev->trusted_sequences && (defer || g_one_shot_call) && n_atts >= 2 && !std::getenv("DMI_NO_FUSED") && !std::getenv("DMI_NO_PLAIN_ORDER")) {   // (a batch's jobs are one-shot too)
     const AttJob& p = job->atts[0];
     int n_nrm = 0, n_uv = 0;
     bool all = p.scheme == kParallelogram && p.nq == 3 && job->tables[0].alias_of < 0 && p.table == 0;
@@ -496,7 +496,7 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
       r.c2p = dev->c2p; r.c2v = resident ? dev->c2v : nullptr; r.opp = resident ? dev->opp : nullptr; r.seq = seq_of[i];
       for (uint32_t k = 0; k < dev->n_att && !resident; ++k)   // an attribute table the device built: its device copies
         if (dev->att_key[k] == tables[i].corner_to_vertex) { r.c2v = dev->att_c2v[k]; r.opp = dev->att_opp[k]; resident = true; }
-      r.F = F; r.V = t.V; r.n_seq = t.n_seq; r.order_item = 0;
+      r.F = F; r.V = t.V; r.n_seq = t.n_seq; r.order_item = 0; r.plain = plain_order ? 1u : 0u;
       r.c2r = t.c2r.as<uint32_t>(); r.opp_out = t.opp.as<uint32_t>(); r.seq_out = t.seq.as<uint32_t>(); r.s2p = t.s2p.as<uint32_t>();
       defer->relabels.push_back(r);
       defer->host_c2v.push_back(resident ? nullptr : tables[i].corner_to_vertex);

@@ -534,6 +534,8 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     HIP_TRY(hipMemsetAsync(b.rank, 0xFF, (size_t)(rv ? rv : 1) * 4, S));
     HIP_TRY(hipMemsetAsync(b.count, 0, nk * 4, S));
     b.items = reinterpret_cast<const RelabelItem*>(d2 + off_items); b.n_items = (uint32_t)items.size();
+    b.any_sorted = 0;
+    for (const RelabelItem& it : items) if (!it.plain) b.any_sorted = 1;
     b.total_faces = (uint32_t)rf; b.total_verts = (uint32_t)rv; b.total_keys = (uint32_t)rk; b.total_seq = (uint32_t)rs; b.total_remap_faces = (uint32_t)rr;
     launch_clear_items(reinterpret_cast<const CopyItem*>(d2 + off_clears), (uint32_t)clears.size(), S);
     launch_scatter_items(reinterpret_cast<const CopyItem*>(d2 + off_copies), (uint32_t)copies.size(), base, S);
