@@ -497,7 +497,7 @@ def main():
                          "traffic": int(traffic) if traffic else None,
                          "traffic_profiled": profiled_traffic(),
                          "kernel": ("quantize+predict pass of a call whose values are in HBM when it starts = every launch of the job's stream between the end of the host walks and the "
-                                    "histogram stage (coding-order gather of the PACKED values, min/max finals, fused predictor sweep); value ranges and the quantization itself (value order, "
+                                    "histogram stage (coding-order gather of the PACKED values, fused predictor sweep, fix-up of deferred entries); value ranges, the quantization itself and the quantized values' joint min/max (value order, "
                                     "streaming) are issued on a side stream BEFORE the walks — 90 ms of an otherwise idle device — and are reported as early_stage_ms / with_early_stage"
                                     if stages["early_ms"] > 0 else
                                     "quantize+predict pass = every launch between the first kernel and the histogram stage of one step "

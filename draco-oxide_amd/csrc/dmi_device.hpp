@@ -63,8 +63,9 @@ struct QuantArgs { QuantAtt a[kMaxGather]; int count; };
 struct SeqQuantArgs { const uint32_t* s2p /* null: value order (entry i reads value i) */; uint32_t n; uint32_t pad; const uint32_t* dest; QuantArgs q; };
 // The early stage of a whole-mesh call (dmi_kernels.hip): rec[v] = the quantized position / normal / texture coordinate of value v in one 16-byte record
 // (value order; nrm / uv null: the mesh has none), then qs_*[i] = the fields of rec[s2p[i]] + per-block joint i32 min/max partials per attribute
-struct ValueRecArgs { const float *pos, *nrm, *uv; const float *pos_meta, *uv_meta; float pos_maxq, uv_maxq; uint32_t n; uint32_t pad; void* rec; };
-struct GatherRecArgs { const uint32_t* s2p; uint32_t n; uint32_t pad; const void* rec; uint64_t* qs_pos; uint16_t* qs_nrm; uint32_t* qs_uv; int32_t* ipartials[3] /* position, normal, texture coordinate */; };
+struct ValueRecArgs { const float *pos, *nrm, *uv; const float *pos_meta, *uv_meta; float pos_maxq, uv_maxq; uint32_t n; uint32_t pad; void* rec; int32_t* ipartials[3] /* position, normal, texture coordinate: 2 * value_quantize_rec_blocks(n) words each */; };
+struct GatherRecArgs { const uint32_t* s2p; uint32_t n; uint32_t pad; const void* rec; uint64_t* qs_pos; uint16_t* qs_nrm; uint32_t* qs_uv; const uint32_t* slot_src[3]; uint32_t* slot_dst[3] /* 32 words each, null = none */; };
+uint32_t value_quantize_rec_blocks(uint32_t n);
 void launch_value_quantize_rec(const ValueRecArgs& a, hipStream_t s);
 void launch_seq_gather_rec(const GatherRecArgs& g, hipStream_t s);
 void launch_seq_quantize(const uint32_t* s2p, const uint32_t* dest, uint32_t n, const QuantArgs& args, hipStream_t s);

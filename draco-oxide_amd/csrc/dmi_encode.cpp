@@ -16,11 +16,7 @@ int encode_phase_a(dmi_job* job, bool plan_only) {   // device: ranges → codin
   const bool timed = job->have_events;
   // ---- stage 1: value ranges (streamed over the unique values) ---------------------------------------------
   const bool early = job->early != nullptr && !plan_only;   // ranges + quantization ran before the host walks (EarlyQuant): the pass gathers packed values
-  if (early) {
-    HIP_TRY(hipStreamWaitEvent(s, job->early->t1, 0));
-    for (size_t i = 0; i < job->atts.size(); ++i)   // the ranges, the seeded scratch words and the zero-normal flag into the job's slab slot ([small 64 B][meta 64 B])
-      HIP_TRY(hipMemcpyAsync(job->atts[i].small.p, job->early->atts[i].slot, 128, hipMemcpyDeviceToDevice, s));
-  }
+  if (early) HIP_TRY(hipStreamWaitEvent(s, job->early->t1, 0));
   if (timed) HIP_TRY(hipEventRecord(job->ev[0], s));
   if (!early) {
     RangeArgs ra{};
@@ -51,9 +47,11 @@ int encode_phase_a(dmi_job* job, bool plan_only) {   // device: ranges → codin
       ga.s2p = t.s2p.as<uint32_t>(); ga.n = t.n_seq; ga.rec = job->early->rec;
       for (size_t i = 0; i < job->atts.size(); ++i) {
         AttJob& a = job->atts[i];
-        if (a.qfmt == QF_P64) { ga.qs_pos = a.qs.as<uint64_t>(); ga.ipartials[0] = a.ipartials.as<int32_t>(); }
-        else if (a.qfmt == QF_B16) { ga.qs_nrm = a.qs.as<uint16_t>(); ga.ipartials[1] = a.ipartials.as<int32_t>(); }
-        else { ga.qs_uv = a.qs.as<uint32_t>(); ga.ipartials[2] = a.ipartials.as<int32_t>(); }
+        // the ranges, the joint min/max, the seeded scratch words and the zero-normal flag into the job's slab slot ([small 64 B][meta 64 B]): the gather's first block
+        ga.slot_src[i] = reinterpret_cast<const uint32_t*>(job->early->atts[i].slot); ga.slot_dst[i] = a.small.as<uint32_t>();
+        if (a.qfmt == QF_P64) ga.qs_pos = a.qs.as<uint64_t>();
+        else if (a.qfmt == QF_B16) ga.qs_nrm = a.qs.as<uint16_t>();
+        else ga.qs_uv = a.qs.as<uint32_t>();
       }
       launch_seq_gather_rec(ga, s);
       continue;
@@ -79,7 +77,7 @@ int encode_phase_a(dmi_job* job, bool plan_only) {   // device: ranges → codin
     }
     flush();
   }
-  {
+  if (!early) {   // (an early stage left the min/max in the slot words copied above)
     MinMaxArgs ma{};
     for (auto& a : job->atts) {
       MinMaxAtt& m = ma.a[ma.count++];

@@ -248,7 +248,7 @@ int dmi::early_quantize_issue(const dmi_attribute* atts, uint32_t n_atts, const 
   }
   if (i_pos != 0 || (i_nrm < 0 && i_uv < 0)) return DMI_OK;   // (positions alone are no fused sweep)
   const uint32_t n = atts[0].num_unique;
-  e->mem.init(cfg.device, side, (size_t)n * 16 + e->atts.size() * ((size_t)kRangeMaxBlocks * 8 * 4 + 4096) + ((size_t)1 << 16));
+  e->mem.init(cfg.device, side, (size_t)n * 16 + e->atts.size() * ((size_t)kRangeMaxBlocks * 8 * 4 + (size_t)value_quantize_rec_blocks(n) * 8 + 8192) + ((size_t)1 << 16));
   e->rec = e->mem.take<uint8_t>((size_t)n * 16);
   if (!e->rec) return DMI_OK;   // (no memory to spare: the job quantizes as always)
   RangeArgs ra{};
@@ -280,7 +280,20 @@ int dmi::early_quantize_issue(const dmi_attribute* atts, uint32_t n_atts, const 
     va.uv_maxq = (float)(uint64_t)((1ull << e->atts[(size_t)i_uv].bits) - 1ull);
   }
   va.n = n; va.rec = e->rec;
+  // the joint i32 min/max of each attribute's quantized values (the wrapped difference's, wrapped_difference.rs:36-52) come out of the same pass:
+  // partial pairs per block, folded into the slot's first two words — where the sweep reads them once the job has copied the slot
+  MinMaxArgs ma{};
+  const int order[3] = {i_pos, i_nrm, i_uv};
+  for (int k = 0; k < 3; ++k) {
+    if (order[k] < 0) continue;
+    int32_t* ip = e->mem.take<int32_t>((size_t)value_quantize_rec_blocks(n) * 2);
+    if (!ip) return DMI_OK;
+    va.ipartials[k] = ip;
+    MinMaxAtt& m = ma.a[ma.count++];
+    m.ipartials = ip; m.minmax = reinterpret_cast<int32_t*>(e->atts[(size_t)order[k]].slot); m.blocks = value_quantize_rec_blocks(n);
+  }
   launch_value_quantize_rec(va, side);
+  launch_i32_minmax_final(ma, side);
   HIP_TRY(hipEventRecord(e->t1, side));
   out = std::move(e);
   return DMI_OK;
@@ -668,7 +681,7 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
     for (uint32_t i = 0; i < n_atts && same; ++i) {
       const EarlyQuant::Att& ea = g_early_quant->atts[i];
       const AttJob& a = job->atts[i];
-      same = ea.values == a.desc.values && ea.n == a.desc.num_unique && !a.desc.point_to_value && a.table == job->atts[0].table && ea.fmt == a.qfmt && ea.fmt != QF_I32 && ea.bits == a.bits && ea.kind == (a.port == kCoordwise ? 0 : 1);
+      same = ea.values == a.desc.values && ea.n == a.desc.num_unique && !a.desc.point_to_value && a.table == job->atts[0].table && job->tables[a.table].n_seq == ea.n /* the sequence holds every value once: the stage's min/max are the sequence's */ && ea.fmt == a.qfmt && ea.fmt != QF_I32 && ea.bits == a.bits && ea.kind == (a.port == kCoordwise ? 0 : 1);
     }
     if (same) job->early = std::shared_ptr<EarlyQuant>(g_early_quant.release());
   }

@@ -438,35 +438,58 @@ __device__ __forceinline__ void k_seq_quantize_body(const SeqQuantArgs& sq, cons
 // (a wavefront-wide gather costs by the distinct lines it touches, not by the bytes it keeps: three attributes were three times the lines).
 // The arithmetic is finish_tile's, call for call: quant_coord per coordinate, oct_quantize for the normal.
 struct alignas(16) QuantRec { uint64_t pos; uint32_t uv; uint16_t nrm; uint16_t pad; };
+// One joint i32 min/max pair per block and attribute as well (wrapped_difference.rs:36-52 takes them over what the SEQUENCE holds: the sequence of a
+// per-point attribute on the position's table holds every value exactly once — job_create_impl adopts the stage only then); k_i32_minmax_final folds them.
 __global__ __launch_bounds__(kBlock) void k_value_quantize_rec(const ValueRecArgs a) {
+  int32_t mn[3], mx[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { mn[k] = 2147483647; mx[k] = (-2147483647 - 1); }
   for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < a.n; v += gridDim.x * kBlock) {
     QuantRec r{0ull, 0u, 0u, 0u};
     {
       const float x = a.pos[3 * (size_t)v], y = a.pos[3 * (size_t)v + 1], z = a.pos[3 * (size_t)v + 2];
-      r.pos = pack_p64(quant_coord(x, a.pos_meta[0], a.pos_meta[3], a.pos_maxq), quant_coord(y, a.pos_meta[1], a.pos_meta[3], a.pos_maxq), quant_coord(z, a.pos_meta[2], a.pos_meta[3], a.pos_maxq));
+      const int32_t q0 = quant_coord(x, a.pos_meta[0], a.pos_meta[3], a.pos_maxq), q1 = quant_coord(y, a.pos_meta[1], a.pos_meta[3], a.pos_maxq), q2 = quant_coord(z, a.pos_meta[2], a.pos_meta[3], a.pos_maxq);
+      r.pos = pack_p64(q0, q1, q2);
+      mn[0] = min(mn[0], min(q0, min(q1, q2))); mx[0] = max(mx[0], max(q0, max(q1, q2)));
     }
     if (a.nrm) {
       int32_t u, w;
       oct_quantize(a.nrm[3 * (size_t)v], a.nrm[3 * (size_t)v + 1], a.nrm[3 * (size_t)v + 2], u, w);
       r.nrm = (uint16_t)((uint32_t)u | ((uint32_t)w << 8));
+      mn[1] = min(mn[1], min(u, w)); mx[1] = max(mx[1], max(u, w));
     }
     if (a.uv) {
       const int32_t qu = quant_coord(a.uv[2 * (size_t)v], a.uv_meta[0], a.uv_meta[2], a.uv_maxq), qw = quant_coord(a.uv[2 * (size_t)v + 1], a.uv_meta[1], a.uv_meta[2], a.uv_maxq);
       r.uv = (uint32_t)qu | ((uint32_t)qw << 16);
+      mn[2] = min(mn[2], min(qu, qw)); mx[2] = max(mx[2], max(qu, qw));
     }
     static_cast<QuantRec*>(a.rec)[v] = r;
   }
+  __shared__ int32_t red[3][2][kBlock / 64];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    int32_t lo = mn[k], hi = mx[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_down(lo, off, 64)); hi = max(hi, __shfl_down(hi, off, 64)); }
+    if ((threadIdx.x & 63) == 0) { red[k][0][threadIdx.x >> 6] = lo; red[k][1][threadIdx.x >> 6] = hi; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3u && a.ipartials[threadIdx.x]) {   // (0 position, 1 normal, 2 texture coordinate)
+    int32_t lo = red[threadIdx.x][0][0], hi = red[threadIdx.x][1][0];
+#pragma unroll
+    for (int w = 1; w < kBlock / 64; ++w) { lo = min(lo, red[threadIdx.x][0][w]); hi = max(hi, red[threadIdx.x][1][w]); }
+    a.ipartials[threadIdx.x][2 * blockIdx.x] = lo;
+    a.ipartials[threadIdx.x][2 * blockIdx.x + 1] = hi;
+  }
 }
-// qs_*[i] = the fields of rec[s2p[i]] + the joint i32 min/max of each attribute over what the SEQUENCE holds (wrapped_difference.rs:36-52).  Four
-// entries per thread, every gather issued before the first is used; tiles are dealt to blocks like every pass over a sequence (an XCD's blocks take
-// one contiguous eighth of it, so that the rings its gathers revisit stay in ITS L2).
+// qs_*[i] = the fields of rec[s2p[i]].  Four entries per thread, every gather issued before the first is used; tiles are dealt to blocks like every
+// pass over a sequence (an XCD's blocks take one contiguous eighth of it, so that the rings its gathers revisit stay in ITS L2).
 constexpr int kGatherPer = 4;
 __global__ __launch_bounds__(kBlock) void k_seq_gather_rec(const GatherRecArgs g) {
-  int32_t mn[3], mx[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) { mn[a] = 2147483647; mx[a] = (-2147483647 - 1); }
   const uint32_t n = g.n;
   const uint32_t blk_ = blockIdx.x, nblk_ = gridDim.x;
+  // the stage's slots ([small 64 B][meta 64 B] per attribute: ranges, min/max, the zero-normal flag) into the job's slab: 32 words each, no copy commands
+  if (blk_ == 0 && threadIdx.x < 96u) { const uint32_t k = threadIdx.x >> 5; if (g.slot_src[k]) g.slot_dst[k][threadIdx.x & 31u] = g.slot_src[k][threadIdx.x & 31u]; }
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   const u32x4* __restrict__ rec = static_cast<const u32x4*>(g.rec);
   DMI_FOR_TILES(base, n, kGatherPer) {
@@ -480,39 +503,10 @@ __global__ __launch_bounds__(kBlock) void k_seq_gather_rec(const GatherRecArgs g
     for (int t = 0; t < kGatherPer; ++t) {
       const uint32_t i = base + t * kBlock + threadIdx.x;
       if (i >= n) continue;
-      const uint64_t pos = (uint64_t)r[t].x | ((uint64_t)r[t].y << 32);
-      g.qs_pos[i] = pos;
-      int32_t o[3];
-      unpack_p64(pos, o);
-      mn[0] = min(mn[0], min(o[0], min(o[1], o[2]))); mx[0] = max(mx[0], max(o[0], max(o[1], o[2])));
-      if (g.qs_uv) {
-        g.qs_uv[i] = r[t].z;
-        const int32_t lo = (int32_t)(r[t].z & 0xFFFFu), hi = (int32_t)(r[t].z >> 16);
-        mn[2] = min(mn[2], min(lo, hi)); mx[2] = max(mx[2], max(lo, hi));
-      }
-      if (g.qs_nrm) {
-        const uint32_t w = r[t].w & 0xFFFFu;
-        g.qs_nrm[i] = (uint16_t)w;
-        const int32_t lo = (int32_t)(w & 0xFFu), hi = (int32_t)(w >> 8);
-        mn[1] = min(mn[1], min(lo, hi)); mx[1] = max(mx[1], max(lo, hi));
-      }
+      g.qs_pos[i] = (uint64_t)r[t].x | ((uint64_t)r[t].y << 32);
+      if (g.qs_uv) g.qs_uv[i] = r[t].z;
+      if (g.qs_nrm) g.qs_nrm[i] = (uint16_t)(r[t].w & 0xFFFFu);
     }
-  }
-  __shared__ int32_t red[3][2][kBlock / 64];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    int32_t lo = mn[a], hi = mx[a];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_down(lo, off, 64)); hi = max(hi, __shfl_down(hi, off, 64)); }
-    if ((threadIdx.x & 63) == 0) { red[a][0][threadIdx.x >> 6] = lo; red[a][1][threadIdx.x >> 6] = hi; }
-  }
-  __syncthreads();
-  if (threadIdx.x < 3u && g.ipartials[threadIdx.x]) {   // one partial pair per block and attribute (0 position, 1 normal, 2 texture coordinate); k_i32_minmax_final folds them
-    int32_t lo = red[threadIdx.x][0][0], hi = red[threadIdx.x][1][0];
-#pragma unroll
-    for (int w = 1; w < kBlock / 64; ++w) { lo = min(lo, red[threadIdx.x][0][w]); hi = max(hi, red[threadIdx.x][1][w]); }
-    g.ipartials[threadIdx.x][2 * blockIdx.x] = lo;
-    g.ipartials[threadIdx.x][2 * blockIdx.x + 1] = hi;
   }
 }
 
@@ -1964,13 +1958,15 @@ void launch_value_ranges(RangeArgs& args, hipStream_t s) {
 }
 
 void launch_i32_minmax_final(const MinMaxArgs& args, hipStream_t s) { emit(K_I32_FINAL, 3, args, (uint32_t)args.count, 0, s); }
-// (launched directly: the early stage exists for single one-shot jobs only, never under a batch's step sink; the gather's grid is launch_seq_quantize's,
-// so that k_i32_minmax_final finds the partials where it expects them)
+// (launched directly: the early stage exists for single one-shot jobs only, never under a batch's step sink)
+uint32_t value_quantize_rec_blocks(uint32_t n) { return grid_for(n, 8192); }   // = partial pairs written per attribute
 void launch_value_quantize_rec(const ValueRecArgs& a, hipStream_t s) {
-  if (a.n) hipLaunchKernelGGL(k_value_quantize_rec, grid_for(a.n, 8192), kBlock, 0, s, a);
+  if (a.n) hipLaunchKernelGGL(k_value_quantize_rec, value_quantize_rec_blocks(a.n), kBlock, 0, s, a);
 }
 void launch_seq_gather_rec(const GatherRecArgs& g, hipStream_t s) {
-  if (g.n) hipLaunchKernelGGL(k_seq_gather_rec, seq_quantize_blocks(g.n), kBlock, 0, s, g);
+  // one tile per block (more entries per thread, non-temporal loads and stores, capped grids: 44.6–47.9 µs all of them on the 10M workload — the gather is
+  // bound by what a permutation of 16-byte records gets out of HBM, 170 MB at 3.7 TB/s)
+  if (g.n) hipLaunchKernelGGL(k_seq_gather_rec, grid_for(((uint64_t)g.n + kGatherPer - 1) / kGatherPer, kSeqQuantizeMaxBlocks), kBlock, 0, s, g);
 }
 
 // grid of k_seq_quantize (a DMI_FOR_TILES kernel: any grid is correct, this one gives every block work): the steps of a batch are recorded
