@@ -522,15 +522,20 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
     uint32_t* d_rank = tmpdev.take<uint32_t>(t.V ? t.V : 1);
     if (!d_rank) return fail(DMI_ERR_OUT_OF_MEMORY, "hipMalloc (relabelling temporaries)");
     if ((rc = t.c2r.alloc(C * 4))) return rc;
-    if ((rc = t.opp.alloc(C * 4))) return rc;
+    if (dev->donor && dev->donor->device == cfg.device) {   // the stage's own array, in place: its pool's chunks now belong to the job
+      t.opp.p = const_cast<uint32_t*>(dev->opp); t.opp.bytes = C * 4; t.opp.pooled = true;
+      job->donated.device = dev->donor->device; job->donated.stream = s; job->donated.zero = false;
+      job->donated.chunks.swap(dev->donor->chunks);
+    } else {
+      if ((rc = t.opp.alloc(C * 4))) return rc;
+      HIP_TRY(hipMemcpyAsync(t.opp.p, dev->opp, C * 4, hipMemcpyDeviceToDevice, s));
+    }
     if ((rc = t.seq.alloc((size_t)t.n_seq * 4))) return rc;
     if ((rc = t.s2p.alloc((size_t)t.n_seq * 4))) return rc;
     if (t.n_seq) HIP_TRY(hipMemcpyAsync(t.seq.p, seq_of[0], (size_t)t.n_seq * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(t.opp.p, dev->opp, C * 4, hipMemcpyDeviceToDevice, s));
     launch_fill_u32(d_rank, t.V, kNone, s);
-    launch_rank_scatter(t.seq.as<uint32_t>(), t.n_seq, dev->c2v, d_rank, s);
+    launch_rank_and_points(t.seq.as<uint32_t>(), t.n_seq, dev->c2v, dev->c2p, d_rank, t.s2p.as<uint32_t>(), s);
     launch_corner_ranks(dev->c2v, d_rank, C, t.c2r.as<uint32_t>(), s);
-    launch_seq_points(t.seq.as<uint32_t>(), t.n_seq, dev->c2p, t.s2p.as<uint32_t>(), s);
   } else if (device_relabel) {
     uint32_t max_seq = 0, max_v = 0;
     for (uint32_t i = 0; i < n_atts; ++i) if (job->tables[i].alias_of < 0) { max_seq = std::max(max_seq, job->tables[i].n_seq); max_v = std::max(max_v, job->tables[i].V); }

@@ -225,6 +225,7 @@ struct dmi_job {
   hipStream_t stream = nullptr;
   std::shared_ptr<StreamHolder> stream_owner;   // set when the library created the stream
   DevPool pool;   // (declared before every DevMem of the job: destroyed after them)
+  DevPool donated;   // chunks taken over from the connectivity stage of a one-shot call (DeviceTableView::donor): released with the job
   std::vector<AttJob> atts;
   std::vector<TableDev> tables;
   DevMem upload_region;   // every array job creation uploads, in one piece (host-relabel form): filled through one pinned staging copy
@@ -303,7 +304,8 @@ struct DeviceTableView { const uint32_t* c2p; const uint32_t* c2v; const uint32_
                          bool values_on_device = false;   // dmi_attribute::values are device pointers (dmi_encode_mesh_device): copied device to device
                          // attribute corner tables the device built (k_att_*): a table whose host corner_to_vertex array is att_key[k] has its device
                          // copies at att_c2v[k] / att_opp[k] (the deferred relabelling reads them there: nothing is uploaded)
-                         uint32_t n_att = 0; const uint32_t* const* att_key = nullptr; const uint32_t* const* att_c2v = nullptr; const uint32_t* const* att_opp = nullptr;
+                         uint32_t n_att = 0; const uint32_t* const* att_key = nullptr; const uint32_t* const* att_c2v = nullptr; const uint32_t* const* att_opp = nullptr;                         // (one-shot calls) the pool `opp` lives in: a job that uses the array as it is (the mesh's own face order) takes the pool's chunks instead of copying 12 bytes per face
+                         struct DevPool* donor = nullptr;
 };
 // Job creation as part of a batch (dmi_meshes_prepare): the job is planned and its memory laid out on a worker thread, but every piece of
 // device work is only RECORDED here — the coordinator runs the uploads, the relabelling, the fan rows and the map compositions of all

@@ -458,7 +458,8 @@ extern "C++" int dmi::mesh_prepare_impl(const dmi_mesh* mesh, const dmi_config* 
     rc = build_connectivity(mesh, o, bytes, dt.valid ? &dt.pre : nullptr, /*view_faces=*/true);
     if (rc) return rc;
     t_conn = ms();
-    const DeviceTableView view{dt.d_faces, dt.d_c2v, dt.d_opp, true, src != nullptr};
+    DeviceTableView view{dt.d_faces, dt.d_c2v, dt.d_opp, true, src != nullptr};
+    if (g_one_shot_call && dt.valid && dt.stream) view.donor = &dt.mem.pool;   // (the job of a one-shot call may keep the stage's arrays: nothing of dt reads its memory after this)
     rc = job_create_impl(mesh->atts, o.views.data(), mesh->num_atts, nullptr, 0, cfg, dt.valid ? &view : nullptr, job);   // (every view carries its sequence: no seeds needed)
     if (rc) return rc;
     t_create = ms();
