@@ -508,8 +508,8 @@ int encode_phase_c3(dmi_job* job, dmi_buffer* out) {   // host: splice the attri
     void f32(float f) { std::memcpy(p + n, &f, 4); n += 4; }
     void leb128(uint64_t v) { do { uint8_t x = v & 0x7F; v >>= 7; u8(v ? (x | 0x80) : x); } while (v); }
     void bytes(const uint8_t* q, size_t k) {
-      if (k >= ((size_t)32 << 20)) {   // a large stream (≈ 100M-triangle meshes): the copy — and the first touch of the output pages — on a few threads
-        const size_t parts = std::min<size_t>(8, k >> 22);
+      if (k >= ((size_t)4 << 20)) {   // a large stream (the position stream of a 10M-triangle mesh is 9 MB): the copy — and the first touch of the output pages — on a few threads
+        const size_t parts = std::min<size_t>(8, k >> 21);
         std::vector<std::thread> th;
         for (size_t t = 0; t < parts; ++t) th.emplace_back([=] { const size_t lo = k * t / parts, hi = k * (t + 1) / parts; std::memcpy(p + n + lo, q + lo, hi - lo); });
         for (auto& x : th) x.join();
@@ -519,7 +519,8 @@ int encode_phase_c3(dmi_job* job, dmi_buffer* out) {   // host: splice the attri
       n += k;
     }
     void bytes(const std::vector<uint8_t>& v) { bytes(v.data(), v.size()); }
-  } w{static_cast<uint8_t*>(std::malloc(bound))};
+  } w{static_cast<uint8_t*>(std::malloc(bound + g_out_prefix)), g_out_prefix};   // (g_out_prefix: room for a one-shot call's header + connectivity in front)
+  bound += g_out_prefix;
   if (!w.p) return fail(DMI_ERR_OUT_OF_MEMORY, "malloc");
   job->last_fixups = 0;
   for (uint32_t i = 0; i < n_atts; ++i)

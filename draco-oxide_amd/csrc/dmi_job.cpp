@@ -8,6 +8,7 @@ namespace dmi {
 thread_local std::string g_last_error;
 thread_local dmi_timings g_last_call{};
 thread_local bool g_one_shot_call = false;
+thread_local size_t g_out_prefix = 0;
 int host_fail(int code, const std::string& msg) { g_last_error = msg; return code; }   // shared with the host-only translation units
 ChunkCache g_chunk_cache;
 thread_local DevPool* g_active_pool = nullptr;

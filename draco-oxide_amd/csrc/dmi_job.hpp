@@ -21,6 +21,7 @@
 namespace dmi {
 extern thread_local std::string g_last_error;
 extern thread_local dmi_timings g_last_call;   // dmi_last_call_timings
+extern thread_local size_t g_out_prefix;        // bytes the splice of the next encode on this thread leaves free in front of the attribute section (a one-shot call puts header + connectivity there: one output buffer, one copy of every stream)
 extern thread_local bool g_one_shot_call;      // set by the create → encode → destroy entry points (dmi_encode_mesh[_device], dmi_encode_attributes): layout work that only pays over many encodes is skipped
 inline int fail(int code, const std::string& msg) { return host_fail(code, msg); }
 

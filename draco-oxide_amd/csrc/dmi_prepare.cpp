@@ -527,20 +527,18 @@ int dmi_encode_mesh(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buffer* out
   int rc = dmi_mesh_prepare(mesh, cfg, &head, &job);
   if (rc) return rc;
   const double t_prep = ms();
+  g_out_prefix = head.len;   // (the splice leaves room for header + connectivity: one buffer, no second copy of the streams)
   rc = dmi_job_encode(job, &att);
+  g_out_prefix = 0;
   const double t_enc = ms();
   { const dmi_timings pre = g_last_call; g_last_call = job->last; g_last_call.tables_ms = pre.tables_ms; g_last_call.connectivity_ms = pre.connectivity_ms; g_last_call.job_create_ms = pre.job_create_ms; g_last_call.job_create_device_ms = pre.job_create_device_ms; }
   dmi_job_destroy(job);
   const double t_destroy = ms();
   if (rc) { dmi_free(&head); return rc; }
-  // header + connectivity + attribute section in one library-owned buffer
-  out->data = static_cast<uint8_t*>(std::malloc(head.len + att.len ? head.len + att.len : 1));
-  if (!out->data) { dmi_free(&head); dmi_free(&att); return fail(DMI_ERR_OUT_OF_MEMORY, "out of host memory"); }
-  std::memcpy(out->data, head.data, head.len);
-  std::memcpy(out->data + head.len, att.data, att.len);
-  out->len = out->cap = head.len + att.len;
+  // header + connectivity + attribute section in one library-owned buffer: the splice's own, with the front part filled in here
+  std::memcpy(att.data, head.data, head.len);
+  *out = att;
   dmi_free(&head);
-  dmi_free(&att);
   g_last_call.call_ms = (float)ms();
   if (trace) std::fprintf(stderr, "[dmi] encode_mesh: prepare %.1f ms, encode %.1f, job destroy %.1f, splice %.1f\n", t_prep, t_enc - t_prep, t_destroy - t_enc, ms() - t_destroy);
   return DMI_OK;
@@ -620,17 +618,15 @@ int dmi_encode_mesh_device(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buff
   }
   if (rc) return rc;
   const double t_prep = ms();
+  g_out_prefix = head.len;   // (see dmi_encode_mesh)
   rc = dmi_job_encode(job, &att);
+  g_out_prefix = 0;
   { const dmi_timings pre = g_last_call; g_last_call = job->last; g_last_call.tables_ms = pre.tables_ms; g_last_call.connectivity_ms = pre.connectivity_ms; g_last_call.job_create_ms = pre.job_create_ms; g_last_call.job_create_device_ms = pre.job_create_device_ms; g_last_call.mesh_readback_ms = (float)t_down; }
   dmi_job_destroy(job);
   if (rc) { dmi_free(&head); return rc; }
-  out->data = static_cast<uint8_t*>(std::malloc(head.len + att.len ? head.len + att.len : 1));
-  if (!out->data) { dmi_free(&head); dmi_free(&att); return fail(DMI_ERR_OUT_OF_MEMORY, "out of host memory"); }
-  std::memcpy(out->data, head.data, head.len);
-  std::memcpy(out->data + head.len, att.data, att.len);
-  out->len = out->cap = head.len + att.len;
+  std::memcpy(att.data, head.data, head.len);
+  *out = att;
   dmi_free(&head);
-  dmi_free(&att);
   g_last_call.call_ms = (float)ms();
   if (trace) std::fprintf(stderr, "[dmi] encode_mesh_device: faces + maps read back %.1f ms, prepare %.1f, encode + splice %.1f\n", t_down, t_prep - t_down, ms() - t_prep);
   return DMI_OK;
