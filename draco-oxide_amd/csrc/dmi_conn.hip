@@ -420,6 +420,18 @@ size_t scan_partials_words(uint32_t n) { return (size_t)(n + kScanTile - 1) / kS
 
 // flags / vmax / cdone zeroed, first filled with DMI_NONE, ecount zeroed by the caller's memsets (conn_tables_clear); efill is unused since round 4
 // (the arrival numbers of the counting atomics replace the second round of atomics)
+// The host's copy of the opposite corners with ids 4·face + k (host_conn.cpp Enc4: the serial walks then find face and position by shift and mask).
+// One streaming pass, beside a read-back that is bound by the link anyway.
+__global__ __launch_bounds__(kBlock) void k_opp_quad(const uint32_t* __restrict__ opp, uint64_t C, uint32_t* __restrict__ out) {
+  for (uint64_t c = (uint64_t)blockIdx.x * kBlock + threadIdx.x; c < C; c += (uint64_t)gridDim.x * kBlock) {
+    const uint32_t o = opp[c];
+    out[c] = o == kNoneD ? kNoneD : o + o / 3u;
+  }
+}
+void launch_opp_quad(const uint32_t* opp, uint64_t C, uint32_t* out, hipStream_t s) {
+  if (C) hipLaunchKernelGGL(k_opp_quad, (uint32_t)std::min<uint64_t>((C + kBlock - 1) / kBlock, 8192), kBlock, 0, s, opp, C, out);
+}
+
 hipError_t conn_tables_clear(const ConnArgs& a, hipStream_t s) {
   hipError_t e;
   const size_t nv = (size_t)a.total_verts + 1, C = 3ull * a.total_faces;

@@ -281,6 +281,7 @@ struct ConnArgs {
 };
 hipError_t conn_tables_clear(const ConnArgs& a, hipStream_t s);   // the memsets launch_conn_tables expects
 void launch_conn_tables(const ConnArgs& a, hipStream_t s);
+void launch_opp_quad(const uint32_t* opp, uint64_t C, uint32_t* out, hipStream_t s);   // out[c] = opp[c] as a 4·face + k id (kNone stays)
 // Attribute corner tables of a batch on the device (core/corner_table/attribute_corner_table.rs:16-137), after launch_conn_tables on the same
 // stream.  An "att item" = one (mesh, non-position attribute) whose point → value map may differ from the position's: seam test per edge
 // (:44-63), attribute vertices per universal vertex = 1 + the seam edges its right swing crosses (:116-133), ids by a prefix sum, seam-aware fan

@@ -201,6 +201,8 @@ struct CornerTables {
   // face array (c2p, and c2v of a mesh without a position map) or in the pinned read-back of the device-built tables (dmi_prepare.cpp).
   const uint32_t *c2p = nullptr, *c2v = nullptr, *opp = nullptr, *lmc = nullptr;
   std::vector<uint32_t> c2p_own, c2v_own, opp_own, lmc_own;
+  bool quad = false;          // the VALUES of `opp` are corner ids 4·face + k (kNone stays kNone; the array itself stays dense): only the device stage writes them so, for
+                              // meshes none of whose attributes needs a corner table of its own (host_conn.cpp Enc4: the two serial walks then shift where they divided)
   bool no_boundary = false;   // known: every corner has an opposite (the device pass reports it) — the Edgebreaker skips its boundary labelling scan
   std::vector<AttTable> att;   // one per non-position attribute, in attribute order
 
@@ -219,13 +221,15 @@ struct EdgebreakerResult {
   // corners_of_edgebreaker (edgebreaker.rs:523-529) = reverse(init_face_connectivity_corners) ++ processed_connectivity_corners, kept as its two
   // parts: the attribute sequencers read them where the traversal left them (no 4-bytes-per-face copy on the critical path)
   std::vector<uint32_t> init_rev, processed;
+  bool processed_quad = false;          // `processed` holds 4·face + k ids (the traversal ran over a CornerTables::quad table)
   std::vector<uint32_t> seeds;          // the concatenation, only when a caller asks for it (materialize_seeds: dmi_encode_connectivity's public view)
   std::vector<uint8_t> connectivity;    // bytes written by encode_connectivity (without the 11-byte header)
   void materialize_seeds() {
     if (!seeds.empty() || (init_rev.empty() && processed.empty())) return;
     pool_fit(seeds, init_rev.size() + processed.size());
     seeds.assign(init_rev.begin(), init_rev.end());
-    seeds.insert(seeds.end(), processed.begin(), processed.end());
+    if (processed_quad) for (uint32_t c : processed) seeds.push_back(c - (c >> 2));
+    else seeds.insert(seeds.end(), processed.begin(), processed.end());
   }
 };
 // Optional call-outs of run_edgebreaker, so that a large mesh's other serial walks overlap it: `seeds_ready` fires when the traversal
@@ -239,14 +243,16 @@ extern std::atomic<uint64_t> g_eb_ns[6];   // (trace)
 struct TableRef {
   uint32_t F, V;
   const uint32_t *c2v, *opp, *lmc;
+  bool quad = false;   // see CornerTables::quad
 };
 // on_boundary (optional): one byte per vertex, != 0 ⇔ the vertex lies on a boundary of `t` (vertex_boundary_flags) — spares the walk two
 // dependent loads per vertex
 void attribute_sequence(const TableRef& t, const uint32_t* seeds, uint32_t n_seeds, std::vector<uint32_t>& seq, const uint8_t* on_boundary = nullptr);
 // the seeds in two parts (first ++ second), e.g. EdgebreakerResult::init_rev ++ processed
-void attribute_sequence(const TableRef& t, const uint32_t* first, uint32_t n_first, const uint32_t* second, uint32_t n_second, std::vector<uint32_t>& seq, const uint8_t* on_boundary = nullptr);
+void attribute_sequence(const TableRef& t, const uint32_t* first, uint32_t n_first, const uint32_t* second, uint32_t n_second, std::vector<uint32_t>& seq, const uint8_t* on_boundary = nullptr,
+                        bool second_quad = false /* the second part holds 4·face + k ids */);
 inline void attribute_sequence(const TableRef& t, const EdgebreakerResult& eb, std::vector<uint32_t>& seq, const uint8_t* on_boundary = nullptr) {
-  attribute_sequence(t, eb.init_rev.data(), (uint32_t)eb.init_rev.size(), eb.processed.data(), (uint32_t)eb.processed.size(), seq, on_boundary);
+  attribute_sequence(t, eb.init_rev.data(), (uint32_t)eb.init_rev.size(), eb.processed.data(), (uint32_t)eb.processed.size(), seq, on_boundary, eb.processed_quad);
 }
 void vertex_boundary_flags(const TableRef& t, std::vector<uint8_t>& on_boundary);   // parallel slices for a large table
 

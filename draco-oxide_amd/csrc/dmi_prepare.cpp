@@ -27,7 +27,8 @@ struct DeviceTables {
   // DMI_OK with valid = true: ct views the tables; DMI_OK with valid = false: not covered (the caller runs the host builder); else an error
   // src_faces / src_pos_map (nullable): the mesh's faces / position map already in device memory (dmi_encode_mesh_device) — used where they
   // are; `mesh` then holds their host copies on huge pages (the staging they were read back into)
-  int build(const dmi_mesh* mesh, std::vector<uint32_t>& c2v_store, const uint32_t* src_faces = nullptr, const uint32_t* src_pos_map = nullptr) {
+  // walks_only: the read-back feeds the library's own walks and nothing else — the opposite corners may come back as 4·face + k ids (see below)
+  int build(const dmi_mesh* mesh, std::vector<uint32_t>& c2v_store, const uint32_t* src_faces = nullptr, const uint32_t* src_pos_map = nullptr, bool walks_only = false) {
     const uint32_t F = mesh->num_faces;
     const size_t C = (size_t)F * 3;
     const dmi_attribute& pos = mesh->atts[0];
@@ -39,11 +40,18 @@ struct DeviceTables {
     HIP_TRY(hipSetDevice(device));
     const bool mapped = pos.point_to_value != nullptr;
     const size_t nv = (size_t)Vcap + 1, parts = scan_partials_words((uint32_t)nv);
-    mem.init(device, stream, C * 4 * (mapped ? 5 : 4) + (mapped ? (size_t)P * 4 : 0) + nv * 4 * 4 + nv + C + parts * 4 + ((size_t)1 << 16));
+    // The host's walks read `opposite` as 4·face + k ids when no attribute needs a corner table of its own — every attribute indexed exactly like the
+    // Position attribute (the same map array, or none: per-point values) — so that nothing on the host reads the VALUES of the array but the two walks
+    // (host_conn.cpp Enc4); the device keeps its own 3·face + k array for its kernels.
+    bool quad = walks_only && F < (1u << 30) && !std::getenv("DMI_NO_QUAD");
+    for (uint32_t i = 1; i < mesh->num_atts && quad; ++i) quad = mesh->atts[i].point_to_value == pos.point_to_value;
+    mem.init(device, stream, C * 4 * (mapped ? 5 : 4) + (quad ? C * 4 : 0) + (mapped ? (size_t)P * 4 : 0) + nv * 4 * 4 + nv + C + parts * 4 + ((size_t)1 << 16));
     d_faces = src_faces ? const_cast<uint32_t*>(src_faces) : mem.take<uint32_t>(C);
     uint32_t* d_p2v = mapped ? (src_pos_map ? const_cast<uint32_t*>(src_pos_map) : mem.take<uint32_t>(P)) : nullptr;
     d_c2v = mapped ? mem.take<uint32_t>(C) : d_faces;
     d_opp = mem.take<uint32_t>(C);
+    uint32_t* d_opp_q = quad ? mem.take<uint32_t>(C) : nullptr;
+    if (quad && !d_opp_q) quad = false;
     d_lmc = mem.take<uint32_t>(nv);
     d_onb = mem.take<uint8_t>(nv);
     ConnArgs a{};
@@ -74,7 +82,8 @@ struct DeviceTables {
     HIP_TRY(conn_tables_clear(a, stream));
     launch_conn_tables(a, stream);
     HIP_TRY(hipMemcpyAsync(hp_words, d_words, 8, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(hp_opp, d_opp, C * 4, hipMemcpyDeviceToHost, stream));
+    if (quad) launch_opp_quad(d_opp, C, d_opp_q, stream);
+    HIP_TRY(hipMemcpyAsync(hp_opp, quad ? d_opp_q : d_opp, C * 4, hipMemcpyDeviceToHost, stream));
     if (mapped) HIP_TRY(hipMemcpyAsync(hp_c2v, d_c2v, C * 4, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(hp_onb, d_onb, Vcap, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(hp_lmc, d_lmc, (size_t)Vcap * 4, hipMemcpyDeviceToHost, stream));
@@ -100,6 +109,7 @@ struct DeviceTables {
     V = hp_words[1] + 1;
     pre.c2v = mapped ? hp_c2v : c2v_host; pre.opp = hp_opp; pre.lmc = hp_lmc; pre.on_boundary = hp_onb; pre.V = V;
     pre.no_boundary = !(flags & CONN_HAS_BOUNDARY);
+    pre.quad = quad;
     valid = true;
     return DMI_OK;
   }
@@ -108,6 +118,7 @@ void view_prebuilt(CornerTables& ct, const dmi_mesh* mesh, const PrebuiltTable& 
   ct.F = mesh->num_faces; ct.V = pre.V;
   ct.c2p = mesh->faces; ct.c2v = pre.c2v; ct.opp = pre.opp; ct.lmc = pre.lmc;
   ct.no_boundary = pre.no_boundary;
+  ct.quad = pre.quad;
   ct.att.clear();
 }
 
@@ -150,6 +161,13 @@ extern "C++" int dmi::build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std
   if (!on_device) {
     rc = o.ct.build_universal(mesh->faces, mesh->num_faces, mesh->atts[0].point_to_value, err, /*copy_faces=*/!view_faces);
     if (rc) return fail(rc, err);
+    // DMI_TEST_QUAD=1 (tests, host only): the walks over 4·face + k ids — what the device stage hands them for meshes none of whose attributes needs
+    // a corner table of its own — on a table the HOST built: the bytes must not change
+    if (std::getenv("DMI_TEST_QUAD") && o.ct.opp == o.ct.opp_own.data() && mesh->num_faces < (1u << 30)) {
+      bool alike = true;
+      for (uint32_t i = 1; i < mesh->num_atts && alike; ++i) alike = mesh->atts[i].point_to_value == mesh->atts[0].point_to_value;
+      if (alike) { for (uint32_t& v : o.ct.opp_own) if (v != kNone) v += v / 3; o.ct.quad = true; }
+    }
   }
   const double t_univ = since(c0);
   // The serial graph walks of one large mesh overlap on a few host threads: the attribute corner tables (their loops are parallel
@@ -168,7 +186,7 @@ extern "C++" int dmi::build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std
   std::vector<uint8_t>& on_boundary = on_boundary_p.v;
   const uint8_t* boundary_flags = on_device ? pre->on_boundary : nullptr;   // per vertex: on a boundary of the universal table (the device pass computes them with the left-most corners)
   auto sequence_universal = [&] {
-    TableRef tr{o.ct.F, o.ct.V, o.ct.c2v, o.ct.opp, o.ct.lmc};
+    TableRef tr{o.ct.F, o.ct.V, o.ct.c2v, o.ct.opp, o.ct.lmc, o.ct.quad};
     attribute_sequence(tr, o.eb, o.seqs[0], boundary_flags ? boundary_flags : (on_boundary.empty() ? nullptr : on_boundary.data()));
   };
 
@@ -449,7 +467,7 @@ extern "C++" int dmi::mesh_prepare_impl(const dmi_mesh* mesh, const dmi_config* 
       }
     }
     if (want_device && dt.stream) {
-      if ((rc = dt.build(mesh, o.ct.c2v_own, src ? src->faces : nullptr, src ? src->pos_map : nullptr))) return rc;
+      if ((rc = dt.build(mesh, o.ct.c2v_own, src ? src->faces : nullptr, src ? src->pos_map : nullptr, /*walks_only=*/true))) return rc;
       g_tables_ms = dt.t_down;
       if (trace) std::fprintf(stderr, "[dmi]   universal table of %u faces on the device: uploads issued %.2f ms, kernels + read-back issued %.2f, arrived %.2f (flags %#x)\n", mesh->num_faces, dt.t_up, dt.t_kernels, dt.t_down, dt.flags);
     }

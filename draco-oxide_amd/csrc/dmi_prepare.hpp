@@ -13,6 +13,7 @@ struct PrebuiltTable {
   const uint8_t* on_boundary = nullptr;
   uint32_t V = 0;
   bool no_boundary = false;
+  bool quad = false;   // `opp` holds 4·face + k ids (CornerTables::quad)
   // attribute corner tables the device built (k_att_*), by index among the mesh's non-position attributes; ready = false: the host builds it
   struct Att { bool ready = false, interior = false; uint32_t nv = 0; const uint8_t* seam = nullptr; const uint32_t *c2v = nullptr, *opp = nullptr, *lmc = nullptr;
                const uint32_t *d_c2v = nullptr, *d_opp = nullptr; };

@@ -468,9 +468,36 @@ inline void set_size_written(std::vector<T>& v, size_t n) {
   v.swap(copy);
 }
 
+// Corner ids inside the two serial walks.  A step goes corner → face → position in the face → next corner → opposite[next] → …: with ids
+// 3·face + k the face is a division (multiply-high + shift ON the dependency chain of the walk) and k a multiply-subtract; with ids 4·face + k (Enc4) a
+// shift and a mask.  The arrays stay dense — three entries per face, entry of corner c at c − face — only the VALUES of `opposite` (CornerTables::quad,
+// written that way by the device stage, dmi_conn.hip k_opp_quad) and what a walk keeps on its stack / in `processed` are 4·face + k.  10M-face grid on the
+// GPU box's EPYC, traversal loop alone: 3.88 → 3.59 ns per face (scripts/experiments/walk_enc4.cpp).
+struct Enc3 {
+  static constexpr bool kQuad = false;
+  static uint32_t face(uint32_t c) { return c / 3; }
+  static uint32_t k(uint32_t c, uint32_t f) { return c - 3 * f; }
+  static uint32_t idx(uint32_t c, uint32_t) { return c; }            // where corner c's entries are
+  static uint32_t from3(uint32_t c3) { return c3; }
+  static uint32_t to3(uint32_t c) { return c; }
+  static uint32_t dense(uint32_t c) { return c; }                     // to3 of a corner known to exist
+};
+struct Enc4 {
+  static constexpr bool kQuad = true;
+  static uint32_t face(uint32_t c) { return c >> 2; }
+  static uint32_t k(uint32_t c, uint32_t) { return c & 3u; }
+  static uint32_t idx(uint32_t c, uint32_t f) { return c - f; }
+  static uint32_t from3(uint32_t c3) { return c3 == kNone ? kNone : c3 + c3 / 3; }
+  static uint32_t to3(uint32_t c) { return c == kNone ? kNone : c - (c >> 2); }
+  static uint32_t dense(uint32_t c) { return c - (c >> 2); }
+};
+
 struct Walker {
   const CornerTables& t;
   const uint32_t C;
+  const bool quad;                    // t.opp holds 4·face + k ids (the walk then keeps its stack and `processed` in that form: EdgebreakerResult::processed_quad)
+  // opposite corner as a 3·face + k id whatever the table holds (everything outside the traversal loop)
+  uint32_t opp3(uint32_t c3) const { const uint32_t o = t.opp[c3]; return quad ? Enc4::to3(o) : o; }
   std::vector<uint8_t> vvis, fvis, hole_done;   // vvis: bit 0 visited, bit 1 the vertex lies on a boundary (hole_of != kNone); fvis: bit 0 visited, bit 1 an S face
   std::vector<uint32_t> hole_of;      // per vertex, kNone = interior
   std::vector<uint32_t> stack, processed, init_corners;
@@ -493,7 +520,7 @@ struct Walker {
   bool face_visited(uint32_t f) const { return use_stamp ? stamp[f] != 0u : (fvis[f] & 1) != 0; }
   void mark_start_face(uint32_t f) { if (use_stamp) stamp[f] = kStampStart; else fvis[f] |= 1; }
 
-  explicit Walker(const CornerTables& tt) : t(tt), C(tt.F * 3) {
+  explicit Walker(const CornerTables& tt) : t(tt), C(tt.F * 3), quad(tt.quad) {
     pool_fit(vvis, t.V); vvis.assign(t.V, 0);
     static const bool no_shadow = std::getenv("DMI_NO_SHADOW") != nullptr;
     static const uint32_t min_faces = std::getenv("DMI_SHADOW_MIN_FACES") ? (uint32_t)std::atol(std::getenv("DMI_SHADOW_MIN_FACES")) : (1u << 16);   // (256-mesh batch: traversal thread time 71 → 68 ms with the meshes of ≥ 2^16 faces on stamps; below, tables and flags sit in L2)
@@ -507,7 +534,7 @@ struct Walker {
   Walker(const Walker&) = delete;
   Walker& operator=(const Walker&) = delete;
   void finish() { set_size_written(processed, n_out); set_size_written(symbols, n_out); }
-  uint32_t swing_right(uint32_t c) const { uint32_t o = t.opp[corner_prev(c)]; return o == kNone ? kNone : corner_prev(o); }
+  uint32_t swing_right(uint32_t c) const { uint32_t o = opp3(corner_prev(c)); return o == kNone ? kNone : corner_prev(o); }
 
   // edgebreaker.rs:195-224 — the inner walk rotates inside one face (never crosses an edge), so
   // each boundary vertex ends up with its own id.
@@ -534,7 +561,7 @@ struct Walker {
   // edgebreaker.rs:226-256
   void mark_boundary(uint32_t start_corner, bool include_first) {
     uint32_t c = corner_prev(start_corner);
-    while (t.opp[c] != kNone) c = corner_next(t.opp[c]);
+    while (t.opp[c] != kNone) c = corner_next(opp3(c));
     const uint32_t sv = t.c2v[start_corner];
     if (include_first) vvis[sv] |= 1;
     if (hole_of.empty() || hole_of[sv] == kNone) { bad = true; return; }
@@ -542,15 +569,16 @@ struct Walker {
     for (uint32_t v = t.c2v[corner_prev(c)]; v != sv; v = t.c2v[corner_prev(c)]) {
       vvis[v] |= 1;
       c = corner_next(c);
-      while (t.opp[c] != kNone) c = corner_next(t.opp[c]);
+      while (t.opp[c] != kNone) c = corner_next(opp3(c));
     }
   }
   // (rare: the face across the edge is an S face — the 8-byte-per-face array of the reference is a map over the S faces only)
   __attribute__((noinline)) void note_split(uint64_t merging, uint8_t right, uint32_t face) { splits.push_back({merging, split_symbol_of_face[face], right}); }
   // an S face: the left branch waits on the stack, the right one is walked first (rare: kept out of the loop's registers)
-  __attribute__((noinline)) void split_here(uint32_t c, uint32_t f, uint32_t v, uint8_t vflags, uint32_t rc, uint32_t lc, uint64_t symbol_idx) {
+  // (c3: the corner as a 3·face + k id; rc / lc: as the loop keeps them)
+  __attribute__((noinline)) void split_here(uint32_t c3, uint32_t f, uint32_t v, uint8_t vflags, uint32_t rc, uint32_t lc, uint64_t symbol_idx) {
     ++num_split_symbols;
-    if ((vflags & 2) && !hole_done[hole_of[v]]) mark_boundary(c, false);
+    if ((vflags & 2) && !hole_done[hole_of[v]]) mark_boundary(c3, false);
     split_symbol_of_face[f] = symbol_idx;
     if (use_stamp) stamp[f] |= kStampS; else fvis[f] |= 2;
     stack.back() = lc;
@@ -558,8 +586,12 @@ struct Walker {
   }
   // edgebreaker.rs:261-350.  The loop keeps its tables and outputs in locals (every flag store is a byte store, which may alias anything the
   // object holds: members would be reloaded after each of them) and writes one (corner, symbol) pair per step through raw pointers.
-  void run_from(uint32_t c) { if (use_stamp) run_from_t<true>(c); else run_from_t<false>(c); }
-  template <bool kStamp>
+  // c3: the corner to start from, a 3·face + k id
+  void run_from(uint32_t c3) {
+    if (quad) { if (use_stamp) run_from_t<true, Enc4>(Enc4::from3(c3)); else run_from_t<false, Enc4>(Enc4::from3(c3)); }
+    else { if (use_stamp) run_from_t<true, Enc3>(c3); else run_from_t<false, Enc3>(c3); }
+  }
+  template <bool kStamp, class E>
   void run_from_t(uint32_t c) {
     const uint32_t* const opp = t.opp;
     const uint32_t* const c2v = t.c2v;
@@ -577,15 +609,16 @@ struct Walker {
     while (!stack.empty() && !bad) {
       c = stack.back();
       if (c == kNone) { bad = true; break; }
-      if (kStamp ? st[c / 3] != 0u : (fv[c / 3] & 1) != 0) { stack.pop_back(); continue; }
+      if (kStamp ? st[E::face(c)] != 0u : (fv[E::face(c)] & 1) != 0) { stack.pop_back(); continue; }
       for (;;) {
         if (c == kNone || n >= cap) { bad = true; break; }
-        prefetch_neighbours(opp + c); prefetch_neighbours(c2v + c);
-        const uint32_t f = c / 3, k = c - 3 * f, v = c2v[c];
+        const uint32_t f = E::face(c), k = E::k(c, f), i = E::idx(c, f);
+        prefetch_neighbours(opp + i); prefetch_neighbours(c2v + i);
+        const uint32_t v = c2v[i];
         const uint32_t cn = k == 2 ? c - 2 : c + 1;
         if (kStamp) {
           const size_t qa = q + kAhead;
-          if (qa < n) { const uint32_t g = proc[qa]; __builtin_prefetch(opp + g, 0, 3); __builtin_prefetch(opp + g + 16, 0, 3); __builtin_prefetch(opp + g - 16, 0, 3); __builtin_prefetch(c2v + g, 0, 3); }
+          if (qa < n) { const uint32_t g = E::dense(proc[qa]); __builtin_prefetch(opp + g, 0, 3); __builtin_prefetch(opp + g + 16, 0, 3); __builtin_prefetch(opp + g - 16, 0, 3); __builtin_prefetch(c2v + g, 0, 3); }
           ++q;
           st[f] = (uint32_t)n + 1u;
         } else {
@@ -594,24 +627,24 @@ struct Walker {
         }
         prefetch_neighbours(vv + v);
         proc[n] = c;
-        const uint32_t gate = opp[c] != kNone ? 0x10u : 0u;   // (the face this one was entered from — or a start face — is always visited)
+        const uint32_t gate = opp[i] != kNone ? 0x10u : 0u;   // (the face this one was entered from — or a start face — is always visited)
         const uint8_t vflags = vv[v];
         if (!(vflags & 1)) {
           vv[v] = vflags | 1;
           // (a C face: its tip was unvisited, so neither the right nor the left face — both hold the tip — has been processed)
-          if (!(vflags & 2)) { sym[n++] = (uint8_t)(SYM_C | gate); c = opp[cn]; continue; }
+          if (!(vflags & 2)) { sym[n++] = (uint8_t)(SYM_C | gate); c = opp[E::idx(cn, f)]; continue; }
         }
         const uint32_t cp = k == 0 ? c + 2 : c - 1;
-        const uint32_t rc = opp[cn], lc = opp[cp];
+        const uint32_t rc = opp[E::idx(cn, f)], lc = opp[E::idx(cp, f)];
         // (neighbour states: byte flags — bit 0 visited, bit 1 S face — or stamps)
         uint32_t rs = 0, ls = 0;
         bool rv, lv, r_split, l_split;
         if (kStamp) {
-          rs = rc == kNone ? 0u : st[rc / 3]; ls = lc == kNone ? 0u : st[lc / 3];
+          rs = rc == kNone ? 0u : st[E::face(rc)]; ls = lc == kNone ? 0u : st[E::face(lc)];
           rv = rc == kNone || rs != 0u; lv = lc == kNone || ls != 0u;
           r_split = (rs & kStampS) != 0u; l_split = (ls & kStampS) != 0u;
         } else {
-          const uint8_t rf = rc == kNone ? 1 : fv[rc / 3], lf = lc == kNone ? 1 : fv[lc / 3];
+          const uint8_t rf = rc == kNone ? 1 : fv[E::face(rc)], lf = lc == kNone ? 1 : fv[E::face(lc)];
           rv = rf & 1; lv = lf & 1;
           r_split = rc != kNone && (rf & 2); l_split = lc != kNone && (lf & 2);
         }
@@ -621,9 +654,9 @@ struct Walker {
         const uint64_t symbol_idx = n;   // (symbols so far = the index of this one)
         if (rv) {
           if (kStamp && rs) q = (size_t)(rs & 0x7FFFFFFFu);   // (the right face was processed at position rs - 1: the shadow moves on from the one after it)
-          if (r_split) note_split(symbol_idx, 1, rc / 3);
+          if (r_split) note_split(symbol_idx, 1, E::face(rc));
           if (lv) {
-            if (l_split) note_split(symbol_idx, 0, lc / 3);
+            if (l_split) note_split(symbol_idx, 0, E::face(lc));
             sym[n++] = (uint8_t)(SYM_E | nb);
             stack.pop_back();
             break;
@@ -632,12 +665,12 @@ struct Walker {
           c = lc;
         } else if (lv) {
           if (kStamp && ls) q = (size_t)(ls & 0x7FFFFFFFu);
-          if (l_split) note_split(symbol_idx, 0, lc / 3);
+          if (l_split) note_split(symbol_idx, 0, E::face(lc));
           sym[n++] = (uint8_t)(SYM_L | nb);
           c = rc;
         } else {
           sym[n++] = (uint8_t)(SYM_S | nb);
-          split_here(c, f, v, vflags, rc, lc, symbol_idx);
+          split_here(E::dense(c), f, v, vflags, rc, lc, symbol_idx);
           break;
         }
       }
@@ -769,7 +802,7 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
       w.vvis[t.c2v[start]] |= 1; w.vvis[t.c2v[corner_next(start)]] |= 1; w.vvis[t.c2v[corner_prev(start)]] |= 1;
       w.mark_start_face(f);
       w.init_corners.push_back(corner_next(start));
-      w.run_from(t.opp[corner_next(start)]);
+      w.run_from(w.opp3(corner_next(start)));
     } else {
       w.mark_boundary(corner_next(start), true);
       w.run_from(start);
@@ -781,9 +814,12 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
   if (w.bad) { err = "edgebreaker: inconsistent connectivity (reference unwrap() panic)"; if (hooks && hooks->before_seams) hooks->before_seams(); return DMI_ERR_CONNECTIVITY; }
   out.init_rev.assign(w.init_corners.rbegin(), w.init_corners.rend());   // edgebreaker.rs:523-529
   pool_give(out.processed);
-  out.processed.swap(w.processed);   // (the walker's own array: its remaining readers below go through `processed`)
+  out.processed.swap(w.processed);   // (the walker's own array: its remaining readers below go through `corner_at`)
+  out.processed_quad = w.quad;
   out.seeds.clear();
   const std::vector<uint32_t>& processed = out.processed;
+  const bool pq = w.quad;
+  auto corner_at = [&processed, pq](size_t i) -> uint32_t { const uint32_t c = processed[i]; return pq ? c - (c >> 2) : c; };   // entry i of `processed` as a 3·face + k id
   if (hooks && hooks->seeds_ready) hooks->seeds_ready();
   s.leb128(w.symbols.size());
   s.leb128(w.num_split_symbols);
@@ -867,8 +903,8 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
     if (sliced && !masks_ok) {
       pool_fit(where, t.F);
       where.assign(t.F, kNone);
-      parallel_for(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) where[processed[i] / 3] = (uint32_t)i; });
-      parallel_for(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) if (where[processed[i] / 3] != (uint32_t)i) { twice.store(1); break; } });
+      parallel_for(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) where[corner_at(i) / 3] = (uint32_t)i; });
+      parallel_for(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) if (where[corner_at(i) / 3] != (uint32_t)i) { twice.store(1); break; } });
     }
     std::vector<std::vector<uint8_t>> fed(A);
     struct GiveBack { std::vector<std::vector<uint8_t>>& v; ~GiveBack() { for (auto& x : v) pool_give(x); } } fed_back{fed};
@@ -886,7 +922,7 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
       // corners of face i whose flag is emitted, as a mask over (c, next, prev)
       auto mask_of = [&](size_t i) -> uint32_t {
         if (masks_ok) return (uint32_t)(w.symbols[i] >> 4);
-        const uint32_t c = processed[i];
+        const uint32_t c = corner_at(i);
         const uint32_t cs[3] = {c, corner_next(c), corner_prev(c)};
         uint32_t m = 0;
         for (int k = 0; k < 3; ++k) {
@@ -925,7 +961,7 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
         for (size_t j = (lo / kChunk) * kChunk; j < lo; ++j) pos += (uint64_t)kBits3[mask[j] & 7u];
         std::vector<uint64_t> z(A, 0);
         for (size_t i = lo; i < hi; ++i) {
-          const uint32_t c = processed[i];
+          const uint32_t c = corner_at(i);
           const uint32_t cs[3] = {c, corner_next(c), corner_prev(c)};
           for (int k = 2; k >= 0; --k) {
             if (!(mask[i] >> k & 1u)) continue;
@@ -940,7 +976,7 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
       for (size_t i = 0; i < n; ++i) total += (uint64_t)kBits3[(w.symbols[i] >> 4) & 7u];
     } else if (A && own.empty() && [&] {   // a small mesh without seams: only the stream length — every face processed once ⇒ the interior-edge count
                  std::vector<uint8_t> seen(t.F, 0);
-                 for (size_t i = 0; i < n; ++i) { uint8_t& f = seen[processed[i] / 3]; if (f) return false; f = 1; }
+                 for (size_t i = 0; i < n; ++i) { uint8_t& f = seen[corner_at(i) / 3]; if (f) return false; f = 1; }
                  return true;
                }()) {
       if (t.no_boundary) total = (uint64_t)t.F * 3 / 2;
@@ -955,7 +991,7 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
         for (size_t i = n; i-- > 0;) {
           const uint32_t m = w.symbols[i] >> 4;
           if (!m) continue;
-          const uint32_t c = processed[i];
+          const uint32_t c = corner_at(i);
           const uint32_t cs[3] = {c, corner_next(c), corner_prev(c)};
           for (int k = 0; k < 3; ++k) {
             if (!(m >> k & 1u)) continue;
@@ -967,7 +1003,7 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
       } else {
         std::vector<uint8_t> fv(t.F, 0);
         for (size_t i = n; i-- > 0;) {
-          const uint32_t c = processed[i];
+          const uint32_t c = corner_at(i);
           const uint32_t cs[3] = {c, corner_next(c), corner_prev(c)};
           fv[c / 3] = 1;
           for (uint32_t cc : cs) {
@@ -1024,7 +1060,7 @@ void vertex_boundary_flags(const TableRef& t, std::vector<uint8_t>& on_boundary)
 }
 
 void attribute_sequence(const TableRef& t, const uint32_t* seeds, uint32_t n_seeds, std::vector<uint32_t>& seq, const uint8_t* on_boundary) {
-  attribute_sequence(t, nullptr, 0, seeds, n_seeds, seq, on_boundary);
+  attribute_sequence(t, nullptr, 0, seeds, n_seeds, seq, on_boundary, false);
 }
 // The reference's stack starts as the seeds and only ever grows above them: what the walk pushes is popped before the next seed.  The seeds
 // are therefore read in place, last to first (second part, then first part), and only the pushes live on a stack of their own.
@@ -1032,8 +1068,10 @@ void attribute_sequence(const TableRef& t, const uint32_t* seeds, uint32_t n_see
 // flag byte: a step whose tip was emitted by the spiral's previous loop then knows where in `seq` that loop passed, a shadow index follows the walk one
 // loop behind, and the table lines of the corner that loop emitted a few entries later are requested into L1 (the traversal's trick, Walker::run_from_t:
 // 10M faces 44.5 → ≈ 40.5 ms).
-template <bool kStamp>
-static void sequence_impl(const TableRef& t, const uint32_t* first, uint32_t n_first, const uint32_t* second, uint32_t n_second, std::vector<uint32_t>& seq, const uint8_t* on_boundary) {
+// E: the form of the corner ids `t.opp` holds (Enc3 / Enc4, see Walker); second_quad: the second part of the seeds holds 4·face + k ids (a traversal over
+// such a table leaves them so).  What the walk EMITS are 3·face + k ids in either form.
+template <bool kStamp, class E>
+static void sequence_impl(const TableRef& t, const uint32_t* first, uint32_t n_first, const uint32_t* second, uint32_t n_second, bool second_quad, std::vector<uint32_t>& seq, const uint8_t* on_boundary) {
   Pooled<uint8_t> vvis_p(kStamp ? 0 : t.V, (uint8_t)0), fvis_p(t.F, (uint8_t)0);
   Pooled<uint32_t> vst_p(kStamp ? t.V : 0, 0u);
   constexpr uint32_t kOnBoundary = 0x80000000u, kPos = 0x7FFFFFFFu;
@@ -1068,21 +1106,26 @@ static void sequence_impl(const TableRef& t, const uint32_t* first, uint32_t n_f
   size_t q = ~(size_t)0 >> 1;          // the shadow: position in `seq` of what the previous loop emitted beside this spot
   constexpr size_t kAhead = 8;
   auto visited = [&](uint32_t v) -> bool { return kStamp ? (vs[v] & kPos) != 0u : (vv[v] & 1) != 0; };
-  auto emit = [&](uint32_t c) {
-    const uint32_t v = c2v[c];
-    if (kStamp) { const uint32_t f = vs[v]; if (!(f & kPos) && nq < qcap) { sq[nq] = c; vs[v] = f | (uint32_t)++nq; } }
-    else { const uint8_t f = vv[v]; if (!(f & 1) && nq < qcap) { vv[v] = f | 1; sq[nq++] = c; } }
+  auto emit = [&](uint32_t i) {   // i: where the corner's entries are (= its 3·face + k id)
+    const uint32_t v = c2v[i];
+    if (kStamp) { const uint32_t f = vs[v]; if (!(f & kPos) && nq < qcap) { sq[nq] = i; vs[v] = f | (uint32_t)++nq; } }
+    else { const uint8_t f = vv[v]; if (!(f & 1) && nq < qcap) { vv[v] = f | 1; sq[nq++] = i; } }
   };
   for (;;) {
     uint32_t c;
     if (!faces_left) break;
     if (sn) c = st[--sn];
-    else if (left) { --left; c = left >= n_first ? second[left - n_first] : first[left]; }
+    else if (left) {
+      --left;
+      if (left >= n_first) { c = second[left - n_first]; if (second_quad != E::kQuad) c = second_quad ? E::from3(Enc4::to3(c)) : E::from3(c); }
+      else c = E::from3(first[left]);
+    }
     else break;
-    const uint32_t f = c / 3;
+    const uint32_t f = E::face(c);
     if (fv[f]) continue;
-    prefetch_neighbours(opp + c); prefetch_neighbours(c2v + c); prefetch_neighbours(fv + f);
-    const uint32_t k = c - 3 * f, nc = k == 2 ? c - 2 : c + 1, pc = k == 0 ? c + 2 : c - 1;
+    const uint32_t k = E::k(c, f), i = E::idx(c, f);
+    prefetch_neighbours(opp + i); prefetch_neighbours(c2v + i); prefetch_neighbours(fv + f);
+    const uint32_t nc = k == 2 ? i - 2 : i + 1, pc = k == 0 ? i + 2 : i - 1;   // (the next / previous corner's entries: 3·face + k ids)
     if (!visited(c2v[nc]) || !visited(c2v[pc])) { emit(nc); emit(pc); push(c); continue; }
     if (kStamp) {
       const size_t qa = q + kAhead;
@@ -1090,12 +1133,12 @@ static void sequence_impl(const TableRef& t, const uint32_t* first, uint32_t n_f
     }
     fv[f] = 1;
     --faces_left;
-    const uint32_t v = c2v[c];
+    const uint32_t v = c2v[i];
     if (!kStamp) prefetch_neighbours(vv + v);
     const uint32_t right = opp[nc], lft = opp[pc];
     const uint32_t vflags = kStamp ? vs[v] : (uint32_t)vv[v];
     if (kStamp ? !(vflags & kPos) : !(vflags & 1)) {
-      emit(c);
+      emit(i);
       ++q;
       bool boundary;
       if (on_boundary) boundary = kStamp ? (vflags & kOnBoundary) != 0u : (vflags & 2) != 0;
@@ -1104,17 +1147,19 @@ static void sequence_impl(const TableRef& t, const uint32_t* first, uint32_t n_f
     } else if (kStamp) {
       q = (size_t)(vflags & kPos);   // (the tip was emitted at position (vflags & kPos) - 1: the shadow moves on from the entry after it)
     }
-    const bool rdone = right != kNone && fv[right / 3], ldone = lft != kNone && fv[lft / 3];
+    const bool rdone = right != kNone && fv[E::face(right)], ldone = lft != kNone && fv[E::face(lft)];
     if (rdone) { if (!ldone && lft != kNone) push(lft); }
     else if (ldone) { if (right != kNone) push(right); }
     else { if (lft != kNone) push(lft); if (right != kNone) push(right); }
   }
   set_size_written(seq, nq);
 }
-void attribute_sequence(const TableRef& t, const uint32_t* first, uint32_t n_first, const uint32_t* second, uint32_t n_second, std::vector<uint32_t>& seq, const uint8_t* on_boundary) {
+void attribute_sequence(const TableRef& t, const uint32_t* first, uint32_t n_first, const uint32_t* second, uint32_t n_second, std::vector<uint32_t>& seq, const uint8_t* on_boundary,
+                        bool second_quad) {
   static const bool no_shadow = std::getenv("DMI_NO_SHADOW") != nullptr || std::getenv("DMI_NO_SEQ_SHADOW") != nullptr;
-  if (t.F >= (1u << 16) && t.V < 0x7FFFFFF0u && !no_shadow) sequence_impl<true>(t, first, n_first, second, n_second, seq, on_boundary);
-  else sequence_impl<false>(t, first, n_first, second, n_second, seq, on_boundary);
+  const bool stamps = t.F >= (1u << 16) && t.V < 0x7FFFFFF0u && !no_shadow;
+  if (t.quad) { if (stamps) sequence_impl<true, Enc4>(t, first, n_first, second, n_second, second_quad, seq, on_boundary); else sequence_impl<false, Enc4>(t, first, n_first, second, n_second, second_quad, seq, on_boundary); }
+  else { if (stamps) sequence_impl<true, Enc3>(t, first, n_first, second, n_second, second_quad, seq, on_boundary); else sequence_impl<false, Enc3>(t, first, n_first, second, n_second, second_quad, seq, on_boundary); }
 }
 
 }  // namespace dmi

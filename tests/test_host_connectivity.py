@@ -76,6 +76,66 @@ def test_connectivity_of_a_million_faces_matches_the_oracle(n, open_boundary):
     _compare_conn(oracle_from_product_mesh(mesh), mesh)
 
 
+def _quad_case(mesh):
+    """bytes, seeds and sequences of the walks over 4·face + k ids (DMI_TEST_QUAD: the form the device stage hands the walks of a mesh none of whose attributes
+    needs a corner table of its own) against the same walks over 3·face + k ids; the table itself must hold the re-coded ids."""
+    plain = dmi.encode_connectivity(mesh)
+    os.environ["DMI_TEST_QUAD"] = "1"
+    try:
+        quad = dmi.encode_connectivity(mesh)
+    finally:
+        del os.environ["DMI_TEST_QUAD"]
+    try:
+        assert quad.bytes == plain.bytes
+        assert (quad.seeds() == plain.seeds()).all()
+        o3, o4 = plain.table(0)["opposite"], quad.table(0)["opposite"]
+        some = o3 != 0xFFFFFFFF
+        assert (o4[~some] == 0xFFFFFFFF).all() and (o4[some] == o3[some] + o3[some] // 3).all(), "the hook did not re-code the table: the case tests nothing"
+        for i in range(len(mesh.attributes)):
+            assert (quad.table(i)["sequence"] == plain.table(i)["sequence"]).all(), f"sequence {i}"
+    finally:
+        plain.close()
+        quad.close()
+
+
+@pytest.mark.parametrize("n,open_boundary", [(12, False), (17, True), (151, True), (190, False), (191, True)])   # (190 / 191: ≥ 2^16 faces, the walks on stamps)
+def test_walks_over_quad_corner_ids_on_grids(n, open_boundary):
+    _quad_case(synth.torus_mesh(n, open_boundary=open_boundary))
+    _quad_case(synth.torus_mesh(n, normals=False, uvs=False, open_boundary=open_boundary))
+
+
+@pytest.mark.parametrize("name", ["tetrahedron", "cube_quads", "sphere", "punctured_sphere", "torus"])
+def test_walks_over_quad_corner_ids_on_fixtures(name):
+    mesh = product_mesh_from_oracle(obj_session(name))
+    pos = mesh.attributes[0]
+    _quad_case(dmi.Mesh(mesh.faces, [pos]))   # (positions alone: the fixtures' other attributes have maps of their own — outside the form's class)
+
+
+def test_walks_over_quad_corner_ids_with_many_components_and_splits():
+    """Several components (one traversal each, interior and boundary start faces), holes (the boundary labelling and marking read the table through opp3),
+    and a handle (S faces with topology splits)."""
+    rng = np.random.default_rng(11)
+    parts, faces, base = [], [], 0
+    for n, open_b in [(9, True), (14, False), (6, True), (30, False)]:
+        m = synth.torus_mesh(n, normals=False, uvs=False, open_boundary=open_b, seed=int(rng.integers(1 << 30)))
+        parts.append(m.attributes[0].values)
+        faces.append(m.faces + base)
+        base += len(m.attributes[0].values)
+    f = np.concatenate(faces)
+    pos = np.concatenate(parts)
+    # holes: faces taken out as long as every vertex keeps another face
+    uses = np.bincount(f.ravel(), minlength=len(pos))
+    drop = []
+    for k in rng.permutation(len(f))[:400]:
+        if (uses[f[k]] > 2).all() and len(drop) < 12:
+            drop.append(int(k)); uses[f[k]] -= 1
+    assert len(drop) == 12
+    f = np.delete(f, drop, axis=0)
+    mesh = dmi.Mesh(f.astype(np.uint32), [dmi.Attribute(pos, dmi.ATT_POSITION)])
+    _compare_conn(oracle_from_product_mesh(mesh), mesh)
+    _quad_case(mesh)
+
+
 def test_connectivity_non_manifold_and_seams():
     rng = np.random.default_rng(5)
     # two fans sharing one vertex (non-manifold vertex), an edge with three faces, and UV seams
