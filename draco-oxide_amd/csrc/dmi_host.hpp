@@ -244,6 +244,7 @@ struct TableRef {
   uint32_t F, V;
   const uint32_t *c2v, *opp, *lmc;
   bool quad = false;   // see CornerTables::quad
+  bool closed = false; // known: every corner has an opposite (CornerTables::no_boundary)
 };
 // on_boundary (optional): one byte per vertex, != 0 ⇔ the vertex lies on a boundary of `t` (vertex_boundary_flags) — spares the walk two
 // dependent loads per vertex

@@ -186,7 +186,7 @@ extern "C++" int dmi::build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std
   std::vector<uint8_t>& on_boundary = on_boundary_p.v;
   const uint8_t* boundary_flags = on_device ? pre->on_boundary : nullptr;   // per vertex: on a boundary of the universal table (the device pass computes them with the left-most corners)
   auto sequence_universal = [&] {
-    TableRef tr{o.ct.F, o.ct.V, o.ct.c2v, o.ct.opp, o.ct.lmc, o.ct.quad};
+    TableRef tr{o.ct.F, o.ct.V, o.ct.c2v, o.ct.opp, o.ct.lmc, o.ct.quad, o.ct.no_boundary};
     attribute_sequence(tr, o.eb, o.seqs[0], boundary_flags ? boundary_flags : (on_boundary.empty() ? nullptr : on_boundary.data()));
   };
 

@@ -588,10 +588,18 @@ struct Walker {
   // object holds: members would be reloaded after each of them) and writes one (corner, symbol) pair per step through raw pointers.
   // c3: the corner to start from, a 3·face + k id
   void run_from(uint32_t c3) {
-    if (quad) { if (use_stamp) run_from_t<true, Enc4>(Enc4::from3(c3)); else run_from_t<false, Enc4>(Enc4::from3(c3)); }
-    else { if (use_stamp) run_from_t<true, Enc3>(c3); else run_from_t<false, Enc3>(c3); }
+    // (kClosed: every corner has an opposite — the device stage reports it — so the loop tests no entry for "none")
+    static const bool no_closed = std::getenv("DMI_NO_CLOSED") != nullptr;
+    const bool closed = t.no_boundary && !no_closed;
+    if (quad) {
+      if (use_stamp) { if (closed) run_from_t<true, Enc4, true>(Enc4::from3(c3)); else run_from_t<true, Enc4, false>(Enc4::from3(c3)); }
+      else run_from_t<false, Enc4, false>(Enc4::from3(c3));
+    } else {
+      if (use_stamp) { if (closed) run_from_t<true, Enc3, true>(c3); else run_from_t<true, Enc3, false>(c3); }
+      else run_from_t<false, Enc3, false>(c3);
+    }
   }
-  template <bool kStamp, class E>
+  template <bool kStamp, class E, bool kClosed>
   void run_from_t(uint32_t c) {
     const uint32_t* const opp = t.opp;
     const uint32_t* const c2v = t.c2v;
@@ -627,7 +635,7 @@ struct Walker {
         }
         prefetch_neighbours(vv + v);
         proc[n] = c;
-        const uint32_t gate = opp[i] != kNone ? 0x10u : 0u;   // (the face this one was entered from — or a start face — is always visited)
+        const uint32_t gate = (kClosed || opp[i] != kNone) ? 0x10u : 0u;   // (the face this one was entered from — or a start face — is always visited)
         const uint8_t vflags = vv[v];
         if (!(vflags & 1)) {
           vv[v] = vflags | 1;
@@ -639,9 +647,10 @@ struct Walker {
         // (neighbour states: byte flags — bit 0 visited, bit 1 S face — or stamps)
         uint32_t rs = 0, ls = 0;
         bool rv, lv, r_split, l_split;
+        const bool r_none = !kClosed && rc == kNone, l_none = !kClosed && lc == kNone;
         if (kStamp) {
-          rs = rc == kNone ? 0u : st[E::face(rc)]; ls = lc == kNone ? 0u : st[E::face(lc)];
-          rv = rc == kNone || rs != 0u; lv = lc == kNone || ls != 0u;
+          rs = r_none ? 0u : st[E::face(rc)]; ls = l_none ? 0u : st[E::face(lc)];
+          rv = r_none || rs != 0u; lv = l_none || ls != 0u;
           r_split = (rs & kStampS) != 0u; l_split = (ls & kStampS) != 0u;
         } else {
           const uint8_t rf = rc == kNone ? 1 : fv[E::face(rc)], lf = lc == kNone ? 1 : fv[E::face(lc)];
@@ -650,7 +659,7 @@ struct Walker {
         }
         // bits 4–6 of a symbol: which of the edges opposite (c, next, prev) lead to a face processed EARLIER (or to a start face) — what the seam
         // streams emit for this face (edgebreaker.rs:611-636 walks the faces last to first and emits the edges whose other face is not visited yet)
-        const uint8_t nb = (uint8_t)(gate | ((rc != kNone && rv) ? 0x20u : 0u) | ((lc != kNone && lv) ? 0x40u : 0u));
+        const uint8_t nb = (uint8_t)(gate | ((!r_none && rv) ? 0x20u : 0u) | ((!l_none && lv) ? 0x40u : 0u));
         const uint64_t symbol_idx = n;   // (symbols so far = the index of this one)
         if (rv) {
           if (kStamp && rs) q = (size_t)(rs & 0x7FFFFFFFu);   // (the right face was processed at position rs - 1: the shadow moves on from the one after it)
@@ -1070,13 +1079,13 @@ void attribute_sequence(const TableRef& t, const uint32_t* seeds, uint32_t n_see
 // 10M faces 44.5 → ≈ 40.5 ms).
 // E: the form of the corner ids `t.opp` holds (Enc3 / Enc4, see Walker); second_quad: the second part of the seeds holds 4·face + k ids (a traversal over
 // such a table leaves them so).  What the walk EMITS are 3·face + k ids in either form.
-template <bool kStamp, class E>
+template <bool kStamp, class E, bool kClosed>
 static void sequence_impl(const TableRef& t, const uint32_t* first, uint32_t n_first, const uint32_t* second, uint32_t n_second, bool second_quad, std::vector<uint32_t>& seq, const uint8_t* on_boundary) {
   Pooled<uint8_t> vvis_p(kStamp ? 0 : t.V, (uint8_t)0), fvis_p(t.F, (uint8_t)0);
   Pooled<uint32_t> vst_p(kStamp ? t.V : 0, 0u);
   constexpr uint32_t kOnBoundary = 0x80000000u, kPos = 0x7FFFFFFFu;
   // bytes: bit 0 visited, bit 1 the vertex lies on a boundary (from on_boundary: one load less per new vertex)
-  if (on_boundary) {
+  if (on_boundary && !kClosed) {
     if (kStamp) parallel_for(t.V, [&](size_t lo, size_t hi) { for (size_t v = lo; v < hi; ++v) vst_p.v[v] = on_boundary[v] ? kOnBoundary : 0u; });
     else parallel_for(t.V, [&](size_t lo, size_t hi) { for (size_t v = lo; v < hi; ++v) vvis_p.v[v] = on_boundary[v] ? 2 : 0; });
   }
@@ -1141,16 +1150,18 @@ static void sequence_impl(const TableRef& t, const uint32_t* first, uint32_t n_f
       emit(i);
       ++q;
       bool boundary;
-      if (on_boundary) boundary = kStamp ? (vflags & kOnBoundary) != 0u : (vflags & 2) != 0;
+      if (kClosed) boundary = false;
+      else if (on_boundary) boundary = kStamp ? (vflags & kOnBoundary) != 0u : (vflags & 2) != 0;
       else { const uint32_t l0 = t.lmc[v]; boundary = opp[corner_next(l0)] == kNone; }   // is_on_boundary: swing_left(lmc) is None
-      if (!boundary) { if (right != kNone) push(right); continue; }
+      if (!boundary) { if (kClosed || right != kNone) push(right); continue; }
     } else if (kStamp) {
       q = (size_t)(vflags & kPos);   // (the tip was emitted at position (vflags & kPos) - 1: the shadow moves on from the entry after it)
     }
-    const bool rdone = right != kNone && fv[E::face(right)], ldone = lft != kNone && fv[E::face(lft)];
-    if (rdone) { if (!ldone && lft != kNone) push(lft); }
-    else if (ldone) { if (right != kNone) push(right); }
-    else { if (lft != kNone) push(lft); if (right != kNone) push(right); }
+    const bool r_has = kClosed || right != kNone, l_has = kClosed || lft != kNone;
+    const bool rdone = r_has && fv[E::face(right)], ldone = l_has && fv[E::face(lft)];
+    if (rdone) { if (!ldone && l_has) push(lft); }
+    else if (ldone) { if (r_has) push(right); }
+    else { if (l_has) push(lft); if (r_has) push(right); }
   }
   set_size_written(seq, nq);
 }
@@ -1158,8 +1169,13 @@ void attribute_sequence(const TableRef& t, const uint32_t* first, uint32_t n_fir
                         bool second_quad) {
   static const bool no_shadow = std::getenv("DMI_NO_SHADOW") != nullptr || std::getenv("DMI_NO_SEQ_SHADOW") != nullptr;
   const bool stamps = t.F >= (1u << 16) && t.V < 0x7FFFFFF0u && !no_shadow;
-  if (t.quad) { if (stamps) sequence_impl<true, Enc4>(t, first, n_first, second, n_second, second_quad, seq, on_boundary); else sequence_impl<false, Enc4>(t, first, n_first, second, n_second, second_quad, seq, on_boundary); }
-  else { if (stamps) sequence_impl<true, Enc3>(t, first, n_first, second, n_second, second_quad, seq, on_boundary); else sequence_impl<false, Enc3>(t, first, n_first, second, n_second, second_quad, seq, on_boundary); }
+  // (closed: every corner has an opposite — the walk then tests no entry for "none" and no vertex for "on a boundary")
+#define DMI_SEQ(S, E, C) sequence_impl<S, E, C>(t, first, n_first, second, n_second, second_quad, seq, on_boundary)
+  static const bool no_closed = std::getenv("DMI_NO_CLOSED") != nullptr;
+  const bool closed = t.closed && !no_closed;
+  if (t.quad) { if (stamps) { if (closed) DMI_SEQ(true, Enc4, true); else DMI_SEQ(true, Enc4, false); } else DMI_SEQ(false, Enc4, false); }
+  else { if (stamps) { if (closed) DMI_SEQ(true, Enc3, true); else DMI_SEQ(true, Enc3, false); } else DMI_SEQ(false, Enc3, false); }
+#undef DMI_SEQ
 }
 
 }  // namespace dmi
