@@ -446,11 +446,11 @@ static const uint8_t kBits3[8] = {0, 1, 1, 2, 1, 2, 2, 3};
 // mesh: the entries a loop of the front touches lie next to — in memory: in the same or the neighbouring cache line of — the entries the
 // previous loop touched.  Touching line L therefore asks for L−1 and L+1 as well: when the front reaches them, a loop later, they wait in
 // L2 instead of DRAM (10M-triangle grid on the GPU box's EPYC: traversal 144 → 93 ms, sequencer 121 → 64 ms together with huge pages).
-// DMI_PF=<entries> sets the distance for uint32 arrays (0 = off); byte arrays use four times as many entries (the same 64 bytes).
-static const int kPfDist = std::getenv("DMI_PF") ? std::atoi(std::getenv("DMI_PF")) : 16;
-static const bool kPfFlags = std::getenv("DMI_PF_FLAGS") != nullptr;   // (the flag arrays stay cache-resident by themselves: prefetching their neighbour lines cost the lean loops 5 % — off unless asked for)
-inline void prefetch_neighbours(const uint32_t* p) { if (kPfDist) { __builtin_prefetch(p + kPfDist, 0, 2); __builtin_prefetch(p - kPfDist, 0, 2); } }
-inline void prefetch_neighbours(const uint8_t* p) { if (kPfDist && kPfFlags) { __builtin_prefetch(p + 4 * kPfDist, 1, 2); __builtin_prefetch(p - 4 * kPfDist, 1, 2); } }
+// The distance is a constant of the loops (the neighbouring 64-byte line on either side): as a run-time setting (rounds 3–4: DMI_PF=<entries>) it cost
+// every step a load, a test and the address arithmetic of each prefetch — a dozen of a step's ≈ 75 instructions, in loops bound by instruction issue.
+// The flag arrays stay cache-resident by themselves (prefetching their neighbour lines cost the lean loops 5 %: not done).
+inline void prefetch_neighbours(const uint32_t* p) { __builtin_prefetch(p + 16, 0, 2); __builtin_prefetch(p - 16, 0, 2); }
+inline void prefetch_neighbours(const uint8_t*) {}
 
 // The size of a vector of trivial elements whose first n slots (n ≤ capacity) were written through data(): the walks fill their output arrays
 // (one entry per face / vertex, capacity known up front) through raw pointers — a push_back per step is a call the compilers do not inline
@@ -600,7 +600,7 @@ struct Walker {
     }
   }
   template <bool kStamp, class E, bool kClosed>
-  void run_from_t(uint32_t c) {
+  void run_from_t(const uint32_t c_start) {
     const uint32_t* const opp = t.opp;
     const uint32_t* const c2v = t.c2v;
     uint8_t* const fv = fvis.data();
@@ -613,13 +613,14 @@ struct Walker {
     size_t q = ~(size_t)0 >> 1;        // the shadow: position in `processed` of the previous loop's face beside this one (far away until a step sees a visited neighbour)
     constexpr size_t kAhead = 12;
     stack.clear();
-    stack.push_back(c);
+    stack.push_back(c_start);
+    uint32_t c;                        // (a local of its own: the parameter's address is taken by push_back — it would live in memory, stored every step)
     while (!stack.empty() && !bad) {
       c = stack.back();
       if (c == kNone) { bad = true; break; }
       if (kStamp ? st[E::face(c)] != 0u : (fv[E::face(c)] & 1) != 0) { stack.pop_back(); continue; }
       for (;;) {
-        if (c == kNone || n >= cap) { bad = true; break; }
+        if ((!kClosed && c == kNone) || n >= cap) { bad = true; break; }
         const uint32_t f = E::face(c), k = E::k(c, f), i = E::idx(c, f);
         prefetch_neighbours(opp + i); prefetch_neighbours(c2v + i);
         const uint32_t v = c2v[i];
