@@ -166,7 +166,12 @@ extern "C++" int dmi::build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std
     if (std::getenv("DMI_TEST_QUAD") && o.ct.opp == o.ct.opp_own.data() && mesh->num_faces < (1u << 30)) {
       bool alike = true;
       for (uint32_t i = 1; i < mesh->num_atts && alike; ++i) alike = mesh->atts[i].point_to_value == mesh->atts[0].point_to_value;
-      if (alike) { for (uint32_t& v : o.ct.opp_own) if (v != kNone) v += v / 3; o.ct.quad = true; }
+      if (alike) {
+        bool open_edge = false;
+        for (uint32_t& v : o.ct.opp_own) { if (v != kNone) v += v / 3; else open_edge = true; }
+        o.ct.quad = true;
+        o.ct.no_boundary = !open_edge;   // (what the device stage reports: the walks of a closed mesh run without their tests for "none")
+      }
     }
   }
   const double t_univ = since(c0);

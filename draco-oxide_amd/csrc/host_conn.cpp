@@ -1080,6 +1080,10 @@ void attribute_sequence(const TableRef& t, const uint32_t* seeds, uint32_t n_see
 // 10M faces 44.5 → ≈ 40.5 ms).
 // E: the form of the corner ids `t.opp` holds (Enc3 / Enc4, see Walker); second_quad: the second part of the seeds holds 4·face + k ids (a traversal over
 // such a table leaves them so).  What the walk EMITS are 3·face + k ids in either form.
+// A face's single successor is walked next without a trip through the stack (the reference pushes it and pops it at once: a store, a load and the
+// forwarding between them on the walk's dependency chain), and the walk is over when every vertex has been emitted.  (Tried: skipping the reference's test
+// of a corner's next / previous vertices for corners that come off the walk's own stack — they lie across an edge of a face just processed, both vertices
+// visited — for tables the device checked: no change, the step is bound by the load of the opposite corner.)
 template <bool kStamp, class E, bool kClosed>
 static void sequence_impl(const TableRef& t, const uint32_t* first, uint32_t n_first, const uint32_t* second, uint32_t n_second, bool second_quad, std::vector<uint32_t>& seq, const uint8_t* on_boundary) {
   Pooled<uint8_t> vvis_p(kStamp ? 0 : t.V, (uint8_t)0), fvis_p(t.F, (uint8_t)0);
@@ -1100,7 +1104,7 @@ static void sequence_impl(const TableRef& t, const uint32_t* first, uint32_t n_f
   if (seq.capacity() < (size_t)t.V) seq.reserve(t.V);
   uint32_t* const sq = seq.data();
   size_t nq = 0;
-  const size_t qcap = t.V;             // (every vertex is emitted once: sequence.rs:41-46)
+  const size_t qcap = t.V;             // every vertex is emitted once (sequence.rs:41-46: its flag is set with the emission), so nq never passes t.V
   std::vector<uint32_t> stack_store(4096);
   uint32_t* st = stack_store.data();
   size_t sn = 0, scap = stack_store.size();
@@ -1109,60 +1113,58 @@ static void sequence_impl(const TableRef& t, const uint32_t* first, uint32_t n_f
     st[sn++] = x;
   };
   uint64_t left = (uint64_t)n_first + n_second;
-  // Every seed and stack entry whose face is already marked is skipped whole: once all faces are marked nothing can be emitted any more — and the
-  // walk from the traversal's last corner marks a whole component before the next seed is read, so a one-component mesh would otherwise
-  // spend F more iterations (10 ms per 10M faces) reading seeds it skips.
-  uint32_t faces_left = t.F;
   size_t q = ~(size_t)0 >> 1;          // the shadow: position in `seq` of what the previous loop emitted beside this spot
   constexpr size_t kAhead = 8;
   auto visited = [&](uint32_t v) -> bool { return kStamp ? (vs[v] & kPos) != 0u : (vv[v] & 1) != 0; };
   auto emit = [&](uint32_t i) {   // i: where the corner's entries are (= its 3·face + k id)
     const uint32_t v = c2v[i];
-    if (kStamp) { const uint32_t f = vs[v]; if (!(f & kPos) && nq < qcap) { sq[nq] = i; vs[v] = f | (uint32_t)++nq; } }
-    else { const uint8_t f = vv[v]; if (!(f & 1) && nq < qcap) { vv[v] = f | 1; sq[nq++] = i; } }
+    if (kStamp) { const uint32_t f = vs[v]; if (!(f & kPos)) { sq[nq] = i; vs[v] = f | (uint32_t)++nq; } }
+    else { const uint8_t f = vv[v]; if (!(f & 1)) { vv[v] = f | 1; sq[nq++] = i; } }
   };
+  uint32_t c;
   for (;;) {
-    uint32_t c;
-    if (!faces_left) break;
     if (sn) c = st[--sn];
-    else if (left) {
+    else {
+      // Seeds.  Once every vertex is emitted nothing can follow — the walk from the traversal's last corner covers a whole component before the next seed
+      // is read: a one-component mesh would otherwise read F more seeds only to skip them (10 ms per 10M faces).
+      if (nq == qcap || !left) break;
       --left;
       if (left >= n_first) { c = second[left - n_first]; if (second_quad != E::kQuad) c = second_quad ? E::from3(Enc4::to3(c)) : E::from3(c); }
       else c = E::from3(first[left]);
     }
-    else break;
+  have_c:
     const uint32_t f = E::face(c);
     if (fv[f]) continue;
     const uint32_t k = E::k(c, f), i = E::idx(c, f);
-    prefetch_neighbours(opp + i); prefetch_neighbours(c2v + i); prefetch_neighbours(fv + f);
+    prefetch_neighbours(opp + i); prefetch_neighbours(c2v + i);
     const uint32_t nc = k == 2 ? i - 2 : i + 1, pc = k == 0 ? i + 2 : i - 1;   // (the next / previous corner's entries: 3·face + k ids)
-    if (!visited(c2v[nc]) || !visited(c2v[pc])) { emit(nc); emit(pc); push(c); continue; }
+    if (!visited(c2v[nc]) || !visited(c2v[pc])) { emit(nc); emit(pc); goto have_c; }   // (pushed and popped at once by the reference)
     if (kStamp) {
       const size_t qa = q + kAhead;
       if (qa < nq) { const uint32_t g = sq[qa]; __builtin_prefetch(opp + g, 0, 3); __builtin_prefetch(opp + g + 16, 0, 3); __builtin_prefetch(opp + g - 16, 0, 3); __builtin_prefetch(c2v + g, 0, 3); }
     }
     fv[f] = 1;
-    --faces_left;
     const uint32_t v = c2v[i];
-    if (!kStamp) prefetch_neighbours(vv + v);
     const uint32_t right = opp[nc], lft = opp[pc];
     const uint32_t vflags = kStamp ? vs[v] : (uint32_t)vv[v];
     if (kStamp ? !(vflags & kPos) : !(vflags & 1)) {
-      emit(i);
+      if (kStamp) { sq[nq] = i; vs[v] = vflags | (uint32_t)++nq; } else { vv[v] = (uint8_t)(vflags | 1); sq[nq++] = i; }
       ++q;
       bool boundary;
       if (kClosed) boundary = false;
       else if (on_boundary) boundary = kStamp ? (vflags & kOnBoundary) != 0u : (vflags & 2) != 0;
       else { const uint32_t l0 = t.lmc[v]; boundary = opp[corner_next(l0)] == kNone; }   // is_on_boundary: swing_left(lmc) is None
-      if (!boundary) { if (kClosed || right != kNone) push(right); continue; }
+      if (!boundary) { if (kClosed || right != kNone) { c = right; goto have_c; } continue; }
     } else if (kStamp) {
       q = (size_t)(vflags & kPos);   // (the tip was emitted at position (vflags & kPos) - 1: the shadow moves on from the entry after it)
     }
     const bool r_has = kClosed || right != kNone, l_has = kClosed || lft != kNone;
     const bool rdone = r_has && fv[E::face(right)], ldone = l_has && fv[E::face(lft)];
-    if (rdone) { if (!ldone && l_has) push(lft); }
-    else if (ldone) { if (r_has) push(right); }
-    else { if (l_has) push(lft); if (r_has) push(right); }
+    if (rdone) { if (!ldone && l_has) { c = lft; goto have_c; } }
+    else if (ldone) { if (r_has) { c = right; goto have_c; } }
+    else if (l_has && r_has) { push(lft); c = right; goto have_c; }
+    else if (l_has) { c = lft; goto have_c; }
+    else if (r_has) { c = right; goto have_c; }
   }
   set_size_written(seq, nq);
 }

@@ -111,12 +111,13 @@ def test_walks_over_quad_corner_ids_on_fixtures(name):
     _quad_case(dmi.Mesh(mesh.faces, [pos]))   # (positions alone: the fixtures' other attributes have maps of their own — outside the form's class)
 
 
-def test_walks_over_quad_corner_ids_with_many_components_and_splits():
+@pytest.mark.parametrize("sizes", [[(9, True), (14, False), (6, True), (30, False)], [(150, True), (120, False), (60, True), (100, False)]])
+def test_walks_over_quad_corner_ids_with_many_components_and_splits(sizes):
     """Several components (one traversal each, interior and boundary start faces), holes (the boundary labelling and marking read the table through opp3),
-    and a handle (S faces with topology splits)."""
+    and a handle (S faces with topology splits); the larger set runs the walks on stamps."""
     rng = np.random.default_rng(11)
     parts, faces, base = [], [], 0
-    for n, open_b in [(9, True), (14, False), (6, True), (30, False)]:
+    for n, open_b in sizes:
         m = synth.torus_mesh(n, normals=False, uvs=False, open_boundary=open_b, seed=int(rng.integers(1 << 30)))
         parts.append(m.attributes[0].values)
         faces.append(m.faces + base)
