@@ -34,12 +34,12 @@ def agg(sub, names):
 
 PASS_PREFIXES = ("k_value_ranges", "k_seq_quantize", "k_i32_minmax_final", "k_predict_fused", "k_predict_packed", "k_orient_summary", "k_pred_parallelogram",
                  "k_pred_texcoord", "k_pred_delta", "k_seq_gather_rec", "k_texcoord_fixup")
-EARLY_PREFIXES = ("k_value_ranges", "k_value_quantize_rec")   # round 5: issued on a side stream BEFORE the host walks when the call has an early stage
+EARLY_PREFIXES = ("k_value_ranges", "k_value_quantize_rec", "k_i32_minmax_final")   # round 5: issued on a side stream BEFORE the host walks when the call has an early stage
 F = agg("fetch", ["FETCH_SIZE"])["FETCH_SIZE"]
 W = agg("write", ["WRITE_SIZE"])["WRITE_SIZE"]
 has_early = any(n.startswith("k_seq_gather_rec") for n in set(F) | set(W))
 if has_early:
-    PASS_PREFIXES = tuple(p for p in PASS_PREFIXES if p != "k_value_ranges")
+    PASS_PREFIXES = tuple(p for p in PASS_PREFIXES if p not in ("k_value_ranges", "k_i32_minmax_final"))
 tf = tw = 0.0
 ef = ew = 0.0
 rows = []
@@ -73,7 +73,7 @@ lines = [f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- 
          "kernel, launches, fetch_MB, fetch_x2_MB, write_MB"] + rows
 lines.append(f"# quantize+predict pass per step: fetch {tf / 1e6:.1f} MB raw / {2 * tf / 1e6:.1f} MB doubled, write {tw / 1e6:.1f} MB, total {traffic / 1e6:.1f} MB")
 if has_early:
-    lines.append(f"# early stage per step (value ranges + value-order quantization into records, on a side stream before the host walks; NOT in the pass above): "
+    lines.append(f"# early stage per step (value ranges + value-order quantization into records + the quantized values' min/max, on a side stream before the host walks; NOT in the pass above): "
                  f"fetch {ef / 1e6:.1f} MB raw / {2 * ef / 1e6:.1f} MB doubled, write {ew / 1e6:.1f} MB, total {(2 * ef + ew) / 1e6:.1f} MB")
 open(f"profiles/{tag}_pmc_traffic.csv", "w").write("\n".join(lines) + "\n")
 
