@@ -83,6 +83,48 @@ struct Eb {
   }
 };
 
+// the same traversal over HOP tables: R[i] = opposite[next(c)], L[i] = opposite[prev(c)] for the corner whose entries are at i (ids 4·face + k): the next
+// corner of a step is ONE load away from the current one (shift, subtract, load) instead of mask, compare, select, subtract, load
+struct EbHops {
+  uint32_t F, V;
+  const uint32_t *R, *L, *c2v;
+  uint32_t* st; uint8_t* vv;
+  uint32_t* proc; uint8_t* sym; size_t n = 0;
+  std::vector<uint32_t> stack;
+  void run_from(uint32_t c) {
+    size_t q = ~(size_t)0 >> 1;
+    constexpr size_t kAhead = 12;
+    stack.clear(); stack.push_back(c);
+    while (!stack.empty()) {
+      c = stack.back();
+      if (st[c >> 2] != 0u) { stack.pop_back(); continue; }
+      for (;;) {
+        const uint32_t f = c >> 2, i = c - f;
+        pf(R + i); pf(c2v + i);
+        const uint32_t v = c2v[i];
+        const uint32_t rc = R[i];
+        { const size_t qa = q + kAhead; if (qa < n) { const uint32_t g = proc[qa]; const uint32_t gi = g - (g >> 2); __builtin_prefetch(R + gi, 0, 3); __builtin_prefetch(R + gi + 16, 0, 3); __builtin_prefetch(R + gi - 16, 0, 3); __builtin_prefetch(c2v + gi, 0, 3); } ++q; }
+        st[f] = (uint32_t)n + 1u;
+        proc[n] = c;
+        const uint8_t vflags = vv[v];
+        if (!(vflags & 1)) { vv[v] = vflags | 1; sym[n++] = SYM_C; c = rc; continue; }
+        const uint32_t lc = L[i];
+        const uint32_t rs = st[rc >> 2], ls = st[lc >> 2];
+        if (rs) {
+          q = (size_t)(rs & 0x7FFFFFFFu);
+          if (ls) { sym[n++] = SYM_E; stack.pop_back(); break; }
+          sym[n++] = SYM_R; c = lc;
+        } else if (ls) {
+          q = (size_t)(ls & 0x7FFFFFFFu);
+          sym[n++] = SYM_L; c = rc;
+        } else {
+          sym[n++] = SYM_S; stack.back() = lc; stack.push_back(rc); break;
+        }
+      }
+    }
+  }
+};
+
 int main(int argc, char** argv) {
   const uint32_t n = argc > 1 ? (uint32_t)std::atoi(argv[1]) : 2236u;
   const int repeats = argc > 2 ? std::atoi(argv[2]) : 5;
@@ -109,13 +151,16 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i + 1 < C; ++i) if (es[i].key == es[i + 1].key) { opp3[es[i].c] = es[i + 1].c; opp3[es[i + 1].c] = es[i].c; ++i; }
     for (size_t c = 0; c < C; ++c) opp4[c] = E4::enc(opp3[c]);
   }
+  uint32_t* hopR = huge_alloc<uint32_t>(C + 64) + 32;
+  uint32_t* hopL = huge_alloc<uint32_t>(C + 64) + 32;
+  for (size_t c = 0; c < C; ++c) { const uint32_t k = (uint32_t)(c % 3); hopR[c] = opp4[k == 2 ? c - 2 : c + 1]; hopL[c] = opp4[k == 0 ? c + 2 : c - 1]; }
   uint32_t* st = huge_alloc<uint32_t>(F + 64) + 32;
   uint8_t* vv = huge_alloc<uint8_t>(V + 256) + 128;
   uint32_t* proc = huge_alloc<uint32_t>(F + 64);
   uint8_t* sym = huge_alloc<uint8_t>(F + 64);
   std::vector<uint32_t> ref;
   for (int r = 0; r < repeats; ++r) {
-    for (int form = 0; form < 2; ++form) {
+    for (int form = 0; form < 3; ++form) {
       std::memset(st, 0, (size_t)F * 4); std::memset(vv, 0, V);
       const double t0 = now_ms();
       size_t done = 0;
@@ -125,8 +170,13 @@ int main(int argc, char** argv) {
         st[0] = 0x7FFFFFFFu; vv[c2v[0]] |= 1; vv[c2v[1]] |= 1; vv[c2v[2]] |= 1;
         w.run_from(opp3[1]);
         done = w.n;
-      } else {
+      } else if (form == 1) {
         Eb<E4> w{F, V, opp4, c2v, st, vv, proc, sym};
+        st[0] = 0x7FFFFFFFu; vv[c2v[0]] |= 1; vv[c2v[1]] |= 1; vv[c2v[2]] |= 1;
+        w.run_from(opp4[1]);
+        done = w.n;
+      } else {
+        EbHops w{F, V, hopR, hopL, c2v, st, vv, proc, sym};
         st[0] = 0x7FFFFFFFu; vv[c2v[0]] |= 1; vv[c2v[1]] |= 1; vv[c2v[2]] |= 1;
         w.run_from(opp4[1]);
         done = w.n;
@@ -135,7 +185,7 @@ int main(int argc, char** argv) {
       bool same = true;
       if (form == 0) ref.assign(proc, proc + done);
       else { same = done == ref.size(); for (size_t i = 0; i < done && same; ++i) same = E4::dec(proc[i]) == ref[i]; }
-      std::printf("%s: %zu faces in %.1f ms (%.2f ns per face)%s\n", form == 0 ? "3f+k" : "4f+k", done, t1 - t0, (t1 - t0) * 1e6 / (double)done, form == 1 ? (same ? "  [same order]" : "  [ORDER DIFFERS]") : "");
+      std::printf("%s: %zu faces in %.1f ms (%.2f ns per face)%s\n", form == 0 ? "3f+k" : (form == 1 ? "4f+k" : "hops"), done, t1 - t0, (t1 - t0) * 1e6 / (double)done, form >= 1 ? (same ? "  [same order]" : "  [ORDER DIFFERS]") : "");
     }
   }
   return 0;
