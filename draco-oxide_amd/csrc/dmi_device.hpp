@@ -326,8 +326,7 @@ struct RelabelBatch {
 void launch_relabel_batch(const RelabelBatch& b, hipStream_t s);
 struct ComposeItem { const uint32_t* s2p; const uint32_t* p2v; uint32_t* s2v; uint32_t off /* Σ n_seq of the items before */, n; };
 void launch_corner_ranks(const uint32_t* c2v, const uint32_t* rank, uint64_t C, uint32_t* c2r, hipStream_t s);   // c2r[c] = rank[c2v[c]]
-void launch_seq_points(const uint32_t* seq, uint32_t n_seq, const uint32_t* c2p, uint32_t* s2p, hipStream_t s);     // s2p[k] = c2p[seq[k]]
-void launch_rank_and_points(const uint32_t* seq, uint32_t n_seq, const uint32_t* c2v, const uint32_t* c2p, uint32_t* rank, uint32_t* s2p, hipStream_t s);   // both of the above in one pass over the sequence
+void launch_rank_and_points(const uint32_t* seq, uint32_t n_seq, const uint32_t* c2v, const uint32_t* c2p, uint32_t* rank, uint32_t* s2p, hipStream_t s);   // rank[c2v[seq[k]]] = k and s2p[k] = c2p[seq[k]] in one pass over the sequence
 void launch_compose_batch(const ComposeItem* items_dev, uint32_t n_items, uint32_t total, hipStream_t s);
 // fan rows of many tables in one launch (k_build_fans per item)
 struct FanItem { const uint32_t *seq, *c2r, *opp; uint32_t *hdr, *apex, *fan; uint32_t off /* Σ n of the items before */, n, centre_in_apex, pad; };

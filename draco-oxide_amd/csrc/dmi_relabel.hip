@@ -92,10 +92,7 @@ __global__ __launch_bounds__(kBlock) void k_remap_seq(const uint32_t* __restrict
 __global__ __launch_bounds__(kBlock) void k_corner_ranks(const uint32_t* __restrict__ c2v, const uint32_t* __restrict__ rank, uint64_t C, uint32_t* __restrict__ c2r) {
   for (uint64_t c = (uint64_t)blockIdx.x * kBlock + threadIdx.x; c < C; c += (uint64_t)gridDim.x * kBlock) c2r[c] = rank[c2v[c]];
 }
-__global__ __launch_bounds__(kBlock) void k_seq_points(const uint32_t* __restrict__ seq, uint32_t n_seq, const uint32_t* __restrict__ c2p, uint32_t* __restrict__ s2p) {
-  for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n_seq; k += gridDim.x * kBlock) s2p[k] = c2p[seq[k]];
-}
-// both at once for a table in the mesh's own face order (one read of the sequence, the two table entries of a corner next to each other in time):
+// for a table in the mesh's own face order (one read of the sequence, the two table entries of a corner next to each other in time):
 // rank[c2v[seq[k]]] = k and s2p[k] = c2p[seq[k]]
 __global__ __launch_bounds__(kBlock) void k_rank_and_points(const uint32_t* __restrict__ seq, uint32_t n_seq, const uint32_t* __restrict__ c2v, const uint32_t* __restrict__ c2p,
                                                             uint32_t* __restrict__ rank, uint32_t* __restrict__ s2p) {
@@ -214,7 +211,6 @@ void launch_corner_ranks(const uint32_t* c2v, const uint32_t* rank, uint64_t C, 
 void launch_rank_and_points(const uint32_t* seq, uint32_t n_seq, const uint32_t* c2v, const uint32_t* c2p, uint32_t* rank, uint32_t* s2p, hipStream_t s) {
   if (n_seq) hipLaunchKernelGGL(k_rank_and_points, grid_of(n_seq), kBlock, 0, s, seq, n_seq, c2v, c2p, rank, s2p);
 }
-void launch_seq_points(const uint32_t* seq, uint32_t n_seq, const uint32_t* c2p, uint32_t* s2p, hipStream_t s) { if (n_seq) hipLaunchKernelGGL(k_seq_points, grid_of(n_seq), kBlock, 0, s, seq, n_seq, c2p, s2p); }
 void launch_compose_s2v(const uint32_t* s2p, uint32_t n_seq, const uint32_t* p2v, uint32_t num_points, uint32_t num_unique, uint32_t* s2v, uint32_t* bad, hipStream_t s) {
   if (n_seq) hipLaunchKernelGGL(k_compose_s2v, grid_of(n_seq), kBlock, 0, s, s2p, n_seq, p2v, num_points, num_unique, s2v, bad);
 }
