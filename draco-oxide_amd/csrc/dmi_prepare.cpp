@@ -86,7 +86,9 @@ struct DeviceTables {
     HIP_TRY(hipMemcpyAsync(hp_opp, quad ? d_opp_q : d_opp, C * 4, hipMemcpyDeviceToHost, stream));
     if (mapped) HIP_TRY(hipMemcpyAsync(hp_c2v, d_c2v, C * 4, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(hp_onb, d_onb, Vcap, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(hp_lmc, d_lmc, (size_t)Vcap * 4, hipMemcpyDeviceToHost, stream));
+    // (left-most corners: on the host only the construction of attribute tables with seams reads them — none exists for a mesh in the quad class, whose
+    // walks take their boundary tests from the flags above: 4 bytes per vertex less on a stage bound by the link)
+    if (!quad) HIP_TRY(hipMemcpyAsync(hp_lmc, d_lmc, (size_t)Vcap * 4, hipMemcpyDeviceToHost, stream));
     t_kernels = ms();
     // while the device works: the vertex ids of a mesh without a position map are its faces — the walks read them at random, so they get a
     // copy on huge pages (the caller's array is on whatever pages its allocator chose); storage from the host pool, written in parallel slices
@@ -107,7 +109,7 @@ struct DeviceTables {
     if (flags & (CONN_DEGENERATE | CONN_NONMANIFOLD_EDGE | CONN_MULTI_FAN)) return DMI_OK;   // the reference's serial walks decide (host_conn.cpp)
     if (flags & CONN_UNUSED_VERTEX) return fail(DMI_ERR_UNUSED_VERTICES, "mesh contains unused vertices");
     V = hp_words[1] + 1;
-    pre.c2v = mapped ? hp_c2v : c2v_host; pre.opp = hp_opp; pre.lmc = hp_lmc; pre.on_boundary = hp_onb; pre.V = V;
+    pre.c2v = mapped ? hp_c2v : c2v_host; pre.opp = hp_opp; pre.lmc = quad ? nullptr : hp_lmc; pre.on_boundary = hp_onb; pre.V = V;
     pre.no_boundary = !(flags & CONN_HAS_BOUNDARY);
     pre.quad = quad;
     valid = true;
