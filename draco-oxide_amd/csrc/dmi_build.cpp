@@ -148,8 +148,9 @@ struct BuildGroup {
   bool in_place = false;                // every array of every member lies in page-locked host memory: DMA straight out of the caller's buffers, no pack
   struct Span { uintptr_t lo, hi; size_t dev_off; };
   std::vector<Span> spans;              // in place: merged host ranges, one DMA each
+  bool settled = false;                 // ev_done has been waited for: nothing of the build is in flight (work issued on S AFTER it — the group's connectivity stage — uses memory of its own)
   ~BuildGroup() {
-    if (S) (void)hipStreamSynchronize(S);
+    if (S && !settled) (void)hipStreamSynchronize(S);
     for (hipEvent_t e : {ev_counts, ev_done, ev_k0, ev_k1}) if (e) (void)hipEventDestroy(e);
     release_stage(up_stage);
   }
@@ -470,6 +471,9 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
     BuildGroup& g = *gp;
     BuiltGroup& bg = *g.built;
     HIP_TRY(hipEventSynchronize(g.ev_done));
+    // (the build's scratch and staging go back without waiting for the stream again: the connectivity stage issued behind the build below would
+    //  otherwise hold this thread — 14 ms per 256-mesh stage with attribute tables — until ITS read-back has landed)
+    g.settled = true; g.scratch.owner_waits = true;
     float km = 0;
     if (hipEventElapsedTime(&km, g.ev_k0, g.ev_k1) == hipSuccess) kernels_ms += km; else (void)hipGetLastError();
     const uint32_t M = (uint32_t)g.meshes.size();

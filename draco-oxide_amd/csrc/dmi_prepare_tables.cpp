@@ -1,5 +1,7 @@
 // dmi_prepare_tables.cpp — the attribute corner tables of a connectivity group on the device (AttStage: dmi_conn.hip k_att_*) and the universal tables of a
 // device-built group issued right behind its build (built_group_issue_tables).  Split out of dmi_prepare.cpp in round 5.
+#include <atomic>
+#include <thread>
 #include "dmi_prepare.hpp"
 
 using namespace dmi;
@@ -96,6 +98,32 @@ int dmi::built_group_issue_tables(BuiltGroup& bg, hipStream_t s) {
   AttStage& st = cn.att;
   st = AttStage{};
   static const bool host_att = std::getenv("DMI_HOST_ATT_TABLES") != nullptr;
+  // (the map comparisons of all members side by side: two full-length memcmp per mesh with normals and texture coordinates — 90 MB for a 256-mesh stage —
+  //  were 9 of a seam stage's 29 ms of build on the one thread that issues its tables)
+  struct Pair { uint32_t mi; size_t a; };
+  std::vector<Pair> pairs;
+  for (uint32_t mi = 0; mi < ND && !host_att; ++mi) {
+    const BuiltGroup::Member& mem = bg.members[mi];
+    if (mem.atts.empty() || !mem.F) continue;
+    for (size_t a = 0; a < mem.atts.size(); ++a)
+      if (mem.atts[a].att_type != DMI_ATT_POSITION && mem.atts[a].map_off != (size_t)-1 && mem.atts[0].map_off != (size_t)-1) pairs.push_back({mi, a});
+  }
+  std::vector<uint8_t> maps_equal(pairs.size(), 0);
+  {
+    std::atomic<size_t> next{0};
+    auto work = [&] {
+      for (size_t q; (q = next.fetch_add(1)) < pairs.size();) {
+        const BuiltGroup::Member& mem = bg.members[pairs[q].mi];
+        maps_equal[q] = std::memcmp(bg.h_a + mem.atts[pairs[q].a].map_off, bg.h_a + mem.atts[0].map_off, (size_t)mem.P * 4) == 0;
+      }
+    };
+    const size_t n_threads = std::min<size_t>({pairs.size(), (size_t)host_threads(), (size_t)16});
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < n_threads; ++t) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+  }
+  size_t next_pair = 0;
   for (uint32_t mi = 0; mi < ND && !host_att; ++mi) {
     const BuiltGroup::Member& mem = bg.members[mi];
     if (mem.atts.empty() || !mem.F) continue;
@@ -103,7 +131,8 @@ int dmi::built_group_issue_tables(BuiltGroup& bg, hipStream_t s) {
     for (size_t a = 0; a < mem.atts.size(); ++a) {
       if (mem.atts[a].att_type == DMI_ATT_POSITION) continue;
       const size_t ma = mem.atts[a].map_off, mp = mem.atts[0].map_off;
-      const bool same = (ma == (size_t)-1 && mp == (size_t)-1) || (ma != (size_t)-1 && mp != (size_t)-1 && std::memcmp(bg.h_a + ma, bg.h_a + mp, (size_t)mem.P * 4) == 0);
+      bool same = ma == (size_t)-1 && mp == (size_t)-1;
+      if (ma != (size_t)-1 && mp != (size_t)-1) same = maps_equal[next_pair++] != 0;
       if (!same) st.add(mi, k, mem.F, mem.atts[0].n_unique, ma == (size_t)-1 ? kNone : (uint32_t)(ma / 4));
       ++k;
     }
