@@ -936,7 +936,7 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
         const uint32_t cs[3] = {c, corner_next(c), corner_prev(c)};
         uint32_t m = 0;
         for (int k = 0; k < 3; ++k) {
-          const uint32_t o = t.opp[cs[k]];
+          const uint32_t o = w.opp3(cs[k]);
           if (o == kNone) continue;
           const uint32_t wo = where[o / 3];
           if (wo == kNone || wo < (uint32_t)i) m |= 1u << k;      // its face comes later in the walk from the back (or never: a start face)
@@ -1017,7 +1017,7 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
           const uint32_t cs[3] = {c, corner_next(c), corner_prev(c)};
           fv[c / 3] = 1;
           for (uint32_t cc : cs) {
-            const uint32_t o = t.opp[cc];
+            const uint32_t o = w.opp3(cc);
             if (o == kNone || fv[o / 3]) continue;
             ++total;
             --at;
