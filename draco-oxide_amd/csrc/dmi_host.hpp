@@ -78,7 +78,6 @@ struct WalkSlots {
   void release() { { std::lock_guard<std::mutex> lock(m); --in_use; } cv.notify_one(); }
 };
 WalkSlots& walk_slots();
-extern thread_local int g_stream_priority_class;   // dmi_streams.cpp
 // [0, n) in contiguous slices on up to 32 host threads (large, embarrassingly parallel index loops); fn(lo, hi)
 template <class Fn>
 inline void parallel_for(size_t n, Fn&& fn) {

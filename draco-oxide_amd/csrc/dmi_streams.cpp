@@ -74,19 +74,17 @@ struct NumaPin {
 namespace {
 struct StreamPool {
   std::mutex m;
-  std::vector<std::pair<int, std::shared_ptr<StreamHolder>>> idle[9];   // [kind + 3 · priority class]
+  std::vector<std::pair<int, std::shared_ptr<StreamHolder>>> idle[3];
   static StreamPool& get() { static StreamPool* p = new StreamPool(); return *p; }   // (never destroyed: threads may exit after static destruction began)
 };
 struct ThreadStreams {
-  std::vector<std::pair<int, std::shared_ptr<StreamHolder>>> mine[9];
+  std::vector<std::pair<int, std::shared_ptr<StreamHolder>>> mine[3];
   ~ThreadStreams() {
     StreamPool& pool = StreamPool::get();
     std::lock_guard<std::mutex> lock(pool.m);
-    for (int k = 0; k < 9; ++k) for (auto& e : mine[k]) pool.idle[k].push_back(std::move(e));
+    for (int k = 0; k < 3; ++k) for (auto& e : mine[k]) pool.idle[k].push_back(std::move(e));
   }
-  std::shared_ptr<StreamHolder> get(int kind0, int device) {
-    const int cls = g_stream_priority_class;   // 0 normal, 1 high, 2 low: the streams this thread creates (a pipeline thread sets it once, by its step)
-    const int kind = kind0 + 3 * cls;
+  std::shared_ptr<StreamHolder> get(int kind, int device) {
     for (auto& e : mine[kind]) if (e.first == device) return e.second;
     std::shared_ptr<StreamHolder> h;
     {
@@ -97,15 +95,7 @@ struct ThreadStreams {
     }
     if (!h) {
       h = std::make_shared<StreamHolder>();
-      hipError_t e = hipSetDevice(device);
-      if (e == hipSuccess) {
-        if (cls == 0) e = kind0 == 0 ? hipStreamCreate(&h->s) : hipStreamCreateWithFlags(&h->s, hipStreamNonBlocking);
-        else {
-          int least = 0, greatest = 0;
-          (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-          e = hipStreamCreateWithPriority(&h->s, kind0 == 0 ? hipStreamDefault : hipStreamNonBlocking, cls == 1 ? greatest : least);
-        }
-      }
+      const hipError_t e = hipSetDevice(device) != hipSuccess ? hipErrorInvalidDevice : (kind == 0 ? hipStreamCreate(&h->s) : hipStreamCreateWithFlags(&h->s, hipStreamNonBlocking));
       if (e != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     }
     mine[kind].push_back({device, h});
@@ -119,7 +109,6 @@ ThreadStreams& thread_streams() { static thread_local ThreadStreams t; return t;
 // Two more library streams per (host thread, device): consecutive groups of a slice alternate between them, so the read-back of one
 // group's tables overlaps the upload of the next group's faces (the two directions of the link run side by side).
 namespace dmi {
-thread_local int g_stream_priority_class = 0;
 std::shared_ptr<StreamHolder> library_thread_stream(int device) { return thread_streams().get(0, device); }
 hipStream_t library_group_stream(int device, int which) {
   const std::shared_ptr<StreamHolder> h = thread_streams().get(1 + (which & 1), device);

@@ -101,10 +101,6 @@ struct dmi_transcoder {
   static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
   void build_loop() {
-    // the builds are the call's critical path (five of them back to back on two threads) and their kernels share the device with the table, relabelling and
-    // chain kernels of the stages behind them: this thread's streams are created with the HIGH priority, the encode threads' with the low one (chain walkers
-    // occupy one wavefront per SIMD for milliseconds).  1024 files: 89.7–91.8 → 84.2–88.9 ms (medians of three alternating runs; DMI_NO_STREAM_PRIO=1)
-    if (!std::getenv("DMI_NO_STREAM_PRIO")) dmi::g_stream_priority_class = 1;
     while (std::unique_ptr<Stage> s = to_build.take()) {
       if (failed()) continue;
       const double t0 = now_ms();
@@ -151,7 +147,6 @@ struct dmi_transcoder {
     if (preparers_left.fetch_sub(1) == 1) to_encode.close();   // (the last prepare thread out)
   }
   void encode_loop() {
-    if (!std::getenv("DMI_NO_STREAM_PRIO")) dmi::g_stream_priority_class = 2;   // (see build_loop)
     while (std::unique_ptr<Stage> s = to_encode.take()) {
       const double t0 = now_ms();
       int r = DMI_OK;
