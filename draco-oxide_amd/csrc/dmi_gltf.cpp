@@ -498,14 +498,24 @@ int dmi_transcode_assets(const dmi_gltf_asset* assets, uint32_t n, const dmi_con
   for (unsigned k = 0; k < n_assemblers; ++k) assemblers.emplace_back(assemble_loop, R.get());
   struct Stop { dmi_transcoded* R; std::vector<std::thread>& th; ~Stop() { { std::lock_guard<std::mutex> lock(R->q_mutex); R->q_closed = true; } R->q_cv.notify_all(); for (auto& t : th) if (t.joinable()) t.join(); } } stop{R.get(), assemblers};
 
-  R->assets.reserve(n);
+  R->assets.resize(n);
   int rc = DMI_OK;
   double ms_parse = 0;
   std::vector<dmi_raw_mesh> raws;
-  for (uint32_t i = 0; i < n && !rc; ++i) {
+  // Largest files first (their size in bytes stands for their triangle count before anything is parsed): the pipeline's LAST stage — whose prepare and encode
+  // nothing overlaps — is then made of the smallest meshes (short walks, short chains: a stage's chain launch is bounded by its longest stream), and the
+  // least-loaded dealing over several devices works on a descending list.  Results are placed by file index: the order of the output does not change.
+  std::vector<uint32_t> order(n);
+  for (uint32_t i = 0; i < n; ++i) order[i] = i;
+  if (!std::getenv("DMI_FILE_ORDER")) {
+    auto bytes_of = [&](uint32_t i) { size_t b = assets[i].glb ? assets[i].glb_bytes : 0; for (uint32_t k = 0; !assets[i].glb && k < assets[i].n_buffers; ++k) b += assets[i].buffers[k].bytes; return b; };
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return bytes_of(x) > bytes_of(y); });
+  }
+  for (uint32_t oi = 0; oi < n && !rc; ++oi) {
+    const uint32_t i = order[oi];
     const double t0 = now_ms();
-    R->assets.emplace_back(new Asset());
-    Asset& a = *R->assets.back();
+    R->assets[i].reset(new Asset());
+    Asset& a = *R->assets[i];
     Span js;
     if (assets[i].glb) {
       Span bin;
