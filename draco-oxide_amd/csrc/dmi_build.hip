@@ -143,11 +143,10 @@ __global__ __launch_bounds__(kBlock) void k_mb_value_insert(const MbArgs a) {
     uint32_t probes = 0;
     for (;; ++probes) {
       if (probes > kMaxProbes) { raise(a.mesh_out, it.mesh, MB_CROWDED); break; }   // rows crafted to collide: the host builder takes the mesh
-      uint32_t s = __atomic_load_n(&tab[h], __ATOMIC_RELAXED);
-      if (s == kNoneD) {
-        s = atomicCAS(&tab[h], kNoneD, p);
-        if (s == kNoneD) break;
-      }
+      // (claim first: most rows of most meshes are the first of their class and find an empty slot — one memory-side operation instead of a load and a claim;
+      //  a failed claim returns the occupant the load would have returned)
+      const uint32_t s = atomicCAS(&tab[h], kNoneD, p);
+      if (s == kNoneD) break;
       bool same = true;   // (s may be lowered meanwhile by another member of ITS class: every index a slot ever holds is of one class)
       for (uint32_t k = 0; k < it.words; ++k) same = same && canon(rows[(size_t)s * it.stride + k], cn) == w[k];
       if (same) { if (p < s) atomicMin(&tab[h], p); break; }
@@ -198,11 +197,10 @@ __global__ __launch_bounds__(kBlock) void k_mb_point_insert(const MbArgs a) {
     uint32_t probes = 0;
     for (;; ++probes) {
       if (probes > kMaxProbes) { raise(a.mesh_out, me.index, MB_CROWDED); break; }
-      uint32_t s = __atomic_load_n(&tab[h], __ATOMIC_RELAXED);
-      if (s == kNoneD) {
-        s = atomicCAS(&tab[h], kNoneD, p);
-        if (s == kNoneD) break;
-      }
+      // (claim first: most rows of most meshes are the first of their class and find an empty slot — one memory-side operation instead of a load and a claim;
+      //  a failed claim returns the occupant the load would have returned)
+      const uint32_t s = atomicCAS(&tab[h], kNoneD, p);
+      if (s == kNoneD) break;
       bool same = true;
       for (uint32_t k = 0; k < me.n_items; ++k) same = same && a.vslot[a.items[me.item0 + k].ap_off + s] == key[k];
       if (same) { if (p < s) atomicMin(&tab[h], p); break; }
