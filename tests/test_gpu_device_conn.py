@@ -1,4 +1,4 @@
-"""The order-free half of the connectivity stage on the device (csrc/dmi_conn.hip) against the host builders (csrc/host_conn.cpp, both
+"""The order-free half of the connectivity stage on the device (csrc/dmi_conn.hip) against the host builders (csrc/host_tables.cpp, both
 pinned to the oracle by tests/test_host_connectivity.py): opposite corners, left-most corners, per-vertex boundary flags, vertex count —
 identical arrays on closed / open grids, the OBJ fixtures, meshes with point → value maps; meshes outside the order-free class
 (vertex-degenerate faces, edges with more than two faces, vertices with several fans) are flagged and take the reference's serial walks;
