@@ -173,10 +173,10 @@ struct Walker {
     const bool closed = t.no_boundary && !no_closed;
     if (quad) {
       if (use_stamp) { if (closed) run_from_t<true, Enc4, true>(Enc4::from3(c3)); else run_from_t<true, Enc4, false>(Enc4::from3(c3)); }
-      else run_from_t<false, Enc4, false>(Enc4::from3(c3));
+      else { if (closed) run_from_t<false, Enc4, true>(Enc4::from3(c3)); else run_from_t<false, Enc4, false>(Enc4::from3(c3)); }
     } else {
       if (use_stamp) { if (closed) run_from_t<true, Enc3, true>(c3); else run_from_t<true, Enc3, false>(c3); }
-      else run_from_t<false, Enc3, false>(c3);
+      else { if (closed) run_from_t<false, Enc3, true>(c3); else run_from_t<false, Enc3, false>(c3); }
     }
   }
   template <bool kStamp, class E, bool kClosed>
@@ -234,9 +234,9 @@ struct Walker {
           rv = r_none || rs != 0u; lv = l_none || ls != 0u;
           r_split = (rs & kStampS) != 0u; l_split = (ls & kStampS) != 0u;
         } else {
-          const uint8_t rf = rc == kNone ? 1 : fv[E::face(rc)], lf = lc == kNone ? 1 : fv[E::face(lc)];
+          const uint8_t rf = r_none ? 1 : fv[E::face(rc)], lf = l_none ? 1 : fv[E::face(lc)];
           rv = rf & 1; lv = lf & 1;
-          r_split = rc != kNone && (rf & 2); l_split = lc != kNone && (lf & 2);
+          r_split = !r_none && (rf & 2); l_split = !l_none && (lf & 2);
         }
         // bits 4–6 of a symbol: which of the edges opposite (c, next, prev) lead to a face processed EARLIER (or to a start face) — what the seam
         // streams emit for this face (edgebreaker.rs:611-636 walks the faces last to first and emits the edges whose other face is not visited yet)
@@ -707,8 +707,13 @@ void attribute_sequence(const TableRef& t, const uint32_t* first, uint32_t n_fir
 #define DMI_SEQ(S, E, C) sequence_impl<S, E, C>(t, first, n_first, second, n_second, second_quad, seq, on_boundary)
   static const bool no_closed = std::getenv("DMI_NO_CLOSED") != nullptr;
   const bool closed = t.closed && !no_closed;
-  if (t.quad) { if (stamps) { if (closed) DMI_SEQ(true, Enc4, true); else DMI_SEQ(true, Enc4, false); } else DMI_SEQ(false, Enc4, false); }
-  else { if (stamps) { if (closed) DMI_SEQ(true, Enc3, true); else DMI_SEQ(true, Enc3, false); } else DMI_SEQ(false, Enc3, false); }
+  if (t.quad) {
+    if (stamps) { if (closed) DMI_SEQ(true, Enc4, true); else DMI_SEQ(true, Enc4, false); }
+    else { if (closed) DMI_SEQ(false, Enc4, true); else DMI_SEQ(false, Enc4, false); }
+  } else {
+    if (stamps) { if (closed) DMI_SEQ(true, Enc3, true); else DMI_SEQ(true, Enc3, false); }
+    else { if (closed) DMI_SEQ(false, Enc3, true); else DMI_SEQ(false, Enc3, false); }
+  }
 #undef DMI_SEQ
 }
 
