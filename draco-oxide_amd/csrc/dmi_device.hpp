@@ -63,8 +63,16 @@ struct QuantArgs { QuantAtt a[kMaxGather]; int count; };
 struct SeqQuantArgs { const uint32_t* s2p /* null: value order (entry i reads value i) */; uint32_t n; uint32_t pad; const uint32_t* dest; QuantArgs q; };
 // The early stage of a whole-mesh call (dmi_kernels.hip): rec[v] = the quantized position / normal / texture coordinate of value v in one 16-byte record
 // (value order; nrm / uv null: the mesh has none), then qs_*[i] = the fields of rec[s2p[i]] + per-block joint i32 min/max partials per attribute
-struct ValueRecArgs { const float *pos, *nrm, *uv; const float *pos_meta, *uv_meta; float pos_maxq, uv_maxq; uint32_t n; uint32_t pad; void* rec; int32_t* ipartials[3] /* position, normal, texture coordinate: 2 * value_quantize_rec_blocks(n) words each */; };
-struct GatherRecArgs { const uint32_t* s2p; uint32_t n; uint32_t pad; const void* rec; uint64_t* qs_pos; uint16_t* qs_nrm; uint32_t* qs_uv; const uint32_t* slot_src[3]; uint32_t* slot_dst[3] /* 32 words each, null = none */; };
+// (indices 0 / 1 / 2 of the per-attribute arrays below = position / normal / texture coordinate; null = the mesh has none)
+// range partials: the per-block pairs of launch_value_range_partials (k_value_ranges without its `_final`): every block of k_value_quantize_rec folds them
+// itself, block 0 also writes the attributes' slots ([small 16 words][meta 16 words], as k_value_ranges_final leaves them)
+struct ValueRecArgs { const float *pos, *nrm, *uv; const float *pos_partials, *uv_partials; const uint32_t* nrm_flags; uint32_t range_blocks[3]; float pos_maxq, uv_maxq; uint32_t n; void* rec;
+                      uint32_t* slot[3]; int32_t* ipartials[3] /* 2 * value_quantize_rec_blocks(n) words each */; };
+// the stage's slots → the job's slab slots, the joint i32 min/max folded from the per-block pairs into words 0–1 (the first block of the consumer kernel)
+struct EarlySlots { const uint32_t* src[3]; uint32_t* dst[3]; const int32_t* ipartials[3]; uint32_t ipartial_blocks; uint32_t pad; };
+struct GatherRecArgs { const uint32_t* s2p; uint32_t n; uint32_t pad; const void* rec; uint64_t* qs_pos; uint16_t* qs_nrm; uint32_t* qs_uv; EarlySlots slots; };
+constexpr uint32_t kEarlyRangeBlocks = 512;   // blocks per attribute of the early stage's range pass = partial pairs every block of k_value_quantize_rec folds
+void launch_value_range_partials(RangeArgs& args, uint32_t max_blocks, hipStream_t s);   // k_value_ranges alone: sets a.blocks / a.first_block
 uint32_t value_quantize_rec_blocks(uint32_t n);
 void launch_value_quantize_rec(const ValueRecArgs& a, hipStream_t s);
 void launch_seq_gather_rec(const GatherRecArgs& g, hipStream_t s);

@@ -47,12 +47,13 @@ int encode_phase_a(dmi_job* job, bool plan_only) {   // device: ranges → codin
       ga.s2p = t.s2p.as<uint32_t>(); ga.n = t.n_seq; ga.rec = job->early->rec;
       for (size_t i = 0; i < job->atts.size(); ++i) {
         AttJob& a = job->atts[i];
-        // the ranges, the joint min/max, the seeded scratch words and the zero-normal flag into the job's slab slot ([small 64 B][meta 64 B]): the gather's first block
-        ga.slot_src[i] = reinterpret_cast<const uint32_t*>(job->early->atts[i].slot); ga.slot_dst[i] = a.small.as<uint32_t>();
         if (a.qfmt == QF_P64) ga.qs_pos = a.qs.as<uint64_t>();
         else if (a.qfmt == QF_B16) ga.qs_nrm = a.qs.as<uint16_t>();
         else ga.qs_uv = a.qs.as<uint32_t>();
       }
+      // the ranges, the seeded scratch words, the zero-normal flag and the joint min/max (folded from the stage's per-block pairs) into the job's slab
+      // slots ([small 64 B][meta 64 B]): the gather's first block
+      ga.slots = job->early->slots_for([&](size_t i) { return job->atts[i].small.as<uint32_t>(); });
       launch_seq_gather_rec(ga, s);
       continue;
     }

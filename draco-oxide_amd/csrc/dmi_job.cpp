@@ -261,7 +261,7 @@ int dmi::early_quantize_issue(const dmi_attribute* atts, uint32_t n_atts, const 
     RangeAtt& r = ra.a[ra.count++];
     r.raw = static_cast<const float*>(ea.values);
     r.partials = partials;
-    r.small = reinterpret_cast<uint32_t*>(ea.slot);         // the slot of a job's slab: [small 64 B][meta 64 B]
+    r.small = reinterpret_cast<uint32_t*>(ea.slot);         // the slot of a job's slab: [small 64 B][meta 64 B] — written by the first block of k_value_quantize_rec
     r.meta = reinterpret_cast<float*>(ea.slot + 64);
     r.zero = reinterpret_cast<uint32_t*>(ea.slot + 64);
     r.zero_words = 16;
@@ -269,32 +269,33 @@ int dmi::early_quantize_issue(const dmi_attribute* atts, uint32_t n_atts, const 
   }
   HIP_TRY(hipEventCreate(&e->t0)); HIP_TRY(hipEventCreate(&e->t1));
   HIP_TRY(hipEventRecord(e->t0, side));
-  launch_value_ranges(ra, side);
+  launch_value_range_partials(ra, kEarlyRangeBlocks, side);   // (no `_final`: every block of the quantizer folds the pairs itself)
   ValueRecArgs va{};
+  const int order[3] = {i_pos, i_nrm, i_uv};
   va.pos = static_cast<const float*>(e->atts[(size_t)i_pos].values);
-  va.pos_meta = reinterpret_cast<const float*>(e->atts[(size_t)i_pos].slot + 64);
+  va.pos_partials = ra.a[i_pos].partials;
   va.pos_maxq = (float)(uint64_t)((1ull << e->atts[(size_t)i_pos].bits) - 1ull);
-  if (i_nrm >= 0) va.nrm = static_cast<const float*>(e->atts[(size_t)i_nrm].values);
+  if (i_nrm >= 0) { va.nrm = static_cast<const float*>(e->atts[(size_t)i_nrm].values); va.nrm_flags = reinterpret_cast<const uint32_t*>(ra.a[i_nrm].partials); }
   if (i_uv >= 0) {
     va.uv = static_cast<const float*>(e->atts[(size_t)i_uv].values);
-    va.uv_meta = reinterpret_cast<const float*>(e->atts[(size_t)i_uv].slot + 64);
+    va.uv_partials = ra.a[i_uv].partials;
     va.uv_maxq = (float)(uint64_t)((1ull << e->atts[(size_t)i_uv].bits) - 1ull);
   }
   va.n = n; va.rec = e->rec;
-  // the joint i32 min/max of each attribute's quantized values (the wrapped difference's, wrapped_difference.rs:36-52) come out of the same pass:
-  // partial pairs per block, folded into the slot's first two words — where the sweep reads them once the job has copied the slot
-  MinMaxArgs ma{};
-  const int order[3] = {i_pos, i_nrm, i_uv};
+  // the joint i32 min/max of each attribute's quantized values (the wrapped difference's, wrapped_difference.rs:36-52) come out of the same pass as
+  // partial pairs per block; the first block of the kernel that consumes the records folds them into the job's slot (EarlySlots)
+  e->ipartial_blocks = value_quantize_rec_blocks(n);
   for (int k = 0; k < 3; ++k) {
+    e->att_of_kind[k] = order[k];
     if (order[k] < 0) continue;
-    int32_t* ip = e->mem.take<int32_t>((size_t)value_quantize_rec_blocks(n) * 2);
+    va.range_blocks[k] = ra.a[order[k]].blocks;
+    va.slot[k] = reinterpret_cast<uint32_t*>(e->atts[(size_t)order[k]].slot);
+    int32_t* ip = e->mem.take<int32_t>((size_t)e->ipartial_blocks * 2);
     if (!ip) return DMI_OK;
     va.ipartials[k] = ip;
-    MinMaxAtt& m = ma.a[ma.count++];
-    m.ipartials = ip; m.minmax = reinterpret_cast<int32_t*>(e->atts[(size_t)order[k]].slot); m.blocks = value_quantize_rec_blocks(n);
+    e->ipartials[k] = ip;
   }
   launch_value_quantize_rec(va, side);
-  launch_i32_minmax_final(ma, side);
   HIP_TRY(hipEventRecord(e->t1, side));
   out = std::move(e);
   return DMI_OK;

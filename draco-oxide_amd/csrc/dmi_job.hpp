@@ -355,6 +355,21 @@ struct EarlyQuant {
   struct Att { const void* values; uint32_t n; int N, kind, fmt, bits; uint8_t* slot /* [small 64 B][meta 64 B] like a job's slab slot */; };
   void* rec = nullptr;   // n records of 16 bytes: the quantized position | texture coordinate | normal of value v (dmi_kernels.hip QuantRec)
   std::vector<Att> atts;
+  int att_of_kind[3] = {-1, -1, -1};              // attribute index of the position / normal / texture coordinate
+  int32_t* ipartials[3] = {nullptr, nullptr, nullptr};   // per-block joint i32 min/max pairs of k_value_quantize_rec, by kind; folded by the consumer's first block
+  uint32_t ipartial_blocks = 0;
+  // EarlySlots of a consumer kernel: the stage's slots → the slab slots of `job_atts` (dst_of(attribute index) = its `small` words)
+  template <class F> EarlySlots slots_for(F dst_of) const {
+    EarlySlots es{};
+    for (int k = 0; k < 3; ++k) {
+      if (att_of_kind[k] < 0) continue;
+      es.src[k] = reinterpret_cast<const uint32_t*>(atts[(size_t)att_of_kind[k]].slot);
+      es.dst[k] = dst_of((size_t)att_of_kind[k]);
+      es.ipartials[k] = ipartials[k];
+    }
+    es.ipartial_blocks = ipartial_blocks;
+    return es;
+  }
   ~EarlyQuant() {
     if (stream) (void)hipStreamSynchronize(stream);
     if (t0) (void)hipEventDestroy(t0);

@@ -438,32 +438,98 @@ __device__ __forceinline__ void k_seq_quantize_body(const SeqQuantArgs& sq, cons
 // (a wavefront-wide gather costs by the distinct lines it touches, not by the bytes it keeps: three attributes were three times the lines).
 // The arithmetic is finish_tile's, call for call: quant_coord per coordinate, oct_quantize for the normal.
 struct alignas(16) QuantRec { uint64_t pos; uint32_t uv; uint16_t nrm; uint16_t pad; };
+// min / max of a block's share of per-block f32 partial pairs ([mn[N] | mx[N]] per producer block, k_value_ranges' layout), reduced over the block:
+// res[0..N) = min, res[N..2N) = max, visible to every thread on return.  The reference's own comparisons (`<`, `>`), seeds +0.0 (Q1).
+template <int N>
+__device__ __forceinline__ void reduce_range_partials(const float* __restrict__ partials, uint32_t blocks, float* res) {
+  float mn[N], mx[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) { mn[k] = 0.0f; mx[k] = 0.0f; }
+  for (uint32_t b = threadIdx.x; b < blocks; b += kBlock) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const float lo = partials[(size_t)b * 2 * N + k], hi = partials[(size_t)b * 2 * N + N + k];
+      if (lo < mn[k]) mn[k] = lo;
+      if (hi > mx[k]) mx[k] = hi;
+    }
+  }
+  block_reduce_minmax<N>(mn, mx, res);
+  __syncthreads();
+}
 // One joint i32 min/max pair per block and attribute as well (wrapped_difference.rs:36-52 takes them over what the SEQUENCE holds: the sequence of a
-// per-point attribute on the position's table holds every value exactly once — job_create_impl adopts the stage only then); k_i32_minmax_final folds them.
-__global__ __launch_bounds__(kBlock) void k_value_quantize_rec(const ValueRecArgs a) {
+// per-point attribute on the position's table holds every value exactly once — job_create_impl adopts the stage only then); the first block of the
+// kernel that consumes the records folds them (k_seq_gather_rec).
+// Round 6: no `_final` launches around it.  Every block folds the range partials of k_value_ranges itself (512 pairs per attribute out of L2: ≈ 1 µs beside
+// 45 µs of streaming) — the shared range (Q2) is the same arithmetic in the same order as k_value_ranges_final's, and block 0 also writes what that
+// kernel wrote into the attribute's slot (ranges, seeded scratch words, the zero-normal flag) — and keeps kRecPer values per thread in flight: every
+// load of a tile is issued before the first value is used (the first form waited for each attribute's row in turn: 56 µs for 240 MB).
+// (HAS_NRM / HAS_UV as template parameters: tested at run time, the attribute's loads sat in branches of their own and the compiler waited for each)
+constexpr int kRecPer = 4;
+template <bool HAS_NRM, bool HAS_UV>
+__device__ __forceinline__ void value_quantize_rec_body(const ValueRecArgs& a) {
+  __shared__ float res_pos[6], res_uv[4];
+  reduce_range_partials<3>(a.pos_partials, a.range_blocks[0], res_pos);
+  if (HAS_UV) reduce_range_partials<2>(a.uv_partials, a.range_blocks[2], res_uv);
+  float pmn[3], prange = 0.0f, umn[2] = {0.0f, 0.0f}, urange = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { pmn[k] = res_pos[k]; const float d = res_pos[3 + k] - res_pos[k]; if (d > prange) prange = d; }   // one shared range (Q2)
+  if (HAS_UV) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { umn[k] = res_uv[k]; const float d = res_uv[2 + k] - res_uv[k]; if (d > urange) urange = d; }
+  }
+  if (blockIdx.x == 0) {   // the slots of the attributes: [small 16 words][meta 16 words] each, as k_value_ranges_final leaves them
+    const uint32_t t = threadIdx.x;
+    if (t < 96u) {
+      const uint32_t k = t >> 5, w = t & 31u;
+      uint32_t* slot = a.slot[k];
+      if (slot) {
+        uint32_t v = w == 0 ? 0x7FFFFFFFu : (w == 1 ? 0x80000000u : 0u);
+        if (k == 0 && w >= 16u) { const uint32_t m = w - 16u; if (m < 3u) v = __float_as_uint(res_pos[m]); else if (m == 3u) v = __float_as_uint(prange); else if (m < 7u) v = __float_as_uint(res_pos[3 + (m - 4u)]); }
+        if (k == 2 && w >= 16u) { const uint32_t m = w - 16u; if (m < 2u) v = __float_as_uint(res_uv[m]); else if (m == 2u) v = __float_as_uint(urange); else if (m < 5u) v = __float_as_uint(res_uv[2 + (m - 3u)]); }
+        if (k == 1 && w == 4u) {   // zero-length normal seen (geom.rs:45): any block flag of k_value_ranges
+          bool bad = false;
+          for (uint32_t b = 0; b < a.range_blocks[1]; ++b) bad |= a.nrm_flags[b] != 0u;
+          v = bad ? 1u : 0u;
+        }
+        slot[w] = v;
+      }
+    }
+  }
   int32_t mn[3], mx[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) { mn[k] = 2147483647; mx[k] = (-2147483647 - 1); }
-  for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < a.n; v += gridDim.x * kBlock) {
-    QuantRec r{0ull, 0u, 0u, 0u};
-    {
-      const float x = a.pos[3 * (size_t)v], y = a.pos[3 * (size_t)v + 1], z = a.pos[3 * (size_t)v + 2];
-      const int32_t q0 = quant_coord(x, a.pos_meta[0], a.pos_meta[3], a.pos_maxq), q1 = quant_coord(y, a.pos_meta[1], a.pos_meta[3], a.pos_maxq), q2 = quant_coord(z, a.pos_meta[2], a.pos_meta[3], a.pos_maxq);
+  const uint32_t n = a.n;
+  constexpr uint32_t kTileRec = kBlock * kRecPer;
+  for (uint32_t base = blockIdx.x * kTileRec; base < n; base += gridDim.x * kTileRec) {
+    float P[kRecPer][3], Q[kRecPer][3], U[kRecPer][2];
+#pragma unroll
+    for (int t = 0; t < kRecPer; ++t) {
+      const uint32_t v0 = base + t * kBlock + threadIdx.x;
+      const size_t v = v0 < n ? v0 : n - 1u;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) P[t][k] = a.pos[3 * v + k];
+      if (HAS_NRM) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Q[t][k] = a.nrm[3 * v + k];
+      }
+      if (HAS_UV) { U[t][0] = a.uv[2 * v]; U[t][1] = a.uv[2 * v + 1]; }
+    }
+#pragma unroll
+    for (int t = 0; t < kRecPer; ++t) {
+      const uint32_t v = base + t * kBlock + threadIdx.x;
+      QuantRec r{0ull, 0u, 0u, 0u};
+      const int32_t q0 = quant_coord(P[t][0], pmn[0], prange, a.pos_maxq), q1 = quant_coord(P[t][1], pmn[1], prange, a.pos_maxq), q2 = quant_coord(P[t][2], pmn[2], prange, a.pos_maxq);
       r.pos = pack_p64(q0, q1, q2);
-      mn[0] = min(mn[0], min(q0, min(q1, q2))); mx[0] = max(mx[0], max(q0, max(q1, q2)));
+      int32_t u = 0, w = 0, qu = 0, qw = 0;
+      if (HAS_NRM) { oct_quantize(Q[t][0], Q[t][1], Q[t][2], u, w); r.nrm = (uint16_t)((uint32_t)u | ((uint32_t)w << 8)); }
+      if (HAS_UV) { qu = quant_coord(U[t][0], umn[0], urange, a.uv_maxq); qw = quant_coord(U[t][1], umn[1], urange, a.uv_maxq); r.uv = (uint32_t)qu | ((uint32_t)qw << 16); }
+      if (v < n) {
+        mn[0] = min(mn[0], min(q0, min(q1, q2))); mx[0] = max(mx[0], max(q0, max(q1, q2)));
+        if (HAS_NRM) { mn[1] = min(mn[1], min(u, w)); mx[1] = max(mx[1], max(u, w)); }
+        if (HAS_UV) { mn[2] = min(mn[2], min(qu, qw)); mx[2] = max(mx[2], max(qu, qw)); }
+        static_cast<QuantRec*>(a.rec)[v] = r;
+      }
     }
-    if (a.nrm) {
-      int32_t u, w;
-      oct_quantize(a.nrm[3 * (size_t)v], a.nrm[3 * (size_t)v + 1], a.nrm[3 * (size_t)v + 2], u, w);
-      r.nrm = (uint16_t)((uint32_t)u | ((uint32_t)w << 8));
-      mn[1] = min(mn[1], min(u, w)); mx[1] = max(mx[1], max(u, w));
-    }
-    if (a.uv) {
-      const int32_t qu = quant_coord(a.uv[2 * (size_t)v], a.uv_meta[0], a.uv_meta[2], a.uv_maxq), qw = quant_coord(a.uv[2 * (size_t)v + 1], a.uv_meta[1], a.uv_meta[2], a.uv_maxq);
-      r.uv = (uint32_t)qu | ((uint32_t)qw << 16);
-      mn[2] = min(mn[2], min(qu, qw)); mx[2] = max(mx[2], max(qu, qw));
-    }
-    static_cast<QuantRec*>(a.rec)[v] = r;
   }
   __shared__ int32_t red[3][2][kBlock / 64];
 #pragma unroll
@@ -482,14 +548,37 @@ __global__ __launch_bounds__(kBlock) void k_value_quantize_rec(const ValueRecArg
     a.ipartials[threadIdx.x][2 * blockIdx.x + 1] = hi;
   }
 }
+__global__ __launch_bounds__(kBlock) void k_value_quantize_rec_pnu(const ValueRecArgs a) { value_quantize_rec_body<true, true>(a); }
+__global__ __launch_bounds__(kBlock) void k_value_quantize_rec_pn(const ValueRecArgs a) { value_quantize_rec_body<true, false>(a); }
+__global__ __launch_bounds__(kBlock) void k_value_quantize_rec_pu(const ValueRecArgs a) { value_quantize_rec_body<false, true>(a); }
+// The first block of the early stage's consumer: the joint i32 min/max of every attribute (the per-block pairs of k_value_quantize_rec, folded here: no
+// `_final` launch) into words 0–1 of the attribute's slot in the job's slab, the other 30 words of the stage's slot (ranges, seeded scratch words, the
+// zero-normal flag) copied beside them — [small 64 B][meta 64 B] per attribute.  All kBlock threads of the block call it.
+__device__ __forceinline__ void early_slots_block(const EarlySlots& e) {
+  __shared__ int32_t red[2][kBlock / 64];
+  for (int k = 0; k < 3; ++k) {
+    if (!e.src[k] || !e.dst[k]) continue;   // (uniform)
+    int32_t lo = 2147483647, hi = (-2147483647 - 1);
+    if (e.ipartials[k]) for (uint32_t b = threadIdx.x; b < e.ipartial_blocks; b += kBlock) { lo = min(lo, e.ipartials[k][2 * b]); hi = max(hi, e.ipartials[k][2 * b + 1]); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_down(lo, off, 64)); hi = max(hi, __shfl_down(hi, off, 64)); }
+    __syncthreads();   // (red of the previous attribute has been read)
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = lo; red[1][threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int w = 1; w < kBlock / 64; ++w) { lo = min(lo, red[0][w]); hi = max(hi, red[1][w]); }
+      e.dst[k][0] = (uint32_t)lo; e.dst[k][1] = (uint32_t)hi;
+    } else if (threadIdx.x >= 2u && threadIdx.x < 32u) e.dst[k][threadIdx.x] = e.src[k][threadIdx.x];
+  }
+}
 // qs_*[i] = the fields of rec[s2p[i]].  Four entries per thread, every gather issued before the first is used; tiles are dealt to blocks like every
 // pass over a sequence (an XCD's blocks take one contiguous eighth of it, so that the rings its gathers revisit stay in ITS L2).
 constexpr int kGatherPer = 4;
 __global__ __launch_bounds__(kBlock) void k_seq_gather_rec(const GatherRecArgs g) {
   const uint32_t n = g.n;
   const uint32_t blk_ = blockIdx.x, nblk_ = gridDim.x;
-  // the stage's slots ([small 64 B][meta 64 B] per attribute: ranges, min/max, the zero-normal flag) into the job's slab: 32 words each, no copy commands
-  if (blk_ == 0 && threadIdx.x < 96u) { const uint32_t k = threadIdx.x >> 5; if (g.slot_src[k]) g.slot_dst[k][threadIdx.x & 31u] = g.slot_src[k][threadIdx.x & 31u]; }
+  if (blk_ == 0) early_slots_block(g.slots);
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   const u32x4* __restrict__ rec = static_cast<const u32x4*>(g.rec);
   DMI_FOR_TILES(base, n, kGatherPer) {
@@ -1957,11 +2046,26 @@ void launch_value_ranges(RangeArgs& args, hipStream_t s) {
   emit(K_RANGES_FINAL, 1, args, (uint32_t)args.count, 0, s);
 }
 
+void launch_value_range_partials(RangeArgs& args, uint32_t max_blocks, hipStream_t s) {
+  uint32_t total = 0;
+  for (int i = 0; i < args.count; ++i) {
+    RangeAtt& a = args.a[i];
+    a.blocks = a.kind == 2 ? 0u : std::min<uint32_t>(std::min(max_blocks, kRangeMaxBlocks), std::max<uint32_t>(1u, (a.n + 4 * kBlock - 1) / (4 * kBlock)));
+    a.first_block = total;
+    total += a.blocks;
+  }
+  if (total) hipLaunchKernelGGL(k_value_ranges, total, kBlock, 0, s, args);
+}
+
 void launch_i32_minmax_final(const MinMaxArgs& args, hipStream_t s) { emit(K_I32_FINAL, 3, args, (uint32_t)args.count, 0, s); }
 // (launched directly: the early stage exists for single one-shot jobs only, never under a batch's step sink)
-uint32_t value_quantize_rec_blocks(uint32_t n) { return grid_for(n, 8192); }   // = partial pairs written per attribute
+uint32_t value_quantize_rec_blocks(uint32_t n) { return grid_for(((uint64_t)n + kRecPer - 1) / kRecPer, 2048); }   // = partial pairs written per attribute
 void launch_value_quantize_rec(const ValueRecArgs& a, hipStream_t s) {
-  if (a.n) hipLaunchKernelGGL(k_value_quantize_rec, value_quantize_rec_blocks(a.n), kBlock, 0, s, a);
+  if (!a.n) return;
+  const uint32_t g = value_quantize_rec_blocks(a.n);
+  if (a.nrm && a.uv) hipLaunchKernelGGL(k_value_quantize_rec_pnu, g, kBlock, 0, s, a);
+  else if (a.nrm) hipLaunchKernelGGL(k_value_quantize_rec_pn, g, kBlock, 0, s, a);
+  else hipLaunchKernelGGL(k_value_quantize_rec_pu, g, kBlock, 0, s, a);
 }
 void launch_seq_gather_rec(const GatherRecArgs& g, hipStream_t s) {
   // one tile per block (more entries per thread, non-temporal loads and stores, capped grids: 44.6–47.9 µs all of them on the 10M workload — the gather is

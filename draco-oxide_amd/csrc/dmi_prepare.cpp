@@ -2,6 +2,7 @@
 // dmi_encode_mesh / dmi_encode_mesh_device, the device corner tables on their own, and the host-core stream coders on their own.  The batch forms
 // are dmi_prepare_batch.cpp, the library streams dmi_streams.cpp (round 5 split).
 #include "dmi_prepare.hpp"
+#include <functional>
 
 using namespace dmi;
 
@@ -9,6 +10,8 @@ namespace {
 
 std::shared_ptr<StreamHolder> thread_stream(int device) { return library_thread_stream(device); }
 using NumaPin = NumaScope;
+// set by dmi_encode_mesh_device for the call it makes into mesh_prepare_impl: run once, right after the device stage has queued its last read-back
+thread_local std::function<void(hipStream_t)> g_after_tables;
 
 // reads them where they are).  Meshes the order-free construction does not cover (flags) take the host builder instead.
 struct DeviceTables {
@@ -89,6 +92,8 @@ struct DeviceTables {
     // (left-most corners: on the host only the construction of attribute tables with seams reads them — none exists for a mesh in the quad class, whose
     // walks take their boundary tests from the flags above: 4 bytes per vertex less on a stage bound by the link)
     if (!quad) HIP_TRY(hipMemcpyAsync(hp_lmc, d_lmc, (size_t)Vcap * 4, hipMemcpyDeviceToHost, stream));
+    // (a whole-mesh call's early stage: issued behind the last read-back, so that its kernels run alone while the host walks — see dmi_encode_mesh_device)
+    if (g_after_tables) { auto hook = std::move(g_after_tables); g_after_tables = nullptr; hook(stream); }
     t_kernels = ms();
     // while the device works: the vertex ids of a mesh without a position map are its faces — the walks read them at random, so they get a
     // copy on huge pages (the caller's array is on whatever pages its allocator chose); storage from the host pool, written in parallel slices
@@ -619,15 +624,24 @@ int dmi_encode_mesh_device(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buff
   const DeviceMeshSrc src{mesh->faces, mesh->atts[0].point_to_value};
   dmi_buffer head{}, att{};
   dmi_job* job = nullptr;
-  struct OneShot { OneShot() { g_one_shot_call = true; } ~OneShot() { g_one_shot_call = false; g_early_quant.reset(); } } one_shot;
+  struct OneShot { OneShot() { g_one_shot_call = true; } ~OneShot() { g_one_shot_call = false; g_after_tables = nullptr; g_early_quant.reset(); } } one_shot;
   // The values are in HBM and the device is about to idle through ≈ 90 ms of host walks (10M triangles): value ranges and the quantization in value
   // order run NOW, on the second group stream; the pass after the walks gathers packed values (EarlyQuant).  Large meshes only: a small mesh's encode
   // is bound by launches and runs its phase A from a captured graph.
+  // Round 6: issued BEHIND the device stage's last read-back (an event of that stream): beside the table kernels and the 245 MB of copies the stage's
+  // kernels ran at a fraction of their speed (k_value_ranges 523 µs on average in round 5's trace instead of 31), which no profile of the call could
+  // tell from a slow kernel; now they run alone, a few ms into the host walks, and their hipEvent span is their kernel time.
   if (mesh->num_faces >= kDeviceTablesMinFaces) {
     dmi_config ec = cfg ? *cfg : dmi_config{};
     ec.device = device;
     hipStream_t s_early = library_group_stream(device, 1);
-    if (s_early) (void)early_quantize_issue(mesh->atts, mesh->num_atts, ec, s_early, g_early_quant);
+    if (s_early) g_after_tables = [mesh, ec, s_early](hipStream_t after) {
+      hipEvent_t ev = nullptr;
+      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return; }
+      if (hipEventRecord(ev, after) == hipSuccess && hipStreamWaitEvent(s_early, ev, 0) == hipSuccess) (void)early_quantize_issue(mesh->atts, mesh->num_atts, ec, s_early, g_early_quant);
+      else (void)hipGetLastError();
+      (void)hipEventDestroy(ev);
+    };
   }
   int rc = mesh_prepare_impl(&shadow, cfg, &head, &job, &src);
   std::vector<std::vector<uint8_t>> host_values;

@@ -133,3 +133,69 @@ def nan_twin_primitives():
 
 def oracle_session_of_specs(specs, faces):
     return orc.Session.from_arrays(faces, [dict(data=np.ascontiguousarray(r), type=t, domain=d, parents=list(p)) for r, t, d, p in specs])
+
+
+def irregular_grid_mesh(n, seed, open_boundary=False, shuffle_points=False, normals=True, uvs=True, hubs=40, single_splits=200):
+    """A torus grid (synth.torus_grid: ≥ 2^16 faces from n = 182 on) made irregular while staying manifold, per-point attributes throughout (no
+    point → value map: the layout a whole-mesh call's early stage takes): `hubs` vertices get EVERY incident face split in three around a new
+    centre vertex — the hub's valence doubles to 12 (its fan row overflows: the corner-table walk), its neighbours' grows to 8, the centres have
+    valence 3 —, `single_splits` further faces are split on their own (valence 7 / 3), optionally the grid is open (boundary fans, vertices
+    without a parallelogram) and the point order is scrambled (the value-order records of the early stage are then read at random)."""
+    from draco_oxide_amd import synth
+    rng = np.random.default_rng(seed)
+    faces, pos, nrm, uv = synth.torus_grid(n, seed=seed, normals=normals, uvs=uvs, open_boundary=open_boundary)
+    faces = faces.astype(np.int64)
+    F, V = len(faces), len(pos)
+    # faces around each chosen hub (hubs far apart: no face is split twice)
+    hub_ids = rng.choice(V, size=hubs * 4, replace=False)
+    taken = np.zeros(F, bool)
+    split = []
+    inc = {}
+    for v in hub_ids:
+        fs = np.nonzero((faces == v).any(axis=1))[0]
+        if len(fs) == 0 or taken[fs].any():
+            continue
+        nb = np.unique(faces[fs])
+        around = np.nonzero(np.isin(faces, nb).any(axis=1))[0]
+        if taken[around].any():
+            continue
+        taken[around] = True
+        split.extend(fs.tolist())
+        if len(split) >= hubs * 6:
+            break
+    free = np.nonzero(~taken)[0]
+    split.extend(rng.choice(free, size=min(single_splits, len(free)), replace=False).tolist())
+    split = np.asarray(sorted(set(split)), np.int64)
+    centre = V + np.arange(len(split))
+    a, b, c = faces[split, 0], faces[split, 1], faces[split, 2]
+    w = rng.uniform(0.2, 0.5, size=(len(split), 3))
+    w /= w.sum(axis=1, keepdims=True)
+
+    def mix(arr):
+        return (arr[a] * w[:, :1] + arr[b] * w[:, 1:2] + arr[c] * w[:, 2:3]).astype(np.float32)
+    pos = np.concatenate([pos, mix(pos) + rng.uniform(-1e-4, 1e-4, size=(len(split), 3)).astype(np.float32)])
+    if nrm is not None:
+        m = mix(nrm) + rng.uniform(-1e-3, 1e-3, size=(len(split), 3)).astype(np.float32)
+        nrm = np.concatenate([nrm, (m / np.linalg.norm(m, axis=1, keepdims=True)).astype(np.float32)])
+    if uv is not None:
+        uv = np.concatenate([uv, np.clip(mix(uv) + rng.uniform(-1e-4, 1e-4, size=(len(split), 2)), 0, 1).astype(np.float32)])
+    keep = np.ones(F, bool)
+    keep[split] = False
+    new = np.concatenate([np.stack([a, b, centre], 1), np.stack([b, c, centre], 1), np.stack([c, a, centre], 1)])
+    faces = np.concatenate([faces[keep], new])
+    faces = faces[rng.permutation(len(faces))]
+    if shuffle_points:
+        perm = rng.permutation(len(pos))            # new id of old point
+        inv = np.empty_like(perm); inv[perm] = np.arange(len(perm))
+        faces = perm[faces]
+        pos = pos[inv]; nrm = None if nrm is None else nrm[inv]; uv = None if uv is None else uv[inv]
+    atts = [dmi.Attribute(pos, dmi.ATT_POSITION, dmi.DOMAIN_POSITION, unique_id=0)]
+    if nrm is not None:
+        atts.append(dmi.Attribute(nrm, dmi.ATT_NORMAL, dmi.DOMAIN_CORNER, unique_id=len(atts), parent_index=0))
+    if uv is not None:
+        atts.append(dmi.Attribute(uv, dmi.ATT_TEXCOORD, dmi.DOMAIN_CORNER, unique_id=len(atts), parent_index=0))
+    for arr in (pos, nrm, uv):   # the early stage takes per-point attributes: no two rows may merge
+        if arr is not None:
+            rows = np.ascontiguousarray(arr + np.float32(0.0)).view(np.dtype((np.void, arr.dtype.itemsize * arr.shape[1]))).ravel()
+            assert len(np.unique(rows)) == len(rows)
+    return dmi.Mesh(faces.astype(np.uint32), atts)

@@ -375,3 +375,47 @@ def test_transcoded_blobs_decode_back_to_the_input_triangles():
         step = float(max(uv.max(), 0) - min(uv.min(), 0)) / 1023
         # per corner: the decoded UV of the corner's point against the input UV of a corner with the same quantized position and a nearby UV
         assert duv.shape[1] == 2 and np.isfinite(duv).all() and duv.min() >= uv.min() - step and duv.max() <= uv.max() + step
+
+
+# ---- the reference's remaining public fixtures (draco-oxide/tests/data: data files only) in the `.gltf` + external `.bin` form ----
+DATA = os.path.join(os.path.dirname(__file__), "golden", "data")
+
+
+def test_reference_gltf_fixtures_parse_like_their_glb():
+    """Duck/Duck.gltf + Duck0.bin is the same asset as Duck.glb (its buffer = the head of the GLB's BIN chunk); Triangle.gltf + simpleTriangle.bin is one
+    face with positions only and no `mode` (TRIANGLES by default)."""
+    doc, bufs = gltf.load_document(os.path.join(DATA, "Duck", "Duck.gltf"))
+    _, gdoc, gbin, _ = _duck()
+    assert len(bufs) == 1 and bytes(bufs[0]) == bytes(gbin[: len(bufs[0])])
+    assert doc["meshes"][0]["primitives"][0]["attributes"] == gdoc["meshes"][0]["primitives"][0]["attributes"]
+    tdoc, tbufs = gltf.load_document(os.path.join(DATA, "Triangle.gltf"))
+    prim = tdoc["meshes"][0]["primitives"][0]
+    assert "mode" not in prim and list(prim["attributes"]) == ["POSITION"] and len(tbufs[0]) == 44
+    assert gltf._accessor_indices(tdoc, tbufs[0], prim["indices"]).tolist() == [0, 1, 2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", [[0], [0, 0]])
+def test_reference_gltf_fixtures_through_the_native_transcoder(devices):
+    """the reference's own `.gltf` + `.bin` assets (io/gltf/transcoder.rs:281-341 names private files; these are the public ones) through
+    dmi_transcode_assets in its `json + buffers` form: Duck's blob = the blob of Duck.glb = the oracle's; Triangle (one face, positions only) = the oracle's."""
+    from draco_oxide_amd import binding
+    duck_gltf, tri_gltf = os.path.join(DATA, "Duck", "Duck.gltf"), os.path.join(DATA, "Triangle.gltf")
+    sources = [duck_gltf, tri_gltf, open(DUCK, "rb").read()]
+    results, st = binding.transcode_assets(gltf._native_assets(sources), devices=devices)
+    assert len(results) == 3 and st["devices"] == len(devices) and st["primitives"] == 3
+    data, doc, binary, prim = _duck()
+    want_duck = _oracle_session(doc, binary, prim).encode()
+    assert bytes(results[0][1][0]) == want_duck and bytes(results[2][1][0]) == want_duck
+    tdoc, tbufs = gltf.load_document(tri_gltf)
+    want_tri = _oracle_session(tdoc, tbufs[0], tdoc["meshes"][0]["primitives"][0]).encode()
+    assert bytes(results[1][1][0]) == want_tri
+    for k, want in ((0, want_duck), (1, want_tri)):
+        (payload, ids), = gltf.draco_blobs_of(results[k][0])
+        assert payload[: len(want)] == want and len(payload) - len(want) < 4
+    assert gltf.draco_blobs_of(results[1][0])[0][1] == {"POSITION": 0}
+    # the written Duck: still names its texture by uri (an external image is not the transcoder's to move), geometry accessors without bufferViews
+    doc2, _ = gltf.read_glb(results[0][0])
+    assert doc2["images"][0]["uri"] == "DuckCM.png" and "KHR_draco_mesh_compression" in doc2["extensionsRequired"]
+    p2 = doc2["meshes"][0]["primitives"][0]
+    assert all("bufferView" not in doc2["accessors"][a] for a in p2["attributes"].values())

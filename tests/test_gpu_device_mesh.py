@@ -75,3 +75,23 @@ def test_early_stage_is_dropped_when_an_attribute_has_seams_of_its_own():
     want = oracle_from_product_mesh(mesh).encode()
     got = dmi.encode_mesh_device(dmi.DeviceMesh.upload(mesh), dmi.Config(flags=dmi.FLAG_TIMINGS))
     _assert_same(got, want, "seam torus from HBM")
+
+
+@pytest.mark.parametrize("open_boundary,shuffle,normals,uvs", [(False, False, True, True), (True, False, True, True), (True, True, True, True), (False, True, True, False),
+                                                               (True, False, False, True)])
+def test_early_stage_on_irregular_meshes(open_boundary, shuffle, normals, uvs, monkeypatch):
+    """The early stage (round 6: range partials folded by every block of the quantizer, the joint min/max by the first block of the record gather — no
+    `_final` launches) on meshes of ≥ 2^16 faces with everything the sweep's fast path does not cover: hubs of valence 12 (fan-row overflow: the
+    corner-table walk), valence 3 / 7 / 8, boundary fans and entries without a parallelogram (open grid), a scrambled point order (the value-order
+    records are then gathered at random).  Same bytes as the oracle's and as the call without an early stage."""
+    from helpers import irregular_grid_mesh
+    mesh = irregular_grid_mesh(192, seed=17 + 2 * open_boundary + shuffle, open_boundary=open_boundary, shuffle_points=shuffle, normals=normals, uvs=uvs)
+    assert len(mesh.faces) >= 1 << 16
+    want = oracle_from_product_mesh(mesh).encode()
+    dm = dmi.DeviceMesh.upload(mesh)
+    cfg = dmi.Config(flags=dmi.FLAG_TIMINGS)
+    got = dmi.encode_mesh_device(dm, cfg)
+    _assert_same(got, want, f"early stage, irregular mesh, open={open_boundary} shuffled={shuffle}")
+    assert dmi.last_call_timings()["early_ms"] > 0
+    monkeypatch.setenv("DMI_NO_EARLY", "1")
+    assert dmi.encode_mesh_device(dm, cfg) == got and dmi.last_call_timings()["early_ms"] == 0
