@@ -355,9 +355,16 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
   }
   g_active_pool = std::getenv("DMI_NO_POOL") ? nullptr : &job->pool;
   const bool needs_clear = g_active_pool && !job->pool.zero;   // pooled buffers do not start as zeros: the ones that must are cleared where they are allocated
-  auto clear_range = [&](void* p, size_t bytes, hipStream_t st) -> hipError_t {   // now, or by the batch's coordinator
+  // (a single job: the ranges are collected and cleared by ONE launch at the end of job creation — nothing reads them before the encode; round 5 issued a
+  //  hipMemsetAsync each: eleven launches of ≈ 5 µs back to back on the job's stream)
+  ClearRanges pending_clears{};
+  auto flush_clears = [&](hipStream_t st) { launch_clear_ranges(pending_clears, st); pending_clears.count = 0; };
+  auto clear_range = [&](void* p, size_t bytes, hipStream_t st) -> hipError_t {   // at the end of job creation, or by the batch's coordinator
     if (defer && needs_clear) { defer->clears.push_back(JobDefer::Clear{p, bytes}); return hipSuccess; }
-    return hipMemsetAsync(p, 0, bytes, st);
+    if (defer || (bytes & 3) || !bytes) return bytes ? hipMemsetAsync(p, 0, bytes, st) : hipSuccess;
+    if (pending_clears.count == kClearRanges) flush_clears(st);
+    pending_clears.p[pending_clears.count] = p; pending_clears.bytes[pending_clears.count] = bytes; ++pending_clears.count;
+    return hipSuccess;
   };
   struct PoolGuard { ~PoolGuard() { g_active_pool = nullptr; } } pool_guard;
 
@@ -882,6 +889,7 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
       }
     }
   }
+  flush_clears(s);
   uint32_t bad_p2v = 0;
   if (d_bad) HIP_TRY(hipMemcpyAsync(&bad_p2v, d_bad, 4, hipMemcpyDeviceToHost, s));
   if (ev_c1) HIP_TRY(hipEventRecord(ev_c1, s));

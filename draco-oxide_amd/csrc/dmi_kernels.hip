@@ -149,18 +149,21 @@ __device__ __forceinline__ void range_slice(const RangeAtt& a, uint32_t block, f
   float mn[N], mx[N];
 #pragma unroll
   for (int k = 0; k < N; ++k) { mn[k] = 0.0f; mx[k] = 0.0f; }
-  // four values per thread and round, all loads issued before the compares (more bytes in flight per lane)
+  // DMI_RANGE_UNROLL values per thread and round, all loads issued before the compares
+#ifndef DMI_RANGE_UNROLL
+#define DMI_RANGE_UNROLL 2   // (4: 33.8 µs, 8: 39.3, 2: 32.2 for the 160 MB of the 10M-triangle workload on 3 × 1024 blocks)
+#endif
   const uint32_t stride = a.blocks * kBlock;
-  for (uint32_t v0 = block * kBlock + threadIdx.x; v0 < a.n; v0 += 4 * stride) {
-    float x[4][N];
+  for (uint32_t v0 = block * kBlock + threadIdx.x; v0 < a.n; v0 += DMI_RANGE_UNROLL * stride) {
+    float x[DMI_RANGE_UNROLL][N];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < DMI_RANGE_UNROLL; ++u) {
       const uint32_t v = v0 + u * stride;
 #pragma unroll
       for (int k = 0; k < N; ++k) x[u][k] = (v < a.n) ? a.raw[(size_t)v * N + k] : 0.0f;   // 0.0 is the seed: neutral
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < DMI_RANGE_UNROLL; ++u) {
 #pragma unroll
       for (int k = 0; k < N; ++k) {
         if (x[u][k] < mn[k]) mn[k] = x[u][k];
@@ -479,6 +482,11 @@ __device__ __forceinline__ void value_quantize_rec_body(const ValueRecArgs& a) {
   }
   if (blockIdx.x == 0) {   // the slots of the attributes: [small 16 words][meta 16 words] each, as k_value_ranges_final leaves them
     const uint32_t t = threadIdx.x;
+    // zero-length normal seen (geom.rs:45): any block flag of k_value_ranges — folded by the whole block (one thread walking 512 flags kept this block,
+    // and with it the launch, 8 µs longer)
+    bool bad_l = false;
+    if (HAS_NRM) for (uint32_t b = t; b < a.range_blocks[1]; b += kBlock) bad_l |= a.nrm_flags[b] != 0u;
+    const int zero_normal = __syncthreads_or(bad_l ? 1 : 0);
     if (t < 96u) {
       const uint32_t k = t >> 5, w = t & 31u;
       uint32_t* slot = a.slot[k];
@@ -486,11 +494,7 @@ __device__ __forceinline__ void value_quantize_rec_body(const ValueRecArgs& a) {
         uint32_t v = w == 0 ? 0x7FFFFFFFu : (w == 1 ? 0x80000000u : 0u);
         if (k == 0 && w >= 16u) { const uint32_t m = w - 16u; if (m < 3u) v = __float_as_uint(res_pos[m]); else if (m == 3u) v = __float_as_uint(prange); else if (m < 7u) v = __float_as_uint(res_pos[3 + (m - 4u)]); }
         if (k == 2 && w >= 16u) { const uint32_t m = w - 16u; if (m < 2u) v = __float_as_uint(res_uv[m]); else if (m == 2u) v = __float_as_uint(urange); else if (m < 5u) v = __float_as_uint(res_uv[2 + (m - 3u)]); }
-        if (k == 1 && w == 4u) {   // zero-length normal seen (geom.rs:45): any block flag of k_value_ranges
-          bool bad = false;
-          for (uint32_t b = 0; b < a.range_blocks[1]; ++b) bad |= a.nrm_flags[b] != 0u;
-          v = bad ? 1u : 0u;
-        }
+        if (k == 1 && w == 4u) v = zero_normal ? 1u : 0u;
         slot[w] = v;
       }
     }
@@ -2050,7 +2054,7 @@ void launch_value_range_partials(RangeArgs& args, uint32_t max_blocks, hipStream
   uint32_t total = 0;
   for (int i = 0; i < args.count; ++i) {
     RangeAtt& a = args.a[i];
-    a.blocks = a.kind == 2 ? 0u : std::min<uint32_t>(std::min(max_blocks, kRangeMaxBlocks), std::max<uint32_t>(1u, (a.n + 4 * kBlock - 1) / (4 * kBlock)));
+    a.blocks = a.kind == 2 ? 0u : std::min<uint32_t>(std::min(max_blocks, kRangeMaxBlocks), std::max<uint32_t>(1u, (a.n + DMI_RANGE_UNROLL * kBlock - 1) / (DMI_RANGE_UNROLL * kBlock)));
     a.first_block = total;
     total += a.blocks;
   }
@@ -2059,7 +2063,7 @@ void launch_value_range_partials(RangeArgs& args, uint32_t max_blocks, hipStream
 
 void launch_i32_minmax_final(const MinMaxArgs& args, hipStream_t s) { emit(K_I32_FINAL, 3, args, (uint32_t)args.count, 0, s); }
 // (launched directly: the early stage exists for single one-shot jobs only, never under a batch's step sink)
-uint32_t value_quantize_rec_blocks(uint32_t n) { return grid_for(((uint64_t)n + kRecPer - 1) / kRecPer, 2048); }   // = partial pairs written per attribute
+uint32_t value_quantize_rec_blocks(uint32_t n) { return grid_for(((uint64_t)n + kRecPer - 1) / kRecPer, 2048); }   // (4096 blocks: 47.6 µs, 8192: 49.9 against 45.4 — every block folds the range partials)   // = partial pairs written per attribute
 void launch_value_quantize_rec(const ValueRecArgs& a, hipStream_t s) {
   if (!a.n) return;
   const uint32_t g = value_quantize_rec_blocks(a.n);
