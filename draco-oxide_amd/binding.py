@@ -101,7 +101,8 @@ class _TranscodeStats(C.Structure):
                 ("primitives_device_built", C.c_uint32), ("primitives_host_built", C.c_uint32), ("primitives_in_place", C.c_uint32), ("pad", C.c_uint32),
                 ("triangles_in", C.c_uint64), ("bytes_in", C.c_uint64), ("bytes_out", C.c_uint64),
                 ("parse_ms", C.c_double), ("pushed_ms", C.c_double), ("finished_ms", C.c_double),
-                ("build_ms", C.c_double), ("prepare_ms", C.c_double), ("encode_ms", C.c_double), ("assemble_ms", C.c_double), ("call_ms", C.c_double)]
+                ("build_ms", C.c_double), ("prepare_ms", C.c_double), ("encode_ms", C.c_double), ("assemble_ms", C.c_double), ("call_ms", C.c_double),
+                ("parse_cpu_ms", C.c_double), ("parse_threads", C.c_uint32), ("stages", C.c_uint32)]
 
 
 class _DecodedAttribute(C.Structure):

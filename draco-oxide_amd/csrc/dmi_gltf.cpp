@@ -99,6 +99,7 @@ struct Asset {
   Value doc;
   std::vector<Span> buffers;
   std::vector<Prim> prims;               // the primitives that get compressed
+  std::vector<dmi_raw_mesh> raws;        // … as the transcoder takes them (views of the caller's bytes and of `owned`)
   std::deque<std::vector<dmi_raw_accessor>> accessors;   // stable storage for the descriptors pushed
   std::deque<std::vector<uint32_t>> owned;               // converted feature ids / generated indices / parent ids
   std::atomic<uint32_t> left{0};         // primitives not final yet
@@ -111,6 +112,7 @@ struct Asset {
 struct PerDevice {
   dmi_transcoder* t = nullptr;
   uint64_t load = 0;                                   // triangles dealt to it
+  uint64_t triangles = 0; uint32_t primitives = 0;     // (its pusher's counts)
   std::mutex owner_mutex;                              // (the transcoder's encode thread reads `owner` while the caller's thread appends)
   std::vector<std::pair<uint32_t, uint32_t>> owner;    // push index → (asset, primitive)
   struct dmi_transcoded* self = nullptr;
@@ -150,14 +152,17 @@ int read_glb(const uint8_t* data, size_t n, Span* js, Span* bin) {
 
 struct AccessorView { const uint8_t* p = nullptr; uint64_t count = 0; uint32_t stride = 0; uint32_t component_type = 0; int components = 0; };
 
-// accessor `index` of the document as bytes of its buffer: elem_bytes per element (0: 4 · components — raw f32 rows), the view's byteStride or tight
+// accessor `index` of the document as bytes of its buffer: elem_bytes per element (0: 4 · components — raw f32 rows), the view's byteStride or tight.
+// Every offset is checked against the bufferView's own byteLength AND the buffer (sums in 64 bits with overflow tests: a crafted offset must not wrap back
+// into range); a stride below the element size or off the 4-byte grid is refused.
 int view_accessor(const Asset& a, uint64_t index, size_t elem_bytes, bool use_stride, AccessorView* out) {
   const Value* accs = member(a.doc, "accessors");
   if (!accs || !accs->is_array() || index >= accs->items.size()) return gfail("accessor index out of range");
   const Value& acc = accs->items[index];
-  uint64_t bv, count, off_a = 0, off_v = 0, stride = 0, buf = 0, ct = 0;
-  if (!index_of(member(acc, "bufferView"), &bv)) return gfail("accessor " + std::to_string(index) + " without a bufferView");
-  if (!index_of(member(acc, "count"), &count)) return gfail("accessor " + std::to_string(index) + " without a count");
+  const std::string who = "accessor " + std::to_string(index);
+  uint64_t bv, count, off_a = 0, off_v = 0, stride = 0, buf = 0, ct = 0, view_len = 0;
+  if (!index_of(member(acc, "bufferView"), &bv)) return gfail(who + " without a bufferView");
+  if (!index_of(member(acc, "count"), &count)) return gfail(who + " without a count");
   if (member(acc, "byteOffset") && !index_of(member(acc, "byteOffset"), &off_a)) return gfail("accessor byteOffset");
   (void)index_of(member(acc, "componentType"), &ct);
   const Value* ty = member(acc, "type");
@@ -168,14 +173,18 @@ int view_accessor(const Asset& a, uint64_t index, size_t elem_bytes, bool use_st
   if (member(view, "byteOffset") && !index_of(member(view, "byteOffset"), &off_v)) return gfail("bufferView byteOffset");
   if (member(view, "byteStride") && !index_of(member(view, "byteStride"), &stride)) return gfail("bufferView byteStride");
   if (member(view, "buffer") && !index_of(member(view, "buffer"), &buf)) return gfail("bufferView buffer");
+  if (!index_of(member(view, "byteLength"), &view_len)) return gfail("bufferView " + std::to_string(bv) + " without a byteLength");
   if (buf >= a.buffers.size()) return gfail("buffer index out of range");
-  if (!elem_bytes) { if (!comps) return gfail("accessor " + std::to_string(index) + ": unknown type"); elem_bytes = 4u * (size_t)comps; }
+  if (!elem_bytes) { if (!comps) return gfail(who + ": unknown type"); elem_bytes = 4u * (size_t)comps; }
   if (!use_stride || !stride) stride = elem_bytes;
-  if (stride > (1u << 20) || count >= (1ull << 32)) return gfail("accessor " + std::to_string(index) + ": stride / count out of range");
+  if (stride < elem_bytes) return gfail(who + ": byteStride below the element size");
+  if (stride > (1u << 20) || count >= (1ull << 32)) return gfail(who + ": stride / count out of range");
   const Span& b = a.buffers[buf];
-  const uint64_t start = off_v + off_a;
-  if (count && (start > b.n || stride * (count - 1) + elem_bytes > b.n - start)) return gfail("accessor " + std::to_string(index) + " reaches past its buffer");
-  out->p = b.p + start; out->count = count; out->stride = (uint32_t)stride; out->component_type = (uint32_t)ct; out->components = comps;
+  if (off_v > b.n || view_len > b.n - off_v) return gfail("bufferView " + std::to_string(bv) + " reaches past its buffer");
+  // extent of the accessor inside its view: off_a + stride·(count − 1) + elem_bytes ≤ view_len (no sum can wrap: count < 2^32, stride ≤ 2^20)
+  const uint64_t extent = count ? stride * (count - 1) + elem_bytes : 0;
+  if (off_a > view_len || extent > view_len - off_a) return gfail(who + " reaches past its bufferView");
+  out->p = b.p + off_v + off_a; out->count = count; out->stride = (uint32_t)stride; out->component_type = (uint32_t)ct; out->components = comps;
   return DMI_OK;
 }
 
@@ -226,6 +235,7 @@ int plan_asset(Asset& a) {
       std::vector<std::string> standard;
       for (const auto& m : atts->members) if (is_standard(m.first)) standard.push_back(m.first);
       std::sort(standard.begin(), standard.end());
+      if (std::adjacent_find(standard.begin(), standard.end()) != standard.end()) return gfail("a primitive names the attribute " + *std::adjacent_find(standard.begin(), standard.end()) + " twice");
       Prim p;
       p.node = &prim;
       for (const auto& k : standard) if (semantic_type(k) >= 0) p.names.push_back(k);
@@ -235,6 +245,7 @@ int plan_asset(Asset& a) {
       std::vector<std::string> feat;
       for (const auto& m : atts->members) if (starts_with(m.first, "_FEATURE_ID_")) feat.push_back(m.first);
       std::sort(feat.begin(), feat.end());   // (the reference walks a HashMap here: its order changes from run to run; name order like gltf.py)
+      if (std::adjacent_find(feat.begin(), feat.end()) != feat.end()) return gfail("a primitive names the attribute " + *std::adjacent_find(feat.begin(), feat.end()) + " twice");
       p.names.insert(p.names.end(), feat.begin(), feat.end());
       a.prims.push_back(std::move(p));
     }
@@ -260,6 +271,11 @@ int raw_of(Asset& a, Prim& p, dmi_raw_mesh* out) {
     if (ty >= 0) {
       AccessorView v;
       if (int rc = view_accessor(a, ai, 0, true, &v)) return rc;
+      // the reference reads these three as raw f32 rows whatever the accessor says (decode.rs:2277-2309); KHR_mesh_quantization / normalized-integer
+      // inputs would come out as valid-looking garbage blobs: refused
+      if (v.component_type != 5126) return gfail("attribute " + name + ": componentType " + std::to_string(v.component_type) + " (only FLOAT accessors are transcoded)");
+      if (v.components != (ty == DMI_ATT_TEXCOORD ? 2 : 3)) return gfail("attribute " + name + ": accessor type is not " + (ty == DMI_ATT_TEXCOORD ? "VEC2" : "VEC3"));
+      if (v.stride & 3u) return gfail("attribute " + name + ": byteStride is not a multiple of 4");
       count = v.count;
       r.data = v.p; r.count = (uint32_t)v.count; r.byte_stride = v.stride == 4u * (uint32_t)v.components ? 0u : v.stride;
       r.component_type = DMI_F32; r.num_components = (uint8_t)v.components; r.att_type = (uint8_t)ty;
@@ -316,16 +332,67 @@ int raw_of(Asset& a, Prim& p, dmi_raw_mesh* out) {
 // ---- assembly of one file (gltf.py _assemble + write_glb; encode.rs:958-1097,362-400) ----
 struct Piece { const uint8_t* p; size_t n; const uint8_t* p2; size_t n2; };   // (a blob is two pieces back to back: header + connectivity, attribute section)
 
-int assemble(dmi_transcoded& R, Asset& a) {
+// How many places of the document name each accessor: attributes, indices and morph targets of EVERY primitive, animation samplers, skins (gltf.py _accessor_users)
+void count_accessor_users(const Value& doc, std::vector<uint32_t>& users) {
+  auto use = [&](const Value* v) { uint64_t i; if (v && v->as_index(&i) && i < users.size()) ++users[i]; };
+  if (const Value* meshes = member(doc, "meshes")) if (meshes->is_array())
+    for (const Value& mesh : meshes->items) {
+      const Value* prims = member(mesh, "primitives");
+      if (!prims || !prims->is_array()) continue;
+      for (const Value& prim : prims->items) {
+        if (const Value* atts = member(prim, "attributes")) if (atts->is_object()) for (const auto& m : atts->members) use(&m.second);
+        use(member(prim, "indices"));
+        if (const Value* tg = member(prim, "targets")) if (tg->is_array()) for (const Value& t : tg->items) if (t.is_object()) for (const auto& m : t.members) use(&m.second);
+      }
+    }
+  if (const Value* anims = member(doc, "animations")) if (anims->is_array())
+    for (const Value& an : anims->items) if (const Value* smp = member(an, "samplers")) if (smp->is_array())
+      for (const Value& sp : smp->items) { use(member(sp, "input")); use(member(sp, "output")); }
+  if (const Value* skins = member(doc, "skins")) if (skins->is_array()) for (const Value& sk : skins->items) use(member(sk, "inverseBindMatrices"));
+}
+
+// A compressed primitive's accessors become placeholders (no bufferView, new counts).  An accessor that something ELSE names too — a primitive that stays
+// uncompressed (another mode, no face left), a second compressed primitive, a morph target, an animation — must keep its data and must not take another
+// primitive's counts: the compressed primitive gets a copy of its own at the end of the accessor list (the reference writes fresh accessors per primitive:
+// encode.rs:958-1097).  compressed[k]: primitive k of a.prims has a face left.
+void privatize_accessors(Asset& a, const std::vector<uint8_t>& compressed) {
   Value* accs = a.doc.find("accessors");
-  const size_t n_acc = accs && accs->is_array() ? accs->items.size() : 0;
-  std::vector<uint8_t> replaced(n_acc, 0);
+  if (!accs || !accs->is_array()) return;
+  std::vector<uint32_t> users(accs->items.size(), 0);
+  count_accessor_users(a.doc, users);
+  for (size_t k = 0; k < a.prims.size(); ++k) {
+    if (!compressed[k]) continue;
+    Prim& p = a.prims[k];
+    Value* atts = p.node->find("attributes");
+    auto own = [&](Value* ref) {
+      uint64_t ai;
+      if (!ref || !ref->as_index(&ai) || ai >= users.size() || users[ai] <= 1) return;
+      --users[ai];
+      Value copy = accs->items[ai];
+      accs->items.push_back(std::move(copy));
+      *ref = Value::number(accs->items.size() - 1);
+    };
+    if (atts && atts->is_object()) for (const std::string& n : p.names) own(atts->find(n.c_str()));
+    own(p.node->find("indices"));
+  }
+}
+
+int assemble(dmi_transcoded& R, Asset& a) {
   struct Res { dmi_buffer head{}, section{}; uint32_t nf = 0, np = 0; };
   std::vector<Res> res(a.prims.size());
+  std::vector<uint8_t> compressed(a.prims.size(), 0);
   for (size_t k = 0; k < a.prims.size(); ++k) {
     Prim& p = a.prims[k];
     PerDevice& d = *R.devs[(size_t)p.device_slot];
     if (int rc = dmi_transcoder_result(d.t, p.push_index, &res[k].head, &res[k].section, &res[k].nf, &res[k].np)) return rc;
+    compressed[k] = res[k].nf ? 1 : 0;
+  }
+  privatize_accessors(a, compressed);
+  Value* accs = a.doc.find("accessors");
+  const size_t n_acc = accs && accs->is_array() ? accs->items.size() : 0;
+  std::vector<uint8_t> replaced(n_acc, 0);
+  for (size_t k = 0; k < a.prims.size(); ++k) {
+    Prim& p = a.prims[k];
     if (!res[k].nf) continue;   // no face left: the reference leaves such a primitive alone (encode.rs:934-936)
     const Value* atts = member(*p.node, "attributes");
     for (const std::string& n : p.names) { uint64_t ai; if (index_of(atts->find(n.c_str()), &ai) && ai < n_acc) replaced[ai] = 1; }
@@ -433,6 +500,7 @@ int assemble(dmi_transcoded& R, Asset& a) {
   // the document, the descriptors and the converted arrays have done their work: released here, on this (assembly) thread, not when the caller drops the result
   a.doc = Value();
   a.prims.clear(); a.prims.shrink_to_fit();
+  a.raws.clear(); a.raws.shrink_to_fit();
   a.accessors.clear(); a.owned.clear();
   return DMI_OK;
 }
@@ -479,77 +547,138 @@ int dmi_transcode_assets(const dmi_gltf_asset* assets, uint32_t n, const dmi_con
   std::vector<int32_t> devs;
   if (devices && n_devices) devs.assign(devices, devices + n_devices); else devs.push_back(cfg ? cfg->device : 0);
   for (int32_t d : devs) if (d < 0 || d >= ndev_visible) return host_fail(DMI_ERR_INVALID_ARGUMENT, "device ordinal out of range");
-  // stage size: about four stages per device; the triangle count is not known before the files are parsed — 26 input bytes per triangle is what
-  // pos + nrm + uv + indices come to (the transcoder clamps the stage to 3M … 12M triangles anyway)
+  const size_t ND = devs.size();
+  // ---- the files are dealt to the devices BEFORE anything is parsed (round 6), by their size in bytes — what stands for a file's triangle count until its
+  //      JSON is read: largest first, each to the device with the least bytes so far (LPT).  A device's transcoder then starts on its first files while the
+  //      others are still being parsed (by a small pool of threads: files are independent), and the pipeline's LAST stage — whose prepare and encode nothing
+  //      overlaps — is made of the smallest meshes.  Results are placed by file index: the order of the output does not depend on any of this.
+  auto bytes_of = [&](uint32_t i) { size_t b = assets[i].glb ? assets[i].glb_bytes : assets[i].json_bytes; for (uint32_t k = 0; !assets[i].glb && k < assets[i].n_buffers; ++k) b += assets[i].buffers[k].bytes; return b; };
   uint64_t in_bytes = 0;
-  for (uint32_t i = 0; i < n; ++i) { in_bytes += assets[i].glb_bytes; for (uint32_t b = 0; b < assets[i].n_buffers; ++b) in_bytes += assets[i].buffers[b].bytes; }
-  const uint64_t expected = in_bytes / 26 / devs.size();
-  for (size_t s = 0; s < devs.size(); ++s) {
+  std::vector<uint32_t> order(n);
+  for (uint32_t i = 0; i < n; ++i) { order[i] = i; in_bytes += bytes_of(i); }
+  if (!std::getenv("DMI_FILE_ORDER")) std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return bytes_of(x) > bytes_of(y); });
+  std::vector<std::vector<uint32_t>> dev_files(ND);
+  std::vector<uint64_t> dev_bytes(ND, 0);
+  for (uint32_t i : order) {
+    size_t best = 0;
+    for (size_t s = 1; s < ND; ++s) if (dev_bytes[s] < dev_bytes[best]) best = s;
+    dev_files[best].push_back(i);
+    dev_bytes[best] += bytes_of(i) + 1;
+  }
+  // stage size per device: a quarter of its share, so that every device pipelines ≥ 4 stages (build ∥ prepare ∥ encode) however many devices split the list —
+  // 26 input bytes per triangle is what pos + nrm + uv + indices come to; between 0.5M triangles (a stage pays fixed costs: its chain launch is bounded by
+  // its longest stream) and 12M (one above ≈ 16M stops overlapping)
+  for (size_t s = 0; s < ND; ++s) {
     R->devs.emplace_back(new PerDevice());
     PerDevice& d = *R->devs.back();
     d.self = R.get(); d.slot = (int)s;
     dmi_config c = cfg ? *cfg : dmi_config{};
     c.device = devs[s];
-    d.t = dmi_transcoder_create(&c, expected, 0, on_done, &d);
+    const uint64_t expected = dev_bytes[s] / 26;
+    const uint64_t stage = std::min<uint64_t>((uint64_t)12 << 20, std::max<uint64_t>((uint64_t)1 << 19, expected / 4));
+    d.t = dmi_transcoder_create(&c, expected, stage, on_done, &d);
     if (!d.t) return host_fail(DMI_ERR_OUT_OF_MEMORY, "dmi_transcoder_create");
   }
-  const unsigned n_assemblers = std::max(1u, std::min(4u, process_host_threads() / 4));
+  const unsigned host_thr = process_host_threads();
+  const unsigned n_assemblers = std::max(1u, std::min(4u, host_thr / 4));
   std::vector<std::thread> assemblers;
   for (unsigned k = 0; k < n_assemblers; ++k) assemblers.emplace_back(assemble_loop, R.get());
   struct Stop { dmi_transcoded* R; std::vector<std::thread>& th; ~Stop() { { std::lock_guard<std::mutex> lock(R->q_mutex); R->q_closed = true; } R->q_cv.notify_all(); for (auto& t : th) if (t.joinable()) t.join(); } } stop{R.get(), assemblers};
 
   R->assets.resize(n);
-  int rc = DMI_OK;
-  double ms_parse = 0;
-  std::vector<dmi_raw_mesh> raws;
-  // Largest files first (their size in bytes stands for their triangle count before anything is parsed): the pipeline's LAST stage — whose prepare and encode
-  // nothing overlaps — is then made of the smallest meshes (short walks, short chains: a stage's chain launch is bounded by its longest stream), and the
-  // least-loaded dealing over several devices works on a descending list.  Results are placed by file index: the order of the output does not change.
-  std::vector<uint32_t> order(n);
-  for (uint32_t i = 0; i < n; ++i) order[i] = i;
-  if (!std::getenv("DMI_FILE_ORDER")) {
-    auto bytes_of = [&](uint32_t i) { size_t b = assets[i].glb ? assets[i].glb_bytes : 0; for (uint32_t k = 0; !assets[i].glb && k < assets[i].n_buffers; ++k) b += assets[i].buffers[k].bytes; return b; };
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return bytes_of(x) > bytes_of(y); });
-  }
-  for (uint32_t oi = 0; oi < n && !rc; ++oi) {
-    const uint32_t i = order[oi];
-    const double t0 = now_ms();
+  // ---- parse: containers, JSON, plans, accessor descriptors — a pool of threads over the files in the order the devices will push them (round-robin over
+  //      the devices' lists: every device's first files first) ----
+  std::vector<uint32_t> parse_seq;
+  parse_seq.reserve(n);
+  for (size_t r = 0; parse_seq.size() < n; ++r) for (size_t s = 0; s < ND; ++s) if (r < dev_files[s].size()) parse_seq.push_back(dev_files[s][r]);
+  std::unique_ptr<std::atomic<uint8_t>[]> state(new std::atomic<uint8_t>[n ? n : 1]);   // 0 pending, 1 parsed, 2 failed
+  for (uint32_t i = 0; i < n; ++i) state[i].store(0, std::memory_order_relaxed);
+  std::mutex parsed_mutex;
+  std::condition_variable parsed_cv;
+  std::atomic<bool> abort{false};
+  std::atomic<uint32_t> next_parse{0}, in_place{0};
+  std::atomic<uint64_t> parse_ns{0};
+  std::atomic<double> last_parse_end{t_start};
+  auto parse_one = [&](uint32_t i) -> int {
     R->assets[i].reset(new Asset());
     Asset& a = *R->assets[i];
     Span js;
     if (assets[i].glb) {
       Span bin;
-      if ((rc = read_glb(assets[i].glb, assets[i].glb_bytes, &js, &bin))) break;
+      if (int rc = read_glb(assets[i].glb, assets[i].glb_bytes, &js, &bin)) return rc;
       a.buffers.push_back(bin);
     } else {
       js = Span{reinterpret_cast<const uint8_t*>(assets[i].json), assets[i].json_bytes};
       for (uint32_t b = 0; b < assets[i].n_buffers; ++b) a.buffers.push_back(Span{assets[i].buffers[b].data, assets[i].buffers[b].bytes});
     }
     std::string perr;
-    if (!js.p || !json::parse(reinterpret_cast<const char*>(js.p), js.n, a.doc, perr) || !a.doc.is_object()) { rc = gfail("asset " + std::to_string(i) + ": " + (perr.empty() ? "the JSON document is not an object" : perr)); break; }
-    if ((rc = plan_asset(a))) break;
-    raws.resize(a.prims.size());
-    for (size_t k = 0; k < a.prims.size() && !rc; ++k) rc = raw_of(a, a.prims[k], &raws[k]);
-    if (rc) break;
-    const double t1 = now_ms();
-    ms_parse += t1 - t0;
-    for (const Span& b : a.buffers) if (b.n && dmi_host_is_registered(b.p, b.n)) ++R->stats.buffers_in_place;
-    a.left.store((uint32_t)a.prims.size());
-    if (a.prims.empty()) { R->enqueue(i); continue; }   // (a file without a compressible primitive)
-    for (size_t k = 0; k < a.prims.size() && !rc; ++k) {
-      size_t best = 0;
-      for (size_t s = 1; s < R->devs.size(); ++s) if (R->devs[s]->load < R->devs[best]->load) best = s;
-      PerDevice& d = *R->devs[best];
-      a.prims[k].device_slot = (int)best;
-      { std::lock_guard<std::mutex> lock(d.owner_mutex); a.prims[k].push_index = (uint32_t)d.owner.size(); d.owner.emplace_back(i, (uint32_t)k); }
-      d.load += a.prims[k].triangles + 1;
-      R->stats.triangles_in += a.prims[k].triangles;
-      ++R->stats.primitives;
-      rc = dmi_transcoder_push(d.t, &raws[k], 1);
+    if (!js.p || !json::parse(reinterpret_cast<const char*>(js.p), js.n, a.doc, perr) || !a.doc.is_object()) return gfail("asset " + std::to_string(i) + ": " + (perr.empty() ? "the JSON document is not an object" : perr));
+    if (int rc = plan_asset(a)) return rc;
+    a.raws.resize(a.prims.size());
+    for (size_t k = 0; k < a.prims.size(); ++k) if (int rc = raw_of(a, a.prims[k], &a.raws[k])) return rc;
+    uint32_t ip = 0;
+    for (const Span& b : a.buffers) if (b.n && dmi_host_is_registered(b.p, b.n)) ++ip;
+    if (ip) in_place.fetch_add(ip);
+    return DMI_OK;
+  };
+  auto parse_loop = [&] {
+    for (;;) {
+      const uint32_t q = next_parse.fetch_add(1);
+      if (q >= n || abort.load()) return;
+      const uint32_t i = parse_seq[q];
+      const auto t0 = std::chrono::steady_clock::now();
+      const int rc = parse_one(i);
+      parse_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+      if (rc) { R->fail_with(rc, dmi_last_error()); abort.store(true); }
+      { std::lock_guard<std::mutex> lock(parsed_mutex); state[i].store(rc ? 2 : 1, std::memory_order_release); const double t = now_ms(); if (t > last_parse_end.load()) last_parse_end.store(t); }
+      parsed_cv.notify_all();
     }
+  };
+  // ---- push: one pusher per device walks ITS list in order (a device's push order — and with it its stages — is the same from run to run) ----
+  auto push_loop = [&](size_t s) {
+    PerDevice& d = *R->devs[s];
+    std::vector<dmi_raw_mesh> raws;
+    for (uint32_t i : dev_files[s]) {
+      {
+        std::unique_lock<std::mutex> lock(parsed_mutex);
+        parsed_cv.wait(lock, [&] { return state[i].load(std::memory_order_acquire) != 0 || abort.load(); });
+      }
+      if (abort.load() || state[i].load() != 1) return;
+      Asset& a = *R->assets[i];
+      const size_t np = a.prims.size();
+      a.left.store((uint32_t)np);
+      if (!np) { R->enqueue(i); continue; }   // (a file without a compressible primitive)
+      // everything that touches the asset happens BEFORE its last primitive is pushed: once that push returns, an assembly thread may already be
+      // releasing the asset's document and descriptors (the transcoder copied the descriptors it was handed)
+      raws.assign(a.raws.begin(), a.raws.end());
+      {
+        std::lock_guard<std::mutex> lock(d.owner_mutex);
+        for (size_t k = 0; k < np; ++k) {
+          a.prims[k].device_slot = (int)s;
+          a.prims[k].push_index = (uint32_t)d.owner.size();
+          d.owner.emplace_back(i, (uint32_t)k);
+          d.load += a.prims[k].triangles + 1;
+          d.triangles += a.prims[k].triangles;
+        }
+        d.primitives += (uint32_t)np;
+      }
+      for (size_t k = 0; k < np; ++k) {
+        if (int rc = dmi_transcoder_push(d.t, &raws[k], 1)) { R->fail_with(rc, dmi_last_error()); abort.store(true); parsed_cv.notify_all(); return; }
+      }
+    }
+  };
+  const unsigned n_parsers = std::max(1u, std::min({8u, host_thr / 4u, n ? n : 1u}));
+  {
+    std::vector<std::thread> parsers, pushers;
+    struct Join { std::vector<std::thread>& a; std::vector<std::thread>& b; ~Join() { for (auto& t : a) if (t.joinable()) t.join(); for (auto& t : b) if (t.joinable()) t.join(); } } join{parsers, pushers};
+    for (unsigned k = 0; k < n_parsers; ++k) parsers.emplace_back(parse_loop);
+    for (size_t s = 1; s < ND; ++s) pushers.emplace_back(push_loop, s);
+    push_loop(0);   // (the caller's thread is the first device's pusher; the parsers run beside it)
   }
   const double t_pushed = now_ms();
-  std::string first_err = rc ? dmi_last_error() : "";
+  int rc = DMI_OK;
+  std::string first_err;
+  { std::lock_guard<std::mutex> lock(R->err_mutex); if (R->rc) { rc = R->rc; first_err = R->err; } }
   for (auto& d : R->devs) {
     const int r = dmi_transcoder_finish(d->t);
     if (r && !rc) { rc = r; first_err = dmi_last_error(); }
@@ -559,6 +688,8 @@ int dmi_transcode_assets(const dmi_gltf_asset* assets, uint32_t n, const dmi_con
     uint64_t nd = 0, nh = 0, np = 0;
     (void)dmi_transcoder_counts(d->t, &nd, &nh, &np);
     R->stats.primitives_device_built += (uint32_t)nd; R->stats.primitives_host_built += (uint32_t)nh; R->stats.primitives_in_place += (uint32_t)np;
+    R->stats.stages += dmi_transcoder_stages(d->t);
+    R->stats.triangles_in += d->triangles; R->stats.primitives += d->primitives;
   }
   const double t_finished = now_ms();
   { std::lock_guard<std::mutex> lock(R->q_mutex); R->q_closed = true; }
@@ -572,7 +703,10 @@ int dmi_transcode_assets(const dmi_gltf_asset* assets, uint32_t n, const dmi_con
   for (const auto& a : R->assets) R->stats.bytes_out += a->out_bytes;
   R->stats.bytes_in = in_bytes;
   R->stats.files = n;
-  R->stats.parse_ms = ms_parse;
+  R->stats.buffers_in_place = in_place.load();
+  R->stats.parse_ms = last_parse_end.load() - t_start;
+  R->stats.parse_cpu_ms = (double)parse_ns.load() * 1e-6;
+  R->stats.parse_threads = n_parsers;
   R->stats.pushed_ms = t_pushed - t_start; R->stats.finished_ms = t_finished - t_start;
   R->stats.assemble_ms = (double)R->assemble_ns.load() * 1e-6;
   R->stats.call_ms = now_ms() - t_start;

@@ -72,6 +72,7 @@ struct dmi_transcoder {
   std::deque<std::vector<dmi_raw_accessor>> accessors;   // (stable addresses)
   std::vector<dmi_raw_mesh> prims;
   uint32_t dispatched = 0;             // primitives already handed to the build step
+  uint32_t stages = 0;                 // stages dispatched so far
   uint64_t pending_triangles = 0;
   bool first_stage = true;
   // results, by primitive
@@ -191,6 +192,7 @@ struct dmi_transcoder {
     s->first = dispatched; s->count = (uint32_t)prims.size() - dispatched;
     s->raw.assign(prims.begin() + dispatched, prims.end());
     dispatched = (uint32_t)prims.size();
+    ++stages;
     pending_triangles = 0;
     first_stage = false;
     start();
@@ -277,6 +279,12 @@ int dmi_transcoder_timings(dmi_transcoder* t, double* build_ms, double* prepare_
   if (prepare_ms) *prepare_ms = t->ms_prepare;
   if (encode_ms) *encode_ms = t->ms_encode;
   return DMI_OK;
+}
+
+uint32_t dmi_transcoder_stages(dmi_transcoder* t) {
+  if (!t) return 0;
+  std::lock_guard<std::mutex> lock(t->push_mutex);
+  return t->stages;
 }
 
 int dmi_transcoder_counts(dmi_transcoder* t, uint64_t* device_built, uint64_t* host_built, uint64_t* in_place) {

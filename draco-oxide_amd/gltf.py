@@ -284,12 +284,61 @@ def _collect(doc, buffers):
     return out
 
 
+def _accessor_users(doc):
+    """How many places of the document name each accessor: primitive attributes, indices and morph targets of EVERY primitive, animation samplers, skins."""
+    users = {}
+
+    def use(v):
+        if isinstance(v, int) and not isinstance(v, bool) and v >= 0:
+            users[v] = users.get(v, 0) + 1
+    for mesh in doc.get("meshes", []):
+        for prim in mesh.get("primitives", []):
+            for v in prim.get("attributes", {}).values():
+                use(v)
+            use(prim.get("indices"))
+            for tgt in prim.get("targets", []) or []:
+                if isinstance(tgt, dict):
+                    for v in tgt.values():
+                        use(v)
+    for anim in doc.get("animations", []) or []:
+        for smp in anim.get("samplers", []) or []:
+            use(smp.get("input"))
+            use(smp.get("output"))
+    for skin in doc.get("skins", []) or []:
+        use(skin.get("inverseBindMatrices"))
+    return users
+
+
+def _privatize_accessors(doc, prims, results):
+    """A compressed primitive's accessors become placeholders (no bufferView, new counts).  An accessor that something ELSE names too — a primitive that stays
+    uncompressed (another mode, no face left), a second compressed primitive, a morph target, an animation — must keep its data / must not take another
+    primitive's counts: the compressed primitive gets a copy of its own at the end of the accessor list (the reference writes fresh accessors per primitive:
+    encode.rs:958-1097).  Same walk, same order as csrc/dmi_gltf.cpp privatize_accessors."""
+    users = _accessor_users(doc)
+    accessors = doc.get("accessors", [])
+    for (prim, names, *_), res in zip(prims, results):
+        if res is None:
+            continue
+        refs = [("attributes", n) for n in names] + ([("indices", None)] if "indices" in prim else [])
+        for where, n in refs:
+            ai = prim["attributes"][n] if where == "attributes" else prim["indices"]
+            if not isinstance(ai, int) or isinstance(ai, bool) or not 0 <= ai < len(accessors) or users.get(ai, 0) <= 1:
+                continue
+            users[ai] -= 1
+            accessors.append(json.loads(json.dumps(accessors[ai])))
+            if where == "attributes":
+                prim["attributes"][n] = len(accessors) - 1
+            else:
+                prim["indices"] = len(accessors) - 1
+
+
 def _assemble(doc, buffers, prims, results):
     """The output GLB of one document.  prims = [(prim, names, …)], results = [(blob, num_faces, num_points) or None] per primitive
     (None: the built mesh has no face — encode.rs:934-936 leaves such a primitive alone).  Compressed primitives get placeholder
     accessors + the extension, every other bufferView (of any input buffer) is carried over into the single BIN chunk.  A blob may be a tuple of
     pieces (header + connectivity bytes, a view of the library-owned attribute section): they meet for the first time in the output file.
     Returns (glb bytes, [blob, ...]) — the blobs as views into the GLB (no second copy of them)."""
+    _privatize_accessors(doc, prims, results)
     replaced = set()
     for (prim, names, *_), res in zip(prims, results):
         if res is None:

@@ -307,6 +307,7 @@ int dmi_transcoder_timings(dmi_transcoder* t, double* build_ms, double* prepare_
 /* how the primitives built so far were built: by the device kernels, by the host builder inside the same call (outside the device form's class, or
  * flagged by the kernels), and — of the former — copied up where they lay (dmi_host_alloc memory) */
 int dmi_transcoder_counts(dmi_transcoder* t, uint64_t* device_built, uint64_t* host_built, uint64_t* in_place);
+uint32_t dmi_transcoder_stages(dmi_transcoder* t);   /* pipeline stages dispatched so far */
 void dmi_transcoder_destroy(dmi_transcoder* t);
 
 /* --- A list of glTF assets in, their Draco-compressed GLBs out (round 5; io/gltf/transcoder.rs:134-151 per file: read_scene → compress_scene →
@@ -333,12 +334,15 @@ typedef struct dmi_transcode_stats {
   uint32_t buffers_in_place;   /* input buffers that lie in dmi_host_alloc memory (their accessors go up without a host pack) */
   uint32_t primitives_device_built, primitives_host_built, primitives_in_place, pad;   /* dmi_transcoder_counts, summed over the devices */
   uint64_t triangles_in, bytes_in, bytes_out;
-  double parse_ms;      /* caller's thread: containers, JSON, primitive plans, accessor descriptors */
+  double parse_ms;      /* containers, JSON, primitive plans, accessor descriptors: wall clock from the start of the call to the last file parsed (a thread pool; pushes run beside it) */
   double pushed_ms;     /* since the start of the call: the last primitive handed to a transcoder */
   double finished_ms;   /* since the start of the call: the last stage of the last device coded */
   double build_ms, prepare_ms, encode_ms;   /* time inside the three stage calls, summed over stages and devices (they overlap) */
   double assemble_ms;   /* assembly threads, summed */
   double call_ms;
+  double parse_cpu_ms;  /* round 6: the parse runs on a pool of threads — parse_ms is its wall-clock span (start of the call → last file parsed), this the threads' summed time */
+  uint32_t parse_threads;
+  uint32_t stages;      /* pipeline stages dispatched, summed over the devices */
 } dmi_transcode_stats;
 typedef struct dmi_transcoded dmi_transcoded;
 int dmi_transcode_assets(const dmi_gltf_asset* assets, uint32_t n, const dmi_config* cfg, const int32_t* devices, uint32_t n_devices, uint32_t flags, dmi_transcoded** out);

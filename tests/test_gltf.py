@@ -419,3 +419,102 @@ def test_reference_gltf_fixtures_through_the_native_transcoder(devices):
     assert doc2["images"][0]["uri"] == "DuckCM.png" and "KHR_draco_mesh_compression" in doc2["extensionsRequired"]
     p2 = doc2["meshes"][0]["primitives"][0]
     assert all("bufferView" not in doc2["accessors"][a] for a in p2["attributes"].values())
+
+
+# ---- accessors shared between primitives (multi-material meshes share POSITION; a LINES primitive beside a TRIANGLES one) ----
+def _shared_accessor_asset():
+    """One mesh, three primitives over ONE set of vertex accessors (POSITION / NORMAL / TEXCOORD_0): two triangle primitives with index accessors of their
+    own (the two halves of a grid: a multi-material mesh) and a LINES primitive on the same POSITION accessor, which stays uncompressed."""
+    p = _prim(12, 77)
+    doc, buf = _make_asset([p])
+    idx = p["idx"].reshape(-1, 3)
+    half = len(idx) // 2
+    buf = bytearray(buf)
+
+    def add(data, ct):
+        off = len(buf)
+        buf.extend(_pad4(bytes(data)))
+        doc["bufferViews"].append({"buffer": 0, "byteOffset": off, "byteLength": len(data)})
+        doc["accessors"].append({"bufferView": len(doc["bufferViews"]) - 1, "componentType": ct, "count": len(data) // (4 if ct == 5125 else 2), "type": "SCALAR"})
+        return len(doc["accessors"]) - 1
+    i0, i1 = add(idx[:half].astype("<u4").tobytes(), 5125), add(idx[half:].astype("<u4").tobytes(), 5125)
+    il = add(np.arange(8, dtype="<u2").tobytes(), 5123)
+    att = doc["meshes"][0]["primitives"][0]["attributes"]
+    doc["meshes"][0]["primitives"] = [{"attributes": dict(att), "indices": i0, "mode": 4, "material": 0}, {"attributes": dict(att), "indices": i1, "mode": 4, "material": 1},
+                                      {"attributes": {"POSITION": att["POSITION"]}, "indices": il, "mode": 1}]
+    doc["materials"] = [{}, {}]
+    doc["buffers"][0]["byteLength"] = len(buf)
+    halves = [dict(p, idx=idx[:half].ravel()), dict(p, idx=idx[half:].ravel())]
+    return doc, bytes(buf), p, halves
+
+
+def test_shared_accessors_get_private_copies_python_assembly():
+    doc, buf, p, halves = _shared_accessor_asset()
+    n_acc = len(doc["accessors"])
+    prims = gltf._plan(doc)
+    assert len(prims) == 2
+    pos = prims[0][0]["attributes"]["POSITION"]
+    gltf._privatize_accessors(doc, prims, [(b"x", 10, 20), (b"y", 11, 21)])
+    a0, a1, line = doc["meshes"][0]["primitives"]
+    assert line["attributes"]["POSITION"] == pos and "bufferView" in doc["accessors"][pos]           # the LINES primitive keeps the original, untouched
+    assert a0["attributes"]["POSITION"] != pos and a1["attributes"]["POSITION"] != pos and a0["attributes"]["POSITION"] != a1["attributes"]["POSITION"]
+    assert a0["attributes"]["NORMAL"] != a1["attributes"]["NORMAL"]                                   # shared by the two compressed ones only: one copy, one original
+    assert len(doc["accessors"]) == n_acc + 2 + 1 + 1                                               # POSITION ×2 (three users), NORMAL, TEXCOORD_0 ×1 each
+    assert a0["indices"] != a1["indices"] and len({a0["indices"], a1["indices"]}) == 2              # index accessors were private already
+
+
+@pytest.mark.gpu
+def test_primitives_that_share_accessors_native_and_python(monkeypatch):
+    """Two compressed primitives and an uncompressed LINES primitive over one POSITION accessor: every compressed primitive ends up with placeholder
+    accessors of its own (its own counts), the LINES primitive's POSITION keeps its bufferView and its bytes; blobs = the oracle's for each half; the native
+    loop and the interpreter's give the same file."""
+    doc, buf, p, halves = _shared_accessor_asset()
+    src = gltf.write_glb(doc, buf)
+    (glb, blobs), = gltf.transcode_files([src])
+    assert [bytes(b) for b in blobs] == [_oracle_blob(h) for h in halves]
+    doc2, bin2 = gltf.read_glb(glb)
+    a0, a1, line = doc2["meshes"][0]["primitives"]
+    acc = doc2["accessors"]
+    for a, blob in ((a0, blobs[0]), (a1, blobs[1])):
+        assert "KHR_draco_mesh_compression" in a["extensions"]
+        assert all("bufferView" not in acc[i] for i in list(a["attributes"].values()) + [a["indices"]])
+    assert set(a0["attributes"].values()).isdisjoint(a1["attributes"].values())
+    lp = acc[line["attributes"]["POSITION"]]
+    assert "extensions" not in line and "bufferView" in lp and lp["count"] == len(p["pos"])
+    v = doc2["bufferViews"][lp["bufferView"]]
+    assert bytes(bin2[v["byteOffset"]: v["byteOffset"] + v["byteLength"]]) == p["pos"].astype("<f4").tobytes()
+    # each compressed primitive's counts are its own (the built meshes of the two halves have different point counts only if a half drops points: both keep
+    # the points their faces use)
+    for a, h in ((a0, halves[0]), (a1, halves[1])):
+        assert acc[a["indices"]]["count"] == len(h["idx"]) and acc[a["attributes"]["POSITION"]]["count"] == len(np.unique(h["idx"]))
+    monkeypatch.setenv("DMI_TRANSCODE_PYTHON", "1")
+    (glb_py, blobs_py), = gltf.transcode_files([src])
+    assert bytes(glb_py) == bytes(glb)
+
+
+@pytest.mark.gpu
+def test_native_transcoder_refuses_accessors_it_would_misread():
+    """normalized-integer / quantized inputs (componentType ≠ FLOAT) for POSITION / NORMAL / TEXCOORD_0, a byteStride below the element size, an
+    accessor that leaves its bufferView (but not its buffer), a duplicated attribute name: refused with the library's message."""
+    from draco_oxide_amd import binding
+    def broken(edit, raw_json=None):
+        doc, buf = _make_asset([_prim(8, 3)])
+        edit(doc)
+        if raw_json is not None:
+            js = raw_json(json.dumps(doc, separators=(",", ":")))
+            return (js.encode(), [buf])
+        return gltf.write_glb(doc, buf)
+    cases = [
+        lambda d: d["accessors"][0].update(componentType=5123),                                   # POSITION as UNSIGNED_SHORT (KHR_mesh_quantization)
+        lambda d: d["accessors"][2].update(type="VEC3"),                                          # TEXCOORD_0 typed VEC3
+        lambda d: d["bufferViews"][0].update(byteStride=8),                                        # stride below a VEC3 row
+        lambda d: d["bufferViews"][0].update(byteLength=d["bufferViews"][0]["byteLength"] - 12),  # the accessor leaves its view
+    ]
+    for edit in cases:
+        with pytest.raises(dmi.DracoMiError, match="gltf"):
+            binding.transcode_assets([broken(edit)], devices=[0])
+    dup = broken(lambda d: None, raw_json=lambda js: js.replace('"attributes":{"POSITION":0', '"attributes":{"POSITION":0,"POSITION":0', 1))
+    with pytest.raises(dmi.DracoMiError, match="twice"):
+        binding.transcode_assets([dup], devices=[0])
+    ok, _ = binding.transcode_assets([broken(lambda d: None)], devices=[0])
+    assert len(ok) == 1
