@@ -393,6 +393,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available() or dmi.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: libdraco_mi has no CPU fallback")
+    # a process dedicated to encoding opts in to what the library no longer does to its host by default (round 6, dmi_configure_process): its large index
+    # arrays on huge pages, the calling thread kept on the GPU's memory node during whole-mesh calls (DMI_BENCH_PLAIN_PROCESS=1: both off, as the tests run)
+    plain_process = os.environ.get("DMI_BENCH_PLAIN_PROCESS") is not None
+    if not plain_process:
+        dmi.configure_process(huge_page_new=True, numa_pin=True)
     # DMI_BENCH_BACKEND=gloo lets the N>1 control flow — and the host-side contention of N ranks on one box — be measured on a 1-GPU box
     # (all ranks share cuda:0, the gather runs on CPU tensors); the driver's multi-GPU runs use the default: nccl = RCCL over xGMI.
     backend = os.environ.get("DMI_BENCH_BACKEND", "nccl")
@@ -495,7 +500,8 @@ def main():
                                    "bytes identical to the oracle's (tests: 10M-triangle byte parity; reference-made .drc files do not exist: parity is oracle-exact)",
                        "triangles_per_gpu": n_tris, "attributes": "pos3+nrm3+uv2", "bitstream_bytes": out_len,
                        "parallelism": f"{world} independent meshes, one per GPU" + (", RCCL gather of bitstreams to rank 0" if world > 1 else ""),
-                       "host_threads_per_rank": host_threads},
+                       "host_threads_per_rank": host_threads,
+                       "process_options": "none (library defaults)" if plain_process else "dmi_configure_process: huge-page operator new + NUMA pin (opt-in)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                          "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBPS, 5), "achievable_gbps": HBM_ACHIEVABLE_GBPS,
                          "traffic": int(traffic) if traffic else None,

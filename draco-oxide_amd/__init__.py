@@ -13,5 +13,6 @@ from .binding import (  # noqa: F401
     encode, encode_mesh, encode_attributes, encode_attributes_batch, encode_connectivity, mesh_prepare, meshes_prepare, jobs_encode, jobs_encode_raw, EncodedBatch, device_count, release_cached_memory, library_path, load_library,
     host_rans_stream, host_rabs_stream, host_rabs_constant_stream, tile_sort_slots, decode_attributes, decode_mesh, decode_connectivity, last_decode_timings, shard_meshes, meshes_prepare_devices, jobs_encode_devices, device_corner_table, DeviceMesh, encode_mesh_device, encode_mesh_device_raw, last_call_timings, init,
     RawMesh, BuiltBatch, Transcoder, meshes_build, built_meshes_prepare, last_build_timings, device_attribute_table,
+    configure_process, debug_from_env,
 )
 from . import binding, gltf, synth  # noqa: E402,F401

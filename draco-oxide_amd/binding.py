@@ -41,9 +41,80 @@ class _CornerTable(C.Structure):
                 ("opposite", C.c_void_p), ("left_most_corner", C.c_void_p), ("sequence", C.c_void_p), ("sequence_len", C.c_uint32)]
 
 
+class _Debug(C.Structure):
+    """dmi_debug (include/draco_mi.h): the typed path-selecting / tuning switches.  The LIBRARY never reads the environment for them (round 6); this
+    binding fills the struct from os.environ on every call — `DMI_NO_FUSED=1 pytest …` and monkeypatch.setenv keep working for tests and bench."""
+    _fields_ = [("flags", C.c_uint64), ("host_threads", C.c_uint32), ("tile_sort", C.c_int32), ("tile_sort_min", C.c_uint32), ("tile_sort_local", C.c_uint32),
+                ("seq_big_entries", C.c_uint32), ("relabel", C.c_uint8), ("chains", C.c_uint8), ("pad0", C.c_uint8), ("pad1", C.c_uint8),
+                ("fused_grid", C.c_uint32), ("fused_lds", C.c_uint32), ("chain_grid", C.c_uint32), ("batch_threads", C.c_uint32), ("split", C.c_uint32),
+                ("shadow_min_faces", C.c_uint32), ("prep_group_faces", C.c_uint64), ("batch_min_faces", C.c_uint64), ("stage_primitives", C.c_uint32), ("pad2", C.c_uint32)]
+
+
 class _Config(C.Structure):
     _fields_ = [("pos_bits", C.c_uint8), ("uv_bits", C.c_uint8), ("generic_bits", C.c_uint8), ("pos_scheme", C.c_uint8),
-                ("device", C.c_int32), ("stream", C.c_void_p), ("flags", C.c_uint32)]
+                ("device", C.c_int32), ("stream", C.c_void_p), ("flags", C.c_uint32), ("debug", C.POINTER(_Debug))]
+
+
+class _ProcessOptions(C.Structure):
+    _fields_ = [("flags", C.c_uint32), ("host_cache_mb", C.c_uint32), ("device_cache_mb", C.c_uint32), ("decode_budget_mb", C.c_uint32)]
+
+
+# environment variable → bit of dmi_debug.flags (set when the variable is present, whatever its value — what the library's getenv tests did)
+_DEBUG_FLAGS = {"DMI_NO_FUSED": 0, "DMI_NO_PACKED": 1, "DMI_NO_SYM16": 2, "DMI_NO_EARLY": 3, "DMI_NO_PLAIN_ORDER": 4, "DMI_HOST_TABLES": 5, "DMI_HOST_CONNECTIVITY": 6,
+                "DMI_HOST_ATT_TABLES": 7, "DMI_HOST_BUILD": 8, "DMI_NO_IN_PLACE": 9, "DMI_NO_POOL": 10, "DMI_POISON": 11, "DMI_ZERO_CHUNKS": 12, "DMI_NO_QUAD": 13,
+                "DMI_TEST_QUAD": 14, "DMI_NO_CLOSED": 15, "DMI_NO_SHADOW": 16, "DMI_NO_SEQ_SHADOW": 17, "DMI_NO_SEAM_MASKS": 18, "DMI_NO_DEFER_SEAMS": 19,
+                "DMI_NO_BATCHED_PHASES": 20, "DMI_FUSED_WINDOWS": 21, "DMI_CHAIN_DENSE": 22, "DMI_SERIAL_TABLES": 23, "DMI_PARALLEL_TABLES": 24, "DMI_FILE_ORDER": 25,
+                "DMI_TRACE": 26, "DMI_TRACE_STAGES": 27, "DMI_TRACE_TABLES": 28, "DMI_BUILD_TRACE": 29}
+_DEBUG_INTS = {"DMI_HOST_THREADS": "host_threads", "DMI_TILE_SORT_MIN": "tile_sort_min", "DMI_TILE_SORT_LOCAL": "tile_sort_local", "DMI_SEQ_BIG_ENTRIES": "seq_big_entries",
+               "DMI_FUSED_GRID": "fused_grid", "DMI_FUSED_LDS": "fused_lds", "DMI_CHAIN_GRID": "chain_grid", "DMI_BATCH_THREADS": "batch_threads",
+               "DMI_SHADOW_MIN_FACES": "shadow_min_faces", "DMI_PREP_GROUP_FACES": "prep_group_faces", "DMI_BATCH_MIN_FACES": "batch_min_faces",
+               "DMI_STAGE_PRIMITIVES": "stage_primitives"}
+
+
+def debug_from_env(env=None):
+    """The dmi_debug struct the environment asks for (DMI_* variables: INTEGRATION.md §4)."""
+    env = os.environ if env is None else env
+    d = _Debug()
+    flags = 0
+    for name, bit in _DEBUG_FLAGS.items():
+        if name in env:
+            flags |= 1 << bit
+    d.flags = flags
+    for name, field in _DEBUG_INTS.items():
+        v = env.get(name)
+        if v:
+            try:
+                n = max(0, int(v))
+            except ValueError:
+                continue
+            if n == 0 and name in ("DMI_SEQ_BIG_ENTRIES", "DMI_TILE_SORT_MIN", "DMI_SHADOW_MIN_FACES"):
+                n = 1                                   # 0 in the struct means "default": a threshold of 0 is asked for as 1 (every real input is above it)
+            setattr(d, field, n)
+    if "DMI_SPLIT" in env:
+        d.split = 1
+    ts = env.get("DMI_TILE_SORT")
+    if ts is not None:
+        try:
+            d.tile_sort = -1 if int(ts) <= 0 else int(ts)      # 0 = default in the struct, -1 = off
+        except ValueError:
+            pass
+    d.relabel = {"device": 1, "host": 2}.get(env.get("DMI_RELABEL", ""), 0)
+    d.chains = {"device": 1, "host": 2}.get(env.get("DMI_CHAINS", ""), 0)
+    return d
+
+
+def _sync_default_debug(L):
+    """Entry points without a dmi_config (dmi_encode_connectivity, dmi_mesh_build, the host coders …) work under the process default: kept equal to the
+    environment's, like every config this binding marshals."""
+    d = debug_from_env()
+    L.dmi_set_default_debug(C.byref(d))
+
+
+def configure_process(huge_page_new=False, numa_pin=False, no_thp=False, host_cache_mb=0, device_cache_mb=0, decode_budget_mb=0):
+    """dmi_configure_process: what the library does to its host process only when asked (round 6): large operator-new blocks of its own containers on huge
+    pages, the calling thread restricted to the GPU's memory node during whole-mesh calls.  bench.py turns both on; the tests run with both off."""
+    o = _ProcessOptions((1 if huge_page_new else 0) | (2 if numa_pin else 0) | (4 if no_thp else 0), int(host_cache_mb), int(device_cache_mb), int(decode_budget_mb))
+    _check(load_library().dmi_configure_process(C.byref(o)))
 
 
 class _Buffer(C.Structure):
@@ -237,7 +308,21 @@ def load_library():
     L.dmi_transcoded_free.argtypes = [C.c_void_p]
     L.dmi_transcoded_free.restype = None
     L.dmi_json_roundtrip.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(_Buffer)]
+    L.dmi_set_default_debug.argtypes = [C.POINTER(_Debug)]
+    L.dmi_set_default_debug.restype = None
+    L.dmi_configure_process.argtypes = [C.POINTER(_ProcessOptions)]
     _lib = L
+    _sync_default_debug(L)
+    # process options the environment asks for (the library reads none of these itself): DMI_HUGE_PAGE_NEW / DMI_NUMA_PIN opt in, DMI_NO_THP opts out,
+    # DMI_HOST_CACHE_MB / DMI_DEVICE_CACHE_MB / DMI_DECODE_BUDGET_MB size the caches and the decoder's allocation budget
+    env = os.environ
+    def _mb(name):
+        try:
+            return max(0, int(env.get(name, "0")))
+        except ValueError:
+            return 0
+    if any(k in env for k in ("DMI_HUGE_PAGE_NEW", "DMI_NUMA_PIN", "DMI_NO_THP", "DMI_HOST_CACHE_MB", "DMI_DEVICE_CACHE_MB", "DMI_DECODE_BUDGET_MB")):
+        configure_process("DMI_HUGE_PAGE_NEW" in env, "DMI_NUMA_PIN" in env, "DMI_NO_THP" in env, _mb("DMI_HOST_CACHE_MB"), _mb("DMI_DEVICE_CACHE_MB"), _mb("DMI_DECODE_BUDGET_MB"))
     return L
 
 
@@ -403,6 +488,7 @@ class MeshBuilder:
             raw[i].parents = par.ctypes.data if len(par) else None
         faces = self._faces if self._faces is not None else np.zeros((0, 3), np.uint32)
         built = _BuiltMesh()
+        _sync_default_debug(L)
         _check(L.dmi_mesh_build(raw, n, faces.ctypes.data if faces.size else None, faces.shape[0], C.byref(built)))
         try:
             m = built.mesh
@@ -809,9 +895,10 @@ class Config:
     """encode::Config — only `Config.default()` is constructible in the reference (encode/mod.rs:22-42).
     The extra fields select the internal variants the reference compiles but does not expose."""
 
-    def __init__(self, pos_bits=0, uv_bits=0, generic_bits=0, pos_scheme=0, device=0, stream=None, flags=0):
+    def __init__(self, pos_bits=0, uv_bits=0, generic_bits=0, pos_scheme=0, device=0, stream=None, flags=0, debug=None):
         self.pos_bits, self.uv_bits, self.generic_bits, self.pos_scheme = pos_bits, uv_bits, generic_bits, pos_scheme
         self.device, self.stream, self.flags = device, stream, flags
+        self.debug = debug
 
     @classmethod
     def default(cls):
@@ -823,6 +910,12 @@ class Config:
         c.device = self.device
         c.stream = self.stream
         c.flags = self.flags
+        # the typed switches: this Config's own (`debug`: a _Debug, e.g. debug_from_env({...})) or what the environment asks for right now
+        dbg = self.debug if self.debug is not None else debug_from_env()
+        c._debug_keep = dbg                      # (the struct must outlive the call that reads the pointer)
+        c.debug = C.pointer(dbg)
+        if _lib is not None:
+            _lib.dmi_set_default_debug(C.byref(dbg))   # entry points without a config (job.encode of …, host stages) see the same switches
         return c
 
 
@@ -851,6 +944,7 @@ class Connectivity:
         self._L = L
         self._conn = _Conn()
         m, out = mesh._c(), _Buffer()
+        _sync_default_debug(L)
         _check(L.dmi_encode_connectivity(C.byref(m), C.byref(out), C.byref(self._conn)))
         self.bytes = _take(out)
         self.num_tables = self._conn.num_tables

@@ -123,7 +123,7 @@ struct BatchPlan {
     std::atomic<size_t> next{0};   // groups differ a lot in size: a few host threads pull them
     auto work = [&] { for (size_t k; (k = next.fetch_add(1)) < groups.size();) fill_group(ph, groups[k]); };
     std::vector<std::thread> th;
-    for (size_t t = 1; t < std::min<size_t>(groups.size(), 8); ++t) th.emplace_back(work);
+    for (size_t t = 1; t < std::min<size_t>(groups.size(), 8); ++t) th.emplace_back(with_debug(work));
     work();
     for (auto& x : th) x.join();
   }
@@ -225,7 +225,7 @@ static int parallel_items(uint32_t n, uint32_t n_threads, int device, const std:
   if (n_threads == 1) work(0);
   else {
     std::vector<std::thread> th;
-    for (uint32_t t = 0; t < n_threads; ++t) th.emplace_back(work, t);
+    for (uint32_t t = 0; t < n_threads; ++t) th.emplace_back(with_debug(work), t);
     for (auto& x : th) x.join();
   }
   for (uint32_t t = 0; t < n_threads; ++t) if (rcs[t]) return fail(rcs[t], errs[t]);
@@ -403,7 +403,7 @@ static int jobs_encode_device(dmi_job** jobs, uint32_t n, dmi_buffer* outs, uint
   hipStream_t main_stream = jobs[0]->stream, side = nullptr;
   bool library_streams = true;   // a caller's stream (dmi_config.stream) is honoured: everything stays on it
   for (uint32_t j = 0; j < n; ++j) if (jobs[j]->cfg.stream) library_streams = false;
-  if (n >= 32 && library_streams && std::getenv("DMI_SPLIT") && batch_stream_pair(device, main_stream, side)) {
+  if (n >= 32 && library_streams && dbg().split && batch_stream_pair(device, main_stream, side)) {
     uint64_t acc = 0;
     n_first = 0;
     while (n_first < n && acc * 100 < total * 45) acc += symbols(order[n_first++]);
@@ -437,6 +437,7 @@ static int jobs_encode_device(dmi_job** jobs, uint32_t n, dmi_buffer* outs, uint
 
 static int jobs_encode_impl(dmi_job** jobs, uint32_t n, dmi_buffer* outs);
 int dmi_jobs_encode(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
+  DebugScope debug_scope((jobs && n && jobs[0]) ? &jobs[0]->debug : nullptr);
   if (!jobs || !outs || n == 0) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
   for (uint32_t j = 0; j < n; ++j) outs[j] = dmi_buffer{};
   const int rc = jobs_encode_impl(jobs, n, outs);
@@ -450,6 +451,7 @@ int dmi_jobs_encode(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
 // One process, several GPUs: the jobs are grouped by the device they live on and every group is coded by its own dmi_jobs_encode
 // on its own host thread — the devices run concurrently, the call returns when all have finished.  All or nothing.
 int dmi_jobs_encode_devices(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
+  DebugScope debug_scope((jobs && n && jobs[0]) ? &jobs[0]->debug : nullptr);
   if (!jobs || !outs || n == 0) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
   for (uint32_t j = 0; j < n; ++j) { outs[j] = dmi_buffer{}; if (!jobs[j]) return fail(DMI_ERR_INVALID_ARGUMENT, "null job"); }
   std::vector<int> devices;
@@ -467,7 +469,7 @@ int dmi_jobs_encode_devices(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
     for (size_t k = 0; k < at.size(); ++k) outs[at[k]] = got[k];
   };
   std::vector<std::thread> th;
-  for (size_t g = 1; g < devices.size(); ++g) th.emplace_back(work, g);
+  for (size_t g = 1; g < devices.size(); ++g) th.emplace_back(with_debug(work), g);
   work(0);
   for (auto& x : th) x.join();
   for (size_t g = 0; g < devices.size(); ++g)
@@ -482,7 +484,7 @@ static int jobs_encode_impl(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
   const int device = jobs[0]->cfg.device;
   // Small meshes are launch-bound, so whatever stays per job (table normalisation; the phases of jobs that cannot be planned ahead) runs on several host
   // threads, each walking a contiguous slice of the jobs (jobs that own their stream then also overlap on the GPU).
-  static const uint32_t thread_cap = std::getenv("DMI_BATCH_THREADS") ? (uint32_t)std::atoi(std::getenv("DMI_BATCH_THREADS")) : 16u;
+  const uint32_t thread_cap = dbg().batch_threads ? dbg().batch_threads : 16u;
   const uint32_t n_threads = std::max(1u, std::min({n, (uint32_t)host_threads(), std::max(1u, thread_cap)}));
   auto parallel = [&](auto&& fn, bool sync_after = true) -> int {
     std::vector<int> rcs(n_threads, DMI_OK);
@@ -503,7 +505,7 @@ static int jobs_encode_impl(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
     if (n_threads == 1) work(0);
     else {
       std::vector<std::thread> th;
-      for (uint32_t t = 0; t < n_threads; ++t) th.emplace_back(work, t);
+      for (uint32_t t = 0; t < n_threads; ++t) th.emplace_back(with_debug(work), t);
       for (auto& x : th) x.join();
     }
     for (uint32_t t = 0; t < n_threads; ++t) if (rcs[t]) return fail(rcs[t], errs[t]);
@@ -511,7 +513,7 @@ static int jobs_encode_impl(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
   };
   hipStream_t s = jobs[0]->stream;
   int rc;
-  const bool trace = std::getenv("DMI_TRACE") != nullptr;
+  const bool trace = dbg_on(DMI_DBG_TRACE);
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   const auto t0 = now();
@@ -526,7 +528,7 @@ static int jobs_encode_impl(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
   std::vector<uint8_t> is_batched(n, 0);
   for (uint32_t j = 0; j < n; ++j) {
     jobs[j]->readback = nullptr;
-    bool ok = !jobs[j]->have_events && !std::getenv("DMI_NO_BATCHED_PHASES");
+    bool ok = !jobs[j]->have_events && !dbg_on(DMI_DBG_NO_BATCHED_PHASES);
     for (auto& a : jobs[j]->atts) if (a.port == kToBits) ok = false;
     if (ok) { batched.push_back(j); is_batched[j] = 1; }
   }
@@ -577,7 +579,7 @@ static int jobs_encode_impl(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
     if (n_threads == 1) work(0);
     else {
       std::vector<std::thread> th;
-      for (uint32_t t = 0; t < n_threads; ++t) th.emplace_back(work, t);
+      for (uint32_t t = 0; t < n_threads; ++t) th.emplace_back(with_debug(work), t);
       for (auto& x : th) x.join();
     }
     for (uint32_t t = 0; t < n_threads; ++t) if (rcs[t]) return fail(rcs[t], errs[t]);
@@ -635,6 +637,7 @@ static int jobs_encode_impl(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
 }
 
 int dmi_encode_attributes_batch(const dmi_batch_item* items, uint32_t n, const dmi_config* cfg_in, dmi_buffer* outs) {
+  DebugScope debug_scope(cfg_in ? cfg_in->debug : nullptr);
   if (!items || !outs || n == 0) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
   dmi_config cfg{};
   if (cfg_in) cfg = *cfg_in;

@@ -50,7 +50,7 @@ int run_parallel(uint32_t count, uint32_t n_threads, const std::function<int(uin
     for (uint32_t i; (i = next.fetch_add(1)) < count;) { const int rc = fn(order[i]); if (rc) { rcs[t] = rc; errs[t] = g_last_error; next.store(count); return; } }
   };
   if (nt == 1) work(0);
-  else { std::vector<std::thread> th; for (uint32_t t = 0; t < nt; ++t) th.emplace_back(work, t); for (auto& x : th) x.join(); }
+  else { std::vector<std::thread> th; for (uint32_t t = 0; t < nt; ++t) th.emplace_back(with_debug(work), t); for (auto& x : th) x.join(); }
   for (uint32_t t = 0; t < nt; ++t) if (rcs[t]) return fail(rcs[t], errs[t]);
   return DMI_OK;
 }
@@ -181,6 +181,7 @@ void dmi_built_meshes_free(dmi_built_mesh* built, uint32_t n) {
 }
 
 int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg, uint32_t flags, dmi_built_mesh* out) {
+  DebugScope debug_scope(cfg ? cfg->debug : nullptr);
   if (!raw || !out || n == 0) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
   for (uint32_t j = 0; j < n; ++j) out[j] = dmi_built_mesh{};
   int ndev = 0;
@@ -191,7 +192,7 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
   NumaScope pin(device);
   const auto t0 = std::chrono::steady_clock::now();
   auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
-  const bool trace = std::getenv("DMI_TRACE") != nullptr;
+  const bool trace = dbg_on(DMI_DBG_TRACE);
   const bool host_values = (flags & DMI_BUILD_HOST_VALUES) != 0;
   const uint32_t n_threads = std::max(1u, std::min((uint32_t)host_threads(), kMaxPrepareWorkers));
   const uint32_t pack_threads = std::max(2u, n_threads / 4);   // (copies into staging: a few cores saturate the memory bus; a transcode pipeline runs the previous stage's host walks beside this)
@@ -201,11 +202,11 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
 
   // ---- groups of ≈ 6M faces (dmi_built_meshes_prepare's connectivity stage takes a group as it is); a primitive of 2^20 faces or more
   //      is a group of its own (it goes through the single-mesh prepare) ----
-  static const uint64_t group_faces = std::getenv("DMI_PREP_GROUP_FACES") ? (uint64_t)std::atoll(std::getenv("DMI_PREP_GROUP_FACES")) : (uint64_t)(6u << 20);
+  const uint64_t group_faces = dbg().prep_group_faces ? dbg().prep_group_faces : (uint64_t)(6u << 20);
   std::vector<std::unique_ptr<BuildGroup>> groups;
   std::vector<uint32_t> host_list;
-  const bool no_device = std::getenv("DMI_HOST_BUILD") != nullptr;
-  const bool no_ingest = std::getenv("DMI_NO_IN_PLACE") != nullptr;   // (A/B: pack + copy even what could go up where it lies)
+  const bool no_device = dbg_on(DMI_DBG_HOST_BUILD);
+  const bool no_ingest = dbg_on(DMI_DBG_NO_IN_PLACE);   // (A/B: pack + copy even what could go up where it lies)
   for (uint32_t j = 0; j < n; ++j) {
     const dmi_raw_mesh& m = raw[j];
     if (no_device || !device_form(m)) { host_list.push_back(j); continue; }
@@ -533,7 +534,7 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
     // (a mesh of 2^20 faces or more goes through the single-mesh prepare, which builds its own)
     bool any_large = false;
     for (const auto& mem : bg.members) any_large = any_large || mem.F >= kDeviceRelabelMinFaces;
-    if (!any_large && faces_seen && !std::getenv("DMI_HOST_CONNECTIVITY") && (rc = built_group_issue_tables(bg, g.S))) return rc;
+    if (!any_large && faces_seen && !dbg_on(DMI_DBG_HOST_CONNECTIVITY) && (rc = built_group_issue_tables(bg, g.S))) return rc;
     bg.stream = nullptr; bg.keep.pool.stream = nullptr; bg.keep.owner_waits = true;   // (a null-stream synchronisation would wait for every other stage of a pipeline)   // (everything of the build has arrived; the library stream belongs to this thread, the group may outlive it)
     release_stage(g.up_stage); g.up_stage = nullptr;
   }

@@ -946,14 +946,14 @@ void launch_scatter_items(const CopyItem* items_dev, uint32_t n_items, const uin
   if (n_items) hipLaunchKernelGGL(k_scatter_items, n_items, 256, 0, s, items_dev, arena);
 }
 uint32_t chain_grid(uint32_t n_streams) {
-  static const uint32_t cap = [] { const char* e = std::getenv("DMI_CHAIN_GRID"); const int v = e ? std::atoi(e) : 0; return v > 0 ? (uint32_t)v : 256u; }();
+  const uint32_t cap = dbg().chain_grid ? dbg().chain_grid : 256u;
   return n_streams < cap ? n_streams : cap;
 }
 // Which form a launch takes.  Dense: 4 pairs per CU, ≈ 20 ns per step (a walker shares its SIMD with an emitter).  Sparse: 2 pairs per CU,
 // ≈ 16.2 ns per step.  A launch lasts about max(longest stream, all steps / walkers) steps — the sparse form wins while the longest
 // stream dominates (single meshes, batches of a few hundred), the dense one when the sum does.
 bool chain_launch_sparse(uint64_t longest_steps, uint64_t total_steps, uint32_t n_streams) {
-  if (std::getenv("DMI_CHAIN_DENSE")) return false;
+  if (dbg_on(DMI_DBG_CHAIN_DENSE)) return false;
   const uint32_t g = chain_grid(n_streams);
   const double dense = 20.0 * (double)std::max<uint64_t>(longest_steps, total_steps / (4ull * g));
   const double sparse = 16.2 * (double)std::max<uint64_t>(longest_steps, total_steps / (2ull * g));

@@ -67,7 +67,7 @@ struct DecodedConnectivity {
 
 int decode_connectivity(Bytes& b, DecodedConnectivity& out) {
   auto bad = [](const char* what) { return host_fail(DMI_ERR_CONNECTIVITY, std::string("connectivity section: ") + what); };
-  const bool trace = std::getenv("DMI_TRACE") != nullptr;
+  const bool trace = dbg_on(DMI_DBG_TRACE);
   auto t_last = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {
     if (!trace) return;
@@ -398,6 +398,7 @@ void dmi_decoded_mesh_free(dmi_decoded_mesh* m) {
 }
 
 int dmi_decode_mesh(const uint8_t* drc, size_t len, const dmi_config* cfg, dmi_decoded_mesh* out) {
+  DebugScope debug_scope(cfg ? cfg->debug : nullptr);
   if (!drc || !out) return host_fail(DMI_ERR_INVALID_ARGUMENT, "null argument");
   *out = dmi_decoded_mesh{};
   const auto t0 = std::chrono::steady_clock::now();

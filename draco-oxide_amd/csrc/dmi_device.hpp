@@ -6,6 +6,8 @@
 
 #include <cstdint>
 
+#include "dmi_debug.hpp"
+
 namespace dmi {
 
 // ---- kernel steps ---------------------------------------------------------------------------------

@@ -204,7 +204,7 @@ int encode_phase_b(dmi_job* job, bool plan_only, bool host_chains) {   // host: 
     AttJob& a = job->atts[i];
     const uint8_t* base = pinned + pin_off[i];
     const uint32_t* small = reinterpret_cast<const uint32_t*>(base);
-    if (std::getenv("DMI_TRACE")) std::fprintf(stderr, "[dmi] attribute %u small: %08x %08x %u %u %u %u %u %u\n", i, small[0], small[1], small[2], small[3], small[4], small[5], small[6], small[7]);
+    if (dbg_on(DMI_DBG_TRACE)) std::fprintf(stderr, "[dmi] attribute %u small: %08x %08x %u %u %u %u %u %u\n", i, small[0], small[1], small[2], small[3], small[4], small[5], small[6], small[7]);
     if (small[4]) return fail(DMI_ERR_ZERO_NORMAL, "attribute " + std::to_string(i) + " contains a zero-length normal (reference assert, geom.rs:45)");
     if (small[5]) return fail(DMI_ERR_ALPHABET_TOO_LARGE, "symbol outside the histogram bound");
     { const int brc = check_value_bounds(a, small, i); if (brc) return brc; }
@@ -440,7 +440,7 @@ static int encode_phase_c2(dmi_job* job) {   // lengths known: async copy of the
   for (uint32_t i = 0; i < n_atts; ++i) {
     const uint32_t* small = reinterpret_cast<const uint32_t*>(pinned + pin_off[i]);
     if (small[9] || small[11]) return fail(DMI_ERR_ENTROPY, small[9] == 1 || small[11] == 1 ? "rANS state too large" : "coder output capacity exceeded");
-    if (std::getenv("DMI_TRACE")) std::fprintf(stderr, "[dmi] attribute %u: rANS chain %.3f ms (%llu symbols), aux chain %.3f ms\n", i, small[12] * 1e-5, (unsigned long long)job->atts[i].n_sym, small[13] * 1e-5);
+    if (dbg_on(DMI_DBG_TRACE)) std::fprintf(stderr, "[dmi] attribute %u: rANS chain %.3f ms (%llu symbols), aux chain %.3f ms\n", i, small[12] * 1e-5, (unsigned long long)job->atts[i].n_sym, small[13] * 1e-5);
     rans_off[i] = total; total += (small[8] + 15u) & ~15u;
     if (aux[i].desc >= 0) { aux_off[i] = total; total += (small[10] + 15u) & ~15u; }
   }
@@ -677,7 +677,7 @@ static int encode_tail_host(dmi_job* job, dmi_buffer* out, float* chain_ms, floa
   {
     const size_t n_threads = std::max<size_t>(1, std::min<size_t>({streams.size(), (size_t)host_threads(), (size_t)16}));
     std::vector<std::thread> th;
-    for (size_t t = 1; t < n_threads; ++t) th.emplace_back(work);
+    for (size_t t = 1; t < n_threads; ++t) th.emplace_back(with_debug(work));
     work();
     for (auto& x : th) x.join();
   }
@@ -742,6 +742,7 @@ int run_phase_a(dmi_job* job) {
 }
 
 int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
+  DebugScope debug_scope(job ? &job->debug : nullptr);
   if (!job || !out) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
   hipStream_t s = job->stream;
   const bool timed = job->have_events;
@@ -816,6 +817,7 @@ int dmi_job_encode(dmi_job* job, dmi_buffer* out) {
 // Device + pinned staging of one batch read-back, kept between calls (grow-only; a small pool so that concurrent
 int dmi_encode_attributes(const dmi_attribute* atts, const dmi_corner_table* tables, uint32_t n_atts, const uint32_t* seeds, uint32_t n_seeds,
                           const dmi_config* cfg, dmi_buffer* out) {
+  DebugScope debug_scope(cfg ? cfg->debug : nullptr);
   dmi_job* job = nullptr;
   const auto t0 = std::chrono::steady_clock::now();
   auto ms = [&] { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); };

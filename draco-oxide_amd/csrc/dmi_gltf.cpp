@@ -537,6 +537,7 @@ void on_done(void* user, uint32_t first, uint32_t count) {
 extern "C" {
 
 int dmi_transcode_assets(const dmi_gltf_asset* assets, uint32_t n, const dmi_config* cfg, const int32_t* devices, uint32_t n_devices, uint32_t flags, dmi_transcoded** out) {
+  DebugScope debug_scope(cfg ? cfg->debug : nullptr);
   (void)flags;
   if (!out || (!assets && n)) return host_fail(DMI_ERR_INVALID_ARGUMENT, "null");
   *out = nullptr;
@@ -556,7 +557,7 @@ int dmi_transcode_assets(const dmi_gltf_asset* assets, uint32_t n, const dmi_con
   uint64_t in_bytes = 0;
   std::vector<uint32_t> order(n);
   for (uint32_t i = 0; i < n; ++i) { order[i] = i; in_bytes += bytes_of(i); }
-  if (!std::getenv("DMI_FILE_ORDER")) std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return bytes_of(x) > bytes_of(y); });
+  if (!dbg_on(DMI_DBG_FILE_ORDER)) std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return bytes_of(x) > bytes_of(y); });
   std::vector<std::vector<uint32_t>> dev_files(ND);
   std::vector<uint64_t> dev_bytes(ND, 0);
   for (uint32_t i : order) {
@@ -580,7 +581,8 @@ int dmi_transcode_assets(const dmi_gltf_asset* assets, uint32_t n, const dmi_con
     if (!d.t) return host_fail(DMI_ERR_OUT_OF_MEMORY, "dmi_transcoder_create");
   }
   const unsigned host_thr = process_host_threads();
-  const unsigned n_assemblers = std::max(1u, std::min(4u, host_thr / 4));
+  // (when the last stage is coded all its files become ready at once and every other thread of the call is idle: half the host's threads write them)
+  const unsigned n_assemblers = std::max(1u, std::min(8u, host_thr / 2));
   std::vector<std::thread> assemblers;
   for (unsigned k = 0; k < n_assemblers; ++k) assemblers.emplace_back(assemble_loop, R.get());
   struct Stop { dmi_transcoded* R; std::vector<std::thread>& th; ~Stop() { { std::lock_guard<std::mutex> lock(R->q_mutex); R->q_closed = true; } R->q_cv.notify_all(); for (auto& t : th) if (t.joinable()) t.join(); } } stop{R.get(), assemblers};
@@ -698,8 +700,12 @@ int dmi_transcode_assets(const dmi_gltf_asset* assets, uint32_t n, const dmi_con
   assemblers.clear();
   if (!rc) { std::lock_guard<std::mutex> lock(R->err_mutex); if (R->rc) { rc = R->rc; first_err = R->err; } }
   if (rc) return host_fail(rc, first_err);
+  const double t_assembled = now_ms();
   // the blobs are in the files now: the transcoders' buffers can go
   for (auto& d : R->devs) { dmi_transcoder_destroy(d->t); d->t = nullptr; }
+  if (dbg_on(DMI_DBG_TRACE | DMI_DBG_TRACE_STAGES))
+    std::fprintf(stderr, "[dmi] transcode_assets: %u files on %zu device(s), %u parse threads: last file parsed %.1f ms, last push %.1f, last stage coded %.1f, files written %.1f, buffers released %.1f\n",
+                 n, ND, n_parsers, last_parse_end.load() - t_start, t_pushed - t_start, t_finished - t_start, t_assembled - t_start, now_ms() - t_start);
   for (const auto& a : R->assets) R->stats.bytes_out += a->out_bytes;
   R->stats.bytes_in = in_bytes;
   R->stats.files = n;

@@ -24,15 +24,17 @@
 #include <vector>
 
 #include "../../include/draco_mi.h"
+#include "dmi_debug.hpp"
 
 namespace dmi {
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 int host_fail(int code, const std::string& msg);   // sets dmi_last_error() for the calling thread, returns code
 
+
 // Host threads the library may use at once in one call: the machine's hardware threads, no more than the CPU quota of the process's
 // cgroup (a container on a 256-thread host may be allowed 16 CPUs' worth of time: threads beyond the quota only add throttling —
-// measured on the GPU box: 1024-mesh prepare 0.36 s on 16 threads, 0.47–0.68 s on 128), capped by DMI_HOST_THREADS (read per call: one
+// measured on the GPU box: 1024-mesh prepare 0.36 s on 16 threads, 0.47–0.68 s on 128), capped by dmi_debug::host_threads (per call: one
 // process per GPU on a shared host sets it to its share, cores / world size).
 inline unsigned cgroup_cpu_quota() {   // 0 = unlimited / unknown
   static const unsigned quota = [] {
@@ -60,7 +62,7 @@ inline unsigned process_host_threads() {   // what the whole process may keep bu
   unsigned hw = std::thread::hardware_concurrency();
   if (!hw) hw = 4;
   if (const unsigned q = cgroup_cpu_quota()) hw = std::min(hw, std::max(1u, q));   // (a 1024-file transcode with 1.5 × / 2 × / 3 × the quota in threads: 86–97 ms either way)
-  if (const char* e = std::getenv("DMI_HOST_THREADS")) { const int v = std::atoi(e); if (v > 0) hw = std::min<unsigned>(hw, (unsigned)v); }
+  if (const uint32_t v = dbg().host_threads) hw = std::min<unsigned>(hw, v);
   return hw;
 }
 inline unsigned host_threads() {
@@ -85,15 +87,16 @@ inline void parallel_for(size_t n, Fn&& fn) {
   const size_t n_threads = n < (1u << 20) ? 1 : std::max<size_t>(1, std::min<size_t>({(size_t)hw, (size_t)32, n >> 18}));
   if (n_threads == 1) { fn((size_t)0, n); return; }
   std::vector<std::thread> th;
-  for (size_t t = 0; t < n_threads; ++t) th.emplace_back([&, t] { fn(n * t / n_threads, n * (t + 1) / n_threads); });
+  const dmi_debug* cur = dbg_ptr();
+  for (size_t t = 0; t < n_threads; ++t) th.emplace_back([&, t] { DebugScope scope(cur); fn(n * t / n_threads, n * (t + 1) / n_threads); });
   for (auto& x : th) x.join();
 }
 
 // ---- recycled host arrays ----
 // The connectivity stage of a large mesh allocates ≈ 190 bytes per face of index arrays (tables, walk state, sequences) and hands them
 // back at the end: ≈ 1.9 GB of first-touch page faults and ≈ 100 ms of munmap per 10M triangles, paid again by the next mesh.  Vectors of
-// at least kPoolMinBytes are therefore taken from / given back to a process-wide pool (capacity kept, contents not): DMI_HOST_CACHE_MB
-// caps what the pool holds (default 4096, 0 = off), dmi_release_cached_memory() empties it.
+// at least kPoolMinBytes are therefore taken from / given back to a process-wide pool (capacity kept, contents not): dmi_process_options::host_cache_mb
+// caps what the pool holds (default 4096), dmi_release_cached_memory() empties it.
 constexpr size_t kPoolMinBytes = (size_t)4 << 20;
 size_t host_pool_limit();                       // bytes
 std::atomic<size_t>& host_pool_bytes();         // bytes held by the pools of every element type
@@ -294,7 +297,9 @@ template <class Fn>
 inline int guarded_pool(size_t n, unsigned max_threads, Fn&& fn) {
   std::atomic<size_t> next{0};
   std::atomic<int> status{0};
+  const dmi_debug* cur = dbg_ptr();
   auto work = [&] {
+    DebugScope scope(cur);
     try {
       for (size_t i; (i = next.fetch_add(1)) < n;) fn(i);
     } catch (const std::bad_alloc&) { status.store(1); next.store(n); }
@@ -308,11 +313,6 @@ inline int guarded_pool(size_t n, unsigned max_threads, Fn&& fn) {
   work();
   for (auto& x : th) x.join();
   return status.load();
-}
-// bytes a decode call may allocate for what a file ASKS for before anything is known to be real (DMI_DECODE_BUDGET_MB, default 16384)
-inline size_t decode_budget_bytes() {
-  static const size_t b = [] { const char* e = std::getenv("DMI_DECODE_BUDGET_MB"); return (size_t)(e && std::atol(e) > 0 ? std::atol(e) : 16384) << 20; }();
-  return b;
 }
 
 // What dmi_built_mesh::owner points to: the host builder's arrays (host_mesh.cpp) or a member of a device-built group (dmi_build.cpp).

@@ -30,7 +30,7 @@ static void stage_free(HostStage* st) {
   st->p = nullptr; st->cap = 0; st->registered = false;
 }
 static bool stage_alloc(HostStage* st, size_t want) {
-  static const bool plain = std::getenv("DMI_NO_THP") != nullptr;
+  const bool plain = (process_flags() & DMI_PROCESS_NO_THP) != 0;
   void* q = nullptr;
   if (!plain && want >= ((size_t)4 << 20) && posix_memalign(&q, (size_t)2 << 20, want) == 0 && q) {
     advise_huge_pages(q, want);
@@ -229,7 +229,7 @@ int to_buffer(const std::vector<uint8_t>& v, dmi_buffer* out) {
 // attribute with seams of its own leaves the sweep): job_create_impl compares its plan with this one.
 int dmi::early_quantize_issue(const dmi_attribute* atts, uint32_t n_atts, const dmi_config& cfg, hipStream_t side, std::unique_ptr<EarlyQuant>& out) {
   out.reset();
-  if (!atts || n_atts == 0 || n_atts > 3 || !side || std::getenv("DMI_NO_EARLY") || std::getenv("DMI_NO_PACKED") || std::getenv("DMI_NO_FUSED")) return DMI_OK;
+  if (!atts || n_atts == 0 || n_atts > 3 || !side || dbg_on(DMI_DBG_NO_EARLY | DMI_DBG_NO_PACKED | DMI_DBG_NO_FUSED)) return DMI_OK;
   std::vector<AttJob> plan;
   if (validate_and_plan(atts, n_atts, cfg, plan) != DMI_OK) return DMI_OK;   // (the call itself reports the error)
   int i_pos = -1, i_nrm = -1, i_uv = -1;
@@ -317,11 +317,14 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
   if (!atts || !tables || !job_out || n_atts == 0 || n_atts > 255) return fail(DMI_ERR_INVALID_ARGUMENT, "null argument or bad attribute count");
   dmi_config cfg{};
   if (cfg_in) cfg = *cfg_in;
+  DebugScope debug_scope(cfg.debug);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(DMI_ERR_NO_DEVICE, "no HIP device visible; libdraco_mi has no CPU fallback");
   HIP_TRY(hipSetDevice(cfg.device));
   const auto t_enter = std::chrono::steady_clock::now();
   std::unique_ptr<dmi_job> job(new dmi_job());
+  job->debug = dbg();
+  cfg.debug = &job->debug;   // (the caller's struct need not outlive the call)
   job->cfg = cfg;
   if (cfg.stream) job->stream = static_cast<hipStream_t>(cfg.stream);
   else if (g_adopt_stream) { job->stream_owner = g_adopt_stream; job->stream = g_adopt_stream->s; }
@@ -350,10 +353,10 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
     // Round 5: a batch job's chunk is not cleared either — a thousand jobs issued a thousand fills of their whole chunks on the coordinator's stream
     // (17 ms of device time per 1024-file transcode, in front of the relabelling); the few ranges that must start as zeros are RECORDED
     // (JobDefer::clears) and the coordinator clears them all in one launch.
-    job->pool.zero = std::getenv("DMI_ZERO_CHUNKS") != nullptr;
-    job->pool.poison = !job->pool.zero && std::getenv("DMI_POISON") != nullptr;
+    job->pool.zero = dbg_on(DMI_DBG_ZERO_CHUNKS);
+    job->pool.poison = !job->pool.zero && dbg_on(DMI_DBG_POISON);
   }
-  g_active_pool = std::getenv("DMI_NO_POOL") ? nullptr : &job->pool;
+  g_active_pool = dbg_on(DMI_DBG_NO_POOL) ? nullptr : &job->pool;
   const bool needs_clear = g_active_pool && !job->pool.zero;   // pooled buffers do not start as zeros: the ones that must are cleared where they are allocated
   // (a single job: the ranges are collected and cleared by ONE launch at the end of job creation — nothing reads them before the encode; round 5 issued a
   //  hipMemsetAsync each: eleven launches of ≈ 5 µs back to back on the job's stream)
@@ -368,7 +371,7 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
   };
   struct PoolGuard { ~PoolGuard() { g_active_pool = nullptr; } } pool_guard;
 
-  const bool trace_create = std::getenv("DMI_TRACE") != nullptr;
+  const bool trace_create = dbg_on(DMI_DBG_TRACE);
   const auto tc0 = std::chrono::steady_clock::now();
   auto since_ms = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
   const uint32_t F = tables[0].num_faces;
@@ -471,13 +474,13 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
     return stage_host + at;
   };
   bool device_relabel = F >= kDeviceRelabelMinFaces || dev != nullptr;
-  if (const char* e = std::getenv("DMI_RELABEL")) device_relabel = std::strcmp(e, "device") == 0 ? true : (std::strcmp(e, "host") == 0 ? (dev != nullptr) : device_relabel);
+  if (dbg().relabel == 1) device_relabel = true; else if (dbg().relabel == 2) device_relabel = dev != nullptr;
   // A one-shot call (create → encode → destroy) whose attributes ALL ride one fused sweep does not re-order its faces: the sweep reads fan rows, the
   // rows are built once from (seq, c2r, opp) in any numbering the three agree on, and the coding-order relabelling — a locality measure for the
   // per-attribute kernels that chase opp / c2r in every encode — would be paid (face keys, counting sort, table remap: 0.65 ms of kernels per 10M
   // faces) to be used exactly once, by the fan build.  The bitstream does not depend on internal face ids (tests: both forms against the oracle).
   bool plain_order = false;
-  if (dev && dev->trusted_sequences && (defer || g_one_shot_call) && n_atts >= 2 && !std::getenv("DMI_NO_FUSED") && !std::getenv("DMI_NO_PLAIN_ORDER")) {   // (a batch's jobs are one-shot too)
+  if (dev && dev->trusted_sequences && (defer || g_one_shot_call) && n_atts >= 2 && !dbg_on(DMI_DBG_NO_FUSED | DMI_DBG_NO_PLAIN_ORDER)) {   // (a batch's jobs are one-shot too)
     const AttJob& p = job->atts[0];
     int n_nrm = 0, n_uv = 0;
     bool all = p.scheme == kParallelogram && p.nq == 3 && job->tables[0].alias_of < 0 && p.table == 0;
@@ -664,7 +667,7 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
   const double t_relabel = since_ms(tc0) - t_seq;
   // Seam-free fast path: a normal / texture-coordinate attribute coded on the same corner table as its parent
   // position attribute (3 components, parallelogram) is predicted together with it in one sweep (k_predict_fused).
-  if (!std::getenv("DMI_NO_FUSED")) {
+  if (!dbg_on(DMI_DBG_NO_FUSED)) {
     for (uint32_t i = 0; i < n_atts; ++i) {
       AttJob& a = job->atts[i];
       if ((a.scheme != kNormal && a.scheme != kTexCoord) || a.parent < 0) continue;
@@ -678,7 +681,7 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
   }
   // Packed quantized values for the attributes of a fused sweep (QFmt: positions ≤ 21 bits in one uint64, octahedral normals in a
   // uint16, texture coordinates ≤ 16 bits in a uint32) — all three of a sweep or none; symbols as uint16 where the alphabet bound allows.
-  if (!std::getenv("DMI_NO_PACKED")) {
+  if (!dbg_on(DMI_DBG_NO_PACKED)) {
     for (auto& a : job->atts) {
       if (a.fused_nrm < 0 && a.fused_uv < 0) continue;
       if (a.port != kCoordwise || a.bits > 21) continue;
@@ -688,7 +691,7 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
       if (a.fused_uv >= 0) job->atts[a.fused_uv].qfmt = QF_H32;
     }
   }
-  if (!std::getenv("DMI_NO_SYM16")) for (auto& a : job->atts) a.sym16 = a.port != kToBits && symbol_bins(a) <= 65536u;
+  if (!dbg_on(DMI_DBG_NO_SYM16)) for (auto& a : job->atts) a.sym16 = a.port != kToBits && symbol_bins(a) <= 65536u;
   // the early stage of a whole-mesh call (EarlyQuant): adopted when this plan is the one it guessed — same values, same packed layouts, same bits
   if (g_early_quant && !defer && dev && dev->values_on_device && g_early_quant->device == cfg.device && g_early_quant->atts.size() == n_atts) {
     bool same = true;
@@ -838,15 +841,14 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
     a.summary = SlabView{base + 128 + (size_t)a.bins_cap * 4, a.scheme == kTexCoord ? (size_t)std::max(1u, orient_summary_blocks(job->tables[a.table].n_seq)) * 16 : 0};
   }
   job->pinned_bytes = pinned_need;   // (the pinned mirror is allocated by the first single-job encode: a batch reads back through its arena)
-  job->dev_tables = !std::getenv("DMI_HOST_TABLES");
+  job->dev_tables = !dbg_on(DMI_DBG_HOST_TABLES);
   for (auto& a : job->atts) if (a.port == kToBits) job->dev_tables = false;
-  {   // where the serial coders of a single-job encode run: DMI_CHAINS=device|host forces, default = by the longest stream
+  {   // where the serial coders of a single-job encode run: dmi_debug::chains forces, default = by the longest stream
     // (a host core steps ≈ 6× faster than a scalar-unit walker, but costs a read-back of the symbols and a few thread starts)
-    const char* m = std::getenv("DMI_CHAINS");
     uint64_t longest = 0;
     for (auto& a : job->atts) longest = std::max<uint64_t>(longest, a.n_sym);
-    if (m && std::strcmp(m, "host") == 0) job->host_chains = true;
-    else if (m && std::strcmp(m, "device") == 0) job->host_chains = false;
+    if (dbg().chains == 2) job->host_chains = true;
+    else if (dbg().chains == 1) job->host_chains = false;
     else job->host_chains = longest >= kHostChainMinSymbols;
   }
   if ((rc = job->descs.alloc(sizeof(ChainDesc) * (size_t)n_atts * 2 + 16)   /* + the chain kernel's pull counter */)) return rc;
@@ -862,10 +864,10 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
   {
     // (read per job creation, not once: the tests run small meshes through every form — DMI_TILE_SORT_MIN lowers the length it starts at,
     //  DMI_TILE_SORT_LOCAL the block size, so that small meshes reach the global-memory strides)
-    const int env_tile = std::getenv("DMI_TILE_SORT") ? std::atoi(std::getenv("DMI_TILE_SORT")) : -1;
-    const uint32_t min_entries = std::getenv("DMI_TILE_SORT_MIN") ? (uint32_t)std::atoi(std::getenv("DMI_TILE_SORT_MIN")) : kTileSortMinEntries;
+    const int env_tile = dbg().tile_sort == 0 ? -1 : (dbg().tile_sort < 0 ? 0 : dbg().tile_sort);   // (below: -1 default, 0 off, > 0 the tile)
+    const uint32_t min_entries = dbg().tile_sort_min ? dbg().tile_sort_min : kTileSortMinEntries;
     uint32_t local_lg = kTileSortMaxLog2;
-    if (const char* e = std::getenv("DMI_TILE_SORT_LOCAL")) { local_lg = 6; while ((1u << local_lg) < (uint32_t)std::atoi(e) && local_lg < kTileSortMaxLog2) ++local_lg; }
+    if (const uint32_t e = dbg().tile_sort_local) { local_lg = 6; while ((1u << local_lg) < e && local_lg < kTileSortMaxLog2) ++local_lg; }
     // a create → encode → destroy call sorts (≈ 0.31 ms per 10M triangles) for ONE gather that the sort makes 14–18 µs faster: only resident
     // jobs (dmi_job_create / dmi_mesh_prepare: encoded many times) or an explicit DMI_TILE_SORT take it
     if (env_tile != 0 && !defer && !(g_one_shot_call && env_tile < 0)) for (auto& t : job->tables) {
@@ -907,6 +909,7 @@ int dmi_tile_sort_slots(const uint32_t* sequence_to_point, uint32_t n, uint32_t 
   if ((!sequence_to_point || !slot_point || !slot_entry) && n) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
   dmi_config cfg{};
   if (cfg_in) cfg = *cfg_in;
+  DebugScope debug_scope(cfg.debug);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(DMI_ERR_NO_DEVICE, "no HIP device visible; libdraco_mi has no CPU fallback");
   HIP_TRY(hipSetDevice(cfg.device));

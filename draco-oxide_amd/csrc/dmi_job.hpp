@@ -56,10 +56,10 @@ struct ChunkCache {
   std::mutex m;
   std::vector<Item> items;
   size_t bytes = 0;
-  // what the cache may hold: DMI_DEVICE_CACHE_MB, default = half of the device's memory, at most 64 GiB (read once)
+  // what the cache may hold: dmi_process_options::device_cache_mb, default = half of the device's memory, at most 64 GiB (read once)
   static size_t limit_bytes() {
     static const size_t limit = [] {
-      if (const char* e = std::getenv("DMI_DEVICE_CACHE_MB")) return (size_t)std::max(0l, std::atol(e)) << 20;
+      if (const size_t mb = device_cache_limit_mb()) return mb << 20;
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || !total_b) return (size_t)16 << 30;
       return std::min<size_t>((size_t)64 << 30, total_b / 2);
@@ -223,6 +223,7 @@ namespace dmi { struct EarlyQuant; }   // (below, behind TempDev)
 struct dmi_job {
   dmi_config cfg{};
   std::shared_ptr<EarlyQuant> early;   // (whole-mesh one-shot calls: see EarlyQuant)
+  dmi_debug debug{};                   // the switches of the call that created the job (cfg.debug points here): dmi_job_encode / dmi_jobs_encode work under them
   hipStream_t stream = nullptr;
   std::shared_ptr<StreamHolder> stream_owner;   // set when the library created the stream
   DevPool pool;   // (declared before every DevMem of the job: destroyed after them)

@@ -309,9 +309,6 @@ __device__ __forceinline__ void gather_tile(const QuantAtt& a, const uint32_t (&
   for (int t = 0; t < KT; ++t) {
     const uint32_t i = base + t * kBlock + threadIdx.x;
     v[t] = (a.s2v && i < n) ? a.s2v[d[t]] : p[t];
-#if defined(DMI_ABLATE) && DMI_ABLATE == 6
-    v[t] = i < n ? i : 0u;
-#endif
   }
 #pragma unroll
   for (int t = 0; t < KT; ++t) {
@@ -328,12 +325,6 @@ __device__ __forceinline__ void finish_tile(const QuantAtt& a, const RawTile<N, 
     const uint32_t i = d[t];   // sequence index this slot is written to (= slot unless the pass runs tile-sorted)
     int32_t out[N];
     int nq = N;
-#if defined(DMI_ABLATE) && DMI_ABLATE == 7
-    if (true) {
-      for (int k = 0; k < N; ++k) out[k] = __float_as_int(r.v[t][k]) & 255;
-      if (a.kind == 1) nq = 2;
-    } else
-#endif
     if (a.kind == 0) {   // coordinate-wise (meta: min[N], range)
 #pragma unroll
       for (int k = 0; k < N; ++k) out[k] = quant_coord(r.v[t][k], a.meta[k], a.meta[N], a.maxq);
@@ -370,19 +361,7 @@ __device__ __forceinline__ void quantize_tiles2(const QuantArgs& q, const uint32
 template <int N0, int N1, int N2, int KT>
 __device__ __forceinline__ void quantize_tiles3(const QuantArgs& q, const uint32_t (&p)[KT], const uint32_t (&d)[KT], uint32_t base, uint32_t n, int32_t (&mn)[kMaxGather], int32_t (&mx)[kMaxGather]) {
   RawTile<N0, KT> r0; RawTile<N1, KT> r1; RawTile<N2, KT> r2;
-#if defined(DMI_ABLATE) && DMI_ABLATE == 9
-  if constexpr (N0 == 3 && N1 == 3 && N2 == 2) {   // what ONE 32-byte gather per entry would cost: eight floats from one row of attribute 0's array (wrapped to stay inside it)
-    const uint32_t rows = n * 3u / 8u;
-#pragma unroll
-    for (int t = 0; t < KT; ++t) {
-      const float4* row = reinterpret_cast<const float4*>(q.a[0].raw) + (size_t)(p[t] % rows) * 2;
-      const float4 lo = row[0], hi = row[1];
-      r0.v[t][0] = lo.x; r0.v[t][1] = lo.y; r0.v[t][2] = lo.z; r1.v[t][0] = lo.w + 2.0f; r1.v[t][1] = hi.x; r1.v[t][2] = hi.y; r2.v[t][0] = hi.z; r2.v[t][1] = hi.w;
-    }
-  } else { gather_tile<N0, KT>(q.a[0], p, d, base, n, r0); gather_tile<N1, KT>(q.a[1], p, d, base, n, r1); gather_tile<N2, KT>(q.a[2], p, d, base, n, r2); }
-#else
   gather_tile<N0, KT>(q.a[0], p, d, base, n, r0); gather_tile<N1, KT>(q.a[1], p, d, base, n, r1); gather_tile<N2, KT>(q.a[2], p, d, base, n, r2);
-#endif
   finish_tile<N0, KT>(q.a[0], r0, d, base, n, mn[0], mx[0]); finish_tile<N1, KT>(q.a[1], r1, d, base, n, mn[1], mx[1]); finish_tile<N2, KT>(q.a[2], r2, d, base, n, mn[2], mx[2]);
 }
 template <int KT>
@@ -1337,11 +1316,7 @@ __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const u
         add_edge_cross<PACKED>(R, L, sum);
 #pragma unroll
         for (uint32_t k = 2; k < kFanSlots; ++k) {
-#if defined(DMI_ABLATE) && DMI_ABLATE == 2
-          if (false) {
-#else
           if (k < cnt) {
-#endif
             int32_t W[3];
             ring(k, W);
             W[0] = wsub(W[0], Pc[0]); W[1] = wsub(W[1], Pc[1]); W[2] = wsub(W[2], Pc[2]);
@@ -1364,26 +1339,11 @@ __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const u
       const bool have = both && ro < i;   // (no opposite corner ⇒ ro == NONE ⇒ false)
       if (have) load_pos_fmt(qs_pos, pos_fmt, ro, Po);
       else if (i > 0) load_pos_fmt(qs_pos, pos_fmt, i - 1u, Plast);
-#if defined(DMI_ABLATE) && (DMI_ABLATE == 10 || DMI_ABLATE == 11)
-      {   // what the three 2-byte stores at a 6-byte stride cost: 10 = one dword + one short per entry, 11 = no position symbol stores at all
-        uint32_t sy[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { const int32_t pred = have ? wsub(wadd(Pn[k], Pp[k]), Po[k]) : Plast[k]; sy[k] = wrap_symbol(Pc[k], pred, wp); }
-#if DMI_ABLATE == 10
-        uint8_t* at = static_cast<uint8_t*>(a.sym_pos) + (size_t)i * 6;
-        __builtin_nontemporal_store(sy[0] | (sy[1] << 16), reinterpret_cast<uint32_t*>(at));
-        __builtin_nontemporal_store((uint16_t)sy[2], reinterpret_cast<uint16_t*>(at + 4));
-#else
-        if ((sy[0] ^ sy[1] ^ sy[2]) == 0x7FFFFFFFu) store_sym(a.sym_pos, s16_pos, (size_t)i * 3, sy[0]);
-#endif
-      }
-#else
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int32_t pred = have ? wsub(wadd(Pn[k], Pp[k]), Po[k]) : Plast[k];   // Q15: previously coded vertex, 0 for the first entry
         store_sym(a.sym_pos, s16_pos, (size_t)i * 3 + k, wrap_symbol(Pc[k], pred, wp));
       }
-#endif
     }
     // ---- normals: mesh_normal_prediction.rs:22-44,75-144 + oct_orthogonal.rs (before the texture coordinates: the fan sums die here) ----
     if (HAS_NRM) {
@@ -1398,11 +1358,7 @@ __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const u
       }
       const int32_t n0 = (int32_t)sum0, n1 = (int32_t)sum1, n2 = (int32_t)sum2;
       int32_t p0 = 0, p1 = 0;
-#if defined(DMI_ABLATE) && (DMI_ABLATE == 4 || DMI_ABLATE == 1)
-      p0 = (n0 ^ n2) & 255; p1 = (n1 + n2) & 255;
-#else
       if (!(n0 == 0 && n1 == 0 && n2 == 0)) oct_quantize((float)n0, (float)n1, (float)n2, p0, p1);
-#endif
       int32_t a0, a1;
       if (own_packed) { const uint32_t v = static_cast<const uint16_t*>(a.qs_nrm)[i]; a0 = (int32_t)(v & 0xFFu); a1 = (int32_t)(v >> 8); }
       else { const int32_t* q = static_cast<const int32_t*>(a.qs_nrm) + (size_t)i * 2; a0 = q[0]; a1 = q[1]; }
@@ -1413,11 +1369,7 @@ __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const u
       if (flip) { p0 = m0; p1 = m1; } else ++n_false;
       __builtin_nontemporal_store((uint8_t)(flip ? 1 : 0), &a.flips[i]);
       uint32_t s0, s1;
-#if defined(DMI_ABLATE) && (DMI_ABLATE == 5 || DMI_ABLATE == 1)
-      s0 = (uint32_t)(a0 + p0) & 255u; s1 = (uint32_t)(a1 ^ p1) & 255u;
-#else
       oct_orthogonal(a0, a1, p0, p1, s0, s1);
-#endif
       if (s16_nrm) DMI_SYM_STORE(s0 | (s1 << 16), static_cast<uint32_t*>(a.sym_nrm) + i);
       else { store_sym(a.sym_nrm, false, (size_t)i * 2, s0); store_sym(a.sym_nrm, false, (size_t)i * 2 + 1, s1); }
     }
@@ -1433,13 +1385,9 @@ __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const u
       if (both) {
         int32_t pu[2];
         load_uv(rp, pu);
-#if defined(DMI_ABLATE) && DMI_ABLATE == 3
-        pred0 = pu[0] + Pn[0] - Pp[1]; pred1 = pu[1] + Pc[2]; done = true;
-#else
         const int st = texcoord_try(cu, nu, pu, Pc, Pn, Pp, pred0, pred1, oflag);
         done = st == 1;
         deferred = st == 2;   // operands outside the f64 tier: k_texcoord_fixup predicts this entry with the general form
-#endif
       }
       if (!done) {
         oflag = 0;
@@ -2080,7 +2028,7 @@ void launch_seq_gather_rec(const GatherRecArgs& g, hipStream_t s) {
 // grid of k_seq_quantize (a DMI_FOR_TILES kernel: any grid is correct, this one gives every block work): the steps of a batch are recorded
 // (step sink) and run as the `_multi` launch, two entries per thread
 // (DMI_SEQ_BIG_ENTRIES: the length above which the big form runs — read per call so that the tests can put small meshes through it)
-static uint32_t seq_big_entries() { const char* e = std::getenv("DMI_SEQ_BIG_ENTRIES"); return e ? (uint32_t)std::atoll(e) : kSeqQuantizeBigEntries; }
+static uint32_t seq_big_entries() { return dbg().seq_big_entries ? dbg().seq_big_entries : kSeqQuantizeBigEntries; }
 uint32_t seq_quantize_blocks(uint32_t n) {
   const uint64_t kt = (step_sink_active() || n > seq_big_entries()) ? DMI_KTILE_MULTI : DMI_KTILE_SINGLE;
   return grid_for(((uint64_t)n + kt - 1) / kt, kSeqQuantizeMaxBlocks);
@@ -2118,7 +2066,7 @@ void launch_build_fans_batch(const FanItem* items_dev, uint32_t n_items, uint32_
 }
 
 uint32_t predict_fused_blocks(uint32_t n) {
-  static const uint32_t env_cap = std::getenv("DMI_FUSED_GRID") ? (uint32_t)std::atoi(std::getenv("DMI_FUSED_GRID")) : 0u;   // tuning aid
+  const uint32_t env_cap = dbg().fused_grid;   // tuning aid
   return grid_for(n, env_cap ? std::min(env_cap, kSweepMaxBlocks) : 8192u);   // 2-3 chunks per block: measured best on the 10M workload
 }
 void launch_predict_fused(const FusedArgs& a, hipStream_t s) {
@@ -2126,9 +2074,9 @@ void launch_predict_fused(const FusedArgs& a, hipStream_t s) {
   const uint32_t g = predict_fused_blocks(a.n);
   int id = !a.sym_pos ? K_FUSED_N /* a normal attribute on its own table */ : ((a.qs_nrm && a.qs_uv) ? K_FUSED_PNU : (a.qs_nrm ? K_FUSED_PN : K_FUSED_PU));
   if (a.packed) id += K_PACKED_PNU - K_FUSED_PNU;
-  static const bool windows = std::getenv("DMI_FUSED_WINDOWS") != nullptr;   // LDS-staged neighbourhoods (see k_predict_window_body)
+  const bool windows = dbg_on(DMI_DBG_FUSED_WINDOWS);   // LDS-staged neighbourhoods (see k_predict_window_body)
   if (windows && a.packed && a.sym_pos) id = id == K_PACKED_PNU ? K_WINDOW_PNU : (id == K_PACKED_PN ? K_WINDOW_PN : K_WINDOW_PU);
-  static const uint32_t env_lds = std::getenv("DMI_FUSED_LDS") ? (uint32_t)std::atoi(std::getenv("DMI_FUSED_LDS")) : 0u;   // tuning aid: unused dynamic LDS per block = fewer blocks per CU
+  const uint32_t env_lds = dbg().fused_lds;   // tuning aid: unused dynamic LDS per block = fewer blocks per CU
   emit(id, 4, a, g, env_lds, s);
   if (a.qs_uv && a.sym_pos && id != K_WINDOW_PNU && id != K_WINDOW_PU) emit(K_TEX_FIXUP, 5, a, 64u, 0, s);   // the entries the sweep deferred (usually none: the launch finds count = 0)
 }

@@ -46,7 +46,7 @@ struct DeviceTables {
     // The host's walks read `opposite` as 4·face + k ids when no attribute needs a corner table of its own — every attribute indexed exactly like the
     // Position attribute (the same map array, or none: per-point values) — so that nothing on the host reads the VALUES of the array but the two walks
     // (host_conn.cpp Enc4); the device keeps its own 3·face + k array for its kernels.
-    bool quad = walks_only && F < (1u << 30) && !std::getenv("DMI_NO_QUAD");
+    bool quad = walks_only && F < (1u << 30) && !dbg_on(DMI_DBG_NO_QUAD);
     for (uint32_t i = 1; i < mesh->num_atts && quad; ++i) quad = mesh->atts[i].point_to_value == pos.point_to_value;
     mem.init(device, stream, C * 4 * (mapped ? 5 : 4) + (quad ? C * 4 : 0) + (mapped ? (size_t)P * 4 : 0) + nv * 4 * 4 + nv + C + parts * 4 + ((size_t)1 << 16));
     d_faces = src_faces ? const_cast<uint32_t*>(src_faces) : mem.take<uint32_t>(C);
@@ -145,7 +145,7 @@ extern "C++" int dmi::build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std
   for (uint32_t i = 0; i < mesh->num_atts; ++i)
     if (mesh->atts[i].point_to_value == nullptr && mesh->atts[i].num_unique < mesh->atts[i].num_points) return fail(DMI_ERR_INVALID_ARGUMENT, "attribute " + std::to_string(i) + ": fewer values than points and no point_to_value map");
   std::string err;
-  const bool trace = std::getenv("DMI_TRACE") != nullptr;
+  const bool trace = dbg_on(DMI_DBG_TRACE);
   auto tick = [] { return std::chrono::steady_clock::now(); };
   auto since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
   auto c0 = tick();
@@ -170,7 +170,7 @@ extern "C++" int dmi::build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std
     if (rc) return fail(rc, err);
     // DMI_TEST_QUAD=1 (tests, host only): the walks over 4·face + k ids — what the device stage hands them for meshes none of whose attributes needs
     // a corner table of its own — on a table the HOST built: the bytes must not change
-    if (std::getenv("DMI_TEST_QUAD") && o.ct.opp == o.ct.opp_own.data() && mesh->num_faces < (1u << 30)) {
+    if (dbg_on(DMI_DBG_TEST_QUAD) && o.ct.opp == o.ct.opp_own.data() && mesh->num_faces < (1u << 30)) {
       bool alike = true;
       for (uint32_t i = 1; i < mesh->num_atts && alike; ++i) alike = mesh->atts[i].point_to_value == mesh->atts[0].point_to_value;
       if (alike) {
@@ -233,7 +233,7 @@ extern "C++" int dmi::build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std
     };
     if (maps.size() > 1 && overlap) {
       std::vector<std::thread> th;
-      for (size_t k = 0; k < maps.size(); ++k) th.emplace_back(build_one, k);
+      for (size_t k = 0; k < maps.size(); ++k) th.emplace_back(with_debug(build_one), k);
       for (auto& x : th) x.join();
     } else {
       for (size_t k = 0; k < maps.size(); ++k) build_one(k);
@@ -246,9 +246,9 @@ extern "C++" int dmi::build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std
   EdgebreakerHooks hooks;
   if (overlap) {
     // the sequencer's per-vertex boundary test, ahead of time (beside the start of the traversal)
-    if (!boundary_flags) flag_thread = std::thread([&] { TableRef tr{o.ct.F, o.ct.V, o.ct.c2v, o.ct.opp, o.ct.lmc}; vertex_boundary_flags(tr, on_boundary); });
-    att_thread = std::thread(build_att_tables);
-    hooks.seeds_ready = [&] { if (flag_thread.joinable()) flag_thread.join(); seq_thread = std::thread([&] { const auto q0 = tick(); sequence_universal(); t_seq = since(q0); }); };
+    if (!boundary_flags) flag_thread = std::thread(with_debug([&] { TableRef tr{o.ct.F, o.ct.V, o.ct.c2v, o.ct.opp, o.ct.lmc}; vertex_boundary_flags(tr, on_boundary); }));
+    att_thread = std::thread(with_debug(build_att_tables));
+    hooks.seeds_ready = [&] { if (flag_thread.joinable()) flag_thread.join(); seq_thread = std::thread(with_debug([&] { const auto q0 = tick(); sequence_universal(); t_seq = since(q0); })); };
     hooks.before_seams = [&] { if (att_thread.joinable()) att_thread.join(); };
   } else {
     build_att_tables();
@@ -281,7 +281,7 @@ extern "C++" int dmi::build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std
         const AttTable& t = o.ct.att[i - 1];
         v.num_vertices = t.num_vertices; v.corner_to_vertex = t.c2v.data(); v.opposite = t.opp.data(); v.left_most_corner = t.lmc.data();
         auto walk = [&o, i, &t] { TableRef tr{o.ct.F, t.num_vertices, t.c2v.data(), t.opp.data(), t.lmc.data()}; attribute_sequence(tr, o.eb, o.seqs[i]); };
-        if (overlap) th.emplace_back(walk); else walk();
+        if (overlap) th.emplace_back(with_debug(walk)); else walk();
       } else {
         // a seam-free attribute table is identical to the universal one (same ids, same order)
         universal_view(v);
@@ -334,6 +334,7 @@ int dmi_init(int device, size_t staging_bytes, size_t device_bytes) {
 
 // The device half of the connectivity stage on its own (tests hold it against the host builders; dmi_mesh_prepare uses it internally).
 int dmi_device_corner_table(const dmi_mesh* mesh, const dmi_config* cfg, uint32_t* opposite, uint32_t* left_most_corner, uint8_t* on_boundary, uint32_t* num_vertices, uint32_t* flags) {
+  DebugScope debug_scope(cfg ? cfg->debug : nullptr);
   if (!mesh || !mesh->atts || mesh->num_atts == 0 || (!mesh->faces && mesh->num_faces) || !opposite || !num_vertices || !flags) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(DMI_ERR_NO_DEVICE, "no HIP device visible; libdraco_mi has no CPU fallback");
@@ -359,6 +360,7 @@ int dmi_device_corner_table(const dmi_mesh* mesh, const dmi_config* cfg, uint32_
 // prepare runs for every (mesh, attribute) whose map differs from the position map, exposed so that tests hold it against the host builder.
 int dmi_device_attribute_table(const dmi_mesh* mesh, const dmi_config* cfg, uint32_t att_index, uint8_t* seam_edge, uint32_t* corner_to_vertex, uint32_t* opposite,
                                uint32_t* left_most_corner, uint32_t* num_vertices, uint32_t* interior_seams, uint32_t* flags) {
+  DebugScope debug_scope(cfg ? cfg->debug : nullptr);
   if (!mesh || !mesh->atts || att_index == 0 || att_index >= mesh->num_atts || !mesh->faces || !mesh->num_faces || !seam_edge || !corner_to_vertex || !opposite || !left_most_corner || !num_vertices || !interior_seams || !flags)
     return fail(DMI_ERR_INVALID_ARGUMENT, "bad argument");
   int ndev = 0;
@@ -448,10 +450,11 @@ int dmi_mesh_prepare(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buffer* he
   return mesh_prepare_impl(mesh, cfg, header_and_connectivity, job, nullptr);
 }
 extern "C++" int dmi::mesh_prepare_impl(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buffer* header_and_connectivity, dmi_job** job, const DeviceMeshSrc* src) {
+  DebugScope debug_scope(cfg ? cfg->debug : nullptr);
   if (!header_and_connectivity || !job) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
   g_tables_ms = 0;
   NumaPin pin(cfg ? cfg->device : 0);
-  const bool trace = std::getenv("DMI_TRACE") != nullptr;
+  const bool trace = dbg_on(DMI_DBG_TRACE);
   const auto t0 = std::chrono::steady_clock::now();
   auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
   double t_conn = 0, t_create = 0, t_buf = 0;
@@ -468,7 +471,7 @@ extern "C++" int dmi::mesh_prepare_impl(const dmi_mesh* mesh, const dmi_config* 
     const bool in_batch = (bool)g_adopt_stream;
     int ndev = 0;
     const bool want_device = mesh && mesh->atts && mesh->num_atts && mesh->faces && mesh->atts[0].att_type == DMI_ATT_POSITION &&
-                             (src || (!std::getenv("DMI_HOST_CONNECTIVITY") && mesh->num_faces >= (in_batch ? kDeviceRelabelMinFaces : kDeviceTablesMinFaces))) &&
+                             (src || (!dbg_on(DMI_DBG_HOST_CONNECTIVITY) && mesh->num_faces >= (in_batch ? kDeviceRelabelMinFaces : kDeviceTablesMinFaces))) &&
                              hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0;
     if (want_device) {
       dt.device = cfg ? cfg->device : 0;
@@ -546,11 +549,12 @@ int dmi_host_rabs_constant_stream(uint8_t zero_prob, uint32_t bit, uint64_t n, d
 }
 
 int dmi_encode_mesh(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buffer* out) {
+  DebugScope debug_scope(cfg ? cfg->debug : nullptr);
   if (!out) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
   NumaPin pin(cfg ? cfg->device : 0);   // (also around the encode: the host-core chains read the symbols the staging DMA brought in)
   dmi_buffer head{}, att{};
   dmi_job* job = nullptr;
-  const bool trace = std::getenv("DMI_TRACE") != nullptr;
+  const bool trace = dbg_on(DMI_DBG_TRACE);
   const auto t0 = std::chrono::steady_clock::now();
   auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
   struct OneShot { OneShot() { g_one_shot_call = true; } ~OneShot() { g_one_shot_call = false; } } one_shot;
@@ -578,6 +582,7 @@ int dmi_encode_mesh(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buffer* out
 // are DEVICE pointers on cfg->device.  Faces and maps are read back once (the Edgebreaker traversal and the sequencer are serial host walks),
 // the values never leave the device; the tables are built from the device faces where they are.
 int dmi_encode_mesh_device(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buffer* out) {
+  DebugScope debug_scope(cfg ? cfg->debug : nullptr);
   if (!out || !mesh || !mesh->atts || mesh->num_atts == 0 || mesh->num_atts > 255 || (!mesh->faces && mesh->num_faces)) return fail(DMI_ERR_INVALID_ARGUMENT, "bad mesh");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(DMI_ERR_NO_DEVICE, "no HIP device visible; libdraco_mi has no CPU fallback");
@@ -587,7 +592,7 @@ int dmi_encode_mesh_device(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buff
   auto holder = thread_stream(device);
   if (!holder) return fail(DMI_ERR_HIP, "hipStreamCreate");
   hipStream_t s = cfg && cfg->stream ? static_cast<hipStream_t>(cfg->stream) : holder->s;
-  const bool trace = std::getenv("DMI_TRACE") != nullptr;
+  const bool trace = dbg_on(DMI_DBG_TRACE);
   const auto t0 = std::chrono::steady_clock::now();
   auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
   // host shadow: faces and the distinct maps in one pinned read-back (huge pages: the walks read the faces from there)

@@ -9,10 +9,12 @@ extern "C" {
 
 static int meshes_prepare_impl(const dmi_mesh* meshes, uint32_t n, const dmi_config* cfg, const int32_t* device_of_mesh, dmi_buffer* header_and_connectivity, dmi_job** jobs);
 int dmi_meshes_prepare(const dmi_mesh* meshes, uint32_t n, const dmi_config* cfg, dmi_buffer* header_and_connectivity, dmi_job** jobs) {
+  DebugScope debug_scope(cfg ? cfg->debug : nullptr);
   return meshes_prepare_impl(meshes, n, cfg, nullptr, header_and_connectivity, jobs);
 }
 // One process, several GPUs: mesh j is prepared on HIP device device_of_mesh[j] (dmi_shard_meshes deals them by triangle count).
 int dmi_meshes_prepare_devices(const dmi_mesh* meshes, uint32_t n, const dmi_config* cfg, const int32_t* device_of_mesh, dmi_buffer* header_and_connectivity, dmi_job** jobs) {
+  DebugScope debug_scope(cfg ? cfg->debug : nullptr);
   if (!device_of_mesh) return fail(DMI_ERR_INVALID_ARGUMENT, "device_of_mesh is null");
   if (cfg && cfg->stream) return fail(DMI_ERR_INVALID_ARGUMENT, "a caller stream belongs to one device: leave dmi_config.stream null for a multi-device batch");
   const int ndev = dmi_device_count();
@@ -94,7 +96,7 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
                                 const std::vector<AdoptedGroup>* adopt = nullptr) {
   const uint32_t M = (uint32_t)which_all.size();
   if (!M) return DMI_OK;
-  const bool trace = std::getenv("DMI_TRACE") != nullptr;
+  const bool trace = dbg_on(DMI_DBG_TRACE);
   const auto t0 = std::chrono::steady_clock::now();
   auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
   HIP_TRY(hipSetDevice(device));
@@ -104,7 +106,7 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
   hipStream_t S = holder->s;   // the coordinator's stream: job chunks are cleared on it, the deferred kernels of all jobs run on it
   struct SyncOnExit { hipStream_t s; ~SyncOnExit() { (void)hipStreamSynchronize(s); } } sync_on_exit{S};   // (also on error paths: a job the caller then destroys must not have its chunk cleared late)
   // ---- groups of ≈ 8M faces: the tables of the first arrive while the last is still being sent ----
-  static const uint64_t group_faces = std::getenv("DMI_PREP_GROUP_FACES") ? (uint64_t)std::atoll(std::getenv("DMI_PREP_GROUP_FACES")) : (uint64_t)(3u << 20);   // (measured, 256 meshes / 11M faces: 6M 21.5–22 ms, 3M 19.4–20.4, 1.5M 22.6–23.1)
+  const uint64_t group_faces = dbg().prep_group_faces ? dbg().prep_group_faces : (uint64_t)(3u << 20);   // (measured, 256 meshes / 11M faces: 6M 21.5–22 ms, 3M 19.4–20.4, 1.5M 22.6–23.1)
   std::vector<std::unique_ptr<PrepGroup>> groups;
   std::vector<std::pair<uint32_t, uint32_t>> where(M);   // position in which_all → (group, index within the group)
   if (adopt) {
@@ -170,7 +172,7 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
       for (uint32_t i; (i = next.fetch_add(1)) < count;) { const int rc = fn(t, order[i]); if (rc) { rcs[t] = rc; errs[t] = g_last_error; next.store(count); return; } }
     };
     if (nt == 1) work(0);
-    else { std::vector<std::thread> th; for (uint32_t t = 0; t < nt; ++t) th.emplace_back(work, t); for (auto& x : th) x.join(); }
+    else { std::vector<std::thread> th; for (uint32_t t = 0; t < nt; ++t) th.emplace_back(with_debug(work), t); for (auto& x : th) x.join(); }
     for (uint32_t t = 0; t < nt; ++t) if (rcs[t]) return fail(rcs[t], errs[t]);
     return DMI_OK;
   };
@@ -246,7 +248,7 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     g_adopt_stream = worker_stream(t % kPrepareStreams, device);   // the job's own stream for its encodes
     struct Drop { ~Drop() { g_adopt_stream.reset(); } } drop;
     // (a mesh with attribute tables of its own — interior seams — is deferred like the others: its seam tables go up with the sequences)
-    static const bool defer_seams = !std::getenv("DMI_NO_DEFER_SEAMS");
+    const bool defer_seams = !dbg_on(DMI_DBG_NO_DEFER_SEAMS);
     bool all_universal = true;
     for (uint32_t a = 1; a < m.num_atts; ++a) all_universal = all_universal && o.views[a].corner_to_vertex == o.views[0].corner_to_vertex && o.views[a].opposite == o.views[0].opposite;
     if (all_universal || defer_seams) {
@@ -324,7 +326,7 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
       g.rb_opp = bg.conn.rb_opp; g.rb_c2v = bg.conn.rb_c2v; g.rb_lmc = bg.conn.rb_lmc; g.rb_onb = bg.conn.rb_onb; g.rb_words = bg.conn.rb_words;
       g.ev_tables_borrowed = bg.conn.ev;
       g.issued.store(1, std::memory_order_release);
-      if (!walkers.joinable() && M > 1) walkers = std::thread([&] { rc_walk = parallel_over(M, walk_one, nullptr); if (rc_walk) err_walk = g_last_error; });
+      if (!walkers.joinable() && M > 1) walkers = std::thread(with_debug([&] { rc_walk = parallel_over(M, walk_one, nullptr); if (rc_walk) err_walk = g_last_error; }));
       continue;
     }
     g.n_desc = Mg;
@@ -365,7 +367,7 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     }
     // attribute corner tables on the device for the attributes whose maps are not the position map entry for entry
     {
-      static const bool host_att = std::getenv("DMI_HOST_ATT_TABLES") != nullptr;
+      const bool host_att = dbg_on(DMI_DBG_HOST_ATT_TABLES);
       for (uint32_t k = 0; k < Mg && !host_att; ++k) {
         const dmi_mesh& m = meshes[g.which[k]];
         if (!m.num_faces) continue;
@@ -448,7 +450,7 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     // wait for this group's tables (walk_one): phase 1 — what every walker waits for — packs faces and maps only
     HIP_TRY(hipEventCreateWithFlags(&g.ev_values, hipEventDisableTiming));
     g.issued.store(1, std::memory_order_release);
-    if (!walkers.joinable() && M > 1) walkers = std::thread([&] { rc_walk = parallel_over(M, walk_one, nullptr); if (rc_walk) err_walk = g_last_error; });
+    if (!walkers.joinable() && M > 1) walkers = std::thread(with_debug([&] { rc_walk = parallel_over(M, walk_one, nullptr); if (rc_walk) err_walk = g_last_error; }));
   }
   const double t_issue = ms();
   if (walkers.joinable()) { walkers.join(); rc = rc_walk; if (rc) fail(rc, err_walk); }
@@ -594,10 +596,10 @@ static int meshes_prepare_impl(const dmi_mesh* meshes, uint32_t n, const dmi_con
   // device form first (prepare_slice_device): the eligible meshes of every device in slices of ≤ 64M faces; whatever it leaves goes mesh by mesh below
   std::vector<uint8_t> done(n, 0);
   int ndev = 0;
-  if (!std::getenv("DMI_HOST_CONNECTIVITY") && hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) {
+  if (!dbg_on(DMI_DBG_HOST_CONNECTIVITY) && hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) {
     std::vector<int> devices;
     for (uint32_t j = 0; j < n; ++j) { const int d = device_of_mesh ? device_of_mesh[j] : (cfg ? cfg->device : 0); if (std::find(devices.begin(), devices.end(), d) == devices.end()) devices.push_back(d); }
-    const uint32_t min_faces = std::getenv("DMI_BATCH_MIN_FACES") ? (uint32_t)std::atoi(std::getenv("DMI_BATCH_MIN_FACES")) : 1u;
+    const uint32_t min_faces = dbg().batch_min_faces ? (uint32_t)dbg().batch_min_faces : 1u;
     auto eligible = [&](const dmi_mesh& m) {
       if (!m.atts || m.num_atts == 0 || m.num_atts > 255 || !m.faces || m.num_faces < min_faces || m.num_faces >= kDeviceRelabelMinFaces) return false;
       if (m.atts[0].att_type != DMI_ATT_POSITION || m.atts[0].num_unique == 0 || m.atts[0].num_points == 0) return false;
@@ -629,7 +631,7 @@ static int meshes_prepare_impl(const dmi_mesh* meshes, uint32_t n, const dmi_con
       if (dev_rc[g]) dev_err[g] = g_last_error;
     };
     if (devices.size() == 1) run_device(0);
-    else { std::vector<std::thread> th; for (size_t g = 0; g < devices.size(); ++g) th.emplace_back(run_device, g); for (auto& x : th) x.join(); }
+    else { std::vector<std::thread> th; for (size_t g = 0; g < devices.size(); ++g) th.emplace_back(with_debug(run_device), g); for (auto& x : th) x.join(); }
     for (size_t g = 0; g < devices.size(); ++g)
       if (dev_rc[g]) {
         for (uint32_t k = 0; k < n; ++k) { if (jobs[k]) { dmi_job_destroy(jobs[k]); jobs[k] = nullptr; } dmi_free(&header_and_connectivity[k]); }
@@ -661,7 +663,7 @@ static int meshes_prepare_impl(const dmi_mesh* meshes, uint32_t n, const dmi_con
   else if (n_threads == 1) work(0);
   else {
     std::vector<std::thread> th;
-    for (uint32_t t = 0; t < n_threads; ++t) th.emplace_back(work, t);
+    for (uint32_t t = 0; t < n_threads; ++t) th.emplace_back(with_debug(work), t);
     for (auto& x : th) x.join();
   }
   for (uint32_t j = 0; j < n; ++j) {
@@ -703,6 +705,7 @@ static int prepare_built_single(const dmi_mesh& view, const BuiltDevice& bd, con
 }
 
 int dmi_built_meshes_prepare(const dmi_built_mesh* built, uint32_t n, const dmi_config* cfg, dmi_buffer* header_and_connectivity, dmi_job** jobs) {
+  DebugScope debug_scope(cfg ? cfg->debug : nullptr);
   if (!built || !header_and_connectivity || !jobs || n == 0) return fail(DMI_ERR_INVALID_ARGUMENT, "null");
   for (uint32_t j = 0; j < n; ++j) { jobs[j] = nullptr; header_and_connectivity[j] = dmi_buffer{}; }
   int ndev = 0;
@@ -761,7 +764,7 @@ int dmi_built_meshes_prepare(const dmi_built_mesh* built, uint32_t n, const dmi_
     bool large = false;
     uint64_t verts = 0;
     for (const auto& mem : bg->members) { large = large || mem.F >= kDeviceRelabelMinFaces; verts += mem.atts.empty() ? 0u : mem.atts[0].n_unique; }
-    if (large || std::getenv("DMI_HOST_CONNECTIVITY")) { for (int32_t j : ag.present) if (j >= 0) singles.push_back((uint32_t)j); continue; }
+    if (large || dbg_on(DMI_DBG_HOST_CONNECTIVITY)) { for (int32_t j : ag.present) if (j >= 0) singles.push_back((uint32_t)j); continue; }
     if (!slice.empty() && (slice_device != bg->device || slice_faces + bg->total_faces > (64u << 20) || slice_verts + verts >= (1u << 30)) && (rc = flush())) return bail(rc);
     slice_device = bg->device;
     for (int32_t j : ag.present) if (j >= 0) slice_which.push_back((uint32_t)j);
@@ -788,7 +791,7 @@ int dmi_built_meshes_prepare(const dmi_built_mesh* built, uint32_t n, const dmi_
       }
     };
     if (nt == 1) work(0);
-    else { std::vector<std::thread> th; for (uint32_t t = 0; t < nt; ++t) th.emplace_back(work, t); for (auto& x : th) x.join(); }
+    else { std::vector<std::thread> th; for (uint32_t t = 0; t < nt; ++t) th.emplace_back(with_debug(work), t); for (auto& x : th) x.join(); }
     for (size_t k = 0; k < singles.size(); ++k) if (rcs[k]) { g_last_error = errs[k]; return bail(rcs[k]); }
   }
   return DMI_OK;

@@ -97,7 +97,7 @@ int dmi::built_group_issue_tables(BuiltGroup& bg, hipStream_t s) {
   // candidates for an attribute table of their own: non-position attributes whose map is not the position map entry for entry
   AttStage& st = cn.att;
   st = AttStage{};
-  static const bool host_att = std::getenv("DMI_HOST_ATT_TABLES") != nullptr;
+  const bool host_att = dbg_on(DMI_DBG_HOST_ATT_TABLES);
   // (the map comparisons of all members side by side: two full-length memcmp per mesh with normals and texture coordinates — 90 MB for a 256-mesh stage —
   //  were 9 of a seam stage's 29 ms of build on the one thread that issues its tables)
   struct Pair { uint32_t mi; size_t a; };
@@ -119,7 +119,7 @@ int dmi::built_group_issue_tables(BuiltGroup& bg, hipStream_t s) {
     };
     const size_t n_threads = std::min<size_t>({pairs.size(), (size_t)host_threads(), (size_t)16});
     std::vector<std::thread> th;
-    for (size_t t = 1; t < n_threads; ++t) th.emplace_back(work);
+    for (size_t t = 1; t < n_threads; ++t) th.emplace_back(with_debug(work));
     work();
     for (auto& x : th) x.join();
   }

@@ -31,8 +31,7 @@ struct NumaPin {
   cpu_set_t old;
   bool active = false;
   explicit NumaPin(int device) {
-    static const bool off = std::getenv("DMI_NO_NUMA_PIN") != nullptr;
-    if (off) return;
+    if (!(process_flags() & DMI_PROCESS_NUMA_PIN)) return;   // (opt-in since round 6: dmi_configure_process)
     const int node = device_numa_node(device);
     if (node < 0) return;
     cpu_set_t want;

@@ -64,6 +64,7 @@ struct Slot {
 
 struct dmi_transcoder {
   dmi_config cfg{};
+  dmi_debug debug{};                   // the switches of the call that created it (cfg.debug points here: every stage call of its threads opens its scope with them)
   uint64_t stage_triangles = 0;
   dmi_transcode_done_fn done = nullptr;
   void* user = nullptr;
@@ -73,6 +74,7 @@ struct dmi_transcoder {
   std::vector<dmi_raw_mesh> prims;
   uint32_t dispatched = 0;             // primitives already handed to the build step
   uint32_t stages = 0;                 // stages dispatched so far
+  uint32_t stage_primitives = 0;       // 0 = no cap on the primitives of a stage
   uint64_t pending_triangles = 0;
   bool first_stage = true;
   // results, by primitive
@@ -88,7 +90,7 @@ struct dmi_transcoder {
   std::string err;
   double ms_build = 0, ms_prepare = 0, ms_encode = 0;
   uint64_t n_device = 0, n_host = 0, n_in_place = 0;   // primitives built by the kernels / by the host builder / of the former: copied up where they lay
-  const bool trace = std::getenv("DMI_TRACE") != nullptr || std::getenv("DMI_TRACE_STAGES") != nullptr;   // (DMI_TRACE_STAGES: only the stage lines below — the full trace prints a line per mesh)
+  bool trace = false;   // (DMI_DBG_TRACE_STAGES: only the stage lines below — the full trace prints a line per mesh)
   const double t_create = now_ms();
   void note(const char* step, const Stage& s, double t0) const { if (trace) std::fprintf(stderr, "[dmi] transcoder %-8s stage@%-5u (%4u primitives) %7.1f -> %7.1f ms\n", step, s.first, s.count, t0 - t_create, now_ms() - t_create); }
   bool started = false, finished = false;
@@ -187,7 +189,10 @@ struct dmi_transcoder {
     // (the first stage runs alone: the sooner it is through, the sooner the steps overlap.  Small LAST stages — half of what is expected to be left,
     // down to a third of a stage — were tried against the tail of the call: no gain beyond the noise, 105–110 against 95–105 ms per 1024 files)
     const uint64_t want = first_stage ? std::max<uint64_t>(1, stage_triangles / 3) : stage_triangles;
-    if (dispatched == prims.size() || (!flush && pending_triangles < want)) return;
+    // (… or stage_primitives of them: with the files taken largest first the last stage of a long list would otherwise hold most of its primitives —
+    //  695 of 1024 — and its build, prepare and encode, which nothing overlaps, pay per primitive)
+    const bool many = stage_primitives && prims.size() - dispatched >= stage_primitives;
+    if (dispatched == prims.size() || (!flush && pending_triangles < want && !many)) return;
     std::unique_ptr<Stage> s(new Stage());
     s->first = dispatched; s->count = (uint32_t)prims.size() - dispatched;
     s->raw.assign(prims.begin() + dispatched, prims.end());
@@ -204,7 +209,12 @@ extern "C" {
 
 dmi_transcoder* dmi_transcoder_create(const dmi_config* cfg, uint64_t expected_triangles, uint64_t stage_triangles, dmi_transcode_done_fn done, void* user) {
   std::unique_ptr<dmi_transcoder> t(new dmi_transcoder());
+  DebugScope scope(cfg ? cfg->debug : nullptr);
   if (cfg) t->cfg = *cfg;
+  t->debug = dbg();
+  t->cfg.debug = &t->debug;
+  t->trace = dbg_on(DMI_DBG_TRACE | DMI_DBG_TRACE_STAGES);
+  t->stage_primitives = dbg().stage_primitives;
   // about four stages (enough to overlap the steps), between 3M and 12M triangles: a stage pays fixed costs (the chain launch of its encode is bounded
   // by its longest stream, ≈ 5 ms) and one above ≈ 16M stops overlapping (measured with the Python driver: DESIGN §6b)
   t->stage_triangles = stage_triangles ? stage_triangles : std::min<uint64_t>((uint64_t)12 << 20, std::max<uint64_t>((uint64_t)3 << 20, expected_triangles / 4));

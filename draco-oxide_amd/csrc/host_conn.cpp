@@ -102,8 +102,8 @@ struct Walker {
 
   explicit Walker(const CornerTables& tt) : t(tt), C(tt.F * 3), quad(tt.quad) {
     pool_fit(vvis, t.V); vvis.assign(t.V, 0);
-    static const bool no_shadow = std::getenv("DMI_NO_SHADOW") != nullptr;
-    static const uint32_t min_faces = std::getenv("DMI_SHADOW_MIN_FACES") ? (uint32_t)std::atol(std::getenv("DMI_SHADOW_MIN_FACES")) : (1u << 16);   // (256-mesh batch: traversal thread time 71 → 68 ms with the meshes of ≥ 2^16 faces on stamps; below, tables and flags sit in L2)
+    const bool no_shadow = dbg_on(DMI_DBG_NO_SHADOW);
+    const uint32_t min_faces = dbg().shadow_min_faces ? dbg().shadow_min_faces : (1u << 16);   // (256-mesh batch: traversal thread time 71 → 68 ms with the meshes of ≥ 2^16 faces on stamps; below, tables and flags sit in L2)
     use_stamp = t.F >= min_faces && t.F < 0x7FFFFFF0u && !no_shadow;
     if (use_stamp) { pool_fit(stamp, t.F); stamp.assign(t.F, 0u); }
     else { pool_fit(fvis, t.F); fvis.assign(t.F, 0); }
@@ -169,7 +169,7 @@ struct Walker {
   // c3: the corner to start from, a 3·face + k id
   void run_from(uint32_t c3) {
     // (kClosed: every corner has an opposite — the device stage reports it — so the loop tests no entry for "none")
-    static const bool no_closed = std::getenv("DMI_NO_CLOSED") != nullptr;
+    const bool no_closed = dbg_on(DMI_DBG_NO_CLOSED);
     const bool closed = t.no_boundary && !no_closed;
     if (quad) {
       if (use_stamp) { if (closed) run_from_t<true, Enc4, true>(Enc4::from3(c3)); else run_from_t<true, Enc4, false>(Enc4::from3(c3)); }
@@ -305,9 +305,9 @@ uint8_t zero_probability(uint64_t count_zero, float denominator) {
 
 std::atomic<uint64_t> g_eb_ns[6];   // trace: thread time of run_edgebreaker by step over all meshes (set-up, traversal, bits, seam streams, count)
 int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& err, const EdgebreakerHooks* hooks) {
-  const bool trace_all = std::getenv("DMI_TRACE") != nullptr;
+  const bool trace_all = dbg_on(DMI_DBG_TRACE);
   struct Whole { bool on; std::chrono::steady_clock::time_point a = std::chrono::steady_clock::now(); ~Whole() { if (on) g_eb_ns[5] += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - a).count(); } } whole{trace_all};   // (declared first: its destructor runs after every other local's)
-  const bool trace = t.F > 100000 && std::getenv("DMI_TRACE") != nullptr;
+  const bool trace = t.F > 100000 && dbg_on(DMI_DBG_TRACE);
   auto tick = [] { return std::chrono::steady_clock::now(); };
   auto since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
   const auto t0 = tick();
@@ -437,7 +437,7 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
     // traversal left in its symbols (bits 4–6: the edges towards faces processed earlier) are the edges the reference's walk from the back emits
     uint64_t interior_starts = 0;
     for (uint8_t b : w.start_interior) interior_starts += b;
-    const bool masks_ok = n + interior_starts == t.F && w.symbols.size() == n && !std::getenv("DMI_NO_SEAM_MASKS");
+    const bool masks_ok = n + interior_starts == t.F && w.symbols.size() == n && !dbg_on(DMI_DBG_NO_SEAM_MASKS);
     Pooled<uint32_t> where_p;                          // position of a face in `processed`
     std::vector<uint32_t>& where = where_p.v;
     std::atomic<int> twice{0};
@@ -571,7 +571,7 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
     if (need_zero) todo.push_back(A);
     if (todo.size() > 1 && n >= (1u << 20) && host_threads() > 1) {
       std::vector<std::thread> th;
-      for (size_t j : todo) th.emplace_back(code_one, j);
+      for (size_t j : todo) th.emplace_back(with_debug(code_one), j);
       for (auto& x : th) x.join();
     } else for (size_t j : todo) code_one(j);
     for (size_t j = 0; j < A; ++j) {
@@ -701,11 +701,11 @@ static void sequence_impl(const TableRef& t, const uint32_t* first, uint32_t n_f
 }
 void attribute_sequence(const TableRef& t, const uint32_t* first, uint32_t n_first, const uint32_t* second, uint32_t n_second, std::vector<uint32_t>& seq, const uint8_t* on_boundary,
                         bool second_quad) {
-  static const bool no_shadow = std::getenv("DMI_NO_SHADOW") != nullptr || std::getenv("DMI_NO_SEQ_SHADOW") != nullptr;
+  const bool no_shadow = dbg_on(DMI_DBG_NO_SHADOW | DMI_DBG_NO_SEQ_SHADOW);
   const bool stamps = t.F >= (1u << 16) && t.V < 0x7FFFFFF0u && !no_shadow;
   // (closed: every corner has an opposite — the walk then tests no entry for "none" and no vertex for "on a boundary")
 #define DMI_SEQ(S, E, C) sequence_impl<S, E, C>(t, first, n_first, second, n_second, second_quad, seq, on_boundary)
-  static const bool no_closed = std::getenv("DMI_NO_CLOSED") != nullptr;
+  const bool no_closed = dbg_on(DMI_DBG_NO_CLOSED);
   const bool closed = t.closed && !no_closed;
   if (t.quad) {
     if (stamps) { if (closed) DMI_SEQ(true, Enc4, true); else DMI_SEQ(true, Enc4, false); }

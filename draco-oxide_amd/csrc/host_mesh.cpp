@@ -198,7 +198,7 @@ extern "C" {
 int dmi_mesh_build(const dmi_raw_attribute* in, uint32_t n_atts, const uint32_t* faces_in, uint32_t num_faces, dmi_built_mesh* out) {
   if (!out || (!in && n_atts) || (!faces_in && num_faces)) return host_fail(DMI_ERR_INVALID_ARGUMENT, "null");
   std::unique_ptr<BuiltOwner> o(new BuiltOwner());
-  const bool trace = std::getenv("DMI_BUILD_TRACE") != nullptr;
+  const bool trace = dbg_on(DMI_DBG_BUILD_TRACE);
   auto t0 = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) { if (!trace) return; const auto t1 = std::chrono::steady_clock::now(); std::fprintf(stderr, "[dmi_mesh_build] %-10s %.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count()); t0 = t1; };
   o->atts.resize(n_atts);

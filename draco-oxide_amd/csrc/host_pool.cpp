@@ -9,14 +9,41 @@
 
 namespace dmi {
 WalkSlots& walk_slots() { static WalkSlots w; return w; }
+
+// ---- the switches of the call a thread is working for, the process's defaults and options (round 6: typed, no environment reads) ----
+namespace {
+dmi_debug g_default_debug{};                        // dmi_set_default_debug
+std::atomic<uint32_t> g_process_flags{0};           // dmi_configure_process
+std::atomic<size_t> g_host_cache_mb{4096}, g_device_cache_mb{0}, g_decode_budget_mb{16384};
+thread_local const dmi_debug* tl_debug = nullptr;
+}  // namespace
+const dmi_debug* dbg_ptr() { return tl_debug ? tl_debug : &g_default_debug; }
+DebugScope::DebugScope(const dmi_debug* d) : prev(tl_debug) { if (d) tl_debug = d; }
+DebugScope::~DebugScope() { tl_debug = prev; }
+uint32_t process_flags() { return g_process_flags.load(std::memory_order_relaxed); }
+size_t decode_budget_bytes() { return g_decode_budget_mb.load() << 20; }
+size_t device_cache_limit_mb() { return g_device_cache_mb.load(); }
 }  // namespace dmi
+
+extern "C" {
+void dmi_set_default_debug(const dmi_debug* d) { dmi::g_default_debug = d ? *d : dmi_debug{}; }
+int dmi_configure_process(const dmi_process_options* o) {
+  if (!o) return dmi::host_fail(DMI_ERR_INVALID_ARGUMENT, "null");
+  dmi::g_process_flags.store(o->flags);
+  dmi::g_host_cache_mb.store(o->host_cache_mb ? o->host_cache_mb : 4096);
+  dmi::g_device_cache_mb.store(o->device_cache_mb);
+  dmi::g_decode_budget_mb.store(o->decode_budget_mb ? o->decode_budget_mb : 16384);
+  return DMI_OK;
+}
+}
 
 // Large heap arrays of THIS library (every std::vector of index / flag arrays: hidden visibility — no other module's allocations come here) start
 // on a 2 MiB boundary and end on one, and ask for transparent huge pages as a whole.  malloc hands a 5 MB flag array out 16 bytes into its
 // mapping: the 2 MiB-aligned interior that advise_huge_pages can flag leaves its first and last megabytes on 4 KiB pages, and the serial walks
 // (one flag byte per step, a mesh row apart: a new page every step) then miss the TLB on 20–40 % of their flag accesses — the 10M-face
 // traversal on the GPU box's EPYC: 64 ms against 48 ms with every array on huge pages.  Memory comes from posix_memalign: released by the
-// default operator delete (free).  DMI_NO_THP=1: plain malloc.
+// default operator delete (free).  OPT-IN since round 6 (dmi_configure_process, DMI_PROCESS_HUGE_PAGE_NEW): without it this operator new is the
+// standard one (malloc or std::bad_alloc) — a drop-in library does not change how its host process allocates unless asked.
 #if defined(__has_feature)
 #if __has_feature(address_sanitizer)
 #define DMI_NO_OPERATOR_NEW 1      // (the sanitizer build keeps the runtime's allocator: it pairs operator new with operator delete)
@@ -28,8 +55,8 @@ WalkSlots& walk_slots() { static WalkSlots w; return w; }
 #ifndef DMI_NO_OPERATOR_NEW
 void* operator new(std::size_t n) {   // (local to the library: libdraco_mi.map)
   constexpr std::size_t kHuge = (std::size_t)2 << 20;
-  static const bool off = std::getenv("DMI_NO_THP") != nullptr;
-  if (n >= kHuge && !off) {
+  const uint32_t pf = dmi::process_flags();
+  if (n >= kHuge && (pf & DMI_PROCESS_HUGE_PAGE_NEW) && !(pf & DMI_PROCESS_NO_THP)) {
     const std::size_t want = (n + kHuge - 1) & ~(kHuge - 1);
     void* p = nullptr;
     if (want >= n && posix_memalign(&p, kHuge, want) == 0 && p) { (void)madvise(p, want, MADV_HUGEPAGE); return p; }
@@ -42,20 +69,13 @@ void* operator new[](std::size_t n) { return ::operator new(n); }
 
 namespace dmi {
 void advise_huge_pages(void* p, size_t bytes) {
-  static const bool off = std::getenv("DMI_NO_THP") != nullptr;
-  if (off || !p) return;
+  if ((process_flags() & DMI_PROCESS_NO_THP) || !p) return;
   constexpr uintptr_t kHuge = (uintptr_t)2 << 20;
   const uintptr_t lo = ((uintptr_t)p + kHuge - 1) & ~(kHuge - 1), hi = ((uintptr_t)p + bytes) & ~(kHuge - 1);
   if (hi > lo) (void)madvise(reinterpret_cast<void*>(lo), hi - lo, MADV_HUGEPAGE);
 }
 
-size_t host_pool_limit() {
-  static const size_t limit = [] {
-    const char* e = std::getenv("DMI_HOST_CACHE_MB");
-    return (size_t)(e ? std::max(0l, std::atol(e)) : 4096l) << 20;
-  }();
-  return limit;
-}
+size_t host_pool_limit() { return g_host_cache_mb.load() << 20; }
 std::atomic<size_t>& host_pool_bytes() { static std::atomic<size_t> b{0}; return b; }
 void host_pool_drop_all() { VecPool<uint8_t>::get().drop_all(); VecPool<uint32_t>::get().drop_all(); VecPool<uint64_t>::get().drop_all(); }
 

@@ -261,7 +261,7 @@ struct UniversalBuilder {
 int CornerTables::build_universal(const uint32_t* faces, uint32_t num_faces, const uint32_t* pos_p2v, std::string& err, bool copy_faces) {
   F = num_faces;
   const uint32_t C = 3 * F;
-  static const bool trace = std::getenv("DMI_TRACE_TABLES") != nullptr;
+  const bool trace = dbg_on(DMI_DBG_TRACE_TABLES);
   const auto t0 = std::chrono::steady_clock::now();
   auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
   if (copy_faces) { pool_fit(c2p_own, C); c2p_own.resize(C); parallel_for(C, [&](size_t lo, size_t hi) { std::copy(faces + lo, faces + hi, c2p_own.data() + lo); }); c2p = c2p_own.data(); }
@@ -287,10 +287,10 @@ int CornerTables::build_universal(const uint32_t* faces, uint32_t num_faces, con
   }
   const double t_ids = ms();
   UniversalBuilder b(*this);
-  const bool serial_only = std::getenv("DMI_SERIAL_TABLES") != nullptr;   // (tests: the literal serial walks on every input)
+  const bool serial_only = dbg_on(DMI_DBG_SERIAL_TABLES);   // (tests: the literal serial walks on every input)
   // (the order-independent builders do more work per corner — atomics, two bucket scans — and only win once their loops really run on
   //  several threads, which parallel_for does from 2^20 items; below that, and in a batch of meshes on a thread each, the serial walks)
-  const bool big = (C >= (1u << 21) || std::getenv("DMI_PARALLEL_TABLES")) && !serial_only;
+  const bool big = (C >= (1u << 21) || dbg_on(DMI_DBG_PARALLEL_TABLES)) && !serial_only;
   const bool matched = serial_only ? false : (big ? b.match_half_edges_parallel<true>() : b.match_half_edges_parallel<false>());
   if (!matched) {
     b.match_half_edges();

@@ -79,6 +79,57 @@ typedef struct dmi_corner_table {
   uint32_t sequence_len;
 } dmi_corner_table;
 
+/* Path-selecting and tuning switches — the typed form (round 6) of what were ≈ 50 environment variables read all over the library.  NONE changes the
+ * bitstream: each selects another implementation of the same stage (the tests run every form against the oracle) or sizes a heuristic.  Hung off
+ * dmi_config: read once per call, kept per job — two concurrent calls may differ.  The library itself never reads the environment for these: a caller
+ * that wants `DMI_NO_FUSED=1 ./app` behaviour fills the struct from its own environment (draco-oxide_amd/binding.py does, per call, for tests / bench).
+ * The reference's nested Config (encode/mod.rs:22-42, attribute_encoder.rs:113-136, portabilization/mod.rs:111-143) carries its own choices the same
+ * way: as typed fields of the value handed to encode(). */
+typedef struct dmi_debug {
+  uint64_t flags;             /* DMI_DBG_* */
+  uint32_t host_threads;      /* host threads a call may keep busy (0 = the machine's, no more than the cgroup quota) */
+  int32_t  tile_sort;         /* quantize gather of resident jobs: 0 default (sorted tiles for large resident jobs), -1 off, > 0 tile entries */
+  uint32_t tile_sort_min, tile_sort_local;   /* 0 = defaults: sequence length the sort starts at / entries one workgroup sorts in LDS */
+  uint32_t seq_big_entries;   /* 0 = default: sequence length from which k_seq_quantize_big runs */
+  uint8_t  relabel;           /* coding-order relabelling: 0 by size, 1 device, 2 host */
+  uint8_t  chains;            /* serial coders of a single job: 0 by the longest stream, 1 device walker, 2 host cores */
+  uint8_t  pad0, pad1;
+  uint32_t fused_grid, fused_lds, chain_grid;   /* tuning aids of the sweep / chain launches (0 = defaults) */
+  uint32_t batch_threads, split;                /* batch encode: worker threads, sub-batches (0 = defaults) */
+  uint32_t shadow_min_faces;                    /* host walks: faces from which the shadow prefetch runs (0 = default) */
+  uint64_t prep_group_faces, batch_min_faces;   /* batch prepare: faces per device group, smallest mesh that takes the device tables (0 = defaults) */
+  uint32_t stage_primitives, pad2;              /* transcoder: a stage is dispatched at this many primitives even below its triangle count (0 = no cap) */
+} dmi_debug;
+#define DMI_DBG_NO_FUSED          (1ull << 0)    /* per-attribute predictor kernels instead of the fused sweep */
+#define DMI_DBG_NO_PACKED         (1ull << 1)    /* int32 quantized values instead of the sweep's packed layouts */
+#define DMI_DBG_NO_SYM16          (1ull << 2)    /* uint32 symbols */
+#define DMI_DBG_NO_EARLY          (1ull << 3)    /* no early stage in whole-mesh calls */
+#define DMI_DBG_NO_PLAIN_ORDER    (1ull << 4)    /* one-shot jobs re-order their faces like resident ones */
+#define DMI_DBG_HOST_TABLES       (1ull << 5)    /* frequency tables normalised on the host */
+#define DMI_DBG_HOST_CONNECTIVITY (1ull << 6)    /* corner tables by the host builder */
+#define DMI_DBG_HOST_ATT_TABLES   (1ull << 7)    /* attribute corner tables by the host builder */
+#define DMI_DBG_HOST_BUILD        (1ull << 8)    /* MeshBuilder::build by the host builder */
+#define DMI_DBG_NO_IN_PLACE       (1ull << 9)    /* pack + copy even what could go up where it lies */
+#define DMI_DBG_NO_POOL           (1ull << 10)   /* a hipMalloc per job buffer */
+#define DMI_DBG_POISON            (1ull << 11)   /* uncleared chunks filled with 0xA5 */
+#define DMI_DBG_ZERO_CHUNKS       (1ull << 12)   /* job chunks cleared as a whole */
+#define DMI_DBG_NO_QUAD           (1ull << 13)   /* the host walks read 3·face + k ids */
+#define DMI_DBG_TEST_QUAD         (1ull << 14)   /* (tests, host only) 4·face + k ids on host-built tables */
+#define DMI_DBG_NO_CLOSED         (1ull << 15)   /* closed meshes run the general walk loops */
+#define DMI_DBG_NO_SHADOW         (1ull << 16)   /* Edgebreaker walk without the shadow prefetch */
+#define DMI_DBG_NO_SEQ_SHADOW     (1ull << 17)   /* sequencer without it */
+#define DMI_DBG_NO_SEAM_MASKS     (1ull << 18)   /* seam streams from per-corner flags instead of per-face masks */
+#define DMI_DBG_NO_DEFER_SEAMS    (1ull << 19)   /* meshes with attribute seams are prepared one by one */
+#define DMI_DBG_NO_BATCHED_PHASES (1ull << 20)   /* a batch encodes job by job */
+#define DMI_DBG_FUSED_WINDOWS     (1ull << 21)   /* the sweep with LDS-staged neighbourhoods (recorded experiment) */
+#define DMI_DBG_CHAIN_DENSE       (1ull << 22)   /* dense chain launches only */
+#define DMI_DBG_SERIAL_TABLES     (1ull << 23)   /* host corner tables on one thread */
+#define DMI_DBG_PARALLEL_TABLES   (1ull << 24)   /* … on all threads whatever the size */
+#define DMI_DBG_FILE_ORDER        (1ull << 25)   /* dmi_transcode_assets takes the files in the caller's order */
+#define DMI_DBG_TRACE             (1ull << 26)   /* stage lines on stderr */
+#define DMI_DBG_TRACE_STAGES      (1ull << 27)   /* the transcoder's stage lines only */
+#define DMI_DBG_TRACE_TABLES      (1ull << 28)
+#define DMI_DBG_BUILD_TRACE       (1ull << 29)
 typedef struct dmi_config {
   uint8_t pos_bits;      /* 0 → 11   portabilization/mod.rs:118-121 */
   uint8_t uv_bits;       /* 0 → 10   :131-134 */
@@ -88,8 +139,17 @@ typedef struct dmi_config {
   int32_t device;        /* HIP device ordinal */
   void* stream;          /* hipStream_t to launch on, NULL = a stream owned by the job */
   uint32_t flags;        /* DMI_FLAG_* */
+  const dmi_debug* debug;   /* NULL = the process defaults (all zeros unless dmi_set_default_debug changed them) */
 } dmi_config;
 #define DMI_FLAG_TIMINGS 1u   /* record per-stage hipEvent timings (dmi_job_timings) */
+/* the switches of calls that carry none (debug == NULL, or no dmi_config at all): copied; NULL = back to all zeros */
+void dmi_set_default_debug(const dmi_debug* d);
+/* Process-wide behaviour the library does NOT take upon itself by default (round 6: a drop-in must not rearrange its host process): */
+#define DMI_PROCESS_HUGE_PAGE_NEW 1u   /* large `operator new` blocks of the library's own containers on 2 MiB-aligned, huge-page-advised memory (host_pool.cpp) */
+#define DMI_PROCESS_NUMA_PIN      2u   /* whole-mesh calls restrict the calling thread to the CPUs of the GPU's memory node for the duration of the call */
+#define DMI_PROCESS_NO_THP        4u   /* never advise transparent huge pages */
+typedef struct dmi_process_options { uint32_t flags; uint32_t host_cache_mb, device_cache_mb, decode_budget_mb; /* 0 = defaults (4096 / 8192 / 16384) */ } dmi_process_options;
+int dmi_configure_process(const dmi_process_options* o);   /* any time; affects calls made afterwards */
 
 typedef struct dmi_buffer { uint8_t* data; size_t len; size_t cap; } dmi_buffer;
 

@@ -7,6 +7,7 @@ sys.path.insert(0, ROOT)
 import draco_oxide_amd as dmi  # noqa: E402
 from draco_oxide_amd import gltf, synth  # noqa: E402
 
+dmi.configure_process(huge_page_new=True, numa_pin=True)   # (as bench.py does)
 kind = sys.argv[1] if len(sys.argv) > 1 else "plain"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else (1024 if kind == "plain" else 256)
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
