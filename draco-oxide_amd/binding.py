@@ -205,7 +205,8 @@ EXPORTS = ["dmi_encode_attributes", "dmi_encode_attributes_batch", "dmi_jobs_enc
            "dmi_init", "dmi_last_call_timings", "dmi_device_corner_table", "dmi_encode_mesh_device", "dmi_meshes_build", "dmi_built_meshes_prepare", "dmi_last_build_timings", "dmi_device_attribute_table", "dmi_built_meshes_info", "dmi_built_meshes_free", "dmi_thread_host_threads", "dmi_usable_host_threads",
            "dmi_transcoder_create", "dmi_transcoder_reserve", "dmi_transcoder_push", "dmi_transcoder_finish", "dmi_transcoder_result", "dmi_transcoder_timings", "dmi_transcoder_counts", "dmi_transcoder_destroy",
            "dmi_host_alloc", "dmi_host_free", "dmi_host_is_registered",
-           "dmi_transcode_assets", "dmi_transcoded_file", "dmi_transcoded_blobs", "dmi_transcoded_stats", "dmi_transcoded_free", "dmi_json_roundtrip", "dmi_transcoded_table"]
+           "dmi_transcode_assets", "dmi_transcoded_file", "dmi_transcoded_blobs", "dmi_transcoded_stats", "dmi_transcoded_free", "dmi_json_roundtrip", "dmi_transcoded_table", "dmi_transcoded_blocks",
+           "dmi_transcoder_stages", "dmi_set_default_debug", "dmi_configure_process"]
 
 
 def library_path():
@@ -300,11 +301,13 @@ def load_library():
     L.dmi_host_free.argtypes = [C.c_void_p]
     L.dmi_host_free.restype = None
     L.dmi_host_is_registered.argtypes = [C.c_void_p, C.c_size_t]
-    L.dmi_transcode_assets.argtypes = [C.POINTER(_GltfAsset), C.c_uint32, C.POINTER(_Config), C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.dmi_transcode_assets.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(_Config), C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
     L.dmi_transcoded_file.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]
     L.dmi_transcoded_blobs.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     L.dmi_transcoded_stats.argtypes = [C.c_void_p, C.POINTER(_TranscodeStats)]
     L.dmi_transcoded_table.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    L.dmi_transcoded_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    L.dmi_transcoded_blocks.restype = C.c_uint32
     L.dmi_transcoded_free.argtypes = [C.c_void_p]
     L.dmi_transcoded_free.restype = None
     L.dmi_json_roundtrip.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(_Buffer)]
@@ -741,37 +744,61 @@ class _TranscodedHandle:
             pass
 
 
+def _fast_address(buf):
+    """(address, length) of a bytes-like object without going through numpy for the common types."""
+    if type(buf) is bytes:
+        return C.cast(C.c_char_p(buf), C.c_void_p).value or 0, len(buf)
+    return _address_of(buf)
+
+
+class AssetList:
+    """A list of assets marshalled for dmi_transcode_assets once (the C array of dmi_gltf_asset + whatever keeps the bytes alive): a caller that
+    transcodes the same list again — or wants the marshalling out of a timed region, like DeviceMesh for a mesh — passes this instead of the list."""
+
+    def __init__(self, assets):
+        n = len(assets)
+        self.n = n
+        self.keep = []
+        tab = np.zeros((max(n, 1), 6), np.uint64)          # dmi_gltf_asset: glb, glb_bytes, json, json_bytes, buffers, n_buffers (48 bytes)
+        assert C.sizeof(_GltfAsset) == 48
+        glb_addr, glb_len = [0] * n, [0] * n
+        for i, a in enumerate(assets):
+            if isinstance(a, tuple):
+                js, buffers = a
+                js = bytes(js)
+                spans = (_Span * max(len(buffers), 1))()
+                for k, b in enumerate(buffers):
+                    addr, nb = _fast_address(b) if len(b) else (0, 0)
+                    spans[k].data, spans[k].bytes = addr, nb
+                self.keep.append((js, buffers, spans))
+                tab[i, 2], tab[i, 3] = _fast_address(js)
+                tab[i, 4], tab[i, 5] = C.addressof(spans), len(buffers)
+            else:
+                glb_addr[i], glb_len[i] = _fast_address(a)
+                self.keep.append(a)
+        if n:
+            tab[:n, 0], tab[:n, 1] = glb_addr, glb_len
+        self.table = tab
+
+    def __len__(self):
+        return self.n
+
+
 def transcode_assets(assets, cfg=None, devices=None):
-    """dmi_transcode_assets: `assets` = GLB containers (bytes-like) or (json_bytes, [buffer bytes-like, ...]) pairs → ([(glb, [blob, ...]), ...], stats).
-    glb and the blobs are memoryviews of memory the library owns (the blobs lie inside their file; everything is released when the last view is
-    gone); stats = dmi_transcode_stats as a dict.  devices: HIP ordinals (one dmi_transcoder each; None: cfg.device)."""
+    """dmi_transcode_assets: `assets` = GLB containers (bytes-like) or (json_bytes, [buffer bytes-like, ...]) pairs — or an AssetList of them →
+    ([(glb, [blob, ...]), ...], stats).  glb and the blobs are memoryviews of memory the library owns (slices of the result's arena blocks; the blobs lie
+    inside their file; everything is released when the last view is gone); stats = dmi_transcode_stats as a dict.  devices: HIP ordinals (one
+    dmi_transcoder each; None: cfg.device)."""
     L = load_library()
     cfg = cfg or Config.default()
-    n = len(assets)
-    arr = (_GltfAsset * max(n, 1))()
-    keep = []
-    for i, a in enumerate(assets):
-        if isinstance(a, tuple):
-            js, buffers = a
-            js = bytes(js)
-            spans = (_Span * max(len(buffers), 1))()
-            for k, b in enumerate(buffers):
-                addr, nb = _address_of(b) if len(b) else (0, 0)
-                spans[k].data, spans[k].bytes = addr, nb
-            keep.append((js, buffers, spans))
-            arr[i].glb, arr[i].glb_bytes = None, 0
-            arr[i].json, arr[i].json_bytes = C.cast(C.c_char_p(js), C.c_void_p), len(js)
-            arr[i].buffers, arr[i].n_buffers = spans, len(buffers)
-        else:
-            addr, nb = _address_of(a)
-            keep.append(a)
-            arr[i].glb, arr[i].glb_bytes = addr, nb
+    al = assets if isinstance(assets, AssetList) else AssetList(assets)
+    n = len(al)
     dev = None
     if devices:
         dev = (C.c_int32 * len(devices))(*[int(d) for d in devices])
     c = cfg._c()
     h = C.c_void_p()
-    _check(L.dmi_transcode_assets(arr, n, C.byref(c), dev, len(devices) if devices else 0, 0, C.byref(h)))
+    _check(L.dmi_transcode_assets(C.c_void_p(al.table.ctypes.data), n, C.byref(c), dev, len(devices) if devices else 0, 0, C.byref(h)))
     owner = _TranscodedHandle(h.value)
     st = _TranscodeStats()
     _check(L.dmi_transcoded_stats(h, C.byref(st)))
@@ -779,14 +806,28 @@ def transcode_assets(assets, cfg=None, devices=None):
     cap = max(1, st.primitives)
     offs, sizes = np.zeros(cap, np.uint64), np.zeros(cap, np.uint64)
     _check(L.dmi_transcoded_table(h, addr.ctypes.data, size.ctypes.data, nblob.ctypes.data, offs.ctypes.data, sizes.ctypes.data, cap))
+    # the arena's blocks, wrapped once each; a file is a slice of its block (a thousand ctypes array types and from_address calls were 3 ms per call)
+    nb = L.dmi_transcoded_blocks(h, None, None, 0)
+    baddr, bbytes = np.zeros(max(nb, 1), np.uint64), np.zeros(max(nb, 1), np.uint64)
+    L.dmi_transcoded_blocks(h, baddr.ctypes.data, bbytes.ctypes.data, nb)
+    blocks = []
+    for k in range(nb):
+        raw = (C.c_uint8 * int(bbytes[k])).from_address(int(baddr[k]))
+        raw._owner = owner
+        blocks.append((int(baddr[k]), int(baddr[k]) + int(bbytes[k]), memoryview(raw).cast("B")))
+    blocks.sort()
+    starts = [b[0] for b in blocks]
+    import bisect
     out = []
     at = 0
-    u8 = C.c_uint8
     addr, size, nblob, offs, ends = addr.tolist(), size.tolist(), nblob.tolist(), offs.tolist(), (offs + sizes).tolist()
+    empty = memoryview(b"")
     for i in range(n):
-        raw = (u8 * size[i]).from_address(addr[i])
-        raw._owner = owner
-        glb = memoryview(raw).cast("B")
+        if size[i]:
+            lo, hi, view = blocks[bisect.bisect_right(starts, addr[i]) - 1]
+            glb = view[addr[i] - lo: addr[i] - lo + size[i]]
+        else:
+            glb = empty
         k = nblob[i]
         out.append((glb, [glb[offs[q]: ends[q]] for q in range(at, at + k)]))
         at += k

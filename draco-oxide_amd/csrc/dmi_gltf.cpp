@@ -754,6 +754,15 @@ int dmi_transcoded_table(const dmi_transcoded* r, uint64_t* file_address, uint64
   return at > blob_capacity && (blob_offsets || blob_sizes) ? host_fail(DMI_ERR_INVALID_ARGUMENT, "blob table too small") : DMI_OK;
 }
 
+// the blocks of the output arena (every file lies inside one of them): a caller in an interpreted language wraps a few blocks once and slices its files
+// out of them instead of wrapping a thousand files one by one.  Returns the number of blocks; fills at most `capacity` entries.
+uint32_t dmi_transcoded_blocks(const dmi_transcoded* r, uint64_t* address, uint64_t* bytes, uint32_t capacity) {
+  if (!r) return 0;
+  const auto& bl = r->arena.blocks;
+  for (size_t k = 0; k < bl.size() && k < capacity; ++k) { if (address) address[k] = (uint64_t)(uintptr_t)bl[k].p; if (bytes) bytes[k] = bl[k].cap; }
+  return (uint32_t)bl.size();
+}
+
 int dmi_transcoded_stats(const dmi_transcoded* r, dmi_transcode_stats* s) {
   if (!r || !s) return host_fail(DMI_ERR_INVALID_ARGUMENT, "null");
   *s = r->stats;

@@ -660,7 +660,11 @@ def transcode_files(sources, cfg=None, devices=None, group=None, device=None, pi
 
 
 def _native_assets(sources):
-    """The sources of a transcode as dmi_transcode_assets takes them: GLB bytes as they are, a `.gltf` as (JSON text, buffers) with its buffers resolved here."""
+    """The sources of a transcode as dmi_transcode_assets takes them: GLB bytes as they are, a `.gltf` as (JSON text, buffers) with its buffers resolved here
+    (a binding.AssetList — marshalled ahead of time — passes through)."""
+    from .binding import AssetList
+    if isinstance(sources, AssetList):
+        return sources
     assets = []
     for src in sources:
         if isinstance(src, (bytes, bytearray, memoryview)):

@@ -413,6 +413,8 @@ int dmi_transcoded_blobs(const dmi_transcoded* r, uint32_t i, uint64_t* offsets,
 /* the same for ALL files in one call: per file its address, size and blob count (arrays of stats.files entries); the blobs' (offset, size) pairs
  * back to back in file order (stats.primitives entries at most: blob_capacity = room in the two arrays) */
 int dmi_transcoded_table(const dmi_transcoded* r, uint64_t* file_address, uint64_t* file_bytes, uint32_t* file_blobs, uint64_t* blob_offsets, uint64_t* blob_sizes, uint64_t blob_capacity);
+/* the blocks of the result's output arena (every file lies inside one): returns their number, fills at most `capacity` (address, bytes) entries */
+uint32_t dmi_transcoded_blocks(const dmi_transcoded* r, uint64_t* address, uint64_t* bytes, uint32_t capacity);
 int dmi_transcoded_stats(const dmi_transcoded* r, dmi_transcode_stats* s);
 void dmi_transcoded_free(dmi_transcoded* r);
 /* The JSON layer of the above on its own (host only, for tests): parse `text`, write it back compactly — members in document order, number tokens

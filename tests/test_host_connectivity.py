@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "draco_mi.h")).read()
-    declared = set(re.findall(r"^(?:int|void|void\*|const char\*|dmi_transcoder\*)\s+(dmi_[a-z_]+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|void|void\*|const char\*|dmi_transcoder\*|uint32_t)\s+(dmi_[a-z_]+)\s*\(", hdr, flags=re.M))
     assert declared >= set(dmi.binding.EXPORTS)
     L = ctypes.CDLL(dmi.library_path())
     for name in sorted(declared):
