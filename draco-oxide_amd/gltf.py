@@ -704,6 +704,8 @@ def _transcode_files(sources, cfg, devices, group, device, pipeline, timings):
         tm.update({"parse_s": st["parse_ms"] * 1e-3, "views_s": 0.0, "build_s": st["build_ms"] * 1e-3, "prepare_s": st["prepare_ms"] * 1e-3,
                    "encode_s": st["encode_ms"] * 1e-3, "assemble_s": st["assemble_ms"] * 1e-3, "primitives_built": st["primitives"], "native": st})
         return out
+    if world0 > 1 and pipeline and os.environ.get("DMI_TRANSCODE_PYTHON", "0") == "0" and sources and encode_raw_batch is _ENCODE_RAW_BATCH:
+        return _transcode_files_ranks(sources, cfg, device, group, tm)
     docs = [load_document(src) for src in sources]
     per_file = [_plan(doc) for doc, _ in docs]
     flat = [(fi, pi) for fi, prims in enumerate(per_file) for pi in range(len(prims))]
@@ -809,6 +811,68 @@ def _transcode_files(sources, cfg, devices, group, device, pipeline, timings):
         out.append((glb, [bytes(v) for v in views]))                            # (bytes: these results travel between processes / threads)
     tm["assemble_s"] = time.perf_counter() - t1
     return out
+
+
+def _source_bytes(src):
+    """What stands for a file's triangle count before anything is parsed: its size in bytes (a `.gltf`: the document + whatever lies beside it under its stem)."""
+    if isinstance(src, (bytes, bytearray, memoryview)):
+        return len(src)
+    n = os.path.getsize(src)
+    stem = os.path.splitext(src)[0]
+    for ext in (".bin", "0.bin"):
+        if os.path.exists(stem + ext):
+            n += os.path.getsize(stem + ext)
+    return n
+
+
+_TRANSCODE_ASSETS = None   # (tests put a stand-in here: the ranks' control flow without a device)
+
+
+def _transcode_files_ranks(sources, cfg, device, group, tm):
+    """The rank-sharded form (round 6): the FILES are dealt to the ranks by their size in bytes (LPT) before anything is parsed — no rank reads, parses or
+    plans a document it does not own —, every rank runs the library's own loop over its files (dmi_transcode_assets: parse pool, stage pipeline, assembly) and
+    the FINISHED files travel: one size exchange + one gather of [blob table | GLB] payloads onto rank 0, no reassembly there.  (Round 5 parsed every JSON
+    on every rank, dealt primitives, gathered blobs padded to the largest share and rebuilt every file on rank 0.)"""
+    import time
+    import torch.distributed as dist
+    from . import distributed
+    t0 = time.perf_counter()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    sizes = [_source_bytes(src) for src in sources]
+    mine = distributed.shard_indices(len(sources), rank, world, weights=sizes)
+    cfg = distributed._rank_config(cfg, device)
+    run = _TRANSCODE_ASSETS or transcode_assets
+    own = [sources[i] for i in mine]
+    if own:
+        out, st = run(_native_assets(own), cfg, devices=[cfg.device])
+    else:
+        out, st = [], {"parse_ms": 0.0, "build_ms": 0.0, "prepare_ms": 0.0, "encode_ms": 0.0, "assemble_ms": 0.0, "primitives": 0}
+    tm.update({"parse_s": st["parse_ms"] * 1e-3, "views_s": 0.0, "build_s": st["build_ms"] * 1e-3, "prepare_s": st["prepare_ms"] * 1e-3, "encode_s": st["encode_ms"] * 1e-3,
+               "assemble_s": st["assemble_ms"] * 1e-3, "primitives_built": st["primitives"], "files_owned": len(own), "native": st, "transcode_s": time.perf_counter() - t0})
+    payloads = []
+    for glb, blobs in out:
+        # where the blobs lie inside their file: [count | (offset, length) …] in front of the file's bytes
+        g = np.frombuffer(glb, np.uint8)
+        base = g.ctypes.data if len(g) else 0
+        tab = np.empty(1 + 2 * len(blobs), np.uint64)
+        tab[0] = len(blobs)
+        for k, b in enumerate(blobs):
+            v = np.frombuffer(b, np.uint8)
+            tab[1 + 2 * k], tab[2 + 2 * k] = (v.ctypes.data - base if len(v) else 0), len(v)
+        payloads.append(tab.tobytes() + bytes(glb))
+    t1 = time.perf_counter()
+    got = distributed.gather_blob_lists(payloads, mine, len(sources), device=device, group=group)
+    tm["gather_s"] = time.perf_counter() - t1
+    if got is None:
+        return None
+    results = []
+    for p in got:
+        p = bytes(p)
+        n = int(np.frombuffer(p, np.uint64, count=1)[0])
+        tab = np.frombuffer(p, np.uint64, count=1 + 2 * n)
+        glb = p[(1 + 2 * n) * 8:]
+        results.append((glb, [glb[int(tab[1 + 2 * k]): int(tab[1 + 2 * k]) + int(tab[2 + 2 * k])] for k in range(n)]))
+    return results
 
 
 def _share_native(raw_of, w_mine, cfg, tm):

@@ -177,3 +177,58 @@ def test_transcode_files_shards_before_building_gloo_world2():
     assert [g for g, _ in res0] == [g for g, _ in single] and [b for _, b in res0] == [b for _, b in single]
     doc, _ = gltf.read_glb(res0[0][0])
     assert doc["accessors"][doc["meshes"][0]["primitives"][1]["indices"]]["count"] == 2 * 14 * 14 * 3
+
+
+# ---- round 6: the rank-sharded transcode deals FILES by size before anything is parsed; finished files travel ----
+def _fake_transcode_assets(assets, cfg=None, devices=None):
+    """Stands in for dmi_transcode_assets: the "GLB" of a file is a digest of its bytes + two "blobs" inside it (memoryviews of the file, like the library's)."""
+    import hashlib
+    out = []
+    for a in assets:
+        h = hashlib.sha256(bytes(a)).digest()
+        glb = memoryview(b"glTF" + h * 3)
+        out.append((glb, [glb[4:36], glb[40:50]]))
+    return out, {"parse_ms": 1.0, "build_ms": 2.0, "prepare_ms": 3.0, "encode_ms": 4.0, "assemble_ms": 5.0, "primitives": len(assets)}
+
+
+def _files_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from draco_oxide_amd import gltf
+        seen = []
+        gltf._TRANSCODE_ASSETS = lambda assets, cfg=None, devices=None: (seen.extend(len(a) for a in assets), _fake_transcode_assets(assets, cfg, devices))[1]
+        gltf.load_document = lambda src: (_ for _ in ()).throw(AssertionError("a rank parsed a document"))   # nothing is parsed outside the library's own loop
+        rng = np.random.default_rng(3)
+        files = [bytes(rng.integers(0, 255, size=int(n), dtype=np.uint8)) for n in (5000, 100, 70000, 3000, 42000, 900, 15000)]
+        tm = {}
+        res = gltf.transcode_files(files, timings=tm)
+        q.put((rank, seen, tm.get("files_owned"), res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_transcode_files_deals_files_by_size_before_parsing_gloo_world2():
+    import hashlib
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_files_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, seen0, n0, res0), (_, seen1, n1, res1) = got
+    sizes = [5000, 100, 70000, 3000, 42000, 900, 15000]
+    own0, own1 = dd.shard_indices(7, 0, 2, weights=sizes), dd.shard_indices(7, 1, 2, weights=sizes)
+    assert seen0 == [sizes[i] for i in own0] and seen1 == [sizes[i] for i in own1] and n0 == len(own0) and n1 == len(own1)     # each rank's library call saw ITS files only
+    assert abs(sum(seen0) - sum(seen1)) <= max(sizes)                                                                   # LPT by bytes
+    assert res1 is None and len(res0) == 7
+    rng = np.random.default_rng(3)
+    files = [bytes(rng.integers(0, 255, size=int(n), dtype=np.uint8)) for n in sizes]
+    for f, (glb, blobs) in zip(files, res0):                                                                             # finished files in input order, blobs cut out of them
+        h = hashlib.sha256(f).digest()
+        assert glb == b"glTF" + h * 3 and blobs == [glb[4:36], glb[40:50]]

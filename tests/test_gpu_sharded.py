@@ -126,14 +126,14 @@ def _transcode_worker(rank, world, port, q):
         from draco_oxide_amd import gltf
         tm = {}
         res = gltf.transcode_files(tdc._fake_assets(), timings=tm)
-        q.put((rank, tm["primitives_built"], None if res is None else [blobs for _, blobs in res]))
+        q.put((rank, tm["primitives_built"], None if res is None else [blobs for _, blobs in res], None if res is None else [bytes(g) for g, _ in res], tm.get("files_owned")))
     finally:
         dist.destroy_process_group()
 
 
 def test_transcode_files_over_two_ranks_builds_only_its_share():
-    """transcode_files in a two-rank job: each rank builds (dmi_meshes_build) and encodes only the primitives dealt to it, rank 0 holds
-    every blob — the same blobs a single process produces."""
+    """transcode_files in a two-rank job (round 6: FILES dealt by size before parsing, each rank runs dmi_transcode_assets over its own, finished files
+    gathered): each rank builds and encodes only its files' primitives, rank 0 holds every file — byte for byte the files a single process writes."""
     import test_distributed_cpu as tdc
     from draco_oxide_amd import gltf
     ctx = mp.get_context("spawn")
@@ -149,3 +149,4 @@ def test_transcode_files_over_two_ranks_builds_only_its_share():
     assert got[0][1] + got[1][1] == 5 and 0 < got[0][1] < 5 and got[1][2] is None
     single = gltf.transcode_files(tdc._fake_assets())
     assert got[0][2] == [blobs for _, blobs in single]
+    assert got[0][3] == [bytes(g) for g, _ in single] and got[0][4] + got[1][4] == 3 and got[0][4] >= 1 and got[1][4] >= 1
