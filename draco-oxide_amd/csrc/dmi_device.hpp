@@ -93,7 +93,8 @@ struct FusedArgs {
   const void* qs_uv; const int32_t* mm_uv; void* sym_uv; uint8_t* orient;
   const uint32_t* fan_hdr; const uint32_t* fan_apex; const uint32_t* fan;   // fan rows of the table (launch_build_fans)
   uint32_t sym16;    // bit 0 / 1 / 2: sym_pos / sym_nrm / sym_uv are uint16 arrays
-  uint32_t pad;
+  uint32_t face_stride;   // 0 / 3: c2r and opp are dense arrays indexed by corner; 8: face records (launch_face_records) — c2r = the records, opp = c2r + 4, entry of
+                          // corner c at 8·(c / 3) + c % 3.  Only rows that overflow (valence > 8) and deferred texture coordinates read them.
   // Texture-coordinate entries outside the sweep's exact f64 tier (large operands) are not predicted in the sweep: their sequence indices
   // go to fix_list (fix_count[0] of them, appended one atomic per wavefront) and k_texcoord_fixup — launched right after the sweep —
   // predicts them with the general i64 form.  The sweep itself then holds no out-of-line call: 58 VGPRs instead of 80, 8 waves per SIMD.
@@ -341,6 +342,10 @@ struct RelabelBatch {
 void launch_relabel_batch(const RelabelBatch& b, hipStream_t s);
 struct ComposeItem { const uint32_t* s2p; const uint32_t* p2v; uint32_t* s2v; uint32_t off /* Σ n_seq of the items before */, n; };
 void launch_corner_ranks(const uint32_t* c2v, const uint32_t* rank, uint64_t C, uint32_t* c2r, hipStream_t s);   // c2r[c] = rank[c2v[c]]
+// frec[8f..8f+2] = rank[c2v[3f..3f+2]], frec[8f+4..8f+6] = opp[3f..3f+2] (8F words): ranks and opposite corners of a face in one 32-byte record
+void launch_face_records(const uint32_t* c2v, const uint32_t* rank, const uint32_t* opp, uint32_t F, uint32_t* frec, hipStream_t s);
+// fan rows from face records (corner ids in seq / the records' opposite corners stay 3·face + k)
+void launch_build_fans_rec(const uint32_t* seq, uint32_t n, const uint32_t* frec, uint32_t* hdr, uint32_t* apex, uint32_t* fan, hipStream_t s);
 void launch_rank_and_points(const uint32_t* seq, uint32_t n_seq, const uint32_t* c2v, const uint32_t* c2p, uint32_t* rank, uint32_t* s2p, hipStream_t s);   // rank[c2v[seq[k]]] = k and s2p[k] = c2p[seq[k]] in one pass over the sequence
 void launch_compose_batch(const ComposeItem* items_dev, uint32_t n_items, uint32_t total, hipStream_t s);
 // fan rows of many tables in one launch (k_build_fans per item)

@@ -100,6 +100,7 @@ int encode_phase_a(dmi_job* job, bool plan_only) {   // device: ranges → codin
     if (a.fused_nrm >= 0 || a.fused_uv >= 0) {
       FusedArgs fa{};
       fa.seq = t.seq.as<uint32_t>(); fa.c2r = t.c2r.as<uint32_t>(); fa.opp = t.opp.as<uint32_t>(); fa.n = n;
+      if (t.frec.p) { fa.c2r = t.frec.as<uint32_t>(); fa.opp = t.frec.as<uint32_t>() + 4; fa.face_stride = 8u; }   // (face records: see TableDev::frec)
       fa.qs_pos = a.qs.p; fa.mm_pos = minmax; fa.sym_pos = a.sym.p;
       fa.packed = a.qfmt == QF_P64 ? 1u : 0u;
       fa.sym16 = a.sym16 ? 1u : 0u;

@@ -533,21 +533,21 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
     TableDev& t = job->tables[0];
     uint32_t* d_rank = tmpdev.take<uint32_t>(t.V ? t.V : 1);
     if (!d_rank) return fail(DMI_ERR_OUT_OF_MEMORY, "hipMalloc (relabelling temporaries)");
-    if ((rc = t.c2r.alloc(C * 4))) return rc;
+    // Round 6: ranks and opposite corners of a face in ONE 32-byte record (launch_face_records) instead of a corner → rank array beside `opp`: a swing of the
+    // fan-row walk is then one read, not two on different lines (k_build_fans 346 → … µs per 10M faces); only overflow rows and deferred texture
+    // coordinates read the records afterwards (FusedArgs::face_stride = 8)
+    if ((rc = t.frec.alloc((size_t)F * 32))) return rc;
     if (dev->donor && dev->donor->device == cfg.device) {   // the stage's own array, in place: its pool's chunks now belong to the job
       t.opp.p = const_cast<uint32_t*>(dev->opp); t.opp.bytes = C * 4; t.opp.pooled = true;
       job->donated.device = dev->donor->device; job->donated.stream = s; job->donated.zero = false;
       job->donated.chunks.swap(dev->donor->chunks);
-    } else {
-      if ((rc = t.opp.alloc(C * 4))) return rc;
-      HIP_TRY(hipMemcpyAsync(t.opp.p, dev->opp, C * 4, hipMemcpyDeviceToDevice, s));
-    }
+    }   // (no donor: the stage's array is read once, by launch_face_records below, on this same stream — the stage outlives job creation; no copy)
     if ((rc = t.seq.alloc((size_t)t.n_seq * 4))) return rc;
     if ((rc = t.s2p.alloc((size_t)t.n_seq * 4))) return rc;
     if (t.n_seq) HIP_TRY(hipMemcpyAsync(t.seq.p, seq_of[0], (size_t)t.n_seq * 4, hipMemcpyHostToDevice, s));
     launch_fill_u32(d_rank, t.V, kNone, s);
     launch_rank_and_points(t.seq.as<uint32_t>(), t.n_seq, dev->c2v, dev->c2p, d_rank, t.s2p.as<uint32_t>(), s);
-    launch_corner_ranks(dev->c2v, d_rank, C, t.c2r.as<uint32_t>(), s);
+    launch_face_records(dev->c2v, d_rank, dev->opp, F, t.frec.as<uint32_t>(), s);
   } else if (device_relabel) {
     uint32_t max_seq = 0, max_v = 0;
     for (uint32_t i = 0; i < n_atts; ++i) if (job->tables[i].alias_of < 0) { max_seq = std::max(max_seq, job->tables[i].n_seq); max_v = std::max(max_v, job->tables[i].V); }
@@ -711,6 +711,7 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
     if ((rc = t.fan_apex.alloc((size_t)t.n_seq * 4))) return rc;
     if ((rc = t.fan.alloc((size_t)t.n_seq * 32))) return rc;
     if (defer) defer->fans.push_back(FanItem{t.seq.as<uint32_t>(), t.c2r.as<uint32_t>(), t.opp.as<uint32_t>(), t.fan_hdr.as<uint32_t>(), t.fan_apex.as<uint32_t>(), t.fan.as<uint32_t>(), 0u, t.n_seq, 0u, 0u});
+    else if (t.frec.p) launch_build_fans_rec(t.seq.as<uint32_t>(), t.n_seq, t.frec.as<uint32_t>(), t.fan_hdr.as<uint32_t>(), t.fan_apex.as<uint32_t>(), t.fan.as<uint32_t>(), s);
     else launch_build_fans(t.seq.as<uint32_t>(), t.n_seq, t.c2r.as<uint32_t>(), t.opp.as<uint32_t>(), t.fan_hdr.as<uint32_t>(), t.fan_apex.as<uint32_t>(), t.fan.as<uint32_t>(), false, s);
   }
   uint32_t max_point = 0;

@@ -167,6 +167,7 @@ struct TableDev {
   DevMem fan_hdr, fan_apex, fan;   // fan rows (only for tables with a fused sweep)
   DevMem s2p_sorted, sorted_dest;   // tile-sorted form of the quantize gather: slot j → point / sequence index (optional)
   DevMem c2r, opp, seq, s2p;   // c2r = corner → sequence index of its vertex; s2p = sequence index → point (= point_idx(seq[i]))
+  DevMem frec;                  // one-shot jobs in the mesh's own face order (round 6): 32-byte face records {ranks[3], -, opposite corners[3], -} instead of c2r (launch_face_records)
   const uint32_t* s2p_host = nullptr;   // (during job creation, host-relabel form) the same array in the upload staging
   // sharing: a table whose arrays equal another table's reuses its device copies
   int alias_of = -1;

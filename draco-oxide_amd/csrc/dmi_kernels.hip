@@ -74,6 +74,9 @@ __device__ __forceinline__ uint32_t zigzag(int32_t v) {   // utils/mod.rs:152-15
   return v >= 0 ? ((uint32_t)v << 1) : ((((uint32_t)(-(v + 1))) << 1) + 1u);
 }
 
+// entry of corner c in a per-corner table: dense arrays (stride 3: the corner itself) or face records (stride 8: see FusedArgs::face_stride)
+__device__ __forceinline__ size_t cidx(uint32_t c, uint32_t face_stride) { return face_stride == 8u ? (size_t)(c / 3u) * 8u + c % 3u : (size_t)c; }
+
 // ---- layouts of quantized values and symbols (QFmt, sym16: dmi_device.hpp) ----
 __device__ __forceinline__ uint64_t pack_p64(int32_t x, int32_t y, int32_t z) { return (uint64_t)(uint32_t)x | ((uint64_t)(uint32_t)y << 21) | ((uint64_t)(uint32_t)z << 42); }
 __device__ __forceinline__ void unpack_p64(uint64_t v, int32_t (&out)[3]) {
@@ -1017,7 +1020,7 @@ __device__ __forceinline__ void add_face_normal(const int32_t (&a)[3], const int
 template <bool PACKED>
 __device__ __forceinline__ void fan_normal_sum(uint32_t c, const uint32_t* __restrict__ opp, const uint32_t* __restrict__ c2r_pos,
                                                const void* __restrict__ qs_pos, const int32_t (&Pc)[3], const int32_t (&Pn)[3], const int32_t (&Pp)[3],
-                                               int64_t (&sum)[3]) {
+                                               int64_t (&sum)[3], uint32_t face_stride = 3u) {
   constexpr int fmt = PACKED ? QF_P64 : QF_I32;
   add_face_normal<PACKED>(Pn, Pp, Pc, sum);
   uint32_t curR = c, curL = c;
@@ -1029,10 +1032,10 @@ __device__ __forceinline__ void fan_normal_sum(uint32_t c, const uint32_t* __res
   for (uint32_t guard = 0; guard < (1u << 24); ++guard) {   // (a consistent table terminates by itself; the guard bounds a malformed one)
     if (!(actR || actL || s1R != kNoneD || s1L != kNoneD || v2R || v2L || v3R || v3L)) break;
     // ---- issue: next hops, ranks of last round's corners, positions of last round's ranks
-    const uint32_t oR = actR ? opp[cprev(curR)] : kNoneD;
-    const uint32_t oL = actL ? opp[cnext(curL)] : kNoneD;
-    const uint32_t rkR = s1R != kNoneD ? c2r_pos[s1R] : kNoneD;
-    const uint32_t rkL = s1L != kNoneD ? c2r_pos[s1L] : kNoneD;
+    const uint32_t oR = actR ? opp[cidx(cprev(curR), face_stride)] : kNoneD;
+    const uint32_t oL = actL ? opp[cidx(cnext(curL), face_stride)] : kNoneD;
+    const uint32_t rkR = s1R != kNoneD ? c2r_pos[cidx(s1R, face_stride)] : kNoneD;
+    const uint32_t rkL = s1L != kNoneD ? c2r_pos[cidx(s1L, face_stride)] : kNoneD;
     int32_t XR[3] = {0, 0, 0}, XL[3] = {0, 0, 0};
     if (v2R) load_pos_fmt(qs_pos, fmt, s2R, XR);
     if (v2L) load_pos_fmt(qs_pos, fmt, s2L, XL);
@@ -1151,6 +1154,81 @@ __global__ __launch_bounds__(kBlock) void k_build_fans_batch(const FanItem* __re
   }
 }
 
+// Fan rows from FACE RECORDS (round 6: one-shot jobs in the mesh's own face order).  A swing lands in a face whose record holds both things the walk wants
+// from it — the rank of the vertex it just reached and the opposite corner it leaves by: one 32-byte read per swing, where build_fan_row reads `opp` and
+// `c2r` on two different lines (51.7 M L1 → L2 requests and 346 µs per 10M faces).  Rows and headers are build_fan_row's, entry for entry.
+__device__ __forceinline__ uint32_t pick3(const uint4& v, uint32_t k) { return k == 0u ? v.x : (k == 1u ? v.y : v.z); }
+__device__ __forceinline__ void build_fan_row_rec(uint32_t i, const uint32_t* __restrict__ seq, const uint4* __restrict__ frec, uint32_t* __restrict__ hdr, uint32_t* __restrict__ apex,
+                                                  uint32_t* __restrict__ fan) {
+  const uint32_t c = seq[i];
+  const uint32_t f0 = c / 3u, k0 = c - 3u * f0;
+  const uint4 r0 = frec[(size_t)f0 * 2], o0 = frec[(size_t)f0 * 2 + 1];
+  uint32_t row[kFanSlots];
+#pragma unroll
+  for (uint32_t k = 0; k < kFanSlots; ++k) row[k] = kNoneD;
+  const uint32_t kn = k0 == 2u ? 0u : k0 + 1u, kp = k0 == 0u ? 2u : k0 - 1u;
+  row[0] = pick3(r0, kn);
+  row[1] = pick3(r0, kp);
+  const uint32_t o = pick3(o0, k0);
+  uint32_t apex_rank = kNoneD;
+  if (o != kNoneD) { const uint32_t fo = o / 3u; apex_rank = pick3(frec[(size_t)fo * 2], o - 3u * fo); }   // (off the walk's dependency chain)
+  uint32_t stored = 2, faces_r = 0, faces_l = 0;
+  bool closed = false, overflow = false;
+  uint32_t pending = kNoneD;
+  uint32_t o2 = pick3(o0, kp);                       // opp[cprev(c)]: the right swing leaves the face by the edge opposite the previous corner
+  for (uint32_t guard = 0; guard < (1u << 24) && o2 != kNoneD; ++guard) {
+    const uint32_t f2 = o2 / 3u, k2 = o2 - 3u * f2;
+    const uint32_t kc = k2 == 0u ? 2u : k2 - 1u;     // cur = cprev(o2)
+    if (f2 == f0 && kc == k0) { closed = true; break; }
+    const uint4 r2 = frec[(size_t)f2 * 2], q2 = frec[(size_t)f2 * 2 + 1];
+    if (pending != kNoneD) {
+      if (stored < kFanSlots) {
+#pragma unroll
+        for (uint32_t k = 2; k < kFanSlots; ++k) if (k == stored) row[k] = pending;
+      } else overflow = true;
+      ++stored;
+    }
+    pending = pick3(r2, k2);
+    ++faces_r;
+    o2 = pick3(q2, kc == 0u ? 2u : kc - 1u);         // opp[cprev(cur)]
+  }
+  if (!closed && pending != kNoneD) {
+    if (stored < kFanSlots) {
+#pragma unroll
+      for (uint32_t k = 2; k < kFanSlots; ++k) if (k == stored) row[k] = pending;
+    } else overflow = true;
+    ++stored;
+  }
+  if (!closed) {
+    o2 = pick3(o0, kn);                              // opp[cnext(c)]
+    for (uint32_t guard = 0; guard < (1u << 24) && o2 != kNoneD; ++guard) {
+      const uint32_t f2 = o2 / 3u, k2 = o2 - 3u * f2;
+      const uint32_t kc = k2 == 2u ? 0u : k2 + 1u;   // cur = cnext(o2)
+      if (f2 == f0 && kc == k0) break;
+      const uint4 r2 = frec[(size_t)f2 * 2], q2 = frec[(size_t)f2 * 2 + 1];
+      const uint32_t w = pick3(r2, k2);
+      if (stored < kFanSlots) {
+#pragma unroll
+        for (uint32_t k = 2; k < kFanSlots; ++k) if (k == stored) row[k] = w;
+      } else overflow = true;
+      ++stored;
+      ++faces_l;
+      o2 = pick3(q2, kc == 2u ? 0u : kc + 1u);       // opp[cnext(cur)]
+    }
+  }
+  if (faces_r > 255u || faces_l > 255u) overflow = true;
+  apex[i] = apex_rank;
+  hdr[i] = (faces_r & 255u) | ((faces_l & 255u) << 8) | (closed ? 1u << 16 : 0u) | (overflow ? 1u << 17 : 0u);
+  uint4* dst = reinterpret_cast<uint4*>(fan + (size_t)i * kFanSlots);
+  dst[0] = make_uint4(row[0], row[1], row[2], row[3]);
+  dst[1] = make_uint4(row[4], row[5], row[6], row[7]);
+}
+__global__ __launch_bounds__(kBlock) void k_build_fans_rec(const uint32_t* __restrict__ seq, uint32_t n, const uint4* __restrict__ frec, uint32_t* __restrict__ hdr,
+                                                           uint32_t* __restrict__ apex, uint32_t* __restrict__ fan) {
+  const uint32_t blk_ = blockIdx.x, nblk_ = gridDim.x;
+  DMI_FOR_SEQUENCE(i, n) build_fan_row_rec(i, seq, frec, hdr, apex, fan);
+}
+
 // the stores of one texture-coordinate entry (orientation flag + wrapped-difference symbols)
 __device__ __forceinline__ void uv_emit(const FusedArgs& a, uint32_t i, const int32_t (&cu)[2], int32_t pred0, int32_t pred1, uint8_t oflag, const WrapParams& wu, bool s16_uv) {
   __builtin_nontemporal_store(oflag, &a.orient[i]);
@@ -1172,7 +1250,7 @@ __device__ __forceinline__ void k_texcoord_fixup_body(const FusedArgs& a, const 
   for (uint32_t k = blk_ * kBlock + threadIdx.x; k < count; k += nblk_ * kBlock) {
     const uint32_t i = a.fix_list[k];
     uint32_t rn, rp;
-    if (a.fan_hdr[i] & (1u << 17)) { const uint32_t c = a.seq[i]; rn = a.c2r[cnext(c)]; rp = a.c2r[cprev(c)]; }
+    if (a.fan_hdr[i] & (1u << 17)) { const uint32_t c = a.seq[i]; rn = a.c2r[cidx(cnext(c), a.face_stride)]; rp = a.c2r[cidx(cprev(c), a.face_stride)]; }
     else { rn = a.fan[(size_t)i * kFanSlots]; rp = a.fan[(size_t)i * kFanSlots + 1]; }
     int32_t Pc[3], Pn[3], Pp[3], cu[2], nu[2], pu[2];
     const int fmt = packed ? QF_P64 : QF_I32;
@@ -1329,9 +1407,9 @@ __device__ __forceinline__ void k_predict_fused_body(const FusedArgs& a, const u
     } else {
       // ---- row overflow (valence > 8): walk the corner table ----
       const uint32_t c = seq[i], nc = cnext(c), pc = cprev(c);
-      rn = c2r[nc]; rp = c2r[pc];
+      rn = c2r[cidx(nc, a.face_stride)]; rp = c2r[cidx(pc, a.face_stride)];
       if (HAS_NRM || (HAS_POS && rn < i && rp < i)) { load_pos_fmt(qs_pos, pos_fmt, rn, Pn); load_pos_fmt(qs_pos, pos_fmt, rp, Pp); }
-      if (HAS_NRM) fan_normal_sum<PACKED>(c, opp, c2r, qs_pos, Pc, Pn, Pp, sum);
+      if (HAS_NRM) fan_normal_sum<PACKED>(c, opp, c2r, qs_pos, Pc, Pn, Pp, sum, a.face_stride);
     }
     const bool both = HAS_POS && rn < i && rp < i;
     if (HAS_POS) {
@@ -2061,6 +2139,10 @@ void launch_build_fans(const uint32_t* seq, uint32_t n, const uint32_t* c2r, con
   if (n) hipLaunchKernelGGL(k_build_fans, grid_for(n, 8192), kBlock, 0, s, seq, n, c2r, opp, hdr, apex, fan, centre_in_apex ? 1 : 0);
 }
 
+void launch_build_fans_rec(const uint32_t* seq, uint32_t n, const uint32_t* frec, uint32_t* hdr, uint32_t* apex, uint32_t* fan, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_build_fans_rec, grid_for(n, 8192), kBlock, 0, s, seq, n, reinterpret_cast<const uint4*>(frec), hdr, apex, fan);
+}
+
 void launch_build_fans_batch(const FanItem* items_dev, uint32_t n_items, uint32_t total, hipStream_t s) {
   if (n_items && total) hipLaunchKernelGGL(k_build_fans_batch, grid_for(total, 65535u * 16u), kBlock, 0, s, items_dev, n_items, total);
 }
@@ -2075,7 +2157,7 @@ void launch_predict_fused(const FusedArgs& a, hipStream_t s) {
   int id = !a.sym_pos ? K_FUSED_N /* a normal attribute on its own table */ : ((a.qs_nrm && a.qs_uv) ? K_FUSED_PNU : (a.qs_nrm ? K_FUSED_PN : K_FUSED_PU));
   if (a.packed) id += K_PACKED_PNU - K_FUSED_PNU;
   const bool windows = dbg_on(DMI_DBG_FUSED_WINDOWS);   // LDS-staged neighbourhoods (see k_predict_window_body)
-  if (windows && a.packed && a.sym_pos) id = id == K_PACKED_PNU ? K_WINDOW_PNU : (id == K_PACKED_PN ? K_WINDOW_PN : K_WINDOW_PU);
+  if (windows && a.packed && a.sym_pos && a.face_stride != 8u) id = id == K_PACKED_PNU ? K_WINDOW_PNU : (id == K_PACKED_PN ? K_WINDOW_PN : K_WINDOW_PU);
   const uint32_t env_lds = dbg().fused_lds;   // tuning aid: unused dynamic LDS per block = fewer blocks per CU
   emit(id, 4, a, g, env_lds, s);
   if (a.qs_uv && a.sym_pos && id != K_WINDOW_PNU && id != K_WINDOW_PU) emit(K_TEX_FIXUP, 5, a, 64u, 0, s);   // the entries the sweep deferred (usually none: the launch finds count = 0)

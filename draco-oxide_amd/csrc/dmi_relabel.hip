@@ -92,6 +92,19 @@ __global__ __launch_bounds__(kBlock) void k_remap_seq(const uint32_t* __restrict
 __global__ __launch_bounds__(kBlock) void k_corner_ranks(const uint32_t* __restrict__ c2v, const uint32_t* __restrict__ rank, uint64_t C, uint32_t* __restrict__ c2r) {
   for (uint64_t c = (uint64_t)blockIdx.x * kBlock + threadIdx.x; c < C; c += (uint64_t)gridDim.x * kBlock) c2r[c] = rank[c2v[c]];
 }
+// Face records (round 6; one-shot jobs in the mesh's own face order): frec[8f .. 8f+2] = the ranks of face f's three vertices, frec[8f+4 .. 8f+6] = its three
+// opposite corners — 32 bytes per face, written once, so that a swing of the fan-row walk (k_build_fans_rec: the rank of the vertex it lands on AND the
+// opposite corner it leaves by belong to one face) is ONE 32-byte read instead of a read of `c2r` and one of `opp` on different lines.
+__global__ __launch_bounds__(kBlock) void k_face_records(const uint32_t* __restrict__ c2v, const uint32_t* __restrict__ rank, const uint32_t* __restrict__ opp, uint32_t F,
+                                                         uint4* __restrict__ frec) {
+  for (uint32_t f = blockIdx.x * kBlock + threadIdx.x; f < F; f += gridDim.x * kBlock) {
+    const size_t c = (size_t)f * 3;
+    const uint32_t v0 = c2v[c], v1 = c2v[c + 1], v2 = c2v[c + 2];
+    const uint32_t o0 = opp[c], o1 = opp[c + 1], o2 = opp[c + 2];
+    frec[(size_t)f * 2] = make_uint4(rank[v0], rank[v1], rank[v2], 0u);
+    frec[(size_t)f * 2 + 1] = make_uint4(o0, o1, o2, 0u);
+  }
+}
 // for a table in the mesh's own face order (one read of the sequence, the two table entries of a corner next to each other in time):
 // rank[c2v[seq[k]]] = k and s2p[k] = c2p[seq[k]]
 __global__ __launch_bounds__(kBlock) void k_rank_and_points(const uint32_t* __restrict__ seq, uint32_t n_seq, const uint32_t* __restrict__ c2v, const uint32_t* __restrict__ c2p,
@@ -208,6 +221,9 @@ void launch_remap_seq(const uint32_t* seq, uint32_t n_seq, const uint32_t* new_f
   if (n_seq) hipLaunchKernelGGL(k_remap_seq, grid_of(n_seq), kBlock, 0, s, seq, n_seq, new_face, c2p, seq_out, s2p_out);
 }
 void launch_corner_ranks(const uint32_t* c2v, const uint32_t* rank, uint64_t C, uint32_t* c2r, hipStream_t s) { if (C) hipLaunchKernelGGL(k_corner_ranks, grid_of(C), kBlock, 0, s, c2v, rank, C, c2r); }
+void launch_face_records(const uint32_t* c2v, const uint32_t* rank, const uint32_t* opp, uint32_t F, uint32_t* frec, hipStream_t s) {
+  if (F) hipLaunchKernelGGL(k_face_records, grid_of(F), kBlock, 0, s, c2v, rank, opp, F, reinterpret_cast<uint4*>(frec));
+}
 void launch_rank_and_points(const uint32_t* seq, uint32_t n_seq, const uint32_t* c2v, const uint32_t* c2p, uint32_t* rank, uint32_t* s2p, hipStream_t s) {
   if (n_seq) hipLaunchKernelGGL(k_rank_and_points, grid_of(n_seq), kBlock, 0, s, seq, n_seq, c2v, c2p, rank, s2p);
 }

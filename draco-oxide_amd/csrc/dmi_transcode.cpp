@@ -214,7 +214,7 @@ dmi_transcoder* dmi_transcoder_create(const dmi_config* cfg, uint64_t expected_t
   t->debug = dbg();
   t->cfg.debug = &t->debug;
   t->trace = dbg_on(DMI_DBG_TRACE | DMI_DBG_TRACE_STAGES);
-  t->stage_primitives = dbg().stage_primitives;
+  t->stage_primitives = dbg().stage_primitives ? dbg().stage_primitives : 256u;   // (1024 files, medians of 7: 80.5 → 80.1, 87.6 → 84.9, 88.4 → 80.8 ms with the cap)
   // about four stages (enough to overlap the steps), between 3M and 12M triangles: a stage pays fixed costs (the chain launch of its encode is bounded
   // by its longest stream, ≈ 5 ms) and one above ≈ 16M stops overlapping (measured with the Python driver: DESIGN §6b)
   t->stage_triangles = stage_triangles ? stage_triangles : std::min<uint64_t>((uint64_t)12 << 20, std::max<uint64_t>((uint64_t)3 << 20, expected_triangles / 4));
