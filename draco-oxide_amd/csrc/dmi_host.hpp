@@ -253,10 +253,13 @@ struct TableRef {
 // dependent loads per vertex
 void attribute_sequence(const TableRef& t, const uint32_t* seeds, uint32_t n_seeds, std::vector<uint32_t>& seq, const uint8_t* on_boundary = nullptr);
 // the seeds in two parts (first ++ second), e.g. EdgebreakerResult::init_rev ++ processed
+// progress (optional): where the walk publishes its output while it runs — `host` once the output array is in place (it does not move afterwards), `written`
+// every 2^16 entries (release: the entries below it are readable) — so that another thread can ship the sequence onwards before the walk is over
+struct SeqProgress { std::atomic<const uint32_t*> host{nullptr}; std::atomic<uint32_t> written{0}; };
 void attribute_sequence(const TableRef& t, const uint32_t* first, uint32_t n_first, const uint32_t* second, uint32_t n_second, std::vector<uint32_t>& seq, const uint8_t* on_boundary = nullptr,
-                        bool second_quad = false /* the second part holds 4·face + k ids */);
-inline void attribute_sequence(const TableRef& t, const EdgebreakerResult& eb, std::vector<uint32_t>& seq, const uint8_t* on_boundary = nullptr) {
-  attribute_sequence(t, eb.init_rev.data(), (uint32_t)eb.init_rev.size(), eb.processed.data(), (uint32_t)eb.processed.size(), seq, on_boundary, eb.processed_quad);
+                        bool second_quad = false /* the second part holds 4·face + k ids */, SeqProgress* progress = nullptr);
+inline void attribute_sequence(const TableRef& t, const EdgebreakerResult& eb, std::vector<uint32_t>& seq, const uint8_t* on_boundary = nullptr, SeqProgress* progress = nullptr) {
+  attribute_sequence(t, eb.init_rev.data(), (uint32_t)eb.init_rev.size(), eb.processed.data(), (uint32_t)eb.processed.size(), seq, on_boundary, eb.processed_quad, progress);
 }
 void vertex_boundary_flags(const TableRef& t, std::vector<uint8_t>& on_boundary);   // parallel slices for a large table
 

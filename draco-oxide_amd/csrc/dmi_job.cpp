@@ -17,7 +17,46 @@ thread_local DevPool* g_active_pool = nullptr;
 using namespace dmi;
 
 thread_local std::shared_ptr<StreamHolder> g_adopt_stream;
-namespace dmi { thread_local std::unique_ptr<EarlyQuant> g_early_quant; }
+namespace dmi { thread_local std::unique_ptr<EarlyQuant> g_early_quant; thread_local std::shared_ptr<SeqStream> g_seq_stream; }
+
+bool dmi::SeqStream::start(int dev, hipStream_t s, uint32_t capacity) {
+  device = dev; stream = s; cap = capacity;
+  if (!s || !capacity) return false;
+  mem.init(dev, s, (size_t)capacity * 4 + 4096);
+  d_seq = mem.take<uint32_t>(capacity);
+  if (!d_seq) return false;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ev = nullptr; return false; }
+  uploader = std::thread([this] {
+    if (hipSetDevice(device) != hipSuccess) { failed.store(true); return; }
+    uint32_t sent = 0;
+    constexpr uint32_t kPiece = 1u << 18;   // 1 MiB pieces: large enough for the link, small enough that the last one is short
+    for (;;) {
+      const uint32_t fin = final_n.load(std::memory_order_acquire);
+      const uint32_t have = fin != 0xFFFFFFFFu ? fin : progress.written.load(std::memory_order_acquire);
+      const uint32_t* h = progress.host.load(std::memory_order_acquire);
+      if (h && have > cap) { failed.store(true); return; }
+      if (h && (have - sent >= kPiece || (fin != 0xFFFFFFFFu && have > sent))) {
+        if (hipMemcpyAsync(d_seq + sent, h + sent, (size_t)(have - sent) * 4, hipMemcpyHostToDevice, stream) != hipSuccess) { (void)hipGetLastError(); failed.store(true); return; }
+        sent = have;
+        continue;
+      }
+      if (fin != 0xFFFFFFFFu) break;
+      std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
+    host = progress.host.load(); n = sent;
+    if (hipEventRecord(ev, stream) != hipSuccess) { (void)hipGetLastError(); failed.store(true); }
+  });
+  return true;
+}
+void dmi::SeqStream::finish(uint32_t n_entries) {
+  final_n.store(n_entries, std::memory_order_release);
+  if (uploader.joinable()) uploader.join();
+}
+dmi::SeqStream::~SeqStream() {
+  if (uploader.joinable()) { final_n.store(0, std::memory_order_release); uploader.join(); }
+  if (stream && d_seq) (void)hipStreamSynchronize(stream);   // (nothing may still be copying into the array when its chunk goes back to the cache)
+  if (ev) (void)hipEventDestroy(ev);
+}
 
 static std::mutex g_stage_mutex;
 static std::vector<HostStage*> g_stages;   // (never freed: process-lifetime staging)
@@ -542,9 +581,17 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
       job->donated.device = dev->donor->device; job->donated.stream = s; job->donated.zero = false;
       job->donated.chunks.swap(dev->donor->chunks);
     }   // (no donor: the stage's array is read once, by launch_face_records below, on this same stream — the stage outlives job creation; no copy)
-    if ((rc = t.seq.alloc((size_t)t.n_seq * 4))) return rc;
+    // the sequence: already on the device when the call shipped it during the walk (SeqStream) — job creation waits for the last piece only
+    if (g_seq_stream && !g_seq_stream->failed.load() && g_seq_stream->host == seq_of[0] && g_seq_stream->n == t.n_seq && g_seq_stream->device == cfg.device && t.n_seq) {
+      HIP_TRY(hipStreamWaitEvent(s, g_seq_stream->ev, 0));
+      t.seq.p = g_seq_stream->d_seq; t.seq.bytes = (size_t)t.n_seq * 4; t.seq.pooled = true;   // (a view: the stream object owns the memory, the job keeps it alive)
+      job->seq_stream = g_seq_stream;
+    } else {
+      if ((rc = t.seq.alloc((size_t)t.n_seq * 4))) return rc;
+      if (t.n_seq) HIP_TRY(hipMemcpyAsync(t.seq.p, seq_of[0], (size_t)t.n_seq * 4, hipMemcpyHostToDevice, s));
+    }
+    g_seq_stream.reset();
     if ((rc = t.s2p.alloc((size_t)t.n_seq * 4))) return rc;
-    if (t.n_seq) HIP_TRY(hipMemcpyAsync(t.seq.p, seq_of[0], (size_t)t.n_seq * 4, hipMemcpyHostToDevice, s));
     launch_fill_u32(d_rank, t.V, kNone, s);
     launch_rank_and_points(t.seq.as<uint32_t>(), t.n_seq, dev->c2v, dev->c2p, d_rank, t.s2p.as<uint32_t>(), s);
     launch_face_records(dev->c2v, d_rank, dev->opp, F, t.frec.as<uint32_t>(), s);

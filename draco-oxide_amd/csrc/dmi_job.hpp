@@ -220,10 +220,11 @@ struct StreamHolder {
 };
 extern thread_local std::shared_ptr<StreamHolder> g_adopt_stream;   // set by a dmi_meshes_prepare worker around dmi_job_create
 
-namespace dmi { struct EarlyQuant; }   // (below, behind TempDev)
+namespace dmi { struct EarlyQuant; struct SeqStream; }   // (below, behind TempDev)
 struct dmi_job {
   dmi_config cfg{};
   std::shared_ptr<EarlyQuant> early;   // (whole-mesh one-shot calls: see EarlyQuant)
+  std::shared_ptr<SeqStream> seq_stream;   // (whole-mesh one-shot calls: the sequence array shipped during the walk — tables[0].seq views its memory)
   dmi_debug debug{};                   // the switches of the call that created the job (cfg.debug points here): dmi_job_encode / dmi_jobs_encode work under them
   hipStream_t stream = nullptr;
   std::shared_ptr<StreamHolder> stream_owner;   // set when the library created the stream
@@ -379,6 +380,30 @@ struct EarlyQuant {
   }
 };
 extern thread_local std::unique_ptr<EarlyQuant> g_early_quant;   // set by dmi_encode_mesh_device around mesh_prepare_impl; taken by job_create_impl
+
+// The universal sequence of a whole-mesh call shipped to the device WHILE the sequencer writes it (round 6).  Job creation used to start with the upload of
+// the finished sequence — 20 MB, ≈ 0.4 ms of a 0.9 ms device span per 10M triangles, with the device idle through the 35 ms the sequencer took to write it.
+// The walk publishes its progress every 2^16 entries (SeqProgress); a thread of this object copies what is new to a device array on a stream of its own;
+// job creation takes the array over (it only waits for the last piece).  Set by dmi_encode_mesh_device for large one-shot calls, used by
+// build_connectivity (the universal sequencer), adopted by job_create_impl when the sequence it is handed IS the streamed one.
+struct SeqStream {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  TempDev mem;
+  uint32_t* d_seq = nullptr;
+  uint32_t cap = 0;                 // entries d_seq holds
+  SeqProgress progress;
+  std::atomic<uint32_t> final_n{0xFFFFFFFFu};   // set by the sequencer's caller when the walk is over
+  std::atomic<bool> failed{false};
+  std::thread uploader;
+  hipEvent_t ev = nullptr;          // recorded behind the last piece
+  const uint32_t* host = nullptr;   // (after join) the array that was shipped
+  uint32_t n = 0;                   // … and its length
+  bool start(int dev, hipStream_t s, uint32_t capacity);
+  void finish(uint32_t n_entries);  // the walk is over: ship the rest, record `ev`, join
+  ~SeqStream();
+};
+extern thread_local std::shared_ptr<SeqStream> g_seq_stream;
 int early_quantize_issue(const dmi_attribute* atts_dev, uint32_t n_atts, const dmi_config& cfg, hipStream_t side, std::unique_ptr<EarlyQuant>& out);
 
 

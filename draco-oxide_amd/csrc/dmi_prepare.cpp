@@ -197,9 +197,11 @@ extern "C++" int dmi::build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std
   Pooled<uint8_t> on_boundary_p;
   std::vector<uint8_t>& on_boundary = on_boundary_p.v;
   const uint8_t* boundary_flags = on_device ? pre->on_boundary : nullptr;   // per vertex: on a boundary of the universal table (the device pass computes them with the left-most corners)
+  std::shared_ptr<SeqStream> seq_stream = g_seq_stream;   // (a whole-mesh call ships the universal sequence to the device while the walk writes it)
   auto sequence_universal = [&] {
     TableRef tr{o.ct.F, o.ct.V, o.ct.c2v, o.ct.opp, o.ct.lmc, o.ct.quad, o.ct.no_boundary};
-    attribute_sequence(tr, o.eb, o.seqs[0], boundary_flags ? boundary_flags : (on_boundary.empty() ? nullptr : on_boundary.data()));
+    attribute_sequence(tr, o.eb, o.seqs[0], boundary_flags ? boundary_flags : (on_boundary.empty() ? nullptr : on_boundary.data()), seq_stream ? &seq_stream->progress : nullptr);
+    if (seq_stream) seq_stream->finish((uint32_t)o.seqs[0].size());
   };
 
   auto build_att_tables = [&] {
@@ -648,6 +650,12 @@ int dmi_encode_mesh_device(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buff
       (void)hipEventDestroy(ev);
     };
   }
+  // … and the universal sequence goes up WHILE the sequencer writes it (SeqStream): job creation finds it on the device
+  if (mesh->num_faces >= kDeviceTablesMinFaces && !dbg_on(DMI_DBG_NO_EARLY)) {
+    auto ss = std::make_shared<SeqStream>();
+    if (ss->start(device, library_group_stream(device, 0) != s ? library_group_stream(device, 0) : library_group_stream(device, 1), mesh->atts[0].num_unique)) g_seq_stream = ss;
+  }
+  struct SeqGuard { ~SeqGuard() { g_seq_stream.reset(); } } seq_guard;
   int rc = mesh_prepare_impl(&shadow, cfg, &head, &job, &src);
   std::vector<std::vector<uint8_t>> host_values;
   if (rc == kNeedHostValues) {   // outside the order-free class: the reference's serial walks and the host relabelling read everything on the host
