@@ -56,6 +56,50 @@ def usable_cpus():
     return n
 
 
+PASS_KERNEL_PREFIXES = ("k_value_ranges", "k_value_quantize_rec", "k_seq_quantize", "k_i32_minmax_final", "k_predict_fused", "k_predict_packed", "k_orient_summary",
+                        "k_pred_parallelogram", "k_pred_texcoord", "k_pred_delta", "k_seq_gather_rec", "k_texcoord_fixup")
+
+
+def measure_traffic(grid):
+    """HBM bytes of the quantize+predict pass per step from the PMC counters, measured by THIS run: two child processes — `rocprofv3 --pmc FETCH_SIZE` and
+    `--pmc WRITE_SIZE` (the two cannot share a pass: MI355X_MICROARCH.md) around `python3 bench.py --steps 2 --warmup 1` without the side measurements — started
+    BEFORE this process touches the GPU.  Counter unit KiB; FETCH_SIZE doubled (gfx950 reports half of a wide coalesced read: exact for the streaming kernels,
+    an upper bound for the gather kernels); summed over every kernel that quantizes or predicts (early stage included), per step.  None when rocprofv3 is not
+    there or fails (the line then carries `traffic_profiled`: the last committed session's figure)."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return None
+    steps, warm = 2, 1
+    sums = {}
+    tmp = tempfile.mkdtemp(prefix="dmi_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [rp, "--pmc", counter, "-d", out, "-o", "p", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warm),
+                   "--grid", str(grid), "--no-cpu-baseline", "--no-batch", "--no-scopes", "--no-traffic"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+            hits = glob.glob(out + "/**/*_counter_collection.csv", recursive=True)
+            if r.returncode != 0 or not hits:
+                return None
+            tot = 0.0
+            for row in csv.DictReader(open(hits[0])):
+                m = re.search(r"(k_[a-z_0-9]+)", row["Kernel_Name"])
+                if row["Counter_Name"] == counter and m and m.group(1).startswith(PASS_KERNEL_PREFIXES):
+                    tot += float(row["Counter_Value"])
+            sums[counter] = tot * 1024 / (steps + warm)
+        return int(2 * sums["FETCH_SIZE"] + sums["WRITE_SIZE"])
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def profiled_traffic():
     """The pass's HBM traffic as the last committed profiling session measured it (profiles/round*_bench.json: FETCH_SIZE / WRITE_SIZE in separate
     rocprofv3 --pmc passes, scripts/profile_round.sh) — NOT measured in this run (`traffic` is, when the run is part of such a session)."""
@@ -407,7 +451,13 @@ def main():
     ap.add_argument("--no-scopes", action="store_true", help="skip the sub-scope measurements (N=1 only, outside the timed steps)")
     ap.add_argument("--batch-meshes", type=int, default=1024, help="size of the sharded batch at N > 1")
     ap.add_argument("--transcode-files", type=int, default=1024, help="GLB files of the transcode regime (BASELINE configs[3]); 0 = skip")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic (N=1 only)")
     args = ap.parse_args()
+    # roofline.traffic of THIS run: child processes under rocprofv3, before this process touches the GPU (N = 1 only; DMI_ROOFLINE_TRAFFIC: a profiling session
+    # — scripts/profile_round.sh — hands its own counters over instead)
+    measured_traffic = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_traffic and not os.environ.get("DMI_ROOFLINE_TRAFFIC"):
+        measured_traffic = measure_traffic(args.grid)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -510,7 +560,7 @@ def main():
         longest_symbols = n_tris // 2 * 3   # the position stream: V·3 symbols
         hybrid = bool(tm["host_chains"])
         gpu_ms = stages["tables_ms"] + stages["quantize_ms"] + stages["predict_ms"] + stages["histogram_ms"] + stages["table_ms"]
-        traffic = os.environ.get("DMI_ROOFLINE_TRAFFIC")   # set by scripts/profile_round.sh from the rocprofv3 PMC passes of the same session; never read from a file
+        traffic = os.environ.get("DMI_ROOFLINE_TRAFFIC") or measured_traffic   # a profiling session's counters (scripts/profile_round.sh), else this run's own child runs; never read from a file
         line = {
             "metric": "Mtriangles/sec encoded (bit-exact .drc) at 1/2/4/8 MI355X vs CPU ref",
             "value": round(value, 3), "unit": "Mtriangles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -528,10 +578,11 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                          "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBPS, 5), "achievable_gbps": HBM_ACHIEVABLE_GBPS,
                          "traffic": int(traffic) if traffic else None,
+                         "traffic_over_algorithmic": round(int(traffic) / max(int(tm["predict_bytes"]), 1), 3) if traffic else None,
                          "traffic_profiled": profiled_traffic(),
                          "kernel": ("quantize+predict pass of a call whose values are in HBM when it starts = EVERY launch that quantizes or predicts: the early stage (value ranges, value-order "
                                     "quantization into 16-byte records + the quantized values' min/max partials; issued behind the device stage's last read-back, so it runs alone during the host walks) "
-                                    "+ every launch of the job's stream between the end of the host walks and the histogram stage (fused predictor sweep reading the records, fix-up of deferred entries)"
+                                    "+ every launch of the job's stream between the end of the host walks and the histogram stage (coding-order gather of the records, fused predictor sweep, fix-up of deferred entries)"
                                     if stages["early_ms"] > 0 else
                                     "quantize+predict pass = every launch between the first kernel and the histogram stage of one step "
                                     "(value ranges, coding-order gather + quantize, min/max finals, fused predictor sweep)") + ", hipEvent-timed on the streams the kernels launch on, inside the timed steps",

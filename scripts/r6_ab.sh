@@ -9,7 +9,7 @@ mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 for v in "$@"; do
   lib=$root/draco-oxide_amd/libdraco_mi.so; [ "$v" != base ] && lib=$lib.$v
-  DMI_LIBRARY=$lib timeout 600 rocprofv3 --kernel-trace --stats -d "$out/$v" -o st --output-format csv -- python3 "$root/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-batch --no-scopes > "$out/$v.log" 2>&1
+  DMI_LIBRARY=$lib timeout 600 rocprofv3 --kernel-trace --stats -d "$out/$v" -o st --output-format csv -- python3 "$root/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-batch --no-scopes --no-traffic > "$out/$v.log" 2>&1
   python3 - "$out" "$v" <<'PY'
 import csv, glob, sys, re, json
 out, v = sys.argv[1], sys.argv[2]

@@ -11,7 +11,7 @@ tests=${*:-tests/test_gpu_device_mesh.py tests/test_gpu_parity.py tests/test_gpu
 timeout 1500 python3 -m pytest $tests -x -q -m gpu > "$out/tests.log" 2>&1
 echo "tests rc=$?"; tail -3 "$out/tests.log"
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d "$out/stats" -o st --output-format csv -- python3 "$root/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-batch --no-scopes > "$out/bench.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d "$out/stats" -o st --output-format csv -- python3 "$root/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-batch --no-scopes --no-traffic > "$out/bench.log" 2>&1
 cd "$root"
 python3 - "$out" <<'PY'
 import csv, glob, sys, re, json

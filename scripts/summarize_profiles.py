@@ -32,14 +32,14 @@ def agg(sub, names):
     return acc
 
 
-PASS_PREFIXES = ("k_value_ranges", "k_seq_quantize", "k_i32_minmax_final", "k_predict_fused", "k_predict_packed", "k_orient_summary", "k_pred_parallelogram",
+# everything that quantizes or predicts (round 6: the early stage — value ranges + value-order quantization, issued behind the device stage's last read-back — is
+# PART of the pass: SURVEY §8d's bytes cover it, so do the durations and the traffic; round 5 listed it beside the pass)
+PASS_PREFIXES = ("k_value_ranges", "k_value_quantize_rec", "k_seq_quantize", "k_i32_minmax_final", "k_predict_fused", "k_predict_packed", "k_orient_summary", "k_pred_parallelogram",
                  "k_pred_texcoord", "k_pred_delta", "k_seq_gather_rec", "k_texcoord_fixup")
-EARLY_PREFIXES = ("k_value_ranges", "k_value_quantize_rec", "k_i32_minmax_final")   # round 5: issued on a side stream BEFORE the host walks when the call has an early stage
+EARLY_PREFIXES = ("k_value_ranges", "k_value_quantize_rec")
 F = agg("fetch", ["FETCH_SIZE"])["FETCH_SIZE"]
 W = agg("write", ["WRITE_SIZE"])["WRITE_SIZE"]
 has_early = any(n.startswith("k_seq_gather_rec") for n in set(F) | set(W))
-if has_early:
-    PASS_PREFIXES = tuple(p for p in PASS_PREFIXES if p not in ("k_value_ranges", "k_i32_minmax_final"))
 tf = tw = 0.0
 ef = ew = 0.0
 rows = []
@@ -50,7 +50,7 @@ for n in sorted(set(F) | set(W)):
     if n.startswith(PASS_PREFIXES):
         tf += sum(f) * 1024 / pmc_steps
         tw += sum(w) * 1024 / pmc_steps
-    elif has_early and n.startswith(EARLY_PREFIXES):
+    if has_early and n.startswith(EARLY_PREFIXES):
         ef += sum(f) * 1024 / pmc_steps
         ew += sum(w) * 1024 / pmc_steps
 traffic = int(2 * tf + tw)
@@ -61,19 +61,29 @@ if traffic_only:
 os.makedirs("profiles", exist_ok=True)
 stats = find("stats", "_kernel_stats.csv")
 out = [f"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-batch --no-scopes   ({tag}, MI355X)",
-       "kernel, calls, total_ms, avg_us, pct"]
+       "# min_us beside avg_us: a kernel that shares the device with another queue's copy shows it in its average, not in its minimum",
+       "kernel, calls, total_ms, avg_us, min_us, pct"]
+pass_avg = pass_min = 0.0
 if stats:
     for r in csv.DictReader(open(stats)):
-        out.append(f"{short(r['Name'])}, {r['Calls']}, {float(r['TotalDurationNs']) / 1e6:.3f}, {float(r['AverageNs']) / 1e3:.2f}, {r['Percentage']}")
+        n = short(r["Name"])
+        out.append(f"{n}, {r['Calls']}, {float(r['TotalDurationNs']) / 1e6:.3f}, {float(r['AverageNs']) / 1e3:.2f}, {float(r['MinNs']) / 1e3:.2f}, {r['Percentage']}")
+        if n.startswith(PASS_PREFIXES):
+            pass_avg += float(r["AverageNs"]) / 1e3
+            pass_min += float(r["MinNs"]) / 1e3
+    out.append(f"# quantize+predict pass (every kernel that quantizes or predicts: {', '.join(PASS_PREFIXES[:2] + PASS_PREFIXES[-2:])} …): sum of averages {pass_avg:.1f} us, of minima {pass_min:.1f} us "
+               f"= {659959872 / max(pass_avg, 1e-9) / 1e6 / 8000:.3f} / {659959872 / max(pass_min, 1e-9) / 1e6 / 8000:.3f} of 8 TB/s for the 659 959 872 algorithmic bytes of the 10M-triangle workload "
+               "(the bench line's hipEvent spans add the gaps between the launches)")
 open(f"profiles/{tag}_kernel_stats.csv", "w").write("\n".join(out) + "\n")
 
 lines = [f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps {pmc_steps - 1} --warmup 1 --no-cpu-baseline --no-batch --no-scopes ({tag})",
          "# per-launch averages, MB; counter unit KiB.  fetch_x2 = FETCH_SIZE doubled (gfx950 reports half of a wide coalesced read; exact for the",
          "# streaming kernels, an upper bound for the gather kernels whose access width is uncalibrated — MI355X_MICROARCH.md §HBM)",
          "kernel, launches, fetch_MB, fetch_x2_MB, write_MB"] + rows
-lines.append(f"# quantize+predict pass per step: fetch {tf / 1e6:.1f} MB raw / {2 * tf / 1e6:.1f} MB doubled, write {tw / 1e6:.1f} MB, total {traffic / 1e6:.1f} MB")
+lines.append(f"# quantize+predict pass per step (early stage included): fetch {tf / 1e6:.1f} MB raw / {2 * tf / 1e6:.1f} MB doubled, write {tw / 1e6:.1f} MB, total {traffic / 1e6:.1f} MB "
+             f"= {traffic / 659959872:.2f} x the 659 959 872 algorithmic bytes")
 if has_early:
-    lines.append(f"# early stage per step (value ranges + value-order quantization into records + the quantized values' min/max, on a side stream before the host walks; NOT in the pass above): "
+    lines.append(f"# of which the early stage (value ranges + value-order quantization into records, behind the device stage's read-backs): "
                  f"fetch {ef / 1e6:.1f} MB raw / {2 * ef / 1e6:.1f} MB doubled, write {ew / 1e6:.1f} MB, total {(2 * ef + ew) / 1e6:.1f} MB")
 open(f"profiles/{tag}_pmc_traffic.csv", "w").write("\n".join(lines) + "\n")
 
