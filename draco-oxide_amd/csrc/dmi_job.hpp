@@ -416,9 +416,18 @@ struct AttStage {
   std::vector<Item> items;            // sorted by member
   std::vector<AttItemDesc> descs;
   size_t corners = 0, verts = 0;
-  uint32_t *d_c2v = nullptr, *d_opp = nullptr;
+  uint32_t *d_c2v = nullptr, *d_opp = nullptr, *d_lmc = nullptr;
   size_t rb_items = 0, rb_info = 0, rb_seam = 0, rb_c2v = 0, rb_opp = 0, rb_lmc = 0;   // offsets in the group's host staging
   const uint8_t* hp = nullptr;        // that staging (set by issue)
+  // Round 6: what comes back.  The attribute's opposite corners are NOT read back (opposite_att[c] = seam[c] ? none : opposite[c]: the host forms them from
+  // the universal table and the seam flags it has anyway — 12 bytes per face less on the link) unless want_opp (dmi_device_attribute_table hands them
+  // to its caller); of the left-most corners — one per ATTRIBUTE vertex, all items' back to back, their number only known once the kernels have run — the
+  // first lmc_first entries come back with the rest of the stage (2 × the universal vertices + 4096: an attribute has its universal vertices plus one per
+  // seam crossing) and complete() fetches what lies beyond once the counts are in: 2–3 bytes per face instead of the worst case's 12.
+  bool want_opp = false;
+  size_t lmc_first = 0;
+  hipStream_t stream = nullptr;
+  int complete();                     // after the stage's event: the left-most corners beyond lmc_first, if any (a blocking copy; rare)
   void add(uint32_t member, uint32_t k, uint32_t F, uint32_t vcap, uint32_t map_off_words);
   size_t layout(size_t at);           // places the read-back regions from offset `at` on; returns their end
   size_t device_bytes() const;

@@ -227,7 +227,15 @@ extern "C++" int dmi::build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std
         a.alias_of = -1; a.interior_seams = true; a.num_vertices = pa.nv;
         pool_fit(a.seam_edge, C); a.seam_edge.assign(pa.seam, pa.seam + C);
         pool_fit(a.c2v, C); a.c2v.assign(pa.c2v, pa.c2v + C);
-        pool_fit(a.opp, C); a.opp.assign(pa.opp, pa.opp + C);
+        pool_fit(a.opp, C);
+        if (pa.opp) a.opp.assign(pa.opp, pa.opp + C);
+        else {   // not read back (AttStage): the attribute's opposite corner is the universal one unless the edge is a seam of the attribute
+          a.opp.resize(C);
+          const uint32_t* uo = o.ct.opp;
+          uint32_t* ao = a.opp.data();
+          if (o.ct.quad) for (size_t c = 0; c < C; ++c) { const uint32_t x = uo[c]; ao[c] = (pa.seam[c] || x == kNone) ? kNone : x - (x >> 2); }   // (4·face + k ids → 3·face + k)
+          else for (size_t c = 0; c < C; ++c) ao[c] = pa.seam[c] ? kNone : uo[c];
+        }
         pool_fit(a.lmc, pa.nv); a.lmc.assign(pa.lmc, pa.lmc + pa.nv);
         return;
       }
@@ -378,6 +386,7 @@ int dmi_device_attribute_table(const dmi_mesh* mesh, const dmi_config* cfg, uint
   const size_t C = (size_t)F * 3, nv = (size_t)Vcap + 1, parts = scan_partials_words((uint32_t)nv);
   if (at.num_points < P) return fail(DMI_ERR_INVALID_ARGUMENT, "attribute has fewer points than the Position attribute");
   AttStage st;
+  st.want_opp = true;
   const size_t map_pos_at = align256(C * 4), map_att_at = map_pos_at + (pos.point_to_value ? align256((size_t)P * 4) : 0), up = map_att_at + (at.point_to_value ? align256((size_t)at.num_points * 4) : 0);
   st.add(0, 0, F, Vcap, at.point_to_value ? (uint32_t)(map_att_at / 4) : kNone);
   const size_t rb_words = align256(up), host_need = st.layout(rb_words + 256 + align256(sizeof(ConnMeshDesc)));
@@ -411,6 +420,7 @@ int dmi_device_attribute_table(const dmi_mesh* mesh, const dmi_config* cfg, uint
   int rc = st.issue(a, mem, hp, s);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(s));
+  if ((rc = st.complete())) return rc;
   *flags = reinterpret_cast<const uint32_t*>(hp + rb_words)[0];
   const AttInfo info = *reinterpret_cast<const AttInfo*>(hp + st.rb_info);
   *num_vertices = 0; *interior_seams = 0;

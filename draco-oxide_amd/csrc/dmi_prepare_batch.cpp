@@ -84,6 +84,7 @@ struct PrepGroup {
     std::lock_guard<std::mutex> lock(wait_mutex);
     if (tables_in) return DMI_OK;
     HIP_TRY(hipEventSynchronize(ev_tables_borrowed ? ev_tables_borrowed : ev_tables));
+    if (int rc = (adopted ? adopted->conn.att : att).complete()) return rc;   // (left-most corners of the attribute tables beyond what came back with the stage: rare)
     tables_in = true;
     return DMI_OK;
   }

@@ -15,7 +15,7 @@ void dmi::AttStage::add(uint32_t member, uint32_t k, uint32_t F, uint32_t vcap, 
 size_t dmi::AttStage::layout(size_t at) {
   if (corners >= (1ull << 32) || verts >= (1ull << 32)) { items.clear(); descs.clear(); corners = verts = 0; }   // (too large for one launch: the host builds them)
   rb_items = at; rb_info = rb_items + align256(items.size() * sizeof(AttItemDesc)); rb_seam = rb_info + align256(items.size() * sizeof(AttInfo));
-  rb_c2v = rb_seam + align256(corners); rb_opp = rb_c2v + align256(corners * 4); rb_lmc = rb_opp + align256(corners * 4);
+  rb_c2v = rb_seam + align256(corners); rb_opp = rb_c2v + align256(corners * 4); rb_lmc = rb_opp + (want_opp ? align256(corners * 4) : 0);
   return rb_lmc + align256(corners * 4);
 }
 size_t dmi::AttStage::device_bytes() const { return corners * 13 + (verts + 1) * 5 + items.size() * (sizeof(AttItemDesc) + sizeof(AttInfo)) + scan_partials_words((uint32_t)verts + 1) * 4 + 4096; }
@@ -34,12 +34,25 @@ int dmi::AttStage::issue(const ConnArgs& a, TempDev& mem, uint8_t* host, hipStre
   t.items = d_items;
   HIP_TRY(att_tables_clear(t, s));
   launch_att_tables(a, t, s);
-  d_c2v = t.c2v; d_opp = t.opp;
+  d_c2v = t.c2v; d_opp = t.opp; d_lmc = t.lmc; stream = s;
+  lmc_first = std::min(corners, 2 * verts + 4096);
   HIP_TRY(hipMemcpyAsync(host + rb_info, t.info, items.size() * sizeof(AttInfo), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(host + rb_seam, t.seam, corners, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(host + rb_c2v, t.c2v, corners * 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(host + rb_opp, t.opp, corners * 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(host + rb_lmc, t.lmc, corners * 4, hipMemcpyDeviceToHost, s));
+  if (want_opp) HIP_TRY(hipMemcpyAsync(host + rb_opp, t.opp, corners * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(host + rb_lmc, t.lmc, lmc_first * 4, hipMemcpyDeviceToHost, s));
+  return DMI_OK;
+}
+int dmi::AttStage::complete() {
+  if (items.empty() || !hp || !d_lmc) return DMI_OK;
+  const AttInfo* info = reinterpret_cast<const AttInfo*>(hp + rb_info);
+  size_t total = 0;
+  for (size_t q = 0; q < items.size(); ++q) if (info[q].done) total = std::max(total, (size_t)info[q].pad + info[q].num_vertices);
+  if (total <= lmc_first) return DMI_OK;
+  if (total > corners) return fail(DMI_ERR_HIP, "attribute corner tables: vertex count out of range");
+  HIP_TRY(hipMemcpyAsync(const_cast<uint8_t*>(hp) + rb_lmc + lmc_first * 4, d_lmc + lmc_first, (total - lmc_first) * 4, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  lmc_first = total;
   return DMI_OK;
 }
 }  // extern "C++"
@@ -56,7 +69,7 @@ void dmi::att_stage_fill(const AttStage& st, uint32_t member, uint32_t n_nonpos,
     pa.ready = true; pa.interior = info[q].interior != 0; pa.nv = info[q].num_vertices;
     pa.seam = st.hp + st.rb_seam + it->corner_off;
     pa.c2v = reinterpret_cast<const uint32_t*>(st.hp + st.rb_c2v) + it->corner_off;
-    pa.opp = reinterpret_cast<const uint32_t*>(st.hp + st.rb_opp) + it->corner_off;
+    pa.opp = st.want_opp ? reinterpret_cast<const uint32_t*>(st.hp + st.rb_opp) + it->corner_off : nullptr;   // (null: seam ? none : the universal table's)
     pa.lmc = reinterpret_cast<const uint32_t*>(st.hp + st.rb_lmc) + info[q].pad;
     pa.d_c2v = st.d_c2v + it->corner_off; pa.d_opp = st.d_opp + it->corner_off;
   }
