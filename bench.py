@@ -370,36 +370,40 @@ def batch_sharded(n_meshes, rank, world, local_rank, gather_dev, steps=2):
 
 
 def transcode_sharded(n_files, rank, world, local_rank, gather_dev, steps=2):
-    """BASELINE configs[3] over the N ranks of this run, as it is worded: n GLB files through gltf.transcode_files in the torch.distributed job —
-    every rank parses the JSON of all files, the primitives are dealt by the triangle counts the JSON states (LPT), each rank builds
-    (dmi_meshes_build), prepares and encodes ONLY its share, rank 0 gathers the blobs (RCCL) and reassembles every file.  Strong scaling."""
+    """BASELINE configs[3] over the N ranks of this run, as it is worded: n GLB files through gltf.transcode_files in the torch.distributed job (round 6) —
+    the FILES are dealt to the ranks by their size in bytes (LPT) before anything is parsed, each rank runs dmi_transcode_assets over its own files (parse
+    pool, build / prepare / encode pipeline, assembly), the finished files are gathered onto rank 0 (RCCL): no JSON is parsed on a rank that does not own
+    it, nothing is reassembled on rank 0.  Strong scaling."""
     from draco_oxide_amd import gltf
     glbs, total = synth.batch_glbs(n_files)
     cfg = dmi.Config(device=local_rank)
     gltf.transcode_files(glbs, cfg, device=gather_dev)
     dist.barrier()
     torch.cuda.synchronize()
-    built = 0
+    owned, gather_s, own_s = 0, 0.0, 0.0
     t0 = time.perf_counter()
     for _ in range(steps):
         tm = {}
         res = gltf.transcode_files(glbs, cfg, device=gather_dev, timings=tm)
-        built = tm["primitives_built"]
+        owned = tm.get("files_owned", 0)
+        gather_s += tm.get("gather_s", 0.0)
+        own_s += tm.get("transcode_s", 0.0)
     torch.cuda.synchronize()
     dist.barrier()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt, float(built), -float(built)], dtype=torch.float64, device=gather_dev)
+    t = torch.tensor([dt, float(owned), -float(owned), gather_s / steps, own_s / steps], dtype=torch.float64, device=gather_dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt, built_max, built_min = float(t[0]), int(t[1]), int(-t[2])
+    dt, own_max, own_min, g_max, o_max = float(t[0]), int(t[1]), int(-t[2]), float(t[3]), float(t[4])
     if rank != 0:
         return None
     doc, binary = gltf.read_glb(glbs[n_files // 2])
     mesh, _ = gltf.primitive_to_mesh(doc, binary, doc["meshes"][0]["primitives"][0])
-    return {"workload": f"BASELINE configs[3]: {n_files} GLB files in memory through gltf.transcode_files over {world} rank(s): primitives dealt from the JSON's counts before anything is built, "
-                        "each rank builds / prepares / encodes its share, blobs gathered on rank 0, files reassembled there", "scaling": "strong", "n_gpus": world,
+    return {"workload": f"BASELINE configs[3]: {n_files} GLB files in memory through gltf.transcode_files over {world} rank(s): files dealt by size before anything is parsed, "
+                        "each rank transcodes its own files inside the library, finished files gathered on rank 0", "scaling": "strong", "n_gpus": world,
             "triangles": int(total), "ms_per_step": round(dt / steps * 1e3, 2), "value": round(total * steps / dt / 1e6, 2), "unit": "Mtriangles/s",
-            "primitives_built_per_rank_min_max": [built_min, built_max], "files_on_rank0": len(res),
-            "sample_blob_equals_whole_mesh_encode": bool(res[n_files // 2][1][0] == dmi.encode_mesh(mesh, cfg))}
+            "files_owned_per_rank_min_max": [own_min, own_max], "files_on_rank0": len(res),
+            "own_files_ms_max_over_ranks": round(o_max * 1e3, 2), "gather_ms_max_over_ranks": round(g_max * 1e3, 2),
+            "sample_blob_equals_whole_mesh_encode": bool(bytes(res[n_files // 2][1][0]) == dmi.encode_mesh(mesh, cfg))}
 
 
 def transcode_one_process(n_files, devices, steps=3):

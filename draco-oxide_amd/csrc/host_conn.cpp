@@ -529,10 +529,21 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
       for (size_t j : own) { pool_fit(fed[j], cap); fed[j].resize(cap); }
       size_t at = cap;
       if (masks_ok) {   // no table look-ups: the traversal recorded which edges every face emits
+        // Seams are rare (a fraction of a percent of the edges): a byte per FACE — does any of its three edges lie on a seam of any of these attributes? —
+        // lets every other face pass with one sequential look-up instead of a gather and a store per emitted edge (≈ 8 of this step's ≈ 14 ns per face;
+        // the flag arrays start as zeros, only the faces on a seam write into them)
+        Pooled<uint8_t> fsum_p(t.F, (uint8_t)0);
+        uint8_t* const fsum = fsum_p.v.data();
+        for (size_t j : own) {
+          const uint8_t* se = t.att[j].seam_edge.data();
+          for (size_t f = 0; f < t.F; ++f) fsum[f] |= (uint8_t)(se[3 * f] | se[3 * f + 1] | se[3 * f + 2]);
+          std::memset(fed[j].data(), 0, cap);
+        }
         for (size_t i = n; i-- > 0;) {
           const uint32_t m = w.symbols[i] >> 4;
           if (!m) continue;
           const uint32_t c = corner_at(i);
+          if (!fsum[c / 3]) { const uint32_t k = kBits3[m & 7u]; total += k; at -= k; for (size_t j : own) zeros[j] += k; continue; }
           const uint32_t cs[3] = {c, corner_next(c), corner_prev(c)};
           for (int k = 0; k < 3; ++k) {
             if (!(m >> k & 1u)) continue;
