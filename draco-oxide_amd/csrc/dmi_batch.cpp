@@ -5,6 +5,19 @@
 
 using namespace dmi;
 
+namespace {
+// the chain launches of batch encodes in flight per device (see jobs_encode_impl)
+struct ChainSlots { std::mutex m; std::condition_variable cv; int in_use[64] = {0}; };
+ChainSlots& chain_slots() { static ChainSlots c; return c; }
+struct ChainSlot {
+  int d;
+  explicit ChainSlot(int device) : d(device & 63) { ChainSlots& c = chain_slots(); std::unique_lock<std::mutex> lock(c.m); c.cv.wait(lock, [&] { return c.in_use[d] < 2; }); ++c.in_use[d]; }
+  ~ChainSlot() { ChainSlots& c = chain_slots(); { std::lock_guard<std::mutex> lock(c.m); --c.in_use[d]; } c.cv.notify_one(); }
+  ChainSlot(const ChainSlot&) = delete;
+  ChainSlot& operator=(const ChainSlot&) = delete;
+};
+}  // namespace
+
 // dmi_jobs_encode calls do not share one).
 struct BatchArena {
   int device = -1;
@@ -420,6 +433,10 @@ static int jobs_encode_device(dmi_job** jobs, uint32_t n, dmi_buffer* outs, uint
   };
   fill(first, 0, n_first, main_stream);
   int rc;
+  // At most two batch encodes per DEVICE have their chain launch in flight (round 6).  k_chains is a persistent launch of walker / emitter wavefront pairs
+  // placed per SIMD: a transcoder's two encode threads are what the device takes side by side — with two transcoders on one device (dmi_transcode_assets
+  // over [0, 0], two callers sharing a GPU) four launches held each other's slots and a 7 ms encode took 70–150 ms (scripts/experiments/one_process_weak.py).
+  ChainSlot chain_slot(device);
   if ((rc = first.begin())) return rc;
   if (n_first < n) {
     fill(second, n_first, n, side);
