@@ -298,6 +298,16 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
         if (ar.i < raw[g.which[ar.k]].n_atts) g.row_at[g.meshes[ar.k].item0 + ar.i] = dev; else g.idx_at[ar.k] = dev;
       }
       at = align256(at);
+      //  the spans carry whatever lies between the arrays — interleaved strides, unused attributes, gaps of up to 16 KiB, accessors shared
+      // between primitives — so their total is unrelated to the packed estimate the group was formed with: a group whose spans come to several times its
+      // packed size, or near the kernels' 2^34-byte reach, is packed like any other instead of failing the call
+      size_t packed = 0;
+      for (uint32_t k = 0; k < M; ++k) {
+        const dmi_raw_mesh& m = raw[g.which[k]];
+        for (uint32_t i = 0; i < m.n_atts; ++i) packed += (size_t)m.atts[i].count * m.atts[i].num_components * 4;
+        packed += (size_t)m.num_faces * 3 * component_bytes(m.index_type);
+      }
+      if (at >= ((size_t)1 << 33) || at > 3 * packed + ((size_t)64 << 20)) { g.in_place = false; g.spans.clear(); at = 0; }
     }
     for (uint32_t i = 0; i < NI; ++i) {
       MbItem& it = g.items[i];

@@ -636,14 +636,15 @@ def encode_batch(meshes, cfg=None, devices=None, group=None, device=None):
             j.close()
 
 
-def transcode_files(sources, cfg=None, devices=None, group=None, device=None, pipeline=True, timings=None):
+def transcode_files(sources, cfg=None, devices=None, group=None, device=None, pipeline=True, timings=None, copy=False):
     """BASELINE configs[3]: a LIST of glTF assets (GLB bytes, `.glb` / `.gltf` paths) → their Draco-compressed GLBs
     (io/gltf/transcoder.rs:134-151 runs the files one by one, io/gltf/encode.rs:1827-1842 their primitives one by one; here the triangle
     primitives of ALL files go through the device together: encode_raw_batch).  One GPU, `devices` GPUs of this process (each takes a
     share by triangle count, a thread per device), or the ranks of a torch.distributed job: the primitives are dealt by the triangle
     counts the JSON states, each rank builds and encodes ONLY its share, rank 0 gathers the blobs and reassembles the files.
     Returns [(glb_bytes, [blob, ...]), ...] in input order — on the destination rank; None on the other ranks of a sharded job.  On one device of one
-    process the blobs are memoryviews INTO their file's bytes (they compare equal to bytes; `bytes(blob)` copies one out).
+    process the files are memoryviews of the library's output arena and the blobs memoryviews INTO their file (they compare equal to bytes; `bytes(blob)` copies one
+    out; json.loads / pickle / dict keys want bytes; ONE surviving view keeps every 32 MiB arena block of the call alive) — copy=True returns bytes objects instead.
     timings (optional dict): parse_s (JSON), views_s (accessor views), build_s, prepare_s, encode_s, assemble_s, primitives_built (this rank)."""
     import gc
     import time
@@ -653,7 +654,11 @@ def transcode_files(sources, cfg=None, devices=None, group=None, device=None, pi
     if gc_was:
         gc.disable()
     try:
-        return _transcode_files(sources, cfg, devices, group, device, pipeline, timings)
+        out = _transcode_files(sources, cfg, devices, group, device, pipeline, timings)
+        if copy and out is not None:
+            # bytes objects of the caller's own (picklable, hashable, json-loadable) instead of views that keep the call's arena blocks alive
+            out = [(bytes(g), [bytes(b) for b in blobs]) for g, blobs in out]
+        return out
     finally:
         if gc_was:
             gc.enable()
