@@ -337,16 +337,12 @@ __global__ __launch_bounds__(kBlock) void k_mb_widen(const MbWiden* __restrict__
 }  // namespace
 
 hipError_t mesh_build_clear(const MbArgs& a, size_t vtab_words, size_t ptab_words, hipStream_t s) {
-  hipError_t e;
-  if ((e = hipMemsetAsync(a.vtab, 0xFF, vtab_words * 4, s)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(a.ptab, 0xFF, ptab_words * 4, s)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(a.mesh_out, 0, (size_t)a.M * sizeof(MbMeshOut), s)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(a.vflag + a.total_ap, 0, 4, s)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(a.vused, 0, ((size_t)a.total_ap + 1) * 4, s)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(a.pflag + a.total_points, 0, 4, s)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(a.used, 0, ((size_t)a.total_points + 1) * 4, s)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(a.keep + a.total_faces, 0, 4, s)) != hipSuccess) return e;
-  return hipSuccess;
+  ClearRanges r{};   // (one launch: eight hipMemsetAsync before)
+  r.add(a.vtab, vtab_words * 4, 0xFF); r.add(a.ptab, ptab_words * 4, 0xFF); r.add(a.mesh_out, (size_t)a.M * sizeof(MbMeshOut));
+  r.add(a.vflag + a.total_ap, 4); r.add(a.vused, ((size_t)a.total_ap + 1) * 4); r.add(a.pflag + a.total_points, 4);
+  r.add(a.used, ((size_t)a.total_points + 1) * 4); r.add(a.keep + a.total_faces, 4);
+  launch_clear_ranges(r, s);
+  return hipGetLastError();
 }
 void launch_mesh_build(const MbArgs& a, hipStream_t s) {
   if (!a.M || !a.total_faces || !a.total_ap) return;

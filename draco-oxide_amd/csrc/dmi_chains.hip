@@ -839,8 +839,10 @@ __global__ __launch_bounds__(256) void k_clear_items(const CopyItem* __restrict_
 // the same for a handful of ranges passed BY VALUE (job creation of one mesh: eleven hipMemsetAsync calls were eleven launches of ≈ 5 µs back to back)
 __global__ __launch_bounds__(256) void k_clear_ranges(const ClearRanges r) {
   uint32_t* __restrict__ d = static_cast<uint32_t*>(r.p[blockIdx.y]);
-  const uint64_t n = r.bytes[blockIdx.y] >> 2;
-  for (uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x; v < n; v += (uint64_t)gridDim.x * 256) d[v] = 0u;
+  const uint64_t bytes = r.bytes[blockIdx.y], n = bytes >> 2;
+  const uint32_t b = r.value[blockIdx.y], w = b * 0x01010101u;
+  for (uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x; v < n; v += (uint64_t)gridDim.x * 256) d[v] = w;
+  if (blockIdx.x == 0 && threadIdx.x < (bytes & 3u)) reinterpret_cast<uint8_t*>(d)[(n << 2) + threadIdx.x] = (uint8_t)b;   // (the last bytes of a range that is no multiple of 4)
 }
 
 inline uint32_t grid256(uint64_t n) { uint64_t g = (n + 255) / 256; return (uint32_t)(g > 4096 ? 4096 : (g ? g : 1)); }
@@ -940,7 +942,7 @@ void launch_clear_ranges(const ClearRanges& r, hipStream_t s) {
   if (!r.count) return;
   uint64_t longest = 0;
   for (uint32_t k = 0; k < r.count; ++k) longest = std::max(longest, r.bytes[k]);
-  hipLaunchKernelGGL(k_clear_ranges, dim3(grid256(longest >> 2) > 64u ? 64u : grid256(longest >> 2), r.count), 256, 0, s, r);
+  hipLaunchKernelGGL(k_clear_ranges, dim3(std::min(grid256(longest >> 2), 512u), r.count), 256, 0, s, r);
 }
 void launch_scatter_items(const CopyItem* items_dev, uint32_t n_items, const uint8_t* arena, hipStream_t s) {
   if (n_items) hipLaunchKernelGGL(k_scatter_items, n_items, 256, 0, s, items_dev, arena);

@@ -433,14 +433,11 @@ void launch_opp_quad(const uint32_t* opp, uint64_t C, uint32_t* out, hipStream_t
 }
 
 hipError_t conn_tables_clear(const ConnArgs& a, hipStream_t s) {
-  hipError_t e;
   const size_t nv = (size_t)a.total_verts + 1, C = 3ull * a.total_faces;
-  if ((e = hipMemsetAsync(a.flags, 0, (size_t)a.M * 4, s)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(a.vmax, 0, (size_t)a.M * 4, s)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(a.ecount, 0, nv * 4, s)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(a.first, 0xFF, nv * 4, s)) != hipSuccess) return e;
-  if (C && (e = hipMemsetAsync(a.cdone, 0, C, s)) != hipSuccess) return e;
-  return hipSuccess;
+  ClearRanges r{};   // (one launch: five hipMemsetAsync before)
+  r.add(a.flags, (size_t)a.M * 4); r.add(a.vmax, (size_t)a.M * 4); r.add(a.ecount, nv * 4); r.add(a.first, nv * 4, 0xFF); r.add(a.cdone, C);
+  launch_clear_ranges(r, s);
+  return hipGetLastError();
 }
 void launch_conn_tables(const ConnArgs& a, hipStream_t s) {
   if (!a.total_faces || !a.M) return;
@@ -453,13 +450,11 @@ void launch_conn_tables(const ConnArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_conn_check, grid_of(C), kBlock, 0, s, a);
 }
 hipError_t att_tables_clear(const AttArgs& t, hipStream_t s) {
-  hipError_t e;
   if (!t.n_items) return hipSuccess;
-  if ((e = hipMemsetAsync(t.seam, 0, t.total_corners, s)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(t.vseam, 0, t.total_verts, s)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(t.count, 0, ((size_t)t.total_verts + 1) * 4, s)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(t.info, 0, (size_t)t.n_items * sizeof(AttInfo), s)) != hipSuccess) return e;
-  return hipSuccess;
+  ClearRanges r{};
+  r.add(t.seam, t.total_corners); r.add(t.vseam, t.total_verts); r.add(t.count, ((size_t)t.total_verts + 1) * 4); r.add(t.info, (size_t)t.n_items * sizeof(AttInfo));
+  launch_clear_ranges(r, s);
+  return hipGetLastError();
 }
 void launch_att_tables(const ConnArgs& a, const AttArgs& t, hipStream_t s) {
   if (!t.n_items || !t.total_corners) return;

@@ -231,9 +231,14 @@ void launch_copy_items(const CopyItem* items_dev, uint32_t n_items, uint8_t* are
 void launch_scatter_items(const CopyItem* items_dev, uint32_t n_items, const uint8_t* arena, hipStream_t s);
 // items[k].src .. +bytes (a device range, a multiple of 4 bytes) := 0, every range of a batch in one launch
 void launch_clear_items(const CopyItem* items_dev, uint32_t n_items, hipStream_t s);
-// up to kClearRanges ranges (multiples of 4 bytes) := 0 in ONE launch, the list passed by value (no descriptor upload)
+// up to kClearRanges ranges (4-byte aligned starts, any length) filled with a byte value each (0 by default) in ONE launch, the list passed by value (no
+// descriptor upload): the hipMemsetAsync calls in front of a stage's kernels were a launch of ≈ 5–10 µs each — 235 of them per 1024-file transcode
 constexpr uint32_t kClearRanges = 24;
-struct ClearRanges { void* p[kClearRanges]; uint64_t bytes[kClearRanges]; uint32_t count; uint32_t pad; };
+struct ClearRanges {
+  void* p[kClearRanges]; uint64_t bytes[kClearRanges]; uint8_t value[kClearRanges]; uint32_t count; uint32_t pad;
+  void add(void* ptr, uint64_t n, uint8_t v = 0) { if (n && count < kClearRanges) { p[count] = ptr; bytes[count] = n; value[count] = v; ++count; } }
+  bool full() const { return count == kClearRanges; }
+};
 void launch_clear_ranges(const ClearRanges& r, hipStream_t s);
 void launch_pack_streams(const ChainDesc* descs_dev, uint32_t n_streams, PackEntry* table, uint8_t* arena, hipStream_t s);
 

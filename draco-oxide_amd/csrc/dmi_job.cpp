@@ -405,7 +405,7 @@ int dmi::job_create_impl(const dmi_attribute* atts, const dmi_corner_table* tabl
     if (defer && needs_clear) { defer->clears.push_back(JobDefer::Clear{p, bytes}); return hipSuccess; }
     if (defer || (bytes & 3) || !bytes) return bytes ? hipMemsetAsync(p, 0, bytes, st) : hipSuccess;
     if (pending_clears.count == kClearRanges) flush_clears(st);
-    pending_clears.p[pending_clears.count] = p; pending_clears.bytes[pending_clears.count] = bytes; ++pending_clears.count;
+    pending_clears.add(p, bytes);
     return hipSuccess;
   };
   struct PoolGuard { ~PoolGuard() { g_active_pool = nullptr; } } pool_guard;

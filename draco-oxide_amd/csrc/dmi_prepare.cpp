@@ -621,9 +621,16 @@ int dmi_encode_mesh_device(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buff
   stage.st = acquire_stage(device, need + 256);
   if (!stage.st) return fail(DMI_ERR_OUT_OF_MEMORY, "hipHostMalloc (mesh read-back)");
   uint8_t* hp = stage.st->p;
-  // (on a stream of its own: the table kernels of mesh_prepare_impl run on the thread's stream meanwhile; the host waits for both before its walks)
-  hipStream_t s_down = cfg && cfg->stream ? s : library_group_stream(device, 0);
+  // (on a stream of its own: the table kernels of mesh_prepare_impl run on the call's stream meanwhile; the host waits for both before its walks.  Round 6: also when the
+  //  caller names a stream — the copy stream first waits for an event of that stream, so whatever the caller queued there to produce the faces is ordered before
+  //  the read-back; on the caller's own stream the 2.2 ms copy of a 10M-triangle mesh ran IN FRONT of the table kernels instead of beside them)
+  hipStream_t s_down = library_group_stream(device, 0);
   if (!s_down) s_down = s;
+  if (s_down != s && cfg && cfg->stream) {
+    hipEvent_t ready = nullptr;
+    if (hipEventCreateWithFlags(&ready, hipEventDisableTiming) == hipSuccess && hipEventRecord(ready, s) == hipSuccess && hipStreamWaitEvent(s_down, ready, 0) == hipSuccess) (void)hipEventDestroy(ready);
+    else { (void)hipGetLastError(); if (ready) (void)hipEventDestroy(ready); s_down = s; }
+  }
   if (C) HIP_TRY(hipMemcpyAsync(hp, mesh->faces, C * 4, hipMemcpyDeviceToHost, s_down));
   for (uint32_t i = 0; i < mesh->num_atts; ++i) {
     if (!atts[i].point_to_value) continue;
