@@ -29,7 +29,7 @@ bool dmi::SeqStream::start(int dev, hipStream_t s, uint32_t capacity) {
   uploader = std::thread([this] {
     if (hipSetDevice(device) != hipSuccess) { failed.store(true); return; }
     uint32_t sent = 0;
-    constexpr uint32_t kPiece = 1u << 18;   // 1 MiB pieces: large enough for the link, small enough that the last one is short
+    constexpr uint32_t kPiece = 1u << 20;   // 4 MiB pieces; the thread wakes once a millisecond (or when the walk is over): a few dozen wake-ups per 10M-triangle mesh
     for (;;) {
       const uint32_t fin = final_n.load(std::memory_order_acquire);
       const uint32_t have = fin != 0xFFFFFFFFu ? fin : progress.written.load(std::memory_order_acquire);
@@ -41,7 +41,8 @@ bool dmi::SeqStream::start(int dev, hipStream_t s, uint32_t capacity) {
         continue;
       }
       if (fin != 0xFFFFFFFFu) break;
-      std::this_thread::sleep_for(std::chrono::microseconds(100));
+      std::unique_lock<std::mutex> lock(wake_mutex);
+      wake.wait_for(lock, std::chrono::milliseconds(1), [&] { return final_n.load(std::memory_order_acquire) != 0xFFFFFFFFu; });
     }
     host = progress.host.load(); n = sent;
     if (hipEventRecord(ev, stream) != hipSuccess) { (void)hipGetLastError(); failed.store(true); }
@@ -49,11 +50,12 @@ bool dmi::SeqStream::start(int dev, hipStream_t s, uint32_t capacity) {
   return true;
 }
 void dmi::SeqStream::finish(uint32_t n_entries) {
-  final_n.store(n_entries, std::memory_order_release);
+  { std::lock_guard<std::mutex> lock(wake_mutex); final_n.store(n_entries, std::memory_order_release); }
+  wake.notify_all();
   if (uploader.joinable()) uploader.join();
 }
 dmi::SeqStream::~SeqStream() {
-  if (uploader.joinable()) { final_n.store(0, std::memory_order_release); uploader.join(); }
+  if (uploader.joinable()) { { std::lock_guard<std::mutex> lock(wake_mutex); final_n.store(0, std::memory_order_release); } wake.notify_all(); uploader.join(); }
   if (stream && d_seq) (void)hipStreamSynchronize(stream);   // (nothing may still be copying into the array when its chunk goes back to the cache)
   if (ev) (void)hipEventDestroy(ev);
 }

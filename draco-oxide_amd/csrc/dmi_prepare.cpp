@@ -668,7 +668,7 @@ int dmi_encode_mesh_device(const dmi_mesh* mesh, const dmi_config* cfg, dmi_buff
     };
   }
   // … and the universal sequence goes up WHILE the sequencer writes it (SeqStream): job creation finds it on the device
-  if (mesh->num_faces >= kDeviceTablesMinFaces && !dbg_on(DMI_DBG_NO_EARLY)) {
+  if (mesh->num_faces >= kDeviceTablesMinFaces && !dbg_on(DMI_DBG_NO_EARLY | DMI_DBG_NO_SEQ_STREAM)) {
     auto ss = std::make_shared<SeqStream>();
     if (ss->start(device, library_group_stream(device, 0) != s ? library_group_stream(device, 0) : library_group_stream(device, 1), mesh->atts[0].num_unique)) g_seq_stream = ss;
   }
