@@ -111,14 +111,34 @@ __device__ __forceinline__ void mesh_max(uint32_t* dst, uint32_t m, uint32_t v, 
 
 // ---- universal corner tables of a batch ----
 // per face: vertex ids (through the position map), range / degenerate checks, half-edge counts per bucket (= smaller endpoint of the
-// edge), a corner per vertex, largest vertex id per mesh
+// edge), a corner per vertex, largest vertex id per mesh.
+// The half-edge of corner j runs from v[j+1] to v[j+2]: its bucket is the smaller endpoint, and its place in the bucket — any numbering of a bucket's
+// half-edges will do, k_conn_match looks at all of them — is parked in `opp` for k_conn_fill.  Round 6: a block takes a TILE of kBlock · FPT consecutive
+// faces and counts the buckets within [the tile's smallest bucket, + kConnWindow) in LDS: a returning LDS atomic per half-edge, then ONE returning global
+// atomic per bucket the tile touched (its count in, the tile's first place out) instead of one per half-edge — memory-side atomics were the kernel
+// (10M faces: 640 µs, 120 without them; scripts/experiments/conn_faces_probe.hip) and a mesh whose vertex ids follow its face order has a tile's ≈ 3 · T
+// half-edges in ≈ T buckets: 160 µs.  Buckets outside the window take the global atomic as before (a mesh with scattered ids: 2.4 ms either way).
+// The corner kept per vertex goes through the window too (16-bit tile-relative id, one global store per vertex and tile).
+constexpr int kConnWindow = 8192;
+template <int FPT>
 __global__ __launch_bounds__(kBlock) void k_conn_faces(const ConnArgs a) {
-  uint32_t cur_m = kNoneD, cur_max = 0;   // largest vertex id seen for mesh cur_m (a single large mesh: the grid is capped and every thread loops)
-  for (uint32_t f = blockIdx.x * kBlock + threadIdx.x; f < a.total_faces; f += gridDim.x * kBlock) {
+  __shared__ uint32_t cnt[kConnWindow];   // half-edges of the tile per bucket, then the tile's first place in the bucket
+  __shared__ uint16_t fst[kConnWindow];   // some corner (tile-relative) of the vertex, 0xFFFF = none in this tile
+  __shared__ uint32_t smin;
+  static_assert(3 * kBlock * FPT < 65535 && kConnWindow % (kBlock * 8) == 0, "tile-relative corner ids are 16 bits");
+  const uint32_t tile0 = blockIdx.x * (uint32_t)(kBlock * FPT);
+  uint32_t gv[FPT][3], rank[FPT][3], foff[FPT];   // (gv: vert_off + vertex — the index into ecount / first)
+  bool ok[FPT];
+  uint32_t mymin = kNoneD, cur_m = kNoneD, cur_max = 0;   // largest vertex id seen for mesh cur_m (a thread's faces ascend, so do their meshes)
+#pragma unroll
+  for (int j = 0; j < FPT; ++j) {
+    const uint32_t f = tile0 + j * kBlock + threadIdx.x;
+    ok[j] = f < a.total_faces;
+    if (!ok[j]) continue;
     const uint32_t m = a.M == 1 ? 0u : find_mesh(a.M, f, [&](uint32_t k) { return a.meshes[k].face_off; });
     if (m != cur_m) { if (cur_m != kNoneD) atomicMax(&a.vmax[cur_m], cur_max); cur_m = m; cur_max = 0; }
     const ConnMeshDesc d = a.meshes[m];
-    const uint32_t lf = f - d.face_off;
+    foff[j] = d.face_off;
     uint32_t v[3];
     bool bad = false;
 #pragma unroll
@@ -129,18 +149,67 @@ __global__ __launch_bounds__(kBlock) void k_conn_faces(const ConnArgs a) {
       if (v[k] >= d.Vcap) { bad = true; v[k] = 0; }
     }
     if (a.c2v != a.faces) { a.c2v[3ull * f] = v[0]; a.c2v[3ull * f + 1] = v[1]; a.c2v[3ull * f + 2] = v[2]; }
-    if (bad) { raise(a.flags, m, CONN_BAD_INDEX); continue; }
-    if (v[0] == v[1] || v[1] == v[2] || v[0] == v[2]) { raise(a.flags, m, CONN_DEGENERATE); continue; }
-    // the half-edge of corner j runs from v[j+1] to v[j+2]: its bucket is the smaller endpoint; the arrival number the counting atomic returns is
-    // the half-edge's place in its bucket (parked in `opp`, which k_conn_match writes later) — k_conn_fill then needs no second round of atomics
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      a.opp[3ull * f + (k + 2) % 3] = atomicAdd(&a.ecount[d.vert_off + min(v[k], v[(k + 1) % 3])], 1u);
-      a.first[d.vert_off + v[k]] = 3u * lf + k;   // SOME corner of the vertex (a plain store: whichever face writes last wins); k_conn_vertices finds the smallest one of the fan itself
-    }
+    if (bad) { raise(a.flags, m, CONN_BAD_INDEX); ok[j] = false; continue; }
+    if (v[0] == v[1] || v[1] == v[2] || v[0] == v[2]) { raise(a.flags, m, CONN_DEGENERATE); ok[j] = false; continue; }
     cur_max = max(cur_max, max(v[0], max(v[1], v[2])));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gv[j][k] = d.vert_off + v[k];
+    mymin = min(mymin, min(gv[j][0], min(gv[j][1], gv[j][2])));
   }
   mesh_max(a.vmax, cur_m, cur_max, cur_m != kNoneD);
+  if (threadIdx.x == 0) smin = kNoneD;
+  for (int i = threadIdx.x; i < kConnWindow; i += kBlock) { cnt[i] = 0; fst[i] = 0xFFFFu; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mymin = min(mymin, (uint32_t)__shfl_down(mymin, off, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0 && mymin != kNoneD) atomicMin(&smin, mymin);
+  __syncthreads();
+  const uint32_t base = smin;   // (kNoneD: no valid face in the tile — nothing below touches the window)
+#pragma unroll
+  for (int j = 0; j < FPT; ++j) {
+    if (!ok[j]) continue;
+    const uint32_t tf = j * kBlock + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const uint32_t low = min(gv[j][k], gv[j][(k + 1) % 3]), dl = low - base;
+      rank[j][k] = dl < (uint32_t)kConnWindow ? atomicAdd(&cnt[dl], 1u) : atomicAdd(&a.ecount[low], 1u);
+      // SOME corner of the vertex (plain stores: whichever face writes last wins); k_conn_vertices finds the smallest one of the fan itself
+      const uint32_t e = gv[j][k] - base;
+      if (e < (uint32_t)kConnWindow) fst[e] = (uint16_t)(3u * tf + k);
+      else a.first[gv[j][k]] = 3u * (tile0 + tf - foff[j]) + k;
+    }
+  }
+  __syncthreads();
+  if (base != kNoneD) {
+    for (int it = 0; it < kConnWindow / kBlock; it += 8) {
+      uint32_t c[8], r[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) c[u] = cnt[(it + u) * kBlock + threadIdx.x];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) r[u] = c[u] ? atomicAdd(&a.ecount[base + (it + u) * kBlock + threadIdx.x], c[u]) : 0u;   // (eight in flight)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) cnt[(it + u) * kBlock + threadIdx.x] = r[u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t x = fst[(it + u) * kBlock + threadIdx.x];
+        if (x == 0xFFFFu) continue;
+        const uint32_t g = base + (it + u) * kBlock + threadIdx.x;   // the corner's id is local to the mesh the vertex belongs to
+        const uint32_t fo = a.M == 1 ? a.meshes[0].face_off : a.meshes[find_mesh(a.M, g, [&](uint32_t k) { return a.meshes[k].vert_off; })].face_off;
+        a.first[g] = (uint32_t)(3ull * tile0 + x - 3ull * fo);
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < FPT; ++j) {
+    if (!ok[j]) continue;
+    const uint32_t f = tile0 + j * kBlock + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const uint32_t dl = min(gv[j][k], gv[j][(k + 1) % 3]) - base;
+      a.opp[3ull * f + (k + 2) % 3] = rank[j][k] + (dl < (uint32_t)kConnWindow ? cnt[dl] : 0u);
+    }
+  }
 }
 // per corner: its half-edge (source = vertex(next), sink = vertex(prev)) into the bucket of the smaller endpoint, keyed by the larger one
 // and the direction (bit 31: the half-edge runs from the larger endpoint down)
@@ -442,7 +511,10 @@ hipError_t conn_tables_clear(const ConnArgs& a, hipStream_t s) {
 void launch_conn_tables(const ConnArgs& a, hipStream_t s) {
   if (!a.total_faces || !a.M) return;
   const uint64_t C = 3ull * a.total_faces;
-  hipLaunchKernelGGL(k_conn_faces, a.M == 1 ? std::min(grid_of(a.total_faces), 2048u) : grid_of(a.total_faces), kBlock, 0, s, a);
+  // tile size by the launch's size: large tiles touch fewer buckets per half-edge, small launches need the blocks
+  if (a.total_faces >= (2u << 20)) hipLaunchKernelGGL(k_conn_faces<16>, grid_of(a.total_faces, 16), kBlock, 0, s, a);
+  else if (a.total_faces >= (1u << 18)) hipLaunchKernelGGL(k_conn_faces<8>, grid_of(a.total_faces, 8), kBlock, 0, s, a);
+  else hipLaunchKernelGGL(k_conn_faces<4>, grid_of(a.total_faces, 4), kBlock, 0, s, a);
   launch_exclusive_scan_u32(a.ecount, a.total_verts + 1, a.scan_partials, s);
   hipLaunchKernelGGL(k_conn_fill, grid_of(C), kBlock, 0, s, a);
   hipLaunchKernelGGL(k_conn_match, grid_of(C), kBlock, 0, s, a);
