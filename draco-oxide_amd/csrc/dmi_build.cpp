@@ -553,7 +553,7 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
   n_host += (uint32_t)redo.size();
   cleanup.armed = false;
   g_last_build = dmi_build_timings{(float)t_pack, (float)kernels_ms, (float)ms(), n_device, n_host, bytes_up, bytes_down, n_in_place, 0u};
-  if (trace) std::fprintf(stderr, "[dmi] meshes_build: %u primitives (%u on the device — %u read in place —, %u on the host): pack %.2f ms, issued by %.2f, kernels %.2f, total %.2f; %.1f MB up, %.1f MB down\n",
+  if (trace || dbg_on(DMI_DBG_TRACE_STAGES)) std::fprintf(stderr, "[dmi] meshes_build: %u primitives (%u on the device — %u read in place —, %u on the host): pack %.2f ms, issued by %.2f, kernels %.2f, total %.2f; %.1f MB up, %.1f MB down\n",
                           n, n_device, n_in_place, n_host, t_pack, t_issued, kernels_ms, ms(), bytes_up / 1e6, bytes_down / 1e6);
   return DMI_OK;
 }

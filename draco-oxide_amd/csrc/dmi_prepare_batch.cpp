@@ -551,7 +551,7 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
   HIP_TRY(hipStreamSynchronize(S));
   const double t_dev = ms();
   groups.clear();
-  if (trace) {
+  if (trace || dbg_on(DMI_DBG_TRACE_STAGES)) {
     uint64_t tf = 0;
     for (uint32_t k = 0; k < M; ++k) tf += meshes[which_all[k]].num_faces;
     std::fprintf(stderr, "[dmi] batch prepare, device form: %u meshes, %llu faces: layout + pack + issue of the connectivity kernels %.2f ms, host walks + job layouts %.2f (%u threads), "

@@ -75,6 +75,7 @@ struct dmi_transcoder {
   uint32_t dispatched = 0;             // primitives already handed to the build step
   uint32_t stages = 0;                 // stages dispatched so far
   uint32_t stage_primitives = 0;       // 0 = no cap on the primitives of a stage
+  uint32_t stage_ramp = 0;             // n > 0: stage k takes min(1, 2^k / n) of stage_triangles
   uint64_t pending_triangles = 0;
   bool first_stage = true;
   // results, by primitive
@@ -188,7 +189,8 @@ struct dmi_transcoder {
   void dispatch(bool flush) {
     // (the first stage runs alone: the sooner it is through, the sooner the steps overlap.  Small LAST stages — half of what is expected to be left,
     // down to a third of a stage — were tried against the tail of the call: no gain beyond the noise, 105–110 against 95–105 ms per 1024 files)
-    const uint64_t want = first_stage ? std::max<uint64_t>(1, stage_triangles / 3) : stage_triangles;
+    const uint64_t want = stage_ramp ? std::max<uint64_t>(1, std::min<uint64_t>(stage_triangles, (stage_triangles / stage_ramp) << std::min<uint32_t>(stages, 16u)))
+                                     : first_stage ? std::max<uint64_t>(1, stage_triangles / 3) : stage_triangles;
     // (… or stage_primitives of them: with the files taken largest first the last stage of a long list would otherwise hold most of its primitives —
     //  695 of 1024 — and its build, prepare and encode, which nothing overlaps, pay per primitive)
     const bool many = stage_primitives && prims.size() - dispatched >= stage_primitives;
@@ -214,6 +216,7 @@ dmi_transcoder* dmi_transcoder_create(const dmi_config* cfg, uint64_t expected_t
   t->debug = dbg();
   t->cfg.debug = &t->debug;
   t->trace = dbg_on(DMI_DBG_TRACE | DMI_DBG_TRACE_STAGES);
+  t->stage_ramp = dbg().stage_ramp;
   t->stage_primitives = dbg().stage_primitives ? dbg().stage_primitives : 256u;   // (1024 files, medians of 7: 80.5 → 80.1, 87.6 → 84.9, 88.4 → 80.8 ms with the cap)
   // about four stages (enough to overlap the steps), between 3M and 12M triangles: a stage pays fixed costs (the chain launch of its encode is bounded
   // by its longest stream, ≈ 5 ms) and one above ≈ 16M stops overlapping (measured with the Python driver: DESIGN §6b)

@@ -98,7 +98,8 @@ typedef struct dmi_debug {
   uint32_t batch_threads, split;                /* batch encode: worker threads, sub-batches (0 = defaults) */
   uint32_t shadow_min_faces;                    /* host walks: faces from which the shadow prefetch runs (0 = default) */
   uint64_t prep_group_faces, batch_min_faces;   /* batch prepare: faces per device group, smallest mesh that takes the device tables (0 = defaults) */
-  uint32_t stage_primitives, pad2;              /* transcoder: a stage is dispatched at this many primitives even below its triangle count (0 = no cap) */
+  uint32_t stage_primitives, stage_ramp;        /* transcoder: a stage is dispatched at this many primitives even below its triangle count (0 = no cap);
+                                                   stage_ramp n > 0: the first stage takes 1/n of a stage's triangles and the following ones double up to a whole stage */
 } dmi_debug;
 #define DMI_DBG_NO_FUSED          (1ull << 0)    /* per-attribute predictor kernels instead of the fused sweep */
 #define DMI_DBG_NO_PACKED         (1ull << 1)    /* int32 quantized values instead of the sweep's packed layouts */

@@ -41,6 +41,32 @@ def test_device_tables_equal_host_tables_on_grids(n, open_boundary):
     _compare(synth.torus_mesh(n, normals=False, uvs=False, open_boundary=open_boundary), f"grid {n} open={open_boundary}")
 
 
+@pytest.mark.parametrize("n,labels,face_order", [(120, "split", "file"), (260, "split", "file"), (260, "random", "file"), (260, "file", "random"), (300, "stride", "random"),
+                                                 (1100, "split", "file"), (1100, "file", "file")])
+def test_device_tables_when_a_tile_of_faces_leaves_its_bucket_window(n, labels, face_order):
+    """k_conn_faces ranks the half-edges of a tile of faces through an LDS window of 8192 buckets above the tile's smallest one; the others take the
+    global atomic.  Vertex labels split into two far-apart halves / strided / random, and random face orders, put a tile's buckets on both sides of the
+    window's end (and n = 1100: 2.4M faces, the 16-faces-per-thread tile)."""
+    faces, pos, _, _ = synth.torus_grid(n, normals=False, uvs=False)
+    V = n * n
+    rng = np.random.default_rng(n)
+    if labels == "split":        # even vertices first, odd ones V/2 further up
+        perm = np.where(np.arange(V) % 2 == 0, np.arange(V) // 2, (V + 1) // 2 + np.arange(V) // 2)
+    elif labels == "stride":     # v → v · 7919 mod V (7919 prime, no factor of n here)
+        perm = (np.arange(V, dtype=np.int64) * 7919) % V
+    elif labels == "random":
+        perm = rng.permutation(V)
+    else:
+        perm = np.arange(V)
+    assert len(np.unique(perm)) == V
+    inv = np.empty(V, np.int64); inv[perm] = np.arange(V)
+    f2 = perm[faces.astype(np.int64)].astype(np.uint32)
+    if face_order == "random":
+        f2 = f2[rng.permutation(len(f2))]
+    mesh = dmi.Mesh(np.ascontiguousarray(f2), [dmi.Attribute(np.ascontiguousarray(pos[inv]), dmi.ATT_POSITION, dmi.DOMAIN_POSITION, unique_id=0)])
+    _compare(mesh, f"grid {n} labels={labels} faces={face_order}")
+
+
 @pytest.mark.parametrize("name", ["tetrahedron", "cube_quads", "sphere", "punctured_sphere", "torus"])
 def test_device_tables_equal_host_tables_on_fixtures(name):
     _compare(product_mesh_from_oracle(obj_session(name)), name)   # position maps (value dedup) included
