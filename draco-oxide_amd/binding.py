@@ -1214,6 +1214,30 @@ def last_call_timings():
     return {k: getattr(t, k) for k, _ in _Timings._fields_}
 
 
+class _HipArray:
+    """A host array copied into hipMalloc'd memory through the HIP runtime the library itself is bound to (DeviceMesh.upload in a process without torch)."""
+    _hip = None
+
+    def __init__(self, arr, device):
+        if _HipArray._hip is None:
+            _HipArray._hip = C.CDLL("libamdhip64.so.7")   # (already loaded as libdraco_mi.so's dependency: the same runtime)
+        hip = _HipArray._hip
+        arr = np.ascontiguousarray(arr)
+        self._p = C.c_void_p()
+        if hip.hipSetDevice(int(device)) or hip.hipMalloc(C.byref(self._p), C.c_size_t(max(arr.nbytes, 4))):
+            raise DracoMiError(1, "hipMalloc failed")
+        if arr.nbytes and hip.hipMemcpy(self._p, C.c_void_p(arr.ctypes.data), C.c_size_t(arr.nbytes), 1):
+            raise DracoMiError(1, "hipMemcpy failed")
+
+    def data_ptr(self):
+        return self._p.value
+
+    def __del__(self):
+        if self._p and _HipArray._hip is not None:
+            _HipArray._hip.hipFree(self._p)
+            self._p = None
+
+
 class DeviceMesh:
     """A mesh whose faces, attribute values and point → value maps live in device memory (torch tensors on one HIP device):
     the input of dmi_encode_mesh_device.  Built from a host `Mesh` by `DeviceMesh.upload(mesh, device)`."""
@@ -1223,6 +1247,14 @@ class DeviceMesh:
 
     @classmethod
     def upload(cls, mesh, device=0):
+        if "torch" not in sys.modules:   # a process without torch (the library on the system's HIP runtime): plain hipMalloc'd arrays
+            load_library()
+            t = {"faces": _HipArray(mesh.faces.view(np.int32), device), "values": [], "maps": {}}
+            for a in mesh.attributes:
+                t["values"].append(_HipArray(np.ascontiguousarray(a.values).view(np.int32), device))
+                if a.point_to_value is not None and id(a.point_to_value) not in t["maps"]:
+                    t["maps"][id(a.point_to_value)] = _HipArray(np.ascontiguousarray(a.point_to_value, dtype=np.uint32).view(np.int32), device)
+            return cls(mesh, t, device)
         import torch
         dev = torch.device("cuda", device)
         t = {"faces": torch.from_numpy(mesh.faces.view(np.int32)).to(dev), "values": [], "maps": {}}

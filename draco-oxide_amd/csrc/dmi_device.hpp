@@ -68,10 +68,10 @@ struct SeqQuantArgs { const uint32_t* s2p /* null: value order (entry i reads va
 // (indices 0 / 1 / 2 of the per-attribute arrays below = position / normal / texture coordinate; null = the mesh has none)
 // range partials: the per-block pairs of launch_value_range_partials (k_value_ranges without its `_final`): every block of k_value_quantize_rec folds them
 // itself, block 0 also writes the attributes' slots ([small 16 words][meta 16 words], as k_value_ranges_final leaves them)
-struct ValueRecArgs { const float *pos, *nrm, *uv; const float *pos_partials, *uv_partials; const uint32_t* nrm_flags; uint32_t range_blocks[3]; float pos_maxq, uv_maxq; uint32_t n; void* rec;
+struct ValueRecArgs { const float *pos, *nrm, *uv; const float *pos_partials, *uv_partials; uint32_t* nrm_flags /* out: a zero-length normal seen, one word per block */; uint32_t range_blocks[3]; float pos_maxq, uv_maxq; uint32_t n; void* rec;
                       uint32_t* slot[3]; int32_t* ipartials[3] /* 2 * value_quantize_rec_blocks(n) words each */; };
 // the stage's slots → the job's slab slots, the joint i32 min/max folded from the per-block pairs into words 0–1 (the first block of the consumer kernel)
-struct EarlySlots { const uint32_t* src[3]; uint32_t* dst[3]; const int32_t* ipartials[3]; uint32_t ipartial_blocks; uint32_t pad; };
+struct EarlySlots { const uint32_t* src[3]; uint32_t* dst[3]; const int32_t* ipartials[3]; const uint32_t* nrm_flags /* per block of the quantizer: folded into word 4 of the normal's slot */; uint32_t ipartial_blocks; uint32_t pad; };
 struct GatherRecArgs { const uint32_t* s2p; uint32_t n; uint32_t pad; const void* rec; uint64_t* qs_pos; uint16_t* qs_nrm; uint32_t* qs_uv; EarlySlots slots; };
 // (measured, 10M triangles: 512 blocks per attribute 38.4 µs + 46.2 for the quantizer that folds them, 768: 34.1 + 47.0, 1024: 32.2 + 48.4 with two values per thread and round)
 constexpr uint32_t kEarlyRangeBlocks = 1024;   // blocks per attribute of the early stage's range pass = partial pairs every block of k_value_quantize_rec folds

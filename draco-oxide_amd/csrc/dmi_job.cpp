@@ -306,7 +306,7 @@ int dmi::early_quantize_issue(const dmi_attribute* atts, uint32_t n_atts, const 
     r.meta = reinterpret_cast<float*>(ea.slot + 64);
     r.zero = reinterpret_cast<uint32_t*>(ea.slot + 64);
     r.zero_words = 16;
-    r.n = ea.n; r.N = ea.N; r.kind = ea.kind;
+    r.n = ea.n; r.N = ea.N; r.kind = ea.kind == 1 ? 2 : ea.kind;   // (normals: no range pass — the zero-length check rides in the quantizer, which reads them anyway)
   }
   HIP_TRY(hipEventCreate(&e->t0)); HIP_TRY(hipEventCreate(&e->t1));
   HIP_TRY(hipEventRecord(e->t0, side));
@@ -316,7 +316,7 @@ int dmi::early_quantize_issue(const dmi_attribute* atts, uint32_t n_atts, const 
   va.pos = static_cast<const float*>(e->atts[(size_t)i_pos].values);
   va.pos_partials = ra.a[i_pos].partials;
   va.pos_maxq = (float)(uint64_t)((1ull << e->atts[(size_t)i_pos].bits) - 1ull);
-  if (i_nrm >= 0) { va.nrm = static_cast<const float*>(e->atts[(size_t)i_nrm].values); va.nrm_flags = reinterpret_cast<const uint32_t*>(ra.a[i_nrm].partials); }
+  if (i_nrm >= 0) { va.nrm = static_cast<const float*>(e->atts[(size_t)i_nrm].values); va.nrm_flags = reinterpret_cast<uint32_t*>(ra.a[i_nrm].partials); e->nrm_flags = va.nrm_flags; }   // (kRangeMaxBlocks · 8 words: the quantizer has at most 2048 blocks)
   if (i_uv >= 0) {
     va.uv = static_cast<const float*>(e->atts[(size_t)i_uv].values);
     va.uv_partials = ra.a[i_uv].partials;

@@ -361,6 +361,7 @@ struct EarlyQuant {
   int att_of_kind[3] = {-1, -1, -1};              // attribute index of the position / normal / texture coordinate
   int32_t* ipartials[3] = {nullptr, nullptr, nullptr};   // per-block joint i32 min/max pairs of k_value_quantize_rec, by kind; folded by the consumer's first block
   uint32_t ipartial_blocks = 0;
+  const uint32_t* nrm_flags = nullptr;   // per block of the quantizer: a zero-length normal seen (ipartial_blocks words)
   // EarlySlots of a consumer kernel: the stage's slots → the slab slots of `job_atts` (dst_of(attribute index) = its `small` words)
   template <class F> EarlySlots slots_for(F dst_of) const {
     EarlySlots es{};
@@ -371,6 +372,7 @@ struct EarlyQuant {
       es.ipartials[k] = ipartials[k];
     }
     es.ipartial_blocks = ipartial_blocks;
+    es.nrm_flags = att_of_kind[1] >= 0 ? nrm_flags : nullptr;
     return es;
   }
   ~EarlyQuant() {

@@ -464,11 +464,8 @@ __device__ __forceinline__ void value_quantize_rec_body(const ValueRecArgs& a) {
   }
   if (blockIdx.x == 0) {   // the slots of the attributes: [small 16 words][meta 16 words] each, as k_value_ranges_final leaves them
     const uint32_t t = threadIdx.x;
-    // zero-length normal seen (geom.rs:45): any block flag of k_value_ranges — folded by the whole block (one thread walking 512 flags kept this block,
-    // and with it the launch, 8 µs longer)
-    bool bad_l = false;
-    if (HAS_NRM) for (uint32_t b = t; b < a.range_blocks[1]; b += kBlock) bad_l |= a.nrm_flags[b] != 0u;
-    const int zero_normal = __syncthreads_or(bad_l ? 1 : 0);
+    // (word 4 of the normal's slot — a zero-length normal seen, geom.rs:45 — is folded by the consumer's first block from this kernel's per-block flags:
+    //  the normals are read HERE, once; the range pass read them a first time for that check alone until round 6 — 60 of its 160 MB)
     if (t < 96u) {
       const uint32_t k = t >> 5, w = t & 31u;
       uint32_t* slot = a.slot[k];
@@ -476,7 +473,6 @@ __device__ __forceinline__ void value_quantize_rec_body(const ValueRecArgs& a) {
         uint32_t v = w == 0 ? 0x7FFFFFFFu : (w == 1 ? 0x80000000u : 0u);
         if (k == 0 && w >= 16u) { const uint32_t m = w - 16u; if (m < 3u) v = __float_as_uint(res_pos[m]); else if (m == 3u) v = __float_as_uint(prange); else if (m < 7u) v = __float_as_uint(res_pos[3 + (m - 4u)]); }
         if (k == 2 && w >= 16u) { const uint32_t m = w - 16u; if (m < 2u) v = __float_as_uint(res_uv[m]); else if (m == 2u) v = __float_as_uint(urange); else if (m < 5u) v = __float_as_uint(res_uv[2 + (m - 3u)]); }
-        if (k == 1 && w == 4u) v = zero_normal ? 1u : 0u;
         slot[w] = v;
       }
     }
@@ -484,6 +480,7 @@ __device__ __forceinline__ void value_quantize_rec_body(const ValueRecArgs& a) {
   int32_t mn[3], mx[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) { mn[k] = 2147483647; mx[k] = (-2147483647 - 1); }
+  bool zero_normal = false;
   const uint32_t n = a.n;
   constexpr uint32_t kTileRec = kBlock * kRecPer;
   for (uint32_t base = blockIdx.x * kTileRec; base < n; base += gridDim.x * kTileRec) {
@@ -511,11 +508,15 @@ __device__ __forceinline__ void value_quantize_rec_body(const ValueRecArgs& a) {
       if (HAS_UV) { qu = quant_coord(U[t][0], umn[0], urange, a.uv_maxq); qw = quant_coord(U[t][1], umn[1], urange, a.uv_maxq); r.uv = (uint32_t)qu | ((uint32_t)qw << 16); }
       if (v < n) {
         mn[0] = min(mn[0], min(q0, min(q1, q2))); mx[0] = max(mx[0], max(q0, max(q1, q2)));
-        if (HAS_NRM) { mn[1] = min(mn[1], min(u, w)); mx[1] = max(mx[1], max(u, w)); }
+        if (HAS_NRM) { mn[1] = min(mn[1], min(u, w)); mx[1] = max(mx[1], max(u, w)); zero_normal |= Q[t][0] == 0.0f && Q[t][1] == 0.0f && Q[t][2] == 0.0f; }
         if (HAS_UV) { mn[2] = min(mn[2], min(qu, qw)); mx[2] = max(mx[2], max(qu, qw)); }
         static_cast<QuantRec*>(a.rec)[v] = r;
       }
     }
+  }
+  if (HAS_NRM) {
+    const int any = __syncthreads_or(zero_normal ? 1 : 0);
+    if (threadIdx.x == 0) a.nrm_flags[blockIdx.x] = any ? 1u : 0u;
   }
   __shared__ int32_t red[3][2][kBlock / 64];
 #pragma unroll
@@ -556,6 +557,12 @@ __device__ __forceinline__ void early_slots_block(const EarlySlots& e) {
       for (int w = 1; w < kBlock / 64; ++w) { lo = min(lo, red[0][w]); hi = max(hi, red[1][w]); }
       e.dst[k][0] = (uint32_t)lo; e.dst[k][1] = (uint32_t)hi;
     } else if (threadIdx.x >= 2u && threadIdx.x < 32u) e.dst[k][threadIdx.x] = e.src[k][threadIdx.x];
+  }
+  if (e.nrm_flags && e.dst[1]) {   // (uniform) a zero-length normal seen by any block of the quantizer (geom.rs:45) → word 4 of the normal's slot
+    bool bad = false;
+    for (uint32_t b = threadIdx.x; b < e.ipartial_blocks; b += kBlock) bad |= e.nrm_flags[b] != 0u;
+    const int any = __syncthreads_or(bad ? 1 : 0);   // (also orders this store behind the copy of word 4 above)
+    if (threadIdx.x == 4u) e.dst[1][4] = any ? 1u : 0u;
   }
 }
 // qs_*[i] = the fields of rec[s2p[i]].  Four entries per thread, every gather issued before the first is used; tiles are dealt to blocks like every

@@ -21,6 +21,7 @@ JSON byte-equality with the reference is not part of the bit-exact contract; the
 import base64
 import json
 import os
+import sys
 import urllib.parse
 import struct
 
@@ -603,6 +604,15 @@ def encode_raw_batch(raws, cfg=None, pipeline=True, timings=None, weights=None, 
 _ENCODE_RAW_BATCH = encode_raw_batch   # (a test's stand-in for encode_raw_batch must keep being used by the sharded driver)
 
 
+def _world_size(group=None):
+    """Ranks of the torch.distributed job this process belongs to — 1 when nobody has imported torch.distributed (never imported HERE: the library does not
+    need torch, and a process without it runs on the system's HIP runtime instead of the one the torch wheel bundles — binding.load_library)."""
+    dist = sys.modules.get("torch.distributed")
+    if dist is None or not dist.is_available() or not dist.is_initialized():
+        return 1
+    return dist.get_world_size(group)
+
+
 def encode_batch(meshes, cfg=None, devices=None, group=None, device=None):
     """Every (already built, host-memory) mesh of a transcode job as ONE batch → list of `.drc` blobs in mesh order (None on the ranks
     that are not the destination of a sharded job).  torch.distributed initialised with more than one rank: the batch is dealt over
@@ -611,11 +621,7 @@ def encode_batch(meshes, cfg=None, devices=None, group=None, device=None):
     (A pipelined form — dmi_meshes_prepare of stage k+1 beside dmi_jobs_encode of stage k — was 1.6 × slower on 256 meshes and is gone.)"""
     if not meshes:
         return []
-    try:
-        import torch.distributed as dist
-        world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-    except ImportError:
-        world = 1
+    world = _world_size(group)
     if world > 1:
         from . import distributed
         return distributed.encode_meshes_sharded(meshes, cfg, device=device, group=group)
@@ -688,11 +694,7 @@ def _transcode_files(sources, cfg, devices, group, device, pipeline, timings):
     import time
     tm = timings if timings is not None else {}
     t0 = time.perf_counter()
-    try:
-        import torch.distributed as dist
-        world0 = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-    except ImportError:
-        world0 = 1
+    world0 = _world_size(group)
     if world0 == 1 and pipeline and os.environ.get("DMI_TRANSCODE_PYTHON", "0") == "0" and sources:
         # One process: the whole loop — container + JSON parse, primitive plans, accessor descriptors, stages on one dmi_transcoder per device,
         # file assembly — runs inside the library (dmi_transcode_assets, csrc/dmi_gltf.cpp); the files come back as views of its memory.
@@ -715,12 +717,8 @@ def _transcode_files(sources, cfg, devices, group, device, pipeline, timings):
     per_file = [_plan(doc) for doc, _ in docs]
     flat = [(fi, pi) for fi, prims in enumerate(per_file) for pi in range(len(prims))]
     weights = [per_file[fi][pi][2] for fi, pi in flat]
-    try:
-        import torch.distributed as dist
-        world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-        rank = dist.get_rank(group) if world > 1 else 0
-    except ImportError:
-        world, rank = 1, 0
+    world = _world_size(group)
+    rank = sys.modules["torch.distributed"].get_rank(group) if world > 1 else 0
     if world > 1:
         from . import distributed
         mine = distributed.shard_indices(len(flat), rank, world, weights=weights)

@@ -61,6 +61,31 @@ def test_early_quantization_before_the_walks_gives_the_same_bytes(n, normals, uv
     assert dmi.encode_mesh_device(dm, cfg) == got and dmi.last_call_timings()["early_ms"] == 0
 
 
+@pytest.mark.parametrize("where", [0, 12345, -1])
+def test_zero_normal_is_an_error_code_with_the_early_stage_too(where, monkeypatch):
+    """geom.rs:45 asserts on a zero-length normal: an error code here.  Round 6: the early stage's quantizer looks for it (it reads the normals anyway; the
+    range pass no longer does) and the first block of the record gather folds its per-block flags into the job's slot."""
+    faces, pos, nrm, uv = synth.torus_grid(200, seed=77)
+    nrm = nrm.copy()
+    nrm[where] = 0
+    atts = [dmi.Attribute(pos, dmi.ATT_POSITION), dmi.Attribute(nrm, dmi.ATT_NORMAL, dmi.DOMAIN_CORNER, unique_id=1, parent_index=0),
+            dmi.Attribute(uv, dmi.ATT_TEXCOORD, dmi.DOMAIN_CORNER, unique_id=2, parent_index=0)]
+    dm = dmi.DeviceMesh.upload(dmi.Mesh(faces, atts))
+    for early in (True, False):
+        if not early:
+            monkeypatch.setenv("DMI_NO_EARLY", "1")
+        with pytest.raises(dmi.DracoMiError) as e:
+            dmi.encode_mesh_device(dm, dmi.Config(flags=dmi.FLAG_TIMINGS))
+        assert e.value.status == 6, early
+    monkeypatch.delenv("DMI_NO_EARLY")
+    nrm[where] = (0.0, 0.0, 1.0)   # the same mesh without the zero: through, and the early stage was entered
+    atts[1] = dmi.Attribute(nrm, dmi.ATT_NORMAL, dmi.DOMAIN_CORNER, unique_id=1, parent_index=0)
+    mesh = dmi.Mesh(faces, atts)
+    got = dmi.encode_mesh_device(dmi.DeviceMesh.upload(mesh), dmi.Config(flags=dmi.FLAG_TIMINGS))
+    assert dmi.last_call_timings()["early_ms"] > 0
+    _assert_same(got, oracle_from_product_mesh(mesh).encode(), "zero normal repaired")
+
+
 def test_early_stage_is_dropped_when_an_attribute_has_seams_of_its_own():
     """The early stage guesses the fused sweep's layouts before any corner table exists; a UV attribute with interior seams leaves the sweep — the job's
     plan then differs from the guess, the early result is dropped and the job quantizes as always.  Same bytes as the oracle's."""
