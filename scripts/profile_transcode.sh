@@ -20,9 +20,9 @@ def short(n):
 rows = list(csv.DictReader(open(hits[0])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows) / 1e6
 out = [f"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 scripts/transcode_profile.py 1024 {calls}   ({tag}, MI355X): {calls} transcodes of 1024 GLB files / 45.1M triangles (the first is the process's warm-up); kernel time summed over all streams {tot / calls:.1f} ms per call",
-       "kernel, calls_per_transcode, ms_per_transcode, avg_us, pct"]
+       "kernel, calls_per_transcode, ms_per_transcode, avg_us, min_us, pct"]
 for r in rows:
-    out.append(f"{short(r['Name'])}, {int(r['Calls']) / calls:.1f}, {float(r['TotalDurationNs']) / 1e6 / calls:.3f}, {float(r['AverageNs']) / 1e3:.2f}, {r['Percentage']}")
+    out.append(f"{short(r['Name'])}, {int(r['Calls']) / calls:.1f}, {float(r['TotalDurationNs']) / 1e6 / calls:.3f}, {float(r['AverageNs']) / 1e3:.2f}, {float(r['MinNs']) / 1e3:.2f}, {r['Percentage']}")
 open(f"profiles/{tag}_transcode_kernel_stats.csv", "w").write("\n".join(out) + "\n")
 print("\n".join(out[:45]))
 PY
