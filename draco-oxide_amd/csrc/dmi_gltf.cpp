@@ -566,6 +566,15 @@ int dmi_transcode_assets(const dmi_gltf_asset* assets, uint32_t n, const dmi_con
     dev_files[best].push_back(i);
     dev_bytes[best] += bytes_of(i) + 1;
   }
+  if (dbg_on(DMI_DBG_SMALL_HEAD)) {   // (experiment: a quick first stage — the device's smallest files, 1/32 of its bytes — in front of the largest-first list)
+    for (size_t s = 0; s < ND; ++s) {
+      std::vector<uint32_t>& f = dev_files[s];
+      uint64_t acc = 0;
+      size_t k = f.size();
+      while (k > 1 && acc + bytes_of(f[k - 1]) <= dev_bytes[s] / 32) acc += bytes_of(f[--k]);
+      std::rotate(f.begin(), f.begin() + k, f.end());
+    }
+  }
   // stage size per device: a quarter of its share, so that every device pipelines ≥ 4 stages (build ∥ prepare ∥ encode) however many devices split the list —
   // 26 input bytes per triangle is what pos + nrm + uv + indices come to; between 0.5M triangles (a stage pays fixed costs: its chain launch is bounded by
   // its longest stream) and 12M (one above ≈ 16M stops overlapping)

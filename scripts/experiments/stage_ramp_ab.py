@@ -8,8 +8,19 @@ from draco_oxide_amd import synth, gltf, binding
 kind = sys.argv[1] if len(sys.argv) > 1 else "plain"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-settings = [s for s in (sys.argv[4] if len(sys.argv) > 4 else "0,6,12,24").split(",")]
-var = os.environ.get("AB_VAR", "DMI_STAGE_RAMP")
+# settings: '/'-separated; each a ','-separated list of VAR=value (or a bare number = DMI_STAGE_RAMP=<n>, 0 = nothing set)
+settings = [s for s in (sys.argv[4] if len(sys.argv) > 4 else "0/6/12/24").split("/")]
+var = "setting"
+def apply(s):
+    for k in ("DMI_STAGE_RAMP", "DMI_SMALL_HEAD", "DMI_STAGE_PRIMITIVES", "DMI_FILE_ORDER"):
+        os.environ.pop(k, None)
+    if s in ("0", ""):
+        return
+    for kv in s.split(","):
+        k, _, v = kv.partition("=")
+        if not v:
+            k, v = "DMI_STAGE_RAMP", k
+        os.environ[k] = v
 binding.configure_process(huge_page_new=True, numa_pin=True)
 glbs, total = synth.batch_glbs(n, seams=(kind == "seams"))
 alist = binding.AssetList(glbs)
@@ -18,10 +29,7 @@ for _ in range(2):
 res = {s: [] for s in settings}
 for rnd in range(3):
     for s in settings:
-        if s in ("0", ""):
-            os.environ.pop(var, None)
-        else:
-            os.environ[var] = s
+        apply(s)
         cfg = dmi.Config(device=0)   # (the binding fills dmi_debug from the environment per Config)
         gltf.transcode_files(alist, cfg)
         for _ in range(reps):
