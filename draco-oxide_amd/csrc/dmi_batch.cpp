@@ -182,7 +182,7 @@ static int run_phase_a_batched(dmi_job** jobs, const std::vector<uint32_t>& whic
   launch_copy_items(reinterpret_cast<const CopyItem*>(pd + off_copies), n, static_cast<uint8_t*>(arena->slabs_dev), s);
   HIP_TRY(hipMemcpyAsync(arena->slabs_host, arena->slabs_dev, slab_bytes, hipMemcpyDeviceToHost, s));
   for (uint32_t k = 0; k < n; ++k) jobs[which[k]]->readback = static_cast<uint8_t*>(arena->slabs_host) + copies[k].dst_offset;
-  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(long_wait_stream(s));
   return DMI_OK;
 }
 
@@ -335,13 +335,13 @@ struct DeviceBatch {
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const auto t1 = now();
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(long_wait_stream(s)   /* the chain launch: bounded by its longest stream, milliseconds */);
     const auto t2 = now();
     const PackEntry* table = static_cast<const PackEntry*>(arena->table_host);
     const size_t total = (size_t)table[n_descs].offset;
     if ((rc = arena->reserve_host(total))) return rc;
     if (total) HIP_TRY(hipMemcpyAsync(arena->bytes_host, arena->bytes_dev, total, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(long_wait_stream(s));
     const auto t3 = now();
     const uint8_t* bytes_host = static_cast<const uint8_t*>(arena->bytes_host);
     if ((rc = parallel_items(n, n_threads, device, [&](uint32_t j) {
@@ -626,7 +626,7 @@ static int jobs_encode_impl(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
     launch_chains(descs_dev.as<ChainDesc>(), reinterpret_cast<const uint32_t*>(static_cast<uint8_t*>(descs_dev.p) + order_at), (uint32_t)all.size(),
                   reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(descs_dev.p) + counter_at), chain_launch_sparse(longest, total, (uint32_t)all.size()), s);
   }
-  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(long_wait_stream(s));
   const auto t5 = now();
   // read-back: every stream of every job packed into one arena on the device → one table copy + one byte copy
   const uint32_t n_streams = (uint32_t)all.size();

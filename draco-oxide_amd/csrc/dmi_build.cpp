@@ -445,7 +445,7 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
     HIP_TRY(hipMemcpyAsync(g.h_mesh_out, a.mesh_out, (size_t)M * sizeof(MbMeshOut), hipMemcpyDeviceToHost, g.S));
     HIP_TRY(hipMemcpyAsync(g.h_item_out, a.item_out, (size_t)NI * sizeof(MbItemOut), hipMemcpyDeviceToHost, g.S));
     HIP_TRY(hipMemcpyAsync(g.h_totals, a.totals, 16, hipMemcpyDeviceToHost, g.S));
-    HIP_TRY(hipEventCreateWithFlags(&g.ev_counts, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&g.ev_counts, long_wait_flags()));
     HIP_TRY(hipEventRecord(g.ev_counts, g.S));
     return DMI_OK;
   };
@@ -453,13 +453,13 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
   auto fetch = [&](size_t gi) -> int {
     BuildGroup& g = *groups[gi];
     BuiltGroup& bg = *g.built;
-    HIP_TRY(hipEventSynchronize(g.ev_counts));
+    HIP_TRY(long_wait_event(g.ev_counts));
     const size_t a_bytes = (size_t)g.h_totals[0] * 4, b_bytes = (size_t)g.h_totals[1] * 4;
     if (a_bytes > bg.a_bytes || b_bytes > bg.b_bytes) return fail(DMI_ERR_HIP, "device mesh build: arena overflow");
     if (a_bytes) HIP_TRY(hipMemcpyAsync(bg.h_a, bg.d_base, a_bytes, hipMemcpyDeviceToHost, g.S));
     if (g.host_values && b_bytes) HIP_TRY(hipMemcpyAsync(bg.h_b, bg.d_base + bg.b_off, b_bytes, hipMemcpyDeviceToHost, g.S));
     bytes_down += a_bytes + (g.host_values ? b_bytes : 0);
-    HIP_TRY(hipEventCreateWithFlags(&g.ev_done, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&g.ev_done, long_wait_flags()));
     HIP_TRY(hipEventRecord(g.ev_done, g.S));
     return DMI_OK;
   };
@@ -481,7 +481,7 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
   for (auto& gp : groups) {
     BuildGroup& g = *gp;
     BuiltGroup& bg = *g.built;
-    HIP_TRY(hipEventSynchronize(g.ev_done));
+    HIP_TRY(long_wait_event(g.ev_done));
     // (the build's scratch and staging go back without waiting for the stream again: the connectivity stage issued behind the build below would
     //  otherwise hold this thread — 14 ms per 256-mesh stage with attribute tables — until ITS read-back has landed)
     g.settled = true; g.scratch.owner_waits = true;

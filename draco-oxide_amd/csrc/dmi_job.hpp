@@ -488,5 +488,14 @@ struct BuiltDevice : BuiltBase {
 // library streams / NUMA placement shared by the whole-mesh translation units (defined in dmi_prepare.cpp)
 std::shared_ptr<StreamHolder> library_thread_stream(int device);
 hipStream_t library_group_stream(int device, int which);
+// Waits of the batch path that last milliseconds (a stage's device tables, a build's kernels and read-backs, an encode's chain launch): hipStreamSynchronize and
+// hipEventSynchronize on a default event SPIN on a host core for as long as they wait — a quarter of a transcode's CPU time was the runtime's wait loop (sampling
+// profile, scripts/experiments/transcode_sigprof.py) with six coordinator threads waiting beside sixteen walkers on a 16-CPU quota.  These POLL instead: hipEventQuery,
+// a few times back to back, then with 50 µs sleeps between (events created with hipEventBlockingSync still spun in the runtime this image's torch wheel bundles: 7 % of the
+// call's CPU samples stayed inside long_wait_stream).  DMI_DBG_SPIN_WAITS restores the runtime's own waits (A/B).  The short waits of a single whole-mesh call keep
+// spinning: their latency is the call's.
+unsigned long_wait_flags();                    // flags for hipEventCreateWithFlags (timing off)
+hipError_t long_wait_event(hipEvent_t e);      // hipEventSynchronize without a spinning core
+hipError_t long_wait_stream(hipStream_t s);    // returns when everything queued on s so far has finished
 struct NumaScope { void* impl = nullptr; explicit NumaScope(int device); ~NumaScope(); NumaScope(const NumaScope&) = delete; NumaScope& operator=(const NumaScope&) = delete; };
 }  // namespace dmi

@@ -83,7 +83,7 @@ struct PrepGroup {
   int wait_tables() {   // (any worker: the first one blocks on the event, the others on the mutex)
     std::lock_guard<std::mutex> lock(wait_mutex);
     if (tables_in) return DMI_OK;
-    HIP_TRY(hipEventSynchronize(ev_tables_borrowed ? ev_tables_borrowed : ev_tables));
+    HIP_TRY(long_wait_event(ev_tables_borrowed ? ev_tables_borrowed : ev_tables));
     if (int rc = (adopted ? adopted->conn.att : att).complete()) return rc;   // (left-most corners of the attribute tables beyond what came back with the stage: rare)
     tables_in = true;
     return DMI_OK;
@@ -445,7 +445,7 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     HIP_TRY(hipMemcpyAsync(hp + g.rb_onb, d_onb, (size_t)g.total_verts, hipMemcpyDeviceToHost, g.S));
     if (!g.att.items.empty()) { want_lmc = true; HIP_TRY(hipMemcpyAsync(hp + g.rb_lmc, d_lmc, (size_t)g.total_verts * 4, hipMemcpyDeviceToHost, g.S)); }
     if ((rc = g.att.issue(a, g.mem, hp, g.S))) return rc;
-    HIP_TRY(hipEventCreateWithFlags(&g.ev_tables, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&g.ev_tables, long_wait_flags()));
     HIP_TRY(hipEventRecord(g.ev_tables, g.S));
     // part B (the values — more than half of the bytes) is packed and sent mesh by mesh by the walkers, first thing, while they would otherwise
     // wait for this group's tables (walk_one): phase 1 — what every walker waits for — packs faces and maps only
@@ -548,7 +548,7 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
   }
   // (while the device works: the meshes' host tables go back to the pool — a thousand small frees — on the worker threads)
   (void)parallel_over(M, [&](uint32_t, uint32_t kk) -> int { owners[kk].reset(); return DMI_OK; }, nullptr);
-  HIP_TRY(hipStreamSynchronize(S));
+  HIP_TRY(long_wait_stream(S));
   const double t_dev = ms();
   groups.clear();
   if (trace || dbg_on(DMI_DBG_TRACE_STAGES)) {

@@ -176,7 +176,7 @@ int dmi::built_group_issue_tables(BuiltGroup& bg, hipStream_t s) {
   if (verts) HIP_TRY(hipMemcpyAsync(hp + cn.rb_lmc, d_lmc, (size_t)verts * 4, hipMemcpyDeviceToHost, s));
   if (verts) HIP_TRY(hipMemcpyAsync(hp + cn.rb_onb, d_onb, (size_t)verts, hipMemcpyDeviceToHost, s));
   if ((rc_att = st.issue(a, cn.mem, hp, s))) return rc_att;
-  HIP_TRY(hipEventCreateWithFlags(&cn.ev, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&cn.ev, long_wait_flags()));
   HIP_TRY(hipEventRecord(cn.ev, s));
   cn.mem.pool.stream = nullptr; cn.mem.owner_waits = true;   // (the stream is a thread's library stream and the group may outlive the thread: its destructor waits for cn.ev instead)
   cn.issued = true;

@@ -4,6 +4,7 @@
 using namespace dmi;
 
 #include <sched.h>
+#include <sys/prctl.h>
 
 namespace {
 
@@ -109,6 +110,43 @@ ThreadStreams& thread_streams() { static thread_local ThreadStreams t; return t;
 // group's tables overlaps the upload of the next group's faces (the two directions of the link run side by side).
 namespace dmi {
 std::shared_ptr<StreamHolder> library_thread_stream(int device) { return thread_streams().get(0, device); }
+unsigned dmi::long_wait_flags() { return dbg_on(DMI_DBG_SPIN_WAITS) ? hipEventDisableTiming : (hipEventDisableTiming | hipEventBlockingSync); }
+hipError_t dmi::long_wait_event(hipEvent_t e) {
+  if (dbg_on(DMI_DBG_SPIN_WAITS)) return hipEventSynchronize(e);
+  // back-to-back queries for the first 60 µs (a wait that short is on somebody's critical path), then 20 µs naps — with the thread's timer slack at 1 µs
+  // instead of the default 50 (per thread, set once: only this thread's own sleeps get more punctual)
+  thread_local bool slack_set = false;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (bool napping = false;;) {
+    const hipError_t r = hipEventQuery(e);
+    if (r == hipSuccess) return hipEventSynchronize(e);   // (done: returns at once; keeps the runtime's own completion bookkeeping in one place)
+    if (r != hipErrorNotReady) return r;
+    (void)hipGetLastError();                              // (hipErrorNotReady is sticky otherwise)
+    if (!napping) {
+      if (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(60)) continue;
+      napping = true;
+      if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 1000ul, 0ul, 0ul, 0ul); slack_set = true; }
+    }
+    std::this_thread::sleep_for(std::chrono::microseconds(20));
+  }
+}
+hipError_t dmi::long_wait_stream(hipStream_t s) {
+  if (dbg_on(DMI_DBG_SPIN_WAITS)) return hipStreamSynchronize(s);
+  // one blocking event per thread and device (an event belongs to the device that was current when it was created)
+  struct Ev { int device = -1; hipEvent_t e = nullptr; ~Ev() { if (e) (void)hipEventDestroy(e); } };
+  thread_local Ev ev[2];
+  int device = 0;
+  if (hipError_t r = hipGetDevice(&device)) return r;
+  Ev* slot = ev[0].device == device ? &ev[0] : (ev[1].device == device ? &ev[1] : nullptr);
+  if (!slot) {
+    slot = ev[0].e ? &ev[1] : &ev[0];
+    if (slot->e) { (void)hipEventDestroy(slot->e); slot->e = nullptr; }
+    if (hipError_t r = hipEventCreateWithFlags(&slot->e, hipEventDisableTiming | hipEventBlockingSync)) { slot->device = -1; return r; }
+    slot->device = device;
+  }
+  if (hipError_t r = hipEventRecord(slot->e, s)) return r;
+  return long_wait_event(slot->e);
+}
 hipStream_t library_group_stream(int device, int which) {
   const std::shared_ptr<StreamHolder> h = thread_streams().get(1 + (which & 1), device);
   return h ? h->s : nullptr;
