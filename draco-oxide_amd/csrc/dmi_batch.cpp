@@ -135,7 +135,7 @@ struct BatchPlan {
     if (groups.size() < 4) { for (const Group& g : groups) fill_group(ph, g); return; }
     std::atomic<size_t> next{0};   // groups differ a lot in size: a few host threads pull them
     auto work = [&] { for (size_t k; (k = next.fetch_add(1)) < groups.size();) fill_group(ph, groups[k]); };
-    std::vector<std::thread> th;
+    std::vector<dmi::Thread> th;
     for (size_t t = 1; t < std::min<size_t>(groups.size(), 8); ++t) th.emplace_back(with_debug(work));
     work();
     for (auto& x : th) x.join();
@@ -237,7 +237,7 @@ static int parallel_items(uint32_t n, uint32_t n_threads, int device, const std:
   };
   if (n_threads == 1) work(0);
   else {
-    std::vector<std::thread> th;
+    std::vector<dmi::Thread> th;
     for (uint32_t t = 0; t < n_threads; ++t) th.emplace_back(with_debug(work), t);
     for (auto& x : th) x.join();
   }
@@ -485,7 +485,7 @@ int dmi_jobs_encode_devices(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
     if (rcs[g]) { errs[g] = g_last_error; return; }
     for (size_t k = 0; k < at.size(); ++k) outs[at[k]] = got[k];
   };
-  std::vector<std::thread> th;
+  std::vector<dmi::Thread> th;
   for (size_t g = 1; g < devices.size(); ++g) th.emplace_back(with_debug(work), g);
   work(0);
   for (auto& x : th) x.join();
@@ -521,7 +521,7 @@ static int jobs_encode_impl(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
     };
     if (n_threads == 1) work(0);
     else {
-      std::vector<std::thread> th;
+      std::vector<dmi::Thread> th;
       for (uint32_t t = 0; t < n_threads; ++t) th.emplace_back(with_debug(work), t);
       for (auto& x : th) x.join();
     }
@@ -595,7 +595,7 @@ static int jobs_encode_impl(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
     };
     if (n_threads == 1) work(0);
     else {
-      std::vector<std::thread> th;
+      std::vector<dmi::Thread> th;
       for (uint32_t t = 0; t < n_threads; ++t) th.emplace_back(with_debug(work), t);
       for (auto& x : th) x.join();
     }

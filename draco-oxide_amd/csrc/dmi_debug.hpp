@@ -20,7 +20,7 @@ struct DebugScope {
   DebugScope(const DebugScope&) = delete;
   DebugScope& operator=(const DebugScope&) = delete;
 };
-// a thread body that works under the spawning thread's switches: std::thread(with_debug([&] { … }))
+// a thread body that works under the spawning thread's switches: dmi::Thread(with_debug([&] { … }))
 template <class F> inline auto with_debug(F f) {
   const dmi_debug* cur = dbg_ptr();
   return [cur, f = std::move(f)](auto&&... args) mutable { DebugScope scope(cur); return f(std::forward<decltype(args)>(args)...); };

@@ -512,7 +512,7 @@ int encode_phase_c3(dmi_job* job, dmi_buffer* out) {   // host: splice the attri
     void bytes(const uint8_t* q, size_t k) {
       if (k >= ((size_t)4 << 20)) {   // a large stream (the position stream of a 10M-triangle mesh is 9 MB): the copy — and the first touch of the output pages — on a few threads
         const size_t parts = std::min<size_t>(8, k >> 21);
-        std::vector<std::thread> th;
+        std::vector<dmi::Thread> th;
         for (size_t t = 0; t < parts; ++t) th.emplace_back([=] { const size_t lo = k * t / parts, hi = k * (t + 1) / parts; std::memcpy(p + n + lo, q + lo, hi - lo); });
         for (auto& x : th) x.join();
       } else if (k) {
@@ -677,7 +677,7 @@ static int encode_tail_host(dmi_job* job, dmi_buffer* out, float* chain_ms, floa
   };
   {
     const size_t n_threads = std::max<size_t>(1, std::min<size_t>({streams.size(), (size_t)host_threads(), (size_t)16}));
-    std::vector<std::thread> th;
+    std::vector<dmi::Thread> th;
     for (size_t t = 1; t < n_threads; ++t) th.emplace_back(with_debug(work));
     work();
     for (auto& x : th) x.join();

@@ -592,9 +592,9 @@ int dmi_transcode_assets(const dmi_gltf_asset* assets, uint32_t n, const dmi_con
   const unsigned host_thr = process_host_threads();
   // (when the last stage is coded all its files become ready at once and every other thread of the call is idle: half the host's threads write them)
   const unsigned n_assemblers = std::max(1u, std::min(8u, host_thr / 2));
-  std::vector<std::thread> assemblers;
+  std::vector<dmi::Thread> assemblers;
   for (unsigned k = 0; k < n_assemblers; ++k) assemblers.emplace_back(assemble_loop, R.get());
-  struct Stop { dmi_transcoded* R; std::vector<std::thread>& th; ~Stop() { { std::lock_guard<std::mutex> lock(R->q_mutex); R->q_closed = true; } R->q_cv.notify_all(); for (auto& t : th) if (t.joinable()) t.join(); } } stop{R.get(), assemblers};
+  struct Stop { dmi_transcoded* R; std::vector<dmi::Thread>& th; ~Stop() { { std::lock_guard<std::mutex> lock(R->q_mutex); R->q_closed = true; } R->q_cv.notify_all(); for (auto& t : th) if (t.joinable()) t.join(); } } stop{R.get(), assemblers};
 
   R->assets.resize(n);
   // ---- parse: containers, JSON, plans, accessor descriptors — a pool of threads over the files in the order the devices will push them (round-robin over
@@ -680,8 +680,8 @@ int dmi_transcode_assets(const dmi_gltf_asset* assets, uint32_t n, const dmi_con
   };
   const unsigned n_parsers = std::max(1u, std::min({8u, host_thr / 4u, n ? n : 1u}));
   {
-    std::vector<std::thread> parsers, pushers;
-    struct Join { std::vector<std::thread>& a; std::vector<std::thread>& b; ~Join() { for (auto& t : a) if (t.joinable()) t.join(); for (auto& t : b) if (t.joinable()) t.join(); } } join{parsers, pushers};
+    std::vector<dmi::Thread> parsers, pushers;
+    struct Join { std::vector<dmi::Thread>& a; std::vector<dmi::Thread>& b; ~Join() { for (auto& t : a) if (t.joinable()) t.join(); for (auto& t : b) if (t.joinable()) t.join(); } } join{parsers, pushers};
     for (unsigned k = 0; k < n_parsers; ++k) parsers.emplace_back(parse_loop);
     for (size_t s = 1; s < ND; ++s) pushers.emplace_back(push_loop, s);
     push_loop(0);   // (the caller's thread is the first device's pusher; the parsers run beside it)

@@ -21,12 +21,47 @@
 #include <mutex>
 #include <new>
 #include <thread>
+#include <memory>
+#include <system_error>
+#include <type_traits>
+#include <pthread.h>
 #include <vector>
 
 #include "../../include/draco_mi.h"
 #include "dmi_debug.hpp"
 
 namespace dmi {
+
+// Library threads: std::thread's interface on pthread_create with a 1 MiB stack.  A stage of the batch path starts dozens of short-lived threads (16 walkers per
+// prepare, the build's packers, the assemblers: ≈ 300 per 1024-file transcode) and glibc keeps at most 40 MB of finished threads' stacks for re-use — five of the
+// default 8 MiB ones: the rest is an mmap, an mprotect, first-touch faults and a munmap each (pthread_create + mprotect + munmap: 7 % of the call's CPU samples,
+// scripts/experiments/transcode_sigprof.py).  At 1 MiB the cache holds them all.  Nothing in the library recurses deeply (the walks keep explicit stacks, the JSON
+// parser stops at 200 levels).
+class Thread {
+  pthread_t h_{};
+  bool joinable_ = false;
+  static void* tramp(void* p) { std::unique_ptr<std::function<void()>> f(static_cast<std::function<void()>*>(p)); (*f)(); return nullptr; }
+ public:
+  Thread() noexcept = default;
+  template <class F, class... A, class = typename std::enable_if<!std::is_same<typename std::decay<F>::type, Thread>::value>::type>
+  explicit Thread(F&& f, A&&... a) {
+    auto* fn = new std::function<void()>(std::bind(std::forward<F>(f), std::forward<A>(a)...));
+    pthread_attr_t at;
+    pthread_attr_init(&at);
+    pthread_attr_setstacksize(&at, (size_t)1 << 20);
+    const int rc = pthread_create(&h_, &at, tramp, fn);
+    pthread_attr_destroy(&at);
+    if (rc) { delete fn; throw std::system_error(rc, std::generic_category(), "pthread_create"); }
+    joinable_ = true;
+  }
+  Thread(const Thread&) = delete;
+  Thread& operator=(const Thread&) = delete;
+  Thread(Thread&& o) noexcept : h_(o.h_), joinable_(o.joinable_) { o.joinable_ = false; }
+  Thread& operator=(Thread&& o) noexcept { if (joinable_) std::terminate(); h_ = o.h_; joinable_ = o.joinable_; o.joinable_ = false; return *this; }
+  ~Thread() { if (joinable_) std::terminate(); }
+  bool joinable() const noexcept { return joinable_; }
+  void join() { if (!joinable_) throw std::system_error(EINVAL, std::generic_category(), "join"); pthread_join(h_, nullptr); joinable_ = false; }
+};
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 int host_fail(int code, const std::string& msg);   // sets dmi_last_error() for the calling thread, returns code
@@ -86,7 +121,7 @@ inline void parallel_for(size_t n, Fn&& fn) {
   const unsigned hw = host_threads();
   const size_t n_threads = n < (1u << 20) ? 1 : std::max<size_t>(1, std::min<size_t>({(size_t)hw, (size_t)32, n >> 18}));
   if (n_threads == 1) { fn((size_t)0, n); return; }
-  std::vector<std::thread> th;
+  std::vector<dmi::Thread> th;
   const dmi_debug* cur = dbg_ptr();
   for (size_t t = 0; t < n_threads; ++t) th.emplace_back([&, t] { DebugScope scope(cur); fn(n * t / n_threads, n * (t + 1) / n_threads); });
   for (auto& x : th) x.join();
@@ -295,7 +330,7 @@ bool append_tagged_state(uint32_t state_minus_base, std::vector<uint8_t>& out); 
 
 // fn(i) for i in [0, n) on at most `max_threads` host threads (a fixed pool, not a thread per item: n may come out of an untrusted file).
 // An exception in a worker — std::bad_alloc on a size a damaged file asked for, std::system_error when the process is out of threads — is
-// caught there (a throw out of a std::thread body is std::terminate) and reported: returns 0, 1 = out of memory, 2 = another exception.
+// caught there (a throw out of a dmi::Thread body is std::terminate) and reported: returns 0, 1 = out of memory, 2 = another exception.
 template <class Fn>
 inline int guarded_pool(size_t n, unsigned max_threads, Fn&& fn) {
   std::atomic<size_t> next{0};
@@ -309,7 +344,7 @@ inline int guarded_pool(size_t n, unsigned max_threads, Fn&& fn) {
     catch (...) { int z = 0; status.compare_exchange_strong(z, 2); next.store(n); }
   };
   const size_t nt = std::max<size_t>(1, std::min<size_t>(n, max_threads ? max_threads : 1));
-  std::vector<std::thread> th;
+  std::vector<dmi::Thread> th;
   try {
     for (size_t t = 1; t < nt; ++t) th.emplace_back(work);
   } catch (...) { /* fewer threads than planned: the ones that started (and this one) take the items */ }

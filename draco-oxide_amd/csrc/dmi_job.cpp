@@ -26,7 +26,7 @@ bool dmi::SeqStream::start(int dev, hipStream_t s, uint32_t capacity) {
   d_seq = mem.take<uint32_t>(capacity);
   if (!d_seq) return false;
   if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ev = nullptr; return false; }
-  uploader = std::thread([this] {
+  uploader = dmi::Thread([this] {
     if (hipSetDevice(device) != hipSuccess) { failed.store(true); return; }
     uint32_t sent = 0;
     constexpr uint32_t kPiece = 1u << 20;   // 4 MiB pieces; the thread wakes once a millisecond (or when the walk is over): a few dozen wake-ups per 10M-triangle mesh

@@ -397,7 +397,7 @@ struct SeqStream {
   SeqProgress progress;
   std::atomic<uint32_t> final_n{0xFFFFFFFFu};   // set by the sequencer's caller when the walk is over
   std::atomic<bool> failed{false};
-  std::thread uploader;
+  dmi::Thread uploader;
   std::mutex wake_mutex; std::condition_variable wake;   // (the walk's end wakes the uploader at once)
   hipEvent_t ev = nullptr;          // recorded behind the last piece
   const uint32_t* host = nullptr;   // (after join) the array that was shipped

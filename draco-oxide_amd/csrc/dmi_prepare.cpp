@@ -242,7 +242,7 @@ extern "C++" int dmi::build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std
       o.ct.build_attribute_into(o.ct.att[k], maps[k], like_position(maps[k], map_points[k]));
     };
     if (maps.size() > 1 && overlap) {
-      std::vector<std::thread> th;
+      std::vector<dmi::Thread> th;
       for (size_t k = 0; k < maps.size(); ++k) th.emplace_back(with_debug(build_one), k);
       for (auto& x : th) x.join();
     } else {
@@ -252,13 +252,13 @@ extern "C++" int dmi::build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std
       for (size_t j = 0; j < k; ++j) if (maps[j] == maps[k]) { o.ct.copy_attribute_into(o.ct.att[k], o.ct.att[j]); o.ct.att[k].alias_of = (int)j; break; }
     t_att = since(a0);
   };
-  std::thread att_thread, seq_thread, flag_thread;
+  dmi::Thread att_thread, seq_thread, flag_thread;
   EdgebreakerHooks hooks;
   if (overlap) {
     // the sequencer's per-vertex boundary test, ahead of time (beside the start of the traversal)
-    if (!boundary_flags) flag_thread = std::thread(with_debug([&] { TableRef tr{o.ct.F, o.ct.V, o.ct.c2v, o.ct.opp, o.ct.lmc}; vertex_boundary_flags(tr, on_boundary); }));
-    att_thread = std::thread(with_debug(build_att_tables));
-    hooks.seeds_ready = [&] { if (flag_thread.joinable()) flag_thread.join(); seq_thread = std::thread(with_debug([&] { const auto q0 = tick(); sequence_universal(); t_seq = since(q0); })); };
+    if (!boundary_flags) flag_thread = dmi::Thread(with_debug([&] { TableRef tr{o.ct.F, o.ct.V, o.ct.c2v, o.ct.opp, o.ct.lmc}; vertex_boundary_flags(tr, on_boundary); }));
+    att_thread = dmi::Thread(with_debug(build_att_tables));
+    hooks.seeds_ready = [&] { if (flag_thread.joinable()) flag_thread.join(); seq_thread = dmi::Thread(with_debug([&] { const auto q0 = tick(); sequence_universal(); t_seq = since(q0); })); };
     hooks.before_seams = [&] { if (att_thread.joinable()) att_thread.join(); };
   } else {
     build_att_tables();
@@ -280,7 +280,7 @@ extern "C++" int dmi::build_connectivity(const dmi_mesh* mesh, ConnOwner& o, std
   // views: attribute i uses the universal table when i == 0 or no attribute table i-1 exists
   // (all_inclusive_corner_table.rs:31-45)
   {
-    std::vector<std::thread> th;   // sequences of attribute tables with seams: independent walks
+    std::vector<dmi::Thread> th;   // sequences of attribute tables with seams: independent walks
     for (uint32_t i = 0; i < mesh->num_atts; ++i) {
       dmi_corner_table& v = o.views[i];
       v.num_faces = o.ct.F;

@@ -173,7 +173,7 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
       for (uint32_t i; (i = next.fetch_add(1)) < count;) { const int rc = fn(t, order[i]); if (rc) { rcs[t] = rc; errs[t] = g_last_error; next.store(count); return; } }
     };
     if (nt == 1) work(0);
-    else { std::vector<std::thread> th; for (uint32_t t = 0; t < nt; ++t) th.emplace_back(with_debug(work), t); for (auto& x : th) x.join(); }
+    else { std::vector<dmi::Thread> th; for (uint32_t t = 0; t < nt; ++t) th.emplace_back(with_debug(work), t); for (auto& x : th) x.join(); }
     for (uint32_t t = 0; t < nt; ++t) if (rcs[t]) return fail(rcs[t], errs[t]);
     return DMI_OK;
   };
@@ -288,10 +288,10 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
   };
   // The walkers start as soon as the FIRST group is on its way: the packing and sending of the later groups (a few threads of their own) runs
   // beside the walks of the earlier ones (phase 1 used to finish for all groups first: 4–5 ms of a 20 ms prepare with every walker idle).
-  std::thread walkers;
+  dmi::Thread walkers;
   int rc_walk = DMI_OK;
   std::string err_walk;
-  struct JoinWalkers { std::thread& t; std::vector<std::unique_ptr<PrepGroup>>& gs; ~JoinWalkers() { if (t.joinable()) { for (auto& g : gs) { int z = 0; g->issued.compare_exchange_strong(z, -1); } t.join(); } } } join_walkers{walkers, groups};
+  struct JoinWalkers { dmi::Thread& t; std::vector<std::unique_ptr<PrepGroup>>& gs; ~JoinWalkers() { if (t.joinable()) { for (auto& g : gs) { int z = 0; g->issued.compare_exchange_strong(z, -1); } t.join(); } } } join_walkers{walkers, groups};
   auto pack_threads = [&]() -> uint32_t { return walkers.joinable() ? std::max(2u, n_threads / 4) : 0u; };   // (0 = all: nothing else runs yet)
   // ---- phase 1, group by group: layout, pack, send, build the tables, fetch them (nothing here waits for the device) ----
   for (size_t gi = 0; gi < groups.size(); ++gi) {
@@ -327,7 +327,7 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
       g.rb_opp = bg.conn.rb_opp; g.rb_c2v = bg.conn.rb_c2v; g.rb_lmc = bg.conn.rb_lmc; g.rb_onb = bg.conn.rb_onb; g.rb_words = bg.conn.rb_words;
       g.ev_tables_borrowed = bg.conn.ev;
       g.issued.store(1, std::memory_order_release);
-      if (!walkers.joinable() && M > 1) walkers = std::thread(with_debug([&] { rc_walk = parallel_over(M, walk_one, nullptr); if (rc_walk) err_walk = g_last_error; }));
+      if (!walkers.joinable() && M > 1) walkers = dmi::Thread(with_debug([&] { rc_walk = parallel_over(M, walk_one, nullptr); if (rc_walk) err_walk = g_last_error; }));
       continue;
     }
     g.n_desc = Mg;
@@ -451,7 +451,7 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     // wait for this group's tables (walk_one): phase 1 — what every walker waits for — packs faces and maps only
     HIP_TRY(hipEventCreateWithFlags(&g.ev_values, hipEventDisableTiming));
     g.issued.store(1, std::memory_order_release);
-    if (!walkers.joinable() && M > 1) walkers = std::thread(with_debug([&] { rc_walk = parallel_over(M, walk_one, nullptr); if (rc_walk) err_walk = g_last_error; }));
+    if (!walkers.joinable() && M > 1) walkers = dmi::Thread(with_debug([&] { rc_walk = parallel_over(M, walk_one, nullptr); if (rc_walk) err_walk = g_last_error; }));
   }
   const double t_issue = ms();
   if (walkers.joinable()) { walkers.join(); rc = rc_walk; if (rc) fail(rc, err_walk); }
@@ -632,7 +632,7 @@ static int meshes_prepare_impl(const dmi_mesh* meshes, uint32_t n, const dmi_con
       if (dev_rc[g]) dev_err[g] = g_last_error;
     };
     if (devices.size() == 1) run_device(0);
-    else { std::vector<std::thread> th; for (size_t g = 0; g < devices.size(); ++g) th.emplace_back(with_debug(run_device), g); for (auto& x : th) x.join(); }
+    else { std::vector<dmi::Thread> th; for (size_t g = 0; g < devices.size(); ++g) th.emplace_back(with_debug(run_device), g); for (auto& x : th) x.join(); }
     for (size_t g = 0; g < devices.size(); ++g)
       if (dev_rc[g]) {
         for (uint32_t k = 0; k < n; ++k) { if (jobs[k]) { dmi_job_destroy(jobs[k]); jobs[k] = nullptr; } dmi_free(&header_and_connectivity[k]); }
@@ -663,7 +663,7 @@ static int meshes_prepare_impl(const dmi_mesh* meshes, uint32_t n, const dmi_con
   if (!any_left) {}
   else if (n_threads == 1) work(0);
   else {
-    std::vector<std::thread> th;
+    std::vector<dmi::Thread> th;
     for (uint32_t t = 0; t < n_threads; ++t) th.emplace_back(with_debug(work), t);
     for (auto& x : th) x.join();
   }
@@ -792,7 +792,7 @@ int dmi_built_meshes_prepare(const dmi_built_mesh* built, uint32_t n, const dmi_
       }
     };
     if (nt == 1) work(0);
-    else { std::vector<std::thread> th; for (uint32_t t = 0; t < nt; ++t) th.emplace_back(with_debug(work), t); for (auto& x : th) x.join(); }
+    else { std::vector<dmi::Thread> th; for (uint32_t t = 0; t < nt; ++t) th.emplace_back(with_debug(work), t); for (auto& x : th) x.join(); }
     for (size_t k = 0; k < singles.size(); ++k) if (rcs[k]) { g_last_error = errs[k]; return bail(rcs[k]); }
   }
   return DMI_OK;

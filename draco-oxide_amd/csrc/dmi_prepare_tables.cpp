@@ -131,7 +131,7 @@ int dmi::built_group_issue_tables(BuiltGroup& bg, hipStream_t s) {
       }
     };
     const size_t n_threads = std::min<size_t>({pairs.size(), (size_t)host_threads(), (size_t)16});
-    std::vector<std::thread> th;
+    std::vector<dmi::Thread> th;
     for (size_t t = 1; t < n_threads; ++t) th.emplace_back(with_debug(work));
     work();
     for (auto& x : th) x.join();

@@ -35,25 +35,36 @@ struct NumaPin {
     if (!(process_flags() & DMI_PROCESS_NUMA_PIN)) return;   // (opt-in since round 6: dmi_configure_process)
     const int node = device_numa_node(device);
     if (node < 0) return;
+    // the node's CPU list, read once per node (a batch pipeline opens a scope per stage step)
+    static std::mutex m;
+    static std::vector<std::pair<int, cpu_set_t>> lists;
     cpu_set_t want;
     CPU_ZERO(&want);
-    const std::string path = "/sys/devices/system/node/node" + std::to_string(node) + "/cpulist";
-    std::FILE* f = std::fopen(path.c_str(), "r");
-    if (!f) return;
-    char buf[1024] = {0};
-    const bool got = std::fgets(buf, sizeof buf, f) != nullptr;
-    std::fclose(f);
-    if (!got) return;
-    for (char* p = buf; *p && *p != '\n';) {   // "0-63,128-191"
-      char* end = nullptr;
-      const long lo = std::strtol(p, &end, 10);
-      if (end == p) break;
-      long hi = lo;
-      p = end;
-      if (*p == '-') { hi = std::strtol(p + 1, &end, 10); p = end; }
-      for (long c = lo; c <= hi && c < CPU_SETSIZE; ++c) CPU_SET((int)c, &want);
-      if (*p == ',') ++p;
+    {
+      std::lock_guard<std::mutex> lock(m);
+      bool known = false;
+      for (auto& e : lists) if (e.first == node) { want = e.second; known = true; }
+      if (!known) {
+        const std::string path = "/sys/devices/system/node/node" + std::to_string(node) + "/cpulist";
+        char buf[1024] = {0};
+        if (std::FILE* f = std::fopen(path.c_str(), "r")) {
+          if (!std::fgets(buf, sizeof buf, f)) buf[0] = 0;
+          std::fclose(f);
+        }
+        for (char* p = buf; *p && *p != '\n';) {   // "0-63,128-191"
+          char* end = nullptr;
+          const long lo = std::strtol(p, &end, 10);
+          if (end == p) break;
+          long hi = lo;
+          p = end;
+          if (*p == '-') { hi = std::strtol(p + 1, &end, 10); p = end; }
+          for (long c = lo; c <= hi && c < CPU_SETSIZE; ++c) CPU_SET((int)c, &want);
+          if (*p == ',') ++p;
+        }
+        lists.push_back({node, want});
+      }
     }
+    if (CPU_COUNT(&want) == 0) return;
     if (sched_getaffinity(0, sizeof old, &old) != 0) return;
     cpu_set_t both;
     CPU_AND(&both, &old, &want);
@@ -110,8 +121,8 @@ ThreadStreams& thread_streams() { static thread_local ThreadStreams t; return t;
 // group's tables overlaps the upload of the next group's faces (the two directions of the link run side by side).
 namespace dmi {
 std::shared_ptr<StreamHolder> library_thread_stream(int device) { return thread_streams().get(0, device); }
-unsigned dmi::long_wait_flags() { return dbg_on(DMI_DBG_SPIN_WAITS) ? hipEventDisableTiming : (hipEventDisableTiming | hipEventBlockingSync); }
-hipError_t dmi::long_wait_event(hipEvent_t e) {
+unsigned long_wait_flags() { return dbg_on(DMI_DBG_SPIN_WAITS) ? hipEventDisableTiming : (hipEventDisableTiming | hipEventBlockingSync); }
+hipError_t long_wait_event(hipEvent_t e) {
   if (dbg_on(DMI_DBG_SPIN_WAITS)) return hipEventSynchronize(e);
   // back-to-back queries for the first 60 µs (a wait that short is on somebody's critical path), then 20 µs naps — with the thread's timer slack at 1 µs
   // instead of the default 50 (per thread, set once: only this thread's own sleeps get more punctual)
@@ -130,7 +141,7 @@ hipError_t dmi::long_wait_event(hipEvent_t e) {
     std::this_thread::sleep_for(std::chrono::microseconds(20));
   }
 }
-hipError_t dmi::long_wait_stream(hipStream_t s) {
+hipError_t long_wait_stream(hipStream_t s) {
   if (dbg_on(DMI_DBG_SPIN_WAITS)) return hipStreamSynchronize(s);
   // one blocking event per thread and device (an event belongs to the device that was current when it was created)
   struct Ev { int device = -1; hipEvent_t e = nullptr; ~Ev() { if (e) (void)hipEventDestroy(e); } };

@@ -84,7 +84,7 @@ struct dmi_transcoder {
   std::mutex result_mutex;
   // steps
   Slot to_build, to_prepare, to_encode;
-  std::thread t_build, t_build2, t_prepare, t_prepare2, t_encode, t_encode2;
+  dmi::Thread t_build, t_build2, t_prepare, t_prepare2, t_encode, t_encode2;
   std::atomic<int> builders_left{0}, preparers_left{0};
   std::mutex err_mutex;
   int rc = DMI_OK;
@@ -177,13 +177,13 @@ struct dmi_transcoder {
     // wavefront per SIMD, the rest of the chip idle) — the launches of consecutive stages overlap instead of queueing at the end of the call.
     // (1024 files, one thread for one of the steps: 100–125 ms against 86–97.)
     builders_left = 2;
-    t_build = std::thread([this] { build_loop(); });
-    t_build2 = std::thread([this] { build_loop(); });
+    t_build = dmi::Thread([this] { build_loop(); });
+    t_build2 = dmi::Thread([this] { build_loop(); });
     preparers_left = 2;
-    t_prepare = std::thread([this] { prepare_loop(); });
-    t_prepare2 = std::thread([this] { prepare_loop(); });
-    t_encode = std::thread([this] { encode_loop(); });
-    t_encode2 = std::thread([this] { encode_loop(); });
+    t_prepare = dmi::Thread([this] { prepare_loop(); });
+    t_prepare2 = dmi::Thread([this] { prepare_loop(); });
+    t_encode = dmi::Thread([this] { encode_loop(); });
+    t_encode2 = dmi::Thread([this] { encode_loop(); });
   }
   // hands the primitives pushed so far to the build step once they make a stage (or all of them: flush)
   void dispatch(bool flush) {

@@ -581,7 +581,7 @@ int run_edgebreaker(const CornerTables& t, EdgebreakerResult& out, std::string& 
     std::vector<size_t> todo(own);
     if (need_zero) todo.push_back(A);
     if (todo.size() > 1 && n >= (1u << 20) && host_threads() > 1) {
-      std::vector<std::thread> th;
+      std::vector<dmi::Thread> th;
       for (size_t j : todo) th.emplace_back(with_debug(code_one), j);
       for (auto& x : th) x.join();
     } else for (size_t j : todo) code_one(j);
