@@ -235,12 +235,7 @@ static int parallel_items(uint32_t n, uint32_t n_threads, int device, const std:
     const uint32_t lo = (uint32_t)((uint64_t)n * t / n_threads), hi = (uint32_t)((uint64_t)n * (t + 1) / n_threads);
     for (uint32_t k = lo; k < hi; ++k) { const int rc = fn(k); if (rc) { rcs[t] = rc; errs[t] = g_last_error; return; } }
   };
-  if (n_threads == 1) work(0);
-  else {
-    std::vector<dmi::Thread> th;
-    for (uint32_t t = 0; t < n_threads; ++t) th.emplace_back(with_debug(work), t);
-    for (auto& x : th) x.join();
-  }
+  run_threads(n_threads, work);
   for (uint32_t t = 0; t < n_threads; ++t) if (rcs[t]) return fail(rcs[t], errs[t]);
   return DMI_OK;
 }
@@ -519,12 +514,7 @@ static int jobs_encode_impl(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
         }
       }
     };
-    if (n_threads == 1) work(0);
-    else {
-      std::vector<dmi::Thread> th;
-      for (uint32_t t = 0; t < n_threads; ++t) th.emplace_back(with_debug(work), t);
-      for (auto& x : th) x.join();
-    }
+    run_threads(n_threads, work);
     for (uint32_t t = 0; t < n_threads; ++t) if (rcs[t]) return fail(rcs[t], errs[t]);
     return DMI_OK;
   };
@@ -593,12 +583,7 @@ static int jobs_encode_impl(dmi_job** jobs, uint32_t n, dmi_buffer* outs) {
       if (trace && t == 0) std::fprintf(stderr, "[dmi] worker 0: %zu jobs, phase A issue %.2f ms, waits for histograms %.2f, phase B host+issue %.2f, final wait %.2f\n", mine.size(),
                                         std::chrono::duration<double, std::milli>(w1 - w0).count(), wait_ms, b_ms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w2).count());
     };
-    if (n_threads == 1) work(0);
-    else {
-      std::vector<dmi::Thread> th;
-      for (uint32_t t = 0; t < n_threads; ++t) th.emplace_back(with_debug(work), t);
-      for (auto& x : th) x.join();
-    }
+    run_threads(n_threads, work);
     for (uint32_t t = 0; t < n_threads; ++t) if (rcs[t]) return fail(rcs[t], errs[t]);
   }
   const auto t3 = now();

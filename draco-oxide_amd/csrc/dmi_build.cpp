@@ -49,8 +49,7 @@ int run_parallel(uint32_t count, uint32_t n_threads, const std::function<int(uin
   auto work = [&](uint32_t t) {
     for (uint32_t i; (i = next.fetch_add(1)) < count;) { const int rc = fn(order[i]); if (rc) { rcs[t] = rc; errs[t] = g_last_error; next.store(count); return; } }
   };
-  if (nt == 1) work(0);
-  else { std::vector<dmi::Thread> th; for (uint32_t t = 0; t < nt; ++t) th.emplace_back(with_debug(work), t); for (auto& x : th) x.join(); }
+  run_threads(nt, work);
   for (uint32_t t = 0; t < nt; ++t) if (rcs[t]) return fail(rcs[t], errs[t]);
   return DMI_OK;
 }

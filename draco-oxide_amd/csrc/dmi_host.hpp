@@ -61,7 +61,15 @@ class Thread {
   ~Thread() { if (joinable_) std::terminate(); }
   bool joinable() const noexcept { return joinable_; }
   void join() { if (!joinable_) throw std::system_error(EINVAL, std::generic_category(), "join"); pthread_join(h_, nullptr); joinable_ = false; }
+  void detach() { if (joinable_) { pthread_detach(h_); joinable_ = false; } }
 };
+// work(t) for t in [0, n): t = 0 on the calling thread, the others on threads of a process-wide pool that outlive the call (they are parked, not joined: a
+// stage of the batch path used to create and join its sixteen walkers, its packers, its coders — pthread_create and thread start-up were 7 % of a transcode's
+// CPU samples and a millisecond of serial spawning per stage).  A pool thread runs under the caller's switches (DebugScope), CPU mask and current HIP device;
+// a task that calls run_threads itself gets further threads (the pool grows to the deepest demand seen, it never waits for a free thread).  Returns when all
+// n calls have returned.  `work` must not throw.
+void run_threads(uint32_t n, const std::function<void(uint32_t)>& work);
+void pool_submit(std::function<void()> fn);   // fn on a parked (or new) pool thread; returns at once
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 int host_fail(int code, const std::string& msg);   // sets dmi_last_error() for the calling thread, returns code
@@ -121,10 +129,7 @@ inline void parallel_for(size_t n, Fn&& fn) {
   const unsigned hw = host_threads();
   const size_t n_threads = n < (1u << 20) ? 1 : std::max<size_t>(1, std::min<size_t>({(size_t)hw, (size_t)32, n >> 18}));
   if (n_threads == 1) { fn((size_t)0, n); return; }
-  std::vector<dmi::Thread> th;
-  const dmi_debug* cur = dbg_ptr();
-  for (size_t t = 0; t < n_threads; ++t) th.emplace_back([&, t] { DebugScope scope(cur); fn(n * t / n_threads, n * (t + 1) / n_threads); });
-  for (auto& x : th) x.join();
+  run_threads((uint32_t)n_threads, [&](uint32_t t) { fn(n * t / n_threads, n * (t + 1) / n_threads); });
 }
 
 // ---- recycled host arrays ----
@@ -344,12 +349,9 @@ inline int guarded_pool(size_t n, unsigned max_threads, Fn&& fn) {
     catch (...) { int z = 0; status.compare_exchange_strong(z, 2); next.store(n); }
   };
   const size_t nt = std::max<size_t>(1, std::min<size_t>(n, max_threads ? max_threads : 1));
-  std::vector<dmi::Thread> th;
   try {
-    for (size_t t = 1; t < nt; ++t) th.emplace_back(work);
-  } catch (...) { /* fewer threads than planned: the ones that started (and this one) take the items */ }
-  work();
-  for (auto& x : th) x.join();
+    run_threads((uint32_t)nt, [&](uint32_t) { work(); });
+  } catch (...) { int z = 0; status.compare_exchange_strong(z, 2); }   // (the process is out of threads)
   return status.load();
 }
 

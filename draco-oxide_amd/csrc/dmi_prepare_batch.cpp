@@ -74,6 +74,10 @@ struct PrepGroup {
   bool tables_in = false;
   std::mutex wait_mutex;
   std::atomic<int> issued{0};   // 1: phase 1 of this group is through (its fields are final, its tables on their way); -1: phase 1 failed — the walkers give up
+  std::mutex issued_mutex;      // (the walkers of a group not yet issued sleep on issued_cv: sixteen of them polling every 50 µs were a tenth of a transcode's CPU samples)
+  std::condition_variable issued_cv;
+  void set_issued(int v) { { std::lock_guard<std::mutex> lock(issued_mutex); issued.store(v, std::memory_order_release); } issued_cv.notify_all(); }
+  bool fail_unissued() { std::lock_guard<std::mutex> lock(issued_mutex); int z = 0; const bool changed = issued.compare_exchange_strong(z, -1); if (changed) issued_cv.notify_all(); return changed; }
   ~PrepGroup() {
     if (S) (void)hipStreamSynchronize(S);
     if (ev_tables) (void)hipEventDestroy(ev_tables);
@@ -172,8 +176,7 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
       (void)hipSetDevice(device);
       for (uint32_t i; (i = next.fetch_add(1)) < count;) { const int rc = fn(t, order[i]); if (rc) { rcs[t] = rc; errs[t] = g_last_error; next.store(count); return; } }
     };
-    if (nt == 1) work(0);
-    else { std::vector<dmi::Thread> th; for (uint32_t t = 0; t < nt; ++t) th.emplace_back(with_debug(work), t); for (auto& x : th) x.join(); }
+    run_threads(nt, work);
     for (uint32_t t = 0; t < nt; ++t) if (rcs[t]) return fail(rcs[t], errs[t]);
     return DMI_OK;
   };
@@ -198,9 +201,10 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     const uint32_t k = where[kk].second, j = g.which[k];
     const dmi_mesh& m = meshes[j];
     const uint64_t w0 = now_ns();
-    for (int st; (st = g.issued.load(std::memory_order_acquire)) != 1;) {   // (the coordinator is still packing / sending this group)
-      if (st < 0) return DMI_ERR_HIP;
-      std::this_thread::sleep_for(std::chrono::microseconds(50));
+    if (g.issued.load(std::memory_order_acquire) != 1) {   // (the coordinator is still packing / sending this group)
+      std::unique_lock<std::mutex> lock(g.issued_mutex);
+      g.issued_cv.wait(lock, [&] { return g.issued.load(std::memory_order_acquire) != 0; });
+      if (g.issued.load(std::memory_order_acquire) < 0) return DMI_ERR_HIP;
     }
     if (!g.adopted) {   // this mesh's values → staging → device, behind the group's table kernels on its stream
       size_t lo = (size_t)-1, hi = 0;
@@ -291,7 +295,7 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
   dmi::Thread walkers;
   int rc_walk = DMI_OK;
   std::string err_walk;
-  struct JoinWalkers { dmi::Thread& t; std::vector<std::unique_ptr<PrepGroup>>& gs; ~JoinWalkers() { if (t.joinable()) { for (auto& g : gs) { int z = 0; g->issued.compare_exchange_strong(z, -1); } t.join(); } } } join_walkers{walkers, groups};
+  struct JoinWalkers { dmi::Thread& t; std::vector<std::unique_ptr<PrepGroup>>& gs; ~JoinWalkers() { if (t.joinable()) { for (auto& g : gs) (void)g->fail_unissued(); t.join(); } } } join_walkers{walkers, groups};
   auto pack_threads = [&]() -> uint32_t { return walkers.joinable() ? std::max(2u, n_threads / 4) : 0u; };   // (0 = all: nothing else runs yet)
   // ---- phase 1, group by group: layout, pack, send, build the tables, fetch them (nothing here waits for the device) ----
   for (size_t gi = 0; gi < groups.size(); ++gi) {
@@ -326,7 +330,7 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
       g.hp = bg.conn.hp;
       g.rb_opp = bg.conn.rb_opp; g.rb_c2v = bg.conn.rb_c2v; g.rb_lmc = bg.conn.rb_lmc; g.rb_onb = bg.conn.rb_onb; g.rb_words = bg.conn.rb_words;
       g.ev_tables_borrowed = bg.conn.ev;
-      g.issued.store(1, std::memory_order_release);
+      g.set_issued(1);
       if (!walkers.joinable() && M > 1) walkers = dmi::Thread(with_debug([&] { rc_walk = parallel_over(M, walk_one, nullptr); if (rc_walk) err_walk = g_last_error; }));
       continue;
     }
@@ -450,7 +454,7 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     // part B (the values — more than half of the bytes) is packed and sent mesh by mesh by the walkers, first thing, while they would otherwise
     // wait for this group's tables (walk_one): phase 1 — what every walker waits for — packs faces and maps only
     HIP_TRY(hipEventCreateWithFlags(&g.ev_values, hipEventDisableTiming));
-    g.issued.store(1, std::memory_order_release);
+    g.set_issued(1);
     if (!walkers.joinable() && M > 1) walkers = dmi::Thread(with_debug([&] { rc_walk = parallel_over(M, walk_one, nullptr); if (rc_walk) err_walk = g_last_error; }));
   }
   const double t_issue = ms();
@@ -661,12 +665,7 @@ static int meshes_prepare_impl(const dmi_mesh* meshes, uint32_t n, const dmi_con
   bool any_left = false;
   for (uint32_t j = 0; j < n; ++j) any_left = any_left || !done[j];
   if (!any_left) {}
-  else if (n_threads == 1) work(0);
-  else {
-    std::vector<dmi::Thread> th;
-    for (uint32_t t = 0; t < n_threads; ++t) th.emplace_back(with_debug(work), t);
-    for (auto& x : th) x.join();
-  }
+  else run_threads(n_threads, work);
   for (uint32_t j = 0; j < n; ++j) {
     if (!rcs[j]) continue;
     const int rc = rcs[j];
@@ -791,8 +790,7 @@ int dmi_built_meshes_prepare(const dmi_built_mesh* built, uint32_t n, const dmi_
         if (rcs[k]) errs[k] = "mesh " + std::to_string(j) + ": " + g_last_error;
       }
     };
-    if (nt == 1) work(0);
-    else { std::vector<dmi::Thread> th; for (uint32_t t = 0; t < nt; ++t) th.emplace_back(with_debug(work), t); for (auto& x : th) x.join(); }
+    run_threads(nt, work);
     for (size_t k = 0; k < singles.size(); ++k) if (rcs[k]) { g_last_error = errs[k]; return bail(rcs[k]); }
   }
   return DMI_OK;

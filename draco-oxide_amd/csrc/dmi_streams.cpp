@@ -165,3 +165,34 @@ hipStream_t library_group_stream(int device, int which) {
 NumaScope::NumaScope(int device) : impl(new NumaPin(device)) {}
 NumaScope::~NumaScope() { delete static_cast<NumaPin*>(impl); }
 }  // namespace dmi
+
+namespace dmi {
+void run_threads(uint32_t n, const std::function<void(uint32_t)>& work) {
+  if (n == 0) return;
+  if (n == 1) { work(0); return; }
+  struct Join { std::mutex m; std::condition_variable cv; uint32_t left; } join;
+  join.left = 0;
+  const dmi_debug* cur = dbg_ptr();
+  cpu_set_t mask;
+  const bool have_mask = sched_getaffinity(0, sizeof mask, &mask) == 0;
+  int device = -1;
+  if (hipGetDevice(&device) != hipSuccess) { (void)hipGetLastError(); device = -1; }
+  auto body = [&](uint32_t t) {
+    {
+      DebugScope scope(cur);
+      if (have_mask) (void)sched_setaffinity(0, sizeof mask, &mask);
+      if (device >= 0) (void)hipSetDevice(device);
+      work(t);
+    }
+    std::lock_guard<std::mutex> lock(join.m);
+    if (--join.left == 0) join.cv.notify_all();
+  };
+  struct Wait { Join& j; ~Wait() { std::unique_lock<std::mutex> lock(j.m); j.cv.wait(lock, [&] { return j.left == 0; }); } } wait{join};   // (also when submit throws: the tasks already out hold references to this frame)
+  for (uint32_t t = 1; t < n; ++t) {
+    { std::lock_guard<std::mutex> lock(join.m); ++join.left; }
+    try { pool_submit([&body, t] { body(t); }); }
+    catch (...) { { std::lock_guard<std::mutex> lock(join.m); --join.left; } throw; }
+  }
+  { DebugScope scope(cur); work(0); }
+}
+}  // namespace dmi

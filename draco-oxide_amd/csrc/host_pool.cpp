@@ -80,3 +80,49 @@ std::atomic<size_t>& host_pool_bytes() { static std::atomic<size_t> b{0}; return
 void host_pool_drop_all() { VecPool<uint8_t>::get().drop_all(); VecPool<uint32_t>::get().drop_all(); VecPool<uint64_t>::get().drop_all(); }
 
 }  // namespace dmi
+
+// ---- the library's worker threads (dmi_host.hpp: run_threads) ----
+namespace dmi {
+namespace {
+struct Worker {
+  std::mutex m;
+  std::condition_variable cv;
+  std::function<void()> task;
+  bool has = false;
+};
+struct WorkerPool {
+  std::mutex m;
+  std::vector<Worker*> idle;
+  static WorkerPool& get() { static WorkerPool* p = new WorkerPool(); return *p; }   // (never destroyed: its threads are parked for the life of the process)
+  static void loop(WorkerPool* pool, Worker* w) {
+    for (;;) {
+      std::function<void()> t;
+      {
+        std::unique_lock<std::mutex> lock(w->m);
+        w->cv.wait(lock, [&] { return w->has; });
+        t = std::move(w->task);
+        w->task = nullptr;
+        w->has = false;
+      }
+      t();
+      t = nullptr;
+      std::lock_guard<std::mutex> lock(pool->m);
+      pool->idle.push_back(w);
+    }
+  }
+  void submit(std::function<void()> fn) {
+    Worker* w = nullptr;
+    { std::lock_guard<std::mutex> lock(m); if (!idle.empty()) { w = idle.back(); idle.pop_back(); } }
+    if (!w) {
+      w = new Worker();
+      Thread th(&WorkerPool::loop, this, w);   // (throws std::system_error when the process is out of threads: the caller's problem, nothing is queued)
+      th.detach();
+    }
+    { std::lock_guard<std::mutex> lock(w->m); w->task = std::move(fn); w->has = true; }
+    w->cv.notify_one();
+  }
+};
+}  // namespace
+
+void pool_submit(std::function<void()> fn) { WorkerPool::get().submit(std::move(fn)); }
+}  // namespace dmi

@@ -63,3 +63,11 @@ inc3 = collections.Counter(first_ours(l) for l in libc)
 print(f"---- samples in unnamed libc code (memcpy / memset ...: {len(libc)} = {len(libc) / n * 100:.1f} %): the libdraco_mi.so function that called in")
 for k, v in inc3.most_common(20):
     print(f"{v / n * 100:6.2f} %  {v / hz / calls * 1e3:7.1f} ms/call  {k[:150]}")
+
+def chain(l, k=3):
+    out = [fr for fr in l.split(" < ") if fr.startswith("libdraco_mi.so!")][:k]
+    return " < ".join(f.replace("libdraco_mi.so!", "") for f in out) or "(no libdraco_mi.so frame)"
+inc4 = collections.Counter(chain(l) for l in libc)
+print("---- the same samples by their three innermost libdraco_mi.so frames")
+for k, v in inc4.most_common(25):
+    print(f"{v / n * 100:6.2f} %  {v / hz / calls * 1e3:7.1f} ms/call  {k[:230]}")
