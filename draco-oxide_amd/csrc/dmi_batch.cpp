@@ -254,7 +254,7 @@ struct DeviceBatch {
   double t_plan = 0, t_wait = 0, t_bytes = 0, t_splice = 0;
   ~DeviceBatch() {
     if (!arena) return;
-    if (s) (void)hipStreamSynchronize(s);   // (also on error paths: nothing of this batch may still be writing into the arena when the next one takes it)
+    if (s) (void)long_wait_stream(s);   // (also on error paths: nothing of this batch may still be writing into the arena when the next one takes it)
     release_batch_arena(arena);
   }
 

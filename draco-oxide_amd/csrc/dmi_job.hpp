@@ -19,6 +19,15 @@
 #include "host_chains.hpp"
 
 namespace dmi {
+// Waits of the batch path that last milliseconds (a stage's device tables, a build's kernels and read-backs, an encode's chain launch): hipStreamSynchronize and
+// hipEventSynchronize on a default event SPIN on a host core for as long as they wait — a quarter of a transcode's CPU time was the runtime's wait loop (sampling
+// profile, scripts/experiments/transcode_sigprof.py) with six coordinator threads waiting beside sixteen walkers on a 16-CPU quota.  These POLL instead: hipEventQuery,
+// a few times back to back, then with 50 µs sleeps between (events created with hipEventBlockingSync still spun in the runtime this image's torch wheel bundles: 7 % of the
+// call's CPU samples stayed inside long_wait_stream).  DMI_DBG_SPIN_WAITS restores the runtime's own waits (A/B).  The short waits of a single whole-mesh call keep
+// spinning: their latency is the call's.
+unsigned long_wait_flags();                    // flags for hipEventCreateWithFlags (timing off)
+hipError_t long_wait_event(hipEvent_t e);      // hipEventSynchronize without a spinning core
+hipError_t long_wait_stream(hipStream_t s);    // returns when everything queued on s so far has finished
 extern thread_local std::string g_last_error;
 extern thread_local dmi_timings g_last_call;   // dmi_last_call_timings
 extern thread_local size_t g_out_prefix;        // bytes the splice of the next encode on this thread leaves free in front of the attribute section (a one-shot call puts header + connectivity there: one output buffer, one copy of every stream)
@@ -270,7 +279,7 @@ struct dmi_job {
   } run;
   ~dmi_job();
   void release() {
-    if (stream) (void)hipStreamSynchronize(stream);   // (the job's device memory goes back to a cache, not through a synchronising hipFree)
+    if (stream) (void)long_wait_stream(stream);   // (the job's device memory goes back to a cache, not through a synchronising hipFree)
     if (pinned) (void)hipHostFree(pinned);
     if (out_pinned) (void)hipHostFree(out_pinned);
     if (graph_a) (void)hipGraphExecDestroy(graph_a);
@@ -341,7 +350,7 @@ struct TempDev {
   DevPool pool;
   void init(int device, hipStream_t s, size_t bytes_hint) { pool.device = device; pool.stream = s; pool.chunk_bytes = bytes_hint; pool.zero = false; }
   bool owner_waits = false;   // the owner itself makes sure the work on the chunks is over before this is destroyed (an event it waits for): no synchronisation here
-  ~TempDev() { if (!owner_waits && !pool.chunks.empty()) (void)hipStreamSynchronize(pool.stream); }   // (nothing may still be using a chunk when the cache hands it to the next taker)
+  ~TempDev() { if (!owner_waits && !pool.chunks.empty()) (void)long_wait_stream(pool.stream); }   // (nothing may still be using a chunk when the cache hands it to the next taker)
   template <class T> T* take(size_t n) { return static_cast<T*>(pool.take((n ? n : 1) * sizeof(T))); }
 };
 
@@ -376,7 +385,7 @@ struct EarlyQuant {
     return es;
   }
   ~EarlyQuant() {
-    if (stream) (void)hipStreamSynchronize(stream);
+    if (stream) (void)long_wait_stream(stream);
     if (t0) (void)hipEventDestroy(t0);
     if (t1) (void)hipEventDestroy(t1);
   }
@@ -472,7 +481,7 @@ struct BuiltGroup {
   BuiltGroup& operator=(const BuiltGroup&) = delete;
   ~BuiltGroup() {
     if (conn.ev) { (void)hipEventSynchronize(conn.ev); (void)hipEventDestroy(conn.ev); }
-    if (stream) (void)hipStreamSynchronize(stream);
+    if (stream) (void)long_wait_stream(stream);
     release_stage(conn.stage);
     release_stage(stage);
   }
@@ -488,14 +497,5 @@ struct BuiltDevice : BuiltBase {
 // library streams / NUMA placement shared by the whole-mesh translation units (defined in dmi_prepare.cpp)
 std::shared_ptr<StreamHolder> library_thread_stream(int device);
 hipStream_t library_group_stream(int device, int which);
-// Waits of the batch path that last milliseconds (a stage's device tables, a build's kernels and read-backs, an encode's chain launch): hipStreamSynchronize and
-// hipEventSynchronize on a default event SPIN on a host core for as long as they wait — a quarter of a transcode's CPU time was the runtime's wait loop (sampling
-// profile, scripts/experiments/transcode_sigprof.py) with six coordinator threads waiting beside sixteen walkers on a 16-CPU quota.  These POLL instead: hipEventQuery,
-// a few times back to back, then with 50 µs sleeps between (events created with hipEventBlockingSync still spun in the runtime this image's torch wheel bundles: 7 % of the
-// call's CPU samples stayed inside long_wait_stream).  DMI_DBG_SPIN_WAITS restores the runtime's own waits (A/B).  The short waits of a single whole-mesh call keep
-// spinning: their latency is the call's.
-unsigned long_wait_flags();                    // flags for hipEventCreateWithFlags (timing off)
-hipError_t long_wait_event(hipEvent_t e);      // hipEventSynchronize without a spinning core
-hipError_t long_wait_stream(hipStream_t s);    // returns when everything queued on s so far has finished
 struct NumaScope { void* impl = nullptr; explicit NumaScope(int device); ~NumaScope(); NumaScope(const NumaScope&) = delete; NumaScope& operator=(const NumaScope&) = delete; };
 }  // namespace dmi

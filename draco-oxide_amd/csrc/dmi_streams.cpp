@@ -143,6 +143,12 @@ hipError_t long_wait_event(hipEvent_t e) {
 }
 hipError_t long_wait_stream(hipStream_t s) {
   if (dbg_on(DMI_DBG_SPIN_WAITS)) return hipStreamSynchronize(s);
+  {   // nothing pending (a job's stream at its release, usually): no event, no wait
+    const hipError_t q = hipStreamQuery(s);
+    if (q == hipSuccess) return hipSuccess;
+    if (q != hipErrorNotReady) return q;
+    (void)hipGetLastError();
+  }
   // one blocking event per thread and device (an event belongs to the device that was current when it was created)
   struct Ev { int device = -1; hipEvent_t e = nullptr; ~Ev() { if (e) (void)hipEventDestroy(e); } };
   thread_local Ev ev[2];
