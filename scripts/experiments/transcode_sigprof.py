@@ -9,15 +9,33 @@ calls = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 hz = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
 sp = C.CDLL(os.path.join(HERE, "libsigprof.so"))
 binding.configure_process(huge_page_new=True, numa_pin=True)
-glbs, total = synth.batch_glbs(1024, seams=(kind == "seams"))
-alist = binding.AssetList(glbs)
 cfg = dmi.Config(device=0)
+if kind == "batch":      # bench.py's batch_regime: 256 host meshes -> dmi_meshes_prepare + dmi_jobs_encode
+    meshes = synth.batch_meshes(256)
+    total = sum(len(m.faces) for m in meshes)
+    def one():
+        jobs = dmi.meshes_prepare(meshes, cfg)
+        with dmi.jobs_encode_raw(jobs):
+            pass
+        for j in jobs:
+            j.close()
+elif kind == "single":   # bench.py's value: one 10M-triangle mesh in HBM -> whole .drc
+    mesh = synth.torus_mesh(2236)
+    total = len(mesh.faces)
+    dm = dmi.DeviceMesh.upload(mesh)
+    def one():
+        dmi.encode_mesh_device(dm, cfg)
+else:
+    glbs, total = synth.batch_glbs(1024, seams=(kind == "seams"))
+    alist = binding.AssetList(glbs)
+    def one():
+        gltf.transcode_files(alist, cfg)
 for _ in range(3):
-    gltf.transcode_files(alist, cfg)
+    one()
 sp.sp_start(hz)
 t0 = time.perf_counter()
 for _ in range(calls):
-    gltf.transcode_files(alist, cfg)
+    one()
 wall = time.perf_counter() - t0
 n = sp.sp_stop()
 out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", f"sigprof_{kind}.txt")
