@@ -404,8 +404,29 @@ def transcode_sharded(n_files, rank, world, local_rank, gather_dev, steps=2):
     t = torch.tensor([dt, float(owned), -float(owned), gather_s / steps, own_s / steps], dtype=torch.float64, device=gather_dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt, own_max, own_min, g_max, o_max = float(t[0]), int(t[1]), int(-t[2]), float(t[3]), float(t[4])
+    # the same job with the finished files left on the ranks that made them (gather="manifest": a transcoder's outputs are files — each rank writes its own —, sizes and
+    # digests of all files reach every rank in one all_reduce): what an N-GPU job costs when nothing but a manifest has to cross the ranks
+    gltf.transcode_files(glbs, cfg, device=gather_dev, gather="manifest")
+    dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    man = None
+    for _ in range(steps):
+        tm2 = {}
+        kept = gltf.transcode_files(glbs, cfg, device=gather_dev, timings=tm2, gather="manifest")
+        man = tm2.get("manifest")
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt_m = time.perf_counter() - t1
+    tmm = torch.tensor([dt_m], dtype=torch.float64, device=gather_dev)
+    dist.all_reduce(tmm, op=dist.ReduceOp.MAX)
+    dt_m = float(tmm[0])
     if rank != 0:
         return None
+    import xxhash
+    mine_ok = all(e is None or (len(e[0]) == int(man[0][i]) and xxhash.xxh64(e[0]).intdigest() == int(man[1][i])) for i, e in enumerate(kept))
+    gathered_ok = all(len(res[i][0]) == int(man[0][i]) and xxhash.xxh64(res[i][0]).intdigest() == int(man[1][i]) for i in range(0, n_files, max(1, n_files // 16)))
+    del kept
     doc, binary = gltf.read_glb(glbs[n_files // 2])
     mesh, _ = gltf.primitive_to_mesh(doc, binary, doc["meshes"][0]["primitives"][0])
     return {"workload": f"BASELINE configs[3]: {n_files} GLB files in memory through gltf.transcode_files over {world} rank(s): files dealt by size before anything is parsed, "
@@ -413,6 +434,9 @@ def transcode_sharded(n_files, rank, world, local_rank, gather_dev, steps=2):
             "triangles": int(total), "ms_per_step": round(dt / steps * 1e3, 2), "value": round(total * steps / dt / 1e6, 2), "unit": "Mtriangles/s",
             "files_owned_per_rank_min_max": [own_min, own_max], "files_on_rank0": len(res),
             "own_files_ms_max_over_ranks": round(o_max * 1e3, 2), "gather_ms_max_over_ranks": round(g_max * 1e3, 2),
+            "files_stay_on_their_ranks": {"what": "gather=\"manifest\": every rank keeps (writes) the files it made; sizes + xxh64 digests of all files on every rank (one all_reduce of 16 bytes per file)",
+                                          "ms_per_step": round(dt_m / steps * 1e3, 2), "value": round(total * steps / dt_m / 1e6, 2), "unit": "Mtriangles/s",
+                                          "manifest_matches_the_gathered_files": bool(mine_ok and gathered_ok)},
             "sample_blob_equals_whole_mesh_encode": bool(bytes(res[n_files // 2][1][0]) == dmi.encode_mesh(mesh, cfg))}
 
 

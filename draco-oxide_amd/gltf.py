@@ -642,7 +642,7 @@ def encode_batch(meshes, cfg=None, devices=None, group=None, device=None):
             j.close()
 
 
-def transcode_files(sources, cfg=None, devices=None, group=None, device=None, pipeline=True, timings=None, copy=False):
+def transcode_files(sources, cfg=None, devices=None, group=None, device=None, pipeline=True, timings=None, copy=False, gather="files"):
     """BASELINE configs[3]: a LIST of glTF assets (GLB bytes, `.glb` / `.gltf` paths) → their Draco-compressed GLBs
     (io/gltf/transcoder.rs:134-151 runs the files one by one, io/gltf/encode.rs:1827-1842 their primitives one by one; here the triangle
     primitives of ALL files go through the device together: encode_raw_batch).  One GPU, `devices` GPUs of this process (each takes a
@@ -651,7 +651,10 @@ def transcode_files(sources, cfg=None, devices=None, group=None, device=None, pi
     Returns [(glb_bytes, [blob, ...]), ...] in input order — on the destination rank; None on the other ranks of a sharded job.  On one device of one
     process the files are memoryviews of the library's output arena and the blobs memoryviews INTO their file (they compare equal to bytes; `bytes(blob)` copies one
     out; json.loads / pickle / dict keys want bytes; ONE surviving view keeps every 32 MiB arena block of the call alive) — copy=True returns bytes objects instead.
-    timings (optional dict): parse_s (JSON), views_s (accessor views), build_s, prepare_s, encode_s, assemble_s, primitives_built (this rank)."""
+    timings (optional dict): parse_s (JSON), views_s (accessor views), build_s, prepare_s, encode_s, assemble_s, primitives_built (this rank).
+    gather (ranks of a torch.distributed job only): "files" — the finished files travel to rank 0 (the default, what the paragraph above describes); "manifest" — the
+    files STAY on the rank that made them (a transcoder's outputs are files: each rank writes its own) and only a manifest crosses the ranks: EVERY rank gets the
+    list in input order with (glb, blobs) at the indices it owns and None elsewhere, and timings["manifest"] = (sizes, xxh64 digests) of all files, uint64 arrays."""
     import gc
     import time
     # The call allocates a few hundred thousand small objects (JSON trees, views, jobs) while four stage threads share the interpreter: a full
@@ -660,10 +663,10 @@ def transcode_files(sources, cfg=None, devices=None, group=None, device=None, pi
     if gc_was:
         gc.disable()
     try:
-        out = _transcode_files(sources, cfg, devices, group, device, pipeline, timings)
+        out = _transcode_files(sources, cfg, devices, group, device, pipeline, timings, gather)
         if copy and out is not None:
             # bytes objects of the caller's own (picklable, hashable, json-loadable) instead of views that keep the call's arena blocks alive
-            out = [(bytes(g), [bytes(b) for b in blobs]) for g, blobs in out]
+            out = [None if e is None else (bytes(e[0]), [bytes(b) for b in e[1]]) for e in out]
         return out
     finally:
         if gc_was:
@@ -690,7 +693,7 @@ def _native_assets(sources):
     return assets
 
 
-def _transcode_files(sources, cfg, devices, group, device, pipeline, timings):
+def _transcode_files(sources, cfg, devices, group, device, pipeline, timings, gather="files"):
     import time
     tm = timings if timings is not None else {}
     t0 = time.perf_counter()
@@ -712,7 +715,9 @@ def _transcode_files(sources, cfg, devices, group, device, pipeline, timings):
                    "encode_s": st["encode_ms"] * 1e-3, "assemble_s": st["assemble_ms"] * 1e-3, "primitives_built": st["primitives"], "native": st})
         return out
     if world0 > 1 and pipeline and os.environ.get("DMI_TRANSCODE_PYTHON", "0") == "0" and sources and encode_raw_batch is _ENCODE_RAW_BATCH:
-        return _transcode_files_ranks(sources, cfg, device, group, tm)
+        return _transcode_files_ranks(sources, cfg, device, group, tm, gather)
+    if gather != "files" and world0 > 1:
+        raise ValueError("gather='manifest' needs the library's own transcode loop (pipeline=True)")
     docs = [load_document(src) for src in sources]
     per_file = [_plan(doc) for doc, _ in docs]
     flat = [(fi, pi) for fi, prims in enumerate(per_file) for pi in range(len(prims))]
@@ -831,7 +836,7 @@ def _source_bytes(src):
 _TRANSCODE_ASSETS = None   # (tests put a stand-in here: the ranks' control flow without a device)
 
 
-def _transcode_files_ranks(sources, cfg, device, group, tm):
+def _transcode_files_ranks(sources, cfg, device, group, tm, gather="files"):
     """The rank-sharded form (round 6): the FILES are dealt to the ranks by their size in bytes (LPT) before anything is parsed — no rank reads, parses or
     plans a document it does not own —, every rank runs the library's own loop over its files (dmi_transcode_assets: parse pool, stage pipeline, assembly) and
     the FINISHED files travel: one size exchange + one gather of [blob table | GLB] payloads onto rank 0, no reassembly there.  (Round 5 parsed every JSON
@@ -852,6 +857,27 @@ def _transcode_files_ranks(sources, cfg, device, group, tm):
         out, st = [], {"parse_ms": 0.0, "build_ms": 0.0, "prepare_ms": 0.0, "encode_ms": 0.0, "assemble_ms": 0.0, "primitives": 0}
     tm.update({"parse_s": st["parse_ms"] * 1e-3, "views_s": 0.0, "build_s": st["build_ms"] * 1e-3, "prepare_s": st["prepare_ms"] * 1e-3, "encode_s": st["encode_ms"] * 1e-3,
                "assemble_s": st["assemble_ms"] * 1e-3, "primitives_built": st["primitives"], "files_owned": len(own), "native": st, "transcode_s": time.perf_counter() - t0})
+    if gather == "manifest":
+        # the files stay here; what crosses the ranks is 16 bytes per file: size and xxh64 digest, every rank's entries summed into one array (an entry has one owner)
+        import torch
+        import xxhash
+        t1 = time.perf_counter()
+        man = np.zeros(2 * len(sources), np.int64)
+        for i, (glb, _) in zip(mine, out):
+            man[2 * i] = len(glb)
+            man[2 * i + 1] = np.uint64(xxhash.xxh64(glb).intdigest()).astype(np.int64)
+        dev = device if device is not None else torch.device("cpu")
+        t = torch.from_numpy(man).to(dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        man = t.cpu().numpy().view(np.uint64)
+        tm["manifest"] = (man[0::2].copy(), man[1::2].copy())
+        tm["gather_s"] = time.perf_counter() - t1
+        results = [None] * len(sources)
+        for i, e in zip(mine, out):
+            results[i] = e
+        return results
+    if gather != "files":
+        raise ValueError("gather: 'files' or 'manifest'")
     payloads = []
     for glb, blobs in out:
         # where the blobs lie inside their file: [count | (offset, length) …] in front of the file's bytes

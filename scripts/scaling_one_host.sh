@@ -26,7 +26,7 @@ for r in rows:
     o = r.get("transcode_one_process_n_devices") or {}
     st, wk = o.get("strong") or {}, o.get("weak") or {}
     print(r["n_gpus"], r["value"], r["ms_per_step"], round(r["value"] / (base * r["n_gpus"]), 3), r["config"].get("host_threads_per_rank"), b.get("value"), b.get("prepare_ms_max_over_ranks"), b.get("encode_ms_max_over_ranks"),
-          t.get("value"), t.get("ms_per_step", t.get("ms_per_batch")), t.get("files_owned_per_rank_min_max", t.get("primitives_built_per_rank_min_max")),
+          t.get("value"), t.get("ms_per_step", t.get("ms_per_batch")), t.get("files_owned_per_rank_min_max", t.get("primitives_built_per_rank_min_max")), ("files stay:", (t.get("files_stay_on_their_ranks") or {}).get("value"), (t.get("files_stay_on_their_ranks") or {}).get("ms_per_step")),
           (st.get("value"), st.get("ms_per_batch"), st.get("parse_ms"), st.get("pushed_ms"), st.get("stages_per_device")), (wk.get("value"), wk.get("ms_per_batch")),
           (r.get("distributed") or {}).get("backend"), (r.get("distributed") or {}).get("gather_ms_per_step_by_rank"))
 PY

@@ -232,3 +232,49 @@ def test_transcode_files_deals_files_by_size_before_parsing_gloo_world2():
     for f, (glb, blobs) in zip(files, res0):                                                                             # finished files in input order, blobs cut out of them
         h = hashlib.sha256(f).digest()
         assert glb == b"glTF" + h * 3 and blobs == [glb[4:36], glb[40:50]]
+
+
+def _manifest_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from draco_oxide_amd import gltf
+        gltf._TRANSCODE_ASSETS = _fake_transcode_assets
+        rng = np.random.default_rng(4)
+        files = [bytes(rng.integers(0, 255, size=int(n), dtype=np.uint8)) for n in (5000, 100, 70000, 3000, 42000, 900, 15000)]
+        tm = {}
+        res = gltf.transcode_files(files, timings=tm, gather="manifest", copy=True)
+        q.put((rank, res, tm["manifest"][0].tolist(), tm["manifest"][1].tolist(), tm.get("files_owned")))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_transcode_files_manifest_mode_keeps_files_on_their_ranks_gloo_world2():
+    """gather="manifest" (round 6): a rank's finished files stay with it — a transcoder's outputs are files, each rank writes its own — and sizes + xxh64 digests of ALL
+    files reach every rank in one all_reduce."""
+    import hashlib
+    import xxhash
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_manifest_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    sizes = [5000, 100, 70000, 3000, 42000, 900, 15000]
+    rng = np.random.default_rng(4)
+    files = [bytes(rng.integers(0, 255, size=int(n), dtype=np.uint8)) for n in sizes]
+    want = [b"glTF" + hashlib.sha256(f).digest() * 3 for f in files]
+    for rank, res, msz, mh, owned in got:
+        own = dd.shard_indices(7, rank, 2, weights=sizes)
+        assert owned == len(own) and len(res) == 7
+        for i in range(7):
+            if i in own:
+                assert res[i][0] == want[i] and res[i][1] == [want[i][4:36], want[i][40:50]]
+            else:
+                assert res[i] is None                                                           # (not gathered)
+        assert msz == [len(w) for w in want] and mh == [xxhash.xxh64(w).intdigest() for w in want]   # every rank holds the whole manifest
