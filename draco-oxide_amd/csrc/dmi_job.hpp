@@ -466,6 +466,7 @@ struct BuiltGroup {
   // host by the time dmi_built_meshes_prepare's walks want them (a transcode pipeline prepares stage k while stage k+1 is built).
   struct Conn {
     bool issued = false, any_mapped = false;
+    bool quad = false;   // the read-back `opp` holds 4·face + k ids (no member has a point → value map: the walks' quad class, CornerTables::quad)
     TempDev mem;
     HostStage* stage = nullptr;
     uint8_t* hp = nullptr;

@@ -237,6 +237,7 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     pre.on_boundary = hp + g.rb_onb + g.lay[k].vert_off;
     pre.V = h_words[g.n_desc + g.lay[k].desc_index] + 1;
     pre.no_boundary = !(flags & CONN_HAS_BOUNDARY);
+    if (g.adopted && g.adopted->conn.quad) { pre.quad = true; pre.lmc = nullptr; }   // (4·face + k ids in `opp`: built_group_issue_tables)
     {   // attribute tables the device built for this mesh (k_att_*)
       uint32_t n_nonpos = 0;
       for (uint32_t a = 0; a < m.num_atts; ++a) n_nonpos += m.atts[a].att_type != DMI_ATT_POSITION;

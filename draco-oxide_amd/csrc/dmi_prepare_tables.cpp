@@ -90,7 +90,7 @@ int dmi::built_group_issue_tables(BuiltGroup& bg, hipStream_t s) {
   const size_t C = (size_t)bg.total_faces * 3, nv = (size_t)verts + 1, parts = scan_partials_words((uint32_t)nv);
   size_t att_bytes = 0;   // (upper bound of the attribute-table arrays: every non-position attribute a candidate)
   for (const auto& mem : bg.members) if (mem.atts.size() > 1) att_bytes += (mem.atts.size() - 1) * ((size_t)mem.F * 3 * 13 + (size_t)(mem.atts[0].n_unique + 1) * 5 + 512);
-  cn.mem.init(bg.device, s, C * 4 * (cn.any_mapped ? 4 : 3) + C + nv * 4 * 4 + nv + parts * 4 + (size_t)ND * (sizeof(ConnMeshDesc) + 8) + att_bytes + ((size_t)2 << 20));
+  cn.mem.init(bg.device, s, C * 4 * (cn.any_mapped ? 5 : 4) + C + nv * 4 * 4 + nv + parts * 4 + (size_t)ND * (sizeof(ConnMeshDesc) + 8) + att_bytes + ((size_t)2 << 20));
   const uint32_t* d_faces = reinterpret_cast<const uint32_t*>(bg.d_base);
   cn.d_c2v = cn.any_mapped ? cn.mem.take<uint32_t>(C) : const_cast<uint32_t*>(d_faces);
   cn.d_opp = cn.mem.take<uint32_t>(C);
@@ -171,7 +171,22 @@ int dmi::built_group_issue_tables(BuiltGroup& bg, hipStream_t s) {
   HIP_TRY(conn_tables_clear(a, s));
   launch_conn_tables(a, s);
   HIP_TRY(hipMemcpyAsync(hp + cn.rb_words, d_words, (size_t)ND * 8, hipMemcpyDeviceToHost, s));
-  if (C) HIP_TRY(hipMemcpyAsync(hp + cn.rb_opp, cn.d_opp, C * 4, hipMemcpyDeviceToHost, s));
+  // Quad class (round 6): when no member has a point → value map — every attribute indexed like the positions, no attribute table of its own —
+  // the host walks read the opposite corners as 4·face + k ids (no division by three per step: host_conn.cpp, what a whole-mesh call has done since round 5);
+  // the device keeps its 3·face + k array for the relabelling and the fan rows, a converted copy goes down.
+  cn.quad = false;
+  if (C && st.items.empty() && !dbg_on(DMI_DBG_NO_QUAD | DMI_DBG_HOST_ATT_TABLES) && C < ((uint64_t)3 << 30)) {
+    bool plain = true;
+    for (uint32_t mi = 0; mi < ND && plain; ++mi) for (const auto& at : bg.members[mi].atts) if (at.map_off != (size_t)-1) { plain = false; break; }
+    if (plain) {
+      if (uint32_t* d_q = cn.mem.take<uint32_t>(C)) {
+        launch_opp_quad(cn.d_opp, C, d_q, s);
+        HIP_TRY(hipMemcpyAsync(hp + cn.rb_opp, d_q, C * 4, hipMemcpyDeviceToHost, s));
+        cn.quad = true;
+      }
+    }
+  }
+  if (C && !cn.quad) HIP_TRY(hipMemcpyAsync(hp + cn.rb_opp, cn.d_opp, C * 4, hipMemcpyDeviceToHost, s));
   if (cn.any_mapped && C) HIP_TRY(hipMemcpyAsync(hp + cn.rb_c2v, cn.d_c2v, C * 4, hipMemcpyDeviceToHost, s));
   if (verts) HIP_TRY(hipMemcpyAsync(hp + cn.rb_lmc, d_lmc, (size_t)verts * 4, hipMemcpyDeviceToHost, s));
   if (verts) HIP_TRY(hipMemcpyAsync(hp + cn.rb_onb, d_onb, (size_t)verts, hipMemcpyDeviceToHost, s));

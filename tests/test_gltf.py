@@ -243,6 +243,23 @@ def test_full_size_files_through_the_transcoder_against_the_oracle(seams):
 
 
 @pytest.mark.gpu
+def test_transcoder_walks_over_quad_ids_give_the_same_files(monkeypatch):
+    """Round 6: a stage none of whose primitives has a point → value map has its opposite corners read back as 4·face + k ids (built_group_issue_tables) and its
+    host walks run over those — the same files as with DMI_NO_QUAD=1, plain ones (the quad class) and exporter-style seams (never in it) alike."""
+    from draco_oxide_amd import synth
+    for seams in (False, True):
+        glbs, _ = synth.batch_glbs(40, seed=synth.SEED + 23, seams=seams)
+        monkeypatch.delenv("DMI_NO_QUAD", raising=False)
+        a = gltf.transcode_files(glbs, copy=True)
+        monkeypatch.setenv("DMI_NO_QUAD", "1")
+        b = gltf.transcode_files(glbs, copy=True)
+        assert a == b, seams
+        monkeypatch.delenv("DMI_NO_QUAD")
+        doc, binary = gltf.read_glb(glbs[7])
+        assert a[7][1][0] == _oracle_session(doc, binary, doc["meshes"][0]["primitives"][0]).encode()
+
+
+@pytest.mark.gpu
 def test_one_process_several_devices_gives_the_one_device_files():
     """dmi_transcode_assets with a device LIST: one dmi_transcoder per entry, the least loaded one takes the next primitive, the files are written by
     the same library threads — no second interpreter, no gather.  devices=[0, 0] (two transcoders on the one GPU of the test box) must give the files
