@@ -69,6 +69,7 @@ struct PrepGroup {
   const uint32_t* d_faces = nullptr;
   uint32_t *d_c2v = nullptr, *d_opp = nullptr;
   size_t rb_opp = 0, rb_c2v = 0, rb_lmc = 0, rb_onb = 0, rb_words = 0;
+  bool quad = false;   // the read-back `opp` holds 4·face + k ids (the walks' quad class)
   hipEvent_t ev_tables = nullptr, ev_values = nullptr;
   hipEvent_t ev_tables_borrowed = nullptr;   // an adopted group's tables were issued by its build: the event belongs to the BuiltGroup
   bool tables_in = false;
@@ -237,7 +238,7 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     pre.on_boundary = hp + g.rb_onb + g.lay[k].vert_off;
     pre.V = h_words[g.n_desc + g.lay[k].desc_index] + 1;
     pre.no_boundary = !(flags & CONN_HAS_BOUNDARY);
-    if (g.adopted && g.adopted->conn.quad) { pre.quad = true; pre.lmc = nullptr; }   // (4·face + k ids in `opp`: built_group_issue_tables)
+    if (g.adopted ? g.adopted->conn.quad : g.quad) { pre.quad = true; pre.lmc = nullptr; }   // (4·face + k ids in `opp`: built_group_issue_tables)
     {   // attribute tables the device built for this mesh (k_att_*)
       uint32_t n_nonpos = 0;
       for (uint32_t a = 0; a < m.num_atts; ++a) n_nonpos += m.atts[a].att_type != DMI_ATT_POSITION;
@@ -394,7 +395,7 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     const size_t nv = (size_t)g.total_verts + 1, parts = scan_partials_words((uint32_t)nv);
     const size_t rb_desc0 = align256(up_bytes) + align256(C * 4) + (g.any_mapped ? align256(C * 4) : 0) + align256(nv * 4) + align256(nv) + align256((size_t)Mg * 8);
     const size_t host_need = g.att.layout(rb_desc0 + align256((size_t)Mg * sizeof(ConnMeshDesc)));   // (may drop the items: before the device memory is sized)
-    g.mem.init(device, g.S, up_bytes + C * 4 * (g.any_mapped ? 4 : 3) + C + nv * 4 * 4 + nv + parts * 4 + (size_t)Mg * (sizeof(ConnMeshDesc) + 8) + g.att.device_bytes() + ((size_t)1 << 20));
+    g.mem.init(device, g.S, up_bytes + C * 4 * (g.any_mapped ? 5 : 4) + C + nv * 4 * 4 + nv + parts * 4 + (size_t)Mg * (sizeof(ConnMeshDesc) + 8) + g.att.device_bytes() + ((size_t)1 << 20));
     g.d_up = g.mem.take<uint8_t>(up_bytes);
     g.d_faces = reinterpret_cast<const uint32_t*>(g.d_up);
     g.d_c2v = g.any_mapped ? g.mem.take<uint32_t>(C) : const_cast<uint32_t*>(g.d_faces);
@@ -444,7 +445,21 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     HIP_TRY(conn_tables_clear(a, g.S));
     launch_conn_tables(a, g.S);
     HIP_TRY(hipMemcpyAsync(hp + g.rb_words, d_words, (size_t)Mg * 8, hipMemcpyDeviceToHost, g.S));
-    HIP_TRY(hipMemcpyAsync(hp + g.rb_opp, g.d_opp, C * 4, hipMemcpyDeviceToHost, g.S));
+    // quad class (as built_group_issue_tables): every attribute of every mesh of the group indexed by the position attribute's map array (or by none) — the walks
+    // read 4·face + k ids; the device keeps its 3·face + k array, a converted copy goes down
+    g.quad = false;
+    if (C && g.att.items.empty() && !dbg_on(DMI_DBG_NO_QUAD | DMI_DBG_HOST_ATT_TABLES) && C < ((uint64_t)3 << 30)) {
+      bool plain = true;
+      for (uint32_t k = 0; k < Mg && plain; ++k) { const dmi_mesh& m = meshes[g.which[k]]; for (uint32_t i = 1; i < m.num_atts; ++i) if (m.atts[i].point_to_value != m.atts[0].point_to_value) { plain = false; break; } }
+      if (plain) {
+        if (uint32_t* d_q = g.mem.take<uint32_t>(C)) {
+          launch_opp_quad(g.d_opp, C, d_q, g.S);
+          HIP_TRY(hipMemcpyAsync(hp + g.rb_opp, d_q, C * 4, hipMemcpyDeviceToHost, g.S));
+          g.quad = true;
+        }
+      }
+    }
+    if (!g.quad) HIP_TRY(hipMemcpyAsync(hp + g.rb_opp, g.d_opp, C * 4, hipMemcpyDeviceToHost, g.S));
     if (g.any_mapped) HIP_TRY(hipMemcpyAsync(hp + g.rb_c2v, g.d_c2v, C * 4, hipMemcpyDeviceToHost, g.S));
     if (want_lmc) HIP_TRY(hipMemcpyAsync(hp + g.rb_lmc, d_lmc, (size_t)g.total_verts * 4, hipMemcpyDeviceToHost, g.S));
     HIP_TRY(hipMemcpyAsync(hp + g.rb_onb, d_onb, (size_t)g.total_verts, hipMemcpyDeviceToHost, g.S));
