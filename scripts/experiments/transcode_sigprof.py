@@ -51,7 +51,10 @@ if offs:
     sym = "/opt/rocm/lib/llvm/bin/llvm-symbolizer"
     res = subprocess.run([sym, "--obj=" + lib, "--functions=linkage", "--demangle", "--no-inlines", "--output-style=LLVM"] + offs, capture_output=True, text=True).stdout.split("\n\n")
     for o, r in zip(offs, res):
-        fn = r.strip().split("\n")[0] if r.strip() else "?"
+        rl = r.strip().split("\n") if r.strip() else ["?"]
+        fn = rl[0]
+        if os.environ.get("SIGPROF_LINES") and len(rl) > 1 and not rl[1].startswith("??"):
+            fn = fn.split("(")[0] + "@" + os.path.basename(rl[1])
         names[o] = re.sub(r"\(.*", "", fn.replace("(anonymous namespace)::", "").replace("'lambda", "{lambda"))[:110]
 def nice(fr):
     m = re.match(r"libdraco_mi\.so![^+ ]*\+(0x[0-9a-f]+)", fr)
