@@ -125,8 +125,12 @@ unsigned long_wait_flags() { return dbg_on(DMI_DBG_SPIN_WAITS) ? hipEventDisable
 hipError_t long_wait_event(hipEvent_t e) {
   if (dbg_on(DMI_DBG_SPIN_WAITS)) return hipEventSynchronize(e);
   // back-to-back queries for the first 60 µs (a wait that short is on somebody's critical path), then 20 µs naps — with the thread's timer slack at 1 µs
-  // instead of the default 50 (per thread, set once: only this thread's own sleeps get more punctual)
-  thread_local bool slack_set = false;
+  // instead of the default 50 for the duration of the wait (the thread may be the caller's: its own value is put back)
+  struct Slack {
+    long old = -1;
+    void tighten() { if (old < 0) { old = prctl(PR_GET_TIMERSLACK, 0ul, 0ul, 0ul, 0ul); if (old >= 0) (void)prctl(PR_SET_TIMERSLACK, 1000ul, 0ul, 0ul, 0ul); } }
+    ~Slack() { if (old >= 0) (void)prctl(PR_SET_TIMERSLACK, (unsigned long)old, 0ul, 0ul, 0ul); }
+  } slack;
   const auto t0 = std::chrono::steady_clock::now();
   for (bool napping = false;;) {
     const hipError_t r = hipEventQuery(e);
@@ -136,7 +140,7 @@ hipError_t long_wait_event(hipEvent_t e) {
     if (!napping) {
       if (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(60)) continue;
       napping = true;
-      if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 1000ul, 0ul, 0ul, 0ul); slack_set = true; }
+      slack.tighten();
     }
     std::this_thread::sleep_for(std::chrono::microseconds(20));
   }
