@@ -64,7 +64,7 @@ _DEBUG_FLAGS = {"DMI_NO_FUSED": 0, "DMI_NO_PACKED": 1, "DMI_NO_SYM16": 2, "DMI_N
                 "DMI_HOST_ATT_TABLES": 7, "DMI_HOST_BUILD": 8, "DMI_NO_IN_PLACE": 9, "DMI_NO_POOL": 10, "DMI_POISON": 11, "DMI_ZERO_CHUNKS": 12, "DMI_NO_QUAD": 13,
                 "DMI_TEST_QUAD": 14, "DMI_NO_CLOSED": 15, "DMI_NO_SHADOW": 16, "DMI_NO_SEQ_SHADOW": 17, "DMI_NO_SEAM_MASKS": 18, "DMI_NO_DEFER_SEAMS": 19,
                 "DMI_NO_BATCHED_PHASES": 20, "DMI_FUSED_WINDOWS": 21, "DMI_CHAIN_DENSE": 22, "DMI_SERIAL_TABLES": 23, "DMI_PARALLEL_TABLES": 24, "DMI_FILE_ORDER": 25,
-                "DMI_TRACE": 26, "DMI_TRACE_STAGES": 27, "DMI_TRACE_TABLES": 28, "DMI_BUILD_TRACE": 29, "DMI_NO_SEQ_STREAM": 30, "DMI_SMALL_HEAD": 31, "DMI_SPIN_WAITS": 32}
+                "DMI_TRACE": 26, "DMI_TRACE_STAGES": 27, "DMI_TRACE_TABLES": 28, "DMI_BUILD_TRACE": 29, "DMI_NO_SEQ_STREAM": 30, "DMI_SMALL_HEAD": 31, "DMI_SPIN_WAITS": 32, "DMI_NO_STREAM_COPY": 33}
 _DEBUG_INTS = {"DMI_HOST_THREADS": "host_threads", "DMI_TILE_SORT_MIN": "tile_sort_min", "DMI_TILE_SORT_LOCAL": "tile_sort_local", "DMI_SEQ_BIG_ENTRIES": "seq_big_entries",
                "DMI_FUSED_GRID": "fused_grid", "DMI_FUSED_LDS": "fused_lds", "DMI_CHAIN_GRID": "chain_grid", "DMI_BATCH_THREADS": "batch_threads",
                "DMI_SHADOW_MIN_FACES": "shadow_min_faces", "DMI_PREP_GROUP_FACES": "prep_group_faces", "DMI_BATCH_MIN_FACES": "batch_min_faces",

@@ -57,7 +57,7 @@ int run_parallel(uint32_t count, uint32_t n_threads, const std::function<int(uin
 // rows of one accessor, tightly packed, into dst (bytes [lo, hi) of the packed form: large accessors are copied in slices)
 void pack_rows(uint8_t* dst, const dmi_raw_accessor& a, size_t row_bytes, size_t lo, size_t hi) {
   const uint8_t* src = static_cast<const uint8_t*>(a.data);
-  if (!a.byte_stride || a.byte_stride == row_bytes) { std::memcpy(dst + lo, src + lo, hi - lo); return; }
+  if (!a.byte_stride || a.byte_stride == row_bytes) { if (dbg_on(DMI_DBG_NO_STREAM_COPY)) std::memcpy(dst + lo, src + lo, hi - lo); else stream_copy(dst + lo, src + lo, hi - lo); return; }
   for (size_t r = lo / row_bytes, e = (hi + row_bytes - 1) / row_bytes; r < e; ++r) std::memcpy(dst + r * row_bytes, src + r * (size_t)a.byte_stride, row_bytes);
 }
 
@@ -405,7 +405,8 @@ int dmi_meshes_build(const dmi_raw_mesh* raw, uint32_t n, const dmi_config* cfg,
           const Task& tk = tasks[t];
           const dmi_raw_mesh& m = raw[g.which[tk.k]];
           if (tk.i < m.n_atts) pack_rows(hp + g.row_at[g.meshes[tk.k].item0 + tk.i], m.atts[tk.i], (size_t)m.atts[tk.i].num_components * 4, tk.lo, tk.hi);
-          else std::memcpy(hp + g.idx_at[tk.k] + tk.lo, static_cast<const uint8_t*>(m.indices) + tk.lo, tk.hi - tk.lo);
+          else if (dbg_on(DMI_DBG_NO_STREAM_COPY)) std::memcpy(hp + g.idx_at[tk.k] + tk.lo, static_cast<const uint8_t*>(m.indices) + tk.lo, tk.hi - tk.lo);
+          else stream_copy(hp + g.idx_at[tk.k] + tk.lo, static_cast<const uint8_t*>(m.indices) + tk.lo, tk.hi - tk.lo);
           return DMI_OK;
         }, [&](uint32_t t) { return (uint64_t)(tasks[t].hi - tasks[t].lo); }))) return rc;
     t_pack += ms() - p0;

@@ -25,6 +25,9 @@
 #include <system_error>
 #include <type_traits>
 #include <pthread.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include <vector>
 
 #include "../../include/draco_mi.h"
@@ -70,6 +73,29 @@ class Thread {
 // n calls have returned.  `work` must not throw.
 void run_threads(uint32_t n, const std::function<void(uint32_t)>& work);
 void pool_submit(std::function<void()> fn);   // fn on a parked (or new) pool thread; returns at once
+
+// memcpy for large blocks that go INTO staging memory (read next by a DMA engine, not by this core): non-temporal 16-byte stores — no read-for-ownership of the
+// destination, the caches keep what the walks use.  The pack of a 1024-file transcode's 1.09 GB of accessors was 13 % of the call's CPU samples as plain memcpy.
+inline void stream_copy(void* dst, const void* src, size_t n) {
+#if defined(__SSE2__)
+  if (n < ((size_t)128 << 10)) { std::memcpy(dst, src, n); return; }
+  uint8_t* d = static_cast<uint8_t*>(dst);
+  const uint8_t* s = static_cast<const uint8_t*>(src);
+  const size_t head = (16u - (size_t)(reinterpret_cast<uintptr_t>(d) & 15u)) & 15u;
+  if (head) { std::memcpy(d, s, head); d += head; s += head; n -= head; }
+  size_t k = n / 64;
+  for (; k; --k, d += 64, s += 64) {
+    const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(s)), b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(s + 16));
+    const __m128i c = _mm_loadu_si128(reinterpret_cast<const __m128i*>(s + 32)), e = _mm_loadu_si128(reinterpret_cast<const __m128i*>(s + 48));
+    _mm_stream_si128(reinterpret_cast<__m128i*>(d), a); _mm_stream_si128(reinterpret_cast<__m128i*>(d + 16), b);
+    _mm_stream_si128(reinterpret_cast<__m128i*>(d + 32), c); _mm_stream_si128(reinterpret_cast<__m128i*>(d + 48), e);
+  }
+  _mm_sfence();
+  if (n & 63) std::memcpy(d, s, n & 63);
+#else
+  std::memcpy(dst, src, n);
+#endif
+}
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 int host_fail(int code, const std::string& msg);   // sets dmi_last_error() for the calling thread, returns code

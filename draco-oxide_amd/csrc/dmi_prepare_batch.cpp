@@ -213,7 +213,7 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
         const dmi_attribute& at = m.atts[a];
         const size_t vb = (size_t)at.num_unique * at.num_components * 4;
         if (!vb) continue;
-        std::memcpy(g.hp + g.lay[k].values[a], at.values, vb);
+        stream_copy(g.hp + g.lay[k].values[a], at.values, vb);
         lo = std::min(lo, g.lay[k].values[a]); hi = std::max(hi, g.lay[k].values[a] + vb);
       }
       if (hi > lo) HIP_TRY(hipMemcpyAsync(g.d_up + lo, g.hp + lo, hi - lo, hipMemcpyHostToDevice, g.S));
@@ -427,14 +427,14 @@ static int prepare_slice_device(const dmi_mesh* meshes, const std::vector<uint32
     auto faces_of = [&](uint32_t k) { return (uint64_t)meshes[g.which[k]].num_faces; };
     if ((rc = parallel_over(Mg, [&](uint32_t, uint32_t k) -> int {
           const dmi_mesh& m = meshes[g.which[k]];
-          std::memcpy(hp + g.lay[k].faces, m.faces, (size_t)m.num_faces * 12);
-          if (g.lay[k].mapped) std::memcpy(hp + g.lay[k].pos_map, m.atts[0].point_to_value, (size_t)m.atts[0].num_points * 4);
+          stream_copy(hp + g.lay[k].faces, m.faces, (size_t)m.num_faces * 12);
+          if (g.lay[k].mapped) stream_copy(hp + g.lay[k].pos_map, m.atts[0].point_to_value, (size_t)m.atts[0].num_points * 4);
           for (uint32_t i = 1; i < m.num_atts; ++i) {
             const dmi_attribute& at = m.atts[i];
             if (!at.point_to_value || at.point_to_value == m.atts[0].point_to_value) continue;
             bool first = true;
             for (uint32_t j = 1; j < i; ++j) if (m.atts[j].point_to_value == at.point_to_value) first = false;
-            if (first) std::memcpy(hp + g.lay[k].maps[i], at.point_to_value, (size_t)at.num_points * 4);
+            if (first) stream_copy(hp + g.lay[k].maps[i], at.point_to_value, (size_t)at.num_points * 4);
           }
           return DMI_OK;
         }, faces_of, pack_threads()))) return rc;

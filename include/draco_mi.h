@@ -132,6 +132,7 @@ typedef struct dmi_debug {
 #define DMI_DBG_TRACE_TABLES      (1ull << 28)
 #define DMI_DBG_BUILD_TRACE       (1ull << 29)
 #define DMI_DBG_NO_SEQ_STREAM      (1ull << 30)   /* whole-mesh calls upload the sequence after the sequencer, in one copy */
+#define DMI_DBG_NO_STREAM_COPY   (1ull << 33)   /* the build's pack of pageable accessors into staging by plain memcpy (default: non-temporal stores) */
 #define DMI_DBG_SPIN_WAITS       (1ull << 32)   /* the batch path's long device waits spin like every other wait (default: blocking events — a waiting thread leaves its core to the walks) */
 #define DMI_DBG_SMALL_HEAD       (1ull << 31)   /* dmi_transcode_assets: a device's smallest files (1/32 of its bytes) go first, the rest largest first */
 typedef struct dmi_config {
