@@ -95,7 +95,17 @@ struct Worker {
 struct WorkerPool {
   std::mutex m;
   std::vector<Worker*> idle;
-  static WorkerPool& get() { static WorkerPool* p = new WorkerPool(); return *p; }   // (never destroyed: its threads are parked for the life of the process)
+  static WorkerPool& get() {   // (never destroyed: its threads are parked for the life of the process)
+    static WorkerPool* p = [] {
+      WorkerPool* q = new WorkerPool();
+      g_pool = q;
+      // a forked child has none of the parent's threads: it starts with an empty pool (the parked workers it inherited on paper are forgotten, not joined)
+      (void)pthread_atfork(nullptr, nullptr, [] { if (g_pool) { new (&g_pool->m) std::mutex(); new (&g_pool->idle) std::vector<Worker*>(); } });
+      return q;
+    }();
+    return *p;
+  }
+  static WorkerPool* g_pool;
   static void loop(WorkerPool* pool, Worker* w) {
     for (;;) {
       std::function<void()> t;
@@ -124,6 +134,7 @@ struct WorkerPool {
     w->cv.notify_one();
   }
 };
+WorkerPool* WorkerPool::g_pool = nullptr;
 }  // namespace
 
 void pool_submit(std::function<void()> fn) { WorkerPool::get().submit(std::move(fn)); }

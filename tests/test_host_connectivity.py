@@ -405,3 +405,28 @@ def test_host_builder_against_the_restated_builder_on_random_primitives():
         if done == 60:
             break
     assert done == 60
+
+
+def test_host_calls_survive_a_fork_of_a_process_that_used_the_worker_pool():
+    """Round 6: the library's short-lived workers are parked pool threads.  A forked child has none of them: it must start with an empty pool, not hand its
+    tasks to threads that do not exist (host-only calls: the HIP runtime itself does not survive a fork)."""
+    import subprocess, sys, os
+    code = r"""
+import os, sys
+sys.path.insert(0, %r)
+os.environ["DMI_NO_TORCH_PREIMPORT"] = "1"
+import draco_oxide_amd as d
+from draco_oxide_amd import synth
+def host_work():
+    faces, pos, nrm, uv = synth.torus_grid(600)
+    b = d.MeshBuilder(); pid = b.add_attribute(pos, d.ATT_POSITION, d.DOMAIN_POSITION); b.add_attribute(uv, d.ATT_TEXCOORD, d.DOMAIN_CORNER, parents=[pid]); b.set_connectivity_attribute(faces)
+    c = d.encode_connectivity(b.build()); n = bytes(c.bytes); c.close(); return n
+a = host_work()
+pid = os.fork()
+if pid == 0:
+    os._exit(0 if host_work() == a else 3)
+_, st = os.waitpid(pid, 0)
+sys.exit(os.WEXITSTATUS(st))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], timeout=300)
+    assert r.returncode == 0
