@@ -45,7 +45,7 @@ class _Debug(C.Structure):
     """dmi_debug (include/draco_mi.h): the typed path-selecting / tuning switches.  The LIBRARY never reads the environment for them (round 6); this
     binding fills the struct from os.environ on every call — `DMI_NO_FUSED=1 pytest …` and monkeypatch.setenv keep working for tests and bench."""
     _fields_ = [("flags", C.c_uint64), ("host_threads", C.c_uint32), ("tile_sort", C.c_int32), ("tile_sort_min", C.c_uint32), ("tile_sort_local", C.c_uint32),
-                ("seq_big_entries", C.c_uint32), ("relabel", C.c_uint8), ("chains", C.c_uint8), ("pad0", C.c_uint8), ("pad1", C.c_uint8),
+                ("seq_big_entries", C.c_uint32), ("relabel", C.c_uint8), ("chains", C.c_uint8), ("prepare_threads", C.c_uint8), ("pad1", C.c_uint8),
                 ("fused_grid", C.c_uint32), ("fused_lds", C.c_uint32), ("chain_grid", C.c_uint32), ("batch_threads", C.c_uint32), ("split", C.c_uint32),
                 ("shadow_min_faces", C.c_uint32), ("prep_group_faces", C.c_uint64), ("batch_min_faces", C.c_uint64), ("stage_primitives", C.c_uint32), ("stage_ramp", C.c_uint32)]
 
@@ -68,7 +68,7 @@ _DEBUG_FLAGS = {"DMI_NO_FUSED": 0, "DMI_NO_PACKED": 1, "DMI_NO_SYM16": 2, "DMI_N
 _DEBUG_INTS = {"DMI_HOST_THREADS": "host_threads", "DMI_TILE_SORT_MIN": "tile_sort_min", "DMI_TILE_SORT_LOCAL": "tile_sort_local", "DMI_SEQ_BIG_ENTRIES": "seq_big_entries",
                "DMI_FUSED_GRID": "fused_grid", "DMI_FUSED_LDS": "fused_lds", "DMI_CHAIN_GRID": "chain_grid", "DMI_BATCH_THREADS": "batch_threads",
                "DMI_SHADOW_MIN_FACES": "shadow_min_faces", "DMI_PREP_GROUP_FACES": "prep_group_faces", "DMI_BATCH_MIN_FACES": "batch_min_faces",
-               "DMI_STAGE_PRIMITIVES": "stage_primitives", "DMI_STAGE_RAMP": "stage_ramp"}
+               "DMI_STAGE_PRIMITIVES": "stage_primitives", "DMI_STAGE_RAMP": "stage_ramp", "DMI_PREPARE_THREADS": "prepare_threads"}
 
 
 def debug_from_env(env=None):

@@ -84,7 +84,8 @@ struct dmi_transcoder {
   std::mutex result_mutex;
   // steps
   Slot to_build, to_prepare, to_encode;
-  dmi::Thread t_build, t_build2, t_prepare, t_prepare2, t_encode, t_encode2;
+  dmi::Thread t_build, t_build2, t_prepare, t_prepare2, t_prepare3, t_prepare4, t_encode, t_encode2;
+  uint32_t prepare_threads = 2;
   std::atomic<int> builders_left{0}, preparers_left{0};
   std::mutex err_mutex;
   int rc = DMI_OK;
@@ -179,9 +180,11 @@ struct dmi_transcoder {
     builders_left = 2;
     t_build = dmi::Thread([this] { build_loop(); });
     t_build2 = dmi::Thread([this] { build_loop(); });
-    preparers_left = 2;
+    preparers_left = (int)prepare_threads;
     t_prepare = dmi::Thread([this] { prepare_loop(); });
-    t_prepare2 = dmi::Thread([this] { prepare_loop(); });
+    if (prepare_threads > 1) t_prepare2 = dmi::Thread([this] { prepare_loop(); });
+    if (prepare_threads > 2) t_prepare3 = dmi::Thread([this] { prepare_loop(); });
+    if (prepare_threads > 3) t_prepare4 = dmi::Thread([this] { prepare_loop(); });
     t_encode = dmi::Thread([this] { encode_loop(); });
     t_encode2 = dmi::Thread([this] { encode_loop(); });
   }
@@ -217,6 +220,7 @@ dmi_transcoder* dmi_transcoder_create(const dmi_config* cfg, uint64_t expected_t
   t->cfg.debug = &t->debug;
   t->trace = dbg_on(DMI_DBG_TRACE | DMI_DBG_TRACE_STAGES);
   t->stage_ramp = dbg().stage_ramp;
+  t->prepare_threads = dbg().prepare_threads ? std::min<uint32_t>(4u, dbg().prepare_threads) : 2u;
   t->stage_primitives = dbg().stage_primitives ? dbg().stage_primitives : 256u;   // (1024 files, medians of 7: 80.5 → 80.1, 87.6 → 84.9, 88.4 → 80.8 ms with the cap)
   // about four stages (enough to overlap the steps), between 3M and 12M triangles: a stage pays fixed costs (the chain launch of its encode is bounded
   // by its longest stream, ≈ 5 ms) and one above ≈ 16M stops overlapping (measured with the Python driver: DESIGN §6b)
@@ -267,6 +271,8 @@ int dmi_transcoder_finish(dmi_transcoder* t) {
     if (t->t_build2.joinable()) t->t_build2.join();
     if (t->t_prepare.joinable()) t->t_prepare.join();
     if (t->t_prepare2.joinable()) t->t_prepare2.join();
+    if (t->t_prepare3.joinable()) t->t_prepare3.join();
+    if (t->t_prepare4.joinable()) t->t_prepare4.join();
     if (t->t_encode.joinable()) t->t_encode.join();
     if (t->t_encode2.joinable()) t->t_encode2.join();
     t->finished = true;

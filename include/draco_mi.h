@@ -93,7 +93,8 @@ typedef struct dmi_debug {
   uint32_t seq_big_entries;   /* 0 = default: sequence length from which k_seq_quantize_big runs */
   uint8_t  relabel;           /* coding-order relabelling: 0 by size, 1 device, 2 host */
   uint8_t  chains;            /* serial coders of a single job: 0 by the longest stream, 1 device walker, 2 host cores */
-  uint8_t  pad0, pad1;
+  uint8_t  prepare_threads;   /* transcoder: threads of the prepare step (0 = default 2) */
+  uint8_t  pad1;
   uint32_t fused_grid, fused_lds, chain_grid;   /* tuning aids of the sweep / chain launches (0 = defaults) */
   uint32_t batch_threads, split;                /* batch encode: worker threads, sub-batches (0 = defaults) */
   uint32_t shadow_min_faces;                    /* host walks: faces from which the shadow prefetch runs (0 = default) */

@@ -12,7 +12,7 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 settings = [s for s in (sys.argv[4] if len(sys.argv) > 4 else "0/6/12/24").split("/")]
 var = "setting"
 def apply(s):
-    for k in ("DMI_STAGE_RAMP", "DMI_SMALL_HEAD", "DMI_STAGE_PRIMITIVES", "DMI_FILE_ORDER", "DMI_SPIN_WAITS", "DMI_NO_QUAD", "DMI_NO_STREAM_COPY"):
+    for k in ("DMI_STAGE_RAMP", "DMI_SMALL_HEAD", "DMI_STAGE_PRIMITIVES", "DMI_FILE_ORDER", "DMI_SPIN_WAITS", "DMI_NO_QUAD", "DMI_NO_STREAM_COPY", "DMI_PREPARE_THREADS"):
         os.environ.pop(k, None)
     if s in ("0", ""):
         return
