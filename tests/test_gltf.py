@@ -243,6 +243,19 @@ def test_full_size_files_through_the_transcoder_against_the_oracle(seams):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,value", [("DMI_SPIN_WAITS", "1"), ("DMI_NO_STREAM_COPY", "1"), ("DMI_SMALL_HEAD", "1"), ("DMI_STAGE_RAMP", "8"), ("DMI_PREPARE_THREADS", "4"), ("DMI_STAGE_PRIMITIVES", "7")])
+def test_transcoder_scheduling_switches_do_not_change_the_files(name, value, monkeypatch):
+    """Round 6's scheduling / waiting / copying switches steer HOW a transcode runs — the runtime's own waits instead of the polling ones, plain memcpy
+    into staging, the smallest files first, ramped stage sizes, four prepare threads, stages of seven primitives —, never what it writes."""
+    from draco_oxide_amd import synth
+    glbs, _ = synth.batch_glbs(48, seed=synth.SEED + 31, seams=(name in ("DMI_SPIN_WAITS", "DMI_PREPARE_THREADS")))
+    monkeypatch.delenv(name, raising=False)
+    want = gltf.transcode_files(glbs, copy=True)
+    monkeypatch.setenv(name, value)
+    assert gltf.transcode_files(glbs, copy=True) == want
+
+
+@pytest.mark.gpu
 def test_transcoder_walks_over_quad_ids_give_the_same_files(monkeypatch):
     """Round 6: a stage none of whose primitives has a point → value map has its opposite corners read back as 4·face + k ids (built_group_issue_tables) and its
     host walks run over those — the same files as with DMI_NO_QUAD=1, plain ones (the quad class) and exporter-style seams (never in it) alike."""
