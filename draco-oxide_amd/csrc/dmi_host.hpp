@@ -73,6 +73,9 @@ class Thread {
 // n calls have returned.  `work` must not throw.
 void run_threads(uint32_t n, const std::function<void(uint32_t)>& work);
 void pool_submit(std::function<void()> fn);   // fn on a parked (or new) pool thread; returns at once
+// set once the library has used the device in this process (a stream, staging, device memory): run_threads hands the caller's current device to its workers only then —
+// a process that only ever calls the host stages (dmi_mesh_build, dmi_encode_connectivity, the decoders' host halves) never initialises the HIP runtime through it
+inline std::atomic<bool>& hip_used() { static std::atomic<bool> f{false}; return f; }
 
 // memcpy for large blocks that go INTO staging memory (read next by a DMA engine, not by this core): non-temporal 16-byte stores — no read-for-ownership of the
 // destination, the caches keep what the walks use.  The pack of a 1024-file transcode's 1.09 GB of accessors was 13 % of the call's CPU samples as plain memcpy.

@@ -84,6 +84,7 @@ static bool stage_alloc(HostStage* st, size_t want) {
   return true;
 }
 HostStage* acquire_stage(int device, size_t bytes) {
+  hip_used().store(true, std::memory_order_relaxed);
   HostStage* best = nullptr;
   {
     std::lock_guard<std::mutex> lock(g_stage_mutex);

@@ -152,6 +152,7 @@ struct DevMem {
     p = nullptr; pooled = false;
     bytes = n;
     if (n == 0) return DMI_OK;
+    hip_used().store(true, std::memory_order_relaxed);
     if (g_active_pool) {
       p = g_active_pool->take(n);
       if (!p) return host_fail(DMI_ERR_OUT_OF_MEMORY, "hipMalloc (job pool)");

@@ -96,6 +96,7 @@ struct ThreadStreams {
     for (int k = 0; k < 3; ++k) for (auto& e : mine[k]) pool.idle[k].push_back(std::move(e));
   }
   std::shared_ptr<StreamHolder> get(int kind, int device) {
+    hip_used().store(true, std::memory_order_relaxed);
     for (auto& e : mine[kind]) if (e.first == device) return e.second;
     std::shared_ptr<StreamHolder> h;
     {
@@ -186,7 +187,7 @@ void run_threads(uint32_t n, const std::function<void(uint32_t)>& work) {
   cpu_set_t mask;
   const bool have_mask = sched_getaffinity(0, sizeof mask, &mask) == 0;
   int device = -1;
-  if (hipGetDevice(&device) != hipSuccess) { (void)hipGetLastError(); device = -1; }
+  if (hip_used().load(std::memory_order_relaxed) && hipGetDevice(&device) != hipSuccess) { (void)hipGetLastError(); device = -1; }
   auto body = [&](uint32_t t) {
     {
       DebugScope scope(cur);
