@@ -19,6 +19,12 @@ if kind == "batch":      # bench.py's batch_regime: 256 host meshes -> dmi_meshe
             pass
         for j in jobs:
             j.close()
+elif kind == "decode":   # dmi_decode_mesh of a 3M-triangle file (the validation-side decoder)
+    mesh = synth.torus_mesh(1225)
+    total = len(mesh.faces)
+    drc = dmi.encode_mesh(mesh, cfg)
+    def one():
+        dmi.decode_mesh(drc)
 elif kind == "single":   # bench.py's value: one 10M-triangle mesh in HBM -> whole .drc
     mesh = synth.torus_mesh(2236)
     total = len(mesh.faces)
